@@ -1,0 +1,258 @@
+/*
+ * sipnet_amd.h -- C-ABI of the MI355X-native SIPNET flux-integration engine.
+ *
+ * The reference (PecanProject/sipnet) has no plugin / FFI layer.  Its de-facto
+ * C boundary for the hot path is the five functions of
+ * /root/reference/src/sipnet/sipnet.h:26-64, called from frontend.c:212-250:
+ *
+ *     initModel(&mp, paramFile, climFile)        sipnet.h:36  (sipnet.c:2001)
+ *     setupModel()                               sipnet.h:45  (sipnet.c:1858)
+ *     runModelOutput(out, dbg, items, header)    sipnet.h:53  (sipnet.c:1954)
+ *     setupOutputItems(items)                    sipnet.h:59  (sipnet.c:1993)
+ *     cleanupModel()                             sipnet.h:64  (sipnet.c:2012)
+ *
+ * Those operate on process globals, one member of one site at a time.  This
+ * header is the batched, re-entrant replacement a reference-side binding would
+ * call instead: an opaque handle holding an ensemble x site batch in HBM, plain
+ * pointers and sizes only, int status returns (0 = ok, otherwise the reference
+ * exit code of common/exitCodes.h:16-27 that the same condition produces in
+ * the reference), no globals.  Mapping:
+ *
+ *     initModel        -> sipnet_io_read_params + sipnet_io_read_clim
+ *                         + sipnet_batch_create/_set_params/_set_climate
+ *     initEvents       -> sipnet_io_read_events + sipnet_batch_set_events
+ *                         (events.c:427-433)
+ *     setupModel       -> sipnet_batch_setup
+ *     runModelOutput   -> sipnet_batch_run (+ sipnet_io_write_out_rows for text)
+ *     setupOutputItems -> the NEE/GPP planes of sipnet_batch_run and
+ *                         sipnet_io_write_single_outputs
+ *     cleanupModel     -> sipnet_batch_destroy
+ *
+ * All compute entry points enqueue work on the HIP stream passed in and need a
+ * gfx950 device; they return SIPNET_ERR_NO_DEVICE (never a CPU fallback) when
+ * none is usable.  The sipnet_io_* functions are host-only.
+ */
+#ifndef SIPNET_AMD_H
+#define SIPNET_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SIPNET_NPARAMS 80 /* include/sipnet_params.def */
+#define SIPNET_NFLAGS 12
+#define SIPNET_NCLIM 11   /* converted climate record, see sipnet_io_read_clim */
+#define SIPNET_NREC 36    /* full per-step output record, see below */
+#define SIPNET_NSTATE 32  /* per-member carried state (doubles), see below */
+#define SIPNET_RING_SLOTS 250 /* MEAN_NPP_MAX_ENTRIES, sipnet.c:39-40 */
+
+/* model flags, order of struct Context (common/context.h:46-57) */
+enum sipnet_flag {
+  SIPNET_F_EVENTS = 0,
+  SIPNET_F_GDD,
+  SIPNET_F_GROWTH_RESP,
+  SIPNET_F_LEAF_WATER,
+  SIPNET_F_LITTER_POOL,
+  SIPNET_F_SNOW,
+  SIPNET_F_SOIL_PHENOL,
+  SIPNET_F_WATER_HRESP,
+  SIPNET_F_NITROGEN_CYCLE,
+  SIPNET_F_ANAEROBIC,
+  SIPNET_F_FLOODING,
+  SIPNET_F_CARBON_SATURATION
+};
+
+/* status codes = reference exit codes (common/exitCodes.h:16-27) + own */
+enum sipnet_status {
+  SIPNET_OK = 0,
+  SIPNET_ERR_FAILURE = 1,
+  SIPNET_ERR_BAD_PARAMETER = 3,    /* EXIT_CODE_BAD_PARAMETER_VALUE */
+  SIPNET_ERR_UNKNOWN_EVENT = 4,    /* EXIT_CODE_UNKNOWN_EVENT_TYPE_OR_PARAM */
+  SIPNET_ERR_INPUT_FILE = 5,       /* EXIT_CODE_INPUT_FILE_ERROR */
+  SIPNET_ERR_FILE_OPEN = 6,        /* EXIT_CODE_FILE_OPEN_OR_READ_ERROR */
+  SIPNET_ERR_INTERNAL = 7,         /* EXIT_CODE_INTERNAL_ERROR */
+  SIPNET_ERR_NO_DEVICE = 100,      /* no usable gfx950 device / HIP failure */
+  SIPNET_ERR_BAD_ARGUMENT = 101
+};
+
+/* arithmetic of the step kernel */
+enum sipnet_precision {
+  SIPNET_F64 = 0,      /* everything in fp64 (parity configuration) */
+  SIPNET_F32_MIXED = 1 /* flux arithmetic fp32, pools and accumulators fp64 */
+};
+
+/* event types, order of enum EventType (sipnet/events.h:17-27) */
+enum sipnet_event_type {
+  SIPNET_EV_FERT = 0,
+  SIPNET_EV_HARVEST,
+  SIPNET_EV_IRRIG,
+  SIPNET_EV_PLANT,
+  SIPNET_EV_TILL,
+  SIPNET_EV_LEAFON,
+  SIPNET_EV_LEAFOFF
+};
+
+/* One agronomic event (events.in line).  p[] per type (events.h:29-97):
+ *   harvest: fracRemovedAbove fracRemovedBelow fracTransferredAbove fracTransferredBelow
+ *   irrig  : amountAdded method(0 canopy, 1 soil)
+ *   fert   : orgN orgC minN        plant: leafC woodC fineRootC coarseRootC
+ *   till   : tillageEffect         leafon / leafoff: none */
+typedef struct sipnet_event {
+  int32_t type, year, day, pad;
+  double p[4];
+} sipnet_event;
+
+/* Full per-step record (SIPNET_NREC doubles), the superset of the `.out` row
+ * (sipnet.c:453-473):
+ *  0 nee 1 gpp 2 evapotranspiration 3 totNee(cumNEE) 4 npp 5 rAboveground
+ *  6 rSoil 7 rRoot 8 ra 9 rh 10 rtot 11 woodCreation 12 soilWetnessFrac
+ * 13 transpiration(flux) 14 plantWoodC 15 plantLeafC 16 soilC 17 soilWater
+ * 18 litterC 19 snow 20 coarseRootC 21 fineRootC 22 minN 23 soilOrgN
+ * 24 litterN 25 plantStorageN 26 plantCAccountingDelta 27 n2o 28 nLeaching
+ * 29 nFixation 30 nUptake 31 methane 32 meanNPP 33 gdd 34 d_till_mod 35 totGpp
+ *
+ * Per-member carried state (SIPNET_NSTATE doubles), what the reference's restart
+ * schema (restart.c:216-296) persists for one member minus site-uniform items:
+ *  0..12 the 13 pools in `Envi` order (state.h:416-463)
+ * 13 ring sum (meanNPP.sum) 14..19 tot{Gpp,Rtot,Ra,Rh,Npp,Nee}
+ * 20..26 yearly{Gpp,Rtot,Ra,Rh,Npp,Nee,Litter} 27 phenology bits
+ * (1 didLeafGrowth | 2 didLeafFall) 28 ring_valid_from (first step whose ring
+ * insert is live; earlier slots count as zero) 29 status
+ * 30 died_at_step (-1 = never) 31 clamp-warning count */
+
+typedef struct sipnet_batch sipnet_batch;
+
+/* ------------------------------------------------------------------ library */
+const char *sipnet_version(void);      /* "sipnet_amd x.y (reference 2.1.0)" */
+const char *sipnet_last_error(void);   /* thread-local message of last failure */
+int sipnet_device_count(void);         /* 0 when no HIP device is visible */
+
+/* ------------------------------------------------------------- batch engine */
+/* Create an ensemble x site batch on HIP device `device`.
+ * Columns are site-major: col = site * n_members + member. */
+int sipnet_batch_create(const int32_t flags[SIPNET_NFLAGS], int32_t n_sites,
+                        int32_t n_members, int32_t precision, int32_t device,
+                        sipnet_batch **out);
+void sipnet_batch_destroy(sipnet_batch *b);
+
+/* Forcing of one site: clim[n_steps][SIPNET_NCLIM] already converted exactly
+ * as readClimData does (sipnet.c:201-238):
+ *   length(d) tair tsoil par(/d) precip(cm) vpd(kPa) vpdSoil vPress wspd gdd time(h)
+ * All sites of a batch must have the same n_steps.  Builds the site plan
+ * (member-independent schedule: running-mean ring weights, GDD sums, year
+ * roll-overs, event matching, tillage decay) on the host and uploads it. */
+int sipnet_batch_set_climate(sipnet_batch *b, int32_t site, int32_t n_steps,
+                             const double *clim, const int32_t *year,
+                             const int32_t *day);
+/* Events of one site in file order; call before sipnet_batch_set_climate or
+ * re-call set_climate afterwards (the plan is rebuilt in either order). */
+int sipnet_batch_set_events(sipnet_batch *b, int32_t site, int32_t n_events,
+                            const sipnet_event *events);
+/* Raw parameters of `count` members of `site`, starting at first_member:
+ * raw[count][SIPNET_NPARAMS], include/sipnet_params.def order, file units. */
+int sipnet_batch_set_params(sipnet_batch *b, int32_t site, int32_t first_member,
+                            int32_t count, const double *raw);
+
+/* Per-member initialisation == setupModel() (sipnet.c:1858-1951): parameter
+ * unit conversion, derived parameters, initial pools, trackers, phenology state
+ * from the first climate record, ring reset.  Members whose allocation
+ * parameters are invalid get status SIPNET_ERR_BAD_PARAMETER and are skipped
+ * by run (the reference exits, sipnet.c:1117-1122). */
+int sipnet_batch_setup(sipnet_batch *b, void *hip_stream);
+
+/* Advance every member n_steps steps starting at climate record step0
+ * (== the while loop of runModelOutput, sipnet.c:1969-1982).  State stays in
+ * HBM between calls, so a run may be split at any step boundary.
+ *
+ * d_nee/d_gpp/d_et: DEVICE pointers (or NULL) to planes [n_steps][ld] written
+ * as plane[t * ld + col]; element type double for SIPNET_F64, float for
+ * SIPNET_F32_MIXED; ld >= n_sites*n_members.
+ * d_rec: DEVICE pointer (or NULL) to [n_steps][SIPNET_NREC][ld] doubles
+ * (full record, for `.out` text and checkpoints). */
+int sipnet_batch_run(sipnet_batch *b, int32_t step0, int32_t n_steps,
+                     void *d_nee, void *d_gpp, void *d_et, double *d_rec,
+                     int64_t ld, void *hip_stream);
+
+/* Ensemble statistics of an output plane: for every step and site, the sum and
+ * sum of squares over the site's members (wavefront-shuffle reduction):
+ *   d_stats[(t * n_sites + site) * 2 + {0,1}]   (double)
+ * `elem_is_f32` selects the plane's element type. */
+int sipnet_batch_reduce_plane(sipnet_batch *b, const void *d_plane,
+                              int32_t elem_is_f32, int32_t n_steps, int64_t ld,
+                              double *d_stats, void *hip_stream);
+
+/* Copy per-member state to / from HOST memory: state[ncol][SIPNET_NSTATE]. */
+int sipnet_batch_get_state(sipnet_batch *b, double *state, void *hip_stream);
+int sipnet_batch_set_state(sipnet_batch *b, const double *state, void *hip_stream);
+/* Ring contents of one column to HOST: values[SIPNET_RING_SLOTS]. */
+int sipnet_batch_get_ring(sipnet_batch *b, int64_t col, double *values,
+                          void *hip_stream);
+/* Per-member status to HOST: status[ncol] (enum sipnet_status). */
+int sipnet_batch_get_status(sipnet_batch *b, int32_t *status, void *hip_stream);
+
+int64_t sipnet_batch_ncol(const sipnet_batch *b);
+int32_t sipnet_batch_nsteps(const sipnet_batch *b);
+/* Site-uniform trajectory computed by the plan: gdd[t] (trackers.gdd after
+ * step t) and d_till_mod[t] (eventTrackers.d_till_mod used in step t). */
+int sipnet_batch_get_site_series(sipnet_batch *b, int32_t site, double *gdd,
+                                 double *d_till_mod);
+/* Last launch's average kernel time in ms measured with HIP events on the
+ * launch stream (for bench.py's roofline line); <0 if none. */
+double sipnet_batch_last_kernel_ms(sipnet_batch *b);
+
+/* Device buffer helpers for callers without their own allocator (the CLI). */
+void *sipnet_dev_alloc(size_t bytes);
+void sipnet_dev_free(void *p);
+int sipnet_dev_to_host(void *host, const void *dev, size_t bytes, void *hip_stream);
+int sipnet_stream_sync(void *hip_stream);
+
+/* --------------------------------------------------------- host I/O (no GPU) */
+typedef struct sipnet_clim_table sipnet_clim_table;
+/* Parse a `<prefix>.clim` file: 12-column or legacy 14-column format,
+ * unit conversions and clamps of readClimData (sipnet.c:128-277).
+ * gdd_flag = ctx.gdd. */
+int sipnet_io_read_clim(const char *path, int32_t gdd_flag,
+                        sipnet_clim_table **out);
+int32_t sipnet_clim_nsteps(const sipnet_clim_table *t);
+const double *sipnet_clim_data(const sipnet_clim_table *t);  /* [n][SIPNET_NCLIM] */
+const int32_t *sipnet_clim_year(const sipnet_clim_table *t);
+const int32_t *sipnet_clim_day(const sipnet_clim_table *t);
+void sipnet_clim_free(sipnet_clim_table *t);
+
+/* Parse a `<prefix>.param` file (modelParams.c:136-230, sipnet.c:290-427):
+ * `name value [ignored...]`, `!` comments, case-insensitive names, unknown names
+ * ignored, duplicates / missing required -> SIPNET_ERR_INPUT_FILE; divisor
+ * clamps applied.  out[SIPNET_NPARAMS]; is_read[SIPNET_NPARAMS] may be NULL. */
+int sipnet_io_read_params(const char *path, const int32_t flags[SIPNET_NFLAGS],
+                          double *out, int32_t *is_read);
+const char *sipnet_param_name(int32_t index); /* file name, "" for derived */
+int32_t sipnet_param_index(const char *name); /* case-insensitive, -1 unknown */
+
+/* Parse an `events.in` file (events.c:263-367).  A missing or empty file yields
+ * zero events.  *out is malloc'ed (free with sipnet_io_free). */
+int sipnet_io_read_events(const char *path, const int32_t flags[SIPNET_NFLAGS],
+                          const double *params, sipnet_event **out,
+                          int32_t *n_events);
+void sipnet_io_free(void *p);
+
+/* `.out` text (sipnet.c:434-473): header line and one row per step from a full
+ * record.  rec points at record t of one member with element stride
+ * rec_stride (1 for a packed [NREC] record, ld for a device-layout plane).
+ * Both append to `buf` (size cap) and return the number of bytes written or
+ * a negative value if the buffer is too small. */
+int sipnet_io_format_out_header(char *buf, size_t cap);
+int sipnet_io_format_out_row(char *buf, size_t cap, int32_t year, int32_t day,
+                             double time, const double *rec, int64_t rec_stride);
+/* Write a whole `.out` file for one member from host records
+ * rec[n_steps][SIPNET_NREC]. */
+int sipnet_io_write_out(const char *path, int32_t print_header, int32_t n_steps,
+                        const int32_t *year, const int32_t *day,
+                        const double *clim, const double *rec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIPNET_AMD_H */

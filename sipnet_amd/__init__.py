@@ -1,0 +1,21 @@
+"""sipnet_amd -- MI355X-native SIPNET flux-integration engine.
+
+Host-side mirror of the reference's C interface for the hot path
+(/root/reference/src/sipnet/sipnet.h:26-64) over the C-ABI in
+include/sipnet_amd.h.  PyTorch is used only for device memory, streams and
+torch.distributed; all model arithmetic runs in hand-written HIP kernels
+(sipnet_amd/csrc/step_kernel.hip).
+"""
+from ._lib import (F32_MIXED, F64, NCLIM, NFLAGS, NPARAMS, NREC, NSTATE, RING_SLOTS,
+                   Event, SipnetError, lib)
+from .config import (DEFAULT_FLAGS, FLAG_NAMES, PARAM_NAMES, flags_from, read_config)
+from .io import (ClimTable, format_out_header, format_out_row, read_clim, read_events,
+                 read_params, write_out)
+from .batch import Batch
+
+__all__ = [
+    "Batch", "ClimTable", "Event", "SipnetError", "lib", "read_clim", "read_params",
+    "read_events", "write_out", "format_out_header", "format_out_row", "read_config",
+    "flags_from", "FLAG_NAMES", "DEFAULT_FLAGS", "PARAM_NAMES", "F64", "F32_MIXED",
+    "NPARAMS", "NFLAGS", "NCLIM", "NREC", "NSTATE", "RING_SLOTS",
+]

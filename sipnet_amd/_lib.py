@@ -1,0 +1,106 @@
+"""ctypes binding of libsipnet_amd.so (include/sipnet_amd.h).
+
+The library is the product; there is no Python or CPU fallback for the compute
+path.  Import fails loudly when the shared object has not been built
+(`python -c "import __graft_entry__ as g; g.build()"` or `make -C sipnet_amd/csrc`).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsipnet_amd.so")
+
+NPARAMS, NFLAGS, NCLIM, NREC, NSTATE, RING_SLOTS = 80, 12, 11, 36, 32, 250
+
+OK = 0
+ERR_BAD_PARAMETER = 3
+ERR_UNKNOWN_EVENT = 4
+ERR_INPUT_FILE = 5
+ERR_FILE_OPEN = 6
+ERR_INTERNAL = 7
+ERR_NO_DEVICE = 100
+ERR_BAD_ARGUMENT = 101
+
+F64, F32_MIXED = 0, 1
+
+
+class Event(C.Structure):
+    """struct sipnet_event"""
+    _fields_ = [("type", C.c_int32), ("year", C.c_int32), ("day", C.c_int32),
+                ("pad", C.c_int32), ("p", C.c_double * 4)]
+
+
+# name -> (restype, argtypes); every symbol declared in include/sipnet_amd.h
+_P = C.c_void_p
+_I32P = C.POINTER(C.c_int32)
+_DP = C.POINTER(C.c_double)
+SIGNATURES = {
+    "sipnet_version": (C.c_char_p, []),
+    "sipnet_last_error": (C.c_char_p, []),
+    "sipnet_device_count": (C.c_int, []),
+    "sipnet_batch_create": (C.c_int, [_I32P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_P)]),
+    "sipnet_batch_destroy": (None, [_P]),
+    "sipnet_batch_set_climate": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P]),
+    "sipnet_batch_set_events": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
+    "sipnet_batch_set_params": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "sipnet_batch_setup": (C.c_int, [_P, _P]),
+    "sipnet_batch_run": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int64, _P]),
+    "sipnet_batch_reduce_plane": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int64, _P, _P]),
+    "sipnet_batch_get_state": (C.c_int, [_P, _P, _P]),
+    "sipnet_batch_set_state": (C.c_int, [_P, _P, _P]),
+    "sipnet_batch_get_ring": (C.c_int, [_P, C.c_int64, _P, _P]),
+    "sipnet_batch_get_status": (C.c_int, [_P, _P, _P]),
+    "sipnet_batch_ncol": (C.c_int64, [_P]),
+    "sipnet_batch_nsteps": (C.c_int32, [_P]),
+    "sipnet_batch_get_site_series": (C.c_int, [_P, C.c_int32, _P, _P]),
+    "sipnet_batch_last_kernel_ms": (C.c_double, [_P]),
+    "sipnet_dev_alloc": (_P, [C.c_size_t]),
+    "sipnet_dev_free": (None, [_P]),
+    "sipnet_dev_to_host": (C.c_int, [_P, _P, C.c_size_t, _P]),
+    "sipnet_stream_sync": (C.c_int, [_P]),
+    "sipnet_io_read_clim": (C.c_int, [C.c_char_p, C.c_int32, C.POINTER(_P)]),
+    "sipnet_clim_nsteps": (C.c_int32, [_P]),
+    "sipnet_clim_data": (_DP, [_P]),
+    "sipnet_clim_year": (_I32P, [_P]),
+    "sipnet_clim_day": (_I32P, [_P]),
+    "sipnet_clim_free": (None, [_P]),
+    "sipnet_io_read_params": (C.c_int, [C.c_char_p, _I32P, _P, _P]),
+    "sipnet_param_name": (C.c_char_p, [C.c_int32]),
+    "sipnet_param_index": (C.c_int32, [C.c_char_p]),
+    "sipnet_io_read_events": (C.c_int, [C.c_char_p, _I32P, _P, C.POINTER(C.POINTER(Event)), _I32P]),
+    "sipnet_io_free": (None, [_P]),
+    "sipnet_io_format_out_header": (C.c_int, [C.c_char_p, C.c_size_t]),
+    "sipnet_io_format_out_row": (C.c_int, [C.c_char_p, C.c_size_t, C.c_int32, C.c_int32, C.c_double, _P, C.c_int64]),
+    "sipnet_io_write_out": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, _P, _P, _P, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the C-ABI library."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built. "
+                "Run `python -c 'import __graft_entry__ as g; g.build()'`. "
+                "sipnet_amd has no CPU fallback.")
+        _lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(_lib, name)
+            fn.restype = res
+            fn.argtypes = args
+    return _lib
+
+
+class SipnetError(RuntimeError):
+    def __init__(self, code, where=""):
+        self.code = code
+        msg = lib().sipnet_last_error().decode(errors="replace")
+        super().__init__(f"{where}: status {code}: {msg}")
+
+
+def check(code, where=""):
+    if code != OK:
+        raise SipnetError(code, where)

@@ -1,0 +1,144 @@
+"""Batch: an ensemble x site batch resident in HBM (sipnet_batch of the C-ABI).
+
+Mirrors the reference call sequence of frontend.c:212-250 --
+initModel / initEvents / setupModel / runModelOutput / cleanupModel -- for many
+members and sites at once.  Outputs live in torch CUDA tensors that the caller
+(or this class) allocates; the C-ABI only ever sees their raw device pointers.
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import F32_MIXED, F64, NPARAMS, NREC, NSTATE, RING_SLOTS, Event, check, lib
+
+
+class Batch:
+    def __init__(self, flags, n_sites, n_members, precision=F64, device=0):
+        import torch  # device memory + streams only
+        self._torch = torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("sipnet_amd.Batch needs a HIP device (no CPU path exists)")
+        self.L = lib()
+        self.flags = list(flags)
+        self.n_sites, self.n_members = int(n_sites), int(n_members)
+        self.ncol = self.n_sites * self.n_members
+        self.precision = precision
+        self.device = torch.device("cuda", device)
+        self.out_dtype = torch.float64 if precision == F64 else torch.float32
+        h = C.c_void_p()
+        fl = (C.c_int32 * 12)(*self.flags)
+        check(self.L.sipnet_batch_create(fl, self.n_sites, self.n_members, precision,
+                                         device, C.byref(h)), "batch_create")
+        self.h = h
+        self.n_steps = 0
+
+    # -- lifetime ---------------------------------------------------------------
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.sipnet_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
+
+    # -- inputs -----------------------------------------------------------------
+    def set_climate(self, site, clim):
+        check(self.L.sipnet_batch_set_climate(self.h, site, clim.n_steps, clim.data.ctypes.data,
+                                              clim.year.ctypes.data, clim.day.ctypes.data),
+              "set_climate")
+        self.n_steps = clim.n_steps
+
+    def set_events(self, site, events):
+        n = len(events)
+        arr = (Event * max(n, 1))(*events)
+        check(self.L.sipnet_batch_set_events(self.h, site, n, arr), "set_events")
+
+    def set_params(self, site, raw, first_member=0):
+        raw = np.ascontiguousarray(raw, dtype=np.float64)
+        if raw.ndim == 1:
+            raw = np.broadcast_to(raw, (self.n_members, NPARAMS)).copy()
+        assert raw.shape[1] == NPARAMS
+        check(self.L.sipnet_batch_set_params(self.h, site, first_member, raw.shape[0],
+                                             raw.ctypes.data), "set_params")
+
+    def setup(self):
+        """== setupModel() for every member (sipnet.c:1858-1951)."""
+        check(self.L.sipnet_batch_setup(self.h, self._stream()), "setup")
+
+    # -- run --------------------------------------------------------------------
+    def alloc_outputs(self, n_steps, full=False):
+        t = self._torch
+        planes = t.empty((3, n_steps, self.ncol), dtype=self.out_dtype, device=self.device)
+        rec = (t.empty((n_steps, NREC, self.ncol), dtype=t.float64, device=self.device)
+               if full else None)
+        return planes, rec
+
+    def run(self, step0=0, n_steps=None, planes=None, rec=None, want_planes=True, full=False):
+        """== the time loop of runModelOutput() (sipnet.c:1969-1982).
+
+        Returns (planes, rec): planes[3][n_steps][ncol] = NEE, GPP, ET per step;
+        rec[n_steps][36][ncol] full records when `full`."""
+        if n_steps is None:
+            n_steps = self.n_steps - step0
+        if planes is None and want_planes:
+            planes, _ = self.alloc_outputs(n_steps, False)
+        if rec is None and full:
+            rec = self._torch.empty((n_steps, NREC, self.ncol), dtype=self._torch.float64,
+                                    device=self.device)
+        ptr = lambda x: C.c_void_p(x.data_ptr()) if x is not None else None
+        nee = planes[0] if planes is not None else None
+        gpp = planes[1] if planes is not None else None
+        et = planes[2] if planes is not None else None
+        check(self.L.sipnet_batch_run(self.h, step0, n_steps, ptr(nee), ptr(gpp), ptr(et),
+                                      ptr(rec), self.ncol, self._stream()), "run")
+        return planes, rec
+
+    def reduce_plane(self, plane, stats=None):
+        """Per (step, site) ensemble sum and sum of squares of one output plane
+        [n_steps][ncol] -> stats[n_steps][n_sites][2] (float64, on device)."""
+        t = self._torch
+        n_steps = plane.shape[0]
+        if stats is None:
+            stats = t.empty((n_steps, self.n_sites, 2), dtype=t.float64, device=self.device)
+        check(self.L.sipnet_batch_reduce_plane(self.h, C.c_void_p(plane.data_ptr()),
+                                               int(plane.dtype == t.float32), n_steps, self.ncol,
+                                               C.c_void_p(stats.data_ptr()), self._stream()),
+              "reduce_plane")
+        return stats
+
+    def last_kernel_ms(self):
+        return self.L.sipnet_batch_last_kernel_ms(self.h)
+
+    # -- state ------------------------------------------------------------------
+    def get_state(self):
+        st = np.zeros((self.ncol, NSTATE))
+        check(self.L.sipnet_batch_get_state(self.h, st.ctypes.data, self._stream()), "get_state")
+        return st
+
+    def set_state(self, st):
+        st = np.ascontiguousarray(st, dtype=np.float64)
+        assert st.shape == (self.ncol, NSTATE)
+        check(self.L.sipnet_batch_set_state(self.h, st.ctypes.data, self._stream()), "set_state")
+
+    def get_status(self):
+        s = np.zeros(self.ncol, dtype=np.int32)
+        check(self.L.sipnet_batch_get_status(self.h, s.ctypes.data, self._stream()), "get_status")
+        return s
+
+    def get_ring(self, col):
+        v = np.zeros(RING_SLOTS)
+        check(self.L.sipnet_batch_get_ring(self.h, col, v.ctypes.data, self._stream()), "get_ring")
+        return v
+
+    def site_series(self, site):
+        g = np.zeros(self.n_steps)
+        d = np.zeros(self.n_steps)
+        check(self.L.sipnet_batch_get_site_series(self.h, site, g.ctypes.data, d.ctypes.data),
+              "site_series")
+        return g, d

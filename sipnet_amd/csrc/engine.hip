@@ -1,0 +1,470 @@
+// engine.hip -- the batch object behind include/sipnet_amd.h: HBM layout,
+// uploads, launches.  No CPU compute path exists here: every compute entry
+// point needs a HIP device and reports SIPNET_ERR_NO_DEVICE otherwise.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/sipnet_amd.h"
+#include "plan.h"
+#include "step_kernel.h"
+
+namespace sipnet {
+thread_local std::string g_lastError;
+void setError(const std::string& s) { g_lastError = s; }
+}  // namespace sipnet
+
+using namespace sipnet;
+
+#define HIP_TRY(expr)                                                         \
+  do {                                                                        \
+    hipError_t e_ = (expr);                                                   \
+    if (e_ != hipSuccess) {                                                   \
+      setError(std::string(#expr) + ": " + hipGetErrorString(e_));            \
+      return SIPNET_ERR_NO_DEVICE;                                            \
+    }                                                                         \
+  } while (0)
+
+struct sipnet_batch {
+  int32_t flags[SIPNET_NFLAGS];
+  int32_t n_sites = 0, n_members = 0, precision = 0, device = 0;
+  int64_t ncol = 0;
+  int32_t n_steps = 0;  // steps per site (all sites equal)
+  bool fastMath = false;
+
+  // host-side inputs kept so the plan can be rebuilt in any call order
+  std::vector<std::vector<double>> clim;       // per site [n_steps*NCLIM]
+  std::vector<std::vector<int32_t>> year, day;
+  std::vector<std::vector<sipnet_event>> events;
+  std::vector<SitePlan> plans;
+  std::vector<int32_t> siteStatus;
+  bool planDirty = true;
+
+  // HBM
+  double* d_raw = nullptr;     // [ncol][NPARAMS] raw upload (AoS)
+  double* d_prm = nullptr;     // [NPARAMS][ncol]
+  double* d_state = nullptr;   // [NSTATE][ncol]
+  double* d_ring = nullptr;    // [RING_SLOTS][ncol]
+  StepRec* d_plan = nullptr;   // [n_sites][n_steps]
+  RingOp* d_ringOps = nullptr;
+  EvRec* d_events = nullptr;
+  int32_t* d_siteStatus = nullptr;
+  size_t planCap = 0, ringOpCap = 0, evCap = 0;
+
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timed = false;
+  double lastMs = -1.0;
+};
+
+static int useDevice(const sipnet_batch* b) {
+  HIP_TRY(hipSetDevice(b->device));
+  return SIPNET_OK;
+}
+
+static int uploadPlan(sipnet_batch* b, hipStream_t stream) {
+  // every site needs forcing of equal length
+  for (int s = 0; s < b->n_sites; s++) {
+    if ((int)b->year[s].size() != b->n_steps || b->n_steps == 0) {
+      setError("sipnet_batch: climate not set for every site (or unequal lengths)");
+      return SIPNET_ERR_BAD_ARGUMENT;
+    }
+  }
+  b->plans.clear();
+  b->plans.reserve(b->n_sites);
+  size_t nOps = 0, nEv = 0;
+  for (int s = 0; s < b->n_sites; s++) {
+    b->plans.push_back(buildSitePlan(b->flags, b->n_steps, b->clim[s].data(),
+                                     b->year[s].data(), b->day[s].data(),
+                                     (int32_t)b->events[s].size(), b->events[s].data()));
+    b->siteStatus[s] = b->plans[s].status;
+    nOps += b->plans[s].ringOps.size();
+    nEv += b->plans[s].events.size();
+  }
+  // flatten: make op / event indices global
+  std::vector<StepRec> steps((size_t)b->n_sites * b->n_steps);
+  std::vector<RingOp> ops;
+  std::vector<EvRec> evs;
+  ops.reserve(nOps + 1);
+  evs.reserve(nEv + 1);
+  for (int s = 0; s < b->n_sites; s++) {
+    const SitePlan& p = b->plans[s];
+    const int32_t opBase = (int32_t)ops.size(), evBase = (int32_t)evs.size();
+    for (int t = 0; t < b->n_steps; t++) {
+      StepRec r = p.steps[t];
+      r.ringOpFirst += opBase;
+      r.evFirst += evBase;
+      steps[(size_t)s * b->n_steps + t] = r;
+    }
+    ops.insert(ops.end(), p.ringOps.begin(), p.ringOps.end());
+    evs.insert(evs.end(), p.events.begin(), p.events.end());
+  }
+  if (ops.empty()) ops.push_back(RingOp{0.0, 0, -1});
+  if (evs.empty()) evs.push_back(EvRec{0, 0, {0, 0, 0, 0}});
+
+  if (steps.size() > b->planCap) {
+    if (b->d_plan) HIP_TRY(hipFree(b->d_plan));
+    HIP_TRY(hipMalloc(&b->d_plan, steps.size() * sizeof(StepRec)));
+    b->planCap = steps.size();
+  }
+  if (ops.size() > b->ringOpCap) {
+    if (b->d_ringOps) HIP_TRY(hipFree(b->d_ringOps));
+    HIP_TRY(hipMalloc(&b->d_ringOps, ops.size() * sizeof(RingOp)));
+    b->ringOpCap = ops.size();
+  }
+  if (evs.size() > b->evCap) {
+    if (b->d_events) HIP_TRY(hipFree(b->d_events));
+    HIP_TRY(hipMalloc(&b->d_events, evs.size() * sizeof(EvRec)));
+    b->evCap = evs.size();
+  }
+  // synchronous copies: the host vectors die at return
+  HIP_TRY(hipMemcpy(b->d_plan, steps.data(), steps.size() * sizeof(StepRec), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(b->d_ringOps, ops.data(), ops.size() * sizeof(RingOp), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(b->d_events, evs.data(), evs.size() * sizeof(EvRec), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(b->d_siteStatus, b->siteStatus.data(), b->n_sites * sizeof(int32_t),
+                    hipMemcpyHostToDevice));
+  (void)stream;
+  b->planDirty = false;
+  return SIPNET_OK;
+}
+
+extern "C" {
+
+const char* sipnet_version(void) { return "sipnet_amd 0.1 (reference SIPNET 2.1.0)"; }
+const char* sipnet_last_error(void) { return g_lastError.c_str(); }
+
+int sipnet_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int sipnet_batch_create(const int32_t* flags, int32_t n_sites, int32_t n_members,
+                        int32_t precision, int32_t device, sipnet_batch** out) {
+  if (!flags || !out || n_sites <= 0 || n_members <= 0 ||
+      (precision != SIPNET_F64 && precision != SIPNET_F32_MIXED)) {
+    setError("sipnet_batch_create: bad argument");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  // flag coupling rules, common/context.c:195-223
+  if ((flags[SIPNET_F_SOIL_PHENOL] && flags[SIPNET_F_GDD]) ||
+      (flags[SIPNET_F_NITROGEN_CYCLE] &&
+       !(flags[SIPNET_F_LITTER_POOL] && flags[SIPNET_F_ANAEROBIC])) ||
+      (flags[SIPNET_F_ANAEROBIC] && !flags[SIPNET_F_WATER_HRESP]) ||
+      (flags[SIPNET_F_CARBON_SATURATION] && !flags[SIPNET_F_LITTER_POOL])) {
+    setError("sipnet_batch_create: incompatible model flags (context.c:195-223)");
+    return SIPNET_ERR_BAD_PARAMETER;
+  }
+  if (sipnet_device_count() <= device || device < 0) {
+    setError("sipnet_batch_create: no usable HIP device (this engine has no CPU path)");
+    return SIPNET_ERR_NO_DEVICE;
+  }
+  sipnet_batch* b = new sipnet_batch();
+  memcpy(b->flags, flags, sizeof(b->flags));
+  b->n_sites = n_sites;
+  b->n_members = n_members;
+  b->precision = precision;
+  b->device = device;
+  b->ncol = (int64_t)n_sites * n_members;
+  b->fastMath = (precision == SIPNET_F32_MIXED);
+  const char* fm = getenv("SIPNET_FAST_MATH");
+  if (fm && precision == SIPNET_F64) b->fastMath = atoi(fm) != 0;
+  b->clim.resize(n_sites);
+  b->year.resize(n_sites);
+  b->day.resize(n_sites);
+  b->events.resize(n_sites);
+  b->siteStatus.assign(n_sites, 0);
+  int rc = useDevice(b);
+  if (rc) { delete b; return rc; }
+  const size_t nc = (size_t)b->ncol;
+  hipError_t e = hipSuccess;
+  if (e == hipSuccess) e = hipMalloc(&b->d_raw, nc * SIPNET_NPARAMS * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(&b->d_prm, nc * SIPNET_NPARAMS * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(&b->d_state, nc * SIPNET_NSTATE * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(&b->d_ring, nc * SIPNET_RING_SLOTS * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(&b->d_siteStatus, n_sites * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMemset(b->d_raw, 0, nc * SIPNET_NPARAMS * sizeof(double));
+  if (e == hipSuccess) e = hipMemset(b->d_state, 0, nc * SIPNET_NSTATE * sizeof(double));
+  if (e == hipSuccess) e = hipEventCreate(&b->ev0);
+  if (e == hipSuccess) e = hipEventCreate(&b->ev1);
+  if (e != hipSuccess) {
+    setError(std::string("sipnet_batch_create: ") + hipGetErrorString(e));
+    sipnet_batch_destroy(b);
+    return SIPNET_ERR_NO_DEVICE;
+  }
+  *out = b;
+  return SIPNET_OK;
+}
+
+void sipnet_batch_destroy(sipnet_batch* b) {
+  if (!b) return;
+  (void)hipSetDevice(b->device);
+  if (b->d_raw) (void)hipFree(b->d_raw);
+  if (b->d_prm) (void)hipFree(b->d_prm);
+  if (b->d_state) (void)hipFree(b->d_state);
+  if (b->d_ring) (void)hipFree(b->d_ring);
+  if (b->d_plan) (void)hipFree(b->d_plan);
+  if (b->d_ringOps) (void)hipFree(b->d_ringOps);
+  if (b->d_events) (void)hipFree(b->d_events);
+  if (b->d_siteStatus) (void)hipFree(b->d_siteStatus);
+  if (b->ev0) (void)hipEventDestroy(b->ev0);
+  if (b->ev1) (void)hipEventDestroy(b->ev1);
+  delete b;
+}
+
+int sipnet_batch_set_climate(sipnet_batch* b, int32_t site, int32_t n_steps,
+                             const double* clim, const int32_t* year, const int32_t* day) {
+  if (!b || site < 0 || site >= b->n_sites || n_steps <= 0 || !clim || !year || !day) {
+    setError("sipnet_batch_set_climate: bad argument");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  if (b->n_steps != 0 && b->n_steps != n_steps) {
+    bool othersSet = false;
+    for (int s = 0; s < b->n_sites; s++)
+      if (s != site && !b->year[s].empty()) othersSet = true;
+    if (othersSet) {
+      setError("sipnet_batch_set_climate: all sites must have the same number of steps");
+      return SIPNET_ERR_BAD_ARGUMENT;
+    }
+  }
+  b->n_steps = n_steps;
+  b->clim[site].assign(clim, clim + (size_t)n_steps * SIPNET_NCLIM);
+  b->year[site].assign(year, year + n_steps);
+  b->day[site].assign(day, day + n_steps);
+  b->planDirty = true;
+  return SIPNET_OK;
+}
+
+int sipnet_batch_set_events(sipnet_batch* b, int32_t site, int32_t n_events,
+                            const sipnet_event* events) {
+  if (!b || site < 0 || site >= b->n_sites || n_events < 0 || (n_events > 0 && !events)) {
+    setError("sipnet_batch_set_events: bad argument");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  for (int i = 0; i < n_events; i++) {
+    if (events[i].type < SIPNET_EV_FERT || events[i].type > SIPNET_EV_LEAFOFF) {
+      setError("sipnet_batch_set_events: unknown event type");
+      return SIPNET_ERR_UNKNOWN_EVENT;
+    }
+    // events.c:334-341: records must be in time-ascending order
+    if (i > 0 && (events[i].year < events[i - 1].year ||
+                  (events[i].year == events[i - 1].year && events[i].day < events[i - 1].day))) {
+      setError("sipnet_batch_set_events: event records must be in time-ascending order");
+      return SIPNET_ERR_INPUT_FILE;
+    }
+  }
+  b->events[site].assign(events, events + n_events);
+  b->planDirty = true;
+  return SIPNET_OK;
+}
+
+int sipnet_batch_set_params(sipnet_batch* b, int32_t site, int32_t first_member,
+                            int32_t count, const double* raw) {
+  if (!b || site < 0 || site >= b->n_sites || first_member < 0 || count <= 0 ||
+      first_member + count > b->n_members || !raw) {
+    setError("sipnet_batch_set_params: bad argument");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  int rc = useDevice(b);
+  if (rc) return rc;
+  const int64_t col0 = (int64_t)site * b->n_members + first_member;
+  HIP_TRY(hipMemcpy(b->d_raw + col0 * SIPNET_NPARAMS, raw,
+                    (size_t)count * SIPNET_NPARAMS * sizeof(double), hipMemcpyHostToDevice));
+  return SIPNET_OK;
+}
+
+int sipnet_batch_setup(sipnet_batch* b, void* hip_stream) {
+  if (!b) return SIPNET_ERR_BAD_ARGUMENT;
+  int rc = useDevice(b);
+  if (rc) return rc;
+  hipStream_t stream = (hipStream_t)hip_stream;
+  if (b->planDirty) {
+    rc = uploadPlan(b, stream);
+    if (rc) return rc;
+  }
+  SetupArgs a;
+  a.plan = b->d_plan;
+  a.raw = b->d_raw;
+  a.prm = b->d_prm;
+  a.state = b->d_state;
+  a.ring = b->d_ring;
+  a.ncol = b->ncol;
+  a.n_sites = b->n_sites;
+  a.n_members = b->n_members;
+  a.n_steps_total = b->n_steps;
+  memcpy(a.flags, b->flags, sizeof(a.flags));
+  a.siteStatus = b->d_siteStatus;
+  launchSetup(a, stream);
+  HIP_TRY(hipGetLastError());
+  // a site-fatal plan condition is reported like the reference's exit code
+  for (int s = 0; s < b->n_sites; s++) {
+    if (b->siteStatus[s] != SIPNET_OK) {
+      setError("site " + std::to_string(s) + ": " + b->plans[s].message);
+      return b->siteStatus[s];
+    }
+  }
+  return SIPNET_OK;
+}
+
+int sipnet_batch_run(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
+                     void* d_gpp, void* d_et, double* d_rec, int64_t ld, void* hip_stream) {
+  if (!b || step0 < 0 || n_steps < 0 || step0 + n_steps > b->n_steps) {
+    setError("sipnet_batch_run: step range outside the climate record");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  if ((d_nee || d_gpp || d_et || d_rec) && ld < b->ncol) {
+    setError("sipnet_batch_run: ld smaller than the number of columns");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  if (b->planDirty) {
+    setError("sipnet_batch_run: call sipnet_batch_setup after changing climate/events");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  if (n_steps == 0) return SIPNET_OK;
+  int rc = useDevice(b);
+  if (rc) return rc;
+  hipStream_t stream = (hipStream_t)hip_stream;
+  KernelArgs a;
+  a.plan = b->d_plan;
+  a.ringOps = b->d_ringOps;
+  a.events = b->d_events;
+  a.prm = b->d_prm;
+  a.state = b->d_state;
+  a.ring = b->d_ring;
+  a.nee = d_nee;
+  a.gpp = d_gpp;
+  a.et = d_et;
+  a.rec = d_rec;
+  a.ncol = b->ncol;
+  a.ld = ld;
+  a.n_sites = b->n_sites;
+  a.n_members = b->n_members;
+  a.n_steps_total = b->n_steps;
+  a.step0 = step0;
+  a.n_steps = n_steps;
+  memcpy(a.flags, b->flags, sizeof(a.flags));
+  HIP_TRY(hipEventRecord(b->ev0, stream));
+  launchStep(a, b->precision, b->fastMath, stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(b->ev1, stream));
+  b->timed = true;
+  return SIPNET_OK;
+}
+
+double sipnet_batch_last_kernel_ms(sipnet_batch* b) {
+  if (!b || !b->timed) return -1.0;
+  if (hipSetDevice(b->device) != hipSuccess) return -1.0;
+  if (hipEventSynchronize(b->ev1) != hipSuccess) return -1.0;
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, b->ev0, b->ev1) != hipSuccess) return -1.0;
+  b->lastMs = ms;
+  return (double)ms;
+}
+
+int sipnet_batch_reduce_plane(sipnet_batch* b, const void* d_plane, int32_t elem_is_f32,
+                              int32_t n_steps, int64_t ld, double* d_stats,
+                              void* hip_stream) {
+  if (!b || !d_plane || !d_stats || n_steps <= 0 || ld < b->ncol) {
+    setError("sipnet_batch_reduce_plane: bad argument");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  int rc = useDevice(b);
+  if (rc) return rc;
+  launchReducePlane(d_plane, elem_is_f32 != 0, n_steps, ld, b->n_sites, b->n_members,
+                    d_stats, (hipStream_t)hip_stream);
+  HIP_TRY(hipGetLastError());
+  return SIPNET_OK;
+}
+
+// state is exchanged with the host as [ncol][NSTATE]; HBM holds [NSTATE][ncol]
+int sipnet_batch_get_state(sipnet_batch* b, double* state, void* hip_stream) {
+  if (!b || !state) return SIPNET_ERR_BAD_ARGUMENT;
+  int rc = useDevice(b);
+  if (rc) return rc;
+  hipStream_t stream = (hipStream_t)hip_stream;
+  HIP_TRY(hipStreamSynchronize(stream));
+  std::vector<double> tmp((size_t)b->ncol * SIPNET_NSTATE);
+  HIP_TRY(hipMemcpy(tmp.data(), b->d_state, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+  for (int k = 0; k < SIPNET_NSTATE; k++)
+    for (int64_t c = 0; c < b->ncol; c++)
+      state[c * SIPNET_NSTATE + k] = tmp[(size_t)k * b->ncol + c];
+  return SIPNET_OK;
+}
+
+int sipnet_batch_set_state(sipnet_batch* b, const double* state, void* hip_stream) {
+  if (!b || !state) return SIPNET_ERR_BAD_ARGUMENT;
+  int rc = useDevice(b);
+  if (rc) return rc;
+  hipStream_t stream = (hipStream_t)hip_stream;
+  HIP_TRY(hipStreamSynchronize(stream));
+  std::vector<double> tmp((size_t)b->ncol * SIPNET_NSTATE);
+  for (int k = 0; k < SIPNET_NSTATE; k++)
+    for (int64_t c = 0; c < b->ncol; c++)
+      tmp[(size_t)k * b->ncol + c] = state[c * SIPNET_NSTATE + k];
+  HIP_TRY(hipMemcpy(b->d_state, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+  return SIPNET_OK;
+}
+
+int sipnet_batch_get_ring(sipnet_batch* b, int64_t col, double* values, void* hip_stream) {
+  if (!b || !values || col < 0 || col >= b->ncol) return SIPNET_ERR_BAD_ARGUMENT;
+  int rc = useDevice(b);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize((hipStream_t)hip_stream));
+  HIP_TRY(hipMemcpy2D(values, sizeof(double), b->d_ring + col, (size_t)b->ncol * sizeof(double),
+                      sizeof(double), SIPNET_RING_SLOTS, hipMemcpyDeviceToHost));
+  return SIPNET_OK;
+}
+
+int sipnet_batch_get_status(sipnet_batch* b, int32_t* status, void* hip_stream) {
+  if (!b || !status) return SIPNET_ERR_BAD_ARGUMENT;
+  int rc = useDevice(b);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize((hipStream_t)hip_stream));
+  std::vector<double> tmp((size_t)b->ncol);
+  HIP_TRY(hipMemcpy(tmp.data(), b->d_state + (size_t)ST_status * b->ncol,
+                    tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+  for (int64_t c = 0; c < b->ncol; c++) status[c] = (int32_t)tmp[c];
+  return SIPNET_OK;
+}
+
+int64_t sipnet_batch_ncol(const sipnet_batch* b) { return b ? b->ncol : 0; }
+int32_t sipnet_batch_nsteps(const sipnet_batch* b) { return b ? b->n_steps : 0; }
+
+int sipnet_batch_get_site_series(sipnet_batch* b, int32_t site, double* gdd,
+                                 double* d_till_mod) {
+  if (!b || site < 0 || site >= b->n_sites || b->planDirty ||
+      (int)b->plans.size() != b->n_sites)
+    return SIPNET_ERR_BAD_ARGUMENT;
+  const SitePlan& p = b->plans[site];
+  for (int t = 0; t < b->n_steps; t++) {
+    if (gdd) gdd[t] = p.steps[t].gddAfter;
+    if (d_till_mod) d_till_mod[t] = p.steps[t].dTill;
+  }
+  return SIPNET_OK;
+}
+
+void* sipnet_dev_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (hipMalloc(&p, bytes) != hipSuccess) {
+    setError("sipnet_dev_alloc: hipMalloc failed");
+    return nullptr;
+  }
+  return p;
+}
+void sipnet_dev_free(void* p) {
+  if (p) (void)hipFree(p);
+}
+int sipnet_dev_to_host(void* host, const void* dev, size_t bytes, void* hip_stream) {
+  HIP_TRY(hipStreamSynchronize((hipStream_t)hip_stream));
+  HIP_TRY(hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost));
+  return SIPNET_OK;
+}
+int sipnet_stream_sync(void* hip_stream) {
+  HIP_TRY(hipStreamSynchronize((hipStream_t)hip_stream));
+  return SIPNET_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,449 @@
+// host_io.cpp -- SIPNET's text formats at the drop-in boundary (host only).
+//
+// Readers for `<prefix>.clim`, `<prefix>.param`, `events.in` and writers for
+// `<prefix>.out`, behaving like the reference's (citations relative to
+// /root/reference/src/), re-written around std::string / std::vector with
+// status returns instead of exit().
+#include <strings.h>
+
+#include <cctype>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/sipnet_amd.h"
+
+namespace sipnet {
+void setError(const std::string& s);
+
+namespace {
+constexpr double kTiny = 0.000001;  // common/util.h:14
+
+struct ParamDef {
+  const char* name;
+  int rule;
+};
+enum Rule {
+  ALWAYS, NEVER, GROWTH_RESP, LEAF_DAY, GDD, SOIL_PHENOL, LITTER_POOL, WATER_HRESP,
+  LEAF_WATER, SNOW, NCYCLE, ANAEROBIC_OR_NCYCLE, ANAEROBIC, FLOODING, CSAT
+};
+const ParamDef kParams[SIPNET_NPARAMS] = {
+#define SIPNET_PARAM(idx, field, fname, rule) {fname, rule},
+#include "../../include/sipnet_params.def"
+#undef SIPNET_PARAM
+};
+
+// required-ness of a parameter under a flag set, sipnet.c:300-396
+bool isRequired(int rule, const int32_t* f) {
+  switch (rule) {
+    case ALWAYS: return true;
+    case NEVER: return false;
+    case GROWTH_RESP: return f[SIPNET_F_GROWTH_RESP] != 0;
+    case LEAF_DAY: return !(f[SIPNET_F_GDD] || f[SIPNET_F_SOIL_PHENOL]);
+    case GDD: return f[SIPNET_F_GDD] != 0;
+    case SOIL_PHENOL: return f[SIPNET_F_SOIL_PHENOL] != 0;
+    case LITTER_POOL: return f[SIPNET_F_LITTER_POOL] != 0;
+    case WATER_HRESP: return f[SIPNET_F_WATER_HRESP] != 0;
+    case LEAF_WATER: return f[SIPNET_F_LEAF_WATER] != 0;
+    case SNOW: return f[SIPNET_F_SNOW] != 0;
+    case NCYCLE: return f[SIPNET_F_NITROGEN_CYCLE] != 0;
+    case ANAEROBIC_OR_NCYCLE: return f[SIPNET_F_ANAEROBIC] || f[SIPNET_F_NITROGEN_CYCLE];
+    case ANAEROBIC: return f[SIPNET_F_ANAEROBIC] != 0;
+    case FLOODING: return f[SIPNET_F_FLOODING] != 0;
+    case CSAT: return f[SIPNET_F_CARBON_SATURATION] != 0;
+  }
+  return false;
+}
+
+std::vector<std::string> splitFields(const std::string& line) {
+  std::vector<std::string> out;
+  size_t i = 0;
+  while (i < line.size()) {
+    while (i < line.size() && strchr(" \t\n\r", line[i])) i++;
+    if (i >= line.size()) break;
+    size_t j = i;
+    while (j < line.size() && !strchr(" \t\n\r", line[j])) j++;
+    out.push_back(line.substr(i, j - i));
+    i = j;
+  }
+  return out;
+}
+
+// strtod over a whole token; false when trailing garbage remains (fscanf %lf
+// semantics: a partial match fails the field)
+bool parseDouble(const std::string& tok, double& v) {
+  char* end = nullptr;
+  v = strtod(tok.c_str(), &end);
+  return end != tok.c_str() && *end == '\0';
+}
+bool parseInt(const std::string& tok, int& v) {
+  char* end = nullptr;
+  long x = strtol(tok.c_str(), &end, 10);
+  v = (int)x;
+  return end != tok.c_str() && *end == '\0';
+}
+}  // namespace
+}  // namespace sipnet
+
+using namespace sipnet;
+
+struct sipnet_clim_table {
+  std::vector<double> data;  // [n][SIPNET_NCLIM]
+  std::vector<int32_t> year, day;
+};
+
+extern "C" {
+
+// ---------------------------------------------------------------- .clim
+// sipnet.c:128-277.  The reference reads the remainder of the file with fscanf,
+// i.e. as one whitespace-separated token stream; line breaks are not significant
+// after the first line, so the same is done here.
+int sipnet_io_read_clim(const char* path, int32_t gdd_flag, sipnet_clim_table** out) {
+  if (!path || !out) return SIPNET_ERR_BAD_ARGUMENT;
+  std::ifstream in(path);
+  if (!in) {
+    setError(std::string("Error opening ") + path + " for reading");
+    return SIPNET_ERR_FILE_OPEN;
+  }
+  std::string first;
+  if (!std::getline(in, first)) {
+    setError(std::string("no climate data in ") + path);
+    return SIPNET_ERR_INPUT_FILE;
+  }
+  const std::vector<std::string> f0 = splitFields(first);
+  int ncols;
+  bool legacy;
+  if (f0.size() == 12) {
+    ncols = 12;
+    legacy = false;
+  } else if (f0.size() == 14) {
+    ncols = 14;
+    legacy = true;
+  } else {
+    setError("format unrecognized in climate file " + std::string(path) + "; " +
+             std::to_string(f0.size()) + " columns found, expected 12 or 14 (legacy format)");
+    return SIPNET_ERR_INPUT_FILE;
+  }
+  std::vector<std::string> toks = f0;
+  {
+    std::string rest((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    std::vector<std::string> more = splitFields(rest);
+    toks.insert(toks.end(), more.begin(), more.end());
+  }
+  auto* tab = new sipnet_clim_table();
+  const size_t nrec = toks.size() / ncols;
+  int firstLoc = 0;
+  int lastYear = 0, lastDay = 0;
+  for (size_t r = 0; r <= nrec; r++) {
+    const size_t base = r * ncols;
+    if (base >= toks.size()) break;
+    if (toks.size() - base < (size_t)ncols) {  // partial trailing record
+      setError("while reading climate file: bad data near year " + std::to_string(lastYear) +
+               " day " + std::to_string(lastDay));
+      delete tab;
+      return SIPNET_ERR_INPUT_FILE;
+    }
+    size_t k = base;
+    int loc = 0, year, day;
+    double v[10];  // time length tair tsoil par precip vpd vpdSoil vPress wspd
+    bool ok = true;
+    if (legacy) ok = ok && parseInt(toks[k++], loc);
+    ok = ok && parseInt(toks[k++], year) && parseInt(toks[k++], day);
+    for (int j = 0; j < 10 && ok; j++) ok = parseDouble(toks[k++], v[j]);
+    if (legacy && ok) {
+      double soilWetness;
+      ok = parseDouble(toks[k++], soilWetness);
+    }
+    if (!ok) {
+      setError(r == 0 ? std::string("while reading climate file: bad data on first line")
+                      : "while reading climate file: bad data near year " +
+                            std::to_string(lastYear) + " day " + std::to_string(lastDay));
+      delete tab;
+      return SIPNET_ERR_INPUT_FILE;
+    }
+    if (legacy) {
+      if (r == 0) {
+        firstLoc = loc;
+      } else if (loc != firstLoc) {  // sipnet.c:258-264
+        setError("while reading legacy climate file " + std::string(path) +
+                 ": multiple locations not supported");
+        delete tab;
+        return SIPNET_ERR_INPUT_FILE;
+      }
+    }
+    lastYear = year;
+    lastDay = day;
+    double time = v[0], length = v[1];
+    const double tair = v[2], tsoil = v[3], par = v[4], precip = v[5];
+    double vpd = v[6];
+    const double vpdSoil = v[7], vPress = v[8];
+    double wspd = v[9];
+    // unit conversions, sipnet.c:209-238
+    if (length < 0) length = length / -86400.;
+    const double parRate = par * (1.0 / length);
+    vpd = vpd * 0.001;
+    if (vpd < kTiny) vpd = kTiny;
+    if (wspd < kTiny) wspd = kTiny;
+    double gdd = 0.0;
+    if (gdd_flag) {
+      gdd = tair * length;
+      if (gdd < 0) gdd = 0;
+    }
+    const double rec[SIPNET_NCLIM] = {length, tair, tsoil, parRate, precip * 0.1, vpd,
+                                      vpdSoil * 0.001, vPress * 0.001, wspd, gdd, time};
+    tab->data.insert(tab->data.end(), rec, rec + SIPNET_NCLIM);
+    tab->year.push_back(year);
+    tab->day.push_back(day);
+  }
+  *out = tab;
+  return SIPNET_OK;
+}
+int32_t sipnet_clim_nsteps(const sipnet_clim_table* t) { return t ? (int32_t)t->year.size() : 0; }
+const double* sipnet_clim_data(const sipnet_clim_table* t) { return t ? t->data.data() : nullptr; }
+const int32_t* sipnet_clim_year(const sipnet_clim_table* t) { return t ? t->year.data() : nullptr; }
+const int32_t* sipnet_clim_day(const sipnet_clim_table* t) { return t ? t->day.data() : nullptr; }
+void sipnet_clim_free(sipnet_clim_table* t) { delete t; }
+
+// ---------------------------------------------------------------- .param
+const char* sipnet_param_name(int32_t index) {
+  if (index < 0 || index >= SIPNET_NPARAMS) return "";
+  return kParams[index].name;
+}
+int32_t sipnet_param_index(const char* name) {  // modelParams.c:240-258
+  if (!name || !*name) return -1;
+  for (int i = 0; i < SIPNET_NPARAMS; i++)
+    if (kParams[i].name[0] && strcasecmp(name, kParams[i].name) == 0) return i;
+  return -1;
+}
+
+// modelParams.c:136-230 + sipnet.c:290-427
+int sipnet_io_read_params(const char* path, const int32_t* flags, double* out,
+                          int32_t* is_read) {
+  if (!path || !flags || !out) return SIPNET_ERR_BAD_ARGUMENT;
+  std::ifstream in(path);
+  if (!in) {
+    setError(std::string("Error opening ") + path + " for reading");
+    return SIPNET_ERR_FILE_OPEN;
+  }
+  bool seen[SIPNET_NPARAMS] = {false};
+  for (int i = 0; i < SIPNET_NPARAMS; i++) out[i] = 0.0;  // globals start at zero
+  std::string line;
+  while (std::getline(in, line)) {
+    const size_t bang = line.find('!');
+    if (bang != std::string::npos) line.erase(bang);
+    const std::vector<std::string> tok = splitFields(line);
+    if (tok.empty()) continue;
+    if (tok.size() < 2) {
+      setError("reading parameter file: no value for " + tok[0]);
+      return SIPNET_ERR_INPUT_FILE;
+    }
+    if (tok[1] == "*") {
+      setError("reading parameter " + tok[0] + "; '*' is no longer supported");
+      return SIPNET_ERR_BAD_PARAMETER;
+    }
+    const int idx = sipnet_param_index(tok[0].c_str());
+    if (idx < 0) continue;  // unknown names are ignored
+    if (seen[idx]) {
+      setError("reading parameter file: read " + tok[0] +
+               ", but this parameter has already been set");
+      return SIPNET_ERR_INPUT_FILE;
+    }
+    out[idx] = strtod(tok[1].c_str(), nullptr);
+    seen[idx] = true;
+  }
+  std::string missing;
+  for (int i = 0; i < SIPNET_NPARAMS; i++) {
+    if (is_read) is_read[i] = seen[i] ? 1 : 0;
+    if (!seen[i] && isRequired(kParams[i].rule, flags)) {
+      if (!missing.empty()) missing += ", ";
+      missing += kParams[i].name;
+    }
+  }
+  if (!missing.empty()) {
+    setError("Did not find required parameter(s): " + missing);
+    return SIPNET_ERR_INPUT_FILE;
+  }
+  // divisor clamps, sipnet.c:404-424
+  const int clamp[] = {25 /*cFracLeaf*/, 12 /*halfSatPar*/, 23 /*soilWHC*/, 24 /*leafCSpWt*/,
+                       66 /*leafCN*/,    67 /*woodCN*/,     68 /*fineRootCN*/};
+  for (int idx : clamp)
+    if (out[idx] < kTiny) out[idx] = kTiny;
+  return SIPNET_OK;
+}
+
+// ---------------------------------------------------------------- events.in
+// events.c:39-184, :210-367
+int sipnet_io_read_events(const char* path, const int32_t* flags, const double* params,
+                          sipnet_event** out, int32_t* n_events) {
+  if (!path || !flags || !out || !n_events) return SIPNET_ERR_BAD_ARGUMENT;
+  *out = nullptr;
+  *n_events = 0;
+  std::ifstream in(path);
+  if (!in) return SIPNET_OK;  // no file: no events (events.c:276-281)
+  std::vector<sipnet_event> evs;
+  std::string line;
+  bool checkedLeaf = false;
+  int curYear = 0, curDay = 0;
+  while (std::getline(in, line)) {
+    if (line.size() >= 1023) {  // events.c:246-252
+      setError("Event line too long (exceeds 1024 chars), data may be truncated");
+      return SIPNET_ERR_INPUT_FILE;
+    }
+    const std::vector<std::string> tok = splitFields(line);
+    int year, day;
+    if (tok.size() < 3 || !parseInt(tok[0], year) || !parseInt(tok[1], day)) {
+      setError(evs.empty() ? std::string("reading event file: bad data on first line")
+                           : "reading event file: bad data on line after year " +
+                                 std::to_string(curYear) + " day " + std::to_string(curDay));
+      return SIPNET_ERR_INPUT_FILE;
+    }
+    static const struct { const char* s; int t; int n; } kinds[] = {
+        {"irrig", SIPNET_EV_IRRIG, 2}, {"fert", SIPNET_EV_FERT, 3},
+        {"plant", SIPNET_EV_PLANT, 4}, {"till", SIPNET_EV_TILL, 1},
+        {"harv", SIPNET_EV_HARVEST, 4}, {"leafon", SIPNET_EV_LEAFON, 0},
+        {"leafoff", SIPNET_EV_LEAFOFF, 0}};
+    int type = -1, nreq = 0;
+    for (const auto& k : kinds)
+      if (tok[2] == k.s) {
+        type = k.t;
+        nreq = k.n;
+      }
+    if (type < 0) {
+      if (tok[2] == "plantdeath") {
+        setError("PLANTDEATH event found, but not implemented as an input event");
+        return SIPNET_ERR_INPUT_FILE;
+      }
+      setError("reading event file: unknown event type " + tok[2]);
+      return SIPNET_ERR_UNKNOWN_EVENT;
+    }
+    if ((type == SIPNET_EV_LEAFON || type == SIPNET_EV_LEAFOFF) && !checkedLeaf) {
+      // events.c:254-261: computed and scheduled leaf events are exclusive
+      const double leafOnDay = params ? params[14] : 0.0, leafOffDay = params ? params[15] : 0.0;
+      if (flags[SIPNET_F_GDD] || flags[SIPNET_F_SOIL_PHENOL] || leafOnDay > 0 || leafOffDay > 0) {
+        setError("calculated leaf events are not compatible with user-specified leaf events "
+                 "in event file");
+        return SIPNET_ERR_BAD_PARAMETER;
+      }
+      checkedLeaf = true;
+    }
+    sipnet_event ev;
+    memset(&ev, 0, sizeof ev);
+    ev.type = type;
+    ev.year = year;
+    ev.day = day;
+    int got = 0;
+    for (size_t k = 3; k < tok.size() && got < 4; k++) {
+      double v;
+      if (type == SIPNET_EV_IRRIG && got == 1) {
+        int m;
+        if (!parseInt(tok[k], m)) break;
+        v = m;
+      } else if (!parseDouble(tok[k], v)) {
+        break;
+      }
+      ev.p[got++] = v;
+    }
+    if (nreq == 0 ? got > 0 : got < nreq) {
+      setError(std::string("parsing ") + tok[2] + " params for year " + std::to_string(year) +
+               " day " + std::to_string(day));
+      return SIPNET_ERR_INPUT_FILE;
+    }
+    if (type == SIPNET_EV_HARVEST && ((ev.p[0] + ev.p[2] > 1) || (ev.p[1] + ev.p[3] > 1))) {
+      setError("invalid harvest event for year " + std::to_string(year) + " day " +
+               std::to_string(day) + "; above and below must each add to 1 or less");
+      return SIPNET_ERR_BAD_PARAMETER;
+    }
+    if (!evs.empty() && ((year < curYear) || ((year == curYear) && (day < curDay)))) {
+      setError("event records must be in time-ascending order");
+      return SIPNET_ERR_INPUT_FILE;
+    }
+    evs.push_back(ev);
+    curYear = year;
+    curDay = day;
+  }
+  if (!evs.empty()) {
+    *out = (sipnet_event*)malloc(evs.size() * sizeof(sipnet_event));
+    memcpy(*out, evs.data(), evs.size() * sizeof(sipnet_event));
+    *n_events = (int32_t)evs.size();
+  }
+  return SIPNET_OK;
+}
+void sipnet_io_free(void* p) { free(p); }
+
+// ---------------------------------------------------------------- .out
+// outputHeader(), sipnet.c:434-444
+int sipnet_io_format_out_header(char* buf, size_t cap) {
+  static const char hdr[] =
+      "year day  time plantWoodC plantLeafC woodCreation     "
+      "soil coarseRootC fineRootC   "
+      "litter  soilWater soilWetnessFrac     snow      "
+      "npp      nee   cumNEE      gpp rAboveground    rSoil    "
+      "rRoot       ra       rh     rtot evapotranspiration "
+      "fluxestranspiration     minN  soilOrgN    litterN  "
+      "plantStorageN       n2o nLeaching  nFixation  nUptake      ch4  "
+      "nppStorage\n";
+  const size_t n = sizeof(hdr) - 1;
+  if (n + 1 > cap) return -1;
+  memcpy(buf, hdr, n + 1);
+  return (int)n;
+}
+
+// outputState(), sipnet.c:453-473
+int sipnet_io_format_out_row(char* buf, size_t cap, int32_t year, int32_t day, double time,
+                             const double* rec, int64_t st) {
+  auto R = [&](int k) { return rec[(int64_t)k * st]; };
+  const double totalWood = R(14) + R(26);  // state.c:17-19
+  const int n = snprintf(
+      buf, cap,
+      "%4d %3d %5.2f %10.2f %10.2f %12.2f "
+      "%8.2f "
+      "%11.2f %9.2f "
+      "%8.2f %10.3f %15.3f %8.2f "
+      "%8.3f %8.3f %8.3f %8.3f %12.3f %8.3f %8.3f %8.3f %8.3f %8.3f %18.8f "
+      "%19.4f %8.4f %9.4f %10.4f %14.4f "
+      "%9.6f %9.4f %10.4f %8.4f %8.4f"
+      "%12.4f\n",
+      year, day, time, totalWood, R(15), R(11),  //
+      R(16),                                      // soilC
+      R(20), R(21),                               // coarse, fine roots
+      R(18), R(17), R(12), R(19),                 // litter soilWater wetness snow
+      R(4), R(0), R(3), R(1), R(5), R(6), R(7), R(8), R(9), R(10), R(2),  //
+      R(13), R(22), R(23), R(24), R(25),          // transpiration + N pools
+      R(27), R(28), R(29), R(30), R(31),          // n2o nLeaching nFixation nUptake ch4
+      R(26));
+  if (n < 0 || (size_t)n >= cap) return -1;
+  return n;
+}
+
+int sipnet_io_write_out(const char* path, int32_t print_header, int32_t n_steps,
+                        const int32_t* year, const int32_t* day, const double* clim,
+                        const double* rec) {
+  FILE* f = fopen(path, "w");
+  if (!f) {
+    setError(std::string("Error opening ") + path + " for writing");
+    return SIPNET_ERR_FILE_OPEN;
+  }
+  char buf[1024];
+  if (print_header) {
+    const int n = sipnet_io_format_out_header(buf, sizeof buf);
+    fwrite(buf, 1, (size_t)n, f);
+  }
+  for (int t = 0; t < n_steps; t++) {
+    const int n = sipnet_io_format_out_row(buf, sizeof buf, year[t], day[t],
+                                           clim[(size_t)t * SIPNET_NCLIM + 10],
+                                           rec + (size_t)t * SIPNET_NREC, 1);
+    if (n < 0) {
+      fclose(f);
+      return SIPNET_ERR_INTERNAL;
+    }
+    fwrite(buf, 1, (size_t)n, f);
+  }
+  fclose(f);
+  return SIPNET_OK;
+}
+
+}  // extern "C"

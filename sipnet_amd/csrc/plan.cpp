@@ -1,0 +1,209 @@
+// plan.cpp -- host-side construction of the per-site plan (see plan.h).
+#include "plan.h"
+
+#include <cmath>
+#include <cstdio>
+
+namespace sipnet {
+
+namespace {
+constexpr double kTiny = 0.000001;            // common/util.h:14
+constexpr double kMeanNppDays = 5.0;          // sipnet.c:39
+constexpr double kTillThreshold = 0.01;       // events.h:56
+constexpr double kTillDecay = 1 / 30.0;       // events.h:58
+// sipnet.c:44-49, :890-891, :968-969
+constexpr double kLambda = 2501000., kLambdaS = 2835000., kRho = 1.3, kCp = 1005.,
+                 kGamma = 66., kEStarSnow = 0.6, kSecPerDay = 86400.0;
+}  // namespace
+
+SitePlan buildSitePlan(const int32_t* flags, int32_t n_steps, const double* clim,
+                       const int32_t* year, const int32_t* day, int32_t n_events,
+                       const sipnet_event* events) {
+  SitePlan plan;
+  plan.steps.resize(n_steps);
+  const bool useEvents = flags[SIPNET_F_EVENTS] != 0;
+  if (!useEvents) {
+    n_events = 0;
+  }
+
+  const double convS = (kRho * kCp) / kGamma * (1. / kLambdaS) * 1000. * 1000. *
+                       (1. / 10000) * kSecPerDay;
+  const double convE = (kRho * kCp) / kGamma * (1. / kLambda) * 1000. * 1000. *
+                       (1. / 10000) * kSecPerDay;
+
+  // ring weights as the reference would hold them if every member inserted on
+  // every step (runmean.c:44-52, :61-116)
+  double w[SIPNET_RING_SLOTS];
+  int32_t insStep[SIPNET_RING_SLOTS];
+  int start = 0, last = 0;
+  w[0] = kMeanNppDays;
+  insStep[0] = -1;
+
+  int trackLastYear = -1;       // trackers.lastYear, sipnet.c:1412
+  double trackGdd = 0.0;        // trackers.gdd
+  int phenLastYear = n_steps > 0 ? year[0] : 0;  // sipnet.c:1524
+  double dTill = 0.0;           // events.c:809
+  int evNext = 0;
+
+  // frontend.c:216-223
+  if (n_events > 0 && n_steps > 0) {
+    const bool before = events[0].year != year[0] ? events[0].year < year[0]
+                                                  : events[0].day < day[0];
+    if (before) {
+      plan.status = SIPNET_ERR_INPUT_FILE;
+      plan.message = "First event occurs before the start of the climate file";
+    }
+  }
+
+  for (int t = 0; t < n_steps; t++) {
+    const double* r = clim + (size_t)SIPNET_NCLIM * t;
+    StepRec& s = plan.steps[t];
+    s = StepRec{};
+    s.length = r[0];
+    s.tair = r[1];
+    s.tsoil = r[2];
+    s.par = r[3];
+    s.precip = r[4];
+    s.vpd = r[5];
+    s.vpdSoil = r[6];
+    s.vPress = r[7];
+    s.wspd = r[8];
+    const double gdd = r[9];
+    s.dayTime = (double)day[t] + r[10] / 24.0;
+    s.year = year[t];
+    s.day = day[t];
+
+    if (!(s.length > 0) && plan.status == SIPNET_OK) {  // events.c:460-465
+      plan.status = SIPNET_ERR_BAD_PARAMETER;
+      char buf[160];
+      snprintf(buf, sizeof buf,
+               "climate length (%f) on year %d day %d is non-positive", s.length,
+               year[t], day[t]);
+      plan.message = buf;
+    }
+
+    // phenology new-year reset, sipnet.c:811-815
+    if (year[t] > phenLastYear) {
+      s.bits |= STEP_PHEN_NEW_YEAR;
+      phenLastYear = year[t];
+    }
+    // GDD seen by pastLeafGrowth() in this step, sipnet.c:706-716 (trackers are
+    // still those of the previous step at that point)
+    double cum = gdd;
+    if (year[t] == trackLastYear) {
+      cum += trackGdd;
+    }
+    s.cumGdd = cum;
+    // updateTrackers(), sipnet.c:1421-1431, :1480-1484
+    if (year[t] != trackLastYear) {
+      s.bits |= STEP_TRACK_NEW_YEAR;
+      trackGdd = 0.0;
+      trackLastYear = year[t];
+    }
+    if (flags[SIPNET_F_GDD]) {
+      trackGdd += gdd;
+    } else {
+      trackGdd = 0.0;
+    }
+    s.gddAfter = trackGdd;
+
+    // events falling on this record, events.c:470-482
+    s.evFirst = (int32_t)plan.events.size();
+    while (evNext < n_events && events[evNext].year <= year[t] &&
+           events[evNext].day <= day[t]) {
+      const sipnet_event& ev = events[evNext];
+      if ((ev.year < year[t] || ev.day < day[t]) && plan.status == SIPNET_OK) {
+        plan.status = SIPNET_ERR_INPUT_FILE;
+        char buf[160];
+        snprintf(buf, sizeof buf,
+                 "Agronomic event found for year: %d day: %d that does not have "
+                 "a corresponding record in the climate file",
+                 ev.year, ev.day);
+        plan.message = buf;
+      }
+      if (ev.type == SIPNET_EV_TILL) {
+        dTill += ev.p[0];  // events.c:629-639
+      }
+      if (ev.type == SIPNET_EV_IRRIG && (int)ev.p[1] != 0 && (int)ev.p[1] != 1 &&
+          plan.status == SIPNET_OK) {
+        plan.status = SIPNET_ERR_UNKNOWN_EVENT;  // events.c:497-500
+        plan.message = "Unknown irrigation method type";
+      }
+      EvRec e;
+      e.type = ev.type;
+      e.pad = 0;
+      for (int k = 0; k < 4; k++) e.p[k] = ev.p[k];
+      plan.events.push_back(e);
+      evNext++;
+    }
+    s.evCount = (int32_t)plan.events.size() - s.evFirst;
+    s.dTill = dTill;
+    // events.c:811-822
+    if (dTill > 0) {
+      dTill *= std::exp(-s.length * kTillDecay);
+      if (dTill < kTillThreshold) {
+        dTill = 0.0;
+      }
+    }
+    s.tillAfter = dTill;
+
+    // running-mean ring schedule, runmean.c:61-116
+    s.ringOpFirst = (int32_t)plan.ringOps.size();
+    const double weight = s.length;
+    if (!(weight > 0)) {
+      s.ringInsSlot = 0;  // unreachable in a valid run (status already set)
+    } else if (weight >= kMeanNppDays) {
+      start = last = 0;
+      w[0] = kMeanNppDays;
+      insStep[0] = t;
+      s.ringInsSlot = -1;
+    } else {
+      double left = weight;
+      int i = start;
+      while (left > 0) {
+        RingOp op;
+        op.slot = i;
+        op.insStep = insStep[i];
+        if (w[i] > left) {
+          w[i] -= left;
+          op.w = left;
+          left = 0;
+        } else {
+          op.w = w[i];
+          left -= w[i];
+          i = (i + 1) % SIPNET_RING_SLOTS;
+        }
+        plan.ringOps.push_back(op);
+      }
+      start = i;
+      i = (last + 1) % SIPNET_RING_SLOTS;
+      if (i == start) {
+        if (plan.status == SIPNET_OK) {  // sipnet.c:1562-1569
+          plan.status = SIPNET_ERR_INTERNAL;
+          plan.message =
+              "running-mean NPP ring overflow (more than 250 steps in 5 days)";
+        }
+        s.ringInsSlot = i;
+      } else {
+        last = i;
+        w[i] = weight;
+        insStep[i] = t;
+        s.ringInsSlot = i;
+      }
+    }
+    s.ringOpCount = (int32_t)plan.ringOps.size() - s.ringOpFirst;
+
+    // member-independent sub-expressions for the fast-math variants
+    s.invLen = 1.0 / s.length;
+    s.tair10 = s.tair / 10.0;
+    s.tsoil10 = s.tsoil / 10.0;
+    s.log2vpd = std::log2(s.vpd > 0 ? s.vpd : kTiny);
+    s.rainRate = s.precip / s.length;
+    s.invWspd = 1.0 / s.wspd;
+    s.sublNum = convS * (kEStarSnow - s.vPress);
+    s.evapNum = convE * s.vpdSoil;
+  }
+  return plan;
+}
+
+}  // namespace sipnet

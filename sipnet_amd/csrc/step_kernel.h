@@ -1,0 +1,89 @@
+// step_kernel.h -- the SIPNET per-timestep state update as a CDNA4 HIP kernel.
+//
+// One thread = one ensemble member; one 64-thread workgroup (one wavefront) =
+// 64 consecutive members of ONE site, so every climate-driven branch is
+// wave-uniform and the site plan (plan.h) arrives through scalar loads.  The
+// time loop runs inside the kernel with the member's pools, accumulators and
+// converted parameters held in registers; per step a thread touches HBM only
+// for its running-mean ring slot(s) ([slot][col], coalesced) and its outputs
+// ([t][col], coalesced).
+//
+// The arithmetic follows updateState() of the reference,
+// /root/reference/src/sipnet/sipnet.c:1818-1855 (citations below are relative to
+// /root/reference/src/).  Two math policies:
+//   Strict : operation order, true divisions and pow/exp calls as the reference
+//            writes them (differences vs glibc are the <=1-2 ulp of OCML's
+//            pow/exp/exp2);
+//   Fast   : member-independent sub-expressions come from the site plan,
+//            x/length becomes x*invLen, pow(q,T/10) becomes exp2(T/10*log2 q)
+//            with log2 q hoisted out of the time loop, the Simpson layers reuse
+//            one exp.  Same model, ~1e-15 relative differences.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "plan.h"
+
+namespace sipnet {
+
+enum ParamIndex : int {
+#define SIPNET_PARAM(idx, field, fname, rule) SP_##field = idx,
+#include "../../include/sipnet_params.def"
+#undef SIPNET_PARAM
+  SP_COUNT
+};
+static_assert(SP_COUNT == SIPNET_NPARAMS, "parameter table size");
+
+// state vector rows (include/sipnet_amd.h)
+enum StateIndex : int {
+  ST_plantWoodC = 0, ST_plantLeafC, ST_soilC, ST_soilWater, ST_litterC, ST_snow,
+  ST_coarseRootC, ST_fineRootC, ST_minN, ST_soilOrgN, ST_litterN,
+  ST_plantStorageN, ST_plantCAccountingDelta,
+  ST_ringSum = 13,
+  ST_totGpp = 14, ST_totRtot, ST_totRa, ST_totRh, ST_totNpp, ST_totNee,
+  ST_yearlyGpp = 20, ST_yearlyRtot, ST_yearlyRa, ST_yearlyRh, ST_yearlyNpp,
+  ST_yearlyNee, ST_yearlyLitter,
+  ST_phenBits = 27, ST_ringValidFrom = 28, ST_status = 29, ST_diedAt = 30,
+  ST_clampCount = 31
+};
+static_assert(ST_clampCount + 1 == SIPNET_NSTATE, "state vector size");
+
+struct KernelArgs {
+  const StepRec* plan;    // [n_sites][n_steps_total]
+  const RingOp* ringOps;  // all sites, StepRec.ringOpFirst is global
+  const EvRec* events;    // all sites, StepRec.evFirst is global
+  const double* prm;      // [SIPNET_NPARAMS][ncol] converted parameters
+  double* state;          // [SIPNET_NSTATE][ncol]
+  double* ring;           // [SIPNET_RING_SLOTS][ncol]
+  void* nee;              // [n_steps][ld] or null
+  void* gpp;
+  void* et;
+  double* rec;            // [n_steps][SIPNET_NREC][ld] or null
+  int64_t ncol, ld;
+  int32_t n_sites, n_members, n_steps_total, step0, n_steps;
+  int32_t flags[SIPNET_NFLAGS];
+};
+
+struct SetupArgs {
+  const StepRec* plan;    // first record of each site is at plan[site*n_steps_total]
+  const double* raw;      // [ncol][SIPNET_NPARAMS] raw parameters (AoS as uploaded)
+  double* prm;            // [SIPNET_NPARAMS][ncol]
+  double* state;          // [SIPNET_NSTATE][ncol]
+  double* ring;           // slot 0 row is zeroed
+  int64_t ncol;
+  int32_t n_sites, n_members, n_steps_total;
+  int32_t flags[SIPNET_NFLAGS];
+  const int32_t* siteStatus;  // [n_sites] plan status (site-fatal conditions)
+};
+
+// launchers (step_kernel.hip)
+void launchSetup(const SetupArgs& a, hipStream_t stream);
+// variant: bit0 = fast math, bit1 = generic flags (runtime), else default flags
+void launchStep(const KernelArgs& a, int precision, bool fastMath, hipStream_t stream);
+void launchReducePlane(const void* plane, bool isF32, int32_t n_steps, int64_t ld,
+                       int32_t n_sites, int32_t n_members, double* stats,
+                       hipStream_t stream);
+const char* stepKernelName(int precision, bool fastMath, bool generic);
+
+}  // namespace sipnet

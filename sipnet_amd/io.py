@@ -1,0 +1,91 @@
+"""SIPNET text formats through the C-ABI host functions (host_io.cpp)."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import NCLIM, NPARAMS, NREC, Event, check, lib
+
+
+class ClimTable:
+    """Converted climate of one site: data[n][11] = length tair tsoil par precip vpd
+    vpdSoil vPress wspd gdd time (units as after readClimData, sipnet.c:201-238)."""
+
+    def __init__(self, data, year, day):
+        self.data = np.ascontiguousarray(data, dtype=np.float64)
+        self.year = np.ascontiguousarray(year, dtype=np.int32)
+        self.day = np.ascontiguousarray(day, dtype=np.int32)
+        assert self.data.shape == (len(self.year), NCLIM)
+
+    @property
+    def n_steps(self):
+        return len(self.year)
+
+    def slice(self, a, b):
+        return ClimTable(self.data[a:b], self.year[a:b], self.day[a:b])
+
+
+def read_clim(path, gdd=1):
+    L = lib()
+    h = C.c_void_p()
+    check(L.sipnet_io_read_clim(str(path).encode(), int(gdd), C.byref(h)), "read_clim")
+    try:
+        n = L.sipnet_clim_nsteps(h)
+        data = np.ctypeslib.as_array(L.sipnet_clim_data(h), shape=(n, NCLIM)).copy()
+        year = np.ctypeslib.as_array(L.sipnet_clim_year(h), shape=(n,)).copy()
+        day = np.ctypeslib.as_array(L.sipnet_clim_day(h), shape=(n,)).copy()
+    finally:
+        L.sipnet_clim_free(h)
+    return ClimTable(data, year, day)
+
+
+def read_params(path, flags):
+    """-> (raw[80] float64, is_read[80] int32)"""
+    L = lib()
+    fl = (C.c_int32 * 12)(*flags)
+    out = np.zeros(NPARAMS)
+    seen = np.zeros(NPARAMS, dtype=np.int32)
+    check(L.sipnet_io_read_params(str(path).encode(), fl, out.ctypes.data, seen.ctypes.data),
+          "read_params")
+    return out, seen
+
+
+def read_events(path, flags, params=None):
+    """-> list of Event"""
+    L = lib()
+    fl = (C.c_int32 * 12)(*flags)
+    ptr = C.POINTER(Event)()
+    n = C.c_int32(0)
+    pp = None if params is None else np.ascontiguousarray(params, dtype=np.float64).ctypes.data
+    check(L.sipnet_io_read_events(str(path).encode(), fl, pp, C.byref(ptr), C.byref(n)),
+          "read_events")
+    evs = []
+    for i in range(n.value):
+        e = Event()
+        C.memmove(C.byref(e), C.byref(ptr[i]), C.sizeof(Event))
+        evs.append(e)
+    if n.value:
+        L.sipnet_io_free(ptr)
+    return evs
+
+
+def format_out_header():
+    buf = C.create_string_buffer(1024)
+    n = lib().sipnet_io_format_out_header(buf, 1024)
+    return buf.raw[:n].decode()
+
+
+def format_out_row(year, day, time, rec):
+    rec = np.ascontiguousarray(rec, dtype=np.float64)
+    assert rec.shape == (NREC,)
+    buf = C.create_string_buffer(1024)
+    n = lib().sipnet_io_format_out_row(buf, 1024, int(year), int(day), float(time),
+                                       rec.ctypes.data, 1)
+    return buf.raw[:n].decode()
+
+
+def write_out(path, clim, rec, print_header=False):
+    rec = np.ascontiguousarray(rec, dtype=np.float64)
+    assert rec.shape == (clim.n_steps, NREC)
+    check(lib().sipnet_io_write_out(str(path).encode(), int(print_header), clim.n_steps,
+                                    clim.year.ctypes.data, clim.day.ctypes.data,
+                                    clim.data.ctypes.data, rec.ctypes.data), "write_out")

@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* from the REAL reference (build container only).
+
+Needs /root/reference and oracle/_ref (make -C oracle ref).  What it commits is
+data only: the input/expected-output files of the reference's own smoke tests
+(tests/smoke/*), and full-precision per-step records obtained by running the
+reference's step loop in-process through oracle/ref_harness.c.  No reference
+source text is stored.
+
+    python tools/make_golden.py
+"""
+import ctypes as C
+import gzip
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+REF = "/root/reference"
+GOLD = os.path.join(REPO, "tests", "golden")
+REF_SO = os.path.join(REPO, "oracle", "_ref", "libsipnet_ref.so")
+NREC = 36
+
+
+def gz_copy(src, dst):
+    with open(src, "rb") as fi, gzip.GzipFile(dst, "wb", mtime=0) as fo:
+        shutil.copyfileobj(fi, fo)
+
+
+def copy_smoke():
+    for case in ["niwot", "russell_1", "russell_2", "russell_3"]:
+        s = os.path.join(REF, "tests", "smoke", case)
+        d = os.path.join(GOLD, "smoke", case)
+        os.makedirs(d, exist_ok=True)
+        for f in ["sipnet.in", "sipnet.param", "events.in", "events.out"]:
+            shutil.copyfile(os.path.join(s, f), os.path.join(d, f))
+        gz_copy(os.path.join(s, "sipnet.out"), os.path.join(d, "sipnet.out.gz"))
+        if case in ("niwot", "russell_1"):  # russell_2/3 use russell_1's forcing
+            gz_copy(os.path.join(s, "sipnet.clim"), os.path.join(d, "sipnet.clim.gz"))
+    a = open(os.path.join(REF, "tests/smoke/russell_1/sipnet.clim"), "rb").read()
+    for c in ("russell_2", "russell_3"):
+        assert open(os.path.join(REF, f"tests/smoke/{c}/sipnet.clim"), "rb").read() == a
+
+
+def ref_run(flags, param_file, clim_file, events_file, raw_members=None):
+    """Run the real reference in a child process (it keeps process-global state).
+    -> rec[n_members][n_steps][36]"""
+    code = r"""
+import ctypes as C, numpy as np, sys, pickle
+flags, param_file, clim_file, events_file, raw_path, out_path, so = pickle.load(open(sys.argv[1],'rb'))
+ref = C.CDLL(so)
+fl = (C.c_int*12)(*flags)
+n = ref.ref_init(fl, param_file.encode(), clim_file.encode(), events_file.encode(), b"/dev/null")
+NP = ref.ref_num_params(); NR = ref.ref_rec_len()
+base = np.zeros(NP); ref.ref_get_base_params(base.ctypes.data_as(C.c_void_p))
+raw = np.load(raw_path) if raw_path else base[None,:]
+out = np.zeros((raw.shape[0], n, NR))
+for m in range(raw.shape[0]):
+    r = np.ascontiguousarray(raw[m])
+    ref.ref_run_member(r.ctypes.data_as(C.c_void_p), out[m].ctypes.data_as(C.c_void_p), None, None, None)
+np.save(out_path, out)
+"""
+    import pickle, tempfile
+    tmp = tempfile.mkdtemp(prefix="mkgold_")
+    raw_path = None
+    if raw_members is not None:
+        raw_path = os.path.join(tmp, "raw.npy")
+        np.save(raw_path, raw_members)
+    out_path = os.path.join(tmp, "out.npy")
+    job = os.path.join(tmp, "job.pkl")
+    pickle.dump((list(flags), param_file, clim_file, events_file, raw_path, out_path, REF_SO),
+                open(job, "wb"))
+    subprocess.check_call([sys.executable, "-c", code, job])
+    out = np.load(out_path)
+    shutil.rmtree(tmp)
+    return out
+
+
+def decimate_index(n, head=300, tail=300, every=7):
+    idx = set(range(min(head, n))) | set(range(max(0, n - tail), n)) | set(range(0, n, every))
+    return np.array(sorted(idx), dtype=np.int32)
+
+
+def smoke_records():
+    import sipnet_amd as sa
+    out = {}
+    for case in ["niwot", "russell_1", "russell_2", "russell_3"]:
+        s = os.path.join(REF, "tests", "smoke", case)
+        cfg = sa.read_config(os.path.join(s, "sipnet.in"))
+        flags = [cfg[n] for n in sa.FLAG_NAMES]
+        rec = ref_run(flags, os.path.join(s, "sipnet.param"), os.path.join(s, "sipnet.clim"),
+                      os.path.join(s, "events.in"))[0]
+        idx = decimate_index(rec.shape[0])
+        out[f"{case}_idx"] = idx
+        out[f"{case}_rec"] = rec[idx]
+        out[f"{case}_final"] = rec[-1]
+        print(case, rec.shape, "kept", len(idx))
+    np.savez_compressed(os.path.join(GOLD, "ref_smoke_records.npz"), **out)
+
+
+def special_members(base):
+    """A small ensemble that walks the rare branches: phenology, mortality, drought."""
+    import sipnet_amd as sa
+    from sipnet_amd.config import param_index as pi
+    from sipnet_amd import synth
+    mem = list(synth.perturbed_params(base, 6, seed=synth.SEED_PARAMS))
+    def variant(**kw):
+        p = base.copy()
+        for k, v in kw.items():
+            assert pi(k) >= 0, k
+            p[pi(k)] = v
+        mem.append(p)
+    variant(leafGrowth=120.0, fracLeafFall=0.6, gddLeafOn=300.0, leafOffDay=280.0)   # deciduous
+    variant(leafGrowth=60.0, fracLeafFall=1.0, gddLeafOn=150.0, leafOffDay=250.0, laiInit=0.0)
+    variant(baseVegResp=2.0, plantWoodInit=300.0)            # respires itself to death (step 10074)
+    variant(plantWoodInit=0.0)                                # dead from the start
+    variant(soilWHC=0.5, soilWFracInit=0.1)                   # drought / tiny bucket
+    variant(snowInit=8.0, frozenSoilEff=0.5, frozenSoilFolREff=0.5, frozenSoilThreshold=1.0)
+    variant(soilRespMoistEffect=1.7, dVpdExp=1.5)             # non-trivial exponents
+    variant(fineRootFrac=0.0005, fineRootAllocation=0.0, fineRootTurnoverRate=0.9)  # root deficit rerouting
+    variant(laiInit=0.05, leafTurnoverRate=0.9, leafAllocation=0.01)                 # leaf deficit rerouting
+    variant(leafGrowth=5000.0, fracLeafFall=0.3, gddLeafOn=200.0, leafOffDay=270.0)  # leaf-on C-limited
+    return np.array(mem)
+
+
+def synthetic():
+    import sipnet_amd as sa
+    from sipnet_amd import synth
+    d = os.path.join(GOLD, "synth")
+    os.makedirs(d, exist_ok=True)
+    raw = synth.round_like_file(synth.half_hourly_year_raw())
+    clim_path = os.path.join(d, "halfhourly.clim")
+    synth.write_clim(clim_path, raw)
+    flags = sa.flags_from()
+    base, _ = sa.read_params(os.path.join(REPO, "sipnet_amd", "data", "base_forest.param"), flags)
+    members = special_members(base)
+    np.save(os.path.join(d, "members_raw.npy"), members)
+    # the reference reads the files; the base param file only seeds `params`, every
+    # member vector is laid over it by the harness
+    rec = ref_run(flags, os.path.join(REPO, "sipnet_amd", "data", "base_forest.param"), clim_path,
+                  "/nonexistent/events.in", members)
+    n = rec.shape[1]
+    idx = decimate_index(n, head=600, tail=300, every=5)
+    np.savez_compressed(os.path.join(d, "ref_synth.npz"), idx=idx,
+                        nee=rec[:, idx, 0], gpp=rec[:, idx, 1], et=rec[:, idx, 2],
+                        final=rec[:, -1, :], sum_nee=rec[:, :, 0].sum(1),
+                        leaf=rec[:, idx, 15], snow=rec[:, idx, 19], wood=rec[:, idx, 14])
+    gz_copy(clim_path, clim_path + ".gz")
+    os.remove(clim_path)
+    print("synthetic members", members.shape, "steps", n, "kept", len(idx))
+    print("  died/zero-wood finals:", rec[:, -1, 14])
+    print("  final snow:", rec[:, -1, 19])
+
+    # variable-flag synthetic: a 3-hourly two-month window with every optional flag on
+    # (the russell_2 parameter file carries the N-cycle parameters)
+    flags2 = sa.flags_from(litterPool=1, nitrogenCycle=1, anaerobic=1, growthResp=1, leafWater=1,
+                           flooding=1, carbonSaturation=1)
+    s = os.path.join(REF, "tests", "smoke", "russell_2")
+    p2, seen = sa.read_params(os.path.join(s, "sipnet.param"), sa.flags_from(litterPool=1, nitrogenCycle=1, anaerobic=1))
+    # the extra flags need a few more parameters than russell_2's file carries
+    from sipnet_amd.config import param_index as pi
+    extra = dict(growthRespFrac=0.2, leafPoolDepth=0.1, waterDrainFrac=0.3, soilCSaturation=6000.0)
+    lines = open(os.path.join(s, "sipnet.param")).read()
+    allp = os.path.join(d, "allflags.param")
+    with open(allp, "w") as fh:
+        fh.write(lines)
+        for k, v in extra.items():
+            if not seen[pi(k)]:
+                fh.write(f"{k} {v}\n")
+    rec2 = ref_run(flags2, allp, os.path.join(s, "sipnet.clim"), os.path.join(s, "events.in"))[0]
+    idx2 = decimate_index(rec2.shape[0])
+    np.savez_compressed(os.path.join(d, "ref_allflags.npz"), idx=idx2, rec=rec2[idx2],
+                        flags=np.array(flags2))
+    print("allflags", rec2.shape)
+
+
+if __name__ == "__main__":
+    subprocess.check_call(["make", "-s", "-C", os.path.join(REPO, "oracle"), "ref", "oracle"])
+    copy_smoke()
+    smoke_records()
+    synthetic()
+    subprocess.run(["du", "-sh", GOLD])
