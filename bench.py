@@ -1,0 +1,281 @@
+#!/usr/bin/env python3
+"""bench.py -- ensemble-site-timesteps/s of the batched SIPNET step loop on MI355X.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W
+  N>1 is launched by torch.distributed.run, one rank per GPU.  One "step" = one pass
+  of the hot path over the whole batch: per-member setup + the time-fused step kernel
+  over every timestep of the forcing + (N>1) the ensemble-statistics reduction and the
+  RCCL all-gather of the NEE/GPP/ET statistics block.  Inputs (parameters, site plan)
+  are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+Workloads (BASELINE.json configs):
+  c10k  1 site x 10240 members, fp64, synthetic half-hourly year (17520 steps)  [default:
+        the configuration the metric "at 10k members" + the fp64 |dNEE| bar are quoted on]
+  c2    1 site x 1024 members, fp64          c3   1 site x 65536 members, fp32-mixed
+  c4    32 sites x 1024 members per GPU, fp64 (256 sites over 8 GPUs)
+Per-GPU work is fixed as N grows ("scaling": "weak").
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+ALGO_BYTES = {"f64": 344.0, "f32": 172.0}   # bytes per member-timestep
+HBM_PEAK_GBPS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+WORKLOADS = {
+    "c10k": dict(sites=1, members=10240, prec="f64", steps=17520),
+    "c2": dict(sites=1, members=1024, prec="f64", steps=17520),
+    "c3": dict(sites=1, members=65536, prec="f32", steps=17520),
+    "c4": dict(sites=32, members=1024, prec="f64", steps=17520),
+}
+
+_CPU_WORKER = r"""
+import ctypes as C, numpy as np, sys, time, os
+kind, so, param_file, clim_file, raw_path, flags_s = sys.argv[1:7]
+flags = [int(x) for x in flags_s.split(',')]
+raw = np.load(raw_path)
+fl = (C.c_int*12)(*flags)
+if kind == 'reference':
+    ref = C.CDLL(so)
+    n = ref.ref_init(fl, param_file.encode(), clim_file.encode(), b'/nonexistent', b'/dev/null')
+    ref.ref_time_members.restype = C.c_double
+    sink = C.c_double()
+    dt = ref.ref_time_members(raw.ctypes.data_as(C.c_void_p), raw.shape[0], C.byref(sink))
+else:
+    sys.path.insert(0, os.environ['SIPNET_REPO'])
+    import sipnet_amd as sa
+    clim = sa.read_clim(clim_file)
+    ora = C.CDLL(so)
+    ora.sipo_time_members.restype = C.c_double
+    sink = C.c_double()
+    n = clim.n_steps
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    dt = ora.sipo_time_members(fl, vp(raw), raw.shape[0], n, vp(clim.data), vp(clim.year), vp(clim.day), C.byref(sink))
+print(dt, raw.shape[0] * n)
+"""
+
+
+def cpu_baseline(flags, members_raw, raw_forcing, target_seconds=12.0):
+    """Time the CPU checker (the real reference build when oracle/_ref travelled,
+    else this repo's restatement) on a bounded sample of the same ensemble, one
+    process per host core.  Test infrastructure used as a *baseline*, never shipped."""
+    from sipnet_amd import synth
+    ref_so = os.path.join(REPO, "oracle", "_ref", "libsipnet_ref.so")
+    ora_so = os.path.join(REPO, "oracle", "liboracle.so")
+    if os.path.exists(ref_so):
+        kind, so = "reference", ref_so
+    else:
+        if not os.path.exists(ora_so):
+            subprocess.check_call(["make", "-s", "-C", os.path.join(REPO, "oracle"), "oracle"])
+        kind, so = "port", ora_so
+    cores = len(os.sched_getaffinity(0))
+    n_steps = len(raw_forcing["year"])
+    # ~350 ns per member-step per core (BASELINE.md probe) -> members per core
+    per_core = max(1, int(target_seconds / (n_steps * 400e-9)))
+    per_core = min(per_core, members_raw.shape[0] // cores if members_raw.shape[0] >= cores else 1)
+    tmp = tempfile.mkdtemp(prefix="sipnet_cpu_")
+    clim_file = os.path.join(tmp, "bench.clim")
+    synth.write_clim(clim_file, raw_forcing)
+    param_file = os.path.join(REPO, "sipnet_amd", "data", "base_forest.param")
+    procs = []
+    env = dict(os.environ, SIPNET_REPO=REPO)
+    t0 = time.time()
+    for c in range(cores):
+        raw_path = os.path.join(tmp, f"raw{c}.npy")
+        np.save(raw_path, np.ascontiguousarray(members_raw[c * per_core:(c + 1) * per_core]))
+        procs.append(subprocess.Popen(
+            [sys.executable, "-c", _CPU_WORKER, kind, so, param_file, clim_file, raw_path,
+             ",".join(str(f) for f in flags)], stdout=subprocess.PIPE, env=env, text=True))
+    secs, units = [], 0
+    for p in procs:
+        out = p.communicate()[0].strip().split()
+        secs.append(float(out[0]))
+        units += int(out[1])
+    wall = time.time() - t0
+    value = units / max(secs)
+    return {
+        "value": value, "unit": "ensemble-site-timesteps/s", "cores": cores, "kind": kind,
+        "per_core": units / sum(secs),
+        "sample": f"{per_core * cores} members x {n_steps} steps of the same synthetic ensemble, "
+                  f"{cores} processes (one per host core), step loop only, gcc -O2; "
+                  f"slowest process {max(secs):.2f}s, wall incl. start-up {wall:.1f}s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default=os.environ.get("SIPNET_BENCH_WORKLOAD", "c10k"),
+                    choices=sorted(WORKLOADS))
+    ap.add_argument("--members", type=int, default=0, help="override members per site per GPU")
+    ap.add_argument("--nsteps", type=int, default=0, help="override timesteps per pass")
+    ap.add_argument("--fast-math", type=int, default=int(os.environ.get("SIPNET_FAST_MATH", "1")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather", default="stats", choices=["stats", "full", "none"])
+    args = ap.parse_args()
+
+    wl = dict(WORKLOADS[args.workload])
+    if args.members:
+        wl["members"] = args.members
+    if args.nsteps:
+        wl["steps"] = args.nsteps
+    os.environ["SIPNET_FAST_MATH"] = str(args.fast_math)
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run (WORLD_SIZE={world})",
+              file=sys.stderr)
+        sys.exit(2)
+
+    import sipnet_amd as sa
+    from sipnet_amd import synth
+
+    flags = sa.flags_from()
+    base, _ = sa.read_params(os.path.join(REPO, "sipnet_amd", "data", "base_forest.param"), flags)
+    S, M, T = wl["sites"], wl["members"], wl["steps"]
+    prec = sa.F64 if wl["prec"] == "f64" else sa.F32_MIXED
+
+    # identical inputs for CPU baseline and GPU: rank r owns global members [r*M, (r+1)*M)
+    # of each of its sites; sites of rank r are r*S .. r*S+S-1
+    raws = [synth.round_like_file(synth.half_hourly_year_raw(T, site=rank * S + s)) for s in range(S)]
+    clims = [synth.convert_raw(r) for r in raws]
+    members = synth.perturbed_params(base, M * world, seed=synth.SEED_PARAMS)[rank * M:(rank + 1) * M]
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # before any HIP initialisation in this process: the workers are plain children
+        cpu = cpu_baseline(flags, synth.perturbed_params(base, max(M, 64), seed=synth.SEED_PARAMS),
+                           raws[0])
+
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    b = sa.Batch(flags, S, M, prec, device=local_rank)
+    for s in range(S):
+        b.set_climate(s, clims[s])
+        b.set_params(s, members)
+    b.setup()
+    planes, _ = b.alloc_outputs(T)
+    stats = torch.empty((3, T, S, 2), dtype=torch.float64, device=b.device)
+    gathered = torch.empty((world,) + tuple(stats.shape), dtype=torch.float64, device=b.device) \
+        if world > 1 and args.gather == "stats" else None
+    gathered_full = None
+    if world > 1 and args.gather == "full":
+        gathered_full = torch.empty((world,) + tuple(planes.shape), dtype=planes.dtype, device=b.device)
+
+    kernel_ms = []
+
+    def one_pass(record):
+        b.setup()                       # setupModel() for every member
+        b.run(0, T, planes=planes)      # the time-fused step kernel
+        if record:
+            kernel_ms.append(None)      # filled after the timed region (event query syncs)
+        if world > 1 and args.gather != "none":
+            for v in range(3):
+                b.reduce_plane(planes[v], stats[v])
+            if args.gather == "stats":
+                dist.all_gather_into_tensor(gathered, stats)
+            else:
+                dist.all_gather_into_tensor(gathered_full, planes)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_pass(False)
+    barrier()
+    # HIP-event kernel timing is collected in an extra, untimed pass per step to keep the
+    # timed region free of host syncs: time K passes wall-clock first
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_pass(False)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=b.device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # dominant kernel's launch duration, HIP events on the launch stream
+    kms = []
+    for _ in range(max(3, min(args.steps, 5))):
+        b.setup()
+        b.run(0, T, planes=planes)
+        kms.append(b.last_kernel_ms())
+    k_ms = float(np.mean(kms))
+
+    units_per_pass = S * M * T * world
+    value = units_per_pass * args.steps / dt
+    per_launch_units = S * M * T
+    achieved = ALGO_BYTES[wl["prec"]] * per_launch_units / (k_ms * 1e-3) / 1e9
+
+    # parity spot-check of this very run against the CPU oracle (checker only)
+    parity = None
+    if rank == 0:
+        try:
+            from tests import helpers
+            ora = helpers.load_oracle()
+            n_chk = min(8, M)
+            po, _, _ = ora.run_block(flags, members[:n_chk], clims[0])
+            pg = planes[:, :, :n_chk].double().cpu().numpy()
+            parity = {"members_checked": n_chk,
+                      "max_abs_dNEE": float(np.abs(pg[0] - po[0]).max()),
+                      "max_abs_dGPP": float(np.abs(pg[1] - po[1]).max()),
+                      "max_abs_dET": float(np.abs(pg[2] - po[2]).max())}
+        except Exception as e:  # the checker is optional for the measurement itself
+            parity = {"error": repr(e)}
+
+    traffic = None
+    tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(args.workload, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    if rank == 0:
+        line = {
+            "metric": "ensemble-site-timesteps/sec", "value": value,
+            "unit": "ensemble-site-timesteps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": wl["prec"], "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {S} site(s) x {M} members per GPU x {T} "
+                                   f"half-hourly steps, perturbed params, default flags",
+                       "sites_per_gpu": S, "members_per_site": M, "timesteps": T,
+                       "fast_math": bool(args.fast_math),
+                       "gather": args.gather if world > 1 else "n/a (1 GPU)",
+                       "parallelism": f"ensemble-sharded x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel": "stepKernel", "kernel_ms": k_ms,
+                         "algorithmic_bytes_per_unit": ALGO_BYTES[wl["prec"]],
+                         "units_per_launch": per_launch_units},
+            "cpu_baseline": cpu, "parity": parity,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+    b.close()
+
+
+if __name__ == "__main__":
+    main()

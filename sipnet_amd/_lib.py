@@ -86,6 +86,16 @@ def lib():
                 f"{LIB_PATH} is missing: the HIP extension has not been built. "
                 "Run `python -c 'import __graft_entry__ as g; g.build()'`. "
                 "sipnet_amd has no CPU fallback.")
+        # Load order matters inside a PyTorch process: torch bundles its own HIP runtime
+        # (SONAME libamdhip64.so.7, requested by torch as "libamdhip64.so").  If this
+        # library pulled in /opt/rocm's copy first, torch would load a second runtime and
+        # one of the two would see no devices.  Importing torch first makes our NEEDED
+        # entry resolve to the runtime torch already loaded, so streams and device
+        # pointers are shared.  (The C++ CLI has no torch and uses /opt/rocm's runtime.)
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         _lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(_lib, name)
