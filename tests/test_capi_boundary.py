@@ -1,0 +1,69 @@
+"""The drop-in boundary: libsipnet_amd.so loads, exports every symbol that
+include/sipnet_amd.h declares, and refuses compute without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import sipnet_amd as sa
+from sipnet_amd import _lib
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    hdr = open(os.path.join(REPO, "include", "sipnet_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(sipnet_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = sa.lib()
+    names = declared_symbols()
+    assert len(names) >= 35
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    # and the Python binding knows the signature of each one
+    unbound = [n for n in names if n not in _lib.SIGNATURES]
+    assert not unbound, unbound
+
+
+def test_version_and_param_table():
+    L = sa.lib()
+    assert b"sipnet_amd" in L.sipnet_version()
+    names = sa.config._load_names()
+    assert len(names) == 80 and names[0] == "plantWoodInit" and names[79] == "soilCSaturation"
+    assert names[9] == "" and names[47] == ""          # psnTMax, coarseRootAllocation are derived
+    assert sa.config.param_index("MINERALNINIT") == 60  # names are case-insensitive
+    assert sa.config.param_index("nope") == -1
+
+
+def test_param_def_order_matches_oracle_record():
+    """include/sipnet_params.def is the single source of the vector layout."""
+    lines = [l for l in open(os.path.join(REPO, "include", "sipnet_params.def"))
+             if l.startswith("SIPNET_PARAM(")]
+    idx = [int(re.match(r"SIPNET_PARAM\(\s*(\d+)", l).group(1)) for l in lines]
+    assert idx == list(range(80))
+
+
+@pytest.mark.skipif(sa.lib().sipnet_device_count() > 0, reason="a GPU is present")
+def test_compute_fails_loudly_without_a_gpu():
+    L = sa.lib()
+    h = C.c_void_p()
+    fl = (C.c_int32 * 12)(*sa.flags_from())
+    rc = L.sipnet_batch_create(fl, 1, 64, sa.F64, 0, C.byref(h))
+    assert rc == _lib.ERR_NO_DEVICE
+    assert b"no usable HIP device" in L.sipnet_last_error()
+    with pytest.raises(RuntimeError):
+        sa.Batch(sa.flags_from(), 1, 64)
+
+
+def test_flag_coupling_rules_are_enforced():
+    """context.c:195-223 -> SIPNET_ERR_BAD_PARAMETER (the reference exits with code 3)."""
+    L = sa.lib()
+    h = C.c_void_p()
+    for bad in (dict(soilPhenol=1, gdd=1), dict(nitrogenCycle=1), dict(anaerobic=1, waterHResp=0),
+                dict(carbonSaturation=1)):
+        fl = (C.c_int32 * 12)(*sa.flags_from(**bad))
+        assert L.sipnet_batch_create(fl, 1, 1, sa.F64, 0, C.byref(h)) == _lib.ERR_BAD_PARAMETER
