@@ -50,6 +50,7 @@ struct sipnet_batch {
   double* d_state = nullptr;   // [NSTATE][ncol]
   double* d_ring = nullptr;    // [RING_SLOTS][ncol]
   StepRec* d_plan = nullptr;   // [n_sites][n_steps]
+  FastRec* d_fast = nullptr;   // [n_sites][n_steps] + kFastTile padding records
   RingOp* d_ringOps = nullptr;
   EvRec* d_events = nullptr;
   int32_t* d_siteStatus = nullptr;
@@ -86,6 +87,7 @@ static int uploadPlan(sipnet_batch* b, hipStream_t stream) {
   }
   // flatten: make op / event indices global
   std::vector<StepRec> steps((size_t)b->n_sites * b->n_steps);
+  std::vector<FastRec> fast((size_t)b->n_sites * b->n_steps + kFastTile);
   std::vector<RingOp> ops;
   std::vector<EvRec> evs;
   ops.reserve(nOps + 1);
@@ -99,6 +101,12 @@ static int uploadPlan(sipnet_batch* b, hipStream_t stream) {
       r.evFirst += evBase;
       steps[(size_t)s * b->n_steps + t] = r;
     }
+    std::vector<FastRec> fr = buildFastRecs(p);
+    for (int t = 0; t < b->n_steps; t++) {
+      fr[t].opFirst += opBase;
+      fr[t].evFirst += evBase;
+      fast[(size_t)s * b->n_steps + t] = fr[t];
+    }
     ops.insert(ops.end(), p.ringOps.begin(), p.ringOps.end());
     evs.insert(evs.end(), p.events.begin(), p.events.end());
   }
@@ -107,9 +115,12 @@ static int uploadPlan(sipnet_batch* b, hipStream_t stream) {
 
   if (steps.size() > b->planCap) {
     if (b->d_plan) HIP_TRY(hipFree(b->d_plan));
+    if (b->d_fast) HIP_TRY(hipFree(b->d_fast));
     HIP_TRY(hipMalloc(&b->d_plan, steps.size() * sizeof(StepRec)));
+    HIP_TRY(hipMalloc(&b->d_fast, fast.size() * sizeof(FastRec)));
     b->planCap = steps.size();
   }
+  HIP_TRY(hipMemcpy(b->d_fast, fast.data(), fast.size() * sizeof(FastRec), hipMemcpyHostToDevice));
   if (ops.size() > b->ringOpCap) {
     if (b->d_ringOps) HIP_TRY(hipFree(b->d_ringOps));
     HIP_TRY(hipMalloc(&b->d_ringOps, ops.size() * sizeof(RingOp)));
@@ -207,6 +218,7 @@ void sipnet_batch_destroy(sipnet_batch* b) {
   if (b->d_state) (void)hipFree(b->d_state);
   if (b->d_ring) (void)hipFree(b->d_ring);
   if (b->d_plan) (void)hipFree(b->d_plan);
+  if (b->d_fast) (void)hipFree(b->d_fast);
   if (b->d_ringOps) (void)hipFree(b->d_ringOps);
   if (b->d_events) (void)hipFree(b->d_events);
   if (b->d_siteStatus) (void)hipFree(b->d_siteStatus);
@@ -347,7 +359,29 @@ int sipnet_batch_run(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_ne
   a.n_steps = n_steps;
   memcpy(a.flags, b->flags, sizeof(a.flags));
   HIP_TRY(hipEventRecord(b->ev0, stream));
-  launchStep(a, b->precision, b->fastMath, stream);
+  if (b->fastMath && !d_rec && isDefaultFlagSet(b->flags) && !getenv("SIPNET_NO_FAST_KERNEL")) {
+    // throughput path: step_fast.hip
+    FastArgs f;
+    f.fast = b->d_fast;
+    f.ringOps = b->d_ringOps;
+    f.events = b->d_events;
+    f.prm = b->d_prm;
+    f.state = b->d_state;
+    f.ring = b->d_ring;
+    f.nee = d_nee;
+    f.gpp = d_gpp;
+    f.et = d_et;
+    f.ncol = b->ncol;
+    f.ld = ld;
+    f.n_sites = b->n_sites;
+    f.n_members = b->n_members;
+    f.n_steps_total = b->n_steps;
+    f.step0 = step0;
+    f.n_steps = n_steps;
+    launchStepFast(f, b->precision, stream);
+  } else {
+    launchStep(a, b->precision, b->fastMath, stream);
+  }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(b->ev1, stream));
   b->timed = true;

@@ -66,6 +66,37 @@ struct EvRec {
 };
 static_assert(sizeof(EvRec) == 40, "EvRec layout");
 
+// Compact record of the fast-math kernels (step_fast.hip): 256 B, staged through LDS in
+// tiles of kFastTile steps.  Holds only what that kernel consumes, pre-combined so that no
+// division by a site quantity is left in the time loop, with the step's first two ring
+// evictions inline and the NEXT step's eviction slots (so the ring values of step t+1 are
+// requested at the top of step t and are in registers long before they are needed).
+struct FastRec {
+  double len, invLen, tair, tsoil;        //  0.. 3
+  double negPar, vpd, log2vpd, vpd2;      //  4.. 7  -par, vpd, log2(vpd), vpd*vpd
+  double rainRate, sublW, evapNum, invWspd;  //  8..11  precip/len, CONV_S*(0.6-vPress)*wspd, CONV*vpdSoil, 1/wspd
+  double tair10, tsoil10, cumGdd, dayTime;   // 12..15
+  double tillP1, w0, w1, gddAfter;        // 16..19  1+d_till_mod; weights of the inline ring evictions
+  double tillAfter, spare0, spare1, spare2;  // 20..23
+  int32_t bits;      // FAST_* below
+  int32_t insSlot;   // slot of this step's insert, -1 = reset ring to the new value
+  int32_t nOps;      // total evictions of this step (first two inline, rest via opFirst)
+  int32_t slot0, slot1, ins0, ins1;  // inline evictions (slot1==slot0, w1==0 when nOps<2)
+  int32_t opFirst;   // global RingOp index of this step's eviction list
+  int32_t evFirst, evCount;
+  int32_t pfSlot0, pfSlot1;  // slots evicted by step t+1 (prefetch targets)
+  int32_t year, day, pad0, pad1;
+};
+static_assert(sizeof(FastRec) == 256, "FastRec must stay 256 bytes");
+constexpr int kFastTile = 16;  // steps per LDS tile (4 KB)
+enum : int32_t {
+  FAST_PHEN_NEW_YEAR = 1, FAST_TRACK_NEW_YEAR = 2,
+  FAST_TAIR_POS = 4,    // tair > 0
+  FAST_PAR_POS = 8,     // par > 0
+  FAST_TSOIL_NEG = 16,  // tsoil < 0
+  FAST_PF_STALE = 32    // a prefetched slot of THIS step was written by step t-1: reload
+};
+
 struct SitePlan {
   std::vector<StepRec> steps;
   std::vector<RingOp> ringOps;  // StepRec.ringOpFirst is local to this vector
@@ -75,6 +106,9 @@ struct SitePlan {
 };
 
 // Build the plan of one site.  clim[n_steps][SIPNET_NCLIM] converted climate.
+// Derive the fast records of one site from its plan (op/event indices stay site-local).
+std::vector<FastRec> buildFastRecs(const SitePlan& plan);
+
 SitePlan buildSitePlan(const int32_t* flags, int32_t n_steps, const double* clim,
                        const int32_t* year, const int32_t* day, int32_t n_events,
                        const sipnet_event* events);

@@ -1,0 +1,580 @@
+// step_fast.hip -- the throughput kernels: default model flags, fast-math policy.
+//
+// Same model as stepKernel<...> in step_kernel.hip (which stays the strict, all-flags
+// reference path on the GPU); this translation unit is where the instruction count of a
+// member-step is driven down, because with one wavefront per SIMD the kernel is bound by
+// VALU issue (4 cycles per wave64 fp64 instruction), not by HBM:
+//
+//   * site-uniform data arrives as FastRec tiles staged through LDS (async global->LDS
+//     DMA one tile ahead, double-buffered), read back with broadcast ds_read_b128;
+//   * the ring value evicted in step t+1 is requested at the top of step t;
+//   * no division by a site quantity and none by a loop-invariant member quantity is left in
+//     the loop; the two remaining true divisions use v_rcp + Newton steps;
+//   * exp2 is an 11th-degree polynomial (<= 1 ulp) + v_ldexp; pow(q, T/10) = exp2(T/10 *
+//     log2 q) with log2 q hoisted; the seven Simpson layers share one exp;
+//   * compiled with -ffp-contract=fast (a*b+c fuses to v_fma_f64).
+//
+// Reference arithmetic being reproduced: /root/reference/src/sipnet/sipnet.c:1256-1336,
+// :1420-1496, :1546-1680, :1688-1767 (citations relative to /root/reference/src/).
+#include <hip/hip_runtime.h>
+
+#include "step_kernel.h"
+
+namespace sipnet {
+namespace {
+
+constexpr double kTiny = 0.000001;
+constexpr double kEps = 1e-8;
+constexpr double kCWeight = 12.0, kTen9 = 1000000000.0, kSecPerDay = 86400.0;
+constexpr double kLog2e = 1.4426950408889634074;
+
+// ---- math ---------------------------------------------------------------------
+__device__ __forceinline__ double ffma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float ffma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+// 2^x, |rel err| <= 1.8e-16: n = rint(x), 2^(x-n) by a degree-11 polynomial on
+// [-0.5, 0.5] (Chebyshev-node interpolant, tools/fit_exp2.py), scaled with v_ldexp_f64.
+__device__ __forceinline__ double fexp2(double x) {
+  const double n = __builtin_rint(x);
+  const double f = x - n;
+  double p = 4.455930741563682e-10;
+  p = ffma(p, f, 7.074197066047615e-09);
+  p = ffma(p, f, 1.0178056472371986e-07);
+  p = ffma(p, f, 1.3215432520547035e-06);
+  p = ffma(p, f, 1.5252733842758916e-05);
+  p = ffma(p, f, 0.0001540353046375614);
+  p = ffma(p, f, 0.0013333558146405434);
+  p = ffma(p, f, 0.009618129107587223);
+  p = ffma(p, f, 0.05550410866482163);
+  p = ffma(p, f, 0.2402265069591016);
+  p = ffma(p, f, 0.6931471805599453);
+  p = ffma(p, f, 1.0);
+  return __builtin_amdgcn_ldexp(p, (int)n);
+}
+__device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// a / b with b > 0 finite and well scaled: v_rcp + two Newton steps + one residual step
+__device__ __forceinline__ double fdiv(double a, double b) {
+  double r = __builtin_amdgcn_rcp(b);
+  r = ffma(ffma(-b, r, 1.0), r, r);
+  r = ffma(ffma(-b, r, 1.0), r, r);
+  const double q = a * r;
+  return ffma(ffma(-b, q, a), r, q);
+}
+__device__ __forceinline__ float fdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+
+__device__ __forceinline__ double flog2(double x) { return log2(x); }
+__device__ __forceinline__ float flog2(float x) { return __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ double fpow(double x, double y) { return pow(x, y); }
+__device__ __forceinline__ float fpow(float x, float y) { return powf(x, y); }
+template <class R> __device__ __forceinline__ R rmax0(R x) { return x > R(0) ? x : R(0); }
+template <class R> __device__ __forceinline__ R clip01(R x) {
+  x = x > R(0) ? x : R(0);
+  return x < R(1) ? x : R(1);
+}
+
+__device__ __forceinline__ int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// site record as it sits in LDS
+struct alignas(16) RecView {
+  const double* d;
+  const int32_t* i;
+};
+
+}  // namespace
+
+// -------------------------------------------------------------------------------
+template <class R>
+__global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
+  // LDS: two tiles of kFastTile site records (2 x 4 KB).  ONE __shared__ object.
+  __shared__ alignas(16) unsigned char lds[2 * kFastTile * sizeof(FastRec)];
+
+  const int chunksPerSite = (a.n_members + 63) >> 6;
+  int site, chunk;
+  {
+    const int b = (int)blockIdx.x;
+    if ((a.n_sites & 7) == 0) {  // keep a site's chunks on one XCD group (speed only)
+      const int g = b & 7, j = b >> 3;
+      site = g + 8 * (j / chunksPerSite);
+      chunk = j % chunksPerSite;
+    } else {
+      site = b / chunksPerSite;
+      chunk = b % chunksPerSite;
+    }
+  }
+  const int lane = (int)threadIdx.x;
+  int m = (chunk << 6) + lane;
+  // lanes past the end of the site keep running on a clamped column (they are needed for the
+  // cooperative tile copies) but never store
+  const bool live = m < a.n_members;
+  if (!live) m = a.n_members - 1;
+  const int64_t col = (int64_t)site * a.n_members + m;
+  const int64_t nc = a.ncol;
+
+  double* __restrict__ stp = a.state + col;
+  const bool skip = stp[(int64_t)ST_status * nc] != 0.0;
+  const bool act = live && !skip;
+
+  // ---- per-member constants ---------------------------------------------------
+  const double* __restrict__ pp = a.prm + col;
+#define PRM(name) (pp[(int64_t)SP_##name * nc])
+  const double leafCSpWt = PRM(leafCSpWt);
+  const double convK = kCWeight * (1.0 / kTen9) * (leafCSpWt / PRM(cFracLeaf)) * kSecPerDay;
+  const double respPerGram = PRM(baseFolRespFrac) * PRM(aMax);
+  const R K_g = (R)((PRM(aMax) * PRM(aMaxFrac) + respPerGram) * convK);
+  const R K_rpg = (R)(respPerGram * convK);
+  const R K_invLcsw = (R)(1.0 / leafCSpWt);
+  const R K_tmin = (R)PRM(psnTMin), K_tmax = (R)PRM(psnTMax);
+  const R K_invDen = (R)(1.0 / (((PRM(psnTMax) - PRM(psnTMin)) / 2.0) * ((PRM(psnTMax) - PRM(psnTMin)) / 2.0)));
+  const R K_slope = (R)PRM(dVpdSlope), K_vexp = (R)PRM(dVpdExp);
+  const R K_attl = (R)(-PRM(attenuation) * (1.0 / 6.0) * kLog2e);
+  const R K_invHalf = (R)(1.0 / PRM(halfSatPar));
+  const R K_tr = (R)(1000.0 * (44.0 / 12.0) * (1.0 / 10000.0) / PRM(wueConst));
+  const R K_whc = (R)PRM(soilWHC), K_invWhc = (R)(1.0 / PRM(soilWHC));
+  const R K_wrf = (R)PRM(waterRemoveFrac);
+  const R K_frozThr = (R)PRM(frozenSoilThreshold), K_frozEff = (R)PRM(frozenSoilEff);
+  const R K_frozFolEff = (R)PRM(frozenSoilFolREff);
+  const R K_immed = (R)PRM(immedEvapFrac), K_ff = (R)PRM(fastFlowFrac);
+  const R K_invRd = (R)(1.0 / PRM(rdConst)), K_rd = (R)PRM(rdConst), K_melt = (R)PRM(snowMelt);
+  const R K_c1l = (R)(PRM(rSoilConst1) * kLog2e), K_c2l = (R)(PRM(rSoilConst2) * kLog2e);
+  const R K_lgVeg = (R)log2(PRM(vegRespQ10)), K_lgSoil = (R)log2(PRM(soilRespQ10));
+  const R K_lgFine = (R)log2(PRM(fineRootQ10)), K_lgCoarse = (R)log2(PRM(coarseRootQ10));
+  const R K_folShift = (R)exp2(-(PRM(psnTOpt) / 10.0) * log2(PRM(vegRespQ10)));
+  const R K_bvr = (R)PRM(baseVegResp), K_bsr = (R)PRM(baseSoilResp);
+  const R K_bfr = (R)PRM(baseFineRootResp), K_bcr = (R)PRM(baseCoarseRootResp);
+  const R K_wtr = (R)PRM(woodTurnoverRate), K_ltr = (R)PRM(leafTurnoverRate);
+  const R K_frt = (R)PRM(fineRootTurnoverRate), K_crt = (R)PRM(coarseRootTurnoverRate);
+  const R K_la = (R)PRM(leafAllocation), K_wa = (R)PRM(woodAllocation);
+  const R K_fa = (R)PRM(fineRootAllocation), K_ca = (R)PRM(coarseRootAllocation);
+  const R K_moistExp = (R)PRM(soilRespMoistEffect);
+  const double gddLeafOn = PRM(gddLeafOn), leafOffDay = PRM(leafOffDay);
+  const R K_leafGrowth = (R)PRM(leafGrowth), K_fracLeafFall = (R)PRM(fracLeafFall);
+  const R K_realloc = (R)PRM(leafOnReallocFrac);
+#undef PRM
+
+  // ---- carried state ----------------------------------------------------------
+#define ST(name) stp[(int64_t)ST_##name * nc]
+  double plantWoodC = ST(plantWoodC), plantLeafC = ST(plantLeafC), soilC = ST(soilC);
+  double soilWater = ST(soilWater), snow = ST(snow);
+  double coarseRootC = ST(coarseRootC), fineRootC = ST(fineRootC);
+  double delta = ST(plantCAccountingDelta);
+  double ringSum = ST(ringSum), totNee = ST(totNee), totGpp = ST(totGpp);
+  int phenBits = (int)ST(phenBits);
+  int ringValidFrom = (int)ST(ringValidFrom);
+  int diedAt = (int)ST(diedAt);
+  int clampCount = (int)ST(clampCount);
+
+  const unsigned char* __restrict__ planBytes =
+      (const unsigned char*)(a.fast + (int64_t)site * a.n_steps_total);
+  double* __restrict__ ringp = a.ring + col;
+  R* __restrict__ oNee = a.nee ? (R*)a.nee + col : nullptr;
+  R* __restrict__ oGpp = a.gpp ? (R*)a.gpp + col : nullptr;
+  R* __restrict__ oEt = a.et ? (R*)a.et + col : nullptr;
+
+  // ---- tile staging: async global -> LDS, 16 B per lane, 4 pieces per 4 KB tile ----
+  constexpr int kTileBytes = kFastTile * (int)sizeof(FastRec);
+  auto stageTile = [&](int tile, int buf) {
+    // records [tile*kFastTile, +kFastTile) clamped to the plan's end (the tail re-reads the
+    // last records; never used)
+    int64_t first = (int64_t)tile * kFastTile;
+    const int64_t lastStart = (int64_t)a.n_steps_total - kFastTile;
+    if (first > lastStart) first = lastStart > 0 ? lastStart : 0;
+    const unsigned char* src = planBytes + first * (int64_t)sizeof(FastRec);
+#pragma unroll
+    for (int k = 0; k < kTileBytes / 1024; k++) {
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(src + k * 1024 + lane * 16),
+          (__attribute__((address_space(3))) void*)(lds + buf * kTileBytes + k * 1024), 16, 0, 0);
+    }
+  };
+  // index of step t inside its staged tile (tiles near the end of the plan are clamped)
+  auto recOffset = [&](int t) -> int {
+    const int tile = t / kFastTile;
+    int64_t first = (int64_t)tile * kFastTile;
+    const int64_t lastStart = (int64_t)a.n_steps_total - kFastTile;
+    if (first > lastStart) first = lastStart > 0 ? lastStart : 0;
+    return (int)(t - first);
+  };
+
+  const int tBegin = a.step0, tEnd = a.step0 + a.n_steps;
+  int curTile = tBegin / kFastTile;
+  stageTile(curTile, curTile & 1);
+  __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) lgkmcnt(0): first tile landed
+  __syncthreads();
+  stageTile(curTile + 1, (curTile + 1) & 1);
+
+  double pfv0 = 0.0, pfv1 = 0.0;  // ring values requested one step ahead
+  bool havePf = false;
+
+  for (int t = tBegin; t < tEnd; t++) {
+    const int tile = t / kFastTile;
+    if (tile != curTile) {
+      // the tile staged one tile-time ago has long landed; drain and move on
+      __builtin_amdgcn_s_waitcnt(0);
+      __syncthreads();
+      curTile = tile;
+      stageTile(curTile + 1, (curTile + 1) & 1);
+    }
+    const unsigned char* recB = lds + (tile & 1) * kTileBytes + recOffset(t) * (int)sizeof(FastRec);
+    const double* rd = (const double*)recB;
+    const int32_t* ri = (const int32_t*)(recB + 24 * sizeof(double));
+
+    const R len = (R)rd[0], invLen = (R)rd[1], tair = (R)rd[2], tsoil = (R)rd[3];
+    const int bits = uni(ri[0]);
+    const int insSlot = uni(ri[1]);
+    const int nOps = uni(ri[2]);
+    const int slot0 = uni(ri[3]), slot1 = uni(ri[4]);
+    const int pfSlot0 = uni(ri[10]), pfSlot1 = uni(ri[11]);
+
+    // ring values of THIS step (prefetched during the previous step unless stale/first)
+    double rv0, rv1;
+    if (havePf && !(bits & FAST_PF_STALE)) {
+      rv0 = pfv0;
+      rv1 = pfv1;
+    } else {
+      rv0 = ringp[(int64_t)slot0 * nc];
+      rv1 = ringp[(int64_t)slot1 * nc];
+    }
+    // request next step's values now
+    pfv0 = ringp[(int64_t)pfSlot0 * nc];
+    pfv1 = ringp[(int64_t)pfSlot1 * nc];
+    havePf = true;
+
+    // ---- 0. start of step (sipnet.c:1821-1828) -------------------------------------
+    bool alive = (plantWoodC > kTiny) && (plantWoodC + delta > kTiny) &&
+                 (fineRootC + coarseRootC > kTiny);
+    const R eWood = (R)plantWoodC, eLeaf = (R)plantLeafC, eSoilC = (R)soilC;
+    const R eWater = (R)soilWater, eSnow = (R)snow;
+    const R eCoarse = (R)coarseRootC, eFine = (R)fineRootC;
+    const R totalWoodC = (R)(plantWoodC + delta);
+
+    // ---- 1. events (events.c:449-742); tillage is folded into the plan ---------------
+    R evLeafC = 0, evWoodC = 0, evFineRootC = 0, evCoarseRootC = 0, evEvap = 0, evSoilWater = 0;
+    R evSoilC = 0, evLeafOnCreation = 0, evLeafOnFromWood = 0, evLeafOffLitter = 0;
+    const int nEv = uni(ri[9]);
+    auto leafOnLimit = [&](R flux) -> R {  // limitations.c:13-64 (no N cycle here)
+      const R cDemand = flux * len;
+      if (cDemand < R(kTiny)) return flux;
+      const R lim = clip01(fdiv((eWood + eCoarse) * K_realloc, cDemand));
+      return lim < R(1) ? flux * lim : flux;
+    };
+    if (nEv > 0) {
+      const int ev0 = uni(ri[8]);
+      for (int k = 0; k < nEv; k++) {
+        const EvRec& ev = a.events[ev0 + k];
+        const int type = uni(ev.type);
+        const R p0 = (R)ev.p[0], p1 = (R)ev.p[1], p2 = (R)ev.p[2], p3 = (R)ev.p[3];
+        if (type == SIPNET_EV_IRRIG) {
+          const R evapAmount = ((int)ev.p[1] == 0) ? K_immed * p0 : R(0);
+          evEvap += evapAmount * invLen;
+          evSoilWater += (p0 - evapAmount) * invLen;
+        } else if (type == SIPNET_EV_PLANT) {
+          evLeafC += p0 * invLen;
+          evWoodC += p1 * invLen;
+          evFineRootC += p2 * invLen;
+          evCoarseRootC += p3 * invLen;
+        } else if (type == SIPNET_EV_HARVEST) {
+          const R woodC = totalWoodC;
+          evSoilC += (p3 * (eFine + eCoarse) + p2 * (eLeaf + woodC)) * invLen;
+          evLeafC += -eLeaf * (p0 + p2) * invLen;
+          evWoodC += -woodC * (p0 + p2) * invLen;
+          evFineRootC += -eFine * (p1 + p3) * invLen;
+          evCoarseRootC += -eCoarse * (p1 + p3) * invLen;
+        } else if (type == SIPNET_EV_FERT) {
+          evSoilC += p1 * invLen;
+        } else if (type == SIPNET_EV_LEAFON) {
+          const R flux = leafOnLimit(K_leafGrowth * invLen);
+          evLeafOnCreation += flux;
+          const R src = eWood + eCoarse;
+          if (src > R(kTiny)) evLeafOnFromWood += fdiv(flux * eWood, src);
+        } else if (type == SIPNET_EV_LEAFOFF) {
+          evLeafOffLitter += eLeaf * K_fracLeafFall * invLen;
+        }
+      }
+    }
+
+    // ---- 2. fluxes (sipnet.c:1256-1336) ---------------------------------------------
+    const R lai = eLeaf * K_invLcsw;
+    // potPsn(), sipnet.c:590-641
+    const R dTemp = rmax0((K_tmax - tair) * (tair - K_tmin) * K_invDen);
+    const R vpdPow = (K_vexp == R(2)) ? (R)rd[7] : fexp2(K_vexp * (R)rd[6]);
+    const R dVpd = rmax0(R(1) - K_slope * vpdPow);
+    R dLight = 0;
+    if ((bits & FAST_PAR_POS) && lai > R(0)) {
+      // calcLightEff(), sipnet.c:517-570: Simpson over 7 layers;
+      // sum c_i (1 - e_i) / 18 = 1 - (sum c_i e_i) / 18, c = 1 4 2 4 2 4 1
+      const R r1 = fexp2(K_attl * lai);
+      const R q = (R)rd[4] * K_invHalf;
+      const R r2 = r1 * r1, r3 = r2 * r1, r4 = r2 * r2, r5 = r4 * r1, r6 = r3 * r3;
+      const R e0 = fexp2(q), e1 = fexp2(q * r1), e2 = fexp2(q * r2), e3 = fexp2(q * r3);
+      const R e4 = fexp2(q * r4), e5 = fexp2(q * r5), e6 = fexp2(q * r6);
+      const R s = (e0 + e6) + R(4) * (e1 + e3 + e5) + R(2) * (e2 + e4);
+      dLight = R(1) - s * R(1.0 / 18.0);
+    }
+    const R potGrossPsn = K_g * lai * dTemp * dVpd * dLight;
+    const R baseFolResp = K_rpg * lai;
+
+    // moisture(), sipnet.c:656-699
+    R transpiration = 0, photosynthesis = potGrossPsn;
+    if (potGrossPsn >= R(kTiny)) {
+      const R potTrans = potGrossPsn * (R)rd[5] * K_tr;
+      R removable = (eWater < K_whc ? eWater : K_whc) * K_wrf;
+      if (tsoil < K_frozThr) removable *= K_frozEff;
+      if (removable < potTrans) {
+        transpiration = removable;
+        photosynthesis = potGrossPsn * fdiv(removable, potTrans);
+      } else {
+        transpiration = potTrans;
+      }
+    }
+
+    // calcPrecip(), sipnet.c:848-882 (uniform branch on the site's air temperature)
+    const bool tairPos = (bits & FAST_TAIR_POS) != 0;
+    const R rate = (R)rd[8];
+    const R rain = tairPos ? rate : R(0), snowFall = tairPos ? R(0) : rate;
+    const R immedEvap = rain * K_immed;
+    const R netRain = rain - immedEvap;
+
+    // snowPack(), sipnet.c:888-946
+    R snowMelt = 0, sublimation = 0;
+    if (eSnow > R(0)) {
+      sublimation = rmax0((R)rd[9] * K_invRd);
+      R remaining = eSnow + snowFall * len;
+      if (remaining - sublimation * len < R(0)) {
+        sublimation = remaining * invLen;
+        remaining = 0;
+      } else {
+        remaining -= sublimation * len;
+      }
+      if (tairPos) {
+        snowMelt = K_melt * tair;
+        if (remaining - snowMelt * len < R(0)) snowMelt = remaining * invLen;
+      }
+    }
+
+    // calcSoilWaterFluxes(), sipnet.c:963-1031
+    R evaporation = 0, drainage = 0, fastFlow;
+    {
+      R netIn = netRain + snowMelt;
+      fastFlow = netIn * K_ff;
+      netIn -= fastFlow;
+      R remaining = eWater + netIn * len - transpiration * len;
+      if (!(eSnow > R(0))) {
+        const R wf = clip01(eWater * K_invWhc);
+        const R rsoil = fexp2(K_c1l - K_c2l * wf);
+        evaporation = rmax0(fdiv((R)rd[10], K_rd * (R)rd[11] + rsoil));
+        if (remaining - evaporation * len < R(kTiny)) {
+          evaporation = (remaining - R(kTiny)) * invLen;
+          remaining = 0;
+        } else {
+          remaining -= evaporation * len;
+        }
+      }
+      if (remaining > K_whc) drainage = (remaining - K_whc) * invLen;
+    }
+
+    const R meanNpp = (R)(ringSum * 0.2);  // runmean.c:119-121 (sum / 5)
+
+    // vegResp(), sipnet.c:1051-1068
+    const R vegQ = fexp2((R)rd[12] * K_lgVeg);
+    R folResp = baseFolResp * (vegQ * K_folShift);
+    if (tsoil < K_frozThr) folResp *= K_frozFolEff;
+    const R rVeg = folResp + K_bvr * totalWoodC * vegQ;
+
+    // calcWoodAndLeafFluxes(), sipnet.c:756-782
+    const R woodLitter = totalWoodC * K_wtr;
+    R leafLitter = eLeaf * K_ltr;
+    R leafCreation = meanNpp * K_la, woodCreation = meanNpp * K_wa;
+
+    // calcLeafOnOffFluxes(), sipnet.c:800-842 (GDD phenology, sipnet.c:705-716)
+    R leafOnCreation = 0, leafOnFromWood = 0;
+    if (bits & FAST_PHEN_NEW_YEAR) phenBits = 0;
+    if (!(phenBits & 1) && rd[14] >= gddLeafOn) {
+      const R leafOn = leafOnLimit(K_leafGrowth * invLen);
+      leafOnCreation = leafOn;
+      const R src = eWood + eCoarse;
+      if (src > R(kTiny)) leafOnFromWood = fdiv(leafOn * eWood, src);
+      phenBits |= 1;
+    }
+    if (!(phenBits & 2) && leafOffDay > 0 && rd[15] >= leafOffDay) {
+      leafLitter += (eLeaf * K_fracLeafFall) * invLen;
+      phenBits |= 2;
+    }
+
+    // roots, sipnet.c:1176-1196
+    const R coarseRootLoss = K_crt * eCoarse, fineRootLoss = K_frt * eFine;
+    R coarseRootCreation = K_ca * meanNpp, fineRootCreation = K_fa * meanNpp;
+    const R tsoil10 = (R)rd[13];
+    const R rCoarseRoot = K_bcr * eCoarse * fexp2(tsoil10 * K_lgCoarse);
+    const R rFineRoot = K_bfr * eFine * fexp2(tsoil10 * K_lgFine);
+
+    // calcSoilRespiration(), sipnet.c:1132-1148 with depeffects.c:23-87
+    R moistEff = 1;
+    if (!(bits & FAST_TSOIL_NEG)) {
+      const R f_whc = clip01(eWater * K_invWhc);
+      moistEff = (K_moistExp == R(1)) ? f_whc : fpow(f_whc, K_moistExp);
+    }
+    const R rSoil = eSoilC * K_bsr * moistEff * fexp2(tsoil10 * K_lgSoil) * (R)rd[16];
+
+    // checkNegativeCreation(), limitations.c:146-182
+    {
+      const R leafDeficit = eLeaf * invLen + leafCreation - eLeaf * K_ltr;
+      if (leafDeficit < R(0)) {
+        woodCreation += leafDeficit;
+        leafCreation -= leafDeficit;
+      }
+      const R fineDef = eFine * invLen + fineRootCreation - fineRootLoss;
+      const R coarseDef = eCoarse * invLen + coarseRootCreation - coarseRootLoss;
+      if ((fineDef < R(0)) != (coarseDef < R(0))) {
+        if (fineDef < R(0)) {
+          coarseRootCreation += fineDef;
+          fineRootCreation -= fineDef;
+        }
+        if (coarseDef < R(0)) {
+          fineRootCreation += coarseDef;
+          coarseRootCreation -= coarseDef;
+        }
+      }
+    }
+
+    // ---- 3. pools (sipnet.c:1769-1806) ------------------------------------------------
+    const double oldDelta = delta;
+    (void)oldDelta;
+    if (nEv > 0) {  // updatePoolsForEvents(), events.c:744-790
+      plantWoodC += (double)(evWoodC * len);
+      plantLeafC += (double)(evLeafC * len);
+      soilC += (double)(evSoilC * len);
+      plantWoodC -= (double)(evLeafOnFromWood * len);
+      coarseRootC -= (double)((evLeafOnCreation - evLeafOnFromWood) * len);
+      plantLeafC += (double)((evLeafOnCreation - evLeafOffLitter) * len);
+      soilC += (double)(evLeafOffLitter * len);
+      coarseRootC += (double)(evCoarseRootC * len);
+      fineRootC += (double)(evFineRootC * len);
+      soilWater += (double)(evSoilWater * len);
+    }
+    {
+      const R r_a = rVeg + rFineRoot + rCoarseRoot;
+      const R alloc = leafCreation + woodCreation + fineRootCreation + coarseRootCreation;
+      delta += (double)(((photosynthesis - r_a) - alloc) * len);
+      plantWoodC += (double)((woodCreation - woodLitter - leafOnFromWood) * len);
+      plantLeafC += (double)((leafCreation + leafOnCreation - leafLitter) * len);
+      soilWater += (double)((rain + snowMelt - immedEvap - fastFlow - evaporation -
+                             transpiration - drainage) * len);
+      snow += (double)((snowFall - snowMelt - sublimation) * len);
+      soilC += (double)((coarseRootLoss + fineRootLoss + woodLitter + leafLitter - rSoil) * len);
+      coarseRootC += (double)((coarseRootCreation - coarseRootLoss -
+                               (leafOnCreation - leafOnFromWood)) * len);
+      fineRootC += (double)((fineRootCreation - fineRootLoss) * len);
+    }
+
+    // checkForMortality(), sipnet.c:1688-1767
+    {
+      const bool sufficient = (plantWoodC > kTiny) && (plantWoodC + delta > kTiny) &&
+                              (fineRootC + coarseRootC > kTiny);
+      if (!alive) {
+        if (sufficient) alive = true;
+      } else if (!sufficient) {
+        alive = false;
+        if (diedAt < 0) diedAt = t;
+        soilC += fineRootC + coarseRootC;
+        soilC += plantWoodC + plantLeafC + delta;
+        plantWoodC = 0.0;
+        plantLeafC = 0.0;
+        coarseRootC = 0.0;
+        fineRootC = 0.0;
+        delta = 0.0;
+        ringSum = 0.0;
+      }
+    }
+    // ensureNonNegativeStocks(), sipnet.c:1368-1397
+#define CLAMP(v, minVal)                           \
+  if (v < (minVal)) {                              \
+    if (__builtin_fabs(v) > kEps) clampCount++;    \
+    v = 0.;                                        \
+  }
+    CLAMP(plantWoodC, 0.0)
+    CLAMP(plantLeafC, 0.0)
+    CLAMP(soilC, 0.0)
+    CLAMP(coarseRootC, 0.0)
+    CLAMP(fineRootC, 0.0)
+    CLAMP(soilWater, 0.0)
+    CLAMP(snow, kTiny)
+#undef CLAMP
+
+    // ---- 4. outputs: updateTrackers(), sipnet.c:1420-1496 ---------------------------
+    const R tGpp = photosynthesis * len;
+    const R tRh = rSoil * len;
+    const R tRa = (rCoarseRoot + rFineRoot) * len + rVeg * len;
+    const R tNee = R(-1.0) * ((tGpp - tRa) - tRh);
+    const R tEt = (transpiration + immedEvap + evaporation + sublimation + evEvap) * len;
+    totGpp += (double)tGpp;
+    totNee += (double)tNee;
+    if (act) {
+      if (oNee) oNee[(int64_t)(t - tBegin) * a.ld] = tNee;
+      if (oGpp) oGpp[(int64_t)(t - tBegin) * a.ld] = tGpp;
+      if (oEt) oEt[(int64_t)(t - tBegin) * a.ld] = tEt;
+    }
+
+    // ---- 5. running mean of NPP (sipnet.c:1546-1570, runmean.c:61-116 via the plan) ----
+    if (alive) {
+      const double npp = (double)(photosynthesis - rVeg - rCoarseRoot - rFineRoot);
+      if (insSlot < 0) {
+        if (act) ringp[0] = npp;
+        ringSum = npp * 5.0;
+      } else {
+        const double w0 = rd[17], w1 = rd[18];
+        if (ringValidFrom > 0) {  // a member that died earlier: older slots count as zero
+          if (uni(ri[5]) < ringValidFrom) rv0 = 0.0;
+          if (uni(ri[6]) < ringValidFrom) rv1 = 0.0;
+        }
+        ringSum = ffma(-w0, rv0, ringSum);
+        ringSum = ffma(-w1, rv1, ringSum);
+        if (nOps > 2) {
+          const int opFirst = uni(ri[7]);
+          for (int k = 2; k < nOps; k++) {
+            const RingOp& op = a.ringOps[opFirst + k];
+            const double v = (uni(op.insStep) >= ringValidFrom)
+                                 ? ringp[(int64_t)uni(op.slot) * nc] : 0.0;
+            ringSum = ffma(-op.w, v, ringSum);
+          }
+        }
+        if (act) ringp[(int64_t)insSlot * nc] = npp;
+        ringSum = ffma(npp, (double)len, ringSum);
+      }
+    } else {
+      ringValidFrom = t + 1;
+    }
+  }
+
+  // ---- state back to HBM ----------------------------------------------------------
+  if (act) {
+    ST(plantWoodC) = plantWoodC;
+    ST(plantLeafC) = plantLeafC;
+    ST(soilC) = soilC;
+    ST(soilWater) = soilWater;
+    ST(snow) = snow;
+    ST(coarseRootC) = coarseRootC;
+    ST(fineRootC) = fineRootC;
+    ST(plantCAccountingDelta) = delta;
+    ST(ringSum) = ringSum;
+    ST(totNee) = totNee;
+    ST(totGpp) = totGpp;
+    ST(phenBits) = (double)phenBits;
+    ST(ringValidFrom) = (double)ringValidFrom;
+    ST(diedAt) = (double)diedAt;
+    ST(clampCount) = (double)clampCount;
+  }
+#undef ST
+}
+
+void launchStepFast(const FastArgs& a, int precision, hipStream_t stream) {
+  const int chunksPerSite = (a.n_members + 63) / 64;
+  const int grid = a.n_sites * chunksPerSite;
+  if (precision == SIPNET_F64) {
+    hipLaunchKernelGGL(stepFastKernel<double>, dim3(grid), dim3(64), 0, stream, a);
+  } else {
+    hipLaunchKernelGGL(stepFastKernel<float>, dim3(grid), dim3(64), 0, stream, a);
+  }
+}
+
+}  // namespace sipnet

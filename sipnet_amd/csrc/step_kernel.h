@@ -77,6 +77,23 @@ struct SetupArgs {
   const int32_t* siteStatus;  // [n_sites] plan status (site-fatal conditions)
 };
 
+// arguments of the throughput kernels (step_fast.hip): default flags, lean outputs
+struct FastArgs {
+  const FastRec* fast;    // [n_sites][n_steps_total] (+ kFastTile records of padding)
+  const RingOp* ringOps;
+  const EvRec* events;
+  const double* prm;
+  double* state;
+  double* ring;
+  void* nee;
+  void* gpp;
+  void* et;
+  int64_t ncol, ld;
+  int32_t n_sites, n_members, n_steps_total, step0, n_steps;
+};
+void launchStepFast(const FastArgs& a, int precision, hipStream_t stream);
+bool isDefaultFlagSet(const int32_t* flags);
+
 // launchers (step_kernel.hip)
 void launchSetup(const SetupArgs& a, hipStream_t stream);
 // variant: bit0 = fast math, bit1 = generic flags (runtime), else default flags

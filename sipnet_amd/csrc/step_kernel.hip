@@ -1133,6 +1133,8 @@ static bool isDefaultFlags(const int32_t* f) {
   return true;
 }
 
+bool isDefaultFlagSet(const int32_t* f) { return isDefaultFlags(f); }
+
 void launchStep(const KernelArgs& a, int precision, bool fastMath, hipStream_t stream) {
   const bool generic = !isDefaultFlags(a.flags);
   const bool full = a.rec != nullptr;

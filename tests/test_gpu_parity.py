@@ -104,7 +104,18 @@ def test_synthetic_special_members_vs_reference_fixture(fast, oracle, tmp_path):
     planes = planes.cpu().numpy()
     final = rec[-1].cpu().numpy().T      # [member][36]
     state = b.get_state()
+    # the lean launch (no full record) is what bench.py times: with fast math and default
+    # flags it runs the throughput kernel of step_fast.hip.  Same answers required.
+    b.setup()
+    planes_lean, _ = b.run()
+    planes_lean = planes_lean.cpu().numpy()
+    state_lean = b.get_state()
     b.close()
+    d_lean = np.abs(planes_lean - planes)
+    print(f"fast={fast} lean-vs-full launch: max|d| {d_lean.max():.3e}")
+    assert d_lean.max() < TOL_F64
+    assert rel_err(state_lean[:, :14], state[:, :14]).max() < 1e-9          # pools + ring sum
+    assert np.array_equal(state_lean[:, 27:31], state[:, 27:31])            # phenology, epoch, status, death step
     idx = ref["idx"]
     d_nee = np.abs(planes[0][idx].T - ref["nee"])
     d_gpp = np.abs(planes[1][idx].T - ref["gpp"])
