@@ -197,34 +197,45 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
   };
 
   const int tBegin = a.step0, tEnd = a.step0 + a.n_steps;
+  const uint32_t ncu = (uint32_t)nc;  // ring element offsets fit 32 bits (250 * ncol < 2^31)
   int curTile = tBegin / kFastTile;
   stageTile(curTile, curTile & 1);
-  __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) lgkmcnt(0): first tile landed
-  __syncthreads();
-  stageTile(curTile + 1, (curTile + 1) & 1);
 
   double pfv0 = 0.0, pfv1 = 0.0;  // ring values requested one step ahead
   bool havePf = false;
 
-  for (int t = tBegin; t < tEnd; t++) {
-    const int tile = t / kFastTile;
-    if (tile != curTile) {
-      // the tile staged one tile-time ago has long landed; drain and move on
-      __builtin_amdgcn_s_waitcnt(0);
-      __syncthreads();
-      curTile = tile;
-      stageTile(curTile + 1, (curTile + 1) & 1);
-    }
-    const unsigned char* recB = lds + (tile & 1) * kTileBytes + recOffset(t) * (int)sizeof(FastRec);
-    const double* rd = (const double*)recB;
-    const int32_t* ri = (const int32_t*)(recB + 24 * sizeof(double));
+  for (int tileStart = curTile * kFastTile; tileStart < tEnd; tileStart += kFastTile, curTile++) {
+    // the tile staged one tile-time ago has long landed; drain, then stage the next one into
+    // the buffer the previous tile just vacated
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    stageTile(curTile + 1, (curTile + 1) & 1);
+    const int tFirst = tileStart > tBegin ? tileStart : tBegin;
+    const int tLast = (tileStart + kFastTile) < tEnd ? (tileStart + kFastTile) : tEnd;
+    const unsigned char* recB =
+        lds + (curTile & 1) * kTileBytes + recOffset(tFirst) * (int)sizeof(FastRec);
+  for (int t = tFirst; t < tLast; t++, recB += sizeof(FastRec)) {
+    // ---- the whole site record in one batch of broadcast LDS reads ------------------
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    typedef int i4 __attribute__((ext_vector_type(4)));
+    const d2* rq = (const d2*)recB;
+    const d2 q0 = rq[0], q1 = rq[1], q2 = rq[2], q3 = rq[3], q4 = rq[4], q5 = rq[5];
+    const d2 q6 = rq[6], q7 = rq[7], q8 = rq[8];
+    const i4* iq = (const i4*)(recB + 24 * sizeof(double));
+    const i4 j0 = iq[0], j1 = iq[1], j2 = iq[2];
+    const double rd_len = q0.x, rd_invLen = q0.y, rd_tair = q1.x, rd_tsoil = q1.y;
+    const double rd_negPar = q2.x, rd_vpd = q2.y, rd_log2vpd = q3.x, rd_vpd2 = q3.y;
+    const double rd_rainRate = q4.x, rd_sublW = q4.y, rd_evapNum = q5.x, rd_invWspd = q5.y;
+    const double rd_tair10 = q6.x, rd_tsoil10 = q6.y, rd_cumGdd = q7.x, rd_dayTime = q7.y;
+    const double rd_tillP1 = q8.x, rd_w0 = q8.y;
+    const double rd_w1 = ((const double*)recB)[18];
 
-    const R len = (R)rd[0], invLen = (R)rd[1], tair = (R)rd[2], tsoil = (R)rd[3];
-    const int bits = uni(ri[0]);
-    const int insSlot = uni(ri[1]);
-    const int nOps = uni(ri[2]);
-    const int slot0 = uni(ri[3]), slot1 = uni(ri[4]);
-    const int pfSlot0 = uni(ri[10]), pfSlot1 = uni(ri[11]);
+    const R len = (R)rd_len, invLen = (R)rd_invLen, tair = (R)rd_tair, tsoil = (R)rd_tsoil;
+    const int bits = uni(j0.x);
+    const int insSlot = uni(j0.y);
+    const int nOps = uni(j0.z);
+    const int slot0 = uni(j0.w), slot1 = uni(j1.x);
+    const int pfSlot0 = uni(j2.z), pfSlot1 = uni(j2.w);
 
     // ring values of THIS step (prefetched during the previous step unless stale/first)
     double rv0, rv1;
@@ -232,12 +243,12 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
       rv0 = pfv0;
       rv1 = pfv1;
     } else {
-      rv0 = ringp[(int64_t)slot0 * nc];
-      rv1 = ringp[(int64_t)slot1 * nc];
+      rv0 = ringp[(uint32_t)slot0 * ncu];
+      rv1 = ringp[(uint32_t)slot1 * ncu];
     }
     // request next step's values now
-    pfv0 = ringp[(int64_t)pfSlot0 * nc];
-    pfv1 = ringp[(int64_t)pfSlot1 * nc];
+    pfv0 = ringp[(uint32_t)pfSlot0 * ncu];
+    pfv1 = ringp[(uint32_t)pfSlot1 * ncu];
     havePf = true;
 
     // ---- 0. start of step (sipnet.c:1821-1828) -------------------------------------
@@ -251,7 +262,7 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
     // ---- 1. events (events.c:449-742); tillage is folded into the plan ---------------
     R evLeafC = 0, evWoodC = 0, evFineRootC = 0, evCoarseRootC = 0, evEvap = 0, evSoilWater = 0;
     R evSoilC = 0, evLeafOnCreation = 0, evLeafOnFromWood = 0, evLeafOffLitter = 0;
-    const int nEv = uni(ri[9]);
+    const int nEv = uni(j2.y);
     auto leafOnLimit = [&](R flux) -> R {  // limitations.c:13-64 (no N cycle here)
       const R cDemand = flux * len;
       if (cDemand < R(kTiny)) return flux;
@@ -259,7 +270,7 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
       return lim < R(1) ? flux * lim : flux;
     };
     if (nEv > 0) {
-      const int ev0 = uni(ri[8]);
+      const int ev0 = uni(j2.x);
       for (int k = 0; k < nEv; k++) {
         const EvRec& ev = a.events[ev0 + k];
         const int type = uni(ev.type);
@@ -297,14 +308,14 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
     const R lai = eLeaf * K_invLcsw;
     // potPsn(), sipnet.c:590-641
     const R dTemp = rmax0((K_tmax - tair) * (tair - K_tmin) * K_invDen);
-    const R vpdPow = (K_vexp == R(2)) ? (R)rd[7] : fexp2(K_vexp * (R)rd[6]);
+    const R vpdPow = (K_vexp == R(2)) ? (R)rd_vpd2 : fexp2(K_vexp * (R)rd_log2vpd);
     const R dVpd = rmax0(R(1) - K_slope * vpdPow);
     R dLight = 0;
     if ((bits & FAST_PAR_POS) && lai > R(0)) {
       // calcLightEff(), sipnet.c:517-570: Simpson over 7 layers;
       // sum c_i (1 - e_i) / 18 = 1 - (sum c_i e_i) / 18, c = 1 4 2 4 2 4 1
       const R r1 = fexp2(K_attl * lai);
-      const R q = (R)rd[4] * K_invHalf;
+      const R q = (R)rd_negPar * K_invHalf;
       const R r2 = r1 * r1, r3 = r2 * r1, r4 = r2 * r2, r5 = r4 * r1, r6 = r3 * r3;
       const R e0 = fexp2(q), e1 = fexp2(q * r1), e2 = fexp2(q * r2), e3 = fexp2(q * r3);
       const R e4 = fexp2(q * r4), e5 = fexp2(q * r5), e6 = fexp2(q * r6);
@@ -317,7 +328,7 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
     // moisture(), sipnet.c:656-699
     R transpiration = 0, photosynthesis = potGrossPsn;
     if (potGrossPsn >= R(kTiny)) {
-      const R potTrans = potGrossPsn * (R)rd[5] * K_tr;
+      const R potTrans = potGrossPsn * (R)rd_vpd * K_tr;
       R removable = (eWater < K_whc ? eWater : K_whc) * K_wrf;
       if (tsoil < K_frozThr) removable *= K_frozEff;
       if (removable < potTrans) {
@@ -330,7 +341,7 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
 
     // calcPrecip(), sipnet.c:848-882 (uniform branch on the site's air temperature)
     const bool tairPos = (bits & FAST_TAIR_POS) != 0;
-    const R rate = (R)rd[8];
+    const R rate = (R)rd_rainRate;
     const R rain = tairPos ? rate : R(0), snowFall = tairPos ? R(0) : rate;
     const R immedEvap = rain * K_immed;
     const R netRain = rain - immedEvap;
@@ -338,7 +349,7 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
     // snowPack(), sipnet.c:888-946
     R snowMelt = 0, sublimation = 0;
     if (eSnow > R(0)) {
-      sublimation = rmax0((R)rd[9] * K_invRd);
+      sublimation = rmax0((R)rd_sublW * K_invRd);
       R remaining = eSnow + snowFall * len;
       if (remaining - sublimation * len < R(0)) {
         sublimation = remaining * invLen;
@@ -362,7 +373,7 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
       if (!(eSnow > R(0))) {
         const R wf = clip01(eWater * K_invWhc);
         const R rsoil = fexp2(K_c1l - K_c2l * wf);
-        evaporation = rmax0(fdiv((R)rd[10], K_rd * (R)rd[11] + rsoil));
+        evaporation = rmax0(fdiv((R)rd_evapNum, K_rd * (R)rd_invWspd + rsoil));
         if (remaining - evaporation * len < R(kTiny)) {
           evaporation = (remaining - R(kTiny)) * invLen;
           remaining = 0;
@@ -376,7 +387,7 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
     const R meanNpp = (R)(ringSum * 0.2);  // runmean.c:119-121 (sum / 5)
 
     // vegResp(), sipnet.c:1051-1068
-    const R vegQ = fexp2((R)rd[12] * K_lgVeg);
+    const R vegQ = fexp2((R)rd_tair10 * K_lgVeg);
     R folResp = baseFolResp * (vegQ * K_folShift);
     if (tsoil < K_frozThr) folResp *= K_frozFolEff;
     const R rVeg = folResp + K_bvr * totalWoodC * vegQ;
@@ -389,14 +400,14 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
     // calcLeafOnOffFluxes(), sipnet.c:800-842 (GDD phenology, sipnet.c:705-716)
     R leafOnCreation = 0, leafOnFromWood = 0;
     if (bits & FAST_PHEN_NEW_YEAR) phenBits = 0;
-    if (!(phenBits & 1) && rd[14] >= gddLeafOn) {
+    if (!(phenBits & 1) && rd_cumGdd >= gddLeafOn) {
       const R leafOn = leafOnLimit(K_leafGrowth * invLen);
       leafOnCreation = leafOn;
       const R src = eWood + eCoarse;
       if (src > R(kTiny)) leafOnFromWood = fdiv(leafOn * eWood, src);
       phenBits |= 1;
     }
-    if (!(phenBits & 2) && leafOffDay > 0 && rd[15] >= leafOffDay) {
+    if (!(phenBits & 2) && leafOffDay > 0 && rd_dayTime >= leafOffDay) {
       leafLitter += (eLeaf * K_fracLeafFall) * invLen;
       phenBits |= 2;
     }
@@ -404,7 +415,7 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
     // roots, sipnet.c:1176-1196
     const R coarseRootLoss = K_crt * eCoarse, fineRootLoss = K_frt * eFine;
     R coarseRootCreation = K_ca * meanNpp, fineRootCreation = K_fa * meanNpp;
-    const R tsoil10 = (R)rd[13];
+    const R tsoil10 = (R)rd_tsoil10;
     const R rCoarseRoot = K_bcr * eCoarse * fexp2(tsoil10 * K_lgCoarse);
     const R rFineRoot = K_bfr * eFine * fexp2(tsoil10 * K_lgFine);
 
@@ -414,7 +425,7 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
       const R f_whc = clip01(eWater * K_invWhc);
       moistEff = (K_moistExp == R(1)) ? f_whc : fpow(f_whc, K_moistExp);
     }
-    const R rSoil = eSoilC * K_bsr * moistEff * fexp2(tsoil10 * K_lgSoil) * (R)rd[16];
+    const R rSoil = eSoilC * K_bsr * moistEff * fexp2(tsoil10 * K_lgSoil) * (R)rd_tillP1;
 
     // checkNegativeCreation(), limitations.c:146-182
     {
@@ -522,29 +533,30 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
         if (act) ringp[0] = npp;
         ringSum = npp * 5.0;
       } else {
-        const double w0 = rd[17], w1 = rd[18];
+        const double w0 = rd_w0, w1 = rd_w1;
         if (ringValidFrom > 0) {  // a member that died earlier: older slots count as zero
-          if (uni(ri[5]) < ringValidFrom) rv0 = 0.0;
-          if (uni(ri[6]) < ringValidFrom) rv1 = 0.0;
+          if (uni(j1.y) < ringValidFrom) rv0 = 0.0;
+          if (uni(j1.z) < ringValidFrom) rv1 = 0.0;
         }
         ringSum = ffma(-w0, rv0, ringSum);
         ringSum = ffma(-w1, rv1, ringSum);
         if (nOps > 2) {
-          const int opFirst = uni(ri[7]);
+          const int opFirst = uni(j1.w);
           for (int k = 2; k < nOps; k++) {
             const RingOp& op = a.ringOps[opFirst + k];
             const double v = (uni(op.insStep) >= ringValidFrom)
-                                 ? ringp[(int64_t)uni(op.slot) * nc] : 0.0;
+                                 ? ringp[(uint32_t)uni(op.slot) * ncu] : 0.0;
             ringSum = ffma(-op.w, v, ringSum);
           }
         }
-        if (act) ringp[(int64_t)insSlot * nc] = npp;
+        if (act) ringp[(uint32_t)insSlot * ncu] = npp;
         ringSum = ffma(npp, (double)len, ringSum);
       }
     } else {
       ringValidFrom = t + 1;
     }
-  }
+  }  // steps of this tile
+  }  // tiles
 
   // ---- state back to HBM ----------------------------------------------------------
   if (act) {
