@@ -378,6 +378,7 @@ int sipnet_batch_run(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_ne
     f.n_steps_total = b->n_steps;
     f.step0 = step0;
     f.n_steps = n_steps;
+    f.dbg = getenv("SIPNET_DBG") ? atoi(getenv("SIPNET_DBG")) : 0;
     launchStepFast(f, b->precision, stream);
   } else {
     launchStep(a, b->precision, b->fastMath, stream);

@@ -75,11 +75,22 @@ template <class R> __device__ __forceinline__ R clip01(R x) {
 
 __device__ __forceinline__ int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
-// site record as it sits in LDS
-struct alignas(16) RecView {
-  const double* d;
-  const int32_t* i;
-};
+// Diagnostic build only (-DSIPNET_STAMPS): s_memtime stamps around the segments of a step,
+// summed per workgroup 0 into g_stamps.  Never compiled into the shipped library.
+#ifdef SIPNET_STAMPS
+__device__ unsigned long long g_stamps[16];
+#define STAMP(k)                                                                     \
+  {                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                               \
+    unsigned long long now_;                                                         \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");     \
+    __builtin_amdgcn_sched_barrier(0);                                               \
+    stampAcc##k += now_ - lastStamp;                                                 \
+    lastStamp = now_;                                                                \
+  }
+#else
+#define STAMP(k)
+#endif
 
 }  // namespace
 
@@ -162,6 +173,11 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
   int phenBits = (int)ST(phenBits);
   int ringValidFrom = (int)ST(ringValidFrom);
   int diedAt = (int)ST(diedAt);
+#ifdef SIPNET_STAMPS
+  unsigned long long stampAcc0 = 0, stampAcc1 = 0, stampAcc2 = 0, stampAcc3 = 0, stampAcc4 = 0,
+                     stampAcc5 = 0, stampAcc6 = 0, stampAcc7 = 0, stampAcc8 = 0, stampAcc9 = 0, stampAcc10 = 0, stampAcc11 = 0, lastStamp;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(lastStamp)::"memory");
+#endif
   int clampCount = (int)ST(clampCount);
 
   const unsigned char* __restrict__ planBytes =
@@ -201,8 +217,15 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
   int curTile = tBegin / kFastTile;
   stageTile(curTile, curTile & 1);
 
-  double pfv0 = 0.0, pfv1 = 0.0;  // ring values requested one step ahead
-  bool havePf = false;
+  // ring values this step will evict; requested at the END of the previous step (before
+  // that step's stores, so that nothing at the top of a step waits on the store queue)
+  double rv0 = 0.0, rv1 = 0.0;
+  bool haveRv = false;
+  // when the slot a step evicts is the very slot the previous step wrote, the value is taken
+  // from that step's NPP register instead of memory (wave-uniform flags)
+  double lastNpp = 0.0;
+  bool useLast0 = false, useLast1 = false;
+  int64_t outOff = 0;  // element offset of this step's row in the output planes
 
   for (int tileStart = curTile * kFastTile; tileStart < tEnd; tileStart += kFastTile, curTile++) {
     // the tile staged one tile-time ago has long landed; drain, then stage the next one into
@@ -237,20 +260,13 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
     const int slot0 = uni(j0.w), slot1 = uni(j1.x);
     const int pfSlot0 = uni(j2.z), pfSlot1 = uni(j2.w);
 
-    // ring values of THIS step (prefetched during the previous step unless stale/first)
-    double rv0, rv1;
-    if (havePf && !(bits & FAST_PF_STALE)) {
-      rv0 = pfv0;
-      rv1 = pfv1;
-    } else {
+    if (!haveRv) {  // first step of a launch only
       rv0 = ringp[(uint32_t)slot0 * ncu];
       rv1 = ringp[(uint32_t)slot1 * ncu];
+      haveRv = true;
     }
-    // request next step's values now
-    pfv0 = ringp[(uint32_t)pfSlot0 * ncu];
-    pfv1 = ringp[(uint32_t)pfSlot1 * ncu];
-    havePf = true;
 
+    STAMP(0)  // record fetch
     // ---- 0. start of step (sipnet.c:1821-1828) -------------------------------------
     bool alive = (plantWoodC > kTiny) && (plantWoodC + delta > kTiny) &&
                  (fineRootC + coarseRootC > kTiny);
@@ -304,6 +320,7 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
       }
     }
 
+    STAMP(1)  // start + events
     // ---- 2. fluxes (sipnet.c:1256-1336) ---------------------------------------------
     const R lai = eLeaf * K_invLcsw;
     // potPsn(), sipnet.c:590-641
@@ -325,6 +342,7 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
     const R potGrossPsn = K_g * lai * dTemp * dVpd * dLight;
     const R baseFolResp = K_rpg * lai;
 
+    STAMP(2)  // potPsn + light
     // moisture(), sipnet.c:656-699
     R transpiration = 0, photosynthesis = potGrossPsn;
     if (potGrossPsn >= R(kTiny)) {
@@ -386,6 +404,7 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
 
     const R meanNpp = (R)(ringSum * 0.2);  // runmean.c:119-121 (sum / 5)
 
+    STAMP(3)  // water
     // vegResp(), sipnet.c:1051-1068
     const R vegQ = fexp2((R)rd_tair10 * K_lgVeg);
     R folResp = baseFolResp * (vegQ * K_folShift);
@@ -448,6 +467,7 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
       }
     }
 
+    STAMP(4)  // respiration + allocation
     // ---- 3. pools (sipnet.c:1769-1806) ------------------------------------------------
     const double oldDelta = delta;
     (void)oldDelta;
@@ -478,6 +498,7 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
       fineRootC += (double)((fineRootCreation - fineRootLoss) * len);
     }
 
+    STAMP(8)  // pool updates
     // checkForMortality(), sipnet.c:1688-1767
     {
       const bool sufficient = (plantWoodC > kTiny) && (plantWoodC + delta > kTiny) &&
@@ -497,6 +518,7 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
         ringSum = 0.0;
       }
     }
+    STAMP(9)  // mortality
     // ensureNonNegativeStocks(), sipnet.c:1368-1397
 #define CLAMP(v, minVal)                           \
   if (v < (minVal)) {                              \
@@ -512,6 +534,7 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
     CLAMP(snow, kTiny)
 #undef CLAMP
 
+    STAMP(5)  // pools, mortality, clamps
     // ---- 4. outputs: updateTrackers(), sipnet.c:1420-1496 ---------------------------
     const R tGpp = photosynthesis * len;
     const R tRh = rSoil * len;
@@ -520,26 +543,20 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
     const R tEt = (transpiration + immedEvap + evaporation + sublimation + evEvap) * len;
     totGpp += (double)tGpp;
     totNee += (double)tNee;
-    if (act) {
-      if (oNee) oNee[(int64_t)(t - tBegin) * a.ld] = tNee;
-      if (oGpp) oGpp[(int64_t)(t - tBegin) * a.ld] = tGpp;
-      if (oEt) oEt[(int64_t)(t - tBegin) * a.ld] = tEt;
-    }
 
     // ---- 5. running mean of NPP (sipnet.c:1546-1570, runmean.c:61-116 via the plan) ----
+    const double npp = (double)(photosynthesis - rVeg - rCoarseRoot - rFineRoot);
     if (alive) {
-      const double npp = (double)(photosynthesis - rVeg - rCoarseRoot - rFineRoot);
       if (insSlot < 0) {
-        if (act) ringp[0] = npp;
         ringSum = npp * 5.0;
       } else {
         const double w0 = rd_w0, w1 = rd_w1;
         if (ringValidFrom > 0) {  // a member that died earlier: older slots count as zero
-          if (uni(j1.y) < ringValidFrom) rv0 = 0.0;
-          if (uni(j1.z) < ringValidFrom) rv1 = 0.0;
+          if (uni(j1.y) < ringValidFrom) { rv0 = 0.0; if (useLast0) lastNpp = 0.0; }
+          if (uni(j1.z) < ringValidFrom) { rv1 = 0.0; if (useLast1) lastNpp = 0.0; }
         }
-        ringSum = ffma(-w0, rv0, ringSum);
-        ringSum = ffma(-w1, rv1, ringSum);
+        ringSum = ffma(-w0, useLast0 ? lastNpp : rv0, ringSum);
+        ringSum = ffma(-w1, useLast1 ? lastNpp : rv1, ringSum);
         if (nOps > 2) {
           const int opFirst = uni(j1.w);
           for (int k = 2; k < nOps; k++) {
@@ -549,15 +566,44 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
             ringSum = ffma(-op.w, v, ringSum);
           }
         }
-        if (act) ringp[(uint32_t)insSlot * ncu] = npp;
         ringSum = ffma(npp, (double)len, ringSum);
       }
     } else {
       ringValidFrom = t + 1;
     }
+    STAMP(10)  // trackers + ring update
+    // request the values the NEXT step evicts, then store: loads ahead of stores in the queue
+    const int insEff = insSlot < 0 ? 0 : insSlot;
+    if (!(a.dbg & 4)) {
+    rv0 = ringp[(uint32_t)pfSlot0 * ncu];
+    rv1 = ringp[(uint32_t)pfSlot1 * ncu];
+    }
+    useLast0 = (pfSlot0 == insEff);  // the slot being written right now (uniform test);
+    useLast1 = (pfSlot1 == insEff);  // consumed a whole step later, no wait here
+    lastNpp = npp;
+    STAMP(11)  // next-step ring loads
+    if (act) {
+      const int64_t o = outOff;
+      if (!(a.dbg & 1)) {
+      if (oNee) oNee[o] = tNee;
+      if (oGpp) oGpp[o] = tGpp;
+      if (oEt) oEt[o] = tEt;
+      }
+      if (alive && !(a.dbg & 2)) ringp[(uint32_t)insEff * ncu] = npp;
+    }
+    outOff += a.ld;
+    STAMP(6)  // trackers, ring, stores
   }  // steps of this tile
+    STAMP(7)  // tile turnover
   }  // tiles
 
+#ifdef SIPNET_STAMPS
+  if (blockIdx.x == 0 && lane == 0) {
+    g_stamps[0] = stampAcc0; g_stamps[1] = stampAcc1; g_stamps[2] = stampAcc2; g_stamps[3] = stampAcc3;
+    g_stamps[4] = stampAcc4; g_stamps[5] = stampAcc5; g_stamps[6] = stampAcc6; g_stamps[7] = stampAcc7;
+    g_stamps[8] = stampAcc8; g_stamps[9] = stampAcc9; g_stamps[10] = stampAcc10; g_stamps[11] = stampAcc11;
+  }
+#endif
   // ---- state back to HBM ----------------------------------------------------------
   if (act) {
     ST(plantWoodC) = plantWoodC;
@@ -578,6 +624,12 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
   }
 #undef ST
 }
+
+#ifdef SIPNET_STAMPS
+extern "C" int sipnet_debug_read_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), 12 * sizeof(unsigned long long));
+}
+#endif
 
 void launchStepFast(const FastArgs& a, int precision, hipStream_t stream) {
   const int chunksPerSite = (a.n_members + 63) / 64;
