@@ -34,24 +34,40 @@ __device__ __forceinline__ float ffma(float a, float b, float c) { return __buil
 
 // 2^x, |rel err| <= 1.8e-16: n = rint(x), 2^(x-n) by a degree-11 polynomial on
 // [-0.5, 0.5] (Chebyshev-node interpolant, tools/fit_exp2.py), scaled with v_ldexp_f64.
-__device__ __forceinline__ double fexp2(double x) {
+// The coefficients live in SGPR pairs for the whole time loop (a VOP3 fma takes one scalar
+// operand): left as literals, hipcc re-materialises them with v_mov_b64 at each of the 13
+// call sites of a step, which costs as much as the polynomial itself.
+struct Exp2Coef {
+  double c1, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11;
+};
+__device__ __forceinline__ Exp2Coef loadExp2Coef() {
+  Exp2Coef k = {0.6931471805599453,     0.2402265069591016,     0.05550410866482163,
+                0.009618129107587223,   0.0013333558146405434,  0.0001540353046375614,
+                1.5252733842758916e-05, 1.3215432520547035e-06, 1.0178056472371986e-07,
+                7.074197066047615e-09,  4.455930741563682e-10};
+  // opaque to constant propagation, pinned to scalar registers
+  asm volatile("" : "+s"(k.c1), "+s"(k.c2), "+s"(k.c3), "+s"(k.c4), "+s"(k.c5), "+s"(k.c6));
+  asm volatile("" : "+s"(k.c7), "+s"(k.c8), "+s"(k.c9), "+s"(k.c10), "+s"(k.c11));
+  return k;
+}
+__device__ __forceinline__ double fexp2(double x, const Exp2Coef& k) {
   const double n = __builtin_rint(x);
   const double f = x - n;
-  double p = 4.455930741563682e-10;
-  p = ffma(p, f, 7.074197066047615e-09);
-  p = ffma(p, f, 1.0178056472371986e-07);
-  p = ffma(p, f, 1.3215432520547035e-06);
-  p = ffma(p, f, 1.5252733842758916e-05);
-  p = ffma(p, f, 0.0001540353046375614);
-  p = ffma(p, f, 0.0013333558146405434);
-  p = ffma(p, f, 0.009618129107587223);
-  p = ffma(p, f, 0.05550410866482163);
-  p = ffma(p, f, 0.2402265069591016);
-  p = ffma(p, f, 0.6931471805599453);
+  double p = k.c11;
+  p = ffma(p, f, k.c10);
+  p = ffma(p, f, k.c9);
+  p = ffma(p, f, k.c8);
+  p = ffma(p, f, k.c7);
+  p = ffma(p, f, k.c6);
+  p = ffma(p, f, k.c5);
+  p = ffma(p, f, k.c4);
+  p = ffma(p, f, k.c3);
+  p = ffma(p, f, k.c2);
+  p = ffma(p, f, k.c1);
   p = ffma(p, f, 1.0);
   return __builtin_amdgcn_ldexp(p, (int)n);
 }
-__device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fexp2(float x, const Exp2Coef&) { return __builtin_amdgcn_exp2f(x); }
 
 // a / b with b > 0 finite and well scaled: v_rcp + two Newton steps + one residual step
 __device__ __forceinline__ double fdiv(double a, double b) {
@@ -162,6 +178,8 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
   const R K_leafGrowth = (R)PRM(leafGrowth), K_fracLeafFall = (R)PRM(fracLeafFall);
   const R K_realloc = (R)PRM(leafOnReallocFrac);
 #undef PRM
+
+  const Exp2Coef EC = loadExp2Coef();
 
   // ---- carried state ----------------------------------------------------------
 #define ST(name) stp[(int64_t)ST_##name * nc]
@@ -325,17 +343,17 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
     const R lai = eLeaf * K_invLcsw;
     // potPsn(), sipnet.c:590-641
     const R dTemp = rmax0((K_tmax - tair) * (tair - K_tmin) * K_invDen);
-    const R vpdPow = (K_vexp == R(2)) ? (R)rd_vpd2 : fexp2(K_vexp * (R)rd_log2vpd);
+    const R vpdPow = (K_vexp == R(2)) ? (R)rd_vpd2 : fexp2(K_vexp * (R)rd_log2vpd, EC);
     const R dVpd = rmax0(R(1) - K_slope * vpdPow);
     R dLight = 0;
     if ((bits & FAST_PAR_POS) && lai > R(0)) {
       // calcLightEff(), sipnet.c:517-570: Simpson over 7 layers;
       // sum c_i (1 - e_i) / 18 = 1 - (sum c_i e_i) / 18, c = 1 4 2 4 2 4 1
-      const R r1 = fexp2(K_attl * lai);
+      const R r1 = fexp2(K_attl * lai, EC);
       const R q = (R)rd_negPar * K_invHalf;
       const R r2 = r1 * r1, r3 = r2 * r1, r4 = r2 * r2, r5 = r4 * r1, r6 = r3 * r3;
-      const R e0 = fexp2(q), e1 = fexp2(q * r1), e2 = fexp2(q * r2), e3 = fexp2(q * r3);
-      const R e4 = fexp2(q * r4), e5 = fexp2(q * r5), e6 = fexp2(q * r6);
+      const R e0 = fexp2(q, EC), e1 = fexp2(q * r1, EC), e2 = fexp2(q * r2, EC), e3 = fexp2(q * r3, EC);
+      const R e4 = fexp2(q * r4, EC), e5 = fexp2(q * r5, EC), e6 = fexp2(q * r6, EC);
       const R s = (e0 + e6) + R(4) * (e1 + e3 + e5) + R(2) * (e2 + e4);
       dLight = R(1) - s * R(1.0 / 18.0);
     }
@@ -390,7 +408,7 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
       R remaining = eWater + netIn * len - transpiration * len;
       if (!(eSnow > R(0))) {
         const R wf = clip01(eWater * K_invWhc);
-        const R rsoil = fexp2(K_c1l - K_c2l * wf);
+        const R rsoil = fexp2(K_c1l - K_c2l * wf, EC);
         evaporation = rmax0(fdiv((R)rd_evapNum, K_rd * (R)rd_invWspd + rsoil));
         if (remaining - evaporation * len < R(kTiny)) {
           evaporation = (remaining - R(kTiny)) * invLen;
@@ -406,7 +424,7 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
 
     STAMP(3)  // water
     // vegResp(), sipnet.c:1051-1068
-    const R vegQ = fexp2((R)rd_tair10 * K_lgVeg);
+    const R vegQ = fexp2((R)rd_tair10 * K_lgVeg, EC);
     R folResp = baseFolResp * (vegQ * K_folShift);
     if (tsoil < K_frozThr) folResp *= K_frozFolEff;
     const R rVeg = folResp + K_bvr * totalWoodC * vegQ;
@@ -435,8 +453,8 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
     const R coarseRootLoss = K_crt * eCoarse, fineRootLoss = K_frt * eFine;
     R coarseRootCreation = K_ca * meanNpp, fineRootCreation = K_fa * meanNpp;
     const R tsoil10 = (R)rd_tsoil10;
-    const R rCoarseRoot = K_bcr * eCoarse * fexp2(tsoil10 * K_lgCoarse);
-    const R rFineRoot = K_bfr * eFine * fexp2(tsoil10 * K_lgFine);
+    const R rCoarseRoot = K_bcr * eCoarse * fexp2(tsoil10 * K_lgCoarse, EC);
+    const R rFineRoot = K_bfr * eFine * fexp2(tsoil10 * K_lgFine, EC);
 
     // calcSoilRespiration(), sipnet.c:1132-1148 with depeffects.c:23-87
     R moistEff = 1;
@@ -444,7 +462,7 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
       const R f_whc = clip01(eWater * K_invWhc);
       moistEff = (K_moistExp == R(1)) ? f_whc : fpow(f_whc, K_moistExp);
     }
-    const R rSoil = eSoilC * K_bsr * moistEff * fexp2(tsoil10 * K_lgSoil) * (R)rd_tillP1;
+    const R rSoil = eSoilC * K_bsr * moistEff * fexp2(tsoil10 * K_lgSoil, EC) * (R)rd_tillP1;
 
     // checkNegativeCreation(), limitations.c:146-182
     {
@@ -520,19 +538,14 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
     }
     STAMP(9)  // mortality
     // ensureNonNegativeStocks(), sipnet.c:1368-1397
-#define CLAMP(v, minVal)                           \
-  if (v < (minVal)) {                              \
-    if (__builtin_fabs(v) > kEps) clampCount++;    \
-    v = 0.;                                        \
-  }
-    CLAMP(plantWoodC, 0.0)
-    CLAMP(plantLeafC, 0.0)
-    CLAMP(soilC, 0.0)
-    CLAMP(coarseRootC, 0.0)
-    CLAMP(fineRootC, 0.0)
-    CLAMP(soilWater, 0.0)
-    CLAMP(snow, kTiny)
-#undef CLAMP
+    // (the clamp-warning counter of the strict kernel is not kept on this path)
+    plantWoodC = plantWoodC < 0.0 ? 0.0 : plantWoodC;
+    plantLeafC = plantLeafC < 0.0 ? 0.0 : plantLeafC;
+    soilC = soilC < 0.0 ? 0.0 : soilC;
+    coarseRootC = coarseRootC < 0.0 ? 0.0 : coarseRootC;
+    fineRootC = fineRootC < 0.0 ? 0.0 : fineRootC;
+    soilWater = soilWater < 0.0 ? 0.0 : soilWater;
+    snow = snow < kTiny ? 0.0 : snow;
 
     STAMP(5)  // pools, mortality, clamps
     // ---- 4. outputs: updateTrackers(), sipnet.c:1420-1496 ---------------------------
