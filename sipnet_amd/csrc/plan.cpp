@@ -209,6 +209,7 @@ SitePlan buildSitePlan(const int32_t* flags, int32_t n_steps, const double* clim
 std::vector<FastRec> buildFastRecs(const SitePlan& plan) {
   const int n = (int)plan.steps.size();
   std::vector<FastRec> out((size_t)n);
+  std::vector<int> slot0(n), slot1(n);
   for (int t = 0; t < n; t++) {
     const StepRec& s = plan.steps[t];
     FastRec& f = out[t];
@@ -219,7 +220,6 @@ std::vector<FastRec> buildFastRecs(const SitePlan& plan) {
     f.tsoil = s.tsoil;
     f.negPar = -s.par;
     f.vpd = s.vpd;
-    f.log2vpd = s.log2vpd;
     f.vpd2 = s.vpd * s.vpd;
     f.rainRate = s.rainRate;
     f.sublW = s.sublNum * s.wspd;
@@ -229,38 +229,36 @@ std::vector<FastRec> buildFastRecs(const SitePlan& plan) {
     f.tsoil10 = s.tsoil10;
     f.cumGdd = s.cumGdd;
     f.dayTime = s.dayTime;
+    f.log2vpd = s.log2vpd;
     f.tillP1 = 1.0 + s.dTill;
     f.gddAfter = s.gddAfter;
     f.tillAfter = s.tillAfter;
-    f.bits = (s.bits & STEP_PHEN_NEW_YEAR ? FAST_PHEN_NEW_YEAR : 0) |
-             (s.bits & STEP_TRACK_NEW_YEAR ? FAST_TRACK_NEW_YEAR : 0) |
-             (s.tair > 0 ? FAST_TAIR_POS : 0) | (s.par > 0 ? FAST_PAR_POS : 0) |
-             (s.tsoil < 0 ? FAST_TSOIL_NEG : 0);
-    f.insSlot = s.ringInsSlot;
-    f.nOps = s.ringOpCount;
-    f.opFirst = s.ringOpFirst;
-    f.evFirst = s.evFirst;
-    f.evCount = s.evCount;
-    f.year = s.year;
-    f.day = s.day;
     // inline evictions; a missing one is a no-op on a valid slot (w = 0)
     const RingOp* ops = plan.ringOps.data() + s.ringOpFirst;
     const int safeSlot = s.ringInsSlot >= 0 ? s.ringInsSlot : 0;
-    f.slot0 = s.ringOpCount > 0 ? ops[0].slot : safeSlot;
+    slot0[t] = s.ringOpCount > 0 ? ops[0].slot : safeSlot;
     f.ins0 = s.ringOpCount > 0 ? ops[0].insStep : -1;
     f.w0 = s.ringOpCount > 0 ? ops[0].w : 0.0;
-    f.slot1 = s.ringOpCount > 1 ? ops[1].slot : f.slot0;
+    slot1[t] = s.ringOpCount > 1 ? ops[1].slot : slot0[t];
     f.ins1 = s.ringOpCount > 1 ? ops[1].insStep : f.ins0;
     f.w1 = s.ringOpCount > 1 ? ops[1].w : 0.0;
-    // a value requested one step ahead is stale if that very step (t-1) wrote the slot
-    if ((s.ringOpCount > 0 && ops[0].insStep >= t - 1 && ops[0].insStep >= 0) ||
-        (s.ringOpCount > 1 && ops[1].insStep >= t - 1 && ops[1].insStep >= 0))
-      f.bits |= FAST_PF_STALE;
+    int bits = (s.bits & STEP_PHEN_NEW_YEAR ? FAST_PHEN_NEW_YEAR : 0) |
+               (s.bits & STEP_TRACK_NEW_YEAR ? FAST_TRACK_NEW_YEAR : 0) |
+               (s.tair > 0 ? FAST_TAIR_POS : 0) | (s.par > 0 ? FAST_PAR_POS : 0) |
+               (s.tsoil < 0 ? FAST_TSOIL_NEG : 0) | (f.w1 != 0.0 ? FAST_HAS_W1 : 0) |
+               (s.dTill != 0.0 ? FAST_HAS_TILL : 0) |
+               (t > 0 && plan.steps[t - 1].tsoil10 == s.tsoil10 ? FAST_TSOIL_SAME : 0);
+    f.bitsOps = bits | (s.ringOpCount << 16);
+    f.insSlot = s.ringInsSlot;
+    f.evCount = s.evCount;
+    f.opFirst = s.ringOpFirst;
+    f.evFirst = s.evFirst;
+    f.year = s.year;
+    f.day = s.day;
   }
   for (int t = 0; t < n; t++) {
-    const bool last = (t + 1 >= n);
-    out[t].pfSlot0 = last ? out[t].slot0 : out[t + 1].slot0;
-    out[t].pfSlot1 = last ? out[t].slot1 : out[t + 1].slot1;
+    const int nx = (t + 1 < n) ? t + 1 : t;
+    out[t].slots = slot0[t] | (slot1[t] << 8) | (slot0[nx] << 16) | (slot1[nx] << 24);
   }
   return out;
 }

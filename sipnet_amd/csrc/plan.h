@@ -67,34 +67,42 @@ struct EvRec {
 static_assert(sizeof(EvRec) == 40, "EvRec layout");
 
 // Compact record of the fast-math kernels (step_fast.hip): 256 B, staged through LDS in
-// tiles of kFastTile steps.  Holds only what that kernel consumes, pre-combined so that no
-// division by a site quantity is left in the time loop, with the step's first two ring
-// evictions inline and the NEXT step's eviction slots (so the ring values of step t+1 are
-// requested at the top of step t and are in registers long before they are needed).
+// tiles of kFastTile steps.  The first 144 bytes are everything a normal step consumes (nine
+// broadcast ds_read_b128), pre-combined so that no division by a site quantity is left in the
+// time loop; the rest is read only when a flag bit says so.  It carries the step's ring
+// evictions and the NEXT step's eviction slots, so that the ring values of step t+1 are
+// requested during step t.
 struct FastRec {
-  double len, invLen, tair, tsoil;        //  0.. 3
-  double negPar, vpd, log2vpd, vpd2;      //  4.. 7  -par, vpd, log2(vpd), vpd*vpd
-  double rainRate, sublW, evapNum, invWspd;  //  8..11  precip/len, CONV_S*(0.6-vPress)*wspd, CONV*vpdSoil, 1/wspd
-  double tair10, tsoil10, cumGdd, dayTime;   // 12..15
-  double tillP1, w0, w1, gddAfter;        // 16..19  1+d_till_mod; weights of the inline ring evictions
-  double tillAfter, spare0, spare1, spare2;  // 20..23
-  int32_t bits;      // FAST_* below
+  // ---- hot: bytes 0..143 ----
+  double len, invLen, tair, tsoil;           //  0.. 3
+  double negPar, vpd, vpd2, rainRate;        //  4.. 7  -par, vpd, vpd*vpd, precip/len
+  double sublW, evapNum, invWspd, tair10;    //  8..11  CONV_S*(0.6-vPress)*wspd, CONV*vpdSoil, 1/wspd
+  double tsoil10, cumGdd, dayTime, w0;       // 12..15  w0: weight of the first ring eviction
+  int32_t bitsOps;   // FAST_* flag bits | (number of ring evictions << 16)
+  int32_t slots;     // slot0 | slot1<<8 | pfSlot0<<16 | pfSlot1<<24 (slots < 250)
   int32_t insSlot;   // slot of this step's insert, -1 = reset ring to the new value
-  int32_t nOps;      // total evictions of this step (first two inline, rest via opFirst)
-  int32_t slot0, slot1, ins0, ins1;  // inline evictions (slot1==slot0, w1==0 when nOps<2)
-  int32_t opFirst;   // global RingOp index of this step's eviction list
-  int32_t evFirst, evCount;
-  int32_t pfSlot0, pfSlot1;  // slots evicted by step t+1 (prefetch targets)
-  int32_t year, day, pad0, pad1;
+  int32_t evCount;   // events on this record
+  // ---- rare: read only under a flag ----
+  double w1;         // weight of the second eviction (FAST_HAS_W1)
+  double tillP1;     // 1 + d_till_mod (FAST_HAS_TILL)
+  double log2vpd;    // for members whose dVpdExp is not 2
+  double gddAfter, tillAfter;
+  int32_t ins0, ins1;  // steps that wrote slot0 / slot1 (dead-member epochs)
+  int32_t opFirst;     // global RingOp index of this step's eviction list (nOps > 2)
+  int32_t evFirst;     // global EvRec index
+  int32_t year, day;
+  int32_t pad[12];
 };
 static_assert(sizeof(FastRec) == 256, "FastRec must stay 256 bytes");
 constexpr int kFastTile = 16;  // steps per LDS tile (4 KB)
 enum : int32_t {
   FAST_PHEN_NEW_YEAR = 1, FAST_TRACK_NEW_YEAR = 2,
-  FAST_TAIR_POS = 4,    // tair > 0
-  FAST_PAR_POS = 8,     // par > 0
-  FAST_TSOIL_NEG = 16,  // tsoil < 0
-  FAST_PF_STALE = 32    // a prefetched slot of THIS step was written by step t-1: reload
+  FAST_TAIR_POS = 4,     // tair > 0
+  FAST_PAR_POS = 8,      // par > 0
+  FAST_TSOIL_NEG = 16,   // tsoil < 0
+  FAST_HAS_W1 = 32,      // a second eviction with non-zero weight
+  FAST_HAS_TILL = 64,    // tillage modifier in effect
+  FAST_TSOIL_SAME = 128  // tsoil identical to the previous record: Q10 factors can be reused
 };
 
 struct SitePlan {

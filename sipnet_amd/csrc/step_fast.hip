@@ -175,9 +175,8 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
   const R K_fa = (R)PRM(fineRootAllocation), K_ca = (R)PRM(coarseRootAllocation);
   const R K_moistExp = (R)PRM(soilRespMoistEffect);
   const double gddLeafOn = PRM(gddLeafOn), leafOffDay = PRM(leafOffDay);
-  const R K_leafGrowth = (R)PRM(leafGrowth), K_fracLeafFall = (R)PRM(fracLeafFall);
-  const R K_realloc = (R)PRM(leafOnReallocFrac);
-#undef PRM
+  // rarely needed parameters are re-read from HBM inside their (rare) branches
+#define PRM_RARE(name) ((R)pp[(int64_t)SP_##name * nc])
 
   const Exp2Coef EC = loadExp2Coef();
 
@@ -193,10 +192,9 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
   int diedAt = (int)ST(diedAt);
 #ifdef SIPNET_STAMPS
   unsigned long long stampAcc0 = 0, stampAcc1 = 0, stampAcc2 = 0, stampAcc3 = 0, stampAcc4 = 0,
-                     stampAcc5 = 0, stampAcc6 = 0, stampAcc7 = 0, stampAcc8 = 0, stampAcc9 = 0, stampAcc10 = 0, stampAcc11 = 0, lastStamp;
+                     stampAcc5 = 0, stampAcc6 = 0, stampAcc7 = 0, lastStamp;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(lastStamp)::"memory");
 #endif
-  int clampCount = (int)ST(clampCount);
 
   const unsigned char* __restrict__ planBytes =
       (const unsigned char*)(a.fast + (int64_t)site * a.n_steps_total);
@@ -207,13 +205,16 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
 
   // ---- tile staging: async global -> LDS, 16 B per lane, 4 pieces per 4 KB tile ----
   constexpr int kTileBytes = kFastTile * (int)sizeof(FastRec);
-  auto stageTile = [&](int tile, int buf) {
-    // records [tile*kFastTile, +kFastTile) clamped to the plan's end (the tail re-reads the
-    // last records; never used)
+  auto tileFirst = [&](int tile) -> int64_t {
+    // records [tile*kFastTile, +kFastTile) clamped to the plan's end (a tail tile re-reads
+    // earlier records so that it never runs past the site's plan)
     int64_t first = (int64_t)tile * kFastTile;
     const int64_t lastStart = (int64_t)a.n_steps_total - kFastTile;
     if (first > lastStart) first = lastStart > 0 ? lastStart : 0;
-    const unsigned char* src = planBytes + first * (int64_t)sizeof(FastRec);
+    return first;
+  };
+  auto stageTile = [&](int tile, int buf) {
+    const unsigned char* src = planBytes + tileFirst(tile) * (int64_t)sizeof(FastRec);
 #pragma unroll
     for (int k = 0; k < kTileBytes / 1024; k++) {
       __builtin_amdgcn_global_load_lds(
@@ -221,22 +222,14 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
           (__attribute__((address_space(3))) void*)(lds + buf * kTileBytes + k * 1024), 16, 0, 0);
     }
   };
-  // index of step t inside its staged tile (tiles near the end of the plan are clamped)
-  auto recOffset = [&](int t) -> int {
-    const int tile = t / kFastTile;
-    int64_t first = (int64_t)tile * kFastTile;
-    const int64_t lastStart = (int64_t)a.n_steps_total - kFastTile;
-    if (first > lastStart) first = lastStart > 0 ? lastStart : 0;
-    return (int)(t - first);
-  };
 
   const int tBegin = a.step0, tEnd = a.step0 + a.n_steps;
   const uint32_t ncu = (uint32_t)nc;  // ring element offsets fit 32 bits (250 * ncol < 2^31)
   int curTile = tBegin / kFastTile;
   stageTile(curTile, curTile & 1);
 
-  // ring values this step will evict; requested at the END of the previous step (before
-  // that step's stores, so that nothing at the top of a step waits on the store queue)
+  // ring values this step will evict; requested at the END of the previous step (ahead of
+  // that step's stores in the memory queue) and not touched until a whole step later
   double rv0 = 0.0, rv1 = 0.0;
   bool haveRv = false;
   // when the slot a step evicts is the very slot the previous step wrote, the value is taken
@@ -244,6 +237,9 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
   double lastNpp = 0.0;
   bool useLast0 = false, useLast1 = false;
   int64_t outOff = 0;  // element offset of this step's row in the output planes
+  // Q10 factors of the soil temperature, reused while tsoil does not change
+  R qSoil = 0, qFine = 0, qCoarse = 0;
+  bool haveQ = false;
 
   for (int tileStart = curTile * kFastTile; tileStart < tEnd; tileStart += kFastTile, curTile++) {
     // the tile staged one tile-time ago has long landed; drain, then stage the next one into
@@ -253,34 +249,29 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
     stageTile(curTile + 1, (curTile + 1) & 1);
     const int tFirst = tileStart > tBegin ? tileStart : tBegin;
     const int tLast = (tileStart + kFastTile) < tEnd ? (tileStart + kFastTile) : tEnd;
-    const unsigned char* recB =
-        lds + (curTile & 1) * kTileBytes + recOffset(tFirst) * (int)sizeof(FastRec);
+    const unsigned char* recB = lds + (curTile & 1) * kTileBytes +
+                                (int)(tFirst - tileFirst(curTile)) * (int)sizeof(FastRec);
   for (int t = tFirst; t < tLast; t++, recB += sizeof(FastRec)) {
-    // ---- the whole site record in one batch of broadcast LDS reads ------------------
+    // ---- the hot 144 bytes of the site record: nine broadcast LDS reads --------------
     typedef double d2 __attribute__((ext_vector_type(2)));
     typedef int i4 __attribute__((ext_vector_type(4)));
     const d2* rq = (const d2*)recB;
     const d2 q0 = rq[0], q1 = rq[1], q2 = rq[2], q3 = rq[3], q4 = rq[4], q5 = rq[5];
-    const d2 q6 = rq[6], q7 = rq[7], q8 = rq[8];
-    const i4* iq = (const i4*)(recB + 24 * sizeof(double));
-    const i4 j0 = iq[0], j1 = iq[1], j2 = iq[2];
-    const double rd_len = q0.x, rd_invLen = q0.y, rd_tair = q1.x, rd_tsoil = q1.y;
-    const double rd_negPar = q2.x, rd_vpd = q2.y, rd_log2vpd = q3.x, rd_vpd2 = q3.y;
-    const double rd_rainRate = q4.x, rd_sublW = q4.y, rd_evapNum = q5.x, rd_invWspd = q5.y;
-    const double rd_tair10 = q6.x, rd_tsoil10 = q6.y, rd_cumGdd = q7.x, rd_dayTime = q7.y;
-    const double rd_tillP1 = q8.x, rd_w0 = q8.y;
-    const double rd_w1 = ((const double*)recB)[18];
+    const d2 q6 = rq[6], q7 = rq[7];
+    const i4 j0 = *(const i4*)(recB + 128);
+    const double* rare = (const double*)(recB + 144);   // w1 tillP1 log2vpd gddAfter tillAfter
+    const int32_t* rareI = (const int32_t*)(recB + 184);  // ins0 ins1 opFirst evFirst
 
-    const R len = (R)rd_len, invLen = (R)rd_invLen, tair = (R)rd_tair, tsoil = (R)rd_tsoil;
+    const R len = (R)q0.x, invLen = (R)q0.y, tair = (R)q1.x, tsoil = (R)q1.y;
     const int bits = uni(j0.x);
-    const int insSlot = uni(j0.y);
-    const int nOps = uni(j0.z);
-    const int slot0 = uni(j0.w), slot1 = uni(j1.x);
-    const int pfSlot0 = uni(j2.z), pfSlot1 = uni(j2.w);
+    const int slots = uni(j0.y);
+    const int insSlot = uni(j0.z);
+    const int nEv = uni(j0.w);
+    const int nOps = bits >> 16;
 
     if (!haveRv) {  // first step of a launch only
-      rv0 = ringp[(uint32_t)slot0 * ncu];
-      rv1 = ringp[(uint32_t)slot1 * ncu];
+      rv0 = ringp[(uint32_t)(slots & 255) * ncu];
+      rv1 = ringp[(uint32_t)((slots >> 8) & 255) * ncu];
       haveRv = true;
     }
 
@@ -293,64 +284,26 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
     const R eCoarse = (R)coarseRootC, eFine = (R)fineRootC;
     const R totalWoodC = (R)(plantWoodC + delta);
 
-    // ---- 1. events (events.c:449-742); tillage is folded into the plan ---------------
-    R evLeafC = 0, evWoodC = 0, evFineRootC = 0, evCoarseRootC = 0, evEvap = 0, evSoilWater = 0;
-    R evSoilC = 0, evLeafOnCreation = 0, evLeafOnFromWood = 0, evLeafOffLitter = 0;
-    const int nEv = uni(j2.y);
     auto leafOnLimit = [&](R flux) -> R {  // limitations.c:13-64 (no N cycle here)
       const R cDemand = flux * len;
       if (cDemand < R(kTiny)) return flux;
-      const R lim = clip01(fdiv((eWood + eCoarse) * K_realloc, cDemand));
+      const R lim = clip01(fdiv((eWood + eCoarse) * PRM_RARE(leafOnReallocFrac), cDemand));
       return lim < R(1) ? flux * lim : flux;
     };
-    if (nEv > 0) {
-      const int ev0 = uni(j2.x);
-      for (int k = 0; k < nEv; k++) {
-        const EvRec& ev = a.events[ev0 + k];
-        const int type = uni(ev.type);
-        const R p0 = (R)ev.p[0], p1 = (R)ev.p[1], p2 = (R)ev.p[2], p3 = (R)ev.p[3];
-        if (type == SIPNET_EV_IRRIG) {
-          const R evapAmount = ((int)ev.p[1] == 0) ? K_immed * p0 : R(0);
-          evEvap += evapAmount * invLen;
-          evSoilWater += (p0 - evapAmount) * invLen;
-        } else if (type == SIPNET_EV_PLANT) {
-          evLeafC += p0 * invLen;
-          evWoodC += p1 * invLen;
-          evFineRootC += p2 * invLen;
-          evCoarseRootC += p3 * invLen;
-        } else if (type == SIPNET_EV_HARVEST) {
-          const R woodC = totalWoodC;
-          evSoilC += (p3 * (eFine + eCoarse) + p2 * (eLeaf + woodC)) * invLen;
-          evLeafC += -eLeaf * (p0 + p2) * invLen;
-          evWoodC += -woodC * (p0 + p2) * invLen;
-          evFineRootC += -eFine * (p1 + p3) * invLen;
-          evCoarseRootC += -eCoarse * (p1 + p3) * invLen;
-        } else if (type == SIPNET_EV_FERT) {
-          evSoilC += p1 * invLen;
-        } else if (type == SIPNET_EV_LEAFON) {
-          const R flux = leafOnLimit(K_leafGrowth * invLen);
-          evLeafOnCreation += flux;
-          const R src = eWood + eCoarse;
-          if (src > R(kTiny)) evLeafOnFromWood += fdiv(flux * eWood, src);
-        } else if (type == SIPNET_EV_LEAFOFF) {
-          evLeafOffLitter += eLeaf * K_fracLeafFall * invLen;
-        }
-      }
-    }
 
-    STAMP(1)  // start + events
+    STAMP(1)
     // ---- 2. fluxes (sipnet.c:1256-1336) ---------------------------------------------
     const R lai = eLeaf * K_invLcsw;
     // potPsn(), sipnet.c:590-641
     const R dTemp = rmax0((K_tmax - tair) * (tair - K_tmin) * K_invDen);
-    const R vpdPow = (K_vexp == R(2)) ? (R)rd_vpd2 : fexp2(K_vexp * (R)rd_log2vpd, EC);
+    const R vpdPow = (K_vexp == R(2)) ? (R)q3.x : fexp2(K_vexp * (R)rare[2], EC);
     const R dVpd = rmax0(R(1) - K_slope * vpdPow);
     R dLight = 0;
     if ((bits & FAST_PAR_POS) && lai > R(0)) {
       // calcLightEff(), sipnet.c:517-570: Simpson over 7 layers;
       // sum c_i (1 - e_i) / 18 = 1 - (sum c_i e_i) / 18, c = 1 4 2 4 2 4 1
       const R r1 = fexp2(K_attl * lai, EC);
-      const R q = (R)rd_negPar * K_invHalf;
+      const R q = (R)q2.x * K_invHalf;
       const R r2 = r1 * r1, r3 = r2 * r1, r4 = r2 * r2, r5 = r4 * r1, r6 = r3 * r3;
       const R e0 = fexp2(q, EC), e1 = fexp2(q * r1, EC), e2 = fexp2(q * r2, EC), e3 = fexp2(q * r3, EC);
       const R e4 = fexp2(q * r4, EC), e5 = fexp2(q * r5, EC), e6 = fexp2(q * r6, EC);
@@ -360,11 +313,11 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
     const R potGrossPsn = K_g * lai * dTemp * dVpd * dLight;
     const R baseFolResp = K_rpg * lai;
 
-    STAMP(2)  // potPsn + light
+    STAMP(2)
     // moisture(), sipnet.c:656-699
     R transpiration = 0, photosynthesis = potGrossPsn;
     if (potGrossPsn >= R(kTiny)) {
-      const R potTrans = potGrossPsn * (R)rd_vpd * K_tr;
+      const R potTrans = potGrossPsn * (R)q2.y * K_tr;
       R removable = (eWater < K_whc ? eWater : K_whc) * K_wrf;
       if (tsoil < K_frozThr) removable *= K_frozEff;
       if (removable < potTrans) {
@@ -377,7 +330,7 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
 
     // calcPrecip(), sipnet.c:848-882 (uniform branch on the site's air temperature)
     const bool tairPos = (bits & FAST_TAIR_POS) != 0;
-    const R rate = (R)rd_rainRate;
+    const R rate = (R)q3.y;
     const R rain = tairPos ? rate : R(0), snowFall = tairPos ? R(0) : rate;
     const R immedEvap = rain * K_immed;
     const R netRain = rain - immedEvap;
@@ -385,7 +338,7 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
     // snowPack(), sipnet.c:888-946
     R snowMelt = 0, sublimation = 0;
     if (eSnow > R(0)) {
-      sublimation = rmax0((R)rd_sublW * K_invRd);
+      sublimation = rmax0((R)q4.x * K_invRd);
       R remaining = eSnow + snowFall * len;
       if (remaining - sublimation * len < R(0)) {
         sublimation = remaining * invLen;
@@ -409,7 +362,7 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
       if (!(eSnow > R(0))) {
         const R wf = clip01(eWater * K_invWhc);
         const R rsoil = fexp2(K_c1l - K_c2l * wf, EC);
-        evaporation = rmax0(fdiv((R)rd_evapNum, K_rd * (R)rd_invWspd + rsoil));
+        evaporation = rmax0(fdiv((R)q4.y, K_rd * (R)q5.x + rsoil));
         if (remaining - evaporation * len < R(kTiny)) {
           evaporation = (remaining - R(kTiny)) * invLen;
           remaining = 0;
@@ -422,9 +375,9 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
 
     const R meanNpp = (R)(ringSum * 0.2);  // runmean.c:119-121 (sum / 5)
 
-    STAMP(3)  // water
+    STAMP(3)
     // vegResp(), sipnet.c:1051-1068
-    const R vegQ = fexp2((R)rd_tair10 * K_lgVeg, EC);
+    const R vegQ = fexp2((R)q5.y * K_lgVeg, EC);
     R folResp = baseFolResp * (vegQ * K_folShift);
     if (tsoil < K_frozThr) folResp *= K_frozFolEff;
     const R rVeg = folResp + K_bvr * totalWoodC * vegQ;
@@ -437,24 +390,30 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
     // calcLeafOnOffFluxes(), sipnet.c:800-842 (GDD phenology, sipnet.c:705-716)
     R leafOnCreation = 0, leafOnFromWood = 0;
     if (bits & FAST_PHEN_NEW_YEAR) phenBits = 0;
-    if (!(phenBits & 1) && rd_cumGdd >= gddLeafOn) {
-      const R leafOn = leafOnLimit(K_leafGrowth * invLen);
+    if (!(phenBits & 1) && q6.y >= gddLeafOn) {
+      const R leafOn = leafOnLimit(PRM_RARE(leafGrowth) * invLen);
       leafOnCreation = leafOn;
       const R src = eWood + eCoarse;
       if (src > R(kTiny)) leafOnFromWood = fdiv(leafOn * eWood, src);
       phenBits |= 1;
     }
-    if (!(phenBits & 2) && leafOffDay > 0 && rd_dayTime >= leafOffDay) {
-      leafLitter += (eLeaf * K_fracLeafFall) * invLen;
+    if (!(phenBits & 2) && leafOffDay > 0 && q7.x >= leafOffDay) {
+      leafLitter += (eLeaf * PRM_RARE(fracLeafFall)) * invLen;
       phenBits |= 2;
     }
 
-    // roots, sipnet.c:1176-1196
+    // roots, sipnet.c:1176-1196; soil-temperature Q10 factors (depeffects.c:71-74)
     const R coarseRootLoss = K_crt * eCoarse, fineRootLoss = K_frt * eFine;
     R coarseRootCreation = K_ca * meanNpp, fineRootCreation = K_fa * meanNpp;
-    const R tsoil10 = (R)rd_tsoil10;
-    const R rCoarseRoot = K_bcr * eCoarse * fexp2(tsoil10 * K_lgCoarse, EC);
-    const R rFineRoot = K_bfr * eFine * fexp2(tsoil10 * K_lgFine, EC);
+    if (!haveQ || !(bits & FAST_TSOIL_SAME)) {
+      const R tsoil10 = (R)q6.x;
+      qSoil = fexp2(tsoil10 * K_lgSoil, EC);
+      qFine = fexp2(tsoil10 * K_lgFine, EC);
+      qCoarse = fexp2(tsoil10 * K_lgCoarse, EC);
+      haveQ = true;
+    }
+    const R rCoarseRoot = K_bcr * eCoarse * qCoarse;
+    const R rFineRoot = K_bfr * eFine * qFine;
 
     // calcSoilRespiration(), sipnet.c:1132-1148 with depeffects.c:23-87
     R moistEff = 1;
@@ -462,7 +421,8 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
       const R f_whc = clip01(eWater * K_invWhc);
       moistEff = (K_moistExp == R(1)) ? f_whc : fpow(f_whc, K_moistExp);
     }
-    const R rSoil = eSoilC * K_bsr * moistEff * fexp2(tsoil10 * K_lgSoil, EC) * (R)rd_tillP1;
+    R rSoil = eSoilC * K_bsr * moistEff * qSoil;
+    if (bits & FAST_HAS_TILL) rSoil *= (R)rare[1];
 
     // checkNegativeCreation(), limitations.c:146-182
     {
@@ -485,11 +445,47 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
       }
     }
 
-    STAMP(4)  // respiration + allocation
-    // ---- 3. pools (sipnet.c:1769-1806) ------------------------------------------------
-    const double oldDelta = delta;
-    (void)oldDelta;
-    if (nEv > 0) {  // updatePoolsForEvents(), events.c:744-790
+    STAMP(4)
+    // ---- 1+3a. events (events.c:449-742) and their pool updates (events.c:744-790).  Event
+    // fluxes only depend on the start-of-step pools and, without the N cycle, feed nothing but
+    // the pools and ET, so they are evaluated here, off the common path.  Tillage is folded
+    // into the plan.
+    R evEvap = 0;
+    if (nEv > 0) {
+      R evLeafC = 0, evWoodC = 0, evFineRootC = 0, evCoarseRootC = 0, evSoilWater = 0;
+      R evSoilC = 0, evLeafOnCreation = 0, evLeafOnFromWood = 0, evLeafOffLitter = 0;
+      const int ev0 = uni(rareI[3]);
+      for (int k = 0; k < nEv; k++) {
+        const EvRec& ev = a.events[ev0 + k];
+        const int type = uni(ev.type);
+        const R p0 = (R)ev.p[0], p1 = (R)ev.p[1], p2 = (R)ev.p[2], p3 = (R)ev.p[3];
+        if (type == SIPNET_EV_IRRIG) {
+          const R evapAmount = ((int)ev.p[1] == 0) ? K_immed * p0 : R(0);
+          evEvap += evapAmount * invLen;
+          evSoilWater += (p0 - evapAmount) * invLen;
+        } else if (type == SIPNET_EV_PLANT) {
+          evLeafC += p0 * invLen;
+          evWoodC += p1 * invLen;
+          evFineRootC += p2 * invLen;
+          evCoarseRootC += p3 * invLen;
+        } else if (type == SIPNET_EV_HARVEST) {
+          const R woodC = totalWoodC;
+          evSoilC += (p3 * (eFine + eCoarse) + p2 * (eLeaf + woodC)) * invLen;
+          evLeafC += -eLeaf * (p0 + p2) * invLen;
+          evWoodC += -woodC * (p0 + p2) * invLen;
+          evFineRootC += -eFine * (p1 + p3) * invLen;
+          evCoarseRootC += -eCoarse * (p1 + p3) * invLen;
+        } else if (type == SIPNET_EV_FERT) {
+          evSoilC += p1 * invLen;
+        } else if (type == SIPNET_EV_LEAFON) {
+          const R flux = leafOnLimit(PRM_RARE(leafGrowth) * invLen);
+          evLeafOnCreation += flux;
+          const R src = eWood + eCoarse;
+          if (src > R(kTiny)) evLeafOnFromWood += fdiv(flux * eWood, src);
+        } else if (type == SIPNET_EV_LEAFOFF) {
+          evLeafOffLitter += eLeaf * PRM_RARE(fracLeafFall) * invLen;
+        }
+      }
       plantWoodC += (double)(evWoodC * len);
       plantLeafC += (double)(evLeafC * len);
       soilC += (double)(evSoilC * len);
@@ -501,6 +497,7 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
       fineRootC += (double)(evFineRootC * len);
       soilWater += (double)(evSoilWater * len);
     }
+    // ---- 3. pools (sipnet.c:1769-1806) ------------------------------------------------
     {
       const R r_a = rVeg + rFineRoot + rCoarseRoot;
       const R alloc = leafCreation + woodCreation + fineRootCreation + coarseRootCreation;
@@ -516,7 +513,6 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
       fineRootC += (double)((fineRootCreation - fineRootLoss) * len);
     }
 
-    STAMP(8)  // pool updates
     // checkForMortality(), sipnet.c:1688-1767
     {
       const bool sufficient = (plantWoodC > kTiny) && (plantWoodC + delta > kTiny) &&
@@ -536,7 +532,6 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
         ringSum = 0.0;
       }
     }
-    STAMP(9)  // mortality
     // ensureNonNegativeStocks(), sipnet.c:1368-1397
     // (the clamp-warning counter of the strict kernel is not kept on this path)
     plantWoodC = plantWoodC < 0.0 ? 0.0 : plantWoodC;
@@ -547,7 +542,7 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
     soilWater = soilWater < 0.0 ? 0.0 : soilWater;
     snow = snow < kTiny ? 0.0 : snow;
 
-    STAMP(5)  // pools, mortality, clamps
+    STAMP(5)
     // ---- 4. outputs: updateTrackers(), sipnet.c:1420-1496 ---------------------------
     const R tGpp = photosynthesis * len;
     const R tRh = rSoil * len;
@@ -563,15 +558,16 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
       if (insSlot < 0) {
         ringSum = npp * 5.0;
       } else {
-        const double w0 = rd_w0, w1 = rd_w1;
+        double v0 = useLast0 ? lastNpp : rv0;
+        double v1 = useLast1 ? lastNpp : rv1;
         if (ringValidFrom > 0) {  // a member that died earlier: older slots count as zero
-          if (uni(j1.y) < ringValidFrom) { rv0 = 0.0; if (useLast0) lastNpp = 0.0; }
-          if (uni(j1.z) < ringValidFrom) { rv1 = 0.0; if (useLast1) lastNpp = 0.0; }
+          if (uni(rareI[0]) < ringValidFrom) v0 = 0.0;
+          if (uni(rareI[1]) < ringValidFrom) v1 = 0.0;
         }
-        ringSum = ffma(-w0, useLast0 ? lastNpp : rv0, ringSum);
-        ringSum = ffma(-w1, useLast1 ? lastNpp : rv1, ringSum);
+        ringSum = ffma(-q7.y, v0, ringSum);
+        if (bits & FAST_HAS_W1) ringSum = ffma(-rare[0], v1, ringSum);
         if (nOps > 2) {
-          const int opFirst = uni(j1.w);
+          const int opFirst = uni(rareI[2]);
           for (int k = 2; k < nOps; k++) {
             const RingOp& op = a.ringOps[opFirst + k];
             const double v = (uni(op.insStep) >= ringValidFrom)
@@ -584,37 +580,34 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
     } else {
       ringValidFrom = t + 1;
     }
-    STAMP(10)  // trackers + ring update
     // request the values the NEXT step evicts, then store: loads ahead of stores in the queue
     const int insEff = insSlot < 0 ? 0 : insSlot;
+    const int pfSlot0 = (slots >> 16) & 255, pfSlot1 = (slots >> 24) & 255;
     if (!(a.dbg & 4)) {
-    rv0 = ringp[(uint32_t)pfSlot0 * ncu];
-    rv1 = ringp[(uint32_t)pfSlot1 * ncu];
+      rv0 = ringp[(uint32_t)pfSlot0 * ncu];
+      rv1 = ringp[(uint32_t)pfSlot1 * ncu];
     }
     useLast0 = (pfSlot0 == insEff);  // the slot being written right now (uniform test);
     useLast1 = (pfSlot1 == insEff);  // consumed a whole step later, no wait here
     lastNpp = npp;
-    STAMP(11)  // next-step ring loads
     if (act) {
-      const int64_t o = outOff;
       if (!(a.dbg & 1)) {
-      if (oNee) oNee[o] = tNee;
-      if (oGpp) oGpp[o] = tGpp;
-      if (oEt) oEt[o] = tEt;
+        if (oNee) oNee[outOff] = tNee;
+        if (oGpp) oGpp[outOff] = tGpp;
+        if (oEt) oEt[outOff] = tEt;
       }
       if (alive && !(a.dbg & 2)) ringp[(uint32_t)insEff * ncu] = npp;
     }
     outOff += a.ld;
-    STAMP(6)  // trackers, ring, stores
+    STAMP(6)
   }  // steps of this tile
-    STAMP(7)  // tile turnover
+    STAMP(7)
   }  // tiles
 
 #ifdef SIPNET_STAMPS
   if (blockIdx.x == 0 && lane == 0) {
     g_stamps[0] = stampAcc0; g_stamps[1] = stampAcc1; g_stamps[2] = stampAcc2; g_stamps[3] = stampAcc3;
     g_stamps[4] = stampAcc4; g_stamps[5] = stampAcc5; g_stamps[6] = stampAcc6; g_stamps[7] = stampAcc7;
-    g_stamps[8] = stampAcc8; g_stamps[9] = stampAcc9; g_stamps[10] = stampAcc10; g_stamps[11] = stampAcc11;
   }
 #endif
   // ---- state back to HBM ----------------------------------------------------------
@@ -633,14 +626,15 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
     ST(phenBits) = (double)phenBits;
     ST(ringValidFrom) = (double)ringValidFrom;
     ST(diedAt) = (double)diedAt;
-    ST(clampCount) = (double)clampCount;
   }
 #undef ST
+#undef PRM
+#undef PRM_RARE
 }
 
 #ifdef SIPNET_STAMPS
 extern "C" int sipnet_debug_read_stamps(unsigned long long* out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), 12 * sizeof(unsigned long long));
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), 8 * sizeof(unsigned long long));
 }
 #endif
 

@@ -20,11 +20,11 @@ for prec, name in ((sa.F64, "f64"),):
     b.set_climate(0, synth.convert_raw(synth.round_like_file(synth.half_hourly_year_raw(T))))
     b.set_params(0, synth.perturbed_params(base, M))
     b.setup(); planes, _ = b.run(); torch.cuda.synchronize()
-    st = (C.c_ulonglong * 12)()
+    st = (C.c_ulonglong * 8)()
     sa.lib().sipnet_debug_read_stamps.argtypes = [C.c_void_p]
     print("rc", sa.lib().sipnet_debug_read_stamps(st))
     v = np.array(list(st), dtype=float)
-    names = ["record fetch", "start+events", "potPsn+light", "water", "resp+alloc", "pools", "stores (seg end)", "tile turnover", "pool updates", "mortality", "trackers+ring update", "next ring loads"]
+    names = ["record fetch", "start+events", "potPsn+light", "water", "resp+alloc", "pools", "trackers+ring+stores", "tile turnover"]
     print(name, "kernel ms", b.last_kernel_ms(), "cycles/step total", v.sum() / T)
     for n, x in zip(names, v):
         print("  %-22s %8.1f cycles/step  %5.1f%%" % (n, x / T, 100 * x / v.sum()))
