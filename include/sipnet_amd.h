@@ -45,7 +45,7 @@ extern "C" {
 #define SIPNET_NPARAMS 80 /* include/sipnet_params.def */
 #define SIPNET_NFLAGS 12
 #define SIPNET_NCLIM 11   /* converted climate record, see sipnet_io_read_clim */
-#define SIPNET_NREC 36    /* full per-step output record, see below */
+#define SIPNET_NREC 44    /* full per-step record: 36 output columns + 8 event-log columns */
 #define SIPNET_NSTATE 32  /* per-member carried state (doubles), see below */
 #define SIPNET_RING_SLOTS 250 /* MEAN_NPP_MAX_ENTRIES, sipnet.c:39-40 */
 
@@ -113,6 +113,10 @@ typedef struct sipnet_event {
  * 18 litterC 19 snow 20 coarseRootC 21 fineRootC 22 minN 23 soilOrgN
  * 24 litterN 25 plantStorageN 26 plantCAccountingDelta 27 n2o 28 nLeaching
  * 29 nFixation 30 nUptake 31 methane 32 meanNPP 33 gdd 34 d_till_mod 35 totGpp
+ * event log (amounts of the computed events of this step, for `events.out`):
+ * 36 leafOnCreation*len 37 leafOnCreationFromWood*len 38 computed leaf-off litter*len
+ * 39 eventLeafOnCreation*len 40 eventLeafOnCreationFromWood*len
+ * 41 totalWoodC and 42 totalRootC at the moment of plant death 43 died-this-step flag
  *
  * Per-member carried state (SIPNET_NSTATE doubles), what the reference's restart
  * schema (restart.c:216-296) persists for one member minus site-uniform items:
@@ -251,6 +255,16 @@ int sipnet_io_format_out_row(char *buf, size_t cap, int32_t year, int32_t day,
 int sipnet_io_write_out(const char *path, int32_t print_header, int32_t n_steps,
                         const int32_t *year, const int32_t *day,
                         const double *clim, const double *rec);
+/* Write the `events.out` file of one member (events.c:369-418 format): the input events
+ * with the pool deltas they caused, the computed leaf-on / leaf-off events and plant death,
+ * regenerated on the host from the member's full records rec[n_steps][SIPNET_NREC], its raw
+ * parameters and its pools before the first step init_pools[13] (`Envi` order). */
+int sipnet_io_write_events_out(const char *path, int32_t print_header,
+                               const int32_t flags[SIPNET_NFLAGS], const double *raw_params,
+                               int32_t n_steps, const int32_t *year, const int32_t *day,
+                               const double *clim, int32_t n_events,
+                               const sipnet_event *events, const double *rec,
+                               const double *init_pools);
 
 #ifdef __cplusplus
 }

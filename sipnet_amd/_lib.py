@@ -10,7 +10,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsipnet_amd.so")
 
-NPARAMS, NFLAGS, NCLIM, NREC, NSTATE, RING_SLOTS = 80, 12, 11, 36, 32, 250
+NPARAMS, NFLAGS, NCLIM, NREC, NSTATE, RING_SLOTS = 80, 12, 11, 44, 32, 250
+NREC_OUT = 36  # the output columns proper; 36..43 are the event log
 
 OK = 0
 ERR_BAD_PARAMETER = 3
@@ -72,6 +73,8 @@ SIGNATURES = {
     "sipnet_io_format_out_header": (C.c_int, [C.c_char_p, C.c_size_t]),
     "sipnet_io_format_out_row": (C.c_int, [C.c_char_p, C.c_size_t, C.c_int32, C.c_int32, C.c_double, _P, C.c_int64]),
     "sipnet_io_write_out": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, _P, _P, _P, _P]),
+    "sipnet_io_write_events_out": (C.c_int, [C.c_char_p, C.c_int32, _I32P, _P, C.c_int32, _P, _P, _P,
+                                             C.c_int32, _P, _P, _P]),
 }
 
 _lib = None

@@ -446,4 +446,170 @@ int sipnet_io_write_out(const char* path, int32_t print_header, int32_t n_steps,
   return SIPNET_OK;
 }
 
+
+// ---------------------------------------------------------------- events.out
+namespace {
+struct EvLine {
+  FILE* f;
+  // events.c:381-407: "%4d  %3d  %-7s  " then name=%-.2f pairs joined by commas
+  void write(int year, int day, const char* type, int n, const char* const* names,
+             const double* vals) const {
+    fprintf(f, "%4d  %3d  %-7s  ", year, day, type);
+    for (int i = 0; i < n - 1; i++) fprintf(f, "%s=%-.2f,", names[i], vals[i]);
+    fprintf(f, "%s=%-.2f\n", names[n - 1], vals[n - 1]);
+  }
+};
+const char* evTypeName(int t) {  // events.c:186-208
+  switch (t) {
+    case SIPNET_EV_IRRIG: return "irrig";
+    case SIPNET_EV_PLANT: return "plant";
+    case SIPNET_EV_HARVEST: return "harv";
+    case SIPNET_EV_FERT: return "fert";
+    case SIPNET_EV_TILL: return "till";
+    case SIPNET_EV_LEAFON: return "leafon";
+    case SIPNET_EV_LEAFOFF: return "leafoff";
+  }
+  return "plantdeath";
+}
+}  // namespace
+
+// Regenerates what the reference prints while stepping (events.c:484-742 for input events,
+// sipnet.c:829-841 and :1230-1247 for computed leaf events, :1759-1765 for plant death),
+// in the reference's order within a step.
+int sipnet_io_write_events_out(const char* path, int32_t print_header, const int32_t* flags,
+                               const double* P, int32_t n_steps, const int32_t* year,
+                               const int32_t* day, const double* clim, int32_t n_events,
+                               const sipnet_event* events, const double* rec,
+                               const double* init_pools) {
+  if (!path || !flags || !P || !year || !day || !clim || !rec || !init_pools)
+    return SIPNET_ERR_BAD_ARGUMENT;
+  FILE* f = fopen(path, "w");
+  if (!f) {
+    setError(std::string("Error opening ") + path + " for writing");
+    return SIPNET_ERR_FILE_OPEN;
+  }
+  if (print_header)  // events.c:371-378
+    fprintf(f, "%4s  %3s  %-7s  %s", "year", "day", "type",
+            "param_name=delta[,param_name=delta,...]\n");
+  const EvLine out{f};
+  const bool litter = flags[SIPNET_F_LITTER_POOL] != 0, ncyc = flags[SIPNET_F_NITROGEN_CYCLE] != 0;
+  const double immedEvapFrac = P[31], leafCN = P[66], woodCN = P[67], fineRootCN = P[68];
+  const double fracLeafFall = P[56], leafNResorptionFrac = P[73];
+  int evNext = 0;
+  if (!flags[SIPNET_F_EVENTS]) n_events = 0;
+  for (int t = 0; t < n_steps; t++) {
+    const double* r = rec + (size_t)t * SIPNET_NREC;
+    const double* pools = t == 0 ? init_pools : rec + (size_t)(t - 1) * SIPNET_NREC + 14;
+    const double plantWoodC = pools[0], plantLeafC = pools[1], fineRootC = pools[7],
+                 coarseRootC = pools[6], delta = pools[12];
+    const double len = clim[(size_t)t * SIPNET_NCLIM];
+    double harvRemoved = 0, harvTransferred = 0;
+    while (evNext < n_events && events[evNext].year <= year[t] && events[evNext].day <= day[t]) {
+      const sipnet_event& ev = events[evNext++];
+      const char* ty = evTypeName(ev.type);
+      switch (ev.type) {
+        case SIPNET_EV_IRRIG: {
+          const double amount = ev.p[0];
+          const double evap = ((int)ev.p[1] == 0) ? immedEvapFrac * amount : 0.0;
+          const char* n[] = {"eventSoilWater", "eventEvap"};
+          const double v[] = {amount - evap, evap};
+          out.write(ev.year, ev.day, ty, 2, n, v);
+        } break;
+        case SIPNET_EV_PLANT: {
+          const double inC = ev.p[0] + ev.p[1] + ev.p[2] + ev.p[3];
+          const double inN = ncyc ? ev.p[0] / leafCN + ev.p[1] / woodCN + ev.p[2] / fineRootCN +
+                                        ev.p[3] / woodCN
+                                  : 0.0;
+          const char* n[] = {"eventLeafC", "eventWoodC", "eventFineRootC", "eventCoarseRootC",
+                             "eventInputC", "eventInputN"};
+          const double v[] = {ev.p[0], ev.p[1], ev.p[2], ev.p[3], inC, inN};
+          out.write(ev.year, ev.day, ty, 6, n, v);
+        } break;
+        case SIPNET_EV_HARVEST: {
+          const double fRA = ev.p[0], fRB = ev.p[1], fTA = ev.p[2], fTB = ev.p[3];
+          const double woodC = plantWoodC + delta;
+          const double above = woodC + plantLeafC, below = fineRootC + coarseRootC;
+          if (above + below > kTiny) {
+            harvRemoved += (fRA * above + fRB * below) / (above + below);
+            harvTransferred += (fTA * above + fTB * below) / (above + below);
+          }
+          double litterAdd = fTA * (plantLeafC + woodC), soilAdd = fTB * (fineRootC + coarseRootC);
+          if (!litter) {
+            soilAdd += litterAdd;
+            litterAdd = 0.0;
+          }
+          double soilN = 0, litterN = 0, outN = 0;
+          if (ncyc) {
+            litterN = fTA * ((plantLeafC / leafCN) + (plantWoodC / woodCN));
+            soilN = fTB * ((fineRootC / fineRootCN) + (coarseRootC / woodCN));
+            outN = (plantWoodC / woodCN + plantLeafC / leafCN) * fRA +
+                   (fineRootC / fineRootCN + coarseRootC / woodCN) * fRB;
+          }
+          const double outC = (woodC + plantLeafC) * fRA + (fineRootC + coarseRootC) * fRB;
+          const char* n[] = {"eventSoilC", "eventLitterC", "eventLeafC", "eventWoodC",
+                             "eventFineRootC", "eventCoarseRootC", "eventSoilOrgN",
+                             "eventLitterN", "eventOutputC", "eventOutputN"};
+          const double v[] = {soilAdd, litterAdd, -plantLeafC * (fRA + fTA), -woodC * (fRA + fTA),
+                              -fineRootC * (fRB + fTB), -coarseRootC * (fRB + fTB), soilN, litterN,
+                              outC, outN};
+          out.write(ev.year, ev.day, ty, 10, n, v);
+        } break;
+        case SIPNET_EV_TILL: {
+          const char* n[] = {"eventTrackers.d_till_mod"};
+          const double v[] = {ev.p[0]};
+          out.write(ev.year, ev.day, ty, 1, n, v);
+        } break;
+        case SIPNET_EV_FERT: {
+          const double orgC = ev.p[1], orgN = ncyc ? ev.p[0] : 0.0, minN = ncyc ? ev.p[2] : 0.0;
+          const char* n[] = {"eventLitterC", "eventSoilC", "eventMinN", "eventLitterN",
+                             "eventInputC", "eventInputN"};
+          const double v[] = {litter ? orgC : 0.0, litter ? 0.0 : orgC, minN, orgN, orgC,
+                              orgN + minN};
+          out.write(ev.year, ev.day, ty, 6, n, v);
+        } break;
+        case SIPNET_EV_LEAFOFF: {
+          const double leafOff = plantLeafC * fracLeafFall;
+          double resorb = 0, litterN = 0;
+          if (ncyc) {
+            const double leafN = leafOff / leafCN;
+            resorb = leafN * leafNResorptionFrac;
+            litterN = leafN - resorb;
+          }
+          const char* n[] = {"eventLeafOffLitter", "eventLeafOffNResorption", "eventLitterN"};
+          const double v[] = {leafOff, resorb, litterN};
+          out.write(ev.year, ev.day, ty, 3, n, v);
+        } break;
+        default:  // leaf-on is written after the N-limitation check (below)
+          break;
+      }
+    }
+    // computed leaf-off (sipnet.c:836-840), then the delayed leaf-on lines (sipnet.c:1230-1247)
+    if (flags[SIPNET_F_EVENTS]) {
+      if (r[38] / len > kTiny) {
+        const char* n[] = {"leafLitter"};
+        const double v[] = {r[38]};
+        out.write(year[t], day[t], "leafoff", 1, n, v);
+      }
+      if (r[36] / len > kTiny) {
+        const char* n[] = {"leafOnCreation", "leafOnCreationFromWood"};
+        const double v[] = {r[36], r[37]};
+        out.write(year[t], day[t], "leafon", 2, n, v);
+      }
+      if (r[39] / len > kTiny) {
+        const char* n[] = {"eventLeafOnCreation", "eventLeafOnCreationFromWood"};
+        const double v[] = {r[39], r[40]};
+        out.write(year[t], day[t], "leafon", 2, n, v);
+      }
+      if (r[43] != 0.0) {
+        const char* n[] = {"harvestFracRemoved", "harvestFracTransferred", "totalWoodC",
+                           "totalRootC"};
+        const double v[] = {harvRemoved, harvTransferred, r[41], r[42]};
+        out.write(year[t], day[t], "plantdeath", 4, n, v);
+      }
+    }
+  }
+  fclose(f);
+  return SIPNET_OK;
+}
+
 }  // extern "C"

@@ -1,4 +1,399 @@
-// placeholder main until the drop-in CLI lands (next commit)
+// sipnet_cli.cpp -- `sipnet`-compatible command line over the C-ABI (drop-in at the process
+// level, the boundary PEcAn uses: one working directory with sipnet.in / <prefix>.param /
+// <prefix>.clim / <events>.in, producing <prefix>.out, <events>.out, <prefix>.config).
+//
+// Behaviour mirrored from the reference (paths relative to /root/reference/src/):
+//   option table and precedence     sipnet/cli.c:20-57,144-229; common/context.c:17-25,143-170
+//   sipnet.in syntax                sipnet/frontend.c:35-128
+//   flag coupling rules             common/context.c:195-223
+//   derived file names, run order   sipnet/frontend.c:130-253
+//   --dump-config format            common/context.c:225-268
+//   single-variable outputs         sipnet/outputItems.c:126-150, sipnet/sipnet.c:1993-1998
+// The model itself runs on the GPU through libsipnet_amd.so; there is no CPU model here.
+//
+// Additive extension (never changes single-run behaviour):
+//   --ensemble-params FILE   whitespace table, first line = parameter names, one row per
+//                            member overriding those parameters; every member runs in ONE
+//                            batch and writes <prefix>.<m>.out (m = 0..M-1)
+#include <getopt.h>
+#include <strings.h>
+
+#include <algorithm>
+#include <cctype>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
 #include "../../include/sipnet_amd.h"
-int main() { std::printf("%s\n", sipnet_version()); return 0; }
+
+namespace {
+
+enum Source { SRC_DEFAULT = 0, SRC_FILE, SRC_CLI, SRC_CALCULATED };
+const char* sourceName(int s) {
+  static const char* n[] = {"DEFAULT", "INPUT_FILE", "COMMAND_LINE", "CALCULATED"};
+  return n[s];
+}
+
+struct Entry {
+  std::string printName;
+  bool isInt;
+  int ival;
+  std::string sval;
+  int source;
+};
+
+// context.c:76-90
+std::string keyOf(const std::string& name) {
+  std::string k;
+  for (char c : name)
+    if (isalnum((unsigned char)c)) k += (char)tolower((unsigned char)c);
+  if (k == "filename") k = "fileprefix";
+  return k;
+}
+
+struct Context {
+  std::map<std::string, Entry> m;  // ordered by key == HASH_SORT(by_name)
+  void addInt(const char* name, const char* print, int v) { m[keyOf(name)] = {print, true, v, "", SRC_DEFAULT}; }
+  void addStr(const char* name, const char* print, const char* v) { m[keyOf(name)] = {print, false, 0, v, SRC_DEFAULT}; }
+  Entry* find(const std::string& name) {
+    auto it = m.find(keyOf(name));
+    return it == m.end() ? nullptr : &it->second;
+  }
+  void setInt(const std::string& name, int v, int src) {
+    Entry* e = find(name);
+    if (e && e->source <= src) { e->ival = v; e->source = src; }
+  }
+  void setStr(const std::string& name, const std::string& v, int src) {
+    Entry* e = find(name);
+    if (e && e->source <= src) { e->sval = v; e->source = src; }
+  }
+  int i(const char* name) { return find(name)->ival; }
+  const std::string& s(const char* name) { return find(name)->sval; }
+};
+
+bool g_quiet = false;
+void logInfo(const std::string& s) { if (!g_quiet) printf("[INFO   ] %s", s.c_str()); }
+void logError(const std::string& s) { printf("[ERROR  ] %s", s.c_str()); }
+
+void initContext(Context& c) {  // context.c:26-71
+  c.addInt("events", "EVENTS", 1);
+  c.addInt("gdd", "GDD", 1);
+  c.addInt("growthResp", "GROWTH_RESP", 0);
+  c.addInt("leafWater", "LEAF_WATER", 0);
+  c.addInt("litterPool", "LITTER_POOL", 0);
+  c.addInt("snow", "SNOW", 1);
+  c.addInt("soilPhenol", "SOIL_PHENOL", 0);
+  c.addInt("waterHResp", "WATER_HRESP", 1);
+  c.addInt("nitrogenCycle", "NITROGEN_CYCLE", 0);
+  c.addInt("anaerobic", "ANAEROBIC", 0);
+  c.addInt("flooding", "FLOODING", 0);
+  c.addInt("carbonSaturation", "CARBON_SATURATION", 0);
+  c.addInt("doMainOutput", "DO_MAIN_OUTPUT", 1);
+  c.addInt("doSingleOutputs", "DO_SINGLE_OUTPUT", 0);
+  c.addInt("dumpConfig", "DUMP_CONFIG", 0);
+  c.addInt("printHeader", "PRINT_HEADER", 1);
+  c.addInt("quiet", "QUIET", 0);
+  c.addStr("paramFile", "PARAM_FILE", "");
+  c.addStr("climFile", "CLIM_FILE", "");
+  c.addStr("outFile", "OUT_FILE", "");
+  c.addStr("outConfigFile", "OUT_CONFIG_FILE", "");
+  c.addStr("eventsPrefix", "EVENTS_PREFIX", "events");
+  c.addStr("inputFile", "INPUT_FILE", "sipnet.in");
+  c.addStr("restartIn", "RESTART_IN", "");
+  c.addStr("restartOut", "RESTART_OUT", "");
+  c.addStr("debugLogPrefix", "DEBUG_LOG_PREFIX", "");
+  c.addStr("filePrefix", "FILE_PREFIX", "sipnet");
+}
+
+const char* kFlagOpts[][2] = {  // cli.c:20-44 option name -> context field
+    {"events", "events"}, {"gdd", "gdd"}, {"growth-resp", "growthResp"},
+    {"leaf-water", "leafWater"}, {"litter-pool", "litterPool"}, {"snow", "snow"},
+    {"soil-phenol", "soilPhenol"}, {"water-hresp", "waterHResp"},
+    {"nitrogen-cycle", "nitrogenCycle"}, {"anaerobic", "anaerobic"}, {"flooding", "flooding"},
+    {"carbon-saturation", "carbonSaturation"}, {"do-main-output", "doMainOutput"},
+    {"do-single-outputs", "doSingleOutputs"}, {"dump-config", "dumpConfig"},
+    {"print-header", "printHeader"}, {"quiet", "quiet"}};
+constexpr int kNumFlagOpts = sizeof(kFlagOpts) / sizeof(kFlagOpts[0]);
+
+void usage(const char* prog) {
+  printf("Usage: %s [OPTIONS]\n\n", prog);
+  printf("Run SIPNET model for one site with configured options (MI355X engine).\n\n");
+  printf("  -i, --input-file <path>     Name of input config file ('sipnet.in')\n");
+  printf("  -f, --file-prefix <name>    Prefix of climate and parameter files ('sipnet')\n");
+  printf("      --file-name <name>      Backward-compatible alias for --file-prefix\n");
+  printf("  -e, --events-prefix <name>  Prefix of events input/output files ('events')\n");
+  printf("Model flags (prepend 'no-' to force off): --anaerobic --events --flooding --gdd\n");
+  printf("  --growth-resp --leaf-water --litter-pool --nitrogen-cycle --snow --soil-phenol\n");
+  printf("  --water-hresp --carbon-saturation\n");
+  printf("Output flags: --do-main-output --do-single-outputs --dump-config --print-header --quiet\n");
+  printf("  --ensemble-params <file>    run one member per row of a parameter table in one batch\n");
+  printf("  -h, --help   -v, --version\n");
+}
+
+[[noreturn]] void die(int code, const std::string& msg) {
+  logError(msg);
+  exit(code);
+}
+
+// frontend.c:35-128
+void readInputFile(Context& c) {
+  const std::string path = c.s("inputFile");
+  logInfo("Reading config from file " + path + "\n");
+  std::ifstream in(path);
+  if (!in) die(6, "Error opening " + path + " for reading\n");
+  std::string line;
+  while (std::getline(in, line)) {
+    const size_t bang = line.find('!');
+    if (bang != std::string::npos) line.erase(bang);
+    // name: up to " \t=:" ; value: up to " \t=:\n\r"
+    std::vector<std::string> tok;
+    size_t i = 0;
+    while (i < line.size() && tok.size() < 2) {
+      while (i < line.size() && strchr(" \t=:\r\n", line[i])) i++;
+      size_t j = i;
+      while (j < line.size() && !strchr(" \t=:\r\n", line[j])) j++;
+      if (j > i) tok.push_back(line.substr(i, j - i));
+      i = j;
+    }
+    if (tok.empty()) continue;
+    if (strcasecmp(tok[0].c_str(), "runtype") == 0) {
+      if (tok.size() > 1 && strcasecmp(tok[1].c_str(), "standard") != 0)
+        die(3, "RUNTYPE is obsolete; only 'standard' is accepted. Please fix " + path + " and re-run\n");
+      continue;
+    }
+    Entry* e = c.find(tok[0]);
+    if (!e) {
+      logInfo("ignoring input file parameter " + tok[0] + "\n");
+      continue;
+    }
+    if (tok.size() < 2)
+      die(3, "Error in input file: No value given for input item " + tok[0] + "\n");
+    if (e->isInt) {
+      char* end = nullptr;
+      const long v = strtol(tok[1].c_str(), &end, 0);
+      if (*end) die(3, "ERROR in input file: Invalid value for " + tok[0] + ": " + tok[1] + "\n");
+      c.setInt(tok[0], (int)v, SRC_FILE);
+    } else {
+      c.setStr(tok[0], tok[1] == "none" ? "" : tok[1], SRC_FILE);
+    }
+  }
+}
+
+// context.c:225-268
+void printConfig(Context& c, FILE* f) {
+  unsigned width = 0;
+  for (auto& kv : c.m)
+    if (!kv.second.isInt) width = std::max<unsigned>(width, (unsigned)kv.second.printName.size());
+  if (c.i("printHeader")) {
+    char ts[100];
+    time_t now;
+    time(&now);
+    strftime(ts, sizeof ts, "%Y-%m-%d %H:%M:%S UTC", gmtime(&now));
+    fprintf(f, "Final config for SIPNET run at %s\n", ts);
+    fprintf(f, "%21s %13s %*s\n", "Name", "Source", width, "Value");
+  }
+  for (auto& kv : c.m) {
+    const Entry& e = kv.second;
+    if (e.isInt)
+      fprintf(f, "%21s %13s %*d\n", e.printName.c_str(), sourceName(e.source), width, e.ival);
+    else
+      fprintf(f, "%21s %13s %*s\n", e.printName.c_str(), sourceName(e.source), width, e.sval.c_str());
+  }
+}
+
+void check(int rc, const char* what) {
+  if (rc != SIPNET_OK) {
+    logError(std::string(what) + ": " + sipnet_last_error() + "\n");
+    exit(rc >= 100 ? 1 : rc);
+  }
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  Context ctx;
+  initContext(ctx);
+
+  // ---- command line (cli.c:144-229) ----
+  std::vector<option> opts;
+  static int tmpFlag = 0;
+  for (int k = 0; k < kNumFlagOpts; k++) {
+    opts.push_back({kFlagOpts[k][0], no_argument, &tmpFlag, 1});
+    opts.push_back({strdup((std::string("no-") + kFlagOpts[k][0]).c_str()), no_argument, &tmpFlag, 0});
+  }
+  enum { OPT_RIN = 1001, OPT_ROUT, OPT_DBG, OPT_ENS };
+  opts.push_back({"input-file", required_argument, nullptr, 'i'});
+  opts.push_back({"file-prefix", required_argument, nullptr, 'f'});
+  opts.push_back({"file-name", required_argument, nullptr, 'f'});
+  opts.push_back({"events-prefix", required_argument, nullptr, 'e'});
+  opts.push_back({"restart-in", required_argument, nullptr, OPT_RIN});
+  opts.push_back({"restart-out", required_argument, nullptr, OPT_ROUT});
+  opts.push_back({"debug-log", required_argument, nullptr, OPT_DBG});
+  opts.push_back({"ensemble-params", required_argument, nullptr, OPT_ENS});
+  opts.push_back({"help", no_argument, nullptr, 'h'});
+  opts.push_back({"version", no_argument, nullptr, 'v'});
+  opts.push_back({nullptr, 0, nullptr, 0});
+  std::string ensembleFile;
+  int longIndex = 0, ch;
+  while ((ch = getopt_long(argc, argv, "he:f:i:v", opts.data(), &longIndex)) != -1) {
+    switch (ch) {
+      case 0: ctx.setInt(kFlagOpts[longIndex / 2][1], tmpFlag, SRC_CLI); break;
+      case 'f': ctx.setStr("filePrefix", optarg, SRC_CLI); break;
+      case 'e': ctx.setStr("eventsPrefix", optarg, SRC_CLI); break;
+      case 'i': ctx.setStr("inputFile", optarg, SRC_CLI); break;
+      case OPT_RIN: ctx.setStr("restartIn", optarg, SRC_CLI); break;
+      case OPT_ROUT: ctx.setStr("restartOut", optarg, SRC_CLI); break;
+      case OPT_DBG: ctx.setStr("debugLogPrefix", optarg, SRC_CLI); break;
+      case OPT_ENS: ensembleFile = optarg; break;
+      case 'h': usage(argv[0]); return 0;
+      case 'v': printf("SIPNET version 2.1.0 (%s)\n", sipnet_version()); return 0;
+      default: usage(argv[0]); return 8;  // EXIT_CODE_BAD_CLI_ARGUMENT
+    }
+  }
+  g_quiet = ctx.i("quiet") != 0;
+  if (ctx.s("filePrefix").empty()) die(3, "filePrefix must be set for SIPNET to run\n");
+  readInputFile(ctx);
+  g_quiet = ctx.i("quiet") != 0;
+
+  // ---- validateContext (context.c:195-223) ----
+  bool bad = false;
+  if (ctx.i("soilPhenol") && ctx.i("gdd")) { logError("soil-phenol and gdd may not both be turned on\n"); bad = true; }
+  if (ctx.i("nitrogenCycle") && !(ctx.i("litterPool") && ctx.i("anaerobic"))) {
+    logError("nitrogen-cycle requires both litter-pool and anaerobic to be turned on\n"); bad = true; }
+  if (ctx.i("anaerobic") && !ctx.i("waterHResp")) { logError("anaerobic requires water-hresp to be turned on\n"); bad = true; }
+  if (ctx.i("carbonSaturation") && !ctx.i("litterPool")) { logError("carbon-saturation requires litter-pool to be turned on\n"); bad = true; }
+  if (bad) return 3;
+  if (!ctx.s("restartIn").empty() || !ctx.s("restartOut").empty() || !ctx.s("debugLogPrefix").empty())
+    die(8, "--restart-in/--restart-out/--debug-log are not supported by this engine yet\n");
+
+  // ---- derived names (frontend.c:164-209) ----
+  const std::string prefix = ctx.s("filePrefix");
+  ctx.setStr("paramFile", prefix + ".param", SRC_CALCULATED);
+  ctx.setStr("climFile", prefix + ".clim", SRC_CALCULATED);
+  const bool useEvents = ctx.i("events") != 0;
+  const std::string eventsIn = useEvents ? ctx.s("eventsPrefix") + ".in" : "";
+  const std::string eventsOut = useEvents ? ctx.s("eventsPrefix") + ".out" : "";
+  if (ctx.i("doMainOutput")) ctx.setStr("outFile", prefix + ".out", SRC_CALCULATED);
+  if (ctx.i("dumpConfig")) {
+    ctx.setStr("outConfigFile", prefix + ".config", SRC_CALCULATED);
+    FILE* f = fopen((prefix + ".config").c_str(), "w");
+    if (!f) die(6, "Error opening " + prefix + ".config for writing\n");
+    printConfig(ctx, f);
+    fclose(f);
+  }
+
+  int32_t flags[SIPNET_NFLAGS] = {ctx.i("events"), ctx.i("gdd"), ctx.i("growthResp"),
+                                  ctx.i("leafWater"), ctx.i("litterPool"), ctx.i("snow"),
+                                  ctx.i("soilPhenol"), ctx.i("waterHResp"), ctx.i("nitrogenCycle"),
+                                  ctx.i("anaerobic"), ctx.i("flooding"), ctx.i("carbonSaturation")};
+
+  // ---- initModel (sipnet.c:2001-2009) ----
+  std::vector<double> base(SIPNET_NPARAMS);
+  check(sipnet_io_read_params(ctx.s("paramFile").c_str(), flags, base.data(), nullptr), "reading parameters");
+  sipnet_clim_table* clim = nullptr;
+  check(sipnet_io_read_clim(ctx.s("climFile").c_str(), flags[SIPNET_F_GDD], &clim), "reading climate");
+  const int T = sipnet_clim_nsteps(clim);
+  sipnet_event* events = nullptr;
+  int32_t nEvents = 0;
+  if (useEvents) {
+    check(sipnet_io_read_events(eventsIn.c_str(), flags, base.data(), &events, &nEvents), "reading events");
+    if (nEvents == 0) logInfo("No event file found, assuming no input events\n");
+  }
+
+  // ---- members ----
+  std::vector<double> members(base);
+  int M = 1;
+  if (!ensembleFile.empty()) {
+    std::ifstream in(ensembleFile);
+    if (!in) die(6, "Error opening " + ensembleFile + " for reading\n");
+    std::string line;
+    std::getline(in, line);
+    std::istringstream hs(line);
+    std::vector<int> cols;
+    for (std::string name; hs >> name;) {
+      const int idx = sipnet_param_index(name.c_str());
+      if (idx < 0) die(5, "unknown parameter " + name + " in " + ensembleFile + "\n");
+      cols.push_back(idx);
+    }
+    members.clear();
+    M = 0;
+    while (std::getline(in, line)) {
+      std::istringstream ls(line);
+      std::vector<double> row(base);
+      size_t k = 0;
+      for (double v; ls >> v && k < cols.size(); k++) row[cols[k]] = v;
+      if (k == 0) continue;
+      if (k != cols.size()) die(5, "short row in " + ensembleFile + "\n");
+      members.insert(members.end(), row.begin(), row.end());
+      M++;
+    }
+    if (M == 0) die(5, "no members in " + ensembleFile + "\n");
+    logInfo("ensemble of " + std::to_string(M) + " members in one batch\n");
+  }
+
+  // ---- run on the GPU ----
+  sipnet_batch* b = nullptr;
+  check(sipnet_batch_create(flags, 1, M, SIPNET_F64, 0, &b), "creating batch");
+  check(sipnet_batch_set_events(b, 0, nEvents, events), "events");
+  check(sipnet_batch_set_climate(b, 0, T, sipnet_clim_data(clim), sipnet_clim_year(clim),
+                                 sipnet_clim_day(clim)), "climate");
+  check(sipnet_batch_set_params(b, 0, 0, M, members.data()), "parameters");
+  check(sipnet_batch_setup(b, nullptr), "setupModel");
+  std::vector<double> state0((size_t)M * SIPNET_NSTATE);
+  check(sipnet_batch_get_state(b, state0.data(), nullptr), "state");
+  const size_t recElems = (size_t)T * SIPNET_NREC * M;
+  double* dRec = (double*)sipnet_dev_alloc(recElems * sizeof(double));
+  if (!dRec) die(1, std::string(sipnet_last_error()) + "\n");
+  check(sipnet_batch_run(b, 0, T, nullptr, nullptr, nullptr, dRec, M, nullptr), "run");
+  std::vector<double> rec(recElems);
+  check(sipnet_dev_to_host(rec.data(), dRec, recElems * sizeof(double), nullptr), "copy back");
+  std::vector<int32_t> status(M);
+  check(sipnet_batch_get_status(b, status.data(), nullptr), "status");
+
+  // ---- outputs ----
+  int worst = 0;
+  std::vector<double> one((size_t)T * SIPNET_NREC);
+  for (int m = 0; m < M; m++) {
+    if (status[m] != 0) {
+      logError("member " + std::to_string(m) + ": status " + std::to_string(status[m]) +
+               " (NPP allocation params must be less than one individually and add to less than one)\n");
+      worst = std::max(worst, status[m]);
+      continue;
+    }
+    for (int t = 0; t < T; t++)
+      for (int k = 0; k < SIPNET_NREC; k++)
+        one[(size_t)t * SIPNET_NREC + k] = rec[((size_t)t * SIPNET_NREC + k) * M + m];
+    const std::string tag = ensembleFile.empty() ? "" : "." + std::to_string(m);
+    if (ctx.i("doMainOutput"))
+      check(sipnet_io_write_out((prefix + tag + ".out").c_str(), ctx.i("printHeader"), T,
+                                sipnet_clim_year(clim), sipnet_clim_day(clim), sipnet_clim_data(clim),
+                                one.data()), "writing output");
+    if (useEvents)
+      check(sipnet_io_write_events_out((ctx.s("eventsPrefix") + tag + ".out").c_str(),
+                                       ctx.i("printHeader"), flags, members.data() + (size_t)m * SIPNET_NPARAMS,
+                                       T, sipnet_clim_year(clim), sipnet_clim_day(clim),
+                                       sipnet_clim_data(clim), nEvents, events, one.data(),
+                                       state0.data() + (size_t)m * SIPNET_NSTATE), "writing events.out");
+    if (ctx.i("doSingleOutputs")) {  // sipnet.c:1993-1998, outputItems.c:126-150
+      const struct { const char* name; int col; } items[] = {{"NEE", 0}, {"NEE_cum", 3}, {"GPP", 1}, {"GPP_cum", 35}};
+      for (const auto& it : items) {
+        FILE* f = fopen((prefix + tag + "." + it.name).c_str(), "w");
+        if (!f) die(6, std::string("Error opening single output file for ") + it.name + "\n");
+        for (int t = 0; t < T; t++) fprintf(f, "%f ", one[(size_t)t * SIPNET_NREC + it.col]);
+        fprintf(f, "\n");
+        fclose(f);
+      }
+    }
+  }
+  sipnet_dev_free(dRec);
+  sipnet_batch_destroy(b);
+  sipnet_clim_free(clim);
+  sipnet_io_free(events);
+  return worst;
+}

@@ -605,7 +605,7 @@ __global__ __launch_bounds__(64) void stepKernel(KernelArgs a) {
     R woodCreation = meanNpp * woodAllocation;
 
     // calcLeafOnOffFluxes(), sipnet.c:800-842
-    R leafOnCreation = 0, leafOnFromWood = 0;
+    R leafOnCreation = 0, leafOnFromWood = 0, leafOffComputed = 0;
     {
       if (bits & STEP_PHEN_NEW_YEAR) phenBits = 0;
       bool pastGrowth;  // pastLeafGrowth(), sipnet.c:705-731
@@ -625,7 +625,8 @@ __global__ __launch_bounds__(64) void stepKernel(KernelArgs a) {
       }
       const bool pastFall = (leafOffDay > R(0)) && (s.dayTime >= (double)leafOffDay);  // sipnet.c:733-742
       if (!(phenBits & 2) && pastFall) {
-        leafLitter += (eLeaf * fracLeafFall) / len;
+        leafOffComputed = (eLeaf * fracLeafFall) / len;
+        leafLitter += leafOffComputed;
         phenBits |= 2;
       }
     }
@@ -886,6 +887,7 @@ __global__ __launch_bounds__(64) void stepKernel(KernelArgs a) {
     (void)dl;
 
     // checkForMortality(), sipnet.c:1688-1767
+    double diedNow = 0.0, deathWood = 0.0, deathRoot = 0.0;
     {
       const bool sufficient = (plantWoodC > kTiny) &&
                               (plantWoodC + plantCAccountingDelta > kTiny) &&
@@ -896,6 +898,9 @@ __global__ __launch_bounds__(64) void stepKernel(KernelArgs a) {
         alive = false;
         if (diedAt < 0) diedAt = t;
         const double root = fineRootC + coarseRootC;
+        diedNow = 1.0;
+        deathWood = plantWoodC + plantCAccountingDelta;
+        deathRoot = root;
         soilC += root;
         if (F.litterPool) {
           litterC += plantWoodC + plantLeafC + plantCAccountingDelta;
@@ -1011,6 +1016,15 @@ __global__ __launch_bounds__(64) void stepKernel(KernelArgs a) {
       r[33 * L] = s.gddAfter;
       r[34 * L] = s.tillAfter;
       r[35 * L] = totGpp;
+      // event log for events.out (sipnet.c:1230-1247, :829-841, :1759-1765)
+      r[36 * L] = (double)(leafOnCreation * len);
+      r[37 * L] = (double)(leafOnFromWood * len);
+      r[38 * L] = (double)(leafOffComputed * len);
+      r[39 * L] = (double)(evLeafOnCreation * len);
+      r[40 * L] = (double)(evLeafOnFromWood * len);
+      r[41 * L] = deathWood;
+      r[42 * L] = deathRoot;
+      r[43 * L] = diedNow;
     }
 
     // ---- 5. running mean of NPP: updateMeanTrackers(), sipnet.c:1546-1570 with

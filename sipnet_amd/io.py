@@ -76,7 +76,7 @@ def format_out_header():
 
 def format_out_row(year, day, time, rec):
     rec = np.ascontiguousarray(rec, dtype=np.float64)
-    assert rec.shape == (NREC,)
+    assert rec.ndim == 1 and rec.shape[0] >= 36    # the 36 output columns (+ optional event log)
     buf = C.create_string_buffer(1024)
     n = lib().sipnet_io_format_out_row(buf, 1024, int(year), int(day), float(time),
                                        rec.ctypes.data, 1)
@@ -84,8 +84,28 @@ def format_out_row(year, day, time, rec):
 
 
 def write_out(path, clim, rec, print_header=False):
-    rec = np.ascontiguousarray(rec, dtype=np.float64)
+    rec = np.asarray(rec, dtype=np.float64)
+    if rec.shape[1] < NREC:   # records without the event-log columns
+        rec = np.concatenate([rec, np.zeros((rec.shape[0], NREC - rec.shape[1]))], axis=1)
+    rec = np.ascontiguousarray(rec)
     assert rec.shape == (clim.n_steps, NREC)
     check(lib().sipnet_io_write_out(str(path).encode(), int(print_header), clim.n_steps,
                                     clim.year.ctypes.data, clim.day.ctypes.data,
                                     clim.data.ctypes.data, rec.ctypes.data), "write_out")
+
+
+def write_events_out(path, flags, raw_params, clim, events, rec, init_pools, print_header=False):
+    """`events.out` of one member regenerated from its full records (events.c:369-418)."""
+    import ctypes as C
+    from ._lib import Event
+    rec = np.ascontiguousarray(rec, dtype=np.float64)
+    assert rec.shape == (clim.n_steps, NREC)
+    raw = np.ascontiguousarray(raw_params, dtype=np.float64)
+    pools = np.ascontiguousarray(init_pools, dtype=np.float64)
+    fl = (C.c_int32 * 12)(*flags)
+    n = len(events)
+    arr = (Event * max(n, 1))(*events)
+    check(lib().sipnet_io_write_events_out(str(path).encode(), int(print_header), fl, raw.ctypes.data,
+                                           clim.n_steps, clim.year.ctypes.data, clim.day.ctypes.data,
+                                           clim.data.ctypes.data, n, arr, rec.ctypes.data,
+                                           pools.ctypes.data), "write_events_out")

@@ -36,7 +36,7 @@ def copy_smoke():
         s = os.path.join(REF, "tests", "smoke", case)
         d = os.path.join(GOLD, "smoke", case)
         os.makedirs(d, exist_ok=True)
-        for f in ["sipnet.in", "sipnet.param", "events.in", "events.out"]:
+        for f in ["sipnet.in", "sipnet.param", "events.in", "events.out", "sipnet.config"]:
             shutil.copyfile(os.path.join(s, f), os.path.join(d, f))
         gz_copy(os.path.join(s, "sipnet.out"), os.path.join(d, "sipnet.out.gz"))
         if case in ("niwot", "russell_1"):  # russell_2/3 use russell_1's forcing
