@@ -194,6 +194,10 @@ int sipnet_batch_set_state(sipnet_batch *b, const double *state, void *hip_strea
 /* Ring contents of one column to HOST: values[SIPNET_RING_SLOTS]. */
 int sipnet_batch_get_ring(sipnet_batch *b, int64_t col, double *values,
                           void *hip_stream);
+/* Whole ring block to / from HOST: rings[ncol][SIPNET_RING_SLOTS].  Together with the state
+ * vector this is the complete per-member checkpoint (what restart.c:216-296 persists). */
+int sipnet_batch_get_rings(sipnet_batch *b, double *rings, void *hip_stream);
+int sipnet_batch_set_rings(sipnet_batch *b, const double *rings, void *hip_stream);
 /* Per-member status to HOST: status[ncol] (enum sipnet_status). */
 int sipnet_batch_get_status(sipnet_batch *b, int32_t *status, void *hip_stream);
 

@@ -50,6 +50,8 @@ SIGNATURES = {
     "sipnet_batch_get_state": (C.c_int, [_P, _P, _P]),
     "sipnet_batch_set_state": (C.c_int, [_P, _P, _P]),
     "sipnet_batch_get_ring": (C.c_int, [_P, C.c_int64, _P, _P]),
+    "sipnet_batch_get_rings": (C.c_int, [_P, _P, _P]),
+    "sipnet_batch_set_rings": (C.c_int, [_P, _P, _P]),
     "sipnet_batch_get_status": (C.c_int, [_P, _P, _P]),
     "sipnet_batch_ncol": (C.c_int64, [_P]),
     "sipnet_batch_nsteps": (C.c_int32, [_P]),

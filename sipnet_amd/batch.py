@@ -136,6 +136,24 @@ class Batch:
         check(self.L.sipnet_batch_get_ring(self.h, col, v.ctypes.data, self._stream()), "get_ring")
         return v
 
+    def get_rings(self):
+        r = np.zeros((self.ncol, RING_SLOTS))
+        check(self.L.sipnet_batch_get_rings(self.h, r.ctypes.data, self._stream()), "get_rings")
+        return r
+
+    def set_rings(self, r):
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        assert r.shape == (self.ncol, RING_SLOTS)
+        check(self.L.sipnet_batch_set_rings(self.h, r.ctypes.data, self._stream()), "set_rings")
+
+    def checkpoint(self):
+        """Complete per-member carried state: (state[ncol][32], rings[ncol][250])."""
+        return self.get_state(), self.get_rings()
+
+    def restore(self, ckpt):
+        self.set_state(ckpt[0])
+        self.set_rings(ckpt[1])
+
     def site_series(self, site):
         g = np.zeros(self.n_steps)
         d = np.zeros(self.n_steps)

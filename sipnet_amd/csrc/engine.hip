@@ -453,6 +453,32 @@ int sipnet_batch_get_ring(sipnet_batch* b, int64_t col, double* values, void* hi
   return SIPNET_OK;
 }
 
+int sipnet_batch_get_rings(sipnet_batch* b, double* rings, void* hip_stream) {
+  if (!b || !rings) return SIPNET_ERR_BAD_ARGUMENT;
+  int rc = useDevice(b);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize((hipStream_t)hip_stream));
+  std::vector<double> tmp((size_t)b->ncol * SIPNET_RING_SLOTS);
+  HIP_TRY(hipMemcpy(tmp.data(), b->d_ring, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+  for (int k = 0; k < SIPNET_RING_SLOTS; k++)
+    for (int64_t c = 0; c < b->ncol; c++)
+      rings[c * SIPNET_RING_SLOTS + k] = tmp[(size_t)k * b->ncol + c];
+  return SIPNET_OK;
+}
+
+int sipnet_batch_set_rings(sipnet_batch* b, const double* rings, void* hip_stream) {
+  if (!b || !rings) return SIPNET_ERR_BAD_ARGUMENT;
+  int rc = useDevice(b);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize((hipStream_t)hip_stream));
+  std::vector<double> tmp((size_t)b->ncol * SIPNET_RING_SLOTS);
+  for (int k = 0; k < SIPNET_RING_SLOTS; k++)
+    for (int64_t c = 0; c < b->ncol; c++)
+      tmp[(size_t)k * b->ncol + c] = rings[c * SIPNET_RING_SLOTS + k];
+  HIP_TRY(hipMemcpy(b->d_ring, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+  return SIPNET_OK;
+}
+
 int sipnet_batch_get_status(sipnet_batch* b, int32_t* status, void* hip_stream) {
   if (!b || !status) return SIPNET_ERR_BAD_ARGUMENT;
   int rc = useDevice(b);

@@ -1,0 +1,232 @@
+"""GPU tests of the batch engine beyond single-member parity: throughput kernel with events,
+chunked (segmented) runs, ragged member counts, several sites, per-member status codes,
+site-fatal plan errors, state round trips, fp32-mixed tolerance, ensemble statistics."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import sipnet_amd as sa
+from sipnet_amd import synth
+from sipnet_amd._lib import SipnetError
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+BASE = os.path.join(helpers.REPO, "sipnet_amd", "data", "base_forest.param")
+
+
+def make_batch(flags, clims, members, prec=sa.F64, events=None, fast=True):
+    os.environ["SIPNET_FAST_MATH"] = "1" if fast else "0"
+    b = sa.Batch(flags, len(clims), members.shape[0], prec)
+    for s, c in enumerate(clims):
+        if events is not None:
+            b.set_events(s, events)
+        b.set_climate(s, c)
+        b.set_params(s, members)
+    b.setup()
+    return b
+
+
+@pytest.fixture(scope="module")
+def base():
+    return sa.read_params(BASE, sa.flags_from())[0]
+
+
+@pytest.fixture(scope="module")
+def short_clim():
+    return synth.convert_raw(synth.round_like_file(synth.half_hourly_year_raw(48 * 40)))
+
+
+def test_throughput_kernel_with_events_matches_oracle(oracle, tmp_path):
+    """russell_1 = default flags + 108 irrigation events: the lean launch takes the fast
+    kernel's event path; perturbed members exercise per-member arithmetic."""
+    case = helpers.load_smoke_case("russell_1", str(tmp_path))
+    members = synth.perturbed_params(case["params"], 70, names={"aMax", "soilWHC", "wueConst", "baseVegResp"})
+    b = make_batch(case["flags"], [case["clim"]], members, events=case["events"])
+    planes, _ = b.run()
+    got = planes.cpu().numpy()
+    b.close()
+    want, _, st = oracle.run_block(case["flags"], members, case["clim"], case["events"])
+    assert (st == 0).all()
+    print("events, fast kernel: max|d|", np.abs(got - want).max())
+    assert np.abs(got - want).max() < 1e-9
+
+
+def test_other_event_types_on_both_kernels(oracle, base, short_clim):
+    """plant / harvest / fertilise / till / canopy irrigation on the default-flag model."""
+    ev = []
+    def add(day, typ, *p):
+        e = sa.Event(); e.type = typ; e.year = int(short_clim.year[0]); e.day = day
+        for i, v in enumerate(p): e.p[i] = v
+        ev.append(e)
+    add(3, 2, 1.5, 0)                      # canopy irrigation
+    add(5, 4, 0.4)                         # tillage
+    add(9, 1, 0.3, 0.2, 0.1, 0.1)          # harvest
+    add(9, 0, 2.0, 30.0, 1.0)              # fertiliser on the same day
+    add(20, 3, 40.0, 300.0, 50.0, 60.0)    # planting
+    add(30, 1, 1.0, 1.0, 0.0, 0.0)         # clear-cut: plant death
+    add(35, 3, 40.0, 300.0, 50.0, 60.0)    # replanting: revival with a fresh ring
+    members = synth.perturbed_params(base, 64)
+    flags = sa.flags_from()
+    want, final_o, st = oracle.run_block(flags, members, short_clim, ev)
+    assert (st == 0).all()
+    for fast in (False, True):
+        b = make_batch(flags, [short_clim], members, events=ev, fast=fast)
+        planes, _ = b.run()
+        got = planes.cpu().numpy()
+        state = b.get_state()
+        b.close()
+        d = np.abs(got - want).max()
+        print(f"fast={fast}: max|d| {d:.3e}; died at", state[0, 30])
+        assert d < 1e-9
+        assert state[0, 30] >= 0               # the clear-cut killed the stand ...
+        assert state[0, 0] > 100.0             # ... and the replanting brought wood back
+
+
+def test_segmented_run_equals_continuous(base, short_clim):
+    """Same guarantee as the reference's testSegmentedEquivalence (testRestartMVP.c:253-303):
+    stopping at any step boundary and continuing from the state in HBM changes nothing."""
+    members = synth.perturbed_params(base, 100)
+    for fast in (False, True):
+        b = make_batch(sa.flags_from(), [short_clim], members, fast=fast)
+        whole, _ = b.run()
+        whole = whole.cpu().numpy()
+        s_whole = b.get_state()
+        b.setup()
+        parts = []
+        for a, n in ((0, 7), (7, 500), (507, 1), (508, short_clim.n_steps - 508)):
+            p, _ = b.run(a, n)
+            parts.append(p.cpu().numpy())
+        seg = np.concatenate(parts, axis=1)
+        s_seg = b.get_state()
+        b.close()
+        assert np.array_equal(seg, whole), f"fast={fast}"
+        assert np.array_equal(s_seg, s_whole)
+
+
+def test_ragged_members_and_multiple_sites(oracle, base):
+    """Member counts that do not fill a wavefront, and 3 / 8 sites (8 takes the XCD-grouped
+    block mapping) with different forcing per site."""
+    flags = sa.flags_from()
+    for n_sites, n_mem in ((3, 37), (8, 65), (1, 1)):
+        clims = [synth.convert_raw(synth.round_like_file(synth.half_hourly_year_raw(48 * 12, site=s)))
+                 for s in range(n_sites)]
+        members = synth.perturbed_params(base, n_mem)
+        b = make_batch(flags, clims, members)
+        planes, _ = b.run()
+        got = planes.cpu().numpy().reshape(3, -1, n_sites, n_mem)
+        b.close()
+        for s in range(n_sites):
+            want, _, _ = oracle.run_block(flags, members, clims[s])
+            assert np.abs(got[:, :, s, :] - want).max() < 1e-9, (n_sites, n_mem, s)
+
+
+def test_bad_member_gets_status_instead_of_killing_the_batch(oracle, base, short_clim):
+    members = synth.perturbed_params(base, 10)
+    members[4, sa.config.param_index("leafAllocation")] = 0.8
+    members[4, sa.config.param_index("woodAllocation")] = 0.5     # sum > 1: sipnet.c:1117-1122
+    b = make_batch(sa.flags_from(), [short_clim], members)
+    planes, _ = b.run()
+    st = b.get_status()
+    got = planes.cpu().numpy()
+    b.close()
+    assert list(st) == [0, 0, 0, 0, 3, 0, 0, 0, 0, 0]
+    want, _, so = oracle.run_block(sa.flags_from(), members, short_clim)
+    assert so[4] == 3
+    ok = [m for m in range(10) if m != 4]
+    assert np.abs(got[:, :, ok] - want[:, :, ok]).max() < 1e-9
+
+
+def test_site_fatal_conditions_return_reference_exit_codes(base):
+    flags = sa.flags_from()
+    raw = synth.round_like_file(synth.half_hourly_year_raw(48 * 8))
+    # steps shorter than 28.8 min overflow the 250-slot running mean (sipnet.c:1562-1569 -> 7)
+    r2 = dict(raw); r2["length"] = np.full(len(raw["year"]), -600.0)
+    b = sa.Batch(flags, 1, 4)
+    b.set_climate(0, synth.convert_raw(r2)); b.set_params(0, base)
+    with pytest.raises(SipnetError) as e:
+        b.setup()
+    assert e.value.code == 7
+    b.close()
+    # non-positive step length (events.c:460-465 -> 3)
+    c = synth.convert_raw(raw); c.data[5, 0] = 0.0
+    b = sa.Batch(flags, 1, 4); b.set_climate(0, c); b.set_params(0, base)
+    with pytest.raises(SipnetError) as e:
+        b.setup()
+    assert e.value.code == 3
+    b.close()
+    # an event before the first climate record (frontend.c:216-223 -> 5)
+    ev = sa.Event(); ev.type = 2; ev.year = int(raw["year"][0]) - 1; ev.day = 200; ev.p[0] = 1.0
+    b = sa.Batch(flags, 1, 4); b.set_events(0, [ev]); b.set_climate(0, synth.convert_raw(raw)); b.set_params(0, base)
+    with pytest.raises(SipnetError) as e:
+        b.setup()
+    assert e.value.code == 5
+    b.close()
+
+
+def test_state_round_trip_and_transplant(base, short_clim):
+    """checkpoint / restore (state vector + ring block = what restart.c persists per member):
+    rewinding a batch, or moving the checkpoint into a fresh batch, continues identically."""
+    members = synth.perturbed_params(base, 33)
+    b1 = make_batch(sa.flags_from(), [short_clim], members, fast=False)
+    b1.run(0, 600, want_planes=False)
+    ck = b1.checkpoint()
+    rest1, _ = b1.run(600, 300)
+    b1.restore(ck)                            # rewind
+    rest2, _ = b1.run(600, 300)
+    assert torch.equal(rest1, rest2)
+    b2 = make_batch(sa.flags_from(), [short_clim], members, fast=True)
+    b2.restore(ck)                            # transplant into another batch / kernel
+    rest3, _ = b2.run(600, 300)
+    assert (rest3 - rest1).abs().max().item() < 1e-9
+    b1.close(); b2.close()
+
+
+def test_fp32_mixed_tolerance(oracle, base):
+    """SIPNET_F32_MIXED: fluxes in fp32, pools fp64.  Stated bound: |dNEE| < 2e-6 gC m-2 per
+    half-hourly step, yearly NEE sum within 0.5 gC m-2 of the fp64 oracle."""
+    clim = synth.convert_raw(synth.round_like_file(synth.half_hourly_year_raw(17520)))
+    members = synth.perturbed_params(base, 64)
+    b = make_batch(sa.flags_from(), [clim], members, prec=sa.F32_MIXED)
+    planes, _ = b.run()
+    assert planes.dtype == torch.float32
+    got = planes.double().cpu().numpy()
+    b.close()
+    want, _, _ = oracle.run_block(sa.flags_from(), members, clim)
+    d = np.abs(got - want)
+    print("fp32-mixed: max|dNEE| %.3e  max|dGPP| %.3e  max|dET| %.3e  max|d sum NEE| %.3e" % (
+        d[0].max(), d[1].max(), d[2].max(), np.abs(got[0].sum(0) - want[0].sum(0)).max()))
+    assert d[0].max() < 2e-6 and d[1].max() < 2e-6 and d[2].max() < 2e-6
+    assert np.abs(got[0].sum(0) - want[0].sum(0)).max() < 0.5
+
+
+def test_reduce_plane_ensemble_statistics(base, short_clim):
+    members = synth.perturbed_params(base, 200)
+    clims = [short_clim, short_clim.slice(0, short_clim.n_steps)]
+    b = make_batch(sa.flags_from(), clims, members)
+    planes, _ = b.run()
+    stats = b.reduce_plane(planes[0]).cpu().numpy()
+    p = planes[0].cpu().numpy().reshape(-1, 2, 200)
+    b.close()
+    assert np.allclose(stats[:, :, 0], p.sum(-1), rtol=1e-12, atol=1e-12)
+    assert np.allclose(stats[:, :, 1], (p * p).sum(-1), rtol=1e-12, atol=1e-12)
+
+
+def test_full_size_properties_10k_members(base):
+    """BASELINE size (10240 members x 17520 steps): checks that need no oracle run -- member 0
+    is the unperturbed base and must equal a 1-member batch bit for bit; duplicated parameter
+    rows give duplicated outputs wherever they sit in a wavefront; NEE sums are finite."""
+    clim = synth.convert_raw(synth.round_like_file(synth.half_hourly_year_raw(17520)))
+    members = synth.perturbed_params(base, 10240)
+    members[5000] = members[77]
+    members[10239] = members[64]
+    b = make_batch(sa.flags_from(), [clim], members)
+    planes, _ = b.run()
+    b1 = make_batch(sa.flags_from(), [clim], members[:1])
+    p1, _ = b1.run()
+    assert torch.equal(planes[:, :, 0], p1[:, :, 0])
+    assert torch.equal(planes[:, :, 5000], planes[:, :, 77])
+    assert torch.equal(planes[:, :, 10239], planes[:, :, 64])
+    assert bool(torch.isfinite(planes).all())
+    b.close(); b1.close()
