@@ -35,6 +35,7 @@ struct sipnet_batch {
   int64_t ncol = 0;
   int32_t n_steps = 0;  // steps per site (all sites equal)
   bool fastMath = false;
+  bool genericExponents = false;  // some member has dVpdExp != 2 or soilRespMoistEffect != 1
 
   // host-side inputs kept so the plan can be rebuilt in any call order
   std::vector<std::vector<double>> clim;       // per site [n_steps*NCLIM]
@@ -282,6 +283,10 @@ int sipnet_batch_set_params(sipnet_batch* b, int32_t site, int32_t first_member,
   }
   int rc = useDevice(b);
   if (rc) return rc;
+  for (int32_t m = 0; m < count; m++) {
+    const double* r = raw + (size_t)m * SIPNET_NPARAMS;
+    if (r[SP_dVpdExp] != 2.0 || r[SP_soilRespMoistEffect] != 1.0) b->genericExponents = true;
+  }
   const int64_t col0 = (int64_t)site * b->n_members + first_member;
   HIP_TRY(hipMemcpy(b->d_raw + col0 * SIPNET_NPARAMS, raw,
                     (size_t)count * SIPNET_NPARAMS * sizeof(double), hipMemcpyHostToDevice));
@@ -378,7 +383,7 @@ int sipnet_batch_run(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_ne
     f.n_steps_total = b->n_steps;
     f.step0 = step0;
     f.n_steps = n_steps;
-    f.dbg = getenv("SIPNET_DBG") ? atoi(getenv("SIPNET_DBG")) : 0;
+    f.plainExp = b->genericExponents ? 0 : 1;
     launchStepFast(f, b->precision, stream);
   } else {
     launchStep(a, b->precision, b->fastMath, stream);

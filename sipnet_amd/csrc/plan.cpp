@@ -220,7 +220,6 @@ std::vector<FastRec> buildFastRecs(const SitePlan& plan) {
     f.tsoil = s.tsoil;
     f.negPar = -s.par;
     f.vpd = s.vpd;
-    f.vpd2 = s.vpd * s.vpd;
     f.rainRate = s.rainRate;
     f.sublW = s.sublNum * s.wspd;
     f.evapNum = s.evapNum;

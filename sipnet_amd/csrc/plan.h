@@ -75,7 +75,7 @@ static_assert(sizeof(EvRec) == 40, "EvRec layout");
 struct FastRec {
   // ---- hot: bytes 0..143 ----
   double len, invLen, tair, tsoil;           //  0.. 3
-  double negPar, vpd, vpd2, rainRate;        //  4.. 7  -par, vpd, vpd*vpd, precip/len
+  double negPar, vpd, tillP1, rainRate;      //  4.. 7  -par, vpd, 1 + d_till_mod, precip/len
   double sublW, evapNum, invWspd, tair10;    //  8..11  CONV_S*(0.6-vPress)*wspd, CONV*vpdSoil, 1/wspd
   double tsoil10, cumGdd, dayTime, w0;       // 12..15  w0: weight of the first ring eviction
   int32_t bitsOps;   // FAST_* flag bits | (number of ring evictions << 16)
@@ -84,7 +84,7 @@ struct FastRec {
   int32_t evCount;   // events on this record
   // ---- rare: read only under a flag ----
   double w1;         // weight of the second eviction (FAST_HAS_W1)
-  double tillP1;     // 1 + d_till_mod (FAST_HAS_TILL)
+  double spareD;
   double log2vpd;    // for members whose dVpdExp is not 2
   double gddAfter, tillAfter;
   int32_t ins0, ins1;  // steps that wrote slot0 / slot1 (dead-member epochs)

@@ -111,7 +111,13 @@ __device__ unsigned long long g_stamps[16];
 }  // namespace
 
 // -------------------------------------------------------------------------------
-template <class R>
+// A lone wavefront cannot hide the instruction-fetch restart after a taken branch (measured:
+// ~31 branch instructions per step cost about a third of the step).  The step is therefore
+// written branch-light: per-lane conditions become selects, rare paths (events, phenology
+// switches, mortality, irregular ring steps) hide behind ONE wave-uniform test each, and the
+// only common-path branches are the day/night test, the snow / bare-soil evaporation split
+// and the Q10 reuse test.
+template <class R, bool PlainExp>
 __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
   // LDS: two tiles of kFastTile site records (2 x 4 KB).  ONE __shared__ object.
   __shared__ alignas(16) unsigned char lds[2 * kFastTile * sizeof(FastRec)];
@@ -174,7 +180,8 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
   const R K_la = (R)PRM(leafAllocation), K_wa = (R)PRM(woodAllocation);
   const R K_fa = (R)PRM(fineRootAllocation), K_ca = (R)PRM(coarseRootAllocation);
   const R K_moistExp = (R)PRM(soilRespMoistEffect);
-  const double gddLeafOn = PRM(gddLeafOn), leafOffDay = PRM(leafOffDay);
+  const double gddLeafOn = PRM(gddLeafOn);
+  const double leafOffDay = PRM(leafOffDay) > 0 ? PRM(leafOffDay) : 1e300;  // "never" (sipnet.c:735)
   // rarely needed parameters are re-read from HBM inside their (rare) branches
 #define PRM_RARE(name) ((R)pp[(int64_t)SP_##name * nc])
 
@@ -199,9 +206,11 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
   const unsigned char* __restrict__ planBytes =
       (const unsigned char*)(a.fast + (int64_t)site * a.n_steps_total);
   double* __restrict__ ringp = a.ring + col;
-  R* __restrict__ oNee = a.nee ? (R*)a.nee + col : nullptr;
-  R* __restrict__ oGpp = a.gpp ? (R*)a.gpp + col : nullptr;
-  R* __restrict__ oEt = a.et ? (R*)a.et + col : nullptr;
+  R* __restrict__ oNee = (R*)a.nee + col;
+  R* __restrict__ oGpp = (R*)a.gpp + col;
+  R* __restrict__ oEt = (R*)a.et + col;
+  const bool wantNee = a.nee != nullptr, wantGpp = a.gpp != nullptr, wantEt = a.et != nullptr;
+  const bool allOut = wantNee && wantGpp && wantEt;
 
   // ---- tile staging: async global -> LDS, 16 B per lane, 4 pieces per 4 KB tile ----
   constexpr int kTileBytes = kFastTile * (int)sizeof(FastRec);
@@ -227,11 +236,19 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
   const uint32_t ncu = (uint32_t)nc;  // ring element offsets fit 32 bits (250 * ncol < 2^31)
   int curTile = tBegin / kFastTile;
   stageTile(curTile, curTile & 1);
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
 
-  // ring values this step will evict; requested at the END of the previous step (ahead of
-  // that step's stores in the memory queue) and not touched until a whole step later
-  double rv0 = 0.0, rv1 = 0.0;
-  bool haveRv = false;
+  // ring values a step evicts are requested at the END of the previous step (ahead of that
+  // step's stores in the memory queue) and consumed a whole step later; the first step's are
+  // requested here
+  double rv0, rv1;
+  {
+    const int32_t slots0 = uni(*(const int32_t*)(lds + (curTile & 1) * kTileBytes +
+                                                 (int)(tBegin - tileFirst(curTile)) * (int)sizeof(FastRec) + 132));
+    rv0 = ringp[(uint32_t)(slots0 & 255) * ncu];
+    rv1 = ringp[(uint32_t)((slots0 >> 8) & 255) * ncu];
+  }
   // when the slot a step evicts is the very slot the previous step wrote, the value is taken
   // from that step's NPP register instead of memory (wave-uniform flags)
   double lastNpp = 0.0;
@@ -242,11 +259,12 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
   bool haveQ = false;
 
   for (int tileStart = curTile * kFastTile; tileStart < tEnd; tileStart += kFastTile, curTile++) {
-    // the tile staged one tile-time ago has long landed; drain, then stage the next one into
-    // the buffer the previous tile just vacated
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-    stageTile(curTile + 1, (curTile + 1) & 1);
+    if (tileStart > tBegin) {
+      // the tile staged one tile-time ago has long landed; drain before reading it
+      __builtin_amdgcn_s_waitcnt(0);
+      __syncthreads();
+    }
+    stageTile(curTile + 1, (curTile + 1) & 1);  // into the buffer the previous tile vacated
     const int tFirst = tileStart > tBegin ? tileStart : tBegin;
     const int tLast = (tileStart + kFastTile) < tEnd ? (tileStart + kFastTile) : tEnd;
     const unsigned char* recB = lds + (curTile & 1) * kTileBytes +
@@ -259,7 +277,7 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
     const d2 q0 = rq[0], q1 = rq[1], q2 = rq[2], q3 = rq[3], q4 = rq[4], q5 = rq[5];
     const d2 q6 = rq[6], q7 = rq[7];
     const i4 j0 = *(const i4*)(recB + 128);
-    const double* rare = (const double*)(recB + 144);   // w1 tillP1 log2vpd gddAfter tillAfter
+    const double* rare = (const double*)(recB + 144);   // w1 - log2vpd gddAfter tillAfter
     const int32_t* rareI = (const int32_t*)(recB + 184);  // ins0 ins1 opFirst evFirst
 
     const R len = (R)q0.x, invLen = (R)q0.y, tair = (R)q1.x, tsoil = (R)q1.y;
@@ -267,18 +285,11 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
     const int slots = uni(j0.y);
     const int insSlot = uni(j0.z);
     const int nEv = uni(j0.w);
-    const int nOps = bits >> 16;
 
-    if (!haveRv) {  // first step of a launch only
-      rv0 = ringp[(uint32_t)(slots & 255) * ncu];
-      rv1 = ringp[(uint32_t)((slots >> 8) & 255) * ncu];
-      haveRv = true;
-    }
-
-    STAMP(0)  // record fetch
+    STAMP(0)
     // ---- 0. start of step (sipnet.c:1821-1828) -------------------------------------
-    bool alive = (plantWoodC > kTiny) && (plantWoodC + delta > kTiny) &&
-                 (fineRootC + coarseRootC > kTiny);
+    const bool alive0 = (plantWoodC > kTiny) && (plantWoodC + delta > kTiny) &&
+                        (fineRootC + coarseRootC > kTiny);
     const R eWood = (R)plantWoodC, eLeaf = (R)plantLeafC, eSoilC = (R)soilC;
     const R eWater = (R)soilWater, eSnow = (R)snow;
     const R eCoarse = (R)coarseRootC, eFine = (R)fineRootC;
@@ -291,95 +302,86 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
       return lim < R(1) ? flux * lim : flux;
     };
 
-    STAMP(1)
     // ---- 2. fluxes (sipnet.c:1256-1336) ---------------------------------------------
     const R lai = eLeaf * K_invLcsw;
-    // potPsn(), sipnet.c:590-641
-    const R dTemp = rmax0((K_tmax - tair) * (tair - K_tmin) * K_invDen);
-    const R vpdPow = (K_vexp == R(2)) ? (R)q3.x : fexp2(K_vexp * (R)rare[2], EC);
-    const R dVpd = rmax0(R(1) - K_slope * vpdPow);
-    R dLight = 0;
-    if ((bits & FAST_PAR_POS) && lai > R(0)) {
-      // calcLightEff(), sipnet.c:517-570: Simpson over 7 layers;
-      // sum c_i (1 - e_i) / 18 = 1 - (sum c_i e_i) / 18, c = 1 4 2 4 2 4 1
+    const R baseFolResp = K_rpg * lai;
+    const bool frozen = tsoil < K_frozThr;
+    // potPsn() + calcLightEff() + moisture(), sipnet.c:517-699: daytime only (uniform test);
+    // at night par = 0 makes potGrossPsn = 0, so transpiration = 0 and GPP = 0
+    R transpiration = 0, photosynthesis = 0;
+    if (bits & FAST_PAR_POS) {
+      const R dTemp = rmax0((K_tmax - tair) * (tair - K_tmin) * K_invDen);
+      R vpdPow = (R)q2.y * (R)q2.y;
+      if (!PlainExp) vpdPow = (K_vexp == R(2)) ? vpdPow : fexp2(K_vexp * (R)rare[2], EC);
+      const R dVpd = rmax0(R(1) - K_slope * vpdPow);
+      // Simpson over 7 canopy layers: sum c_i (1 - e_i) / 18 = 1 - (sum c_i e_i) / 18,
+      // c = 1 4 2 4 2 4 1.  lai = 0 needs no special case: potGrossPsn carries the factor lai.
       const R r1 = fexp2(K_attl * lai, EC);
       const R q = (R)q2.x * K_invHalf;
       const R r2 = r1 * r1, r3 = r2 * r1, r4 = r2 * r2, r5 = r4 * r1, r6 = r3 * r3;
       const R e0 = fexp2(q, EC), e1 = fexp2(q * r1, EC), e2 = fexp2(q * r2, EC), e3 = fexp2(q * r3, EC);
       const R e4 = fexp2(q * r4, EC), e5 = fexp2(q * r5, EC), e6 = fexp2(q * r6, EC);
       const R s = (e0 + e6) + R(4) * (e1 + e3 + e5) + R(2) * (e2 + e4);
-      dLight = R(1) - s * R(1.0 / 18.0);
-    }
-    const R potGrossPsn = K_g * lai * dTemp * dVpd * dLight;
-    const R baseFolResp = K_rpg * lai;
-
-    STAMP(2)
-    // moisture(), sipnet.c:656-699
-    R transpiration = 0, photosynthesis = potGrossPsn;
-    if (potGrossPsn >= R(kTiny)) {
+      const R dLight = R(1) - s * R(1.0 / 18.0);
+      const R potGrossPsn = K_g * lai * dTemp * dVpd * dLight;
+      // moisture(), sipnet.c:656-699, branch-free
       const R potTrans = potGrossPsn * (R)q2.y * K_tr;
       R removable = (eWater < K_whc ? eWater : K_whc) * K_wrf;
-      if (tsoil < K_frozThr) removable *= K_frozEff;
-      if (removable < potTrans) {
-        transpiration = removable;
-        photosynthesis = potGrossPsn * fdiv(removable, potTrans);
-      } else {
-        transpiration = potTrans;
-      }
+      removable = frozen ? removable * K_frozEff : removable;
+      const bool hasPsn = potGrossPsn >= R(kTiny);
+      const bool limited = removable < potTrans;
+      const R dWater = fdiv(removable, potTrans);  // only used where limited && hasPsn
+      transpiration = hasPsn ? (limited ? removable : potTrans) : R(0);
+      photosynthesis = (hasPsn && limited) ? potGrossPsn * dWater : potGrossPsn;
     }
+    STAMP(1)
 
-    // calcPrecip(), sipnet.c:848-882 (uniform branch on the site's air temperature)
+    // calcPrecip(), sipnet.c:848-882 (the site's air temperature decides rain or snow)
     const bool tairPos = (bits & FAST_TAIR_POS) != 0;
     const R rate = (R)q3.y;
     const R rain = tairPos ? rate : R(0), snowFall = tairPos ? R(0) : rate;
     const R immedEvap = rain * K_immed;
     const R netRain = rain - immedEvap;
 
-    // snowPack(), sipnet.c:888-946
-    R snowMelt = 0, sublimation = 0;
-    if (eSnow > R(0)) {
-      sublimation = rmax0((R)q4.x * K_invRd);
+    // snowPack() sipnet.c:888-946 and bare-soil evaporation sipnet.c:984-1016: a member either
+    // has a snow pack or evaporates from the soil
+    R snowMelt = 0, sublimation = 0, evaporationPot = 0;
+    const bool hasSnow = eSnow > R(0);
+    if (hasSnow) {
+      R subl = rmax0((R)q4.x * K_invRd);
       R remaining = eSnow + snowFall * len;
-      if (remaining - sublimation * len < R(0)) {
-        sublimation = remaining * invLen;
-        remaining = 0;
-      } else {
-        remaining -= sublimation * len;
-      }
-      if (tairPos) {
-        snowMelt = K_melt * tair;
-        if (remaining - snowMelt * len < R(0)) snowMelt = remaining * invLen;
-      }
+      const bool allGone = remaining - subl * len < R(0);
+      subl = allGone ? remaining * invLen : subl;
+      remaining = allGone ? R(0) : remaining - subl * len;
+      R melt = tairPos ? K_melt * tair : R(0);
+      melt = (tairPos && (remaining - melt * len < R(0))) ? remaining * invLen : melt;
+      sublimation = subl;
+      snowMelt = melt;
+    } else {
+      const R wf = clip01(eWater * K_invWhc);
+      const R rsoil = fexp2(K_c1l - K_c2l * wf, EC);
+      evaporationPot = rmax0(fdiv((R)q4.y, K_rd * (R)q5.x + rsoil));
     }
-
     // calcSoilWaterFluxes(), sipnet.c:963-1031
-    R evaporation = 0, drainage = 0, fastFlow;
+    R evaporation, drainage, fastFlow;
     {
       R netIn = netRain + snowMelt;
       fastFlow = netIn * K_ff;
       netIn -= fastFlow;
       R remaining = eWater + netIn * len - transpiration * len;
-      if (!(eSnow > R(0))) {
-        const R wf = clip01(eWater * K_invWhc);
-        const R rsoil = fexp2(K_c1l - K_c2l * wf, EC);
-        evaporation = rmax0(fdiv((R)q4.y, K_rd * (R)q5.x + rsoil));
-        if (remaining - evaporation * len < R(kTiny)) {
-          evaporation = (remaining - R(kTiny)) * invLen;
-          remaining = 0;
-        } else {
-          remaining -= evaporation * len;
-        }
-      }
-      if (remaining > K_whc) drainage = (remaining - K_whc) * invLen;
+      const bool dryOut = !hasSnow && (remaining - evaporationPot * len < R(kTiny));
+      evaporation = dryOut ? (remaining - R(kTiny)) * invLen : evaporationPot;
+      remaining = hasSnow ? remaining : (dryOut ? R(0) : remaining - evaporationPot * len);
+      drainage = remaining > K_whc ? (remaining - K_whc) * invLen : R(0);
     }
+    STAMP(2)
 
     const R meanNpp = (R)(ringSum * 0.2);  // runmean.c:119-121 (sum / 5)
 
-    STAMP(3)
     // vegResp(), sipnet.c:1051-1068
     const R vegQ = fexp2((R)q5.y * K_lgVeg, EC);
     R folResp = baseFolResp * (vegQ * K_folShift);
-    if (tsoil < K_frozThr) folResp *= K_frozFolEff;
+    folResp = frozen ? folResp * K_frozFolEff : folResp;
     const R rVeg = folResp + K_bvr * totalWoodC * vegQ;
 
     // calcWoodAndLeafFluxes(), sipnet.c:756-782
@@ -387,19 +389,26 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
     R leafLitter = eLeaf * K_ltr;
     R leafCreation = meanNpp * K_la, woodCreation = meanNpp * K_wa;
 
-    // calcLeafOnOffFluxes(), sipnet.c:800-842 (GDD phenology, sipnet.c:705-716)
+    // calcLeafOnOffFluxes(), sipnet.c:800-842 (GDD phenology, sipnet.c:705-716): the two
+    // switches fire once a year each; one combined test keeps them off the common path
     R leafOnCreation = 0, leafOnFromWood = 0;
     if (bits & FAST_PHEN_NEW_YEAR) phenBits = 0;
-    if (!(phenBits & 1) && q6.y >= gddLeafOn) {
-      const R leafOn = leafOnLimit(PRM_RARE(leafGrowth) * invLen);
-      leafOnCreation = leafOn;
-      const R src = eWood + eCoarse;
-      if (src > R(kTiny)) leafOnFromWood = fdiv(leafOn * eWood, src);
-      phenBits |= 1;
-    }
-    if (!(phenBits & 2) && leafOffDay > 0 && q7.x >= leafOffDay) {
-      leafLitter += (eLeaf * PRM_RARE(fracLeafFall)) * invLen;
-      phenBits |= 2;
+    {
+      const bool doOn = !(phenBits & 1) && q6.y >= gddLeafOn;
+      const bool doOff = !(phenBits & 2) && q7.x >= leafOffDay;
+      if (__builtin_expect(doOn || doOff, 0)) {
+        if (doOn) {
+          const R leafOn = leafOnLimit(PRM_RARE(leafGrowth) * invLen);
+          leafOnCreation = leafOn;
+          const R src = eWood + eCoarse;
+          if (src > R(kTiny)) leafOnFromWood = fdiv(leafOn * eWood, src);
+          phenBits |= 1;
+        }
+        if (doOff) {
+          leafLitter += (eLeaf * PRM_RARE(fracLeafFall)) * invLen;
+          phenBits |= 2;
+        }
+      }
     }
 
     // roots, sipnet.c:1176-1196; soil-temperature Q10 factors (depeffects.c:71-74)
@@ -416,42 +425,32 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
     const R rFineRoot = K_bfr * eFine * qFine;
 
     // calcSoilRespiration(), sipnet.c:1132-1148 with depeffects.c:23-87
-    R moistEff = 1;
-    if (!(bits & FAST_TSOIL_NEG)) {
-      const R f_whc = clip01(eWater * K_invWhc);
-      moistEff = (K_moistExp == R(1)) ? f_whc : fpow(f_whc, K_moistExp);
-    }
-    R rSoil = eSoilC * K_bsr * moistEff * qSoil;
-    if (bits & FAST_HAS_TILL) rSoil *= (R)rare[1];
+    R moistEff = clip01(eWater * K_invWhc);
+    if (!PlainExp) moistEff = (K_moistExp == R(1)) ? moistEff : fpow(moistEff, K_moistExp);
+    moistEff = (bits & FAST_TSOIL_NEG) ? R(1) : moistEff;
+    const R rSoil = eSoilC * K_bsr * moistEff * qSoil * (R)q3.x;
 
-    // checkNegativeCreation(), limitations.c:146-182
+    // checkNegativeCreation(), limitations.c:146-182, as selects
     {
       const R leafDeficit = eLeaf * invLen + leafCreation - eLeaf * K_ltr;
-      if (leafDeficit < R(0)) {
-        woodCreation += leafDeficit;
-        leafCreation -= leafDeficit;
-      }
+      const R ld = leafDeficit < R(0) ? leafDeficit : R(0);
+      woodCreation += ld;
+      leafCreation -= ld;
       const R fineDef = eFine * invLen + fineRootCreation - fineRootLoss;
       const R coarseDef = eCoarse * invLen + coarseRootCreation - coarseRootLoss;
-      if ((fineDef < R(0)) != (coarseDef < R(0))) {
-        if (fineDef < R(0)) {
-          coarseRootCreation += fineDef;
-          fineRootCreation -= fineDef;
-        }
-        if (coarseDef < R(0)) {
-          fineRootCreation += coarseDef;
-          coarseRootCreation -= coarseDef;
-        }
-      }
+      const bool fNeg = fineDef < R(0), cNeg = coarseDef < R(0);
+      const R shift = (fNeg != cNeg) ? (fNeg ? fineDef : -coarseDef) : R(0);
+      coarseRootCreation += shift;   // fine deficit is taken from coarse roots (shift < 0) ...
+      fineRootCreation -= shift;     // ... a coarse deficit from fine roots (shift > 0)
     }
+    STAMP(3)
 
-    STAMP(4)
     // ---- 1+3a. events (events.c:449-742) and their pool updates (events.c:744-790).  Event
     // fluxes only depend on the start-of-step pools and, without the N cycle, feed nothing but
     // the pools and ET, so they are evaluated here, off the common path.  Tillage is folded
     // into the plan.
     R evEvap = 0;
-    if (nEv > 0) {
+    if (__builtin_expect(nEv > 0, 0)) {
       R evLeafC = 0, evWoodC = 0, evFineRootC = 0, evCoarseRootC = 0, evSoilWater = 0;
       R evSoilC = 0, evLeafOnCreation = 0, evLeafOnFromWood = 0, evLeafOffLitter = 0;
       const int ev0 = uni(rareI[3]);
@@ -513,23 +512,26 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
       fineRootC += (double)((fineRootCreation - fineRootLoss) * len);
     }
 
-    // checkForMortality(), sipnet.c:1688-1767
+    // checkForMortality(), sipnet.c:1688-1767: only a change of the alive flag does anything
+    bool alive = alive0;
     {
       const bool sufficient = (plantWoodC > kTiny) && (plantWoodC + delta > kTiny) &&
                               (fineRootC + coarseRootC > kTiny);
-      if (!alive) {
-        if (sufficient) alive = true;
-      } else if (!sufficient) {
-        alive = false;
-        if (diedAt < 0) diedAt = t;
-        soilC += fineRootC + coarseRootC;
-        soilC += plantWoodC + plantLeafC + delta;
-        plantWoodC = 0.0;
-        plantLeafC = 0.0;
-        coarseRootC = 0.0;
-        fineRootC = 0.0;
-        delta = 0.0;
-        ringSum = 0.0;
+      if (__builtin_expect(sufficient != alive0, 0)) {
+        if (!alive0) {
+          alive = true;  // it is back (planting)
+        } else {
+          alive = false;
+          if (diedAt < 0) diedAt = t;
+          soilC += fineRootC + coarseRootC;
+          soilC += plantWoodC + plantLeafC + delta;
+          plantWoodC = 0.0;
+          plantLeafC = 0.0;
+          coarseRootC = 0.0;
+          fineRootC = 0.0;
+          delta = 0.0;
+          ringSum = 0.0;
+        }
       }
     }
     // ensureNonNegativeStocks(), sipnet.c:1368-1397
@@ -541,8 +543,8 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
     fineRootC = fineRootC < 0.0 ? 0.0 : fineRootC;
     soilWater = soilWater < 0.0 ? 0.0 : soilWater;
     snow = snow < kTiny ? 0.0 : snow;
+    STAMP(4)
 
-    STAMP(5)
     // ---- 4. outputs: updateTrackers(), sipnet.c:1420-1496 ---------------------------
     const R tGpp = photosynthesis * len;
     const R tRh = rSoil * len;
@@ -554,54 +556,63 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
 
     // ---- 5. running mean of NPP (sipnet.c:1546-1570, runmean.c:61-116 via the plan) ----
     const double npp = (double)(photosynthesis - rVeg - rCoarseRoot - rFineRoot);
-    if (alive) {
-      if (insSlot < 0) {
-        ringSum = npp * 5.0;
-      } else {
-        double v0 = useLast0 ? lastNpp : rv0;
-        double v1 = useLast1 ? lastNpp : rv1;
-        if (ringValidFrom > 0) {  // a member that died earlier: older slots count as zero
-          if (uni(rareI[0]) < ringValidFrom) v0 = 0.0;
-          if (uni(rareI[1]) < ringValidFrom) v1 = 0.0;
-        }
+    STAMP(5)
+    {
+      const double v0 = useLast0 ? lastNpp : rv0;
+      const int nOps = bits >> 16;
+      // regular step: every lane alive with an untouched ring epoch, one eviction, plain insert
+      const bool irregular = __builtin_amdgcn_ballot_w64(!alive || ringValidFrom > 0) != 0 ||
+                             insSlot < 0 || nOps != 1;
+      if (__builtin_expect(!irregular, 1)) {
         ringSum = ffma(-q7.y, v0, ringSum);
-        if (bits & FAST_HAS_W1) ringSum = ffma(-rare[0], v1, ringSum);
-        if (nOps > 2) {
-          const int opFirst = uni(rareI[2]);
+        ringSum = ffma(npp, (double)len, ringSum);
+      } else if (alive) {
+        if (insSlot < 0) {
+          ringSum = npp * 5.0;
+        } else {
+          double w0v = v0, w1v = useLast1 ? lastNpp : rv1;
+          if (ringValidFrom > 0) {  // a member that died earlier: older slots count as zero
+            if (uni(rareI[0]) < ringValidFrom) w0v = 0.0;
+            if (uni(rareI[1]) < ringValidFrom) w1v = 0.0;
+          }
+          ringSum = ffma(-q7.y, w0v, ringSum);
+          ringSum = ffma(-rare[0], w1v, ringSum);  // w1 = 0 when there is no second eviction
           for (int k = 2; k < nOps; k++) {
-            const RingOp& op = a.ringOps[opFirst + k];
+            const RingOp& op = a.ringOps[uni(rareI[2]) + k];
             const double v = (uni(op.insStep) >= ringValidFrom)
                                  ? ringp[(uint32_t)uni(op.slot) * ncu] : 0.0;
             ringSum = ffma(-op.w, v, ringSum);
           }
+          ringSum = ffma(npp, (double)len, ringSum);
         }
-        ringSum = ffma(npp, (double)len, ringSum);
+      } else {
+        ringValidFrom = t + 1;
       }
-    } else {
-      ringValidFrom = t + 1;
     }
+    STAMP(6)
     // request the values the NEXT step evicts, then store: loads ahead of stores in the queue
     const int insEff = insSlot < 0 ? 0 : insSlot;
     const int pfSlot0 = (slots >> 16) & 255, pfSlot1 = (slots >> 24) & 255;
-    if (!(a.dbg & 4)) {
-      rv0 = ringp[(uint32_t)pfSlot0 * ncu];
-      rv1 = ringp[(uint32_t)pfSlot1 * ncu];
-    }
+    rv0 = ringp[(uint32_t)pfSlot0 * ncu];
+    rv1 = ringp[(uint32_t)pfSlot1 * ncu];
     useLast0 = (pfSlot0 == insEff);  // the slot being written right now (uniform test);
     useLast1 = (pfSlot1 == insEff);  // consumed a whole step later, no wait here
     lastNpp = npp;
     if (act) {
-      if (!(a.dbg & 1)) {
-        if (oNee) oNee[outOff] = tNee;
-        if (oGpp) oGpp[outOff] = tGpp;
-        if (oEt) oEt[outOff] = tEt;
+      if (__builtin_expect(allOut, 1)) {
+        oNee[outOff] = tNee;
+        oGpp[outOff] = tGpp;
+        oEt[outOff] = tEt;
+      } else {
+        if (wantNee) oNee[outOff] = tNee;
+        if (wantGpp) oGpp[outOff] = tGpp;
+        if (wantEt) oEt[outOff] = tEt;
       }
-      if (alive && !(a.dbg & 2)) ringp[(uint32_t)insEff * ncu] = npp;
+      if (alive) ringp[(uint32_t)insEff * ncu] = npp;
     }
     outOff += a.ld;
-    STAMP(6)
-  }  // steps of this tile
     STAMP(7)
+  }  // steps of this tile
   }  // tiles
 
 #ifdef SIPNET_STAMPS
@@ -642,9 +653,11 @@ void launchStepFast(const FastArgs& a, int precision, hipStream_t stream) {
   const int chunksPerSite = (a.n_members + 63) / 64;
   const int grid = a.n_sites * chunksPerSite;
   if (precision == SIPNET_F64) {
-    hipLaunchKernelGGL(stepFastKernel<double>, dim3(grid), dim3(64), 0, stream, a);
+    if (a.plainExp) hipLaunchKernelGGL((stepFastKernel<double, true>), dim3(grid), dim3(64), 0, stream, a);
+    else hipLaunchKernelGGL((stepFastKernel<double, false>), dim3(grid), dim3(64), 0, stream, a);
   } else {
-    hipLaunchKernelGGL(stepFastKernel<float>, dim3(grid), dim3(64), 0, stream, a);
+    if (a.plainExp) hipLaunchKernelGGL((stepFastKernel<float, true>), dim3(grid), dim3(64), 0, stream, a);
+    else hipLaunchKernelGGL((stepFastKernel<float, false>), dim3(grid), dim3(64), 0, stream, a);
   }
 }
 

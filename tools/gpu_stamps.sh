@@ -24,7 +24,7 @@ for prec, name in ((sa.F64, "f64"),):
     sa.lib().sipnet_debug_read_stamps.argtypes = [C.c_void_p]
     print("rc", sa.lib().sipnet_debug_read_stamps(st))
     v = np.array(list(st), dtype=float)
-    names = ["record fetch", "start+events", "potPsn+light", "water", "resp+alloc", "pools", "trackers+ring+stores", "tile turnover"]
+    names = ["record fetch", "start", "potPsn+light", "water", "resp..clamps", "trackers", "ring consume (wait)", "next loads+stores"]
     print(name, "kernel ms", b.last_kernel_ms(), "cycles/step total", v.sum() / T)
     for n, x in zip(names, v):
         print("  %-22s %8.1f cycles/step  %5.1f%%" % (n, x / T, 100 * x / v.sum()))
