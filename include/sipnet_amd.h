@@ -173,7 +173,8 @@ int sipnet_batch_setup(sipnet_batch *b, void *hip_stream);
  *
  * d_nee/d_gpp/d_et: DEVICE pointers (or NULL) to planes [n_steps][ld] written
  * as plane[t * ld + col]; element type double for SIPNET_F64, float for
- * SIPNET_F32_MIXED; ld >= n_sites*n_members.
+ * SIPNET_F32_MIXED; ld >= n_sites*n_members.  Plane entries of members whose status is
+ * non-zero (skipped members) are undefined.
  * d_rec: DEVICE pointer (or NULL) to [n_steps][SIPNET_NREC][ld] doubles
  * (full record, for `.out` text and checkpoints). */
 int sipnet_batch_run(sipnet_batch *b, int32_t step0, int32_t n_steps,

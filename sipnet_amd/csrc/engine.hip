@@ -52,6 +52,7 @@ struct sipnet_batch {
   double* d_ring = nullptr;    // [RING_SLOTS][ncol]
   StepRec* d_plan = nullptr;   // [n_sites][n_steps]
   FastRec* d_fast = nullptr;   // [n_sites][n_steps] + kFastTile padding records
+  double* d_scratchRow = nullptr;  // [ncol]
   RingOp* d_ringOps = nullptr;
   EvRec* d_events = nullptr;
   int32_t* d_siteStatus = nullptr;
@@ -198,6 +199,7 @@ int sipnet_batch_create(const int32_t* flags, int32_t n_sites, int32_t n_members
   if (e == hipSuccess) e = hipMalloc(&b->d_state, nc * SIPNET_NSTATE * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&b->d_ring, nc * SIPNET_RING_SLOTS * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&b->d_siteStatus, n_sites * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMalloc(&b->d_scratchRow, nc * sizeof(double));
   if (e == hipSuccess) e = hipMemset(b->d_raw, 0, nc * SIPNET_NPARAMS * sizeof(double));
   if (e == hipSuccess) e = hipMemset(b->d_state, 0, nc * SIPNET_NSTATE * sizeof(double));
   if (e == hipSuccess) e = hipEventCreate(&b->ev0);
@@ -220,6 +222,7 @@ void sipnet_batch_destroy(sipnet_batch* b) {
   if (b->d_ring) (void)hipFree(b->d_ring);
   if (b->d_plan) (void)hipFree(b->d_plan);
   if (b->d_fast) (void)hipFree(b->d_fast);
+  if (b->d_scratchRow) (void)hipFree(b->d_scratchRow);
   if (b->d_ringOps) (void)hipFree(b->d_ringOps);
   if (b->d_events) (void)hipFree(b->d_events);
   if (b->d_siteStatus) (void)hipFree(b->d_siteStatus);
@@ -384,6 +387,7 @@ int sipnet_batch_run(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_ne
     f.step0 = step0;
     f.n_steps = n_steps;
     f.plainExp = b->genericExponents ? 0 : 1;
+    f.scratchRow = b->d_scratchRow;
     launchStepFast(f, b->precision, stream);
   } else {
     launchStep(a, b->precision, b->fastMath, stream);

@@ -206,11 +206,14 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
   const unsigned char* __restrict__ planBytes =
       (const unsigned char*)(a.fast + (int64_t)site * a.n_steps_total);
   double* __restrict__ ringp = a.ring + col;
-  R* __restrict__ oNee = (R*)a.nee + col;
-  R* __restrict__ oGpp = (R*)a.gpp + col;
-  R* __restrict__ oEt = (R*)a.et + col;
-  const bool wantNee = a.nee != nullptr, wantGpp = a.gpp != nullptr, wantEt = a.et != nullptr;
-  const bool allOut = wantNee && wantGpp && wantEt;
+  // Output planes: a plane the caller does not want is pointed at a one-row scratch buffer
+  // with stride 0, so the stores below need no test.  Lanes past the end of a site work on a
+  // copy of the site's last member and store identical values to its addresses; members with
+  // a non-zero status compute garbage, so their plane entries are undefined (documented).
+  R* __restrict__ oNee = (R*)(a.nee ? a.nee : a.scratchRow) + col;
+  R* __restrict__ oGpp = (R*)(a.gpp ? a.gpp : a.scratchRow) + col;
+  R* __restrict__ oEt = (R*)(a.et ? a.et : a.scratchRow) + col;
+  const int64_t ldNee = a.nee ? a.ld : 0, ldGpp = a.gpp ? a.ld : 0, ldEt = a.et ? a.ld : 0;
 
   // ---- tile staging: async global -> LDS, 16 B per lane, 4 pieces per 4 KB tile ----
   constexpr int kTileBytes = kFastTile * (int)sizeof(FastRec);
@@ -253,7 +256,6 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
   // from that step's NPP register instead of memory (wave-uniform flags)
   double lastNpp = 0.0;
   bool useLast0 = false, useLast1 = false;
-  int64_t outOff = 0;  // element offset of this step's row in the output planes
   // Q10 factors of the soil temperature, reused while tsoil does not change
   R qSoil = 0, qFine = 0, qCoarse = 0;
   bool haveQ = false;
@@ -598,19 +600,15 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
     useLast0 = (pfSlot0 == insEff);  // the slot being written right now (uniform test);
     useLast1 = (pfSlot1 == insEff);  // consumed a whole step later, no wait here
     lastNpp = npp;
-    if (act) {
-      if (__builtin_expect(allOut, 1)) {
-        oNee[outOff] = tNee;
-        oGpp[outOff] = tGpp;
-        oEt[outOff] = tEt;
-      } else {
-        if (wantNee) oNee[outOff] = tNee;
-        if (wantGpp) oGpp[outOff] = tGpp;
-        if (wantEt) oEt[outOff] = tEt;
-      }
-      if (alive) ringp[(uint32_t)insEff * ncu] = npp;
-    }
-    outOff += a.ld;
+    *oNee = tNee;
+    *oGpp = tGpp;
+    *oEt = tEt;
+    oNee += ldNee;
+    oGpp += ldGpp;
+    oEt += ldEt;
+    // a dead member's slot is never read as live data again (ringValidFrom), so the insert
+    // needs no alive test
+    ringp[(uint32_t)insEff * ncu] = npp;
     STAMP(7)
   }  // steps of this tile
   }  // tiles

@@ -90,6 +90,7 @@ struct FastArgs {
   void* et;
   int64_t ncol, ld;
   int32_t n_sites, n_members, n_steps_total, step0, n_steps;
+  void* scratchRow;  // [ncol] doubles: target of the stores of planes the caller left NULL
   int32_t plainExp;  // 1: every member has dVpdExp == 2 and soilRespMoistEffect == 1
 };
 void launchStepFast(const FastArgs& a, int precision, hipStream_t stream);
