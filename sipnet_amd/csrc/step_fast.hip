@@ -83,11 +83,13 @@ __device__ __forceinline__ double flog2(double x) { return log2(x); }
 __device__ __forceinline__ float flog2(float x) { return __builtin_amdgcn_logf(x); }
 __device__ __forceinline__ double fpow(double x, double y) { return pow(x, y); }
 __device__ __forceinline__ float fpow(float x, float y) { return powf(x, y); }
-template <class R> __device__ __forceinline__ R rmax0(R x) { return x > R(0) ? x : R(0); }
-template <class R> __device__ __forceinline__ R clip01(R x) {
-  x = x > R(0) ? x : R(0);
-  return x < R(1) ? x : R(1);
-}
+// one v_max / v_min each (operands are never NaN here)
+__device__ __forceinline__ double rminv(double a, double b) { return __builtin_fmin(a, b); }
+__device__ __forceinline__ float rminv(float a, float b) { return __builtin_fminf(a, b); }
+__device__ __forceinline__ double rmax0(double x) { return __builtin_fmax(x, 0.0); }
+__device__ __forceinline__ float rmax0(float x) { return __builtin_fmaxf(x, 0.0f); }
+__device__ __forceinline__ double clip01(double x) { return __builtin_fmin(__builtin_fmax(x, 0.0), 1.0); }
+__device__ __forceinline__ float clip01(float x) { return __builtin_fminf(__builtin_fmaxf(x, 0.0f), 1.0f); }
 
 __device__ __forceinline__ int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -328,7 +330,7 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
       const R potGrossPsn = K_g * lai * dTemp * dVpd * dLight;
       // moisture(), sipnet.c:656-699, branch-free
       const R potTrans = potGrossPsn * (R)q2.y * K_tr;
-      R removable = (eWater < K_whc ? eWater : K_whc) * K_wrf;
+      R removable = rminv(eWater, K_whc) * K_wrf;
       removable = frozen ? removable * K_frozEff : removable;
       const bool hasPsn = potGrossPsn >= R(kTiny);
       const bool limited = removable < potTrans;
@@ -392,26 +394,12 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
     R leafCreation = meanNpp * K_la, woodCreation = meanNpp * K_wa;
 
     // calcLeafOnOffFluxes(), sipnet.c:800-842 (GDD phenology, sipnet.c:705-716): the two
-    // switches fire once a year each; one combined test keeps them off the common path
+    // switches fire once a year each and only feed the pools; they are handled together with
+    // the events in the one rare block below
     R leafOnCreation = 0, leafOnFromWood = 0;
     if (bits & FAST_PHEN_NEW_YEAR) phenBits = 0;
-    {
-      const bool doOn = !(phenBits & 1) && q6.y >= gddLeafOn;
-      const bool doOff = !(phenBits & 2) && q7.x >= leafOffDay;
-      if (__builtin_expect(doOn || doOff, 0)) {
-        if (doOn) {
-          const R leafOn = leafOnLimit(PRM_RARE(leafGrowth) * invLen);
-          leafOnCreation = leafOn;
-          const R src = eWood + eCoarse;
-          if (src > R(kTiny)) leafOnFromWood = fdiv(leafOn * eWood, src);
-          phenBits |= 1;
-        }
-        if (doOff) {
-          leafLitter += (eLeaf * PRM_RARE(fracLeafFall)) * invLen;
-          phenBits |= 2;
-        }
-      }
-    }
+    const bool doOn = !(phenBits & 1) && q6.y >= gddLeafOn;
+    const bool doOff = !(phenBits & 2) && q7.x >= leafOffDay;
 
     // roots, sipnet.c:1176-1196; soil-temperature Q10 factors (depeffects.c:71-74)
     const R coarseRootLoss = K_crt * eCoarse, fineRootLoss = K_frt * eFine;
@@ -435,7 +423,7 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
     // checkNegativeCreation(), limitations.c:146-182, as selects
     {
       const R leafDeficit = eLeaf * invLen + leafCreation - eLeaf * K_ltr;
-      const R ld = leafDeficit < R(0) ? leafDeficit : R(0);
+      const R ld = rminv(leafDeficit, R(0));
       woodCreation += ld;
       leafCreation -= ld;
       const R fineDef = eFine * invLen + fineRootCreation - fineRootLoss;
@@ -452,7 +440,18 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
     // the pools and ET, so they are evaluated here, off the common path.  Tillage is folded
     // into the plan.
     R evEvap = 0;
-    if (__builtin_expect(nEv > 0, 0)) {
+    if (__builtin_expect(nEv > 0 || __builtin_amdgcn_ballot_w64(doOn || doOff) != 0, 0)) {
+      if (doOn) {
+        const R leafOn = leafOnLimit(PRM_RARE(leafGrowth) * invLen);
+        leafOnCreation = leafOn;
+        const R src = eWood + eCoarse;
+        if (src > R(kTiny)) leafOnFromWood = fdiv(leafOn * eWood, src);
+        phenBits |= 1;
+      }
+      if (doOff) {
+        leafLitter += (eLeaf * PRM_RARE(fracLeafFall)) * invLen;
+        phenBits |= 2;
+      }
       R evLeafC = 0, evWoodC = 0, evFineRootC = 0, evCoarseRootC = 0, evSoilWater = 0;
       R evSoilC = 0, evLeafOnCreation = 0, evLeafOnFromWood = 0, evLeafOffLitter = 0;
       const int ev0 = uni(rareI[3]);
@@ -538,12 +537,12 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
     }
     // ensureNonNegativeStocks(), sipnet.c:1368-1397
     // (the clamp-warning counter of the strict kernel is not kept on this path)
-    plantWoodC = plantWoodC < 0.0 ? 0.0 : plantWoodC;
-    plantLeafC = plantLeafC < 0.0 ? 0.0 : plantLeafC;
-    soilC = soilC < 0.0 ? 0.0 : soilC;
-    coarseRootC = coarseRootC < 0.0 ? 0.0 : coarseRootC;
-    fineRootC = fineRootC < 0.0 ? 0.0 : fineRootC;
-    soilWater = soilWater < 0.0 ? 0.0 : soilWater;
+    plantWoodC = rmax0(plantWoodC);
+    plantLeafC = rmax0(plantLeafC);
+    soilC = rmax0(soilC);
+    coarseRootC = rmax0(coarseRootC);
+    fineRootC = rmax0(fineRootC);
+    soilWater = rmax0(soilWater);
     snow = snow < kTiny ? 0.0 : snow;
     STAMP(4)
 
