@@ -222,7 +222,18 @@ def test_full_size_properties_10k_members(base):
     members[5000] = members[77]
     members[10239] = members[64]
     b = make_batch(sa.flags_from(), [clim], members)
+    s0 = b.get_state()
     planes, _ = b.run()
+    s1 = b.get_state()
+    # carbon conservation over the whole year for every member (the property behind the
+    # reference's per-step balance check, balance.c:122-169): the change of the summed carbon
+    # pools equals minus the accumulated NEE
+    def total_c(s):   # wood + leaf + soil + coarse + fine roots + accounting delta
+        return s[:, 0] + s[:, 1] + s[:, 2] + s[:, 6] + s[:, 7] + s[:, 12]
+    resid = (total_c(s1) - total_c(s0)) + s1[:, 19]
+    print("carbon balance residual over 17520 steps: max %.3e gC m-2" % np.abs(resid).max())
+    assert np.abs(resid).max() < 1e-6
+    assert np.allclose(s1[:, 19], planes[0].double().sum(0).cpu().numpy(), rtol=0, atol=1e-8)
     b1 = make_batch(sa.flags_from(), [clim], members[:1])
     p1, _ = b1.run()
     assert torch.equal(planes[:, :, 0], p1[:, :, 0])
