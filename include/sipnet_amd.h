@@ -74,6 +74,8 @@ enum sipnet_status {
   SIPNET_ERR_INPUT_FILE = 5,       /* EXIT_CODE_INPUT_FILE_ERROR */
   SIPNET_ERR_FILE_OPEN = 6,        /* EXIT_CODE_FILE_OPEN_OR_READ_ERROR */
   SIPNET_ERR_INTERNAL = 7,         /* EXIT_CODE_INTERNAL_ERROR */
+  SIPNET_ERR_BAD_CLI = 8,          /* EXIT_CODE_BAD_CLI_ARGUMENT */
+  SIPNET_ERR_RESTART = 9,          /* EXIT_CODE_BAD_RESTART_PARAMETER */
   SIPNET_ERR_NO_DEVICE = 100,      /* no usable gfx950 device / HIP failure */
   SIPNET_ERR_BAD_ARGUMENT = 101
 };
@@ -128,6 +130,43 @@ typedef struct sipnet_event {
  * 30 died_at_step (-1 = never) 31 clamp-warning count */
 
 typedef struct sipnet_batch sipnet_batch;
+
+/* One member's restart checkpoint: the content of a `SIPNET_RESTART` file
+ * (sipnet/restart.c:152-305 lists the keys; docs/developer-guide/restart-checkpoint.md).
+ * trackers[] holds the 32 double-valued `trackers.*` keys in file order
+ * (restart.c:236-268; the integer trackers.lastYear is a separate member). */
+enum sipnet_restart_tracker {
+  SIPNET_RT_GPP = 0, SIPNET_RT_RTOT, SIPNET_RT_RA, SIPNET_RT_RH, SIPNET_RT_RROOT,
+  SIPNET_RT_RSOIL, SIPNET_RT_RABOVEGROUND, SIPNET_RT_NPP, SIPNET_RT_NEE,
+  SIPNET_RT_WOODCREATION, SIPNET_RT_GDD, SIPNET_RT_ET, SIPNET_RT_SOILWETNESSFRAC,
+  SIPNET_RT_YEARLYGPP, SIPNET_RT_YEARLYRTOT, SIPNET_RT_YEARLYRA, SIPNET_RT_YEARLYRH,
+  SIPNET_RT_YEARLYNPP, SIPNET_RT_YEARLYNEE, SIPNET_RT_YEARLYLITTER,
+  SIPNET_RT_TOTGPP, SIPNET_RT_TOTRTOT, SIPNET_RT_TOTRA, SIPNET_RT_TOTRH,
+  SIPNET_RT_TOTNPP, SIPNET_RT_TOTNEE, SIPNET_RT_METHANE, SIPNET_RT_N2O,
+  SIPNET_RT_NLEACHING, SIPNET_RT_NFIXATION, SIPNET_RT_NUPTAKE, SIPNET_RT_MEANNPP,
+  SIPNET_RT_COUNT
+};
+typedef struct sipnet_restart {
+  char model_version[32];          /* meta_info.model_version, must equal "2.1.0" */
+  char build_info[96];             /* meta_info.build_info (informational) */
+  int64_t checkpoint_utc_epoch;    /* meta_info.checkpoint_utc_epoch */
+  int64_t processed_steps;         /* meta_info.processed_steps */
+  int32_t flags[SIPNET_NFLAGS];    /* flags.* in enum sipnet_flag order */
+  int32_t boundary_year, boundary_day; /* last processed climate record */
+  double boundary_time, boundary_length;
+  double envi[13];                 /* envi.* in `Envi` order (= state rows 0..12) */
+  double trackers[SIPNET_RT_COUNT];
+  int32_t trackers_last_year;      /* trackers.lastYear */
+  int32_t did_leaf_growth, did_leaf_fall, phenology_last_year; /* phenology.* */
+  int32_t is_alive;                /* survival.isAlive */
+  int32_t mean_length;             /* mean.npp.length, must be SIPNET_RING_SLOTS */
+  double d_till_mod, harvest_frac_removed, harvest_frac_transferred; /* event_trackers.* */
+  double mean_tot_weight;          /* mean.npp.totWeight (5 days) */
+  int32_t mean_start, mean_last;   /* ring cursors */
+  double mean_sum;                 /* mean.npp.sum */
+  double mean_values[SIPNET_RING_SLOTS];
+  double mean_weights[SIPNET_RING_SLOTS];
+} sipnet_restart;
 
 /* ------------------------------------------------------------------ library */
 const char *sipnet_version(void);      /* "sipnet_amd x.y (reference 2.1.0)" */
@@ -202,6 +241,36 @@ int sipnet_batch_set_rings(sipnet_batch *b, const double *rings, void *hip_strea
 /* Per-member status to HOST: status[ncol] (enum sipnet_status). */
 int sipnet_batch_get_status(sipnet_batch *b, int32_t *status, void *hip_stream);
 
+/* ---- restart checkpoints (runModelOutput's hooks, sipnet.c:1965-1989) ----
+ * Resume sequence == the reference's (restart-checkpoint.md "Runtime sequence"):
+ *   set_climate/events/params of the NEW segment -> set_resume -> setup ->
+ *   import_restart (overwrites the members' state) -> run.
+ *
+ * set_resume: the site-uniform part of a checkpoint that the site plan owns --
+ * trackers.gdd, trackers.lastYear, phenology.lastYear, event_trackers.d_till_mod and the
+ * ring layout (weights, cursors).  r == NULL clears it.  Call before setup. */
+int sipnet_batch_set_resume(sipnet_batch *b, int32_t site, const sipnet_restart *r);
+/* import_restart: after setup, overwrite the carried state and ring values of `count`
+ * members of `site` with r[count].  A member whose ring layout differs from the site's
+ * (a member that died and was re-planted in the earlier segment) is re-laid onto the
+ * site layout when its older entries are all zero, else SIPNET_ERR_RESTART.
+ * survival.isAlive is implied by the pools (sipnet.c:1530-1544); a checkpoint that
+ * contradicts them is rejected. */
+int sipnet_batch_import_restart(sipnet_batch *b, int32_t site, int32_t first_member,
+                                int32_t count, const sipnet_restart *r, void *hip_stream);
+/* export_restart: checkpoint of one member after the first n_steps_done records
+ * (== restartWriteCheckpoint, restart.c:932-996; boundary = record n_steps_done-1).
+ * last_rec[SIPNET_NREC] (HOST, may be NULL) is the member's full record of that last
+ * step and supplies the per-step `trackers.*` values, which a resume overwrites
+ * before use; prev_pools[13] (HOST, may be NULL) are the pools before that step and
+ * are only needed for harvest fractions when a harvest falls on the last record.
+ * meta_info: model_version "2.1.0", build_info = sipnet_version() sanitised,
+ * epoch = now, processed_steps = n_steps_done. */
+int sipnet_batch_export_restart(sipnet_batch *b, int32_t site, int32_t member,
+                                int32_t n_steps_done, const double *last_rec,
+                                const double *prev_pools, sipnet_restart *out,
+                                void *hip_stream);
+
 int64_t sipnet_batch_ncol(const sipnet_batch *b);
 int32_t sipnet_batch_nsteps(const sipnet_batch *b);
 /* Site-uniform trajectory computed by the plan: gdd[t] (trackers.gdd after
@@ -270,6 +339,31 @@ int sipnet_io_write_events_out(const char *path, int32_t print_header,
                                const double *clim, int32_t n_events,
                                const sipnet_event *events, const double *rec,
                                const double *init_pools);
+
+
+/* `SIPNET_RESTART` checkpoint text (restart.c): read follows readRestartState
+ * (restart.c:590-756: magic line, `<key> <value>` lines, strict number parsing, duplicate /
+ * unknown / missing keys, schema_layout sizes, complete ring arrays, lines after
+ * `end_restart` ignored); write follows writeRestartState (restart.c:787-828: key order,
+ * %.17g, blank line between groups).  Failures return SIPNET_ERR_RESTART (9). */
+int sipnet_io_read_restart(const char *path, sipnet_restart *out);
+int sipnet_io_write_restart(const char *path, const sipnet_restart *in);
+/* The load-time checks of restartLoadCheckpoint (restart.c:968-996) against the run that
+ * is about to resume: positive boundary length, identical model flags, model version,
+ * first climate record strictly after the boundary, ring cursors in range.
+ * *warnings gets SIPNET_RESTART_WARN_* bits for the conditions the reference only warns
+ * about.  has_climate = 0 -> SIPNET_ERR_INPUT_FILE like the reference. */
+enum sipnet_restart_warning {
+  SIPNET_RESTART_WARN_BOUNDARY_NOT_MIDNIGHT = 1, /* restart.c:380-388 */
+  SIPNET_RESTART_WARN_BUILD_INFO = 2,            /* restart.c:862-865 */
+  SIPNET_RESTART_WARN_TIME_GAP = 4               /* restart.c:899-909 */
+};
+int sipnet_restart_check(const sipnet_restart *r, const int32_t flags[SIPNET_NFLAGS],
+                         int32_t has_climate, int32_t year0, int32_t day0, double time0,
+                         double length0, int32_t *warnings);
+/* restartWriteCheckpoint's own check (restart.c:344-366): 0, SIPNET_ERR_RESTART for a
+ * non-positive boundary length; *warnings gets SIPNET_RESTART_WARN_BOUNDARY_NOT_MIDNIGHT. */
+int sipnet_restart_check_boundary_for_write(const sipnet_restart *r, int32_t *warnings);
 
 #ifdef __cplusplus
 }

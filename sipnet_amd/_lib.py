@@ -19,6 +19,8 @@ ERR_UNKNOWN_EVENT = 4
 ERR_INPUT_FILE = 5
 ERR_FILE_OPEN = 6
 ERR_INTERNAL = 7
+ERR_BAD_CLI = 8
+ERR_RESTART = 9
 ERR_NO_DEVICE = 100
 ERR_BAD_ARGUMENT = 101
 
@@ -30,6 +32,45 @@ class Event(C.Structure):
     _fields_ = [("type", C.c_int32), ("year", C.c_int32), ("day", C.c_int32),
                 ("pad", C.c_int32), ("p", C.c_double * 4)]
 
+
+RT_NAMES = ("gpp", "rtot", "ra", "rh", "rRoot", "rSoil", "rAboveground", "npp", "nee",
+            "woodCreation", "gdd", "evapotranspiration", "soilWetnessFrac", "yearlyGpp",
+            "yearlyRtot", "yearlyRa", "yearlyRh", "yearlyNpp", "yearlyNee", "yearlyLitter",
+            "totGpp", "totRtot", "totRa", "totRh", "totNpp", "totNee", "methane", "n2o",
+            "nLeaching", "nFixation", "nUptake", "meanNPP")   # enum sipnet_restart_tracker
+
+
+class Restart(C.Structure):
+    """struct sipnet_restart: one member's `SIPNET_RESTART` checkpoint"""
+    _fields_ = [("model_version", C.c_char * 32), ("build_info", C.c_char * 96),
+                ("checkpoint_utc_epoch", C.c_int64), ("processed_steps", C.c_int64),
+                ("flags", C.c_int32 * 12),
+                ("boundary_year", C.c_int32), ("boundary_day", C.c_int32),
+                ("boundary_time", C.c_double), ("boundary_length", C.c_double),
+                ("envi", C.c_double * 13), ("trackers", C.c_double * 32),
+                ("trackers_last_year", C.c_int32),
+                ("did_leaf_growth", C.c_int32), ("did_leaf_fall", C.c_int32),
+                ("phenology_last_year", C.c_int32), ("is_alive", C.c_int32),
+                ("mean_length", C.c_int32),
+                ("d_till_mod", C.c_double), ("harvest_frac_removed", C.c_double),
+                ("harvest_frac_transferred", C.c_double), ("mean_tot_weight", C.c_double),
+                ("mean_start", C.c_int32), ("mean_last", C.c_int32), ("mean_sum", C.c_double),
+                ("mean_values", C.c_double * 250), ("mean_weights", C.c_double * 250)]
+
+    def tracker(self, name):
+        return self.trackers[RT_NAMES.index(name)]
+
+    def live_slots(self):
+        """ring slots from the oldest to the newest entry"""
+        out, i = [], self.mean_start
+        while True:
+            out.append(i)
+            if i == self.mean_last:
+                return out
+            i = (i + 1) % 250
+
+
+RESTART_WARN_BOUNDARY_NOT_MIDNIGHT, RESTART_WARN_BUILD_INFO, RESTART_WARN_TIME_GAP = 1, 2, 4
 
 # name -> (restype, argtypes); every symbol declared in include/sipnet_amd.h
 _P = C.c_void_p
@@ -53,6 +94,9 @@ SIGNATURES = {
     "sipnet_batch_get_rings": (C.c_int, [_P, _P, _P]),
     "sipnet_batch_set_rings": (C.c_int, [_P, _P, _P]),
     "sipnet_batch_get_status": (C.c_int, [_P, _P, _P]),
+    "sipnet_batch_set_resume": (C.c_int, [_P, C.c_int32, _P]),
+    "sipnet_batch_import_restart": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
+    "sipnet_batch_export_restart": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P]),
     "sipnet_batch_ncol": (C.c_int64, [_P]),
     "sipnet_batch_nsteps": (C.c_int32, [_P]),
     "sipnet_batch_get_site_series": (C.c_int, [_P, C.c_int32, _P, _P]),
@@ -77,6 +121,11 @@ SIGNATURES = {
     "sipnet_io_write_out": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, _P, _P, _P, _P]),
     "sipnet_io_write_events_out": (C.c_int, [C.c_char_p, C.c_int32, _I32P, _P, C.c_int32, _P, _P, _P,
                                              C.c_int32, _P, _P, _P]),
+    "sipnet_io_read_restart": (C.c_int, [C.c_char_p, _P]),
+    "sipnet_io_write_restart": (C.c_int, [C.c_char_p, _P]),
+    "sipnet_restart_check": (C.c_int, [_P, _I32P, C.c_int32, C.c_int32, C.c_int32, C.c_double,
+                                       C.c_double, _I32P]),
+    "sipnet_restart_check_boundary_for_write": (C.c_int, [_P, _I32P]),
 }
 
 _lib = None

@@ -154,6 +154,36 @@ class Batch:
         self.set_state(ckpt[0])
         self.set_rings(ckpt[1])
 
+    # -- restart checkpoints (sipnet.c:1963-1989, restart.c) ---------------------
+    def set_resume(self, site, restart):
+        """Site-uniform part of a checkpoint (gdd, lastYear, d_till_mod, ring layout); call
+        before setup().  restart=None clears it."""
+        ptr = C.byref(restart) if restart is not None else None
+        check(self.L.sipnet_batch_set_resume(self.h, site, ptr), "set_resume")
+
+    def import_restart(self, site, restarts, first_member=0):
+        """After setup(): overwrite the carried state of len(restarts) members of `site`."""
+        from ._lib import Restart
+        arr = (Restart * len(restarts))(*restarts)
+        check(self.L.sipnet_batch_import_restart(self.h, site, first_member, len(restarts), arr,
+                                                 self._stream()), "import_restart")
+
+    def export_restart(self, site, member, n_steps_done, last_rec=None, prev_pools=None):
+        """Checkpoint of one member after n_steps_done records (restartWriteCheckpoint)."""
+        from ._lib import Restart
+        r = Restart()
+        lr = pp = None
+        if last_rec is not None:
+            lr = np.ascontiguousarray(last_rec, dtype=np.float64)
+            assert lr.shape == (NREC,)
+        if prev_pools is not None:
+            pp = np.ascontiguousarray(prev_pools, dtype=np.float64)
+            assert pp.shape[0] >= 13
+        check(self.L.sipnet_batch_export_restart(
+            self.h, site, member, int(n_steps_done), lr.ctypes.data if lr is not None else None,
+            pp.ctypes.data if pp is not None else None, C.byref(r), self._stream()), "export_restart")
+        return r
+
     def site_series(self, site):
         g = np.zeros(self.n_steps)
         d = np.zeros(self.n_steps)

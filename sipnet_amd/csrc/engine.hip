@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <vector>
 
@@ -42,8 +43,10 @@ struct sipnet_batch {
   std::vector<std::vector<int32_t>> year, day;
   std::vector<std::vector<sipnet_event>> events;
   std::vector<SitePlan> plans;
+  std::vector<PlanCarry> resume;  // per site: state the plan starts from (restart)
   std::vector<int32_t> siteStatus;
   bool planDirty = true;
+  int32_t stepsDone = 0;       // records the carried state reflects, -1 = unknown
 
   // HBM
   double* d_raw = nullptr;     // [ncol][NPARAMS] raw upload (AoS)
@@ -82,7 +85,8 @@ static int uploadPlan(sipnet_batch* b, hipStream_t stream) {
   for (int s = 0; s < b->n_sites; s++) {
     b->plans.push_back(buildSitePlan(b->flags, b->n_steps, b->clim[s].data(),
                                      b->year[s].data(), b->day[s].data(),
-                                     (int32_t)b->events[s].size(), b->events[s].data()));
+                                     (int32_t)b->events[s].size(), b->events[s].data(),
+                                     b->resume[s].set ? &b->resume[s] : nullptr));
     b->siteStatus[s] = b->plans[s].status;
     nOps += b->plans[s].ringOps.size();
     nEv += b->plans[s].events.size();
@@ -189,6 +193,7 @@ int sipnet_batch_create(const int32_t* flags, int32_t n_sites, int32_t n_members
   b->year.resize(n_sites);
   b->day.resize(n_sites);
   b->events.resize(n_sites);
+  b->resume.resize(n_sites);
   b->siteStatus.assign(n_sites, 0);
   int rc = useDevice(b);
   if (rc) { delete b; return rc; }
@@ -319,6 +324,7 @@ int sipnet_batch_setup(sipnet_batch* b, void* hip_stream) {
   a.siteStatus = b->d_siteStatus;
   launchSetup(a, stream);
   HIP_TRY(hipGetLastError());
+  b->stepsDone = 0;
   // a site-fatal plan condition is reported like the reference's exit code
   for (int s = 0; s < b->n_sites; s++) {
     if (b->siteStatus[s] != SIPNET_OK) {
@@ -395,6 +401,7 @@ int sipnet_batch_run(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_ne
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(b->ev1, stream));
   b->timed = true;
+  b->stepsDone = (b->stepsDone == step0) ? step0 + n_steps : -1;
   return SIPNET_OK;
 }
 
@@ -449,6 +456,7 @@ int sipnet_batch_set_state(sipnet_batch* b, const double* state, void* hip_strea
     for (int64_t c = 0; c < b->ncol; c++)
       tmp[(size_t)k * b->ncol + c] = state[c * SIPNET_NSTATE + k];
   HIP_TRY(hipMemcpy(b->d_state, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+  b->stepsDone = -1;  // the caller moved the state; only it knows to which record
   return SIPNET_OK;
 }
 
@@ -497,6 +505,322 @@ int sipnet_batch_get_status(sipnet_batch* b, int32_t* status, void* hip_stream) 
   HIP_TRY(hipMemcpy(tmp.data(), b->d_state + (size_t)ST_status * b->ncol,
                     tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
   for (int64_t c = 0; c < b->ncol; c++) status[c] = (int32_t)tmp[c];
+  return SIPNET_OK;
+}
+
+// ---- restart checkpoints ------------------------------------------------------
+namespace {
+constexpr double kTinyBiomass = 0.000001;  // common/util.h:14
+constexpr double kRingWindow = 5.0;        // MEAN_NPP_DAYS, sipnet.c:39
+
+bool sufficientBiomass(const double* envi) {  // hasSufficientBiomass(), sipnet.c:1530-1537
+  return envi[0] > kTinyBiomass && envi[0] + envi[12] > kTinyBiomass &&
+         envi[7] + envi[6] > kTinyBiomass;
+}
+int nextSlot(int i) { return (i + 1) % SIPNET_RING_SLOTS; }
+int prevSlot(int i) { return (i + SIPNET_RING_SLOTS - 1) % SIPNET_RING_SLOTS; }
+
+bool sameLayout(const sipnet_restart& r, const RingSched& s) {
+  if (r.mean_start != s.start || r.mean_last != s.last) return false;
+  for (int i = s.start;; i = nextSlot(i)) {
+    if (r.mean_weights[i] != s.w[i]) return false;
+    if (i == s.last) break;
+  }
+  return true;
+}
+
+// Re-express a member's ring on the site's layout: entries are matched newest first; the
+// member's remaining (older) entries must all hold zero, which any layout represents.
+bool relayRing(const sipnet_restart& r, const RingSched& s, double* values) {
+  for (int i = 0; i < SIPNET_RING_SLOTS; i++) values[i] = 0.0;
+  int im = r.mean_last, is = s.last;
+  for (;;) {
+    bool restZero = true;
+    for (int k = r.mean_start;; k = nextSlot(k)) {
+      if (r.mean_values[k] != 0.0) restZero = false;
+      if (k == im) break;
+    }
+    if (restZero) return true;
+    if (r.mean_weights[im] != s.w[is]) return false;
+    values[is] = r.mean_values[im];
+    if (im == r.mean_start) return true;
+    if (is == s.start) return false;
+    im = prevSlot(im);
+    is = prevSlot(is);
+  }
+}
+}  // namespace
+
+int sipnet_batch_set_resume(sipnet_batch* b, int32_t site, const sipnet_restart* r) {
+  if (!b || site < 0 || site >= b->n_sites) {
+    setError("sipnet_batch_set_resume: bad argument");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  PlanCarry& c = b->resume[site];
+  c = PlanCarry{};
+  b->planDirty = true;
+  if (!r) return SIPNET_OK;
+  if (r->mean_length != SIPNET_RING_SLOTS || r->mean_start < 0 ||
+      r->mean_start >= SIPNET_RING_SLOTS || r->mean_last < 0 ||
+      r->mean_last >= SIPNET_RING_SLOTS) {  // restart.c:727-733, :987-992
+    setError("Restart mean-tracker length or cursor out of range");
+    return SIPNET_ERR_RESTART;
+  }
+  c.set = true;
+  c.gdd = r->trackers[SIPNET_RT_GDD];
+  c.trackLastYear = r->trackers_last_year;
+  c.phenLastYear = r->phenology_last_year;
+  c.dTill = r->d_till_mod;
+  c.ring.start = r->mean_start;
+  c.ring.last = r->mean_last;
+  for (int i = 0; i < SIPNET_RING_SLOTS; i++) {
+    c.ring.w[i] = r->mean_weights[i];
+    c.ring.insStep[i] = 0;
+  }
+  return SIPNET_OK;
+}
+
+int sipnet_batch_import_restart(sipnet_batch* b, int32_t site, int32_t first_member,
+                                int32_t count, const sipnet_restart* r, void* hip_stream) {
+  if (!b || site < 0 || site >= b->n_sites || first_member < 0 || count <= 0 ||
+      first_member + count > b->n_members || !r) {
+    setError("sipnet_batch_import_restart: bad argument");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  if (b->planDirty || !b->resume[site].set) {
+    setError("sipnet_batch_import_restart: call sipnet_batch_set_resume and "
+             "sipnet_batch_setup first");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  int rc = useDevice(b);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize((hipStream_t)hip_stream));
+  const PlanCarry& c = b->resume[site];
+  const int64_t col0 = (int64_t)site * b->n_members + first_member;
+  const size_t pitchD = (size_t)b->ncol * sizeof(double), pitchH = (size_t)count * sizeof(double);
+  // current state block [NSTATE][count]: keeps what setup decided (status, diagnostics)
+  std::vector<double> st((size_t)SIPNET_NSTATE * count), ring((size_t)SIPNET_RING_SLOTS * count);
+  HIP_TRY(hipMemcpy2D(st.data(), pitchH, b->d_state + col0, pitchD, pitchH, SIPNET_NSTATE,
+                      hipMemcpyDeviceToHost));
+  double vals[SIPNET_RING_SLOTS];
+  for (int32_t m = 0; m < count; m++) {
+    const sipnet_restart& k = r[m];
+    const std::string who = "member " + std::to_string(first_member + m) + " of site " +
+                            std::to_string(site);
+    for (int i = 0; i < SIPNET_NFLAGS; i++) {
+      if (k.flags[i] != b->flags[i]) {
+        setError("Restart context mismatch: model flags must match checkpoint exactly (" + who + ")");
+        return SIPNET_ERR_RESTART;
+      }
+    }
+    if (k.trackers[SIPNET_RT_GDD] != c.gdd || k.trackers_last_year != c.trackLastYear ||
+        k.phenology_last_year != c.phenLastYear || k.d_till_mod != c.dTill) {
+      setError("sipnet_batch_import_restart: " + who + " disagrees with the site's resume "
+               "state (gdd, lastYear or d_till_mod); members of a site share one forcing history");
+      return SIPNET_ERR_RESTART;
+    }
+    if ((k.is_alive != 0) != sufficientBiomass(k.envi)) {
+      setError("sipnet_batch_import_restart: survival.isAlive of " + who +
+               " contradicts its pools (sipnet.c:1530-1544)");
+      return SIPNET_ERR_RESTART;
+    }
+    if (k.mean_length != SIPNET_RING_SLOTS || k.mean_start < 0 ||
+        k.mean_start >= SIPNET_RING_SLOTS || k.mean_last < 0 ||
+        k.mean_last >= SIPNET_RING_SLOTS) {
+      setError("Restart mean-tracker length or cursor out of range (" + who + ")");
+      return SIPNET_ERR_RESTART;
+    }
+    if (sameLayout(k, c.ring)) {
+      memcpy(vals, k.mean_values, sizeof vals);
+    } else if (!relayRing(k, c.ring, vals)) {
+      setError("sipnet_batch_import_restart: running-mean ring layout of " + who +
+               " cannot be expressed on the site's layout");
+      return SIPNET_ERR_RESTART;
+    }
+    for (int i = 0; i < SIPNET_RING_SLOTS; i++) ring[(size_t)i * count + m] = vals[i];
+    double* s = st.data() + m;
+    auto S = [&](int row) -> double& { return s[(size_t)row * count]; };
+    for (int i = 0; i < 13; i++) S(i) = k.envi[i];
+    S(ST_ringSum) = k.mean_sum;
+    S(ST_totGpp) = k.trackers[SIPNET_RT_TOTGPP];
+    S(ST_totRtot) = k.trackers[SIPNET_RT_TOTRTOT];
+    S(ST_totRa) = k.trackers[SIPNET_RT_TOTRA];
+    S(ST_totRh) = k.trackers[SIPNET_RT_TOTRH];
+    S(ST_totNpp) = k.trackers[SIPNET_RT_TOTNPP];
+    S(ST_totNee) = k.trackers[SIPNET_RT_TOTNEE];
+    S(ST_yearlyGpp) = k.trackers[SIPNET_RT_YEARLYGPP];
+    S(ST_yearlyRtot) = k.trackers[SIPNET_RT_YEARLYRTOT];
+    S(ST_yearlyRa) = k.trackers[SIPNET_RT_YEARLYRA];
+    S(ST_yearlyRh) = k.trackers[SIPNET_RT_YEARLYRH];
+    S(ST_yearlyNpp) = k.trackers[SIPNET_RT_YEARLYNPP];
+    S(ST_yearlyNee) = k.trackers[SIPNET_RT_YEARLYNEE];
+    S(ST_yearlyLitter) = k.trackers[SIPNET_RT_YEARLYLITTER];
+    S(ST_phenBits) = (double)((k.did_leaf_growth ? 1 : 0) | (k.did_leaf_fall ? 2 : 0));
+    S(ST_ringValidFrom) = 0.0;
+  }
+  HIP_TRY(hipMemcpy2D(b->d_state + col0, pitchD, st.data(), pitchH, pitchH, SIPNET_NSTATE,
+                      hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy2D(b->d_ring + col0, pitchD, ring.data(), pitchH, pitchH, SIPNET_RING_SLOTS,
+                      hipMemcpyHostToDevice));
+  return SIPNET_OK;
+}
+
+int sipnet_batch_export_restart(sipnet_batch* b, int32_t site, int32_t member,
+                                int32_t n_steps_done, const double* last_rec,
+                                const double* prev_pools, sipnet_restart* out,
+                                void* hip_stream) {
+  if (!b || site < 0 || site >= b->n_sites || member < 0 || member >= b->n_members || !out) {
+    setError("sipnet_batch_export_restart: bad argument");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  if (b->planDirty) {
+    setError("sipnet_batch_export_restart: no run to take a checkpoint of");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  if (n_steps_done <= 0 || n_steps_done > b->n_steps) {  // restart.c:933-937
+    setError("Cannot write restart checkpoint: no timestep processed");
+    return SIPNET_ERR_RESTART;
+  }
+  if (b->stepsDone >= 0 && b->stepsDone != n_steps_done) {
+    setError("sipnet_batch_export_restart: the carried state is at record " +
+             std::to_string(b->stepsDone) + ", not " + std::to_string(n_steps_done));
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  int rc = useDevice(b);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize((hipStream_t)hip_stream));
+  const int64_t col = (int64_t)site * b->n_members + member;
+  const size_t pitchD = (size_t)b->ncol * sizeof(double);
+  double st[SIPNET_NSTATE], ring[SIPNET_RING_SLOTS];
+  HIP_TRY(hipMemcpy2D(st, sizeof(double), b->d_state + col, pitchD, sizeof(double),
+                      SIPNET_NSTATE, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy2D(ring, sizeof(double), b->d_ring + col, pitchD, sizeof(double),
+                      SIPNET_RING_SLOTS, hipMemcpyDeviceToHost));
+  if ((int)st[ST_status] != SIPNET_OK) {
+    setError("sipnet_batch_export_restart: member did not run (status " +
+             std::to_string((int)st[ST_status]) + ")");
+    return (int)st[ST_status];
+  }
+
+  // what the plan owns, after n_steps_done records
+  const int n = n_steps_done;
+  PlanCarry fin;
+  const SitePlan head = buildSitePlan(
+      b->flags, n, b->clim[site].data(), b->year[site].data(), b->day[site].data(),
+      (int32_t)b->events[site].size(), b->events[site].data(),
+      b->resume[site].set ? &b->resume[site] : nullptr, &fin);
+  const double* lastClim = b->clim[site].data() + (size_t)SIPNET_NCLIM * (n - 1);
+
+  memset(out, 0, sizeof(*out));
+  snprintf(out->model_version, sizeof out->model_version, "2.1.0");
+  {
+    std::string info = sipnet_version();
+    for (char& ch : info)
+      if (ch == ' ' || ch == '\t' || ch == '\r' || ch == '\n') ch = '_';
+    snprintf(out->build_info, sizeof out->build_info, "%s", info.c_str());
+  }
+  out->checkpoint_utc_epoch = (int64_t)time(nullptr);
+  out->processed_steps = n;
+  memcpy(out->flags, b->flags, sizeof out->flags);
+  out->boundary_year = b->year[site][n - 1];
+  out->boundary_day = b->day[site][n - 1];
+  out->boundary_time = lastClim[10];
+  out->boundary_length = lastClim[0];
+  for (int i = 0; i < 13; i++) out->envi[i] = st[i];
+  double* T = out->trackers;
+  if (last_rec) {  // the per-step trackers of the last record, sipnet.c:1433-1497
+    T[SIPNET_RT_GPP] = last_rec[1];
+    T[SIPNET_RT_RTOT] = last_rec[10];
+    T[SIPNET_RT_RA] = last_rec[8];
+    T[SIPNET_RT_RH] = last_rec[9];
+    T[SIPNET_RT_RROOT] = last_rec[7];
+    T[SIPNET_RT_RSOIL] = last_rec[6];
+    T[SIPNET_RT_RABOVEGROUND] = last_rec[5];
+    T[SIPNET_RT_NPP] = last_rec[4];
+    T[SIPNET_RT_NEE] = last_rec[0];
+    T[SIPNET_RT_WOODCREATION] = last_rec[11];
+    T[SIPNET_RT_ET] = last_rec[2];
+    T[SIPNET_RT_SOILWETNESSFRAC] = last_rec[12];
+    T[SIPNET_RT_METHANE] = last_rec[31];
+    T[SIPNET_RT_N2O] = last_rec[27];
+    T[SIPNET_RT_NLEACHING] = last_rec[28];
+    T[SIPNET_RT_NFIXATION] = last_rec[29];
+    T[SIPNET_RT_NUPTAKE] = last_rec[30];
+    T[SIPNET_RT_MEANNPP] = last_rec[32];
+  } else {
+    T[SIPNET_RT_MEANNPP] = st[ST_ringSum] / kRingWindow;
+  }
+  T[SIPNET_RT_GDD] = fin.gdd;
+  T[SIPNET_RT_YEARLYGPP] = st[ST_yearlyGpp];
+  T[SIPNET_RT_YEARLYRTOT] = st[ST_yearlyRtot];
+  T[SIPNET_RT_YEARLYRA] = st[ST_yearlyRa];
+  T[SIPNET_RT_YEARLYRH] = st[ST_yearlyRh];
+  T[SIPNET_RT_YEARLYNPP] = st[ST_yearlyNpp];
+  T[SIPNET_RT_YEARLYNEE] = st[ST_yearlyNee];
+  T[SIPNET_RT_YEARLYLITTER] = st[ST_yearlyLitter];
+  T[SIPNET_RT_TOTGPP] = st[ST_totGpp];
+  T[SIPNET_RT_TOTRTOT] = st[ST_totRtot];
+  T[SIPNET_RT_TOTRA] = st[ST_totRa];
+  T[SIPNET_RT_TOTRH] = st[ST_totRh];
+  T[SIPNET_RT_TOTNPP] = st[ST_totNpp];
+  T[SIPNET_RT_TOTNEE] = st[ST_totNee];
+  out->trackers_last_year = fin.trackLastYear;
+  const int phenBits = (int)st[ST_phenBits];
+  out->did_leaf_growth = phenBits & 1;
+  out->did_leaf_fall = (phenBits >> 1) & 1;
+  out->phenology_last_year = fin.phenLastYear;
+  out->is_alive = sufficientBiomass(out->envi) ? 1 : 0;
+  out->d_till_mod = fin.dTill;
+  // harvest fractions of the last record's events (events.c:467-469, :553-562)
+  if (prev_pools && b->flags[SIPNET_F_EVENTS]) {
+    const StepRec& ls = head.steps[n - 1];
+    const double woodC = prev_pools[0] + prev_pools[12];
+    const double above = woodC + prev_pools[1], below = prev_pools[7] + prev_pools[6];
+    for (int e = 0; e < ls.evCount; e++) {
+      const EvRec& ev = head.events[ls.evFirst + e];
+      if (ev.type == SIPNET_EV_HARVEST && above + below > kTinyBiomass) {
+        out->harvest_frac_removed += (ev.p[0] * above + ev.p[1] * below) / (above + below);
+        out->harvest_frac_transferred += (ev.p[2] * above + ev.p[3] * below) / (above + below);
+      }
+    }
+  }
+
+  // running-mean ring in the reference's own layout
+  out->mean_length = SIPNET_RING_SLOTS;
+  out->mean_tot_weight = kRingWindow;
+  out->mean_sum = st[ST_ringSum];
+  const int validFrom = (int)st[ST_ringValidFrom];
+  if (validFrom <= 0) {
+    // a member that never died holds exactly the plan's ring
+    out->mean_start = fin.ring.start;
+    out->mean_last = fin.ring.last;
+    for (int i = 0; i < SIPNET_RING_SLOTS; i++) {
+      out->mean_weights[i] = fin.ring.w[i];
+      out->mean_values[i] = ring[i];
+    }
+  } else {
+    // the reference reset this member's ring when it died (sipnet.c:1757) and inserted
+    // again from record validFrom on: replay that schedule, take the values by insert step
+    RingSched fresh;
+    bool overflow = false;
+    for (int t = validFrom; t < n; t++)
+      fresh.advance(t, b->clim[site][(size_t)SIPNET_NCLIM * t], nullptr, &overflow);
+    out->mean_start = fresh.start;
+    out->mean_last = fresh.last;
+    for (int i = 0; i < SIPNET_RING_SLOTS; i++) out->mean_weights[i] = fresh.w[i];
+    for (int i = fresh.start;; i = nextSlot(i)) {
+      const int ins = fresh.insStep[i];
+      if (ins >= validFrom) {
+        for (int j = 0; j < SIPNET_RING_SLOTS; j++) {
+          if (fin.ring.insStep[j] == ins) {
+            out->mean_values[i] = ring[j];
+            break;
+          }
+        }
+      }
+      if (i == fresh.last) break;
+    }
+  }
   return SIPNET_OK;
 }
 

@@ -16,9 +16,53 @@ constexpr double kLambda = 2501000., kLambdaS = 2835000., kRho = 1.3, kCp = 1005
                  kGamma = 66., kEStarSnow = 0.6, kSecPerDay = 86400.0;
 }  // namespace
 
+void RingSched::reset(int32_t step) {
+  start = last = 0;
+  w[0] = kMeanNppDays;
+  insStep[0] = step;
+}
+
+int32_t RingSched::advance(int32_t step, double weight, std::vector<RingOp>* ops,
+                           bool* overflow) {
+  if (!(weight > 0)) {
+    return 0;  // unreachable in a valid run (the plan carries a site-fatal status)
+  }
+  if (weight >= kMeanNppDays) {  // runmean.c:67-69
+    reset(step);
+    return -1;
+  }
+  double left = weight;
+  int i = start;
+  while (left > 0) {  // runmean.c:76-86
+    RingOp op;
+    op.slot = i;
+    op.insStep = insStep[i];
+    if (w[i] > left) {
+      w[i] -= left;
+      op.w = left;
+      left = 0;
+    } else {
+      op.w = w[i];
+      left -= w[i];
+      i = (i + 1) % SIPNET_RING_SLOTS;
+    }
+    if (ops) ops->push_back(op);
+  }
+  start = i;
+  i = (last + 1) % SIPNET_RING_SLOTS;
+  if (i == start) {  // runmean.c:93-95
+    if (overflow) *overflow = true;
+    return i;
+  }
+  last = i;
+  w[i] = weight;
+  insStep[i] = step;
+  return i;
+}
+
 SitePlan buildSitePlan(const int32_t* flags, int32_t n_steps, const double* clim,
                        const int32_t* year, const int32_t* day, int32_t n_events,
-                       const sipnet_event* events) {
+                       const sipnet_event* events, const PlanCarry* init, PlanCarry* fin) {
   SitePlan plan;
   plan.steps.resize(n_steps);
   const bool useEvents = flags[SIPNET_F_EVENTS] != 0;
@@ -31,19 +75,23 @@ SitePlan buildSitePlan(const int32_t* flags, int32_t n_steps, const double* clim
   const double convE = (kRho * kCp) / kGamma * (1. / kLambda) * 1000. * 1000. *
                        (1. / 10000) * kSecPerDay;
 
-  // ring weights as the reference would hold them if every member inserted on
-  // every step (runmean.c:44-52, :61-116)
-  double w[SIPNET_RING_SLOTS];
-  int32_t insStep[SIPNET_RING_SLOTS];
-  int start = 0, last = 0;
-  w[0] = kMeanNppDays;
-  insStep[0] = -1;
-
+  RingSched ring;               // fresh: one zero entry, insStep -1
   int trackLastYear = -1;       // trackers.lastYear, sipnet.c:1412
   double trackGdd = 0.0;        // trackers.gdd
   int phenLastYear = n_steps > 0 ? year[0] : 0;  // sipnet.c:1524
   double dTill = 0.0;           // events.c:809
   int evNext = 0;
+  if (init && init->set) {
+    // resumed segment: the checkpoint overwrites what setupModel() initialised
+    // (sipnet.c:1963-1967).  Pre-loaded ring entries are live for every member, so they
+    // carry insert step 0 (>= any member's ring_valid_from of 0).
+    ring = init->ring;
+    for (int i = 0; i < SIPNET_RING_SLOTS; i++) ring.insStep[i] = 0;
+    trackLastYear = init->trackLastYear;
+    trackGdd = init->gdd;
+    phenLastYear = init->phenLastYear;
+    dTill = init->dTill;
+  }
 
   // frontend.c:216-223
   if (n_events > 0 && n_steps > 0) {
@@ -149,47 +197,11 @@ SitePlan buildSitePlan(const int32_t* flags, int32_t n_steps, const double* clim
 
     // running-mean ring schedule, runmean.c:61-116
     s.ringOpFirst = (int32_t)plan.ringOps.size();
-    const double weight = s.length;
-    if (!(weight > 0)) {
-      s.ringInsSlot = 0;  // unreachable in a valid run (status already set)
-    } else if (weight >= kMeanNppDays) {
-      start = last = 0;
-      w[0] = kMeanNppDays;
-      insStep[0] = t;
-      s.ringInsSlot = -1;
-    } else {
-      double left = weight;
-      int i = start;
-      while (left > 0) {
-        RingOp op;
-        op.slot = i;
-        op.insStep = insStep[i];
-        if (w[i] > left) {
-          w[i] -= left;
-          op.w = left;
-          left = 0;
-        } else {
-          op.w = w[i];
-          left -= w[i];
-          i = (i + 1) % SIPNET_RING_SLOTS;
-        }
-        plan.ringOps.push_back(op);
-      }
-      start = i;
-      i = (last + 1) % SIPNET_RING_SLOTS;
-      if (i == start) {
-        if (plan.status == SIPNET_OK) {  // sipnet.c:1562-1569
-          plan.status = SIPNET_ERR_INTERNAL;
-          plan.message =
-              "running-mean NPP ring overflow (more than 250 steps in 5 days)";
-        }
-        s.ringInsSlot = i;
-      } else {
-        last = i;
-        w[i] = weight;
-        insStep[i] = t;
-        s.ringInsSlot = i;
-      }
+    bool overflow = false;
+    s.ringInsSlot = ring.advance(t, s.length, &plan.ringOps, &overflow);
+    if (overflow && plan.status == SIPNET_OK) {  // sipnet.c:1562-1569
+      plan.status = SIPNET_ERR_INTERNAL;
+      plan.message = "running-mean NPP ring overflow (more than 250 steps in 5 days)";
     }
     s.ringOpCount = (int32_t)plan.ringOps.size() - s.ringOpFirst;
 
@@ -202,6 +214,14 @@ SitePlan buildSitePlan(const int32_t* flags, int32_t n_steps, const double* clim
     s.invWspd = 1.0 / s.wspd;
     s.sublNum = convS * (kEStarSnow - s.vPress);
     s.evapNum = convE * s.vpdSoil;
+  }
+  if (fin) {
+    fin->set = true;
+    fin->gdd = trackGdd;
+    fin->trackLastYear = trackLastYear;
+    fin->phenLastYear = phenLastYear;
+    fin->dTill = dTill;
+    fin->ring = ring;
   }
   return plan;
 }

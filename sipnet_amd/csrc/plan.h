@@ -105,6 +105,38 @@ enum : int32_t {
   FAST_TSOIL_SAME = 128  // tsoil identical to the previous record: Q10 factors can be reused
 };
 
+// Weights and cursors of the running-mean ring as the reference holds them when a member
+// inserts on every step (runmean.c:44-52, :61-116); they depend on the step lengths only.
+struct RingSched {
+  double w[SIPNET_RING_SLOTS];
+  int32_t insStep[SIPNET_RING_SLOTS];  // step that wrote the slot (RingOp.insStep)
+  int32_t start = 0, last = 0;
+  RingSched() {
+    for (int i = 0; i < SIPNET_RING_SLOTS; i++) {
+      w[i] = 0.0;
+      insStep[i] = -1;
+    }
+    reset(-1);
+  }
+  // resetMeanTracker(), runmean.c:44-52: one entry carrying the whole window
+  void reset(int32_t step);
+  // addValueToMeanTracker(), runmean.c:61-116, for a step of length `weight`: appends the
+  // evictions to *ops (may be null), returns the insert slot (-1 = ring reset to the new
+  // value); *overflow is set when the ring is full (return code -2 of the reference).
+  int32_t advance(int32_t step, double weight, std::vector<RingOp>* ops, bool* overflow);
+};
+
+// Site-uniform state a plan starts from / ends with: what a restart checkpoint carries for
+// the quantities the plan owns (restart.c:246, :262, :278, :294 and the mean.npp.* layout).
+struct PlanCarry {
+  bool set = false;
+  double gdd = 0.0;          // trackers.gdd
+  int32_t trackLastYear = -1;  // trackers.lastYear (sipnet.c:1412)
+  int32_t phenLastYear = 0;  // phenologyTrackers.lastYear (sipnet.c:1524)
+  double dTill = 0.0;        // eventTrackers.d_till_mod (events.c:809)
+  RingSched ring;
+};
+
 struct SitePlan {
   std::vector<StepRec> steps;
   std::vector<RingOp> ringOps;  // StepRec.ringOpFirst is local to this vector
@@ -119,6 +151,7 @@ std::vector<FastRec> buildFastRecs(const SitePlan& plan);
 
 SitePlan buildSitePlan(const int32_t* flags, int32_t n_steps, const double* clim,
                        const int32_t* year, const int32_t* day, int32_t n_events,
-                       const sipnet_event* events);
+                       const sipnet_event* events, const PlanCarry* init = nullptr,
+                       PlanCarry* fin = nullptr);
 
 }  // namespace sipnet

@@ -9,12 +9,14 @@
 //   derived file names, run order   sipnet/frontend.c:130-253
 //   --dump-config format            common/context.c:225-268
 //   single-variable outputs         sipnet/outputItems.c:126-150, sipnet/sipnet.c:1993-1998
+//   restart checkpoints             sipnet/sipnet.c:1963-1989, sipnet/restart.c:932-996
 // The model itself runs on the GPU through libsipnet_amd.so; there is no CPU model here.
 //
 // Additive extension (never changes single-run behaviour):
 //   --ensemble-params FILE   whitespace table, first line = parameter names, one row per
 //                            member overriding those parameters; every member runs in ONE
-//                            batch and writes <prefix>.<m>.out (m = 0..M-1)
+//                            batch and writes <prefix>.<m>.out (m = 0..M-1); restart paths
+//                            get the same .<m> suffix
 #include <getopt.h>
 #include <strings.h>
 
@@ -80,6 +82,7 @@ struct Context {
 bool g_quiet = false;
 void logInfo(const std::string& s) { if (!g_quiet) printf("[INFO   ] %s", s.c_str()); }
 void logError(const std::string& s) { printf("[ERROR  ] %s", s.c_str()); }
+void logWarning(const std::string& s) { printf("[WARNING] %s", s.c_str()); }
 
 void initContext(Context& c) {  // context.c:26-71
   c.addInt("events", "EVENTS", 1);
@@ -132,6 +135,8 @@ void usage(const char* prog) {
   printf("  --growth-resp --leaf-water --litter-pool --nitrogen-cycle --snow --soil-phenol\n");
   printf("  --water-hresp --carbon-saturation\n");
   printf("Output flags: --do-main-output --do-single-outputs --dump-config --print-header --quiet\n");
+  printf("      --restart-in <path>     Read a restart checkpoint from path\n");
+  printf("      --restart-out <path>    Write a restart checkpoint to path at end of run\n");
   printf("  --ensemble-params <file>    run one member per row of a parameter table in one batch\n");
   printf("  -h, --help   -v, --version\n");
 }
@@ -269,8 +274,8 @@ int main(int argc, char** argv) {
   if (ctx.i("anaerobic") && !ctx.i("waterHResp")) { logError("anaerobic requires water-hresp to be turned on\n"); bad = true; }
   if (ctx.i("carbonSaturation") && !ctx.i("litterPool")) { logError("carbon-saturation requires litter-pool to be turned on\n"); bad = true; }
   if (bad) return 3;
-  if (!ctx.s("restartIn").empty() || !ctx.s("restartOut").empty() || !ctx.s("debugLogPrefix").empty())
-    die(8, "--restart-in/--restart-out/--debug-log are not supported by this engine yet\n");
+  if (!ctx.s("debugLogPrefix").empty())
+    die(8, "--debug-log is not supported by this engine\n");
 
   // ---- derived names (frontend.c:164-209) ----
   const std::string prefix = ctx.s("filePrefix");
@@ -337,6 +342,30 @@ int main(int argc, char** argv) {
     logInfo("ensemble of " + std::to_string(M) + " members in one batch\n");
   }
 
+  // ---- restart checkpoint to resume from (restartLoadCheckpoint, restart.c:968-996) ----
+  const std::string restartIn = ctx.s("restartIn"), restartOut = ctx.s("restartOut");
+  std::vector<sipnet_restart> resume;
+  if (!restartIn.empty()) {
+    resume.resize(M);
+    const double* c0 = sipnet_clim_data(clim);
+    for (int m = 0; m < M; m++) {
+      const std::string path = ensembleFile.empty() ? restartIn : restartIn + "." + std::to_string(m);
+      check(sipnet_io_read_restart(path.c_str(), &resume[m]), "reading restart checkpoint");
+      int32_t warn = 0;
+      check(sipnet_restart_check(&resume[m], flags, T > 0, T > 0 ? sipnet_clim_year(clim)[0] : 0,
+                                 T > 0 ? sipnet_clim_day(clim)[0] : 0, T > 0 ? c0[10] : 0.0,
+                                 T > 0 ? c0[0] : 0.0, &warn), "restart checkpoint");
+      if (warn & SIPNET_RESTART_WARN_BOUNDARY_NOT_MIDNIGHT)
+        logWarning("Restart checkpoint boundary in " + path + " is more than one timestep before "
+                   "midnight; there is a time gap on resume.\n");
+      if (warn & SIPNET_RESTART_WARN_BUILD_INFO)
+        logInfo(std::string("Restart build info mismatch: checkpoint=") + resume[m].build_info + "\n");
+      if (warn & SIPNET_RESTART_WARN_TIME_GAP)
+        logWarning("Restart resumed segment starts more than one timestep after midnight "
+                   "checkpoint boundary; there is a time gap\n");
+    }
+  }
+
   // ---- run on the GPU ----
   sipnet_batch* b = nullptr;
   check(sipnet_batch_create(flags, 1, M, SIPNET_F64, 0, &b), "creating batch");
@@ -344,7 +373,10 @@ int main(int argc, char** argv) {
   check(sipnet_batch_set_climate(b, 0, T, sipnet_clim_data(clim), sipnet_clim_year(clim),
                                  sipnet_clim_day(clim)), "climate");
   check(sipnet_batch_set_params(b, 0, 0, M, members.data()), "parameters");
+  if (!resume.empty()) check(sipnet_batch_set_resume(b, 0, &resume[0]), "restart checkpoint");
   check(sipnet_batch_setup(b, nullptr), "setupModel");
+  if (!resume.empty())
+    check(sipnet_batch_import_restart(b, 0, 0, M, resume.data(), nullptr), "restart checkpoint");
   std::vector<double> state0((size_t)M * SIPNET_NSTATE);
   check(sipnet_batch_get_state(b, state0.data(), nullptr), "state");
   const size_t recElems = (size_t)T * SIPNET_NREC * M;
@@ -380,6 +412,20 @@ int main(int argc, char** argv) {
                                        T, sipnet_clim_year(clim), sipnet_clim_day(clim),
                                        sipnet_clim_data(clim), nEvents, events, one.data(),
                                        state0.data() + (size_t)m * SIPNET_NSTATE), "writing events.out");
+    if (!restartOut.empty()) {  // restartWriteCheckpoint, restart.c:932-996
+      const std::string path = restartOut + tag;
+      sipnet_restart ck;
+      const double* prevPools = T >= 2 ? one.data() + (size_t)(T - 2) * SIPNET_NREC + 14
+                                       : state0.data() + (size_t)m * SIPNET_NSTATE;
+      check(sipnet_batch_export_restart(b, 0, m, T, one.data() + (size_t)(T - 1) * SIPNET_NREC,
+                                        prevPools, &ck, nullptr), "restart checkpoint");
+      int32_t warn = 0;
+      check(sipnet_restart_check_boundary_for_write(&ck, &warn), "restart checkpoint");
+      if (warn & SIPNET_RESTART_WARN_BOUNDARY_NOT_MIDNIGHT)
+        logWarning("Restart checkpoint " + path + " ends more than one timestep before midnight; "
+                   "there will be a time gap if this file is used to resume.\n");
+      check(sipnet_io_write_restart(path.c_str(), &ck), "writing restart checkpoint");
+    }
     if (ctx.i("doSingleOutputs")) {  // sipnet.c:1993-1998, outputItems.c:126-150
       const struct { const char* name; int col; } items[] = {{"NEE", 0}, {"NEE_cum", 3}, {"GPP", 1}, {"GPP_cum", 35}};
       for (const auto& it : items) {

@@ -109,3 +109,31 @@ def write_events_out(path, flags, raw_params, clim, events, rec, init_pools, pri
                                            clim.n_steps, clim.year.ctypes.data, clim.day.ctypes.data,
                                            clim.data.ctypes.data, n, arr, rec.ctypes.data,
                                            pools.ctypes.data), "write_events_out")
+
+
+def read_restart(path):
+    """Parse a `SIPNET_RESTART` checkpoint (restart.c:590-756) -> _lib.Restart."""
+    from ._lib import Restart
+    r = Restart()
+    check(lib().sipnet_io_read_restart(str(path).encode(), C.byref(r)), "read_restart")
+    return r
+
+
+def write_restart(path, restart):
+    """Write a checkpoint in the reference's text layout (restart.c:787-828)."""
+    check(lib().sipnet_io_write_restart(str(path).encode(), C.byref(restart)), "write_restart")
+
+
+def check_restart(restart, flags, clim):
+    """Load-time checks of restartLoadCheckpoint (restart.c:968-996) against the segment
+    about to run; returns the warning bits, raises SipnetError(9) on a mismatch."""
+    fl = (C.c_int32 * 12)(*flags)
+    warn = C.c_int32(0)
+    has = 1 if clim is not None and clim.n_steps > 0 else 0
+    y0 = int(clim.year[0]) if has else 0
+    d0 = int(clim.day[0]) if has else 0
+    t0 = float(clim.data[0, 10]) if has else 0.0
+    l0 = float(clim.data[0, 0]) if has else 0.0
+    check(lib().sipnet_restart_check(C.byref(restart), fl, has, y0, d0, t0, l0, C.byref(warn)),
+          "check_restart")
+    return warn.value

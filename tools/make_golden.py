@@ -178,9 +178,131 @@ def synthetic():
     print("allflags", rec2.shape)
 
 
+REF_BIN = os.path.join(REPO, "oracle", "_ref", "sipnet_ref")
+
+
+def run_ref_cli(workdir, args):
+    r = subprocess.run([REF_BIN] + args, cwd=workdir, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True)
+    assert r.returncode == 0, (args, r.stdout[-2000:])
+    return r.stdout
+
+
+def day_split_index(lines, ycol, approx):
+    """first row index >= approx that starts a new day"""
+    key = lambda ln: tuple(ln.split()[ycol:ycol + 2])
+    k = approx
+    while key(lines[k]) == key(lines[k - 1]):
+        k += 1
+    return k
+
+
+def restart_case(name, param_src, clim_lines, split, in_text, events_full, events_seg1, events_seg2,
+                 keep_inputs):
+    """Run the real reference continuous / segment 1 / segment 2 (resuming from its own
+    checkpoint) and keep: seg1.restart, seg2.restart, seg1.out, seg2.out (+ events.out)."""
+    import tempfile
+    d = os.path.join(GOLD, "restart", name)
+    os.makedirs(d, exist_ok=True)
+    with tempfile.TemporaryDirectory() as w:
+        shutil.copyfile(param_src, os.path.join(w, "run.param"))
+        open(os.path.join(w, "sipnet.in"), "w").write(in_text)
+        def go(lines, events, extra):
+            open(os.path.join(w, "run.clim"), "w").writelines(lines)
+            open(os.path.join(w, "events.in"), "w").write(events)
+            run_ref_cli(w, ["-i", "sipnet.in", "-f", "run"] + extra)
+        go(clim_lines, events_full, [])
+        shutil.copyfile(os.path.join(w, "run.out"), os.path.join(w, "continuous.out"))
+        shutil.copyfile(os.path.join(w, "events.out"), os.path.join(w, "continuous.events.out"))
+        go(clim_lines[:split], events_seg1, ["--restart-out", "seg1.restart"])
+        shutil.copyfile(os.path.join(w, "run.out"), os.path.join(w, "seg1.out"))
+        shutil.copyfile(os.path.join(w, "events.out"), os.path.join(w, "seg1.events.out"))
+        go(clim_lines[split:], events_seg2, ["--restart-in", "seg1.restart", "--restart-out", "seg2.restart"])
+        shutil.copyfile(os.path.join(w, "run.out"), os.path.join(w, "seg2.out"))
+        shutil.copyfile(os.path.join(w, "events.out"), os.path.join(w, "seg2.events.out"))
+        # the property the reference's own test asserts (testRestartMVP.c:253-304)
+        cont = open(os.path.join(w, "continuous.out")).read().splitlines()
+        s1 = open(os.path.join(w, "seg1.out")).read().splitlines()
+        s2 = open(os.path.join(w, "seg2.out")).read().splitlines()
+        hdr = 1 if "year" in cont[0] else 0
+        assert cont == s1 + s2[hdr:], f"{name}: reference segmented run differs from continuous"
+        for f in ["seg1.restart", "seg2.restart", "seg1.events.out", "seg2.events.out"]:
+            shutil.copyfile(os.path.join(w, f), os.path.join(d, f))
+        gz_copy(os.path.join(w, "seg1.out"), os.path.join(d, "seg1.out.gz"))
+        gz_copy(os.path.join(w, "seg2.out"), os.path.join(d, "seg2.out.gz"))
+    open(os.path.join(d, "sipnet.in"), "w").write(in_text)
+    open(os.path.join(d, "events_seg1.in"), "w").write(events_seg1)
+    open(os.path.join(d, "events_seg2.in"), "w").write(events_seg2)
+    open(os.path.join(d, "split.txt"), "w").write(f"{split}\n")
+    if keep_inputs:
+        shutil.copyfile(param_src, os.path.join(d, "run.param"))
+        open(os.path.join(d, "full.clim"), "w").writelines(clim_lines)
+    print("restart case", name, "split", split, "of", len(clim_lines))
+
+
+def split_events(text, clim_lines, split, ycol):
+    """events before / from the first record of segment 2"""
+    y, dd = (int(v) for v in clim_lines[split].split()[ycol:ycol + 2])
+    a, b = [], []
+    for ln in text.splitlines(True):
+        t = ln.split()
+        if len(t) < 3:
+            continue
+        (a if (int(t[0]), int(t[1])) < (y, dd) else b).append(ln)
+    return "".join(a), "".join(b)
+
+
+def restart_cases():
+    R = os.path.join(REF, "tests", "sipnet", "test_restart_infrastructure")
+    rd = lambda f: open(os.path.join(R, f)).read()
+    # 1. the reference's own restart test case (testRestartMVP.c): its data files
+    d = os.path.join(GOLD, "restart", "mvp")
+    os.makedirs(d, exist_ok=True)
+    for f in ["restart_segment2_bad.clim", "restart_segment2_late.clim",
+              "restart_segment1_not_midnight.clim"]:
+        shutil.copyfile(os.path.join(R, f), os.path.join(d, f))
+    full = open(os.path.join(R, "restart_full.clim")).readlines()
+    n1 = len(open(os.path.join(R, "restart_segment1.clim")).readlines())
+    assert full[:n1] == open(os.path.join(R, "restart_segment1.clim")).readlines()
+    assert full[n1:] == open(os.path.join(R, "restart_segment2.clim")).readlines()
+    restart_case("mvp", os.path.join(R, "restart.param"), full, n1, "EVENTS 1\nQUIET 1\n",
+                 rd("events_base.in"), rd("events_segment1.in"), rd("events_segment2.in"), True)
+
+    sm = os.path.join(REF, "tests", "smoke")
+    # 2. niwot: default flags, day/night steps, no events
+    lines = open(os.path.join(sm, "niwot", "sipnet.clim")).readlines()
+    k = day_split_index(lines, 1, 2700)
+    restart_case("niwot", os.path.join(sm, "niwot", "sipnet.param"), lines, k,
+                 "PRINT_HEADER = 0\nQUIET = 1\n", "", "", "", False)
+    # 3. russell_2: litter pool + nitrogen cycle + anaerobic, irrigation and fertiliser events
+    lines = open(os.path.join(sm, "russell_1", "sipnet.clim")).readlines()
+    k = day_split_index(lines, 0, 1500)
+    ev = open(os.path.join(sm, "russell_2", "events.in")).read()
+    e1, e2 = split_events(ev, lines, k, 0)
+    restart_case("russell_2", os.path.join(sm, "russell_2", "sipnet.param"), lines, k,
+                 "EVENTS = 1\nLITTER_POOL = 1\nNITROGEN_CYCLE = 1\nANAEROBIC = 1\nQUIET = 1\n",
+                 ev, e1, e2, False)
+    # 4. clear-cut and re-planting shortly before the boundary: the member dies (ring reset,
+    #    sipnet.c:1757), is re-planted, and the checkpoint is taken while the ring still
+    #    holds its reset entry; tillage modifier still decaying across the boundary
+    ev = ("2016 150 harv 1.0 1.0 0.0 0.0\n2016 158 till 0.4\n"
+          "2016 160 plant 20 300 40 60\n2016 170 irrig 2.5 0\n")
+    k = day_split_index(lines, 0, 8 * 161 + 4)
+    e1, e2 = split_events(ev, lines, k, 0)
+    restart_case("russell_replant", os.path.join(sm, "russell_1", "sipnet.param"), lines, k,
+                 "EVENTS = 1\nQUIET = 1\n", ev, e1, e2, False)
+    # 5. half-hourly synthetic year: 240 live ring entries, cursors wrapped several times
+    import gzip as gz
+    lines = gz.open(os.path.join(GOLD, "synth", "halfhourly.clim.gz"), "rt").readlines()
+    k = day_split_index(lines, 0, 48 * 200 + 7)
+    restart_case("halfhourly", os.path.join(REPO, "sipnet_amd", "data", "base_forest.param"), lines, k,
+                 "PRINT_HEADER = 0\nQUIET = 1\n", "", "", "", False)
+
+
 if __name__ == "__main__":
     subprocess.check_call(["make", "-s", "-C", os.path.join(REPO, "oracle"), "ref", "oracle"])
     copy_smoke()
     smoke_records()
     synthetic()
+    restart_cases()
     subprocess.run(["du", "-sh", GOLD])
