@@ -265,7 +265,7 @@ int sipnet_batch_import_restart(sipnet_batch *b, int32_t site, int32_t first_mem
  * before use; prev_pools[13] (HOST, may be NULL) are the pools before that step and
  * are only needed for harvest fractions when a harvest falls on the last record.
  * meta_info: model_version "2.1.0", build_info = sipnet_version() sanitised,
- * epoch = now, processed_steps = n_steps_done. */
+ * epoch = now, processed_steps = n_steps_done (+ the count resumed from). */
 int sipnet_batch_export_restart(sipnet_batch *b, int32_t site, int32_t member,
                                 int32_t n_steps_done, const double *last_rec,
                                 const double *prev_pools, sipnet_restart *out,

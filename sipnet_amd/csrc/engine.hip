@@ -44,6 +44,7 @@ struct sipnet_batch {
   std::vector<std::vector<sipnet_event>> events;
   std::vector<SitePlan> plans;
   std::vector<PlanCarry> resume;  // per site: state the plan starts from (restart)
+  std::vector<int64_t> resumeProcessed;  // per site: meta_info.processed_steps resumed from
   std::vector<int32_t> siteStatus;
   bool planDirty = true;
   int32_t stepsDone = 0;       // records the carried state reflects, -1 = unknown
@@ -194,6 +195,7 @@ int sipnet_batch_create(const int32_t* flags, int32_t n_sites, int32_t n_members
   b->day.resize(n_sites);
   b->events.resize(n_sites);
   b->resume.resize(n_sites);
+  b->resumeProcessed.assign(n_sites, 0);
   b->siteStatus.assign(n_sites, 0);
   int rc = useDevice(b);
   if (rc) { delete b; return rc; }
@@ -558,6 +560,7 @@ int sipnet_batch_set_resume(sipnet_batch* b, int32_t site, const sipnet_restart*
   }
   PlanCarry& c = b->resume[site];
   c = PlanCarry{};
+  b->resumeProcessed[site] = 0;
   b->planDirty = true;
   if (!r) return SIPNET_OK;
   if (r->mean_length != SIPNET_RING_SLOTS || r->mean_start < 0 ||
@@ -567,6 +570,7 @@ int sipnet_batch_set_resume(sipnet_batch* b, int32_t site, const sipnet_restart*
     return SIPNET_ERR_RESTART;
   }
   c.set = true;
+  b->resumeProcessed[site] = r->processed_steps;  // the count runs on, restart.c:912-920
   c.gdd = r->trackers[SIPNET_RT_GDD];
   c.trackLastYear = r->trackers_last_year;
   c.phenLastYear = r->phenology_last_year;
@@ -720,7 +724,7 @@ int sipnet_batch_export_restart(sipnet_batch* b, int32_t site, int32_t member,
     snprintf(out->build_info, sizeof out->build_info, "%s", info.c_str());
   }
   out->checkpoint_utc_epoch = (int64_t)time(nullptr);
-  out->processed_steps = n;
+  out->processed_steps = b->resumeProcessed[site] + n;
   memcpy(out->flags, b->flags, sizeof out->flags);
   out->boundary_year = b->year[site][n - 1];
   out->boundary_day = b->day[site][n - 1];
