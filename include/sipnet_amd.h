@@ -271,6 +271,42 @@ int sipnet_batch_export_restart(sipnet_batch *b, int32_t site, int32_t member,
                                 const double *prev_pools, sipnet_restart *out,
                                 void *hip_stream);
 
+/* ---- particle-filter analysis step (BASELINE config C5) -------------------
+ * The reference has no particle filter: PEcAn runs one process per particle and moves
+ * restart files between cycles.  Here a cycle is: sipnet_batch_run (forecast) ->
+ * pf_log_weights -> [all-gather of log-weights across GPUs] -> pf_systematic_ancestors over
+ * the GLOBAL particle set (computed redundantly and bit-identically on every rank) ->
+ * pack_members for the columns other ranks need -> [all-to-all] -> resample.  What moves per
+ * particle is its checkpoint: the carried state vector and ring (+ converted parameters
+ * when particles carry their own parameters).  One site per batch.
+ *
+ * logw[col] = -0.5 * ((sum_t plane[t][col] - obs) / sigma)^2 (Gaussian likelihood of an
+ * observed flux sum, e.g. daily NEE); -inf for members whose status is non-zero. */
+int sipnet_batch_pf_log_weights(sipnet_batch *b, const void *d_plane, int32_t elem_is_f32,
+                                int32_t n_steps, int64_t ld, double obs, double sigma,
+                                double *d_logw, void *hip_stream);
+/* Systematic resampling: w_i = llrint(exp(logw_i - max logw) * 2^30) (integer weights make
+ * the prefix sum exact and the result identical on every rank), S = sum w,
+ * ancestor[j] = first i with cdf[i] > min(((j + u0) * S) / n, S - 1), 0 <= u0 < 1.
+ * Ancestors are non-decreasing.  d_logw[n], d_ancestors[n], optional d_fixed_weights[n]
+ * (the integer weights, for checking) are DEVICE pointers; n <= 4 194 304. */
+int sipnet_pf_systematic_ancestors(const double *d_logw, int64_t n, double u0,
+                                   int32_t *d_ancestors, int64_t *d_fixed_weights,
+                                   void *hip_stream);
+/* doubles per particle in a packed block: SIPNET_NSTATE + SIPNET_RING_SLOTS (+ SIPNET_NPARAMS) */
+int32_t sipnet_pf_member_words(int32_t with_params);
+/* Pack columns d_cols[n] (DEVICE, local column indices) into d_buf laid out
+ * [sipnet_pf_member_words][n]: state rows, ring rows, then parameter rows. */
+int sipnet_batch_pack_members(sipnet_batch *b, const int32_t *d_cols, int64_t n,
+                              int32_t with_params, double *d_buf, void *hip_stream);
+/* Replace every column j by its ancestor d_src[j] (DEVICE, [ncol]): an index < ncol is one
+ * of this batch's own (old) columns; ncol + k is received column k, where d_recv is the
+ * concatenation of n_blocks packed blocks with block_cols[s] (HOST) columns each.
+ * Gathers into spare buffers and swaps them in. */
+int sipnet_batch_resample(sipnet_batch *b, const int32_t *d_src, const double *d_recv,
+                          int32_t n_blocks, const int64_t *block_cols, int32_t with_params,
+                          void *hip_stream);
+
 int64_t sipnet_batch_ncol(const sipnet_batch *b);
 int32_t sipnet_batch_nsteps(const sipnet_batch *b);
 /* Site-uniform trajectory computed by the plan: gdd[t] (trackers.gdd after

@@ -184,6 +184,43 @@ class Batch:
             pp.ctypes.data if pp is not None else None, C.byref(r), self._stream()), "export_restart")
         return r
 
+    # -- particle-filter analysis step (pf.hip; BASELINE config C5) ---------------
+    def pf_log_weights(self, plane, obs, sigma, out=None):
+        """Gaussian log-likelihood of an observed flux sum: plane[T][ncol] (NEE, GPP or ET
+        plane of the forecast) -> logw[ncol] f64 on the device."""
+        t = self._torch
+        if out is None:
+            out = t.empty(self.ncol, dtype=t.float64, device=self.device)
+        check(self.L.sipnet_batch_pf_log_weights(
+            self.h, C.c_void_p(plane.data_ptr()), int(plane.dtype == t.float32), plane.shape[0],
+            plane.shape[1], float(obs), float(sigma), C.c_void_p(out.data_ptr()), self._stream()),
+            "pf_log_weights")
+        return out
+
+    def pack_members(self, cols, with_params=False):
+        """cols: int32 device tensor of local column indices -> packed block [words][n] f64"""
+        t = self._torch
+        words = self.L.sipnet_pf_member_words(int(with_params))
+        cols = cols.to(device=self.device, dtype=t.int32).contiguous()
+        buf = t.empty((words, cols.numel()), dtype=t.float64, device=self.device)
+        if cols.numel():
+            check(self.L.sipnet_batch_pack_members(self.h, C.c_void_p(cols.data_ptr()), cols.numel(),
+                                                   int(with_params), C.c_void_p(buf.data_ptr()),
+                                                   self._stream()), "pack_members")
+        return buf
+
+    def resample(self, src, recv=None, block_cols=(), with_params=False):
+        """Column j becomes its ancestor src[j]: < ncol = own old column, ncol + k = received
+        column k of `recv` (concatenated packed blocks with block_cols[s] columns each)."""
+        t = self._torch
+        src = src.to(device=self.device, dtype=t.int32).contiguous()
+        assert src.numel() == self.ncol
+        nb = len(block_cols)
+        bc = (C.c_int64 * max(nb, 1))(*[int(x) for x in block_cols])
+        rp = C.c_void_p(recv.data_ptr()) if recv is not None and recv.numel() else None
+        check(self.L.sipnet_batch_resample(self.h, C.c_void_p(src.data_ptr()), rp, nb, bc,
+                                           int(with_params), self._stream()), "resample")
+
     def site_series(self, site):
         g = np.zeros(self.n_steps)
         d = np.zeros(self.n_steps)

@@ -1,0 +1,72 @@
+// batch_impl.h -- the batch object behind include/sipnet_amd.h (shared by engine.hip and pf.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/sipnet_amd.h"
+#include "plan.h"
+#include "step_kernel.h"
+
+namespace sipnet {
+void setError(const std::string& s);
+}
+using namespace sipnet;  // internal header: only engine.hip and pf.hip include it
+
+#define HIP_TRY(expr)                                                         \
+  do {                                                                        \
+    hipError_t e_ = (expr);                                                   \
+    if (e_ != hipSuccess) {                                                   \
+      setError(std::string(#expr) + ": " + hipGetErrorString(e_));            \
+      return SIPNET_ERR_NO_DEVICE;                                            \
+    }                                                                         \
+  } while (0)
+
+struct sipnet_batch {
+  int32_t flags[SIPNET_NFLAGS];
+  int32_t n_sites = 0, n_members = 0, precision = 0, device = 0;
+  int64_t ncol = 0;
+  int32_t n_steps = 0;  // steps per site (all sites equal)
+  bool fastMath = false;
+  bool genericExponents = false;  // some member has dVpdExp != 2 or soilRespMoistEffect != 1
+
+  // host-side inputs kept so the plan can be rebuilt in any call order
+  std::vector<std::vector<double>> clim;       // per site [n_steps*NCLIM]
+  std::vector<std::vector<int32_t>> year, day;
+  std::vector<std::vector<sipnet_event>> events;
+  std::vector<SitePlan> plans;
+  std::vector<PlanCarry> resume;  // per site: state the plan starts from (restart)
+  std::vector<int64_t> resumeProcessed;  // per site: meta_info.processed_steps resumed from
+  std::vector<int32_t> siteStatus;
+  bool planDirty = true;
+  int32_t stepsDone = 0;       // records the carried state reflects, -1 = unknown
+
+  // HBM
+  double* d_raw = nullptr;     // [ncol][NPARAMS] raw upload (AoS)
+  double* d_prm = nullptr;     // [NPARAMS][ncol]
+  double* d_state = nullptr;   // [NSTATE][ncol]
+  double* d_ring = nullptr;    // [RING_SLOTS][ncol]
+  // second copies for particle-filter resampling (gather into the spare, then swap); lazily made
+  double* d_prm2 = nullptr;
+  double* d_state2 = nullptr;
+  double* d_ring2 = nullptr;
+  StepRec* d_plan = nullptr;   // [n_sites][n_steps]
+  FastRec* d_fast = nullptr;   // [n_sites][n_steps] + kFastTile padding records
+  double* d_scratchRow = nullptr;  // [ncol]
+  RingOp* d_ringOps = nullptr;
+  EvRec* d_events = nullptr;
+  int32_t* d_siteStatus = nullptr;
+  size_t planCap = 0, ringOpCap = 0, evCap = 0;
+
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timed = false;
+  double lastMs = -1.0;
+};
+
+inline int useDevice(const sipnet_batch* b) {
+  HIP_TRY(hipSetDevice(b->device));
+  return SIPNET_OK;
+}
+

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/sipnet_amd.h"
+#include "batch_impl.h"
 #include "plan.h"
 #include "step_kernel.h"
 
@@ -20,57 +21,6 @@ void setError(const std::string& s) { g_lastError = s; }
 }  // namespace sipnet
 
 using namespace sipnet;
-
-#define HIP_TRY(expr)                                                         \
-  do {                                                                        \
-    hipError_t e_ = (expr);                                                   \
-    if (e_ != hipSuccess) {                                                   \
-      setError(std::string(#expr) + ": " + hipGetErrorString(e_));            \
-      return SIPNET_ERR_NO_DEVICE;                                            \
-    }                                                                         \
-  } while (0)
-
-struct sipnet_batch {
-  int32_t flags[SIPNET_NFLAGS];
-  int32_t n_sites = 0, n_members = 0, precision = 0, device = 0;
-  int64_t ncol = 0;
-  int32_t n_steps = 0;  // steps per site (all sites equal)
-  bool fastMath = false;
-  bool genericExponents = false;  // some member has dVpdExp != 2 or soilRespMoistEffect != 1
-
-  // host-side inputs kept so the plan can be rebuilt in any call order
-  std::vector<std::vector<double>> clim;       // per site [n_steps*NCLIM]
-  std::vector<std::vector<int32_t>> year, day;
-  std::vector<std::vector<sipnet_event>> events;
-  std::vector<SitePlan> plans;
-  std::vector<PlanCarry> resume;  // per site: state the plan starts from (restart)
-  std::vector<int64_t> resumeProcessed;  // per site: meta_info.processed_steps resumed from
-  std::vector<int32_t> siteStatus;
-  bool planDirty = true;
-  int32_t stepsDone = 0;       // records the carried state reflects, -1 = unknown
-
-  // HBM
-  double* d_raw = nullptr;     // [ncol][NPARAMS] raw upload (AoS)
-  double* d_prm = nullptr;     // [NPARAMS][ncol]
-  double* d_state = nullptr;   // [NSTATE][ncol]
-  double* d_ring = nullptr;    // [RING_SLOTS][ncol]
-  StepRec* d_plan = nullptr;   // [n_sites][n_steps]
-  FastRec* d_fast = nullptr;   // [n_sites][n_steps] + kFastTile padding records
-  double* d_scratchRow = nullptr;  // [ncol]
-  RingOp* d_ringOps = nullptr;
-  EvRec* d_events = nullptr;
-  int32_t* d_siteStatus = nullptr;
-  size_t planCap = 0, ringOpCap = 0, evCap = 0;
-
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  bool timed = false;
-  double lastMs = -1.0;
-};
-
-static int useDevice(const sipnet_batch* b) {
-  HIP_TRY(hipSetDevice(b->device));
-  return SIPNET_OK;
-}
 
 static int uploadPlan(sipnet_batch* b, hipStream_t stream) {
   // every site needs forcing of equal length
@@ -227,6 +177,9 @@ void sipnet_batch_destroy(sipnet_batch* b) {
   if (b->d_prm) (void)hipFree(b->d_prm);
   if (b->d_state) (void)hipFree(b->d_state);
   if (b->d_ring) (void)hipFree(b->d_ring);
+  if (b->d_prm2) (void)hipFree(b->d_prm2);
+  if (b->d_state2) (void)hipFree(b->d_state2);
+  if (b->d_ring2) (void)hipFree(b->d_ring2);
   if (b->d_plan) (void)hipFree(b->d_plan);
   if (b->d_fast) (void)hipFree(b->d_fast);
   if (b->d_scratchRow) (void)hipFree(b->d_scratchRow);

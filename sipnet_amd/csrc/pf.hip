@@ -1,0 +1,318 @@
+// pf.hip -- particle-filter analysis step for an ensemble batch (BASELINE config C5,
+// SURVEY.md 8(e) "PF extra exchange"): likelihood weights from an output plane, systematic
+// resampling over the GLOBAL particle set, and the column gathers that move member state
+// (carried state vector + running-mean ring, optionally the converted parameters) inside a
+// GPU and into / out of the packed blocks that travel between GPUs.
+//
+// The reference has no particle filter (PEcAn drives one process per particle and copies
+// restart files between cycles, docs/developer-guide/restart-checkpoint.md); what a cycle
+// exchanges there is exactly a member's checkpoint, which is what these kernels move.
+//
+// All kernels are HBM-bound column gathers over SoA matrices [rows][ncol]: thread = column,
+// blockIdx.y = row, so reads of the index vector and writes are coalesced; after systematic
+// resampling ancestors are non-decreasing, so the gathered reads are near-coalesced too.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <cmath>
+#include <cstdint>
+#include <limits>
+#include <string>
+
+#include "../../include/sipnet_amd.h"
+#include "batch_impl.h"
+
+namespace sipnet {
+namespace {
+
+constexpr int kMaxBlocks = 16;  // source ranks whose packed blocks one gather can read
+
+// Where the received columns live: block s holds [rows][n[s]] doubles at off[s]; received
+// column k (0-based over all blocks) is in the block with start[s] <= k < start[s+1].
+struct RecvMap {
+  int32_t nBlocks;
+  int64_t start[kMaxBlocks + 1];
+  int64_t off[kMaxBlocks];
+  int64_t n[kMaxBlocks];
+};
+
+// dst[row][j] = (src[j] < ncol) ? own[row][src[j]] : recv(row + recvRow0, src[j] - ncol)
+__global__ __launch_bounds__(256) void gatherColumnsKernel(
+    const double* __restrict__ own, int64_t ownPitch, int64_t ncol,
+    const double* __restrict__ recv, RecvMap map, int32_t recvRow0,
+    const int32_t* __restrict__ src, int64_t nOut, double* __restrict__ dst, int64_t dstPitch) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nOut) return;
+  const int row = blockIdx.y;
+  const int64_t s = src[j];
+  double v;
+  if (s < ncol) {
+    v = own[(int64_t)row * ownPitch + s];
+  } else {
+    const int64_t k = s - ncol;
+    int blk = 0;
+    for (int q = 1; q < map.nBlocks; q++)
+      if (k >= map.start[q]) blk = q;
+    v = recv[map.off[blk] + (int64_t)(row + recvRow0) * map.n[blk] + (k - map.start[blk])];
+  }
+  dst[(int64_t)row * dstPitch + j] = v;
+}
+
+// logw[col] = -0.5 * ((sum_t plane[t][col] - obs) / sigma)^2, -inf for members that did not run
+template <typename T>
+__global__ __launch_bounds__(256) void logWeightKernel(const T* __restrict__ plane, int32_t nSteps,
+                                                       int64_t ld, int64_t ncol,
+                                                       const double* __restrict__ status,
+                                                       double obs, double invSigma,
+                                                       double* __restrict__ logw) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncol) return;
+  double acc = 0.0;
+  for (int t = 0; t < nSteps; t++) acc += (double)plane[(int64_t)t * ld + c];
+  const double z = (acc - obs) * invSigma;
+  logw[c] = (status[c] != 0.0) ? -INFINITY : -0.5 * z * z;
+}
+
+// max of the finite log-weights (one block; n is at most a few million)
+__global__ __launch_bounds__(1024) void maxKernel(const double* __restrict__ x, int64_t n,
+                                                  double* __restrict__ out) {
+  __shared__ double sm[1024];
+  double m = -INFINITY;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) m = fmax(m, x[i]);
+  sm[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = 512; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sm[threadIdx.x] = fmax(sm[threadIdx.x], sm[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = sm[0];
+}
+
+// fixed-point weights: w = llrint(exp(logw - max) * 2^30).  Integer weights make the prefix
+// sum exact, so every rank computes bit-identical ancestors from the same gathered logw.
+__global__ __launch_bounds__(256) void fixedWeightKernel(const double* __restrict__ logw,
+                                                         int64_t n, const double* __restrict__ mx,
+                                                         int64_t* __restrict__ w) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double m = mx[0];
+  const double e = exp(logw[i] - m);
+  w[i] = (!(logw[i] > -INFINITY) || !(m > -INFINITY)) ? 0 : llrint(e * 1073741824.0);
+}
+
+// ancestor[j] = first i with cdf[i] > p_j, p_j = ((j + u0) * S) / n  (S = cdf[n-1] < 2^53)
+__global__ __launch_bounds__(256) void ancestorKernel(const int64_t* __restrict__ cdf, int64_t n,
+                                                      double u0, int32_t* __restrict__ anc) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const double S = (double)cdf[n - 1];
+  // S - 1 keeps the search inside the support when (j + u0) rounds up to n
+  const double p = fmin((((double)j + u0) * S) / (double)n, S - 1.0);
+  int64_t lo = 0, hi = n - 1;  // invariant: answer in [lo, hi]
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if ((double)cdf[mid] > p) {
+      hi = mid;
+    } else {
+      lo = mid + 1;
+    }
+  }
+  anc[j] = (int32_t)lo;
+}
+
+// 1 when any member needs the generic-exponent kernel variant (dVpdExp != 2 or
+// soilRespMoistEffect != 1), see engine.hip set_params
+__global__ __launch_bounds__(256) void exponentCheckKernel(const double* __restrict__ prm,
+                                                           int64_t ncol, int32_t* __restrict__ flag) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncol) return;
+  if (prm[(int64_t)SP_dVpdExp * ncol + c] != 2.0 ||
+      prm[(int64_t)SP_soilRespMoistEffect * ncol + c] != 1.0)
+    atomicOr(flag, 1);
+}
+
+void launchGather(const double* own, int64_t ownPitch, int64_t ncol, const double* recv,
+                  const RecvMap& map, int recvRow0, const int32_t* src, int64_t nOut, double* dst,
+                  int64_t dstPitch, int rows, hipStream_t stream) {
+  if (nOut <= 0) return;
+  dim3 grid((unsigned)((nOut + 255) / 256), (unsigned)rows);
+  hipLaunchKernelGGL(gatherColumnsKernel, grid, dim3(256), 0, stream, own, ownPitch, ncol, recv,
+                     map, recvRow0, src, nOut, dst, dstPitch);
+}
+
+}  // namespace
+}  // namespace sipnet
+
+using namespace sipnet;
+
+extern "C" {
+
+int32_t sipnet_pf_member_words(int32_t with_params) {
+  return SIPNET_NSTATE + SIPNET_RING_SLOTS + (with_params ? SIPNET_NPARAMS : 0);
+}
+
+int sipnet_batch_pf_log_weights(sipnet_batch* b, const void* d_plane, int32_t elem_is_f32,
+                                int32_t n_steps, int64_t ld, double obs, double sigma,
+                                double* d_logw, void* hip_stream) {
+  if (!b || !d_plane || !d_logw || n_steps <= 0 || ld < b->ncol || !(sigma > 0)) {
+    setError("sipnet_batch_pf_log_weights: bad argument");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  int rc = useDevice(b);
+  if (rc) return rc;
+  hipStream_t stream = (hipStream_t)hip_stream;
+  const int grid = (int)((b->ncol + 255) / 256);
+  const double* status = b->d_state + (size_t)ST_status * b->ncol;
+  if (elem_is_f32) {
+    hipLaunchKernelGGL(logWeightKernel<float>, dim3(grid), dim3(256), 0, stream,
+                       (const float*)d_plane, n_steps, ld, b->ncol, status, obs, 1.0 / sigma, d_logw);
+  } else {
+    hipLaunchKernelGGL(logWeightKernel<double>, dim3(grid), dim3(256), 0, stream,
+                       (const double*)d_plane, n_steps, ld, b->ncol, status, obs, 1.0 / sigma, d_logw);
+  }
+  HIP_TRY(hipGetLastError());
+  return SIPNET_OK;
+}
+
+int sipnet_pf_systematic_ancestors(const double* d_logw, int64_t n, double u0,
+                                   int32_t* d_ancestors, int64_t* d_fixed_weights,
+                                   void* hip_stream) {
+  if (!d_logw || !d_ancestors || n <= 0 || n > (int64_t)1 << 22 || !(u0 >= 0.0) || !(u0 < 1.0)) {
+    setError("sipnet_pf_systematic_ancestors: bad argument (n <= 4194304, 0 <= u0 < 1)");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  hipStream_t stream = (hipStream_t)hip_stream;
+  double* d_max = nullptr;
+  int64_t *d_w = nullptr, *d_cdf = nullptr;
+  void* d_tmp = nullptr;
+  size_t tmpBytes = 0;
+  auto cleanup = [&]() {
+    if (d_max) (void)hipFree(d_max);
+    if (d_w) (void)hipFree(d_w);
+    if (d_cdf) (void)hipFree(d_cdf);
+    if (d_tmp) (void)hipFree(d_tmp);
+  };
+#define PF_TRY(expr)                                                    \
+  do {                                                                  \
+    hipError_t e_ = (expr);                                             \
+    if (e_ != hipSuccess) {                                             \
+      setError(std::string(#expr) + ": " + hipGetErrorString(e_));      \
+      cleanup();                                                        \
+      return SIPNET_ERR_NO_DEVICE;                                      \
+    }                                                                   \
+  } while (0)
+  PF_TRY(hipMalloc(&d_max, sizeof(double)));
+  PF_TRY(hipMalloc(&d_w, (size_t)n * sizeof(int64_t)));
+  PF_TRY(hipMalloc(&d_cdf, (size_t)n * sizeof(int64_t)));
+  PF_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, tmpBytes, d_w, d_cdf, (int)n, stream));
+  PF_TRY(hipMalloc(&d_tmp, tmpBytes));
+  const int grid = (int)((n + 255) / 256);
+  hipLaunchKernelGGL(maxKernel, dim3(1), dim3(1024), 0, stream, d_logw, n, d_max);
+  hipLaunchKernelGGL(fixedWeightKernel, dim3(grid), dim3(256), 0, stream, d_logw, n, d_max, d_w);
+  PF_TRY(hipcub::DeviceScan::InclusiveSum(d_tmp, tmpBytes, d_w, d_cdf, (int)n, stream));
+  int64_t total = 0;
+  PF_TRY(hipMemcpyAsync(&total, d_cdf + (n - 1), sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+  PF_TRY(hipStreamSynchronize(stream));
+  if (total <= 0) {
+    setError("sipnet_pf_systematic_ancestors: every particle has zero weight");
+    cleanup();
+    return SIPNET_ERR_BAD_PARAMETER;
+  }
+  hipLaunchKernelGGL(ancestorKernel, dim3(grid), dim3(256), 0, stream, d_cdf, n, u0, d_ancestors);
+  PF_TRY(hipGetLastError());
+  if (d_fixed_weights)
+    PF_TRY(hipMemcpyAsync(d_fixed_weights, d_w, (size_t)n * sizeof(int64_t),
+                          hipMemcpyDeviceToDevice, stream));
+  PF_TRY(hipStreamSynchronize(stream));
+#undef PF_TRY
+  cleanup();
+  return SIPNET_OK;
+}
+
+int sipnet_batch_pack_members(sipnet_batch* b, const int32_t* d_cols, int64_t n,
+                              int32_t with_params, double* d_buf, void* hip_stream) {
+  if (!b || n < 0 || (n > 0 && (!d_cols || !d_buf))) {
+    setError("sipnet_batch_pack_members: bad argument");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  int rc = useDevice(b);
+  if (rc) return rc;
+  hipStream_t stream = (hipStream_t)hip_stream;
+  RecvMap none{};
+  // block layout: [NSTATE rows | RING_SLOTS rows | NPARAMS rows] x n columns
+  launchGather(b->d_state, b->ncol, b->ncol, nullptr, none, 0, d_cols, n, d_buf, n, SIPNET_NSTATE, stream);
+  launchGather(b->d_ring, b->ncol, b->ncol, nullptr, none, 0, d_cols, n,
+               d_buf + (size_t)SIPNET_NSTATE * n, n, SIPNET_RING_SLOTS, stream);
+  if (with_params)
+    launchGather(b->d_prm, b->ncol, b->ncol, nullptr, none, 0, d_cols, n,
+                 d_buf + (size_t)(SIPNET_NSTATE + SIPNET_RING_SLOTS) * n, n, SIPNET_NPARAMS, stream);
+  HIP_TRY(hipGetLastError());
+  return SIPNET_OK;
+}
+
+int sipnet_batch_resample(sipnet_batch* b, const int32_t* d_src, const double* d_recv,
+                          int32_t n_blocks, const int64_t* block_cols, int32_t with_params,
+                          void* hip_stream) {
+  if (!b || !d_src || n_blocks < 0 || n_blocks > kMaxBlocks || (n_blocks > 0 && !block_cols)) {
+    setError("sipnet_batch_resample: bad argument");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  if (b->n_sites != 1) {
+    setError("sipnet_batch_resample: particles of different sites must not mix (n_sites must be 1)");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  int rc = useDevice(b);
+  if (rc) return rc;
+  hipStream_t stream = (hipStream_t)hip_stream;
+  const size_t nc = (size_t)b->ncol;
+  if (!b->d_state2) HIP_TRY(hipMalloc(&b->d_state2, nc * SIPNET_NSTATE * sizeof(double)));
+  if (!b->d_ring2) HIP_TRY(hipMalloc(&b->d_ring2, nc * SIPNET_RING_SLOTS * sizeof(double)));
+  if (with_params && !b->d_prm2) HIP_TRY(hipMalloc(&b->d_prm2, nc * SIPNET_NPARAMS * sizeof(double)));
+  const int words = sipnet_pf_member_words(with_params);
+  RecvMap map{};
+  map.nBlocks = n_blocks;
+  int64_t start = 0, off = 0;
+  for (int s = 0; s < n_blocks; s++) {
+    if (block_cols[s] < 0) {
+      setError("sipnet_batch_resample: negative block size");
+      return SIPNET_ERR_BAD_ARGUMENT;
+    }
+    map.start[s] = start;
+    map.off[s] = off;
+    map.n[s] = block_cols[s];
+    start += block_cols[s];
+    off += block_cols[s] * words;
+  }
+  map.start[n_blocks] = start;
+  if (start > 0 && !d_recv) {
+    setError("sipnet_batch_resample: received columns announced but no buffer given");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  launchGather(b->d_state, b->ncol, b->ncol, d_recv, map, 0, d_src, b->ncol, b->d_state2,
+               b->ncol, SIPNET_NSTATE, stream);
+  launchGather(b->d_ring, b->ncol, b->ncol, d_recv, map, SIPNET_NSTATE, d_src, b->ncol,
+               b->d_ring2, b->ncol, SIPNET_RING_SLOTS, stream);
+  if (with_params)
+    launchGather(b->d_prm, b->ncol, b->ncol, d_recv, map, SIPNET_NSTATE + SIPNET_RING_SLOTS,
+                 d_src, b->ncol, b->d_prm2, b->ncol, SIPNET_NPARAMS, stream);
+  HIP_TRY(hipGetLastError());
+  std::swap(b->d_state, b->d_state2);
+  std::swap(b->d_ring, b->d_ring2);
+  if (with_params) {
+    std::swap(b->d_prm, b->d_prm2);
+    // travelling parameters may change which kernel variant the batch needs
+    int32_t* d_flag = nullptr;
+    HIP_TRY(hipMalloc(&d_flag, sizeof(int32_t)));
+    HIP_TRY(hipMemsetAsync(d_flag, 0, sizeof(int32_t), stream));
+    hipLaunchKernelGGL(exponentCheckKernel, dim3((unsigned)((b->ncol + 255) / 256)), dim3(256), 0,
+                       stream, b->d_prm, b->ncol, d_flag);
+    int32_t flag = 0;
+    HIP_TRY(hipMemcpyAsync(&flag, d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(hipFree(d_flag));
+    b->genericExponents = flag != 0;
+  }
+  return SIPNET_OK;
+}
+
+}  // extern "C"

@@ -65,3 +65,96 @@ def all_gather_planes(planes, group=None):
         return planes.unsqueeze(0)
     world = dist.get_world_size(group)
     return _gather0(planes, world, group)
+
+
+# ---- particle-filter analysis step (BASELINE config C5) ---------------------------
+def pf_systematic_ancestors(logw, u0, return_fixed=False):
+    """Systematic resampling over the global particle set on the device (pf.hip):
+    logw f64 CUDA tensor [n] -> int32 ancestors [n], non-decreasing, identical on every rank."""
+    import ctypes as C
+    import torch
+    from ._lib import check, lib
+    logw = logw.contiguous()
+    assert logw.dtype == torch.float64 and logw.is_cuda
+    anc = torch.empty(logw.numel(), dtype=torch.int32, device=logw.device)
+    fixed = torch.empty(logw.numel(), dtype=torch.int64, device=logw.device) if return_fixed else None
+    stream = C.c_void_p(torch.cuda.current_stream(logw.device).cuda_stream)
+    check(lib().sipnet_pf_systematic_ancestors(
+        C.c_void_p(logw.data_ptr()), logw.numel(), float(u0), C.c_void_p(anc.data_ptr()),
+        C.c_void_p(fixed.data_ptr()) if return_fixed else None, stream), "pf_systematic_ancestors")
+    return (anc, fixed) if return_fixed else anc
+
+
+def pf_exchange_plan(ancestors, n_local, world, rank):
+    """Who sends what: from the global ancestor vector (identical on every rank) ->
+    (send_cols[d]: local columns rank d needs from me, each once;
+     src[n_local]: for my new column j, < n_local = my own old column, n_local + k = k-th
+     received column; recv_counts[s]: columns arriving from rank s).
+    Works on any torch device (the gloo tests run it on CPU tensors)."""
+    import torch
+    n, lo = n_local, rank * n_local
+    anc = ancestors.long()
+    send_cols = []
+    for d in range(world):
+        if d == rank:
+            send_cols.append(anc.new_empty(0, dtype=torch.int32))
+            continue
+        seg = anc[d * n:(d + 1) * n]
+        sel = seg[(seg >= lo) & (seg < lo + n)]
+        send_cols.append((torch.unique_consecutive(sel) - lo).to(torch.int32))
+    mine = anc[lo:lo + n]
+    owner = torch.div(mine, n, rounding_mode="floor")
+    src = torch.empty(n, dtype=torch.int32, device=anc.device)
+    recv_counts, start = [], 0
+    for s in range(world):
+        m = owner == s
+        if s == rank:
+            src[m] = (mine[m] - lo).to(torch.int32)
+            recv_counts.append(0)
+            continue
+        u, inv = torch.unique_consecutive(mine[m], return_inverse=True)
+        src[m] = (n + start + inv).to(torch.int32)
+        recv_counts.append(int(u.numel()))
+        start += int(u.numel())
+    return send_cols, src, recv_counts
+
+
+def pf_resample(batch, ancestors, rank=0, world=1, group=None, with_params=False):
+    """Move particle state so that global particle g becomes old global particle
+    ancestors[g]: local gather for ancestors this rank already holds, ONE all-to-all
+    (RCCL over xGMI) of packed checkpoints for the rest, every needed ancestor sent once
+    per destination.  `batch` needs ncol, pack_members(), resample().
+    Returns {"sent": columns sent, "received": columns received, "bytes_sent": ...}."""
+    import torch
+    import torch.distributed as dist
+    n = batch.ncol
+    if world == 1:
+        batch.resample(ancestors[:n].to(torch.int32), None, (), with_params)
+        return {"sent": 0, "received": 0, "bytes_sent": 0}
+    send_cols, src, recv_counts = pf_exchange_plan(ancestors, n, world, rank)
+    blocks = [batch.pack_members(c, with_params) for c in send_cols]
+    words = blocks[0].shape[0]
+    send = torch.cat([b.reshape(-1) for b in blocks])
+    recv = torch.empty(words * sum(recv_counts), dtype=send.dtype, device=send.device)
+    dist.all_to_all_single(recv, send, output_split_sizes=[words * c for c in recv_counts],
+                           input_split_sizes=[int(b.numel()) for b in blocks], group=group)
+    batch.resample(src, recv, recv_counts, with_params)
+    sent = sum(int(c.numel()) for c in send_cols)
+    return {"sent": sent, "received": sum(recv_counts), "bytes_sent": sent * words * 8}
+
+
+def pf_analysis(batch, plane, obs, sigma, u0, rank=0, world=1, group=None, with_params=False):
+    """One analysis step after a forecast: likelihood weights of this rank's particles ->
+    all-gather of log-weights (n_total x 8 B) -> systematic resampling (redundant, identical
+    on every rank) -> pf_resample.  Returns (ancestors, info)."""
+    import torch
+    import torch.distributed as dist
+    logw = batch.pf_log_weights(plane, obs, sigma)
+    if world > 1:
+        logw = _gather0(logw, world, group).reshape(-1)
+    anc = pf_systematic_ancestors(logw, u0)
+    info = pf_resample(batch, anc, rank, world, group, with_params)
+    w = torch.exp(logw - logw.max())
+    info["ess"] = float(w.sum() ** 2 / (w * w).sum())
+    info["unique_ancestors"] = int(torch.unique_consecutive(anc).numel())
+    return anc, info

@@ -1,0 +1,172 @@
+"""Particle-filter analysis step on the GPU (pf.hip; BASELINE config C5):
+likelihood weights, systematic resampling, packing and the resampling gather against the
+numpy oracle (oracle/pf_oracle.py), and a forecast -> analysis -> forecast cycle whose
+resampled particles continue exactly like their ancestors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import sipnet_amd as sa
+from oracle import pf_oracle as po
+from sipnet_amd import dist as sd
+from sipnet_amd import synth
+from sipnet_amd.config import param_index as pi
+from tests import helpers
+from tests.test_pf import weights_case
+
+pytestmark = pytest.mark.gpu
+BASE = os.path.join(helpers.REPO, "sipnet_amd", "data", "base_forest.param")
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def base():
+    return sa.read_params(BASE, sa.flags_from())[0]
+
+
+@pytest.fixture(scope="module")
+def clim():
+    return synth.convert_raw(synth.round_like_file(synth.half_hourly_year_raw(48 * 12)))
+
+
+def batch_of(clim, members, prec=sa.F64):
+    os.environ["SIPNET_FAST_MATH"] = "1"
+    b = sa.Batch(sa.flags_from(), 1, members.shape[0], prec)
+    b.set_climate(0, clim)
+    b.set_params(0, members)
+    b.setup()
+    return b
+
+
+@pytest.mark.parametrize("prec", [sa.F64, sa.F32_MIXED])
+def test_log_weights_match_oracle(base, clim, prec):
+    members = synth.perturbed_params(base, 200)
+    members[7, pi("leafAllocation")] = 0.9            # invalid allocation: status 3, weight -inf
+    members[7, pi("woodAllocation")] = 0.9
+    b = batch_of(clim, members, prec)
+    planes, _ = b.run(0, 96)
+    st = b.get_status()
+    assert st[7] != 0 and (np.delete(st, 7) == 0).all()
+    nee = planes[0]
+    obs, sigma = float(nee[:, 0].double().sum()) * 0.9, 0.05
+    got = b.pf_log_weights(nee, obs, sigma).cpu().numpy()
+    want = po.log_weights(nee.cpu().numpy(), obs, sigma, st)
+    b.close()
+    assert got[7] == -np.inf
+    ok = np.isfinite(want)
+    np.testing.assert_allclose(got[ok], want[ok], rtol=1e-13, atol=1e-13)
+
+
+@pytest.mark.parametrize("kind", ["uniform", "mild", "degenerate", "one"])
+@pytest.mark.parametrize("n", [1, 5, 4096, 1 << 20])
+def test_systematic_ancestors_match_oracle(kind, n):
+    if n < 8 and kind in ("degenerate", "one"):
+        pytest.skip("needs more particles")
+    lw = weights_case(n, kind)
+    for u0 in (0.0, 0.41, 0.999999999):
+        anc, fixed = sd.pf_systematic_ancestors(torch.from_numpy(lw).to(DEV), u0, return_fixed=True)
+        fixed = fixed.cpu().numpy()
+        # integer weights: device exp vs glibc exp may round a weight to the neighbouring integer
+        assert np.abs(fixed - po.fixed_weights(lw)).max() <= 1
+        # given the same integer weights the resampling is exact
+        np.testing.assert_array_equal(anc.cpu().numpy(), po.systematic_ancestors(fixed, u0))
+    with pytest.raises(sa.SipnetError):
+        sd.pf_systematic_ancestors(torch.full((16,), -np.inf, dtype=torch.float64, device=DEV), 0.3)
+
+
+@pytest.mark.parametrize("with_params", [False, True])
+def test_pack_and_resample_match_numpy(base, clim, with_params):
+    n = 300
+    members = synth.perturbed_params(base, n)
+    b = batch_of(clim, members)
+    b.run(0, 300)                                     # fills state and ring with distinct values
+    state, rings = b.get_state(), b.get_rings()       # [n][32], [n][250]
+    words = 32 + 250 + (80 if with_params else 0)
+    rng = np.random.default_rng(1)
+    cols = np.sort(rng.choice(n, 37, replace=False)).astype(np.int32)
+    blk = b.pack_members(torch.from_numpy(cols).to(DEV), with_params).cpu().numpy()
+    assert blk.shape == (words, 37)
+    np.testing.assert_array_equal(blk[:32], state[cols].T)
+    np.testing.assert_array_equal(blk[32:282], rings[cols].T)
+    # received blocks: two "ranks" of 5 and 9 foreign particles with recognisable contents
+    r1 = rng.normal(size=(words, 5))
+    r2 = rng.normal(size=(words, 9))
+    recv = torch.from_numpy(np.concatenate([r1.ravel(), np.zeros(0), r2.ravel()])).to(DEV)
+    src = np.sort(rng.integers(0, n + 14, size=n)).astype(np.int32)
+    prm_before = b.pack_members(torch.arange(n, dtype=torch.int32, device=DEV), True).cpu().numpy()[282:]
+    b.resample(torch.from_numpy(src).to(DEV), recv, [5, 0, 9], with_params)
+    new_state, new_rings = b.get_state(), b.get_rings()
+    pool_state = np.concatenate([state.T, r1[:32], r2[:32]], axis=1)
+    pool_ring = np.concatenate([rings.T, r1[32:282], r2[32:282]], axis=1)
+    np.testing.assert_array_equal(new_state.T, pool_state[:, src])
+    np.testing.assert_array_equal(new_rings.T, pool_ring[:, src])
+    prm_after = b.pack_members(torch.arange(n, dtype=torch.int32, device=DEV), True).cpu().numpy()[282:]
+    if with_params:
+        pool_prm = np.concatenate([prm_before, r1[282:], r2[282:]], axis=1)
+        np.testing.assert_array_equal(prm_after, pool_prm[:, src])
+    else:
+        np.testing.assert_array_equal(prm_after, prm_before)
+    b.close()
+
+
+@pytest.mark.parametrize("prec,with_params", [(sa.F64, True), (sa.F32_MIXED, True), (sa.F64, False)])
+def test_cycle_resampled_particles_continue_like_their_ancestors(base, clim, prec, with_params):
+    """forecast 2 days -> analysis on the 2-day NEE sum -> forecast 2 more days.  Particle j of
+    the filtered batch must equal particle ancestors[j] of an unfiltered twin, bit for bit."""
+    n, T1, T2 = 512, 96, 96
+    if with_params:
+        members = synth.perturbed_params(base, n)
+    else:
+        # state-only filter: particles differ in their initial pools, not in parameters that the
+        # step reads (setupModel consumes the *Init parameters, sipnet.c:1905-1940)
+        rng = np.random.default_rng(2)
+        members = np.tile(base, (n, 1))
+        for name in ("plantWoodInit", "soilInit", "litterInit", "soilWFracInit", "laiInit"):
+            members[:, pi(name)] *= np.exp(rng.normal(0, 0.1, n))
+        members[:, pi("soilWFracInit")] = np.clip(members[:, pi("soilWFracInit")], 0.05, 1.0)
+    twin = batch_of(clim, members, prec)
+    twin.run(0, T1)
+    twin2, _ = twin.run(T1, T2)
+    twin2 = twin2.cpu().numpy()
+    twin_state = twin.get_state()
+    twin.close()
+
+    b = batch_of(clim, members, prec)
+    p1, _ = b.run(0, T1)
+    obs = float(np.median(p1[0].double().sum(0).cpu().numpy()))
+    sigma = float(p1[0].double().sum(0).std().cpu()) * 0.5 + 1e-12
+    anc, info = sd.pf_analysis(b, p1[0], obs, sigma, u0=0.43, with_params=with_params)
+    anc = anc.cpu().numpy()
+    assert 1.0 < info["ess"] < n and info["sent"] == 0
+    assert 1 < info["unique_ancestors"] < n                # the filter did select
+    p2, _ = b.run(T1, T2)
+    got = p2.cpu().numpy()
+    np.testing.assert_array_equal(got, twin2[:, :, anc])
+    np.testing.assert_array_equal(b.get_state()[:, :28], twin_state[anc][:, :28])
+    b.close()
+
+
+def test_two_ranks_emulated_on_one_gpu(base, clim):
+    """two batches stand in for two ranks: exchange plan + pack + resample with received blocks
+    reproduce the global gather (the all-to-all itself is covered over gloo in test_pf.py)"""
+    n, world = 256, 2
+    members = synth.perturbed_params(base, n * world)
+    ranks = [batch_of(clim, members[r * n:(r + 1) * n]) for r in range(world)]
+    for b in ranks:
+        b.run(0, 96)
+    before = [np.concatenate([b.get_state().T, b.get_rings().T], axis=0) for b in ranks]
+    lw = weights_case(n * world, "mild", seed=9)
+    anc = sd.pf_systematic_ancestors(torch.from_numpy(lw).to(DEV), 0.77)
+    want = po.resample_global(before, anc.cpu().numpy())
+    plans = [sd.pf_exchange_plan(anc, n, world, r) for r in range(world)]
+    packed = [[ranks[r].pack_members(plans[r][0][d], True) for d in range(world)] for r in range(world)]
+    for r in range(world):
+        _, src, counts = plans[r]
+        recv = torch.cat([packed[s][r].reshape(-1) for s in range(world)])
+        ranks[r].resample(src, recv, counts, True)
+    for r in range(world):
+        after = np.concatenate([ranks[r].get_state().T, ranks[r].get_rings().T], axis=0)
+        np.testing.assert_array_equal(after, want[r])
+        ranks[r].close()
