@@ -13,6 +13,9 @@ Workloads (BASELINE.json configs):
         the configuration the metric "at 10k members" + the fp64 |dNEE| bar are quoted on]
   c2    1 site x 1024 members, fp64          c3   1 site x 65536 members, fp32-mixed
   c4    32 sites x 1024 members per GPU, fp64 (256 sites over 8 GPUs)
+  c5    particle-filter cycle: 131072 particles per GPU (1 M over 8), fp32-mixed, one day
+        (48 steps) of forecast + the analysis step (likelihood weights, all-gather of
+        log-weights, systematic resampling, all-to-all of resampled checkpoints, gather)
 Per-GPU work is fixed as N grows ("scaling": "weak").
 """
 import argparse
@@ -36,6 +39,7 @@ WORKLOADS = {
     "c2": dict(sites=1, members=1024, prec="f64", steps=17520),
     "c3": dict(sites=1, members=65536, prec="f32", steps=17520),
     "c4": dict(sites=32, members=1024, prec="f64", steps=17520),
+    "c5": dict(sites=1, members=131072, prec="f32", steps=48, pf=True),
 }
 
 _CPU_WORKER = r"""
@@ -199,10 +203,26 @@ def main():
         gathered_full = torch.empty((world,) + tuple(planes.shape), dtype=planes.dtype, device=b.device)
 
     kernel_ms = []
+    pf = bool(wl.get("pf"))
+    pf_info = {}
+    if pf:
+        # the "observation": the ensemble's median daily NEE with a spread that leaves an
+        # effective sample size of roughly half the ensemble
+        from sipnet_amd import dist as sd
+        b.run(0, T, planes=planes)
+        tot = planes[0].double().sum(0)
+        if world > 1:
+            tot = sd._gather0(tot, world, None).reshape(-1)
+        pf_obs, pf_sigma = float(tot.median()), float(tot.std()) * 1.5 + 1e-12
 
     def one_pass(record):
         b.setup()                       # setupModel() for every member
         b.run(0, T, planes=planes)      # the time-fused step kernel
+        if pf:
+            _, info = sd.pf_analysis(b, planes[0], pf_obs, pf_sigma, u0=0.5, rank=rank, world=world,
+                                     with_params=True, diagnostics=record)
+            pf_info.update(info)
+            return
         if world > 1 and args.gather != "none":
             for v in range(3):
                 b.reduce_plane(planes[v], stats[v])
@@ -217,7 +237,7 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        one_pass(False)
+        one_pass(True)
     barrier()
     # HIP-event kernel timing is collected in an extra, untimed pass per step to keep the
     # timed region free of host syncs: time K passes wall-clock first
@@ -238,6 +258,20 @@ def main():
         b.run(0, T, planes=planes)
         kms.append(b.last_kernel_ms())
     k_ms = float(np.mean(kms))
+    if pf:   # the analysis step alone, torch events on the current stream (all its work is there)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ams = []
+        for _ in range(3):
+            b.setup()
+            b.run(0, T, planes=planes)
+            barrier()
+            e0.record()
+            sd.pf_analysis(b, planes[0], pf_obs, pf_sigma, u0=0.5, rank=rank, world=world, with_params=True,
+                           diagnostics=False)
+            e1.record()
+            torch.cuda.synchronize()
+            ams.append(e0.elapsed_time(e1))
+        pf_info["analysis_ms"] = float(np.mean(ams))
 
     units_per_pass = S * M * T * world
     value = units_per_pass * args.steps / dt
@@ -252,6 +286,9 @@ def main():
             ora = helpers.load_oracle()
             n_chk = min(8, M)
             po, _, _ = ora.run_block(flags, members[:n_chk], clims[0])
+            if pf:      # the planes of the last forecast (the analysis does not touch them)
+                b.setup()
+                b.run(0, T, planes=planes)
             pg = planes[:, :, :n_chk].double().cpu().numpy()
             parity = {"members_checked": n_chk,
                       "max_abs_dNEE": float(np.abs(pg[0] - po[0]).max()),
@@ -276,11 +313,13 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": wl["prec"], "data": "synthetic",
             "config": {"workload": f"{args.workload}: {S} site(s) x {M} members per GPU x {T} "
-                                   f"half-hourly steps, perturbed params, default flags",
+                                   f"half-hourly steps, perturbed params, default flags"
+                                   + (", particle-filter cycle (forecast + analysis)" if pf else ""),
                        "sites_per_gpu": S, "members_per_site": M, "timesteps": T,
                        "fast_math": bool(args.fast_math),
                        "gather": args.gather if world > 1 else "n/a (1 GPU)",
-                       "parallelism": f"ensemble-sharded x{world}"},
+                       "parallelism": f"ensemble-sharded x{world}",
+                       **({"particle_filter": pf_info} if pf else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": "stepFastKernel" if args.fast_math else "stepKernel", "kernel_ms": k_ms,

@@ -73,19 +73,21 @@ __global__ __launch_bounds__(256) void logWeightKernel(const T* __restrict__ pla
   logw[c] = (status[c] != 0.0) ? -INFINITY : -0.5 * z * z;
 }
 
-// max of the finite log-weights (one block; n is at most a few million)
-__global__ __launch_bounds__(1024) void maxKernel(const double* __restrict__ x, int64_t n,
-                                                  double* __restrict__ out) {
-  __shared__ double sm[1024];
+// max of the log-weights, two stages: per-block partial maxima, then one block over them
+__global__ __launch_bounds__(256) void maxPartialKernel(const double* __restrict__ x, int64_t n,
+                                                        double* __restrict__ part) {
+  __shared__ double sm[256];
   double m = -INFINITY;
-  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) m = fmax(m, x[i]);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    m = fmax(m, x[i]);
   sm[threadIdx.x] = m;
   __syncthreads();
-  for (int s = 512; s > 0; s >>= 1) {
+  for (int s = 128; s > 0; s >>= 1) {
     if ((int)threadIdx.x < s) sm[threadIdx.x] = fmax(sm[threadIdx.x], sm[threadIdx.x + s]);
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[0] = sm[0];
+  if (threadIdx.x == 0) part[blockIdx.x] = sm[0];
 }
 
 // fixed-point weights: w = llrint(exp(logw - max) * 2^30).  Integer weights make the prefix
@@ -174,6 +176,29 @@ int sipnet_batch_pf_log_weights(sipnet_batch* b, const void* d_plane, int32_t el
   return SIPNET_OK;
 }
 
+namespace {
+// scratch of the resampling, kept between calls (one per host thread and device)
+struct PfScratch {
+  int device = -1;
+  int64_t cap = 0;
+  double* d_max = nullptr;  // [kMaxParts + 1]: partial maxima, then the maximum
+  int64_t* d_w = nullptr;
+  int64_t* d_cdf = nullptr;
+  void* d_tmp = nullptr;
+  size_t tmpBytes = 0;
+  void release() {
+    if (d_max) (void)hipFree(d_max);
+    if (d_w) (void)hipFree(d_w);
+    if (d_cdf) (void)hipFree(d_cdf);
+    if (d_tmp) (void)hipFree(d_tmp);
+    d_max = nullptr; d_w = d_cdf = nullptr; d_tmp = nullptr; cap = 0; tmpBytes = 0;
+  }
+  ~PfScratch() { release(); }
+};
+constexpr int kMaxParts = 256;
+thread_local PfScratch g_pf;
+}  // namespace
+
 int sipnet_pf_systematic_ancestors(const double* d_logw, int64_t n, double u0,
                                    int32_t* d_ancestors, int64_t* d_fixed_weights,
                                    void* hip_stream) {
@@ -182,50 +207,41 @@ int sipnet_pf_systematic_ancestors(const double* d_logw, int64_t n, double u0,
     return SIPNET_ERR_BAD_ARGUMENT;
   }
   hipStream_t stream = (hipStream_t)hip_stream;
-  double* d_max = nullptr;
-  int64_t *d_w = nullptr, *d_cdf = nullptr;
-  void* d_tmp = nullptr;
-  size_t tmpBytes = 0;
-  auto cleanup = [&]() {
-    if (d_max) (void)hipFree(d_max);
-    if (d_w) (void)hipFree(d_w);
-    if (d_cdf) (void)hipFree(d_cdf);
-    if (d_tmp) (void)hipFree(d_tmp);
-  };
-#define PF_TRY(expr)                                                    \
-  do {                                                                  \
-    hipError_t e_ = (expr);                                             \
-    if (e_ != hipSuccess) {                                             \
-      setError(std::string(#expr) + ": " + hipGetErrorString(e_));      \
-      cleanup();                                                        \
-      return SIPNET_ERR_NO_DEVICE;                                      \
-    }                                                                   \
-  } while (0)
-  PF_TRY(hipMalloc(&d_max, sizeof(double)));
-  PF_TRY(hipMalloc(&d_w, (size_t)n * sizeof(int64_t)));
-  PF_TRY(hipMalloc(&d_cdf, (size_t)n * sizeof(int64_t)));
-  PF_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, tmpBytes, d_w, d_cdf, (int)n, stream));
-  PF_TRY(hipMalloc(&d_tmp, tmpBytes));
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  PfScratch& sc = g_pf;
+  if (sc.device != dev || sc.cap < n) {
+    sc.release();
+    sc.device = dev;
+    HIP_TRY(hipMalloc(&sc.d_max, (kMaxParts + 1) * sizeof(double)));
+    HIP_TRY(hipMalloc(&sc.d_w, (size_t)n * sizeof(int64_t)));
+    HIP_TRY(hipMalloc(&sc.d_cdf, (size_t)n * sizeof(int64_t)));
+    HIP_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, sc.tmpBytes, sc.d_w, sc.d_cdf, (int)n, stream));
+    HIP_TRY(hipMalloc(&sc.d_tmp, sc.tmpBytes));
+    sc.cap = n;
+  }
   const int grid = (int)((n + 255) / 256);
-  hipLaunchKernelGGL(maxKernel, dim3(1), dim3(1024), 0, stream, d_logw, n, d_max);
-  hipLaunchKernelGGL(fixedWeightKernel, dim3(grid), dim3(256), 0, stream, d_logw, n, d_max, d_w);
-  PF_TRY(hipcub::DeviceScan::InclusiveSum(d_tmp, tmpBytes, d_w, d_cdf, (int)n, stream));
+  const int parts = grid < kMaxParts ? grid : kMaxParts;
+  hipLaunchKernelGGL(maxPartialKernel, dim3(parts), dim3(256), 0, stream, d_logw, n, sc.d_max);
+  hipLaunchKernelGGL(maxPartialKernel, dim3(1), dim3(256), 0, stream, sc.d_max, (int64_t)parts,
+                     sc.d_max + kMaxParts);
+  hipLaunchKernelGGL(fixedWeightKernel, dim3(grid), dim3(256), 0, stream, d_logw, n,
+                     sc.d_max + kMaxParts, sc.d_w);
+  size_t tmpBytes = sc.tmpBytes;
+  HIP_TRY(hipcub::DeviceScan::InclusiveSum(sc.d_tmp, tmpBytes, sc.d_w, sc.d_cdf, (int)n, stream));
+  hipLaunchKernelGGL(ancestorKernel, dim3(grid), dim3(256), 0, stream, sc.d_cdf, n, u0, d_ancestors);
+  HIP_TRY(hipGetLastError());
+  if (d_fixed_weights)
+    HIP_TRY(hipMemcpyAsync(d_fixed_weights, sc.d_w, (size_t)n * sizeof(int64_t),
+                           hipMemcpyDeviceToDevice, stream));
+  // the one host round trip: a filter with no surviving particle must be reported
   int64_t total = 0;
-  PF_TRY(hipMemcpyAsync(&total, d_cdf + (n - 1), sizeof(int64_t), hipMemcpyDeviceToHost, stream));
-  PF_TRY(hipStreamSynchronize(stream));
+  HIP_TRY(hipMemcpyAsync(&total, sc.d_cdf + (n - 1), sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
   if (total <= 0) {
     setError("sipnet_pf_systematic_ancestors: every particle has zero weight");
-    cleanup();
     return SIPNET_ERR_BAD_PARAMETER;
   }
-  hipLaunchKernelGGL(ancestorKernel, dim3(grid), dim3(256), 0, stream, d_cdf, n, u0, d_ancestors);
-  PF_TRY(hipGetLastError());
-  if (d_fixed_weights)
-    PF_TRY(hipMemcpyAsync(d_fixed_weights, d_w, (size_t)n * sizeof(int64_t),
-                          hipMemcpyDeviceToDevice, stream));
-  PF_TRY(hipStreamSynchronize(stream));
-#undef PF_TRY
-  cleanup();
   return SIPNET_OK;
 }
 
@@ -298,9 +314,9 @@ int sipnet_batch_resample(sipnet_batch* b, const int32_t* d_src, const double* d
   HIP_TRY(hipGetLastError());
   std::swap(b->d_state, b->d_state2);
   std::swap(b->d_ring, b->d_ring2);
-  if (with_params) {
-    std::swap(b->d_prm, b->d_prm2);
-    // travelling parameters may change which kernel variant the batch needs
+  if (with_params) std::swap(b->d_prm, b->d_prm2);
+  if (with_params && start > 0) {
+    // parameters that arrived from other ranks may change which kernel variant the batch needs
     int32_t* d_flag = nullptr;
     HIP_TRY(hipMalloc(&d_flag, sizeof(int32_t)));
     HIP_TRY(hipMemsetAsync(d_flag, 0, sizeof(int32_t), stream));

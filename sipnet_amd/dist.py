@@ -143,7 +143,8 @@ def pf_resample(batch, ancestors, rank=0, world=1, group=None, with_params=False
     return {"sent": sent, "received": sum(recv_counts), "bytes_sent": sent * words * 8}
 
 
-def pf_analysis(batch, plane, obs, sigma, u0, rank=0, world=1, group=None, with_params=False):
+def pf_analysis(batch, plane, obs, sigma, u0, rank=0, world=1, group=None, with_params=False,
+                diagnostics=True):
     """One analysis step after a forecast: likelihood weights of this rank's particles ->
     all-gather of log-weights (n_total x 8 B) -> systematic resampling (redundant, identical
     on every rank) -> pf_resample.  Returns (ancestors, info)."""
@@ -154,6 +155,8 @@ def pf_analysis(batch, plane, obs, sigma, u0, rank=0, world=1, group=None, with_
         logw = _gather0(logw, world, group).reshape(-1)
     anc = pf_systematic_ancestors(logw, u0)
     info = pf_resample(batch, anc, rank, world, group, with_params)
+    if not diagnostics:
+        return anc, info
     w = torch.exp(logw - logw.max())
     info["ess"] = float(w.sum() ** 2 / (w * w).sum())
     info["unique_ancestors"] = int(torch.unique_consecutive(anc).numel())
