@@ -27,6 +27,7 @@ using namespace sipnet;  // internal header: only engine.hip and pf.hip include 
 struct sipnet_batch {
   int32_t flags[SIPNET_NFLAGS];
   int32_t n_sites = 0, n_members = 0, precision = 0, device = 0;
+  int32_t numCUs = 256;
   int64_t ncol = 0;
   int32_t n_steps = 0;  // steps per site (all sites equal)
   bool fastMath = false;

@@ -137,6 +137,10 @@ int sipnet_batch_create(const int32_t* flags, int32_t n_sites, int32_t n_members
   b->precision = precision;
   b->device = device;
   b->ncol = (int64_t)n_sites * n_members;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) b->numCUs = prop.multiProcessorCount;
+  }
   b->fastMath = (precision == SIPNET_F32_MIXED);
   const char* fm = getenv("SIPNET_FAST_MATH");
   if (fm && precision == SIPNET_F64) b->fastMath = atoi(fm) != 0;
@@ -349,7 +353,14 @@ int sipnet_batch_run(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_ne
     f.n_steps = n_steps;
     f.plainExp = b->genericExponents ? 0 : 1;
     f.scratchRow = b->d_scratchRow;
-    launchStepFast(f, b->precision, stream);
+    // At most one 64-member chunk per CU: the step is bound by what one wavefront can issue,
+    // so three wavefronts share each chunk and its ring stays in LDS (step_coop.hip, one
+    // workgroup per CU).  Bigger batches fill the chip with the one-wave kernel.
+    const int64_t blocks = (int64_t)b->n_sites * ((b->n_members + 63) / 64);
+    const char* coopEnv = getenv("SIPNET_COOP");
+    const bool coop = coopEnv ? atoi(coopEnv) != 0 : blocks <= b->numCUs;
+    if (coop) launchStepCoop(f, b->precision, stream);
+    else launchStepFast(f, b->precision, stream);
   } else {
     launchStep(a, b->precision, b->fastMath, stream);
   }

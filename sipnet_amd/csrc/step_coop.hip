@@ -1,0 +1,727 @@
+// step_coop.hip -- the cooperative throughput kernel: THREE wavefronts per 64 members.
+//
+// Why: with <= 1 wavefront per SIMD (every BASELINE configuration up to 64 k members) the step
+// loop is bound by what ONE wavefront can issue -- one instruction per ~4.3 cycles whatever its
+// kind -- while three quarters of the chip idle.  A member-step is a
+// chain of three blocks with thin interfaces:
+//
+//   L  light      lai(t)            -> potGrossPsn(t)          (dTemp, dVpd, 7-layer Simpson)
+//   W  water      potGrossPsn(t)    -> photosynthesis(t), ET(t), soilWater(t+1), snow(t+1)
+//   C  carbon     photosynthesis(t), soilWater(t) -> pools(t+1), ring, NEE(t), GPP(t), lai(t+1)
+//
+// so a workgroup is three wavefronts on three SIMDs of one CU, each running its OWN time loop
+// over the same 64 members and the same site records, and passing one double per member and
+// step through LDS mailboxes guarded by sequence flags (release store / acquire spin-load at
+// workgroup scope).  W and C overlap almost completely; L runs concurrently with the parts of
+// W and C that do not need it.  The arithmetic, its order and therefore the results are those
+// of stepFastKernel (bit-identical; tests/test_gpu_parity.py).
+//
+// Mailbox slots are indexed by step & 3; the wait-for graph keeps every producer within three
+// steps of its consumers:  L(t) waits lai(t) [C finished t-1];  W(t) waits C finished t-1 and,
+// by day, potGrossPsn(t);  C(t) waits soilWater(t) [W finished t-1] and, by day, psn(t).
+#include <hip/hip_runtime.h>
+
+#include "fast_math.h"
+#include "step_kernel.h"
+
+namespace sipnet {
+namespace {
+
+constexpr int kTileBytes = kFastTile * (int)sizeof(FastRec);
+
+// Hand-over through LDS.  DS instructions of one wavefront are executed in issue order, so a
+// producer needs no wait between the value and the flag (two plain ds_write), and a consumer
+// that issues the flag read BEFORE the value read and finds the flag current has the published
+// value: one LDS round trip per hand-over when the data is already there.
+__device__ __forceinline__ void post(double* slot, int* flag, double v, int step) {
+  asm volatile("ds_write_b64 %0, %1\n\tds_write_b32 %2, %3"
+               :: "v"((unsigned)(size_t)slot), "v"(v), "v"((unsigned)(size_t)flag), "v"(step) : "memory");
+}
+__device__ __forceinline__ void post(float* slot, int* flag, float v, int step) {
+  asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %2, %3"
+               :: "v"((unsigned)(size_t)slot), "v"(v), "v"((unsigned)(size_t)flag), "v"(step) : "memory");
+}
+__device__ __forceinline__ double take(const double* slot, const int* flag, int step) {
+  double v;
+  int f;
+  do {
+    asm volatile("ds_read_b32 %0, %2\n\tds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(f), "=&v"(v) : "v"((unsigned)(size_t)flag), "v"((unsigned)(size_t)slot) : "memory");
+  } while (uni(f) < step);
+  return v;
+}
+__device__ __forceinline__ float take(const float* slot, const int* flag, int step) {
+  float v;
+  int f;
+  do {
+    asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(f), "=&v"(v) : "v"((unsigned)(size_t)flag), "v"((unsigned)(size_t)slot) : "memory");
+  } while (uni(f) < step);
+  return v;
+}
+// Site-record reads and ring-value loads are issued from inline assembly on purpose: hipcc
+// (ROCm 7.2) drains ALL vector-memory traffic -- `s_waitcnt vmcnt(0)`, i.e. the previous step's
+// stores, ~800 cycles -- in front of every DS read that might alias a pending LDS-DMA and of
+// every use of an ordinary global load while an LDS-DMA is in flight (cdna_hip_programming.md,
+// glds note).  Here every wait of the hot path is placed by hand: loads at the top of a step,
+// ONE `vmcnt(0)` right before the step's stores (everything older has had a whole step to
+// land), stores and the next tile's DMA last.
+typedef double d2_t __attribute__((ext_vector_type(2)));
+typedef int i4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned ldsAddr(const void* p) { return (unsigned)(size_t)p; }
+__device__ __forceinline__ void ringLoad2(double& v0, double& v1, const double* p0, const double* p1) {
+  asm volatile("global_load_dwordx2 %0, %2, off\n\tglobal_load_dwordx2 %1, %3, off"
+               : "=&v"(v0), "=&v"(v1) : "v"(p0), "v"(p1) : "memory");
+}
+__device__ __forceinline__ void vmemDrain(double& v0, double& v1) {
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(v0), "+v"(v1) :: "memory");
+}
+// progress-only wait (no value)
+__device__ __forceinline__ void awaitAtLeast(const int* flag, int step) {
+  int f;
+  do {
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(f) : "v"((unsigned)(size_t)flag) : "memory");
+  } while (uni(f) < step);
+}
+
+#ifdef SIPNET_STAMPS
+__device__ unsigned long long g_coopStamps[16];
+#define CSTAMP(k)                                                                    \
+  {                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                               \
+    unsigned long long now_;                                                         \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");     \
+    __builtin_amdgcn_sched_barrier(0);                                               \
+    cAcc[k] += now_ - cLast;                                                         \
+    cLast = now_;                                                                    \
+  }
+#else
+#define CSTAMP(k)
+#endif
+}  // namespace
+
+template <class R, bool PlainExp>
+__global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
+  // per-wave private record tiles (each wave stages and awaits its own DMA) + mailboxes
+  __shared__ alignas(16) unsigned char ldsTiles[3][2 * kTileBytes];
+  __shared__ R mailLai[4][64], mailPgp[4][64], mailPsn[4][64], mailWater[4][64];
+  __shared__ int seqLai, seqPgp, seqPsn, seqWater;
+  // The running-mean ring of the 64 members lives in LDS for the whole launch (250 x 64 x 8 B =
+  // 125 KB; one workgroup per CU).  A wave that stores to HBM every step must not also load
+  // from HBM every step: vector-memory operations complete in issue order, so each step's ring
+  // loads would queue behind the previous step's output stores (~1800 cycles to their ack).
+  __shared__ double ringL[SIPNET_RING_SLOTS * 64];
+
+  const int role = uni((int)threadIdx.x >> 6);  // 0 carbon, 1 water, 2 light
+  const int lane = (int)threadIdx.x & 63;
+  unsigned char* lds = ldsTiles[role];
+
+  const int chunksPerSite = (a.n_members + 63) >> 6;
+  int site, chunk;
+  {
+    const int b = (int)blockIdx.x;
+    if ((a.n_sites & 7) == 0) {  // keep a site's chunks on one XCD group (speed only)
+      const int g = b & 7, j = b >> 3;
+      site = g + 8 * (j / chunksPerSite);
+      chunk = j % chunksPerSite;
+    } else {
+      site = b / chunksPerSite;
+      chunk = b % chunksPerSite;
+    }
+  }
+  int m = (chunk << 6) + lane;
+  const bool live = m < a.n_members;
+  if (!live) m = a.n_members - 1;  // clamped lanes recompute the last member, never store state
+  const int64_t col = (int64_t)site * a.n_members + m;
+  const int64_t nc = a.ncol;
+  double* __restrict__ stp = a.state + col;
+  const bool skip = stp[(int64_t)ST_status * nc] != 0.0;
+  const bool act = live && !skip;
+  const double* __restrict__ pp = a.prm + col;
+#define PRM(name) (pp[(int64_t)SP_##name * nc])
+#define PRM_RARE(name) ((R)pp[(int64_t)SP_##name * nc])
+#define ST(name) stp[(int64_t)ST_##name * nc]
+
+  const int tBegin = a.step0, tEnd = a.step0 + a.n_steps;
+  if (threadIdx.x == 0) {
+    seqLai = tBegin - 1;
+    seqPgp = tBegin - 1;
+    seqPsn = tBegin - 1;
+    seqWater = tBegin - 1;
+  }
+  __syncthreads();  // the only workgroup barrier: flags initialised before anyone spins
+
+  const unsigned char* __restrict__ planBytes =
+      (const unsigned char*)(a.fast + (int64_t)site * a.n_steps_total);
+  auto tileFirst = [&](int tile) -> int64_t {
+    int64_t first = (int64_t)tile * kFastTile;
+    const int64_t lastStart = (int64_t)a.n_steps_total - kFastTile;
+    if (first > lastStart) first = lastStart > 0 ? lastStart : 0;
+    return first;
+  };
+  auto stageTile = [&](int tile, int buf) {
+    const unsigned char* src = planBytes + tileFirst(tile) * (int64_t)sizeof(FastRec);
+#pragma unroll
+    for (int k = 0; k < kTileBytes / 1024; k++) {
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(src + k * 1024 + lane * 16),
+          (__attribute__((address_space(3))) void*)(lds + buf * kTileBytes + k * 1024), 16, 0, 0);
+    }
+  };
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  typedef int i4 __attribute__((ext_vector_type(4)));
+  const Exp2Coef EC = loadExp2Coef();
+  int curTile = tBegin / kFastTile;
+  stageTile(curTile, curTile & 1);
+  __builtin_amdgcn_s_waitcnt(0);
+
+  // =============================================================================================
+  if (role == 2) {
+    // ---- L: potPsn() + calcLightEff(), sipnet.c:517-641 -------------------------------------
+    const double leafCSpWt = PRM(leafCSpWt);
+    const double convK = kCWeight * (1.0 / kTen9) * (leafCSpWt / PRM(cFracLeaf)) * kSecPerDay;
+    const double respPerGram = PRM(baseFolRespFrac) * PRM(aMax);
+    const R K_g = (R)((PRM(aMax) * PRM(aMaxFrac) + respPerGram) * convK);
+    const R K_tmin = (R)PRM(psnTMin), K_tmax = (R)PRM(psnTMax);
+    const R K_invDen = (R)(1.0 / (((PRM(psnTMax) - PRM(psnTMin)) / 2.0) * ((PRM(psnTMax) - PRM(psnTMin)) / 2.0)));
+    const R K_slope = (R)PRM(dVpdSlope), K_vexp = (R)PRM(dVpdExp);
+    const R K_attl = (R)(-PRM(attenuation) * (1.0 / 6.0) * kLog2e);
+    const R K_invHalf = (R)(1.0 / PRM(halfSatPar));
+    for (int tileStart = curTile * kFastTile; tileStart < tEnd; tileStart += kFastTile, curTile++) {
+      if (tileStart > tBegin) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMA of 16 steps ago
+      stageTile(curTile + 1, (curTile + 1) & 1);
+      const int tFirst = tileStart > tBegin ? tileStart : tBegin;
+      const int tLast = (tileStart + kFastTile) < tEnd ? (tileStart + kFastTile) : tEnd;
+      const unsigned char* recB = lds + (curTile & 1) * kTileBytes +
+                                  (int)(tFirst - tileFirst(curTile)) * (int)sizeof(FastRec);
+      for (int t = tFirst; t < tLast; t++, recB += sizeof(FastRec)) {
+        d2 q1, q2;
+        int bitsV;
+        asm volatile("ds_read_b32 %0, %3 offset:128\n\tds_read_b128 %1, %3 offset:16\n\t"
+                     "ds_read_b128 %2, %3 offset:32\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(bitsV), "=&v"(q1), "=&v"(q2) : "v"(ldsAddr(recB)) : "memory");
+        const int bits = uni(bitsV);
+        if (!(bits & FAST_PAR_POS)) continue;  // night: potGrossPsn = 0, nobody waits for it
+        const R tair = (R)q1.x;
+        // climate-only factors first, then the leaf area of this step
+        const R dTemp = rmax0((K_tmax - tair) * (tair - K_tmin) * K_invDen);
+        R vpdPow = (R)q2.y * (R)q2.y;
+        if (!PlainExp)
+          vpdPow = (K_vexp == R(2)) ? vpdPow : fexp2(K_vexp * (R)((const double*)(recB + 144))[2], EC);
+        const R dVpd = rmax0(R(1) - K_slope * vpdPow);
+        const R q = (R)q2.x * K_invHalf;
+        const R e0 = fexp2(q, EC);
+        const R lai = take(&mailLai[t & 3][lane], &seqLai, t);
+#if defined(COOP_EXP) && COOP_EXP == 1
+        post(&mailPgp[t & 3][lane], &seqPgp, lai * dTemp * dVpd * e0, t);
+        continue;
+#endif
+        const R r1 = fexp2(K_attl * lai, EC);
+        const R r2 = r1 * r1, r3 = r2 * r1, r4 = r2 * r2, r5 = r4 * r1, r6 = r3 * r3;
+        const R e1 = fexp2(q * r1, EC), e2 = fexp2(q * r2, EC), e3 = fexp2(q * r3, EC);
+        const R e4 = fexp2(q * r4, EC), e5 = fexp2(q * r5, EC), e6 = fexp2(q * r6, EC);
+        const R s = (e0 + e6) + R(4) * (e1 + e3 + e5) + R(2) * (e2 + e4);
+        const R dLight = R(1) - s * R(1.0 / 18.0);
+        post(&mailPgp[t & 3][lane], &seqPgp, K_g * lai * dTemp * dVpd * dLight, t);
+      }
+    }
+    return;
+  }
+
+  // =============================================================================================
+  if (role == 1) {
+    // ---- W: moisture(), calcPrecip(), snowPack(), calcSoilWaterFluxes(), sipnet.c:656-1031 ----
+    const R K_tr = (R)(1000.0 * (44.0 / 12.0) * (1.0 / 10000.0) / PRM(wueConst));
+    const R K_whc = (R)PRM(soilWHC), K_invWhc = (R)(1.0 / PRM(soilWHC));
+    const R K_wrf = (R)PRM(waterRemoveFrac);
+    const R K_frozThr = (R)PRM(frozenSoilThreshold), K_frozEff = (R)PRM(frozenSoilEff);
+    const R K_immed = (R)PRM(immedEvapFrac), K_ff = (R)PRM(fastFlowFrac);
+    const R K_invRd = (R)(1.0 / PRM(rdConst)), K_rd = (R)PRM(rdConst), K_melt = (R)PRM(snowMelt);
+    const R K_c1l = (R)(PRM(rSoilConst1) * kLog2e), K_c2l = (R)(PRM(rSoilConst2) * kLog2e);
+    double soilWater = ST(soilWater), snow = ST(snow);
+    R* __restrict__ oEt = (R*)(a.et ? a.et : a.scratchRow) + col;
+    const int64_t ldEt = a.et ? a.ld : 0;
+    post(&mailWater[tBegin & 3][lane], &seqWater, (R)soilWater, tBegin);
+
+    for (int tileStart = curTile * kFastTile; tileStart < tEnd; tileStart += kFastTile, curTile++) {
+      // the DMA of 16 steps ago has landed: all but the youngest operation (the last ET store)
+      if (tileStart > tBegin) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      stageTile(curTile + 1, (curTile + 1) & 1);
+      const int tFirst = tileStart > tBegin ? tileStart : tBegin;
+      const int tLast = (tileStart + kFastTile) < tEnd ? (tileStart + kFastTile) : tEnd;
+      const unsigned char* recB = lds + (curTile & 1) * kTileBytes +
+                                  (int)(tFirst - tileFirst(curTile)) * (int)sizeof(FastRec);
+      for (int t = tFirst; t < tLast; t++, recB += sizeof(FastRec)) {
+        d2 q0, q1, q2, q3, q4, q5;
+        i4 j0;
+        asm volatile("ds_read_b128 %0, %7\n\tds_read_b128 %1, %7 offset:16\n\tds_read_b128 %2, %7 offset:32\n\t"
+                     "ds_read_b128 %3, %7 offset:48\n\tds_read_b128 %4, %7 offset:64\n\t"
+                     "ds_read_b128 %5, %7 offset:80\n\tds_read_b128 %6, %7 offset:128\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4), "=&v"(q5), "=&v"(j0)
+                     : "v"(ldsAddr(recB)) : "memory");
+        const int32_t* rareI = (const int32_t*)(recB + 184);
+        const R len = (R)q0.x, invLen = (R)q0.y, tair = (R)q1.x, tsoil = (R)q1.y;
+        const int bits = uni(j0.x);
+        const int nEv = uni(j0.w);
+        const R eWater = (R)soilWater, eSnow = (R)snow;
+        const bool frozen = tsoil < K_frozThr;
+
+        // everything that does not need the light block first
+        const bool tairPos = (bits & FAST_TAIR_POS) != 0;
+        const R rate = (R)q3.y;
+        const R rain = tairPos ? rate : R(0), snowFall = tairPos ? R(0) : rate;
+        const R immedEvap = rain * K_immed;
+        const R netRain = rain - immedEvap;
+        R snowMelt = 0, sublimation = 0, evaporationPot = 0;
+        const bool hasSnow = eSnow > R(0);
+        if (hasSnow) {
+          R subl = rmax0((R)q4.x * K_invRd);
+          R remaining = eSnow + snowFall * len;
+          const bool allGone = remaining - subl * len < R(0);
+          subl = allGone ? remaining * invLen : subl;
+          remaining = allGone ? R(0) : remaining - subl * len;
+          R melt = tairPos ? K_melt * tair : R(0);
+          melt = (tairPos && (remaining - melt * len < R(0))) ? remaining * invLen : melt;
+          sublimation = subl;
+          snowMelt = melt;
+        } else {
+          const R wf = clip01(eWater * K_invWhc);
+          const R rsoil = fexp2(K_c1l - K_c2l * wf, EC);
+          evaporationPot = rmax0(fdiv((R)q4.y, K_rd * (R)q5.x + rsoil));
+        }
+        R removable = rminv(eWater, K_whc) * K_wrf;
+        removable = frozen ? removable * K_frozEff : removable;
+
+        // moisture(), sipnet.c:656-699, with the potential photosynthesis of wave L
+        R transpiration = 0, photosynthesis = 0;
+        if (bits & FAST_PAR_POS) {
+#if defined(COOP_EXP) && COOP_EXP >= 2
+          const R potGrossPsn = R(0.01);
+#else
+          const R potGrossPsn = take(&mailPgp[t & 3][lane], &seqPgp, t);
+#endif
+          const R potTrans = potGrossPsn * (R)q2.y * K_tr;
+          const bool hasPsn = potGrossPsn >= R(kTiny);
+          const bool limited = removable < potTrans;
+          const R dWater = fdiv(removable, potTrans);
+          transpiration = hasPsn ? (limited ? removable : potTrans) : R(0);
+          photosynthesis = (hasPsn && limited) ? potGrossPsn * dWater : potGrossPsn;
+          post(&mailPsn[t & 3][lane], &seqPsn, photosynthesis, t);
+        }
+
+        R evaporation, drainage, fastFlow;
+        {
+          R netIn = netRain + snowMelt;
+          fastFlow = netIn * K_ff;
+          netIn -= fastFlow;
+          R remaining = eWater + netIn * len - transpiration * len;
+          const bool dryOut = !hasSnow && (remaining - evaporationPot * len < R(kTiny));
+          evaporation = dryOut ? (remaining - R(kTiny)) * invLen : evaporationPot;
+          remaining = hasSnow ? remaining : (dryOut ? R(0) : remaining - evaporationPot * len);
+          drainage = remaining > K_whc ? (remaining - K_whc) * invLen : R(0);
+        }
+        // irrigation, events.c:484-543
+        R evEvap = 0;
+        if (__builtin_expect(nEv > 0, 0)) {
+          R evSoilWater = 0;
+          const int ev0 = uni(rareI[3]);
+          for (int k = 0; k < nEv; k++) {
+            const EvRec& ev = a.events[ev0 + k];
+            if (uni(ev.type) == SIPNET_EV_IRRIG) {
+              const R p0 = (R)ev.p[0];
+              const R evapAmount = ((int)ev.p[1] == 0) ? K_immed * p0 : R(0);
+              evEvap += evapAmount * invLen;
+              evSoilWater += (p0 - evapAmount) * invLen;
+            }
+          }
+          soilWater += (double)(evSoilWater * len);
+        }
+        soilWater += (double)((rain + snowMelt - immedEvap - fastFlow - evaporation -
+                               transpiration - drainage) * len);
+        snow += (double)((snowFall - snowMelt - sublimation) * len);
+        soilWater = rmax0(soilWater);
+        snow = snow < kTiny ? 0.0 : snow;
+
+        // hand soilWater(t+1) to C, but never run more than one step ahead of it (the mailbox
+        // ring has four slots)
+        awaitAtLeast(&seqLai, t);
+        post(&mailWater[(t + 1) & 3][lane], &seqWater, (R)soilWater, t + 1);
+
+        *oEt = (transpiration + immedEvap + evaporation + sublimation + evEvap) * len;
+        oEt += ldEt;
+      }
+    }
+    if (act) {
+      ST(soilWater) = soilWater;
+      ST(snow) = snow;
+    }
+    return;
+  }
+
+  // =============================================================================================
+  // ---- C: carbon fluxes, pools, trackers, running mean (sipnet.c:756-842, 1051-1196, 1420-1806)
+  const R K_rpg = (R)((PRM(baseFolRespFrac) * PRM(aMax)) *
+                      (kCWeight * (1.0 / kTen9) * (PRM(leafCSpWt) / PRM(cFracLeaf)) * kSecPerDay));
+  const R K_invLcsw = (R)(1.0 / PRM(leafCSpWt));
+  const R K_invWhc = (R)(1.0 / PRM(soilWHC));
+  const R K_frozThr = (R)PRM(frozenSoilThreshold), K_frozFolEff = (R)PRM(frozenSoilFolREff);
+  const R K_lgVeg = (R)log2(PRM(vegRespQ10)), K_lgSoil = (R)log2(PRM(soilRespQ10));
+  const R K_lgFine = (R)log2(PRM(fineRootQ10)), K_lgCoarse = (R)log2(PRM(coarseRootQ10));
+  const R K_folShift = (R)exp2(-(PRM(psnTOpt) / 10.0) * log2(PRM(vegRespQ10)));
+  const R K_bvr = (R)PRM(baseVegResp), K_bsr = (R)PRM(baseSoilResp);
+  const R K_bfr = (R)PRM(baseFineRootResp), K_bcr = (R)PRM(baseCoarseRootResp);
+  const R K_wtr = (R)PRM(woodTurnoverRate), K_ltr = (R)PRM(leafTurnoverRate);
+  const R K_frt = (R)PRM(fineRootTurnoverRate), K_crt = (R)PRM(coarseRootTurnoverRate);
+  const R K_la = (R)PRM(leafAllocation), K_wa = (R)PRM(woodAllocation);
+  const R K_fa = (R)PRM(fineRootAllocation), K_ca = (R)PRM(coarseRootAllocation);
+  const R K_moistExp = (R)PRM(soilRespMoistEffect);
+  const double gddLeafOn = PRM(gddLeafOn);
+  const double leafOffDay = PRM(leafOffDay) > 0 ? PRM(leafOffDay) : 1e300;
+
+  double plantWoodC = ST(plantWoodC), plantLeafC = ST(plantLeafC), soilC = ST(soilC);
+  double coarseRootC = ST(coarseRootC), fineRootC = ST(fineRootC);
+  double delta = ST(plantCAccountingDelta);
+  double ringSum = ST(ringSum), totNee = ST(totNee), totGpp = ST(totGpp);
+  int phenBits = (int)ST(phenBits);
+  int ringValidFrom = (int)ST(ringValidFrom);
+  int diedAt = (int)ST(diedAt);
+
+  double* __restrict__ ringp = a.ring + col;
+  R* __restrict__ oNee = (R*)(a.nee ? a.nee : a.scratchRow) + col;
+  R* __restrict__ oGpp = (R*)(a.gpp ? a.gpp : a.scratchRow) + col;
+  const int64_t ldNee = a.nee ? a.ld : 0, ldGpp = a.gpp ? a.ld : 0;
+  const uint32_t ncu = (uint32_t)nc;
+
+  post(&mailLai[tBegin & 3][lane], &seqLai, (R)plantLeafC * K_invLcsw, tBegin);
+  for (int k = 0; k < SIPNET_RING_SLOTS; k++) ringL[k * 64 + lane] = ringp[(uint32_t)k * ncu];
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#ifdef SIPNET_STAMPS
+  unsigned long long cAcc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cLast;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(cLast)::"memory");
+#endif
+
+  R qSoil = 0, qFine = 0, qCoarse = 0;
+  bool haveQ = false;
+
+  for (int tileStart = curTile * kFastTile; tileStart < tEnd; tileStart += kFastTile, curTile++) {
+    // the DMA of this tile was issued a tile ago; only the last step's two stores may still be
+    // in flight behind it
+    if (tileStart > tBegin) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    stageTile(curTile + 1, (curTile + 1) & 1);
+    const int tFirst = tileStart > tBegin ? tileStart : tBegin;
+    const int tLast = (tileStart + kFastTile) < tEnd ? (tileStart + kFastTile) : tEnd;
+    const unsigned char* recB = lds + (curTile & 1) * kTileBytes +
+                                (int)(tFirst - tileFirst(curTile)) * (int)sizeof(FastRec);
+  for (int t = tFirst; t < tLast; t++, recB += sizeof(FastRec)) {
+    d2 q0, q1, q3, q5, q6, q7;
+    i4 j0;
+    asm volatile("ds_read_b128 %0, %7\n\tds_read_b128 %1, %7 offset:16\n\tds_read_b128 %2, %7 offset:48\n\t"
+                 "ds_read_b128 %3, %7 offset:80\n\tds_read_b128 %4, %7 offset:96\n\t"
+                 "ds_read_b128 %5, %7 offset:112\n\tds_read_b128 %6, %7 offset:128\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(q0), "=&v"(q1), "=&v"(q3), "=&v"(q5), "=&v"(q6), "=&v"(q7), "=&v"(j0)
+                 : "v"(ldsAddr(recB)) : "memory");
+    const double* rare = (const double*)(recB + 144);
+    const int32_t* rareI = (const int32_t*)(recB + 184);
+    CSTAMP(0)
+    const R len = (R)q0.x, invLen = (R)q0.y, tsoil = (R)q1.y;
+    const int bits = uni(j0.x);
+    const int slots = uni(j0.y);
+    const int insSlot = uni(j0.z);
+    const int nEv = uni(j0.w);
+    const int evSlot0 = slots & 255, evSlot1 = (slots >> 8) & 255;
+
+    const bool alive0 = (plantWoodC > kTiny) && (plantWoodC + delta > kTiny) &&
+                        (fineRootC + coarseRootC > kTiny);
+    const R eWood = (R)plantWoodC, eLeaf = (R)plantLeafC, eSoilC = (R)soilC;
+    const R eCoarse = (R)coarseRootC, eFine = (R)fineRootC;
+    const R totalWoodC = (R)(plantWoodC + delta);
+
+    auto leafOnLimit = [&](R flux) -> R {  // limitations.c:13-64 (no N cycle here)
+      const R cDemand = flux * len;
+      if (cDemand < R(kTiny)) return flux;
+      const R lim = clip01(fdiv((eWood + eCoarse) * PRM_RARE(leafOnReallocFrac), cDemand));
+      return lim < R(1) ? flux * lim : flux;
+    };
+
+    const R lai = eLeaf * K_invLcsw;
+    const R baseFolResp = K_rpg * lai;
+    const bool frozen = tsoil < K_frozThr;
+    const R meanNpp = (R)(ringSum * 0.2);
+
+    const R vegQ = fexp2((R)q5.y * K_lgVeg, EC);
+    R folResp = baseFolResp * (vegQ * K_folShift);
+    folResp = frozen ? folResp * K_frozFolEff : folResp;
+    const R rVeg = folResp + K_bvr * totalWoodC * vegQ;
+
+    const R woodLitter = totalWoodC * K_wtr;
+    R leafLitter = eLeaf * K_ltr;
+    R leafCreation = meanNpp * K_la, woodCreation = meanNpp * K_wa;
+
+    R leafOnCreation = 0, leafOnFromWood = 0;
+    if (bits & FAST_PHEN_NEW_YEAR) phenBits = 0;
+    const bool doOn = !(phenBits & 1) && q6.y >= gddLeafOn;
+    const bool doOff = !(phenBits & 2) && q7.x >= leafOffDay;
+
+    const R coarseRootLoss = K_crt * eCoarse, fineRootLoss = K_frt * eFine;
+    R coarseRootCreation = K_ca * meanNpp, fineRootCreation = K_fa * meanNpp;
+    if (!haveQ || !(bits & FAST_TSOIL_SAME)) {
+      const R tsoil10 = (R)q6.x;
+      qSoil = fexp2(tsoil10 * K_lgSoil, EC);
+      qFine = fexp2(tsoil10 * K_lgFine, EC);
+      qCoarse = fexp2(tsoil10 * K_lgCoarse, EC);
+      haveQ = true;
+    }
+    const R rCoarseRoot = K_bcr * eCoarse * qCoarse;
+    const R rFineRoot = K_bfr * eFine * qFine;
+
+    // checkNegativeCreation(), limitations.c:146-182, as selects
+    {
+      const R leafDeficit = eLeaf * invLen + leafCreation - eLeaf * K_ltr;
+      const R ld = rminv(leafDeficit, R(0));
+      woodCreation += ld;
+      leafCreation -= ld;
+      const R fineDef = eFine * invLen + fineRootCreation - fineRootLoss;
+      const R coarseDef = eCoarse * invLen + coarseRootCreation - coarseRootLoss;
+      const bool fNeg = fineDef < R(0), cNeg = coarseDef < R(0);
+      const R shift = (fNeg != cNeg) ? (fNeg ? fineDef : -coarseDef) : R(0);
+      coarseRootCreation += shift;
+      fineRootCreation -= shift;
+    }
+
+    CSTAMP(1)
+    // soil respiration needs the soil water of the start of this step (wave W, step t-1)
+#if defined(COOP_EXP) && COOP_EXP >= 3
+    const R eWater = R(5.0);
+#else
+    const R eWater = take(&mailWater[t & 3][lane], &seqWater, t);
+#endif
+    R moistEff = clip01(eWater * K_invWhc);
+    if (!PlainExp) moistEff = (K_moistExp == R(1)) ? moistEff : fpow(moistEff, K_moistExp);
+    moistEff = (bits & FAST_TSOIL_NEG) ? R(1) : moistEff;
+    const R rSoil = eSoilC * K_bsr * moistEff * qSoil * (R)q3.x;
+
+    // events (carbon side; irrigation belongs to wave W) and the yearly phenology switches
+    if (__builtin_expect(nEv > 0 || __builtin_amdgcn_ballot_w64(doOn || doOff) != 0, 0)) {
+      if (doOn) {
+        const R leafOn = leafOnLimit(PRM_RARE(leafGrowth) * invLen);
+        leafOnCreation = leafOn;
+        const R src = eWood + eCoarse;
+        if (src > R(kTiny)) leafOnFromWood = fdiv(leafOn * eWood, src);
+        phenBits |= 1;
+      }
+      if (doOff) {
+        leafLitter += (eLeaf * PRM_RARE(fracLeafFall)) * invLen;
+        phenBits |= 2;
+      }
+      R evLeafC = 0, evWoodC = 0, evFineRootC = 0, evCoarseRootC = 0;
+      R evSoilC = 0, evLeafOnCreation = 0, evLeafOnFromWood = 0, evLeafOffLitter = 0;
+      const int ev0 = uni(rareI[3]);
+      for (int k = 0; k < nEv; k++) {
+        const EvRec& ev = a.events[ev0 + k];
+        const int type = uni(ev.type);
+        const R p0 = (R)ev.p[0], p1 = (R)ev.p[1], p2 = (R)ev.p[2], p3 = (R)ev.p[3];
+        if (type == SIPNET_EV_PLANT) {
+          evLeafC += p0 * invLen;
+          evWoodC += p1 * invLen;
+          evFineRootC += p2 * invLen;
+          evCoarseRootC += p3 * invLen;
+        } else if (type == SIPNET_EV_HARVEST) {
+          const R woodC = totalWoodC;
+          evSoilC += (p3 * (eFine + eCoarse) + p2 * (eLeaf + woodC)) * invLen;
+          evLeafC += -eLeaf * (p0 + p2) * invLen;
+          evWoodC += -woodC * (p0 + p2) * invLen;
+          evFineRootC += -eFine * (p1 + p3) * invLen;
+          evCoarseRootC += -eCoarse * (p1 + p3) * invLen;
+        } else if (type == SIPNET_EV_FERT) {
+          evSoilC += p1 * invLen;
+        } else if (type == SIPNET_EV_LEAFON) {
+          const R flux = leafOnLimit(PRM_RARE(leafGrowth) * invLen);
+          evLeafOnCreation += flux;
+          const R src = eWood + eCoarse;
+          if (src > R(kTiny)) evLeafOnFromWood += fdiv(flux * eWood, src);
+        } else if (type == SIPNET_EV_LEAFOFF) {
+          evLeafOffLitter += eLeaf * PRM_RARE(fracLeafFall) * invLen;
+        }
+      }
+      plantWoodC += (double)(evWoodC * len);
+      plantLeafC += (double)(evLeafC * len);
+      soilC += (double)(evSoilC * len);
+      plantWoodC -= (double)(evLeafOnFromWood * len);
+      coarseRootC -= (double)((evLeafOnCreation - evLeafOnFromWood) * len);
+      plantLeafC += (double)((evLeafOnCreation - evLeafOffLitter) * len);
+      soilC += (double)(evLeafOffLitter * len);
+      coarseRootC += (double)(evCoarseRootC * len);
+      fineRootC += (double)(evFineRootC * len);
+    }
+
+    CSTAMP(2)
+    // photosynthesis of this step (wave W after wave L); nights need no hand-over
+    R photosynthesis = 0;
+    if (bits & FAST_PAR_POS) {
+#if defined(COOP_EXP) && COOP_EXP >= 2
+      photosynthesis = R(0.01);
+#else
+      photosynthesis = take(&mailPsn[t & 3][lane], &seqPsn, t);
+#endif
+    }
+
+    CSTAMP(3)
+    // ---- pools (sipnet.c:1769-1806): plant pools first, so that the next step's leaf area
+    // can leave for wave L as early as possible
+    {
+      const R r_a = rVeg + rFineRoot + rCoarseRoot;
+      const R alloc = leafCreation + woodCreation + fineRootCreation + coarseRootCreation;
+      delta += (double)(((photosynthesis - r_a) - alloc) * len);
+      plantWoodC += (double)((woodCreation - woodLitter - leafOnFromWood) * len);
+      plantLeafC += (double)((leafCreation + leafOnCreation - leafLitter) * len);
+      coarseRootC += (double)((coarseRootCreation - coarseRootLoss -
+                               (leafOnCreation - leafOnFromWood)) * len);
+      fineRootC += (double)((fineRootCreation - fineRootLoss) * len);
+    }
+    const double soilGain = (double)((coarseRootLoss + fineRootLoss + woodLitter + leafLitter - rSoil) * len);
+    // checkForMortality(), sipnet.c:1688-1767
+    bool alive = alive0;
+    double deathToSoil0 = 0.0, deathToSoil1 = 0.0;
+    bool diedNow = false;
+    {
+      const bool sufficient = (plantWoodC > kTiny) && (plantWoodC + delta > kTiny) &&
+                              (fineRootC + coarseRootC > kTiny);
+      if (__builtin_expect(sufficient != alive0, 0)) {
+        if (!alive0) {
+          alive = true;
+        } else {
+          alive = false;
+          diedNow = true;
+          if (diedAt < 0) diedAt = t;
+          deathToSoil0 = fineRootC + coarseRootC;
+          deathToSoil1 = plantWoodC + plantLeafC + delta;
+          plantWoodC = 0.0;
+          plantLeafC = 0.0;
+          coarseRootC = 0.0;
+          fineRootC = 0.0;
+          delta = 0.0;
+          ringSum = 0.0;
+        }
+      }
+    }
+    plantWoodC = rmax0(plantWoodC);
+    plantLeafC = rmax0(plantLeafC);
+    coarseRootC = rmax0(coarseRootC);
+    fineRootC = rmax0(fineRootC);
+    // lai(t+1) -> wave L; also tells wave W that step t is done here
+    post(&mailLai[(t + 1) & 3][lane], &seqLai, (R)plantLeafC * K_invLcsw, t + 1);
+
+    CSTAMP(4)
+    soilC += soilGain;
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(diedNow) != 0, 0)) {
+      if (diedNow) {
+        soilC += deathToSoil0;
+        soilC += deathToSoil1;
+      }
+    }
+    soilC = rmax0(soilC);
+
+    // ---- outputs: updateTrackers(), sipnet.c:1420-1496 ---------------------------------------
+    const R tGpp = photosynthesis * len;
+    const R tRh = rSoil * len;
+    const R tRa = (rCoarseRoot + rFineRoot) * len + rVeg * len;
+    const R tNee = R(-1.0) * ((tGpp - tRa) - tRh);
+    totGpp += (double)tGpp;
+    totNee += (double)tNee;
+
+    // ---- running mean of NPP (sipnet.c:1546-1570, runmean.c:61-116 via the plan) -------------
+    const double npp = (double)(photosynthesis - rVeg - rCoarseRoot - rFineRoot);
+    CSTAMP(5)
+    {
+#if defined(COOP_EXP) && COOP_EXP >= 5
+      const double v0 = npp * 0.5;
+#else
+      const double v0 = ringL[evSlot0 * 64 + lane];
+#endif
+      const int nOps = bits >> 16;
+      const bool irregular = __builtin_amdgcn_ballot_w64(!alive || ringValidFrom > 0) != 0 ||
+                             insSlot < 0 || nOps != 1;
+      if (__builtin_expect(!irregular, 1)) {
+        ringSum = ffma(-q7.y, v0, ringSum);
+        ringSum = ffma(npp, (double)len, ringSum);
+      } else if (alive) {
+        if (insSlot < 0) {
+          ringSum = npp * 5.0;
+        } else {
+          double w0v = v0, w1v = ringL[evSlot1 * 64 + lane];
+          if (ringValidFrom > 0) {
+            if (uni(rareI[0]) < ringValidFrom) w0v = 0.0;
+            if (uni(rareI[1]) < ringValidFrom) w1v = 0.0;
+          }
+          ringSum = ffma(-q7.y, w0v, ringSum);
+          ringSum = ffma(-rare[0], w1v, ringSum);
+          for (int k = 2; k < nOps; k++) {
+            const RingOp& op = a.ringOps[uni(rareI[2]) + k];
+            const double v = (uni(op.insStep) >= ringValidFrom) ? ringL[uni(op.slot) * 64 + lane] : 0.0;
+            ringSum = ffma(-op.w, v, ringSum);
+          }
+          ringSum = ffma(npp, (double)len, ringSum);
+        }
+      } else {
+        ringValidFrom = t + 1;
+      }
+    }
+    const int insEff = insSlot < 0 ? 0 : insSlot;
+#if !defined(COOP_EXP) || COOP_EXP < 5
+    ringL[insEff * 64 + lane] = npp;
+#endif
+#if !defined(COOP_EXP) || COOP_EXP < 4
+    *oNee = tNee;
+    *oGpp = tGpp;
+#else
+    if (t == tEnd - 1) { *oNee = tNee; *oGpp = tGpp; }
+#endif
+    oNee += ldNee;
+    oGpp += ldGpp;
+    CSTAMP(6)
+  }  // steps of this tile
+  }  // tiles
+
+#ifdef SIPNET_STAMPS
+  if (blockIdx.x == 0 && lane == 0)
+    for (int k = 0; k < 8; k++) g_coopStamps[k] = cAcc[k];
+#endif
+  if (act) {
+    for (int k = 0; k < SIPNET_RING_SLOTS; k++) ringp[(uint32_t)k * ncu] = ringL[k * 64 + lane];
+    ST(plantWoodC) = plantWoodC;
+    ST(plantLeafC) = plantLeafC;
+    ST(soilC) = soilC;
+    ST(coarseRootC) = coarseRootC;
+    ST(fineRootC) = fineRootC;
+    ST(plantCAccountingDelta) = delta;
+    ST(ringSum) = ringSum;
+    ST(totNee) = totNee;
+    ST(totGpp) = totGpp;
+    ST(phenBits) = (double)phenBits;
+    ST(ringValidFrom) = (double)ringValidFrom;
+    ST(diedAt) = (double)diedAt;
+  }
+#undef ST
+#undef PRM
+#undef PRM_RARE
+}
+
+#ifdef SIPNET_STAMPS
+extern "C" int sipnet_debug_read_coop_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_coopStamps), 8 * sizeof(unsigned long long));
+}
+#endif
+
+void launchStepCoop(const FastArgs& a, int precision, hipStream_t stream) {
+  const int chunksPerSite = (a.n_members + 63) / 64;
+  const int grid = a.n_sites * chunksPerSite;
+  if (precision == SIPNET_F64) {
+    if (a.plainExp) hipLaunchKernelGGL((stepCoopKernel<double, true>), dim3(grid), dim3(192), 0, stream, a);
+    else hipLaunchKernelGGL((stepCoopKernel<double, false>), dim3(grid), dim3(192), 0, stream, a);
+  } else {
+    if (a.plainExp) hipLaunchKernelGGL((stepCoopKernel<float, true>), dim3(grid), dim3(192), 0, stream, a);
+    else hipLaunchKernelGGL((stepCoopKernel<float, false>), dim3(grid), dim3(192), 0, stream, a);
+  }
+}
+
+}  // namespace sipnet

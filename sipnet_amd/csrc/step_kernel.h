@@ -94,6 +94,8 @@ struct FastArgs {
   int32_t plainExp;  // 1: every member has dVpdExp == 2 and soilRespMoistEffect == 1
 };
 void launchStepFast(const FastArgs& a, int precision, hipStream_t stream);
+// three cooperating wavefronts per 64 members (step_coop.hip); same results as launchStepFast
+void launchStepCoop(const FastArgs& a, int precision, hipStream_t stream);
 bool isDefaultFlagSet(const int32_t* flags);
 
 // launchers (step_kernel.hip)
