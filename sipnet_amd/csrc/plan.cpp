@@ -266,7 +266,8 @@ std::vector<FastRec> buildFastRecs(const SitePlan& plan) {
                (s.tair > 0 ? FAST_TAIR_POS : 0) | (s.par > 0 ? FAST_PAR_POS : 0) |
                (s.tsoil < 0 ? FAST_TSOIL_NEG : 0) | (f.w1 != 0.0 ? FAST_HAS_W1 : 0) |
                (s.dTill != 0.0 ? FAST_HAS_TILL : 0) |
-               (t > 0 && plan.steps[t - 1].tsoil10 == s.tsoil10 ? FAST_TSOIL_SAME : 0);
+               (t > 0 && plan.steps[t - 1].tsoil10 == s.tsoil10 ? FAST_TSOIL_SAME : 0) |
+               (s.ringOpCount == 1 && s.ringInsSlot >= 0 ? FAST_RING_REGULAR : 0);
     f.bitsOps = bits | (s.ringOpCount << 16);
     f.insSlot = s.ringInsSlot;
     f.evCount = s.evCount;

@@ -102,7 +102,8 @@ enum : int32_t {
   FAST_TSOIL_NEG = 16,   // tsoil < 0
   FAST_HAS_W1 = 32,      // a second eviction with non-zero weight
   FAST_HAS_TILL = 64,    // tillage modifier in effect
-  FAST_TSOIL_SAME = 128  // tsoil identical to the previous record: Q10 factors can be reused
+  FAST_TSOIL_SAME = 128, // tsoil identical to the previous record: Q10 factors can be reused
+  FAST_RING_REGULAR = 256  // exactly one eviction and a plain insert (no ring reset)
 };
 
 // Weights and cursors of the running-mean ring as the reference holds them when a member

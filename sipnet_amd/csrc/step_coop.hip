@@ -6,8 +6,10 @@
 // chain of three blocks with thin interfaces:
 //
 //   L  light      lai(t)            -> potGrossPsn(t)          (dTemp, dVpd, 7-layer Simpson)
-//   W  water      potGrossPsn(t)    -> photosynthesis(t), ET(t), soilWater(t+1), snow(t+1)
-//   C  carbon     photosynthesis(t), soilWater(t) -> pools(t+1), ring, NEE(t), GPP(t), lai(t+1)
+//   W  water      potGrossPsn(t)    -> photosynthesis(t), ET(t), soilWater(t+1), snow(t+1);
+//                 also every factor of C's respiration terms that depends on climate, soil
+//                 water and parameters only (Q10 terms, moisture effect, tillage)
+//   C  carbon     photosynthesis(t), factors(t) -> pools(t+1), ring, NEE(t), GPP(t), lai(t+1)
 //
 // so a workgroup is three wavefronts on three SIMDs of one CU, each running its OWN time loop
 // over the same 64 members and the same site records, and passing one double per member and
@@ -16,9 +18,10 @@
 // W and C that do not need it.  The arithmetic, its order and therefore the results are those
 // of stepFastKernel (bit-identical; tests/test_gpu_parity.py).
 //
-// Mailbox slots are indexed by step & 3; the wait-for graph keeps every producer within three
-// steps of its consumers:  L(t) waits lai(t) [C finished t-1];  W(t) waits C finished t-1 and,
-// by day, potGrossPsn(t);  C(t) waits soilWater(t) [W finished t-1] and, by day, psn(t).
+// Mailbox slots are indexed by step & 1; the wait-for graph keeps every producer at most one
+// step ahead of its consumer:  L(t) waits lai(t) [C past the pools of t-1];  W(t) ends only
+// when C is past the pools of t-1 and, by day, waits potGrossPsn(t);  C(t) waits the factors
+// W posts when it STARTS step t and, by day, psn(t).
 #include <hip/hip_runtime.h>
 
 #include "fast_math.h"
@@ -76,6 +79,17 @@ __device__ __forceinline__ void ringLoad2(double& v0, double& v1, const double* 
 __device__ __forceinline__ void vmemDrain(double& v0, double& v1) {
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(v0), "+v"(v1) :: "memory");
 }
+// five values + flag (wave W -> wave C)
+template <class R>
+__device__ __forceinline__ void post5(R* base, int* flag, R v0, R v1, R v2, R v3, R v4, int step) {
+  base[0 * 64] = v0;  // DS writes of one wave execute in issue order ...
+  base[1 * 64] = v1;
+  base[2 * 64] = v2;
+  base[3 * 64] = v3;
+  base[4 * 64] = v4;
+  asm volatile("" ::: "memory");
+  *(volatile int*)flag = step;  // ... so the flag lands after the values
+}
 // progress-only wait (no value)
 __device__ __forceinline__ void awaitAtLeast(const int* flag, int step) {
   int f;
@@ -104,8 +118,9 @@ template <class R, bool PlainExp>
 __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
   // per-wave private record tiles (each wave stages and awaits its own DMA) + mailboxes
   __shared__ alignas(16) unsigned char ldsTiles[3][2 * kTileBytes];
-  __shared__ R mailLai[4][64], mailPgp[4][64], mailPsn[4][64], mailWater[4][64];
-  __shared__ int seqLai, seqPgp, seqPsn, seqWater;
+  __shared__ R mailLai[2][64], mailPgp[2][64], mailPsn[2][64];
+  __shared__ R mailFac[2][5][64];  // g1 g2 fSoil gFine gCoarse of a step (see wave W)
+  __shared__ int seqLai, seqPgp, seqPsn, seqFac;
   // The running-mean ring of the 64 members lives in LDS for the whole launch (250 x 64 x 8 B =
   // 125 KB; one workgroup per CU).  A wave that stores to HBM every step must not also load
   // from HBM every step: vector-memory operations complete in issue order, so each step's ring
@@ -147,7 +162,7 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
     seqLai = tBegin - 1;
     seqPgp = tBegin - 1;
     seqPsn = tBegin - 1;
-    seqWater = tBegin - 1;
+    seqFac = tBegin - 1;
   }
   __syncthreads();  // the only workgroup barrier: flags initialised before anyone spins
 
@@ -211,18 +226,14 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
         const R dVpd = rmax0(R(1) - K_slope * vpdPow);
         const R q = (R)q2.x * K_invHalf;
         const R e0 = fexp2(q, EC);
-        const R lai = take(&mailLai[t & 3][lane], &seqLai, t);
-#if defined(COOP_EXP) && COOP_EXP == 1
-        post(&mailPgp[t & 3][lane], &seqPgp, lai * dTemp * dVpd * e0, t);
-        continue;
-#endif
+        const R lai = take(&mailLai[t & 1][lane], &seqLai, t);
         const R r1 = fexp2(K_attl * lai, EC);
         const R r2 = r1 * r1, r3 = r2 * r1, r4 = r2 * r2, r5 = r4 * r1, r6 = r3 * r3;
         const R e1 = fexp2(q * r1, EC), e2 = fexp2(q * r2, EC), e3 = fexp2(q * r3, EC);
         const R e4 = fexp2(q * r4, EC), e5 = fexp2(q * r5, EC), e6 = fexp2(q * r6, EC);
         const R s = (e0 + e6) + R(4) * (e1 + e3 + e5) + R(2) * (e2 + e4);
         const R dLight = R(1) - s * R(1.0 / 18.0);
-        post(&mailPgp[t & 3][lane], &seqPgp, K_g * lai * dTemp * dVpd * dLight, t);
+        post(&mailPgp[t & 1][lane], &seqPgp, K_g * lai * dTemp * dVpd * dLight, t);
       }
     }
     return;
@@ -238,10 +249,21 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
     const R K_immed = (R)PRM(immedEvapFrac), K_ff = (R)PRM(fastFlowFrac);
     const R K_invRd = (R)(1.0 / PRM(rdConst)), K_rd = (R)PRM(rdConst), K_melt = (R)PRM(snowMelt);
     const R K_c1l = (R)(PRM(rSoilConst1) * kLog2e), K_c2l = (R)(PRM(rSoilConst2) * kLog2e);
+    // for wave C's respiration factors
+    const R K_lgVeg = (R)log2(PRM(vegRespQ10)), K_lgSoil = (R)log2(PRM(soilRespQ10));
+    const R K_lgFine = (R)log2(PRM(fineRootQ10)), K_lgCoarse = (R)log2(PRM(coarseRootQ10));
+    const R K_fol = (R)((PRM(baseFolRespFrac) * PRM(aMax)) *
+                        (kCWeight * (1.0 / kTen9) * (PRM(leafCSpWt) / PRM(cFracLeaf)) * kSecPerDay) *
+                        (1.0 / PRM(leafCSpWt)) * exp2(-(PRM(psnTOpt) / 10.0) * log2(PRM(vegRespQ10))));
+    const R K_frozFolEff = (R)PRM(frozenSoilFolREff);
+    const R K_bvr = (R)PRM(baseVegResp), K_bsr = (R)PRM(baseSoilResp);
+    const R K_bfr = (R)PRM(baseFineRootResp), K_bcr = (R)PRM(baseCoarseRootResp);
+    const R K_moistExp = (R)PRM(soilRespMoistEffect);
+    R qSoil = 0, gFine = 0, gCoarse = 0;
+    bool haveQ = false;
     double soilWater = ST(soilWater), snow = ST(snow);
     R* __restrict__ oEt = (R*)(a.et ? a.et : a.scratchRow) + col;
     const int64_t ldEt = a.et ? a.ld : 0;
-    post(&mailWater[tBegin & 3][lane], &seqWater, (R)soilWater, tBegin);
 
     for (int tileStart = curTile * kFastTile; tileStart < tEnd; tileStart += kFastTile, curTile++) {
       // the DMA of 16 steps ago has landed: all but the youngest operation (the last ET store)
@@ -253,11 +275,13 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
                                   (int)(tFirst - tileFirst(curTile)) * (int)sizeof(FastRec);
       for (int t = tFirst; t < tLast; t++, recB += sizeof(FastRec)) {
         d2 q0, q1, q2, q3, q4, q5;
+        double q6x;
         i4 j0;
-        asm volatile("ds_read_b128 %0, %7\n\tds_read_b128 %1, %7 offset:16\n\tds_read_b128 %2, %7 offset:32\n\t"
-                     "ds_read_b128 %3, %7 offset:48\n\tds_read_b128 %4, %7 offset:64\n\t"
-                     "ds_read_b128 %5, %7 offset:80\n\tds_read_b128 %6, %7 offset:128\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4), "=&v"(q5), "=&v"(j0)
+        asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\tds_read_b128 %2, %8 offset:32\n\t"
+                     "ds_read_b128 %3, %8 offset:48\n\tds_read_b128 %4, %8 offset:64\n\t"
+                     "ds_read_b128 %5, %8 offset:80\n\tds_read_b64 %6, %8 offset:96\n\t"
+                     "ds_read_b128 %7, %8 offset:128\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4), "=&v"(q5), "=&v"(q6x), "=&v"(j0)
                      : "v"(ldsAddr(recB)) : "memory");
         const int32_t* rareI = (const int32_t*)(recB + 184);
         const R len = (R)q0.x, invLen = (R)q0.y, tair = (R)q1.x, tsoil = (R)q1.y;
@@ -265,6 +289,30 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
         const int nEv = uni(j0.w);
         const R eWater = (R)soilWater, eSnow = (R)snow;
         const bool frozen = tsoil < K_frozThr;
+
+        // ---- for wave C: the climate / soil-water / parameter part of its respiration terms
+        // of THIS step (vegResp sipnet.c:1051-1068, calcRootResp :1073, calcSoilRespiration
+        // :1132-1148 with depeffects.c:23-87), posted before anything else so that C never
+        // waits for it:  folResp = leafC * g1,  rVeg = folResp + totalWoodC * g2,
+        // rSoil = soilC * fSoil,  rFineRoot = fineRootC * gFine,  rCoarseRoot = coarseRootC * gCoarse
+        {
+          const R vegQ = fexp2((R)q5.y * K_lgVeg, EC);
+          R g1 = K_fol * vegQ;
+          g1 = frozen ? g1 * K_frozFolEff : g1;
+          const R g2 = K_bvr * vegQ;
+          if (!haveQ || !(bits & FAST_TSOIL_SAME)) {
+            const R tsoil10 = (R)q6x;
+            qSoil = fexp2(tsoil10 * K_lgSoil, EC);
+            gFine = K_bfr * fexp2(tsoil10 * K_lgFine, EC);
+            gCoarse = K_bcr * fexp2(tsoil10 * K_lgCoarse, EC);
+            haveQ = true;
+          }
+          R moistEff = clip01(eWater * K_invWhc);
+          if (!PlainExp) moistEff = (K_moistExp == R(1)) ? moistEff : fpow(moistEff, K_moistExp);
+          moistEff = (bits & FAST_TSOIL_NEG) ? R(1) : moistEff;
+          const R fSoil = K_bsr * moistEff * qSoil * (R)q3.x;
+          post5(&mailFac[t & 1][0][lane], &seqFac, g1, g2, fSoil, gFine, gCoarse, t);
+        }
 
         // everything that does not need the light block first
         const bool tairPos = (bits & FAST_TAIR_POS) != 0;
@@ -295,18 +343,14 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
         // moisture(), sipnet.c:656-699, with the potential photosynthesis of wave L
         R transpiration = 0, photosynthesis = 0;
         if (bits & FAST_PAR_POS) {
-#if defined(COOP_EXP) && COOP_EXP >= 2
-          const R potGrossPsn = R(0.01);
-#else
-          const R potGrossPsn = take(&mailPgp[t & 3][lane], &seqPgp, t);
-#endif
+          const R potGrossPsn = take(&mailPgp[t & 1][lane], &seqPgp, t);
           const R potTrans = potGrossPsn * (R)q2.y * K_tr;
           const bool hasPsn = potGrossPsn >= R(kTiny);
           const bool limited = removable < potTrans;
           const R dWater = fdiv(removable, potTrans);
           transpiration = hasPsn ? (limited ? removable : potTrans) : R(0);
           photosynthesis = (hasPsn && limited) ? potGrossPsn * dWater : potGrossPsn;
-          post(&mailPsn[t & 3][lane], &seqPsn, photosynthesis, t);
+          post(&mailPsn[t & 1][lane], &seqPsn, photosynthesis, t);
         }
 
         R evaporation, drainage, fastFlow;
@@ -342,10 +386,9 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
         soilWater = rmax0(soilWater);
         snow = snow < kTiny ? 0.0 : snow;
 
-        // hand soilWater(t+1) to C, but never run more than one step ahead of it (the mailbox
-        // ring has four slots)
+        // never run more than one step ahead of C (the mailboxes have two slots): C is past the
+        // pools of step t-1 once it has posted lai(t)
         awaitAtLeast(&seqLai, t);
-        post(&mailWater[(t + 1) & 3][lane], &seqWater, (R)soilWater, t + 1);
 
         *oEt = (transpiration + immedEvap + evaporation + sublimation + evEvap) * len;
         oEt += ldEt;
@@ -360,21 +403,11 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
 
   // =============================================================================================
   // ---- C: carbon fluxes, pools, trackers, running mean (sipnet.c:756-842, 1051-1196, 1420-1806)
-  const R K_rpg = (R)((PRM(baseFolRespFrac) * PRM(aMax)) *
-                      (kCWeight * (1.0 / kTen9) * (PRM(leafCSpWt) / PRM(cFracLeaf)) * kSecPerDay));
   const R K_invLcsw = (R)(1.0 / PRM(leafCSpWt));
-  const R K_invWhc = (R)(1.0 / PRM(soilWHC));
-  const R K_frozThr = (R)PRM(frozenSoilThreshold), K_frozFolEff = (R)PRM(frozenSoilFolREff);
-  const R K_lgVeg = (R)log2(PRM(vegRespQ10)), K_lgSoil = (R)log2(PRM(soilRespQ10));
-  const R K_lgFine = (R)log2(PRM(fineRootQ10)), K_lgCoarse = (R)log2(PRM(coarseRootQ10));
-  const R K_folShift = (R)exp2(-(PRM(psnTOpt) / 10.0) * log2(PRM(vegRespQ10)));
-  const R K_bvr = (R)PRM(baseVegResp), K_bsr = (R)PRM(baseSoilResp);
-  const R K_bfr = (R)PRM(baseFineRootResp), K_bcr = (R)PRM(baseCoarseRootResp);
   const R K_wtr = (R)PRM(woodTurnoverRate), K_ltr = (R)PRM(leafTurnoverRate);
   const R K_frt = (R)PRM(fineRootTurnoverRate), K_crt = (R)PRM(coarseRootTurnoverRate);
   const R K_la = (R)PRM(leafAllocation), K_wa = (R)PRM(woodAllocation);
   const R K_fa = (R)PRM(fineRootAllocation), K_ca = (R)PRM(coarseRootAllocation);
-  const R K_moistExp = (R)PRM(soilRespMoistEffect);
   const double gddLeafOn = PRM(gddLeafOn);
   const double leafOffDay = PRM(leafOffDay) > 0 ? PRM(leafOffDay) : 1e300;
 
@@ -392,16 +425,17 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
   const int64_t ldNee = a.nee ? a.ld : 0, ldGpp = a.gpp ? a.ld : 0;
   const uint32_t ncu = (uint32_t)nc;
 
-  post(&mailLai[tBegin & 3][lane], &seqLai, (R)plantLeafC * K_invLcsw, tBegin);
+  post(&mailLai[tBegin & 1][lane], &seqLai, (R)plantLeafC * K_invLcsw, tBegin);
+  // carried: this member's alive flag (sipnet.c:1530-1544) and, for the whole wave, "every
+  // member alive with an untouched ring epoch" (what the regular ring update needs)
+  bool aliveC = (plantWoodC > kTiny) && (plantWoodC + delta > kTiny) && (fineRootC + coarseRootC > kTiny);
+  bool ringClean = __builtin_amdgcn_ballot_w64(!aliveC || ringValidFrom > 0) == 0;
   for (int k = 0; k < SIPNET_RING_SLOTS; k++) ringL[k * 64 + lane] = ringp[(uint32_t)k * ncu];
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #ifdef SIPNET_STAMPS
   unsigned long long cAcc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cLast;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(cLast)::"memory");
 #endif
-
-  R qSoil = 0, qFine = 0, qCoarse = 0;
-  bool haveQ = false;
 
   for (int tileStart = curTile * kFastTile; tileStart < tEnd; tileStart += kFastTile, curTile++) {
     // the DMA of this tile was issued a tile ago; only the last step's two stores may still be
@@ -413,25 +447,48 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
     const unsigned char* recB = lds + (curTile & 1) * kTileBytes +
                                 (int)(tFirst - tileFirst(curTile)) * (int)sizeof(FastRec);
   for (int t = tFirst; t < tLast; t++, recB += sizeof(FastRec)) {
-    d2 q0, q1, q3, q5, q6, q7;
+    // record fields of the carbon block (len invLen | tsoil10 cumGdd | dayTime w0 | ints) and the
+    // five factors wave W posted for this step, in ONE LDS round trip; the flag is read before
+    // the values (DS reads return in order), so a current flag vouches for what follows it
+    d2 q0, q6, q7;
     i4 j0;
-    asm volatile("ds_read_b128 %0, %7\n\tds_read_b128 %1, %7 offset:16\n\tds_read_b128 %2, %7 offset:48\n\t"
-                 "ds_read_b128 %3, %7 offset:80\n\tds_read_b128 %4, %7 offset:96\n\t"
-                 "ds_read_b128 %5, %7 offset:112\n\tds_read_b128 %6, %7 offset:128\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(q0), "=&v"(q1), "=&v"(q3), "=&v"(q5), "=&v"(q6), "=&v"(q7), "=&v"(j0)
-                 : "v"(ldsAddr(recB)) : "memory");
+    R g1, g2, fSoil, gFine, gCoarse;
+    int facSeq;
+    {
+      const unsigned fac = ldsAddr(&mailFac[t & 1][0][lane]);
+      // (re-reading the record while spinning is harmless; one asm statement defines every value,
+      // so no copies are needed when the first look already finds the flag current)
+      do {
+        if (sizeof(R) == 8) {
+          asm volatile("ds_read_b128 %0, %10\n\tds_read_b128 %1, %10 offset:96\n\tds_read_b128 %2, %10 offset:112\n\t"
+                       "ds_read_b128 %3, %10 offset:128\n\tds_read_b32 %4, %11\n\t"
+                       "ds_read_b64 %5, %12\n\tds_read_b64 %6, %12 offset:512\n\tds_read_b64 %7, %12 offset:1024\n\t"
+                       "ds_read_b64 %8, %12 offset:1536\n\tds_read_b64 %9, %12 offset:2048\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(q0), "=&v"(q6), "=&v"(q7), "=&v"(j0), "=&v"(facSeq), "=&v"(g1), "=&v"(g2),
+                         "=&v"(fSoil), "=&v"(gFine), "=&v"(gCoarse)
+                       : "v"(ldsAddr(recB)), "v"(ldsAddr(&seqFac)), "v"(fac) : "memory");
+        } else {
+          asm volatile("ds_read_b128 %0, %10\n\tds_read_b128 %1, %10 offset:96\n\tds_read_b128 %2, %10 offset:112\n\t"
+                       "ds_read_b128 %3, %10 offset:128\n\tds_read_b32 %4, %11\n\t"
+                       "ds_read_b32 %5, %12\n\tds_read_b32 %6, %12 offset:256\n\tds_read_b32 %7, %12 offset:512\n\t"
+                       "ds_read_b32 %8, %12 offset:768\n\tds_read_b32 %9, %12 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(q0), "=&v"(q6), "=&v"(q7), "=&v"(j0), "=&v"(facSeq), "=&v"(g1), "=&v"(g2),
+                         "=&v"(fSoil), "=&v"(gFine), "=&v"(gCoarse)
+                       : "v"(ldsAddr(recB)), "v"(ldsAddr(&seqFac)), "v"(fac) : "memory");
+        }
+      } while (uni(facSeq) < t);
+    }
     const double* rare = (const double*)(recB + 144);
     const int32_t* rareI = (const int32_t*)(recB + 184);
     CSTAMP(0)
-    const R len = (R)q0.x, invLen = (R)q0.y, tsoil = (R)q1.y;
+    const R len = (R)q0.x, invLen = (R)q0.y;
     const int bits = uni(j0.x);
     const int slots = uni(j0.y);
     const int insSlot = uni(j0.z);
     const int nEv = uni(j0.w);
     const int evSlot0 = slots & 255, evSlot1 = (slots >> 8) & 255;
 
-    const bool alive0 = (plantWoodC > kTiny) && (plantWoodC + delta > kTiny) &&
-                        (fineRootC + coarseRootC > kTiny);
+    const bool alive0 = aliveC;
     const R eWood = (R)plantWoodC, eLeaf = (R)plantLeafC, eSoilC = (R)soilC;
     const R eCoarse = (R)coarseRootC, eFine = (R)fineRootC;
     const R totalWoodC = (R)(plantWoodC + delta);
@@ -443,15 +500,14 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
       return lim < R(1) ? flux * lim : flux;
     };
 
-    const R lai = eLeaf * K_invLcsw;
-    const R baseFolResp = K_rpg * lai;
-    const bool frozen = tsoil < K_frozThr;
     const R meanNpp = (R)(ringSum * 0.2);
 
-    const R vegQ = fexp2((R)q5.y * K_lgVeg, EC);
-    R folResp = baseFolResp * (vegQ * K_folShift);
-    folResp = frozen ? folResp * K_frozFolEff : folResp;
-    const R rVeg = folResp + K_bvr * totalWoodC * vegQ;
+    // vegResp(), calcRootResp(), calcSoilRespiration() with wave W's factors
+    const R folResp = eLeaf * g1;
+    const R rVeg = folResp + totalWoodC * g2;
+    const R rCoarseRoot = eCoarse * gCoarse;
+    const R rFineRoot = eFine * gFine;
+    const R rSoil = eSoilC * fSoil;
 
     const R woodLitter = totalWoodC * K_wtr;
     R leafLitter = eLeaf * K_ltr;
@@ -464,15 +520,6 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
 
     const R coarseRootLoss = K_crt * eCoarse, fineRootLoss = K_frt * eFine;
     R coarseRootCreation = K_ca * meanNpp, fineRootCreation = K_fa * meanNpp;
-    if (!haveQ || !(bits & FAST_TSOIL_SAME)) {
-      const R tsoil10 = (R)q6.x;
-      qSoil = fexp2(tsoil10 * K_lgSoil, EC);
-      qFine = fexp2(tsoil10 * K_lgFine, EC);
-      qCoarse = fexp2(tsoil10 * K_lgCoarse, EC);
-      haveQ = true;
-    }
-    const R rCoarseRoot = K_bcr * eCoarse * qCoarse;
-    const R rFineRoot = K_bfr * eFine * qFine;
 
     // checkNegativeCreation(), limitations.c:146-182, as selects
     {
@@ -489,16 +536,6 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
     }
 
     CSTAMP(1)
-    // soil respiration needs the soil water of the start of this step (wave W, step t-1)
-#if defined(COOP_EXP) && COOP_EXP >= 3
-    const R eWater = R(5.0);
-#else
-    const R eWater = take(&mailWater[t & 3][lane], &seqWater, t);
-#endif
-    R moistEff = clip01(eWater * K_invWhc);
-    if (!PlainExp) moistEff = (K_moistExp == R(1)) ? moistEff : fpow(moistEff, K_moistExp);
-    moistEff = (bits & FAST_TSOIL_NEG) ? R(1) : moistEff;
-    const R rSoil = eSoilC * K_bsr * moistEff * qSoil * (R)q3.x;
 
     // events (carbon side; irrigation belongs to wave W) and the yearly phenology switches
     if (__builtin_expect(nEv > 0 || __builtin_amdgcn_ballot_w64(doOn || doOff) != 0, 0)) {
@@ -558,11 +595,7 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
     // photosynthesis of this step (wave W after wave L); nights need no hand-over
     R photosynthesis = 0;
     if (bits & FAST_PAR_POS) {
-#if defined(COOP_EXP) && COOP_EXP >= 2
-      photosynthesis = R(0.01);
-#else
-      photosynthesis = take(&mailPsn[t & 3][lane], &seqPsn, t);
-#endif
+      photosynthesis = take(&mailPsn[t & 1][lane], &seqPsn, t);
     }
 
     CSTAMP(3)
@@ -587,6 +620,7 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
       const bool sufficient = (plantWoodC > kTiny) && (plantWoodC + delta > kTiny) &&
                               (fineRootC + coarseRootC > kTiny);
       if (__builtin_expect(sufficient != alive0, 0)) {
+        ringClean = false;  // a ring epoch stays behind: this wave takes the general ring path from now on
         if (!alive0) {
           alive = true;
         } else {
@@ -604,12 +638,13 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
         }
       }
     }
+    aliveC = alive;
     plantWoodC = rmax0(plantWoodC);
     plantLeafC = rmax0(plantLeafC);
     coarseRootC = rmax0(coarseRootC);
     fineRootC = rmax0(fineRootC);
     // lai(t+1) -> wave L; also tells wave W that step t is done here
-    post(&mailLai[(t + 1) & 3][lane], &seqLai, (R)plantLeafC * K_invLcsw, t + 1);
+    post(&mailLai[(t + 1) & 1][lane], &seqLai, (R)plantLeafC * K_invLcsw, t + 1);
 
     CSTAMP(4)
     soilC += soilGain;
@@ -633,15 +668,9 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
     const double npp = (double)(photosynthesis - rVeg - rCoarseRoot - rFineRoot);
     CSTAMP(5)
     {
-#if defined(COOP_EXP) && COOP_EXP >= 5
-      const double v0 = npp * 0.5;
-#else
       const double v0 = ringL[evSlot0 * 64 + lane];
-#endif
       const int nOps = bits >> 16;
-      const bool irregular = __builtin_amdgcn_ballot_w64(!alive || ringValidFrom > 0) != 0 ||
-                             insSlot < 0 || nOps != 1;
-      if (__builtin_expect(!irregular, 1)) {
+      if (__builtin_expect(ringClean && (bits & FAST_RING_REGULAR), 1)) {
         ringSum = ffma(-q7.y, v0, ringSum);
         ringSum = ffma(npp, (double)len, ringSum);
       } else if (alive) {
@@ -667,15 +696,9 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
       }
     }
     const int insEff = insSlot < 0 ? 0 : insSlot;
-#if !defined(COOP_EXP) || COOP_EXP < 5
     ringL[insEff * 64 + lane] = npp;
-#endif
-#if !defined(COOP_EXP) || COOP_EXP < 4
     *oNee = tNee;
     *oGpp = tGpp;
-#else
-    if (t == tEnd - 1) { *oNee = tNee; *oGpp = tGpp; }
-#endif
     oNee += ldNee;
     oGpp += ldGpp;
     CSTAMP(6)

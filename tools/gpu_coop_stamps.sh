@@ -22,9 +22,9 @@ st = (C.c_ulonglong * 8)()
 sa.lib().sipnet_debug_read_coop_stamps.argtypes = [C.c_void_p]
 sa.lib().sipnet_debug_read_coop_stamps(st)
 v = np.array(list(st), dtype=float)
-names = ["record read", "resp/alloc fluxes", "take water + rSoil + events test", "take psn", "pools+mortality+post lai", "soilC+outputs", "ring + stores"]
-print("EXP $e kernel ms", b.last_kernel_ms(), "C-wave cycles/step (100 MHz ticks x24)", v.sum() / T * 24)
-for n, x in zip(names, v): print("  %-34s %8.1f cycles/step" % (n, x / T * 24))
+names = ["loop+record+factors take", "fluxes", "events test", "take psn", "pools+mortality+post lai", "soilC+outputs", "ring + stores"]
+print("EXP $e kernel ms", b.last_kernel_ms(), "C-wave cycles/step (100 MHz ticks x24)", v.sum() / T)
+for n, x in zip(names, v): print("  %-34s %8.1f cycles/step" % (n, x / T))
 PY
 )
 done
