@@ -52,7 +52,7 @@ if means:
         if "sipnet" in k:
             out.append(f"| `{k[:70]}` | {c} | {v:.6g} |")
     out.append("")
-    step = [k for (k, c) in means if "stepKernel" in k or "stepFastKernel" in k]
+    step = [k for (k, c) in means if "stepKernel" in k or "stepFastKernel" in k or "stepCoopKernel" in k]
     red = [k for (k, c) in means if "reducePlane" in k]
     if step and red:
         sk, rk = step[0], red[0]

@@ -11,7 +11,7 @@ import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.defaultdict(list)
 for r in rows:
-    if "stepFast" in r["Kernel_Name"]:
+    if "stepFast" in r["Kernel_Name"] or "stepCoop" in r["Kernel_Name"]:
         agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in sorted(agg.items()):
     print(k, "mean=%.6g" % (sum(v) / len(v)))
