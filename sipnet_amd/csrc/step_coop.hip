@@ -18,6 +18,11 @@
 // W and C that do not need it.  The arithmetic, its order and therefore the results are those
 // of stepFastKernel (bit-identical; tests/test_gpu_parity.py).
 //
+// lai(t+1) only depends on photosynthesis(t) through plant death (the leaf pool update has no
+// photosynthesis term, sipnet.c:1579-1626), so C posts it BEFORE it waits for photosynthesis(t)
+// and confirms it after the mortality test; W zeroes potGrossPsn(t+1) of a member that died in
+// step t (its leaf pool was zeroed: lai = 0, hence potGrossPsn = 0, sipnet.c:590-641).  This takes
+// the L -> W -> C chain off C's critical path.
 // Mailbox slots are indexed by step & 1; the wait-for graph keeps every producer at most one
 // step ahead of its consumer:  L(t) waits lai(t) [C past the pools of t-1];  W(t) ends only
 // when C is past the pools of t-1 and, by day, waits potGrossPsn(t);  C(t) waits the factors
@@ -79,6 +84,29 @@ __device__ __forceinline__ void ringLoad2(double& v0, double& v1, const double* 
 __device__ __forceinline__ void vmemDrain(double& v0, double& v1) {
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(v0), "+v"(v1) :: "memory");
 }
+// two independent mailboxes (each flag, then its value) in ONE round trip
+__device__ __forceinline__ void takePair(const double* slotA, const int* flagA, const double* slotB,
+                                         const int* flagB, int step, double& a, double& b) {
+  int fa, fb;
+  do {
+    asm volatile("ds_read_b32 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b32 %2, %6\n\tds_read_b64 %3, %7\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(fa), "=&v"(a), "=&v"(fb), "=&v"(b)
+                 : "v"((unsigned)(size_t)flagA), "v"((unsigned)(size_t)slotA), "v"((unsigned)(size_t)flagB),
+                   "v"((unsigned)(size_t)slotB) : "memory");
+  } while (uni(fa) < step || uni(fb) < step);
+}
+__device__ __forceinline__ void takePair(const float* slotA, const int* flagA, const float* slotB,
+                                         const int* flagB, int step, float& a, float& b) {
+  int fa, fb;
+  do {
+    asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %5\n\tds_read_b32 %2, %6\n\tds_read_b32 %3, %7\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(fa), "=&v"(a), "=&v"(fb), "=&v"(b)
+                 : "v"((unsigned)(size_t)flagA), "v"((unsigned)(size_t)slotA), "v"((unsigned)(size_t)flagB),
+                   "v"((unsigned)(size_t)slotB) : "memory");
+  } while (uni(fa) < step || uni(fb) < step);
+}
 // five values + flag (wave W -> wave C)
 template <class R>
 __device__ __forceinline__ void post5(R* base, int* flag, R v0, R v1, R v2, R v3, R v4, int step) {
@@ -120,7 +148,8 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
   __shared__ alignas(16) unsigned char ldsTiles[3][2 * kTileBytes];
   __shared__ R mailLai[2][64], mailPgp[2][64], mailPsn[2][64];
   __shared__ R mailFac[2][5][64];  // g1 g2 fSoil gFine gCoarse of a step (see wave W)
-  __shared__ int seqLai, seqPgp, seqPsn, seqFac;
+  __shared__ R mailAlive[2][64];   // 0: the member died in the step before (its posted lai is void)
+  __shared__ int seqLai, seqPgp, seqPsn, seqFac, seqAlive;
   // The running-mean ring of the 64 members lives in LDS for the whole launch (250 x 64 x 8 B =
   // 125 KB; one workgroup per CU).  A wave that stores to HBM every step must not also load
   // from HBM every step: vector-memory operations complete in issue order, so each step's ring
@@ -163,6 +192,7 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
     seqPgp = tBegin - 1;
     seqPsn = tBegin - 1;
     seqFac = tBegin - 1;
+    seqAlive = tBegin - 1;
   }
   __syncthreads();  // the only workgroup barrier: flags initialised before anyone spins
 
@@ -343,7 +373,9 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
         // moisture(), sipnet.c:656-699, with the potential photosynthesis of wave L
         R transpiration = 0, photosynthesis = 0;
         if (bits & FAST_PAR_POS) {
-          const R potGrossPsn = take(&mailPgp[t & 1][lane], &seqPgp, t);
+          R pgpSpec, aliveF;
+          takePair(&mailPgp[t & 1][lane], &seqPgp, &mailAlive[t & 1][lane], &seqAlive, t, pgpSpec, aliveF);
+          const R potGrossPsn = aliveF != R(0) ? pgpSpec : R(0);
           const R potTrans = potGrossPsn * (R)q2.y * K_tr;
           const bool hasPsn = potGrossPsn >= R(kTiny);
           const bool limited = removable < potTrans;
@@ -426,6 +458,7 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
   const uint32_t ncu = (uint32_t)nc;
 
   post(&mailLai[tBegin & 1][lane], &seqLai, (R)plantLeafC * K_invLcsw, tBegin);
+  post(&mailAlive[tBegin & 1][lane], &seqAlive, R(1), tBegin);  // lai(tBegin) is not speculative
   // carried: this member's alive flag (sipnet.c:1530-1544) and, for the whole wave, "every
   // member alive with an untouched ring epoch" (what the regular ring update needs)
   bool aliveC = (plantWoodC > kTiny) && (plantWoodC + delta > kTiny) && (fineRootC + coarseRootC > kTiny);
@@ -592,6 +625,21 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
     }
 
     CSTAMP(2)
+    // the leaf pool of the next step does not involve this step's photosynthesis: update it
+    // now and let wave L start on step t+1 (speculative only with respect to plant death)
+    plantLeafC += (double)((leafCreation + leafOnCreation - leafLitter) * len);
+    post(&mailLai[(t + 1) & 1][lane], &seqLai, (R)rmax0(plantLeafC) * K_invLcsw, t + 1);
+
+    // plant pools that do not involve this step's photosynthesis (sipnet.c:1579-1626)
+    plantWoodC += (double)((woodCreation - woodLitter - leafOnFromWood) * len);
+    coarseRootC += (double)((coarseRootCreation - coarseRootLoss -
+                             (leafOnCreation - leafOnFromWood)) * len);
+    fineRootC += (double)((fineRootCreation - fineRootLoss) * len);
+    const double soilGain = (double)((coarseRootLoss + fineRootLoss + woodLitter + leafLitter - rSoil) * len);
+    const R r_a = rVeg + rFineRoot + rCoarseRoot;
+    const R alloc = leafCreation + woodCreation + fineRootCreation + coarseRootCreation;
+    const bool rootsOk = (plantWoodC > kTiny) && (fineRootC + coarseRootC > kTiny);
+
     // photosynthesis of this step (wave W after wave L); nights need no hand-over
     R photosynthesis = 0;
     if (bits & FAST_PAR_POS) {
@@ -601,24 +649,13 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
     CSTAMP(3)
     // ---- pools (sipnet.c:1769-1806): plant pools first, so that the next step's leaf area
     // can leave for wave L as early as possible
-    {
-      const R r_a = rVeg + rFineRoot + rCoarseRoot;
-      const R alloc = leafCreation + woodCreation + fineRootCreation + coarseRootCreation;
-      delta += (double)(((photosynthesis - r_a) - alloc) * len);
-      plantWoodC += (double)((woodCreation - woodLitter - leafOnFromWood) * len);
-      plantLeafC += (double)((leafCreation + leafOnCreation - leafLitter) * len);
-      coarseRootC += (double)((coarseRootCreation - coarseRootLoss -
-                               (leafOnCreation - leafOnFromWood)) * len);
-      fineRootC += (double)((fineRootCreation - fineRootLoss) * len);
-    }
-    const double soilGain = (double)((coarseRootLoss + fineRootLoss + woodLitter + leafLitter - rSoil) * len);
+    delta += (double)(((photosynthesis - r_a) - alloc) * len);
     // checkForMortality(), sipnet.c:1688-1767
     bool alive = alive0;
     double deathToSoil0 = 0.0, deathToSoil1 = 0.0;
     bool diedNow = false;
     {
-      const bool sufficient = (plantWoodC > kTiny) && (plantWoodC + delta > kTiny) &&
-                              (fineRootC + coarseRootC > kTiny);
+      const bool sufficient = rootsOk && (plantWoodC + delta > kTiny);
       if (__builtin_expect(sufficient != alive0, 0)) {
         ringClean = false;  // a ring epoch stays behind: this wave takes the general ring path from now on
         if (!alive0) {
@@ -643,8 +680,9 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
     plantLeafC = rmax0(plantLeafC);
     coarseRootC = rmax0(coarseRootC);
     fineRootC = rmax0(fineRootC);
-    // lai(t+1) -> wave L; also tells wave W that step t is done here
-    post(&mailLai[(t + 1) & 1][lane], &seqLai, (R)plantLeafC * K_invLcsw, t + 1);
+    // confirms the lai(t+1) posted above, or revokes it when the stand died in this step (its
+    // leaf pool was just zeroed); a stand that was never alive keeps its leaves and its lai
+    post(&mailAlive[(t + 1) & 1][lane], &seqAlive, diedNow ? R(0) : R(1), t + 1);
 
     CSTAMP(4)
     soilC += soilGain;

@@ -241,3 +241,42 @@ def test_full_size_properties_10k_members(base):
     assert torch.equal(planes[:, :, 10239], planes[:, :, 64])
     assert bool(torch.isfinite(planes).all())
     b.close(); b1.close()
+
+
+def test_cooperative_and_one_wave_kernels_agree(base, tmp_path, monkeypatch):
+    """the engine picks the three-wavefront kernel (step_coop.hip) for batches of at most one
+    64-member chunk per CU and the one-wave kernel (step_fast.hip) above; both must give the same
+    trajectories -- including the rare paths: clear-cut + death, re-planting, irrigation, a member
+    dead from the start, ragged last chunk, a launch split at arbitrary steps"""
+    clim = synth.convert_raw(synth.round_like_file(synth.half_hourly_year_raw(48 * 60)))
+    ev = []
+    def add(day, typ, *p):
+        e = sa.Event(); e.type = typ; e.year = int(clim.year[0]); e.day = day
+        for i, v in enumerate(p): e.p[i] = v
+        ev.append(e)
+    add(4, 2, 1.5, 0)
+    add(9, 1, 0.3, 0.2, 0.1, 0.1)
+    add(20, 1, 1.0, 1.0, 0.0, 0.0)         # clear-cut: every member dies
+    add(30, 3, 40.0, 300.0, 50.0, 60.0)    # re-planting
+    add(41, 2, 2.0, 1)
+    members = synth.perturbed_params(base, 150)     # 3 chunks, the last one ragged
+    from sipnet_amd.config import param_index as pi
+    members[5, pi("plantWoodInit")] = 0.0           # never alive, keeps its leaves
+    out = {}
+    for prec in (sa.F64, sa.F32_MIXED):
+        for coop in ("1", "0"):
+            monkeypatch.setenv("SIPNET_COOP", coop)
+            b = make_batch(sa.flags_from(), [clim], members, prec=prec, events=ev)
+            T = clim.n_steps
+            planes, _ = b.alloc_outputs(T)
+            for a, z in ((0, 7), (7, 1000), (1000, 1015), (1015, T)):   # odd cuts, a one-step tile tail
+                b.run(a, z - a, planes=planes[:, a:z])
+            out[coop] = (planes.cpu().numpy().astype(np.float64), b.get_state(), b.get_rings())
+            b.close()
+        tol = 1e-12 if prec == sa.F64 else 2e-4
+        d = np.abs(out["1"][0] - out["0"][0]).max()
+        print("precision", prec, "coop vs one-wave: max|d|", d)
+        assert d < tol
+        np.testing.assert_allclose(out["1"][1][:, :27], out["0"][1][:, :27], rtol=1e-9 if prec == sa.F64 else 1e-3, atol=1e-9)
+        assert (out["1"][1][:, 28:31] == out["0"][1][:, 28:31]).all()      # ring epoch, status, died-at
+        np.testing.assert_allclose(out["1"][2], out["0"][2], rtol=1e-9 if prec == sa.F64 else 1e-3, atol=1e-9)
