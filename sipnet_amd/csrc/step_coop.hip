@@ -459,6 +459,16 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
 
   post(&mailLai[tBegin & 1][lane], &seqLai, (R)plantLeafC * K_invLcsw, tBegin);
   post(&mailAlive[tBegin & 1][lane], &seqAlive, R(1), tBegin);  // lai(tBegin) is not speculative
+  // The two phenology switches fire once a year per member; whether ANY member of the wave can
+  // fire in a step is decided with two wave-uniform compares against the smallest thresholds
+  // of the wave, and not at all once every member has fired
+  double minGddOn = gddLeafOn, minOffDay = leafOffDay;
+  for (int off = 32; off > 0; off >>= 1) {
+    minGddOn = fmin(minGddOn, __shfl_xor(minGddOn, off, 64));
+    minOffDay = fmin(minOffDay, __shfl_xor(minOffDay, off, 64));
+  }
+  bool allOn = __builtin_amdgcn_ballot_w64((phenBits & 1) == 0) == 0;
+  bool allOff = __builtin_amdgcn_ballot_w64((phenBits & 2) == 0) == 0;
   // carried: this member's alive flag (sipnet.c:1530-1544) and, for the whole wave, "every
   // member alive with an untouched ring epoch" (what the regular ring update needs)
   bool aliveC = (plantWoodC > kTiny) && (plantWoodC + delta > kTiny) && (fineRootC + coarseRootC > kTiny);
@@ -547,9 +557,7 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
     R leafCreation = meanNpp * K_la, woodCreation = meanNpp * K_wa;
 
     R leafOnCreation = 0, leafOnFromWood = 0;
-    if (bits & FAST_PHEN_NEW_YEAR) phenBits = 0;
-    const bool doOn = !(phenBits & 1) && q6.y >= gddLeafOn;
-    const bool doOff = !(phenBits & 2) && q7.x >= leafOffDay;
+    const bool phenMay = (!allOn && q6.y >= minGddOn) || (!allOff && q7.x >= minOffDay);
 
     const R coarseRootLoss = K_crt * eCoarse, fineRootLoss = K_frt * eFine;
     R coarseRootCreation = K_ca * meanNpp, fineRootCreation = K_fa * meanNpp;
@@ -571,7 +579,11 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
     CSTAMP(1)
 
     // events (carbon side; irrigation belongs to wave W) and the yearly phenology switches
-    if (__builtin_expect(nEv > 0 || __builtin_amdgcn_ballot_w64(doOn || doOff) != 0, 0)) {
+    if (__builtin_expect(nEv > 0 || (bits & FAST_PHEN_NEW_YEAR) ||
+                         __builtin_amdgcn_ballot_w64(phenMay) != 0, 0)) {
+      if (bits & FAST_PHEN_NEW_YEAR) phenBits = 0;
+      const bool doOn = !(phenBits & 1) && q6.y >= gddLeafOn;
+      const bool doOff = !(phenBits & 2) && q7.x >= leafOffDay;
       if (doOn) {
         const R leafOn = leafOnLimit(PRM_RARE(leafGrowth) * invLen);
         leafOnCreation = leafOn;
@@ -583,6 +595,8 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
         leafLitter += (eLeaf * PRM_RARE(fracLeafFall)) * invLen;
         phenBits |= 2;
       }
+      allOn = __builtin_amdgcn_ballot_w64((phenBits & 1) == 0) == 0;
+      allOff = __builtin_amdgcn_ballot_w64((phenBits & 2) == 0) == 0;
       R evLeafC = 0, evWoodC = 0, evFineRootC = 0, evCoarseRootC = 0;
       R evSoilC = 0, evLeafOnCreation = 0, evLeafOnFromWood = 0, evLeafOffLitter = 0;
       const int ev0 = uni(rareI[3]);
