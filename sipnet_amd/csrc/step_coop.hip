@@ -71,19 +71,11 @@ __device__ __forceinline__ float take(const float* slot, const int* flag, int st
 // (ROCm 7.2) drains ALL vector-memory traffic -- `s_waitcnt vmcnt(0)`, i.e. the previous step's
 // stores, ~800 cycles -- in front of every DS read that might alias a pending LDS-DMA and of
 // every use of an ordinary global load while an LDS-DMA is in flight (cdna_hip_programming.md,
-// glds note).  Here every wait of the hot path is placed by hand: loads at the top of a step,
-// ONE `vmcnt(0)` right before the step's stores (everything older has had a whole step to
-// land), stores and the next tile's DMA last.
+// glds note).  Here every wait of the hot path is placed by hand, and the hot loop of a wave that
+// stores issues no vector-memory load at all (the ring lives in LDS).
 typedef double d2_t __attribute__((ext_vector_type(2)));
 typedef int i4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ unsigned ldsAddr(const void* p) { return (unsigned)(size_t)p; }
-__device__ __forceinline__ void ringLoad2(double& v0, double& v1, const double* p0, const double* p1) {
-  asm volatile("global_load_dwordx2 %0, %2, off\n\tglobal_load_dwordx2 %1, %3, off"
-               : "=&v"(v0), "=&v"(v1) : "v"(p0), "v"(p1) : "memory");
-}
-__device__ __forceinline__ void vmemDrain(double& v0, double& v1) {
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(v0), "+v"(v1) :: "memory");
-}
 // two independent mailboxes (each flag, then its value) in ONE round trip
 __device__ __forceinline__ void takePair(const double* slotA, const int* flagA, const double* slotB,
                                          const int* flagB, int step, double& a, double& b) {
