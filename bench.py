@@ -322,7 +322,7 @@ def main():
                        **({"particle_filter": pf_info} if pf else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": ("stepCoopKernel" if S * ((M + 63) // 64) <= 256 and os.environ.get("SIPNET_COOP", "1") != "0" else "stepFastKernel") if args.fast_math else "stepKernel", "kernel_ms": k_ms,
+                         "kernel": ("stepCoopKernel" if S * ((M + 63) // 64) <= 512 and os.environ.get("SIPNET_COOP", "1") != "0" else "stepFastKernel") if args.fast_math else "stepKernel", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_unit": ALGO_BYTES[wl["prec"]],
                          "units_per_launch": per_launch_units},
             "cpu_baseline": cpu, "parity": parity,

@@ -353,13 +353,17 @@ int sipnet_batch_run(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_ne
     f.n_steps = n_steps;
     f.plainExp = b->genericExponents ? 0 : 1;
     f.scratchRow = b->d_scratchRow;
-    // At most one 64-member chunk per CU: the step is bound by what one wavefront can issue,
-    // so three wavefronts share each chunk and its ring stays in LDS (step_coop.hip, one
-    // workgroup per CU).  Bigger batches fill the chip with the one-wave kernel.
+    // Few 64-member chunks per CU: the step is bound by what one wavefront can issue, so three
+    // wavefronts share each chunk (step_coop.hip) -- with the chunk's ring in LDS when there is
+    // at most one chunk per CU (c10k 12.4 vs 18.2 ms), in HBM up to two per CU (c4 16.0 vs
+    // 19.3 ms).  Bigger batches fill the SIMDs with the one-wave kernel (c3: 16.9 vs 27.6 ms).
     const int64_t blocks = (int64_t)b->n_sites * ((b->n_members + 63) / 64);
     const char* coopEnv = getenv("SIPNET_COOP");
-    const bool coop = coopEnv ? atoi(coopEnv) != 0 : blocks <= b->numCUs;
-    if (coop) launchStepCoop(f, b->precision, stream);
+    // SIPNET_COOP: 0 one-wave kernel, 1 cooperative (ring in LDS when it fits), 2 cooperative with
+    // the ring in HBM (development switch)
+    const int coopMode = coopEnv ? atoi(coopEnv) : (blocks <= 2 * (int64_t)b->numCUs ? 1 : 0);
+    const bool coop = coopMode != 0;
+    if (coop) launchStepCoop(f, b->precision, coopMode == 1 && blocks <= b->numCUs, stream);
     else launchStepFast(f, b->precision, stream);
   } else {
     launchStep(a, b->precision, b->fastMath, stream);

@@ -134,7 +134,9 @@ __device__ unsigned long long g_coopStamps[16];
 #endif
 }  // namespace
 
-template <class R, bool PlainExp>
+// RingLds: the running-mean ring of the 64 members stays in LDS for the whole launch (one
+// workgroup per CU); otherwise it stays in HBM and up to four workgroups share a CU.
+template <class R, bool PlainExp, bool RingLds>
 __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
   // per-wave private record tiles (each wave stages and awaits its own DMA) + mailboxes
   __shared__ alignas(16) unsigned char ldsTiles[3][2 * kTileBytes];
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
   // 125 KB; one workgroup per CU).  A wave that stores to HBM every step must not also load
   // from HBM every step: vector-memory operations complete in issue order, so each step's ring
   // loads would queue behind the previous step's output stores (~1800 cycles to their ack).
-  __shared__ double ringL[SIPNET_RING_SLOTS * 64];
+  __shared__ double ringL[RingLds ? SIPNET_RING_SLOTS * 64 : 64];
 
   const int role = uni((int)threadIdx.x >> 6);  // 0 carbon, 1 water, 2 light
   const int lane = (int)threadIdx.x & 63;
@@ -465,8 +467,13 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
   // member alive with an untouched ring epoch" (what the regular ring update needs)
   bool aliveC = (plantWoodC > kTiny) && (plantWoodC + delta > kTiny) && (fineRootC + coarseRootC > kTiny);
   bool ringClean = __builtin_amdgcn_ballot_w64(!aliveC || ringValidFrom > 0) == 0;
-  for (int k = 0; k < SIPNET_RING_SLOTS; k++) ringL[k * 64 + lane] = ringp[(uint32_t)k * ncu];
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  if (RingLds) {
+    for (int k = 0; k < SIPNET_RING_SLOTS; k++) ringL[k * 64 + lane] = ringp[(uint32_t)k * ncu];
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  }
+  // HBM ring: the value written by the previous step is forwarded from a register
+  double lastNpp = 0.0;
+  int lastIns = -1;
 #ifdef SIPNET_STAMPS
   unsigned long long cAcc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cLast;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(cLast)::"memory");
@@ -475,7 +482,10 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
   for (int tileStart = curTile * kFastTile; tileStart < tEnd; tileStart += kFastTile, curTile++) {
     // the DMA of this tile was issued a tile ago; only the last step's two stores may still be
     // in flight behind it
-    if (tileStart > tBegin) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    if (tileStart > tBegin) {
+      if (RingLds) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");  // + the ring store
+    }
     stageTile(curTile + 1, (curTile + 1) & 1);
     const int tFirst = tileStart > tBegin ? tileStart : tBegin;
     const int tLast = (tileStart + kFastTile) < tEnd ? (tileStart + kFastTile) : tEnd;
@@ -522,6 +532,15 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
     const int insSlot = uni(j0.z);
     const int nEv = uni(j0.w);
     const int evSlot0 = slots & 255, evSlot1 = (slots >> 8) & 255;
+    // HBM ring: the values this step evicts are requested now (asm: see the note on waits) and
+    // awaited once, right before they are needed at the end of the step
+    double rv0 = 0.0, rv1 = 0.0;
+    if (!RingLds) {
+      asm volatile("global_load_dwordx2 %0, %2, off\n\tglobal_load_dwordx2 %1, %3, off"
+                   : "=&v"(rv0), "=&v"(rv1)
+                   : "v"(ringp + (uint32_t)evSlot0 * ncu), "v"(ringp + (uint32_t)evSlot1 * ncu) : "memory");
+    }
+    const bool useLast0 = evSlot0 == lastIns, useLast1 = evSlot1 == lastIns;
 
     const bool alive0 = aliveC;
     const R eWood = (R)plantWoodC, eLeaf = (R)plantLeafC, eSoilC = (R)soilC;
@@ -712,7 +731,8 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
     const double npp = (double)(photosynthesis - rVeg - rCoarseRoot - rFineRoot);
     CSTAMP(5)
     {
-      const double v0 = ringL[evSlot0 * 64 + lane];
+      if (!RingLds) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rv0), "+v"(rv1) :: "memory");
+      const double v0 = RingLds ? ringL[evSlot0 * 64 + lane] : (useLast0 ? lastNpp : rv0);
       const int nOps = bits >> 16;
       if (__builtin_expect(ringClean && (bits & FAST_RING_REGULAR), 1)) {
         ringSum = ffma(-q7.y, v0, ringSum);
@@ -721,7 +741,7 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
         if (insSlot < 0) {
           ringSum = npp * 5.0;
         } else {
-          double w0v = v0, w1v = ringL[evSlot1 * 64 + lane];
+          double w0v = v0, w1v = RingLds ? ringL[evSlot1 * 64 + lane] : (useLast1 ? lastNpp : rv1);
           if (ringValidFrom > 0) {
             if (uni(rareI[0]) < ringValidFrom) w0v = 0.0;
             if (uni(rareI[1]) < ringValidFrom) w1v = 0.0;
@@ -730,7 +750,10 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
           ringSum = ffma(-rare[0], w1v, ringSum);
           for (int k = 2; k < nOps; k++) {
             const RingOp& op = a.ringOps[uni(rareI[2]) + k];
-            const double v = (uni(op.insStep) >= ringValidFrom) ? ringL[uni(op.slot) * 64 + lane] : 0.0;
+            const int os = uni(op.slot);
+            const double rvk = RingLds ? ringL[os * 64 + lane]
+                                       : (os == lastIns ? lastNpp : ringp[(uint32_t)os * ncu]);
+            const double v = (uni(op.insStep) >= ringValidFrom) ? rvk : 0.0;
             ringSum = ffma(-op.w, v, ringSum);
           }
           ringSum = ffma(npp, (double)len, ringSum);
@@ -740,7 +763,13 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
       }
     }
     const int insEff = insSlot < 0 ? 0 : insSlot;
-    ringL[insEff * 64 + lane] = npp;
+    if (RingLds) {
+      ringL[insEff * 64 + lane] = npp;
+    } else {
+      ringp[(uint32_t)insEff * ncu] = npp;
+      lastIns = insEff;
+      lastNpp = npp;
+    }
     *oNee = tNee;
     *oGpp = tGpp;
     oNee += ldNee;
@@ -754,7 +783,8 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
     for (int k = 0; k < 8; k++) g_coopStamps[k] = cAcc[k];
 #endif
   if (act) {
-    for (int k = 0; k < SIPNET_RING_SLOTS; k++) ringp[(uint32_t)k * ncu] = ringL[k * 64 + lane];
+    if (RingLds)
+      for (int k = 0; k < SIPNET_RING_SLOTS; k++) ringp[(uint32_t)k * ncu] = ringL[k * 64 + lane];
     ST(plantWoodC) = plantWoodC;
     ST(plantLeafC) = plantLeafC;
     ST(soilC) = soilC;
@@ -779,16 +809,18 @@ extern "C" int sipnet_debug_read_coop_stamps(unsigned long long* out) {
 }
 #endif
 
-void launchStepCoop(const FastArgs& a, int precision, hipStream_t stream) {
+void launchStepCoop(const FastArgs& a, int precision, bool ringInLds, hipStream_t stream) {
   const int chunksPerSite = (a.n_members + 63) / 64;
-  const int grid = a.n_sites * chunksPerSite;
+  const dim3 grid(a.n_sites * chunksPerSite), block(192);
+#define COOP_LAUNCH(R, P, L) hipLaunchKernelGGL((stepCoopKernel<R, P, L>), grid, block, 0, stream, a)
   if (precision == SIPNET_F64) {
-    if (a.plainExp) hipLaunchKernelGGL((stepCoopKernel<double, true>), dim3(grid), dim3(192), 0, stream, a);
-    else hipLaunchKernelGGL((stepCoopKernel<double, false>), dim3(grid), dim3(192), 0, stream, a);
+    if (a.plainExp) { if (ringInLds) COOP_LAUNCH(double, true, true); else COOP_LAUNCH(double, true, false); }
+    else { if (ringInLds) COOP_LAUNCH(double, false, true); else COOP_LAUNCH(double, false, false); }
   } else {
-    if (a.plainExp) hipLaunchKernelGGL((stepCoopKernel<float, true>), dim3(grid), dim3(192), 0, stream, a);
-    else hipLaunchKernelGGL((stepCoopKernel<float, false>), dim3(grid), dim3(192), 0, stream, a);
+    if (a.plainExp) { if (ringInLds) COOP_LAUNCH(float, true, true); else COOP_LAUNCH(float, true, false); }
+    else { if (ringInLds) COOP_LAUNCH(float, false, true); else COOP_LAUNCH(float, false, false); }
   }
+#undef COOP_LAUNCH
 }
 
 }  // namespace sipnet

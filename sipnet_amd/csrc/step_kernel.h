@@ -95,7 +95,7 @@ struct FastArgs {
 };
 void launchStepFast(const FastArgs& a, int precision, hipStream_t stream);
 // three cooperating wavefronts per 64 members (step_coop.hip); same results as launchStepFast
-void launchStepCoop(const FastArgs& a, int precision, hipStream_t stream);
+void launchStepCoop(const FastArgs& a, int precision, bool ringInLds, hipStream_t stream);
 bool isDefaultFlagSet(const int32_t* flags);
 
 // launchers (step_kernel.hip)

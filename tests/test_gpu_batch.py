@@ -264,7 +264,7 @@ def test_cooperative_and_one_wave_kernels_agree(base, tmp_path, monkeypatch):
     members[5, pi("plantWoodInit")] = 0.0           # never alive, keeps its leaves
     out = {}
     for prec in (sa.F64, sa.F32_MIXED):
-        for coop in ("1", "0"):
+        for coop in ("1", "2", "0"):       # cooperative with the ring in LDS / in HBM, one-wave
             monkeypatch.setenv("SIPNET_COOP", coop)
             b = make_batch(sa.flags_from(), [clim], members, prec=prec, events=ev)
             T = clim.n_steps
@@ -274,9 +274,11 @@ def test_cooperative_and_one_wave_kernels_agree(base, tmp_path, monkeypatch):
             out[coop] = (planes.cpu().numpy().astype(np.float64), b.get_state(), b.get_rings())
             b.close()
         tol = 1e-12 if prec == sa.F64 else 2e-4
-        d = np.abs(out["1"][0] - out["0"][0]).max()
-        print("precision", prec, "coop vs one-wave: max|d|", d)
-        assert d < tol
-        np.testing.assert_allclose(out["1"][1][:, :27], out["0"][1][:, :27], rtol=1e-9 if prec == sa.F64 else 1e-3, atol=1e-9)
-        assert (out["1"][1][:, 28:31] == out["0"][1][:, 28:31]).all()      # ring epoch, status, died-at
-        np.testing.assert_allclose(out["1"][2], out["0"][2], rtol=1e-9 if prec == sa.F64 else 1e-3, atol=1e-9)
+        for mode in ("1", "2"):
+            d = np.abs(out[mode][0] - out["0"][0]).max()
+            print("precision", prec, "coop mode", mode, "vs one-wave: max|d|", d)
+            assert d < tol
+            np.testing.assert_allclose(out[mode][1][:, :27], out["0"][1][:, :27], rtol=1e-9 if prec == sa.F64 else 1e-3, atol=1e-9)
+            assert (out[mode][1][:, 28:31] == out["0"][1][:, 28:31]).all()      # ring epoch, status, died-at
+            np.testing.assert_allclose(out[mode][2], out["0"][2], rtol=1e-9 if prec == sa.F64 else 1e-3, atol=1e-9)
+        np.testing.assert_array_equal(out["1"][0], out["2"][0])   # ring placement does not change arithmetic
