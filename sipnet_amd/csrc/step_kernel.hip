@@ -1108,12 +1108,43 @@ __global__ __launch_bounds__(256) void reducePlaneKernel(const T* __restrict__ p
   if (wave >= nItems) return;
   const int t = wave / n_sites, site = wave % n_sites;
   const T* __restrict__ row = plane + (int64_t)t * ld + (int64_t)site * n_members;
-  double s1 = 0.0, s2 = 0.0;
-  for (int m = lane; m < n_members; m += 64) {
-    const double v = (double)row[m];
-    s1 += v;
-    s2 += v * v;
+  // 16-byte loads, four independent accumulator pairs: enough bytes in flight per wave to
+  // stream at HBM rate; a scalar tail / fallback covers odd lengths and unaligned rows
+  double a1 = 0.0, a2 = 0.0, b1 = 0.0, b2 = 0.0, c1 = 0.0, c2 = 0.0, d1 = 0.0, d2 = 0.0;
+  constexpr int kPer = 16 / (int)sizeof(T);  // elements per 16-byte load
+  int done = 0;
+  if ((reinterpret_cast<uintptr_t>(row) & 15) == 0) {
+    typedef T vec_t __attribute__((ext_vector_type(kPer)));
+    const vec_t* __restrict__ rv = reinterpret_cast<const vec_t*>(row);
+    const int nVec = n_members / kPer;
+    int i = lane;
+    for (; i + 192 < nVec; i += 256) {
+      const vec_t v0 = rv[i], v1 = rv[i + 64], v2 = rv[i + 128], v3 = rv[i + 192];
+#pragma unroll
+      for (int k = 0; k < kPer; k++) {
+        const double x0 = (double)v0[k], x1 = (double)v1[k], x2 = (double)v2[k], x3 = (double)v3[k];
+        a1 += x0; a2 += x0 * x0;
+        b1 += x1; b2 += x1 * x1;
+        c1 += x2; c2 += x2 * x2;
+        d1 += x3; d2 += x3 * x3;
+      }
+    }
+    for (; i < nVec; i += 64) {
+      const vec_t v0 = rv[i];
+#pragma unroll
+      for (int k = 0; k < kPer; k++) {
+        const double x0 = (double)v0[k];
+        a1 += x0; a2 += x0 * x0;
+      }
+    }
+    done = nVec * kPer;
   }
+  for (int m = done + lane; m < n_members; m += 64) {
+    const double v = (double)row[m];
+    a1 += v;
+    a2 += v * v;
+  }
+  double s1 = (a1 + b1) + (c1 + d1), s2 = (a2 + b2) + (c2 + d2);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     s1 += __shfl_xor(s1, off, 64);

@@ -211,6 +211,16 @@ def test_reduce_plane_ensemble_statistics(base, short_clim):
     b.close()
     assert np.allclose(stats[:, :, 0], p.sum(-1), rtol=1e-12, atol=1e-12)
     assert np.allclose(stats[:, :, 1], (p * p).sum(-1), rtol=1e-12, atol=1e-12)
+    # odd member counts: rows that are not 16-byte aligned and scalar tails; fp32 planes
+    for prec in (sa.F64, sa.F32_MIXED):
+        members = synth.perturbed_params(base, 67)
+        b = make_batch(sa.flags_from(), [short_clim, short_clim, short_clim], members, prec=prec)
+        planes, _ = b.run(0, 50)
+        stats = b.reduce_plane(planes[1]).cpu().numpy()
+        p = planes[1].double().cpu().numpy().reshape(50, 3, 67)
+        b.close()
+        assert np.allclose(stats[:, :, 0], p.sum(-1), rtol=1e-12, atol=1e-12)
+        assert np.allclose(stats[:, :, 1], (p * p).sum(-1), rtol=1e-12, atol=1e-12)
 
 
 def test_full_size_properties_10k_members(base):
