@@ -1562,3 +1562,86 @@ double sipo_ring_probe(int n, const double *values, const double *weights,
   }
   return ringMean(&r);
 }
+
+/* ---- probes on an arbitrary state: the pattern of the reference's own unit tests, which set
+ * the globals `envi` / `params` / `ctx` / `climate` directly and call one stage of the step
+ * (tests/sipnet/test_events_types/ *.c -> procEvents(); test_modeling/testMethane.c,
+ * testCarbonSaturation.c, testFluxCalculations.c -> calculateFluxes() pieces). ---------------- */
+static void probeMember(Member *M, const int *flags, const double *params, const double *envi) {
+  memset(M, 0, sizeof(*M));
+  M->flag = flags;
+  memcpy(M->p, params, sizeof(M->p));
+  memcpy(&M->e, envi, sizeof(M->e));
+  ringReset(&M->ring, 0.0);
+  M->ring.length = SIPO_RING_SLOTS;
+  M->ring.totWeight = MEAN_NPP_DAYS;
+  M->isAlive = hasSufficientBiomass(M) ? 1 : 0;
+}
+
+/* processEvents() + updatePoolsForEvents() (events.c:449-790): envi[13] in/out, d_till_mod in/out;
+ * rates_out (may be NULL) receives the Rates struct as doubles. */
+int sipo_probe_events(const int *flags, const double *params, double *envi, double length,
+                      int year, int day, int n_events, const sipo_event *events,
+                      double *d_till_mod, double *rates_out) {
+  Member M;
+  probeMember(&M, flags, params, envi);
+  M.d_till_mod = d_till_mod ? *d_till_mod : 0.0;
+  M.n_events = n_events;
+  M.events = events;
+  Clim c;
+  memset(&c, 0, sizeof(c));
+  c.year = year;
+  c.day = day;
+  c.length = length;
+  processEvents(&M, &c);
+  if (M.status) return M.status;
+  updatePoolsForEvents(&M, length);
+  memcpy(envi, &M.e, sizeof(M.e));
+  if (d_till_mod) *d_till_mod = M.d_till_mod;
+  if (rates_out) memcpy(rates_out, &M.f, sizeof(M.f));
+  return 0;
+}
+
+/* calculateFluxes() (sipnet.c:1256-1336) on the given pools and climate record clim[11] (layout
+ * of sipo_run_member); mean_npp seeds the running mean, gdd_so_far / last_year the trackers used
+ * by the phenology tests.  rates_out receives the Rates struct as doubles. */
+int sipo_probe_fluxes(const int *flags, const double *params, const double *envi,
+                      const double *clim, int year, int day, double mean_npp, double d_till_mod,
+                      double gdd_so_far, int did_leaf_growth, int did_leaf_fall,
+                      double *rates_out) {
+  Member M;
+  probeMember(&M, flags, params, envi);
+  ringReset(&M.ring, mean_npp);
+  M.d_till_mod = d_till_mod;
+  M.tr.gdd = gdd_so_far;
+  M.tr.lastYear = year;
+  M.phenLastYear = year;
+  M.didLeafGrowth = did_leaf_growth;
+  M.didLeafFall = did_leaf_fall;
+  Clim c = climAt(clim, &year, &day, 0);
+  calculateFluxes(&M, &c);
+  if (M.status) return M.status;
+  memcpy(rates_out, &M.f, sizeof(M.f));
+  return 0;
+}
+
+/* updatePoolsAndBalance() (sipnet.c:1769-1806: event, main, soil and N pool updates, mortality,
+ * non-negativity clamps) with the given per-step rates: envi[13] in/out. */
+int sipo_probe_pools(const int *flags, const double *params, double *envi, const double *rates,
+                     double length) {
+  Member M;
+  probeMember(&M, flags, params, envi);
+  memcpy(&M.f, rates, sizeof(M.f));
+  M.diag.died_at_step = -1;
+  Clim c;
+  memset(&c, 0, sizeof(c));
+  c.year = 2024;
+  c.day = 70;
+  c.length = length;
+  updatePoolsAndBalance(&M, &c, 0);
+  if (M.status) return M.status;
+  memcpy(envi, &M.e, sizeof(M.e));
+  return 0;
+}
+
+int sipo_num_rates(void) { return (int)(sizeof(Rates) / sizeof(double)); }

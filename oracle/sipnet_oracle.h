@@ -148,6 +148,18 @@ void sipo_moisture(const double *params, double tsoil, double potGrossPsn,
 double sipo_light_eff(const double *params, double lai, double par);
 /* runmean.c:61-116 on a fresh ring (initMean 0, totWeight 5, 250 slots):
  * push n (value, weight) pairs, return mean; err receives last status */
+/* stage probes on an arbitrary state (the reference's unit-test pattern); Rates order =
+ * sipnet/state.h:469-645 */
+int sipo_probe_events(const int *flags, const double *params, double *envi, double length,
+                      int year, int day, int n_events, const sipo_event *events,
+                      double *d_till_mod, double *rates_out);
+int sipo_probe_fluxes(const int *flags, const double *params, const double *envi,
+                      const double *clim, int year, int day, double mean_npp, double d_till_mod,
+                      double gdd_so_far, int did_leaf_growth, int did_leaf_fall,
+                      double *rates_out);
+int sipo_probe_pools(const int *flags, const double *params, double *envi, const double *rates,
+                     double length);
+int sipo_num_rates(void);
 double sipo_ring_probe(int n, const double *values, const double *weights,
                        int *err);
 

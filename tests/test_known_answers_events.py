@@ -1,0 +1,246 @@
+"""Known answers of the reference's per-event-type unit tests
+(tests/sipnet/test_events_types/testEvent{Irrigation,Planting,Harvest,Fertilization,Tillage}.c),
+replayed on the oracle with the same inputs: pools set directly, ONE pass of processEvents() +
+updatePoolsForEvents() on a 0.125-day record of 2024 day 70, pools compared with the
+reference tests' expected values (tolerance 1e-6 = tests/utils/tUtils.h:57-59).
+
+The event files of those tests are tiny; their content is restated here as data."""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+import pytest
+
+import sipnet_amd as sa
+from sipnet_amd.config import param_index as pi
+from tests import helpers
+
+TOL = 1e-6
+YEAR, DAY, LEN = 2024, 70, 0.125
+ENVI = ("plantWoodC", "plantLeafC", "soilC", "soilWater", "litterC", "snow", "coarseRootC",
+        "fineRootC", "minN", "soilOrgN", "litterN", "plantStorageN", "plantCAccountingDelta")
+TYPE = {"fert": 0, "harv": 1, "irrig": 2, "plant": 3, "till": 4, "leafon": 5, "leafoff": 6}
+
+
+def events_of(text):
+    out = []
+    for line in text.strip().splitlines():
+        tok = line.split("#")[0].split()
+        e = sa.Event()
+        e.year, e.day, e.type = int(tok[0]), int(tok[1]), TYPE[tok[2]]
+        for i, v in enumerate(tok[3:]):
+            e.p[i] = float(v)
+        out.append(e)
+    return out
+
+
+def probe(oracle, flags, params, envi, events, d_till=0.0, day=DAY):
+    """-> (pools dict after the events, d_till_mod, rates)"""
+    L = oracle.lib
+    L.sipo_probe_events.restype = C.c_int
+    L.sipo_num_rates.restype = C.c_int
+    p = np.zeros(80)
+    for k, v in params.items():
+        p[pi(k)] = v
+    e = np.array([envi.get(n, 0.0) for n in ENVI], dtype=np.float64)
+    n, arr = oracle._events(events)
+    till = C.c_double(d_till)
+    rates = np.zeros(L.sipo_num_rates())
+    fl = (C.c_int * 12)(*flags)
+    rc = L.sipo_probe_events(fl, p.ctypes.data_as(C.c_void_p), e.ctypes.data_as(C.c_void_p),
+                             C.c_double(LEN), YEAR, day, n, arr, C.byref(till),
+                             rates.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    return dict(zip(ENVI, e)), till.value, rates
+
+
+def close(a, b):
+    return abs(a - b) <= TOL
+
+
+def test_irrigation(oracle):
+    """testEventIrrigation.c: immedEvapFrac 0.5; soil irrigation adds all, canopy half"""
+    fl = sa.flags_from()
+    e, _, r = probe(oracle, fl, {"immedEvapFrac": 0.5}, {"soilWater": 0.0}, events_of("2024 70 irrig 5 1"))
+    assert close(e["soilWater"], 5.0)
+    e, _, r = probe(oracle, fl, {"immedEvapFrac": 0.5}, {"soilWater": 5.0},
+                    events_of("2024 70 irrig 3 1\n2024 70 irrig 4 0"))
+    assert close(e["soilWater"], 10.0)
+    # fluxes.eventEvap * length == 2 (half of the canopy irrigation); Rates index 39 = eventEvap
+    assert close(r[39] * LEN, 2.0)
+
+
+def test_planting(oracle):
+    """testEventPlanting.c: additions to the four plant pools, two events are additive"""
+    fl = sa.flags_from()
+    start = {"plantLeafC": 1, "plantWoodC": 2, "fineRootC": 3, "coarseRootC": 4}
+    e, _, _ = probe(oracle, fl, {}, start, events_of("2024 70 plant 10 5 4 3"))
+    assert [e["plantLeafC"], e["plantWoodC"], e["fineRootC"], e["coarseRootC"]] == pytest.approx([11, 7, 7, 7], abs=TOL)
+    e, _, _ = probe(oracle, fl, {}, start, events_of("2024 70 plant 10 5 4 3\n2024 70 plant 9 6 8 4"))
+    assert [e["plantLeafC"], e["plantWoodC"], e["fineRootC"], e["coarseRootC"]] == pytest.approx([20, 13, 15, 11], abs=TOL)
+
+
+def test_harvest(oracle):
+    """testEventHarvest.c: removed / transferred fractions above and below ground; with the
+    litter pool and the N cycle the transfers split between litter and soil and carry N"""
+    start = {"soilC": 10, "litterC": 0, "plantLeafC": 2, "plantWoodC": 3, "fineRootC": 4, "coarseRootC": 5,
+             "soilWater": 10.0, "minN": 10.0}
+    e, _, _ = probe(oracle, sa.flags_from(), {}, start, events_of("2024 70 harv 0.1 0.2 0.3 0.4"))
+    assert close(e["soilC"], 10 + 0.3 * (2 + 3) + 0.4 * (4 + 5)) and close(e["litterC"], 0.0)
+    assert close(e["plantLeafC"], 2 * (1 - 0.1 - 0.3)) and close(e["plantWoodC"], 3 * (1 - 0.1 - 0.3))
+    assert close(e["fineRootC"], 4 * (1 - 0.2 - 0.4)) and close(e["coarseRootC"], 5 * (1 - 0.2 - 0.4))
+    fl = sa.flags_from(litterPool=1, nitrogenCycle=1, anaerobic=1)
+    cn = {"woodCN": 10, "leafCN": 20, "fineRootCN": 30}
+    start2 = dict(start, litterC=15, soilOrgN=2.0, litterN=3.0)
+    e, _, _ = probe(oracle, fl, cn, start2, events_of("2024 70 harv 0.1 0.2 0.3 0.4\n2024 70 harv 0.2 0.1 0.2 0.1"))
+    assert close(e["soilC"], 10 + (0.4 + 0.1) * (4 + 5)) and close(e["litterC"], 15 + (0.3 + 0.2) * (2 + 3))
+    assert close(e["plantLeafC"], 2 * (1 - 0.1 - 0.3 - 0.2 - 0.2)) and close(e["plantWoodC"], 3 * (1 - 0.1 - 0.3 - 0.2 - 0.2))
+    assert close(e["fineRootC"], 4 * (1 - 0.2 - 0.4 - 0.1 - 0.1)) and close(e["coarseRootC"], 5 * (1 - 0.2 - 0.4 - 0.1 - 0.1))
+    assert close(e["soilOrgN"], 2 + (4 * 0.5) / 30 + (5 * 0.5) / 10)
+    assert close(e["litterN"], 3 + (3 * 0.5) / 10 + (2 * 0.5) / 20)
+
+
+def test_fertilization(oracle):
+    """testEventFertilization.c: org C to soil (litter pool off) or litter; N only with the N cycle"""
+    e, _, _ = probe(oracle, sa.flags_from(), {}, {"soilC": 1.5, "litterC": 1, "minN": 0, "litterN": 0},
+                    events_of("2024 70 fert 15 5 10"))
+    assert close(e["soilC"], 1.5 + 5) and close(e["litterN"], 0.0) and close(e["minN"], 0.0)
+    fl = sa.flags_from(litterPool=1, nitrogenCycle=1, anaerobic=1)
+    e, _, _ = probe(oracle, fl, {}, {"soilC": 1.5, "litterC": 1, "minN": 2, "litterN": 3},
+                    events_of("2024 70 fert 15 5 10\n2024 70 fert 5 2 3"))
+    assert close(e["litterC"], 1 + 5 + 2) and close(e["litterN"], 3 + 15 + 5) and close(e["minN"], 2 + 10 + 3)
+
+
+def test_tillage_modifier_and_decay(oracle):
+    """testEventTillage.c: d_till_mod adds up and decays with exp(-length / 30) per record"""
+    fl = sa.flags_from()
+    _, till, _ = probe(oracle, fl, {}, {}, events_of("2024 70 till 0.5"))
+    assert close(till, 0.5)
+    # full steps: the 3-hourly forcing of days 70-76 with a second tillage on day 75
+    clim = sa.ClimTable(np.tile([[LEN, 10, 10, 0, 0, 1, 1, 1, 1, 0, 0]], (56, 1)) + 0.0,
+                        np.full(56, YEAR), 70 + np.arange(56) // 8)
+    clim.data[:, 10] = (np.arange(56) % 8) * 3.0
+    base, _ = sa.read_params(os.path.join(helpers.REPO, "sipnet_amd", "data", "base_forest.param"), fl)
+    st, rec, _ = oracle.run_member(fl, base, clim, events_of("2024 70 till 0.5\n2024 75 till 0.2"))
+    assert st == 0
+    expect, mod = [], 0.5
+    for t in range(56):
+        if t == 40:
+            mod += 0.2
+        mod *= math.exp(-LEN / 30.0)
+        expect.append(mod)
+    assert np.abs(rec[:, 34] - np.array(expect)).max() < TOL       # column 34 = d_till_mod after the step
+
+
+# ---- testCarbonSaturation.c / testMethane.c: soil pool update with prescribed rates ------------
+RATE = {n: i for i, n in enumerate(
+    "photosynthesis leafLitter woodLitter rVeg rSoil rain transpiration drainage litterToSoil rLitter "
+    "snowFall snowMelt sublimation immedEvap fastFlow evaporation fineRootLoss coarseRootLoss "
+    "fineRootCreation coarseRootCreation rCoarseRoot rFineRoot leafCreation woodCreation leafOnCreation "
+    "leafOnCreationFromWood nVolatilization nLeaching nOrgSoil nOrgLitter nMin nFixation nUptake "
+    "leafOffNResorption reductionNResorption eventLeafC eventWoodC eventFineRootC eventCoarseRootC "
+    "eventEvap eventSoilWater eventSoilC eventLitterC eventMinN eventSoilOrgN eventLitterN eventInputC "
+    "eventOutputC eventInputN eventOutputN eventLeafOnCreation eventLeafOnCreationFromWood "
+    "eventLeafOffLitter eventLeafOffNResorption soilMethane litterMethane".split())}
+
+
+def pools_probe(oracle, flags, params, envi, rates):
+    L = oracle.lib
+    L.sipo_probe_pools.restype = C.c_int
+    L.sipo_num_rates.restype = C.c_int
+    assert L.sipo_num_rates() == len(RATE)
+    p = np.zeros(80)
+    for k, v in params.items():
+        p[pi(k)] = v
+    e = np.array([envi.get(n, 0.0) for n in ENVI], dtype=np.float64)
+    r = np.zeros(len(RATE))
+    for k, v in rates.items():
+        r[RATE[k]] = v
+    fl = (C.c_int * 12)(*flags)
+    assert L.sipo_probe_pools(fl, p.ctypes.data_as(C.c_void_p), e.ctypes.data_as(C.c_void_p),
+                              r.ctypes.data_as(C.c_void_p), C.c_double(LEN)) == 0
+    return dict(zip(ENVI, e))
+
+
+@pytest.mark.parametrize("soil0,root_loss,r_soil", [(2.5, 100, 0), (2.5, 200, 0), (7.5, 100, 0),
+                                                    (7.5, 200, 0), (12.5, 200, 50)])
+def test_carbon_saturation(oracle, soil0, root_loss, r_soil):
+    """testCarbonSaturation.c: the saturated fraction of the soil inputs stays in the litter"""
+    fl = sa.flags_from(litterPool=1, carbonSaturation=1)
+    e = pools_probe(oracle, fl, {"soilCSaturation": 10.0}, {"soilC": soil0, "litterC": 10.0},
+                    {"coarseRootLoss": root_loss, "rSoil": r_soil})
+    sat = min(max(soil0 / 10.0, 0.0), 1.0)
+    assert close(e["litterC"], 10 + root_loss * sat * LEN)
+    assert close(e["soilC"], soil0 + (root_loss * (1 - sat) - r_soil) * LEN)
+
+
+def test_methane_fluxes_leave_their_pools(oracle):
+    """testMethane.c: flux = rate * pool * tempEffect * methaneMoistEffect, removed from soil / litter"""
+    L = oracle.lib
+    prm = dict(soilWHC=10.0, soilRespQ10=3.0, fAnoxia=0.6, anaerobicDecompRate=0.5, anaerobicTransExp=2.0,
+               soilMethaneRate=0.05, litterMethaneRate=0.1)
+    p = np.zeros(80)
+    for k, v in prm.items():
+        p[pi(k)] = v
+    L.sipo_temp_effect.restype = C.c_double
+    L.sipo_methane_moist_effect.restype = C.c_double
+    te = L.sipo_temp_effect(p.ctypes.data_as(C.c_void_p), C.c_double(20.0))
+    me = L.sipo_methane_moist_effect(p.ctypes.data_as(C.c_void_p), C.c_double(7.5), C.c_double(10.0))
+    assert close(te, 9.0) and 0.0 < me <= 1.0
+    f_soil, f_litter = 0.05 * 15.0 * te * me, 0.1 * 7.5 * te * me
+    fl = sa.flags_from(litterPool=1, anaerobic=1)
+    e = pools_probe(oracle, fl, prm, {"soilWater": 7.5, "soilC": 15.0, "soilOrgN": 2.0, "litterC": 7.5, "litterN": 1.5},
+                    {"soilMethane": f_soil, "litterMethane": f_litter})
+    assert close(e["soilC"], 15 - f_soil * LEN) and close(e["litterC"], 7.5 - f_litter * LEN)
+    # no litter pool: everything comes out of the soil pool
+    f_soil = 0.05 * 20.0 * te * me
+    e = pools_probe(oracle, sa.flags_from(), prm, {"soilWater": 7.5, "soilC": 20.0}, {"soilMethane": f_soil})
+    assert close(e["soilC"], 20 - f_soil * LEN) and close(e["litterC"], 0.0)
+
+
+def fluxes_probe(oracle, flags, params, envi, clim, mean_npp=0.0, d_till=0.0):
+    L = oracle.lib
+    L.sipo_probe_fluxes.restype = C.c_int
+    p = np.zeros(80)
+    for k, v in params.items():
+        p[pi(k)] = v
+    e = np.array([envi.get(n, 0.0) for n in ENVI], dtype=np.float64)
+    c = np.array([clim.get(k, 0.0) for k in ("length", "tair", "tsoil", "par", "precip", "vpd", "vpdSoil",
+                                             "vPress", "wspd", "gdd", "time")], dtype=np.float64)
+    r = np.zeros(len(RATE))
+    fl = (C.c_int * 12)(*flags)
+    rc = L.sipo_probe_fluxes(fl, p.ctypes.data_as(C.c_void_p), e.ctypes.data_as(C.c_void_p),
+                             c.ctypes.data_as(C.c_void_p), YEAR, DAY, C.c_double(mean_npp),
+                             C.c_double(d_till), C.c_double(0.0), 1, 0, r.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    return {n: r[i] for n, i in RATE.items()}
+
+
+def test_methane_flux_formula_inside_calculate_fluxes(oracle):
+    """testMethane.c expectations through the whole calculateFluxes(): 0.75 * tempEffect * moistEffect
+    for both pools with the litter pool, 1.0 * ... from the soil without it"""
+    base, _ = sa.read_params(os.path.join(helpers.REPO, "sipnet_amd", "data", "base_forest.param"),
+                             sa.flags_from())
+    # converted-parameter vector: take the file's values and override what the test pins; the
+    # per-year rates of the file only scale fluxes this test does not look at
+    names = [sa.lib().sipnet_param_name(i).decode() for i in range(80)]
+    prm = {names[i]: base[i] for i in range(80) if names[i]}
+    prm.update(soilWHC=10.0, soilRespQ10=3.0, fAnoxia=0.6, anaerobicDecompRate=0.5, anaerobicTransExp=2.0,
+               soilMethaneRate=0.05, litterMethaneRate=0.1, litterBreakdownRate=0.1, fracLitterRespired=0.5)
+    L = oracle.lib
+    L.sipo_temp_effect.restype = C.c_double
+    L.sipo_methane_moist_effect.restype = C.c_double
+    p = np.zeros(80)
+    for k, v in prm.items():
+        p[pi(k)] = v
+    te = L.sipo_temp_effect(p.ctypes.data_as(C.c_void_p), C.c_double(20.0))
+    me = L.sipo_methane_moist_effect(p.ctypes.data_as(C.c_void_p), C.c_double(7.5), C.c_double(10.0))
+    clim = dict(length=LEN, tair=15.0, tsoil=20.0, par=0.0, vpd=0.5, vpdSoil=0.5, vPress=1.0, wspd=1.0)
+    envi = {"plantWoodC": 1000, "plantLeafC": 100, "coarseRootC": 100, "fineRootC": 100, "soilWater": 7.5,
+            "soilC": 15.0, "soilOrgN": 2.0, "litterC": 7.5, "litterN": 1.5}
+    f = fluxes_probe(oracle, sa.flags_from(litterPool=1, anaerobic=1), prm, envi, clim)
+    assert close(f["soilMethane"], 0.75 * te * me) and close(f["litterMethane"], 0.75 * te * me)
+    envi.update(soilC=20.0, litterC=0.0)
+    f = fluxes_probe(oracle, sa.flags_from(anaerobic=1), prm, envi, clim)
+    assert close(f["soilMethane"], 1.0 * te * me) and close(f["litterMethane"], 0.0)
