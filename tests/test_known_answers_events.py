@@ -23,6 +23,15 @@ ENVI = ("plantWoodC", "plantLeafC", "soilC", "soilWater", "litterC", "snow", "co
 TYPE = {"fert": 0, "harv": 1, "irrig": 2, "plant": 3, "till": 4, "leafon": 5, "leafoff": 6}
 
 
+DERIVED = {"psnTMax": 9, "coarseRootAllocation": 47}   # struct slots without a file name (sipnet_params.def)
+
+
+def pidx(name):
+    i = DERIVED.get(name, pi(name))
+    assert i >= 0, name
+    return i
+
+
 def events_of(text):
     out = []
     for line in text.strip().splitlines():
@@ -42,7 +51,7 @@ def probe(oracle, flags, params, envi, events, d_till=0.0, day=DAY):
     L.sipo_num_rates.restype = C.c_int
     p = np.zeros(80)
     for k, v in params.items():
-        p[pi(k)] = v
+        p[pidx(k)] = v
     e = np.array([envi.get(n, 0.0) for n in ENVI], dtype=np.float64)
     n, arr = oracle._events(events)
     till = C.c_double(d_till)
@@ -152,7 +161,7 @@ def pools_probe(oracle, flags, params, envi, rates):
     assert L.sipo_num_rates() == len(RATE)
     p = np.zeros(80)
     for k, v in params.items():
-        p[pi(k)] = v
+        p[pidx(k)] = v
     e = np.array([envi.get(n, 0.0) for n in ENVI], dtype=np.float64)
     r = np.zeros(len(RATE))
     for k, v in rates.items():
@@ -182,7 +191,7 @@ def test_methane_fluxes_leave_their_pools(oracle):
                soilMethaneRate=0.05, litterMethaneRate=0.1)
     p = np.zeros(80)
     for k, v in prm.items():
-        p[pi(k)] = v
+        p[pidx(k)] = v
     L.sipo_temp_effect.restype = C.c_double
     L.sipo_methane_moist_effect.restype = C.c_double
     te = L.sipo_temp_effect(p.ctypes.data_as(C.c_void_p), C.c_double(20.0))
@@ -204,7 +213,7 @@ def fluxes_probe(oracle, flags, params, envi, clim, mean_npp=0.0, d_till=0.0):
     L.sipo_probe_fluxes.restype = C.c_int
     p = np.zeros(80)
     for k, v in params.items():
-        p[pi(k)] = v
+        p[pidx(k)] = v
     e = np.array([envi.get(n, 0.0) for n in ENVI], dtype=np.float64)
     c = np.array([clim.get(k, 0.0) for k in ("length", "tair", "tsoil", "par", "precip", "vpd", "vpdSoil",
                                              "vPress", "wspd", "gdd", "time")], dtype=np.float64)
@@ -233,7 +242,7 @@ def test_methane_flux_formula_inside_calculate_fluxes(oracle):
     L.sipo_methane_moist_effect.restype = C.c_double
     p = np.zeros(80)
     for k, v in prm.items():
-        p[pi(k)] = v
+        p[pidx(k)] = v
     te = L.sipo_temp_effect(p.ctypes.data_as(C.c_void_p), C.c_double(20.0))
     me = L.sipo_methane_moist_effect(p.ctypes.data_as(C.c_void_p), C.c_double(7.5), C.c_double(10.0))
     clim = dict(length=LEN, tair=15.0, tsoil=20.0, par=0.0, vpd=0.5, vpdSoil=0.5, vPress=1.0, wspd=1.0)
@@ -244,3 +253,44 @@ def test_methane_flux_formula_inside_calculate_fluxes(oracle):
     envi.update(soilC=20.0, litterC=0.0)
     f = fluxes_probe(oracle, sa.flags_from(anaerobic=1), prm, envi, clim)
     assert close(f["soilMethane"], 1.0 * te * me) and close(f["litterMethane"], 0.0)
+
+
+# ---- testFluxCalculations.c: allocation of the mean NPP and the negative-creation reroutes -----
+NIGHT = dict(length=LEN, tair=10.0, tsoil=20.0, par=0.0, vpd=0.5, vpdSoil=0.5, vPress=1.0, wspd=1.0)
+BENIGN = dict(soilWHC=10.0, leafCSpWt=50.0, cFracLeaf=0.5, vegRespQ10=2.0, soilRespQ10=2.0, fineRootQ10=2.0,
+              coarseRootQ10=2.0, rdConst=100.0, rSoilConst1=8.0, rSoilConst2=4.0, wueConst=10.0,
+              halfSatPar=17.0, attenuation=0.5, psnTMin=0.0, psnTOpt=20.0, psnTMax=40.0, dVpdExp=2.0,
+              soilRespMoistEffect=1.0, waterRemoveFrac=0.1, leafCN=20.0, woodCN=100.0, fineRootCN=40.0)
+
+
+def test_wood_and_leaf_allocation_known_answers(oracle):
+    fl = sa.flags_from()
+    prm = dict(BENIGN, woodTurnoverRate=0.1, leafTurnoverRate=0.2, leafAllocation=0.3, woodAllocation=0.4)
+    env = {"plantWoodC": 5.0, "plantLeafC": 3.0, "soilWater": 5.0, "soilC": 100.0}
+    f = fluxes_probe(oracle, fl, prm, env, NIGHT, mean_npp=10.0)            # positive NPP
+    assert close(f["woodLitter"], 0.5) and close(f["leafLitter"], 0.6)
+    assert close(f["leafCreation"], 3.0) and close(f["woodCreation"], 4.0)
+    f = fluxes_probe(oracle, fl, prm, env, NIGHT, mean_npp=-2.0)            # negative NPP
+    assert close(f["leafCreation"], -0.6) and close(f["woodCreation"], -0.8)
+    prm0 = dict(prm, woodTurnoverRate=0.0, leafTurnoverRate=0.0)           # empty leaf pool
+    f = fluxes_probe(oracle, fl, prm0, {"plantWoodC": 10.0, "plantLeafC": 0.0, "soilWater": 5.0}, NIGHT, mean_npp=-5.0)
+    assert close(f["leafCreation"], 0.0) and close(f["woodCreation"], -3.5)
+    prm1 = dict(prm, leafTurnoverRate=0.0)                                  # accounting delta counts as wood
+    f = fluxes_probe(oracle, fl, prm1, {"plantWoodC": 5.0, "plantCAccountingDelta": 3.0, "soilWater": 5.0},
+                     NIGHT, mean_npp=0.0)
+    assert close(f["woodLitter"], 0.8)
+
+
+def test_root_allocation_known_answers(oracle):
+    fl = sa.flags_from()
+    prm = dict(BENIGN, coarseRootAllocation=0.1, fineRootAllocation=0.2, coarseRootTurnoverRate=0.01,
+               fineRootTurnoverRate=0.02)
+    f = fluxes_probe(oracle, fl, prm, {"coarseRootC": 5.0, "fineRootC": 3.0, "soilWater": 5.0}, NIGHT, mean_npp=8.0)
+    assert close(f["coarseRootCreation"], 0.8) and close(f["fineRootCreation"], 1.6)
+    assert close(f["coarseRootLoss"], 0.05) and close(f["fineRootLoss"], 0.06)
+    prm = dict(prm, coarseRootTurnoverRate=0.0, fineRootTurnoverRate=0.0)
+    for npp, coarse, fine, exp_c, exp_f in ((-4.0, 5.0, 3.0, -0.4, -0.8), (-32.0, 5.0, 0.5, -5.6, -4.0),
+                                             (-32.0, 0.2, 5.0, -1.6, -8.0)):
+        f = fluxes_probe(oracle, fl, prm, {"coarseRootC": coarse, "fineRootC": fine, "soilWater": 5.0},
+                         NIGHT, mean_npp=npp)
+        assert close(f["coarseRootCreation"], exp_c) and close(f["fineRootCreation"], exp_f), (npp, coarse, fine)
