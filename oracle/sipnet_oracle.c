@@ -1628,9 +1628,10 @@ int sipo_probe_fluxes(const int *flags, const double *params, const double *envi
 /* updatePoolsAndBalance() (sipnet.c:1769-1806: event, main, soil and N pool updates, mortality,
  * non-negativity clamps) with the given per-step rates: envi[13] in/out. */
 int sipo_probe_pools(const int *flags, const double *params, double *envi, const double *rates,
-                     double length) {
+                     double length, int was_alive, int *alive_out) {
   Member M;
   probeMember(&M, flags, params, envi);
+  if (was_alive >= 0) M.isAlive = was_alive; /* the tracker of the step before, state.h:750-756 */
   memcpy(&M.f, rates, sizeof(M.f));
   M.diag.died_at_step = -1;
   Clim c;
@@ -1641,6 +1642,7 @@ int sipo_probe_pools(const int *flags, const double *params, double *envi, const
   updatePoolsAndBalance(&M, &c, 0);
   if (M.status) return M.status;
   memcpy(envi, &M.e, sizeof(M.e));
+  if (alive_out) *alive_out = M.isAlive;
   return 0;
 }
 

@@ -158,7 +158,7 @@ int sipo_probe_fluxes(const int *flags, const double *params, const double *envi
                       double gdd_so_far, int did_leaf_growth, int did_leaf_fall,
                       double *rates_out);
 int sipo_probe_pools(const int *flags, const double *params, double *envi, const double *rates,
-                     double length);
+                     double length, int was_alive, int *alive_out);
 int sipo_num_rates(void);
 double sipo_ring_probe(int n, const double *values, const double *weights,
                        int *err);

@@ -1,10 +1,15 @@
-"""Known answers of the reference's per-event-type unit tests
-(tests/sipnet/test_events_types/testEvent{Irrigation,Planting,Harvest,Fertilization,Tillage}.c),
-replayed on the oracle with the same inputs: pools set directly, ONE pass of processEvents() +
-updatePoolsForEvents() on a 0.125-day record of 2024 day 70, pools compared with the
-reference tests' expected values (tolerance 1e-6 = tests/utils/tUtils.h:57-59).
+"""Known answers of the reference's white-box unit tests of single stages of a step, replayed
+on the oracle's stage probes with the same inputs (tolerance 1e-6 = tests/utils/tUtils.h:57-59):
 
-The event files of those tests are tiny; their content is restated here as data."""
+  tests/sipnet/test_events_types/testEvent{Irrigation,Planting,Harvest,Fertilization,Tillage}.c
+      pools set directly, ONE pass of processEvents() + updatePoolsForEvents() on a 0.125-day
+      record of 2024 day 70
+  tests/sipnet/test_modeling/testCarbonSaturation.c, testMethane.c   soil pool update / fluxes
+  tests/sipnet/test_modeling/testFluxCalculations.c                  allocation, negative creation
+  tests/sipnet/test_modeling/testPlantMortality.c                    checkForMortality() transitions
+
+The event files of those tests are tiny; their content is restated here as data, the expected
+values as the arithmetic the reference tests state."""
 import ctypes as C
 import math
 import os
@@ -154,7 +159,7 @@ RATE = {n: i for i, n in enumerate(
     "eventLeafOffLitter eventLeafOffNResorption soilMethane litterMethane".split())}
 
 
-def pools_probe(oracle, flags, params, envi, rates):
+def pools_probe(oracle, flags, params, envi, rates, was_alive=-1, want_alive=False):
     L = oracle.lib
     L.sipo_probe_pools.restype = C.c_int
     L.sipo_num_rates.restype = C.c_int
@@ -167,9 +172,11 @@ def pools_probe(oracle, flags, params, envi, rates):
     for k, v in rates.items():
         r[RATE[k]] = v
     fl = (C.c_int * 12)(*flags)
+    alive = C.c_int(-1)
     assert L.sipo_probe_pools(fl, p.ctypes.data_as(C.c_void_p), e.ctypes.data_as(C.c_void_p),
-                              r.ctypes.data_as(C.c_void_p), C.c_double(LEN)) == 0
-    return dict(zip(ENVI, e))
+                              r.ctypes.data_as(C.c_void_p), C.c_double(LEN), was_alive, C.byref(alive)) == 0
+    out = dict(zip(ENVI, e))
+    return (out, alive.value) if want_alive else out
 
 
 @pytest.mark.parametrize("soil0,root_loss,r_soil", [(2.5, 100, 0), (2.5, 200, 0), (7.5, 100, 0),
@@ -294,3 +301,31 @@ def test_root_allocation_known_answers(oracle):
         f = fluxes_probe(oracle, fl, prm, {"coarseRootC": coarse, "fineRootC": fine, "soilWater": 5.0},
                          NIGHT, mean_npp=npp)
         assert close(f["coarseRootCreation"], exp_c) and close(f["fineRootCreation"], exp_f), (npp, coarse, fine)
+
+
+# ---- testPlantMortality.c: checkForMortality() transitions --------------------------------------
+STAND = {"plantWoodC": 5.0, "plantLeafC": 2.0, "fineRootC": 3.0, "coarseRootC": 4.0, "soilC": 10.0}
+
+
+def test_mortality_transitions(oracle):
+    fl = sa.flags_from()
+    e, alive = pools_probe(oracle, fl, {}, STAND, {}, was_alive=1, want_alive=True)       # stays alive
+    assert alive == 1 and close(e["plantWoodC"], 5.0) and close(e["soilC"], 10.0)
+    e, alive = pools_probe(oracle, fl, {}, dict(STAND, plantWoodC=0.0), {}, was_alive=1, want_alive=True)
+    assert alive == 0 and close(e["soilC"], 10 + 3 + 4 + 0 + 2 + 0)                      # dies, no litter pool
+    assert all(close(e[k], 0.0) for k in ("plantWoodC", "plantLeafC", "fineRootC", "coarseRootC", "plantCAccountingDelta"))
+    e = pools_probe(oracle, sa.flags_from(litterPool=1), {}, dict(STAND, plantWoodC=0.0, litterC=5.0), {}, was_alive=1)
+    assert close(e["soilC"], 10 + 3 + 4) and close(e["litterC"], 5 + 0 + 2 + 0)          # with the litter pool
+    fln = sa.flags_from(litterPool=1, anaerobic=1, nitrogenCycle=1)
+    e = pools_probe(oracle, fln, {"woodCN": 100.0, "leafCN": 20.0, "fineRootCN": 40.0},
+                    dict(STAND, plantWoodC=0.0, litterC=5.0, soilOrgN=2.0, litterN=3.0, plantStorageN=0.5), {}, was_alive=1)
+    assert close(e["soilOrgN"], 2 + 3 / 40 + 4 / 100) and close(e["litterN"], 3 + 0 / 100 + 2 / 20 + 0.5)
+    assert close(e["plantStorageN"], 0.0)
+    bare = {"soilC": 10.0}
+    e, alive = pools_probe(oracle, fl, {}, bare, {}, was_alive=0, want_alive=True)        # dead stays dead
+    assert alive == 0 and close(e["soilC"], 10.0)
+    e, alive = pools_probe(oracle, fl, {}, STAND, {}, was_alive=0, want_alive=True)       # re-emergence
+    assert alive == 1 and close(e["plantWoodC"], 5.0) and close(e["soilC"], 10.0)
+    e, alive = pools_probe(oracle, fl, {}, dict(STAND, plantWoodC=1.0, plantCAccountingDelta=-1.5), {},
+                           was_alive=1, want_alive=True)                                   # negative total wood
+    assert alive == 0 and close(e["soilC"], 10 + 3 + 4 + 1 + 2 - 1.5)
