@@ -1,7 +1,7 @@
 """Known answers of the reference's white-box unit tests of single stages of a step, replayed
 on the oracle's stage probes with the same inputs (tolerance 1e-6 = tests/utils/tUtils.h:57-59):
 
-  tests/sipnet/test_events_types/testEvent{Irrigation,Planting,Harvest,Fertilization,Tillage}.c
+  tests/sipnet/test_events_types/testEvent{Irrigation,Planting,Harvest,Fertilization,Tillage,LeafOnOff}.c
       pools set directly, ONE pass of processEvents() + updatePoolsForEvents() on a 0.125-day
       record of 2024 day 70
   tests/sipnet/test_modeling/testCarbonSaturation.c, testMethane.c   soil pool update / fluxes
@@ -329,3 +329,39 @@ def test_mortality_transitions(oracle):
     e, alive = pools_probe(oracle, fl, {}, dict(STAND, plantWoodC=1.0, plantCAccountingDelta=-1.5), {},
                            was_alive=1, want_alive=True)                                   # negative total wood
     assert alive == 0 and close(e["soilC"], 10 + 3 + 4 + 1 + 2 - 1.5)
+
+
+# ---- testEventLeafOnOff.c: user-specified leaf-on / leaf-off events ----------------------------
+LEAF_PRM = dict(leafGrowth=3.0, fracLeafFall=0.5, leafCN=30.0, leafOnReallocFrac=0.5, woodCN=100.0)
+
+
+def test_leaf_on_events(oracle):
+    fl = sa.flags_from(litterPool=1, gdd=0)
+    one, two = events_of("2024 70 leafon"), events_of("2024 70 leafon\n2024 70 leafon")
+    e, _, _ = probe(oracle, fl, LEAF_PRM, {"plantWoodC": 10.0}, one)
+    assert close(e["plantWoodC"], 7.0) and close(e["coarseRootC"], 0.0) and close(e["plantLeafC"], 3.0)
+    e, _, _ = probe(oracle, fl, LEAF_PRM, {"plantWoodC": 10.0}, two)
+    assert close(e["plantWoodC"], 4.0) and close(e["plantLeafC"], 6.0)
+    e, _, _ = probe(oracle, fl, LEAF_PRM, {"plantWoodC": 6.0, "coarseRootC": 4.0}, one)      # proportional split
+    assert close(e["plantWoodC"], 6 - 1.8) and close(e["coarseRootC"], 4 - 1.2) and close(e["plantLeafC"], 3.0)
+    e, _, _ = probe(oracle, fl, LEAF_PRM, {"plantWoodC": 1.0}, one)                          # C-limited
+    assert close(e["plantWoodC"], 0.5) and close(e["plantLeafC"], 0.5)
+    fln = sa.flags_from(litterPool=1, gdd=0, anaerobic=1, nitrogenCycle=1)                   # N-limited
+    e, _, _ = probe(oracle, fln, LEAF_PRM, {"plantWoodC": 10.0, "plantStorageN": 0.05}, one)
+    moved = 3.0 * (0.05 / (3.0 / 30.0 - 3.0 / 100.0))
+    assert close(e["plantWoodC"], 10 - moved) and close(e["plantLeafC"], moved)
+
+
+def test_leaf_off_events(oracle):
+    one = events_of("2024 70 leafoff")
+    start = {"plantWoodC": 5.0, "plantLeafC": 10.0}
+    e, _, _ = probe(oracle, sa.flags_from(litterPool=1, gdd=0), LEAF_PRM, start, one)
+    assert close(e["plantLeafC"], 5.0) and close(e["litterC"], 5.0) and close(e["litterN"], 0.0)
+    fln = sa.flags_from(litterPool=1, gdd=0, anaerobic=1, nitrogenCycle=1)
+    e, _, _ = probe(oracle, fln, LEAF_PRM, start, one)
+    assert close(e["plantLeafC"], 5.0) and close(e["litterC"], 5.0) and close(e["litterN"], 5.0 / 30.0)
+    e, _, _ = probe(oracle, sa.flags_from(gdd=0), LEAF_PRM, start, one)                      # no litter pool
+    assert close(e["plantLeafC"], 5.0) and close(e["soilC"], 5.0) and close(e["litterN"], 0.0)
+    e, _, _ = probe(oracle, fln, dict(LEAF_PRM, leafNResorptionFrac=0.3), start, one)        # N resorption
+    leaf_n = 5.0 / 30.0
+    assert close(e["litterN"], leaf_n * 0.7) and close(e["plantStorageN"], leaf_n * 0.3)
