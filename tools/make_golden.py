@@ -299,10 +299,20 @@ def restart_cases():
                  "PRINT_HEADER = 0\nQUIET = 1\n", "", "", "", False)
 
 
+def balance_case():
+    """data files of the reference's mass-balance test (tests/sipnet/test_modeling/testBalance.c)"""
+    R = os.path.join(REF, "tests", "sipnet", "test_modeling")
+    d = os.path.join(GOLD, "balance")
+    os.makedirs(d, exist_ok=True)
+    for f in ["balance.clim", "balance.param", "events_leaf.in"]:
+        shutil.copyfile(os.path.join(R, f), os.path.join(d, f))
+
+
 if __name__ == "__main__":
     subprocess.check_call(["make", "-s", "-C", os.path.join(REPO, "oracle"), "ref", "oracle"])
     copy_smoke()
     smoke_records()
     synthetic()
     restart_cases()
+    balance_case()
     subprocess.run(["du", "-sh", GOLD])
