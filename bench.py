@@ -146,6 +146,9 @@ def main():
     ap.add_argument("--fast-math", type=int, default=int(os.environ.get("SIPNET_FAST_MATH", "1")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather", default="stats", choices=["stats", "full", "none"])
+    ap.add_argument("--rehearse", action="store_true",
+                    help="development: run the N>1 path on ONE GPU (all ranks share device 0, gloo "
+                         "collectives through host copies); the numbers mean nothing")
     args = ap.parse_args()
 
     wl = dict(WORKLOADS[args.workload])
@@ -185,9 +188,22 @@ def main():
 
     import torch
     import torch.distributed as dist
+    if args.rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def all_gather_into(out, x):
+        if args.rehearse:   # gloo: through the host
+            o = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(o.view((-1,) + tuple(x.shape[1:])) if x.dim() else o, x.cpu().contiguous())
+            out.copy_(o)
+        else:
+            dist.all_gather_into_tensor(out, x)
 
     b = sa.Batch(flags, S, M, prec, device=local_rank)
     for s in range(S):
@@ -227,9 +243,9 @@ def main():
             for v in range(3):
                 b.reduce_plane(planes[v], stats[v])
             if args.gather == "stats":
-                dist.all_gather_into_tensor(gathered, stats)
+                all_gather_into(gathered, stats)
             else:
-                dist.all_gather_into_tensor(gathered_full, planes)
+                all_gather_into(gathered_full, planes)
 
     def barrier():
         if world > 1:
@@ -247,7 +263,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=b.device)
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.rehearse else b.device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 

@@ -2,8 +2,8 @@
 # dev: where does the carbon wave of the cooperative kernel spend a step?  (-DSIPNET_STAMPS build)
 cd "$GRAFT_REPO_ROOT/sipnet_amd/csrc" || exit 1
 cp ../libsipnet_amd.so /tmp/lib_orig.so
-for e in ${EXPS:-0 3}; do
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -fno-gpu-rdc -DSIPNET_STAMPS -DCOOP_EXP=$e -c step_coop.hip -o /tmp/step_coop_s.o || exit 1
+for e in 0; do
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -fno-gpu-rdc -DSIPNET_STAMPS -c step_coop.hip -o /tmp/step_coop_s.o || exit 1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libsipnet_amd.so engine.o step_kernel.o step_fast.o /tmp/step_coop_s.o pf.o plan.o host_io.o restart_io.o || exit 1
 (cd ../..; SIPNET_COOP=1 python3 - <<PY
 import os, sys, ctypes as C, numpy as np
@@ -23,7 +23,7 @@ sa.lib().sipnet_debug_read_coop_stamps.argtypes = [C.c_void_p]
 sa.lib().sipnet_debug_read_coop_stamps(st)
 v = np.array(list(st), dtype=float)
 names = ["loop+record+factors take", "fluxes", "events test", "take psn", "pools+mortality+post lai", "soilC+outputs", "ring + stores"]
-print("EXP $e kernel ms", b.last_kernel_ms(), "C-wave cycles/step (100 MHz ticks x24)", v.sum() / T)
+print("kernel ms", b.last_kernel_ms(), "C-wave cycles/step (100 MHz ticks x24)", v.sum() / T)
 for n, x in zip(names, v): print("  %-34s %8.1f cycles/step" % (n, x / T))
 PY
 )
