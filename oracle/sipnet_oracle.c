@@ -283,11 +283,9 @@ static void nFixationAndUptake(Member *M, double len) {
   M->f.nFixation = frac * rem;
   M->f.nUptake = (1 - frac) * rem;
 }
-/* nitrogen.c:199-207 with the five helpers :15-82,170-196 */
-static void nitrogenFluxes(Member *M, const Clim *c) {
+/* nitrogen.c:170-196 */
+static void nResorptionFluxes(Member *M) {
   Rates *f = &M->f;
-  const Pools *e = &M->e;
-  /* resorption, nitrogen.c:170-196 */
   if (f->woodCreation + f->leafCreation + f->fineRootCreation +
           f->coarseRootCreation <
       0.0) {
@@ -298,40 +296,50 @@ static void nitrogenFluxes(Member *M, const Clim *c) {
   }
   double nResorp = P(M, leafNResorptionFrac) * f->leafLitter / P(M, leafCN);
   f->leafOffNResorption += nResorp;
-  /* volatilisation, nitrogen.c:15-26 */
-  {
-    double d_temp = tempEffect(M->p, c->tsoil);
-    double d_water = volatilizationMoistEffect(M->p, e->soilWater, P(M, soilWHC));
-    f->nVolatilization = P(M, nVolatilizationFrac) * e->minN * d_temp * d_water;
+}
+/* nitrogen.c:15-26 */
+static void nVolatilizationFlux(Member *M, const Clim *c) {
+  double d_temp = tempEffect(M->p, c->tsoil);
+  double d_water = volatilizationMoistEffect(M->p, M->e.soilWater, P(M, soilWHC));
+  M->f.nVolatilization = P(M, nVolatilizationFrac) * M->e.minN * d_temp * d_water;
+}
+/* nitrogen.c:31-41 */
+static void nLeachingFlux(Member *M) {
+  Rates *f = &M->f;
+  double phi;
+  if ((f->drainage / P(M, soilWHC)) < 1) {
+    phi = f->drainage / P(M, soilWHC);
+  } else {
+    phi = 1;
   }
-  /* leaching, nitrogen.c:31-41 */
-  {
-    double phi;
-    if ((f->drainage / P(M, soilWHC)) < 1) {
-      phi = f->drainage / P(M, soilWHC);
-    } else {
-      phi = 1;
-    }
-    f->nLeaching = e->minN * phi * P(M, nLeachingFrac);
-  }
-  /* pool fluxes, nitrogen.c:45-82 */
-  {
-    double litterCN = calcRatio(e->litterC, e->litterN);
-    double soilCN = calcRatio(e->soilC, e->soilOrgN);
-    double litterMin = f->rLitter / litterCN;
-    double soilMin = f->rSoil / soilCN;
-    double soilNInputs = f->litterToSoil / litterCN +
-                         f->fineRootLoss / P(M, fineRootCN) +
-                         f->coarseRootLoss / P(M, woodCN);
-    double sat = FLAG(M, CARBON_SATURATION)
-                     ? unitClip(e->soilC / P(M, soilCSaturation))
-                     : 0.0;
-    f->nOrgLitter = f->leafLitter / P(M, leafCN) - f->leafOffNResorption +
-                    f->woodLitter / P(M, woodCN) - litterMin -
-                    f->litterToSoil / litterCN + (soilNInputs * sat);
-    f->nOrgSoil = soilNInputs * (1 - sat) - soilMin;
-    f->nMin = litterMin + soilMin;
-  }
+  f->nLeaching = M->e.minN * phi * P(M, nLeachingFrac);
+}
+/* nitrogen.c:45-82 */
+static void nPoolFluxes(Member *M) {
+  Rates *f = &M->f;
+  const Pools *e = &M->e;
+  double litterCN = calcRatio(e->litterC, e->litterN);
+  double soilCN = calcRatio(e->soilC, e->soilOrgN);
+  double litterMin = f->rLitter / litterCN;
+  double soilMin = f->rSoil / soilCN;
+  double soilNInputs = f->litterToSoil / litterCN +
+                       f->fineRootLoss / P(M, fineRootCN) +
+                       f->coarseRootLoss / P(M, woodCN);
+  double sat = FLAG(M, CARBON_SATURATION)
+                   ? unitClip(e->soilC / P(M, soilCSaturation))
+                   : 0.0;
+  f->nOrgLitter = f->leafLitter / P(M, leafCN) - f->leafOffNResorption +
+                  f->woodLitter / P(M, woodCN) - litterMin -
+                  f->litterToSoil / litterCN + (soilNInputs * sat);
+  f->nOrgSoil = soilNInputs * (1 - sat) - soilMin;
+  f->nMin = litterMin + soilMin;
+}
+/* nitrogen.c:199-207 */
+static void nitrogenFluxes(Member *M, const Clim *c) {
+  nResorptionFluxes(M);
+  nVolatilizationFlux(M, c);
+  nLeachingFlux(M);
+  nPoolFluxes(M);
   nFixationAndUptake(M, c->length);
 }
 /* nitrogen.c:210-239 */
@@ -1643,6 +1651,35 @@ int sipo_probe_pools(const int *flags, const double *params, double *envi, const
   if (M.status) return M.status;
   memcpy(envi, &M.e, sizeof(M.e));
   if (alive_out) *alive_out = M.isAlive;
+  return 0;
+}
+
+/* The stages of the nitrogen cycle one by one, on prescribed rates (the pattern of
+ * test_modeling/testNitrogenCycle.c): stage bits 1 resorption (nitrogen.c:170-196), 2 volatilisation
+ * (:15-26), 4 leaching (:31-41), 8 organic-pool fluxes (:45-82), 16 fixation + uptake (:155-168),
+ * 32 mineral-N limitation (limitations.c:119-129), 64 nitrogen limitation (limitations.c:69-114),
+ * 128 updateNitrogenPools (nitrogen.c:210-239).  envi[13] and rates[] in/out. */
+int sipo_probe_nitrogen(const int *flags, const double *params, double *envi, double *rates,
+                        double length, double tsoil, int stages) {
+  Member M;
+  probeMember(&M, flags, params, envi);
+  memcpy(&M.f, rates, sizeof(M.f));
+  Clim c;
+  memset(&c, 0, sizeof(c));
+  c.year = 2024;
+  c.day = 70;
+  c.length = length;
+  c.tsoil = tsoil;
+  if (stages & 1) nResorptionFluxes(&M);
+  if (stages & 2) nVolatilizationFlux(&M, &c);
+  if (stages & 4) nLeachingFlux(&M);
+  if (stages & 8) nPoolFluxes(&M);
+  if (stages & 16) nFixationAndUptake(&M, length);
+  if (stages & 32) mineralNLimitation(&M, length);
+  if (stages & 64) nitrogenLimitation(&M, length);
+  if (stages & 128) updateNitrogenPools(&M, length);
+  memcpy(envi, &M.e, sizeof(M.e));
+  memcpy(rates, &M.f, sizeof(M.f));
   return 0;
 }
 

@@ -159,6 +159,8 @@ int sipo_probe_fluxes(const int *flags, const double *params, const double *envi
                       double *rates_out);
 int sipo_probe_pools(const int *flags, const double *params, double *envi, const double *rates,
                      double length, int was_alive, int *alive_out);
+int sipo_probe_nitrogen(const int *flags, const double *params, double *envi, double *rates,
+                        double length, double tsoil, int stages);
 int sipo_num_rates(void);
 double sipo_ring_probe(int n, const double *values, const double *weights,
                        int *err);

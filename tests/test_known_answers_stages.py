@@ -7,6 +7,7 @@ on the oracle's stage probes with the same inputs (tolerance 1e-6 = tests/utils/
   tests/sipnet/test_modeling/testCarbonSaturation.c, testMethane.c   soil pool update / fluxes
   tests/sipnet/test_modeling/testFluxCalculations.c                  allocation, negative creation
   tests/sipnet/test_modeling/testPlantMortality.c                    checkForMortality() transitions
+  tests/sipnet/test_modeling/testNitrogenCycle.c                     the N-cycle stages one by one
 
 The event files of those tests are tiny; their content is restated here as data, the expected
 values as the arithmetic the reference tests state."""
@@ -365,3 +366,108 @@ def test_leaf_off_events(oracle):
     e, _, _ = probe(oracle, fln, dict(LEAF_PRM, leafNResorptionFrac=0.3), start, one)        # N resorption
     leaf_n = 5.0 / 30.0
     assert close(e["litterN"], leaf_n * 0.7) and close(e["plantStorageN"], leaf_n * 0.3)
+
+
+# ---- testNitrogenCycle.c: the stages of the N cycle on prescribed rates --------------------------
+N_FLAGS = dict(litterPool=1, nitrogenCycle=1, anaerobic=1)
+N_PRM = dict(soilWHC=10.0, soilRespMoistEffect=1.0, baseSoilResp=0.06, soilRespQ10=2.9, leafCN=20.0,
+             woodCN=100.0, fineRootCN=40.0)
+N_ENVI = {"soilWater": 5.0, "soilC": 1.5, "litterC": 1.0}
+RESORB, VOLAT, LEACH, POOLF, FIXUP, MINLIM, NLIM, UPDATE = 1, 2, 4, 8, 16, 32, 64, 128
+DEMAND10 = {"leafCreation": 60.0, "woodCreation": 500.0, "fineRootCreation": 40.0, "coarseRootCreation": 100.0}
+
+
+def n_probe(oracle, params, envi, rates, stages, tsoil=20.0):
+    L = oracle.lib
+    L.sipo_probe_nitrogen.restype = C.c_int
+    p = np.zeros(80)
+    for k, v in dict(N_PRM, **params).items():
+        p[pidx(k)] = v
+    e = np.array([dict(N_ENVI, **envi).get(n, 0.0) for n in ENVI], dtype=np.float64)
+    r = np.zeros(len(RATE))
+    for k, v in rates.items():
+        r[RATE[k]] = v
+    fl = (C.c_int * 12)(*sa.flags_from(**N_FLAGS))
+    assert L.sipo_probe_nitrogen(fl, p.ctypes.data_as(C.c_void_p), e.ctypes.data_as(C.c_void_p),
+                                 r.ctypes.data_as(C.c_void_p), C.c_double(LEN), C.c_double(tsoil), stages) == 0
+    return dict(zip(ENVI, e)), {n: r[i] for n, i in RATE.items()}, p
+
+
+def test_n_volatilization_and_leaching(oracle):
+    L = oracle.lib
+    L.sipo_temp_effect.restype = C.c_double
+    L.sipo_volatilization_moist_effect.restype = C.c_double
+    _, _, p = n_probe(oracle, {}, {}, {}, 0)
+    te = L.sipo_temp_effect(p.ctypes.data_as(C.c_void_p), C.c_double(20.0))
+    me = L.sipo_volatilization_moist_effect(p.ctypes.data_as(C.c_void_p), C.c_double(5.0), C.c_double(10.0))
+    _, f, _ = n_probe(oracle, {"nVolatilizationFrac": 0.1}, {"minN": 2.0}, {}, VOLAT)
+    assert close(f["nVolatilization"], 0.1 * 2 * te * me)
+    e, f, _ = n_probe(oracle, {"nVolatilizationFrac": 0.1}, {"minN": 4.0}, {}, VOLAT | UPDATE)
+    assert close(f["nVolatilization"], 0.1 * 4 * te * me) and close(e["minN"], 4 - 0.1 * 4 * te * me * LEN)
+    _, f, _ = n_probe(oracle, {"nLeachingFrac": 0.5}, {"minN": 1.0}, {"drainage": 5.0}, LEACH)
+    assert close(f["nLeaching"], 1 * 0.5 * 0.5)                    # phi = drainage / whc
+    e, f, _ = n_probe(oracle, {"nLeachingFrac": 0.5}, {"minN": 1.0}, {"drainage": 20.0}, LEACH | UPDATE)
+    assert close(f["nLeaching"], 1 * 1.0 * 0.5) and close(e["minN"], 1 - 0.5 * LEN)   # phi capped at 1
+
+
+@pytest.mark.parametrize("min_n,frac_max,half,red", [(4.0, 1.0, 2.0, 1.0), (1.0, 0.75, 1.0, 1.0),
+                                                     (0.5, 0.75, 1.0, 0.8)])
+def test_n_fixation_and_uptake(oracle, min_n, frac_max, half, red):
+    prm = {"nFixationFracMax": frac_max, "halfNFixationMax": half}
+    e, f, _ = n_probe(oracle, prm, {"minN": min_n}, DEMAND10, FIXUP | NLIM | UPDATE)
+    frac = frac_max * half / (half + min_n)
+    assert close(f["nFixation"], frac * 10 * red) and close(f["nUptake"], (1 - frac) * 10 * red)
+    assert close(e["minN"], min_n - (1 - frac) * 10 * red * LEN)
+
+
+def test_n_fixation_without_mineral_n(oracle):
+    e, f, _ = n_probe(oracle, {"nFixationFracMax": 0.5, "halfNFixationMax": 2.0}, {"minN": 0.0}, DEMAND10,
+                      FIXUP | NLIM | UPDATE)
+    assert close(f["nFixation"], 0.0) and close(f["nUptake"], 0.0) and close(e["minN"], 0.0)
+
+
+def test_n_limitation_scales_creation(oracle):
+    _, f, _ = n_probe(oracle, {}, {"minN": 0.625}, DEMAND10, FIXUP | NLIM)        # half the demand is met
+    for k, v in DEMAND10.items():
+        assert close(f[k], v * 0.5), k
+    _, f, _ = n_probe(oracle, {}, {"minN": 0.1}, dict(DEMAND10, nMin=12.0), FIXUP | NLIM)   # mineralisation covers it
+    assert close(f["leafCreation"], 60.0) and close(f["woodCreation"], 500.0)
+    _, f, _ = n_probe(oracle, {}, {"minN": 0.75, "plantStorageN": 0.5}, dict(DEMAND10, leafOnCreation=50.0),
+                      FIXUP | NLIM)                                                # leaf-on claims storage first
+    assert close(f["leafOnCreation"], 50.0) and close(f["woodCreation"], 400.0) and close(f["leafCreation"], 48.0)
+    e, f, _ = n_probe(oracle, {}, {"minN": 0.625, "plantStorageN": 0.625}, DEMAND10, FIXUP | NLIM | UPDATE)
+    for k, v in DEMAND10.items():                                                  # storage covers the rest
+        assert close(f[k], v), k
+    assert close(e["minN"], 0.0) and close(e["plantStorageN"], 0.0)
+
+
+def test_organic_n_pool_fluxes(oracle):
+    env = {"minN": 1.0, "litterC": 2.0, "soilC": 3.0, "litterN": 2.0, "soilOrgN": 3.0}
+    rates = {"leafLitter": 20.0, "woodLitter": 100.0, "fineRootLoss": 40.0, "coarseRootLoss": 100.0,
+             "rLitter": 1.0, "litterToSoil": 1.0, "rSoil": 1.0}
+    e, f, _ = n_probe(oracle, {}, env, rates, POOLF | UPDATE)
+    assert close(f["nOrgLitter"], 0.0) and close(f["nOrgSoil"], 2.0) and close(e["minN"], 1 + 2 * LEN)
+    _, f, _ = n_probe(oracle, {}, env, dict(rates, leafOffNResorption=0.5), POOLF)
+    assert close(f["nOrgLitter"], -0.5)
+
+
+def test_plant_storage_n(oracle):
+    grow = {"leafCreation": 40.0, "woodCreation": 200.0, "fineRootCreation": 80.0, "coarseRootCreation": 200.0}
+    e, f, _ = n_probe(oracle, {}, {"minN": 1.0, "plantStorageN": 2.0}, grow, FIXUP | UPDATE)   # demand 8/d = 1.0 per step
+    assert close(e["plantStorageN"], 1.0) and close(f["nUptake"], 0.0) and close(e["minN"], 1.0)
+    e, f, _ = n_probe(oracle, {}, {"minN": 1.0, "plantStorageN": 0.5}, grow, FIXUP | UPDATE)
+    assert close(e["plantStorageN"], 0.0) and close(f["nUptake"], 0.5 / LEN) and close(e["minN"], 0.5)
+    e, _, _ = n_probe(oracle, {}, {"minN": 1.0}, {"leafOffNResorption": 2.0}, UPDATE)           # resorbed N is stored
+    assert close(e["plantStorageN"], 2.0 * LEN)
+    e, f, _ = n_probe(oracle, {}, {"minN": 0.625}, dict(DEMAND10, leafOffNResorption=2.0), FIXUP | NLIM | UPDATE)
+    assert close(f["leafCreation"], 30.0) and close(f["woodCreation"], 250.0)
+    assert close(e["minN"], 0.0) and close(e["plantStorageN"], 2.0 * LEN)
+
+
+def test_mineral_n_cannot_go_negative(oracle):
+    prm = {"fAnoxia": 0.6, "soilRespQ10": 2.5, "nVolatilizationFrac": 1.0, "nLeachingFrac": 0.5}
+    env = {"minN": 1.0, "soilWater": 8.0}
+    _, f, _ = n_probe(oracle, prm, env, {"nMin": 2.0}, VOLAT | LEACH, tsoil=30.0)
+    assert close(f["nVolatilization"], 15.625) and close(f["nLeaching"], 0.0)       # Q10^3, D_water = 1
+    e, f, _ = n_probe(oracle, prm, env, {"nMin": 2.0}, VOLAT | LEACH | MINLIM | UPDATE, tsoil=30.0)
+    assert close(f["nVolatilization"], 10.0) and close(e["minN"], 0.0)              # capped at pool + inputs
