@@ -1610,6 +1610,38 @@ int sipo_probe_events(const int *flags, const double *params, double *envi, doub
   return 0;
 }
 
+/* The same over a series of records, pools carried from one to the next, with the events.out
+ * text the reference writes while processing (events.c:369-418): the pattern of
+ * test_events_infrastructure/testEventOutputFile.c. */
+int sipo_probe_events_series(const int *flags, const double *params, double *envi, int n_rec,
+                             const int *year, const int *day, const double *length, int n_events,
+                             const sipo_event *events, const char *out_path, int print_header) {
+  Member M;
+  probeMember(&M, flags, params, envi);
+  M.n_events = n_events;
+  M.events = events;
+  FILE *out = fopen(out_path, "w");
+  if (!out) return SIPO_ERR_INPUT_FILE;
+  if (print_header) {
+    fprintf(out, "%4s  %3s  %-7s  %s", "year", "day", "type",
+            "param_name=delta[,param_name=delta,...]\n");
+  }
+  M.evout = out;
+  for (int i = 0; i < n_rec && !M.status; i++) {
+    Clim c;
+    memset(&c, 0, sizeof(c));
+    c.year = year[i];
+    c.day = day[i];
+    c.length = length[i];
+    memset(&M.f, 0, sizeof(M.f));
+    processEvents(&M, &c);
+    if (!M.status) updatePoolsForEvents(&M, c.length);
+  }
+  fclose(out);
+  memcpy(envi, &M.e, sizeof(M.e));
+  return M.status;
+}
+
 /* calculateFluxes() (sipnet.c:1256-1336) on the given pools and climate record clim[11] (layout
  * of sipo_run_member); mean_npp seeds the running mean, gdd_so_far / last_year the trackers used
  * by the phenology tests.  rates_out receives the Rates struct as doubles. */

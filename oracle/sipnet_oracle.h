@@ -153,6 +153,9 @@ double sipo_light_eff(const double *params, double lai, double par);
 int sipo_probe_events(const int *flags, const double *params, double *envi, double length,
                       int year, int day, int n_events, const sipo_event *events,
                       double *d_till_mod, double *rates_out);
+int sipo_probe_events_series(const int *flags, const double *params, double *envi, int n_rec,
+                             const int *year, const int *day, const double *length, int n_events,
+                             const sipo_event *events, const char *out_path, int print_header);
 int sipo_probe_fluxes(const int *flags, const double *params, const double *envi,
                       const double *clim, int year, int day, double mean_npp, double d_till_mod,
                       double gdd_so_far, int did_leaf_growth, int did_leaf_fall,

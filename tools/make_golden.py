@@ -299,6 +299,21 @@ def restart_cases():
                  "PRINT_HEADER = 0\nQUIET = 1\n", "", "", "", False)
 
 
+def events_infra_case():
+    """data files of the reference's events.out format test and of its event-file parser tests
+    (tests/sipnet/test_events_infrastructure, tests/sipnet/test_bugfixes)"""
+    d = os.path.join(GOLD, "events_infra")
+    os.makedirs(d, exist_ok=True)
+    R = os.path.join(REF, "tests", "sipnet", "test_events_infrastructure")
+    for f in os.listdir(R):
+        if f.endswith(".in") or f.endswith(".out"):
+            shutil.copyfile(os.path.join(R, f), os.path.join(d, f))
+    R = os.path.join(REF, "tests", "sipnet", "test_bugfixes")
+    for f in os.listdir(R):
+        if f.endswith(".in"):
+            shutil.copyfile(os.path.join(R, f), os.path.join(d, f))
+
+
 def balance_case():
     """data files of the reference's mass-balance test (tests/sipnet/test_modeling/testBalance.c)"""
     R = os.path.join(REF, "tests", "sipnet", "test_modeling")
@@ -315,4 +330,5 @@ if __name__ == "__main__":
     synthetic()
     restart_cases()
     balance_case()
+    events_infra_case()
     subprocess.run(["du", "-sh", GOLD])
