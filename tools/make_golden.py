@@ -314,6 +314,16 @@ def events_infra_case():
             shutil.copyfile(os.path.join(R, f), os.path.join(d, f))
 
 
+def sipnet_infra_case():
+    """data files of the reference's input-reader tests (tests/sipnet/test_sipnet_infrastructure)"""
+    d = os.path.join(GOLD, "sipnet_infra")
+    os.makedirs(d, exist_ok=True)
+    R = os.path.join(REF, "tests", "sipnet", "test_sipnet_infrastructure")
+    for f in os.listdir(R):
+        if f.endswith((".clim", ".param", ".exp")):
+            shutil.copyfile(os.path.join(R, f), os.path.join(d, f))
+
+
 def balance_case():
     """data files of the reference's mass-balance test (tests/sipnet/test_modeling/testBalance.c)"""
     R = os.path.join(REF, "tests", "sipnet", "test_modeling")
@@ -331,4 +341,5 @@ if __name__ == "__main__":
     restart_cases()
     balance_case()
     events_infra_case()
+    sipnet_infra_case()
     subprocess.run(["du", "-sh", GOLD])
