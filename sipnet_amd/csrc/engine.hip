@@ -332,8 +332,9 @@ int sipnet_batch_run(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_ne
   a.n_steps = n_steps;
   memcpy(a.flags, b->flags, sizeof(a.flags));
   HIP_TRY(hipEventRecord(b->ev0, stream));
-  if (b->fastMath && !d_rec && isDefaultFlagSet(b->flags) && !getenv("SIPNET_NO_FAST_KERNEL")) {
-    // throughput path: step_fast.hip
+  if (b->fastMath && !d_rec && !getenv("SIPNET_NO_FAST_KERNEL")) {
+    // throughput path: step_fast.hip / step_coop.hip
+    const bool defaultFlags = isDefaultFlagSet(b->flags);
     FastArgs f;
     f.fast = b->d_fast;
     f.ringOps = b->d_ringOps;
@@ -353,6 +354,7 @@ int sipnet_batch_run(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_ne
     f.n_steps = n_steps;
     f.plainExp = b->genericExponents ? 0 : 1;
     f.scratchRow = b->d_scratchRow;
+    memcpy(f.flags, b->flags, sizeof(f.flags));
     // Few 64-member chunks per CU: the step is bound by what one wavefront can issue, so three
     // wavefronts share each chunk (step_coop.hip) -- with the chunk's ring in LDS when there is
     // at most one chunk per CU (c10k 12.4 vs 18.2 ms), in HBM up to two per CU (c4 16.0 vs
@@ -361,8 +363,10 @@ int sipnet_batch_run(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_ne
     const char* coopEnv = getenv("SIPNET_COOP");
     // SIPNET_COOP: 0 one-wave kernel, 1 cooperative (ring in LDS when it fits), 2 cooperative with
     // the ring in HBM (development switch)
+    // Optional model flags (litter pool, nitrogen cycle, ...) always take the one-wave kernel's
+    // run-time-flag instantiation.
     const int coopMode = coopEnv ? atoi(coopEnv) : (blocks <= 2 * (int64_t)b->numCUs ? 1 : 0);
-    const bool coop = coopMode != 0;
+    const bool coop = coopMode != 0 && defaultFlags;
     if (coop) launchStepCoop(f, b->precision, coopMode == 1 && blocks <= b->numCUs, stream);
     else launchStepFast(f, b->precision, stream);
   } else {

@@ -1,4 +1,7 @@
-// step_fast.hip -- the throughput kernels: default model flags, fast-math policy.
+// step_fast.hip -- the throughput kernels: fast-math policy; default model flags compiled in
+// (Generic = false) or any flag set read at run time (Generic = true: litter pool, nitrogen
+// cycle, anaerobic / methane, carbon saturation, flooding, growth respiration, leaf water,
+// soil-temperature / calendar phenology, no moisture effect on heterotrophic respiration).
 //
 // Same model as stepKernel<...> in step_kernel.hip (which stays the strict, all-flags
 // reference path on the GPU); this translation unit is where the instruction count of a
@@ -50,8 +53,33 @@ __device__ unsigned long long g_stamps[16];
 // switches, mortality, irregular ring steps) hide behind ONE wave-uniform test each, and the
 // only common-path branches are the day/night test, the snow / bare-soil evaporation split
 // and the Q10 reuse test.
-template <class R, bool PlainExp>
+//
+// Generic = true adds the optional-flag arithmetic of the reference (nitrogen.c:15-239,
+// limitations.c:69-139, depeffects.c:23-96, sipnet.c:1084-1103, :1150-1171, :1201-1214,
+// :1645-1668) under wave-uniform run-time flags, with the same conventions: reciprocals of the
+// per-member C:N ratios hoisted out of the loop, divisions by pools through v_rcp + Newton.
+template <bool G>
+struct FastFlags {
+  bool gdd, growthResp, leafWater, litterPool, soilPhenol, waterHResp, nitrogen, anaerobic,
+      flooding, carbonSat;
+  __device__ explicit FastFlags(const int32_t* f) {
+    auto get = [&](int i, bool dflt) { return G ? (f[i] != 0) : dflt; };  // context.c:35-53
+    gdd = get(SIPNET_F_GDD, true);
+    growthResp = get(SIPNET_F_GROWTH_RESP, false);
+    leafWater = get(SIPNET_F_LEAF_WATER, false);
+    litterPool = get(SIPNET_F_LITTER_POOL, false);
+    soilPhenol = get(SIPNET_F_SOIL_PHENOL, false);
+    waterHResp = get(SIPNET_F_WATER_HRESP, true);
+    nitrogen = get(SIPNET_F_NITROGEN_CYCLE, false);
+    anaerobic = get(SIPNET_F_ANAEROBIC, false);
+    flooding = get(SIPNET_F_FLOODING, false);
+    carbonSat = get(SIPNET_F_CARBON_SATURATION, false);
+  }
+};
+
+template <class R, bool PlainExp, bool Generic>
 __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
+  const FastFlags<Generic> F(a.flags);
   // LDS: two tiles of kFastTile site records (2 x 4 KB).  ONE __shared__ object.
   __shared__ alignas(16) unsigned char lds[2 * kFastTile * sizeof(FastRec)];
 
@@ -113,7 +141,34 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
   const R K_la = (R)PRM(leafAllocation), K_wa = (R)PRM(woodAllocation);
   const R K_fa = (R)PRM(fineRootAllocation), K_ca = (R)PRM(coarseRootAllocation);
   const R K_moistExp = (R)PRM(soilRespMoistEffect);
-  const double gddLeafOn = PRM(gddLeafOn);
+  // leaf-on test "x >= threshold" (sipnet.c:705-731): x is the year-to-date GDD, the soil
+  // temperature or the day of year, by flag; a non-positive leafOnDay never fires
+  const double gddLeafOn = !Generic || F.gdd ? PRM(gddLeafOn)
+                           : F.soilPhenol    ? PRM(soilTempLeafOn)
+                                             : (PRM(leafOnDay) > 0 ? PRM(leafOnDay) : 1e300);
+  // optional-flag parameters (Generic only; dead code otherwise)
+  const R G_growthFrac = Generic ? (R)PRM(growthRespFrac) : R(0);
+  const R G_leafPool = Generic ? (R)PRM(leafPoolDepth) : R(0);
+  const R G_drainFrac = Generic ? (R)PRM(waterDrainFrac) : R(0);
+  const R G_lbr = Generic ? (R)PRM(litterBreakdownRate) : R(0);
+  const R G_flr = Generic ? (R)PRM(fracLitterRespired) : R(0);
+  const R G_nVol = Generic ? (R)PRM(nVolatilizationFrac) : R(0);
+  const R G_nLeach = Generic ? (R)PRM(nLeachingFrac) : R(0);
+  const R G_iLeafCN = Generic ? (R)(1.0 / PRM(leafCN)) : R(0);
+  const R G_iWoodCN = Generic ? (R)(1.0 / PRM(woodCN)) : R(0);
+  const R G_iFineCN = Generic ? (R)(1.0 / PRM(fineRootCN)) : R(0);
+  const R G_kCN = Generic ? (R)PRM(kCN) : R(0);
+  const R G_nFixMax = Generic ? (R)PRM(nFixationFracMax) : R(0);
+  const R G_halfNFix = Generic ? (R)PRM(halfNFixationMax) : R(0);
+  const R G_resorb = Generic ? (R)PRM(leafNResorptionFrac) : R(0);
+  const R G_fAnox = Generic ? (R)PRM(fAnoxia) : R(0);
+  const R G_iFAnox = Generic ? (R)(1.0 / PRM(fAnoxia)) : R(0);
+  const R G_iOneMinusAnox = Generic ? (R)(1.0 / (1.0 - PRM(fAnoxia))) : R(0);
+  const R G_anDecomp = Generic ? (R)PRM(anaerobicDecompRate) : R(0);
+  const R G_anExp = Generic ? (R)PRM(anaerobicTransExp) : R(0);
+  const R G_soilCH4 = Generic ? (R)PRM(soilMethaneRate) : R(0);
+  const R G_litCH4 = Generic ? (R)PRM(litterMethaneRate) : R(0);
+  const R G_iSoilCSat = Generic ? (R)(1.0 / PRM(soilCSaturation)) : R(0);
   const double leafOffDay = PRM(leafOffDay) > 0 ? PRM(leafOffDay) : 1e300;  // "never" (sipnet.c:735)
   // rarely needed parameters are re-read from HBM inside their (rare) branches
 #define PRM_RARE(name) ((R)pp[(int64_t)SP_##name * nc])
@@ -126,6 +181,9 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
   double soilWater = ST(soilWater), snow = ST(snow);
   double coarseRootC = ST(coarseRootC), fineRootC = ST(fineRootC);
   double delta = ST(plantCAccountingDelta);
+  double litterC = Generic ? ST(litterC) : 0.0, minN = Generic ? ST(minN) : 0.0;
+  double soilOrgN = Generic ? ST(soilOrgN) : 0.0, litterN = Generic ? ST(litterN) : 0.0;
+  double storN = Generic ? ST(plantStorageN) : 0.0;
   double ringSum = ST(ringSum), totNee = ST(totNee), totGpp = ST(totGpp);
   int phenBits = (int)ST(phenBits);
   int ringValidFrom = (int)ST(ringValidFrom);
@@ -229,11 +287,21 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
     const R eWater = (R)soilWater, eSnow = (R)snow;
     const R eCoarse = (R)coarseRootC, eFine = (R)fineRootC;
     const R totalWoodC = (R)(plantWoodC + delta);
+    const R eLitter = (R)litterC, eMinN = (R)minN, eSoilOrgN = (R)soilOrgN;
+    const R eLitterN = (R)litterN, eStorN = (R)storN;
 
-    auto leafOnLimit = [&](R flux) -> R {  // limitations.c:13-64 (no N cycle here)
+    auto leafOnNFromC = [&](R leafOnC) -> R {  // nitrogen.c:84-86
+      return rmax0(leafOnC * G_iLeafCN - leafOnC * G_iWoodCN);
+    };
+    auto leafOnLimit = [&](R flux) -> R {  // limitations.c:13-64
       const R cDemand = flux * len;
       if (cDemand < R(kTiny)) return flux;
-      const R lim = clip01(fdiv((eWood + eCoarse) * PRM_RARE(leafOnReallocFrac), cDemand));
+      R lim = fdiv((eWood + eCoarse) * PRM_RARE(leafOnReallocFrac), cDemand);
+      if (Generic && F.nitrogen) {
+        const R nDemand = leafOnNFromC(cDemand);
+        if (nDemand > R(kTiny)) lim = rminv(lim, fdiv(eStorN, nDemand));
+      }
+      lim = clip01(lim);
       return lim < R(1) ? flux * lim : flux;
     };
 
@@ -275,7 +343,8 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
     const bool tairPos = (bits & FAST_TAIR_POS) != 0;
     const R rate = (R)q3.y;
     const R rain = tairPos ? rate : R(0), snowFall = tairPos ? R(0) : rate;
-    const R immedEvap = rain * K_immed;
+    R immedEvap = rain * K_immed;
+    if (Generic && F.leafWater) immedEvap = rminv(immedEvap, lai * G_leafPool);  // sipnet.c:872-878
     const R netRain = rain - immedEvap;
 
     // snowPack() sipnet.c:888-946 and bare-soil evaporation sipnet.c:984-1016: a member either
@@ -308,6 +377,10 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
       evaporation = dryOut ? (remaining - R(kTiny)) * invLen : evaporationPot;
       remaining = hasSnow ? remaining : (dryOut ? R(0) : remaining - evaporationPot * len);
       drainage = remaining > K_whc ? (remaining - K_whc) * invLen : R(0);
+      if (Generic && F.flooding) {  // sipnet.c:1019-1027
+        const R excess = remaining - K_whc;
+        drainage = remaining > K_whc ? rminv(excess * G_drainFrac, excess * invLen) : R(0);
+      }
     }
     STAMP(2)
 
@@ -317,7 +390,8 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
     const R vegQ = fexp2((R)q5.y * K_lgVeg, EC);
     R folResp = baseFolResp * (vegQ * K_folShift);
     folResp = frozen ? folResp * K_frozFolEff : folResp;
-    const R rVeg = folResp + K_bvr * totalWoodC * vegQ;
+    R rVeg = folResp + K_bvr * totalWoodC * vegQ;
+    if (Generic && F.growthResp) rVeg += rmax0(G_growthFrac * meanNpp);  // vegResp2(), sipnet.c:1084-1103
 
     // calcWoodAndLeafFluxes(), sipnet.c:756-782
     const R woodLitter = totalWoodC * K_wtr;
@@ -329,7 +403,8 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
     // the events in the one rare block below
     R leafOnCreation = 0, leafOnFromWood = 0;
     if (bits & FAST_PHEN_NEW_YEAR) phenBits = 0;
-    const bool doOn = !(phenBits & 1) && q6.y >= gddLeafOn;
+    const double phenX = (!Generic || F.gdd) ? q6.y : (F.soilPhenol ? q1.y : q7.x);
+    const bool doOn = !(phenBits & 1) && phenX >= gddLeafOn;
     const bool doOff = !(phenBits & 2) && q7.x >= leafOffDay;
 
     // roots, sipnet.c:1176-1196; soil-temperature Q10 factors (depeffects.c:71-74)
@@ -346,10 +421,41 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
     const R rFineRoot = K_bfr * eFine * qFine;
 
     // calcSoilRespiration(), sipnet.c:1132-1148 with depeffects.c:23-87
-    R moistEff = clip01(eWater * K_invWhc);
+    const R fWhc = clip01(eWater * K_invWhc);
+    R moistEff = fWhc;
     if (!PlainExp) moistEff = (K_moistExp == R(1)) ? moistEff : fpow(moistEff, K_moistExp);
-    moistEff = (bits & FAST_TSOIL_NEG) ? R(1) : moistEff;
-    const R rSoil = eSoilC * K_bsr * moistEff * qSoil * (R)q3.x;
+    R anoxic = 0;  // anaerobic share A of depeffects.c:46-57, :89-96
+    if (Generic && F.anaerobic) {
+      anoxic = clip01((fWhc - G_fAnox) * G_iOneMinusAnox);
+      moistEff = (R(1) - anoxic) * clip01(fWhc * G_iFAnox) + G_anDecomp * anoxic;
+    }
+    moistEff = ((bits & FAST_TSOIL_NEG) || (Generic && !F.waterHResp)) ? R(1) : moistEff;
+    R rSoil = eSoilC * K_bsr * moistEff * qSoil * (R)q3.x;
+    // optional pools: calcLitterFluxes() sipnet.c:1150-1171, C:N effect depeffects.c:78-87,
+    // calcMethaneFlux() sipnet.c:1201-1214
+    R rLitter = 0, litterToSoil = 0, soilMethane = 0, litterMethane = 0;
+    R denLitterN = 0, denSoilN = 0;
+    if (Generic) {
+      if (F.nitrogen) {
+        // cn = kCN / (kCN + C/N) = kCN N / (kCN N + C), N floored at TINY (util.c:72-75)
+        denLitterN = eLitterN < R(kTiny) ? R(kTiny) : eLitterN;
+        denSoilN = eSoilOrgN < R(kTiny) ? R(kTiny) : eSoilOrgN;
+        rSoil *= fdiv(G_kCN * denSoilN, G_kCN * denSoilN + eSoilC);
+      }
+      if (F.litterPool) {
+        R breakdown = eLitter * G_lbr * qSoil * moistEff * (R)q3.x;
+        if (F.nitrogen) breakdown *= fdiv(G_kCN * denLitterN, G_kCN * denLitterN + eLitter);
+        rLitter = breakdown * G_flr;
+        litterToSoil = breakdown * (R(1) - G_flr);
+      }
+      if (F.anaerobic) {
+        R mMoist = 0;
+        if (__builtin_amdgcn_ballot_w64(anoxic > R(0) || G_anExp <= R(0)) != 0)
+          mMoist = (anoxic > R(0) || G_anExp <= R(0)) ? fpow(anoxic, G_anExp) : R(0);
+        soilMethane = G_soilCH4 * eSoilC * qSoil * mMoist;
+        if (F.litterPool) litterMethane = G_litCH4 * eLitter * qSoil * mMoist;
+      }
+    }
 
     // checkNegativeCreation(), limitations.c:146-182, as selects
     {
@@ -371,6 +477,7 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
     // the pools and ET, so they are evaluated here, off the common path.  Tillage is folded
     // into the plan.
     R evEvap = 0;
+    R evMinN = 0, evLeafOnTotal = 0;  // event fluxes the N limitations look at (Generic)
     if (__builtin_expect(nEv > 0 || __builtin_amdgcn_ballot_w64(doOn || doOff) != 0, 0)) {
       if (doOn) {
         const R leafOn = leafOnLimit(PRM_RARE(leafGrowth) * invLen);
@@ -385,6 +492,9 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
       }
       R evLeafC = 0, evWoodC = 0, evFineRootC = 0, evCoarseRootC = 0, evSoilWater = 0;
       R evSoilC = 0, evLeafOnCreation = 0, evLeafOnFromWood = 0, evLeafOffLitter = 0;
+      R evLitterC = 0, evSoilOrgN = 0, evLitterN = 0, evLeafOffNResorp = 0;
+      const bool toLitter = Generic && F.litterPool;
+      const bool withN = Generic && F.nitrogen;
       const int ev0 = uni(rareI[3]);
       for (int k = 0; k < nEv; k++) {
         const EvRec& ev = a.events[ev0 + k];
@@ -401,32 +511,132 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
           evCoarseRootC += p3 * invLen;
         } else if (type == SIPNET_EV_HARVEST) {
           const R woodC = totalWoodC;
-          evSoilC += (p3 * (eFine + eCoarse) + p2 * (eLeaf + woodC)) * invLen;
+          if (toLitter) {  // events.c:575-580
+            evLitterC += (p2 * (eLeaf + woodC)) * invLen;
+            evSoilC += (p3 * (eFine + eCoarse)) * invLen;
+          } else {
+            evSoilC += (p3 * (eFine + eCoarse) + p2 * (eLeaf + woodC)) * invLen;
+          }
+          if (withN) {  // events.c:596-620
+            evSoilOrgN += (p3 * (eFine * G_iFineCN + eCoarse * G_iWoodCN)) * invLen;
+            evLitterN += (p2 * (eLeaf * G_iLeafCN + eWood * G_iWoodCN)) * invLen;
+          }
           evLeafC += -eLeaf * (p0 + p2) * invLen;
           evWoodC += -woodC * (p0 + p2) * invLen;
           evFineRootC += -eFine * (p1 + p3) * invLen;
           evCoarseRootC += -eCoarse * (p1 + p3) * invLen;
         } else if (type == SIPNET_EV_FERT) {
-          evSoilC += p1 * invLen;
+          if (toLitter) evLitterC += p1 * invLen;
+          else evSoilC += p1 * invLen;
+          if (withN) {  // events.c:660-672
+            evLitterN += p0 * invLen;
+            evMinN += p2 * invLen;
+          }
         } else if (type == SIPNET_EV_LEAFON) {
           const R flux = leafOnLimit(PRM_RARE(leafGrowth) * invLen);
           evLeafOnCreation += flux;
           const R src = eWood + eCoarse;
           if (src > R(kTiny)) evLeafOnFromWood += fdiv(flux * eWood, src);
         } else if (type == SIPNET_EV_LEAFOFF) {
-          evLeafOffLitter += eLeaf * PRM_RARE(fracLeafFall) * invLen;
+          const R leafOff = eLeaf * PRM_RARE(fracLeafFall);
+          evLeafOffLitter += leafOff * invLen;
+          if (withN) {  // events.c:712-722
+            const R leafN = leafOff * G_iLeafCN;
+            const R resorb = leafN * G_resorb;
+            evLeafOffNResorp += resorb * invLen;
+            evLitterN += (leafN - resorb) * invLen;
+          }
         }
       }
+      evLeafOnTotal = evLeafOnCreation;
       plantWoodC += (double)(evWoodC * len);
       plantLeafC += (double)(evLeafC * len);
       soilC += (double)(evSoilC * len);
       plantWoodC -= (double)(evLeafOnFromWood * len);
       coarseRootC -= (double)((evLeafOnCreation - evLeafOnFromWood) * len);
       plantLeafC += (double)((evLeafOnCreation - evLeafOffLitter) * len);
-      soilC += (double)(evLeafOffLitter * len);
+      if (toLitter) {
+        litterC += (double)(evLitterC * len);
+        litterC += (double)(evLeafOffLitter * len);
+      } else {
+        soilC += (double)(evLeafOffLitter * len);
+      }
       coarseRootC += (double)(evCoarseRootC * len);
       fineRootC += (double)(evFineRootC * len);
       soilWater += (double)(evSoilWater * len);
+      if (withN) {  // events.c:778-789
+        minN += (double)(evMinN * len);
+        soilOrgN += (double)(evSoilOrgN * len);
+        litterN += (double)(evLitterN * len);
+        storN += (double)((evLeafOffNResorp - leafOnNFromC(evLeafOnCreation)) * len);
+      }
+    }
+
+    // nitrogen cycle: nitrogen.c:15-207 with limitations.c:69-139 (after the phenology switches
+    // and the events, whose leaf-on and mineral-N fluxes it looks at)
+    R nVolatilization = 0, nLeaching = 0, nOrgSoil = 0, nOrgLitter = 0, nMin = 0;
+    R nFixation = 0, nUptake = 0, leafOffNResorption = 0, reductionNResorption = 0;
+    if (Generic && F.nitrogen) {
+      auto plantNDemand = [&]() -> R {  // nitrogen.c:89-104
+        return rmax0(woodCreation * G_iWoodCN + leafCreation * G_iLeafCN +
+                     fineRootCreation * G_iFineCN + coarseRootCreation * G_iWoodCN);
+      };
+      // unclaimed storage nitrogen.c:127-134, fixation share nitrogen.c:137-152
+      const R unclaimed = rmax0(eStorN - leafOnNFromC(leafOnCreation + evLeafOnTotal) * len);
+      const R fixDen = G_halfNFix + eMinN;
+      const R fixFrac = G_nFixMax * ((fixDen < R(kTiny)) ? R(1) : fdiv(G_halfNFix, fixDen));
+      auto fixationAndUptake = [&]() {  // nitrogen.c:155-168
+        const R rem = rmax0(plantNDemand() - unclaimed * invLen);
+        nFixation = fixFrac * rem;
+        nUptake = (R(1) - fixFrac) * rem;
+      };
+      // resorption, nitrogen.c:170-196
+      if (woodCreation + leafCreation + fineRootCreation + coarseRootCreation < R(0)) {
+        reductionNResorption -= (leafCreation * G_iLeafCN + woodCreation * G_iWoodCN +
+                                 coarseRootCreation * G_iWoodCN + fineRootCreation * G_iFineCN);
+      }
+      leafOffNResorption = G_resorb * leafLitter * G_iLeafCN;
+      // volatilisation nitrogen.c:15-26, leaching nitrogen.c:31-41
+      nVolatilization = G_nVol * eMinN * qSoil * (R(0.05) + R(3.8) * anoxic * (R(1) - anoxic));
+      nLeaching = eMinN * rminv(drainage * K_invWhc, R(1)) * G_nLeach;
+      // pool fluxes, nitrogen.c:45-82: x / (C/N) = x * N / C
+      {
+        const R iLitterCN = fdiv(denLitterN, eLitter);
+        const R iSoilCN = fdiv(denSoilN, eSoilC);
+        const R litterMin = rLitter * iLitterCN;
+        const R soilMin = rSoil * iSoilCN;
+        const R soilNInputs = litterToSoil * iLitterCN + fineRootLoss * G_iFineCN +
+                              coarseRootLoss * G_iWoodCN;
+        const R sat = F.carbonSat ? clip01(eSoilC * G_iSoilCSat) : R(0);
+        nOrgLitter = leafLitter * G_iLeafCN - leafOffNResorption + woodLitter * G_iWoodCN -
+                     litterMin - litterToSoil * iLitterCN + (soilNInputs * sat);
+        nOrgSoil = soilNInputs * (R(1) - sat) - soilMin;
+        nMin = litterMin + soilMin;
+      }
+      fixationAndUptake();
+      // checkMineralNLimitation, limitations.c:119-129
+      {
+        const R pool = eMinN + (nMin + evMinN) * len;
+        const R loss = (nLeaching + nVolatilization) * len;
+        const R red = (loss > R(kTiny) && loss > pool) ? fdiv(pool, loss) : R(1);
+        nLeaching *= red;
+        nVolatilization *= red;
+      }
+      // checkNitrogenLimitation, limitations.c:69-114
+      {
+        const R uptakeDemand = nUptake * len;
+        const R availableMinN = eMinN + (nMin - nVolatilization - nLeaching) * len;
+        const bool limited = uptakeDemand > R(kTiny) && uptakeDemand > availableMinN;
+        if (__builtin_amdgcn_ballot_w64(limited) != 0) {
+          const R demand = plantNDemand() * len;
+          const R red = limited ? fdiv(fdiv(availableMinN, R(1) - fixFrac) + unclaimed, demand) : R(1);
+          woodCreation *= red;
+          leafCreation *= red;
+          fineRootCreation *= red;
+          coarseRootCreation *= red;
+          fixationAndUptake();  // unchanged where red = 1
+        }
+      }
     }
     // ---- 3. pools (sipnet.c:1769-1806) ------------------------------------------------
     {
@@ -438,10 +648,32 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
       soilWater += (double)((rain + snowMelt - immedEvap - fastFlow - evaporation -
                              transpiration - drainage) * len);
       snow += (double)((snowFall - snowMelt - sublimation) * len);
-      soilC += (double)((coarseRootLoss + fineRootLoss + woodLitter + leafLitter - rSoil) * len);
+      if (Generic && F.litterPool) {  // updatePoolsForSoil(), sipnet.c:1645-1668
+        const R soilInputs = coarseRootLoss + fineRootLoss + litterToSoil;
+        // the soil carbon the reference looks at here already holds this step's event fluxes
+        const R sat = F.carbonSat ? clip01((R)soilC * G_iSoilCSat) : R(0);
+        litterC += (double)((woodLitter + leafLitter + (soilInputs * sat) - litterToSoil -
+                             rLitter - litterMethane) * len);
+        soilC += (double)((soilInputs * (R(1) - sat) - rSoil - soilMethane) * len);
+      } else if (Generic) {
+        soilC += (double)((coarseRootLoss + fineRootLoss + woodLitter + leafLitter - rSoil -
+                           soilMethane) * len);
+      } else {
+        soilC += (double)((coarseRootLoss + fineRootLoss + woodLitter + leafLitter - rSoil) * len);
+      }
       coarseRootC += (double)((coarseRootCreation - coarseRootLoss -
                                (leafOnCreation - leafOnFromWood)) * len);
       fineRootC += (double)((fineRootCreation - fineRootLoss) * len);
+      if (Generic && F.nitrogen) {  // updateNitrogenPools(), nitrogen.c:210-239
+        const R demand = rmax0(woodCreation * G_iWoodCN + leafCreation * G_iLeafCN +
+                               fineRootCreation * G_iFineCN + coarseRootCreation * G_iWoodCN);
+        const R storageDemand = demand - nUptake - nFixation;
+        storN += (double)((leafOffNResorption + reductionNResorption - storageDemand -
+                           leafOnNFromC(leafOnCreation)) * len);
+        minN += (double)(((nMin - nVolatilization - nLeaching) - nUptake) * len);
+        soilOrgN += (double)(nOrgSoil * len);
+        litterN += (double)(nOrgLitter * len);
+      }
     }
 
     // checkForMortality(), sipnet.c:1688-1767: only a change of the alive flag does anything
@@ -456,7 +688,13 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
           alive = false;
           if (diedAt < 0) diedAt = t;
           soilC += fineRootC + coarseRootC;
-          soilC += plantWoodC + plantLeafC + delta;
+          if (Generic && F.litterPool) litterC += plantWoodC + plantLeafC + delta;
+          else soilC += plantWoodC + plantLeafC + delta;
+          if (Generic && F.nitrogen) {  // sipnet.c:1735-1746
+            soilOrgN += fineRootC * (double)G_iFineCN + coarseRootC * (double)G_iWoodCN;
+            litterN += plantWoodC * (double)G_iWoodCN + plantLeafC * (double)G_iLeafCN + storN;
+            storN = 0.0;
+          }
           plantWoodC = 0.0;
           plantLeafC = 0.0;
           coarseRootC = 0.0;
@@ -475,11 +713,18 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
     fineRootC = rmax0(fineRootC);
     soilWater = rmax0(soilWater);
     snow = snow < kTiny ? 0.0 : snow;
+    if (Generic) {
+      litterC = rmax0(litterC);
+      minN = rmax0(minN);
+      soilOrgN = rmax0(soilOrgN);
+      litterN = rmax0(litterN);
+      storN = rmax0(storN);
+    }
     STAMP(4)
 
     // ---- 4. outputs: updateTrackers(), sipnet.c:1420-1496 ---------------------------
     const R tGpp = photosynthesis * len;
-    const R tRh = rSoil * len;
+    const R tRh = Generic ? (rLitter + rSoil) * len : rSoil * len;
     const R tRa = (rCoarseRoot + rFineRoot) * len + rVeg * len;
     const R tNee = R(-1.0) * ((tGpp - tRa) - tRh);
     const R tEt = (transpiration + immedEvap + evaporation + sublimation + evEvap) * len;
@@ -559,6 +804,13 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
     ST(coarseRootC) = coarseRootC;
     ST(fineRootC) = fineRootC;
     ST(plantCAccountingDelta) = delta;
+    if (Generic) {
+      ST(litterC) = litterC;
+      ST(minN) = minN;
+      ST(soilOrgN) = soilOrgN;
+      ST(litterN) = litterN;
+      ST(plantStorageN) = storN;
+    }
     ST(ringSum) = ringSum;
     ST(totNee) = totNee;
     ST(totGpp) = totGpp;
@@ -580,12 +832,15 @@ extern "C" int sipnet_debug_read_stamps(unsigned long long* out) {
 void launchStepFast(const FastArgs& a, int precision, hipStream_t stream) {
   const int chunksPerSite = (a.n_members + 63) / 64;
   const int grid = a.n_sites * chunksPerSite;
-  if (precision == SIPNET_F64) {
-    if (a.plainExp) hipLaunchKernelGGL((stepFastKernel<double, true>), dim3(grid), dim3(64), 0, stream, a);
-    else hipLaunchKernelGGL((stepFastKernel<double, false>), dim3(grid), dim3(64), 0, stream, a);
+  if (!isDefaultFlagSet(a.flags)) {  // any other flag set: the run-time-flag instantiation
+    if (precision == SIPNET_F64) hipLaunchKernelGGL((stepFastKernel<double, false, true>), dim3(grid), dim3(64), 0, stream, a);
+    else hipLaunchKernelGGL((stepFastKernel<float, false, true>), dim3(grid), dim3(64), 0, stream, a);
+  } else if (precision == SIPNET_F64) {
+    if (a.plainExp) hipLaunchKernelGGL((stepFastKernel<double, true, false>), dim3(grid), dim3(64), 0, stream, a);
+    else hipLaunchKernelGGL((stepFastKernel<double, false, false>), dim3(grid), dim3(64), 0, stream, a);
   } else {
-    if (a.plainExp) hipLaunchKernelGGL((stepFastKernel<float, true>), dim3(grid), dim3(64), 0, stream, a);
-    else hipLaunchKernelGGL((stepFastKernel<float, false>), dim3(grid), dim3(64), 0, stream, a);
+    if (a.plainExp) hipLaunchKernelGGL((stepFastKernel<float, true, false>), dim3(grid), dim3(64), 0, stream, a);
+    else hipLaunchKernelGGL((stepFastKernel<float, false, false>), dim3(grid), dim3(64), 0, stream, a);
   }
 }
 

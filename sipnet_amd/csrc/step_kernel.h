@@ -77,7 +77,7 @@ struct SetupArgs {
   const int32_t* siteStatus;  // [n_sites] plan status (site-fatal conditions)
 };
 
-// arguments of the throughput kernels (step_fast.hip): default flags, lean outputs
+// arguments of the throughput kernels (step_fast.hip, step_coop.hip): lean outputs
 struct FastArgs {
   const FastRec* fast;    // [n_sites][n_steps_total] (+ kFastTile records of padding)
   const RingOp* ringOps;
@@ -92,6 +92,8 @@ struct FastArgs {
   int32_t n_sites, n_members, n_steps_total, step0, n_steps;
   void* scratchRow;  // [ncol] doubles: target of the stores of planes the caller left NULL
   int32_t plainExp;  // 1: every member has dVpdExp == 2 and soilRespMoistEffect == 1
+  int32_t flags[SIPNET_NFLAGS];  // model flags; anything but the default set selects the
+                                 // run-time-flag instantiation of the one-wave kernel
 };
 void launchStepFast(const FastArgs& a, int precision, hipStream_t stream);
 // three cooperating wavefronts per 64 members (step_coop.hip); same results as launchStepFast

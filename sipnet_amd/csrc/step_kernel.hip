@@ -858,7 +858,9 @@ __global__ __launch_bounds__(64) void stepKernel(KernelArgs a) {
     {
       if (F.litterPool) {
         const R soilInputs = coarseRootLoss + fineRootLoss + litterToSoil;
-        const R sat = F.carbonSaturation ? unitClip(eSoilC / soilCSaturation) : R(0);
+        // envi.soilC at this point already holds this step's event fluxes (events.c:744-790
+        // runs first), unlike the start-of-step value the nitrogen fluxes saw
+        const R sat = F.carbonSaturation ? unitClip((R)soilC / soilCSaturation) : R(0);
         litterC += (double)((woodLitter + leafLitter + (soilInputs * sat) - litterToSoil -
                              rLitter - litterMethane) * len);
         soilC += (double)((soilInputs * (R(1) - sat) - rSoil - soilMethane) * len);

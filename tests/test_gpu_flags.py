@@ -1,0 +1,183 @@
+"""GPU parity of the throughput kernel's run-time-flag instantiation (step_fast.hip,
+Generic = true): every optional model flag of the reference (context.c:35-53 -- litter pool,
+nitrogen cycle, anaerobic / methane, carbon saturation, flooding, growth respiration, leaf
+water, soil-temperature and calendar phenology, no moisture effect on heterotrophic
+respiration) through the lean launch that bench-style callers use, against the oracle on the
+same members, climate and events.  Tolerance: 1e-9 absolute on the flux planes
+(gC or cm per step; the reference's own tolerance is 1e-6, tUtils.h:57-59), 1e-9 relative on
+the final pools."""
+import os
+
+import numpy as np
+import pytest
+
+import sipnet_amd as sa
+from sipnet_amd import synth
+from sipnet_amd.config import param_index
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+BASE = os.path.join(helpers.GOLDEN, "synth", "allflags.param")  # every optional parameter set
+POOLS = slice(14, 27)  # record columns holding the 13 pools (include/sipnet_amd.h)
+
+
+def lean_run(flags, clim, members, events=None, fast=True, prec=sa.F64):
+    os.environ["SIPNET_FAST_MATH"] = "1" if fast else "0"
+    b = sa.Batch(flags, 1, members.shape[0], prec)
+    if events is not None:
+        b.set_events(0, events)
+    b.set_climate(0, clim)
+    b.set_params(0, members)
+    b.setup()
+    planes, _ = b.run()
+    status = b.get_status()
+    name = ""
+    state = b.get_state()
+    got = planes.cpu().numpy()
+    b.close()
+    return got, state, status, name
+
+
+def compare(tag, got, state, want, final):
+    d = np.abs(got - want).max()
+    pools_g = state[:, :13]
+    pools_o = final[:, POOLS]
+    scale = np.maximum(np.abs(pools_o), 1e-3)
+    dp = (np.abs(pools_g - pools_o) / scale).max()
+    print(f"{tag}: max|d planes| {d:.3e}  max rel d pools {dp:.3e}")
+    assert np.isfinite(got).all()
+    assert d < 1e-9
+    assert dp < 1e-9
+
+
+@pytest.mark.parametrize("case_name", ["russell_2", "russell_3"])
+def test_smoke_cases_with_optional_flags(case_name, oracle, tmp_path):
+    """russell_2 = litter pool + nitrogen cycle + anaerobic with the full event file;
+    russell_3 = growth respiration + leaf water + litter pool, no moisture effect."""
+    case = helpers.load_smoke_case(case_name, str(tmp_path))
+    names = {"aMax", "soilWHC", "wueConst", "baseVegResp", "leafCN", "kCN", "litterBreakdownRate"}
+    members = synth.perturbed_params(case["params"], 70, names=names)
+    got, state, status, _ = lean_run(case["flags"], case["clim"], members, case["events"])
+    want, final, st = oracle.run_block(case["flags"], members, case["clim"], case["events"])
+    assert (st == 0).all() and (np.asarray(status) == 0).all()
+    compare(case_name, got, state, want, final)
+
+
+def _events_all_types(clim):
+    ev = []
+
+    def add(day, typ, *p):
+        e = sa.Event()
+        e.type = typ
+        e.year = int(clim.year[0])
+        e.day = day
+        for i, v in enumerate(p):
+            e.p[i] = v
+        ev.append(e)
+
+    FERT, HARVEST, IRRIG, PLANT, TILL, LEAFON, LEAFOFF = range(7)  # include/sipnet_amd.h:91-97
+    add(40, FERT, 12.0, 40.0, 6.0)                # org-N, org-C, min-N
+    add(45, TILL, 0.3)
+    add(120, IRRIG, 2.5, 0)                       # canopy irrigation
+    add(121, IRRIG, 1.5, 1)                       # soil irrigation
+    add(130, LEAFON)
+    add(200, HARVEST, 0.2, 0.05, 0.3, 0.1)
+    add(205, PLANT, 10.0, 30.0, 5.0, 8.0)
+    add(206, FERT, 0.0, 0.0, 20.0)
+    add(300, LEAFOFF)
+    return ev
+
+
+_flags = sa.flags_from
+F_EVENTS = sa.FLAG_NAMES.index("events")
+
+FLAG_SETS = {
+    "growth_resp": dict(growthResp=1),
+    "leaf_water": dict(leafWater=1),
+    "litter_pool": dict(litterPool=1),
+    "no_water_hresp": dict(waterHResp=0),
+    "anaerobic": dict(anaerobic=1),
+    "anaerobic_litter": dict(anaerobic=1, litterPool=1),
+    "flooding": dict(flooding=1),
+    "carbon_saturation": dict(litterPool=1, carbonSaturation=1),
+    "soil_phenol": dict(gdd=0, soilPhenol=1),
+    "calendar_phenology": dict(gdd=0),
+    "no_events": dict(events=0),
+    "nitrogen": dict(litterPool=1, anaerobic=1, nitrogenCycle=1),
+    "everything": dict(litterPool=1, anaerobic=1, nitrogenCycle=1, carbonSaturation=1,
+                       flooding=1, growthResp=1, leafWater=1),
+}
+ALL_ON = dict(litterPool=1, anaerobic=1, nitrogenCycle=1, carbonSaturation=1, flooding=1,
+              growthResp=1, leafWater=1, soilPhenol=1)
+
+
+@pytest.fixture(scope="module")
+def clim60():
+    """one synthetic half-hourly year (SURVEY 8d generator): winter snow, leaf-on by GDD / soil
+    temperature / calendar, summer drought stress, leaf-off"""
+    return synth.convert_raw(synth.round_like_file(synth.half_hourly_year_raw(17520)))
+
+
+@pytest.fixture(scope="module")
+def members70():
+    """70 members (one full chunk + a ragged one): the throughput benchmark's perturbation plus
+    log-normal spread on the parameters only the optional flags read"""
+    base = sa.read_params(BASE, _flags(**ALL_ON))[0]
+    out = synth.perturbed_params(base, 70)
+    rng = np.random.default_rng(77)
+    for name in ["leafCN", "woodCN", "fineRootCN", "kCN", "litterBreakdownRate",
+                 "fracLitterRespired", "fAnoxia", "mineralNInit", "soilOrgNInit", "litterOrgNInit",
+                 "plantStorageNInit", "nVolatilizationFrac", "nLeachingFrac",
+                 "halfNFixationMax", "growthRespFrac", "leafPoolDepth", "waterDrainFrac",
+                 "soilCSaturation", "soilMethaneRate", "litterMethaneRate",
+                 "anaerobicTransExp", "leafNResorptionFrac"]:
+        k = param_index(name)
+        assert k >= 0, name
+        f = np.exp(rng.normal(0.0, 0.15, 70))
+        f[0] = 1.0
+        v = out[:, k] * f
+        if name in ("fracLitterRespired", "fAnoxia", "leafNResorptionFrac", "nVolatilizationFrac",
+                    "nLeachingFrac"):
+            v = np.clip(v, 0.0, 0.95)
+        out[:, k] = v
+    # carbon saturation level around the soil carbon stock, so that the unit clip is exercised on
+    # both sides; partial flood drainage
+    out[:, param_index("soilCSaturation")] = out[:, param_index("soilInit")] * rng.uniform(0.5, 3.0, 70)
+    out[:, param_index("waterDrainFrac")] = rng.uniform(0.2, 1.0, 70)
+    # the synthetic soil temperature peaks near 10 C: thresholds the members cross on different days
+    out[:, param_index("soilTempLeafOn")] = rng.uniform(4.0, 9.0, 70)
+    return out
+
+
+@pytest.mark.parametrize("name", list(FLAG_SETS))
+def test_each_flag_set_matches_oracle(name, oracle, clim60, members70):
+    flags = _flags(**FLAG_SETS[name])
+    ev = _events_all_types(clim60) if flags[F_EVENTS] else None
+    got, state, status, _ = lean_run(flags, clim60, members70, ev)
+    want, final, st = oracle.run_block(flags, members70, clim60, ev)
+    assert (st == 0).all() and (np.asarray(status) == 0).all()
+    compare(name, got, state, want, final)
+
+
+def test_generic_throughput_kernel_agrees_with_strict_kernel(clim60, members70):
+    flags = _flags(**FLAG_SETS["everything"])
+    ev = _events_all_types(clim60)
+    g_fast, s_fast, _, _ = lean_run(flags, clim60, members70, ev, fast=True)
+    g_strict, s_strict, _, _ = lean_run(flags, clim60, members70, ev, fast=False)
+    d = np.abs(g_fast - g_strict).max()
+    print("generic throughput vs strict kernel: max|d|", d)
+    assert d < 1e-9
+    assert np.allclose(s_fast[:, :13], s_strict[:, :13], rtol=1e-9, atol=1e-9)
+
+
+def test_fp32_mixed_with_nitrogen_cycle(oracle, clim60, members70):
+    """fp32 flux arithmetic over fp64 pools: same tolerance class as the default-flag fp32 test."""
+    flags = _flags(**FLAG_SETS["nitrogen"])
+    ev = _events_all_types(clim60)
+    got, state, status, _ = lean_run(flags, clim60, members70, ev, prec=sa.F32_MIXED)
+    want, final, st = oracle.run_block(flags, members70, clim60, ev)
+    scale = np.abs(want).max(axis=(1, 2), keepdims=True)
+    rel = (np.abs(got - want) / scale).max()
+    print("fp32-mixed, nitrogen cycle: max |d| / max|plane|", rel)
+    assert np.isfinite(got).all()
+    assert rel < 2e-3
