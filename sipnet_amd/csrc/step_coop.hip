@@ -332,7 +332,8 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
             haveQ = true;
           }
           R moistEff = clip01(eWater * K_invWhc);
-          if (!PlainExp) moistEff = (K_moistExp == R(1)) ? moistEff : fpow(moistEff, K_moistExp);
+          if (!PlainExp && __builtin_amdgcn_ballot_w64(K_moistExp != R(1)) != 0)  // pow only where some member needs it
+      moistEff = (K_moistExp == R(1)) ? moistEff : fpow(moistEff, K_moistExp);
           moistEff = (bits & FAST_TSOIL_NEG) ? R(1) : moistEff;
           const R fSoil = K_bsr * moistEff * qSoil * (R)q3.x;
           post5(&mailFac[t & 1][0][lane], &seqFac, g1, g2, fSoil, gFine, gCoarse, t);

@@ -58,28 +58,48 @@ __device__ unsigned long long g_stamps[16];
 // limitations.c:69-139, depeffects.c:23-96, sipnet.c:1084-1103, :1150-1171, :1201-1214,
 // :1645-1668) under wave-uniform run-time flags, with the same conventions: reciprocals of the
 // per-member C:N ratios hoisted out of the loop, divisions by pools through v_rcp + Newton.
-template <bool G>
+//
+// Mode: kFlagsDefault = the reference's default flag set compiled in; kFlagsRuntime = flags
+// read from the launch arguments (wave-uniform branches); kFlagsNCycle = the nitrogen-cycle
+// configuration (litter pool + anaerobic + nitrogen cycle on top of the defaults -- what
+// nitrogen-cycle requires, context.c:203-212) compiled in, so that its flag tests cost no
+// branches either.
+enum : int { kFlagsDefault = 0, kFlagsRuntime = 1, kFlagsNCycle = 2 };
+template <int Mode>
 struct FastFlags {
   bool gdd, growthResp, leafWater, litterPool, soilPhenol, waterHResp, nitrogen, anaerobic,
       flooding, carbonSat;
   __device__ explicit FastFlags(const int32_t* f) {
-    auto get = [&](int i, bool dflt) { return G ? (f[i] != 0) : dflt; };  // context.c:35-53
-    gdd = get(SIPNET_F_GDD, true);
-    growthResp = get(SIPNET_F_GROWTH_RESP, false);
-    leafWater = get(SIPNET_F_LEAF_WATER, false);
-    litterPool = get(SIPNET_F_LITTER_POOL, false);
-    soilPhenol = get(SIPNET_F_SOIL_PHENOL, false);
-    waterHResp = get(SIPNET_F_WATER_HRESP, true);
-    nitrogen = get(SIPNET_F_NITROGEN_CYCLE, false);
-    anaerobic = get(SIPNET_F_ANAEROBIC, false);
-    flooding = get(SIPNET_F_FLOODING, false);
-    carbonSat = get(SIPNET_F_CARBON_SATURATION, false);
+    auto get = [&](int i, bool dflt, bool nset) {  // defaults: context.c:35-53
+      return Mode == kFlagsRuntime ? (f[i] != 0) : (Mode == kFlagsNCycle ? nset : dflt);
+    };
+    gdd = get(SIPNET_F_GDD, true, true);
+    growthResp = get(SIPNET_F_GROWTH_RESP, false, false);
+    leafWater = get(SIPNET_F_LEAF_WATER, false, false);
+    litterPool = get(SIPNET_F_LITTER_POOL, false, true);
+    soilPhenol = get(SIPNET_F_SOIL_PHENOL, false, false);
+    waterHResp = get(SIPNET_F_WATER_HRESP, true, true);
+    nitrogen = get(SIPNET_F_NITROGEN_CYCLE, false, true);
+    anaerobic = get(SIPNET_F_ANAEROBIC, false, true);
+    flooding = get(SIPNET_F_FLOODING, false, false);
+    carbonSat = get(SIPNET_F_CARBON_SATURATION, false, false);
   }
 };
+bool isNCycleFlagSet(const int32_t* f) {
+  for (int i = 0; i < SIPNET_NFLAGS; i++) {
+    if (i == SIPNET_F_SNOW) continue;  // snow only gates a parameter's required-ness
+    const bool want = i == SIPNET_F_EVENTS || i == SIPNET_F_GDD || i == SIPNET_F_WATER_HRESP ||
+                      i == SIPNET_F_LITTER_POOL || i == SIPNET_F_NITROGEN_CYCLE ||
+                      i == SIPNET_F_ANAEROBIC;
+    if ((f[i] != 0) != want) return false;
+  }
+  return true;
+}
 
-template <class R, bool PlainExp, bool Generic>
+template <class R, bool PlainExp, int Mode>
 __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
-  const FastFlags<Generic> F(a.flags);
+  constexpr bool Generic = Mode != kFlagsDefault;
+  const FastFlags<Mode> F(a.flags);
   // LDS: two tiles of kFastTile site records (2 x 4 KB).  ONE __shared__ object.
   __shared__ alignas(16) unsigned char lds[2 * kFastTile * sizeof(FastRec)];
 
@@ -146,11 +166,16 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
   const double gddLeafOn = !Generic || F.gdd ? PRM(gddLeafOn)
                            : F.soilPhenol    ? PRM(soilTempLeafOn)
                                              : (PRM(leafOnDay) > 0 ? PRM(leafOnDay) : 1e300);
-  // optional-flag parameters (Generic only; dead code otherwise)
-  const R G_growthFrac = Generic ? (R)PRM(growthRespFrac) : R(0);
+  // Optional-flag parameters (Generic only; dead code otherwise).  A taken branch costs a lone
+  // wavefront an instruction-fetch restart, so the small options are not branched around: with
+  // the flag off their parameter takes a neutral value (rate 0, cap "infinite") and the same
+  // few instructions run to an exactly unchanged result; only the nitrogen cycle and the
+  // methane pow() sit behind wave-uniform branches.
+  constexpr double kNoCap = 3.0e38;  // finite in fp32 too
+  const R G_growthFrac = Generic && F.growthResp ? (R)PRM(growthRespFrac) : R(0);
   const R G_leafPool = Generic ? (R)PRM(leafPoolDepth) : R(0);
-  const R G_drainFrac = Generic ? (R)PRM(waterDrainFrac) : R(0);
-  const R G_lbr = Generic ? (R)PRM(litterBreakdownRate) : R(0);
+  const R G_drainFrac = Generic && F.flooding ? (R)PRM(waterDrainFrac) : R(kNoCap);
+  const R G_lbr = Generic && F.litterPool ? (R)PRM(litterBreakdownRate) : R(0);
   const R G_flr = Generic ? (R)PRM(fracLitterRespired) : R(0);
   const R G_nVol = Generic ? (R)PRM(nVolatilizationFrac) : R(0);
   const R G_nLeach = Generic ? (R)PRM(nLeachingFrac) : R(0);
@@ -166,8 +191,8 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
   const R G_iOneMinusAnox = Generic ? (R)(1.0 / (1.0 - PRM(fAnoxia))) : R(0);
   const R G_anDecomp = Generic ? (R)PRM(anaerobicDecompRate) : R(0);
   const R G_anExp = Generic ? (R)PRM(anaerobicTransExp) : R(0);
-  const R G_soilCH4 = Generic ? (R)PRM(soilMethaneRate) : R(0);
-  const R G_litCH4 = Generic ? (R)PRM(litterMethaneRate) : R(0);
+  const R G_soilCH4 = Generic && F.anaerobic ? (R)PRM(soilMethaneRate) : R(0);
+  const R G_litCH4 = Generic && F.anaerobic && F.litterPool ? (R)PRM(litterMethaneRate) : R(0);
   const R G_iSoilCSat = Generic ? (R)(1.0 / PRM(soilCSaturation)) : R(0);
   const double leafOffDay = PRM(leafOffDay) > 0 ? PRM(leafOffDay) : 1e300;  // "never" (sipnet.c:735)
   // rarely needed parameters are re-read from HBM inside their (rare) branches
@@ -344,7 +369,7 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
     const R rate = (R)q3.y;
     const R rain = tairPos ? rate : R(0), snowFall = tairPos ? R(0) : rate;
     R immedEvap = rain * K_immed;
-    if (Generic && F.leafWater) immedEvap = rminv(immedEvap, lai * G_leafPool);  // sipnet.c:872-878
+    if (Generic) immedEvap = rminv(immedEvap, F.leafWater ? lai * G_leafPool : R(kNoCap));  // sipnet.c:872-878
     const R netRain = rain - immedEvap;
 
     // snowPack() sipnet.c:888-946 and bare-soil evaporation sipnet.c:984-1016: a member either
@@ -377,7 +402,7 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
       evaporation = dryOut ? (remaining - R(kTiny)) * invLen : evaporationPot;
       remaining = hasSnow ? remaining : (dryOut ? R(0) : remaining - evaporationPot * len);
       drainage = remaining > K_whc ? (remaining - K_whc) * invLen : R(0);
-      if (Generic && F.flooding) {  // sipnet.c:1019-1027
+      if (Generic) {  // flooding, sipnet.c:1019-1027 (no cap with the flag off)
         const R excess = remaining - K_whc;
         drainage = remaining > K_whc ? rminv(excess * G_drainFrac, excess * invLen) : R(0);
       }
@@ -391,7 +416,7 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
     R folResp = baseFolResp * (vegQ * K_folShift);
     folResp = frozen ? folResp * K_frozFolEff : folResp;
     R rVeg = folResp + K_bvr * totalWoodC * vegQ;
-    if (Generic && F.growthResp) rVeg += rmax0(G_growthFrac * meanNpp);  // vegResp2(), sipnet.c:1084-1103
+    if (Generic) rVeg += rmax0(G_growthFrac * meanNpp);  // vegResp2(), sipnet.c:1084-1103 (+0 when off)
 
     // calcWoodAndLeafFluxes(), sipnet.c:756-782
     const R woodLitter = totalWoodC * K_wtr;
@@ -423,11 +448,13 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
     // calcSoilRespiration(), sipnet.c:1132-1148 with depeffects.c:23-87
     const R fWhc = clip01(eWater * K_invWhc);
     R moistEff = fWhc;
-    if (!PlainExp) moistEff = (K_moistExp == R(1)) ? moistEff : fpow(moistEff, K_moistExp);
+    if (!PlainExp && __builtin_amdgcn_ballot_w64(K_moistExp != R(1)) != 0)  // pow only where some member needs it
+      moistEff = (K_moistExp == R(1)) ? moistEff : fpow(moistEff, K_moistExp);
     R anoxic = 0;  // anaerobic share A of depeffects.c:46-57, :89-96
-    if (Generic && F.anaerobic) {
-      anoxic = clip01((fWhc - G_fAnox) * G_iOneMinusAnox);
-      moistEff = (R(1) - anoxic) * clip01(fWhc * G_iFAnox) + G_anDecomp * anoxic;
+    if (Generic) {
+      anoxic = F.anaerobic ? clip01((fWhc - G_fAnox) * G_iOneMinusAnox) : R(0);
+      const R anMoist = (R(1) - anoxic) * clip01(fWhc * G_iFAnox) + G_anDecomp * anoxic;
+      moistEff = F.anaerobic ? anMoist : moistEff;
     }
     moistEff = ((bits & FAST_TSOIL_NEG) || (Generic && !F.waterHResp)) ? R(1) : moistEff;
     R rSoil = eSoilC * K_bsr * moistEff * qSoil * (R)q3.x;
@@ -436,25 +463,26 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
     R rLitter = 0, litterToSoil = 0, soilMethane = 0, litterMethane = 0;
     R denLitterN = 0, denSoilN = 0;
     if (Generic) {
+      R cnSoil = 1, cnLitter = 1;
       if (F.nitrogen) {
         // cn = kCN / (kCN + C/N) = kCN N / (kCN N + C), N floored at TINY (util.c:72-75)
         denLitterN = eLitterN < R(kTiny) ? R(kTiny) : eLitterN;
         denSoilN = eSoilOrgN < R(kTiny) ? R(kTiny) : eSoilOrgN;
-        rSoil *= fdiv(G_kCN * denSoilN, G_kCN * denSoilN + eSoilC);
+        cnSoil = fdiv(G_kCN * denSoilN, G_kCN * denSoilN + eSoilC);
+        cnLitter = fdiv(G_kCN * denLitterN, G_kCN * denLitterN + eLitter);
       }
-      if (F.litterPool) {
-        R breakdown = eLitter * G_lbr * qSoil * moistEff * (R)q3.x;
-        if (F.nitrogen) breakdown *= fdiv(G_kCN * denLitterN, G_kCN * denLitterN + eLitter);
-        rLitter = breakdown * G_flr;
-        litterToSoil = breakdown * (R(1) - G_flr);
+      rSoil *= cnSoil;
+      // without a litter pool the pool is empty and its rate 0: both fluxes come out as 0
+      const R breakdown = eLitter * G_lbr * qSoil * moistEff * (R)q3.x * cnLitter;
+      rLitter = breakdown * G_flr;
+      litterToSoil = breakdown * (R(1) - G_flr);
+      R mMoist = anoxic * anoxic;  // pow(A, anaerobicTransExp) with the usual exponent 2
+      if (__builtin_expect(F.anaerobic && __builtin_amdgcn_ballot_w64(G_anExp != R(2)) != 0, 0)) {
+        const bool general = G_anExp != R(2) && (anoxic > R(0) || G_anExp <= R(0));
+        mMoist = general ? fpow(anoxic, G_anExp) : (G_anExp != R(2) ? R(0) : mMoist);
       }
-      if (F.anaerobic) {
-        R mMoist = 0;
-        if (__builtin_amdgcn_ballot_w64(anoxic > R(0) || G_anExp <= R(0)) != 0)
-          mMoist = (anoxic > R(0) || G_anExp <= R(0)) ? fpow(anoxic, G_anExp) : R(0);
-        soilMethane = G_soilCH4 * eSoilC * qSoil * mMoist;
-        if (F.litterPool) litterMethane = G_litCH4 * eLitter * qSoil * mMoist;
-      }
+      soilMethane = G_soilCH4 * eSoilC * qSoil * mMoist;  // rates are 0 with the flag off
+      litterMethane = G_litCH4 * eLitter * qSoil * mMoist;
     }
 
     // checkNegativeCreation(), limitations.c:146-182, as selects
@@ -637,6 +665,15 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
           fixationAndUptake();  // unchanged where red = 1
         }
       }
+      // updateNitrogenPools(), nitrogen.c:210-239 (the creation fluxes are final here)
+      {
+        const R storageDemand = plantNDemand() - nUptake - nFixation;
+        storN += (double)((leafOffNResorption + reductionNResorption - storageDemand -
+                           leafOnNFromC(leafOnCreation)) * len);
+        minN += (double)(((nMin - nVolatilization - nLeaching) - nUptake) * len);
+        soilOrgN += (double)(nOrgSoil * len);
+        litterN += (double)(nOrgLitter * len);
+      }
     }
     // ---- 3. pools (sipnet.c:1769-1806) ------------------------------------------------
     {
@@ -648,32 +685,23 @@ __global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
       soilWater += (double)((rain + snowMelt - immedEvap - fastFlow - evaporation -
                              transpiration - drainage) * len);
       snow += (double)((snowFall - snowMelt - sublimation) * len);
-      if (Generic && F.litterPool) {  // updatePoolsForSoil(), sipnet.c:1645-1668
+      if (Generic) {  // updatePoolsForSoil(), sipnet.c:1645-1668: both forms, one select
         const R soilInputs = coarseRootLoss + fineRootLoss + litterToSoil;
         // the soil carbon the reference looks at here already holds this step's event fluxes
         const R sat = F.carbonSat ? clip01((R)soilC * G_iSoilCSat) : R(0);
-        litterC += (double)((woodLitter + leafLitter + (soilInputs * sat) - litterToSoil -
-                             rLitter - litterMethane) * len);
-        soilC += (double)((soilInputs * (R(1) - sat) - rSoil - soilMethane) * len);
-      } else if (Generic) {
-        soilC += (double)((coarseRootLoss + fineRootLoss + woodLitter + leafLitter - rSoil -
-                           soilMethane) * len);
+        const R dLitter = (woodLitter + leafLitter + (soilInputs * sat) - litterToSoil -
+                           rLitter - litterMethane) * len;
+        const R dSoilTwo = (soilInputs * (R(1) - sat) - rSoil - soilMethane) * len;
+        const R dSoilOne = (coarseRootLoss + fineRootLoss + woodLitter + leafLitter - rSoil -
+                            soilMethane) * len;
+        litterC += (double)(F.litterPool ? dLitter : R(0));
+        soilC += (double)(F.litterPool ? dSoilTwo : dSoilOne);
       } else {
         soilC += (double)((coarseRootLoss + fineRootLoss + woodLitter + leafLitter - rSoil) * len);
       }
       coarseRootC += (double)((coarseRootCreation - coarseRootLoss -
                                (leafOnCreation - leafOnFromWood)) * len);
       fineRootC += (double)((fineRootCreation - fineRootLoss) * len);
-      if (Generic && F.nitrogen) {  // updateNitrogenPools(), nitrogen.c:210-239
-        const R demand = rmax0(woodCreation * G_iWoodCN + leafCreation * G_iLeafCN +
-                               fineRootCreation * G_iFineCN + coarseRootCreation * G_iWoodCN);
-        const R storageDemand = demand - nUptake - nFixation;
-        storN += (double)((leafOffNResorption + reductionNResorption - storageDemand -
-                           leafOnNFromC(leafOnCreation)) * len);
-        minN += (double)(((nMin - nVolatilization - nLeaching) - nUptake) * len);
-        soilOrgN += (double)(nOrgSoil * len);
-        litterN += (double)(nOrgLitter * len);
-      }
     }
 
     // checkForMortality(), sipnet.c:1688-1767: only a change of the alive flag does anything
@@ -832,16 +860,27 @@ extern "C" int sipnet_debug_read_stamps(unsigned long long* out) {
 void launchStepFast(const FastArgs& a, int precision, hipStream_t stream) {
   const int chunksPerSite = (a.n_members + 63) / 64;
   const int grid = a.n_sites * chunksPerSite;
-  if (!isDefaultFlagSet(a.flags)) {  // any other flag set: the run-time-flag instantiation
-    if (precision == SIPNET_F64) hipLaunchKernelGGL((stepFastKernel<double, false, true>), dim3(grid), dim3(64), 0, stream, a);
-    else hipLaunchKernelGGL((stepFastKernel<float, false, true>), dim3(grid), dim3(64), 0, stream, a);
-  } else if (precision == SIPNET_F64) {
-    if (a.plainExp) hipLaunchKernelGGL((stepFastKernel<double, true, false>), dim3(grid), dim3(64), 0, stream, a);
-    else hipLaunchKernelGGL((stepFastKernel<double, false, false>), dim3(grid), dim3(64), 0, stream, a);
-  } else {
-    if (a.plainExp) hipLaunchKernelGGL((stepFastKernel<float, true, false>), dim3(grid), dim3(64), 0, stream, a);
-    else hipLaunchKernelGGL((stepFastKernel<float, false, false>), dim3(grid), dim3(64), 0, stream, a);
+#define LAUNCH(R, PLAIN, MODE) \
+  hipLaunchKernelGGL((stepFastKernel<R, PLAIN, MODE>), dim3(grid), dim3(64), 0, stream, a)
+#define LAUNCH_MODE(MODE)                             \
+  if (precision == SIPNET_F64) {                      \
+    if (a.plainExp) LAUNCH(double, true, MODE);       \
+    else LAUNCH(double, false, MODE);                 \
+  } else {                                            \
+    if (a.plainExp) LAUNCH(float, true, MODE);        \
+    else LAUNCH(float, false, MODE);                  \
   }
+  // SIPNET_RUNTIME_FLAGS=1 (development switch): always the run-time-flag instantiation
+  const bool forceRuntime = getenv("SIPNET_RUNTIME_FLAGS") != nullptr;
+  if (isDefaultFlagSet(a.flags) && !forceRuntime) {
+    LAUNCH_MODE(kFlagsDefault)
+  } else if (isNCycleFlagSet(a.flags) && !forceRuntime) {
+    LAUNCH_MODE(kFlagsNCycle)
+  } else {  // any other flag set
+    LAUNCH_MODE(kFlagsRuntime)
+  }
+#undef LAUNCH_MODE
+#undef LAUNCH
 }
 
 }  // namespace sipnet
