@@ -46,6 +46,7 @@ extern "C" {
 #define SIPNET_NFLAGS 12
 #define SIPNET_NCLIM 11   /* converted climate record, see sipnet_io_read_clim */
 #define SIPNET_NREC 44    /* full per-step record: 36 output columns + 8 event-log columns */
+#define SIPNET_NDBG 72    /* per-step debug plane (--debug-log): 56 fluxes + 14 tracker fields */
 #define SIPNET_NSTATE 32  /* per-member carried state (doubles), see below */
 #define SIPNET_RING_SLOTS 250 /* MEAN_NPP_MAX_ENTRIES, sipnet.c:39-40 */
 
@@ -220,6 +221,18 @@ int sipnet_batch_run(sipnet_batch *b, int32_t step0, int32_t n_steps,
                      void *d_nee, void *d_gpp, void *d_et, double *d_rec,
                      int64_t ld, void *hip_stream);
 
+/* The same advance with the reference's `--debug-log` content (outputDebugState,
+ * debug_log.c:285-312, called after every updateState, sipnet.c:1974): besides the full
+ * record d_rec, d_dbg[n_steps][SIPNET_NDBG][ld] (DEVICE, doubles) receives per step
+ *   0..55  the 56 `Fluxes` fields in the order of the fluxes log (debug_log.c:70-125)
+ *   56..62 trackers.yearlyGpp, yearlyRtot, yearlyRa, yearlyRh, yearlyNpp, yearlyNee, yearlyLitter
+ *   63..66 trackers.totRtot, totRa, totRh, totNpp
+ *   67..69 phenologyTrackers.didLeafGrowth, didLeafFall, plantSurvivalTracker.isAlive
+ * Always runs the strict-order kernel (no fast-math substitutions of the flux expressions
+ * unless the batch is fast-math). */
+int sipnet_batch_run_debug(sipnet_batch *b, int32_t step0, int32_t n_steps, double *d_rec,
+                           double *d_dbg, int64_t ld, void *hip_stream);
+
 /* Ensemble statistics of an output plane: for every step and site, the sum and
  * sum of squares over the site's members (wavefront-shuffle reduction):
  *   d_stats[(t * n_sites + site) * 2 + {0,1}]   (double)
@@ -376,6 +389,15 @@ int sipnet_io_write_events_out(const char *path, int32_t print_header,
                                const sipnet_event *events, const double *rec,
                                const double *init_pools);
 
+/* Write the three `--debug-log` files of one member, <prefix>_envi.log, <prefix>_fluxes.log
+ * and <prefix>_trackers.log (debug_log.c:181-312: header `year day time <names>` when
+ * print_header is set (sipnet.c:1959-1961), rows
+ * `%4d %3d %5.2f` then ` %.15g` per double / ` %d` per int), from host records
+ * rec[n_steps][SIPNET_NREC] and dbg[n_steps][SIPNET_NDBG].  Returns 6 when a file cannot be
+ * opened, 3 when the prefix is too long (debug_log.c:169-178). */
+int sipnet_io_write_debug_logs(const char *prefix, int32_t print_header, int32_t n_steps,
+                               const int32_t *year, const int32_t *day, const double *clim,
+                               const double *rec, const double *dbg);
 
 /* `SIPNET_RESTART` checkpoint text (restart.c): read follows readRestartState
  * (restart.c:590-756: magic line, `<key> <value>` lines, strict number parsing, duplicate /

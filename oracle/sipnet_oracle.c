@@ -1412,7 +1412,7 @@ static int runMember(Member *M, const int *flags, const double *raw_params,
                      int n_steps, const double *clim, const int *year,
                      const int *day, int n_events, const sipo_event *events,
                      double *rec, double *nee, double *gpp, double *et,
-                     size_t out_stride, FILE *evout) {
+                     size_t out_stride, FILE *evout, double *dbg) {
   if (n_steps <= 0) {
     return SIPO_OK;
   }
@@ -1433,6 +1433,26 @@ static int runMember(Member *M, const int *flags, const double *raw_params,
     }
     if (rec) {
       capture(M, rec + (size_t)SIPO_NREC * t);
+    }
+    if (dbg) { /* what outputDebugState() prints beyond the record: debug_log.c:285-312 */
+      double *g = dbg + (size_t)SIPO_NDBG * t;
+      memcpy(g, &M->f, 56 * sizeof(double)); /* Rates is declared in the log's field order */
+      g[56] = M->tr.yearlyGpp;
+      g[57] = M->tr.yearlyRtot;
+      g[58] = M->tr.yearlyRa;
+      g[59] = M->tr.yearlyRh;
+      g[60] = M->tr.yearlyNpp;
+      g[61] = M->tr.yearlyNee;
+      g[62] = M->tr.yearlyLitter;
+      g[63] = M->tr.totRtot;
+      g[64] = M->tr.totRa;
+      g[65] = M->tr.totRh;
+      g[66] = M->tr.totNpp;
+      g[67] = M->didLeafGrowth;
+      g[68] = M->didLeafFall;
+      g[69] = M->isAlive;
+      g[70] = M->tr.lastYear;
+      g[71] = M->phenLastYear;
     }
     if (nee) {
       nee[out_stride * t] = M->tr.nee;
@@ -1458,13 +1478,24 @@ int sipo_run_member(const int *flags, const double *raw_params, int n_steps,
     evout = fopen(events_out, "w");
   }
   int st = runMember(M, flags, raw_params, n_steps, clim, year, day, n_events,
-                     events, rec, nee, gpp, et, 1, evout);
+                     events, rec, nee, gpp, et, 1, evout, NULL);
   if (evout) {
     fclose(evout);
   }
   if (diag) {
     *diag = M->diag;
   }
+  free(M);
+  return st;
+}
+
+int sipo_run_member_debug(const int *flags, const double *raw_params, int n_steps,
+                          const double *clim, const int *year, const int *day,
+                          int n_events, const sipo_event *events, double *rec,
+                          double *dbg) {
+  Member *M = (Member *)malloc(sizeof(Member));
+  int st = runMember(M, flags, raw_params, n_steps, clim, year, day, n_events,
+                     events, rec, NULL, NULL, NULL, 1, NULL, dbg);
   free(M);
   return st;
 }
@@ -1480,7 +1511,7 @@ int sipo_run_block(const int *flags, const double *raw_params, int m0, int m1,
     int st = runMember(M, flags, raw_params + (size_t)SIPO_NPARAMS * m, n_steps,
                        clim, year, day, n_events, events, NULL,
                        nee ? nee + m : NULL, gpp ? gpp + m : NULL,
-                       et ? et + m : NULL, (size_t)n_members_total, NULL);
+                       et ? et + m : NULL, (size_t)n_members_total, NULL, NULL);
     if (status) {
       status[m] = st;
     }
@@ -1504,7 +1535,7 @@ double sipo_time_members(const int *flags, const double *raw_params,
   clock_gettime(CLOCK_MONOTONIC, &t0);
   for (int m = 0; m < n_members; m++) {
     runMember(M, flags, raw_params + (size_t)SIPO_NPARAMS * m, n_steps, clim,
-              year, day, 0, NULL, NULL, NULL, NULL, NULL, 1, NULL);
+              year, day, 0, NULL, NULL, NULL, NULL, NULL, 1, NULL, NULL);
     acc += M->tr.totNee;
   }
   clock_gettime(CLOCK_MONOTONIC, &t1);

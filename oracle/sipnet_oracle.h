@@ -111,6 +111,16 @@ int sipo_run_member(const int *flags, const double *raw_params, int n_steps,
                     double *nee, double *gpp, double *et,
                     const char *events_out, sipo_diag *diag);
 
+/* Same run, additionally filling dbg[n_steps][SIPO_NDBG] with what the reference's
+ * --debug-log prints beyond the record (debug_log.c:285-312): 0..55 the Fluxes fields in the
+ * fluxes log's order, 56..62 yearly trackers, 63..66 totRtot/totRa/totRh/totNpp,
+ * 67..69 didLeafGrowth / didLeafFall / isAlive, 70 trackers.lastYear, 71 phenology lastYear. */
+#define SIPO_NDBG 72
+int sipo_run_member_debug(const int *flags, const double *raw_params, int n_steps,
+                          const double *clim, const int *year, const int *day,
+                          int n_events, const sipo_event *events, double *rec,
+                          double *dbg);
+
 /* Time n_members member runs back to back (no capture); returns seconds. */
 double sipo_time_members(const int *flags, const double *raw_params,
                          int n_members, int n_steps, const double *clim,

@@ -10,14 +10,14 @@ from ._lib import (F32_MIXED, F64, NCLIM, NFLAGS, NPARAMS, NREC, NSTATE, RING_SL
                    Event, Restart, SipnetError, lib)
 from .config import (DEFAULT_FLAGS, FLAG_NAMES, PARAM_NAMES, flags_from, read_config)
 from .io import (ClimTable, format_out_header, format_out_row, read_clim, read_events,
-                 read_params, read_restart, check_restart, write_events_out, write_out,
+                 read_params, read_restart, check_restart, write_debug_logs, write_events_out, write_out,
                  write_restart)
 from .batch import Batch
 
 __all__ = [
     "Batch", "ClimTable", "Event", "Restart", "SipnetError", "read_restart", "write_restart",
     "check_restart", "lib", "read_clim", "read_params",
-    "read_events", "write_out", "write_events_out", "format_out_header", "format_out_row", "read_config",
+    "read_events", "write_out", "write_events_out", "write_debug_logs", "format_out_header", "format_out_row", "read_config",
     "flags_from", "FLAG_NAMES", "DEFAULT_FLAGS", "PARAM_NAMES", "F64", "F32_MIXED",
     "NPARAMS", "NFLAGS", "NCLIM", "NREC", "NSTATE", "RING_SLOTS",
 ]

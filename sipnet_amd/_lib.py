@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsipnet_amd.so")
 
 NPARAMS, NFLAGS, NCLIM, NREC, NSTATE, RING_SLOTS = 80, 12, 11, 44, 32, 250
+NDBG = 72  # --debug-log plane: 56 fluxes + tracker fields (include/sipnet_amd.h)
 NREC_OUT = 36  # the output columns proper; 36..43 are the event log
 
 OK = 0
@@ -87,6 +88,7 @@ SIGNATURES = {
     "sipnet_batch_set_params": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "sipnet_batch_setup": (C.c_int, [_P, _P]),
     "sipnet_batch_run": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int64, _P]),
+    "sipnet_batch_run_debug": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, C.c_int64, _P]),
     "sipnet_batch_reduce_plane": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int64, _P, _P]),
     "sipnet_batch_get_state": (C.c_int, [_P, _P, _P]),
     "sipnet_batch_set_state": (C.c_int, [_P, _P, _P]),
@@ -125,6 +127,7 @@ SIGNATURES = {
     "sipnet_io_format_out_header": (C.c_int, [C.c_char_p, C.c_size_t]),
     "sipnet_io_format_out_row": (C.c_int, [C.c_char_p, C.c_size_t, C.c_int32, C.c_int32, C.c_double, _P, C.c_int64]),
     "sipnet_io_write_out": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, _P, _P, _P, _P]),
+    "sipnet_io_write_debug_logs": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
     "sipnet_io_write_events_out": (C.c_int, [C.c_char_p, C.c_int32, _I32P, _P, C.c_int32, _P, _P, _P,
                                              C.c_int32, _P, _P, _P]),
     "sipnet_io_read_restart": (C.c_int, [C.c_char_p, _P]),

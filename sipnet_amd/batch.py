@@ -99,6 +99,21 @@ class Batch:
                                       ptr(rec), self.ncol, self._stream()), "run")
         return planes, rec
 
+    def run_debug(self, step0=0, n_steps=None):
+        """The same advance with the reference's `--debug-log` content (debug_log.c:285-312).
+
+        Returns (rec[n_steps][NREC][ncol], dbg[n_steps][NDBG][ncol]) device tensors."""
+        from ._lib import NDBG
+        t = self._torch
+        if n_steps is None:
+            n_steps = self.n_steps - step0
+        rec = t.empty((n_steps, NREC, self.ncol), dtype=t.float64, device=self.device)
+        dbg = t.empty((n_steps, NDBG, self.ncol), dtype=t.float64, device=self.device)
+        check(self.L.sipnet_batch_run_debug(self.h, step0, n_steps, C.c_void_p(rec.data_ptr()),
+                                            C.c_void_p(dbg.data_ptr()), self.ncol,
+                                            self._stream()), "run_debug")
+        return rec, dbg
+
     def reduce_plane(self, plane, stats=None):
         """Per (step, site) ensemble sum and sum of squares of one output plane
         [n_steps][ncol] -> stats[n_steps][n_sites][2] (float64, on device)."""

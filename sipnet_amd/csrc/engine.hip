@@ -294,8 +294,25 @@ int sipnet_batch_setup(sipnet_batch* b, void* hip_stream) {
   return SIPNET_OK;
 }
 
+static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee, void* d_gpp,
+                   void* d_et, double* d_rec, double* d_dbg, int64_t ld, void* hip_stream);
+
 int sipnet_batch_run(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
                      void* d_gpp, void* d_et, double* d_rec, int64_t ld, void* hip_stream) {
+  return runImpl(b, step0, n_steps, d_nee, d_gpp, d_et, d_rec, nullptr, ld, hip_stream);
+}
+
+int sipnet_batch_run_debug(sipnet_batch* b, int32_t step0, int32_t n_steps, double* d_rec,
+                           double* d_dbg, int64_t ld, void* hip_stream) {
+  if (!d_rec || !d_dbg) {
+    setError("sipnet_batch_run_debug: needs both the record and the debug plane");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  return runImpl(b, step0, n_steps, nullptr, nullptr, nullptr, d_rec, d_dbg, ld, hip_stream);
+}
+
+static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee, void* d_gpp,
+                   void* d_et, double* d_rec, double* d_dbg, int64_t ld, void* hip_stream) {
   if (!b || step0 < 0 || n_steps < 0 || step0 + n_steps > b->n_steps) {
     setError("sipnet_batch_run: step range outside the climate record");
     return SIPNET_ERR_BAD_ARGUMENT;
@@ -323,6 +340,7 @@ int sipnet_batch_run(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_ne
   a.gpp = d_gpp;
   a.et = d_et;
   a.rec = d_rec;
+  a.dbg = d_dbg;
   a.ncol = b->ncol;
   a.ld = ld;
   a.n_sites = b->n_sites;

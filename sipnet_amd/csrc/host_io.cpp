@@ -447,6 +447,89 @@ int sipnet_io_write_out(const char* path, int32_t print_header, int32_t n_steps,
 }
 
 
+// ---------------------------------------------------------------- --debug-log files
+// debug_log.c:40-166 (field tables), :181-212 (formats), :258-312 (what goes in which file)
+int sipnet_io_write_debug_logs(const char* prefix, int32_t print_header, int32_t n_steps,
+                               const int32_t* year, const int32_t* day, const double* clim,
+                               const double* rec, const double* dbg) {
+  static const char* const enviNames[13] = {
+      "plantWoodC", "plantLeafC", "soilC", "soilWater", "litterC", "snow", "coarseRootC",
+      "fineRootC", "minN", "soilOrgN", "litterN", "plantStorageN", "plantCAccountingDelta"};
+  static const char* const fluxNames[56] = {
+      "photosynthesis", "leafLitter", "woodLitter", "rVeg", "rSoil", "rain", "transpiration",
+      "drainage", "litterToSoil", "rLitter", "snowFall", "snowMelt", "sublimation",
+      "immedEvap", "fastFlow", "evaporation", "fineRootLoss", "coarseRootLoss",
+      "fineRootCreation", "coarseRootCreation", "rCoarseRoot", "rFineRoot", "leafCreation",
+      "woodCreation", "leafOnCreation", "leafOnCreationFromWood", "nVolatilization",
+      "nLeaching", "nOrgSoil", "nOrgLitter", "nMin", "nFixation", "nUptake",
+      "leafOffNResorption", "reductionNResorption", "eventLeafC", "eventWoodC",
+      "eventFineRootC", "eventCoarseRootC", "eventEvap", "eventSoilWater", "eventSoilC",
+      "eventLitterC", "eventMinN", "eventSoilOrgN", "eventLitterN", "eventInputC",
+      "eventOutputC", "eventInputN", "eventOutputN", "eventLeafOnCreation",
+      "eventLeafOnCreationFromWood", "eventLeafOffLitter", "eventLeafOffNResorption",
+      "soilMethane", "litterMethane"};
+  // tracker fields: name, source (record column r, debug column d, or the year y)
+  struct TF { const char* name; char src; int col; };
+  static const TF trk[33] = {
+      {"gpp", 'r', 1}, {"rtot", 'r', 10}, {"ra", 'r', 8}, {"rh", 'r', 9}, {"rRoot", 'r', 7},
+      {"rSoil", 'r', 6}, {"rAboveground", 'r', 5}, {"npp", 'r', 4}, {"nee", 'r', 0},
+      {"woodCreation", 'r', 11}, {"gdd", 'r', 33}, {"evapotranspiration", 'r', 2},
+      {"soilWetnessFrac", 'r', 12}, {"yearlyGpp", 'd', 56}, {"yearlyRtot", 'd', 57},
+      {"yearlyRa", 'd', 58}, {"yearlyRh", 'd', 59}, {"yearlyNpp", 'd', 60},
+      {"yearlyNee", 'd', 61}, {"yearlyLitter", 'd', 62}, {"totGpp", 'r', 35},
+      {"totRtot", 'd', 63}, {"totRa", 'd', 64}, {"totRh", 'd', 65}, {"totNpp", 'd', 66},
+      {"totNee", 'r', 3}, {"lastYear", 'y', 0}, {"methane", 'r', 31}, {"n2o", 'r', 27},
+      {"nLeaching", 'r', 28}, {"nFixation", 'r', 29}, {"nUptake", 'r', 30},
+      {"meanNPP", 'r', 32}};
+  const std::string pre(prefix ? prefix : "");
+  if (pre.size() + 13 >= 256) {  // FILENAME_MAXLEN, debug_log.c:169-178
+    setError("debug-log prefix '" + pre + "' is too long");
+    return SIPNET_ERR_BAD_PARAMETER;
+  }
+  FILE* fe = fopen((pre + "_envi.log").c_str(), "w");
+  FILE* ff = fopen((pre + "_fluxes.log").c_str(), "w");
+  FILE* ft = fopen((pre + "_trackers.log").c_str(), "w");
+  if (!fe || !ff || !ft) {
+    if (fe) fclose(fe);
+    if (ff) fclose(ff);
+    if (ft) fclose(ft);
+    setError("Error opening debug log files with prefix " + pre);
+    return SIPNET_ERR_FILE_OPEN;
+  }
+  if (print_header) {  // sipnet.c:1959-1961
+    fprintf(fe, "year day time");
+    for (const char* n : enviNames) fprintf(fe, " %s", n);
+    fprintf(fe, "\n");
+    fprintf(ff, "year day time");
+    for (const char* n : fluxNames) fprintf(ff, " %s", n);
+    fprintf(ff, "\n");
+    fprintf(ft, "year day time");
+    for (const TF& t : trk) fprintf(ft, " t.%s", t.name);
+    fprintf(ft, " pt.didLeafGrowth pt.didLeafFall pt.lastYear s.isAlive\n");
+  }
+  for (int t = 0; t < n_steps; t++) {
+    const double* r = rec + (size_t)t * SIPNET_NREC;
+    const double* d = dbg + (size_t)t * SIPNET_NDBG;
+    const double time = clim[(size_t)t * SIPNET_NCLIM + 10];
+    fprintf(fe, "%4d %3d %5.2f", year[t], day[t], time);
+    for (int k = 0; k < 13; k++) fprintf(fe, " %.15g", r[14 + k]);
+    fprintf(fe, "\n");
+    fprintf(ff, "%4d %3d %5.2f", year[t], day[t], time);
+    for (int k = 0; k < 56; k++) fprintf(ff, " %.15g", d[k]);
+    fprintf(ff, "\n");
+    fprintf(ft, "%4d %3d %5.2f", year[t], day[t], time);
+    for (const TF& f : trk) {
+      if (f.src == 'y') fprintf(ft, " %d", year[t]);
+      else fprintf(ft, " %.15g", f.src == 'r' ? r[f.col] : d[f.col]);
+    }
+    fprintf(ft, " %d %d %d %d\n", (int)d[67], (int)d[68], year[t], (int)d[69]);
+  }
+  fclose(fe);
+  fclose(ff);
+  fclose(ft);
+  return SIPNET_OK;
+}
+
 // ---------------------------------------------------------------- events.out
 namespace {
 struct EvLine {

@@ -274,8 +274,7 @@ int main(int argc, char** argv) {
   if (ctx.i("anaerobic") && !ctx.i("waterHResp")) { logError("anaerobic requires water-hresp to be turned on\n"); bad = true; }
   if (ctx.i("carbonSaturation") && !ctx.i("litterPool")) { logError("carbon-saturation requires litter-pool to be turned on\n"); bad = true; }
   if (bad) return 3;
-  if (!ctx.s("debugLogPrefix").empty())
-    die(8, "--debug-log is not supported by this engine\n");
+  const std::string debugLog = ctx.s("debugLogPrefix");
 
   // ---- derived names (frontend.c:164-209) ----
   const std::string prefix = ctx.s("filePrefix");
@@ -382,15 +381,25 @@ int main(int argc, char** argv) {
   const size_t recElems = (size_t)T * SIPNET_NREC * M;
   double* dRec = (double*)sipnet_dev_alloc(recElems * sizeof(double));
   if (!dRec) die(1, std::string(sipnet_last_error()) + "\n");
-  check(sipnet_batch_run(b, 0, T, nullptr, nullptr, nullptr, dRec, M, nullptr), "run");
+  const size_t dbgElems = debugLog.empty() ? 0 : (size_t)T * SIPNET_NDBG * M;
+  double* dDbg = nullptr;
+  std::vector<double> dbg(dbgElems);
+  if (dbgElems) {  // --debug-log: the per-step flux / tracker dump of debug_log.c
+    dDbg = (double*)sipnet_dev_alloc(dbgElems * sizeof(double));
+    if (!dDbg) die(1, std::string(sipnet_last_error()) + "\n");
+    check(sipnet_batch_run_debug(b, 0, T, dRec, dDbg, M, nullptr), "run");
+  } else {
+    check(sipnet_batch_run(b, 0, T, nullptr, nullptr, nullptr, dRec, M, nullptr), "run");
+  }
   std::vector<double> rec(recElems);
   check(sipnet_dev_to_host(rec.data(), dRec, recElems * sizeof(double), nullptr), "copy back");
+  if (dbgElems) check(sipnet_dev_to_host(dbg.data(), dDbg, dbgElems * sizeof(double), nullptr), "copy back");
   std::vector<int32_t> status(M);
   check(sipnet_batch_get_status(b, status.data(), nullptr), "status");
 
   // ---- outputs ----
   int worst = 0;
-  std::vector<double> one((size_t)T * SIPNET_NREC);
+  std::vector<double> one((size_t)T * SIPNET_NREC), oneDbg(dbgElems ? (size_t)T * SIPNET_NDBG : 0);
   for (int m = 0; m < M; m++) {
     if (status[m] != 0) {
       logError("member " + std::to_string(m) + ": status " + std::to_string(status[m]) +
@@ -402,6 +411,14 @@ int main(int argc, char** argv) {
       for (int k = 0; k < SIPNET_NREC; k++)
         one[(size_t)t * SIPNET_NREC + k] = rec[((size_t)t * SIPNET_NREC + k) * M + m];
     const std::string tag = ensembleFile.empty() ? "" : "." + std::to_string(m);
+    if (dbgElems) {
+      for (int t = 0; t < T; t++)
+        for (int k = 0; k < SIPNET_NDBG; k++)
+          oneDbg[(size_t)t * SIPNET_NDBG + k] = dbg[((size_t)t * SIPNET_NDBG + k) * M + m];
+      check(sipnet_io_write_debug_logs((debugLog + tag).c_str(), ctx.i("printHeader"), T, sipnet_clim_year(clim),
+                                       sipnet_clim_day(clim), sipnet_clim_data(clim), one.data(),
+                                       oneDbg.data()), "writing debug logs");
+    }
     if (ctx.i("doMainOutput"))
       check(sipnet_io_write_out((prefix + tag + ".out").c_str(), ctx.i("printHeader"), T,
                                 sipnet_clim_year(clim), sipnet_clim_day(clim), sipnet_clim_data(clim),
@@ -438,6 +455,7 @@ int main(int argc, char** argv) {
     }
   }
   sipnet_dev_free(dRec);
+  if (dDbg) sipnet_dev_free(dDbg);
   sipnet_batch_destroy(b);
   sipnet_clim_free(clim);
   sipnet_io_free(events);

@@ -60,6 +60,7 @@ struct KernelArgs {
   void* gpp;
   void* et;
   double* rec;            // [n_steps][SIPNET_NREC][ld] or null
+  double* dbg;            // [n_steps][SIPNET_NDBG][ld] or null (only with rec)
   int64_t ncol, ld;
   int32_t n_sites, n_members, n_steps_total, step0, n_steps;
   int32_t flags[SIPNET_NFLAGS];

@@ -1027,6 +1027,39 @@ __global__ __launch_bounds__(64) void stepKernel(KernelArgs a) {
       r[41 * L] = deathWood;
       r[42 * L] = deathRoot;
       r[43 * L] = diedNow;
+      // debug plane (--debug-log): the 56 Fluxes fields in the order of the reference's
+      // fluxes log (debug_log.c:70-125), then the tracker fields no record column carries
+      if (a.dbg) {
+        double* __restrict__ g = a.dbg + (int64_t)tl * SIPNET_NDBG * a.ld + col;
+        const R v[SIPNET_NDBG] = {
+            photosynthesis, leafLitter, woodLitter, rVeg, rSoil, rain, transpiration, drainage,
+            litterToSoil, rLitter, snowFall, snowMelt, sublimation, immedEvap, fastFlow,
+            evaporation, fineRootLoss, coarseRootLoss, fineRootCreation, coarseRootCreation,
+            rCoarseRoot, rFineRoot, leafCreation, woodCreation, leafOnCreation, leafOnFromWood,
+            nVolatilization, nLeaching, nOrgSoil, nOrgLitter, nMin, nFixation, nUptake,
+            leafOffNResorption, reductionNResorption, evLeafC, evWoodC, evFineRootC,
+            evCoarseRootC, evEvap, evSoilWater, evSoilC, evLitterC, evMinN, evSoilOrgN,
+            evLitterN, evInputC, evOutputC, evInputN, evOutputN, evLeafOnCreation,
+            evLeafOnFromWood, evLeafOffLitter, evLeafOffNResorp, soilMethane, litterMethane};
+#pragma unroll
+        for (int k = 0; k < 56; k++) g[(int64_t)k * L] = (double)v[k];
+        g[56 * L] = yearlyGpp;
+        g[57 * L] = yearlyRtot;
+        g[58 * L] = yearlyRa;
+        g[59 * L] = yearlyRh;
+        g[60 * L] = yearlyNpp;
+        g[61 * L] = yearlyNee;
+        g[62 * L] = yearlyLitter;
+        g[63 * L] = totRtot;
+        g[64 * L] = totRa;
+        g[65 * L] = totRh;
+        g[66 * L] = totNpp;
+        g[67 * L] = (double)(phenBits & 1);
+        g[68 * L] = (double)((phenBits >> 1) & 1);
+        g[69 * L] = alive ? 1.0 : 0.0;
+        g[70 * L] = 0.0;
+        g[71 * L] = 0.0;
+      }
     }
 
     // ---- 5. running mean of NPP: updateMeanTrackers(), sipnet.c:1546-1570 with

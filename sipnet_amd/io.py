@@ -94,6 +94,19 @@ def write_out(path, clim, rec, print_header=False):
                                     clim.data.ctypes.data, rec.ctypes.data), "write_out")
 
 
+def write_debug_logs(prefix, clim, rec, dbg, print_header=False):
+    """`<prefix>_envi.log`, `_fluxes.log`, `_trackers.log` of one member (debug_log.c:181-312)
+    from its records rec[n_steps][NREC] and debug plane dbg[n_steps][NDBG]."""
+    from ._lib import NDBG
+    rec = np.ascontiguousarray(rec, dtype=np.float64)
+    dbg = np.ascontiguousarray(dbg, dtype=np.float64)
+    assert rec.shape == (clim.n_steps, NREC) and dbg.shape == (clim.n_steps, NDBG)
+    check(lib().sipnet_io_write_debug_logs(str(prefix).encode(), int(print_header), clim.n_steps,
+                                           clim.year.ctypes.data, clim.day.ctypes.data,
+                                           clim.data.ctypes.data, rec.ctypes.data,
+                                           dbg.ctypes.data), "write_debug_logs")
+
+
 def write_events_out(path, flags, raw_params, clim, events, rec, init_pools, print_header=False):
     """`events.out` of one member regenerated from its full records (events.c:369-418)."""
     import ctypes as C

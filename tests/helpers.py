@@ -68,6 +68,20 @@ class Oracle:
             events_out.encode() if events_out else None, C.byref(diag))
         return st, rec, diag
 
+    def run_member_debug(self, flags, raw, clim, events=None):
+        """-> (status, rec[n][36], dbg[n][72]): the record plus what --debug-log prints"""
+        fl = (C.c_int * 12)(*flags)
+        raw = np.ascontiguousarray(raw, dtype=np.float64)
+        n = clim.n_steps
+        rec = np.zeros((n, NREC))
+        dbg = np.zeros((n, 72))
+        nev, evarr = self._events(events)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        self.lib.sipo_run_member_debug.restype = C.c_int
+        st = self.lib.sipo_run_member_debug(fl, vp(raw), n, vp(clim.data), vp(clim.year),
+                                            vp(clim.day), nev, evarr, vp(rec), vp(dbg))
+        return st, rec, dbg
+
     def run_block(self, flags, raw, clim, events=None, m0=0, m1=None, want_final=True):
         """raw[n_members][80] -> planes[3][n_steps][n_members], final[n_members][36], status"""
         fl = (C.c_int * 12)(*flags)

@@ -1,0 +1,143 @@
+"""`--debug-log` (debug_log.c): the per-step dump of all 13 pools, 56 fluxes and 37 tracker
+fields -- the finest-grained view of updateState() the reference offers, used here as a parity
+instrument for every intermediate flux, not only NEE / GPP / ET.
+
+Golden rows: the reference binary's own logs on niwot (default flags) and russell_2 (litter
+pool + nitrogen cycle + anaerobic, 108 events), decimated by tools/make_golden.py
+(tests/golden/debug_log/).
+
+CPU: the oracle's records + debug plane written by the host writer must reproduce those rows
+BYTE FOR BYTE (pins the oracle on every flux and the writer's format).
+GPU: the drop-in CLI's logs must match the golden rows field by field (integers exactly,
+doubles to 1e-9 relative / 1e-12 absolute -- OCML vs glibc pow/exp differ in the last bits, so the %.15g text
+is not always identical), and the strict kernel's debug plane must match the oracle's on a
+configuration with every optional flag on."""
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import sipnet_amd as sa
+from sipnet_amd import synth
+from sipnet_amd._lib import NDBG, NREC
+from tests import helpers
+from tests.test_cli import CLI, run_cli, stage
+
+GOLD = os.path.join(helpers.GOLDEN, "debug_log")
+KINDS = ["envi", "fluxes", "trackers"]
+
+
+def golden(case, kind):
+    with gzip.open(os.path.join(GOLD, f"{case}_{kind}.log.gz"), "rt") as fh:
+        lines = fh.read().split("\n")[:-1]
+    rows = [int(x) for x in open(os.path.join(GOLD, f"{case}_rows.txt")).read().split()]
+    header = [lines[0]] if lines[0].startswith("year") else []
+    body = lines[len(header):]
+    assert len(body) == len(rows)
+    return header, rows, body
+
+
+def picked(path, rows, has_header):
+    lines = open(path).read().split("\n")[:-1]
+    header = lines[:1] if has_header else []
+    body = lines[len(header):]
+    return header, [body[r] for r in rows], len(body)
+
+
+@pytest.mark.parametrize("case", ["niwot", "russell_2"])
+def test_oracle_debug_rows_equal_reference_logs_byte_for_byte(case, oracle, tmp_path):
+    c = helpers.load_smoke_case(case, str(tmp_path))
+    st, rec, dbg = oracle.run_member_debug(c["flags"], c["params"], c["clim"], c["events"])
+    assert st == 0
+    rec44 = np.concatenate([rec, np.zeros((rec.shape[0], NREC - rec.shape[1]))], axis=1)
+    has_header = bool(c["cfg"]["printHeader"])
+    sa.write_debug_logs(tmp_path / "dbg", c["clim"], rec44, dbg, print_header=has_header)
+    for kind in KINDS:
+        gh, rows, gbody = golden(case, kind)
+        h, body, n = picked(tmp_path / f"dbg_{kind}.log", rows, has_header)
+        assert n == c["clim"].n_steps
+        assert h == gh
+        bad = [(r, a, b) for r, a, b in zip(rows, body, gbody) if a != b]
+        assert not bad, f"{case} {kind}: {len(bad)} rows differ, first: {bad[0]}"
+    # the two year fields the writer takes from the climate record (trackers.lastYear,
+    # phenologyTrackers.lastYear) are what the oracle carries
+    assert (dbg[:, 70] == c["clim"].year).all() and (dbg[:, 71] == c["clim"].year).all()
+
+
+def test_writer_rejects_unopenable_and_overlong_prefix(tmp_path):
+    clim = synth.convert_raw(synth.round_like_file(synth.half_hourly_year_raw(4)))
+    rec, dbg = np.zeros((4, NREC)), np.zeros((4, NDBG))
+    with pytest.raises(sa.SipnetError) as e:
+        sa.write_debug_logs(tmp_path / "no_such_dir" / "x", clim, rec, dbg)
+    assert e.value.code == 6          # EXIT_CODE_FILE_OPEN_OR_READ_ERROR
+    with pytest.raises(sa.SipnetError) as e:
+        sa.write_debug_logs("p" * 250, clim, rec, dbg)
+    assert e.value.code == 3          # EXIT_CODE_BAD_PARAMETER_VALUE, debug_log.c:174-177
+
+
+def _fields(line):
+    t = line.split()
+    return t[:3], t[3:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["niwot", "russell_2"])
+def test_cli_debug_log_matches_reference_rows(case, tmp_path):
+    stage(case, tmp_path)
+    r = run_cli(tmp_path, "-i", "sipnet.in", "--debug-log", "dbg")
+    assert r.returncode == 0, r.stdout + r.stderr
+    cfg = sa.read_config(os.path.join(helpers.smoke_dir(case), "sipnet.in"))
+    worst, same, total, where = 0.0, 0, 0, None
+    for kind in KINDS:
+        gh, rows, gbody = golden(case, kind)
+        h, body, _ = picked(tmp_path / f"dbg_{kind}.log", rows, bool(cfg["printHeader"]))
+        assert h == gh
+        for row, a, b in zip(rows, body, gbody):
+            total += 1
+            same += a == b
+            (ta, va), (tb, vb) = _fields(a), _fields(b)
+            assert ta == tb and len(va) == len(vb)
+            for k, (x, y) in enumerate(zip(va, vb)):
+                if "." not in y and "e" not in y and "." not in x and "e" not in x:
+                    assert int(x) == int(y) or float(y) == 0.0 == float(x)
+                fx, fy = float(x), float(y)
+                # 1e-9 relative with a 1e-12 absolute floor; plantCAccountingDelta (envi field 12)
+                # is a running sum of differences of O(1) terms that hovers around zero:
+                # absolute 1e-9 there (observed 6.5e-12 after 5237 steps)
+                floor = 1.0 if (kind == "envi" and k == 12) else 1e-3
+                err = abs(fx - fy) / max(abs(fy), floor)
+                if err > worst:
+                    worst, where = err, (kind, row, k, x, y)
+    print(f"{case}: {same}/{total} golden rows byte-identical, worst field error {worst:.2e} at {where}")
+    assert worst < 1e-9
+
+
+@pytest.mark.gpu
+def test_debug_plane_matches_oracle_with_every_flag_on(oracle):
+    from tests.test_gpu_flags import ALL_ON, BASE, _events_all_types
+    os.environ["SIPNET_FAST_MATH"] = "0"
+    flags = sa.flags_from(**{k: v for k, v in ALL_ON.items() if k != "soilPhenol"})
+    clim = synth.convert_raw(synth.round_like_file(synth.half_hourly_year_raw(17520)))
+    base = sa.read_params(BASE, flags)[0]
+    members = synth.perturbed_params(base, 3)
+    ev = _events_all_types(clim)
+    b = sa.Batch(flags, 1, 3)
+    b.set_events(0, ev)
+    b.set_climate(0, clim)
+    b.set_params(0, members)
+    b.setup()
+    rec, dbg = b.run_debug()
+    rec, dbg = rec.cpu().numpy(), dbg.cpu().numpy()
+    b.close()
+    for m in range(3):
+        st, orec, odbg = oracle.run_member_debug(flags, members[m], clim, ev)
+        assert st == 0
+        got, want = dbg[:, :70, m], odbg[:, :70]
+        scale = np.maximum(np.abs(want).max(axis=0, keepdims=True), 1e-3)  # 1e-12 absolute floor
+        err = (np.abs(got - want) / scale).max(axis=0)
+        k = int(err.argmax())
+        print(f"member {m}: worst debug column {k}: {err[k]:.2e} of the column's range")
+        assert err.max() < 1e-9
+        assert np.abs(rec[:, :36, m] - orec).max() / np.abs(orec).max() < 1e-9

@@ -333,6 +333,34 @@ def balance_case():
         shutil.copyfile(os.path.join(R, f), os.path.join(d, f))
 
 
+def debug_log_cases():
+    """the three --debug-log files (debug_log.c) of the reference binary on two smoke cases:
+    header + a decimated set of rows (row numbers in <case>_rows.txt), gzipped"""
+    import tempfile
+    d = os.path.join(GOLD, "debug_log")
+    os.makedirs(d, exist_ok=True)
+    for case in ["niwot", "russell_2"]:
+        src = os.path.join(REF, "tests", "smoke", case)
+        tmp = tempfile.mkdtemp(prefix="mkgold_dbg_")
+        for f in ["sipnet.in", "sipnet.param", "sipnet.clim", "events.in"]:
+            shutil.copyfile(os.path.join(src, f), os.path.join(tmp, f))
+        run_ref_cli(tmp, ["-i", "sipnet.in", "--debug-log", "dbg"])
+        first = open(os.path.join(tmp, "dbg_envi.log")).readline()
+        hdr = 1 if first.startswith("year") else 0  # headers only with PRINT_HEADER (sipnet.c:1959)
+        n = sum(1 for _ in open(os.path.join(tmp, "dbg_envi.log"))) - hdr
+        idx = decimate_index(n, head=40, tail=40, every=53)
+        with open(os.path.join(d, f"{case}_rows.txt"), "w") as fo:
+            fo.write(" ".join(str(int(i)) for i in idx) + "\n")
+        for kind in ["envi", "fluxes", "trackers"]:
+            lines = open(os.path.join(tmp, f"dbg_{kind}.log")).read().split("\n")
+            assert lines[-1] == "" and len(lines) == n + hdr + 1
+            keep = lines[:hdr] + [lines[hdr + int(i)] for i in idx]
+            with gzip.GzipFile(os.path.join(d, f"{case}_{kind}.log.gz"), "wb", mtime=0) as fo:
+                fo.write(("\n".join(keep) + "\n").encode())
+        shutil.rmtree(tmp)
+        print("debug log", case, n, "rows, kept", len(idx))
+
+
 if __name__ == "__main__":
     subprocess.check_call(["make", "-s", "-C", os.path.join(REPO, "oracle"), "ref", "oracle"])
     copy_smoke()
@@ -342,4 +370,5 @@ if __name__ == "__main__":
     balance_case()
     events_infra_case()
     sipnet_infra_case()
+    debug_log_cases()
     subprocess.run(["du", "-sh", GOLD])
