@@ -218,6 +218,19 @@ def main():
     if world > 1 and args.gather == "full":
         gathered_full = torch.empty((world,) + tuple(planes.shape), dtype=planes.dtype, device=b.device)
 
+    # N > 1, statistics gather: the ensemble statistics of pass k (three streaming reductions
+    # + one small all-gather) run on a side stream under the step kernel of pass k+1, which
+    # writes the other of two output-plane buffers
+    overlap = world > 1 and args.gather == "stats" and not wl.get("pf")
+    if overlap:
+        planes2, _ = b.alloc_outputs(T)
+        stats2 = torch.empty_like(stats)
+        gathered2 = torch.empty_like(gathered)
+        side = torch.cuda.Stream(device=b.device)
+        bufs = [dict(planes=planes, stats=stats, gathered=gathered, ran=torch.cuda.Event(), done=None),
+                dict(planes=planes2, stats=stats2, gathered=gathered2, ran=torch.cuda.Event(), done=None)]
+        npass = [0]
+
     kernel_ms = []
     pf = bool(wl.get("pf"))
     pf_info = {}
@@ -232,6 +245,23 @@ def main():
         pf_obs, pf_sigma = float(tot.median()), float(tot.std()) * 1.5 + 1e-12
 
     def one_pass(record):
+        if overlap:
+            buf = bufs[npass[0] & 1]
+            npass[0] += 1
+            main = torch.cuda.current_stream()
+            if buf["done"] is not None:
+                main.wait_event(buf["done"])       # its statistics (two passes ago) have left
+            b.setup()
+            b.run(0, T, planes=buf["planes"])
+            buf["ran"].record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(buf["ran"])
+                for v in range(3):
+                    b.reduce_plane(buf["planes"][v], buf["stats"][v])
+                all_gather_into(buf["gathered"], buf["stats"])
+                buf["done"] = torch.cuda.Event()
+                buf["done"].record(side)
+            return
         b.setup()                       # setupModel() for every member
         b.run(0, T, planes=planes)      # the time-fused step kernel
         if pf:
