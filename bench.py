@@ -16,6 +16,8 @@ Workloads (BASELINE.json configs):
   c5    particle-filter cycle: 131072 particles per GPU (1 M over 8), fp32-mixed, one day
         (48 steps) of forecast + the analysis step (likelihood weights, all-gather of
         log-weights, systematic resampling, all-to-all of resampled checkpoints, gather)
+  c10kn c10k's shape with the nitrogen-cycle flag set (litter pool + anaerobic + N cycle): the
+        optional-flag instantiation of the throughput kernel (not a BASELINE config)
 Per-GPU work is fixed as N grows ("scaling": "weak").
 """
 import argparse
@@ -40,6 +42,9 @@ WORKLOADS = {
     "c3": dict(sites=1, members=65536, prec="f32", steps=17520),
     "c4": dict(sites=32, members=1024, prec="f64", steps=17520),
     "c5": dict(sites=1, members=131072, prec="f32", steps=48, pf=True),
+    # c10k's shape with the nitrogen-cycle flag set (litter pool + anaerobic + N cycle)
+    "c10kn": dict(sites=1, members=10240, prec="f64", steps=17520, param="allflags_forest.param",
+                  flags=dict(litterPool=1, anaerobic=1, nitrogenCycle=1)),
 }
 
 _CPU_WORKER = r"""
@@ -87,7 +92,7 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(flags, members_raw, raw_forcing, target_seconds=12.0):
+def cpu_baseline(flags, members_raw, raw_forcing, target_seconds=12.0, param_name="base_forest.param"):
     """Time the CPU checker (the real reference build when oracle/_ref travelled,
     else this repo's restatement) on a bounded sample of the same ensemble, one
     process per host core.  Test infrastructure used as a *baseline*, never shipped."""
@@ -108,7 +113,7 @@ def cpu_baseline(flags, members_raw, raw_forcing, target_seconds=12.0):
     tmp = tempfile.mkdtemp(prefix="sipnet_cpu_")
     clim_file = os.path.join(tmp, "bench.clim")
     synth.write_clim(clim_file, raw_forcing)
-    param_file = os.path.join(REPO, "sipnet_amd", "data", "base_forest.param")
+    param_file = os.path.join(REPO, "sipnet_amd", "data", param_name)
     procs = []
     env = dict(os.environ, SIPNET_REPO=REPO)
     t0 = time.time()
@@ -169,8 +174,9 @@ def main():
     import sipnet_amd as sa
     from sipnet_amd import synth
 
-    flags = sa.flags_from()
-    base, _ = sa.read_params(os.path.join(REPO, "sipnet_amd", "data", "base_forest.param"), flags)
+    flags = sa.flags_from(**wl.get("flags", {}))
+    param_name = wl.get("param", "base_forest.param")
+    base, _ = sa.read_params(os.path.join(REPO, "sipnet_amd", "data", param_name), flags)
     S, M, T = wl["sites"], wl["members"], wl["steps"]
     prec = sa.F64 if wl["prec"] == "f64" else sa.F32_MIXED
 
@@ -184,7 +190,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # before any HIP initialisation in this process: the workers are plain children
         cpu = cpu_baseline(flags, synth.perturbed_params(base, max(M, 64), seed=synth.SEED_PARAMS),
-                           raws[0])
+                           raws[0], param_name=param_name)
 
     import torch
     import torch.distributed as dist
@@ -359,7 +365,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": wl["prec"], "data": "synthetic",
             "config": {"workload": f"{args.workload}: {S} site(s) x {M} members per GPU x {T} "
-                                   f"half-hourly steps, perturbed params, default flags"
+                                   f"half-hourly steps, perturbed params, " + ("default flags" if not wl.get("flags") else "flags " + "+".join(sorted(wl["flags"])))
                                    + (", particle-filter cycle (forecast + analysis)" if pf else ""),
                        "sites_per_gpu": S, "members_per_site": M, "timesteps": T,
                        "fast_math": bool(args.fast_math),
@@ -368,7 +374,7 @@ def main():
                        **({"particle_filter": pf_info} if pf else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": ("stepCoopKernel" if S * ((M + 63) // 64) <= 512 and os.environ.get("SIPNET_COOP", "1") != "0" else "stepFastKernel") if args.fast_math else "stepKernel", "kernel_ms": k_ms,
+                         "kernel": ("stepCoopKernel" if S * ((M + 63) // 64) <= 512 and os.environ.get("SIPNET_COOP", "1") != "0" and not wl.get("flags") else "stepFastKernel") if args.fast_math else "stepKernel", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_unit": ALGO_BYTES[wl["prec"]],
                          "units_per_launch": per_launch_units},
             "cpu_baseline": cpu, "parity": parity,

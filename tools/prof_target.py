@@ -13,8 +13,8 @@ from bench import WORKLOADS
 wl = WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "c10k"]
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 os.environ.setdefault("SIPNET_FAST_MATH", "1")
-flags = sa.flags_from()
-base, _ = sa.read_params(os.path.join(REPO, "sipnet_amd", "data", "base_forest.param"), flags)
+flags = sa.flags_from(**wl.get("flags", {}))
+base, _ = sa.read_params(os.path.join(REPO, "sipnet_amd", "data", wl.get("param", "base_forest.param")), flags)
 S, M, T = wl["sites"], wl["members"], wl["steps"]
 prec = sa.F64 if wl["prec"] == "f64" else sa.F32_MIXED
 b = sa.Batch(flags, S, M, prec)
