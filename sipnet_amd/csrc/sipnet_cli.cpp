@@ -16,11 +16,14 @@
 //   --ensemble-params FILE   whitespace table, first line = parameter names, one row per
 //                            member overriding those parameters; every member runs in ONE
 //                            batch and writes <prefix>.<m>.out (m = 0..M-1); restart paths
-//                            get the same .<m> suffix
+//                            get the same .<m> suffix; the members' text files are written
+//                            by a pool of host threads
 #include <getopt.h>
+#include <sched.h>
 #include <strings.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cctype>
 #include <cstdio>
 #include <cstdlib>
@@ -28,8 +31,10 @@
 #include <ctime>
 #include <fstream>
 #include <map>
+#include <mutex>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/sipnet_amd.h"
@@ -398,15 +403,21 @@ int main(int argc, char** argv) {
   check(sipnet_batch_get_status(b, status.data(), nullptr), "status");
 
   // ---- outputs ----
+  // The text of an ensemble is the slow part of the job (about 120 MB/s of printf per host
+  // thread against tens of ms of GPU time), so members are formatted by a pool of host threads;
+  // only the checkpoint export, which talks to the GPU through the one batch handle, is
+  // serialised.
   int worst = 0;
-  std::vector<double> one((size_t)T * SIPNET_NREC), oneDbg(dbgElems ? (size_t)T * SIPNET_NDBG : 0);
   for (int m = 0; m < M; m++) {
     if (status[m] != 0) {
       logError("member " + std::to_string(m) + ": status " + std::to_string(status[m]) +
                " (NPP allocation params must be less than one individually and add to less than one)\n");
       worst = std::max(worst, status[m]);
-      continue;
     }
+  }
+  std::mutex gpuMutex;
+  auto writeMember = [&](int m, std::vector<double>& one, std::vector<double>& oneDbg) {
+    if (status[m] != 0) return;
     for (int t = 0; t < T; t++)
       for (int k = 0; k < SIPNET_NREC; k++)
         one[(size_t)t * SIPNET_NREC + k] = rec[((size_t)t * SIPNET_NREC + k) * M + m];
@@ -434,8 +445,11 @@ int main(int argc, char** argv) {
       sipnet_restart ck;
       const double* prevPools = T >= 2 ? one.data() + (size_t)(T - 2) * SIPNET_NREC + 14
                                        : state0.data() + (size_t)m * SIPNET_NSTATE;
-      check(sipnet_batch_export_restart(b, 0, m, T, one.data() + (size_t)(T - 1) * SIPNET_NREC,
-                                        prevPools, &ck, nullptr), "restart checkpoint");
+      {
+        std::lock_guard<std::mutex> lock(gpuMutex);
+        check(sipnet_batch_export_restart(b, 0, m, T, one.data() + (size_t)(T - 1) * SIPNET_NREC,
+                                          prevPools, &ck, nullptr), "restart checkpoint");
+      }
       int32_t warn = 0;
       check(sipnet_restart_check_boundary_for_write(&ck, &warn), "restart checkpoint");
       if (warn & SIPNET_RESTART_WARN_BOUNDARY_NOT_MIDNIGHT)
@@ -452,6 +466,24 @@ int main(int argc, char** argv) {
         fprintf(f, "\n");
         fclose(f);
       }
+    }
+  };
+  {
+    cpu_set_t cpus;
+    int nThreads = 1;
+    if (sched_getaffinity(0, sizeof cpus, &cpus) == 0) nThreads = CPU_COUNT(&cpus);
+    nThreads = std::max(1, std::min({nThreads, M, 64}));
+    std::atomic<int> next{0};
+    auto worker = [&]() {
+      std::vector<double> one((size_t)T * SIPNET_NREC), oneDbg(dbgElems ? (size_t)T * SIPNET_NDBG : 0);
+      for (int m = next.fetch_add(1); m < M; m = next.fetch_add(1)) writeMember(m, one, oneDbg);
+    };
+    if (nThreads == 1) {
+      worker();
+    } else {
+      std::vector<std::thread> pool;
+      for (int i = 0; i < nThreads; i++) pool.emplace_back(worker);
+      for (auto& th : pool) th.join();
     }
   }
   sipnet_dev_free(dRec);
