@@ -132,6 +132,35 @@ __device__ unsigned long long g_coopStamps[16];
 #else
 #define CSTAMP(k)
 #endif
+// -DSIPNET_WAITS (diagnostic build): cycles each wave spends inside its hand-over waits
+#ifdef SIPNET_WAITS
+__device__ unsigned long long g_coopWaits[16];
+#define WAIT_BEGIN()                                                                 \
+  unsigned long long w0_;                                                            \
+  __builtin_amdgcn_sched_barrier(0);                                                 \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w0_)::"memory");
+#define WAIT_END(k)                                                                  \
+  {                                                                                  \
+    unsigned long long w1_;                                                          \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w1_)::"memory");       \
+    __builtin_amdgcn_sched_barrier(0);                                               \
+    wAcc[k] += w1_ - w0_;                                                            \
+  }
+#define WAIT_DECL() unsigned long long wAcc[4] = {0, 0, 0, 0}; unsigned long long wT0_; \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wT0_)::"memory");
+#define WAIT_STORE(base)                                                             \
+  if (blockIdx.x == 0 && lane == 0) {                                                \
+    unsigned long long wT1_;                                                         \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wT1_)::"memory");     \
+    for (int k = 0; k < 3; k++) g_coopWaits[base + k] = wAcc[k];                     \
+    g_coopWaits[base + 3] = wT1_ - wT0_;                                             \
+  }
+#else
+#define WAIT_BEGIN()
+#define WAIT_END(k)
+#define WAIT_DECL()
+#define WAIT_STORE(base)
+#endif
 }  // namespace
 
 // RingLds: the running-mean ring of the 64 members stays in LDS for the whole launch (one
@@ -226,6 +255,7 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
     const R K_slope = (R)PRM(dVpdSlope), K_vexp = (R)PRM(dVpdExp);
     const R K_attl = (R)(-PRM(attenuation) * (1.0 / 6.0) * kLog2e);
     const R K_invHalf = (R)(1.0 / PRM(halfSatPar));
+    WAIT_DECL()
     for (int tileStart = curTile * kFastTile; tileStart < tEnd; tileStart += kFastTile, curTile++) {
       if (tileStart > tBegin) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMA of 16 steps ago
       stageTile(curTile + 1, (curTile + 1) & 1);
@@ -250,7 +280,9 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
         const R dVpd = rmax0(R(1) - K_slope * vpdPow);
         const R q = (R)q2.x * K_invHalf;
         const R e0 = fexp2(q, EC);
+        WAIT_BEGIN()
         const R lai = take(&mailLai[t & 1][lane], &seqLai, t);
+        WAIT_END(0)
         const R r1 = fexp2(K_attl * lai, EC);
         const R r2 = r1 * r1, r3 = r2 * r1, r4 = r2 * r2, r5 = r4 * r1, r6 = r3 * r3;
         const R e1 = fexp2(q * r1, EC), e2 = fexp2(q * r2, EC), e3 = fexp2(q * r3, EC);
@@ -260,6 +292,7 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
         post(&mailPgp[t & 1][lane], &seqPgp, K_g * lai * dTemp * dVpd * dLight, t);
       }
     }
+    WAIT_STORE(0)
     return;
   }
 
@@ -288,6 +321,7 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
     double soilWater = ST(soilWater), snow = ST(snow);
     R* __restrict__ oEt = (R*)(a.et ? a.et : a.scratchRow) + col;
     const int64_t ldEt = a.et ? a.ld : 0;
+    WAIT_DECL()
 
     for (int tileStart = curTile * kFastTile; tileStart < tEnd; tileStart += kFastTile, curTile++) {
       // the DMA of 16 steps ago has landed: all but the youngest operation (the last ET store)
@@ -369,7 +403,9 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
         R transpiration = 0, photosynthesis = 0;
         if (bits & FAST_PAR_POS) {
           R pgpSpec, aliveF;
+          WAIT_BEGIN()
           takePair(&mailPgp[t & 1][lane], &seqPgp, &mailAlive[t & 1][lane], &seqAlive, t, pgpSpec, aliveF);
+          WAIT_END(0)
           const R potGrossPsn = aliveF != R(0) ? pgpSpec : R(0);
           const R potTrans = potGrossPsn * (R)q2.y * K_tr;
           const bool hasPsn = potGrossPsn >= R(kTiny);
@@ -415,12 +451,17 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
 
         // never run more than one step ahead of C (the mailboxes have two slots): C is past the
         // pools of step t-1 once it has posted lai(t)
-        awaitAtLeast(&seqLai, t);
+        {
+          WAIT_BEGIN()
+          awaitAtLeast(&seqLai, t);
+          WAIT_END(1)
+        }
 
         *oEt = (transpiration + immedEvap + evaporation + sublimation + evEvap) * len;
         oEt += ldEt;
       }
     }
+    WAIT_STORE(4)
     if (act) {
       ST(soilWater) = soilWater;
       ST(snow) = snow;
@@ -472,6 +513,7 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
     for (int k = 0; k < SIPNET_RING_SLOTS; k++) ringL[k * 64 + lane] = ringp[(uint32_t)k * ncu];
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   }
+  WAIT_DECL()
   // HBM ring: the value written by the previous step is forwarded from a register
   double lastNpp = 0.0;
   int lastIns = -1;
@@ -501,6 +543,7 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
     R g1, g2, fSoil, gFine, gCoarse;
     int facSeq;
     {
+      WAIT_BEGIN()
       const unsigned fac = ldsAddr(&mailFac[t & 1][0][lane]);
       // (re-reading the record while spinning is harmless; one asm statement defines every value,
       // so no copies are needed when the first look already finds the flag current)
@@ -523,6 +566,7 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
                        : "v"(ldsAddr(recB)), "v"(ldsAddr(&seqFac)), "v"(fac) : "memory");
         }
       } while (uni(facSeq) < t);
+      WAIT_END(0)
     }
     const double* rare = (const double*)(recB + 144);
     const int32_t* rareI = (const int32_t*)(recB + 184);
@@ -669,7 +713,9 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
     // photosynthesis of this step (wave W after wave L); nights need no hand-over
     R photosynthesis = 0;
     if (bits & FAST_PAR_POS) {
+      WAIT_BEGIN()
       photosynthesis = take(&mailPsn[t & 1][lane], &seqPsn, t);
+      WAIT_END(1)
     }
 
     CSTAMP(3)
@@ -783,6 +829,7 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
   if (blockIdx.x == 0 && lane == 0)
     for (int k = 0; k < 8; k++) g_coopStamps[k] = cAcc[k];
 #endif
+  WAIT_STORE(8)
   if (act) {
     if (RingLds)
       for (int k = 0; k < SIPNET_RING_SLOTS; k++) ringp[(uint32_t)k * ncu] = ringL[k * 64 + lane];
@@ -804,6 +851,11 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
 #undef PRM_RARE
 }
 
+#ifdef SIPNET_WAITS
+extern "C" int sipnet_debug_read_coop_waits(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_coopWaits), 16 * sizeof(unsigned long long));
+}
+#endif
 #ifdef SIPNET_STAMPS
 extern "C" int sipnet_debug_read_coop_stamps(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_coopStamps), 8 * sizeof(unsigned long long));
