@@ -141,3 +141,25 @@ def test_debug_plane_matches_oracle_with_every_flag_on(oracle):
         print(f"member {m}: worst debug column {k}: {err[k]:.2e} of the column's range")
         assert err.max() < 1e-9
         assert np.abs(rec[:, :36, m] - orec).max() / np.abs(orec).max() < 1e-9
+
+
+@pytest.mark.gpu
+def test_reference_debug_log_files_test_on_russell_1(tmp_path):
+    """tests/sipnet/test_sipnet_infrastructure/testDebugLogFiles.c restated: run russell_1 with
+    `--debug-log debug_logs/sipnet_debug`; each log's header starts with `year day time`, has
+    3 + {13 Envi, 56 Fluxes, 33 Trackers + 3 phenology + 1 survival} tokens and carries the
+    named fields; every log has as many lines as sipnet.out."""
+    stage("russell_1", tmp_path)
+    os.makedirs(tmp_path / "debug_logs")
+    r = run_cli(tmp_path, "-i", "sipnet.in", "--debug-log", "debug_logs/sipnet_debug")
+    assert r.returncode == 0, r.stdout + r.stderr
+    want = {"envi": (3 + 13, "plantWoodC", "plantCAccountingDelta"),
+            "fluxes": (3 + 56, "photosynthesis", "litterMethane"),
+            "trackers": (3 + 33 + 3 + 1, "t.gpp", "pt.lastYear")}
+    main_lines = len(open(tmp_path / "sipnet.out").read().split("\n")) - 1
+    for kind, (ntok, tok1, tok2) in want.items():
+        lines = open(tmp_path / "debug_logs" / f"sipnet_debug_{kind}.log").read().split("\n")[:-1]
+        assert lines[0].startswith("year day time ")
+        assert len(lines[0].split()) == ntok
+        assert tok1 in lines[0].split() and tok2 in lines[0].split()
+        assert len(lines) == main_lines
