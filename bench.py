@@ -250,6 +250,9 @@ def main():
             tot = sd._gather0(tot, world, None).reshape(-1)
         pf_obs, pf_sigma = float(tot.median()), float(tot.std()) * 1.5 + 1e-12
 
+    pf_totals = torch.ones(max(args.steps + args.warmup, 1), dtype=torch.int64, device=b.device)
+    pf_cycle = [0]
+
     def one_pass(record):
         if overlap:
             buf = bufs[npass[0] & 1]
@@ -271,8 +274,12 @@ def main():
         b.setup()                       # setupModel() for every member
         b.run(0, T, planes=planes)      # the time-fused step kernel
         if pf:
+            # no host round trip inside a cycle: each cycle's total weight lands in its own slot
+            # and "a particle survived" is checked for all cycles after the closing barrier
+            slot = pf_totals[pf_cycle[0] % len(pf_totals):][:1]
+            pf_cycle[0] += 1
             _, info = sd.pf_analysis(b, planes[0], pf_obs, pf_sigma, u0=0.5, rank=rank, world=world,
-                                     with_params=True, diagnostics=record)
+                                     with_params=True, diagnostics=record, total_out=slot)
             pf_info.update(info)
             return
         if world > 1 and args.gather != "none":
@@ -298,6 +305,8 @@ def main():
         one_pass(False)
     barrier()
     dt = time.perf_counter() - t0
+    if pf and not bool((pf_totals > 0).all()):
+        raise RuntimeError("particle filter: a cycle ended with every particle at zero weight")
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.rehearse else b.device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

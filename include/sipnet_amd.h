@@ -306,6 +306,12 @@ int sipnet_batch_pf_log_weights(sipnet_batch *b, const void *d_plane, int32_t el
 int sipnet_pf_systematic_ancestors(const double *d_logw, int64_t n, double u0,
                                    int32_t *d_ancestors, int64_t *d_fixed_weights,
                                    void *hip_stream);
+/* The same without the host round trip: nothing is synchronised; the total integer weight S
+ * goes to d_total (DEVICE int64, may be NULL) and the caller tests S > 0 ("a particle
+ * survived") at its next natural synchronisation point.  With S = 0 the ancestors are all 0. */
+int sipnet_pf_systematic_ancestors_async(const double *d_logw, int64_t n, double u0,
+                                         int32_t *d_ancestors, int64_t *d_fixed_weights,
+                                         int64_t *d_total, void *hip_stream);
 /* doubles per particle in a packed block: SIPNET_NSTATE + SIPNET_RING_SLOTS (+ SIPNET_NPARAMS) */
 int32_t sipnet_pf_member_words(int32_t with_params);
 /* Pack columns d_cols[n] (DEVICE, local column indices) into d_buf laid out

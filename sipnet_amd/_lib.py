@@ -102,6 +102,7 @@ SIGNATURES = {
     "sipnet_batch_pf_log_weights": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int64, C.c_double,
                                               C.c_double, _P, _P]),
     "sipnet_pf_systematic_ancestors": (C.c_int, [_P, C.c_int64, C.c_double, _P, _P, _P]),
+    "sipnet_pf_systematic_ancestors_async": (C.c_int, [_P, C.c_int64, C.c_double, _P, _P, _P, _P]),
     "sipnet_pf_member_words": (C.c_int32, [C.c_int32]),
     "sipnet_batch_pack_members": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P]),
     "sipnet_batch_resample": (C.c_int, [_P, _P, _P, C.c_int32, _P, C.c_int32, _P]),

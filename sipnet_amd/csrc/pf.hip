@@ -199,9 +199,9 @@ constexpr int kMaxParts = 256;
 thread_local PfScratch g_pf;
 }  // namespace
 
-int sipnet_pf_systematic_ancestors(const double* d_logw, int64_t n, double u0,
-                                   int32_t* d_ancestors, int64_t* d_fixed_weights,
-                                   void* hip_stream) {
+int sipnet_pf_systematic_ancestors_async(const double* d_logw, int64_t n, double u0,
+                                         int32_t* d_ancestors, int64_t* d_fixed_weights,
+                                         int64_t* d_total, void* hip_stream) {
   if (!d_logw || !d_ancestors || n <= 0 || n > (int64_t)1 << 22 || !(u0 >= 0.0) || !(u0 < 1.0)) {
     setError("sipnet_pf_systematic_ancestors: bad argument (n <= 4194304, 0 <= u0 < 1)");
     return SIPNET_ERR_BAD_ARGUMENT;
@@ -234,9 +234,21 @@ int sipnet_pf_systematic_ancestors(const double* d_logw, int64_t n, double u0,
   if (d_fixed_weights)
     HIP_TRY(hipMemcpyAsync(d_fixed_weights, sc.d_w, (size_t)n * sizeof(int64_t),
                            hipMemcpyDeviceToDevice, stream));
+  if (d_total)
+    HIP_TRY(hipMemcpyAsync(d_total, sc.d_cdf + (n - 1), sizeof(int64_t), hipMemcpyDeviceToDevice, stream));
+  return SIPNET_OK;
+}
+
+int sipnet_pf_systematic_ancestors(const double* d_logw, int64_t n, double u0,
+                                   int32_t* d_ancestors, int64_t* d_fixed_weights,
+                                   void* hip_stream) {
+  int rc = sipnet_pf_systematic_ancestors_async(d_logw, n, u0, d_ancestors, d_fixed_weights,
+                                                nullptr, hip_stream);
+  if (rc) return rc;
   // the one host round trip: a filter with no surviving particle must be reported
+  hipStream_t stream = (hipStream_t)hip_stream;
   int64_t total = 0;
-  HIP_TRY(hipMemcpyAsync(&total, sc.d_cdf + (n - 1), sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipMemcpyAsync(&total, g_pf.d_cdf + (n - 1), sizeof(int64_t), hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
   if (total <= 0) {
     setError("sipnet_pf_systematic_ancestors: every particle has zero weight");

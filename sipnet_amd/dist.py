@@ -68,9 +68,11 @@ def all_gather_planes(planes, group=None):
 
 
 # ---- particle-filter analysis step (BASELINE config C5) ---------------------------
-def pf_systematic_ancestors(logw, u0, return_fixed=False):
+def pf_systematic_ancestors(logw, u0, return_fixed=False, total_out=None):
     """Systematic resampling over the global particle set on the device (pf.hip):
-    logw f64 CUDA tensor [n] -> int32 ancestors [n], non-decreasing, identical on every rank."""
+    logw f64 CUDA tensor [n] -> int32 ancestors [n], non-decreasing, identical on every rank.
+    With `total_out` (int64 CUDA tensor [1]) nothing is synchronised: the total integer weight
+    is left there and the caller checks `total_out > 0` (a particle survived) later."""
     import ctypes as C
     import torch
     from ._lib import check, lib
@@ -79,9 +81,16 @@ def pf_systematic_ancestors(logw, u0, return_fixed=False):
     anc = torch.empty(logw.numel(), dtype=torch.int32, device=logw.device)
     fixed = torch.empty(logw.numel(), dtype=torch.int64, device=logw.device) if return_fixed else None
     stream = C.c_void_p(torch.cuda.current_stream(logw.device).cuda_stream)
-    check(lib().sipnet_pf_systematic_ancestors(
-        C.c_void_p(logw.data_ptr()), logw.numel(), float(u0), C.c_void_p(anc.data_ptr()),
-        C.c_void_p(fixed.data_ptr()) if return_fixed else None, stream), "pf_systematic_ancestors")
+    if total_out is not None:
+        assert total_out.dtype == torch.int64 and total_out.is_cuda
+        check(lib().sipnet_pf_systematic_ancestors_async(
+            C.c_void_p(logw.data_ptr()), logw.numel(), float(u0), C.c_void_p(anc.data_ptr()),
+            C.c_void_p(fixed.data_ptr()) if return_fixed else None,
+            C.c_void_p(total_out.data_ptr()), stream), "pf_systematic_ancestors")
+    else:
+        check(lib().sipnet_pf_systematic_ancestors(
+            C.c_void_p(logw.data_ptr()), logw.numel(), float(u0), C.c_void_p(anc.data_ptr()),
+            C.c_void_p(fixed.data_ptr()) if return_fixed else None, stream), "pf_systematic_ancestors")
     return (anc, fixed) if return_fixed else anc
 
 
@@ -144,16 +153,17 @@ def pf_resample(batch, ancestors, rank=0, world=1, group=None, with_params=False
 
 
 def pf_analysis(batch, plane, obs, sigma, u0, rank=0, world=1, group=None, with_params=False,
-                diagnostics=True):
+                diagnostics=True, total_out=None):
     """One analysis step after a forecast: likelihood weights of this rank's particles ->
     all-gather of log-weights (n_total x 8 B) -> systematic resampling (redundant, identical
-    on every rank) -> pf_resample.  Returns (ancestors, info)."""
+    on every rank) -> pf_resample.  Returns (ancestors, info).  `total_out` (int64 CUDA tensor
+    [1]): run without a host round trip and leave the total weight there for a later check."""
     import torch
     import torch.distributed as dist
     logw = batch.pf_log_weights(plane, obs, sigma)
     if world > 1:
         logw = _gather0(logw, world, group).reshape(-1)
-    anc = pf_systematic_ancestors(logw, u0)
+    anc = pf_systematic_ancestors(logw, u0, total_out=total_out)
     info = pf_resample(batch, anc, rank, world, group, with_params)
     if not diagnostics:
         return anc, info

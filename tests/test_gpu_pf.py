@@ -76,6 +76,20 @@ def test_systematic_ancestors_match_oracle(kind, n):
         sd.pf_systematic_ancestors(torch.full((16,), -np.inf, dtype=torch.float64, device=DEV), 0.3)
 
 
+def test_ancestors_without_host_round_trip_equal_the_synchronous_call():
+    """the asynchronous entry point: same ancestors, the total weight left on the device
+    (0 when no particle survives, instead of the synchronous call's error)"""
+    lw = weights_case(4096, "mild")
+    total = torch.full((1,), -7, dtype=torch.int64, device=DEV)
+    anc_s, fixed = sd.pf_systematic_ancestors(torch.from_numpy(lw).to(DEV), 0.41, return_fixed=True)
+    anc_a = sd.pf_systematic_ancestors(torch.from_numpy(lw).to(DEV), 0.41, total_out=total)
+    assert torch.equal(anc_s, anc_a)
+    assert int(total.item()) == int(fixed.sum().item()) > 0
+    sd.pf_systematic_ancestors(torch.full((16,), -np.inf, dtype=torch.float64, device=DEV), 0.3,
+                               total_out=total)
+    assert int(total.item()) == 0
+
+
 @pytest.mark.parametrize("with_params", [False, True])
 def test_pack_and_resample_match_numpy(base, clim, with_params):
     n = 300
