@@ -170,14 +170,15 @@ def test_generic_throughput_kernel_agrees_with_strict_kernel(clim60, members70):
     assert np.allclose(s_fast[:, :13], s_strict[:, :13], rtol=1e-9, atol=1e-9)
 
 
-def test_fp32_mixed_with_nitrogen_cycle(oracle, clim60, members70):
+@pytest.mark.parametrize("name", ["nitrogen", "everything", "soil_phenol", "carbon_saturation"])
+def test_fp32_mixed_with_optional_flags(name, oracle, clim60, members70):
     """fp32 flux arithmetic over fp64 pools: same tolerance class as the default-flag fp32 test."""
-    flags = _flags(**FLAG_SETS["nitrogen"])
+    flags = _flags(**FLAG_SETS[name])
     ev = _events_all_types(clim60)
     got, state, status, _ = lean_run(flags, clim60, members70, ev, prec=sa.F32_MIXED)
     want, final, st = oracle.run_block(flags, members70, clim60, ev)
     scale = np.abs(want).max(axis=(1, 2), keepdims=True)
     rel = (np.abs(got - want) / scale).max()
-    print("fp32-mixed, nitrogen cycle: max |d| / max|plane|", rel)
+    print(f"fp32-mixed, {name}: max |d| / max|plane|", rel)
     assert np.isfinite(got).all()
     assert rel < 2e-3
