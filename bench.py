@@ -211,7 +211,7 @@ def main():
         else:
             dist.all_gather_into_tensor(out, x)
 
-    b = sa.Batch(flags, S, M, prec, device=local_rank)
+    b = sa.Batch(flags, S, M, prec, device=local_rank, fast_math=bool(args.fast_math))
     for s in range(S):
         b.set_climate(s, clims[s])
         b.set_params(s, members)

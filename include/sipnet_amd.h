@@ -200,6 +200,19 @@ int sipnet_batch_set_events(sipnet_batch *b, int32_t site, int32_t n_events,
 int sipnet_batch_set_params(sipnet_batch *b, int32_t site, int32_t first_member,
                             int32_t count, const double *raw);
 
+/* Arithmetic policy of an fp64 batch (an fp32-mixed batch is always SIPNET_MATH_FAST):
+ *   SIPNET_MATH_STRICT  operation order, true divisions and pow / exp calls as the reference
+ *                       writes them (differences are OCML-vs-glibc rounding, <= 1.1e-14);
+ *                       one-wavefront kernel, all flags, full records
+ *   SIPNET_MATH_FAST    the throughput kernels: site-only sub-expressions from the host plan,
+ *                       reciprocals instead of divisions, polynomial exp2; <= 2.5e-16 on NEE
+ *                       against the reference on the benchmark ensemble; launches that ask for
+ *                       full records still use the strict-order kernel's fast-math variant
+ * A new fp64 batch is STRICT unless the environment variable SIPNET_FAST_MATH=1 is set when it
+ * is created; this call overrides either.  May be changed between runs. */
+enum sipnet_math { SIPNET_MATH_STRICT = 0, SIPNET_MATH_FAST = 1 };
+int sipnet_batch_set_math(sipnet_batch *b, int32_t policy);
+
 /* Per-member initialisation == setupModel() (sipnet.c:1858-1951): parameter
  * unit conversion, derived parameters, initial pools, trackers, phenology state
  * from the first climate record, ring reset.  Members whose allocation

@@ -87,6 +87,7 @@ SIGNATURES = {
     "sipnet_batch_set_events": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
     "sipnet_batch_set_params": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "sipnet_batch_setup": (C.c_int, [_P, _P]),
+    "sipnet_batch_set_math": (C.c_int, [_P, C.c_int32]),
     "sipnet_batch_run": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int64, _P]),
     "sipnet_batch_run_debug": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, C.c_int64, _P]),
     "sipnet_batch_reduce_plane": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int64, _P, _P]),

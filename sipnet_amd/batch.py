@@ -13,7 +13,9 @@ from ._lib import F32_MIXED, F64, NPARAMS, NREC, NSTATE, RING_SLOTS, Event, chec
 
 
 class Batch:
-    def __init__(self, flags, n_sites, n_members, precision=F64, device=0):
+    def __init__(self, flags, n_sites, n_members, precision=F64, device=0, fast_math=None):
+        """fast_math (fp64 batches): True = throughput kernels, False = strict reference order,
+        None = the library default (strict unless SIPNET_FAST_MATH=1 in the environment)."""
         import torch  # device memory + streams only
         self._torch = torch
         if not torch.cuda.is_available():
@@ -31,6 +33,12 @@ class Batch:
                                          device, C.byref(h)), "batch_create")
         self.h = h
         self.n_steps = 0
+        if fast_math is not None and precision == F64:
+            self.set_math(fast_math)
+
+    def set_math(self, fast):
+        """sipnet_batch_set_math: arithmetic policy of an fp64 batch (strict order / throughput)"""
+        check(self.L.sipnet_batch_set_math(self.h, 1 if fast else 0), "set_math")
 
     # -- lifetime ---------------------------------------------------------------
     def close(self):

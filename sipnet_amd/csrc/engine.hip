@@ -297,6 +297,19 @@ int sipnet_batch_setup(sipnet_batch* b, void* hip_stream) {
 static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee, void* d_gpp,
                    void* d_et, double* d_rec, double* d_dbg, int64_t ld, void* hip_stream);
 
+int sipnet_batch_set_math(sipnet_batch* b, int32_t policy) {
+  if (!b || (policy != SIPNET_MATH_STRICT && policy != SIPNET_MATH_FAST)) {
+    setError("sipnet_batch_set_math: bad argument");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  if (b->precision == SIPNET_F32_MIXED && policy == SIPNET_MATH_STRICT) {
+    setError("sipnet_batch_set_math: an fp32-mixed batch has no strict-order arithmetic");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  b->fastMath = policy == SIPNET_MATH_FAST;
+  return SIPNET_OK;
+}
+
 int sipnet_batch_run(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
                      void* d_gpp, void* d_et, double* d_rec, int64_t ld, void* hip_stream) {
   return runImpl(b, step0, n_steps, d_nee, d_gpp, d_et, d_rec, nullptr, ld, hip_stream);

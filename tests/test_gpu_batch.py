@@ -17,8 +17,8 @@ BASE = os.path.join(helpers.REPO, "sipnet_amd", "data", "base_forest.param")
 
 
 def make_batch(flags, clims, members, prec=sa.F64, events=None, fast=True):
-    os.environ["SIPNET_FAST_MATH"] = "1" if fast else "0"
-    b = sa.Batch(flags, len(clims), members.shape[0], prec)
+    os.environ.pop("SIPNET_FAST_MATH", None)
+    b = sa.Batch(flags, len(clims), members.shape[0], prec, fast_math=fast)
     for s, c in enumerate(clims):
         if events is not None:
             b.set_events(s, events)
@@ -292,3 +292,36 @@ def test_cooperative_and_one_wave_kernels_agree(base, tmp_path, monkeypatch):
             assert (out[mode][1][:, 28:31] == out["0"][1][:, 28:31]).all()      # ring epoch, status, died-at
             np.testing.assert_allclose(out[mode][2], out["0"][2], rtol=1e-9 if prec == sa.F64 else 1e-3, atol=1e-9)
         np.testing.assert_array_equal(out["1"][0], out["2"][0])   # ring placement does not change arithmetic
+
+
+def test_math_policy_is_an_explicit_choice(base, short_clim, monkeypatch):
+    """sipnet_batch_set_math: strict reference order vs throughput kernels on the same batch;
+    the environment variable only sets the default of a new batch; fp32-mixed has no strict mode."""
+    members = synth.perturbed_params(base, 64)
+    monkeypatch.delenv("SIPNET_FAST_MATH", raising=False)
+    b = sa.Batch(sa.flags_from(), 1, 64)
+    b.set_climate(0, short_clim)
+    b.set_params(0, members)
+    b.setup()
+    strict = b.run()[0].cpu().numpy()                  # default: strict
+    b.set_math(True)
+    b.setup()
+    fast = b.run()[0].cpu().numpy()
+    b.set_math(False)
+    b.setup()
+    strict2 = b.run()[0].cpu().numpy()
+    b.close()
+    assert np.array_equal(strict, strict2)
+    d = np.abs(strict - fast).max()
+    assert 0 < d < 1e-12                                # different instruction streams, same model
+    monkeypatch.setenv("SIPNET_FAST_MATH", "1")
+    b = sa.Batch(sa.flags_from(), 1, 64)
+    b.set_climate(0, short_clim)
+    b.set_params(0, members)
+    b.setup()
+    assert np.array_equal(b.run()[0].cpu().numpy(), fast)
+    b.close()
+    b32 = sa.Batch(sa.flags_from(), 1, 64, sa.F32_MIXED)
+    with pytest.raises(SipnetError):
+        b32.set_math(False)
+    b32.close()
