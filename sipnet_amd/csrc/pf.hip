@@ -37,25 +37,44 @@ struct RecvMap {
 };
 
 // dst[row][j] = (src[j] < ncol) ? own[row][src[j]] : recv(row + recvRow0, src[j] - ncol)
+// One thread moves kGatherRows rows of its column: the source index is read once and
+// kGatherRows independent loads are in flight per thread (HBM-bound streaming copy).
+constexpr int kGatherRows = 8;
 __global__ __launch_bounds__(256) void gatherColumnsKernel(
     const double* __restrict__ own, int64_t ownPitch, int64_t ncol,
     const double* __restrict__ recv, RecvMap map, int32_t recvRow0,
-    const int32_t* __restrict__ src, int64_t nOut, double* __restrict__ dst, int64_t dstPitch) {
+    const int32_t* __restrict__ src, int64_t nOut, double* __restrict__ dst, int64_t dstPitch,
+    int32_t rows) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= nOut) return;
-  const int row = blockIdx.y;
+  const int row0 = blockIdx.y * kGatherRows;
+  const int nr = rows - row0 < kGatherRows ? rows - row0 : kGatherRows;
   const int64_t s = src[j];
-  double v;
+  double v[kGatherRows];
   if (s < ncol) {
-    v = own[(int64_t)row * ownPitch + s];
+    const double* __restrict__ p = own + (int64_t)row0 * ownPitch + s;
+    if (nr == kGatherRows) {
+#pragma unroll
+      for (int r = 0; r < kGatherRows; r++) v[r] = p[(int64_t)r * ownPitch];
+    } else {
+      for (int r = 0; r < nr; r++) v[r] = p[(int64_t)r * ownPitch];
+    }
   } else {
     const int64_t k = s - ncol;
     int blk = 0;
     for (int q = 1; q < map.nBlocks; q++)
       if (k >= map.start[q]) blk = q;
-    v = recv[map.off[blk] + (int64_t)(row + recvRow0) * map.n[blk] + (k - map.start[blk])];
+    const double* __restrict__ p = recv + map.off[blk] + (int64_t)(row0 + recvRow0) * map.n[blk] +
+                                   (k - map.start[blk]);
+    for (int r = 0; r < nr; r++) v[r] = p[(int64_t)r * map.n[blk]];
   }
-  dst[(int64_t)row * dstPitch + j] = v;
+  double* __restrict__ q = dst + (int64_t)row0 * dstPitch + j;
+  if (nr == kGatherRows) {
+#pragma unroll
+    for (int r = 0; r < kGatherRows; r++) q[(int64_t)r * dstPitch] = v[r];
+  } else {
+    for (int r = 0; r < nr; r++) q[(int64_t)r * dstPitch] = v[r];
+  }
 }
 
 // logw[col] = -0.5 * ((sum_t plane[t][col] - obs) / sigma)^2, -inf for members that did not run
@@ -137,9 +156,9 @@ void launchGather(const double* own, int64_t ownPitch, int64_t ncol, const doubl
                   const RecvMap& map, int recvRow0, const int32_t* src, int64_t nOut, double* dst,
                   int64_t dstPitch, int rows, hipStream_t stream) {
   if (nOut <= 0) return;
-  dim3 grid((unsigned)((nOut + 255) / 256), (unsigned)rows);
+  dim3 grid((unsigned)((nOut + 255) / 256), (unsigned)((rows + kGatherRows - 1) / kGatherRows));
   hipLaunchKernelGGL(gatherColumnsKernel, grid, dim3(256), 0, stream, own, ownPitch, ncol, recv,
-                     map, recvRow0, src, nOut, dst, dstPitch);
+                     map, recvRow0, src, nOut, dst, dstPitch, rows);
 }
 
 }  // namespace
