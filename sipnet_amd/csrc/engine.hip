@@ -386,6 +386,7 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
     f.plainExp = b->genericExponents ? 0 : 1;
     f.scratchRow = b->d_scratchRow;
     memcpy(f.flags, b->flags, sizeof(f.flags));
+    f.numCUs = b->numCUs;
     // Few 64-member chunks per CU: the step is bound by what one wavefront can issue, so three
     // wavefronts share each chunk (step_coop.hip) -- with the chunk's ring in LDS when there is
     // at most one chunk per CU (c10k 12.4 vs 18.2 ms), in HBM up to two per CU (c4 16.0 vs

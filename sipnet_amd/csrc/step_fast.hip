@@ -96,8 +96,16 @@ bool isNCycleFlagSet(const int32_t* f) {
   return true;
 }
 
-template <class R, bool PlainExp, int Mode>
-__global__ __launch_bounds__(64) void stepFastKernel(FastArgs a) {
+// Occ = wavefronts per SIMD the register budget is cut for: 1 (up to 512 VGPRs: the fp64
+// instantiations take 257-400) or 2 (at most 256 VGPRs; the fp64 default-flag kernel then
+// spills two registers).  With more chunks than SIMDs two resident waves hide each other's
+// issue gaps (fp64, 131 072 members: 77 vs 61 G steps/s); with at most one chunk per SIMD the
+// tighter budget only costs (19.6 vs 18.7 ms at 65 536 members), so the launcher picks.  (fp32:
+// 191-198 VGPRs, two waves as it is; a 168-VGPR cut for three gains 13 % only beyond 500 000
+// members and a 128-VGPR cut for four halves the rate through spills -- neither is built.)
+template <class R, bool PlainExp, int Mode, int Occ>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(Occ)))
+void stepFastKernel(FastArgs a) {
   constexpr bool Generic = Mode != kFlagsDefault;
   const FastFlags<Mode> F(a.flags);
   // LDS: two tiles of kFastTile site records (2 x 4 KB).  ONE __shared__ object.
@@ -860,8 +868,17 @@ extern "C" int sipnet_debug_read_stamps(unsigned long long* out) {
 void launchStepFast(const FastArgs& a, int precision, hipStream_t stream) {
   const int chunksPerSite = (a.n_members + 63) / 64;
   const int grid = a.n_sites * chunksPerSite;
-#define LAUNCH(R, PLAIN, MODE) \
-  hipLaunchKernelGGL((stepFastKernel<R, PLAIN, MODE>), dim3(grid), dim3(64), 0, stream, a)
+  // fp32 instantiations fit two waves per SIMD as they are; fp64 default flags: by grid size
+  const bool occ2 = precision == SIPNET_F64 && isDefaultFlagSet(a.flags) && grid > 4 * a.numCUs &&
+                    !getenv("SIPNET_OCC1");
+#define LAUNCH(R, PLAIN, MODE)                                                                   \
+  do {                                                                                           \
+    if (MODE == kFlagsDefault && sizeof(R) == 8 && occ2)                                         \
+      hipLaunchKernelGGL((stepFastKernel<R, PLAIN, MODE, (MODE == kFlagsDefault && sizeof(R) == 8) ? 2 : 1>), \
+                         dim3(grid), dim3(64), 0, stream, a);                                    \
+    else                                                                                         \
+      hipLaunchKernelGGL((stepFastKernel<R, PLAIN, MODE, 1>), dim3(grid), dim3(64), 0, stream, a); \
+  } while (0)
 #define LAUNCH_MODE(MODE)                             \
   if (precision == SIPNET_F64) {                      \
     if (a.plainExp) LAUNCH(double, true, MODE);       \

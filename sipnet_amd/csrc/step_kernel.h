@@ -93,6 +93,7 @@ struct FastArgs {
   int32_t n_sites, n_members, n_steps_total, step0, n_steps;
   void* scratchRow;  // [ncol] doubles: target of the stores of planes the caller left NULL
   int32_t plainExp;  // 1: every member has dVpdExp == 2 and soilRespMoistEffect == 1
+  int32_t numCUs;                // compute units of the device (kernel / occupancy choice)
   int32_t flags[SIPNET_NFLAGS];  // model flags; anything but the default set selects the
                                  // run-time-flag instantiation of the one-wave kernel
 };
