@@ -865,39 +865,38 @@ extern "C" int sipnet_debug_read_stamps(unsigned long long* out) {
 }
 #endif
 
+namespace {
+template <class R, bool Plain, int Mode>
+void launchFastOne(const FastArgs& a, int grid, bool twoWaves, hipStream_t stream) {
+  // only the fp64 default-flag kernel has a second, 256-VGPR build (fp32 fits two waves as it is)
+  constexpr int kOcc2 = (Mode == kFlagsDefault && sizeof(R) == 8) ? 2 : 1;
+  if (kOcc2 == 2 && twoWaves)
+    hipLaunchKernelGGL((stepFastKernel<R, Plain, Mode, kOcc2>), dim3(grid), dim3(64), 0, stream, a);
+  else
+    hipLaunchKernelGGL((stepFastKernel<R, Plain, Mode, 1>), dim3(grid), dim3(64), 0, stream, a);
+}
+template <int Mode>
+void launchFastMode(const FastArgs& a, int precision, int grid, bool twoWaves, hipStream_t stream) {
+  if (precision == SIPNET_F64) {
+    if (a.plainExp) launchFastOne<double, true, Mode>(a, grid, twoWaves, stream);
+    else launchFastOne<double, false, Mode>(a, grid, twoWaves, stream);
+  } else {
+    if (a.plainExp) launchFastOne<float, true, Mode>(a, grid, twoWaves, stream);
+    else launchFastOne<float, false, Mode>(a, grid, twoWaves, stream);
+  }
+}
+}  // namespace
+
 void launchStepFast(const FastArgs& a, int precision, hipStream_t stream) {
   const int chunksPerSite = (a.n_members + 63) / 64;
   const int grid = a.n_sites * chunksPerSite;
-  // fp32 instantiations fit two waves per SIMD as they are; fp64 default flags: by grid size
-  const bool occ2 = precision == SIPNET_F64 && isDefaultFlagSet(a.flags) && grid > 4 * a.numCUs &&
-                    !getenv("SIPNET_OCC1");
-#define LAUNCH(R, PLAIN, MODE)                                                                   \
-  do {                                                                                           \
-    if (MODE == kFlagsDefault && sizeof(R) == 8 && occ2)                                         \
-      hipLaunchKernelGGL((stepFastKernel<R, PLAIN, MODE, (MODE == kFlagsDefault && sizeof(R) == 8) ? 2 : 1>), \
-                         dim3(grid), dim3(64), 0, stream, a);                                    \
-    else                                                                                         \
-      hipLaunchKernelGGL((stepFastKernel<R, PLAIN, MODE, 1>), dim3(grid), dim3(64), 0, stream, a); \
-  } while (0)
-#define LAUNCH_MODE(MODE)                             \
-  if (precision == SIPNET_F64) {                      \
-    if (a.plainExp) LAUNCH(double, true, MODE);       \
-    else LAUNCH(double, false, MODE);                 \
-  } else {                                            \
-    if (a.plainExp) LAUNCH(float, true, MODE);        \
-    else LAUNCH(float, false, MODE);                  \
-  }
+  // more chunks than SIMDs: two resident wavefronts per SIMD pay (SIPNET_OCC1: development switch)
+  const bool twoWaves = grid > 4 * a.numCUs && !getenv("SIPNET_OCC1");
   // SIPNET_RUNTIME_FLAGS=1 (development switch): always the run-time-flag instantiation
   const bool forceRuntime = getenv("SIPNET_RUNTIME_FLAGS") != nullptr;
-  if (isDefaultFlagSet(a.flags) && !forceRuntime) {
-    LAUNCH_MODE(kFlagsDefault)
-  } else if (isNCycleFlagSet(a.flags) && !forceRuntime) {
-    LAUNCH_MODE(kFlagsNCycle)
-  } else {  // any other flag set
-    LAUNCH_MODE(kFlagsRuntime)
-  }
-#undef LAUNCH_MODE
-#undef LAUNCH
+  if (isDefaultFlagSet(a.flags) && !forceRuntime) launchFastMode<kFlagsDefault>(a, precision, grid, twoWaves, stream);
+  else if (isNCycleFlagSet(a.flags) && !forceRuntime) launchFastMode<kFlagsNCycle>(a, precision, grid, twoWaves, stream);
+  else launchFastMode<kFlagsRuntime>(a, precision, grid, twoWaves, stream);
 }
 
 }  // namespace sipnet
