@@ -116,7 +116,7 @@ def load_oracle():
 
 
 # ---- golden smoke cases (inputs + expected outputs of the reference's own tests) ----
-SMOKE_CASES = ["niwot", "russell_1", "russell_2", "russell_3"]
+SMOKE_CASES = ["niwot", "russell_1", "russell_2", "russell_3", "russell_4"]
 
 
 def smoke_dir(case):
