@@ -868,8 +868,11 @@ extern "C" int sipnet_debug_read_stamps(unsigned long long* out) {
 namespace {
 template <class R, bool Plain, int Mode>
 void launchFastOne(const FastArgs& a, int grid, bool twoWaves, hipStream_t stream) {
-  // only the fp64 default-flag kernel has a second, 256-VGPR build (fp32 fits two waves as it is)
-  constexpr int kOcc2 = (Mode == kFlagsDefault && sizeof(R) == 8) ? 2 : 1;
+  // a second, 256-VGPR build exists where it costs at most a few spilled registers: the fp64
+  // default-flag kernel (257 -> 256) and the fp32 run-time-flag kernel (260-266 -> 256); the other
+  // fp32 kernels fit two waves as they are, the fp64 optional-flag kernels (378-400) do not
+  constexpr int kOcc2 = ((Mode == kFlagsDefault && sizeof(R) == 8) ||
+                         (Mode == kFlagsRuntime && sizeof(R) == 4)) ? 2 : 1;
   if (kOcc2 == 2 && twoWaves)
     hipLaunchKernelGGL((stepFastKernel<R, Plain, Mode, kOcc2>), dim3(grid), dim3(64), 0, stream, a);
   else

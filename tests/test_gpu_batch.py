@@ -327,24 +327,32 @@ def test_math_policy_is_an_explicit_choice(base, short_clim, monkeypatch):
     b32.close()
 
 
-def test_two_waves_per_simd_build_of_the_one_wave_kernel(oracle, base, monkeypatch):
-    """More chunks than SIMDs (> 65 536 fp64 members): the launcher takes the instantiation cut to
-    256 VGPRs (two resident wavefronts per SIMD, two spilled registers).  Same arithmetic: the
-    planes must equal the 512-VGPR build's bit for bit, and sampled members the oracle's."""
+@pytest.mark.parametrize("which", ["f64_default_flags", "f32_runtime_flags"])
+def test_two_waves_per_simd_build_of_the_one_wave_kernel(which, oracle, base, monkeypatch):
+    """More chunks than SIMDs (> 65 536 members): the launcher takes the instantiation cut to
+    256 VGPRs (two resident wavefronts per SIMD, a few spilled registers) of the fp64 default-flag
+    kernel and of the fp32 run-time-flag kernel.  Same arithmetic: the planes must equal the
+    512-VGPR build's bit for bit, and sampled members the oracle's."""
     M, T = 66_048, 48 * 12
     clim = synth.convert_raw(synth.round_like_file(synth.half_hourly_year_raw(T)))
-    members = synth.perturbed_params(base, M)
+    if which == "f64_default_flags":
+        flags, prec, tol = sa.flags_from(), sa.F64, 1e-12
+        members = synth.perturbed_params(base, M)
+    else:
+        flags, prec, tol = sa.flags_from(litterPool=1, growthResp=1, leafWater=1), sa.F32_MIXED, 2e-6
+        allp = sa.read_params(os.path.join(helpers.GOLDEN, "synth", "allflags.param"), flags)[0]
+        members = synth.perturbed_params(allp, M)
     outs = []
     for occ1 in (False, True):
         if occ1:
             monkeypatch.setenv("SIPNET_OCC1", "1")
         else:
             monkeypatch.delenv("SIPNET_OCC1", raising=False)
-        b = make_batch(sa.flags_from(), [clim], members)
-        outs.append(b.run()[0].cpu().numpy())
+        b = make_batch(flags, [clim], members, prec=prec)
+        outs.append(b.run()[0].double().cpu().numpy())
         b.close()
     assert np.array_equal(outs[0], outs[1])
     pick = np.r_[0:16, M // 2:M // 2 + 16, M - 16:M]
-    want, _, st = oracle.run_block(sa.flags_from(), members[pick], clim)
+    want, _, st = oracle.run_block(flags, members[pick], clim)
     assert (st == 0).all()
-    assert np.abs(outs[0][:, :, pick] - want).max() < 1e-12
+    assert np.abs(outs[0][:, :, pick] - want).max() < tol
