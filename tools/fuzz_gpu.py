@@ -65,9 +65,14 @@ for trial in range(trials):
     M = int(rng.choice([1, 7, 64, 70, 130, 200]))
     T = 48 * int(rng.integers(20, 200))
     start = int(rng.integers(0, 300)) * 48
-    raw = synth.half_hourly_year_raw(start + T, site=int(rng.integers(0, 5)))
-    raw = {k: v[start:] for k, v in raw.items()}
-    clim = synth.convert_raw(synth.round_like_file(raw))
+    S = int(rng.choice([1, 1, 1, 2, 3, 8]))            # sites (8: the XCD-aware block mapping)
+    site0 = int(rng.integers(0, 5))
+    clims = []
+    for sidx in range(S):
+        raw = synth.half_hourly_year_raw(start + T, site=site0 + sidx)
+        raw = {k: v[start:] for k, v in raw.items()}
+        clims.append(synth.convert_raw(synth.round_like_file(raw)))
+    clim = clims[0]
     members = synth.perturbed_params(base, M, seed=int(rng.integers(1 << 30)), scale=float(rng.choice([1.0, 3.0])))
     if M > 3:      # a few hard cases
         members[1, pi("plantWoodInit")] *= 0.001        # barely alive
@@ -76,7 +81,10 @@ for trial in range(trials):
     ev = random_events(clim, int(rng.integers(1, 12))) if flags[0] else None
     fast = bool(rng.random() < 0.7)
     prec = sa.F32_MIXED if (fast and rng.random() < 0.25) else sa.F64
-    want, final, st = oracle.run_block(flags, members, clim, ev)
+    runs = [oracle.run_block(flags, members, c, ev) for c in clims]
+    want = np.concatenate([r[0] for r in runs], axis=2)
+    final = np.concatenate([r[1] for r in runs], axis=0)
+    st = np.concatenate([r[2] for r in runs])
     # kernel choice: default policy, or forced one-wave / HBM-ring cooperative / run-time flags
     for k in ("SIPNET_COOP", "SIPNET_RUNTIME_FLAGS"):
         os.environ.pop(k, None)
@@ -85,9 +93,11 @@ for trial in range(trials):
     if r < 0.3: os.environ["SIPNET_COOP"] = "0"; forced = " one-wave"
     elif r < 0.45: os.environ["SIPNET_COOP"] = "2"; forced = " coop-hbm"
     if rng.random() < 0.3: os.environ["SIPNET_RUNTIME_FLAGS"] = "1"; forced += " rt-flags"
-    b = sa.Batch(flags, 1, M, prec, fast_math=fast)
-    if ev is not None: b.set_events(0, ev)
-    b.set_climate(0, clim); b.set_params(0, members); b.setup()
+    b = sa.Batch(flags, S, M, prec, fast_math=fast)
+    for sidx in range(S):
+        if ev is not None: b.set_events(sidx, ev)
+        b.set_climate(sidx, clims[sidx]); b.set_params(sidx, members)
+    b.setup()
     cuts = sorted(set([0, T] + [int(x) for x in rng.integers(1, T, size=int(rng.integers(0, 4)))]))
     parts = [b.run(a0, a1 - a0)[0] for a0, a1 in zip(cuts[:-1], cuts[1:])]
     got = torch.cat(parts, dim=1).double().cpu().numpy()
@@ -121,7 +131,7 @@ for trial in range(trials):
         assert outliers < 2e-3 and sums.max() < 2e-3, "MISMATCH (fp32)"
         err = 0.0
     flag_s = "+".join(k for k, v in kw.items() if v != sa.DEFAULT_FLAGS.get(k)) or "default"
-    print(f"trial {trial:3d}: M={M:3d} T={T:5d} segs={len(cuts)-1} {'f32' if prec else 'f64'} {'fast' if fast else 'strict'} "
+    print(f"trial {trial:3d}: S={S} M={M:3d} T={T:5d} segs={len(cuts)-1} {'f32' if prec else 'f64'} {'fast' if fast else 'strict'} "
           f"ev={0 if ev is None else len(ev):2d} [{flag_s}]{forced} planes {err:.2e} pools {perr:.2e}", flush=True)
     assert np.isfinite(got[:, :, ok]).all()
     assert err < tol and perr < ptol, "MISMATCH"
