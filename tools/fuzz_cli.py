@@ -1,0 +1,128 @@
+#!/usr/bin/env python3
+"""dev: process-level differential test -- the drop-in CLI (GPU) against the REAL reference binary
+(oracle/_ref/sipnet_ref, which travels to the GPU box) on randomised run directories: random valid
+flag sets in sipnet.in, perturbed parameter files, random event files, random output options.
+Compared: exit codes, sipnet.config (byte-identical below its time-stamp line), sipnet.out and
+events.out (same lines and tokens; numbers within half a unit of the last printed digit + 1e-6
+relative, since OCML's pow / exp differ from glibc's in the last bits), single-variable outputs.
+usage: fuzz_cli.py [trials] [seed]"""
+import gzip, os, shutil, subprocess, sys, tempfile
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import numpy as np
+
+REF_BIN = os.path.join(REPO, "oracle", "_ref", "sipnet_ref")
+CLI = os.path.join(REPO, "sipnet_amd", "bin", "sipnet")
+G = os.path.join(REPO, "tests", "golden", "smoke")
+trials = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+if not os.path.exists(REF_BIN):
+    print("oracle/_ref/sipnet_ref is not on this box"); sys.exit(3)
+
+def random_flags(rng):
+    f = dict(EVENTS=int(rng.random() < 0.8), GDD=1, GROWTH_RESP=int(rng.random() < 0.3),
+             LEAF_WATER=int(rng.random() < 0.3), LITTER_POOL=int(rng.random() < 0.5), WATER_HRESP=1,
+             ANAEROBIC=0, NITROGEN_CYCLE=0, FLOODING=int(rng.random() < 0.3), CARBON_SATURATION=0,
+             SOIL_PHENOL=0, SNOW=int(rng.random() < 0.9))
+    r = rng.random()
+    if r < 0.2: f["GDD"] = 0
+    elif r < 0.4: f["GDD"], f["SOIL_PHENOL"] = 0, 1
+    if rng.random() < 0.4: f["ANAEROBIC"] = 1
+    elif rng.random() < 0.2: f["WATER_HRESP"] = 0
+    if f["ANAEROBIC"] and f["LITTER_POOL"] and rng.random() < 0.6: f["NITROGEN_CYCLE"] = 1
+    if f["LITTER_POOL"] and rng.random() < 0.4: f["CARBON_SATURATION"] = 1
+    return f
+
+def write_case(d, rng):
+    flags = random_flags(rng)
+    # user-specified leaf events exclude every computed phenology (the reference exits 3 otherwise;
+    # a tenth of the trials keep the conflict to check that both binaries reject it alike)
+    user_leaf = rng.random() < 0.3
+    conflict = rng.random() < 0.1
+    if user_leaf and not conflict:
+        flags["GDD"], flags["SOIL_PHENOL"] = 0, 0
+    opts = dict(DO_MAIN_OUTPUT=1, DO_SINGLE_OUTPUTS=int(rng.random() < 0.3), DUMP_CONFIG=1,
+                PRINT_HEADER=int(rng.random() < 0.5), QUIET=1)
+    with open(os.path.join(d, "sipnet.in"), "w") as f:
+        for k, v in {**opts, **flags}.items():
+            f.write(f"{k} = {v}\n")
+    keep = {"leafAllocation", "woodAllocation", "fineRootAllocation", "fineRootFrac", "coarseRootFrac",
+            "laiInit", "leafOnDay", "leafOffDay", "dVpdExp", "soilRespMoistEffect", "cFracLeaf"}
+    out = []
+    for line in open(os.path.join(G, "russell_2", "sipnet.param")):
+        t = line.split()
+        bounded = any(k in t[0] for k in ("Frac", "Allocation", "Eff", "fAnoxia")) if t else True
+        if len(t) >= 2 and t[0] not in keep and not bounded and not t[0].startswith("!") and rng.random() < 0.5:
+            t[1] = repr(float(t[1]) * float(rng.uniform(0.85, 1.15)))
+        if len(t) >= 2 and t[0] in ("leafOnDay", "leafOffDay") and user_leaf and not conflict:
+            t[1] = "0"
+        out.append(" ".join(t))
+    extra = {"soilCSaturation": 3000.0 * rng.uniform(0.5, 2), "waterDrainFrac": rng.uniform(0.2, 1.0),
+             "soilTempLeafOn": rng.uniform(2, 12), "growthRespFrac": 0.2, "leafPoolDepth": 0.1}
+    have = {l.split()[0] for l in out if l.split()}
+    out += [f"{k} {v!r}" for k, v in extra.items() if k not in have]
+    open(os.path.join(d, "sipnet.param"), "w").write("\n".join(out) + "\n")
+    with gzip.open(os.path.join(G, "russell_1", "sipnet.clim.gz"), "rb") as fi, open(os.path.join(d, "sipnet.clim"), "wb") as fo:
+        shutil.copyfileobj(fi, fo)
+    n = int(rng.integers(0, 14))
+    days = sorted(set(int(x) for x in rng.integers(2, 360, size=n)))
+    year = 2016
+    with open(os.path.join(d, "events.in"), "w") as f:
+        for day in days:
+            typ = ["fert", "harv", "irrig", "plant", "till", "leafon", "leafoff"][int(rng.integers(0, 7 if user_leaf else 5))]
+            if typ == "fert": p = f"{rng.uniform(0, 20):.3f} {rng.uniform(0, 60):.3f} {rng.uniform(0, 10):.3f}"
+            elif typ == "harv":
+                a, b = rng.random(), rng.random()
+                p = "1 1 0 0" if rng.random() < 0.15 else f"{a*0.9:.3f} {b*0.9:.3f} {(1-a)*0.9:.3f} {(1-b)*0.9:.3f}"
+            elif typ == "irrig": p = f"{rng.uniform(0.1, 5):.2f} {int(rng.integers(0, 2))}"
+            elif typ == "plant": p = f"{rng.uniform(0, 30):.2f} {rng.uniform(0, 300):.2f} {rng.uniform(0, 40):.2f} {rng.uniform(0, 40):.2f}"
+            elif typ == "till": p = f"{rng.uniform(0.05, 0.6):.3f}"
+            else: p = ""
+            f.write(f"{year} {day} {typ} {p}\n".replace("  ", " "))
+    return flags, opts, n
+
+def isnum(x):
+    try: float(x); return True
+    except ValueError: return False
+
+def compare_text(a, b, what):
+    la, lb = a.split("\n"), b.split("\n")
+    assert len(la) == len(lb), f"{what}: {len(la)} vs {len(lb)} lines"
+    same = 0
+    for i, (x, y) in enumerate(zip(la, lb)):
+        if x == y: same += 1; continue
+        tx, ty = x.replace(",", " ").replace("=", " ").split(), y.replace(",", " ").replace("=", " ").split()
+        assert len(tx) == len(ty), f"{what} line {i}: {x!r} vs {y!r}"
+        for u, v in zip(tx, ty):
+            if u == v: continue
+            assert isnum(u) and isnum(v), f"{what} line {i}: {u!r} vs {v!r}"
+            dec = len(v.split(".")[1]) if "." in v else 0
+            tol = 0.6 * 10 ** (-dec) + 1e-6 * abs(float(v))
+            assert abs(float(u) - float(v)) <= tol, f"{what} line {i}: {u} vs {v}\n{x}\n{y}"
+    return same, len(la)
+
+for trial in range(trials):
+    rng = np.random.default_rng(seed0 * 100003 + trial)
+    da, db = tempfile.mkdtemp(prefix="fz_ref_"), tempfile.mkdtemp(prefix="fz_gpu_")
+    flags, opts, nev = write_case(da, rng)
+    for f in os.listdir(da): shutil.copyfile(os.path.join(da, f), os.path.join(db, f))
+    ra = subprocess.run([REF_BIN, "-i", "sipnet.in"], cwd=da, capture_output=True, text=True)
+    rb = subprocess.run([CLI, "-i", "sipnet.in"], cwd=db, capture_output=True, text=True)
+    tag = "+".join(k for k, v in flags.items() if v != dict(EVENTS=1, GDD=1, WATER_HRESP=1, SNOW=1).get(k, 0))
+    assert ra.returncode == rb.returncode, (trial, ra.returncode, rb.returncode, ra.stdout[-500:], rb.stdout[-500:])
+    if ra.returncode != 0:
+        why = [l for l in ra.stdout.split("\n") if "ERROR" in l]
+        print("           reference:", why[-1][:150] if why else ra.stdout[-150:])
+    report = []
+    if ra.returncode == 0:
+        body = lambda p: open(p).read().split("\n", 1)[1]
+        assert body(os.path.join(da, "sipnet.config")) == body(os.path.join(db, "sipnet.config")), "sipnet.config differs"
+        names = ["sipnet.out"] + (["events.out"] if flags["EVENTS"] else [])
+        if opts["DO_SINGLE_OUTPUTS"]: names += ["sipnet.NEE", "sipnet.NEE_cum", "sipnet.GPP", "sipnet.GPP_cum"]
+        for nm in names:
+            same, tot = compare_text(open(os.path.join(db, nm)).read(), open(os.path.join(da, nm)).read(), nm)
+            report.append(f"{nm} {same}/{tot}")
+        assert os.path.exists(os.path.join(da, "events.out")) == os.path.exists(os.path.join(db, "events.out"))
+    print(f"trial {trial:3d}: rc={ra.returncode} events={nev:2d} [{tag or 'default'}] identical lines: " + ", ".join(report), flush=True)
+    shutil.rmtree(da); shutil.rmtree(db)
+print(f"{trials} trials ok")
