@@ -36,8 +36,10 @@ def test_fuzz_cli_against_the_reference_binary():
     reference's sources, travels with the repository snapshot) side by side on randomised run
     directories -- flags, perturbed parameter files, event files incl. ones the reference must
     reject, output options.  Same exit codes; sipnet.config identical; sipnet.out / events.out /
-    single-variable files token for token (numbers within the last printed digit).  When written:
-    300 trials, 461 of 465 output files byte-identical, the other four off in one or two lines."""
+    single-variable files token for token (numbers within the last printed digit); half of the
+    trials also split the run at a random midnight and hand the checkpoint over in both
+    directions.  When written: 550 trials; of 1 237 output files tallied 1 227 byte-identical, the
+    rest off in one to five lines; 103 two-way restart interchanges reproduced the continuous run."""
     r = subprocess.run([sys.executable, os.path.join(helpers.REPO, "tools", "fuzz_cli.py"), "16", "5"],
                        capture_output=True, text=True, timeout=900)
     print(r.stdout[-3000:])

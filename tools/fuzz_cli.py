@@ -123,6 +123,37 @@ for trial in range(trials):
             same, tot = compare_text(open(os.path.join(db, nm)).read(), open(os.path.join(da, nm)).read(), nm)
             report.append(f"{nm} {same}/{tot}")
         assert os.path.exists(os.path.join(da, "events.out")) == os.path.exists(os.path.join(db, "events.out"))
+    # restart interchange on a random midnight: OUR segment 1 + the REFERENCE resuming from our
+    # checkpoint, and the reference's segment 1 + US resuming from its checkpoint, must both
+    # reproduce the reference's continuous run (restart.c; sipnet.c:1963-1989)
+    if ra.returncode == 0 and rng.random() < 0.5:
+        lines = open(os.path.join(da, "sipnet.clim")).read().split("\n")[:-1]
+        days = [i for i in range(1, len(lines)) if lines[i].split()[:2] != lines[i - 1].split()[:2]]  # year day ...
+        k = days[int(rng.integers(len(days) // 5, 4 * len(days) // 5))]
+        by, bd = int(lines[k].split()[0]), int(lines[k].split()[1])
+        evl = open(os.path.join(da, "events.in")).read().split("\n")[:-1]
+        before = [l for l in evl if (int(l.split()[0]), int(l.split()[1])) < (by, bd)]
+        after = [l for l in evl if (int(l.split()[0]), int(l.split()[1])) >= (by, bd)]
+        full_out = open(os.path.join(da, "sipnet.out")).read()
+        hdr = 1 if opts["PRINT_HEADER"] else 0
+        for first, second, who in ((CLI, REF_BIN, "ours->ref"), (REF_BIN, CLI, "ref->ours")):
+            d1, d2 = tempfile.mkdtemp(prefix="fz_s1_"), tempfile.mkdtemp(prefix="fz_s2_")
+            for d_, cl, ev in ((d1, lines[:k], before), (d2, lines[k:], after)):
+                for f in ("sipnet.in", "sipnet.param"):
+                    shutil.copyfile(os.path.join(da, f), os.path.join(d_, f))
+                open(os.path.join(d_, "sipnet.clim"), "w").write("\n".join(cl) + "\n")
+                open(os.path.join(d_, "events.in"), "w").write("".join(x + "\n" for x in ev))
+            r1 = subprocess.run([first, "-i", "sipnet.in", "--restart-out", "ck"], cwd=d1, capture_output=True, text=True)
+            assert r1.returncode == 0, (who, "segment 1", r1.stdout[-800:])
+            shutil.copyfile(os.path.join(d1, "ck"), os.path.join(d2, "ck"))
+            r2 = subprocess.run([second, "-i", "sipnet.in", "--restart-in", "ck"], cwd=d2, capture_output=True, text=True)
+            assert r2.returncode == 0, (who, "segment 2", r2.stdout[-800:])
+            o1 = open(os.path.join(d1, "sipnet.out")).read().split("\n")[:-1]
+            o2 = open(os.path.join(d2, "sipnet.out")).read().split("\n")[:-1]
+            joined = "\n".join(o1 + o2[hdr:]) + "\n"
+            same, tot = compare_text(joined, full_out, f"restart {who} sipnet.out")
+            report.append(f"restart {who} {same}/{tot}")
+            shutil.rmtree(d1); shutil.rmtree(d2)
     print(f"trial {trial:3d}: rc={ra.returncode} events={nev:2d} [{tag or 'default'}] identical lines: " + ", ".join(report), flush=True)
     shutil.rmtree(da); shutil.rmtree(db)
 print(f"{trials} trials ok")
