@@ -62,11 +62,16 @@ def write_case(d, rng):
     have = {l.split()[0] for l in out if l.split()}
     out += [f"{k} {v!r}" for k, v in extra.items() if k not in have]
     open(os.path.join(d, "sipnet.param"), "w").write("\n".join(out) + "\n")
-    with gzip.open(os.path.join(G, "russell_1", "sipnet.clim.gz"), "rb") as fi, open(os.path.join(d, "sipnet.clim"), "wb") as fo:
+    # forcing: russell (3-hourly, two years) or niwot (legacy 14-column file with a location
+    # column, two steps of unequal length per day: the irregular running-mean ring schedule)
+    forcing = "niwot" if rng.random() < 0.35 else "russell_1"
+    with gzip.open(os.path.join(G, forcing, "sipnet.clim.gz"), "rb") as fi, open(os.path.join(d, "sipnet.clim"), "wb") as fo:
         shutil.copyfileobj(fi, fo)
     n = int(rng.integers(0, 14))
-    days = sorted(set(int(x) for x in rng.integers(2, 360, size=n)))
-    year = 2016
+    if forcing == "niwot":
+        days, year = sorted(set(int(x) for x in rng.integers(2, 300, size=n))), 1999
+    else:
+        days, year = sorted(set(int(x) for x in rng.integers(2, 360, size=n))), 2016
     with open(os.path.join(d, "events.in"), "w") as f:
         for day in days:
             typ = ["fert", "harv", "irrig", "plant", "till", "leafon", "leafoff"][int(rng.integers(0, 7 if user_leaf else 5))]
@@ -128,9 +133,10 @@ for trial in range(trials):
     # reproduce the reference's continuous run (restart.c; sipnet.c:1963-1989)
     if ra.returncode == 0 and rng.random() < 0.5:
         lines = open(os.path.join(da, "sipnet.clim")).read().split("\n")[:-1]
-        days = [i for i in range(1, len(lines)) if lines[i].split()[:2] != lines[i - 1].split()[:2]]  # year day ...
+        c0 = 1 if len(lines[0].split()) == 14 else 0       # legacy files start with a location column
+        days = [i for i in range(1, len(lines)) if lines[i].split()[c0:c0 + 2] != lines[i - 1].split()[c0:c0 + 2]]
         k = days[int(rng.integers(len(days) // 5, 4 * len(days) // 5))]
-        by, bd = int(lines[k].split()[0]), int(lines[k].split()[1])
+        by, bd = int(lines[k].split()[c0]), int(lines[k].split()[c0 + 1])
         evl = open(os.path.join(da, "events.in")).read().split("\n")[:-1]
         before = [l for l in evl if (int(l.split()[0]), int(l.split()[1])) < (by, bd)]
         after = [l for l in evl if (int(l.split()[0]), int(l.split()[1])) >= (by, bd)]
