@@ -160,6 +160,36 @@ for trial in range(trials):
             same, tot = compare_text(joined, full_out, f"restart {who} sipnet.out")
             report.append(f"restart {who} {same}/{tot}")
             shutil.rmtree(d1); shutil.rmtree(d2)
+    # the ensemble extension: every row of a parameter table is one member of ONE batch; each
+    # member's files must equal what the reference writes for that parameter set on its own
+    if ra.returncode == 0 and rng.random() < 0.25:
+        names = [str(x) for x in rng.choice(["aMax", "psnTOpt", "baseVegResp", "soilWHC", "wueConst", "halfSatPar"], size=3, replace=False)]
+        cur = {l.split()[0]: float(l.split()[1]) for l in open(os.path.join(da, "sipnet.param")) if len(l.split()) >= 2 and l.split()[0] in names}
+        M = int(rng.integers(2, 6))
+        rows = [[cur[n] * float(rng.uniform(0.9, 1.1)) for n in names] for _ in range(M)]
+        with open(os.path.join(db, "members.txt"), "w") as f:
+            f.write(" ".join(names) + "\n")
+            for r_ in rows: f.write(" ".join(repr(v) for v in r_) + "\n")
+        re_ = subprocess.run([CLI, "-i", "sipnet.in", "--ensemble-params", "members.txt"], cwd=db, capture_output=True, text=True)
+        assert re_.returncode == 0, re_.stdout[-800:]
+        same_all = 0
+        for m, r_ in enumerate(rows):
+            dm = tempfile.mkdtemp(prefix="fz_mem_")
+            for f in ("sipnet.in", "sipnet.clim", "events.in"): shutil.copyfile(os.path.join(da, f), os.path.join(dm, f))
+            out = []
+            for l in open(os.path.join(da, "sipnet.param")):
+                t = l.split()
+                if len(t) >= 2 and t[0] in names: t[1] = repr(r_[names.index(t[0])])
+                out.append(" ".join(t))
+            open(os.path.join(dm, "sipnet.param"), "w").write("\n".join(out) + "\n")
+            rm = subprocess.run([REF_BIN, "-i", "sipnet.in"], cwd=dm, capture_output=True, text=True)
+            assert rm.returncode == 0
+            same, tot = compare_text(open(os.path.join(db, f"sipnet.{m}.out")).read(), open(os.path.join(dm, "sipnet.out")).read(), f"member {m} sipnet.out")
+            same_all += same == tot
+            if flags["EVENTS"]:
+                compare_text(open(os.path.join(db, f"events.{m}.out")).read(), open(os.path.join(dm, "events.out")).read(), f"member {m} events.out")
+            shutil.rmtree(dm)
+        report.append(f"ensemble {same_all}/{M} members identical")
     print(f"trial {trial:3d}: rc={ra.returncode} events={nev:2d} [{tag or 'default'}] identical lines: " + ", ".join(report), flush=True)
     shutil.rmtree(da); shutil.rmtree(db)
 print(f"{trials} trials ok")
