@@ -160,6 +160,27 @@ for trial in range(trials):
             same, tot = compare_text(joined, full_out, f"restart {who} sipnet.out")
             report.append(f"restart {who} {same}/{tot}")
             shutil.rmtree(d1); shutil.rmtree(d2)
+    # --debug-log: 13 pools, 56 fluxes, 37 tracker fields per step (%.15g: compared to 1e-9
+    # relative with a 1e-9 absolute floor -- plantCAccountingDelta is a running sum of differences)
+    if ra.returncode == 0 and rng.random() < 0.2:
+        for d_, binary in ((da, REF_BIN), (db, CLI)):
+            rr = subprocess.run([binary, "-i", "sipnet.in", "--debug-log", "dbg"], cwd=d_, capture_output=True, text=True)
+            assert rr.returncode == 0, rr.stdout[-500:]
+        worst = 0.0
+        for kind in ("envi", "fluxes", "trackers"):
+            la = open(os.path.join(da, f"dbg_{kind}.log")).read().split("\n")
+            lb = open(os.path.join(db, f"dbg_{kind}.log")).read().split("\n")
+            assert len(la) == len(lb), f"debug {kind}: line counts"
+            for i, (x, y) in enumerate(zip(la, lb)):
+                if x == y: continue
+                tx, ty = x.split(), y.split()
+                assert len(tx) == len(ty), f"debug {kind} line {i}"
+                for u, v in zip(tx, ty):
+                    if u == v: continue
+                    e = abs(float(u) - float(v)) / max(abs(float(u)), 1.0)
+                    worst = max(worst, e)
+                    assert e < 1e-9, f"debug {kind} line {i}: {u} vs {v}"
+        report.append(f"debug logs worst {worst:.1e}")
     # the ensemble extension: every row of a parameter table is one member of ONE batch; each
     # member's files must equal what the reference writes for that parameter set on its own
     if ra.returncode == 0 and rng.random() < 0.25:
