@@ -1,0 +1,57 @@
+"""include/sipnet_amd.h consumed from plain C (gcc -std=c99 -pedantic, no C++): the header is valid C,
+the library links from C, the host-side entry points work; without a GPU batch creation answers
+SIPNET_ERR_NO_DEVICE (there is no CPU path), with one a two-member batch runs through the C-ABI
+alone (no Python binding, no CLI) and matches the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import sipnet_amd as sa
+from tests import helpers
+
+SRC = os.path.join(helpers.REPO, "tests", "c", "capi_consumer.c")
+
+
+def build(tmp_path):
+    exe = str(tmp_path / "capi_consumer")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror",
+                        "-I" + os.path.join(helpers.REPO, "include"), SRC, "-o", exe,
+                        "-L" + os.path.join(helpers.REPO, "sipnet_amd"), "-lsipnet_amd",
+                        "-Wl,-rpath," + os.path.join(helpers.REPO, "sipnet_amd")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def run(exe, tmp_path):
+    clim = str(tmp_path / "niwot.clim")
+    helpers.gunzip_to(os.path.join(helpers.smoke_dir("niwot"), "sipnet.clim.gz"), clim)
+    r = subprocess.run([exe, os.path.join(helpers.smoke_dir("niwot"), "sipnet.param"), clim],
+                       capture_output=True, text=True, timeout=300)
+    kv = dict(l.split("=", 1) for l in r.stdout.strip().split("\n") if "=" in l)
+    return r.returncode, kv
+
+
+@pytest.mark.skipif(sa.lib().sipnet_device_count() > 0, reason="a GPU is present")
+def test_header_is_plain_c_and_there_is_no_cpu_path(tmp_path):
+    rc, kv = run(build(tmp_path), tmp_path)
+    assert rc == 0
+    assert kv["n_steps"] == "5237" and kv["index_aMax"] == "4" and float(kv["aMax"]) == 8.3
+    assert int(kv["header_bytes"]) > 300
+    assert kv["create"] == "100" and "no usable HIP device" in kv["no_device_message"]
+
+
+@pytest.mark.gpu
+def test_two_member_batch_through_the_c_abi_alone(oracle, tmp_path):
+    rc, kv = run(build(tmp_path), tmp_path)
+    assert rc == 0 and kv["create"] == "0"
+    case = helpers.load_smoke_case("niwot", str(tmp_path))
+    members = np.stack([case["params"], case["params"]])
+    members[1, sa.config.param_index("aMax")] *= 1.1
+    want, _, st = oracle.run_block(case["flags"], members, case["clim"], None)
+    assert (st == 0).all()
+    assert float(kv["sum_nee_0"]) == pytest.approx(want[0][:, 0].sum(), abs=1e-8)
+    assert float(kv["sum_nee_1"]) == pytest.approx(want[0][:, 1].sum(), abs=1e-8)
+    assert abs(float(kv["sum_nee_0"]) - float(kv["sum_nee_1"])) > 1e-3
