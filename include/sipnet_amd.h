@@ -208,10 +208,32 @@ int sipnet_batch_set_params(sipnet_batch *b, int32_t site, int32_t first_member,
  *                       reciprocals instead of divisions, polynomial exp2; <= 2.5e-16 on NEE
  *                       against the reference on the benchmark ensemble; launches that ask for
  *                       full records still use the strict-order kernel's fast-math variant
- * A new fp64 batch is STRICT unless the environment variable SIPNET_FAST_MATH=1 is set when it
- * is created; this call overrides either.  May be changed between runs. */
+ * A new fp64 batch is STRICT (no environment variable changes that).  May be changed between
+ * runs. */
 enum sipnet_math { SIPNET_MATH_STRICT = 0, SIPNET_MATH_FAST = 1 };
 int sipnet_batch_set_math(sipnet_batch *b, int32_t policy);
+
+/* Which step kernel sipnet_batch_run launches.  AUTO (the default) picks by batch shape: with
+ * SIPNET_MATH_FAST and the default model flags the three-wavefront cooperative kernel while there
+ * are at most two 64-member chunks per compute unit (running-mean ring in LDS up to one chunk per
+ * CU, in HBM above), the one-wavefront throughput kernel for bigger batches and for optional model
+ * flags; with SIPNET_MATH_STRICT the strict-order kernel.  The other values force one kernel
+ * (tests and measurements compare every instantiation with the oracle this way); a forced kernel
+ * that cannot run the batch (throughput kernels under SIPNET_MATH_STRICT, cooperative kernels with
+ * optional model flags) makes sipnet_batch_run return
+ * SIPNET_ERR_BAD_ARGUMENT.  Nothing in the launch path reads the environment. */
+enum sipnet_kernel {
+  SIPNET_KERNEL_AUTO = 0,
+  SIPNET_KERNEL_ONE_WAVE = 1, /* stepFastKernel: one wavefront per 64 members */
+  SIPNET_KERNEL_COOP_LDS = 2, /* stepCoopKernel, ring in LDS (one workgroup per CU) */
+  SIPNET_KERNEL_COOP_HBM = 3, /* stepCoopKernel, ring in HBM */
+  SIPNET_KERNEL_STRICT = 4    /* stepKernel (with SIPNET_MATH_FAST: its fast-math variant) */
+};
+enum sipnet_kernel_option {
+  SIPNET_KOPT_ONE_WAVE_PER_SIMD = 1, /* one-wave kernel: never the 256-VGPR (two waves/SIMD) build */
+  SIPNET_KOPT_RUNTIME_FLAGS = 2      /* one-wave kernel: always the run-time-flag instantiation */
+};
+int sipnet_batch_set_kernel(sipnet_batch *b, int32_t kernel, int32_t options);
 
 /* Per-member initialisation == setupModel() (sipnet.c:1858-1951): parameter
  * unit conversion, derived parameters, initial pools, trackers, phenology state
@@ -348,6 +370,21 @@ int sipnet_batch_get_site_series(sipnet_batch *b, int32_t site, double *gdd,
 /* Last launch's average kernel time in ms measured with HIP events on the
  * launch stream (for bench.py's roofline line); <0 if none. */
 double sipnet_batch_last_kernel_ms(sipnet_batch *b);
+/* What the last sipnet_batch_run actually launched: the step kernel's instantiation as
+ * rocprofv3 names it (e.g. "stepCoopKernel<double, true, true>"), its launch shape, and the
+ * host-side costs of the last sipnet_batch_setup that rebuilt the site plans. */
+typedef struct sipnet_launch_info {
+  char kernel[96];
+  int32_t grid, block_threads;  /* workgroups, threads per workgroup */
+  int32_t waves_per_simd;       /* resident wavefronts per SIMD the register budget allows */
+  int32_t lds_bytes;            /* static LDS per workgroup */
+  int32_t num_cus;              /* compute units of the device */
+  int32_t plan_threads;         /* host threads that built the site plans */
+  double plan_build_ms;         /* host: building all site plans */
+  double plan_upload_ms;        /* host -> device copy of the plans */
+} sipnet_launch_info;
+int sipnet_batch_last_launch(sipnet_batch *b, sipnet_launch_info *out);
+const char *sipnet_batch_last_kernel_name(sipnet_batch *b); /* "" before the first run */
 
 /* Device buffer helpers for callers without their own allocator (the CLI). */
 void *sipnet_dev_alloc(size_t bytes);

@@ -26,6 +26,9 @@ ERR_NO_DEVICE = 100
 ERR_BAD_ARGUMENT = 101
 
 F64, F32_MIXED = 0, 1
+# enum sipnet_kernel / sipnet_kernel_option
+KERNEL_AUTO, KERNEL_ONE_WAVE, KERNEL_COOP_LDS, KERNEL_COOP_HBM, KERNEL_STRICT = range(5)
+KOPT_ONE_WAVE_PER_SIMD, KOPT_RUNTIME_FLAGS = 1, 2
 
 
 class Event(C.Structure):
@@ -71,6 +74,14 @@ class Restart(C.Structure):
             i = (i + 1) % 250
 
 
+class LaunchInfo(C.Structure):
+    """struct sipnet_launch_info"""
+    _fields_ = [("kernel", C.c_char * 96), ("grid", C.c_int32), ("block_threads", C.c_int32),
+                ("waves_per_simd", C.c_int32), ("lds_bytes", C.c_int32), ("num_cus", C.c_int32),
+                ("plan_threads", C.c_int32), ("plan_build_ms", C.c_double),
+                ("plan_upload_ms", C.c_double)]
+
+
 RESTART_WARN_BOUNDARY_NOT_MIDNIGHT, RESTART_WARN_BUILD_INFO, RESTART_WARN_TIME_GAP = 1, 2, 4
 
 # name -> (restype, argtypes); every symbol declared in include/sipnet_amd.h
@@ -88,6 +99,9 @@ SIGNATURES = {
     "sipnet_batch_set_params": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "sipnet_batch_setup": (C.c_int, [_P, _P]),
     "sipnet_batch_set_math": (C.c_int, [_P, C.c_int32]),
+    "sipnet_batch_set_kernel": (C.c_int, [_P, C.c_int32, C.c_int32]),
+    "sipnet_batch_last_launch": (C.c_int, [_P, _P]),
+    "sipnet_batch_last_kernel_name": (C.c_char_p, [_P]),
     "sipnet_batch_run": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int64, _P]),
     "sipnet_batch_run_debug": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, C.c_int64, _P]),
     "sipnet_batch_reduce_plane": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int64, _P, _P]),
@@ -140,6 +154,16 @@ SIGNATURES = {
 }
 
 _lib = None
+
+
+def use_library(path):
+    """Development hook (tools/variant_bench.py): load another build of the C-ABI library
+    instead of the in-tree product.  Must be called before the first lib(); never read from
+    the environment."""
+    global LIB_PATH
+    if _lib is not None:
+        raise RuntimeError("sipnet_amd: the library is already loaded")
+    LIB_PATH = os.path.abspath(path)
 
 
 def lib():

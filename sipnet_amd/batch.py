@@ -9,13 +9,16 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import F32_MIXED, F64, NPARAMS, NREC, NSTATE, RING_SLOTS, Event, check, lib
+from ._lib import (F32_MIXED, F64, KERNEL_AUTO, NPARAMS, NREC, NSTATE, RING_SLOTS, Event, LaunchInfo,
+                   check, lib)
 
 
 class Batch:
-    def __init__(self, flags, n_sites, n_members, precision=F64, device=0, fast_math=None):
-        """fast_math (fp64 batches): True = throughput kernels, False = strict reference order,
-        None = the library default (strict unless SIPNET_FAST_MATH=1 in the environment)."""
+    def __init__(self, flags, n_sites, n_members, precision=F64, device=0, fast_math=None,
+                 kernel=KERNEL_AUTO, kernel_options=0):
+        """fast_math (fp64 batches): True = throughput kernels, False / None = strict reference
+        order (the library default; no environment variable changes it).  kernel /
+        kernel_options: sipnet_batch_set_kernel (KERNEL_* / KOPT_* of _lib)."""
         import torch  # device memory + streams only
         self._torch = torch
         if not torch.cuda.is_available():
@@ -35,10 +38,25 @@ class Batch:
         self.n_steps = 0
         if fast_math is not None and precision == F64:
             self.set_math(fast_math)
+        if kernel != KERNEL_AUTO or kernel_options:
+            self.set_kernel(kernel, kernel_options)
 
     def set_math(self, fast):
         """sipnet_batch_set_math: arithmetic policy of an fp64 batch (strict order / throughput)"""
         check(self.L.sipnet_batch_set_math(self.h, 1 if fast else 0), "set_math")
+
+    def set_kernel(self, kernel=KERNEL_AUTO, options=0):
+        """sipnet_batch_set_kernel: force one step kernel (KERNEL_ONE_WAVE / COOP_LDS / COOP_HBM /
+        STRICT) or go back to the shape-based choice (KERNEL_AUTO)."""
+        check(self.L.sipnet_batch_set_kernel(self.h, int(kernel), int(options)), "set_kernel")
+
+    def last_launch(self):
+        """What the last run() launched: dict(kernel, grid, block_threads, waves_per_simd,
+        lds_bytes, num_cus, plan_threads, plan_build_ms, plan_upload_ms)."""
+        li = LaunchInfo()
+        check(self.L.sipnet_batch_last_launch(self.h, C.byref(li)), "last_launch")
+        return {n: (getattr(li, n).decode() if n == "kernel" else getattr(li, n))
+                for n, _ in LaunchInfo._fields_}
 
     # -- lifetime ---------------------------------------------------------------
     def close(self):

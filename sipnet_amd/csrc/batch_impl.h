@@ -31,6 +31,10 @@ struct sipnet_batch {
   int64_t ncol = 0;
   int32_t n_steps = 0;  // steps per site (all sites equal)
   bool fastMath = false;
+  int32_t kernelPolicy = SIPNET_KERNEL_AUTO, kernelOptions = 0;
+  LaunchInfo lastLaunch{};
+  int32_t planThreads = 0;
+  double planBuildMs = 0.0, planUploadMs = 0.0;
   bool genericExponents = false;  // some member has dVpdExp != 2 or soilRespMoistEffect != 1
 
   // host-side inputs kept so the plan can be rebuilt in any call order
@@ -45,8 +49,9 @@ struct sipnet_batch {
   int32_t stepsDone = 0;       // records the carried state reflects, -1 = unknown
 
   // HBM
-  double* d_raw = nullptr;     // [ncol][NPARAMS] raw upload (AoS)
-  double* d_prm = nullptr;     // [NPARAMS][ncol]
+  double* d_rawStage = nullptr;  // [rawStageCap][NPARAMS] raw rows of one set_params call
+  size_t rawStageCap = 0;
+  double* d_prm = nullptr;     // [NPARAMS][ncol] converted parameters: the one copy on the device
   double* d_state = nullptr;   // [NSTATE][ncol]
   double* d_ring = nullptr;    // [RING_SLOTS][ncol]
   // second copies for particle-filter resampling (gather into the spare, then swap); lazily made

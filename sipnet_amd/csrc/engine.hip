@@ -3,11 +3,14 @@
 // point needs a HIP device and reports SIPNET_ERR_NO_DEVICE otherwise.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/sipnet_amd.h"
@@ -22,6 +25,13 @@ void setError(const std::string& s) { g_lastError = s; }
 
 using namespace sipnet;
 
+static double nowMs() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// Site plans are independent of each other: they are built by a pool of host threads (one site
+// at a time each) straight into the flattened upload buffers, so a 32-site batch costs about
+// what one site costs (bench.py reports plan_ms).
 static int uploadPlan(sipnet_batch* b, hipStream_t stream) {
   // every site needs forcing of equal length
   for (int s = 0; s < b->n_sites; s++) {
@@ -30,49 +40,80 @@ static int uploadPlan(sipnet_batch* b, hipStream_t stream) {
       return SIPNET_ERR_BAD_ARGUMENT;
     }
   }
+  const double t0 = nowMs();
+  const int nS = b->n_sites, nT = b->n_steps;
   b->plans.clear();
-  b->plans.reserve(b->n_sites);
-  size_t nOps = 0, nEv = 0;
-  for (int s = 0; s < b->n_sites; s++) {
-    b->plans.push_back(buildSitePlan(b->flags, b->n_steps, b->clim[s].data(),
-                                     b->year[s].data(), b->day[s].data(),
-                                     (int32_t)b->events[s].size(), b->events[s].data(),
-                                     b->resume[s].set ? &b->resume[s] : nullptr));
+  b->plans.resize(nS);
+  std::vector<StepRec> steps((size_t)nS * nT);
+  std::vector<FastRec> fast((size_t)nS * nT + kFastTile);
+  int nThreads = (int)std::thread::hardware_concurrency();
+  if (nThreads < 1) nThreads = 1;
+  if (nThreads > 16) nThreads = 16;
+  if (nThreads > nS) nThreads = nS;
+  // phase 1: plans (parallel over sites); the fast records are derived per site with site-local
+  // op / event indices and rebased in phase 2 once the totals are known
+  std::atomic<int> next{0};
+  auto build = [&]() {
+    for (int s = next.fetch_add(1); s < nS; s = next.fetch_add(1)) {
+      b->plans[s] = buildSitePlan(b->flags, nT, b->clim[s].data(), b->year[s].data(),
+                                  b->day[s].data(), (int32_t)b->events[s].size(),
+                                  b->events[s].data(), b->resume[s].set ? &b->resume[s] : nullptr);
+      const std::vector<FastRec> fr = buildFastRecs(b->plans[s]);
+      memcpy(fast.data() + (size_t)s * nT, fr.data(), (size_t)nT * sizeof(FastRec));
+      memcpy(steps.data() + (size_t)s * nT, b->plans[s].steps.data(), (size_t)nT * sizeof(StepRec));
+    }
+  };
+  {
+    std::vector<std::thread> pool;
+    for (int i = 1; i < nThreads; i++) pool.emplace_back(build);
+    build();
+    for (auto& th : pool) th.join();
+  }
+  // phase 2: make op / event indices global
+  std::vector<int32_t> opBase(nS + 1, 0), evBase(nS + 1, 0);
+  for (int s = 0; s < nS; s++) {
     b->siteStatus[s] = b->plans[s].status;
-    nOps += b->plans[s].ringOps.size();
-    nEv += b->plans[s].events.size();
+    opBase[s + 1] = opBase[s] + (int32_t)b->plans[s].ringOps.size();
+    evBase[s + 1] = evBase[s] + (int32_t)b->plans[s].events.size();
   }
-  // flatten: make op / event indices global
-  std::vector<StepRec> steps((size_t)b->n_sites * b->n_steps);
-  std::vector<FastRec> fast((size_t)b->n_sites * b->n_steps + kFastTile);
-  std::vector<RingOp> ops;
-  std::vector<EvRec> evs;
-  ops.reserve(nOps + 1);
-  evs.reserve(nEv + 1);
-  for (int s = 0; s < b->n_sites; s++) {
-    const SitePlan& p = b->plans[s];
-    const int32_t opBase = (int32_t)ops.size(), evBase = (int32_t)evs.size();
-    for (int t = 0; t < b->n_steps; t++) {
-      StepRec r = p.steps[t];
-      r.ringOpFirst += opBase;
-      r.evFirst += evBase;
-      steps[(size_t)s * b->n_steps + t] = r;
+  std::vector<RingOp> ops((size_t)opBase[nS] + 1);
+  std::vector<EvRec> evs((size_t)evBase[nS] + 1);
+  next = 0;
+  auto rebase = [&]() {
+    for (int s = next.fetch_add(1); s < nS; s = next.fetch_add(1)) {
+      const SitePlan& p = b->plans[s];
+      if (opBase[s] || evBase[s]) {
+        StepRec* st = steps.data() + (size_t)s * nT;
+        FastRec* fr = fast.data() + (size_t)s * nT;
+        for (int t = 0; t < nT; t++) {
+          st[t].ringOpFirst += opBase[s];
+          st[t].evFirst += evBase[s];
+          fr[t].opFirst += opBase[s];
+          fr[t].evFirst += evBase[s];
+        }
+      }
+      if (!p.ringOps.empty()) memcpy(ops.data() + opBase[s], p.ringOps.data(), p.ringOps.size() * sizeof(RingOp));
+      if (!p.events.empty()) memcpy(evs.data() + evBase[s], p.events.data(), p.events.size() * sizeof(EvRec));
     }
-    std::vector<FastRec> fr = buildFastRecs(p);
-    for (int t = 0; t < b->n_steps; t++) {
-      fr[t].opFirst += opBase;
-      fr[t].evFirst += evBase;
-      fast[(size_t)s * b->n_steps + t] = fr[t];
-    }
-    ops.insert(ops.end(), p.ringOps.begin(), p.ringOps.end());
-    evs.insert(evs.end(), p.events.begin(), p.events.end());
+  };
+  {
+    std::vector<std::thread> pool;
+    for (int i = 1; i < nThreads; i++) pool.emplace_back(rebase);
+    rebase();
+    for (auto& th : pool) th.join();
   }
-  if (ops.empty()) ops.push_back(RingOp{0.0, 0, -1});
-  if (evs.empty()) evs.push_back(EvRec{0, 0, {0, 0, 0, 0}});
+  if (opBase[nS] == 0) ops[0] = RingOp{0.0, 0, -1};
+  if (evBase[nS] == 0) evs[0] = EvRec{0, 0, {0, 0, 0, 0}};
+  const double t1 = nowMs();
 
+  // a launch that still reads the previous plan (on any stream) must have finished
+  HIP_TRY(hipDeviceSynchronize());
   if (steps.size() > b->planCap) {
     if (b->d_plan) HIP_TRY(hipFree(b->d_plan));
     if (b->d_fast) HIP_TRY(hipFree(b->d_fast));
+    b->d_plan = nullptr;
+    b->d_fast = nullptr;
+    b->planCap = 0;
     HIP_TRY(hipMalloc(&b->d_plan, steps.size() * sizeof(StepRec)));
     HIP_TRY(hipMalloc(&b->d_fast, fast.size() * sizeof(FastRec)));
     b->planCap = steps.size();
@@ -80,11 +121,15 @@ static int uploadPlan(sipnet_batch* b, hipStream_t stream) {
   HIP_TRY(hipMemcpy(b->d_fast, fast.data(), fast.size() * sizeof(FastRec), hipMemcpyHostToDevice));
   if (ops.size() > b->ringOpCap) {
     if (b->d_ringOps) HIP_TRY(hipFree(b->d_ringOps));
+    b->d_ringOps = nullptr;
+    b->ringOpCap = 0;
     HIP_TRY(hipMalloc(&b->d_ringOps, ops.size() * sizeof(RingOp)));
     b->ringOpCap = ops.size();
   }
   if (evs.size() > b->evCap) {
     if (b->d_events) HIP_TRY(hipFree(b->d_events));
+    b->d_events = nullptr;
+    b->evCap = 0;
     HIP_TRY(hipMalloc(&b->d_events, evs.size() * sizeof(EvRec)));
     b->evCap = evs.size();
   }
@@ -94,8 +139,11 @@ static int uploadPlan(sipnet_batch* b, hipStream_t stream) {
   HIP_TRY(hipMemcpy(b->d_events, evs.data(), evs.size() * sizeof(EvRec), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(b->d_siteStatus, b->siteStatus.data(), b->n_sites * sizeof(int32_t),
                     hipMemcpyHostToDevice));
-  (void)stream;
+  (void)stream;  // synchronous copies on the null stream after the device-wide wait above
   b->planDirty = false;
+  b->planThreads = nThreads;
+  b->planBuildMs = t1 - t0;
+  b->planUploadMs = nowMs() - t1;
   return SIPNET_OK;
 }
 
@@ -137,13 +185,18 @@ int sipnet_batch_create(const int32_t* flags, int32_t n_sites, int32_t n_members
   b->precision = precision;
   b->device = device;
   b->ncol = (int64_t)n_sites * n_members;
+  // the throughput kernels index the ring [slot][col] with 32-bit element offsets
+  if (b->ncol * SIPNET_RING_SLOTS >= (int64_t)1 << 31) {
+    setError("sipnet_batch_create: n_sites * n_members * 250 must stay below 2^31 "
+             "(8.5 M columns per batch); split the ensemble into several batches");
+    delete b;
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) b->numCUs = prop.multiProcessorCount;
   }
   b->fastMath = (precision == SIPNET_F32_MIXED);
-  const char* fm = getenv("SIPNET_FAST_MATH");
-  if (fm && precision == SIPNET_F64) b->fastMath = atoi(fm) != 0;
   b->clim.resize(n_sites);
   b->year.resize(n_sites);
   b->day.resize(n_sites);
@@ -155,13 +208,12 @@ int sipnet_batch_create(const int32_t* flags, int32_t n_sites, int32_t n_members
   if (rc) { delete b; return rc; }
   const size_t nc = (size_t)b->ncol;
   hipError_t e = hipSuccess;
-  if (e == hipSuccess) e = hipMalloc(&b->d_raw, nc * SIPNET_NPARAMS * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&b->d_prm, nc * SIPNET_NPARAMS * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&b->d_state, nc * SIPNET_NSTATE * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&b->d_ring, nc * SIPNET_RING_SLOTS * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&b->d_siteStatus, n_sites * sizeof(int32_t));
   if (e == hipSuccess) e = hipMalloc(&b->d_scratchRow, nc * sizeof(double));
-  if (e == hipSuccess) e = hipMemset(b->d_raw, 0, nc * SIPNET_NPARAMS * sizeof(double));
+  if (e == hipSuccess) e = hipMemset(b->d_prm, 0, nc * SIPNET_NPARAMS * sizeof(double));
   if (e == hipSuccess) e = hipMemset(b->d_state, 0, nc * SIPNET_NSTATE * sizeof(double));
   if (e == hipSuccess) e = hipEventCreate(&b->ev0);
   if (e == hipSuccess) e = hipEventCreate(&b->ev1);
@@ -177,7 +229,7 @@ int sipnet_batch_create(const int32_t* flags, int32_t n_sites, int32_t n_members
 void sipnet_batch_destroy(sipnet_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
-  if (b->d_raw) (void)hipFree(b->d_raw);
+  if (b->d_rawStage) (void)hipFree(b->d_rawStage);
   if (b->d_prm) (void)hipFree(b->d_prm);
   if (b->d_state) (void)hipFree(b->d_state);
   if (b->d_ring) (void)hipFree(b->d_ring);
@@ -255,8 +307,23 @@ int sipnet_batch_set_params(sipnet_batch* b, int32_t site, int32_t first_member,
     if (r[SP_dVpdExp] != 2.0 || r[SP_soilRespMoistEffect] != 1.0) b->genericExponents = true;
   }
   const int64_t col0 = (int64_t)site * b->n_members + first_member;
-  HIP_TRY(hipMemcpy(b->d_raw + col0 * SIPNET_NPARAMS, raw,
-                    (size_t)count * SIPNET_NPARAMS * sizeof(double), hipMemcpyHostToDevice));
+  // no launch of this batch may still be reading the parameter block (callers' streams are
+  // non-blocking with respect to the null stream used here)
+  HIP_TRY(hipDeviceSynchronize());
+  if ((size_t)count > b->rawStageCap) {
+    if (b->d_rawStage) HIP_TRY(hipFree(b->d_rawStage));
+    b->d_rawStage = nullptr;
+    b->rawStageCap = 0;
+    HIP_TRY(hipMalloc(&b->d_rawStage, (size_t)count * SIPNET_NPARAMS * sizeof(double)));
+    b->rawStageCap = (size_t)count;
+  }
+  HIP_TRY(hipMemcpy(b->d_rawStage, raw, (size_t)count * SIPNET_NPARAMS * sizeof(double),
+                    hipMemcpyHostToDevice));
+  // the parameter half of setupModel() (sipnet.c:1873-1916): from here on the converted block is
+  // the only copy of the members' parameters on the device
+  launchConvertParams(b->d_rawStage, b->d_prm, b->ncol, col0, count, nullptr);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(nullptr));
   return SIPNET_OK;
 }
 
@@ -271,7 +338,6 @@ int sipnet_batch_setup(sipnet_batch* b, void* hip_stream) {
   }
   SetupArgs a;
   a.plan = b->d_plan;
-  a.raw = b->d_raw;
   a.prm = b->d_prm;
   a.state = b->d_state;
   a.ring = b->d_ring;
@@ -307,6 +373,17 @@ int sipnet_batch_set_math(sipnet_batch* b, int32_t policy) {
     return SIPNET_ERR_BAD_ARGUMENT;
   }
   b->fastMath = policy == SIPNET_MATH_FAST;
+  return SIPNET_OK;
+}
+
+int sipnet_batch_set_kernel(sipnet_batch* b, int32_t kernel, int32_t options) {
+  if (!b || kernel < SIPNET_KERNEL_AUTO || kernel > SIPNET_KERNEL_STRICT ||
+      (options & ~(SIPNET_KOPT_ONE_WAVE_PER_SIMD | SIPNET_KOPT_RUNTIME_FLAGS))) {
+    setError("sipnet_batch_set_kernel: bad argument");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  b->kernelPolicy = kernel;
+  b->kernelOptions = options;
   return SIPNET_OK;
 }
 
@@ -362,10 +439,38 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
   a.step0 = step0;
   a.n_steps = n_steps;
   memcpy(a.flags, b->flags, sizeof(a.flags));
+  // ---- kernel choice (sipnet_batch_set_kernel); nothing here reads the environment ----------
+  const bool defaultFlags = isDefaultFlagSet(b->flags);
+  const int64_t blocks = (int64_t)b->n_sites * ((b->n_members + 63) / 64);
+  int kernel = b->kernelPolicy;
+  if (kernel == SIPNET_KERNEL_AUTO) {
+    // Few 64-member chunks per CU: the step is bound by what one wavefront can issue, so three
+    // wavefronts share each chunk (step_coop.hip) -- with the chunk's ring in LDS when there is
+    // at most one chunk per CU (c10k 12.4 vs 18.2 ms), in HBM up to two per CU (c4 16.0 vs
+    // 19.3 ms).  Bigger batches fill the SIMDs with the one-wave kernel (c3: 16.9 vs 27.6 ms).
+    // Optional model flags (litter pool, nitrogen cycle, ...) always take the one-wave kernel.
+    // Full records and strict arithmetic: the strict-order kernel.
+    if (!b->fastMath || d_rec) kernel = SIPNET_KERNEL_STRICT;
+    else if (defaultFlags && blocks <= (int64_t)b->numCUs) kernel = SIPNET_KERNEL_COOP_LDS;
+    else if (defaultFlags && blocks <= 2 * (int64_t)b->numCUs) kernel = SIPNET_KERNEL_COOP_HBM;
+    else kernel = SIPNET_KERNEL_ONE_WAVE;
+  } else if (kernel != SIPNET_KERNEL_STRICT) {
+    if (!b->fastMath) {
+      setError("sipnet_batch_run: the throughput kernels need SIPNET_MATH_FAST (sipnet_batch_set_math)");
+      return SIPNET_ERR_BAD_ARGUMENT;
+    }
+    if (d_rec) {
+      setError("sipnet_batch_run: full records are written by the strict-order kernel only");
+      return SIPNET_ERR_BAD_ARGUMENT;
+    }
+    if (kernel != SIPNET_KERNEL_ONE_WAVE && !defaultFlags) {
+      setError("sipnet_batch_run: the cooperative kernel has the default model flags compiled in");
+      return SIPNET_ERR_BAD_ARGUMENT;
+    }
+  }
   HIP_TRY(hipEventRecord(b->ev0, stream));
-  if (b->fastMath && !d_rec && !getenv("SIPNET_NO_FAST_KERNEL")) {
+  if (kernel != SIPNET_KERNEL_STRICT) {
     // throughput path: step_fast.hip / step_coop.hip
-    const bool defaultFlags = isDefaultFlagSet(b->flags);
     FastArgs f;
     f.fast = b->d_fast;
     f.ringOps = b->d_ringOps;
@@ -387,22 +492,10 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
     f.scratchRow = b->d_scratchRow;
     memcpy(f.flags, b->flags, sizeof(f.flags));
     f.numCUs = b->numCUs;
-    // Few 64-member chunks per CU: the step is bound by what one wavefront can issue, so three
-    // wavefronts share each chunk (step_coop.hip) -- with the chunk's ring in LDS when there is
-    // at most one chunk per CU (c10k 12.4 vs 18.2 ms), in HBM up to two per CU (c4 16.0 vs
-    // 19.3 ms).  Bigger batches fill the SIMDs with the one-wave kernel (c3: 16.9 vs 27.6 ms).
-    const int64_t blocks = (int64_t)b->n_sites * ((b->n_members + 63) / 64);
-    const char* coopEnv = getenv("SIPNET_COOP");
-    // SIPNET_COOP: 0 one-wave kernel, 1 cooperative (ring in LDS when it fits), 2 cooperative with
-    // the ring in HBM (development switch)
-    // Optional model flags (litter pool, nitrogen cycle, ...) always take the one-wave kernel's
-    // run-time-flag instantiation.
-    const int coopMode = coopEnv ? atoi(coopEnv) : (blocks <= 2 * (int64_t)b->numCUs ? 1 : 0);
-    const bool coop = coopMode != 0 && defaultFlags;
-    if (coop) launchStepCoop(f, b->precision, coopMode == 1 && blocks <= b->numCUs, stream);
-    else launchStepFast(f, b->precision, stream);
+    if (kernel == SIPNET_KERNEL_ONE_WAVE) launchStepFast(f, b->precision, b->kernelOptions, stream, &b->lastLaunch);
+    else launchStepCoop(f, b->precision, kernel == SIPNET_KERNEL_COOP_LDS, stream, &b->lastLaunch);
   } else {
-    launchStep(a, b->precision, b->fastMath, stream);
+    launchStep(a, b->precision, b->fastMath, stream, &b->lastLaunch);
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(b->ev1, stream));
@@ -420,6 +513,22 @@ double sipnet_batch_last_kernel_ms(sipnet_batch* b) {
   b->lastMs = ms;
   return (double)ms;
 }
+
+int sipnet_batch_last_launch(sipnet_batch* b, sipnet_launch_info* out) {
+  if (!b || !out) return SIPNET_ERR_BAD_ARGUMENT;
+  memset(out, 0, sizeof(*out));
+  snprintf(out->kernel, sizeof out->kernel, "%s", b->lastLaunch.kernel);
+  out->grid = b->lastLaunch.grid;
+  out->block_threads = b->lastLaunch.block;
+  out->waves_per_simd = b->lastLaunch.wavesPerSimd;
+  out->lds_bytes = b->lastLaunch.ldsBytes;
+  out->num_cus = b->numCUs;
+  out->plan_threads = b->planThreads;
+  out->plan_build_ms = b->planBuildMs;
+  out->plan_upload_ms = b->planUploadMs;
+  return SIPNET_OK;
+}
+const char* sipnet_batch_last_kernel_name(sipnet_batch* b) { return b ? b->lastLaunch.kernel : ""; }
 
 int sipnet_batch_reduce_plane(sipnet_batch* b, const void* d_plane, int32_t elem_is_f32,
                               int32_t n_steps, int64_t ld, double* d_stats,

@@ -357,7 +357,7 @@ int sipnet_batch_resample(sipnet_batch* b, const int32_t* d_src, const double* d
     HIP_TRY(hipMemcpyAsync(&flag, d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     HIP_TRY(hipFree(d_flag));
-    b->genericExponents = flag != 0;
+    if (flag != 0) b->genericExponents = true;  // only ever widened: plain-exponent kernels must never see a general exponent
   }
   return SIPNET_OK;
 }

@@ -373,6 +373,8 @@ int main(int argc, char** argv) {
   // ---- run on the GPU ----
   sipnet_batch* b = nullptr;
   check(sipnet_batch_create(flags, 1, M, SIPNET_F64, 0, &b), "creating batch");
+  // the drop-in writes the reference's bytes: strict operation order, whatever the environment says
+  check(sipnet_batch_set_math(b, SIPNET_MATH_STRICT), "math policy");
   check(sipnet_batch_set_events(b, 0, nEvents, events), "events");
   check(sipnet_batch_set_climate(b, 0, T, sipnet_clim_data(clim), sipnet_clim_year(clim),
                                  sipnet_clim_day(clim)), "climate");

@@ -29,6 +29,8 @@
 // W posts when it STARTS step t and, by day, psn(t).
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+
 #include "fast_math.h"
 #include "step_kernel.h"
 
@@ -862,7 +864,7 @@ extern "C" int sipnet_debug_read_coop_stamps(unsigned long long* out) {
 }
 #endif
 
-void launchStepCoop(const FastArgs& a, int precision, bool ringInLds, hipStream_t stream) {
+void launchStepCoop(const FastArgs& a, int precision, bool ringInLds, hipStream_t stream, LaunchInfo* info) {
   const int chunksPerSite = (a.n_members + 63) / 64;
   const dim3 grid(a.n_sites * chunksPerSite), block(192);
 #define COOP_LAUNCH(R, P, L) hipLaunchKernelGGL((stepCoopKernel<R, P, L>), grid, block, 0, stream, a)
@@ -874,6 +876,17 @@ void launchStepCoop(const FastArgs& a, int precision, bool ringInLds, hipStream_
     else { if (ringInLds) COOP_LAUNCH(float, false, true); else COOP_LAUNCH(float, false, false); }
   }
 #undef COOP_LAUNCH
+  if (info) {
+    snprintf(info->kernel, sizeof info->kernel, "stepCoopKernel<%s, %s, %s>",
+             precision == SIPNET_F64 ? "double" : "float", a.plainExp ? "true" : "false",
+             ringInLds ? "true" : "false");
+    info->grid = (int32_t)grid.x;
+    info->block = 192;
+    info->wavesPerSimd = 1;
+    const int elem = precision == SIPNET_F64 ? 8 : 4;
+    info->ldsBytes = 3 * 2 * kTileBytes + (2 * 64 * 3 + 2 * 5 * 64 + 2 * 64) * elem + 5 * 4 +
+                     (ringInLds ? SIPNET_RING_SLOTS * 64 : 64) * 8;
+  }
 }
 
 }  // namespace sipnet

@@ -21,6 +21,8 @@
 // :1420-1496, :1546-1680, :1688-1767 (citations relative to /root/reference/src/).
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+
 #include "fast_math.h"
 #include "step_kernel.h"
 
@@ -867,39 +869,51 @@ extern "C" int sipnet_debug_read_stamps(unsigned long long* out) {
 
 namespace {
 template <class R, bool Plain, int Mode>
-void launchFastOne(const FastArgs& a, int grid, bool twoWaves, hipStream_t stream) {
+void launchFastOne(const FastArgs& a, int grid, bool twoWaves, hipStream_t stream, LaunchInfo* info) {
   // a second, 256-VGPR build exists where it costs at most a few spilled registers: the fp64
   // default-flag kernel (257 -> 256) and the fp32 run-time-flag kernel (260-266 -> 256); the other
   // fp32 kernels fit two waves as they are, the fp64 optional-flag kernels (378-400) do not
   constexpr int kOcc2 = ((Mode == kFlagsDefault && sizeof(R) == 8) ||
                          (Mode == kFlagsRuntime && sizeof(R) == 4)) ? 2 : 1;
-  if (kOcc2 == 2 && twoWaves)
+  const bool occ2 = kOcc2 == 2 && twoWaves;
+  if (occ2)
     hipLaunchKernelGGL((stepFastKernel<R, Plain, Mode, kOcc2>), dim3(grid), dim3(64), 0, stream, a);
   else
     hipLaunchKernelGGL((stepFastKernel<R, Plain, Mode, 1>), dim3(grid), dim3(64), 0, stream, a);
+  if (info) {
+    snprintf(info->kernel, sizeof info->kernel, "stepFastKernel<%s, %s, %d, %d>",
+             sizeof(R) == 8 ? "double" : "float", Plain ? "true" : "false", Mode, occ2 ? 2 : 1);
+    info->grid = grid;
+    info->block = 64;
+    // the fp32 default-flag / N-cycle builds need < 256 VGPRs: two waves fit as they are
+    info->wavesPerSimd = (occ2 || (sizeof(R) == 4 && Mode != kFlagsRuntime)) ? 2 : 1;
+    info->ldsBytes = 2 * kFastTile * (int)sizeof(FastRec);
+  }
 }
 template <int Mode>
-void launchFastMode(const FastArgs& a, int precision, int grid, bool twoWaves, hipStream_t stream) {
+void launchFastMode(const FastArgs& a, int precision, int grid, bool twoWaves, hipStream_t stream,
+                    LaunchInfo* info) {
   if (precision == SIPNET_F64) {
-    if (a.plainExp) launchFastOne<double, true, Mode>(a, grid, twoWaves, stream);
-    else launchFastOne<double, false, Mode>(a, grid, twoWaves, stream);
+    if (a.plainExp) launchFastOne<double, true, Mode>(a, grid, twoWaves, stream, info);
+    else launchFastOne<double, false, Mode>(a, grid, twoWaves, stream, info);
   } else {
-    if (a.plainExp) launchFastOne<float, true, Mode>(a, grid, twoWaves, stream);
-    else launchFastOne<float, false, Mode>(a, grid, twoWaves, stream);
+    if (a.plainExp) launchFastOne<float, true, Mode>(a, grid, twoWaves, stream, info);
+    else launchFastOne<float, false, Mode>(a, grid, twoWaves, stream, info);
   }
 }
 }  // namespace
 
-void launchStepFast(const FastArgs& a, int precision, hipStream_t stream) {
+void launchStepFast(const FastArgs& a, int precision, int options, hipStream_t stream, LaunchInfo* info) {
   const int chunksPerSite = (a.n_members + 63) / 64;
   const int grid = a.n_sites * chunksPerSite;
-  // more chunks than SIMDs: two resident wavefronts per SIMD pay (SIPNET_OCC1: development switch)
-  const bool twoWaves = grid > 4 * a.numCUs && !getenv("SIPNET_OCC1");
-  // SIPNET_RUNTIME_FLAGS=1 (development switch): always the run-time-flag instantiation
-  const bool forceRuntime = getenv("SIPNET_RUNTIME_FLAGS") != nullptr;
-  if (isDefaultFlagSet(a.flags) && !forceRuntime) launchFastMode<kFlagsDefault>(a, precision, grid, twoWaves, stream);
-  else if (isNCycleFlagSet(a.flags) && !forceRuntime) launchFastMode<kFlagsNCycle>(a, precision, grid, twoWaves, stream);
-  else launchFastMode<kFlagsRuntime>(a, precision, grid, twoWaves, stream);
+  // more chunks than SIMDs: two resident wavefronts per SIMD pay (SIPNET_KOPT_ONE_WAVE_PER_SIMD
+  // keeps the full register budget anyway)
+  const bool twoWaves = grid > 4 * a.numCUs && !(options & SIPNET_KOPT_ONE_WAVE_PER_SIMD);
+  // SIPNET_KOPT_RUNTIME_FLAGS: always the run-time-flag instantiation
+  const bool forceRuntime = (options & SIPNET_KOPT_RUNTIME_FLAGS) != 0;
+  if (isDefaultFlagSet(a.flags) && !forceRuntime) launchFastMode<kFlagsDefault>(a, precision, grid, twoWaves, stream, info);
+  else if (isNCycleFlagSet(a.flags) && !forceRuntime) launchFastMode<kFlagsNCycle>(a, precision, grid, twoWaves, stream, info);
+  else launchFastMode<kFlagsRuntime>(a, precision, grid, twoWaves, stream, info);
 }
 
 }  // namespace sipnet

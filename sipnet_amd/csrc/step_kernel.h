@@ -68,8 +68,7 @@ struct KernelArgs {
 
 struct SetupArgs {
   const StepRec* plan;    // first record of each site is at plan[site*n_steps_total]
-  const double* raw;      // [ncol][SIPNET_NPARAMS] raw parameters (AoS as uploaded)
-  double* prm;            // [SIPNET_NPARAMS][ncol]
+  const double* prm;      // [SIPNET_NPARAMS][ncol] converted parameters (launchConvertParams)
   double* state;          // [SIPNET_NSTATE][ncol]
   double* ring;           // slot 0 row is zeroed
   int64_t ncol;
@@ -97,18 +96,29 @@ struct FastArgs {
   int32_t flags[SIPNET_NFLAGS];  // model flags; anything but the default set selects the
                                  // run-time-flag instantiation of the one-wave kernel
 };
-void launchStepFast(const FastArgs& a, int precision, hipStream_t stream);
+// What a launcher actually put on the stream (sipnet_batch_last_launch): the instantiation's
+// name as rocprofv3 prints its template arguments, and the launch shape.
+struct LaunchInfo {
+  char kernel[96];
+  int32_t grid, block;      // workgroups, threads per workgroup
+  int32_t wavesPerSimd;     // resident wavefronts per SIMD the instantiation's register budget allows
+  int32_t ldsBytes;         // static LDS per workgroup
+};
+// options: SIPNET_KOPT_* bits of include/sipnet_amd.h
+void launchStepFast(const FastArgs& a, int precision, int options, hipStream_t stream, LaunchInfo* info);
 // three cooperating wavefronts per 64 members (step_coop.hip); same results as launchStepFast
-void launchStepCoop(const FastArgs& a, int precision, bool ringInLds, hipStream_t stream);
+void launchStepCoop(const FastArgs& a, int precision, bool ringInLds, hipStream_t stream, LaunchInfo* info);
 bool isDefaultFlagSet(const int32_t* flags);
 
 // launchers (step_kernel.hip)
 void launchSetup(const SetupArgs& a, hipStream_t stream);
+// raw parameter rows [count][SIPNET_NPARAMS] (DEVICE staging) -> columns col0.. of prm[NPARAMS][ncol]
+void launchConvertParams(const double* rawRows, double* prm, int64_t ncol, int64_t col0,
+                         int32_t count, hipStream_t stream);
 // variant: bit0 = fast math, bit1 = generic flags (runtime), else default flags
-void launchStep(const KernelArgs& a, int precision, bool fastMath, hipStream_t stream);
+void launchStep(const KernelArgs& a, int precision, bool fastMath, hipStream_t stream, LaunchInfo* info);
 void launchReducePlane(const void* plane, bool isF32, int32_t n_steps, int64_t ld,
                        int32_t n_sites, int32_t n_members, double* stats,
                        hipStream_t stream);
-const char* stepKernelName(int precision, bool fastMath, bool generic);
 
 }  // namespace sipnet

@@ -5,6 +5,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+
 namespace sipnet {
 
 namespace {
@@ -93,27 +95,26 @@ __device__ __forceinline__ void blockToSiteChunk(int b, int n_sites, int chunksP
 __device__ __forceinline__ int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // -----------------------------------------------------------------------------
-// setup kernel == setupModel(), sipnet.c:1858-1951 (+ :1111-1123, :1406-1413,
-// :1501-1527).  One thread per member; runs once, so plain AoS reads are fine.
+// setupModel(), sipnet.c:1858-1951 (+ :1111-1123, :1406-1413, :1501-1527), in two kernels:
+//   convertParamsKernel  the parameter half (unit conversions, derived parameters, clamps), run
+//                        when parameters are uploaded: raw rows (AoS, as in the file) -> the
+//                        converted SoA block, which is from then on the ONLY copy of a member's
+//                        parameters on the device (a particle-filter resampling permutes it);
+//   setupKernel          the state half (initial pools, trackers, phenology state from the first
+//                        climate record, ring reset), from the converted block.
+// One thread per member; both run once, so plain AoS reads are fine.
 // -----------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void setupKernel(SetupArgs a) {
-  const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= a.ncol) return;
-  const int site = (int)(col / a.n_members);
-  const StepRec& s0 = a.plan[(int64_t)site * a.n_steps_total];
-
+__global__ __launch_bounds__(256) void convertParamsKernel(const double* __restrict__ raw,
+                                                           double* __restrict__ prm, int64_t ncol,
+                                                           int64_t col0, int32_t count) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
   double p[SIPNET_NPARAMS];
 #pragma unroll
-  for (int k = 0; k < SIPNET_NPARAMS; k++) p[k] = a.raw[col * SIPNET_NPARAMS + k];
-
-  int status = a.siteStatus[site];
-  // ensureAllocation, sipnet.c:1111-1123
+  for (int k = 0; k < SIPNET_NPARAMS; k++) p[k] = raw[i * SIPNET_NPARAMS + k];
+  // ensureAllocation, sipnet.c:1111-1123 (the validity test itself is in setupKernel)
   p[SP_coarseRootAllocation] =
       1 - p[SP_leafAllocation] - p[SP_woodAllocation] - p[SP_fineRootAllocation];
-  if ((p[SP_leafAllocation] >= 1.0) || (p[SP_woodAllocation] >= 1.0) ||
-      (p[SP_fineRootAllocation] >= 1.0) || (p[SP_coarseRootAllocation] < 0)) {
-    if (status == 0) status = SIPNET_ERR_BAD_PARAMETER;
-  }
   // per-year -> per-day, sipnet.c:1873-1877, :1898-1902
   p[SP_baseVegResp] /= 365.0;
   p[SP_litterBreakdownRate] /= 365.0;
@@ -136,48 +137,64 @@ __global__ __launch_bounds__(256) void setupKernel(SetupArgs a) {
   } else if (p[SP_anaerobicDecompRate] > 1.0) {
     p[SP_anaerobicDecompRate] = 1.0;
   }
+#pragma unroll
+  for (int k = 0; k < SIPNET_NPARAMS; k++) prm[(int64_t)k * ncol + col0 + i] = p[k];
+}
+
+__global__ __launch_bounds__(256) void setupKernel(SetupArgs a) {
+  const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= a.ncol) return;
+  const int site = (int)(col / a.n_members);
+  const StepRec& s0 = a.plan[(int64_t)site * a.n_steps_total];
+  const double* __restrict__ pp = a.prm + col;
+#define P(name) pp[(int64_t)SP_##name * a.ncol]
+
+  int status = a.siteStatus[site];
+  // ensureAllocation, sipnet.c:1111-1123
+  if ((P(leafAllocation) >= 1.0) || (P(woodAllocation) >= 1.0) ||
+      (P(fineRootAllocation) >= 1.0) || (P(coarseRootAllocation) < 0)) {
+    if (status == 0) status = SIPNET_ERR_BAD_PARAMETER;
+  }
 
   double st[SIPNET_NSTATE];
 #pragma unroll
   for (int k = 0; k < SIPNET_NSTATE; k++) st[k] = 0.0;
   // pools, sipnet.c:1884-1940
-  st[ST_plantWoodC] =
-      (1 - p[SP_coarseRootFrac] - p[SP_fineRootFrac]) * p[SP_plantWoodInit];
-  st[ST_plantLeafC] = p[SP_laiInit] * p[SP_leafCSpWt];
-  st[ST_litterC] = a.flags[SIPNET_F_LITTER_POOL] ? p[SP_litterInit] : 0.0;
-  st[ST_soilC] = p[SP_soilInit];
-  st[ST_coarseRootC] = p[SP_coarseRootFrac] * p[SP_plantWoodInit];
-  st[ST_fineRootC] = p[SP_fineRootFrac] * p[SP_plantWoodInit];
-  double sw = p[SP_soilWFracInit] * p[SP_soilWHC];
+  st[ST_plantWoodC] = (1 - P(coarseRootFrac) - P(fineRootFrac)) * P(plantWoodInit);
+  st[ST_plantLeafC] = P(laiInit) * P(leafCSpWt);
+  st[ST_litterC] = a.flags[SIPNET_F_LITTER_POOL] ? P(litterInit) : 0.0;
+  st[ST_soilC] = P(soilInit);
+  st[ST_coarseRootC] = P(coarseRootFrac) * P(plantWoodInit);
+  st[ST_fineRootC] = P(fineRootFrac) * P(plantWoodInit);
+  double sw = P(soilWFracInit) * P(soilWHC);
   if (sw < 0) sw = 0;
   st[ST_soilWater] = sw;
-  st[ST_snow] = p[SP_snowInit];
+  st[ST_snow] = P(snowInit);
   if (a.flags[SIPNET_F_NITROGEN_CYCLE]) {
-    st[ST_minN] = p[SP_minNInit];
-    st[ST_soilOrgN] = p[SP_soilOrgNInit];
-    st[ST_litterN] = p[SP_litterOrgNInit];
-    st[ST_plantStorageN] = p[SP_plantStorageNInit];
+    st[ST_minN] = P(minNInit);
+    st[ST_soilOrgN] = P(soilOrgNInit);
+    st[ST_litterN] = P(litterOrgNInit);
+    st[ST_plantStorageN] = P(plantStorageNInit);
   }
   // phenology state from the first record, sipnet.c:1501-1527 with :705-742
   int grew = 0, fell = 0;
   if (a.flags[SIPNET_F_GDD]) {
-    grew = (s0.cumGdd >= p[SP_gddLeafOn]);
+    grew = (s0.cumGdd >= P(gddLeafOn));
   } else if (a.flags[SIPNET_F_SOIL_PHENOL]) {
-    grew = (s0.tsoil >= p[SP_soilTempLeafOn]);
-  } else if (p[SP_leafOnDay] > 0) {
-    grew = (s0.dayTime >= p[SP_leafOnDay]);
+    grew = (s0.tsoil >= P(soilTempLeafOn));
+  } else if (P(leafOnDay) > 0) {
+    grew = (s0.dayTime >= P(leafOnDay));
   }
-  if (p[SP_leafOffDay] > 0) {
-    fell = (s0.dayTime >= p[SP_leafOffDay]);
+  if (P(leafOffDay) > 0) {
+    fell = (s0.dayTime >= P(leafOffDay));
   }
   if (fell && !grew) grew = 1;
   st[ST_phenBits] = (double)(grew | (fell << 1));
   st[ST_ringValidFrom] = 0.0;
   st[ST_status] = (double)status;
   st[ST_diedAt] = -1.0;
+#undef P
 
-#pragma unroll
-  for (int k = 0; k < SIPNET_NPARAMS; k++) a.prm[(int64_t)k * a.ncol + col] = p[k];
 #pragma unroll
   for (int k = 0; k < SIPNET_NSTATE; k++) a.state[(int64_t)k * a.ncol + col] = st[k];
   a.ring[col] = 0.0;  // slot 0 = the initial (mean 0, weight 5) entry
@@ -1204,6 +1221,11 @@ void launchSetup(const SetupArgs& a, hipStream_t stream) {
   const int grid = (int)((a.ncol + 255) / 256);
   hipLaunchKernelGGL(setupKernel, dim3(grid), dim3(256), 0, stream, a);
 }
+void launchConvertParams(const double* rawRows, double* prm, int64_t ncol, int64_t col0,
+                         int32_t count, hipStream_t stream) {
+  hipLaunchKernelGGL(convertParamsKernel, dim3((count + 255) / 256), dim3(256), 0, stream, rawRows,
+                     prm, ncol, col0, count);
+}
 
 static bool isDefaultFlags(const int32_t* f) {
   for (int i = 0; i < SIPNET_NFLAGS; i++) {
@@ -1215,7 +1237,7 @@ static bool isDefaultFlags(const int32_t* f) {
 
 bool isDefaultFlagSet(const int32_t* f) { return isDefaultFlags(f); }
 
-void launchStep(const KernelArgs& a, int precision, bool fastMath, hipStream_t stream) {
+void launchStep(const KernelArgs& a, int precision, bool fastMath, hipStream_t stream, LaunchInfo* info) {
   const bool generic = !isDefaultFlags(a.flags);
   const bool full = a.rec != nullptr;
   // full-record launches (CLI text output, checkpoints) always use the generic
@@ -1236,14 +1258,16 @@ void launchStep(const KernelArgs& a, int precision, bool fastMath, hipStream_t s
     else if (generic) launchOne<Cfg<float, true, true, false>>(a, stream);
     else launchOne<Cfg<float, true, false, false>>(a, stream);
   }
-}
-
-const char* stepKernelName(int precision, bool fastMath, bool generic) {
-  if (precision == SIPNET_F64) {
-    if (generic) return fastMath ? "stepKernel<f64,fast,generic>" : "stepKernel<f64,strict,generic>";
-    return fastMath ? "stepKernel<f64,fast,default>" : "stepKernel<f64,strict,default>";
+  if (info) {
+    const bool fm = fastMath || precision != SIPNET_F64;
+    snprintf(info->kernel, sizeof info->kernel, "stepKernel<Cfg<%s, %s, %s, %s>>",
+             precision == SIPNET_F64 ? "double" : "float", fm ? "true" : "false",
+             (full || generic) ? "true" : "false", full ? "true" : "false");
+    info->grid = a.n_sites * ((a.n_members + 63) / 64);
+    info->block = 64;
+    info->wavesPerSimd = 1;
+    info->ldsBytes = 0;
   }
-  return generic ? "stepKernel<f32mixed,fast,generic>" : "stepKernel<f32mixed,fast,default>";
 }
 
 void launchReducePlane(const void* plane, bool isF32, int32_t n_steps, int64_t ld,

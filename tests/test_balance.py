@@ -46,8 +46,7 @@ def test_gpu_strict_kernel_on_the_balance_case(oracle, name):
     flags, params, clim, events = load(name)
     st, want, _ = oracle.run_member(flags, params, clim, events)
     assert st == 0
-    os.environ["SIPNET_FAST_MATH"] = "0"
-    b = sa.Batch(flags, 1, 1, sa.F64)
+    b = sa.Batch(flags, 1, 1, sa.F64, fast_math=False)
     b.set_events(0, events)
     b.set_climate(0, clim)
     b.set_params(0, params)

@@ -117,13 +117,12 @@ def test_cli_debug_log_matches_reference_rows(case, tmp_path):
 @pytest.mark.gpu
 def test_debug_plane_matches_oracle_with_every_flag_on(oracle):
     from tests.test_gpu_flags import ALL_ON, BASE, _events_all_types
-    os.environ["SIPNET_FAST_MATH"] = "0"
     flags = sa.flags_from(**{k: v for k, v in ALL_ON.items() if k != "soilPhenol"})
     clim = synth.convert_raw(synth.round_like_file(synth.half_hourly_year_raw(17520)))
     base = sa.read_params(BASE, flags)[0]
     members = synth.perturbed_params(base, 3)
     ev = _events_all_types(clim)
-    b = sa.Batch(flags, 1, 3)
+    b = sa.Batch(flags, 1, 3, fast_math=False)
     b.set_events(0, ev)
     b.set_climate(0, clim)
     b.set_params(0, members)

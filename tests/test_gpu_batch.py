@@ -16,9 +16,10 @@ pytestmark = pytest.mark.gpu
 BASE = os.path.join(helpers.REPO, "sipnet_amd", "data", "base_forest.param")
 
 
-def make_batch(flags, clims, members, prec=sa.F64, events=None, fast=True):
-    os.environ.pop("SIPNET_FAST_MATH", None)
-    b = sa.Batch(flags, len(clims), members.shape[0], prec, fast_math=fast)
+def make_batch(flags, clims, members, prec=sa.F64, events=None, fast=True, kernel=sa.KERNEL_AUTO,
+               kernel_options=0):
+    b = sa.Batch(flags, len(clims), members.shape[0], prec, fast_math=fast, kernel=kernel,
+                 kernel_options=kernel_options)
     for s, c in enumerate(clims):
         if events is not None:
             b.set_events(s, events)
@@ -253,7 +254,7 @@ def test_full_size_properties_10k_members(base):
     b.close(); b1.close()
 
 
-def test_cooperative_and_one_wave_kernels_agree(base, tmp_path, monkeypatch):
+def test_cooperative_and_one_wave_kernels_agree(base, tmp_path):
     """the engine picks the three-wavefront kernel (step_coop.hip) for batches of at most one
     64-member chunk per CU and the one-wave kernel (step_fast.hip) above; both must give the same
     trajectories -- including the rare paths: clear-cut + death, re-planting, irrigation, a member
@@ -274,13 +275,13 @@ def test_cooperative_and_one_wave_kernels_agree(base, tmp_path, monkeypatch):
     members[5, pi("plantWoodInit")] = 0.0           # never alive, keeps its leaves
     out = {}
     for prec in (sa.F64, sa.F32_MIXED):
-        for coop in ("1", "2", "0"):       # cooperative with the ring in LDS / in HBM, one-wave
-            monkeypatch.setenv("SIPNET_COOP", coop)
-            b = make_batch(sa.flags_from(), [clim], members, prec=prec, events=ev)
+        for coop, kern in (("1", sa.KERNEL_COOP_LDS), ("2", sa.KERNEL_COOP_HBM), ("0", sa.KERNEL_ONE_WAVE)):
+            b = make_batch(sa.flags_from(), [clim], members, prec=prec, events=ev, kernel=kern)
             T = clim.n_steps
             planes, _ = b.alloc_outputs(T)
             for a, z in ((0, 7), (7, 1000), (1000, 1015), (1015, T)):   # odd cuts, a one-step tile tail
                 b.run(a, z - a, planes=planes[:, a:z])
+            assert b.last_launch()["kernel"].startswith("stepFastKernel" if coop == "0" else "stepCoopKernel")
             out[coop] = (planes.cpu().numpy().astype(np.float64), b.get_state(), b.get_rings())
             b.close()
         tol = 1e-12 if prec == sa.F64 else 2e-4
@@ -296,17 +297,20 @@ def test_cooperative_and_one_wave_kernels_agree(base, tmp_path, monkeypatch):
 
 def test_math_policy_is_an_explicit_choice(base, short_clim, monkeypatch):
     """sipnet_batch_set_math: strict reference order vs throughput kernels on the same batch;
-    the environment variable only sets the default of a new batch; fp32-mixed has no strict mode."""
+    no environment variable steers the launch path; fp32-mixed has no strict mode."""
     members = synth.perturbed_params(base, 64)
-    monkeypatch.delenv("SIPNET_FAST_MATH", raising=False)
+    for k, v in (("SIPNET_FAST_MATH", "1"), ("SIPNET_COOP", "0"), ("SIPNET_NO_FAST_KERNEL", "1")):
+        monkeypatch.setenv(k, v)            # round-1 switches: must be ignored now
     b = sa.Batch(sa.flags_from(), 1, 64)
     b.set_climate(0, short_clim)
     b.set_params(0, members)
     b.setup()
     strict = b.run()[0].cpu().numpy()                  # default: strict
+    assert b.last_launch()["kernel"] == "stepKernel<Cfg<double, false, false, false>>"
     b.set_math(True)
     b.setup()
     fast = b.run()[0].cpu().numpy()
+    assert b.last_launch()["kernel"] == "stepCoopKernel<double, true, true>"
     b.set_math(False)
     b.setup()
     strict2 = b.run()[0].cpu().numpy()
@@ -314,11 +318,14 @@ def test_math_policy_is_an_explicit_choice(base, short_clim, monkeypatch):
     assert np.array_equal(strict, strict2)
     d = np.abs(strict - fast).max()
     assert 0 < d < 1e-12                                # different instruction streams, same model
-    monkeypatch.setenv("SIPNET_FAST_MATH", "1")
-    b = sa.Batch(sa.flags_from(), 1, 64)
+    # a forced kernel that cannot run the batch is refused, not silently replaced
+    b = sa.Batch(sa.flags_from(), 1, 64, kernel=sa.KERNEL_COOP_LDS)
     b.set_climate(0, short_clim)
     b.set_params(0, members)
     b.setup()
+    with pytest.raises(SipnetError):
+        b.run()                                          # throughput kernel under strict math
+    b.set_math(True)
     assert np.array_equal(b.run()[0].cpu().numpy(), fast)
     b.close()
     b32 = sa.Batch(sa.flags_from(), 1, 64, sa.F32_MIXED)
@@ -328,7 +335,7 @@ def test_math_policy_is_an_explicit_choice(base, short_clim, monkeypatch):
 
 
 @pytest.mark.parametrize("which", ["f64_default_flags", "f32_runtime_flags"])
-def test_two_waves_per_simd_build_of_the_one_wave_kernel(which, oracle, base, monkeypatch):
+def test_two_waves_per_simd_build_of_the_one_wave_kernel(which, oracle, base):
     """More chunks than SIMDs (> 65 536 members): the launcher takes the instantiation cut to
     256 VGPRs (two resident wavefronts per SIMD, a few spilled registers) of the fp64 default-flag
     kernel and of the fp32 run-time-flag kernel.  Same arithmetic: the planes must equal the
@@ -344,12 +351,10 @@ def test_two_waves_per_simd_build_of_the_one_wave_kernel(which, oracle, base, mo
         members = synth.perturbed_params(allp, M)
     outs = []
     for occ1 in (False, True):
-        if occ1:
-            monkeypatch.setenv("SIPNET_OCC1", "1")
-        else:
-            monkeypatch.delenv("SIPNET_OCC1", raising=False)
-        b = make_batch(flags, [clim], members, prec=prec)
+        b = make_batch(flags, [clim], members, prec=prec,
+                       kernel_options=sa.KOPT_ONE_WAVE_PER_SIMD if occ1 else 0)
         outs.append(b.run()[0].double().cpu().numpy())
+        assert b.last_launch()["kernel"].endswith(", 1>" if occ1 else ", 2>"), b.last_launch()
         b.close()
     assert np.array_equal(outs[0], outs[1])
     pick = np.r_[0:16, M // 2:M // 2 + 16, M - 16:M]

@@ -1,0 +1,300 @@
+"""Every BASELINE.json configuration at its OWN shape against the CPU oracle, and every
+throughput-kernel instantiation against the oracle (not against a sibling kernel).
+
+  C2  1 site x 1024 members, fp64, 17 520 steps       -> every member vs the oracle
+  C3  1 site x 65 536 members, fp32-mixed, 17 520     -> 48 sampled members (first / middle / last chunk)
+  C4  32 sites x 1024 members, fp64 (one GPU's share of 256 x 1024), 17 520 steps
+                                                      -> 2 sampled members of every site
+  C5  131 072 particles x 48 steps + one analysis     -> forecast of sampled particles, weights,
+      ancestors, resampled state vs their ancestors' oracle trajectories, second forecast vs an
+      unfiltered twin
+Each test also asserts WHICH kernel instantiation the engine launched (sipnet_batch_last_launch),
+so a change of the selection policy cannot silently move a configuration to another kernel.
+
+Tolerances (stated): fp64 1e-9 gC m-2 (cm) per step on NEE / GPP / ET, against a bar of 1e-6;
+fp32-mixed 2e-6 per step on flux planes (pools and accumulators stay fp64).  The oracle is
+oracle/sipnet_oracle.c, bit-identical to the real reference (tests/test_oracle_golden.py);
+the C5 analysis oracle (oracle/pf_oracle.py) is textbook code -- parity unpinned by any
+reference, the reference has no filter.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import sipnet_amd as sa
+from oracle import pf_oracle as po
+from sipnet_amd import dist as sd
+from sipnet_amd import synth
+from sipnet_amd.config import param_index as pi
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+BASE = os.path.join(helpers.REPO, "sipnet_amd", "data", "base_forest.param")
+TOL_F64, TOL_F32 = 1e-9, 2e-6
+T_YEAR = 17520
+
+
+@pytest.fixture(scope="module")
+def base():
+    return sa.read_params(BASE, sa.flags_from())[0]
+
+
+def year_clim(site=0, n=T_YEAR, start_day=0):
+    raw = synth.half_hourly_year_raw(start_day * 48 + n, site=site)
+    raw = {k: v[start_day * 48:] for k, v in raw.items()}
+    return synth.convert_raw(synth.round_like_file(raw))
+
+
+def build(flags, clims, members, prec, kernel=sa.KERNEL_AUTO, options=0, events=None):
+    b = sa.Batch(flags, len(clims), members.shape[0], prec,
+                 fast_math=True if prec == sa.F64 else None, kernel=kernel, kernel_options=options)
+    for s, c in enumerate(clims):
+        if events is not None:
+            b.set_events(s, events)
+        b.set_climate(s, c)
+        b.set_params(s, members)
+    b.setup()
+    return b
+
+
+def branch_flips(got, want, scale_floor=1e-3):
+    """members whose trajectory leaves the oracle's by more than 1e-4 of a plane's maximum on any
+    step: what a threshold branch taken one step apart (snow gone, soil dry) looks like"""
+    scale = np.maximum(np.abs(want).max(axis=(1, 2), keepdims=True), scale_floor)
+    return int(((np.abs(got - want) / scale) > 1e-4).any(axis=(0, 1)).sum())
+
+
+# ---------------------------------------------------------------------------------------------
+def test_c2_1024_members_fp64_every_member(oracle, base):
+    clim = year_clim()
+    members = synth.perturbed_params(base, 1024)
+    b = build(sa.flags_from(), [clim], members, sa.F64)
+    planes, _ = b.run()
+    li = b.last_launch()
+    got = planes.cpu().numpy()
+    st = b.get_status()
+    b.close()
+    assert li["kernel"] == "stepCoopKernel<double, true, true>" and li["grid"] == 16
+    want, _, so = oracle.run_block(sa.flags_from(), members, clim)
+    assert (st == 0).all() and (so == 0).all()
+    d = np.abs(got - want).max(axis=(1, 2))
+    print("C2 1x1024 f64 x 17520: max|dNEE| %.3e |dGPP| %.3e |dET| %.3e, branch-flip members %d"
+          % (d[0], d[1], d[2], branch_flips(got, want)))
+    assert d.max() < TOL_F64
+
+
+def test_c3_65536_members_fp32_mixed(oracle, base):
+    """the HBM-roofline configuration: 13.8 GB of fp32 planes stay resident"""
+    M = 65536
+    clim = year_clim()
+    members = synth.perturbed_params(base, M)
+    b = build(sa.flags_from(), [clim], members, sa.F32_MIXED)
+    planes, _ = b.run()
+    li = b.last_launch()
+    assert planes.dtype == torch.float32 and tuple(planes.shape) == (3, T_YEAR, M)
+    pick = np.r_[0:16, M // 2:M // 2 + 16, M - 16:M]
+    got = planes[:, :, torch.from_numpy(pick).to(planes.device)].double().cpu().numpy()
+    st = b.get_status()
+    finite = bool(torch.isfinite(planes).all())
+    state = b.get_state()
+    b.close()
+    del planes
+    torch.cuda.empty_cache()
+    assert li["kernel"] == "stepFastKernel<float, true, 0, 1>" and li["grid"] == 1024, li
+    assert (st == 0).all() and finite
+    want, final, so = oracle.run_block(sa.flags_from(), members[pick], clim)
+    assert (so == 0).all()
+    d = np.abs(got - want)
+    flips = branch_flips(got, want)
+    print("C3 1x65536 f32-mixed x 17520, 48 sampled members: max|dNEE| %.3e |dGPP| %.3e |dET| %.3e, "
+          "yearly NEE sum off by at most %.3e gC m-2, branch-flip members %d"
+          % (d[0].max(), d[1].max(), d[2].max(), np.abs(got[0].sum(0) - want[0].sum(0)).max(), flips))
+    assert d.max() < TOL_F32
+    assert flips == 0
+    assert np.abs(got[0].sum(0) - want[0].sum(0)).max() < 0.5
+    # pools (fp64 on the device) of the sampled members after the year
+    np.testing.assert_allclose(state[pick, :13], final[:, 14:27], rtol=2e-4, atol=1e-3)
+
+
+def test_c4_32_sites_x_1024_members_fp64(oracle, base):
+    """one GPU's share of the 256-site configuration: cooperative kernel with the ring in HBM and
+    the XCD-grouped block mapping (n_sites % 8 == 0), every site with its own forcing"""
+    S, M = 32, 1024
+    clims = [year_clim(site=s) for s in range(S)]
+    members = synth.perturbed_params(base, M)
+    b = build(sa.flags_from(), clims, members, sa.F64)
+    planes, _ = b.run()
+    li = b.last_launch()
+    rng = np.random.default_rng(4)
+    pick = np.stack([np.sort(rng.choice(M, 2, replace=False)) for _ in range(S)])      # [S][2]
+    cols = (np.arange(S)[:, None] * M + pick).reshape(-1)
+    got = planes[:, :, torch.from_numpy(cols).to(planes.device)].cpu().numpy().reshape(3, T_YEAR, S, 2)
+    st = b.get_status()
+    b.close()
+    del planes
+    torch.cuda.empty_cache()
+    assert li["kernel"] == "stepCoopKernel<double, true, false>" and li["grid"] == 512, li
+    assert li["plan_threads"] >= 1 and li["plan_build_ms"] > 0
+    assert (st == 0).all()
+    worst = 0.0
+    for s in range(S):
+        want, _, so = oracle.run_block(sa.flags_from(), members[pick[s]], clims[s])
+        assert (so == 0).all()
+        worst = max(worst, float(np.abs(got[:, :, s, :] - want).max()))
+        assert np.abs(got[:, :, s, :] - want).max() < TOL_F64, s
+    print("C4 32x1024 f64 x 17520, 2 members of every site: max|d| %.3e; plans built by %d threads in %.1f ms, "
+          "uploaded in %.1f ms" % (worst, li["plan_threads"], li["plan_build_ms"], li["plan_upload_ms"]))
+
+
+def test_c5_particle_filter_cycle_131072_particles(oracle, base):
+    """forecast (one day) -> analysis -> forecast: one GPU's share of the 1 M-particle cycle"""
+    n, T1 = 131072, 48
+    clim = year_clim(n=2 * T1, start_day=150)           # two summer days
+    flags = sa.flags_from()
+    members = synth.perturbed_params(base, n)
+    twin = build(flags, [clim], members, sa.F32_MIXED)
+    twin.run(0, T1, want_planes=False)
+    twin_state = twin.get_state()
+    twin2, _ = twin.run(T1, T1)
+    twin.close()
+
+    b = build(flags, [clim], members, sa.F32_MIXED)
+    p1, _ = b.run(0, T1)
+    li = b.last_launch()
+    assert li["kernel"] == "stepFastKernel<float, true, 0, 1>" and li["grid"] == 2048, li
+    pick = np.r_[0:24, n // 2:n // 2 + 16, n - 24:n]
+    want, final, so = oracle.run_block(flags, members[pick], clim.slice(0, T1))
+    assert (so == 0).all()
+    got = p1[:, :, torch.from_numpy(pick).to(p1.device)].double().cpu().numpy()
+    print("C5 forecast, 64 sampled particles: max|d| %.3e" % np.abs(got - want).max())
+    assert np.abs(got - want).max() < TOL_F32
+
+    # analysis: weights, ancestors (oracle/pf_oracle.py)
+    tot = p1[0].double().sum(0)
+    obs, sigma = float(tot.median()), float(tot.std()) * 1.5 + 1e-12
+    st = b.get_status()
+    logw = b.pf_log_weights(p1[0], obs, sigma)
+    np.testing.assert_allclose(logw.cpu().numpy(), po.log_weights(p1[0].cpu().numpy(), obs, sigma, st),
+                               rtol=1e-12, atol=1e-12)
+    anc, fixed = sd.pf_systematic_ancestors(logw, 0.5, return_fixed=True)
+    fixed = fixed.cpu().numpy()
+    assert np.abs(fixed - po.fixed_weights(logw.cpu().numpy())).max() <= 1
+    anc_np = anc.cpu().numpy()
+    np.testing.assert_array_equal(anc_np, po.systematic_ancestors(fixed, 0.5))
+    uniq = int(np.unique(anc_np).size)
+    assert 1 < uniq < n                                   # the filter did select
+    info = sd.pf_resample(b, anc, with_params=True)
+    assert info["sent"] == 0
+    # resampled particle j carries its ancestor's state: bit for bit vs the unfiltered twin ...
+    state = b.get_state()
+    np.testing.assert_array_equal(state[:, :28], twin_state[anc_np][:, :28])
+    # ... and, for the sampled ancestors, the oracle's pools after the day
+    j = np.nonzero(np.isin(anc_np, pick))[0][:64]
+    where = {int(c): k for k, c in enumerate(pick)}
+    rows = np.array([where[int(a)] for a in anc_np[j]])
+    np.testing.assert_allclose(state[j, :13], final[rows, 14:27], rtol=1e-5, atol=1e-5)
+    # second forecast: particle j continues exactly like particle anc[j] of the twin
+    p2, _ = b.run(T1, T1)
+    assert torch.equal(p2, twin2[:, :, anc.long()])
+    # a setup() after the resampling re-initialises the RESAMPLED parameter sets (the converted
+    # block is the only copy): particle j then reproduces member anc[j]'s first day
+    b.setup()
+    p3, _ = b.run(0, T1)
+    assert torch.equal(p3, p1[:, :, anc.long()])
+    b.close()
+    print("C5 analysis: %d unique ancestors of %d, resampled state == ancestors' (twin bit-exact, oracle pools "
+          "within 1e-5)" % (uniq, n))
+
+
+# ---------------------------------------------------------------------------------------------
+def _scenario(base, lethal):
+    """60 days from day 130 (spring: leaf-on through growing degree days falls inside, GPP is on by
+    day and off by night), 150 members (three chunks, the last one ragged), events of every carbon
+    type; with `lethal` also a clear-cut that kills every stand, a re-planting and a member dead
+    from the start.  The launch is cut at odd steps (a one-step tile tail included)."""
+    clim = year_clim(n=48 * 60, start_day=129)
+    ev = []
+
+    def add(day, typ, *p):
+        e = sa.Event(); e.type = typ; e.year = int(clim.year[0]); e.day = 129 + day
+        for i, v in enumerate(p):
+            e.p[i] = v
+        ev.append(e)
+    add(4, 2, 1.5, 0)                          # canopy irrigation
+    add(6, 4, 0.4)                             # tillage
+    add(9, 1, 0.3, 0.2, 0.1, 0.1)              # partial harvest
+    add(9, 0, 2.0, 30.0, 1.0)                  # fertiliser, same day
+    if lethal:
+        add(20, 1, 1.0, 1.0, 0.0, 0.0)         # clear-cut: every member dies
+        add(30, 3, 40.0, 300.0, 50.0, 60.0)    # re-planting
+    add(41, 2, 2.0, 1)                         # soil irrigation
+    members = synth.perturbed_params(base, 150)
+    if lethal:
+        members[5, pi("plantWoodInit")] = 0.0  # never alive, keeps its leaves
+    return clim, ev, members
+
+
+KERNELS = [
+    ("one_wave_f64", sa.F64, sa.KERNEL_ONE_WAVE, 0, "stepFastKernel<double, true, 0, 1>"),
+    ("one_wave_f32", sa.F32_MIXED, sa.KERNEL_ONE_WAVE, 0, "stepFastKernel<float, true, 0, 1>"),
+    ("coop_lds_f64", sa.F64, sa.KERNEL_COOP_LDS, 0, "stepCoopKernel<double, true, true>"),
+    ("coop_lds_f32", sa.F32_MIXED, sa.KERNEL_COOP_LDS, 0, "stepCoopKernel<float, true, true>"),
+    ("coop_hbm_f64", sa.F64, sa.KERNEL_COOP_HBM, 0, "stepCoopKernel<double, true, false>"),
+    ("coop_hbm_f32", sa.F32_MIXED, sa.KERNEL_COOP_HBM, 0, "stepCoopKernel<float, true, false>"),
+    ("runtime_flags_f64", sa.F64, sa.KERNEL_ONE_WAVE, sa.KOPT_RUNTIME_FLAGS, "stepFastKernel<double, true, 1, 1>"),
+    ("runtime_flags_f32", sa.F32_MIXED, sa.KERNEL_ONE_WAVE, sa.KOPT_RUNTIME_FLAGS, "stepFastKernel<float, true, 1, 1>"),
+]
+
+
+@pytest.mark.parametrize("name,prec,kernel,options,expect", KERNELS, ids=[k[0] for k in KERNELS])
+def test_every_throughput_kernel_instantiation_against_the_oracle(name, prec, kernel, options, expect,
+                                                                  oracle, base):
+    """each forced kernel vs the ORACLE: fp64 at 1e-9 incl. the rare paths (clear-cut + death,
+    re-planting, a member dead from the start, ragged chunk, split launch); fp32-mixed at 2e-6 on
+    the same schedule without the lethal events (emptied pools keep ~1e-5 gC of fp32 residue,
+    which the fuzz test judges by time sums instead)"""
+    flags = sa.flags_from()
+    clim, ev, members = _scenario(base, lethal=prec == sa.F64)
+    b = build(flags, [clim], members, prec, kernel, options, events=ev)
+    T = clim.n_steps
+    planes, _ = b.alloc_outputs(T)
+    for a, z in ((0, 7), (7, 1000), (1000, 1015), (1015, T)):
+        b.run(a, z - a, planes=planes[:, a:z])
+    li = b.last_launch()
+    got = planes.double().cpu().numpy()
+    state = b.get_state()
+    st = b.get_status()
+    b.close()
+    assert li["kernel"] == expect, li
+    want, final, so = oracle.run_block(flags, members, clim, ev)
+    assert (st == 0).all() and (so == 0).all()
+    d = np.abs(got - want).max(axis=(1, 2))
+    print("%s [%s]: max|dNEE| %.3e |dGPP| %.3e |dET| %.3e" % (name, li["kernel"], d[0], d[1], d[2]))
+    assert d.max() < (TOL_F64 if prec == sa.F64 else TOL_F32)
+    assert want[1].max() > 0.05 and (want[1] == 0).any()         # photosynthesis by day, none by night
+    if prec == sa.F64:
+        np.testing.assert_allclose(state[:, :13], final[:, 14:27], rtol=1e-9, atol=1e-9)
+        assert state[0, 30] >= 0 and state[0, 0] > 100.0        # died at the clear-cut, wood is back
+
+
+def test_non_plain_exponents_take_the_general_instantiations(oracle, base):
+    """members with dVpdExp != 2 or soilRespMoistEffect != 1 need the PlainExp = false builds of
+    both throughput kernels (pow through exp2 / OCML)"""
+    flags = sa.flags_from()
+    clim = year_clim(n=48 * 40, start_day=150)
+    members = synth.perturbed_params(base, 130)
+    members[3, pi("dVpdExp")] = 1.7
+    members[70, pi("soilRespMoistEffect")] = 1.4
+    want, _, so = oracle.run_block(flags, members, clim)
+    assert (so == 0).all()
+    for kernel, expect in ((sa.KERNEL_COOP_LDS, "stepCoopKernel<double, false, true>"),
+                           (sa.KERNEL_COOP_HBM, "stepCoopKernel<double, false, false>"),
+                           (sa.KERNEL_ONE_WAVE, "stepFastKernel<double, false, 0, 1>")):
+        b = build(flags, [clim], members, sa.F64, kernel)
+        got = b.run()[0].cpu().numpy()
+        li = b.last_launch()
+        b.close()
+        assert li["kernel"] == expect, li
+        assert np.abs(got - want).max() < TOL_F64, expect

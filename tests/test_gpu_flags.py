@@ -22,8 +22,7 @@ POOLS = slice(14, 27)  # record columns holding the 13 pools (include/sipnet_amd
 
 
 def lean_run(flags, clim, members, events=None, fast=True, prec=sa.F64):
-    os.environ["SIPNET_FAST_MATH"] = "1" if fast else "0"
-    b = sa.Batch(flags, 1, members.shape[0], prec)
+    b = sa.Batch(flags, 1, members.shape[0], prec, fast_math=fast if prec == sa.F64 else None)
     if events is not None:
         b.set_events(0, events)
     b.set_climate(0, clim)

@@ -24,8 +24,7 @@ POOL_COLS = list(range(14, 27))
 
 
 def run_gpu_single(case, fast):
-    os.environ["SIPNET_FAST_MATH"] = "1" if fast else "0"
-    b = sa.Batch(case["flags"], 1, 1, sa.F64)
+    b = sa.Batch(case["flags"], 1, 1, sa.F64, fast_math=fast)
     b.set_events(0, case["events"])
     b.set_climate(0, case["clim"])
     b.set_params(0, case["params"][None, :])
@@ -90,8 +89,7 @@ def test_events_out_regenerated_from_gpu_records_matches_golden(case_name, tmp_p
     """events.out (input events with their pool deltas, computed leaf-on / leaf-off) written
     from the GPU's full records reproduces the reference's committed golden byte for byte."""
     case = helpers.load_smoke_case(case_name, str(tmp_path))
-    os.environ["SIPNET_FAST_MATH"] = "0"
-    b = sa.Batch(case["flags"], 1, 1, sa.F64)
+    b = sa.Batch(case["flags"], 1, 1, sa.F64, fast_math=False)
     b.set_events(0, case["events"])
     b.set_climate(0, case["clim"])
     b.set_params(0, case["params"][None, :])
@@ -122,8 +120,7 @@ def test_synthetic_special_members_vs_reference_fixture(fast, oracle, tmp_path):
     members = np.load(os.path.join(helpers.GOLDEN, "synth", "members_raw.npy"))
     ref = np.load(os.path.join(helpers.GOLDEN, "synth", "ref_synth.npz"))
     flags = sa.flags_from()
-    os.environ["SIPNET_FAST_MATH"] = "1" if fast else "0"
-    b = sa.Batch(flags, 1, members.shape[0], sa.F64)
+    b = sa.Batch(flags, 1, members.shape[0], sa.F64, fast_math=fast)
     b.set_climate(0, clim)
     b.set_params(0, members)
     b.setup()

@@ -32,8 +32,7 @@ def clim():
 
 
 def batch_of(clim, members, prec=sa.F64):
-    os.environ["SIPNET_FAST_MATH"] = "1"
-    b = sa.Batch(sa.flags_from(), 1, members.shape[0], prec)
+    b = sa.Batch(sa.flags_from(), 1, members.shape[0], prec, fast_math=True)
     b.set_climate(0, clim)
     b.set_params(0, members)
     b.setup()

@@ -199,13 +199,13 @@ def test_cli_restart_failures_exit_9(tmp_path):
     assert r.returncode == 0 and "before midnight" in r.stdout and os.path.exists(os.path.join(w, "early.restart"))
 
 
-def _setup_batch(case, lines, events, members, tmp_path, tag, precision=sa.F64):
+def _setup_batch(case, lines, events, members, tmp_path, tag, precision=sa.F64, fast=False):
     p = tmp_path / f"{tag}.clim"
     p.write_text("".join(lines))
     flags = sa.flags_from(**{k: v for k, v in sa.read_config(os.path.join(GOLD, case, "sipnet.in")).items()
                              if k in sa.FLAG_NAMES})
     clim = sa.read_clim(p, gdd=flags[1])
-    b = sa.Batch(flags, 1, members.shape[0], precision)
+    b = sa.Batch(flags, 1, members.shape[0], precision, fast_math=fast if precision == sa.F64 else None)
     b.set_events(0, events)
     b.set_climate(0, clim)
     b.set_params(0, members)
@@ -226,8 +226,6 @@ def test_batch_export_import_equals_continuous(case, precision, tmp_path, monkey
     """ensemble: run segment 1, export every member, build a NEW batch for segment 2, import,
     run -> NEE/GPP/ET planes identical to the continuous run (throughput kernel where the
     flags allow it, strict otherwise)"""
-    if precision == sa.F64:
-        monkeypatch.setenv("SIPNET_FAST_MATH", "1")
     param, lines, k = case_inputs(case)
     flags0 = sa.flags_from(**{kk: v for kk, v in sa.read_config(os.path.join(GOLD, case, "sipnet.in")).items()
                               if kk in sa.FLAG_NAMES})
@@ -241,13 +239,13 @@ def test_batch_export_import_equals_continuous(case, precision, tmp_path, monkey
     ev2 = _events(case, flags0, base, tmp_path, ["events_seg2.in"])
     T = len(lines)
 
-    b, clim, flags = _setup_batch(case, lines, ev_all, members, tmp_path, "full", precision)
+    b, clim, flags = _setup_batch(case, lines, ev_all, members, tmp_path, "full", precision, fast=True)
     b.setup()
     cont = b.run(0, T)[0].cpu().numpy()
     ok = b.get_status() == 0
     b.close()
 
-    b1, _, _ = _setup_batch(case, lines[:k], ev1, members, tmp_path, "s1", precision)
+    b1, _, _ = _setup_batch(case, lines[:k], ev1, members, tmp_path, "s1", precision, fast=True)
     b1.setup()
     s1 = b1.run(0, k)[0].cpu().numpy()
     cks = [b1.export_restart(0, m, k) for m in range(M)]
@@ -260,7 +258,7 @@ def test_batch_export_import_equals_continuous(case, precision, tmp_path, monkey
         np.testing.assert_allclose(np.array(cks[0].envi), np.array(ref1.envi), rtol=1e-9,
                                    atol=1e-9 * max(abs(v) for v in ref1.envi))
 
-    b2, clim2, _ = _setup_batch(case, lines[k:], ev2, members, tmp_path, "s2", precision)
+    b2, clim2, _ = _setup_batch(case, lines[k:], ev2, members, tmp_path, "s2", precision, fast=True)
     assert sa.check_restart(cks[0], flags, clim2) & _lib.RESTART_WARN_TIME_GAP == 0
     b2.set_resume(0, cks[0])
     b2.setup()

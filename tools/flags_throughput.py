@@ -21,19 +21,17 @@ for name, kw, fm in (("default flags, fast math (throughput kernels)", {}, "1"),
                      ("litterPool only, fast math", dict(litterPool=1), "1")):
     if PREC != sa.F64 and fm == "0":
         continue
-    os.environ.pop("SIPNET_RUNTIME_FLAGS", None)
-    os.environ.pop("SIPNET_COOP", None)
+    kern, kopt = sa.KERNEL_AUTO, 0
     if fm in ("ow", "owrt"):
-        os.environ["SIPNET_COOP"] = "0"
+        kern = sa.KERNEL_ONE_WAVE
         if fm == "owrt":
-            os.environ["SIPNET_RUNTIME_FLAGS"] = "1"
+            kopt = sa.KOPT_RUNTIME_FLAGS
         fm = "1"
     if fm == "rt":
-        os.environ["SIPNET_RUNTIME_FLAGS"] = "1"
+        kopt = sa.KOPT_RUNTIME_FLAGS
         fm = "1"
-    os.environ["SIPNET_FAST_MATH"] = fm
     flags = sa.flags_from(**kw)
     base, _ = sa.read_params("tests/golden/synth/allflags.param", flags)
-    b = sa.Batch(flags, 1, M, PREC); b.set_climate(0, clim); b.set_params(0, synth.perturbed_params(base, M))
+    b = sa.Batch(flags, 1, M, PREC, fast_math=(fm == "1") if PREC == sa.F64 else None, kernel=kern, kernel_options=kopt); b.set_climate(0, clim); b.set_params(0, synth.perturbed_params(base, M))
     b.setup(); b.run(); torch.cuda.synchronize(); b.setup(); b.run(); ms = b.last_kernel_ms(); b.close()
     print(f"{name:50s}: {ms:8.2f} ms  {M*T/ms/1e6:7.2f} G steps/s", flush=True)

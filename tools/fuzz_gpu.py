@@ -86,14 +86,15 @@ for trial in range(trials):
     final = np.concatenate([r[1] for r in runs], axis=0)
     st = np.concatenate([r[2] for r in runs])
     # kernel choice: default policy, or forced one-wave / HBM-ring cooperative / run-time flags
-    for k in ("SIPNET_COOP", "SIPNET_RUNTIME_FLAGS"):
-        os.environ.pop(k, None)
-    forced = ""
+    forced, kern, kopt = "", sa.KERNEL_AUTO, 0
     r = rng.random()
-    if r < 0.3: os.environ["SIPNET_COOP"] = "0"; forced = " one-wave"
-    elif r < 0.45: os.environ["SIPNET_COOP"] = "2"; forced = " coop-hbm"
-    if rng.random() < 0.3: os.environ["SIPNET_RUNTIME_FLAGS"] = "1"; forced += " rt-flags"
-    b = sa.Batch(flags, S, M, prec, fast_math=fast)
+    default_flags = not any(v != sa.DEFAULT_FLAGS.get(k) for k, v in kw.items())
+    if fast or prec == sa.F32_MIXED:
+        if r < 0.3: kern = sa.KERNEL_ONE_WAVE; forced = " one-wave"
+        elif r < 0.45 and default_flags: kern = sa.KERNEL_COOP_HBM; forced = " coop-hbm"
+        elif r < 0.6 and default_flags: kern = sa.KERNEL_COOP_LDS; forced = " coop-lds"
+    if rng.random() < 0.3: kopt = sa.KOPT_RUNTIME_FLAGS; forced += " rt-flags"
+    b = sa.Batch(flags, S, M, prec, fast_math=fast, kernel=kern, kernel_options=kopt)
     for sidx in range(S):
         if ev is not None: b.set_events(sidx, ev)
         b.set_climate(sidx, clims[sidx]); b.set_params(sidx, members)

@@ -12,12 +12,11 @@ from bench import WORKLOADS
 
 wl = WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "c10k"]
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-os.environ.setdefault("SIPNET_FAST_MATH", "1")
 flags = sa.flags_from(**wl.get("flags", {}))
 base, _ = sa.read_params(os.path.join(REPO, "sipnet_amd", "data", wl.get("param", "base_forest.param")), flags)
 S, M, T = wl["sites"], wl["members"], wl["steps"]
 prec = sa.F64 if wl["prec"] == "f64" else sa.F32_MIXED
-b = sa.Batch(flags, S, M, prec)
+b = sa.Batch(flags, S, M, prec, fast_math=True if prec == sa.F64 else None)
 members = synth.perturbed_params(base, M)
 for s in range(S):
     b.set_climate(s, synth.convert_raw(synth.round_like_file(synth.half_hourly_year_raw(T, site=s))))
