@@ -12,13 +12,26 @@ Workloads (BASELINE.json configs):
   c10k  1 site x 10240 members, fp64, synthetic half-hourly year (17520 steps)  [default:
         the configuration the metric "at 10k members" + the fp64 |dNEE| bar are quoted on]
   c2    1 site x 1024 members, fp64          c3   1 site x 65536 members, fp32-mixed
-  c4    32 sites x 1024 members per GPU, fp64 (256 sites over 8 GPUs)
+  c4    32 sites x 1024 members per GPU, fp64 (256 sites over 8 GPUs; rank r owns sites 32r..32r+31)
   c5    particle-filter cycle: 131072 particles per GPU (1 M over 8), fp32-mixed, one day
         (48 steps) of forecast + the analysis step (likelihood weights, all-gather of
         log-weights, systematic resampling, all-to-all of resampled checkpoints, gather)
   c10kn c10k's shape with the nitrogen-cycle flag set (litter pool + anaerobic + N cycle): the
         optional-flag instantiation of the throughput kernel (not a BASELINE config)
 Per-GPU work is fixed as N grows ("scaling": "weak").
+
+What the JSON line says about the kernel (the `roofline` object):
+  frac               SURVEY 8(d)'s contract number: 344 B (172 B fp32) of ALGORITHMIC state traffic
+                     per member-step x units per launch / kernel time / 8 TB/s.  It is a normalised
+                     throughput: the time-fused kernel keeps state in registers and LDS, so ...
+  hbm_measured_frac  ... the bytes that really cross HBM (rocprofv3 PMC, profiles/pmc_traffic.json,
+                     tagged with the round they were collected in) / kernel time / 8 TB/s;
+  waves_per_simd, cus_used, simds_used   the launch shape (from the library, not re-derived here);
+  issue_frac         this run's rate / the rate the same model reaches on this GPU once every SIMD
+                     holds two wavefronts (a short 131 072-member probe of the one-wave kernel, run
+                     untimed in this process): how much of the chip's instruction issue the launch uses;
+  plan_ms, setup_ms  host-side site-plan build + upload (once per forcing, before the timed region)
+                     and the per-pass setupModel() kernel (inside it).
 """
 import argparse
 import json
@@ -49,7 +62,9 @@ WORKLOADS = {
 
 _CPU_WORKER = r"""
 import ctypes as C, numpy as np, sys, time, os
-kind, so, param_file, clim_file, raw_path, flags_s = sys.argv[1:7]
+kind, so, param_file, clim_file, raw_path, flags_s, cpu = sys.argv[1:8]
+if int(cpu) >= 0:
+    os.sched_setaffinity(0, {int(cpu)})          # one worker pinned to one host core
 flags = [int(x) for x in flags_s.split(',')]
 raw = np.load(raw_path)
 fl = (C.c_int*12)(*flags)
@@ -73,10 +88,11 @@ print(dt, raw.shape[0] * n)
 """
 
 
-def usable_cores():
-    """Host cores this process may really use: CPU affinity capped by the cgroup CPU quota
-    (the GPU box shows 256 logical CPUs but grants a 16-CPU quota)."""
-    n = len(os.sched_getaffinity(0))
+def usable_cpus():
+    """Host cores this process may really use: the CPU affinity list capped by the cgroup CPU
+    quota (the GPU box shows 256 logical CPUs but grants a 16-CPU quota)."""
+    cpus = sorted(os.sched_getaffinity(0))
+    n = len(cpus)
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
         if quota != "max":
@@ -89,15 +105,51 @@ def usable_cores():
                 n = min(n, max(1, q // p))
         except Exception:
             pass
-    return n
+    return cpus[:n]
 
 
-def cpu_baseline(flags, members_raw, raw_forcing, target_seconds=12.0, param_name="base_forest.param"):
-    """Time the CPU checker (the real reference build when oracle/_ref travelled,
-    else this repo's restatement) on a bounded sample of the same ensemble, one
-    process per host core.  Test infrastructure used as a *baseline*, never shipped."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def _cpu_leg(kind, so, flags, members_raw, n_steps, clim_file, param_file, cpus, target_seconds, ns_guess):
+    """one timed leg: len(cpus) worker processes, each pinned to its own core"""
+    cores = len(cpus)
+    per_core = max(1, int(target_seconds / (n_steps * ns_guess * 1e-9)))
+    per_core = min(per_core, members_raw.shape[0] // cores if members_raw.shape[0] >= cores else 1)
+    tmp = os.path.dirname(clim_file)
+    procs = []
+    env = dict(os.environ, SIPNET_REPO=REPO)
+    t0 = time.time()
+    for c, cpu in enumerate(cpus):
+        raw_path = os.path.join(tmp, f"raw{c}.npy")
+        np.save(raw_path, np.ascontiguousarray(members_raw[c * per_core:(c + 1) * per_core]))
+        procs.append(subprocess.Popen(
+            [sys.executable, "-c", _CPU_WORKER, kind, so, param_file, clim_file, raw_path,
+             ",".join(str(f) for f in flags), str(cpu)], stdout=subprocess.PIPE, env=env, text=True))
+    secs, units = [], 0
+    for p in procs:
+        out = p.communicate()[0].strip().split()
+        secs.append(float(out[0]))
+        units += int(out[1])
+    return dict(value=units / max(secs), per_core=units / sum(secs), members=per_core * cores,
+                slowest_s=max(secs), wall_s=time.time() - t0)
+
+
+def cpu_baseline(flags, members_raw, raw_forcing, param_name="base_forest.param"):
+    """Time the CPU checker (the real reference build when oracle/_ref travelled, else this
+    repo's restatement) on a bounded sample of the same ensemble, one PINNED process per usable
+    host core, at gcc -O2 (`value`) and at -O0, the level the reference's own Makefile ships
+    (`value_O0`).  Test infrastructure used as a *baseline*, never shipped."""
     from sipnet_amd import synth
     ref_so = os.path.join(REPO, "oracle", "_ref", "libsipnet_ref.so")
+    ref_o0 = os.path.join(REPO, "oracle", "_ref", "libsipnet_ref_O0.so")
     ora_so = os.path.join(REPO, "oracle", "liboracle.so")
     if os.path.exists(ref_so):
         kind, so = "reference", ref_so
@@ -105,38 +157,52 @@ def cpu_baseline(flags, members_raw, raw_forcing, target_seconds=12.0, param_nam
         if not os.path.exists(ora_so):
             subprocess.check_call(["make", "-s", "-C", os.path.join(REPO, "oracle"), "oracle"])
         kind, so = "port", ora_so
-    cores = usable_cores()
+    cpus = usable_cpus()
     n_steps = len(raw_forcing["year"])
-    # ~350 ns per member-step per core (BASELINE.md probe) -> members per core
-    per_core = max(1, int(target_seconds / (n_steps * 150e-9)))
-    per_core = min(per_core, members_raw.shape[0] // cores if members_raw.shape[0] >= cores else 1)
     tmp = tempfile.mkdtemp(prefix="sipnet_cpu_")
     clim_file = os.path.join(tmp, "bench.clim")
     synth.write_clim(clim_file, raw_forcing)
     param_file = os.path.join(REPO, "sipnet_amd", "data", param_name)
-    procs = []
-    env = dict(os.environ, SIPNET_REPO=REPO)
-    t0 = time.time()
-    for c in range(cores):
-        raw_path = os.path.join(tmp, f"raw{c}.npy")
-        np.save(raw_path, np.ascontiguousarray(members_raw[c * per_core:(c + 1) * per_core]))
-        procs.append(subprocess.Popen(
-            [sys.executable, "-c", _CPU_WORKER, kind, so, param_file, clim_file, raw_path,
-             ",".join(str(f) for f in flags)], stdout=subprocess.PIPE, env=env, text=True))
-    secs, units = [], 0
-    for p in procs:
-        out = p.communicate()[0].strip().split()
-        secs.append(float(out[0]))
-        units += int(out[1])
-    wall = time.time() - t0
-    value = units / max(secs)
+    o2 = _cpu_leg(kind, so, flags, members_raw, n_steps, clim_file, param_file, cpus, 8.0, 150)
+    o0 = None
+    if kind == "reference" and os.path.exists(ref_o0):
+        o0 = _cpu_leg(kind, ref_o0, flags, members_raw, n_steps, clim_file, param_file, cpus, 6.0, 400)
     return {
-        "value": value, "unit": "ensemble-site-timesteps/s", "cores": cores, "kind": kind,
-        "per_core": units / sum(secs),
-        "sample": f"{per_core * cores} members x {n_steps} steps of the same synthetic ensemble, "
-                  f"{cores} processes (one per host core), step loop only, gcc -O2; "
-                  f"slowest process {max(secs):.2f}s, wall incl. start-up {wall:.1f}s",
+        "value": o2["value"], "unit": "ensemble-site-timesteps/s", "cores": len(cpus), "kind": kind,
+        "per_core": o2["per_core"], "pinned": True, "cpu_model": cpu_model(),
+        "value_O0": o0["value"] if o0 else None, "per_core_O0": o0["per_core"] if o0 else None,
+        "sample": f"{o2['members']} members x {n_steps} steps of the same synthetic ensemble, "
+                  f"{len(cpus)} processes each pinned to one host core, step loop only, gcc -O2 "
+                  f"(slowest process {o2['slowest_s']:.2f}s, wall incl. start-up {o2['wall_s']:.1f}s)"
+                  + (f"; the same at -O0 (the reference Makefile's level) on {o0['members']} members "
+                     f"(slowest {o0['slowest_s']:.2f}s)" if o0 else ""),
     }
+
+
+def fill_probe(sa, synth, flags, base, prec_name, device):
+    """Rate of the same model on this GPU with every SIMD holding two wavefronts: 131 072 members
+    of the one-wave throughput kernel over 960 steps (NEE plane only).  Untimed extra; gives
+    `issue_frac` its denominator."""
+    import torch
+    M, T = 131072, 960
+    prec = sa.F64 if prec_name == "f64" else sa.F32_MIXED
+    b = sa.Batch(flags, 1, M, prec, device=device, fast_math=True if prec == sa.F64 else None,
+                 kernel=sa.KERNEL_ONE_WAVE)
+    b.set_climate(0, synth.convert_raw(synth.round_like_file(synth.half_hourly_year_raw(T))))
+    b.set_params(0, synth.perturbed_params(base, M, seed=synth.SEED_PARAMS))
+    nee = torch.empty((1, T, M), dtype=b.out_dtype, device=b.device)
+    import ctypes as C
+    ms = []
+    for _ in range(3):
+        b.setup()
+        sa._lib.check(b.L.sipnet_batch_run(b.h, 0, T, C.c_void_p(nee.data_ptr()), None, None, None,
+                                           M, b._stream()), "run")
+        torch.cuda.synchronize()
+        ms.append(b.last_kernel_ms())
+    li = b.last_launch()
+    b.close()
+    return {"rate": M * T / (min(ms) * 1e-3), "kernel": li["kernel"], "members": M, "timesteps": T,
+            "kernel_ms": min(ms), "waves_per_simd": li["waves_per_simd"]}
 
 
 def main():
@@ -148,9 +214,14 @@ def main():
                     choices=sorted(WORKLOADS))
     ap.add_argument("--members", type=int, default=0, help="override members per site per GPU")
     ap.add_argument("--nsteps", type=int, default=0, help="override timesteps per pass")
-    ap.add_argument("--fast-math", type=int, default=int(os.environ.get("SIPNET_FAST_MATH", "1")))
+    ap.add_argument("--fast-math", type=int, default=1,
+                    help="1: throughput kernels (default, what the metric is quoted on); 0: strict-order kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fill-probe", action="store_true")
     ap.add_argument("--gather", default="stats", choices=["stats", "full", "none"])
+    ap.add_argument("--dump-stats", default="",
+                    help="rank 0 writes the whole ensemble's statistics block [3][T][sites][2] (sum, sum of "
+                         "squares over ALL ranks' members) of the last pass to this .npy file")
     ap.add_argument("--rehearse", action="store_true",
                     help="development: run the N>1 path on ONE GPU (all ranks share device 0, gloo "
                          "collectives through host copies); the numbers mean nothing")
@@ -161,7 +232,6 @@ def main():
         wl["members"] = args.members
     if args.nsteps:
         wl["steps"] = args.nsteps
-    os.environ["SIPNET_FAST_MATH"] = str(args.fast_math)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -181,7 +251,7 @@ def main():
     prec = sa.F64 if wl["prec"] == "f64" else sa.F32_MIXED
 
     # identical inputs for CPU baseline and GPU: rank r owns global members [r*M, (r+1)*M)
-    # of each of its sites; sites of rank r are r*S .. r*S+S-1
+    # of each of its sites; whole sites are sharded: sites of rank r are r*S .. r*S+S-1
     raws = [synth.round_like_file(synth.half_hourly_year_raw(T, site=rank * S + s)) for s in range(S)]
     clims = [synth.convert_raw(r) for r in raws]
     members = synth.perturbed_params(base, M * world, seed=synth.SEED_PARAMS)[rank * M:(rank + 1) * M]
@@ -204,18 +274,41 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     def all_gather_into(out, x):
+        """out[world, *x.shape] <- every rank's x; passed to the collective in its concatenated
+        form (world * x.shape[0], ...), which RCCL and gloo both accept"""
+        flat = (world * x.shape[0],) + tuple(x.shape[1:])
         if args.rehearse:   # gloo: through the host
-            o = torch.empty(out.shape, dtype=out.dtype)
-            dist.all_gather_into_tensor(o.view((-1,) + tuple(x.shape[1:])) if x.dim() else o, x.cpu().contiguous())
-            out.copy_(o)
+            o = torch.empty(flat, dtype=out.dtype)
+            dist.all_gather_into_tensor(o, x.cpu().contiguous())
+            out.copy_(o.view(out.shape))
         else:
-            dist.all_gather_into_tensor(out, x)
+            dist.all_gather_into_tensor(out.view(flat), x.contiguous())
 
-    b = sa.Batch(flags, S, M, prec, device=local_rank, fast_math=bool(args.fast_math))
+    # who takes part: every rank's device identity, gathered (proof that N ranks drove N devices)
+    ranks_seen, devices_seen = 1, None
+    props = torch.cuda.get_device_properties(local_rank)
+    ident = f"{getattr(props, 'uuid', '')}|{getattr(props, 'pci_bus_id', '')}|{getattr(props, 'pci_device_id', '')}|{props.name}"
+    if world > 1:
+        me = torch.zeros(128, dtype=torch.uint8)
+        raw_id = ident.encode()[:128]
+        me[:len(raw_id)] = torch.tensor(list(raw_id), dtype=torch.uint8)
+        allid = torch.zeros(world * 128, dtype=torch.uint8, device="cpu" if args.rehearse else torch.device("cuda", local_rank))
+        dist.all_gather_into_tensor(allid, me.to(allid.device))
+        ids = [bytes(allid[r * 128:(r + 1) * 128].cpu().tolist()).rstrip(b"\0").decode(errors="replace")
+               for r in range(world)]
+        ranks_seen, devices_seen = len(ids), len(set(ids))
+        device_ids = ids
+    else:
+        device_ids = [ident]
+        devices_seen = 1
+
+    b = sa.Batch(flags, S, M, prec, device=local_rank, fast_math=bool(args.fast_math) if prec == sa.F64 else None)
     for s in range(S):
         b.set_climate(s, clims[s])
         b.set_params(s, members)
-    b.setup()
+    b.setup()                       # builds and uploads the site plans (host side; timed by the library)
+    li0 = b.last_launch()
+    plan_ms = li0["plan_build_ms"] + li0["plan_upload_ms"]
     planes, _ = b.alloc_outputs(T)
     stats = torch.empty((3, T, S, 2), dtype=torch.float64, device=b.device)
     gathered = torch.empty((world,) + tuple(stats.shape), dtype=torch.float64, device=b.device) \
@@ -228,16 +321,15 @@ def main():
     # + one small all-gather) run on a side stream under the step kernel of pass k+1, which
     # writes the other of two output-plane buffers
     overlap = world > 1 and args.gather == "stats" and not wl.get("pf")
+    side = torch.cuda.Stream(device=b.device) if world > 1 else None
     if overlap:
         planes2, _ = b.alloc_outputs(T)
         stats2 = torch.empty_like(stats)
         gathered2 = torch.empty_like(gathered)
-        side = torch.cuda.Stream(device=b.device)
         bufs = [dict(planes=planes, stats=stats, gathered=gathered, ran=torch.cuda.Event(), done=None),
                 dict(planes=planes2, stats=stats2, gathered=gathered2, ran=torch.cuda.Event(), done=None)]
         npass = [0]
 
-    kernel_ms = []
     pf = bool(wl.get("pf"))
     pf_info = {}
     if pf:
@@ -298,8 +390,8 @@ def main():
     for _ in range(args.warmup):
         one_pass(True)
     barrier()
-    # HIP-event kernel timing is collected in an extra, untimed pass per step to keep the
-    # timed region free of host syncs: time K passes wall-clock first
+    # HIP-event kernel timing is collected in extra, untimed passes below to keep the timed
+    # region free of host syncs: time K passes wall-clock first
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_pass(False)
@@ -312,15 +404,22 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    # dominant kernel's launch duration, HIP events on the launch stream
-    kms = []
+    # dominant kernel's launch duration (HIP events on the launch stream, inside the library) and
+    # the per-pass setupModel() kernel (torch events on the same, current, stream)
+    kms, sms = [], []
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for _ in range(max(3, min(args.steps, 5))):
+        e0.record()
         b.setup()
+        e1.record()
         b.run(0, T, planes=planes)
+        torch.cuda.synchronize()
         kms.append(b.last_kernel_ms())
+        sms.append(e0.elapsed_time(e1))
     k_ms = float(np.mean(kms))
+    setup_ms = float(np.mean(sms))
+    li = b.last_launch()
     if pf:   # the analysis step alone, torch events on the current stream (all its work is there)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ams = []
         for _ in range(3):
             b.setup()
@@ -333,6 +432,54 @@ def main():
             torch.cuda.synchronize()
             ams.append(e0.elapsed_time(e1))
         pf_info["analysis_ms"] = float(np.mean(ams))
+
+    # N > 1: the north star's exchange as written -- the member-resolved NEE/GPP/ET block of every
+    # rank all-gathered -- measured in an extra untimed pass: the launch is cut into 10 segments
+    # and segment k's planes travel on the side stream while segment k+1 computes
+    gather_full = None
+    if world > 1 and not pf:
+        nseg = 10
+        cuts = [T * k // nseg for k in range(nseg + 1)]
+        seglen = max(z - a for a, z in zip(cuts[:-1], cuts[1:]))
+        stage = [torch.empty((world, 3, seglen, b.ncol), dtype=planes.dtype, device=b.device) for _ in range(2)]
+        free = [None, None]
+        barrier()
+        main = torch.cuda.current_stream()
+        tg0 = time.perf_counter()
+        b.setup()
+        for k, (a, z) in enumerate(zip(cuts[:-1], cuts[1:])):
+            b.run(a, z - a, planes=planes[:, a:z])
+            ran = torch.cuda.Event()
+            ran.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ran)
+                buf = stage[k & 1]
+                seg = planes[:, a:z].contiguous() if z - a == seglen else \
+                    torch.cat([planes[:, a:z], planes[:, a:a + seglen - (z - a)]], dim=1)
+                all_gather_into(buf, seg)
+                free[k & 1] = torch.cuda.Event()
+                free[k & 1].record(side)
+        barrier()
+        tg = time.perf_counter() - tg0
+        tmax = torch.tensor([tg], dtype=torch.float64, device="cpu" if args.rehearse else b.device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        gather_full = {"ms": float(tmax.item()) * 1e3, "segments": nseg,
+                       "bytes_received_per_rank": int((world - 1) * 3 * T * b.ncol * planes.element_size()),
+                       "note": "one pass with the member-resolved planes of every rank all-gathered "
+                               "(segment k travels under the kernel of segment k+1)"}
+
+    if args.dump_stats and not pf:
+        if world > 1 and args.gather == "stats":
+            g = (bufs[(npass[0] - 1) & 1]["gathered"] if overlap else gathered)
+            # ranks hold different sites in c4 and the same site's members otherwise: a rank's block
+            # is added to the others' (members) or stands beside them (sites)
+            total = g.sum(0) if S == 1 else torch.cat([g[r] for r in range(world)], dim=2)
+        else:
+            for v in range(3):
+                b.reduce_plane(planes[v], stats[v])
+            total = stats
+        if rank == 0:
+            np.save(args.dump_stats, total.cpu().numpy())
 
     units_per_pass = S * M * T * world
     value = units_per_pass * args.steps / dt
@@ -347,26 +494,43 @@ def main():
             ora = helpers.load_oracle()
             n_chk = min(8, M)
             po, _, _ = ora.run_block(flags, members[:n_chk], clims[0])
-            if pf:      # the planes of the last forecast (the analysis does not touch them)
+            if pf or world > 1:      # the planes of a whole forecast from a fresh setup
                 b.setup()
                 b.run(0, T, planes=planes)
             pg = planes[:, :, :n_chk].double().cpu().numpy()
+            scale = np.maximum(np.abs(po).max(axis=(1, 2), keepdims=True), 1e-3)
+            flips = int(((np.abs(pg - po) / scale) > 1e-4).any(axis=(0, 1)).sum())
             parity = {"members_checked": n_chk,
                       "max_abs_dNEE": float(np.abs(pg[0] - po[0]).max()),
                       "max_abs_dGPP": float(np.abs(pg[1] - po[1]).max()),
-                      "max_abs_dET": float(np.abs(pg[2] - po[2]).max())}
+                      "max_abs_dET": float(np.abs(pg[2] - po[2]).max()),
+                      "branch_flip_members": flips,
+                      "tolerance": 1e-9 if wl["prec"] == "f64" else 2e-6}
         except Exception as e:  # the checker is optional for the measurement itself
             parity = {"error": repr(e)}
 
-    traffic = None
+    traffic, traffic_tag = None, None
     tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(args.workload, {}).get("hbm_bytes_per_launch")
+            ent = json.load(open(tpath)).get(args.workload, {})
+            # only valid for the kernel it was collected on
+            if ent.get("kernel") in (None, li["kernel"]):
+                traffic, traffic_tag = ent.get("hbm_bytes_per_launch"), ent.get("tag")
         except Exception:
             traffic = None
 
+    probe = None
+    if rank == 0 and world == 1 and not args.no_fill_probe and not pf and args.fast_math:
+        try:
+            probe = fill_probe(sa, synth, flags, base, wl["prec"], local_rank)
+        except Exception as e:
+            probe = {"error": repr(e)}
+
     if rank == 0:
+        waves_per_block = li["block_threads"] // 64
+        cus_used = min(li["grid"], li["num_cus"]) if "Coop" in li["kernel"] else min((li["grid"] + 3) // 4, li["num_cus"])
+        simds_used = min(li["grid"] * waves_per_block, 4 * li["num_cus"])
         line = {
             "metric": "ensemble-site-timesteps/sec", "value": value,
             "unit": "ensemble-site-timesteps/s", "n_gpus": world, "steps": args.steps,
@@ -380,10 +544,22 @@ def main():
                        "fast_math": bool(args.fast_math),
                        "gather": args.gather if world > 1 else "n/a (1 GPU)",
                        "parallelism": f"ensemble-sharded x{world}",
+                       "ranks_seen": ranks_seen, "devices_seen": devices_seen, "device_ids": device_ids,
+                       **({"gather_full": gather_full} if gather_full else {}),
                        **({"particle_filter": pf_info} if pf else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": ("stepCoopKernel" if S * ((M + 63) // 64) <= 512 and os.environ.get("SIPNET_COOP", "1") != "0" and not wl.get("flags") else "stepFastKernel") if args.fast_math else "stepKernel", "kernel_ms": k_ms,
+                         "traffic_tag": traffic_tag,
+                         "hbm_measured_frac": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+                         "kernel": li["kernel"], "kernel_ms": k_ms,
+                         "grid": li["grid"], "block_threads": li["block_threads"],
+                         "waves_per_simd": li["waves_per_simd"] if li["grid"] * waves_per_block > 4 * li["num_cus"] else 1,
+                         "cus_used": cus_used, "cus_total": li["num_cus"],
+                         "simds_used": simds_used, "simds_total": 4 * li["num_cus"],
+                         "lds_bytes_per_workgroup": li["lds_bytes"],
+                         "issue_frac": (per_launch_units / (k_ms * 1e-3) / probe["rate"]) if probe and "rate" in probe else None,
+                         "fill_probe": probe,
+                         "plan_ms": plan_ms, "plan_threads": li0["plan_threads"], "setup_ms": setup_ms,
                          "algorithmic_bytes_per_unit": ALGO_BYTES[wl["prec"]],
                          "units_per_launch": per_launch_units},
             "cpu_baseline": cpu, "parity": parity,

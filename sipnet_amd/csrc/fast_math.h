@@ -17,31 +17,61 @@ constexpr double kLog2e = 1.4426950408889634074;
 __device__ __forceinline__ double ffma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ float ffma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
-// 2^x, |rel err| <= 1.8e-16: n = rint(x), 2^(x-n) by a degree-11 polynomial on
-// [-0.5, 0.5] (Chebyshev-node interpolant, tools/fit_exp2.py), scaled with v_ldexp_f64.
+// 2^x: n = rint(x), 2^(x-n) by a polynomial on [-0.5, 0.5] -- the interpolant of (2^f - 1)/f
+// through the Chebyshev nodes, coefficients correctly rounded from a 50-digit computation
+// (tools/fit_exp2.py prints them and the measured error) -- scaled with v_ldexp_f64.
+//   degree 11: |rel err| <= 1.7e-16 (the shipped build)   degree 9: 3.7e-14   degree 8: 2.1e-12
 // The coefficients live in SGPR pairs for the whole time loop (a VOP3 fma takes one scalar
 // operand): left as literals, hipcc re-materialises them with v_mov_b64 at each of the 13
 // call sites of a step, which costs as much as the polynomial itself.
+#ifndef SIPNET_EXP2_DEGREE
+#define SIPNET_EXP2_DEGREE 11
+#endif
 struct Exp2Coef {
   double c1, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11;
 };
 __device__ __forceinline__ Exp2Coef loadExp2Coef() {
-  Exp2Coef k = {0.6931471805599453,     0.2402265069591016,     0.05550410866482163,
-                0.009618129107587223,   0.0013333558146405434,  0.0001540353046375614,
-                1.5252733842758916e-05, 1.3215432520547035e-06, 1.0178056472371986e-07,
-                7.074197066047615e-09,  4.455930741563682e-10};
+#if SIPNET_EXP2_DEGREE == 11
+  Exp2Coef k = {0.6931471805599453,    0.24022650695910097,   0.0555041086648216,
+                0.009618129107606888,  0.0013333558146416936, 0.0001540353044173605,
+                1.525273382983612e-05, 1.321544258792169e-06, 1.0178062445845774e-07,
+                7.072585949269223e-09, 4.4549605981865186e-10};
+#elif SIPNET_EXP2_DEGREE == 9
+  Exp2Coef k = {0.6931471805599453,    0.2402265069581299,     0.055504108664760424,
+                0.009618129159402558,  0.0013333558179043112,  0.00015403455852453838,
+                1.525268684626772e-05, 1.3255224878668817e-06, 1.0203121063391729e-07, 0.0, 0.0};
+#elif SIPNET_EXP2_DEGREE == 8
+  Exp2Coef k = {0.6931471805568324,     0.24022650695888503,   0.055504109063258665,
+                0.00961812913523614,    0.0013333478473685416, 0.00015403475186530786,
+                1.5303700711365693e-05, 1.325080551750225e-06, 0.0, 0.0, 0.0};
+#else
+#error "SIPNET_EXP2_DEGREE must be 8, 9 or 11 (tools/fit_exp2.py)"
+#endif
   // opaque to constant propagation, pinned to scalar registers
   asm volatile("" : "+s"(k.c1), "+s"(k.c2), "+s"(k.c3), "+s"(k.c4), "+s"(k.c5), "+s"(k.c6));
-  asm volatile("" : "+s"(k.c7), "+s"(k.c8), "+s"(k.c9), "+s"(k.c10), "+s"(k.c11));
+  asm volatile("" : "+s"(k.c7), "+s"(k.c8));
+#if SIPNET_EXP2_DEGREE >= 9
+  asm volatile("" : "+s"(k.c9));
+#endif
+#if SIPNET_EXP2_DEGREE >= 11
+  asm volatile("" : "+s"(k.c10), "+s"(k.c11));
+#endif
   return k;
 }
 __device__ __forceinline__ double fexp2(double x, const Exp2Coef& k) {
   const double n = __builtin_rint(x);
   const double f = x - n;
+#if SIPNET_EXP2_DEGREE == 11
   double p = k.c11;
   p = ffma(p, f, k.c10);
   p = ffma(p, f, k.c9);
   p = ffma(p, f, k.c8);
+#elif SIPNET_EXP2_DEGREE == 9
+  double p = k.c9;
+  p = ffma(p, f, k.c8);
+#else
+  double p = k.c8;
+#endif
   p = ffma(p, f, k.c7);
   p = ffma(p, f, k.c6);
   p = ffma(p, f, k.c5);
@@ -54,11 +84,16 @@ __device__ __forceinline__ double fexp2(double x, const Exp2Coef& k) {
 }
 __device__ __forceinline__ float fexp2(float x, const Exp2Coef&) { return __builtin_amdgcn_exp2f(x); }
 
-// a / b with b > 0 finite and well scaled: v_rcp + two Newton steps + one residual step
+// a / b with b > 0 finite and well scaled: v_rcp + Newton steps + one residual step
+#ifndef SIPNET_FDIV_NEWTON
+#define SIPNET_FDIV_NEWTON 2
+#endif
 __device__ __forceinline__ double fdiv(double a, double b) {
   double r = __builtin_amdgcn_rcp(b);
   r = ffma(ffma(-b, r, 1.0), r, r);
+#if SIPNET_FDIV_NEWTON >= 2
   r = ffma(ffma(-b, r, 1.0), r, r);
+#endif
   const double q = a * r;
   return ffma(ffma(-b, q, a), r, q);
 }

@@ -1,0 +1,68 @@
+"""The N > 1 path of bench.py as the driver launches it -- `python -m torch.distributed.run
+--nproc-per-node 2 ... bench.py --gpus 2` -- started as a FRESH child process (the launcher runs
+before anything touches the GPU), rehearsed on the one GPU of this box: both ranks share device
+0 and the collectives go over gloo through host copies (`--rehearse`), everything else -- member
+sharding, double-buffered planes, side-stream statistics, the all-gather of the statistics
+block, the segmented full-plane gather, the barrier / max-over-ranks timing -- is the code the
+8-GPU run executes.  The gathered ensemble statistics must equal a single-process run over the
+same 2 x M members."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+BENCH = os.path.join(helpers.REPO, "bench.py")
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _last_json(text):
+    for line in reversed(text.strip().splitlines()):
+        if line.startswith("{"):
+            return json.loads(line)
+    raise AssertionError("no JSON line in:\n" + text[-2000:])
+
+
+@pytest.mark.parametrize("workload,members,nsteps", [("c2", 192, 48 * 30), ("c4", 64, 48 * 10)])
+def test_two_ranks_rehearsed_on_one_gpu_equal_a_single_process(workload, members, nsteps, tmp_path):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    two = str(tmp_path / "two.npy")
+    one = str(tmp_path / "one.npy")
+    common = ["--workload", workload, "--nsteps", str(nsteps), "--steps", "2", "--warmup", "1",
+              "--no-cpu-baseline", "--no-fill-probe"]
+    r2 = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+         "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), BENCH, "--gpus", "2",
+         "--rehearse", "--members", str(members), "--dump-stats", two] + common,
+        capture_output=True, text=True, timeout=600, env=env, cwd=helpers.REPO)
+    assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-3000:]
+    j2 = _last_json(r2.stdout)
+    assert j2["n_gpus"] == 2 and j2["config"]["ranks_seen"] == 2
+    assert j2["config"]["devices_seen"] == 1          # rehearsal: both ranks on device 0 (8-GPU run: 8)
+    assert j2["config"]["gather_full"]["ms"] > 0 and j2["config"]["gather_full"]["segments"] == 10
+    assert j2["parity"]["max_abs_dNEE"] < 1e-9
+    if workload == "c2":
+        # the same site, members 0 .. 2M-1 in one process
+        r1 = subprocess.run([sys.executable, BENCH, "--members", str(2 * members), "--dump-stats", one] + common,
+                            capture_output=True, text=True, timeout=600, env=env, cwd=helpers.REPO)
+        assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-3000:]
+        a, b = np.load(two), np.load(one)
+        assert a.shape == b.shape == (3, nsteps, 1, 2)
+        np.testing.assert_allclose(a, b, rtol=1e-11, atol=1e-12)
+    else:
+        # c4 shards whole sites: rank r owns sites 32r .. 32r+31 with members 0 .. M-1 of the ensemble
+        # slice it was dealt; the combined block lists 64 sites
+        a = np.load(two)
+        assert a.shape == (3, nsteps, 64, 2) and np.isfinite(a).all()
+        assert not np.allclose(a[:, :, 0], a[:, :, 32])          # different forcing per site
