@@ -64,7 +64,14 @@ struct sipnet_batch {
   RingOp* d_ringOps = nullptr;
   EvRec* d_events = nullptr;
   int32_t* d_siteStatus = nullptr;
-  size_t planCap = 0, ringOpCap = 0, evCap = 0;
+  SiteStart* d_siteStart = nullptr;  // [n_sites] what setupModel() reads of a site's first record
+  size_t planCap = 0, fastCap = 0, ringOpCap = 0, evCap = 0;
+  std::vector<int32_t> opBase, evBase;  // per site: offset of its ring ops / events in the flat arrays
+  bool stepRecsUploaded = false, fastRecsUploaded = false;  // per-step records: uploaded on first use
+  // last boundary a checkpoint was exported at (sipnet_batch_export_restart)
+  int32_t exportCacheSite = -1, exportCacheN = -1;
+  SitePlan exportHead;
+  PlanCarry exportFin;
 
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;

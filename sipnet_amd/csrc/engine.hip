@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <ctime>
 #include <string>
 #include <thread>
@@ -30,8 +31,29 @@ static double nowMs() {
 }
 
 // Site plans are independent of each other: they are built by a pool of host threads (one site
-// at a time each) straight into the flattened upload buffers, so a 32-site batch costs about
-// what one site costs (bench.py reports plan_ms).
+// at a time each).  What every launch needs (ring evictions, events, site status, the first
+// record's phenology inputs) is uploaded right away; the per-step records -- 256 B per step for
+// the strict-order kernel, 256 B per step for the throughput kernels -- are flattened and uploaded
+// on the first launch that reads them (ensureStepRecs / ensureFastRecs), so a batch pays for the
+// record type it uses only.  bench.py reports the sum as plan_ms.
+static int planThreadsFor(int nS) {
+  int n = (int)std::thread::hardware_concurrency();
+  if (n < 1) n = 1;
+  if (n > 16) n = 16;
+  return n > nS ? nS : n;
+}
+template <class F>
+static void forEachSite(int nS, int nThreads, F f) {
+  std::atomic<int> next{0};
+  auto work = [&]() {
+    for (int s = next.fetch_add(1); s < nS; s = next.fetch_add(1)) f(s);
+  };
+  std::vector<std::thread> pool;
+  for (int i = 1; i < nThreads; i++) pool.emplace_back(work);
+  work();
+  for (auto& th : pool) th.join();
+}
+
 static int uploadPlan(sipnet_batch* b, hipStream_t stream) {
   // every site needs forcing of equal length
   for (int s = 0; s < b->n_sites; s++) {
@@ -42,83 +64,38 @@ static int uploadPlan(sipnet_batch* b, hipStream_t stream) {
   }
   const double t0 = nowMs();
   const int nS = b->n_sites, nT = b->n_steps;
+  const int nThreads = planThreadsFor(nS);
   b->plans.clear();
   b->plans.resize(nS);
-  std::vector<StepRec> steps((size_t)nS * nT);
-  std::vector<FastRec> fast((size_t)nS * nT + kFastTile);
-  int nThreads = (int)std::thread::hardware_concurrency();
-  if (nThreads < 1) nThreads = 1;
-  if (nThreads > 16) nThreads = 16;
-  if (nThreads > nS) nThreads = nS;
-  // phase 1: plans (parallel over sites); the fast records are derived per site with site-local
-  // op / event indices and rebased in phase 2 once the totals are known
-  std::atomic<int> next{0};
-  auto build = [&]() {
-    for (int s = next.fetch_add(1); s < nS; s = next.fetch_add(1)) {
-      b->plans[s] = buildSitePlan(b->flags, nT, b->clim[s].data(), b->year[s].data(),
-                                  b->day[s].data(), (int32_t)b->events[s].size(),
-                                  b->events[s].data(), b->resume[s].set ? &b->resume[s] : nullptr);
-      const std::vector<FastRec> fr = buildFastRecs(b->plans[s]);
-      memcpy(fast.data() + (size_t)s * nT, fr.data(), (size_t)nT * sizeof(FastRec));
-      memcpy(steps.data() + (size_t)s * nT, b->plans[s].steps.data(), (size_t)nT * sizeof(StepRec));
-    }
-  };
-  {
-    std::vector<std::thread> pool;
-    for (int i = 1; i < nThreads; i++) pool.emplace_back(build);
-    build();
-    for (auto& th : pool) th.join();
-  }
-  // phase 2: make op / event indices global
-  std::vector<int32_t> opBase(nS + 1, 0), evBase(nS + 1, 0);
+  forEachSite(nS, nThreads, [&](int s) {
+    b->plans[s] = buildSitePlan(b->flags, nT, b->clim[s].data(), b->year[s].data(), b->day[s].data(),
+                                (int32_t)b->events[s].size(), b->events[s].data(),
+                                b->resume[s].set ? &b->resume[s] : nullptr);
+  });
+  // op / event indices become global
+  b->opBase.assign(nS + 1, 0);
+  b->evBase.assign(nS + 1, 0);
+  std::vector<SiteStart> starts(nS);
   for (int s = 0; s < nS; s++) {
-    b->siteStatus[s] = b->plans[s].status;
-    opBase[s + 1] = opBase[s] + (int32_t)b->plans[s].ringOps.size();
-    evBase[s + 1] = evBase[s] + (int32_t)b->plans[s].events.size();
+    const SitePlan& p = b->plans[s];
+    b->siteStatus[s] = p.status;
+    b->opBase[s + 1] = b->opBase[s] + (int32_t)p.ringOps.size();
+    b->evBase[s + 1] = b->evBase[s] + (int32_t)p.events.size();
+    starts[s] = SiteStart{p.steps[0].cumGdd, p.steps[0].tsoil, p.steps[0].dayTime};
   }
-  std::vector<RingOp> ops((size_t)opBase[nS] + 1);
-  std::vector<EvRec> evs((size_t)evBase[nS] + 1);
-  next = 0;
-  auto rebase = [&]() {
-    for (int s = next.fetch_add(1); s < nS; s = next.fetch_add(1)) {
-      const SitePlan& p = b->plans[s];
-      if (opBase[s] || evBase[s]) {
-        StepRec* st = steps.data() + (size_t)s * nT;
-        FastRec* fr = fast.data() + (size_t)s * nT;
-        for (int t = 0; t < nT; t++) {
-          st[t].ringOpFirst += opBase[s];
-          st[t].evFirst += evBase[s];
-          fr[t].opFirst += opBase[s];
-          fr[t].evFirst += evBase[s];
-        }
-      }
-      if (!p.ringOps.empty()) memcpy(ops.data() + opBase[s], p.ringOps.data(), p.ringOps.size() * sizeof(RingOp));
-      if (!p.events.empty()) memcpy(evs.data() + evBase[s], p.events.data(), p.events.size() * sizeof(EvRec));
-    }
-  };
-  {
-    std::vector<std::thread> pool;
-    for (int i = 1; i < nThreads; i++) pool.emplace_back(rebase);
-    rebase();
-    for (auto& th : pool) th.join();
+  std::vector<RingOp> ops((size_t)b->opBase[nS] + 1);
+  std::vector<EvRec> evs((size_t)b->evBase[nS] + 1);
+  for (int s = 0; s < nS; s++) {
+    const SitePlan& p = b->plans[s];
+    if (!p.ringOps.empty()) memcpy(ops.data() + b->opBase[s], p.ringOps.data(), p.ringOps.size() * sizeof(RingOp));
+    if (!p.events.empty()) memcpy(evs.data() + b->evBase[s], p.events.data(), p.events.size() * sizeof(EvRec));
   }
-  if (opBase[nS] == 0) ops[0] = RingOp{0.0, 0, -1};
-  if (evBase[nS] == 0) evs[0] = EvRec{0, 0, {0, 0, 0, 0}};
+  if (b->opBase[nS] == 0) ops[0] = RingOp{0.0, 0, -1};
+  if (b->evBase[nS] == 0) evs[0] = EvRec{0, 0, {0, 0, 0, 0}};
   const double t1 = nowMs();
 
   // a launch that still reads the previous plan (on any stream) must have finished
   HIP_TRY(hipDeviceSynchronize());
-  if (steps.size() > b->planCap) {
-    if (b->d_plan) HIP_TRY(hipFree(b->d_plan));
-    if (b->d_fast) HIP_TRY(hipFree(b->d_fast));
-    b->d_plan = nullptr;
-    b->d_fast = nullptr;
-    b->planCap = 0;
-    HIP_TRY(hipMalloc(&b->d_plan, steps.size() * sizeof(StepRec)));
-    HIP_TRY(hipMalloc(&b->d_fast, fast.size() * sizeof(FastRec)));
-    b->planCap = steps.size();
-  }
-  HIP_TRY(hipMemcpy(b->d_fast, fast.data(), fast.size() * sizeof(FastRec), hipMemcpyHostToDevice));
   if (ops.size() > b->ringOpCap) {
     if (b->d_ringOps) HIP_TRY(hipFree(b->d_ringOps));
     b->d_ringOps = nullptr;
@@ -134,16 +111,76 @@ static int uploadPlan(sipnet_batch* b, hipStream_t stream) {
     b->evCap = evs.size();
   }
   // synchronous copies: the host vectors die at return
-  HIP_TRY(hipMemcpy(b->d_plan, steps.data(), steps.size() * sizeof(StepRec), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(b->d_ringOps, ops.data(), ops.size() * sizeof(RingOp), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(b->d_events, evs.data(), evs.size() * sizeof(EvRec), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(b->d_siteStatus, b->siteStatus.data(), b->n_sites * sizeof(int32_t),
-                    hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(b->d_siteStatus, b->siteStatus.data(), nS * sizeof(int32_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(b->d_siteStart, starts.data(), nS * sizeof(SiteStart), hipMemcpyHostToDevice));
   (void)stream;  // synchronous copies on the null stream after the device-wide wait above
   b->planDirty = false;
+  b->stepRecsUploaded = false;
+  b->fastRecsUploaded = false;
+  b->exportCacheSite = -1;
   b->planThreads = nThreads;
   b->planBuildMs = t1 - t0;
   b->planUploadMs = nowMs() - t1;
+  return SIPNET_OK;
+}
+
+// flat record buffers are written by the worker threads (first touch in parallel), so they are
+// allocated without value-initialisation
+template <class Rec>
+static int uploadRecords(sipnet_batch* b, Rec** d_ptr, size_t* cap, size_t count, const Rec* host) {
+  HIP_TRY(hipDeviceSynchronize());
+  if (count > *cap) {
+    if (*d_ptr) HIP_TRY(hipFree(*d_ptr));
+    *d_ptr = nullptr;
+    *cap = 0;
+    HIP_TRY(hipMalloc(d_ptr, count * sizeof(Rec)));
+    *cap = count;
+  }
+  HIP_TRY(hipMemcpy(*d_ptr, host, count * sizeof(Rec), hipMemcpyHostToDevice));
+  return SIPNET_OK;
+}
+
+static int ensureStepRecs(sipnet_batch* b) {  // records of the strict-order kernel
+  if (b->stepRecsUploaded) return SIPNET_OK;
+  const double t0 = nowMs();
+  const int nS = b->n_sites, nT = b->n_steps;
+  std::unique_ptr<StepRec[]> steps(new StepRec[(size_t)nS * nT]);
+  forEachSite(nS, planThreadsFor(nS), [&](int s) {
+    StepRec* dst = steps.get() + (size_t)s * nT;
+    memcpy(dst, b->plans[s].steps.data(), (size_t)nT * sizeof(StepRec));
+    if (b->opBase[s] || b->evBase[s])
+      for (int t = 0; t < nT; t++) {
+        dst[t].ringOpFirst += b->opBase[s];
+        dst[t].evFirst += b->evBase[s];
+      }
+  });
+  const double t1 = nowMs();
+  int rc = uploadRecords(b, &b->d_plan, &b->planCap, (size_t)nS * nT, steps.get());
+  if (rc) return rc;
+  b->stepRecsUploaded = true;
+  b->planBuildMs += t1 - t0;
+  b->planUploadMs += nowMs() - t1;
+  return SIPNET_OK;
+}
+
+static int ensureFastRecs(sipnet_batch* b) {  // records of the throughput kernels
+  if (b->fastRecsUploaded) return SIPNET_OK;
+  const double t0 = nowMs();
+  const int nS = b->n_sites, nT = b->n_steps;
+  const size_t count = (size_t)nS * nT + kFastTile;
+  std::unique_ptr<FastRec[]> fast(new FastRec[count]);
+  forEachSite(nS, planThreadsFor(nS), [&](int s) {
+    buildFastRecs(b->plans[s], fast.get() + (size_t)s * nT, b->opBase[s], b->evBase[s]);
+  });
+  memset((void*)(fast.get() + (size_t)nS * nT), 0, kFastTile * sizeof(FastRec));  // tile padding
+  const double t1 = nowMs();
+  int rc = uploadRecords(b, &b->d_fast, &b->fastCap, count, fast.get());
+  if (rc) return rc;
+  b->fastRecsUploaded = true;
+  b->planBuildMs += t1 - t0;
+  b->planUploadMs += nowMs() - t1;
   return SIPNET_OK;
 }
 
@@ -212,6 +249,7 @@ int sipnet_batch_create(const int32_t* flags, int32_t n_sites, int32_t n_members
   if (e == hipSuccess) e = hipMalloc(&b->d_state, nc * SIPNET_NSTATE * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&b->d_ring, nc * SIPNET_RING_SLOTS * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&b->d_siteStatus, n_sites * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMalloc(&b->d_siteStart, n_sites * sizeof(SiteStart));
   if (e == hipSuccess) e = hipMalloc(&b->d_scratchRow, nc * sizeof(double));
   if (e == hipSuccess) e = hipMemset(b->d_prm, 0, nc * SIPNET_NPARAMS * sizeof(double));
   if (e == hipSuccess) e = hipMemset(b->d_state, 0, nc * SIPNET_NSTATE * sizeof(double));
@@ -242,6 +280,7 @@ void sipnet_batch_destroy(sipnet_batch* b) {
   if (b->d_ringOps) (void)hipFree(b->d_ringOps);
   if (b->d_events) (void)hipFree(b->d_events);
   if (b->d_siteStatus) (void)hipFree(b->d_siteStatus);
+  if (b->d_siteStart) (void)hipFree(b->d_siteStart);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
   delete b;
@@ -337,14 +376,13 @@ int sipnet_batch_setup(sipnet_batch* b, void* hip_stream) {
     if (rc) return rc;
   }
   SetupArgs a;
-  a.plan = b->d_plan;
+  a.siteStart = b->d_siteStart;
   a.prm = b->d_prm;
   a.state = b->d_state;
   a.ring = b->d_ring;
   a.ncol = b->ncol;
   a.n_sites = b->n_sites;
   a.n_members = b->n_members;
-  a.n_steps_total = b->n_steps;
   memcpy(a.flags, b->flags, sizeof(a.flags));
   a.siteStatus = b->d_siteStatus;
   launchSetup(a, stream);
@@ -468,6 +506,9 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
       return SIPNET_ERR_BAD_ARGUMENT;
     }
   }
+  rc = kernel != SIPNET_KERNEL_STRICT ? ensureFastRecs(b) : ensureStepRecs(b);
+  if (rc) return rc;
+  a.plan = b->d_plan;
   HIP_TRY(hipEventRecord(b->ev0, stream));
   if (kernel != SIPNET_KERNEL_STRICT) {
     // throughput path: step_fast.hip / step_coop.hip
@@ -821,11 +862,17 @@ int sipnet_batch_export_restart(sipnet_batch* b, int32_t site, int32_t member,
 
   // what the plan owns, after n_steps_done records
   const int n = n_steps_done;
-  PlanCarry fin;
-  const SitePlan head = buildSitePlan(
-      b->flags, n, b->clim[site].data(), b->year[site].data(), b->day[site].data(),
-      (int32_t)b->events[site].size(), b->events[site].data(),
-      b->resume[site].set ? &b->resume[site] : nullptr, &fin);
+  // (cached: a CLI exporting every member of a site asks for the same boundary again and again)
+  if (b->exportCacheSite != site || b->exportCacheN != n) {
+    b->exportHead = buildSitePlan(
+        b->flags, n, b->clim[site].data(), b->year[site].data(), b->day[site].data(),
+        (int32_t)b->events[site].size(), b->events[site].data(),
+        b->resume[site].set ? &b->resume[site] : nullptr, &b->exportFin);
+    b->exportCacheSite = site;
+    b->exportCacheN = n;
+  }
+  const PlanCarry& fin = b->exportFin;
+  const SitePlan& head = b->exportHead;
   const double* lastClim = b->clim[site].data() + (size_t)SIPNET_NCLIM * (n - 1);
 
   memset(out, 0, sizeof(*out));

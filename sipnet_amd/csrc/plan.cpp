@@ -226,9 +226,8 @@ SitePlan buildSitePlan(const int32_t* flags, int32_t n_steps, const double* clim
   return plan;
 }
 
-std::vector<FastRec> buildFastRecs(const SitePlan& plan) {
+void buildFastRecs(const SitePlan& plan, FastRec* out, int32_t opBase, int32_t evBase) {
   const int n = (int)plan.steps.size();
-  std::vector<FastRec> out((size_t)n);
   std::vector<int> slot0(n), slot1(n);
   for (int t = 0; t < n; t++) {
     const StepRec& s = plan.steps[t];
@@ -271,8 +270,8 @@ std::vector<FastRec> buildFastRecs(const SitePlan& plan) {
     f.bitsOps = bits | (s.ringOpCount << 16);
     f.insSlot = s.ringInsSlot;
     f.evCount = s.evCount;
-    f.opFirst = s.ringOpFirst;
-    f.evFirst = s.evFirst;
+    f.opFirst = s.ringOpFirst + opBase;
+    f.evFirst = s.evFirst + evBase;
     f.year = s.year;
     f.day = s.day;
   }
@@ -280,7 +279,6 @@ std::vector<FastRec> buildFastRecs(const SitePlan& plan) {
     const int nx = (t + 1 < n) ? t + 1 : t;
     out[t].slots = slot0[t] | (slot1[t] << 8) | (slot0[nx] << 16) | (slot1[nx] << 24);
   }
-  return out;
 }
 
 }  // namespace sipnet

@@ -147,8 +147,9 @@ struct SitePlan {
 };
 
 // Build the plan of one site.  clim[n_steps][SIPNET_NCLIM] converted climate.
-// Derive the fast records of one site from its plan (op/event indices stay site-local).
-std::vector<FastRec> buildFastRecs(const SitePlan& plan);
+// Derive the fast records of one site from its plan into out[plan.steps.size()] (which need not
+// be initialised); opBase / evBase are added to the site-local op / event indices.
+void buildFastRecs(const SitePlan& plan, FastRec* out, int32_t opBase, int32_t evBase);
 
 SitePlan buildSitePlan(const int32_t* flags, int32_t n_steps, const double* clim,
                        const int32_t* year, const int32_t* day, int32_t n_events,

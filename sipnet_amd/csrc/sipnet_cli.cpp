@@ -13,6 +13,9 @@
 // The model itself runs on the GPU through libsipnet_amd.so; there is no CPU model here.
 //
 // Additive extension (never changes single-run behaviour):
+//   --devices LIST           HIP devices the ensemble shards across (0-7, 0,2,3; default 0): member
+//                            rows are split into contiguous ranges, one host thread + one batch
+//                            per device, every shard writes its own members' files
 //   --ensemble-params FILE   whitespace table, first line = parameter names, one row per
 //                            member overriding those parameters; every member runs in ONE
 //                            batch and writes <prefix>.<m>.out (m = 0..M-1); restart paths
@@ -143,6 +146,7 @@ void usage(const char* prog) {
   printf("      --restart-in <path>     Read a restart checkpoint from path\n");
   printf("      --restart-out <path>    Write a restart checkpoint to path at end of run\n");
   printf("  --ensemble-params <file>    run one member per row of a parameter table in one batch\n");
+  printf("  --devices <list>            HIP devices the ensemble shards across, e.g. 0-7 or 0,2,3 ('0')\n");
   printf("  -h, --help   -v, --version\n");
 }
 
@@ -217,6 +221,27 @@ void printConfig(Context& c, FILE* f) {
   }
 }
 
+// "--devices 0-7", "0,2,3", "0,0" (two shards on one device): HIP device ordinals, one shard each
+std::vector<int> parseDevices(const std::string& arg) {
+  std::vector<int> out;
+  std::istringstream in(arg);
+  for (std::string tok; std::getline(in, tok, ',');) {
+    if (tok.empty()) continue;
+    const size_t dash = tok.find('-', 1);
+    char* end = nullptr;
+    const long a = strtol(tok.c_str(), &end, 10);
+    long z = a;
+    if (dash != std::string::npos) {
+      if (end != tok.c_str() + dash) die(8, "bad --devices list: " + arg + "\n");
+      z = strtol(tok.c_str() + dash + 1, &end, 10);
+    }
+    if (*end || a < 0 || z < a || z - a > 1023) die(8, "bad --devices list: " + arg + "\n");
+    for (long d = a; d <= z; d++) out.push_back((int)d);
+  }
+  if (out.empty()) die(8, "bad --devices list: " + arg + "\n");
+  return out;
+}
+
 void check(int rc, const char* what) {
   if (rc != SIPNET_OK) {
     logError(std::string(what) + ": " + sipnet_last_error() + "\n");
@@ -237,7 +262,7 @@ int main(int argc, char** argv) {
     opts.push_back({kFlagOpts[k][0], no_argument, &tmpFlag, 1});
     opts.push_back({strdup((std::string("no-") + kFlagOpts[k][0]).c_str()), no_argument, &tmpFlag, 0});
   }
-  enum { OPT_RIN = 1001, OPT_ROUT, OPT_DBG, OPT_ENS };
+  enum { OPT_RIN = 1001, OPT_ROUT, OPT_DBG, OPT_ENS, OPT_DEV };
   opts.push_back({"input-file", required_argument, nullptr, 'i'});
   opts.push_back({"file-prefix", required_argument, nullptr, 'f'});
   opts.push_back({"file-name", required_argument, nullptr, 'f'});
@@ -246,10 +271,11 @@ int main(int argc, char** argv) {
   opts.push_back({"restart-out", required_argument, nullptr, OPT_ROUT});
   opts.push_back({"debug-log", required_argument, nullptr, OPT_DBG});
   opts.push_back({"ensemble-params", required_argument, nullptr, OPT_ENS});
+  opts.push_back({"devices", required_argument, nullptr, OPT_DEV});
   opts.push_back({"help", no_argument, nullptr, 'h'});
   opts.push_back({"version", no_argument, nullptr, 'v'});
   opts.push_back({nullptr, 0, nullptr, 0});
-  std::string ensembleFile;
+  std::string ensembleFile, devicesArg = "0";
   int longIndex = 0, ch;
   while ((ch = getopt_long(argc, argv, "he:f:i:v", opts.data(), &longIndex)) != -1) {
     switch (ch) {
@@ -261,11 +287,13 @@ int main(int argc, char** argv) {
       case OPT_ROUT: ctx.setStr("restartOut", optarg, SRC_CLI); break;
       case OPT_DBG: ctx.setStr("debugLogPrefix", optarg, SRC_CLI); break;
       case OPT_ENS: ensembleFile = optarg; break;
+      case OPT_DEV: devicesArg = optarg; break;
       case 'h': usage(argv[0]); return 0;
       case 'v': printf("SIPNET version 2.1.0 (%s)\n", sipnet_version()); return 0;
       default: usage(argv[0]); return 8;  // EXIT_CODE_BAD_CLI_ARGUMENT
     }
   }
+  std::vector<int> devices = parseDevices(devicesArg);  // syntax errors are CLI errors (exit 8)
   g_quiet = ctx.i("quiet") != 0;
   if (ctx.s("filePrefix").empty()) die(3, "filePrefix must be set for SIPNET to run\n");
   readInputFile(ctx);
@@ -370,128 +398,161 @@ int main(int argc, char** argv) {
     }
   }
 
-  // ---- run on the GPU ----
-  sipnet_batch* b = nullptr;
-  check(sipnet_batch_create(flags, 1, M, SIPNET_F64, 0, &b), "creating batch");
-  // the drop-in writes the reference's bytes: strict operation order, whatever the environment says
-  check(sipnet_batch_set_math(b, SIPNET_MATH_STRICT), "math policy");
-  check(sipnet_batch_set_events(b, 0, nEvents, events), "events");
-  check(sipnet_batch_set_climate(b, 0, T, sipnet_clim_data(clim), sipnet_clim_year(clim),
-                                 sipnet_clim_day(clim)), "climate");
-  check(sipnet_batch_set_params(b, 0, 0, M, members.data()), "parameters");
-  if (!resume.empty()) check(sipnet_batch_set_resume(b, 0, &resume[0]), "restart checkpoint");
-  check(sipnet_batch_setup(b, nullptr), "setupModel");
-  if (!resume.empty())
-    check(sipnet_batch_import_restart(b, 0, 0, M, resume.data(), nullptr), "restart checkpoint");
-  std::vector<double> state0((size_t)M * SIPNET_NSTATE);
-  check(sipnet_batch_get_state(b, state0.data(), nullptr), "state");
-  const size_t recElems = (size_t)T * SIPNET_NREC * M;
-  double* dRec = (double*)sipnet_dev_alloc(recElems * sizeof(double));
-  if (!dRec) die(1, std::string(sipnet_last_error()) + "\n");
-  const size_t dbgElems = debugLog.empty() ? 0 : (size_t)T * SIPNET_NDBG * M;
-  double* dDbg = nullptr;
-  std::vector<double> dbg(dbgElems);
-  if (dbgElems) {  // --debug-log: the per-step flux / tracker dump of debug_log.c
-    dDbg = (double*)sipnet_dev_alloc(dbgElems * sizeof(double));
-    if (!dDbg) die(1, std::string(sipnet_last_error()) + "\n");
-    check(sipnet_batch_run_debug(b, 0, T, dRec, dDbg, M, nullptr), "run");
-  } else {
-    check(sipnet_batch_run(b, 0, T, nullptr, nullptr, nullptr, dRec, M, nullptr), "run");
+  // ---- run on the GPU(s) ----
+  // The ensemble axis shards across the devices given with --devices: contiguous member ranges,
+  // one host thread and one sipnet_batch per device, every shard writing its own members'
+  // files (members are independent, so no exchange is needed for file output).
+  {
+    const int have = sipnet_device_count();
+    for (int d : devices)
+      if (d >= have)
+        die(1, "--devices names device " + std::to_string(d) + " but only " + std::to_string(have) +
+                   " HIP device(s) are visible (this engine has no CPU path)\n");
   }
-  std::vector<double> rec(recElems);
-  check(sipnet_dev_to_host(rec.data(), dRec, recElems * sizeof(double), nullptr), "copy back");
-  if (dbgElems) check(sipnet_dev_to_host(dbg.data(), dDbg, dbgElems * sizeof(double), nullptr), "copy back");
-  std::vector<int32_t> status(M);
-  check(sipnet_batch_get_status(b, status.data(), nullptr), "status");
-
-  // ---- outputs ----
-  // The text of an ensemble is the slow part of the job (about 120 MB/s of printf per host
-  // thread against tens of ms of GPU time), so members are formatted by a pool of host threads;
-  // only the checkpoint export, which talks to the GPU through the one batch handle, is
-  // serialised.
-  int worst = 0;
-  for (int m = 0; m < M; m++) {
-    if (status[m] != 0) {
-      logError("member " + std::to_string(m) + ": status " + std::to_string(status[m]) +
-               " (NPP allocation params must be less than one individually and add to less than one)\n");
-      worst = std::max(worst, status[m]);
-    }
-  }
-  std::mutex gpuMutex;
-  auto writeMember = [&](int m, std::vector<double>& one, std::vector<double>& oneDbg) {
-    if (status[m] != 0) return;
-    for (int t = 0; t < T; t++)
-      for (int k = 0; k < SIPNET_NREC; k++)
-        one[(size_t)t * SIPNET_NREC + k] = rec[((size_t)t * SIPNET_NREC + k) * M + m];
-    const std::string tag = ensembleFile.empty() ? "" : "." + std::to_string(m);
-    if (dbgElems) {
-      for (int t = 0; t < T; t++)
-        for (int k = 0; k < SIPNET_NDBG; k++)
-          oneDbg[(size_t)t * SIPNET_NDBG + k] = dbg[((size_t)t * SIPNET_NDBG + k) * M + m];
-      check(sipnet_io_write_debug_logs((debugLog + tag).c_str(), ctx.i("printHeader"), T, sipnet_clim_year(clim),
-                                       sipnet_clim_day(clim), sipnet_clim_data(clim), one.data(),
-                                       oneDbg.data()), "writing debug logs");
-    }
-    if (ctx.i("doMainOutput"))
-      check(sipnet_io_write_out((prefix + tag + ".out").c_str(), ctx.i("printHeader"), T,
-                                sipnet_clim_year(clim), sipnet_clim_day(clim), sipnet_clim_data(clim),
-                                one.data()), "writing output");
-    if (useEvents)
-      check(sipnet_io_write_events_out((ctx.s("eventsPrefix") + tag + ".out").c_str(),
-                                       ctx.i("printHeader"), flags, members.data() + (size_t)m * SIPNET_NPARAMS,
-                                       T, sipnet_clim_year(clim), sipnet_clim_day(clim),
-                                       sipnet_clim_data(clim), nEvents, events, one.data(),
-                                       state0.data() + (size_t)m * SIPNET_NSTATE), "writing events.out");
-    if (!restartOut.empty()) {  // restartWriteCheckpoint, restart.c:932-996
-      const std::string path = restartOut + tag;
-      sipnet_restart ck;
-      const double* prevPools = T >= 2 ? one.data() + (size_t)(T - 2) * SIPNET_NREC + 14
-                                       : state0.data() + (size_t)m * SIPNET_NSTATE;
-      {
-        std::lock_guard<std::mutex> lock(gpuMutex);
-        check(sipnet_batch_export_restart(b, 0, m, T, one.data() + (size_t)(T - 1) * SIPNET_NREC,
-                                          prevPools, &ck, nullptr), "restart checkpoint");
-      }
-      int32_t warn = 0;
-      check(sipnet_restart_check_boundary_for_write(&ck, &warn), "restart checkpoint");
-      if (warn & SIPNET_RESTART_WARN_BOUNDARY_NOT_MIDNIGHT)
-        logWarning("Restart checkpoint " + path + " ends more than one timestep before midnight; "
-                   "there will be a time gap if this file is used to resume.\n");
-      check(sipnet_io_write_restart(path.c_str(), &ck), "writing restart checkpoint");
-    }
-    if (ctx.i("doSingleOutputs")) {  // sipnet.c:1993-1998, outputItems.c:126-150
-      const struct { const char* name; int col; } items[] = {{"NEE", 0}, {"NEE_cum", 3}, {"GPP", 1}, {"GPP_cum", 35}};
-      for (const auto& it : items) {
-        FILE* f = fopen((prefix + tag + "." + it.name).c_str(), "w");
-        if (!f) die(6, std::string("Error opening single output file for ") + it.name + "\n");
-        for (int t = 0; t < T; t++) fprintf(f, "%f ", one[(size_t)t * SIPNET_NREC + it.col]);
-        fprintf(f, "\n");
-        fclose(f);
-      }
-    }
-  };
+  if ((int)devices.size() > M) devices.resize(M);
+  const int nShards = (int)devices.size();
+  if (nShards > 1)
+    logInfo("ensemble sharded over " + std::to_string(nShards) + " device(s)\n");
+  std::atomic<int> worst{0};
+  std::mutex logMutex;
+  int hostThreads = 1;
   {
     cpu_set_t cpus;
-    int nThreads = 1;
-    if (sched_getaffinity(0, sizeof cpus, &cpus) == 0) nThreads = CPU_COUNT(&cpus);
-    nThreads = std::max(1, std::min({nThreads, M, 64}));
-    std::atomic<int> next{0};
-    auto worker = [&]() {
-      std::vector<double> one((size_t)T * SIPNET_NREC), oneDbg(dbgElems ? (size_t)T * SIPNET_NDBG : 0);
-      for (int m = next.fetch_add(1); m < M; m = next.fetch_add(1)) writeMember(m, one, oneDbg);
-    };
-    if (nThreads == 1) {
-      worker();
-    } else {
-      std::vector<std::thread> pool;
-      for (int i = 0; i < nThreads; i++) pool.emplace_back(worker);
-      for (auto& th : pool) th.join();
-    }
+    if (sched_getaffinity(0, sizeof cpus, &cpus) == 0) hostThreads = CPU_COUNT(&cpus);
   }
-  sipnet_dev_free(dRec);
-  if (dDbg) sipnet_dev_free(dDbg);
-  sipnet_batch_destroy(b);
+  auto runShard = [&](int shard) {
+    const int m0 = (int)((int64_t)M * shard / nShards), m1 = (int)((int64_t)M * (shard + 1) / nShards);
+    const int Ms = m1 - m0;
+    const double* shardParams = members.data() + (size_t)m0 * SIPNET_NPARAMS;
+    sipnet_batch* b = nullptr;
+    check(sipnet_batch_create(flags, 1, Ms, SIPNET_F64, devices[shard], &b), "creating batch");
+    // the drop-in writes the reference's bytes: strict operation order, whatever the environment says
+    check(sipnet_batch_set_math(b, SIPNET_MATH_STRICT), "math policy");
+    check(sipnet_batch_set_events(b, 0, nEvents, events), "events");
+    check(sipnet_batch_set_climate(b, 0, T, sipnet_clim_data(clim), sipnet_clim_year(clim),
+                                   sipnet_clim_day(clim)), "climate");
+    check(sipnet_batch_set_params(b, 0, 0, Ms, shardParams), "parameters");
+    if (!resume.empty()) check(sipnet_batch_set_resume(b, 0, &resume[m0]), "restart checkpoint");
+    check(sipnet_batch_setup(b, nullptr), "setupModel");
+    if (!resume.empty())
+      check(sipnet_batch_import_restart(b, 0, 0, Ms, resume.data() + m0, nullptr), "restart checkpoint");
+    std::vector<double> state0((size_t)Ms * SIPNET_NSTATE);
+    check(sipnet_batch_get_state(b, state0.data(), nullptr), "state");
+    const size_t recElems = (size_t)T * SIPNET_NREC * Ms;
+    double* dRec = (double*)sipnet_dev_alloc(recElems * sizeof(double));
+    if (!dRec) die(1, std::string(sipnet_last_error()) + "\n");
+    const size_t dbgElems = debugLog.empty() ? 0 : (size_t)T * SIPNET_NDBG * Ms;
+    double* dDbg = nullptr;
+    std::vector<double> dbg(dbgElems);
+    if (dbgElems) {  // --debug-log: the per-step flux / tracker dump of debug_log.c
+      dDbg = (double*)sipnet_dev_alloc(dbgElems * sizeof(double));
+      if (!dDbg) die(1, std::string(sipnet_last_error()) + "\n");
+      check(sipnet_batch_run_debug(b, 0, T, dRec, dDbg, Ms, nullptr), "run");
+    } else {
+      check(sipnet_batch_run(b, 0, T, nullptr, nullptr, nullptr, dRec, Ms, nullptr), "run");
+    }
+    std::vector<double> rec(recElems);
+    check(sipnet_dev_to_host(rec.data(), dRec, recElems * sizeof(double), nullptr), "copy back");
+    if (dbgElems) check(sipnet_dev_to_host(dbg.data(), dDbg, dbgElems * sizeof(double), nullptr), "copy back");
+    std::vector<int32_t> status(Ms);
+    check(sipnet_batch_get_status(b, status.data(), nullptr), "status");
+
+    // ---- outputs ----
+    // The text of an ensemble is the slow part of the job (about 120 MB/s of printf per host
+    // thread against tens of ms of GPU time), so members are formatted by a pool of host threads;
+    // only the checkpoint export, which talks to the GPU through the one batch handle, is
+    // serialised.
+    for (int m = 0; m < Ms; m++) {
+      if (status[m] != 0) {
+        std::lock_guard<std::mutex> lock(logMutex);
+        logError("member " + std::to_string(m0 + m) + ": status " + std::to_string(status[m]) +
+                 " (NPP allocation params must be less than one individually and add to less than one)\n");
+        int w = worst.load();
+        while (status[m] > w && !worst.compare_exchange_weak(w, status[m])) {}
+      }
+    }
+    std::mutex gpuMutex;
+    auto writeMember = [&](int m, std::vector<double>& one, std::vector<double>& oneDbg) {
+      if (status[m] != 0) return;
+      for (int t = 0; t < T; t++)
+        for (int k = 0; k < SIPNET_NREC; k++)
+          one[(size_t)t * SIPNET_NREC + k] = rec[((size_t)t * SIPNET_NREC + k) * Ms + m];
+      const std::string tag = ensembleFile.empty() ? "" : "." + std::to_string(m0 + m);
+      if (dbgElems) {
+        for (int t = 0; t < T; t++)
+          for (int k = 0; k < SIPNET_NDBG; k++)
+            oneDbg[(size_t)t * SIPNET_NDBG + k] = dbg[((size_t)t * SIPNET_NDBG + k) * Ms + m];
+        check(sipnet_io_write_debug_logs((debugLog + tag).c_str(), ctx.i("printHeader"), T, sipnet_clim_year(clim),
+                                         sipnet_clim_day(clim), sipnet_clim_data(clim), one.data(),
+                                         oneDbg.data()), "writing debug logs");
+      }
+      if (ctx.i("doMainOutput"))
+        check(sipnet_io_write_out((prefix + tag + ".out").c_str(), ctx.i("printHeader"), T,
+                                  sipnet_clim_year(clim), sipnet_clim_day(clim), sipnet_clim_data(clim),
+                                  one.data()), "writing output");
+      if (useEvents)
+        check(sipnet_io_write_events_out((ctx.s("eventsPrefix") + tag + ".out").c_str(),
+                                         ctx.i("printHeader"), flags, shardParams + (size_t)m * SIPNET_NPARAMS,
+                                         T, sipnet_clim_year(clim), sipnet_clim_day(clim),
+                                         sipnet_clim_data(clim), nEvents, events, one.data(),
+                                         state0.data() + (size_t)m * SIPNET_NSTATE), "writing events.out");
+      if (!restartOut.empty()) {  // restartWriteCheckpoint, restart.c:932-996
+        const std::string path = restartOut + tag;
+        sipnet_restart ck;
+        const double* prevPools = T >= 2 ? one.data() + (size_t)(T - 2) * SIPNET_NREC + 14
+                                         : state0.data() + (size_t)m * SIPNET_NSTATE;
+        {
+          std::lock_guard<std::mutex> lock(gpuMutex);
+          check(sipnet_batch_export_restart(b, 0, m, T, one.data() + (size_t)(T - 1) * SIPNET_NREC,
+                                            prevPools, &ck, nullptr), "restart checkpoint");
+        }
+        int32_t warn = 0;
+        check(sipnet_restart_check_boundary_for_write(&ck, &warn), "restart checkpoint");
+        if (warn & SIPNET_RESTART_WARN_BOUNDARY_NOT_MIDNIGHT) {
+          std::lock_guard<std::mutex> lock(logMutex);
+          logWarning("Restart checkpoint " + path + " ends more than one timestep before midnight; "
+                     "there will be a time gap if this file is used to resume.\n");
+        }
+        check(sipnet_io_write_restart(path.c_str(), &ck), "writing restart checkpoint");
+      }
+      if (ctx.i("doSingleOutputs")) {  // sipnet.c:1993-1998, outputItems.c:126-150
+        const struct { const char* name; int col; } items[] = {{"NEE", 0}, {"NEE_cum", 3}, {"GPP", 1}, {"GPP_cum", 35}};
+        for (const auto& it : items) {
+          FILE* f = fopen((prefix + tag + "." + it.name).c_str(), "w");
+          if (!f) die(6, std::string("Error opening single output file for ") + it.name + "\n");
+          for (int t = 0; t < T; t++) fprintf(f, "%f ", one[(size_t)t * SIPNET_NREC + it.col]);
+          fprintf(f, "\n");
+          fclose(f);
+        }
+      }
+    };
+    {
+      const int nThreads = std::max(1, std::min({hostThreads / nShards, Ms, 64}));
+      std::atomic<int> next{0};
+      auto worker = [&]() {
+        std::vector<double> one((size_t)T * SIPNET_NREC), oneDbg(dbgElems ? (size_t)T * SIPNET_NDBG : 0);
+        for (int m = next.fetch_add(1); m < Ms; m = next.fetch_add(1)) writeMember(m, one, oneDbg);
+      };
+      if (nThreads == 1) {
+        worker();
+      } else {
+        std::vector<std::thread> pool;
+        for (int i = 0; i < nThreads; i++) pool.emplace_back(worker);
+        for (auto& th : pool) th.join();
+      }
+    }
+    sipnet_dev_free(dRec);
+    if (dDbg) sipnet_dev_free(dDbg);
+    sipnet_batch_destroy(b);
+  };
+  if (nShards == 1) {
+    runShard(0);
+  } else {
+    std::vector<std::thread> shards;
+    for (int k = 0; k < nShards; k++) shards.emplace_back(runShard, k);
+    for (auto& th : shards) th.join();
+  }
   sipnet_clim_free(clim);
   sipnet_io_free(events);
-  return worst;
+  return worst.load();
 }

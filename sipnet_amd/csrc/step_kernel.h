@@ -66,13 +66,17 @@ struct KernelArgs {
   int32_t flags[SIPNET_NFLAGS];
 };
 
+// what setupModel() reads of a site's first climate record (phenology state, sipnet.c:1501-1527)
+struct SiteStart {
+  double cumGdd, tsoil, dayTime;
+};
 struct SetupArgs {
-  const StepRec* plan;    // first record of each site is at plan[site*n_steps_total]
+  const SiteStart* siteStart;  // [n_sites]
   const double* prm;      // [SIPNET_NPARAMS][ncol] converted parameters (launchConvertParams)
   double* state;          // [SIPNET_NSTATE][ncol]
   double* ring;           // slot 0 row is zeroed
   int64_t ncol;
-  int32_t n_sites, n_members, n_steps_total;
+  int32_t n_sites, n_members;
   int32_t flags[SIPNET_NFLAGS];
   const int32_t* siteStatus;  // [n_sites] plan status (site-fatal conditions)
 };

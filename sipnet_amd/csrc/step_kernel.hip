@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void setupKernel(SetupArgs a) {
   const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= a.ncol) return;
   const int site = (int)(col / a.n_members);
-  const StepRec& s0 = a.plan[(int64_t)site * a.n_steps_total];
+  const SiteStart s0 = a.siteStart[site];
   const double* __restrict__ pp = a.prm + col;
 #define P(name) pp[(int64_t)SP_##name * a.ncol]
 

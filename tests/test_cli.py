@@ -103,3 +103,42 @@ def test_cli_ensemble_extension(tmp_path):
     assert open(tmp_path / "sipnet.0.out", "rb").read() == gold_out
     a, b = open(tmp_path / "sipnet.1.out").read(), open(tmp_path / "sipnet.2.out").read()
     assert a != b and len(a.splitlines()) == 5237
+
+
+def test_cli_devices_list_is_validated(tmp_path):
+    """--devices: malformed lists are a CLI error (exit 8) before anything else happens"""
+    stage("niwot", tmp_path)
+    for bad in ("x", "3-1", "1-", "-1", ",", "0-x"):
+        r = run_cli(tmp_path, "-i", "sipnet.in", "--devices", bad)
+        assert r.returncode == 8, (bad, r.returncode, r.stdout)
+
+
+@pytest.mark.gpu
+def test_cli_ensemble_sharded_over_devices_equals_one_batch(tmp_path):
+    """--devices: the ensemble axis shards across HIP devices behind the C boundary (one host thread
+    + one sipnet_batch per device, every shard writes its members' files).  `--devices 0,0,0` on this
+    one-GPU box = three shards of a 7-member ensemble: every member's .out / events.out /
+    restart checkpoint equals the single-batch run's byte for byte."""
+    import filecmp
+    rows = ["aMax psnTOpt soilWHC"] + ["%.3f %.2f %.2f" % (7.5 + 0.3 * i, 22.0 + 0.5 * i, 10.0 + i) for i in range(7)]
+    outs = {}
+    for tag, dev in (("one", "0"), ("three", "0,0,0")):
+        d = tmp_path / tag
+        d.mkdir()
+        stage("russell_1", d)
+        open(d / "members.txt", "w").write("\n".join(rows) + "\n")
+        r = run_cli(d, "-i", "sipnet.in", "--ensemble-params", "members.txt", "--devices", dev,
+                    "--restart-out", "ck")
+        assert r.returncode == 0, r.stdout + r.stderr
+        if tag == "three":
+            assert "sharded over 3 device(s)" in r.stdout
+        outs[tag] = d
+    for m in range(7):
+        for name in (f"sipnet.{m}.out", f"events.{m}.out"):
+            assert filecmp.cmp(outs["one"] / name, outs["three"] / name, shallow=False), name
+        a = [l for l in open(outs["one"] / f"ck.{m}") if "checkpoint_utc_epoch" not in l]
+        b = [l for l in open(outs["three"] / f"ck.{m}") if "checkpoint_utc_epoch" not in l]
+        assert a == b
+    # a device that does not exist is refused up front
+    r = run_cli(outs["one"], "-i", "sipnet.in", "--devices", "0,99")
+    assert r.returncode == 1 and "only" in r.stdout
