@@ -206,8 +206,7 @@ int sipnet_batch_set_params(sipnet_batch *b, int32_t site, int32_t first_member,
  *                       one-wavefront kernel, all flags, full records
  *   SIPNET_MATH_FAST    the throughput kernels: site-only sub-expressions from the host plan,
  *                       reciprocals instead of divisions, polynomial exp2; <= 2.5e-16 on NEE
- *                       against the reference on the benchmark ensemble; launches that ask for
- *                       full records still use the strict-order kernel's fast-math variant
+ *                       against the reference on the benchmark ensemble
  * A new fp64 batch is STRICT (no environment variable changes that).  May be changed between
  * runs. */
 enum sipnet_math { SIPNET_MATH_STRICT = 0, SIPNET_MATH_FAST = 1 };
@@ -231,7 +230,11 @@ enum sipnet_kernel {
 };
 enum sipnet_kernel_option {
   SIPNET_KOPT_ONE_WAVE_PER_SIMD = 1, /* one-wave kernel: never the 256-VGPR (two waves/SIMD) build */
-  SIPNET_KOPT_RUNTIME_FLAGS = 2      /* one-wave kernel: always the run-time-flag instantiation */
+  SIPNET_KOPT_RUNTIME_FLAGS = 2,     /* one-wave kernel: always the run-time-flag instantiation */
+  SIPNET_KOPT_FULL_STATE = 4         /* throughput kernels: advance EVERY accumulator of the restart
+                                        schema (trackers.tot*, trackers.yearly*); without it only
+                                        totNee / totGpp advance on the throughput path.  Implied by a
+                                        full record (d_rec) and by enabled diagnostics */
 };
 int sipnet_batch_set_kernel(sipnet_batch *b, int32_t kernel, int32_t options);
 
@@ -251,10 +254,22 @@ int sipnet_batch_setup(sipnet_batch *b, void *hip_stream);
  * SIPNET_F32_MIXED; ld >= n_sites*n_members.  Plane entries of members whose status is
  * non-zero (skipped members) are undefined.
  * d_rec: DEVICE pointer (or NULL) to [n_steps][SIPNET_NREC][ld] doubles
- * (full record, for `.out` text and checkpoints). */
+ * (full record, for `.out` text and checkpoints); written by whichever kernel the policy picks
+ * (SIPNET_MATH_FAST: the throughput kernels' Full instantiations). */
 int sipnet_batch_run(sipnet_batch *b, int32_t step0, int32_t n_steps,
                      void *d_nee, void *d_gpp, void *d_et, double *d_rec,
                      int64_t ld, void *hip_stream);
+
+/* Per-member counts of the reference's per-step self-checks (diagnostics only, no effect on
+ * state): n_clamp_warn = ensureNonNegative() warnings, a pool clamped to 0 from |v| > 1e-8
+ * (sipnet.c:1346-1356); n_balance_warn = checkBalance() warnings, |carbon or nitrogen mass
+ * balance residual of a step| >= 1e-8 (balance.c:122-169); max_abs_dC / max_abs_dN = the largest
+ * residual seen.  Enabled per batch (a [4][ncol] device block; every step kernel then runs its
+ * counting variant), zeroed by sipnet_batch_setup, accumulated over launches, read back into HOST
+ * arrays of ncol entries (any may be NULL). */
+int sipnet_batch_enable_diagnostics(sipnet_batch *b, int32_t on);
+int sipnet_batch_get_diagnostics(sipnet_batch *b, int64_t *n_clamp_warn, int64_t *n_balance_warn,
+                                 double *max_abs_dC, double *max_abs_dN, void *hip_stream);
 
 /* The same advance with the reference's `--debug-log` content (outputDebugState,
  * debug_log.c:285-312, called after every updateState, sipnet.c:1974): besides the full

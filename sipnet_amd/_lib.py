@@ -28,7 +28,7 @@ ERR_BAD_ARGUMENT = 101
 F64, F32_MIXED = 0, 1
 # enum sipnet_kernel / sipnet_kernel_option
 KERNEL_AUTO, KERNEL_ONE_WAVE, KERNEL_COOP_LDS, KERNEL_COOP_HBM, KERNEL_STRICT = range(5)
-KOPT_ONE_WAVE_PER_SIMD, KOPT_RUNTIME_FLAGS = 1, 2
+KOPT_ONE_WAVE_PER_SIMD, KOPT_RUNTIME_FLAGS, KOPT_FULL_STATE = 1, 2, 4
 
 
 class Event(C.Structure):
@@ -102,6 +102,8 @@ SIGNATURES = {
     "sipnet_batch_set_kernel": (C.c_int, [_P, C.c_int32, C.c_int32]),
     "sipnet_batch_last_launch": (C.c_int, [_P, _P]),
     "sipnet_batch_last_kernel_name": (C.c_char_p, [_P]),
+    "sipnet_batch_enable_diagnostics": (C.c_int, [_P, C.c_int32]),
+    "sipnet_batch_get_diagnostics": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "sipnet_batch_run": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int64, _P]),
     "sipnet_batch_run_debug": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, C.c_int64, _P]),
     "sipnet_batch_reduce_plane": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int64, _P, _P]),

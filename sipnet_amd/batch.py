@@ -50,6 +50,19 @@ class Batch:
         STRICT) or go back to the shape-based choice (KERNEL_AUTO)."""
         check(self.L.sipnet_batch_set_kernel(self.h, int(kernel), int(options)), "set_kernel")
 
+    def enable_diagnostics(self, on=True):
+        """count the reference's per-step clamp / mass-balance warnings per member"""
+        check(self.L.sipnet_batch_enable_diagnostics(self.h, int(on)), "enable_diagnostics")
+
+    def get_diagnostics(self):
+        """-> dict(n_clamp_warn[ncol], n_balance_warn[ncol], max_abs_dC[ncol], max_abs_dN[ncol])"""
+        c = np.zeros(self.ncol, dtype=np.int64)
+        w = np.zeros(self.ncol, dtype=np.int64)
+        dc, dn = np.zeros(self.ncol), np.zeros(self.ncol)
+        check(self.L.sipnet_batch_get_diagnostics(self.h, c.ctypes.data, w.ctypes.data, dc.ctypes.data,
+                                                  dn.ctypes.data, self._stream()), "get_diagnostics")
+        return dict(n_clamp_warn=c, n_balance_warn=w, max_abs_dC=dc, max_abs_dN=dn)
+
     def last_launch(self):
         """What the last run() launched: dict(kernel, grid, block_threads, waves_per_simd,
         lds_bytes, num_cus, plan_threads, plan_build_ms, plan_upload_ms)."""

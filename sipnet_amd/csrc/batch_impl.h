@@ -64,6 +64,7 @@ struct sipnet_batch {
   RingOp* d_ringOps = nullptr;
   EvRec* d_events = nullptr;
   int32_t* d_siteStatus = nullptr;
+  double* d_diag = nullptr;          // [4][ncol] per-member diagnostics, allocated on request
   SiteStart* d_siteStart = nullptr;  // [n_sites] what setupModel() reads of a site's first record
   size_t planCap = 0, fastCap = 0, ringOpCap = 0, evCap = 0;
   std::vector<int32_t> opBase, evBase;  // per site: offset of its ring ops / events in the flat arrays

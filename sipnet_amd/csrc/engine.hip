@@ -281,6 +281,7 @@ void sipnet_batch_destroy(sipnet_batch* b) {
   if (b->d_events) (void)hipFree(b->d_events);
   if (b->d_siteStatus) (void)hipFree(b->d_siteStatus);
   if (b->d_siteStart) (void)hipFree(b->d_siteStart);
+  if (b->d_diag) (void)hipFree(b->d_diag);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
   delete b;
@@ -387,6 +388,7 @@ int sipnet_batch_setup(sipnet_batch* b, void* hip_stream) {
   a.siteStatus = b->d_siteStatus;
   launchSetup(a, stream);
   HIP_TRY(hipGetLastError());
+  if (b->d_diag) HIP_TRY(hipMemsetAsync(b->d_diag, 0, (size_t)4 * b->ncol * sizeof(double), stream));
   b->stepsDone = 0;
   // a site-fatal plan condition is reported like the reference's exit code
   for (int s = 0; s < b->n_sites; s++) {
@@ -416,12 +418,48 @@ int sipnet_batch_set_math(sipnet_batch* b, int32_t policy) {
 
 int sipnet_batch_set_kernel(sipnet_batch* b, int32_t kernel, int32_t options) {
   if (!b || kernel < SIPNET_KERNEL_AUTO || kernel > SIPNET_KERNEL_STRICT ||
-      (options & ~(SIPNET_KOPT_ONE_WAVE_PER_SIMD | SIPNET_KOPT_RUNTIME_FLAGS))) {
+      (options & ~(SIPNET_KOPT_ONE_WAVE_PER_SIMD | SIPNET_KOPT_RUNTIME_FLAGS | SIPNET_KOPT_FULL_STATE))) {
     setError("sipnet_batch_set_kernel: bad argument");
     return SIPNET_ERR_BAD_ARGUMENT;
   }
   b->kernelPolicy = kernel;
   b->kernelOptions = options;
+  return SIPNET_OK;
+}
+
+int sipnet_batch_enable_diagnostics(sipnet_batch* b, int32_t on) {
+  if (!b) return SIPNET_ERR_BAD_ARGUMENT;
+  int rc = useDevice(b);
+  if (rc) return rc;
+  if (on && !b->d_diag) {
+    HIP_TRY(hipMalloc(&b->d_diag, (size_t)4 * b->ncol * sizeof(double)));
+    HIP_TRY(hipMemset(b->d_diag, 0, (size_t)4 * b->ncol * sizeof(double)));
+  } else if (!on && b->d_diag) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipFree(b->d_diag));
+    b->d_diag = nullptr;
+  }
+  return SIPNET_OK;
+}
+
+int sipnet_batch_get_diagnostics(sipnet_batch* b, int64_t* n_clamp_warn, int64_t* n_balance_warn,
+                                 double* max_abs_dC, double* max_abs_dN, void* hip_stream) {
+  if (!b) return SIPNET_ERR_BAD_ARGUMENT;
+  if (!b->d_diag) {
+    setError("sipnet_batch_get_diagnostics: call sipnet_batch_enable_diagnostics first");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  int rc = useDevice(b);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize((hipStream_t)hip_stream));
+  std::vector<double> tmp((size_t)4 * b->ncol);
+  HIP_TRY(hipMemcpy(tmp.data(), b->d_diag, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+  for (int64_t c = 0; c < b->ncol; c++) {
+    if (n_clamp_warn) n_clamp_warn[c] = (int64_t)tmp[c];
+    if (n_balance_warn) n_balance_warn[c] = (int64_t)tmp[(size_t)b->ncol + c];
+    if (max_abs_dC) max_abs_dC[c] = tmp[(size_t)2 * b->ncol + c];
+    if (max_abs_dN) max_abs_dN[c] = tmp[(size_t)3 * b->ncol + c];
+  }
   return SIPNET_OK;
 }
 
@@ -469,6 +507,7 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
   a.et = d_et;
   a.rec = d_rec;
   a.dbg = d_dbg;
+  a.diag = b->d_diag;
   a.ncol = b->ncol;
   a.ld = ld;
   a.n_sites = b->n_sites;
@@ -487,8 +526,9 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
     // at most one chunk per CU (c10k 12.4 vs 18.2 ms), in HBM up to two per CU (c4 16.0 vs
     // 19.3 ms).  Bigger batches fill the SIMDs with the one-wave kernel (c3: 16.9 vs 27.6 ms).
     // Optional model flags (litter pool, nitrogen cycle, ...) always take the one-wave kernel.
-    // Full records and strict arithmetic: the strict-order kernel.
-    if (!b->fastMath || d_rec) kernel = SIPNET_KERNEL_STRICT;
+    // Strict arithmetic and the debug plane: the strict-order kernel.  Full records, diagnostics
+    // and SIPNET_KOPT_FULL_STATE: the "Full" instantiations of the same throughput kernels.
+    if (!b->fastMath || d_dbg) kernel = SIPNET_KERNEL_STRICT;
     else if (defaultFlags && blocks <= (int64_t)b->numCUs) kernel = SIPNET_KERNEL_COOP_LDS;
     else if (defaultFlags && blocks <= 2 * (int64_t)b->numCUs) kernel = SIPNET_KERNEL_COOP_HBM;
     else kernel = SIPNET_KERNEL_ONE_WAVE;
@@ -497,8 +537,8 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
       setError("sipnet_batch_run: the throughput kernels need SIPNET_MATH_FAST (sipnet_batch_set_math)");
       return SIPNET_ERR_BAD_ARGUMENT;
     }
-    if (d_rec) {
-      setError("sipnet_batch_run: full records are written by the strict-order kernel only");
+    if (d_dbg) {
+      setError("sipnet_batch_run_debug: the debug plane is written by the strict-order kernel only");
       return SIPNET_ERR_BAD_ARGUMENT;
     }
     if (kernel != SIPNET_KERNEL_ONE_WAVE && !defaultFlags) {
@@ -530,6 +570,9 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
     f.step0 = step0;
     f.n_steps = n_steps;
     f.plainExp = b->genericExponents ? 0 : 1;
+    f.rec = d_rec;
+    f.diag = b->d_diag;
+    f.full = (d_rec || b->d_diag || (b->kernelOptions & SIPNET_KOPT_FULL_STATE)) ? 1 : 0;
     f.scratchRow = b->d_scratchRow;
     memcpy(f.flags, b->flags, sizeof(f.flags));
     f.numCUs = b->numCUs;

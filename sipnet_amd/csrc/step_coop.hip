@@ -167,7 +167,11 @@ __device__ unsigned long long g_coopWaits[16];
 
 // RingLds: the running-mean ring of the 64 members stays in LDS for the whole launch (one
 // workgroup per CU); otherwise it stays in HBM and up to four workgroups share a CU.
-template <class R, bool PlainExp, bool RingLds>
+// Full: see stepFastKernel -- every accumulator of the restart schema, the optional 44-column record
+// (the carbon wave writes the carbon / tracker columns, the water wave columns 2, 12, 13, 17, 19)
+// and the optional per-member diagnostics (clamp and carbon-balance warnings; default flags have no
+// nitrogen balance).  Same flux arithmetic and hand-overs as the lean variant.
+template <class R, bool PlainExp, bool RingLds, bool Full>
 __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
   // per-wave private record tiles (each wave stages and awaits its own DMA) + mailboxes
   __shared__ alignas(16) unsigned char ldsTiles[3][2 * kTileBytes];
@@ -323,6 +327,10 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
     double soilWater = ST(soilWater), snow = ST(snow);
     R* __restrict__ oEt = (R*)(a.et ? a.et : a.scratchRow) + col;
     const int64_t ldEt = a.et ? a.ld : 0;
+    const bool wantDiagW = Full && a.diag != nullptr;
+    const double K_whc2 = Full ? 2.0 * PRM(soilWHC) : 0.0;
+    double* __restrict__ recw = Full && a.rec ? a.rec + col : nullptr;
+    int clampWarnW = 0;
     WAIT_DECL()
 
     for (int tileStart = curTile * kFastTile; tileStart < tEnd; tileStart += kFastTile, curTile++) {
@@ -348,6 +356,7 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
         const int bits = uni(j0.x);
         const int nEv = uni(j0.w);
         const R eWater = (R)soilWater, eSnow = (R)snow;
+        const double oldSoilWater = soilWater;  // before this step's irrigation, sipnet.c:1470
         const bool frozen = tsoil < K_frozThr;
 
         // ---- for wave C: the climate / soil-water / parameter part of its respiration terms
@@ -448,6 +457,10 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
         soilWater += (double)((rain + snowMelt - immedEvap - fastFlow - evaporation -
                                transpiration - drainage) * len);
         snow += (double)((snowFall - snowMelt - sublimation) * len);
+        if (wantDiagW) {  // clamp warnings of the two water pools, sipnet.c:1346-1356
+          if (soilWater < 0.0 && fabs(soilWater) > kEps) clampWarnW++;
+          if (snow < kTiny && fabs(snow) > kEps) clampWarnW++;
+        }
         soilWater = rmax0(soilWater);
         snow = snow < kTiny ? 0.0 : snow;
 
@@ -459,14 +472,25 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
           WAIT_END(1)
         }
 
-        *oEt = (transpiration + immedEvap + evaporation + sublimation + evEvap) * len;
+        const R tEt = (transpiration + immedEvap + evaporation + sublimation + evEvap) * len;
+        *oEt = tEt;
         oEt += ldEt;
+        if (Full && recw) {
+          const int64_t L = a.ld;
+          recw[2 * L] = (double)tEt;
+          recw[12 * L] = (oldSoilWater + soilWater) / K_whc2;
+          recw[13 * L] = (double)transpiration;
+          recw[17 * L] = soilWater;
+          recw[19 * L] = snow;
+          recw += (int64_t)SIPNET_NREC * L;
+        }
       }
     }
     WAIT_STORE(4)
     if (act) {
       ST(soilWater) = soilWater;
       ST(snow) = snow;
+      if (wantDiagW && clampWarnW) atomicAdd(a.diag + col, (double)clampWarnW);
     }
     return;
   }
@@ -488,6 +512,21 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
   int phenBits = (int)ST(phenBits);
   int ringValidFrom = (int)ST(ringValidFrom);
   int diedAt = (int)ST(diedAt);
+  // Full: the other accumulators of updateTrackers(), the record's constant columns (pools the
+  // default flag set never touches) and the diagnostics counters
+  double totRtot = Full ? ST(totRtot) : 0.0, totRa = Full ? ST(totRa) : 0.0;
+  double totRh = Full ? ST(totRh) : 0.0, totNpp = Full ? ST(totNpp) : 0.0;
+  double yGpp = Full ? ST(yearlyGpp) : 0.0, yRtot = Full ? ST(yearlyRtot) : 0.0;
+  double yRa = Full ? ST(yearlyRa) : 0.0, yRh = Full ? ST(yearlyRh) : 0.0;
+  double yNpp = Full ? ST(yearlyNpp) : 0.0, yNee = Full ? ST(yearlyNee) : 0.0;
+  double yLitter = Full ? ST(yearlyLitter) : 0.0;
+  const double cLitterC = Full ? ST(litterC) : 0.0, cMinN = Full ? ST(minN) : 0.0;
+  const double cSoilOrgN = Full ? ST(soilOrgN) : 0.0, cLitterN = Full ? ST(litterN) : 0.0;
+  const double cStorN = Full ? ST(plantStorageN) : 0.0;
+  const bool wantDiag = Full && a.diag != nullptr;
+  int clampWarn = 0, balanceWarn = 0;
+  double maxDC = 0.0;
+  double* __restrict__ recp = Full && a.rec ? a.rec + col : nullptr;
 
   double* __restrict__ ringp = a.ring + col;
   R* __restrict__ oNee = (R*)(a.nee ? a.nee : a.scratchRow) + col;
@@ -593,6 +632,11 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
     const R eWood = (R)plantWoodC, eLeaf = (R)plantLeafC, eSoilC = (R)soilC;
     const R eCoarse = (R)coarseRootC, eFine = (R)fineRootC;
     const R totalWoodC = (R)(plantWoodC + delta);
+    // getMassTotals() before the pool updates, balance.c:13-36 (carbon; default flags)
+    double preC = 0.0;
+    if (wantDiag) preC = (plantWoodC + delta) + plantLeafC + fineRootC + coarseRootC + soilC;
+    R recLeafOffComputed = 0, recEvLeafOn = 0, recEvLeafOnFromWood = 0, recEvLeafOffLitter = 0;
+    R evInC = 0, evOutC = 0;
 
     auto leafOnLimit = [&](R flux) -> R {  // limitations.c:13-64 (no N cycle here)
       const R cDemand = flux * len;
@@ -650,7 +694,9 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
         phenBits |= 1;
       }
       if (doOff) {
-        leafLitter += (eLeaf * PRM_RARE(fracLeafFall)) * invLen;
+        const R off = (eLeaf * PRM_RARE(fracLeafFall)) * invLen;
+        leafLitter += off;
+        if (Full) recLeafOffComputed = off;
         phenBits |= 2;
       }
       allOn = __builtin_amdgcn_ballot_w64((phenBits & 1) == 0) == 0;
@@ -667,8 +713,10 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
           evWoodC += p1 * invLen;
           evFineRootC += p2 * invLen;
           evCoarseRootC += p3 * invLen;
+          if (Full) evInC += (p0 + p1 + p2 + p3) * invLen;  // events.c:530-541
         } else if (type == SIPNET_EV_HARVEST) {
           const R woodC = totalWoodC;
+          if (Full) evOutC += ((woodC + eLeaf) * p0 + (eFine + eCoarse) * p1) * invLen;  // events.c:582-594
           evSoilC += (p3 * (eFine + eCoarse) + p2 * (eLeaf + woodC)) * invLen;
           evLeafC += -eLeaf * (p0 + p2) * invLen;
           evWoodC += -woodC * (p0 + p2) * invLen;
@@ -676,6 +724,7 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
           evCoarseRootC += -eCoarse * (p1 + p3) * invLen;
         } else if (type == SIPNET_EV_FERT) {
           evSoilC += p1 * invLen;
+          if (Full) evInC += p1 * invLen;
         } else if (type == SIPNET_EV_LEAFON) {
           const R flux = leafOnLimit(PRM_RARE(leafGrowth) * invLen);
           evLeafOnCreation += flux;
@@ -684,6 +733,11 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
         } else if (type == SIPNET_EV_LEAFOFF) {
           evLeafOffLitter += eLeaf * PRM_RARE(fracLeafFall) * invLen;
         }
+      }
+      if (Full) {
+        recEvLeafOn = evLeafOnCreation;
+        recEvLeafOnFromWood = evLeafOnFromWood;
+        recEvLeafOffLitter = evLeafOffLitter;
       }
       plantWoodC += (double)(evWoodC * len);
       plantLeafC += (double)(evLeafC * len);
@@ -724,6 +778,9 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
     // ---- pools (sipnet.c:1769-1806): plant pools first, so that the next step's leaf area
     // can leave for wave L as early as possible
     delta += (double)(((photosynthesis - r_a) - alloc) * len);
+    double postC = 0.0;  // getMassTotals() after the pool updates (the soil pool's is still pending here)
+    if (wantDiag) postC = (plantWoodC + delta) + plantLeafC + fineRootC + coarseRootC + (soilC + soilGain);
+    double deathWood = 0.0, deathRoot = 0.0;  // record columns 41, 42
     // checkForMortality(), sipnet.c:1688-1767
     bool alive = alive0;
     double deathToSoil0 = 0.0, deathToSoil1 = 0.0;
@@ -740,6 +797,10 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
           if (diedAt < 0) diedAt = t;
           deathToSoil0 = fineRootC + coarseRootC;
           deathToSoil1 = plantWoodC + plantLeafC + delta;
+          if (Full) {
+            deathWood = plantWoodC + delta;
+            deathRoot = deathToSoil0;
+          }
           plantWoodC = 0.0;
           plantLeafC = 0.0;
           coarseRootC = 0.0;
@@ -750,6 +811,10 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
       }
     }
     aliveC = alive;
+    if (wantDiag) {  // clamp warnings, sipnet.c:1346-1356
+      clampWarn += (plantWoodC < 0.0 && fabs(plantWoodC) > kEps) + (plantLeafC < 0.0 && fabs(plantLeafC) > kEps) +
+                   (coarseRootC < 0.0 && fabs(coarseRootC) > kEps) + (fineRootC < 0.0 && fabs(fineRootC) > kEps);
+    }
     plantWoodC = rmax0(plantWoodC);
     plantLeafC = rmax0(plantLeafC);
     coarseRootC = rmax0(coarseRootC);
@@ -766,7 +831,20 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
         soilC += deathToSoil1;
       }
     }
+    if (wantDiag && soilC < 0.0 && fabs(soilC) > kEps) clampWarn++;
     soilC = rmax0(soilC);
+    if (wantDiag) {  // updateBalanceTrackerPostClamp() + checkBalance(), balance.c:40-169
+      const double finC = (plantWoodC + delta) + plantLeafC + fineRootC + coarseRootC + soilC;
+      double clampedC = finC - postC;
+      if (clampedC < kEps) clampedC = 0.0;
+      double inC = ((double)photosynthesis + (double)evInC) * (double)len;
+      const double outC = ((double)rVeg + (double)rFineRoot + (double)rCoarseRoot + (double)rSoil +
+                           (double)evOutC) * (double)len;
+      inC += clampedC;
+      const double dC = (finC - preC) - (inC - outC);
+      maxDC = fmax(maxDC, fabs(dC));
+      if (!(fabs(dC) < kEps)) balanceWarn++;
+    }
 
     // ---- outputs: updateTrackers(), sipnet.c:1420-1496 ---------------------------------------
     const R tGpp = photosynthesis * len;
@@ -775,6 +853,26 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
     const R tNee = R(-1.0) * ((tGpp - tRa) - tRh);
     totGpp += (double)tGpp;
     totNee += (double)tNee;
+    R tRAbove = 0, tRRoot = 0, tRSoil = 0, tRtot = 0, tNpp = 0;
+    if (Full) {
+      if (bits & FAST_TRACK_NEW_YEAR) yGpp = yRtot = yRa = yRh = yNpp = yNee = 0.0;
+      tRAbove = rVeg * len;
+      tRRoot = (rCoarseRoot + rFineRoot) * len;
+      tRSoil = tRRoot + tRh;
+      tRtot = tRa + tRh;
+      tNpp = tGpp - tRa;
+      yGpp += (double)tGpp;
+      yRa += (double)tRa;
+      yRh += (double)tRh;
+      yRtot += (double)tRtot;
+      yNpp += (double)tNpp;
+      yNee += (double)tNee;
+      totRa += (double)tRa;
+      totRh += (double)tRh;
+      totRtot += (double)tRtot;
+      totNpp += (double)tNpp;
+      yLitter += (double)(leafLitter + recEvLeafOffLitter);
+    }
 
     // ---- running mean of NPP (sipnet.c:1546-1570, runmean.c:61-116 via the plan) -------------
     const double npp = (double)(photosynthesis - rVeg - rCoarseRoot - rFineRoot);
@@ -819,6 +917,50 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
       lastIns = insEff;
       lastNpp = npp;
     }
+    if (Full && recp) {  // the carbon / tracker columns of the strict kernel's record row
+      double* __restrict__ r = recp;
+      const int64_t L = a.ld;
+      r[0 * L] = (double)tNee;
+      r[1 * L] = (double)tGpp;
+      r[3 * L] = totNee;
+      r[4 * L] = (double)tNpp;
+      r[5 * L] = (double)tRAbove;
+      r[6 * L] = (double)tRSoil;
+      r[7 * L] = (double)tRRoot;
+      r[8 * L] = (double)tRa;
+      r[9 * L] = (double)tRh;
+      r[10 * L] = (double)tRtot;
+      r[11 * L] = (double)(woodCreation * len);
+      r[14 * L] = plantWoodC;
+      r[15 * L] = plantLeafC;
+      r[16 * L] = soilC;
+      r[18 * L] = cLitterC;
+      r[20 * L] = coarseRootC;
+      r[21 * L] = fineRootC;
+      r[22 * L] = cMinN;
+      r[23 * L] = cSoilOrgN;
+      r[24 * L] = cLitterN;
+      r[25 * L] = cStorN;
+      r[26 * L] = delta;
+      r[27 * L] = 0.0;
+      r[28 * L] = 0.0;
+      r[29 * L] = 0.0;
+      r[30 * L] = 0.0;
+      r[31 * L] = 0.0;
+      r[32 * L] = ringSum / 5.0;
+      r[33 * L] = rare[3];  // gddAfter
+      r[34 * L] = rare[4];  // tillAfter
+      r[35 * L] = totGpp;
+      r[36 * L] = (double)(leafOnCreation * len);
+      r[37 * L] = (double)(leafOnFromWood * len);
+      r[38 * L] = (double)(recLeafOffComputed * len);
+      r[39 * L] = (double)(recEvLeafOn * len);
+      r[40 * L] = (double)(recEvLeafOnFromWood * len);
+      r[41 * L] = deathWood;
+      r[42 * L] = deathRoot;
+      r[43 * L] = diedNow ? 1.0 : 0.0;
+      recp += (int64_t)SIPNET_NREC * L;
+    }
     *oNee = tNee;
     *oGpp = tGpp;
     oNee += ldNee;
@@ -847,6 +989,25 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
     ST(phenBits) = (double)phenBits;
     ST(ringValidFrom) = (double)ringValidFrom;
     ST(diedAt) = (double)diedAt;
+    if (Full) {
+      ST(totRtot) = totRtot;
+      ST(totRa) = totRa;
+      ST(totRh) = totRh;
+      ST(totNpp) = totNpp;
+      ST(yearlyGpp) = yGpp;
+      ST(yearlyRtot) = yRtot;
+      ST(yearlyRa) = yRa;
+      ST(yearlyRh) = yRh;
+      ST(yearlyNpp) = yNpp;
+      ST(yearlyNee) = yNee;
+      ST(yearlyLitter) = yLitter;
+    }
+    if (wantDiag) {
+      double* __restrict__ dg = a.diag + col;
+      if (clampWarn) atomicAdd(dg, (double)clampWarn);  // the water wave adds its two pools' count
+      dg[1 * nc] += (double)balanceWarn;
+      dg[2 * nc] = fmax(dg[2 * nc], maxDC);
+    }
   }
 #undef ST
 #undef PRM
@@ -867,19 +1028,23 @@ extern "C" int sipnet_debug_read_coop_stamps(unsigned long long* out) {
 void launchStepCoop(const FastArgs& a, int precision, bool ringInLds, hipStream_t stream, LaunchInfo* info) {
   const int chunksPerSite = (a.n_members + 63) / 64;
   const dim3 grid(a.n_sites * chunksPerSite), block(192);
-#define COOP_LAUNCH(R, P, L) hipLaunchKernelGGL((stepCoopKernel<R, P, L>), grid, block, 0, stream, a)
+#define COOP_LAUNCH(R, P, L)                                                                        \
+  {                                                                                                 \
+    if (a.full) hipLaunchKernelGGL((stepCoopKernel<R, P, L, true>), grid, block, 0, stream, a);      \
+    else hipLaunchKernelGGL((stepCoopKernel<R, P, L, false>), grid, block, 0, stream, a);           \
+  }
   if (precision == SIPNET_F64) {
-    if (a.plainExp) { if (ringInLds) COOP_LAUNCH(double, true, true); else COOP_LAUNCH(double, true, false); }
-    else { if (ringInLds) COOP_LAUNCH(double, false, true); else COOP_LAUNCH(double, false, false); }
+    if (a.plainExp) { if (ringInLds) COOP_LAUNCH(double, true, true) else COOP_LAUNCH(double, true, false) }
+    else { if (ringInLds) COOP_LAUNCH(double, false, true) else COOP_LAUNCH(double, false, false) }
   } else {
-    if (a.plainExp) { if (ringInLds) COOP_LAUNCH(float, true, true); else COOP_LAUNCH(float, true, false); }
-    else { if (ringInLds) COOP_LAUNCH(float, false, true); else COOP_LAUNCH(float, false, false); }
+    if (a.plainExp) { if (ringInLds) COOP_LAUNCH(float, true, true) else COOP_LAUNCH(float, true, false) }
+    else { if (ringInLds) COOP_LAUNCH(float, false, true) else COOP_LAUNCH(float, false, false) }
   }
 #undef COOP_LAUNCH
   if (info) {
-    snprintf(info->kernel, sizeof info->kernel, "stepCoopKernel<%s, %s, %s>",
+    snprintf(info->kernel, sizeof info->kernel, "stepCoopKernel<%s, %s, %s, %s>",
              precision == SIPNET_F64 ? "double" : "float", a.plainExp ? "true" : "false",
-             ringInLds ? "true" : "false");
+             ringInLds ? "true" : "false", a.full ? "true" : "false");
     info->grid = (int32_t)grid.x;
     info->block = 192;
     info->wavesPerSimd = 1;

@@ -105,7 +105,13 @@ bool isNCycleFlagSet(const int32_t* f) {
 // tighter budget only costs (19.6 vs 18.7 ms at 65 536 members), so the launcher picks.  (fp32:
 // 191-198 VGPRs, two waves as it is; a 168-VGPR cut for three gains 13 % only beyond 500 000
 // members and a 128-VGPR cut for four halves the rate through spills -- neither is built.)
-template <class R, bool PlainExp, int Mode, int Occ>
+// Full = true: the "complete" variant for callers that want more than the three flux planes --
+// every accumulator of the restart schema advances (trackers.tot*, trackers.yearly*, sipnet.c:
+// 1420-1496), the 44-column per-step record of the strict kernel can be written (a.rec: `.out` /
+// `events.out` text and checkpoints from the throughput path), and the reference's per-step
+// diagnostics are counted per member (a.diag: clamp warnings sipnet.c:1346-1356, mass-balance
+// warnings balance.c:40-169).  Same flux arithmetic; the lean variant stays the benchmarked one.
+template <class R, bool PlainExp, int Mode, int Occ, bool Full>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(Occ)))
 void stepFastKernel(FastArgs a) {
   constexpr bool Generic = Mode != kFlagsDefault;
@@ -223,6 +229,18 @@ void stepFastKernel(FastArgs a) {
   int phenBits = (int)ST(phenBits);
   int ringValidFrom = (int)ST(ringValidFrom);
   int diedAt = (int)ST(diedAt);
+  // Full: the other accumulators of updateTrackers() and the diagnostics counters
+  double totRtot = Full ? ST(totRtot) : 0.0, totRa = Full ? ST(totRa) : 0.0;
+  double totRh = Full ? ST(totRh) : 0.0, totNpp = Full ? ST(totNpp) : 0.0;
+  double yGpp = Full ? ST(yearlyGpp) : 0.0, yRtot = Full ? ST(yearlyRtot) : 0.0;
+  double yRa = Full ? ST(yearlyRa) : 0.0, yRh = Full ? ST(yearlyRh) : 0.0;
+  double yNpp = Full ? ST(yearlyNpp) : 0.0, yNee = Full ? ST(yearlyNee) : 0.0;
+  double yLitter = Full ? ST(yearlyLitter) : 0.0;
+  const bool wantDiag = Full && a.diag != nullptr;
+  const double K_whc2 = Full ? 2.0 * PRM(soilWHC) : 0.0;  // soilWetnessFrac denominator, sipnet.c:1470
+  int clampWarn = 0, balanceWarn = 0;
+  double maxDC = 0.0, maxDN = 0.0;
+  double* __restrict__ recp = Full && a.rec ? a.rec + col : nullptr;
 #ifdef SIPNET_STAMPS
   unsigned long long stampAcc0 = 0, stampAcc1 = 0, stampAcc2 = 0, stampAcc3 = 0, stampAcc4 = 0,
                      stampAcc5 = 0, stampAcc6 = 0, stampAcc7 = 0, lastStamp;
@@ -324,6 +342,27 @@ void stepFastKernel(FastArgs a) {
     const R totalWoodC = (R)(plantWoodC + delta);
     const R eLitter = (R)litterC, eMinN = (R)minN, eSoilOrgN = (R)soilOrgN;
     const R eLitterN = (R)litterN, eStorN = (R)storN;
+    const double oldSoilWater = soilWater;  // soilWetnessFrac, sipnet.c:1470
+    // getMassTotals() before the pool updates, balance.c:13-36
+    auto massC = [&]() -> double {
+      double c = (plantWoodC + delta) + plantLeafC + fineRootC + coarseRootC + soilC;
+      if (Generic && F.litterPool) c += litterC;
+      return c;
+    };
+    auto massN = [&]() -> double {
+      if (!(Generic && F.nitrogen)) return 0.0;
+      return plantWoodC * (double)G_iWoodCN + plantLeafC * (double)G_iLeafCN +
+             fineRootC * (double)G_iFineCN + coarseRootC * (double)G_iWoodCN + soilOrgN + litterN +
+             minN + storN;
+    };
+    double preC = 0.0, preN = 0.0;
+    if (wantDiag) {
+      preC = massC();
+      preN = massN();
+    }
+    // Full: event-log columns of the record and the events' contribution to the mass balance
+    R recLeafOffComputed = 0, recEvLeafOn = 0, recEvLeafOnFromWood = 0, recEvLeafOffLitterAll = 0;
+    R evInC = 0, evOutC = 0, evInN = 0, evOutN = 0;
 
     auto leafOnNFromC = [&](R leafOnC) -> R {  // nitrogen.c:84-86
       return rmax0(leafOnC * G_iLeafCN - leafOnC * G_iWoodCN);
@@ -525,7 +564,9 @@ void stepFastKernel(FastArgs a) {
         phenBits |= 1;
       }
       if (doOff) {
-        leafLitter += (eLeaf * PRM_RARE(fracLeafFall)) * invLen;
+        const R off = (eLeaf * PRM_RARE(fracLeafFall)) * invLen;
+        leafLitter += off;
+        if (Full) recLeafOffComputed = off;
         phenBits |= 2;
       }
       R evLeafC = 0, evWoodC = 0, evFineRootC = 0, evCoarseRootC = 0, evSoilWater = 0;
@@ -547,8 +588,18 @@ void stepFastKernel(FastArgs a) {
           evWoodC += p1 * invLen;
           evFineRootC += p2 * invLen;
           evCoarseRootC += p3 * invLen;
+          if (Full) {  // events.c:530-541
+            evInC += (p0 + p1 + p2 + p3) * invLen;
+            if (withN) evInN += (p0 * G_iLeafCN + p1 * G_iWoodCN + p2 * G_iFineCN + p3 * G_iWoodCN) * invLen;
+          }
         } else if (type == SIPNET_EV_HARVEST) {
           const R woodC = totalWoodC;
+          if (Full) {  // events.c:582-594
+            evOutC += ((woodC + eLeaf) * p0 + (eFine + eCoarse) * p1) * invLen;
+            if (withN)
+              evOutN += ((eWood * G_iWoodCN + eLeaf * G_iLeafCN) * p0 +
+                         (eFine * G_iFineCN + eCoarse * G_iWoodCN) * p1) * invLen;
+          }
           if (toLitter) {  // events.c:575-580
             evLitterC += (p2 * (eLeaf + woodC)) * invLen;
             evSoilC += (p3 * (eFine + eCoarse)) * invLen;
@@ -570,6 +621,10 @@ void stepFastKernel(FastArgs a) {
             evLitterN += p0 * invLen;
             evMinN += p2 * invLen;
           }
+          if (Full) {
+            evInC += p1 * invLen;
+            if (withN) evInN += (p0 + p2) * invLen;
+          }
         } else if (type == SIPNET_EV_LEAFON) {
           const R flux = leafOnLimit(PRM_RARE(leafGrowth) * invLen);
           evLeafOnCreation += flux;
@@ -587,6 +642,11 @@ void stepFastKernel(FastArgs a) {
         }
       }
       evLeafOnTotal = evLeafOnCreation;
+      if (Full) {
+        recEvLeafOn = evLeafOnCreation;
+        recEvLeafOnFromWood = evLeafOnFromWood;
+        recEvLeafOffLitterAll = evLeafOffLitter;
+      }
       plantWoodC += (double)(evWoodC * len);
       plantLeafC += (double)(evLeafC * len);
       soilC += (double)(evSoilC * len);
@@ -714,6 +774,12 @@ void stepFastKernel(FastArgs a) {
       fineRootC += (double)((fineRootCreation - fineRootLoss) * len);
     }
 
+    double postC = 0.0, postN = 0.0;
+    if (wantDiag) {
+      postC = massC();
+      postN = massN();
+    }
+    double deathWood = 0.0, deathRoot = 0.0, diedNowRec = 0.0;  // record columns 41..43
     // checkForMortality(), sipnet.c:1688-1767: only a change of the alive flag does anything
     bool alive = alive0;
     {
@@ -725,6 +791,11 @@ void stepFastKernel(FastArgs a) {
         } else {
           alive = false;
           if (diedAt < 0) diedAt = t;
+          if (Full) {
+            deathWood = plantWoodC + delta;
+            deathRoot = fineRootC + coarseRootC;
+            diedNowRec = 1.0;
+          }
           soilC += fineRootC + coarseRootC;
           if (Generic && F.litterPool) litterC += plantWoodC + plantLeafC + delta;
           else soilC += plantWoodC + plantLeafC + delta;
@@ -743,20 +814,68 @@ void stepFastKernel(FastArgs a) {
       }
     }
     // ensureNonNegativeStocks(), sipnet.c:1368-1397
-    // (the clamp-warning counter of the strict kernel is not kept on this path)
-    plantWoodC = rmax0(plantWoodC);
-    plantLeafC = rmax0(plantLeafC);
-    soilC = rmax0(soilC);
-    coarseRootC = rmax0(coarseRootC);
-    fineRootC = rmax0(fineRootC);
-    soilWater = rmax0(soilWater);
-    snow = snow < kTiny ? 0.0 : snow;
-    if (Generic) {
-      litterC = rmax0(litterC);
-      minN = rmax0(minN);
-      soilOrgN = rmax0(soilOrgN);
-      litterN = rmax0(litterN);
-      storN = rmax0(storN);
+    if (wantDiag) {  // with the reference's warning count (|v| > EPS), sipnet.c:1346-1356
+      auto clampW = [&](double& v, double minVal) {
+        if (v < minVal) {
+          if (fabs(v) > kEps) clampWarn++;
+          v = 0.0;
+        }
+      };
+      clampW(plantWoodC, 0.0);
+      clampW(plantLeafC, 0.0);
+      if (Generic && F.litterPool) clampW(litterC, 0.0);
+      clampW(soilC, 0.0);
+      clampW(coarseRootC, 0.0);
+      clampW(fineRootC, 0.0);
+      clampW(soilWater, 0.0);
+      clampW(snow, kTiny);
+      if (Generic) {
+        clampW(minN, 0.0);
+        clampW(soilOrgN, 0.0);
+        clampW(litterN, 0.0);
+        clampW(storN, 0.0);
+        if (!F.litterPool) litterC = rmax0(litterC);
+      }
+    } else {
+      plantWoodC = rmax0(plantWoodC);
+      plantLeafC = rmax0(plantLeafC);
+      soilC = rmax0(soilC);
+      coarseRootC = rmax0(coarseRootC);
+      fineRootC = rmax0(fineRootC);
+      soilWater = rmax0(soilWater);
+      snow = snow < kTiny ? 0.0 : snow;
+      if (Generic) {
+        litterC = rmax0(litterC);
+        minN = rmax0(minN);
+        soilOrgN = rmax0(soilOrgN);
+        litterN = rmax0(litterN);
+        storN = rmax0(storN);
+      }
+    }
+    if (wantDiag) {  // updateBalanceTrackerPostClamp() + checkBalance(), balance.c:40-169
+      const double finC = massC(), finN = massN();
+      double clampedC = finC - postC, clampedN = finN - postN;
+      if (clampedC < kEps) clampedC = 0.0;
+      if (clampedN < kEps) clampedN = 0.0;
+      double inC = (double)photosynthesis + (double)evInC;
+      double outC = (double)rVeg + (double)rFineRoot + (double)rCoarseRoot + (double)rSoil +
+                    (double)soilMethane + (double)evOutC;
+      if (Generic && F.litterPool) outC += (double)rLitter + (double)litterMethane;
+      inC *= (double)len;
+      outC *= (double)len;
+      double inN = 0.0, outN = 0.0;
+      if (Generic && F.nitrogen) {
+        inN = ((double)nFixation + (double)evInN) * (double)len;
+        outN = ((double)nLeaching + (double)nVolatilization + (double)evOutN) * (double)len;
+      }
+      inC += clampedC;
+      if (Generic && F.nitrogen) inN += clampedN;
+      const double dC = (finC - preC) - (inC - outC);
+      const double dN = (finN - preN) + (outN - inN);
+      maxDC = fmax(maxDC, fabs(dC));
+      maxDN = fmax(maxDN, fabs(dN));
+      if (!(fabs(dC) < kEps)) balanceWarn++;
+      if (!(fabs(dN) < kEps)) balanceWarn++;
     }
     STAMP(4)
 
@@ -768,6 +887,26 @@ void stepFastKernel(FastArgs a) {
     const R tEt = (transpiration + immedEvap + evaporation + sublimation + evEvap) * len;
     totGpp += (double)tGpp;
     totNee += (double)tNee;
+    R tRAbove = 0, tRRoot = 0, tRSoil = 0, tRtot = 0, tNpp = 0;
+    if (Full) {  // the rest of updateTrackers(), sipnet.c:1420-1496
+      if (bits & FAST_TRACK_NEW_YEAR) yGpp = yRtot = yRa = yRh = yNpp = yNee = 0.0;
+      tRAbove = rVeg * len;
+      tRRoot = (rCoarseRoot + rFineRoot) * len;
+      tRSoil = tRRoot + tRh;
+      tRtot = tRa + tRh;
+      tNpp = tGpp - tRa;
+      yGpp += (double)tGpp;
+      yRa += (double)tRa;
+      yRh += (double)tRh;
+      yRtot += (double)tRtot;
+      yNpp += (double)tNpp;
+      yNee += (double)tNee;
+      totRa += (double)tRa;
+      totRh += (double)tRh;
+      totRtot += (double)tRtot;
+      totNpp += (double)tNpp;
+      yLitter += (double)(leafLitter + recEvLeafOffLitterAll);
+    }
 
     // ---- 5. running mean of NPP (sipnet.c:1546-1570, runmean.c:61-116 via the plan) ----
     const double npp = (double)(photosynthesis - rVeg - rCoarseRoot - rFineRoot);
@@ -805,6 +944,55 @@ void stepFastKernel(FastArgs a) {
       }
     }
     STAMP(6)
+    if (Full && recp) {  // the strict kernel's record row (include/sipnet_amd.h), sipnet.c:453-473
+      double* __restrict__ r = recp;
+      const int64_t L = a.ld;
+      r[0 * L] = (double)tNee;
+      r[1 * L] = (double)tGpp;
+      r[2 * L] = (double)tEt;
+      r[3 * L] = totNee;
+      r[4 * L] = (double)tNpp;
+      r[5 * L] = (double)tRAbove;
+      r[6 * L] = (double)tRSoil;
+      r[7 * L] = (double)tRRoot;
+      r[8 * L] = (double)tRa;
+      r[9 * L] = (double)tRh;
+      r[10 * L] = (double)tRtot;
+      r[11 * L] = (double)(woodCreation * len);
+      r[12 * L] = (oldSoilWater + soilWater) / K_whc2;
+      r[13 * L] = (double)transpiration;
+      r[14 * L] = plantWoodC;
+      r[15 * L] = plantLeafC;
+      r[16 * L] = soilC;
+      r[17 * L] = soilWater;
+      r[18 * L] = litterC;
+      r[19 * L] = snow;
+      r[20 * L] = coarseRootC;
+      r[21 * L] = fineRootC;
+      r[22 * L] = minN;
+      r[23 * L] = soilOrgN;
+      r[24 * L] = litterN;
+      r[25 * L] = storN;
+      r[26 * L] = delta;
+      r[27 * L] = (double)(nVolatilization * len);
+      r[28 * L] = (double)(nLeaching * len);
+      r[29 * L] = (double)(nFixation * len);
+      r[30 * L] = (double)(nUptake * len);
+      r[31 * L] = (double)((soilMethane + litterMethane) * len);
+      r[32 * L] = ringSum / 5.0;
+      r[33 * L] = rare[3];  // gddAfter
+      r[34 * L] = rare[4];  // tillAfter
+      r[35 * L] = totGpp;
+      r[36 * L] = (double)(leafOnCreation * len);
+      r[37 * L] = (double)(leafOnFromWood * len);
+      r[38 * L] = (double)(recLeafOffComputed * len);
+      r[39 * L] = (double)(recEvLeafOn * len);
+      r[40 * L] = (double)(recEvLeafOnFromWood * len);
+      r[41 * L] = deathWood;
+      r[42 * L] = deathRoot;
+      r[43 * L] = diedNowRec;
+      recp += (int64_t)SIPNET_NREC * L;
+    }
     // request the values the NEXT step evicts, then store: loads ahead of stores in the queue
     const int insEff = insSlot < 0 ? 0 : insSlot;
     const int pfSlot0 = (slots >> 16) & 255, pfSlot1 = (slots >> 24) & 255;
@@ -855,6 +1043,26 @@ void stepFastKernel(FastArgs a) {
     ST(phenBits) = (double)phenBits;
     ST(ringValidFrom) = (double)ringValidFrom;
     ST(diedAt) = (double)diedAt;
+    if (Full) {
+      ST(totRtot) = totRtot;
+      ST(totRa) = totRa;
+      ST(totRh) = totRh;
+      ST(totNpp) = totNpp;
+      ST(yearlyGpp) = yGpp;
+      ST(yearlyRtot) = yRtot;
+      ST(yearlyRa) = yRa;
+      ST(yearlyRh) = yRh;
+      ST(yearlyNpp) = yNpp;
+      ST(yearlyNee) = yNee;
+      ST(yearlyLitter) = yLitter;
+    }
+    if (wantDiag) {
+      double* __restrict__ dg = a.diag + col;
+      dg[0 * nc] += (double)clampWarn;
+      dg[1 * nc] += (double)balanceWarn;
+      dg[2 * nc] = fmax(dg[2 * nc], maxDC);
+      dg[3 * nc] = fmax(dg[3 * nc], maxDN);
+    }
   }
 #undef ST
 #undef PRM
@@ -872,21 +1080,25 @@ template <class R, bool Plain, int Mode>
 void launchFastOne(const FastArgs& a, int grid, bool twoWaves, hipStream_t stream, LaunchInfo* info) {
   // a second, 256-VGPR build exists where it costs at most a few spilled registers: the fp64
   // default-flag kernel (257 -> 256) and the fp32 run-time-flag kernel (260-266 -> 256); the other
-  // fp32 kernels fit two waves as they are, the fp64 optional-flag kernels (378-400) do not
+  // fp32 kernels fit two waves as they are, the fp64 optional-flag kernels (378-400) do not.
+  // The Full variants exist in the one-wave-per-SIMD register budget only.
   constexpr int kOcc2 = ((Mode == kFlagsDefault && sizeof(R) == 8) ||
                          (Mode == kFlagsRuntime && sizeof(R) == 4)) ? 2 : 1;
-  const bool occ2 = kOcc2 == 2 && twoWaves;
-  if (occ2)
-    hipLaunchKernelGGL((stepFastKernel<R, Plain, Mode, kOcc2>), dim3(grid), dim3(64), 0, stream, a);
+  const bool occ2 = kOcc2 == 2 && twoWaves && !a.full;
+  if (a.full)
+    hipLaunchKernelGGL((stepFastKernel<R, Plain, Mode, 1, true>), dim3(grid), dim3(64), 0, stream, a);
+  else if (occ2)
+    hipLaunchKernelGGL((stepFastKernel<R, Plain, Mode, kOcc2, false>), dim3(grid), dim3(64), 0, stream, a);
   else
-    hipLaunchKernelGGL((stepFastKernel<R, Plain, Mode, 1>), dim3(grid), dim3(64), 0, stream, a);
+    hipLaunchKernelGGL((stepFastKernel<R, Plain, Mode, 1, false>), dim3(grid), dim3(64), 0, stream, a);
   if (info) {
-    snprintf(info->kernel, sizeof info->kernel, "stepFastKernel<%s, %s, %d, %d>",
-             sizeof(R) == 8 ? "double" : "float", Plain ? "true" : "false", Mode, occ2 ? 2 : 1);
+    snprintf(info->kernel, sizeof info->kernel, "stepFastKernel<%s, %s, %d, %d, %s>",
+             sizeof(R) == 8 ? "double" : "float", Plain ? "true" : "false", Mode, occ2 ? 2 : 1,
+             a.full ? "true" : "false");
     info->grid = grid;
     info->block = 64;
     // the fp32 default-flag / N-cycle builds need < 256 VGPRs: two waves fit as they are
-    info->wavesPerSimd = (occ2 || (sizeof(R) == 4 && Mode != kFlagsRuntime)) ? 2 : 1;
+    info->wavesPerSimd = (occ2 || (sizeof(R) == 4 && Mode != kFlagsRuntime && !a.full)) ? 2 : 1;
     info->ldsBytes = 2 * kFastTile * (int)sizeof(FastRec);
   }
 }

@@ -61,6 +61,7 @@ struct KernelArgs {
   void* et;
   double* rec;            // [n_steps][SIPNET_NREC][ld] or null
   double* dbg;            // [n_steps][SIPNET_NDBG][ld] or null (only with rec)
+  double* diag;           // [4][ncol] diagnostics (see FastArgs) or null
   int64_t ncol, ld;
   int32_t n_sites, n_members, n_steps_total, step0, n_steps;
   int32_t flags[SIPNET_NFLAGS];
@@ -94,6 +95,11 @@ struct FastArgs {
   void* et;
   int64_t ncol, ld;
   int32_t n_sites, n_members, n_steps_total, step0, n_steps;
+  // "full" launches (the Full instantiations): every accumulator of the restart schema advances,
+  // and optionally the per-step record and the per-member diagnostics are written
+  double* rec;       // [n_steps][SIPNET_NREC][ld] or null
+  double* diag;      // [4][ncol]: clamp warnings, balance warnings, max|dC|, max|dN|; or null
+  int32_t full;      // 1: take the Full instantiation
   void* scratchRow;  // [ncol] doubles: target of the stores of planes the caller left NULL
   int32_t plainExp;  // 1: every member has dVpdExp == 2 and soilRespMoistEffect == 1
   int32_t numCUs;                // compute units of the device (kernel / occupancy choice)

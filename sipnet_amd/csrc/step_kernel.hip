@@ -305,6 +305,9 @@ __global__ __launch_bounds__(64) void stepKernel(KernelArgs a) {
   int ringValidFrom = (int)ST(ringValidFrom);
   int diedAt = (int)ST(diedAt);
   int clampCount = (int)ST(clampCount);
+  const int clampCount0 = clampCount;
+  int balanceWarn = 0;
+  double diagMaxDC = 0.0, diagMaxDN = 0.0;
 
   const StepRec* __restrict__ plan = a.plan + (int64_t)site * a.n_steps_total;
   double* __restrict__ ringp = a.ring + col;
@@ -344,7 +347,6 @@ __global__ __launch_bounds__(64) void stepKernel(KernelArgs a) {
     R evSoilC = 0, evLitterC = 0, evMinN = 0, evSoilOrgN = 0, evLitterN = 0;
     R evLeafOnCreation = 0, evLeafOnFromWood = 0, evLeafOffLitter = 0, evLeafOffNResorp = 0;
     R evInputC = 0, evOutputC = 0, evInputN = 0, evOutputN = 0;
-    (void)evInputC; (void)evOutputC; (void)evInputN; (void)evOutputN;
     const R dTill = (R)s.dTill;
 
     auto leafOnNFromC = [&](R leafOnC) -> R {  // nitrogen.c:84-86
@@ -834,6 +836,22 @@ __global__ __launch_bounds__(64) void stepKernel(KernelArgs a) {
 
     // ---- 3. pools: updatePoolsAndBalance(), sipnet.c:1769-1806 ---------------
     const double dl = (double)len;
+    // getMassTotals(), balance.c:13-36, for the per-step balance diagnostics (a.diag)
+    auto massC = [&]() -> double {
+      double c = (plantWoodC + plantCAccountingDelta) + plantLeafC + fineRootC + coarseRootC + soilC;
+      if (F.litterPool) c += litterC;
+      return c;
+    };
+    auto massN = [&]() -> double {
+      if (!F.nitrogenCycle) return 0.0;
+      return plantWoodC / (double)woodCN + plantLeafC / (double)leafCN + fineRootC / (double)fineRootCN +
+             coarseRootC / (double)woodCN + soilOrgN + litterN + minN + plantStorageN;
+    };
+    double preC = 0.0, preN = 0.0, postC = 0.0, postN = 0.0;
+    if (a.diag) {
+      preC = massC();
+      preN = massN();
+    }
     // updatePoolsForEvents(), events.c:744-790
     if (F.events) {
       plantWoodC += (double)(evWoodC * len);
@@ -904,6 +922,10 @@ __global__ __launch_bounds__(64) void stepKernel(KernelArgs a) {
       litterN += (double)(nOrgLitter * len);
     }
     (void)dl;
+    if (a.diag) {
+      postC = massC();
+      postN = massN();
+    }
 
     // checkForMortality(), sipnet.c:1688-1767
     double diedNow = 0.0, deathWood = 0.0, deathRoot = 0.0;
@@ -963,6 +985,31 @@ __global__ __launch_bounds__(64) void stepKernel(KernelArgs a) {
       CLAMP(plantStorageN, 0.0)
     }
 #undef CLAMP
+    if (a.diag) {  // updateBalanceTrackerPostClamp() + checkBalance(), balance.c:40-169
+      const double finC = massC(), finN = massN();
+      double clampedC = finC - postC, clampedN = finN - postN;
+      if (clampedC < kEps) clampedC = 0.0;
+      if (clampedN < kEps) clampedN = 0.0;
+      double inC = (double)photosynthesis + (double)evInputC;
+      double outC = (double)rVeg + (double)rFineRoot + (double)rCoarseRoot + (double)rSoil +
+                    (double)soilMethane + (double)evOutputC;
+      if (F.litterPool) outC += (double)rLitter + (double)litterMethane;
+      inC *= (double)len;
+      outC *= (double)len;
+      double inN = 0.0, outN = 0.0;
+      if (F.nitrogenCycle) {
+        inN = ((double)nFixation + (double)evInputN) * (double)len;
+        outN = ((double)nLeaching + (double)nVolatilization + (double)evOutputN) * (double)len;
+      }
+      inC += clampedC;
+      if (F.nitrogenCycle) inN += clampedN;
+      const double dC = (finC - preC) - (inC - outC);
+      const double dN = (finN - preN) + (outN - inN);
+      diagMaxDC = fmax(diagMaxDC, fabs(dC));
+      diagMaxDN = fmax(diagMaxDN, fabs(dN));
+      if (!(fabs(dC) < kEps)) balanceWarn++;
+      if (!(fabs(dN) < kEps)) balanceWarn++;
+    }
 
     // ---- 4. trackers: updateTrackers(), sipnet.c:1420-1496 --------------------
     if (bits & STEP_TRACK_NEW_YEAR) {
@@ -1140,6 +1187,13 @@ __global__ __launch_bounds__(64) void stepKernel(KernelArgs a) {
   ST(ringValidFrom) = (double)ringValidFrom;
   ST(diedAt) = (double)diedAt;
   ST(clampCount) = (double)clampCount;
+  if (a.diag) {
+    double* __restrict__ dg = a.diag + col;
+    dg[0 * nc] += (double)(clampCount - clampCount0);
+    dg[1 * nc] += (double)balanceWarn;
+    dg[2 * nc] = fmax(dg[2 * nc], diagMaxDC);
+    dg[3 * nc] = fmax(dg[3 * nc], diagMaxDN);
+  }
 #undef ST
 }
 

@@ -96,13 +96,33 @@ def test_cli_ensemble_extension(tmp_path):
     unchanged values equals the single run."""
     stage("niwot", tmp_path)
     open(tmp_path / "members.txt", "w").write("aMax psnTOpt\n8.3 24\n9.0 22.5\n7.1 25\n")
-    r = run_cli(tmp_path, "-i", "sipnet.in", "--ensemble-params", "members.txt")
+    r = run_cli(tmp_path, "-i", "sipnet.in", "--ensemble-params", "members.txt", "--math", "strict")
     assert r.returncode == 0, r.stdout
     import gzip
     gold_out = gzip.open(os.path.join(helpers.smoke_dir("niwot"), "sipnet.out.gz"), "rb").read()
     assert open(tmp_path / "sipnet.0.out", "rb").read() == gold_out
     a, b = open(tmp_path / "sipnet.1.out").read(), open(tmp_path / "sipnet.2.out").read()
     assert a != b and len(a.splitlines()) == 5237
+    strict = {m: open(tmp_path / f"sipnet.{m}.out").read() for m in range(3)}
+    # default for an ensemble: the throughput kernels write the record (their Full instantiations);
+    # at the precision `.out` prints the files agree with the strict ones (token by token, at
+    # most the last printed digit apart)
+    r = run_cli(tmp_path, "-i", "sipnet.in", "--ensemble-params", "members.txt")
+    assert r.returncode == 0, r.stdout
+    for m in range(3):
+        fast = open(tmp_path / f"sipnet.{m}.out").read()
+        la, lb = fast.split("\n"), strict[m].split("\n")
+        assert len(la) == len(lb)
+        differing = 0
+        for x, y in zip(la, lb):
+            if x == y:
+                continue
+            differing += 1
+            for u, v in zip(x.split(), y.split()):
+                if u != v:
+                    dec = len(v.split(".")[1]) if "." in v else 0
+                    assert abs(float(u) - float(v)) <= 1.01 * 10 ** (-dec), (x, y)
+        assert differing <= 5, differing
 
 
 def test_cli_devices_list_is_validated(tmp_path):
@@ -128,7 +148,7 @@ def test_cli_ensemble_sharded_over_devices_equals_one_batch(tmp_path):
         stage("russell_1", d)
         open(d / "members.txt", "w").write("\n".join(rows) + "\n")
         r = run_cli(d, "-i", "sipnet.in", "--ensemble-params", "members.txt", "--devices", dev,
-                    "--restart-out", "ck")
+                    "--restart-out", "ck")           # an ensemble: throughput kernels, full records
         assert r.returncode == 0, r.stdout + r.stderr
         if tag == "three":
             assert "sharded over 3 device(s)" in r.stdout
