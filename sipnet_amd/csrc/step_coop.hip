@@ -876,6 +876,7 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
 
     // ---- running mean of NPP (sipnet.c:1546-1570, runmean.c:61-116 via the plan) -------------
     const double npp = (double)(photosynthesis - rVeg - rCoarseRoot - rFineRoot);
+    const double recMeanNpp = Full ? ringSum / 5.0 : 0.0;  // trackers.meanNPP: the mean BEFORE this step's insert
     CSTAMP(5)
     {
       if (!RingLds) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rv0), "+v"(rv1) :: "memory");
@@ -947,7 +948,7 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
       r[29 * L] = 0.0;
       r[30 * L] = 0.0;
       r[31 * L] = 0.0;
-      r[32 * L] = ringSum / 5.0;
+      r[32 * L] = recMeanNpp;
       r[33 * L] = rare[3];  // gddAfter
       r[34 * L] = rare[4];  // tillAfter
       r[35 * L] = totGpp;

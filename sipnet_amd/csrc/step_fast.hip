@@ -910,6 +910,7 @@ void stepFastKernel(FastArgs a) {
 
     // ---- 5. running mean of NPP (sipnet.c:1546-1570, runmean.c:61-116 via the plan) ----
     const double npp = (double)(photosynthesis - rVeg - rCoarseRoot - rFineRoot);
+    const double recMeanNpp = Full ? ringSum / 5.0 : 0.0;  // trackers.meanNPP: the mean BEFORE this step's insert
     STAMP(5)
     {
       const double v0 = useLast0 ? lastNpp : rv0;
@@ -979,7 +980,7 @@ void stepFastKernel(FastArgs a) {
       r[29 * L] = (double)(nFixation * len);
       r[30 * L] = (double)(nUptake * len);
       r[31 * L] = (double)((soilMethane + litterMethane) * len);
-      r[32 * L] = ringSum / 5.0;
+      r[32 * L] = recMeanNpp;
       r[33 * L] = rare[3];  // gddAfter
       r[34 * L] = rare[4];  // tillAfter
       r[35 * L] = totGpp;

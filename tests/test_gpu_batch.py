@@ -310,7 +310,7 @@ def test_math_policy_is_an_explicit_choice(base, short_clim, monkeypatch):
     b.set_math(True)
     b.setup()
     fast = b.run()[0].cpu().numpy()
-    assert b.last_launch()["kernel"] == "stepCoopKernel<double, true, true>"
+    assert b.last_launch()["kernel"] == "stepCoopKernel<double, true, true, false>"
     b.set_math(False)
     b.setup()
     strict2 = b.run()[0].cpu().numpy()
@@ -354,7 +354,7 @@ def test_two_waves_per_simd_build_of_the_one_wave_kernel(which, oracle, base):
         b = make_batch(flags, [clim], members, prec=prec,
                        kernel_options=sa.KOPT_ONE_WAVE_PER_SIMD if occ1 else 0)
         outs.append(b.run()[0].double().cpu().numpy())
-        assert b.last_launch()["kernel"].endswith(", 1>" if occ1 else ", 2>"), b.last_launch()
+        assert b.last_launch()["kernel"].endswith(", 1, false>" if occ1 else ", 2, false>"), b.last_launch()
         b.close()
     assert np.array_equal(outs[0], outs[1])
     pick = np.r_[0:16, M // 2:M // 2 + 16, M - 16:M]

@@ -76,7 +76,7 @@ def test_c2_1024_members_fp64_every_member(oracle, base):
     got = planes.cpu().numpy()
     st = b.get_status()
     b.close()
-    assert li["kernel"] == "stepCoopKernel<double, true, true>" and li["grid"] == 16
+    assert li["kernel"] == "stepCoopKernel<double, true, true, false>" and li["grid"] == 16
     want, _, so = oracle.run_block(sa.flags_from(), members, clim)
     assert (st == 0).all() and (so == 0).all()
     d = np.abs(got - want).max(axis=(1, 2))
@@ -102,7 +102,7 @@ def test_c3_65536_members_fp32_mixed(oracle, base):
     b.close()
     del planes
     torch.cuda.empty_cache()
-    assert li["kernel"] == "stepFastKernel<float, true, 0, 1>" and li["grid"] == 1024, li
+    assert li["kernel"] == "stepFastKernel<float, true, 0, 1, false>" and li["grid"] == 1024, li
     assert (st == 0).all() and finite
     want, final, so = oracle.run_block(sa.flags_from(), members[pick], clim)
     assert (so == 0).all()
@@ -135,7 +135,7 @@ def test_c4_32_sites_x_1024_members_fp64(oracle, base):
     b.close()
     del planes
     torch.cuda.empty_cache()
-    assert li["kernel"] == "stepCoopKernel<double, true, false>" and li["grid"] == 512, li
+    assert li["kernel"] == "stepCoopKernel<double, true, false, false>" and li["grid"] == 512, li
     assert li["plan_threads"] >= 1 and li["plan_build_ms"] > 0
     assert (st == 0).all()
     worst = 0.0
@@ -163,7 +163,7 @@ def test_c5_particle_filter_cycle_131072_particles(oracle, base):
     b = build(flags, [clim], members, sa.F32_MIXED)
     p1, _ = b.run(0, T1)
     li = b.last_launch()
-    assert li["kernel"] == "stepFastKernel<float, true, 0, 1>" and li["grid"] == 2048, li
+    assert li["kernel"] == "stepFastKernel<float, true, 0, 1, false>" and li["grid"] == 2048, li
     pick = np.r_[0:24, n // 2:n // 2 + 16, n - 24:n]
     want, final, so = oracle.run_block(flags, members[pick], clim.slice(0, T1))
     assert (so == 0).all()
@@ -237,14 +237,14 @@ def _scenario(base, lethal):
 
 
 KERNELS = [
-    ("one_wave_f64", sa.F64, sa.KERNEL_ONE_WAVE, 0, "stepFastKernel<double, true, 0, 1>"),
-    ("one_wave_f32", sa.F32_MIXED, sa.KERNEL_ONE_WAVE, 0, "stepFastKernel<float, true, 0, 1>"),
-    ("coop_lds_f64", sa.F64, sa.KERNEL_COOP_LDS, 0, "stepCoopKernel<double, true, true>"),
-    ("coop_lds_f32", sa.F32_MIXED, sa.KERNEL_COOP_LDS, 0, "stepCoopKernel<float, true, true>"),
-    ("coop_hbm_f64", sa.F64, sa.KERNEL_COOP_HBM, 0, "stepCoopKernel<double, true, false>"),
-    ("coop_hbm_f32", sa.F32_MIXED, sa.KERNEL_COOP_HBM, 0, "stepCoopKernel<float, true, false>"),
-    ("runtime_flags_f64", sa.F64, sa.KERNEL_ONE_WAVE, sa.KOPT_RUNTIME_FLAGS, "stepFastKernel<double, true, 1, 1>"),
-    ("runtime_flags_f32", sa.F32_MIXED, sa.KERNEL_ONE_WAVE, sa.KOPT_RUNTIME_FLAGS, "stepFastKernel<float, true, 1, 1>"),
+    ("one_wave_f64", sa.F64, sa.KERNEL_ONE_WAVE, 0, "stepFastKernel<double, true, 0, 1, false>"),
+    ("one_wave_f32", sa.F32_MIXED, sa.KERNEL_ONE_WAVE, 0, "stepFastKernel<float, true, 0, 1, false>"),
+    ("coop_lds_f64", sa.F64, sa.KERNEL_COOP_LDS, 0, "stepCoopKernel<double, true, true, false>"),
+    ("coop_lds_f32", sa.F32_MIXED, sa.KERNEL_COOP_LDS, 0, "stepCoopKernel<float, true, true, false>"),
+    ("coop_hbm_f64", sa.F64, sa.KERNEL_COOP_HBM, 0, "stepCoopKernel<double, true, false, false>"),
+    ("coop_hbm_f32", sa.F32_MIXED, sa.KERNEL_COOP_HBM, 0, "stepCoopKernel<float, true, false, false>"),
+    ("runtime_flags_f64", sa.F64, sa.KERNEL_ONE_WAVE, sa.KOPT_RUNTIME_FLAGS, "stepFastKernel<double, true, 1, 1, false>"),
+    ("runtime_flags_f32", sa.F32_MIXED, sa.KERNEL_ONE_WAVE, sa.KOPT_RUNTIME_FLAGS, "stepFastKernel<float, true, 1, 1, false>"),
 ]
 
 
@@ -289,9 +289,9 @@ def test_non_plain_exponents_take_the_general_instantiations(oracle, base):
     members[70, pi("soilRespMoistEffect")] = 1.4
     want, _, so = oracle.run_block(flags, members, clim)
     assert (so == 0).all()
-    for kernel, expect in ((sa.KERNEL_COOP_LDS, "stepCoopKernel<double, false, true>"),
-                           (sa.KERNEL_COOP_HBM, "stepCoopKernel<double, false, false>"),
-                           (sa.KERNEL_ONE_WAVE, "stepFastKernel<double, false, 0, 1>")):
+    for kernel, expect in ((sa.KERNEL_COOP_LDS, "stepCoopKernel<double, false, true, false>"),
+                           (sa.KERNEL_COOP_HBM, "stepCoopKernel<double, false, false, false>"),
+                           (sa.KERNEL_ONE_WAVE, "stepFastKernel<double, false, 0, 1, false>")):
         b = build(flags, [clim], members, sa.F64, kernel)
         got = b.run()[0].cpu().numpy()
         li = b.last_launch()
