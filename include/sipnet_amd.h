@@ -231,6 +231,9 @@ enum sipnet_kernel {
 enum sipnet_kernel_option {
   SIPNET_KOPT_ONE_WAVE_PER_SIMD = 1, /* one-wave kernel: never the 256-VGPR (two waves/SIMD) build */
   SIPNET_KOPT_RUNTIME_FLAGS = 2,     /* one-wave kernel: always the run-time-flag instantiation */
+  SIPNET_KOPT_NO_REGULAR_TILES = 8,  /* cooperative kernel: always the general per-step path, never the
+                                        record-free path of regular 16-step tiles (A/B measurement,
+                                        tests of the two paths against each other) */
   SIPNET_KOPT_FULL_STATE = 4         /* throughput kernels: advance EVERY accumulator of the restart
                                         schema (trackers.tot*, trackers.yearly*); without it only
                                         totNee / totGpp advance on the throughput path.  Implied by a

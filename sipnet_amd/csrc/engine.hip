@@ -418,7 +418,8 @@ int sipnet_batch_set_math(sipnet_batch* b, int32_t policy) {
 
 int sipnet_batch_set_kernel(sipnet_batch* b, int32_t kernel, int32_t options) {
   if (!b || kernel < SIPNET_KERNEL_AUTO || kernel > SIPNET_KERNEL_STRICT ||
-      (options & ~(SIPNET_KOPT_ONE_WAVE_PER_SIMD | SIPNET_KOPT_RUNTIME_FLAGS | SIPNET_KOPT_FULL_STATE))) {
+      (options & ~(SIPNET_KOPT_ONE_WAVE_PER_SIMD | SIPNET_KOPT_RUNTIME_FLAGS | SIPNET_KOPT_FULL_STATE |
+                   SIPNET_KOPT_NO_REGULAR_TILES))) {
     setError("sipnet_batch_set_kernel: bad argument");
     return SIPNET_ERR_BAD_ARGUMENT;
   }
@@ -573,6 +574,7 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
     f.rec = d_rec;
     f.diag = b->d_diag;
     f.full = (d_rec || b->d_diag || (b->kernelOptions & SIPNET_KOPT_FULL_STATE)) ? 1 : 0;
+    f.options = b->kernelOptions;
     f.scratchRow = b->d_scratchRow;
     memcpy(f.flags, b->flags, sizeof(f.flags));
     f.numCUs = b->numCUs;

@@ -279,6 +279,35 @@ void buildFastRecs(const SitePlan& plan, FastRec* out, int32_t opBase, int32_t e
     const int nx = (t + 1 < n) ? t + 1 : t;
     out[t].slots = slot0[t] | (slot1[t] << 8) | (slot0[nx] << 16) | (slot1[nx] << 24);
   }
+  // tile summaries (see FastRec::tileBits)
+  for (int b = 0; b < n; b += kFastTile) {
+    const int e = b + kFastTile < n ? b + kFastTile : n;
+    bool regular = true;
+    int32_t dayMask = 0;
+    const int nOps0 = out[b].bitsOps >> 16;
+    if (nOps0 < 1 || nOps0 > 2) regular = false;
+    for (int t = b; t < e; t++) {
+      const FastRec& f = out[t];
+      const int bits = f.bitsOps & 0xffff;
+      if (bits & FAST_PAR_POS) dayMask |= 1 << (t - b);
+      if ((bits & (FAST_PHEN_NEW_YEAR | FAST_TRACK_NEW_YEAR)) || f.evCount != 0 || f.insSlot < 0 ||
+          (f.bitsOps >> 16) != nOps0 || f.len != out[b].len || f.invLen != out[b].invLen ||
+          f.w0 != out[b].w0 || f.w1 != out[b].w1)
+        regular = false;
+      if (t > b) {
+        auto next = [](int s) { return s + 1 == SIPNET_RING_SLOTS ? 0 : s + 1; };
+        if (slot0[t] != next(slot0[t - 1]) || slot1[t] != next(slot1[t - 1]) ||
+            f.insSlot != next(out[t - 1].insSlot))
+          regular = false;
+      }
+    }
+    for (int t = b; t < e; t++) {
+      out[t].tileBits = (regular ? FAST_TILE_REGULAR : 0) | (dayMask << 16);
+      out[t].tilePad = 0;
+      out[t].tileEndCumGdd = out[e - 1].cumGdd;
+      out[t].tileEndDayTime = out[e - 1].dayTime;
+    }
+  }
 }
 
 }  // namespace sipnet

@@ -10,6 +10,7 @@
 // modifier and its decay (events.c:629-639, :811-822).  None of it depends on
 // member state, so a batch does it once per site.
 #pragma once
+#include <cstddef>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -91,9 +92,22 @@ struct FastRec {
   int32_t opFirst;     // global RingOp index of this step's eviction list (nOps > 2)
   int32_t evFirst;     // global EvRec index
   int32_t year, day;
-  int32_t pad[12];
+  // ---- the 16-step tile this record belongs to (steps [16k, 16k+16) of the site) ----
+  // tileBits: FAST_TILE_REGULAR when every step of the tile has the same length, the same one or
+  // two ring evictions (weights w0, w1 constant; with half-hourly steps the steady state is TWO:
+  // a 3e-15 residue of the oldest entry and all but that of the next one, because 240 x (1/48)
+  // is not exactly 5 in floating point) and a plain insert, all slots advancing by one per step,
+  // no events and no year roll-over: a wavefront then needs NO per-step record at all (constants
+  // hoisted, slots counted) and reads this block once per tile.  Bits 16..31: the tile's
+  // FAST_PAR_POS flags, bit 16+k for step 16k' + k.
+  int32_t tileBits;                       // offset 208
+  int32_t tilePad;
+  double tileEndCumGdd, tileEndDayTime;   // 216, 224: cumGdd / dayTime of the tile's last step
+  int32_t pad[6];
 };
 static_assert(sizeof(FastRec) == 256, "FastRec must stay 256 bytes");
+static_assert(offsetof(FastRec, tileBits) == 208 && offsetof(FastRec, tileEndCumGdd) == 216, "FastRec tile block");
+enum : int32_t { FAST_TILE_REGULAR = 1 };
 constexpr int kFastTile = 16;  // steps per LDS tile (4 KB)
 enum : int32_t {
   FAST_PHEN_NEW_YEAR = 1, FAST_TRACK_NEW_YEAR = 2,

@@ -575,7 +575,195 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
     const int tLast = (tileStart + kFastTile) < tEnd ? (tileStart + kFastTile) : tEnd;
     const unsigned char* recB = lds + (curTile & 1) * kTileBytes +
                                 (int)(tFirst - tileFirst(curTile)) * (int)sizeof(FastRec);
-  for (int t = tFirst; t < tLast; t++, recB += sizeof(FastRec)) {
+    int t = tFirst;
+    // ======== regular tile (plan.h, FastRec::tileBits) ==========================================
+    // Every step of the tile has the same length and the same one or two ring evictions with all
+    // slots advancing by one, no events, no year roll-over; and, for THIS wavefront, every member
+    // is alive with an untouched ring epoch and no phenology switch can fire before the tile ends
+    // (year-to-date GDD and the day of year only grow inside a tile).  Then the carbon block needs
+    // no per-step record at all: step length and eviction weights are hoisted, the slots counted,
+    // the day / night flags come from the tile's mask, and the oldest ring value is the one read
+    // as "second eviction" the step before.  Same arithmetic as the general step below; left at
+    // the first step on which a member dies.  (Lean instantiation only: records, all accumulators
+    // and diagnostics take the general step.)
+    if (!Full && ringClean && !(a.options & SIPNET_KOPT_NO_REGULAR_TILES)) {
+      d2 h0, h7;
+      i4 hj;
+      double hW1, hEndGdd, hEndDay;
+      int hTile;
+      asm volatile("ds_read_b128 %0, %7\n\tds_read_b128 %1, %7 offset:112\n\tds_read_b128 %2, %7 offset:128\n\t"
+                   "ds_read_b64 %3, %7 offset:144\n\tds_read_b32 %4, %7 offset:208\n\tds_read_b64 %5, %7 offset:216\n\t"
+                   "ds_read_b64 %6, %7 offset:224\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(h0), "=&v"(h7), "=&v"(hj), "=&v"(hW1), "=&v"(hTile), "=&v"(hEndGdd), "=&v"(hEndDay)
+                   : "v"(ldsAddr(recB)) : "memory");
+      const int tileBits = uni(hTile);
+      const bool phenSafe = (allOn || hEndGdd < minGddOn) && (allOff || hEndDay < minOffDay);
+      if ((tileBits & FAST_TILE_REGULAR) && __builtin_amdgcn_ballot_w64(!phenSafe) == 0) {
+        const R len = (R)h0.x, invLen = (R)h0.y;
+        const int nOps = uni(hj.x) >> 16;
+        const int slots0 = uni(hj.y);
+        auto nextSlot = [](int s) { return s + 1 == SIPNET_RING_SLOTS ? 0 : s + 1; };
+        // two evictions: the first one's value is the one read as second eviction a step earlier
+        const double wA = nOps == 2 ? h7.y : 0.0, wB = nOps == 2 ? hW1 : h7.y;
+        int readSlot = nOps == 2 ? ((slots0 >> 8) & 255) : (slots0 & 255);
+        int insSlot = uni(hj.z);
+        double vPrev = 0.0;
+        if (nOps == 2) {
+          const int s0 = slots0 & 255;
+          vPrev = RingLds ? ringL[s0 * 64 + lane] : (s0 == lastIns ? lastNpp : ringp[(uint32_t)s0 * ncu]);
+        }
+        unsigned dayMask = ((unsigned)tileBits >> 16) >> (t - tileStart);
+        bool stay = true;
+        for (; t < tLast && stay; t++, dayMask >>= 1) {
+          R g1, g2, fSoil, gFine, gCoarse;
+          int facSeq;
+          {
+            WAIT_BEGIN()
+            const unsigned fac = ldsAddr(&mailFac[t & 1][0][lane]);
+            do {
+              if (sizeof(R) == 8) {
+                asm volatile("ds_read_b32 %0, %6\n\tds_read_b64 %1, %7\n\tds_read_b64 %2, %7 offset:512\n\t"
+                             "ds_read_b64 %3, %7 offset:1024\n\tds_read_b64 %4, %7 offset:1536\n\t"
+                             "ds_read_b64 %5, %7 offset:2048\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(facSeq), "=&v"(g1), "=&v"(g2), "=&v"(fSoil), "=&v"(gFine), "=&v"(gCoarse)
+                             : "v"(ldsAddr(&seqFac)), "v"(fac) : "memory");
+              } else {
+                asm volatile("ds_read_b32 %0, %6\n\tds_read_b32 %1, %7\n\tds_read_b32 %2, %7 offset:256\n\t"
+                             "ds_read_b32 %3, %7 offset:512\n\tds_read_b32 %4, %7 offset:768\n\t"
+                             "ds_read_b32 %5, %7 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(facSeq), "=&v"(g1), "=&v"(g2), "=&v"(fSoil), "=&v"(gFine), "=&v"(gCoarse)
+                             : "v"(ldsAddr(&seqFac)), "v"(fac) : "memory");
+              }
+            } while (uni(facSeq) < t);
+            WAIT_END(0)
+          }
+          double rvN = 0.0;
+          if (!RingLds)
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(rvN) : "v"(ringp + (uint32_t)readSlot * ncu) : "memory");
+          const bool useLast = readSlot == lastIns;
+          const bool isDay = (dayMask & 1u) != 0;
+
+          const R eLeaf = (R)plantLeafC, eSoilC = (R)soilC;
+          const R eCoarse = (R)coarseRootC, eFine = (R)fineRootC;
+          const R totalWoodC = (R)(plantWoodC + delta);
+          const R meanNpp = (R)(ringSum * 0.2);
+          const R folResp = eLeaf * g1;
+          const R rVeg = folResp + totalWoodC * g2;
+          const R rCoarseRoot = eCoarse * gCoarse;
+          const R rFineRoot = eFine * gFine;
+          const R rSoil = eSoilC * fSoil;
+          const R woodLitter = totalWoodC * K_wtr;
+          R leafLitter = eLeaf * K_ltr;
+          R leafCreation = meanNpp * K_la, woodCreation = meanNpp * K_wa;
+          R leafOnCreation = 0, leafOnFromWood = 0;
+          // In the general step these three pass through the events / phenology block (they are
+          // merged values there); kept opaque here so that the compiler fuses multiply-adds around
+          // them exactly as it does there -- the two paths must give the same bits, because which
+          // one a wavefront takes depends on the other 63 members of its chunk
+          asm volatile("" : "+v"(leafLitter), "+v"(leafOnCreation), "+v"(leafOnFromWood));
+          const R coarseRootLoss = K_crt * eCoarse, fineRootLoss = K_frt * eFine;
+          R coarseRootCreation = K_ca * meanNpp, fineRootCreation = K_fa * meanNpp;
+          {  // checkNegativeCreation(), limitations.c:146-182, as selects
+            const R leafDeficit = eLeaf * invLen + leafCreation - eLeaf * K_ltr;
+            const R ld = rminv(leafDeficit, R(0));
+            woodCreation += ld;
+            leafCreation -= ld;
+            const R fineDef = eFine * invLen + fineRootCreation - fineRootLoss;
+            const R coarseDef = eCoarse * invLen + coarseRootCreation - coarseRootLoss;
+            const bool fNeg = fineDef < R(0), cNeg = coarseDef < R(0);
+            const R shift = (fNeg != cNeg) ? (fNeg ? fineDef : -coarseDef) : R(0);
+            coarseRootCreation += shift;
+            fineRootCreation -= shift;
+          }
+          plantLeafC += (double)((leafCreation + leafOnCreation - leafLitter) * len);
+          post(&mailLai[(t + 1) & 1][lane], &seqLai, (R)rmax0(plantLeafC) * K_invLcsw, t + 1);
+          plantWoodC += (double)((woodCreation - woodLitter - leafOnFromWood) * len);
+          coarseRootC += (double)((coarseRootCreation - coarseRootLoss -
+                                   (leafOnCreation - leafOnFromWood)) * len);
+          fineRootC += (double)((fineRootCreation - fineRootLoss) * len);
+          const double soilGain = (double)((coarseRootLoss + fineRootLoss + woodLitter + leafLitter - rSoil) * len);
+          const R r_a = rVeg + rFineRoot + rCoarseRoot;
+          const R alloc = leafCreation + woodCreation + fineRootCreation + coarseRootCreation;
+          const bool rootsOk = (plantWoodC > kTiny) && (fineRootC + coarseRootC > kTiny);
+          R photosynthesis = 0;
+          if (isDay) {
+            WAIT_BEGIN()
+            photosynthesis = take(&mailPsn[t & 1][lane], &seqPsn, t);
+            WAIT_END(1)
+          }
+          delta += (double)(((photosynthesis - r_a) - alloc) * len);
+          bool diedNow = false;
+          double deathToSoil0 = 0.0, deathToSoil1 = 0.0;
+          if (__builtin_expect(!(rootsOk && (plantWoodC + delta > kTiny)), 0)) {  // every member was alive
+            ringClean = false;
+            aliveC = false;
+            diedNow = true;
+            if (diedAt < 0) diedAt = t;
+            deathToSoil0 = fineRootC + coarseRootC;
+            deathToSoil1 = plantWoodC + plantLeafC + delta;
+            plantWoodC = 0.0;
+            plantLeafC = 0.0;
+            coarseRootC = 0.0;
+            fineRootC = 0.0;
+            delta = 0.0;
+            ringSum = 0.0;
+          }
+          plantWoodC = rmax0(plantWoodC);
+          plantLeafC = rmax0(plantLeafC);
+          coarseRootC = rmax0(coarseRootC);
+          fineRootC = rmax0(fineRootC);
+          post(&mailAlive[(t + 1) & 1][lane], &seqAlive, diedNow ? R(0) : R(1), t + 1);
+          soilC += soilGain;
+          const bool anyDied = __builtin_amdgcn_ballot_w64(diedNow) != 0;
+          if (__builtin_expect(anyDied, 0)) {
+            if (diedNow) {
+              soilC += deathToSoil0;
+              soilC += deathToSoil1;
+            }
+          }
+          soilC = rmax0(soilC);
+          const R tGpp = photosynthesis * len;
+          const R tRh = rSoil * len;
+          const R tRa = (rCoarseRoot + rFineRoot) * len + rVeg * len;
+          const R tNee = R(-1.0) * ((tGpp - tRa) - tRh);
+          totGpp += (double)tGpp;
+          totNee += (double)tNee;
+          const double npp = (double)(photosynthesis - rVeg - rCoarseRoot - rFineRoot);
+          if (!RingLds) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rvN) :: "memory");
+          const double vNew = RingLds ? ringL[readSlot * 64 + lane] : (useLast ? lastNpp : rvN);
+          if (__builtin_expect(!anyDied, 1)) {
+            ringSum = ffma(-wA, vPrev, ringSum);
+            ringSum = ffma(-wB, vNew, ringSum);
+            ringSum = ffma(npp, (double)len, ringSum);
+          } else {  // a member died in this step: its ring epoch starts over, the others carry on
+            if (!diedNow) {
+              ringSum = ffma(-wA, vPrev, ringSum);
+              ringSum = ffma(-wB, vNew, ringSum);
+              ringSum = ffma(npp, (double)len, ringSum);
+            } else {
+              ringValidFrom = t + 1;
+            }
+            stay = false;  // the general step from the next one on
+          }
+          vPrev = vNew;
+          if (RingLds) {
+            ringL[insSlot * 64 + lane] = npp;
+          } else {
+            ringp[(uint32_t)insSlot * ncu] = npp;
+            lastIns = insSlot;
+            lastNpp = npp;
+          }
+          *oNee = tNee;
+          *oGpp = tGpp;
+          oNee += ldNee;
+          oGpp += ldGpp;
+          readSlot = nextSlot(readSlot);
+          insSlot = nextSlot(insSlot);
+        }
+        recB += (int)(t - tFirst) * (int)sizeof(FastRec);
+      }
+    }
+  for (; t < tLast; t++, recB += sizeof(FastRec)) {
     // record fields of the carbon block (len invLen | tsoil10 cumGdd | dayTime w0 | ints) and the
     // five factors wave W posted for this step, in ONE LDS round trip; the flag is read before
     // the values (DS reads return in order), so a current flag vouches for what follows it

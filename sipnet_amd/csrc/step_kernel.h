@@ -100,6 +100,7 @@ struct FastArgs {
   double* rec;       // [n_steps][SIPNET_NREC][ld] or null
   double* diag;      // [4][ncol]: clamp warnings, balance warnings, max|dC|, max|dN|; or null
   int32_t full;      // 1: take the Full instantiation
+  int32_t options;   // SIPNET_KOPT_* bits the kernels themselves look at
   void* scratchRow;  // [ncol] doubles: target of the stores of planes the caller left NULL
   int32_t plainExp;  // 1: every member has dVpdExp == 2 and soilRespMoistEffect == 1
   int32_t numCUs;                // compute units of the device (kernel / occupancy choice)

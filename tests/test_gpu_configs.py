@@ -298,3 +298,37 @@ def test_non_plain_exponents_take_the_general_instantiations(oracle, base):
         b.close()
         assert li["kernel"] == expect, li
         assert np.abs(got - want).max() < TOL_F64, expect
+
+
+def test_regular_tile_path_equals_the_general_step_bit_for_bit(oracle, base):
+    """the cooperative kernel's carbon wave runs regular 16-step tiles (uniform step length, the
+    steady one- or two-eviction ring pattern, no events / year roll-over / pending phenology, every
+    member of the wavefront alive) without per-step records, and everything else through the
+    general step.  Which path a wavefront takes depends on its neighbours (one dead member sends 64
+    members down the general path), so the two must give the same bits: the same ensemble with the
+    path disabled (SIPNET_KOPT_NO_REGULAR_TILES), with a never-alive member in one chunk, over a
+    whole year (spring leaf-on and autumn leaf-off fall inside tiles), split at odd steps"""
+    flags = sa.flags_from()
+    clim = year_clim()
+    members = synth.perturbed_params(base, 192)
+    members[70, pi("plantWoodInit")] = 0.0               # chunk 1 never leaves the general path
+    members[130] = members[3]                            # the same member in chunk 0 and chunk 2
+    T = clim.n_steps
+    outs = {}
+    for kernel in (sa.KERNEL_COOP_LDS, sa.KERNEL_COOP_HBM):
+        for opt in (0, sa.KOPT_NO_REGULAR_TILES):
+            b = build(flags, [clim], members, sa.F64, kernel, opt)
+            planes, _ = b.alloc_outputs(T)
+            for a, z in ((0, 5), (5, 8003), (8003, T)):
+                b.run(a, z - a, planes=planes[:, a:z])
+            outs[(kernel, opt)] = (planes.cpu().numpy(), b.get_state(), b.get_rings())
+            b.close()
+        fastp, gen = outs[(kernel, 0)], outs[(kernel, sa.KOPT_NO_REGULAR_TILES)]
+        np.testing.assert_array_equal(fastp[0], gen[0])
+        np.testing.assert_array_equal(fastp[1], gen[1])
+        np.testing.assert_array_equal(fastp[2], gen[2])
+        assert np.array_equal(fastp[0][:, :, 130], fastp[0][:, :, 3])
+    np.testing.assert_array_equal(outs[(sa.KERNEL_COOP_LDS, 0)][0], outs[(sa.KERNEL_COOP_HBM, 0)][0])
+    pick = np.r_[0:8, 64:72, 128:136]
+    want, _, _ = oracle.run_block(flags, members[pick], clim)
+    assert np.abs(outs[(sa.KERNEL_COOP_LDS, 0)][0][:, :, pick] - want).max() < TOL_F64

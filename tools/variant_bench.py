@@ -16,7 +16,7 @@ sys.path.insert(0, REPO)
 CHILD = r"""
 import json, os, sys
 sys.path.insert(0, sys.argv[1])
-lib, wl_name, reps, kern = sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5]
+lib, wl_name, reps, kern, kopt = sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5], int(sys.argv[6])
 from sipnet_amd import _lib
 if lib != "product":
     _lib.use_library(lib)
@@ -31,7 +31,7 @@ base, _ = sa.read_params(os.path.join(sys.argv[1], "sipnet_amd", "data", wl.get(
 S, M, T = wl["sites"], wl["members"], wl["steps"]
 prec = sa.F64 if wl["prec"] == "f64" else sa.F32_MIXED
 K = dict(auto=sa.KERNEL_AUTO, one_wave=sa.KERNEL_ONE_WAVE, coop_lds=sa.KERNEL_COOP_LDS, coop_hbm=sa.KERNEL_COOP_HBM)[kern]
-b = sa.Batch(flags, S, M, prec, fast_math=True if prec == sa.F64 else None, kernel=K)
+b = sa.Batch(flags, S, M, prec, fast_math=True if prec == sa.F64 else None, kernel=K, kernel_options=kopt)
 members = synth.perturbed_params(base, M)
 clims = [synth.convert_raw(synth.round_like_file(synth.half_hourly_year_raw(T, site=s))) for s in range(S)]
 for s in range(S):
@@ -53,6 +53,7 @@ if __name__ == "__main__":
     ap.add_argument("--workload", default="c10k")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--kernel", default="auto")
+    ap.add_argument("--kopt", type=int, default=0, help="SIPNET_KOPT_* bits (8 = no regular tiles)")
     ap.add_argument("names", nargs="*")
     args = ap.parse_args()
     vdir = os.path.join(REPO, "build", "variants")
@@ -60,7 +61,7 @@ if __name__ == "__main__":
     for n in names:
         lib = "product" if n == "product" else os.path.join(vdir, n, "libsipnet_amd.so")
         fl = "" if n == "product" else open(os.path.join(vdir, n, "FLAGS")).read().strip()
-        r = subprocess.run([sys.executable, "-c", CHILD, REPO, lib, args.workload, str(args.reps), args.kernel],
+        r = subprocess.run([sys.executable, "-c", CHILD, REPO, lib, args.workload, str(args.reps), args.kernel, str(args.kopt)],
                            capture_output=True, text=True, timeout=600)
         line = r.stdout.strip().splitlines()[-1] if r.returncode == 0 and r.stdout.strip() else "FAILED rc=%d %s" % (r.returncode, r.stderr[-400:])
         print(f"{n:24s} [{fl}] {line}", flush=True)
