@@ -5,10 +5,11 @@
 // kind -- while three quarters of the chip idle.  A member-step is a
 // chain of three blocks with thin interfaces:
 //
-//   L  light      lai(t)            -> potGrossPsn(t)          (dTemp, dVpd, 7-layer Simpson)
+//   L  light      lai(t)            -> potGrossPsn(t)          (dTemp, dVpd, 7-layer Simpson);
+//                 also, while it waits for the leaf area (and all night): every factor of C's
+//                 respiration terms that depends on climate and parameters only (Q10 terms, tillage)
 //   W  water      potGrossPsn(t)    -> photosynthesis(t), ET(t), soilWater(t+1), snow(t+1);
-//                 also every factor of C's respiration terms that depends on climate, soil
-//                 water and parameters only (Q10 terms, moisture effect, tillage)
+//                 also the soil-moisture effect on C's heterotrophic respiration (its own state)
 //   C  carbon     photosynthesis(t), factors(t) -> pools(t+1), ring, NEE(t), GPP(t), lai(t+1)
 //
 // so a workgroup is three wavefronts on three SIMDs of one CU, each running its OWN time loop
@@ -101,16 +102,23 @@ __device__ __forceinline__ void takePair(const float* slotA, const int* flagA, c
                    "v"((unsigned)(size_t)slotB) : "memory");
   } while (uni(fa) < step || uni(fb) < step);
 }
-// five values + flag (wave W -> wave C)
-template <class R>
-__device__ __forceinline__ void post5(R* base, int* flag, R v0, R v1, R v2, R v3, R v4, int step) {
-  base[0 * 64] = v0;  // DS writes of one wave execute in issue order ...
-  base[1 * 64] = v1;
-  base[2 * 64] = v2;
-  base[3 * 64] = v3;
-  base[4 * 64] = v4;
-  asm volatile("" ::: "memory");
-  *(volatile int*)flag = step;  // ... so the flag lands after the values
+// five values + flag.  DS writes of one wave execute in issue order, so the flag lands after the
+// values.  Written as DS instructions by hand: the compiler's version of the flag store is a FLAT
+// store followed by a full `s_waitcnt vmcnt(0)`, and its value stores wait for the LDS-DMA tile
+// in flight.
+__device__ __forceinline__ void post5(double* base, int* flag, double v0, double v1, double v2, double v3,
+                                      double v4, int step) {
+  asm volatile("ds_write_b64 %0, %1\n\tds_write_b64 %0, %2 offset:512\n\tds_write_b64 %0, %3 offset:1024\n\t"
+               "ds_write_b64 %0, %4 offset:1536\n\tds_write_b64 %0, %5 offset:2048\n\tds_write_b32 %6, %7"
+               :: "v"(ldsAddr(base)), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(ldsAddr(flag)), "v"(step)
+               : "memory");
+}
+__device__ __forceinline__ void post5(float* base, int* flag, float v0, float v1, float v2, float v3,
+                                      float v4, int step) {
+  asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:256\n\tds_write_b32 %0, %3 offset:512\n\t"
+               "ds_write_b32 %0, %4 offset:768\n\tds_write_b32 %0, %5 offset:1024\n\tds_write_b32 %6, %7"
+               :: "v"(ldsAddr(base)), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(ldsAddr(flag)), "v"(step)
+               : "memory");
 }
 // progress-only wait (no value)
 __device__ __forceinline__ void awaitAtLeast(const int* flag, int step) {
@@ -176,9 +184,10 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
   // per-wave private record tiles (each wave stages and awaits its own DMA) + mailboxes
   __shared__ alignas(16) unsigned char ldsTiles[3][2 * kTileBytes];
   __shared__ R mailLai[2][64], mailPgp[2][64], mailPsn[2][64];
-  __shared__ R mailFac[2][5][64];  // g1 g2 fSoil gFine gCoarse of a step (see wave W)
+  __shared__ R mailFac[2][5][64];  // g1 g2 qSoilT gFine gCoarse of a step (wave L: climate x parameters only)
+  __shared__ R mailMoist[2][64];   // the soil-moisture effect on heterotrophic respiration (wave W: its state)
   __shared__ R mailAlive[2][64];   // 0: the member died in the step before (its posted lai is void)
-  __shared__ int seqLai, seqPgp, seqPsn, seqFac, seqAlive;
+  __shared__ int seqLai, seqPgp, seqPsn, seqFac, seqAlive, seqMoist;
   // The running-mean ring of the 64 members lives in LDS for the whole launch (250 x 64 x 8 B =
   // 125 KB; one workgroup per CU).  A wave that stores to HBM every step must not also load
   // from HBM every step: vector-memory operations complete in issue order, so each step's ring
@@ -221,6 +230,7 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
     seqPgp = tBegin - 1;
     seqPsn = tBegin - 1;
     seqFac = tBegin - 1;
+    seqMoist = tBegin - 1;
     seqAlive = tBegin - 1;
   }
   __syncthreads();  // the only workgroup barrier: flags initialised before anyone spins
@@ -261,6 +271,18 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
     const R K_slope = (R)PRM(dVpdSlope), K_vexp = (R)PRM(dVpdExp);
     const R K_attl = (R)(-PRM(attenuation) * (1.0 / 6.0) * kLog2e);
     const R K_invHalf = (R)(1.0 / PRM(halfSatPar));
+    // for wave C's respiration terms: everything that depends on climate and parameters only
+    const R K_frozThr = (R)PRM(frozenSoilThreshold);
+    const R K_lgVeg = (R)log2(PRM(vegRespQ10)), K_lgSoil = (R)log2(PRM(soilRespQ10));
+    const R K_lgFine = (R)log2(PRM(fineRootQ10)), K_lgCoarse = (R)log2(PRM(coarseRootQ10));
+    const R K_fol = (R)((PRM(baseFolRespFrac) * PRM(aMax)) *
+                        (kCWeight * (1.0 / kTen9) * (PRM(leafCSpWt) / PRM(cFracLeaf)) * kSecPerDay) *
+                        (1.0 / PRM(leafCSpWt)) * exp2(-(PRM(psnTOpt) / 10.0) * log2(PRM(vegRespQ10))));
+    const R K_frozFolEff = (R)PRM(frozenSoilFolREff);
+    const R K_bvr = (R)PRM(baseVegResp), K_bsr = (R)PRM(baseSoilResp);
+    const R K_bfr = (R)PRM(baseFineRootResp), K_bcr = (R)PRM(baseCoarseRootResp);
+    R qSoil = 0, gFine = 0, gCoarse = 0;
+    bool haveQ = false;
     WAIT_DECL()
     for (int tileStart = curTile * kFastTile; tileStart < tEnd; tileStart += kFastTile, curTile++) {
       if (tileStart > tBegin) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMA of 16 steps ago
@@ -270,12 +292,41 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
       const unsigned char* recB = lds + (curTile & 1) * kTileBytes +
                                   (int)(tFirst - tileFirst(curTile)) * (int)sizeof(FastRec);
       for (int t = tFirst; t < tLast; t++, recB += sizeof(FastRec)) {
-        d2 q1, q2;
+        d2 q1, q2, q3, q5;
+        double q6x;
         int bitsV;
-        asm volatile("ds_read_b32 %0, %3 offset:128\n\tds_read_b128 %1, %3 offset:16\n\t"
-                     "ds_read_b128 %2, %3 offset:32\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(bitsV), "=&v"(q1), "=&v"(q2) : "v"(ldsAddr(recB)) : "memory");
+        asm volatile("ds_read_b32 %0, %6 offset:128\n\tds_read_b128 %1, %6 offset:16\n\t"
+                     "ds_read_b128 %2, %6 offset:32\n\tds_read_b128 %3, %6 offset:48\n\t"
+                     "ds_read_b128 %4, %6 offset:80\n\tds_read_b64 %5, %6 offset:96\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(bitsV), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q5), "=&v"(q6x)
+                     : "v"(ldsAddr(recB)) : "memory");
         const int bits = uni(bitsV);
+        // ---- for wave C: the climate / parameter part of its respiration terms of THIS step
+        // (vegResp sipnet.c:1051-1068, calcRootResp :1073, calcSoilRespiration :1132-1148 with
+        // depeffects.c:71-74):  folResp = leafC * g1,  rVeg = folResp + totalWoodC * g2,
+        // rSoil = soilC * (qSoilT * moistEff[wave W]),  rFineRoot = fineRootC * gFine,
+        // rCoarseRoot = coarseRootC * gCoarse.  Nothing here depends on member state, so this
+        // wave -- idle at night and while it waits for the leaf area by day -- runs it ahead of
+        // C: the slot of step t was last used for step t-2, which C is past once it has posted
+        // the leaf area of step t-1
+        {
+          WAIT_BEGIN()
+          awaitAtLeast(&seqLai, t - 1);
+          WAIT_END(1)
+          const R vegQ = fexp2((R)q5.y * K_lgVeg, EC);
+          R g1 = K_fol * vegQ;
+          g1 = ((R)q1.y < K_frozThr) ? g1 * K_frozFolEff : g1;
+          const R g2 = K_bvr * vegQ;
+          if (!haveQ || !(bits & FAST_TSOIL_SAME)) {
+            const R tsoil10 = (R)q6x;
+            qSoil = fexp2(tsoil10 * K_lgSoil, EC);
+            gFine = K_bfr * fexp2(tsoil10 * K_lgFine, EC);
+            gCoarse = K_bcr * fexp2(tsoil10 * K_lgCoarse, EC);
+            haveQ = true;
+          }
+          const R qSoilT = K_bsr * qSoil * (R)q3.x;
+          post5(&mailFac[t & 1][0][lane], &seqFac, g1, g2, qSoilT, gFine, gCoarse, t);
+        }
         if (!(bits & FAST_PAR_POS)) continue;  // night: potGrossPsn = 0, nobody waits for it
         const R tair = (R)q1.x;
         // climate-only factors first, then the leaf area of this step
@@ -312,18 +363,7 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
     const R K_immed = (R)PRM(immedEvapFrac), K_ff = (R)PRM(fastFlowFrac);
     const R K_invRd = (R)(1.0 / PRM(rdConst)), K_rd = (R)PRM(rdConst), K_melt = (R)PRM(snowMelt);
     const R K_c1l = (R)(PRM(rSoilConst1) * kLog2e), K_c2l = (R)(PRM(rSoilConst2) * kLog2e);
-    // for wave C's respiration factors
-    const R K_lgVeg = (R)log2(PRM(vegRespQ10)), K_lgSoil = (R)log2(PRM(soilRespQ10));
-    const R K_lgFine = (R)log2(PRM(fineRootQ10)), K_lgCoarse = (R)log2(PRM(coarseRootQ10));
-    const R K_fol = (R)((PRM(baseFolRespFrac) * PRM(aMax)) *
-                        (kCWeight * (1.0 / kTen9) * (PRM(leafCSpWt) / PRM(cFracLeaf)) * kSecPerDay) *
-                        (1.0 / PRM(leafCSpWt)) * exp2(-(PRM(psnTOpt) / 10.0) * log2(PRM(vegRespQ10))));
-    const R K_frozFolEff = (R)PRM(frozenSoilFolREff);
-    const R K_bvr = (R)PRM(baseVegResp), K_bsr = (R)PRM(baseSoilResp);
-    const R K_bfr = (R)PRM(baseFineRootResp), K_bcr = (R)PRM(baseCoarseRootResp);
     const R K_moistExp = (R)PRM(soilRespMoistEffect);
-    R qSoil = 0, gFine = 0, gCoarse = 0;
-    bool haveQ = false;
     double soilWater = ST(soilWater), snow = ST(snow);
     R* __restrict__ oEt = (R*)(a.et ? a.et : a.scratchRow) + col;
     const int64_t ldEt = a.et ? a.ld : 0;
@@ -343,13 +383,11 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
                                   (int)(tFirst - tileFirst(curTile)) * (int)sizeof(FastRec);
       for (int t = tFirst; t < tLast; t++, recB += sizeof(FastRec)) {
         d2 q0, q1, q2, q3, q4, q5;
-        double q6x;
         i4 j0;
-        asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\tds_read_b128 %2, %8 offset:32\n\t"
-                     "ds_read_b128 %3, %8 offset:48\n\tds_read_b128 %4, %8 offset:64\n\t"
-                     "ds_read_b128 %5, %8 offset:80\n\tds_read_b64 %6, %8 offset:96\n\t"
-                     "ds_read_b128 %7, %8 offset:128\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4), "=&v"(q5), "=&v"(q6x), "=&v"(j0)
+        asm volatile("ds_read_b128 %0, %7\n\tds_read_b128 %1, %7 offset:16\n\tds_read_b128 %2, %7 offset:32\n\t"
+                     "ds_read_b128 %3, %7 offset:48\n\tds_read_b128 %4, %7 offset:64\n\t"
+                     "ds_read_b128 %5, %7 offset:80\n\tds_read_b128 %6, %7 offset:128\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4), "=&v"(q5), "=&v"(j0)
                      : "v"(ldsAddr(recB)) : "memory");
         const int32_t* rareI = (const int32_t*)(recB + 184);
         const R len = (R)q0.x, invLen = (R)q0.y, tair = (R)q1.x, tsoil = (R)q1.y;
@@ -359,29 +397,15 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
         const double oldSoilWater = soilWater;  // before this step's irrigation, sipnet.c:1470
         const bool frozen = tsoil < K_frozThr;
 
-        // ---- for wave C: the climate / soil-water / parameter part of its respiration terms
-        // of THIS step (vegResp sipnet.c:1051-1068, calcRootResp :1073, calcSoilRespiration
-        // :1132-1148 with depeffects.c:23-87), posted before anything else so that C never
-        // waits for it:  folResp = leafC * g1,  rVeg = folResp + totalWoodC * g2,
-        // rSoil = soilC * fSoil,  rFineRoot = fineRootC * gFine,  rCoarseRoot = coarseRootC * gCoarse
+        // ---- for wave C: the soil-moisture effect on heterotrophic respiration of THIS step
+        // (depeffects.c:23-57; the Q10 / tillage part comes from wave L), posted before anything
+        // else so that C never waits for it
         {
-          const R vegQ = fexp2((R)q5.y * K_lgVeg, EC);
-          R g1 = K_fol * vegQ;
-          g1 = frozen ? g1 * K_frozFolEff : g1;
-          const R g2 = K_bvr * vegQ;
-          if (!haveQ || !(bits & FAST_TSOIL_SAME)) {
-            const R tsoil10 = (R)q6x;
-            qSoil = fexp2(tsoil10 * K_lgSoil, EC);
-            gFine = K_bfr * fexp2(tsoil10 * K_lgFine, EC);
-            gCoarse = K_bcr * fexp2(tsoil10 * K_lgCoarse, EC);
-            haveQ = true;
-          }
           R moistEff = clip01(eWater * K_invWhc);
           if (!PlainExp && __builtin_amdgcn_ballot_w64(K_moistExp != R(1)) != 0)  // pow only where some member needs it
-      moistEff = (K_moistExp == R(1)) ? moistEff : fpow(moistEff, K_moistExp);
+            moistEff = (K_moistExp == R(1)) ? moistEff : fpow(moistEff, K_moistExp);
           moistEff = (bits & FAST_TSOIL_NEG) ? R(1) : moistEff;
-          const R fSoil = K_bsr * moistEff * qSoil * (R)q3.x;
-          post5(&mailFac[t & 1][0][lane], &seqFac, g1, g2, fSoil, gFine, gCoarse, t);
+          post(&mailMoist[t & 1][lane], &seqMoist, moistEff, t);
         }
 
         // everything that does not need the light block first
@@ -615,28 +639,36 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
         unsigned dayMask = ((unsigned)tileBits >> 16) >> (t - tileStart);
         bool stay = true;
         for (; t < tLast && stay; t++, dayMask >>= 1) {
-          R g1, g2, fSoil, gFine, gCoarse;
-          int facSeq;
+          // this step's factors: five from wave L, the moisture effect from wave W (each flag read
+          // before its values, one LDS round trip when both are current)
+          R g1, g2, qSoilT, gFine, gCoarse, moistEff;
+          int facSeq, moistSeq;
           {
             WAIT_BEGIN()
             const unsigned fac = ldsAddr(&mailFac[t & 1][0][lane]);
+            const unsigned mst = ldsAddr(&mailMoist[t & 1][lane]);
             do {
               if (sizeof(R) == 8) {
-                asm volatile("ds_read_b32 %0, %6\n\tds_read_b64 %1, %7\n\tds_read_b64 %2, %7 offset:512\n\t"
-                             "ds_read_b64 %3, %7 offset:1024\n\tds_read_b64 %4, %7 offset:1536\n\t"
-                             "ds_read_b64 %5, %7 offset:2048\n\ts_waitcnt lgkmcnt(0)"
-                             : "=&v"(facSeq), "=&v"(g1), "=&v"(g2), "=&v"(fSoil), "=&v"(gFine), "=&v"(gCoarse)
-                             : "v"(ldsAddr(&seqFac)), "v"(fac) : "memory");
+                asm volatile("ds_read_b32 %0, %8\n\tds_read_b64 %1, %9\n\tds_read_b64 %2, %9 offset:512\n\t"
+                             "ds_read_b64 %3, %9 offset:1024\n\tds_read_b64 %4, %9 offset:1536\n\t"
+                             "ds_read_b64 %5, %9 offset:2048\n\tds_read_b32 %6, %10\n\tds_read_b64 %7, %11\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(facSeq), "=&v"(g1), "=&v"(g2), "=&v"(qSoilT), "=&v"(gFine), "=&v"(gCoarse),
+                               "=&v"(moistSeq), "=&v"(moistEff)
+                             : "v"(ldsAddr(&seqFac)), "v"(fac), "v"(ldsAddr(&seqMoist)), "v"(mst) : "memory");
               } else {
-                asm volatile("ds_read_b32 %0, %6\n\tds_read_b32 %1, %7\n\tds_read_b32 %2, %7 offset:256\n\t"
-                             "ds_read_b32 %3, %7 offset:512\n\tds_read_b32 %4, %7 offset:768\n\t"
-                             "ds_read_b32 %5, %7 offset:1024\n\ts_waitcnt lgkmcnt(0)"
-                             : "=&v"(facSeq), "=&v"(g1), "=&v"(g2), "=&v"(fSoil), "=&v"(gFine), "=&v"(gCoarse)
-                             : "v"(ldsAddr(&seqFac)), "v"(fac) : "memory");
+                asm volatile("ds_read_b32 %0, %8\n\tds_read_b32 %1, %9\n\tds_read_b32 %2, %9 offset:256\n\t"
+                             "ds_read_b32 %3, %9 offset:512\n\tds_read_b32 %4, %9 offset:768\n\t"
+                             "ds_read_b32 %5, %9 offset:1024\n\tds_read_b32 %6, %10\n\tds_read_b32 %7, %11\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(facSeq), "=&v"(g1), "=&v"(g2), "=&v"(qSoilT), "=&v"(gFine), "=&v"(gCoarse),
+                               "=&v"(moistSeq), "=&v"(moistEff)
+                             : "v"(ldsAddr(&seqFac)), "v"(fac), "v"(ldsAddr(&seqMoist)), "v"(mst) : "memory");
               }
-            } while (uni(facSeq) < t);
+            } while (uni(facSeq) < t || uni(moistSeq) < t);
             WAIT_END(0)
           }
+          const R fSoil = qSoilT * moistEff;
           double rvN = 0.0;
           if (!RingLds)
             asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(rvN) : "v"(ringp + (uint32_t)readSlot * ncu) : "memory");
@@ -769,34 +801,40 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
     // the values (DS reads return in order), so a current flag vouches for what follows it
     d2 q0, q6, q7;
     i4 j0;
-    R g1, g2, fSoil, gFine, gCoarse;
-    int facSeq;
+    R g1, g2, qSoilT, gFine, gCoarse, moistEff;
+    int facSeq, moistSeq;
     {
       WAIT_BEGIN()
       const unsigned fac = ldsAddr(&mailFac[t & 1][0][lane]);
+      const unsigned mst = ldsAddr(&mailMoist[t & 1][lane]);
       // (re-reading the record while spinning is harmless; one asm statement defines every value,
-      // so no copies are needed when the first look already finds the flag current)
+      // so no copies are needed when the first look already finds the flags current)
       do {
         if (sizeof(R) == 8) {
-          asm volatile("ds_read_b128 %0, %10\n\tds_read_b128 %1, %10 offset:96\n\tds_read_b128 %2, %10 offset:112\n\t"
-                       "ds_read_b128 %3, %10 offset:128\n\tds_read_b32 %4, %11\n\t"
-                       "ds_read_b64 %5, %12\n\tds_read_b64 %6, %12 offset:512\n\tds_read_b64 %7, %12 offset:1024\n\t"
-                       "ds_read_b64 %8, %12 offset:1536\n\tds_read_b64 %9, %12 offset:2048\n\ts_waitcnt lgkmcnt(0)"
+          asm volatile("ds_read_b128 %0, %12\n\tds_read_b128 %1, %12 offset:96\n\tds_read_b128 %2, %12 offset:112\n\t"
+                       "ds_read_b128 %3, %12 offset:128\n\tds_read_b32 %4, %13\n\t"
+                       "ds_read_b64 %5, %14\n\tds_read_b64 %6, %14 offset:512\n\tds_read_b64 %7, %14 offset:1024\n\t"
+                       "ds_read_b64 %8, %14 offset:1536\n\tds_read_b64 %9, %14 offset:2048\n\t"
+                       "ds_read_b32 %10, %15\n\tds_read_b64 %11, %16\n\ts_waitcnt lgkmcnt(0)"
                        : "=&v"(q0), "=&v"(q6), "=&v"(q7), "=&v"(j0), "=&v"(facSeq), "=&v"(g1), "=&v"(g2),
-                         "=&v"(fSoil), "=&v"(gFine), "=&v"(gCoarse)
-                       : "v"(ldsAddr(recB)), "v"(ldsAddr(&seqFac)), "v"(fac) : "memory");
+                         "=&v"(qSoilT), "=&v"(gFine), "=&v"(gCoarse), "=&v"(moistSeq), "=&v"(moistEff)
+                       : "v"(ldsAddr(recB)), "v"(ldsAddr(&seqFac)), "v"(fac), "v"(ldsAddr(&seqMoist)), "v"(mst)
+                       : "memory");
         } else {
-          asm volatile("ds_read_b128 %0, %10\n\tds_read_b128 %1, %10 offset:96\n\tds_read_b128 %2, %10 offset:112\n\t"
-                       "ds_read_b128 %3, %10 offset:128\n\tds_read_b32 %4, %11\n\t"
-                       "ds_read_b32 %5, %12\n\tds_read_b32 %6, %12 offset:256\n\tds_read_b32 %7, %12 offset:512\n\t"
-                       "ds_read_b32 %8, %12 offset:768\n\tds_read_b32 %9, %12 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+          asm volatile("ds_read_b128 %0, %12\n\tds_read_b128 %1, %12 offset:96\n\tds_read_b128 %2, %12 offset:112\n\t"
+                       "ds_read_b128 %3, %12 offset:128\n\tds_read_b32 %4, %13\n\t"
+                       "ds_read_b32 %5, %14\n\tds_read_b32 %6, %14 offset:256\n\tds_read_b32 %7, %14 offset:512\n\t"
+                       "ds_read_b32 %8, %14 offset:768\n\tds_read_b32 %9, %14 offset:1024\n\t"
+                       "ds_read_b32 %10, %15\n\tds_read_b32 %11, %16\n\ts_waitcnt lgkmcnt(0)"
                        : "=&v"(q0), "=&v"(q6), "=&v"(q7), "=&v"(j0), "=&v"(facSeq), "=&v"(g1), "=&v"(g2),
-                         "=&v"(fSoil), "=&v"(gFine), "=&v"(gCoarse)
-                       : "v"(ldsAddr(recB)), "v"(ldsAddr(&seqFac)), "v"(fac) : "memory");
+                         "=&v"(qSoilT), "=&v"(gFine), "=&v"(gCoarse), "=&v"(moistSeq), "=&v"(moistEff)
+                       : "v"(ldsAddr(recB)), "v"(ldsAddr(&seqFac)), "v"(fac), "v"(ldsAddr(&seqMoist)), "v"(mst)
+                       : "memory");
         }
-      } while (uni(facSeq) < t);
+      } while (uni(facSeq) < t || uni(moistSeq) < t);
       WAIT_END(0)
     }
+    const R fSoil = qSoilT * moistEff;
     const double* rare = (const double*)(recB + 144);
     const int32_t* rareI = (const int32_t*)(recB + 184);
     CSTAMP(0)

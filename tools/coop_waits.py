@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""dev (GPU box): who waits for whom in the cooperative kernel.  Needs the diagnostic build
+`python tools/build_variants.py waits=-DSIPNET_WAITS` (sums s_memtime differences around every
+hand-over wait of workgroup 0).  Prints cycles per step (100 MHz s_memtime ticks x 24 at 2.4 GHz)."""
+import ctypes as C, os, sys
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from sipnet_amd import _lib
+_lib.use_library(os.path.join(REPO, "build", "variants", "waits", "libsipnet_amd.so"))
+import torch, sipnet_amd as sa
+from sipnet_amd import synth
+flags = sa.flags_from()
+base, _ = sa.read_params(os.path.join(REPO, "sipnet_amd", "data", "base_forest.param"), flags)
+M, T = 10240, 17520
+b = sa.Batch(flags, 1, M, sa.F64, fast_math=True, kernel_options=int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+b.set_climate(0, synth.convert_raw(synth.round_like_file(synth.half_hourly_year_raw(T))))
+b.set_params(0, synth.perturbed_params(base, M))
+b.setup(); b.run(want_planes=True); torch.cuda.synchronize()
+b.setup(); b.run(want_planes=True); torch.cuda.synchronize()
+out = (C.c_ulonglong * 16)()
+_lib.lib().sipnet_debug_read_coop_waits(out)
+tick = 24.0   # s_memtime counts at 100 MHz; 2.4 GHz core clock
+names = {0: "L: wait for lai", 3: "L: total", 4: "W: take pgp+alive", 5: "W: wait for C's progress", 7: "W: total",
+         8: "C: take factors (+record)", 9: "C: take psn", 11: "C: total"}
+print("kernel", b.last_launch()["kernel"], "%.2f ms" % b.last_kernel_ms())
+for k in sorted(names):
+    print("%-28s %8.0f cycles/step" % (names[k], out[k] * tick / T))
