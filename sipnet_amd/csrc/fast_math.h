@@ -20,12 +20,16 @@ __device__ __forceinline__ float ffma(float a, float b, float c) { return __buil
 // 2^x: n = rint(x), 2^(x-n) by a polynomial on [-0.5, 0.5] -- the interpolant of (2^f - 1)/f
 // through the Chebyshev nodes, coefficients correctly rounded from a 50-digit computation
 // (tools/fit_exp2.py prints them and the measured error) -- scaled with v_ldexp_f64.
-//   degree 11: |rel err| <= 1.7e-16 (the shipped build)   degree 9: 3.7e-14   degree 8: 2.1e-12
+//   degree 11: |rel err| <= 1.7e-16   degree 9: 3.7e-14 (the shipped build)   degree 8: 2.1e-12
+// Degree 9 spends some of the tolerance (the bar is |dNEE| < 1e-6, the tests hold 1e-9): c10k's
+// worst |dNEE| against the reference goes from 2.5e-16 to 1.4e-14 and the light wave's chain
+// lai -> potential photosynthesis gets 14 instructions shorter (c10k -3 %, c4 -6 %); degree 8
+// measured no faster than 9.
 // The coefficients live in SGPR pairs for the whole time loop (a VOP3 fma takes one scalar
 // operand): left as literals, hipcc re-materialises them with v_mov_b64 at each of the 13
 // call sites of a step, which costs as much as the polynomial itself.
 #ifndef SIPNET_EXP2_DEGREE
-#define SIPNET_EXP2_DEGREE 11
+#define SIPNET_EXP2_DEGREE 9
 #endif
 struct Exp2Coef {
   double c1, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11;

@@ -79,28 +79,75 @@ __device__ __forceinline__ float take(const float* slot, const int* flag, int st
 typedef double d2_t __attribute__((ext_vector_type(2)));
 typedef int i4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ unsigned ldsAddr(const void* p) { return (unsigned)(size_t)p; }
-// two independent mailboxes (each flag, then its value) in ONE round trip
-__device__ __forceinline__ void takePair(const double* slotA, const int* flagA, const double* slotB,
-                                         const int* flagB, int step, double& a, double& b) {
-  int fa, fb;
-  do {
-    asm volatile("ds_read_b32 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b32 %2, %6\n\tds_read_b64 %3, %7\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(fa), "=&v"(a), "=&v"(fb), "=&v"(b)
-                 : "v"((unsigned)(size_t)flagA), "v"((unsigned)(size_t)slotA), "v"((unsigned)(size_t)flagB),
-                   "v"((unsigned)(size_t)slotB) : "memory");
-  } while (uni(fa) < step || uni(fb) < step);
+// The "alive" confirmation of wave C is ONE per-lane word: magnitude = step + 2 (so that 0 / 1 are
+// "nothing yet" whatever the first step of a launch is), negative when the member died in the
+// step before (its posted leaf area is void).  Sequence and value travel in one DS operation.
+__device__ __forceinline__ int aliveWord(int step, bool died) { return died ? -(step + 2) : (step + 2); }
+__device__ __forceinline__ void postAlive(int* slot, int step, bool died) {
+  asm volatile("ds_write_b32 %0, %1" :: "v"((unsigned)(size_t)slot), "v"(aliveWord(step, died)) : "memory");
 }
-__device__ __forceinline__ void takePair(const float* slotA, const int* flagA, const float* slotB,
-                                         const int* flagB, int step, float& a, float& b) {
-  int fa, fb;
+// wave W: potential photosynthesis of wave L (flag, then value) and wave C's alive word, one round trip
+__device__ __forceinline__ void takePgp(const double* slot, const int* flag, const int* alive, int step,
+                                        double& pgp, bool& died) {
+  int f, w;
   do {
-    asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %5\n\tds_read_b32 %2, %6\n\tds_read_b32 %3, %7\n\t"
+    asm volatile("ds_read_b32 %0, %3\n\tds_read_b64 %1, %4\n\tds_read_b32 %2, %5\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(f), "=&v"(pgp), "=&v"(w)
+                 : "v"((unsigned)(size_t)flag), "v"((unsigned)(size_t)slot), "v"((unsigned)(size_t)alive) : "memory");
+  } while (uni(f) < step || uni(w < 0 ? -w : w) < step + 2);
+  died = w < 0;
+}
+__device__ __forceinline__ void takePgp(const float* slot, const int* flag, const int* alive, int step,
+                                        float& pgp, bool& died) {
+  int f, w;
+  do {
+    asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %4\n\tds_read_b32 %2, %5\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(f), "=&v"(pgp), "=&v"(w)
+                 : "v"((unsigned)(size_t)flag), "v"((unsigned)(size_t)slot), "v"((unsigned)(size_t)alive) : "memory");
+  } while (uni(f) < step || uni(w < 0 ? -w : w) < step + 2);
+  died = w < 0;
+}
+// wave C: this step's six factors -- rows 0..4 of the block from wave L, row 5 (the moisture
+// effect) from wave W -- and both producers' sequence flags: the two flags in one ds_read2_b32
+// (they are neighbours), the six values in three ds_read2st64 (rows are 64 elements apart).
+// Flags are read before the values (DS reads return in order): current flags vouch for them.
+typedef double d2v __attribute__((ext_vector_type(2)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef int i2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void takeFactors(const double* block, const int* flags2, int step, double& g1,
+                                            double& g2, double& qSoilT, double& gFine, double& gCoarse,
+                                            double& moist) {
+  i2v f;
+  d2v a, b, c;
+  do {
+#ifdef SIPNET_NO_READ2
+    asm volatile("ds_read2_b32 %0, %7 offset1:1\n\tds_read_b64 %1, %8\n\tds_read_b64 %2, %8 offset:512\n\t"
+                 "ds_read_b64 %3, %8 offset:1024\n\tds_read_b64 %4, %8 offset:1536\n\tds_read_b64 %5, %8 offset:2048\n\t"
+                 "ds_read_b64 %6, %8 offset:2560\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(f), "=&v"(a.x), "=&v"(a.y), "=&v"(b.x), "=&v"(b.y), "=&v"(c.x), "=&v"(c.y)
+                 : "v"((unsigned)(size_t)flags2), "v"((unsigned)(size_t)block) : "memory");
+#else
+    asm volatile("ds_read2_b32 %0, %4 offset1:1\n\tds_read2st64_b64 %1, %5 offset1:1\n\t"
+                 "ds_read2st64_b64 %2, %5 offset0:2 offset1:3\n\tds_read2st64_b64 %3, %5 offset0:4 offset1:5\n\t"
                  "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(fa), "=&v"(a), "=&v"(fb), "=&v"(b)
-                 : "v"((unsigned)(size_t)flagA), "v"((unsigned)(size_t)slotA), "v"((unsigned)(size_t)flagB),
-                   "v"((unsigned)(size_t)slotB) : "memory");
-  } while (uni(fa) < step || uni(fb) < step);
+                 : "=&v"(f), "=&v"(a), "=&v"(b), "=&v"(c)
+                 : "v"((unsigned)(size_t)flags2), "v"((unsigned)(size_t)block) : "memory");
+#endif
+  } while (uni(f.x < f.y ? f.x : f.y) < step);
+  g1 = a.x; g2 = a.y; qSoilT = b.x; gFine = b.y; gCoarse = c.x; moist = c.y;
+}
+__device__ __forceinline__ void takeFactors(const float* block, const int* flags2, int step, float& g1,
+                                            float& g2, float& qSoilT, float& gFine, float& gCoarse, float& moist) {
+  i2v f;
+  f2v a, b, c;
+  do {
+    asm volatile("ds_read2_b32 %0, %4 offset1:1\n\tds_read2st64_b32 %1, %5 offset1:1\n\t"
+                 "ds_read2st64_b32 %2, %5 offset0:2 offset1:3\n\tds_read2st64_b32 %3, %5 offset0:4 offset1:5\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(f), "=&v"(a), "=&v"(b), "=&v"(c)
+                 : "v"((unsigned)(size_t)flags2), "v"((unsigned)(size_t)block) : "memory");
+  } while (uni(f.x < f.y ? f.x : f.y) < step);
+  g1 = a.x; g2 = a.y; qSoilT = b.x; gFine = b.y; gCoarse = c.x; moist = c.y;
 }
 // five values + flag.  DS writes of one wave execute in issue order, so the flag lands after the
 // values.  Written as DS instructions by hand: the compiler's version of the flag store is a FLAT
@@ -108,15 +155,20 @@ __device__ __forceinline__ void takePair(const float* slotA, const int* flagA, c
 // in flight.
 __device__ __forceinline__ void post5(double* base, int* flag, double v0, double v1, double v2, double v3,
                                       double v4, int step) {
+#ifdef SIPNET_NO_WRITE2
   asm volatile("ds_write_b64 %0, %1\n\tds_write_b64 %0, %2 offset:512\n\tds_write_b64 %0, %3 offset:1024\n\t"
                "ds_write_b64 %0, %4 offset:1536\n\tds_write_b64 %0, %5 offset:2048\n\tds_write_b32 %6, %7"
+#else
+  asm volatile("ds_write2st64_b64 %0, %1, %2 offset1:1\n\tds_write2st64_b64 %0, %3, %4 offset0:2 offset1:3\n\t"
+               "ds_write_b64 %0, %5 offset:2048\n\tds_write_b32 %6, %7"
+#endif
                :: "v"(ldsAddr(base)), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(ldsAddr(flag)), "v"(step)
                : "memory");
 }
 __device__ __forceinline__ void post5(float* base, int* flag, float v0, float v1, float v2, float v3,
                                       float v4, int step) {
-  asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:256\n\tds_write_b32 %0, %3 offset:512\n\t"
-               "ds_write_b32 %0, %4 offset:768\n\tds_write_b32 %0, %5 offset:1024\n\tds_write_b32 %6, %7"
+  asm volatile("ds_write2st64_b32 %0, %1, %2 offset1:1\n\tds_write2st64_b32 %0, %3, %4 offset0:2 offset1:3\n\t"
+               "ds_write_b32 %0, %5 offset:1024\n\tds_write_b32 %6, %7"
                :: "v"(ldsAddr(base)), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(ldsAddr(flag)), "v"(step)
                : "memory");
 }
@@ -184,10 +236,14 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
   // per-wave private record tiles (each wave stages and awaits its own DMA) + mailboxes
   __shared__ alignas(16) unsigned char ldsTiles[3][2 * kTileBytes];
   __shared__ R mailLai[2][64], mailPgp[2][64], mailPsn[2][64];
-  __shared__ R mailFac[2][5][64];  // g1 g2 qSoilT gFine gCoarse of a step (wave L: climate x parameters only)
-  __shared__ R mailMoist[2][64];   // the soil-moisture effect on heterotrophic respiration (wave W: its state)
-  __shared__ R mailAlive[2][64];   // 0: the member died in the step before (its posted lai is void)
-  __shared__ int seqLai, seqPgp, seqPsn, seqFac, seqAlive, seqMoist;
+  // rows 0..4: g1 g2 qSoilT gFine gCoarse of a step (wave L: climate x parameters only); row 5: the
+  // soil-moisture effect on heterotrophic respiration (wave W: its state)
+  __shared__ alignas(16) R mailFac[2][6][64];
+  __shared__ int mailAlive[2][64];  // aliveWord(): wave C's confirmation of the leaf area it posted
+  __shared__ int seqLai, seqPgp, seqPsn;
+  __shared__ alignas(8) int seqFacMoist[2];  // [0] wave L's factor rows, [1] wave W's moisture row
+#define seqFac seqFacMoist[0]
+#define seqMoist seqFacMoist[1]
   // The running-mean ring of the 64 members lives in LDS for the whole launch (250 x 64 x 8 B =
   // 125 KB; one workgroup per CU).  A wave that stores to HBM every step must not also load
   // from HBM every step: vector-memory operations complete in issue order, so each step's ring
@@ -231,7 +287,10 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
     seqPsn = tBegin - 1;
     seqFac = tBegin - 1;
     seqMoist = tBegin - 1;
-    seqAlive = tBegin - 1;
+  }
+  if (role == 0) {
+    mailAlive[0][lane] = 0;
+    mailAlive[1][lane] = 0;
   }
   __syncthreads();  // the only workgroup barrier: flags initialised before anyone spins
 
@@ -405,7 +464,7 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
           if (!PlainExp && __builtin_amdgcn_ballot_w64(K_moistExp != R(1)) != 0)  // pow only where some member needs it
             moistEff = (K_moistExp == R(1)) ? moistEff : fpow(moistEff, K_moistExp);
           moistEff = (bits & FAST_TSOIL_NEG) ? R(1) : moistEff;
-          post(&mailMoist[t & 1][lane], &seqMoist, moistEff, t);
+          post(&mailFac[t & 1][5][lane], &seqMoist, moistEff, t);
         }
 
         // everything that does not need the light block first
@@ -437,11 +496,12 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
         // moisture(), sipnet.c:656-699, with the potential photosynthesis of wave L
         R transpiration = 0, photosynthesis = 0;
         if (bits & FAST_PAR_POS) {
-          R pgpSpec, aliveF;
+          R pgpSpec;
+          bool diedBefore;
           WAIT_BEGIN()
-          takePair(&mailPgp[t & 1][lane], &seqPgp, &mailAlive[t & 1][lane], &seqAlive, t, pgpSpec, aliveF);
+          takePgp(&mailPgp[t & 1][lane], &seqPgp, &mailAlive[t & 1][lane], t, pgpSpec, diedBefore);
           WAIT_END(0)
-          const R potGrossPsn = aliveF != R(0) ? pgpSpec : R(0);
+          const R potGrossPsn = diedBefore ? R(0) : pgpSpec;
           const R potTrans = potGrossPsn * (R)q2.y * K_tr;
           const bool hasPsn = potGrossPsn >= R(kTiny);
           const bool limited = removable < potTrans;
@@ -559,7 +619,7 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
   const uint32_t ncu = (uint32_t)nc;
 
   post(&mailLai[tBegin & 1][lane], &seqLai, (R)plantLeafC * K_invLcsw, tBegin);
-  post(&mailAlive[tBegin & 1][lane], &seqAlive, R(1), tBegin);  // lai(tBegin) is not speculative
+  postAlive(&mailAlive[tBegin & 1][lane], tBegin, false);  // lai(tBegin) is not speculative
   // The two phenology switches fire once a year per member; whether ANY member of the wave can
   // fire in a step is decided with two wave-uniform compares against the smallest thresholds
   // of the wave, and not at all once every member has fired
@@ -642,30 +702,9 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
           // this step's factors: five from wave L, the moisture effect from wave W (each flag read
           // before its values, one LDS round trip when both are current)
           R g1, g2, qSoilT, gFine, gCoarse, moistEff;
-          int facSeq, moistSeq;
           {
             WAIT_BEGIN()
-            const unsigned fac = ldsAddr(&mailFac[t & 1][0][lane]);
-            const unsigned mst = ldsAddr(&mailMoist[t & 1][lane]);
-            do {
-              if (sizeof(R) == 8) {
-                asm volatile("ds_read_b32 %0, %8\n\tds_read_b64 %1, %9\n\tds_read_b64 %2, %9 offset:512\n\t"
-                             "ds_read_b64 %3, %9 offset:1024\n\tds_read_b64 %4, %9 offset:1536\n\t"
-                             "ds_read_b64 %5, %9 offset:2048\n\tds_read_b32 %6, %10\n\tds_read_b64 %7, %11\n\t"
-                             "s_waitcnt lgkmcnt(0)"
-                             : "=&v"(facSeq), "=&v"(g1), "=&v"(g2), "=&v"(qSoilT), "=&v"(gFine), "=&v"(gCoarse),
-                               "=&v"(moistSeq), "=&v"(moistEff)
-                             : "v"(ldsAddr(&seqFac)), "v"(fac), "v"(ldsAddr(&seqMoist)), "v"(mst) : "memory");
-              } else {
-                asm volatile("ds_read_b32 %0, %8\n\tds_read_b32 %1, %9\n\tds_read_b32 %2, %9 offset:256\n\t"
-                             "ds_read_b32 %3, %9 offset:512\n\tds_read_b32 %4, %9 offset:768\n\t"
-                             "ds_read_b32 %5, %9 offset:1024\n\tds_read_b32 %6, %10\n\tds_read_b32 %7, %11\n\t"
-                             "s_waitcnt lgkmcnt(0)"
-                             : "=&v"(facSeq), "=&v"(g1), "=&v"(g2), "=&v"(qSoilT), "=&v"(gFine), "=&v"(gCoarse),
-                               "=&v"(moistSeq), "=&v"(moistEff)
-                             : "v"(ldsAddr(&seqFac)), "v"(fac), "v"(ldsAddr(&seqMoist)), "v"(mst) : "memory");
-              }
-            } while (uni(facSeq) < t || uni(moistSeq) < t);
+            takeFactors(&mailFac[t & 1][0][lane], seqFacMoist, t, g1, g2, qSoilT, gFine, gCoarse, moistEff);
             WAIT_END(0)
           }
           const R fSoil = qSoilT * moistEff;
@@ -744,7 +783,7 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
           plantLeafC = rmax0(plantLeafC);
           coarseRootC = rmax0(coarseRootC);
           fineRootC = rmax0(fineRootC);
-          post(&mailAlive[(t + 1) & 1][lane], &seqAlive, diedNow ? R(0) : R(1), t + 1);
+          postAlive(&mailAlive[(t + 1) & 1][lane], t + 1, diedNow);
           soilC += soilGain;
           const bool anyDied = __builtin_amdgcn_ballot_w64(diedNow) != 0;
           if (__builtin_expect(anyDied, 0)) {
@@ -806,7 +845,7 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
     {
       WAIT_BEGIN()
       const unsigned fac = ldsAddr(&mailFac[t & 1][0][lane]);
-      const unsigned mst = ldsAddr(&mailMoist[t & 1][lane]);
+      const unsigned mst = ldsAddr(&mailFac[t & 1][5][lane]);
       // (re-reading the record while spinning is harmless; one asm statement defines every value,
       // so no copies are needed when the first look already finds the flags current)
       do {
@@ -1047,7 +1086,7 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
     fineRootC = rmax0(fineRootC);
     // confirms the lai(t+1) posted above, or revokes it when the stand died in this step (its
     // leaf pool was just zeroed); a stand that was never alive keeps its leaves and its lai
-    post(&mailAlive[(t + 1) & 1][lane], &seqAlive, diedNow ? R(0) : R(1), t + 1);
+    postAlive(&mailAlive[(t + 1) & 1][lane], t + 1, diedNow);
 
     CSTAMP(4)
     soilC += soilGain;
@@ -1239,6 +1278,8 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
 #undef ST
 #undef PRM
 #undef PRM_RARE
+#undef seqFac
+#undef seqMoist
 }
 
 #ifdef SIPNET_WAITS
@@ -1276,7 +1317,7 @@ void launchStepCoop(const FastArgs& a, int precision, bool ringInLds, hipStream_
     info->block = 192;
     info->wavesPerSimd = 1;
     const int elem = precision == SIPNET_F64 ? 8 : 4;
-    info->ldsBytes = 3 * 2 * kTileBytes + (2 * 64 * 3 + 2 * 5 * 64 + 2 * 64) * elem + 5 * 4 +
+    info->ldsBytes = 3 * 2 * kTileBytes + (2 * 64 * 3 + 2 * 6 * 64) * elem + 2 * 64 * 4 + 5 * 4 +
                      (ringInLds ? SIPNET_RING_SLOTS * 64 : 64) * 8;
   }
 }

@@ -26,7 +26,7 @@ def build(name, flags):
     objs = []
     for src in FAST_SRCS:
         o = os.path.join(out, src.replace(".hip", ".o"))
-        subprocess.check_call([HIPCC] + BASE + ["-ffp-contract=fast"] + flags.split() +
+        subprocess.check_call([HIPCC] + BASE + ["-ffp-contract=fast", "-fno-honor-nans"] + flags.split() +
                               ["-c", os.path.join(CSRC, src), "-o", o])
         objs.append(o)
     objs += [os.path.join(CSRC, o) for o in OTHER_OBJS]

@@ -19,9 +19,9 @@ b.setup(); b.run(want_planes=True); torch.cuda.synchronize()
 b.setup(); b.run(want_planes=True); torch.cuda.synchronize()
 out = (C.c_ulonglong * 16)()
 _lib.lib().sipnet_debug_read_coop_waits(out)
-tick = 24.0   # s_memtime counts at 100 MHz; 2.4 GHz core clock
-names = {0: "L: wait for lai", 3: "L: total", 4: "W: take pgp+alive", 5: "W: wait for C's progress", 7: "W: total",
-         8: "C: take factors (+record)", 9: "C: take psn", 11: "C: total"}
+tick = 1.0    # s_memtime ticks are core-clock cycles on this part (total = kernel time x 2.4 GHz)
+names = {0: "L: wait for lai", 1: "L: wait for C before posting factors", 3: "L: total", 4: "W: take pgp+alive", 5: "W: wait for C's progress", 7: "W: total",
+         8: "C: take factors + moisture (+record)", 9: "C: take psn", 11: "C: total"}
 print("kernel", b.last_launch()["kernel"], "%.2f ms" % b.last_kernel_ms())
 for k in sorted(names):
     print("%-28s %8.0f cycles/step" % (names[k], out[k] * tick / T))
