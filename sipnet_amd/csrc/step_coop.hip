@@ -31,6 +31,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <type_traits>
 
 #include "fast_math.h"
 #include "step_kernel.h"
@@ -179,6 +180,11 @@ __device__ __forceinline__ void awaitAtLeast(const int* flag, int step) {
     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(f) : "v"((unsigned)(size_t)flag) : "memory");
   } while (uni(f) < step);
 }
+
+// pool += x * len, the forward-Euler update (sipnet.c:1579-1680): one fma in fp64; in fp32-mixed the
+// product is formed in fp32 and added to the fp64 pool
+__device__ __forceinline__ void accum(double& pool, double x, double len) { pool = __builtin_fma(x, len, pool); }
+__device__ __forceinline__ void accum(double& pool, float x, float len) { pool += (double)(x * len); }
 
 #ifdef SIPNET_STAMPS
 __device__ unsigned long long g_coopStamps[16];
@@ -697,8 +703,12 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
           vPrev = RingLds ? ringL[s0 * 64 + lane] : (s0 == lastIns ? lastNpp : ringp[(uint32_t)s0 * ncu]);
         }
         unsigned dayMask = ((unsigned)tileBits >> 16) >> (t - tileStart);
-        bool stay = true;
-        for (; t < tLast && stay; t++, dayMask >>= 1) {
+        for (; t < tLast; t++, dayMask >>= 1) {
+          // The carbon wave's arithmetic is written out with explicit fused multiply-adds and
+          // compiled with contraction off (here and in the general step below): which of the two
+          // paths a wavefront takes depends on its 63 neighbours, so they must not differ by what
+          // the compiler happens to fuse in one context and not in the other.
+#pragma clang fp contract(off)
           // this step's factors: five from wave L, the moisture effect from wave W (each flag read
           // before its values, one LDS round trip when both are current)
           R g1, g2, qSoilT, gFine, gCoarse, moistEff;
@@ -719,39 +729,32 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
           const R totalWoodC = (R)(plantWoodC + delta);
           const R meanNpp = (R)(ringSum * 0.2);
           const R folResp = eLeaf * g1;
-          const R rVeg = folResp + totalWoodC * g2;
+          const R rVeg = ffma(totalWoodC, g2, folResp);
           const R rCoarseRoot = eCoarse * gCoarse;
           const R rFineRoot = eFine * gFine;
           const R rSoil = eSoilC * fSoil;
           const R woodLitter = totalWoodC * K_wtr;
-          R leafLitter = eLeaf * K_ltr;
+          const R leafLitter = eLeaf * K_ltr;
           R leafCreation = meanNpp * K_la, woodCreation = meanNpp * K_wa;
-          R leafOnCreation = 0, leafOnFromWood = 0;
-          // In the general step these three pass through the events / phenology block (they are
-          // merged values there); kept opaque here so that the compiler fuses multiply-adds around
-          // them exactly as it does there -- the two paths must give the same bits, because which
-          // one a wavefront takes depends on the other 63 members of its chunk
-          asm volatile("" : "+v"(leafLitter), "+v"(leafOnCreation), "+v"(leafOnFromWood));
           const R coarseRootLoss = K_crt * eCoarse, fineRootLoss = K_frt * eFine;
           R coarseRootCreation = K_ca * meanNpp, fineRootCreation = K_fa * meanNpp;
           {  // checkNegativeCreation(), limitations.c:146-182, as selects
-            const R leafDeficit = eLeaf * invLen + leafCreation - eLeaf * K_ltr;
+            const R leafDeficit = ffma(eLeaf, invLen, leafCreation) - leafLitter;
             const R ld = rminv(leafDeficit, R(0));
             woodCreation += ld;
             leafCreation -= ld;
-            const R fineDef = eFine * invLen + fineRootCreation - fineRootLoss;
-            const R coarseDef = eCoarse * invLen + coarseRootCreation - coarseRootLoss;
+            const R fineDef = ffma(eFine, invLen, fineRootCreation) - fineRootLoss;
+            const R coarseDef = ffma(eCoarse, invLen, coarseRootCreation) - coarseRootLoss;
             const bool fNeg = fineDef < R(0), cNeg = coarseDef < R(0);
             const R shift = (fNeg != cNeg) ? (fNeg ? fineDef : -coarseDef) : R(0);
             coarseRootCreation += shift;
             fineRootCreation -= shift;
           }
-          plantLeafC += (double)((leafCreation + leafOnCreation - leafLitter) * len);
+          accum(plantLeafC, leafCreation - leafLitter, len);
           post(&mailLai[(t + 1) & 1][lane], &seqLai, (R)rmax0(plantLeafC) * K_invLcsw, t + 1);
-          plantWoodC += (double)((woodCreation - woodLitter - leafOnFromWood) * len);
-          coarseRootC += (double)((coarseRootCreation - coarseRootLoss -
-                                   (leafOnCreation - leafOnFromWood)) * len);
-          fineRootC += (double)((fineRootCreation - fineRootLoss) * len);
+          accum(plantWoodC, woodCreation - woodLitter, len);
+          accum(coarseRootC, coarseRootCreation - coarseRootLoss, len);
+          accum(fineRootC, fineRootCreation - fineRootLoss, len);
           const double soilGain = (double)((coarseRootLoss + fineRootLoss + woodLitter + leafLitter - rSoil) * len);
           const R r_a = rVeg + rFineRoot + rCoarseRoot;
           const R alloc = leafCreation + woodCreation + fineRootCreation + coarseRootCreation;
@@ -762,72 +765,76 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
             photosynthesis = take(&mailPsn[t & 1][lane], &seqPsn, t);
             WAIT_END(1)
           }
-          delta += (double)(((photosynthesis - r_a) - alloc) * len);
-          bool diedNow = false;
-          double deathToSoil0 = 0.0, deathToSoil1 = 0.0;
-          if (__builtin_expect(!(rootsOk && (plantWoodC + delta > kTiny)), 0)) {  // every member was alive
-            ringClean = false;
-            aliveC = false;
-            diedNow = true;
-            if (diedAt < 0) diedAt = t;
-            deathToSoil0 = fineRootC + coarseRootC;
-            deathToSoil1 = plantWoodC + plantLeafC + delta;
-            plantWoodC = 0.0;
-            plantLeafC = 0.0;
-            coarseRootC = 0.0;
-            fineRootC = 0.0;
-            delta = 0.0;
-            ringSum = 0.0;
-          }
-          plantWoodC = rmax0(plantWoodC);
-          plantLeafC = rmax0(plantLeafC);
-          coarseRootC = rmax0(coarseRootC);
-          fineRootC = rmax0(fineRootC);
-          postAlive(&mailAlive[(t + 1) & 1][lane], t + 1, diedNow);
-          soilC += soilGain;
-          const bool anyDied = __builtin_amdgcn_ballot_w64(diedNow) != 0;
-          if (__builtin_expect(anyDied, 0)) {
-            if (diedNow) {
+          accum(delta, (photosynthesis - r_a) - alloc, len);
+          // the rest of the step, written once and instantiated twice: the common case (nobody
+          // dies: no mortality code at all behind ONE wave-uniform test) and the step on which a
+          // member of the wavefront dies (after which the wavefront takes the general step)
+          auto finishStep = [&](auto mayDie) {
+#pragma clang fp contract(off)
+            constexpr bool MayDie = decltype(mayDie)::value;
+            bool diedNow = false;
+            double deathToSoil0 = 0.0, deathToSoil1 = 0.0;
+            if (MayDie && !(rootsOk && (plantWoodC + delta > kTiny))) {  // every member was alive before
+              ringClean = false;
+              aliveC = false;
+              diedNow = true;
+              if (diedAt < 0) diedAt = t;
+              deathToSoil0 = fineRootC + coarseRootC;
+              deathToSoil1 = plantWoodC + plantLeafC + delta;
+              plantWoodC = 0.0;
+              plantLeafC = 0.0;
+              coarseRootC = 0.0;
+              fineRootC = 0.0;
+              delta = 0.0;
+              ringSum = 0.0;
+            }
+            plantWoodC = rmax0(plantWoodC);
+            plantLeafC = rmax0(plantLeafC);
+            coarseRootC = rmax0(coarseRootC);
+            fineRootC = rmax0(fineRootC);
+            postAlive(&mailAlive[(t + 1) & 1][lane], t + 1, diedNow);
+            soilC += soilGain;
+            if (MayDie && diedNow) {
               soilC += deathToSoil0;
               soilC += deathToSoil1;
             }
-          }
-          soilC = rmax0(soilC);
-          const R tGpp = photosynthesis * len;
-          const R tRh = rSoil * len;
-          const R tRa = (rCoarseRoot + rFineRoot) * len + rVeg * len;
-          const R tNee = R(-1.0) * ((tGpp - tRa) - tRh);
-          totGpp += (double)tGpp;
-          totNee += (double)tNee;
-          const double npp = (double)(photosynthesis - rVeg - rCoarseRoot - rFineRoot);
-          if (!RingLds) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rvN) :: "memory");
-          const double vNew = RingLds ? ringL[readSlot * 64 + lane] : (useLast ? lastNpp : rvN);
-          if (__builtin_expect(!anyDied, 1)) {
-            ringSum = ffma(-wA, vPrev, ringSum);
-            ringSum = ffma(-wB, vNew, ringSum);
-            ringSum = ffma(npp, (double)len, ringSum);
-          } else {  // a member died in this step: its ring epoch starts over, the others carry on
-            if (!diedNow) {
+            soilC = rmax0(soilC);
+            const R tGpp = photosynthesis * len;
+            const R tRh = rSoil * len;
+            const R tRa = ffma(rVeg, len, (rCoarseRoot + rFineRoot) * len);
+            const R tNee = R(-1.0) * ((tGpp - tRa) - tRh);
+            totGpp += (double)tGpp;
+            totNee += (double)tNee;
+            const double npp = (double)(photosynthesis - rVeg - rCoarseRoot - rFineRoot);
+            if (!RingLds) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rvN) :: "memory");
+            const double vNew = RingLds ? ringL[readSlot * 64 + lane] : (useLast ? lastNpp : rvN);
+            if (!(MayDie && diedNow)) {
               ringSum = ffma(-wA, vPrev, ringSum);
               ringSum = ffma(-wB, vNew, ringSum);
               ringSum = ffma(npp, (double)len, ringSum);
-            } else {
+            } else {  // its ring epoch starts over; the other members carry on
               ringValidFrom = t + 1;
             }
-            stay = false;  // the general step from the next one on
+            vPrev = vNew;
+            if (RingLds) {
+              ringL[insSlot * 64 + lane] = npp;
+            } else {
+              ringp[(uint32_t)insSlot * ncu] = npp;
+              lastIns = insSlot;
+              lastNpp = npp;
+            }
+            *oNee = tNee;
+            *oGpp = tGpp;
+            oNee += ldNee;
+            oGpp += ldGpp;
+          };
+          const bool dies = !(rootsOk && (plantWoodC + delta > kTiny));
+          if (__builtin_expect(__builtin_amdgcn_ballot_w64(dies) != 0, 0)) {
+            finishStep(std::true_type{});
+            t++;
+            break;  // the general step from the next one on
           }
-          vPrev = vNew;
-          if (RingLds) {
-            ringL[insSlot * 64 + lane] = npp;
-          } else {
-            ringp[(uint32_t)insSlot * ncu] = npp;
-            lastIns = insSlot;
-            lastNpp = npp;
-          }
-          *oNee = tNee;
-          *oGpp = tGpp;
-          oNee += ldNee;
-          oGpp += ldGpp;
+          finishStep(std::false_type{});
           readSlot = nextSlot(readSlot);
           insSlot = nextSlot(insSlot);
         }
@@ -835,6 +842,7 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
       }
     }
   for (; t < tLast; t++, recB += sizeof(FastRec)) {
+#pragma clang fp contract(off)  // explicit fused multiply-adds only: see the regular-tile path
     // record fields of the carbon block (len invLen | tsoil10 cumGdd | dayTime w0 | ints) and the
     // five factors wave W posted for this step, in ONE LDS round trip; the flag is read before
     // the values (DS reads return in order), so a current flag vouches for what follows it
@@ -914,7 +922,7 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
 
     // vegResp(), calcRootResp(), calcSoilRespiration() with wave W's factors
     const R folResp = eLeaf * g1;
-    const R rVeg = folResp + totalWoodC * g2;
+    const R rVeg = ffma(totalWoodC, g2, folResp);
     const R rCoarseRoot = eCoarse * gCoarse;
     const R rFineRoot = eFine * gFine;
     const R rSoil = eSoilC * fSoil;
@@ -931,12 +939,12 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
 
     // checkNegativeCreation(), limitations.c:146-182, as selects
     {
-      const R leafDeficit = eLeaf * invLen + leafCreation - eLeaf * K_ltr;
+      const R leafDeficit = ffma(eLeaf, invLen, leafCreation) - eLeaf * K_ltr;
       const R ld = rminv(leafDeficit, R(0));
       woodCreation += ld;
       leafCreation -= ld;
-      const R fineDef = eFine * invLen + fineRootCreation - fineRootLoss;
-      const R coarseDef = eCoarse * invLen + coarseRootCreation - coarseRootLoss;
+      const R fineDef = ffma(eFine, invLen, fineRootCreation) - fineRootLoss;
+      const R coarseDef = ffma(eCoarse, invLen, coarseRootCreation) - coarseRootLoss;
       const bool fNeg = fineDef < R(0), cNeg = coarseDef < R(0);
       const R shift = (fNeg != cNeg) ? (fNeg ? fineDef : -coarseDef) : R(0);
       coarseRootCreation += shift;
@@ -1018,14 +1026,13 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
     CSTAMP(2)
     // the leaf pool of the next step does not involve this step's photosynthesis: update it
     // now and let wave L start on step t+1 (speculative only with respect to plant death)
-    plantLeafC += (double)((leafCreation + leafOnCreation - leafLitter) * len);
+    accum(plantLeafC, leafCreation + leafOnCreation - leafLitter, len);
     post(&mailLai[(t + 1) & 1][lane], &seqLai, (R)rmax0(plantLeafC) * K_invLcsw, t + 1);
 
     // plant pools that do not involve this step's photosynthesis (sipnet.c:1579-1626)
-    plantWoodC += (double)((woodCreation - woodLitter - leafOnFromWood) * len);
-    coarseRootC += (double)((coarseRootCreation - coarseRootLoss -
-                             (leafOnCreation - leafOnFromWood)) * len);
-    fineRootC += (double)((fineRootCreation - fineRootLoss) * len);
+    accum(plantWoodC, woodCreation - woodLitter - leafOnFromWood, len);
+    accum(coarseRootC, coarseRootCreation - coarseRootLoss - (leafOnCreation - leafOnFromWood), len);
+    accum(fineRootC, fineRootCreation - fineRootLoss, len);
     const double soilGain = (double)((coarseRootLoss + fineRootLoss + woodLitter + leafLitter - rSoil) * len);
     const R r_a = rVeg + rFineRoot + rCoarseRoot;
     const R alloc = leafCreation + woodCreation + fineRootCreation + coarseRootCreation;
@@ -1042,7 +1049,7 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
     CSTAMP(3)
     // ---- pools (sipnet.c:1769-1806): plant pools first, so that the next step's leaf area
     // can leave for wave L as early as possible
-    delta += (double)(((photosynthesis - r_a) - alloc) * len);
+    accum(delta, (photosynthesis - r_a) - alloc, len);
     double postC = 0.0;  // getMassTotals() after the pool updates (the soil pool's is still pending here)
     if (wantDiag) postC = (plantWoodC + delta) + plantLeafC + fineRootC + coarseRootC + (soilC + soilGain);
     double deathWood = 0.0, deathRoot = 0.0;  // record columns 41, 42
@@ -1114,7 +1121,7 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
     // ---- outputs: updateTrackers(), sipnet.c:1420-1496 ---------------------------------------
     const R tGpp = photosynthesis * len;
     const R tRh = rSoil * len;
-    const R tRa = (rCoarseRoot + rFineRoot) * len + rVeg * len;
+    const R tRa = ffma(rVeg, len, (rCoarseRoot + rFineRoot) * len);
     const R tNee = R(-1.0) * ((tGpp - tRa) - tRh);
     totGpp += (double)tGpp;
     totNee += (double)tNee;

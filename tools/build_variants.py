@@ -26,7 +26,8 @@ def build(name, flags):
     objs = []
     for src in FAST_SRCS:
         o = os.path.join(out, src.replace(".hip", ".o"))
-        subprocess.check_call([HIPCC] + BASE + ["-ffp-contract=fast", "-fno-honor-nans"] + flags.split() +
+        contract = "-ffp-contract=fast-honor-pragmas" if src == "step_coop.hip" else "-ffp-contract=fast"
+        subprocess.check_call([HIPCC] + BASE + [contract, "-fno-honor-nans"] + flags.split() +
                               ["-c", os.path.join(CSRC, src), "-o", o])
         objs.append(o)
     objs += [os.path.join(CSRC, o) for o in OTHER_OBJS]
