@@ -23,14 +23,27 @@ def shard_sites(n_sites, world, rank):
     return shard_members(n_sites, world, rank)
 
 
+def _host_staged(x, group):
+    """gloo has no all-gather / all-to-all on device tensors: in a rehearsal of the multi-GPU path
+    on one GPU (bench.py --rehearse, tests/test_gpu_multirank.py) the exchange goes through host
+    copies; on RCCL ("nccl") tensors stay on the device"""
+    import torch.distributed as dist
+    return x.is_cuda and dist.get_backend(group) == "gloo"
+
+
 def _gather0(x, world, group):
     """all_gather_into_tensor along a new leading axis (the output is the concatenation
     along dim 0, which both RCCL and gloo accept)."""
     import torch
     import torch.distributed as dist
     x = x.contiguous()
-    out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-    dist.all_gather_into_tensor(out, x, group=group)
+    if _host_staged(x, group):
+        out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype)
+        dist.all_gather_into_tensor(out, x.cpu(), group=group)
+        out = out.to(x.device)
+    else:
+        out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, x, group=group)
     return out.view((world,) + tuple(x.shape))
 
 
@@ -144,9 +157,16 @@ def pf_resample(batch, ancestors, rank=0, world=1, group=None, with_params=False
     blocks = [batch.pack_members(c, with_params) for c in send_cols]
     words = blocks[0].shape[0]
     send = torch.cat([b.reshape(-1) for b in blocks])
-    recv = torch.empty(words * sum(recv_counts), dtype=send.dtype, device=send.device)
-    dist.all_to_all_single(recv, send, output_split_sizes=[words * c for c in recv_counts],
-                           input_split_sizes=[int(b.numel()) for b in blocks], group=group)
+    out_splits = [words * c for c in recv_counts]
+    in_splits = [int(b.numel()) for b in blocks]
+    if _host_staged(send, group):
+        recv_h = torch.empty(sum(out_splits), dtype=send.dtype)
+        dist.all_to_all_single(recv_h, send.cpu(), output_split_sizes=out_splits, input_split_sizes=in_splits,
+                               group=group)
+        recv = recv_h.to(send.device)
+    else:
+        recv = torch.empty(sum(out_splits), dtype=send.dtype, device=send.device)
+        dist.all_to_all_single(recv, send, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
     batch.resample(src, recv, recv_counts, with_params)
     sent = sum(int(c.numel()) for c in send_cols)
     return {"sent": sent, "received": sum(recv_counts), "bytes_sent": sent * words * 8}

@@ -66,3 +66,25 @@ def test_two_ranks_rehearsed_on_one_gpu_equal_a_single_process(workload, members
         a = np.load(two)
         assert a.shape == (3, nsteps, 64, 2) and np.isfinite(a).all()
         assert not np.allclose(a[:, :, 0], a[:, :, 32])          # different forcing per site
+
+
+def test_particle_filter_cycle_two_ranks_rehearsed(tmp_path):
+    """c5 with two ranks on this one GPU: likelihood weights -> all-gather of log-weights ->
+    redundant systematic resampling -> ONE all-to-all of packed checkpoints (parameters travel
+    with the particles) -> gather -> the next cycle's setupModel() on the RESAMPLED parameter
+    sets.  The collectives go over gloo through host copies; the plan, pack and resample kernels
+    and the bookkeeping are the 8-GPU code."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+         "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), BENCH, "--gpus", "2",
+         "--rehearse", "--workload", "c5", "--members", "4096", "--steps", "3", "--warmup", "1",
+         "--no-cpu-baseline", "--no-fill-probe"],
+        capture_output=True, text=True, timeout=600, env=env, cwd=helpers.REPO)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    j = _last_json(r.stdout)
+    pf = j["config"]["particle_filter"]
+    assert j["n_gpus"] == 2 and j["config"]["ranks_seen"] == 2
+    assert pf["received"] > 0 and pf["sent"] > 0          # particles did cross between the ranks
+    assert 1 < pf["unique_ancestors"] < 2 * 4096
+    assert j["parity"]["max_abs_dNEE"] < 2e-6

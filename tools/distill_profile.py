@@ -73,7 +73,8 @@ if means:
                     f"* **traffic = {hbm/1e9:.3f} GB per launch**", ""]
             tj = os.path.join(dst, "pmc_traffic.json")
             d = json.load(open(tj)) if os.path.exists(tj) else {}
-            d[wl] = {"hbm_bytes_per_launch": hbm, "tag": tag, "fetch_correction": corr}
+            kname = sk.replace("void sipnet::", "").split("(sipnet::")[0]
+            d[wl] = {"hbm_bytes_per_launch": hbm, "tag": tag, "fetch_correction": corr, "kernel": kname}
             json.dump(d, open(tj, "w"), indent=1)
         sq = {c: means[(sk, c)] for (k, c) in means if k == sk and c.startswith("SQ_")}
         if sq:
