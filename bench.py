@@ -122,7 +122,8 @@ def cpu_model():
 
 
 def _cpu_leg(kind, so, flags, members_raw, n_steps, clim_file, param_file, cpus, target_seconds, ns_guess):
-    """one timed leg: len(cpus) worker processes, each pinned to its own core"""
+    """one timed leg: len(cpus) worker processes, each pinned to its own core (cpu = -1: left
+    to the host's scheduler)"""
     cores = len(cpus)
     per_core = max(1, int(target_seconds / (n_steps * ns_guess * 1e-9)))
     per_core = min(per_core, members_raw.shape[0] // cores if members_raw.shape[0] >= cores else 1)
@@ -166,17 +167,25 @@ def cpu_baseline(flags, members_raw, raw_forcing, param_name="base_forest.param"
     clim_file = os.path.join(tmp, "bench.clim")
     synth.write_clim(clim_file, raw_forcing)
     param_file = os.path.join(REPO, "sipnet_amd", "data", param_name)
-    o2 = _cpu_leg(kind, so, flags, members_raw, n_steps, clim_file, param_file, cpus, 8.0, 150)
+    # the box is shared: which cores are quiet differs from run to run, so the -O2 leg runs twice --
+    # pinned (one worker per core of a spread-out set) and unpinned (the host scheduler places the
+    # workers) -- and the FASTER of the two is the baseline's value; both are reported
+    pin = _cpu_leg(kind, so, flags, members_raw, n_steps, clim_file, param_file, cpus, 6.0, 150)
+    free = _cpu_leg(kind, so, flags, members_raw, n_steps, clim_file, param_file, [-1] * len(cpus), 6.0, 150)
+    o2 = pin if pin["value"] >= free["value"] else free
     o0 = None
     if kind == "reference" and os.path.exists(ref_o0):
-        o0 = _cpu_leg(kind, ref_o0, flags, members_raw, n_steps, clim_file, param_file, cpus, 6.0, 400)
+        o0 = _cpu_leg(kind, ref_o0, flags, members_raw, n_steps, clim_file, param_file,
+                      cpus if o2 is pin else [-1] * len(cpus), 5.0, 400)
     return {
         "value": o2["value"], "unit": "ensemble-site-timesteps/s", "cores": len(cpus), "kind": kind,
-        "per_core": o2["per_core"], "pinned": True, "cpu_model": cpu_model(),
+        "per_core": o2["per_core"], "pinned": o2 is pin, "value_pinned": pin["value"],
+        "value_unpinned": free["value"], "cpu_model": cpu_model(),
         "value_O0": o0["value"] if o0 else None, "per_core_O0": o0["per_core"] if o0 else None,
         "sample": f"{o2['members']} members x {n_steps} steps of the same synthetic ensemble, "
-                  f"{len(cpus)} processes each pinned to one host core, step loop only, gcc -O2 "
-                  f"(slowest process {o2['slowest_s']:.2f}s, wall incl. start-up {o2['wall_s']:.1f}s)"
+                  f"{len(cpus)} processes (one per usable host core; pinned {pin['value'] / 1e6:.1f} M/s, "
+                  f"unpinned {free['value'] / 1e6:.1f} M/s, the faster one is `value`), step loop only, gcc -O2 "
+                  f"(slowest process {o2['slowest_s']:.2f}s)"
                   + (f"; the same at -O0 (the reference Makefile's level) on {o0['members']} members "
                      f"(slowest {o0['slowest_s']:.2f}s)" if o0 else ""),
     }
@@ -559,7 +568,8 @@ def main():
                          "hbm_measured_frac": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
                          "kernel": li["kernel"], "kernel_ms": k_ms,
                          "grid": li["grid"], "block_threads": li["block_threads"],
-                         "waves_per_simd": li["waves_per_simd"] if li["grid"] * waves_per_block > 4 * li["num_cus"] else 1,
+                         "waves_per_simd": li["grid"] * waves_per_block / (4.0 * li["num_cus"]),
+                         "waves_per_simd_register_budget": li["waves_per_simd"],
                          "cus_used": cus_used, "cus_total": li["num_cus"],
                          "simds_used": simds_used, "simds_total": 4 * li["num_cus"],
                          "lds_bytes_per_workgroup": li["lds_bytes"],
