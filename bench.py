@@ -351,6 +351,9 @@ def main():
         # effective sample size of roughly half the ensemble
         from sipnet_amd import dist as sd
         b.run(0, T, planes=planes)
+        # the parity sample is taken from this first forecast: later cycles run RESAMPLED
+        # parameter sets (particles carry their parameters), member k is no longer draw k
+        pf_first = planes[:, :, :min(8, M)].double().cpu().numpy()
         tot = planes[0].double().sum(0)
         if world > 1:
             tot = sd._gather0(tot, world, None).reshape(-1)
@@ -509,10 +512,13 @@ def main():
             ora = helpers.load_oracle()
             n_chk = min(8, M)
             po, _, _ = ora.run_block(flags, members[:n_chk], clims[0])
-            if pf or world > 1:      # the planes of a whole forecast from a fresh setup
-                b.setup()
-                b.run(0, T, planes=planes)
-            pg = planes[:, :, :n_chk].double().cpu().numpy()
+            if pf:
+                pg = pf_first
+            else:
+                if world > 1:        # the planes of a whole pass from a fresh setup
+                    b.setup()
+                    b.run(0, T, planes=planes)
+                pg = planes[:, :, :n_chk].double().cpu().numpy()
             scale = np.maximum(np.abs(po).max(axis=(1, 2), keepdims=True), 1e-3)
             flips = int(((np.abs(pg - po) / scale) > 1e-4).any(axis=(0, 1)).sum())
             parity = {"members_checked": n_chk,

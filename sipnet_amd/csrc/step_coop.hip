@@ -1154,8 +1154,12 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
       if (!RingLds) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rv0), "+v"(rv1) :: "memory");
       const double v0 = RingLds ? ringL[evSlot0 * 64 + lane] : (useLast0 ? lastNpp : rv0);
       const int nOps = bits >> 16;
-      if (__builtin_expect(ringClean && (bits & FAST_RING_REGULAR), 1)) {
+      // one or two evictions and a plain insert (two is the steady state of half-hourly forcing,
+      // see the regular-tile path); with one eviction w1 is 0 and its term an exact no-op
+      if (__builtin_expect(ringClean && insSlot >= 0 && nOps <= 2, 1)) {
+        const double v1 = RingLds ? ringL[evSlot1 * 64 + lane] : (useLast1 ? lastNpp : rv1);
         ringSum = ffma(-q7.y, v0, ringSum);
+        ringSum = ffma(-rare[0], v1, ringSum);
         ringSum = ffma(npp, (double)len, ringSum);
       } else if (alive) {
         if (insSlot < 0) {
