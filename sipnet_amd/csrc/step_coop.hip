@@ -234,7 +234,7 @@ __device__ unsigned long long g_coopWaits[16];
 // RingLds: the running-mean ring of the 64 members stays in LDS for the whole launch (one
 // workgroup per CU); otherwise it stays in HBM and up to four workgroups share a CU.
 // Full: see stepFastKernel -- every accumulator of the restart schema, the optional 44-column record
-// (the carbon wave writes the carbon / tracker columns, the water wave columns 2, 12, 13, 17, 19)
+// (the carbon wave writes the carbon / tracker columns, the water wave columns 1, 2, 12, 13, 17, 19, 35)
 // and the optional per-member diagnostics (clamp and carbon-balance warnings; default flags have no
 // nitrogen balance).  Same flux arithmetic and hand-overs as the lean variant.
 template <class R, bool PlainExp, bool RingLds, bool Full>
@@ -430,8 +430,10 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
     const R K_c1l = (R)(PRM(rSoilConst1) * kLog2e), K_c2l = (R)(PRM(rSoilConst2) * kLog2e);
     const R K_moistExp = (R)PRM(soilRespMoistEffect);
     double soilWater = ST(soilWater), snow = ST(snow);
+    double totGpp = ST(totGpp);  // GPP is this wave's own product: it stores the plane and keeps the total
     R* __restrict__ oEt = (R*)(a.et ? a.et : a.scratchRow) + col;
-    const int64_t ldEt = a.et ? a.ld : 0;
+    R* __restrict__ oGpp = (R*)(a.gpp ? a.gpp : a.scratchRow) + col;
+    const int64_t ldEt = a.et ? a.ld : 0, ldGpp = a.gpp ? a.ld : 0;
     const bool wantDiagW = Full && a.diag != nullptr;
     const double K_whc2 = Full ? 2.0 * PRM(soilWHC) : 0.0;
     double* __restrict__ recw = Full && a.rec ? a.rec + col : nullptr;
@@ -439,8 +441,9 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
     WAIT_DECL()
 
     for (int tileStart = curTile * kFastTile; tileStart < tEnd; tileStart += kFastTile, curTile++) {
-      // the DMA of 16 steps ago has landed: all but the youngest operation (the last ET store)
-      if (tileStart > tBegin) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      // the DMA of 16 steps ago has landed: all but the two youngest operations (the last step's
+      // ET and GPP stores)
+      if (tileStart > tBegin) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
       stageTile(curTile + 1, (curTile + 1) & 1);
       const int tFirst = tileStart > tBegin ? tileStart : tBegin;
       const int tLast = (tileStart + kFastTile) < tEnd ? (tileStart + kFastTile) : tEnd;
@@ -563,10 +566,20 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
         }
 
         const R tEt = (transpiration + immedEvap + evaporation + sublimation + evEvap) * len;
+        R tGpp;
+        {
+#pragma clang fp contract(off)  // the total is the sum of the ROUNDED per-step values (sipnet.c:1433-1450)
+          tGpp = photosynthesis * len;
+          totGpp += (double)tGpp;
+        }
         *oEt = tEt;
+        *oGpp = tGpp;
         oEt += ldEt;
+        oGpp += ldGpp;
         if (Full && recw) {
           const int64_t L = a.ld;
+          recw[1 * L] = (double)tGpp;
+          recw[35 * L] = totGpp;
           recw[2 * L] = (double)tEt;
           recw[12 * L] = (oldSoilWater + soilWater) / K_whc2;
           recw[13 * L] = (double)transpiration;
@@ -580,6 +593,7 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
     if (act) {
       ST(soilWater) = soilWater;
       ST(snow) = snow;
+      ST(totGpp) = totGpp;
       if (wantDiagW && clampWarnW) atomicAdd(a.diag + col, (double)clampWarnW);
     }
     return;
@@ -598,7 +612,7 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
   double plantWoodC = ST(plantWoodC), plantLeafC = ST(plantLeafC), soilC = ST(soilC);
   double coarseRootC = ST(coarseRootC), fineRootC = ST(fineRootC);
   double delta = ST(plantCAccountingDelta);
-  double ringSum = ST(ringSum), totNee = ST(totNee), totGpp = ST(totGpp);
+  double ringSum = ST(ringSum), totNee = ST(totNee);
   int phenBits = (int)ST(phenBits);
   int ringValidFrom = (int)ST(ringValidFrom);
   int diedAt = (int)ST(diedAt);
@@ -620,8 +634,7 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
 
   double* __restrict__ ringp = a.ring + col;
   R* __restrict__ oNee = (R*)(a.nee ? a.nee : a.scratchRow) + col;
-  R* __restrict__ oGpp = (R*)(a.gpp ? a.gpp : a.scratchRow) + col;
-  const int64_t ldNee = a.nee ? a.ld : 0, ldGpp = a.gpp ? a.ld : 0;
+  const int64_t ldNee = a.nee ? a.ld : 0;
   const uint32_t ncu = (uint32_t)nc;
 
   post(&mailLai[tBegin & 1][lane], &seqLai, (R)plantLeafC * K_invLcsw, tBegin);
@@ -657,8 +670,8 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
     // the DMA of this tile was issued a tile ago; only the last step's two stores may still be
     // in flight behind it
     if (tileStart > tBegin) {
-      if (RingLds) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");  // + the ring store
+      if (RingLds) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // + the ring store
     }
     stageTile(curTile + 1, (curTile + 1) & 1);
     const int tFirst = tileStart > tBegin ? tileStart : tBegin;
@@ -803,7 +816,6 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
             const R tRh = rSoil * len;
             const R tRa = ffma(rVeg, len, (rCoarseRoot + rFineRoot) * len);
             const R tNee = R(-1.0) * ((tGpp - tRa) - tRh);
-            totGpp += (double)tGpp;
             totNee += (double)tNee;
             const double npp = (double)(photosynthesis - rVeg - rCoarseRoot - rFineRoot);
             if (!RingLds) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rvN) :: "memory");
@@ -824,9 +836,7 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
               lastNpp = npp;
             }
             *oNee = tNee;
-            *oGpp = tGpp;
             oNee += ldNee;
-            oGpp += ldGpp;
           };
           const bool dies = !(rootsOk && (plantWoodC + delta > kTiny));
           if (__builtin_expect(__builtin_amdgcn_ballot_w64(dies) != 0, 0)) {
@@ -1123,7 +1133,6 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
     const R tRh = rSoil * len;
     const R tRa = ffma(rVeg, len, (rCoarseRoot + rFineRoot) * len);
     const R tNee = R(-1.0) * ((tGpp - tRa) - tRh);
-    totGpp += (double)tGpp;
     totNee += (double)tNee;
     R tRAbove = 0, tRRoot = 0, tRSoil = 0, tRtot = 0, tNpp = 0;
     if (Full) {
@@ -1198,7 +1207,6 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
       double* __restrict__ r = recp;
       const int64_t L = a.ld;
       r[0 * L] = (double)tNee;
-      r[1 * L] = (double)tGpp;
       r[3 * L] = totNee;
       r[4 * L] = (double)tNpp;
       r[5 * L] = (double)tRAbove;
@@ -1227,7 +1235,6 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
       r[32 * L] = recMeanNpp;
       r[33 * L] = rare[3];  // gddAfter
       r[34 * L] = rare[4];  // tillAfter
-      r[35 * L] = totGpp;
       r[36 * L] = (double)(leafOnCreation * len);
       r[37 * L] = (double)(leafOnFromWood * len);
       r[38 * L] = (double)(recLeafOffComputed * len);
@@ -1239,9 +1246,7 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
       recp += (int64_t)SIPNET_NREC * L;
     }
     *oNee = tNee;
-    *oGpp = tGpp;
     oNee += ldNee;
-    oGpp += ldGpp;
     CSTAMP(6)
   }  // steps of this tile
   }  // tiles
@@ -1262,7 +1267,6 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
     ST(plantCAccountingDelta) = delta;
     ST(ringSum) = ringSum;
     ST(totNee) = totNee;
-    ST(totGpp) = totGpp;
     ST(phenBits) = (double)phenBits;
     ST(ringValidFrom) = (double)ringValidFrom;
     ST(diedAt) = (double)diedAt;
