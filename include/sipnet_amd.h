@@ -365,6 +365,17 @@ int sipnet_pf_systematic_ancestors(const double *d_logw, int64_t n, double u0,
 int sipnet_pf_systematic_ancestors_async(const double *d_logw, int64_t n, double u0,
                                          int32_t *d_ancestors, int64_t *d_fixed_weights,
                                          int64_t *d_total, void *hip_stream);
+/* Who sends what, from the GLOBAL ancestor vector d_ancestors[world * n_local] (DEVICE; identical
+ * on every rank, non-decreasing): for every destination rank d the local columns it needs from
+ * this rank, each once, concatenated in rank order into d_send_cols (DEVICE, capacity
+ * world * n_local; send_counts[d] entries for rank d, 0 for d == rank); d_src[n_local] (DEVICE):
+ * where this rank's new column j comes from -- < n_local: its own old column, n_local + k: the
+ * k-th received column, received blocks concatenated in source-rank order with recv_counts[s]
+ * columns each.  send_counts / recv_counts are HOST arrays of `world` entries (the split sizes
+ * of the all-to-all; filling them is the plan's one host synchronisation).  world <= 64. */
+int sipnet_pf_exchange_plan(const int32_t *d_ancestors, int64_t n_local, int32_t world, int32_t rank,
+                            int32_t *d_send_cols, int32_t *d_src, int64_t *send_counts,
+                            int64_t *recv_counts, void *hip_stream);
 /* doubles per particle in a packed block: SIPNET_NSTATE + SIPNET_RING_SLOTS (+ SIPNET_NPARAMS) */
 int32_t sipnet_pf_member_words(int32_t with_params);
 /* Pack columns d_cols[n] (DEVICE, local column indices) into d_buf laid out

@@ -120,6 +120,7 @@ SIGNATURES = {
                                               C.c_double, _P, _P]),
     "sipnet_pf_systematic_ancestors": (C.c_int, [_P, C.c_int64, C.c_double, _P, _P, _P]),
     "sipnet_pf_systematic_ancestors_async": (C.c_int, [_P, C.c_int64, C.c_double, _P, _P, _P, _P]),
+    "sipnet_pf_exchange_plan": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
     "sipnet_pf_member_words": (C.c_int32, [C.c_int32]),
     "sipnet_batch_pack_members": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P]),
     "sipnet_batch_resample": (C.c_int, [_P, _P, _P, C.c_int32, _P, C.c_int32, _P]),

@@ -152,6 +152,85 @@ __global__ __launch_bounds__(256) void exponentCheckKernel(const double* __restr
     atomicOr(flag, 1);
 }
 
+// ---- exchange plan of a resampling over `world` ranks with n particles each ----------------
+// The global ancestor vector (identical on every rank, non-decreasing) is cut into destination
+// blocks [d*n, (d+1)*n); inside a block the ancestors owned by source rank s (anc / n == s) are
+// contiguous.  A particle that has to cross ranks (s != d) travels ONCE per destination: the
+// first of a run of equal ancestors inside a destination block is its "head".
+//   first[d][s]  first index of block d whose ancestor belongs to rank >= s   (binary search)
+//   head[i]      1 when entry i is a cross-rank head                          (exclusive scan -> P)
+//   count[d][s]  = P[first[d][s+1]] - P[first[d][s]]                          (columns d receives from s)
+constexpr int kMaxWorld = 64;
+__global__ void planFirstKernel(const int32_t* __restrict__ anc, int64_t n, int32_t world,
+                                int64_t* __restrict__ first) {
+  const int d = blockIdx.x, s = threadIdx.x;  // s in 0..world
+  if (s > world) return;
+  const int64_t target = (int64_t)s * n;      // first ancestor value owned by rank s
+  int64_t lo = (int64_t)d * n, hi = lo + n;   // lower bound of `target` in anc[lo, hi)
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if ((int64_t)anc[mid] < target) lo = mid + 1; else hi = mid;
+  }
+  first[(int64_t)d * (world + 1) + s] = lo;
+}
+__global__ __launch_bounds__(256) void planHeadKernel(const int32_t* __restrict__ anc, int64_t n,
+                                                      int64_t total, int32_t* __restrict__ head) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int64_t a = anc[i];
+  const int64_t d = i / n, s = a / n;
+  const bool newRun = (i % n == 0) || anc[i - 1] != a;
+  head[i] = (newRun && s != d) ? 1 : 0;
+}
+// one block: counts, the bases of this rank's send / receive blocks (in rank order, self skipped)
+__global__ void planCountKernel(const int64_t* __restrict__ first, const int32_t* __restrict__ P,
+                                const int32_t* __restrict__ head, int64_t total, int32_t world,
+                                int32_t rank, int64_t* __restrict__ counts /* [2][world]: send, recv */,
+                                int64_t* __restrict__ bases /* [2][world] */) {
+  if (threadIdx.x != 0) return;
+  auto Pat = [&](int64_t i) -> int64_t { return i < total ? (int64_t)P[i] : (int64_t)P[total - 1] + head[total - 1]; };
+  int64_t sb = 0, rb = 0;
+  for (int q = 0; q < world; q++) {
+    const int64_t* fs = first + (int64_t)q * (world + 1);       // destination q, what I (rank) send it
+    const int64_t send = q == rank ? 0 : Pat(fs[rank + 1]) - Pat(fs[rank]);
+    const int64_t* fr = first + (int64_t)rank * (world + 1);    // my block, what comes from source q
+    const int64_t recv = q == rank ? 0 : Pat(fr[q + 1]) - Pat(fr[q]);
+    counts[q] = send;
+    counts[world + q] = recv;
+    bases[q] = sb;
+    bases[world + q] = rb;
+    sb += send;
+    rb += recv;
+  }
+}
+__global__ __launch_bounds__(256) void planFillKernel(const int32_t* __restrict__ anc, int64_t n,
+                                                      int64_t total, int32_t world, int32_t rank,
+                                                      const int64_t* __restrict__ first,
+                                                      const int32_t* __restrict__ P,
+                                                      const int32_t* __restrict__ head,
+                                                      const int64_t* __restrict__ bases,
+                                                      int32_t* __restrict__ sendCols,
+                                                      int32_t* __restrict__ src) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int64_t a = anc[i];
+  const int64_t d = i / n, s = a / n, lo = (int64_t)rank * n;
+  if (s == rank && d != rank && head[i]) {   // a column of mine that rank d needs (once)
+    const int64_t f = first[d * (world + 1) + rank];
+    sendCols[bases[d] + ((int64_t)P[i] - (int64_t)P[f])] = (int32_t)(a - lo);
+  }
+  if (d == rank) {                           // where my new column j comes from
+    const int64_t j = i - lo;
+    if (s == rank) {
+      src[j] = (int32_t)(a - lo);
+    } else {
+      const int64_t f = first[(int64_t)rank * (world + 1) + s];
+      const int64_t k = ((int64_t)P[i] + head[i] - 1) - (int64_t)P[f];   // index among the heads from s
+      src[j] = (int32_t)(n + bases[world + s] + k);
+    }
+  }
+}
+
 void launchGather(const double* own, int64_t ownPitch, int64_t ncol, const double* recv,
                   const RecvMap& map, int recvRow0, const int32_t* src, int64_t nOut, double* dst,
                   int64_t dstPitch, int rows, hipStream_t stream) {
@@ -272,6 +351,75 @@ int sipnet_pf_systematic_ancestors(const double* d_logw, int64_t n, double u0,
   if (total <= 0) {
     setError("sipnet_pf_systematic_ancestors: every particle has zero weight");
     return SIPNET_ERR_BAD_PARAMETER;
+  }
+  return SIPNET_OK;
+}
+
+namespace {
+struct PlanScratch {
+  int device = -1;
+  int64_t cap = 0;
+  int32_t *d_head = nullptr, *d_P = nullptr;
+  int64_t *d_first = nullptr, *d_counts = nullptr;  // [(kMaxWorld+1)*kMaxWorld], [4*kMaxWorld]
+  void* d_tmp = nullptr;
+  size_t tmpBytes = 0;
+  void release() {
+    if (d_head) (void)hipFree(d_head);
+    if (d_P) (void)hipFree(d_P);
+    if (d_first) (void)hipFree(d_first);
+    if (d_counts) (void)hipFree(d_counts);
+    if (d_tmp) (void)hipFree(d_tmp);
+    d_head = d_P = nullptr; d_first = d_counts = nullptr; d_tmp = nullptr; cap = 0; tmpBytes = 0;
+  }
+  ~PlanScratch() { release(); }
+};
+thread_local PlanScratch g_plan;
+}  // namespace
+
+int sipnet_pf_exchange_plan(const int32_t* d_ancestors, int64_t n_local, int32_t world, int32_t rank,
+                            int32_t* d_send_cols, int32_t* d_src, int64_t* send_counts,
+                            int64_t* recv_counts, void* hip_stream) {
+  if (!d_ancestors || !d_send_cols || !d_src || !send_counts || !recv_counts || n_local <= 0 ||
+      world < 1 || world > kMaxWorld || rank < 0 || rank >= world ||
+      n_local * world > (int64_t)1 << 30) {
+    setError("sipnet_pf_exchange_plan: bad argument (world <= 64)");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  hipStream_t stream = (hipStream_t)hip_stream;
+  const int64_t total = n_local * world;
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  PlanScratch& sc = g_plan;
+  if (sc.device != dev || sc.cap < total) {
+    sc.release();
+    sc.device = dev;
+    HIP_TRY(hipMalloc(&sc.d_head, (size_t)total * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&sc.d_P, (size_t)total * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&sc.d_first, (size_t)(kMaxWorld + 1) * kMaxWorld * sizeof(int64_t)));
+    HIP_TRY(hipMalloc(&sc.d_counts, (size_t)4 * kMaxWorld * sizeof(int64_t)));
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, sc.tmpBytes, sc.d_head, sc.d_P, (int)total, stream));
+    HIP_TRY(hipMalloc(&sc.d_tmp, sc.tmpBytes));
+    sc.cap = total;
+  }
+  const int grid = (int)((total + 255) / 256);
+  hipLaunchKernelGGL(planFirstKernel, dim3(world), dim3(kMaxWorld + 1), 0, stream, d_ancestors, n_local,
+                     world, sc.d_first);
+  hipLaunchKernelGGL(planHeadKernel, dim3(grid), dim3(256), 0, stream, d_ancestors, n_local, total, sc.d_head);
+  size_t tmpBytes = sc.tmpBytes;
+  HIP_TRY(hipcub::DeviceScan::ExclusiveSum(sc.d_tmp, tmpBytes, sc.d_head, sc.d_P, (int)total, stream));
+  int64_t* d_bases = sc.d_counts + 2 * kMaxWorld;
+  hipLaunchKernelGGL(planCountKernel, dim3(1), dim3(64), 0, stream, sc.d_first, sc.d_P, sc.d_head, total,
+                     world, rank, sc.d_counts, d_bases);
+  hipLaunchKernelGGL(planFillKernel, dim3(grid), dim3(256), 0, stream, d_ancestors, n_local, total, world,
+                     rank, sc.d_first, sc.d_P, sc.d_head, d_bases, d_send_cols, d_src);
+  HIP_TRY(hipGetLastError());
+  // the one host round trip of the plan: the split sizes of the all-to-all
+  int64_t h[2 * kMaxWorld];
+  HIP_TRY(hipMemcpyAsync(h, sc.d_counts, (size_t)2 * world * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  for (int q = 0; q < world; q++) {
+    send_counts[q] = h[q];
+    recv_counts[q] = h[world + q];
   }
   return SIPNET_OK;
 }

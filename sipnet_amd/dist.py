@@ -112,7 +112,31 @@ def pf_exchange_plan(ancestors, n_local, world, rank):
     (send_cols[d]: local columns rank d needs from me, each once;
      src[n_local]: for my new column j, < n_local = my own old column, n_local + k = k-th
      received column; recv_counts[s]: columns arriving from rank s).
-    Works on any torch device (the gloo tests run it on CPU tensors)."""
+    Device tensors go through the library (sipnet_pf_exchange_plan: four kernels, one scan and
+    ONE host synchronisation for the split sizes, whatever the number of ranks); the torch
+    formulation below is the same plan for CPU tensors (the gloo tests) and its reference."""
+    import torch
+    if ancestors.is_cuda:
+        import ctypes as C
+        from ._lib import check, lib
+        anc = ancestors.to(torch.int32).contiguous()
+        send = torch.empty(world * n_local, dtype=torch.int32, device=anc.device)
+        src = torch.empty(n_local, dtype=torch.int32, device=anc.device)
+        sc, rc = (C.c_int64 * world)(), (C.c_int64 * world)()
+        stream = C.c_void_p(torch.cuda.current_stream(anc.device).cuda_stream)
+        check(lib().sipnet_pf_exchange_plan(C.c_void_p(anc.data_ptr()), n_local, world, rank,
+                                            C.c_void_p(send.data_ptr()), C.c_void_p(src.data_ptr()),
+                                            sc, rc, stream), "pf_exchange_plan")
+        cols, off = [], 0
+        for d in range(world):
+            cols.append(send[off:off + sc[d]])
+            off += sc[d]
+        return cols, src, [int(x) for x in rc]
+    return pf_exchange_plan_reference(ancestors, n_local, world, rank)
+
+
+def pf_exchange_plan_reference(ancestors, n_local, world, rank):
+    """the exchange plan in torch operations (any device)"""
     import torch
     n, lo = n_local, rank * n_local
     anc = ancestors.long()

@@ -183,3 +183,22 @@ def test_two_ranks_emulated_on_one_gpu(base, clim):
         after = np.concatenate([ranks[r].get_state().T, ranks[r].get_rings().T], axis=0)
         np.testing.assert_array_equal(after, want[r])
         ranks[r].close()
+
+
+@pytest.mark.parametrize("world,n,kind", [(2, 256, "mild"), (4, 1000, "mild"), (8, 4096, "mild"),
+                                          (8, 4096, "degenerate"), (3, 77, "uniform"), (8, 131072, "mild")])
+def test_native_exchange_plan_equals_the_torch_formulation(world, n, kind):
+    """sipnet_pf_exchange_plan (kernels + one scan + one host sync) against the torch plan it
+    replaces, for every rank of an emulated world: same send lists, same source map, same counts"""
+    lw = weights_case(n * world, kind, seed=world)
+    anc = sd.pf_systematic_ancestors(torch.from_numpy(lw).to(DEV), 0.37)
+    for rank in range(world):
+        got = sd.pf_exchange_plan(anc, n, world, rank)
+        want = sd.pf_exchange_plan_reference(anc, n, world, rank)
+        assert got[2] == want[2], (rank, got[2], want[2])
+        assert torch.equal(got[1], want[1]), rank
+        for d in range(world):
+            assert torch.equal(got[0][d], want[0][d].to(torch.int32)), (rank, d)
+    total_sent = sum(int(c.numel()) for r in range(world) for c in sd.pf_exchange_plan(anc, n, world, r)[0])
+    total_recv = sum(sum(sd.pf_exchange_plan(anc, n, world, r)[2]) for r in range(world))
+    assert total_sent == total_recv
