@@ -150,6 +150,36 @@ __device__ __forceinline__ void takeFactors(const float* block, const int* flags
   } while (uni(f.x < f.y ? f.x : f.y) < step);
   g1 = a.x; g2 = a.y; qSoilT = b.x; gFine = b.y; gCoarse = c.x; moist = c.y;
 }
+// the same with the ring value the step will evict riding in the same round trip (LDS ring, regular
+// tiles: the slot is known at the top of the step, the value is consumed at its end)
+__device__ __forceinline__ void takeFactorsRing(const double* block, const int* flags2, unsigned ringAddr,
+                                                int step, double& g1, double& g2, double& qSoilT,
+                                                double& gFine, double& gCoarse, double& moist, double& ringV) {
+  i2v f;
+  d2v a, b, c;
+  do {
+    asm volatile("ds_read2_b32 %0, %5 offset1:1\n\tds_read2st64_b64 %1, %6 offset1:1\n\t"
+                 "ds_read2st64_b64 %2, %6 offset0:2 offset1:3\n\tds_read2st64_b64 %3, %6 offset0:4 offset1:5\n\t"
+                 "ds_read_b64 %4, %7\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(f), "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(ringV)
+                 : "v"((unsigned)(size_t)flags2), "v"((unsigned)(size_t)block), "v"(ringAddr) : "memory");
+  } while (uni(f.x < f.y ? f.x : f.y) < step);
+  g1 = a.x; g2 = a.y; qSoilT = b.x; gFine = b.y; gCoarse = c.x; moist = c.y;
+}
+__device__ __forceinline__ void takeFactorsRing(const float* block, const int* flags2, unsigned ringAddr,
+                                                int step, float& g1, float& g2, float& qSoilT, float& gFine,
+                                                float& gCoarse, float& moist, double& ringV) {
+  i2v f;
+  f2v a, b, c;
+  do {
+    asm volatile("ds_read2_b32 %0, %5 offset1:1\n\tds_read2st64_b32 %1, %6 offset1:1\n\t"
+                 "ds_read2st64_b32 %2, %6 offset0:2 offset1:3\n\tds_read2st64_b32 %3, %6 offset0:4 offset1:5\n\t"
+                 "ds_read_b64 %4, %7\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(f), "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(ringV)
+                 : "v"((unsigned)(size_t)flags2), "v"((unsigned)(size_t)block), "v"(ringAddr) : "memory");
+  } while (uni(f.x < f.y ? f.x : f.y) < step);
+  g1 = a.x; g2 = a.y; qSoilT = b.x; gFine = b.y; gCoarse = c.x; moist = c.y;
+}
 // five values + flag.  DS writes of one wave execute in issue order, so the flag lands after the
 // values.  Written as DS instructions by hand: the compiler's version of the flag store is a FLAT
 // store followed by a full `s_waitcnt vmcnt(0)`, and its value stores wait for the LDS-DMA tile
@@ -725,9 +755,14 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
           // this step's factors: five from wave L, the moisture effect from wave W (each flag read
           // before its values, one LDS round trip when both are current)
           R g1, g2, qSoilT, gFine, gCoarse, moistEff;
+          double ringNew = 0.0;  // LDS ring: the value this step evicts, read in the same round trip
           {
             WAIT_BEGIN()
-            takeFactors(&mailFac[t & 1][0][lane], seqFacMoist, t, g1, g2, qSoilT, gFine, gCoarse, moistEff);
+            if (RingLds)
+              takeFactorsRing(&mailFac[t & 1][0][lane], seqFacMoist, ldsAddr(&ringL[readSlot * 64 + lane]), t, g1,
+                              g2, qSoilT, gFine, gCoarse, moistEff, ringNew);
+            else
+              takeFactors(&mailFac[t & 1][0][lane], seqFacMoist, t, g1, g2, qSoilT, gFine, gCoarse, moistEff);
             WAIT_END(0)
           }
           const R fSoil = qSoilT * moistEff;
@@ -819,7 +854,7 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
             totNee += (double)tNee;
             const double npp = (double)(photosynthesis - rVeg - rCoarseRoot - rFineRoot);
             if (!RingLds) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rvN) :: "memory");
-            const double vNew = RingLds ? ringL[readSlot * 64 + lane] : (useLast ? lastNpp : rvN);
+            const double vNew = RingLds ? ringNew : (useLast ? lastNpp : rvN);
             if (!(MayDie && diedNow)) {
               ringSum = ffma(-wA, vPrev, ringSum);
               ringSum = ffma(-wB, vNew, ringSum);
