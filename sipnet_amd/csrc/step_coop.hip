@@ -216,6 +216,12 @@ __device__ __forceinline__ void awaitAtLeast(const int* flag, int step) {
 __device__ __forceinline__ void accum(double& pool, double x, double len) { pool = __builtin_fma(x, len, pool); }
 __device__ __forceinline__ void accum(double& pool, float x, float len) { pool += (double)(x * len); }
 
+// -DSIPNET_HWID (diagnostic build): where each wavefront of the first 4096 workgroups ran --
+// HW_ID (wave slot, SIMD, CU, shader array / engine) and XCC_ID -- to check that the three waves of
+// a workgroup sit on three different SIMDs and where the waves of co-resident workgroups land
+#ifdef SIPNET_HWID
+__device__ unsigned g_coopHwId[4096 * 3 * 2];
+#endif
 #ifdef SIPNET_STAMPS
 __device__ unsigned long long g_coopStamps[16];
 #define CSTAMP(k)                                                                    \
@@ -288,6 +294,14 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
 
   const int role = uni((int)threadIdx.x >> 6);  // 0 carbon, 1 water, 2 light
   const int lane = (int)threadIdx.x & 63;
+#ifdef SIPNET_HWID
+  if (lane == 0 && blockIdx.x < 4096) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
+    g_coopHwId[(blockIdx.x * 3 + role) * 2] = hw;
+    g_coopHwId[(blockIdx.x * 3 + role) * 2 + 1] = xcc;
+  }
+#endif
   unsigned char* lds = ldsTiles[role];
 
   const int chunksPerSite = (a.n_members + 63) >> 6;
@@ -1332,6 +1346,11 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
 #undef seqMoist
 }
 
+#ifdef SIPNET_HWID
+extern "C" int sipnet_debug_read_coop_hwid(unsigned* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_coopHwId), sizeof(unsigned) * 4096 * 3 * 2);
+}
+#endif
 #ifdef SIPNET_WAITS
 extern "C" int sipnet_debug_read_coop_waits(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_coopWaits), 16 * sizeof(unsigned long long));
