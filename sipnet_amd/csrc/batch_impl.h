@@ -67,7 +67,7 @@ struct sipnet_batch {
   double* d_diag = nullptr;          // [4][ncol] per-member diagnostics, allocated on request
   SiteStart* d_siteStart = nullptr;  // [n_sites] what setupModel() reads of a site's first record
   size_t planCap = 0, fastCap = 0, ringOpCap = 0, evCap = 0;
-  std::vector<int32_t> opBase, evBase;  // per site: offset of its ring ops / events in the flat arrays
+  int32_t* d_siteBase = nullptr;  // [n_sites][2]: offset of a site's ring ops / events in the flat arrays
   bool stepRecsUploaded = false, fastRecsUploaded = false;  // per-step records: uploaded on first use
   // last boundary a checkpoint was exported at (sipnet_batch_export_restart)
   int32_t exportCacheSite = -1, exportCacheN = -1;

@@ -54,6 +54,60 @@ static void forEachSite(int nS, int nThreads, F f) {
   for (auto& th : pool) th.join();
 }
 
+// flat record buffers are written by the worker threads (first touch in parallel), so they are
+// allocated without value-initialisation
+template <class Rec>
+static int uploadRecords(sipnet_batch* b, Rec** d_ptr, size_t* cap, size_t count, const Rec* host) {
+  // a launch that still reads the previous plan (on any stream) must have finished
+  HIP_TRY(hipDeviceSynchronize());
+  if (count > *cap) {
+    if (*d_ptr) HIP_TRY(hipFree(*d_ptr));
+    *d_ptr = nullptr;
+    *cap = 0;
+    HIP_TRY(hipMalloc(d_ptr, count * sizeof(Rec)));
+    *cap = count;
+  }
+  HIP_TRY(hipMemcpy(*d_ptr, host, count * sizeof(Rec), hipMemcpyHostToDevice));
+  return SIPNET_OK;
+}
+
+// Which record type the next launch will read, as far as it is known at setup time: the
+// throughput kernels' FastRec, or the strict-order kernel's StepRec.
+static bool wantsFastRecs(const sipnet_batch* b) {
+  return b->fastMath && b->kernelPolicy != SIPNET_KERNEL_STRICT;
+}
+
+// One pass per site (buildSitePlan) writes the record type the batch is set up for straight
+// into the flat upload buffer; the other type is produced by a second pass only if a launch ever
+// asks for it (ensureRecords).
+static int buildAndUpload(sipnet_batch* b, bool fastType, bool first) {
+  const double t0 = nowMs();
+  const int nS = b->n_sites, nT = b->n_steps;
+  const int nThreads = planThreadsFor(nS);
+  std::unique_ptr<FastRec[]> fast;
+  std::unique_ptr<StepRec[]> steps;
+  const size_t nFast = (size_t)nS * nT + kFastTile;
+  if (fastType) fast.reset(new FastRec[nFast]);
+  else steps.reset(new StepRec[(size_t)nS * nT]);
+  forEachSite(nS, nThreads, [&](int s) {
+    SitePlan p = buildSitePlan(b->flags, nT, b->clim[s].data(), b->year[s].data(), b->day[s].data(),
+                               (int32_t)b->events[s].size(), b->events[s].data(),
+                               b->resume[s].set ? &b->resume[s] : nullptr, nullptr, /*wantSteps=*/false,
+                               fastType ? nullptr : steps.get() + (size_t)s * nT,
+                               fastType ? fast.get() + (size_t)s * nT : nullptr);
+    if (first) b->plans[s] = std::move(p);
+  });
+  if (fastType) memset((void*)(fast.get() + (size_t)nS * nT), 0, kFastTile * sizeof(FastRec));  // tile padding
+  const double t1 = nowMs();
+  int rc = fastType ? uploadRecords(b, &b->d_fast, &b->fastCap, nFast, fast.get())
+                    : uploadRecords(b, &b->d_plan, &b->planCap, (size_t)nS * nT, steps.get());
+  if (rc) return rc;
+  (fastType ? b->fastRecsUploaded : b->stepRecsUploaded) = true;
+  b->planBuildMs += t1 - t0;
+  b->planUploadMs += nowMs() - t1;
+  return SIPNET_OK;
+}
+
 static int uploadPlan(sipnet_batch* b, hipStream_t stream) {
   // every site needs forcing of equal length
   for (int s = 0; s < b->n_sites; s++) {
@@ -62,40 +116,40 @@ static int uploadPlan(sipnet_batch* b, hipStream_t stream) {
       return SIPNET_ERR_BAD_ARGUMENT;
     }
   }
-  const double t0 = nowMs();
-  const int nS = b->n_sites, nT = b->n_steps;
-  const int nThreads = planThreadsFor(nS);
+  const int nS = b->n_sites;
   b->plans.clear();
   b->plans.resize(nS);
-  forEachSite(nS, nThreads, [&](int s) {
-    b->plans[s] = buildSitePlan(b->flags, nT, b->clim[s].data(), b->year[s].data(), b->day[s].data(),
-                                (int32_t)b->events[s].size(), b->events[s].data(),
-                                b->resume[s].set ? &b->resume[s] : nullptr);
-  });
-  // op / event indices become global
-  b->opBase.assign(nS + 1, 0);
-  b->evBase.assign(nS + 1, 0);
+  b->stepRecsUploaded = false;
+  b->fastRecsUploaded = false;
+  b->planBuildMs = b->planUploadMs = 0.0;
+  b->planThreads = planThreadsFor(nS);
+  int rc = buildAndUpload(b, wantsFastRecs(b), /*first=*/true);
+  if (rc) return rc;
+  const double t0 = nowMs();
+  // ring evictions and events of all sites in one array each; the records index them site-locally
+  // and the kernels add the site's base
+  std::vector<int32_t> bases((size_t)2 * nS);
   std::vector<SiteStart> starts(nS);
+  size_t nOps = 0, nEv = 0;
   for (int s = 0; s < nS; s++) {
     const SitePlan& p = b->plans[s];
     b->siteStatus[s] = p.status;
-    b->opBase[s + 1] = b->opBase[s] + (int32_t)p.ringOps.size();
-    b->evBase[s + 1] = b->evBase[s] + (int32_t)p.events.size();
-    starts[s] = SiteStart{p.steps[0].cumGdd, p.steps[0].tsoil, p.steps[0].dayTime};
+    bases[2 * s] = (int32_t)nOps;
+    bases[2 * s + 1] = (int32_t)nEv;
+    nOps += p.ringOps.size();
+    nEv += p.events.size();
+    starts[s] = SiteStart{p.startCumGdd, p.startTsoil, p.startDayTime};
   }
-  std::vector<RingOp> ops((size_t)b->opBase[nS] + 1);
-  std::vector<EvRec> evs((size_t)b->evBase[nS] + 1);
+  std::vector<RingOp> ops(nOps + 1);
+  std::vector<EvRec> evs(nEv + 1);
   for (int s = 0; s < nS; s++) {
     const SitePlan& p = b->plans[s];
-    if (!p.ringOps.empty()) memcpy(ops.data() + b->opBase[s], p.ringOps.data(), p.ringOps.size() * sizeof(RingOp));
-    if (!p.events.empty()) memcpy(evs.data() + b->evBase[s], p.events.data(), p.events.size() * sizeof(EvRec));
+    if (!p.ringOps.empty()) memcpy(ops.data() + bases[2 * s], p.ringOps.data(), p.ringOps.size() * sizeof(RingOp));
+    if (!p.events.empty()) memcpy(evs.data() + bases[2 * s + 1], p.events.data(), p.events.size() * sizeof(EvRec));
   }
-  if (b->opBase[nS] == 0) ops[0] = RingOp{0.0, 0, -1};
-  if (b->evBase[nS] == 0) evs[0] = EvRec{0, 0, {0, 0, 0, 0}};
+  if (nOps == 0) ops[0] = RingOp{0.0, 0, -1};
+  if (nEv == 0) evs[0] = EvRec{0, 0, {0, 0, 0, 0}};
   const double t1 = nowMs();
-
-  // a launch that still reads the previous plan (on any stream) must have finished
-  HIP_TRY(hipDeviceSynchronize());
   if (ops.size() > b->ringOpCap) {
     if (b->d_ringOps) HIP_TRY(hipFree(b->d_ringOps));
     b->d_ringOps = nullptr;
@@ -110,78 +164,26 @@ static int uploadPlan(sipnet_batch* b, hipStream_t stream) {
     HIP_TRY(hipMalloc(&b->d_events, evs.size() * sizeof(EvRec)));
     b->evCap = evs.size();
   }
-  // synchronous copies: the host vectors die at return
+  // synchronous copies: the host vectors die at return (uploadRecords above has waited for
+  // every launch that might still read the previous plan)
   HIP_TRY(hipMemcpy(b->d_ringOps, ops.data(), ops.size() * sizeof(RingOp), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(b->d_events, evs.data(), evs.size() * sizeof(EvRec), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(b->d_siteStatus, b->siteStatus.data(), nS * sizeof(int32_t), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(b->d_siteStart, starts.data(), nS * sizeof(SiteStart), hipMemcpyHostToDevice));
-  (void)stream;  // synchronous copies on the null stream after the device-wide wait above
+  HIP_TRY(hipMemcpy(b->d_siteBase, bases.data(), bases.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  (void)stream;
   b->planDirty = false;
-  b->stepRecsUploaded = false;
-  b->fastRecsUploaded = false;
   b->exportCacheSite = -1;
-  b->planThreads = nThreads;
-  b->planBuildMs = t1 - t0;
-  b->planUploadMs = nowMs() - t1;
-  return SIPNET_OK;
-}
-
-// flat record buffers are written by the worker threads (first touch in parallel), so they are
-// allocated without value-initialisation
-template <class Rec>
-static int uploadRecords(sipnet_batch* b, Rec** d_ptr, size_t* cap, size_t count, const Rec* host) {
-  HIP_TRY(hipDeviceSynchronize());
-  if (count > *cap) {
-    if (*d_ptr) HIP_TRY(hipFree(*d_ptr));
-    *d_ptr = nullptr;
-    *cap = 0;
-    HIP_TRY(hipMalloc(d_ptr, count * sizeof(Rec)));
-    *cap = count;
-  }
-  HIP_TRY(hipMemcpy(*d_ptr, host, count * sizeof(Rec), hipMemcpyHostToDevice));
+  b->planBuildMs += t1 - t0;
+  b->planUploadMs += nowMs() - t1;
   return SIPNET_OK;
 }
 
 static int ensureStepRecs(sipnet_batch* b) {  // records of the strict-order kernel
-  if (b->stepRecsUploaded) return SIPNET_OK;
-  const double t0 = nowMs();
-  const int nS = b->n_sites, nT = b->n_steps;
-  std::unique_ptr<StepRec[]> steps(new StepRec[(size_t)nS * nT]);
-  forEachSite(nS, planThreadsFor(nS), [&](int s) {
-    StepRec* dst = steps.get() + (size_t)s * nT;
-    memcpy(dst, b->plans[s].steps.data(), (size_t)nT * sizeof(StepRec));
-    if (b->opBase[s] || b->evBase[s])
-      for (int t = 0; t < nT; t++) {
-        dst[t].ringOpFirst += b->opBase[s];
-        dst[t].evFirst += b->evBase[s];
-      }
-  });
-  const double t1 = nowMs();
-  int rc = uploadRecords(b, &b->d_plan, &b->planCap, (size_t)nS * nT, steps.get());
-  if (rc) return rc;
-  b->stepRecsUploaded = true;
-  b->planBuildMs += t1 - t0;
-  b->planUploadMs += nowMs() - t1;
-  return SIPNET_OK;
+  return b->stepRecsUploaded ? SIPNET_OK : buildAndUpload(b, /*fastType=*/false, /*first=*/false);
 }
-
 static int ensureFastRecs(sipnet_batch* b) {  // records of the throughput kernels
-  if (b->fastRecsUploaded) return SIPNET_OK;
-  const double t0 = nowMs();
-  const int nS = b->n_sites, nT = b->n_steps;
-  const size_t count = (size_t)nS * nT + kFastTile;
-  std::unique_ptr<FastRec[]> fast(new FastRec[count]);
-  forEachSite(nS, planThreadsFor(nS), [&](int s) {
-    buildFastRecs(b->plans[s], fast.get() + (size_t)s * nT, b->opBase[s], b->evBase[s]);
-  });
-  memset((void*)(fast.get() + (size_t)nS * nT), 0, kFastTile * sizeof(FastRec));  // tile padding
-  const double t1 = nowMs();
-  int rc = uploadRecords(b, &b->d_fast, &b->fastCap, count, fast.get());
-  if (rc) return rc;
-  b->fastRecsUploaded = true;
-  b->planBuildMs += t1 - t0;
-  b->planUploadMs += nowMs() - t1;
-  return SIPNET_OK;
+  return b->fastRecsUploaded ? SIPNET_OK : buildAndUpload(b, /*fastType=*/true, /*first=*/false);
 }
 
 extern "C" {
@@ -250,6 +252,7 @@ int sipnet_batch_create(const int32_t* flags, int32_t n_sites, int32_t n_members
   if (e == hipSuccess) e = hipMalloc(&b->d_ring, nc * SIPNET_RING_SLOTS * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&b->d_siteStatus, n_sites * sizeof(int32_t));
   if (e == hipSuccess) e = hipMalloc(&b->d_siteStart, n_sites * sizeof(SiteStart));
+  if (e == hipSuccess) e = hipMalloc(&b->d_siteBase, (size_t)2 * n_sites * sizeof(int32_t));
   if (e == hipSuccess) e = hipMalloc(&b->d_scratchRow, nc * sizeof(double));
   if (e == hipSuccess) e = hipMemset(b->d_prm, 0, nc * SIPNET_NPARAMS * sizeof(double));
   if (e == hipSuccess) e = hipMemset(b->d_state, 0, nc * SIPNET_NSTATE * sizeof(double));
@@ -281,6 +284,7 @@ void sipnet_batch_destroy(sipnet_batch* b) {
   if (b->d_events) (void)hipFree(b->d_events);
   if (b->d_siteStatus) (void)hipFree(b->d_siteStatus);
   if (b->d_siteStart) (void)hipFree(b->d_siteStart);
+  if (b->d_siteBase) (void)hipFree(b->d_siteBase);
   if (b->d_diag) (void)hipFree(b->d_diag);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
@@ -500,6 +504,7 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
   a.plan = b->d_plan;
   a.ringOps = b->d_ringOps;
   a.events = b->d_events;
+  a.siteBase = b->d_siteBase;
   a.prm = b->d_prm;
   a.state = b->d_state;
   a.ring = b->d_ring;
@@ -557,6 +562,7 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
     f.fast = b->d_fast;
     f.ringOps = b->d_ringOps;
     f.events = b->d_events;
+    f.siteBase = b->d_siteBase;
     f.prm = b->d_prm;
     f.state = b->d_state;
     f.ring = b->d_ring;
@@ -1043,8 +1049,8 @@ int sipnet_batch_get_site_series(sipnet_batch* b, int32_t site, double* gdd,
     return SIPNET_ERR_BAD_ARGUMENT;
   const SitePlan& p = b->plans[site];
   for (int t = 0; t < b->n_steps; t++) {
-    if (gdd) gdd[t] = p.steps[t].gddAfter;
-    if (d_till_mod) d_till_mod[t] = p.steps[t].dTill;
+    if (gdd) gdd[t] = p.gddAfter[t];
+    if (d_till_mod) d_till_mod[t] = p.dTill[t];
   }
   return SIPNET_OK;
 }

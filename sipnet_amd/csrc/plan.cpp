@@ -60,11 +60,91 @@ int32_t RingSched::advance(int32_t step, double weight, std::vector<RingOp>* ops
   return i;
 }
 
+namespace {
+// the fast record of one step from its StepRec and its ring evictions (slots of the NEXT step and
+// the tile summary are patched in by the caller once they are known)
+void fillFastRec(const StepRec& s, const RingOp* ops, bool tsoilSame, FastRec& f, int& slot0, int& slot1) {
+  f = FastRec{};
+  f.len = s.length;
+  f.invLen = s.invLen;
+  f.tair = s.tair;
+  f.tsoil = s.tsoil;
+  f.negPar = -s.par;
+  f.vpd = s.vpd;
+  f.rainRate = s.rainRate;
+  f.sublW = s.sublNum * s.wspd;
+  f.evapNum = s.evapNum;
+  f.invWspd = s.invWspd;
+  f.tair10 = s.tair10;
+  f.tsoil10 = s.tsoil10;
+  f.cumGdd = s.cumGdd;
+  f.dayTime = s.dayTime;
+  f.log2vpd = s.log2vpd;
+  f.tillP1 = 1.0 + s.dTill;
+  f.gddAfter = s.gddAfter;
+  f.tillAfter = s.tillAfter;
+  // inline evictions; a missing one is a no-op on a valid slot (w = 0)
+  const int safeSlot = s.ringInsSlot >= 0 ? s.ringInsSlot : 0;
+  slot0 = s.ringOpCount > 0 ? ops[0].slot : safeSlot;
+  f.ins0 = s.ringOpCount > 0 ? ops[0].insStep : -1;
+  f.w0 = s.ringOpCount > 0 ? ops[0].w : 0.0;
+  slot1 = s.ringOpCount > 1 ? ops[1].slot : slot0;
+  f.ins1 = s.ringOpCount > 1 ? ops[1].insStep : f.ins0;
+  f.w1 = s.ringOpCount > 1 ? ops[1].w : 0.0;
+  const int bits = (s.bits & STEP_PHEN_NEW_YEAR ? FAST_PHEN_NEW_YEAR : 0) |
+                   (s.bits & STEP_TRACK_NEW_YEAR ? FAST_TRACK_NEW_YEAR : 0) |
+                   (s.tair > 0 ? FAST_TAIR_POS : 0) | (s.par > 0 ? FAST_PAR_POS : 0) |
+                   (s.tsoil < 0 ? FAST_TSOIL_NEG : 0) | (f.w1 != 0.0 ? FAST_HAS_W1 : 0) |
+                   (s.dTill != 0.0 ? FAST_HAS_TILL : 0) | (tsoilSame ? FAST_TSOIL_SAME : 0) |
+                   (s.ringOpCount == 1 && s.ringInsSlot >= 0 ? FAST_RING_REGULAR : 0);
+  f.bitsOps = bits | (s.ringOpCount << 16);
+  f.insSlot = s.ringInsSlot;
+  f.evCount = s.evCount;
+  f.opFirst = s.ringOpFirst;
+  f.evFirst = s.evFirst;
+  f.year = s.year;
+  f.day = s.day;
+}
+
+// summary of the tile [b, e) (see FastRec::tileBits); slot0 / slot1 hold the tile's eviction slots
+void summariseTile(FastRec* out, int b, int e, const int* slot0, const int* slot1) {
+  bool regular = true;
+  int32_t dayMask = 0;
+  const int nOps0 = out[b].bitsOps >> 16;
+  if (nOps0 < 1 || nOps0 > 2) regular = false;
+  auto next = [](int s) { return s + 1 == SIPNET_RING_SLOTS ? 0 : s + 1; };
+  for (int t = b; t < e; t++) {
+    const FastRec& f = out[t];
+    const int bits = f.bitsOps & 0xffff;
+    if (bits & FAST_PAR_POS) dayMask |= 1 << (t - b);
+    if ((bits & (FAST_PHEN_NEW_YEAR | FAST_TRACK_NEW_YEAR)) || f.evCount != 0 || f.insSlot < 0 ||
+        (f.bitsOps >> 16) != nOps0 || f.len != out[b].len || f.invLen != out[b].invLen ||
+        f.w0 != out[b].w0 || f.w1 != out[b].w1)
+      regular = false;
+    if (t > b && (slot0[t - b] != next(slot0[t - b - 1]) || slot1[t - b] != next(slot1[t - b - 1]) ||
+                  f.insSlot != next(out[t - 1].insSlot)))
+      regular = false;
+  }
+  for (int t = b; t < e; t++) {
+    out[t].tileBits = (regular ? FAST_TILE_REGULAR : 0) | (dayMask << 16);
+    out[t].tilePad = 0;
+    out[t].tileEndCumGdd = out[e - 1].cumGdd;
+    out[t].tileEndDayTime = out[e - 1].dayTime;
+  }
+}
+}  // namespace
+
 SitePlan buildSitePlan(const int32_t* flags, int32_t n_steps, const double* clim,
                        const int32_t* year, const int32_t* day, int32_t n_events,
-                       const sipnet_event* events, const PlanCarry* init, PlanCarry* fin) {
+                       const sipnet_event* events, const PlanCarry* init, PlanCarry* fin,
+                       bool wantSteps, StepRec* stepsOut, FastRec* fastOut) {
   SitePlan plan;
-  plan.steps.resize(n_steps);
+  if (wantSteps) plan.steps.resize(n_steps);
+  plan.gddAfter.resize(n_steps);
+  plan.dTill.resize(n_steps);
+  plan.ringOps.reserve((size_t)n_steps * 2 + 8);
+  double prevTsoil10 = 0.0;
+  int tileSlot0[kFastTile], tileSlot1[kFastTile];
   const bool useEvents = flags[SIPNET_F_EVENTS] != 0;
   if (!useEvents) {
     n_events = 0;
@@ -105,8 +185,7 @@ SitePlan buildSitePlan(const int32_t* flags, int32_t n_steps, const double* clim
 
   for (int t = 0; t < n_steps; t++) {
     const double* r = clim + (size_t)SIPNET_NCLIM * t;
-    StepRec& s = plan.steps[t];
-    s = StepRec{};
+    StepRec s = StepRec{};
     s.length = r[0];
     s.tair = r[1];
     s.tsoil = r[2];
@@ -214,6 +293,28 @@ SitePlan buildSitePlan(const int32_t* flags, int32_t n_steps, const double* clim
     s.invWspd = 1.0 / s.wspd;
     s.sublNum = convS * (kEStarSnow - s.vPress);
     s.evapNum = convE * s.vpdSoil;
+
+    plan.gddAfter[t] = s.gddAfter;
+    plan.dTill[t] = s.dTill;
+    if (t == 0) {
+      plan.startCumGdd = s.cumGdd;
+      plan.startTsoil = s.tsoil;
+      plan.startDayTime = s.dayTime;
+    }
+    if (wantSteps) plan.steps[t] = s;
+    if (stepsOut) stepsOut[t] = s;
+    if (fastOut) {
+      int s0, s1;
+      fillFastRec(s, plan.ringOps.data() + s.ringOpFirst, t > 0 && prevTsoil10 == s.tsoil10, fastOut[t], s0, s1);
+      // eviction slots: this step's, and (in the record of the step before) the next step's
+      fastOut[t].slots = s0 | (s1 << 8) | (s0 << 16) | (s1 << 24);
+      if (t > 0) fastOut[t - 1].slots = (fastOut[t - 1].slots & 0xffff) | (s0 << 16) | (s1 << 24);
+      tileSlot0[t % kFastTile] = s0;
+      tileSlot1[t % kFastTile] = s1;
+      if (t % kFastTile == kFastTile - 1 || t == n_steps - 1)
+        summariseTile(fastOut, t - t % kFastTile, t + 1, tileSlot0, tileSlot1);
+    }
+    prevTsoil10 = s.tsoil10;
   }
   if (fin) {
     fin->set = true;
@@ -224,90 +325,6 @@ SitePlan buildSitePlan(const int32_t* flags, int32_t n_steps, const double* clim
     fin->ring = ring;
   }
   return plan;
-}
-
-void buildFastRecs(const SitePlan& plan, FastRec* out, int32_t opBase, int32_t evBase) {
-  const int n = (int)plan.steps.size();
-  std::vector<int> slot0(n), slot1(n);
-  for (int t = 0; t < n; t++) {
-    const StepRec& s = plan.steps[t];
-    FastRec& f = out[t];
-    f = FastRec{};
-    f.len = s.length;
-    f.invLen = s.invLen;
-    f.tair = s.tair;
-    f.tsoil = s.tsoil;
-    f.negPar = -s.par;
-    f.vpd = s.vpd;
-    f.rainRate = s.rainRate;
-    f.sublW = s.sublNum * s.wspd;
-    f.evapNum = s.evapNum;
-    f.invWspd = s.invWspd;
-    f.tair10 = s.tair10;
-    f.tsoil10 = s.tsoil10;
-    f.cumGdd = s.cumGdd;
-    f.dayTime = s.dayTime;
-    f.log2vpd = s.log2vpd;
-    f.tillP1 = 1.0 + s.dTill;
-    f.gddAfter = s.gddAfter;
-    f.tillAfter = s.tillAfter;
-    // inline evictions; a missing one is a no-op on a valid slot (w = 0)
-    const RingOp* ops = plan.ringOps.data() + s.ringOpFirst;
-    const int safeSlot = s.ringInsSlot >= 0 ? s.ringInsSlot : 0;
-    slot0[t] = s.ringOpCount > 0 ? ops[0].slot : safeSlot;
-    f.ins0 = s.ringOpCount > 0 ? ops[0].insStep : -1;
-    f.w0 = s.ringOpCount > 0 ? ops[0].w : 0.0;
-    slot1[t] = s.ringOpCount > 1 ? ops[1].slot : slot0[t];
-    f.ins1 = s.ringOpCount > 1 ? ops[1].insStep : f.ins0;
-    f.w1 = s.ringOpCount > 1 ? ops[1].w : 0.0;
-    int bits = (s.bits & STEP_PHEN_NEW_YEAR ? FAST_PHEN_NEW_YEAR : 0) |
-               (s.bits & STEP_TRACK_NEW_YEAR ? FAST_TRACK_NEW_YEAR : 0) |
-               (s.tair > 0 ? FAST_TAIR_POS : 0) | (s.par > 0 ? FAST_PAR_POS : 0) |
-               (s.tsoil < 0 ? FAST_TSOIL_NEG : 0) | (f.w1 != 0.0 ? FAST_HAS_W1 : 0) |
-               (s.dTill != 0.0 ? FAST_HAS_TILL : 0) |
-               (t > 0 && plan.steps[t - 1].tsoil10 == s.tsoil10 ? FAST_TSOIL_SAME : 0) |
-               (s.ringOpCount == 1 && s.ringInsSlot >= 0 ? FAST_RING_REGULAR : 0);
-    f.bitsOps = bits | (s.ringOpCount << 16);
-    f.insSlot = s.ringInsSlot;
-    f.evCount = s.evCount;
-    f.opFirst = s.ringOpFirst + opBase;
-    f.evFirst = s.evFirst + evBase;
-    f.year = s.year;
-    f.day = s.day;
-  }
-  for (int t = 0; t < n; t++) {
-    const int nx = (t + 1 < n) ? t + 1 : t;
-    out[t].slots = slot0[t] | (slot1[t] << 8) | (slot0[nx] << 16) | (slot1[nx] << 24);
-  }
-  // tile summaries (see FastRec::tileBits)
-  for (int b = 0; b < n; b += kFastTile) {
-    const int e = b + kFastTile < n ? b + kFastTile : n;
-    bool regular = true;
-    int32_t dayMask = 0;
-    const int nOps0 = out[b].bitsOps >> 16;
-    if (nOps0 < 1 || nOps0 > 2) regular = false;
-    for (int t = b; t < e; t++) {
-      const FastRec& f = out[t];
-      const int bits = f.bitsOps & 0xffff;
-      if (bits & FAST_PAR_POS) dayMask |= 1 << (t - b);
-      if ((bits & (FAST_PHEN_NEW_YEAR | FAST_TRACK_NEW_YEAR)) || f.evCount != 0 || f.insSlot < 0 ||
-          (f.bitsOps >> 16) != nOps0 || f.len != out[b].len || f.invLen != out[b].invLen ||
-          f.w0 != out[b].w0 || f.w1 != out[b].w1)
-        regular = false;
-      if (t > b) {
-        auto next = [](int s) { return s + 1 == SIPNET_RING_SLOTS ? 0 : s + 1; };
-        if (slot0[t] != next(slot0[t - 1]) || slot1[t] != next(slot1[t - 1]) ||
-            f.insSlot != next(out[t - 1].insSlot))
-          regular = false;
-      }
-    }
-    for (int t = b; t < e; t++) {
-      out[t].tileBits = (regular ? FAST_TILE_REGULAR : 0) | (dayMask << 16);
-      out[t].tilePad = 0;
-      out[t].tileEndCumGdd = out[e - 1].cumGdd;
-      out[t].tileEndDayTime = out[e - 1].dayTime;
-    }
-  }
 }
 
 }  // namespace sipnet

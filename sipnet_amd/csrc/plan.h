@@ -153,21 +153,25 @@ struct PlanCarry {
 };
 
 struct SitePlan {
-  std::vector<StepRec> steps;
-  std::vector<RingOp> ringOps;  // StepRec.ringOpFirst is local to this vector
-  std::vector<EvRec> events;    // StepRec.evFirst is local to this vector
+  std::vector<StepRec> steps;   // only when the caller asked for them (strict-order kernel, checkpoints)
+  std::vector<double> gddAfter, dTill;  // per step: trackers.gdd after it, d_till_mod during it
+  double startCumGdd = 0.0, startTsoil = 0.0, startDayTime = 0.0;  // of the first record (setupModel)
+  std::vector<RingOp> ringOps;  // StepRec.ringOpFirst / FastRec.opFirst are local to this vector
+  std::vector<EvRec> events;    // StepRec.evFirst / FastRec.evFirst are local to this vector
   int status = SIPNET_OK;       // site-fatal condition found while planning
   std::string message;
 };
 
-// Build the plan of one site.  clim[n_steps][SIPNET_NCLIM] converted climate.
-// Derive the fast records of one site from its plan into out[plan.steps.size()] (which need not
-// be initialised); opBase / evBase are added to the site-local op / event indices.
-void buildFastRecs(const SitePlan& plan, FastRec* out, int32_t opBase, int32_t evBase);
-
+// Build the plan of one site in ONE pass over its climate.  clim[n_steps][SIPNET_NCLIM] converted
+// climate.  The per-step records go where the caller wants them: stepsOut[n_steps] (StepRec, the
+// strict-order kernel) and / or fastOut[n_steps] (FastRec with tile summaries, the throughput
+// kernels) -- neither needs to be initialised, either may be null; wantSteps additionally keeps a
+// copy of the StepRecs in the returned plan.  Ring-op and event indices in the records are local to
+// the site (the kernels add the site's base, KernelArgs::siteBase).
 SitePlan buildSitePlan(const int32_t* flags, int32_t n_steps, const double* clim,
                        const int32_t* year, const int32_t* day, int32_t n_events,
                        const sipnet_event* events, const PlanCarry* init = nullptr,
-                       PlanCarry* fin = nullptr);
+                       PlanCarry* fin = nullptr, bool wantSteps = true, StepRec* stepsOut = nullptr,
+                       FastRec* fastOut = nullptr);
 
 }  // namespace sipnet

@@ -321,6 +321,8 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
   const bool live = m < a.n_members;
   if (!live) m = a.n_members - 1;  // clamped lanes recompute the last member, never store state
   const int64_t col = (int64_t)site * a.n_members + m;
+  // ring-eviction and event indices in the site's records are local to the site
+  const int opBase = uni(a.siteBase[2 * site]), evBase = uni(a.siteBase[2 * site + 1]);
   const int64_t nc = a.ncol;
   double* __restrict__ stp = a.state + col;
   const bool skip = stp[(int64_t)ST_status * nc] != 0.0;
@@ -581,7 +583,7 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
           R evSoilWater = 0;
           const int ev0 = uni(rareI[3]);
           for (int k = 0; k < nEv; k++) {
-            const EvRec& ev = a.events[ev0 + k];
+            const EvRec& ev = a.events[evBase + ev0 + k];
             if (uni(ev.type) == SIPNET_EV_IRRIG) {
               const R p0 = (R)ev.p[0];
               const R evapAmount = ((int)ev.p[1] == 0) ? K_immed * p0 : R(0);
@@ -1037,7 +1039,7 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
       R evSoilC = 0, evLeafOnCreation = 0, evLeafOnFromWood = 0, evLeafOffLitter = 0;
       const int ev0 = uni(rareI[3]);
       for (int k = 0; k < nEv; k++) {
-        const EvRec& ev = a.events[ev0 + k];
+        const EvRec& ev = a.events[evBase + ev0 + k];
         const int type = uni(ev.type);
         const R p0 = (R)ev.p[0], p1 = (R)ev.p[1], p2 = (R)ev.p[2], p3 = (R)ev.p[3];
         if (type == SIPNET_EV_PLANT) {
@@ -1231,7 +1233,7 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
           ringSum = ffma(-q7.y, w0v, ringSum);
           ringSum = ffma(-rare[0], w1v, ringSum);
           for (int k = 2; k < nOps; k++) {
-            const RingOp& op = a.ringOps[uni(rareI[2]) + k];
+            const RingOp& op = a.ringOps[opBase + uni(rareI[2]) + k];
             const int os = uni(op.slot);
             const double rvk = RingLds ? ringL[os * 64 + lane]
                                        : (os == lastIns ? lastNpp : ringp[(uint32_t)os * ncu]);

@@ -139,6 +139,8 @@ void stepFastKernel(FastArgs a) {
   const bool live = m < a.n_members;
   if (!live) m = a.n_members - 1;
   const int64_t col = (int64_t)site * a.n_members + m;
+  // ring-eviction and event indices in the site's records are local to the site
+  const int opBase = uni(a.siteBase[2 * site]), evBase = uni(a.siteBase[2 * site + 1]);
   const int64_t nc = a.ncol;
 
   double* __restrict__ stp = a.state + col;
@@ -576,7 +578,7 @@ void stepFastKernel(FastArgs a) {
       const bool withN = Generic && F.nitrogen;
       const int ev0 = uni(rareI[3]);
       for (int k = 0; k < nEv; k++) {
-        const EvRec& ev = a.events[ev0 + k];
+        const EvRec& ev = a.events[evBase + ev0 + k];
         const int type = uni(ev.type);
         const R p0 = (R)ev.p[0], p1 = (R)ev.p[1], p2 = (R)ev.p[2], p3 = (R)ev.p[3];
         if (type == SIPNET_EV_IRRIG) {
@@ -939,7 +941,7 @@ void stepFastKernel(FastArgs a) {
           ringSum = ffma(-q7.y, w0v, ringSum);
           ringSum = ffma(-rare[0], w1v, ringSum);  // w1 = 0 when there is no second eviction
           for (int k = 2; k < nOps; k++) {
-            const RingOp& op = a.ringOps[uni(rareI[2]) + k];
+            const RingOp& op = a.ringOps[opBase + uni(rareI[2]) + k];
             const double v = (uni(op.insStep) >= ringValidFrom)
                                  ? ringp[(uint32_t)uni(op.slot) * ncu] : 0.0;
             ringSum = ffma(-op.w, v, ringSum);

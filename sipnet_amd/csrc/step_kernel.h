@@ -51,8 +51,9 @@ static_assert(ST_clampCount + 1 == SIPNET_NSTATE, "state vector size");
 
 struct KernelArgs {
   const StepRec* plan;    // [n_sites][n_steps_total]
-  const RingOp* ringOps;  // all sites, StepRec.ringOpFirst is global
-  const EvRec* events;    // all sites, StepRec.evFirst is global
+  const RingOp* ringOps;  // all sites; StepRec.ringOpFirst is site-local, siteBase[2*site] its base
+  const EvRec* events;    // all sites; StepRec.evFirst is site-local, siteBase[2*site+1] its base
+  const int32_t* siteBase;
   const double* prm;      // [SIPNET_NPARAMS][ncol] converted parameters
   double* state;          // [SIPNET_NSTATE][ncol]
   double* ring;           // [SIPNET_RING_SLOTS][ncol]
@@ -85,8 +86,9 @@ struct SetupArgs {
 // arguments of the throughput kernels (step_fast.hip, step_coop.hip): lean outputs
 struct FastArgs {
   const FastRec* fast;    // [n_sites][n_steps_total] (+ kFastTile records of padding)
-  const RingOp* ringOps;
+  const RingOp* ringOps;      // all sites; FastRec.opFirst / evFirst are site-local ...
   const EvRec* events;
+  const int32_t* siteBase;    // ... [n_sites][2]: the site's base in ringOps / events
   const double* prm;
   double* state;
   double* ring;

@@ -214,6 +214,8 @@ __global__ __launch_bounds__(64) void stepKernel(KernelArgs a) {
   const int m = (chunk << 6) + (int)threadIdx.x;
   if (m >= a.n_members) return;  // no barriers below: a lane may simply leave
   const int64_t col = (int64_t)site * a.n_members + m;
+  // ring-eviction and event indices in the site's records are local to the site
+  const int opBase = uni(a.siteBase[2 * site]), evBase = uni(a.siteBase[2 * site + 1]);
   const int64_t nc = a.ncol;
 
   double* __restrict__ stp = a.state + col;
@@ -370,7 +372,7 @@ __global__ __launch_bounds__(64) void stepKernel(KernelArgs a) {
       const int nEv = uni(s.evCount);
       const int ev0 = uni(s.evFirst);
       for (int k = 0; k < nEv; k++) {
-        const EvRec& ev = a.events[ev0 + k];
+        const EvRec& ev = a.events[evBase + ev0 + k];
         const int type = uni(ev.type);
         const R p0 = (R)ev.p[0], p1 = (R)ev.p[1], p2 = (R)ev.p[2], p3 = (R)ev.p[3];
         if (type == SIPNET_EV_IRRIG) {  // events.c:484-506
@@ -1138,7 +1140,7 @@ __global__ __launch_bounds__(64) void stepKernel(KernelArgs a) {
           ringSum = npp * kMeanNppDays;
         } else {
           for (int k = 0; k < nOps; k++) {
-            const RingOp& op = a.ringOps[opFirst + k];
+            const RingOp& op = a.ringOps[opBase + opFirst + k];
             const int slot = uni(op.slot);
             const int ins = uni(op.insStep);
             const double v = (ins >= ringValidFrom) ? ringp[(int64_t)slot * nc] : 0.0;
