@@ -98,11 +98,34 @@ for trial in range(trials):
     for sidx in range(S):
         if ev is not None: b.set_events(sidx, ev)
         b.set_climate(sidx, clims[sidx]); b.set_params(sidx, members)
+    # a third of the trials also ask for the 44-column record and the diagnostics counters (the
+    # "full" instantiations of the throughput kernels, or the strict kernel's)
+    want_full = bool(rng.random() < 0.33)
+    if want_full:
+        b.enable_diagnostics()
+        forced += " full"
     b.setup()
     cuts = sorted(set([0, T] + [int(x) for x in rng.integers(1, T, size=int(rng.integers(0, 4)))]))
-    parts = [b.run(a0, a1 - a0)[0] for a0, a1 in zip(cuts[:-1], cuts[1:])]
-    got = torch.cat(parts, dim=1).double().cpu().numpy()
+    runs_g = [b.run(a0, a1 - a0, full=want_full) for a0, a1 in zip(cuts[:-1], cuts[1:])]
+    got = torch.cat([r_[0] for r_ in runs_g], dim=1).double().cpu().numpy()
+    if want_full:
+        rec_g = torch.cat([r_[1] for r_ in runs_g], dim=0).cpu().numpy()
+        diag_g = b.get_diagnostics()
     status = np.asarray(b.get_status()); state = b.get_state(); b.close()
+    if want_full:
+        # two members of the first site against the oracle's records and counters
+        for m in sorted(set([0, M - 1])):
+            if st[m] != 0:
+                continue
+            so, rec_o, dg = oracle.run_member(flags, members[m], clims[0], ev)
+            assert so == 0
+            cs = np.maximum(np.abs(rec_o).max(axis=0), 1e-3)
+            rtol = 1e-9 if prec == sa.F64 else 5e-3
+            rerr = (np.abs(rec_g[:, :36, m] - rec_o) / cs).max()
+            assert rerr < rtol, f"MISMATCH (record) member {m}: {rerr:.3e}"
+            if prec == sa.F64:
+                assert diag_g["n_clamp_warn"][m] == dg.n_clamp_warn, ("clamp warnings", m, diag_g["n_clamp_warn"][m], dg.n_clamp_warn)
+                assert diag_g["n_balance_warn"][m] == dg.n_balance_warn, ("balance warnings", m)
     ok = (st == 0)
     assert (status[ok] == 0).all() and ((status != 0) == (st != 0)).all(), (trial, status, st)
     # error relative to each plane's maximum, with an absolute floor (a plane can be all ~0:
