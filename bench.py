@@ -560,8 +560,10 @@ def main():
 
     if rank == 0:
         waves_per_block = li["block_threads"] // 64
+        if "Pair" in li["kernel"]:
+            waves_per_block = 6      # two of the eight wavefronts only keep the SIMD rotation and leave at once
         cus_used = min(li["grid"], li["num_cus"]) if "Coop" in li["kernel"] else min((li["grid"] + 3) // 4, li["num_cus"])
-        simds_used = min(li["grid"] * waves_per_block, 4 * li["num_cus"])
+        simds_used = min(li["grid"] * min(waves_per_block, 4), 4 * li["num_cus"])
         line = {
             "metric": "ensemble-site-timesteps/sec", "value": value,
             "unit": "ensemble-site-timesteps/s", "n_gpus": world, "steps": args.steps,

@@ -421,7 +421,7 @@ int sipnet_batch_set_math(sipnet_batch* b, int32_t policy) {
 }
 
 int sipnet_batch_set_kernel(sipnet_batch* b, int32_t kernel, int32_t options) {
-  if (!b || kernel < SIPNET_KERNEL_AUTO || kernel > SIPNET_KERNEL_STRICT ||
+  if (!b || kernel < SIPNET_KERNEL_AUTO || kernel > SIPNET_KERNEL_COOP_PAIR ||
       (options & ~(SIPNET_KOPT_ONE_WAVE_PER_SIMD | SIPNET_KOPT_RUNTIME_FLAGS | SIPNET_KOPT_FULL_STATE |
                    SIPNET_KOPT_NO_REGULAR_TILES))) {
     setError("sipnet_batch_set_kernel: bad argument");
@@ -536,7 +536,7 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
     // and SIPNET_KOPT_FULL_STATE: the "Full" instantiations of the same throughput kernels.
     if (!b->fastMath || d_dbg) kernel = SIPNET_KERNEL_STRICT;
     else if (defaultFlags && blocks <= (int64_t)b->numCUs) kernel = SIPNET_KERNEL_COOP_LDS;
-    else if (defaultFlags && blocks <= 2 * (int64_t)b->numCUs) kernel = SIPNET_KERNEL_COOP_HBM;
+    else if (defaultFlags && blocks <= 2 * (int64_t)b->numCUs) kernel = SIPNET_KERNEL_COOP_PAIR;
     else kernel = SIPNET_KERNEL_ONE_WAVE;
   } else if (kernel != SIPNET_KERNEL_STRICT) {
     if (!b->fastMath) {
@@ -585,7 +585,10 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
     memcpy(f.flags, b->flags, sizeof(f.flags));
     f.numCUs = b->numCUs;
     if (kernel == SIPNET_KERNEL_ONE_WAVE) launchStepFast(f, b->precision, b->kernelOptions, stream, &b->lastLaunch);
-    else launchStepCoop(f, b->precision, kernel == SIPNET_KERNEL_COOP_LDS, stream, &b->lastLaunch);
+    else launchStepCoop(f, b->precision,
+                        kernel == SIPNET_KERNEL_COOP_LDS ? COOP_RING_LDS
+                        : kernel == SIPNET_KERNEL_COOP_PAIR ? COOP_PAIR : COOP_RING_HBM,
+                        stream, &b->lastLaunch);
   } else {
     launchStep(a, b->precision, b->fastMath, stream, &b->lastLaunch);
   }

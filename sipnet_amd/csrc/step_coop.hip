@@ -253,7 +253,7 @@ __device__ unsigned long long g_coopWaits[16];
 #define WAIT_DECL() unsigned long long wAcc[4] = {0, 0, 0, 0}; unsigned long long wT0_; \
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wT0_)::"memory");
 #define WAIT_STORE(base)                                                             \
-  if (blockIdx.x == 0 && lane == 0) {                                                \
+  if (firstChunk && lane == 0) {                                                     \
     unsigned long long wT1_;                                                         \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wT1_)::"memory");     \
     for (int k = 0; k < 3; k++) g_coopWaits[base + k] = wAcc[k];                     \
@@ -273,17 +273,25 @@ __device__ unsigned long long g_coopWaits[16];
 // (the carbon wave writes the carbon / tracker columns, the water wave columns 1, 2, 12, 13, 17, 19, 35)
 // and the optional per-member diagnostics (clamp and carbon-balance warnings; default flags have no
 // nitrogen balance).  Same flux arithmetic and hand-overs as the lean variant.
-template <class R, bool PlainExp, bool RingLds, bool Full>
-__global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
+// Pair: one workgroup of eight wavefronts carries TWO chunks (ring in HBM).  Waves go to the CU's
+// four SIMDs round-robin, so with the roles laid out as  C0 C1 W0 W1 -- -- L0 L1  (waves 4 and 5
+// leave at once) each carbon wave has a SIMD to itself and a chunk's water and light waves -- busy at
+// different times of a step -- share one, whatever SIMD the workgroup starts on.  Two separate
+// three-wave workgroups on a CU put the second one's water wave on the first one's carbon SIMD
+// (tools/coop_placement.py), which costs the carbon wave a third of its issue rate.
+template <class R, bool PlainExp, bool RingLds, bool Full, bool Pair>
+__device__ __forceinline__ void coopBody(const FastArgs& a) {
+  static_assert(!(Pair && RingLds), "two chunks' rings do not fit one CU's LDS");
+  constexpr int NP = Pair ? 2 : 1;
   // per-wave private record tiles (each wave stages and awaits its own DMA) + mailboxes
-  __shared__ alignas(16) unsigned char ldsTiles[3][2 * kTileBytes];
-  __shared__ R mailLai[2][64], mailPgp[2][64], mailPsn[2][64];
+  __shared__ alignas(16) unsigned char ldsTilesAll[NP][3][2 * kTileBytes];
+  __shared__ R mailLaiAll[NP][2][64], mailPgpAll[NP][2][64], mailPsnAll[NP][2][64];
   // rows 0..4: g1 g2 qSoilT gFine gCoarse of a step (wave L: climate x parameters only); row 5: the
   // soil-moisture effect on heterotrophic respiration (wave W: its state)
-  __shared__ alignas(16) R mailFac[2][6][64];
-  __shared__ int mailAlive[2][64];  // aliveWord(): wave C's confirmation of the leaf area it posted
-  __shared__ int seqLai, seqPgp, seqPsn;
-  __shared__ alignas(8) int seqFacMoist[2];  // [0] wave L's factor rows, [1] wave W's moisture row
+  __shared__ alignas(16) R mailFacAll[NP][2][6][64];
+  __shared__ int mailAliveAll[NP][2][64];  // aliveWord(): wave C's confirmation of the leaf area it posted
+  __shared__ int seqLaiAll[NP], seqPgpAll[NP], seqPsnAll[NP];
+  __shared__ alignas(8) int seqFacMoistAll[NP][2];  // [0] wave L's factor rows, [1] wave W's moisture row
 #define seqFac seqFacMoist[0]
 #define seqMoist seqFacMoist[1]
   // The running-mean ring of the 64 members lives in LDS for the whole launch (250 x 64 x 8 B =
@@ -292,31 +300,48 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
   // loads would queue behind the previous step's output stores (~1800 cycles to their ack).
   __shared__ double ringL[RingLds ? SIPNET_RING_SLOTS * 64 : 64];
 
-  const int role = uni((int)threadIdx.x >> 6);  // 0 carbon, 1 water, 2 light
+  const int wave = uni((int)threadIdx.x >> 6);
+  // 0 carbon, 1 water, 2 light; -1: a placeholder wave that only keeps the SIMD rotation
+  const int sub = Pair ? (wave & 1) : 0;  // which of the workgroup's chunks
+  const int role = Pair ? ((wave >> 1) == 3 ? 2 : (wave >> 1) == 2 ? -1 : (wave >> 1)) : wave;
   const int lane = (int)threadIdx.x & 63;
+  auto& mailLai = mailLaiAll[sub];
+  auto& mailPgp = mailPgpAll[sub];
+  auto& mailPsn = mailPsnAll[sub];
+  auto& mailFac = mailFacAll[sub];
+  auto& mailAlive = mailAliveAll[sub];
+  int& seqLai = seqLaiAll[sub];
+  int& seqPgp = seqPgpAll[sub];
+  int& seqPsn = seqPsnAll[sub];
+  auto& seqFacMoist = seqFacMoistAll[sub];
+  [[maybe_unused]] const bool firstChunk = blockIdx.x == 0 && sub == 0;  // diagnostics builds report this one
 #ifdef SIPNET_HWID
-  if (lane == 0 && blockIdx.x < 4096) {
+  if (lane == 0 && role >= 0 && (blockIdx.x * NP + sub) < 4096) {
     unsigned hw, xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
-    g_coopHwId[(blockIdx.x * 3 + role) * 2] = hw;
-    g_coopHwId[(blockIdx.x * 3 + role) * 2 + 1] = xcc;
+    g_coopHwId[((blockIdx.x * NP + sub) * 3 + role) * 2] = hw;
+    g_coopHwId[((blockIdx.x * NP + sub) * 3 + role) * 2 + 1] = xcc;
   }
 #endif
-  unsigned char* lds = ldsTiles[role];
+  unsigned char* lds = ldsTilesAll[sub][role < 0 ? 0 : role];
 
   const int chunksPerSite = (a.n_members + 63) >> 6;
   int site, chunk;
   {
-    const int b = (int)blockIdx.x;
+    const int pb = (int)blockIdx.x;
     if ((a.n_sites & 7) == 0) {  // keep a site's chunks on one XCD group (speed only)
-      const int g = b & 7, j = b >> 3;
+      const int g = pb & 7, j = (pb >> 3) * NP + sub;
       site = g + 8 * (j / chunksPerSite);
       chunk = j % chunksPerSite;
     } else {
+      const int b = pb * NP + sub;
       site = b / chunksPerSite;
       chunk = b % chunksPerSite;
     }
   }
+  // an odd number of chunks leaves the last workgroup's second half empty
+  const bool present = uni((int)(site < a.n_sites)) != 0 && role >= 0;
+  if (!present) site = 0, chunk = 0;
   int m = (chunk << 6) + lane;
   const bool live = m < a.n_members;
   if (!live) m = a.n_members - 1;  // clamped lanes recompute the last member, never store state
@@ -333,18 +358,19 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
 #define ST(name) stp[(int64_t)ST_##name * nc]
 
   const int tBegin = a.step0, tEnd = a.step0 + a.n_steps;
-  if (threadIdx.x == 0) {
-    seqLai = tBegin - 1;
-    seqPgp = tBegin - 1;
-    seqPsn = tBegin - 1;
-    seqFac = tBegin - 1;
-    seqMoist = tBegin - 1;
-  }
   if (role == 0) {
+    if (lane == 0) {
+      seqLai = tBegin - 1;
+      seqPgp = tBegin - 1;
+      seqPsn = tBegin - 1;
+      seqFac = tBegin - 1;
+      seqMoist = tBegin - 1;
+    }
     mailAlive[0][lane] = 0;
     mailAlive[1][lane] = 0;
   }
   __syncthreads();  // the only workgroup barrier: flags initialised before anyone spins
+  if (!present) return;
 
   const unsigned char* __restrict__ planBytes =
       (const unsigned char*)(a.fast + (int64_t)site * a.n_steps_total);
@@ -1303,7 +1329,7 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
   }  // tiles
 
 #ifdef SIPNET_STAMPS
-  if (blockIdx.x == 0 && lane == 0)
+  if (firstChunk && lane == 0)
     for (int k = 0; k < 8; k++) g_coopStamps[k] = cAcc[k];
 #endif
   WAIT_STORE(8)
@@ -1348,6 +1374,16 @@ __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
 #undef seqMoist
 }
 
+template <class R, bool PlainExp, bool RingLds, bool Full>
+__global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
+  coopBody<R, PlainExp, RingLds, Full, false>(a);
+}
+
+template <class R, bool PlainExp, bool Full>
+__global__ __launch_bounds__(512) void stepCoopPairKernel(FastArgs a) {
+  coopBody<R, PlainExp, false, Full, true>(a);
+}
+
 #ifdef SIPNET_HWID
 extern "C" int sipnet_debug_read_coop_hwid(unsigned* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_coopHwId), sizeof(unsigned) * 4096 * 3 * 2);
@@ -1364,15 +1400,27 @@ extern "C" int sipnet_debug_read_coop_stamps(unsigned long long* out) {
 }
 #endif
 
-void launchStepCoop(const FastArgs& a, int precision, bool ringInLds, hipStream_t stream, LaunchInfo* info) {
+void launchStepCoop(const FastArgs& a, int precision, int layout, hipStream_t stream, LaunchInfo* info) {
   const int chunksPerSite = (a.n_members + 63) / 64;
-  const dim3 grid(a.n_sites * chunksPerSite), block(192);
+  const bool ringInLds = layout == COOP_RING_LDS, pair = layout == COOP_PAIR;
+  const int chunks = a.n_sites * chunksPerSite;
+  // paired chunks: with the XCD-grouped mapping every group of eight workgroups carries 16 chunks
+  const int pairGroups = (a.n_sites & 7) == 0 ? 8 * ((chunks / 8 + 1) / 2) : (chunks + 1) / 2;
+  const dim3 grid(pair ? pairGroups : chunks), block(pair ? 512 : 192);
 #define COOP_LAUNCH(R, P, L)                                                                        \
   {                                                                                                 \
     if (a.full) hipLaunchKernelGGL((stepCoopKernel<R, P, L, true>), grid, block, 0, stream, a);      \
     else hipLaunchKernelGGL((stepCoopKernel<R, P, L, false>), grid, block, 0, stream, a);           \
   }
-  if (precision == SIPNET_F64) {
+#define PAIR_LAUNCH(R, P)                                                                           \
+  {                                                                                                 \
+    if (a.full) hipLaunchKernelGGL((stepCoopPairKernel<R, P, true>), grid, block, 0, stream, a);     \
+    else hipLaunchKernelGGL((stepCoopPairKernel<R, P, false>), grid, block, 0, stream, a);          \
+  }
+  if (pair) {
+    if (precision == SIPNET_F64) { if (a.plainExp) PAIR_LAUNCH(double, true) else PAIR_LAUNCH(double, false) }
+    else { if (a.plainExp) PAIR_LAUNCH(float, true) else PAIR_LAUNCH(float, false) }
+  } else if (precision == SIPNET_F64) {
     if (a.plainExp) { if (ringInLds) COOP_LAUNCH(double, true, true) else COOP_LAUNCH(double, true, false) }
     else { if (ringInLds) COOP_LAUNCH(double, false, true) else COOP_LAUNCH(double, false, false) }
   } else {
@@ -1380,15 +1428,19 @@ void launchStepCoop(const FastArgs& a, int precision, bool ringInLds, hipStream_
     else { if (ringInLds) COOP_LAUNCH(float, false, true) else COOP_LAUNCH(float, false, false) }
   }
 #undef COOP_LAUNCH
+#undef PAIR_LAUNCH
   if (info) {
-    snprintf(info->kernel, sizeof info->kernel, "stepCoopKernel<%s, %s, %s, %s>",
-             precision == SIPNET_F64 ? "double" : "float", a.plainExp ? "true" : "false",
-             ringInLds ? "true" : "false", a.full ? "true" : "false");
+    const char* r = precision == SIPNET_F64 ? "double" : "float";
+    const char* pe = a.plainExp ? "true" : "false";
+    const char* fu = a.full ? "true" : "false";
+    if (pair) snprintf(info->kernel, sizeof info->kernel, "stepCoopPairKernel<%s, %s, %s>", r, pe, fu);
+    else snprintf(info->kernel, sizeof info->kernel, "stepCoopKernel<%s, %s, %s, %s>", r, pe,
+                  ringInLds ? "true" : "false", fu);
     info->grid = (int32_t)grid.x;
-    info->block = 192;
-    info->wavesPerSimd = 1;
+    info->block = (int32_t)block.x;
+    info->wavesPerSimd = pair ? 2 : 1;
     const int elem = precision == SIPNET_F64 ? 8 : 4;
-    info->ldsBytes = 3 * 2 * kTileBytes + (2 * 64 * 3 + 2 * 6 * 64) * elem + 2 * 64 * 4 + 5 * 4 +
+    info->ldsBytes = (pair ? 2 : 1) * (3 * 2 * kTileBytes + (2 * 64 * 3 + 2 * 6 * 64) * elem + 2 * 64 * 4 + 5 * 4) +
                      (ringInLds ? SIPNET_RING_SLOTS * 64 : 64) * 8;
   }
 }

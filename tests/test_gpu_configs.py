@@ -119,8 +119,9 @@ def test_c3_65536_members_fp32_mixed(oracle, base):
 
 
 def test_c4_32_sites_x_1024_members_fp64(oracle, base):
-    """one GPU's share of the 256-site configuration: cooperative kernel with the ring in HBM and
-    the XCD-grouped block mapping (n_sites % 8 == 0), every site with its own forcing"""
+    """one GPU's share of the 256-site configuration: the paired-chunk cooperative kernel (two
+    chunks per workgroup, ring in HBM) with the XCD-grouped block mapping (n_sites % 8 == 0), every
+    site with its own forcing"""
     S, M = 32, 1024
     clims = [year_clim(site=s) for s in range(S)]
     members = synth.perturbed_params(base, M)
@@ -135,7 +136,7 @@ def test_c4_32_sites_x_1024_members_fp64(oracle, base):
     b.close()
     del planes
     torch.cuda.empty_cache()
-    assert li["kernel"] == "stepCoopKernel<double, true, false, false>" and li["grid"] == 512, li
+    assert li["kernel"] == "stepCoopPairKernel<double, true, false>" and li["grid"] == 256, li
     assert li["plan_threads"] >= 1 and li["plan_build_ms"] > 0
     assert (st == 0).all()
     worst = 0.0
@@ -243,6 +244,8 @@ KERNELS = [
     ("coop_lds_f32", sa.F32_MIXED, sa.KERNEL_COOP_LDS, 0, "stepCoopKernel<float, true, true, false>"),
     ("coop_hbm_f64", sa.F64, sa.KERNEL_COOP_HBM, 0, "stepCoopKernel<double, true, false, false>"),
     ("coop_hbm_f32", sa.F32_MIXED, sa.KERNEL_COOP_HBM, 0, "stepCoopKernel<float, true, false, false>"),
+    ("coop_pair_f64", sa.F64, sa.KERNEL_COOP_PAIR, 0, "stepCoopPairKernel<double, true, false>"),
+    ("coop_pair_f32", sa.F32_MIXED, sa.KERNEL_COOP_PAIR, 0, "stepCoopPairKernel<float, true, false>"),
     ("runtime_flags_f64", sa.F64, sa.KERNEL_ONE_WAVE, sa.KOPT_RUNTIME_FLAGS, "stepFastKernel<double, true, 1, 1, false>"),
     ("runtime_flags_f32", sa.F32_MIXED, sa.KERNEL_ONE_WAVE, sa.KOPT_RUNTIME_FLAGS, "stepFastKernel<float, true, 1, 1, false>"),
 ]
@@ -291,6 +294,7 @@ def test_non_plain_exponents_take_the_general_instantiations(oracle, base):
     assert (so == 0).all()
     for kernel, expect in ((sa.KERNEL_COOP_LDS, "stepCoopKernel<double, false, true, false>"),
                            (sa.KERNEL_COOP_HBM, "stepCoopKernel<double, false, false, false>"),
+                           (sa.KERNEL_COOP_PAIR, "stepCoopPairKernel<double, false, false>"),
                            (sa.KERNEL_ONE_WAVE, "stepFastKernel<double, false, 0, 1, false>")):
         b = build(flags, [clim], members, sa.F64, kernel)
         got = b.run()[0].cpu().numpy()
@@ -315,7 +319,7 @@ def test_regular_tile_path_equals_the_general_step_bit_for_bit(oracle, base):
     members[130] = members[3]                            # the same member in chunk 0 and chunk 2
     T = clim.n_steps
     outs = {}
-    for kernel in (sa.KERNEL_COOP_LDS, sa.KERNEL_COOP_HBM):
+    for kernel in (sa.KERNEL_COOP_LDS, sa.KERNEL_COOP_HBM, sa.KERNEL_COOP_PAIR):
         for opt in (0, sa.KOPT_NO_REGULAR_TILES):
             b = build(flags, [clim], members, sa.F64, kernel, opt)
             planes, _ = b.alloc_outputs(T)
@@ -329,6 +333,40 @@ def test_regular_tile_path_equals_the_general_step_bit_for_bit(oracle, base):
         np.testing.assert_array_equal(fastp[2], gen[2])
         assert np.array_equal(fastp[0][:, :, 130], fastp[0][:, :, 3])
     np.testing.assert_array_equal(outs[(sa.KERNEL_COOP_LDS, 0)][0], outs[(sa.KERNEL_COOP_HBM, 0)][0])
+    np.testing.assert_array_equal(outs[(sa.KERNEL_COOP_LDS, 0)][0], outs[(sa.KERNEL_COOP_PAIR, 0)][0])
     pick = np.r_[0:8, 64:72, 128:136]
     want, _, _ = oracle.run_block(flags, members[pick], clim)
     assert np.abs(outs[(sa.KERNEL_COOP_LDS, 0)][0][:, :, pick] - want).max() < TOL_F64
+
+
+@pytest.mark.parametrize("S,M", [(8, 192), (3, 130), (3, 200), (16, 64), (1, 64)])
+def test_paired_chunk_workgroups_cover_every_chunk_once(S, M, oracle, base):
+    """stepCoopPairKernel maps two chunks to a workgroup: with the XCD-grouped mapping (8 | S) and
+    without, with an odd number of chunks (the last workgroup's second half is empty), ragged last
+    chunks, a single chunk.  Same bits as the one-chunk workgroups, state and rings included; two
+    members of every site against the oracle"""
+    flags = sa.flags_from()
+    clims = [year_clim(site=s, n=48 * 12, start_day=170) for s in range(S)]
+    members = synth.perturbed_params(base, M)
+    outs = {}
+    for kernel in (sa.KERNEL_COOP_HBM, sa.KERNEL_COOP_PAIR):
+        b = build(flags, clims, members, sa.F64, kernel)
+        planes, _ = b.alloc_outputs(clims[0].n_steps)
+        planes.fill_(float("nan"))
+        for a, z in ((0, 21), (21, clims[0].n_steps)):
+            b.run(a, z - a, planes=planes[:, a:z])
+        li = b.last_launch()
+        outs[kernel] = (planes.cpu().numpy(), b.get_state(), b.get_rings(), li)
+        b.close()
+    li = outs[sa.KERNEL_COOP_PAIR][3]
+    chunks = S * ((M + 63) // 64)
+    assert li["kernel"] == "stepCoopPairKernel<double, true, false>" and li["block_threads"] == 512
+    assert li["grid"] == (8 * ((chunks // 8 + 1) // 2) if S % 8 == 0 else (chunks + 1) // 2), li
+    for k in range(3):
+        np.testing.assert_array_equal(outs[sa.KERNEL_COOP_PAIR][k], outs[sa.KERNEL_COOP_HBM][k])
+    got = outs[sa.KERNEL_COOP_PAIR][0].reshape(3, -1, S, M)
+    assert np.isfinite(got).all()
+    for s in range(S):
+        pick = np.array([0, M - 1])
+        want, _, _ = oracle.run_block(flags, members[pick], clims[s])
+        assert np.abs(got[:, :, s, pick] - want).max() < TOL_F64, s

@@ -17,6 +17,7 @@ pytestmark = pytest.mark.gpu
 BASE = os.path.join(helpers.REPO, "sipnet_amd", "data", "base_forest.param")
 KERNELS = [("coop_lds", sa.KERNEL_COOP_LDS, 0, "stepCoopKernel<double, true, true, true>"),
            ("coop_hbm", sa.KERNEL_COOP_HBM, 0, "stepCoopKernel<double, true, false, true>"),
+           ("coop_pair", sa.KERNEL_COOP_PAIR, 0, "stepCoopPairKernel<double, true, true>"),
            ("one_wave", sa.KERNEL_ONE_WAVE, 0, "stepFastKernel<double, true, 0, 1, true>"),
            ("runtime_flags", sa.KERNEL_ONE_WAVE, sa.KOPT_RUNTIME_FLAGS, "stepFastKernel<double, true, 1, 1, true>")]
 
@@ -108,7 +109,8 @@ def test_lean_launches_leave_the_other_accumulators_alone_and_full_state_advance
 
 
 SPECIAL = [("strict", False, sa.KERNEL_AUTO, 0), ("coop_lds", True, sa.KERNEL_COOP_LDS, 0),
-           ("coop_hbm", True, sa.KERNEL_COOP_HBM, 0), ("one_wave", True, sa.KERNEL_ONE_WAVE, 0),
+           ("coop_hbm", True, sa.KERNEL_COOP_HBM, 0), ("coop_pair", True, sa.KERNEL_COOP_PAIR, 0),
+           ("one_wave", True, sa.KERNEL_ONE_WAVE, 0),
            ("runtime_flags", True, sa.KERNEL_ONE_WAVE, sa.KOPT_RUNTIME_FLAGS)]
 
 

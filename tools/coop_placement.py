@@ -13,7 +13,7 @@ import numpy as np, torch, sipnet_amd as sa
 from sipnet_amd import synth
 from bench import WORKLOADS
 wl = WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "c10k"]
-kern = dict(auto=sa.KERNEL_AUTO, coop_hbm=sa.KERNEL_COOP_HBM, coop_lds=sa.KERNEL_COOP_LDS)[sys.argv[2] if len(sys.argv) > 2 else "auto"]
+kern = dict(auto=sa.KERNEL_AUTO, coop_hbm=sa.KERNEL_COOP_HBM, coop_lds=sa.KERNEL_COOP_LDS, coop_pair=sa.KERNEL_COOP_PAIR)[sys.argv[2] if len(sys.argv) > 2 else "auto"]
 flags = sa.flags_from()
 base, _ = sa.read_params(os.path.join(REPO, "sipnet_amd", "data", "base_forest.param"), flags)
 S, M, T = wl["sites"], wl["members"], 48 * 20

@@ -91,7 +91,8 @@ for trial in range(trials):
     default_flags = not any(v != sa.DEFAULT_FLAGS.get(k) for k, v in kw.items())
     if fast or prec == sa.F32_MIXED:
         if r < 0.3: kern = sa.KERNEL_ONE_WAVE; forced = " one-wave"
-        elif r < 0.45 and default_flags: kern = sa.KERNEL_COOP_HBM; forced = " coop-hbm"
+        elif r < 0.4 and default_flags: kern = sa.KERNEL_COOP_HBM; forced = " coop-hbm"
+        elif r < 0.5 and default_flags: kern = sa.KERNEL_COOP_PAIR; forced = " coop-pair"
         elif r < 0.6 and default_flags: kern = sa.KERNEL_COOP_LDS; forced = " coop-lds"
     if rng.random() < 0.3: kopt = sa.KOPT_RUNTIME_FLAGS; forced += " rt-flags"
     b = sa.Batch(flags, S, M, prec, fast_math=fast, kernel=kern, kernel_options=kopt)
