@@ -529,8 +529,10 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
   if (kernel == SIPNET_KERNEL_AUTO) {
     // Few 64-member chunks per CU: the step is bound by what one wavefront can issue, so three
     // wavefronts share each chunk (step_coop.hip) -- with the chunk's ring in LDS when there is
-    // at most one chunk per CU (c10k 12.4 vs 18.2 ms), in HBM up to two per CU (c4 16.0 vs
-    // 19.3 ms).  Bigger batches fill the SIMDs with the one-wave kernel (c3: 16.9 vs 27.6 ms).
+    // at most one chunk per CU (c10k 9.0 vs 18.2 ms); up to two per CU as ONE eight-wave workgroup
+    // per CU carrying two chunks with their rings in HBM, which keeps every carbon wave alone on
+    // its SIMD (c4 10.6 ms; two three-wave workgroups per CU: 12.4; one-wave kernel: 19.3).
+    // Bigger batches fill the SIMDs with the one-wave kernel (c3: 16.9 vs 27.6 ms).
     // Optional model flags (litter pool, nitrogen cycle, ...) always take the one-wave kernel.
     // Strict arithmetic and the debug plane: the strict-order kernel.  Full records, diagnostics
     // and SIPNET_KOPT_FULL_STATE: the "Full" instantiations of the same throughput kernels.
