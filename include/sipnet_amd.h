@@ -228,7 +228,8 @@ enum sipnet_kernel {
   SIPNET_KERNEL_COOP_LDS = 2, /* stepCoopKernel, ring in LDS (one workgroup per CU) */
   SIPNET_KERNEL_COOP_HBM = 3, /* stepCoopKernel, ring in HBM */
   SIPNET_KERNEL_STRICT = 4,   /* stepKernel (with SIPNET_MATH_FAST: its fast-math variant) */
-  SIPNET_KERNEL_COOP_PAIR = 5 /* stepCoopPairKernel: two chunks per workgroup, ring in HBM */
+  SIPNET_KERNEL_COOP_PAIR = 5, /* stepCoopPairKernel: two chunks per workgroup, ring in HBM */
+  SIPNET_KERNEL_COOP_QUAD = 6  /* stepCoopQuadKernel: four chunks per twelve-wave workgroup */
 };
 enum sipnet_kernel_option {
   SIPNET_KOPT_ONE_WAVE_PER_SIMD = 1, /* one-wave kernel: never the 256-VGPR (two waves/SIMD) build */

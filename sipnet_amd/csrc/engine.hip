@@ -421,7 +421,7 @@ int sipnet_batch_set_math(sipnet_batch* b, int32_t policy) {
 }
 
 int sipnet_batch_set_kernel(sipnet_batch* b, int32_t kernel, int32_t options) {
-  if (!b || kernel < SIPNET_KERNEL_AUTO || kernel > SIPNET_KERNEL_COOP_PAIR ||
+  if (!b || kernel < SIPNET_KERNEL_AUTO || kernel > SIPNET_KERNEL_COOP_QUAD ||
       (options & ~(SIPNET_KOPT_ONE_WAVE_PER_SIMD | SIPNET_KOPT_RUNTIME_FLAGS | SIPNET_KOPT_FULL_STATE |
                    SIPNET_KOPT_NO_REGULAR_TILES))) {
     setError("sipnet_batch_set_kernel: bad argument");
@@ -526,19 +526,23 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
   const bool defaultFlags = isDefaultFlagSet(b->flags);
   const int64_t blocks = (int64_t)b->n_sites * ((b->n_members + 63) / 64);
   int kernel = b->kernelPolicy;
+  const bool wantFull = d_rec || b->d_diag || (b->kernelOptions & SIPNET_KOPT_FULL_STATE);
   if (kernel == SIPNET_KERNEL_AUTO) {
     // Few 64-member chunks per CU: the step is bound by what one wavefront can issue, so three
     // wavefronts share each chunk (step_coop.hip) -- with the chunk's ring in LDS when there is
     // at most one chunk per CU (c10k 9.0 vs 18.2 ms); up to two per CU as ONE eight-wave workgroup
     // per CU carrying two chunks with their rings in HBM, which keeps every carbon wave alone on
     // its SIMD (c4 10.6 ms; two three-wave workgroups per CU: 12.4; one-wave kernel: 19.3).
-    // Bigger batches fill the SIMDs with the one-wave kernel (c3: 16.9 vs 27.6 ms).
+    // Up to four per CU: one twelve-wave workgroup per four chunks, every SIMD running the three
+    // waves of one chunk (c3 13.0 ms; one-wave kernel 15.3); no full-state build of that one (VGPRs).
+    // Bigger batches fill the SIMDs with the one-wave kernel, two waves per SIMD.
     // Optional model flags (litter pool, nitrogen cycle, ...) always take the one-wave kernel.
     // Strict arithmetic and the debug plane: the strict-order kernel.  Full records, diagnostics
     // and SIPNET_KOPT_FULL_STATE: the "Full" instantiations of the same throughput kernels.
     if (!b->fastMath || d_dbg) kernel = SIPNET_KERNEL_STRICT;
     else if (defaultFlags && blocks <= (int64_t)b->numCUs) kernel = SIPNET_KERNEL_COOP_LDS;
     else if (defaultFlags && blocks <= 2 * (int64_t)b->numCUs) kernel = SIPNET_KERNEL_COOP_PAIR;
+    else if (defaultFlags && blocks <= 4 * (int64_t)b->numCUs && !wantFull) kernel = SIPNET_KERNEL_COOP_QUAD;
     else kernel = SIPNET_KERNEL_ONE_WAVE;
   } else if (kernel != SIPNET_KERNEL_STRICT) {
     if (!b->fastMath) {
@@ -551,6 +555,11 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
     }
     if (kernel != SIPNET_KERNEL_ONE_WAVE && !defaultFlags) {
       setError("sipnet_batch_run: the cooperative kernel has the default model flags compiled in");
+      return SIPNET_ERR_BAD_ARGUMENT;
+    }
+    if (kernel == SIPNET_KERNEL_COOP_QUAD && wantFull) {
+      setError("sipnet_batch_run: the four-chunk cooperative kernel has no full-state instantiation "
+               "(records, diagnostics, SIPNET_KOPT_FULL_STATE)");
       return SIPNET_ERR_BAD_ARGUMENT;
     }
   }
@@ -581,7 +590,7 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
     f.plainExp = b->genericExponents ? 0 : 1;
     f.rec = d_rec;
     f.diag = b->d_diag;
-    f.full = (d_rec || b->d_diag || (b->kernelOptions & SIPNET_KOPT_FULL_STATE)) ? 1 : 0;
+    f.full = wantFull ? 1 : 0;
     f.options = b->kernelOptions;
     f.scratchRow = b->d_scratchRow;
     memcpy(f.flags, b->flags, sizeof(f.flags));
@@ -589,7 +598,8 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
     if (kernel == SIPNET_KERNEL_ONE_WAVE) launchStepFast(f, b->precision, b->kernelOptions, stream, &b->lastLaunch);
     else launchStepCoop(f, b->precision,
                         kernel == SIPNET_KERNEL_COOP_LDS ? COOP_RING_LDS
-                        : kernel == SIPNET_KERNEL_COOP_PAIR ? COOP_PAIR : COOP_RING_HBM,
+                        : kernel == SIPNET_KERNEL_COOP_PAIR ? COOP_PAIR
+                        : kernel == SIPNET_KERNEL_COOP_QUAD ? COOP_QUAD : COOP_RING_HBM,
                         stream, &b->lastLaunch);
   } else {
     launchStep(a, b->precision, b->fastMath, stream, &b->lastLaunch);

@@ -273,16 +273,19 @@ __device__ unsigned long long g_coopWaits[16];
 // (the carbon wave writes the carbon / tracker columns, the water wave columns 1, 2, 12, 13, 17, 19, 35)
 // and the optional per-member diagnostics (clamp and carbon-balance warnings; default flags have no
 // nitrogen balance).  Same flux arithmetic and hand-overs as the lean variant.
-// Pair: one workgroup of eight wavefronts carries TWO chunks (ring in HBM).  Waves go to the CU's
-// four SIMDs round-robin, so with the roles laid out as  C0 C1 W0 W1 -- -- L0 L1  (waves 4 and 5
-// leave at once) each carbon wave has a SIMD to itself and a chunk's water and light waves -- busy at
-// different times of a step -- share one, whatever SIMD the workgroup starts on.  Two separate
-// three-wave workgroups on a CU put the second one's water wave on the first one's carbon SIMD
-// (tools/coop_placement.py), which costs the carbon wave a third of its issue rate.
-template <class R, bool PlainExp, bool RingLds, bool Full, bool Pair>
+// NP = 2 (stepCoopPairKernel): one workgroup of eight wavefronts carries TWO chunks (ring in HBM).
+// Waves go to the CU's four SIMDs round-robin, so with the roles laid out as  C0 C1 W0 W1 -- -- L0 L1
+// (waves 4 and 5 leave at once) each carbon wave has a SIMD to itself and a chunk's water and light
+// waves -- busy at different times of a step -- share one, whatever SIMD the workgroup starts on.
+// Two separate three-wave workgroups on a CU put the second one's water wave on the first one's
+// carbon SIMD (tools/coop_placement.py), which costs the carbon wave a third of its issue rate.
+// NP = 4 (stepCoopQuadKernel): twelve wavefronts carry FOUR chunks, C0..C3 W0..W3 L0..L3: every SIMD
+// runs the three waves of one chunk, which fill each other's dependency and hand-over gaps -- for
+// batches of up to four chunks per CU, where the one-wave kernel leaves every SIMD with a lone wave.
+template <class R, bool PlainExp, bool RingLds, bool Full, int NP>
 __device__ __forceinline__ void coopBody(const FastArgs& a) {
-  static_assert(!(Pair && RingLds), "two chunks' rings do not fit one CU's LDS");
-  constexpr int NP = Pair ? 2 : 1;
+  static_assert(!(NP > 1 && RingLds), "two chunks' rings do not fit one CU's LDS");
+  constexpr bool Pair = NP == 2;
   // per-wave private record tiles (each wave stages and awaits its own DMA) + mailboxes
   __shared__ alignas(16) unsigned char ldsTilesAll[NP][3][2 * kTileBytes];
   __shared__ R mailLaiAll[NP][2][64], mailPgpAll[NP][2][64], mailPsnAll[NP][2][64];
@@ -302,8 +305,9 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
 
   const int wave = uni((int)threadIdx.x >> 6);
   // 0 carbon, 1 water, 2 light; -1: a placeholder wave that only keeps the SIMD rotation
-  const int sub = Pair ? (wave & 1) : 0;  // which of the workgroup's chunks
-  const int role = Pair ? ((wave >> 1) == 3 ? 2 : (wave >> 1) == 2 ? -1 : (wave >> 1)) : wave;
+  // which of the workgroup's chunks; NP == 4: C0..C3 W0..W3 L0..L3, a chunk's three waves on one SIMD
+  const int sub = Pair ? (wave & 1) : NP == 4 ? (wave & 3) : 0;
+  const int role = Pair ? ((wave >> 1) == 3 ? 2 : (wave >> 1) == 2 ? -1 : (wave >> 1)) : NP == 4 ? (wave >> 2) : wave;
   const int lane = (int)threadIdx.x & 63;
   auto& mailLai = mailLaiAll[sub];
   auto& mailPgp = mailPgpAll[sub];
@@ -1376,12 +1380,17 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
 
 template <class R, bool PlainExp, bool RingLds, bool Full>
 __global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
-  coopBody<R, PlainExp, RingLds, Full, false>(a);
+  coopBody<R, PlainExp, RingLds, Full, 1>(a);
 }
 
 template <class R, bool PlainExp, bool Full>
 __global__ __launch_bounds__(512) void stepCoopPairKernel(FastArgs a) {
-  coopBody<R, PlainExp, false, Full, true>(a);
+  coopBody<R, PlainExp, false, Full, 2>(a);
+}
+
+template <class R, bool PlainExp>
+__global__ __launch_bounds__(768) void stepCoopQuadKernel(FastArgs a) {
+  coopBody<R, PlainExp, false, false, 4>(a);
 }
 
 #ifdef SIPNET_HWID
@@ -1402,11 +1411,12 @@ extern "C" int sipnet_debug_read_coop_stamps(unsigned long long* out) {
 
 void launchStepCoop(const FastArgs& a, int precision, int layout, hipStream_t stream, LaunchInfo* info) {
   const int chunksPerSite = (a.n_members + 63) / 64;
-  const bool ringInLds = layout == COOP_RING_LDS, pair = layout == COOP_PAIR;
+  const bool ringInLds = layout == COOP_RING_LDS, pair = layout == COOP_PAIR, quad = layout == COOP_QUAD;
   const int chunks = a.n_sites * chunksPerSite;
   // paired chunks: with the XCD-grouped mapping every group of eight workgroups carries 16 chunks
   const int pairGroups = (a.n_sites & 7) == 0 ? 8 * ((chunks / 8 + 1) / 2) : (chunks + 1) / 2;
-  const dim3 grid(pair ? pairGroups : chunks), block(pair ? 512 : 192);
+  const int quadGroups = (a.n_sites & 7) == 0 ? 8 * ((chunks / 8 + 3) / 4) : (chunks + 3) / 4;
+  const dim3 grid(pair ? pairGroups : quad ? quadGroups : chunks), block(pair ? 512 : quad ? 768 : 192);
 #define COOP_LAUNCH(R, P, L)                                                                        \
   {                                                                                                 \
     if (a.full) hipLaunchKernelGGL((stepCoopKernel<R, P, L, true>), grid, block, 0, stream, a);      \
@@ -1417,7 +1427,15 @@ void launchStepCoop(const FastArgs& a, int precision, int layout, hipStream_t st
     if (a.full) hipLaunchKernelGGL((stepCoopPairKernel<R, P, true>), grid, block, 0, stream, a);     \
     else hipLaunchKernelGGL((stepCoopPairKernel<R, P, false>), grid, block, 0, stream, a);          \
   }
-  if (pair) {
+  if (quad) {
+    if (precision == SIPNET_F64) {
+      if (a.plainExp) hipLaunchKernelGGL((stepCoopQuadKernel<double, true>), grid, block, 0, stream, a);
+      else hipLaunchKernelGGL((stepCoopQuadKernel<double, false>), grid, block, 0, stream, a);
+    } else {
+      if (a.plainExp) hipLaunchKernelGGL((stepCoopQuadKernel<float, true>), grid, block, 0, stream, a);
+      else hipLaunchKernelGGL((stepCoopQuadKernel<float, false>), grid, block, 0, stream, a);
+    }
+  } else if (pair) {
     if (precision == SIPNET_F64) { if (a.plainExp) PAIR_LAUNCH(double, true) else PAIR_LAUNCH(double, false) }
     else { if (a.plainExp) PAIR_LAUNCH(float, true) else PAIR_LAUNCH(float, false) }
   } else if (precision == SIPNET_F64) {
@@ -1433,14 +1451,15 @@ void launchStepCoop(const FastArgs& a, int precision, int layout, hipStream_t st
     const char* r = precision == SIPNET_F64 ? "double" : "float";
     const char* pe = a.plainExp ? "true" : "false";
     const char* fu = a.full ? "true" : "false";
-    if (pair) snprintf(info->kernel, sizeof info->kernel, "stepCoopPairKernel<%s, %s, %s>", r, pe, fu);
+    if (quad) snprintf(info->kernel, sizeof info->kernel, "stepCoopQuadKernel<%s, %s>", r, pe);
+    else if (pair) snprintf(info->kernel, sizeof info->kernel, "stepCoopPairKernel<%s, %s, %s>", r, pe, fu);
     else snprintf(info->kernel, sizeof info->kernel, "stepCoopKernel<%s, %s, %s, %s>", r, pe,
                   ringInLds ? "true" : "false", fu);
     info->grid = (int32_t)grid.x;
     info->block = (int32_t)block.x;
-    info->wavesPerSimd = pair ? 2 : 1;
+    info->wavesPerSimd = pair ? 2 : quad ? 3 : 1;
     const int elem = precision == SIPNET_F64 ? 8 : 4;
-    info->ldsBytes = (pair ? 2 : 1) * (3 * 2 * kTileBytes + (2 * 64 * 3 + 2 * 6 * 64) * elem + 2 * 64 * 4 + 5 * 4) +
+    info->ldsBytes = (pair ? 2 : quad ? 4 : 1) * (3 * 2 * kTileBytes + (2 * 64 * 3 + 2 * 6 * 64) * elem + 2 * 64 * 4 + 5 * 4) +
                      (ringInLds ? SIPNET_RING_SLOTS * 64 : 64) * 8;
   }
 }

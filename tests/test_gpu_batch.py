@@ -276,17 +276,17 @@ def test_cooperative_and_one_wave_kernels_agree(base, tmp_path):
     out = {}
     for prec in (sa.F64, sa.F32_MIXED):
         for coop, kern in (("1", sa.KERNEL_COOP_LDS), ("2", sa.KERNEL_COOP_HBM), ("3", sa.KERNEL_COOP_PAIR),
-                           ("0", sa.KERNEL_ONE_WAVE)):
+                           ("4", sa.KERNEL_COOP_QUAD), ("0", sa.KERNEL_ONE_WAVE)):
             b = make_batch(sa.flags_from(), [clim], members, prec=prec, events=ev, kernel=kern)
             T = clim.n_steps
             planes, _ = b.alloc_outputs(T)
             for a, z in ((0, 7), (7, 1000), (1000, 1015), (1015, T)):   # odd cuts, a one-step tile tail
                 b.run(a, z - a, planes=planes[:, a:z])
-            assert b.last_launch()["kernel"].startswith("stepFastKernel" if coop == "0" else "stepCoopPair" if coop == "3" else "stepCoopKernel<")
+            assert b.last_launch()["kernel"].startswith("stepFastKernel" if coop == "0" else "stepCoopPair" if coop == "3" else "stepCoopQuad" if coop == "4" else "stepCoopKernel<")
             out[coop] = (planes.cpu().numpy().astype(np.float64), b.get_state(), b.get_rings())
             b.close()
         tol = 1e-12 if prec == sa.F64 else 2e-4
-        for mode in ("1", "2", "3"):
+        for mode in ("1", "2", "3", "4"):
             d = np.abs(out[mode][0] - out["0"][0]).max()
             print("precision", prec, "coop mode", mode, "vs one-wave: max|d|", d)
             assert d < tol
@@ -294,7 +294,8 @@ def test_cooperative_and_one_wave_kernels_agree(base, tmp_path):
             assert (out[mode][1][:, 28:31] == out["0"][1][:, 28:31]).all()      # ring epoch, status, died-at
             np.testing.assert_allclose(out[mode][2], out["0"][2], rtol=1e-9 if prec == sa.F64 else 1e-3, atol=1e-9)
         np.testing.assert_array_equal(out["1"][0], out["2"][0])   # ring placement does not change arithmetic
-        np.testing.assert_array_equal(out["1"][0], out["3"][0])   # nor does the paired-chunk layout
+        np.testing.assert_array_equal(out["1"][0], out["3"][0])   # nor do the multi-chunk workgroups
+        np.testing.assert_array_equal(out["1"][0], out["4"][0])
 
 
 def test_math_policy_is_an_explicit_choice(base, short_clim, monkeypatch):

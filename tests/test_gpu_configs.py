@@ -86,7 +86,8 @@ def test_c2_1024_members_fp64_every_member(oracle, base):
 
 
 def test_c3_65536_members_fp32_mixed(oracle, base):
-    """the HBM-roofline configuration: 13.8 GB of fp32 planes stay resident"""
+    """the HBM-roofline configuration: 13.8 GB of fp32 planes stay resident; four chunks per CU run
+    as twelve-wave workgroups of the cooperative kernel"""
     M = 65536
     clim = year_clim()
     members = synth.perturbed_params(base, M)
@@ -102,7 +103,7 @@ def test_c3_65536_members_fp32_mixed(oracle, base):
     b.close()
     del planes
     torch.cuda.empty_cache()
-    assert li["kernel"] == "stepFastKernel<float, true, 0, 1, false>" and li["grid"] == 1024, li
+    assert li["kernel"] == "stepCoopQuadKernel<float, true>" and li["grid"] == 256, li
     assert (st == 0).all() and finite
     want, final, so = oracle.run_block(sa.flags_from(), members[pick], clim)
     assert (so == 0).all()
@@ -246,6 +247,8 @@ KERNELS = [
     ("coop_hbm_f32", sa.F32_MIXED, sa.KERNEL_COOP_HBM, 0, "stepCoopKernel<float, true, false, false>"),
     ("coop_pair_f64", sa.F64, sa.KERNEL_COOP_PAIR, 0, "stepCoopPairKernel<double, true, false>"),
     ("coop_pair_f32", sa.F32_MIXED, sa.KERNEL_COOP_PAIR, 0, "stepCoopPairKernel<float, true, false>"),
+    ("coop_quad_f64", sa.F64, sa.KERNEL_COOP_QUAD, 0, "stepCoopQuadKernel<double, true>"),
+    ("coop_quad_f32", sa.F32_MIXED, sa.KERNEL_COOP_QUAD, 0, "stepCoopQuadKernel<float, true>"),
     ("runtime_flags_f64", sa.F64, sa.KERNEL_ONE_WAVE, sa.KOPT_RUNTIME_FLAGS, "stepFastKernel<double, true, 1, 1, false>"),
     ("runtime_flags_f32", sa.F32_MIXED, sa.KERNEL_ONE_WAVE, sa.KOPT_RUNTIME_FLAGS, "stepFastKernel<float, true, 1, 1, false>"),
 ]
@@ -295,6 +298,7 @@ def test_non_plain_exponents_take_the_general_instantiations(oracle, base):
     for kernel, expect in ((sa.KERNEL_COOP_LDS, "stepCoopKernel<double, false, true, false>"),
                            (sa.KERNEL_COOP_HBM, "stepCoopKernel<double, false, false, false>"),
                            (sa.KERNEL_COOP_PAIR, "stepCoopPairKernel<double, false, false>"),
+                           (sa.KERNEL_COOP_QUAD, "stepCoopQuadKernel<double, false>"),
                            (sa.KERNEL_ONE_WAVE, "stepFastKernel<double, false, 0, 1, false>")):
         b = build(flags, [clim], members, sa.F64, kernel)
         got = b.run()[0].cpu().numpy()
@@ -319,7 +323,7 @@ def test_regular_tile_path_equals_the_general_step_bit_for_bit(oracle, base):
     members[130] = members[3]                            # the same member in chunk 0 and chunk 2
     T = clim.n_steps
     outs = {}
-    for kernel in (sa.KERNEL_COOP_LDS, sa.KERNEL_COOP_HBM, sa.KERNEL_COOP_PAIR):
+    for kernel in (sa.KERNEL_COOP_LDS, sa.KERNEL_COOP_HBM, sa.KERNEL_COOP_PAIR, sa.KERNEL_COOP_QUAD):
         for opt in (0, sa.KOPT_NO_REGULAR_TILES):
             b = build(flags, [clim], members, sa.F64, kernel, opt)
             planes, _ = b.alloc_outputs(T)
@@ -334,39 +338,53 @@ def test_regular_tile_path_equals_the_general_step_bit_for_bit(oracle, base):
         assert np.array_equal(fastp[0][:, :, 130], fastp[0][:, :, 3])
     np.testing.assert_array_equal(outs[(sa.KERNEL_COOP_LDS, 0)][0], outs[(sa.KERNEL_COOP_HBM, 0)][0])
     np.testing.assert_array_equal(outs[(sa.KERNEL_COOP_LDS, 0)][0], outs[(sa.KERNEL_COOP_PAIR, 0)][0])
+    np.testing.assert_array_equal(outs[(sa.KERNEL_COOP_LDS, 0)][0], outs[(sa.KERNEL_COOP_QUAD, 0)][0])
     pick = np.r_[0:8, 64:72, 128:136]
     want, _, _ = oracle.run_block(flags, members[pick], clim)
     assert np.abs(outs[(sa.KERNEL_COOP_LDS, 0)][0][:, :, pick] - want).max() < TOL_F64
 
 
-@pytest.mark.parametrize("S,M", [(8, 192), (3, 130), (3, 200), (16, 64), (1, 64)])
-def test_paired_chunk_workgroups_cover_every_chunk_once(S, M, oracle, base):
-    """stepCoopPairKernel maps two chunks to a workgroup: with the XCD-grouped mapping (8 | S) and
-    without, with an odd number of chunks (the last workgroup's second half is empty), ragged last
-    chunks, a single chunk.  Same bits as the one-chunk workgroups, state and rings included; two
-    members of every site against the oracle"""
+@pytest.mark.parametrize("kernel,per", [(sa.KERNEL_COOP_PAIR, 2), (sa.KERNEL_COOP_QUAD, 4)], ids=["pair", "quad"])
+@pytest.mark.parametrize("S,M", [(8, 192), (3, 130), (3, 200), (16, 64), (1, 64), (8, 320)])
+def test_multi_chunk_workgroups_cover_every_chunk_once(S, M, kernel, per, oracle, base):
+    """stepCoopPairKernel / stepCoopQuadKernel map two / four chunks to a workgroup: with the
+    XCD-grouped mapping (8 | S) and without, with chunk counts that leave the last workgroup partly
+    empty, ragged last chunks, a single chunk.  Same bits as the one-chunk workgroups, state and
+    rings included; two members of every site against the oracle"""
     flags = sa.flags_from()
     clims = [year_clim(site=s, n=48 * 12, start_day=170) for s in range(S)]
     members = synth.perturbed_params(base, M)
     outs = {}
-    for kernel in (sa.KERNEL_COOP_HBM, sa.KERNEL_COOP_PAIR):
-        b = build(flags, clims, members, sa.F64, kernel)
+    for k in (sa.KERNEL_COOP_HBM, kernel):
+        b = build(flags, clims, members, sa.F64, k)
         planes, _ = b.alloc_outputs(clims[0].n_steps)
         planes.fill_(float("nan"))
         for a, z in ((0, 21), (21, clims[0].n_steps)):
             b.run(a, z - a, planes=planes[:, a:z])
         li = b.last_launch()
-        outs[kernel] = (planes.cpu().numpy(), b.get_state(), b.get_rings(), li)
+        outs[k] = (planes.cpu().numpy(), b.get_state(), b.get_rings(), li)
         b.close()
-    li = outs[sa.KERNEL_COOP_PAIR][3]
+    li = outs[kernel][3]
     chunks = S * ((M + 63) // 64)
-    assert li["kernel"] == "stepCoopPairKernel<double, true, false>" and li["block_threads"] == 512
-    assert li["grid"] == (8 * ((chunks // 8 + 1) // 2) if S % 8 == 0 else (chunks + 1) // 2), li
+    assert li["kernel"] == ("stepCoopPairKernel<double, true, false>" if per == 2 else "stepCoopQuadKernel<double, true>")
+    assert li["block_threads"] == (512 if per == 2 else 768)
+    assert li["grid"] == (8 * ((chunks // 8 + per - 1) // per) if S % 8 == 0 else (chunks + per - 1) // per), li
     for k in range(3):
-        np.testing.assert_array_equal(outs[sa.KERNEL_COOP_PAIR][k], outs[sa.KERNEL_COOP_HBM][k])
-    got = outs[sa.KERNEL_COOP_PAIR][0].reshape(3, -1, S, M)
+        np.testing.assert_array_equal(outs[kernel][k], outs[sa.KERNEL_COOP_HBM][k])
+    got = outs[kernel][0].reshape(3, -1, S, M)
     assert np.isfinite(got).all()
     for s in range(S):
         pick = np.array([0, M - 1])
         want, _, _ = oracle.run_block(flags, members[pick], clims[s])
         assert np.abs(got[:, :, s, pick] - want).max() < TOL_F64, s
+
+
+def test_quad_kernel_has_no_full_state_build(base):
+    """a forced four-chunk kernel refuses records / diagnostics loudly; AUTO falls back to the
+    one-wave kernel's Full build for such a batch"""
+    clim = year_clim(n=48)
+    members = synth.perturbed_params(base, 64)
+    b = build(sa.flags_from(), [clim], members, sa.F64, sa.KERNEL_COOP_QUAD)
+    with pytest.raises(sa.SipnetError, match="no full-state"):
+        b.run(full=True)
+    b.close()

@@ -29,8 +29,8 @@ wl = WORKLOADS[wl_name]
 flags = sa.flags_from(**wl.get("flags", {}))
 base, _ = sa.read_params(os.path.join(sys.argv[1], "sipnet_amd", "data", wl.get("param", "base_forest.param")), flags)
 S, M, T = wl["sites"], wl["members"], wl["steps"]
-prec = sa.F64 if wl["prec"] == "f64" else sa.F32_MIXED
-K = dict(auto=sa.KERNEL_AUTO, one_wave=sa.KERNEL_ONE_WAVE, coop_lds=sa.KERNEL_COOP_LDS, coop_hbm=sa.KERNEL_COOP_HBM, coop_pair=sa.KERNEL_COOP_PAIR)[kern]
+prec = sa.F64 if os.environ.get("VB_PREC", wl["prec"]) == "f64" else sa.F32_MIXED
+K = dict(auto=sa.KERNEL_AUTO, one_wave=sa.KERNEL_ONE_WAVE, coop_lds=sa.KERNEL_COOP_LDS, coop_hbm=sa.KERNEL_COOP_HBM, coop_pair=sa.KERNEL_COOP_PAIR, coop_quad=sa.KERNEL_COOP_QUAD)[kern]
 b = sa.Batch(flags, S, M, prec, fast_math=True if prec == sa.F64 else None, kernel=K, kernel_options=kopt)
 members = synth.perturbed_params(base, M)
 clims = [synth.convert_raw(synth.round_like_file(synth.half_hourly_year_raw(T, site=s))) for s in range(S)]
