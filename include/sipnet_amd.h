@@ -214,9 +214,10 @@ int sipnet_batch_set_math(sipnet_batch *b, int32_t policy);
 
 /* Which step kernel sipnet_batch_run launches.  AUTO (the default) picks by batch shape: with
  * SIPNET_MATH_FAST and the default model flags the three-wavefront cooperative kernel while there
- * are at most two 64-member chunks per compute unit (up to one chunk per CU: one three-wave
- * workgroup per chunk, running-mean ring in LDS; above: one eight-wave workgroup per TWO chunks,
- * rings in HBM), the one-wavefront throughput kernel for bigger batches and for optional model
+ * are at most four 64-member chunks per compute unit (up to one chunk per CU: one three-wave
+ * workgroup per chunk, running-mean ring in LDS; up to two: one eight-wave workgroup per TWO
+ * chunks, rings in HBM; up to four, lean state only: one twelve-wave workgroup per FOUR chunks),
+ * the one-wavefront throughput kernel for bigger batches, full records there, and optional model
  * flags; with SIPNET_MATH_STRICT the strict-order kernel.  The other values force one kernel
  * (tests and measurements compare every instantiation with the oracle this way); a forced kernel
  * that cannot run the batch (throughput kernels under SIPNET_MATH_STRICT, cooperative kernels with
