@@ -4,6 +4,7 @@
 
 #include <cstdint>
 #include <string>
+#include <memory>
 #include <vector>
 
 #include "../../include/sipnet_amd.h"
@@ -67,6 +68,11 @@ struct sipnet_batch {
   double* d_diag = nullptr;          // [4][ncol] per-member diagnostics, allocated on request
   SiteStart* d_siteStart = nullptr;  // [n_sites] what setupModel() reads of a site's first record
   size_t planCap = 0, fastCap = 0, ringOpCap = 0, evCap = 0;
+  // host staging of the flat per-step records, kept between hand-overs of a forcing: a fresh buffer
+  // costs its first touch (143 MB at c4: 24 ms of page faults, more than building the records)
+  std::unique_ptr<FastRec[]> hostFast;
+  std::unique_ptr<StepRec[]> hostSteps;
+  size_t hostFastCap = 0, hostStepsCap = 0;
   int32_t* d_siteBase = nullptr;  // [n_sites][2]: offset of a site's ring ops / events in the flat arrays
   bool stepRecsUploaded = false, fastRecsUploaded = false;  // per-step records: uploaded on first use
   // last boundary a checkpoint was exported at (sipnet_batch_export_restart)

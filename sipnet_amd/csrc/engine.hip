@@ -55,10 +55,11 @@ static void forEachSite(int nS, int nThreads, F f) {
 }
 
 // flat record buffers are written by the worker threads (first touch in parallel), so they are
-// allocated without value-initialisation
+// allocated without value-initialisation; the batch keeps them for the next hand-over of a forcing
+// device buffer for `count` records; a launch that still reads the previous plan (on any stream)
+// must have finished before the first site's records land in it
 template <class Rec>
-static int uploadRecords(sipnet_batch* b, Rec** d_ptr, size_t* cap, size_t count, const Rec* host) {
-  // a launch that still reads the previous plan (on any stream) must have finished
+static int reserveRecords(Rec** d_ptr, size_t* cap, size_t count) {
   HIP_TRY(hipDeviceSynchronize());
   if (count > *cap) {
     if (*d_ptr) HIP_TRY(hipFree(*d_ptr));
@@ -67,7 +68,6 @@ static int uploadRecords(sipnet_batch* b, Rec** d_ptr, size_t* cap, size_t count
     HIP_TRY(hipMalloc(d_ptr, count * sizeof(Rec)));
     *cap = count;
   }
-  HIP_TRY(hipMemcpy(*d_ptr, host, count * sizeof(Rec), hipMemcpyHostToDevice));
   return SIPNET_OK;
 }
 
@@ -84,27 +84,54 @@ static int buildAndUpload(sipnet_batch* b, bool fastType, bool first) {
   const double t0 = nowMs();
   const int nS = b->n_sites, nT = b->n_steps;
   const int nThreads = planThreadsFor(nS);
-  std::unique_ptr<FastRec[]> fast;
-  std::unique_ptr<StepRec[]> steps;
-  const size_t nFast = (size_t)nS * nT + kFastTile;
-  if (fastType) fast.reset(new FastRec[nFast]);
-  else steps.reset(new StepRec[(size_t)nS * nT]);
+  const size_t nFast = (size_t)nS * nT + kFastTile, nSteps = (size_t)nS * nT;
+  if (fastType && b->hostFastCap < nFast) {
+    b->hostFast.reset();
+    b->hostFast.reset(new FastRec[nFast]);
+    b->hostFastCap = nFast;
+  }
+  if (!fastType && b->hostStepsCap < nSteps) {
+    b->hostSteps.reset();
+    b->hostSteps.reset(new StepRec[nSteps]);
+    b->hostStepsCap = nSteps;
+  }
+  FastRec* const fast = b->hostFast.get();
+  StepRec* const steps = b->hostSteps.get();
+  int rc = fastType ? reserveRecords(&b->d_fast, &b->fastCap, nFast) : reserveRecords(&b->d_plan, &b->planCap, nSteps);
+  if (rc) return rc;
+  // every worker uploads the site it has just built while the others go on building: the copies
+  // (57 GB/s from this buffer once it has been touched) hide behind the build
+  std::atomic<int> copyErr{0};
+  std::atomic<int64_t> copyUs{0};
   forEachSite(nS, nThreads, [&](int s) {
     SitePlan p = buildSitePlan(b->flags, nT, b->clim[s].data(), b->year[s].data(), b->day[s].data(),
                                (int32_t)b->events[s].size(), b->events[s].data(),
                                b->resume[s].set ? &b->resume[s] : nullptr, nullptr, /*wantSteps=*/false,
-                               fastType ? nullptr : steps.get() + (size_t)s * nT,
-                               fastType ? fast.get() + (size_t)s * nT : nullptr);
+                               fastType ? nullptr : steps + (size_t)s * nT,
+                               fastType ? fast + (size_t)s * nT : nullptr);
     if (first) b->plans[s] = std::move(p);
+    const double c0 = nowMs();
+    hipError_t e = hipSetDevice(b->device);
+    if (e == hipSuccess) {
+      const size_t tail = (fastType && s == nS - 1) ? kFastTile : 0;  // tile padding after the last site
+      if (tail) memset((void*)(fast + (size_t)nS * nT), 0, tail * sizeof(FastRec));
+      e = fastType ? hipMemcpy(b->d_fast + (size_t)s * nT, fast + (size_t)s * nT, ((size_t)nT + tail) * sizeof(FastRec),
+                               hipMemcpyHostToDevice)
+                   : hipMemcpy(b->d_plan + (size_t)s * nT, steps + (size_t)s * nT, (size_t)nT * sizeof(StepRec),
+                               hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) copyErr.store((int)e);
+    copyUs.fetch_add((int64_t)((nowMs() - c0) * 1e3));
   });
-  if (fastType) memset((void*)(fast.get() + (size_t)nS * nT), 0, kFastTile * sizeof(FastRec));  // tile padding
-  const double t1 = nowMs();
-  int rc = fastType ? uploadRecords(b, &b->d_fast, &b->fastCap, nFast, fast.get())
-                    : uploadRecords(b, &b->d_plan, &b->planCap, (size_t)nS * nT, steps.get());
-  if (rc) return rc;
+  if (copyErr.load() != 0) {
+    setError(std::string("sipnet_batch: uploading the site records failed: ") + hipGetErrorString((hipError_t)copyErr.load()));
+    return SIPNET_ERR_INTERNAL;
+  }
   (fastType ? b->fastRecsUploaded : b->stepRecsUploaded) = true;
-  b->planBuildMs += t1 - t0;
-  b->planUploadMs += nowMs() - t1;
+  // wall time of the whole pass; the copies' share of the workers' time is reported as the upload part
+  const double wall = nowMs() - t0, copyShare = copyUs.load() * 1e-3 / nThreads;
+  b->planBuildMs += wall - (copyShare < wall ? copyShare : wall);
+  b->planUploadMs += copyShare < wall ? copyShare : wall;
   return SIPNET_OK;
 }
 
@@ -140,34 +167,38 @@ static int uploadPlan(sipnet_batch* b, hipStream_t stream) {
     nEv += p.events.size();
     starts[s] = SiteStart{p.startCumGdd, p.startTsoil, p.startDayTime};
   }
-  std::vector<RingOp> ops(nOps + 1);
-  std::vector<EvRec> evs(nEv + 1);
-  for (int s = 0; s < nS; s++) {
-    const SitePlan& p = b->plans[s];
-    if (!p.ringOps.empty()) memcpy(ops.data() + bases[2 * s], p.ringOps.data(), p.ringOps.size() * sizeof(RingOp));
-    if (!p.events.empty()) memcpy(evs.data() + bases[2 * s + 1], p.events.data(), p.events.size() * sizeof(EvRec));
-  }
-  if (nOps == 0) ops[0] = RingOp{0.0, 0, -1};
-  if (nEv == 0) evs[0] = EvRec{0, 0, {0, 0, 0, 0}};
   const double t1 = nowMs();
-  if (ops.size() > b->ringOpCap) {
+  if (nOps + 1 > b->ringOpCap) {
     if (b->d_ringOps) HIP_TRY(hipFree(b->d_ringOps));
     b->d_ringOps = nullptr;
     b->ringOpCap = 0;
-    HIP_TRY(hipMalloc(&b->d_ringOps, ops.size() * sizeof(RingOp)));
-    b->ringOpCap = ops.size();
+    HIP_TRY(hipMalloc(&b->d_ringOps, (nOps + 1) * sizeof(RingOp)));
+    b->ringOpCap = nOps + 1;
   }
-  if (evs.size() > b->evCap) {
+  if (nEv + 1 > b->evCap) {
     if (b->d_events) HIP_TRY(hipFree(b->d_events));
     b->d_events = nullptr;
     b->evCap = 0;
-    HIP_TRY(hipMalloc(&b->d_events, evs.size() * sizeof(EvRec)));
-    b->evCap = evs.size();
+    HIP_TRY(hipMalloc(&b->d_events, (nEv + 1) * sizeof(EvRec)));
+    b->evCap = nEv + 1;
   }
-  // synchronous copies: the host vectors die at return (uploadRecords above has waited for
-  // every launch that might still read the previous plan)
-  HIP_TRY(hipMemcpy(b->d_ringOps, ops.data(), ops.size() * sizeof(RingOp), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(b->d_events, evs.data(), evs.size() * sizeof(EvRec), hipMemcpyHostToDevice));
+  // synchronous copies straight from the sites' plans (reserveRecords above has waited for every
+  // launch that might still read the previous plan); an empty list keeps one inert entry
+  for (int s = 0; s < nS; s++) {
+    const SitePlan& p = b->plans[s];
+    if (!p.ringOps.empty())
+      HIP_TRY(hipMemcpy(b->d_ringOps + bases[2 * s], p.ringOps.data(), p.ringOps.size() * sizeof(RingOp), hipMemcpyHostToDevice));
+    if (!p.events.empty())
+      HIP_TRY(hipMemcpy(b->d_events + bases[2 * s + 1], p.events.data(), p.events.size() * sizeof(EvRec), hipMemcpyHostToDevice));
+  }
+  if (nOps == 0) {
+    const RingOp none{0.0, 0, -1};
+    HIP_TRY(hipMemcpy(b->d_ringOps, &none, sizeof none, hipMemcpyHostToDevice));
+  }
+  if (nEv == 0) {
+    const EvRec none{0, 0, {0, 0, 0, 0}};
+    HIP_TRY(hipMemcpy(b->d_events, &none, sizeof none, hipMemcpyHostToDevice));
+  }
   HIP_TRY(hipMemcpy(b->d_siteStatus, b->siteStatus.data(), nS * sizeof(int32_t), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(b->d_siteStart, starts.data(), nS * sizeof(SiteStart), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(b->d_siteBase, bases.data(), bases.size() * sizeof(int32_t), hipMemcpyHostToDevice));
