@@ -80,6 +80,15 @@ __device__ __forceinline__ float take(const float* slot, const int* flag, int st
 typedef double d2_t __attribute__((ext_vector_type(2)));
 typedef int i4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ unsigned ldsAddr(const void* p) { return (unsigned)(size_t)p; }
+// Q10 exponent (temperature / 10) x log2(Q10), rounded as a product of its own: the factor block runs
+// on the light wave in some layouts and on a wave of its own (uniform temperature operand) in
+// others, and the compiler must not fuse the product into exp2's range reduction in one of them only
+template <class R>
+__device__ __forceinline__ R q10Arg(R t10, R lg) {
+  R x = t10 * lg;
+  asm volatile("" : "+v"(x));
+  return x;
+}
 // The "alive" confirmation of wave C is ONE per-lane word: magnitude = step + 2 (so that 0 / 1 are
 // "nothing yet" whatever the first step of a launch is), negative when the member died in the
 // step before (its posted leaf area is void).  Sequence and value travel in one DS operation.
@@ -286,6 +295,12 @@ template <class R, bool PlainExp, bool RingLds, bool Full, int NP>
 __device__ __forceinline__ void coopBody(const FastArgs& a) {
   static_assert(!(NP > 1 && RingLds), "two chunks' rings do not fit one CU's LDS");
   constexpr bool Pair = NP == 2;
+  // a fourth wavefront computes the climate-only factors when the workgroup has a CU to itself
+#ifdef SIPNET_NO_FACWAVE
+  constexpr bool FacWave = false;
+#else
+  constexpr bool FacWave = RingLds;
+#endif
   // per-wave private record tiles (each wave stages and awaits its own DMA) + mailboxes
   __shared__ alignas(16) unsigned char ldsTilesAll[NP][3][2 * kTileBytes];
   __shared__ R mailLaiAll[NP][2][64], mailPgpAll[NP][2][64], mailPsnAll[NP][2][64];
@@ -320,14 +335,14 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   auto& seqFacMoist = seqFacMoistAll[sub];
   [[maybe_unused]] const bool firstChunk = blockIdx.x == 0 && sub == 0;  // diagnostics builds report this one
 #ifdef SIPNET_HWID
-  if (lane == 0 && role >= 0 && (blockIdx.x * NP + sub) < 4096) {
+  if (lane == 0 && role >= 0 && role < 3 && (blockIdx.x * NP + sub) < 4096) {
     unsigned hw, xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
     g_coopHwId[((blockIdx.x * NP + sub) * 3 + role) * 2] = hw;
     g_coopHwId[((blockIdx.x * NP + sub) * 3 + role) * 2 + 1] = xcc;
   }
 #endif
-  unsigned char* lds = ldsTilesAll[sub][role < 0 ? 0 : role];
+  unsigned char* lds = ldsTilesAll[sub][(role < 0 || role > 2) ? 0 : role];
 
   const int chunksPerSite = (a.n_members + 63) >> 6;
   int site, chunk;
@@ -378,6 +393,78 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
 
   const unsigned char* __restrict__ planBytes =
       (const unsigned char*)(a.fast + (int64_t)site * a.n_steps_total);
+  const Exp2Coef EC = loadExp2Coef();
+
+  // =============================================================================================
+  // ---- F (one workgroup per CU only: the CU's fourth SIMD is free): the climate / parameter part
+  // of wave C's respiration terms (vegResp sipnet.c:1051-1068, calcRootResp :1073,
+  // calcSoilRespiration :1132-1148 with depeffects.c:71-74):  folResp = leafC * g1,
+  // rVeg = folResp + totalWoodC * g2,  rSoil = soilC * (qSoilT * moistEff[wave W]),
+  // rFineRoot = fineRootC * gFine,  rCoarseRoot = coarseRootC * gCoarse.  Nothing here depends on
+  // member state.  By day the light wave is the busiest of the three (seven exp2 of the canopy
+  // layers on top of these one to four); with the factors on a wave of their own the day step is
+  // the carbon wave's again.  No room for a fourth record tile in LDS (ring 125 KB + 3 tiles
+  // + mailboxes = 158.5 of 160 KB): lane k loads the five fields of step 16j + k one tile ahead
+  // and the step's values are read back with v_readlane.
+  if (FacWave && role == 3) {
+#pragma clang fp contract(off)  // same bits as the light wave's copy of this block (see there)
+    const R K_frozThr = (R)PRM(frozenSoilThreshold);
+    const R K_lgVeg = (R)log2(PRM(vegRespQ10)), K_lgSoil = (R)log2(PRM(soilRespQ10));
+    const R K_lgFine = (R)log2(PRM(fineRootQ10)), K_lgCoarse = (R)log2(PRM(coarseRootQ10));
+    const R K_fol = (R)((PRM(baseFolRespFrac) * PRM(aMax)) *
+                        (kCWeight * (1.0 / kTen9) * (PRM(leafCSpWt) / PRM(cFracLeaf)) * kSecPerDay) *
+                        (1.0 / PRM(leafCSpWt)) * exp2(-(PRM(psnTOpt) / 10.0) * log2(PRM(vegRespQ10))));
+    const R K_frozFolEff = (R)PRM(frozenSoilFolREff);
+    const R K_bvr = (R)PRM(baseVegResp), K_bsr = (R)PRM(baseSoilResp);
+    const R K_bfr = (R)PRM(baseFineRootResp), K_bcr = (R)PRM(baseCoarseRootResp);
+    const FastRec* __restrict__ recs = (const FastRec*)planBytes;
+    const int lastStep = a.n_steps_total - 1;
+    struct TileFields { double tair10, tsoil, tsoil10, tillP1; int bits; };
+    auto loadFields = [&](int tileStart) {
+      int t = tileStart + (lane & (kFastTile - 1));
+      t = t > lastStep ? lastStep : t;
+      const FastRec* r = recs + t;
+      return TileFields{r->tair10, r->tsoil, r->tsoil10, r->tillP1, r->bitsOps};
+    };
+    auto laneD = [](double v, int l) {
+      const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+      const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+      return __hiloint2double(hi, lo);
+    };
+    R qSoil = 0, gFine = 0, gCoarse = 0;
+    bool haveQ = false;
+    int fTile = tBegin / kFastTile;
+    TileFields cur = loadFields(fTile * kFastTile);
+    for (int tileStart = fTile * kFastTile; tileStart < tEnd; tileStart += kFastTile) {
+      const TileFields nxt = loadFields(tileStart + kFastTile);
+      const int tFirst = tileStart > tBegin ? tileStart : tBegin;
+      const int tLast = (tileStart + kFastTile) < tEnd ? (tileStart + kFastTile) : tEnd;
+      for (int t = tFirst; t < tLast; t++) {
+        const int j = t - tileStart;
+        const R tair10 = (R)laneD(cur.tair10, j), tsoil = (R)laneD(cur.tsoil, j);
+        const R tillP1 = (R)laneD(cur.tillP1, j);
+        const int bits = __builtin_amdgcn_readlane(cur.bits, j);
+        // the slot of step t was last used for step t-2, which C is past once it has posted the
+        // leaf area of step t-1
+        awaitAtLeast(&seqLai, t - 1);
+        const R vegQ = fexp2(q10Arg(tair10, K_lgVeg), EC);
+        R g1 = K_fol * vegQ;
+        g1 = (tsoil < K_frozThr) ? g1 * K_frozFolEff : g1;
+        const R g2 = K_bvr * vegQ;
+        if (!haveQ || !(bits & FAST_TSOIL_SAME)) {
+          const R tsoil10 = (R)laneD(cur.tsoil10, j);
+          qSoil = fexp2(q10Arg(tsoil10, K_lgSoil), EC);
+          gFine = K_bfr * fexp2(q10Arg(tsoil10, K_lgFine), EC);
+          gCoarse = K_bcr * fexp2(q10Arg(tsoil10, K_lgCoarse), EC);
+          haveQ = true;
+        }
+        const R qSoilT = K_bsr * qSoil * tillP1;
+        post5(&mailFac[t & 1][0][lane], &seqFac, g1, g2, qSoilT, gFine, gCoarse, t);
+      }
+      cur = nxt;
+    }
+    return;
+  }
   auto tileFirst = [&](int tile) -> int64_t {
     int64_t first = (int64_t)tile * kFastTile;
     const int64_t lastStart = (int64_t)a.n_steps_total - kFastTile;
@@ -395,13 +482,18 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   };
   typedef double d2 __attribute__((ext_vector_type(2)));
   typedef int i4 __attribute__((ext_vector_type(4)));
-  const Exp2Coef EC = loadExp2Coef();
   int curTile = tBegin / kFastTile;
   stageTile(curTile, curTile & 1);
   __builtin_amdgcn_s_waitcnt(0);
 
   // =============================================================================================
   if (role == 2) {
+    // Every layout of this wave must produce the same bits (they are tested against each other),
+    // and what fuses into an FMA under -ffp-contract=fast depends on which neighbouring
+    // expressions share a product (the factor block is here in some layouts and on wave F in
+    // others): so no implicit fusion in this wave, constants included; the FMAs that matter are
+    // written out below
+#pragma clang fp contract(off)
     // ---- L: potPsn() + calcLightEff(), sipnet.c:517-641 -------------------------------------
     const double leafCSpWt = PRM(leafCSpWt);
     const double convK = kCWeight * (1.0 / kTen9) * (leafCSpWt / PRM(cFracLeaf)) * kSecPerDay;
@@ -450,32 +542,33 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         // wave -- idle at night and while it waits for the leaf area by day -- runs it ahead of
         // C: the slot of step t was last used for step t-2, which C is past once it has posted
         // the leaf area of step t-1
-        {
+        if (!FacWave) {  // (wave F's job when there is one)
           WAIT_BEGIN()
           awaitAtLeast(&seqLai, t - 1);
           WAIT_END(1)
-          const R vegQ = fexp2((R)q5.y * K_lgVeg, EC);
+          const R vegQ = fexp2(q10Arg((R)q5.y, K_lgVeg), EC);
           R g1 = K_fol * vegQ;
           g1 = ((R)q1.y < K_frozThr) ? g1 * K_frozFolEff : g1;
           const R g2 = K_bvr * vegQ;
           if (!haveQ || !(bits & FAST_TSOIL_SAME)) {
             const R tsoil10 = (R)q6x;
-            qSoil = fexp2(tsoil10 * K_lgSoil, EC);
-            gFine = K_bfr * fexp2(tsoil10 * K_lgFine, EC);
-            gCoarse = K_bcr * fexp2(tsoil10 * K_lgCoarse, EC);
+            qSoil = fexp2(q10Arg(tsoil10, K_lgSoil), EC);
+            gFine = K_bfr * fexp2(q10Arg(tsoil10, K_lgFine), EC);
+            gCoarse = K_bcr * fexp2(q10Arg(tsoil10, K_lgCoarse), EC);
             haveQ = true;
           }
           const R qSoilT = K_bsr * qSoil * (R)q3.x;
           post5(&mailFac[t & 1][0][lane], &seqFac, g1, g2, qSoilT, gFine, gCoarse, t);
         }
         if (!(bits & FAST_PAR_POS)) continue;  // night: potGrossPsn = 0, nobody waits for it
+        {
         const R tair = (R)q1.x;
         // climate-only factors first, then the leaf area of this step
         const R dTemp = rmax0((K_tmax - tair) * (tair - K_tmin) * K_invDen);
         R vpdPow = (R)q2.y * (R)q2.y;
         if (!PlainExp)
           vpdPow = (K_vexp == R(2)) ? vpdPow : fexp2(K_vexp * (R)((const double*)(recB + 144))[2], EC);
-        const R dVpd = rmax0(R(1) - K_slope * vpdPow);
+        const R dVpd = rmax0(ffma(-K_slope, vpdPow, R(1)));
         const R q = (R)q2.x * K_invHalf;
         const R e0 = fexp2(q, EC);
         WAIT_BEGIN()
@@ -485,9 +578,10 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         const R r2 = r1 * r1, r3 = r2 * r1, r4 = r2 * r2, r5 = r4 * r1, r6 = r3 * r3;
         const R e1 = fexp2(q * r1, EC), e2 = fexp2(q * r2, EC), e3 = fexp2(q * r3, EC);
         const R e4 = fexp2(q * r4, EC), e5 = fexp2(q * r5, EC), e6 = fexp2(q * r6, EC);
-        const R s = (e0 + e6) + R(4) * (e1 + e3 + e5) + R(2) * (e2 + e4);
-        const R dLight = R(1) - s * R(1.0 / 18.0);
+        const R s = ffma(R(2), e2 + e4, ffma(R(4), (e1 + e3) + e5, e0 + e6));
+        const R dLight = ffma(-s, R(1.0 / 18.0), R(1));
         post(&mailPgp[t & 1][lane], &seqPgp, K_g * lai * dTemp * dVpd * dLight, t);
+        }
       }
     }
     WAIT_STORE(0)
@@ -1378,8 +1472,13 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
 #undef seqMoist
 }
 
+#ifdef SIPNET_NO_FACWAVE
+constexpr bool kFacWaveBuilt = false;
+#else
+constexpr bool kFacWaveBuilt = true;
+#endif
 template <class R, bool PlainExp, bool RingLds, bool Full>
-__global__ __launch_bounds__(192) void stepCoopKernel(FastArgs a) {
+__global__ __launch_bounds__(RingLds ? 256 : 192) void stepCoopKernel(FastArgs a) {
   coopBody<R, PlainExp, RingLds, Full, 1>(a);
 }
 
@@ -1416,7 +1515,7 @@ void launchStepCoop(const FastArgs& a, int precision, int layout, hipStream_t st
   // paired chunks: with the XCD-grouped mapping every group of eight workgroups carries 16 chunks
   const int pairGroups = (a.n_sites & 7) == 0 ? 8 * ((chunks / 8 + 1) / 2) : (chunks + 1) / 2;
   const int quadGroups = (a.n_sites & 7) == 0 ? 8 * ((chunks / 8 + 3) / 4) : (chunks + 3) / 4;
-  const dim3 grid(pair ? pairGroups : quad ? quadGroups : chunks), block(pair ? 512 : quad ? 768 : 192);
+  const dim3 grid(pair ? pairGroups : quad ? quadGroups : chunks), block(pair ? 512 : quad ? 768 : (ringInLds && kFacWaveBuilt) ? 256 : 192);
 #define COOP_LAUNCH(R, P, L)                                                                        \
   {                                                                                                 \
     if (a.full) hipLaunchKernelGGL((stepCoopKernel<R, P, L, true>), grid, block, 0, stream, a);      \

@@ -13,7 +13,13 @@ flags = sa.flags_from()
 base, _ = sa.read_params(os.path.join(REPO, "sipnet_amd", "data", "base_forest.param"), flags)
 M, T = 10240, 17520
 b = sa.Batch(flags, 1, M, sa.F64, fast_math=True, kernel_options=int(sys.argv[1]) if len(sys.argv) > 1 else 0)
-b.set_climate(0, synth.convert_raw(synth.round_like_file(synth.half_hourly_year_raw(T))))
+raw = synth.half_hourly_year_raw(T)
+light = os.environ.get("LIGHT", "asis")        # day / night: midnight sun / polar night (see day_night_time.py)
+if light == "night": raw["par"][:] = 0.0
+if light == "day":
+    import numpy as np
+    raw["par"] = np.maximum(raw["par"], 2.0)
+b.set_climate(0, synth.convert_raw(synth.round_like_file(raw)))
 b.set_params(0, synth.perturbed_params(base, M))
 b.setup(); b.run(want_planes=True); torch.cuda.synchronize()
 b.setup(); b.run(want_planes=True); torch.cuda.synchronize()
@@ -22,6 +28,6 @@ _lib.lib().sipnet_debug_read_coop_waits(out)
 tick = 1.0    # s_memtime ticks are core-clock cycles on this part (total = kernel time x 2.4 GHz)
 names = {0: "L: wait for lai", 1: "L: wait for C before posting factors", 3: "L: total", 4: "W: take pgp+alive", 5: "W: wait for C's progress", 7: "W: total",
          8: "C: take factors + moisture (+record)", 9: "C: take psn", 11: "C: total"}
-print("kernel", b.last_launch()["kernel"], "%.2f ms" % b.last_kernel_ms())
+print("light:", light, "kernel", b.last_launch()["kernel"], "%.2f ms" % b.last_kernel_ms())
 for k in sorted(names):
     print("%-28s %8.0f cycles/step" % (names[k], out[k] * tick / T))
