@@ -620,12 +620,15 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
       const unsigned char* recB = lds + (curTile & 1) * kTileBytes +
                                   (int)(tFirst - tileFirst(curTile)) * (int)sizeof(FastRec);
       for (int t = tFirst; t < tLast; t++, recB += sizeof(FastRec)) {
+        // only the fields this wave uses (80 of the record's 144 hot bytes: a lone wave pays LDS
+        // reads by the byte): len invLen | tair tsoil | vpd | rainRate | sublW evapNum | invWspd | bits | evCount
         d2 q0, q1, q2, q3, q4, q5;
         i4 j0;
-        asm volatile("ds_read_b128 %0, %7\n\tds_read_b128 %1, %7 offset:16\n\tds_read_b128 %2, %7 offset:32\n\t"
-                     "ds_read_b128 %3, %7 offset:48\n\tds_read_b128 %4, %7 offset:64\n\t"
-                     "ds_read_b128 %5, %7 offset:80\n\tds_read_b128 %6, %7 offset:128\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4), "=&v"(q5), "=&v"(j0)
+        asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\tds_read_b64 %2, %8 offset:40\n\t"
+                     "ds_read_b64 %3, %8 offset:56\n\tds_read_b128 %4, %8 offset:64\n\t"
+                     "ds_read_b64 %5, %8 offset:80\n\tds_read_b32 %6, %8 offset:128\n\t"
+                     "ds_read_b32 %7, %8 offset:140\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(q0), "=&v"(q1), "=&v"(q2.y), "=&v"(q3.y), "=&v"(q4), "=&v"(q5.x), "=&v"(j0.x), "=&v"(j0.w)
                      : "v"(ldsAddr(recB)) : "memory");
         const int32_t* rareI = (const int32_t*)(recB + 184);
         const R len = (R)q0.x, invLen = (R)q0.y, tair = (R)q1.x, tsoil = (R)q1.y;
