@@ -731,8 +731,9 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         snow = snow < kTiny ? 0.0 : snow;
 
         // never run more than one step ahead of C (the mailboxes have two slots): C is past the
-        // pools of step t-1 once it has posted lai(t)
-        {
+        // pools of step t-1 once it has posted lai(t).  By day that is implied: this wave has taken
+        // pgp(t), which wave L computed from lai(t)
+        if (!(bits & FAST_PAR_POS)) {
           WAIT_BEGIN()
           awaitAtLeast(&seqLai, t);
           WAIT_END(1)
