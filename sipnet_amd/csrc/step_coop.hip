@@ -1,23 +1,29 @@
-// step_coop.hip -- the cooperative throughput kernel: THREE wavefronts per 64 members.
+// step_coop.hip -- the cooperative throughput kernel: three (or four) wavefronts per 64 members.
 //
 // Why: with <= 1 wavefront per SIMD (every BASELINE configuration up to 64 k members) the step
 // loop is bound by what ONE wavefront can issue -- one instruction per ~4.3 cycles whatever its
 // kind -- while three quarters of the chip idle.  A member-step is a
 // chain of three blocks with thin interfaces:
 //
-//   L  light      lai(t)            -> potGrossPsn(t)          (dTemp, dVpd, 7-layer Simpson);
-//                 also, while it waits for the leaf area (and all night): every factor of C's
-//                 respiration terms that depends on climate and parameters only (Q10 terms, tillage)
-//   W  water      potGrossPsn(t)    -> photosynthesis(t), ET(t), soilWater(t+1), snow(t+1);
+//   L  light      lai(t)            -> potGrossPsn(t)          (dTemp, dVpd, 7-layer Simpson)
+//   W  water      potGrossPsn(t)    -> photosynthesis(t), ET(t), GPP(t), soilWater(t+1), snow(t+1);
 //                 also the soil-moisture effect on C's heterotrophic respiration (its own state)
-//   C  carbon     photosynthesis(t), factors(t) -> pools(t+1), ring, NEE(t), GPP(t), lai(t+1)
+//   C  carbon     photosynthesis(t), factors(t) -> pools(t+1), ring, NEE(t), lai(t+1)
+//   F  factors    every factor of C's respiration terms that depends on climate and parameters only
+//                 (Q10 terms, frozen-soil effect, tillage) -- a wave of its own when the workgroup
+//                 has a CU to itself (its fourth SIMD is free), else part of L
 //
-// so a workgroup is three wavefronts on three SIMDs of one CU, each running its OWN time loop
-// over the same 64 members and the same site records, and passing one double per member and
-// step through LDS mailboxes guarded by sequence flags (release store / acquire spin-load at
-// workgroup scope).  W and C overlap almost completely; L runs concurrently with the parts of
-// W and C that do not need it.  The arithmetic, its order and therefore the results are those
-// of stepFastKernel (bit-identical; tests/test_gpu_parity.py).
+// so a workgroup is three or four wavefronts on as many SIMDs of one CU, each running its OWN
+// time loop over the same 64 members and the same site records, and passing a few doubles per
+// member and step through LDS mailboxes guarded by sequence flags (DS operations of a wave execute
+// in order: value then flag on the producer side, flag then value in one round trip on the
+// consumer side).  The results are those of stepFastKernel to rounding (tests/test_gpu_batch.py),
+// and every layout of this kernel gives the same bits (tests/test_gpu_configs.py).
+//
+// Layouts (coopBody<..., NP>): one chunk per workgroup, ring in LDS, with wave F (stepCoopKernel<..,
+// true, ..>: batches of at most one chunk per CU) or ring in HBM without it; two chunks per
+// eight-wave workgroup (stepCoopPairKernel: up to two chunks per CU); four chunks per twelve-wave
+// workgroup (stepCoopQuadKernel: up to four).  See the comment above coopBody.
 //
 // lai(t+1) only depends on photosynthesis(t) through plant death (the leaf pool update has no
 // photosynthesis term, sipnet.c:1579-1626), so C posts it BEFORE it waits for photosynthesis(t)
