@@ -895,6 +895,70 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
           const int s0 = slots0 & 255;
           vPrev = RingLds ? ringL[s0 * 64 + lane] : (s0 == lastIns ? lastNpp : ringp[(uint32_t)s0 * ncu]);
         }
+        // The rest of a step, written once and instantiated twice: the common case (nobody dies: no
+        // mortality code at all behind ONE wave-uniform test) inside the loop, and the step on which a
+        // member of the wavefront dies AFTER the loop, which that step leaves (the wavefront takes the
+        // general step from then on) -- the loop body stays one straight run of code.  What the
+        // tail needs from the step lives outside the loop for that.
+        R photosynthesis = 0, rSoil = 0, rVeg = 0, rCoarseRoot = 0, rFineRoot = 0;
+        double soilGain = 0.0, ringNew = 0.0, rvN = 0.0;
+        bool rootsOk = true, useLast = false, dyingStep = false;
+        auto finishStep = [&](auto mayDie) {
+#pragma clang fp contract(off)
+          constexpr bool MayDie = decltype(mayDie)::value;
+          bool diedNow = false;
+          double deathToSoil0 = 0.0, deathToSoil1 = 0.0;
+          if (MayDie && !(rootsOk && (plantWoodC + delta > kTiny))) {  // every member was alive before
+            ringClean = false;
+            aliveC = false;
+            diedNow = true;
+            if (diedAt < 0) diedAt = t;
+            deathToSoil0 = fineRootC + coarseRootC;
+            deathToSoil1 = plantWoodC + plantLeafC + delta;
+            plantWoodC = 0.0;
+            plantLeafC = 0.0;
+            coarseRootC = 0.0;
+            fineRootC = 0.0;
+            delta = 0.0;
+            ringSum = 0.0;
+          }
+          plantWoodC = rmax0(plantWoodC);
+          plantLeafC = rmax0(plantLeafC);
+          coarseRootC = rmax0(coarseRootC);
+          fineRootC = rmax0(fineRootC);
+          postAlive(&mailAlive[(t + 1) & 1][lane], t + 1, diedNow);
+          soilC += soilGain;
+          if (MayDie && diedNow) {
+            soilC += deathToSoil0;
+            soilC += deathToSoil1;
+          }
+          soilC = rmax0(soilC);
+          const R tGpp = photosynthesis * len;
+          const R tRh = rSoil * len;
+          const R tRa = ffma(rVeg, len, (rCoarseRoot + rFineRoot) * len);
+          const R tNee = R(-1.0) * ((tGpp - tRa) - tRh);
+          totNee += (double)tNee;
+          const double npp = (double)(photosynthesis - rVeg - rCoarseRoot - rFineRoot);
+          if (!RingLds) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rvN) :: "memory");
+          const double vNew = RingLds ? ringNew : (useLast ? lastNpp : rvN);
+          if (!(MayDie && diedNow)) {
+            ringSum = ffma(-wA, vPrev, ringSum);
+            ringSum = ffma(-wB, vNew, ringSum);
+            ringSum = ffma(npp, (double)len, ringSum);
+          } else {  // its ring epoch starts over; the other members carry on
+            ringValidFrom = t + 1;
+          }
+          vPrev = vNew;
+          if (RingLds) {
+            ringL[insSlot * 64 + lane] = npp;
+          } else {
+            ringp[(uint32_t)insSlot * ncu] = npp;
+            lastIns = insSlot;
+            lastNpp = npp;
+          }
+          *oNee = tNee;
+          oNee += ldNee;
+        };
         unsigned dayMask = ((unsigned)tileBits >> 16) >> (t - tileStart);
         for (; t < tLast; t++, dayMask >>= 1) {
           // The carbon wave's arithmetic is written out with explicit fused multiply-adds and
@@ -905,7 +969,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
           // this step's factors: five from wave L, the moisture effect from wave W (each flag read
           // before its values, one LDS round trip when both are current)
           R g1, g2, qSoilT, gFine, gCoarse, moistEff;
-          double ringNew = 0.0;  // LDS ring: the value this step evicts, read in the same round trip
+          ringNew = 0.0;  // LDS ring: the value this step evicts, read in the same round trip
           {
             WAIT_BEGIN()
             if (RingLds)
@@ -916,10 +980,10 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
             WAIT_END(0)
           }
           const R fSoil = qSoilT * moistEff;
-          double rvN = 0.0;
+          rvN = 0.0;
           if (!RingLds)
             asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(rvN) : "v"(ringp + (uint32_t)readSlot * ncu) : "memory");
-          const bool useLast = readSlot == lastIns;
+          useLast = readSlot == lastIns;
           const bool isDay = (dayMask & 1u) != 0;
 
           const R eLeaf = (R)plantLeafC, eSoilC = (R)soilC;
@@ -927,10 +991,10 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
           const R totalWoodC = (R)(plantWoodC + delta);
           const R meanNpp = (R)(ringSum * 0.2);
           const R folResp = eLeaf * g1;
-          const R rVeg = ffma(totalWoodC, g2, folResp);
-          const R rCoarseRoot = eCoarse * gCoarse;
-          const R rFineRoot = eFine * gFine;
-          const R rSoil = eSoilC * fSoil;
+          rVeg = ffma(totalWoodC, g2, folResp);
+          rCoarseRoot = eCoarse * gCoarse;
+          rFineRoot = eFine * gFine;
+          rSoil = eSoilC * fSoil;
           const R woodLitter = totalWoodC * K_wtr;
           const R leafLitter = eLeaf * K_ltr;
           R leafCreation = meanNpp * K_la, woodCreation = meanNpp * K_wa;
@@ -953,85 +1017,29 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
           accum(plantWoodC, woodCreation - woodLitter, len);
           accum(coarseRootC, coarseRootCreation - coarseRootLoss, len);
           accum(fineRootC, fineRootCreation - fineRootLoss, len);
-          const double soilGain = (double)((coarseRootLoss + fineRootLoss + woodLitter + leafLitter - rSoil) * len);
+          soilGain = (double)((coarseRootLoss + fineRootLoss + woodLitter + leafLitter - rSoil) * len);
           const R r_a = rVeg + rFineRoot + rCoarseRoot;
           const R alloc = leafCreation + woodCreation + fineRootCreation + coarseRootCreation;
-          const bool rootsOk = (plantWoodC > kTiny) && (fineRootC + coarseRootC > kTiny);
-          R photosynthesis = 0;
+          rootsOk = (plantWoodC > kTiny) && (fineRootC + coarseRootC > kTiny);
+          photosynthesis = 0;
           if (isDay) {
             WAIT_BEGIN()
             photosynthesis = take(&mailPsn[t & 1][lane], &seqPsn, t);
             WAIT_END(1)
           }
           accum(delta, (photosynthesis - r_a) - alloc, len);
-          // the rest of the step, written once and instantiated twice: the common case (nobody
-          // dies: no mortality code at all behind ONE wave-uniform test) and the step on which a
-          // member of the wavefront dies (after which the wavefront takes the general step)
-          auto finishStep = [&](auto mayDie) {
-#pragma clang fp contract(off)
-            constexpr bool MayDie = decltype(mayDie)::value;
-            bool diedNow = false;
-            double deathToSoil0 = 0.0, deathToSoil1 = 0.0;
-            if (MayDie && !(rootsOk && (plantWoodC + delta > kTiny))) {  // every member was alive before
-              ringClean = false;
-              aliveC = false;
-              diedNow = true;
-              if (diedAt < 0) diedAt = t;
-              deathToSoil0 = fineRootC + coarseRootC;
-              deathToSoil1 = plantWoodC + plantLeafC + delta;
-              plantWoodC = 0.0;
-              plantLeafC = 0.0;
-              coarseRootC = 0.0;
-              fineRootC = 0.0;
-              delta = 0.0;
-              ringSum = 0.0;
-            }
-            plantWoodC = rmax0(plantWoodC);
-            plantLeafC = rmax0(plantLeafC);
-            coarseRootC = rmax0(coarseRootC);
-            fineRootC = rmax0(fineRootC);
-            postAlive(&mailAlive[(t + 1) & 1][lane], t + 1, diedNow);
-            soilC += soilGain;
-            if (MayDie && diedNow) {
-              soilC += deathToSoil0;
-              soilC += deathToSoil1;
-            }
-            soilC = rmax0(soilC);
-            const R tGpp = photosynthesis * len;
-            const R tRh = rSoil * len;
-            const R tRa = ffma(rVeg, len, (rCoarseRoot + rFineRoot) * len);
-            const R tNee = R(-1.0) * ((tGpp - tRa) - tRh);
-            totNee += (double)tNee;
-            const double npp = (double)(photosynthesis - rVeg - rCoarseRoot - rFineRoot);
-            if (!RingLds) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rvN) :: "memory");
-            const double vNew = RingLds ? ringNew : (useLast ? lastNpp : rvN);
-            if (!(MayDie && diedNow)) {
-              ringSum = ffma(-wA, vPrev, ringSum);
-              ringSum = ffma(-wB, vNew, ringSum);
-              ringSum = ffma(npp, (double)len, ringSum);
-            } else {  // its ring epoch starts over; the other members carry on
-              ringValidFrom = t + 1;
-            }
-            vPrev = vNew;
-            if (RingLds) {
-              ringL[insSlot * 64 + lane] = npp;
-            } else {
-              ringp[(uint32_t)insSlot * ncu] = npp;
-              lastIns = insSlot;
-              lastNpp = npp;
-            }
-            *oNee = tNee;
-            oNee += ldNee;
-          };
           const bool dies = !(rootsOk && (plantWoodC + delta > kTiny));
           if (__builtin_expect(__builtin_amdgcn_ballot_w64(dies) != 0, 0)) {
-            finishStep(std::true_type{});
-            t++;
-            break;  // the general step from the next one on
+            dyingStep = true;
+            break;
           }
           finishStep(std::false_type{});
           readSlot = nextSlot(readSlot);
           insSlot = nextSlot(insSlot);
+        }
+        if (dyingStep) {  // finish that step with the mortality code; the general step from the next one on
+          finishStep(std::true_type{});
+          t++;
         }
         recB += (int)(t - tFirst) * (int)sizeof(FastRec);
       }
