@@ -1022,7 +1022,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
           const R alloc = leafCreation + woodCreation + fineRootCreation + coarseRootCreation;
           rootsOk = (plantWoodC > kTiny) && (fineRootC + coarseRootC > kTiny);
           photosynthesis = 0;
-          if (isDay) {
+          if (__builtin_expect(isDay, 0)) {  // laid out for the night step: by night this wave is the critical one
             WAIT_BEGIN()
             photosynthesis = take(&mailPsn[t & 1][lane], &seqPsn, t);
             WAIT_END(1)
