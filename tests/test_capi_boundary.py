@@ -67,3 +67,18 @@ def test_flag_coupling_rules_are_enforced():
                 dict(carbonSaturation=1)):
         fl = (C.c_int32 * 12)(*sa.flags_from(**bad))
         assert L.sipnet_batch_create(fl, 1, 1, sa.F64, 0, C.byref(h)) == _lib.ERR_BAD_PARAMETER
+
+
+def test_python_constants_mirror_the_header_enums():
+    """the ctypes mirror's KERNEL_* / KOPT_* / MATH_* numbers are the header's (enum values are
+    part of the C-ABI: a caller passes plain ints)"""
+    import re
+    import sipnet_amd as sa
+    text = open(os.path.join(REPO, "include", "sipnet_amd.h")).read()
+    enums = {m.group(1): int(m.group(2)) for m in re.finditer(r"\b(SIPNET_(?:KERNEL|KOPT|MATH)_[A-Z_0-9]+)\s*=\s*(\d+)", text)}
+    assert len([k for k in enums if k.startswith("SIPNET_KERNEL_")]) == 7
+    for name, value in enums.items():
+        py = name[len("SIPNET_"):]
+        if py.startswith("MATH_"):
+            continue                      # exposed as Batch(fast_math=...) / set_math(bool)
+        assert getattr(sa, py) == value, (name, value, getattr(sa, py, None))
