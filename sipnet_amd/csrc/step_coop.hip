@@ -908,8 +908,11 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
           constexpr bool MayDie = decltype(mayDie)::value;
           bool diedNow = false;
           double deathToSoil0 = 0.0, deathToSoil1 = 0.0;
+          // wave-uniform (this instantiation runs only when some member dies): the whole wavefront
+          // takes the general step from now on -- a per-lane flag would send the survivors down the
+          // regular tiles and the dead member down the general step of the SAME tile afterwards
+          if (MayDie) ringClean = false;
           if (MayDie && !(rootsOk && (plantWoodC + delta > kTiny))) {  // every member was alive before
-            ringClean = false;
             aliveC = false;
             diedNow = true;
             if (diedAt < 0) diedAt = t;
@@ -1262,8 +1265,12 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
     bool diedNow = false;
     {
       const bool sufficient = rootsOk && (plantWoodC + delta > kTiny);
+      // a ring epoch stays behind: the whole wavefront takes the general path from now on.  The flag
+      // must stay wave-uniform -- set per lane it sent the survivors through the regular tiles and
+      // the dead member through the general step of the same tile afterwards (found by the fuzzer:
+      // a single member killed by a harvest, regular tiles following)
+      if (__builtin_amdgcn_ballot_w64(sufficient != alive0) != 0) ringClean = false;
       if (__builtin_expect(sufficient != alive0, 0)) {
-        ringClean = false;  // a ring epoch stays behind: this wave takes the general ring path from now on
         if (!alive0) {
           alive = true;
         } else {

@@ -42,3 +42,19 @@ def test_fuzz_cli_against_the_reference_binary():
     print(r.stdout[-3000:])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "16 trials ok" in r.stdout
+
+
+@pytest.mark.parametrize("kernel", ["coop_lds", "coop_hbm", "coop_pair", "coop_quad"])
+def test_single_member_killed_by_a_harvest_then_regular_tiles(kernel):
+    """the trial on which a 2 500-trial campaign found a wrong result: ONE member of a wavefront is
+    killed by a harvest while its 63 neighbours live on through regular 16-step tiles.  The carbon
+    wave's "ring epochs are clean" flag had been cleared in the dying lane only, so the survivors took
+    the regular tiles and the dead member the general step of the same tiles afterwards, reading the
+    factor slots of sixteen steps later (its NEE off by 2e-3 of the plane maximum and growing).
+    The flag is wave-uniform now; this replays the trial on every cooperative layout."""
+    env = dict(os.environ, FUZZ_KERNEL=kernel)
+    r = subprocess.run([sys.executable, os.path.join(helpers.REPO, "tools", "fuzz_gpu.py"), "2500", "20261002", "1709"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    print(r.stdout[-2000:])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "trial 1709" in r.stdout and "forced-" + kernel in r.stdout

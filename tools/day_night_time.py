@@ -2,10 +2,13 @@
 """dev (GPU box): c10k with the synthetic year's light forced to polar night / midnight sun, to
 read off what a night step and a day step of the cooperative kernel cost (the day step carries the
 leaf-area -> potential-photosynthesis -> photosynthesis chain through all three wavefronts).
-usage: day_night_time.py [kernel: auto|coop_lds|one_wave]"""
+usage: [SIPNET_LIB=build/variants/<name>/libsipnet_amd.so] day_night_time.py [kernel: auto|coop_lds|one_wave]"""
 import os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
+if os.environ.get("SIPNET_LIB"):                 # an experimental build from tools/build_variants.py
+    from sipnet_amd import _lib
+    _lib.use_library(os.environ["SIPNET_LIB"])
 import numpy as np, torch
 import sipnet_amd as sa
 from sipnet_amd import synth

@@ -5,6 +5,9 @@ schedules, random segmentation of the run, both math policies.  usage: fuzz_gpu.
 import os, sys, time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
+if os.environ.get("SIPNET_LIB"):                 # an experimental / older build (tools/build_variants.py)
+    from sipnet_amd import _lib
+    _lib.use_library(os.environ["SIPNET_LIB"])
 import numpy as np, torch
 import sipnet_amd as sa
 from sipnet_amd import synth
@@ -96,6 +99,9 @@ for trial in range(trials):
         elif r < 0.56 and default_flags: kern = sa.KERNEL_COOP_QUAD; forced = " coop-quad"
         elif r < 0.6 and default_flags: kern = sa.KERNEL_COOP_LDS; forced = " coop-lds"
     if rng.random() < 0.3: kopt = sa.KOPT_RUNTIME_FLAGS; forced += " rt-flags"
+    if os.environ.get("FUZZ_KOPT"): kopt = int(os.environ["FUZZ_KOPT"])
+    if os.environ.get("FUZZ_KERNEL"):     # rerun a trial on another kernel (with the trial index as third argument)
+        kern = getattr(sa, "KERNEL_" + os.environ["FUZZ_KERNEL"].upper()); forced = " forced-" + os.environ["FUZZ_KERNEL"]
     b = sa.Batch(flags, S, M, prec, fast_math=fast, kernel=kern, kernel_options=kopt)
     for sidx in range(S):
         if ev is not None: b.set_events(sidx, ev)
@@ -115,6 +121,20 @@ for trial in range(trials):
         diag_g = b.get_diagnostics()
     b_kernel = b.last_launch()["kernel"]
     status = np.asarray(b.get_status()); state = b.get_state(); b.close()
+    if only >= 0 and os.environ.get("FUZZ_STOP"):    # pools of one member after N steps, this kernel vs the one-wave kernel
+        nstop, mdbg = int(os.environ["FUZZ_STOP"]), int(os.environ.get("FUZZ_MEMBER", "0"))
+        for kk, nm in ((kern, "forced"), (sa.KERNEL_ONE_WAVE, "one-wave")):
+            bb = sa.Batch(flags, S, M, prec, fast_math=fast, kernel=kk, kernel_options=kopt)
+            for sidx in range(S):
+                if ev is not None: bb.set_events(sidx, ev)
+                bb.set_climate(sidx, clims[sidx]); bb.set_params(sidx, members)
+            bb.setup()
+            for a0, a1 in zip(cuts[:-1], cuts[1:]):
+                if a0 >= nstop: break
+                bb.run(a0, min(a1, nstop) - a0)
+            st_ = bb.get_state()[mdbg]
+            print("           %-8s after %d steps, member %d:" % (nm, nstop, mdbg), " ".join("%.10g" % v for v in st_[:31]))
+            bb.close()
     if want_full:
         # two members of the first site against the oracle's records and counters
         for m in sorted(set([0, M - 1])):
@@ -167,6 +187,33 @@ for trial in range(trials):
     print(f"trial {trial:3d}: S={S} M={M:3d} T={T:5d} segs={len(cuts)-1} {'f32' if prec else 'f64'} {'fast' if fast else 'strict'} "
           f"ev={0 if ev is None else len(ev):2d} [{flag_s}]{forced} planes {err:.2e} pools {perr:.2e}", flush=True)
     assert np.isfinite(got[:, :, ok]).all()
+    if only >= 0 and prec == sa.F64 and ok.any():   # where a mismatch starts
+        rel = np.abs(got[:, :, ok] - want[:, :, ok]) / scale
+        badm = np.nonzero((rel > 1e-9).any(axis=(0, 1)))[0]
+        print("           cuts", cuts, "kernel", b_kernel, "members over 1e-9:", badm[:16], "of", int(ok.sum()))
+        if len(badm):
+            m0 = int(badm[0]); first = int(np.nonzero((rel[:, :, m0] > 1e-9).any(axis=0))[0][0])
+            print("           member", m0, "first step", first, "year/day", clim.year[first], clim.day[first],
+                  "got", got[:, first, ok][:, m0], "want", want[:, first, ok][:, m0])
+            steps_bad = np.nonzero((rel[:, :, m0] > 1e-9).any(axis=0))[0]
+            print("           member", m0, "steps over 1e-9:", steps_bad[:40], "count", len(steps_bad))
+            print("           at that step, all members' |dNEE|/scale:", np.round(rel[0, first, :] * 1e6, 2)[:16], "(x1e-6)")
+            print("           NEE got/want around:", [(int(tt), float(got[0, tt, ok][m0]), float(want[0, tt, ok][m0])) for tt in range(first - 2, first + 20)])
+            if os.environ.get("FUZZ_REC"):   # the 44-column record of that member around that step, kernel vs oracle
+                bb = sa.Batch(flags, S, M, prec, fast_math=fast, kernel=kern, kernel_options=kopt)
+                for sidx in range(S):
+                    if ev is not None: bb.set_events(sidx, ev)
+                    bb.set_climate(sidx, clims[sidx]); bb.set_params(sidx, members)
+                bb.setup()
+                recs_ = [bb.run(a0, a1 - a0, full=True)[1] for a0, a1 in zip(cuts[:-1], cuts[1:])]
+                rec_g = torch.cat(recs_, dim=0).cpu().numpy()
+                bb.close()
+                _, rec_o, _ = oracle.run_member(flags, members[m0], clims[0], ev)
+                for tt in (first - 1, first, first + 1):
+                    d_ = np.abs(rec_g[tt, :36, m0] - rec_o[tt])
+                    print("           step", tt, "record columns differing > 1e-12:", {int(c): (float(rec_g[tt, c, m0]), float(rec_o[tt, c])) for c in np.nonzero(d_ > 1e-12)[0]})
+            if ev is not None:
+                print("           events:", [(e.year, e.day, e.type, [round(x, 3) for x in e.p[:4]]) for e in ev])
     assert err < tol and perr < ptol, "MISMATCH"
     worst = max(worst, err if prec == sa.F64 else 0.0)
 print(f"{trials} trials ok in {time.time()-t00:.0f} s; worst fp64 plane error {worst:.2e} of the plane maximum")
