@@ -14,6 +14,9 @@ from sipnet_amd import synth
 from sipnet_amd.config import param_index as pi
 from tests import helpers
 
+# FUZZ_COOP=1: a campaign on the cooperative kernels only -- default flags, throughput arithmetic, every
+# layout forced in turn, and a few fragile members that single events kill in the middle of a run
+COOP_ONLY = bool(os.environ.get("FUZZ_COOP"))
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
 only = int(sys.argv[3]) if len(sys.argv) > 3 else -1      # rerun one trial with details
@@ -34,7 +37,7 @@ def random_flags():
     elif rng.random() < 0.2: f["waterHResp"] = 0
     if f["anaerobic"] and f["litterPool"] and rng.random() < 0.6: f["nitrogenCycle"] = 1
     if f["litterPool"] and rng.random() < 0.4: f["carbonSaturation"] = 1
-    if rng.random() < 0.25: f = {}          # default flags: throughput / cooperative kernels
+    if rng.random() < 0.25 or COOP_ONLY: f = {}          # default flags: throughput / cooperative kernels
     return f
 
 def random_events(clim, n):
@@ -82,7 +85,10 @@ for trial in range(trials):
         members[2, pi("soilWFracInit")] = 0.02          # drought
         members[3, pi("leafTurnoverRate")] = 0.9
     ev = random_events(clim, int(rng.integers(1, 12))) if flags[0] else None
-    fast = bool(rng.random() < 0.7)
+    if COOP_ONLY and M > 8:
+        for mm in rng.choice(M, size=min(4, M // 8), replace=False):      # fragile stands: a harvest may finish them off
+            members[mm, pi("plantWoodInit")] *= float(10.0 ** -rng.uniform(1.5, 4.0))
+    fast = bool(rng.random() < 0.7) or COOP_ONLY
     prec = sa.F32_MIXED if (fast and rng.random() < 0.25) else sa.F64
     runs = [oracle.run_block(flags, members, c, ev) for c in clims]
     want = np.concatenate([r[0] for r in runs], axis=2)
@@ -99,6 +105,10 @@ for trial in range(trials):
         elif r < 0.56 and default_flags: kern = sa.KERNEL_COOP_QUAD; forced = " coop-quad"
         elif r < 0.6 and default_flags: kern = sa.KERNEL_COOP_LDS; forced = " coop-lds"
     if rng.random() < 0.3: kopt = sa.KOPT_RUNTIME_FLAGS; forced += " rt-flags"
+    if COOP_ONLY:
+        kopt = 0
+        kern, forced = [(sa.KERNEL_AUTO, ""), (sa.KERNEL_COOP_LDS, " coop-lds"), (sa.KERNEL_COOP_HBM, " coop-hbm"),
+                        (sa.KERNEL_COOP_PAIR, " coop-pair"), (sa.KERNEL_COOP_QUAD, " coop-quad")][int(rng.integers(0, 5))]
     if os.environ.get("FUZZ_KOPT"): kopt = int(os.environ["FUZZ_KOPT"])
     if os.environ.get("FUZZ_KERNEL"):     # rerun a trial on another kernel (with the trial index as third argument)
         kern = getattr(sa, "KERNEL_" + os.environ["FUZZ_KERNEL"].upper()); forced = " forced-" + os.environ["FUZZ_KERNEL"]
