@@ -388,3 +388,31 @@ def test_quad_kernel_has_no_full_state_build(base):
     with pytest.raises(sa.SipnetError, match="no full-state"):
         b.run(full=True)
     b.close()
+
+
+def test_a_member_starving_in_the_middle_of_a_regular_tile(oracle, base):
+    """no events: one stand's root pools decay below the survival threshold at step 2 508, the
+    thirteenth step of a regular 16-step tile, while its 63 neighbours live on.  The carbon wave
+    leaves the regular path on that step (its tail is finished after the loop with the mortality
+    code) and must stay on the general step as a whole wavefront from then on -- every layout of
+    the cooperative kernel against the oracle, the starving member and its neighbours"""
+    flags = sa.flags_from()
+    clim = year_clim(n=48 * 70)
+    members = synth.perturbed_params(base, 192)
+    members[3, pi("plantWoodInit")] *= 2.65e-10
+    pick = np.r_[0:8, 60:68]
+    want, _, so = oracle.run_block(flags, members[pick], clim)
+    assert (so == 0).all()
+    _, rec, _ = oracle.run_member(flags, members[3], clim, None)
+    roots = rec[:, 20] + rec[:, 21]
+    died = int(np.nonzero(roots == 0.0)[0][0])
+    assert 1000 < died < clim.n_steps - 200 and died % 16 not in (0, 15), died   # in the middle of a tile
+    for kernel in (sa.KERNEL_COOP_LDS, sa.KERNEL_COOP_HBM, sa.KERNEL_COOP_PAIR, sa.KERNEL_COOP_QUAD, sa.KERNEL_ONE_WAVE):
+        b = build(flags, [clim], members, sa.F64, kernel)
+        got = b.run()[0].cpu().numpy()
+        state = b.get_state()
+        b.close()
+        d = np.abs(got[:, :, pick] - want).max(axis=(1, 2))
+        print("kernel %d: max|d| %.3e; member 3 died at step %d (oracle %d)" % (kernel, d.max(), int(state[3, 30]), died))
+        assert d.max() < TOL_F64, kernel
+        assert int(state[3, 30]) == died
