@@ -58,3 +58,15 @@ def test_single_member_killed_by_a_harvest_then_regular_tiles(kernel):
     print(r.stdout[-2000:])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "trial 1709" in r.stdout and "forced-" + kernel in r.stdout
+
+
+def test_fuzz_cooperative_layouts_with_fragile_members():
+    """a fixed-seed slice of the cooperative-only campaign (FUZZ_COOP=1: default flags, throughput
+    arithmetic, the one-, two- and four-chunk layouts and the default policy in turn, a few stands so
+    small that single harvests finish them off in the middle of a run)"""
+    env = dict(os.environ, FUZZ_COOP="1")
+    r = subprocess.run([sys.executable, os.path.join(helpers.REPO, "tools", "fuzz_gpu.py"), "40", "7"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "40 trials ok" in r.stdout
