@@ -123,7 +123,7 @@ __device__ __forceinline__ void takePgp(const float* slot, const int* flag, cons
   } while (uni(f) < step || uni(w < 0 ? -w : w) < step + 2);
   died = w < 0;
 }
-// wave C: this step's six factors -- rows 0..4 of the block from wave L, row 5 (the moisture
+// wave C: this step's six factors -- rows 0..4 of the block from wave F (or L), row 5 (the moisture
 // effect) from wave W -- and both producers' sequence flags: the two flags in one ds_read2_b32
 // (they are neighbours), the six values in three ds_read2st64 (rows are 64 elements apart).
 // Flags are read before the values (DS reads return in order): current flags vouch for them.
@@ -315,7 +315,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   __shared__ alignas(16) R mailFacAll[NP][2][6][64];
   __shared__ int mailAliveAll[NP][2][64];  // aliveWord(): wave C's confirmation of the leaf area it posted
   __shared__ int seqLaiAll[NP], seqPgpAll[NP], seqPsnAll[NP];
-  __shared__ alignas(8) int seqFacMoistAll[NP][2];  // [0] wave L's factor rows, [1] wave W's moisture row
+  __shared__ alignas(8) int seqFacMoistAll[NP][2];  // [0] wave F's / L's factor rows, [1] wave W's moisture row
 #define seqFac seqFacMoist[0]
 #define seqMoist seqFacMoist[1]
   // The running-mean ring of the 64 members lives in LDS for the whole launch (250 x 64 x 8 B =
@@ -645,7 +645,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         const bool frozen = tsoil < K_frozThr;
 
         // ---- for wave C: the soil-moisture effect on heterotrophic respiration of THIS step
-        // (depeffects.c:23-57; the Q10 / tillage part comes from wave L), posted before anything
+        // (depeffects.c:23-57; the Q10 / tillage part comes from wave F or L), posted before anything
         // else so that C never waits for it
         {
           R moistEff = clip01(eWater * K_invWhc);
@@ -969,7 +969,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
           // paths a wavefront takes depends on its 63 neighbours, so they must not differ by what
           // the compiler happens to fuse in one context and not in the other.
 #pragma clang fp contract(off)
-          // this step's factors: five from wave L, the moisture effect from wave W (each flag read
+          // this step's factors: five from wave F / L, the moisture effect from wave W (each flag read
           // before its values, one LDS round trip when both are current)
           R g1, g2, qSoilT, gFine, gCoarse, moistEff;
           ringNew = 0.0;  // LDS ring: the value this step evicts, read in the same round trip
@@ -1050,7 +1050,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   for (; t < tLast; t++, recB += sizeof(FastRec)) {
 #pragma clang fp contract(off)  // explicit fused multiply-adds only: see the regular-tile path
     // record fields of the carbon block (len invLen | tsoil10 cumGdd | dayTime w0 | ints) and the
-    // five factors wave W posted for this step, in ONE LDS round trip; the flag is read before
+    // five factors of wave F / L and wave W's moisture effect for this step, in ONE LDS round trip; each flag is read before
     // the values (DS reads return in order), so a current flag vouches for what follows it
     d2 q0, q6, q7;
     i4 j0;
