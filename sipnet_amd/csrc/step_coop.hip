@@ -235,7 +235,7 @@ __device__ __forceinline__ void accum(double& pool, float x, float len) { pool +
 // HW_ID (wave slot, SIMD, CU, shader array / engine) and XCC_ID -- to check that the three waves of
 // a workgroup sit on three different SIMDs and where the waves of co-resident workgroups land
 #ifdef SIPNET_HWID
-__device__ unsigned g_coopHwId[4096 * 3 * 2];
+__device__ unsigned g_coopHwId[4096 * 4 * 2];  // [chunk][carbon, water, light, factors][HW_ID, XCC_ID]
 #endif
 #ifdef SIPNET_STAMPS
 __device__ unsigned long long g_coopStamps[16];
@@ -341,11 +341,11 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   auto& seqFacMoist = seqFacMoistAll[sub];
   [[maybe_unused]] const bool firstChunk = blockIdx.x == 0 && sub == 0;  // diagnostics builds report this one
 #ifdef SIPNET_HWID
-  if (lane == 0 && role >= 0 && role < 3 && (blockIdx.x * NP + sub) < 4096) {
+  if (lane == 0 && role >= 0 && (blockIdx.x * NP + sub) < 4096) {
     unsigned hw, xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
-    g_coopHwId[((blockIdx.x * NP + sub) * 3 + role) * 2] = hw;
-    g_coopHwId[((blockIdx.x * NP + sub) * 3 + role) * 2 + 1] = xcc;
+    g_coopHwId[((blockIdx.x * NP + sub) * 4 + role) * 2] = hw;
+    g_coopHwId[((blockIdx.x * NP + sub) * 4 + role) * 2 + 1] = xcc;
   }
 #endif
   unsigned char* lds = ldsTilesAll[sub][(role < 0 || role > 2) ? 0 : role];
@@ -1519,7 +1519,7 @@ __global__ __launch_bounds__(768) void stepCoopQuadKernel(FastArgs a) {
 
 #ifdef SIPNET_HWID
 extern "C" int sipnet_debug_read_coop_hwid(unsigned* out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_coopHwId), sizeof(unsigned) * 4096 * 3 * 2);
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_coopHwId), sizeof(unsigned) * 4096 * 4 * 2);
 }
 #endif
 #ifdef SIPNET_WAITS
