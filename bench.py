@@ -16,6 +16,7 @@ Workloads (BASELINE.json configs):
   c5    particle-filter cycle: 131072 particles per GPU (1 M over 8), fp32-mixed, one day
         (48 steps) of forecast + the analysis step (likelihood weights, all-gather of
         log-weights, systematic resampling, all-to-all of resampled checkpoints, gather)
+  c2x16 16 sites x 1024 members per GPU, fp64: c2 stacked 16-fold (INTEGRATION.md "small ensembles")
   c10kn c10k's shape with the nitrogen-cycle flag set (litter pool + anaerobic + N cycle): the
         optional-flag instantiation of the throughput kernel (not a BASELINE config)
 Per-GPU work is fixed as N grows ("scaling": "weak").
@@ -56,6 +57,9 @@ WORKLOADS = {
     "c2": dict(sites=1, members=1024, prec="f64", steps=17520),
     "c3": dict(sites=1, members=65536, prec="f32", steps=17520),
     "c4": dict(sites=32, members=1024, prec="f64", steps=17520),
+    # what a caller with a SMALL ensemble should hand over: 16 sites (or years / scenarios) of
+    # 1 024 members stacked into one batch -- 256 chunks, one per CU, for the launch time of c2
+    "c2x16": dict(sites=16, members=1024, prec="f64", steps=17520),
     "c5": dict(sites=1, members=131072, prec="f32", steps=48, pf=True),
     # c10k's shape with the nitrogen-cycle flag set (litter pool + anaerobic + N cycle)
     "c10kn": dict(sites=1, members=10240, prec="f64", steps=17520, param="allflags_forest.param",
@@ -236,6 +240,10 @@ def main():
     ap.add_argument("--dump-stats", default="",
                     help="rank 0 writes the whole ensemble's statistics block [3][T][sites][2] (sum, sum of "
                          "squares over ALL ranks' members) of the last pass to this .npy file")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the N>1 path (RCCL process group, side-stream statistics + all-gather, segmented "
+                         "full gather, the particle filter's all-gather / all-to-all) even with ONE rank, and "
+                         "report its cost against the plain pass as config.dist_overhead_ms")
     ap.add_argument("--rehearse", action="store_true",
                     help="development: run the N>1 path on ONE GPU (all ranks share device 0, gloo "
                          "collectives through host copies); the numbers mean nothing")
@@ -283,10 +291,16 @@ def main():
     if args.rehearse:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # distd: the exchange path of an N-rank run is executed (N > 1, or --force-dist with one rank:
+    # RCCL itself, the side stream and every collective call run exactly as they do at N = 8)
+    distd = world > 1 or args.force_dist
+    if distd:
         if args.rehearse:
             dist.init_process_group("gloo")
         else:
+            if world == 1 and "MASTER_ADDR" not in os.environ:     # started without the launcher
+                os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29531"),
+                                  RANK="0", WORLD_SIZE="1")
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     def all_gather_into(out, x):
@@ -304,7 +318,7 @@ def main():
     ranks_seen, devices_seen = 1, None
     props = torch.cuda.get_device_properties(local_rank)
     ident = f"{getattr(props, 'uuid', '')}|{getattr(props, 'pci_bus_id', '')}|{getattr(props, 'pci_device_id', '')}|{props.name}"
-    if world > 1:
+    if distd:
         me = torch.zeros(128, dtype=torch.uint8)
         raw_id = ident.encode()[:128]
         me[:len(raw_id)] = torch.tensor(list(raw_id), dtype=torch.uint8)
@@ -328,16 +342,16 @@ def main():
     planes, _ = b.alloc_outputs(T)
     stats = torch.empty((3, T, S, 2), dtype=torch.float64, device=b.device)
     gathered = torch.empty((world,) + tuple(stats.shape), dtype=torch.float64, device=b.device) \
-        if world > 1 and args.gather == "stats" else None
+        if distd and args.gather == "stats" else None
     gathered_full = None
-    if world > 1 and args.gather == "full":
+    if distd and args.gather == "full":
         gathered_full = torch.empty((world,) + tuple(planes.shape), dtype=planes.dtype, device=b.device)
 
     # N > 1, statistics gather: the ensemble statistics of pass k (three streaming reductions
     # + one small all-gather) run on a side stream under the step kernel of pass k+1, which
     # writes the other of two output-plane buffers
-    overlap = world > 1 and args.gather == "stats" and not wl.get("pf")
-    side = torch.cuda.Stream(device=b.device) if world > 1 else None
+    overlap = distd and args.gather == "stats" and not wl.get("pf")
+    side = torch.cuda.Stream(device=b.device) if distd else None
     if overlap:
         planes2, _ = b.alloc_outputs(T)
         stats2 = torch.empty_like(stats)
@@ -357,15 +371,17 @@ def main():
         # parameter sets (particles carry their parameters), member k is no longer draw k
         pf_first = planes[:, :, :min(8, M)].double().cpu().numpy()
         tot = planes[0].double().sum(0)
-        if world > 1:
+        if distd:
             tot = sd._gather0(tot, world, None).reshape(-1)
         pf_obs, pf_sigma = float(tot.median()), float(tot.std()) * 1.5 + 1e-12
 
     pf_totals = torch.ones(max(args.steps + args.warmup, 1), dtype=torch.int64, device=b.device)
     pf_cycle = [0]
 
-    def one_pass(record):
-        if overlap:
+    def one_pass(record, plain=False):
+        """plain: the pass of a single-GPU run (no exchange path at all) -- what --force-dist
+        compares the distributed pass with"""
+        if overlap and not plain:
             buf = bufs[npass[0] & 1]
             npass[0] += 1
             main = torch.cuda.current_stream()
@@ -390,10 +406,11 @@ def main():
             slot = pf_totals[pf_cycle[0] % len(pf_totals):][:1]
             pf_cycle[0] += 1
             _, info = sd.pf_analysis(b, planes[0], pf_obs, pf_sigma, u0=0.5, rank=rank, world=world,
-                                     with_params=True, diagnostics=record, total_out=slot)
+                                     with_params=True, diagnostics=record, total_out=slot,
+                                     collectives=distd and not plain)
             pf_info.update(info)
             return
-        if world > 1 and args.gather != "none":
+        if distd and not plain and args.gather != "none":
             for v in range(3):
                 b.reduce_plane(planes[v], stats[v])
             if args.gather == "stats":
@@ -402,7 +419,7 @@ def main():
                 all_gather_into(gathered_full, planes)
 
     def barrier():
-        if world > 1:
+        if distd:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -418,10 +435,31 @@ def main():
     dt = time.perf_counter() - t0
     if pf and not bool((pf_totals > 0).all()):
         raise RuntimeError("particle filter: a cycle ended with every particle at zero weight")
-    if world > 1:
+    if distd:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.rehearse else b.device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    # --force-dist: the same K passes without the exchange path, and the difference per pass
+    dist_overhead = None
+    if args.force_dist:
+        pf_cycle[0] = 0
+        for _ in range(args.warmup):
+            one_pass(False, plain=True)
+        barrier()
+        tp0 = time.perf_counter()
+        for _ in range(args.steps):
+            one_pass(False, plain=True)
+        barrier()
+        dtp = time.perf_counter() - tp0
+        dist_overhead = {"ms_per_step_dist": dt / args.steps * 1e3, "ms_per_step_plain": dtp / args.steps * 1e3,
+                         "dist_overhead_ms": (dt - dtp) / args.steps * 1e3,
+                         "predicted_weak_scaling_efficiency": dtp / dt,
+                         "backend": dist.get_backend(), "world": world,
+                         "note": "K passes with the exchange path of an N-rank run (RCCL group, "
+                                 + ("side-stream ensemble statistics + all-gather of the statistics block under the next pass's step kernel"
+                                    if overlap else "the particle filter's all-gather of log-weights + all-to-all of checkpoints" if pf
+                                    else f"gather={args.gather} in line")
+                                 + ") against K plain passes; the link time of a real N-rank exchange is not in it"}
 
     # dominant kernel's launch duration (HIP events on the launch stream, inside the library) and
     # the per-pass setupModel() kernel (torch events on the same, current, stream)
@@ -455,7 +493,7 @@ def main():
             barrier()
             e0.record()
             sd.pf_analysis(b, planes[0], pf_obs, pf_sigma, u0=0.5, rank=rank, world=world, with_params=True,
-                           diagnostics=False)
+                           diagnostics=False, collectives=distd)
             e1.record()
             torch.cuda.synchronize()
             ams.append(e0.elapsed_time(e1))
@@ -465,7 +503,7 @@ def main():
     # rank all-gathered -- measured in an extra untimed pass: the launch is cut into 10 segments
     # and segment k's planes travel on the side stream while segment k+1 computes
     gather_full = None
-    if world > 1 and not pf:
+    if distd and not pf:
         nseg = 10
         cuts = [T * k // nseg for k in range(nseg + 1)]
         seglen = max(z - a for a, z in zip(cuts[:-1], cuts[1:]))
@@ -497,7 +535,7 @@ def main():
                                "(segment k travels under the kernel of segment k+1)"}
 
     if args.dump_stats and not pf:
-        if world > 1 and args.gather == "stats":
+        if distd and args.gather == "stats":
             g = (bufs[(npass[0] - 1) & 1]["gathered"] if overlap else gathered)
             # ranks hold different sites in c4 and the same site's members otherwise: a rank's block
             # is added to the others' (members) or stands beside them (sites)
@@ -525,7 +563,7 @@ def main():
             if pf:
                 pg = pf_first
             else:
-                if world > 1:        # the planes of a whole pass from a fresh setup
+                if distd:        # the planes of a whole pass from a fresh setup
                     b.setup()
                     b.run(0, T, planes=planes)
                 pg = planes[:, :, :n_chk].double().cpu().numpy()
@@ -575,7 +613,8 @@ def main():
                                    + (", particle-filter cycle (forecast + analysis)" if pf else ""),
                        "sites_per_gpu": S, "members_per_site": M, "timesteps": T,
                        "fast_math": bool(args.fast_math),
-                       "gather": args.gather if world > 1 else "n/a (1 GPU)",
+                       "gather": args.gather if distd else "n/a (1 GPU)",
+                       **({"dist_overhead": dist_overhead} if dist_overhead else {}),
                        "parallelism": f"ensemble-sharded x{world}",
                        "ranks_seen": ranks_seen, "devices_seen": devices_seen, "device_ids": device_ids,
                        **({"gather_full": gather_full} if gather_full else {}),
@@ -599,7 +638,7 @@ def main():
             "cpu_baseline": cpu, "parity": parity,
         }
         print(json.dumps(line))
-    if world > 1:
+    if distd:
         dist.destroy_process_group()
     b.close()
 

@@ -165,20 +165,24 @@ def pf_exchange_plan_reference(ancestors, n_local, world, rank):
     return send_cols, src, recv_counts
 
 
-def pf_resample(batch, ancestors, rank=0, world=1, group=None, with_params=False):
+def pf_resample(batch, ancestors, rank=0, world=1, group=None, with_params=False, collectives=None):
     """Move particle state so that global particle g becomes old global particle
     ancestors[g]: local gather for ancestors this rank already holds, ONE all-to-all
     (RCCL over xGMI) of packed checkpoints for the rest, every needed ancestor sent once
     per destination.  `batch` needs ncol, pack_members(), resample().
-    Returns {"sent": columns sent, "received": columns received, "bytes_sent": ...}."""
+    Returns {"sent": columns sent, "received": columns received, "bytes_sent": ...}.
+    `collectives`: None = only with more than one rank; True = plan, pack and all-to-all even in a
+    one-rank group (bench.py --force-dist runs the N-rank code path on one GPU that way)."""
     import torch
     import torch.distributed as dist
     n = batch.ncol
-    if world == 1:
+    if collectives is None:
+        collectives = world > 1
+    if not collectives:
         batch.resample(ancestors[:n].to(torch.int32), None, (), with_params)
         return {"sent": 0, "received": 0, "bytes_sent": 0}
     send_cols, src, recv_counts = pf_exchange_plan(ancestors, n, world, rank)
-    blocks = [batch.pack_members(c, with_params) for c in send_cols]
+    blocks = [batch.pack_members(c, with_params) for c in send_cols]   # (an empty block is [words][0])
     words = blocks[0].shape[0]
     send = torch.cat([b.reshape(-1) for b in blocks])
     out_splits = [words * c for c in recv_counts]
@@ -197,18 +201,20 @@ def pf_resample(batch, ancestors, rank=0, world=1, group=None, with_params=False
 
 
 def pf_analysis(batch, plane, obs, sigma, u0, rank=0, world=1, group=None, with_params=False,
-                diagnostics=True, total_out=None):
+                diagnostics=True, total_out=None, collectives=None):
     """One analysis step after a forecast: likelihood weights of this rank's particles ->
     all-gather of log-weights (n_total x 8 B) -> systematic resampling (redundant, identical
     on every rank) -> pf_resample.  Returns (ancestors, info).  `total_out` (int64 CUDA tensor
     [1]): run without a host round trip and leave the total weight there for a later check."""
     import torch
     import torch.distributed as dist
+    if collectives is None:
+        collectives = world > 1
     logw = batch.pf_log_weights(plane, obs, sigma)
-    if world > 1:
+    if collectives:
         logw = _gather0(logw, world, group).reshape(-1)
     anc = pf_systematic_ancestors(logw, u0, total_out=total_out)
-    info = pf_resample(batch, anc, rank, world, group, with_params)
+    info = pf_resample(batch, anc, rank, world, group, with_params, collectives)
     if not diagnostics:
         return anc, info
     w = torch.exp(logw - logw.max())

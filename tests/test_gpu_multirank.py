@@ -88,3 +88,48 @@ def test_particle_filter_cycle_two_ranks_rehearsed(tmp_path):
     assert pf["received"] + pf["sent"] > 0                 # particles did cross between the ranks
     assert 1 < pf["unique_ancestors"] < 2 * 4096
     assert j["parity"]["max_abs_dNEE"] < 2e-6
+
+
+# ---- the real RCCL backend, one rank -----------------------------------------------------------
+# Everything of the N-rank path that does not need a second GPU, executed under "nccl" (= RCCL):
+# process-group initialisation with device_id, all_gather_into_tensor on device views, the
+# side-stream ordering of reductions + collective against the next pass's step kernel, the
+# segmented full gather, and the particle filter's all-gather / all_to_all_single with split sizes.
+def _rccl_one_rank(args, tmp_path, timeout=900):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+         "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), BENCH, "--gpus", "1",
+         "--force-dist", "--no-cpu-baseline", "--no-fill-probe"] + args,
+        capture_output=True, text=True, timeout=timeout, env=env, cwd=helpers.REPO)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    return _last_json(r.stdout)
+
+
+@pytest.mark.parametrize("workload,members,nsteps", [("c2", 192, 48 * 30), ("c4", 64, 48 * 10)])
+def test_rccl_one_rank_statistics_equal_the_plain_run_bit_for_bit(workload, members, nsteps, tmp_path):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    d, p = str(tmp_path / "dist.npy"), str(tmp_path / "plain.npy")
+    common = ["--workload", workload, "--members", str(members), "--nsteps", str(nsteps), "--steps", "3",
+              "--warmup", "1"]
+    j = _rccl_one_rank(common + ["--dump-stats", d], tmp_path)
+    assert j["config"]["dist_overhead"]["backend"] == "nccl"
+    assert j["config"]["ranks_seen"] == 1 and j["config"]["devices_seen"] == 1
+    assert j["config"]["gather"] == "stats"
+    assert j["config"]["gather_full"]["ms"] > 0 and j["config"]["gather_full"]["segments"] == 10
+    assert j["config"]["dist_overhead"]["ms_per_step_plain"] > 0
+    assert j["parity"]["max_abs_dNEE"] < 1e-9
+    r1 = subprocess.run([sys.executable, BENCH, "--dump-stats", p, "--no-cpu-baseline", "--no-fill-probe"] + common,
+                        capture_output=True, text=True, timeout=600, env=env, cwd=helpers.REPO)
+    assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-3000:]
+    a, b = np.load(d), np.load(p)
+    assert a.shape == b.shape and np.array_equal(a, b)       # bit for bit
+
+
+def test_rccl_one_rank_particle_filter_cycle(tmp_path):
+    j = _rccl_one_rank(["--workload", "c5", "--members", "4096", "--steps", "3", "--warmup", "1"], tmp_path)
+    pf = j["config"]["particle_filter"]
+    assert j["config"]["dist_overhead"]["backend"] == "nccl"
+    assert pf["unique_ancestors"] > 64 and pf["ess"] > 64
+    assert pf["sent"] == 0 and pf["received"] == 0          # one rank: every ancestor is local
+    assert j["parity"]["max_abs_dNEE"] < 2e-6
