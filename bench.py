@@ -4,8 +4,8 @@
 Contract (driver):  python bench.py --gpus N --steps K --warmup W
   N>1 is launched by torch.distributed.run, one rank per GPU.  One "step" = one pass
   of the hot path over the whole batch: per-member setup + the time-fused step kernel
-  over every timestep of the forcing + (N>1) the ensemble-statistics reduction and the
-  RCCL all-gather of the NEE/GPP/ET statistics block.  Inputs (parameters, site plan)
+  over every timestep of the forcing + (N>1) the ensemble statistics (summed inside the
+  step kernel's launch) and the RCCL all-gather of the NEE/GPP/ET statistics block.  Inputs (parameters, site plan)
   are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 
 Workloads (BASELINE.json configs):
@@ -347,9 +347,9 @@ def main():
     if distd and args.gather == "full":
         gathered_full = torch.empty((world,) + tuple(planes.shape), dtype=planes.dtype, device=b.device)
 
-    # N > 1, statistics gather: the ensemble statistics of pass k (three streaming reductions
-    # + one small all-gather) run on a side stream under the step kernel of pass k+1, which
-    # writes the other of two output-plane buffers
+    # N > 1, statistics gather: the ensemble statistics of pass k come out of the step kernel's own
+    # launch (sipnet_batch_run_stats); their all-gather runs on a side stream under the step kernel
+    # of pass k+1, which writes the other of two output-plane / statistics buffers
     overlap = distd and args.gather == "stats" and not wl.get("pf")
     side = torch.cuda.Stream(device=b.device) if distd else None
     if overlap:
@@ -388,12 +388,12 @@ def main():
             if buf["done"] is not None:
                 main.wait_event(buf["done"])       # its statistics (two passes ago) have left
             b.setup()
-            b.run(0, T, planes=buf["planes"])
+            # the step kernel leaves the per-(step, site) sums behind (its light wave adds up the
+            # plane tiles while they are in L2; sipnet_batch_run_stats) ...
+            b.run_stats(0, T, planes=buf["planes"], stats=buf["stats"])
             buf["ran"].record(main)
-            with torch.cuda.stream(side):
+            with torch.cuda.stream(side):   # ... and the 0.84 MB block travels under the next pass
                 side.wait_event(buf["ran"])
-                for v in range(3):
-                    b.reduce_plane(buf["planes"][v], buf["stats"][v])
                 all_gather_into(buf["gathered"], buf["stats"])
                 buf["done"] = torch.cuda.Event()
                 buf["done"].record(side)
@@ -411,9 +411,9 @@ def main():
             pf_info.update(info)
             return
         if distd and not plain and args.gather != "none":
-            for v in range(3):
-                b.reduce_plane(planes[v], stats[v])
             if args.gather == "stats":
+                for v in range(3):
+                    b.reduce_plane(planes[v], stats[v])
                 all_gather_into(gathered, stats)
             else:
                 all_gather_into(gathered_full, planes)
@@ -541,8 +541,8 @@ def main():
             # is added to the others' (members) or stands beside them (sites)
             total = g.sum(0) if S == 1 else torch.cat([g[r] for r in range(world)], dim=2)
         else:
-            for v in range(3):
-                b.reduce_plane(planes[v], stats[v])
+            b.setup()
+            b.run_stats(0, T, planes=planes, stats=stats)
             total = stats
         if rank == 0:
             np.save(args.dump_stats, total.cpu().numpy())

@@ -238,6 +238,10 @@ enum sipnet_kernel_option {
   SIPNET_KOPT_NO_REGULAR_TILES = 8,  /* cooperative kernel: always the general per-step path, never the
                                         record-free path of regular 16-step tiles (A/B measurement,
                                         tests of the two paths against each other) */
+  SIPNET_KOPT_STATS_IN_KERNEL = 16,  /* sipnet_batch_run_stats: sum the plane tiles inside the step kernel on
+                                        EVERY cooperative layout (default: only where a workgroup has a
+                                        compute unit to itself and its fourth wavefront does the summing;
+                                        on the two- / four-chunk layouts three reduction passes are cheaper) */
   SIPNET_KOPT_FULL_STATE = 4         /* throughput kernels: advance EVERY accumulator of the restart
                                         schema (trackers.tot*, trackers.yearly*); without it only
                                         totNee / totGpp advance on the throughput path.  Implied by a
@@ -297,6 +301,19 @@ int sipnet_batch_run_debug(sipnet_batch *b, int32_t step0, int32_t n_steps, doub
 int sipnet_batch_reduce_plane(sipnet_batch *b, const void *d_plane,
                               int32_t elem_is_f32, int32_t n_steps, int64_t ld,
                               double *d_stats, void *hip_stream);
+
+/* sipnet_batch_run with the ensemble statistics of the three planes produced by the same
+ * launch: d_stats[((v * n_steps + t) * n_sites + site) * 2 + {0,1}] (DEVICE, doubles; v = 0 NEE,
+ * 1 GPP, 2 ET) = sum / sum of squares over the site's members of step step0 + t -- the block the
+ * ranks of a multi-GPU run all-gather.  All three planes are required.  On the
+ * one-chunk-per-compute-unit cooperative kernel (batches of up to 64 x #CUs members: c10k, c2 and
+ * its stacked form) the workgroup's fourth wavefront sums the tiles the carbon and water wavefronts
+ * have just stored (from L2: the planes are not read from HBM again) and a small second kernel adds
+ * the chunks of a site up; on the other kernels the launch is followed by three
+ * sipnet_batch_reduce_plane passes.  Both give the same sums up to the order of the additions. */
+int sipnet_batch_run_stats(sipnet_batch *b, int32_t step0, int32_t n_steps, void *d_nee,
+                           void *d_gpp, void *d_et, int64_t ld, double *d_stats,
+                           void *hip_stream);
 
 /* Copy per-member state to / from HOST memory: state[ncol][SIPNET_NSTATE]. */
 int sipnet_batch_get_state(sipnet_batch *b, double *state, void *hip_stream);

@@ -29,6 +29,7 @@ F64, F32_MIXED = 0, 1
 # enum sipnet_kernel / sipnet_kernel_option
 KERNEL_AUTO, KERNEL_ONE_WAVE, KERNEL_COOP_LDS, KERNEL_COOP_HBM, KERNEL_STRICT, KERNEL_COOP_PAIR, KERNEL_COOP_QUAD = range(7)
 KOPT_ONE_WAVE_PER_SIMD, KOPT_RUNTIME_FLAGS, KOPT_FULL_STATE, KOPT_NO_REGULAR_TILES = 1, 2, 4, 8
+KOPT_STATS_IN_KERNEL = 16
 
 
 class Event(C.Structure):
@@ -107,6 +108,7 @@ SIGNATURES = {
     "sipnet_batch_run": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int64, _P]),
     "sipnet_batch_run_debug": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, C.c_int64, _P]),
     "sipnet_batch_reduce_plane": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int64, _P, _P]),
+    "sipnet_batch_run_stats": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, C.c_int64, _P, _P]),
     "sipnet_batch_get_state": (C.c_int, [_P, _P, _P]),
     "sipnet_batch_set_state": (C.c_int, [_P, _P, _P]),
     "sipnet_batch_get_ring": (C.c_int, [_P, C.c_int64, _P, _P]),

@@ -153,6 +153,23 @@ class Batch:
                                             self._stream()), "run_debug")
         return rec, dbg
 
+    def run_stats(self, step0=0, n_steps=None, planes=None, stats=None):
+        """run() + the ensemble statistics of the three planes from the same launch
+        (sipnet_batch_run_stats): stats[3][n_steps][n_sites][2] = sum, sum of squares over each
+        site's members.  Returns (planes, stats)."""
+        t = self._torch
+        if n_steps is None:
+            n_steps = self.n_steps - step0
+        if planes is None:
+            planes, _ = self.alloc_outputs(n_steps, False)
+        if stats is None:
+            stats = t.empty((3, n_steps, self.n_sites, 2), dtype=t.float64, device=self.device)
+        assert stats.is_contiguous() and stats.dtype == t.float64
+        check(self.L.sipnet_batch_run_stats(self.h, step0, n_steps, C.c_void_p(planes[0].data_ptr()),
+                                            C.c_void_p(planes[1].data_ptr()), C.c_void_p(planes[2].data_ptr()),
+                                            self.ncol, C.c_void_p(stats.data_ptr()), self._stream()), "run_stats")
+        return planes, stats
+
     def reduce_plane(self, plane, stats=None):
         """Per (step, site) ensemble sum and sum of squares of one output plane
         [n_steps][ncol] -> stats[n_steps][n_sites][2] (float64, on device)."""

@@ -65,6 +65,8 @@ struct sipnet_batch {
   RingOp* d_ringOps = nullptr;
   EvRec* d_events = nullptr;
   int32_t* d_siteStatus = nullptr;
+  double* d_statsPart = nullptr;     // [3][chunks][n_steps of the launch][2]: per-chunk plane statistics
+  size_t statsPartCap = 0;           //   (sipnet_batch_run_stats on a cooperative kernel), doubles
   double* d_diag = nullptr;          // [4][ncol] per-member diagnostics, allocated on request
   SiteStart* d_siteStart = nullptr;  // [n_sites] what setupModel() reads of a site's first record
   size_t planCap = 0, fastCap = 0, ringOpCap = 0, evCap = 0;

@@ -317,6 +317,7 @@ void sipnet_batch_destroy(sipnet_batch* b) {
   if (b->d_siteStart) (void)hipFree(b->d_siteStart);
   if (b->d_siteBase) (void)hipFree(b->d_siteBase);
   if (b->d_diag) (void)hipFree(b->d_diag);
+  if (b->d_statsPart) (void)hipFree(b->d_statsPart);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
   delete b;
@@ -436,7 +437,8 @@ int sipnet_batch_setup(sipnet_batch* b, void* hip_stream) {
 }
 
 static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee, void* d_gpp,
-                   void* d_et, double* d_rec, double* d_dbg, int64_t ld, void* hip_stream);
+                   void* d_et, double* d_rec, double* d_dbg, int64_t ld, void* hip_stream,
+                   double* d_stats = nullptr);
 
 int sipnet_batch_set_math(sipnet_batch* b, int32_t policy) {
   if (!b || (policy != SIPNET_MATH_STRICT && policy != SIPNET_MATH_FAST)) {
@@ -454,7 +456,7 @@ int sipnet_batch_set_math(sipnet_batch* b, int32_t policy) {
 int sipnet_batch_set_kernel(sipnet_batch* b, int32_t kernel, int32_t options) {
   if (!b || kernel < SIPNET_KERNEL_AUTO || kernel > SIPNET_KERNEL_COOP_QUAD ||
       (options & ~(SIPNET_KOPT_ONE_WAVE_PER_SIMD | SIPNET_KOPT_RUNTIME_FLAGS | SIPNET_KOPT_FULL_STATE |
-                   SIPNET_KOPT_NO_REGULAR_TILES))) {
+                   SIPNET_KOPT_NO_REGULAR_TILES | SIPNET_KOPT_STATS_IN_KERNEL))) {
     setError("sipnet_batch_set_kernel: bad argument");
     return SIPNET_ERR_BAD_ARGUMENT;
   }
@@ -504,6 +506,15 @@ int sipnet_batch_run(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_ne
   return runImpl(b, step0, n_steps, d_nee, d_gpp, d_et, d_rec, nullptr, ld, hip_stream);
 }
 
+int sipnet_batch_run_stats(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee, void* d_gpp,
+                           void* d_et, int64_t ld, double* d_stats, void* hip_stream) {
+  if (!d_nee || !d_gpp || !d_et || !d_stats) {
+    setError("sipnet_batch_run_stats: needs the three planes and the statistics block");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  return runImpl(b, step0, n_steps, d_nee, d_gpp, d_et, nullptr, nullptr, ld, hip_stream, d_stats);
+}
+
 int sipnet_batch_run_debug(sipnet_batch* b, int32_t step0, int32_t n_steps, double* d_rec,
                            double* d_dbg, int64_t ld, void* hip_stream) {
   if (!d_rec || !d_dbg) {
@@ -514,7 +525,7 @@ int sipnet_batch_run_debug(sipnet_batch* b, int32_t step0, int32_t n_steps, doub
 }
 
 static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee, void* d_gpp,
-                   void* d_et, double* d_rec, double* d_dbg, int64_t ld, void* hip_stream) {
+                   void* d_et, double* d_rec, double* d_dbg, int64_t ld, void* hip_stream, double* d_stats) {
   if (!b || step0 < 0 || n_steps < 0 || step0 + n_steps > b->n_steps) {
     setError("sipnet_batch_run: step range outside the climate record");
     return SIPNET_ERR_BAD_ARGUMENT;
@@ -596,6 +607,28 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
   }
   rc = kernel != SIPNET_KERNEL_STRICT ? ensureFastRecs(b) : ensureStepRecs(b);
   if (rc) return rc;
+  // ensemble statistics with the launch (sipnet_batch_run_stats): a wavefront of the cooperative
+  // kernel sums the planes' tiles per chunk while they are still in L2; any other kernel is
+  // followed by three streaming reductions over the finished planes
+  // (measured, DESIGN.md section 5: on the one-chunk-per-CU layout, whose fourth wavefront does the
+  // summing, the launch grows by 3-5 % against 10-15 % for the three passes; on the two- / four-chunk
+  // layouts the light wave would do it and its loads cost more than the passes -- SIPNET_KOPT_STATS_IN_KERNEL
+  // forces it there for tests and measurements)
+  const bool coop = kernel == SIPNET_KERNEL_COOP_LDS ||
+                    ((b->kernelOptions & SIPNET_KOPT_STATS_IN_KERNEL) && kernel != SIPNET_KERNEL_STRICT &&
+                     kernel != SIPNET_KERNEL_ONE_WAVE);
+  const int chunksPerSite = (b->n_members + 63) / 64;
+  if (d_stats && coop) {
+    const size_t need = (size_t)3 * b->n_sites * chunksPerSite * n_steps * 2;
+    if (need > b->statsPartCap) {
+      HIP_TRY(hipStreamSynchronize(stream));
+      if (b->d_statsPart) HIP_TRY(hipFree(b->d_statsPart));
+      b->d_statsPart = nullptr;
+      b->statsPartCap = 0;
+      HIP_TRY(hipMalloc(&b->d_statsPart, need * sizeof(double)));
+      b->statsPartCap = need;
+    }
+  }
   a.plan = b->d_plan;
   HIP_TRY(hipEventRecord(b->ev0, stream));
   if (kernel != SIPNET_KERNEL_STRICT) {
@@ -626,6 +659,8 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
     f.scratchRow = b->d_scratchRow;
     memcpy(f.flags, b->flags, sizeof(f.flags));
     f.numCUs = b->numCUs;
+    f.statsPart = (d_stats && coop) ? b->d_statsPart : nullptr;
+    f.statsChunks = b->n_sites * chunksPerSite;
     if (kernel == SIPNET_KERNEL_ONE_WAVE) launchStepFast(f, b->precision, b->kernelOptions, stream, &b->lastLaunch);
     else launchStepCoop(f, b->precision,
                         kernel == SIPNET_KERNEL_COOP_LDS ? COOP_RING_LDS
@@ -637,6 +672,18 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(b->ev1, stream));
+  if (d_stats) {
+    if (coop) {
+      launchFinishStats(b->d_statsPart, n_steps, b->n_sites, chunksPerSite, d_stats, stream);
+    } else {
+      const bool f32 = b->precision == SIPNET_F32_MIXED;
+      const size_t plane = (size_t)n_steps * b->n_sites * 2;
+      launchReducePlane(d_nee, f32, n_steps, ld, b->n_sites, b->n_members, d_stats, stream);
+      launchReducePlane(d_gpp, f32, n_steps, ld, b->n_sites, b->n_members, d_stats + plane, stream);
+      launchReducePlane(d_et, f32, n_steps, ld, b->n_sites, b->n_members, d_stats + 2 * plane, stream);
+    }
+    HIP_TRY(hipGetLastError());
+  }
   b->timed = true;
   b->stepsDone = (b->stepsDone == step0) ? step0 + n_steps : -1;
   return SIPNET_OK;

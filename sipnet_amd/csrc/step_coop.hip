@@ -316,6 +316,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   __shared__ int mailAliveAll[NP][2][64];  // aliveWord(): wave C's confirmation of the leaf area it posted
   __shared__ int seqLaiAll[NP], seqPgpAll[NP], seqPsnAll[NP];
   __shared__ alignas(8) int seqFacMoistAll[NP][2];  // [0] wave F's / L's factor rows, [1] wave W's moisture row
+  __shared__ int seqDoneAll[NP][2];  // statistics: wave C's / wave W's plane stores of the whole launch have completed
 #define seqFac seqFacMoist[0]
 #define seqMoist seqFacMoist[1]
   // The running-mean ring of the 64 members lives in LDS for the whole launch (250 x 64 x 8 B =
@@ -339,6 +340,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   int& seqPgp = seqPgpAll[sub];
   int& seqPsn = seqPsnAll[sub];
   auto& seqFacMoist = seqFacMoistAll[sub];
+  auto& seqDone = seqDoneAll[sub];
   [[maybe_unused]] const bool firstChunk = blockIdx.x == 0 && sub == 0;  // diagnostics builds report this one
 #ifdef SIPNET_HWID
   if (lane == 0 && role >= 0 && (blockIdx.x * NP + sub) < 4096) {
@@ -390,6 +392,8 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
       seqPsn = tBegin - 1;
       seqFac = tBegin - 1;
       seqMoist = tBegin - 1;
+      seqDone[0] = 0;
+      seqDone[1] = 0;
     }
     mailAlive[0][lane] = 0;
     mailAlive[1][lane] = 0;
@@ -400,6 +404,137 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   const unsigned char* __restrict__ planBytes =
       (const unsigned char*)(a.fast + (int64_t)site * a.n_steps_total);
   const Exp2Coef EC = loadExp2Coef();
+
+  // =============================================================================================
+  // ---- ensemble statistics of the output planes (a.statsPart; sipnet_batch_run_stats) ------------
+  // One wavefront of the workgroup -- wave F where there is one (it runs up to two steps ahead of C and
+  // is busy a quarter of the time), else wave L -- sums the plane tiles waves C and W have stored,
+  // three tiles behind them, while the lines are still in L2: lane 4r + q takes 16 of the chunk's 64
+  // columns of step 16k + r, two quad permutations join the four quarters, lane 4r stores the row's
+  // (sum, sum of squares) into the per-chunk block that launchFinishStats adds up.  Why the data is
+  // there: C and W drain their memory queue at every tile start down to the last step's stores (the
+  // s_waitcnt in front of their tile DMA; memory operations complete in issue order), and C takes W's
+  // moisture factor of a step before it posts the next leaf area -- so once C has posted the leaf
+  // area of the SECOND step of tile k + 2, both waves' stores of tile k have reached L2.  Ordinary
+  // loads: every line read here was stored through THIS compute unit's vector L1 (write-through) by
+  // this workgroup and is read once, so a hit there is current and a miss goes to that L2.
+  // Which 16 columns a lane takes is chosen for the vector L1, which serves one 128-byte line per
+  // cycle to the whole compute unit (C's and W's stores and tile DMAs queue behind these loads): the
+  // four lanes of a row read NEIGHBOURING 16-byte pieces (fp64: columns 8k + 2q, 8k + 2q + 1 on load
+  // k; fp32: 16k + 4q .. + 3), 16 lines per load instruction -- with 16 consecutive columns per lane
+  // every lane of every load hit a line of its own (1.3 us of L1 time per tile at c10k, 3 us at c4).
+  // One plane per turn, on steps 4, 9 and 14 of a tile (never right behind this wave's own tile
+  // loads), load + wait + sum + store in one go.  Measured alternatives: loads issued five
+  // steps before their sums, an L1 prefetch two steps before the turn, half planes per turn, the turn
+  // after the factor post -- none cheaper; what costs is the loads themselves (they take C's and W's
+  // place in the memory pipeline), not the wait for them.
+  const bool statsHere = a.statsPart != nullptr && role == (FacWave ? 3 : 2);
+  int statTile = tBegin / kFastTile;                    // tile being summed
+  int statPlane = 0;                                    // its next plane
+  int statNext = (statTile + 3) * kFastTile + 4;        // step of this wave on which that plane is due
+  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+  constexpr int kPer16 = 16 / (int)sizeof(R);          // elements per 16-byte load
+  constexpr int kLoads = 16 / kPer16;                  // 16-byte loads per lane and plane
+  // 16-byte loads need a full chunk and 16-byte aligned row segments; the ragged last chunk of a
+  // site and odd layouts go element by element (column 4e + q) with clamped addresses
+  const bool statFast = uni((int)((chunk << 6) + 64 <= a.n_members && (((a.ld | a.n_members) & (kPer16 - 1)) == 0) &&
+                                  ((((uintptr_t)a.nee | (uintptr_t)a.gpp | (uintptr_t)a.et) & 15) == 0))) != 0;
+  const int statRow = lane >> 2, statQ = lane & 3;
+  // per-lane cursors: this lane's piece of row 16 * statTile + statRow of each plane and of the
+  // partial-sum block, advanced by one tile per round (no multiplications in the loop)
+  const int64_t statRow0 = (int64_t)statTile * kFastTile + statRow - tBegin;   // < 0 for rows before a launch that starts inside a tile
+  const int64_t statOff0 = statRow0 * a.ld + ((int64_t)site * a.n_members + (chunk << 6) + (statFast ? kPer16 * statQ : 0));
+  const R* statPtr0 = (const R*)a.nee + statOff0;
+  const R* statPtr1 = (const R*)a.gpp + statOff0;
+  const R* statPtr2 = (const R*)a.et + statOff0;
+  const int64_t statTileStride = (int64_t)kFastTile * a.ld;
+  const int64_t statPlaneStride = (int64_t)a.statsChunks * a.n_steps * 2;
+  double* statDst = a.statsPart + (((int64_t)site * chunksPerSite + chunk) * a.n_steps + statRow0) * 2;
+  auto quadSum = [](double v) -> double {  // over the four lanes of a row: two quad permutations (DPP)
+    auto perm = [](double x, auto ctrl) -> double {
+      const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), decltype(ctrl)::value, 0xf, 0xf, false);
+      const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), decltype(ctrl)::value, 0xf, 0xf, false);
+      return __hiloint2double(hi, lo);
+    };
+    v += perm(v, std::integral_constant<int, 0xB1>{});   // quad_perm:[1,0,3,2]
+    v += perm(v, std::integral_constant<int, 0x4E>{});   // quad_perm:[2,3,0,1]
+    return v;
+  };
+  auto statPlaneTurn = [&](const R* ptr, double* dst) {
+    const int t = statTile * kFastTile + statRow;
+    bool rowOk = true;
+    // rows outside the launch (a first or last, partial tile) are read from the nearest row inside
+    // and not stored
+    if (__builtin_expect(statTile * kFastTile < tBegin || (statTile + 1) * kFastTile > tEnd, 0)) {
+      const int tc = t < tBegin ? tBegin : t >= tEnd ? tEnd - 1 : t;
+      ptr += (int64_t)(tc - t) * a.ld;
+      rowOk = tc == t;
+    }
+    double s1 = 0.0, s2 = 0.0;
+    if (__builtin_expect(statFast, 1)) {
+      const u64x2* src = (const u64x2*)ptr;
+      u64x2 v[kLoads];
+#pragma unroll
+      for (int k = 0; k < kLoads; k++) v[k] = src[4 * k];
+#pragma unroll
+      for (int k = 0; k < kLoads; k++) {
+        if (sizeof(R) == 8) {
+          const double x0 = __longlong_as_double((long long)v[k].x), x1 = __longlong_as_double((long long)v[k].y);
+          s1 += x0;
+          s2 = __builtin_fma(x0, x0, s2);
+          s1 += x1;
+          s2 = __builtin_fma(x1, x1, s2);
+        } else {
+#pragma unroll
+          for (int h = 0; h < 4; h++) {
+            const unsigned long long w = (h & 2) ? v[k].y : v[k].x;
+            const double x = (double)__uint_as_float((unsigned)(w >> (32 * (h & 1))));
+            s1 += x;
+            s2 = __builtin_fma(x, x, s2);
+          }
+        }
+      }
+    } else {
+      const int nLeft = a.n_members - (chunk << 6);   // >= 1: the chunk exists
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const int c = 4 * e + statQ;
+        const double x = c < nLeft ? (double)ptr[c < nLeft ? c : 0] : 0.0;
+        s1 += x;
+        s2 = __builtin_fma(x, x, s2);
+      }
+    }
+    s1 = quadSum(s1);
+    s2 = quadSum(s2);
+    if (statQ == 0 && rowOk) {
+      typedef double d2s __attribute__((ext_vector_type(2)));
+      *(d2s*)dst = d2s{s1, s2};
+    }
+  };
+  // the plane that is due; `settled`: C and W have finished (nothing of theirs is in flight any more)
+  auto statAct = [&](bool settled) {
+    if (statPlane == 0) {
+      if (!settled) awaitAtLeast(&seqLai, (statTile + 2) * kFastTile + 1);
+      statPlaneTurn(statPtr0, statDst);
+    } else if (statPlane == 1) {
+      statPlaneTurn(statPtr1, statDst + statPlaneStride);
+    } else {
+      statPlaneTurn(statPtr2, statDst + 2 * statPlaneStride);
+      statPtr0 += statTileStride;
+      statPtr1 += statTileStride;
+      statPtr2 += statTileStride;
+      statDst += 2 * kFastTile;
+    }
+    const bool last = statPlane == 2;
+    statPlane = last ? 0 : statPlane + 1;
+    statTile += last ? 1 : 0;
+    statNext += last ? 6 : 5;
+  };
+  auto statFinish = [&]() {  // after the wave's loop: the last tiles, once C and W have drained their stores
+    awaitAtLeast(&seqDone[0], 1);
+    awaitAtLeast(&seqDone[1], 1);
+    while (statTile * kFastTile < tEnd) statAct(true);
+  };
 
   // =============================================================================================
   // ---- F (one workgroup per CU only: the CU's fourth SIMD is free): the climate / parameter part
@@ -453,6 +588,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         // the slot of step t was last used for step t-2, which C is past once it has posted the
         // leaf area of step t-1
         awaitAtLeast(&seqLai, t - 1);
+        if (statsHere && t == statNext) statAct(false);
         const R vegQ = fexp2(q10Arg(tair10, K_lgVeg), EC);
         R g1 = K_fol * vegQ;
         g1 = (tsoil < K_frozThr) ? g1 * K_frozFolEff : g1;
@@ -469,6 +605,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
       }
       cur = nxt;
     }
+    if (statsHere) statFinish();
     return;
   }
   auto tileFirst = [&](int tile) -> int64_t {
@@ -523,6 +660,11 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
     R qSoil = 0, gFine = 0, gCoarse = 0;
     bool haveQ = false;
     WAIT_DECL()
+    // Every parameter load above has landed before the loop starts, and the compiler is told so (a
+    // wait it can see): its wait-count bookkeeping would otherwise put a full `s_waitcnt vmcnt(0)` in
+    // front of the first in-loop use of each of these constants -- in the middle of the day step, where
+    // it would sit out the statistics loads (and the tile DMA) on every iteration
+    __builtin_amdgcn_s_waitcnt(0);
     for (int tileStart = curTile * kFastTile; tileStart < tEnd; tileStart += kFastTile, curTile++) {
       if (tileStart > tBegin) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMA of 16 steps ago
       stageTile(curTile + 1, (curTile + 1) & 1);
@@ -540,6 +682,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
                      : "=&v"(bitsV), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q5), "=&v"(q6x)
                      : "v"(ldsAddr(recB)) : "memory");
         const int bits = uni(bitsV);
+        if (statsHere && t == statNext) statAct(false);
         // ---- for wave C: the climate / parameter part of its respiration terms of THIS step
         // (vegResp sipnet.c:1051-1068, calcRootResp :1073, calcSoilRespiration :1132-1148 with
         // depeffects.c:71-74):  folResp = leafC * g1,  rVeg = folResp + totalWoodC * g2,
@@ -591,6 +734,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
       }
     }
     WAIT_STORE(0)
+    if (statsHere) statFinish();
     return;
   }
 
@@ -770,6 +914,10 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
       }
     }
     WAIT_STORE(4)
+    if (a.statsPart) {  // every ET / GPP store of the launch has reached L2: wave L may sum the last tiles
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("ds_write_b32 %0, %1" :: "v"(ldsAddr(&seqDone[1])), "v"(1) : "memory");
+    }
     if (act) {
       ST(soilWater) = soilWater;
       ST(snow) = snow;
@@ -1456,6 +1604,10 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
     for (int k = 0; k < 8; k++) g_coopStamps[k] = cAcc[k];
 #endif
   WAIT_STORE(8)
+  if (a.statsPart) {  // every NEE store of the launch has reached L2 (see wave L's statistics)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("ds_write_b32 %0, %1" :: "v"(ldsAddr(&seqDone[0])), "v"(1) : "memory");
+  }
   if (act) {
     if (RingLds)
       for (int k = 0; k < SIPNET_RING_SLOTS; k++) ringp[(uint32_t)k * ncu] = ringL[k * 64 + lane];
@@ -1583,7 +1735,7 @@ void launchStepCoop(const FastArgs& a, int precision, int layout, hipStream_t st
     info->block = (int32_t)block.x;
     info->wavesPerSimd = pair ? 2 : quad ? 3 : 1;
     const int elem = precision == SIPNET_F64 ? 8 : 4;
-    info->ldsBytes = (pair ? 2 : quad ? 4 : 1) * (3 * 2 * kTileBytes + (2 * 64 * 3 + 2 * 6 * 64) * elem + 2 * 64 * 4 + 5 * 4) +
+    info->ldsBytes = (pair ? 2 : quad ? 4 : 1) * (3 * 2 * kTileBytes + (2 * 64 * 3 + 2 * 6 * 64) * elem + 2 * 64 * 4 + 7 * 4) +
                      (ringInLds ? SIPNET_RING_SLOTS * 64 : 64) * 8;
   }
 }

@@ -108,6 +108,13 @@ struct FastArgs {
   int32_t numCUs;                // compute units of the device (kernel / occupancy choice)
   int32_t flags[SIPNET_NFLAGS];  // model flags; anything but the default set selects the
                                  // run-time-flag instantiation of the one-wave kernel
+  // cooperative kernels only: per-chunk ensemble statistics of the three planes, written by the
+  // light wave from the planes' freshly stored tiles (still in L2) --
+  // statsPart[((plane * statsChunks + site * chunksPerSite + chunk) * n_steps + (t - step0)) * 2 + {0, 1}]
+  // = sum / sum of squares over the chunk's members of plane[t]; null: not wanted.  All three
+  // planes must be given.  launchFinishStats adds the chunks of a site up.
+  double* statsPart;
+  int32_t statsChunks;           // n_sites * chunksPerSite
 };
 // What a launcher actually put on the stream (sipnet_batch_last_launch): the instantiation's
 // name as rocprofv3 prints its template arguments, and the launch shape.
@@ -131,6 +138,9 @@ void launchConvertParams(const double* rawRows, double* prm, int64_t ncol, int64
                          int32_t count, hipStream_t stream);
 // variant: bit0 = fast math, bit1 = generic flags (runtime), else default flags
 void launchStep(const KernelArgs& a, int precision, bool fastMath, hipStream_t stream, LaunchInfo* info);
+// stats[((plane * n_steps + t) * n_sites + site) * 2 + {0, 1}] = sum over the site's chunks of statsPart
+void launchFinishStats(const double* statsPart, int32_t n_steps, int32_t n_sites, int32_t chunksPerSite,
+                       double* stats, hipStream_t stream);
 void launchReducePlane(const void* plane, bool isF32, int32_t n_steps, int64_t ld,
                        int32_t n_sites, int32_t n_members, double* stats,
                        hipStream_t stream);

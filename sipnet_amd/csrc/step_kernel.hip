@@ -1264,6 +1264,32 @@ __global__ __launch_bounds__(256) void reducePlaneKernel(const T* __restrict__ p
   }
 }
 
+// second stage of the in-kernel ensemble statistics (step_coop.hip, wave L): one thread per
+// (plane, step, site) adds up the site's per-chunk partial sums, chunk by chunk in index order
+// (deterministic); neighbouring threads read neighbouring steps
+__global__ __launch_bounds__(256) void finishStatsKernel(const double* __restrict__ part, int32_t n_steps,
+                                                         int32_t n_sites, int32_t chunksPerSite,
+                                                         double* __restrict__ stats) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t perPlane = (int64_t)n_steps * n_sites;
+  if (i >= 3 * perPlane) return;
+  const int p = (int)(i / perPlane);
+  const int64_t rem = i - (int64_t)p * perPlane;
+  const int site = (int)(rem / n_steps), t = (int)(rem % n_steps);
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  const d2* __restrict__ src =
+      reinterpret_cast<const d2*>(part) + ((int64_t)p * n_sites + site) * chunksPerSite * n_steps + t;
+  double s1 = 0.0, s2 = 0.0;
+  for (int c = 0; c < chunksPerSite; c++) {
+    const d2 v = src[(int64_t)c * n_steps];
+    s1 += v.x;
+    s2 += v.y;
+  }
+  double* dst = stats + (((int64_t)p * n_steps + t) * n_sites + site) * 2;
+  dst[0] = s1;
+  dst[1] = s2;
+}
+
 template <class C>
 void launchOne(const KernelArgs& a, hipStream_t stream) {
   const int chunksPerSite = (a.n_members + 63) / 64;
@@ -1273,6 +1299,12 @@ void launchOne(const KernelArgs& a, hipStream_t stream) {
 
 }  // namespace
 
+void launchFinishStats(const double* statsPart, int32_t n_steps, int32_t n_sites, int32_t chunksPerSite,
+                       double* stats, hipStream_t stream) {
+  const int64_t n = (int64_t)3 * n_steps * n_sites;
+  hipLaunchKernelGGL(finishStatsKernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, statsPart,
+                     n_steps, n_sites, chunksPerSite, stats);
+}
 void launchSetup(const SetupArgs& a, hipStream_t stream) {
   const int grid = (int)((a.ncol + 255) / 256);
   hipLaunchKernelGGL(setupKernel, dim3(grid), dim3(256), 0, stream, a);

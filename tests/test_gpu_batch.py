@@ -364,3 +364,46 @@ def test_two_waves_per_simd_build_of_the_one_wave_kernel(which, oracle, base):
     want, _, st = oracle.run_block(flags, members[pick], clim)
     assert (st == 0).all()
     assert np.abs(outs[0][:, :, pick] - want).max() < tol
+
+
+STAT_KERNELS = [("coop_lds", sa.KERNEL_COOP_LDS), ("coop_hbm", sa.KERNEL_COOP_HBM), ("coop_pair", sa.KERNEL_COOP_PAIR),
+                ("coop_quad", sa.KERNEL_COOP_QUAD), ("one_wave", sa.KERNEL_ONE_WAVE), ("strict", sa.KERNEL_STRICT)]
+
+
+@pytest.mark.parametrize("name,kernel", STAT_KERNELS, ids=[k[0] for k in STAT_KERNELS])
+@pytest.mark.parametrize("prec", [sa.F64, sa.F32_MIXED], ids=["f64", "f32"])
+def test_run_stats_equals_the_sums_over_the_planes(name, kernel, prec, base, short_clim):
+    """sipnet_batch_run_stats: the statistics block of a launch -- summed by the cooperative kernels'
+    light wave from the freshly stored plane tiles, or by three reduction passes behind the other
+    kernels -- equals the sums over the very planes the launch wrote.  Ragged chunks (67 and 200
+    members), three sites (odd number of chunks per workgroup pair / quad), launches cut at steps
+    that are not tile boundaries, a one-step launch."""
+    if prec == sa.F32_MIXED and kernel == sa.KERNEL_STRICT:
+        pytest.skip("fp32-mixed has no strict kernel")
+    T = 48 * 12 + 5
+    clim = short_clim.slice(0, T)
+    for M in (67, 200):
+        members = synth.perturbed_params(base, M)
+        # (KOPT_STATS_IN_KERNEL: the light wave sums on the two- / four-chunk layouts as well, where
+        # the default is the three reduction passes)
+        b = make_batch(sa.flags_from(), [clim, clim.slice(0, T), clim.slice(0, T)], members, prec=prec,
+                       fast=kernel != sa.KERNEL_STRICT, kernel=kernel,
+                       kernel_options=sa.KOPT_STATS_IN_KERNEL if name.startswith("coop") else 0)
+        planes, _ = b.alloc_outputs(T)
+        stats = torch.full((3, T, 3, 2), float("nan"), dtype=torch.float64, device=planes.device)
+        for a0, z in ((0, 1), (1, 23), (23, 400), (400, T)):
+            _, st = b.run_stats(a0, z - a0, planes=planes[:, a0:z])
+            stats[:, a0:z] = st
+        li = b.last_launch()
+        p = planes.double().cpu().numpy().reshape(3, T, 3, M)
+        got = stats.cpu().numpy()
+        # the same planes as a plain run writes
+        b.setup()
+        ref, _ = b.run()
+        same = bool((ref == planes).all())
+        b.close()
+        assert same, li
+        scale = np.abs(p).sum(-1).max()
+        assert np.isfinite(got).all(), li
+        assert np.abs(got[..., 0] - p.sum(-1)).max() < 1e-12 * max(scale, 1.0), li
+        assert np.abs(got[..., 1] - (p * p).sum(-1)).max() < 1e-12 * max((p * p).sum(-1).max(), 1.0), li

@@ -21,12 +21,13 @@ if light == "day":
     raw["par"] = np.maximum(raw["par"], 2.0)
 b.set_climate(0, synth.convert_raw(synth.round_like_file(raw)))
 b.set_params(0, synth.perturbed_params(base, M))
-b.setup(); b.run(want_planes=True); torch.cuda.synchronize()
-b.setup(); b.run(want_planes=True); torch.cuda.synchronize()
+runner = b.run_stats if os.environ.get("STATS") else (lambda: b.run(want_planes=True))   # STATS=1: with the light wave's statistics
+b.setup(); runner(); torch.cuda.synchronize()
+b.setup(); runner(); torch.cuda.synchronize()
 out = (C.c_ulonglong * 16)()
 _lib.lib().sipnet_debug_read_coop_waits(out)
 tick = 1.0    # s_memtime ticks are core-clock cycles on this part (total = kernel time x 2.4 GHz)
-names = {0: "L: wait for lai", 1: "L: wait for C before posting factors", 3: "L: total", 4: "W: take pgp+alive", 5: "W: wait for C's progress", 7: "W: total",
+names = {0: "L: wait for lai", 2: "L: statistics loads (vmcnt)", 1: "L: wait for C before posting factors", 3: "L: total", 4: "W: take pgp+alive", 5: "W: wait for C's progress", 7: "W: total",
          8: "C: take factors + moisture (+record)", 9: "C: take psn", 11: "C: total"}
 print("light:", light, "kernel", b.last_launch()["kernel"], "%.2f ms" % b.last_kernel_ms())
 for k in sorted(names):
