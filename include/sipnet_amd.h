@@ -411,6 +411,56 @@ int sipnet_batch_resample(sipnet_batch *b, const int32_t *d_src, const double *d
                           int32_t n_blocks, const int64_t *block_cols, int32_t with_params,
                           void *hip_stream);
 
+/* ---- one node, several GPUs (north star: "the ensemble axis shards across the 8 GPUs of one node
+ * with a single RCCL all-gather over xGMI of the NEE/GPP/ET output block", from the C host) --------
+ * A sipnet_node is the multi-GPU host object of ONE process: one sipnet_batch, one HIP stream and
+ * one RCCL rank (ncclCommInitAll) per listed device; the n_members members of every site are
+ * sharded contiguously (device k holds members [first_k, first_k + count_k), sizes differ by at
+ * most one).  It replaces, for an ensemble, the reference's one-process-per-member host
+ * (frontend.c:212-250): set_* = initModel / initEvents, setup = setupModel, run = runModelOutput's
+ * loop on every device at once (statistics included: sipnet_batch_run_stats), gather_* = the
+ * collective.  RCCL (librccl.so.1) is loaded on first use; without it create fails with
+ * SIPNET_ERR_NO_DEVICE -- there is no fallback.  A node with ONE device is valid (and still goes
+ * through RCCL).  Calls on one node must come from one thread at a time. */
+typedef struct sipnet_node sipnet_node;
+int sipnet_node_create(const int32_t flags[SIPNET_NFLAGS], int32_t n_sites, int32_t n_members,
+                       int32_t precision, const int32_t *devices, int32_t n_devices,
+                       sipnet_node **out);
+void sipnet_node_destroy(sipnet_node *nd);
+int32_t sipnet_node_n_devices(const sipnet_node *nd);
+sipnet_batch *sipnet_node_batch(sipnet_node *nd, int32_t k);   /* device k's batch (its own members only) */
+int sipnet_node_member_range(const sipnet_node *nd, int32_t k, int32_t *first, int32_t *count);
+const char *sipnet_node_collective_library(const sipnet_node *nd); /* "librccl.so.1 (RCCL 22204)" */
+/* inputs, as for a batch; parameters are dealt to the devices that own the members */
+int sipnet_node_set_climate(sipnet_node *nd, int32_t site, int32_t n_steps, const double *clim,
+                            const int32_t *year, const int32_t *day);
+int sipnet_node_set_events(sipnet_node *nd, int32_t site, int32_t n_events, const sipnet_event *events);
+int sipnet_node_set_params(sipnet_node *nd, int32_t site, int32_t first_member, int32_t count,
+                           const double *raw);
+int sipnet_node_set_math(sipnet_node *nd, int32_t policy);
+int sipnet_node_set_kernel(sipnet_node *nd, int32_t kernel, int32_t options);
+int sipnet_node_setup(sipnet_node *nd);
+/* Every device advances its members n_steps steps from record step0 on its own stream (one host
+ * thread per device enqueues) into node-owned planes [3][n_steps][ld] and a statistics block
+ * [3][n_steps][n_sites][2]; ld = sipnet_node_ld = n_sites * (largest shard, rounded up to even);
+ * columns past a device's own members are zero.  Returns once everything is enqueued. */
+int sipnet_node_run(sipnet_node *nd, int32_t step0, int32_t n_steps);
+int sipnet_node_sync(sipnet_node *nd);
+int64_t sipnet_node_ld(const sipnet_node *nd);
+void *sipnet_node_planes(sipnet_node *nd, int32_t k);     /* DEVICE k: [3][n_steps][ld], double / float */
+double *sipnet_node_stats(sipnet_node *nd, int32_t k);    /* DEVICE k: its members' sums */
+/* ONE ncclAllGather (grouped over the devices): afterwards every device holds every device's
+ * statistics block, sipnet_node_gathered_stats(nd, k)[n_devices][3][n_steps][n_sites][2]; host_total
+ * (HOST, may be NULL) receives their sum over the devices = the whole ensemble's sum / sum of squares
+ * per (variable, step, site).  0.84 MB per device and half-hourly year. */
+int sipnet_node_gather_stats(sipnet_node *nd, double *host_total);
+double *sipnet_node_gathered_stats(sipnet_node *nd, int32_t k);
+/* The north star's exchange as written -- ONE ncclAllGather of the member-resolved output block:
+ * afterwards sipnet_node_gathered_planes(nd, k) on every device is [n_devices][3][n_steps][ld].
+ * (4.3 GB per device at 10 240 members x 17 520 steps: see DESIGN.md section 5 for what it costs.) */
+int sipnet_node_gather_planes(sipnet_node *nd);
+void *sipnet_node_gathered_planes(sipnet_node *nd, int32_t k);
+
 int64_t sipnet_batch_ncol(const sipnet_batch *b);
 int32_t sipnet_batch_nsteps(const sipnet_batch *b);
 /* Site-uniform trajectory computed by the plan: gdd[t] (trackers.gdd after

@@ -126,6 +126,27 @@ SIGNATURES = {
     "sipnet_pf_member_words": (C.c_int32, [C.c_int32]),
     "sipnet_batch_pack_members": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P]),
     "sipnet_batch_resample": (C.c_int, [_P, _P, _P, C.c_int32, _P, C.c_int32, _P]),
+    "sipnet_node_create": (C.c_int, [_I32P, C.c_int32, C.c_int32, C.c_int32, _I32P, C.c_int32, C.POINTER(_P)]),
+    "sipnet_node_destroy": (None, [_P]),
+    "sipnet_node_n_devices": (C.c_int32, [_P]),
+    "sipnet_node_batch": (_P, [_P, C.c_int32]),
+    "sipnet_node_member_range": (C.c_int, [_P, C.c_int32, _I32P, _I32P]),
+    "sipnet_node_collective_library": (C.c_char_p, [_P]),
+    "sipnet_node_set_climate": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P]),
+    "sipnet_node_set_events": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
+    "sipnet_node_set_params": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "sipnet_node_set_math": (C.c_int, [_P, C.c_int32]),
+    "sipnet_node_set_kernel": (C.c_int, [_P, C.c_int32, C.c_int32]),
+    "sipnet_node_setup": (C.c_int, [_P]),
+    "sipnet_node_run": (C.c_int, [_P, C.c_int32, C.c_int32]),
+    "sipnet_node_sync": (C.c_int, [_P]),
+    "sipnet_node_ld": (C.c_int64, [_P]),
+    "sipnet_node_planes": (_P, [_P, C.c_int32]),
+    "sipnet_node_stats": (_P, [_P, C.c_int32]),
+    "sipnet_node_gather_stats": (C.c_int, [_P, _P]),
+    "sipnet_node_gathered_stats": (_P, [_P, C.c_int32]),
+    "sipnet_node_gather_planes": (C.c_int, [_P]),
+    "sipnet_node_gathered_planes": (_P, [_P, C.c_int32]),
     "sipnet_batch_ncol": (C.c_int64, [_P]),
     "sipnet_batch_nsteps": (C.c_int32, [_P]),
     "sipnet_batch_get_site_series": (C.c_int, [_P, C.c_int32, _P, _P]),

@@ -24,7 +24,13 @@
 //                            batch and writes <prefix>.<m>.out (m = 0..M-1); restart paths
 //                            get the same .<m> suffix; the members' text files are written
 //                            by a pool of host threads
+//   --ensemble-stats FILE    (with --ensemble-params) the ensemble's per-step statistics instead of
+//                            the members' files: the members shard over --devices as ONE sipnet_node
+//                            (one RCCL rank per device), every device runs its members on the
+//                            throughput kernels, ONE all-gather of the statistics block joins them,
+//                            and FILE gets `year day time n mean/sd of NEE, GPP, ET` per step
 #include <getopt.h>
+#include <cmath>
 #include <sched.h>
 #include <strings.h>
 
@@ -151,6 +157,7 @@ void usage(const char* prog) {
   printf("  --ensemble-params <file>    run one member per row of a parameter table in one batch\n");
   printf("  --math strict|fast|auto     arithmetic of the step kernel (auto: strict for one run, fast for an ensemble)\n");
   printf("  --devices <list>            HIP devices the ensemble shards across, e.g. 0-7 or 0,2,3 ('0')\n");
+  printf("  --ensemble-stats <file>     per-step ensemble mean / sd of NEE, GPP, ET instead of the members' files\n");
   printf("  -h, --help   -v, --version\n");
 }
 
@@ -266,7 +273,7 @@ int main(int argc, char** argv) {
     opts.push_back({kFlagOpts[k][0], no_argument, &tmpFlag, 1});
     opts.push_back({strdup((std::string("no-") + kFlagOpts[k][0]).c_str()), no_argument, &tmpFlag, 0});
   }
-  enum { OPT_RIN = 1001, OPT_ROUT, OPT_DBG, OPT_ENS, OPT_DEV, OPT_MATH };
+  enum { OPT_RIN = 1001, OPT_ROUT, OPT_DBG, OPT_ENS, OPT_DEV, OPT_MATH, OPT_ESTATS };
   opts.push_back({"input-file", required_argument, nullptr, 'i'});
   opts.push_back({"file-prefix", required_argument, nullptr, 'f'});
   opts.push_back({"file-name", required_argument, nullptr, 'f'});
@@ -277,10 +284,11 @@ int main(int argc, char** argv) {
   opts.push_back({"ensemble-params", required_argument, nullptr, OPT_ENS});
   opts.push_back({"devices", required_argument, nullptr, OPT_DEV});
   opts.push_back({"math", required_argument, nullptr, OPT_MATH});
+  opts.push_back({"ensemble-stats", required_argument, nullptr, OPT_ESTATS});
   opts.push_back({"help", no_argument, nullptr, 'h'});
   opts.push_back({"version", no_argument, nullptr, 'v'});
   opts.push_back({nullptr, 0, nullptr, 0});
-  std::string ensembleFile, devicesArg = "0", mathArg = "auto";
+  std::string ensembleFile, devicesArg = "0", mathArg = "auto", ensembleStats;
   int longIndex = 0, ch;
   while ((ch = getopt_long(argc, argv, "he:f:i:v", opts.data(), &longIndex)) != -1) {
     switch (ch) {
@@ -294,6 +302,7 @@ int main(int argc, char** argv) {
       case OPT_ENS: ensembleFile = optarg; break;
       case OPT_DEV: devicesArg = optarg; break;
       case OPT_MATH: mathArg = optarg; break;
+      case OPT_ESTATS: ensembleStats = optarg; break;
       case 'h': usage(argv[0]); return 0;
       case 'v': printf("SIPNET version 2.1.0 (%s)\n", sipnet_version()); return 0;
       default: usage(argv[0]); return 8;  // EXIT_CODE_BAD_CLI_ARGUMENT
@@ -302,6 +311,10 @@ int main(int argc, char** argv) {
   std::vector<int> devices = parseDevices(devicesArg);  // syntax errors are CLI errors (exit 8)
   if (mathArg != "auto" && mathArg != "strict" && mathArg != "fast") {
     logError("--math takes strict, fast or auto\n");
+    return 8;
+  }
+  if (!ensembleStats.empty() && ensembleFile.empty()) {
+    logError("--ensemble-stats needs --ensemble-params\n");
     return 8;
   }
   g_quiet = ctx.i("quiet") != 0;
@@ -420,6 +433,58 @@ int main(int argc, char** argv) {
                    " HIP device(s) are visible (this engine has no CPU path)\n");
   }
   if ((int)devices.size() > M) devices.resize(M);
+  if (!ensembleStats.empty()) {
+    // ---- the ensemble as ONE node object: shards, RCCL ranks and the all-gather behind the C-ABI ----
+    if (!restartIn.empty() || !restartOut.empty() || !debugLog.empty())
+      die(8, "--ensemble-stats does not combine with restart checkpoints or --debug-log\n");
+    std::vector<int32_t> devs(devices.begin(), devices.end());
+    sipnet_node* nd = nullptr;
+    check(sipnet_node_create(flags, 1, M, SIPNET_F64, devs.data(), (int32_t)devs.size(), &nd), "creating the node");
+    logInfo("ensemble of " + std::to_string(M) + " members on " + std::to_string(devs.size()) +
+            " device(s), collectives: " + sipnet_node_collective_library(nd) + "\n");
+    check(sipnet_node_set_math(nd, mathArg == "strict" ? SIPNET_MATH_STRICT : SIPNET_MATH_FAST), "math policy");
+    check(sipnet_node_set_events(nd, 0, nEvents, events), "events");
+    check(sipnet_node_set_climate(nd, 0, T, sipnet_clim_data(clim), sipnet_clim_year(clim), sipnet_clim_day(clim)),
+          "climate");
+    check(sipnet_node_set_params(nd, 0, 0, M, members.data()), "parameters");
+    check(sipnet_node_setup(nd), "setupModel");
+    check(sipnet_node_run(nd, 0, T), "run");
+    std::vector<double> total((size_t)3 * T * 2);
+    check(sipnet_node_gather_stats(nd, total.data()), "all-gather of the statistics");
+    int worstStatus = 0, skipped = 0;
+    for (int k = 0; k < sipnet_node_n_devices(nd); k++) {
+      int32_t first = 0, count = 0;
+      sipnet_node_member_range(nd, k, &first, &count);
+      std::vector<int32_t> status(count);
+      check(sipnet_batch_get_status(sipnet_node_batch(nd, k), status.data(), nullptr), "status");
+      for (int m = 0; m < count; m++)
+        if (status[m] != 0) {
+          logError("member " + std::to_string(first + m) + ": status " + std::to_string(status[m]) +
+                   " (NPP allocation params must be less than one individually and add to less than one)\n");
+          worstStatus = std::max(worstStatus, (int)status[m]);
+          skipped++;
+        }
+    }
+    if (skipped) die(worstStatus, "the statistics would include members that did not run\n");
+    FILE* f = fopen(ensembleStats.c_str(), "w");
+    if (!f) die(6, "Error opening " + ensembleStats + " for writing\n");
+    if (ctx.i("printHeader")) fprintf(f, "year day time n meanNEE sdNEE meanGPP sdGPP meanET sdET\n");
+    const double* cd = sipnet_clim_data(clim);
+    for (int t = 0; t < T; t++) {
+      fprintf(f, "%4d %3d %5.2f %d", sipnet_clim_year(clim)[t], sipnet_clim_day(clim)[t], cd[(size_t)t * SIPNET_NCLIM + 10], M);
+      for (int v = 0; v < 3; v++) {
+        const double s1 = total[((size_t)v * T + t) * 2], s2 = total[((size_t)v * T + t) * 2 + 1];
+        const double mean = s1 / M, var = s2 / M - mean * mean;
+        fprintf(f, " %.10g %.10g", mean, var > 0 ? sqrt(var) : 0.0);
+      }
+      fprintf(f, "\n");
+    }
+    fclose(f);
+    sipnet_node_destroy(nd);
+    sipnet_clim_free(clim);
+    sipnet_io_free(events);
+    return 0;
+  }
   const int nShards = (int)devices.size();
   if (nShards > 1)
     logInfo("ensemble sharded over " + std::to_string(nShards) + " device(s)\n");

@@ -12,12 +12,13 @@ import sipnet_amd as sa
 from tests import helpers
 
 SRC = os.path.join(helpers.REPO, "tests", "c", "capi_consumer.c")
+NODE_SRC = os.path.join(helpers.REPO, "tests", "c", "node_consumer.c")
 
 
-def build(tmp_path):
-    exe = str(tmp_path / "capi_consumer")
+def build(tmp_path, src=SRC):
+    exe = str(tmp_path / os.path.basename(src)[:-2])
     r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror",
-                        "-I" + os.path.join(helpers.REPO, "include"), SRC, "-o", exe,
+                        "-I" + os.path.join(helpers.REPO, "include"), src, "-o", exe,
                         "-L" + os.path.join(helpers.REPO, "sipnet_amd"), "-lsipnet_amd",
                         "-Wl,-rpath," + os.path.join(helpers.REPO, "sipnet_amd")],
                        capture_output=True, text=True)
@@ -55,3 +56,41 @@ def test_two_member_batch_through_the_c_abi_alone(oracle, tmp_path):
     assert float(kv["sum_nee_0"]) == pytest.approx(want[0][:, 0].sum(), abs=1e-8)
     assert float(kv["sum_nee_1"]) == pytest.approx(want[0][:, 1].sum(), abs=1e-8)
     assert abs(float(kv["sum_nee_0"]) - float(kv["sum_nee_1"])) > 1e-3
+
+
+def run_node(exe, tmp_path, members, devices="0"):
+    clim = str(tmp_path / "niwot.clim")
+    helpers.gunzip_to(os.path.join(helpers.smoke_dir("niwot"), "sipnet.clim.gz"), clim)
+    r = subprocess.run([exe, os.path.join(helpers.smoke_dir("niwot"), "sipnet.param"), clim, str(members), devices],
+                       capture_output=True, text=True, timeout=600)
+    kv = dict(l.split("=", 1) for l in r.stdout.strip().split("\n") if "=" in l)
+    return r.returncode, kv, r.stdout + r.stderr
+
+
+@pytest.mark.skipif(sa.lib().sipnet_device_count() > 0, reason="a GPU is present")
+def test_node_object_links_from_c_and_needs_a_device(tmp_path):
+    """the multi-GPU host object (sipnet_node_*, RCCL behind it) compiles and links from plain C;
+    without a device it answers SIPNET_ERR_NO_DEVICE before it touches RCCL"""
+    rc, kv, out = run_node(build(tmp_path, NODE_SRC), tmp_path, 130)
+    assert rc == 0, out
+    assert kv["create"] == "100" and "no usable HIP device" in kv["no_device_message"]
+
+
+@pytest.mark.gpu
+def test_node_of_one_device_all_gathers_through_rccl_from_c(oracle, tmp_path):
+    """sipnet_node with devices = {0}: 130 members (a ragged third chunk) on the throughput kernel,
+    sipnet_node_gather_stats and sipnet_node_gather_planes through a one-rank RCCL communicator, from
+    a C99 program; the statistics equal the sums over the gathered planes and the members the oracle"""
+    rc, kv, out = run_node(build(tmp_path, NODE_SRC), tmp_path, 130)
+    assert rc == 0 and kv["create"] == "0", out
+    assert "RCCL" in kv["collective_library"] and kv["n_devices"] == "1"
+    assert kv["gathered_stats_identical"] == "1"
+    assert float(kv["stats_vs_planes_max_abs"]) < 1e-9
+    assert kv["kernel"].startswith("stepCoopKernel<double")
+    case = helpers.load_smoke_case("niwot", str(tmp_path))
+    members = np.stack([case["params"], case["params"]])
+    members[1, sa.config.param_index("aMax")] *= 1.0 + 0.001 * 129
+    want, _, st = oracle.run_block(case["flags"], members, case["clim"], None)
+    assert (st == 0).all()
+    assert float(kv["sum_nee_member_0"]) == pytest.approx(want[0][:, 0].sum(), abs=1e-8)
+    assert float(kv["sum_nee_member_last"]) == pytest.approx(want[0][:, 1].sum(), abs=1e-8)

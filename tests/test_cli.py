@@ -5,6 +5,7 @@ import os
 import shutil
 import subprocess
 
+import numpy as np
 import pytest
 
 from tests import helpers
@@ -162,3 +163,39 @@ def test_cli_ensemble_sharded_over_devices_equals_one_batch(tmp_path):
     # a device that does not exist is refused up front
     r = run_cli(outs["one"], "-i", "sipnet.in", "--devices", "0,99")
     assert r.returncode == 1 and "only" in r.stdout
+
+
+def test_cli_ensemble_stats_needs_an_ensemble(tmp_path):
+    stage("niwot", tmp_path)
+    r = run_cli(tmp_path, "-i", "sipnet.in", "--ensemble-stats", "stats.txt")
+    assert r.returncode == 8 and "--ensemble-params" in r.stdout
+
+
+@pytest.mark.gpu
+def test_cli_ensemble_stats_through_the_node_object(tmp_path):
+    """--ensemble-stats: the ensemble runs as ONE sipnet_node (the C host object: member shards, one
+    RCCL rank per device, one all-gather of the statistics block) and the CLI prints per-step mean and
+    sd of NEE / GPP / ET -- equal to what the members' own .out files give (russell_1: events)."""
+    M = 9
+    rows = ["aMax psnTOpt soilWHC"] + ["%.3f %.2f %.2f" % (7.5 + 0.3 * i, 22.0 + 0.5 * i, 10.0 + i) for i in range(M)]
+    stage("russell_1", tmp_path)
+    open(tmp_path / "members.txt", "w").write("\n".join(rows) + "\n")
+    r = run_cli(tmp_path, "-i", "sipnet.in", "--ensemble-params", "members.txt", "--ensemble-stats", "stats.txt",
+                "--print-header")
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "RCCL" in r.stdout
+    lines = open(tmp_path / "stats.txt").read().splitlines()
+    assert lines[0].split() == "year day time n meanNEE sdNEE meanGPP sdGPP meanET sdET".split()
+    st = np.array([[float(x) for x in l.split()] for l in lines[1:]])
+    r = run_cli(tmp_path, "-i", "sipnet.in", "--ensemble-params", "members.txt", "--print-header")
+    assert r.returncode == 0, r.stdout + r.stderr
+    header = open(tmp_path / "sipnet.0.out").readline().split()
+    assert header[0] == "year"
+    outs = np.stack([np.loadtxt(tmp_path / f"sipnet.{m}.out", skiprows=1) for m in range(M)])     # [M][T][cols]
+    assert st.shape[0] == outs.shape[1] and (st[:, 3] == M).all()
+    for name, col, digits in (("nee", 4, 3), ("gpp", 6, 3), ("evapotranspiration", 8, 5)):
+        x = outs[:, :, header.index(name)]
+        # the members' files print `digits` decimals (sipnet.c:453-473): their mean is within half a unit
+        np.testing.assert_allclose(st[:, col], x.mean(0), atol=0.51 * 10 ** -digits)
+        np.testing.assert_allclose(st[:, col + 1], x.std(0), atol=1.1 * 10 ** -digits)
+    assert st[:, 6].max() > 0.05 and st[:, 5].max() > 1e-3      # there is a signal and a spread

@@ -17,7 +17,7 @@ HIPCC = "/opt/rocm/bin/hipcc"
 BASE = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall",
         "-Wno-unused-function"]
 FAST_SRCS = ["step_fast.hip", "step_coop.hip"]                      # -ffp-contract=fast
-OTHER_OBJS = ["engine.o", "step_kernel.o", "pf.o", "plan.o", "host_io.o", "restart_io.o"]
+OTHER_OBJS = ["engine.o", "step_kernel.o", "pf.o", "plan.o", "host_io.o", "restart_io.o", "node.o"]
 
 
 def build(name, flags):
@@ -32,7 +32,7 @@ def build(name, flags):
         objs.append(o)
     objs += [os.path.join(CSRC, o) for o in OTHER_OBJS]
     so = os.path.join(out, "libsipnet_amd.so")
-    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + objs)
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + objs + ["-ldl"])
     open(os.path.join(out, "FLAGS"), "w").write(flags + "\n")
     return name, so
 
