@@ -230,7 +230,10 @@ enum sipnet_kernel {
   SIPNET_KERNEL_COOP_HBM = 3, /* stepCoopKernel, ring in HBM */
   SIPNET_KERNEL_STRICT = 4,   /* stepKernel (with SIPNET_MATH_FAST: its fast-math variant) */
   SIPNET_KERNEL_COOP_PAIR = 5, /* stepCoopPairKernel: two chunks per workgroup, ring in HBM */
-  SIPNET_KERNEL_COOP_QUAD = 6  /* stepCoopQuadKernel: four chunks per twelve-wave workgroup */
+  SIPNET_KERNEL_COOP_QUAD = 6, /* stepCoopQuadKernel: four chunks per twelve-wave workgroup */
+  SIPNET_KERNEL_COOP_NCYCLE = 7 /* stepCoopNKernel: the nitrogen-cycle flag set (litter pool + anaerobic +
+                                   nitrogen cycle), four wavefronts per chunk, soil and nitrogen on the
+                                   water wave */
 };
 enum sipnet_kernel_option {
   SIPNET_KOPT_ONE_WAVE_PER_SIMD = 1, /* one-wave kernel: never the 256-VGPR (two waves/SIMD) build */

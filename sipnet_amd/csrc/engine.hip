@@ -454,7 +454,7 @@ int sipnet_batch_set_math(sipnet_batch* b, int32_t policy) {
 }
 
 int sipnet_batch_set_kernel(sipnet_batch* b, int32_t kernel, int32_t options) {
-  if (!b || kernel < SIPNET_KERNEL_AUTO || kernel > SIPNET_KERNEL_COOP_QUAD ||
+  if (!b || kernel < SIPNET_KERNEL_AUTO || kernel > SIPNET_KERNEL_COOP_NCYCLE ||
       (options & ~(SIPNET_KOPT_ONE_WAVE_PER_SIMD | SIPNET_KOPT_RUNTIME_FLAGS | SIPNET_KOPT_FULL_STATE |
                    SIPNET_KOPT_NO_REGULAR_TILES | SIPNET_KOPT_STATS_IN_KERNEL))) {
     setError("sipnet_batch_set_kernel: bad argument");
@@ -585,6 +585,9 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
     else if (defaultFlags && blocks <= (int64_t)b->numCUs) kernel = SIPNET_KERNEL_COOP_LDS;
     else if (defaultFlags && blocks <= 2 * (int64_t)b->numCUs) kernel = SIPNET_KERNEL_COOP_PAIR;
     else if (defaultFlags && blocks <= 4 * (int64_t)b->numCUs && !wantFull) kernel = SIPNET_KERNEL_COOP_QUAD;
+    // the nitrogen-cycle flag set has a cooperative kernel of its own (lean state, one chunk per CU:
+    // its fp64 build takes 272 registers, one wavefront per SIMD)
+    else if (isNCycleFlagSet(b->flags) && blocks <= (int64_t)b->numCUs && !wantFull) kernel = SIPNET_KERNEL_COOP_NCYCLE;
     else kernel = SIPNET_KERNEL_ONE_WAVE;
   } else if (kernel != SIPNET_KERNEL_STRICT) {
     if (!b->fastMath) {
@@ -595,7 +598,13 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
       setError("sipnet_batch_run_debug: the debug plane is written by the strict-order kernel only");
       return SIPNET_ERR_BAD_ARGUMENT;
     }
-    if (kernel != SIPNET_KERNEL_ONE_WAVE && !defaultFlags) {
+    if (kernel == SIPNET_KERNEL_COOP_NCYCLE) {
+      if (!isNCycleFlagSet(b->flags) || wantFull) {
+        setError("sipnet_batch_run: the nitrogen-cycle cooperative kernel has its flag set (litter pool + anaerobic + "
+                 "nitrogen cycle) compiled in and no full-state instantiation");
+        return SIPNET_ERR_BAD_ARGUMENT;
+      }
+    } else if (kernel != SIPNET_KERNEL_ONE_WAVE && !defaultFlags) {
       setError("sipnet_batch_run: the cooperative kernel has the default model flags compiled in");
       return SIPNET_ERR_BAD_ARGUMENT;
     }
@@ -665,7 +674,8 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
     else launchStepCoop(f, b->precision,
                         kernel == SIPNET_KERNEL_COOP_LDS ? COOP_RING_LDS
                         : kernel == SIPNET_KERNEL_COOP_PAIR ? COOP_PAIR
-                        : kernel == SIPNET_KERNEL_COOP_QUAD ? COOP_QUAD : COOP_RING_HBM,
+                        : kernel == SIPNET_KERNEL_COOP_QUAD ? COOP_QUAD
+                        : kernel == SIPNET_KERNEL_COOP_NCYCLE ? COOP_NCYCLE : COOP_RING_HBM,
                         stream, &b->lastLaunch);
   } else {
     launchStep(a, b->precision, b->fastMath, stream, &b->lastLaunch);

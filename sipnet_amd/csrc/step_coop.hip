@@ -218,6 +218,102 @@ __device__ __forceinline__ void post5(float* base, int* flag, float v0, float v1
                :: "v"(ldsAddr(base)), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(ldsAddr(flag)), "v"(step)
                : "memory");
 }
+// Blocks of doubles (rows 64 apart) + a sequence flag, for the hand-overs of the nitrogen-cycle layout:
+// values first, flag last (DS writes of a wave execute in order); a reader takes the flag first and
+// everything in one round trip.  One asm statement per take: every value is defined by it.
+__device__ __forceinline__ void postRaw(double* p, double v) {
+  asm volatile("ds_write_b64 %0, %1" :: "v"((unsigned)(size_t)p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void postRaw(float* p, float v) {
+  asm volatile("ds_write_b32 %0, %1" :: "v"((unsigned)(size_t)p), "v"(v) : "memory");
+}
+// two rows of an R-typed block behind one flag (wave W: the tillage-scaled and the plain soil Q10 factor)
+__device__ __forceinline__ void takeR2(const double* a, const double* b, const int* flag, int step, double& va, double& vb) {
+  int f;
+  do {
+    asm volatile("ds_read_b32 %0, %3\n\tds_read_b64 %1, %4\n\tds_read_b64 %2, %5\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(f), "=&v"(va), "=&v"(vb)
+                 : "v"((unsigned)(size_t)flag), "v"((unsigned)(size_t)a), "v"((unsigned)(size_t)b) : "memory");
+  } while (uni(f) < step);
+}
+__device__ __forceinline__ void takeR2(const float* a, const float* b, const int* flag, int step, float& va, float& vb) {
+  int f;
+  do {
+    asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %4\n\tds_read_b32 %2, %5\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(f), "=&v"(va), "=&v"(vb)
+                 : "v"((unsigned)(size_t)flag), "v"((unsigned)(size_t)a), "v"((unsigned)(size_t)b) : "memory");
+  } while (uni(f) < step);
+}
+__device__ __forceinline__ void postD(double* row0, int k, double v) {
+  asm volatile("ds_write_b64 %0, %1" :: "v"((unsigned)(size_t)(row0 + 64 * k)), "v"(v) : "memory");
+}
+__device__ __forceinline__ void postFlag(int* flag, int step) {
+  asm volatile("ds_write_b32 %0, %1" :: "v"((unsigned)(size_t)flag), "v"(step) : "memory");
+}
+__device__ __forceinline__ void takeD1(const double* b, const int* flag, int step, double& v0) {
+  int f;
+  do {
+    asm volatile("ds_read_b32 %0, %2\n\tds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(f), "=&v"(v0) : "v"((unsigned)(size_t)flag), "v"((unsigned)(size_t)b) : "memory");
+  } while (uni(f) < step);
+}
+__device__ __forceinline__ void takeD3(const double* b, const int* flag, int step, double& v0, double& v1, double& v2) {
+  int f;
+  do {
+    asm volatile("ds_read_b32 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %5 offset:512\n\t"
+                 "ds_read_b64 %3, %5 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(f), "=&v"(v0), "=&v"(v1), "=&v"(v2)
+                 : "v"((unsigned)(size_t)flag), "v"((unsigned)(size_t)b) : "memory");
+  } while (uni(f) < step);
+}
+__device__ __forceinline__ void takeD4(const double* b, const int* flag, int step, double& v0, double& v1, double& v2,
+                                       double& v3) {
+  int f;
+  do {
+    asm volatile("ds_read_b32 %0, %5\n\tds_read_b64 %1, %6\n\tds_read_b64 %2, %6 offset:512\n\t"
+                 "ds_read_b64 %3, %6 offset:1024\n\tds_read_b64 %4, %6 offset:1536\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(f), "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
+                 : "v"((unsigned)(size_t)flag), "v"((unsigned)(size_t)b) : "memory");
+  } while (uni(f) < step);
+}
+__device__ __forceinline__ void takeD6(const double* b, const int* flag, int step, double& v0, double& v1, double& v2,
+                                       double& v3, double& v4, double& v5) {
+  int f;
+  do {
+    asm volatile("ds_read_b32 %0, %7\n\tds_read_b64 %1, %8\n\tds_read_b64 %2, %8 offset:512\n\t"
+                 "ds_read_b64 %3, %8 offset:1024\n\tds_read_b64 %4, %8 offset:1536\n\t"
+                 "ds_read_b64 %5, %8 offset:2048\n\tds_read_b64 %6, %8 offset:2560\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(f), "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(v4), "=&v"(v5)
+                 : "v"((unsigned)(size_t)flag), "v"((unsigned)(size_t)b) : "memory");
+  } while (uni(f) < step);
+}
+__device__ __forceinline__ void takeD8(const double* b, const int* flag, int step, double& v0, double& v1, double& v2,
+                                       double& v3, double& v4, double& v5, double& v6, double& v7) {
+  int f;
+  do {
+    asm volatile("ds_read_b32 %0, %9\n\tds_read_b64 %1, %10\n\tds_read_b64 %2, %10 offset:512\n\t"
+                 "ds_read_b64 %3, %10 offset:1024\n\tds_read_b64 %4, %10 offset:1536\n\t"
+                 "ds_read_b64 %5, %10 offset:2048\n\tds_read_b64 %6, %10 offset:2560\n\t"
+                 "ds_read_b64 %7, %10 offset:3072\n\tds_read_b64 %8, %10 offset:3584\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(f), "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(v4), "=&v"(v5), "=&v"(v6), "=&v"(v7)
+                 : "v"((unsigned)(size_t)flag), "v"((unsigned)(size_t)b) : "memory");
+  } while (uni(f) < step);
+}
+// The "mineral nitrogen is plentiful" test both wave C and wave W evaluate for a step (they must
+// come to the SAME wave-uniform answer, so it is one function, compiled without contraction): a lower
+// bound of what checkNitrogenLimitation() (limitations.c:69-114) calls availableMinN --
+// minN + (nMin - nVolatilization - nLeaching) * len >= minN * (1 - (nVolFrac * qSoil + nLeachFrac) * len),
+// since nMin >= 0, the volatilisation moisture term is at most 0.05 + 3.8 / 4 = 1 (nitrogen.c:15-26) and
+// the leached share at most 1 (nitrogen.c:31-41) -- against the plants' whole demand, of which the
+// uptake is a part.  Where it holds for all 64 members nobody is limited, and neither wave waits for
+// the other's exact numbers.
+__device__ __forceinline__ bool nPlentiful(double minN, double qSoil, double len, double nVolFrac, double nLeachFrac,
+                                           double demand) {
+#pragma clang fp contract(off)
+  const double lossShare = (nVolFrac * qSoil + nLeachFrac) * len;
+  const double lower = minN * (1.0 - lossShare);
+  return !(demand * len > lower);
+}
 // progress-only wait (no value)
 __device__ __forceinline__ void awaitAtLeast(const int* flag, int step) {
   int f;
@@ -297,26 +393,48 @@ __device__ unsigned long long g_coopWaits[16];
 // NP = 4 (stepCoopQuadKernel): twelve wavefronts carry FOUR chunks, C0..C3 W0..W3 L0..L3: every SIMD
 // runs the three waves of one chunk, which fill each other's dependency and hand-over gaps -- for
 // batches of up to four chunks per CU, where the one-wave kernel leaves every SIMD with a lone wave.
-template <class R, bool PlainExp, bool RingLds, bool Full, int NP>
+// NCyc (stepCoopNKernel): the nitrogen-cycle flag set (litter pool + anaerobic + nitrogen cycle on top
+// of the defaults: what nitrogen-cycle requires, context.c:203-212) compiled in.  The soil side of the
+// model moves to wave W, which owns the soil water the anaerobic and leaching terms look at: W keeps
+// soil carbon, the litter pool and the four nitrogen pools and computes heterotrophic respiration,
+// litter breakdown, methane and nitrogen.c's fluxes; C keeps the plants.  Per step C hands W the
+// plants' litter fluxes and nitrogen demand, W hands C R_h (for NEE) and the mineral nitrogen the
+// limitation test needs; rare things (events, plant death, a nitrogen-limited step) travel in blocks
+// of their own.  One chunk per workgroup, ring in HBM (the new mailboxes take the LDS the ring would),
+// wave F on the fourth SIMD, lean state only.
+template <class R, bool PlainExp, bool RingLds, bool Full, int NP, bool NCyc = false>
 __device__ __forceinline__ void coopBody(const FastArgs& a) {
   static_assert(!(NP > 1 && RingLds), "two chunks' rings do not fit one CU's LDS");
+  static_assert(!NCyc || (NP == 1 && !RingLds && !Full), "nitrogen-cycle layout: one chunk, ring in HBM, lean");
   constexpr bool Pair = NP == 2;
   // a fourth wavefront computes the climate-only factors when the workgroup has a CU to itself
 #ifdef SIPNET_NO_FACWAVE
   constexpr bool FacWave = false;
 #else
-  constexpr bool FacWave = RingLds;
+  constexpr bool FacWave = RingLds || NCyc;
 #endif
   // per-wave private record tiles (each wave stages and awaits its own DMA) + mailboxes
   __shared__ alignas(16) unsigned char ldsTilesAll[NP][3][2 * kTileBytes];
   __shared__ R mailLaiAll[NP][2][64], mailPgpAll[NP][2][64], mailPsnAll[NP][2][64];
   // rows 0..4: g1 g2 qSoilT gFine gCoarse of a step (wave L: climate x parameters only); row 5: the
   // soil-moisture effect on heterotrophic respiration (wave W: its state)
-  __shared__ alignas(16) R mailFacAll[NP][2][6][64];
+  // (NCyc: row 6 = the plain soil-temperature Q10 factor, for methane, volatilisation, litter breakdown)
+  __shared__ alignas(16) R mailFacAll[NP][2][NCyc ? 7 : 6][64];
   __shared__ int mailAliveAll[NP][2][64];  // aliveWord(): wave C's confirmation of the leaf area it posted
   __shared__ int seqLaiAll[NP], seqPgpAll[NP], seqPsnAll[NP];
   __shared__ alignas(8) int seqFacMoistAll[NP][2];  // [0] wave F's / L's factor rows, [1] wave W's moisture row
   __shared__ int seqDoneAll[NP][2];  // statistics: wave C's / wave W's plane stores of the whole launch have completed
+  // NCyc hand-overs (doubles whatever R is).  C -> W per step: leafLitter woodLitter fineRootLoss
+  // coarseRootLoss nDemand reductionNResorption leafOnN(all) leafOnN(computed switch) [rates]; W -> C per
+  // step: R_h (two slots: W may post the next one before C has taken this one) and the mineral N at the
+  // start of the step; W -> C after the mortality hand-over: storage N.  Rare: C -> W the soil-side
+  // increments of events [litterC soilC minN soilOrgN litterN storN, rates] and of plant death
+  // [to soilC, to litterC, to soilOrgN, to litterN]; a nitrogen-limited step: W -> C {availableMinN,
+  // fixation share, unclaimed storage}, C -> W the final demand.
+  __shared__ alignas(16) double mailPlant[NCyc ? 8 : 1][64], mailRh[NCyc ? 2 : 1][64], mailMinN[NCyc ? 2 : 1][64];
+  __shared__ alignas(16) double mailStorN[NCyc ? 2 : 1][64], mailEvent[NCyc ? 6 : 1][64], mailDeath[NCyc ? 4 : 1][64];
+  __shared__ alignas(16) double mailSupply[NCyc ? 3 : 1][64], mailDemand[1][64];
+  __shared__ int seqPlant, seqRh, seqMinN, seqStorN, seqEvent, seqSupply, seqDemand;
 #define seqFac seqFacMoist[0]
 #define seqMoist seqFacMoist[1]
   // The running-mean ring of the 64 members lives in LDS for the whole launch (250 x 64 x 8 B =
@@ -394,6 +512,15 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
       seqMoist = tBegin - 1;
       seqDone[0] = 0;
       seqDone[1] = 0;
+      if (NCyc) {
+        seqPlant = tBegin - 1;
+        seqRh = tBegin - 1;
+        seqMinN = tBegin - 1;
+        seqStorN = tBegin - 1;
+        seqEvent = tBegin - 1;
+        seqSupply = tBegin - 1;
+        seqDemand = tBegin - 1;
+      }
     }
     mailAlive[0][lane] = 0;
     mailAlive[1][lane] = 0;
@@ -601,6 +728,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
           haveQ = true;
         }
         const R qSoilT = K_bsr * qSoil * tillP1;
+        if (NCyc) postRaw(&mailFac[t & 1][6][lane], qSoil);   // before the flag post5 sets
         post5(&mailFac[t & 1][0][lane], &seqFac, g1, g2, qSoilT, gFine, gCoarse, t);
       }
       cur = nxt;
@@ -751,6 +879,28 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
     const R K_moistExp = (R)PRM(soilRespMoistEffect);
     double soilWater = ST(soilWater), snow = ST(snow);
     double totGpp = ST(totGpp);  // GPP is this wave's own product: it stores the plane and keeps the total
+    // NCyc: the soil side (step_fast.hip's Generic block with the nitrogen-cycle flag set; same
+    // conventions: reciprocal C:N ratios, x / (C/N) = x N / C, divisions through v_rcp + Newton)
+    const R G_lbr = NCyc ? (R)PRM(litterBreakdownRate) : R(0), G_flr = NCyc ? (R)PRM(fracLitterRespired) : R(0);
+    const R G_nVol = NCyc ? (R)PRM(nVolatilizationFrac) : R(0), G_nLeach = NCyc ? (R)PRM(nLeachingFrac) : R(0);
+    const double G_nVolD = NCyc ? PRM(nVolatilizationFrac) : 0.0, G_nLeachD = NCyc ? PRM(nLeachingFrac) : 0.0;
+    const R G_iLeafCN = NCyc ? (R)(1.0 / PRM(leafCN)) : R(0), G_iWoodCN = NCyc ? (R)(1.0 / PRM(woodCN)) : R(0);
+    const R G_iFineCN = NCyc ? (R)(1.0 / PRM(fineRootCN)) : R(0);
+    const R G_kCN = NCyc ? (R)PRM(kCN) : R(0), G_nFixMax = NCyc ? (R)PRM(nFixationFracMax) : R(0);
+    const R G_halfNFix = NCyc ? (R)PRM(halfNFixationMax) : R(0), G_resorb = NCyc ? (R)PRM(leafNResorptionFrac) : R(0);
+    const R G_fAnox = NCyc ? (R)PRM(fAnoxia) : R(0), G_iFAnox = NCyc ? (R)(1.0 / PRM(fAnoxia)) : R(0);
+    const R G_iOneMinusAnox = NCyc ? (R)(1.0 / (1.0 - PRM(fAnoxia))) : R(0);
+    const R G_anDecomp = NCyc ? (R)PRM(anaerobicDecompRate) : R(0), G_anExp = NCyc ? (R)PRM(anaerobicTransExp) : R(0);
+    const R G_soilCH4 = NCyc ? (R)PRM(soilMethaneRate) : R(0), G_litCH4 = NCyc ? (R)PRM(litterMethaneRate) : R(0);
+    const R K_iBsr = NCyc ? (R)(1.0 / PRM(baseSoilResp)) : R(0);
+    double soilC = NCyc ? ST(soilC) : 0.0, litterC = NCyc ? ST(litterC) : 0.0, minN = NCyc ? ST(minN) : 0.0;
+    double soilOrgN = NCyc ? ST(soilOrgN) : 0.0, litterN = NCyc ? ST(litterN) : 0.0, storN = NCyc ? ST(plantStorageN) : 0.0;
+    if (NCyc) {  // what C needs of this wave's pools at the start of the first step
+      postD(&mailMinN[tBegin & 1][lane], 0, minN);
+      postFlag(&seqMinN, tBegin);
+      postD(&mailStorN[tBegin & 1][lane], 0, storN);
+      postFlag(&seqStorN, tBegin);
+    }
     R* __restrict__ oEt = (R*)(a.et ? a.et : a.scratchRow) + col;
     R* __restrict__ oGpp = (R*)(a.gpp ? a.gpp : a.scratchRow) + col;
     const int64_t ldEt = a.et ? a.ld : 0, ldGpp = a.gpp ? a.ld : 0;
@@ -791,12 +941,46 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         // ---- for wave C: the soil-moisture effect on heterotrophic respiration of THIS step
         // (depeffects.c:23-57; the Q10 / tillage part comes from wave F or L), posted before anything
         // else so that C never waits for it
-        {
+        if (!NCyc) {
           R moistEff = clip01(eWater * K_invWhc);
           if (!PlainExp && __builtin_amdgcn_ballot_w64(K_moistExp != R(1)) != 0)  // pow only where some member needs it
             moistEff = (K_moistExp == R(1)) ? moistEff : fpow(moistEff, K_moistExp);
           moistEff = (bits & FAST_TSOIL_NEG) ? R(1) : moistEff;
           post(&mailFac[t & 1][5][lane], &seqMoist, moistEff, t);
+        }
+        // ---- NCyc: heterotrophic respiration, litter breakdown, methane (sipnet.c:1132-1171, :1201-1214,
+        // depeffects.c:23-96) from this wave's pools; R_h goes to C at once (its NEE needs it at the END
+        // of its step)
+        const R eSoilC = (R)soilC, eLitter = (R)litterC, eMinN = (R)minN, eSoilOrgN = (R)soilOrgN;
+        const R eLitterN = (R)litterN, eStorN = (R)storN;
+        const double minN0 = minN;   // the value C has been given for this step's limitation test
+        R anoxic = 0, qSoil = 0, rSoil = 0, rLitter = 0, litterToSoil = 0, soilMethane = 0, litterMethane = 0;
+        R denLitterN = 0, denSoilN = 0;
+        if (NCyc) {
+          const R fWhc = clip01(eWater * K_invWhc);
+          anoxic = clip01((fWhc - G_fAnox) * G_iOneMinusAnox);
+          R moistEff = (R(1) - anoxic) * clip01(fWhc * G_iFAnox) + G_anDecomp * anoxic;
+          moistEff = (bits & FAST_TSOIL_NEG) ? R(1) : moistEff;
+          R qSoilT;
+          takeR2(&mailFac[t & 1][2][lane], &mailFac[t & 1][6][lane], &seqFac, t, qSoilT, qSoil);
+          // cn = kCN / (kCN + C/N) = kCN N / (kCN N + C), N floored at TINY (util.c:72-75)
+          denLitterN = eLitterN < R(kTiny) ? R(kTiny) : eLitterN;
+          denSoilN = eSoilOrgN < R(kTiny) ? R(kTiny) : eSoilOrgN;
+          const R cnSoil = fdiv(G_kCN * denSoilN, G_kCN * denSoilN + eSoilC);
+          const R cnLitter = fdiv(G_kCN * denLitterN, G_kCN * denLitterN + eLitter);
+          rSoil = eSoilC * (qSoilT * moistEff) * cnSoil;
+          const R breakdown = eLitter * G_lbr * (qSoilT * K_iBsr) * moistEff * cnLitter;
+          rLitter = breakdown * G_flr;
+          litterToSoil = breakdown * (R(1) - G_flr);
+          R mMoist = anoxic * anoxic;  // pow(A, anaerobicTransExp) with the usual exponent 2
+          if (__builtin_expect(__builtin_amdgcn_ballot_w64(G_anExp != R(2)) != 0, 0)) {
+            const bool general = G_anExp != R(2) && (anoxic > R(0) || G_anExp <= R(0));
+            mMoist = general ? fpow(anoxic, G_anExp) : (G_anExp != R(2) ? R(0) : mMoist);
+          }
+          soilMethane = G_soilCH4 * eSoilC * qSoil * mMoist;
+          litterMethane = G_litCH4 * eLitter * qSoil * mMoist;
+          postD(&mailRh[t & 1][lane], 0, (double)(rLitter + rSoil));
+          postFlag(&seqRh, t);
         }
 
         // everything that does not need the light block first
@@ -824,6 +1008,93 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         }
         R removable = rminv(eWater, K_whc) * K_wrf;
         removable = frozen ? removable * K_frozEff : removable;
+
+        // ---- NCyc: nitrogen.c:15-239 with limitations.c:69-139, the litter / soil carbon and the nitrogen
+        // pools (sipnet.c:1645-1668, nitrogen.c:210-239).  Needs C's litter fluxes and demand of this step
+        // (posted early in C's step) and the drainage, which by day is known only after the photosynthesis
+        // hand-over -- unless the soil cannot reach its holding capacity in this step whatever the plants
+        // take (the common case, decided for the wavefront): then the block runs BEFORE that hand-over and
+        // C finds next step's mineral nitrogen waiting.
+        auto nBlock = [&](R drainage) {
+          double pLeafLitter, pWoodLitter, pFineLoss, pCoarseLoss, pDemand, pReduction, pLeafOnAll, pLeafOn;
+          takeD8(&mailPlant[0][lane], &seqPlant, t, pLeafLitter, pWoodLitter, pFineLoss, pCoarseLoss, pDemand,
+                 pReduction, pLeafOnAll, pLeafOn);
+          const R leafLitter = (R)pLeafLitter, woodLitter = (R)pWoodLitter, fineRootLoss = (R)pFineLoss;
+          const R coarseRootLoss = (R)pCoarseLoss, reductionN = (R)pReduction, leafOnN = (R)pLeafOn;
+          R nDemand = (R)pDemand, evMinN = 0;
+          if (__builtin_expect(nEv > 0, 0)) {  // the soil side of this step's events, worked out by C (it has the plants)
+            double eLit, eSoil, eMin, eOrg, eLitN, eStor;
+            takeD6(&mailEvent[0][lane], &seqEvent, t, eLit, eSoil, eMin, eOrg, eLitN, eStor);
+            evMinN = (R)eMin;
+            litterC += (double)((R)eLit * len);
+            soilC += (double)((R)eSoil * len);
+            minN += (double)(evMinN * len);
+            soilOrgN += (double)((R)eOrg * len);
+            litterN += (double)((R)eLitN * len);
+            storN += (double)((R)eStor * len);
+          }
+          // unclaimed storage nitrogen.c:127-134, fixation share nitrogen.c:137-152
+          const R unclaimed = rmax0(eStorN - (R)pLeafOnAll * len);
+          const R fixDen = G_halfNFix + eMinN;
+          const R fixFrac = G_nFixMax * ((fixDen < R(kTiny)) ? R(1) : fdiv(G_halfNFix, fixDen));
+          const R leafOffNResorption = G_resorb * leafLitter * G_iLeafCN;
+          // volatilisation nitrogen.c:15-26, leaching nitrogen.c:31-41
+          R nVolatilization = G_nVol * eMinN * qSoil * (R(0.05) + R(3.8) * anoxic * (R(1) - anoxic));
+          R nLeaching = eMinN * rminv(drainage * K_invWhc, R(1)) * G_nLeach;
+          // pool fluxes, nitrogen.c:45-82: x / (C/N) = x * N / C
+          const R iLitterCN = fdiv(denLitterN, eLitter), iSoilCN = fdiv(denSoilN, eSoilC);
+          const R litterMin = rLitter * iLitterCN, soilMin = rSoil * iSoilCN;
+          const R soilNInputs = litterToSoil * iLitterCN + fineRootLoss * G_iFineCN + coarseRootLoss * G_iWoodCN;
+          const R nOrgLitter = leafLitter * G_iLeafCN - leafOffNResorption + woodLitter * G_iWoodCN - litterMin -
+                               litterToSoil * iLitterCN;
+          const R nOrgSoil = soilNInputs - soilMin;
+          const R nMin = litterMin + soilMin;
+          // checkMineralNLimitation, limitations.c:119-129
+          {
+            const R pool = eMinN + (nMin + evMinN) * len;
+            const R loss = (nLeaching + nVolatilization) * len;
+            const R red = (loss > R(kTiny) && loss > pool) ? fdiv(pool, loss) : R(1);
+            nLeaching *= red;
+            nVolatilization *= red;
+          }
+          // checkNitrogenLimitation, limitations.c:69-114: nobody is limited where the cheap test both
+          // waves make holds; otherwise C gets the exact supply, scales its creation fluxes and answers
+          // with the demand that is left
+          if (__builtin_expect(__builtin_amdgcn_ballot_w64(!nPlentiful(minN0, (double)qSoil, (double)len, G_nVolD, G_nLeachD,
+                                                                         pDemand)) != 0, 0)) {
+            const R availableMinN = eMinN + (nMin - nVolatilization - nLeaching) * len;
+            postD(&mailSupply[0][lane], 0, (double)availableMinN);
+            postD(&mailSupply[0][lane], 1, (double)fixFrac);
+            postD(&mailSupply[0][lane], 2, (double)unclaimed);
+            postFlag(&seqSupply, t);
+            double dFinal;
+            takeD1(&mailDemand[0][lane], &seqDemand, t, dFinal);
+            nDemand = (R)dFinal;
+          }
+          // fixation and uptake, nitrogen.c:155-168
+          const R rem = rmax0(nDemand - unclaimed * invLen);
+          const R nFixation = fixFrac * rem, nUptake = (R(1) - fixFrac) * rem;
+          // updateNitrogenPools(), nitrogen.c:210-239
+          const R storageDemand = nDemand - nUptake - nFixation;
+          storN += (double)((leafOffNResorption + reductionN - storageDemand - leafOnN) * len);
+          minN += (double)(((nMin - nVolatilization - nLeaching) - nUptake) * len);
+          soilOrgN += (double)(nOrgSoil * len);
+          litterN += (double)(nOrgLitter * len);
+          minN = rmax0(minN);   // (plant death, which comes later in the step, does not touch this pool)
+          postD(&mailMinN[(t + 1) & 1][lane], 0, minN);
+          postFlag(&seqMinN, t + 1);
+          // updatePoolsForSoil(), sipnet.c:1645-1668 (litter pool on, no carbon saturation)
+          const R soilInputs = coarseRootLoss + fineRootLoss + litterToSoil;
+          litterC += (double)((woodLitter + leafLitter - litterToSoil - rLitter - litterMethane) * len);
+          soilC += (double)((soilInputs - rSoil - soilMethane) * len);
+        };
+        bool nDone = false;
+        if (NCyc) {
+          R netIn0 = netRain + snowMelt;
+          netIn0 -= netIn0 * K_ff;
+          nDone = __builtin_amdgcn_ballot_w64(!(eWater + netIn0 * len <= K_whc)) == 0;
+          if (nDone) nBlock(R(0));
+        }
 
         // moisture(), sipnet.c:656-699, with the potential photosynthesis of wave L
         R transpiration = 0, photosynthesis = 0;
@@ -870,6 +1141,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
           }
           soilWater += (double)(evSoilWater * len);
         }
+        if (NCyc && !nDone) nBlock(drainage);
         soilWater += (double)((rain + snowMelt - immedEvap - fastFlow - evaporation -
                                transpiration - drainage) * len);
         snow += (double)((snowFall - snowMelt - sublimation) * len);
@@ -883,7 +1155,37 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         // never run more than one step ahead of C (the mailboxes have two slots): C is past the
         // pools of step t-1 once it has posted lai(t).  By day that is implied: this wave has taken
         // pgp(t), which wave L computed from lai(t)
-        if (!(bits & FAST_PAR_POS)) {
+        if (NCyc) {
+          // the end of C's step: its mortality verdict (one word per lane; it follows the leaf area of
+          // step t + 1, so this is also the throttle) and, where a stand died, what its biomass adds to
+          // this wave's pools (sipnet.c:1688-1767); then ensureNonNegativeStocks() for them
+          int w;
+          WAIT_BEGIN()
+          do {
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(w) : "v"(ldsAddr(&mailAlive[(t + 1) & 1][lane])) : "memory");
+          } while (uni(w < 0 ? -w : w) < t + 3);
+          WAIT_END(1)
+          if (__builtin_expect(__builtin_amdgcn_ballot_w64(w < 0) != 0, 0)) {
+            double d0, d1, d2, d3;
+            asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:512\n\tds_read_b64 %2, %4 offset:1024\n\t"
+                         "ds_read_b64 %3, %4 offset:1536\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3) : "v"(ldsAddr(&mailDeath[0][lane])) : "memory");
+            if (w < 0) {
+              soilC += d0;
+              litterC += d1;
+              soilOrgN += d2;
+              litterN += d3 + storN;
+              storN = 0.0;
+            }
+          }
+          soilC = rmax0(soilC);
+          litterC = rmax0(litterC);
+          soilOrgN = rmax0(soilOrgN);
+          litterN = rmax0(litterN);
+          storN = rmax0(storN);
+          postD(&mailStorN[(t + 1) & 1][lane], 0, storN);
+          postFlag(&seqStorN, t + 1);
+        } else if (!(bits & FAST_PAR_POS)) {
           WAIT_BEGIN()
           awaitAtLeast(&seqLai, t);
           WAIT_END(1)
@@ -922,6 +1224,14 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
       ST(soilWater) = soilWater;
       ST(snow) = snow;
       ST(totGpp) = totGpp;
+      if (NCyc) {
+        ST(soilC) = soilC;
+        ST(litterC) = litterC;
+        ST(minN) = minN;
+        ST(soilOrgN) = soilOrgN;
+        ST(litterN) = litterN;
+        ST(plantStorageN) = storN;
+      }
       if (wantDiagW && clampWarnW) atomicAdd(a.diag + col, (double)clampWarnW);
     }
     return;
@@ -937,7 +1247,12 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   const double gddLeafOn = PRM(gddLeafOn);
   const double leafOffDay = PRM(leafOffDay) > 0 ? PRM(leafOffDay) : 1e300;
 
-  double plantWoodC = ST(plantWoodC), plantLeafC = ST(plantLeafC), soilC = ST(soilC);
+  // NCyc: reciprocal C:N ratios for the plants' nitrogen demand (nitrogen.c:89-104) and the test both
+  // waves make (nPlentiful); soil carbon lives on wave W then
+  const R G_iLeafCN = NCyc ? (R)(1.0 / PRM(leafCN)) : R(0), G_iWoodCN = NCyc ? (R)(1.0 / PRM(woodCN)) : R(0);
+  const R G_iFineCN = NCyc ? (R)(1.0 / PRM(fineRootCN)) : R(0), G_resorbC = NCyc ? (R)PRM(leafNResorptionFrac) : R(0);
+  const double G_nVolD = NCyc ? PRM(nVolatilizationFrac) : 0.0, G_nLeachD = NCyc ? PRM(nLeachingFrac) : 0.0;
+  double plantWoodC = ST(plantWoodC), plantLeafC = ST(plantLeafC), soilC = NCyc ? 0.0 : ST(soilC);
   double coarseRootC = ST(coarseRootC), fineRootC = ST(fineRootC);
   double delta = ST(plantCAccountingDelta);
   double ringSum = ST(ringSum), totNee = ST(totNee);
@@ -1017,7 +1332,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
     // as "second eviction" the step before.  Same arithmetic as the general step below; left at
     // the first step on which a member dies.  (Lean instantiation only: records, all accumulators
     // and diagnostics take the general step.)
-    if (!Full && ringClean && !(a.options & SIPNET_KOPT_NO_REGULAR_TILES)) {
+    if (!Full && !NCyc && ringClean && !(a.options & SIPNET_KOPT_NO_REGULAR_TILES)) {
       d2 h0, h7;
       i4 hj;
       double hW1, hEndGdd, hEndDay;
@@ -1204,7 +1519,39 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
     i4 j0;
     R g1, g2, qSoilT, gFine, gCoarse, moistEff;
     int facSeq, moistSeq;
-    {
+    double minNStep = 0.0;   // NCyc: wave W's mineral nitrogen at the start of this step
+    if (NCyc) {
+      // record fields, wave F's factors (rows 0 1 3 4 and the plain soil Q10 factor, row 6 -- carried in
+      // `moistEff`'s place) and wave W's mineral nitrogen, each behind its flag, one round trip
+      WAIT_BEGIN()
+      const unsigned fac = ldsAddr(&mailFac[t & 1][0][lane]);
+      const unsigned mnn = ldsAddr(&mailMinN[t & 1][lane]);
+      do {
+        if (sizeof(R) == 8) {
+          asm volatile("ds_read_b128 %0, %12\n\tds_read_b128 %1, %12 offset:96\n\tds_read_b128 %2, %12 offset:112\n\t"
+                       "ds_read_b128 %3, %12 offset:128\n\tds_read_b32 %4, %13\n\t"
+                       "ds_read_b64 %5, %14\n\tds_read_b64 %6, %14 offset:512\n\tds_read_b64 %7, %14 offset:3072\n\t"
+                       "ds_read_b64 %8, %14 offset:1536\n\tds_read_b64 %9, %14 offset:2048\n\t"
+                       "ds_read_b32 %10, %15\n\tds_read_b64 %11, %16\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(q0), "=&v"(q6), "=&v"(q7), "=&v"(j0), "=&v"(facSeq), "=&v"(g1), "=&v"(g2),
+                         "=&v"(moistEff), "=&v"(gFine), "=&v"(gCoarse), "=&v"(moistSeq), "=&v"(minNStep)
+                       : "v"(ldsAddr(recB)), "v"(ldsAddr(&seqFac)), "v"(fac), "v"(ldsAddr(&seqMinN)), "v"(mnn)
+                       : "memory");
+        } else {
+          asm volatile("ds_read_b128 %0, %12\n\tds_read_b128 %1, %12 offset:96\n\tds_read_b128 %2, %12 offset:112\n\t"
+                       "ds_read_b128 %3, %12 offset:128\n\tds_read_b32 %4, %13\n\t"
+                       "ds_read_b32 %5, %14\n\tds_read_b32 %6, %14 offset:256\n\tds_read_b32 %7, %14 offset:1536\n\t"
+                       "ds_read_b32 %8, %14 offset:768\n\tds_read_b32 %9, %14 offset:1024\n\t"
+                       "ds_read_b32 %10, %15\n\tds_read_b64 %11, %16\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(q0), "=&v"(q6), "=&v"(q7), "=&v"(j0), "=&v"(facSeq), "=&v"(g1), "=&v"(g2),
+                         "=&v"(moistEff), "=&v"(gFine), "=&v"(gCoarse), "=&v"(moistSeq), "=&v"(minNStep)
+                       : "v"(ldsAddr(recB)), "v"(ldsAddr(&seqFac)), "v"(fac), "v"(ldsAddr(&seqMinN)), "v"(mnn)
+                       : "memory");
+        }
+      } while (uni(facSeq) < t || uni(moistSeq) < t);
+      qSoilT = 0;
+      WAIT_END(0)
+    } else {
       WAIT_BEGIN()
       const unsigned fac = ldsAddr(&mailFac[t & 1][0][lane]);
       const unsigned mst = ldsAddr(&mailFac[t & 1][5][lane]);
@@ -1265,10 +1612,20 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
     R recLeafOffComputed = 0, recEvLeafOn = 0, recEvLeafOnFromWood = 0, recEvLeafOffLitter = 0;
     R evInC = 0, evOutC = 0;
 
-    auto leafOnLimit = [&](R flux) -> R {  // limitations.c:13-64 (no N cycle here)
+    auto leafOnNFromC = [&](R leafOnC) -> R {  // nitrogen.c:84-86
+      return rmax0(leafOnC * G_iLeafCN - leafOnC * G_iWoodCN);
+    };
+    auto leafOnLimit = [&](R flux) -> R {  // limitations.c:13-64
       const R cDemand = flux * len;
       if (cDemand < R(kTiny)) return flux;
-      const R lim = clip01(fdiv((eWood + eCoarse) * PRM_RARE(leafOnReallocFrac), cDemand));
+      R lim = fdiv((eWood + eCoarse) * PRM_RARE(leafOnReallocFrac), cDemand);
+      if (NCyc) {  // the storage nitrogen is wave W's: its value at the start of this step
+        double sN;
+        takeD1(&mailStorN[t & 1][lane], &seqStorN, t, sN);
+        const R nDemand = leafOnNFromC(cDemand);
+        if (nDemand > R(kTiny)) lim = rminv(lim, fdiv((R)sN, nDemand));
+      }
+      lim = clip01(lim);
       return lim < R(1) ? flux * lim : flux;
     };
 
@@ -1279,13 +1636,14 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
     const R rVeg = ffma(totalWoodC, g2, folResp);
     const R rCoarseRoot = eCoarse * gCoarse;
     const R rFineRoot = eFine * gFine;
-    const R rSoil = eSoilC * fSoil;
+    const R rSoil = NCyc ? R(0) : eSoilC * fSoil;
 
     const R woodLitter = totalWoodC * K_wtr;
     R leafLitter = eLeaf * K_ltr;
     R leafCreation = meanNpp * K_la, woodCreation = meanNpp * K_wa;
 
     R leafOnCreation = 0, leafOnFromWood = 0;
+    R evLeafOnAll = 0;   // NCyc: leaf-on by event (its nitrogen is part of the step's claim on the storage)
     const bool phenMay = (!allOn && q6.y >= minGddOn) || (!allOff && q7.x >= minOffDay);
 
     const R coarseRootLoss = K_crt * eCoarse, fineRootLoss = K_frt * eFine;
@@ -1330,6 +1688,8 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
       allOff = __builtin_amdgcn_ballot_w64((phenBits & 2) == 0) == 0;
       R evLeafC = 0, evWoodC = 0, evFineRootC = 0, evCoarseRootC = 0;
       R evSoilC = 0, evLeafOnCreation = 0, evLeafOnFromWood = 0, evLeafOffLitter = 0;
+      // NCyc: the soil side of the events (events.c:575-620, :660-672, :712-722, :778-789), for wave W
+      R evLitterC = 0, evMinN = 0, evSoilOrgN = 0, evLitterN = 0, evLeafOffNResorp = 0;
       const int ev0 = uni(rareI[3]);
       for (int k = 0; k < nEv; k++) {
         const EvRec& ev = a.events[evBase + ev0 + k];
@@ -1344,13 +1704,26 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         } else if (type == SIPNET_EV_HARVEST) {
           const R woodC = totalWoodC;
           if (Full) evOutC += ((woodC + eLeaf) * p0 + (eFine + eCoarse) * p1) * invLen;  // events.c:582-594
-          evSoilC += (p3 * (eFine + eCoarse) + p2 * (eLeaf + woodC)) * invLen;
+          if (NCyc) {
+            evLitterC += (p2 * (eLeaf + woodC)) * invLen;
+            evSoilC += (p3 * (eFine + eCoarse)) * invLen;
+            evSoilOrgN += (p3 * (eFine * G_iFineCN + eCoarse * G_iWoodCN)) * invLen;
+            evLitterN += (p2 * (eLeaf * G_iLeafCN + eWood * G_iWoodCN)) * invLen;
+          } else {
+            evSoilC += (p3 * (eFine + eCoarse) + p2 * (eLeaf + woodC)) * invLen;
+          }
           evLeafC += -eLeaf * (p0 + p2) * invLen;
           evWoodC += -woodC * (p0 + p2) * invLen;
           evFineRootC += -eFine * (p1 + p3) * invLen;
           evCoarseRootC += -eCoarse * (p1 + p3) * invLen;
         } else if (type == SIPNET_EV_FERT) {
-          evSoilC += p1 * invLen;
+          if (NCyc) {
+            evLitterC += p1 * invLen;
+            evLitterN += p0 * invLen;
+            evMinN += p2 * invLen;
+          } else {
+            evSoilC += p1 * invLen;
+          }
           if (Full) evInC += p1 * invLen;
         } else if (type == SIPNET_EV_LEAFON) {
           const R flux = leafOnLimit(PRM_RARE(leafGrowth) * invLen);
@@ -1358,7 +1731,26 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
           const R src = eWood + eCoarse;
           if (src > R(kTiny)) evLeafOnFromWood += fdiv(flux * eWood, src);
         } else if (type == SIPNET_EV_LEAFOFF) {
-          evLeafOffLitter += eLeaf * PRM_RARE(fracLeafFall) * invLen;
+          const R leafOff = eLeaf * PRM_RARE(fracLeafFall);
+          evLeafOffLitter += leafOff * invLen;
+          if (NCyc) {
+            const R leafN = leafOff * G_iLeafCN;
+            const R resorb = leafN * G_resorbC;
+            evLeafOffNResorp += resorb * invLen;
+            evLitterN += (leafN - resorb) * invLen;
+          }
+        }
+      }
+      if (NCyc) {
+        evLeafOnAll = evLeafOnCreation;
+        if (nEv > 0) {  // (W reads this block on every step whose record carries events)
+          postD(&mailEvent[0][lane], 0, (double)(evLitterC + evLeafOffLitter));
+          postD(&mailEvent[0][lane], 1, (double)evSoilC);
+          postD(&mailEvent[0][lane], 2, (double)evMinN);
+          postD(&mailEvent[0][lane], 3, (double)evSoilOrgN);
+          postD(&mailEvent[0][lane], 4, (double)evLitterN);
+          postD(&mailEvent[0][lane], 5, (double)(evLeafOffNResorp - leafOnNFromC(evLeafOnCreation)));
+          postFlag(&seqEvent, t);
         }
       }
       if (Full) {
@@ -1368,13 +1760,55 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
       }
       plantWoodC += (double)(evWoodC * len);
       plantLeafC += (double)(evLeafC * len);
-      soilC += (double)(evSoilC * len);
+      if (!NCyc) soilC += (double)(evSoilC * len);
       plantWoodC -= (double)(evLeafOnFromWood * len);
       coarseRootC -= (double)((evLeafOnCreation - evLeafOnFromWood) * len);
       plantLeafC += (double)((evLeafOnCreation - evLeafOffLitter) * len);
-      soilC += (double)(evLeafOffLitter * len);
+      if (!NCyc) soilC += (double)(evLeafOffLitter * len);
       coarseRootC += (double)(evCoarseRootC * len);
       fineRootC += (double)(evFineRootC * len);
+    }
+
+    // ---- NCyc: what wave W needs of this step's plant side (the litter fluxes, the nitrogen demand of
+    // the creation fluxes nitrogen.c:89-104, the resorption of a negative total creation :170-196, the
+    // leaf-on nitrogen :84-86), posted now -- W is working on the soil side of the same step -- and
+    // checkNitrogenLimitation() (limitations.c:69-114): both waves test "plentiful" with the same
+    // numbers; only where it fails for some member does C wait for W's exact supply
+    if (NCyc) {
+      auto plantNDemand = [&]() -> R {
+        return rmax0(woodCreation * G_iWoodCN + leafCreation * G_iLeafCN + fineRootCreation * G_iFineCN +
+                     coarseRootCreation * G_iWoodCN);
+      };
+      R reductionN = 0;
+      if (woodCreation + leafCreation + fineRootCreation + coarseRootCreation < R(0))
+        reductionN -= (leafCreation * G_iLeafCN + woodCreation * G_iWoodCN + coarseRootCreation * G_iWoodCN +
+                       fineRootCreation * G_iFineCN);
+      const R nDemand = plantNDemand();
+      postD(&mailPlant[0][lane], 0, (double)leafLitter);
+      postD(&mailPlant[0][lane], 1, (double)woodLitter);
+      postD(&mailPlant[0][lane], 2, (double)fineRootLoss);
+      postD(&mailPlant[0][lane], 3, (double)coarseRootLoss);
+      postD(&mailPlant[0][lane], 4, (double)nDemand);
+      postD(&mailPlant[0][lane], 5, (double)reductionN);
+      postD(&mailPlant[0][lane], 6, (double)leafOnNFromC(leafOnCreation + evLeafOnAll));
+      postD(&mailPlant[0][lane], 7, (double)leafOnNFromC(leafOnCreation));
+      postFlag(&seqPlant, t);
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(!nPlentiful(minNStep, (double)moistEff /* plain qSoil */, (double)q0.x,
+                                                                     G_nVolD, G_nLeachD, (double)nDemand)) != 0, 0)) {
+        double sAvail, sFixFrac, sUnclaimed;
+        takeD3(&mailSupply[0][lane], &seqSupply, t, sAvail, sFixFrac, sUnclaimed);
+        const R availableMinN = (R)sAvail, fixFrac = (R)sFixFrac, unclaimed = (R)sUnclaimed;
+        const R nUptake = (R(1) - fixFrac) * rmax0(nDemand - unclaimed * invLen);
+        const R uptakeDemand = nUptake * len;
+        const bool limited = uptakeDemand > R(kTiny) && uptakeDemand > availableMinN;
+        const R red = limited ? fdiv(fdiv(availableMinN, R(1) - fixFrac) + unclaimed, nDemand * len) : R(1);
+        woodCreation *= red;
+        leafCreation *= red;
+        fineRootCreation *= red;
+        coarseRootCreation *= red;
+        postD(&mailDemand[0][lane], 0, (double)plantNDemand());
+        postFlag(&seqDemand, t);
+      }
     }
 
     CSTAMP(2)
@@ -1387,7 +1821,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
     accum(plantWoodC, woodCreation - woodLitter - leafOnFromWood, len);
     accum(coarseRootC, coarseRootCreation - coarseRootLoss - (leafOnCreation - leafOnFromWood), len);
     accum(fineRootC, fineRootCreation - fineRootLoss, len);
-    const double soilGain = (double)((coarseRootLoss + fineRootLoss + woodLitter + leafLitter - rSoil) * len);
+    const double soilGain = NCyc ? 0.0 : (double)((coarseRootLoss + fineRootLoss + woodLitter + leafLitter - rSoil) * len);
     const R r_a = rVeg + rFineRoot + rCoarseRoot;
     const R alloc = leafCreation + woodCreation + fineRootCreation + coarseRootCreation;
     const bool rootsOk = (plantWoodC > kTiny) && (fineRootC + coarseRootC > kTiny);
@@ -1427,6 +1861,12 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
           if (diedAt < 0) diedAt = t;
           deathToSoil0 = fineRootC + coarseRootC;
           deathToSoil1 = plantWoodC + plantLeafC + delta;
+          if (NCyc) {  // sipnet.c:1735-1746: to wave W's pools; posted before the verdict word that announces it
+            postD(&mailDeath[0][lane], 0, deathToSoil0);
+            postD(&mailDeath[0][lane], 1, deathToSoil1);
+            postD(&mailDeath[0][lane], 2, fineRootC * (double)G_iFineCN + coarseRootC * (double)G_iWoodCN);
+            postD(&mailDeath[0][lane], 3, plantWoodC * (double)G_iWoodCN + plantLeafC * (double)G_iLeafCN);
+          }
           if (Full) {
             deathWood = plantWoodC + delta;
             deathRoot = deathToSoil0;
@@ -1455,7 +1895,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
 
     CSTAMP(4)
     soilC += soilGain;
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(diedNow) != 0, 0)) {
+    if (!NCyc && __builtin_expect(__builtin_amdgcn_ballot_w64(diedNow) != 0, 0)) {
       if (diedNow) {
         soilC += deathToSoil0;
         soilC += deathToSoil1;
@@ -1478,7 +1918,13 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
 
     // ---- outputs: updateTrackers(), sipnet.c:1420-1496 ---------------------------------------
     const R tGpp = photosynthesis * len;
-    const R tRh = rSoil * len;
+    R rHet = rSoil;
+    if (NCyc) {  // heterotrophic respiration (litter + soil) is wave W's, posted early in its step
+      double rh;
+      takeD1(&mailRh[t & 1][lane], &seqRh, t, rh);
+      rHet = (R)rh;
+    }
+    const R tRh = rHet * len;
     const R tRa = ffma(rVeg, len, (rCoarseRoot + rFineRoot) * len);
     const R tNee = R(-1.0) * ((tGpp - tRa) - tRh);
     totNee += (double)tNee;
@@ -1613,7 +2059,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
       for (int k = 0; k < SIPNET_RING_SLOTS; k++) ringp[(uint32_t)k * ncu] = ringL[k * 64 + lane];
     ST(plantWoodC) = plantWoodC;
     ST(plantLeafC) = plantLeafC;
-    ST(soilC) = soilC;
+    if (!NCyc) ST(soilC) = soilC;
     ST(coarseRootC) = coarseRootC;
     ST(fineRootC) = fineRootC;
     ST(plantCAccountingDelta) = delta;
@@ -1669,6 +2115,12 @@ __global__ __launch_bounds__(768) void stepCoopQuadKernel(FastArgs a) {
   coopBody<R, PlainExp, false, false, 4>(a);
 }
 
+// the nitrogen-cycle flag set: four wavefronts per chunk (F L W C), soil + nitrogen on wave W
+template <class R, bool PlainExp>
+__global__ __launch_bounds__(256) void stepCoopNKernel(FastArgs a) {
+  coopBody<R, PlainExp, false, false, 1, true>(a);
+}
+
 #ifdef SIPNET_HWID
 extern "C" int sipnet_debug_read_coop_hwid(unsigned* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_coopHwId), sizeof(unsigned) * 4096 * 4 * 2);
@@ -1688,6 +2140,27 @@ extern "C" int sipnet_debug_read_coop_stamps(unsigned long long* out) {
 void launchStepCoop(const FastArgs& a, int precision, int layout, hipStream_t stream, LaunchInfo* info) {
   const int chunksPerSite = (a.n_members + 63) / 64;
   const bool ringInLds = layout == COOP_RING_LDS, pair = layout == COOP_PAIR, quad = layout == COOP_QUAD;
+  if (layout == COOP_NCYCLE) {
+    const dim3 gridN(a.n_sites * chunksPerSite), blockN(256);
+    if (precision == SIPNET_F64) {
+      if (a.plainExp) hipLaunchKernelGGL((stepCoopNKernel<double, true>), gridN, blockN, 0, stream, a);
+      else hipLaunchKernelGGL((stepCoopNKernel<double, false>), gridN, blockN, 0, stream, a);
+    } else {
+      if (a.plainExp) hipLaunchKernelGGL((stepCoopNKernel<float, true>), gridN, blockN, 0, stream, a);
+      else hipLaunchKernelGGL((stepCoopNKernel<float, false>), gridN, blockN, 0, stream, a);
+    }
+    if (info) {
+      snprintf(info->kernel, sizeof info->kernel, "stepCoopNKernel<%s, %s>", precision == SIPNET_F64 ? "double" : "float",
+               a.plainExp ? "true" : "false");
+      info->grid = (int32_t)gridN.x;
+      info->block = 256;
+      info->wavesPerSimd = 1;
+      const int elem = precision == SIPNET_F64 ? 8 : 4;
+      info->ldsBytes = 3 * 2 * kTileBytes + (2 * 64 * 3 + 2 * 7 * 64) * elem + 2 * 64 * 4 + 14 * 4 + 64 * 8 +
+                       (8 + 2 + 2 + 2 + 6 + 4 + 3 + 1) * 64 * 8;
+    }
+    return;
+  }
   const int chunks = a.n_sites * chunksPerSite;
   // paired chunks: with the XCD-grouped mapping every group of eight workgroups carries 16 chunks
   const int pairGroups = (a.n_sites & 7) == 0 ? 8 * ((chunks / 8 + 1) / 2) : (chunks + 1) / 2;

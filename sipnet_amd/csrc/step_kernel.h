@@ -127,9 +127,10 @@ struct LaunchInfo {
 // options: SIPNET_KOPT_* bits of include/sipnet_amd.h
 void launchStepFast(const FastArgs& a, int precision, int options, hipStream_t stream, LaunchInfo* info);
 // three cooperating wavefronts per 64 members (step_coop.hip); same results as launchStepFast
-enum CoopLayout { COOP_RING_LDS = 0, COOP_RING_HBM = 1, COOP_PAIR = 2, COOP_QUAD = 3 };  // step_coop.hip
+enum CoopLayout { COOP_RING_LDS = 0, COOP_RING_HBM = 1, COOP_PAIR = 2, COOP_QUAD = 3, COOP_NCYCLE = 4 };  // step_coop.hip
 void launchStepCoop(const FastArgs& a, int precision, int layout, hipStream_t stream, LaunchInfo* info);
 bool isDefaultFlagSet(const int32_t* flags);
+bool isNCycleFlagSet(const int32_t* flags);   // defaults + litter pool + anaerobic + nitrogen cycle (step_fast.hip)
 
 // launchers (step_kernel.hip)
 void launchSetup(const SetupArgs& a, hipStream_t stream);

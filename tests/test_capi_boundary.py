@@ -76,7 +76,7 @@ def test_python_constants_mirror_the_header_enums():
     import sipnet_amd as sa
     text = open(os.path.join(REPO, "include", "sipnet_amd.h")).read()
     enums = {m.group(1): int(m.group(2)) for m in re.finditer(r"\b(SIPNET_(?:KERNEL|KOPT|MATH)_[A-Z_0-9]+)\s*=\s*(\d+)", text)}
-    assert len([k for k in enums if k.startswith("SIPNET_KERNEL_")]) == 7
+    assert len([k for k in enums if k.startswith("SIPNET_KERNEL_")]) == 8
     for name, value in enums.items():
         py = name[len("SIPNET_"):]
         if py.startswith("MATH_"):

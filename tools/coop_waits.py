@@ -9,8 +9,9 @@ from sipnet_amd import _lib
 _lib.use_library(os.path.join(REPO, "build", "variants", "waits", "libsipnet_amd.so"))
 import torch, sipnet_amd as sa
 from sipnet_amd import synth
-flags = sa.flags_from()
-base, _ = sa.read_params(os.path.join(REPO, "sipnet_amd", "data", "base_forest.param"), flags)
+ncyc = bool(os.environ.get("NCYC"))          # NCYC=1: the nitrogen-cycle flag set (stepCoopNKernel)
+flags = sa.flags_from(litterPool=1, anaerobic=1, nitrogenCycle=1) if ncyc else sa.flags_from()
+base, _ = sa.read_params(os.path.join(REPO, "sipnet_amd", "data", "allflags_forest.param" if ncyc else "base_forest.param"), flags)
 M, T = 10240, 17520
 b = sa.Batch(flags, 1, M, sa.F64, fast_math=True, kernel_options=int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 raw = synth.half_hourly_year_raw(T)
