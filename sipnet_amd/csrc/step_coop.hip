@@ -395,13 +395,15 @@ __device__ unsigned long long g_coopWaits[16];
 // batches of up to four chunks per CU, where the one-wave kernel leaves every SIMD with a lone wave.
 // NCyc (stepCoopNKernel): the nitrogen-cycle flag set (litter pool + anaerobic + nitrogen cycle on top
 // of the defaults: what nitrogen-cycle requires, context.c:203-212) compiled in.  The soil side of the
-// model moves to wave W, which owns the soil water the anaerobic and leaching terms look at: W keeps
-// soil carbon, the litter pool and the four nitrogen pools and computes heterotrophic respiration,
-// litter breakdown, methane and nitrogen.c's fluxes; C keeps the plants.  Per step C hands W the
-// plants' litter fluxes and nitrogen demand, W hands C R_h (for NEE) and the mineral nitrogen the
-// limitation test needs; rare things (events, plant death, a nitrogen-limited step) travel in blocks
-// of their own.  One chunk per workgroup, ring in HBM (the new mailboxes take the LDS the ring would),
-// wave F on the fourth SIMD, lean state only.
+// model becomes a wave of its own, S, on the fourth SIMD (it also does wave F's job, one step ahead):
+// S keeps soil carbon, the litter pool and the four nitrogen pools and computes heterotrophic
+// respiration, litter breakdown, methane and nitrogen.c's fluxes; C keeps the plants, W the water.
+// Per step W hands S the anaerobic moisture terms and the leached share, C hands S the plants' litter
+// fluxes and nitrogen demand, S hands C R_h (for NEE) and the mineral nitrogen the limitation test
+// needs; rare things (events, plant death, a nitrogen-limited step) travel in blocks of their own.
+// (The first version had this block on wave W: 2 400 cycles per night step there against C's 1 800;
+// c10kn 20.3 ms.)  One chunk per workgroup, ring in HBM (the new mailboxes take the LDS the ring
+// would), lean state only.
 template <class R, bool PlainExp, bool RingLds, bool Full, int NP, bool NCyc = false>
 __device__ __forceinline__ void coopBody(const FastArgs& a) {
   static_assert(!(NP > 1 && RingLds), "two chunks' rings do not fit one CU's LDS");
@@ -434,7 +436,11 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   __shared__ alignas(16) double mailPlant[NCyc ? 8 : 1][64], mailRh[NCyc ? 2 : 1][64], mailMinN[NCyc ? 2 : 1][64];
   __shared__ alignas(16) double mailStorN[NCyc ? 2 : 1][64], mailEvent[NCyc ? 6 : 1][64], mailDeath[NCyc ? 4 : 1][64];
   __shared__ alignas(16) double mailSupply[NCyc ? 3 : 1][64], mailDemand[1][64];
-  __shared__ int seqPlant, seqRh, seqMinN, seqStorN, seqEvent, seqSupply, seqDemand;
+  // wave W -> wave S per step: [anaerobic moisture effect, anoxic share] at its start (seqWat), the
+  // leached share of the mineral nitrogen once the drainage is known (seqLeach)
+  // (four slots: W runs at most one step ahead of C, and C at most two ahead of S's consumption)
+  __shared__ alignas(16) double mailWat[NCyc ? 4 : 1][NCyc ? 3 : 1][64];
+  __shared__ int seqPlant, seqRh, seqMinN, seqStorN, seqEvent, seqSupply, seqDemand, seqWat, seqLeach;
 #define seqFac seqFacMoist[0]
 #define seqMoist seqFacMoist[1]
   // The running-mean ring of the 64 members lives in LDS for the whole launch (250 x 64 x 8 B =
@@ -520,6 +526,8 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         seqEvent = tBegin - 1;
         seqSupply = tBegin - 1;
         seqDemand = tBegin - 1;
+        seqWat = tBegin - 1;
+        seqLeach = tBegin - 1;
       }
     }
     mailAlive[0][lane] = 0;
@@ -664,6 +672,247 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   };
 
   // =============================================================================================
+  // ---- S (NCyc): wave F's factors, one step ahead, + the soil: heterotrophic respiration, litter
+  // breakdown, methane (sipnet.c:1132-1171, :1201-1214, depeffects.c:23-96), nitrogen.c:15-239 with
+  // limitations.c:69-139, the litter / soil carbon and nitrogen pools (sipnet.c:1645-1668,
+  // nitrogen.c:210-239).  step_fast.hip's Generic block with the nitrogen-cycle flag set, same
+  // conventions: reciprocal C:N ratios, x / (C/N) = x N / C, divisions through v_rcp + Newton.
+  if (NCyc && role == 3) {
+    const R K_frozThr = (R)PRM(frozenSoilThreshold);
+    const R K_lgVeg = (R)log2(PRM(vegRespQ10)), K_lgSoil = (R)log2(PRM(soilRespQ10));
+    const R K_lgFine = (R)log2(PRM(fineRootQ10)), K_lgCoarse = (R)log2(PRM(coarseRootQ10));
+    const R K_fol = (R)((PRM(baseFolRespFrac) * PRM(aMax)) *
+                        (kCWeight * (1.0 / kTen9) * (PRM(leafCSpWt) / PRM(cFracLeaf)) * kSecPerDay) *
+                        (1.0 / PRM(leafCSpWt)) * exp2(-(PRM(psnTOpt) / 10.0) * log2(PRM(vegRespQ10))));
+    const R K_frozFolEff = (R)PRM(frozenSoilFolREff);
+    const R K_bvr = (R)PRM(baseVegResp), K_bsr = (R)PRM(baseSoilResp);
+    const R K_bfr = (R)PRM(baseFineRootResp), K_bcr = (R)PRM(baseCoarseRootResp);
+    const R G_lbr = (R)PRM(litterBreakdownRate), G_flr = (R)PRM(fracLitterRespired);
+    const R G_nVol = (R)PRM(nVolatilizationFrac), G_nLeach = (R)PRM(nLeachingFrac);
+    const double G_nVolD = PRM(nVolatilizationFrac), G_nLeachD = PRM(nLeachingFrac);
+    const R G_iLeafCN = (R)(1.0 / PRM(leafCN)), G_iWoodCN = (R)(1.0 / PRM(woodCN)), G_iFineCN = (R)(1.0 / PRM(fineRootCN));
+    const R G_kCN = (R)PRM(kCN), G_nFixMax = (R)PRM(nFixationFracMax), G_halfNFix = (R)PRM(halfNFixationMax);
+    const R G_resorb = (R)PRM(leafNResorptionFrac), G_anExp = (R)PRM(anaerobicTransExp);
+    const R G_soilCH4 = (R)PRM(soilMethaneRate), G_litCH4 = (R)PRM(litterMethaneRate);
+    double soilC = ST(soilC), litterC = ST(litterC), minN = ST(minN);
+    double soilOrgN = ST(soilOrgN), litterN = ST(litterN), storN = ST(plantStorageN);
+    // what C needs of these pools at the start of the first step
+    postD(&mailMinN[tBegin & 1][lane], 0, minN);
+    postFlag(&seqMinN, tBegin);
+    postD(&mailStorN[tBegin & 1][lane], 0, storN);
+    postFlag(&seqStorN, tBegin);
+
+    const FastRec* __restrict__ recs = (const FastRec*)planBytes;
+    const int lastStep = a.n_steps_total - 1;
+    // no room for a record tile of this wave's own: lane k loads the fields of step 16j + k one tile
+    // ahead, a step's values come back through v_readlane
+    struct TileFields { double tair10, tsoil, tsoil10, tillP1, len, invLen; int bits, evCount; };
+    auto loadFields = [&](int tileStart) {
+      int t = tileStart + (lane & (kFastTile - 1));
+      t = t > lastStep ? lastStep : t;
+      const FastRec* r = recs + t;
+      return TileFields{r->tair10, r->tsoil, r->tsoil10, r->tillP1, r->len, r->invLen, r->bitsOps, r->evCount};
+    };
+    auto laneD = [](double v, int l) {
+      const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+      const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+      return __hiloint2double(hi, lo);
+    };
+    R qSoilQ = 0, gFine = 0, gCoarse = 0;   // Q10 factors of the last soil temperature seen
+    bool haveQ = false;
+    // factors of one step (wave F's job, same arithmetic -- contraction off like there), posted to C;
+    // returns the two this wave needs itself for that step
+    auto factorsOf = [&](const TileFields& f, int j, int tt, R& qSoilOut, R& qSoilTOut) {
+#pragma clang fp contract(off)
+      const R tair10 = (R)laneD(f.tair10, j), tsoil = (R)laneD(f.tsoil, j);
+      const R tillP1 = (R)laneD(f.tillP1, j);
+      const int bits = __builtin_amdgcn_readlane(f.bits, j);
+      const R vegQ = fexp2(q10Arg(tair10, K_lgVeg), EC);
+      R g1 = K_fol * vegQ;
+      g1 = (tsoil < K_frozThr) ? g1 * K_frozFolEff : g1;
+      const R g2 = K_bvr * vegQ;
+      if (!haveQ || !(bits & FAST_TSOIL_SAME)) {
+        const R tsoil10 = (R)laneD(f.tsoil10, j);
+        qSoilQ = fexp2(q10Arg(tsoil10, K_lgSoil), EC);
+        gFine = K_bfr * fexp2(q10Arg(tsoil10, K_lgFine), EC);
+        gCoarse = K_bcr * fexp2(q10Arg(tsoil10, K_lgCoarse), EC);
+        haveQ = true;
+      }
+      const R qSoilT = K_bsr * qSoilQ * tillP1;
+      postRaw(&mailFac[tt & 1][6][lane], qSoilQ);   // before the flag post5 sets
+      post5(&mailFac[tt & 1][0][lane], &seqFac, g1, g2, qSoilT, gFine, gCoarse, tt);
+      qSoilOut = qSoilQ;
+      qSoilTOut = qSoilT;
+    };
+    int fTile = tBegin / kFastTile;
+    TileFields cur = loadFields(fTile * kFastTile);
+    R qSoil = 0, qSoilT = 0;        // of the step whose soil block runs
+    factorsOf(cur, tBegin - fTile * kFastTile, tBegin, qSoil, qSoilT);
+    for (int tileStart = fTile * kFastTile; tileStart < tEnd; tileStart += kFastTile) {
+      const TileFields nxt = loadFields(tileStart + kFastTile);
+      const int tFirst = tileStart > tBegin ? tileStart : tBegin;
+      const int tLast = (tileStart + kFastTile) < tEnd ? (tileStart + kFastTile) : tEnd;
+      for (int t = tFirst; t < tLast; t++) {
+        const int j = t - tileStart;
+        // next step's factors first (C starts that step with them): its slot was last used for step
+        // t - 1, which C is past once it has posted the leaf area of step t
+        R qSoilN = 0, qSoilTN = 0;
+        if (t + 1 < tEnd) {
+          awaitAtLeast(&seqLai, t);
+          if (j + 1 < kFastTile) factorsOf(cur, j + 1, t + 1, qSoilN, qSoilTN);
+          else factorsOf(nxt, 0, t + 1, qSoilN, qSoilTN);
+        }
+        const R len = (R)laneD(cur.len, j), invLen = (R)laneD(cur.invLen, j);
+        const double lenD = laneD(cur.len, j);
+        const int nEv = __builtin_amdgcn_readlane(cur.evCount, j);
+
+        const R eSoilC = (R)soilC, eLitter = (R)litterC, eMinN = (R)minN, eSoilOrgN = (R)soilOrgN;
+        const R eLitterN = (R)litterN, eStorN = (R)storN;
+        const double minN0 = minN;   // the value C has been given for this step's limitation test
+        double wMoist, wAnoxic;
+        takeR2(&mailWat[t & 3][0][lane], &mailWat[t & 3][1][lane], &seqWat, t, wMoist, wAnoxic);
+        const R moistEff = (R)wMoist, anoxic = (R)wAnoxic;
+        // cn = kCN / (kCN + C/N) = kCN N / (kCN N + C), N floored at TINY (util.c:72-75)
+        const R denLitterN = eLitterN < R(kTiny) ? R(kTiny) : eLitterN;
+        const R denSoilN = eSoilOrgN < R(kTiny) ? R(kTiny) : eSoilOrgN;
+        const R cnSoil = fdiv(G_kCN * denSoilN, G_kCN * denSoilN + eSoilC);
+        const R cnLitter = fdiv(G_kCN * denLitterN, G_kCN * denLitterN + eLitter);
+        const R rSoil = eSoilC * (qSoilT * moistEff) * cnSoil;
+        const R breakdown = eLitter * G_lbr * (qSoilT * (R(1) / K_bsr)) * moistEff * cnLitter;
+        const R rLitter = breakdown * G_flr;
+        const R litterToSoil = breakdown * (R(1) - G_flr);
+        R mMoist = anoxic * anoxic;  // pow(A, anaerobicTransExp) with the usual exponent 2
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(G_anExp != R(2)) != 0, 0)) {
+          const bool general = G_anExp != R(2) && (anoxic > R(0) || G_anExp <= R(0));
+          mMoist = general ? fpow(anoxic, G_anExp) : (G_anExp != R(2) ? R(0) : mMoist);
+        }
+        const R soilMethane = G_soilCH4 * eSoilC * qSoil * mMoist;
+        const R litterMethane = G_litCH4 * eLitter * qSoil * mMoist;
+        // R_h goes to C at once (its NEE needs it at the END of its step)
+        postD(&mailRh[t & 1][lane], 0, (double)(rLitter + rSoil));
+        postFlag(&seqRh, t);
+
+        // ---- the plants' side of the step (C posts it early in its step) and the nitrogen block
+        double pLeafLitter, pWoodLitter, pFineLoss, pCoarseLoss, pDemand, pReduction, pLeafOnAll, pLeafOn;
+        takeD8(&mailPlant[0][lane], &seqPlant, t, pLeafLitter, pWoodLitter, pFineLoss, pCoarseLoss, pDemand,
+               pReduction, pLeafOnAll, pLeafOn);
+        const R leafLitter = (R)pLeafLitter, woodLitter = (R)pWoodLitter, fineRootLoss = (R)pFineLoss;
+        const R coarseRootLoss = (R)pCoarseLoss, reductionN = (R)pReduction, leafOnN = (R)pLeafOn;
+        R nDemand = (R)pDemand, evMinN = 0;
+        if (__builtin_expect(nEv > 0, 0)) {  // the soil side of this step's events, worked out by C (it has the plants)
+          double eLit, eSoil, eMin, eOrg, eLitN, eStor;
+          takeD6(&mailEvent[0][lane], &seqEvent, t, eLit, eSoil, eMin, eOrg, eLitN, eStor);
+          evMinN = (R)eMin;
+          litterC += (double)((R)eLit * len);
+          soilC += (double)((R)eSoil * len);
+          minN += (double)(evMinN * len);
+          soilOrgN += (double)((R)eOrg * len);
+          litterN += (double)((R)eLitN * len);
+          storN += (double)((R)eStor * len);
+        }
+        // unclaimed storage nitrogen.c:127-134, fixation share nitrogen.c:137-152
+        const R unclaimed = rmax0(eStorN - (R)pLeafOnAll * len);
+        const R fixDen = G_halfNFix + eMinN;
+        const R fixFrac = G_nFixMax * ((fixDen < R(kTiny)) ? R(1) : fdiv(G_halfNFix, fixDen));
+        const R leafOffNResorption = G_resorb * leafLitter * G_iLeafCN;
+        // pool fluxes, nitrogen.c:45-82: x / (C/N) = x * N / C
+        const R iLitterCN = fdiv(denLitterN, eLitter), iSoilCN = fdiv(denSoilN, eSoilC);
+        const R litterMin = rLitter * iLitterCN, soilMin = rSoil * iSoilCN;
+        const R soilNInputs = litterToSoil * iLitterCN + fineRootLoss * G_iFineCN + coarseRootLoss * G_iWoodCN;
+        const R nOrgLitter = leafLitter * G_iLeafCN - leafOffNResorption + woodLitter * G_iWoodCN - litterMin -
+                             litterToSoil * iLitterCN;
+        const R nOrgSoil = soilNInputs - soilMin;
+        const R nMin = litterMin + soilMin;
+        // volatilisation nitrogen.c:15-26, leaching nitrogen.c:31-41 (the leached share is wave W's:
+        // it has the drainage -- by day only after the photosynthesis hand-over, unless the soil cannot
+        // fill up in this step)
+        R nVolatilization = G_nVol * eMinN * qSoil * (R(0.05) + R(3.8) * anoxic * (R(1) - anoxic));
+        double wLeach;
+        takeD1(&mailWat[t & 3][2][lane], &seqLeach, t, wLeach);
+        R nLeaching = eMinN * (R)wLeach * G_nLeach;
+        // checkMineralNLimitation, limitations.c:119-129
+        {
+          const R pool = eMinN + (nMin + evMinN) * len;
+          const R loss = (nLeaching + nVolatilization) * len;
+          if (__builtin_expect(__builtin_amdgcn_ballot_w64(loss > R(kTiny) && loss > pool) != 0, 0)) {
+            const R red = (loss > R(kTiny) && loss > pool) ? fdiv(pool, loss) : R(1);
+            nLeaching *= red;
+            nVolatilization *= red;
+          }
+        }
+        // checkNitrogenLimitation, limitations.c:69-114: nobody is limited where the cheap test both
+        // waves make holds; otherwise C gets the exact supply, scales its creation fluxes and answers
+        // with the demand that is left
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!nPlentiful(minN0, (double)qSoil, lenD, G_nVolD, G_nLeachD, pDemand)) != 0, 0)) {
+          const R availableMinN = eMinN + (nMin - nVolatilization - nLeaching) * len;
+          postD(&mailSupply[0][lane], 0, (double)availableMinN);
+          postD(&mailSupply[0][lane], 1, (double)fixFrac);
+          postD(&mailSupply[0][lane], 2, (double)unclaimed);
+          postFlag(&seqSupply, t);
+          double dFinal;
+          takeD1(&mailDemand[0][lane], &seqDemand, t, dFinal);
+          nDemand = (R)dFinal;
+        }
+        // fixation and uptake, nitrogen.c:155-168
+        const R rem = rmax0(nDemand - unclaimed * invLen);
+        const R nFixation = fixFrac * rem, nUptake = (R(1) - fixFrac) * rem;
+        // updateNitrogenPools(), nitrogen.c:210-239
+        const R storageDemand = nDemand - nUptake - nFixation;
+        storN += (double)((leafOffNResorption + reductionN - storageDemand - leafOnN) * len);
+        minN += (double)(((nMin - nVolatilization - nLeaching) - nUptake) * len);
+        soilOrgN += (double)(nOrgSoil * len);
+        litterN += (double)(nOrgLitter * len);
+        minN = rmax0(minN);   // (plant death, which comes later in the step, does not touch this pool)
+        postD(&mailMinN[(t + 1) & 1][lane], 0, minN);
+        postFlag(&seqMinN, t + 1);
+        // updatePoolsForSoil(), sipnet.c:1645-1668 (litter pool on, no carbon saturation)
+        const R soilInputs = coarseRootLoss + fineRootLoss + litterToSoil;
+        litterC += (double)((woodLitter + leafLitter - litterToSoil - rLitter - litterMethane) * len);
+        soilC += (double)((soilInputs - rSoil - soilMethane) * len);
+
+        // the end of C's step: its mortality verdict (one word per lane) and, where a stand died, what its
+        // biomass adds to these pools (sipnet.c:1688-1767); then ensureNonNegativeStocks() for them
+        int w;
+        do {
+          asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(w) : "v"(ldsAddr(&mailAlive[(t + 1) & 1][lane])) : "memory");
+        } while (uni(w < 0 ? -w : w) < t + 3);
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(w < 0) != 0, 0)) {
+          double d0, d1, d2, d3;
+          asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:512\n\tds_read_b64 %2, %4 offset:1024\n\t"
+                       "ds_read_b64 %3, %4 offset:1536\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3) : "v"(ldsAddr(&mailDeath[0][lane])) : "memory");
+          if (w < 0) {
+            soilC += d0;
+            litterC += d1;
+            soilOrgN += d2;
+            litterN += d3 + storN;
+            storN = 0.0;
+          }
+        }
+        soilC = rmax0(soilC);
+        litterC = rmax0(litterC);
+        soilOrgN = rmax0(soilOrgN);
+        litterN = rmax0(litterN);
+        storN = rmax0(storN);
+        postD(&mailStorN[(t + 1) & 1][lane], 0, storN);
+        postFlag(&seqStorN, t + 1);
+        qSoil = qSoilN;
+        qSoilT = qSoilTN;
+      }
+      cur = nxt;
+    }
+    if (act) {
+      ST(soilC) = soilC;
+      ST(litterC) = litterC;
+      ST(minN) = minN;
+      ST(soilOrgN) = soilOrgN;
+      ST(litterN) = litterN;
+      ST(plantStorageN) = storN;
+    }
+    return;
+  }
+
+  // =============================================================================================
   // ---- F (one workgroup per CU only: the CU's fourth SIMD is free): the climate / parameter part
   // of wave C's respiration terms (vegResp sipnet.c:1051-1068, calcRootResp :1073,
   // calcSoilRespiration :1132-1148 with depeffects.c:71-74):  folResp = leafC * g1,
@@ -728,7 +977,6 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
           haveQ = true;
         }
         const R qSoilT = K_bsr * qSoil * tillP1;
-        if (NCyc) postRaw(&mailFac[t & 1][6][lane], qSoil);   // before the flag post5 sets
         post5(&mailFac[t & 1][0][lane], &seqFac, g1, g2, qSoilT, gFine, gCoarse, t);
       }
       cur = nxt;
@@ -879,28 +1127,12 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
     const R K_moistExp = (R)PRM(soilRespMoistEffect);
     double soilWater = ST(soilWater), snow = ST(snow);
     double totGpp = ST(totGpp);  // GPP is this wave's own product: it stores the plane and keeps the total
-    // NCyc: the soil side (step_fast.hip's Generic block with the nitrogen-cycle flag set; same
-    // conventions: reciprocal C:N ratios, x / (C/N) = x N / C, divisions through v_rcp + Newton)
-    const R G_lbr = NCyc ? (R)PRM(litterBreakdownRate) : R(0), G_flr = NCyc ? (R)PRM(fracLitterRespired) : R(0);
-    const R G_nVol = NCyc ? (R)PRM(nVolatilizationFrac) : R(0), G_nLeach = NCyc ? (R)PRM(nLeachingFrac) : R(0);
-    const double G_nVolD = NCyc ? PRM(nVolatilizationFrac) : 0.0, G_nLeachD = NCyc ? PRM(nLeachingFrac) : 0.0;
-    const R G_iLeafCN = NCyc ? (R)(1.0 / PRM(leafCN)) : R(0), G_iWoodCN = NCyc ? (R)(1.0 / PRM(woodCN)) : R(0);
-    const R G_iFineCN = NCyc ? (R)(1.0 / PRM(fineRootCN)) : R(0);
-    const R G_kCN = NCyc ? (R)PRM(kCN) : R(0), G_nFixMax = NCyc ? (R)PRM(nFixationFracMax) : R(0);
-    const R G_halfNFix = NCyc ? (R)PRM(halfNFixationMax) : R(0), G_resorb = NCyc ? (R)PRM(leafNResorptionFrac) : R(0);
+    // NCyc: what wave S needs of the soil water -- the anaerobic moisture effect and the anoxic share
+    // (depeffects.c:46-57, :89-96) at the start of a step, the leached share of the mineral nitrogen
+    // (nitrogen.c:31-41) once the drainage is known
     const R G_fAnox = NCyc ? (R)PRM(fAnoxia) : R(0), G_iFAnox = NCyc ? (R)(1.0 / PRM(fAnoxia)) : R(0);
     const R G_iOneMinusAnox = NCyc ? (R)(1.0 / (1.0 - PRM(fAnoxia))) : R(0);
-    const R G_anDecomp = NCyc ? (R)PRM(anaerobicDecompRate) : R(0), G_anExp = NCyc ? (R)PRM(anaerobicTransExp) : R(0);
-    const R G_soilCH4 = NCyc ? (R)PRM(soilMethaneRate) : R(0), G_litCH4 = NCyc ? (R)PRM(litterMethaneRate) : R(0);
-    const R K_iBsr = NCyc ? (R)(1.0 / PRM(baseSoilResp)) : R(0);
-    double soilC = NCyc ? ST(soilC) : 0.0, litterC = NCyc ? ST(litterC) : 0.0, minN = NCyc ? ST(minN) : 0.0;
-    double soilOrgN = NCyc ? ST(soilOrgN) : 0.0, litterN = NCyc ? ST(litterN) : 0.0, storN = NCyc ? ST(plantStorageN) : 0.0;
-    if (NCyc) {  // what C needs of this wave's pools at the start of the first step
-      postD(&mailMinN[tBegin & 1][lane], 0, minN);
-      postFlag(&seqMinN, tBegin);
-      postD(&mailStorN[tBegin & 1][lane], 0, storN);
-      postFlag(&seqStorN, tBegin);
-    }
+    const R G_anDecomp = NCyc ? (R)PRM(anaerobicDecompRate) : R(0);
     R* __restrict__ oEt = (R*)(a.et ? a.et : a.scratchRow) + col;
     R* __restrict__ oGpp = (R*)(a.gpp ? a.gpp : a.scratchRow) + col;
     const int64_t ldEt = a.et ? a.ld : 0, ldGpp = a.gpp ? a.ld : 0;
@@ -948,39 +1180,14 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
           moistEff = (bits & FAST_TSOIL_NEG) ? R(1) : moistEff;
           post(&mailFac[t & 1][5][lane], &seqMoist, moistEff, t);
         }
-        // ---- NCyc: heterotrophic respiration, litter breakdown, methane (sipnet.c:1132-1171, :1201-1214,
-        // depeffects.c:23-96) from this wave's pools; R_h goes to C at once (its NEE needs it at the END
-        // of its step)
-        const R eSoilC = (R)soilC, eLitter = (R)litterC, eMinN = (R)minN, eSoilOrgN = (R)soilOrgN;
-        const R eLitterN = (R)litterN, eStorN = (R)storN;
-        const double minN0 = minN;   // the value C has been given for this step's limitation test
-        R anoxic = 0, qSoil = 0, rSoil = 0, rLitter = 0, litterToSoil = 0, soilMethane = 0, litterMethane = 0;
-        R denLitterN = 0, denSoilN = 0;
         if (NCyc) {
           const R fWhc = clip01(eWater * K_invWhc);
-          anoxic = clip01((fWhc - G_fAnox) * G_iOneMinusAnox);
+          const R anoxic = clip01((fWhc - G_fAnox) * G_iOneMinusAnox);
           R moistEff = (R(1) - anoxic) * clip01(fWhc * G_iFAnox) + G_anDecomp * anoxic;
           moistEff = (bits & FAST_TSOIL_NEG) ? R(1) : moistEff;
-          R qSoilT;
-          takeR2(&mailFac[t & 1][2][lane], &mailFac[t & 1][6][lane], &seqFac, t, qSoilT, qSoil);
-          // cn = kCN / (kCN + C/N) = kCN N / (kCN N + C), N floored at TINY (util.c:72-75)
-          denLitterN = eLitterN < R(kTiny) ? R(kTiny) : eLitterN;
-          denSoilN = eSoilOrgN < R(kTiny) ? R(kTiny) : eSoilOrgN;
-          const R cnSoil = fdiv(G_kCN * denSoilN, G_kCN * denSoilN + eSoilC);
-          const R cnLitter = fdiv(G_kCN * denLitterN, G_kCN * denLitterN + eLitter);
-          rSoil = eSoilC * (qSoilT * moistEff) * cnSoil;
-          const R breakdown = eLitter * G_lbr * (qSoilT * K_iBsr) * moistEff * cnLitter;
-          rLitter = breakdown * G_flr;
-          litterToSoil = breakdown * (R(1) - G_flr);
-          R mMoist = anoxic * anoxic;  // pow(A, anaerobicTransExp) with the usual exponent 2
-          if (__builtin_expect(__builtin_amdgcn_ballot_w64(G_anExp != R(2)) != 0, 0)) {
-            const bool general = G_anExp != R(2) && (anoxic > R(0) || G_anExp <= R(0));
-            mMoist = general ? fpow(anoxic, G_anExp) : (G_anExp != R(2) ? R(0) : mMoist);
-          }
-          soilMethane = G_soilCH4 * eSoilC * qSoil * mMoist;
-          litterMethane = G_litCH4 * eLitter * qSoil * mMoist;
-          postD(&mailRh[t & 1][lane], 0, (double)(rLitter + rSoil));
-          postFlag(&seqRh, t);
+          postD(&mailWat[t & 3][0][lane], 0, (double)moistEff);
+          postD(&mailWat[t & 3][0][lane], 1, (double)anoxic);
+          postFlag(&seqWat, t);
         }
 
         // everything that does not need the light block first
@@ -1009,91 +1216,18 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         R removable = rminv(eWater, K_whc) * K_wrf;
         removable = frozen ? removable * K_frozEff : removable;
 
-        // ---- NCyc: nitrogen.c:15-239 with limitations.c:69-139, the litter / soil carbon and the nitrogen
-        // pools (sipnet.c:1645-1668, nitrogen.c:210-239).  Needs C's litter fluxes and demand of this step
-        // (posted early in C's step) and the drainage, which by day is known only after the photosynthesis
+        // NCyc: the leached share needs the drainage, which by day is known only after the photosynthesis
         // hand-over -- unless the soil cannot reach its holding capacity in this step whatever the plants
-        // take (the common case, decided for the wavefront): then the block runs BEFORE that hand-over and
-        // C finds next step's mineral nitrogen waiting.
-        auto nBlock = [&](R drainage) {
-          double pLeafLitter, pWoodLitter, pFineLoss, pCoarseLoss, pDemand, pReduction, pLeafOnAll, pLeafOn;
-          takeD8(&mailPlant[0][lane], &seqPlant, t, pLeafLitter, pWoodLitter, pFineLoss, pCoarseLoss, pDemand,
-                 pReduction, pLeafOnAll, pLeafOn);
-          const R leafLitter = (R)pLeafLitter, woodLitter = (R)pWoodLitter, fineRootLoss = (R)pFineLoss;
-          const R coarseRootLoss = (R)pCoarseLoss, reductionN = (R)pReduction, leafOnN = (R)pLeafOn;
-          R nDemand = (R)pDemand, evMinN = 0;
-          if (__builtin_expect(nEv > 0, 0)) {  // the soil side of this step's events, worked out by C (it has the plants)
-            double eLit, eSoil, eMin, eOrg, eLitN, eStor;
-            takeD6(&mailEvent[0][lane], &seqEvent, t, eLit, eSoil, eMin, eOrg, eLitN, eStor);
-            evMinN = (R)eMin;
-            litterC += (double)((R)eLit * len);
-            soilC += (double)((R)eSoil * len);
-            minN += (double)(evMinN * len);
-            soilOrgN += (double)((R)eOrg * len);
-            litterN += (double)((R)eLitN * len);
-            storN += (double)((R)eStor * len);
-          }
-          // unclaimed storage nitrogen.c:127-134, fixation share nitrogen.c:137-152
-          const R unclaimed = rmax0(eStorN - (R)pLeafOnAll * len);
-          const R fixDen = G_halfNFix + eMinN;
-          const R fixFrac = G_nFixMax * ((fixDen < R(kTiny)) ? R(1) : fdiv(G_halfNFix, fixDen));
-          const R leafOffNResorption = G_resorb * leafLitter * G_iLeafCN;
-          // volatilisation nitrogen.c:15-26, leaching nitrogen.c:31-41
-          R nVolatilization = G_nVol * eMinN * qSoil * (R(0.05) + R(3.8) * anoxic * (R(1) - anoxic));
-          R nLeaching = eMinN * rminv(drainage * K_invWhc, R(1)) * G_nLeach;
-          // pool fluxes, nitrogen.c:45-82: x / (C/N) = x * N / C
-          const R iLitterCN = fdiv(denLitterN, eLitter), iSoilCN = fdiv(denSoilN, eSoilC);
-          const R litterMin = rLitter * iLitterCN, soilMin = rSoil * iSoilCN;
-          const R soilNInputs = litterToSoil * iLitterCN + fineRootLoss * G_iFineCN + coarseRootLoss * G_iWoodCN;
-          const R nOrgLitter = leafLitter * G_iLeafCN - leafOffNResorption + woodLitter * G_iWoodCN - litterMin -
-                               litterToSoil * iLitterCN;
-          const R nOrgSoil = soilNInputs - soilMin;
-          const R nMin = litterMin + soilMin;
-          // checkMineralNLimitation, limitations.c:119-129
-          {
-            const R pool = eMinN + (nMin + evMinN) * len;
-            const R loss = (nLeaching + nVolatilization) * len;
-            const R red = (loss > R(kTiny) && loss > pool) ? fdiv(pool, loss) : R(1);
-            nLeaching *= red;
-            nVolatilization *= red;
-          }
-          // checkNitrogenLimitation, limitations.c:69-114: nobody is limited where the cheap test both
-          // waves make holds; otherwise C gets the exact supply, scales its creation fluxes and answers
-          // with the demand that is left
-          if (__builtin_expect(__builtin_amdgcn_ballot_w64(!nPlentiful(minN0, (double)qSoil, (double)len, G_nVolD, G_nLeachD,
-                                                                         pDemand)) != 0, 0)) {
-            const R availableMinN = eMinN + (nMin - nVolatilization - nLeaching) * len;
-            postD(&mailSupply[0][lane], 0, (double)availableMinN);
-            postD(&mailSupply[0][lane], 1, (double)fixFrac);
-            postD(&mailSupply[0][lane], 2, (double)unclaimed);
-            postFlag(&seqSupply, t);
-            double dFinal;
-            takeD1(&mailDemand[0][lane], &seqDemand, t, dFinal);
-            nDemand = (R)dFinal;
-          }
-          // fixation and uptake, nitrogen.c:155-168
-          const R rem = rmax0(nDemand - unclaimed * invLen);
-          const R nFixation = fixFrac * rem, nUptake = (R(1) - fixFrac) * rem;
-          // updateNitrogenPools(), nitrogen.c:210-239
-          const R storageDemand = nDemand - nUptake - nFixation;
-          storN += (double)((leafOffNResorption + reductionN - storageDemand - leafOnN) * len);
-          minN += (double)(((nMin - nVolatilization - nLeaching) - nUptake) * len);
-          soilOrgN += (double)(nOrgSoil * len);
-          litterN += (double)(nOrgLitter * len);
-          minN = rmax0(minN);   // (plant death, which comes later in the step, does not touch this pool)
-          postD(&mailMinN[(t + 1) & 1][lane], 0, minN);
-          postFlag(&seqMinN, t + 1);
-          // updatePoolsForSoil(), sipnet.c:1645-1668 (litter pool on, no carbon saturation)
-          const R soilInputs = coarseRootLoss + fineRootLoss + litterToSoil;
-          litterC += (double)((woodLitter + leafLitter - litterToSoil - rLitter - litterMethane) * len);
-          soilC += (double)((soilInputs - rSoil - soilMethane) * len);
-        };
-        bool nDone = false;
+        // take (the common case, decided for the wavefront): then it is zero and wave S gets it now
+        bool leachPosted = false;
         if (NCyc) {
           R netIn0 = netRain + snowMelt;
           netIn0 -= netIn0 * K_ff;
-          nDone = __builtin_amdgcn_ballot_w64(!(eWater + netIn0 * len <= K_whc)) == 0;
-          if (nDone) nBlock(R(0));
+          leachPosted = __builtin_amdgcn_ballot_w64(!(eWater + netIn0 * len <= K_whc)) == 0;
+          if (leachPosted) {
+            postD(&mailWat[t & 3][0][lane], 2, 0.0);
+            postFlag(&seqLeach, t);
+          }
         }
 
         // moisture(), sipnet.c:656-699, with the potential photosynthesis of wave L
@@ -1141,7 +1275,10 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
           }
           soilWater += (double)(evSoilWater * len);
         }
-        if (NCyc && !nDone) nBlock(drainage);
+        if (NCyc && !leachPosted) {
+          postD(&mailWat[t & 3][0][lane], 2, (double)rminv(drainage * K_invWhc, R(1)));
+          postFlag(&seqLeach, t);
+        }
         soilWater += (double)((rain + snowMelt - immedEvap - fastFlow - evaporation -
                                transpiration - drainage) * len);
         snow += (double)((snowFall - snowMelt - sublimation) * len);
@@ -1155,37 +1292,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         // never run more than one step ahead of C (the mailboxes have two slots): C is past the
         // pools of step t-1 once it has posted lai(t).  By day that is implied: this wave has taken
         // pgp(t), which wave L computed from lai(t)
-        if (NCyc) {
-          // the end of C's step: its mortality verdict (one word per lane; it follows the leaf area of
-          // step t + 1, so this is also the throttle) and, where a stand died, what its biomass adds to
-          // this wave's pools (sipnet.c:1688-1767); then ensureNonNegativeStocks() for them
-          int w;
-          WAIT_BEGIN()
-          do {
-            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(w) : "v"(ldsAddr(&mailAlive[(t + 1) & 1][lane])) : "memory");
-          } while (uni(w < 0 ? -w : w) < t + 3);
-          WAIT_END(1)
-          if (__builtin_expect(__builtin_amdgcn_ballot_w64(w < 0) != 0, 0)) {
-            double d0, d1, d2, d3;
-            asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:512\n\tds_read_b64 %2, %4 offset:1024\n\t"
-                         "ds_read_b64 %3, %4 offset:1536\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3) : "v"(ldsAddr(&mailDeath[0][lane])) : "memory");
-            if (w < 0) {
-              soilC += d0;
-              litterC += d1;
-              soilOrgN += d2;
-              litterN += d3 + storN;
-              storN = 0.0;
-            }
-          }
-          soilC = rmax0(soilC);
-          litterC = rmax0(litterC);
-          soilOrgN = rmax0(soilOrgN);
-          litterN = rmax0(litterN);
-          storN = rmax0(storN);
-          postD(&mailStorN[(t + 1) & 1][lane], 0, storN);
-          postFlag(&seqStorN, t + 1);
-        } else if (!(bits & FAST_PAR_POS)) {
+        if (!(bits & FAST_PAR_POS)) {
           WAIT_BEGIN()
           awaitAtLeast(&seqLai, t);
           WAIT_END(1)
@@ -1224,14 +1331,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
       ST(soilWater) = soilWater;
       ST(snow) = snow;
       ST(totGpp) = totGpp;
-      if (NCyc) {
-        ST(soilC) = soilC;
-        ST(litterC) = litterC;
-        ST(minN) = minN;
-        ST(soilOrgN) = soilOrgN;
-        ST(litterN) = litterN;
-        ST(plantStorageN) = storN;
-      }
+
       if (wantDiagW && clampWarnW) atomicAdd(a.diag + col, (double)clampWarnW);
     }
     return;
@@ -2156,8 +2256,8 @@ void launchStepCoop(const FastArgs& a, int precision, int layout, hipStream_t st
       info->block = 256;
       info->wavesPerSimd = 1;
       const int elem = precision == SIPNET_F64 ? 8 : 4;
-      info->ldsBytes = 3 * 2 * kTileBytes + (2 * 64 * 3 + 2 * 7 * 64) * elem + 2 * 64 * 4 + 14 * 4 + 64 * 8 +
-                       (8 + 2 + 2 + 2 + 6 + 4 + 3 + 1) * 64 * 8;
+      info->ldsBytes = 3 * 2 * kTileBytes + (2 * 64 * 3 + 2 * 7 * 64) * elem + 2 * 64 * 4 + 16 * 4 + 64 * 8 +
+                       (8 + 2 + 2 + 2 + 6 + 4 + 3 + 1 + 12) * 64 * 8;
     }
     return;
   }

@@ -44,6 +44,8 @@ def compare(tag, got, state, want, final):
     scale = np.maximum(np.abs(pools_o), 1e-3)
     dp = (np.abs(pools_g - pools_o) / scale).max()
     print(f"{tag}: max|d planes| {d:.3e}  max rel d pools {dp:.3e}")
+    per_pool = (np.abs(pools_g - pools_o) / scale).max(axis=0)     # Envi order, state.h:416-463
+    print("   per pool:", " ".join(f"{v:.1e}" for v in per_pool), " worst member", int((np.abs(pools_g - pools_o) / scale).max(axis=1).argmax()))
     assert np.isfinite(got).all()
     assert d < 1e-9
     assert dp < 1e-9
