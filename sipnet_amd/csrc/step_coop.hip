@@ -165,6 +165,36 @@ __device__ __forceinline__ void takeFactors(const float* block, const int* flags
   } while (uni(f.x < f.y ? f.x : f.y) < step);
   g1 = a.x; g2 = a.y; qSoilT = b.x; gFine = b.y; gCoarse = c.x; moist = c.y;
 }
+// NCyc, wave C: rows 0 1 | 3 4 | 6 of the factor block behind wave L's flag and wave S's mineral nitrogen
+// behind its own, one round trip
+__device__ __forceinline__ void takeFactorsN(const double* block, const int* facFlag, const double* minNSlot, const int* minNFlag,
+                                             int step, double& g1, double& g2, double& gFine, double& gCoarse, double& qSoil,
+                                             double& minN) {
+  int f0, f1;
+  d2v a, b;
+  do {
+    asm volatile("ds_read_b32 %0, %6\n\tds_read2st64_b64 %1, %7 offset1:1\n\tds_read2st64_b64 %2, %7 offset0:3 offset1:4\n\t"
+                 "ds_read_b64 %3, %7 offset:3072\n\tds_read_b32 %4, %8\n\tds_read_b64 %5, %9\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(f0), "=&v"(a), "=&v"(b), "=&v"(qSoil), "=&v"(f1), "=&v"(minN)
+                 : "v"((unsigned)(size_t)facFlag), "v"((unsigned)(size_t)block), "v"((unsigned)(size_t)minNFlag),
+                   "v"((unsigned)(size_t)minNSlot) : "memory");
+  } while (uni(f0) < step || uni(f1) < step);
+  g1 = a.x; g2 = a.y; gFine = b.x; gCoarse = b.y;
+}
+__device__ __forceinline__ void takeFactorsN(const float* block, const int* facFlag, const double* minNSlot, const int* minNFlag,
+                                             int step, float& g1, float& g2, float& gFine, float& gCoarse, float& qSoil,
+                                             double& minN) {
+  int f0, f1;
+  f2v a, b;
+  do {
+    asm volatile("ds_read_b32 %0, %6\n\tds_read2st64_b32 %1, %7 offset1:1\n\tds_read2st64_b32 %2, %7 offset0:3 offset1:4\n\t"
+                 "ds_read_b32 %3, %7 offset:1536\n\tds_read_b32 %4, %8\n\tds_read_b64 %5, %9\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(f0), "=&v"(a), "=&v"(b), "=&v"(qSoil), "=&v"(f1), "=&v"(minN)
+                 : "v"((unsigned)(size_t)facFlag), "v"((unsigned)(size_t)block), "v"((unsigned)(size_t)minNFlag),
+                   "v"((unsigned)(size_t)minNSlot) : "memory");
+  } while (uni(f0) < step || uni(f1) < step);
+  g1 = a.x; g2 = a.y; gFine = b.x; gCoarse = b.y;
+}
 // the same with the ring value the step will evict riding in the same round trip (LDS ring, regular
 // tiles: the slot is known at the top of the step, the value is consumed at its end)
 __device__ __forceinline__ void takeFactorsRing(const double* block, const int* flags2, unsigned ringAddr,
@@ -413,10 +443,10 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
 #ifdef SIPNET_NO_FACWAVE
   constexpr bool FacWave = false;
 #else
-  constexpr bool FacWave = RingLds || NCyc;
+  constexpr bool FacWave = RingLds;   // (NCyc: the fourth wavefront is the soil wave S; the factors stay with L)
 #endif
   // per-wave private record tiles (each wave stages and awaits its own DMA) + mailboxes
-  __shared__ alignas(16) unsigned char ldsTilesAll[NP][3][2 * kTileBytes];
+  __shared__ alignas(16) unsigned char ldsTilesAll[NP][NCyc ? 4 : 3][2 * kTileBytes];
   __shared__ R mailLaiAll[NP][2][64], mailPgpAll[NP][2][64], mailPsnAll[NP][2][64];
   // rows 0..4: g1 g2 qSoilT gFine gCoarse of a step (wave L: climate x parameters only); row 5: the
   // soil-moisture effect on heterotrophic respiration (wave W: its state)
@@ -474,7 +504,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
     g_coopHwId[((blockIdx.x * NP + sub) * 4 + role) * 2 + 1] = xcc;
   }
 #endif
-  unsigned char* lds = ldsTilesAll[sub][(role < 0 || role > 2) ? 0 : role];
+  unsigned char* lds = ldsTilesAll[sub][(role < 0 || role > (NCyc ? 3 : 2)) ? 0 : role];
 
   const int chunksPerSite = (a.n_members + 63) >> 6;
   int site, chunk;
@@ -672,247 +702,6 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   };
 
   // =============================================================================================
-  // ---- S (NCyc): wave F's factors, one step ahead, + the soil: heterotrophic respiration, litter
-  // breakdown, methane (sipnet.c:1132-1171, :1201-1214, depeffects.c:23-96), nitrogen.c:15-239 with
-  // limitations.c:69-139, the litter / soil carbon and nitrogen pools (sipnet.c:1645-1668,
-  // nitrogen.c:210-239).  step_fast.hip's Generic block with the nitrogen-cycle flag set, same
-  // conventions: reciprocal C:N ratios, x / (C/N) = x N / C, divisions through v_rcp + Newton.
-  if (NCyc && role == 3) {
-    const R K_frozThr = (R)PRM(frozenSoilThreshold);
-    const R K_lgVeg = (R)log2(PRM(vegRespQ10)), K_lgSoil = (R)log2(PRM(soilRespQ10));
-    const R K_lgFine = (R)log2(PRM(fineRootQ10)), K_lgCoarse = (R)log2(PRM(coarseRootQ10));
-    const R K_fol = (R)((PRM(baseFolRespFrac) * PRM(aMax)) *
-                        (kCWeight * (1.0 / kTen9) * (PRM(leafCSpWt) / PRM(cFracLeaf)) * kSecPerDay) *
-                        (1.0 / PRM(leafCSpWt)) * exp2(-(PRM(psnTOpt) / 10.0) * log2(PRM(vegRespQ10))));
-    const R K_frozFolEff = (R)PRM(frozenSoilFolREff);
-    const R K_bvr = (R)PRM(baseVegResp), K_bsr = (R)PRM(baseSoilResp);
-    const R K_bfr = (R)PRM(baseFineRootResp), K_bcr = (R)PRM(baseCoarseRootResp);
-    const R G_lbr = (R)PRM(litterBreakdownRate), G_flr = (R)PRM(fracLitterRespired);
-    const R G_nVol = (R)PRM(nVolatilizationFrac), G_nLeach = (R)PRM(nLeachingFrac);
-    const double G_nVolD = PRM(nVolatilizationFrac), G_nLeachD = PRM(nLeachingFrac);
-    const R G_iLeafCN = (R)(1.0 / PRM(leafCN)), G_iWoodCN = (R)(1.0 / PRM(woodCN)), G_iFineCN = (R)(1.0 / PRM(fineRootCN));
-    const R G_kCN = (R)PRM(kCN), G_nFixMax = (R)PRM(nFixationFracMax), G_halfNFix = (R)PRM(halfNFixationMax);
-    const R G_resorb = (R)PRM(leafNResorptionFrac), G_anExp = (R)PRM(anaerobicTransExp);
-    const R G_soilCH4 = (R)PRM(soilMethaneRate), G_litCH4 = (R)PRM(litterMethaneRate);
-    double soilC = ST(soilC), litterC = ST(litterC), minN = ST(minN);
-    double soilOrgN = ST(soilOrgN), litterN = ST(litterN), storN = ST(plantStorageN);
-    // what C needs of these pools at the start of the first step
-    postD(&mailMinN[tBegin & 1][lane], 0, minN);
-    postFlag(&seqMinN, tBegin);
-    postD(&mailStorN[tBegin & 1][lane], 0, storN);
-    postFlag(&seqStorN, tBegin);
-
-    const FastRec* __restrict__ recs = (const FastRec*)planBytes;
-    const int lastStep = a.n_steps_total - 1;
-    // no room for a record tile of this wave's own: lane k loads the fields of step 16j + k one tile
-    // ahead, a step's values come back through v_readlane
-    struct TileFields { double tair10, tsoil, tsoil10, tillP1, len, invLen; int bits, evCount; };
-    auto loadFields = [&](int tileStart) {
-      int t = tileStart + (lane & (kFastTile - 1));
-      t = t > lastStep ? lastStep : t;
-      const FastRec* r = recs + t;
-      return TileFields{r->tair10, r->tsoil, r->tsoil10, r->tillP1, r->len, r->invLen, r->bitsOps, r->evCount};
-    };
-    auto laneD = [](double v, int l) {
-      const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
-      const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
-      return __hiloint2double(hi, lo);
-    };
-    R qSoilQ = 0, gFine = 0, gCoarse = 0;   // Q10 factors of the last soil temperature seen
-    bool haveQ = false;
-    // factors of one step (wave F's job, same arithmetic -- contraction off like there), posted to C;
-    // returns the two this wave needs itself for that step
-    auto factorsOf = [&](const TileFields& f, int j, int tt, R& qSoilOut, R& qSoilTOut) {
-#pragma clang fp contract(off)
-      const R tair10 = (R)laneD(f.tair10, j), tsoil = (R)laneD(f.tsoil, j);
-      const R tillP1 = (R)laneD(f.tillP1, j);
-      const int bits = __builtin_amdgcn_readlane(f.bits, j);
-      const R vegQ = fexp2(q10Arg(tair10, K_lgVeg), EC);
-      R g1 = K_fol * vegQ;
-      g1 = (tsoil < K_frozThr) ? g1 * K_frozFolEff : g1;
-      const R g2 = K_bvr * vegQ;
-      if (!haveQ || !(bits & FAST_TSOIL_SAME)) {
-        const R tsoil10 = (R)laneD(f.tsoil10, j);
-        qSoilQ = fexp2(q10Arg(tsoil10, K_lgSoil), EC);
-        gFine = K_bfr * fexp2(q10Arg(tsoil10, K_lgFine), EC);
-        gCoarse = K_bcr * fexp2(q10Arg(tsoil10, K_lgCoarse), EC);
-        haveQ = true;
-      }
-      const R qSoilT = K_bsr * qSoilQ * tillP1;
-      postRaw(&mailFac[tt & 1][6][lane], qSoilQ);   // before the flag post5 sets
-      post5(&mailFac[tt & 1][0][lane], &seqFac, g1, g2, qSoilT, gFine, gCoarse, tt);
-      qSoilOut = qSoilQ;
-      qSoilTOut = qSoilT;
-    };
-    int fTile = tBegin / kFastTile;
-    TileFields cur = loadFields(fTile * kFastTile);
-    R qSoil = 0, qSoilT = 0;        // of the step whose soil block runs
-    factorsOf(cur, tBegin - fTile * kFastTile, tBegin, qSoil, qSoilT);
-    for (int tileStart = fTile * kFastTile; tileStart < tEnd; tileStart += kFastTile) {
-      const TileFields nxt = loadFields(tileStart + kFastTile);
-      const int tFirst = tileStart > tBegin ? tileStart : tBegin;
-      const int tLast = (tileStart + kFastTile) < tEnd ? (tileStart + kFastTile) : tEnd;
-      for (int t = tFirst; t < tLast; t++) {
-        const int j = t - tileStart;
-        // next step's factors first (C starts that step with them): its slot was last used for step
-        // t - 1, which C is past once it has posted the leaf area of step t
-        R qSoilN = 0, qSoilTN = 0;
-        if (t + 1 < tEnd) {
-          awaitAtLeast(&seqLai, t);
-          if (j + 1 < kFastTile) factorsOf(cur, j + 1, t + 1, qSoilN, qSoilTN);
-          else factorsOf(nxt, 0, t + 1, qSoilN, qSoilTN);
-        }
-        const R len = (R)laneD(cur.len, j), invLen = (R)laneD(cur.invLen, j);
-        const double lenD = laneD(cur.len, j);
-        const int nEv = __builtin_amdgcn_readlane(cur.evCount, j);
-
-        const R eSoilC = (R)soilC, eLitter = (R)litterC, eMinN = (R)minN, eSoilOrgN = (R)soilOrgN;
-        const R eLitterN = (R)litterN, eStorN = (R)storN;
-        const double minN0 = minN;   // the value C has been given for this step's limitation test
-        double wMoist, wAnoxic;
-        takeR2(&mailWat[t & 3][0][lane], &mailWat[t & 3][1][lane], &seqWat, t, wMoist, wAnoxic);
-        const R moistEff = (R)wMoist, anoxic = (R)wAnoxic;
-        // cn = kCN / (kCN + C/N) = kCN N / (kCN N + C), N floored at TINY (util.c:72-75)
-        const R denLitterN = eLitterN < R(kTiny) ? R(kTiny) : eLitterN;
-        const R denSoilN = eSoilOrgN < R(kTiny) ? R(kTiny) : eSoilOrgN;
-        const R cnSoil = fdiv(G_kCN * denSoilN, G_kCN * denSoilN + eSoilC);
-        const R cnLitter = fdiv(G_kCN * denLitterN, G_kCN * denLitterN + eLitter);
-        const R rSoil = eSoilC * (qSoilT * moistEff) * cnSoil;
-        const R breakdown = eLitter * G_lbr * (qSoilT * (R(1) / K_bsr)) * moistEff * cnLitter;
-        const R rLitter = breakdown * G_flr;
-        const R litterToSoil = breakdown * (R(1) - G_flr);
-        R mMoist = anoxic * anoxic;  // pow(A, anaerobicTransExp) with the usual exponent 2
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(G_anExp != R(2)) != 0, 0)) {
-          const bool general = G_anExp != R(2) && (anoxic > R(0) || G_anExp <= R(0));
-          mMoist = general ? fpow(anoxic, G_anExp) : (G_anExp != R(2) ? R(0) : mMoist);
-        }
-        const R soilMethane = G_soilCH4 * eSoilC * qSoil * mMoist;
-        const R litterMethane = G_litCH4 * eLitter * qSoil * mMoist;
-        // R_h goes to C at once (its NEE needs it at the END of its step)
-        postD(&mailRh[t & 1][lane], 0, (double)(rLitter + rSoil));
-        postFlag(&seqRh, t);
-
-        // ---- the plants' side of the step (C posts it early in its step) and the nitrogen block
-        double pLeafLitter, pWoodLitter, pFineLoss, pCoarseLoss, pDemand, pReduction, pLeafOnAll, pLeafOn;
-        takeD8(&mailPlant[0][lane], &seqPlant, t, pLeafLitter, pWoodLitter, pFineLoss, pCoarseLoss, pDemand,
-               pReduction, pLeafOnAll, pLeafOn);
-        const R leafLitter = (R)pLeafLitter, woodLitter = (R)pWoodLitter, fineRootLoss = (R)pFineLoss;
-        const R coarseRootLoss = (R)pCoarseLoss, reductionN = (R)pReduction, leafOnN = (R)pLeafOn;
-        R nDemand = (R)pDemand, evMinN = 0;
-        if (__builtin_expect(nEv > 0, 0)) {  // the soil side of this step's events, worked out by C (it has the plants)
-          double eLit, eSoil, eMin, eOrg, eLitN, eStor;
-          takeD6(&mailEvent[0][lane], &seqEvent, t, eLit, eSoil, eMin, eOrg, eLitN, eStor);
-          evMinN = (R)eMin;
-          litterC += (double)((R)eLit * len);
-          soilC += (double)((R)eSoil * len);
-          minN += (double)(evMinN * len);
-          soilOrgN += (double)((R)eOrg * len);
-          litterN += (double)((R)eLitN * len);
-          storN += (double)((R)eStor * len);
-        }
-        // unclaimed storage nitrogen.c:127-134, fixation share nitrogen.c:137-152
-        const R unclaimed = rmax0(eStorN - (R)pLeafOnAll * len);
-        const R fixDen = G_halfNFix + eMinN;
-        const R fixFrac = G_nFixMax * ((fixDen < R(kTiny)) ? R(1) : fdiv(G_halfNFix, fixDen));
-        const R leafOffNResorption = G_resorb * leafLitter * G_iLeafCN;
-        // pool fluxes, nitrogen.c:45-82: x / (C/N) = x * N / C
-        const R iLitterCN = fdiv(denLitterN, eLitter), iSoilCN = fdiv(denSoilN, eSoilC);
-        const R litterMin = rLitter * iLitterCN, soilMin = rSoil * iSoilCN;
-        const R soilNInputs = litterToSoil * iLitterCN + fineRootLoss * G_iFineCN + coarseRootLoss * G_iWoodCN;
-        const R nOrgLitter = leafLitter * G_iLeafCN - leafOffNResorption + woodLitter * G_iWoodCN - litterMin -
-                             litterToSoil * iLitterCN;
-        const R nOrgSoil = soilNInputs - soilMin;
-        const R nMin = litterMin + soilMin;
-        // volatilisation nitrogen.c:15-26, leaching nitrogen.c:31-41 (the leached share is wave W's:
-        // it has the drainage -- by day only after the photosynthesis hand-over, unless the soil cannot
-        // fill up in this step)
-        R nVolatilization = G_nVol * eMinN * qSoil * (R(0.05) + R(3.8) * anoxic * (R(1) - anoxic));
-        double wLeach;
-        takeD1(&mailWat[t & 3][2][lane], &seqLeach, t, wLeach);
-        R nLeaching = eMinN * (R)wLeach * G_nLeach;
-        // checkMineralNLimitation, limitations.c:119-129
-        {
-          const R pool = eMinN + (nMin + evMinN) * len;
-          const R loss = (nLeaching + nVolatilization) * len;
-          if (__builtin_expect(__builtin_amdgcn_ballot_w64(loss > R(kTiny) && loss > pool) != 0, 0)) {
-            const R red = (loss > R(kTiny) && loss > pool) ? fdiv(pool, loss) : R(1);
-            nLeaching *= red;
-            nVolatilization *= red;
-          }
-        }
-        // checkNitrogenLimitation, limitations.c:69-114: nobody is limited where the cheap test both
-        // waves make holds; otherwise C gets the exact supply, scales its creation fluxes and answers
-        // with the demand that is left
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!nPlentiful(minN0, (double)qSoil, lenD, G_nVolD, G_nLeachD, pDemand)) != 0, 0)) {
-          const R availableMinN = eMinN + (nMin - nVolatilization - nLeaching) * len;
-          postD(&mailSupply[0][lane], 0, (double)availableMinN);
-          postD(&mailSupply[0][lane], 1, (double)fixFrac);
-          postD(&mailSupply[0][lane], 2, (double)unclaimed);
-          postFlag(&seqSupply, t);
-          double dFinal;
-          takeD1(&mailDemand[0][lane], &seqDemand, t, dFinal);
-          nDemand = (R)dFinal;
-        }
-        // fixation and uptake, nitrogen.c:155-168
-        const R rem = rmax0(nDemand - unclaimed * invLen);
-        const R nFixation = fixFrac * rem, nUptake = (R(1) - fixFrac) * rem;
-        // updateNitrogenPools(), nitrogen.c:210-239
-        const R storageDemand = nDemand - nUptake - nFixation;
-        storN += (double)((leafOffNResorption + reductionN - storageDemand - leafOnN) * len);
-        minN += (double)(((nMin - nVolatilization - nLeaching) - nUptake) * len);
-        soilOrgN += (double)(nOrgSoil * len);
-        litterN += (double)(nOrgLitter * len);
-        minN = rmax0(minN);   // (plant death, which comes later in the step, does not touch this pool)
-        postD(&mailMinN[(t + 1) & 1][lane], 0, minN);
-        postFlag(&seqMinN, t + 1);
-        // updatePoolsForSoil(), sipnet.c:1645-1668 (litter pool on, no carbon saturation)
-        const R soilInputs = coarseRootLoss + fineRootLoss + litterToSoil;
-        litterC += (double)((woodLitter + leafLitter - litterToSoil - rLitter - litterMethane) * len);
-        soilC += (double)((soilInputs - rSoil - soilMethane) * len);
-
-        // the end of C's step: its mortality verdict (one word per lane) and, where a stand died, what its
-        // biomass adds to these pools (sipnet.c:1688-1767); then ensureNonNegativeStocks() for them
-        int w;
-        do {
-          asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(w) : "v"(ldsAddr(&mailAlive[(t + 1) & 1][lane])) : "memory");
-        } while (uni(w < 0 ? -w : w) < t + 3);
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(w < 0) != 0, 0)) {
-          double d0, d1, d2, d3;
-          asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:512\n\tds_read_b64 %2, %4 offset:1024\n\t"
-                       "ds_read_b64 %3, %4 offset:1536\n\ts_waitcnt lgkmcnt(0)"
-                       : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3) : "v"(ldsAddr(&mailDeath[0][lane])) : "memory");
-          if (w < 0) {
-            soilC += d0;
-            litterC += d1;
-            soilOrgN += d2;
-            litterN += d3 + storN;
-            storN = 0.0;
-          }
-        }
-        soilC = rmax0(soilC);
-        litterC = rmax0(litterC);
-        soilOrgN = rmax0(soilOrgN);
-        litterN = rmax0(litterN);
-        storN = rmax0(storN);
-        postD(&mailStorN[(t + 1) & 1][lane], 0, storN);
-        postFlag(&seqStorN, t + 1);
-        qSoil = qSoilN;
-        qSoilT = qSoilTN;
-      }
-      cur = nxt;
-    }
-    if (act) {
-      ST(soilC) = soilC;
-      ST(litterC) = litterC;
-      ST(minN) = minN;
-      ST(soilOrgN) = soilOrgN;
-      ST(litterN) = litterN;
-      ST(plantStorageN) = storN;
-    }
-    return;
-  }
-
-  // =============================================================================================
   // ---- F (one workgroup per CU only: the CU's fourth SIMD is free): the climate / parameter part
   // of wave C's respiration terms (vegResp sipnet.c:1051-1068, calcRootResp :1073,
   // calcSoilRespiration :1132-1148 with depeffects.c:71-74):  folResp = leafC * g1,
@@ -1006,6 +795,220 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   __builtin_amdgcn_s_waitcnt(0);
 
   // =============================================================================================
+  // ---- S (NCyc): the soil -- heterotrophic respiration, litter breakdown, methane (sipnet.c:1132-1171,
+  // :1201-1214, depeffects.c:23-96), nitrogen.c:15-239 with limitations.c:69-139, the litter / soil
+  // carbon and nitrogen pools (sipnet.c:1645-1668, nitrogen.c:210-239).  step_fast.hip's Generic
+  // block with the nitrogen-cycle flag set, same conventions: reciprocal C:N ratios, x / (C/N) = x N / C,
+  // divisions through v_rcp + Newton.  Of the site record it needs the step length and the event
+  // count only.
+  if (NCyc && role == 3) {
+    const R K_bsr = (R)PRM(baseSoilResp);
+    const R G_lbr = (R)PRM(litterBreakdownRate), G_flr = (R)PRM(fracLitterRespired);
+    const R G_nVol = (R)PRM(nVolatilizationFrac), G_nLeach = (R)PRM(nLeachingFrac);
+    const double G_nVolD = PRM(nVolatilizationFrac), G_nLeachD = PRM(nLeachingFrac);
+    const R G_iLeafCN = (R)(1.0 / PRM(leafCN)), G_iWoodCN = (R)(1.0 / PRM(woodCN)), G_iFineCN = (R)(1.0 / PRM(fineRootCN));
+    const R G_kCN = (R)PRM(kCN), G_nFixMax = (R)PRM(nFixationFracMax), G_halfNFix = (R)PRM(halfNFixationMax);
+    const R G_resorb = (R)PRM(leafNResorptionFrac), G_anExp = (R)PRM(anaerobicTransExp);
+    const R G_soilCH4 = (R)PRM(soilMethaneRate), G_litCH4 = (R)PRM(litterMethaneRate);
+    double soilC = ST(soilC), litterC = ST(litterC), minN = ST(minN);
+    double soilOrgN = ST(soilOrgN), litterN = ST(litterN), storN = ST(plantStorageN);
+    // what C needs of these pools at the start of the first step
+    postD(&mailMinN[tBegin & 1][lane], 0, minN);
+    postFlag(&seqMinN, tBegin);
+    postD(&mailStorN[tBegin & 1][lane], 0, storN);
+    postFlag(&seqStorN, tBegin);
+
+    WAIT_DECL()
+    for (int tileStart = curTile * kFastTile; tileStart < tEnd; tileStart += kFastTile, curTile++) {
+      if (tileStart > tBegin) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMA of 16 steps ago
+      stageTile(curTile + 1, (curTile + 1) & 1);
+      const int tFirst = tileStart > tBegin ? tileStart : tBegin;
+      const int tLast = (tileStart + kFastTile) < tEnd ? (tileStart + kFastTile) : tEnd;
+      const unsigned char* recB = lds + (curTile & 1) * kTileBytes +
+                                  (int)(tFirst - tileFirst(curTile)) * (int)sizeof(FastRec);
+      for (int t = tFirst; t < tLast; t++, recB += sizeof(FastRec)) {
+        d2 q0;
+        int nEvV;
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b32 %1, %2 offset:140\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(q0), "=&v"(nEvV) : "v"(ldsAddr(recB)) : "memory");
+        const R len = (R)q0.x, invLen = (R)q0.y;
+        const double lenD = q0.x;
+        const int nEv = uni(nEvV);
+
+        const R eSoilC = (R)soilC, eLitter = (R)litterC, eMinN = (R)minN, eSoilOrgN = (R)soilOrgN;
+        const R eLitterN = (R)litterN, eStorN = (R)storN;
+        const double minN0 = minN;   // the value C has been given for this step's limitation test
+        // wave L's soil-temperature factors of this step (the tillage-scaled one and the plain one) and
+        // wave W's moisture terms, each pair behind its flag, one round trip
+        double wMoist, wAnoxic;
+        R qSoilT, qSoil;
+        {
+          WAIT_BEGIN()
+          int fSeq, wSeq;
+          do {
+            if (sizeof(R) == 8)
+              asm volatile("ds_read_b32 %0, %6\n\tds_read_b64 %1, %7\n\tds_read_b64 %2, %7 offset:2048\n\t"
+                           "ds_read_b32 %3, %8\n\tds_read_b64 %4, %9\n\tds_read_b64 %5, %9 offset:512\n\ts_waitcnt lgkmcnt(0)"
+                           : "=&v"(fSeq), "=&v"(qSoilT), "=&v"(qSoil), "=&v"(wSeq), "=&v"(wMoist), "=&v"(wAnoxic)
+                           : "v"(ldsAddr(&seqFac)), "v"(ldsAddr(&mailFac[t & 1][2][lane])), "v"(ldsAddr(&seqWat)),
+                             "v"(ldsAddr(&mailWat[t & 3][0][lane])) : "memory");
+            else
+              asm volatile("ds_read_b32 %0, %6\n\tds_read_b32 %1, %7\n\tds_read_b32 %2, %7 offset:1024\n\t"
+                           "ds_read_b32 %3, %8\n\tds_read_b64 %4, %9\n\tds_read_b64 %5, %9 offset:512\n\ts_waitcnt lgkmcnt(0)"
+                           : "=&v"(fSeq), "=&v"(qSoilT), "=&v"(qSoil), "=&v"(wSeq), "=&v"(wMoist), "=&v"(wAnoxic)
+                           : "v"(ldsAddr(&seqFac)), "v"(ldsAddr(&mailFac[t & 1][2][lane])), "v"(ldsAddr(&seqWat)),
+                             "v"(ldsAddr(&mailWat[t & 3][0][lane])) : "memory");
+          } while (uni(fSeq) < t || uni(wSeq) < t);
+          WAIT_END(0)
+        }
+        const R moistEff = (R)wMoist, anoxic = (R)wAnoxic;
+        // cn = kCN / (kCN + C/N) = kCN N / (kCN N + C), N floored at TINY (util.c:72-75)
+        const R denLitterN = eLitterN < R(kTiny) ? R(kTiny) : eLitterN;
+        const R denSoilN = eSoilOrgN < R(kTiny) ? R(kTiny) : eSoilOrgN;
+        const R cnSoil = fdiv(G_kCN * denSoilN, G_kCN * denSoilN + eSoilC);
+        const R cnLitter = fdiv(G_kCN * denLitterN, G_kCN * denLitterN + eLitter);
+        const R rSoil = eSoilC * (qSoilT * moistEff) * cnSoil;
+        const R breakdown = eLitter * G_lbr * (qSoilT * (R(1) / K_bsr)) * moistEff * cnLitter;
+        const R rLitter = breakdown * G_flr;
+        const R litterToSoil = breakdown * (R(1) - G_flr);
+        R mMoist = anoxic * anoxic;  // pow(A, anaerobicTransExp) with the usual exponent 2
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(G_anExp != R(2)) != 0, 0)) {
+          const bool general = G_anExp != R(2) && (anoxic > R(0) || G_anExp <= R(0));
+          mMoist = general ? fpow(anoxic, G_anExp) : (G_anExp != R(2) ? R(0) : mMoist);
+        }
+        const R soilMethane = G_soilCH4 * eSoilC * qSoil * mMoist;
+        const R litterMethane = G_litCH4 * eLitter * qSoil * mMoist;
+        // R_h goes to C at once (its NEE needs it at the END of its step)
+        postD(&mailRh[t & 1][lane], 0, (double)(rLitter + rSoil));
+        postFlag(&seqRh, t);
+
+        // ---- the plants' side of the step (C posts it early in its step) and the nitrogen block
+        double pLeafLitter, pWoodLitter, pFineLoss, pCoarseLoss, pDemand, pReduction, pLeafOnAll, pLeafOn;
+        {
+          WAIT_BEGIN()
+          takeD8(&mailPlant[0][lane], &seqPlant, t, pLeafLitter, pWoodLitter, pFineLoss, pCoarseLoss, pDemand,
+                 pReduction, pLeafOnAll, pLeafOn);
+          WAIT_END(1)
+        }
+        const R leafLitter = (R)pLeafLitter, woodLitter = (R)pWoodLitter, fineRootLoss = (R)pFineLoss;
+        const R coarseRootLoss = (R)pCoarseLoss, reductionN = (R)pReduction, leafOnN = (R)pLeafOn;
+        R nDemand = (R)pDemand, evMinN = 0;
+        if (__builtin_expect(nEv > 0, 0)) {  // the soil side of this step's events, worked out by C (it has the plants)
+          double eLit, eSoil, eMin, eOrg, eLitN, eStor;
+          takeD6(&mailEvent[0][lane], &seqEvent, t, eLit, eSoil, eMin, eOrg, eLitN, eStor);
+          evMinN = (R)eMin;
+          litterC += (double)((R)eLit * len);
+          soilC += (double)((R)eSoil * len);
+          minN += (double)(evMinN * len);
+          soilOrgN += (double)((R)eOrg * len);
+          litterN += (double)((R)eLitN * len);
+          storN += (double)((R)eStor * len);
+        }
+        // unclaimed storage nitrogen.c:127-134, fixation share nitrogen.c:137-152
+        const R unclaimed = rmax0(eStorN - (R)pLeafOnAll * len);
+        const R fixDen = G_halfNFix + eMinN;
+        const R fixFrac = G_nFixMax * ((fixDen < R(kTiny)) ? R(1) : fdiv(G_halfNFix, fixDen));
+        const R leafOffNResorption = G_resorb * leafLitter * G_iLeafCN;
+        // pool fluxes, nitrogen.c:45-82: x / (C/N) = x * N / C
+        const R iLitterCN = fdiv(denLitterN, eLitter), iSoilCN = fdiv(denSoilN, eSoilC);
+        const R litterMin = rLitter * iLitterCN, soilMin = rSoil * iSoilCN;
+        const R soilNInputs = litterToSoil * iLitterCN + fineRootLoss * G_iFineCN + coarseRootLoss * G_iWoodCN;
+        const R nOrgLitter = leafLitter * G_iLeafCN - leafOffNResorption + woodLitter * G_iWoodCN - litterMin -
+                             litterToSoil * iLitterCN;
+        const R nOrgSoil = soilNInputs - soilMin;
+        const R nMin = litterMin + soilMin;
+        // volatilisation nitrogen.c:15-26, leaching nitrogen.c:31-41 (the leached share is wave W's:
+        // it has the drainage -- by day only after the photosynthesis hand-over, unless the soil cannot
+        // fill up in this step)
+        R nVolatilization = G_nVol * eMinN * qSoil * (R(0.05) + R(3.8) * anoxic * (R(1) - anoxic));
+        double wLeach;
+        {
+          WAIT_BEGIN()
+          takeD1(&mailWat[t & 3][2][lane], &seqLeach, t, wLeach);
+          WAIT_END(2)
+        }
+        R nLeaching = eMinN * (R)wLeach * G_nLeach;
+        // checkMineralNLimitation, limitations.c:119-129
+        {
+          const R pool = eMinN + (nMin + evMinN) * len;
+          const R loss = (nLeaching + nVolatilization) * len;
+          if (__builtin_expect(__builtin_amdgcn_ballot_w64(loss > R(kTiny) && loss > pool) != 0, 0)) {
+            const R red = (loss > R(kTiny) && loss > pool) ? fdiv(pool, loss) : R(1);
+            nLeaching *= red;
+            nVolatilization *= red;
+          }
+        }
+        // checkNitrogenLimitation, limitations.c:69-114: nobody is limited where the cheap test both
+        // waves make holds; otherwise C gets the exact supply, scales its creation fluxes and answers
+        // with the demand that is left
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!nPlentiful(minN0, (double)qSoil, lenD, G_nVolD, G_nLeachD, pDemand)) != 0, 0)) {
+          const R availableMinN = eMinN + (nMin - nVolatilization - nLeaching) * len;
+          postD(&mailSupply[0][lane], 0, (double)availableMinN);
+          postD(&mailSupply[0][lane], 1, (double)fixFrac);
+          postD(&mailSupply[0][lane], 2, (double)unclaimed);
+          postFlag(&seqSupply, t);
+          double dFinal;
+          takeD1(&mailDemand[0][lane], &seqDemand, t, dFinal);
+          nDemand = (R)dFinal;
+        }
+        // fixation and uptake, nitrogen.c:155-168
+        const R rem = rmax0(nDemand - unclaimed * invLen);
+        const R nFixation = fixFrac * rem, nUptake = (R(1) - fixFrac) * rem;
+        // updateNitrogenPools(), nitrogen.c:210-239
+        const R storageDemand = nDemand - nUptake - nFixation;
+        storN += (double)((leafOffNResorption + reductionN - storageDemand - leafOnN) * len);
+        minN += (double)(((nMin - nVolatilization - nLeaching) - nUptake) * len);
+        soilOrgN += (double)(nOrgSoil * len);
+        litterN += (double)(nOrgLitter * len);
+        minN = rmax0(minN);   // (plant death, which comes later in the step, does not touch this pool)
+        postD(&mailMinN[(t + 1) & 1][lane], 0, minN);
+        postFlag(&seqMinN, t + 1);
+        // updatePoolsForSoil(), sipnet.c:1645-1668 (litter pool on, no carbon saturation)
+        const R soilInputs = coarseRootLoss + fineRootLoss + litterToSoil;
+        litterC += (double)((woodLitter + leafLitter - litterToSoil - rLitter - litterMethane) * len);
+        soilC += (double)((soilInputs - rSoil - soilMethane) * len);
+
+        // the end of C's step: its mortality verdict (one word per lane) and, where a stand died, what its
+        // biomass adds to these pools (sipnet.c:1688-1767); then ensureNonNegativeStocks() for them
+        int w;
+        do {
+          asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(w) : "v"(ldsAddr(&mailAlive[(t + 1) & 1][lane])) : "memory");
+        } while (uni(w < 0 ? -w : w) < t + 3);
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(w < 0) != 0, 0)) {
+          double d0, d1, d2, d3;
+          asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:512\n\tds_read_b64 %2, %4 offset:1024\n\t"
+                       "ds_read_b64 %3, %4 offset:1536\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3) : "v"(ldsAddr(&mailDeath[0][lane])) : "memory");
+          if (w < 0) {
+            soilC += d0;
+            litterC += d1;
+            soilOrgN += d2;
+            litterN += d3 + storN;
+            storN = 0.0;
+          }
+        }
+        soilC = rmax0(soilC);
+        litterC = rmax0(litterC);
+        soilOrgN = rmax0(soilOrgN);
+        litterN = rmax0(litterN);
+        storN = rmax0(storN);
+        postD(&mailStorN[(t + 1) & 1][lane], 0, storN);
+        postFlag(&seqStorN, t + 1);
+      }
+    }
+    WAIT_STORE(12)
+    if (act) {
+      ST(soilC) = soilC;
+      ST(litterC) = litterC;
+      ST(minN) = minN;
+      ST(soilOrgN) = soilOrgN;
+      ST(litterN) = litterN;
+      ST(plantStorageN) = storN;
+    }
+    return;
+  }
+
+  // =============================================================================================
   if (role == 2) {
     // Every layout of this wave must produce the same bits (they are tested against each other),
     // and what fuses into an FMA under -ffp-contract=fast depends on which neighbouring
@@ -1083,6 +1086,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
             haveQ = true;
           }
           const R qSoilT = K_bsr * qSoil * (R)q3.x;
+          if (NCyc) postRaw(&mailFac[t & 1][6][lane], qSoil);   // before the flag post5 sets
           post5(&mailFac[t & 1][0][lane], &seqFac, g1, g2, qSoilT, gFine, gCoarse, t);
         }
         if (!(bits & FAST_PAR_POS)) continue;  // night: potGrossPsn = 0, nobody waits for it
@@ -1409,6 +1413,52 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(cLast)::"memory");
 #endif
 
+  // NCyc: what wave S needs of a step's plant side (the litter fluxes, the nitrogen demand of the creation
+  // fluxes nitrogen.c:89-104, the resorption of a negative total creation :170-196, the leaf-on nitrogen
+  // :84-86), posted as soon as the creation fluxes are known -- S is working on the soil side of the same
+  // step -- and checkNitrogenLimitation() (limitations.c:69-114): both waves test "plentiful" with the
+  // same numbers; only where it fails for some member does C wait for S's exact supply, scale its
+  // creation fluxes and answer with the demand that is left
+  auto plantSideN = [&](int t, R len, R invLen, double minNStep, double qSoilD, double lenD, R leafLitter, R woodLitter,
+                        R fineRootLoss, R coarseRootLoss, R leafOnCreation, R evLeafOnAll, R& leafCreation,
+                        R& woodCreation, R& fineRootCreation, R& coarseRootCreation) {
+#pragma clang fp contract(off)
+    auto leafOnN = [&](R leafOnC) -> R { return rmax0(leafOnC * G_iLeafCN - leafOnC * G_iWoodCN); };
+    auto plantNDemand = [&]() -> R {
+      return rmax0(woodCreation * G_iWoodCN + leafCreation * G_iLeafCN + fineRootCreation * G_iFineCN +
+                   coarseRootCreation * G_iWoodCN);
+    };
+    R reductionN = 0;
+    if (woodCreation + leafCreation + fineRootCreation + coarseRootCreation < R(0))
+      reductionN -= (leafCreation * G_iLeafCN + woodCreation * G_iWoodCN + coarseRootCreation * G_iWoodCN +
+                     fineRootCreation * G_iFineCN);
+    const R nDemand = plantNDemand();
+    postD(&mailPlant[0][lane], 0, (double)leafLitter);
+    postD(&mailPlant[0][lane], 1, (double)woodLitter);
+    postD(&mailPlant[0][lane], 2, (double)fineRootLoss);
+    postD(&mailPlant[0][lane], 3, (double)coarseRootLoss);
+    postD(&mailPlant[0][lane], 4, (double)nDemand);
+    postD(&mailPlant[0][lane], 5, (double)reductionN);
+    postD(&mailPlant[0][lane], 6, (double)leafOnN(leafOnCreation + evLeafOnAll));
+    postD(&mailPlant[0][lane], 7, (double)leafOnN(leafOnCreation));
+    postFlag(&seqPlant, t);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!nPlentiful(minNStep, qSoilD, lenD, G_nVolD, G_nLeachD, (double)nDemand)) != 0, 0)) {
+      double sAvail, sFixFrac, sUnclaimed;
+      takeD3(&mailSupply[0][lane], &seqSupply, t, sAvail, sFixFrac, sUnclaimed);
+      const R availableMinN = (R)sAvail, fixFrac = (R)sFixFrac, unclaimed = (R)sUnclaimed;
+      const R nUptake = (R(1) - fixFrac) * rmax0(nDemand - unclaimed * invLen);
+      const R uptakeDemand = nUptake * len;
+      const bool limited = uptakeDemand > R(kTiny) && uptakeDemand > availableMinN;
+      const R red = limited ? fdiv(fdiv(availableMinN, R(1) - fixFrac) + unclaimed, nDemand * len) : R(1);
+      woodCreation *= red;
+      leafCreation *= red;
+      fineRootCreation *= red;
+      coarseRootCreation *= red;
+      postD(&mailDemand[0][lane], 0, (double)plantNDemand());
+      postFlag(&seqDemand, t);
+    }
+  };
+
   for (int tileStart = curTile * kFastTile; tileStart < tEnd; tileStart += kFastTile, curTile++) {
     // the DMA of this tile was issued a tile ago; only the last step's two stores may still be
     // in flight behind it
@@ -1432,7 +1482,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
     // as "second eviction" the step before.  Same arithmetic as the general step below; left at
     // the first step on which a member dies.  (Lean instantiation only: records, all accumulators
     // and diagnostics take the general step.)
-    if (!Full && !NCyc && ringClean && !(a.options & SIPNET_KOPT_NO_REGULAR_TILES)) {
+    if (!Full && ringClean && !(a.options & SIPNET_KOPT_NO_REGULAR_TILES)) {
       d2 h0, h7;
       i4 hj;
       double hW1, hEndGdd, hEndDay;
@@ -1481,6 +1531,12 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
             if (diedAt < 0) diedAt = t;
             deathToSoil0 = fineRootC + coarseRootC;
             deathToSoil1 = plantWoodC + plantLeafC + delta;
+            if (NCyc) {  // to wave S's pools (sipnet.c:1735-1746), before the verdict word that announces it
+              postD(&mailDeath[0][lane], 0, deathToSoil0);
+              postD(&mailDeath[0][lane], 1, deathToSoil1);
+              postD(&mailDeath[0][lane], 2, fineRootC * (double)G_iFineCN + coarseRootC * (double)G_iWoodCN);
+              postD(&mailDeath[0][lane], 3, plantWoodC * (double)G_iWoodCN + plantLeafC * (double)G_iLeafCN);
+            }
             plantWoodC = 0.0;
             plantLeafC = 0.0;
             coarseRootC = 0.0;
@@ -1493,14 +1549,24 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
           coarseRootC = rmax0(coarseRootC);
           fineRootC = rmax0(fineRootC);
           postAlive(&mailAlive[(t + 1) & 1][lane], t + 1, diedNow);
-          soilC += soilGain;
-          if (MayDie && diedNow) {
-            soilC += deathToSoil0;
-            soilC += deathToSoil1;
+          if (!NCyc) {
+            soilC += soilGain;
+            if (MayDie && diedNow) {
+              soilC += deathToSoil0;
+              soilC += deathToSoil1;
+            }
+            soilC = rmax0(soilC);
           }
-          soilC = rmax0(soilC);
           const R tGpp = photosynthesis * len;
-          const R tRh = rSoil * len;
+          R rHet = rSoil;
+          if (NCyc) {  // heterotrophic respiration (litter + soil) is wave S's, posted early in its step
+            double rh;
+            WAIT_BEGIN()
+            takeD1(&mailRh[t & 1][lane], &seqRh, t, rh);
+            WAIT_END(2)
+            rHet = (R)rh;
+          }
+          const R tRh = rHet * len;
           const R tRa = ffma(rVeg, len, (rCoarseRoot + rFineRoot) * len);
           const R tNee = R(-1.0) * ((tGpp - tRa) - tRh);
           totNee += (double)tNee;
@@ -1536,16 +1602,20 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
           // before its values, one LDS round trip when both are current)
           R g1, g2, qSoilT, gFine, gCoarse, moistEff;
           ringNew = 0.0;  // LDS ring: the value this step evicts, read in the same round trip
+          double minNStep = 0.0;   // NCyc: wave S's mineral nitrogen at the start of this step
           {
             WAIT_BEGIN()
-            if (RingLds)
+            if (NCyc)   // rows 0 1 3 4 and the plain soil Q10 factor (row 6, carried in `moistEff`'s place) + the mineral N
+              takeFactorsN(&mailFac[t & 1][0][lane], &seqFac, &mailMinN[t & 1][lane], &seqMinN, t, g1, g2, gFine, gCoarse,
+                           moistEff, minNStep);
+            else if (RingLds)
               takeFactorsRing(&mailFac[t & 1][0][lane], seqFacMoist, ldsAddr(&ringL[readSlot * 64 + lane]), t, g1,
                               g2, qSoilT, gFine, gCoarse, moistEff, ringNew);
             else
               takeFactors(&mailFac[t & 1][0][lane], seqFacMoist, t, g1, g2, qSoilT, gFine, gCoarse, moistEff);
             WAIT_END(0)
           }
-          const R fSoil = qSoilT * moistEff;
+          const R fSoil = NCyc ? R(0) : qSoilT * moistEff;
           rvN = 0.0;
           if (!RingLds)
             asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(rvN) : "v"(ringp + (uint32_t)readSlot * ncu) : "memory");
@@ -1578,12 +1648,15 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
             coarseRootCreation += shift;
             fineRootCreation -= shift;
           }
+          if (NCyc)   // the plants' side of the step for wave S, and checkNitrogenLimitation() (see the general step)
+            plantSideN(t, len, invLen, minNStep, (double)moistEff, (double)h0.x, leafLitter, woodLitter, fineRootLoss,
+                       coarseRootLoss, R(0), R(0), leafCreation, woodCreation, fineRootCreation, coarseRootCreation);
           accum(plantLeafC, leafCreation - leafLitter, len);
           post(&mailLai[(t + 1) & 1][lane], &seqLai, (R)rmax0(plantLeafC) * K_invLcsw, t + 1);
           accum(plantWoodC, woodCreation - woodLitter, len);
           accum(coarseRootC, coarseRootCreation - coarseRootLoss, len);
           accum(fineRootC, fineRootCreation - fineRootLoss, len);
-          soilGain = (double)((coarseRootLoss + fineRootLoss + woodLitter + leafLitter - rSoil) * len);
+          if (!NCyc) soilGain = (double)((coarseRootLoss + fineRootLoss + woodLitter + leafLitter - rSoil) * len);
           const R r_a = rVeg + rFineRoot + rCoarseRoot;
           const R alloc = leafCreation + woodCreation + fineRootCreation + coarseRootCreation;
           rootsOk = (plantWoodC > kTiny) && (fineRootC + coarseRootC > kTiny);
@@ -1869,47 +1942,11 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
       fineRootC += (double)(evFineRootC * len);
     }
 
-    // ---- NCyc: what wave W needs of this step's plant side (the litter fluxes, the nitrogen demand of
-    // the creation fluxes nitrogen.c:89-104, the resorption of a negative total creation :170-196, the
-    // leaf-on nitrogen :84-86), posted now -- W is working on the soil side of the same step -- and
-    // checkNitrogenLimitation() (limitations.c:69-114): both waves test "plentiful" with the same
-    // numbers; only where it fails for some member does C wait for W's exact supply
-    if (NCyc) {
-      auto plantNDemand = [&]() -> R {
-        return rmax0(woodCreation * G_iWoodCN + leafCreation * G_iLeafCN + fineRootCreation * G_iFineCN +
-                     coarseRootCreation * G_iWoodCN);
-      };
-      R reductionN = 0;
-      if (woodCreation + leafCreation + fineRootCreation + coarseRootCreation < R(0))
-        reductionN -= (leafCreation * G_iLeafCN + woodCreation * G_iWoodCN + coarseRootCreation * G_iWoodCN +
-                       fineRootCreation * G_iFineCN);
-      const R nDemand = plantNDemand();
-      postD(&mailPlant[0][lane], 0, (double)leafLitter);
-      postD(&mailPlant[0][lane], 1, (double)woodLitter);
-      postD(&mailPlant[0][lane], 2, (double)fineRootLoss);
-      postD(&mailPlant[0][lane], 3, (double)coarseRootLoss);
-      postD(&mailPlant[0][lane], 4, (double)nDemand);
-      postD(&mailPlant[0][lane], 5, (double)reductionN);
-      postD(&mailPlant[0][lane], 6, (double)leafOnNFromC(leafOnCreation + evLeafOnAll));
-      postD(&mailPlant[0][lane], 7, (double)leafOnNFromC(leafOnCreation));
-      postFlag(&seqPlant, t);
-      if (__builtin_expect(__builtin_amdgcn_ballot_w64(!nPlentiful(minNStep, (double)moistEff /* plain qSoil */, (double)q0.x,
-                                                                     G_nVolD, G_nLeachD, (double)nDemand)) != 0, 0)) {
-        double sAvail, sFixFrac, sUnclaimed;
-        takeD3(&mailSupply[0][lane], &seqSupply, t, sAvail, sFixFrac, sUnclaimed);
-        const R availableMinN = (R)sAvail, fixFrac = (R)sFixFrac, unclaimed = (R)sUnclaimed;
-        const R nUptake = (R(1) - fixFrac) * rmax0(nDemand - unclaimed * invLen);
-        const R uptakeDemand = nUptake * len;
-        const bool limited = uptakeDemand > R(kTiny) && uptakeDemand > availableMinN;
-        const R red = limited ? fdiv(fdiv(availableMinN, R(1) - fixFrac) + unclaimed, nDemand * len) : R(1);
-        woodCreation *= red;
-        leafCreation *= red;
-        fineRootCreation *= red;
-        coarseRootCreation *= red;
-        postD(&mailDemand[0][lane], 0, (double)plantNDemand());
-        postFlag(&seqDemand, t);
-      }
-    }
+    // ---- NCyc: the plants' side of the step for wave S, and checkNitrogenLimitation() (plantSideN)
+    if (NCyc)
+      plantSideN(t, len, invLen, minNStep, (double)moistEff /* the plain soil Q10 factor */, q0.x, leafLitter, woodLitter,
+                 fineRootLoss, coarseRootLoss, leafOnCreation, evLeafOnAll, leafCreation, woodCreation, fineRootCreation,
+                 coarseRootCreation);
 
     CSTAMP(2)
     // the leaf pool of the next step does not involve this step's photosynthesis: update it
@@ -2021,7 +2058,9 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
     R rHet = rSoil;
     if (NCyc) {  // heterotrophic respiration (litter + soil) is wave W's, posted early in its step
       double rh;
+      WAIT_BEGIN()
       takeD1(&mailRh[t & 1][lane], &seqRh, t, rh);
+      WAIT_END(2)
       rHet = (R)rh;
     }
     const R tRh = rHet * len;
@@ -2257,7 +2296,7 @@ void launchStepCoop(const FastArgs& a, int precision, int layout, hipStream_t st
       info->wavesPerSimd = 1;
       const int elem = precision == SIPNET_F64 ? 8 : 4;
       info->ldsBytes = 3 * 2 * kTileBytes + (2 * 64 * 3 + 2 * 7 * 64) * elem + 2 * 64 * 4 + 16 * 4 + 64 * 8 +
-                       (8 + 2 + 2 + 2 + 6 + 4 + 3 + 1 + 12) * 64 * 8;
+                       (8 + 2 + 2 + 2 + 6 + 4 + 3 + 1 + 12) * 64 * 8 + 2 * kTileBytes;
     }
     return;
   }
