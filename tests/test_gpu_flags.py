@@ -183,3 +183,106 @@ def test_fp32_mixed_with_optional_flags(name, oracle, clim60, members70):
     print(f"fp32-mixed, {name}: max |d| / max|plane|", rel)
     assert np.isfinite(got).all()
     assert rel < 2e-3
+
+
+# ---- the cooperative kernel of the nitrogen-cycle flag set (stepCoopNKernel) ----------------------
+NCYCLE = dict(litterPool=1, anaerobic=1, nitrogenCycle=1)
+
+
+def _ncycle_scenario(clim60, members70, lethal=True):
+    """the year of the flag-set tests with every event type, plus what the cooperative kernel's rare
+    hand-overs need: a clear-cut that kills every stand and a re-planting (death block), a member dead
+    from the start, members starved of nitrogen (tiny mineral pool, no fixation, small storage: the
+    exact-supply round trip of checkNitrogenLimitation), a ragged second chunk"""
+    ev = _events_all_types(clim60)
+    if lethal:
+        def add(day, typ, *p):
+            e = sa.Event(); e.type = typ; e.year = int(clim60.year[0]); e.day = day
+            for i, v in enumerate(p):
+                e.p[i] = v
+            ev.append(e)
+        add(230, 1, 1.0, 1.0, 0.0, 0.0)          # clear-cut: every member dies
+        add(240, 3, 40.0, 300.0, 50.0, 60.0)     # re-planting
+        ev.sort(key=lambda e: (e.year, e.day))
+    members = members70.copy()
+    if lethal:
+        members[5, param_index("plantWoodInit")] = 0.0
+    for m in (2, 9, 40, 66):                      # productive stands whose uptake demand exceeds the mineral pool
+        members[m] = members70[0]                 # (member 0 = the unperturbed parameter file)
+        members[m, param_index("aMax")] *= 3.0    # (the base stand loses carbon: no creation, no nitrogen demand)
+        members[m, param_index("baseVegResp")] *= 0.3
+        if m != 2:
+            members[m, param_index("mineralNInit")] = 1e-4 * (1 + m)
+            members[m, param_index("plantStorageNInit")] = 0.02
+            members[m, param_index("soilOrgNInit")] *= 0.01
+            members[m, param_index("litterOrgNInit")] *= 0.01
+    return ev, members
+
+
+@pytest.mark.parametrize("prec", [sa.F64, sa.F32_MIXED], ids=["f64", "f32"])
+def test_nitrogen_cycle_cooperative_kernel_against_the_oracle(prec, oracle, clim60, members70):
+    """stepCoopNKernel forced, launch cut at odd steps (a one-step piece and a tile tail included):
+    fp64 at 1e-9 on planes and final pools with the lethal events, fp32-mixed at 2e-6 of the plane
+    maximum without them; the nitrogen-starved members do get limited (their wood creation differs from
+    an unstarved twin's), i.e. the slow hand-over ran"""
+    flags = _flags(**NCYCLE)
+    ev, members = _ncycle_scenario(clim60, members70, lethal=prec == sa.F64)
+    T = clim60.n_steps
+    b = sa.Batch(flags, 1, members.shape[0], prec, fast_math=True if prec == sa.F64 else None, kernel=sa.KERNEL_COOP_NCYCLE)
+    b.set_events(0, ev)
+    b.set_climate(0, clim60)
+    b.set_params(0, members)
+    b.setup()
+    planes, _ = b.alloc_outputs(T)
+    for a, z in ((0, 1), (1, 7), (7, 6000), (6000, 6015), (6015, T)):
+        b.run(a, z - a, planes=planes[:, a:z])
+    li = b.last_launch()
+    got = planes.double().cpu().numpy()
+    state, status = b.get_state(), b.get_status()
+    b.close()
+    assert li["kernel"] == "stepCoopNKernel<%s, false>" % ("double" if prec == sa.F64 else "float"), li
+    want, final, st = oracle.run_block(flags, members, clim60, ev)
+    assert (st == 0).all() and (np.asarray(status) == 0).all()
+    if prec == sa.F64:
+        compare("ncycle coop f64", got, state, want, final)
+        assert state[0, 30] >= 0 and state[0, 0] > 100.0          # died at the clear-cut, wood is back
+    else:
+        scale = np.abs(want).max(axis=(1, 2), keepdims=True)
+        assert (np.abs(got - want) / scale).max() < 2e-6
+    # the productive members WERE limited (the exact-supply hand-over between the carbon and the soil wave ran):
+    # with nitrogen in abundance the oracle grows more wood on some steps
+    for m in (2, 40):
+        rich = members[m].copy()
+        rich[param_index("mineralNInit")] = 1e4
+        rich[param_index("plantStorageNInit")] = 1e4
+        _, rec_poor, _ = oracle.run_member(flags, members[m], clim60, ev)
+        _, rec_rich, _ = oracle.run_member(flags, rich, clim60, ev)
+        assert (rec_rich[:, 11] - rec_poor[:, 11] > 1e-7).sum() > 100          # woodCreation, column 11
+
+
+def test_nitrogen_cycle_kernel_paths_give_the_same_bits(clim60, members70):
+    """regular 16-step tiles against the general step (SIPNET_KOPT_NO_REGULAR_TILES), and the cooperative
+    kernel against a re-run of itself: identical planes, state and rings (which path a wavefront takes
+    depends on its neighbours); against the one-wave kernel of the same flag set: to rounding"""
+    flags = _flags(**NCYCLE)
+    ev, members = _ncycle_scenario(clim60, members70, lethal=False)
+    members = np.concatenate([members, members[:58]])                 # 128 members: two full chunks
+    members[70, param_index("plantWoodInit")] = 0.0                   # chunk 1 never leaves the general step
+    T = clim60.n_steps
+    outs = {}
+    for key, kernel, opt in (("reg", sa.KERNEL_COOP_NCYCLE, 0), ("gen", sa.KERNEL_COOP_NCYCLE, sa.KOPT_NO_REGULAR_TILES),
+                             ("again", sa.KERNEL_COOP_NCYCLE, 0), ("one", sa.KERNEL_ONE_WAVE, 0)):
+        b = sa.Batch(flags, 1, members.shape[0], sa.F64, fast_math=True, kernel=kernel, kernel_options=opt)
+        b.set_climate(0, clim60)
+        b.set_params(0, members)
+        b.setup()
+        planes, _ = b.alloc_outputs(T)
+        for a, z in ((0, 5), (5, 8003), (8003, T)):
+            b.run(a, z - a, planes=planes[:, a:z])
+        outs[key] = (planes.cpu().numpy(), b.get_state(), b.get_rings())
+        b.close()
+    for k in range(3):
+        np.testing.assert_array_equal(outs["reg"][k], outs["gen"][k])
+        np.testing.assert_array_equal(outs["reg"][k], outs["again"][k])
+    assert np.array_equal(outs["reg"][0][:, :, 3], outs["reg"][0][:, :, 73])      # the same member in both chunks
+    assert np.abs(outs["reg"][0] - outs["one"][0]).max() < 1e-11
