@@ -140,6 +140,10 @@ static void captureRecord(double *r) {
   r[35] = trackers.totGpp;
 }
 
+/* Let the reference print its own [WARNING] lines (ensureNonNegative sipnet.c:1346-1356, checkBalance
+ * balance.c:149-163): tools/make_golden.py counts them per member to pin the oracle's diagnostics. */
+void ref_set_quiet(int quiet) { ctx.quiet = quiet; }
+
 /* Run one member over the whole climate file.
  *   raw_params : NUM_PARAMS doubles in `Params` struct order, PRE-setupModel units
  *   rec        : NULL or [n_steps][REF_NREC]

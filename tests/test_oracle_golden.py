@@ -101,3 +101,36 @@ def test_oracle_status_codes(oracle, tmp_path):
     c2.data[10, 0] = 0.0                                  # non-positive step length: events.c:460-465
     st, _, _ = oracle.run_member(case["flags"], case["params"], c2)
     assert st == 3
+
+
+def test_oracle_diagnostics_equal_the_reference_binarys_own_warning_lines(oracle, tmp_path):
+    """tests/golden/synth/ref_warning_counts.json holds what the REAL reference printed (not quiet,
+    tools/make_golden.py: warning_counts): per member the number of ensureNonNegative() warnings
+    (sipnet.c:1346-1356) and of checkBalance() failures (balance.c:149-163) -- on the 16 special
+    members over the synthetic year, and on a 1e11-gC stand whose carbon total has an ulp above the
+    balance threshold.  The oracle's sipo_diag counters, which the GPU counters are held against
+    (tests/test_gpu_full.py), must be those numbers."""
+    import json
+    from sipnet_amd import synth
+    from sipnet_amd.config import param_index as pi
+    gold = json.load(open(os.path.join(helpers.GOLDEN, "synth", "ref_warning_counts.json")))
+    flags = sa.flags_from()
+    helpers.gunzip_to(os.path.join(helpers.GOLDEN, "synth", "halfhourly.clim.gz"), str(tmp_path / "hh.clim"))
+    clim = sa.read_clim(str(tmp_path / "hh.clim"))
+    members = np.load(os.path.join(helpers.GOLDEN, "synth", "members_raw.npy"))
+    diags = [oracle.run_member(flags, members[m], clim, want_rec=False)[2] for m in range(members.shape[0])]
+    assert [d.n_clamp_warn for d in diags] == gold["special16"]["n_clamp_warn"]
+    assert [d.n_balance_warn for d in diags] == gold["special16"]["n_balance_warn"]
+    assert sum(gold["special16"]["n_clamp_warn"]) > 10000        # the reference did warn (member 9's snow pack)
+    # the heavy stand: 20 days from day 150 of the same generator
+    base, _ = sa.read_params(os.path.join(helpers.REPO, "sipnet_amd", "data", "base_forest.param"), flags)
+    heavy = synth.perturbed_params(base, 8)
+    heavy[:, pi("plantWoodInit")] = 1e11
+    raw = synth.half_hourly_year_raw(150 * 48 + 48 * 20)
+    raw = {k: v[150 * 48:] for k, v in raw.items()}
+    synth.write_clim(str(tmp_path / "d20.clim"), synth.round_like_file(raw))
+    clim20 = sa.read_clim(str(tmp_path / "d20.clim"))
+    dh = [oracle.run_member(flags, heavy[m], clim20, want_rec=False)[2] for m in range(8)]
+    g = gold["wood1e11_20days_from_day150"]
+    assert [d.n_balance_warn for d in dh] == g["n_balance_warn"] and min(g["n_balance_warn"]) > 900
+    assert [d.n_clamp_warn for d in dh] == g["n_clamp_warn"]

@@ -17,6 +17,11 @@ from tests import helpers
 # FUZZ_COOP=1: a campaign on the cooperative kernels only -- default flags, throughput arithmetic, every
 # layout forced in turn, and a few fragile members that single events kill in the middle of a run
 COOP_ONLY = bool(os.environ.get("FUZZ_COOP"))
+# FUZZ_NCYC=1: a campaign on the nitrogen-cycle flag set (litter pool + anaerobic + nitrogen cycle): the
+# cooperative kernel of that set (stepCoopNKernel: carbon / water / light / soil wavefronts) forced or picked
+# by the shape policy, fragile members, and productive members short of nitrogen (the exact-supply
+# hand-over of checkNitrogenLimitation)
+NCYC_ONLY = bool(os.environ.get("FUZZ_NCYC"))
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
 only = int(sys.argv[3]) if len(sys.argv) > 3 else -1      # rerun one trial with details
@@ -38,6 +43,7 @@ def random_flags():
     if f["anaerobic"] and f["litterPool"] and rng.random() < 0.6: f["nitrogenCycle"] = 1
     if f["litterPool"] and rng.random() < 0.4: f["carbonSaturation"] = 1
     if rng.random() < 0.25 or COOP_ONLY: f = {}          # default flags: throughput / cooperative kernels
+    if NCYC_ONLY: f = dict(litterPool=1, anaerobic=1, nitrogenCycle=1, events=int(rng.random() < 0.8))
     return f
 
 def random_events(clim, n):
@@ -88,7 +94,17 @@ for trial in range(trials):
     if COOP_ONLY and M > 8:
         for mm in rng.choice(M, size=min(4, M // 8), replace=False):      # fragile stands: a harvest may finish them off
             members[mm, pi("plantWoodInit")] *= float(10.0 ** -rng.uniform(1.5, 4.0))
-    fast = bool(rng.random() < 0.7) or COOP_ONLY
+    if NCYC_ONLY and M > 8:
+        for mm in rng.choice(M, size=min(4, M // 8), replace=False):      # fragile stands
+            members[mm, pi("plantWoodInit")] *= float(10.0 ** -rng.uniform(1.5, 4.0))
+        for mm in rng.choice(M, size=min(6, M // 6), replace=False):      # productive, and short of nitrogen
+            members[mm, pi("aMax")] *= float(rng.uniform(2.0, 4.0))
+            members[mm, pi("baseVegResp")] *= float(rng.uniform(0.2, 0.5))
+            if rng.random() < 0.5:
+                members[mm, pi("mineralNInit")] = float(10.0 ** -rng.uniform(1, 5))
+                members[mm, pi("plantStorageNInit")] = float(10.0 ** -rng.uniform(0, 4))
+                members[mm, pi("soilOrgNInit")] *= float(10.0 ** -rng.uniform(0, 3))
+    fast = bool(rng.random() < 0.7) or COOP_ONLY or NCYC_ONLY
     prec = sa.F32_MIXED if (fast and rng.random() < 0.25) else sa.F64
     runs = [oracle.run_block(flags, members, c, ev) for c in clims]
     want = np.concatenate([r[0] for r in runs], axis=2)
@@ -109,6 +125,12 @@ for trial in range(trials):
         kopt = 0
         kern, forced = [(sa.KERNEL_AUTO, ""), (sa.KERNEL_COOP_LDS, " coop-lds"), (sa.KERNEL_COOP_HBM, " coop-hbm"),
                         (sa.KERNEL_COOP_PAIR, " coop-pair"), (sa.KERNEL_COOP_QUAD, " coop-quad")][int(rng.integers(0, 5))]
+    if NCYC_ONLY:
+        kopt = sa.KOPT_NO_REGULAR_TILES if rng.random() < 0.2 else 0
+        kern, forced = [(sa.KERNEL_AUTO, ""), (sa.KERNEL_COOP_NCYCLE, " coop-ncycle"), (sa.KERNEL_COOP_NCYCLE, " coop-ncycle"),
+                        (sa.KERNEL_ONE_WAVE, " one-wave")][int(rng.integers(0, 4))]
+        if kern == sa.KERNEL_COOP_NCYCLE and not flags[0]:      # (the compiled-in set has events on)
+            kern, forced = sa.KERNEL_AUTO, ""
     if os.environ.get("FUZZ_KOPT"): kopt = int(os.environ["FUZZ_KOPT"])
     if os.environ.get("FUZZ_KERNEL"):     # rerun a trial on another kernel (with the trial index as third argument)
         kern = getattr(sa, "KERNEL_" + os.environ["FUZZ_KERNEL"].upper()); forced = " forced-" + os.environ["FUZZ_KERNEL"]
@@ -118,7 +140,7 @@ for trial in range(trials):
         b.set_climate(sidx, clims[sidx]); b.set_params(sidx, members)
     # a third of the trials also ask for the 44-column record and the diagnostics counters (the
     # "full" instantiations of the throughput kernels, or the strict kernel's)
-    want_full = bool(rng.random() < 0.33) and kern != sa.KERNEL_COOP_QUAD    # no full-state quad build
+    want_full = bool(rng.random() < 0.33) and kern not in (sa.KERNEL_COOP_QUAD, sa.KERNEL_COOP_NCYCLE)    # no full-state builds of these
     if want_full:
         b.enable_diagnostics()
         forced += " full"

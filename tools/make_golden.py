@@ -15,6 +15,7 @@ import os
 import shutil
 import subprocess
 import sys
+import tempfile
 
 import numpy as np
 
@@ -96,6 +97,82 @@ np.save(out_path, out)
     out = np.load(out_path)
     shutil.rmtree(tmp)
     return out
+
+
+def ref_warning_counts(flags, param_file, clim_file, raw_members, first_steps=None):
+    """The reference's OWN per-step self-check warnings, counted per member: the real reference (not
+    quiet) runs every member in a child process whose stdout is parsed for
+      "[WARNING] ... Non-negative stock constraint applied for ..."   ensureNonNegative(), sipnet.c:1346-1356
+      "[WARNING] ... Carbon / Nitrogen balance check failed ..."      checkBalance(), balance.c:149-163
+    -> (n_clamp_warn[n_members], n_balance_warn[n_members])"""
+    code = r"""
+import ctypes as C, numpy as np, sys, pickle, os
+flags, param_file, clim_file, raw_path, so = pickle.load(open(sys.argv[1],'rb'))
+ref = C.CDLL(so); libc = C.CDLL(None)
+fl = (C.c_int*12)(*flags)
+n = ref.ref_init(fl, param_file.encode(), clim_file.encode(), b"/nonexistent/events.in", b"/dev/null")
+ref.ref_set_quiet(0)
+raw = np.load(raw_path)
+for m in range(raw.shape[0]):
+    libc.fflush(None); os.write(1, b"\n@@MEMBER %d\n" % m)
+    r = np.ascontiguousarray(raw[m])
+    ref.ref_run_member(r.ctypes.data_as(C.c_void_p), None, None, None, None)
+libc.fflush(None)
+"""
+    import pickle, tempfile
+    tmp = tempfile.mkdtemp(prefix="mkgold_")
+    raw_path = os.path.join(tmp, "raw.npy")
+    np.save(raw_path, raw_members)
+    job = os.path.join(tmp, "job.pkl")
+    pickle.dump((list(flags), param_file, clim_file, raw_path, REF_SO), open(job, "wb"))
+    out = subprocess.run([sys.executable, "-c", code, job], check=True, capture_output=True).stdout.decode(errors="replace")
+    shutil.rmtree(tmp)
+    clamp, bal = np.zeros(len(raw_members), dtype=np.int64), np.zeros(len(raw_members), dtype=np.int64)
+    m = -1
+    for line in out.split("\n"):
+        if line.startswith("@@MEMBER"):
+            m = int(line.split()[1])
+        elif "[WARNING]" in line and m >= 0:
+            if "Non-negative stock constraint applied" in line:
+                clamp[m] += 1
+            elif "balance check failed" in line:
+                bal[m] += 1
+    return clamp, bal
+
+
+def warning_counts():
+    """tests/golden/synth/ref_warning_counts.json: the reference's warning lines on the 16 special
+    members (synthetic half-hourly year) and on a 1e11-gC stand (20 days), for
+    tests/test_oracle_golden.py to hold the oracle's sipo_diag counters against"""
+    import json
+    import sipnet_amd as sa
+    from sipnet_amd import synth
+    from sipnet_amd.config import param_index as pi
+    d = os.path.join(GOLD, "synth")
+    flags = sa.flags_from()
+    base_file = os.path.join(REPO, "sipnet_amd", "data", "base_forest.param")
+    tmp = tempfile.mkdtemp(prefix="mkgold_")
+    clim_path = os.path.join(tmp, "hh.clim")
+    with gzip.open(os.path.join(d, "halfhourly.clim.gz"), "rb") as fi, open(clim_path, "wb") as fo:
+        shutil.copyfileobj(fi, fo)
+    members = np.load(os.path.join(d, "members_raw.npy"))
+    c16, b16 = ref_warning_counts(flags, base_file, clim_path, members)
+    # the heavy stand of tests/test_gpu_full.py: one ulp of its carbon total exceeds the balance threshold
+    base, _ = sa.read_params(base_file, flags)
+    heavy = synth.perturbed_params(base, 8)
+    heavy[:, pi("plantWoodInit")] = 1e11
+    raw = synth.half_hourly_year_raw(150 * 48 + 48 * 20)
+    raw = {k: v[150 * 48:] for k, v in raw.items()}
+    clim20 = os.path.join(tmp, "d20.clim")
+    synth.write_clim(clim20, synth.round_like_file(raw))
+    ch, bh = ref_warning_counts(flags, base_file, clim20, heavy)
+    shutil.rmtree(tmp)
+    out = {"what": "lines the real reference (oracle/_ref/libsipnet_ref.so, not quiet) printed per member: "
+                   "ensureNonNegative() warnings (sipnet.c:1346-1356) and checkBalance() failures (balance.c:149-163)",
+           "special16": {"n_clamp_warn": c16.tolist(), "n_balance_warn": b16.tolist()},
+           "wood1e11_20days_from_day150": {"n_clamp_warn": ch.tolist(), "n_balance_warn": bh.tolist()}}
+    json.dump(out, open(os.path.join(d, "ref_warning_counts.json"), "w"), indent=1)
+    print("warning counts:", out["special16"], out["wood1e11_20days_from_day150"])
 
 
 def decimate_index(n, head=300, tail=300, every=7):
@@ -384,6 +461,7 @@ if __name__ == "__main__":
     copy_smoke()
     smoke_records()
     synthetic()
+    warning_counts()
     restart_cases()
     balance_case()
     events_infra_case()
