@@ -31,6 +31,8 @@ What the JSON line says about the kernel (the `roofline` object):
   issue_frac         this run's rate / the rate the same model reaches on this GPU once every SIMD
                      holds two wavefronts (a short 131 072-member probe of the one-wave kernel, run
                      untimed in this process): how much of the chip's instruction issue the launch uses;
+  end_to_end         the whole job with the PCIe legs (parameters + climate up, plan, setup, kernel with
+                     statistics, statistics down), measured untimed in the same run: never `value`;
   plan_ms, setup_ms  host-side site-plan build + upload (once per forcing, before the timed region;
                      measured on a second hand-over of the same climate, the first one in a
                      process also pays the runtime's first-use costs: plan_ms_first_in_process)
@@ -236,6 +238,7 @@ def main():
                     help="1: throughput kernels (default, what the metric is quoted on); 0: strict-order kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fill-probe", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--gather", default="stats", choices=["stats", "full", "none"])
     ap.add_argument("--dump-stats", default="",
                     help="rank 0 writes the whole ensemble's statistics block [3][T][sites][2] (sum, sum of "
@@ -589,6 +592,33 @@ def main():
         except Exception:
             traffic = None
 
+    # whole job, PCIe included (never `value`): hand the raw parameters and the climate over from host
+    # memory, build + upload the site plan, setupModel(), the step kernel with the ensemble statistics,
+    # and bring the statistics block back to the host -- what a caller pays per forcing + ensemble
+    end_to_end = None
+    if rank == 0 and not pf and not args.no_end_to_end:
+        try:
+            e2e = []
+            for _ in range(4):
+                torch.cuda.synchronize()
+                te0 = time.perf_counter()
+                for s_ in range(S):
+                    b.set_climate(s_, clims[s_])
+                    b.set_params(s_, members)
+                b.setup()
+                b.run_stats(0, T, planes=planes, stats=stats)
+                host_stats = stats.cpu()
+                e2e.append(time.perf_counter() - te0)
+            e2e_s = float(np.median(e2e[1:]))
+            end_to_end = {"ms": e2e_s * 1e3, "value": per_launch_units / e2e_s, "unit": "ensemble-site-timesteps/s",
+                          "bytes_up": int(S * (members.nbytes + clims[0].data.nbytes + clims[0].year.nbytes + clims[0].day.nbytes)),
+                          "bytes_down": int(host_stats.numel() * 8),
+                          "includes": "raw parameters + climate from host memory, site-plan build + upload, setupModel(), "
+                                      "step kernel + ensemble statistics, the statistics block back on the host "
+                                      "(median of 3 after one warm-up; the member-resolved planes stay in HBM)"}
+        except Exception as e:
+            end_to_end = {"error": repr(e)}
+
     probe = None
     if rank == 0 and world == 1 and not args.no_fill_probe and not pf and args.fast_math:
         try:
@@ -633,6 +663,7 @@ def main():
                          "issue_frac": (per_launch_units / (k_ms * 1e-3) / probe["rate"]) if probe and "rate" in probe else None,
                          "fill_probe": probe,
                          "plan_ms": plan_ms, "plan_ms_first_in_process": plan_first, "plan_build_ms": li["plan_build_ms"], "plan_upload_ms": li["plan_upload_ms"], "plan_threads": li["plan_threads"], "setup_ms": setup_ms,
+                         "end_to_end": end_to_end,
                          "algorithmic_bytes_per_unit": ALGO_BYTES[wl["prec"]],
                          "units_per_launch": per_launch_units},
             "cpu_baseline": cpu, "parity": parity,

@@ -205,8 +205,9 @@ int sipnet_batch_set_params(sipnet_batch *b, int32_t site, int32_t first_member,
  *                       writes them (differences are OCML-vs-glibc rounding, <= 1.1e-14);
  *                       one-wavefront kernel, all flags, full records
  *   SIPNET_MATH_FAST    the throughput kernels: site-only sub-expressions from the host plan,
- *                       reciprocals instead of divisions, polynomial exp2; <= 2.5e-16 on NEE
- *                       against the reference on the benchmark ensemble
+ *                       reciprocals instead of divisions, a degree-9 polynomial exp2 (3.7e-14
+ *                       relative); <= 2e-14 gC m-2 per step on NEE against the reference on the
+ *                       benchmark ensemble (measured 1.5e-14; the tests hold 1e-9, the bar is 1e-6)
  * A new fp64 batch is STRICT (no environment variable changes that).  May be changed between
  * runs. */
 enum sipnet_math { SIPNET_MATH_STRICT = 0, SIPNET_MATH_FAST = 1 };
@@ -251,6 +252,12 @@ enum sipnet_kernel_option {
                                         full record (d_rec) and by enabled diagnostics */
 };
 int sipnet_batch_set_kernel(sipnet_batch *b, int32_t kernel, int32_t options);
+/* What SIPNET_KERNEL_AUTO picks for a batch shape on a device with num_cus compute units (MI355X: 256):
+ * host-only, no device needed (tools and tests ask it; sipnet_batch_run uses the same function).
+ * math = enum sipnet_math (ignored for SIPNET_F32_MIXED); want_full = records / diagnostics /
+ * SIPNET_KOPT_FULL_STATE.  Returns an enum sipnet_kernel, -1 on a bad argument. */
+int32_t sipnet_kernel_choice(const int32_t flags[SIPNET_NFLAGS], int32_t n_sites, int32_t n_members,
+                             int32_t precision, int32_t math, int32_t want_full, int32_t num_cus);
 
 /* Per-member initialisation == setupModel() (sipnet.c:1858-1951): parameter
  * unit conversion, derived parameters, initial pools, trackers, phenology state
@@ -396,10 +403,15 @@ int sipnet_pf_systematic_ancestors_async(const double *d_logw, int64_t n, double
  * where this rank's new column j comes from -- < n_local: its own old column, n_local + k: the
  * k-th received column, received blocks concatenated in source-rank order with recv_counts[s]
  * columns each.  send_counts / recv_counts are HOST arrays of `world` entries (the split sizes
- * of the all-to-all; filling them is the plan's one host synchronisation).  world <= 64. */
+ * of the all-to-all; filling them is the plan's one host synchronisation).  world <= 64.
+ * An ancestor outside [0, world * n_local) or a decreasing pair is detected on the device and answered
+ * with SIPNET_ERR_BAD_ARGUMENT (no index of such a vector is ever used). */
 int sipnet_pf_exchange_plan(const int32_t *d_ancestors, int64_t n_local, int32_t world, int32_t rank,
                             int32_t *d_send_cols, int32_t *d_src, int64_t *send_counts,
                             int64_t *recv_counts, void *hip_stream);
+/* The resampling and the exchange plan keep device scratch per host thread between calls; this frees
+ * the calling thread's (call it before the thread ends or the device is reset; nothing else does). */
+void sipnet_pf_release_scratch(void);
 /* doubles per particle in a packed block: SIPNET_NSTATE + SIPNET_RING_SLOTS (+ SIPNET_NPARAMS) */
 int32_t sipnet_pf_member_words(int32_t with_params);
 /* Pack columns d_cols[n] (DEVICE, local column indices) into d_buf laid out

@@ -102,6 +102,7 @@ SIGNATURES = {
     "sipnet_batch_setup": (C.c_int, [_P, _P]),
     "sipnet_batch_set_math": (C.c_int, [_P, C.c_int32]),
     "sipnet_batch_set_kernel": (C.c_int, [_P, C.c_int32, C.c_int32]),
+    "sipnet_kernel_choice": (C.c_int32, [_I32P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "sipnet_batch_last_launch": (C.c_int, [_P, _P]),
     "sipnet_batch_last_kernel_name": (C.c_char_p, [_P]),
     "sipnet_batch_enable_diagnostics": (C.c_int, [_P, C.c_int32]),
@@ -124,6 +125,7 @@ SIGNATURES = {
     "sipnet_pf_systematic_ancestors": (C.c_int, [_P, C.c_int64, C.c_double, _P, _P, _P]),
     "sipnet_pf_systematic_ancestors_async": (C.c_int, [_P, C.c_int64, C.c_double, _P, _P, _P, _P]),
     "sipnet_pf_exchange_plan": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
+    "sipnet_pf_release_scratch": (None, []),
     "sipnet_pf_member_words": (C.c_int32, [C.c_int32]),
     "sipnet_batch_pack_members": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P]),
     "sipnet_batch_resample": (C.c_int, [_P, _P, _P, C.c_int32, _P, C.c_int32, _P]),

@@ -217,7 +217,40 @@ static int ensureFastRecs(sipnet_batch* b) {  // records of the throughput kerne
   return b->fastRecsUploaded ? SIPNET_OK : buildAndUpload(b, /*fastType=*/true, /*first=*/false);
 }
 
+// The shape-based kernel choice of SIPNET_KERNEL_AUTO (also exported as sipnet_kernel_choice, so
+// that tools and tests can ask without a device).
+// Few 64-member chunks per CU: the step is bound by what one wavefront can issue, so three
+// wavefronts share each chunk (step_coop.hip) -- with the chunk's ring in LDS when there is
+// at most one chunk per CU (c10k 9.0 vs 18.2 ms); up to two per CU as ONE eight-wave workgroup
+// per CU carrying two chunks with their rings in HBM, which keeps every carbon wave alone on
+// its SIMD (c4 10.6 ms; two three-wave workgroups per CU: 12.4; one-wave kernel: 19.3).
+// Up to four per CU: one twelve-wave workgroup per four chunks, every SIMD running the three
+// waves of one chunk (c3 13.0 ms; one-wave kernel 15.3); no full-state build of that one (VGPRs).
+// Bigger batches fill the SIMDs with the one-wave kernel, two waves per SIMD.
+// The nitrogen-cycle flag set has a cooperative kernel of its own (lean state, one chunk per CU:
+// its fp64 build takes 232 registers and 64 KB of LDS); every other optional flag set takes the
+// one-wave kernel.  Strict arithmetic and the debug plane: the strict-order kernel.  Full records,
+// diagnostics and SIPNET_KOPT_FULL_STATE: the "Full" instantiations of the same throughput kernels.
+static int autoKernel(const int32_t* flags, int32_t n_sites, int32_t n_members, bool fastMath, bool debugPlane,
+                      bool wantFull, int32_t numCUs) {
+  const bool defaultFlags = isDefaultFlagSet(flags);
+  const int64_t blocks = (int64_t)n_sites * ((n_members + 63) / 64);
+  if (!fastMath || debugPlane) return SIPNET_KERNEL_STRICT;
+  if (defaultFlags && blocks <= (int64_t)numCUs) return SIPNET_KERNEL_COOP_LDS;
+  if (defaultFlags && blocks <= 2 * (int64_t)numCUs) return SIPNET_KERNEL_COOP_PAIR;
+  if (defaultFlags && blocks <= 4 * (int64_t)numCUs && !wantFull) return SIPNET_KERNEL_COOP_QUAD;
+  if (isNCycleFlagSet(flags) && blocks <= (int64_t)numCUs && !wantFull) return SIPNET_KERNEL_COOP_NCYCLE;
+  return SIPNET_KERNEL_ONE_WAVE;
+}
+
 extern "C" {
+
+int32_t sipnet_kernel_choice(const int32_t* flags, int32_t n_sites, int32_t n_members, int32_t precision,
+                             int32_t math, int32_t want_full, int32_t num_cus) {
+  if (!flags || n_sites <= 0 || n_members <= 0 || num_cus <= 0) return -1;
+  const bool fast = precision == SIPNET_F32_MIXED || math == SIPNET_MATH_FAST;
+  return autoKernel(flags, n_sites, n_members, fast, false, want_full != 0, num_cus);
+}
 
 const char* sipnet_version(void) { return "sipnet_amd 0.1 (reference SIPNET 2.1.0)"; }
 const char* sipnet_last_error(void) { return g_lastError.c_str(); }
@@ -566,29 +599,10 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
   memcpy(a.flags, b->flags, sizeof(a.flags));
   // ---- kernel choice (sipnet_batch_set_kernel); nothing here reads the environment ----------
   const bool defaultFlags = isDefaultFlagSet(b->flags);
-  const int64_t blocks = (int64_t)b->n_sites * ((b->n_members + 63) / 64);
   int kernel = b->kernelPolicy;
   const bool wantFull = d_rec || b->d_diag || (b->kernelOptions & SIPNET_KOPT_FULL_STATE);
   if (kernel == SIPNET_KERNEL_AUTO) {
-    // Few 64-member chunks per CU: the step is bound by what one wavefront can issue, so three
-    // wavefronts share each chunk (step_coop.hip) -- with the chunk's ring in LDS when there is
-    // at most one chunk per CU (c10k 9.0 vs 18.2 ms); up to two per CU as ONE eight-wave workgroup
-    // per CU carrying two chunks with their rings in HBM, which keeps every carbon wave alone on
-    // its SIMD (c4 10.6 ms; two three-wave workgroups per CU: 12.4; one-wave kernel: 19.3).
-    // Up to four per CU: one twelve-wave workgroup per four chunks, every SIMD running the three
-    // waves of one chunk (c3 13.0 ms; one-wave kernel 15.3); no full-state build of that one (VGPRs).
-    // Bigger batches fill the SIMDs with the one-wave kernel, two waves per SIMD.
-    // Optional model flags (litter pool, nitrogen cycle, ...) always take the one-wave kernel.
-    // Strict arithmetic and the debug plane: the strict-order kernel.  Full records, diagnostics
-    // and SIPNET_KOPT_FULL_STATE: the "Full" instantiations of the same throughput kernels.
-    if (!b->fastMath || d_dbg) kernel = SIPNET_KERNEL_STRICT;
-    else if (defaultFlags && blocks <= (int64_t)b->numCUs) kernel = SIPNET_KERNEL_COOP_LDS;
-    else if (defaultFlags && blocks <= 2 * (int64_t)b->numCUs) kernel = SIPNET_KERNEL_COOP_PAIR;
-    else if (defaultFlags && blocks <= 4 * (int64_t)b->numCUs && !wantFull) kernel = SIPNET_KERNEL_COOP_QUAD;
-    // the nitrogen-cycle flag set has a cooperative kernel of its own (lean state, one chunk per CU:
-    // its fp64 build takes 272 registers, one wavefront per SIMD)
-    else if (isNCycleFlagSet(b->flags) && blocks <= (int64_t)b->numCUs && !wantFull) kernel = SIPNET_KERNEL_COOP_NCYCLE;
-    else kernel = SIPNET_KERNEL_ONE_WAVE;
+    kernel = autoKernel(b->flags, b->n_sites, b->n_members, b->fastMath, d_dbg != nullptr, wantFull, b->numCUs);
   } else if (kernel != SIPNET_KERNEL_STRICT) {
     if (!b->fastMath) {
       setError("sipnet_batch_run: the throughput kernels need SIPNET_MATH_FAST (sipnet_batch_set_math)");

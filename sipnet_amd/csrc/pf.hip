@@ -77,6 +77,59 @@ __global__ __launch_bounds__(256) void gatherColumnsKernel(
   }
 }
 
+// The same for the three matrices of a member's checkpoint in ONE launch (state rows, ring rows,
+// then parameter rows: the row order of a packed block): blockIdx.y walks the row groups of all three,
+// so a resampling or a pack is one kernel instead of three (launch gaps were a third of the analysis
+// step's GPU time, profiles/r02_c5.md)
+struct GatherPart {
+  const double* own;   // [rows][ownPitch]
+  double* dst;         // [rows][dstPitch]
+  int32_t rows, group0, recvRow0;   // first row group of this part; its first row inside a packed block
+};
+struct GatherParts {
+  GatherPart p[3];
+  int32_t n;
+};
+__global__ __launch_bounds__(256) void gatherMemberKernel(GatherParts parts, int64_t ownPitch, int64_t ncol,
+                                                          const double* __restrict__ recv, RecvMap map,
+                                                          const int32_t* __restrict__ src, int64_t nOut,
+                                                          int64_t dstPitch) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nOut) return;
+  int k = 0;
+  for (int q = 1; q < parts.n; q++)
+    if ((int)blockIdx.y >= parts.p[q].group0) k = q;
+  const GatherPart part = parts.p[k];
+  const int row0 = ((int)blockIdx.y - part.group0) * kGatherRows;
+  const int nr = part.rows - row0 < kGatherRows ? part.rows - row0 : kGatherRows;
+  const int64_t s = src[j];
+  double v[kGatherRows];
+  if (s < ncol) {
+    const double* __restrict__ p = part.own + (int64_t)row0 * ownPitch + s;
+    if (nr == kGatherRows) {
+#pragma unroll
+      for (int r = 0; r < kGatherRows; r++) v[r] = p[(int64_t)r * ownPitch];
+    } else {
+      for (int r = 0; r < nr; r++) v[r] = p[(int64_t)r * ownPitch];
+    }
+  } else {
+    const int64_t kk = s - ncol;
+    int blk = 0;
+    for (int q = 1; q < map.nBlocks; q++)
+      if (kk >= map.start[q]) blk = q;
+    const double* __restrict__ p = recv + map.off[blk] + (int64_t)(row0 + part.recvRow0) * map.n[blk] +
+                                   (kk - map.start[blk]);
+    for (int r = 0; r < nr; r++) v[r] = p[(int64_t)r * map.n[blk]];
+  }
+  double* __restrict__ q = part.dst + (int64_t)row0 * dstPitch + j;
+  if (nr == kGatherRows) {
+#pragma unroll
+    for (int r = 0; r < kGatherRows; r++) q[(int64_t)r * dstPitch] = v[r];
+  } else {
+    for (int r = 0; r < nr; r++) q[(int64_t)r * dstPitch] = v[r];
+  }
+}
+
 // logw[col] = -0.5 * ((sum_t plane[t][col] - obs) / sigma)^2, -inf for members that did not run
 template <typename T>
 __global__ __launch_bounds__(256) void logWeightKernel(const T* __restrict__ plane, int32_t nSteps,
@@ -91,6 +144,8 @@ __global__ __launch_bounds__(256) void logWeightKernel(const T* __restrict__ pla
   const double z = (acc - obs) * invSigma;
   logw[c] = (status[c] != 0.0) ? -INFINITY : -0.5 * z * z;
 }
+// (the scratch blocks are freed by sipnet_pf_release_scratch, not by a thread-exit destructor: that
+// may run after the HIP runtime has shut down)
 
 // max of the log-weights, two stages: per-block partial maxima, then one block over them
 __global__ __launch_bounds__(256) void maxPartialKernel(const double* __restrict__ x, int64_t n,
@@ -173,11 +228,19 @@ __global__ void planFirstKernel(const int32_t* __restrict__ anc, int64_t n, int3
   }
   first[(int64_t)d * (world + 1) + s] = lo;
 }
+// (also validates the vector: every ancestor inside [0, total) and non-decreasing -- anything else
+// (NaN weights upstream, a caller's bug) raises *bad and the plan's indices are never used)
 __global__ __launch_bounds__(256) void planHeadKernel(const int32_t* __restrict__ anc, int64_t n,
-                                                      int64_t total, int32_t* __restrict__ head) {
+                                                      int64_t total, int32_t* __restrict__ head,
+                                                      int32_t* __restrict__ bad) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int64_t a = anc[i];
+  if (a < 0 || a >= total || (i > 0 && anc[i - 1] > a)) {
+    atomicOr(bad, 1);
+    head[i] = 0;
+    return;
+  }
   const int64_t d = i / n, s = a / n;
   const bool newRun = (i % n == 0) || anc[i - 1] != a;
   head[i] = (newRun && s != d) ? 1 : 0;
@@ -188,6 +251,10 @@ __global__ void planCountKernel(const int64_t* __restrict__ first, const int32_t
                                 int32_t rank, int64_t* __restrict__ counts /* [2][world]: send, recv */,
                                 int64_t* __restrict__ bases /* [2][world] */) {
   if (threadIdx.x != 0) return;
+  if (counts[2 * kMaxWorld * 2] != 0) {   // (the validity flag lives behind the counts and bases)
+    for (int q = 0; q < 2 * world; q++) counts[q] = 0, bases[q] = 0;
+    return;
+  }
   auto Pat = [&](int64_t i) -> int64_t { return i < total ? (int64_t)P[i] : (int64_t)P[total - 1] + head[total - 1]; };
   int64_t sb = 0, rb = 0;
   for (int q = 0; q < world; q++) {
@@ -210,9 +277,10 @@ __global__ __launch_bounds__(256) void planFillKernel(const int32_t* __restrict_
                                                       const int32_t* __restrict__ head,
                                                       const int64_t* __restrict__ bases,
                                                       int32_t* __restrict__ sendCols,
-                                                      int32_t* __restrict__ src) {
+                                                      int32_t* __restrict__ src, const int32_t* __restrict__ bad) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
+  if (*bad) return;
   const int64_t a = anc[i];
   const int64_t d = i / n, s = a / n, lo = (int64_t)rank * n;
   if (s == rank && d != rank && head[i]) {   // a column of mine that rank d needs (once)
@@ -238,6 +306,26 @@ void launchGather(const double* own, int64_t ownPitch, int64_t ncol, const doubl
   dim3 grid((unsigned)((nOut + 255) / 256), (unsigned)((rows + kGatherRows - 1) / kGatherRows));
   hipLaunchKernelGGL(gatherColumnsKernel, grid, dim3(256), 0, stream, own, ownPitch, ncol, recv,
                      map, recvRow0, src, nOut, dst, dstPitch, rows);
+}
+
+// state + ring (+ parameters) of the columns src[0..nOut) in one launch
+void launchGatherMember(const double* state, const double* ring, const double* prm, int64_t ncol,
+                        const double* recv, const RecvMap& map, const int32_t* src, int64_t nOut,
+                        double* dState, double* dRing, double* dPrm, int64_t dstPitch, hipStream_t stream) {
+  if (nOut <= 0) return;
+  auto groups = [](int rows) { return (rows + kGatherRows - 1) / kGatherRows; };
+  GatherParts parts{};
+  parts.p[0] = GatherPart{state, dState, SIPNET_NSTATE, 0, 0};
+  parts.p[1] = GatherPart{ring, dRing, SIPNET_RING_SLOTS, groups(SIPNET_NSTATE), SIPNET_NSTATE};
+  parts.n = 2;
+  int total = groups(SIPNET_NSTATE) + groups(SIPNET_RING_SLOTS);
+  if (prm) {
+    parts.p[2] = GatherPart{prm, dPrm, SIPNET_NPARAMS, total, SIPNET_NSTATE + SIPNET_RING_SLOTS};
+    parts.n = 3;
+    total += groups(SIPNET_NPARAMS);
+  }
+  dim3 grid((unsigned)((nOut + 255) / 256), (unsigned)total);
+  hipLaunchKernelGGL(gatherMemberKernel, grid, dim3(256), 0, stream, parts, ncol, ncol, recv, map, src, nOut, dstPitch);
 }
 
 }  // namespace
@@ -291,7 +379,7 @@ struct PfScratch {
     if (d_tmp) (void)hipFree(d_tmp);
     d_max = nullptr; d_w = d_cdf = nullptr; d_tmp = nullptr; cap = 0; tmpBytes = 0;
   }
-  ~PfScratch() { release(); }
+  // no destructor: a thread_local's would run at thread exit, possibly after the HIP runtime is gone
 };
 constexpr int kMaxParts = 256;
 thread_local PfScratch g_pf;
@@ -371,7 +459,7 @@ struct PlanScratch {
     if (d_tmp) (void)hipFree(d_tmp);
     d_head = d_P = nullptr; d_first = d_counts = nullptr; d_tmp = nullptr; cap = 0; tmpBytes = 0;
   }
-  ~PlanScratch() { release(); }
+  // (no destructor, see PfScratch)
 };
 thread_local PlanScratch g_plan;
 }  // namespace
@@ -396,7 +484,7 @@ int sipnet_pf_exchange_plan(const int32_t* d_ancestors, int64_t n_local, int32_t
     HIP_TRY(hipMalloc(&sc.d_head, (size_t)total * sizeof(int32_t)));
     HIP_TRY(hipMalloc(&sc.d_P, (size_t)total * sizeof(int32_t)));
     HIP_TRY(hipMalloc(&sc.d_first, (size_t)(kMaxWorld + 1) * kMaxWorld * sizeof(int64_t)));
-    HIP_TRY(hipMalloc(&sc.d_counts, (size_t)4 * kMaxWorld * sizeof(int64_t)));
+    HIP_TRY(hipMalloc(&sc.d_counts, (size_t)(4 * kMaxWorld + 1) * sizeof(int64_t)));   // counts, bases, validity flag
     HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, sc.tmpBytes, sc.d_head, sc.d_P, (int)total, stream));
     HIP_TRY(hipMalloc(&sc.d_tmp, sc.tmpBytes));
     sc.cap = total;
@@ -404,24 +492,35 @@ int sipnet_pf_exchange_plan(const int32_t* d_ancestors, int64_t n_local, int32_t
   const int grid = (int)((total + 255) / 256);
   hipLaunchKernelGGL(planFirstKernel, dim3(world), dim3(kMaxWorld + 1), 0, stream, d_ancestors, n_local,
                      world, sc.d_first);
-  hipLaunchKernelGGL(planHeadKernel, dim3(grid), dim3(256), 0, stream, d_ancestors, n_local, total, sc.d_head);
+  int32_t* d_bad = (int32_t*)(sc.d_counts + 4 * kMaxWorld);
+  HIP_TRY(hipMemsetAsync(d_bad, 0, sizeof(int64_t), stream));
+  hipLaunchKernelGGL(planHeadKernel, dim3(grid), dim3(256), 0, stream, d_ancestors, n_local, total, sc.d_head, d_bad);
   size_t tmpBytes = sc.tmpBytes;
   HIP_TRY(hipcub::DeviceScan::ExclusiveSum(sc.d_tmp, tmpBytes, sc.d_head, sc.d_P, (int)total, stream));
   int64_t* d_bases = sc.d_counts + 2 * kMaxWorld;
   hipLaunchKernelGGL(planCountKernel, dim3(1), dim3(64), 0, stream, sc.d_first, sc.d_P, sc.d_head, total,
                      world, rank, sc.d_counts, d_bases);
   hipLaunchKernelGGL(planFillKernel, dim3(grid), dim3(256), 0, stream, d_ancestors, n_local, total, world,
-                     rank, sc.d_first, sc.d_P, sc.d_head, d_bases, d_send_cols, d_src);
+                     rank, sc.d_first, sc.d_P, sc.d_head, d_bases, d_send_cols, d_src, d_bad);
   HIP_TRY(hipGetLastError());
   // the one host round trip of the plan: the split sizes of the all-to-all
-  int64_t h[2 * kMaxWorld];
-  HIP_TRY(hipMemcpyAsync(h, sc.d_counts, (size_t)2 * world * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+  int64_t h[4 * kMaxWorld + 1];
+  HIP_TRY(hipMemcpyAsync(h, sc.d_counts, (size_t)(4 * kMaxWorld + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
+  if (h[4 * kMaxWorld] != 0) {
+    setError("sipnet_pf_exchange_plan: the ancestor vector is not non-decreasing inside [0, world * n_local)");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
   for (int q = 0; q < world; q++) {
     send_counts[q] = h[q];
     recv_counts[q] = h[world + q];
   }
   return SIPNET_OK;
+}
+
+void sipnet_pf_release_scratch(void) {
+  g_pf.release();
+  g_plan.release();
 }
 
 int sipnet_batch_pack_members(sipnet_batch* b, const int32_t* d_cols, int64_t n,
@@ -435,12 +534,8 @@ int sipnet_batch_pack_members(sipnet_batch* b, const int32_t* d_cols, int64_t n,
   hipStream_t stream = (hipStream_t)hip_stream;
   RecvMap none{};
   // block layout: [NSTATE rows | RING_SLOTS rows | NPARAMS rows] x n columns
-  launchGather(b->d_state, b->ncol, b->ncol, nullptr, none, 0, d_cols, n, d_buf, n, SIPNET_NSTATE, stream);
-  launchGather(b->d_ring, b->ncol, b->ncol, nullptr, none, 0, d_cols, n,
-               d_buf + (size_t)SIPNET_NSTATE * n, n, SIPNET_RING_SLOTS, stream);
-  if (with_params)
-    launchGather(b->d_prm, b->ncol, b->ncol, nullptr, none, 0, d_cols, n,
-                 d_buf + (size_t)(SIPNET_NSTATE + SIPNET_RING_SLOTS) * n, n, SIPNET_NPARAMS, stream);
+  launchGatherMember(b->d_state, b->d_ring, with_params ? b->d_prm : nullptr, b->ncol, nullptr, none, d_cols, n, d_buf,
+                     d_buf + (size_t)SIPNET_NSTATE * n, d_buf + (size_t)(SIPNET_NSTATE + SIPNET_RING_SLOTS) * n, n, stream);
   HIP_TRY(hipGetLastError());
   return SIPNET_OK;
 }
@@ -483,13 +578,8 @@ int sipnet_batch_resample(sipnet_batch* b, const int32_t* d_src, const double* d
     setError("sipnet_batch_resample: received columns announced but no buffer given");
     return SIPNET_ERR_BAD_ARGUMENT;
   }
-  launchGather(b->d_state, b->ncol, b->ncol, d_recv, map, 0, d_src, b->ncol, b->d_state2,
-               b->ncol, SIPNET_NSTATE, stream);
-  launchGather(b->d_ring, b->ncol, b->ncol, d_recv, map, SIPNET_NSTATE, d_src, b->ncol,
-               b->d_ring2, b->ncol, SIPNET_RING_SLOTS, stream);
-  if (with_params)
-    launchGather(b->d_prm, b->ncol, b->ncol, d_recv, map, SIPNET_NSTATE + SIPNET_RING_SLOTS,
-                 d_src, b->ncol, b->d_prm2, b->ncol, SIPNET_NPARAMS, stream);
+  launchGatherMember(b->d_state, b->d_ring, with_params ? b->d_prm : nullptr, b->ncol, d_recv, map, d_src, b->ncol,
+                     b->d_state2, b->d_ring2, b->d_prm2, b->ncol, stream);
   HIP_TRY(hipGetLastError());
   std::swap(b->d_state, b->d_state2);
   std::swap(b->d_ring, b->d_ring2);

@@ -125,11 +125,20 @@ void summariseTile(FastRec* out, int b, int e, const int* slot0, const int* slot
                   f.insSlot != next(out[t - 1].insSlot)))
       regular = false;
   }
+  // what the regular path compares with the members' phenology thresholds: the LARGEST year-to-date
+  // GDD and day of year of the tile (inside a tile without a year roll-over both normally only grow,
+  // but a forcing file with misordered or duplicated records may step back: the maximum, not the
+  // last record's value, proves that no switch can fire anywhere in the tile)
+  double maxGdd = out[b].cumGdd, maxDay = out[b].dayTime;
+  for (int t = b + 1; t < e; t++) {
+    if (out[t].cumGdd > maxGdd) maxGdd = out[t].cumGdd;
+    if (out[t].dayTime > maxDay) maxDay = out[t].dayTime;
+  }
   for (int t = b; t < e; t++) {
     out[t].tileBits = (regular ? FAST_TILE_REGULAR : 0) | (dayMask << 16);
     out[t].tilePad = 0;
-    out[t].tileEndCumGdd = out[e - 1].cumGdd;
-    out[t].tileEndDayTime = out[e - 1].dayTime;
+    out[t].tileEndCumGdd = maxGdd;
+    out[t].tileEndDayTime = maxDay;
   }
 }
 }  // namespace

@@ -89,8 +89,8 @@ struct FastRec {
   double log2vpd;    // for members whose dVpdExp is not 2
   double gddAfter, tillAfter;
   int32_t ins0, ins1;  // steps that wrote slot0 / slot1 (dead-member epochs)
-  int32_t opFirst;     // global RingOp index of this step's eviction list (nOps > 2)
-  int32_t evFirst;     // global EvRec index
+  int32_t opFirst;     // site-local RingOp index of this step's eviction list (nOps > 2); + siteBase[2 * site]
+  int32_t evFirst;     // site-local EvRec index; + siteBase[2 * site + 1]
   int32_t year, day;
   // ---- the 16-step tile this record belongs to (steps [16k, 16k+16) of the site) ----
   // tileBits: FAST_TILE_REGULAR when every step of the tile has the same length, the same one or
@@ -102,7 +102,7 @@ struct FastRec {
   // FAST_PAR_POS flags, bit 16+k for step 16k' + k.
   int32_t tileBits;                       // offset 208
   int32_t tilePad;
-  double tileEndCumGdd, tileEndDayTime;   // 216, 224: cumGdd / dayTime of the tile's last step
+  double tileEndCumGdd, tileEndDayTime;   // 216, 224: the largest cumGdd / dayTime of the tile's steps
   int32_t pad[6];
 };
 static_assert(sizeof(FastRec) == 256, "FastRec must stay 256 bytes");

@@ -503,7 +503,7 @@ int main(int argc, char** argv) {
     check(sipnet_batch_create(flags, 1, Ms, SIPNET_F64, devices[shard], &b), "creating batch");
     // A single run writes the reference's bytes: strict operation order (never the environment's
     // choice).  An ensemble runs on the throughput kernels (their Full instantiations write the
-    // same 44-column record; <= 2.5e-16 from the strict kernel on the fluxes, invisible at the
+    // same 44-column record; <= 2e-14 from the strict kernel on the fluxes, invisible at the
     // precision `.out` prints) unless --math strict asks otherwise; --debug-log needs strict.
     const bool fastMath = debugLog.empty() && (mathArg == "fast" || (mathArg == "auto" && !ensembleFile.empty()));
     check(sipnet_batch_set_math(b, fastMath ? SIPNET_MATH_FAST : SIPNET_MATH_STRICT), "math policy");

@@ -1073,6 +1073,11 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         if (!FacWave) {  // (wave F's job when there is one)
           WAIT_BEGIN()
           awaitAtLeast(&seqLai, t - 1);
+          // NCyc: wave S reads two rows of the block too, at the start of ITS step -- which C's progress
+          // does not vouch for (C(t-1) only needs S's nitrogen block of step t-2 done): the slot is free
+          // once S has posted R_h of step t-2, which it does right after that read (found by the fuzzer:
+          // one trial in 600 had S take the soil factors of step t+2 for step t, 2e-5 off on NEE)
+          if (NCyc) awaitAtLeast(&seqRh, t - 2);
           WAIT_END(1)
           const R vegQ = fexp2(q10Arg((R)q5.y, K_lgVeg), EC);
           R g1 = K_fol * vegQ;

@@ -13,8 +13,9 @@
 //   * the ring value evicted in step t+1 is requested at the top of step t;
 //   * no division by a site quantity and none by a loop-invariant member quantity is left in
 //     the loop; the two remaining true divisions use v_rcp + Newton steps;
-//   * exp2 is an 11th-degree polynomial (<= 1 ulp) + v_ldexp; pow(q, T/10) = exp2(T/10 *
-//     log2 q) with log2 q hoisted; the seven Simpson layers share one exp;
+//   * exp2 is a 9th-degree polynomial (<= 3.7e-14 relative; fast_math.h, tools/fit_exp2.py) +
+//     v_ldexp; pow(q, T/10) = exp2(T/10 * log2 q) with log2 q hoisted; the seven Simpson layers
+//     share one exp;
 //   * compiled with -ffp-contract=fast (a*b+c fuses to v_fma_f64).
 //
 // Reference arithmetic being reproduced: /root/reference/src/sipnet/sipnet.c:1256-1336,

@@ -82,3 +82,27 @@ def test_python_constants_mirror_the_header_enums():
         if py.startswith("MATH_"):
             continue                      # exposed as Batch(fast_math=...) / set_math(bool)
         assert getattr(sa, py) == value, (name, value, getattr(sa, py, None))
+
+
+def test_every_bench_workload_has_traffic_evidence_for_the_kernel_auto_picks():
+    """profiles/pmc_traffic.json (rocprofv3 PMC, tools/distill_profile.py) feeds bench.py's
+    `roofline.traffic`: every workload of bench.WORKLOADS has an entry, and the kernel it was collected
+    on is the one SIPNET_KERNEL_AUTO picks for that shape on a 256-CU device (sipnet_kernel_choice, the
+    function sipnet_batch_run uses) -- a stale entry would silently print `traffic: null`."""
+    import json
+    import sipnet_amd as sa
+    from bench import WORKLOADS
+    L = sa.lib()
+    traffic = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
+    family = {sa.KERNEL_ONE_WAVE: "stepFastKernel<", sa.KERNEL_COOP_LDS: "stepCoopKernel<", sa.KERNEL_COOP_PAIR: "stepCoopPairKernel<",
+              sa.KERNEL_COOP_QUAD: "stepCoopQuadKernel<", sa.KERNEL_COOP_NCYCLE: "stepCoopNKernel<", sa.KERNEL_STRICT: "stepKernel<"}
+    for name, wl in WORKLOADS.items():
+        flags = (C.c_int32 * 12)(*sa.flags_from(**wl.get("flags", {})))
+        prec = sa.F64 if wl["prec"] == "f64" else sa.F32_MIXED
+        k = L.sipnet_kernel_choice(flags, wl["sites"], wl["members"], prec, 1, 0, 256)
+        assert k in family, (name, k)
+        ent = traffic.get(name)
+        assert ent and ent.get("hbm_bytes_per_launch", 0) > 0, f"no HBM-traffic evidence for workload {name}"
+        assert ent.get("kernel", "").startswith(family[k]), (name, ent.get("kernel"), family[k])
+        if k == sa.KERNEL_COOP_LDS:       # the ring-in-LDS instantiation: third template argument true
+            assert ent["kernel"].split(",")[2].strip() == "true", ent["kernel"]

@@ -52,7 +52,20 @@ if means:
         if "sipnet" in k:
             out.append(f"| `{k[:70]}` | {c} | {v:.6g} |")
     out.append("")
-    step = [k for (k, c) in means if "stepKernel" in k or "stepFastKernel" in k or "stepCoopKernel" in k]
+    # the step kernel: the instantiation the library says it launched (tools/prof_target.py prints
+    # sipnet_batch_last_launch's name), else any step*Kernel of this engine
+    import re
+    launched = None
+    try:
+        for line in open(os.path.join(src, "pmc_fetch.log")):
+            if line.startswith("step kernel name"):
+                launched = line.split("name", 1)[1].strip()
+    except OSError:
+        pass
+    norm = lambda k: k.replace("void sipnet::", "").replace("(anonymous namespace)::", "").split("(sipnet::")[0].strip()
+    step = [k for (k, c) in means if launched and norm(k) == launched]
+    if not step:
+        step = [k for (k, c) in means if re.search(r"\bstep(Coop[A-Za-z]*|Fast)?Kernel<", k)]
     red = [k for (k, c) in means if "reducePlane" in k]
     if step and red:
         sk, rk = step[0], red[0]
@@ -73,7 +86,7 @@ if means:
                     f"* **traffic = {hbm/1e9:.3f} GB per launch**", ""]
             tj = os.path.join(dst, "pmc_traffic.json")
             d = json.load(open(tj)) if os.path.exists(tj) else {}
-            kname = sk.replace("void sipnet::", "").split("(sipnet::")[0]
+            kname = norm(sk)
             d[wl] = {"hbm_bytes_per_launch": hbm, "tag": tag, "fetch_correction": corr, "kernel": kname}
             json.dump(d, open(tj, "w"), indent=1)
         sq = {c: means[(sk, c)] for (k, c) in means if k == sk and c.startswith("SQ_")}

@@ -28,3 +28,4 @@ for _ in range(reps):
     st = b.reduce_plane(planes[0])
 torch.cuda.synchronize()
 print("kernel ms", b.last_kernel_ms(), "plane bytes", planes[0].numel() * planes[0].element_size())
+print("step kernel name", b.last_launch()["kernel"])
