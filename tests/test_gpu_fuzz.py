@@ -70,3 +70,18 @@ def test_fuzz_cooperative_layouts_with_fragile_members():
     print(r.stdout[-3000:])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "40 trials ok" in r.stdout
+
+
+def test_fuzz_nitrogen_cycle_cooperative_kernel():
+    """a fixed-seed slice of the nitrogen-cycle campaign (FUZZ_NCYC=1: litter pool + anaerobic + nitrogen
+    cycle; stepCoopNKernel forced or picked by the shape policy, the one-wave kernel of the same flag set,
+    regular tiles on and off, fragile stands, productive stands short of nitrogen, random events and
+    launch cuts).  Trial 127 of seed 777 is in the slice: the run on which the soil wave once read the
+    light wave's factor rows of step t + 2 for step t (the slot's re-use was guarded by the carbon wave's
+    progress only) -- a timing-dependent 2e-5 on NEE that the fixed tests never showed."""
+    env = dict(os.environ, FUZZ_NCYC="1")
+    r = subprocess.run([sys.executable, os.path.join(helpers.REPO, "tools", "fuzz_gpu.py"), "140", "777"],
+                       capture_output=True, text=True, timeout=1200, env=env)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "140 trials ok" in r.stdout and "coop-ncycle" in r.stdout
