@@ -2259,7 +2259,22 @@ __global__ __launch_bounds__(768) void stepCoopQuadKernel(FastArgs a) {
   coopBody<R, PlainExp, false, false, 4>(a);
 }
 
-// the nitrogen-cycle flag set: four wavefronts per chunk (F L W C), soil + nitrogen on wave W
+#ifdef SIPNET_QUAD_FULL_PROBE
+// dev probe (tools/kernel_resources.py step_coop.hip -DSIPNET_QUAD_FULL_PROBE): what a full-state build of
+// the four-chunk layout would cost under its 168-register budget (twelve wavefronts per CU).  Measured:
+// fp64 284 bytes of scratch per lane (71 spilled dwords, the carbon wave's record columns and accumulators)
+// against 0 for the lean build, fp32-mixed 136 -- which is why such batches take the one-wave kernel's
+// Full build instead (28 ms at c10k's shape with the record; spilled registers in the carbon wave's loop
+// go to scratch memory every step).
+template <class R, bool PlainExp>
+__global__ __launch_bounds__(768) void stepCoopQuadFullProbeKernel(FastArgs a) {
+  coopBody<R, PlainExp, false, true, 4>(a);
+}
+template __global__ void stepCoopQuadFullProbeKernel<double, true>(FastArgs);
+template __global__ void stepCoopQuadFullProbeKernel<float, true>(FastArgs);
+#endif
+
+// the nitrogen-cycle flag set: four wavefronts per chunk (L W C S), soil + nitrogen on wave S
 template <class R, bool PlainExp>
 __global__ __launch_bounds__(256) void stepCoopNKernel(FastArgs a) {
   coopBody<R, PlainExp, false, false, 1, true>(a);
