@@ -637,9 +637,10 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
   // summing, the launch grows by 3-5 % against 10-15 % for the three passes; on the two- / four-chunk
   // layouts the light wave would do it and its loads cost more than the passes -- SIPNET_KOPT_STATS_IN_KERNEL
   // forces it there for tests and measurements)
-  const bool coop = kernel == SIPNET_KERNEL_COOP_LDS ||
+  const bool coop = kernel == SIPNET_KERNEL_COOP_LDS || kernel == SIPNET_KERNEL_COOP_PAIR ||
+                    (kernel == SIPNET_KERNEL_COOP_QUAD && b->precision == SIPNET_F32_MIXED) ||
                     ((b->kernelOptions & SIPNET_KOPT_STATS_IN_KERNEL) && kernel != SIPNET_KERNEL_STRICT &&
-                     kernel != SIPNET_KERNEL_ONE_WAVE);
+                     kernel != SIPNET_KERNEL_ONE_WAVE && kernel != SIPNET_KERNEL_COOP_NCYCLE);
   const int chunksPerSite = (b->n_members + 63) / 64;
   if (d_stats && coop) {
     const size_t need = (size_t)3 * b->n_sites * chunksPerSite * n_steps * 2;

@@ -456,6 +456,14 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   __shared__ int seqLaiAll[NP], seqPgpAll[NP], seqPsnAll[NP];
   __shared__ alignas(8) int seqFacMoistAll[NP][2];  // [0] wave F's / L's factor rows, [1] wave W's moisture row
   __shared__ int seqDoneAll[NP][2];  // statistics: wave C's / wave W's plane stores of the whole launch have completed
+  // Two- and four-chunk layouts (no wave F; the planes do not stay in L2 there: the HBM rings of 512-1 024
+  // chunks stream through it): with sipnet_batch_run_stats waves C and W also put every value they store
+  // into an LDS staging block -- two halves of kStageR steps -- and wave L sums a half, one plane per
+  // step, once both are past it: the planes are never read back.  (Four chunks in fp64 have no LDS left
+  // for it; such a launch is followed by the reduction passes.)
+  constexpr bool Staged = NP >= 2 && !Full && !NCyc && !(NP == 4 && sizeof(R) == 8);
+  constexpr int kStageR = NP == 4 ? 4 : 8;
+  __shared__ alignas(16) R stageAll[NP][3][Staged ? 2 * kStageR : 1][64];
   // NCyc hand-overs (doubles whatever R is).  C -> W per step: leafLitter woodLitter fineRootLoss
   // coarseRootLoss nDemand reductionNResorption leafOnN(all) leafOnN(computed switch) [rates]; W -> C per
   // step: R_h (two slots: W may post the next one before C has taken this one) and the mineral N at the
@@ -495,6 +503,8 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   int& seqPsn = seqPsnAll[sub];
   auto& seqFacMoist = seqFacMoistAll[sub];
   auto& seqDone = seqDoneAll[sub];
+  auto& stage = stageAll[sub];
+  const bool stageOn = Staged && a.statsPart != nullptr;
   [[maybe_unused]] const bool firstChunk = blockIdx.x == 0 && sub == 0;  // diagnostics builds report this one
 #ifdef SIPNET_HWID
   if (lane == 0 && role >= 0 && (blockIdx.x * NP + sub) < 4096) {
@@ -695,6 +705,117 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
     statTile += last ? 1 : 0;
     statNext += last ? 6 : 5;
   };
+  // ---- the staged variant (two- / four-chunk layouts): a half of kStageR steps, one plane per action on
+  // three consecutive steps after the half is complete (C and W are past a step once C has posted the
+  // leaf area of the step after next).  64 / kStageR lanes per row, each sums kStageR interleaved columns;
+  // DPP permutations join the lanes of a row.
+  int stageBlock = 0;          // half being summed: steps [tBegin + stageBlock * kStageR, + kStageR)
+  auto stagedPlane = [&](int p, int tLimit) {
+    constexpr int kLanesPerRow = 64 / kStageR;
+    const int r = lane / kLanesPerRow, c0 = lane % kLanesPerRow;
+    const int rowIdx = ((stageBlock & 1) * kStageR + r);
+    const R* src = &stage[p][rowIdx][c0];
+    double s1 = 0.0, s2 = 0.0;
+    if (sizeof(R) == 8) {
+      double v0, v1, v2, v3, v4, v5, v6, v7;
+      // (kStageR == 8: eight doubles, columns c0 + 8 i)
+      asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:64\n\tds_read_b64 %2, %8 offset:128\n\t"
+                   "ds_read_b64 %3, %8 offset:192\n\tds_read_b64 %4, %8 offset:256\n\tds_read_b64 %5, %8 offset:320\n\t"
+                   "ds_read_b64 %6, %8 offset:384\n\tds_read_b64 %7, %8 offset:448\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(v4), "=&v"(v5), "=&v"(v6), "=&v"(v7)
+                   : "v"(ldsAddr(src)) : "memory");
+      const double v[8] = {v0, v1, v2, v3, v4, v5, v6, v7};
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        s1 += v[i];
+        s2 = __builtin_fma(v[i], v[i], s2);
+      }
+    } else if (kStageR == 8) {
+      float v0, v1, v2, v3, v4, v5, v6, v7;
+      asm volatile("ds_read_b32 %0, %8\n\tds_read_b32 %1, %8 offset:32\n\tds_read_b32 %2, %8 offset:64\n\t"
+                   "ds_read_b32 %3, %8 offset:96\n\tds_read_b32 %4, %8 offset:128\n\tds_read_b32 %5, %8 offset:160\n\t"
+                   "ds_read_b32 %6, %8 offset:192\n\tds_read_b32 %7, %8 offset:224\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(v4), "=&v"(v5), "=&v"(v6), "=&v"(v7)
+                   : "v"(ldsAddr(src)) : "memory");
+      const float v[8] = {v0, v1, v2, v3, v4, v5, v6, v7};
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const double x = (double)v[i];
+        s1 += x;
+        s2 = __builtin_fma(x, x, s2);
+      }
+    } else {
+      float v0, v1, v2, v3;   // kStageR == 4: sixteen lanes per row, columns c0 + 16 i
+      asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:64\n\tds_read_b32 %2, %4 offset:128\n\t"
+                   "ds_read_b32 %3, %4 offset:192\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(ldsAddr(src)) : "memory");
+      const float v[4] = {v0, v1, v2, v3};
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const double x = (double)v[i];
+        s1 += x;
+        s2 = __builtin_fma(x, x, s2);
+      }
+    }
+    // columns past the site's last member hold copies of that member (clamped lanes): not part of the sums
+    if (__builtin_expect((chunk << 6) + 64 > a.n_members, 0)) {
+      // (rare: the ragged last chunk) recompute with the mask, element by element
+      s1 = 0.0;
+      s2 = 0.0;
+      for (int i = 0; i < kStageR; i++) {
+        const int c = c0 + kLanesPerRow * i;
+        const double x = ((chunk << 6) + c < a.n_members) ? (double)stage[p][rowIdx][c] : 0.0;
+        s1 += x;
+        s2 = __builtin_fma(x, x, s2);
+      }
+    }
+    auto dppAdd = [](double v, auto ctrl) -> double {
+      const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), decltype(ctrl)::value, 0xf, 0xf, false);
+      const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), decltype(ctrl)::value, 0xf, 0xf, false);
+      return v + __hiloint2double(hi, lo);
+    };
+    auto rowSum = [&](double v) -> double {
+      v = dppAdd(v, std::integral_constant<int, 0xB1>{});    // quad_perm:[1,0,3,2]
+      v = dppAdd(v, std::integral_constant<int, 0x4E>{});    // quad_perm:[2,3,0,1]
+      v = dppAdd(v, std::integral_constant<int, 0x141>{});   // row_half_mirror: the other quad of the 8
+      if (kLanesPerRow == 16) v = dppAdd(v, std::integral_constant<int, 0x140>{});   // row_mirror: the other half of the 16
+      return v;
+    };
+    s1 = rowSum(s1);
+    s2 = rowSum(s2);
+    const int t = tBegin + stageBlock * kStageR + r;
+    if (c0 == 0 && t < tLimit) {
+      const int64_t gChunk = (int64_t)site * chunksPerSite + chunk;
+      double* dst = a.statsPart + (((int64_t)p * a.statsChunks + gChunk) * a.n_steps + (t - tBegin)) * 2;
+      typedef double d2s __attribute__((ext_vector_type(2)));
+      *(d2s*)dst = d2s{s1, s2};
+    }
+  };
+  // the staged action that is due (statNext): planes 0, 1, 2 of a half on three consecutive steps
+  auto stagedAct = [&]() {
+    const int blockEnd = tBegin + (stageBlock + 1) * kStageR;
+    if (statPlane == 0) awaitAtLeast(&seqLai, blockEnd + 1);
+    // W's planes (GPP, ET) first, C's (NEE) last: at night W may store the first step of the half after
+    // next -- the same rows -- as soon as C has posted that step's leaf area, which C can do once this wave
+    // has posted the factors of the step before, i.e. while this wave is on the LAST of its three turns;
+    // C itself needs this wave's next factors before it gets there
+    stagedPlane(statPlane == 0 ? 1 : statPlane == 1 ? 2 : 0, tEnd);
+    const bool last = statPlane == 2;
+    statPlane = last ? 0 : statPlane + 1;
+    stageBlock += last ? 1 : 0;
+    statNext = last ? (tBegin + (stageBlock + 1) * kStageR + 1) : statNext + 1;
+  };
+  auto stagedFinish = [&]() {  // after the loop: what is left, once C and W have finished
+    awaitAtLeast(&seqDone[0], 1);
+    awaitAtLeast(&seqDone[1], 1);
+    while (tBegin + stageBlock * kStageR < tEnd) {
+      stagedPlane(statPlane == 0 ? 1 : statPlane == 1 ? 2 : 0, tEnd);
+      const bool last = statPlane == 2;
+      statPlane = last ? 0 : statPlane + 1;
+      stageBlock += last ? 1 : 0;
+    }
+  };
+  if (Staged) statNext = tBegin + kStageR + 1;
   auto statFinish = [&]() {  // after the wave's loop: the last tiles, once C and W have drained their stores
     awaitAtLeast(&seqDone[0], 1);
     awaitAtLeast(&seqDone[1], 1);
@@ -1061,7 +1182,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
                      : "=&v"(bitsV), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q5), "=&v"(q6x)
                      : "v"(ldsAddr(recB)) : "memory");
         const int bits = uni(bitsV);
-        if (statsHere && t == statNext) statAct(false);
+        if (!Staged && statsHere && t == statNext) statAct(false);
         // ---- for wave C: the climate / parameter part of its respiration terms of THIS step
         // (vegResp sipnet.c:1051-1068, calcRootResp :1073, calcSoilRespiration :1132-1148 with
         // depeffects.c:71-74):  folResp = leafC * g1,  rVeg = folResp + totalWoodC * g2,
@@ -1093,6 +1214,8 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
           const R qSoilT = K_bsr * qSoil * (R)q3.x;
           if (NCyc) postRaw(&mailFac[t & 1][6][lane], qSoil);   // before the flag post5 sets
           post5(&mailFac[t & 1][0][lane], &seqFac, g1, g2, qSoilT, gFine, gCoarse, t);
+          // (staged statistics: after the post, so that C has what it waits for; a third of a half per step)
+          if (Staged && stageOn && t == statNext) stagedAct();
         }
         if (!(bits & FAST_PAR_POS)) continue;  // night: potGrossPsn = 0, nobody waits for it
         {
@@ -1119,7 +1242,8 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
       }
     }
     WAIT_STORE(0)
-    if (statsHere) statFinish();
+    if (Staged && stageOn) stagedFinish();
+    else if (statsHere) statFinish();
     return;
   }
 
@@ -1318,6 +1442,10 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         *oGpp = tGpp;
         oEt += ldEt;
         oGpp += ldGpp;
+        if (__builtin_expect(stageOn, 0)) {   // sipnet_batch_run_stats on a two- / four-chunk layout: for wave L
+          postRaw(&stage[1][(t - tBegin) & (2 * kStageR - 1)][lane], tGpp);
+          postRaw(&stage[2][(t - tBegin) & (2 * kStageR - 1)][lane], tEt);
+        }
         if (Full && recw) {
           const int64_t L = a.ld;
           recw[1 * L] = (double)tGpp;
@@ -1595,6 +1723,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
           }
           *oNee = tNee;
           oNee += ldNee;
+          if (__builtin_expect(stageOn, 0)) postRaw(&stage[0][(t - tBegin) & (2 * kStageR - 1)][lane], tNee);
         };
         unsigned dayMask = ((unsigned)tileBits >> 16) >> (t - tileStart);
         for (; t < tLast; t++, dayMask >>= 1) {
@@ -2185,6 +2314,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
     }
     *oNee = tNee;
     oNee += ldNee;
+    if (__builtin_expect(stageOn, 0)) postRaw(&stage[0][(t - tBegin) & (2 * kStageR - 1)][lane], tNee);
     CSTAMP(6)
   }  // steps of this tile
   }  // tiles

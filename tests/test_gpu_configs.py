@@ -416,3 +416,32 @@ def test_a_member_starving_in_the_middle_of_a_regular_tile(oracle, base):
         print("kernel %d: max|d| %.3e; member 3 died at step %d (oracle %d)" % (kernel, d.max(), int(state[3, 30]), died))
         assert d.max() < TOL_F64, kernel
         assert int(state[3, 30]) == died
+
+
+@pytest.mark.parametrize("workload", ["c4", "c3", "c10k"])
+def test_run_stats_at_the_baseline_shapes_equals_the_sums_over_the_planes(workload, base):
+    """sipnet_batch_run_stats at full size (every CU busy for a whole year: the hand-overs between the
+    storing wavefronts and the summing one are exercised 17 520 x 512..1 024 times): the statistics block
+    of the launch equals the sums over the very planes it wrote -- c4 (two-chunk workgroups: values staged
+    in LDS, summed by the light wave), c3 (four-chunk, fp32), c10k (fourth wavefront reads the tiles back
+    from L2) -- and the planes are those of a plain run"""
+    from bench import WORKLOADS
+    wl = WORKLOADS[workload]
+    S, M, T = wl["sites"], wl["members"], wl["steps"]
+    prec = sa.F64 if wl["prec"] == "f64" else sa.F32_MIXED
+    clims = [year_clim(site=s) for s in range(S)]
+    members = synth.perturbed_params(base, M)
+    b = build(sa.flags_from(), clims, members, prec)
+    planes, stats = b.run_stats(0, T)
+    li = b.last_launch()
+    want1 = torch.stack([planes[v].double().view(T, S, M).sum(-1) for v in range(3)])
+    want2 = torch.stack([(planes[v].double().view(T, S, M) ** 2).sum(-1) for v in range(3)])
+    d1 = float((stats[..., 0] - want1).abs().max() / want1.abs().max())
+    d2 = float((stats[..., 1] - want2).abs().max() / want2.abs().max())
+    b.setup()
+    ref, _ = b.run(0, T)
+    same = bool(torch.equal(ref, planes))
+    b.close()
+    print(workload, li["kernel"], "stats vs planes: %.2e %.2e" % (d1, d2))
+    assert d1 < 1e-12 and d2 < 1e-12, li
+    assert same, li
