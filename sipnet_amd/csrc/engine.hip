@@ -42,11 +42,21 @@ static int planThreadsFor(int nS) {
   if (n > 16) n = 16;
   return n > nS ? nS : n;
 }
+// (a worker that fails -- f returns false, or throws: std::bad_alloc on a huge forcing must not reach
+// std::terminate in the caller's process -- stops the others at their next site; *failed says so)
 template <class F>
-static void forEachSite(int nS, int nThreads, F f) {
+static void forEachSite(int nS, int nThreads, std::atomic<bool>* failed, F f) {
   std::atomic<int> next{0};
   auto work = [&]() {
-    for (int s = next.fetch_add(1); s < nS; s = next.fetch_add(1)) f(s);
+    for (int s = next.fetch_add(1); s < nS && !failed->load(); s = next.fetch_add(1)) {
+      bool ok = false;
+      try {
+        ok = f(s);
+      } catch (...) {
+        ok = false;
+      }
+      if (!ok) failed->store(true);
+    }
   };
   std::vector<std::thread> pool;
   for (int i = 1; i < nThreads; i++) pool.emplace_back(work);
@@ -103,7 +113,8 @@ static int buildAndUpload(sipnet_batch* b, bool fastType, bool first) {
   // (57 GB/s from this buffer once it has been touched) hide behind the build
   std::atomic<int> copyErr{0};
   std::atomic<int64_t> copyUs{0};
-  forEachSite(nS, nThreads, [&](int s) {
+  std::atomic<bool> failed{false};
+  forEachSite(nS, nThreads, &failed, [&](int s) -> bool {
     SitePlan p = buildSitePlan(b->flags, nT, b->clim[s].data(), b->year[s].data(), b->day[s].data(),
                                (int32_t)b->events[s].size(), b->events[s].data(),
                                b->resume[s].set ? &b->resume[s] : nullptr, nullptr, /*wantSteps=*/false,
@@ -120,11 +131,19 @@ static int buildAndUpload(sipnet_batch* b, bool fastType, bool first) {
                    : hipMemcpy(b->d_plan + (size_t)s * nT, steps + (size_t)s * nT, (size_t)nT * sizeof(StepRec),
                                hipMemcpyHostToDevice);
     }
-    if (e != hipSuccess) copyErr.store((int)e);
+    if (e != hipSuccess) {
+      int none = 0;
+      copyErr.compare_exchange_strong(none, (int)e);   // the FIRST error is the one reported
+    }
     copyUs.fetch_add((int64_t)((nowMs() - c0) * 1e3));
+    return e == hipSuccess;
   });
   if (copyErr.load() != 0) {
     setError(std::string("sipnet_batch: uploading the site records failed: ") + hipGetErrorString((hipError_t)copyErr.load()));
+    return SIPNET_ERR_INTERNAL;
+  }
+  if (failed.load()) {
+    setError("sipnet_batch: building the site plans failed (out of host memory?)");
     return SIPNET_ERR_INTERNAL;
   }
   (fastType ? b->fastRecsUploaded : b->stepRecsUploaded) = true;
@@ -288,13 +307,7 @@ int sipnet_batch_create(const int32_t* flags, int32_t n_sites, int32_t n_members
   b->precision = precision;
   b->device = device;
   b->ncol = (int64_t)n_sites * n_members;
-  // the throughput kernels index the ring [slot][col] with 32-bit element offsets
-  if (b->ncol * SIPNET_RING_SLOTS >= (int64_t)1 << 31) {
-    setError("sipnet_batch_create: n_sites * n_members * 250 must stay below 2^31 "
-             "(8.5 M columns per batch); split the ensemble into several batches");
-    delete b;
-    return SIPNET_ERR_BAD_ARGUMENT;
-  }
+
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) b->numCUs = prop.multiProcessorCount;
@@ -627,6 +640,13 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
                "(records, diagnostics, SIPNET_KOPT_FULL_STATE)");
       return SIPNET_ERR_BAD_ARGUMENT;
     }
+  }
+  // the throughput kernels index the ring [slot][col] with 32-bit element offsets (the strict-order kernel
+  // uses 64-bit ones and takes any size)
+  if (kernel != SIPNET_KERNEL_STRICT && b->ncol * SIPNET_RING_SLOTS >= (int64_t)1 << 31) {
+    setError("sipnet_batch_run: the throughput kernels need n_sites * n_members * 250 < 2^31 (8.5 M columns per "
+             "batch); split the ensemble into several batches or use SIPNET_MATH_STRICT");
+    return SIPNET_ERR_BAD_ARGUMENT;
   }
   rc = kernel != SIPNET_KERNEL_STRICT ? ensureFastRecs(b) : ensureStepRecs(b);
   if (rc) return rc;

@@ -504,7 +504,11 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   auto& seqFacMoist = seqFacMoistAll[sub];
   auto& seqDone = seqDoneAll[sub];
   auto& stage = stageAll[sub];
+#ifdef SIPNET_NO_STATS
+  const bool stageOn = false;
+#else
   const bool stageOn = Staged && a.statsPart != nullptr;
+#endif
   [[maybe_unused]] const bool firstChunk = blockIdx.x == 0 && sub == 0;  // diagnostics builds report this one
 #ifdef SIPNET_HWID
   if (lane == 0 && role >= 0 && (blockIdx.x * NP + sub) < 4096) {
@@ -603,7 +607,11 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   // steps before their sums, an L1 prefetch two steps before the turn, half planes per turn, the turn
   // after the factor post -- none cheaper; what costs is the loads themselves (they take C's and W's
   // place in the memory pipeline), not the wait for them.
+#ifdef SIPNET_NO_STATS   // (A/B probe: what the statistics machinery costs a launch that does not use it)
+  const bool statsHere = false;
+#else
   const bool statsHere = a.statsPart != nullptr && role == (FacWave ? 3 : 2);
+#endif
   int statTile = tBegin / kFastTile;                    // tile being summed
   int statPlane = 0;                                    // its next plane
   int statNext = (statTile + 3) * kFastTile + 4;        // step of this wave on which that plane is due
