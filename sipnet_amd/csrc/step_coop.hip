@@ -165,11 +165,11 @@ __device__ __forceinline__ void takeFactors(const float* block, const int* flags
   } while (uni(f.x < f.y ? f.x : f.y) < step);
   g1 = a.x; g2 = a.y; qSoilT = b.x; gFine = b.y; gCoarse = c.x; moist = c.y;
 }
-// NCyc, wave C: rows 0 1 | 3 4 | 6 of the factor block behind wave L's flag and wave S's mineral nitrogen
-// behind its own, one round trip
+// NCyc, wave C: rows 0 1 | 3 4 | 6 of the factor block behind wave L's flag, and -- in the same round trip,
+// if it is there already -- wave S's mineral nitrogen with its flag
 __device__ __forceinline__ void takeFactorsN(const double* block, const int* facFlag, const double* minNSlot, const int* minNFlag,
                                              int step, double& g1, double& g2, double& gFine, double& gCoarse, double& qSoil,
-                                             double& minN) {
+                                             double& minN, int& minNSeq) {
   int f0, f1;
   d2v a, b;
   do {
@@ -178,12 +178,13 @@ __device__ __forceinline__ void takeFactorsN(const double* block, const int* fac
                  : "=&v"(f0), "=&v"(a), "=&v"(b), "=&v"(qSoil), "=&v"(f1), "=&v"(minN)
                  : "v"((unsigned)(size_t)facFlag), "v"((unsigned)(size_t)block), "v"((unsigned)(size_t)minNFlag),
                    "v"((unsigned)(size_t)minNSlot) : "memory");
-  } while (uni(f0) < step || uni(f1) < step);
+  } while (uni(f0) < step);   // (the mineral nitrogen is looked at, not waited for: see plantSideN)
+  minNSeq = uni(f1);
   g1 = a.x; g2 = a.y; gFine = b.x; gCoarse = b.y;
 }
 __device__ __forceinline__ void takeFactorsN(const float* block, const int* facFlag, const double* minNSlot, const int* minNFlag,
                                              int step, float& g1, float& g2, float& gFine, float& gCoarse, float& qSoil,
-                                             double& minN) {
+                                             double& minN, int& minNSeq) {
   int f0, f1;
   f2v a, b;
   do {
@@ -192,7 +193,8 @@ __device__ __forceinline__ void takeFactorsN(const float* block, const int* facF
                  : "=&v"(f0), "=&v"(a), "=&v"(b), "=&v"(qSoil), "=&v"(f1), "=&v"(minN)
                  : "v"((unsigned)(size_t)facFlag), "v"((unsigned)(size_t)block), "v"((unsigned)(size_t)minNFlag),
                    "v"((unsigned)(size_t)minNSlot) : "memory");
-  } while (uni(f0) < step || uni(f1) < step);
+  } while (uni(f0) < step);   // (the mineral nitrogen is looked at, not waited for: see plantSideN)
+  minNSeq = uni(f1);
   g1 = a.x; g2 = a.y; gFine = b.x; gCoarse = b.y;
 }
 // the same with the ring value the step will evict riding in the same round trip (LDS ring, regular
@@ -465,20 +467,22 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   constexpr int kStageR = NP == 4 ? 4 : 8;
   __shared__ alignas(16) R stageAll[NP][3][Staged ? 2 * kStageR : 1][64];
   // NCyc hand-overs (doubles whatever R is).  C -> W per step: leafLitter woodLitter fineRootLoss
-  // coarseRootLoss nDemand reductionNResorption leafOnN(all) leafOnN(computed switch) [rates]; W -> C per
-  // step: R_h (two slots: W may post the next one before C has taken this one) and the mineral N at the
-  // start of the step; W -> C after the mortality hand-over: storage N.  Rare: C -> W the soil-side
+  // coarseRootLoss nDemand reductionNResorption leafOnN(all) leafOnN(computed switch) [rates] early in its
+  // step and GPP - R_a of the step at its end (S has R_h: it forms, stores and totals NEE); S -> C per
+  // step: the mineral N at the start of the step; after the mortality hand-over: storage N.  Rare: C -> W the soil-side
   // increments of events [litterC soilC minN soilOrgN litterN storN, rates] and of plant death
   // [to soilC, to litterC, to soilOrgN, to litterN]; a nitrogen-limited step: W -> C {availableMinN,
   // fixation share, unclaimed storage}, C -> W the final demand.
-  __shared__ alignas(16) double mailPlant[NCyc ? 8 : 1][64], mailRh[NCyc ? 2 : 1][64], mailMinN[NCyc ? 2 : 1][64];
-  __shared__ alignas(16) double mailStorN[NCyc ? 2 : 1][64], mailEvent[NCyc ? 6 : 1][64], mailDeath[NCyc ? 4 : 1][64];
+  // (plant fluxes and event increments in two slots: C posts a step's before it has S's mineral nitrogen
+  // of that step, i.e. possibly before S has consumed the step before)
+  __shared__ alignas(16) double mailPlant[NCyc ? 2 : 1][NCyc ? 8 : 1][64], mailPend[NCyc ? 2 : 1][64], mailMinN[NCyc ? 2 : 1][64];
+  __shared__ alignas(16) double mailStorN[NCyc ? 2 : 1][64], mailEvent[NCyc ? 2 : 1][NCyc ? 6 : 1][64], mailDeath[NCyc ? 4 : 1][64];
   __shared__ alignas(16) double mailSupply[NCyc ? 3 : 1][64], mailDemand[1][64];
   // wave W -> wave S per step: [anaerobic moisture effect, anoxic share] at its start (seqWat), the
   // leached share of the mineral nitrogen once the drainage is known (seqLeach)
   // (four slots: W runs at most one step ahead of C, and C at most two ahead of S's consumption)
   __shared__ alignas(16) double mailWat[NCyc ? 4 : 1][NCyc ? 3 : 1][64];
-  __shared__ int seqPlant, seqRh, seqMinN, seqStorN, seqEvent, seqSupply, seqDemand, seqWat, seqLeach;
+  __shared__ int seqPlant, seqMinN, seqStorN, seqEvent, seqSupply, seqDemand, seqWat, seqLeach;
 #define seqFac seqFacMoist[0]
 #define seqMoist seqFacMoist[1]
   // The running-mean ring of the 64 members lives in LDS for the whole launch (250 x 64 x 8 B =
@@ -564,7 +568,6 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
       seqDone[1] = 0;
       if (NCyc) {
         seqPlant = tBegin - 1;
-        seqRh = tBegin - 1;
         seqMinN = tBegin - 1;
         seqStorN = tBegin - 1;
         seqEvent = tBegin - 1;
@@ -941,6 +944,9 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
     const R G_soilCH4 = (R)PRM(soilMethaneRate), G_litCH4 = (R)PRM(litterMethaneRate);
     double soilC = ST(soilC), litterC = ST(litterC), minN = ST(minN);
     double soilOrgN = ST(soilOrgN), litterN = ST(litterN), storN = ST(plantStorageN);
+    double totNee = ST(totNee);
+    R* __restrict__ oNee = (R*)(a.nee ? a.nee : a.scratchRow) + col;
+    const int64_t ldNee = a.nee ? a.ld : 0;
     // what C needs of these pools at the start of the first step
     postD(&mailMinN[tBegin & 1][lane], 0, minN);
     postFlag(&seqMinN, tBegin);
@@ -949,7 +955,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
 
     WAIT_DECL()
     for (int tileStart = curTile * kFastTile; tileStart < tEnd; tileStart += kFastTile, curTile++) {
-      if (tileStart > tBegin) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMA of 16 steps ago
+      if (tileStart > tBegin) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");  // DMA of 16 steps ago; all but the last NEE store
       stageTile(curTile + 1, (curTile + 1) & 1);
       const int tFirst = tileStart > tBegin ? tileStart : tBegin;
       const int tLast = (tileStart + kFastTile) < tEnd ? (tileStart + kFastTile) : tEnd;
@@ -969,24 +975,39 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         const double minN0 = minN;   // the value C has been given for this step's limitation test
         // wave L's soil-temperature factors of this step (the tillage-scaled one and the plain one) and
         // wave W's moisture terms, each pair behind its flag, one round trip
+        // In the same round trip, looked at but not waited for: C's plant-side block of this step and W's
+        // leached share (each behind its own flag) -- when they are there already, the nitrogen block below
+        // needs no round trip of its own, and the mineral nitrogen of the next step reaches C before C asks.
         double wMoist, wAnoxic;
         R qSoilT, qSoil;
+        double pLeafLitter, pWoodLitter, pFineLoss, pCoarseLoss, pDemand, pReduction, pLeafOnAll, pLeafOn, wLeach;
+        int plantSeq, leachSeq;
         {
           WAIT_BEGIN()
           int fSeq, wSeq;
           do {
+            // (one statement: the compiler may put instructions of its own between two, and does)
+#define SIPNET_S_TAKE(RD_R, OFF_R)                                                                                   \
+  asm volatile("ds_read_b32 %0, %17\n\t" RD_R " %1, %18\n\t" RD_R " %2, %18 offset:" OFF_R "\n\t"                   \
+               "ds_read_b32 %3, %19\n\tds_read_b64 %4, %20\n\tds_read_b64 %5, %20 offset:512\n\t"                    \
+               "ds_read_b32 %6, %21\n\tds_read_b64 %7, %22\n\tds_read_b64 %8, %22 offset:512\n\t"                    \
+               "ds_read_b64 %9, %22 offset:1024\n\tds_read_b64 %10, %22 offset:1536\n\t"                             \
+               "ds_read_b64 %11, %22 offset:2048\n\tds_read_b64 %12, %22 offset:2560\n\t"                            \
+               "ds_read_b64 %13, %22 offset:3072\n\tds_read_b64 %14, %22 offset:3584\n\t"                            \
+               "ds_read_b32 %15, %23\n\tds_read_b64 %16, %24\n\ts_waitcnt lgkmcnt(0)"                                \
+               : "=&v"(fSeq), "=&v"(qSoilT), "=&v"(qSoil), "=&v"(wSeq), "=&v"(wMoist), "=&v"(wAnoxic),              \
+                 "=&v"(plantSeq), "=&v"(pLeafLitter), "=&v"(pWoodLitter), "=&v"(pFineLoss), "=&v"(pCoarseLoss),      \
+                 "=&v"(pDemand), "=&v"(pReduction), "=&v"(pLeafOnAll), "=&v"(pLeafOn), "=&v"(leachSeq), "=&v"(wLeach) \
+               : "v"(ldsAddr(&seqFac)), "v"(ldsAddr(&mailFac[t & 1][2][lane])), "v"(ldsAddr(&seqWat)),                \
+                 "v"(ldsAddr(&mailWat[t & 3][0][lane])), "v"(ldsAddr(&seqPlant)),                                    \
+                 "v"(ldsAddr(&mailPlant[t & 1][0][lane])), "v"(ldsAddr(&seqLeach)),                                  \
+                 "v"(ldsAddr(&mailWat[t & 3][2][lane]))                                                              \
+               : "memory")
             if (sizeof(R) == 8)
-              asm volatile("ds_read_b32 %0, %6\n\tds_read_b64 %1, %7\n\tds_read_b64 %2, %7 offset:2048\n\t"
-                           "ds_read_b32 %3, %8\n\tds_read_b64 %4, %9\n\tds_read_b64 %5, %9 offset:512\n\ts_waitcnt lgkmcnt(0)"
-                           : "=&v"(fSeq), "=&v"(qSoilT), "=&v"(qSoil), "=&v"(wSeq), "=&v"(wMoist), "=&v"(wAnoxic)
-                           : "v"(ldsAddr(&seqFac)), "v"(ldsAddr(&mailFac[t & 1][2][lane])), "v"(ldsAddr(&seqWat)),
-                             "v"(ldsAddr(&mailWat[t & 3][0][lane])) : "memory");
+              SIPNET_S_TAKE("ds_read_b64", "2048");
             else
-              asm volatile("ds_read_b32 %0, %6\n\tds_read_b32 %1, %7\n\tds_read_b32 %2, %7 offset:1024\n\t"
-                           "ds_read_b32 %3, %8\n\tds_read_b64 %4, %9\n\tds_read_b64 %5, %9 offset:512\n\ts_waitcnt lgkmcnt(0)"
-                           : "=&v"(fSeq), "=&v"(qSoilT), "=&v"(qSoil), "=&v"(wSeq), "=&v"(wMoist), "=&v"(wAnoxic)
-                           : "v"(ldsAddr(&seqFac)), "v"(ldsAddr(&mailFac[t & 1][2][lane])), "v"(ldsAddr(&seqWat)),
-                             "v"(ldsAddr(&mailWat[t & 3][0][lane])) : "memory");
+              SIPNET_S_TAKE("ds_read_b32", "1024");
+#undef SIPNET_S_TAKE
           } while (uni(fSeq) < t || uni(wSeq) < t);
           WAIT_END(0)
         }
@@ -1007,15 +1028,12 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         }
         const R soilMethane = G_soilCH4 * eSoilC * qSoil * mMoist;
         const R litterMethane = G_litCH4 * eLitter * qSoil * mMoist;
-        // R_h goes to C at once (its NEE needs it at the END of its step)
-        postD(&mailRh[t & 1][lane], 0, (double)(rLitter + rSoil));
-        postFlag(&seqRh, t);
+        const R rHet = (R)(double)(rLitter + rSoil);   // R_h: NEE is formed here, at the end of the step
 
         // ---- the plants' side of the step (C posts it early in its step) and the nitrogen block
-        double pLeafLitter, pWoodLitter, pFineLoss, pCoarseLoss, pDemand, pReduction, pLeafOnAll, pLeafOn;
-        {
+        if (uni(plantSeq) < t) {   // not there yet at the start of the step
           WAIT_BEGIN()
-          takeD8(&mailPlant[0][lane], &seqPlant, t, pLeafLitter, pWoodLitter, pFineLoss, pCoarseLoss, pDemand,
+          takeD8(&mailPlant[t & 1][0][lane], &seqPlant, t, pLeafLitter, pWoodLitter, pFineLoss, pCoarseLoss, pDemand,
                  pReduction, pLeafOnAll, pLeafOn);
           WAIT_END(1)
         }
@@ -1024,7 +1042,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         R nDemand = (R)pDemand, evMinN = 0;
         if (__builtin_expect(nEv > 0, 0)) {  // the soil side of this step's events, worked out by C (it has the plants)
           double eLit, eSoil, eMin, eOrg, eLitN, eStor;
-          takeD6(&mailEvent[0][lane], &seqEvent, t, eLit, eSoil, eMin, eOrg, eLitN, eStor);
+          takeD6(&mailEvent[t & 1][0][lane], &seqEvent, t, eLit, eSoil, eMin, eOrg, eLitN, eStor);
           evMinN = (R)eMin;
           litterC += (double)((R)eLit * len);
           soilC += (double)((R)eSoil * len);
@@ -1050,8 +1068,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         // it has the drainage -- by day only after the photosynthesis hand-over, unless the soil cannot
         // fill up in this step)
         R nVolatilization = G_nVol * eMinN * qSoil * (R(0.05) + R(3.8) * anoxic * (R(1) - anoxic));
-        double wLeach;
-        {
+        if (uni(leachSeq) < t) {   // (by day, in a soil that may fill up: W knows it only after the photosynthesis hand-over)
           WAIT_BEGIN()
           takeD1(&mailWat[t & 3][2][lane], &seqLeach, t, wLeach);
           WAIT_END(2)
@@ -1100,8 +1117,11 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         // the end of C's step: its mortality verdict (one word per lane) and, where a stand died, what its
         // biomass adds to these pools (sipnet.c:1688-1767); then ensureNonNegativeStocks() for them
         int w;
+        double pend;   // GPP - R_a of this step (C posts it right before the verdict word)
         do {
-          asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(w) : "v"(ldsAddr(&mailAlive[(t + 1) & 1][lane])) : "memory");
+          asm volatile("ds_read_b32 %0, %2\n\tds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(w), "=&v"(pend)
+                       : "v"(ldsAddr(&mailAlive[(t + 1) & 1][lane])), "v"(ldsAddr(&mailPend[t & 1][lane])) : "memory");
         } while (uni(w < 0 ? -w : w) < t + 3);
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(w < 0) != 0, 0)) {
           double d0, d1, d2, d3;
@@ -1123,6 +1143,14 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         storN = rmax0(storN);
         postD(&mailStorN[(t + 1) & 1][lane], 0, storN);
         postFlag(&seqStorN, t + 1);
+        {  // NEE = -(NPP - R_h), sipnet.c:1433-1450: GPP - R_a from C, R_h = (litter + soil respiration) here
+#pragma clang fp contract(off)
+          const R tRh = rHet * len;
+          const R tNee = R(-1.0) * ((R)pend - tRh);
+          totNee += (double)tNee;
+          *oNee = tNee;
+          oNee += ldNee;
+        }
       }
     }
     WAIT_STORE(12)
@@ -1133,6 +1161,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
       ST(soilOrgN) = soilOrgN;
       ST(litterN) = litterN;
       ST(plantStorageN) = storN;
+      ST(totNee) = totNee;
     }
     return;
   }
@@ -1206,7 +1235,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
           // does not vouch for (C(t-1) only needs S's nitrogen block of step t-2 done): the slot is free
           // once S has posted R_h of step t-2, which it does right after that read (found by the fuzzer:
           // one trial in 600 had S take the soil factors of step t+2 for step t, 2e-5 off on NEE)
-          if (NCyc) awaitAtLeast(&seqRh, t - 2);
+          if (NCyc) awaitAtLeast(&seqMinN, t - 1);
           WAIT_END(1)
           const R vegQ = fexp2(q10Arg((R)q5.y, K_lgVeg), EC);
           R g1 = K_fol * vegQ;
@@ -1560,7 +1589,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   // step -- and checkNitrogenLimitation() (limitations.c:69-114): both waves test "plentiful" with the
   // same numbers; only where it fails for some member does C wait for S's exact supply, scale its
   // creation fluxes and answer with the demand that is left
-  auto plantSideN = [&](int t, R len, R invLen, double minNStep, double qSoilD, double lenD, R leafLitter, R woodLitter,
+  auto plantSideN = [&](int t, R len, R invLen, double minNStep, int minNSeq, double qSoilD, double lenD, R leafLitter, R woodLitter,
                         R fineRootLoss, R coarseRootLoss, R leafOnCreation, R evLeafOnAll, R& leafCreation,
                         R& woodCreation, R& fineRootCreation, R& coarseRootCreation) {
 #pragma clang fp contract(off)
@@ -1574,15 +1603,23 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
       reductionN -= (leafCreation * G_iLeafCN + woodCreation * G_iWoodCN + coarseRootCreation * G_iWoodCN +
                      fineRootCreation * G_iFineCN);
     const R nDemand = plantNDemand();
-    postD(&mailPlant[0][lane], 0, (double)leafLitter);
-    postD(&mailPlant[0][lane], 1, (double)woodLitter);
-    postD(&mailPlant[0][lane], 2, (double)fineRootLoss);
-    postD(&mailPlant[0][lane], 3, (double)coarseRootLoss);
-    postD(&mailPlant[0][lane], 4, (double)nDemand);
-    postD(&mailPlant[0][lane], 5, (double)reductionN);
-    postD(&mailPlant[0][lane], 6, (double)leafOnN(leafOnCreation + evLeafOnAll));
-    postD(&mailPlant[0][lane], 7, (double)leafOnN(leafOnCreation));
+    postD(&mailPlant[t & 1][0][lane], 0, (double)leafLitter);
+    postD(&mailPlant[t & 1][0][lane], 1, (double)woodLitter);
+    postD(&mailPlant[t & 1][0][lane], 2, (double)fineRootLoss);
+    postD(&mailPlant[t & 1][0][lane], 3, (double)coarseRootLoss);
+    postD(&mailPlant[t & 1][0][lane], 4, (double)nDemand);
+    postD(&mailPlant[t & 1][0][lane], 5, (double)reductionN);
+    postD(&mailPlant[t & 1][0][lane], 6, (double)leafOnN(leafOnCreation + evLeafOnAll));
+    postD(&mailPlant[t & 1][0][lane], 7, (double)leafOnN(leafOnCreation));
     postFlag(&seqPlant, t);
+    // S's mineral nitrogen of this step: normally it came with the factors; if S was not that far yet
+    // it is waited for only NOW, after the post S itself is waiting for (C -> S -> C would otherwise be
+    // one latency chain per step)
+    if (__builtin_expect(minNSeq < t, 0)) {
+      WAIT_BEGIN()
+      takeD1(&mailMinN[t & 1][lane], &seqMinN, t, minNStep);
+      WAIT_END(2)
+    }
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(!nPlentiful(minNStep, qSoilD, lenD, G_nVolD, G_nLeachD, (double)nDemand)) != 0, 0)) {
       double sAvail, sFixFrac, sUnclaimed;
       takeD3(&mailSupply[0][lane], &seqSupply, t, sAvail, sFixFrac, sUnclaimed);
@@ -1689,6 +1726,9 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
           plantLeafC = rmax0(plantLeafC);
           coarseRootC = rmax0(coarseRootC);
           fineRootC = rmax0(fineRootC);
+          const R tGpp = photosynthesis * len;
+          const R tRa = ffma(rVeg, len, (rCoarseRoot + rFineRoot) * len);
+          if (NCyc) postD(&mailPend[t & 1][lane], 0, (double)(tGpp - tRa));   // S forms NEE (it has R_h); before the verdict word
           postAlive(&mailAlive[(t + 1) & 1][lane], t + 1, diedNow);
           if (!NCyc) {
             soilC += soilGain;
@@ -1698,19 +1738,9 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
             }
             soilC = rmax0(soilC);
           }
-          const R tGpp = photosynthesis * len;
-          R rHet = rSoil;
-          if (NCyc) {  // heterotrophic respiration (litter + soil) is wave S's, posted early in its step
-            double rh;
-            WAIT_BEGIN()
-            takeD1(&mailRh[t & 1][lane], &seqRh, t, rh);
-            WAIT_END(2)
-            rHet = (R)rh;
-          }
-          const R tRh = rHet * len;
-          const R tRa = ffma(rVeg, len, (rCoarseRoot + rFineRoot) * len);
+          const R tRh = rSoil * len;
           const R tNee = R(-1.0) * ((tGpp - tRa) - tRh);
-          totNee += (double)tNee;
+          if (!NCyc) totNee += (double)tNee;
           const double npp = (double)(photosynthesis - rVeg - rCoarseRoot - rFineRoot);
           if (!RingLds) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rvN) :: "memory");
           const double vNew = RingLds ? ringNew : (useLast ? lastNpp : rvN);
@@ -1729,8 +1759,10 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
             lastIns = insSlot;
             lastNpp = npp;
           }
-          *oNee = tNee;
-          oNee += ldNee;
+          if (!NCyc) {
+            *oNee = tNee;
+            oNee += ldNee;
+          }
           if (__builtin_expect(stageOn, 0)) postRaw(&stage[0][(t - tBegin) & (2 * kStageR - 1)][lane], tNee);
         };
         unsigned dayMask = ((unsigned)tileBits >> 16) >> (t - tileStart);
@@ -1745,11 +1777,12 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
           R g1, g2, qSoilT, gFine, gCoarse, moistEff;
           ringNew = 0.0;  // LDS ring: the value this step evicts, read in the same round trip
           double minNStep = 0.0;   // NCyc: wave S's mineral nitrogen at the start of this step
+          int minNSeq = 0;
           {
             WAIT_BEGIN()
             if (NCyc)   // rows 0 1 3 4 and the plain soil Q10 factor (row 6, carried in `moistEff`'s place) + the mineral N
               takeFactorsN(&mailFac[t & 1][0][lane], &seqFac, &mailMinN[t & 1][lane], &seqMinN, t, g1, g2, gFine, gCoarse,
-                           moistEff, minNStep);
+                           moistEff, minNStep, minNSeq);
             else if (RingLds)
               takeFactorsRing(&mailFac[t & 1][0][lane], seqFacMoist, ldsAddr(&ringL[readSlot * 64 + lane]), t, g1,
                               g2, qSoilT, gFine, gCoarse, moistEff, ringNew);
@@ -1791,7 +1824,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
             fineRootCreation -= shift;
           }
           if (NCyc)   // the plants' side of the step for wave S, and checkNitrogenLimitation() (see the general step)
-            plantSideN(t, len, invLen, minNStep, (double)moistEff, (double)h0.x, leafLitter, woodLitter, fineRootLoss,
+            plantSideN(t, len, invLen, minNStep, minNSeq, (double)moistEff, (double)h0.x, leafLitter, woodLitter, fineRootLoss,
                        coarseRootLoss, R(0), R(0), leafCreation, woodCreation, fineRootCreation, coarseRootCreation);
           accum(plantLeafC, leafCreation - leafLitter, len);
           post(&mailLai[(t + 1) & 1][lane], &seqLai, (R)rmax0(plantLeafC) * K_invLcsw, t + 1);
@@ -1863,7 +1896,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
                        : "v"(ldsAddr(recB)), "v"(ldsAddr(&seqFac)), "v"(fac), "v"(ldsAddr(&seqMinN)), "v"(mnn)
                        : "memory");
         }
-      } while (uni(facSeq) < t || uni(moistSeq) < t);
+      } while (uni(facSeq) < t);   // (`moistSeq`: the mineral nitrogen's flag, looked at in plantSideN)
       qSoilT = 0;
       WAIT_END(0)
     } else {
@@ -2059,12 +2092,12 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
       if (NCyc) {
         evLeafOnAll = evLeafOnCreation;
         if (nEv > 0) {  // (W reads this block on every step whose record carries events)
-          postD(&mailEvent[0][lane], 0, (double)(evLitterC + evLeafOffLitter));
-          postD(&mailEvent[0][lane], 1, (double)evSoilC);
-          postD(&mailEvent[0][lane], 2, (double)evMinN);
-          postD(&mailEvent[0][lane], 3, (double)evSoilOrgN);
-          postD(&mailEvent[0][lane], 4, (double)evLitterN);
-          postD(&mailEvent[0][lane], 5, (double)(evLeafOffNResorp - leafOnNFromC(evLeafOnCreation)));
+          postD(&mailEvent[t & 1][0][lane], 0, (double)(evLitterC + evLeafOffLitter));
+          postD(&mailEvent[t & 1][0][lane], 1, (double)evSoilC);
+          postD(&mailEvent[t & 1][0][lane], 2, (double)evMinN);
+          postD(&mailEvent[t & 1][0][lane], 3, (double)evSoilOrgN);
+          postD(&mailEvent[t & 1][0][lane], 4, (double)evLitterN);
+          postD(&mailEvent[t & 1][0][lane], 5, (double)(evLeafOffNResorp - leafOnNFromC(evLeafOnCreation)));
           postFlag(&seqEvent, t);
         }
       }
@@ -2086,7 +2119,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
 
     // ---- NCyc: the plants' side of the step for wave S, and checkNitrogenLimitation() (plantSideN)
     if (NCyc)
-      plantSideN(t, len, invLen, minNStep, (double)moistEff /* the plain soil Q10 factor */, q0.x, leafLitter, woodLitter,
+      plantSideN(t, len, invLen, minNStep, uni(moistSeq), (double)moistEff /* the plain soil Q10 factor */, q0.x, leafLitter, woodLitter,
                  fineRootLoss, coarseRootLoss, leafOnCreation, evLeafOnAll, leafCreation, woodCreation, fineRootCreation,
                  coarseRootCreation);
 
@@ -2168,6 +2201,9 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
     plantLeafC = rmax0(plantLeafC);
     coarseRootC = rmax0(coarseRootC);
     fineRootC = rmax0(fineRootC);
+    // NCyc: GPP - R_a of this step for wave S, which has R_h and forms NEE; before the verdict word
+    if (NCyc)
+      postD(&mailPend[t & 1][lane], 0, (double)(photosynthesis * len - ffma(rVeg, len, (rCoarseRoot + rFineRoot) * len)));
     // confirms the lai(t+1) posted above, or revokes it when the stand died in this step (its
     // leaf pool was just zeroed); a stand that was never alive keeps its leaves and its lai
     postAlive(&mailAlive[(t + 1) & 1][lane], t + 1, diedNow);
@@ -2197,18 +2233,10 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
 
     // ---- outputs: updateTrackers(), sipnet.c:1420-1496 ---------------------------------------
     const R tGpp = photosynthesis * len;
-    R rHet = rSoil;
-    if (NCyc) {  // heterotrophic respiration (litter + soil) is wave W's, posted early in its step
-      double rh;
-      WAIT_BEGIN()
-      takeD1(&mailRh[t & 1][lane], &seqRh, t, rh);
-      WAIT_END(2)
-      rHet = (R)rh;
-    }
-    const R tRh = rHet * len;
+    const R tRh = rSoil * len;
     const R tRa = ffma(rVeg, len, (rCoarseRoot + rFineRoot) * len);
     const R tNee = R(-1.0) * ((tGpp - tRa) - tRh);
-    totNee += (double)tNee;
+    if (!NCyc) totNee += (double)tNee;
     R tRAbove = 0, tRRoot = 0, tRSoil = 0, tRtot = 0, tNpp = 0;
     if (Full) {
       if (bits & FAST_TRACK_NEW_YEAR) yGpp = yRtot = yRa = yRh = yNpp = yNee = 0.0;
@@ -2320,8 +2348,10 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
       r[43 * L] = diedNow ? 1.0 : 0.0;
       recp += (int64_t)SIPNET_NREC * L;
     }
-    *oNee = tNee;
-    oNee += ldNee;
+    if (!NCyc) {
+      *oNee = tNee;
+      oNee += ldNee;
+    }
     if (__builtin_expect(stageOn, 0)) postRaw(&stage[0][(t - tBegin) & (2 * kStageR - 1)][lane], tNee);
     CSTAMP(6)
   }  // steps of this tile
@@ -2346,7 +2376,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
     ST(fineRootC) = fineRootC;
     ST(plantCAccountingDelta) = delta;
     ST(ringSum) = ringSum;
-    ST(totNee) = totNee;
+    if (!NCyc) ST(totNee) = totNee;
     ST(phenBits) = (double)phenBits;
     ST(ringValidFrom) = (double)ringValidFrom;
     ST(diedAt) = (double)diedAt;
@@ -2454,7 +2484,7 @@ void launchStepCoop(const FastArgs& a, int precision, int layout, hipStream_t st
       info->wavesPerSimd = 1;
       const int elem = precision == SIPNET_F64 ? 8 : 4;
       info->ldsBytes = 3 * 2 * kTileBytes + (2 * 64 * 3 + 2 * 7 * 64) * elem + 2 * 64 * 4 + 16 * 4 + 64 * 8 +
-                       (8 + 2 + 2 + 2 + 6 + 4 + 3 + 1 + 12) * 64 * 8 + 2 * kTileBytes;
+                       (16 + 2 + 2 + 2 + 12 + 4 + 3 + 1 + 12) * 64 * 8 + 2 * kTileBytes;
     }
     return;
   }
