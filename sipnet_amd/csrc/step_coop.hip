@@ -379,6 +379,12 @@ __device__ unsigned long long g_coopStamps[16];
 #else
 #define CSTAMP(k)
 #endif
+// -DSIPNET_MARKERS (reading the assembly, tools/kernel_resources.py): comments around the hot loops
+#ifdef SIPNET_MARKERS
+#define MARK(text) asm volatile("; ##### " text);
+#else
+#define MARK(text)
+#endif
 // -DSIPNET_WAITS (diagnostic build): cycles each wave spends inside its hand-over waits
 #ifdef SIPNET_WAITS
 __device__ unsigned long long g_coopWaits[16];
@@ -1322,6 +1328,12 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
       const unsigned char* recB = lds + (curTile & 1) * kTileBytes +
                                   (int)(tFirst - tileFirst(curTile)) * (int)sizeof(FastRec);
       for (int t = tFirst; t < tLast; t++, recB += sizeof(FastRec)) {
+        // Explicit fused multiply-adds only, as on the carbon wave: what the compiler chose to fuse differed
+        // between the layouts' instantiations (fp32: the last sublimation of a snow pack, one ulp of ET).
+#ifndef SIPNET_W_CONTRACT_FAST
+#pragma clang fp contract(off)
+#endif
+        MARK("W step begin")
         // only the fields this wave uses (80 of the record's 144 hot bytes: a lone wave pays LDS
         // reads by the byte): len invLen | tair tsoil | vpd | rainRate | sublW evapNum | invWspd | bits | evCount
         d2 q0, q1, q2, q3, q4, q5;
@@ -1353,7 +1365,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         if (NCyc) {
           const R fWhc = clip01(eWater * K_invWhc);
           const R anoxic = clip01((fWhc - G_fAnox) * G_iOneMinusAnox);
-          R moistEff = (R(1) - anoxic) * clip01(fWhc * G_iFAnox) + G_anDecomp * anoxic;
+          R moistEff = ffma(G_anDecomp, anoxic, (R(1) - anoxic) * clip01(fWhc * G_iFAnox));
           moistEff = (bits & FAST_TSOIL_NEG) ? R(1) : moistEff;
           postD(&mailWat[t & 3][0][lane], 0, (double)moistEff);
           postD(&mailWat[t & 3][0][lane], 1, (double)anoxic);
@@ -1364,24 +1376,24 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         const bool tairPos = (bits & FAST_TAIR_POS) != 0;
         const R rate = (R)q3.y;
         const R rain = tairPos ? rate : R(0), snowFall = tairPos ? R(0) : rate;
-        const R immedEvap = rain * K_immed;
-        const R netRain = rain - immedEvap;
+        const R netRain = ffma(-rain, K_immed, rain);   // (beside the product, not behind it)
         R snowMelt = 0, sublimation = 0, evaporationPot = 0;
         const bool hasSnow = eSnow > R(0);
         if (hasSnow) {
           R subl = rmax0((R)q4.x * K_invRd);
-          R remaining = eSnow + snowFall * len;
-          const bool allGone = remaining - subl * len < R(0);
+          R remaining = ffma(snowFall, len, eSnow);
+          const R afterSubl = ffma(-subl, len, remaining);
+          const bool allGone = afterSubl < R(0);
           subl = allGone ? remaining * invLen : subl;
-          remaining = allGone ? R(0) : remaining - subl * len;
+          remaining = allGone ? R(0) : afterSubl;
           R melt = tairPos ? K_melt * tair : R(0);
-          melt = (tairPos && (remaining - melt * len < R(0))) ? remaining * invLen : melt;
+          melt = (tairPos && (ffma(-melt, len, remaining) < R(0))) ? remaining * invLen : melt;
           sublimation = subl;
           snowMelt = melt;
         } else {
           const R wf = clip01(eWater * K_invWhc);
-          const R rsoil = fexp2(K_c1l - K_c2l * wf, EC);
-          evaporationPot = rmax0(fdiv((R)q4.y, K_rd * (R)q5.x + rsoil));
+          const R rsoil = fexp2(ffma(-K_c2l, wf, K_c1l), EC);
+          evaporationPot = rmax0(fdiv((R)q4.y, ffma(K_rd, (R)q5.x, rsoil)));
         }
         R removable = rminv(eWater, K_whc) * K_wrf;
         removable = frozen ? removable * K_frozEff : removable;
@@ -1392,8 +1404,8 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         bool leachPosted = false;
         if (NCyc) {
           R netIn0 = netRain + snowMelt;
-          netIn0 -= netIn0 * K_ff;
-          leachPosted = __builtin_amdgcn_ballot_w64(!(eWater + netIn0 * len <= K_whc)) == 0;
+          netIn0 = ffma(-netIn0, K_ff, netIn0);
+          leachPosted = __builtin_amdgcn_ballot_w64(!(ffma(netIn0, len, eWater) <= K_whc)) == 0;
           if (leachPosted) {
             postD(&mailWat[t & 3][0][lane], 2, 0.0);
             postFlag(&seqLeach, t);
@@ -1411,22 +1423,28 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
           const R potGrossPsn = diedBefore ? R(0) : pgpSpec;
           const R potTrans = potGrossPsn * (R)q2.y * K_tr;
           const bool hasPsn = potGrossPsn >= R(kTiny);
-          const bool limited = removable < potTrans;
-          const R dWater = fdiv(removable, potTrans);
+          const bool limited = hasPsn && removable < potTrans;
           transpiration = hasPsn ? (limited ? removable : potTrans) : R(0);
-          photosynthesis = (hasPsn && limited) ? potGrossPsn * dWater : potGrossPsn;
+          photosynthesis = potGrossPsn;
+          // (the division only where the water limits some member of the wavefront: this wave's day step is
+          // as long as the carbon wave's, and the carbon wave waits for what is posted next)
+          if (__builtin_expect(__builtin_amdgcn_ballot_w64(limited) != 0, 0))
+            photosynthesis = limited ? potGrossPsn * fdiv(removable, potTrans) : potGrossPsn;
           post(&mailPsn[t & 1][lane], &seqPsn, photosynthesis, t);
         }
+        const R tGpp = photosynthesis * len;
+        totGpp += (double)tGpp;   // the total is the sum of the ROUNDED per-step values (sipnet.c:1433-1450)
 
-        R evaporation, drainage, fastFlow;
+        R evaporation, drainage, wetting;   // wetting: rain + melt - immediate evaporation - fast flow
         {
           R netIn = netRain + snowMelt;
-          fastFlow = netIn * K_ff;
-          netIn -= fastFlow;
-          R remaining = eWater + netIn * len - transpiration * len;
-          const bool dryOut = !hasSnow && (remaining - evaporationPot * len < R(kTiny));
+          wetting = ffma(-netIn, K_ff, ffma(-rain, K_immed, rain + snowMelt));
+          netIn = ffma(-netIn, K_ff, netIn);
+          R remaining = ffma(-transpiration, len, ffma(netIn, len, eWater));
+          const R afterEvap = ffma(-evaporationPot, len, remaining);
+          const bool dryOut = !hasSnow && (afterEvap < R(kTiny));
           evaporation = dryOut ? (remaining - R(kTiny)) * invLen : evaporationPot;
-          remaining = hasSnow ? remaining : (dryOut ? R(0) : remaining - evaporationPot * len);
+          remaining = hasSnow ? remaining : (dryOut ? R(0) : afterEvap);
           drainage = remaining > K_whc ? (remaining - K_whc) * invLen : R(0);
         }
         // irrigation, events.c:484-543
@@ -1439,19 +1457,18 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
             if (uni(ev.type) == SIPNET_EV_IRRIG) {
               const R p0 = (R)ev.p[0];
               const R evapAmount = ((int)ev.p[1] == 0) ? K_immed * p0 : R(0);
-              evEvap += evapAmount * invLen;
-              evSoilWater += (p0 - evapAmount) * invLen;
+              evEvap = ffma(evapAmount, invLen, evEvap);
+              evSoilWater = ffma(p0 - evapAmount, invLen, evSoilWater);
             }
           }
-          soilWater += (double)(evSoilWater * len);
+          accum(soilWater, evSoilWater, len);
         }
         if (NCyc && !leachPosted) {
           postD(&mailWat[t & 3][0][lane], 2, (double)rminv(drainage * K_invWhc, R(1)));
           postFlag(&seqLeach, t);
         }
-        soilWater += (double)((rain + snowMelt - immedEvap - fastFlow - evaporation -
-                               transpiration - drainage) * len);
-        snow += (double)((snowFall - snowMelt - sublimation) * len);
+        accum(soilWater, wetting - evaporation - transpiration - drainage, len);
+        accum(snow, snowFall - snowMelt - sublimation, len);
         if (wantDiagW) {  // clamp warnings of the two water pools, sipnet.c:1346-1356
           if (soilWater < 0.0 && fabs(soilWater) > kEps) clampWarnW++;
           if (snow < kTiny && fabs(snow) > kEps) clampWarnW++;
@@ -1468,13 +1485,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
           WAIT_END(1)
         }
 
-        const R tEt = (transpiration + immedEvap + evaporation + sublimation + evEvap) * len;
-        R tGpp;
-        {
-#pragma clang fp contract(off)  // the total is the sum of the ROUNDED per-step values (sipnet.c:1433-1450)
-          tGpp = photosynthesis * len;
-          totGpp += (double)tGpp;
-        }
+        const R tEt = (ffma(rain, K_immed, transpiration) + evaporation + sublimation + evEvap) * len;
         *oEt = tEt;
         *oGpp = tGpp;
         oEt += ldEt;
@@ -1483,6 +1494,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
           postRaw(&stage[1][(t - tBegin) & (2 * kStageR - 1)][lane], tGpp);
           postRaw(&stage[2][(t - tBegin) & (2 * kStageR - 1)][lane], tEt);
         }
+        MARK("W step end")
         if (Full && recw) {
           const int64_t L = a.ld;
           recw[1 * L] = (double)tGpp;
@@ -1772,6 +1784,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
           // paths a wavefront takes depends on its 63 neighbours, so they must not differ by what
           // the compiler happens to fuse in one context and not in the other.
 #pragma clang fp contract(off)
+          MARK("C regular step begin")
           // this step's factors: five from wave F / L, the moisture effect from wave W (each flag read
           // before its values, one LDS round trip when both are current)
           R g1, g2, qSoilT, gFine, gCoarse, moistEff;
@@ -1850,6 +1863,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
           finishStep(std::false_type{});
           readSlot = nextSlot(readSlot);
           insSlot = nextSlot(insSlot);
+          MARK("C regular step end")
         }
         if (dyingStep) {  // finish that step with the mortality code; the general step from the next one on
           finishStep(std::true_type{});

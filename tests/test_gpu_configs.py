@@ -251,7 +251,14 @@ KERNELS = [
     ("coop_quad_f32", sa.F32_MIXED, sa.KERNEL_COOP_QUAD, 0, "stepCoopQuadKernel<float, true>"),
     ("runtime_flags_f64", sa.F64, sa.KERNEL_ONE_WAVE, sa.KOPT_RUNTIME_FLAGS, "stepFastKernel<double, true, 1, 1, false>"),
     ("runtime_flags_f32", sa.F32_MIXED, sa.KERNEL_ONE_WAVE, sa.KOPT_RUNTIME_FLAGS, "stepFastKernel<float, true, 1, 1, false>"),
+    # the nitrogen-cycle flag set (litter pool + anaerobic + nitrogen cycle, sipnet_amd/data/allflags_forest.param)
+    # (that file's dVpdExp / soilRespMoistEffect are not 2 / 1: the general-exponent builds; "_plain" sets them so)
+    ("coop_ncycle_f64", sa.F64, sa.KERNEL_COOP_NCYCLE, 0, "stepCoopNKernel<double, false>"),
+    ("coop_ncycle_f32", sa.F32_MIXED, sa.KERNEL_COOP_NCYCLE, 0, "stepCoopNKernel<float, false>"),
+    ("coop_ncycle_f64_plain", sa.F64, sa.KERNEL_COOP_NCYCLE, 0, "stepCoopNKernel<double, true>"),
+    ("coop_ncycle_f32_plain", sa.F32_MIXED, sa.KERNEL_COOP_NCYCLE, 0, "stepCoopNKernel<float, true>"),
 ]
+NCYCLE_FLAGS = dict(litterPool=1, anaerobic=1, nitrogenCycle=1)
 
 
 @pytest.mark.parametrize("name,prec,kernel,options,expect", KERNELS, ids=[k[0] for k in KERNELS])
@@ -262,7 +269,13 @@ def test_every_throughput_kernel_instantiation_against_the_oracle(name, prec, ke
     the same schedule without the lethal events (emptied pools keep ~1e-5 gC of fp32 residue,
     which the fuzz test judges by time sums instead)"""
     flags = sa.flags_from()
+    if kernel == sa.KERNEL_COOP_NCYCLE:
+        flags = sa.flags_from(**NCYCLE_FLAGS)
+        base = sa.read_params(os.path.join(os.path.dirname(BASE), "allflags_forest.param"), flags)[0]
     clim, ev, members = _scenario(base, lethal=prec == sa.F64)
+    if name.endswith("_plain"):
+        members[:, pi("dVpdExp")] = 2.0
+        members[:, pi("soilRespMoistEffect")] = 1.0
     b = build(flags, [clim], members, prec, kernel, options, events=ev)
     T = clim.n_steps
     planes, _ = b.alloc_outputs(T)
