@@ -412,10 +412,16 @@ int sipnet_pf_exchange_plan(const int32_t *d_ancestors, int64_t n_local, int32_t
 /* The resampling and the exchange plan keep device scratch per host thread between calls; this frees
  * the calling thread's (call it before the thread ends or the device is reset; nothing else does). */
 void sipnet_pf_release_scratch(void);
-/* doubles per particle in a packed block: SIPNET_NSTATE + SIPNET_RING_SLOTS (+ SIPNET_NPARAMS) */
+/* 8-byte words per particle in a packed block of a SIPNET_F64 batch: SIPNET_NSTATE + SIPNET_RING_SLOTS
+ * (+ SIPNET_NPARAMS) ... */
 int32_t sipnet_pf_member_words(int32_t with_params);
+/* ... and of batch b: a SIPNET_F32_MIXED batch keeps its running-mean ring in fp32 (the values are NPP
+ * rates, fp32 numbers there), on the device and in a packed block, where the SIPNET_RING_SLOTS rows of
+ * n floats take SIPNET_RING_SLOTS / 2 rows of words -- a third less to move per resampled particle.
+ * (sipnet_batch_get_ring(s) / set_rings and the restart records stay in doubles.) */
+int32_t sipnet_batch_member_words(const sipnet_batch *b, int32_t with_params);
 /* Pack columns d_cols[n] (DEVICE, local column indices) into d_buf laid out
- * [sipnet_pf_member_words][n]: state rows, ring rows, then parameter rows. */
+ * [sipnet_batch_member_words][n]: state rows, ring rows, then parameter rows. */
 int sipnet_batch_pack_members(sipnet_batch *b, const int32_t *d_cols, int64_t n,
                               int32_t with_params, double *d_buf, void *hip_stream);
 /* Replace every column j by its ancestor d_src[j] (DEVICE, [ncol]): an index < ncol is one

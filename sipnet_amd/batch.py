@@ -269,9 +269,10 @@ class Batch:
         return out
 
     def pack_members(self, cols, with_params=False):
-        """cols: int32 device tensor of local column indices -> packed block [words][n] f64"""
+        """cols: int32 device tensor of local column indices -> packed block [words][n] of 8-byte words
+        (state rows, ring rows -- floats for an fp32-mixed batch --, parameter rows)"""
         t = self._torch
-        words = self.L.sipnet_pf_member_words(int(with_params))
+        words = self.L.sipnet_batch_member_words(self.h, int(with_params))
         cols = cols.to(device=self.device, dtype=t.int32).contiguous()
         buf = t.empty((words, cols.numel()), dtype=t.float64, device=self.device)
         if cols.numel():

@@ -54,7 +54,7 @@ struct sipnet_batch {
   size_t rawStageCap = 0;
   double* d_prm = nullptr;     // [NPARAMS][ncol] converted parameters: the one copy on the device
   double* d_state = nullptr;   // [NSTATE][ncol]
-  double* d_ring = nullptr;    // [RING_SLOTS][ncol]
+  double* d_ring = nullptr;    // [RING_SLOTS][ncol] doubles; fp32-mixed batches: floats (ringElemBytes)
   // second copies for particle-filter resampling (gather into the spare, then swap); lazily made
   double* d_prm2 = nullptr;
   double* d_state2 = nullptr;
@@ -86,6 +86,12 @@ struct sipnet_batch {
   bool timed = false;
   double lastMs = -1.0;
 };
+
+// bytes of a ring element: fp32-mixed batches keep the running-mean ring in fp32 (its values are NPP rates such
+// a batch computes in fp32)
+inline size_t ringElemBytes(const sipnet_batch* b) {
+  return b->precision == SIPNET_F32_MIXED ? sizeof(float) : sizeof(double);
+}
 
 inline int useDevice(const sipnet_batch* b) {
   HIP_TRY(hipSetDevice(b->device));

@@ -250,6 +250,37 @@ static int ensureFastRecs(sipnet_batch* b) {  // records of the throughput kerne
 // its fp64 build takes 232 registers and 64 KB of LDS); every other optional flag set takes the
 // one-wave kernel.  Strict arithmetic and the debug plane: the strict-order kernel.  Full records,
 // diagnostics and SIPNET_KOPT_FULL_STATE: the "Full" instantiations of the same throughput kernels.
+// The running-mean ring on the device, [SIPNET_RING_SLOTS][ncol]: doubles, or -- fp32-mixed batches -- floats:
+// the values are NPP rates, which such a batch computes in fp32, so the narrower store loses nothing and
+// halves what a resampling moves (a ring value IMPORTED from a checkpoint is rounded to fp32 there).
+// Host <-> device copies of ncols columns from col0, host side [slot][ncols] doubles.
+static int ringToHost(sipnet_batch* b, int64_t col0, int64_t ncols, double* out) {
+  const size_t eb = ringElemBytes(b);
+  if (eb == sizeof(double)) {
+    HIP_TRY(hipMemcpy2D(out, (size_t)ncols * eb, b->d_ring + col0, (size_t)b->ncol * eb, (size_t)ncols * eb,
+                        SIPNET_RING_SLOTS, hipMemcpyDeviceToHost));
+    return SIPNET_OK;
+  }
+  std::vector<float> tmp((size_t)ncols * SIPNET_RING_SLOTS);
+  HIP_TRY(hipMemcpy2D(tmp.data(), (size_t)ncols * eb, (const float*)b->d_ring + col0, (size_t)b->ncol * eb,
+                      (size_t)ncols * eb, SIPNET_RING_SLOTS, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < tmp.size(); i++) out[i] = (double)tmp[i];
+  return SIPNET_OK;
+}
+static int ringFromHost(sipnet_batch* b, int64_t col0, int64_t ncols, const double* in) {
+  const size_t eb = ringElemBytes(b);
+  if (eb == sizeof(double)) {
+    HIP_TRY(hipMemcpy2D(b->d_ring + col0, (size_t)b->ncol * eb, in, (size_t)ncols * eb, (size_t)ncols * eb,
+                        SIPNET_RING_SLOTS, hipMemcpyHostToDevice));
+    return SIPNET_OK;
+  }
+  std::vector<float> tmp((size_t)ncols * SIPNET_RING_SLOTS);
+  for (size_t i = 0; i < tmp.size(); i++) tmp[i] = (float)in[i];
+  HIP_TRY(hipMemcpy2D((float*)b->d_ring + col0, (size_t)b->ncol * eb, tmp.data(), (size_t)ncols * eb,
+                      (size_t)ncols * eb, SIPNET_RING_SLOTS, hipMemcpyHostToDevice));
+  return SIPNET_OK;
+}
+
 static int autoKernel(const int32_t* flags, int32_t n_sites, int32_t n_members, bool fastMath, bool debugPlane,
                       bool wantFull, int32_t numCUs) {
   const bool defaultFlags = isDefaultFlagSet(flags);
@@ -326,7 +357,7 @@ int sipnet_batch_create(const int32_t* flags, int32_t n_sites, int32_t n_members
   hipError_t e = hipSuccess;
   if (e == hipSuccess) e = hipMalloc(&b->d_prm, nc * SIPNET_NPARAMS * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&b->d_state, nc * SIPNET_NSTATE * sizeof(double));
-  if (e == hipSuccess) e = hipMalloc(&b->d_ring, nc * SIPNET_RING_SLOTS * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(&b->d_ring, nc * SIPNET_RING_SLOTS * ringElemBytes(b));
   if (e == hipSuccess) e = hipMalloc(&b->d_siteStatus, n_sites * sizeof(int32_t));
   if (e == hipSuccess) e = hipMalloc(&b->d_siteStart, n_sites * sizeof(SiteStart));
   if (e == hipSuccess) e = hipMalloc(&b->d_siteBase, (size_t)2 * n_sites * sizeof(int32_t));
@@ -463,6 +494,7 @@ int sipnet_batch_setup(sipnet_batch* b, void* hip_stream) {
   a.prm = b->d_prm;
   a.state = b->d_state;
   a.ring = b->d_ring;
+  a.ringF32 = b->precision == SIPNET_F32_MIXED;
   a.ncol = b->ncol;
   a.n_sites = b->n_sites;
   a.n_members = b->n_members;
@@ -810,9 +842,7 @@ int sipnet_batch_get_ring(sipnet_batch* b, int64_t col, double* values, void* hi
   int rc = useDevice(b);
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize((hipStream_t)hip_stream));
-  HIP_TRY(hipMemcpy2D(values, sizeof(double), b->d_ring + col, (size_t)b->ncol * sizeof(double),
-                      sizeof(double), SIPNET_RING_SLOTS, hipMemcpyDeviceToHost));
-  return SIPNET_OK;
+  return ringToHost(b, col, 1, values);
 }
 
 int sipnet_batch_get_rings(sipnet_batch* b, double* rings, void* hip_stream) {
@@ -821,7 +851,8 @@ int sipnet_batch_get_rings(sipnet_batch* b, double* rings, void* hip_stream) {
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize((hipStream_t)hip_stream));
   std::vector<double> tmp((size_t)b->ncol * SIPNET_RING_SLOTS);
-  HIP_TRY(hipMemcpy(tmp.data(), b->d_ring, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+  rc = ringToHost(b, 0, b->ncol, tmp.data());
+  if (rc) return rc;
   for (int k = 0; k < SIPNET_RING_SLOTS; k++)
     for (int64_t c = 0; c < b->ncol; c++)
       rings[c * SIPNET_RING_SLOTS + k] = tmp[(size_t)k * b->ncol + c];
@@ -837,8 +868,7 @@ int sipnet_batch_set_rings(sipnet_batch* b, const double* rings, void* hip_strea
   for (int k = 0; k < SIPNET_RING_SLOTS; k++)
     for (int64_t c = 0; c < b->ncol; c++)
       tmp[(size_t)k * b->ncol + c] = rings[c * SIPNET_RING_SLOTS + k];
-  HIP_TRY(hipMemcpy(b->d_ring, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
-  return SIPNET_OK;
+  return ringFromHost(b, 0, b->ncol, tmp.data());
 }
 
 int sipnet_batch_get_status(sipnet_batch* b, int32_t* status, void* hip_stream) {
@@ -1007,9 +1037,7 @@ int sipnet_batch_import_restart(sipnet_batch* b, int32_t site, int32_t first_mem
   }
   HIP_TRY(hipMemcpy2D(b->d_state + col0, pitchD, st.data(), pitchH, pitchH, SIPNET_NSTATE,
                       hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy2D(b->d_ring + col0, pitchD, ring.data(), pitchH, pitchH, SIPNET_RING_SLOTS,
-                      hipMemcpyHostToDevice));
-  return SIPNET_OK;
+  return ringFromHost(b, col0, count, ring.data());
 }
 
 int sipnet_batch_export_restart(sipnet_batch* b, int32_t site, int32_t member,
@@ -1041,8 +1069,8 @@ int sipnet_batch_export_restart(sipnet_batch* b, int32_t site, int32_t member,
   double st[SIPNET_NSTATE], ring[SIPNET_RING_SLOTS];
   HIP_TRY(hipMemcpy2D(st, sizeof(double), b->d_state + col, pitchD, sizeof(double),
                       SIPNET_NSTATE, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy2D(ring, sizeof(double), b->d_ring + col, pitchD, sizeof(double),
-                      SIPNET_RING_SLOTS, hipMemcpyDeviceToHost));
+  rc = ringToHost(b, col, 1, ring);
+  if (rc) return rc;
   if ((int)st[ST_status] != SIPNET_OK) {
     setError("sipnet_batch_export_restart: member did not run (status " +
              std::to_string((int)st[ST_status]) + ")");

@@ -40,6 +40,9 @@ struct RecvMap {
 // One thread moves kGatherRows rows of its column: the source index is read once and
 // kGatherRows independent loads are in flight per thread (HBM-bound streaming copy).
 constexpr int kGatherRows = 8;
+// rows of 8-byte words the ring takes in a packed block (a row of floats = half a row of words; 250 is even)
+static inline int ringWords(bool ringF32) { return ringF32 ? SIPNET_RING_SLOTS / 2 : SIPNET_RING_SLOTS; }
+static_assert(SIPNET_RING_SLOTS % 2 == 0, "a packed block keeps the parameter rows 8-byte aligned");
 __global__ __launch_bounds__(256) void gatherColumnsKernel(
     const double* __restrict__ own, int64_t ownPitch, int64_t ncol,
     const double* __restrict__ recv, RecvMap map, int32_t recvRow0,
@@ -82,14 +85,47 @@ __global__ __launch_bounds__(256) void gatherColumnsKernel(
 // so a resampling or a pack is one kernel instead of three (launch gaps were a third of the analysis
 // step's GPU time, profiles/r02_c5.md)
 struct GatherPart {
-  const double* own;   // [rows][ownPitch]
-  double* dst;         // [rows][dstPitch]
-  int32_t rows, group0, recvRow0;   // first row group of this part; its first row inside a packed block
+  const void* own;     // [rows][ownPitch] of 8-byte (doubles) or 4-byte (floats: the ring of an fp32-mixed batch) elements
+  void* dst;           // [rows][dstPitch]
+  int32_t rows, group0;   // group0: first row group (blockIdx.y) of this part
+  int32_t recvRow0;       // where the part starts inside a packed block, in rows of 8-byte words
+  int32_t elem4;          // 4-byte elements
 };
 struct GatherParts {
   GatherPart p[3];
   int32_t n;
 };
+template <typename T>
+__device__ __forceinline__ void gatherRows(const GatherPart& part, int row0, int nr, int64_t s, int64_t j, int64_t ownPitch,
+                                           int64_t ncol, const double* __restrict__ recv, const RecvMap& map,
+                                           int64_t dstPitch) {
+  T v[kGatherRows];
+  if (s < ncol) {
+    const T* __restrict__ p = (const T*)part.own + (int64_t)row0 * ownPitch + s;
+    if (nr == kGatherRows) {
+#pragma unroll
+      for (int r = 0; r < kGatherRows; r++) v[r] = p[(int64_t)r * ownPitch];
+    } else {
+      for (int r = 0; r < nr; r++) v[r] = p[(int64_t)r * ownPitch];
+    }
+  } else {
+    const int64_t kk = s - ncol;
+    int blk = 0;
+    for (int q = 1; q < map.nBlocks; q++)
+      if (kk >= map.start[q]) blk = q;
+    // (the part's first word inside the block, then rows of the part's own element type)
+    const T* __restrict__ p = (const T*)(recv + map.off[blk] + (int64_t)part.recvRow0 * map.n[blk]) +
+                              (int64_t)row0 * map.n[blk] + (kk - map.start[blk]);
+    for (int r = 0; r < nr; r++) v[r] = p[(int64_t)r * map.n[blk]];
+  }
+  T* __restrict__ q = (T*)part.dst + (int64_t)row0 * dstPitch + j;
+  if (nr == kGatherRows) {
+#pragma unroll
+    for (int r = 0; r < kGatherRows; r++) q[(int64_t)r * dstPitch] = v[r];
+  } else {
+    for (int r = 0; r < nr; r++) q[(int64_t)r * dstPitch] = v[r];
+  }
+}
 __global__ __launch_bounds__(256) void gatherMemberKernel(GatherParts parts, int64_t ownPitch, int64_t ncol,
                                                           const double* __restrict__ recv, RecvMap map,
                                                           const int32_t* __restrict__ src, int64_t nOut,
@@ -103,31 +139,8 @@ __global__ __launch_bounds__(256) void gatherMemberKernel(GatherParts parts, int
   const int row0 = ((int)blockIdx.y - part.group0) * kGatherRows;
   const int nr = part.rows - row0 < kGatherRows ? part.rows - row0 : kGatherRows;
   const int64_t s = src[j];
-  double v[kGatherRows];
-  if (s < ncol) {
-    const double* __restrict__ p = part.own + (int64_t)row0 * ownPitch + s;
-    if (nr == kGatherRows) {
-#pragma unroll
-      for (int r = 0; r < kGatherRows; r++) v[r] = p[(int64_t)r * ownPitch];
-    } else {
-      for (int r = 0; r < nr; r++) v[r] = p[(int64_t)r * ownPitch];
-    }
-  } else {
-    const int64_t kk = s - ncol;
-    int blk = 0;
-    for (int q = 1; q < map.nBlocks; q++)
-      if (kk >= map.start[q]) blk = q;
-    const double* __restrict__ p = recv + map.off[blk] + (int64_t)(row0 + part.recvRow0) * map.n[blk] +
-                                   (kk - map.start[blk]);
-    for (int r = 0; r < nr; r++) v[r] = p[(int64_t)r * map.n[blk]];
-  }
-  double* __restrict__ q = part.dst + (int64_t)row0 * dstPitch + j;
-  if (nr == kGatherRows) {
-#pragma unroll
-    for (int r = 0; r < kGatherRows; r++) q[(int64_t)r * dstPitch] = v[r];
-  } else {
-    for (int r = 0; r < nr; r++) q[(int64_t)r * dstPitch] = v[r];
-  }
+  if (part.elem4) gatherRows<float>(part, row0, nr, s, j, ownPitch, ncol, recv, map, dstPitch);
+  else gatherRows<double>(part, row0, nr, s, j, ownPitch, ncol, recv, map, dstPitch);
 }
 
 // logw[col] = -0.5 * ((sum_t plane[t][col] - obs) / sigma)^2, -inf for members that did not run
@@ -309,18 +322,19 @@ void launchGather(const double* own, int64_t ownPitch, int64_t ncol, const doubl
 }
 
 // state + ring (+ parameters) of the columns src[0..nOut) in one launch
-void launchGatherMember(const double* state, const double* ring, const double* prm, int64_t ncol,
+// (ringF32: the ring rows are floats, in the batch and in a packed block, where they take SIPNET_RING_SLOTS / 2 rows of words)
+void launchGatherMember(const double* state, const void* ring, bool ringF32, const double* prm, int64_t ncol,
                         const double* recv, const RecvMap& map, const int32_t* src, int64_t nOut,
-                        double* dState, double* dRing, double* dPrm, int64_t dstPitch, hipStream_t stream) {
+                        double* dState, void* dRing, double* dPrm, int64_t dstPitch, hipStream_t stream) {
   if (nOut <= 0) return;
   auto groups = [](int rows) { return (rows + kGatherRows - 1) / kGatherRows; };
   GatherParts parts{};
-  parts.p[0] = GatherPart{state, dState, SIPNET_NSTATE, 0, 0};
-  parts.p[1] = GatherPart{ring, dRing, SIPNET_RING_SLOTS, groups(SIPNET_NSTATE), SIPNET_NSTATE};
+  parts.p[0] = GatherPart{state, dState, SIPNET_NSTATE, 0, 0, 0};
+  parts.p[1] = GatherPart{ring, dRing, SIPNET_RING_SLOTS, groups(SIPNET_NSTATE), SIPNET_NSTATE, ringF32 ? 1 : 0};
   parts.n = 2;
   int total = groups(SIPNET_NSTATE) + groups(SIPNET_RING_SLOTS);
   if (prm) {
-    parts.p[2] = GatherPart{prm, dPrm, SIPNET_NPARAMS, total, SIPNET_NSTATE + SIPNET_RING_SLOTS};
+    parts.p[2] = GatherPart{prm, dPrm, SIPNET_NPARAMS, total, SIPNET_NSTATE + ringWords(ringF32), 0};
     parts.n = 3;
     total += groups(SIPNET_NPARAMS);
   }
@@ -337,6 +351,11 @@ extern "C" {
 
 int32_t sipnet_pf_member_words(int32_t with_params) {
   return SIPNET_NSTATE + SIPNET_RING_SLOTS + (with_params ? SIPNET_NPARAMS : 0);
+}
+
+int32_t sipnet_batch_member_words(const sipnet_batch* b, int32_t with_params) {
+  if (!b) return -1;
+  return SIPNET_NSTATE + ringWords(b->precision == SIPNET_F32_MIXED) + (with_params ? SIPNET_NPARAMS : 0);
 }
 
 int sipnet_batch_pf_log_weights(sipnet_batch* b, const void* d_plane, int32_t elem_is_f32,
@@ -533,9 +552,10 @@ int sipnet_batch_pack_members(sipnet_batch* b, const int32_t* d_cols, int64_t n,
   if (rc) return rc;
   hipStream_t stream = (hipStream_t)hip_stream;
   RecvMap none{};
-  // block layout: [NSTATE rows | RING_SLOTS rows | NPARAMS rows] x n columns
-  launchGatherMember(b->d_state, b->d_ring, with_params ? b->d_prm : nullptr, b->ncol, nullptr, none, d_cols, n, d_buf,
-                     d_buf + (size_t)SIPNET_NSTATE * n, d_buf + (size_t)(SIPNET_NSTATE + SIPNET_RING_SLOTS) * n, n, stream);
+  // block layout: [NSTATE rows | RING_SLOTS rows (fp32-mixed batches: of floats) | NPARAMS rows] x n columns
+  const bool rf = b->precision == SIPNET_F32_MIXED;
+  launchGatherMember(b->d_state, b->d_ring, rf, with_params ? b->d_prm : nullptr, b->ncol, nullptr, none, d_cols, n, d_buf,
+                     d_buf + (size_t)SIPNET_NSTATE * n, d_buf + (size_t)(SIPNET_NSTATE + ringWords(rf)) * n, n, stream);
   HIP_TRY(hipGetLastError());
   return SIPNET_OK;
 }
@@ -556,9 +576,9 @@ int sipnet_batch_resample(sipnet_batch* b, const int32_t* d_src, const double* d
   hipStream_t stream = (hipStream_t)hip_stream;
   const size_t nc = (size_t)b->ncol;
   if (!b->d_state2) HIP_TRY(hipMalloc(&b->d_state2, nc * SIPNET_NSTATE * sizeof(double)));
-  if (!b->d_ring2) HIP_TRY(hipMalloc(&b->d_ring2, nc * SIPNET_RING_SLOTS * sizeof(double)));
+  if (!b->d_ring2) HIP_TRY(hipMalloc(&b->d_ring2, nc * SIPNET_RING_SLOTS * ringElemBytes(b)));
   if (with_params && !b->d_prm2) HIP_TRY(hipMalloc(&b->d_prm2, nc * SIPNET_NPARAMS * sizeof(double)));
-  const int words = sipnet_pf_member_words(with_params);
+  const int words = sipnet_batch_member_words(b, with_params);
   RecvMap map{};
   map.nBlocks = n_blocks;
   int64_t start = 0, off = 0;
@@ -578,8 +598,8 @@ int sipnet_batch_resample(sipnet_batch* b, const int32_t* d_src, const double* d
     setError("sipnet_batch_resample: received columns announced but no buffer given");
     return SIPNET_ERR_BAD_ARGUMENT;
   }
-  launchGatherMember(b->d_state, b->d_ring, with_params ? b->d_prm : nullptr, b->ncol, d_recv, map, d_src, b->ncol,
-                     b->d_state2, b->d_ring2, b->d_prm2, b->ncol, stream);
+  launchGatherMember(b->d_state, b->d_ring, b->precision == SIPNET_F32_MIXED, with_params ? b->d_prm : nullptr, b->ncol,
+                     d_recv, map, d_src, b->ncol, b->d_state2, b->d_ring2, b->d_prm2, b->ncol, stream);
   HIP_TRY(hipGetLastError());
   std::swap(b->d_state, b->d_state2);
   std::swap(b->d_ring, b->d_ring2);

@@ -1561,7 +1561,8 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   double maxDC = 0.0;
   double* __restrict__ recp = Full && a.rec ? a.rec + col : nullptr;
 
-  double* __restrict__ ringp = a.ring + col;
+  // the ring in HBM holds NPP values of type R (fp32-mixed batches: fp32 numbers, stored as such); the LDS copy is fp64
+  R* __restrict__ ringp = (R*)a.ring + col;
   R* __restrict__ oNee = (R*)(a.nee ? a.nee : a.scratchRow) + col;
   const int64_t ldNee = a.nee ? a.ld : 0;
   const uint32_t ncu = (uint32_t)nc;
@@ -1583,7 +1584,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   bool aliveC = (plantWoodC > kTiny) && (plantWoodC + delta > kTiny) && (fineRootC + coarseRootC > kTiny);
   bool ringClean = __builtin_amdgcn_ballot_w64(!aliveC || ringValidFrom > 0) == 0;
   if (RingLds) {
-    for (int k = 0; k < SIPNET_RING_SLOTS; k++) ringL[k * 64 + lane] = ringp[(uint32_t)k * ncu];
+    for (int k = 0; k < SIPNET_RING_SLOTS; k++) ringL[k * 64 + lane] = (double)ringp[(uint32_t)k * ncu];
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   }
   WAIT_DECL()
@@ -1696,7 +1697,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         double vPrev = 0.0;
         if (nOps == 2) {
           const int s0 = slots0 & 255;
-          vPrev = RingLds ? ringL[s0 * 64 + lane] : (s0 == lastIns ? lastNpp : ringp[(uint32_t)s0 * ncu]);
+          vPrev = RingLds ? ringL[s0 * 64 + lane] : (s0 == lastIns ? lastNpp : (double)ringp[(uint32_t)s0 * ncu]);
         }
         // The rest of a step, written once and instantiated twice: the common case (nobody dies: no
         // mortality code at all behind ONE wave-uniform test) inside the loop, and the step on which a
@@ -1704,7 +1705,8 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         // general step from then on) -- the loop body stays one straight run of code.  What the
         // tail needs from the step lives outside the loop for that.
         R photosynthesis = 0, rSoil = 0, rVeg = 0, rCoarseRoot = 0, rFineRoot = 0;
-        double soilGain = 0.0, ringNew = 0.0, rvN = 0.0;
+        double soilGain = 0.0, ringNew = 0.0;
+        R rvN = 0;
         bool rootsOk = true, useLast = false, dyingStep = false;
         auto finishStep = [&](auto mayDie) {
 #pragma clang fp contract(off)
@@ -1755,7 +1757,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
           if (!NCyc) totNee += (double)tNee;
           const double npp = (double)(photosynthesis - rVeg - rCoarseRoot - rFineRoot);
           if (!RingLds) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rvN) :: "memory");
-          const double vNew = RingLds ? ringNew : (useLast ? lastNpp : rvN);
+          const double vNew = RingLds ? ringNew : (useLast ? lastNpp : (double)rvN);
           if (!(MayDie && diedNow)) {
             ringSum = ffma(-wA, vPrev, ringSum);
             ringSum = ffma(-wB, vNew, ringSum);
@@ -1767,7 +1769,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
           if (RingLds) {
             ringL[insSlot * 64 + lane] = npp;
           } else {
-            ringp[(uint32_t)insSlot * ncu] = npp;
+            ringp[(uint32_t)insSlot * ncu] = (R)npp;   // (npp is an R-typed difference: nothing is lost)
             lastIns = insSlot;
             lastNpp = npp;
           }
@@ -1804,9 +1806,13 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
             WAIT_END(0)
           }
           const R fSoil = NCyc ? R(0) : qSoilT * moistEff;
-          rvN = 0.0;
-          if (!RingLds)
-            asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(rvN) : "v"(ringp + (uint32_t)readSlot * ncu) : "memory");
+          rvN = 0;
+          if (!RingLds) {
+            if (sizeof(R) == 8)
+              asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(rvN) : "v"(ringp + (uint32_t)readSlot * ncu) : "memory");
+            else
+              asm volatile("global_load_dword %0, %1, off" : "=&v"(rvN) : "v"(ringp + (uint32_t)readSlot * ncu) : "memory");
+          }
           useLast = readSlot == lastIns;
           const bool isDay = (dayMask & 1u) != 0;
 
@@ -1956,11 +1962,16 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
     const int evSlot0 = slots & 255, evSlot1 = (slots >> 8) & 255;
     // HBM ring: the values this step evicts are requested now (asm: see the note on waits) and
     // awaited once, right before they are needed at the end of the step
-    double rv0 = 0.0, rv1 = 0.0;
+    R rv0 = 0, rv1 = 0;
     if (!RingLds) {
-      asm volatile("global_load_dwordx2 %0, %2, off\n\tglobal_load_dwordx2 %1, %3, off"
-                   : "=&v"(rv0), "=&v"(rv1)
-                   : "v"(ringp + (uint32_t)evSlot0 * ncu), "v"(ringp + (uint32_t)evSlot1 * ncu) : "memory");
+      if (sizeof(R) == 8)
+        asm volatile("global_load_dwordx2 %0, %2, off\n\tglobal_load_dwordx2 %1, %3, off"
+                     : "=&v"(rv0), "=&v"(rv1)
+                     : "v"(ringp + (uint32_t)evSlot0 * ncu), "v"(ringp + (uint32_t)evSlot1 * ncu) : "memory");
+      else
+        asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %3, off"
+                     : "=&v"(rv0), "=&v"(rv1)
+                     : "v"(ringp + (uint32_t)evSlot0 * ncu), "v"(ringp + (uint32_t)evSlot1 * ncu) : "memory");
     }
     const bool useLast0 = evSlot0 == lastIns, useLast1 = evSlot1 == lastIns;
 
@@ -2278,12 +2289,12 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
     CSTAMP(5)
     {
       if (!RingLds) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rv0), "+v"(rv1) :: "memory");
-      const double v0 = RingLds ? ringL[evSlot0 * 64 + lane] : (useLast0 ? lastNpp : rv0);
+      const double v0 = RingLds ? ringL[evSlot0 * 64 + lane] : (useLast0 ? lastNpp : (double)rv0);
       const int nOps = bits >> 16;
       // one or two evictions and a plain insert (two is the steady state of half-hourly forcing,
       // see the regular-tile path); with one eviction w1 is 0 and its term an exact no-op
       if (__builtin_expect(ringClean && insSlot >= 0 && nOps <= 2, 1)) {
-        const double v1 = RingLds ? ringL[evSlot1 * 64 + lane] : (useLast1 ? lastNpp : rv1);
+        const double v1 = RingLds ? ringL[evSlot1 * 64 + lane] : (useLast1 ? lastNpp : (double)rv1);
         ringSum = ffma(-q7.y, v0, ringSum);
         ringSum = ffma(-rare[0], v1, ringSum);
         ringSum = ffma(npp, (double)len, ringSum);
@@ -2291,7 +2302,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         if (insSlot < 0) {
           ringSum = npp * 5.0;
         } else {
-          double w0v = v0, w1v = RingLds ? ringL[evSlot1 * 64 + lane] : (useLast1 ? lastNpp : rv1);
+          double w0v = v0, w1v = RingLds ? ringL[evSlot1 * 64 + lane] : (useLast1 ? lastNpp : (double)rv1);
           if (ringValidFrom > 0) {
             if (uni(rareI[0]) < ringValidFrom) w0v = 0.0;
             if (uni(rareI[1]) < ringValidFrom) w1v = 0.0;
@@ -2302,7 +2313,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
             const RingOp& op = a.ringOps[opBase + uni(rareI[2]) + k];
             const int os = uni(op.slot);
             const double rvk = RingLds ? ringL[os * 64 + lane]
-                                       : (os == lastIns ? lastNpp : ringp[(uint32_t)os * ncu]);
+                                       : (os == lastIns ? lastNpp : (double)ringp[(uint32_t)os * ncu]);
             const double v = (uni(op.insStep) >= ringValidFrom) ? rvk : 0.0;
             ringSum = ffma(-op.w, v, ringSum);
           }
@@ -2316,7 +2327,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
     if (RingLds) {
       ringL[insEff * 64 + lane] = npp;
     } else {
-      ringp[(uint32_t)insEff * ncu] = npp;
+      ringp[(uint32_t)insEff * ncu] = (R)npp;
       lastIns = insEff;
       lastNpp = npp;
     }
@@ -2382,7 +2393,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   }
   if (act) {
     if (RingLds)
-      for (int k = 0; k < SIPNET_RING_SLOTS; k++) ringp[(uint32_t)k * ncu] = ringL[k * 64 + lane];
+      for (int k = 0; k < SIPNET_RING_SLOTS; k++) ringp[(uint32_t)k * ncu] = (R)ringL[k * 64 + lane];
     ST(plantWoodC) = plantWoodC;
     ST(plantLeafC) = plantLeafC;
     if (!NCyc) ST(soilC) = soilC;

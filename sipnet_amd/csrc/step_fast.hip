@@ -252,7 +252,8 @@ void stepFastKernel(FastArgs a) {
 
   const unsigned char* __restrict__ planBytes =
       (const unsigned char*)(a.fast + (int64_t)site * a.n_steps_total);
-  double* __restrict__ ringp = a.ring + col;
+  // the ring holds NPP values of type R (fp32-mixed batches: fp32 numbers, stored as such)
+  R* __restrict__ ringp = (R*)a.ring + col;
   // Output planes: a plane the caller does not want is pointed at a one-row scratch buffer
   // with stride 0, so the stores below need no test.  Lanes past the end of a site work on a
   // copy of the site's last member and store identical values to its addresses; members with
@@ -292,7 +293,7 @@ void stepFastKernel(FastArgs a) {
   // ring values a step evicts are requested at the END of the previous step (ahead of that
   // step's stores in the memory queue) and consumed a whole step later; the first step's are
   // requested here
-  double rv0, rv1;
+  R rv0, rv1;
   {
     const int32_t slots0 = uni(*(const int32_t*)(lds + (curTile & 1) * kTileBytes +
                                                  (int)(tBegin - tileFirst(curTile)) * (int)sizeof(FastRec) + 132));
@@ -916,7 +917,7 @@ void stepFastKernel(FastArgs a) {
     const double recMeanNpp = Full ? ringSum / 5.0 : 0.0;  // trackers.meanNPP: the mean BEFORE this step's insert
     STAMP(5)
     {
-      const double v0 = useLast0 ? lastNpp : rv0;
+      const double v0 = useLast0 ? lastNpp : (double)rv0;
       const int nOps = bits >> 16;
       // regular step: every lane alive with an untouched ring epoch, one or two evictions, plain
       // insert.  TWO evictions is the steady state of half-hourly forcing (240 x 1/48 is not
@@ -926,7 +927,7 @@ void stepFastKernel(FastArgs a) {
       const bool irregular = __builtin_amdgcn_ballot_w64(!alive || ringValidFrom > 0) != 0 ||
                              insSlot < 0 || nOps > 2;
       if (__builtin_expect(!irregular, 1)) {
-        const double v1 = useLast1 ? lastNpp : rv1;
+        const double v1 = useLast1 ? lastNpp : (double)rv1;
         ringSum = ffma(-q7.y, v0, ringSum);
         ringSum = ffma(-rare[0], v1, ringSum);
         ringSum = ffma(npp, (double)len, ringSum);
@@ -934,7 +935,7 @@ void stepFastKernel(FastArgs a) {
         if (insSlot < 0) {
           ringSum = npp * 5.0;
         } else {
-          double w0v = v0, w1v = useLast1 ? lastNpp : rv1;
+          double w0v = v0, w1v = useLast1 ? lastNpp : (double)rv1;
           if (ringValidFrom > 0) {  // a member that died earlier: older slots count as zero
             if (uni(rareI[0]) < ringValidFrom) w0v = 0.0;
             if (uni(rareI[1]) < ringValidFrom) w1v = 0.0;
@@ -944,7 +945,7 @@ void stepFastKernel(FastArgs a) {
           for (int k = 2; k < nOps; k++) {
             const RingOp& op = a.ringOps[opBase + uni(rareI[2]) + k];
             const double v = (uni(op.insStep) >= ringValidFrom)
-                                 ? ringp[(uint32_t)uni(op.slot) * ncu] : 0.0;
+                                 ? (double)ringp[(uint32_t)uni(op.slot) * ncu] : 0.0;
             ringSum = ffma(-op.w, v, ringSum);
           }
           ringSum = ffma(npp, (double)len, ringSum);
@@ -1019,7 +1020,7 @@ void stepFastKernel(FastArgs a) {
     oEt += ldEt;
     // a dead member's slot is never read as live data again (ringValidFrom), so the insert
     // needs no alive test
-    ringp[(uint32_t)insEff * ncu] = npp;
+    ringp[(uint32_t)insEff * ncu] = (R)npp;   // (npp is an R-typed difference: nothing is lost)
     STAMP(7)
   }  // steps of this tile
   }  // tiles

@@ -56,7 +56,7 @@ struct KernelArgs {
   const int32_t* siteBase;
   const double* prm;      // [SIPNET_NPARAMS][ncol] converted parameters
   double* state;          // [SIPNET_NSTATE][ncol]
-  double* ring;           // [SIPNET_RING_SLOTS][ncol]
+  double* ring;           // [SIPNET_RING_SLOTS][ncol] of the kernel's real type (floats for fp32-mixed batches)
   void* nee;              // [n_steps][ld] or null
   void* gpp;
   void* et;
@@ -77,6 +77,7 @@ struct SetupArgs {
   const double* prm;      // [SIPNET_NPARAMS][ncol] converted parameters (launchConvertParams)
   double* state;          // [SIPNET_NSTATE][ncol]
   double* ring;           // slot 0 row is zeroed
+  int32_t ringF32;        // fp32-mixed batches: the ring is [SIPNET_RING_SLOTS][ncol] floats (see sipnet_batch)
   int64_t ncol;
   int32_t n_sites, n_members;
   int32_t flags[SIPNET_NFLAGS];

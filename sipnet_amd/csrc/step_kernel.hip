@@ -197,7 +197,9 @@ __global__ __launch_bounds__(256) void setupKernel(SetupArgs a) {
 
 #pragma unroll
   for (int k = 0; k < SIPNET_NSTATE; k++) a.state[(int64_t)k * a.ncol + col] = st[k];
-  a.ring[col] = 0.0;  // slot 0 = the initial (mean 0, weight 5) entry
+  // slot 0 = the initial (mean 0, weight 5) entry
+  if (a.ringF32) ((float*)a.ring)[col] = 0.0f;
+  else a.ring[col] = 0.0;
 }
 
 // -----------------------------------------------------------------------------
@@ -312,7 +314,7 @@ __global__ __launch_bounds__(64) void stepKernel(KernelArgs a) {
   double diagMaxDC = 0.0, diagMaxDN = 0.0;
 
   const StepRec* __restrict__ plan = a.plan + (int64_t)site * a.n_steps_total;
-  double* __restrict__ ringp = a.ring + col;
+  R* __restrict__ ringp = (R*)a.ring + col;   // NPP values of type R (fp32-mixed batches keep them as fp32)
   R* __restrict__ oNee = a.nee ? (R*)a.nee + col : nullptr;
   R* __restrict__ oGpp = a.gpp ? (R*)a.gpp + col : nullptr;
   R* __restrict__ oEt = a.et ? (R*)a.et + col : nullptr;
@@ -1136,17 +1138,17 @@ __global__ __launch_bounds__(64) void stepKernel(KernelArgs a) {
         const double npp = (double)(photosynthesis - rVeg - rCoarseRoot - rFineRoot);
         if (insSlot < 0) {
           // weight >= totWeight: the new value replaces everything (runmean.c:67-69)
-          ringp[0] = npp;
+          ringp[0] = (R)npp;
           ringSum = npp * kMeanNppDays;
         } else {
           for (int k = 0; k < nOps; k++) {
             const RingOp& op = a.ringOps[opBase + opFirst + k];
             const int slot = uni(op.slot);
             const int ins = uni(op.insStep);
-            const double v = (ins >= ringValidFrom) ? ringp[(int64_t)slot * nc] : 0.0;
+            const double v = (ins >= ringValidFrom) ? (double)ringp[(int64_t)slot * nc] : 0.0;
             ringSum -= op.w * v;
           }
-          ringp[(int64_t)insSlot * nc] = npp;
+          ringp[(int64_t)insSlot * nc] = (R)npp;
           ringSum += npp * dl;
         }
       } else {

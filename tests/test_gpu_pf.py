@@ -89,35 +89,65 @@ def test_ancestors_without_host_round_trip_equal_the_synchronous_call():
     assert int(total.item()) == 0
 
 
+def _block_parts(blk, n, f32):
+    """a packed block [words][n] of 8-byte words -> state [32][n], ring [250][n] (floats in an fp32-mixed
+    batch: 250 rows of n floats in 125 rows of words), parameters [..][n]"""
+    rw = 125 if f32 else 250
+    ring = blk[32:32 + rw]
+    if f32:
+        ring = np.ascontiguousarray(ring).reshape(-1).view(np.float32).reshape(250, n).astype(np.float64)
+    return blk[:32], ring, blk[32 + rw:]
+
+
+def _make_block(rng, k, f32, with_params):
+    """a foreign block of k particles with recognisable contents, as words + its three parts"""
+    st = rng.normal(size=(32, k))
+    ring = rng.normal(size=(250, k))
+    prm = rng.normal(size=(80 if with_params else 0, k))
+    if f32:
+        ring = ring.astype(np.float32)
+        words = np.concatenate([st.reshape(-1), ring.reshape(-1).view(np.float64), prm.reshape(-1)])
+        ring = ring.astype(np.float64)
+    else:
+        words = np.concatenate([st.reshape(-1), ring.reshape(-1), prm.reshape(-1)])
+    return words, st, ring, prm
+
+
+@pytest.mark.parametrize("prec", [sa.F64, sa.F32_MIXED], ids=["f64", "f32ring"])
 @pytest.mark.parametrize("with_params", [False, True])
-def test_pack_and_resample_match_numpy(base, clim, with_params):
+def test_pack_and_resample_match_numpy(base, clim, with_params, prec):
+    """(fp32-mixed batches keep the ring in fp32, in the batch and in a packed block)"""
     n = 300
+    f32 = prec == sa.F32_MIXED
     members = synth.perturbed_params(base, n)
-    b = batch_of(clim, members)
+    b = batch_of(clim, members, prec)
     b.run(0, 300)                                     # fills state and ring with distinct values
     state, rings = b.get_state(), b.get_rings()       # [n][32], [n][250]
-    words = 32 + 250 + (80 if with_params else 0)
+    assert np.abs(rings[:, 1:200]).min() > 0
+    words = 32 + (125 if f32 else 250) + (80 if with_params else 0)
     rng = np.random.default_rng(1)
     cols = np.sort(rng.choice(n, 37, replace=False)).astype(np.int32)
     blk = b.pack_members(torch.from_numpy(cols).to(DEV), with_params).cpu().numpy()
     assert blk.shape == (words, 37)
-    np.testing.assert_array_equal(blk[:32], state[cols].T)
-    np.testing.assert_array_equal(blk[32:282], rings[cols].T)
+    bs, br, _ = _block_parts(blk, 37, f32)
+    np.testing.assert_array_equal(bs, state[cols].T)
+    np.testing.assert_array_equal(br, rings[cols].T)
     # received blocks: two "ranks" of 5 and 9 foreign particles with recognisable contents
-    r1 = rng.normal(size=(words, 5))
-    r2 = rng.normal(size=(words, 9))
-    recv = torch.from_numpy(np.concatenate([r1.ravel(), np.zeros(0), r2.ravel()])).to(DEV)
+    w1, s1, g1, p1 = _make_block(rng, 5, f32, with_params)
+    w2, s2, g2, p2 = _make_block(rng, 9, f32, with_params)
+    recv = torch.from_numpy(np.concatenate([w1, np.zeros(0), w2])).to(DEV)
     src = np.sort(rng.integers(0, n + 14, size=n)).astype(np.int32)
-    prm_before = b.pack_members(torch.arange(n, dtype=torch.int32, device=DEV), True).cpu().numpy()[282:]
+    everyone = torch.arange(n, dtype=torch.int32, device=DEV)
+    prm_before = _block_parts(b.pack_members(everyone, True).cpu().numpy(), n, f32)[2]
     b.resample(torch.from_numpy(src).to(DEV), recv, [5, 0, 9], with_params)
     new_state, new_rings = b.get_state(), b.get_rings()
-    pool_state = np.concatenate([state.T, r1[:32], r2[:32]], axis=1)
-    pool_ring = np.concatenate([rings.T, r1[32:282], r2[32:282]], axis=1)
+    pool_state = np.concatenate([state.T, s1, s2], axis=1)
+    pool_ring = np.concatenate([rings.T, g1, g2], axis=1)
     np.testing.assert_array_equal(new_state.T, pool_state[:, src])
     np.testing.assert_array_equal(new_rings.T, pool_ring[:, src])
-    prm_after = b.pack_members(torch.arange(n, dtype=torch.int32, device=DEV), True).cpu().numpy()[282:]
+    prm_after = _block_parts(b.pack_members(everyone, True).cpu().numpy(), n, f32)[2]
     if with_params:
-        pool_prm = np.concatenate([prm_before, r1[282:], r2[282:]], axis=1)
+        pool_prm = np.concatenate([prm_before, p1, p2], axis=1)
         np.testing.assert_array_equal(prm_after, pool_prm[:, src])
     else:
         np.testing.assert_array_equal(prm_after, prm_before)
@@ -161,12 +191,13 @@ def test_cycle_resampled_particles_continue_like_their_ancestors(base, clim, pre
     b.close()
 
 
-def test_two_ranks_emulated_on_one_gpu(base, clim):
+@pytest.mark.parametrize("prec", [sa.F64, sa.F32_MIXED], ids=["f64", "f32ring"])
+def test_two_ranks_emulated_on_one_gpu(base, clim, prec):
     """two batches stand in for two ranks: exchange plan + pack + resample with received blocks
     reproduce the global gather (the all-to-all itself is covered over gloo in test_pf.py)"""
     n, world = 256, 2
     members = synth.perturbed_params(base, n * world)
-    ranks = [batch_of(clim, members[r * n:(r + 1) * n]) for r in range(world)]
+    ranks = [batch_of(clim, members[r * n:(r + 1) * n], prec) for r in range(world)]
     for b in ranks:
         b.run(0, 96)
     before = [np.concatenate([b.get_state().T, b.get_rings().T], axis=0) for b in ranks]
