@@ -432,6 +432,16 @@ int sipnet_batch_resample(sipnet_batch *b, const int32_t *d_src, const double *d
                           int32_t n_blocks, const int64_t *block_cols, int32_t with_params,
                           void *hip_stream);
 
+/* The whole analysis step of a filter whose particles all live in this batch (one rank), in one call:
+ * sipnet_batch_pf_log_weights -> sipnet_pf_systematic_ancestors(_async when d_total is given: no host
+ * round trip, see there) -> sipnet_batch_resample with the ancestors.  d_logw, d_ancestors: DEVICE [ncol],
+ * filled.  (A filter spread over ranks calls the three steps itself, with its all-gather and all-to-all
+ * in between; this entry exists because the host-side cost of six calls was the analysis step's
+ * duration at C5's shape.) */
+int sipnet_batch_pf_analysis(sipnet_batch *b, const void *d_plane, int32_t elem_is_f32, int32_t n_steps,
+                             int64_t ld, double obs, double sigma, double u0, int32_t with_params,
+                             double *d_logw, int32_t *d_ancestors, int64_t *d_total, void *hip_stream);
+
 /* ---- one node, several GPUs (north star: "the ensemble axis shards across the 8 GPUs of one node
  * with a single RCCL all-gather over xGMI of the NEE/GPP/ET output block", from the C host) --------
  * A sipnet_node is the multi-GPU host object of ONE process: one sipnet_batch, one HIP stream and

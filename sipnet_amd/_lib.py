@@ -128,6 +128,8 @@ SIGNATURES = {
     "sipnet_pf_release_scratch": (None, []),
     "sipnet_pf_member_words": (C.c_int32, [C.c_int32]),
     "sipnet_batch_member_words": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "sipnet_batch_pf_analysis": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int64, C.c_double, C.c_double, C.c_double,
+                                           C.c_int32, _P, _P, _P, _P]),
     "sipnet_batch_pack_members": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P]),
     "sipnet_batch_resample": (C.c_int, [_P, _P, _P, C.c_int32, _P, C.c_int32, _P]),
     "sipnet_node_create": (C.c_int, [_I32P, C.c_int32, C.c_int32, C.c_int32, _I32P, C.c_int32, C.POINTER(_P)]),

@@ -268,6 +268,21 @@ class Batch:
             "pf_log_weights")
         return out
 
+    def pf_analysis_local(self, plane, obs, sigma, u0, with_params=False, total_out=None):
+        """log-weights -> systematic resampling -> resample, all particles in this batch, ONE library call
+        (sipnet_batch_pf_analysis).  Returns (ancestors int32 [ncol], logw f64 [ncol]) on the device."""
+        t = self._torch
+        if getattr(self, "_pf_buf", None) is None:
+            self._pf_buf = (t.empty(self.ncol, dtype=t.float64, device=self.device),
+                            t.empty(self.ncol, dtype=t.int32, device=self.device))
+        logw, anc = self._pf_buf
+        check(self.L.sipnet_batch_pf_analysis(
+            self.h, C.c_void_p(plane.data_ptr()), int(plane.dtype == t.float32), plane.shape[0], plane.shape[1],
+            float(obs), float(sigma), float(u0), int(with_params), C.c_void_p(logw.data_ptr()),
+            C.c_void_p(anc.data_ptr()), C.c_void_p(total_out.data_ptr()) if total_out is not None else None,
+            self._stream()), "pf_analysis")
+        return anc, logw
+
     def pack_members(self, cols, with_params=False):
         """cols: int32 device tensor of local column indices -> packed block [words][n] of 8-byte words
         (state rows, ring rows -- floats for an fp32-mixed batch --, parameter rows)"""

@@ -43,44 +43,7 @@ constexpr int kGatherRows = 8;
 // rows of 8-byte words the ring takes in a packed block (a row of floats = half a row of words; 250 is even)
 static inline int ringWords(bool ringF32) { return ringF32 ? SIPNET_RING_SLOTS / 2 : SIPNET_RING_SLOTS; }
 static_assert(SIPNET_RING_SLOTS % 2 == 0, "a packed block keeps the parameter rows 8-byte aligned");
-__global__ __launch_bounds__(256) void gatherColumnsKernel(
-    const double* __restrict__ own, int64_t ownPitch, int64_t ncol,
-    const double* __restrict__ recv, RecvMap map, int32_t recvRow0,
-    const int32_t* __restrict__ src, int64_t nOut, double* __restrict__ dst, int64_t dstPitch,
-    int32_t rows) {
-  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= nOut) return;
-  const int row0 = blockIdx.y * kGatherRows;
-  const int nr = rows - row0 < kGatherRows ? rows - row0 : kGatherRows;
-  const int64_t s = src[j];
-  double v[kGatherRows];
-  if (s < ncol) {
-    const double* __restrict__ p = own + (int64_t)row0 * ownPitch + s;
-    if (nr == kGatherRows) {
-#pragma unroll
-      for (int r = 0; r < kGatherRows; r++) v[r] = p[(int64_t)r * ownPitch];
-    } else {
-      for (int r = 0; r < nr; r++) v[r] = p[(int64_t)r * ownPitch];
-    }
-  } else {
-    const int64_t k = s - ncol;
-    int blk = 0;
-    for (int q = 1; q < map.nBlocks; q++)
-      if (k >= map.start[q]) blk = q;
-    const double* __restrict__ p = recv + map.off[blk] + (int64_t)(row0 + recvRow0) * map.n[blk] +
-                                   (k - map.start[blk]);
-    for (int r = 0; r < nr; r++) v[r] = p[(int64_t)r * map.n[blk]];
-  }
-  double* __restrict__ q = dst + (int64_t)row0 * dstPitch + j;
-  if (nr == kGatherRows) {
-#pragma unroll
-    for (int r = 0; r < kGatherRows; r++) q[(int64_t)r * dstPitch] = v[r];
-  } else {
-    for (int r = 0; r < nr; r++) q[(int64_t)r * dstPitch] = v[r];
-  }
-}
-
-// The same for the three matrices of a member's checkpoint in ONE launch (state rows, ring rows,
+// One launch for the three matrices of a member's checkpoint (state rows, ring rows,
 // then parameter rows: the row order of a packed block): blockIdx.y walks the row groups of all three,
 // so a resampling or a pack is one kernel instead of three (launch gaps were a third of the analysis
 // step's GPU time, profiles/r02_c5.md)
@@ -145,22 +108,51 @@ __global__ __launch_bounds__(256) void gatherMemberKernel(GatherParts parts, int
 
 // logw[col] = -0.5 * ((sum_t plane[t][col] - obs) / sigma)^2, -inf for members that did not run
 template <typename T>
+__device__ __forceinline__ double logWeightOf(const T* __restrict__ plane, int32_t nSteps, int64_t ld, int64_t c,
+                                              const double* __restrict__ status, double obs, double invSigma,
+                                              double* __restrict__ logw) {
+  // the sum in step order; eight loads in flight at a time (one dependent load per step left the kernel
+  // latency-bound: 25 MB in 14.7 us at C5's shape)
+  double acc = 0.0;
+  int t = 0;
+  for (; t + 8 <= nSteps; t += 8) {
+    T v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = plane[(int64_t)(t + k) * ld + c];
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc += (double)v[k];
+  }
+  for (; t < nSteps; t++) acc += (double)plane[(int64_t)t * ld + c];
+  const double z = (acc - obs) * invSigma;
+  const double lw = (status[c] != 0.0) ? -INFINITY : -0.5 * z * z;
+  logw[c] = lw;
+  return lw;
+}
+// (part, if given: the block's maximum -- what maxPartialKernel would compute in a launch of its own)
+template <typename T>
 __global__ __launch_bounds__(256) void logWeightKernel(const T* __restrict__ plane, int32_t nSteps,
                                                        int64_t ld, int64_t ncol,
                                                        const double* __restrict__ status,
                                                        double obs, double invSigma,
-                                                       double* __restrict__ logw) {
+                                                       double* __restrict__ logw, double* __restrict__ part) {
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= ncol) return;
-  double acc = 0.0;
-  for (int t = 0; t < nSteps; t++) acc += (double)plane[(int64_t)t * ld + c];
-  const double z = (acc - obs) * invSigma;
-  logw[c] = (status[c] != 0.0) ? -INFINITY : -0.5 * z * z;
+  double mine = -INFINITY;
+  if (c < ncol) mine = logWeightOf(plane, nSteps, ld, c, status, obs, invSigma, logw);
+  if (part) {
+    __shared__ double sm[256];
+    sm[threadIdx.x] = mine;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if ((int)threadIdx.x < s) sm[threadIdx.x] = fmax(sm[threadIdx.x], sm[threadIdx.x + s]);
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = sm[0];
+  }
 }
 // (the scratch blocks are freed by sipnet_pf_release_scratch, not by a thread-exit destructor: that
 // may run after the HIP runtime has shut down)
 
-// max of the log-weights, two stages: per-block partial maxima, then one block over them
+// max of the log-weights: per-block partial maxima (the consumer, fixedWeightKernel, takes their maximum)
 __global__ __launch_bounds__(256) void maxPartialKernel(const double* __restrict__ x, int64_t n,
                                                         double* __restrict__ part) {
   __shared__ double sm[256];
@@ -179,21 +171,34 @@ __global__ __launch_bounds__(256) void maxPartialKernel(const double* __restrict
 
 // fixed-point weights: w = llrint(exp(logw - max) * 2^30).  Integer weights make the prefix
 // sum exact, so every rank computes bit-identical ancestors from the same gathered logw.
+// (every block first takes the maximum of the `parts` partial maxima itself: one launch less)
 __global__ __launch_bounds__(256) void fixedWeightKernel(const double* __restrict__ logw,
-                                                         int64_t n, const double* __restrict__ mx,
+                                                         int64_t n, const double* __restrict__ part, int parts,
                                                          int64_t* __restrict__ w) {
+  __shared__ double sm[256];
+  double pm = -INFINITY;
+  for (int k = threadIdx.x; k < parts; k += 256) pm = fmax(pm, part[k]);
+  sm[threadIdx.x] = pm;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sm[threadIdx.x] = fmax(sm[threadIdx.x], sm[threadIdx.x + s]);
+    __syncthreads();
+  }
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const double m = mx[0];
+  const double m = sm[0];
   const double e = exp(logw[i] - m);
   w[i] = (!(logw[i] > -INFINITY) || !(m > -INFINITY)) ? 0 : llrint(e * 1073741824.0);
 }
 
 // ancestor[j] = first i with cdf[i] > p_j, p_j = ((j + u0) * S) / n  (S = cdf[n-1] < 2^53)
+// (total, if wanted: the total integer weight, for the caller's "a particle survived" check)
 __global__ __launch_bounds__(256) void ancestorKernel(const int64_t* __restrict__ cdf, int64_t n,
-                                                      double u0, int32_t* __restrict__ anc) {
+                                                      double u0, int32_t* __restrict__ anc,
+                                                      int64_t* __restrict__ total) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
+  if (j == 0 && total) *total = cdf[n - 1];
   const double S = (double)cdf[n - 1];
   // S - 1 keeps the search inside the support when (j + u0) rounds up to n
   const double p = fmin((((double)j + u0) * S) / (double)n, S - 1.0);
@@ -312,15 +317,6 @@ __global__ __launch_bounds__(256) void planFillKernel(const int32_t* __restrict_
   }
 }
 
-void launchGather(const double* own, int64_t ownPitch, int64_t ncol, const double* recv,
-                  const RecvMap& map, int recvRow0, const int32_t* src, int64_t nOut, double* dst,
-                  int64_t dstPitch, int rows, hipStream_t stream) {
-  if (nOut <= 0) return;
-  dim3 grid((unsigned)((nOut + 255) / 256), (unsigned)((rows + kGatherRows - 1) / kGatherRows));
-  hipLaunchKernelGGL(gatherColumnsKernel, grid, dim3(256), 0, stream, own, ownPitch, ncol, recv,
-                     map, recvRow0, src, nOut, dst, dstPitch, rows);
-}
-
 // state + ring (+ parameters) of the columns src[0..nOut) in one launch
 // (ringF32: the ring rows are floats, in the batch and in a packed block, where they take SIPNET_RING_SLOTS / 2 rows of words)
 void launchGatherMember(const double* state, const void* ring, bool ringF32, const double* prm, int64_t ncol,
@@ -358,9 +354,9 @@ int32_t sipnet_batch_member_words(const sipnet_batch* b, int32_t with_params) {
   return SIPNET_NSTATE + ringWords(b->precision == SIPNET_F32_MIXED) + (with_params ? SIPNET_NPARAMS : 0);
 }
 
-int sipnet_batch_pf_log_weights(sipnet_batch* b, const void* d_plane, int32_t elem_is_f32,
-                                int32_t n_steps, int64_t ld, double obs, double sigma,
-                                double* d_logw, void* hip_stream) {
+// d_part (optional, DEVICE, one double per 256 columns): the blocks' maxima, for the resampling that follows
+static int logWeights(sipnet_batch* b, const void* d_plane, int32_t elem_is_f32, int32_t n_steps, int64_t ld,
+                      double obs, double sigma, double* d_logw, double* d_part, void* hip_stream) {
   if (!b || !d_plane || !d_logw || n_steps <= 0 || ld < b->ncol || !(sigma > 0)) {
     setError("sipnet_batch_pf_log_weights: bad argument");
     return SIPNET_ERR_BAD_ARGUMENT;
@@ -372,13 +368,19 @@ int sipnet_batch_pf_log_weights(sipnet_batch* b, const void* d_plane, int32_t el
   const double* status = b->d_state + (size_t)ST_status * b->ncol;
   if (elem_is_f32) {
     hipLaunchKernelGGL(logWeightKernel<float>, dim3(grid), dim3(256), 0, stream,
-                       (const float*)d_plane, n_steps, ld, b->ncol, status, obs, 1.0 / sigma, d_logw);
+                       (const float*)d_plane, n_steps, ld, b->ncol, status, obs, 1.0 / sigma, d_logw, d_part);
   } else {
     hipLaunchKernelGGL(logWeightKernel<double>, dim3(grid), dim3(256), 0, stream,
-                       (const double*)d_plane, n_steps, ld, b->ncol, status, obs, 1.0 / sigma, d_logw);
+                       (const double*)d_plane, n_steps, ld, b->ncol, status, obs, 1.0 / sigma, d_logw, d_part);
   }
   HIP_TRY(hipGetLastError());
   return SIPNET_OK;
+}
+
+extern "C" int sipnet_batch_pf_log_weights(sipnet_batch* b, const void* d_plane, int32_t elem_is_f32,
+                                           int32_t n_steps, int64_t ld, double obs, double sigma,
+                                           double* d_logw, void* hip_stream) {
+  return logWeights(b, d_plane, elem_is_f32, n_steps, ld, obs, sigma, d_logw, nullptr, hip_stream);
 }
 
 namespace {
@@ -386,7 +388,7 @@ namespace {
 struct PfScratch {
   int device = -1;
   int64_t cap = 0;
-  double* d_max = nullptr;  // [kMaxParts + 1]: partial maxima, then the maximum
+  double* d_max = nullptr;  // partial maxima of the log-weights (one per 256 weights at most)
   int64_t* d_w = nullptr;
   int64_t* d_cdf = nullptr;
   void* d_tmp = nullptr;
@@ -404,44 +406,56 @@ constexpr int kMaxParts = 256;
 thread_local PfScratch g_pf;
 }  // namespace
 
-int sipnet_pf_systematic_ancestors_async(const double* d_logw, int64_t n, double u0,
-                                         int32_t* d_ancestors, int64_t* d_fixed_weights,
-                                         int64_t* d_total, void* hip_stream) {
-  if (!d_logw || !d_ancestors || n <= 0 || n > (int64_t)1 << 22 || !(u0 >= 0.0) || !(u0 < 1.0)) {
-    setError("sipnet_pf_systematic_ancestors: bad argument (n <= 4194304, 0 <= u0 < 1)");
-    return SIPNET_ERR_BAD_ARGUMENT;
-  }
-  hipStream_t stream = (hipStream_t)hip_stream;
+// scratch of the calling thread for n weights (the partial maxima: one per 256 of them at most)
+static int pfScratchFor(int64_t n, hipStream_t stream) {
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
   PfScratch& sc = g_pf;
   if (sc.device != dev || sc.cap < n) {
     sc.release();
     sc.device = dev;
-    HIP_TRY(hipMalloc(&sc.d_max, (kMaxParts + 1) * sizeof(double)));
+    HIP_TRY(hipMalloc(&sc.d_max, (size_t)((n + 255) / 256 + kMaxParts) * sizeof(double)));
     HIP_TRY(hipMalloc(&sc.d_w, (size_t)n * sizeof(int64_t)));
     HIP_TRY(hipMalloc(&sc.d_cdf, (size_t)n * sizeof(int64_t)));
     HIP_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, sc.tmpBytes, sc.d_w, sc.d_cdf, (int)n, stream));
     HIP_TRY(hipMalloc(&sc.d_tmp, sc.tmpBytes));
     sc.cap = n;
   }
+  return SIPNET_OK;
+}
+
+// partsGiven > 0: the partial maxima of d_logw are in the scratch block already (logWeights put them there)
+static int ancestorsImpl(const double* d_logw, int64_t n, double u0, int32_t* d_ancestors, int64_t* d_fixed_weights,
+                         int64_t* d_total, int partsGiven, void* hip_stream) {
+  if (!d_logw || !d_ancestors || n <= 0 || n > (int64_t)1 << 22 || !(u0 >= 0.0) || !(u0 < 1.0)) {
+    setError("sipnet_pf_systematic_ancestors: bad argument (n <= 4194304, 0 <= u0 < 1)");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  hipStream_t stream = (hipStream_t)hip_stream;
+  int rc = pfScratchFor(n, stream);
+  if (rc) return rc;
+  PfScratch& sc = g_pf;
   const int grid = (int)((n + 255) / 256);
-  const int parts = grid < kMaxParts ? grid : kMaxParts;
-  hipLaunchKernelGGL(maxPartialKernel, dim3(parts), dim3(256), 0, stream, d_logw, n, sc.d_max);
-  hipLaunchKernelGGL(maxPartialKernel, dim3(1), dim3(256), 0, stream, sc.d_max, (int64_t)parts,
-                     sc.d_max + kMaxParts);
-  hipLaunchKernelGGL(fixedWeightKernel, dim3(grid), dim3(256), 0, stream, d_logw, n,
-                     sc.d_max + kMaxParts, sc.d_w);
+  int parts = partsGiven;
+  if (parts <= 0) {
+    parts = grid < kMaxParts ? grid : kMaxParts;
+    hipLaunchKernelGGL(maxPartialKernel, dim3(parts), dim3(256), 0, stream, d_logw, n, sc.d_max);
+  }
+  hipLaunchKernelGGL(fixedWeightKernel, dim3(grid), dim3(256), 0, stream, d_logw, n, sc.d_max, parts, sc.d_w);
   size_t tmpBytes = sc.tmpBytes;
   HIP_TRY(hipcub::DeviceScan::InclusiveSum(sc.d_tmp, tmpBytes, sc.d_w, sc.d_cdf, (int)n, stream));
-  hipLaunchKernelGGL(ancestorKernel, dim3(grid), dim3(256), 0, stream, sc.d_cdf, n, u0, d_ancestors);
+  hipLaunchKernelGGL(ancestorKernel, dim3(grid), dim3(256), 0, stream, sc.d_cdf, n, u0, d_ancestors, d_total);
   HIP_TRY(hipGetLastError());
   if (d_fixed_weights)
     HIP_TRY(hipMemcpyAsync(d_fixed_weights, sc.d_w, (size_t)n * sizeof(int64_t),
                            hipMemcpyDeviceToDevice, stream));
-  if (d_total)
-    HIP_TRY(hipMemcpyAsync(d_total, sc.d_cdf + (n - 1), sizeof(int64_t), hipMemcpyDeviceToDevice, stream));
   return SIPNET_OK;
+}
+
+extern "C" int sipnet_pf_systematic_ancestors_async(const double* d_logw, int64_t n, double u0,
+                                                    int32_t* d_ancestors, int64_t* d_fixed_weights,
+                                                    int64_t* d_total, void* hip_stream) {
+  return ancestorsImpl(d_logw, n, u0, d_ancestors, d_fixed_weights, d_total, 0, hip_stream);
 }
 
 int sipnet_pf_systematic_ancestors(const double* d_logw, int64_t n, double u0,
@@ -618,6 +632,34 @@ int sipnet_batch_resample(sipnet_batch* b, const int32_t* d_src, const double* d
     if (flag != 0) b->genericExponents = true;  // only ever widened: plain-exponent kernels must never see a general exponent
   }
   return SIPNET_OK;
+}
+
+int sipnet_batch_pf_analysis(sipnet_batch* b, const void* d_plane, int32_t elem_is_f32, int32_t n_steps,
+                             int64_t ld, double obs, double sigma, double u0, int32_t with_params,
+                             double* d_logw, int32_t* d_ancestors, int64_t* d_total, void* hip_stream) {
+  if (!b || !d_logw || !d_ancestors) {
+    setError("sipnet_batch_pf_analysis: bad argument");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  int rc = useDevice(b);
+  if (rc) return rc;
+  rc = pfScratchFor(b->ncol, (hipStream_t)hip_stream);
+  if (rc) return rc;
+  // the log-weight kernel leaves its blocks' maxima where the resampling looks for them
+  rc = logWeights(b, d_plane, elem_is_f32, n_steps, ld, obs, sigma, d_logw, g_pf.d_max, hip_stream);
+  if (rc) return rc;
+  rc = ancestorsImpl(d_logw, b->ncol, u0, d_ancestors, nullptr, d_total, (int)((b->ncol + 255) / 256), hip_stream);
+  if (rc) return rc;
+  if (!d_total) {   // the synchronous check of sipnet_pf_systematic_ancestors
+    int64_t total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, g_pf.d_cdf + (b->ncol - 1), sizeof(int64_t), hipMemcpyDeviceToHost, (hipStream_t)hip_stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)hip_stream));
+    if (total <= 0) {
+      setError("sipnet_batch_pf_analysis: every particle has zero weight");
+      return SIPNET_ERR_BAD_PARAMETER;
+    }
+  }
+  return sipnet_batch_resample(b, d_ancestors, nullptr, 0, nullptr, with_params, hip_stream);
 }
 
 }  // extern "C"

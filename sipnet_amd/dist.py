@@ -210,11 +210,19 @@ def pf_analysis(batch, plane, obs, sigma, u0, rank=0, world=1, group=None, with_
     import torch.distributed as dist
     if collectives is None:
         collectives = world > 1
-    logw = batch.pf_log_weights(plane, obs, sigma)
-    if collectives:
-        logw = _gather0(logw, world, group).reshape(-1)
-    anc = pf_systematic_ancestors(logw, u0, total_out=total_out)
-    info = pf_resample(batch, anc, rank, world, group, with_params, collectives)
+    if not collectives and hasattr(batch, "pf_analysis_local"):
+        # every particle is here: the three steps in one library call (without `diagnostics` the ancestors
+        # returned are the batch's own buffer, overwritten by its next analysis)
+        anc, logw = batch.pf_analysis_local(plane, obs, sigma, u0, with_params, total_out)
+        if diagnostics:
+            anc, logw = anc.clone(), logw.clone()
+        info = {"sent": 0, "received": 0, "bytes_sent": 0}
+    else:
+        logw = batch.pf_log_weights(plane, obs, sigma)
+        if collectives:
+            logw = _gather0(logw, world, group).reshape(-1)
+        anc = pf_systematic_ancestors(logw, u0, total_out=total_out)
+        info = pf_resample(batch, anc, rank, world, group, with_params, collectives)
     if not diagnostics:
         return anc, info
     w = torch.exp(logw - logw.max())

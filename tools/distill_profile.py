@@ -15,8 +15,10 @@ dst = os.path.join(REPO, "profiles")
 os.makedirs(dst, exist_ok=True)
 
 def one(pattern):
+    # (gpurun MERGES a call's output into gpurun_out/: an earlier call's files, with other process ids in
+    # their names, may still be there -- take the newest)
     g = glob.glob(os.path.join(src, pattern), recursive=True)
-    return g[0] if g else None
+    return max(g, key=os.path.getmtime) if g else None
 
 out = [f"# rocprofv3 summary -- {tag}, workload {wl}", ""]
 ks = one("trace/**/*kernel_stats.csv")
