@@ -471,7 +471,9 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   // for it; such a launch is followed by the reduction passes.)
   constexpr bool Staged = NP >= 2 && !Full && !NCyc && !(NP == 4 && sizeof(R) == 8);
   constexpr int kStageR = NP == 4 ? 4 : 8;
-  __shared__ alignas(16) R stageAll[NP][3][Staged ? 2 * kStageR : 1][64];
+  // (rows kStageLpr elements longer than the 64 members: the summing lanes of neighbouring rows then hit different banks)
+  constexpr int kStageLpr = kStageR == 4 ? 4 : 2;   // lanes that share the sum of a row
+  __shared__ alignas(16) R stageAll[NP][3][Staged ? 2 * kStageR : 1][64 + kStageLpr];
   // NCyc hand-overs (doubles whatever R is).  C -> W per step: leafLitter woodLitter fineRootLoss
   // coarseRootLoss nDemand reductionNResorption leafOnN(all) leafOnN(computed switch) [rates] early in its
   // step and GPP - R_a of the step at its end (S has R_h: it forms, stores and totals NEE); S -> C per
@@ -722,68 +724,59 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
     statTile += last ? 1 : 0;
     statNext += last ? 6 : 5;
   };
-  // ---- the staged variant (two- / four-chunk layouts): a half of kStageR steps, one plane per action on
-  // three consecutive steps after the half is complete (C and W are past a step once C has posted the
-  // leaf area of the step after next).  64 / kStageR lanes per row, each sums kStageR interleaved columns;
-  // DPP permutations join the lanes of a row.
+  // ---- the staged variant (two- / four-chunk layouts): once C and W are past a half of kStageR steps (C has
+  // posted the leaf area of the step after it) the light wave sums the half's 3 x kStageR rows in ONE action:
+  // kStageLpr lanes per row (48 lanes busy), each 64 / kStageLpr interleaved columns, a DPP permutation or two
+  // to join them.  (The first version took a plane per step with 64 / kStageR lanes per row: 52 instructions
+  // per step on the four-chunk layout, where the three waves of a chunk share a SIMD; this one 22.)
   int stageBlock = 0;          // half being summed: steps [tBegin + stageBlock * kStageR, + kStageR)
-  auto stagedPlane = [&](int p, int tLimit) {
-    constexpr int kLanesPerRow = 64 / kStageR;
-    const int r = lane / kLanesPerRow, c0 = lane % kLanesPerRow;
-    const int rowIdx = ((stageBlock & 1) * kStageR + r);
+  auto stagedHalf = [&](int tLimit) {
+    constexpr int LPR = kStageLpr, NV = 64 / LPR;
+    const int row = lane / LPR, c0 = lane % LPR;           // row = plane * kStageR + step of the half
+    const bool rowOk = row < 3 * kStageR;
+    const int p = rowOk ? row / kStageR : 0, r = row % kStageR;
+    const int rowIdx = (stageBlock & 1) * kStageR + r;
     const R* src = &stage[p][rowIdx][c0];
     double s1 = 0.0, s2 = 0.0;
-    if (sizeof(R) == 8) {
-      double v0, v1, v2, v3, v4, v5, v6, v7;
-      // (kStageR == 8: eight doubles, columns c0 + 8 i)
-      asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:64\n\tds_read_b64 %2, %8 offset:128\n\t"
-                   "ds_read_b64 %3, %8 offset:192\n\tds_read_b64 %4, %8 offset:256\n\tds_read_b64 %5, %8 offset:320\n\t"
-                   "ds_read_b64 %6, %8 offset:384\n\tds_read_b64 %7, %8 offset:448\n\ts_waitcnt lgkmcnt(0)"
-                   : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(v4), "=&v"(v5), "=&v"(v6), "=&v"(v7)
-                   : "v"(ldsAddr(src)) : "memory");
-      const double v[8] = {v0, v1, v2, v3, v4, v5, v6, v7};
-#pragma unroll
-      for (int i = 0; i < 8; i++) {
-        s1 += v[i];
-        s2 = __builtin_fma(v[i], v[i], s2);
-      }
-    } else if (kStageR == 8) {
-      float v0, v1, v2, v3, v4, v5, v6, v7;
-      asm volatile("ds_read_b32 %0, %8\n\tds_read_b32 %1, %8 offset:32\n\tds_read_b32 %2, %8 offset:64\n\t"
-                   "ds_read_b32 %3, %8 offset:96\n\tds_read_b32 %4, %8 offset:128\n\tds_read_b32 %5, %8 offset:160\n\t"
-                   "ds_read_b32 %6, %8 offset:192\n\tds_read_b32 %7, %8 offset:224\n\ts_waitcnt lgkmcnt(0)"
-                   : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(v4), "=&v"(v5), "=&v"(v6), "=&v"(v7)
-                   : "v"(ldsAddr(src)) : "memory");
-      const float v[8] = {v0, v1, v2, v3, v4, v5, v6, v7};
-#pragma unroll
-      for (int i = 0; i < 8; i++) {
-        const double x = (double)v[i];
+    if (__builtin_expect((chunk << 6) + 64 > a.n_members, 0)) {
+      // (rare: the ragged last chunk) columns past the site's last member hold copies of that member
+      // (clamped lanes) and are not part of the sums: element by element, with the mask
+      for (int i = 0; i < NV; i++) {
+        const int c = c0 + LPR * i;
+        const double x = ((chunk << 6) + c < a.n_members) ? (double)stage[p][rowIdx][c] : 0.0;
         s1 += x;
         s2 = __builtin_fma(x, x, s2);
       }
     } else {
-      float v0, v1, v2, v3;   // kStageR == 4: sixteen lanes per row, columns c0 + 16 i
-      asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:64\n\tds_read_b32 %2, %4 offset:128\n\t"
-                   "ds_read_b32 %3, %4 offset:192\n\ts_waitcnt lgkmcnt(0)"
-                   : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(ldsAddr(src)) : "memory");
-      const float v[4] = {v0, v1, v2, v3};
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const double x = (double)v[i];
-        s1 += x;
-        s2 = __builtin_fma(x, x, s2);
-      }
-    }
-    // columns past the site's last member hold copies of that member (clamped lanes): not part of the sums
-    if (__builtin_expect((chunk << 6) + 64 > a.n_members, 0)) {
-      // (rare: the ragged last chunk) recompute with the mask, element by element
-      s1 = 0.0;
-      s2 = 0.0;
-      for (int i = 0; i < kStageR; i++) {
-        const int c = c0 + kLanesPerRow * i;
-        const double x = ((chunk << 6) + c < a.n_members) ? (double)stage[p][rowIdx][c] : 0.0;
-        s1 += x;
-        s2 = __builtin_fma(x, x, s2);
+      for (int g = 0; g < NV; g += 8) {   // eight reads in flight; columns c0 + LPR (g + k)
+        R v0, v1, v2, v3, v4, v5, v6, v7;
+        const unsigned base = ldsAddr(src) + (unsigned)(g * LPR * sizeof(R));
+        if (sizeof(R) == 8)        // LPR == 2: 16 bytes apart
+          asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:16\n\tds_read_b64 %2, %8 offset:32\n\t"
+                       "ds_read_b64 %3, %8 offset:48\n\tds_read_b64 %4, %8 offset:64\n\tds_read_b64 %5, %8 offset:80\n\t"
+                       "ds_read_b64 %6, %8 offset:96\n\tds_read_b64 %7, %8 offset:112\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(v4), "=&v"(v5), "=&v"(v6), "=&v"(v7)
+                       : "v"(base) : "memory");
+        else if (LPR == 4)         // 16 bytes apart
+          asm volatile("ds_read_b32 %0, %8\n\tds_read_b32 %1, %8 offset:16\n\tds_read_b32 %2, %8 offset:32\n\t"
+                       "ds_read_b32 %3, %8 offset:48\n\tds_read_b32 %4, %8 offset:64\n\tds_read_b32 %5, %8 offset:80\n\t"
+                       "ds_read_b32 %6, %8 offset:96\n\tds_read_b32 %7, %8 offset:112\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(v4), "=&v"(v5), "=&v"(v6), "=&v"(v7)
+                       : "v"(base) : "memory");
+        else                       // floats, LPR == 2: 8 bytes apart
+          asm volatile("ds_read_b32 %0, %8\n\tds_read_b32 %1, %8 offset:8\n\tds_read_b32 %2, %8 offset:16\n\t"
+                       "ds_read_b32 %3, %8 offset:24\n\tds_read_b32 %4, %8 offset:32\n\tds_read_b32 %5, %8 offset:40\n\t"
+                       "ds_read_b32 %6, %8 offset:48\n\tds_read_b32 %7, %8 offset:56\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(v4), "=&v"(v5), "=&v"(v6), "=&v"(v7)
+                       : "v"(base) : "memory");
+        const R v[8] = {v0, v1, v2, v3, v4, v5, v6, v7};
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const double x = (double)v[i];
+          s1 += x;
+          s2 = __builtin_fma(x, x, s2);
+        }
       }
     }
     auto dppAdd = [](double v, auto ctrl) -> double {
@@ -792,44 +785,35 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
       return v + __hiloint2double(hi, lo);
     };
     auto rowSum = [&](double v) -> double {
-      v = dppAdd(v, std::integral_constant<int, 0xB1>{});    // quad_perm:[1,0,3,2]
-      v = dppAdd(v, std::integral_constant<int, 0x4E>{});    // quad_perm:[2,3,0,1]
-      v = dppAdd(v, std::integral_constant<int, 0x141>{});   // row_half_mirror: the other quad of the 8
-      if (kLanesPerRow == 16) v = dppAdd(v, std::integral_constant<int, 0x140>{});   // row_mirror: the other half of the 16
+      v = dppAdd(v, std::integral_constant<int, 0xB1>{});                 // quad_perm:[1,0,3,2]
+      if (LPR == 4) v = dppAdd(v, std::integral_constant<int, 0x4E>{});   // quad_perm:[2,3,0,1]
       return v;
     };
     s1 = rowSum(s1);
     s2 = rowSum(s2);
     const int t = tBegin + stageBlock * kStageR + r;
-    if (c0 == 0 && t < tLimit) {
+    if (c0 == 0 && rowOk && t < tLimit) {
       const int64_t gChunk = (int64_t)site * chunksPerSite + chunk;
       double* dst = a.statsPart + (((int64_t)p * a.statsChunks + gChunk) * a.n_steps + (t - tBegin)) * 2;
       typedef double d2s __attribute__((ext_vector_type(2)));
       *(d2s*)dst = d2s{s1, s2};
     }
   };
-  // the staged action that is due (statNext): planes 0, 1, 2 of a half on three consecutive steps
+  // the staged action that is due (statNext): the half C and W have just left.  They cannot come back to its
+  // rows before this wave has posted the factors of the step after next.
   auto stagedAct = [&]() {
     const int blockEnd = tBegin + (stageBlock + 1) * kStageR;
-    if (statPlane == 0) awaitAtLeast(&seqLai, blockEnd + 1);
-    // W's planes (GPP, ET) first, C's (NEE) last: at night W may store the first step of the half after
-    // next -- the same rows -- as soon as C has posted that step's leaf area, which C can do once this wave
-    // has posted the factors of the step before, i.e. while this wave is on the LAST of its three turns;
-    // C itself needs this wave's next factors before it gets there
-    stagedPlane(statPlane == 0 ? 1 : statPlane == 1 ? 2 : 0, tEnd);
-    const bool last = statPlane == 2;
-    statPlane = last ? 0 : statPlane + 1;
-    stageBlock += last ? 1 : 0;
-    statNext = last ? (tBegin + (stageBlock + 1) * kStageR + 1) : statNext + 1;
+    awaitAtLeast(&seqLai, blockEnd + 1);
+    stagedHalf(tEnd);
+    stageBlock++;
+    statNext = tBegin + (stageBlock + 1) * kStageR + 1;
   };
   auto stagedFinish = [&]() {  // after the loop: what is left, once C and W have finished
     awaitAtLeast(&seqDone[0], 1);
     awaitAtLeast(&seqDone[1], 1);
     while (tBegin + stageBlock * kStageR < tEnd) {
-      stagedPlane(statPlane == 0 ? 1 : statPlane == 1 ? 2 : 0, tEnd);
-      const bool last = statPlane == 2;
-      statPlane = last ? 0 : statPlane + 1;
-      stageBlock += last ? 1 : 0;
+      stagedHalf(tEnd);
+      stageBlock++;
     }
   };
   if (Staged) statNext = tBegin + kStageR + 1;

@@ -1282,7 +1282,18 @@ __global__ __launch_bounds__(256) void finishStatsKernel(const double* __restric
   const d2* __restrict__ src =
       reinterpret_cast<const d2*>(part) + ((int64_t)p * n_sites + site) * chunksPerSite * n_steps + t;
   double s1 = 0.0, s2 = 0.0;
-  for (int c = 0; c < chunksPerSite; c++) {
+  int c = 0;
+  for (; c + 8 <= chunksPerSite; c += 8) {   // eight loads in flight, added in chunk order (1 024 chunks at C3:
+    d2 v[8];                                 // one dependent load at a time took 0.5 ms)
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = src[(int64_t)(c + k) * n_steps];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      s1 += v[k].x;
+      s2 += v[k].y;
+    }
+  }
+  for (; c < chunksPerSite; c++) {
     const d2 v = src[(int64_t)c * n_steps];
     s1 += v.x;
     s2 += v.y;
