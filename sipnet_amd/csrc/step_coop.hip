@@ -423,9 +423,12 @@ __device__ unsigned long long g_coopWaits[16];
 // and the optional per-member diagnostics (clamp and carbon-balance warnings; default flags have no
 // nitrogen balance).  Same flux arithmetic and hand-overs as the lean variant.
 // NP = 2 (stepCoopPairKernel): one workgroup of eight wavefronts carries TWO chunks (ring in HBM).
-// Waves go to the CU's four SIMDs round-robin, so with the roles laid out as  C0 C1 W0 W1 -- -- L0 L1
-// (waves 4 and 5 leave at once) each carbon wave has a SIMD to itself and a chunk's water and light
-// waves -- busy at different times of a step -- share one, whatever SIMD the workgroup starts on.
+// Waves go to the CU's four SIMDs round-robin, so with the roles laid out as  C0 C1 W0 W1 | L1 L0 F0 F1
+// a carbon wave shares its SIMD with the OTHER chunk's light wave (idle at night, when the carbon wave is
+// the step; by day neither waits for the other) and a water wave with its chunk's factor wave, whatever
+// SIMD the workgroup starts on.  (Round 2's layout C0 C1 W0 W1 -- -- L0 L1 kept the carbon waves alone and
+// put a chunk's water and light waves -- factors included -- on one SIMD: 1 741 cycles per day step
+// against 1 185 by night; this one 1 426 / 1 260, c4 10.5 -> 9.6 ms.)
 // Two separate three-wave workgroups on a CU put the second one's water wave on the first one's
 // carbon SIMD (tools/coop_placement.py), which costs the carbon wave a third of its issue rate.
 // NP = 4 (stepCoopQuadKernel): twelve wavefronts carry FOUR chunks, C0..C3 W0..W3 L0..L3: every SIMD
@@ -451,7 +454,14 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
 #ifdef SIPNET_NO_FACWAVE
   constexpr bool FacWave = false;
 #else
+#ifdef SIPNET_PAIR_NO_FACWAVE
   constexpr bool FacWave = RingLds;   // (NCyc: the fourth wavefront is the soil wave S; the factors stay with L)
+#else
+  // two chunks per workgroup: the two spare wavefronts of the eight are the chunks' factor waves, and the
+  // layout is  C0 C1 W0 W1 | L1 L0 F0 F1 : a carbon wave shares its SIMD with the OTHER chunk's light wave
+  // (idle at night, when the carbon wave is the step), a water wave with its chunk's factor wave
+  constexpr bool FacWave = RingLds || Pair;
+#endif
 #endif
   // per-wave private record tiles (each wave stages and awaits its own DMA) + mailboxes
   __shared__ alignas(16) unsigned char ldsTilesAll[NP][NCyc ? 4 : 3][2 * kTileBytes];
@@ -502,8 +512,13 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   const int wave = uni((int)threadIdx.x >> 6);
   // 0 carbon, 1 water, 2 light; -1: a placeholder wave that only keeps the SIMD rotation
   // which of the workgroup's chunks; NP == 4: C0..C3 W0..W3 L0..L3, a chunk's three waves on one SIMD
+#ifdef SIPNET_PAIR_NO_FACWAVE
   const int sub = Pair ? (wave & 1) : NP == 4 ? (wave & 3) : 0;
   const int role = Pair ? ((wave >> 1) == 3 ? 2 : (wave >> 1) == 2 ? -1 : (wave >> 1)) : NP == 4 ? (wave >> 2) : wave;
+#else
+  const int sub = Pair ? ((wave >> 1) == 2 ? ((wave & 1) ^ 1) : (wave & 1)) : NP == 4 ? (wave & 3) : 0;
+  const int role = Pair ? (wave >> 1) : NP == 4 ? (wave >> 2) : wave;
+#endif
   const int lane = (int)threadIdx.x & 63;
   auto& mailLai = mailLaiAll[sub];
   auto& mailPgp = mailPgpAll[sub];
@@ -875,7 +890,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         // the slot of step t was last used for step t-2, which C is past once it has posted the
         // leaf area of step t-1
         awaitAtLeast(&seqLai, t - 1);
-        if (statsHere && t == statNext) statAct(false);
+        if (!Staged && statsHere && t == statNext) statAct(false);
         const R vegQ = fexp2(q10Arg(tair10, K_lgVeg), EC);
         R g1 = K_fol * vegQ;
         g1 = (tsoil < K_frozThr) ? g1 * K_frozFolEff : g1;
@@ -892,7 +907,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
       }
       cur = nxt;
     }
-    if (statsHere) statFinish();
+    if (!Staged && statsHere) statFinish();
     return;
   }
   auto tileFirst = [&](int tile) -> int64_t {
@@ -1241,9 +1256,11 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
           const R qSoilT = K_bsr * qSoil * (R)q3.x;
           if (NCyc) postRaw(&mailFac[t & 1][6][lane], qSoil);   // before the flag post5 sets
           post5(&mailFac[t & 1][0][lane], &seqFac, g1, g2, qSoilT, gFine, gCoarse, t);
-          // (staged statistics: after the post, so that C has what it waits for; a third of a half per step)
-          if (Staged && stageOn && t == statNext) stagedAct();
         }
+        // (staged statistics: after the factor post, so that C has what it waits for.  C and W cannot be back
+        // at the half's rows before this wave is done with them: they are kStageR - 1 steps away from it when
+        // the action starts, and by day they need this wave's potential photosynthesis to go on)
+        if (Staged && stageOn && t == statNext) stagedAct();
         if (!(bits & FAST_PAR_POS)) continue;  // night: potGrossPsn = 0, nobody waits for it
         {
         const R tair = (R)q1.x;

@@ -2,7 +2,7 @@
 """dev (GPU box): c10k with the synthetic year's light forced to polar night / midnight sun, to
 read off what a night step and a day step of the cooperative kernel cost (the day step carries the
 leaf-area -> potential-photosynthesis -> photosynthesis chain through all three wavefronts).
-usage: [SIPNET_LIB=build/variants/<name>/libsipnet_amd.so] day_night_time.py [kernel: auto|coop_lds|one_wave]"""
+usage: [SIPNET_LIB=build/variants/<name>/libsipnet_amd.so] [M=members] day_night_time.py [kernel: auto|coop_lds|coop_hbm|coop_pair|coop_quad|one_wave]"""
 import os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
@@ -13,10 +13,11 @@ import numpy as np, torch
 import sipnet_amd as sa
 from sipnet_amd import synth
 
-kern = dict(auto=sa.KERNEL_AUTO, coop_lds=sa.KERNEL_COOP_LDS, one_wave=sa.KERNEL_ONE_WAVE)[sys.argv[1] if len(sys.argv) > 1 else "auto"]
+kern = dict(auto=sa.KERNEL_AUTO, coop_lds=sa.KERNEL_COOP_LDS, coop_hbm=sa.KERNEL_COOP_HBM, coop_pair=sa.KERNEL_COOP_PAIR,
+            coop_quad=sa.KERNEL_COOP_QUAD, one_wave=sa.KERNEL_ONE_WAVE)[sys.argv[1] if len(sys.argv) > 1 else "auto"]
 flags = sa.flags_from()
 base, _ = sa.read_params(os.path.join(REPO, "sipnet_amd", "data", "base_forest.param"), flags)
-M, T = 10240, 17520
+M, T = int(os.environ.get("M", "10240")), 17520
 members = synth.perturbed_params(base, M)
 for name in ("as is", "night", "day"):
     raw = synth.half_hourly_year_raw(T)
