@@ -214,12 +214,16 @@ enum sipnet_math { SIPNET_MATH_STRICT = 0, SIPNET_MATH_FAST = 1 };
 int sipnet_batch_set_math(sipnet_batch *b, int32_t policy);
 
 /* Which step kernel sipnet_batch_run launches.  AUTO (the default) picks by batch shape: with
- * SIPNET_MATH_FAST and the default model flags the three-wavefront cooperative kernel while there
- * are at most four 64-member chunks per compute unit (up to one chunk per CU: one three-wave
+ * SIPNET_MATH_FAST and the default model flags the cooperative kernel while there
+ * are at most four 64-member chunks per compute unit (up to one chunk per CU: one four-wave
  * workgroup per chunk, running-mean ring in LDS; up to two: one eight-wave workgroup per TWO
  * chunks, rings in HBM; up to four, lean state only: one twelve-wave workgroup per FOUR chunks),
- * the one-wavefront throughput kernel for bigger batches, full records there, and optional model
- * flags; with SIPNET_MATH_STRICT the strict-order kernel.  The other values force one kernel
+ * with the nitrogen-cycle flag set (litter pool + anaerobic + nitrogen cycle) its own cooperative kernel
+ * up to one chunk per CU, the one-wavefront throughput kernel for bigger batches, full records there,
+ * and the other optional model flags; with SIPNET_MATH_STRICT the strict-order kernel.  "Default model
+ * flags" here means the physics: events, gdd and soil_phenol may have any legal value (no events; leaf-on
+ * by growing degree days, soil temperature or day of year -- russell_4's set) -- they change what the
+ * site plan puts into the step records, not the kernels.  The other values force one kernel
  * (tests and measurements compare every instantiation with the oracle this way); a forced kernel
  * that cannot run the batch (throughput kernels under SIPNET_MATH_STRICT, cooperative kernels with
  * optional model flags) makes sipnet_batch_run return
@@ -233,8 +237,8 @@ enum sipnet_kernel {
   SIPNET_KERNEL_COOP_PAIR = 5, /* stepCoopPairKernel: two chunks per workgroup, ring in HBM */
   SIPNET_KERNEL_COOP_QUAD = 6, /* stepCoopQuadKernel: four chunks per twelve-wave workgroup */
   SIPNET_KERNEL_COOP_NCYCLE = 7 /* stepCoopNKernel: the nitrogen-cycle flag set (litter pool + anaerobic +
-                                   nitrogen cycle), four wavefronts per chunk, soil and nitrogen on the
-                                   water wave */
+                                   nitrogen cycle), four wavefronts per chunk, soil and nitrogen on a
+                                   wavefront of their own */
 };
 enum sipnet_kernel_option {
   SIPNET_KOPT_ONE_WAVE_PER_SIMD = 1, /* one-wave kernel: never the 256-VGPR (two waves/SIMD) build */

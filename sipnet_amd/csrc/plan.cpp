@@ -63,7 +63,9 @@ int32_t RingSched::advance(int32_t step, double weight, std::vector<RingOp>* ops
 namespace {
 // the fast record of one step from its StepRec and its ring evictions (slots of the NEXT step and
 // the tile summary are patched in by the caller once they are known)
-void fillFastRec(const StepRec& s, const RingOp* ops, bool tsoilSame, FastRec& f, int& slot0, int& slot1) {
+// phenMode: what the leaf-on test compares with its threshold (sipnet.c:705-731) -- 0 the year-to-date GDD,
+// 1 the soil temperature (soil-phenology flag), 2 the day of year (both flags off)
+void fillFastRec(const StepRec& s, const RingOp* ops, bool tsoilSame, int phenMode, FastRec& f, int& slot0, int& slot1) {
   f = FastRec{};
   f.len = s.length;
   f.invLen = s.invLen;
@@ -77,7 +79,7 @@ void fillFastRec(const StepRec& s, const RingOp* ops, bool tsoilSame, FastRec& f
   f.invWspd = s.invWspd;
   f.tair10 = s.tair10;
   f.tsoil10 = s.tsoil10;
-  f.cumGdd = s.cumGdd;
+  f.cumGdd = phenMode == 0 ? s.cumGdd : phenMode == 1 ? s.tsoil : s.dayTime;
   f.dayTime = s.dayTime;
   f.log2vpd = s.log2vpd;
   f.tillP1 = 1.0 + s.dTill;
@@ -125,8 +127,8 @@ void summariseTile(FastRec* out, int b, int e, const int* slot0, const int* slot
                   f.insSlot != next(out[t - 1].insSlot)))
       regular = false;
   }
-  // what the regular path compares with the members' phenology thresholds: the LARGEST year-to-date
-  // GDD and day of year of the tile (inside a tile without a year roll-over both normally only grow,
+  // what the regular path compares with the members' phenology thresholds: the LARGEST leaf-on variable
+  // (year-to-date GDD; soil temperature or day of year with the GDD flag off) and day of year of the tile (inside a tile without a year roll-over both normally only grow,
   // but a forcing file with misordered or duplicated records may step back: the maximum, not the
   // last record's value, proves that no switch can fire anywhere in the tile)
   double maxGdd = out[b].cumGdd, maxDay = out[b].dayTime;
@@ -314,7 +316,8 @@ SitePlan buildSitePlan(const int32_t* flags, int32_t n_steps, const double* clim
     if (stepsOut) stepsOut[t] = s;
     if (fastOut) {
       int s0, s1;
-      fillFastRec(s, plan.ringOps.data() + s.ringOpFirst, t > 0 && prevTsoil10 == s.tsoil10, fastOut[t], s0, s1);
+      fillFastRec(s, plan.ringOps.data() + s.ringOpFirst, t > 0 && prevTsoil10 == s.tsoil10,
+                  flags[SIPNET_F_GDD] ? 0 : flags[SIPNET_F_SOIL_PHENOL] ? 1 : 2, fastOut[t], s0, s1);
       // eviction slots: this step's, and (in the record of the step before) the next step's
       fastOut[t].slots = s0 | (s1 << 8) | (s0 << 16) | (s1 << 24);
       if (t > 0) fastOut[t - 1].slots = (fastOut[t - 1].slots & 0xffff) | (s0 << 16) | (s1 << 24);

@@ -78,7 +78,8 @@ struct FastRec {
   double len, invLen, tair, tsoil;           //  0.. 3
   double negPar, vpd, tillP1, rainRate;      //  4.. 7  -par, vpd, 1 + d_till_mod, precip/len
   double sublW, evapNum, invWspd, tair10;    //  8..11  CONV_S*(0.6-vPress)*wspd, CONV*vpdSoil, 1/wspd
-  double tsoil10, cumGdd, dayTime, w0;       // 12..15  w0: weight of the first ring eviction
+  double tsoil10, cumGdd, dayTime, w0;       // 12..15  cumGdd: the leaf-on variable (year-to-date GDD; soil temperature
+                                             //         or day of year by flag); w0: weight of the first ring eviction
   int32_t bitsOps;   // FAST_* flag bits | (number of ring evictions << 16)
   int32_t slots;     // slot0 | slot1<<8 | pfSlot0<<16 | pfSlot1<<24 (slots < 250)
   int32_t insSlot;   // slot of this step's insert, -1 = reset ring to the new value

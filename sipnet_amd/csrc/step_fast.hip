@@ -90,9 +90,8 @@ struct FastFlags {
 };
 bool isNCycleFlagSet(const int32_t* f) {
   for (int i = 0; i < SIPNET_NFLAGS; i++) {
-    if (i == SIPNET_F_SNOW) continue;  // snow only gates a parameter's required-ness
-    const bool want = i == SIPNET_F_EVENTS || i == SIPNET_F_GDD || i == SIPNET_F_WATER_HRESP ||
-                      i == SIPNET_F_LITTER_POOL || i == SIPNET_F_NITROGEN_CYCLE ||
+    if (i == SIPNET_F_SNOW || isPhenologyOrEventsFlag(i)) continue;  // (data, not code: see isDefaultFlagSet)
+    const bool want = i == SIPNET_F_WATER_HRESP || i == SIPNET_F_LITTER_POOL || i == SIPNET_F_NITROGEN_CYCLE ||
                       i == SIPNET_F_ANAEROBIC;
     if ((f[i] != 0) != want) return false;
   }
@@ -182,9 +181,13 @@ void stepFastKernel(FastArgs a) {
   const R K_moistExp = (R)PRM(soilRespMoistEffect);
   // leaf-on test "x >= threshold" (sipnet.c:705-731): x is the year-to-date GDD, the soil
   // temperature or the day of year, by flag; a non-positive leafOnDay never fires
-  const double gddLeafOn = !Generic || F.gdd ? PRM(gddLeafOn)
-                           : F.soilPhenol    ? PRM(soilTempLeafOn)
-                                             : (PRM(leafOnDay) > 0 ? PRM(leafOnDay) : 1e300);
+  // (the compiled-in flag sets leave the phenology mode to the launch: the plan puts the matching variable
+  // into the record's cumGdd field)
+  const bool fGdd = Mode == kFlagsRuntime ? F.gdd : a.flags[SIPNET_F_GDD] != 0;
+  const bool fSoilPhenol = Mode == kFlagsRuntime ? F.soilPhenol : a.flags[SIPNET_F_SOIL_PHENOL] != 0;
+  const double gddLeafOn = fGdd          ? PRM(gddLeafOn)
+                           : fSoilPhenol ? PRM(soilTempLeafOn)
+                                         : (PRM(leafOnDay) > 0 ? PRM(leafOnDay) : 1e300);
   // Optional-flag parameters (Generic only; dead code otherwise).  A taken branch costs a lone
   // wavefront an instruction-fetch restart, so the small options are not branched around: with
   // the flag off their parameter takes a neutral value (rate 0, cap "infinite") and the same
@@ -481,7 +484,7 @@ void stepFastKernel(FastArgs a) {
     // the events in the one rare block below
     R leafOnCreation = 0, leafOnFromWood = 0;
     if (bits & FAST_PHEN_NEW_YEAR) phenBits = 0;
-    const double phenX = (!Generic || F.gdd) ? q6.y : (F.soilPhenol ? q1.y : q7.x);
+    const double phenX = q6.y;   // year-to-date GDD, soil temperature or day of year: the plan's choice by flag
     const bool doOn = !(phenBits & 1) && phenX >= gddLeafOn;
     const bool doOff = !(phenBits & 2) && q7.x >= leafOffDay;
 

@@ -1336,7 +1336,17 @@ static bool isDefaultFlags(const int32_t* f) {
   return true;
 }
 
-bool isDefaultFlagSet(const int32_t* f) { return isDefaultFlags(f); }
+// For the throughput kernels with the default flag set compiled in, three flags are DATA, not code: events
+// (no events, no event records), and the phenology pair gdd / soil_phenol (the plan puts the leaf-on variable
+// the flags ask for into the record, the kernel picks the matching threshold at launch).
+bool isPhenologyOrEventsFlag(int i) { return i == SIPNET_F_EVENTS || i == SIPNET_F_GDD || i == SIPNET_F_SOIL_PHENOL; }
+bool isDefaultFlagSet(const int32_t* f) {
+  for (int i = 0; i < SIPNET_NFLAGS; i++) {
+    if (i == SIPNET_F_SNOW || isPhenologyOrEventsFlag(i)) continue;  // (snow only gates a parameter's required-ness)
+    if ((f[i] != 0) != defaultFlag(i)) return false;
+  }
+  return true;
+}
 
 void launchStep(const KernelArgs& a, int precision, bool fastMath, hipStream_t stream, LaunchInfo* info) {
   const bool generic = !isDefaultFlags(a.flags);

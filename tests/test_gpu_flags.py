@@ -160,6 +160,51 @@ def test_each_flag_set_matches_oracle(name, oracle, clim60, members70):
     compare(name, got, state, want, final)
 
 
+PHENOLOGY_MODES = {"gdd": dict(), "soil_phenol": dict(gdd=0, soilPhenol=1), "calendar": dict(gdd=0),
+                   "russell_4": dict(events=0, gdd=0, soilPhenol=1)}
+
+
+@pytest.mark.parametrize("mode", list(PHENOLOGY_MODES))
+def test_phenology_mode_and_events_are_data_for_the_compiled_in_flag_sets(mode, oracle, clim60, members70):
+    """events / gdd / soil_phenol do not change the code of the throughput kernels: the plan puts the leaf-on
+    variable the flags ask for into the record, the kernel picks the matching threshold -- so these flag
+    sets (russell_4's among them) take the cooperative kernels, every layout of them, the one-wave kernel's
+    default-flag build and the nitrogen-cycle kernel, against the oracle"""
+    def run(flags, kernel, ev):
+        b = sa.Batch(flags, 1, members70.shape[0], sa.F64, fast_math=True, kernel=kernel)
+        if ev is not None:
+            b.set_events(0, ev)
+        b.set_climate(0, clim60)
+        b.set_params(0, members70)
+        b.setup()
+        planes, _ = b.run()
+        out = planes.cpu().numpy(), b.get_state(), b.last_launch()["kernel"]
+        assert (np.asarray(b.get_status()) == 0).all()
+        b.close()
+        return out
+    flags = _flags(**PHENOLOGY_MODES[mode])
+    ev = _events_all_types(clim60) if flags[F_EVENTS] else None
+    want, final, st = oracle.run_block(flags, members70, clim60, ev)
+    assert (st == 0).all()
+    got = {}
+    # (members70's dVpdExp is not 2: the general-exponent builds)
+    for kernel, expect in ((sa.KERNEL_AUTO, "stepCoopKernel<double, false, true, false>"),
+                           (sa.KERNEL_COOP_PAIR, "stepCoopPairKernel<double, false, false>"),
+                           (sa.KERNEL_COOP_QUAD, "stepCoopQuadKernel<double, false>"),
+                           (sa.KERNEL_ONE_WAVE, "stepFastKernel<double, false, 0, 1, false>")):
+        planes, state, name = run(flags, kernel, ev)
+        assert name == expect, name
+        compare(f"{mode} {name}", planes, state, want, final)
+        got[kernel] = planes
+    np.testing.assert_array_equal(got[sa.KERNEL_AUTO], got[sa.KERNEL_COOP_PAIR])
+    np.testing.assert_array_equal(got[sa.KERNEL_AUTO], got[sa.KERNEL_COOP_QUAD])
+    nflags = _flags(litterPool=1, anaerobic=1, nitrogenCycle=1, **PHENOLOGY_MODES[mode])
+    want, final, st = oracle.run_block(nflags, members70, clim60, ev)
+    planes, state, name = run(nflags, sa.KERNEL_AUTO, ev)
+    assert name.startswith("stepCoopNKernel<double"), name
+    compare(f"{mode} {name}", planes, state, want, final)
+
+
 def test_generic_throughput_kernel_agrees_with_strict_kernel(clim60, members70):
     flags = _flags(**FLAG_SETS["everything"])
     ev = _events_all_types(clim60)
