@@ -474,7 +474,8 @@ int sipnet_batch_set_params(sipnet_batch* b, int32_t site, int32_t first_member,
                     hipMemcpyHostToDevice));
   // the parameter half of setupModel() (sipnet.c:1873-1916): from here on the converted block is
   // the only copy of the members' parameters on the device
-  launchConvertParams(b->d_rawStage, b->d_prm, b->ncol, col0, count, nullptr);
+  launchConvertParams(b->d_rawStage, b->d_prm, b->ncol, col0, count,
+                      b->flags[SIPNET_F_GDD] ? 0 : b->flags[SIPNET_F_SOIL_PHENOL] ? 1 : 2, nullptr);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(nullptr));
   return SIPNET_OK;

@@ -1531,11 +1531,11 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   const R K_frt = (R)PRM(fineRootTurnoverRate), K_crt = (R)PRM(coarseRootTurnoverRate);
   const R K_la = (R)PRM(leafAllocation), K_wa = (R)PRM(woodAllocation);
   const R K_fa = (R)PRM(fineRootAllocation), K_ca = (R)PRM(coarseRootAllocation);
-  // leaf-on threshold of the variable the plan put into the record (year-to-date GDD / soil temperature / day of
-  // year, by flag: sipnet.c:705-731; a non-positive leafOnDay never fires)
-  const double gddLeafOn = a.flags[SIPNET_F_GDD]           ? PRM(gddLeafOn)
-                           : a.flags[SIPNET_F_SOIL_PHENOL] ? PRM(soilTempLeafOn)
-                                                           : (PRM(leafOnDay) > 0 ? PRM(leafOnDay) : 1e300);
+  // leaf-on threshold of the variable the plan put into the record: year-to-date GDD -- or, with the gdd flag
+  // off, soil temperature / day of year, whose threshold convertParamsKernel has then put into this row
+  // (choosing among the three parameters here, by flag or by a row index from the host, cost the
+  // one-chunk kernel 0.6 - 3 %: register allocation, not work)
+  const double gddLeafOn = PRM(gddLeafOn);
   const double leafOffDay = PRM(leafOffDay) > 0 ? PRM(leafOffDay) : 1e300;
 
   // NCyc: reciprocal C:N ratios for the plants' nitrogen demand (nitrogen.c:89-104) and the test both

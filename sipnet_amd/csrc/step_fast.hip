@@ -183,11 +183,8 @@ void stepFastKernel(FastArgs a) {
   // temperature or the day of year, by flag; a non-positive leafOnDay never fires
   // (the compiled-in flag sets leave the phenology mode to the launch: the plan puts the matching variable
   // into the record's cumGdd field)
-  const bool fGdd = Mode == kFlagsRuntime ? F.gdd : a.flags[SIPNET_F_GDD] != 0;
-  const bool fSoilPhenol = Mode == kFlagsRuntime ? F.soilPhenol : a.flags[SIPNET_F_SOIL_PHENOL] != 0;
-  const double gddLeafOn = fGdd          ? PRM(gddLeafOn)
-                           : fSoilPhenol ? PRM(soilTempLeafOn)
-                                         : (PRM(leafOnDay) > 0 ? PRM(leafOnDay) : 1e300);
+  // (with the gdd flag off convertParamsKernel has put the soil-temperature / day-of-year threshold into this row)
+  const double gddLeafOn = PRM(gddLeafOn);
   // Optional-flag parameters (Generic only; dead code otherwise).  A taken branch costs a lone
   // wavefront an instruction-fetch restart, so the small options are not branched around: with
   // the flag off their parameter takes a neutral value (rate 0, cap "infinite") and the same
