@@ -221,9 +221,10 @@ int sipnet_batch_set_math(sipnet_batch *b, int32_t policy);
  * with the nitrogen-cycle flag set (litter pool + anaerobic + nitrogen cycle) its own cooperative kernel
  * up to one chunk per CU, the one-wavefront throughput kernel for bigger batches, full records there,
  * and the other optional model flags; with SIPNET_MATH_STRICT the strict-order kernel.  "Default model
- * flags" here means the physics: events, gdd and soil_phenol may have any legal value (no events; leaf-on
- * by growing degree days, soil temperature or day of year -- russell_4's set) -- they change what the
- * site plan puts into the step records, not the kernels.  The other values force one kernel
+ * flags" here means the physics: events, gdd, soil_phenol and water_hresp may have any legal value (no
+ * events; leaf-on by growing degree days, soil temperature or day of year -- russell_4's set; no moisture
+ * effect on heterotrophic respiration) -- they change what the site plan puts into the step records, not
+ * the kernels.  The other values force one kernel
  * (tests and measurements compare every instantiation with the oracle this way); a forced kernel
  * that cannot run the batch (throughput kernels under SIPNET_MATH_STRICT, cooperative kernels with
  * optional model flags) makes sipnet_batch_run return

@@ -65,7 +65,10 @@ namespace {
 // the tile summary are patched in by the caller once they are known)
 // phenMode: what the leaf-on test compares with its threshold (sipnet.c:705-731) -- 0 the year-to-date GDD,
 // 1 the soil temperature (soil-phenology flag), 2 the day of year (both flags off)
-void fillFastRec(const StepRec& s, const RingOp* ops, bool tsoilSame, int phenMode, FastRec& f, int& slot0, int& slot1) {
+// moistHResp: the water_hresp flag; off = heterotrophic respiration never sees the soil moisture (depeffects.c:23-57),
+// which is what the kernels do on a step with frozen soil: the same bit says both
+void fillFastRec(const StepRec& s, const RingOp* ops, bool tsoilSame, int phenMode, bool moistHResp, FastRec& f, int& slot0,
+                 int& slot1) {
   f = FastRec{};
   f.len = s.length;
   f.invLen = s.invLen;
@@ -96,7 +99,7 @@ void fillFastRec(const StepRec& s, const RingOp* ops, bool tsoilSame, int phenMo
   const int bits = (s.bits & STEP_PHEN_NEW_YEAR ? FAST_PHEN_NEW_YEAR : 0) |
                    (s.bits & STEP_TRACK_NEW_YEAR ? FAST_TRACK_NEW_YEAR : 0) |
                    (s.tair > 0 ? FAST_TAIR_POS : 0) | (s.par > 0 ? FAST_PAR_POS : 0) |
-                   (s.tsoil < 0 ? FAST_TSOIL_NEG : 0) | (f.w1 != 0.0 ? FAST_HAS_W1 : 0) |
+                   ((s.tsoil < 0 || !moistHResp) ? FAST_TSOIL_NEG : 0) | (f.w1 != 0.0 ? FAST_HAS_W1 : 0) |
                    (s.dTill != 0.0 ? FAST_HAS_TILL : 0) | (tsoilSame ? FAST_TSOIL_SAME : 0) |
                    (s.ringOpCount == 1 && s.ringInsSlot >= 0 ? FAST_RING_REGULAR : 0);
   f.bitsOps = bits | (s.ringOpCount << 16);
@@ -317,7 +320,8 @@ SitePlan buildSitePlan(const int32_t* flags, int32_t n_steps, const double* clim
     if (fastOut) {
       int s0, s1;
       fillFastRec(s, plan.ringOps.data() + s.ringOpFirst, t > 0 && prevTsoil10 == s.tsoil10,
-                  flags[SIPNET_F_GDD] ? 0 : flags[SIPNET_F_SOIL_PHENOL] ? 1 : 2, fastOut[t], s0, s1);
+                  flags[SIPNET_F_GDD] ? 0 : flags[SIPNET_F_SOIL_PHENOL] ? 1 : 2, flags[SIPNET_F_WATER_HRESP] != 0, fastOut[t],
+                  s0, s1);
       // eviction slots: this step's, and (in the record of the step before) the next step's
       fastOut[t].slots = s0 | (s1 << 8) | (s0 << 16) | (s1 << 24);
       if (t > 0) fastOut[t - 1].slots = (fastOut[t - 1].slots & 0xffff) | (s0 << 16) | (s1 << 24);

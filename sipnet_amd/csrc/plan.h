@@ -114,7 +114,7 @@ enum : int32_t {
   FAST_PHEN_NEW_YEAR = 1, FAST_TRACK_NEW_YEAR = 2,
   FAST_TAIR_POS = 4,     // tair > 0
   FAST_PAR_POS = 8,      // par > 0
-  FAST_TSOIL_NEG = 16,   // tsoil < 0
+  FAST_TSOIL_NEG = 16,   // tsoil < 0 -- or the water_hresp flag is off: no moisture effect on heterotrophic respiration
   FAST_HAS_W1 = 32,      // a second eviction with non-zero weight
   FAST_HAS_TILL = 64,    // tillage modifier in effect
   FAST_TSOIL_SAME = 128, // tsoil identical to the previous record: Q10 factors can be reused

@@ -509,7 +509,7 @@ void stepFastKernel(FastArgs a) {
       const R anMoist = (R(1) - anoxic) * clip01(fWhc * G_iFAnox) + G_anDecomp * anoxic;
       moistEff = F.anaerobic ? anMoist : moistEff;
     }
-    moistEff = ((bits & FAST_TSOIL_NEG) || (Generic && !F.waterHResp)) ? R(1) : moistEff;
+    moistEff = (bits & FAST_TSOIL_NEG) ? R(1) : moistEff;   // (frozen soil, or the water_hresp flag off: the plan's bit)
     R rSoil = eSoilC * K_bsr * moistEff * qSoil * (R)q3.x;
     // optional pools: calcLitterFluxes() sipnet.c:1150-1171, C:N effect depeffects.c:78-87,
     // calcMethaneFlux() sipnet.c:1201-1214

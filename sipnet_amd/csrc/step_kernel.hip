@@ -1339,13 +1339,14 @@ static bool isDefaultFlags(const int32_t* f) {
   return true;
 }
 
-// For the throughput kernels with the default flag set compiled in, three flags are DATA, not code: events
-// (no events, no event records), and the phenology pair gdd / soil_phenol (the plan puts the leaf-on variable
-// the flags ask for into the record, the kernel picks the matching threshold at launch).
+// For the throughput kernels with the default flag set compiled in, four flags are DATA, not code: events
+// (no events, no event records), the phenology pair gdd / soil_phenol (the plan puts the leaf-on variable the
+// flags ask for into the record, the parameter conversion the matching threshold into the row the kernels read)
+// and water_hresp (off = the plan marks every step like one with frozen soil: moisture effect 1).
 bool isPhenologyOrEventsFlag(int i) { return i == SIPNET_F_EVENTS || i == SIPNET_F_GDD || i == SIPNET_F_SOIL_PHENOL; }
 bool isDefaultFlagSet(const int32_t* f) {
   for (int i = 0; i < SIPNET_NFLAGS; i++) {
-    if (i == SIPNET_F_SNOW || isPhenologyOrEventsFlag(i)) continue;  // (snow only gates a parameter's required-ness)
+    if (i == SIPNET_F_SNOW || i == SIPNET_F_WATER_HRESP || isPhenologyOrEventsFlag(i)) continue;  // (snow only gates a parameter's required-ness)
     if ((f[i] != 0) != defaultFlag(i)) return false;
   }
   return true;

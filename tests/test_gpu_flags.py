@@ -161,15 +161,16 @@ def test_each_flag_set_matches_oracle(name, oracle, clim60, members70):
 
 
 PHENOLOGY_MODES = {"gdd": dict(), "soil_phenol": dict(gdd=0, soilPhenol=1), "calendar": dict(gdd=0),
-                   "russell_4": dict(events=0, gdd=0, soilPhenol=1)}
+                   "russell_4": dict(events=0, gdd=0, soilPhenol=1), "no_water_hresp": dict(waterHResp=0)}
 
 
 @pytest.mark.parametrize("mode", list(PHENOLOGY_MODES))
 def test_phenology_mode_and_events_are_data_for_the_compiled_in_flag_sets(mode, oracle, clim60, members70):
-    """events / gdd / soil_phenol do not change the code of the throughput kernels: the plan puts the leaf-on
-    variable the flags ask for into the record, the kernel picks the matching threshold -- so these flag
-    sets (russell_4's among them) take the cooperative kernels, every layout of them, the one-wave kernel's
-    default-flag build and the nitrogen-cycle kernel, against the oracle"""
+    """events / gdd / soil_phenol / water_hresp do not change the code of the throughput kernels: the plan puts
+    the leaf-on variable the flags ask for into the record (and marks every step "no moisture effect" with
+    water_hresp off), the parameter conversion the matching threshold into the row the kernels read -- so
+    these flag sets (russell_4's among them) take the cooperative kernels, every layout of them, the one-wave
+    kernel's default-flag build and the nitrogen-cycle kernel, against the oracle"""
     def run(flags, kernel, ev):
         b = sa.Batch(flags, 1, members70.shape[0], sa.F64, fast_math=True, kernel=kernel)
         if ev is not None:
@@ -198,6 +199,8 @@ def test_phenology_mode_and_events_are_data_for_the_compiled_in_flag_sets(mode, 
         got[kernel] = planes
     np.testing.assert_array_equal(got[sa.KERNEL_AUTO], got[sa.KERNEL_COOP_PAIR])
     np.testing.assert_array_equal(got[sa.KERNEL_AUTO], got[sa.KERNEL_COOP_QUAD])
+    if mode == "no_water_hresp":
+        return                     # (anaerobic needs water_hresp: context.c:203-212)
     nflags = _flags(litterPool=1, anaerobic=1, nitrogenCycle=1, **PHENOLOGY_MODES[mode])
     want, final, st = oracle.run_block(nflags, members70, clim60, ev)
     planes, state, name = run(nflags, sa.KERNEL_AUTO, ev)
