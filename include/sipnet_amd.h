@@ -206,8 +206,9 @@ int sipnet_batch_set_params(sipnet_batch *b, int32_t site, int32_t first_member,
  *                       one-wavefront kernel, all flags, full records
  *   SIPNET_MATH_FAST    the throughput kernels: site-only sub-expressions from the host plan,
  *                       reciprocals instead of divisions, a degree-9 polynomial exp2 (3.7e-14
- *                       relative); <= 2e-14 gC m-2 per step on NEE against the reference on the
- *                       benchmark ensemble (measured 1.5e-14; the tests hold 1e-9, the bar is 1e-6)
+ *                       relative); <= 2e-14 gC m-2 per step on NEE, GPP and ET against the reference
+ *                       over a year of the benchmark ensemble's first 1 024 members (measured 1.9e-14,
+ *                       pinned by tests/test_gpu_configs.py::test_c2_...; the bar is 1e-6)
  * A new fp64 batch is STRICT (no environment variable changes that).  May be changed between
  * runs. */
 enum sipnet_math { SIPNET_MATH_STRICT = 0, SIPNET_MATH_FAST = 1 };
