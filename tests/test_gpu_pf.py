@@ -191,6 +191,36 @@ def test_cycle_resampled_particles_continue_like_their_ancestors(base, clim, pre
     b.close()
 
 
+@pytest.mark.parametrize("prec", [sa.F64, sa.F32_MIXED], ids=["f64", "f32"])
+def test_one_call_analysis_equals_the_three_steps(base, clim, prec):
+    """sipnet_batch_pf_analysis (log-weights with block maxima -> ancestors -> resample in one library call) against
+    the three entry points called one by one, on twin batches: same log-weights, ancestors, total weight and
+    resampled state, ring and parameters, bit for bit"""
+    n = 1000                                             # (a ragged last block of 256)
+    members = synth.perturbed_params(base, n)
+    twins = [batch_of(clim, members, prec) for _ in range(2)]
+    planes = [b.run(0, 96)[0] for b in twins]
+    assert torch.equal(planes[0], planes[1])
+    nee = planes[0][0]
+    obs, sigma = float(nee[:, 3].double().sum()), float(nee.double().sum(0).std()) * 0.7
+    total = torch.zeros(1, dtype=torch.int64, device=DEV)
+    anc1, logw1 = twins[0].pf_analysis_local(nee, obs, sigma, 0.37, with_params=True, total_out=total)
+    logw2 = twins[1].pf_log_weights(planes[1][0], obs, sigma)
+    anc2, fixed = sd.pf_systematic_ancestors(logw2, 0.37, return_fixed=True)
+    twins[1].resample(anc2, None, (), True)
+    assert torch.equal(logw1, logw2) and torch.equal(anc1, anc2)
+    assert int(total.item()) == int(fixed.sum().item()) > 0
+    assert 1 < int(torch.unique_consecutive(anc1).numel()) < n
+    np.testing.assert_array_equal(twins[0].get_state(), twins[1].get_state())
+    # (ring slots no step has written yet are uninitialised memory: slot 0 and the 96 inserts)
+    np.testing.assert_array_equal(twins[0].get_rings()[:, :97], twins[1].get_rings()[:, :97])
+    everyone = torch.arange(n, dtype=torch.int32, device=DEV)
+    w = 32 + (125 if prec == sa.F32_MIXED else 250)
+    assert torch.equal(twins[0].pack_members(everyone, True)[w:], twins[1].pack_members(everyone, True)[w:])   # parameters
+    for b in twins:
+        b.close()
+
+
 @pytest.mark.parametrize("prec", [sa.F64, sa.F32_MIXED], ids=["f64", "f32ring"])
 def test_two_ranks_emulated_on_one_gpu(base, clim, prec):
     """two batches stand in for two ranks: exchange plan + pack + resample with received blocks
