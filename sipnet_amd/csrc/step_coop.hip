@@ -440,8 +440,8 @@ __device__ unsigned long long g_coopWaits[16];
 // S keeps soil carbon, the litter pool and the four nitrogen pools and computes heterotrophic
 // respiration, litter breakdown, methane and nitrogen.c's fluxes; C keeps the plants, W the water.
 // Per step W hands S the anaerobic moisture terms and the leached share, C hands S the plants' litter
-// fluxes and nitrogen demand, S hands C R_h (for NEE) and the mineral nitrogen the limitation test
-// needs; rare things (events, plant death, a nitrogen-limited step) travel in blocks of their own.
+// fluxes and nitrogen demand and, at the end of its step, GPP - R_a (S has R_h: it forms, stores and totals
+// NEE); S hands C the mineral nitrogen the limitation test needs; rare things (events, plant death, a nitrogen-limited step) travel in blocks of their own.
 // (The first version had this block on wave W: 2 400 cycles per night step there against C's 1 800;
 // c10kn 20.3 ms.)  One chunk per workgroup, ring in HBM (the new mailboxes take the LDS the ring
 // would), lean state only.
@@ -1238,7 +1238,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
           awaitAtLeast(&seqLai, t - 1);
           // NCyc: wave S reads two rows of the block too, at the start of ITS step -- which C's progress
           // does not vouch for (C(t-1) only needs S's nitrogen block of step t-2 done): the slot is free
-          // once S has posted R_h of step t-2, which it does right after that read (found by the fuzzer:
+          // once S has posted the mineral nitrogen of step t-1, which it does after that read (found by the fuzzer:
           // one trial in 600 had S take the soil factors of step t+2 for step t, 2e-5 off on NEE)
           if (NCyc) awaitAtLeast(&seqMinN, t - 1);
           WAIT_END(1)
@@ -1892,10 +1892,10 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
     i4 j0;
     R g1, g2, qSoilT, gFine, gCoarse, moistEff;
     int facSeq, moistSeq;
-    double minNStep = 0.0;   // NCyc: wave W's mineral nitrogen at the start of this step
+    double minNStep = 0.0;   // NCyc: wave S's mineral nitrogen at the start of this step
     if (NCyc) {
       // record fields, wave F's factors (rows 0 1 3 4 and the plain soil Q10 factor, row 6 -- carried in
-      // `moistEff`'s place) and wave W's mineral nitrogen, each behind its flag, one round trip
+      // `moistEff`'s place) and wave S's mineral nitrogen, each behind its flag, one round trip
       WAIT_BEGIN()
       const unsigned fac = ldsAddr(&mailFac[t & 1][0][lane]);
       const unsigned mnn = ldsAddr(&mailMinN[t & 1][lane]);

@@ -29,7 +29,7 @@ out = (C.c_ulonglong * 16)()
 _lib.lib().sipnet_debug_read_coop_waits(out)
 tick = 1.0    # s_memtime ticks are core-clock cycles on this part (total = kernel time x 2.4 GHz)
 names = {0: "L: wait for lai", 2: "L: statistics loads (vmcnt)", 1: "L: wait for C before posting factors", 3: "L: total", 4: "W: take pgp+alive", 5: "W: wait for C's progress", 7: "W: total",
-         8: "C: take factors + moisture (+record)", 9: "C: take psn", 10: "C: take R_h (NCYC)", 11: "C: total",
+         8: "C: take factors + moisture (+record)", 9: "C: take psn", 10: "C: late take of S's mineral N (NCYC)", 11: "C: total",
          12: "S: take moisture terms (NCYC)", 13: "S: take plant fluxes", 14: "S: take leached share", 15: "S: total"}
 print("light:", light, "kernel", b.last_launch()["kernel"], "%.2f ms" % b.last_kernel_ms())
 for k in sorted(names):
