@@ -17,6 +17,7 @@ Workloads (BASELINE.json configs):
         (48 steps) of forecast + the analysis step (likelihood weights, all-gather of
         log-weights, systematic resampling, all-to-all of resampled checkpoints, gather)
   c2x16 16 sites x 1024 members per GPU, fp64: c2 stacked 16-fold (INTEGRATION.md "small ensembles")
+  c4n   c4's shape with the nitrogen-cycle flag set (two chunks per CU)
   c10kn c10k's shape with the nitrogen-cycle flag set (litter pool + anaerobic + N cycle): the
         optional-flag instantiation of the throughput kernel (not a BASELINE config)
 Per-GPU work is fixed as N grows ("scaling": "weak").
@@ -66,6 +67,9 @@ WORKLOADS = {
     # c10k's shape with the nitrogen-cycle flag set (litter pool + anaerobic + N cycle)
     "c10kn": dict(sites=1, members=10240, prec="f64", steps=17520, param="allflags_forest.param",
                   flags=dict(litterPool=1, anaerobic=1, nitrogenCycle=1)),
+    # ... and c4's (two chunks per CU: the two-chunk layout of that kernel)
+    "c4n": dict(sites=32, members=1024, prec="f64", steps=17520, param="allflags_forest.param",
+                flags=dict(litterPool=1, anaerobic=1, nitrogenCycle=1)),
 }
 
 _CPU_WORKER = r"""

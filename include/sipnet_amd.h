@@ -220,7 +220,7 @@ int sipnet_batch_set_math(sipnet_batch *b, int32_t policy);
  * workgroup per chunk, running-mean ring in LDS; up to two: one eight-wave workgroup per TWO
  * chunks, rings in HBM; up to four, lean state only: one twelve-wave workgroup per FOUR chunks),
  * with the nitrogen-cycle flag set (litter pool + anaerobic + nitrogen cycle) its own cooperative kernel
- * up to one chunk per CU, the one-wavefront throughput kernel for bigger batches, full records there,
+ * up to two chunks per CU, the one-wavefront throughput kernel for bigger batches, full records there,
  * and the other optional model flags; with SIPNET_MATH_STRICT the strict-order kernel.  "Default model
  * flags" here means the physics: events, gdd, soil_phenol and water_hresp may have any legal value (no
  * events; leaf-on by growing degree days, soil temperature or day of year -- russell_4's set; no moisture
@@ -238,9 +238,11 @@ enum sipnet_kernel {
   SIPNET_KERNEL_STRICT = 4,   /* stepKernel (with SIPNET_MATH_FAST: its fast-math variant) */
   SIPNET_KERNEL_COOP_PAIR = 5, /* stepCoopPairKernel: two chunks per workgroup, ring in HBM */
   SIPNET_KERNEL_COOP_QUAD = 6, /* stepCoopQuadKernel: four chunks per twelve-wave workgroup */
-  SIPNET_KERNEL_COOP_NCYCLE = 7 /* stepCoopNKernel: the nitrogen-cycle flag set (litter pool + anaerobic +
+  SIPNET_KERNEL_COOP_NCYCLE = 7, /* stepCoopNKernel: the nitrogen-cycle flag set (litter pool + anaerobic +
                                    nitrogen cycle), four wavefronts per chunk, soil and nitrogen on a
                                    wavefront of their own */
+  SIPNET_KERNEL_COOP_NCYCLE_PAIR = 8 /* stepCoopNPairKernel: the same, two chunks per eight-wave workgroup
+                                   (AUTO's choice between one and two chunks per CU) */
 };
 enum sipnet_kernel_option {
   SIPNET_KOPT_ONE_WAVE_PER_SIMD = 1, /* one-wave kernel: never the 256-VGPR (two waves/SIMD) build */

@@ -6,7 +6,7 @@ include/sipnet_amd.h.  PyTorch is used only for device memory, streams and
 torch.distributed; all model arithmetic runs in hand-written HIP kernels
 (sipnet_amd/csrc/step_kernel.hip).
 """
-from ._lib import (KERNEL_AUTO, KERNEL_COOP_HBM, KERNEL_COOP_LDS, KERNEL_COOP_PAIR, KERNEL_COOP_QUAD, KERNEL_COOP_NCYCLE, KERNEL_ONE_WAVE, KERNEL_STRICT,
+from ._lib import (KERNEL_AUTO, KERNEL_COOP_HBM, KERNEL_COOP_LDS, KERNEL_COOP_PAIR, KERNEL_COOP_QUAD, KERNEL_COOP_NCYCLE, KERNEL_COOP_NCYCLE_PAIR, KERNEL_ONE_WAVE, KERNEL_STRICT,
                    KOPT_FULL_STATE, KOPT_NO_REGULAR_TILES, KOPT_ONE_WAVE_PER_SIMD, KOPT_RUNTIME_FLAGS,
                    KOPT_STATS_IN_KERNEL)
 from ._lib import (F32_MIXED, F64, NCLIM, NFLAGS, NPARAMS, NREC, NSTATE, RING_SLOTS,
@@ -22,7 +22,7 @@ __all__ = [
     "check_restart", "lib", "read_clim", "read_params",
     "read_events", "write_out", "write_events_out", "write_debug_logs", "format_out_header", "format_out_row", "read_config",
     "flags_from", "FLAG_NAMES", "DEFAULT_FLAGS", "PARAM_NAMES", "F64", "F32_MIXED",
-    "KERNEL_AUTO", "KERNEL_ONE_WAVE", "KERNEL_COOP_LDS", "KERNEL_COOP_HBM", "KERNEL_COOP_PAIR", "KERNEL_COOP_QUAD", "KERNEL_COOP_NCYCLE", "KERNEL_STRICT",
+    "KERNEL_AUTO", "KERNEL_ONE_WAVE", "KERNEL_COOP_LDS", "KERNEL_COOP_HBM", "KERNEL_COOP_PAIR", "KERNEL_COOP_QUAD", "KERNEL_COOP_NCYCLE", "KERNEL_COOP_NCYCLE_PAIR", "KERNEL_STRICT",
     "KOPT_ONE_WAVE_PER_SIMD", "KOPT_RUNTIME_FLAGS", "KOPT_FULL_STATE", "KOPT_NO_REGULAR_TILES", "KOPT_STATS_IN_KERNEL",
     "NPARAMS", "NFLAGS", "NCLIM", "NREC", "NSTATE", "RING_SLOTS",
 ]

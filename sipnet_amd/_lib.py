@@ -29,6 +29,7 @@ F64, F32_MIXED = 0, 1
 # enum sipnet_kernel / sipnet_kernel_option
 KERNEL_AUTO, KERNEL_ONE_WAVE, KERNEL_COOP_LDS, KERNEL_COOP_HBM, KERNEL_STRICT, KERNEL_COOP_PAIR, KERNEL_COOP_QUAD = range(7)
 KERNEL_COOP_NCYCLE = 7
+KERNEL_COOP_NCYCLE_PAIR = 8
 KOPT_ONE_WAVE_PER_SIMD, KOPT_RUNTIME_FLAGS, KOPT_FULL_STATE, KOPT_NO_REGULAR_TILES = 1, 2, 4, 8
 KOPT_STATS_IN_KERNEL = 16
 

@@ -290,6 +290,7 @@ static int autoKernel(const int32_t* flags, int32_t n_sites, int32_t n_members, 
   if (defaultFlags && blocks <= 2 * (int64_t)numCUs) return SIPNET_KERNEL_COOP_PAIR;
   if (defaultFlags && blocks <= 4 * (int64_t)numCUs && !wantFull) return SIPNET_KERNEL_COOP_QUAD;
   if (isNCycleFlagSet(flags) && blocks <= (int64_t)numCUs && !wantFull) return SIPNET_KERNEL_COOP_NCYCLE;
+  if (isNCycleFlagSet(flags) && blocks <= 2 * (int64_t)numCUs && !wantFull) return SIPNET_KERNEL_COOP_NCYCLE_PAIR;
   return SIPNET_KERNEL_ONE_WAVE;
 }
 
@@ -533,7 +534,7 @@ int sipnet_batch_set_math(sipnet_batch* b, int32_t policy) {
 }
 
 int sipnet_batch_set_kernel(sipnet_batch* b, int32_t kernel, int32_t options) {
-  if (!b || kernel < SIPNET_KERNEL_AUTO || kernel > SIPNET_KERNEL_COOP_NCYCLE ||
+  if (!b || kernel < SIPNET_KERNEL_AUTO || kernel > SIPNET_KERNEL_COOP_NCYCLE_PAIR ||
       (options & ~(SIPNET_KOPT_ONE_WAVE_PER_SIMD | SIPNET_KOPT_RUNTIME_FLAGS | SIPNET_KOPT_FULL_STATE |
                    SIPNET_KOPT_NO_REGULAR_TILES | SIPNET_KOPT_STATS_IN_KERNEL))) {
     setError("sipnet_batch_set_kernel: bad argument");
@@ -658,7 +659,7 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
       setError("sipnet_batch_run_debug: the debug plane is written by the strict-order kernel only");
       return SIPNET_ERR_BAD_ARGUMENT;
     }
-    if (kernel == SIPNET_KERNEL_COOP_NCYCLE) {
+    if (kernel == SIPNET_KERNEL_COOP_NCYCLE || kernel == SIPNET_KERNEL_COOP_NCYCLE_PAIR) {
       if (!isNCycleFlagSet(b->flags) || wantFull) {
         setError("sipnet_batch_run: the nitrogen-cycle cooperative kernel has its flag set (litter pool + anaerobic + "
                  "nitrogen cycle) compiled in and no full-state instantiation");
@@ -693,7 +694,8 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
   const bool coop = kernel == SIPNET_KERNEL_COOP_LDS || kernel == SIPNET_KERNEL_COOP_PAIR ||
                     (kernel == SIPNET_KERNEL_COOP_QUAD && b->precision == SIPNET_F32_MIXED) ||
                     ((b->kernelOptions & SIPNET_KOPT_STATS_IN_KERNEL) && kernel != SIPNET_KERNEL_STRICT &&
-                     kernel != SIPNET_KERNEL_ONE_WAVE && kernel != SIPNET_KERNEL_COOP_NCYCLE);
+                     kernel != SIPNET_KERNEL_ONE_WAVE && kernel != SIPNET_KERNEL_COOP_NCYCLE &&
+                     kernel != SIPNET_KERNEL_COOP_NCYCLE_PAIR);
   const int chunksPerSite = (b->n_members + 63) / 64;
   if (d_stats && coop) {
     const size_t need = (size_t)3 * b->n_sites * chunksPerSite * n_steps * 2;
@@ -743,7 +745,8 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
                         kernel == SIPNET_KERNEL_COOP_LDS ? COOP_RING_LDS
                         : kernel == SIPNET_KERNEL_COOP_PAIR ? COOP_PAIR
                         : kernel == SIPNET_KERNEL_COOP_QUAD ? COOP_QUAD
-                        : kernel == SIPNET_KERNEL_COOP_NCYCLE ? COOP_NCYCLE : COOP_RING_HBM,
+                        : kernel == SIPNET_KERNEL_COOP_NCYCLE ? COOP_NCYCLE
+                        : kernel == SIPNET_KERNEL_COOP_NCYCLE_PAIR ? COOP_NCYCLE_PAIR : COOP_RING_HBM,
                         stream, &b->lastLaunch);
   } else {
     launchStep(a, b->precision, b->fastMath, stream, &b->lastLaunch);

@@ -448,7 +448,7 @@ __device__ unsigned long long g_coopWaits[16];
 template <class R, bool PlainExp, bool RingLds, bool Full, int NP, bool NCyc = false>
 __device__ __forceinline__ void coopBody(const FastArgs& a) {
   static_assert(!(NP > 1 && RingLds), "two chunks' rings do not fit one CU's LDS");
-  static_assert(!NCyc || (NP == 1 && !RingLds && !Full), "nitrogen-cycle layout: one chunk, ring in HBM, lean");
+  static_assert(!NCyc || (NP <= 2 && !RingLds && !Full), "nitrogen-cycle layout: one or two chunks, ring in HBM, lean");
   constexpr bool Pair = NP == 2;
   // a fourth wavefront computes the climate-only factors when the workgroup has a CU to itself
 #ifdef SIPNET_NO_FACWAVE
@@ -460,7 +460,10 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   // two chunks per workgroup: the two spare wavefronts of the eight are the chunks' factor waves, and the
   // layout is  C0 C1 W0 W1 | L1 L0 F0 F1 : a carbon wave shares its SIMD with the OTHER chunk's light wave
   // (idle at night, when the carbon wave is the step), a water wave with its chunk's factor wave
-  constexpr bool FacWave = RingLds || Pair;
+  // (NCyc: the fourth role is the soil wave S, the factors stay with L; its two-chunk layout is
+  // C0 C1 S0 S1 | W1 W0 L1 L0 : the two busiest waves of a chunk, C and S, each share a SIMD with a water or light
+  // wave of the OTHER chunk)
+  constexpr bool FacWave = RingLds || (Pair && !NCyc);
 #endif
 #endif
   // per-wave private record tiles (each wave stages and awaits its own DMA) + mailboxes
@@ -493,14 +496,17 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   // fixation share, unclaimed storage}, C -> W the final demand.
   // (plant fluxes and event increments in two slots: C posts a step's before it has S's mineral nitrogen
   // of that step, i.e. possibly before S has consumed the step before)
-  __shared__ alignas(16) double mailPlant[NCyc ? 2 : 1][NCyc ? 8 : 1][64], mailPend[NCyc ? 2 : 1][64], mailMinN[NCyc ? 2 : 1][64];
-  __shared__ alignas(16) double mailStorN[NCyc ? 2 : 1][64], mailEvent[NCyc ? 2 : 1][NCyc ? 6 : 1][64], mailDeath[NCyc ? 4 : 1][64];
-  __shared__ alignas(16) double mailSupply[NCyc ? 3 : 1][64], mailDemand[1][64];
+  constexpr int NPN = NCyc ? NP : 1;   // (per chunk of the workgroup, like the mailboxes above)
+  __shared__ alignas(16) double mailPlantAll[NPN][NCyc ? 2 : 1][NCyc ? 8 : 1][64], mailPendAll[NPN][NCyc ? 2 : 1][64],
+      mailMinNAll[NPN][NCyc ? 2 : 1][64];
+  __shared__ alignas(16) double mailStorNAll[NPN][NCyc ? 2 : 1][64], mailEventAll[NPN][NCyc ? 2 : 1][NCyc ? 6 : 1][64],
+      mailDeathAll[NPN][NCyc ? 4 : 1][64];
+  __shared__ alignas(16) double mailSupplyAll[NPN][NCyc ? 3 : 1][64], mailDemandAll[NPN][1][64];
   // wave W -> wave S per step: [anaerobic moisture effect, anoxic share] at its start (seqWat), the
   // leached share of the mineral nitrogen once the drainage is known (seqLeach)
   // (four slots: W runs at most one step ahead of C, and C at most two ahead of S's consumption)
-  __shared__ alignas(16) double mailWat[NCyc ? 4 : 1][NCyc ? 3 : 1][64];
-  __shared__ int seqPlant, seqMinN, seqStorN, seqEvent, seqSupply, seqDemand, seqWat, seqLeach;
+  __shared__ alignas(16) double mailWatAll[NPN][NCyc ? 4 : 1][NCyc ? 3 : 1][64];
+  __shared__ int seqNAll[NPN][8];   // seqPlant seqMinN seqStorN seqEvent seqSupply seqDemand seqWat seqLeach
 #define seqFac seqFacMoist[0]
 #define seqMoist seqFacMoist[1]
   // The running-mean ring of the 64 members lives in LDS for the whole launch (250 x 64 x 8 B =
@@ -516,8 +522,11 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   const int sub = Pair ? (wave & 1) : NP == 4 ? (wave & 3) : 0;
   const int role = Pair ? ((wave >> 1) == 3 ? 2 : (wave >> 1) == 2 ? -1 : (wave >> 1)) : NP == 4 ? (wave >> 2) : wave;
 #else
-  const int sub = Pair ? ((wave >> 1) == 2 ? ((wave & 1) ^ 1) : (wave & 1)) : NP == 4 ? (wave & 3) : 0;
-  const int role = Pair ? (wave >> 1) : NP == 4 ? (wave >> 2) : wave;
+  // pairs: the second four wavefronts serve the OTHER chunk of their SIMD's first one
+  const int sub = Pair ? ((NCyc ? (wave >> 2) == 1 : (wave >> 1) == 2) ? ((wave & 1) ^ 1) : (wave & 1)) : NP == 4 ? (wave & 3) : 0;
+  // (NCyc pair: C0 C1 S0 S1 | W1 W0 L1 L0 -> roles 0 0 3 3 1 1 2 2)
+  const int role = Pair ? (NCyc ? ((wave >> 1) == 0 ? 0 : (wave >> 1) == 1 ? 3 : (wave >> 1) == 2 ? 1 : 2) : (wave >> 1))
+                        : NP == 4 ? (wave >> 2) : wave;
 #endif
   const int lane = (int)threadIdx.x & 63;
   auto& mailLai = mailLaiAll[sub];
@@ -531,6 +540,24 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   auto& seqFacMoist = seqFacMoistAll[sub];
   auto& seqDone = seqDoneAll[sub];
   auto& stage = stageAll[sub];
+  const int subN = NCyc ? sub : 0;
+  auto& mailPlant = mailPlantAll[subN];
+  auto& mailPend = mailPendAll[subN];
+  auto& mailMinN = mailMinNAll[subN];
+  auto& mailStorN = mailStorNAll[subN];
+  auto& mailEvent = mailEventAll[subN];
+  auto& mailDeath = mailDeathAll[subN];
+  auto& mailSupply = mailSupplyAll[subN];
+  auto& mailDemand = mailDemandAll[subN];
+  auto& mailWat = mailWatAll[subN];
+  int& seqPlant = seqNAll[subN][0];
+  int& seqMinN = seqNAll[subN][1];
+  int& seqStorN = seqNAll[subN][2];
+  int& seqEvent = seqNAll[subN][3];
+  int& seqSupply = seqNAll[subN][4];
+  int& seqDemand = seqNAll[subN][5];
+  int& seqWat = seqNAll[subN][6];
+  int& seqLeach = seqNAll[subN][7];
 #ifdef SIPNET_NO_STATS
   const bool stageOn = false;
 #else
@@ -2477,6 +2504,11 @@ template <class R, bool PlainExp>
 __global__ __launch_bounds__(256) void stepCoopNKernel(FastArgs a) {
   coopBody<R, PlainExp, false, false, 1, true>(a);
 }
+// ... and two chunks per eight-wave workgroup, for batches of up to two chunks per CU
+template <class R, bool PlainExp>
+__global__ __launch_bounds__(512) void stepCoopNPairKernel(FastArgs a) {
+  coopBody<R, PlainExp, false, false, 2, true>(a);
+}
 
 #ifdef SIPNET_HWID
 extern "C" int sipnet_debug_read_coop_hwid(unsigned* out) {
@@ -2497,24 +2529,30 @@ extern "C" int sipnet_debug_read_coop_stamps(unsigned long long* out) {
 void launchStepCoop(const FastArgs& a, int precision, int layout, hipStream_t stream, LaunchInfo* info) {
   const int chunksPerSite = (a.n_members + 63) / 64;
   const bool ringInLds = layout == COOP_RING_LDS, pair = layout == COOP_PAIR, quad = layout == COOP_QUAD;
-  if (layout == COOP_NCYCLE) {
-    const dim3 gridN(a.n_sites * chunksPerSite), blockN(256);
-    if (precision == SIPNET_F64) {
-      if (a.plainExp) hipLaunchKernelGGL((stepCoopNKernel<double, true>), gridN, blockN, 0, stream, a);
-      else hipLaunchKernelGGL((stepCoopNKernel<double, false>), gridN, blockN, 0, stream, a);
-    } else {
-      if (a.plainExp) hipLaunchKernelGGL((stepCoopNKernel<float, true>), gridN, blockN, 0, stream, a);
-      else hipLaunchKernelGGL((stepCoopNKernel<float, false>), gridN, blockN, 0, stream, a);
+  if (layout == COOP_NCYCLE || layout == COOP_NCYCLE_PAIR) {
+    const bool pairN = layout == COOP_NCYCLE_PAIR;
+    const int chunksN = a.n_sites * chunksPerSite;
+    const int groupsN = (a.n_sites & 7) == 0 ? 8 * ((chunksN / 8 + 1) / 2) : (chunksN + 1) / 2;   // (see pairGroups below)
+    const dim3 gridN(pairN ? groupsN : chunksN), blockN(pairN ? 512 : 256);
+#define NCYC_LAUNCH(K)                                                                          \
+    if (precision == SIPNET_F64) {                                                                \
+      if (a.plainExp) hipLaunchKernelGGL((K<double, true>), gridN, blockN, 0, stream, a);         \
+      else hipLaunchKernelGGL((K<double, false>), gridN, blockN, 0, stream, a);                   \
+    } else {                                                                                      \
+      if (a.plainExp) hipLaunchKernelGGL((K<float, true>), gridN, blockN, 0, stream, a);          \
+      else hipLaunchKernelGGL((K<float, false>), gridN, blockN, 0, stream, a);                    \
     }
+    if (pairN) { NCYC_LAUNCH(stepCoopNPairKernel) } else { NCYC_LAUNCH(stepCoopNKernel) }
+#undef NCYC_LAUNCH
     if (info) {
-      snprintf(info->kernel, sizeof info->kernel, "stepCoopNKernel<%s, %s>", precision == SIPNET_F64 ? "double" : "float",
-               a.plainExp ? "true" : "false");
+      snprintf(info->kernel, sizeof info->kernel, "%s<%s, %s>", pairN ? "stepCoopNPairKernel" : "stepCoopNKernel",
+               precision == SIPNET_F64 ? "double" : "float", a.plainExp ? "true" : "false");
       info->grid = (int32_t)gridN.x;
-      info->block = 256;
-      info->wavesPerSimd = 1;
+      info->block = pairN ? 512 : 256;
+      info->wavesPerSimd = pairN ? 2 : 1;
       const int elem = precision == SIPNET_F64 ? 8 : 4;
-      info->ldsBytes = 3 * 2 * kTileBytes + (2 * 64 * 3 + 2 * 7 * 64) * elem + 2 * 64 * 4 + 16 * 4 + 64 * 8 +
-                       (16 + 2 + 2 + 2 + 12 + 4 + 3 + 1 + 12) * 64 * 8 + 2 * kTileBytes;
+      info->ldsBytes = (pairN ? 2 : 1) * (3 * 2 * kTileBytes + (2 * 64 * 3 + 2 * 7 * 64) * elem + 2 * 64 * 4 + 16 * 4 + 64 * 8 +
+                                          (16 + 2 + 2 + 2 + 12 + 4 + 3 + 1 + 12) * 64 * 8 + 2 * kTileBytes);
     }
     return;
   }

@@ -128,7 +128,7 @@ struct LaunchInfo {
 // options: SIPNET_KOPT_* bits of include/sipnet_amd.h
 void launchStepFast(const FastArgs& a, int precision, int options, hipStream_t stream, LaunchInfo* info);
 // three cooperating wavefronts per 64 members (step_coop.hip); same results as launchStepFast
-enum CoopLayout { COOP_RING_LDS = 0, COOP_RING_HBM = 1, COOP_PAIR = 2, COOP_QUAD = 3, COOP_NCYCLE = 4 };  // step_coop.hip
+enum CoopLayout { COOP_RING_LDS = 0, COOP_RING_HBM = 1, COOP_PAIR = 2, COOP_QUAD = 3, COOP_NCYCLE = 4, COOP_NCYCLE_PAIR = 5 };  // step_coop.hip
 void launchStepCoop(const FastArgs& a, int precision, int layout, hipStream_t stream, LaunchInfo* info);
 // the flag sets the throughput kernels have compiled in; events, gdd and soil_phenol may take any (legal) value
 // in both -- they only change what the plan puts into the records (step_kernel.hip)

@@ -76,7 +76,7 @@ def test_python_constants_mirror_the_header_enums():
     import sipnet_amd as sa
     text = open(os.path.join(REPO, "include", "sipnet_amd.h")).read()
     enums = {m.group(1): int(m.group(2)) for m in re.finditer(r"\b(SIPNET_(?:KERNEL|KOPT|MATH)_[A-Z_0-9]+)\s*=\s*(\d+)", text)}
-    assert len([k for k in enums if k.startswith("SIPNET_KERNEL_")]) == 8
+    assert len([k for k in enums if k.startswith("SIPNET_KERNEL_")]) == 9
     for name, value in enums.items():
         py = name[len("SIPNET_"):]
         if py.startswith("MATH_"):
@@ -95,7 +95,8 @@ def test_every_bench_workload_has_traffic_evidence_for_the_kernel_auto_picks():
     L = sa.lib()
     traffic = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
     family = {sa.KERNEL_ONE_WAVE: "stepFastKernel<", sa.KERNEL_COOP_LDS: "stepCoopKernel<", sa.KERNEL_COOP_PAIR: "stepCoopPairKernel<",
-              sa.KERNEL_COOP_QUAD: "stepCoopQuadKernel<", sa.KERNEL_COOP_NCYCLE: "stepCoopNKernel<", sa.KERNEL_STRICT: "stepKernel<"}
+              sa.KERNEL_COOP_QUAD: "stepCoopQuadKernel<", sa.KERNEL_COOP_NCYCLE: "stepCoopNKernel<", sa.KERNEL_COOP_NCYCLE_PAIR: "stepCoopNPairKernel<",
+              sa.KERNEL_STRICT: "stepKernel<"}
     for name, wl in WORKLOADS.items():
         flags = (C.c_int32 * 12)(*sa.flags_from(**wl.get("flags", {})))
         prec = sa.F64 if wl["prec"] == "f64" else sa.F32_MIXED

@@ -259,6 +259,9 @@ KERNELS = [
     ("coop_ncycle_f32", sa.F32_MIXED, sa.KERNEL_COOP_NCYCLE, 0, "stepCoopNKernel<float, false>"),
     ("coop_ncycle_f64_plain", sa.F64, sa.KERNEL_COOP_NCYCLE, 0, "stepCoopNKernel<double, true>"),
     ("coop_ncycle_f32_plain", sa.F32_MIXED, sa.KERNEL_COOP_NCYCLE, 0, "stepCoopNKernel<float, true>"),
+    ("coop_ncycle_pair_f64", sa.F64, sa.KERNEL_COOP_NCYCLE_PAIR, 0, "stepCoopNPairKernel<double, false>"),
+    ("coop_ncycle_pair_f32", sa.F32_MIXED, sa.KERNEL_COOP_NCYCLE_PAIR, 0, "stepCoopNPairKernel<float, false>"),
+    ("coop_ncycle_pair_f64_plain", sa.F64, sa.KERNEL_COOP_NCYCLE_PAIR, 0, "stepCoopNPairKernel<double, true>"),
 ]
 NCYCLE_FLAGS = dict(litterPool=1, anaerobic=1, nitrogenCycle=1)
 
@@ -271,7 +274,7 @@ def test_every_throughput_kernel_instantiation_against_the_oracle(name, prec, ke
     the same schedule without the lethal events (emptied pools keep ~1e-5 gC of fp32 residue,
     which the fuzz test judges by time sums instead)"""
     flags = sa.flags_from()
-    if kernel == sa.KERNEL_COOP_NCYCLE:
+    if kernel in (sa.KERNEL_COOP_NCYCLE, sa.KERNEL_COOP_NCYCLE_PAIR):
         flags = sa.flags_from(**NCYCLE_FLAGS)
         base = sa.read_params(os.path.join(os.path.dirname(BASE), "allflags_forest.param"), flags)[0]
     clim, ev, members = _scenario(base, lethal=prec == sa.F64)

@@ -319,7 +319,8 @@ def test_nitrogen_cycle_kernel_paths_give_the_same_bits(clim60, members70):
     T = clim60.n_steps
     outs = {}
     for key, kernel, opt in (("reg", sa.KERNEL_COOP_NCYCLE, 0), ("gen", sa.KERNEL_COOP_NCYCLE, sa.KOPT_NO_REGULAR_TILES),
-                             ("again", sa.KERNEL_COOP_NCYCLE, 0), ("one", sa.KERNEL_ONE_WAVE, 0)):
+                             ("again", sa.KERNEL_COOP_NCYCLE, 0), ("pair", sa.KERNEL_COOP_NCYCLE_PAIR, 0),
+                             ("pair_gen", sa.KERNEL_COOP_NCYCLE_PAIR, sa.KOPT_NO_REGULAR_TILES), ("one", sa.KERNEL_ONE_WAVE, 0)):
         b = sa.Batch(flags, 1, members.shape[0], sa.F64, fast_math=True, kernel=kernel, kernel_options=opt)
         b.set_climate(0, clim60)
         b.set_params(0, members)
@@ -332,5 +333,7 @@ def test_nitrogen_cycle_kernel_paths_give_the_same_bits(clim60, members70):
     for k in range(3):
         np.testing.assert_array_equal(outs["reg"][k], outs["gen"][k])
         np.testing.assert_array_equal(outs["reg"][k], outs["again"][k])
+        np.testing.assert_array_equal(outs["reg"][k], outs["pair"][k])         # two chunks per eight-wave workgroup
+        np.testing.assert_array_equal(outs["reg"][k], outs["pair_gen"][k])
     assert np.array_equal(outs["reg"][0][:, :, 3], outs["reg"][0][:, :, 73])      # the same member in both chunks
     assert np.abs(outs["reg"][0] - outs["one"][0]).max() < 1e-11

@@ -127,10 +127,8 @@ for trial in range(trials):
                         (sa.KERNEL_COOP_PAIR, " coop-pair"), (sa.KERNEL_COOP_QUAD, " coop-quad")][int(rng.integers(0, 5))]
     if NCYC_ONLY:
         kopt = sa.KOPT_NO_REGULAR_TILES if rng.random() < 0.2 else 0
-        kern, forced = [(sa.KERNEL_AUTO, ""), (sa.KERNEL_COOP_NCYCLE, " coop-ncycle"), (sa.KERNEL_COOP_NCYCLE, " coop-ncycle"),
+        kern, forced = [(sa.KERNEL_AUTO, ""), (sa.KERNEL_COOP_NCYCLE, " coop-ncycle"), (sa.KERNEL_COOP_NCYCLE_PAIR, " coop-ncycle-pair"),
                         (sa.KERNEL_ONE_WAVE, " one-wave")][int(rng.integers(0, 4))]
-        if kern == sa.KERNEL_COOP_NCYCLE and not flags[0]:      # (the compiled-in set has events on)
-            kern, forced = sa.KERNEL_AUTO, ""
     if os.environ.get("FUZZ_KOPT"): kopt = int(os.environ["FUZZ_KOPT"])
     if os.environ.get("FUZZ_KERNEL"):     # rerun a trial on another kernel (with the trial index as third argument)
         kern = getattr(sa, "KERNEL_" + os.environ["FUZZ_KERNEL"].upper()); forced = " forced-" + os.environ["FUZZ_KERNEL"]
@@ -140,7 +138,7 @@ for trial in range(trials):
         b.set_climate(sidx, clims[sidx]); b.set_params(sidx, members)
     # a third of the trials also ask for the 44-column record and the diagnostics counters (the
     # "full" instantiations of the throughput kernels, or the strict kernel's)
-    want_full = bool(rng.random() < 0.33) and kern not in (sa.KERNEL_COOP_QUAD, sa.KERNEL_COOP_NCYCLE)    # no full-state builds of these
+    want_full = bool(rng.random() < 0.33) and kern not in (sa.KERNEL_COOP_QUAD, sa.KERNEL_COOP_NCYCLE, sa.KERNEL_COOP_NCYCLE_PAIR)    # no full-state builds of these
     if want_full:
         b.enable_diagnostics()
         forced += " full"
