@@ -496,7 +496,11 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   // fixation share, unclaimed storage}, C -> W the final demand.
   // (plant fluxes and event increments in two slots: C posts a step's before it has S's mineral nitrogen
   // of that step, i.e. possibly before S has consumed the step before)
-  constexpr int NPN = NCyc ? NP : 1;   // (per chunk of the workgroup, like the mailboxes above)
+  // (one chunk: plain arrays, as the one-chunk kernel was tuned -- the per-chunk ones cost it 1.3 %; two chunks: per chunk)
+  constexpr int NPN = (NCyc && NP > 1) ? NP : 1;
+  __shared__ alignas(16) double mailPlant1[NCyc ? 2 : 1][NCyc ? 8 : 1][64], mailPend1[NCyc ? 2 : 1][64], mailMinN1[NCyc ? 2 : 1][64];
+  __shared__ alignas(16) double mailStorN1[NCyc ? 2 : 1][64], mailEvent1[NCyc ? 2 : 1][NCyc ? 6 : 1][64], mailDeath1[NCyc ? 4 : 1][64];
+  __shared__ alignas(16) double mailSupply1[NCyc ? 3 : 1][64], mailDemand1[1][64];
   __shared__ alignas(16) double mailPlantAll[NPN][NCyc ? 2 : 1][NCyc ? 8 : 1][64], mailPendAll[NPN][NCyc ? 2 : 1][64],
       mailMinNAll[NPN][NCyc ? 2 : 1][64];
   __shared__ alignas(16) double mailStorNAll[NPN][NCyc ? 2 : 1][64], mailEventAll[NPN][NCyc ? 2 : 1][NCyc ? 6 : 1][64],
@@ -505,6 +509,8 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   // wave W -> wave S per step: [anaerobic moisture effect, anoxic share] at its start (seqWat), the
   // leached share of the mineral nitrogen once the drainage is known (seqLeach)
   // (four slots: W runs at most one step ahead of C, and C at most two ahead of S's consumption)
+  __shared__ alignas(16) double mailWat1[NCyc ? 4 : 1][NCyc ? 3 : 1][64];
+  __shared__ int seqPlant1, seqMinN1, seqStorN1, seqEvent1, seqSupply1, seqDemand1, seqWat1, seqLeach1;
   __shared__ alignas(16) double mailWatAll[NPN][NCyc ? 4 : 1][NCyc ? 3 : 1][64];
   __shared__ int seqNAll[NPN][8];   // seqPlant seqMinN seqStorN seqEvent seqSupply seqDemand seqWat seqLeach
 #define seqFac seqFacMoist[0]
@@ -540,24 +546,25 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   auto& seqFacMoist = seqFacMoistAll[sub];
   auto& seqDone = seqDoneAll[sub];
   auto& stage = stageAll[sub];
-  const int subN = NCyc ? sub : 0;
-  auto& mailPlant = mailPlantAll[subN];
-  auto& mailPend = mailPendAll[subN];
-  auto& mailMinN = mailMinNAll[subN];
-  auto& mailStorN = mailStorNAll[subN];
-  auto& mailEvent = mailEventAll[subN];
-  auto& mailDeath = mailDeathAll[subN];
-  auto& mailSupply = mailSupplyAll[subN];
-  auto& mailDemand = mailDemandAll[subN];
-  auto& mailWat = mailWatAll[subN];
-  int& seqPlant = seqNAll[subN][0];
-  int& seqMinN = seqNAll[subN][1];
-  int& seqStorN = seqNAll[subN][2];
-  int& seqEvent = seqNAll[subN][3];
-  int& seqSupply = seqNAll[subN][4];
-  int& seqDemand = seqNAll[subN][5];
-  int& seqWat = seqNAll[subN][6];
-  int& seqLeach = seqNAll[subN][7];
+  constexpr bool OneN = !(NCyc && NP > 1);
+  const int subN = OneN ? 0 : sub;
+  auto& mailPlant = OneN ? mailPlant1 : mailPlantAll[subN];
+  auto& mailPend = OneN ? mailPend1 : mailPendAll[subN];
+  auto& mailMinN = OneN ? mailMinN1 : mailMinNAll[subN];
+  auto& mailStorN = OneN ? mailStorN1 : mailStorNAll[subN];
+  auto& mailEvent = OneN ? mailEvent1 : mailEventAll[subN];
+  auto& mailDeath = OneN ? mailDeath1 : mailDeathAll[subN];
+  auto& mailSupply = OneN ? mailSupply1 : mailSupplyAll[subN];
+  auto& mailDemand = OneN ? mailDemand1 : mailDemandAll[subN];
+  auto& mailWat = OneN ? mailWat1 : mailWatAll[subN];
+  int& seqPlant = OneN ? seqPlant1 : seqNAll[subN][0];
+  int& seqMinN = OneN ? seqMinN1 : seqNAll[subN][1];
+  int& seqStorN = OneN ? seqStorN1 : seqNAll[subN][2];
+  int& seqEvent = OneN ? seqEvent1 : seqNAll[subN][3];
+  int& seqSupply = OneN ? seqSupply1 : seqNAll[subN][4];
+  int& seqDemand = OneN ? seqDemand1 : seqNAll[subN][5];
+  int& seqWat = OneN ? seqWat1 : seqNAll[subN][6];
+  int& seqLeach = OneN ? seqLeach1 : seqNAll[subN][7];
 #ifdef SIPNET_NO_STATS
   const bool stageOn = false;
 #else
