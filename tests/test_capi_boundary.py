@@ -107,3 +107,35 @@ def test_every_bench_workload_has_traffic_evidence_for_the_kernel_auto_picks():
         assert ent.get("kernel", "").startswith(family[k]), (name, ent.get("kernel"), family[k])
         if k == sa.KERNEL_COOP_LDS:       # the ring-in-LDS instantiation: third template argument true
             assert ent["kernel"].split(",")[2].strip() == "true", ent["kernel"]
+
+
+def test_auto_kernel_policy_by_shape_and_flags():
+    """sipnet_kernel_choice (host-only; the function sipnet_batch_run uses): layouts by chunks per CU, the flags
+    that are data (events, gdd, soil_phenol, water_hresp) keep the default-physics kernels, the nitrogen-cycle
+    set has its own one- and two-chunk kernels, every other optional flag takes the one-wave kernel, strict
+    math the strict kernel"""
+    import sipnet_amd as sa
+    L = sa.lib()
+
+    def choice(members, sites=1, prec=sa.F64, math=1, full=0, cus=256, **fl):
+        flags = (C.c_int32 * 12)(*sa.flags_from(**fl))
+        return L.sipnet_kernel_choice(flags, sites, members, prec, math, full, cus)
+    assert choice(1024) == choice(16384) == sa.KERNEL_COOP_LDS                 # <= 1 chunk per CU
+    assert choice(16385) == choice(32768) == sa.KERNEL_COOP_PAIR               # <= 2
+    assert choice(32769) == choice(65536) == sa.KERNEL_COOP_QUAD               # <= 4, lean
+    assert choice(65536, full=1) == choice(65537) == sa.KERNEL_ONE_WAVE
+    assert choice(1024, sites=32) == sa.KERNEL_COOP_PAIR                       # C4: 512 chunks
+    assert choice(10240, math=0) == sa.KERNEL_STRICT
+    assert choice(10240, math=0, prec=sa.F32_MIXED) == sa.KERNEL_COOP_LDS      # fp32-mixed is always fast
+    for data_flags in (dict(events=0), dict(gdd=0), dict(gdd=0, soilPhenol=1), dict(waterHResp=0),
+                       dict(events=0, gdd=0, soilPhenol=1)):                   # (the last: russell_4)
+        assert choice(10240, **data_flags) == sa.KERNEL_COOP_LDS, data_flags
+        assert choice(1024, sites=32, **data_flags) == sa.KERNEL_COOP_PAIR, data_flags
+    ncyc = dict(litterPool=1, anaerobic=1, nitrogenCycle=1)
+    assert choice(10240, **ncyc) == choice(10240, gdd=0, soilPhenol=1, **ncyc) == sa.KERNEL_COOP_NCYCLE
+    assert choice(1024, sites=32, **ncyc) == sa.KERNEL_COOP_NCYCLE_PAIR
+    assert choice(32769, **ncyc) == choice(10240, full=1, **ncyc) == sa.KERNEL_ONE_WAVE
+    for other in (dict(growthResp=1), dict(leafWater=1), dict(litterPool=1), dict(flooding=1),
+                  dict(litterPool=1, carbonSaturation=1), dict(anaerobic=1)):
+        assert choice(10240, **other) == sa.KERNEL_ONE_WAVE, other
+    assert choice(0) == -1 and choice(64, cus=0) == -1
