@@ -184,6 +184,27 @@ def test_state_round_trip_and_transplant(base, short_clim):
     b1.close(); b2.close()
 
 
+def test_fp32_mixed_checkpoint_round_trip_with_its_fp32_ring(base, short_clim):
+    """an fp32-mixed batch keeps its running-mean ring in fp32 on the device (the values are fp32 numbers there);
+    get_rings / set_rings speak doubles: a checkpoint taken and restored -- in place, and into another batch
+    and another cooperative layout -- continues bit for bit"""
+    members = synth.perturbed_params(base, 130)
+    b1 = make_batch(sa.flags_from(), [short_clim], members, prec=sa.F32_MIXED)
+    b1.run(0, 600, want_planes=False)
+    ck = b1.checkpoint()
+    assert np.array_equal(ck[1], ck[1].astype(np.float32).astype(np.float64))     # fp32 numbers
+    rest1, _ = b1.run(600, 300)
+    b1.restore(ck)
+    rest2, _ = b1.run(600, 300)
+    assert torch.equal(rest1, rest2)
+    b2 = make_batch(sa.flags_from(), [short_clim], members, prec=sa.F32_MIXED, kernel=sa.KERNEL_COOP_PAIR)
+    b2.restore(ck)
+    rest3, _ = b2.run(600, 300)
+    assert b2.last_launch()["kernel"].startswith("stepCoopPairKernel<float")
+    assert torch.equal(rest1, rest3)
+    b1.close(); b2.close()
+
+
 def test_fp32_mixed_tolerance(oracle, base):
     """SIPNET_F32_MIXED: fluxes in fp32, pools fp64.  Stated bound: |dNEE| < 2e-6 gC m-2 per
     half-hourly step, yearly NEE sum within 0.5 gC m-2 of the fp64 oracle."""
