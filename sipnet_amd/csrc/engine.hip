@@ -246,9 +246,9 @@ static int ensureFastRecs(sipnet_batch* b) {  // records of the throughput kerne
 // Up to four per CU: one twelve-wave workgroup per four chunks, every SIMD running the three
 // waves of one chunk (c3 13.0 ms; one-wave kernel 15.3); no full-state build of that one (VGPRs).
 // Bigger batches fill the SIMDs with the one-wave kernel, two waves per SIMD.
-// The nitrogen-cycle flag set has a cooperative kernel of its own (lean state, one chunk per CU:
-// its fp64 build takes 232 registers and 64 KB of LDS); every other optional flag set takes the
-// one-wave kernel.  Strict arithmetic and the debug plane: the strict-order kernel.  Full records,
+// The nitrogen-cycle flag set has cooperative kernels of its own (lean state; a soil wave S next to
+// L, W, C: one chunk per CU in 213 registers / 71 KB of LDS, or two chunks per eight-wave workgroup);
+// every other optional flag set takes the one-wave kernel.  Strict arithmetic and the debug plane: the strict-order kernel.  Full records,
 // diagnostics and SIPNET_KOPT_FULL_STATE: the "Full" instantiations of the same throughput kernels.
 // The running-mean ring on the device, [SIPNET_RING_SLOTS][ncol]: doubles, or -- fp32-mixed batches -- floats:
 // the values are NPP rates, which such a batch computes in fp32, so the narrower store loses nothing and
