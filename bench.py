@@ -14,8 +14,10 @@ Workloads (BASELINE.json configs):
   c2    1 site x 1024 members, fp64          c3   1 site x 65536 members, fp32-mixed
   c4    32 sites x 1024 members per GPU, fp64 (256 sites over 8 GPUs; rank r owns sites 32r..32r+31)
   c5    particle-filter cycle: 131072 particles per GPU (1 M over 8), fp32-mixed, one day
-        (48 steps) of forecast + the analysis step (likelihood weights, all-gather of
-        log-weights, systematic resampling, all-to-all of resampled checkpoints, gather)
+        (48 steps) of forecast + the analysis step (likelihood weights, ONE all-gather of the
+        log-weight blocks, systematic resampling of the rank's own particles over the gathered
+        weights, one gather that reads every ancestor where it lives -- peer HBM over xGMI;
+        --pf-exchange alltoall: the all-to-all of packed checkpoints instead)
   c2x16 16 sites x 1024 members per GPU, fp64: c2 stacked 16-fold (INTEGRATION.md "small ensembles")
   c4n   c4's shape with the nitrogen-cycle flag set (two chunks per CU)
   c10kn c10k's shape with the nitrogen-cycle flag set (litter pool + anaerobic + N cycle): the
@@ -251,6 +253,10 @@ def main():
                     help="run the N>1 path (RCCL process group, side-stream statistics + all-gather, segmented "
                          "full gather, the particle filter's all-gather / all-to-all) even with ONE rank, and "
                          "report its cost against the plain pass as config.dist_overhead_ms")
+    ap.add_argument("--pf-exchange", default="peer", choices=["peer", "alltoall"],
+                    help="c5, N > 1: how resampled particles cross ranks -- peer: ONE all-gather of log-weight blocks, "
+                         "then every rank reads its ancestors straight out of its peers' HBM (IPC-mapped, xGMI); "
+                         "alltoall: all-gather + exchange plan (one host round trip) + all_to_all_single of packed checkpoints")
     ap.add_argument("--rehearse", action="store_true",
                     help="development: run the N>1 path on ONE GPU (all ranks share device 0, gloo "
                          "collectives through host copies); the numbers mean nothing")
@@ -381,6 +387,18 @@ def main():
         if distd:
             tot = sd._gather0(tot, world, None).reshape(-1)
         pf_obs, pf_sigma = float(tot.median()), float(tot.std()) * 1.5 + 1e-12
+        pf_exchange = args.pf_exchange if distd else "n/a (1 GPU)"
+        if distd and args.pf_exchange == "peer":
+            try:    # once per filter, off the cycle: publish / map the checkpoint matrices of every rank
+                sd.pf_connect_peers(b, rank, world, with_params=True)
+            except Exception as e:   # (no IPC between these processes: the all-to-all path is the other product path)
+                pf_exchange = f"alltoall (peer mapping failed: {e!r})"
+            if world > 1:            # every rank takes the same path
+                ok = torch.tensor([1 if pf_exchange == "peer" else 0], dtype=torch.int32,
+                                  device="cpu" if args.rehearse else b.device)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) == 0 and pf_exchange == "peer":
+                    pf_exchange = "alltoall (a peer could not map)"
 
     pf_totals = torch.ones(max(args.steps + args.warmup, 1), dtype=torch.int64, device=b.device)
     pf_cycle = [0]
@@ -412,6 +430,12 @@ def main():
             # and "a particle survived" is checked for all cycles after the closing barrier
             slot = pf_totals[pf_cycle[0] % len(pf_totals):][:1]
             pf_cycle[0] += 1
+            if distd and not plain and pf_exchange == "peer":
+                _, info = sd.pf_analysis_peers(b, planes[0], pf_obs, pf_sigma, 0.5, rank=rank, world=world,
+                                               total_out=slot, collectives=True, diagnostics=record)
+                if record:
+                    pf_info.update(info)
+                return
             _, info = sd.pf_analysis(b, planes[0], pf_obs, pf_sigma, u0=0.5, rank=rank, world=world,
                                      with_params=True, diagnostics=record, total_out=slot,
                                      collectives=distd and not plain)
@@ -464,7 +488,8 @@ def main():
                          "backend": dist.get_backend(), "world": world,
                          "note": "K passes with the exchange path of an N-rank run (RCCL group, "
                                  + ("side-stream ensemble statistics + all-gather of the statistics block under the next pass's step kernel"
-                                    if overlap else "the particle filter's all-gather of log-weights + all-to-all of checkpoints" if pf
+                                    if overlap else ("the particle filter's ONE all-gather of log-weight blocks + peer-read resampling" if pf_exchange == "peer"
+                                                     else "the particle filter's all-gather of log-weights + all-to-all of checkpoints") if pf
                                     else f"gather={args.gather} in line")
                                  + ") against K plain passes; the link time of a real N-rank exchange is not in it"}
 
@@ -499,12 +524,16 @@ def main():
             b.run(0, T, planes=planes)
             barrier()
             e0.record()
-            sd.pf_analysis(b, planes[0], pf_obs, pf_sigma, u0=0.5, rank=rank, world=world, with_params=True,
-                           diagnostics=False, collectives=distd)
+            if distd and pf_exchange == "peer":
+                sd.pf_analysis_peers(b, planes[0], pf_obs, pf_sigma, 0.5, rank=rank, world=world, collectives=True)
+            else:
+                sd.pf_analysis(b, planes[0], pf_obs, pf_sigma, u0=0.5, rank=rank, world=world, with_params=True,
+                               diagnostics=False, collectives=distd)
             e1.record()
             torch.cuda.synchronize()
             ams.append(e0.elapsed_time(e1))
         pf_info["analysis_ms"] = float(np.mean(ams))
+        pf_info["exchange"] = pf_exchange
 
     # N > 1: the north star's exchange as written -- the member-resolved NEE/GPP/ET block of every
     # rank all-gathered -- measured in an extra untimed pass: the launch is cut into 10 segments

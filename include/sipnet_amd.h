@@ -196,7 +196,10 @@ int sipnet_batch_set_climate(sipnet_batch *b, int32_t site, int32_t n_steps,
 int sipnet_batch_set_events(sipnet_batch *b, int32_t site, int32_t n_events,
                             const sipnet_event *events);
 /* Raw parameters of `count` members of `site`, starting at first_member:
- * raw[count][SIPNET_NPARAMS], include/sipnet_params.def order, file units. */
+ * raw[count][SIPNET_NPARAMS], include/sipnet_params.def order, file units.
+ * site = SIPNET_ALL_SITES: the same members at every site of the batch (the usual ensemble: one
+ * parameter draw, many sites) -- ONE upload and one conversion launch instead of one per site. */
+#define SIPNET_ALL_SITES (-1)
 int sipnet_batch_set_params(sipnet_batch *b, int32_t site, int32_t first_member,
                             int32_t count, const double *raw);
 
@@ -450,6 +453,54 @@ int sipnet_batch_pf_analysis(sipnet_batch *b, const void *d_plane, int32_t elem_
                              int64_t ld, double obs, double sigma, double u0, int32_t with_params,
                              double *d_logw, int32_t *d_ancestors, int64_t *d_total, void *hip_stream);
 
+/* ---- the filter across ranks WITHOUT an all-to-all: peer reads over xGMI -----------------------------
+ * After systematic resampling the ancestors a rank needs from another rank are few (the two ends of its
+ * range) and known on the device only; RCCL's send / receive sizes are host arguments, so an all-to-all
+ * costs a device -> host round trip per cycle (sipnet_pf_exchange_plan), or padded slots.  On one node
+ * every GPU can instead LOAD from its peers' HBM: each rank publishes its checkpoint matrices once
+ * (state, ring, converted parameters, and their spares: a resampling gathers into the spare and swaps, all
+ * ranks in lockstep), maps the others' -- the addresses themselves inside one process
+ * (hipDeviceEnablePeerAccess; the node object below), hipIpcMemHandle mappings between processes (one
+ * process per GPU under torch.distributed) -- and a cycle's exchange is then
+ *     sipnet_batch_pf_local_weights  -> my block [nmax log-weights | their 256-wide block maxima]
+ *     ONE all-gather of the blocks   (RCCL; the caller's, or sipnet_node_pf_cycle's)
+ *     sipnet_batch_pf_resample_peers -> weights of all slots, exact prefix sum, the ancestors of MY particles,
+ *                                       one gather kernel that reads every ancestor where it lives
+ * with no host synchronisation and no second collective.  The all-gather is also the only ordering the
+ * scheme needs: a rank's block leaves after its forecast, so whoever holds the gathered blocks may read
+ * any rank's current buffers; and a rank overwrites a buffer its peers read in cycle c only after the
+ * all-gather of cycle c + 1, which needs every peer's block, which that peer enqueued after its gather.
+ * Ranks may hold different numbers of particles (nmax = the largest; the slots past a rank's own particles
+ * weigh nothing); world <= 16; one site per batch.  Results are bit-identical to sipnet_batch_pf_analysis
+ * over the concatenated particle set. */
+typedef struct sipnet_pf_peer {
+  int64_t process_id;        /* getpid() of the publishing process */
+  int32_t device, n_particles, precision, with_params;
+  int32_t ipc_valid;         /* 0: hipIpcGetMemHandle failed (peers in the same process do not need it) */
+  int32_t generic_exponents; /* some particle's parameters need the general-exponent kernel variant */
+  uint64_t address[6];       /* state, spare state, ring, spare ring, parameters, spare parameters */
+  unsigned char ipc[6][64];  /* hipIpcMemHandle_t of the same six allocations */
+} sipnet_pf_peer;
+/* Allocate the spare buffers and describe this batch's matrices; with_params: particles carry their
+ * (converted) parameters.  Exchange the descriptors by any means (they are plain bytes), then ... */
+int sipnet_batch_pf_publish(sipnet_batch *b, int32_t with_params, sipnet_pf_peer *out);
+/* ... connect: peers[world] in rank order, peers[rank] this batch's own.  Once connected, resample only
+ * through sipnet_batch_pf_resample_peers (or sipnet_batch_resample on EVERY rank in the same cycle). */
+int sipnet_batch_pf_connect(sipnet_batch *b, int32_t world, int32_t rank, const sipnet_pf_peer *peers);
+/* doubles per rank in the gathered buffer: nmax + ceil(nmax / 256) */
+int64_t sipnet_batch_pf_block_len(const sipnet_batch *b);
+/* sipnet_batch_pf_log_weights into this rank's block d_block[sipnet_batch_pf_block_len] (DEVICE) */
+int sipnet_batch_pf_local_weights(sipnet_batch *b, const void *d_plane, int32_t elem_is_f32,
+                                  int32_t n_steps, int64_t ld, double obs, double sigma,
+                                  double *d_block, void *hip_stream);
+/* d_gathered[world][block_len] (DEVICE): every rank's block.  d_ancestors[ncol] (DEVICE) receives, for
+ * each of this rank's particles, the slot (rank * nmax + particle) it was copied from; d_total (DEVICE
+ * int64, may be NULL) the total integer weight -- 0 = no particle survived, every ancestor is slot 0 --
+ * for the caller's check at its next synchronisation point.  Nothing is synchronised.  A batch that was
+ * never connected is a filter of one rank. */
+int sipnet_batch_pf_resample_peers(sipnet_batch *b, const double *d_gathered, double u0,
+                                   int32_t *d_ancestors, int64_t *d_total, void *hip_stream);
+
 /* ---- one node, several GPUs (north star: "the ensemble axis shards across the 8 GPUs of one node
  * with a single RCCL all-gather over xGMI of the NEE/GPP/ET output block", from the C host) --------
  * A sipnet_node is the multi-GPU host object of ONE process: one sipnet_batch, one HIP stream and
@@ -462,11 +513,30 @@ int sipnet_batch_pf_analysis(sipnet_batch *b, const void *d_plane, int32_t elem_
  * SIPNET_ERR_NO_DEVICE -- there is no fallback.  A node with ONE device is valid (and still goes
  * through RCCL).  Calls on one node must come from one thread at a time. */
 typedef struct sipnet_node sipnet_node;
+/* How a node cuts the batch (SURVEY 8(e) "Partitioning"): MEMBERS -- every shard holds a contiguous range of
+ * every site's members and every site's forcing (one-site ensembles, the particle filter); SITES -- every
+ * shard holds whole sites with all their members, so a site's forcing, events and plan exist on ONE device
+ * (BASELINE config 4: 256 sites x 1 024 members = 32 sites per GPU). */
+enum sipnet_shard_mode { SIPNET_SHARD_MEMBERS = 0, SIPNET_SHARD_SITES = 1 };
 int sipnet_node_create(const int32_t flags[SIPNET_NFLAGS], int32_t n_sites, int32_t n_members,
                        int32_t precision, const int32_t *devices, int32_t n_devices,
                        sipnet_node **out);
+/* The same with the cut chosen (sipnet_node_create = SIPNET_SHARD_MEMBERS).  Here a device MAY be listed more
+ * than once: several shards then share it -- the rehearsal of an N-shard run on a smaller machine.  RCCL
+ * refuses two ranks on one device, so the all-gathers of such a node are device-to-device copies ordered by
+ * HIP events between the shards' streams (sipnet_node_collective_library says so); sharding, uploads,
+ * kernels, peer tables and gathered layouts are the same code as with one device per shard.
+ * SIPNET_SHARD_SITES: shard k owns sites [k S / N, (k + 1) S / N) (sipnet_node_site_range) with all n_members
+ * members; set_climate / set_events / set_params of a site reach its owner only; ld = (most sites of a shard)
+ * x n_members; sipnet_node_gather_stats's host_total lists the sites in global order. */
+int sipnet_node_create_sharded(const int32_t flags[SIPNET_NFLAGS], int32_t n_sites, int32_t n_members,
+                               int32_t precision, const int32_t *devices, int32_t n_devices,
+                               int32_t shard_mode, sipnet_node **out);
 void sipnet_node_destroy(sipnet_node *nd);
 int32_t sipnet_node_n_devices(const sipnet_node *nd);
+int32_t sipnet_node_shard_mode(const sipnet_node *nd);
+int sipnet_node_site_range(const sipnet_node *nd, int32_t k, int32_t *first, int32_t *count);
+void *sipnet_node_stream(sipnet_node *nd, int32_t k);          /* shard k's HIP stream */
 sipnet_batch *sipnet_node_batch(sipnet_node *nd, int32_t k);   /* device k's batch (its own members only) */
 int sipnet_node_member_range(const sipnet_node *nd, int32_t k, int32_t *first, int32_t *count);
 const char *sipnet_node_collective_library(const sipnet_node *nd); /* "librccl.so.1 (RCCL 22204)" */
@@ -484,7 +554,11 @@ int sipnet_node_setup(sipnet_node *nd);
  * [3][n_steps][n_sites][2]; ld = sipnet_node_ld = n_sites * (largest shard, rounded up to even);
  * columns past a device's own members are zero.  Returns once everything is enqueued. */
 int sipnet_node_run(sipnet_node *nd, int32_t step0, int32_t n_steps);
+/* the same without the statistics (planes only: the forecast of a particle-filter cycle) */
+int sipnet_node_forecast(sipnet_node *nd, int32_t step0, int32_t n_steps);
 int sipnet_node_sync(sipnet_node *nd);
+/* every member's status, status[n_sites][n_members] (HOST), after synchronising every shard's stream */
+int sipnet_node_get_status(sipnet_node *nd, int32_t *status);
 int64_t sipnet_node_ld(const sipnet_node *nd);
 void *sipnet_node_planes(sipnet_node *nd, int32_t k);     /* DEVICE k: [3][n_steps][ld], double / float */
 double *sipnet_node_stats(sipnet_node *nd, int32_t k);    /* DEVICE k: its members' sums */
@@ -499,6 +573,29 @@ double *sipnet_node_gathered_stats(sipnet_node *nd, int32_t k);
  * (4.3 GB per device at 10 240 members x 17 520 steps: see DESIGN.md section 5 for what it costs.) */
 int sipnet_node_gather_planes(sipnet_node *nd);
 void *sipnet_node_gathered_planes(sipnet_node *nd, int32_t k);
+/* Column layout of a plane row: shard k's member m of its local site s sits at s * count_k + m (count_k =
+ * the shard's own member count: the site stride is NOT the common maximum); columns from n_sites_k * count_k
+ * up to ld are zero.  Any run length may be gathered (the planes of a run are [3][n_steps][ld] at the start
+ * of the buffer). */
+
+/* The particle filter over a node's shards (BASELINE config 5; SURVEY 8(e) "PF extra exchange"): one site,
+ * SIPNET_SHARD_MEMBERS, at most 16 devices.  pf_connect publishes and maps every shard's checkpoint
+ * matrices once (sipnet_batch_pf_publish / _connect).  A cycle is then
+ *     sipnet_node_setup / sipnet_node_forecast(step0, n_steps)   each shard's particles forward
+ *     sipnet_node_pf_analysis(variable, obs, sigma, u0)          likelihood of the observed sum of plane
+ *         `variable` (0 NEE, 1 GPP, 2 ET) over the forecast -> ONE all-gather of the log-weight blocks ->
+ *         every shard resamples its own particles, reading each ancestor where it lives (peer HBM)
+ * with nothing synchronised: every shard's host thread only enqueues.  The total weight of each cycle is kept
+ * on the devices (a ring of 64 cycles); sipnet_node_pf_check synchronises and answers SIPNET_ERR_BAD_PARAMETER
+ * if a cycle since the last check ended with every particle at zero weight (its resampling then copied
+ * particle 0 everywhere), SIPNET_ERR_INTERNAL if the shards disagree.  sipnet_node_pf_ancestors(nd, k):
+ * DEVICE k, the slots (shard * nmax + particle, nmax = the largest shard) its particles were copied from in
+ * the last cycle. */
+int sipnet_node_pf_connect(sipnet_node *nd, int32_t with_params);
+int sipnet_node_pf_analysis(sipnet_node *nd, int32_t variable, double obs, double sigma, double u0);
+int sipnet_node_pf_check(sipnet_node *nd, int32_t *n_cycles_checked);
+int32_t *sipnet_node_pf_ancestors(sipnet_node *nd, int32_t k);
+int64_t sipnet_node_pf_block_len(const sipnet_node *nd);
 
 int64_t sipnet_batch_ncol(const sipnet_batch *b);
 int32_t sipnet_batch_nsteps(const sipnet_batch *b);

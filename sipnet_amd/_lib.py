@@ -32,6 +32,8 @@ KERNEL_COOP_NCYCLE = 7
 KERNEL_COOP_NCYCLE_PAIR = 8
 KOPT_ONE_WAVE_PER_SIMD, KOPT_RUNTIME_FLAGS, KOPT_FULL_STATE, KOPT_NO_REGULAR_TILES = 1, 2, 4, 8
 KOPT_STATS_IN_KERNEL = 16
+SHARD_MEMBERS, SHARD_SITES = 0, 1
+ALL_SITES = -1
 
 
 class Event(C.Structure):
@@ -85,6 +87,14 @@ class LaunchInfo(C.Structure):
                 ("plan_upload_ms", C.c_double)]
 
 
+class PfPeer(C.Structure):
+    """struct sipnet_pf_peer: where a rank keeps its particles' checkpoint matrices (plain bytes: ranks
+    exchange it with all_gather_object / any byte channel)"""
+    _fields_ = [("process_id", C.c_int64), ("device", C.c_int32), ("n_particles", C.c_int32),
+                ("precision", C.c_int32), ("with_params", C.c_int32), ("ipc_valid", C.c_int32),
+                ("generic_exponents", C.c_int32), ("address", C.c_uint64 * 6), ("ipc", (C.c_ubyte * 64) * 6)]
+
+
 RESTART_WARN_BOUNDARY_NOT_MIDNIGHT, RESTART_WARN_BUILD_INFO, RESTART_WARN_TIME_GAP = 1, 2, 4
 
 # name -> (restype, argtypes); every symbol declared in include/sipnet_amd.h
@@ -131,9 +141,25 @@ SIGNATURES = {
     "sipnet_batch_member_words": (C.c_int32, [C.c_void_p, C.c_int32]),
     "sipnet_batch_pf_analysis": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int64, C.c_double, C.c_double, C.c_double,
                                            C.c_int32, _P, _P, _P, _P]),
+    "sipnet_batch_pf_publish": (C.c_int, [_P, C.c_int32, _P]),
+    "sipnet_batch_pf_connect": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
+    "sipnet_batch_pf_block_len": (C.c_int64, [_P]),
+    "sipnet_batch_pf_local_weights": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int64, C.c_double, C.c_double, _P, _P]),
+    "sipnet_batch_pf_resample_peers": (C.c_int, [_P, _P, C.c_double, _P, _P, _P]),
     "sipnet_batch_pack_members": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P]),
     "sipnet_batch_resample": (C.c_int, [_P, _P, _P, C.c_int32, _P, C.c_int32, _P]),
     "sipnet_node_create": (C.c_int, [_I32P, C.c_int32, C.c_int32, C.c_int32, _I32P, C.c_int32, C.POINTER(_P)]),
+    "sipnet_node_create_sharded": (C.c_int, [_I32P, C.c_int32, C.c_int32, C.c_int32, _I32P, C.c_int32, C.c_int32, C.POINTER(_P)]),
+    "sipnet_node_shard_mode": (C.c_int32, [_P]),
+    "sipnet_node_site_range": (C.c_int, [_P, C.c_int32, _I32P, _I32P]),
+    "sipnet_node_stream": (_P, [_P, C.c_int32]),
+    "sipnet_node_forecast": (C.c_int, [_P, C.c_int32, C.c_int32]),
+    "sipnet_node_get_status": (C.c_int, [_P, _P]),
+    "sipnet_node_pf_connect": (C.c_int, [_P, C.c_int32]),
+    "sipnet_node_pf_analysis": (C.c_int, [_P, C.c_int32, C.c_double, C.c_double, C.c_double]),
+    "sipnet_node_pf_check": (C.c_int, [_P, _I32P]),
+    "sipnet_node_pf_ancestors": (_P, [_P, C.c_int32]),
+    "sipnet_node_pf_block_len": (C.c_int64, [_P]),
     "sipnet_node_destroy": (None, [_P]),
     "sipnet_node_n_devices": (C.c_int32, [_P]),
     "sipnet_node_batch": (_P, [_P, C.c_int32]),

@@ -283,6 +283,46 @@ class Batch:
             self._stream()), "pf_analysis")
         return anc, logw
 
+    # -- the filter across ranks by peer reads (sipnet_batch_pf_publish / _connect / _resample_peers) ----------
+    def pf_publish(self, with_params=True):
+        """-> bytes of this batch's sipnet_pf_peer descriptor (exchange them, then pf_connect)"""
+        from ._lib import PfPeer
+        d = PfPeer()
+        check(self.L.sipnet_batch_pf_publish(self.h, int(with_params), C.byref(d)), "pf_publish")
+        return bytes(d)
+
+    def pf_connect(self, descriptors, rank):
+        """descriptors: every rank's pf_publish() bytes in rank order"""
+        from ._lib import PfPeer
+        arr = (PfPeer * len(descriptors))(*[PfPeer.from_buffer_copy(x) for x in descriptors])
+        check(self.L.sipnet_batch_pf_connect(self.h, len(descriptors), int(rank), arr), "pf_connect")
+        self._pf_gathered = None
+
+    def pf_block_len(self):
+        return int(self.L.sipnet_batch_pf_block_len(self.h))
+
+    def pf_local_weights(self, plane, obs, sigma, block):
+        """this rank's block [nmax log-weights | block maxima] of the all-gather, into `block` (f64 device
+        tensor of pf_block_len() entries, e.g. this rank's slice of the gathered buffer)"""
+        t = self._torch
+        assert block.dtype == t.float64 and block.is_contiguous() and block.numel() == self.pf_block_len()
+        check(self.L.sipnet_batch_pf_local_weights(
+            self.h, C.c_void_p(plane.data_ptr()), int(plane.dtype == t.float32), plane.shape[0], plane.shape[1],
+            float(obs), float(sigma), C.c_void_p(block.data_ptr()), self._stream()), "pf_local_weights")
+        return block
+
+    def pf_resample_peers(self, gathered, u0, ancestors=None, total_out=None):
+        """gathered[world][pf_block_len()]: every rank's block.  Resamples this rank's particles from wherever
+        their ancestors live (peer reads); returns the ancestors' slots (int32 [ncol])."""
+        t = self._torch
+        assert gathered.dtype == t.float64 and gathered.is_contiguous()
+        if ancestors is None:
+            ancestors = t.empty(self.ncol, dtype=t.int32, device=self.device)
+        check(self.L.sipnet_batch_pf_resample_peers(
+            self.h, C.c_void_p(gathered.data_ptr()), float(u0), C.c_void_p(ancestors.data_ptr()),
+            C.c_void_p(total_out.data_ptr()) if total_out is not None else None, self._stream()), "pf_resample_peers")
+        return ancestors
+
     def pack_members(self, cols, with_params=False):
         """cols: int32 device tensor of local column indices -> packed block [words][n] of 8-byte words
         (state rows, ring rows -- floats for an fp32-mixed batch --, parameter rows)"""

@@ -25,6 +25,9 @@ using namespace sipnet;  // internal header: only engine.hip and pf.hip include 
     }                                                                         \
   } while (0)
 
+struct PfScratch;  // pf.hip
+struct PfPeers;
+
 struct sipnet_batch {
   int32_t flags[SIPNET_NFLAGS];
   int32_t n_sites = 0, n_members = 0, precision = 0, device = 0;
@@ -82,6 +85,11 @@ struct sipnet_batch {
   SitePlan exportHead;
   PlanCarry exportFin;
 
+  // particle filter (pf.hip): resampling scratch owned by the batch, and -- between sipnet_batch_pf_connect and
+  // destroy -- the table of the peers' checkpoint matrices a cross-rank resampling reads from
+  PfScratch* pfScratch = nullptr;
+  PfPeers* pfPeers = nullptr;
+
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
   double lastMs = -1.0;
@@ -92,6 +100,8 @@ struct sipnet_batch {
 inline size_t ringElemBytes(const sipnet_batch* b) {
   return b->precision == SIPNET_F32_MIXED ? sizeof(float) : sizeof(double);
 }
+
+void pfRelease(sipnet_batch* b);   // pf.hip: frees pfScratch / pfPeers (called by sipnet_batch_destroy, device current)
 
 inline int useDevice(const sipnet_batch* b) {
   HIP_TRY(hipSetDevice(b->device));

@@ -379,6 +379,7 @@ int sipnet_batch_create(const int32_t* flags, int32_t n_sites, int32_t n_members
 void sipnet_batch_destroy(sipnet_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
+  pfRelease(b);
   if (b->d_rawStage) (void)hipFree(b->d_rawStage);
   if (b->d_prm) (void)hipFree(b->d_prm);
   if (b->d_state) (void)hipFree(b->d_state);
@@ -449,11 +450,13 @@ int sipnet_batch_set_events(sipnet_batch* b, int32_t site, int32_t n_events,
 
 int sipnet_batch_set_params(sipnet_batch* b, int32_t site, int32_t first_member,
                             int32_t count, const double* raw) {
-  if (!b || site < 0 || site >= b->n_sites || first_member < 0 || count <= 0 ||
+  if (!b || (site != SIPNET_ALL_SITES && (site < 0 || site >= b->n_sites)) || first_member < 0 || count <= 0 ||
       first_member + count > b->n_members || !raw) {
     setError("sipnet_batch_set_params: bad argument");
     return SIPNET_ERR_BAD_ARGUMENT;
   }
+  const int32_t nRep = site == SIPNET_ALL_SITES ? b->n_sites : 1;
+  if (site == SIPNET_ALL_SITES) site = 0;
   int rc = useDevice(b);
   if (rc) return rc;
   for (int32_t m = 0; m < count; m++) {
@@ -476,7 +479,7 @@ int sipnet_batch_set_params(sipnet_batch* b, int32_t site, int32_t first_member,
   // the parameter half of setupModel() (sipnet.c:1873-1916): from here on the converted block is
   // the only copy of the members' parameters on the device
   launchConvertParams(b->d_rawStage, b->d_prm, b->ncol, col0, count,
-                      b->flags[SIPNET_F_GDD] ? 0 : b->flags[SIPNET_F_SOIL_PHENOL] ? 1 : 2, nullptr);
+                      b->flags[SIPNET_F_GDD] ? 0 : b->flags[SIPNET_F_SOIL_PHENOL] ? 1 : 2, nullptr, nRep, b->n_members);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(nullptr));
   return SIPNET_OK;

@@ -3,25 +3,36 @@
 // The reference runs one process per ensemble member (frontend.c:212-250 is its whole host side);
 // the north star asks for the ensemble axis sharded over the GPUs of one node with ONE RCCL
 // all-gather over xGMI of the output block, issued from the C host.  A sipnet_node is that host
-// object: one sipnet_batch, one HIP stream and one RCCL communicator rank per device, all in one
-// process (ncclCommInitAll; the per-device calls of a collective are fused with ncclGroupStart /
-// ncclGroupEnd, RCCL's single-process multi-GPU idiom), members sharded contiguously.  The
-// forward model has no coupling between members, so the step kernels never exchange anything; the
-// collective is the all-gather of what the devices computed:
+// object: per listed device one SHARD = one sipnet_batch, one HIP stream, one RCCL communicator rank
+// (ncclCommInitAll) and one host thread that lives as long as the node and enqueues the shard's work.
+// Two ways to cut the batch (SURVEY 8(e) "Partitioning"):
+//   SIPNET_SHARD_MEMBERS  every shard holds a contiguous range of every site's members (c10k, c3, c5);
+//   SIPNET_SHARD_SITES    every shard holds whole sites with all their members, so a site's forcing,
+//                         events and plan exist on ONE device only (c4: 32 of 256 sites per GPU).
+// The forward model has no coupling between members, so the step kernels never exchange anything;
+// the collectives are all-gathers of what the shards computed:
 //   sipnet_node_gather_stats   the per-(variable, step, site) sum / sum of squares block of every
-//                              device (0.84 MB per device and year) -- the default exchange, after
-//                              which every device and the host hold the ensemble statistics;
-//   sipnet_node_gather_planes  the north star's exchange as written: the member-resolved NEE / GPP /
-//                              ET planes of every device on every device.
+//                              shard (0.84 MB per device and year) -- the default exchange;
+//   sipnet_node_gather_planes  the north star's exchange as written: the member-resolved planes;
+//   sipnet_node_pf_analysis    the particle filter's one exchange step: ONE all-gather of the
+//                              log-weight blocks, after which every shard reads the ancestors it needs
+//                              straight out of its peers' HBM (pf.hip: sipnet_batch_pf_resample_peers).
 // RCCL is loaded on first use (dlopen of librccl.so.1: a process that already holds one -- PyTorch
 // ships its own -- keeps using that one; a single-GPU batch never pays for the 570 MB library).
 // Without a usable RCCL sipnet_node_create fails loudly; there is no fallback path.
+// A device listed more than once (sipnet_node_create_sharded only) puts several shards on it -- the
+// rehearsal of an N-shard run on a smaller machine.  RCCL refuses two ranks on one device, so such a
+// node's all-gathers are device-to-device copies ordered by HIP events between the shards' streams;
+// sharding, uploads, kernels, the peer tables and the gathered layouts are the same code.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -78,24 +89,73 @@ Rccl* loadRccl() {
   return &r;
 }
 
+// all shard threads meet here (only the event-ordered transport needs it: an event must have been
+// recorded by its owner before another thread makes its stream wait for it)
+struct HostBarrier {
+  std::mutex mu;
+  std::condition_variable cv;
+  int n = 1, waiting = 0;
+  uint64_t phase = 0;
+  void arrive() {
+    if (n <= 1) return;
+    std::unique_lock<std::mutex> lk(mu);
+    const uint64_t p = phase;
+    if (++waiting == n) {
+      waiting = 0;
+      phase++;
+      cv.notify_all();
+    } else {
+      cv.wait(lk, [&] { return phase != p; });
+    }
+  }
+};
+
 }  // namespace
 
 struct sipnet_node {
   int32_t flags[SIPNET_NFLAGS];
-  int32_t n_sites = 0, n_members = 0, precision = 0;
-  std::vector<int32_t> devices, first, count;
+  int32_t n_sites = 0, n_members = 0, precision = 0, mode = SIPNET_SHARD_MEMBERS;
+  std::vector<int32_t> devices;
+  // shard k owns members [first, first + count) of every site (member mode: sites0 = 0, nSites = n_sites)
+  // or sites [sites0, sites0 + nSites) with all members (site mode: first = 0, count = n_members)
+  std::vector<int32_t> first, count, sites0, nSites;
   std::vector<sipnet_batch*> batches;
   std::vector<hipStream_t> streams;
-  std::vector<ncclComm_t> comms;
+  std::vector<ncclComm_t> comms;   // empty: event-ordered copies (a device is listed twice)
   Rccl* rccl = nullptr;
-  int32_t maxCount = 0;   // members per device, rounded up: the planes' leading dimension / n_sites
-  int64_t ld = 0;         // n_sites * maxCount: every device's planes have this leading dimension
-  // per device: planes [3][n_alloc][ld] (element type by precision), statistics [3][n_alloc][n_sites][2],
-  // gathered statistics [n_dev][3][n_run][n_sites][2], gathered planes [n_dev][3][n_run][ld] (on request)
+  int32_t maxCount = 0;   // member mode: members per shard, rounded up to even; site mode: n_members
+  int32_t maxSites = 0;   // site mode: sites per shard at most; member mode: n_sites
+  int64_t ld = 0;         // maxSites * maxCount: every shard's planes have this leading dimension
+  // per shard: planes [3][n_run][ld] (element type by precision), statistics [3][n_run][maxSites][2],
+  // gathered statistics [n][3][n_run][maxSites][2], gathered planes [n][3][n_run][ld] (on request)
   int32_t nAlloc = 0, nRun = 0, step0 = 0;
   std::vector<void*> planes, gatheredPlanes;
-  std::vector<double*> stats, gatheredStats;
+  std::vector<double*> stats, gatheredStats, statsCompact;
+  std::vector<size_t> statsCompactCap;
   size_t gatheredPlanesCap = 0, gatheredStatsCap = 0;
+  // particle filter: per shard the gathered log-weight blocks, its particles' ancestors, a ring of total weights
+  bool pfConnected = false;
+  int64_t pfBlock = 0;
+  int32_t pfCycles = 0;
+  std::vector<double*> pfGathered;
+  std::vector<int32_t*> pfAnc;
+  std::vector<int64_t*> pfTotals;
+  static constexpr int kPfTotals = 64;
+  // event-ordered transport
+  std::vector<hipEvent_t> evReady, evCopied;
+  std::vector<const void*> agSend;
+  HostBarrier bar;
+  // the shards' host threads
+  std::vector<std::thread> workers;
+  std::mutex mu;
+  std::condition_variable cvWork, cvDone;
+  std::function<int(int)> task;
+  uint64_t gen = 0;
+  int pending = 0;
+  bool quit = false;
+  std::vector<int> rc;
+  std::vector<std::string> msg;
+
   size_t elem() const { return precision == SIPNET_F64 ? 8 : 4; }
   int n() const { return (int)devices.size(); }
 };
@@ -117,68 +177,126 @@ struct sipnet_node {
     }                                                                         \
   } while (0)
 
-// f on every device, one host thread each (the batch calls block on uploads); first failure wins
-template <class F>
-static int onEveryDevice(sipnet_node* nd, F f) {
-  const int n = nd->n();
-  std::vector<int> rc(n, SIPNET_OK);
-  std::vector<std::string> msg(n);
-  auto body = [&](int k) {
-    if (hipSetDevice(nd->devices[k]) != hipSuccess) {
-      rc[k] = SIPNET_ERR_NO_DEVICE;
-      msg[k] = "hipSetDevice failed";
-      return;
+static void runShardTask(sipnet_node* nd, int k) {
+  nd->rc[k] = nd->task(k);
+  nd->msg[k] = nd->rc[k] != SIPNET_OK ? sipnet_last_error() : "";   // thread-local: carry it to the caller's thread
+}
+
+static void workerLoop(sipnet_node* nd, int k) {
+  const bool dev = hipSetDevice(nd->devices[k]) == hipSuccess;
+  uint64_t seen = 0;
+  for (;;) {
+    {
+      std::unique_lock<std::mutex> lk(nd->mu);
+      nd->cvWork.wait(lk, [&] { return nd->quit || nd->gen != seen; });
+      if (nd->quit) return;
+      seen = nd->gen;
     }
-    rc[k] = f(k);
-    if (rc[k] != SIPNET_OK) msg[k] = sipnet_last_error();   // thread-local: carry it to the caller's thread
-  };
-  if (n == 1) {
-    body(0);
-  } else {
-    std::vector<std::thread> th;
-    for (int k = 0; k < n; k++) th.emplace_back(body, k);
-    for (auto& t : th) t.join();
+    if (dev) {
+      runShardTask(nd, k);
+    } else {
+      nd->rc[k] = SIPNET_ERR_NO_DEVICE;
+      nd->msg[k] = "hipSetDevice failed";
+    }
+    {
+      std::lock_guard<std::mutex> lk(nd->mu);
+      if (--nd->pending == 0) nd->cvDone.notify_all();
+    }
   }
+}
+
+// f(k) for every shard k, each on the shard's own host thread (a node of one shard: on the caller's);
+// returns when all have returned, the first failure wins
+template <class F>
+static int onEveryShard(sipnet_node* nd, F f) {
+  const int n = nd->n();
+  nd->task = f;
+  if (n == 1) {
+    if (hipSetDevice(nd->devices[0]) != hipSuccess) {
+      setError("sipnet_node: hipSetDevice failed");
+      return SIPNET_ERR_NO_DEVICE;
+    }
+    runShardTask(nd, 0);
+  } else {
+    std::unique_lock<std::mutex> lk(nd->mu);
+    nd->pending = n;
+    nd->gen++;
+    nd->cvWork.notify_all();
+    nd->cvDone.wait(lk, [&] { return nd->pending == 0; });
+  }
+  nd->task = nullptr;
   for (int k = 0; k < n; k++)
-    if (rc[k] != SIPNET_OK) {
-      setError("device " + std::to_string(nd->devices[k]) + ": " + msg[k]);
-      return rc[k];
+    if (nd->rc[k] != SIPNET_OK) {
+      setError("device " + std::to_string(nd->devices[k]) + " (shard " + std::to_string(k) + "): " + nd->msg[k]);
+      return nd->rc[k];
     }
   return SIPNET_OK;
 }
 
-extern "C" {
+// All-gather of `bytes` per shard among the shards, called by shard k's thread from inside an onEveryShard
+// task: recv = [n][bytes] on shard k's device, send = this shard's block (may be its own slice of recv).
+// RCCL when every shard has a device of its own; otherwise copies ordered by events (see the file header).
+static int allGatherShard(sipnet_node* nd, int k, const void* send, void* recv, size_t bytes) {
+  const int n = nd->n();
+  if (!nd->comms.empty()) {
+    NODE_RCCL(nd, nd->rccl->allGather(send, recv, bytes, ncclChar, nd->comms[k], nd->streams[k]));
+    return SIPNET_OK;
+  }
+  nd->agSend[k] = send;
+  NODE_HIP(hipEventRecord(nd->evReady[k], nd->streams[k]));
+  nd->bar.arrive();
+  for (int s = 0; s < n; s++) {
+    char* dst = (char*)recv + (size_t)s * bytes;
+    if (s != k) NODE_HIP(hipStreamWaitEvent(nd->streams[k], nd->evReady[s], 0));
+    if ((const void*)dst != nd->agSend[s])
+      NODE_HIP(hipMemcpyAsync(dst, nd->agSend[s], bytes, hipMemcpyDeviceToDevice, nd->streams[k]));
+  }
+  NODE_HIP(hipEventRecord(nd->evCopied[k], nd->streams[k]));
+  nd->bar.arrive();
+  // what follows on this stream may overwrite the block the others copy from
+  for (int s = 0; s < n; s++)
+    if (s != k) NODE_HIP(hipStreamWaitEvent(nd->streams[k], nd->evCopied[s], 0));
+  return SIPNET_OK;
+}
 
-int sipnet_node_create(const int32_t* flags, int32_t n_sites, int32_t n_members, int32_t precision,
-                       const int32_t* devices, int32_t n_devices, sipnet_node** out) {
-  if (!flags || !out || !devices || n_devices <= 0 || n_devices > 64 || n_sites <= 0 || n_members < n_devices) {
-    setError("sipnet_node_create: bad argument (needs at least one member per device)");
+static int createNode(const int32_t* flags, int32_t n_sites, int32_t n_members, int32_t precision,
+                      const int32_t* devices, int32_t n_devices, int32_t mode, bool allowShared, sipnet_node** out) {
+  const char* fn = allowShared ? "sipnet_node_create_sharded" : "sipnet_node_create";
+  if (!flags || !out || !devices || n_devices <= 0 || n_devices > 64 || n_sites <= 0 || n_members <= 0 ||
+      (mode != SIPNET_SHARD_MEMBERS && mode != SIPNET_SHARD_SITES) ||
+      (mode == SIPNET_SHARD_MEMBERS ? n_members : n_sites) < n_devices) {
+    setError(std::string(fn) + ": bad argument (needs at least one member -- or, sharding sites, one site -- per device)");
     return SIPNET_ERR_BAD_ARGUMENT;
   }
   const int have = sipnet_device_count();
+  bool shared = false;
   for (int k = 0; k < n_devices; k++) {
     if (devices[k] < 0 || devices[k] >= have) {
-      setError("sipnet_node_create: no usable HIP device " + std::to_string(devices[k]) +
-               " (this engine has no CPU path)");
+      setError(std::string(fn) + ": no usable HIP device " + std::to_string(devices[k]) + " (this engine has no CPU path)");
       return SIPNET_ERR_NO_DEVICE;
     }
     for (int j = 0; j < k; j++)
-      if (devices[j] == devices[k]) {
-        setError("sipnet_node_create: a device is listed twice");
-        return SIPNET_ERR_BAD_ARGUMENT;
-      }
+      if (devices[j] == devices[k]) shared = true;
   }
-  Rccl* r = loadRccl();
-  if (!r) {
-    const char* why = dlerror();
-    setError(std::string("sipnet_node_create: RCCL (librccl.so.1) cannot be loaded: ") + (why ? why : "missing symbol"));
-    return SIPNET_ERR_NO_DEVICE;
+  if (shared && !allowShared) {
+    setError("sipnet_node_create: a device is listed twice");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  Rccl* r = nullptr;
+  if (!shared) {
+    r = loadRccl();
+    if (!r) {
+      const char* why = dlerror();
+      setError(std::string(fn) + ": RCCL (librccl.so.1) cannot be loaded: " + (why ? why : "missing symbol"));
+      return SIPNET_ERR_NO_DEVICE;
+    }
   }
   sipnet_node* nd = new sipnet_node();
   memcpy(nd->flags, flags, sizeof nd->flags);
   nd->n_sites = n_sites;
   nd->n_members = n_members;
   nd->precision = precision;
+  nd->mode = mode;
   nd->rccl = r;
   nd->devices.assign(devices, devices + n_devices);
   nd->batches.assign(n_devices, nullptr);
@@ -187,28 +305,57 @@ int sipnet_node_create(const int32_t* flags, int32_t n_sites, int32_t n_members,
   nd->gatheredPlanes.assign(n_devices, nullptr);
   nd->stats.assign(n_devices, nullptr);
   nd->gatheredStats.assign(n_devices, nullptr);
-  for (int k = 0; k < n_devices; k++) {  // contiguous member ranges, sizes differ by at most one
-    const int32_t a = (int32_t)((int64_t)n_members * k / n_devices), z = (int32_t)((int64_t)n_members * (k + 1) / n_devices);
-    nd->first.push_back(a);
-    nd->count.push_back(z - a);
-    if (z - a > nd->maxCount) nd->maxCount = z - a;
+  nd->statsCompact.assign(n_devices, nullptr);
+  nd->statsCompactCap.assign(n_devices, 0);
+  nd->pfGathered.assign(n_devices, nullptr);
+  nd->pfAnc.assign(n_devices, nullptr);
+  nd->pfTotals.assign(n_devices, nullptr);
+  nd->evReady.assign(n_devices, nullptr);
+  nd->evCopied.assign(n_devices, nullptr);
+  nd->agSend.assign(n_devices, nullptr);
+  nd->rc.assign(n_devices, SIPNET_OK);
+  nd->msg.assign(n_devices, "");
+  nd->bar.n = n_devices;
+  for (int k = 0; k < n_devices; k++) {  // contiguous ranges, sizes differ by at most one
+    const int32_t total = mode == SIPNET_SHARD_MEMBERS ? n_members : n_sites;
+    const int32_t a = (int32_t)((int64_t)total * k / n_devices), z = (int32_t)((int64_t)total * (k + 1) / n_devices);
+    if (mode == SIPNET_SHARD_MEMBERS) {
+      nd->first.push_back(a);
+      nd->count.push_back(z - a);
+      nd->sites0.push_back(0);
+      nd->nSites.push_back(n_sites);
+      nd->maxCount = std::max(nd->maxCount, z - a);
+    } else {
+      nd->first.push_back(0);
+      nd->count.push_back(n_members);
+      nd->sites0.push_back(a);
+      nd->nSites.push_back(z - a);
+      nd->maxSites = std::max(nd->maxSites, z - a);
+    }
   }
-  nd->maxCount = (nd->maxCount + 1) & ~1;  // even: 16-byte aligned fp64 rows
-  nd->ld = (int64_t)n_sites * nd->maxCount;
+  if (mode == SIPNET_SHARD_MEMBERS) {
+    nd->maxCount = (nd->maxCount + 1) & ~1;  // even: 16-byte aligned fp64 rows
+    nd->maxSites = n_sites;
+  } else {
+    nd->maxCount = n_members;
+  }
+  nd->ld = (int64_t)nd->maxSites * nd->maxCount;
   int rc = SIPNET_OK;
   for (int k = 0; k < n_devices && rc == SIPNET_OK; k++) {
-    rc = sipnet_batch_create(flags, n_sites, nd->count[k], precision, devices[k], &nd->batches[k]);
+    rc = sipnet_batch_create(flags, nd->nSites[k], nd->count[k], precision, devices[k], &nd->batches[k]);
     if (rc == SIPNET_OK && (hipSetDevice(devices[k]) != hipSuccess ||
-                            hipStreamCreateWithFlags(&nd->streams[k], hipStreamNonBlocking) != hipSuccess)) {
-      setError("sipnet_node_create: hipStreamCreate failed");
+                            hipStreamCreateWithFlags(&nd->streams[k], hipStreamNonBlocking) != hipSuccess ||
+                            hipEventCreateWithFlags(&nd->evReady[k], hipEventDisableTiming) != hipSuccess ||
+                            hipEventCreateWithFlags(&nd->evCopied[k], hipEventDisableTiming) != hipSuccess)) {
+      setError(std::string(fn) + ": hipStreamCreate / hipEventCreate failed");
       rc = SIPNET_ERR_NO_DEVICE;
     }
   }
-  if (rc == SIPNET_OK) {
+  if (rc == SIPNET_OK && !shared) {
     nd->comms.assign(n_devices, nullptr);
     ncclResult_t nr = r->commInitAll(nd->comms.data(), n_devices, nd->devices.data());
     if (nr != ncclSuccess) {
-      setError(std::string("sipnet_node_create: ncclCommInitAll: ") + r->errorString(nr));
+      setError(std::string(fn) + ": ncclCommInitAll: " + r->errorString(nr));
       nd->comms.clear();
       rc = SIPNET_ERR_NO_DEVICE;
     }
@@ -219,20 +366,50 @@ int sipnet_node_create(const int32_t* flags, int32_t n_sites, int32_t n_members,
     setError(keep);
     return rc;
   }
+  if (n_devices > 1)
+    for (int k = 0; k < n_devices; k++) nd->workers.emplace_back(workerLoop, nd, k);
   *out = nd;
   return SIPNET_OK;
 }
 
+extern "C" {
+
+int sipnet_node_create(const int32_t* flags, int32_t n_sites, int32_t n_members, int32_t precision,
+                       const int32_t* devices, int32_t n_devices, sipnet_node** out) {
+  return createNode(flags, n_sites, n_members, precision, devices, n_devices, SIPNET_SHARD_MEMBERS, false, out);
+}
+int sipnet_node_create_sharded(const int32_t* flags, int32_t n_sites, int32_t n_members, int32_t precision,
+                               const int32_t* devices, int32_t n_devices, int32_t shard_mode, sipnet_node** out) {
+  return createNode(flags, n_sites, n_members, precision, devices, n_devices, shard_mode, true, out);
+}
+
 void sipnet_node_destroy(sipnet_node* nd) {
   if (!nd) return;
+  if (!nd->workers.empty()) {
+    {
+      std::lock_guard<std::mutex> lk(nd->mu);
+      nd->quit = true;
+    }
+    nd->cvWork.notify_all();
+    for (auto& t : nd->workers) t.join();
+  }
   for (int k = 0; k < nd->n(); k++) {
     (void)hipSetDevice(nd->devices[k]);
     if (nd->streams[k]) (void)hipStreamSynchronize(nd->streams[k]);
+  }
+  for (int k = 0; k < nd->n(); k++) {
+    (void)hipSetDevice(nd->devices[k]);
     if (k < (int)nd->comms.size() && nd->comms[k]) nd->rccl->commDestroy(nd->comms[k]);
     if (nd->planes[k]) (void)hipFree(nd->planes[k]);
     if (nd->gatheredPlanes[k]) (void)hipFree(nd->gatheredPlanes[k]);
     if (nd->stats[k]) (void)hipFree(nd->stats[k]);
     if (nd->gatheredStats[k]) (void)hipFree(nd->gatheredStats[k]);
+    if (nd->statsCompact[k]) (void)hipFree(nd->statsCompact[k]);
+    if (nd->pfGathered[k]) (void)hipFree(nd->pfGathered[k]);
+    if (nd->pfAnc[k]) (void)hipFree(nd->pfAnc[k]);
+    if (nd->pfTotals[k]) (void)hipFree(nd->pfTotals[k]);
+    if (nd->evReady[k]) (void)hipEventDestroy(nd->evReady[k]);
+    if (nd->evCopied[k]) (void)hipEventDestroy(nd->evCopied[k]);
     if (nd->batches[k]) sipnet_batch_destroy(nd->batches[k]);
     if (nd->streams[k]) (void)hipStreamDestroy(nd->streams[k]);
   }
@@ -240,28 +417,51 @@ void sipnet_node_destroy(sipnet_node* nd) {
 }
 
 int32_t sipnet_node_n_devices(const sipnet_node* nd) { return nd ? nd->n() : 0; }
+int32_t sipnet_node_shard_mode(const sipnet_node* nd) { return nd ? nd->mode : -1; }
 sipnet_batch* sipnet_node_batch(sipnet_node* nd, int32_t k) {
   return (nd && k >= 0 && k < nd->n()) ? nd->batches[k] : nullptr;
 }
+void* sipnet_node_stream(sipnet_node* nd, int32_t k) { return (nd && k >= 0 && k < nd->n()) ? (void*)nd->streams[k] : nullptr; }
 int sipnet_node_member_range(const sipnet_node* nd, int32_t k, int32_t* first, int32_t* count) {
   if (!nd || k < 0 || k >= nd->n()) return SIPNET_ERR_BAD_ARGUMENT;
   if (first) *first = nd->first[k];
   if (count) *count = nd->count[k];
   return SIPNET_OK;
 }
+int sipnet_node_site_range(const sipnet_node* nd, int32_t k, int32_t* first, int32_t* count) {
+  if (!nd || k < 0 || k >= nd->n()) return SIPNET_ERR_BAD_ARGUMENT;
+  if (first) *first = nd->sites0[k];
+  if (count) *count = nd->nSites[k];
+  return SIPNET_OK;
+}
 int64_t sipnet_node_ld(const sipnet_node* nd) { return nd ? nd->ld : 0; }
 const char* sipnet_node_collective_library(const sipnet_node* nd) {
   static thread_local std::string s;
-  if (!nd || !nd->rccl) return "";
+  if (!nd) return "";
+  if (!nd->rccl) return "event-ordered device copies (shards share a device; no RCCL communicator)";
   int v = 0;
   nd->rccl->getVersion(&v);
   s = nd->rccl->path + " (RCCL " + std::to_string(v) + ")";
   return s.c_str();
 }
 
+// the shard that owns `site` and the site's index inside that shard's batch (member mode: every shard, same index)
+static int ownerOf(const sipnet_node* nd, int32_t site) {
+  for (int k = 0; k < nd->n(); k++)
+    if (site >= nd->sites0[k] && site < nd->sites0[k] + nd->nSites[k]) return k;
+  return -1;
+}
+
 int sipnet_node_set_climate(sipnet_node* nd, int32_t site, int32_t n_steps, const double* clim,
                             const int32_t* year, const int32_t* day) {
-  if (!nd) return SIPNET_ERR_BAD_ARGUMENT;
+  if (!nd || site < 0 || site >= nd->n_sites) {
+    setError("sipnet_node_set_climate: bad argument");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  if (nd->mode == SIPNET_SHARD_SITES) {   // the forcing of a site goes to the ONE shard that owns the site
+    const int k = ownerOf(nd, site);
+    return sipnet_batch_set_climate(nd->batches[k], site - nd->sites0[k], n_steps, clim, year, day);
+  }
   for (int k = 0; k < nd->n(); k++) {
     int rc = sipnet_batch_set_climate(nd->batches[k], site, n_steps, clim, year, day);
     if (rc) return rc;
@@ -269,7 +469,14 @@ int sipnet_node_set_climate(sipnet_node* nd, int32_t site, int32_t n_steps, cons
   return SIPNET_OK;
 }
 int sipnet_node_set_events(sipnet_node* nd, int32_t site, int32_t n_events, const sipnet_event* events) {
-  if (!nd) return SIPNET_ERR_BAD_ARGUMENT;
+  if (!nd || site < 0 || site >= nd->n_sites) {
+    setError("sipnet_node_set_events: bad argument");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  if (nd->mode == SIPNET_SHARD_SITES) {
+    const int k = ownerOf(nd, site);
+    return sipnet_batch_set_events(nd->batches[k], site - nd->sites0[k], n_events, events);
+  }
   for (int k = 0; k < nd->n(); k++) {
     int rc = sipnet_batch_set_events(nd->batches[k], site, n_events, events);
     if (rc) return rc;
@@ -277,15 +484,21 @@ int sipnet_node_set_events(sipnet_node* nd, int32_t site, int32_t n_events, cons
   return SIPNET_OK;
 }
 int sipnet_node_set_params(sipnet_node* nd, int32_t site, int32_t first_member, int32_t count, const double* raw) {
-  if (!nd || !raw || first_member < 0 || count <= 0 || first_member + count > nd->n_members) {
+  if (!nd || !raw || first_member < 0 || count <= 0 || first_member + count > nd->n_members ||
+      (site != SIPNET_ALL_SITES && (site < 0 || site >= nd->n_sites))) {
     setError("sipnet_node_set_params: bad argument");
     return SIPNET_ERR_BAD_ARGUMENT;
   }
-  return onEveryDevice(nd, [&](int k) -> int {
+  return onEveryShard(nd, [&](int k) -> int {
+    int32_t local = site;
+    if (nd->mode == SIPNET_SHARD_SITES && site != SIPNET_ALL_SITES) {
+      if (site < nd->sites0[k] || site >= nd->sites0[k] + nd->nSites[k]) return SIPNET_OK;
+      local = site - nd->sites0[k];
+    }
     const int32_t a = std::max(first_member, nd->first[k]);
     const int32_t z = std::min(first_member + count, nd->first[k] + nd->count[k]);
     if (z <= a) return SIPNET_OK;
-    return sipnet_batch_set_params(nd->batches[k], site, a - nd->first[k], z - a,
+    return sipnet_batch_set_params(nd->batches[k], local, a - nd->first[k], z - a,
                                    raw + (size_t)(a - first_member) * SIPNET_NPARAMS);
   });
 }
@@ -308,18 +521,18 @@ int sipnet_node_set_kernel(sipnet_node* nd, int32_t kernel, int32_t options) {
 
 int sipnet_node_setup(sipnet_node* nd) {
   if (!nd) return SIPNET_ERR_BAD_ARGUMENT;
-  return onEveryDevice(nd, [&](int k) -> int { return sipnet_batch_setup(nd->batches[k], nd->streams[k]); });
+  return onEveryShard(nd, [&](int k) -> int { return sipnet_batch_setup(nd->batches[k], nd->streams[k]); });
 }
 
-int sipnet_node_run(sipnet_node* nd, int32_t step0, int32_t n_steps) {
+static int runShards(sipnet_node* nd, int32_t step0, int32_t n_steps, bool withStats) {
   if (!nd || n_steps <= 0) {
     setError("sipnet_node_run: bad argument");
     return SIPNET_ERR_BAD_ARGUMENT;
   }
   const size_t planeBytes = (size_t)3 * n_steps * nd->ld * nd->elem();
-  const size_t statDoubles = (size_t)3 * n_steps * nd->n_sites * 2;
+  const size_t statDoubles = (size_t)3 * n_steps * nd->maxSites * 2;
   const bool grow = n_steps > nd->nAlloc;
-  int rc = onEveryDevice(nd, [&](int k) -> int {
+  int rc = onEveryShard(nd, [&](int k) -> int {
     if (grow) {
       NODE_HIP(hipStreamSynchronize(nd->streams[k]));
       if (nd->planes[k]) NODE_HIP(hipFree(nd->planes[k]));
@@ -328,13 +541,35 @@ int sipnet_node_run(sipnet_node* nd, int32_t step0, int32_t n_steps) {
       nd->stats[k] = nullptr;
       NODE_HIP(hipMalloc(&nd->planes[k], planeBytes));
       NODE_HIP(hipMalloc(&nd->stats[k], statDoubles * sizeof(double)));
-      // columns past a device's own members (the padding up to the common leading dimension) stay zero
+      // columns past a shard's own (the padding up to the common leading dimension) and the statistics of
+      // sites it does not have stay zero: no kernel ever writes them, whatever the length of a run
       NODE_HIP(hipMemsetAsync(nd->planes[k], 0, planeBytes, nd->streams[k]));
+      NODE_HIP(hipMemsetAsync(nd->stats[k], 0, statDoubles * sizeof(double), nd->streams[k]));
     }
     char* p = (char*)nd->planes[k];
     const size_t one = (size_t)n_steps * nd->ld * nd->elem();
-    return sipnet_batch_run_stats(nd->batches[k], step0, n_steps, p, p + one, p + 2 * one, nd->ld, nd->stats[k],
-                                  nd->streams[k]);
+    if (!withStats)
+      return sipnet_batch_run(nd->batches[k], step0, n_steps, p, p + one, p + 2 * one, nullptr, nd->ld, nd->streams[k]);
+    if (nd->nSites[k] == nd->maxSites)
+      return sipnet_batch_run_stats(nd->batches[k], step0, n_steps, p, p + one, p + 2 * one, nd->ld, nd->stats[k],
+                                    nd->streams[k]);
+    // a shard with fewer sites than the largest: its block [3][n_steps][nSites][2] is produced compactly and spread
+    // out to the common shape [3][n_steps][maxSites][2] (the entries of the sites it does not have stay zero)
+    const size_t compactDoubles = (size_t)3 * n_steps * nd->nSites[k] * 2;
+    if (compactDoubles > nd->statsCompactCap[k]) {
+      NODE_HIP(hipStreamSynchronize(nd->streams[k]));
+      if (nd->statsCompact[k]) NODE_HIP(hipFree(nd->statsCompact[k]));
+      nd->statsCompact[k] = nullptr;
+      NODE_HIP(hipMalloc(&nd->statsCompact[k], compactDoubles * sizeof(double)));
+      nd->statsCompactCap[k] = compactDoubles;
+    }
+    int rc2 = sipnet_batch_run_stats(nd->batches[k], step0, n_steps, p, p + one, p + 2 * one, nd->ld, nd->statsCompact[k],
+                                     nd->streams[k]);
+    if (rc2) return rc2;
+    NODE_HIP(hipMemcpy2DAsync(nd->stats[k], (size_t)nd->maxSites * 2 * sizeof(double), nd->statsCompact[k],
+                              (size_t)nd->nSites[k] * 2 * sizeof(double), (size_t)nd->nSites[k] * 2 * sizeof(double),
+                              (size_t)3 * n_steps, hipMemcpyDeviceToDevice, nd->streams[k]));
+    return SIPNET_OK;
   });
   if (rc) return rc;
   if (grow) nd->nAlloc = n_steps;
@@ -343,11 +578,29 @@ int sipnet_node_run(sipnet_node* nd, int32_t step0, int32_t n_steps) {
   return SIPNET_OK;
 }
 
+int sipnet_node_run(sipnet_node* nd, int32_t step0, int32_t n_steps) { return runShards(nd, step0, n_steps, true); }
+int sipnet_node_forecast(sipnet_node* nd, int32_t step0, int32_t n_steps) { return runShards(nd, step0, n_steps, false); }
+
 int sipnet_node_sync(sipnet_node* nd) {
   if (!nd) return SIPNET_ERR_BAD_ARGUMENT;
   for (int k = 0; k < nd->n(); k++) {
     NODE_HIP(hipSetDevice(nd->devices[k]));
     NODE_HIP(hipStreamSynchronize(nd->streams[k]));
+  }
+  return SIPNET_OK;
+}
+
+int sipnet_node_get_status(sipnet_node* nd, int32_t* status) {
+  if (!nd || !status) return SIPNET_ERR_BAD_ARGUMENT;
+  std::vector<int32_t> loc;
+  for (int k = 0; k < nd->n(); k++) {
+    NODE_HIP(hipSetDevice(nd->devices[k]));
+    loc.resize((size_t)nd->nSites[k] * nd->count[k]);
+    int rc = sipnet_batch_get_status(nd->batches[k], loc.data(), nd->streams[k]);   // synchronises the shard's stream
+    if (rc) return rc;
+    for (int32_t s = 0; s < nd->nSites[k]; s++)
+      memcpy(status + (size_t)(nd->sites0[k] + s) * nd->n_members + nd->first[k], loc.data() + (size_t)s * nd->count[k],
+             (size_t)nd->count[k] * sizeof(int32_t));
   }
   return SIPNET_OK;
 }
@@ -361,14 +614,14 @@ void* sipnet_node_gathered_planes(sipnet_node* nd, int32_t k) {
   return (nd && k >= 0 && k < nd->n()) ? nd->gatheredPlanes[k] : nullptr;
 }
 
-// ONE all-gather: every device's statistics block of the last sipnet_node_run to every device
+// ONE all-gather: every shard's statistics block of the last sipnet_node_run to every shard
 int sipnet_node_gather_stats(sipnet_node* nd, double* host_total) {
   if (!nd || nd->nRun <= 0) {
     setError("sipnet_node_gather_stats: nothing has run");
     return SIPNET_ERR_BAD_ARGUMENT;
   }
   const int n = nd->n();
-  const size_t block = (size_t)3 * nd->nRun * nd->n_sites * 2;  // doubles per device
+  const size_t block = (size_t)3 * nd->nRun * nd->maxSites * 2;  // doubles per shard
   if (block * n > nd->gatheredStatsCap) {
     for (int k = 0; k < n; k++) {
       NODE_HIP(hipSetDevice(nd->devices[k]));
@@ -379,39 +632,53 @@ int sipnet_node_gather_stats(sipnet_node* nd, double* host_total) {
     }
     nd->gatheredStatsCap = block * n;
   }
-  NODE_RCCL(nd, nd->rccl->groupStart());
-  for (int k = 0; k < n; k++) {
-    NODE_HIP(hipSetDevice(nd->devices[k]));
-    NODE_RCCL(nd, nd->rccl->allGather(nd->stats[k], nd->gatheredStats[k], block, ncclDouble, nd->comms[k], nd->streams[k]));
+  if (!nd->comms.empty()) {   // one thread, the per-device calls of the collective fused (RCCL's single-process idiom)
+    NODE_RCCL(nd, nd->rccl->groupStart());
+    for (int k = 0; k < n; k++) {
+      NODE_HIP(hipSetDevice(nd->devices[k]));
+      NODE_RCCL(nd, nd->rccl->allGather(nd->stats[k], nd->gatheredStats[k], block, ncclDouble, nd->comms[k], nd->streams[k]));
+    }
+    NODE_RCCL(nd, nd->rccl->groupEnd());
+  } else {
+    int rc = onEveryShard(nd, [&](int k) -> int {
+      return allGatherShard(nd, k, nd->stats[k], nd->gatheredStats[k], block * sizeof(double));
+    });
+    if (rc) return rc;
   }
-  NODE_RCCL(nd, nd->rccl->groupEnd());
-  if (host_total) {  // the ensemble's totals: the devices' blocks added up in device order (deterministic)
+  if (host_total) {
+    // the ensemble's totals [3][n_run][n_sites][2]: members sharded -- the shards' blocks added up in shard order
+    // (deterministic); sites sharded -- shard k's sites stand at sites0[k] .. (concatenation along the site axis)
     std::vector<double> all(block * n);
     NODE_HIP(hipSetDevice(nd->devices[0]));
-    NODE_HIP(hipStreamSynchronize(nd->streams[0]));
+    NODE_HIP(hipStreamSynchronize(nd->streams[0]));   // shard 0's copy of everybody's block: complete when its all-gather is
     NODE_HIP(hipMemcpy(all.data(), nd->gatheredStats[0], all.size() * sizeof(double), hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < block; i++) {
-      double s = 0.0;
-      for (int k = 0; k < n; k++) s += all[(size_t)k * block + i];
-      host_total[i] = s;
+    if (nd->mode == SIPNET_SHARD_MEMBERS) {
+      for (size_t i = 0; i < block; i++) {
+        double s = 0.0;
+        for (int k = 0; k < n; k++) s += all[(size_t)k * block + i];
+        host_total[i] = s;
+      }
+    } else {
+      for (int k = 0; k < n; k++)
+        for (size_t vt = 0; vt < (size_t)3 * nd->nRun; vt++)
+          memcpy(host_total + (vt * nd->n_sites + nd->sites0[k]) * 2, all.data() + (size_t)k * block + vt * nd->maxSites * 2,
+                 (size_t)nd->nSites[k] * 2 * sizeof(double));
     }
   }
   return SIPNET_OK;
 }
 
-// ONE all-gather of the member-resolved planes of the last run: on every device
-// gathered[(k * 3 + v) * n_steps + t][ld] = device k's plane v (columns past its members are zero)
+// ONE all-gather of the member-resolved planes of the last run: on every shard
+// gathered[(k * 3 + v) * n_run + t][ld] = shard k's plane v; inside a row shard k's column of (its local site s,
+// its member m) is s * count_k + m -- the site stride is the SHARD's member count, not the common maximum --
+// and the columns from n_sites_k * count_k to ld are zero
 int sipnet_node_gather_planes(sipnet_node* nd) {
   if (!nd || nd->nRun <= 0) {
     setError("sipnet_node_gather_planes: nothing has run");
     return SIPNET_ERR_BAD_ARGUMENT;
   }
-  if (nd->nRun != nd->nAlloc) {
-    setError("sipnet_node_gather_planes: the last run must fill the plane buffers (run the longest segment last)");
-    return SIPNET_ERR_BAD_ARGUMENT;
-  }
   const int n = nd->n();
-  const size_t count = (size_t)3 * nd->nRun * nd->ld;  // elements per device
+  const size_t count = (size_t)3 * nd->nRun * nd->ld;  // elements per shard
   if (count * n > nd->gatheredPlanesCap) {
     for (int k = 0; k < n; k++) {
       NODE_HIP(hipSetDevice(nd->devices[k]));
@@ -422,14 +689,103 @@ int sipnet_node_gather_planes(sipnet_node* nd) {
     }
     nd->gatheredPlanesCap = count * n;
   }
-  NODE_RCCL(nd, nd->rccl->groupStart());
-  for (int k = 0; k < n; k++) {
-    NODE_HIP(hipSetDevice(nd->devices[k]));
-    NODE_RCCL(nd, nd->rccl->allGather(nd->planes[k], nd->gatheredPlanes[k], count,
-                                      nd->precision == SIPNET_F64 ? ncclDouble : ncclFloat, nd->comms[k], nd->streams[k]));
+  if (!nd->comms.empty()) {
+    NODE_RCCL(nd, nd->rccl->groupStart());
+    for (int k = 0; k < n; k++) {
+      NODE_HIP(hipSetDevice(nd->devices[k]));
+      NODE_RCCL(nd, nd->rccl->allGather(nd->planes[k], nd->gatheredPlanes[k], count,
+                                        nd->precision == SIPNET_F64 ? ncclDouble : ncclFloat, nd->comms[k], nd->streams[k]));
+    }
+    NODE_RCCL(nd, nd->rccl->groupEnd());
+    return SIPNET_OK;
   }
-  NODE_RCCL(nd, nd->rccl->groupEnd());
+  return onEveryShard(nd, [&](int k) -> int {
+    return allGatherShard(nd, k, nd->planes[k], nd->gatheredPlanes[k], count * nd->elem());
+  });
+}
+
+// ---- particle filter over the node's shards (BASELINE config C5; SURVEY 8(e) "PF extra exchange") --------------
+int sipnet_node_pf_connect(sipnet_node* nd, int32_t with_params) {
+  if (!nd || nd->mode != SIPNET_SHARD_MEMBERS || nd->n_sites != 1 || nd->n() > 16) {
+    setError("sipnet_node_pf_connect: a filter needs ONE site, its particles sharded as members over at most 16 devices");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  const int n = nd->n();
+  std::vector<sipnet_pf_peer> peers(n);
+  int rc = onEveryShard(nd, [&](int k) -> int { return sipnet_batch_pf_publish(nd->batches[k], with_params, &peers[k]); });
+  if (rc) return rc;
+  rc = onEveryShard(nd, [&](int k) -> int {
+    int r2 = sipnet_batch_pf_connect(nd->batches[k], n, k, peers.data());
+    if (r2) return r2;
+    NODE_HIP(hipStreamSynchronize(nd->streams[k]));
+    if (nd->pfGathered[k]) NODE_HIP(hipFree(nd->pfGathered[k]));
+    if (nd->pfAnc[k]) NODE_HIP(hipFree(nd->pfAnc[k]));
+    if (nd->pfTotals[k]) NODE_HIP(hipFree(nd->pfTotals[k]));
+    nd->pfGathered[k] = nullptr;
+    nd->pfAnc[k] = nullptr;
+    nd->pfTotals[k] = nullptr;
+    const int64_t L = sipnet_batch_pf_block_len(nd->batches[k]);
+    NODE_HIP(hipMalloc(&nd->pfGathered[k], (size_t)n * L * sizeof(double)));
+    NODE_HIP(hipMalloc(&nd->pfAnc[k], (size_t)nd->count[k] * sizeof(int32_t)));
+    NODE_HIP(hipMalloc(&nd->pfTotals[k], sipnet_node::kPfTotals * sizeof(int64_t)));
+    NODE_HIP(hipMemset(nd->pfTotals[k], 0xff, sipnet_node::kPfTotals * sizeof(int64_t)));   // -1: "no cycle wrote this slot"
+    return SIPNET_OK;
+  });
+  if (rc) return rc;
+  nd->pfBlock = sipnet_batch_pf_block_len(nd->batches[0]);
+  nd->pfConnected = true;
+  nd->pfCycles = 0;
   return SIPNET_OK;
 }
+
+int sipnet_node_pf_analysis(sipnet_node* nd, int32_t variable, double obs, double sigma, double u0) {
+  if (!nd || !nd->pfConnected || nd->nRun <= 0 || variable < 0 || variable > 2) {
+    setError("sipnet_node_pf_analysis: needs sipnet_node_pf_connect and a forecast (sipnet_node_forecast / _run)");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  const int slot = nd->pfCycles % sipnet_node::kPfTotals;
+  int rc = onEveryShard(nd, [&](int k) -> int {
+    const char* plane = (const char*)nd->planes[k] + (size_t)variable * nd->nRun * nd->ld * nd->elem();
+    double* mine = nd->pfGathered[k] + (size_t)k * nd->pfBlock;
+    int r2 = sipnet_batch_pf_local_weights(nd->batches[k], plane, nd->precision == SIPNET_F32_MIXED, nd->nRun, nd->ld, obs,
+                                           sigma, mine, nd->streams[k]);
+    if (r2) return r2;
+    r2 = allGatherShard(nd, k, mine, nd->pfGathered[k], (size_t)nd->pfBlock * sizeof(double));   // in place
+    if (r2) return r2;
+    return sipnet_batch_pf_resample_peers(nd->batches[k], nd->pfGathered[k], u0, nd->pfAnc[k], nd->pfTotals[k] + slot,
+                                          nd->streams[k]);
+  });
+  if (rc) return rc;
+  nd->pfCycles++;
+  return SIPNET_OK;
+}
+
+int sipnet_node_pf_check(sipnet_node* nd, int32_t* n_cycles_checked) {
+  if (!nd || !nd->pfConnected) return SIPNET_ERR_BAD_ARGUMENT;
+  const int m = std::min<int>(nd->pfCycles, sipnet_node::kPfTotals);
+  std::vector<int64_t> t0(sipnet_node::kPfTotals), tk(sipnet_node::kPfTotals);
+  for (int k = 0; k < nd->n(); k++) {
+    NODE_HIP(hipSetDevice(nd->devices[k]));
+    NODE_HIP(hipStreamSynchronize(nd->streams[k]));
+    NODE_HIP(hipMemcpy(tk.data(), nd->pfTotals[k], tk.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (k == 0) t0 = tk;
+    for (int c = 0; c < m; c++) {
+      if (tk[c] != t0[c]) {
+        setError("sipnet_node_pf_check: the shards disagree on a cycle's total weight (the gathered blocks differ)");
+        return SIPNET_ERR_INTERNAL;
+      }
+      if (tk[c] <= 0) {
+        setError("sipnet_node_pf_check: a cycle ended with every particle at zero weight");
+        return SIPNET_ERR_BAD_PARAMETER;
+      }
+    }
+  }
+  if (n_cycles_checked) *n_cycles_checked = m;
+  nd->pfCycles = 0;
+  return SIPNET_OK;
+}
+
+int32_t* sipnet_node_pf_ancestors(sipnet_node* nd, int32_t k) { return (nd && k >= 0 && k < nd->n()) ? nd->pfAnc[k] : nullptr; }
+int64_t sipnet_node_pf_block_len(const sipnet_node* nd) { return nd ? nd->pfBlock : 0; }
 
 }  // extern "C"

@@ -14,10 +14,14 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <unistd.h>
+
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <limits>
 #include <string>
+#include <vector>
 
 #include "../../include/sipnet_amd.h"
 #include "batch_impl.h"
@@ -134,10 +138,12 @@ __global__ __launch_bounds__(256) void logWeightKernel(const T* __restrict__ pla
                                                        int64_t ld, int64_t ncol,
                                                        const double* __restrict__ status,
                                                        double obs, double invSigma,
-                                                       double* __restrict__ logw, double* __restrict__ part) {
+                                                       double* __restrict__ logw, double* __restrict__ part,
+                                                       int64_t npad) {
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   double mine = -INFINITY;
   if (c < ncol) mine = logWeightOf(plane, nSteps, ld, c, status, obs, invSigma, logw);
+  else if (c < npad) logw[c] = -INFINITY;   // slots of a rank's block no particle fills (ragged shards): weight zero
   if (part) {
     __shared__ double sm[256];
     sm[threadIdx.x] = mine;
@@ -191,18 +197,21 @@ __global__ __launch_bounds__(256) void fixedWeightKernel(const double* __restric
   w[i] = (!(logw[i] > -INFINITY) || !(m > -INFINITY)) ? 0 : llrint(e * 1073741824.0);
 }
 
-// ancestor[j] = first i with cdf[i] > p_j, p_j = ((j + u0) * S) / n  (S = cdf[n-1] < 2^53)
+// ancestor[j] = first slot i with cdf[i] > p_j, p_j = ((j0 + j + u0) * S) / nTotal  (S = cdf[nSlots-1] < 2^53)
+// for the nOut particles j0 .. j0 + nOut - 1 of a filter of nTotal particles whose weights sit in nSlots >= nTotal
+// slots (one rank: nSlots = nTotal = nOut, j0 = 0; several ranks: a rank resamples its own particles over the
+// gathered weights of all, and slots no particle fills weigh nothing)
 // (total, if wanted: the total integer weight, for the caller's "a particle survived" check)
-__global__ __launch_bounds__(256) void ancestorKernel(const int64_t* __restrict__ cdf, int64_t n,
-                                                      double u0, int32_t* __restrict__ anc,
-                                                      int64_t* __restrict__ total) {
+__global__ __launch_bounds__(256) void ancestorKernel(const int64_t* __restrict__ cdf, int64_t nSlots, int64_t j0,
+                                                      int64_t nOut, int64_t nTotal, double u0,
+                                                      int32_t* __restrict__ anc, int64_t* __restrict__ total) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
-  if (j == 0 && total) *total = cdf[n - 1];
-  const double S = (double)cdf[n - 1];
+  if (j >= nOut) return;
+  if (j == 0 && total) *total = cdf[nSlots - 1];
+  const double S = (double)cdf[nSlots - 1];
   // S - 1 keeps the search inside the support when (j + u0) rounds up to n
-  const double p = fmin((((double)j + u0) * S) / (double)n, S - 1.0);
-  int64_t lo = 0, hi = n - 1;  // invariant: answer in [lo, hi]
+  const double p = fmin((((double)(j0 + j) + u0) * S) / (double)nTotal, S - 1.0);
+  int64_t lo = 0, hi = nSlots - 1;  // invariant: answer in [lo, hi]
   while (lo < hi) {
     const int64_t mid = (lo + hi) >> 1;
     if ((double)cdf[mid] > p) {
@@ -212,6 +221,84 @@ __global__ __launch_bounds__(256) void ancestorKernel(const int64_t* __restrict_
     }
   }
   anc[j] = (int32_t)lo;
+}
+
+// ---- a filter spread over ranks, without an all-to-all: every rank reads the ancestors it needs straight out
+// of its peers' checkpoint matrices (peer-mapped HBM over xGMI; sipnet_batch_pf_publish / _connect) -------------
+// What the ranks all-gather is one block per rank: [nmax log-weights (slots past the rank's own particles: -inf) |
+// P = ceil(nmax / 256) block maxima of them], stride = nmax + P doubles.  Slot s * nmax + c = particle c of rank s.
+constexpr int kMaxPeers = 16;
+struct PeerPtrs {            // kernel argument: where rank s keeps its particles' checkpoint matrices
+  int32_t world, nmax;
+  const double* state[kMaxPeers];
+  const void* ring[kMaxPeers];
+  const double* prm[kMaxPeers];
+  int32_t pitch[kMaxPeers];  // particles of rank s = the leading dimension of its matrices
+};
+// fixed-point weights of all slots (fixedWeightKernel over the gathered blocks)
+__global__ __launch_bounds__(256) void fixedWeightGatheredKernel(const double* __restrict__ gathered, int32_t world,
+                                                                 int32_t nmax, int64_t stride, int64_t* __restrict__ w) {
+  __shared__ double sm[256];
+  const int P = (nmax + 255) / 256;
+  double pm = -INFINITY;
+  for (int k = threadIdx.x; k < world * P; k += 256) pm = fmax(pm, gathered[(int64_t)(k / P) * stride + nmax + k % P]);
+  sm[threadIdx.x] = pm;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sm[threadIdx.x] = fmax(sm[threadIdx.x], sm[threadIdx.x + s]);
+    __syncthreads();
+  }
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)world * nmax) return;
+  const double m = sm[0];
+  const double lw = gathered[(i / nmax) * stride + i % nmax];
+  const double e = exp(lw - m);
+  w[i] = (!(lw > -INFINITY) || !(m > -INFINITY)) ? 0 : llrint(e * 1073741824.0);
+}
+// dst[row][j] = matrix of rank (anc[j] / nmax)[row][anc[j] % nmax] for the three matrices of a checkpoint
+struct PeerPart {
+  void* dst;
+  int32_t rows, group0, elem4;
+};
+struct PeerParts {
+  PeerPart p[3];
+  int32_t n;
+};
+template <typename T>
+__device__ __forceinline__ void gatherPeerRows(const T* __restrict__ p, int64_t srcPitch, T* __restrict__ q,
+                                               int64_t dstPitch, int nr) {
+  T v[kGatherRows];
+  if (nr == kGatherRows) {
+#pragma unroll
+    for (int r = 0; r < kGatherRows; r++) v[r] = p[(int64_t)r * srcPitch];
+#pragma unroll
+    for (int r = 0; r < kGatherRows; r++) q[(int64_t)r * dstPitch] = v[r];
+  } else {
+    for (int r = 0; r < nr; r++) v[r] = p[(int64_t)r * srcPitch];
+    for (int r = 0; r < nr; r++) q[(int64_t)r * dstPitch] = v[r];
+  }
+}
+__global__ __launch_bounds__(256) void gatherPeerKernel(PeerParts parts, PeerPtrs peers,
+                                                        const int32_t* __restrict__ anc, int64_t nOut,
+                                                        int64_t dstPitch) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nOut) return;
+  int k = 0;
+  for (int q = 1; q < parts.n; q++)
+    if ((int)blockIdx.y >= parts.p[q].group0) k = q;
+  const PeerPart part = parts.p[k];
+  const int row0 = ((int)blockIdx.y - part.group0) * kGatherRows;
+  const int nr = part.rows - row0 < kGatherRows ? part.rows - row0 : kGatherRows;
+  const int32_t a = anc[j];
+  const int s = a / peers.nmax;
+  const int64_t c = a - s * peers.nmax, pitch = peers.pitch[s];
+  const void* base = k == 0 ? (const void*)peers.state[s] : k == 1 ? peers.ring[s] : (const void*)peers.prm[s];
+  if (part.elem4)
+    gatherPeerRows<float>((const float*)base + (int64_t)row0 * pitch + c, pitch, (float*)part.dst + (int64_t)row0 * dstPitch + j,
+                          dstPitch, nr);
+  else
+    gatherPeerRows<double>((const double*)base + (int64_t)row0 * pitch + c, pitch,
+                           (double*)part.dst + (int64_t)row0 * dstPitch + j, dstPitch, nr);
 }
 
 // 1 when any member needs the generic-exponent kernel variant (dVpdExp != 2 or
@@ -343,6 +430,20 @@ void launchGatherMember(const double* state, const void* ring, bool ringF32, con
 
 using namespace sipnet;
 
+// Host side of PeerPtrs: for each of the two buffers a batch's checkpoint matrices alternate between (a resampling
+// gathers into the spare and swaps), where every rank keeps them.  All ranks resample in lockstep, so the local
+// parity says which buffer is current everywhere.
+struct PfPeers {
+  int32_t world = 1, rank = 0, nmax = 0, withParams = 0;
+  int64_t nTotal = 0, first = 0;       // particles of all ranks; global index of this rank's first particle
+  int32_t count[kMaxPeers] = {};
+  const double* state[2][kMaxPeers] = {};
+  const void* ring[2][kMaxPeers] = {};
+  const double* prm[2][kMaxPeers] = {};
+  std::vector<void*> opened;           // hipIpcOpenMemHandle mappings, closed on release
+  int parity = 0;
+};
+
 extern "C" {
 
 int32_t sipnet_pf_member_words(int32_t with_params) {
@@ -355,8 +456,9 @@ int32_t sipnet_batch_member_words(const sipnet_batch* b, int32_t with_params) {
 }
 
 // d_part (optional, DEVICE, one double per 256 columns): the blocks' maxima, for the resampling that follows
+// (npad >= ncol: log-weight slots to fill, the ones past the batch's particles with -inf)
 static int logWeights(sipnet_batch* b, const void* d_plane, int32_t elem_is_f32, int32_t n_steps, int64_t ld,
-                      double obs, double sigma, double* d_logw, double* d_part, void* hip_stream) {
+                      double obs, double sigma, double* d_logw, double* d_part, void* hip_stream, int64_t npad = 0) {
   if (!b || !d_plane || !d_logw || n_steps <= 0 || ld < b->ncol || !(sigma > 0)) {
     setError("sipnet_batch_pf_log_weights: bad argument");
     return SIPNET_ERR_BAD_ARGUMENT;
@@ -364,14 +466,15 @@ static int logWeights(sipnet_batch* b, const void* d_plane, int32_t elem_is_f32,
   int rc = useDevice(b);
   if (rc) return rc;
   hipStream_t stream = (hipStream_t)hip_stream;
-  const int grid = (int)((b->ncol + 255) / 256);
+  if (npad < b->ncol) npad = b->ncol;
+  const int grid = (int)((npad + 255) / 256);
   const double* status = b->d_state + (size_t)ST_status * b->ncol;
   if (elem_is_f32) {
     hipLaunchKernelGGL(logWeightKernel<float>, dim3(grid), dim3(256), 0, stream,
-                       (const float*)d_plane, n_steps, ld, b->ncol, status, obs, 1.0 / sigma, d_logw, d_part);
+                       (const float*)d_plane, n_steps, ld, b->ncol, status, obs, 1.0 / sigma, d_logw, d_part, npad);
   } else {
     hipLaunchKernelGGL(logWeightKernel<double>, dim3(grid), dim3(256), 0, stream,
-                       (const double*)d_plane, n_steps, ld, b->ncol, status, obs, 1.0 / sigma, d_logw, d_part);
+                       (const double*)d_plane, n_steps, ld, b->ncol, status, obs, 1.0 / sigma, d_logw, d_part, npad);
   }
   HIP_TRY(hipGetLastError());
   return SIPNET_OK;
@@ -383,8 +486,8 @@ extern "C" int sipnet_batch_pf_log_weights(sipnet_batch* b, const void* d_plane,
   return logWeights(b, d_plane, elem_is_f32, n_steps, ld, obs, sigma, d_logw, nullptr, hip_stream);
 }
 
-namespace {
-// scratch of the resampling, kept between calls (one per host thread and device)
+// scratch of the resampling, kept between calls: one per batch for the sipnet_batch_pf_* entry points (freed by
+// sipnet_batch_destroy), one per host thread for the batch-less sipnet_pf_* ones (sipnet_pf_release_scratch)
 struct PfScratch {
   int device = -1;
   int64_t cap = 0;
@@ -402,15 +505,15 @@ struct PfScratch {
   }
   // no destructor: a thread_local's would run at thread exit, possibly after the HIP runtime is gone
 };
+namespace {
 constexpr int kMaxParts = 256;
 thread_local PfScratch g_pf;
 }  // namespace
 
-// scratch of the calling thread for n weights (the partial maxima: one per 256 of them at most)
-static int pfScratchFor(int64_t n, hipStream_t stream) {
+// scratch for n weights (the partial maxima: one per 256 of them at most)
+static int pfScratchFor(PfScratch& sc, int64_t n, hipStream_t stream) {
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
-  PfScratch& sc = g_pf;
   if (sc.device != dev || sc.cap < n) {
     sc.release();
     sc.device = dev;
@@ -423,18 +526,21 @@ static int pfScratchFor(int64_t n, hipStream_t stream) {
   }
   return SIPNET_OK;
 }
+static PfScratch& scratchOf(sipnet_batch* b) {
+  if (!b->pfScratch) b->pfScratch = new PfScratch();
+  return *b->pfScratch;
+}
 
 // partsGiven > 0: the partial maxima of d_logw are in the scratch block already (logWeights put them there)
-static int ancestorsImpl(const double* d_logw, int64_t n, double u0, int32_t* d_ancestors, int64_t* d_fixed_weights,
-                         int64_t* d_total, int partsGiven, void* hip_stream) {
+static int ancestorsImpl(PfScratch& sc, const double* d_logw, int64_t n, double u0, int32_t* d_ancestors,
+                         int64_t* d_fixed_weights, int64_t* d_total, int partsGiven, void* hip_stream) {
   if (!d_logw || !d_ancestors || n <= 0 || n > (int64_t)1 << 22 || !(u0 >= 0.0) || !(u0 < 1.0)) {
     setError("sipnet_pf_systematic_ancestors: bad argument (n <= 4194304, 0 <= u0 < 1)");
     return SIPNET_ERR_BAD_ARGUMENT;
   }
   hipStream_t stream = (hipStream_t)hip_stream;
-  int rc = pfScratchFor(n, stream);
+  int rc = pfScratchFor(sc, n, stream);
   if (rc) return rc;
-  PfScratch& sc = g_pf;
   const int grid = (int)((n + 255) / 256);
   int parts = partsGiven;
   if (parts <= 0) {
@@ -444,7 +550,8 @@ static int ancestorsImpl(const double* d_logw, int64_t n, double u0, int32_t* d_
   hipLaunchKernelGGL(fixedWeightKernel, dim3(grid), dim3(256), 0, stream, d_logw, n, sc.d_max, parts, sc.d_w);
   size_t tmpBytes = sc.tmpBytes;
   HIP_TRY(hipcub::DeviceScan::InclusiveSum(sc.d_tmp, tmpBytes, sc.d_w, sc.d_cdf, (int)n, stream));
-  hipLaunchKernelGGL(ancestorKernel, dim3(grid), dim3(256), 0, stream, sc.d_cdf, n, u0, d_ancestors, d_total);
+  hipLaunchKernelGGL(ancestorKernel, dim3(grid), dim3(256), 0, stream, sc.d_cdf, n, (int64_t)0, n, n, u0, d_ancestors,
+                     d_total);
   HIP_TRY(hipGetLastError());
   if (d_fixed_weights)
     HIP_TRY(hipMemcpyAsync(d_fixed_weights, sc.d_w, (size_t)n * sizeof(int64_t),
@@ -455,7 +562,7 @@ static int ancestorsImpl(const double* d_logw, int64_t n, double u0, int32_t* d_
 extern "C" int sipnet_pf_systematic_ancestors_async(const double* d_logw, int64_t n, double u0,
                                                     int32_t* d_ancestors, int64_t* d_fixed_weights,
                                                     int64_t* d_total, void* hip_stream) {
-  return ancestorsImpl(d_logw, n, u0, d_ancestors, d_fixed_weights, d_total, 0, hip_stream);
+  return ancestorsImpl(g_pf, d_logw, n, u0, d_ancestors, d_fixed_weights, d_total, 0, hip_stream);
 }
 
 int sipnet_pf_systematic_ancestors(const double* d_logw, int64_t n, double u0,
@@ -618,6 +725,7 @@ int sipnet_batch_resample(sipnet_batch* b, const int32_t* d_src, const double* d
   std::swap(b->d_state, b->d_state2);
   std::swap(b->d_ring, b->d_ring2);
   if (with_params) std::swap(b->d_prm, b->d_prm2);
+  if (b->pfPeers) b->pfPeers->parity ^= 1;   // (connected ranks resample in lockstep, whichever entry point they use)
   if (with_params && start > 0) {
     // parameters that arrived from other ranks may change which kernel variant the batch needs
     int32_t* d_flag = nullptr;
@@ -643,16 +751,17 @@ int sipnet_batch_pf_analysis(sipnet_batch* b, const void* d_plane, int32_t elem_
   }
   int rc = useDevice(b);
   if (rc) return rc;
-  rc = pfScratchFor(b->ncol, (hipStream_t)hip_stream);
+  PfScratch& sc = scratchOf(b);
+  rc = pfScratchFor(sc, b->ncol, (hipStream_t)hip_stream);
   if (rc) return rc;
   // the log-weight kernel leaves its blocks' maxima where the resampling looks for them
-  rc = logWeights(b, d_plane, elem_is_f32, n_steps, ld, obs, sigma, d_logw, g_pf.d_max, hip_stream);
+  rc = logWeights(b, d_plane, elem_is_f32, n_steps, ld, obs, sigma, d_logw, sc.d_max, hip_stream);
   if (rc) return rc;
-  rc = ancestorsImpl(d_logw, b->ncol, u0, d_ancestors, nullptr, d_total, (int)((b->ncol + 255) / 256), hip_stream);
+  rc = ancestorsImpl(sc, d_logw, b->ncol, u0, d_ancestors, nullptr, d_total, (int)((b->ncol + 255) / 256), hip_stream);
   if (rc) return rc;
   if (!d_total) {   // the synchronous check of sipnet_pf_systematic_ancestors
     int64_t total = 0;
-    HIP_TRY(hipMemcpyAsync(&total, g_pf.d_cdf + (b->ncol - 1), sizeof(int64_t), hipMemcpyDeviceToHost, (hipStream_t)hip_stream));
+    HIP_TRY(hipMemcpyAsync(&total, sc.d_cdf + (b->ncol - 1), sizeof(int64_t), hipMemcpyDeviceToHost, (hipStream_t)hip_stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)hip_stream));
     if (total <= 0) {
       setError("sipnet_batch_pf_analysis: every particle has zero weight");
@@ -660,6 +769,237 @@ int sipnet_batch_pf_analysis(sipnet_batch* b, const void* d_plane, int32_t elem_
     }
   }
   return sipnet_batch_resample(b, d_ancestors, nullptr, 0, nullptr, with_params, hip_stream);
+}
+
+}  // extern "C"
+
+// ---- the filter across ranks by peer reads --------------------------------------------------------------------
+void pfRelease(sipnet_batch* b) {
+  if (b->pfScratch) {
+    b->pfScratch->release();
+    delete b->pfScratch;
+    b->pfScratch = nullptr;
+  }
+  if (b->pfPeers) {
+    for (void* p : b->pfPeers->opened) (void)hipIpcCloseMemHandle(p);
+    delete b->pfPeers;
+    b->pfPeers = nullptr;
+  }
+}
+
+static_assert(sizeof(hipIpcMemHandle_t) <= sizeof(((sipnet_pf_peer*)nullptr)->ipc[0]), "sipnet_pf_peer::ipc holds a hipIpcMemHandle_t");
+
+static int ensureSpares(sipnet_batch* b, bool withParams) {
+  const size_t nc = (size_t)b->ncol;
+  if (!b->d_state2) HIP_TRY(hipMalloc(&b->d_state2, nc * SIPNET_NSTATE * sizeof(double)));
+  if (!b->d_ring2) HIP_TRY(hipMalloc(&b->d_ring2, nc * SIPNET_RING_SLOTS * ringElemBytes(b)));
+  if (withParams && !b->d_prm2) HIP_TRY(hipMalloc(&b->d_prm2, nc * SIPNET_NPARAMS * sizeof(double)));
+  return SIPNET_OK;
+}
+
+extern "C" {
+
+int sipnet_batch_pf_publish(sipnet_batch* b, int32_t with_params, sipnet_pf_peer* out) {
+  if (!b || !out) {
+    setError("sipnet_batch_pf_publish: bad argument");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  if (b->n_sites != 1) {
+    setError("sipnet_batch_pf_publish: particles of different sites must not mix (n_sites must be 1)");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  int rc = useDevice(b);
+  if (rc) return rc;
+  rc = ensureSpares(b, with_params != 0);
+  if (rc) return rc;
+  memset(out, 0, sizeof *out);
+  out->process_id = (int64_t)getpid();
+  out->device = b->device;
+  out->n_particles = (int32_t)b->ncol;
+  out->precision = b->precision;
+  out->with_params = with_params ? 1 : 0;
+  out->generic_exponents = b->genericExponents ? 1 : 0;
+  void* ptr[6] = {b->d_state, b->d_state2, b->d_ring, b->d_ring2, with_params ? b->d_prm : nullptr,
+                  with_params ? b->d_prm2 : nullptr};
+  out->ipc_valid = 1;
+  for (int k = 0; k < 6; k++) {
+    out->address[k] = (uint64_t)(uintptr_t)ptr[k];
+    if (!ptr[k]) continue;
+    hipIpcMemHandle_t h;
+    if (hipIpcGetMemHandle(&h, ptr[k]) != hipSuccess) {   // peers inside this process do not need it
+      (void)hipGetLastError();
+      out->ipc_valid = 0;
+      continue;
+    }
+    memcpy(out->ipc[k], &h, sizeof h);
+  }
+  return SIPNET_OK;
+}
+
+int sipnet_batch_pf_connect(sipnet_batch* b, int32_t world, int32_t rank, const sipnet_pf_peer* peers) {
+  if (!b || !peers || world < 1 || world > kMaxPeers || rank < 0 || rank >= world) {
+    setError("sipnet_batch_pf_connect: bad argument (world <= 16)");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  int rc = useDevice(b);
+  if (rc) return rc;
+  const sipnet_pf_peer& me = peers[rank];
+  if (me.process_id != (int64_t)getpid() || me.address[0] != (uint64_t)(uintptr_t)b->d_state ||
+      me.address[1] != (uint64_t)(uintptr_t)b->d_state2 || me.n_particles != b->ncol) {
+    setError("sipnet_batch_pf_connect: peers[rank] is not what this batch published (publish, then connect, with no "
+             "resampling in between)");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  if (b->pfPeers) {
+    for (void* p : b->pfPeers->opened) (void)hipIpcCloseMemHandle(p);
+    delete b->pfPeers;
+    b->pfPeers = nullptr;
+  }
+  PfPeers* pp = new PfPeers();
+  pp->world = world;
+  pp->rank = rank;
+  pp->withParams = me.with_params;
+  bool generic = false;
+  auto fail = [&](const std::string& why, int code) {
+    for (void* p : pp->opened) (void)hipIpcCloseMemHandle(p);
+    delete pp;
+    setError("sipnet_batch_pf_connect: " + why);
+    return code;
+  };
+  for (int s = 0; s < world; s++) {
+    const sipnet_pf_peer& q = peers[s];
+    if (q.precision != me.precision || q.with_params != me.with_params || q.n_particles <= 0)
+      return fail("rank " + std::to_string(s) + " published another precision / parameter mode", SIPNET_ERR_BAD_ARGUMENT);
+    pp->count[s] = q.n_particles;
+    if (q.n_particles > pp->nmax) pp->nmax = q.n_particles;
+    if (s < rank) pp->first += q.n_particles;
+    pp->nTotal += q.n_particles;
+    generic = generic || q.generic_exponents != 0;
+    void* ptr[6];
+    if (q.process_id == me.process_id) {   // same process (the node object): the addresses themselves
+      for (int k = 0; k < 6; k++) ptr[k] = (void*)(uintptr_t)q.address[k];
+      if (q.device != b->device) {
+        hipError_t e = hipDeviceEnablePeerAccess(q.device, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+          return fail(std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e), SIPNET_ERR_NO_DEVICE);
+        (void)hipGetLastError();
+      }
+    } else {                               // another process: map its allocations (dmabuf IPC)
+      if (!q.ipc_valid) return fail("rank " + std::to_string(s) + " could not export IPC handles", SIPNET_ERR_NO_DEVICE);
+      for (int k = 0; k < 6; k++) {
+        ptr[k] = nullptr;
+        if (!q.address[k]) continue;
+        hipIpcMemHandle_t h;
+        memcpy(&h, q.ipc[k], sizeof h);
+        hipError_t e = hipIpcOpenMemHandle(&ptr[k], h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) return fail(std::string("hipIpcOpenMemHandle: ") + hipGetErrorString(e), SIPNET_ERR_NO_DEVICE);
+        pp->opened.push_back(ptr[k]);
+      }
+    }
+    for (int par = 0; par < 2; par++) {
+      pp->state[par][s] = (const double*)ptr[0 + par];
+      pp->ring[par][s] = ptr[2 + par];
+      pp->prm[par][s] = (const double*)ptr[4 + par];
+    }
+  }
+  if ((int64_t)world * pp->nmax > (int64_t)1 << 22) return fail("more than 4 194 304 weight slots", SIPNET_ERR_BAD_ARGUMENT);
+  // particles carry their parameters between ranks: every rank runs the kernel variant the most general
+  // parameter set anywhere needs (decided here, once -- not by a device -> host check after every exchange)
+  if (generic && me.with_params) b->genericExponents = true;
+  b->pfPeers = pp;
+  return SIPNET_OK;
+}
+
+int64_t sipnet_batch_pf_block_len(const sipnet_batch* b) {
+  if (!b) return -1;
+  const int64_t nmax = b->pfPeers ? b->pfPeers->nmax : b->ncol;
+  return nmax + (nmax + 255) / 256;
+}
+
+int sipnet_batch_pf_local_weights(sipnet_batch* b, const void* d_plane, int32_t elem_is_f32, int32_t n_steps,
+                                  int64_t ld, double obs, double sigma, double* d_block, void* hip_stream) {
+  if (!b || !d_block) {
+    setError("sipnet_batch_pf_local_weights: bad argument");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  const int64_t nmax = b->pfPeers ? b->pfPeers->nmax : b->ncol;
+  return logWeights(b, d_plane, elem_is_f32, n_steps, ld, obs, sigma, d_block, d_block + nmax, hip_stream, nmax);
+}
+
+int sipnet_batch_pf_resample_peers(sipnet_batch* b, const double* d_gathered, double u0, int32_t* d_ancestors,
+                                   int64_t* d_total, void* hip_stream) {
+  if (!b || !d_gathered || !d_ancestors || !(u0 >= 0.0) || !(u0 < 1.0)) {
+    setError("sipnet_batch_pf_resample_peers: bad argument (0 <= u0 < 1)");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  if (b->n_sites != 1) {
+    setError("sipnet_batch_pf_resample_peers: particles of different sites must not mix (n_sites must be 1)");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  int rc = useDevice(b);
+  if (rc) return rc;
+  hipStream_t stream = (hipStream_t)hip_stream;
+  PeerPtrs tab{};
+  int64_t nTotal = b->ncol, first = 0;
+  bool withParams;
+  if (b->pfPeers) {
+    const PfPeers& pp = *b->pfPeers;
+    tab.world = pp.world;
+    tab.nmax = pp.nmax;
+    for (int s = 0; s < pp.world; s++) {
+      tab.state[s] = pp.state[pp.parity][s];
+      tab.ring[s] = pp.ring[pp.parity][s];
+      tab.prm[s] = pp.prm[pp.parity][s];
+      tab.pitch[s] = pp.count[s];
+    }
+    nTotal = pp.nTotal;
+    first = pp.first;
+    withParams = pp.withParams != 0;
+    if (tab.state[pp.rank] != b->d_state) {
+      setError("sipnet_batch_pf_resample_peers: the batch was resampled behind the peers' back");
+      return SIPNET_ERR_INTERNAL;
+    }
+  } else {   // not connected: a filter of this batch alone (parameters travel with the particles)
+    tab.world = 1;
+    tab.nmax = (int32_t)b->ncol;
+    tab.state[0] = b->d_state;
+    tab.ring[0] = b->d_ring;
+    tab.prm[0] = b->d_prm;
+    tab.pitch[0] = (int32_t)b->ncol;
+    withParams = true;
+  }
+  rc = ensureSpares(b, withParams);
+  if (rc) return rc;
+  const int64_t nSlots = (int64_t)tab.world * tab.nmax, stride = tab.nmax + (tab.nmax + 255) / 256;
+  PfScratch& sc = scratchOf(b);
+  rc = pfScratchFor(sc, nSlots, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(fixedWeightGatheredKernel, dim3((unsigned)((nSlots + 255) / 256)), dim3(256), 0, stream, d_gathered,
+                     tab.world, tab.nmax, stride, sc.d_w);
+  size_t tmpBytes = sc.tmpBytes;
+  HIP_TRY(hipcub::DeviceScan::InclusiveSum(sc.d_tmp, tmpBytes, sc.d_w, sc.d_cdf, (int)nSlots, stream));
+  const int64_t n = b->ncol;
+  hipLaunchKernelGGL(ancestorKernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, sc.d_cdf, nSlots, first, n,
+                     nTotal, u0, d_ancestors, d_total);
+  auto groups = [](int rows) { return (rows + kGatherRows - 1) / kGatherRows; };
+  PeerParts parts{};
+  parts.p[0] = PeerPart{b->d_state2, SIPNET_NSTATE, 0, 0};
+  parts.p[1] = PeerPart{b->d_ring2, SIPNET_RING_SLOTS, groups(SIPNET_NSTATE), b->precision == SIPNET_F32_MIXED ? 1 : 0};
+  parts.n = 2;
+  int total = groups(SIPNET_NSTATE) + groups(SIPNET_RING_SLOTS);
+  if (withParams) {
+    parts.p[2] = PeerPart{b->d_prm2, SIPNET_NPARAMS, total, 0};
+    parts.n = 3;
+    total += groups(SIPNET_NPARAMS);
+  }
+  hipLaunchKernelGGL(gatherPeerKernel, dim3((unsigned)((n + 255) / 256), (unsigned)total), dim3(256), 0, stream, parts, tab,
+                     d_ancestors, n, n);
+  HIP_TRY(hipGetLastError());
+  std::swap(b->d_state, b->d_state2);
+  std::swap(b->d_ring, b->d_ring2);
+  if (withParams) std::swap(b->d_prm, b->d_prm2);
+  if (b->pfPeers) b->pfPeers->parity ^= 1;
+  return SIPNET_OK;
 }
 
 }  // extern "C"

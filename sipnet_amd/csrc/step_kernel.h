@@ -143,7 +143,8 @@ void launchSetup(const SetupArgs& a, hipStream_t stream);
 // the threshold of THAT mode (soilTempLeafOn; leafOnDay, +inf when non-positive: sipnet.c:705-731), which is what
 // the throughput kernels compare the plan's leaf-on variable with; the strict kernel reads the original rows
 void launchConvertParams(const double* rawRows, double* prm, int64_t ncol, int64_t col0,
-                         int32_t count, int32_t leafOnMode, hipStream_t stream);
+                         int32_t count, int32_t leafOnMode, hipStream_t stream, int32_t nRep = 1,
+                         int64_t repStride = 0);
 // variant: bit0 = fast math, bit1 = generic flags (runtime), else default flags
 void launchStep(const KernelArgs& a, int precision, bool fastMath, hipStream_t stream, LaunchInfo* info);
 // stats[((plane * n_steps + t) * n_sites + site) * 2 + {0, 1}] = sum over the site's chunks of statsPart

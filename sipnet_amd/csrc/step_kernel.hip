@@ -106,7 +106,8 @@ __device__ __forceinline__ int32_t uni(int32_t v) { return __builtin_amdgcn_read
 // -----------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void convertParamsKernel(const double* __restrict__ raw,
                                                            double* __restrict__ prm, int64_t ncol,
-                                                           int64_t col0, int32_t count, int32_t leafOnMode) {
+                                                           int64_t col0, int32_t count, int32_t leafOnMode,
+                                                           int32_t nRep, int64_t repStride) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
   double p[SIPNET_NPARAMS];
@@ -140,8 +141,11 @@ __global__ __launch_bounds__(256) void convertParamsKernel(const double* __restr
   // the throughput kernels' leaf-on threshold (step_kernel.h): unused as a GDD sum in these modes
   if (leafOnMode == 1) p[SP_gddLeafOn] = p[SP_soilTempLeafOn];
   if (leafOnMode == 2) p[SP_gddLeafOn] = p[SP_leafOnDay] > 0 ? p[SP_leafOnDay] : 1e300;
+  // (nRep > 1: the same members at nRep sites, repStride columns apart -- SIPNET_ALL_SITES)
+  for (int r = 0; r < nRep; r++) {
 #pragma unroll
-  for (int k = 0; k < SIPNET_NPARAMS; k++) prm[(int64_t)k * ncol + col0 + i] = p[k];
+    for (int k = 0; k < SIPNET_NPARAMS; k++) prm[(int64_t)k * ncol + col0 + (int64_t)r * repStride + i] = p[k];
+  }
 }
 
 __global__ __launch_bounds__(256) void setupKernel(SetupArgs a) {
@@ -1326,9 +1330,9 @@ void launchSetup(const SetupArgs& a, hipStream_t stream) {
   hipLaunchKernelGGL(setupKernel, dim3(grid), dim3(256), 0, stream, a);
 }
 void launchConvertParams(const double* rawRows, double* prm, int64_t ncol, int64_t col0,
-                         int32_t count, int32_t leafOnMode, hipStream_t stream) {
+                         int32_t count, int32_t leafOnMode, hipStream_t stream, int32_t nRep, int64_t repStride) {
   hipLaunchKernelGGL(convertParamsKernel, dim3((count + 255) / 256), dim3(256), 0, stream, rawRows,
-                     prm, ncol, col0, count, leafOnMode);
+                     prm, ncol, col0, count, leafOnMode, nRep, repStride);
 }
 
 static bool isDefaultFlags(const int32_t* f) {

@@ -229,3 +229,58 @@ def pf_analysis(batch, plane, obs, sigma, u0, rank=0, world=1, group=None, with_
     info["ess"] = float(w.sum() ** 2 / (w * w).sum())
     info["unique_ancestors"] = int(torch.unique_consecutive(anc).numel())
     return anc, info
+
+
+# ---- the same analysis step without an all-to-all: peer reads (include/sipnet_amd.h, "the filter across ranks
+# WITHOUT an all-to-all") ------------------------------------------------------------------------------------
+def pf_connect_peers(batch, rank=0, world=1, group=None, with_params=True):
+    """Once per filter: every rank publishes where its particles' checkpoint matrices live and maps the
+    others' (hipIpc handles between processes).  Host-side, off the cycle."""
+    import torch.distributed as dist
+    mine = batch.pf_publish(with_params)
+    if world > 1:
+        every = [None] * world
+        dist.all_gather_object(every, mine, group=group)
+    else:
+        every = [mine]
+    batch.pf_connect(every, rank)
+
+
+def pf_analysis_peers(batch, plane, obs, sigma, u0, rank=0, world=1, group=None, total_out=None,
+                      collectives=None, gathered=None, ancestors=None, diagnostics=False):
+    """One analysis step of a connected filter (pf_connect_peers): this rank's log-weight block -> ONE
+    all-gather of the blocks -> weights, prefix sum and this rank's ancestors -> one gather that reads each
+    ancestor where it lives.  No host synchronisation, no second collective.  Returns (ancestor slots
+    int32 [ncol] -- rank * nmax + particle --, gathered blocks)."""
+    import torch
+    import torch.distributed as dist
+    if collectives is None:
+        collectives = world > 1
+    L = batch.pf_block_len()
+    if gathered is None:
+        gathered = getattr(batch, "_pf_gathered", None)
+        if gathered is None or gathered.shape != (world, L):
+            gathered = batch._pf_gathered = torch.empty((world, L), dtype=torch.float64, device=batch.device)
+    mine = gathered[rank]
+    batch.pf_local_weights(plane, obs, sigma, mine)
+    if collectives:
+        if _host_staged(mine, group):
+            out = torch.empty((world, L), dtype=torch.float64)
+            dist.all_gather_into_tensor(out.view(-1), mine.cpu(), group=group)
+            gathered.copy_(out)
+        else:   # in place: rank r's input is its own slice of the output
+            dist.all_gather_into_tensor(gathered.view(-1), mine, group=group)
+    anc = batch.pf_resample_peers(gathered, u0, ancestors, total_out)
+    if not diagnostics:
+        return anc, gathered
+    # L = nmax + ceil(nmax / 256)  ->  nmax: the largest m with m + ceil(m / 256) == L
+    nmax = (L * 256) // 257
+    while nmax + (nmax + 255) // 256 < L:
+        nmax += 1
+    logw = gathered[:, :nmax].reshape(-1)
+    w = torch.exp(logw - logw.max())
+    crossed = int(((anc // nmax) != rank).sum())
+    words = batch.L.sipnet_batch_member_words(batch.h, 1)
+    info = {"ess": float(w.sum() ** 2 / (w * w).sum()), "unique_ancestors": int(torch.unique_consecutive(anc).numel()),
+            "received": crossed, "sent": 0, "bytes_received": crossed * words * 8, "exchange": "peer reads"}
+    return anc, info

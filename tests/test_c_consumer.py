@@ -94,3 +94,37 @@ def test_node_of_one_device_all_gathers_through_rccl_from_c(oracle, tmp_path):
     assert (st == 0).all()
     assert float(kv["sum_nee_member_0"]) == pytest.approx(want[0][:, 0].sum(), abs=1e-8)
     assert float(kv["sum_nee_member_last"]) == pytest.approx(want[0][:, 1].sum(), abs=1e-8)
+
+
+PF_SRC = os.path.join(helpers.REPO, "tests", "c", "pf_consumer.c")
+
+
+def run_pf(exe, tmp_path, n, devices, cycles=5, n_steps=48):
+    from sipnet_amd import synth
+    clim = str(tmp_path / "day.clim")
+    synth.write_clim(clim, synth.round_like_file(synth.half_hourly_year_raw(n_steps)))
+    r = subprocess.run([exe, os.path.join(helpers.REPO, "sipnet_amd", "data", "base_forest.param"), clim, str(n), devices,
+                        str(cycles), str(n_steps)], capture_output=True, text=True, timeout=600)
+    kv = dict(l.split("=", 1) for l in r.stdout.strip().split("\n") if "=" in l)
+    return r.returncode, kv, r.stdout + r.stderr
+
+
+@pytest.mark.skipif(sa.lib().sipnet_device_count() > 0, reason="a GPU is present")
+def test_filter_consumer_links_from_c_and_needs_a_device(tmp_path):
+    rc, kv, out = run_pf(build(tmp_path, PF_SRC), tmp_path, 512, "0")
+    assert rc == 0, out
+    assert kv["create"] == "100" and "no usable HIP device" in kv["no_device_message"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", ["0", "0,0"], ids=["rccl-one-rank", "two-shards-one-gpu"])
+def test_filter_cycles_through_the_node_object_from_c(tmp_path, devices):
+    """config 5's cycle from a C99 program: setupModel -> forecast -> sipnet_node_pf_analysis (ONE all-gather of
+    the log-weight blocks through a one-rank RCCL communicator, or between two shards of one GPU; peer-read
+    resampling), 8 cycles with no host synchronisation, against the same cycles on ONE batch: identical state"""
+    rc, kv, out = run_pf(build(tmp_path, PF_SRC), tmp_path, 16384, devices, cycles=8)
+    assert rc == 0 and kv["create"] == "0", out
+    assert ("RCCL" in kv["collective_library"]) == (devices == "0")
+    assert kv["state_identical"] == "1", out
+    assert int(kv["distinct_neighbours"]) > 100          # the filter kept many distinct particles
+    assert float(kv["ms_per_cycle_node"]) > 0 and float(kv["ms_per_cycle_plain"]) > 0

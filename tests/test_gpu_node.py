@@ -1,0 +1,275 @@
+"""The C host's multi-GPU object (sipnet_node_*, csrc/node.cpp) beyond one member-sharded device:
+whole-site shards (SURVEY 8(e) "Partitioning": BASELINE config 4's cut), ragged member shards, and the
+particle filter's exchange step by peer reads (config 5) -- each against ONE batch holding everything.
+A one-GPU box runs several shards on device 0 (sipnet_node_create_sharded allows a device to be listed
+more than once: the all-gathers are then event-ordered device copies); with devices = [0] the same calls
+go through a one-rank RCCL communicator.  Everything else -- sharding, uploads, kernels, peer tables,
+gathered layouts -- is the code an 8-GPU node executes."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import sipnet_amd as sa
+from sipnet_amd import synth
+from sipnet_amd._lib import SHARD_MEMBERS, SHARD_SITES
+from sipnet_amd.node import Node
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+BASE = os.path.join(helpers.REPO, "sipnet_amd", "data", "base_forest.param")
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def base():
+    return sa.read_params(BASE, sa.flags_from())[0]
+
+
+def site_clims(n_sites, T):
+    return [synth.convert_raw(synth.round_like_file(synth.half_hourly_year_raw(T, site=s))) for s in range(n_sites)]
+
+
+def one_batch(flags, clims, members, prec=sa.F64, per_site_members=None):
+    S, M = len(clims), members.shape[0]
+    b = sa.Batch(flags, S, M, prec, fast_math=True)
+    for s in range(S):
+        b.set_climate(s, clims[s])
+        b.set_params(s, members if per_site_members is None else per_site_members[s])
+    b.setup()
+    return b
+
+
+@pytest.mark.parametrize("devices,n_sites", [([0, 0], 6), ([0, 0, 0], 5), ([0], 3)], ids=["2x3", "ragged-1-2-2", "rccl-one-rank"])
+def test_site_sharded_node_equals_one_batch_of_all_sites(base, devices, n_sites):
+    """shard k owns sites [k S / N, (k + 1) S / N) with all members: planes, statistics (concatenated along the
+    site axis by gather_stats) and member status equal ONE batch of all sites bit for bit; each shard holds
+    only its own sites' plans; a different member matrix at one site reaches that site's owner only"""
+    M, T = 130, 48 * 6
+    flags = sa.flags_from()
+    clims = site_clims(n_sites, T)
+    members = synth.perturbed_params(base, M)
+    odd = synth.perturbed_params(base, M, seed=77)           # site 1 gets another draw
+    per_site = [odd if s == 1 else members for s in range(n_sites)]
+    b = one_batch(flags, clims, members, per_site_members=per_site)
+    planes, stats = b.run_stats(0, T)
+    want_planes = planes.cpu().numpy().reshape(3, T, n_sites, M)
+    want_stats = stats.cpu().numpy()
+    b.close()
+
+    nd = Node(flags, n_sites, M, devices=devices, shard=SHARD_SITES, fast_math=True)
+    assert nd.ld == max(nd.site_range(k)[1] for k in range(nd.n)) * M
+    assert [nd.site_range(k)[0] for k in range(nd.n)] == [n_sites * k // nd.n for k in range(nd.n)]
+    assert sum(nd.site_range(k)[1] for k in range(nd.n)) == n_sites
+    if len(devices) > 1:
+        assert "event-ordered" in nd.collective_library()
+    else:
+        assert "RCCL" in nd.collective_library()
+    for s in range(n_sites):
+        nd.set_climate(s, clims[s])
+    nd.set_params(None, members)                                # SIPNET_ALL_SITES: one upload per shard
+    nd.set_params(1, odd)
+    nd.setup()
+    nd.run(0, T)
+    got_stats = nd.gather_stats()
+    got_planes = nd.member_planes()
+    np.testing.assert_array_equal(got_planes, want_planes)
+    np.testing.assert_array_equal(got_stats, want_stats)
+    assert (nd.status() == 0).all()
+    # every shard's copy of the gathered statistics is the same, and holds shard k's sites in block k
+    g0, gl = nd.gathered_stats(0), nd.gathered_stats(nd.n - 1)
+    np.testing.assert_array_equal(g0, gl)
+    for k in range(nd.n):
+        s0, sc = nd.site_range(k)
+        np.testing.assert_array_equal(g0[k][:, :, :sc], want_stats[:, :, s0:s0 + sc])
+        assert (g0[k][:, :, sc:] == 0).all()
+        # plan memory: a shard's batch was created with its own sites only
+        assert nd.L.sipnet_batch_ncol(nd.L.sipnet_node_batch(nd.h, k)) == sc * M
+    # a shorter second run (any length may be gathered), member-resolved planes gathered
+    nd.setup()
+    nd.run(0, T // 2)
+    nd.gather_planes()
+    nd.sync()
+    gp = nd.gathered_planes(nd.n - 1)
+    for k in range(nd.n):
+        s0, sc = nd.site_range(k)
+        np.testing.assert_array_equal(gp[k][:, :, :sc * M].reshape(3, T // 2, sc, M), want_planes[:, :T // 2, s0:s0 + sc])
+        assert (gp[k][:, :, sc * M:] == 0).all()
+    nd.close()
+
+
+def test_member_sharded_node_with_ragged_shards_equals_one_batch(base):
+    """SIPNET_SHARD_MEMBERS over three shards, 200 members (67 / 66 / 67) at two sites: the summed statistics equal
+    one batch's up to the order of the additions, the planes bit for bit; column layout site * count_k + member"""
+    S, M, T = 2, 200, 48 * 5
+    flags = sa.flags_from()
+    clims = site_clims(S, T)
+    members = synth.perturbed_params(base, M)
+    b = one_batch(flags, clims, members)
+    planes, stats = b.run_stats(0, T)
+    want_planes = planes.cpu().numpy().reshape(3, T, S, M)
+    want_stats = stats.cpu().numpy()
+    b.close()
+    nd = Node(flags, S, M, devices=[0, 0, 0], shard=SHARD_MEMBERS, fast_math=True)
+    counts = [nd.member_range(k)[1] for k in range(3)]
+    assert sorted(counts) == [66, 67, 67] and nd.ld == S * 68
+    for s in range(S):
+        nd.set_climate(s, clims[s])
+        nd.set_params(s, members)
+    nd.setup()
+    nd.run(0, T)
+    tot = nd.gather_stats()
+    np.testing.assert_array_equal(nd.member_planes(), want_planes)
+    np.testing.assert_allclose(tot, want_stats, rtol=1e-12, atol=1e-12)
+    nd.gather_planes()
+    nd.sync()
+    gp = nd.gathered_planes(0)
+    for k in range(3):
+        m0, mc = nd.member_range(k)
+        np.testing.assert_array_equal(gp[k][:, :, :S * mc].reshape(3, T, S, mc), want_planes[:, :, :, m0:m0 + mc])
+    nd.close()
+
+
+# ---- the particle filter's exchange step by peer reads -----------------------------------------------------
+def _filter_twin(base, clim, members, prec, T, obs_sigma=None, u0=0.43):
+    """ONE batch with every particle: forecast, analysis in one library call; -> state, rings, parameters after
+    the analysis + the ancestors + (obs, sigma) used"""
+    n = members.shape[0]
+    b = sa.Batch(sa.flags_from(), 1, n, prec, fast_math=True)
+    b.set_climate(0, clim)
+    b.set_params(0, members)
+    b.setup()
+    p, _ = b.run(0, T)
+    if obs_sigma is None:
+        tot = p[0].double().sum(0)
+        obs_sigma = (float(tot.median()), float(tot.std()) * 0.5 + 1e-12)
+    total = torch.zeros(1, dtype=torch.int64, device=DEV)
+    anc, _ = b.pf_analysis_local(p[0], obs_sigma[0], obs_sigma[1], u0, with_params=True, total_out=total)
+    anc = anc.cpu().numpy().copy()
+    everyone = torch.arange(n, dtype=torch.int32, device=DEV)
+    w = 32 + (125 if prec == sa.F32_MIXED else 250)
+    prm = b.pack_members(everyone, True)[w:].cpu().numpy()
+    state = b.get_state()                      # right after the analysis
+    p2, _ = b.run(T, T)                        # the resampled particles continue
+    out = dict(state=state, rings=b.get_rings(), prm=prm, anc=anc, obs_sigma=obs_sigma, total=int(total.item()),
+               next=p2.cpu().numpy())
+    b.close()
+    return out
+
+
+@pytest.mark.parametrize("prec", [sa.F64, sa.F32_MIXED], ids=["f64", "f32ring"])
+@pytest.mark.parametrize("devices,n", [([0, 0], 1024), ([0, 0, 0], 1000), ([0], 700)], ids=["two-shards", "ragged-three", "rccl-one-rank"])
+def test_node_filter_cycle_equals_the_one_batch_analysis(base, devices, n, prec):
+    """forecast -> sipnet_node_pf_analysis (log-weight blocks, ONE all-gather, peer-read resampling) over member
+    shards on one GPU against sipnet_batch_pf_analysis over all particles in one batch: same ancestors, state,
+    rings (the slots written so far) and parameters bit for bit, and the resampled particles' next forecast equal"""
+    T = 96
+    clim = synth.convert_raw(synth.round_like_file(synth.half_hourly_year_raw(2 * T)))
+    members = synth.perturbed_params(base, n)
+    twin = _filter_twin(base, clim, members, prec, T)
+    assert 1 < len(np.unique(twin["anc"])) < n
+
+    nd = Node(sa.flags_from(), 1, n, precision=prec, devices=devices, shard=SHARD_MEMBERS, fast_math=True)
+    nd.set_climate(0, clim)
+    nd.set_params(0, members)
+    nd.setup()
+    nd.pf_connect(with_params=True)
+    nd.forecast(0, T)
+    nd.pf_analysis(0, twin["obs_sigma"][0], twin["obs_sigma"][1], 0.43)
+    assert nd.pf_check() == 1
+    nmax = max(nd.member_range(k)[1] for k in range(nd.n))
+    firsts = [nd.member_range(k)[0] for k in range(nd.n)]
+    crossed = 0
+    for k in range(nd.n):
+        m0, mc = nd.member_range(k)
+        slots = nd.pf_ancestors(k)
+        glob = np.array([firsts[s // nmax] + s % nmax for s in slots])       # slot -> global particle
+        np.testing.assert_array_equal(glob, twin["anc"][m0:m0 + mc])
+        crossed += int(((slots // nmax) != k).sum())
+        np.testing.assert_array_equal(nd.shard_state(k), twin["state"][m0:m0 + mc])
+    if nd.n > 1:
+        assert crossed > 0                                                   # particles did cross between the shards
+    nd.forecast(T, T)
+    got = nd.member_planes()[:, :, 0, :]
+    np.testing.assert_array_equal(got, twin["next"])
+    for k in range(nd.n):
+        m0, mc = nd.member_range(k)
+        np.testing.assert_array_equal(nd.shard_rings(k)[:, :2 * T + 1], twin["rings"][m0:m0 + mc][:, :2 * T + 1])
+    nd.close()
+
+
+def test_node_filter_several_cycles_and_a_dead_filter(base):
+    """three cycles without a host synchronisation in between (buffers alternate, peers read the current ones),
+    then an observation no particle is near: every weight underflows to zero, pf_check reports the cycle"""
+    T, n = 48, 768
+    clim = synth.convert_raw(synth.round_like_file(synth.half_hourly_year_raw(4 * T)))
+    members = synth.perturbed_params(base, n)
+    # the twin: one batch, three one-call analyses
+    b = sa.Batch(sa.flags_from(), 1, n, sa.F32_MIXED)
+    b.set_climate(0, clim)
+    b.set_params(0, members)
+    b.setup()
+    obs = []
+    total = torch.zeros(1, dtype=torch.int64, device=DEV)
+    for c in range(3):
+        p, _ = b.run(c * T, T)
+        tot = p[0].double().sum(0)
+        obs.append((float(tot.median()), float(tot.std()) * 0.7 + 1e-12))
+        b.pf_analysis_local(p[0], obs[-1][0], obs[-1][1], 0.1 + 0.3 * c, with_params=True, total_out=total)
+    want = b.get_state()
+    b.close()
+    nd = Node(sa.flags_from(), 1, n, precision=sa.F32_MIXED, devices=[0, 0, 0], shard=SHARD_MEMBERS)
+    nd.set_climate(0, clim)
+    nd.set_params(0, members)
+    nd.setup()
+    nd.pf_connect(with_params=True)
+    for c in range(3):
+        nd.forecast(c * T, T)
+        nd.pf_analysis(0, obs[c][0], obs[c][1], 0.1 + 0.3 * c)
+    assert nd.pf_check() == 3
+    got = np.concatenate([nd.shard_state(k) for k in range(3)])
+    np.testing.assert_array_equal(got, want)
+    nd.close()
+    # a filter none of whose particles can run (invalid allocation: status 3, weight -inf)
+    from sipnet_amd.config import param_index as pi
+    bad = members[:256].copy()
+    bad[:, pi("leafAllocation")] = 0.9
+    bad[:, pi("woodAllocation")] = 0.9
+    nd = Node(sa.flags_from(), 1, 256, precision=sa.F32_MIXED, devices=[0, 0], shard=SHARD_MEMBERS)
+    nd.set_climate(0, clim)
+    nd.set_params(0, bad)
+    nd.setup()
+    nd.pf_connect(with_params=True)
+    nd.forecast(0, T)
+    nd.pf_analysis(0, 0.0, 1.0, 0.5)
+    with pytest.raises(sa.SipnetError) as e:
+        nd.pf_check()
+    assert e.value.code == 3 and "zero weight" in str(e.value)
+    nd.close()
+
+
+def test_peer_resampling_of_an_unconnected_batch_is_the_one_call_analysis(base):
+    """sipnet_batch_pf_local_weights + sipnet_batch_pf_resample_peers on a batch that never connected (a filter of
+    one rank, no collective) = sipnet_batch_pf_analysis"""
+    T, n = 96, 1000
+    clim = synth.convert_raw(synth.round_like_file(synth.half_hourly_year_raw(T)))
+    members = synth.perturbed_params(base, n)
+    twin = _filter_twin(base, clim, members, sa.F64, T // 2)
+    b = sa.Batch(sa.flags_from(), 1, n, sa.F64, fast_math=True)
+    b.set_climate(0, clim)
+    b.set_params(0, members)
+    b.setup()
+    p, _ = b.run(0, T // 2)
+    L = b.pf_block_len()
+    assert L == n + 4
+    block = torch.empty((1, L), dtype=torch.float64, device=DEV)
+    b.pf_local_weights(p[0], twin["obs_sigma"][0], twin["obs_sigma"][1], block[0])
+    total = torch.zeros(1, dtype=torch.int64, device=DEV)
+    anc = b.pf_resample_peers(block, 0.43, total_out=total)
+    np.testing.assert_array_equal(anc.cpu().numpy(), twin["anc"])
+    assert int(total.item()) == twin["total"] > 0
+    np.testing.assert_array_equal(b.get_state(), twin["state"])
+    p2, _ = b.run(T // 2, T // 2)
+    np.testing.assert_array_equal(p2.cpu().numpy(), twin["next"])
+    b.close()
