@@ -68,23 +68,27 @@ def test_two_ranks_rehearsed_on_one_gpu_equal_a_single_process(workload, members
         assert not np.allclose(a[:, :, 0], a[:, :, 32])          # different forcing per site
 
 
-def test_particle_filter_cycle_two_ranks_rehearsed(tmp_path):
-    """c5 with two ranks on this one GPU: likelihood weights -> all-gather of log-weights ->
-    redundant systematic resampling -> ONE all-to-all of packed checkpoints (parameters travel
-    with the particles) -> gather -> the next cycle's setupModel() on the RESAMPLED parameter
-    sets.  The collectives go over gloo through host copies; the plan, pack and resample kernels
-    and the bookkeeping are the 8-GPU code."""
+@pytest.mark.parametrize("exchange", ["peer", "alltoall"])
+def test_particle_filter_cycle_two_ranks_rehearsed(tmp_path, exchange):
+    """c5 with two ranks (two PROCESSES) on this one GPU.  peer: likelihood weights -> ONE all-gather of the
+    log-weight blocks -> each rank resamples its own particles over the gathered weights and reads every
+    ancestor where it lives -- the other process's checkpoint matrices, mapped through hipIpc handles
+    exchanged once (on an 8-GPU node: peer HBM over xGMI).  alltoall: all-gather of log-weights -> redundant
+    resampling -> exchange plan -> ONE all-to-all of packed checkpoints.  Either way parameters travel with
+    the particles and the next cycle's setupModel() runs on the RESAMPLED parameter sets.  The collectives go
+    over gloo through host copies; the kernels and the bookkeeping are the 8-GPU code."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run(
         [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), BENCH, "--gpus", "2",
          "--rehearse", "--workload", "c5", "--members", "4096", "--steps", "3", "--warmup", "1",
-         "--no-cpu-baseline", "--no-fill-probe"],
+         "--no-cpu-baseline", "--no-fill-probe", "--pf-exchange", exchange],
         capture_output=True, text=True, timeout=600, env=env, cwd=helpers.REPO)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     j = _last_json(r.stdout)
     pf = j["config"]["particle_filter"]
     assert j["n_gpus"] == 2 and j["config"]["ranks_seen"] == 2
+    assert pf["exchange"] == exchange                      # (peer: the IPC mapping between the two processes worked)
     assert pf["received"] + pf["sent"] > 0                 # particles did cross between the ranks
     assert 1 < pf["unique_ancestors"] < 2 * 4096
     assert j["parity"]["max_abs_dNEE"] < 2e-6
@@ -126,9 +130,12 @@ def test_rccl_one_rank_statistics_equal_the_plain_run_bit_for_bit(workload, memb
     assert a.shape == b.shape and np.array_equal(a, b)       # bit for bit
 
 
-def test_rccl_one_rank_particle_filter_cycle(tmp_path):
-    j = _rccl_one_rank(["--workload", "c5", "--members", "4096", "--steps", "3", "--warmup", "1"], tmp_path)
+@pytest.mark.parametrize("exchange", ["peer", "alltoall"])
+def test_rccl_one_rank_particle_filter_cycle(tmp_path, exchange):
+    j = _rccl_one_rank(["--workload", "c5", "--members", "4096", "--steps", "3", "--warmup", "1",
+                        "--pf-exchange", exchange], tmp_path)
     pf = j["config"]["particle_filter"]
+    assert pf["exchange"] == exchange
     assert j["config"]["dist_overhead"]["backend"] == "nccl"
     assert pf["unique_ancestors"] > 64 and pf["ess"] > 64
     assert pf["sent"] == 0 and pf["received"] == 0          # one rank: every ancestor is local
