@@ -31,6 +31,9 @@ What the JSON line says about the kernel (the `roofline` object):
   hbm_measured_frac  ... the bytes that really cross HBM (rocprofv3 PMC, profiles/pmc_traffic.json,
                      tagged with the round they were collected in) / kernel time / 8 TB/s;
   waves_per_simd, cus_used, simds_used   the launch shape (from the library, not re-derived here);
+  valu_busy_frac     the physical ceiling of a time-fused fp64 kernel (SURVEY 8(d) "ALU cross-check"): SIMD-cycles
+                     with the vector ALU executing (SQ_ACTIVE_INST_VALU x 4, committed profile) / (all SIMDs x
+                     kernel time x 2.4 GHz); valu_busy_frac_of_used_simds: the same over the SIMDs the launch occupies;
   issue_frac         this run's rate / the rate the same model reaches on this GPU once every SIMD
                      holds two wavefronts (a short 131 072-member probe of the one-wave kernel, run
                      untimed in this process): how much of the chip's instruction issue the launch uses;
@@ -56,6 +59,7 @@ sys.path.insert(0, REPO)
 
 ALGO_BYTES = {"f64": 344.0, "f32": 172.0}   # bytes per member-timestep
 HBM_PEAK_GBPS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8 TB/s
+SCLK_PEAK_HZ = 2.4e9                         # MI355X_MICROARCH.md: max clock 2400 MHz
 
 WORKLOADS = {
     "c10k": dict(sites=1, members=10240, prec="f64", steps=17520),
@@ -614,7 +618,7 @@ def main():
         except Exception as e:  # the checker is optional for the measurement itself
             parity = {"error": repr(e)}
 
-    traffic, traffic_tag = None, None
+    traffic, traffic_tag, valu_cycles = None, None, None
     tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
@@ -622,6 +626,7 @@ def main():
             # only valid for the kernel it was collected on
             if ent.get("kernel") in (None, li["kernel"]):
                 traffic, traffic_tag = ent.get("hbm_bytes_per_launch"), ent.get("tag")
+                valu_cycles = ent.get("valu_active_cycles_per_launch")
         except Exception:
             traffic = None
 
@@ -698,6 +703,13 @@ def main():
                          "cus_used": cus_used, "cus_total": li["num_cus"],
                          "simds_used": simds_used, "simds_total": 4 * li["num_cus"],
                          "lds_bytes_per_workgroup": li["lds_bytes"],
+                         # the PHYSICAL ceiling beside the contract number (SURVEY 8(d) "ALU cross-check"): the share of
+                         # SIMD-cycles in which a vector ALU was executing -- SQ_ACTIVE_INST_VALU x 4 of the committed
+                         # profile (profiles/pmc_traffic.json, like `traffic`) over SIMDs x this run's kernel time at
+                         # the 2.4 GHz peak clock (a lower clock under load makes the true fraction higher)
+                         "valu_busy_frac": (valu_cycles / (4.0 * li["num_cus"] * k_ms * 1e-3 * SCLK_PEAK_HZ)) if valu_cycles else None,
+                         "valu_busy_frac_of_used_simds": (valu_cycles / (simds_used * k_ms * 1e-3 * SCLK_PEAK_HZ)) if valu_cycles else None,
+                         "valu_clock_ghz_assumed": SCLK_PEAK_HZ / 1e9,
                          "issue_frac": (per_launch_units / (k_ms * 1e-3) / probe["rate"]) if probe and "rate" in probe else None,
                          "fill_probe": probe,
                          "plan_ms": plan_ms, "plan_ms_first_in_process": plan_first, "plan_build_ms": li["plan_build_ms"], "plan_upload_ms": li["plan_upload_ms"], "plan_threads": li["plan_threads"], "setup_ms": setup_ms,

@@ -90,6 +90,15 @@ if means:
             d = json.load(open(tj)) if os.path.exists(tj) else {}
             kname = norm(sk)
             d[wl] = {"hbm_bytes_per_launch": hbm, "tag": tag, "fetch_correction": corr, "kernel": kname}
+            # the ALU cross-check of SURVEY 8(d): cycles in which a SIMD's vector ALU was executing, summed over
+            # the chip (SQ_ACTIVE_INST_VALU counts quad-cycles) -- bench.py divides by SIMDs x kernel cycles
+            av = means.get((sk, "SQ_ACTIVE_INST_VALU"))
+            if av:
+                d[wl]["valu_active_cycles_per_launch"] = av * 4.0
+                if ks:
+                    for r in csv.DictReader(open(ks)):
+                        if norm(r["Name"]) == kname:
+                            d[wl]["profiled_kernel_avg_ns"] = float(r["AverageNs"])
             json.dump(d, open(tj, "w"), indent=1)
         sq = {c: means[(sk, c)] for (k, c) in means if k == sk and c.startswith("SQ_")}
         if sq:
