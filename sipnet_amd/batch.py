@@ -99,6 +99,9 @@ class Batch:
         check(self.L.sipnet_batch_set_events(self.h, site, n, arr), "set_events")
 
     def set_params(self, site, raw, first_member=0):
+        """site: a site index, or None / ALL_SITES = the same members at every site (one upload)"""
+        if site is None:
+            site = -1   # SIPNET_ALL_SITES
         raw = np.ascontiguousarray(raw, dtype=np.float64)
         if raw.ndim == 1:
             raw = np.broadcast_to(raw, (self.n_members, NPARAMS)).copy()
