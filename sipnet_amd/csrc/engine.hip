@@ -286,11 +286,19 @@ static int autoKernel(const int32_t* flags, int32_t n_sites, int32_t n_members, 
   const bool defaultFlags = isDefaultFlagSet(flags);
   const int64_t blocks = (int64_t)n_sites * ((n_members + 63) / 64);
   if (!fastMath || debugPlane) return SIPNET_KERNEL_STRICT;
-  if (defaultFlags && blocks <= (int64_t)numCUs) return SIPNET_KERNEL_COOP_LDS;
-  if (defaultFlags && blocks <= 2 * (int64_t)numCUs) return SIPNET_KERNEL_COOP_PAIR;
-  if (defaultFlags && blocks <= 4 * (int64_t)numCUs && !wantFull) return SIPNET_KERNEL_COOP_QUAD;
-  if (isNCycleFlagSet(flags) && blocks <= (int64_t)numCUs && !wantFull) return SIPNET_KERNEL_COOP_NCYCLE;
-  if (isNCycleFlagSet(flags) && blocks <= 2 * (int64_t)numCUs && !wantFull) return SIPNET_KERNEL_COOP_NCYCLE_PAIR;
+  if (!flags[SIPNET_F_NITROGEN_CYCLE]) {
+    // default physics, or -- lean launches of up to two chunks per CU -- its optional-physics instantiations
+    // (growth respiration, leaf water, flooding, litter pool, carbon saturation, anaerobic: run-time flags)
+    const bool ext = !defaultFlags;
+    if (ext && wantFull) return SIPNET_KERNEL_ONE_WAVE;
+    if (blocks <= (int64_t)numCUs) return SIPNET_KERNEL_COOP_LDS;
+    if (blocks <= 2 * (int64_t)numCUs) return SIPNET_KERNEL_COOP_PAIR;
+    if (!ext && blocks <= 4 * (int64_t)numCUs && !wantFull) return SIPNET_KERNEL_COOP_QUAD;
+    return SIPNET_KERNEL_ONE_WAVE;
+  }
+  // the nitrogen cycle (with litter pool + anaerobic, which it requires), alone or with the other options
+  if (blocks <= (int64_t)numCUs && !wantFull) return SIPNET_KERNEL_COOP_NCYCLE;
+  if (blocks <= 2 * (int64_t)numCUs && !wantFull) return SIPNET_KERNEL_COOP_NCYCLE_PAIR;
   return SIPNET_KERNEL_ONE_WAVE;
 }
 
@@ -663,13 +671,17 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
       return SIPNET_ERR_BAD_ARGUMENT;
     }
     if (kernel == SIPNET_KERNEL_COOP_NCYCLE || kernel == SIPNET_KERNEL_COOP_NCYCLE_PAIR) {
-      if (!isNCycleFlagSet(b->flags) || wantFull) {
-        setError("sipnet_batch_run: the nitrogen-cycle cooperative kernel has its flag set (litter pool + anaerobic + "
-                 "nitrogen cycle) compiled in and no full-state instantiation");
+      if (!b->flags[SIPNET_F_NITROGEN_CYCLE] || wantFull) {
+        setError("sipnet_batch_run: the nitrogen-cycle cooperative kernels run flag sets with the nitrogen cycle on and have "
+                 "no full-state instantiation");
         return SIPNET_ERR_BAD_ARGUMENT;
       }
-    } else if (kernel != SIPNET_KERNEL_ONE_WAVE && !defaultFlags) {
-      setError("sipnet_batch_run: the cooperative kernel has the default model flags compiled in");
+    } else if (kernel != SIPNET_KERNEL_ONE_WAVE && b->flags[SIPNET_F_NITROGEN_CYCLE]) {
+      setError("sipnet_batch_run: a flag set with the nitrogen cycle takes SIPNET_KERNEL_COOP_NCYCLE(_PAIR) or the one-wave kernel");
+      return SIPNET_ERR_BAD_ARGUMENT;
+    } else if (kernel != SIPNET_KERNEL_ONE_WAVE && !defaultFlags && (wantFull || kernel == SIPNET_KERNEL_COOP_QUAD)) {
+      setError("sipnet_batch_run: the optional-physics instantiations of the cooperative kernel are lean (no records, "
+               "diagnostics, SIPNET_KOPT_FULL_STATE) and carry one or two chunks per workgroup");
       return SIPNET_ERR_BAD_ARGUMENT;
     }
     if (kernel == SIPNET_KERNEL_COOP_QUAD && wantFull) {

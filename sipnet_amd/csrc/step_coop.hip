@@ -250,6 +250,71 @@ __device__ __forceinline__ void post5(float* base, int* flag, float v0, float v1
                :: "v"(ldsAddr(base)), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(ldsAddr(flag)), "v"(step)
                : "memory");
 }
+// Ext (optional physics without the nitrogen cycle), wave W: rows 5 and 6 of the factor block -- the moisture effect
+// on heterotrophic respiration and the methane moisture term -- behind its flag
+__device__ __forceinline__ void post2(double* base, int* flag, double v0, double v1, int step) {
+  asm volatile("ds_write2st64_b64 %0, %1, %2 offset1:1\n\tds_write_b32 %3, %4"
+               :: "v"(ldsAddr(base)), "v"(v0), "v"(v1), "v"(ldsAddr(flag)), "v"(step) : "memory");
+}
+__device__ __forceinline__ void post2(float* base, int* flag, float v0, float v1, int step) {
+  asm volatile("ds_write2st64_b32 %0, %1, %2 offset1:1\n\tds_write_b32 %3, %4"
+               :: "v"(ldsAddr(base)), "v"(v0), "v"(v1), "v"(ldsAddr(flag)), "v"(step) : "memory");
+}
+// ... and wave C's take of all seven rows (takeFactors / takeFactorsRing with row 6)
+__device__ __forceinline__ void takeFactors7(const double* block, const int* flags2, int step, double& g1, double& g2,
+                                             double& qSoilT, double& gFine, double& gCoarse, double& moist, double& mK) {
+  i2v f;
+  d2v a, b, c;
+  do {
+    asm volatile("ds_read2_b32 %0, %5 offset1:1\n\tds_read2st64_b64 %1, %6 offset1:1\n\t"
+                 "ds_read2st64_b64 %2, %6 offset0:2 offset1:3\n\tds_read2st64_b64 %3, %6 offset0:4 offset1:5\n\t"
+                 "ds_read_b64 %4, %6 offset:3072\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(f), "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(mK)
+                 : "v"((unsigned)(size_t)flags2), "v"((unsigned)(size_t)block) : "memory");
+  } while (uni(f.x < f.y ? f.x : f.y) < step);
+  g1 = a.x; g2 = a.y; qSoilT = b.x; gFine = b.y; gCoarse = c.x; moist = c.y;
+}
+__device__ __forceinline__ void takeFactors7(const float* block, const int* flags2, int step, float& g1, float& g2,
+                                             float& qSoilT, float& gFine, float& gCoarse, float& moist, float& mK) {
+  i2v f;
+  f2v a, b, c;
+  do {
+    asm volatile("ds_read2_b32 %0, %5 offset1:1\n\tds_read2st64_b32 %1, %6 offset1:1\n\t"
+                 "ds_read2st64_b32 %2, %6 offset0:2 offset1:3\n\tds_read2st64_b32 %3, %6 offset0:4 offset1:5\n\t"
+                 "ds_read_b32 %4, %6 offset:1536\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(f), "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(mK)
+                 : "v"((unsigned)(size_t)flags2), "v"((unsigned)(size_t)block) : "memory");
+  } while (uni(f.x < f.y ? f.x : f.y) < step);
+  g1 = a.x; g2 = a.y; qSoilT = b.x; gFine = b.y; gCoarse = c.x; moist = c.y;
+}
+__device__ __forceinline__ void takeFactorsRing7(const double* block, const int* flags2, unsigned ringAddr, int step,
+                                                 double& g1, double& g2, double& qSoilT, double& gFine, double& gCoarse,
+                                                 double& moist, double& mK, double& ringV) {
+  i2v f;
+  d2v a, b, c;
+  do {
+    asm volatile("ds_read2_b32 %0, %6 offset1:1\n\tds_read2st64_b64 %1, %7 offset1:1\n\t"
+                 "ds_read2st64_b64 %2, %7 offset0:2 offset1:3\n\tds_read2st64_b64 %3, %7 offset0:4 offset1:5\n\t"
+                 "ds_read_b64 %4, %7 offset:3072\n\tds_read_b64 %5, %8\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(f), "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(mK), "=&v"(ringV)
+                 : "v"((unsigned)(size_t)flags2), "v"((unsigned)(size_t)block), "v"(ringAddr) : "memory");
+  } while (uni(f.x < f.y ? f.x : f.y) < step);
+  g1 = a.x; g2 = a.y; qSoilT = b.x; gFine = b.y; gCoarse = c.x; moist = c.y;
+}
+__device__ __forceinline__ void takeFactorsRing7(const float* block, const int* flags2, unsigned ringAddr, int step,
+                                                 float& g1, float& g2, float& qSoilT, float& gFine, float& gCoarse,
+                                                 float& moist, float& mK, double& ringV) {
+  i2v f;
+  f2v a, b, c;
+  do {
+    asm volatile("ds_read2_b32 %0, %6 offset1:1\n\tds_read2st64_b32 %1, %7 offset1:1\n\t"
+                 "ds_read2st64_b32 %2, %7 offset0:2 offset1:3\n\tds_read2st64_b32 %3, %7 offset0:4 offset1:5\n\t"
+                 "ds_read_b32 %4, %7 offset:1536\n\tds_read_b64 %5, %8\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(f), "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(mK), "=&v"(ringV)
+                 : "v"((unsigned)(size_t)flags2), "v"((unsigned)(size_t)block), "v"(ringAddr) : "memory");
+  } while (uni(f.x < f.y ? f.x : f.y) < step);
+  g1 = a.x; g2 = a.y; qSoilT = b.x; gFine = b.y; gCoarse = c.x; moist = c.y;
+}
 // Blocks of doubles (rows 64 apart) + a sequence flag, for the hand-overs of the nitrogen-cycle layout:
 // values first, flag last (DS writes of a wave execute in order); a reader takes the flag first and
 // everything in one round trip.  One asm statement per take: every value is defined by it.
@@ -445,10 +510,34 @@ __device__ unsigned long long g_coopWaits[16];
 // (The first version had this block on wave W: 2 400 cycles per night step there against C's 1 800;
 // c10kn 20.3 ms.)  One chunk per workgroup, ring in HBM (the new mailboxes take the LDS the ring
 // would), lean state only.
-template <class R, bool PlainExp, bool RingLds, bool Full, int NP, bool NCyc = false>
+// Ext: the reference's other optional physics under RUN-TIME flags (a.flags; wave-uniform, and written so that a
+// flag that is off costs an exactly neutral operand -- rate 0, cap "infinite" -- rather than a branch):
+//   growth respiration (vegResp2, sipnet.c:1084-1103)            wave C: rVeg += max(0, growthRespFrac * mean NPP)
+//   leaf-water interception (calcPrecip, sipnet.c:848-882)       wave W: immediate evaporation capped by lai x
+//                                                                leafPoolDepth -- it takes lai(t) (and C's alive
+//                                                                word) on the steps with rain only
+//   flooding (calcSoilWaterFluxes, sipnet.c:1019-1027)           wave W: drainage capped by waterDrainFrac
+//   carbon saturation (updatePoolsForSoil, sipnet.c:1645-1668)   whoever owns soil carbon (C; NCyc: S)
+// and, without the nitrogen cycle (NCyc = false: "the optional-physics layouts", russell_3's flag family):
+//   litter pool (calcLitterFluxes, sipnet.c:1150-1171)           wave C keeps litterC next to soilC: breakdown =
+//                                                                litterC x (litterBreakdownRate / baseSoilResp) x
+//                                                                fSoil, R_h = rSoil + rLitter
+//   anaerobic moisture effect + methane (depeffects.c:46-96,     wave W posts the anaerobic form of the moisture
+//   sipnet.c:1201-1214)                                          effect and, as row 6 of the factor block, the methane
+//                                                                moisture term / (baseSoilResp x (1 + tillage)), so
+//                                                                that C's methane = rate x pool x qSoilT x row 6
+// Same waves, same hand-overs as the default layouts (one more factor row); lean state only.
+template <class R, bool PlainExp, bool RingLds, bool Full, int NP, bool NCyc = false, bool Ext = false>
 __device__ __forceinline__ void coopBody(const FastArgs& a) {
   static_assert(!(NP > 1 && RingLds), "two chunks' rings do not fit one CU's LDS");
   static_assert(!NCyc || (NP <= 2 && !RingLds && !Full), "nitrogen-cycle layout: one or two chunks, ring in HBM, lean");
+  static_assert(!Ext || !Full, "optional-physics layouts: lean state only");
+  constexpr bool Opt = Ext && !NCyc;   // the optional pools live on wave C
+  // the run-time flags (all false without Ext: dead code then)
+  const bool F_growthResp = Ext && a.flags[SIPNET_F_GROWTH_RESP] != 0, F_leafWater = Ext && a.flags[SIPNET_F_LEAF_WATER] != 0;
+  const bool F_flooding = Ext && a.flags[SIPNET_F_FLOODING] != 0, F_carbonSat = Ext && a.flags[SIPNET_F_CARBON_SATURATION] != 0;
+  const bool F_litterPool = Opt && a.flags[SIPNET_F_LITTER_POOL] != 0, F_anaerobic = Opt && a.flags[SIPNET_F_ANAEROBIC] != 0;
+  constexpr double kNoCap = 3.0e38;  // finite in fp32 too
   constexpr bool Pair = NP == 2;
   // a fourth wavefront computes the climate-only factors when the workgroup has a CU to itself
 #ifdef SIPNET_NO_FACWAVE
@@ -472,7 +561,8 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   // rows 0..4: g1 g2 qSoilT gFine gCoarse of a step (wave L: climate x parameters only); row 5: the
   // soil-moisture effect on heterotrophic respiration (wave W: its state)
   // (NCyc: row 6 = the plain soil-temperature Q10 factor, for methane, volatilisation, litter breakdown)
-  __shared__ alignas(16) R mailFacAll[NP][2][NCyc ? 7 : 6][64];
+  // (Opt: row 6 = wave W's methane moisture term, behind W's flag like row 5)
+  __shared__ alignas(16) R mailFacAll[NP][2][(NCyc || Ext) ? 7 : 6][64];
   __shared__ int mailAliveAll[NP][2][64];  // aliveWord(): wave C's confirmation of the leaf area it posted
   __shared__ int seqLaiAll[NP], seqPgpAll[NP], seqPsnAll[NP];
   __shared__ alignas(8) int seqFacMoistAll[NP][2];  // [0] wave F's / L's factor rows, [1] wave W's moisture row
@@ -981,6 +1071,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
     const R G_kCN = (R)PRM(kCN), G_nFixMax = (R)PRM(nFixationFracMax), G_halfNFix = (R)PRM(halfNFixationMax);
     const R G_resorb = (R)PRM(leafNResorptionFrac), G_anExp = (R)PRM(anaerobicTransExp);
     const R G_soilCH4 = (R)PRM(soilMethaneRate), G_litCH4 = (R)PRM(litterMethaneRate);
+    const R X_iSoilCSat = F_carbonSat ? (R)(1.0 / PRM(soilCSaturation)) : R(0);   // Ext: carbon saturation (share 0 when off)
     double soilC = ST(soilC), litterC = ST(litterC), minN = ST(minN);
     double soilOrgN = ST(soilOrgN), litterN = ST(litterN), storN = ST(plantStorageN);
     double totNee = ST(totNee);
@@ -1099,9 +1190,14 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         const R iLitterCN = fdiv(denLitterN, eLitter), iSoilCN = fdiv(denSoilN, eSoilC);
         const R litterMin = rLitter * iLitterCN, soilMin = rSoil * iSoilCN;
         const R soilNInputs = litterToSoil * iLitterCN + fineRootLoss * G_iFineCN + coarseRootLoss * G_iWoodCN;
-        const R nOrgLitter = leafLitter * G_iLeafCN - leafOffNResorption + woodLitter * G_iWoodCN - litterMin -
-                             litterToSoil * iLitterCN;
-        const R nOrgSoil = soilNInputs - soilMin;
+        R nOrgLitter = leafLitter * G_iLeafCN - leafOffNResorption + woodLitter * G_iWoodCN - litterMin -
+                       litterToSoil * iLitterCN;
+        R nOrgSoil = soilNInputs - soilMin;
+        if (Ext) {   // carbon saturation, nitrogen.c:60-82: the saturated share of the soil's inputs stays in the litter
+          const R sat = clip01(eSoilC * X_iSoilCSat);
+          nOrgLitter += soilNInputs * sat;
+          nOrgSoil = soilNInputs * (R(1) - sat) - soilMin;
+        }
         const R nMin = litterMin + soilMin;
         // volatilisation nitrogen.c:15-26, leaching nitrogen.c:31-41 (the leached share is wave W's:
         // it has the drainage -- by day only after the photosynthesis hand-over, unless the soil cannot
@@ -1150,8 +1246,14 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         postFlag(&seqMinN, t + 1);
         // updatePoolsForSoil(), sipnet.c:1645-1668 (litter pool on, no carbon saturation)
         const R soilInputs = coarseRootLoss + fineRootLoss + litterToSoil;
-        litterC += (double)((woodLitter + leafLitter - litterToSoil - rLitter - litterMethane) * len);
-        soilC += (double)((soilInputs - rSoil - soilMethane) * len);
+        if (Ext) {   // (the soil carbon the reference looks at here already holds this step's event fluxes)
+          const R sat = clip01((R)soilC * X_iSoilCSat);
+          litterC += (double)((woodLitter + leafLitter + (soilInputs * sat) - litterToSoil - rLitter - litterMethane) * len);
+          soilC += (double)((soilInputs * (R(1) - sat) - rSoil - soilMethane) * len);
+        } else {
+          litterC += (double)((woodLitter + leafLitter - litterToSoil - rLitter - litterMethane) * len);
+          soilC += (double)((soilInputs - rSoil - soilMethane) * len);
+        }
 
         // the end of C's step: its mortality verdict (one word per lane) and, where a stand died, what its
         // biomass adds to these pools (sipnet.c:1688-1767); then ensureNonNegativeStocks() for them
@@ -1344,6 +1446,12 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
     const R G_fAnox = NCyc ? (R)PRM(fAnoxia) : R(0), G_iFAnox = NCyc ? (R)(1.0 / PRM(fAnoxia)) : R(0);
     const R G_iOneMinusAnox = NCyc ? (R)(1.0 / (1.0 - PRM(fAnoxia))) : R(0);
     const R G_anDecomp = NCyc ? (R)PRM(anaerobicDecompRate) : R(0);
+    // Ext: leaf-water interception, flooding; Opt: the anaerobic moisture effect and the methane moisture term
+    const R X_leafPool = Ext ? (R)PRM(leafPoolDepth) : R(0);
+    const R X_drainFrac = F_flooding ? (R)PRM(waterDrainFrac) : R(kNoCap);
+    const R X_fAnox = Opt ? (R)PRM(fAnoxia) : R(0), X_iFAnox = Opt ? (R)(1.0 / PRM(fAnoxia)) : R(0);
+    const R X_iOneMinusAnox = Opt ? (R)(1.0 / (1.0 - PRM(fAnoxia))) : R(0), X_anDecomp = Opt ? (R)PRM(anaerobicDecompRate) : R(0);
+    const R X_anExp = Opt ? (R)PRM(anaerobicTransExp) : R(0), X_iBsr = Opt ? (R)(1.0 / PRM(baseSoilResp)) : R(0);
     R* __restrict__ oEt = (R*)(a.et ? a.et : a.scratchRow) + col;
     R* __restrict__ oGpp = (R*)(a.gpp ? a.gpp : a.scratchRow) + col;
     const int64_t ldEt = a.et ? a.ld : 0, ldGpp = a.gpp ? a.ld : 0;
@@ -1394,8 +1502,22 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
           R moistEff = clip01(eWater * K_invWhc);
           if (!PlainExp && __builtin_amdgcn_ballot_w64(K_moistExp != R(1)) != 0)  // pow only where some member needs it
             moistEff = (K_moistExp == R(1)) ? moistEff : fpow(moistEff, K_moistExp);
+          R mK = 0;   // Opt: the methane moisture term over baseSoilResp x (1 + tillage) (C multiplies by qSoilT)
+          if (Opt && F_anaerobic) {   // depeffects.c:46-57, :89-96 (replaces the aerobic form; the pow above then ran idle)
+            const R fWhc = clip01(eWater * K_invWhc);
+            const R anoxic = clip01((fWhc - X_fAnox) * X_iOneMinusAnox);
+            moistEff = ffma(X_anDecomp, anoxic, (R(1) - anoxic) * clip01(fWhc * X_iFAnox));
+            R mMoist = anoxic * anoxic;  // pow(A, anaerobicTransExp) with the usual exponent 2
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(X_anExp != R(2)) != 0, 0)) {
+              const bool general = X_anExp != R(2) && (anoxic > R(0) || X_anExp <= R(0));
+              mMoist = general ? fpow(anoxic, X_anExp) : (X_anExp != R(2) ? R(0) : mMoist);
+            }
+            mK = mMoist * X_iBsr;
+            if (__builtin_expect(bits & FAST_HAS_TILL, 0)) mK = fdiv(mK, (R)((const double*)recB)[6]);   // FastRec::tillP1
+          }
           moistEff = (bits & FAST_TSOIL_NEG) ? R(1) : moistEff;
-          post(&mailFac[t & 1][5][lane], &seqMoist, moistEff, t);
+          if (Opt) post2(&mailFac[t & 1][5][lane], &seqMoist, moistEff, mK, t);
+          else post(&mailFac[t & 1][5][lane], &seqMoist, moistEff, t);
         }
         if (NCyc) {
           const R fWhc = clip01(eWater * K_invWhc);
@@ -1411,7 +1533,17 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         const bool tairPos = (bits & FAST_TAIR_POS) != 0;
         const R rate = (R)q3.y;
         const R rain = tairPos ? rate : R(0), snowFall = tairPos ? R(0) : rate;
-        const R netRain = ffma(-rain, K_immed, rain);   // (beside the product, not behind it)
+        // calcPrecip(), sipnet.c:848-882.  Ext: with the leaf-water flag the immediate evaporation is capped by what
+        // the canopy holds, lai(t) x leafPoolDepth -- asked for on steps with rain only (the site's: wave-uniform);
+        // lai(t) is C's post of the step before, void (0) for a member that died in it
+        R immedEvap = rain * K_immed;
+        if (Ext && F_leafWater && __builtin_amdgcn_ballot_w64(rain > R(0)) != 0) {
+          R laiNow;
+          bool diedBefore;
+          takePgp(&mailLai[t & 1][lane], &seqLai, &mailAlive[t & 1][lane], t, laiNow, diedBefore);
+          immedEvap = rminv(immedEvap, diedBefore ? R(0) : laiNow * X_leafPool);
+        }
+        const R netRain = Ext ? rain - immedEvap : ffma(-rain, K_immed, rain);   // (beside the product, not behind it)
         R snowMelt = 0, sublimation = 0, evaporationPot = 0;
         const bool hasSnow = eSnow > R(0);
         if (hasSnow) {
@@ -1473,7 +1605,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         R evaporation, drainage, wetting;   // wetting: rain + melt - immediate evaporation - fast flow
         {
           R netIn = netRain + snowMelt;
-          wetting = ffma(-netIn, K_ff, ffma(-rain, K_immed, rain + snowMelt));
+          wetting = Ext ? ffma(-netIn, K_ff, (rain + snowMelt) - immedEvap) : ffma(-netIn, K_ff, ffma(-rain, K_immed, rain + snowMelt));
           netIn = ffma(-netIn, K_ff, netIn);
           R remaining = ffma(-transpiration, len, ffma(netIn, len, eWater));
           const R afterEvap = ffma(-evaporationPot, len, remaining);
@@ -1481,6 +1613,10 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
           evaporation = dryOut ? (remaining - R(kTiny)) * invLen : evaporationPot;
           remaining = hasSnow ? remaining : (dryOut ? R(0) : afterEvap);
           drainage = remaining > K_whc ? (remaining - K_whc) * invLen : R(0);
+          if (Ext) {   // flooding, sipnet.c:1019-1027 (no cap with the flag off)
+            const R excess = remaining - K_whc;
+            drainage = remaining > K_whc ? rminv(excess * X_drainFrac, excess * invLen) : R(0);
+          }
         }
         // irrigation, events.c:484-543
         R evEvap = 0;
@@ -1520,7 +1656,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
           WAIT_END(1)
         }
 
-        const R tEt = (ffma(rain, K_immed, transpiration) + evaporation + sublimation + evEvap) * len;
+        const R tEt = ((Ext ? transpiration + immedEvap : ffma(rain, K_immed, transpiration)) + evaporation + sublimation + evEvap) * len;
         *oEt = tEt;
         *oGpp = tGpp;
         oEt += ldEt;
@@ -1579,6 +1715,36 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   const double G_nVolD = NCyc ? PRM(nVolatilizationFrac) : 0.0, G_nLeachD = NCyc ? PRM(nLeachingFrac) : 0.0;
   double plantWoodC = ST(plantWoodC), plantLeafC = ST(plantLeafC), soilC = NCyc ? 0.0 : ST(soilC);
   double coarseRootC = ST(coarseRootC), fineRootC = ST(fineRootC);
+  // Ext: growth respiration; Opt: the litter pool, methane and carbon saturation on this wave (rates 0 / share 0
+  // with their flags off: the same few instructions run to an exactly unchanged result)
+  const R X_growthFrac = F_growthResp ? (R)PRM(growthRespFrac) : R(0);
+  const R X_lbrK = F_litterPool ? (R)(PRM(litterBreakdownRate) / PRM(baseSoilResp)) : R(0);
+  const R X_flr = Opt ? (R)PRM(fracLitterRespired) : R(0), X_1mFlr = Opt ? (R)(1.0 - PRM(fracLitterRespired)) : R(0);
+  const R X_soilCH4 = F_anaerobic ? (R)PRM(soilMethaneRate) : R(0);
+  const R X_litCH4 = (F_anaerobic && F_litterPool) ? (R)PRM(litterMethaneRate) : R(0);
+  const R X_iSoilCSat = (Opt && F_carbonSat) ? (R)(1.0 / PRM(soilCSaturation)) : R(0);
+  double litterC = Opt ? ST(litterC) : 0.0;
+  // the soil side of a step with the optional pools (Opt), ONE piece of code for the regular-tile path and the
+  // general step (a wavefront's path depends on its neighbours: same bits): calcSoilRespiration / calcLitterFluxes /
+  // calcMethaneFlux (sipnet.c:1132-1214) and updatePoolsForSoil (sipnet.c:1645-1668, both forms, one select).
+  // soilCNow: the soil carbon the reference looks at for the saturation share -- it already holds the step's events.
+  auto optSoilSide = [&](R eSoilC, R eLitter, R soilCNow, R fSoil, R qSoilT, R mK, R rootLoss, R aboveLitter, R len,
+                         R& rSoil, R& rHet, double& soilGain, double& litterGain) {
+#pragma clang fp contract(off)
+    rSoil = eSoilC * fSoil;
+    const R breakdown = eLitter * (X_lbrK * fSoil);
+    const R rLitter = breakdown * X_flr, litterToSoil = breakdown * X_1mFlr;
+    const R qm = qSoilT * mK;
+    const R soilMethane = X_soilCH4 * eSoilC * qm, litterMethane = X_litCH4 * eLitter * qm;
+    const R sat = clip01(soilCNow * X_iSoilCSat);          // 0 without carbon saturation
+    const R soilInputs = rootLoss + litterToSoil;
+    const R dLitter = aboveLitter + soilInputs * sat - litterToSoil - rLitter - litterMethane;
+    const R dSoilTwo = soilInputs * (R(1) - sat) - rSoil - soilMethane;
+    const R dSoilOne = rootLoss + aboveLitter - rSoil - soilMethane;
+    soilGain = (double)((F_litterPool ? dSoilTwo : dSoilOne) * len);
+    litterGain = (double)((F_litterPool ? dLitter : R(0)) * len);
+    rHet = rSoil + rLitter;
+  };
   double delta = ST(plantCAccountingDelta);
   double ringSum = ST(ringSum), totNee = ST(totNee);
   int phenBits = (int)ST(phenBits);
@@ -1743,8 +1909,8 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         // member of the wavefront dies AFTER the loop, which that step leaves (the wavefront takes the
         // general step from then on) -- the loop body stays one straight run of code.  What the
         // tail needs from the step lives outside the loop for that.
-        R photosynthesis = 0, rSoil = 0, rVeg = 0, rCoarseRoot = 0, rFineRoot = 0;
-        double soilGain = 0.0, ringNew = 0.0;
+        R photosynthesis = 0, rSoil = 0, rVeg = 0, rCoarseRoot = 0, rFineRoot = 0, rHet = 0;
+        double soilGain = 0.0, litterGain = 0.0, ringNew = 0.0;
         R rvN = 0;
         bool rootsOk = true, useLast = false, dyingStep = false;
         auto finishStep = [&](auto mayDie) {
@@ -1785,13 +1951,16 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
           postAlive(&mailAlive[(t + 1) & 1][lane], t + 1, diedNow);
           if (!NCyc) {
             soilC += soilGain;
+            if (Opt) litterC += litterGain;
             if (MayDie && diedNow) {
               soilC += deathToSoil0;
-              soilC += deathToSoil1;
+              if (Opt && F_litterPool) litterC += deathToSoil1;   // sipnet.c:1735-1746: above-ground biomass to the litter pool
+              else soilC += deathToSoil1;
             }
             soilC = rmax0(soilC);
+            if (Opt) litterC = rmax0(litterC);
           }
-          const R tRh = rSoil * len;
+          const R tRh = (Opt ? rHet : rSoil) * len;
           const R tNee = R(-1.0) * ((tGpp - tRa) - tRh);
           if (!NCyc) totNee += (double)tNee;
           const double npp = (double)(photosynthesis - rVeg - rCoarseRoot - rFineRoot);
@@ -1829,6 +1998,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
           // this step's factors: five from wave F / L, the moisture effect from wave W (each flag read
           // before its values, one LDS round trip when both are current)
           R g1, g2, qSoilT, gFine, gCoarse, moistEff;
+          R mK = 0;       // Opt: row 6, wave W's methane moisture term
           ringNew = 0.0;  // LDS ring: the value this step evicts, read in the same round trip
           double minNStep = 0.0;   // NCyc: wave S's mineral nitrogen at the start of this step
           int minNSeq = 0;
@@ -1837,6 +2007,11 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
             if (NCyc)   // rows 0 1 3 4 and the plain soil Q10 factor (row 6, carried in `moistEff`'s place) + the mineral N
               takeFactorsN(&mailFac[t & 1][0][lane], &seqFac, &mailMinN[t & 1][lane], &seqMinN, t, g1, g2, gFine, gCoarse,
                            moistEff, minNStep, minNSeq);
+            else if (Opt && RingLds)
+              takeFactorsRing7(&mailFac[t & 1][0][lane], seqFacMoist, ldsAddr(&ringL[readSlot * 64 + lane]), t, g1,
+                               g2, qSoilT, gFine, gCoarse, moistEff, mK, ringNew);
+            else if (Opt)
+              takeFactors7(&mailFac[t & 1][0][lane], seqFacMoist, t, g1, g2, qSoilT, gFine, gCoarse, moistEff, mK);
             else if (RingLds)
               takeFactorsRing(&mailFac[t & 1][0][lane], seqFacMoist, ldsAddr(&ringL[readSlot * 64 + lane]), t, g1,
                               g2, qSoilT, gFine, gCoarse, moistEff, ringNew);
@@ -1861,9 +2036,10 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
           const R meanNpp = (R)(ringSum * 0.2);
           const R folResp = eLeaf * g1;
           rVeg = ffma(totalWoodC, g2, folResp);
+          if (Ext) rVeg += rmax0(X_growthFrac * meanNpp);   // vegResp2(), sipnet.c:1084-1103 (+0 with the flag off)
           rCoarseRoot = eCoarse * gCoarse;
           rFineRoot = eFine * gFine;
-          rSoil = eSoilC * fSoil;
+          if (!Opt) rSoil = eSoilC * fSoil;
           const R woodLitter = totalWoodC * K_wtr;
           const R leafLitter = eLeaf * K_ltr;
           R leafCreation = meanNpp * K_la, woodCreation = meanNpp * K_wa;
@@ -1889,7 +2065,10 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
           accum(plantWoodC, woodCreation - woodLitter, len);
           accum(coarseRootC, coarseRootCreation - coarseRootLoss, len);
           accum(fineRootC, fineRootCreation - fineRootLoss, len);
-          if (!NCyc) soilGain = (double)((coarseRootLoss + fineRootLoss + woodLitter + leafLitter - rSoil) * len);
+          if (Opt)
+            optSoilSide(eSoilC, (R)litterC, eSoilC, fSoil, qSoilT, mK, coarseRootLoss + fineRootLoss, woodLitter + leafLitter, len,
+                        rSoil, rHet, soilGain, litterGain);
+          else if (!NCyc) soilGain = (double)((coarseRootLoss + fineRootLoss + woodLitter + leafLitter - rSoil) * len);
           const R r_a = rVeg + rFineRoot + rCoarseRoot;
           const R alloc = leafCreation + woodCreation + fineRootCreation + coarseRootCreation;
           rootsOk = (plantWoodC > kTiny) && (fineRootC + coarseRootC > kTiny);
@@ -1925,9 +2104,39 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
     d2 q0, q6, q7;
     i4 j0;
     R g1, g2, qSoilT, gFine, gCoarse, moistEff;
+    R mK = 0;   // Opt: row 6 of the factor block, wave W's methane moisture term
     int facSeq, moistSeq;
     double minNStep = 0.0;   // NCyc: wave S's mineral nitrogen at the start of this step
-    if (NCyc) {
+    if (Opt) {
+      // as the default take below, with row 6 (behind wave W's flag, like row 5)
+      WAIT_BEGIN()
+      const unsigned fac = ldsAddr(&mailFac[t & 1][0][lane]);
+      const unsigned mst = ldsAddr(&mailFac[t & 1][5][lane]);
+      do {
+        if (sizeof(R) == 8) {
+          asm volatile("ds_read_b128 %0, %13\n\tds_read_b128 %1, %13 offset:96\n\tds_read_b128 %2, %13 offset:112\n\t"
+                       "ds_read_b128 %3, %13 offset:128\n\tds_read_b32 %4, %14\n\t"
+                       "ds_read_b64 %5, %15\n\tds_read_b64 %6, %15 offset:512\n\tds_read_b64 %7, %15 offset:1024\n\t"
+                       "ds_read_b64 %8, %15 offset:1536\n\tds_read_b64 %9, %15 offset:2048\n\t"
+                       "ds_read_b32 %10, %16\n\tds_read_b64 %11, %17\n\tds_read_b64 %12, %17 offset:512\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(q0), "=&v"(q6), "=&v"(q7), "=&v"(j0), "=&v"(facSeq), "=&v"(g1), "=&v"(g2),
+                         "=&v"(qSoilT), "=&v"(gFine), "=&v"(gCoarse), "=&v"(moistSeq), "=&v"(moistEff), "=&v"(mK)
+                       : "v"(ldsAddr(recB)), "v"(ldsAddr(&seqFac)), "v"(fac), "v"(ldsAddr(&seqMoist)), "v"(mst)
+                       : "memory");
+        } else {
+          asm volatile("ds_read_b128 %0, %13\n\tds_read_b128 %1, %13 offset:96\n\tds_read_b128 %2, %13 offset:112\n\t"
+                       "ds_read_b128 %3, %13 offset:128\n\tds_read_b32 %4, %14\n\t"
+                       "ds_read_b32 %5, %15\n\tds_read_b32 %6, %15 offset:256\n\tds_read_b32 %7, %15 offset:512\n\t"
+                       "ds_read_b32 %8, %15 offset:768\n\tds_read_b32 %9, %15 offset:1024\n\t"
+                       "ds_read_b32 %10, %16\n\tds_read_b32 %11, %17\n\tds_read_b32 %12, %17 offset:256\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(q0), "=&v"(q6), "=&v"(q7), "=&v"(j0), "=&v"(facSeq), "=&v"(g1), "=&v"(g2),
+                         "=&v"(qSoilT), "=&v"(gFine), "=&v"(gCoarse), "=&v"(moistSeq), "=&v"(moistEff), "=&v"(mK)
+                       : "v"(ldsAddr(recB)), "v"(ldsAddr(&seqFac)), "v"(fac), "v"(ldsAddr(&seqMoist)), "v"(mst)
+                       : "memory");
+        }
+      } while (uni(facSeq) < t || uni(moistSeq) < t);
+      WAIT_END(0)
+    } else if (NCyc) {
       // record fields, wave F's factors (rows 0 1 3 4 and the plain soil Q10 factor, row 6 -- carried in
       // `moistEff`'s place) and wave S's mineral nitrogen, each behind its flag, one round trip
       WAIT_BEGIN()
@@ -2017,6 +2226,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
     const bool alive0 = aliveC;
     const R eWood = (R)plantWoodC, eLeaf = (R)plantLeafC, eSoilC = (R)soilC;
     const R eCoarse = (R)coarseRootC, eFine = (R)fineRootC;
+    const R eLitter = (R)litterC;   // (Opt) before this step's events, like every pool the fluxes look at
     const R totalWoodC = (R)(plantWoodC + delta);
     // getMassTotals() before the pool updates, balance.c:13-36 (carbon; default flags)
     double preC = 0.0;
@@ -2045,10 +2255,12 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
 
     // vegResp(), calcRootResp(), calcSoilRespiration() with wave W's factors
     const R folResp = eLeaf * g1;
-    const R rVeg = ffma(totalWoodC, g2, folResp);
+    R rVeg = ffma(totalWoodC, g2, folResp);
+    if (Ext) rVeg += rmax0(X_growthFrac * meanNpp);   // vegResp2(), sipnet.c:1084-1103 (+0 with the flag off)
     const R rCoarseRoot = eCoarse * gCoarse;
     const R rFineRoot = eFine * gFine;
-    const R rSoil = NCyc ? R(0) : eSoilC * fSoil;
+    R rSoil = (NCyc || Opt) ? R(0) : eSoilC * fSoil;   // (Opt: optSoilSide, after the events)
+    R rHet = 0;
 
     const R woodLitter = totalWoodC * K_wtr;
     R leafLitter = eLeaf * K_ltr;
@@ -2102,6 +2314,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
       R evSoilC = 0, evLeafOnCreation = 0, evLeafOnFromWood = 0, evLeafOffLitter = 0;
       // NCyc: the soil side of the events (events.c:575-620, :660-672, :712-722, :778-789), for wave W
       R evLitterC = 0, evMinN = 0, evSoilOrgN = 0, evLitterN = 0, evLeafOffNResorp = 0;
+      const bool toLitter = Opt && F_litterPool;   // Opt: above-ground transfers and organic carbon go to the litter pool
       const int ev0 = uni(rareI[3]);
       for (int k = 0; k < nEv; k++) {
         const EvRec& ev = a.events[evBase + ev0 + k];
@@ -2121,6 +2334,9 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
             evSoilC += (p3 * (eFine + eCoarse)) * invLen;
             evSoilOrgN += (p3 * (eFine * G_iFineCN + eCoarse * G_iWoodCN)) * invLen;
             evLitterN += (p2 * (eLeaf * G_iLeafCN + eWood * G_iWoodCN)) * invLen;
+          } else if (toLitter) {   // events.c:575-580
+            evLitterC += (p2 * (eLeaf + woodC)) * invLen;
+            evSoilC += (p3 * (eFine + eCoarse)) * invLen;
           } else {
             evSoilC += (p3 * (eFine + eCoarse) + p2 * (eLeaf + woodC)) * invLen;
           }
@@ -2133,6 +2349,8 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
             evLitterC += p1 * invLen;
             evLitterN += p0 * invLen;
             evMinN += p2 * invLen;
+          } else if (toLitter) {
+            evLitterC += p1 * invLen;
           } else {
             evSoilC += p1 * invLen;
           }
@@ -2176,7 +2394,12 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
       plantWoodC -= (double)(evLeafOnFromWood * len);
       coarseRootC -= (double)((evLeafOnCreation - evLeafOnFromWood) * len);
       plantLeafC += (double)((evLeafOnCreation - evLeafOffLitter) * len);
-      if (!NCyc) soilC += (double)(evLeafOffLitter * len);
+      if (toLitter) {
+        litterC += (double)(evLitterC * len);
+        litterC += (double)(evLeafOffLitter * len);
+      } else if (!NCyc) {
+        soilC += (double)(evLeafOffLitter * len);
+      }
       coarseRootC += (double)(evCoarseRootC * len);
       fineRootC += (double)(evFineRootC * len);
     }
@@ -2197,7 +2420,11 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
     accum(plantWoodC, woodCreation - woodLitter - leafOnFromWood, len);
     accum(coarseRootC, coarseRootCreation - coarseRootLoss - (leafOnCreation - leafOnFromWood), len);
     accum(fineRootC, fineRootCreation - fineRootLoss, len);
-    const double soilGain = NCyc ? 0.0 : (double)((coarseRootLoss + fineRootLoss + woodLitter + leafLitter - rSoil) * len);
+    double soilGain = 0.0, litterGain = 0.0;
+    if (Opt)
+      optSoilSide(eSoilC, eLitter, (R)soilC, fSoil, qSoilT, mK, coarseRootLoss + fineRootLoss, woodLitter + leafLitter, len,
+                  rSoil, rHet, soilGain, litterGain);
+    else if (!NCyc) soilGain = (double)((coarseRootLoss + fineRootLoss + woodLitter + leafLitter - rSoil) * len);
     const R r_a = rVeg + rFineRoot + rCoarseRoot;
     const R alloc = leafCreation + woodCreation + fineRootCreation + coarseRootCreation;
     const bool rootsOk = (plantWoodC > kTiny) && (fineRootC + coarseRootC > kTiny);
@@ -2274,14 +2501,17 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
 
     CSTAMP(4)
     soilC += soilGain;
+    if (Opt) litterC += litterGain;
     if (!NCyc && __builtin_expect(__builtin_amdgcn_ballot_w64(diedNow) != 0, 0)) {
       if (diedNow) {
         soilC += deathToSoil0;
-        soilC += deathToSoil1;
+        if (Opt && F_litterPool) litterC += deathToSoil1;   // sipnet.c:1735-1746
+        else soilC += deathToSoil1;
       }
     }
     if (wantDiag && soilC < 0.0 && fabs(soilC) > kEps) clampWarn++;
     soilC = rmax0(soilC);
+    if (Opt) litterC = rmax0(litterC);
     if (wantDiag) {  // updateBalanceTrackerPostClamp() + checkBalance(), balance.c:40-169
       const double finC = (plantWoodC + delta) + plantLeafC + fineRootC + coarseRootC + soilC;
       double clampedC = finC - postC;
@@ -2297,7 +2527,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
 
     // ---- outputs: updateTrackers(), sipnet.c:1420-1496 ---------------------------------------
     const R tGpp = photosynthesis * len;
-    const R tRh = rSoil * len;
+    const R tRh = (Opt ? rHet : rSoil) * len;
     const R tRa = ffma(rVeg, len, (rCoarseRoot + rFineRoot) * len);
     const R tNee = R(-1.0) * ((tGpp - tRa) - tRh);
     if (!NCyc) totNee += (double)tNee;
@@ -2436,6 +2666,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
     ST(plantWoodC) = plantWoodC;
     ST(plantLeafC) = plantLeafC;
     if (!NCyc) ST(soilC) = soilC;
+    if (Opt) ST(litterC) = litterC;
     ST(coarseRootC) = coarseRootC;
     ST(fineRootC) = fineRootC;
     ST(plantCAccountingDelta) = delta;
@@ -2517,6 +2748,26 @@ __global__ __launch_bounds__(512) void stepCoopNPairKernel(FastArgs a) {
   coopBody<R, PlainExp, false, false, 2, true>(a);
 }
 
+// ---- Ext: the optional-physics instantiations (run-time flags; see coopBody) -----------------------------------
+// default pools + growth respiration / leaf water / flooding / litter pool / carbon saturation / anaerobic + methane
+template <class R, bool PlainExp, bool RingLds>
+__global__ __launch_bounds__(RingLds ? 256 : 192) void stepCoopXKernel(FastArgs a) {
+  coopBody<R, PlainExp, RingLds, false, 1, false, true>(a);
+}
+template <class R, bool PlainExp>
+__global__ __launch_bounds__(512) void stepCoopXPairKernel(FastArgs a) {
+  coopBody<R, PlainExp, false, false, 2, false, true>(a);
+}
+// the nitrogen-cycle flag set + growth respiration / leaf water / flooding / carbon saturation
+template <class R, bool PlainExp>
+__global__ __launch_bounds__(256) void stepCoopNXKernel(FastArgs a) {
+  coopBody<R, PlainExp, false, false, 1, true, true>(a);
+}
+template <class R, bool PlainExp>
+__global__ __launch_bounds__(512) void stepCoopNXPairKernel(FastArgs a) {
+  coopBody<R, PlainExp, false, false, 2, true, true>(a);
+}
+
 #ifdef SIPNET_HWID
 extern "C" int sipnet_debug_read_coop_hwid(unsigned* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_coopHwId), sizeof(unsigned) * 4096 * 4 * 2);
@@ -2536,7 +2787,10 @@ extern "C" int sipnet_debug_read_coop_stamps(unsigned long long* out) {
 void launchStepCoop(const FastArgs& a, int precision, int layout, hipStream_t stream, LaunchInfo* info) {
   const int chunksPerSite = (a.n_members + 63) / 64;
   const bool ringInLds = layout == COOP_RING_LDS, pair = layout == COOP_PAIR, quad = layout == COOP_QUAD;
-  if (layout == COOP_NCYCLE || layout == COOP_NCYCLE_PAIR) {
+  // flags beyond the compiled-in set of the layout's family: the optional-physics instantiations (run-time flags)
+  const bool nFamily = layout == COOP_NCYCLE || layout == COOP_NCYCLE_PAIR;
+  const bool ext = nFamily ? !isNCycleFlagSet(a.flags) : !isDefaultFlagSet(a.flags);
+  if (nFamily) {
     const bool pairN = layout == COOP_NCYCLE_PAIR;
     const int chunksN = a.n_sites * chunksPerSite;
     const int groupsN = (a.n_sites & 7) == 0 ? 8 * ((chunksN / 8 + 1) / 2) : (chunksN + 1) / 2;   // (see pairGroups below)
@@ -2549,10 +2803,15 @@ void launchStepCoop(const FastArgs& a, int precision, int layout, hipStream_t st
       if (a.plainExp) hipLaunchKernelGGL((K<float, true>), gridN, blockN, 0, stream, a);          \
       else hipLaunchKernelGGL((K<float, false>), gridN, blockN, 0, stream, a);                    \
     }
-    if (pairN) { NCYC_LAUNCH(stepCoopNPairKernel) } else { NCYC_LAUNCH(stepCoopNKernel) }
+    if (ext) {
+      if (pairN) { NCYC_LAUNCH(stepCoopNXPairKernel) } else { NCYC_LAUNCH(stepCoopNXKernel) }
+    } else {
+      if (pairN) { NCYC_LAUNCH(stepCoopNPairKernel) } else { NCYC_LAUNCH(stepCoopNKernel) }
+    }
 #undef NCYC_LAUNCH
     if (info) {
-      snprintf(info->kernel, sizeof info->kernel, "%s<%s, %s>", pairN ? "stepCoopNPairKernel" : "stepCoopNKernel",
+      snprintf(info->kernel, sizeof info->kernel, "%s<%s, %s>",
+               ext ? (pairN ? "stepCoopNXPairKernel" : "stepCoopNXKernel") : (pairN ? "stepCoopNPairKernel" : "stepCoopNKernel"),
                precision == SIPNET_F64 ? "double" : "float", a.plainExp ? "true" : "false");
       info->grid = (int32_t)gridN.x;
       info->block = pairN ? 512 : 256;
@@ -2578,7 +2837,17 @@ void launchStepCoop(const FastArgs& a, int precision, int layout, hipStream_t st
     if (a.full) hipLaunchKernelGGL((stepCoopPairKernel<R, P, true>), grid, block, 0, stream, a);     \
     else hipLaunchKernelGGL((stepCoopPairKernel<R, P, false>), grid, block, 0, stream, a);          \
   }
-  if (quad) {
+  if (ext) {   // (one or two chunks per workgroup, lean: the engine does not ask for anything else)
+#define X_LAUNCH(R, P)                                                                                        \
+  {                                                                                                           \
+    if (pair) hipLaunchKernelGGL((stepCoopXPairKernel<R, P>), grid, block, 0, stream, a);                     \
+    else if (ringInLds) hipLaunchKernelGGL((stepCoopXKernel<R, P, true>), grid, block, 0, stream, a);         \
+    else hipLaunchKernelGGL((stepCoopXKernel<R, P, false>), grid, block, 0, stream, a);                       \
+  }
+    if (precision == SIPNET_F64) { if (a.plainExp) X_LAUNCH(double, true) else X_LAUNCH(double, false) }
+    else { if (a.plainExp) X_LAUNCH(float, true) else X_LAUNCH(float, false) }
+#undef X_LAUNCH
+  } else if (quad) {
     if (precision == SIPNET_F64) {
       if (a.plainExp) hipLaunchKernelGGL((stepCoopQuadKernel<double, true>), grid, block, 0, stream, a);
       else hipLaunchKernelGGL((stepCoopQuadKernel<double, false>), grid, block, 0, stream, a);
@@ -2602,7 +2871,9 @@ void launchStepCoop(const FastArgs& a, int precision, int layout, hipStream_t st
     const char* r = precision == SIPNET_F64 ? "double" : "float";
     const char* pe = a.plainExp ? "true" : "false";
     const char* fu = a.full ? "true" : "false";
-    if (quad) snprintf(info->kernel, sizeof info->kernel, "stepCoopQuadKernel<%s, %s>", r, pe);
+    if (ext && pair) snprintf(info->kernel, sizeof info->kernel, "stepCoopXPairKernel<%s, %s>", r, pe);
+    else if (ext) snprintf(info->kernel, sizeof info->kernel, "stepCoopXKernel<%s, %s, %s>", r, pe, ringInLds ? "true" : "false");
+    else if (quad) snprintf(info->kernel, sizeof info->kernel, "stepCoopQuadKernel<%s, %s>", r, pe);
     else if (pair) snprintf(info->kernel, sizeof info->kernel, "stepCoopPairKernel<%s, %s, %s>", r, pe, fu);
     else snprintf(info->kernel, sizeof info->kernel, "stepCoopKernel<%s, %s, %s, %s>", r, pe,
                   ringInLds ? "true" : "false", fu);
@@ -2610,7 +2881,7 @@ void launchStepCoop(const FastArgs& a, int precision, int layout, hipStream_t st
     info->block = (int32_t)block.x;
     info->wavesPerSimd = pair ? 2 : quad ? 3 : 1;
     const int elem = precision == SIPNET_F64 ? 8 : 4;
-    info->ldsBytes = (pair ? 2 : quad ? 4 : 1) * (3 * 2 * kTileBytes + (2 * 64 * 3 + 2 * 6 * 64) * elem + 2 * 64 * 4 + 7 * 4) +
+    info->ldsBytes = (pair ? 2 : quad ? 4 : 1) * (3 * 2 * kTileBytes + (2 * 64 * 3 + 2 * (ext ? 7 : 6) * 64) * elem + 2 * 64 * 4 + 7 * 4) +
                      (ringInLds ? SIPNET_RING_SLOTS * 64 : 64) * 8;
   }
 }

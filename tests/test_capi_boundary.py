@@ -117,8 +117,8 @@ def test_every_bench_workload_has_traffic_evidence_for_the_kernel_auto_picks():
 def test_auto_kernel_policy_by_shape_and_flags():
     """sipnet_kernel_choice (host-only; the function sipnet_batch_run uses): layouts by chunks per CU, the flags
     that are data (events, gdd, soil_phenol, water_hresp) keep the default-physics kernels, the nitrogen-cycle
-    set has its own one- and two-chunk kernels, every other optional flag takes the one-wave kernel, strict
-    math the strict kernel"""
+    sets have their own one- and two-chunk kernels, every other optional flag takes the optional-physics
+    instantiations of the one- and two-chunk layouts, strict math the strict kernel"""
     import sipnet_amd as sa
     L = sa.lib()
 
@@ -140,7 +140,15 @@ def test_auto_kernel_policy_by_shape_and_flags():
     assert choice(10240, **ncyc) == choice(10240, gdd=0, soilPhenol=1, **ncyc) == sa.KERNEL_COOP_NCYCLE
     assert choice(1024, sites=32, **ncyc) == sa.KERNEL_COOP_NCYCLE_PAIR
     assert choice(32769, **ncyc) == choice(10240, full=1, **ncyc) == sa.KERNEL_ONE_WAVE
+    # every other optional flag: the optional-physics instantiations of the one- and two-chunk layouts (lean), the
+    # one-wave kernel beyond two chunks per CU and for full-state launches; with the nitrogen cycle on top: its kernels
     for other in (dict(growthResp=1), dict(leafWater=1), dict(litterPool=1), dict(flooding=1),
-                  dict(litterPool=1, carbonSaturation=1), dict(anaerobic=1)):
-        assert choice(10240, **other) == sa.KERNEL_ONE_WAVE, other
+                  dict(litterPool=1, carbonSaturation=1), dict(anaerobic=1),
+                  dict(growthResp=1, leafWater=1, litterPool=1, waterHResp=0)):                  # (the last: russell_3)
+        assert choice(10240, **other) == sa.KERNEL_COOP_LDS, other
+        assert choice(1024, sites=32, **other) == sa.KERNEL_COOP_PAIR, other
+        assert choice(65536, **other) == choice(10240, full=1, **other) == sa.KERNEL_ONE_WAVE, other
+    everything = dict(carbonSaturation=1, flooding=1, growthResp=1, leafWater=1, **ncyc)
+    assert choice(10240, **everything) == sa.KERNEL_COOP_NCYCLE and choice(1024, sites=32, **everything) == sa.KERNEL_COOP_NCYCLE_PAIR
+    assert choice(10240, full=1, **everything) == sa.KERNEL_ONE_WAVE
     assert choice(0) == -1 and choice(64, cus=0) == -1

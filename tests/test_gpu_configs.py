@@ -262,8 +262,26 @@ KERNELS = [
     ("coop_ncycle_pair_f64", sa.F64, sa.KERNEL_COOP_NCYCLE_PAIR, 0, "stepCoopNPairKernel<double, false>"),
     ("coop_ncycle_pair_f32", sa.F32_MIXED, sa.KERNEL_COOP_NCYCLE_PAIR, 0, "stepCoopNPairKernel<float, false>"),
     ("coop_ncycle_pair_f64_plain", sa.F64, sa.KERNEL_COOP_NCYCLE_PAIR, 0, "stepCoopNPairKernel<double, true>"),
+    # the optional-physics instantiations (run-time flags; the flag set rides in the row's name): russell_3's family
+    # on the default pools' layouts, "everything" on the nitrogen-cycle ones
+    ("x_russell3_lds_f64", sa.F64, sa.KERNEL_COOP_LDS, 0, "stepCoopXKernel<double, false, true>"),
+    ("x_russell3_lds_f32", sa.F32_MIXED, sa.KERNEL_COOP_LDS, 0, "stepCoopXKernel<float, false, true>"),
+    ("x_russell3_hbm_f64", sa.F64, sa.KERNEL_COOP_HBM, 0, "stepCoopXKernel<double, false, false>"),
+    ("x_russell3_pair_f64", sa.F64, sa.KERNEL_COOP_PAIR, 0, "stepCoopXPairKernel<double, false>"),
+    ("x_russell3_pair_f32", sa.F32_MIXED, sa.KERNEL_COOP_PAIR, 0, "stepCoopXPairKernel<float, false>"),
+    ("x_russell3_lds_f64_plain", sa.F64, sa.KERNEL_COOP_LDS, 0, "stepCoopXKernel<double, true, true>"),
+    ("x_anaerobic_sat_flood_lds_f64", sa.F64, sa.KERNEL_COOP_LDS, 0, "stepCoopXKernel<double, false, true>"),
+    ("x_anaerobic_sat_flood_pair_f64", sa.F64, sa.KERNEL_COOP_PAIR, 0, "stepCoopXPairKernel<double, false>"),
+    ("x_anaerobic_sat_flood_pair_f32", sa.F32_MIXED, sa.KERNEL_COOP_PAIR, 0, "stepCoopXPairKernel<float, false>"),
+    ("x_everything_ncycle_f64", sa.F64, sa.KERNEL_COOP_NCYCLE, 0, "stepCoopNXKernel<double, false>"),
+    ("x_everything_ncycle_f32", sa.F32_MIXED, sa.KERNEL_COOP_NCYCLE, 0, "stepCoopNXKernel<float, false>"),
+    ("x_everything_ncycle_pair_f64", sa.F64, sa.KERNEL_COOP_NCYCLE_PAIR, 0, "stepCoopNXPairKernel<double, false>"),
+    ("x_everything_ncycle_pair_f64_plain", sa.F64, sa.KERNEL_COOP_NCYCLE_PAIR, 0, "stepCoopNXPairKernel<double, true>"),
 ]
 NCYCLE_FLAGS = dict(litterPool=1, anaerobic=1, nitrogenCycle=1)
+X_FLAGS = {"russell3": dict(growthResp=1, leafWater=1, litterPool=1, waterHResp=0),
+           "anaerobic_sat_flood": dict(anaerobic=1, litterPool=1, carbonSaturation=1, flooding=1, growthResp=1, leafWater=1),
+           "everything": dict(carbonSaturation=1, flooding=1, growthResp=1, leafWater=1, **NCYCLE_FLAGS)}
 
 
 @pytest.mark.parametrize("name,prec,kernel,options,expect", KERNELS, ids=[k[0] for k in KERNELS])
@@ -274,10 +292,23 @@ def test_every_throughput_kernel_instantiation_against_the_oracle(name, prec, ke
     the same schedule without the lethal events (emptied pools keep ~1e-5 gC of fp32 residue,
     which the fuzz test judges by time sums instead)"""
     flags = sa.flags_from()
-    if kernel in (sa.KERNEL_COOP_NCYCLE, sa.KERNEL_COOP_NCYCLE_PAIR):
+    if name.startswith("x_"):
+        flags = sa.flags_from(**X_FLAGS[[k for k in X_FLAGS if name.startswith("x_" + k)][0]])
+        base = sa.read_params(os.path.join(os.path.dirname(BASE), "allflags_forest.param"), flags)[0]
+    elif kernel in (sa.KERNEL_COOP_NCYCLE, sa.KERNEL_COOP_NCYCLE_PAIR):
         flags = sa.flags_from(**NCYCLE_FLAGS)
         base = sa.read_params(os.path.join(os.path.dirname(BASE), "allflags_forest.param"), flags)[0]
     clim, ev, members = _scenario(base, lethal=prec == sa.F64)
+    if name.startswith("x_"):
+        # spread on what only the optional flags read (the saturation level around the soil carbon stock, so that the
+        # unit clip works on both sides; partial flood drainage; a canopy that holds little water)
+        rng = np.random.default_rng(5)
+        n = members.shape[0]
+        members[:, pi("soilCSaturation")] = members[:, pi("soilInit")] * rng.uniform(0.5, 3.0, n)
+        members[:, pi("waterDrainFrac")] = rng.uniform(0.2, 1.0, n)
+        members[:, pi("leafPoolDepth")] *= rng.uniform(0.02, 1.5, n)
+        members[:, pi("growthRespFrac")] *= rng.uniform(0.5, 1.5, n)
+        members[:, pi("litterBreakdownRate")] *= rng.uniform(0.5, 2.0, n)
     if name.endswith("_plain"):
         members[:, pi("dVpdExp")] = 2.0
         members[:, pi("soilRespMoistEffect")] = 1.0

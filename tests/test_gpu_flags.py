@@ -21,8 +21,8 @@ BASE = os.path.join(helpers.GOLDEN, "synth", "allflags.param")  # every optional
 POOLS = slice(14, 27)  # record columns holding the 13 pools (include/sipnet_amd.h)
 
 
-def lean_run(flags, clim, members, events=None, fast=True, prec=sa.F64):
-    b = sa.Batch(flags, 1, members.shape[0], prec, fast_math=fast if prec == sa.F64 else None)
+def lean_run(flags, clim, members, events=None, fast=True, prec=sa.F64, kernel=sa.KERNEL_AUTO):
+    b = sa.Batch(flags, 1, members.shape[0], prec, fast_math=fast if prec == sa.F64 else None, kernel=kernel)
     if events is not None:
         b.set_events(0, events)
     b.set_climate(0, clim)
@@ -30,7 +30,7 @@ def lean_run(flags, clim, members, events=None, fast=True, prec=sa.F64):
     b.setup()
     planes, _ = b.run()
     status = b.get_status()
-    name = ""
+    name = b.last_launch()["kernel"]
     state = b.get_state()
     got = planes.cpu().numpy()
     b.close()
@@ -154,10 +154,19 @@ def members70():
 def test_each_flag_set_matches_oracle(name, oracle, clim60, members70):
     flags = _flags(**FLAG_SETS[name])
     ev = _events_all_types(clim60) if flags[F_EVENTS] else None
-    got, state, status, _ = lean_run(flags, clim60, members70, ev)
+    got, state, status, kernel = lean_run(flags, clim60, members70, ev)
     want, final, st = oracle.run_block(flags, members70, clim60, ev)
     assert (st == 0).all() and (np.asarray(status) == 0).all()
-    compare(name, got, state, want, final)
+    # AUTO at two chunks: a cooperative kernel for EVERY flag set -- the default-physics one where the flags are data, the
+    # nitrogen-cycle one, and their optional-physics instantiations (run-time flags) for the rest
+    family = ("stepCoopNKernel<" if name == "nitrogen" else "stepCoopNXKernel<" if name == "everything" else
+              "stepCoopKernel<" if name in ("no_water_hresp", "soil_phenol", "calendar_phenology", "no_events") else "stepCoopXKernel<")
+    assert kernel.startswith(family), (name, kernel)
+    compare(f"{name} [{kernel}]", got, state, want, final)
+    # ... and the one-wave kernel's run-time-flag build, which bigger batches and full-state launches of these sets take
+    got, state, status, kernel = lean_run(flags, clim60, members70, ev, kernel=sa.KERNEL_ONE_WAVE)
+    assert kernel.startswith("stepFastKernel<double"), kernel
+    compare(f"{name} [{kernel}]", got, state, want, final)
 
 
 PHENOLOGY_MODES = {"gdd": dict(), "soil_phenol": dict(gdd=0, soilPhenol=1), "calendar": dict(gdd=0),
@@ -337,3 +346,96 @@ def test_nitrogen_cycle_kernel_paths_give_the_same_bits(clim60, members70):
         np.testing.assert_array_equal(outs["reg"][k], outs["pair_gen"][k])
     assert np.array_equal(outs["reg"][0][:, :, 3], outs["reg"][0][:, :, 73])      # the same member in both chunks
     assert np.abs(outs["reg"][0] - outs["one"][0]).max() < 1e-11
+
+
+# ---- the optional-physics instantiations of the cooperative layouts (stepCoopXKernel & co: run-time flags) ----------
+OPT_SETS = {
+    "russell_3": (dict(growthResp=1, leafWater=1, litterPool=1, waterHResp=0), "stepCoopX"),
+    "anaerobic_litter_saturation_flooding": (dict(anaerobic=1, litterPool=1, carbonSaturation=1, flooding=1), "stepCoopX"),
+    "growth_resp_leaf_water": (dict(growthResp=1, leafWater=1), "stepCoopX"),
+    "anaerobic_alone": (dict(anaerobic=1), "stepCoopX"),
+    "everything": (FLAG_SETS["everything"], "stepCoopNX"),
+}
+
+
+@pytest.mark.parametrize("name", list(OPT_SETS))
+def test_optional_physics_layouts_give_the_same_bits_and_match_the_oracle(name, oracle, clim60, members70):
+    """every cooperative layout of an optional flag set -- ring in LDS / in HBM, two chunks per workgroup, regular
+    tiles against the general step -- forced in turn on a year with every event type, a clear-cut that kills every
+    stand, a re-planting, a member dead from the start and a launch cut at odd steps: identical planes, state and
+    rings (which path a wavefront takes depends on its neighbours), 1e-9 against the oracle, the one-wave kernel's
+    run-time-flag build to rounding"""
+    kw, family = OPT_SETS[name]
+    flags = _flags(**kw)
+    ncyc = family == "stepCoopNX"
+    ev, members = _ncycle_scenario(clim60, members70, lethal=True) if ncyc else (None, None)
+    if not ncyc:
+        ev = _events_all_types(clim60)
+        def add(day, typ, *p):
+            e = sa.Event(); e.type = typ; e.year = int(clim60.year[0]); e.day = day
+            for i, v in enumerate(p):
+                e.p[i] = v
+            ev.append(e)
+        add(230, 1, 1.0, 1.0, 0.0, 0.0)          # clear-cut: every member dies
+        add(240, 3, 40.0, 300.0, 50.0, 60.0)     # re-planting
+        ev.sort(key=lambda e: (e.year, e.day))
+        members = members70.copy()
+        members[5, param_index("plantWoodInit")] = 0.0
+    members = np.concatenate([members, members[:58]])                 # 128 members: two full chunks
+    T = clim60.n_steps
+    one, two = (sa.KERNEL_COOP_NCYCLE, sa.KERNEL_COOP_NCYCLE_PAIR) if ncyc else (sa.KERNEL_COOP_LDS, sa.KERNEL_COOP_PAIR)
+    runs = [("reg", one, 0), ("gen", one, sa.KOPT_NO_REGULAR_TILES), ("pair", two, 0), ("pair_gen", two, sa.KOPT_NO_REGULAR_TILES),
+            ("one_wave", sa.KERNEL_ONE_WAVE, 0)]
+    if not ncyc:
+        runs.insert(2, ("hbm", sa.KERNEL_COOP_HBM, 0))
+    outs, names = {}, {}
+    for key, kernel, opt in runs:
+        b = sa.Batch(flags, 1, members.shape[0], sa.F64, fast_math=True, kernel=kernel, kernel_options=opt)
+        b.set_events(0, ev)
+        b.set_climate(0, clim60)
+        b.set_params(0, members)
+        b.setup()
+        planes, _ = b.alloc_outputs(T)
+        for a, z in ((0, 1), (1, 7), (7, 8003), (8003, 8019), (8019, T)):
+            b.run(a, z - a, planes=planes[:, a:z])
+        names[key] = b.last_launch()["kernel"]
+        assert (np.asarray(b.get_status()) == 0).all()
+        outs[key] = (planes.cpu().numpy(), b.get_state(), b.get_rings())
+        b.close()
+    assert names["reg"].startswith(family + "Kernel<double"), names
+    assert names["pair"].startswith(family + "PairKernel<double"), names
+    assert names["one_wave"].startswith("stepFastKernel<double, false, 1,"), names
+    want, final, st = oracle.run_block(flags, members, clim60, ev)
+    assert (st == 0).all()
+    compare(f"{name} {names['reg']}", outs["reg"][0], outs["reg"][1], want, final)
+    for key in outs:
+        if key in ("reg", "one_wave"):
+            continue
+        for k in range(3):
+            np.testing.assert_array_equal(outs["reg"][k], outs[key][k], err_msg=f"{key} [{k}]")
+    assert np.abs(outs["reg"][0] - outs["one_wave"][0]).max() < 1e-10
+    assert outs["reg"][1][0, 30] >= 0 and outs["reg"][1][0, 0] > 100.0          # died at the clear-cut, wood is back
+
+
+@pytest.mark.parametrize("name", ["russell_3", "anaerobic_litter_saturation_flooding"])
+def test_optional_physics_layouts_in_fp32_mixed(name, oracle, clim60, members70):
+    kw, family = OPT_SETS[name]
+    flags = _flags(**kw)
+    ev = _events_all_types(clim60)
+    want, final, st = oracle.run_block(flags, members70, clim60, ev)
+    scale = np.abs(want).max(axis=(1, 2), keepdims=True)
+    got = {}
+    for kernel in (sa.KERNEL_COOP_LDS, sa.KERNEL_COOP_PAIR):
+        b = sa.Batch(flags, 1, members70.shape[0], sa.F32_MIXED, kernel=kernel)
+        b.set_events(0, ev)
+        b.set_climate(0, clim60)
+        b.set_params(0, members70)
+        b.setup()
+        planes, _ = b.run()
+        assert b.last_launch()["kernel"].startswith(family), b.last_launch()
+        got[kernel] = planes.double().cpu().numpy()
+        b.close()
+        rel = (np.abs(got[kernel] - want) / scale).max()
+        print(f"fp32-mixed {name} kernel {kernel}: max |d| / max|plane| = {rel:.3e}")
+        assert rel < 2e-3
+    np.testing.assert_array_equal(got[sa.KERNEL_COOP_LDS], got[sa.KERNEL_COOP_PAIR])

@@ -85,3 +85,16 @@ def test_fuzz_nitrogen_cycle_cooperative_kernel():
     print(r.stdout[-3000:])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "140 trials ok" in r.stdout and "coop-ncycle" in r.stdout
+
+
+def test_fuzz_optional_physics_cooperative_kernels():
+    """a fixed-seed slice of the optional-physics campaign (FUZZ_OPT=1: growth respiration, leaf water, flooding,
+    litter pool, carbon saturation, anaerobic -- alone or on top of the nitrogen cycle; the cooperative layouts'
+    run-time-flag instantiations forced in turn or picked by the shape policy, regular tiles on and off, fragile
+    stands, random events and launch cuts)"""
+    env = dict(os.environ, FUZZ_OPT="1")
+    r = subprocess.run([sys.executable, os.path.join(helpers.REPO, "tools", "fuzz_gpu.py"), "60", "41"],
+                       capture_output=True, text=True, timeout=1200, env=env)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "60 trials ok" in r.stdout and "stepCoopX" in r.stdout and "stepCoopNX" in r.stdout

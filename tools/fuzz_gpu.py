@@ -22,6 +22,10 @@ COOP_ONLY = bool(os.environ.get("FUZZ_COOP"))
 # by the shape policy, fragile members, and productive members short of nitrogen (the exact-supply
 # hand-over of checkNitrogenLimitation)
 NCYC_ONLY = bool(os.environ.get("FUZZ_NCYC"))
+# FUZZ_OPT=1: a campaign on the optional-physics instantiations of the cooperative layouts (stepCoopXKernel & co,
+# stepCoopNXKernel & co: run-time flags): always some optional flag on, throughput arithmetic, lean launches, the
+# one- and two-chunk layouts forced in turn or picked by the shape policy, regular tiles on and off, fragile stands
+OPT_ONLY = bool(os.environ.get("FUZZ_OPT"))
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
 only = int(sys.argv[3]) if len(sys.argv) > 3 else -1      # rerun one trial with details
@@ -44,6 +48,20 @@ def random_flags():
     if f["litterPool"] and rng.random() < 0.4: f["carbonSaturation"] = 1
     if rng.random() < 0.25 or COOP_ONLY: f = {}          # default flags: throughput / cooperative kernels
     if NCYC_ONLY: f = dict(litterPool=1, anaerobic=1, nitrogenCycle=1, events=int(rng.random() < 0.8))
+    if OPT_ONLY:
+        while True:
+            f = dict(events=int(rng.random() < 0.8), growthResp=int(rng.random() < 0.4), leafWater=int(rng.random() < 0.4),
+                     litterPool=int(rng.random() < 0.5), flooding=int(rng.random() < 0.3), anaerobic=int(rng.random() < 0.4),
+                     waterHResp=1, carbonSaturation=0, nitrogenCycle=0)
+            if not f["anaerobic"] and rng.random() < 0.2: f["waterHResp"] = 0
+            if f["litterPool"] and rng.random() < 0.4: f["carbonSaturation"] = 1
+            if f["anaerobic"] and f["litterPool"] and rng.random() < 0.4: f["nitrogenCycle"] = 1
+            r = rng.random()
+            if r < 0.2: f["gdd"] = 0
+            elif r < 0.4: f["gdd"], f["soilPhenol"] = 0, 1
+            extras = f["growthResp"] + f["leafWater"] + f["flooding"] + f["carbonSaturation"]
+            if (f["nitrogenCycle"] and extras) or (not f["nitrogenCycle"] and (extras or f["litterPool"] or f["anaerobic"])):
+                break
     return f
 
 def random_events(clim, n):
@@ -94,6 +112,14 @@ for trial in range(trials):
     if COOP_ONLY and M > 8:
         for mm in rng.choice(M, size=min(4, M // 8), replace=False):      # fragile stands: a harvest may finish them off
             members[mm, pi("plantWoodInit")] *= float(10.0 ** -rng.uniform(1.5, 4.0))
+    if OPT_ONLY and M > 8:
+        for mm in rng.choice(M, size=min(4, M // 8), replace=False):      # fragile stands: a harvest may finish them off
+            members[mm, pi("plantWoodInit")] *= float(10.0 ** -rng.uniform(1.5, 4.0))
+        n_ = M
+        members[:, pi("soilCSaturation")] = members[:, pi("soilInit")] * rng.uniform(0.5, 3.0, n_)
+        members[:, pi("waterDrainFrac")] = rng.uniform(0.2, 1.0, n_)
+        members[:, pi("leafPoolDepth")] *= rng.uniform(0.02, 1.5, n_)
+        if rng.random() < 0.3: members[:, pi("anaerobicTransExp")] = rng.uniform(1.0, 3.0, n_)
     if NCYC_ONLY and M > 8:
         for mm in rng.choice(M, size=min(4, M // 8), replace=False):      # fragile stands
             members[mm, pi("plantWoodInit")] *= float(10.0 ** -rng.uniform(1.5, 4.0))
@@ -104,7 +130,7 @@ for trial in range(trials):
                 members[mm, pi("mineralNInit")] = float(10.0 ** -rng.uniform(1, 5))
                 members[mm, pi("plantStorageNInit")] = float(10.0 ** -rng.uniform(0, 4))
                 members[mm, pi("soilOrgNInit")] *= float(10.0 ** -rng.uniform(0, 3))
-    fast = bool(rng.random() < 0.7) or COOP_ONLY or NCYC_ONLY
+    fast = bool(rng.random() < 0.7) or COOP_ONLY or NCYC_ONLY or OPT_ONLY
     prec = sa.F32_MIXED if (fast and rng.random() < 0.25) else sa.F64
     runs = [oracle.run_block(flags, members, c, ev) for c in clims]
     want = np.concatenate([r[0] for r in runs], axis=2)
@@ -129,6 +155,13 @@ for trial in range(trials):
         kopt = sa.KOPT_NO_REGULAR_TILES if rng.random() < 0.2 else 0
         kern, forced = [(sa.KERNEL_AUTO, ""), (sa.KERNEL_COOP_NCYCLE, " coop-ncycle"), (sa.KERNEL_COOP_NCYCLE_PAIR, " coop-ncycle-pair"),
                         (sa.KERNEL_ONE_WAVE, " one-wave")][int(rng.integers(0, 4))]
+    if OPT_ONLY:
+        kopt = sa.KOPT_NO_REGULAR_TILES if rng.random() < 0.2 else 0
+        if flags[sa.FLAG_NAMES.index("nitrogenCycle")]:
+            kern, forced = [(sa.KERNEL_AUTO, ""), (sa.KERNEL_COOP_NCYCLE, " coop-ncycle"), (sa.KERNEL_COOP_NCYCLE_PAIR, " coop-ncycle-pair")][int(rng.integers(0, 3))]
+        else:
+            kern, forced = [(sa.KERNEL_AUTO, ""), (sa.KERNEL_COOP_LDS, " coop-lds"), (sa.KERNEL_COOP_HBM, " coop-hbm"),
+                            (sa.KERNEL_COOP_PAIR, " coop-pair")][int(rng.integers(0, 4))]
     if os.environ.get("FUZZ_KOPT"): kopt = int(os.environ["FUZZ_KOPT"])
     if os.environ.get("FUZZ_KERNEL"):     # rerun a trial on another kernel (with the trial index as third argument)
         kern = getattr(sa, "KERNEL_" + os.environ["FUZZ_KERNEL"].upper()); forced = " forced-" + os.environ["FUZZ_KERNEL"]
@@ -139,6 +172,7 @@ for trial in range(trials):
     # a third of the trials also ask for the 44-column record and the diagnostics counters (the
     # "full" instantiations of the throughput kernels, or the strict kernel's)
     want_full = bool(rng.random() < 0.33) and kern not in (sa.KERNEL_COOP_QUAD, sa.KERNEL_COOP_NCYCLE, sa.KERNEL_COOP_NCYCLE_PAIR)    # no full-state builds of these
+    if OPT_ONLY: want_full = False       # (the optional-physics instantiations are lean)
     if want_full:
         b.enable_diagnostics()
         forced += " full"
@@ -215,7 +249,7 @@ for trial in range(trials):
         err = 0.0
     flag_s = "+".join(k for k, v in kw.items() if v != sa.DEFAULT_FLAGS.get(k)) or "default"
     print(f"trial {trial:3d}: S={S} M={M:3d} T={T:5d} segs={len(cuts)-1} {'f32' if prec else 'f64'} {'fast' if fast else 'strict'} "
-          f"ev={0 if ev is None else len(ev):2d} [{flag_s}]{forced} planes {err:.2e} pools {perr:.2e}", flush=True)
+          f"ev={0 if ev is None else len(ev):2d} [{flag_s}]{forced} {b_kernel.split('<')[0]} planes {err:.2e} pools {perr:.2e}", flush=True)
     assert np.isfinite(got[:, :, ok]).all()
     if only >= 0 and prec == sa.F64 and ok.any():   # where a mismatch starts
         rel = np.abs(got[:, :, ok] - want[:, :, ok]) / scale
