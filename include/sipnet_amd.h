@@ -627,6 +627,10 @@ void *sipnet_dev_alloc(size_t bytes);
 void sipnet_dev_free(void *p);
 int sipnet_dev_to_host(void *host, const void *dev, size_t bytes, void *hip_stream);
 int sipnet_stream_sync(void *hip_stream);
+/* a HIP stream of the caller's own on `device` (non-blocking with respect to the null stream): what a host that
+ * pipelines forcings over two batches gives each of them (NULL on failure) */
+void *sipnet_stream_create(int32_t device);
+void sipnet_stream_destroy(void *hip_stream);
 
 /* --------------------------------------------------------- host I/O (no GPU) */
 typedef struct sipnet_clim_table sipnet_clim_table;

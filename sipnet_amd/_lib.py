@@ -188,6 +188,8 @@ SIGNATURES = {
     "sipnet_dev_free": (None, [_P]),
     "sipnet_dev_to_host": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "sipnet_stream_sync": (C.c_int, [_P]),
+    "sipnet_stream_create": (_P, [C.c_int32]),
+    "sipnet_stream_destroy": (None, [_P]),
     "sipnet_io_read_clim": (C.c_int, [C.c_char_p, C.c_int32, C.POINTER(_P)]),
     "sipnet_clim_nsteps": (C.c_int32, [_P]),
     "sipnet_clim_data": (_DP, [_P]),

@@ -53,8 +53,16 @@ struct sipnet_batch {
   int32_t stepsDone = 0;       // records the carried state reflects, -1 = unknown
 
   // HBM
-  double* d_rawStage = nullptr;  // [rawStageCap][NPARAMS] raw rows of one set_params call
+  double* d_rawStage = nullptr;  // [rawStageCap][NPARAMS] raw rows of the set_params calls since the last launch
   size_t rawStageCap = 0;
+  // set_params is host-only: the raw rows go into PINNED staging and a list of pending conversions; the next
+  // stream-taking entry point (setup, run, the particle filter's) uploads and converts them on ITS stream -- no
+  // kernel of this batch then runs, and nothing of it blocks, while another batch's step kernel fills the device
+  // (a conversion kernel on a stream of its own, and synchronous copies, were measured stuck behind that kernel)
+  double* hostRaw = nullptr;     // pinned [hostRawCap][NPARAMS]
+  size_t hostRawCap = 0, hostRawUsed = 0;
+  struct PendingParams { size_t row0; int64_t col0; int32_t count, nRep; };
+  std::vector<PendingParams> pendingParams;
   double* d_prm = nullptr;     // [NPARAMS][ncol] converted parameters: the one copy on the device
   double* d_state = nullptr;   // [NSTATE][ncol]
   double* d_ring = nullptr;    // [RING_SLOTS][ncol] doubles; fp32-mixed batches: floats (ringElemBytes)
@@ -75,9 +83,12 @@ struct sipnet_batch {
   size_t planCap = 0, fastCap = 0, ringOpCap = 0, evCap = 0;
   // host staging of the flat per-step records, kept between hand-overs of a forcing: a fresh buffer
   // costs its first touch (143 MB at c4: 24 ms of page faults, more than building the records)
-  std::unique_ptr<FastRec[]> hostFast;
-  std::unique_ptr<StepRec[]> hostSteps;
+  // (pinned: the sites' records leave by hipMemcpyAsync on the setup's stream as the worker threads finish them)
+  FastRec* hostFast = nullptr;
+  StepRec* hostSteps = nullptr;
   size_t hostFastCap = 0, hostStepsCap = 0;
+  unsigned char* hostMisc = nullptr;   // pinned staging of the small per-plan arrays (ring evictions, events, site tables)
+  size_t hostMiscCap = 0;
   int32_t* d_siteBase = nullptr;  // [n_sites][2]: offset of a site's ring ops / events in the flat arrays
   bool stepRecsUploaded = false, fastRecsUploaded = false;  // per-step records: uploaded on first use
   // last boundary a checkpoint was exported at (sipnet_batch_export_restart)
@@ -93,7 +104,42 @@ struct sipnet_batch {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
   double lastMs = -1.0;
+  // recorded behind every launch of this batch that reads its inputs (setupModel, a step kernel): what an upload
+  // that overwrites those inputs waits for -- this batch's own work only, not the device (another batch's kernel
+  // may be running: a caller pipelines forcings over two batches, bench.py's end_to_end.pipelined)
+  hipEvent_t evBusy = nullptr;
+  bool busy = false;
+  hipEvent_t evStaged = nullptr;   // behind the last copy out of the pinned staging blocks
+  hipEvent_t evOrder = nullptr;    // caller's stream -> copy stream ordering
+  bool staged = false;
+  // uploads that need a kernel (the parameter conversion) run on a stream of the batch's own: on the null stream
+  // they would queue behind whatever another batch is running on a blocking stream
+  hipStream_t upStream = nullptr;
 };
+int flushParams(sipnet_batch* b, hipStream_t stream);   // engine.hip: upload + convert what set_params left pending
+
+inline int markBusy(sipnet_batch* b, hipStream_t stream) {
+  HIP_TRY(hipEventRecord(b->evBusy, stream));
+  b->busy = true;
+  return SIPNET_OK;
+}
+inline int waitIdle(sipnet_batch* b) {
+  if (b->busy) HIP_TRY(hipEventSynchronize(b->evBusy));
+  b->busy = false;
+  return SIPNET_OK;
+}
+// the pinned staging blocks (raw parameter rows, site records, the small plan arrays): free for the host to write
+// again once the copies out of them have completed -- long before the kernels that read the device side have
+inline int markStaged(sipnet_batch* b, hipStream_t stream) {
+  HIP_TRY(hipEventRecord(b->evStaged, stream));
+  b->staged = true;
+  return SIPNET_OK;
+}
+inline int waitStaged(sipnet_batch* b) {
+  if (b->staged) HIP_TRY(hipEventSynchronize(b->evStaged));
+  b->staged = false;
+  return SIPNET_OK;
+}
 
 // bytes of a ring element: fp32-mixed batches keep the running-mean ring in fp32 (its values are NPP rates such
 // a batch computes in fp32)

@@ -29,6 +29,12 @@ using namespace sipnet;
 static double nowMs() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
+// -DSIPNET_TRACE_HOST (diagnostic build): where the host side of an upload spends its time / blocks
+#ifdef SIPNET_TRACE_HOST
+#define TRACE_T(label) fprintf(stderr, "  [host %.3f] %s\n", nowMs(), label)
+#else
+#define TRACE_T(label)
+#endif
 
 // Site plans are independent of each other: they are built by a pool of host threads (one site
 // at a time each).  What every launch needs (ring evictions, events, site status, the first
@@ -69,9 +75,10 @@ static void forEachSite(int nS, int nThreads, std::atomic<bool>* failed, F f) {
 // device buffer for `count` records; a launch that still reads the previous plan (on any stream)
 // must have finished before the first site's records land in it
 template <class Rec>
-static int reserveRecords(Rec** d_ptr, size_t* cap, size_t count) {
-  HIP_TRY(hipDeviceSynchronize());
+static int reserveRecords(sipnet_batch* b, Rec** d_ptr, size_t* cap, size_t count) {
   if (count > *cap) {
+    int rcIdle = waitIdle(b);
+    if (rcIdle) return rcIdle;
     if (*d_ptr) HIP_TRY(hipFree(*d_ptr));
     *d_ptr = nullptr;
     *cap = 0;
@@ -90,27 +97,51 @@ static bool wantsFastRecs(const sipnet_batch* b) {
 // One pass per site (buildSitePlan) writes the record type the batch is set up for straight
 // into the flat upload buffer; the other type is produced by a second pass only if a launch ever
 // asks for it (ensureRecords).
-static int buildAndUpload(sipnet_batch* b, bool fastType, bool first) {
+// pinned host block of at least `count` records (kept between hand-overs of a forcing: a fresh buffer costs its
+// first touch -- 143 MB at c4: 24 ms of page faults, more than building the records -- and its pinning)
+template <class Rec>
+static int reservePinned(Rec** ptr, size_t* cap, size_t count) {
+  if (count <= *cap) return SIPNET_OK;
+  if (*ptr) HIP_TRY(hipHostFree(*ptr));
+  *ptr = nullptr;
+  *cap = 0;
+  HIP_TRY(hipHostMalloc((void**)ptr, count * sizeof(Rec), hipHostMallocDefault));
+  *cap = count;
+  return SIPNET_OK;
+}
+
+// uploads travel on the batch's own copy stream (nothing but copies is ever queued on it, so they are not held up
+// behind another batch's step kernel in a shared hardware queue); the caller's stream waits for them
+static int joinUploads(sipnet_batch* b, hipStream_t stream) {
+  HIP_TRY(hipEventRecord(b->evStaged, b->upStream));
+  b->staged = true;
+  HIP_TRY(hipStreamWaitEvent(stream, b->evStaged, 0));
+  return SIPNET_OK;
+}
+
+static int buildAndUpload(sipnet_batch* b, bool fastType, bool first, hipStream_t stream) {
   const double t0 = nowMs();
   const int nS = b->n_sites, nT = b->n_steps;
   const int nThreads = planThreadsFor(nS);
   const size_t nFast = (size_t)nS * nT + kFastTile, nSteps = (size_t)nS * nT;
-  if (fastType && b->hostFastCap < nFast) {
-    b->hostFast.reset();
-    b->hostFast.reset(new FastRec[nFast]);
-    b->hostFastCap = nFast;
-  }
-  if (!fastType && b->hostStepsCap < nSteps) {
-    b->hostSteps.reset();
-    b->hostSteps.reset(new StepRec[nSteps]);
-    b->hostStepsCap = nSteps;
-  }
-  FastRec* const fast = b->hostFast.get();
-  StepRec* const steps = b->hostSteps.get();
-  int rc = fastType ? reserveRecords(&b->d_fast, &b->fastCap, nFast) : reserveRecords(&b->d_plan, &b->planCap, nSteps);
+  TRACE_T("plan: begin");
+  // the staging block must be free (the copies of the previous hand-over done: an event behind them); the DEVICE
+  // records may still be read by this batch's last launch -- then the sites are built first (host only) and sent
+  // once that launch has finished, instead of as they are built
+  int rc = waitStaged(b);
   if (rc) return rc;
-  // every worker uploads the site it has just built while the others go on building: the copies
-  // (57 GB/s from this buffer once it has been touched) hide behind the build
+  rc = fastType ? reserveRecords(b, &b->d_fast, &b->fastCap, nFast) : reserveRecords(b, &b->d_plan, &b->planCap, nSteps);
+  if (rc) return rc;
+  const bool deferCopies = b->busy && hipEventQuery(b->evBusy) == hipErrorNotReady;
+  (void)hipGetLastError();
+  rc = fastType ? reservePinned(&b->hostFast, &b->hostFastCap, nFast) : reservePinned(&b->hostSteps, &b->hostStepsCap, nSteps);
+  if (rc) return rc;
+  TRACE_T("plan: reserved");
+  FastRec* const fast = b->hostFast;
+  StepRec* const steps = b->hostSteps;
+  // every worker sends off the site it has just built while the others go on building: asynchronous copies out
+  // of the pinned block on the caller's stream (the setup and step kernels that follow on it are ordered behind
+  // them; the host does not wait, and nothing here needs a compute queue)
   std::atomic<int> copyErr{0};
   std::atomic<int64_t> copyUs{0};
   std::atomic<bool> failed{false};
@@ -122,14 +153,15 @@ static int buildAndUpload(sipnet_batch* b, bool fastType, bool first) {
                                fastType ? fast + (size_t)s * nT : nullptr);
     if (first) b->plans[s] = std::move(p);
     const double c0 = nowMs();
+    const size_t tail = (fastType && s == nS - 1) ? kFastTile : 0;  // tile padding after the last site
+    if (tail) memset((void*)(fast + (size_t)nS * nT), 0, tail * sizeof(FastRec));
+    if (deferCopies) return true;
     hipError_t e = hipSetDevice(b->device);
     if (e == hipSuccess) {
-      const size_t tail = (fastType && s == nS - 1) ? kFastTile : 0;  // tile padding after the last site
-      if (tail) memset((void*)(fast + (size_t)nS * nT), 0, tail * sizeof(FastRec));
-      e = fastType ? hipMemcpy(b->d_fast + (size_t)s * nT, fast + (size_t)s * nT, ((size_t)nT + tail) * sizeof(FastRec),
-                               hipMemcpyHostToDevice)
-                   : hipMemcpy(b->d_plan + (size_t)s * nT, steps + (size_t)s * nT, (size_t)nT * sizeof(StepRec),
-                               hipMemcpyHostToDevice);
+      e = fastType ? hipMemcpyAsync(b->d_fast + (size_t)s * nT, fast + (size_t)s * nT, ((size_t)nT + tail) * sizeof(FastRec),
+                                    hipMemcpyHostToDevice, b->upStream)
+                   : hipMemcpyAsync(b->d_plan + (size_t)s * nT, steps + (size_t)s * nT, (size_t)nT * sizeof(StepRec),
+                                    hipMemcpyHostToDevice, b->upStream);
     }
     if (e != hipSuccess) {
       int none = 0;
@@ -146,12 +178,21 @@ static int buildAndUpload(sipnet_batch* b, bool fastType, bool first) {
     setError("sipnet_batch: building the site plans failed (out of host memory?)");
     return SIPNET_ERR_INTERNAL;
   }
+  if (deferCopies) {   // everything in one piece, once this batch's last launch is through with the old records
+    rc = waitIdle(b);
+    if (rc) return rc;
+    if (fastType) HIP_TRY(hipMemcpyAsync(b->d_fast, fast, nFast * sizeof(FastRec), hipMemcpyHostToDevice, b->upStream));
+    else HIP_TRY(hipMemcpyAsync(b->d_plan, steps, nSteps * sizeof(StepRec), hipMemcpyHostToDevice, b->upStream));
+  }
+  TRACE_T("plan: sites built, copies enqueued");
   (fastType ? b->fastRecsUploaded : b->stepRecsUploaded) = true;
-  // wall time of the whole pass; the copies' share of the workers' time is reported as the upload part
+  // wall time of the whole pass; the workers' share spent enqueueing the copies is reported as the upload part
+  // (the copies themselves run on the stream, under the build of the following sites)
   const double wall = nowMs() - t0, copyShare = copyUs.load() * 1e-3 / nThreads;
   b->planBuildMs += wall - (copyShare < wall ? copyShare : wall);
   b->planUploadMs += copyShare < wall ? copyShare : wall;
-  return SIPNET_OK;
+  rc = joinUploads(b, stream);
+  return rc ? rc : markBusy(b, stream);
 }
 
 static int uploadPlan(sipnet_batch* b, hipStream_t stream) {
@@ -169,7 +210,7 @@ static int uploadPlan(sipnet_batch* b, hipStream_t stream) {
   b->fastRecsUploaded = false;
   b->planBuildMs = b->planUploadMs = 0.0;
   b->planThreads = planThreadsFor(nS);
-  int rc = buildAndUpload(b, wantsFastRecs(b), /*first=*/true);
+  int rc = buildAndUpload(b, wantsFastRecs(b), /*first=*/true, stream);
   if (rc) return rc;
   const double t0 = nowMs();
   // ring evictions and events of all sites in one array each; the records index them site-locally
@@ -201,27 +242,36 @@ static int uploadPlan(sipnet_batch* b, hipStream_t stream) {
     HIP_TRY(hipMalloc(&b->d_events, (nEv + 1) * sizeof(EvRec)));
     b->evCap = nEv + 1;
   }
-  // synchronous copies straight from the sites' plans (reserveRecords above has waited for every
-  // launch that might still read the previous plan); an empty list keeps one inert entry
+  // the small arrays: flattened into one pinned block and sent on the same stream (buildAndUpload has waited for
+  // every launch that might still read the previous plan; an empty list keeps one inert entry)
+  const size_t opsBytes = (nOps ? nOps : 1) * sizeof(RingOp), evBytes = (nEv ? nEv : 1) * sizeof(EvRec);
+  auto align16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+  const size_t offEv = align16(opsBytes), offStatus = offEv + align16(evBytes), offStart = offStatus + align16(nS * sizeof(int32_t)),
+               offBase = offStart + align16(nS * sizeof(SiteStart)), total = offBase + align16(bases.size() * sizeof(int32_t));
+  rc = reservePinned(&b->hostMisc, &b->hostMiscCap, total);
+  if (rc) return rc;
+  RingOp* hOps = (RingOp*)b->hostMisc;
+  EvRec* hEv = (EvRec*)(b->hostMisc + offEv);
   for (int s = 0; s < nS; s++) {
     const SitePlan& p = b->plans[s];
-    if (!p.ringOps.empty())
-      HIP_TRY(hipMemcpy(b->d_ringOps + bases[2 * s], p.ringOps.data(), p.ringOps.size() * sizeof(RingOp), hipMemcpyHostToDevice));
-    if (!p.events.empty())
-      HIP_TRY(hipMemcpy(b->d_events + bases[2 * s + 1], p.events.data(), p.events.size() * sizeof(EvRec), hipMemcpyHostToDevice));
+    if (!p.ringOps.empty()) memcpy(hOps + bases[2 * s], p.ringOps.data(), p.ringOps.size() * sizeof(RingOp));
+    if (!p.events.empty()) memcpy(hEv + bases[2 * s + 1], p.events.data(), p.events.size() * sizeof(EvRec));
   }
-  if (nOps == 0) {
-    const RingOp none{0.0, 0, -1};
-    HIP_TRY(hipMemcpy(b->d_ringOps, &none, sizeof none, hipMemcpyHostToDevice));
-  }
-  if (nEv == 0) {
-    const EvRec none{0, 0, {0, 0, 0, 0}};
-    HIP_TRY(hipMemcpy(b->d_events, &none, sizeof none, hipMemcpyHostToDevice));
-  }
-  HIP_TRY(hipMemcpy(b->d_siteStatus, b->siteStatus.data(), nS * sizeof(int32_t), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(b->d_siteStart, starts.data(), nS * sizeof(SiteStart), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(b->d_siteBase, bases.data(), bases.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-  (void)stream;
+  if (nOps == 0) hOps[0] = RingOp{0.0, 0, -1};
+  if (nEv == 0) hEv[0] = EvRec{0, 0, {0, 0, 0, 0}};
+  memcpy(b->hostMisc + offStatus, b->siteStatus.data(), nS * sizeof(int32_t));
+  memcpy(b->hostMisc + offStart, starts.data(), nS * sizeof(SiteStart));
+  memcpy(b->hostMisc + offBase, bases.data(), bases.size() * sizeof(int32_t));
+  HIP_TRY(hipMemcpyAsync(b->d_ringOps, hOps, opsBytes, hipMemcpyHostToDevice, b->upStream));
+  HIP_TRY(hipMemcpyAsync(b->d_events, hEv, evBytes, hipMemcpyHostToDevice, b->upStream));
+  HIP_TRY(hipMemcpyAsync(b->d_siteStatus, b->hostMisc + offStatus, nS * sizeof(int32_t), hipMemcpyHostToDevice, b->upStream));
+  HIP_TRY(hipMemcpyAsync(b->d_siteStart, b->hostMisc + offStart, nS * sizeof(SiteStart), hipMemcpyHostToDevice, b->upStream));
+  HIP_TRY(hipMemcpyAsync(b->d_siteBase, b->hostMisc + offBase, bases.size() * sizeof(int32_t), hipMemcpyHostToDevice, b->upStream));
+  rc = joinUploads(b, stream);
+  if (rc) return rc;
+  rc = markBusy(b, stream);
+  if (rc) return rc;
+  TRACE_T("plan: small arrays enqueued");
   b->planDirty = false;
   b->exportCacheSite = -1;
   b->planBuildMs += t1 - t0;
@@ -229,11 +279,11 @@ static int uploadPlan(sipnet_batch* b, hipStream_t stream) {
   return SIPNET_OK;
 }
 
-static int ensureStepRecs(sipnet_batch* b) {  // records of the strict-order kernel
-  return b->stepRecsUploaded ? SIPNET_OK : buildAndUpload(b, /*fastType=*/false, /*first=*/false);
+static int ensureStepRecs(sipnet_batch* b, hipStream_t stream) {  // records of the strict-order kernel
+  return b->stepRecsUploaded ? SIPNET_OK : buildAndUpload(b, /*fastType=*/false, /*first=*/false, stream);
 }
-static int ensureFastRecs(sipnet_batch* b) {  // records of the throughput kernels
-  return b->fastRecsUploaded ? SIPNET_OK : buildAndUpload(b, /*fastType=*/true, /*first=*/false);
+static int ensureFastRecs(sipnet_batch* b, hipStream_t stream) {  // records of the throughput kernels
+  return b->fastRecsUploaded ? SIPNET_OK : buildAndUpload(b, /*fastType=*/true, /*first=*/false, stream);
 }
 
 // The shape-based kernel choice of SIPNET_KERNEL_AUTO (also exported as sipnet_kernel_choice, so
@@ -375,6 +425,10 @@ int sipnet_batch_create(const int32_t* flags, int32_t n_sites, int32_t n_members
   if (e == hipSuccess) e = hipMemset(b->d_state, 0, nc * SIPNET_NSTATE * sizeof(double));
   if (e == hipSuccess) e = hipEventCreate(&b->ev0);
   if (e == hipSuccess) e = hipEventCreate(&b->ev1);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&b->evBusy, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&b->evStaged, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&b->evOrder, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&b->upStream, hipStreamNonBlocking);
   if (e != hipSuccess) {
     setError(std::string("sipnet_batch_create: ") + hipGetErrorString(e));
     sipnet_batch_destroy(b);
@@ -389,6 +443,10 @@ void sipnet_batch_destroy(sipnet_batch* b) {
   (void)hipSetDevice(b->device);
   pfRelease(b);
   if (b->d_rawStage) (void)hipFree(b->d_rawStage);
+  if (b->hostRaw) (void)hipHostFree(b->hostRaw);
+  if (b->hostFast) (void)hipHostFree(b->hostFast);
+  if (b->hostSteps) (void)hipHostFree(b->hostSteps);
+  if (b->hostMisc) (void)hipHostFree(b->hostMisc);
   if (b->d_prm) (void)hipFree(b->d_prm);
   if (b->d_state) (void)hipFree(b->d_state);
   if (b->d_ring) (void)hipFree(b->d_ring);
@@ -407,6 +465,10 @@ void sipnet_batch_destroy(sipnet_batch* b) {
   if (b->d_statsPart) (void)hipFree(b->d_statsPart);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
+  if (b->evBusy) (void)hipEventDestroy(b->evBusy);
+  if (b->evStaged) (void)hipEventDestroy(b->evStaged);
+  if (b->evOrder) (void)hipEventDestroy(b->evOrder);
+  if (b->upStream) (void)hipStreamDestroy(b->upStream);
   delete b;
 }
 
@@ -472,26 +534,57 @@ int sipnet_batch_set_params(sipnet_batch* b, int32_t site, int32_t first_member,
     if (r[SP_dVpdExp] != 2.0 || r[SP_soilRespMoistEffect] != 1.0) b->genericExponents = true;
   }
   const int64_t col0 = (int64_t)site * b->n_members + first_member;
-  // no launch of this batch may still be reading the parameter block (callers' streams are
-  // non-blocking with respect to the null stream used here)
-  HIP_TRY(hipDeviceSynchronize());
-  if ((size_t)count > b->rawStageCap) {
+  // no upload of earlier rows may still be reading the staging block (an event is recorded behind the copy)
+  rc = waitStaged(b);
+  if (rc) return rc;
+  const size_t need = b->hostRawUsed + (size_t)count;
+  if (need > b->hostRawCap) {
+    double* bigger = nullptr;
+    const size_t cap = need > 2 * b->hostRawCap ? need : 2 * b->hostRawCap;
+    HIP_TRY(hipHostMalloc((void**)&bigger, cap * SIPNET_NPARAMS * sizeof(double), hipHostMallocDefault));
+    if (b->hostRawUsed) memcpy(bigger, b->hostRaw, b->hostRawUsed * SIPNET_NPARAMS * sizeof(double));
+    if (b->hostRaw) HIP_TRY(hipHostFree(b->hostRaw));
+    b->hostRaw = bigger;
+    b->hostRawCap = cap;
+  }
+  memcpy(b->hostRaw + b->hostRawUsed * SIPNET_NPARAMS, raw, (size_t)count * SIPNET_NPARAMS * sizeof(double));
+  b->pendingParams.push_back({b->hostRawUsed, col0, count, nRep});
+  b->hostRawUsed = need;
+  return SIPNET_OK;
+}
+
+}  // extern "C"
+
+// The parameter half of setupModel() (sipnet.c:1873-1916) for everything set_params has staged, on the caller's
+// stream: ONE upload of the raw rows, one conversion launch per set_params call; from here on the converted block
+// is the only copy of the members' parameters on the device.  The caller records the batch busy behind it.
+int flushParams(sipnet_batch* b, hipStream_t stream) {
+  if (b->pendingParams.empty()) return SIPNET_OK;
+  if (b->hostRawUsed > b->rawStageCap) {
+    int rcI = waitIdle(b);
+    if (rcI) return rcI;
     if (b->d_rawStage) HIP_TRY(hipFree(b->d_rawStage));
     b->d_rawStage = nullptr;
     b->rawStageCap = 0;
-    HIP_TRY(hipMalloc(&b->d_rawStage, (size_t)count * SIPNET_NPARAMS * sizeof(double)));
-    b->rawStageCap = (size_t)count;
+    HIP_TRY(hipMalloc(&b->d_rawStage, b->hostRawUsed * SIPNET_NPARAMS * sizeof(double)));
+    b->rawStageCap = b->hostRawUsed;
   }
-  HIP_TRY(hipMemcpy(b->d_rawStage, raw, (size_t)count * SIPNET_NPARAMS * sizeof(double),
-                    hipMemcpyHostToDevice));
-  // the parameter half of setupModel() (sipnet.c:1873-1916): from here on the converted block is
-  // the only copy of the members' parameters on the device
-  launchConvertParams(b->d_rawStage, b->d_prm, b->ncol, col0, count,
-                      b->flags[SIPNET_F_GDD] ? 0 : b->flags[SIPNET_F_SOIL_PHENOL] ? 1 : 2, nullptr, nRep, b->n_members);
+  // (an earlier conversion on `stream` may still read the device block: the copy stream waits for the caller's first)
+  HIP_TRY(hipEventRecord(b->evOrder, stream));
+  HIP_TRY(hipStreamWaitEvent(b->upStream, b->evOrder, 0));
+  HIP_TRY(hipMemcpyAsync(b->d_rawStage, b->hostRaw, b->hostRawUsed * SIPNET_NPARAMS * sizeof(double), hipMemcpyHostToDevice, b->upStream));
+  int rcS = joinUploads(b, stream);
+  if (rcS) return rcS;
+  for (const auto& p : b->pendingParams)
+    launchConvertParams(b->d_rawStage + p.row0 * SIPNET_NPARAMS, b->d_prm, b->ncol, p.col0, p.count,
+                        b->flags[SIPNET_F_GDD] ? 0 : b->flags[SIPNET_F_SOIL_PHENOL] ? 1 : 2, stream, p.nRep, b->n_members);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(nullptr));
+  b->pendingParams.clear();
+  b->hostRawUsed = 0;
   return SIPNET_OK;
 }
+
+extern "C" {
 
 int sipnet_batch_setup(sipnet_batch* b, void* hip_stream) {
   if (!b) return SIPNET_ERR_BAD_ARGUMENT;
@@ -502,6 +595,8 @@ int sipnet_batch_setup(sipnet_batch* b, void* hip_stream) {
     rc = uploadPlan(b, stream);
     if (rc) return rc;
   }
+  rc = flushParams(b, stream);
+  if (rc) return rc;
   SetupArgs a;
   a.siteStart = b->d_siteStart;
   a.prm = b->d_prm;
@@ -516,6 +611,8 @@ int sipnet_batch_setup(sipnet_batch* b, void* hip_stream) {
   launchSetup(a, stream);
   HIP_TRY(hipGetLastError());
   if (b->d_diag) HIP_TRY(hipMemsetAsync(b->d_diag, 0, (size_t)4 * b->ncol * sizeof(double), stream));
+  rc = markBusy(b, stream);
+  if (rc) return rc;
   b->stepsDone = 0;
   // a site-fatal plan condition is reported like the reference's exit code
   for (int s = 0; s < b->n_sites; s++) {
@@ -633,6 +730,8 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
   int rc = useDevice(b);
   if (rc) return rc;
   hipStream_t stream = (hipStream_t)hip_stream;
+  rc = flushParams(b, stream);   // (parameters set after the last setup: a particle filter's, a re-draw)
+  if (rc) return rc;
   KernelArgs a;
   a.plan = b->d_plan;
   a.ringOps = b->d_ringOps;
@@ -697,7 +796,7 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
              "batch); split the ensemble into several batches or use SIPNET_MATH_STRICT");
     return SIPNET_ERR_BAD_ARGUMENT;
   }
-  rc = kernel != SIPNET_KERNEL_STRICT ? ensureFastRecs(b) : ensureStepRecs(b);
+  rc = kernel != SIPNET_KERNEL_STRICT ? ensureFastRecs(b, stream) : ensureStepRecs(b, stream);
   if (rc) return rc;
   // ensemble statistics with the launch (sipnet_batch_run_stats): a wavefront of the cooperative
   // kernel sums the planes' tiles per chunk while they are still in L2; any other kernel is
@@ -782,7 +881,7 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
   }
   b->timed = true;
   b->stepsDone = (b->stepsDone == step0) ? step0 + n_steps : -1;
-  return SIPNET_OK;
+  return markBusy(b, stream);
 }
 
 double sipnet_batch_last_kernel_ms(sipnet_batch* b) {
@@ -1259,6 +1358,17 @@ int sipnet_dev_to_host(void* host, const void* dev, size_t bytes, void* hip_stre
 int sipnet_stream_sync(void* hip_stream) {
   HIP_TRY(hipStreamSynchronize((hipStream_t)hip_stream));
   return SIPNET_OK;
+}
+void* sipnet_stream_create(int32_t device) {
+  hipStream_t s = nullptr;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+    setError("sipnet_stream_create: hipStreamCreate failed");
+    return nullptr;
+  }
+  return (void*)s;
+}
+void sipnet_stream_destroy(void* hip_stream) {
+  if (hip_stream) (void)hipStreamDestroy((hipStream_t)hip_stream);
 }
 
 }  // extern "C"

@@ -672,6 +672,8 @@ int sipnet_batch_pack_members(sipnet_batch* b, const int32_t* d_cols, int64_t n,
   int rc = useDevice(b);
   if (rc) return rc;
   hipStream_t stream = (hipStream_t)hip_stream;
+  rc = flushParams(b, stream);
+  if (rc) return rc;
   RecvMap none{};
   // block layout: [NSTATE rows | RING_SLOTS rows (fp32-mixed batches: of floats) | NPARAMS rows] x n columns
   const bool rf = b->precision == SIPNET_F32_MIXED;
@@ -695,6 +697,8 @@ int sipnet_batch_resample(sipnet_batch* b, const int32_t* d_src, const double* d
   int rc = useDevice(b);
   if (rc) return rc;
   hipStream_t stream = (hipStream_t)hip_stream;
+  rc = flushParams(b, stream);
+  if (rc) return rc;
   const size_t nc = (size_t)b->ncol;
   if (!b->d_state2) HIP_TRY(hipMalloc(&b->d_state2, nc * SIPNET_NSTATE * sizeof(double)));
   if (!b->d_ring2) HIP_TRY(hipMalloc(&b->d_ring2, nc * SIPNET_RING_SLOTS * ringElemBytes(b)));
@@ -726,6 +730,8 @@ int sipnet_batch_resample(sipnet_batch* b, const int32_t* d_src, const double* d
   std::swap(b->d_ring, b->d_ring2);
   if (with_params) std::swap(b->d_prm, b->d_prm2);
   if (b->pfPeers) b->pfPeers->parity ^= 1;   // (connected ranks resample in lockstep, whichever entry point they use)
+  rc = markBusy(b, stream);                  // (an upload of new parameters waits for the gather that is writing them)
+  if (rc) return rc;
   if (with_params && start > 0) {
     // parameters that arrived from other ranks may change which kernel variant the batch needs
     int32_t* d_flag = nullptr;
@@ -812,6 +818,9 @@ int sipnet_batch_pf_publish(sipnet_batch* b, int32_t with_params, sipnet_pf_peer
   if (rc) return rc;
   rc = ensureSpares(b, with_params != 0);
   if (rc) return rc;
+  rc = flushParams(b, nullptr);          // (peers will read the converted block)
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(nullptr));
   memset(out, 0, sizeof *out);
   out->process_id = (int64_t)getpid();
   out->device = b->device;
@@ -939,6 +948,8 @@ int sipnet_batch_pf_resample_peers(sipnet_batch* b, const double* d_gathered, do
   int rc = useDevice(b);
   if (rc) return rc;
   hipStream_t stream = (hipStream_t)hip_stream;
+  rc = flushParams(b, stream);
+  if (rc) return rc;
   PeerPtrs tab{};
   int64_t nTotal = b->ncol, first = 0;
   bool withParams;
@@ -999,7 +1010,7 @@ int sipnet_batch_pf_resample_peers(sipnet_batch* b, const double* d_gathered, do
   std::swap(b->d_ring, b->d_ring2);
   if (withParams) std::swap(b->d_prm, b->d_prm2);
   if (b->pfPeers) b->pfPeers->parity ^= 1;
-  return SIPNET_OK;
+  return markBusy(b, stream);
 }
 
 }  // extern "C"

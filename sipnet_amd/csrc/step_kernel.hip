@@ -104,48 +104,38 @@ __device__ __forceinline__ int32_t uni(int32_t v) { return __builtin_amdgcn_read
 //                        climate record, ring reset), from the converted block.
 // One thread per member; both run once, so plain AoS reads are fine.
 // -----------------------------------------------------------------------------
+// (one thread per member and PARAMETER ROW, blockIdx.y = row: a handful of registers, so that an upload's conversion
+// finds room on a device another batch's step kernel is filling -- with one thread per member and the 80 values in
+// registers it had to wait for that kernel to end, which serialised a pipeline of forcings over two batches)
 __global__ __launch_bounds__(256) void convertParamsKernel(const double* __restrict__ raw,
                                                            double* __restrict__ prm, int64_t ncol,
                                                            int64_t col0, int32_t count, int32_t leafOnMode,
                                                            int32_t nRep, int64_t repStride) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = (int)blockIdx.y;
   if (i >= count) return;
-  double p[SIPNET_NPARAMS];
-#pragma unroll
-  for (int k = 0; k < SIPNET_NPARAMS; k++) p[k] = raw[i * SIPNET_NPARAMS + k];
-  // ensureAllocation, sipnet.c:1111-1123 (the validity test itself is in setupKernel)
-  p[SP_coarseRootAllocation] =
-      1 - p[SP_leafAllocation] - p[SP_woodAllocation] - p[SP_fineRootAllocation];
-  // per-year -> per-day, sipnet.c:1873-1877, :1898-1902
-  p[SP_baseVegResp] /= 365.0;
-  p[SP_litterBreakdownRate] /= 365.0;
-  p[SP_baseSoilResp] /= 365.0;
-  p[SP_woodTurnoverRate] /= 365.0;
-  p[SP_leafTurnoverRate] /= 365.0;
-  p[SP_psnTMax] = p[SP_psnTOpt] + (p[SP_psnTOpt] - p[SP_psnTMin]);
-  p[SP_fineRootTurnoverRate] /= 365.0;
-  p[SP_coarseRootTurnoverRate] /= 365.0;
-  p[SP_baseCoarseRootResp] /= 365.0;
-  p[SP_baseFineRootResp] /= 365.0;
-  // sipnet.c:1905-1916
-  if (p[SP_fAnoxia] <= 0.0) {
-    p[SP_fAnoxia] = kTiny;
-  } else if (p[SP_fAnoxia] >= 1.0) {
-    p[SP_fAnoxia] = 1.0 - kTiny;
+  const double* __restrict__ r = raw + i * SIPNET_NPARAMS;
+  double v = r[k];
+  switch (k) {
+    // ensureAllocation, sipnet.c:1111-1123 (the validity test itself is in setupKernel)
+    case SP_coarseRootAllocation: v = 1 - r[SP_leafAllocation] - r[SP_woodAllocation] - r[SP_fineRootAllocation]; break;
+    // per-year -> per-day, sipnet.c:1873-1877, :1898-1902
+    case SP_baseVegResp: case SP_litterBreakdownRate: case SP_baseSoilResp: case SP_woodTurnoverRate:
+    case SP_leafTurnoverRate: case SP_fineRootTurnoverRate: case SP_coarseRootTurnoverRate:
+    case SP_baseCoarseRootResp: case SP_baseFineRootResp: v /= 365.0; break;
+    case SP_psnTMax: v = r[SP_psnTOpt] + (r[SP_psnTOpt] - r[SP_psnTMin]); break;
+    // sipnet.c:1905-1916
+    case SP_fAnoxia: v = v <= 0.0 ? kTiny : (v >= 1.0 ? 1.0 - kTiny : v); break;
+    case SP_anaerobicDecompRate: v = v <= 0.0 ? kTiny : (v > 1.0 ? 1.0 : v); break;
+    // the throughput kernels' leaf-on threshold (step_kernel.h): unused as a GDD sum in these modes
+    case SP_gddLeafOn:
+      if (leafOnMode == 1) v = r[SP_soilTempLeafOn];
+      if (leafOnMode == 2) v = r[SP_leafOnDay] > 0 ? r[SP_leafOnDay] : 1e300;
+      break;
+    default: break;
   }
-  if (p[SP_anaerobicDecompRate] <= 0.0) {
-    p[SP_anaerobicDecompRate] = kTiny;
-  } else if (p[SP_anaerobicDecompRate] > 1.0) {
-    p[SP_anaerobicDecompRate] = 1.0;
-  }
-  // the throughput kernels' leaf-on threshold (step_kernel.h): unused as a GDD sum in these modes
-  if (leafOnMode == 1) p[SP_gddLeafOn] = p[SP_soilTempLeafOn];
-  if (leafOnMode == 2) p[SP_gddLeafOn] = p[SP_leafOnDay] > 0 ? p[SP_leafOnDay] : 1e300;
   // (nRep > 1: the same members at nRep sites, repStride columns apart -- SIPNET_ALL_SITES)
-  for (int r = 0; r < nRep; r++) {
-#pragma unroll
-    for (int k = 0; k < SIPNET_NPARAMS; k++) prm[(int64_t)k * ncol + col0 + (int64_t)r * repStride + i] = p[k];
-  }
+  for (int rep = 0; rep < nRep; rep++) prm[(int64_t)k * ncol + col0 + (int64_t)rep * repStride + i] = v;
 }
 
 __global__ __launch_bounds__(256) void setupKernel(SetupArgs a) {
@@ -1331,7 +1321,7 @@ void launchSetup(const SetupArgs& a, hipStream_t stream) {
 }
 void launchConvertParams(const double* rawRows, double* prm, int64_t ncol, int64_t col0,
                          int32_t count, int32_t leafOnMode, hipStream_t stream, int32_t nRep, int64_t repStride) {
-  hipLaunchKernelGGL(convertParamsKernel, dim3((count + 255) / 256), dim3(256), 0, stream, rawRows,
+  hipLaunchKernelGGL(convertParamsKernel, dim3((count + 255) / 256, SIPNET_NPARAMS), dim3(256), 0, stream, rawRows,
                      prm, ncol, col0, count, leafOnMode, nRep, repStride);
 }
 

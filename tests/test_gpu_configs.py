@@ -97,7 +97,10 @@ def test_c3_65536_members_fp32_mixed(oracle, base):
     planes, _ = b.run()
     li = b.last_launch()
     assert planes.dtype == torch.float32 and tuple(planes.shape) == (3, T_YEAR, M)
-    pick = np.r_[0:16, M // 2:M // 2 + 16, M - 16:M]
+    # the first / middle / last sixteen members and ONE random member of every 64-member chunk (1 024 chunks: the
+    # workgroup -> chunk mapping of the four-chunk layout is then checked at the full shape, not only at small ones)
+    rng = np.random.default_rng(3)
+    pick = np.unique(np.r_[0:16, M // 2:M // 2 + 16, M - 16:M, np.arange(M // 64) * 64 + rng.integers(0, 64, M // 64)])
     got = planes[:, :, torch.from_numpy(pick).to(planes.device)].double().cpu().numpy()
     st = b.get_status()
     finite = bool(torch.isfinite(planes).all())
@@ -111,9 +114,9 @@ def test_c3_65536_members_fp32_mixed(oracle, base):
     assert (so == 0).all()
     d = np.abs(got - want)
     flips = branch_flips(got, want)
-    print("C3 1x65536 f32-mixed x 17520, 48 sampled members: max|dNEE| %.3e |dGPP| %.3e |dET| %.3e, "
+    print("C3 1x65536 f32-mixed x 17520, %d sampled members (one of every chunk): max|dNEE| %.3e |dGPP| %.3e |dET| %.3e, "
           "yearly NEE sum off by at most %.3e gC m-2, branch-flip members %d"
-          % (d[0].max(), d[1].max(), d[2].max(), np.abs(got[0].sum(0) - want[0].sum(0)).max(), flips))
+          % (len(pick), d[0].max(), d[1].max(), d[2].max(), np.abs(got[0].sum(0) - want[0].sum(0)).max(), flips))
     assert d.max() < TOL_F32
     assert flips == 0
     assert np.abs(got[0].sum(0) - want[0].sum(0)).max() < 0.5
@@ -132,9 +135,12 @@ def test_c4_32_sites_x_1024_members_fp64(oracle, base):
     planes, _ = b.run()
     li = b.last_launch()
     rng = np.random.default_rng(4)
-    pick = np.stack([np.sort(rng.choice(M, 2, replace=False)) for _ in range(S)])      # [S][2]
+    # one random member of EVERY chunk of every site (512 chunks: the paired, XCD-grouped workgroup -> chunk mapping
+    # is checked at the full shape)
+    K = M // 64
+    pick = np.stack([np.arange(K) * 64 + rng.integers(0, 64, K) for _ in range(S)])      # [S][K]
     cols = (np.arange(S)[:, None] * M + pick).reshape(-1)
-    got = planes[:, :, torch.from_numpy(cols).to(planes.device)].cpu().numpy().reshape(3, T_YEAR, S, 2)
+    got = planes[:, :, torch.from_numpy(cols).to(planes.device)].cpu().numpy().reshape(3, T_YEAR, S, K)
     st = b.get_status()
     b.close()
     del planes
@@ -148,7 +154,7 @@ def test_c4_32_sites_x_1024_members_fp64(oracle, base):
         assert (so == 0).all()
         worst = max(worst, float(np.abs(got[:, :, s, :] - want).max()))
         assert np.abs(got[:, :, s, :] - want).max() < TOL_F64, s
-    print("C4 32x1024 f64 x 17520, 2 members of every site: max|d| %.3e; plans built by %d threads in %.1f ms, "
+    print("C4 32x1024 f64 x 17520, one member of every chunk of every site (512): max|d| %.3e; plans built by %d threads in %.1f ms, "
           "uploaded in %.1f ms" % (worst, li["plan_threads"], li["plan_build_ms"], li["plan_upload_ms"]))
 
 

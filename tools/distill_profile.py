@@ -24,7 +24,7 @@ out = [f"# rocprofv3 summary -- {tag}, workload {wl}", ""]
 ks = one("trace/**/*kernel_stats.csv")
 if ks:
     shutil.copyfile(ks, os.path.join(dst, f"{name}_kernel_stats.csv"))
-    out += ["## `rocprofv3 --kernel-trace --stats -- python3 bench.py --workload %s --steps 5 --warmup 1`" % wl, "",
+    out += ["## `rocprofv3 --kernel-trace --stats -- python3 bench.py --workload %s --steps 5 --warmup 1 --no-cpu-baseline --no-fill-probe --no-end-to-end`" % wl, "",
             "| kernel | calls | total ns | avg ns | % |", "|---|---|---|---|---|"]
     for r in csv.DictReader(open(ks)):
         out.append(f"| `{r['Name'][:90]}` | {r['Calls']} | {r['TotalDurationNs']} | {float(r['AverageNs']):.0f} | {r['Percentage']} |")
