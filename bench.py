@@ -22,6 +22,8 @@ Workloads (BASELINE.json configs):
   c4n   c4's shape with the nitrogen-cycle flag set (two chunks per CU)
   c10kn c10k's shape with the nitrogen-cycle flag set (litter pool + anaerobic + N cycle): the
         optional-flag instantiation of the throughput kernel (not a BASELINE config)
+  c10kr3 c10k's shape with russell_3's flags (growth respiration + leaf water + litter pool): the
+        optional-physics instantiation of the cooperative kernel (not a BASELINE config)
 Per-GPU work is fixed as N grows ("scaling": "weak").
 
 What the JSON line says about the kernel (the `roofline` object):
@@ -73,6 +75,10 @@ WORKLOADS = {
     # c10k's shape with the nitrogen-cycle flag set (litter pool + anaerobic + N cycle)
     "c10kn": dict(sites=1, members=10240, prec="f64", steps=17520, param="allflags_forest.param",
                   flags=dict(litterPool=1, anaerobic=1, nitrogenCycle=1)),
+    # c10k's shape with russell_3's flag family (growth respiration + leaf water + litter pool, no moisture effect on
+    # heterotrophic respiration): the optional-physics instantiation of the one-chunk cooperative kernel (run-time flags)
+    "c10kr3": dict(sites=1, members=10240, prec="f64", steps=17520, param="allflags_forest.param",
+                   flags=dict(growthResp=1, leafWater=1, litterPool=1, waterHResp=0)),
     # ... and c4's (two chunks per CU: the two-chunk layout of that kernel)
     "c4n": dict(sites=32, members=1024, prec="f64", steps=17520, param="allflags_forest.param",
                 flags=dict(litterPool=1, anaerobic=1, nitrogenCycle=1)),

@@ -423,8 +423,10 @@ int sipnet_pf_exchange_plan(const int32_t *d_ancestors, int64_t n_local, int32_t
 /* The resampling and the exchange plan keep device scratch per host thread between calls; this frees
  * the calling thread's (call it before the thread ends or the device is reset; nothing else does). */
 void sipnet_pf_release_scratch(void);
-/* 8-byte words per particle in a packed block of a SIPNET_F64 batch: SIPNET_NSTATE + SIPNET_RING_SLOTS
- * (+ SIPNET_NPARAMS) ... */
+/* DEPRECATED -- SIPNET_F64 batches only: 8-byte words per particle in a packed block, SIPNET_NSTATE +
+ * SIPNET_RING_SLOTS (+ SIPNET_NPARAMS).  A SIPNET_F32_MIXED batch packs fewer (its ring travels in fp32): size
+ * blocks, all-to-all splits and offsets with sipnet_batch_member_words(b, ...) of the batch that packs / resamples;
+ * this one stays exported for callers built against the fp64-only layout ... */
 int32_t sipnet_pf_member_words(int32_t with_params);
 /* ... and of batch b: a SIPNET_F32_MIXED batch keeps its running-mean ring in fp32 (the values are NPP
  * rates, fp32 numbers there), on the device and in a packed block, where the SIPNET_RING_SLOTS rows of

@@ -76,6 +76,9 @@ class Batch:
         if getattr(self, "h", None):
             self.L.sipnet_batch_destroy(self.h)
             self.h = None
+            # the batch-less sipnet_pf_* entry points (dist.pf_systematic_ancestors, pf_exchange_plan) keep device
+            # scratch per host thread; nothing else frees it
+            self.L.sipnet_pf_release_scratch()
 
     def __del__(self):
         try:

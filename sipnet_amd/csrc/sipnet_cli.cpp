@@ -452,14 +452,12 @@ int main(int argc, char** argv) {
     std::vector<double> total((size_t)3 * T * 2);
     check(sipnet_node_gather_stats(nd, total.data()), "all-gather of the statistics");
     int worstStatus = 0, skipped = 0;
-    for (int k = 0; k < sipnet_node_n_devices(nd); k++) {
-      int32_t first = 0, count = 0;
-      sipnet_node_member_range(nd, k, &first, &count);
-      std::vector<int32_t> status(count);
-      check(sipnet_batch_get_status(sipnet_node_batch(nd, k), status.data(), nullptr), "status");
-      for (int m = 0; m < count; m++)
+    {
+      std::vector<int32_t> status(M);   // (synchronises every shard's stream: the runs are complete when it returns)
+      check(sipnet_node_get_status(nd, status.data()), "status");
+      for (int m = 0; m < M; m++)
         if (status[m] != 0) {
-          logError("member " + std::to_string(first + m) + ": status " + std::to_string(status[m]) +
+          logError("member " + std::to_string(m) + ": status " + std::to_string(status[m]) +
                    " (NPP allocation params must be less than one individually and add to less than one)\n");
           worstStatus = std::max(worstStatus, (int)status[m]);
           skipped++;
@@ -474,7 +472,9 @@ int main(int argc, char** argv) {
       fprintf(f, "%4d %3d %5.2f %d", sipnet_clim_year(clim)[t], sipnet_clim_day(clim)[t], cd[(size_t)t * SIPNET_NCLIM + 10], M);
       for (int v = 0; v < 3; v++) {
         const double s1 = total[((size_t)v * T + t) * 2], s2 = total[((size_t)v * T + t) * 2 + 1];
-        const double mean = s1 / M, var = s2 / M - mean * mean;
+        // (s2 - s1^2 / M) / M in extended precision: s2 / M - mean^2 cancels badly when |mean| >> sd
+        const long double s1l = s1, s2l = s2;
+        const double mean = s1 / M, var = (double)((s2l - s1l * s1l / (long double)M) / (long double)M);
         fprintf(f, " %.10g %.10g", mean, var > 0 ? sqrt(var) : 0.0);
       }
       fprintf(f, "\n");

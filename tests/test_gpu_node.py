@@ -273,3 +273,40 @@ def test_peer_resampling_of_an_unconnected_batch_is_the_one_call_analysis(base):
     p2, _ = b.run(T // 2, T // 2)
     np.testing.assert_array_equal(p2.cpu().numpy(), twin["next"])
     b.close()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (one-GPU boxes run the shards on device 0)")
+def test_node_over_two_real_devices_equals_one_batch(base):
+    """devices = [0, 1]: the thread-per-shard path, the grouped ncclAllGather over two communicators, ragged shards
+    (201 members: 100 / 101), and the filter's peer reads across two GPUs -- against ONE batch on device 0"""
+    S, M, T = 1, 201, 48 * 4
+    flags = sa.flags_from()
+    clims = site_clims(S, 2 * T)
+    members = synth.perturbed_params(base, M)
+    b = one_batch(flags, clims, members)
+    planes, stats = b.run_stats(0, T)
+    want_planes = planes.cpu().numpy().reshape(3, T, S, M)
+    want_stats = stats.cpu().numpy()
+    b.close()
+    nd = Node(flags, S, M, devices=[0, 1], shard=SHARD_MEMBERS, fast_math=True)
+    assert "RCCL" in nd.collective_library() and sorted(nd.member_range(k)[1] for k in range(2)) == [100, 101]
+    nd.set_climate(0, clims[0])
+    nd.set_params(0, members)
+    nd.setup()
+    nd.run(0, T)
+    tot = nd.gather_stats()
+    np.testing.assert_array_equal(nd.member_planes(), want_planes)
+    np.testing.assert_allclose(tot, want_stats, rtol=1e-12, atol=1e-12)
+    nd.gather_planes()
+    nd.sync()
+    np.testing.assert_array_equal(nd.gathered_planes(0), nd.gathered_planes(1))
+    twin = _filter_twin(base, clims[0], members, sa.F64, T)
+    nd.setup()
+    nd.pf_connect(with_params=True)
+    nd.forecast(0, T)
+    nd.pf_analysis(0, twin["obs_sigma"][0], twin["obs_sigma"][1], 0.43)
+    assert nd.pf_check() == 1
+    for k in range(2):
+        m0, mc = nd.member_range(k)
+        np.testing.assert_array_equal(nd.shard_state(k), twin["state"][m0:m0 + mc])
+    nd.close()
