@@ -29,7 +29,17 @@
 //                            (one RCCL rank per device), every device runs its members on the
 //                            throughput kernels, ONE all-gather of the statistics block joins them,
 //                            and FILE gets `year day time n mean/sd of NEE, GPP, ET` per step
+//   --sites FILE             stacking at the process boundary PEcAn uses: FILE lists run directories (one per
+//                            line, `#` comments), each with its own sipnet.in / <prefix>.param / <prefix>.clim /
+//                            <events>.in.  Every directory is resolved exactly like a run started inside it (the
+//                            options of THIS command line take precedence over each sipnet.in, cli.c:144-229), runs
+//                            whose forcing (climate + events) is identical become members of one site, runs with the
+//                            same model flags and step count share ONE batch, and every directory gets the files its
+//                            own run would have written (<prefix>.out, <events>.out, <prefix>.config, single-variable
+//                            outputs) -- byte for byte with --math auto / strict (the strict-order kernel), to the last
+//                            printed digit with --math fast (the throughput kernels)
 #include <getopt.h>
+#include <unistd.h>
 #include <cmath>
 #include <sched.h>
 #include <strings.h>
@@ -158,6 +168,7 @@ void usage(const char* prog) {
   printf("  --math strict|fast|auto     arithmetic of the step kernel (auto: strict for one run, fast for an ensemble)\n");
   printf("  --devices <list>            HIP devices the ensemble shards across, e.g. 0-7 or 0,2,3 ('0')\n");
   printf("  --ensemble-stats <file>     per-step ensemble mean / sd of NEE, GPP, ET instead of the members' files\n");
+  printf("  --sites <file>              run every directory listed in <file> (one per line) in shared batches\n");
   printf("  -h, --help   -v, --version\n");
 }
 
@@ -260,6 +271,219 @@ void check(int rc, const char* what) {
   }
 }
 
+// ---- --sites: many run directories, few batches ---------------------------------------------------------------
+struct SiteRun {
+  std::string dir;           // absolute
+  Context ctx;               // resolved like a run started inside dir
+  int32_t flags[SIPNET_NFLAGS];
+  std::vector<double> params;
+  sipnet_clim_table* clim = nullptr;
+  sipnet_event* events = nullptr;
+  int32_t nEvents = 0;
+  int T = 0;
+};
+
+bool sameForcing(const SiteRun& a, const SiteRun& b) {
+  if (a.T != b.T || a.nEvents != b.nEvents) return false;
+  if (memcmp(sipnet_clim_data(a.clim), sipnet_clim_data(b.clim), (size_t)a.T * SIPNET_NCLIM * sizeof(double)) != 0) return false;
+  if (memcmp(sipnet_clim_year(a.clim), sipnet_clim_year(b.clim), (size_t)a.T * sizeof(int32_t)) != 0) return false;
+  if (memcmp(sipnet_clim_day(a.clim), sipnet_clim_day(b.clim), (size_t)a.T * sizeof(int32_t)) != 0) return false;
+  for (int k = 0; k < a.nEvents; k++) {
+    const sipnet_event &x = a.events[k], &y = b.events[k];
+    if (x.type != y.type || x.year != y.year || x.day != y.day || memcmp(x.p, y.p, sizeof x.p) != 0) return false;
+  }
+  return true;
+}
+
+// the part of main() between the command line and the run, for one directory (the process is inside it)
+void resolveRun(SiteRun& r) {
+  Context& ctx = r.ctx;
+  if (ctx.s("filePrefix").empty()) die(3, "filePrefix must be set for SIPNET to run\n");
+  readInputFile(ctx);
+  bool bad = false;
+  if (ctx.i("soilPhenol") && ctx.i("gdd")) { logError("soil-phenol and gdd may not both be turned on\n"); bad = true; }
+  if (ctx.i("nitrogenCycle") && !(ctx.i("litterPool") && ctx.i("anaerobic"))) {
+    logError("nitrogen-cycle requires both litter-pool and anaerobic to be turned on\n"); bad = true; }
+  if (ctx.i("anaerobic") && !ctx.i("waterHResp")) { logError("anaerobic requires water-hresp to be turned on\n"); bad = true; }
+  if (ctx.i("carbonSaturation") && !ctx.i("litterPool")) { logError("carbon-saturation requires litter-pool to be turned on\n"); bad = true; }
+  if (bad) exit(3);
+  if (!ctx.s("restartIn").empty() || !ctx.s("restartOut").empty() || !ctx.s("debugLogPrefix").empty())
+    die(8, "--sites does not combine with restart checkpoints or --debug-log (" + r.dir + ")\n");
+  const std::string prefix = ctx.s("filePrefix");
+  ctx.setStr("paramFile", prefix + ".param", SRC_CALCULATED);
+  ctx.setStr("climFile", prefix + ".clim", SRC_CALCULATED);
+  if (ctx.i("doMainOutput")) ctx.setStr("outFile", prefix + ".out", SRC_CALCULATED);
+  if (ctx.i("dumpConfig")) {
+    ctx.setStr("outConfigFile", prefix + ".config", SRC_CALCULATED);
+    FILE* f = fopen((prefix + ".config").c_str(), "w");
+    if (!f) die(6, "Error opening " + prefix + ".config for writing\n");
+    printConfig(ctx, f);
+    fclose(f);
+  }
+  const int32_t fl[SIPNET_NFLAGS] = {ctx.i("events"), ctx.i("gdd"), ctx.i("growthResp"), ctx.i("leafWater"), ctx.i("litterPool"),
+                                     ctx.i("snow"), ctx.i("soilPhenol"), ctx.i("waterHResp"), ctx.i("nitrogenCycle"),
+                                     ctx.i("anaerobic"), ctx.i("flooding"), ctx.i("carbonSaturation")};
+  memcpy(r.flags, fl, sizeof fl);
+  r.params.resize(SIPNET_NPARAMS);
+  check(sipnet_io_read_params(ctx.s("paramFile").c_str(), r.flags, r.params.data(), nullptr), "reading parameters");
+  check(sipnet_io_read_clim(ctx.s("climFile").c_str(), r.flags[SIPNET_F_GDD], &r.clim), "reading climate");
+  r.T = sipnet_clim_nsteps(r.clim);
+  if (ctx.i("events")) {
+    check(sipnet_io_read_events((ctx.s("eventsPrefix") + ".in").c_str(), r.flags, r.params.data(), &r.events, &r.nEvents),
+          "reading events");
+    if (r.nEvents == 0) logInfo("No event file found, assuming no input events\n");
+  }
+}
+
+int runSites(const Context& cliCtx, const std::string& listFile, const std::string& mathArg, int device) {
+  std::vector<std::string> dirs;
+  {
+    std::ifstream in(listFile);
+    if (!in) die(6, "Error opening " + listFile + " for reading\n");
+    for (std::string line; std::getline(in, line);) {
+      const size_t hash = line.find('#');
+      if (hash != std::string::npos) line.erase(hash);
+      const size_t a = line.find_first_not_of(" \t\r"), z = line.find_last_not_of(" \t\r");
+      if (a == std::string::npos) continue;
+      dirs.push_back(line.substr(a, z - a + 1));
+    }
+  }
+  if (dirs.empty()) die(5, "no run directories in " + listFile + "\n");
+  char cwd0[4096];
+  if (!getcwd(cwd0, sizeof cwd0)) die(1, "getcwd failed\n");
+  std::vector<SiteRun> runs(dirs.size());
+  for (size_t k = 0; k < dirs.size(); k++) {
+    if (chdir(cwd0) != 0 || chdir(dirs[k].c_str()) != 0) die(6, "cannot enter run directory " + dirs[k] + "\n");
+    char here[4096];
+    if (!getcwd(here, sizeof here)) die(1, "getcwd failed\n");
+    runs[k].dir = here;
+    runs[k].ctx = cliCtx;
+    resolveRun(runs[k]);
+  }
+  if (chdir(cwd0) != 0) die(1, "cannot return to the start directory\n");
+  if (device >= sipnet_device_count())
+    die(1, "--devices names device " + std::to_string(device) + " but only " + std::to_string(sipnet_device_count()) +
+               " HIP device(s) are visible (this engine has no CPU path)\n");
+  const bool fastMath = mathArg == "fast";
+  // batches: same model flags and step count; inside a batch, runs with identical forcing are members of ONE site
+  std::vector<char> done(runs.size(), 0);
+  int worst = 0, nBatches = 0;
+  for (size_t lead = 0; lead < runs.size(); lead++) {
+    if (done[lead]) continue;
+    std::vector<std::vector<int>> sites;   // [site][member] -> run index
+    for (size_t k = lead; k < runs.size(); k++) {
+      if (done[k] || runs[k].T != runs[lead].T || memcmp(runs[k].flags, runs[lead].flags, sizeof runs[k].flags) != 0) continue;
+      done[k] = 1;
+      bool placed = false;
+      for (auto& st : sites)
+        if (sameForcing(runs[st[0]], runs[k])) {
+          st.push_back((int)k);
+          placed = true;
+          break;
+        }
+      if (!placed) sites.push_back({(int)k});
+    }
+    const int S = (int)sites.size(), T = runs[lead].T;
+    int M = 0;
+    for (auto& st : sites) M = std::max(M, (int)st.size());
+    nBatches++;
+    logInfo("batch " + std::to_string(nBatches) + ": " + std::to_string(S) + " site(s) x up to " + std::to_string(M) +
+            " member(s), " + std::to_string(T) + " steps\n");
+    sipnet_batch* b = nullptr;
+    check(sipnet_batch_create(runs[lead].flags, S, M, SIPNET_F64, device, &b), "creating batch");
+    check(sipnet_batch_set_math(b, fastMath ? SIPNET_MATH_FAST : SIPNET_MATH_STRICT), "math policy");
+    std::vector<double> rows((size_t)M * SIPNET_NPARAMS);
+    for (int s = 0; s < S; s++) {
+      const SiteRun& r0 = runs[sites[s][0]];
+      check(sipnet_batch_set_events(b, s, r0.nEvents, r0.events), "events");
+      check(sipnet_batch_set_climate(b, s, T, sipnet_clim_data(r0.clim), sipnet_clim_year(r0.clim), sipnet_clim_day(r0.clim)), "climate");
+      for (int m = 0; m < M; m++) {   // (a site with fewer runs than the widest one: its first run's parameters fill the rest)
+        const SiteRun& r = runs[sites[s][m < (int)sites[s].size() ? m : 0]];
+        memcpy(rows.data() + (size_t)m * SIPNET_NPARAMS, r.params.data(), SIPNET_NPARAMS * sizeof(double));
+      }
+      check(sipnet_batch_set_params(b, s, 0, M, rows.data()), "parameters");
+    }
+    check(sipnet_batch_setup(b, nullptr), "setupModel");
+    const int64_t ncol = (int64_t)S * M;
+    std::vector<double> state0((size_t)ncol * SIPNET_NSTATE);
+    check(sipnet_batch_get_state(b, state0.data(), nullptr), "state");
+    const size_t recElems = (size_t)T * SIPNET_NREC * ncol;
+    double* dRec = (double*)sipnet_dev_alloc(recElems * sizeof(double));
+    if (!dRec) die(1, std::string(sipnet_last_error()) + "\n");
+    check(sipnet_batch_run(b, 0, T, nullptr, nullptr, nullptr, dRec, ncol, nullptr), "run");
+    std::vector<double> rec(recElems);
+    check(sipnet_dev_to_host(rec.data(), dRec, recElems * sizeof(double), nullptr), "copy back");
+    std::vector<int32_t> status(ncol);
+    check(sipnet_batch_get_status(b, status.data(), nullptr), "status");
+    sipnet_dev_free(dRec);
+    sipnet_batch_destroy(b);
+    // every run's files, into its own directory (absolute paths), by a pool of host threads
+    struct Job { int run; int64_t col; };
+    std::vector<Job> jobs;
+    for (int s = 0; s < S; s++)
+      for (int m = 0; m < (int)sites[s].size(); m++) jobs.push_back({sites[s][m], (int64_t)s * M + m});
+    std::atomic<int> next{0}, worstA{0};
+    std::mutex logMutex;
+    auto worker = [&]() {
+      std::vector<double> one((size_t)T * SIPNET_NREC);
+      for (int j = next.fetch_add(1); j < (int)jobs.size(); j = next.fetch_add(1)) {
+        SiteRun& r = runs[jobs[j].run];
+        const int64_t c = jobs[j].col;
+        if (status[c] != 0) {
+          std::lock_guard<std::mutex> lock(logMutex);
+          logError(r.dir + ": status " + std::to_string(status[c]) +
+                   " (NPP allocation params must be less than one individually and add to less than one)\n");
+          int w = worstA.load();
+          while (status[c] > w && !worstA.compare_exchange_weak(w, status[c])) {}
+          continue;
+        }
+        for (int t = 0; t < T; t++)
+          for (int k = 0; k < SIPNET_NREC; k++) one[(size_t)t * SIPNET_NREC + k] = rec[((size_t)t * SIPNET_NREC + k) * ncol + c];
+        Context& ctx = r.ctx;
+        const std::string prefix = r.dir + "/" + ctx.s("filePrefix");
+        if (ctx.i("doMainOutput"))
+          check(sipnet_io_write_out((prefix + ".out").c_str(), ctx.i("printHeader"), T, sipnet_clim_year(r.clim), sipnet_clim_day(r.clim),
+                                    sipnet_clim_data(r.clim), one.data()), "writing output");
+        if (ctx.i("events"))
+          check(sipnet_io_write_events_out((r.dir + "/" + ctx.s("eventsPrefix") + ".out").c_str(), ctx.i("printHeader"), r.flags,
+                                           r.params.data(), T, sipnet_clim_year(r.clim), sipnet_clim_day(r.clim),
+                                           sipnet_clim_data(r.clim), r.nEvents, r.events, one.data(),
+                                           state0.data() + (size_t)c * SIPNET_NSTATE), "writing events.out");
+        if (ctx.i("doSingleOutputs")) {  // sipnet.c:1993-1998, outputItems.c:126-150
+          const struct { const char* name; int col; } items[] = {{"NEE", 0}, {"NEE_cum", 3}, {"GPP", 1}, {"GPP_cum", 35}};
+          for (const auto& it : items) {
+            FILE* f = fopen((prefix + "." + it.name).c_str(), "w");
+            if (!f) die(6, std::string("Error opening single output file for ") + it.name + "\n");
+            for (int t = 0; t < T; t++) fprintf(f, "%f ", one[(size_t)t * SIPNET_NREC + it.col]);
+            fprintf(f, "\n");
+            fclose(f);
+          }
+        }
+      }
+    };
+    int hostThreads = 1;
+    {
+      cpu_set_t cpus;
+      if (sched_getaffinity(0, sizeof cpus, &cpus) == 0) hostThreads = CPU_COUNT(&cpus);
+    }
+    const int nThreads = std::max(1, std::min({hostThreads, (int)jobs.size(), 64}));
+    if (nThreads == 1) {
+      worker();
+    } else {
+      std::vector<std::thread> pool;
+      for (int i = 0; i < nThreads; i++) pool.emplace_back(worker);
+      for (auto& th : pool) th.join();
+    }
+    worst = std::max(worst, worstA.load());
+  }
+  logInfo(std::to_string(runs.size()) + " run(s) in " + std::to_string(nBatches) + " batch(es)\n");
+  for (auto& r : runs) {
+    sipnet_clim_free(r.clim);
+    sipnet_io_free(r.events);
+  }
+  return worst;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -273,7 +497,7 @@ int main(int argc, char** argv) {
     opts.push_back({kFlagOpts[k][0], no_argument, &tmpFlag, 1});
     opts.push_back({strdup((std::string("no-") + kFlagOpts[k][0]).c_str()), no_argument, &tmpFlag, 0});
   }
-  enum { OPT_RIN = 1001, OPT_ROUT, OPT_DBG, OPT_ENS, OPT_DEV, OPT_MATH, OPT_ESTATS };
+  enum { OPT_RIN = 1001, OPT_ROUT, OPT_DBG, OPT_ENS, OPT_DEV, OPT_MATH, OPT_ESTATS, OPT_SITES };
   opts.push_back({"input-file", required_argument, nullptr, 'i'});
   opts.push_back({"file-prefix", required_argument, nullptr, 'f'});
   opts.push_back({"file-name", required_argument, nullptr, 'f'});
@@ -285,10 +509,11 @@ int main(int argc, char** argv) {
   opts.push_back({"devices", required_argument, nullptr, OPT_DEV});
   opts.push_back({"math", required_argument, nullptr, OPT_MATH});
   opts.push_back({"ensemble-stats", required_argument, nullptr, OPT_ESTATS});
+  opts.push_back({"sites", required_argument, nullptr, OPT_SITES});
   opts.push_back({"help", no_argument, nullptr, 'h'});
   opts.push_back({"version", no_argument, nullptr, 'v'});
   opts.push_back({nullptr, 0, nullptr, 0});
-  std::string ensembleFile, devicesArg = "0", mathArg = "auto", ensembleStats;
+  std::string ensembleFile, devicesArg = "0", mathArg = "auto", ensembleStats, sitesFile;
   int longIndex = 0, ch;
   while ((ch = getopt_long(argc, argv, "he:f:i:v", opts.data(), &longIndex)) != -1) {
     switch (ch) {
@@ -303,6 +528,7 @@ int main(int argc, char** argv) {
       case OPT_DEV: devicesArg = optarg; break;
       case OPT_MATH: mathArg = optarg; break;
       case OPT_ESTATS: ensembleStats = optarg; break;
+      case OPT_SITES: sitesFile = optarg; break;
       case 'h': usage(argv[0]); return 0;
       case 'v': printf("SIPNET version 2.1.0 (%s)\n", sipnet_version()); return 0;
       default: usage(argv[0]); return 8;  // EXIT_CODE_BAD_CLI_ARGUMENT
@@ -318,6 +544,13 @@ int main(int argc, char** argv) {
     return 8;
   }
   g_quiet = ctx.i("quiet") != 0;
+  if (!sitesFile.empty()) {
+    if (!ensembleFile.empty() || !ensembleStats.empty()) {
+      logError("--sites does not combine with --ensemble-params / --ensemble-stats\n");
+      return 8;
+    }
+    return runSites(ctx, sitesFile, mathArg, devices[0]);
+  }
   if (ctx.s("filePrefix").empty()) die(3, "filePrefix must be set for SIPNET to run\n");
   readInputFile(ctx);
   g_quiet = ctx.i("quiet") != 0;

@@ -199,3 +199,70 @@ def test_cli_ensemble_stats_through_the_node_object(tmp_path):
         np.testing.assert_allclose(st[:, col], x.mean(0), atol=0.51 * 10 ** -digits)
         np.testing.assert_allclose(st[:, col + 1], x.std(0), atol=1.1 * 10 ** -digits)
     assert st[:, 6].max() > 0.05 and st[:, 5].max() > 1e-3      # there is a signal and a spread
+
+
+def test_cli_sites_option_errors_need_no_gpu(tmp_path):
+    """--sites: a missing list -> 6, an empty one -> 5, combined with --ensemble-params -> 8, a run directory that
+    does not exist -> 6"""
+    assert run_cli(tmp_path, "--sites", "nope.txt").returncode == 6
+    open(tmp_path / "runs.txt", "w").write("# nothing\n\n")
+    assert run_cli(tmp_path, "--sites", "runs.txt").returncode == 5
+    open(tmp_path / "runs.txt", "w").write("no_such_dir\n")
+    open(tmp_path / "m.txt", "w").write("aMax\n8\n")
+    assert run_cli(tmp_path, "--sites", "runs.txt", "--ensemble-params", "m.txt").returncode == 8
+    assert run_cli(tmp_path, "--sites", "runs.txt").returncode == 6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("math", ["auto", "fast"])
+def test_cli_sites_stacks_run_directories_into_shared_batches(tmp_path, math):
+    """`sipnet --sites runs.txt`: the reference's five smoke directories (three flag sets, two step counts) plus three
+    re-parameterised copies of russell_1 (same forcing: members of ONE site) in one process.  Every directory gets
+    the files its own run writes: with --math auto (strict kernel) byte-identical to the reference's goldens and to
+    separate runs; with --math fast (throughput kernels) to the last printed digit"""
+    import gzip
+    dirs = []
+    for case in helpers.SMOKE_CASES:
+        d = tmp_path / case
+        d.mkdir()
+        stage(case, d)
+        dirs.append(case)
+    for k, amax in enumerate((6.9, 7.7, 8.8)):           # an ensemble at russell_1's site: same clim + events, other aMax
+        d = tmp_path / f"ens{k}"
+        d.mkdir()
+        stage("russell_1", d)
+        txt = open(d / "sipnet.param").read().splitlines()
+        txt = [(f"aMax {amax}" if l.split() and l.split()[0] == "aMax" else l) for l in txt]
+        open(d / "sipnet.param", "w").write("\n".join(txt) + "\n")
+        dirs.append(f"ens{k}")
+    open(tmp_path / "runs.txt", "w").write("# the smoke cases and an ensemble\n" + "\n".join(dirs) + "\n")
+    r = run_cli(tmp_path, "--sites", "runs.txt", "-i", "sipnet.in", "--math", math)   # (options apply to every directory)
+    assert r.returncode == 0, r.stdout + r.stderr
+    # russell_1 + its three copies share one site (4 members); russell_1/4-like flag sets and niwot's step count differ
+    assert "8 run(s) in" in r.stdout and "4 member(s)" in r.stdout, r.stdout
+
+    def same(a, b):
+        if math == "auto":
+            return a == b
+        ta, tb = a.split(), b.split()
+        return len(ta) == len(tb) and all(x == y or abs(float(x) - float(y)) <= 1.01 * 10 ** -(len(x.split(b".")[-1]) if b"." in x else 0)
+                                          for x, y in zip(ta, tb))
+    for case in helpers.SMOKE_CASES:
+        gold_out = gzip.open(os.path.join(helpers.smoke_dir(case), "sipnet.out.gz"), "rb").read()
+        assert same(open(tmp_path / case / "sipnet.out", "rb").read(), gold_out), case
+        if case == "russell_4":
+            assert not os.path.exists(tmp_path / case / "events.out")
+        else:
+            gold_ev = open(os.path.join(helpers.smoke_dir(case), "events.out"), "rb").read()
+            assert same(open(tmp_path / case / "events.out", "rb").read(), gold_ev), case
+        got = open(tmp_path / case / "sipnet.config").read()
+        assert config_body(got) == config_body(open(os.path.join(helpers.smoke_dir(case), "sipnet.config")).read())
+    # the re-parameterised members against separate runs of the same CLI in copies of their directories
+    for k in range(3):
+        solo = tmp_path / f"solo{k}"
+        shutil.copytree(tmp_path / f"ens{k}", solo, ignore=shutil.ignore_patterns("*.out", "*.config"))
+        r1 = run_cli(solo, "-i", "sipnet.in", "--math", "strict" if math == "auto" else "fast")
+        assert r1.returncode == 0, r1.stdout
+        for f in ("sipnet.out", "events.out"):
+            assert same(open(tmp_path / f"ens{k}" / f, "rb").read(), open(solo / f, "rb").read()), (k, f)
+    assert open(tmp_path / "ens0" / "sipnet.out", "rb").read() != open(tmp_path / "ens2" / "sipnet.out", "rb").read()
