@@ -337,10 +337,9 @@ static int autoKernel(const int32_t* flags, int32_t n_sites, int32_t n_members, 
   const int64_t blocks = (int64_t)n_sites * ((n_members + 63) / 64);
   if (!fastMath || debugPlane) return SIPNET_KERNEL_STRICT;
   if (!flags[SIPNET_F_NITROGEN_CYCLE]) {
-    // default physics, or -- lean launches of up to two chunks per CU -- its optional-physics instantiations
+    // default physics, or -- up to two chunks per CU -- its optional-physics instantiations
     // (growth respiration, leaf water, flooding, litter pool, carbon saturation, anaerobic: run-time flags)
     const bool ext = !defaultFlags;
-    if (ext && wantFull) return SIPNET_KERNEL_ONE_WAVE;
     if (blocks <= (int64_t)numCUs) return SIPNET_KERNEL_COOP_LDS;
     if (blocks <= 2 * (int64_t)numCUs) return SIPNET_KERNEL_COOP_PAIR;
     if (!ext && blocks <= 4 * (int64_t)numCUs && !wantFull) return SIPNET_KERNEL_COOP_QUAD;
@@ -778,9 +777,9 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
     } else if (kernel != SIPNET_KERNEL_ONE_WAVE && b->flags[SIPNET_F_NITROGEN_CYCLE]) {
       setError("sipnet_batch_run: a flag set with the nitrogen cycle takes SIPNET_KERNEL_COOP_NCYCLE(_PAIR) or the one-wave kernel");
       return SIPNET_ERR_BAD_ARGUMENT;
-    } else if (kernel != SIPNET_KERNEL_ONE_WAVE && !defaultFlags && (wantFull || kernel == SIPNET_KERNEL_COOP_QUAD)) {
-      setError("sipnet_batch_run: the optional-physics instantiations of the cooperative kernel are lean (no records, "
-               "diagnostics, SIPNET_KOPT_FULL_STATE) and carry one or two chunks per workgroup");
+    } else if (kernel == SIPNET_KERNEL_COOP_QUAD && !defaultFlags) {
+      setError("sipnet_batch_run: the optional-physics instantiations of the cooperative kernel carry one or two chunks per "
+               "workgroup");
       return SIPNET_ERR_BAD_ARGUMENT;
     }
     if (kernel == SIPNET_KERNEL_COOP_QUAD && wantFull) {

@@ -531,7 +531,7 @@ template <class R, bool PlainExp, bool RingLds, bool Full, int NP, bool NCyc = f
 __device__ __forceinline__ void coopBody(const FastArgs& a) {
   static_assert(!(NP > 1 && RingLds), "two chunks' rings do not fit one CU's LDS");
   static_assert(!NCyc || (NP <= 2 && !RingLds && !Full), "nitrogen-cycle layout: one or two chunks, ring in HBM, lean");
-  static_assert(!Ext || !Full, "optional-physics layouts: lean state only");
+  static_assert(!(Ext && NCyc && Full), "nitrogen cycle + extras: lean state only");
   constexpr bool Opt = Ext && !NCyc;   // the optional pools live on wave C
   // the run-time flags (all false without Ext: dead code then)
   const bool F_growthResp = Ext && a.flags[SIPNET_F_GROWTH_RESP] != 0, F_leafWater = Ext && a.flags[SIPNET_F_LEAF_WATER] != 0;
@@ -1729,7 +1729,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   // calcMethaneFlux (sipnet.c:1132-1214) and updatePoolsForSoil (sipnet.c:1645-1668, both forms, one select).
   // soilCNow: the soil carbon the reference looks at for the saturation share -- it already holds the step's events.
   auto optSoilSide = [&](R eSoilC, R eLitter, R soilCNow, R fSoil, R qSoilT, R mK, R rootLoss, R aboveLitter, R len,
-                         R& rSoil, R& rHet, double& soilGain, double& litterGain) {
+                         R& rSoil, R& rHet, double& soilGain, double& litterGain, R& methane) {
 #pragma clang fp contract(off)
     rSoil = eSoilC * fSoil;
     const R breakdown = eLitter * (X_lbrK * fSoil);
@@ -1744,6 +1744,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
     soilGain = (double)((F_litterPool ? dSoilTwo : dSoilOne) * len);
     litterGain = (double)((F_litterPool ? dLitter : R(0)) * len);
     rHet = rSoil + rLitter;
+    methane = soilMethane + litterMethane;   // (Full: record column 31, and the carbon balance)
   };
   double delta = ST(plantCAccountingDelta);
   double ringSum = ST(ringSum), totNee = ST(totNee);
@@ -1910,6 +1911,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         // general step from then on) -- the loop body stays one straight run of code.  What the
         // tail needs from the step lives outside the loop for that.
         R photosynthesis = 0, rSoil = 0, rVeg = 0, rCoarseRoot = 0, rFineRoot = 0, rHet = 0;
+        [[maybe_unused]] R methaneReg = 0;
         double soilGain = 0.0, litterGain = 0.0, ringNew = 0.0;
         R rvN = 0;
         bool rootsOk = true, useLast = false, dyingStep = false;
@@ -2067,7 +2069,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
           accum(fineRootC, fineRootCreation - fineRootLoss, len);
           if (Opt)
             optSoilSide(eSoilC, (R)litterC, eSoilC, fSoil, qSoilT, mK, coarseRootLoss + fineRootLoss, woodLitter + leafLitter, len,
-                        rSoil, rHet, soilGain, litterGain);
+                        rSoil, rHet, soilGain, litterGain, methaneReg);
           else if (!NCyc) soilGain = (double)((coarseRootLoss + fineRootLoss + woodLitter + leafLitter - rSoil) * len);
           const R r_a = rVeg + rFineRoot + rCoarseRoot;
           const R alloc = leafCreation + woodCreation + fineRootCreation + coarseRootCreation;
@@ -2230,7 +2232,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
     const R totalWoodC = (R)(plantWoodC + delta);
     // getMassTotals() before the pool updates, balance.c:13-36 (carbon; default flags)
     double preC = 0.0;
-    if (wantDiag) preC = (plantWoodC + delta) + plantLeafC + fineRootC + coarseRootC + soilC;
+    if (wantDiag) preC = (plantWoodC + delta) + plantLeafC + fineRootC + coarseRootC + soilC + (Opt && F_litterPool ? litterC : 0.0);
     R recLeafOffComputed = 0, recEvLeafOn = 0, recEvLeafOnFromWood = 0, recEvLeafOffLitter = 0;
     R evInC = 0, evOutC = 0;
 
@@ -2421,9 +2423,10 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
     accum(coarseRootC, coarseRootCreation - coarseRootLoss - (leafOnCreation - leafOnFromWood), len);
     accum(fineRootC, fineRootCreation - fineRootLoss, len);
     double soilGain = 0.0, litterGain = 0.0;
+    R methane = 0;
     if (Opt)
       optSoilSide(eSoilC, eLitter, (R)soilC, fSoil, qSoilT, mK, coarseRootLoss + fineRootLoss, woodLitter + leafLitter, len,
-                  rSoil, rHet, soilGain, litterGain);
+                  rSoil, rHet, soilGain, litterGain, methane);
     else if (!NCyc) soilGain = (double)((coarseRootLoss + fineRootLoss + woodLitter + leafLitter - rSoil) * len);
     const R r_a = rVeg + rFineRoot + rCoarseRoot;
     const R alloc = leafCreation + woodCreation + fineRootCreation + coarseRootCreation;
@@ -2442,7 +2445,9 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
     // can leave for wave L as early as possible
     accum(delta, (photosynthesis - r_a) - alloc, len);
     double postC = 0.0;  // getMassTotals() after the pool updates (the soil pool's is still pending here)
-    if (wantDiag) postC = (plantWoodC + delta) + plantLeafC + fineRootC + coarseRootC + (soilC + soilGain);
+    if (wantDiag)
+      postC = (plantWoodC + delta) + plantLeafC + fineRootC + coarseRootC + (soilC + soilGain) +
+              (Opt && F_litterPool ? litterC + litterGain : 0.0);
     double deathWood = 0.0, deathRoot = 0.0;  // record columns 41, 42
     // checkForMortality(), sipnet.c:1688-1767
     bool alive = alive0;
@@ -2511,14 +2516,15 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
     }
     if (wantDiag && soilC < 0.0 && fabs(soilC) > kEps) clampWarn++;
     soilC = rmax0(soilC);
+    if (Opt && wantDiag && F_litterPool && litterC < 0.0 && fabs(litterC) > kEps) clampWarn++;
     if (Opt) litterC = rmax0(litterC);
     if (wantDiag) {  // updateBalanceTrackerPostClamp() + checkBalance(), balance.c:40-169
-      const double finC = (plantWoodC + delta) + plantLeafC + fineRootC + coarseRootC + soilC;
+      const double finC = (plantWoodC + delta) + plantLeafC + fineRootC + coarseRootC + soilC + (Opt && F_litterPool ? litterC : 0.0);
       double clampedC = finC - postC;
       if (clampedC < kEps) clampedC = 0.0;
       double inC = ((double)photosynthesis + (double)evInC) * (double)len;
-      const double outC = ((double)rVeg + (double)rFineRoot + (double)rCoarseRoot + (double)rSoil +
-                           (double)evOutC) * (double)len;
+      const double outC = ((double)rVeg + (double)rFineRoot + (double)rCoarseRoot + (double)(Opt ? rHet : rSoil) +
+                           (double)methane + (double)evOutC) * (double)len;
       inC += clampedC;
       const double dC = (finC - preC) - (inC - outC);
       maxDC = fmax(maxDC, fabs(dC));
@@ -2616,7 +2622,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
       r[14 * L] = plantWoodC;
       r[15 * L] = plantLeafC;
       r[16 * L] = soilC;
-      r[18 * L] = cLitterC;
+      r[18 * L] = Opt ? litterC : cLitterC;
       r[20 * L] = coarseRootC;
       r[21 * L] = fineRootC;
       r[22 * L] = cMinN;
@@ -2628,7 +2634,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
       r[28 * L] = 0.0;
       r[29 * L] = 0.0;
       r[30 * L] = 0.0;
-      r[31 * L] = 0.0;
+      r[31 * L] = (double)(methane * len);
       r[32 * L] = recMeanNpp;
       r[33 * L] = rare[3];  // gddAfter
       r[34 * L] = rare[4];  // tillAfter
@@ -2750,13 +2756,13 @@ __global__ __launch_bounds__(512) void stepCoopNPairKernel(FastArgs a) {
 
 // ---- Ext: the optional-physics instantiations (run-time flags; see coopBody) -----------------------------------
 // default pools + growth respiration / leaf water / flooding / litter pool / carbon saturation / anaerobic + methane
-template <class R, bool PlainExp, bool RingLds>
+template <class R, bool PlainExp, bool RingLds, bool Full>
 __global__ __launch_bounds__(RingLds ? 256 : 192) void stepCoopXKernel(FastArgs a) {
-  coopBody<R, PlainExp, RingLds, false, 1, false, true>(a);
+  coopBody<R, PlainExp, RingLds, Full, 1, false, true>(a);
 }
-template <class R, bool PlainExp>
+template <class R, bool PlainExp, bool Full>
 __global__ __launch_bounds__(512) void stepCoopXPairKernel(FastArgs a) {
-  coopBody<R, PlainExp, false, false, 2, false, true>(a);
+  coopBody<R, PlainExp, false, Full, 2, false, true>(a);
 }
 // the nitrogen-cycle flag set + growth respiration / leaf water / flooding / carbon saturation
 template <class R, bool PlainExp>
@@ -2838,15 +2844,17 @@ void launchStepCoop(const FastArgs& a, int precision, int layout, hipStream_t st
     else hipLaunchKernelGGL((stepCoopPairKernel<R, P, false>), grid, block, 0, stream, a);          \
   }
   if (ext) {   // (one or two chunks per workgroup, lean: the engine does not ask for anything else)
-#define X_LAUNCH(R, P)                                                                                        \
+#define X_LAUNCH2(R, P, F)                                                                                    \
   {                                                                                                           \
-    if (pair) hipLaunchKernelGGL((stepCoopXPairKernel<R, P>), grid, block, 0, stream, a);                     \
-    else if (ringInLds) hipLaunchKernelGGL((stepCoopXKernel<R, P, true>), grid, block, 0, stream, a);         \
-    else hipLaunchKernelGGL((stepCoopXKernel<R, P, false>), grid, block, 0, stream, a);                       \
+    if (pair) hipLaunchKernelGGL((stepCoopXPairKernel<R, P, F>), grid, block, 0, stream, a);                  \
+    else if (ringInLds) hipLaunchKernelGGL((stepCoopXKernel<R, P, true, F>), grid, block, 0, stream, a);      \
+    else hipLaunchKernelGGL((stepCoopXKernel<R, P, false, F>), grid, block, 0, stream, a);                    \
   }
+#define X_LAUNCH(R, P) { if (a.full) X_LAUNCH2(R, P, true) else X_LAUNCH2(R, P, false) }
     if (precision == SIPNET_F64) { if (a.plainExp) X_LAUNCH(double, true) else X_LAUNCH(double, false) }
     else { if (a.plainExp) X_LAUNCH(float, true) else X_LAUNCH(float, false) }
 #undef X_LAUNCH
+#undef X_LAUNCH2
   } else if (quad) {
     if (precision == SIPNET_F64) {
       if (a.plainExp) hipLaunchKernelGGL((stepCoopQuadKernel<double, true>), grid, block, 0, stream, a);
@@ -2871,8 +2879,8 @@ void launchStepCoop(const FastArgs& a, int precision, int layout, hipStream_t st
     const char* r = precision == SIPNET_F64 ? "double" : "float";
     const char* pe = a.plainExp ? "true" : "false";
     const char* fu = a.full ? "true" : "false";
-    if (ext && pair) snprintf(info->kernel, sizeof info->kernel, "stepCoopXPairKernel<%s, %s>", r, pe);
-    else if (ext) snprintf(info->kernel, sizeof info->kernel, "stepCoopXKernel<%s, %s, %s>", r, pe, ringInLds ? "true" : "false");
+    if (ext && pair) snprintf(info->kernel, sizeof info->kernel, "stepCoopXPairKernel<%s, %s, %s>", r, pe, fu);
+    else if (ext) snprintf(info->kernel, sizeof info->kernel, "stepCoopXKernel<%s, %s, %s, %s>", r, pe, ringInLds ? "true" : "false", fu);
     else if (quad) snprintf(info->kernel, sizeof info->kernel, "stepCoopQuadKernel<%s, %s>", r, pe);
     else if (pair) snprintf(info->kernel, sizeof info->kernel, "stepCoopPairKernel<%s, %s, %s>", r, pe, fu);
     else snprintf(info->kernel, sizeof info->kernel, "stepCoopKernel<%s, %s, %s, %s>", r, pe,

@@ -144,14 +144,14 @@ def test_auto_kernel_policy_by_shape_and_flags():
     assert choice(10240, **ncyc) == choice(10240, gdd=0, soilPhenol=1, **ncyc) == sa.KERNEL_COOP_NCYCLE
     assert choice(1024, sites=32, **ncyc) == sa.KERNEL_COOP_NCYCLE_PAIR
     assert choice(32769, **ncyc) == choice(10240, full=1, **ncyc) == sa.KERNEL_ONE_WAVE
-    # every other optional flag: the optional-physics instantiations of the one- and two-chunk layouts (lean), the
-    # one-wave kernel beyond two chunks per CU and for full-state launches; with the nitrogen cycle on top: its kernels
+    # every other optional flag: the optional-physics instantiations of the one- and two-chunk layouts (lean or full
+    # state), the one-wave kernel beyond two chunks per CU; with the nitrogen cycle on top: its kernels
     for other in (dict(growthResp=1), dict(leafWater=1), dict(litterPool=1), dict(flooding=1),
                   dict(litterPool=1, carbonSaturation=1), dict(anaerobic=1),
                   dict(growthResp=1, leafWater=1, litterPool=1, waterHResp=0)):                  # (the last: russell_3)
         assert choice(10240, **other) == sa.KERNEL_COOP_LDS, other
         assert choice(1024, sites=32, **other) == sa.KERNEL_COOP_PAIR, other
-        assert choice(65536, **other) == choice(10240, full=1, **other) == sa.KERNEL_ONE_WAVE, other
+        assert choice(65536, **other) == sa.KERNEL_ONE_WAVE and choice(10240, full=1, **other) == sa.KERNEL_COOP_LDS, other
     everything = dict(carbonSaturation=1, flooding=1, growthResp=1, leafWater=1, **ncyc)
     assert choice(10240, **everything) == sa.KERNEL_COOP_NCYCLE and choice(1024, sites=32, **everything) == sa.KERNEL_COOP_NCYCLE_PAIR
     assert choice(10240, full=1, **everything) == sa.KERNEL_ONE_WAVE

@@ -19,7 +19,13 @@ KERNELS = [("coop_lds", sa.KERNEL_COOP_LDS, 0, "stepCoopKernel<double, true, tru
            ("coop_hbm", sa.KERNEL_COOP_HBM, 0, "stepCoopKernel<double, true, false, true>"),
            ("coop_pair", sa.KERNEL_COOP_PAIR, 0, "stepCoopPairKernel<double, true, true>"),
            ("one_wave", sa.KERNEL_ONE_WAVE, 0, "stepFastKernel<double, true, 0, 1, true>"),
-           ("runtime_flags", sa.KERNEL_ONE_WAVE, sa.KOPT_RUNTIME_FLAGS, "stepFastKernel<double, true, 1, 1, true>")]
+           ("runtime_flags", sa.KERNEL_ONE_WAVE, sa.KOPT_RUNTIME_FLAGS, "stepFastKernel<double, true, 1, 1, true>"),
+           # the optional-physics instantiations (russell_3's flag family + anaerobic, carbon saturation, flooding)
+           ("x_lds", sa.KERNEL_COOP_LDS, 0, "stepCoopXKernel<double, false, true, true>"),
+           ("x_hbm", sa.KERNEL_COOP_HBM, 0, "stepCoopXKernel<double, false, false, true>"),
+           ("x_pair", sa.KERNEL_COOP_PAIR, 0, "stepCoopXPairKernel<double, false, true>"),
+           ("x_one_wave", sa.KERNEL_ONE_WAVE, 0, "stepFastKernel<double, false, 1, 1, true>")]
+X_FLAGS = dict(anaerobic=1, litterPool=1, carbonSaturation=1, flooding=1, growthResp=1, leafWater=1)
 
 
 @pytest.fixture(scope="module")
@@ -45,8 +51,17 @@ def test_full_record_from_the_throughput_kernels(name, kernel, options, expect, 
     """all 36 `.out` columns of every step against the oracle, the 8 event-log columns and the
     carried accumulators against the strict-order kernel; the launch is split at odd steps"""
     flags = sa.flags_from()
+    if name.startswith("x_"):
+        flags = sa.flags_from(**X_FLAGS)
+        base = sa.read_params(os.path.join(os.path.dirname(BASE), "allflags_forest.param"), flags)[0]
     clim, ev, members = _scenario(base, lethal=True)
     members = members[:70]
+    if name.startswith("x_"):
+        rng = np.random.default_rng(5)
+        from sipnet_amd.config import param_index as pi
+        members[:, pi("soilCSaturation")] = members[:, pi("soilInit")] * rng.uniform(0.5, 3.0, 70)
+        members[:, pi("waterDrainFrac")] = rng.uniform(0.2, 1.0, 70)
+        members[:, pi("leafPoolDepth")] *= rng.uniform(0.02, 1.5, 70)
     T = clim.n_steps
     strict = _batch(flags, clim, members, ev, fast=False)
     _, rec_s = strict.run(full=True, want_planes=False)
@@ -182,3 +197,25 @@ def test_balance_warnings_are_counted_when_rounding_exceeds_the_threshold(oracle
         b.close()
         print("balance warnings: oracle", want.tolist(), "gpu", got.tolist())
         assert (np.abs(got - want) <= 0.25 * want).all()
+
+
+@pytest.mark.parametrize("kernel", [sa.KERNEL_COOP_LDS, sa.KERNEL_COOP_PAIR, sa.KERNEL_ONE_WAVE], ids=["x_lds", "x_pair", "one_wave"])
+def test_diagnostics_of_the_optional_physics_kernels_match_the_oracle(kernel, oracle, base):
+    """clamp and carbon-balance counters with the litter pool, methane, carbon saturation, flooding, growth
+    respiration and leaf water on (the optional-physics Full instantiations): equal to the oracle's on the events
+    scenario (harvests, a clear-cut, re-planting: the litter pool takes the transfers and the dead stands)"""
+    flags = sa.flags_from(**X_FLAGS)
+    xbase = sa.read_params(os.path.join(os.path.dirname(BASE), "allflags_forest.param"), flags)[0]
+    clim, ev, members = _scenario(xbase, lethal=True)
+    members = members[:70]
+    want = [oracle.run_member(flags, members[m], clim, ev, want_rec=False)[2] for m in range(70)]
+    b = _batch(flags, clim, members, ev, fast=True, kernel=kernel, diag=True)
+    b.run(0, 1001, want_planes=False)
+    b.run(1001, clim.n_steps - 1001, want_planes=False)
+    d = b.get_diagnostics()
+    li = b.last_launch()
+    b.close()
+    assert li["kernel"].endswith("true>") and ("stepCoopX" in li["kernel"] or kernel == sa.KERNEL_ONE_WAVE), li
+    np.testing.assert_array_equal(d["n_clamp_warn"], np.array([w.n_clamp_warn for w in want]))
+    np.testing.assert_array_equal(d["n_balance_warn"], np.array([w.n_balance_warn for w in want]))
+    assert d["max_abs_dC"].max() < 1e-9
