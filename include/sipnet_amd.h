@@ -265,8 +265,8 @@ enum sipnet_kernel_option {
 int sipnet_batch_set_kernel(sipnet_batch *b, int32_t kernel, int32_t options);
 /* What SIPNET_KERNEL_AUTO picks for a batch shape on a device with num_cus compute units (MI355X: 256):
  * host-only, no device needed (tools and tests ask it; sipnet_batch_run uses the same function).
- * math = enum sipnet_math (ignored for SIPNET_F32_MIXED); want_full = records / diagnostics /
- * SIPNET_KOPT_FULL_STATE.  Returns an enum sipnet_kernel, -1 on a bad argument. */
+ * math = enum sipnet_math (ignored for SIPNET_F32_MIXED); want_full = 0 lean, 1 records /
+ * SIPNET_KOPT_FULL_STATE, 2 the diagnostics counters as well.  Returns an enum sipnet_kernel, -1 on a bad argument. */
 int32_t sipnet_kernel_choice(const int32_t flags[SIPNET_NFLAGS], int32_t n_sites, int32_t n_members,
                              int32_t precision, int32_t math, int32_t want_full, int32_t num_cus);
 

@@ -331,8 +331,9 @@ static int ringFromHost(sipnet_batch* b, int64_t col0, int64_t ncols, const doub
   return SIPNET_OK;
 }
 
+// wantFull: 0 lean, 1 record / SIPNET_KOPT_FULL_STATE, 2 diagnostics counters as well
 static int autoKernel(const int32_t* flags, int32_t n_sites, int32_t n_members, bool fastMath, bool debugPlane,
-                      bool wantFull, int32_t numCUs) {
+                      int wantFull, int32_t numCUs) {
   const bool defaultFlags = isDefaultFlagSet(flags);
   const int64_t blocks = (int64_t)n_sites * ((n_members + 63) / 64);
   if (!fastMath || debugPlane) return SIPNET_KERNEL_STRICT;
@@ -345,9 +346,11 @@ static int autoKernel(const int32_t* flags, int32_t n_sites, int32_t n_members, 
     if (!ext && blocks <= 4 * (int64_t)numCUs && !wantFull) return SIPNET_KERNEL_COOP_QUAD;
     return SIPNET_KERNEL_ONE_WAVE;
   }
-  // the nitrogen cycle (with litter pool + anaerobic, which it requires), alone or with the other options
-  if (blocks <= (int64_t)numCUs && !wantFull) return SIPNET_KERNEL_COOP_NCYCLE;
-  if (blocks <= 2 * (int64_t)numCUs && !wantFull) return SIPNET_KERNEL_COOP_NCYCLE_PAIR;
+  // the nitrogen cycle (with litter pool + anaerobic, which it requires), alone or with the other options; full state
+  // (record, every accumulator) for the nitrogen-cycle set itself, but no diagnostics counters (wantFull == 2)
+  const bool fullOk = wantFull == 0 || (wantFull == 1 && isNCycleFlagSet(flags));
+  if (blocks <= (int64_t)numCUs && fullOk) return SIPNET_KERNEL_COOP_NCYCLE;
+  if (blocks <= 2 * (int64_t)numCUs && fullOk) return SIPNET_KERNEL_COOP_NCYCLE_PAIR;
   return SIPNET_KERNEL_ONE_WAVE;
 }
 
@@ -357,7 +360,7 @@ int32_t sipnet_kernel_choice(const int32_t* flags, int32_t n_sites, int32_t n_me
                              int32_t math, int32_t want_full, int32_t num_cus) {
   if (!flags || n_sites <= 0 || n_members <= 0 || num_cus <= 0) return -1;
   const bool fast = precision == SIPNET_F32_MIXED || math == SIPNET_MATH_FAST;
-  return autoKernel(flags, n_sites, n_members, fast, false, want_full != 0, num_cus);
+  return autoKernel(flags, n_sites, n_members, fast, false, want_full, num_cus);
 }
 
 const char* sipnet_version(void) { return "sipnet_amd 0.1 (reference SIPNET 2.1.0)"; }
@@ -758,7 +761,7 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
   int kernel = b->kernelPolicy;
   const bool wantFull = d_rec || b->d_diag || (b->kernelOptions & SIPNET_KOPT_FULL_STATE);
   if (kernel == SIPNET_KERNEL_AUTO) {
-    kernel = autoKernel(b->flags, b->n_sites, b->n_members, b->fastMath, d_dbg != nullptr, wantFull, b->numCUs);
+    kernel = autoKernel(b->flags, b->n_sites, b->n_members, b->fastMath, d_dbg != nullptr, b->d_diag ? 2 : wantFull ? 1 : 0, b->numCUs);
   } else if (kernel != SIPNET_KERNEL_STRICT) {
     if (!b->fastMath) {
       setError("sipnet_batch_run: the throughput kernels need SIPNET_MATH_FAST (sipnet_batch_set_math)");
@@ -769,9 +772,9 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
       return SIPNET_ERR_BAD_ARGUMENT;
     }
     if (kernel == SIPNET_KERNEL_COOP_NCYCLE || kernel == SIPNET_KERNEL_COOP_NCYCLE_PAIR) {
-      if (!b->flags[SIPNET_F_NITROGEN_CYCLE] || wantFull) {
-        setError("sipnet_batch_run: the nitrogen-cycle cooperative kernels run flag sets with the nitrogen cycle on and have "
-                 "no full-state instantiation");
+      if (!b->flags[SIPNET_F_NITROGEN_CYCLE] || b->d_diag || (wantFull && !isNCycleFlagSet(b->flags))) {
+        setError("sipnet_batch_run: the nitrogen-cycle cooperative kernels run flag sets with the nitrogen cycle on; full "
+                 "state (records, SIPNET_KOPT_FULL_STATE) for the nitrogen-cycle set itself only, never the diagnostics counters");
         return SIPNET_ERR_BAD_ARGUMENT;
       }
     } else if (kernel != SIPNET_KERNEL_ONE_WAVE && b->flags[SIPNET_F_NITROGEN_CYCLE]) {

@@ -530,7 +530,7 @@ __device__ unsigned long long g_coopWaits[16];
 template <class R, bool PlainExp, bool RingLds, bool Full, int NP, bool NCyc = false, bool Ext = false>
 __device__ __forceinline__ void coopBody(const FastArgs& a) {
   static_assert(!(NP > 1 && RingLds), "two chunks' rings do not fit one CU's LDS");
-  static_assert(!NCyc || (NP <= 2 && !RingLds && !Full), "nitrogen-cycle layout: one or two chunks, ring in HBM, lean");
+  static_assert(!NCyc || (NP <= 2 && !RingLds), "nitrogen-cycle layout: one or two chunks, ring in HBM");
   static_assert(!(Ext && NCyc && Full), "nitrogen cycle + extras: lean state only");
   constexpr bool Opt = Ext && !NCyc;   // the optional pools live on wave C
   // the run-time flags (all false without Ext: dead code then)
@@ -588,10 +588,13 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   // of that step, i.e. possibly before S has consumed the step before)
   // (one chunk: plain arrays, as the one-chunk kernel was tuned -- the per-chunk ones cost it 1.3 %; two chunks: per chunk)
   constexpr int NPN = (NCyc && NP > 1) ? NP : 1;
-  __shared__ alignas(16) double mailPlant1[NCyc ? 2 : 1][NCyc ? 8 : 1][64], mailPend1[NCyc ? 2 : 1][64], mailMinN1[NCyc ? 2 : 1][64];
+  // (mailPend: GPP - R_a of the step; a full-state launch adds R_a and the root respiration -- wave S writes the
+  // record's R_soil / R_tot columns and carries those accumulators)
+  constexpr int kPendRows = (NCyc && Full) ? 3 : 1;
+  __shared__ alignas(16) double mailPlant1[NCyc ? 2 : 1][NCyc ? 8 : 1][64], mailPend1[NCyc ? 2 : 1][kPendRows][64], mailMinN1[NCyc ? 2 : 1][64];
   __shared__ alignas(16) double mailStorN1[NCyc ? 2 : 1][64], mailEvent1[NCyc ? 2 : 1][NCyc ? 6 : 1][64], mailDeath1[NCyc ? 4 : 1][64];
   __shared__ alignas(16) double mailSupply1[NCyc ? 3 : 1][64], mailDemand1[1][64];
-  __shared__ alignas(16) double mailPlantAll[NPN][NCyc ? 2 : 1][NCyc ? 8 : 1][64], mailPendAll[NPN][NCyc ? 2 : 1][64],
+  __shared__ alignas(16) double mailPlantAll[NPN][NCyc ? 2 : 1][NCyc ? 8 : 1][64], mailPendAll[NPN][NCyc ? 2 : 1][kPendRows][64],
       mailMinNAll[NPN][NCyc ? 2 : 1][64];
   __shared__ alignas(16) double mailStorNAll[NPN][NCyc ? 2 : 1][64], mailEventAll[NPN][NCyc ? 2 : 1][NCyc ? 6 : 1][64],
       mailDeathAll[NPN][NCyc ? 4 : 1][64];
@@ -1075,6 +1078,10 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
     double soilC = ST(soilC), litterC = ST(litterC), minN = ST(minN);
     double soilOrgN = ST(soilOrgN), litterN = ST(litterN), storN = ST(plantStorageN);
     double totNee = ST(totNee);
+    // Full: the heterotrophic side of updateTrackers() (sipnet.c:1420-1496) and the record columns this wave owns
+    double totRh = Full ? ST(totRh) : 0.0, totRtot = Full ? ST(totRtot) : 0.0;
+    double yRh = Full ? ST(yearlyRh) : 0.0, yRtot = Full ? ST(yearlyRtot) : 0.0, yNee = Full ? ST(yearlyNee) : 0.0;
+    double* __restrict__ recs = Full && a.rec ? a.rec + col : nullptr;
     R* __restrict__ oNee = (R*)(a.nee ? a.nee : a.scratchRow) + col;
     const int64_t ldNee = a.nee ? a.ld : 0;
     // what C needs of these pools at the start of the first step
@@ -1262,8 +1269,17 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         do {
           asm volatile("ds_read_b32 %0, %2\n\tds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)"
                        : "=&v"(w), "=&v"(pend)
-                       : "v"(ldsAddr(&mailAlive[(t + 1) & 1][lane])), "v"(ldsAddr(&mailPend[t & 1][lane])) : "memory");
+                       : "v"(ldsAddr(&mailAlive[(t + 1) & 1][lane])), "v"(ldsAddr(&mailPend[t & 1][0][lane])) : "memory");
         } while (uni(w < 0 ? -w : w) < t + 3);
+        double pendRa = 0.0, pendRRoot = 0.0;   // Full: R_a and the root respiration of the step (posted with GPP - R_a)
+        int bitsS = 0;
+        if (Full) {
+          asm volatile("ds_read_b64 %0, %3 offset:512\n\tds_read_b64 %1, %3 offset:1024\n\tds_read_b32 %2, %4 offset:128\n\t"
+                       "s_waitcnt lgkmcnt(0)"
+                       : "=&v"(pendRa), "=&v"(pendRRoot), "=&v"(bitsS)
+                       : "v"(ldsAddr(&mailPend[t & 1][0][lane])), "v"(ldsAddr(recB)) : "memory");
+          bitsS = uni(bitsS);
+        }
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(w < 0) != 0, 0)) {
           double d0, d1, d2, d3;
           asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:512\n\tds_read_b64 %2, %4 offset:1024\n\t"
@@ -1291,6 +1307,37 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
           totNee += (double)tNee;
           *oNee = tNee;
           oNee += ldNee;
+          if (Full) {
+            if (bitsS & FAST_TRACK_NEW_YEAR) yRh = yRtot = yNee = 0.0;
+            const R tRa = (R)pendRa, tRRoot = (R)pendRRoot;
+            const R tRtot = tRa + tRh;
+            yRh += (double)tRh;
+            yRtot += (double)tRtot;
+            yNee += (double)tNee;
+            totRh += (double)tRh;
+            totRtot += (double)tRtot;
+            if (recs) {
+              double* __restrict__ r = recs;
+              const int64_t L = a.ld;
+              r[0 * L] = (double)tNee;
+              r[3 * L] = totNee;
+              r[6 * L] = (double)(tRRoot + tRh);
+              r[9 * L] = (double)tRh;
+              r[10 * L] = (double)tRtot;
+              r[16 * L] = soilC;
+              r[18 * L] = litterC;
+              r[22 * L] = minN;
+              r[23 * L] = soilOrgN;
+              r[24 * L] = litterN;
+              r[25 * L] = storN;
+              r[27 * L] = (double)(nVolatilization * len);
+              r[28 * L] = (double)(nLeaching * len);
+              r[29 * L] = (double)(nFixation * len);
+              r[30 * L] = (double)(nUptake * len);
+              r[31 * L] = (double)((soilMethane + litterMethane) * len);
+              recs += (int64_t)SIPNET_NREC * L;
+            }
+          }
         }
       }
     }
@@ -1303,6 +1350,13 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
       ST(litterN) = litterN;
       ST(plantStorageN) = storN;
       ST(totNee) = totNee;
+      if (Full) {
+        ST(totRh) = totRh;
+        ST(totRtot) = totRtot;
+        ST(yearlyRh) = yRh;
+        ST(yearlyRtot) = yRtot;
+        ST(yearlyNee) = yNee;
+      }
     }
     return;
   }
@@ -1762,7 +1816,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   const double cLitterC = Full ? ST(litterC) : 0.0, cMinN = Full ? ST(minN) : 0.0;
   const double cSoilOrgN = Full ? ST(soilOrgN) : 0.0, cLitterN = Full ? ST(litterN) : 0.0;
   const double cStorN = Full ? ST(plantStorageN) : 0.0;
-  const bool wantDiag = Full && a.diag != nullptr;
+  const bool wantDiag = Full && !NCyc && a.diag != nullptr;   // (NCyc: the pools are spread over two wavefronts: no counters)
   int clampWarn = 0, balanceWarn = 0;
   double maxDC = 0.0;
   double* __restrict__ recp = Full && a.rec ? a.rec + col : nullptr;
@@ -1949,7 +2003,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
           fineRootC = rmax0(fineRootC);
           const R tGpp = photosynthesis * len;
           const R tRa = ffma(rVeg, len, (rCoarseRoot + rFineRoot) * len);
-          if (NCyc) postD(&mailPend[t & 1][lane], 0, (double)(tGpp - tRa));   // S forms NEE (it has R_h); before the verdict word
+          if (NCyc) postD(&mailPend[t & 1][0][lane], 0, (double)(tGpp - tRa));   // S forms NEE (it has R_h); before the verdict word
           postAlive(&mailAlive[(t + 1) & 1][lane], t + 1, diedNow);
           if (!NCyc) {
             soilC += soilGain;
@@ -2498,8 +2552,13 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
     coarseRootC = rmax0(coarseRootC);
     fineRootC = rmax0(fineRootC);
     // NCyc: GPP - R_a of this step for wave S, which has R_h and forms NEE; before the verdict word
-    if (NCyc)
-      postD(&mailPend[t & 1][lane], 0, (double)(photosynthesis * len - ffma(rVeg, len, (rCoarseRoot + rFineRoot) * len)));
+    if (NCyc) {
+      postD(&mailPend[t & 1][0][lane], 0, (double)(photosynthesis * len - ffma(rVeg, len, (rCoarseRoot + rFineRoot) * len)));
+      if (Full) {
+        postD(&mailPend[t & 1][0][lane], 1, (double)ffma(rVeg, len, (rCoarseRoot + rFineRoot) * len));
+        postD(&mailPend[t & 1][0][lane], 2, (double)((rCoarseRoot + rFineRoot) * len));
+      }
+    }
     // confirms the lai(t+1) posted above, or revokes it when the stand died in this step (its
     // leaf pool was just zeroed); a stand that was never alive keeps its leaves and its lai
     postAlive(&mailAlive[(t + 1) & 1][lane], t + 1, diedNow);
@@ -2609,32 +2668,34 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
     if (Full && recp) {  // the carbon / tracker columns of the strict kernel's record row
       double* __restrict__ r = recp;
       const int64_t L = a.ld;
-      r[0 * L] = (double)tNee;
-      r[3 * L] = totNee;
+      if (!NCyc) {   // (NCyc: wave S has the heterotrophic side and the soil / nitrogen pools, and writes these)
+        r[0 * L] = (double)tNee;
+        r[3 * L] = totNee;
+        r[6 * L] = (double)tRSoil;
+        r[9 * L] = (double)tRh;
+        r[10 * L] = (double)tRtot;
+        r[16 * L] = soilC;
+        r[18 * L] = Opt ? litterC : cLitterC;
+        r[22 * L] = cMinN;
+        r[23 * L] = cSoilOrgN;
+        r[24 * L] = cLitterN;
+        r[25 * L] = cStorN;
+        r[27 * L] = 0.0;
+        r[28 * L] = 0.0;
+        r[29 * L] = 0.0;
+        r[30 * L] = 0.0;
+        r[31 * L] = (double)(methane * len);
+      }
       r[4 * L] = (double)tNpp;
       r[5 * L] = (double)tRAbove;
-      r[6 * L] = (double)tRSoil;
       r[7 * L] = (double)tRRoot;
       r[8 * L] = (double)tRa;
-      r[9 * L] = (double)tRh;
-      r[10 * L] = (double)tRtot;
       r[11 * L] = (double)(woodCreation * len);
       r[14 * L] = plantWoodC;
       r[15 * L] = plantLeafC;
-      r[16 * L] = soilC;
-      r[18 * L] = Opt ? litterC : cLitterC;
       r[20 * L] = coarseRootC;
       r[21 * L] = fineRootC;
-      r[22 * L] = cMinN;
-      r[23 * L] = cSoilOrgN;
-      r[24 * L] = cLitterN;
-      r[25 * L] = cStorN;
       r[26 * L] = delta;
-      r[27 * L] = 0.0;
-      r[28 * L] = 0.0;
-      r[29 * L] = 0.0;
-      r[30 * L] = 0.0;
-      r[31 * L] = (double)(methane * len);
       r[32 * L] = recMeanNpp;
       r[33 * L] = rare[3];  // gddAfter
       r[34 * L] = rare[4];  // tillAfter
@@ -2682,17 +2743,19 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
     ST(ringValidFrom) = (double)ringValidFrom;
     ST(diedAt) = (double)diedAt;
     if (Full) {
-      ST(totRtot) = totRtot;
       ST(totRa) = totRa;
-      ST(totRh) = totRh;
       ST(totNpp) = totNpp;
       ST(yearlyGpp) = yGpp;
-      ST(yearlyRtot) = yRtot;
       ST(yearlyRa) = yRa;
-      ST(yearlyRh) = yRh;
       ST(yearlyNpp) = yNpp;
-      ST(yearlyNee) = yNee;
       ST(yearlyLitter) = yLitter;
+      if (!NCyc) {   // (NCyc: the accumulators with R_h in them are wave S's)
+        ST(totRtot) = totRtot;
+        ST(totRh) = totRh;
+        ST(yearlyRtot) = yRtot;
+        ST(yearlyRh) = yRh;
+        ST(yearlyNee) = yNee;
+      }
     }
     if (wantDiag) {
       double* __restrict__ dg = a.diag + col;
@@ -2754,6 +2817,17 @@ __global__ __launch_bounds__(512) void stepCoopNPairKernel(FastArgs a) {
   coopBody<R, PlainExp, false, false, 2, true>(a);
 }
 
+// ... and their full-state builds (record, every accumulator; no diagnostics counters: the pools of a member are
+// spread over two wavefronts)
+template <class R, bool PlainExp>
+__global__ __launch_bounds__(256) void stepCoopNFullKernel(FastArgs a) {
+  coopBody<R, PlainExp, false, true, 1, true>(a);
+}
+template <class R, bool PlainExp>
+__global__ __launch_bounds__(512) void stepCoopNPairFullKernel(FastArgs a) {
+  coopBody<R, PlainExp, false, true, 2, true>(a);
+}
+
 // ---- Ext: the optional-physics instantiations (run-time flags; see coopBody) -----------------------------------
 // default pools + growth respiration / leaf water / flooding / litter pool / carbon saturation / anaerobic + methane
 template <class R, bool PlainExp, bool RingLds, bool Full>
@@ -2811,13 +2885,16 @@ void launchStepCoop(const FastArgs& a, int precision, int layout, hipStream_t st
     }
     if (ext) {
       if (pairN) { NCYC_LAUNCH(stepCoopNXPairKernel) } else { NCYC_LAUNCH(stepCoopNXKernel) }
+    } else if (a.full) {
+      if (pairN) { NCYC_LAUNCH(stepCoopNPairFullKernel) } else { NCYC_LAUNCH(stepCoopNFullKernel) }
     } else {
       if (pairN) { NCYC_LAUNCH(stepCoopNPairKernel) } else { NCYC_LAUNCH(stepCoopNKernel) }
     }
 #undef NCYC_LAUNCH
     if (info) {
       snprintf(info->kernel, sizeof info->kernel, "%s<%s, %s>",
-               ext ? (pairN ? "stepCoopNXPairKernel" : "stepCoopNXKernel") : (pairN ? "stepCoopNPairKernel" : "stepCoopNKernel"),
+               ext ? (pairN ? "stepCoopNXPairKernel" : "stepCoopNXKernel")
+                   : a.full ? (pairN ? "stepCoopNPairFullKernel" : "stepCoopNFullKernel") : (pairN ? "stepCoopNPairKernel" : "stepCoopNKernel"),
                precision == SIPNET_F64 ? "double" : "float", a.plainExp ? "true" : "false");
       info->grid = (int32_t)gridN.x;
       info->block = pairN ? 512 : 256;

@@ -143,7 +143,8 @@ def test_auto_kernel_policy_by_shape_and_flags():
     ncyc = dict(litterPool=1, anaerobic=1, nitrogenCycle=1)
     assert choice(10240, **ncyc) == choice(10240, gdd=0, soilPhenol=1, **ncyc) == sa.KERNEL_COOP_NCYCLE
     assert choice(1024, sites=32, **ncyc) == sa.KERNEL_COOP_NCYCLE_PAIR
-    assert choice(32769, **ncyc) == choice(10240, full=1, **ncyc) == sa.KERNEL_ONE_WAVE
+    assert choice(32769, **ncyc) == choice(10240, full=2, **ncyc) == sa.KERNEL_ONE_WAVE      # (2: diagnostics counters)
+    assert choice(10240, full=1, **ncyc) == sa.KERNEL_COOP_NCYCLE and choice(1024, sites=32, full=1, **ncyc) == sa.KERNEL_COOP_NCYCLE_PAIR
     # every other optional flag: the optional-physics instantiations of the one- and two-chunk layouts (lean or full
     # state), the one-wave kernel beyond two chunks per CU; with the nitrogen cycle on top: its kernels
     for other in (dict(growthResp=1), dict(leafWater=1), dict(litterPool=1), dict(flooding=1),

@@ -24,7 +24,12 @@ KERNELS = [("coop_lds", sa.KERNEL_COOP_LDS, 0, "stepCoopKernel<double, true, tru
            ("x_lds", sa.KERNEL_COOP_LDS, 0, "stepCoopXKernel<double, false, true, true>"),
            ("x_hbm", sa.KERNEL_COOP_HBM, 0, "stepCoopXKernel<double, false, false, true>"),
            ("x_pair", sa.KERNEL_COOP_PAIR, 0, "stepCoopXPairKernel<double, false, true>"),
-           ("x_one_wave", sa.KERNEL_ONE_WAVE, 0, "stepFastKernel<double, false, 1, 1, true>")]
+           ("x_one_wave", sa.KERNEL_ONE_WAVE, 0, "stepFastKernel<double, false, 1, 1, true>"),
+           # the nitrogen-cycle flag set: record and accumulators from the cooperative kernels (the soil wave writes the
+           # heterotrophic / soil / nitrogen columns, the carbon wave the plants', the water wave its own)
+           ("n_full", sa.KERNEL_COOP_NCYCLE, 0, "stepCoopNFullKernel<double, false>"),
+           ("n_pair_full", sa.KERNEL_COOP_NCYCLE_PAIR, 0, "stepCoopNPairFullKernel<double, false>"),
+           ("n_one_wave", sa.KERNEL_ONE_WAVE, 0, "stepFastKernel<double, false, 2, 1, true>")]
 X_FLAGS = dict(anaerobic=1, litterPool=1, carbonSaturation=1, flooding=1, growthResp=1, leafWater=1)
 
 
@@ -51,8 +56,8 @@ def test_full_record_from_the_throughput_kernels(name, kernel, options, expect, 
     """all 36 `.out` columns of every step against the oracle, the 8 event-log columns and the
     carried accumulators against the strict-order kernel; the launch is split at odd steps"""
     flags = sa.flags_from()
-    if name.startswith("x_"):
-        flags = sa.flags_from(**X_FLAGS)
+    if name.startswith("x_") or name.startswith("n_"):
+        flags = sa.flags_from(**(X_FLAGS if name.startswith("x_") else dict(litterPool=1, anaerobic=1, nitrogenCycle=1)))
         base = sa.read_params(os.path.join(os.path.dirname(BASE), "allflags_forest.param"), flags)[0]
     clim, ev, members = _scenario(base, lethal=True)
     members = members[:70]
