@@ -257,6 +257,13 @@ enum sipnet_kernel_option {
                                         EVERY cooperative layout (default: only where a workgroup has a
                                         compute unit to itself and its fourth wavefront does the summing;
                                         on the two- / four-chunk layouts three reduction passes are cheaper) */
+  SIPNET_KOPT_BOUNDED_WAITS = 32,    /* cooperative kernels, lean launches: the build whose hand-over waits have a budget of
+                                        polls (the product's spin without an exit: a protocol bug would hang the GPU).  A wait
+                                        that exhausts it ends the launch; sipnet_batch_run then synchronises the stream and
+                                        answers SIPNET_ERR_INTERNAL naming the wait and the step.  ~10 % slower: for fuzz
+                                        campaigns and tests, never chosen by SIPNET_KERNEL_AUTO */
+  SIPNET_KOPT_WAIT_SELFTEST = 64,    /* with SIPNET_KOPT_BOUNDED_WAITS only: the light wavefront stops posting after 100 steps --
+                                        the test of the error path itself (the launch must end with SIPNET_ERR_INTERNAL) */
   SIPNET_KOPT_FULL_STATE = 4         /* throughput kernels: advance EVERY accumulator of the restart
                                         schema (trackers.tot*, trackers.yearly*); without it only
                                         totNee / totGpp advance on the throughput path.  Implied by a

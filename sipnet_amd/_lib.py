@@ -32,6 +32,8 @@ KERNEL_COOP_NCYCLE = 7
 KERNEL_COOP_NCYCLE_PAIR = 8
 KOPT_ONE_WAVE_PER_SIMD, KOPT_RUNTIME_FLAGS, KOPT_FULL_STATE, KOPT_NO_REGULAR_TILES = 1, 2, 4, 8
 KOPT_STATS_IN_KERNEL = 16
+KOPT_BOUNDED_WAITS = 32
+KOPT_WAIT_SELFTEST = 64
 SHARD_MEMBERS, SHARD_SITES = 0, 1
 ALL_SITES = -1
 

@@ -646,7 +646,7 @@ int sipnet_batch_set_math(sipnet_batch* b, int32_t policy) {
 int sipnet_batch_set_kernel(sipnet_batch* b, int32_t kernel, int32_t options) {
   if (!b || kernel < SIPNET_KERNEL_AUTO || kernel > SIPNET_KERNEL_COOP_NCYCLE_PAIR ||
       (options & ~(SIPNET_KOPT_ONE_WAVE_PER_SIMD | SIPNET_KOPT_RUNTIME_FLAGS | SIPNET_KOPT_FULL_STATE |
-                   SIPNET_KOPT_NO_REGULAR_TILES | SIPNET_KOPT_STATS_IN_KERNEL))) {
+                   SIPNET_KOPT_NO_REGULAR_TILES | SIPNET_KOPT_STATS_IN_KERNEL | SIPNET_KOPT_BOUNDED_WAITS | SIPNET_KOPT_WAIT_SELFTEST))) {
     setError("sipnet_batch_set_kernel: bad argument");
     return SIPNET_ERR_BAD_ARGUMENT;
   }
@@ -825,6 +825,7 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
     }
   }
   a.plan = b->d_plan;
+  bool boundedWaits = false;
   HIP_TRY(hipEventRecord(b->ev0, stream));
   if (kernel != SIPNET_KERNEL_STRICT) {
     // throughput path: step_fast.hip / step_coop.hip
@@ -856,14 +857,15 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
     f.numCUs = b->numCUs;
     f.statsPart = (d_stats && coop) ? b->d_statsPart : nullptr;
     f.statsChunks = b->n_sites * chunksPerSite;
+    const int layout = kernel == SIPNET_KERNEL_COOP_LDS ? COOP_RING_LDS
+                       : kernel == SIPNET_KERNEL_COOP_PAIR ? COOP_PAIR
+                       : kernel == SIPNET_KERNEL_COOP_QUAD ? COOP_QUAD
+                       : kernel == SIPNET_KERNEL_COOP_NCYCLE ? COOP_NCYCLE
+                       : kernel == SIPNET_KERNEL_COOP_NCYCLE_PAIR ? COOP_NCYCLE_PAIR : COOP_RING_HBM;
+    boundedWaits = (b->kernelOptions & SIPNET_KOPT_BOUNDED_WAITS) && kernel != SIPNET_KERNEL_ONE_WAVE && !wantFull;
     if (kernel == SIPNET_KERNEL_ONE_WAVE) launchStepFast(f, b->precision, b->kernelOptions, stream, &b->lastLaunch);
-    else launchStepCoop(f, b->precision,
-                        kernel == SIPNET_KERNEL_COOP_LDS ? COOP_RING_LDS
-                        : kernel == SIPNET_KERNEL_COOP_PAIR ? COOP_PAIR
-                        : kernel == SIPNET_KERNEL_COOP_QUAD ? COOP_QUAD
-                        : kernel == SIPNET_KERNEL_COOP_NCYCLE ? COOP_NCYCLE
-                        : kernel == SIPNET_KERNEL_COOP_NCYCLE_PAIR ? COOP_NCYCLE_PAIR : COOP_RING_HBM,
-                        stream, &b->lastLaunch);
+    else if (boundedWaits) bounded::launchStepCoop(f, b->precision, layout, stream, &b->lastLaunch);
+    else launchStepCoop(f, b->precision, layout, stream, &b->lastLaunch);
   } else {
     launchStep(a, b->precision, b->fastMath, stream, &b->lastLaunch);
   }
@@ -883,7 +885,22 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
   }
   b->timed = true;
   b->stepsDone = (b->stepsDone == step0) ? step0 + n_steps : -1;
-  return markBusy(b, stream);
+  rc = markBusy(b, stream);
+  if (rc) return rc;
+  if (boundedWaits) {   // the diagnostic build: did a hand-over wait give up?
+    unsigned long long stuck[2] = {0, 0};
+    if (bounded::readCoopStuck(stuck, stream) != 0) {
+      setError("sipnet_batch_run: reading the bounded-wait report failed");
+      return SIPNET_ERR_INTERNAL;
+    }
+    if (stuck[0] != 0) {
+      setError("sipnet_batch_run: hand-over wait " + std::to_string((unsigned)((stuck[0] >> 32) & 0x7fffffffu)) + " (step_coop.hip, \"hand-over waits\") of workgroup " +
+               std::to_string(stuck[1]) + " gave up at step " + std::to_string((int)(unsigned)(stuck[0] & 0xffffffffu)) + " of " + b->lastLaunch.kernel +
+               ": a producer never posted (the launch's results are void)");
+      return SIPNET_ERR_INTERNAL;
+    }
+  }
+  return SIPNET_OK;
 }
 
 double sipnet_batch_last_kernel_ms(sipnet_batch* b) {

@@ -43,9 +43,71 @@
 #include "step_kernel.h"
 
 namespace sipnet {
+#ifdef SIPNET_COOP_BOUNDED
+namespace bounded {   // (step_coop_bounded.hip: the same kernels with bounded waits, under names of their own)
+#endif
 namespace {
 
 constexpr int kTileBytes = kFastTile * (int)sizeof(FastRec);
+
+// ---- hand-over waits.  Every one of them is a spin on a sequence flag in LDS with no exit: the protocol guarantees the
+// producer's progress (see the file header), and a back-off hook on the exit path of every poll costs the c10k step 11 %.
+// A protocol bug therefore shows as a hung GPU.  The BOUNDED build of this file (step_coop_bounded.hip: the same code,
+// -DSIPNET_COOP_BOUNDED, lean instantiations only; SIPNET_KOPT_BOUNDED_WAITS selects it -- fuzz campaigns and the
+// fixed-seed slices, never the shape policy) gives every wait a budget of polls; a wait that exhausts it reports which one
+// (the numbers below) and at which step, poisons its workgroup -- every later wait of the workgroup gives up at once, so the
+// launch ends, with garbage -- and sipnet_batch_run answers SIPNET_ERR_INTERNAL naming the wait.
+//    1  take
+//    2  take
+//    3  takePgp
+//    4  takePgp
+//    5  takeFactors
+//    6  takeFactors
+//    7  takeFactorsN
+//    8  takeFactorsN
+//    9  takeFactorsRing
+//   10  takeFactorsRing
+//   11  takeFactors7
+//   12  takeFactors7
+//   13  takeFactorsRing7
+//   14  takeFactorsRing7
+//   15  takeR2
+//   16  takeR2
+//   17  takeD1
+//   18  takeD3
+//   19  takeD4
+//   20  takeD6
+//   21  takeD8
+//   22  awaitAtLeast
+//   23  wave S: factors + moisture take
+//   24  wave S: verdict word + GPP - R_a
+//   25  wave C general step: record + factor take (Opt)
+//   26  wave C general step: record + factor take (NCyc)
+//   27  wave C general step: record + factor take
+#ifdef SIPNET_COOP_BOUNDED
+__device__ unsigned long long g_coopStuck[2];   // [0]: 1 << 63 | wait id << 32 | step of the FIRST wait that gave up; [1]: its workgroup
+__shared__ int g_coopPoison;
+constexpr int kSpinBudget = 1 << 22;            // polls (~0.2 s of a lone wave)
+__device__ __forceinline__ bool spinOut(int& n, int id, int step) {
+  n++;
+  if ((n & 255) != 1) return false;             // look at the poison word on the 1st, 257th, ... failed poll
+  int p;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(p) : "v"((unsigned)(size_t)&g_coopPoison) : "memory");
+  if (__builtin_amdgcn_readfirstlane(p)) return true;
+  if (n < kSpinBudget) return false;
+  if ((threadIdx.x & 63) == 0) {
+    const unsigned long long rep = (1ull << 63) | ((unsigned long long)(unsigned)id << 32) | (unsigned)step;
+    if (atomicCAS(&g_coopStuck[0], 0ull, rep) == 0ull) g_coopStuck[1] = blockIdx.x;
+  }
+  asm volatile("ds_write_b32 %0, %1" :: "v"((unsigned)(size_t)&g_coopPoison), "v"(1) : "memory");
+  return true;
+}
+#define WAIT_DO for (int spin_ = 0, once_ = 1; once_; once_ = 0) do
+#define WAIT_WHILE(cond, id, step) while ((cond) && !spinOut(spin_, id, step))
+#else
+#define WAIT_DO do
+#define WAIT_WHILE(cond, id, step) while (cond)
+#endif
 
 // Hand-over through LDS.  DS instructions of one wavefront are executed in issue order, so a
 // producer needs no wait between the value and the flag (two plain ds_write), and a consumer
@@ -62,19 +124,19 @@ __device__ __forceinline__ void post(float* slot, int* flag, float v, int step) 
 __device__ __forceinline__ double take(const double* slot, const int* flag, int step) {
   double v;
   int f;
-  do {
+  WAIT_DO {
     asm volatile("ds_read_b32 %0, %2\n\tds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)"
                  : "=&v"(f), "=&v"(v) : "v"((unsigned)(size_t)flag), "v"((unsigned)(size_t)slot) : "memory");
-  } while (uni(f) < step);
+  } WAIT_WHILE(uni(f) < step, 1, step);
   return v;
 }
 __device__ __forceinline__ float take(const float* slot, const int* flag, int step) {
   float v;
   int f;
-  do {
+  WAIT_DO {
     asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)"
                  : "=&v"(f), "=&v"(v) : "v"((unsigned)(size_t)flag), "v"((unsigned)(size_t)slot) : "memory");
-  } while (uni(f) < step);
+  } WAIT_WHILE(uni(f) < step, 2, step);
   return v;
 }
 // Site-record reads and ring-value loads are issued from inline assembly on purpose: hipcc
@@ -106,21 +168,21 @@ __device__ __forceinline__ void postAlive(int* slot, int step, bool died) {
 __device__ __forceinline__ void takePgp(const double* slot, const int* flag, const int* alive, int step,
                                         double& pgp, bool& died) {
   int f, w;
-  do {
+  WAIT_DO {
     asm volatile("ds_read_b32 %0, %3\n\tds_read_b64 %1, %4\n\tds_read_b32 %2, %5\n\ts_waitcnt lgkmcnt(0)"
                  : "=&v"(f), "=&v"(pgp), "=&v"(w)
                  : "v"((unsigned)(size_t)flag), "v"((unsigned)(size_t)slot), "v"((unsigned)(size_t)alive) : "memory");
-  } while (uni(f) < step || uni(w < 0 ? -w : w) < step + 2);
+  } WAIT_WHILE(uni(f) < step || uni(w < 0 ? -w : w) < step + 2, 3, step);
   died = w < 0;
 }
 __device__ __forceinline__ void takePgp(const float* slot, const int* flag, const int* alive, int step,
                                         float& pgp, bool& died) {
   int f, w;
-  do {
+  WAIT_DO {
     asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %4\n\tds_read_b32 %2, %5\n\ts_waitcnt lgkmcnt(0)"
                  : "=&v"(f), "=&v"(pgp), "=&v"(w)
                  : "v"((unsigned)(size_t)flag), "v"((unsigned)(size_t)slot), "v"((unsigned)(size_t)alive) : "memory");
-  } while (uni(f) < step || uni(w < 0 ? -w : w) < step + 2);
+  } WAIT_WHILE(uni(f) < step || uni(w < 0 ? -w : w) < step + 2, 4, step);
   died = w < 0;
 }
 // wave C: this step's six factors -- rows 0..4 of the block from wave F (or L), row 5 (the moisture
@@ -135,7 +197,7 @@ __device__ __forceinline__ void takeFactors(const double* block, const int* flag
                                             double& moist) {
   i2v f;
   d2v a, b, c;
-  do {
+  WAIT_DO {
 #ifdef SIPNET_NO_READ2
     asm volatile("ds_read2_b32 %0, %7 offset1:1\n\tds_read_b64 %1, %8\n\tds_read_b64 %2, %8 offset:512\n\t"
                  "ds_read_b64 %3, %8 offset:1024\n\tds_read_b64 %4, %8 offset:1536\n\tds_read_b64 %5, %8 offset:2048\n\t"
@@ -149,20 +211,20 @@ __device__ __forceinline__ void takeFactors(const double* block, const int* flag
                  : "=&v"(f), "=&v"(a), "=&v"(b), "=&v"(c)
                  : "v"((unsigned)(size_t)flags2), "v"((unsigned)(size_t)block) : "memory");
 #endif
-  } while (uni(f.x < f.y ? f.x : f.y) < step);
+  } WAIT_WHILE(uni(f.x < f.y ? f.x : f.y) < step, 5, step);
   g1 = a.x; g2 = a.y; qSoilT = b.x; gFine = b.y; gCoarse = c.x; moist = c.y;
 }
 __device__ __forceinline__ void takeFactors(const float* block, const int* flags2, int step, float& g1,
                                             float& g2, float& qSoilT, float& gFine, float& gCoarse, float& moist) {
   i2v f;
   f2v a, b, c;
-  do {
+  WAIT_DO {
     asm volatile("ds_read2_b32 %0, %4 offset1:1\n\tds_read2st64_b32 %1, %5 offset1:1\n\t"
                  "ds_read2st64_b32 %2, %5 offset0:2 offset1:3\n\tds_read2st64_b32 %3, %5 offset0:4 offset1:5\n\t"
                  "s_waitcnt lgkmcnt(0)"
                  : "=&v"(f), "=&v"(a), "=&v"(b), "=&v"(c)
                  : "v"((unsigned)(size_t)flags2), "v"((unsigned)(size_t)block) : "memory");
-  } while (uni(f.x < f.y ? f.x : f.y) < step);
+  } WAIT_WHILE(uni(f.x < f.y ? f.x : f.y) < step, 6, step);
   g1 = a.x; g2 = a.y; qSoilT = b.x; gFine = b.y; gCoarse = c.x; moist = c.y;
 }
 // NCyc, wave C: rows 0 1 | 3 4 | 6 of the factor block behind wave L's flag, and -- in the same round trip,
@@ -172,13 +234,13 @@ __device__ __forceinline__ void takeFactorsN(const double* block, const int* fac
                                              double& minN, int& minNSeq) {
   int f0, f1;
   d2v a, b;
-  do {
+  WAIT_DO {
     asm volatile("ds_read_b32 %0, %6\n\tds_read2st64_b64 %1, %7 offset1:1\n\tds_read2st64_b64 %2, %7 offset0:3 offset1:4\n\t"
                  "ds_read_b64 %3, %7 offset:3072\n\tds_read_b32 %4, %8\n\tds_read_b64 %5, %9\n\ts_waitcnt lgkmcnt(0)"
                  : "=&v"(f0), "=&v"(a), "=&v"(b), "=&v"(qSoil), "=&v"(f1), "=&v"(minN)
                  : "v"((unsigned)(size_t)facFlag), "v"((unsigned)(size_t)block), "v"((unsigned)(size_t)minNFlag),
                    "v"((unsigned)(size_t)minNSlot) : "memory");
-  } while (uni(f0) < step);   // (the mineral nitrogen is looked at, not waited for: see plantSideN)
+  } WAIT_WHILE(uni(f0) < step, 7, step);   // (the mineral nitrogen is looked at, not waited for: see plantSideN)
   minNSeq = uni(f1);
   g1 = a.x; g2 = a.y; gFine = b.x; gCoarse = b.y;
 }
@@ -187,13 +249,13 @@ __device__ __forceinline__ void takeFactorsN(const float* block, const int* facF
                                              double& minN, int& minNSeq) {
   int f0, f1;
   f2v a, b;
-  do {
+  WAIT_DO {
     asm volatile("ds_read_b32 %0, %6\n\tds_read2st64_b32 %1, %7 offset1:1\n\tds_read2st64_b32 %2, %7 offset0:3 offset1:4\n\t"
                  "ds_read_b32 %3, %7 offset:1536\n\tds_read_b32 %4, %8\n\tds_read_b64 %5, %9\n\ts_waitcnt lgkmcnt(0)"
                  : "=&v"(f0), "=&v"(a), "=&v"(b), "=&v"(qSoil), "=&v"(f1), "=&v"(minN)
                  : "v"((unsigned)(size_t)facFlag), "v"((unsigned)(size_t)block), "v"((unsigned)(size_t)minNFlag),
                    "v"((unsigned)(size_t)minNSlot) : "memory");
-  } while (uni(f0) < step);   // (the mineral nitrogen is looked at, not waited for: see plantSideN)
+  } WAIT_WHILE(uni(f0) < step, 8, step);   // (the mineral nitrogen is looked at, not waited for: see plantSideN)
   minNSeq = uni(f1);
   g1 = a.x; g2 = a.y; gFine = b.x; gCoarse = b.y;
 }
@@ -204,13 +266,13 @@ __device__ __forceinline__ void takeFactorsRing(const double* block, const int* 
                                                 double& gFine, double& gCoarse, double& moist, double& ringV) {
   i2v f;
   d2v a, b, c;
-  do {
+  WAIT_DO {
     asm volatile("ds_read2_b32 %0, %5 offset1:1\n\tds_read2st64_b64 %1, %6 offset1:1\n\t"
                  "ds_read2st64_b64 %2, %6 offset0:2 offset1:3\n\tds_read2st64_b64 %3, %6 offset0:4 offset1:5\n\t"
                  "ds_read_b64 %4, %7\n\ts_waitcnt lgkmcnt(0)"
                  : "=&v"(f), "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(ringV)
                  : "v"((unsigned)(size_t)flags2), "v"((unsigned)(size_t)block), "v"(ringAddr) : "memory");
-  } while (uni(f.x < f.y ? f.x : f.y) < step);
+  } WAIT_WHILE(uni(f.x < f.y ? f.x : f.y) < step, 9, step);
   g1 = a.x; g2 = a.y; qSoilT = b.x; gFine = b.y; gCoarse = c.x; moist = c.y;
 }
 __device__ __forceinline__ void takeFactorsRing(const float* block, const int* flags2, unsigned ringAddr,
@@ -218,13 +280,13 @@ __device__ __forceinline__ void takeFactorsRing(const float* block, const int* f
                                                 float& gCoarse, float& moist, double& ringV) {
   i2v f;
   f2v a, b, c;
-  do {
+  WAIT_DO {
     asm volatile("ds_read2_b32 %0, %5 offset1:1\n\tds_read2st64_b32 %1, %6 offset1:1\n\t"
                  "ds_read2st64_b32 %2, %6 offset0:2 offset1:3\n\tds_read2st64_b32 %3, %6 offset0:4 offset1:5\n\t"
                  "ds_read_b64 %4, %7\n\ts_waitcnt lgkmcnt(0)"
                  : "=&v"(f), "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(ringV)
                  : "v"((unsigned)(size_t)flags2), "v"((unsigned)(size_t)block), "v"(ringAddr) : "memory");
-  } while (uni(f.x < f.y ? f.x : f.y) < step);
+  } WAIT_WHILE(uni(f.x < f.y ? f.x : f.y) < step, 10, step);
   g1 = a.x; g2 = a.y; qSoilT = b.x; gFine = b.y; gCoarse = c.x; moist = c.y;
 }
 // five values + flag.  DS writes of one wave execute in issue order, so the flag lands after the
@@ -265,26 +327,26 @@ __device__ __forceinline__ void takeFactors7(const double* block, const int* fla
                                              double& qSoilT, double& gFine, double& gCoarse, double& moist, double& mK) {
   i2v f;
   d2v a, b, c;
-  do {
+  WAIT_DO {
     asm volatile("ds_read2_b32 %0, %5 offset1:1\n\tds_read2st64_b64 %1, %6 offset1:1\n\t"
                  "ds_read2st64_b64 %2, %6 offset0:2 offset1:3\n\tds_read2st64_b64 %3, %6 offset0:4 offset1:5\n\t"
                  "ds_read_b64 %4, %6 offset:3072\n\ts_waitcnt lgkmcnt(0)"
                  : "=&v"(f), "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(mK)
                  : "v"((unsigned)(size_t)flags2), "v"((unsigned)(size_t)block) : "memory");
-  } while (uni(f.x < f.y ? f.x : f.y) < step);
+  } WAIT_WHILE(uni(f.x < f.y ? f.x : f.y) < step, 11, step);
   g1 = a.x; g2 = a.y; qSoilT = b.x; gFine = b.y; gCoarse = c.x; moist = c.y;
 }
 __device__ __forceinline__ void takeFactors7(const float* block, const int* flags2, int step, float& g1, float& g2,
                                              float& qSoilT, float& gFine, float& gCoarse, float& moist, float& mK) {
   i2v f;
   f2v a, b, c;
-  do {
+  WAIT_DO {
     asm volatile("ds_read2_b32 %0, %5 offset1:1\n\tds_read2st64_b32 %1, %6 offset1:1\n\t"
                  "ds_read2st64_b32 %2, %6 offset0:2 offset1:3\n\tds_read2st64_b32 %3, %6 offset0:4 offset1:5\n\t"
                  "ds_read_b32 %4, %6 offset:1536\n\ts_waitcnt lgkmcnt(0)"
                  : "=&v"(f), "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(mK)
                  : "v"((unsigned)(size_t)flags2), "v"((unsigned)(size_t)block) : "memory");
-  } while (uni(f.x < f.y ? f.x : f.y) < step);
+  } WAIT_WHILE(uni(f.x < f.y ? f.x : f.y) < step, 12, step);
   g1 = a.x; g2 = a.y; qSoilT = b.x; gFine = b.y; gCoarse = c.x; moist = c.y;
 }
 __device__ __forceinline__ void takeFactorsRing7(const double* block, const int* flags2, unsigned ringAddr, int step,
@@ -292,13 +354,13 @@ __device__ __forceinline__ void takeFactorsRing7(const double* block, const int*
                                                  double& moist, double& mK, double& ringV) {
   i2v f;
   d2v a, b, c;
-  do {
+  WAIT_DO {
     asm volatile("ds_read2_b32 %0, %6 offset1:1\n\tds_read2st64_b64 %1, %7 offset1:1\n\t"
                  "ds_read2st64_b64 %2, %7 offset0:2 offset1:3\n\tds_read2st64_b64 %3, %7 offset0:4 offset1:5\n\t"
                  "ds_read_b64 %4, %7 offset:3072\n\tds_read_b64 %5, %8\n\ts_waitcnt lgkmcnt(0)"
                  : "=&v"(f), "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(mK), "=&v"(ringV)
                  : "v"((unsigned)(size_t)flags2), "v"((unsigned)(size_t)block), "v"(ringAddr) : "memory");
-  } while (uni(f.x < f.y ? f.x : f.y) < step);
+  } WAIT_WHILE(uni(f.x < f.y ? f.x : f.y) < step, 13, step);
   g1 = a.x; g2 = a.y; qSoilT = b.x; gFine = b.y; gCoarse = c.x; moist = c.y;
 }
 __device__ __forceinline__ void takeFactorsRing7(const float* block, const int* flags2, unsigned ringAddr, int step,
@@ -306,13 +368,13 @@ __device__ __forceinline__ void takeFactorsRing7(const float* block, const int* 
                                                  float& moist, float& mK, double& ringV) {
   i2v f;
   f2v a, b, c;
-  do {
+  WAIT_DO {
     asm volatile("ds_read2_b32 %0, %6 offset1:1\n\tds_read2st64_b32 %1, %7 offset1:1\n\t"
                  "ds_read2st64_b32 %2, %7 offset0:2 offset1:3\n\tds_read2st64_b32 %3, %7 offset0:4 offset1:5\n\t"
                  "ds_read_b32 %4, %7 offset:1536\n\tds_read_b64 %5, %8\n\ts_waitcnt lgkmcnt(0)"
                  : "=&v"(f), "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(mK), "=&v"(ringV)
                  : "v"((unsigned)(size_t)flags2), "v"((unsigned)(size_t)block), "v"(ringAddr) : "memory");
-  } while (uni(f.x < f.y ? f.x : f.y) < step);
+  } WAIT_WHILE(uni(f.x < f.y ? f.x : f.y) < step, 14, step);
   g1 = a.x; g2 = a.y; qSoilT = b.x; gFine = b.y; gCoarse = c.x; moist = c.y;
 }
 // Blocks of doubles (rows 64 apart) + a sequence flag, for the hand-overs of the nitrogen-cycle layout:
@@ -327,19 +389,19 @@ __device__ __forceinline__ void postRaw(float* p, float v) {
 // two rows of an R-typed block behind one flag (wave W: the tillage-scaled and the plain soil Q10 factor)
 __device__ __forceinline__ void takeR2(const double* a, const double* b, const int* flag, int step, double& va, double& vb) {
   int f;
-  do {
+  WAIT_DO {
     asm volatile("ds_read_b32 %0, %3\n\tds_read_b64 %1, %4\n\tds_read_b64 %2, %5\n\ts_waitcnt lgkmcnt(0)"
                  : "=&v"(f), "=&v"(va), "=&v"(vb)
                  : "v"((unsigned)(size_t)flag), "v"((unsigned)(size_t)a), "v"((unsigned)(size_t)b) : "memory");
-  } while (uni(f) < step);
+  } WAIT_WHILE(uni(f) < step, 15, step);
 }
 __device__ __forceinline__ void takeR2(const float* a, const float* b, const int* flag, int step, float& va, float& vb) {
   int f;
-  do {
+  WAIT_DO {
     asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %4\n\tds_read_b32 %2, %5\n\ts_waitcnt lgkmcnt(0)"
                  : "=&v"(f), "=&v"(va), "=&v"(vb)
                  : "v"((unsigned)(size_t)flag), "v"((unsigned)(size_t)a), "v"((unsigned)(size_t)b) : "memory");
-  } while (uni(f) < step);
+  } WAIT_WHILE(uni(f) < step, 16, step);
 }
 __device__ __forceinline__ void postD(double* row0, int k, double v) {
   asm volatile("ds_write_b64 %0, %1" :: "v"((unsigned)(size_t)(row0 + 64 * k)), "v"(v) : "memory");
@@ -349,52 +411,52 @@ __device__ __forceinline__ void postFlag(int* flag, int step) {
 }
 __device__ __forceinline__ void takeD1(const double* b, const int* flag, int step, double& v0) {
   int f;
-  do {
+  WAIT_DO {
     asm volatile("ds_read_b32 %0, %2\n\tds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)"
                  : "=&v"(f), "=&v"(v0) : "v"((unsigned)(size_t)flag), "v"((unsigned)(size_t)b) : "memory");
-  } while (uni(f) < step);
+  } WAIT_WHILE(uni(f) < step, 17, step);
 }
 __device__ __forceinline__ void takeD3(const double* b, const int* flag, int step, double& v0, double& v1, double& v2) {
   int f;
-  do {
+  WAIT_DO {
     asm volatile("ds_read_b32 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %5 offset:512\n\t"
                  "ds_read_b64 %3, %5 offset:1024\n\ts_waitcnt lgkmcnt(0)"
                  : "=&v"(f), "=&v"(v0), "=&v"(v1), "=&v"(v2)
                  : "v"((unsigned)(size_t)flag), "v"((unsigned)(size_t)b) : "memory");
-  } while (uni(f) < step);
+  } WAIT_WHILE(uni(f) < step, 18, step);
 }
 __device__ __forceinline__ void takeD4(const double* b, const int* flag, int step, double& v0, double& v1, double& v2,
                                        double& v3) {
   int f;
-  do {
+  WAIT_DO {
     asm volatile("ds_read_b32 %0, %5\n\tds_read_b64 %1, %6\n\tds_read_b64 %2, %6 offset:512\n\t"
                  "ds_read_b64 %3, %6 offset:1024\n\tds_read_b64 %4, %6 offset:1536\n\ts_waitcnt lgkmcnt(0)"
                  : "=&v"(f), "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
                  : "v"((unsigned)(size_t)flag), "v"((unsigned)(size_t)b) : "memory");
-  } while (uni(f) < step);
+  } WAIT_WHILE(uni(f) < step, 19, step);
 }
 __device__ __forceinline__ void takeD6(const double* b, const int* flag, int step, double& v0, double& v1, double& v2,
                                        double& v3, double& v4, double& v5) {
   int f;
-  do {
+  WAIT_DO {
     asm volatile("ds_read_b32 %0, %7\n\tds_read_b64 %1, %8\n\tds_read_b64 %2, %8 offset:512\n\t"
                  "ds_read_b64 %3, %8 offset:1024\n\tds_read_b64 %4, %8 offset:1536\n\t"
                  "ds_read_b64 %5, %8 offset:2048\n\tds_read_b64 %6, %8 offset:2560\n\ts_waitcnt lgkmcnt(0)"
                  : "=&v"(f), "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(v4), "=&v"(v5)
                  : "v"((unsigned)(size_t)flag), "v"((unsigned)(size_t)b) : "memory");
-  } while (uni(f) < step);
+  } WAIT_WHILE(uni(f) < step, 20, step);
 }
 __device__ __forceinline__ void takeD8(const double* b, const int* flag, int step, double& v0, double& v1, double& v2,
                                        double& v3, double& v4, double& v5, double& v6, double& v7) {
   int f;
-  do {
+  WAIT_DO {
     asm volatile("ds_read_b32 %0, %9\n\tds_read_b64 %1, %10\n\tds_read_b64 %2, %10 offset:512\n\t"
                  "ds_read_b64 %3, %10 offset:1024\n\tds_read_b64 %4, %10 offset:1536\n\t"
                  "ds_read_b64 %5, %10 offset:2048\n\tds_read_b64 %6, %10 offset:2560\n\t"
                  "ds_read_b64 %7, %10 offset:3072\n\tds_read_b64 %8, %10 offset:3584\n\ts_waitcnt lgkmcnt(0)"
                  : "=&v"(f), "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(v4), "=&v"(v5), "=&v"(v6), "=&v"(v7)
                  : "v"((unsigned)(size_t)flag), "v"((unsigned)(size_t)b) : "memory");
-  } while (uni(f) < step);
+  } WAIT_WHILE(uni(f) < step, 21, step);
 }
 // The "mineral nitrogen is plentiful" test both wave C and wave W evaluate for a step (they must
 // come to the SAME wave-uniform answer, so it is one function, compiled without contraction): a lower
@@ -414,9 +476,9 @@ __device__ __forceinline__ bool nPlentiful(double minN, double qSoil, double len
 // progress-only wait (no value)
 __device__ __forceinline__ void awaitAtLeast(const int* flag, int step) {
   int f;
-  do {
+  WAIT_DO {
     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(f) : "v"((unsigned)(size_t)flag) : "memory");
-  } while (uni(f) < step);
+  } WAIT_WHILE(uni(f) < step, 22, step);
 }
 
 // pool += x * len, the forward-Euler update (sipnet.c:1579-1680): one fma in fp64; in fp32-mixed the
@@ -730,6 +792,9 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
     mailAlive[0][lane] = 0;
     mailAlive[1][lane] = 0;
   }
+#ifdef SIPNET_COOP_BOUNDED
+  if (threadIdx.x == 0) g_coopPoison = 0;
+#endif
   __syncthreads();  // the only workgroup barrier: flags initialised before anyone spins
   if (!present) return;
 
@@ -1122,7 +1187,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         {
           WAIT_BEGIN()
           int fSeq, wSeq;
-          do {
+          WAIT_DO {
             // (one statement: the compiler may put instructions of its own between two, and does)
 #define SIPNET_S_TAKE(RD_R, OFF_R)                                                                                   \
   asm volatile("ds_read_b32 %0, %17\n\t" RD_R " %1, %18\n\t" RD_R " %2, %18 offset:" OFF_R "\n\t"                   \
@@ -1145,7 +1210,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
             else
               SIPNET_S_TAKE("ds_read_b32", "1024");
 #undef SIPNET_S_TAKE
-          } while (uni(fSeq) < t || uni(wSeq) < t);
+          } WAIT_WHILE(uni(fSeq) < t || uni(wSeq) < t, 23, t);
           WAIT_END(0)
         }
         const R moistEff = (R)wMoist, anoxic = (R)wAnoxic;
@@ -1266,11 +1331,11 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         // biomass adds to these pools (sipnet.c:1688-1767); then ensureNonNegativeStocks() for them
         int w;
         double pend;   // GPP - R_a of this step (C posts it right before the verdict word)
-        do {
+        WAIT_DO {
           asm volatile("ds_read_b32 %0, %2\n\tds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)"
                        : "=&v"(w), "=&v"(pend)
                        : "v"(ldsAddr(&mailAlive[(t + 1) & 1][lane])), "v"(ldsAddr(&mailPend[t & 1][0][lane])) : "memory");
-        } while (uni(w < 0 ? -w : w) < t + 3);
+        } WAIT_WHILE(uni(w < 0 ? -w : w) < t + 3, 24, t);
         double pendRa = 0.0, pendRRoot = 0.0;   // Full: R_a and the root respiration of the step (posted with GPP - R_a)
         int bitsS = 0;
         if (Full) {
@@ -1414,6 +1479,11 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
                      : "=&v"(bitsV), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q5), "=&v"(q6x)
                      : "v"(ldsAddr(recB)) : "memory");
         const int bits = uni(bitsV);
+#ifdef SIPNET_COOP_BOUNDED
+        // the error path's own test (SIPNET_KOPT_WAIT_SELFTEST): this wave stops posting after 100 steps, the others'
+        // waits must give up and the launch must end with the report
+        if ((a.options & SIPNET_KOPT_WAIT_SELFTEST) && t == tBegin + 100) return;
+#endif
         if (!Staged && statsHere && t == statNext) statAct(false);
         // ---- for wave C: the climate / parameter part of its respiration terms of THIS step
         // (vegResp sipnet.c:1051-1068, calcRootResp :1073, calcSoilRespiration :1132-1148 with
@@ -2168,7 +2238,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
       WAIT_BEGIN()
       const unsigned fac = ldsAddr(&mailFac[t & 1][0][lane]);
       const unsigned mst = ldsAddr(&mailFac[t & 1][5][lane]);
-      do {
+      WAIT_DO {
         if (sizeof(R) == 8) {
           asm volatile("ds_read_b128 %0, %13\n\tds_read_b128 %1, %13 offset:96\n\tds_read_b128 %2, %13 offset:112\n\t"
                        "ds_read_b128 %3, %13 offset:128\n\tds_read_b32 %4, %14\n\t"
@@ -2190,7 +2260,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
                        : "v"(ldsAddr(recB)), "v"(ldsAddr(&seqFac)), "v"(fac), "v"(ldsAddr(&seqMoist)), "v"(mst)
                        : "memory");
         }
-      } while (uni(facSeq) < t || uni(moistSeq) < t);
+      } WAIT_WHILE(uni(facSeq) < t || uni(moistSeq) < t, 25, t);
       WAIT_END(0)
     } else if (NCyc) {
       // record fields, wave F's factors (rows 0 1 3 4 and the plain soil Q10 factor, row 6 -- carried in
@@ -2198,7 +2268,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
       WAIT_BEGIN()
       const unsigned fac = ldsAddr(&mailFac[t & 1][0][lane]);
       const unsigned mnn = ldsAddr(&mailMinN[t & 1][lane]);
-      do {
+      WAIT_DO {
         if (sizeof(R) == 8) {
           asm volatile("ds_read_b128 %0, %12\n\tds_read_b128 %1, %12 offset:96\n\tds_read_b128 %2, %12 offset:112\n\t"
                        "ds_read_b128 %3, %12 offset:128\n\tds_read_b32 %4, %13\n\t"
@@ -2220,7 +2290,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
                        : "v"(ldsAddr(recB)), "v"(ldsAddr(&seqFac)), "v"(fac), "v"(ldsAddr(&seqMinN)), "v"(mnn)
                        : "memory");
         }
-      } while (uni(facSeq) < t);   // (`moistSeq`: the mineral nitrogen's flag, looked at in plantSideN)
+      } WAIT_WHILE(uni(facSeq) < t, 26, t);   // (`moistSeq`: the mineral nitrogen's flag, looked at in plantSideN)
       qSoilT = 0;
       WAIT_END(0)
     } else {
@@ -2229,7 +2299,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
       const unsigned mst = ldsAddr(&mailFac[t & 1][5][lane]);
       // (re-reading the record while spinning is harmless; one asm statement defines every value,
       // so no copies are needed when the first look already finds the flags current)
-      do {
+      WAIT_DO {
         if (sizeof(R) == 8) {
           asm volatile("ds_read_b128 %0, %12\n\tds_read_b128 %1, %12 offset:96\n\tds_read_b128 %2, %12 offset:112\n\t"
                        "ds_read_b128 %3, %12 offset:128\n\tds_read_b32 %4, %13\n\t"
@@ -2251,7 +2321,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
                        : "v"(ldsAddr(recB)), "v"(ldsAddr(&seqFac)), "v"(fac), "v"(ldsAddr(&seqMoist)), "v"(mst)
                        : "memory");
         }
-      } while (uni(facSeq) < t || uni(moistSeq) < t);
+      } WAIT_WHILE(uni(facSeq) < t || uni(moistSeq) < t, 27, t);
       WAIT_END(0)
     }
     const R fSoil = qSoilT * moistEff;
@@ -2864,7 +2934,20 @@ extern "C" int sipnet_debug_read_coop_stamps(unsigned long long* out) {
 }
 #endif
 
+#ifdef SIPNET_COOP_BOUNDED
+// what the first wait that gave up reported (0 0: none), after synchronising the stream
+int readCoopStuck(unsigned long long out[2], hipStream_t stream) {
+  if (hipStreamSynchronize(stream) != hipSuccess) return 1;
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_coopStuck), 2 * sizeof(unsigned long long));
+}
+#endif
 void launchStepCoop(const FastArgs& a, int precision, int layout, hipStream_t stream, LaunchInfo* info) {
+#ifdef SIPNET_COOP_BOUNDED
+  {
+    static const unsigned long long zero[2] = {0ull, 0ull};
+    (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_coopStuck), zero, sizeof zero, 0, hipMemcpyHostToDevice, stream);
+  }
+#endif
   const int chunksPerSite = (a.n_members + 63) / 64;
   const bool ringInLds = layout == COOP_RING_LDS, pair = layout == COOP_PAIR, quad = layout == COOP_QUAD;
   // flags beyond the compiled-in set of the layout's family: the optional-physics instantiations (run-time flags)
@@ -2885,8 +2968,10 @@ void launchStepCoop(const FastArgs& a, int precision, int layout, hipStream_t st
     }
     if (ext) {
       if (pairN) { NCYC_LAUNCH(stepCoopNXPairKernel) } else { NCYC_LAUNCH(stepCoopNXKernel) }
+#ifndef SIPNET_COOP_BOUNDED
     } else if (a.full) {
       if (pairN) { NCYC_LAUNCH(stepCoopNPairFullKernel) } else { NCYC_LAUNCH(stepCoopNFullKernel) }
+#endif
     } else {
       if (pairN) { NCYC_LAUNCH(stepCoopNPairKernel) } else { NCYC_LAUNCH(stepCoopNKernel) }
     }
@@ -2910,6 +2995,10 @@ void launchStepCoop(const FastArgs& a, int precision, int layout, hipStream_t st
   const int pairGroups = (a.n_sites & 7) == 0 ? 8 * ((chunks / 8 + 1) / 2) : (chunks + 1) / 2;
   const int quadGroups = (a.n_sites & 7) == 0 ? 8 * ((chunks / 8 + 3) / 4) : (chunks + 3) / 4;
   const dim3 grid(pair ? pairGroups : quad ? quadGroups : chunks), block(pair ? 512 : quad ? 768 : (ringInLds && kFacWaveBuilt) ? 256 : 192);
+#ifdef SIPNET_COOP_BOUNDED   // (lean instantiations only: the engine does not send full-state launches here)
+#define COOP_LAUNCH(R, P, L) { hipLaunchKernelGGL((stepCoopKernel<R, P, L, false>), grid, block, 0, stream, a); }
+#define PAIR_LAUNCH(R, P) { hipLaunchKernelGGL((stepCoopPairKernel<R, P, false>), grid, block, 0, stream, a); }
+#else
 #define COOP_LAUNCH(R, P, L)                                                                        \
   {                                                                                                 \
     if (a.full) hipLaunchKernelGGL((stepCoopKernel<R, P, L, true>), grid, block, 0, stream, a);      \
@@ -2920,6 +3009,7 @@ void launchStepCoop(const FastArgs& a, int precision, int layout, hipStream_t st
     if (a.full) hipLaunchKernelGGL((stepCoopPairKernel<R, P, true>), grid, block, 0, stream, a);     \
     else hipLaunchKernelGGL((stepCoopPairKernel<R, P, false>), grid, block, 0, stream, a);          \
   }
+#endif
   if (ext) {   // (one or two chunks per workgroup, lean: the engine does not ask for anything else)
 #define X_LAUNCH2(R, P, F)                                                                                    \
   {                                                                                                           \
@@ -2927,7 +3017,11 @@ void launchStepCoop(const FastArgs& a, int precision, int layout, hipStream_t st
     else if (ringInLds) hipLaunchKernelGGL((stepCoopXKernel<R, P, true, F>), grid, block, 0, stream, a);      \
     else hipLaunchKernelGGL((stepCoopXKernel<R, P, false, F>), grid, block, 0, stream, a);                    \
   }
+#ifdef SIPNET_COOP_BOUNDED
+#define X_LAUNCH(R, P) { X_LAUNCH2(R, P, false) }
+#else
 #define X_LAUNCH(R, P) { if (a.full) X_LAUNCH2(R, P, true) else X_LAUNCH2(R, P, false) }
+#endif
     if (precision == SIPNET_F64) { if (a.plainExp) X_LAUNCH(double, true) else X_LAUNCH(double, false) }
     else { if (a.plainExp) X_LAUNCH(float, true) else X_LAUNCH(float, false) }
 #undef X_LAUNCH
@@ -2971,4 +3065,7 @@ void launchStepCoop(const FastArgs& a, int precision, int layout, hipStream_t st
   }
 }
 
+#ifdef SIPNET_COOP_BOUNDED
+}  // namespace bounded
+#endif
 }  // namespace sipnet

@@ -130,6 +130,10 @@ void launchStepFast(const FastArgs& a, int precision, int options, hipStream_t s
 // three cooperating wavefronts per 64 members (step_coop.hip); same results as launchStepFast
 enum CoopLayout { COOP_RING_LDS = 0, COOP_RING_HBM = 1, COOP_PAIR = 2, COOP_QUAD = 3, COOP_NCYCLE = 4, COOP_NCYCLE_PAIR = 5 };  // step_coop.hip
 void launchStepCoop(const FastArgs& a, int precision, int layout, hipStream_t stream, LaunchInfo* info);
+namespace bounded {   // step_coop_bounded.hip: the same with bounded hand-over waits (SIPNET_KOPT_BOUNDED_WAITS)
+void launchStepCoop(const FastArgs& a, int precision, int layout, hipStream_t stream, LaunchInfo* info);
+int readCoopStuck(unsigned long long out[2], hipStream_t stream);
+}
 // the flag sets the throughput kernels have compiled in; events, gdd and soil_phenol may take any (legal) value
 // in both -- they only change what the plan puts into the records (step_kernel.hip)
 bool isPhenologyOrEventsFlag(int flag);

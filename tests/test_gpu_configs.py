@@ -500,3 +500,46 @@ def test_run_stats_at_the_baseline_shapes_equals_the_sums_over_the_planes(worklo
     print(workload, li["kernel"], "stats vs planes: %.2e %.2e" % (d1, d2))
     assert d1 < 1e-12 and d2 < 1e-12, li
     assert same, li
+
+
+# ---- the cooperative kernels' build with bounded hand-over waits (SIPNET_KOPT_BOUNDED_WAITS) -------------------------
+BOUNDED = [("coop_lds", sa.KERNEL_COOP_LDS, {}), ("coop_hbm", sa.KERNEL_COOP_HBM, {}), ("coop_pair", sa.KERNEL_COOP_PAIR, {}),
+           ("coop_quad", sa.KERNEL_COOP_QUAD, {}), ("ncycle", sa.KERNEL_COOP_NCYCLE, NCYCLE_FLAGS),
+           ("ncycle_pair", sa.KERNEL_COOP_NCYCLE_PAIR, NCYCLE_FLAGS), ("x_lds", sa.KERNEL_COOP_LDS, X_FLAGS["russell3"]),
+           ("nx_pair", sa.KERNEL_COOP_NCYCLE_PAIR, X_FLAGS["everything"])]
+
+
+@pytest.mark.parametrize("name,kernel,kw", BOUNDED, ids=[k[0] for k in BOUNDED])
+def test_bounded_wait_build_gives_the_products_bits_and_reports_a_wait_that_never_ends(name, kernel, kw, base):
+    """step_coop_bounded.hip = step_coop.hip compiled with a budget of polls on every hand-over wait: the same planes,
+    state and rings as the product's kernels, bit for bit; and with SIPNET_KOPT_WAIT_SELFTEST (the light wave stops
+    posting after 100 steps) the launch ENDS -- sipnet_batch_run answers SIPNET_ERR_INTERNAL naming a wait and a step
+    instead of hanging the device"""
+    flags = sa.flags_from(**kw)
+    if kw:
+        base = sa.read_params(os.path.join(os.path.dirname(BASE), "allflags_forest.param"), flags)[0]
+    clim, ev, members = _scenario(base, lethal=True)
+    outs = []
+    for opt in (0, sa.KOPT_BOUNDED_WAITS):
+        b = build(flags, [clim], members, sa.F64, kernel, opt, events=ev)
+        planes, _ = b.alloc_outputs(clim.n_steps)
+        for a, z in ((0, 7), (7, 1000), (1000, clim.n_steps)):
+            b.run(a, z - a, planes=planes[:, a:z])
+        outs.append((planes.cpu().numpy(), b.get_state(), b.get_rings(), b.last_launch()["kernel"]))
+        b.close()
+    assert outs[0][3] == outs[1][3]                       # the same instantiation, from the other translation unit
+    for k in range(3):
+        np.testing.assert_array_equal(outs[0][k], outs[1][k])
+    b = build(flags, [clim], members, sa.F64, kernel, sa.KOPT_BOUNDED_WAITS | sa.KOPT_WAIT_SELFTEST, events=ev)
+    import time
+    t0 = time.time()
+    with pytest.raises(sa.SipnetError) as e:
+        b.run(0, 1000)
+    assert e.value.code == 7 and "hand-over wait" in str(e.value) and "gave up at step" in str(e.value), str(e.value)
+    assert time.time() - t0 < 60
+    b.close()
+    # the device is fine afterwards
+    b = build(flags, [clim], members, sa.F64, kernel, 0, events=ev)
+    got = b.run(0, 1000)[0].cpu().numpy()
+    b.close()
+    np.testing.assert_array_equal(got, outs[0][0][:, :1000])

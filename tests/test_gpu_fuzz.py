@@ -64,7 +64,7 @@ def test_fuzz_cooperative_layouts_with_fragile_members():
     """a fixed-seed slice of the cooperative-only campaign (FUZZ_COOP=1: default flags, throughput
     arithmetic, the one-, two- and four-chunk layouts and the default policy in turn, a few stands so
     small that single harvests finish them off in the middle of a run)"""
-    env = dict(os.environ, FUZZ_COOP="1")
+    env = dict(os.environ, FUZZ_COOP="1", FUZZ_BOUNDED="1")     # (the build with bounded waits: a hang would be a report)
     r = subprocess.run([sys.executable, os.path.join(helpers.REPO, "tools", "fuzz_gpu.py"), "40", "7"],
                        capture_output=True, text=True, timeout=900, env=env)
     print(r.stdout[-3000:])
@@ -79,7 +79,7 @@ def test_fuzz_nitrogen_cycle_cooperative_kernel():
     launch cuts).  Trial 127 of seed 777 is in the slice: the run on which the soil wave once read the
     light wave's factor rows of step t + 2 for step t (the slot's re-use was guarded by the carbon wave's
     progress only) -- a timing-dependent 2e-5 on NEE that the fixed tests never showed."""
-    env = dict(os.environ, FUZZ_NCYC="1")
+    env = dict(os.environ, FUZZ_NCYC="1", FUZZ_BOUNDED="1")
     r = subprocess.run([sys.executable, os.path.join(helpers.REPO, "tools", "fuzz_gpu.py"), "140", "777"],
                        capture_output=True, text=True, timeout=1200, env=env)
     print(r.stdout[-3000:])
@@ -92,7 +92,7 @@ def test_fuzz_optional_physics_cooperative_kernels():
     litter pool, carbon saturation, anaerobic -- alone or on top of the nitrogen cycle; the cooperative layouts'
     run-time-flag instantiations forced in turn or picked by the shape policy, regular tiles on and off, fragile
     stands, random events and launch cuts)"""
-    env = dict(os.environ, FUZZ_OPT="1")
+    env = dict(os.environ, FUZZ_OPT="1", FUZZ_BOUNDED="1")
     r = subprocess.run([sys.executable, os.path.join(helpers.REPO, "tools", "fuzz_gpu.py"), "60", "41"],
                        capture_output=True, text=True, timeout=1200, env=env)
     print(r.stdout[-3000:])

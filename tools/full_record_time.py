@@ -1,14 +1,20 @@
 #!/usr/bin/env python3
 """dev (GPU box): c10k kernel time with the 44-column record -- strict kernel (round-1 path of the
-ensemble CLI) vs the Full instantiations of the throughput kernels."""
+ensemble CLI) vs the Full instantiations of the throughput kernels.
+usage: full_record_time.py [members] [default|russell_2|russell_3]   (the flag set; russell_2 = litter pool + anaerobic
++ nitrogen cycle, russell_3 = growth respiration + leaf water + litter pool, no moisture effect)"""
 import os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import torch
 import sipnet_amd as sa
 from sipnet_amd import synth
-flags = sa.flags_from()
-base, _ = sa.read_params(os.path.join(REPO, "sipnet_amd", "data", "base_forest.param"), flags)
+SETS = {"default": ({}, "base_forest.param"), "russell_2": (dict(litterPool=1, anaerobic=1, nitrogenCycle=1), "allflags_forest.param"),
+        "russell_3": (dict(growthResp=1, leafWater=1, litterPool=1, waterHResp=0), "allflags_forest.param")}
+which = sys.argv[2] if len(sys.argv) > 2 else "default"
+flags = sa.flags_from(**SETS[which][0])
+base, _ = sa.read_params(os.path.join(REPO, "sipnet_amd", "data", SETS[which][1]), flags)
+print("flag set:", which)
 M, T = int(sys.argv[1]) if len(sys.argv) > 1 else 10240, 17520
 clim = synth.convert_raw(synth.round_like_file(synth.half_hourly_year_raw(T)))
 members = synth.perturbed_params(base, M)

@@ -162,6 +162,7 @@ for trial in range(trials):
         else:
             kern, forced = [(sa.KERNEL_AUTO, ""), (sa.KERNEL_COOP_LDS, " coop-lds"), (sa.KERNEL_COOP_HBM, " coop-hbm"),
                             (sa.KERNEL_COOP_PAIR, " coop-pair")][int(rng.integers(0, 4))]
+    if os.environ.get("FUZZ_BOUNDED"): kopt |= sa.KOPT_BOUNDED_WAITS      # the cooperative kernels' build with bounded waits: a protocol bug ends the launch with a report instead of hanging the GPU
     if os.environ.get("FUZZ_KOPT"): kopt = int(os.environ["FUZZ_KOPT"])
     if os.environ.get("FUZZ_KERNEL"):     # rerun a trial on another kernel (with the trial index as third argument)
         kern = getattr(sa, "KERNEL_" + os.environ["FUZZ_KERNEL"].upper()); forced = " forced-" + os.environ["FUZZ_KERNEL"]
