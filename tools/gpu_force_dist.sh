@@ -7,9 +7,9 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 : > gpurun_out/force_dist.jsonl
 for wl in ${@:-c10k c4 c3 c5 c2x16}; do
-  steps=10; [ "$wl" = c5 ] && steps=50
+  steps=10; warm=2; [ "$wl" = c5 ] && steps=400 && warm=40   # (c5: a 0.2 ms cycle -- RCCL's first-collective costs need a real warm-up)
   timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 \
-      --master-port 29517 bench.py --gpus 1 --force-dist --workload $wl --steps $steps --warmup 2 \
+      --master-port 29517 bench.py --gpus 1 --force-dist --workload $wl --steps $steps --warmup $warm \
       --no-cpu-baseline --no-fill-probe > gpurun_out/force_dist_$wl.log 2>&1
   echo "rc=$? $wl"
   grep '^{' gpurun_out/force_dist_$wl.log | tail -1 >> gpurun_out/force_dist.jsonl
