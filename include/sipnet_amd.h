@@ -185,7 +185,9 @@ void sipnet_batch_destroy(sipnet_batch *b);
 /* Forcing of one site: clim[n_steps][SIPNET_NCLIM] already converted exactly
  * as readClimData does (sipnet.c:201-238):
  *   length(d) tair tsoil par(/d) precip(cm) vpd(kPa) vpdSoil vPress wspd gdd time(h)
- * All sites of a batch must have the same n_steps.  Builds the site plan
+ * Sites of a batch may differ in n_steps: a launch advances every site to the end of ITS records (sipnet_batch_nsteps
+ * = the longest site's; plane / record rows past a site's last record are left untouched, its statistics there are
+ * zero with sipnet_batch_run_stats on a cooperative kernel, undefined otherwise).  Builds the site plan
  * (member-independent schedule: running-mean ring weights, GDD sums, year
  * roll-overs, event matching, tillage decay) on the host and uploads it. */
 int sipnet_batch_set_climate(sipnet_batch *b, int32_t site, int32_t n_steps,

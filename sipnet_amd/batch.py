@@ -94,7 +94,7 @@ class Batch:
         check(self.L.sipnet_batch_set_climate(self.h, site, clim.n_steps, clim.data.ctypes.data,
                                               clim.year.ctypes.data, clim.day.ctypes.data),
               "set_climate")
-        self.n_steps = clim.n_steps
+        self.n_steps = int(self.L.sipnet_batch_nsteps(self.h))     # the longest site's (sites may differ in length)
 
     def set_events(self, site, events):
         n = len(events)

@@ -33,7 +33,8 @@ struct sipnet_batch {
   int32_t n_sites = 0, n_members = 0, precision = 0, device = 0;
   int32_t numCUs = 256;
   int64_t ncol = 0;
-  int32_t n_steps = 0;  // steps per site (all sites equal)
+  int32_t n_steps = 0;  // records of the longest site (the stride of the per-step records; sites may be shorter: siteSteps)
+  std::vector<int32_t> siteSteps;   // per site: its number of climate records
   bool fastMath = false;
   int32_t kernelPolicy = SIPNET_KERNEL_AUTO, kernelOptions = 0;
   LaunchInfo lastLaunch{};
@@ -89,7 +90,7 @@ struct sipnet_batch {
   size_t hostFastCap = 0, hostStepsCap = 0;
   unsigned char* hostMisc = nullptr;   // pinned staging of the small per-plan arrays (ring evictions, events, site tables)
   size_t hostMiscCap = 0;
-  int32_t* d_siteBase = nullptr;  // [n_sites][2]: offset of a site's ring ops / events in the flat arrays
+  int32_t* d_siteBase = nullptr;  // [n_sites][3]: offset of a site's ring ops / events in the flat arrays, its number of records
   bool stepRecsUploaded = false, fastRecsUploaded = false;  // per-step records: uploaded on first use
   // last boundary a checkpoint was exported at (sipnet_batch_export_restart)
   int32_t exportCacheSite = -1, exportCacheN = -1;

@@ -121,7 +121,7 @@ static int joinUploads(sipnet_batch* b, hipStream_t stream) {
 
 static int buildAndUpload(sipnet_batch* b, bool fastType, bool first, hipStream_t stream) {
   const double t0 = nowMs();
-  const int nS = b->n_sites, nT = b->n_steps;
+  const int nS = b->n_sites, nT = b->n_steps;   // nT: the longest site's records = the stride of the record arrays
   const int nThreads = planThreadsFor(nS);
   const size_t nFast = (size_t)nS * nT + kFastTile, nSteps = (size_t)nS * nT;
   TRACE_T("plan: begin");
@@ -146,7 +146,8 @@ static int buildAndUpload(sipnet_batch* b, bool fastType, bool first, hipStream_
   std::atomic<int64_t> copyUs{0};
   std::atomic<bool> failed{false};
   forEachSite(nS, nThreads, &failed, [&](int s) -> bool {
-    SitePlan p = buildSitePlan(b->flags, nT, b->clim[s].data(), b->year[s].data(), b->day[s].data(),
+    const int nTs = b->siteSteps[s];            // this site's own length (its tail of the stride is never read)
+    SitePlan p = buildSitePlan(b->flags, nTs, b->clim[s].data(), b->year[s].data(), b->day[s].data(),
                                (int32_t)b->events[s].size(), b->events[s].data(),
                                b->resume[s].set ? &b->resume[s] : nullptr, nullptr, /*wantSteps=*/false,
                                fastType ? nullptr : steps + (size_t)s * nT,
@@ -196,14 +197,18 @@ static int buildAndUpload(sipnet_batch* b, bool fastType, bool first, hipStream_
 }
 
 static int uploadPlan(sipnet_batch* b, hipStream_t stream) {
-  // every site needs forcing of equal length
-  for (int s = 0; s < b->n_sites; s++) {
-    if ((int)b->year[s].size() != b->n_steps || b->n_steps == 0) {
-      setError("sipnet_batch: climate not set for every site (or unequal lengths)");
+  // every site needs a forcing; they may differ in length (a launch advances each site to the end of ITS records)
+  const int nS = b->n_sites;
+  b->siteSteps.assign(nS, 0);
+  b->n_steps = 0;
+  for (int s = 0; s < nS; s++) {
+    if (b->year[s].empty()) {
+      setError("sipnet_batch: climate not set for every site");
       return SIPNET_ERR_BAD_ARGUMENT;
     }
+    b->siteSteps[s] = (int32_t)b->year[s].size();
+    if (b->siteSteps[s] > b->n_steps) b->n_steps = b->siteSteps[s];
   }
-  const int nS = b->n_sites;
   b->plans.clear();
   b->plans.resize(nS);
   b->stepRecsUploaded = false;
@@ -215,14 +220,15 @@ static int uploadPlan(sipnet_batch* b, hipStream_t stream) {
   const double t0 = nowMs();
   // ring evictions and events of all sites in one array each; the records index them site-locally
   // and the kernels add the site's base
-  std::vector<int32_t> bases((size_t)2 * nS);
+  std::vector<int32_t> bases((size_t)3 * nS);   // per site: ring-op base, event base, number of records
   std::vector<SiteStart> starts(nS);
   size_t nOps = 0, nEv = 0;
   for (int s = 0; s < nS; s++) {
     const SitePlan& p = b->plans[s];
     b->siteStatus[s] = p.status;
-    bases[2 * s] = (int32_t)nOps;
-    bases[2 * s + 1] = (int32_t)nEv;
+    bases[3 * s] = (int32_t)nOps;
+    bases[3 * s + 1] = (int32_t)nEv;
+    bases[3 * s + 2] = b->siteSteps[s];
     nOps += p.ringOps.size();
     nEv += p.events.size();
     starts[s] = SiteStart{p.startCumGdd, p.startTsoil, p.startDayTime};
@@ -254,8 +260,8 @@ static int uploadPlan(sipnet_batch* b, hipStream_t stream) {
   EvRec* hEv = (EvRec*)(b->hostMisc + offEv);
   for (int s = 0; s < nS; s++) {
     const SitePlan& p = b->plans[s];
-    if (!p.ringOps.empty()) memcpy(hOps + bases[2 * s], p.ringOps.data(), p.ringOps.size() * sizeof(RingOp));
-    if (!p.events.empty()) memcpy(hEv + bases[2 * s + 1], p.events.data(), p.events.size() * sizeof(EvRec));
+    if (!p.ringOps.empty()) memcpy(hOps + bases[3 * s], p.ringOps.data(), p.ringOps.size() * sizeof(RingOp));
+    if (!p.events.empty()) memcpy(hEv + bases[3 * s + 1], p.events.data(), p.events.size() * sizeof(EvRec));
   }
   if (nOps == 0) hOps[0] = RingOp{0.0, 0, -1};
   if (nEv == 0) hEv[0] = EvRec{0, 0, {0, 0, 0, 0}};
@@ -421,7 +427,7 @@ int sipnet_batch_create(const int32_t* flags, int32_t n_sites, int32_t n_members
   if (e == hipSuccess) e = hipMalloc(&b->d_ring, nc * SIPNET_RING_SLOTS * ringElemBytes(b));
   if (e == hipSuccess) e = hipMalloc(&b->d_siteStatus, n_sites * sizeof(int32_t));
   if (e == hipSuccess) e = hipMalloc(&b->d_siteStart, n_sites * sizeof(SiteStart));
-  if (e == hipSuccess) e = hipMalloc(&b->d_siteBase, (size_t)2 * n_sites * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMalloc(&b->d_siteBase, (size_t)3 * n_sites * sizeof(int32_t));
   if (e == hipSuccess) e = hipMalloc(&b->d_scratchRow, nc * sizeof(double));
   if (e == hipSuccess) e = hipMemset(b->d_prm, 0, nc * SIPNET_NPARAMS * sizeof(double));
   if (e == hipSuccess) e = hipMemset(b->d_state, 0, nc * SIPNET_NSTATE * sizeof(double));
@@ -480,19 +486,11 @@ int sipnet_batch_set_climate(sipnet_batch* b, int32_t site, int32_t n_steps,
     setError("sipnet_batch_set_climate: bad argument");
     return SIPNET_ERR_BAD_ARGUMENT;
   }
-  if (b->n_steps != 0 && b->n_steps != n_steps) {
-    bool othersSet = false;
-    for (int s = 0; s < b->n_sites; s++)
-      if (s != site && !b->year[s].empty()) othersSet = true;
-    if (othersSet) {
-      setError("sipnet_batch_set_climate: all sites must have the same number of steps");
-      return SIPNET_ERR_BAD_ARGUMENT;
-    }
-  }
-  b->n_steps = n_steps;
   b->clim[site].assign(clim, clim + (size_t)n_steps * SIPNET_NCLIM);
   b->year[site].assign(year, year + n_steps);
   b->day[site].assign(day, day + n_steps);
+  b->n_steps = 0;   // the longest site set so far (sites may differ in length; the plan is rebuilt anyway)
+  for (int s = 0; s < b->n_sites; s++) b->n_steps = std::max<int32_t>(b->n_steps, (int32_t)b->year[s].size());
   b->planDirty = true;
   return SIPNET_OK;
 }
@@ -823,6 +821,10 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
       HIP_TRY(hipMalloc(&b->d_statsPart, need * sizeof(double)));
       b->statsPartCap = need;
     }
+    // sites of different lengths: the rows past a site's last record are never written -- zero sums there
+    bool ragged = false;
+    for (int s = 0; s < b->n_sites; s++) ragged = ragged || b->siteSteps[s] != b->n_steps;
+    if (ragged) HIP_TRY(hipMemsetAsync(b->d_statsPart, 0, need * sizeof(double), stream));
   }
   a.plan = b->d_plan;
   bool boundedWaits = false;
@@ -1189,11 +1191,12 @@ int sipnet_batch_export_restart(sipnet_batch* b, int32_t site, int32_t member,
     setError("sipnet_batch_export_restart: no run to take a checkpoint of");
     return SIPNET_ERR_BAD_ARGUMENT;
   }
-  if (n_steps_done <= 0 || n_steps_done > b->n_steps) {  // restart.c:933-937
+  if (n_steps_done <= 0 || n_steps_done > b->siteSteps[site]) {  // restart.c:933-937
     setError("Cannot write restart checkpoint: no timestep processed");
     return SIPNET_ERR_RESTART;
   }
-  if (b->stepsDone >= 0 && b->stepsDone != n_steps_done) {
+  // (a site shorter than the batch's longest stops at its own last record)
+  if (b->stepsDone >= 0 && std::min(b->stepsDone, b->siteSteps[site]) != n_steps_done) {
     setError("sipnet_batch_export_restart: the carried state is at record " +
              std::to_string(b->stepsDone) + ", not " + std::to_string(n_steps_done));
     return SIPNET_ERR_BAD_ARGUMENT;
@@ -1351,7 +1354,7 @@ int sipnet_batch_get_site_series(sipnet_batch* b, int32_t site, double* gdd,
       (int)b->plans.size() != b->n_sites)
     return SIPNET_ERR_BAD_ARGUMENT;
   const SitePlan& p = b->plans[site];
-  for (int t = 0; t < b->n_steps; t++) {
+  for (int t = 0; t < b->siteSteps[site]; t++) {   // (the site's own length: sipnet_batch_nsteps is the longest site's)
     if (gdd) gdd[t] = p.gddAfter[t];
     if (d_till_mod) d_till_mod[t] = p.dTill[t];
   }

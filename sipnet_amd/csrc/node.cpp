@@ -548,14 +548,19 @@ static int runShards(sipnet_node* nd, int32_t step0, int32_t n_steps, bool withS
     }
     char* p = (char*)nd->planes[k];
     const size_t one = (size_t)n_steps * nd->ld * nd->elem();
+    // (site shards may hold forcings of different lengths: a shard runs to the end of ITS longest site; the rows
+    // past it stay what they are -- zero -- in the common [n_steps] layout)
+    const int32_t have = sipnet_batch_nsteps(nd->batches[k]);
+    const int32_t nLoc = step0 + n_steps <= have ? n_steps : have - step0;
+    if (nLoc <= 0) return SIPNET_OK;
     if (!withStats)
-      return sipnet_batch_run(nd->batches[k], step0, n_steps, p, p + one, p + 2 * one, nullptr, nd->ld, nd->streams[k]);
-    if (nd->nSites[k] == nd->maxSites)
+      return sipnet_batch_run(nd->batches[k], step0, nLoc, p, p + one, p + 2 * one, nullptr, nd->ld, nd->streams[k]);
+    if (nd->nSites[k] == nd->maxSites && nLoc == n_steps)
       return sipnet_batch_run_stats(nd->batches[k], step0, n_steps, p, p + one, p + 2 * one, nd->ld, nd->stats[k],
                                     nd->streams[k]);
-    // a shard with fewer sites than the largest: its block [3][n_steps][nSites][2] is produced compactly and spread
-    // out to the common shape [3][n_steps][maxSites][2] (the entries of the sites it does not have stay zero)
-    const size_t compactDoubles = (size_t)3 * n_steps * nd->nSites[k] * 2;
+    // a shard with fewer sites than the largest, or a shorter run: its block [3][nLoc][nSites][2] is produced
+    // compactly and spread out to the common shape [3][n_steps][maxSites][2] (everything else stays zero)
+    const size_t compactDoubles = (size_t)3 * nLoc * nd->nSites[k] * 2;
     if (compactDoubles > nd->statsCompactCap[k]) {
       NODE_HIP(hipStreamSynchronize(nd->streams[k]));
       if (nd->statsCompact[k]) NODE_HIP(hipFree(nd->statsCompact[k]));
@@ -563,12 +568,15 @@ static int runShards(sipnet_node* nd, int32_t step0, int32_t n_steps, bool withS
       NODE_HIP(hipMalloc(&nd->statsCompact[k], compactDoubles * sizeof(double)));
       nd->statsCompactCap[k] = compactDoubles;
     }
-    int rc2 = sipnet_batch_run_stats(nd->batches[k], step0, n_steps, p, p + one, p + 2 * one, nd->ld, nd->statsCompact[k],
+    int rc2 = sipnet_batch_run_stats(nd->batches[k], step0, nLoc, p, p + one, p + 2 * one, nd->ld, nd->statsCompact[k],
                                      nd->streams[k]);
     if (rc2) return rc2;
-    NODE_HIP(hipMemcpy2DAsync(nd->stats[k], (size_t)nd->maxSites * 2 * sizeof(double), nd->statsCompact[k],
-                              (size_t)nd->nSites[k] * 2 * sizeof(double), (size_t)nd->nSites[k] * 2 * sizeof(double),
-                              (size_t)3 * n_steps, hipMemcpyDeviceToDevice, nd->streams[k]));
+    if (nLoc != n_steps) NODE_HIP(hipMemsetAsync(nd->stats[k], 0, statDoubles * sizeof(double), nd->streams[k]));
+    for (int v = 0; v < 3; v++)
+      NODE_HIP(hipMemcpy2DAsync(nd->stats[k] + (size_t)v * n_steps * nd->maxSites * 2, (size_t)nd->maxSites * 2 * sizeof(double),
+                                nd->statsCompact[k] + (size_t)v * nLoc * nd->nSites[k] * 2,
+                                (size_t)nd->nSites[k] * 2 * sizeof(double), (size_t)nd->nSites[k] * 2 * sizeof(double),
+                                (size_t)nLoc, hipMemcpyDeviceToDevice, nd->streams[k]));
     return SIPNET_OK;
   });
   if (rc) return rc;

@@ -90,8 +90,8 @@ struct FastRec {
   double log2vpd;    // for members whose dVpdExp is not 2
   double gddAfter, tillAfter;
   int32_t ins0, ins1;  // steps that wrote slot0 / slot1 (dead-member epochs)
-  int32_t opFirst;     // site-local RingOp index of this step's eviction list (nOps > 2); + siteBase[2 * site]
-  int32_t evFirst;     // site-local EvRec index; + siteBase[2 * site + 1]
+  int32_t opFirst;     // site-local RingOp index of this step's eviction list (nOps > 2); + siteBase[3 * site]
+  int32_t evFirst;     // site-local EvRec index; + siteBase[3 * site + 1]
   int32_t year, day;
   // ---- the 16-step tile this record belongs to (steps [16k, 16k+16) of the site) ----
   // tileBits: FAST_TILE_REGULAR when every step of the tile has the same length, the same one or

@@ -34,7 +34,7 @@
 //                            <events>.in.  Every directory is resolved exactly like a run started inside it (the
 //                            options of THIS command line take precedence over each sipnet.in, cli.c:144-229), runs
 //                            whose forcing (climate + events) is identical become members of one site, runs with the
-//                            same model flags and step count share ONE batch, and every directory gets the files its
+//                            same model flags share ONE batch (whatever their lengths), and every directory gets the files its
 //                            own run would have written (<prefix>.out, <events>.out, <prefix>.config, single-variable
 //                            outputs) -- byte for byte with --math auto / strict (the strict-order kernel), to the last
 //                            printed digit with --math fast (the throughput kernels)
@@ -372,7 +372,7 @@ int runSites(const Context& cliCtx, const std::string& listFile, const std::stri
     if (done[lead]) continue;
     std::vector<std::vector<int>> sites;   // [site][member] -> run index
     for (size_t k = lead; k < runs.size(); k++) {
-      if (done[k] || runs[k].T != runs[lead].T || memcmp(runs[k].flags, runs[lead].flags, sizeof runs[k].flags) != 0) continue;
+      if (done[k] || memcmp(runs[k].flags, runs[lead].flags, sizeof runs[k].flags) != 0) continue;   // (any length)
       done[k] = 1;
       bool placed = false;
       for (auto& st : sites)
@@ -383,12 +383,15 @@ int runSites(const Context& cliCtx, const std::string& listFile, const std::stri
         }
       if (!placed) sites.push_back({(int)k});
     }
-    const int S = (int)sites.size(), T = runs[lead].T;
-    int M = 0;
-    for (auto& st : sites) M = std::max(M, (int)st.size());
+    const int S = (int)sites.size();
+    int M = 0, T = 0;   // T: the longest forcing of the batch (its sites may be shorter)
+    for (auto& st : sites) {
+      M = std::max(M, (int)st.size());
+      T = std::max(T, runs[st[0]].T);
+    }
     nBatches++;
     logInfo("batch " + std::to_string(nBatches) + ": " + std::to_string(S) + " site(s) x up to " + std::to_string(M) +
-            " member(s), " + std::to_string(T) + " steps\n");
+            " member(s), up to " + std::to_string(T) + " steps\n");
     sipnet_batch* b = nullptr;
     check(sipnet_batch_create(runs[lead].flags, S, M, SIPNET_F64, device, &b), "creating batch");
     check(sipnet_batch_set_math(b, fastMath ? SIPNET_MATH_FAST : SIPNET_MATH_STRICT), "math policy");
@@ -396,7 +399,7 @@ int runSites(const Context& cliCtx, const std::string& listFile, const std::stri
     for (int s = 0; s < S; s++) {
       const SiteRun& r0 = runs[sites[s][0]];
       check(sipnet_batch_set_events(b, s, r0.nEvents, r0.events), "events");
-      check(sipnet_batch_set_climate(b, s, T, sipnet_clim_data(r0.clim), sipnet_clim_year(r0.clim), sipnet_clim_day(r0.clim)), "climate");
+      check(sipnet_batch_set_climate(b, s, r0.T, sipnet_clim_data(r0.clim), sipnet_clim_year(r0.clim), sipnet_clim_day(r0.clim)), "climate");
       for (int m = 0; m < M; m++) {   // (a site with fewer runs than the widest one: its first run's parameters fill the rest)
         const SiteRun& r = runs[sites[s][m < (int)sites[s].size() ? m : 0]];
         memcpy(rows.data() + (size_t)m * SIPNET_NPARAMS, r.params.data(), SIPNET_NPARAMS * sizeof(double));
@@ -429,6 +432,7 @@ int runSites(const Context& cliCtx, const std::string& listFile, const std::stri
       for (int j = next.fetch_add(1); j < (int)jobs.size(); j = next.fetch_add(1)) {
         SiteRun& r = runs[jobs[j].run];
         const int64_t c = jobs[j].col;
+        const int T = r.T;   // (this run's own length: shadows the batch's longest)
         if (status[c] != 0) {
           std::lock_guard<std::mutex> lock(logMutex);
           logError(r.dir + ": status " + std::to_string(status[c]) +

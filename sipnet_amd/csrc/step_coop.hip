@@ -751,14 +751,14 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
     }
   }
   // an odd number of chunks leaves the last workgroup's second half empty
-  const bool present = uni((int)(site < a.n_sites)) != 0 && role >= 0;
+  bool present = uni((int)(site < a.n_sites)) != 0 && role >= 0;
   if (!present) site = 0, chunk = 0;
   int m = (chunk << 6) + lane;
   const bool live = m < a.n_members;
   if (!live) m = a.n_members - 1;  // clamped lanes recompute the last member, never store state
   const int64_t col = (int64_t)site * a.n_members + m;
   // ring-eviction and event indices in the site's records are local to the site
-  const int opBase = uni(a.siteBase[2 * site]), evBase = uni(a.siteBase[2 * site + 1]);
+  const int opBase = uni(a.siteBase[3 * site]), evBase = uni(a.siteBase[3 * site + 1]);
   const int64_t nc = a.ncol;
   double* __restrict__ stp = a.state + col;
   const bool skip = stp[(int64_t)ST_status * nc] != 0.0;
@@ -768,7 +768,11 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
 #define PRM_RARE(name) ((R)pp[(int64_t)SP_##name * nc])
 #define ST(name) stp[(int64_t)ST_##name * nc]
 
-  const int tBegin = a.step0, tEnd = a.step0 + a.n_steps;
+  // (sites of a batch may differ in length: a chunk runs to the end of ITS site's records, and not at all when they
+  // ended before the launch's range)
+  const int siteSteps = uni(a.siteBase[3 * site + 2]);
+  const int tBegin = a.step0, tEnd = a.step0 + a.n_steps < siteSteps ? a.step0 + a.n_steps : siteSteps;
+  present = present && tBegin < tEnd;
   if (role == 0) {
     if (lane == 0) {
       seqLai = tBegin - 1;

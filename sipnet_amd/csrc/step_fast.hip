@@ -140,7 +140,8 @@ void stepFastKernel(FastArgs a) {
   if (!live) m = a.n_members - 1;
   const int64_t col = (int64_t)site * a.n_members + m;
   // ring-eviction and event indices in the site's records are local to the site
-  const int opBase = uni(a.siteBase[2 * site]), evBase = uni(a.siteBase[2 * site + 1]);
+  const int opBase = uni(a.siteBase[3 * site]), evBase = uni(a.siteBase[3 * site + 1]);
+  const int siteSteps = uni(a.siteBase[3 * site + 2]);   // records of THIS site (sites of a batch may differ in length)
   const int64_t nc = a.ncol;
 
   double* __restrict__ stp = a.state + col;
@@ -283,7 +284,8 @@ void stepFastKernel(FastArgs a) {
     }
   };
 
-  const int tBegin = a.step0, tEnd = a.step0 + a.n_steps;
+  const int tBegin = a.step0, tEnd = a.step0 + a.n_steps < siteSteps ? a.step0 + a.n_steps : siteSteps;
+  if (tBegin >= tEnd) return;   // this site's forcing ended before the launch's range (wave-uniform; no barrier has been met)
   const uint32_t ncu = (uint32_t)nc;  // ring element offsets fit 32 bits (250 * ncol < 2^31)
   int curTile = tBegin / kFastTile;
   stageTile(curTile, curTile & 1);

@@ -51,9 +51,9 @@ static_assert(ST_clampCount + 1 == SIPNET_NSTATE, "state vector size");
 
 struct KernelArgs {
   const StepRec* plan;    // [n_sites][n_steps_total]
-  const RingOp* ringOps;  // all sites; StepRec.ringOpFirst is site-local, siteBase[2*site] its base
-  const EvRec* events;    // all sites; StepRec.evFirst is site-local, siteBase[2*site+1] its base
-  const int32_t* siteBase;
+  const RingOp* ringOps;  // all sites; StepRec.ringOpFirst is site-local, siteBase[3*site] its base
+  const EvRec* events;    // all sites; StepRec.evFirst is site-local, siteBase[3*site+1] its base
+  const int32_t* siteBase;  // [n_sites][3]: ring-op base, event base, the site's number of records (<= n_steps_total)
   const double* prm;      // [SIPNET_NPARAMS][ncol] converted parameters
   double* state;          // [SIPNET_NSTATE][ncol]
   double* ring;           // [SIPNET_RING_SLOTS][ncol] of the kernel's real type (floats for fp32-mixed batches)
@@ -89,7 +89,7 @@ struct FastArgs {
   const FastRec* fast;    // [n_sites][n_steps_total] (+ kFastTile records of padding)
   const RingOp* ringOps;      // all sites; FastRec.opFirst / evFirst are site-local ...
   const EvRec* events;
-  const int32_t* siteBase;    // ... [n_sites][2]: the site's base in ringOps / events
+  const int32_t* siteBase;    // ... [n_sites][3]: the site's base in ringOps / events, its number of records (<= n_steps_total)
   const double* prm;
   double* state;
   double* ring;

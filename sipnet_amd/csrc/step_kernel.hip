@@ -214,7 +214,8 @@ __global__ __launch_bounds__(64) void stepKernel(KernelArgs a) {
   if (m >= a.n_members) return;  // no barriers below: a lane may simply leave
   const int64_t col = (int64_t)site * a.n_members + m;
   // ring-eviction and event indices in the site's records are local to the site
-  const int opBase = uni(a.siteBase[2 * site]), evBase = uni(a.siteBase[2 * site + 1]);
+  const int opBase = uni(a.siteBase[3 * site]), evBase = uni(a.siteBase[3 * site + 1]);
+  const int siteSteps = uni(a.siteBase[3 * site + 2]);   // records of THIS site (sites of a batch may differ in length)
   const int64_t nc = a.ncol;
 
   double* __restrict__ stp = a.state + col;
@@ -316,7 +317,8 @@ __global__ __launch_bounds__(64) void stepKernel(KernelArgs a) {
   R* __restrict__ oGpp = a.gpp ? (R*)a.gpp + col : nullptr;
   R* __restrict__ oEt = a.et ? (R*)a.et + col : nullptr;
 
-  for (int tl = 0; tl < a.n_steps; tl++) {
+  const int nLocal = a.step0 + a.n_steps <= siteSteps ? a.n_steps : siteSteps - a.step0;   // (<= 0: the site ended earlier)
+  for (int tl = 0; tl < nLocal; tl++) {
     const int t = a.step0 + tl;
     const StepRec& s = plan[t];
     const R len = (R)s.length, tair = (R)s.tair, tsoil = (R)s.tsoil, par = (R)s.par;

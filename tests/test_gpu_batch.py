@@ -428,3 +428,46 @@ def test_run_stats_equals_the_sums_over_the_planes(name, kernel, prec, base, sho
         assert np.isfinite(got).all(), li
         assert np.abs(got[..., 0] - p.sum(-1)).max() < 1e-12 * max(scale, 1.0), li
         assert np.abs(got[..., 1] - (p * p).sum(-1)).max() < 1e-12 * max((p * p).sum(-1).max(), 1.0), li
+
+
+@pytest.mark.parametrize("name,fast,kernel", [("strict", False, sa.KERNEL_AUTO), ("one_wave", True, sa.KERNEL_ONE_WAVE),
+                                              ("coop_lds", True, sa.KERNEL_COOP_LDS), ("coop_hbm", True, sa.KERNEL_COOP_HBM),
+                                              ("coop_pair", True, sa.KERNEL_COOP_PAIR), ("coop_quad", True, sa.KERNEL_COOP_QUAD)])
+def test_sites_of_different_lengths_in_one_batch(name, fast, kernel):
+    """three sites whose forcings have 4 800, 4 023 and 2 400 records in ONE batch (a launch advances every site to
+    the end of its own records; launches cut at odd steps, one of them across a site's end): planes, statistics and
+    final state equal three one-site batches, bit for bit; rows past a site's end are left untouched"""
+    flags = sa.flags_from()
+    base = sa.read_params(os.path.join(helpers.REPO, "sipnet_amd", "data", "base_forest.param"), flags)[0]
+    lens = [4800, 4023, 2400]
+    clims = [synth.convert_raw(synth.round_like_file(synth.half_hourly_year_raw(n, site=s))) for s, n in enumerate(lens)]
+    M = 130
+    members = synth.perturbed_params(base, M)
+    b = sa.Batch(flags, 3, M, sa.F64, fast_math=fast, kernel=kernel)
+    for s in range(3):
+        b.set_climate(s, clims[s])
+        b.set_params(s, members)
+    b.setup()
+    assert b.n_steps == 4800
+    T = 4800
+    planes = torch.full((3, T, 3 * M), -7.0, dtype=torch.float64, device="cuda")
+    stats = torch.zeros((3, T, 3, 2), dtype=torch.float64, device="cuda")
+    cuts = [0, 7, 2399, 2405, 4030, T]
+    for a, z in zip(cuts[:-1], cuts[1:]):
+        b.run_stats(a, z - a, planes=planes[:, a:z], stats=stats[:, a:z])
+    got, state, st = planes.cpu().numpy().reshape(3, T, 3, M), b.get_state().reshape(3, M, -1), stats.cpu().numpy()
+    li = b.last_launch()["kernel"]
+    g, _ = b.site_series(1)
+    b.close()
+    for s in range(3):
+        one = sa.Batch(flags, 1, M, sa.F64, fast_math=fast, kernel=kernel)
+        one.set_climate(0, clims[s])
+        one.set_params(0, members)
+        one.setup()
+        p1, s1 = one.run_stats(0, lens[s])
+        assert one.last_launch()["kernel"] == li
+        np.testing.assert_array_equal(got[:, :lens[s], s], p1.cpu().numpy(), err_msg=f"site {s}")
+        np.testing.assert_array_equal(state[s][:, :28], one.get_state()[:, :28], err_msg=f"site {s}")
+        np.testing.assert_allclose(st[:, :lens[s], s], s1.cpu().numpy()[:, :, 0], rtol=1e-12, atol=1e-12)
+        assert (got[:, lens[s]:, s] == -7.0).all()                     # rows past the site's end: untouched
+        one.close()
