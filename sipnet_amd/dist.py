@@ -273,8 +273,7 @@ def pf_analysis_peers(batch, plane, obs, sigma, u0, rank=0, world=1, group=None,
     anc = batch.pf_resample_peers(gathered, u0, ancestors, total_out)
     if not diagnostics:
         return anc, gathered
-    # L = nmax + ceil(nmax / 256)  ->  nmax: the largest m with m + ceil(m / 256) == L
-    nmax = (L * 256) // 257
+    nmax = (L * 256) // 257                      # L = nmax + ceil(nmax / 256)
     while nmax + (nmax + 255) // 256 < L:
         nmax += 1
     logw = gathered[:, :nmax].reshape(-1)

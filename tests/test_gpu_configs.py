@@ -270,15 +270,15 @@ KERNELS = [
     ("coop_ncycle_pair_f64_plain", sa.F64, sa.KERNEL_COOP_NCYCLE_PAIR, 0, "stepCoopNPairKernel<double, true>"),
     # the optional-physics instantiations (run-time flags; the flag set rides in the row's name): russell_3's family
     # on the default pools' layouts, "everything" on the nitrogen-cycle ones
-    ("x_russell3_lds_f64", sa.F64, sa.KERNEL_COOP_LDS, 0, "stepCoopXKernel<double, false, true>"),
-    ("x_russell3_lds_f32", sa.F32_MIXED, sa.KERNEL_COOP_LDS, 0, "stepCoopXKernel<float, false, true>"),
-    ("x_russell3_hbm_f64", sa.F64, sa.KERNEL_COOP_HBM, 0, "stepCoopXKernel<double, false, false>"),
-    ("x_russell3_pair_f64", sa.F64, sa.KERNEL_COOP_PAIR, 0, "stepCoopXPairKernel<double, false>"),
-    ("x_russell3_pair_f32", sa.F32_MIXED, sa.KERNEL_COOP_PAIR, 0, "stepCoopXPairKernel<float, false>"),
-    ("x_russell3_lds_f64_plain", sa.F64, sa.KERNEL_COOP_LDS, 0, "stepCoopXKernel<double, true, true>"),
-    ("x_anaerobic_sat_flood_lds_f64", sa.F64, sa.KERNEL_COOP_LDS, 0, "stepCoopXKernel<double, false, true>"),
-    ("x_anaerobic_sat_flood_pair_f64", sa.F64, sa.KERNEL_COOP_PAIR, 0, "stepCoopXPairKernel<double, false>"),
-    ("x_anaerobic_sat_flood_pair_f32", sa.F32_MIXED, sa.KERNEL_COOP_PAIR, 0, "stepCoopXPairKernel<float, false>"),
+    ("x_russell3_lds_f64", sa.F64, sa.KERNEL_COOP_LDS, 0, "stepCoopXKernel<double, false, true, false>"),
+    ("x_russell3_lds_f32", sa.F32_MIXED, sa.KERNEL_COOP_LDS, 0, "stepCoopXKernel<float, false, true, false>"),
+    ("x_russell3_hbm_f64", sa.F64, sa.KERNEL_COOP_HBM, 0, "stepCoopXKernel<double, false, false, false>"),
+    ("x_russell3_pair_f64", sa.F64, sa.KERNEL_COOP_PAIR, 0, "stepCoopXPairKernel<double, false, false>"),
+    ("x_russell3_pair_f32", sa.F32_MIXED, sa.KERNEL_COOP_PAIR, 0, "stepCoopXPairKernel<float, false, false>"),
+    ("x_russell3_lds_f64_plain", sa.F64, sa.KERNEL_COOP_LDS, 0, "stepCoopXKernel<double, true, true, false>"),
+    ("x_anaerobic_sat_flood_lds_f64", sa.F64, sa.KERNEL_COOP_LDS, 0, "stepCoopXKernel<double, false, true, false>"),
+    ("x_anaerobic_sat_flood_pair_f64", sa.F64, sa.KERNEL_COOP_PAIR, 0, "stepCoopXPairKernel<double, false, false>"),
+    ("x_anaerobic_sat_flood_pair_f32", sa.F32_MIXED, sa.KERNEL_COOP_PAIR, 0, "stepCoopXPairKernel<float, false, false>"),
     ("x_everything_ncycle_f64", sa.F64, sa.KERNEL_COOP_NCYCLE, 0, "stepCoopNXKernel<double, false>"),
     ("x_everything_ncycle_f32", sa.F32_MIXED, sa.KERNEL_COOP_NCYCLE, 0, "stepCoopNXKernel<float, false>"),
     ("x_everything_ncycle_pair_f64", sa.F64, sa.KERNEL_COOP_NCYCLE_PAIR, 0, "stepCoopNXPairKernel<double, false>"),
