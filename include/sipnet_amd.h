@@ -584,6 +584,16 @@ double *sipnet_node_gathered_stats(sipnet_node *nd, int32_t k);
  * (4.3 GB per device at 10 240 members x 17 520 steps: see DESIGN.md section 5 for what it costs.) */
 int sipnet_node_gather_planes(sipnet_node *nd);
 void *sipnet_node_gathered_planes(sipnet_node *nd, int32_t k);
+/* The same exchange overlapped with the computation (SURVEY 8(e) "gather per chunk ... on a side stream"): the run
+ * [step0, step0 + n_steps) is cut into n_segments launches (at whole 16-step tiles where the segments are long
+ * enough) and segment j's planes travel -- ONE all-gather per segment on each shard's second stream -- under the
+ * step kernel of segment j + 1.  No statistics.  Returns once everything is enqueued; sipnet_node_sync waits for
+ * the gathers too.  Afterwards, on device k, sipnet_node_gathered_segment(nd, k, j, &first, &len) is segment j of
+ * every shard, [n_devices][3][len][ld] (first = its first record, len = its length), and the shard's own planes
+ * (sipnet_node_planes) hold the segments one after the other, [3][len_j][ld] each. */
+int sipnet_node_run_gathering(sipnet_node *nd, int32_t step0, int32_t n_steps, int32_t n_segments);
+int32_t sipnet_node_n_segments(const sipnet_node *nd);   /* of the last sipnet_node_run_gathering; 0 after a plain run */
+void *sipnet_node_gathered_segment(sipnet_node *nd, int32_t k, int32_t segment, int32_t *first_step, int32_t *n_steps);
 /* Column layout of a plane row: shard k's member m of its local site s sits at s * count_k + m (count_k =
  * the shard's own member count: the site stride is NOT the common maximum); columns from n_sites_k * count_k
  * up to ld are zero.  Any run length may be gathered (the planes of a run are [3][n_steps][ld] at the start

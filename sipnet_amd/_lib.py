@@ -182,6 +182,9 @@ SIGNATURES = {
     "sipnet_node_gathered_stats": (_P, [_P, C.c_int32]),
     "sipnet_node_gather_planes": (C.c_int, [_P]),
     "sipnet_node_gathered_planes": (_P, [_P, C.c_int32]),
+    "sipnet_node_run_gathering": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32]),
+    "sipnet_node_n_segments": (C.c_int32, [_P]),
+    "sipnet_node_gathered_segment": (_P, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "sipnet_batch_ncol": (C.c_int64, [_P]),
     "sipnet_batch_nsteps": (C.c_int32, [_P]),
     "sipnet_batch_get_site_series": (C.c_int, [_P, C.c_int32, _P, _P]),

@@ -141,6 +141,13 @@ struct sipnet_node {
   std::vector<int32_t*> pfAnc;
   std::vector<int64_t*> pfTotals;
   static constexpr int kPfTotals = 64;
+  // sipnet_node_run_gathering: the run cut into segments, segment j at rows [3 * segCuts[j], 3 * segCuts[j + 1]) of
+  // every shard's planes ([3][len_j][ld] each) and at [n][3][len_j][ld] from element n * 3 * ld * segCuts[j] of the
+  // gathered planes; the all-gathers run on the shards' second streams
+  bool segmented = false;
+  std::vector<int32_t> segCuts;
+  std::vector<hipStream_t> gatherStreams;
+  std::vector<hipEvent_t> evSeg, evGathered;
   // event-ordered transport
   std::vector<hipEvent_t> evReady, evCopied;
   std::vector<const void*> agSend;
@@ -236,26 +243,27 @@ static int onEveryShard(sipnet_node* nd, F f) {
 // All-gather of `bytes` per shard among the shards, called by shard k's thread from inside an onEveryShard
 // task: recv = [n][bytes] on shard k's device, send = this shard's block (may be its own slice of recv).
 // RCCL when every shard has a device of its own; otherwise copies ordered by events (see the file header).
-static int allGatherShard(sipnet_node* nd, int k, const void* send, void* recv, size_t bytes) {
+static int allGatherShard(sipnet_node* nd, int k, const void* send, void* recv, size_t bytes, hipStream_t stream = nullptr) {
   const int n = nd->n();
+  if (!stream) stream = nd->streams[k];
   if (!nd->comms.empty()) {
-    NODE_RCCL(nd, nd->rccl->allGather(send, recv, bytes, ncclChar, nd->comms[k], nd->streams[k]));
+    NODE_RCCL(nd, nd->rccl->allGather(send, recv, bytes, ncclChar, nd->comms[k], stream));
     return SIPNET_OK;
   }
   nd->agSend[k] = send;
-  NODE_HIP(hipEventRecord(nd->evReady[k], nd->streams[k]));
+  NODE_HIP(hipEventRecord(nd->evReady[k], stream));
   nd->bar.arrive();
   for (int s = 0; s < n; s++) {
     char* dst = (char*)recv + (size_t)s * bytes;
-    if (s != k) NODE_HIP(hipStreamWaitEvent(nd->streams[k], nd->evReady[s], 0));
+    if (s != k) NODE_HIP(hipStreamWaitEvent(stream, nd->evReady[s], 0));
     if ((const void*)dst != nd->agSend[s])
-      NODE_HIP(hipMemcpyAsync(dst, nd->agSend[s], bytes, hipMemcpyDeviceToDevice, nd->streams[k]));
+      NODE_HIP(hipMemcpyAsync(dst, nd->agSend[s], bytes, hipMemcpyDeviceToDevice, stream));
   }
-  NODE_HIP(hipEventRecord(nd->evCopied[k], nd->streams[k]));
+  NODE_HIP(hipEventRecord(nd->evCopied[k], stream));
   nd->bar.arrive();
   // what follows on this stream may overwrite the block the others copy from
   for (int s = 0; s < n; s++)
-    if (s != k) NODE_HIP(hipStreamWaitEvent(nd->streams[k], nd->evCopied[s], 0));
+    if (s != k) NODE_HIP(hipStreamWaitEvent(stream, nd->evCopied[s], 0));
   return SIPNET_OK;
 }
 
@@ -312,6 +320,9 @@ static int createNode(const int32_t* flags, int32_t n_sites, int32_t n_members, 
   nd->pfTotals.assign(n_devices, nullptr);
   nd->evReady.assign(n_devices, nullptr);
   nd->evCopied.assign(n_devices, nullptr);
+  nd->gatherStreams.assign(n_devices, nullptr);
+  nd->evSeg.assign(n_devices, nullptr);
+  nd->evGathered.assign(n_devices, nullptr);
   nd->agSend.assign(n_devices, nullptr);
   nd->rc.assign(n_devices, SIPNET_OK);
   nd->msg.assign(n_devices, "");
@@ -346,7 +357,10 @@ static int createNode(const int32_t* flags, int32_t n_sites, int32_t n_members, 
     if (rc == SIPNET_OK && (hipSetDevice(devices[k]) != hipSuccess ||
                             hipStreamCreateWithFlags(&nd->streams[k], hipStreamNonBlocking) != hipSuccess ||
                             hipEventCreateWithFlags(&nd->evReady[k], hipEventDisableTiming) != hipSuccess ||
-                            hipEventCreateWithFlags(&nd->evCopied[k], hipEventDisableTiming) != hipSuccess)) {
+                            hipEventCreateWithFlags(&nd->evCopied[k], hipEventDisableTiming) != hipSuccess ||
+                            hipStreamCreateWithFlags(&nd->gatherStreams[k], hipStreamNonBlocking) != hipSuccess ||
+                            hipEventCreateWithFlags(&nd->evSeg[k], hipEventDisableTiming) != hipSuccess ||
+                            hipEventCreateWithFlags(&nd->evGathered[k], hipEventDisableTiming) != hipSuccess)) {
       setError(std::string(fn) + ": hipStreamCreate / hipEventCreate failed");
       rc = SIPNET_ERR_NO_DEVICE;
     }
@@ -396,6 +410,7 @@ void sipnet_node_destroy(sipnet_node* nd) {
   for (int k = 0; k < nd->n(); k++) {
     (void)hipSetDevice(nd->devices[k]);
     if (nd->streams[k]) (void)hipStreamSynchronize(nd->streams[k]);
+    if (nd->gatherStreams[k]) (void)hipStreamSynchronize(nd->gatherStreams[k]);
   }
   for (int k = 0; k < nd->n(); k++) {
     (void)hipSetDevice(nd->devices[k]);
@@ -410,6 +425,9 @@ void sipnet_node_destroy(sipnet_node* nd) {
     if (nd->pfTotals[k]) (void)hipFree(nd->pfTotals[k]);
     if (nd->evReady[k]) (void)hipEventDestroy(nd->evReady[k]);
     if (nd->evCopied[k]) (void)hipEventDestroy(nd->evCopied[k]);
+    if (nd->evSeg[k]) (void)hipEventDestroy(nd->evSeg[k]);
+    if (nd->evGathered[k]) (void)hipEventDestroy(nd->evGathered[k]);
+    if (nd->gatherStreams[k]) (void)hipStreamDestroy(nd->gatherStreams[k]);
     if (nd->batches[k]) sipnet_batch_destroy(nd->batches[k]);
     if (nd->streams[k]) (void)hipStreamDestroy(nd->streams[k]);
   }
@@ -524,27 +542,35 @@ int sipnet_node_setup(sipnet_node* nd) {
   return onEveryShard(nd, [&](int k) -> int { return sipnet_batch_setup(nd->batches[k], nd->streams[k]); });
 }
 
+// shard k's planes and statistics block for runs of up to n_steps records (called on the shard's thread)
+static int growRunBuffers(sipnet_node* nd, int k, int32_t n_steps) {
+  const size_t planeBytes = (size_t)3 * n_steps * nd->ld * nd->elem();
+  const size_t statDoubles = (size_t)3 * n_steps * nd->maxSites * 2;
+  NODE_HIP(hipStreamSynchronize(nd->streams[k]));
+  if (nd->planes[k]) NODE_HIP(hipFree(nd->planes[k]));
+  if (nd->stats[k]) NODE_HIP(hipFree(nd->stats[k]));
+  nd->planes[k] = nullptr;
+  nd->stats[k] = nullptr;
+  NODE_HIP(hipMalloc(&nd->planes[k], planeBytes));
+  NODE_HIP(hipMalloc(&nd->stats[k], statDoubles * sizeof(double)));
+  // columns past a shard's own (the padding up to the common leading dimension) and the statistics of
+  // sites it does not have stay zero: no kernel ever writes them, whatever the length of a run
+  NODE_HIP(hipMemsetAsync(nd->planes[k], 0, planeBytes, nd->streams[k]));
+  NODE_HIP(hipMemsetAsync(nd->stats[k], 0, statDoubles * sizeof(double), nd->streams[k]));
+  return SIPNET_OK;
+}
+
 static int runShards(sipnet_node* nd, int32_t step0, int32_t n_steps, bool withStats) {
   if (!nd || n_steps <= 0) {
     setError("sipnet_node_run: bad argument");
     return SIPNET_ERR_BAD_ARGUMENT;
   }
-  const size_t planeBytes = (size_t)3 * n_steps * nd->ld * nd->elem();
   const size_t statDoubles = (size_t)3 * n_steps * nd->maxSites * 2;
   const bool grow = n_steps > nd->nAlloc;
   int rc = onEveryShard(nd, [&](int k) -> int {
     if (grow) {
-      NODE_HIP(hipStreamSynchronize(nd->streams[k]));
-      if (nd->planes[k]) NODE_HIP(hipFree(nd->planes[k]));
-      if (nd->stats[k]) NODE_HIP(hipFree(nd->stats[k]));
-      nd->planes[k] = nullptr;
-      nd->stats[k] = nullptr;
-      NODE_HIP(hipMalloc(&nd->planes[k], planeBytes));
-      NODE_HIP(hipMalloc(&nd->stats[k], statDoubles * sizeof(double)));
-      // columns past a shard's own (the padding up to the common leading dimension) and the statistics of
-      // sites it does not have stay zero: no kernel ever writes them, whatever the length of a run
-      NODE_HIP(hipMemsetAsync(nd->planes[k], 0, planeBytes, nd->streams[k]));
-      NODE_HIP(hipMemsetAsync(nd->stats[k], 0, statDoubles * sizeof(double), nd->streams[k]));
+      int rcg = growRunBuffers(nd, k, n_steps);
+      if (rcg) return rcg;
     }
     char* p = (char*)nd->planes[k];
     const size_t one = (size_t)n_steps * nd->ld * nd->elem();
@@ -583,7 +609,103 @@ static int runShards(sipnet_node* nd, int32_t step0, int32_t n_steps, bool withS
   if (grow) nd->nAlloc = n_steps;
   nd->nRun = n_steps;
   nd->step0 = step0;
+  nd->segmented = false;
   return SIPNET_OK;
+}
+
+// The north star's exchange as written, overlapped (SURVEY 8(e) "Collective": "gather per chunk ... overlapped on a
+// side stream"): the run is cut into segments -- one launch each -- and the member-resolved planes of segment j
+// travel (one all-gather per segment, on every shard's SECOND stream) under the step kernel of segment j + 1.
+// Every segment has its own place in the shard's planes and in the gathered block, so nothing is double-buffered
+// and nothing waits for a consumer (288 GB of HBM: the gathered year of c4's shape is 8 x 13.8 GB).
+static int runGathering(sipnet_node* nd, int32_t step0, int32_t n_steps, int32_t n_segments) {
+  if (!nd || n_steps <= 0 || n_segments <= 0 || n_segments > n_steps || step0 < 0) {
+    setError("sipnet_node_run_gathering: bad argument");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  const int n = nd->n();
+  const size_t count = (size_t)3 * n_steps * nd->ld;   // elements per shard
+  const bool grow = n_steps > nd->nAlloc;
+  const bool growGathered = count * n > nd->gatheredPlanesCap;
+  // cuts at whole 16-step tiles of the site plan where the segments are long enough for that
+  std::vector<int32_t> cuts(n_segments + 1, 0);
+  cuts[n_segments] = n_steps;
+  for (int j = 1; j < n_segments; j++) {
+    const int32_t raw = (int32_t)((int64_t)n_steps * j / n_segments);
+    const int32_t tile = ((step0 + raw) & ~15) - step0;
+    cuts[j] = tile > cuts[j - 1] ? tile : raw;
+  }
+  int rc = onEveryShard(nd, [&](int k) -> int {
+    if (grow) {
+      NODE_HIP(hipStreamSynchronize(nd->gatherStreams[k]));
+      int rcg = growRunBuffers(nd, k, n_steps);
+      if (rcg) return rcg;
+    }
+    if (growGathered) {
+      NODE_HIP(hipStreamSynchronize(nd->streams[k]));
+      NODE_HIP(hipStreamSynchronize(nd->gatherStreams[k]));
+      if (nd->gatheredPlanes[k]) NODE_HIP(hipFree(nd->gatheredPlanes[k]));
+      nd->gatheredPlanes[k] = nullptr;
+      NODE_HIP(hipMalloc(&nd->gatheredPlanes[k], count * n * nd->elem()));
+    }
+    return SIPNET_OK;
+  });
+  if (rc) return rc;
+  if (grow) nd->nAlloc = n_steps;
+  if (growGathered) nd->gatheredPlanesCap = count * n;
+  for (int j = 0; j < n_segments; j++) {
+    const int32_t a = cuts[j], len = cuts[j + 1] - a;
+    const size_t one = (size_t)len * nd->ld * nd->elem();              // one variable of the segment
+    const size_t segOff = (size_t)3 * a * nd->ld * nd->elem();         // the segment in a shard's planes
+    rc = onEveryShard(nd, [&](int k) -> int {
+      char* p = (char*)nd->planes[k] + segOff;
+      const int32_t have = sipnet_batch_nsteps(nd->batches[k]);
+      const int32_t nLoc = step0 + a + len <= have ? len : have - (step0 + a);
+      // (a site shard whose forcings end inside the segment: the rows past its end travel as zeros)
+      if (nLoc < len) NODE_HIP(hipMemsetAsync(p, 0, 3 * one, nd->streams[k]));
+      if (nLoc > 0) {
+        int rcr = sipnet_batch_run(nd->batches[k], step0 + a, nLoc, p, p + one, p + 2 * one, nullptr, nd->ld, nd->streams[k]);
+        if (rcr) return rcr;
+      }
+      NODE_HIP(hipEventRecord(nd->evSeg[k], nd->streams[k]));
+      NODE_HIP(hipStreamWaitEvent(nd->gatherStreams[k], nd->evSeg[k], 0));
+      if (!nd->comms.empty()) return SIPNET_OK;
+      return allGatherShard(nd, k, p, (char*)nd->gatheredPlanes[k] + (size_t)n * segOff, 3 * one, nd->gatherStreams[k]);
+    });
+    if (rc) return rc;
+    if (!nd->comms.empty()) {   // one thread, the per-device calls of the collective fused (RCCL's single-process idiom)
+      NODE_RCCL(nd, nd->rccl->groupStart());
+      for (int k = 0; k < n; k++) {
+        NODE_HIP(hipSetDevice(nd->devices[k]));
+        NODE_RCCL(nd, nd->rccl->allGather((char*)nd->planes[k] + segOff, (char*)nd->gatheredPlanes[k] + (size_t)n * segOff,
+                                          (size_t)3 * len * nd->ld, nd->precision == SIPNET_F64 ? ncclDouble : ncclFloat,
+                                          nd->comms[k], nd->gatherStreams[k]));
+      }
+      NODE_RCCL(nd, nd->rccl->groupEnd());
+    }
+  }
+  // whatever follows on a shard's stream (the next run writes the same planes) comes after its gathers
+  for (int k = 0; k < n; k++) {
+    NODE_HIP(hipSetDevice(nd->devices[k]));
+    NODE_HIP(hipEventRecord(nd->evGathered[k], nd->gatherStreams[k]));
+    NODE_HIP(hipStreamWaitEvent(nd->streams[k], nd->evGathered[k], 0));
+  }
+  nd->nRun = n_steps;
+  nd->step0 = step0;
+  nd->segmented = true;
+  nd->segCuts = cuts;
+  return SIPNET_OK;
+}
+
+int sipnet_node_run_gathering(sipnet_node* nd, int32_t step0, int32_t n_steps, int32_t n_segments) {
+  return runGathering(nd, step0, n_steps, n_segments);
+}
+int32_t sipnet_node_n_segments(const sipnet_node* nd) { return (nd && nd->segmented) ? (int32_t)nd->segCuts.size() - 1 : 0; }
+void* sipnet_node_gathered_segment(sipnet_node* nd, int32_t k, int32_t segment, int32_t* first_step, int32_t* n_steps) {
+  if (!nd || !nd->segmented || k < 0 || k >= nd->n() || segment < 0 || segment + 1 >= (int32_t)nd->segCuts.size()) return nullptr;
+  if (first_step) *first_step = nd->step0 + nd->segCuts[segment];
+  if (n_steps) *n_steps = nd->segCuts[segment + 1] - nd->segCuts[segment];
+  return (char*)nd->gatheredPlanes[k] + (size_t)nd->n() * 3 * nd->segCuts[segment] * nd->ld * nd->elem();
 }
 
 int sipnet_node_run(sipnet_node* nd, int32_t step0, int32_t n_steps) { return runShards(nd, step0, n_steps, true); }
@@ -624,8 +746,8 @@ void* sipnet_node_gathered_planes(sipnet_node* nd, int32_t k) {
 
 // ONE all-gather: every shard's statistics block of the last sipnet_node_run to every shard
 int sipnet_node_gather_stats(sipnet_node* nd, double* host_total) {
-  if (!nd || nd->nRun <= 0) {
-    setError("sipnet_node_gather_stats: nothing has run");
+  if (!nd || nd->nRun <= 0 || nd->segmented) {
+    setError("sipnet_node_gather_stats: nothing has run (sipnet_node_run_gathering leaves no statistics)");
     return SIPNET_ERR_BAD_ARGUMENT;
   }
   const int n = nd->n();
@@ -681,8 +803,8 @@ int sipnet_node_gather_stats(sipnet_node* nd, double* host_total) {
 // its member m) is s * count_k + m -- the site stride is the SHARD's member count, not the common maximum --
 // and the columns from n_sites_k * count_k to ld are zero
 int sipnet_node_gather_planes(sipnet_node* nd) {
-  if (!nd || nd->nRun <= 0) {
-    setError("sipnet_node_gather_planes: nothing has run");
+  if (!nd || nd->nRun <= 0 || nd->segmented) {
+    setError("sipnet_node_gather_planes: nothing has run (after sipnet_node_run_gathering the planes are gathered already)");
     return SIPNET_ERR_BAD_ARGUMENT;
   }
   const int n = nd->n();

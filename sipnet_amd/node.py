@@ -121,6 +121,34 @@ class Node:
     def gathered_planes(self, k):
         return self._to_host(self.L.sipnet_node_gathered_planes(self.h, k), (self.n, 3, self.n_run, self.ld), self._elem())
 
+    def run_gathering(self, step0, n_steps, n_segments):
+        """the run in n_segments launches, segment j's member-resolved planes all-gathered on the shards' second
+        streams under the kernel of segment j + 1 (no statistics)"""
+        check(self.L.sipnet_node_run_gathering(self.h, step0, n_steps, n_segments), "node_run_gathering")
+        self.n_run = n_steps
+
+    def gathered_segment(self, k, j):
+        """-> (first record, segment j of every shard as device k holds it: [n][3][len][ld]) on the host (after sync)"""
+        first, length = C.c_int32(0), C.c_int32(0)
+        ptr = self.L.sipnet_node_gathered_segment(self.h, k, j, C.byref(first), C.byref(length))
+        if not ptr:
+            raise ValueError("no such segment")
+        return first.value, self._to_host(ptr, (self.n, 3, length.value, self.ld), self._elem())
+
+    def gathered_member_planes(self, k):
+        """what device k holds after run_gathering, as [3][n_run][n_sites][n_members] on the host"""
+        self.sync()
+        out = np.zeros((3, self.n_run, self.n_sites, self.n_members), dtype=self._elem())
+        t = 0
+        for j in range(self.L.sipnet_node_n_segments(self.h)):
+            _, g = self.gathered_segment(k, j)
+            for q in range(self.n):
+                m0, mc = self.member_range(q)
+                s0, sc = self.site_range(q)
+                out[:, t:t + g.shape[2], s0:s0 + sc, m0:m0 + mc] = g[q][:, :, :sc * mc].reshape(3, g.shape[2], sc, mc)
+            t += g.shape[2]
+        return out
+
     def gathered_stats(self, k):
         mx = self.n_sites if self.shard == SHARD_MEMBERS else max(self.site_range(j)[1] for j in range(self.n))
         return self._to_host(self.L.sipnet_node_gathered_stats(self.h, k), (self.n, 3, self.n_run, mx, 2), np.float64)

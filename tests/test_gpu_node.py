@@ -99,6 +99,57 @@ def test_site_sharded_node_equals_one_batch_of_all_sites(base, devices, n_sites)
     nd.close()
 
 
+@pytest.mark.parametrize("devices,shard,n_sites,nseg", [([0, 0], SHARD_MEMBERS, 2, 5), ([0, 0, 0], SHARD_SITES, 5, 3),
+                                                         ([0], SHARD_MEMBERS, 1, 4)],
+                         ids=["members-2-shards", "sites-ragged-3-shards", "rccl-one-rank"])
+def test_run_gathering_overlapped_plane_gather_equals_one_batch(base, devices, shard, n_sites, nseg):
+    """sipnet_node_run_gathering: the run in segments, segment j's planes all-gathered on the shards' second streams
+    under segment j + 1 -- what EVERY device holds afterwards equals ONE batch's planes bit for bit (first from a
+    non-zero step0 cut at odd places, then a second, shorter call over the same buffers), and a plain run afterwards
+    still gathers statistics"""
+    M, T = 150, 48 * 7
+    flags = sa.flags_from()
+    clims = site_clims(n_sites, T)
+    members = synth.perturbed_params(base, M)
+    b = one_batch(flags, clims, members)
+    planes, stats = b.run_stats(0, T)
+    want = planes.cpu().numpy().reshape(3, T, n_sites, M)
+    want_stats = stats.cpu().numpy()
+    b.close()
+
+    nd = Node(flags, n_sites, M, devices=devices, shard=shard, fast_math=True)
+    for s in range(n_sites):
+        nd.set_climate(s, clims[s])
+    nd.set_params(None, members)
+    nd.setup()
+    nd.run_gathering(0, T, nseg)
+    assert nd.L.sipnet_node_n_segments(nd.h) == nseg
+    firsts = [nd.gathered_segment(0, j)[0] for j in range(nseg)]
+    assert firsts[0] == 0 and all(f % 16 == 0 for f in firsts) and firsts == sorted(set(firsts))
+    for k in range(nd.n):
+        np.testing.assert_array_equal(nd.gathered_member_planes(k), want)
+    with pytest.raises(sa.SipnetError):
+        nd.gather_stats()                          # a gathering run leaves no statistics
+    # a second call from the state the first one left (record 0 again after setup), 7 segments of a shorter run,
+    # then the rest of the year from step0 = 100 (segments cut at the plan's 16-step tiles: 112, 128, ...)
+    nd.setup()
+    nd.run_gathering(0, 100, 7)
+    np.testing.assert_array_equal(nd.gathered_member_planes(nd.n - 1), want[:, :100])
+    nd.run_gathering(100, T - 100, 4)
+    assert nd.gathered_segment(0, 1)[0] % 16 == 0
+    np.testing.assert_array_equal(nd.gathered_member_planes(0), want[:, 100:])
+    assert (nd.status() == 0).all()
+    nd.setup()
+    nd.run(0, T)
+    got = nd.gather_stats()
+    if shard == SHARD_SITES or nd.n == 1:
+        np.testing.assert_array_equal(got, want_stats)
+    else:
+        np.testing.assert_allclose(got, want_stats, rtol=1e-12, atol=1e-12)
+    assert nd.L.sipnet_node_n_segments(nd.h) == 0
+    nd.close()
+
+
 def test_member_sharded_node_with_ragged_shards_equals_one_batch(base):
     """SIPNET_SHARD_MEMBERS over three shards, 200 members (67 / 66 / 67) at two sites: the summed statistics equal
     one batch's up to the order of the additions, the planes bit for bit; column layout site * count_k + member"""
