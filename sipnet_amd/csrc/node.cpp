@@ -653,37 +653,31 @@ static int runGathering(sipnet_node* nd, int32_t step0, int32_t n_steps, int32_t
   if (rc) return rc;
   if (grow) nd->nAlloc = n_steps;
   if (growGathered) nd->gatheredPlanesCap = count * n;
-  for (int j = 0; j < n_segments; j++) {
-    const int32_t a = cuts[j], len = cuts[j + 1] - a;
-    const size_t one = (size_t)len * nd->ld * nd->elem();              // one variable of the segment
-    const size_t segOff = (size_t)3 * a * nd->ld * nd->elem();         // the segment in a shard's planes
-    rc = onEveryShard(nd, [&](int k) -> int {
+  // every shard's host thread walks the segments on its own: launch, hand over to the second stream, all-gather there
+  // (RCCL: one communicator per thread, the multi-thread idiom; shards sharing a device: event-ordered copies, the
+  // threads meeting at a host barrier per segment)
+  rc = onEveryShard(nd, [&](int k) -> int {
+    const int32_t have = sipnet_batch_nsteps(nd->batches[k]);
+    for (int j = 0; j < n_segments; j++) {
+      const int32_t a = cuts[j], len = cuts[j + 1] - a;
+      const size_t one = (size_t)len * nd->ld * nd->elem();              // one variable of the segment
+      const size_t segOff = (size_t)3 * a * nd->ld * nd->elem();         // the segment in a shard's planes
       char* p = (char*)nd->planes[k] + segOff;
-      const int32_t have = sipnet_batch_nsteps(nd->batches[k]);
       const int32_t nLoc = step0 + a + len <= have ? len : have - (step0 + a);
       // (a site shard whose forcings end inside the segment: the rows past its end travel as zeros)
       if (nLoc < len) NODE_HIP(hipMemsetAsync(p, 0, 3 * one, nd->streams[k]));
       if (nLoc > 0) {
         int rcr = sipnet_batch_run(nd->batches[k], step0 + a, nLoc, p, p + one, p + 2 * one, nullptr, nd->ld, nd->streams[k]);
-        if (rcr) return rcr;
+        if (rcr) return rcr;   // (every shard fails alike -- same arguments -- so nobody is left at the barrier)
       }
       NODE_HIP(hipEventRecord(nd->evSeg[k], nd->streams[k]));
       NODE_HIP(hipStreamWaitEvent(nd->gatherStreams[k], nd->evSeg[k], 0));
-      if (!nd->comms.empty()) return SIPNET_OK;
-      return allGatherShard(nd, k, p, (char*)nd->gatheredPlanes[k] + (size_t)n * segOff, 3 * one, nd->gatherStreams[k]);
-    });
-    if (rc) return rc;
-    if (!nd->comms.empty()) {   // one thread, the per-device calls of the collective fused (RCCL's single-process idiom)
-      NODE_RCCL(nd, nd->rccl->groupStart());
-      for (int k = 0; k < n; k++) {
-        NODE_HIP(hipSetDevice(nd->devices[k]));
-        NODE_RCCL(nd, nd->rccl->allGather((char*)nd->planes[k] + segOff, (char*)nd->gatheredPlanes[k] + (size_t)n * segOff,
-                                          (size_t)3 * len * nd->ld, nd->precision == SIPNET_F64 ? ncclDouble : ncclFloat,
-                                          nd->comms[k], nd->gatherStreams[k]));
-      }
-      NODE_RCCL(nd, nd->rccl->groupEnd());
+      int rcg = allGatherShard(nd, k, p, (char*)nd->gatheredPlanes[k] + (size_t)n * segOff, 3 * one, nd->gatherStreams[k]);
+      if (rcg) return rcg;
     }
-  }
+    return SIPNET_OK;
+  });
+  if (rc) return rc;
   // whatever follows on a shard's stream (the next run writes the same planes) comes after its gathers
   for (int k = 0; k < n; k++) {
     NODE_HIP(hipSetDevice(nd->devices[k]));
