@@ -98,3 +98,18 @@ def test_fuzz_optional_physics_cooperative_kernels():
     print(r.stdout[-3000:])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "60 trials ok" in r.stdout and "stepCoopX" in r.stdout and "stepCoopNX" in r.stdout
+
+
+@pytest.mark.parametrize("campaign", ["FUZZ_COOP", "FUZZ_OPT", "FUZZ_NCYC", ""], ids=["coop", "opt", "ncyc", "all"])
+def test_fuzz_sites_of_different_lengths(campaign):
+    """a fixed-seed slice with FUZZ_RAGGED=1 on top of each campaign: 2-8 sites per batch whose forcings end at
+    different records (one step, one step around a 16-step tile, anywhere), the launch cut before, at and after those
+    ends, every kernel family; each site against the oracle run over ITS forcing"""
+    env = dict(os.environ, FUZZ_RAGGED="1", FUZZ_BOUNDED="1")
+    if campaign:
+        env[campaign] = "1"
+    r = subprocess.run([sys.executable, os.path.join(helpers.REPO, "tools", "fuzz_gpu.py"), "30", "515"],
+                       capture_output=True, text=True, timeout=1200, env=env)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "30 trials ok" in r.stdout

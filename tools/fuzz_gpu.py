@@ -26,6 +26,9 @@ NCYC_ONLY = bool(os.environ.get("FUZZ_NCYC"))
 # stepCoopNXKernel & co: run-time flags): always some optional flag on, throughput arithmetic, lean launches, the
 # one- and two-chunk layouts forced in turn or picked by the shape policy, regular tiles on and off, fragile stands
 OPT_ONLY = bool(os.environ.get("FUZZ_OPT"))
+# FUZZ_RAGGED=1 (on top of any of the above, or alone): every trial has several sites and the sites' forcings end at
+# different records (a site's members stop at ITS last record; the launch cuts fall before, at and after those ends)
+RAGGED = bool(os.environ.get("FUZZ_RAGGED"))
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
 only = int(sys.argv[3]) if len(sys.argv) > 3 else -1      # rerun one trial with details
@@ -97,12 +100,19 @@ for trial in range(trials):
     start = int(rng.integers(0, 300)) * 48
     S = int(rng.choice([1, 1, 1, 2, 3, 8]))            # sites (8: the XCD-aware block mapping)
     site0 = int(rng.integers(0, 5))
+    site_T = [T] * S
+    if RAGGED:      # (a generator of its own: the trials of the other campaigns stay what their seeds made them)
+        rng_r = np.random.default_rng(seed0 * 7919 + trial)
+        S = int(rng_r.choice([2, 3, 5, 8]))
+        site_T = [int(x) for x in rng_r.integers(1, T + 1, size=S)]
+        if rng_r.random() < 0.3: site_T[0] = int(rng_r.choice([1, 15, 16, 17, 47]))
+        site_T[int(rng_r.integers(1, S))] = T          # the batch is as long as its longest site
     clims = []
     for sidx in range(S):
         raw = synth.half_hourly_year_raw(start + T, site=site0 + sidx)
-        raw = {k: v[start:] for k, v in raw.items()}
+        raw = {k: v[start:start + site_T[sidx]] for k, v in raw.items()}
         clims.append(synth.convert_raw(synth.round_like_file(raw)))
-    clim = clims[0]
+    clim = clims[int(np.argmax(site_T))]     # (the longest: the event schedule spans it)
     members = synth.perturbed_params(base, M, seed=int(rng.integers(1 << 30)), scale=float(rng.choice([1.0, 3.0])))
     if M > 3:      # a few hard cases
         members[1, pi("plantWoodInit")] *= 0.001        # barely alive
@@ -133,7 +143,9 @@ for trial in range(trials):
     fast = bool(rng.random() < 0.7) or COOP_ONLY or NCYC_ONLY or OPT_ONLY
     prec = sa.F32_MIXED if (fast and rng.random() < 0.25) else sa.F64
     runs = [oracle.run_block(flags, members, c, ev) for c in clims]
-    want = np.concatenate([r[0] for r in runs], axis=2)
+    # (rows past a site's last record: nothing is computed there, neither side is looked at)
+    want = np.concatenate([np.concatenate([r[0], np.zeros((3, T - r[0].shape[1], M))], axis=1) for r in runs], axis=2)
+    valid = np.concatenate([np.repeat((np.arange(T) < tl)[:, None], M, axis=1) for tl in site_T], axis=1)
     final = np.concatenate([r[1] for r in runs], axis=0)
     st = np.concatenate([r[2] for r in runs])
     # kernel choice: default policy, or forced one-wave / HBM-ring cooperative / run-time flags
@@ -181,6 +193,7 @@ for trial in range(trials):
     cuts = sorted(set([0, T] + [int(x) for x in rng.integers(1, T, size=int(rng.integers(0, 4)))]))
     runs_g = [b.run(a0, a1 - a0, full=want_full) for a0, a1 in zip(cuts[:-1], cuts[1:])]
     got = torch.cat([r_[0] for r_ in runs_g], dim=1).double().cpu().numpy()
+    got = np.where(valid[None], got, 0.0)
     if want_full:
         rec_g = torch.cat([r_[1] for r_ in runs_g], dim=0).cpu().numpy()
         diag_g = b.get_diagnostics()
@@ -209,7 +222,7 @@ for trial in range(trials):
             assert so == 0
             cs = np.maximum(np.abs(rec_o).max(axis=0), 1e-3)
             rtol = 1e-9 if prec == sa.F64 else 5e-3
-            rel_ = np.abs(rec_g[:, :36, m] - rec_o) / cs
+            rel_ = np.abs(rec_g[:site_T[0], :36, m] - rec_o) / cs
             rerr = rel_.max()
             if prec == sa.F32_MIXED and rerr < 5e-2 and float((rel_ > rtol).mean()) < 1e-4:
                 rerr = 0.0      # fp32 flux arithmetic: a threshold branch taken a step apart, judged by share (as the planes are)
