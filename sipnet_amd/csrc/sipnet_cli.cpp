@@ -15,7 +15,8 @@
 // Additive extension (never changes single-run behaviour):
 //   --devices LIST           HIP devices the ensemble shards across (0-7, 0,2,3; default 0): member
 //                            rows are split into contiguous ranges, one host thread + one batch
-//                            per device, every shard writes its own members' files
+//                            per device, every shard writes its own members' files; with --sites:
+//                            the sites of a flag set in contiguous ranges, one batch per device
 //   --math strict|fast|auto  step-kernel arithmetic: strict = the reference's operation order (the
 //                            default for a single run), fast = the throughput kernels (the default
 //                            with --ensemble-params)
@@ -335,7 +336,7 @@ void resolveRun(SiteRun& r) {
   }
 }
 
-int runSites(const Context& cliCtx, const std::string& listFile, const std::string& mathArg, int device) {
+int runSites(const Context& cliCtx, const std::string& listFile, const std::string& mathArg, const std::vector<int>& devices) {
   std::vector<std::string> dirs;
   {
     std::ifstream in(listFile);
@@ -361,9 +362,10 @@ int runSites(const Context& cliCtx, const std::string& listFile, const std::stri
     resolveRun(runs[k]);
   }
   if (chdir(cwd0) != 0) die(1, "cannot return to the start directory\n");
-  if (device >= sipnet_device_count())
-    die(1, "--devices names device " + std::to_string(device) + " but only " + std::to_string(sipnet_device_count()) +
-               " HIP device(s) are visible (this engine has no CPU path)\n");
+  for (int device : devices)
+    if (device >= sipnet_device_count())
+      die(1, "--devices names device " + std::to_string(device) + " but only " + std::to_string(sipnet_device_count()) +
+                 " HIP device(s) are visible (this engine has no CPU path)\n");
   const bool fastMath = mathArg == "fast";
   // batches: same model flags and step count; inside a batch, runs with identical forcing are members of ONE site
   std::vector<char> done(runs.size(), 0);
@@ -383,15 +385,30 @@ int runSites(const Context& cliCtx, const std::string& listFile, const std::stri
         }
       if (!placed) sites.push_back({(int)k});
     }
+    // the sites of a flag set are dealt to the listed devices in contiguous ranges (whole sites per device, as
+    // SIPNET_SHARD_SITES does: a site's forcing, events and plan exist on one device only); each range is one batch,
+    // driven by a host thread of its own
+    const int nParts = std::max(1, std::min((int)devices.size(), (int)sites.size()));
+    const std::vector<std::vector<int>> allSites = sites;
+    std::vector<int> partWorst(nParts, 0);
+    std::mutex batchMutex;
+    auto runPart = [&](int part) {
+    const std::vector<std::vector<int>> sites(allSites.begin() + (size_t)allSites.size() * part / nParts,
+                                              allSites.begin() + (size_t)allSites.size() * (part + 1) / nParts);
+    const int device = devices[part];
+    int worst = 0;
     const int S = (int)sites.size();
     int M = 0, T = 0;   // T: the longest forcing of the batch (its sites may be shorter)
     for (auto& st : sites) {
       M = std::max(M, (int)st.size());
       T = std::max(T, runs[st[0]].T);
     }
-    nBatches++;
-    logInfo("batch " + std::to_string(nBatches) + ": " + std::to_string(S) + " site(s) x up to " + std::to_string(M) +
-            " member(s), up to " + std::to_string(T) + " steps\n");
+    {
+      std::lock_guard<std::mutex> lock(batchMutex);
+      nBatches++;
+      logInfo("batch " + std::to_string(nBatches) + " (device " + std::to_string(device) + "): " + std::to_string(S) +
+              " site(s) x up to " + std::to_string(M) + " member(s), up to " + std::to_string(T) + " steps\n");
+    }
     sipnet_batch* b = nullptr;
     check(sipnet_batch_create(runs[lead].flags, S, M, SIPNET_F64, device, &b), "creating batch");
     check(sipnet_batch_set_math(b, fastMath ? SIPNET_MATH_FAST : SIPNET_MATH_STRICT), "math policy");
@@ -470,7 +487,7 @@ int runSites(const Context& cliCtx, const std::string& listFile, const std::stri
       cpu_set_t cpus;
       if (sched_getaffinity(0, sizeof cpus, &cpus) == 0) hostThreads = CPU_COUNT(&cpus);
     }
-    const int nThreads = std::max(1, std::min({hostThreads, (int)jobs.size(), 64}));
+    const int nThreads = std::max(1, std::min({hostThreads / nParts, (int)jobs.size(), 64}));
     if (nThreads == 1) {
       worker();
     } else {
@@ -479,6 +496,16 @@ int runSites(const Context& cliCtx, const std::string& listFile, const std::stri
       for (auto& th : pool) th.join();
     }
     worst = std::max(worst, worstA.load());
+    partWorst[part] = worst;
+    };   // runPart
+    if (nParts == 1) {
+      runPart(0);
+    } else {
+      std::vector<std::thread> parts;
+      for (int p = 0; p < nParts; p++) parts.emplace_back(runPart, p);
+      for (auto& th : parts) th.join();
+    }
+    for (int w : partWorst) worst = std::max(worst, w);
   }
   logInfo(std::to_string(runs.size()) + " run(s) in " + std::to_string(nBatches) + " batch(es)\n");
   for (auto& r : runs) {
@@ -553,7 +580,7 @@ int main(int argc, char** argv) {
       logError("--sites does not combine with --ensemble-params / --ensemble-stats\n");
       return 8;
     }
-    return runSites(ctx, sitesFile, mathArg, devices[0]);
+    return runSites(ctx, sitesFile, mathArg, devices);
   }
   if (ctx.s("filePrefix").empty()) die(3, "filePrefix must be set for SIPNET to run\n");
   readInputFile(ctx);

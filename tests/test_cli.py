@@ -214,12 +214,13 @@ def test_cli_sites_option_errors_need_no_gpu(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("math", ["auto", "fast"])
-def test_cli_sites_stacks_run_directories_into_shared_batches(tmp_path, math):
+@pytest.mark.parametrize("math,devices", [("auto", "0"), ("fast", "0"), ("auto", "0,0,0")], ids=["auto", "fast", "auto-3-shards"])
+def test_cli_sites_stacks_run_directories_into_shared_batches(tmp_path, math, devices):
     """`sipnet --sites runs.txt`: the reference's five smoke directories (three flag sets, two step counts) plus three
     re-parameterised copies of russell_1 (same forcing: members of ONE site) in one process.  Every directory gets
     the files its own run writes: with --math auto (strict kernel) byte-identical to the reference's goldens and to
-    separate runs; with --math fast (throughput kernels) to the last printed digit"""
+    separate runs; with --math fast (throughput kernels) to the last printed digit; with --devices naming several
+    shards the same files"""
     import gzip
     dirs = []
     for case in helpers.SMOKE_CASES:
@@ -236,8 +237,12 @@ def test_cli_sites_stacks_run_directories_into_shared_batches(tmp_path, math):
         open(d / "sipnet.param", "w").write("\n".join(txt) + "\n")
         dirs.append(f"ens{k}")
     open(tmp_path / "runs.txt", "w").write("# the smoke cases and an ensemble\n" + "\n".join(dirs) + "\n")
-    r = run_cli(tmp_path, "--sites", "runs.txt", "-i", "sipnet.in", "--math", math)   # (options apply to every directory)
+    # (options apply to every directory; --devices deals the sites of a flag set to the devices, one batch and one
+    # host thread each -- here three shards on device 0)
+    r = run_cli(tmp_path, "--sites", "runs.txt", "-i", "sipnet.in", "--math", math, "--devices", devices)
     assert r.returncode == 0, r.stdout + r.stderr
+    if devices != "0":
+        assert r.stdout.count("(device 0)") > 3, r.stdout
     # russell_1 + its three copies share one site (4 members); russell_1/4-like flag sets and niwot's step count differ
     assert "8 run(s) in" in r.stdout and "4 member(s)" in r.stdout, r.stdout
 
