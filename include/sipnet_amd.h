@@ -619,7 +619,8 @@ int32_t *sipnet_node_pf_ancestors(sipnet_node *nd, int32_t k);
 int64_t sipnet_node_pf_block_len(const sipnet_node *nd);
 
 int64_t sipnet_batch_ncol(const sipnet_batch *b);
-int32_t sipnet_batch_nsteps(const sipnet_batch *b);
+int32_t sipnet_batch_nsteps(const sipnet_batch *b);                     /* the longest site's record count */
+int32_t sipnet_batch_site_nsteps(const sipnet_batch *b, int32_t site);  /* this site's (0: no forcing set yet) */
 /* Site-uniform trajectory computed by the plan: gdd[t] (trackers.gdd after
  * step t) and d_till_mod[t] (eventTrackers.d_till_mod used in step t). */
 int sipnet_batch_get_site_series(sipnet_batch *b, int32_t site, double *gdd,

@@ -187,6 +187,7 @@ SIGNATURES = {
     "sipnet_node_gathered_segment": (_P, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "sipnet_batch_ncol": (C.c_int64, [_P]),
     "sipnet_batch_nsteps": (C.c_int32, [_P]),
+    "sipnet_batch_site_nsteps": (C.c_int32, [_P, C.c_int32]),
     "sipnet_batch_get_site_series": (C.c_int, [_P, C.c_int32, _P, _P]),
     "sipnet_batch_last_kernel_ms": (C.c_double, [_P]),
     "sipnet_dev_alloc": (_P, [C.c_size_t]),

@@ -1347,6 +1347,9 @@ int sipnet_batch_export_restart(sipnet_batch* b, int32_t site, int32_t member,
 
 int64_t sipnet_batch_ncol(const sipnet_batch* b) { return b ? b->ncol : 0; }
 int32_t sipnet_batch_nsteps(const sipnet_batch* b) { return b ? b->n_steps : 0; }
+int32_t sipnet_batch_site_nsteps(const sipnet_batch* b, int32_t site) {
+  return (b && site >= 0 && site < b->n_sites) ? (int32_t)b->year[site].size() : 0;
+}
 
 int sipnet_batch_get_site_series(sipnet_batch* b, int32_t site, double* gdd,
                                  double* d_till_mod) {

@@ -560,6 +560,15 @@ static int growRunBuffers(sipnet_node* nd, int k, int32_t n_steps) {
   return SIPNET_OK;
 }
 
+// does a site of shard k end before record `upTo`?  Then the kernels leave rows of the shard's planes unwritten, and
+// what stands there depends on the layout of the run before (plain or segmented): such a shard's planes are cleared
+// at the start of every run
+static bool shardEndsEarly(const sipnet_node* nd, int k, int32_t upTo) {
+  for (int32_t s = 0; s < nd->nSites[k]; s++)
+    if (sipnet_batch_site_nsteps(nd->batches[k], s) < upTo) return true;
+  return false;
+}
+
 static int runShards(sipnet_node* nd, int32_t step0, int32_t n_steps, bool withStats) {
   if (!nd || n_steps <= 0) {
     setError("sipnet_node_run: bad argument");
@@ -574,6 +583,7 @@ static int runShards(sipnet_node* nd, int32_t step0, int32_t n_steps, bool withS
     }
     char* p = (char*)nd->planes[k];
     const size_t one = (size_t)n_steps * nd->ld * nd->elem();
+    if (!grow && shardEndsEarly(nd, k, step0 + n_steps)) NODE_HIP(hipMemsetAsync(p, 0, 3 * one, nd->streams[k]));
     // (site shards may hold forcings of different lengths: a shard runs to the end of ITS longest site; the rows
     // past it stay what they are -- zero -- in the common [n_steps] layout)
     const int32_t have = sipnet_batch_nsteps(nd->batches[k]);
@@ -658,6 +668,8 @@ static int runGathering(sipnet_node* nd, int32_t step0, int32_t n_steps, int32_t
   // threads meeting at a host barrier per segment)
   rc = onEveryShard(nd, [&](int k) -> int {
     const int32_t have = sipnet_batch_nsteps(nd->batches[k]);
+    if (!grow && shardEndsEarly(nd, k, step0 + n_steps))
+      NODE_HIP(hipMemsetAsync(nd->planes[k], 0, count * nd->elem(), nd->streams[k]));
     for (int j = 0; j < n_segments; j++) {
       const int32_t a = cuts[j], len = cuts[j + 1] - a;
       const size_t one = (size_t)len * nd->ld * nd->elem();              // one variable of the segment
@@ -665,7 +677,6 @@ static int runGathering(sipnet_node* nd, int32_t step0, int32_t n_steps, int32_t
       char* p = (char*)nd->planes[k] + segOff;
       const int32_t nLoc = step0 + a + len <= have ? len : have - (step0 + a);
       // (a site shard whose forcings end inside the segment: the rows past its end travel as zeros)
-      if (nLoc < len) NODE_HIP(hipMemsetAsync(p, 0, 3 * one, nd->streams[k]));
       if (nLoc > 0) {
         int rcr = sipnet_batch_run(nd->batches[k], step0 + a, nLoc, p, p + one, p + 2 * one, nullptr, nd->ld, nd->streams[k]);
         if (rcr) return rcr;   // (every shard fails alike -- same arguments -- so nobody is left at the barrier)

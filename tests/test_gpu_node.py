@@ -150,6 +150,44 @@ def test_run_gathering_overlapped_plane_gather_equals_one_batch(base, devices, s
     nd.close()
 
 
+def test_site_shards_with_sites_of_different_lengths(base):
+    """five sites whose forcings end at different records on three site shards (1 + 2 + 2 sites; the shards' longest
+    sites differ too): planes, statistics and the overlapped plane gather equal ONE batch of the five sites bit for
+    bit, and the rows past a site's end are zero in everything the node owns"""
+    M, T = 70, 48 * 6
+    lengths = [T // 2, T, 100, 37, T - 16]
+    flags = sa.flags_from()
+    clims = []
+    for s_, tl in enumerate(lengths):
+        raw = synth.half_hourly_year_raw(T, site=s_)
+        clims.append(synth.convert_raw(synth.round_like_file({k: v[:tl] for k, v in raw.items()})))
+    members = synth.perturbed_params(base, M)
+    b = one_batch(flags, clims, members)
+    assert b.n_steps == T
+    planes = torch.zeros((3, T, 5 * M), dtype=torch.float64, device=DEV)
+    _, stats = b.run_stats(0, T, planes=planes)
+    want = planes.cpu().numpy().reshape(3, T, 5, M)
+    want_stats = stats.cpu().numpy()
+    b.close()
+    for s_, tl in enumerate(lengths):
+        assert (want[:, tl:, s_] == 0).all() and (want_stats[:, tl:, s_] == 0).all() and np.abs(want[0, :tl, s_]).max() > 0
+
+    nd = Node(flags, 5, M, devices=[0, 0, 0], shard=SHARD_SITES, fast_math=True)
+    for s_ in range(5):
+        nd.set_climate(s_, clims[s_])
+    nd.set_params(None, members)
+    nd.setup()
+    nd.run(0, T)
+    np.testing.assert_array_equal(nd.gather_stats(), want_stats)
+    np.testing.assert_array_equal(nd.member_planes(), want)
+    nd.setup()
+    nd.run_gathering(0, T, 4)                      # cuts at 64, 144, 208: inside, at and past the sites' ends
+    for k in range(nd.n):
+        np.testing.assert_array_equal(nd.gathered_member_planes(k), want)
+    assert (nd.status() == 0).all()
+    nd.close()
+
+
 def test_member_sharded_node_with_ragged_shards_equals_one_batch(base):
     """SIPNET_SHARD_MEMBERS over three shards, 200 members (67 / 66 / 67) at two sites: the summed statistics equal
     one batch's up to the order of the additions, the planes bit for bit; column layout site * count_k + member"""
