@@ -589,6 +589,24 @@ __device__ unsigned long long g_coopWaits[16];
 //                                                                moisture term / (baseSoilResp x (1 + tillage)), so
 //                                                                that C's methane = rate x pool x qSoilT x row 6
 // Same waves, same hand-overs as the default layouts (one more factor row); lean state only.
+// the code phase of an instantiation: s_nop count after the 32-byte boundary in coopBody's prologue (see there)
+template <class R, bool PlainExp, bool RingLds, bool Full, int NP, bool NCyc, bool Ext>
+__device__ constexpr int coopCodePhase() {
+#ifdef SIPNET_PAD_NOPS
+  return SIPNET_PAD_NOPS;
+#else
+  // measured on the instantiations the workloads launch (tools/gpu_phase_sweep.sh, profiles/r04_phase_sweep.txt:
+  // best against worst phase 1.5-5 %); relatives that were not measured take their family's value
+  constexpr bool f64 = sizeof(R) == 8;
+  if (NCyc) return 4;                          // N f64 12.98 -> 12.64 ms, NPair f64 15.19 -> 15.10
+  if (Ext) return 4;                           // X (LDS ring) f64 9.68 -> 9.54
+  if (NP == 4) return f64 ? 6 : 3;             // quad f32 9.26 -> 9.23 (9.36 at the worst phase), quad f64 18.44 -> 17.44
+  if (NP == 2) return Full ? 0 : f64 ? 4 : 7;  // pair f64 9.76 -> 9.72 (9.91 at the worst), pair f32 8.90 -> 8.85 (9.17)
+  if (!RingLds) return 0;                      // HBM ring f64 9.34 (9.59 at the worst)
+  return (Full || f64) ? 3 : 4;                // LDS ring f64 8.51 -> 8.32, its full-state build 14.71 -> 14.21, f32 8.15 -> 8.08
+#endif
+}
+
 template <class R, bool PlainExp, bool RingLds, bool Full, int NP, bool NCyc = false, bool Ext = false>
 __device__ __forceinline__ void coopBody(const FastArgs& a) {
   static_assert(!(NP > 1 && RingLds), "two chunks' rings do not fit one CU's LDS");
@@ -773,6 +791,11 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   const int siteSteps = uni(a.siteBase[3 * site + 2]);
   const int tBegin = a.step0, tEnd = a.step0 + a.n_steps < siteSteps ? a.step0 + a.n_steps : siteSteps;
   present = present && tBegin < tEnd;
+  // Where the loops lie in the instruction cache's 32-byte fetch windows is worth +-1.5 % of the step (a lone wave
+  // pays every taken branch with a fetch; NOTES.md "Round 4: code placement"): everything from here on starts at a
+  // 32-byte boundary plus a per-instantiation number of s_nop (4 bytes each), measured -- not at wherever the
+  // prologue happens to end.  -DSIPNET_PAD_NOPS=k overrides it for all instantiations (tools/build_variants.py).
+  asm volatile(".p2align 5\n .rept %0\n s_nop 0\n .endr" ::"n"(coopCodePhase<R, PlainExp, RingLds, Full, NP, NCyc, Ext>()));
   if (role == 0) {
     if (lane == 0) {
       seqLai = tBegin - 1;
