@@ -590,8 +590,39 @@ __device__ unsigned long long g_coopWaits[16];
 //                                                                that C's methane = rate x pool x qSoilT x row 6
 // Same waves, same hand-overs as the default layouts (one more factor row); lean state only.
 // the code phase of an instantiation: s_nop count after the 32-byte boundary in coopBody's prologue (see there)
+// (role: 0 carbon, 1 water, 2 light, 3 factor / soil wave -- each wave's code starts at a boundary of its own --
+// 4 the common prologue)
 template <class R, bool PlainExp, bool RingLds, bool Full, int NP, bool NCyc, bool Ext>
-__device__ constexpr int coopCodePhase() {
+__device__ constexpr int coopCodePhase(int role) {
+#ifdef SIPNET_PH_C
+  if (role == 0) return SIPNET_PH_C;
+#endif
+#ifdef SIPNET_PH_W
+  if (role == 1) return SIPNET_PH_W;
+#endif
+#ifdef SIPNET_PH_L
+  if (role == 2) return SIPNET_PH_L;
+#endif
+#ifdef SIPNET_PH_F
+  if (role == 3) return SIPNET_PH_F;
+#endif
+  if (role == 0) {   // the carbon wave (profiles/r04_phase_sweep_roles.txt)
+    if (NCyc) return 0;
+    if (Ext) return 7;
+    if (NP == 2) return 2;
+    if (NP == 1 && RingLds) return Full ? 4 : 6;
+    return 0;
+  }
+  if (role == 1) {   // the water wave
+    if (NCyc) return 0;
+    if (Ext) return 1;                            // X (LDS ring) f64 9.65 -> 9.49
+    if (NP == 2) return 4;
+    if (NP == 1 && RingLds) return Full ? 5 : 6;
+    return 0;
+  }
+  if (role == 2) return (NP == 1 && RingLds && !Full && !NCyc && !Ext) ? 3 : 0;   // the light wave has slack: +-0.3 %
+  if (role == 3) return (NCyc && NP == 1) ? 4 : 0;   // the soil wave: N f64 12.78 -> 12.69 (13.0 at its worst phases)
+  if (role != 4) return 0;
 #ifdef SIPNET_PAD_NOPS
   return SIPNET_PAD_NOPS;
 #else
@@ -795,7 +826,9 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   // pays every taken branch with a fetch; NOTES.md "Round 4: code placement"): everything from here on starts at a
   // 32-byte boundary plus a per-instantiation number of s_nop (4 bytes each), measured -- not at wherever the
   // prologue happens to end.  -DSIPNET_PAD_NOPS=k overrides it for all instantiations (tools/build_variants.py).
-  asm volatile(".p2align 5\n .rept %0\n s_nop 0\n .endr" ::"n"(coopCodePhase<R, PlainExp, RingLds, Full, NP, NCyc, Ext>()));
+#define COOP_CODE_PHASE(ROLE) \
+  asm volatile(".p2align 5\n .rept %0\n s_nop 0\n .endr" ::"n"(coopCodePhase<R, PlainExp, RingLds, Full, NP, NCyc, Ext>(ROLE)))
+  COOP_CODE_PHASE(4);
   if (role == 0) {
     if (lane == 0) {
       seqLai = tBegin - 1;
@@ -1070,6 +1103,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   // and the step's values are read back with v_readlane.
   if (FacWave && role == 3) {
 #pragma clang fp contract(off)  // same bits as the light wave's copy of this block (see there)
+    COOP_CODE_PHASE(3);
     const R K_frozThr = (R)PRM(frozenSoilThreshold);
     const R K_lgVeg = (R)log2(PRM(vegRespQ10)), K_lgSoil = (R)log2(PRM(soilRespQ10));
     const R K_lgFine = (R)log2(PRM(fineRootQ10)), K_lgCoarse = (R)log2(PRM(coarseRootQ10));
@@ -1158,6 +1192,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   // divisions through v_rcp + Newton.  Of the site record it needs the step length and the event
   // count only.
   if (NCyc && role == 3) {
+    COOP_CODE_PHASE(3);
     const R K_bsr = (R)PRM(baseSoilResp);
     const R G_lbr = (R)PRM(litterBreakdownRate), G_flr = (R)PRM(fracLitterRespired);
     const R G_nVol = (R)PRM(nVolatilizationFrac), G_nLeach = (R)PRM(nLeachingFrac);
@@ -1461,6 +1496,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
     // others): so no implicit fusion in this wave, constants included; the FMAs that matter are
     // written out below
 #pragma clang fp contract(off)
+    COOP_CODE_PHASE(2);
     // ---- L: potPsn() + calcLightEff(), sipnet.c:517-641 -------------------------------------
     const double leafCSpWt = PRM(leafCSpWt);
     const double convK = kCWeight * (1.0 / kTen9) * (leafCSpWt / PRM(cFracLeaf)) * kSecPerDay;
@@ -1580,6 +1616,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
 
   // =============================================================================================
   if (role == 1) {
+    COOP_CODE_PHASE(1);
     // ---- W: moisture(), calcPrecip(), snowPack(), calcSoilWaterFluxes(), sipnet.c:656-1031 ----
     const R K_tr = (R)(1000.0 * (44.0 / 12.0) * (1.0 / 10000.0) / PRM(wueConst));
     const R K_whc = (R)PRM(soilWHC), K_invWhc = (R)(1.0 / PRM(soilWHC));
@@ -1847,6 +1884,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
 
   // =============================================================================================
   // ---- C: carbon fluxes, pools, trackers, running mean (sipnet.c:756-842, 1051-1196, 1420-1806)
+  COOP_CODE_PHASE(0);
   const R K_invLcsw = (R)(1.0 / PRM(leafCSpWt));
   const R K_wtr = (R)PRM(woodTurnoverRate), K_ltr = (R)PRM(leafTurnoverRate);
   const R K_frt = (R)PRM(fineRootTurnoverRate), K_crt = (R)PRM(coarseRootTurnoverRate);
