@@ -96,6 +96,10 @@ class Batch:
               "set_climate")
         self.n_steps = int(self.L.sipnet_batch_nsteps(self.h))     # the longest site's (sites may differ in length)
 
+    def site_n_steps(self, site):
+        """the number of records of this site's forcing (self.n_steps is the longest site's)"""
+        return int(self.L.sipnet_batch_site_nsteps(self.h, site))
+
     def set_events(self, site, events):
         n = len(events)
         arr = (Event * max(n, 1))(*events)

@@ -448,7 +448,7 @@ def test_sites_of_different_lengths_in_one_batch(name, fast, kernel):
         b.set_climate(s, clims[s])
         b.set_params(s, members)
     b.setup()
-    assert b.n_steps == 4800
+    assert b.n_steps == 4800 and [b.site_n_steps(s) for s in range(3)] == lens
     T = 4800
     planes = torch.full((3, T, 3 * M), -7.0, dtype=torch.float64, device="cuda")
     stats = torch.zeros((3, T, 3, 2), dtype=torch.float64, device="cuda")
