@@ -96,17 +96,31 @@ struct HostBarrier {
   std::condition_variable cv;
   int n = 1, waiting = 0;
   uint64_t phase = 0;
-  void arrive() {
-    if (n <= 1) return;
+  bool broken = false;   // a shard's task failed: nobody waits for it any more (reset per task)
+  // false: a shard has failed, the others give up too
+  bool arrive() {
+    if (n <= 1) return true;
     std::unique_lock<std::mutex> lk(mu);
+    if (broken) return false;
     const uint64_t p = phase;
     if (++waiting == n) {
       waiting = 0;
       phase++;
       cv.notify_all();
     } else {
-      cv.wait(lk, [&] { return phase != p; });
+      cv.wait(lk, [&] { return phase != p || broken; });
     }
+    return !broken;
+  }
+  void fail() {
+    std::lock_guard<std::mutex> lk(mu);
+    broken = true;
+    cv.notify_all();
+  }
+  void reset() {
+    std::lock_guard<std::mutex> lk(mu);
+    broken = false;
+    waiting = 0;
   }
 };
 
@@ -186,6 +200,7 @@ struct sipnet_node {
 
 static void runShardTask(sipnet_node* nd, int k) {
   nd->rc[k] = nd->task(k);
+  if (nd->rc[k] != SIPNET_OK) nd->bar.fail();   // the other shards must not wait for this one at a barrier
   nd->msg[k] = nd->rc[k] != SIPNET_OK ? sipnet_last_error() : "";   // thread-local: carry it to the caller's thread
 }
 
@@ -218,6 +233,7 @@ template <class F>
 static int onEveryShard(sipnet_node* nd, F f) {
   const int n = nd->n();
   nd->task = f;
+  nd->bar.reset();
   if (n == 1) {
     if (hipSetDevice(nd->devices[0]) != hipSuccess) {
       setError("sipnet_node: hipSetDevice failed");
@@ -232,11 +248,13 @@ static int onEveryShard(sipnet_node* nd, F f) {
     nd->cvDone.wait(lk, [&] { return nd->pending == 0; });
   }
   nd->task = nullptr;
-  for (int k = 0; k < n; k++)
-    if (nd->rc[k] != SIPNET_OK) {
-      setError("device " + std::to_string(nd->devices[k]) + " (shard " + std::to_string(k) + "): " + nd->msg[k]);
-      return nd->rc[k];
-    }
+  // (a shard that only gave up at a barrier because another one failed does not hide that one's message)
+  for (int pass = 0; pass < 2; pass++)
+    for (int k = 0; k < n; k++)
+      if (nd->rc[k] != SIPNET_OK && (pass == 1 || nd->msg[k].find("another shard failed") == std::string::npos)) {
+        setError("device " + std::to_string(nd->devices[k]) + " (shard " + std::to_string(k) + "): " + nd->msg[k]);
+        return nd->rc[k];
+      }
   return SIPNET_OK;
 }
 
@@ -252,7 +270,10 @@ static int allGatherShard(sipnet_node* nd, int k, const void* send, void* recv, 
   }
   nd->agSend[k] = send;
   NODE_HIP(hipEventRecord(nd->evReady[k], stream));
-  nd->bar.arrive();
+  if (!nd->bar.arrive()) {
+    setError("sipnet_node: another shard failed");
+    return SIPNET_ERR_INTERNAL;
+  }
   for (int s = 0; s < n; s++) {
     char* dst = (char*)recv + (size_t)s * bytes;
     if (s != k) NODE_HIP(hipStreamWaitEvent(stream, nd->evReady[s], 0));
@@ -260,7 +281,10 @@ static int allGatherShard(sipnet_node* nd, int k, const void* send, void* recv, 
       NODE_HIP(hipMemcpyAsync(dst, nd->agSend[s], bytes, hipMemcpyDeviceToDevice, stream));
   }
   NODE_HIP(hipEventRecord(nd->evCopied[k], stream));
-  nd->bar.arrive();
+  if (!nd->bar.arrive()) {
+    setError("sipnet_node: another shard failed");
+    return SIPNET_ERR_INTERNAL;
+  }
   // what follows on this stream may overwrite the block the others copy from
   for (int s = 0; s < n; s++)
     if (s != k) NODE_HIP(hipStreamWaitEvent(stream, nd->evCopied[s], 0));
@@ -679,7 +703,7 @@ static int runGathering(sipnet_node* nd, int32_t step0, int32_t n_steps, int32_t
       // (a site shard whose forcings end inside the segment: the rows past its end travel as zeros)
       if (nLoc > 0) {
         int rcr = sipnet_batch_run(nd->batches[k], step0 + a, nLoc, p, p + one, p + 2 * one, nullptr, nd->ld, nd->streams[k]);
-        if (rcr) return rcr;   // (every shard fails alike -- same arguments -- so nobody is left at the barrier)
+        if (rcr) return rcr;   // (the barrier is told: the other shards give up at their next arrival)
       }
       NODE_HIP(hipEventRecord(nd->evSeg[k], nd->streams[k]));
       NODE_HIP(hipStreamWaitEvent(nd->gatherStreams[k], nd->evSeg[k], 0));

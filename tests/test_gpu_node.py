@@ -188,6 +188,33 @@ def test_site_shards_with_sites_of_different_lengths(base):
     nd.close()
 
 
+@pytest.mark.timeout(180)
+def test_a_failing_shard_does_not_leave_the_others_at_the_barrier(base):
+    """two site shards on one device (event-ordered all-gathers: the shards' threads meet at a host barrier per
+    segment); a new forcing for a site of shard 0 without a new setup makes THAT shard's launch fail -- the call
+    returns its error (the other shard gives up at the barrier instead of waiting for ever), and after setup the same
+    node runs again"""
+    M, T = 64, 48 * 3
+    flags = sa.flags_from()
+    clims = site_clims(4, T)
+    members = synth.perturbed_params(base, M)
+    nd = Node(flags, 4, M, devices=[0, 0], shard=SHARD_SITES, fast_math=True)
+    for s in range(4):
+        nd.set_climate(s, clims[s])
+    nd.set_params(None, members)
+    nd.setup()
+    nd.run_gathering(0, T, 3)
+    want = nd.gathered_member_planes(1)
+    nd.set_climate(0, clims[0])                     # shard 0's plan is stale now, shard 1's is not
+    with pytest.raises(sa.SipnetError) as e:
+        nd.run_gathering(0, T, 3)
+    assert "shard 0" in str(e.value) and "sipnet_batch_setup" in str(e.value), str(e.value)
+    nd.setup()
+    nd.run_gathering(0, T, 3)
+    np.testing.assert_array_equal(nd.gathered_member_planes(0), want)
+    nd.close()
+
+
 def test_member_sharded_node_with_ragged_shards_equals_one_batch(base):
     """SIPNET_SHARD_MEMBERS over three shards, 200 members (67 / 66 / 67) at two sites: the summed statistics equal
     one batch's up to the order of the additions, the planes bit for bit; column layout site * count_k + member"""
