@@ -90,6 +90,30 @@ int main(int argc, char **argv) {
   printf("stats_vs_planes_max_abs=%.3e\nsum_nee_ensemble=%.10f\nsum_nee_member_0=%.10f\nsum_nee_member_last=%.10f\n",
          worst, yearNee, yearNee0, yearNeeLast);
   printf("kernel=%s\n", sipnet_batch_last_kernel_name(sipnet_node_batch(nd, 0)));
+
+  /* the same exchange overlapped with the computation: the run in 3 segments, each all-gathered on the shards'
+   * second streams under the next segment's kernel -- the last device's copy must hold the planes gathered above */
+  rc = sipnet_node_setup(nd);
+  if (!rc) rc = sipnet_node_run_gathering(nd, 0, T, 3);
+  if (!rc) rc = sipnet_node_sync(nd);
+  if (rc) { printf("run_gathering=%d %s\n", rc, sipnet_last_error()); return 1; }
+  int segmentsEqual = sipnet_node_n_segments(nd) == 3, covered = 0;
+  for (int32_t j = 0; j < sipnet_node_n_segments(nd); j++) {
+    int32_t first = -1, len = 0;
+    void *dev = sipnet_node_gathered_segment(nd, nDev - 1, j, &first, &len);
+    if (!dev || first != covered || len <= 0) { segmentsEqual = 0; break; }
+    double *seg = (double *)malloc(sizeof(double) * (size_t)nDev * 3 * (size_t)len * (size_t)ld);
+    rc = sipnet_dev_to_host(seg, dev, sizeof(double) * (size_t)nDev * 3 * (size_t)len * (size_t)ld, NULL);
+    if (rc) { printf("copy_segment=%d %s\n", rc, sipnet_last_error()); return 1; }
+    for (int32_t k = 0; k < nDev; k++)          /* segment layout [n_devices][3][len][ld] against [n_devices][3][T][ld] */
+      for (int v = 0; v < 3; v++)
+        if (memcmp(seg + (((size_t)k * 3 + (size_t)v) * (size_t)len) * (size_t)ld,
+                   g + (((size_t)k * 3 + (size_t)v) * (size_t)T + (size_t)first) * (size_t)ld, sizeof(double) * (size_t)len * (size_t)ld) != 0)
+          segmentsEqual = 0;
+    free(seg);
+    covered += len;
+  }
+  printf("gathering_segments_equal_gathered_planes=%d\n", segmentsEqual && covered == T);
   free(g); free(gs0); free(gsk); free(total); free(members);
   sipnet_node_destroy(nd);
   sipnet_clim_free(clim);

@@ -85,6 +85,7 @@ def test_node_of_one_device_all_gathers_through_rccl_from_c(oracle, tmp_path):
     assert rc == 0 and kv["create"] == "0", out
     assert "RCCL" in kv["collective_library"] and kv["n_devices"] == "1"
     assert kv["gathered_stats_identical"] == "1"
+    assert kv["gathering_segments_equal_gathered_planes"] == "1"      # sipnet_node_run_gathering: the overlapped plane gather from C
     assert float(kv["stats_vs_planes_max_abs"]) < 1e-9
     assert kv["kernel"].startswith("stepCoopKernel<double")
     case = helpers.load_smoke_case("niwot", str(tmp_path))
