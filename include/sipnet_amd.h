@@ -648,6 +648,10 @@ const char *sipnet_batch_last_kernel_name(sipnet_batch *b); /* "" before the fir
 void *sipnet_dev_alloc(size_t bytes);
 void sipnet_dev_free(void *p);
 int sipnet_dev_to_host(void *host, const void *dev, size_t bytes, void *hip_stream);
+/* `rows` pieces of width_bytes, dev_pitch apart on the device, host_pitch apart on the host: one column of a
+ * record block [n_steps][SIPNET_NREC][ld] as a dense [n_steps][n_members] array, for the ensemble output block */
+int sipnet_dev_to_host_2d(void *host, size_t host_pitch, const void *dev, size_t dev_pitch,
+                          size_t width_bytes, size_t rows, void *hip_stream);
 int sipnet_stream_sync(void *hip_stream);
 /* a HIP stream of the caller's own on `device` (non-blocking with respect to the null stream): what a host that
  * pipelines forcings over two batches gives each of them (NULL on failure) */
@@ -716,6 +720,54 @@ int sipnet_io_write_events_out(const char *path, int32_t print_header,
 int sipnet_io_write_debug_logs(const char *prefix, int32_t print_header, int32_t n_steps,
                                const int32_t *year, const int32_t *day, const double *clim,
                                const double *rec, const double *dbg);
+
+/* ---- ensemble output block ----------------------------------------------
+ * The reference writes one `<prefix>.out` text file per process (outputHeader / outputState,
+ * sipnet.c:434-473; single-variable files outputItems.c:126-150): a 10 240-member year is
+ * 10 240 files and 20 GB of text that PEcAn's model2netcdf parses again.  This is the bulk path:
+ * every member's outputs in ONE self-describing NetCDF-3 file, written here without a NetCDF
+ * library (classic format, CDF-2 / 64-bit offsets; CDF-5 when a variable exceeds 4 GiB).
+ *   dimensions   time = n_steps, member = n_members
+ *   coordinates  year(time) i4, day(time) i4 [day of year], hour(time) f8 [clim column 10],
+ *                length(time) f8 [days, clim column 0], member(member) i4 [member_ids or 0..M-1]
+ *   data         <name>(time, member) f8 (or f4 with store_f32) + attribute `units`
+ * Data variables are fixed-size and contiguous: sipnet_io_ensemble_put may fill any (step range x
+ * member range) of any variable, in any order, from several threads at once (pwrite) -- device
+ * shards stream their own member ranges one variable at a time; what is never `put` reads as 0.
+ * attrs: global attributes as "key=value" lines (may be NULL); units[v] may be NULL (the `.out`
+ * column table's units for a name it knows, else none).  store_f32: SIPNET_NC_* bits. */
+enum sipnet_nc_storage {
+  SIPNET_NC_F64 = 0,        /* data variables as doubles */
+  SIPNET_NC_F32 = 1,        /* ... as floats (half the file; fp32-mixed batches lose nothing) */
+  SIPNET_NC_FORCE_CDF5 = 2  /* the 64-bit-data format even when CDF-2 would do */
+};
+typedef struct sipnet_ensemble_file sipnet_ensemble_file;
+int sipnet_io_ensemble_create(const char *path, int32_t n_steps, int32_t n_members,
+                              const int32_t *year, const int32_t *day, const double *clim,
+                              const int32_t *member_ids, int32_t n_vars,
+                              const char *const *names, const char *const *units,
+                              int32_t store_f32, const char *attrs, sipnet_ensemble_file **out);
+/* data: HOST rows [n_steps][ld] of doubles (floats with data_is_f32), row t = step step0 + t,
+ * element m = member member0 + m. */
+int sipnet_io_ensemble_put(sipnet_ensemble_file *f, int32_t var, int32_t step0, int32_t n_steps,
+                           int32_t member0, int32_t n_members, const void *data, int64_t ld,
+                           int32_t data_is_f32);
+int sipnet_io_ensemble_close(sipnet_ensemble_file *f);
+/* The `.out` columns (order of outputHeader, sipnet.c:434-444) as record columns: value =
+ * rec[rec0] (+ rec[rec1] when rec1 >= 0: plantWoodC is printed with the accounting delta,
+ * state.c:17-19).  index = -1 for an unknown name. */
+int32_t sipnet_io_out_column_count(void);
+int32_t sipnet_io_out_column_index(const char *name);
+int sipnet_io_out_column(int32_t k, const char **name, int32_t *rec0, int32_t *rec1,
+                         const char **units);
+/* One call for host-resident results: planes[3][n_steps][ld] (NEE, GPP, ET -> nee, gpp,
+ * evapotranspiration) or, when rec != NULL, the columns named in the comma-separated list
+ * `columns` (NULL / "" = all 32) from rec[n_steps][SIPNET_NREC][ld]. */
+int sipnet_io_write_ensemble_block(const char *path, int32_t n_steps, int32_t n_members,
+                                   const int32_t *year, const int32_t *day, const double *clim,
+                                   const int32_t *member_ids, const double *planes,
+                                   const double *rec, int64_t ld, const char *columns,
+                                   int32_t store_f32, const char *attrs);
 
 /* `SIPNET_RESTART` checkpoint text (restart.c): read follows readRestartState
  * (restart.c:590-756: magic line, `<key> <value>` lines, strict number parsing, duplicate /

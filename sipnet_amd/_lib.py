@@ -193,6 +193,7 @@ SIGNATURES = {
     "sipnet_dev_alloc": (_P, [C.c_size_t]),
     "sipnet_dev_free": (None, [_P]),
     "sipnet_dev_to_host": (C.c_int, [_P, _P, C.c_size_t, _P]),
+    "sipnet_dev_to_host_2d": (C.c_int, [_P, C.c_size_t, _P, C.c_size_t, C.c_size_t, C.c_size_t, _P]),
     "sipnet_stream_sync": (C.c_int, [_P]),
     "sipnet_stream_create": (_P, [C.c_int32]),
     "sipnet_stream_destroy": (None, [_P]),
@@ -213,6 +214,16 @@ SIGNATURES = {
     "sipnet_io_write_debug_logs": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
     "sipnet_io_write_events_out": (C.c_int, [C.c_char_p, C.c_int32, _I32P, _P, C.c_int32, _P, _P, _P,
                                              C.c_int32, _P, _P, _P]),
+    "sipnet_io_ensemble_create": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int32, _P, _P,
+                                            C.c_int32, C.c_char_p, C.POINTER(_P)]),
+    "sipnet_io_ensemble_put": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int64,
+                                         C.c_int32]),
+    "sipnet_io_ensemble_close": (C.c_int, [_P]),
+    "sipnet_io_out_column_count": (C.c_int32, []),
+    "sipnet_io_out_column_index": (C.c_int32, [C.c_char_p]),
+    "sipnet_io_out_column": (C.c_int, [C.c_int32, C.POINTER(C.c_char_p), _I32P, _I32P, C.POINTER(C.c_char_p)]),
+    "sipnet_io_write_ensemble_block": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_int64,
+                                                 C.c_char_p, C.c_int32, C.c_char_p]),
     "sipnet_io_read_restart": (C.c_int, [C.c_char_p, _P]),
     "sipnet_io_write_restart": (C.c_int, [C.c_char_p, _P]),
     "sipnet_restart_check": (C.c_int, [_P, _I32P, C.c_int32, C.c_int32, C.c_int32, C.c_double,
@@ -221,16 +232,18 @@ SIGNATURES = {
 }
 
 _lib = None
+_DEV_LIBRARY = False
 
 
 def use_library(path):
     """Development hook (tools/variant_bench.py): load another build of the C-ABI library
     instead of the in-tree product.  Must be called before the first lib(); never read from
     the environment."""
-    global LIB_PATH
+    global LIB_PATH, _DEV_LIBRARY
     if _lib is not None:
         raise RuntimeError("sipnet_amd: the library is already loaded")
     LIB_PATH = os.path.abspath(path)
+    _DEV_LIBRARY = True
 
 
 def lib():
@@ -254,6 +267,8 @@ def lib():
             pass
         _lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
+            if _DEV_LIBRARY and not hasattr(_lib, name):
+                continue   # (an older / experimental build under build/variants: tools only, never the product)
             fn = getattr(_lib, name)
             fn.restype = res
             fn.argtypes = args

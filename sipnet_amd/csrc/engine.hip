@@ -151,7 +151,8 @@ static int buildAndUpload(sipnet_batch* b, bool fastType, bool first, hipStream_
                                (int32_t)b->events[s].size(), b->events[s].data(),
                                b->resume[s].set ? &b->resume[s] : nullptr, nullptr, /*wantSteps=*/false,
                                fastType ? nullptr : steps + (size_t)s * nT,
-                               fastType ? fast + (size_t)s * nT : nullptr);
+                               fastType ? fast + (size_t)s * nT : nullptr,
+                               /*narrowFast=*/b->precision == SIPNET_F32_MIXED);
     if (first) b->plans[s] = std::move(p);
     const double c0 = nowMs();
     const size_t tail = (fastType && s == nS - 1) ? kFastTile : 0;  // tile padding after the last site
@@ -1378,6 +1379,12 @@ void sipnet_dev_free(void* p) {
 int sipnet_dev_to_host(void* host, const void* dev, size_t bytes, void* hip_stream) {
   HIP_TRY(hipStreamSynchronize((hipStream_t)hip_stream));
   HIP_TRY(hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost));
+  return SIPNET_OK;
+}
+int sipnet_dev_to_host_2d(void* host, size_t host_pitch, const void* dev, size_t dev_pitch, size_t width_bytes, size_t rows,
+                          void* hip_stream) {
+  HIP_TRY(hipStreamSynchronize((hipStream_t)hip_stream));
+  HIP_TRY(hipMemcpy2D(host, host_pitch, dev, dev_pitch, width_bytes, rows, hipMemcpyDeviceToHost));
   return SIPNET_OK;
 }
 int sipnet_stream_sync(void* hip_stream) {

@@ -117,5 +117,17 @@ __device__ __forceinline__ float clip01(float x) { return __builtin_fminf(__buil
 
 __device__ __forceinline__ int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// A NARROW field of the site record (plan.h, FastRec: climate values the step only ever uses at the
+// precision of the flux arithmetic).  An fp64 batch holds a double there; the plan of an fp32-mixed
+// batch holds the correctly rounded float in the slot's low word (its high word is a quiet-NaN tag, so
+// that a reader that forgets this fails loudly): the conversion happens once per site on the host
+// instead of in every wavefront on every step (7-14 v_cvt_f32_f64 of wave-uniform values per step).
+template <class R>
+__device__ __forceinline__ R recR(double slot);
+template <>
+__device__ __forceinline__ double recR<double>(double slot) { return slot; }
+template <>
+__device__ __forceinline__ float recR<float>(double slot) { return __int_as_float(__double2loint(slot)); }
+
 }  // namespace
 }  // namespace sipnet

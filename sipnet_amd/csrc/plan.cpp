@@ -1,6 +1,8 @@
 // plan.cpp -- host-side construction of the per-site plan (see plan.h).
 #include "plan.h"
 
+#include <cstring>
+
 #include <cmath>
 #include <cstdio>
 
@@ -111,6 +113,22 @@ void fillFastRec(const StepRec& s, const RingOp* ops, bool tsoilSame, int phenMo
   f.day = s.day;
 }
 
+// the narrow fields of an fp32-mixed batch's records (plan.h): float in the low word, quiet-NaN tag in the high one
+double narrowSlot(double v) {
+  const float f = (float)v;   // round to nearest even, as v_cvt_f32_f64 does
+  uint32_t lo;
+  std::memcpy(&lo, &f, sizeof lo);
+  const uint64_t bits = 0x7FF8000000000000ull | lo;
+  double d;
+  std::memcpy(&d, &bits, sizeof d);
+  return d;
+}
+void narrowFastRec(FastRec& f) {
+  double* const slots[] = {&f.tair,  &f.tsoil,   &f.negPar,  &f.vpd,    &f.tillP1,  &f.rainRate,
+                           &f.sublW, &f.evapNum, &f.invWspd, &f.tair10, &f.tsoil10, &f.log2vpd};
+  for (double* p : slots) *p = narrowSlot(*p);
+}
+
 // summary of the tile [b, e) (see FastRec::tileBits); slot0 / slot1 hold the tile's eviction slots
 void summariseTile(FastRec* out, int b, int e, const int* slot0, const int* slot1) {
   bool regular = true;
@@ -151,7 +169,7 @@ void summariseTile(FastRec* out, int b, int e, const int* slot0, const int* slot
 SitePlan buildSitePlan(const int32_t* flags, int32_t n_steps, const double* clim,
                        const int32_t* year, const int32_t* day, int32_t n_events,
                        const sipnet_event* events, const PlanCarry* init, PlanCarry* fin,
-                       bool wantSteps, StepRec* stepsOut, FastRec* fastOut) {
+                       bool wantSteps, StepRec* stepsOut, FastRec* fastOut, bool narrowFast) {
   SitePlan plan;
   if (wantSteps) plan.steps.resize(n_steps);
   plan.gddAfter.resize(n_steps);
@@ -327,8 +345,12 @@ SitePlan buildSitePlan(const int32_t* flags, int32_t n_steps, const double* clim
       if (t > 0) fastOut[t - 1].slots = (fastOut[t - 1].slots & 0xffff) | (s0 << 16) | (s1 << 24);
       tileSlot0[t % kFastTile] = s0;
       tileSlot1[t % kFastTile] = s1;
-      if (t % kFastTile == kFastTile - 1 || t == n_steps - 1)
+      if (t % kFastTile == kFastTile - 1 || t == n_steps - 1) {
         summariseTile(fastOut, t - t % kFastTile, t + 1, tileSlot0, tileSlot1);
+        // (after the summary, which compares the tile's records as doubles; while the tile is still in the cache)
+        if (narrowFast)
+          for (int k = t - t % kFastTile; k <= t; k++) narrowFastRec(fastOut[k]);
+      }
     }
     prevTsoil10 = s.tsoil10;
   }

@@ -73,8 +73,12 @@ static_assert(sizeof(EvRec) == 40, "EvRec layout");
 // time loop; the rest is read only when a flag bit says so.  It carries the step's ring
 // evictions and the NEXT step's eviction slots, so that the ring values of step t+1 are
 // requested during step t.
+// NARROW fields (marked [n]): climate values the step only uses at the precision of its flux arithmetic.  In the
+// records of an fp32-mixed batch (buildSitePlan(..., narrowFast = true)) such a slot holds the correctly rounded
+// FLOAT in its low four bytes and a quiet-NaN tag in the high four; the fp32 kernels take the low word (fast_math.h,
+// recR) instead of converting a wave-uniform double in every wavefront on every step.  fp64 batches: plain doubles.
 struct FastRec {
-  // ---- hot: bytes 0..143 ----
+  // ---- hot: bytes 0..143 ----   [n] tair tsoil | negPar vpd tillP1 rainRate | sublW evapNum invWspd tair10 | tsoil10; rare: log2vpd
   double len, invLen, tair, tsoil;           //  0.. 3
   double negPar, vpd, tillP1, rainRate;      //  4.. 7  -par, vpd, 1 + d_till_mod, precip/len
   double sublW, evapNum, invWspd, tair10;    //  8..11  CONV_S*(0.6-vPress)*wspd, CONV*vpdSoil, 1/wspd
@@ -173,6 +177,6 @@ SitePlan buildSitePlan(const int32_t* flags, int32_t n_steps, const double* clim
                        const int32_t* year, const int32_t* day, int32_t n_events,
                        const sipnet_event* events, const PlanCarry* init = nullptr,
                        PlanCarry* fin = nullptr, bool wantSteps = true, StepRec* stepsOut = nullptr,
-                       FastRec* fastOut = nullptr);
+                       FastRec* fastOut = nullptr, bool narrowFast = false);
 
 }  // namespace sipnet

@@ -30,6 +30,16 @@
 //                            (one RCCL rank per device), every device runs its members on the
 //                            throughput kernels, ONE all-gather of the statistics block joins them,
 //                            and FILE gets `year day time n mean/sd of NEE, GPP, ET` per step
+//   --ensemble-out FILE      (with --ensemble-params or --sites) every member's outputs as ONE NetCDF-3 block
+//                            (include/sipnet_amd.h "ensemble output block": dimensions time x member, the `.out`
+//                            columns' names and units) INSTEAD of the members' text files: nee, gpp and
+//                            evapotranspiration by default -- the lean throughput kernels, three planes -- or the
+//                            `.out` columns named with --ensemble-out-columns a,b,c|all (the 44-column record);
+//                            --ensemble-out-f32 stores floats; --ensemble-text writes the text files as well.
+//                            Device shards stream their member ranges into the one file.  With --sites one block
+//                            per distinct forcing: FILE itself when there is one, else <stem>.<k><ext> with k = the
+//                            position in the list of the site's first run; member = position in the list, the global
+//                            attribute run_dirs names the directories
 //   --sites FILE             stacking at the process boundary PEcAn uses: FILE lists run directories (one per
 //                            line, `#` comments), each with its own sipnet.in / <prefix>.param / <prefix>.clim /
 //                            <events>.in.  Every directory is resolved exactly like a run started inside it (the
@@ -38,7 +48,12 @@
 //                            same model flags share ONE batch (whatever their lengths), and every directory gets the files its
 //                            own run would have written (<prefix>.out, <events>.out, <prefix>.config, single-variable
 //                            outputs) -- byte for byte with --math auto / strict (the strict-order kernel), to the last
-//                            printed digit with --math fast (the throughput kernels)
+//                            printed digit with --math fast (the throughput kernels).  RESTART_IN / RESTART_OUT of a
+//                            directory's sipnet.in are honoured (PEcAn's assimilation cycles: one directory per member
+//                            and cycle, sipnet.c:1963-1989, restart.c:932-996): runs share a site only when their
+//                            checkpoints agree in what the site plan owns (year-to-date GDD, year counters, tillage
+//                            modifier, ring layout, processed steps), every member resumes from its own checkpoint
+//                            and is checkpointed at the end of ITS forcing
 #include <getopt.h>
 #include <unistd.h>
 #include <cmath>
@@ -170,12 +185,69 @@ void usage(const char* prog) {
   printf("  --devices <list>            HIP devices the ensemble shards across, e.g. 0-7 or 0,2,3 ('0')\n");
   printf("  --ensemble-stats <file>     per-step ensemble mean / sd of NEE, GPP, ET instead of the members' files\n");
   printf("  --sites <file>              run every directory listed in <file> (one per line) in shared batches\n");
+  printf("  --ensemble-out <file.nc>    (--ensemble-params / --sites) all members' outputs as one NetCDF-3 block instead of\n");
+  printf("                              the members' text files: nee, gpp, evapotranspiration -- or, with\n");
+  printf("      --ensemble-out-columns <a,b,..|all>  the named .out columns; --ensemble-out-f32 stores floats;\n");
+  printf("      --ensemble-text         writes the text files as well\n");
   printf("  -h, --help   -v, --version\n");
 }
 
+// A fatal condition ends the process with the reference's exit code -- from the main thread.  Host threads (device
+// shards, file writers) must not call exit() while other threads hold batches: they throw, the first error is kept, and
+// the main thread reports it after the joins.
+struct Fatal {
+  int code;
+  std::string msg;
+};
+thread_local bool t_worker = false;
 [[noreturn]] void die(int code, const std::string& msg) {
+  if (t_worker) throw Fatal{code, msg};
   logError(msg);
   exit(code);
+}
+struct FirstFatal {
+  std::mutex mu;
+  bool set = false;
+  Fatal f{0, ""};
+  void take(const Fatal& x) {
+    std::lock_guard<std::mutex> lock(mu);
+    if (!set) {
+      set = true;
+      f = x;
+    }
+  }
+  void exitIfSet() {   // main thread, after the joins
+    if (set) {
+      logError(f.msg);
+      exit(f.code);
+    }
+  }
+};
+template <class F>
+void guarded(FirstFatal& sink, F&& fn) {   // body of a host thread
+  t_worker = true;
+  try {
+    fn();
+  } catch (const Fatal& f) {
+    sink.take(f);
+  }
+}
+// run `fn` on n host threads (inline when n == 1); a fatal condition in any of them ends the process afterwards
+template <class F>
+void runThreads(int n, F&& fn) {
+  if (n <= 1) {
+    fn();
+    return;
+  }
+  FirstFatal sink;
+  std::vector<std::thread> pool;
+  for (int i = 0; i < n; i++) pool.emplace_back([&]() { guarded(sink, fn); });
+  for (auto& th : pool) th.join();
+  if (sink.set) die(sink.f.code, sink.f.msg);   // (rethrown when this is itself a worker thread)
+}
+// a path named in a sipnet.in, seen from outside its directory
+std::string joinPath(const std::string& dir, const std::string& p) {
+  return (!p.empty() && p[0] == '/') ? p : dir + "/" + p;
 }
 
 // frontend.c:35-128
@@ -266,9 +338,75 @@ std::vector<int> parseDevices(const std::string& arg) {
 }
 
 void check(int rc, const char* what) {
-  if (rc != SIPNET_OK) {
-    logError(std::string(what) + ": " + sipnet_last_error() + "\n");
-    exit(rc >= 100 ? 1 : rc);
+  if (rc != SIPNET_OK) die(rc >= 100 ? 1 : rc, std::string(what) + ": " + sipnet_last_error() + "\n");
+}
+
+// ---- the ensemble output block (--ensemble-out) ---------------------------------------------------------------
+struct BlockSpec {
+  std::string path;                // empty: no block
+  std::vector<int> cols;           // `.out` column indices (sipnet_io_out_column); empty: the three planes
+  bool f32 = false, text = false;  // store floats; write the members' text files as well
+  bool on() const { return !path.empty(); }
+  bool planesOnly() const { return cols.empty(); }
+};
+void parseBlockColumns(BlockSpec& spec, const std::string& arg) {
+  if (arg == "all") {
+    for (int k = 0; k < sipnet_io_out_column_count(); k++) spec.cols.push_back(k);
+    return;
+  }
+  std::istringstream in(arg);
+  for (std::string tok; std::getline(in, tok, ',');) {
+    if (tok.empty()) continue;
+    const int k = sipnet_io_out_column_index(tok.c_str());
+    if (k < 0) die(8, "--ensemble-out-columns: unknown .out column " + tok + "\n");
+    spec.cols.push_back(k);
+  }
+  if (spec.cols.empty()) die(8, "--ensemble-out-columns: no columns\n");
+}
+sipnet_ensemble_file* createBlock(const BlockSpec& spec, const std::string& path, int T, int M, const sipnet_clim_table* clim,
+                                  const int32_t* memberIds, const std::string& attrs) {
+  std::vector<const char*> names;
+  if (spec.planesOnly()) {
+    names = {"nee", "gpp", "evapotranspiration"};
+  } else {
+    for (int k : spec.cols) {
+      const char* nm = nullptr;
+      check(sipnet_io_out_column(k, &nm, nullptr, nullptr, nullptr), "column table");
+      names.push_back(nm);
+    }
+  }
+  sipnet_ensemble_file* f = nullptr;
+  check(sipnet_io_ensemble_create(path.c_str(), T, M, sipnet_clim_year(clim), sipnet_clim_day(clim), sipnet_clim_data(clim),
+                                  memberIds, (int32_t)names.size(), names.data(), nullptr, spec.f32 ? SIPNET_NC_F32 : SIPNET_NC_F64,
+                                  attrs.c_str(), &f), "creating the ensemble block");
+  return f;
+}
+// members [col0, col0 + n) of a device result -> members [member0, member0 + n) of the block, one variable at a time
+// (a dense [T][n] host array per variable: nothing the size of the record ever exists on the host).
+// planes: dPlanes[3][Tld][ld] (NEE, GPP, ET); records: dRec[Tld][SIPNET_NREC][ld].
+void putBlock(sipnet_ensemble_file* f, const BlockSpec& spec, int T, int64_t ld, int64_t Tld, int64_t col0, int n, int member0,
+              const double* dPlanes, const double* dRec) {
+  std::vector<double> host((size_t)T * n), second;
+  const size_t w = (size_t)n * sizeof(double);
+  if (spec.planesOnly()) {
+    for (int v = 0; v < 3; v++) {
+      check(sipnet_dev_to_host_2d(host.data(), w, dPlanes + ((size_t)v * Tld) * ld + col0, (size_t)ld * sizeof(double), w, (size_t)T,
+                                  nullptr), "copy back");
+      check(sipnet_io_ensemble_put(f, v, 0, T, member0, n, host.data(), n, 0), "writing the ensemble block");
+    }
+    return;
+  }
+  const size_t pitch = (size_t)SIPNET_NREC * ld * sizeof(double);
+  for (size_t v = 0; v < spec.cols.size(); v++) {
+    int32_t r0 = 0, r1 = -1;
+    check(sipnet_io_out_column(spec.cols[v], nullptr, &r0, &r1, nullptr), "column table");
+    check(sipnet_dev_to_host_2d(host.data(), w, dRec + (size_t)r0 * ld + col0, pitch, w, (size_t)T, nullptr), "copy back");
+    if (r1 >= 0) {   // total wood = plantWoodC + accounting delta (state.c:17-19)
+      second.resize(host.size());
+      check(sipnet_dev_to_host_2d(second.data(), w, dRec + (size_t)r1 * ld + col0, pitch, w, (size_t)T, nullptr), "copy back");
+      for (size_t i = 0; i < host.size(); i++) host[i] += second[i];
+    }
+    check(sipnet_io_ensemble_put(f, (int32_t)v, 0, T, member0, n, host.data(), n, 0), "writing the ensemble block");
   }
 }
 
@@ -282,10 +420,22 @@ struct SiteRun {
   sipnet_event* events = nullptr;
   int32_t nEvents = 0;
   int T = 0;
+  bool hasResume = false;    // RESTART_IN: the checkpoint this run resumes from (restartLoadCheckpoint, restart.c:968-996)
+  sipnet_restart resume;
+  std::string restartOut;    // RESTART_OUT as an absolute path ("" = none)
 };
 
+// what the site plan takes from a checkpoint (sipnet_batch_set_resume): members of one site must agree in it
+bool samePlanCarry(const sipnet_restart& a, const sipnet_restart& b) {
+  return a.trackers[SIPNET_RT_GDD] == b.trackers[SIPNET_RT_GDD] && a.trackers_last_year == b.trackers_last_year &&
+         a.phenology_last_year == b.phenology_last_year && a.d_till_mod == b.d_till_mod && a.mean_start == b.mean_start &&
+         a.mean_last == b.mean_last && a.processed_steps == b.processed_steps &&
+         memcmp(a.mean_weights, b.mean_weights, sizeof a.mean_weights) == 0;
+}
+
 bool sameForcing(const SiteRun& a, const SiteRun& b) {
-  if (a.T != b.T || a.nEvents != b.nEvents) return false;
+  if (a.T != b.T || a.nEvents != b.nEvents || a.hasResume != b.hasResume) return false;
+  if (a.hasResume && !samePlanCarry(a.resume, b.resume)) return false;
   if (memcmp(sipnet_clim_data(a.clim), sipnet_clim_data(b.clim), (size_t)a.T * SIPNET_NCLIM * sizeof(double)) != 0) return false;
   if (memcmp(sipnet_clim_year(a.clim), sipnet_clim_year(b.clim), (size_t)a.T * sizeof(int32_t)) != 0) return false;
   if (memcmp(sipnet_clim_day(a.clim), sipnet_clim_day(b.clim), (size_t)a.T * sizeof(int32_t)) != 0) return false;
@@ -294,6 +444,41 @@ bool sameForcing(const SiteRun& a, const SiteRun& b) {
     if (x.type != y.type || x.year != y.year || x.day != y.day || memcmp(x.p, y.p, sizeof x.p) != 0) return false;
   }
   return true;
+}
+
+// restartLoadCheckpoint's checks (restart.c:968-996) with the reference's log lines
+void checkResume(const sipnet_restart& r, const std::string& path, const int32_t* flags, const sipnet_clim_table* clim) {
+  const int T = sipnet_clim_nsteps(clim);
+  const double* c0 = sipnet_clim_data(clim);
+  int32_t warn = 0;
+  check(sipnet_restart_check(&r, flags, T > 0, T > 0 ? sipnet_clim_year(clim)[0] : 0, T > 0 ? sipnet_clim_day(clim)[0] : 0,
+                             T > 0 ? c0[10] : 0.0, T > 0 ? c0[0] : 0.0, &warn), "restart checkpoint");
+  if (warn & SIPNET_RESTART_WARN_BOUNDARY_NOT_MIDNIGHT)
+    logWarning("Restart checkpoint boundary in " + path + " is more than one timestep before "
+               "midnight; there is a time gap on resume.\n");
+  if (warn & SIPNET_RESTART_WARN_BUILD_INFO)
+    logInfo(std::string("Restart build info mismatch: checkpoint=") + r.build_info + "\n");
+  if (warn & SIPNET_RESTART_WARN_TIME_GAP)
+    logWarning("Restart resumed segment starts more than one timestep after midnight "
+               "checkpoint boundary; there is a time gap\n");
+}
+
+// restartWriteCheckpoint (restart.c:932-996) of one member of a batch that has run its site to the end
+void writeCheckpoint(sipnet_batch* b, std::mutex& gpuMutex, std::mutex& logMutex, int site, int member, int T, const double* lastRec,
+                     const double* prevPools, const std::string& path) {
+  sipnet_restart ck;
+  {
+    std::lock_guard<std::mutex> lock(gpuMutex);   // (the export talks to the GPU through the one batch handle)
+    check(sipnet_batch_export_restart(b, site, member, T, lastRec, prevPools, &ck, nullptr), "restart checkpoint");
+  }
+  int32_t warn = 0;
+  check(sipnet_restart_check_boundary_for_write(&ck, &warn), "restart checkpoint");
+  if (warn & SIPNET_RESTART_WARN_BOUNDARY_NOT_MIDNIGHT) {
+    std::lock_guard<std::mutex> lock(logMutex);
+    logWarning("Restart checkpoint " + path + " ends more than one timestep before midnight; "
+               "there will be a time gap if this file is used to resume.\n");
+  }
+  check(sipnet_io_write_restart(path.c_str(), &ck), "writing restart checkpoint");
 }
 
 // the part of main() between the command line and the run, for one directory (the process is inside it)
@@ -308,8 +493,7 @@ void resolveRun(SiteRun& r) {
   if (ctx.i("anaerobic") && !ctx.i("waterHResp")) { logError("anaerobic requires water-hresp to be turned on\n"); bad = true; }
   if (ctx.i("carbonSaturation") && !ctx.i("litterPool")) { logError("carbon-saturation requires litter-pool to be turned on\n"); bad = true; }
   if (bad) exit(3);
-  if (!ctx.s("restartIn").empty() || !ctx.s("restartOut").empty() || !ctx.s("debugLogPrefix").empty())
-    die(8, "--sites does not combine with restart checkpoints or --debug-log (" + r.dir + ")\n");
+  if (!ctx.s("debugLogPrefix").empty()) die(8, "--sites does not combine with --debug-log (" + r.dir + ")\n");
   const std::string prefix = ctx.s("filePrefix");
   ctx.setStr("paramFile", prefix + ".param", SRC_CALCULATED);
   ctx.setStr("climFile", prefix + ".clim", SRC_CALCULATED);
@@ -334,9 +518,16 @@ void resolveRun(SiteRun& r) {
           "reading events");
     if (r.nEvents == 0) logInfo("No event file found, assuming no input events\n");
   }
+  if (!ctx.s("restartIn").empty()) {
+    check(sipnet_io_read_restart(ctx.s("restartIn").c_str(), &r.resume), "reading restart checkpoint");
+    checkResume(r.resume, ctx.s("restartIn"), r.flags, r.clim);
+    r.hasResume = true;
+  }
+  if (!ctx.s("restartOut").empty()) r.restartOut = joinPath(r.dir, ctx.s("restartOut"));
 }
 
-int runSites(const Context& cliCtx, const std::string& listFile, const std::string& mathArg, const std::vector<int>& devices) {
+int runSites(const Context& cliCtx, const std::string& listFile, const std::string& mathArg, const std::vector<int>& devices,
+             const BlockSpec& block) {
   std::vector<std::string> dirs;
   {
     std::ifstream in(listFile);
@@ -366,13 +557,15 @@ int runSites(const Context& cliCtx, const std::string& listFile, const std::stri
     if (device >= sipnet_device_count())
       die(1, "--devices names device " + std::to_string(device) + " but only " + std::to_string(sipnet_device_count()) +
                  " HIP device(s) are visible (this engine has no CPU path)\n");
-  const bool fastMath = mathArg == "fast";
-  // batches: same model flags and step count; inside a batch, runs with identical forcing are members of ONE site
+  const bool fastMath = mathArg == "fast" || (mathArg == "auto" && block.on() && !block.text);
+  const bool wantText = !block.on() || block.text;
+  // batches: same model flags; inside a batch, runs with identical forcing (and resume state) are members of ONE site
   std::vector<char> done(runs.size(), 0);
-  int worst = 0, nBatches = 0;
+  std::vector<std::vector<std::vector<int>>> groups;   // [batch][site][member] -> run index
+  size_t nSitesTotal = 0;
   for (size_t lead = 0; lead < runs.size(); lead++) {
     if (done[lead]) continue;
-    std::vector<std::vector<int>> sites;   // [site][member] -> run index
+    std::vector<std::vector<int>> sites;
     for (size_t k = lead; k < runs.size(); k++) {
       if (done[k] || memcmp(runs[k].flags, runs[lead].flags, sizeof runs[k].flags) != 0) continue;   // (any length)
       done[k] = 1;
@@ -385,23 +578,41 @@ int runSites(const Context& cliCtx, const std::string& listFile, const std::stri
         }
       if (!placed) sites.push_back({(int)k});
     }
+    nSitesTotal += sites.size();
+    groups.push_back(std::move(sites));
+  }
+  auto blockPathOf = [&](int firstRun) -> std::string {   // one block per distinct forcing
+    if (nSitesTotal == 1) return block.path;
+    const size_t slash = block.path.find_last_of('/'), dot = block.path.find_last_of('.');
+    const bool hasExt = dot != std::string::npos && (slash == std::string::npos || dot > slash);
+    const std::string stem = hasExt ? block.path.substr(0, dot) : block.path, ext = hasExt ? block.path.substr(dot) : "";
+    return stem + "." + std::to_string(firstRun) + ext;
+  };
+  int worst = 0, nBatches = 0;
+  for (const auto& allSites : groups) {
+    const size_t lead = (size_t)allSites[0][0];
     // the sites of a flag set are dealt to the listed devices in contiguous ranges (whole sites per device, as
     // SIPNET_SHARD_SITES does: a site's forcing, events and plan exist on one device only); each range is one batch,
     // driven by a host thread of its own
-    const int nParts = std::max(1, std::min((int)devices.size(), (int)sites.size()));
-    const std::vector<std::vector<int>> allSites = sites;
+    const int nParts = std::max(1, std::min((int)devices.size(), (int)allSites.size()));
     std::vector<int> partWorst(nParts, 0);
     std::mutex batchMutex;
+    int hostThreads = 1;
+    {
+      cpu_set_t cpus;
+      if (sched_getaffinity(0, sizeof cpus, &cpus) == 0) hostThreads = CPU_COUNT(&cpus);
+    }
     auto runPart = [&](int part) {
     const std::vector<std::vector<int>> sites(allSites.begin() + (size_t)allSites.size() * part / nParts,
                                               allSites.begin() + (size_t)allSites.size() * (part + 1) / nParts);
     const int device = devices[part];
-    int worst = 0;
     const int S = (int)sites.size();
     int M = 0, T = 0;   // T: the longest forcing of the batch (its sites may be shorter)
+    bool anyCheckpoint = false;
     for (auto& st : sites) {
       M = std::max(M, (int)st.size());
       T = std::max(T, runs[st[0]].T);
+      for (int k : st) anyCheckpoint = anyCheckpoint || !runs[k].restartOut.empty();
     }
     {
       std::lock_guard<std::mutex> lock(batchMutex);
@@ -422,28 +633,67 @@ int runSites(const Context& cliCtx, const std::string& listFile, const std::stri
         memcpy(rows.data() + (size_t)m * SIPNET_NPARAMS, r.params.data(), SIPNET_NPARAMS * sizeof(double));
       }
       check(sipnet_batch_set_params(b, s, 0, M, rows.data()), "parameters");
+      if (r0.hasResume) check(sipnet_batch_set_resume(b, s, &r0.resume), "restart checkpoint");
     }
     check(sipnet_batch_setup(b, nullptr), "setupModel");
+    for (int s = 0; s < S; s++) {   // every member from its own checkpoint (the filling columns repeat the first run's)
+      if (!runs[sites[s][0]].hasResume) continue;
+      std::vector<sipnet_restart> cks(M);
+      for (int m = 0; m < M; m++) cks[m] = runs[sites[s][m < (int)sites[s].size() ? m : 0]].resume;
+      check(sipnet_batch_import_restart(b, s, 0, M, cks.data(), nullptr), "restart checkpoint");
+    }
     const int64_t ncol = (int64_t)S * M;
-    std::vector<double> state0((size_t)ncol * SIPNET_NSTATE);
-    check(sipnet_batch_get_state(b, state0.data(), nullptr), "state");
-    const size_t recElems = (size_t)T * SIPNET_NREC * ncol;
-    double* dRec = (double*)sipnet_dev_alloc(recElems * sizeof(double));
-    if (!dRec) die(1, std::string(sipnet_last_error()) + "\n");
-    check(sipnet_batch_run(b, 0, T, nullptr, nullptr, nullptr, dRec, ncol, nullptr), "run");
-    std::vector<double> rec(recElems);
-    check(sipnet_dev_to_host(rec.data(), dRec, recElems * sizeof(double), nullptr), "copy back");
+    std::vector<double> state0;
+    if (wantText || anyCheckpoint) {
+      state0.resize((size_t)ncol * SIPNET_NSTATE);
+      check(sipnet_batch_get_state(b, state0.data(), nullptr), "state");
+    }
+    // the block alone, planes: the lean kernels and three planes; anything else needs the 44-column record
+    const bool needRec = wantText || anyCheckpoint || (block.on() && !block.planesOnly());
+    const size_t recElems = needRec ? (size_t)T * SIPNET_NREC * ncol : 0, planeElems = needRec ? 0 : (size_t)3 * T * ncol;
+    double* dRec = recElems ? (double*)sipnet_dev_alloc(recElems * sizeof(double)) : nullptr;
+    double* dPlanes = planeElems ? (double*)sipnet_dev_alloc(planeElems * sizeof(double)) : nullptr;
+    if ((recElems && !dRec) || (planeElems && !dPlanes)) die(1, std::string(sipnet_last_error()) + "\n");
+    if (needRec)
+      check(sipnet_batch_run(b, 0, T, nullptr, nullptr, nullptr, dRec, ncol, nullptr), "run");
+    else
+      check(sipnet_batch_run(b, 0, T, dPlanes, dPlanes + (size_t)T * ncol, dPlanes + (size_t)2 * T * ncol, nullptr, ncol, nullptr), "run");
     std::vector<int32_t> status(ncol);
     check(sipnet_batch_get_status(b, status.data(), nullptr), "status");
-    sipnet_dev_free(dRec);
-    sipnet_batch_destroy(b);
+    std::atomic<int> worstA{0};
+    std::mutex logMutex, gpuMutex;
+    auto reportStatus = [&](const SiteRun& r, int st) {
+      std::lock_guard<std::mutex> lock(logMutex);
+      logError(r.dir + ": status " + std::to_string(st) +
+               " (NPP allocation params must be less than one individually and add to less than one)\n");
+      int w = worstA.load();
+      while (st > w && !worstA.compare_exchange_weak(w, st)) {}
+    };
+    if (block.on()) {   // one block per site: its runs are the members
+      for (int s = 0; s < S; s++) {
+        const SiteRun& r0 = runs[sites[s][0]];
+        const int n = (int)sites[s].size();
+        std::vector<int32_t> ids(sites[s].begin(), sites[s].end());
+        std::string attrs = "run_dirs=";
+        for (int m = 0; m < n; m++) attrs += (m ? " " : "") + runs[sites[s][m]].dir;
+        attrs += "\nmath=" + std::string(fastMath ? "fast" : "strict");
+        sipnet_ensemble_file* f = createBlock(block, blockPathOf(sites[s][0]), r0.T, n, r0.clim, ids.data(), attrs);
+        putBlock(f, block, r0.T, ncol, T, (int64_t)s * M, n, 0, dPlanes, dRec);
+        check(sipnet_io_ensemble_close(f), "closing the ensemble block");
+        if (!wantText)
+          for (int m = 0; m < n; m++)
+            if (status[(size_t)s * M + m] != 0) reportStatus(runs[sites[s][m]], status[(size_t)s * M + m]);
+      }
+    }
+    if (wantText || anyCheckpoint) {
+    std::vector<double> rec(recElems);
+    check(sipnet_dev_to_host(rec.data(), dRec, recElems * sizeof(double), nullptr), "copy back");
     // every run's files, into its own directory (absolute paths), by a pool of host threads
-    struct Job { int run; int64_t col; };
+    struct Job { int run, site, member; int64_t col; };
     std::vector<Job> jobs;
     for (int s = 0; s < S; s++)
-      for (int m = 0; m < (int)sites[s].size(); m++) jobs.push_back({sites[s][m], (int64_t)s * M + m});
-    std::atomic<int> next{0}, worstA{0};
-    std::mutex logMutex;
+      for (int m = 0; m < (int)sites[s].size(); m++) jobs.push_back({sites[s][m], s, m, (int64_t)s * M + m});
+    std::atomic<int> next{0};
     auto worker = [&]() {
       std::vector<double> one((size_t)T * SIPNET_NREC);
       for (int j = next.fetch_add(1); j < (int)jobs.size(); j = next.fetch_add(1)) {
@@ -451,26 +701,27 @@ int runSites(const Context& cliCtx, const std::string& listFile, const std::stri
         const int64_t c = jobs[j].col;
         const int T = r.T;   // (this run's own length: shadows the batch's longest)
         if (status[c] != 0) {
-          std::lock_guard<std::mutex> lock(logMutex);
-          logError(r.dir + ": status " + std::to_string(status[c]) +
-                   " (NPP allocation params must be less than one individually and add to less than one)\n");
-          int w = worstA.load();
-          while (status[c] > w && !worstA.compare_exchange_weak(w, status[c])) {}
+          if (wantText) reportStatus(r, status[c]);
           continue;
         }
         for (int t = 0; t < T; t++)
           for (int k = 0; k < SIPNET_NREC; k++) one[(size_t)t * SIPNET_NREC + k] = rec[((size_t)t * SIPNET_NREC + k) * ncol + c];
         Context& ctx = r.ctx;
-        const std::string prefix = r.dir + "/" + ctx.s("filePrefix");
-        if (ctx.i("doMainOutput"))
+        const std::string prefix = joinPath(r.dir, ctx.s("filePrefix"));
+        if (wantText && ctx.i("doMainOutput"))
           check(sipnet_io_write_out((prefix + ".out").c_str(), ctx.i("printHeader"), T, sipnet_clim_year(r.clim), sipnet_clim_day(r.clim),
                                     sipnet_clim_data(r.clim), one.data()), "writing output");
-        if (ctx.i("events"))
-          check(sipnet_io_write_events_out((r.dir + "/" + ctx.s("eventsPrefix") + ".out").c_str(), ctx.i("printHeader"), r.flags,
+        if (wantText && ctx.i("events"))
+          check(sipnet_io_write_events_out((joinPath(r.dir, ctx.s("eventsPrefix")) + ".out").c_str(), ctx.i("printHeader"), r.flags,
                                            r.params.data(), T, sipnet_clim_year(r.clim), sipnet_clim_day(r.clim),
                                            sipnet_clim_data(r.clim), r.nEvents, r.events, one.data(),
                                            state0.data() + (size_t)c * SIPNET_NSTATE), "writing events.out");
-        if (ctx.i("doSingleOutputs")) {  // sipnet.c:1993-1998, outputItems.c:126-150
+        if (!r.restartOut.empty()) {
+          const double* prevPools = T >= 2 ? one.data() + (size_t)(T - 2) * SIPNET_NREC + 14 : state0.data() + (size_t)c * SIPNET_NSTATE;
+          writeCheckpoint(b, gpuMutex, logMutex, jobs[j].site, jobs[j].member, T, one.data() + (size_t)(T - 1) * SIPNET_NREC, prevPools,
+                          r.restartOut);
+        }
+        if (wantText && ctx.i("doSingleOutputs")) {  // sipnet.c:1993-1998, outputItems.c:126-150
           const struct { const char* name; int col; } items[] = {{"NEE", 0}, {"NEE_cum", 3}, {"GPP", 1}, {"GPP_cum", 35}};
           for (const auto& it : items) {
             FILE* f = fopen((prefix + "." + it.name).c_str(), "w");
@@ -482,28 +733,21 @@ int runSites(const Context& cliCtx, const std::string& listFile, const std::stri
         }
       }
     };
-    int hostThreads = 1;
-    {
-      cpu_set_t cpus;
-      if (sched_getaffinity(0, sizeof cpus, &cpus) == 0) hostThreads = CPU_COUNT(&cpus);
+    runThreads(std::max(1, std::min({hostThreads / nParts, (int)jobs.size(), 64})), worker);
     }
-    const int nThreads = std::max(1, std::min({hostThreads / nParts, (int)jobs.size(), 64}));
-    if (nThreads == 1) {
-      worker();
-    } else {
-      std::vector<std::thread> pool;
-      for (int i = 0; i < nThreads; i++) pool.emplace_back(worker);
-      for (auto& th : pool) th.join();
-    }
-    worst = std::max(worst, worstA.load());
-    partWorst[part] = worst;
+    if (dRec) sipnet_dev_free(dRec);
+    if (dPlanes) sipnet_dev_free(dPlanes);
+    sipnet_batch_destroy(b);
+    partWorst[part] = worstA.load();
     };   // runPart
     if (nParts == 1) {
       runPart(0);
     } else {
+      FirstFatal sink;
       std::vector<std::thread> parts;
-      for (int p = 0; p < nParts; p++) parts.emplace_back(runPart, p);
+      for (int p = 0; p < nParts; p++) parts.emplace_back([&, p]() { guarded(sink, [&]() { runPart(p); }); });
       for (auto& th : parts) th.join();
+      sink.exitIfSet();
     }
     for (int w : partWorst) worst = std::max(worst, w);
   }
@@ -528,7 +772,7 @@ int main(int argc, char** argv) {
     opts.push_back({kFlagOpts[k][0], no_argument, &tmpFlag, 1});
     opts.push_back({strdup((std::string("no-") + kFlagOpts[k][0]).c_str()), no_argument, &tmpFlag, 0});
   }
-  enum { OPT_RIN = 1001, OPT_ROUT, OPT_DBG, OPT_ENS, OPT_DEV, OPT_MATH, OPT_ESTATS, OPT_SITES };
+  enum { OPT_RIN = 1001, OPT_ROUT, OPT_DBG, OPT_ENS, OPT_DEV, OPT_MATH, OPT_ESTATS, OPT_SITES, OPT_EOUT, OPT_ECOLS, OPT_EF32, OPT_ETEXT };
   opts.push_back({"input-file", required_argument, nullptr, 'i'});
   opts.push_back({"file-prefix", required_argument, nullptr, 'f'});
   opts.push_back({"file-name", required_argument, nullptr, 'f'});
@@ -541,10 +785,15 @@ int main(int argc, char** argv) {
   opts.push_back({"math", required_argument, nullptr, OPT_MATH});
   opts.push_back({"ensemble-stats", required_argument, nullptr, OPT_ESTATS});
   opts.push_back({"sites", required_argument, nullptr, OPT_SITES});
+  opts.push_back({"ensemble-out", required_argument, nullptr, OPT_EOUT});
+  opts.push_back({"ensemble-out-columns", required_argument, nullptr, OPT_ECOLS});
+  opts.push_back({"ensemble-out-f32", no_argument, nullptr, OPT_EF32});
+  opts.push_back({"ensemble-text", no_argument, nullptr, OPT_ETEXT});
   opts.push_back({"help", no_argument, nullptr, 'h'});
   opts.push_back({"version", no_argument, nullptr, 'v'});
   opts.push_back({nullptr, 0, nullptr, 0});
-  std::string ensembleFile, devicesArg = "0", mathArg = "auto", ensembleStats, sitesFile;
+  std::string ensembleFile, devicesArg = "0", mathArg = "auto", ensembleStats, sitesFile, blockColumns;
+  BlockSpec block;
   int longIndex = 0, ch;
   while ((ch = getopt_long(argc, argv, "he:f:i:v", opts.data(), &longIndex)) != -1) {
     switch (ch) {
@@ -560,6 +809,10 @@ int main(int argc, char** argv) {
       case OPT_MATH: mathArg = optarg; break;
       case OPT_ESTATS: ensembleStats = optarg; break;
       case OPT_SITES: sitesFile = optarg; break;
+      case OPT_EOUT: block.path = optarg; break;
+      case OPT_ECOLS: blockColumns = optarg; break;
+      case OPT_EF32: block.f32 = true; break;
+      case OPT_ETEXT: block.text = true; break;
       case 'h': usage(argv[0]); return 0;
       case 'v': printf("SIPNET version 2.1.0 (%s)\n", sipnet_version()); return 0;
       default: usage(argv[0]); return 8;  // EXIT_CODE_BAD_CLI_ARGUMENT
@@ -574,13 +827,20 @@ int main(int argc, char** argv) {
     logError("--ensemble-stats needs --ensemble-params\n");
     return 8;
   }
+  if (block.on() ? (ensembleFile.empty() && sitesFile.empty()) || !ensembleStats.empty()
+                 : (!blockColumns.empty() || block.f32 || block.text)) {
+    logError("--ensemble-out needs --ensemble-params or --sites (not --ensemble-stats); "
+             "--ensemble-out-columns / -f32 / --ensemble-text need --ensemble-out\n");
+    return 8;
+  }
+  if (!blockColumns.empty()) parseBlockColumns(block, blockColumns);
   g_quiet = ctx.i("quiet") != 0;
   if (!sitesFile.empty()) {
     if (!ensembleFile.empty() || !ensembleStats.empty()) {
       logError("--sites does not combine with --ensemble-params / --ensemble-stats\n");
       return 8;
     }
-    return runSites(ctx, sitesFile, mathArg, devices);
+    return runSites(ctx, sitesFile, mathArg, devices, block);
   }
   if (ctx.s("filePrefix").empty()) die(3, "filePrefix must be set for SIPNET to run\n");
   readInputFile(ctx);
@@ -666,22 +926,10 @@ int main(int argc, char** argv) {
   std::vector<sipnet_restart> resume;
   if (!restartIn.empty()) {
     resume.resize(M);
-    const double* c0 = sipnet_clim_data(clim);
     for (int m = 0; m < M; m++) {
       const std::string path = ensembleFile.empty() ? restartIn : restartIn + "." + std::to_string(m);
       check(sipnet_io_read_restart(path.c_str(), &resume[m]), "reading restart checkpoint");
-      int32_t warn = 0;
-      check(sipnet_restart_check(&resume[m], flags, T > 0, T > 0 ? sipnet_clim_year(clim)[0] : 0,
-                                 T > 0 ? sipnet_clim_day(clim)[0] : 0, T > 0 ? c0[10] : 0.0,
-                                 T > 0 ? c0[0] : 0.0, &warn), "restart checkpoint");
-      if (warn & SIPNET_RESTART_WARN_BOUNDARY_NOT_MIDNIGHT)
-        logWarning("Restart checkpoint boundary in " + path + " is more than one timestep before "
-                   "midnight; there is a time gap on resume.\n");
-      if (warn & SIPNET_RESTART_WARN_BUILD_INFO)
-        logInfo(std::string("Restart build info mismatch: checkpoint=") + resume[m].build_info + "\n");
-      if (warn & SIPNET_RESTART_WARN_TIME_GAP)
-        logWarning("Restart resumed segment starts more than one timestep after midnight "
-                   "checkpoint boundary; there is a time gap\n");
+      checkResume(resume[m], path, flags, clim);
     }
   }
 
@@ -752,6 +1000,15 @@ int main(int argc, char** argv) {
   const int nShards = (int)devices.size();
   if (nShards > 1)
     logInfo("ensemble sharded over " + std::to_string(nShards) + " device(s)\n");
+  if (block.on() && !debugLog.empty()) die(8, "--ensemble-out does not combine with --debug-log\n");
+  // the block is created once; every shard streams its own member range into it
+  const bool wantText = !block.on() || block.text;
+  const bool needRec = wantText || !restartOut.empty() || (block.on() && !block.planesOnly());
+  const bool blockFast = mathArg == "fast" || (mathArg == "auto" && !ensembleFile.empty());
+  sipnet_ensemble_file* blockFile =
+      block.on() ? createBlock(block, block.path, T, M, clim, nullptr,
+                               "parameter_table=" + ensembleFile + "\nmath=" + (blockFast ? "fast" : "strict"))
+                 : nullptr;
   std::atomic<int> worst{0};
   std::mutex logMutex;
   int hostThreads = 1;
@@ -781,6 +1038,25 @@ int main(int argc, char** argv) {
       check(sipnet_batch_import_restart(b, 0, 0, Ms, resume.data() + m0, nullptr), "restart checkpoint");
     std::vector<double> state0((size_t)Ms * SIPNET_NSTATE);
     check(sipnet_batch_get_state(b, state0.data(), nullptr), "state");
+    if (!needRec) {   // the block alone, three planes: the lean kernels, nothing but the planes leaves the device
+      double* dPlanes = (double*)sipnet_dev_alloc((size_t)3 * T * Ms * sizeof(double));
+      if (!dPlanes) die(1, std::string(sipnet_last_error()) + "\n");
+      check(sipnet_batch_run(b, 0, T, dPlanes, dPlanes + (size_t)T * Ms, dPlanes + (size_t)2 * T * Ms, nullptr, Ms, nullptr), "run");
+      std::vector<int32_t> status(Ms);
+      check(sipnet_batch_get_status(b, status.data(), nullptr), "status");
+      for (int m = 0; m < Ms; m++)
+        if (status[m] != 0) {
+          std::lock_guard<std::mutex> lock(logMutex);
+          logError("member " + std::to_string(m0 + m) + ": status " + std::to_string(status[m]) +
+                   " (NPP allocation params must be less than one individually and add to less than one)\n");
+          int w = worst.load();
+          while (status[m] > w && !worst.compare_exchange_weak(w, status[m])) {}
+        }
+      putBlock(blockFile, block, T, Ms, T, 0, Ms, m0, dPlanes, nullptr);
+      sipnet_dev_free(dPlanes);
+      sipnet_batch_destroy(b);
+      return;
+    }
     const size_t recElems = (size_t)T * SIPNET_NREC * Ms;
     double* dRec = (double*)sipnet_dev_alloc(recElems * sizeof(double));
     if (!dRec) die(1, std::string(sipnet_last_error()) + "\n");
@@ -794,6 +1070,13 @@ int main(int argc, char** argv) {
     } else {
       check(sipnet_batch_run(b, 0, T, nullptr, nullptr, nullptr, dRec, Ms, nullptr), "run");
     }
+    if (blockFile && !block.planesOnly()) putBlock(blockFile, block, T, Ms, T, 0, Ms, m0, nullptr, dRec);
+    if (blockFile && block.planesOnly()) {   // (with text or checkpoints: the three planes are record columns 0, 1, 2)
+      BlockSpec asCols = block;
+      asCols.cols = {sipnet_io_out_column_index("nee"), sipnet_io_out_column_index("gpp"), sipnet_io_out_column_index("evapotranspiration")};
+      putBlock(blockFile, asCols, T, Ms, T, 0, Ms, m0, nullptr, dRec);
+    }
+    // (what follows needs every record on the host: the members' text files and checkpoints)
     std::vector<double> rec(recElems);
     check(sipnet_dev_to_host(rec.data(), dRec, recElems * sizeof(double), nullptr), "copy back");
     if (dbgElems) check(sipnet_dev_to_host(dbg.data(), dDbg, dbgElems * sizeof(double), nullptr), "copy back");
@@ -829,36 +1112,22 @@ int main(int argc, char** argv) {
                                          sipnet_clim_day(clim), sipnet_clim_data(clim), one.data(),
                                          oneDbg.data()), "writing debug logs");
       }
-      if (ctx.i("doMainOutput"))
+      if (wantText && ctx.i("doMainOutput"))
         check(sipnet_io_write_out((prefix + tag + ".out").c_str(), ctx.i("printHeader"), T,
                                   sipnet_clim_year(clim), sipnet_clim_day(clim), sipnet_clim_data(clim),
                                   one.data()), "writing output");
-      if (useEvents)
+      if (wantText && useEvents)
         check(sipnet_io_write_events_out((ctx.s("eventsPrefix") + tag + ".out").c_str(),
                                          ctx.i("printHeader"), flags, shardParams + (size_t)m * SIPNET_NPARAMS,
                                          T, sipnet_clim_year(clim), sipnet_clim_day(clim),
                                          sipnet_clim_data(clim), nEvents, events, one.data(),
                                          state0.data() + (size_t)m * SIPNET_NSTATE), "writing events.out");
       if (!restartOut.empty()) {  // restartWriteCheckpoint, restart.c:932-996
-        const std::string path = restartOut + tag;
-        sipnet_restart ck;
         const double* prevPools = T >= 2 ? one.data() + (size_t)(T - 2) * SIPNET_NREC + 14
                                          : state0.data() + (size_t)m * SIPNET_NSTATE;
-        {
-          std::lock_guard<std::mutex> lock(gpuMutex);
-          check(sipnet_batch_export_restart(b, 0, m, T, one.data() + (size_t)(T - 1) * SIPNET_NREC,
-                                            prevPools, &ck, nullptr), "restart checkpoint");
-        }
-        int32_t warn = 0;
-        check(sipnet_restart_check_boundary_for_write(&ck, &warn), "restart checkpoint");
-        if (warn & SIPNET_RESTART_WARN_BOUNDARY_NOT_MIDNIGHT) {
-          std::lock_guard<std::mutex> lock(logMutex);
-          logWarning("Restart checkpoint " + path + " ends more than one timestep before midnight; "
-                     "there will be a time gap if this file is used to resume.\n");
-        }
-        check(sipnet_io_write_restart(path.c_str(), &ck), "writing restart checkpoint");
+        writeCheckpoint(b, gpuMutex, logMutex, 0, m, T, one.data() + (size_t)(T - 1) * SIPNET_NREC, prevPools, restartOut + tag);
       }
-      if (ctx.i("doSingleOutputs")) {  // sipnet.c:1993-1998, outputItems.c:126-150
+      if (wantText && ctx.i("doSingleOutputs")) {  // sipnet.c:1993-1998, outputItems.c:126-150
         const struct { const char* name; int col; } items[] = {{"NEE", 0}, {"NEE_cum", 3}, {"GPP", 1}, {"GPP_cum", 35}};
         for (const auto& it : items) {
           FILE* f = fopen((prefix + tag + "." + it.name).c_str(), "w");
@@ -870,19 +1139,12 @@ int main(int argc, char** argv) {
       }
     };
     {
-      const int nThreads = std::max(1, std::min({hostThreads / nShards, Ms, 64}));
       std::atomic<int> next{0};
       auto worker = [&]() {
         std::vector<double> one((size_t)T * SIPNET_NREC), oneDbg(dbgElems ? (size_t)T * SIPNET_NDBG : 0);
         for (int m = next.fetch_add(1); m < Ms; m = next.fetch_add(1)) writeMember(m, one, oneDbg);
       };
-      if (nThreads == 1) {
-        worker();
-      } else {
-        std::vector<std::thread> pool;
-        for (int i = 0; i < nThreads; i++) pool.emplace_back(worker);
-        for (auto& th : pool) th.join();
-      }
+      runThreads(std::max(1, std::min({hostThreads / nShards, Ms, 64})), worker);
     }
     sipnet_dev_free(dRec);
     if (dDbg) sipnet_dev_free(dDbg);
@@ -891,10 +1153,13 @@ int main(int argc, char** argv) {
   if (nShards == 1) {
     runShard(0);
   } else {
+    FirstFatal sink;
     std::vector<std::thread> shards;
-    for (int k = 0; k < nShards; k++) shards.emplace_back(runShard, k);
+    for (int k = 0; k < nShards; k++) shards.emplace_back([&, k]() { guarded(sink, [&]() { runShard(k); }); });
     for (auto& th : shards) th.join();
+    sink.exitIfSet();
   }
+  if (blockFile) check(sipnet_io_ensemble_close(blockFile), "closing the ensemble block");
   sipnet_clim_free(clim);
   sipnet_io_free(events);
   return worst.load();

@@ -857,6 +857,15 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
 #endif
   __syncthreads();  // the only workgroup barrier: flags initialised before anyone spins
   if (!present) return;
+#ifdef SIPNET_PROBE_PRIO   // (probe: wave priorities by role, 0xCWLF two bits each -- tools/build_variants.py)
+  {
+    constexpr int pr = SIPNET_PROBE_PRIO;
+    if (role == 0) __builtin_amdgcn_s_setprio((pr >> 12) & 3);
+    else if (role == 1) __builtin_amdgcn_s_setprio((pr >> 8) & 3);
+    else if (role == 2) __builtin_amdgcn_s_setprio((pr >> 4) & 3);
+    else __builtin_amdgcn_s_setprio(pr & 3);
+  }
+#endif
 
   const unsigned char* __restrict__ planBytes =
       (const unsigned char*)(a.fast + (int64_t)site * a.n_steps_total);
@@ -1122,10 +1131,12 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
       const FastRec* r = recs + t;
       return TileFields{r->tair10, r->tsoil, r->tsoil10, r->tillP1, r->bitsOps};
     };
-    auto laneD = [](double v, int l) {
+    // (narrow record fields, fast_math.h recR: an fp32-mixed batch has the float in the low word)
+    auto laneR = [](double v, int l) -> R {
       const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+      if (sizeof(R) == 4) return recR<R>(__hiloint2double(0, lo));
       const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
-      return __hiloint2double(hi, lo);
+      return recR<R>(__hiloint2double(hi, lo));
     };
     R qSoil = 0, gFine = 0, gCoarse = 0;
     bool haveQ = false;
@@ -1137,8 +1148,8 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
       const int tLast = (tileStart + kFastTile) < tEnd ? (tileStart + kFastTile) : tEnd;
       for (int t = tFirst; t < tLast; t++) {
         const int j = t - tileStart;
-        const R tair10 = (R)laneD(cur.tair10, j), tsoil = (R)laneD(cur.tsoil, j);
-        const R tillP1 = (R)laneD(cur.tillP1, j);
+        const R tair10 = laneR(cur.tair10, j), tsoil = laneR(cur.tsoil, j);
+        const R tillP1 = laneR(cur.tillP1, j);
         const int bits = __builtin_amdgcn_readlane(cur.bits, j);
         // the slot of step t was last used for step t-2, which C is past once it has posted the
         // leaf area of step t-1
@@ -1149,7 +1160,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         g1 = (tsoil < K_frozThr) ? g1 * K_frozFolEff : g1;
         const R g2 = K_bvr * vegQ;
         if (!haveQ || !(bits & FAST_TSOIL_SAME)) {
-          const R tsoil10 = (R)laneD(cur.tsoil10, j);
+          const R tsoil10 = laneR(cur.tsoil10, j);
           qSoil = fexp2(q10Arg(tsoil10, K_lgSoil), EC);
           gFine = K_bfr * fexp2(q10Arg(tsoil10, K_lgFine), EC);
           gCoarse = K_bcr * fexp2(q10Arg(tsoil10, K_lgCoarse), EC);
@@ -1565,18 +1576,18 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
           // one trial in 600 had S take the soil factors of step t+2 for step t, 2e-5 off on NEE)
           if (NCyc) awaitAtLeast(&seqMinN, t - 1);
           WAIT_END(1)
-          const R vegQ = fexp2(q10Arg((R)q5.y, K_lgVeg), EC);
+          const R vegQ = fexp2(q10Arg(recR<R>(q5.y), K_lgVeg), EC);
           R g1 = K_fol * vegQ;
-          g1 = ((R)q1.y < K_frozThr) ? g1 * K_frozFolEff : g1;
+          g1 = (recR<R>(q1.y) < K_frozThr) ? g1 * K_frozFolEff : g1;
           const R g2 = K_bvr * vegQ;
           if (!haveQ || !(bits & FAST_TSOIL_SAME)) {
-            const R tsoil10 = (R)q6x;
+            const R tsoil10 = recR<R>(q6x);
             qSoil = fexp2(q10Arg(tsoil10, K_lgSoil), EC);
             gFine = K_bfr * fexp2(q10Arg(tsoil10, K_lgFine), EC);
             gCoarse = K_bcr * fexp2(q10Arg(tsoil10, K_lgCoarse), EC);
             haveQ = true;
           }
-          const R qSoilT = K_bsr * qSoil * (R)q3.x;
+          const R qSoilT = K_bsr * qSoil * recR<R>(q3.x);
           if (NCyc) postRaw(&mailFac[t & 1][6][lane], qSoil);   // before the flag post5 sets
           post5(&mailFac[t & 1][0][lane], &seqFac, g1, g2, qSoilT, gFine, gCoarse, t);
         }
@@ -1586,14 +1597,14 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         if (Staged && stageOn && t == statNext) stagedAct();
         if (!(bits & FAST_PAR_POS)) continue;  // night: potGrossPsn = 0, nobody waits for it
         {
-        const R tair = (R)q1.x;
+        const R tair = recR<R>(q1.x);
         // climate-only factors first, then the leaf area of this step
         const R dTemp = rmax0((K_tmax - tair) * (tair - K_tmin) * K_invDen);
-        R vpdPow = (R)q2.y * (R)q2.y;
+        R vpdPow = recR<R>(q2.y) * recR<R>(q2.y);
         if (!PlainExp)
-          vpdPow = (K_vexp == R(2)) ? vpdPow : fexp2(K_vexp * (R)((const double*)(recB + 144))[2], EC);
+          vpdPow = (K_vexp == R(2)) ? vpdPow : fexp2(K_vexp * recR<R>(((const double*)(recB + 144))[2]), EC);
         const R dVpd = rmax0(ffma(-K_slope, vpdPow, R(1)));
-        const R q = (R)q2.x * K_invHalf;
+        const R q = recR<R>(q2.x) * K_invHalf;
         const R e0 = fexp2(q, EC);
         WAIT_BEGIN()
         const R lai = take(&mailLai[t & 1][lane], &seqLai, t);
@@ -1676,7 +1687,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
                      : "=&v"(q0), "=&v"(q1), "=&v"(q2.y), "=&v"(q3.y), "=&v"(q4), "=&v"(q5.x), "=&v"(j0.x), "=&v"(j0.w)
                      : "v"(ldsAddr(recB)) : "memory");
         const int32_t* rareI = (const int32_t*)(recB + 184);
-        const R len = (R)q0.x, invLen = (R)q0.y, tair = (R)q1.x, tsoil = (R)q1.y;
+        const R len = (R)q0.x, invLen = (R)q0.y, tair = recR<R>(q1.x), tsoil = recR<R>(q1.y);
         const int bits = uni(j0.x);
         const int nEv = uni(j0.w);
         const R eWater = (R)soilWater, eSnow = (R)snow;
@@ -1701,7 +1712,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
               mMoist = general ? fpow(anoxic, X_anExp) : (X_anExp != R(2) ? R(0) : mMoist);
             }
             mK = mMoist * X_iBsr;
-            if (__builtin_expect(bits & FAST_HAS_TILL, 0)) mK = fdiv(mK, (R)((const double*)recB)[6]);   // FastRec::tillP1
+            if (__builtin_expect(bits & FAST_HAS_TILL, 0)) mK = fdiv(mK, recR<R>(((const double*)recB)[6]));   // FastRec::tillP1
           }
           moistEff = (bits & FAST_TSOIL_NEG) ? R(1) : moistEff;
           if (Opt) post2(&mailFac[t & 1][5][lane], &seqMoist, moistEff, mK, t);
@@ -1719,7 +1730,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
 
         // everything that does not need the light block first
         const bool tairPos = (bits & FAST_TAIR_POS) != 0;
-        const R rate = (R)q3.y;
+        const R rate = recR<R>(q3.y);
         const R rain = tairPos ? rate : R(0), snowFall = tairPos ? R(0) : rate;
         // calcPrecip(), sipnet.c:848-882.  Ext: with the leaf-water flag the immediate evaporation is capped by what
         // the canopy holds, lai(t) x leafPoolDepth -- asked for on steps with rain only (the site's: wave-uniform);
@@ -1735,7 +1746,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         R snowMelt = 0, sublimation = 0, evaporationPot = 0;
         const bool hasSnow = eSnow > R(0);
         if (hasSnow) {
-          R subl = rmax0((R)q4.x * K_invRd);
+          R subl = rmax0(recR<R>(q4.x) * K_invRd);
           R remaining = ffma(snowFall, len, eSnow);
           const R afterSubl = ffma(-subl, len, remaining);
           const bool allGone = afterSubl < R(0);
@@ -1748,7 +1759,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         } else {
           const R wf = clip01(eWater * K_invWhc);
           const R rsoil = fexp2(ffma(-K_c2l, wf, K_c1l), EC);
-          evaporationPot = rmax0(fdiv((R)q4.y, ffma(K_rd, (R)q5.x, rsoil)));
+          evaporationPot = rmax0(fdiv(recR<R>(q4.y), ffma(K_rd, recR<R>(q5.x), rsoil)));
         }
         R removable = rminv(eWater, K_whc) * K_wrf;
         removable = frozen ? removable * K_frozEff : removable;
@@ -1776,7 +1787,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
           takePgp(&mailPgp[t & 1][lane], &seqPgp, &mailAlive[t & 1][lane], t, pgpSpec, diedBefore);
           WAIT_END(0)
           const R potGrossPsn = diedBefore ? R(0) : pgpSpec;
-          const R potTrans = potGrossPsn * (R)q2.y * K_tr;
+          const R potTrans = potGrossPsn * recR<R>(q2.y) * K_tr;
           const bool hasPsn = potGrossPsn >= R(kTiny);
           const bool limited = hasPsn && removable < potTrans;
           transpiration = hasPsn ? (limited ? removable : potTrans) : R(0);

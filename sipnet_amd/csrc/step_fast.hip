@@ -332,7 +332,7 @@ void stepFastKernel(FastArgs a) {
     const double* rare = (const double*)(recB + 144);   // w1 - log2vpd gddAfter tillAfter
     const int32_t* rareI = (const int32_t*)(recB + 184);  // ins0 ins1 opFirst evFirst
 
-    const R len = (R)q0.x, invLen = (R)q0.y, tair = (R)q1.x, tsoil = (R)q1.y;
+    const R len = (R)q0.x, invLen = (R)q0.y, tair = recR<R>(q1.x), tsoil = recR<R>(q1.y);
     const int bits = uni(j0.x);
     const int slots = uni(j0.y);
     const int insSlot = uni(j0.z);
@@ -394,13 +394,13 @@ void stepFastKernel(FastArgs a) {
     R transpiration = 0, photosynthesis = 0;
     if (bits & FAST_PAR_POS) {
       const R dTemp = rmax0((K_tmax - tair) * (tair - K_tmin) * K_invDen);
-      R vpdPow = (R)q2.y * (R)q2.y;
-      if (!PlainExp) vpdPow = (K_vexp == R(2)) ? vpdPow : fexp2(K_vexp * (R)rare[2], EC);
+      R vpdPow = recR<R>(q2.y) * recR<R>(q2.y);
+      if (!PlainExp) vpdPow = (K_vexp == R(2)) ? vpdPow : fexp2(K_vexp * recR<R>(rare[2]), EC);
       const R dVpd = rmax0(R(1) - K_slope * vpdPow);
       // Simpson over 7 canopy layers: sum c_i (1 - e_i) / 18 = 1 - (sum c_i e_i) / 18,
       // c = 1 4 2 4 2 4 1.  lai = 0 needs no special case: potGrossPsn carries the factor lai.
       const R r1 = fexp2(K_attl * lai, EC);
-      const R q = (R)q2.x * K_invHalf;
+      const R q = recR<R>(q2.x) * K_invHalf;
       const R r2 = r1 * r1, r3 = r2 * r1, r4 = r2 * r2, r5 = r4 * r1, r6 = r3 * r3;
       const R e0 = fexp2(q, EC), e1 = fexp2(q * r1, EC), e2 = fexp2(q * r2, EC), e3 = fexp2(q * r3, EC);
       const R e4 = fexp2(q * r4, EC), e5 = fexp2(q * r5, EC), e6 = fexp2(q * r6, EC);
@@ -408,7 +408,7 @@ void stepFastKernel(FastArgs a) {
       const R dLight = R(1) - s * R(1.0 / 18.0);
       const R potGrossPsn = K_g * lai * dTemp * dVpd * dLight;
       // moisture(), sipnet.c:656-699, branch-free
-      const R potTrans = potGrossPsn * (R)q2.y * K_tr;
+      const R potTrans = potGrossPsn * recR<R>(q2.y) * K_tr;
       R removable = rminv(eWater, K_whc) * K_wrf;
       removable = frozen ? removable * K_frozEff : removable;
       const bool hasPsn = potGrossPsn >= R(kTiny);
@@ -421,7 +421,7 @@ void stepFastKernel(FastArgs a) {
 
     // calcPrecip(), sipnet.c:848-882 (the site's air temperature decides rain or snow)
     const bool tairPos = (bits & FAST_TAIR_POS) != 0;
-    const R rate = (R)q3.y;
+    const R rate = recR<R>(q3.y);
     const R rain = tairPos ? rate : R(0), snowFall = tairPos ? R(0) : rate;
     R immedEvap = rain * K_immed;
     if (Generic) immedEvap = rminv(immedEvap, F.leafWater ? lai * G_leafPool : R(kNoCap));  // sipnet.c:872-878
@@ -432,7 +432,7 @@ void stepFastKernel(FastArgs a) {
     R snowMelt = 0, sublimation = 0, evaporationPot = 0;
     const bool hasSnow = eSnow > R(0);
     if (hasSnow) {
-      R subl = rmax0((R)q4.x * K_invRd);
+      R subl = rmax0(recR<R>(q4.x) * K_invRd);
       R remaining = eSnow + snowFall * len;
       const bool allGone = remaining - subl * len < R(0);
       subl = allGone ? remaining * invLen : subl;
@@ -444,7 +444,7 @@ void stepFastKernel(FastArgs a) {
     } else {
       const R wf = clip01(eWater * K_invWhc);
       const R rsoil = fexp2(K_c1l - K_c2l * wf, EC);
-      evaporationPot = rmax0(fdiv((R)q4.y, K_rd * (R)q5.x + rsoil));
+      evaporationPot = rmax0(fdiv(recR<R>(q4.y), K_rd * recR<R>(q5.x) + rsoil));
     }
     // calcSoilWaterFluxes(), sipnet.c:963-1031
     R evaporation, drainage, fastFlow;
@@ -467,7 +467,7 @@ void stepFastKernel(FastArgs a) {
     const R meanNpp = (R)(ringSum * 0.2);  // runmean.c:119-121 (sum / 5)
 
     // vegResp(), sipnet.c:1051-1068
-    const R vegQ = fexp2((R)q5.y * K_lgVeg, EC);
+    const R vegQ = fexp2(recR<R>(q5.y) * K_lgVeg, EC);
     R folResp = baseFolResp * (vegQ * K_folShift);
     folResp = frozen ? folResp * K_frozFolEff : folResp;
     R rVeg = folResp + K_bvr * totalWoodC * vegQ;
@@ -491,7 +491,7 @@ void stepFastKernel(FastArgs a) {
     const R coarseRootLoss = K_crt * eCoarse, fineRootLoss = K_frt * eFine;
     R coarseRootCreation = K_ca * meanNpp, fineRootCreation = K_fa * meanNpp;
     if (!haveQ || !(bits & FAST_TSOIL_SAME)) {
-      const R tsoil10 = (R)q6.x;
+      const R tsoil10 = recR<R>(q6.x);
       qSoil = fexp2(tsoil10 * K_lgSoil, EC);
       qFine = fexp2(tsoil10 * K_lgFine, EC);
       qCoarse = fexp2(tsoil10 * K_lgCoarse, EC);
@@ -512,7 +512,7 @@ void stepFastKernel(FastArgs a) {
       moistEff = F.anaerobic ? anMoist : moistEff;
     }
     moistEff = (bits & FAST_TSOIL_NEG) ? R(1) : moistEff;   // (frozen soil, or the water_hresp flag off: the plan's bit)
-    R rSoil = eSoilC * K_bsr * moistEff * qSoil * (R)q3.x;
+    R rSoil = eSoilC * K_bsr * moistEff * qSoil * recR<R>(q3.x);
     // optional pools: calcLitterFluxes() sipnet.c:1150-1171, C:N effect depeffects.c:78-87,
     // calcMethaneFlux() sipnet.c:1201-1214
     R rLitter = 0, litterToSoil = 0, soilMethane = 0, litterMethane = 0;
@@ -528,7 +528,7 @@ void stepFastKernel(FastArgs a) {
       }
       rSoil *= cnSoil;
       // without a litter pool the pool is empty and its rate 0: both fluxes come out as 0
-      const R breakdown = eLitter * G_lbr * qSoil * moistEff * (R)q3.x * cnLitter;
+      const R breakdown = eLitter * G_lbr * qSoil * moistEff * recR<R>(q3.x) * cnLitter;
       rLitter = breakdown * G_flr;
       litterToSoil = breakdown * (R(1) - G_flr);
       R mMoist = anoxic * anoxic;  // pow(A, anaerobicTransExp) with the usual exponent 2

@@ -271,3 +271,127 @@ def test_cli_sites_stacks_run_directories_into_shared_batches(tmp_path, math, de
         for f in ("sipnet.out", "events.out"):
             assert same(open(tmp_path / f"ens{k}" / f, "rb").read(), open(solo / f, "rb").read()), (k, f)
     assert open(tmp_path / "ens0" / "sipnet.out", "rb").read() != open(tmp_path / "ens2" / "sipnet.out", "rb").read()
+
+
+def test_cli_ensemble_out_option_errors_need_no_gpu(tmp_path):
+    """--ensemble-out without an ensemble, its satellites without it, an unknown column -> 8"""
+    stage("niwot", tmp_path)
+    assert run_cli(tmp_path, "-i", "sipnet.in", "--ensemble-out", "e.nc").returncode == 8
+    open(tmp_path / "m.txt", "w").write("aMax\n8\n")
+    assert run_cli(tmp_path, "-i", "sipnet.in", "--ensemble-params", "m.txt", "--ensemble-out-f32").returncode == 8
+    assert run_cli(tmp_path, "-i", "sipnet.in", "--ensemble-params", "m.txt", "--ensemble-text").returncode == 8
+    assert run_cli(tmp_path, "-i", "sipnet.in", "--ensemble-params", "m.txt", "--ensemble-out", "e.nc",
+                   "--ensemble-out-columns", "nee,frobnication").returncode == 8
+    assert run_cli(tmp_path, "-i", "sipnet.in", "--ensemble-params", "m.txt", "--ensemble-out", "e.nc",
+                   "--ensemble-stats", "s.txt").returncode == 8
+
+
+def _out_table(text):
+    """`.out` text -> (header names, list of rows of tokens)"""
+    lines = text.splitlines()
+    return lines[0].split(), [l.split() for l in lines[1:]]
+
+
+def _assert_block_matches_text(block, names, rows, member, where):
+    """every variable of the block against the printed `.out` columns, at print precision"""
+    for j, name in enumerate(names):
+        if name in ("year", "day", "time"):
+            continue
+        col = block[name][:, member]
+        for t in (0, 1, len(rows) // 2, len(rows) - 1):
+            text = rows[t][j]
+            digits = len(text.split(".")[1]) if "." in text else 0
+            assert abs(float(text) - col[t]) <= 0.5000001 * 10 ** -digits, (where, name, t, text, col[t])
+
+
+@pytest.mark.gpu
+def test_cli_ensemble_out_block_against_the_goldens_and_the_members_text(tmp_path):
+    """`sipnet --ensemble-params T --ensemble-out e.nc --ensemble-out-columns all --ensemble-text` on russell_1 with a
+    3-member table: every variable of the block equals, at print precision, the columns of the reference's golden
+    `.out` (member 0 = the unchanged parameters) and of the members' own text files; the default block (three planes
+    from the lean throughput kernels, no text) and the sharded run (--devices 0,0: two shards streaming their member
+    ranges into the one file) hold the same numbers; --ensemble-out-f32 halves the file"""
+    import gzip
+    from sipnet_amd import ensemble_io as eio
+    stage("russell_1", tmp_path)
+    open(tmp_path / "members.txt", "w").write("aMax psnTOpt\n" + "\n".join(
+        f"{a} {o}" for a, o in ((_param(tmp_path, "aMax"), _param(tmp_path, "psnTOpt")), (8.1, 23.0), (6.4, 25.5))) + "\n")
+    r = run_cli(tmp_path, "-i", "sipnet.in", "--ensemble-params", "members.txt", "--ensemble-out", "all.nc",
+                "--ensemble-out-columns", "all", "--ensemble-text", "--math", "strict")
+    assert r.returncode == 0, r.stdout + r.stderr
+    block = eio.read_ensemble_netcdf(tmp_path / "all.nc")
+    _, dims, gatts, units = eio.open_ensemble_netcdf(tmp_path / "all.nc")
+    gold = gzip.open(os.path.join(helpers.smoke_dir("russell_1"), "sipnet.out.gz"), "rt").read()
+    names, rows = _out_table(gold)
+    assert dims == {"time": len(rows), "member": 3} and gatts["math"] == "strict"
+    assert [n for n in names if n not in ("year", "day", "time")] == [k for k in block if k not in ("year", "day", "hour", "length", "member")]
+    _assert_block_matches_text(block, names, rows, 0, "golden")
+    assert [int(r_[0]) for r_ in rows] == block["year"].tolist() and [int(r_[1]) for r_ in rows] == block["day"].tolist()
+    assert open(tmp_path / "sipnet.0.out").read() == gold            # --ensemble-text: the text files as before
+    for m in range(3):
+        n2, rows_m = _out_table(open(tmp_path / f"sipnet.{m}.out").read())
+        _assert_block_matches_text(block, n2, rows_m, m, f"member {m}")
+    assert np.abs(block["nee"][:, 1] - block["nee"][:, 2]).max() > 1e-3
+    assert units["soilWater"] == "cm" and units["nee"] == "g C m-2 step-1"
+    # the default block: planes only, throughput kernels, no text files
+    for f in os.listdir(tmp_path):
+        if f.endswith(".out"):
+            os.remove(tmp_path / f)
+    r = run_cli(tmp_path, "-i", "sipnet.in", "--ensemble-params", "members.txt", "--ensemble-out", "planes.nc")
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert not [f for f in os.listdir(tmp_path) if f.endswith(".out")]
+    planes = eio.read_ensemble_netcdf(tmp_path / "planes.nc")
+    assert set(planes) == {"year", "day", "hour", "length", "member", "nee", "gpp", "evapotranspiration"}
+    for k in ("nee", "gpp", "evapotranspiration"):
+        np.testing.assert_allclose(planes[k], block[k], rtol=0, atol=1e-11)
+    # two shards on one device stream into ONE file; single precision
+    r = run_cli(tmp_path, "-i", "sipnet.in", "--ensemble-params", "members.txt", "--ensemble-out", "sharded.nc",
+                "--devices", "0,0", "--ensemble-out-f32", "--ensemble-out-columns", "nee,plantWoodC,soilWater")
+    assert r.returncode == 0, r.stdout + r.stderr
+    sh = eio.read_ensemble_netcdf(tmp_path / "sharded.nc")
+    assert sh["nee"].dtype == np.float32 and sh["member"].tolist() == [0, 1, 2]
+    for k in ("nee", "plantWoodC", "soilWater"):
+        np.testing.assert_allclose(sh[k], block[k].astype(np.float32), rtol=2e-7, atol=1e-11)
+    assert os.path.getsize(tmp_path / "sharded.nc") < 0.2 * os.path.getsize(tmp_path / "all.nc")
+
+
+def _param(d, name):
+    for l in open(os.path.join(d, "sipnet.param")):
+        t = l.split()
+        if t and t[0] == name:
+            return float(t[1])
+    raise KeyError(name)
+
+
+@pytest.mark.gpu
+def test_cli_sites_ensemble_out_one_block_per_forcing(tmp_path):
+    """--sites + --ensemble-out: one block per distinct forcing, named after the position of the site's first run;
+    members = positions in the list; the numbers are those of the directories' own text files"""
+    from sipnet_amd import ensemble_io as eio
+    dirs = []
+    for k, (case, amax) in enumerate((("russell_1", None), ("niwot", None), ("russell_1", 7.3))):
+        d = tmp_path / f"r{k}"
+        d.mkdir()
+        stage(case, d)
+        if amax is not None:
+            txt = [(f"aMax {amax}" if l.split() and l.split()[0] == "aMax" else l) for l in open(d / "sipnet.param").read().splitlines()]
+            open(d / "sipnet.param", "w").write("\n".join(txt) + "\n")
+        dirs.append(f"r{k}")
+    open(tmp_path / "runs.txt", "w").write("\n".join(dirs) + "\n")
+    r = run_cli(tmp_path, "--sites", "runs.txt", "-i", "sipnet.in", "--ensemble-out", "out/blk.nc", "--ensemble-out-columns", "all",
+                "--ensemble-text", "--math", "strict")
+    assert r.returncode == 6                      # the directory of the block does not exist: a file-open failure
+    os.mkdir(tmp_path / "out")
+    r = run_cli(tmp_path, "--sites", "runs.txt", "-i", "sipnet.in", "--ensemble-out", "out/blk.nc", "--ensemble-out-columns", "all",
+                "--ensemble-text", "--math", "strict")
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert sorted(os.listdir(tmp_path / "out")) == ["blk.0.nc", "blk.1.nc"]
+    b0 = eio.read_ensemble_netcdf(tmp_path / "out" / "blk.0.nc")      # russell_1's forcing: runs 0 and 2
+    b1 = eio.read_ensemble_netcdf(tmp_path / "out" / "blk.1.nc")      # niwot: run 1
+    assert b0["member"].tolist() == [0, 2] and b1["member"].tolist() == [1]
+    _, _, gatts, _ = eio.open_ensemble_netcdf(tmp_path / "out" / "blk.0.nc")
+    assert gatts["run_dirs"].split() == [str(tmp_path / "r0"), str(tmp_path / "r2")]
+    for blk, run, m in ((b0, 0, 0), (b0, 2, 1), (b1, 1, 0)):
+        names, rows = _out_table(open(tmp_path / f"r{run}" / "sipnet.out").read())
+        assert blk["nee"].shape[0] == len(rows)
+        _assert_block_matches_text(blk, names, rows, m, f"run {run}")

@@ -341,3 +341,123 @@ def test_batch_import_relays_a_reset_ring_onto_the_site_layout(tmp_path):
     with pytest.raises(sa.SipnetError):
         b.export_restart(0, 0, 5)
     b.close()
+
+
+
+SITE_CASES = ["niwot", "russell_2", "russell_replant", "halfhourly"]
+
+
+def _stage_sites(root, seg, extra_in):
+    """one run directory per case under root/<case>: segment 1 or 2 of its forcing; sipnet.in += extra_in(case)"""
+    for case in SITE_CASES:
+        _, lines, k = case_inputs(case)
+        w = os.path.join(root, case)
+        os.makedirs(w, exist_ok=True)
+        stage(case, w, lines[:k] if seg == 1 else lines[k:], f"events_seg{seg}.in")
+        with open(os.path.join(w, "sipnet.in"), "a") as f:
+            f.write(extra_in(case))
+    open(os.path.join(root, "runs.txt"), "w").write("\n".join(SITE_CASES) + "\n")
+
+
+def run_sites(root, *args):
+    return subprocess.run([CLI, "--sites", "runs.txt", "-i", "sipnet.in", "-f", "run", *args], cwd=root, capture_output=True,
+                          text=True, timeout=900)
+
+
+def test_sites_with_restart_checkpoints_two_invocations(tmp_path):
+    """SDA at the process boundary: `sipnet --sites` over one directory per member, RESTART_OUT / RESTART_IN in each
+    directory's sipnet.in (frontend.c:164-209, sipnet.c:1963-1989).  Invocation 1 (segment-1 directories of four
+    cases: three flag sets, three step lengths, in shared batches) writes the files and checkpoints of
+    test_cli_segments_against_the_reference; invocation 2 resumes every directory from the REFERENCE's checkpoint and
+    gives the reference's segment-2 text and end checkpoints; resumed from OUR checkpoints it gives the same text"""
+    root = str(tmp_path)
+    _stage_sites(root, 1, lambda case: "RESTART_OUT = mine1.restart\n")
+    r = run_sites(root)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for case in SITE_CASES:
+        w = os.path.join(root, case)
+        assert open(os.path.join(w, "run.out")).read() == gold_text(case, "seg1.out.gz"), case
+        assert open(os.path.join(w, "events.out")).read() == open(os.path.join(GOLD, case, "seg1.events.out")).read(), case
+        assert_checkpoints_close(sa.read_restart(os.path.join(w, "mine1.restart")), sa.read_restart(os.path.join(GOLD, case, "seg1.restart")))
+        shutil.copyfile(os.path.join(w, "mine1.restart"), os.path.join(root, f"{case}.mine1"))
+    # segment 2 from the reference's checkpoints (RESTART_IN relative to the run directory, RESTART_OUT absolute)
+    _stage_sites(root, 2, lambda case: f"RESTART_IN = ref1.restart\nRESTART_OUT = {root}/{case}.mine2\n")
+    for case in SITE_CASES:
+        shutil.copyfile(os.path.join(GOLD, case, "seg1.restart"), os.path.join(root, case, "ref1.restart"))
+    r = run_sites(root)
+    assert r.returncode == 0, r.stdout + r.stderr
+    seg2 = {}
+    for case in SITE_CASES:
+        w = os.path.join(root, case)
+        seg2[case] = open(os.path.join(w, "run.out")).read()
+        assert seg2[case] == gold_text(case, "seg2.out.gz"), case
+        assert open(os.path.join(w, "events.out")).read() == open(os.path.join(GOLD, case, "seg2.events.out")).read(), case
+        mine2 = sa.read_restart(os.path.join(root, f"{case}.mine2"))
+        assert mine2.processed_steps == len(case_inputs(case)[1])
+        assert_checkpoints_close(mine2, sa.read_restart(os.path.join(GOLD, case, "seg2.restart")))
+    # ... and from our own
+    _stage_sites(root, 2, lambda case: "RESTART_IN = own1.restart\n")
+    for case in SITE_CASES:
+        shutil.copyfile(os.path.join(root, f"{case}.mine1"), os.path.join(root, case, "own1.restart"))
+    r = run_sites(root)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for case in SITE_CASES:
+        assert open(os.path.join(root, case, "run.out")).read() == seg2[case], case
+    # the drop-in direction: the REFERENCE binary resumes from a checkpoint `--sites` wrote (each directory's sipnet.in
+    # still names own1.restart = the copy of mine1.restart)
+    if os.path.exists(REF_BIN):
+        for case in ("russell_2", "russell_replant", "halfhourly"):
+            w = os.path.join(root, case)
+            os.remove(os.path.join(w, "run.out"))
+            r = run(REF_BIN, w)
+            assert r.returncode == 0, r.stdout + r.stderr
+            assert open(os.path.join(w, "run.out")).read() == gold_text(case, "seg2.out.gz"), case
+
+
+def test_sites_members_resume_from_their_own_checkpoints_in_one_site(tmp_path):
+    """three members of ONE site (same forcing, other parameters), two cycles: `--sites` twice with checkpoints
+    == `--ensemble-params` in one piece.  A fourth directory whose checkpoint comes from another history (other year
+    counters / GDD) must not share their site -- and still runs"""
+    root = str(tmp_path)
+    case = "halfhourly"
+    _, lines, k = case_inputs(case)
+    amax = (7.2, 8.4, 9.1)
+    def stage_members(seg, extra):
+        for m, a in enumerate(amax):
+            w = os.path.join(root, f"m{m}")
+            os.makedirs(w, exist_ok=True)
+            stage(case, w, lines[:k] if seg == 1 else lines[k:], f"events_seg{seg}.in")
+            txt = [(f"aMax {a}" if l.split() and l.split()[0] == "aMax" else l) for l in open(os.path.join(w, "run.param")).read().splitlines()]
+            open(os.path.join(w, "run.param"), "w").write("\n".join(txt) + "\n")
+            with open(os.path.join(w, "sipnet.in"), "a") as f:
+                f.write(extra)
+    stage_members(1, "RESTART_OUT = cycle1.restart\n")
+    open(os.path.join(root, "runs.txt"), "w").write("m0\nm1\nm2\n")
+    r = run_sites(root)
+    assert r.returncode == 0 and "1 site(s) x up to 3 member(s)" in r.stdout, r.stdout + r.stderr
+    seg1 = [open(os.path.join(root, f"m{m}", "run.out")).read() for m in range(3)]
+    stage_members(2, "RESTART_IN = cycle1.restart\n")
+    # an intruder: same segment-2 forcing, but a checkpoint of a DIFFERENT history (niwot's would have other flags; use
+    # member 0's with the year-to-date GDD moved) -- it must get a site of its own
+    w = os.path.join(root, "odd")
+    shutil.copytree(os.path.join(root, "m0"), w)
+    ck = sa.read_restart(os.path.join(w, "cycle1.restart"))
+    ck.trackers[_lib.RT_NAMES.index("gdd")] += 1.0
+    sa.write_restart(os.path.join(w, "cycle1.restart"), ck)
+    open(os.path.join(root, "runs.txt"), "w").write("m0\nm1\nodd\nm2\n")
+    r = run_sites(root)
+    assert r.returncode == 0 and "2 site(s) x up to 3 member(s)" in r.stdout, r.stdout + r.stderr
+    seg2 = [open(os.path.join(root, f"m{m}", "run.out")).read() for m in range(3)]
+    # the same three members in one piece
+    w = os.path.join(root, "whole")
+    os.makedirs(w)
+    stage(case, w, lines, None)
+    open(os.path.join(w, "members.txt"), "w").write("aMax\n" + "\n".join(str(a) for a in amax) + "\n")
+    r = subprocess.run([CLI, "-i", "sipnet.in", "-f", "run", "--ensemble-params", "members.txt", "--math", "strict"], cwd=w,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for m in range(3):
+        whole = open(os.path.join(w, f"run.{m}.out")).read().splitlines()
+        hdr = 1 if "year" in whole[0] else 0
+        assert whole == seg1[m].splitlines() + seg2[m].splitlines()[hdr:], m
+    assert seg2[0] != seg2[2]

@@ -2,7 +2,7 @@
 """dev (GPU box): c10k with the synthetic year's light forced to polar night / midnight sun, to
 read off what a night step and a day step of the cooperative kernel cost (the day step carries the
 leaf-area -> potential-photosynthesis -> photosynthesis chain through all three wavefronts).
-usage: [SIPNET_LIB=build/variants/<name>/libsipnet_amd.so] [M=members] day_night_time.py [kernel: auto|coop_lds|coop_hbm|coop_pair|coop_quad|one_wave]"""
+usage: [SIPNET_LIB=build/variants/<name>/libsipnet_amd.so] [M=members] [PREC=f64|f32] day_night_time.py [kernel: auto|coop_lds|coop_hbm|coop_pair|coop_quad|one_wave]"""
 import os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
@@ -24,7 +24,8 @@ for name in ("as is", "night", "day"):
     if name == "night": raw["par"][:] = 0.0
     if name == "day": raw["par"] = np.maximum(raw["par"], 2.0)
     clim = synth.convert_raw(synth.round_like_file(raw))
-    b = sa.Batch(flags, 1, M, sa.F64, fast_math=True, kernel=kern)
+    f32 = os.environ.get("PREC", "f64") == "f32"
+    b = sa.Batch(flags, 1, M, sa.F32_MIXED if f32 else sa.F64, fast_math=None if f32 else True, kernel=kern)
     b.set_climate(0, clim); b.set_params(0, members)
     planes, _ = b.alloc_outputs(T)
     ms = []
