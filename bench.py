@@ -299,7 +299,10 @@ def main():
     # rank runs site 0 with global members [r*M, (r+1)*M).  c4 shards whole SITES: rank r owns
     # sites r*S .. r*S+S-1 (and uploads only their plans), each with members [r*M, (r+1)*M) of the draw.
     site_ids = [rank * S + s for s in range(S)] if S > 1 else [0]
-    raws = [synth.round_like_file(synth.half_hourly_year_raw(T, site=sid)) for sid in site_ids]
+    # a particle filter advances: cycle k forecasts day k of the forcing from the resampled state (no setupModel()
+    # inside a cycle); the forcing holds as many days as the run has cycles (wrapping, with a fresh setup, beyond that)
+    pf_days = min(365, max(64, args.warmup + args.steps + 48)) if wl.get("pf") else 1
+    raws = [synth.round_like_file(synth.half_hourly_year_raw(T * pf_days, site=sid)) for sid in site_ids]
     clims = [synth.convert_raw(r) for r in raws]
     members = synth.perturbed_params(base, M * world, seed=synth.SEED_PARAMS)[rank * M:(rank + 1) * M]
 
@@ -307,7 +310,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # before any HIP initialisation in this process: the workers are plain children
         cpu = cpu_baseline(flags, synth.perturbed_params(base, max(M, 64), seed=synth.SEED_PARAMS),
-                           raws[0], param_name=param_name)
+                           {k: v[:T] for k, v in raws[0].items()}, param_name=param_name)
 
     import torch
     import torch.distributed as dist
@@ -397,6 +400,17 @@ def main():
         if distd:
             tot = sd._gather0(tot, world, None).reshape(-1)
         pf_obs, pf_sigma = float(tot.median()), float(tot.std()) * 1.5 + 1e-12
+        # the observation series: what the free-running ensemble says on each day (untimed pre-pass), so that the
+        # weights stay as informative on day k as on day 0
+        pf_obs_k, pf_sigma_k = [pf_obs], [pf_sigma]
+        for k in range(1, pf_days):
+            b.run(k * T, T, planes=planes)
+            tot = planes[0].double().sum(0)
+            if distd:
+                tot = sd._gather0(tot, world, None).reshape(-1)
+            pf_obs_k.append(float(tot.median()))
+            pf_sigma_k.append(float(tot.std()) * 1.5 + 1e-12)
+        b.setup()
         pf_exchange = args.pf_exchange if distd else "n/a (1 GPU)"
         if distd and args.pf_exchange == "peer":
             try:    # once per filter, off the cycle: publish / map the checkpoint matrices of every rank
@@ -433,24 +447,30 @@ def main():
                 buf["done"] = torch.cuda.Event()
                 buf["done"].record(side)
             return
-        b.setup()                       # setupModel() for every member
-        b.run(0, T, planes=planes)      # the time-fused step kernel
         if pf:
-            # no host round trip inside a cycle: each cycle's total weight lands in its own slot
+            # one cycle: forecast of day k from the resampled state, analysis.  A filter does not re-run setupModel();
+            # only when the forcing's days are used up does the ensemble start over (never inside the timed passes of
+            # a default run).  No host round trip inside a cycle: each cycle's total weight lands in its own slot
             # and "a particle survived" is checked for all cycles after the closing barrier
+            k = pf_cycle[0] % pf_days
+            if k == 0 and pf_cycle[0] > 0:
+                b.setup()
+            b.run(k * T, T, planes=planes)      # the time-fused step kernel
             slot = pf_totals[pf_cycle[0] % len(pf_totals):][:1]
             pf_cycle[0] += 1
             if distd and not plain and pf_exchange == "peer":
-                _, info = sd.pf_analysis_peers(b, planes[0], pf_obs, pf_sigma, 0.5, rank=rank, world=world,
+                _, info = sd.pf_analysis_peers(b, planes[0], pf_obs_k[k], pf_sigma_k[k], 0.5, rank=rank, world=world,
                                                total_out=slot, collectives=True, diagnostics=record)
                 if record:
                     pf_info.update(info)
                 return
-            _, info = sd.pf_analysis(b, planes[0], pf_obs, pf_sigma, u0=0.5, rank=rank, world=world,
+            _, info = sd.pf_analysis(b, planes[0], pf_obs_k[k], pf_sigma_k[k], u0=0.5, rank=rank, world=world,
                                      with_params=True, diagnostics=record, total_out=slot,
                                      collectives=distd and not plain)
             pf_info.update(info)
             return
+        b.setup()                       # setupModel() for every member
+        b.run(0, T, planes=planes)      # the time-fused step kernel
         if distd and not plain and args.gather != "none":
             if args.gather == "stats":
                 for v in range(3):
@@ -484,6 +504,8 @@ def main():
     dist_overhead = None
     if args.force_dist:
         pf_cycle[0] = 0
+        if pf:
+            b.setup()
         for _ in range(args.warmup):
             one_pass(False, plain=True)
         barrier()
@@ -605,7 +627,7 @@ def main():
             from tests import helpers
             ora = helpers.load_oracle()
             n_chk = min(8, M)
-            po, _, _ = ora.run_block(flags, members[:n_chk], clims[0])
+            po, _, _ = ora.run_block(flags, members[:n_chk], clims[0].slice(0, T) if pf else clims[0])
             if pf:
                 pg = pf_first
             else:
@@ -724,7 +746,7 @@ def main():
             "dtype": wl["prec"], "data": "synthetic",
             "config": {"workload": f"{args.workload}: {S} site(s) x {M} members per GPU x {T} "
                                    f"half-hourly steps, perturbed params, " + ("default flags" if not wl.get("flags") else "flags " + "+".join(sorted(wl["flags"])))
-                                   + (", particle-filter cycle (forecast + analysis)" if pf else ""),
+                                   + (", particle-filter cycle (forecast of day k from the resampled state + analysis; no setupModel() in a cycle)" if pf else ""),
                        "sites_per_gpu": S, "members_per_site": M, "timesteps": T,
                        "fast_math": bool(args.fast_math),
                        "gather": args.gather if distd else "n/a (1 GPU)",

@@ -219,22 +219,29 @@ int sipnet_batch_set_params(sipnet_batch *b, int32_t site, int32_t first_member,
 enum sipnet_math { SIPNET_MATH_STRICT = 0, SIPNET_MATH_FAST = 1 };
 int sipnet_batch_set_math(sipnet_batch *b, int32_t policy);
 
-/* Which step kernel sipnet_batch_run launches.  AUTO (the default) picks by batch shape: with
- * SIPNET_MATH_FAST and the default model flags the cooperative kernel while there
- * are at most four 64-member chunks per compute unit (up to one chunk per CU: one four-wave
- * workgroup per chunk, running-mean ring in LDS; up to two: one eight-wave workgroup per TWO
- * chunks, rings in HBM; up to four, lean state only: one twelve-wave workgroup per FOUR chunks),
- * with the nitrogen-cycle flag set (litter pool + anaerobic + nitrogen cycle) its own cooperative kernel
- * up to two chunks per CU, the one-wavefront throughput kernel for bigger batches, full records there,
- * and the other optional model flags; with SIPNET_MATH_STRICT the strict-order kernel.  "Default model
- * flags" here means the physics: events, gdd, soil_phenol and water_hresp may have any legal value (no
- * events; leaf-on by growing degree days, soil temperature or day of year -- russell_4's set; no moisture
- * effect on heterotrophic respiration) -- they change what the site plan puts into the step records, not
- * the kernels.  The other values force one kernel
- * (tests and measurements compare every instantiation with the oracle this way); a forced kernel
- * that cannot run the batch (throughput kernels under SIPNET_MATH_STRICT, cooperative kernels with
- * optional model flags) makes sipnet_batch_run return
- * SIPNET_ERR_BAD_ARGUMENT.  Nothing in the launch path reads the environment. */
+/* Which step kernel sipnet_batch_run launches.  AUTO (the default) picks by batch shape (sipnet_kernel_choice
+ * answers without a device).  With SIPNET_MATH_STRICT, or for the debug plane: the strict-order kernel.  With
+ * SIPNET_MATH_FAST, by 64-member chunks per compute unit (CU):
+ *   - flag sets WITHOUT the nitrogen cycle -- the default physics and every combination of growth respiration,
+ *     leaf water, flooding, litter pool, carbon saturation, anaerobic + methane (run-time flags of the
+ *     optional-physics instantiations) --: up to one chunk per CU one four-wave workgroup per chunk with the
+ *     running-mean ring in LDS; up to two, one eight-wave workgroup per TWO chunks (rings in HBM); up to four,
+ *     default physics and lean state only, one twelve-wave workgroup per FOUR chunks; beyond that the
+ *     one-wavefront kernel;
+ *   - flag sets WITH the nitrogen cycle (alone = litter pool + anaerobic + nitrogen cycle, or with any of the other
+ *     options): their own cooperative kernels (a soil wave next to light, water, carbon) up to two chunks per CU;
+ *     records / SIPNET_KOPT_FULL_STATE there for the nitrogen-cycle set itself and for the sets with further options;
+ *     the one-wavefront kernel beyond two chunks per CU;
+ *   - records, SIPNET_KOPT_FULL_STATE and the diagnostics counters take the "Full" instantiations of the same
+ *     kernels (not the four-chunk layout; the counters with the nitrogen cycle: see sipnet_batch_enable_diagnostics).
+ * "Default physics" means the model, not the flag values: events, gdd, soil_phenol and water_hresp may have any
+ * legal value (no events; leaf-on by growing degree days, soil temperature or day of year -- russell_4's set; no
+ * moisture effect on heterotrophic respiration): they change what the site plan puts into the step records, not the
+ * kernels.  The other values of the enum force one kernel (tests and measurements compare every instantiation with
+ * the oracle this way); a forced kernel that cannot run the batch (a throughput kernel under SIPNET_MATH_STRICT,
+ * the four-chunk layout with optional physics or full state, a nitrogen-cycle kernel without the nitrogen cycle or
+ * the other way round) makes sipnet_batch_run return SIPNET_ERR_BAD_ARGUMENT.  Nothing in the launch path reads the
+ * environment. */
 enum sipnet_kernel {
   SIPNET_KERNEL_AUTO = 0,
   SIPNET_KERNEL_ONE_WAVE = 1, /* stepFastKernel: one wavefront per 64 members */
@@ -474,7 +481,7 @@ int sipnet_batch_pf_analysis(sipnet_batch *b, const void *d_plane, int32_t elem_
  * (hipDeviceEnablePeerAccess; the node object below), hipIpcMemHandle mappings between processes (one
  * process per GPU under torch.distributed) -- and a cycle's exchange is then
  *     sipnet_batch_pf_local_weights  -> my block [nmax log-weights | their 256-wide block maxima]
- *     ONE all-gather of the blocks   (RCCL; the caller's, or sipnet_node_pf_cycle's)
+ *     ONE all-gather of the blocks   (RCCL; the caller's, or sipnet_node_pf_analysis's)
  *     sipnet_batch_pf_resample_peers -> weights of all slots, exact prefix sum, the ancestors of MY particles,
  *                                       one gather kernel that reads every ancestor where it lives
  * with no host synchronisation and no second collective.  The all-gather is also the only ordering the
@@ -590,7 +597,12 @@ void *sipnet_node_gathered_planes(sipnet_node *nd, int32_t k);
  * step kernel of segment j + 1.  No statistics.  Returns once everything is enqueued; sipnet_node_sync waits for
  * the gathers too.  Afterwards, on device k, sipnet_node_gathered_segment(nd, k, j, &first, &len) is segment j of
  * every shard, [n_devices][3][len][ld] (first = its first record, len = its length), and the shard's own planes
- * (sipnet_node_planes) hold the segments one after the other, [3][len_j][ld] each. */
+ * (sipnet_node_planes) hold the segments one after the other, [3][len_j][ld] each -- NOT one [3][n_steps][ld]
+ * block: until the next sipnet_node_run / _forecast, sipnet_node_gather_stats, sipnet_node_gather_planes and
+ * sipnet_node_pf_analysis return SIPNET_ERR_BAD_ARGUMENT, and a reader of sipnet_node_planes must walk the
+ * segments (sipnet_node_n_segments, sipnet_node_gathered_segment's first / len).  A shard whose task fails (a stale
+ * plan, a launch error) makes every shard give up BEFORE the segment's collective is enqueued: the call returns that
+ * shard's error and the node stays usable. */
 int sipnet_node_run_gathering(sipnet_node *nd, int32_t step0, int32_t n_steps, int32_t n_segments);
 int32_t sipnet_node_n_segments(const sipnet_node *nd);   /* of the last sipnet_node_run_gathering; 0 after a plain run */
 void *sipnet_node_gathered_segment(sipnet_node *nd, int32_t k, int32_t segment, int32_t *first_step, int32_t *n_steps);

@@ -570,6 +570,9 @@ int flushParams(sipnet_batch* b, hipStream_t stream) {
     HIP_TRY(hipMalloc(&b->d_rawStage, b->hostRawUsed * SIPNET_NPARAMS * sizeof(double)));
     b->rawStageCap = b->hostRawUsed;
   }
+  // The conversion writes d_prm: it must not start while this batch's last launch -- possibly on ANOTHER stream of
+  // the caller's (a node shard's, the null stream of pf_publish) -- still reads it.  A device-side wait, no host stall.
+  if (b->busy) HIP_TRY(hipStreamWaitEvent(stream, b->evBusy, 0));
   // (an earlier conversion on `stream` may still read the device block: the copy stream waits for the caller's first)
   HIP_TRY(hipEventRecord(b->evOrder, stream));
   HIP_TRY(hipStreamWaitEvent(b->upStream, b->evOrder, 0));
@@ -582,7 +585,7 @@ int flushParams(sipnet_batch* b, hipStream_t stream) {
   HIP_TRY(hipGetLastError());
   b->pendingParams.clear();
   b->hostRawUsed = 0;
-  return SIPNET_OK;
+  return markBusy(b, stream);   // (whoever flushes next, on whatever stream, waits for these conversions)
 }
 
 extern "C" {

@@ -38,6 +38,7 @@
 #include <vector>
 
 #include "../../include/sipnet_amd.h"
+#include "shard_pool.h"
 
 namespace sipnet {
 void setError(const std::string& s);
@@ -89,41 +90,6 @@ Rccl* loadRccl() {
   return &r;
 }
 
-// all shard threads meet here (only the event-ordered transport needs it: an event must have been
-// recorded by its owner before another thread makes its stream wait for it)
-struct HostBarrier {
-  std::mutex mu;
-  std::condition_variable cv;
-  int n = 1, waiting = 0;
-  uint64_t phase = 0;
-  bool broken = false;   // a shard's task failed: nobody waits for it any more (reset per task)
-  // false: a shard has failed, the others give up too
-  bool arrive() {
-    if (n <= 1) return true;
-    std::unique_lock<std::mutex> lk(mu);
-    if (broken) return false;
-    const uint64_t p = phase;
-    if (++waiting == n) {
-      waiting = 0;
-      phase++;
-      cv.notify_all();
-    } else {
-      cv.wait(lk, [&] { return phase != p || broken; });
-    }
-    return !broken;
-  }
-  void fail() {
-    std::lock_guard<std::mutex> lk(mu);
-    broken = true;
-    cv.notify_all();
-  }
-  void reset() {
-    std::lock_guard<std::mutex> lk(mu);
-    broken = false;
-    waiting = 0;
-  }
-};
-
 }  // namespace
 
 struct sipnet_node {
@@ -165,17 +131,8 @@ struct sipnet_node {
   // event-ordered transport
   std::vector<hipEvent_t> evReady, evCopied;
   std::vector<const void*> agSend;
-  HostBarrier bar;
-  // the shards' host threads
-  std::vector<std::thread> workers;
-  std::mutex mu;
-  std::condition_variable cvWork, cvDone;
-  std::function<int(int)> task;
-  uint64_t gen = 0;
-  int pending = 0;
-  bool quit = false;
-  std::vector<int> rc;
-  std::vector<std::string> msg;
+  // the shards' host threads, the task hand-over and the barrier they meet at (shard_pool.h: no HIP in it)
+  sipnet::ShardPool pool;
 
   size_t elem() const { return precision == SIPNET_F64 ? 8 : 4; }
   int n() const { return (int)devices.size(); }
@@ -198,64 +155,14 @@ struct sipnet_node {
     }                                                                         \
   } while (0)
 
-static void runShardTask(sipnet_node* nd, int k) {
-  nd->rc[k] = nd->task(k);
-  if (nd->rc[k] != SIPNET_OK) nd->bar.fail();   // the other shards must not wait for this one at a barrier
-  nd->msg[k] = nd->rc[k] != SIPNET_OK ? sipnet_last_error() : "";   // thread-local: carry it to the caller's thread
-}
-
-static void workerLoop(sipnet_node* nd, int k) {
-  const bool dev = hipSetDevice(nd->devices[k]) == hipSuccess;
-  uint64_t seen = 0;
-  for (;;) {
-    {
-      std::unique_lock<std::mutex> lk(nd->mu);
-      nd->cvWork.wait(lk, [&] { return nd->quit || nd->gen != seen; });
-      if (nd->quit) return;
-      seen = nd->gen;
-    }
-    if (dev) {
-      runShardTask(nd, k);
-    } else {
-      nd->rc[k] = SIPNET_ERR_NO_DEVICE;
-      nd->msg[k] = "hipSetDevice failed";
-    }
-    {
-      std::lock_guard<std::mutex> lk(nd->mu);
-      if (--nd->pending == 0) nd->cvDone.notify_all();
-    }
-  }
-}
-
 // f(k) for every shard k, each on the shard's own host thread (a node of one shard: on the caller's);
 // returns when all have returned, the first failure wins
 template <class F>
 static int onEveryShard(sipnet_node* nd, F f) {
-  const int n = nd->n();
-  nd->task = f;
-  nd->bar.reset();
-  if (n == 1) {
-    if (hipSetDevice(nd->devices[0]) != hipSuccess) {
-      setError("sipnet_node: hipSetDevice failed");
-      return SIPNET_ERR_NO_DEVICE;
-    }
-    runShardTask(nd, 0);
-  } else {
-    std::unique_lock<std::mutex> lk(nd->mu);
-    nd->pending = n;
-    nd->gen++;
-    nd->cvWork.notify_all();
-    nd->cvDone.wait(lk, [&] { return nd->pending == 0; });
-  }
-  nd->task = nullptr;
-  // (a shard that only gave up at a barrier because another one failed does not hide that one's message)
-  for (int pass = 0; pass < 2; pass++)
-    for (int k = 0; k < n; k++)
-      if (nd->rc[k] != SIPNET_OK && (pass == 1 || nd->msg[k].find("another shard failed") == std::string::npos)) {
-        setError("device " + std::to_string(nd->devices[k]) + " (shard " + std::to_string(k) + "): " + nd->msg[k]);
-        return nd->rc[k];
-      }
-  return SIPNET_OK;
+  const int bad = nd->pool.run(f);
+  if (bad < 0) return SIPNET_OK;
+  setError("device " + std::to_string(nd->devices[bad]) + " (shard " + std::to_string(bad) + "): " + nd->pool.msg[bad]);
+  return nd->pool.rc[bad];
 }
 
 // All-gather of `bytes` per shard among the shards, called by shard k's thread from inside an onEveryShard
@@ -265,12 +172,20 @@ static int allGatherShard(sipnet_node* nd, int k, const void* send, void* recv, 
   const int n = nd->n();
   if (!stream) stream = nd->streams[k];
   if (!nd->comms.empty()) {
+    // A collective nobody may be missing from: a shard whose task has failed (its launch, an upload) returns WITHOUT
+    // enqueuing its part, and the others' ncclAllGather would then never complete -- the next synchronisation of their
+    // streams would hang instead of reporting the error.  So the shards' host threads first agree that all of them
+    // have come this far (the host barrier; a failed shard breaks it): either everybody enqueues or nobody does.
+    if (!nd->pool.bar.arrive()) {
+      setError("sipnet_node: another shard failed");
+      return SIPNET_ERR_INTERNAL;
+    }
     NODE_RCCL(nd, nd->rccl->allGather(send, recv, bytes, ncclChar, nd->comms[k], stream));
     return SIPNET_OK;
   }
   nd->agSend[k] = send;
   NODE_HIP(hipEventRecord(nd->evReady[k], stream));
-  if (!nd->bar.arrive()) {
+  if (!nd->pool.bar.arrive()) {
     setError("sipnet_node: another shard failed");
     return SIPNET_ERR_INTERNAL;
   }
@@ -281,7 +196,7 @@ static int allGatherShard(sipnet_node* nd, int k, const void* send, void* recv, 
       NODE_HIP(hipMemcpyAsync(dst, nd->agSend[s], bytes, hipMemcpyDeviceToDevice, stream));
   }
   NODE_HIP(hipEventRecord(nd->evCopied[k], stream));
-  if (!nd->bar.arrive()) {
+  if (!nd->pool.bar.arrive()) {
     setError("sipnet_node: another shard failed");
     return SIPNET_ERR_INTERNAL;
   }
@@ -348,9 +263,6 @@ static int createNode(const int32_t* flags, int32_t n_sites, int32_t n_members, 
   nd->evSeg.assign(n_devices, nullptr);
   nd->evGathered.assign(n_devices, nullptr);
   nd->agSend.assign(n_devices, nullptr);
-  nd->rc.assign(n_devices, SIPNET_OK);
-  nd->msg.assign(n_devices, "");
-  nd->bar.n = n_devices;
   for (int k = 0; k < n_devices; k++) {  // contiguous ranges, sizes differ by at most one
     const int32_t total = mode == SIPNET_SHARD_MEMBERS ? n_members : n_sites;
     const int32_t a = (int32_t)((int64_t)total * k / n_devices), z = (int32_t)((int64_t)total * (k + 1) / n_devices);
@@ -404,8 +316,9 @@ static int createNode(const int32_t* flags, int32_t n_sites, int32_t n_members, 
     setError(keep);
     return rc;
   }
-  if (n_devices > 1)
-    for (int k = 0; k < n_devices; k++) nd->workers.emplace_back(workerLoop, nd, k);
+  // one host thread per shard from here on (none for a node of one shard: its tasks run on the caller's thread)
+  nd->pool.start(n_devices, [nd](int k) { return hipSetDevice(nd->devices[k]) == hipSuccess; },
+                 [] { return std::string(sipnet_last_error()); }, SIPNET_ERR_NO_DEVICE);
   *out = nd;
   return SIPNET_OK;
 }
@@ -423,14 +336,7 @@ int sipnet_node_create_sharded(const int32_t* flags, int32_t n_sites, int32_t n_
 
 void sipnet_node_destroy(sipnet_node* nd) {
   if (!nd) return;
-  if (!nd->workers.empty()) {
-    {
-      std::lock_guard<std::mutex> lk(nd->mu);
-      nd->quit = true;
-    }
-    nd->cvWork.notify_all();
-    for (auto& t : nd->workers) t.join();
-  }
+  nd->pool.stop();
   for (int k = 0; k < nd->n(); k++) {
     (void)hipSetDevice(nd->devices[k]);
     if (nd->streams[k]) (void)hipStreamSynchronize(nd->streams[k]);
@@ -900,6 +806,11 @@ int sipnet_node_pf_connect(sipnet_node* nd, int32_t with_params) {
 int sipnet_node_pf_analysis(sipnet_node* nd, int32_t variable, double obs, double sigma, double u0) {
   if (!nd || !nd->pfConnected || nd->nRun <= 0 || variable < 0 || variable > 2) {
     setError("sipnet_node_pf_analysis: needs sipnet_node_pf_connect and a forecast (sipnet_node_forecast / _run)");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  if (nd->segmented) {   // the planes lie segment by segment ([3][len_j][ld] each): a plane is not one [n_run][ld] block
+    setError("sipnet_node_pf_analysis: the last run was sipnet_node_run_gathering (segmented planes); forecast with "
+             "sipnet_node_forecast / sipnet_node_run");
     return SIPNET_ERR_BAD_ARGUMENT;
   }
   const int slot = nd->pfCycles % sipnet_node::kPfTotals;

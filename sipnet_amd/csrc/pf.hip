@@ -255,6 +255,168 @@ __global__ __launch_bounds__(256) void fixedWeightGatheredKernel(const double* _
   const double e = exp(lw - m);
   w[i] = (!(lw > -INFINITY) || !(m > -INFINITY)) ? 0 : llrint(e * 1073741824.0);
 }
+// ---- the analysis in ONE launch (round 5) -------------------------------------------------------------------------
+// Log-weights + maximum | fixed-point weights + prefix sum | ancestors were five launches plus hipCUB's two (and
+// its temporaries' fills and copies): 40 us of a 200 us cycle at C5's shape for 15 us of work.  Here they are the
+// phases of one kernel whose workgroups are all resident (at most kFusedBlocks x 256 threads: two workgroups per
+// CU) and meet at barriers in device memory.  Workgroup b owns the contiguous slots [b * chunk, (b + 1) * chunk):
+// it scans them tile by tile with a running carry (cdfLocal = the chunk's own inclusive sums), the chunks' totals
+// are summed by every workgroup for itself (<= 512 values), and an ancestor is found by a search over the chunk
+// totals followed by one inside the chunk.  Integer weights: the result does not depend on the order of the
+// additions, so the ancestors are those of fixedWeightKernel + DeviceScan + ancestorKernel bit for bit
+// (tests/test_gpu_pf.py holds both paths to the same oracle).
+constexpr int kFusedBlocks = 512;
+struct FusedArgs {
+  // phase 1 (the one-batch analysis): log-weights from the forecast's plane
+  const void* plane;
+  int32_t nSteps;
+  int64_t ld, ncol;
+  const double* status;
+  double obs, invSigma;
+  double* logw;              // [nSlots] written by phase 1, read by phase 2
+  // phase 2 over gathered blocks instead (the filter across ranks): slot i = gathered[(i / nmax) * stride + i % nmax],
+  // the blocks' maxima behind each rank's nmax log-weights
+  const double* gathered;
+  int32_t world, nmax;
+  int64_t stride;
+  int64_t nSlots, chunk;
+  double* blockMax;          // [gridDim.x]
+  int64_t* cdfLocal;         // [nSlots]
+  int64_t* blockSum;         // [gridDim.x]
+  unsigned long long* barrier;   // arrivals so far, all launches (never reset)
+  unsigned long long base;       // its value before this launch
+  // phase 3
+  int64_t j0, nOut, nTotal;
+  double u0;
+  int32_t* anc;
+  int64_t* total;            // may be null
+  int64_t* totalScratch;     // always written
+};
+// What the workgroups exchange (chunk maxima, chunk sums, the chunks' inclusive sums) is written and read with
+// agent-scope relaxed atomics: such accesses are coherent across the chip's eight XCDs (each has an L2 of its own) without
+// cache maintenance.  The first version used plain accesses and release / acquire fences at the barriers: an
+// agent-scope release is an L2 write-back, an acquire an L2 invalidate -- 2 048 waves x 2 barriers of them made the
+// launch 131 us.  Ordering: a workgroup's stores have been acknowledged (vmcnt(0)) before it arrives.
+__device__ __forceinline__ void stAgent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ldAgent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void stAgent(long long* p, long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ long long ldAgent(const long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void gridBarrier(unsigned long long* ctr, unsigned long long target) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores have been acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ double blockMax256(double v, double* sm) {
+  sm[threadIdx.x] = v;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sm[threadIdx.x] = fmax(sm[threadIdx.x], sm[threadIdx.x + s]);
+    __syncthreads();
+  }
+  const double r = sm[0];
+  __syncthreads();
+  return r;
+}
+// inclusive sum over the 256 threads of a workgroup; *totalOut = the sum of all
+__device__ __forceinline__ long long blockScan256(long long v, long long* smWave, long long* totalOut) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int off = 1; off < 64; off <<= 1) {
+    const long long o = __shfl_up(v, off, 64);
+    if (lane >= off) v += o;
+  }
+  if (lane == 63) smWave[wave] = v;
+  __syncthreads();
+  long long before = 0;
+  for (int k = 0; k < wave; k++) before += smWave[k];
+  *totalOut = smWave[0] + smWave[1] + smWave[2] + smWave[3];
+  __syncthreads();
+  return v + before;
+}
+template <typename T, bool Gathered>
+__global__ __launch_bounds__(256) void pfFusedKernel(FusedArgs a) {
+  __shared__ double smD[256];
+  __shared__ long long smWave[4];
+  __shared__ long long prefix[kFusedBlocks + 1];
+  const int tid = (int)threadIdx.x, nb = (int)gridDim.x, b = (int)blockIdx.x;
+  const int64_t lo = (int64_t)b * a.chunk, hi = lo + a.chunk < a.nSlots ? lo + a.chunk : a.nSlots;
+  int nBarrier = 0;
+  double m = -INFINITY;
+  if (!Gathered) {
+    // ---- phase 1: this chunk's log-weights and their maximum ----
+    double mine = -INFINITY;
+    for (int64_t i = lo + tid; i < hi; i += 256)
+      mine = fmax(mine, logWeightOf((const T*)a.plane, a.nSteps, a.ld, i, a.status, a.obs, a.invSigma, a.logw));
+    mine = blockMax256(mine, smD);
+    if (tid == 0) stAgent(&a.blockMax[b], mine);
+    gridBarrier(a.barrier, a.base + (unsigned long long)(++nBarrier) * nb);
+    double pm = -INFINITY;
+    for (int k = tid; k < nb; k += 256) pm = fmax(pm, ldAgent(&a.blockMax[k]));
+    m = blockMax256(pm, smD);
+  } else {
+    const int P = (a.nmax + 255) / 256;
+    double pm = -INFINITY;
+    for (int k = tid; k < a.world * P; k += 256) pm = fmax(pm, a.gathered[(int64_t)(k / P) * a.stride + a.nmax + k % P]);
+    m = blockMax256(pm, smD);
+  }
+  // ---- phase 2: fixed-point weights (fixedWeightKernel's formula) and the chunk's inclusive sums ----
+  long long carry = 0;
+  for (int64_t tile = lo; tile < hi; tile += 256) {
+    const int64_t i = tile + tid;
+    long long w = 0;
+    if (i < hi) {
+      const double lw = Gathered ? a.gathered[(i / a.nmax) * a.stride + i % a.nmax] : a.logw[i];
+      const double e = exp(lw - m);
+      w = (!(lw > -INFINITY) || !(m > -INFINITY)) ? 0 : llrint(e * 1073741824.0);
+    }
+    long long tileTotal;
+    const long long inc = blockScan256(w, smWave, &tileTotal);
+    if (i < hi) stAgent((long long*)&a.cdfLocal[i], carry + inc);
+    carry += tileTotal;
+  }
+  if (tid == 0) stAgent((long long*)&a.blockSum[b], carry);
+  gridBarrier(a.barrier, a.base + (unsigned long long)(++nBarrier) * nb);
+  // ---- phase 3: the chunks' offsets (every workgroup for itself), then the ancestors ----
+  {
+    // two entries per thread (nb <= 512), scanned as pairs
+    const int k0 = 2 * tid, k1 = 2 * tid + 1;
+    const long long s0 = k0 < nb ? ldAgent((const long long*)&a.blockSum[k0]) : 0, s1 = k1 < nb ? ldAgent((const long long*)&a.blockSum[k1]) : 0;
+    long long all;
+    const long long inc = blockScan256(s0 + s1, smWave, &all);
+    if (tid == 0) prefix[0] = 0;
+    if (k0 < nb) prefix[k0 + 1] = inc - s1;
+    if (k1 < nb) prefix[k1 + 1] = inc;
+    __syncthreads();
+  }
+  const long long Sll = prefix[nb];
+  if (b == 0 && tid == 0) {
+    if (a.total) *a.total = Sll;
+    *a.totalScratch = Sll;
+  }
+  const double S = (double)Sll;
+  for (int64_t j = (int64_t)b * 256 + tid; j < a.nOut; j += (int64_t)nb * 256) {
+    // ancestorKernel's position: S - 1 keeps the search inside the support when (j + u0) rounds up to n
+    const double p = fmin((((double)(a.j0 + j) + a.u0) * S) / (double)a.nTotal, S - 1.0);
+    int bl = 0, bh = nb - 1;   // first chunk whose inclusive total exceeds p
+    while (bl < bh) {
+      const int mid = (bl + bh) >> 1;
+      if ((double)prefix[mid + 1] > p) bh = mid;
+      else bl = mid + 1;
+    }
+    const long long off = prefix[bl];
+    int64_t l = (int64_t)bl * a.chunk, h = l + a.chunk < a.nSlots ? l + a.chunk - 1 : a.nSlots - 1;
+    while (l < h) {
+      const int64_t mid = (l + h) >> 1;
+      if ((double)(off + ldAgent((const long long*)&a.cdfLocal[mid])) > p) h = mid;
+      else l = mid + 1;
+    }
+    a.anc[j] = (int32_t)l;
+  }
+}
+
 // dst[row][j] = matrix of rank (anc[j] / nmax)[row][anc[j] % nmax] for the three matrices of a checkpoint
 struct PeerPart {
   void* dst;
@@ -496,12 +658,20 @@ struct PfScratch {
   int64_t* d_cdf = nullptr;
   void* d_tmp = nullptr;
   size_t tmpBytes = 0;
+  // the one-launch analysis (pfFusedKernel): chunk totals, the device-memory barrier's arrival count (never reset: a
+  // launch is told its value so far) and the total weight
+  int64_t* d_blockSum = nullptr;      // [kFusedBlocks] + 1: the total
+  unsigned long long* d_barrier = nullptr;
+  unsigned long long barrierBase = 0;
   void release() {
     if (d_max) (void)hipFree(d_max);
     if (d_w) (void)hipFree(d_w);
     if (d_cdf) (void)hipFree(d_cdf);
     if (d_tmp) (void)hipFree(d_tmp);
+    if (d_blockSum) (void)hipFree(d_blockSum);
+    if (d_barrier) (void)hipFree(d_barrier);
     d_max = nullptr; d_w = d_cdf = nullptr; d_tmp = nullptr; cap = 0; tmpBytes = 0;
+    d_blockSum = nullptr; d_barrier = nullptr; barrierBase = 0;
   }
   // no destructor: a thread_local's would run at thread exit, possibly after the HIP runtime is gone
 };
@@ -522,9 +692,21 @@ static int pfScratchFor(PfScratch& sc, int64_t n, hipStream_t stream) {
     HIP_TRY(hipMalloc(&sc.d_cdf, (size_t)n * sizeof(int64_t)));
     HIP_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, sc.tmpBytes, sc.d_w, sc.d_cdf, (int)n, stream));
     HIP_TRY(hipMalloc(&sc.d_tmp, sc.tmpBytes));
+    HIP_TRY(hipMalloc(&sc.d_blockSum, (size_t)(kFusedBlocks + 1) * sizeof(int64_t)));
+    HIP_TRY(hipMalloc(&sc.d_barrier, sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(sc.d_barrier, 0, sizeof(unsigned long long), stream));
+    sc.barrierBase = 0;
     sc.cap = n;
   }
   return SIPNET_OK;
+}
+// geometry of the one-launch analysis over nSlots weights: every workgroup resident, contiguous chunks of whole tiles
+static void fusedGeometry(int64_t nSlots, int* grid, int64_t* chunk) {
+  const int64_t tiles = (nSlots + 255) / 256;
+  const int64_t nb = tiles < kFusedBlocks ? tiles : kFusedBlocks;
+  const int64_t tilesPer = (tiles + nb - 1) / nb;
+  *chunk = tilesPer * 256;
+  *grid = (int)((nSlots + *chunk - 1) / *chunk);
 }
 static PfScratch& scratchOf(sipnet_batch* b) {
   if (!b->pfScratch) b->pfScratch = new PfScratch();
@@ -760,14 +942,43 @@ int sipnet_batch_pf_analysis(sipnet_batch* b, const void* d_plane, int32_t elem_
   PfScratch& sc = scratchOf(b);
   rc = pfScratchFor(sc, b->ncol, (hipStream_t)hip_stream);
   if (rc) return rc;
-  // the log-weight kernel leaves its blocks' maxima where the resampling looks for them
-  rc = logWeights(b, d_plane, elem_is_f32, n_steps, ld, obs, sigma, d_logw, sc.d_max, hip_stream);
-  if (rc) return rc;
-  rc = ancestorsImpl(sc, d_logw, b->ncol, u0, d_ancestors, nullptr, d_total, (int)((b->ncol + 255) / 256), hip_stream);
-  if (rc) return rc;
+  if (!d_plane || n_steps <= 0 || ld < b->ncol || !(sigma > 0) || !(u0 >= 0.0) || !(u0 < 1.0) || b->ncol > (int64_t)1 << 22) {
+    setError("sipnet_batch_pf_analysis: bad argument (sigma > 0, 0 <= u0 < 1, at most 4194304 particles)");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  // log-weights, fixed-point weights, prefix sum and ancestors: ONE launch (pfFusedKernel)
+  {
+    FusedArgs fa{};
+    fa.plane = d_plane;
+    fa.nSteps = n_steps;
+    fa.ld = ld;
+    fa.ncol = b->ncol;
+    fa.status = b->d_state + (size_t)ST_status * b->ncol;
+    fa.obs = obs;
+    fa.invSigma = 1.0 / sigma;
+    fa.logw = d_logw;
+    fa.nSlots = b->ncol;
+    int grid;
+    fusedGeometry(fa.nSlots, &grid, &fa.chunk);
+    fa.blockMax = sc.d_max;
+    fa.cdfLocal = sc.d_cdf;
+    fa.blockSum = sc.d_blockSum;
+    fa.barrier = sc.d_barrier;
+    fa.base = sc.barrierBase;
+    sc.barrierBase += 2ull * grid;
+    fa.j0 = 0;
+    fa.nOut = fa.nTotal = b->ncol;
+    fa.u0 = u0;
+    fa.anc = d_ancestors;
+    fa.total = d_total;
+    fa.totalScratch = sc.d_blockSum + kFusedBlocks;
+    if (elem_is_f32) hipLaunchKernelGGL((pfFusedKernel<float, false>), dim3(grid), dim3(256), 0, (hipStream_t)hip_stream, fa);
+    else hipLaunchKernelGGL((pfFusedKernel<double, false>), dim3(grid), dim3(256), 0, (hipStream_t)hip_stream, fa);
+    HIP_TRY(hipGetLastError());
+  }
   if (!d_total) {   // the synchronous check of sipnet_pf_systematic_ancestors
     int64_t total = 0;
-    HIP_TRY(hipMemcpyAsync(&total, sc.d_cdf + (b->ncol - 1), sizeof(int64_t), hipMemcpyDeviceToHost, (hipStream_t)hip_stream));
+    HIP_TRY(hipMemcpyAsync(&total, sc.d_blockSum + kFusedBlocks, sizeof(int64_t), hipMemcpyDeviceToHost, (hipStream_t)hip_stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)hip_stream));
     if (total <= 0) {
       setError("sipnet_batch_pf_analysis: every particle has zero weight");
@@ -818,9 +1029,12 @@ int sipnet_batch_pf_publish(sipnet_batch* b, int32_t with_params, sipnet_pf_peer
   if (rc) return rc;
   rc = ensureSpares(b, with_params != 0);
   if (rc) return rc;
+  rc = waitIdle(b);                      // (whatever stream the batch last ran on: the spares and the parameters settle)
+  if (rc) return rc;
   rc = flushParams(b, nullptr);          // (peers will read the converted block)
   if (rc) return rc;
-  HIP_TRY(hipStreamSynchronize(nullptr));
+  rc = waitIdle(b);
+  if (rc) return rc;
   memset(out, 0, sizeof *out);
   out->process_id = (int64_t)getpid();
   out->device = b->device;
@@ -985,13 +1199,31 @@ int sipnet_batch_pf_resample_peers(sipnet_batch* b, const double* d_gathered, do
   PfScratch& sc = scratchOf(b);
   rc = pfScratchFor(sc, nSlots, stream);
   if (rc) return rc;
-  hipLaunchKernelGGL(fixedWeightGatheredKernel, dim3((unsigned)((nSlots + 255) / 256)), dim3(256), 0, stream, d_gathered,
-                     tab.world, tab.nmax, stride, sc.d_w);
-  size_t tmpBytes = sc.tmpBytes;
-  HIP_TRY(hipcub::DeviceScan::InclusiveSum(sc.d_tmp, tmpBytes, sc.d_w, sc.d_cdf, (int)nSlots, stream));
   const int64_t n = b->ncol;
-  hipLaunchKernelGGL(ancestorKernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, sc.d_cdf, nSlots, first, n,
-                     nTotal, u0, d_ancestors, d_total);
+  {   // weights over all slots, prefix sum, the ancestors of MY particles: one launch (pfFusedKernel)
+    FusedArgs fa{};
+    fa.gathered = d_gathered;
+    fa.world = tab.world;
+    fa.nmax = tab.nmax;
+    fa.stride = stride;
+    fa.nSlots = nSlots;
+    int grid;
+    fusedGeometry(fa.nSlots, &grid, &fa.chunk);
+    fa.blockMax = sc.d_max;
+    fa.cdfLocal = sc.d_cdf;
+    fa.blockSum = sc.d_blockSum;
+    fa.barrier = sc.d_barrier;
+    fa.base = sc.barrierBase;
+    sc.barrierBase += 1ull * grid;
+    fa.j0 = first;
+    fa.nOut = n;
+    fa.nTotal = nTotal;
+    fa.u0 = u0;
+    fa.anc = d_ancestors;
+    fa.total = d_total;
+    fa.totalScratch = sc.d_blockSum + kFusedBlocks;
+    hipLaunchKernelGGL((pfFusedKernel<double, true>), dim3(grid), dim3(256), 0, stream, fa);
+  }
   auto groups = [](int rows) { return (rows + kGatherRows - 1) / kGatherRows; };
   PeerParts parts{};
   parts.p[0] = PeerPart{b->d_state2, SIPNET_NSTATE, 0, 0};

@@ -112,8 +112,21 @@ class Node:
         return np.float64 if self.precision == F64 else np.float32
 
     def planes(self, k):
-        """shard k's planes [3][n_run][ld] on the host (after sync)"""
-        return self._to_host(self.L.sipnet_node_planes(self.h, k), (3, self.n_run, self.ld), self._elem())
+        """shard k's planes [3][n_run][ld] on the host (after sync).  After run_gathering the device block lies
+        segment by segment ([3][len_j][ld] each, include/sipnet_amd.h): reassembled here."""
+        nseg = self.L.sipnet_node_n_segments(self.h)
+        if nseg == 0:
+            return self._to_host(self.L.sipnet_node_planes(self.h, k), (3, self.n_run, self.ld), self._elem())
+        flat = self._to_host(self.L.sipnet_node_planes(self.h, k), (3 * self.n_run * self.ld,), self._elem())
+        out = np.empty((3, self.n_run, self.ld), dtype=flat.dtype)
+        first0 = None
+        for j in range(nseg):
+            first, length = C.c_int32(0), C.c_int32(0)
+            self.L.sipnet_node_gathered_segment(self.h, k, j, C.byref(first), C.byref(length))
+            first0 = first.value if first0 is None else first0
+            a, n = first.value - first0, length.value
+            out[:, a:a + n] = flat[3 * a * self.ld:3 * (a + n) * self.ld].reshape(3, n, self.ld)
+        return out
 
     def gather_planes(self):
         check(self.L.sipnet_node_gather_planes(self.h), "node_gather_planes")
