@@ -655,6 +655,11 @@ def main():
             if ent.get("kernel") in (None, li["kernel"]):
                 traffic, traffic_tag = ent.get("hbm_bytes_per_launch"), ent.get("tag")
                 valu_cycles = ent.get("valu_active_cycles_per_launch")
+                # ... and for the kernel SOURCES it was collected on: a profile of an older build is quoted as such
+                from sipnet_amd._lib import kernel_source_sha16
+                if ent.get("source_sha16") != kernel_source_sha16():
+                    traffic_tag = f"{traffic_tag} (STALE: profiled on kernel sources {ent.get('source_sha16', 'unknown')}, " \
+                                  f"this tree has {kernel_source_sha16()})"
         except Exception:
             traffic = None
 

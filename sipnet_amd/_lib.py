@@ -275,6 +275,20 @@ def lib():
     return _lib
 
 
+def kernel_source_sha16():
+    """sha256 (first 16 hex digits) of the device sources the step kernels are built from: stamped into
+    profiles/pmc_traffic.json by the profiling target and checked by bench.py, so that a counter collected on an
+    older kernel is not quoted under a fresh kernel time"""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(_HERE, "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(csrc, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 class SipnetError(RuntimeError):
     def __init__(self, code, where=""):
         self.code = code

@@ -261,8 +261,8 @@ __global__ __launch_bounds__(256) void fixedWeightGatheredKernel(const double* _
 // phases of one kernel whose workgroups are all resident (at most kFusedBlocks x 256 threads: two workgroups per
 // CU) and meet at barriers in device memory.  Workgroup b owns the contiguous slots [b * chunk, (b + 1) * chunk):
 // it scans them tile by tile with a running carry (cdfLocal = the chunk's own inclusive sums), the chunks' totals
-// are summed by every workgroup for itself (<= 512 values), and an ancestor is found by a search over the chunk
-// totals followed by one inside the chunk.  Integer weights: the result does not depend on the order of the
+// are summed by every workgroup for itself (<= 512 values), and every slot writes the run of particles that take it
+// as their ancestor.  Integer weights: the result does not depend on the order of the
 // additions, so the ancestors are those of fixedWeightKernel + DeviceScan + ancestorKernel bit for bit
 // (tests/test_gpu_pf.py holds both paths to the same oracle).
 constexpr int kFusedBlocks = 512;
@@ -281,7 +281,8 @@ struct FusedArgs {
   int64_t stride;
   int64_t nSlots, chunk;
   double* blockMax;          // [gridDim.x]
-  int64_t* cdfLocal;         // [nSlots]
+  int64_t* cdfLocal;         // [nSlots] inclusive sums inside a chunk
+  int64_t* w;                // [nSlots] the fixed-point weights
   int64_t* blockSum;         // [gridDim.x]
   unsigned long long* barrier;   // arrivals so far, all launches (never reset)
   unsigned long long base;       // its value before this launch
@@ -374,7 +375,10 @@ __global__ __launch_bounds__(256) void pfFusedKernel(FusedArgs a) {
     }
     long long tileTotal;
     const long long inc = blockScan256(w, smWave, &tileTotal);
-    if (i < hi) stAgent((long long*)&a.cdfLocal[i], carry + inc);
+    if (i < hi) {   // (read back by this very thread in phase 3: plain accesses)
+      a.cdfLocal[i] = carry + inc;
+      a.w[i] = w;
+    }
     carry += tileTotal;
   }
   if (tid == 0) stAgent((long long*)&a.blockSum[b], carry);
@@ -396,24 +400,50 @@ __global__ __launch_bounds__(256) void pfFusedKernel(FusedArgs a) {
     if (a.total) *a.total = Sll;
     *a.totalScratch = Sll;
   }
-  const double S = (double)Sll;
-  for (int64_t j = (int64_t)b * 256 + tid; j < a.nOut; j += (int64_t)nb * 256) {
-    // ancestorKernel's position: S - 1 keeps the search inside the support when (j + u0) rounds up to n
-    const double p = fmin((((double)(a.j0 + j) + a.u0) * S) / (double)a.nTotal, S - 1.0);
-    int bl = 0, bh = nb - 1;   // first chunk whose inclusive total exceeds p
-    while (bl < bh) {
-      const int mid = (bl + bh) >> 1;
-      if ((double)prefix[mid + 1] > p) bh = mid;
-      else bl = mid + 1;
+  // ancestorKernel's rule -- particle j takes the first slot i with cdf[i] > P(j), P(j) = min(((j0 + j + u0) S) / nTotal,
+  // S - 1) -- turned round: slot i is taken by the particles j with cdf[i-1] <= P(j) < cdf[i], a run of consecutive j
+  // (P is non-decreasing in j) that the slot's own thread finds from ITS two sums and writes itself.  No search through
+  // other chunks' sums: the first version looked them up with eight dependent device-coherent loads per particle, 12 us.
+  const double S = (double)Sll, nTot = (double)a.nTotal;
+  auto P = [&](int64_t g) -> double { return fmin((((double)g + a.u0) * S) / nTot, S - 1.0); };   // g: global particle index
+  auto firstAtLeast = [&](double c) -> int64_t {   // the first global particle g in [0, nTotal] with P(g) >= c
+    if (!(S > 0.0)) return a.nTotal;
+    double est = ceil(c * nTot / S - a.u0);
+    int64_t g = est < 0.0 ? 0 : est > nTot ? a.nTotal : (int64_t)est;
+    while (g > 0 && P(g - 1) >= c) g--;
+    while (g < a.nTotal && P(g) < c) g++;
+    return g;
+  };
+  __shared__ int64_t bigLo[256], bigHi[256];
+  __shared__ int32_t bigSlot[256];
+  __shared__ int nBig;
+  const long long off = prefix[b];
+  const int64_t gLo = a.j0, gHi = a.j0 + a.nOut;   // this launch writes the ancestors of the global particles [gLo, gHi)
+  for (int64_t tile = lo; tile < hi; tile += 256) {
+    if (tid == 0) nBig = 0;
+    __syncthreads();
+    const int64_t i = tile + tid;
+    if (i < hi) {
+      const long long incl = off + a.cdfLocal[i], w = a.w[i];   // (this thread's own stores of phase 2)
+      if (w > 0 || i == 0) {
+        int64_t g0 = i == 0 ? 0 : firstAtLeast((double)(incl - w));
+        int64_t g1 = firstAtLeast((double)incl);
+        if (g0 < gLo) g0 = gLo;
+        if (g1 > gHi) g1 = gHi;
+        if (g1 - g0 > 32) {   // a heavy particle: the whole workgroup writes its copies
+          const int q = atomicAdd(&nBig, 1);
+          bigLo[q] = g0;
+          bigHi[q] = g1;
+          bigSlot[q] = (int32_t)i;
+        } else {
+          for (int64_t g = g0; g < g1; g++) a.anc[g - gLo] = (int32_t)i;
+        }
+      }
     }
-    const long long off = prefix[bl];
-    int64_t l = (int64_t)bl * a.chunk, h = l + a.chunk < a.nSlots ? l + a.chunk - 1 : a.nSlots - 1;
-    while (l < h) {
-      const int64_t mid = (l + h) >> 1;
-      if ((double)(off + ldAgent((const long long*)&a.cdfLocal[mid])) > p) h = mid;
-      else l = mid + 1;
-    }
-    a.anc[j] = (int32_t)l;
+    __syncthreads();
+    for (int q = 0; q < nBig; q++)
+      for (int64_t g = bigLo[q] + tid; g < bigHi[q]; g += 256) a.anc[g - gLo] = bigSlot[q];
+    __syncthreads();
   }
 }
 
@@ -962,6 +992,7 @@ int sipnet_batch_pf_analysis(sipnet_batch* b, const void* d_plane, int32_t elem_
     fusedGeometry(fa.nSlots, &grid, &fa.chunk);
     fa.blockMax = sc.d_max;
     fa.cdfLocal = sc.d_cdf;
+    fa.w = sc.d_w;
     fa.blockSum = sc.d_blockSum;
     fa.barrier = sc.d_barrier;
     fa.base = sc.barrierBase;
@@ -1211,6 +1242,7 @@ int sipnet_batch_pf_resample_peers(sipnet_batch* b, const double* d_gathered, do
     fusedGeometry(fa.nSlots, &grid, &fa.chunk);
     fa.blockMax = sc.d_max;
     fa.cdfLocal = sc.d_cdf;
+    fa.w = sc.d_w;
     fa.blockSum = sc.d_blockSum;
     fa.barrier = sc.d_barrier;
     fa.base = sc.barrierBase;

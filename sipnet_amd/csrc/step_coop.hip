@@ -198,19 +198,11 @@ __device__ __forceinline__ void takeFactors(const double* block, const int* flag
   i2v f;
   d2v a, b, c;
   WAIT_DO {
-#ifdef SIPNET_NO_READ2
-    asm volatile("ds_read2_b32 %0, %7 offset1:1\n\tds_read_b64 %1, %8\n\tds_read_b64 %2, %8 offset:512\n\t"
-                 "ds_read_b64 %3, %8 offset:1024\n\tds_read_b64 %4, %8 offset:1536\n\tds_read_b64 %5, %8 offset:2048\n\t"
-                 "ds_read_b64 %6, %8 offset:2560\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(f), "=&v"(a.x), "=&v"(a.y), "=&v"(b.x), "=&v"(b.y), "=&v"(c.x), "=&v"(c.y)
-                 : "v"((unsigned)(size_t)flags2), "v"((unsigned)(size_t)block) : "memory");
-#else
     asm volatile("ds_read2_b32 %0, %4 offset1:1\n\tds_read2st64_b64 %1, %5 offset1:1\n\t"
                  "ds_read2st64_b64 %2, %5 offset0:2 offset1:3\n\tds_read2st64_b64 %3, %5 offset0:4 offset1:5\n\t"
                  "s_waitcnt lgkmcnt(0)"
                  : "=&v"(f), "=&v"(a), "=&v"(b), "=&v"(c)
                  : "v"((unsigned)(size_t)flags2), "v"((unsigned)(size_t)block) : "memory");
-#endif
   } WAIT_WHILE(uni(f.x < f.y ? f.x : f.y) < step, 5, step);
   g1 = a.x; g2 = a.y; qSoilT = b.x; gFine = b.y; gCoarse = c.x; moist = c.y;
 }
@@ -295,13 +287,8 @@ __device__ __forceinline__ void takeFactorsRing(const float* block, const int* f
 // in flight.
 __device__ __forceinline__ void post5(double* base, int* flag, double v0, double v1, double v2, double v3,
                                       double v4, int step) {
-#ifdef SIPNET_NO_WRITE2
-  asm volatile("ds_write_b64 %0, %1\n\tds_write_b64 %0, %2 offset:512\n\tds_write_b64 %0, %3 offset:1024\n\t"
-               "ds_write_b64 %0, %4 offset:1536\n\tds_write_b64 %0, %5 offset:2048\n\tds_write_b32 %6, %7"
-#else
   asm volatile("ds_write2st64_b64 %0, %1, %2 offset1:1\n\tds_write2st64_b64 %0, %3, %4 offset0:2 offset1:3\n\t"
                "ds_write_b64 %0, %5 offset:2048\n\tds_write_b32 %6, %7"
-#endif
                :: "v"(ldsAddr(base)), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(ldsAddr(flag)), "v"(step)
                : "memory");
 }
@@ -486,61 +473,7 @@ __device__ __forceinline__ void awaitAtLeast(const int* flag, int step) {
 __device__ __forceinline__ void accum(double& pool, double x, double len) { pool = __builtin_fma(x, len, pool); }
 __device__ __forceinline__ void accum(double& pool, float x, float len) { pool += (double)(x * len); }
 
-// -DSIPNET_HWID (diagnostic build): where each wavefront of the first 4096 workgroups ran --
-// HW_ID (wave slot, SIMD, CU, shader array / engine) and XCC_ID -- to check that the three waves of
-// a workgroup sit on three different SIMDs and where the waves of co-resident workgroups land
-#ifdef SIPNET_HWID
-__device__ unsigned g_coopHwId[4096 * 4 * 2];  // [chunk][carbon, water, light, factors][HW_ID, XCC_ID]
-#endif
-#ifdef SIPNET_STAMPS
-__device__ unsigned long long g_coopStamps[16];
-#define CSTAMP(k)                                                                    \
-  {                                                                                  \
-    __builtin_amdgcn_sched_barrier(0);                                               \
-    unsigned long long now_;                                                         \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");     \
-    __builtin_amdgcn_sched_barrier(0);                                               \
-    cAcc[k] += now_ - cLast;                                                         \
-    cLast = now_;                                                                    \
-  }
-#else
-#define CSTAMP(k)
-#endif
-// -DSIPNET_MARKERS (reading the assembly, tools/kernel_resources.py): comments around the hot loops
-#ifdef SIPNET_MARKERS
-#define MARK(text) asm volatile("; ##### " text);
-#else
-#define MARK(text)
-#endif
-// -DSIPNET_WAITS (diagnostic build): cycles each wave spends inside its hand-over waits
-#ifdef SIPNET_WAITS
-__device__ unsigned long long g_coopWaits[16];
-#define WAIT_BEGIN()                                                                 \
-  unsigned long long w0_;                                                            \
-  __builtin_amdgcn_sched_barrier(0);                                                 \
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w0_)::"memory");
-#define WAIT_END(k)                                                                  \
-  {                                                                                  \
-    unsigned long long w1_;                                                          \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w1_)::"memory");       \
-    __builtin_amdgcn_sched_barrier(0);                                               \
-    wAcc[k] += w1_ - w0_;                                                            \
-  }
-#define WAIT_DECL() unsigned long long wAcc[4] = {0, 0, 0, 0}; unsigned long long wT0_; \
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wT0_)::"memory");
-#define WAIT_STORE(base)                                                             \
-  if (firstChunk && lane == 0) {                                                     \
-    unsigned long long wT1_;                                                         \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wT1_)::"memory");     \
-    for (int k = 0; k < 3; k++) g_coopWaits[base + k] = wAcc[k];                     \
-    g_coopWaits[base + 3] = wT1_ - wT0_;                                             \
-  }
-#else
-#define WAIT_BEGIN()
-#define WAIT_END(k)
-#define WAIT_DECL()
-#define WAIT_STORE(base)
-#endif
+#include "coop_probes.h"   // measurement scaffolding (-DSIPNET_PROBES builds only; empty macros otherwise)
 }  // namespace
 
 // RingLds: the running-mean ring of the 64 members stays in LDS for the whole launch (one
@@ -651,12 +584,6 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   constexpr double kNoCap = 3.0e38;  // finite in fp32 too
   constexpr bool Pair = NP == 2;
   // a fourth wavefront computes the climate-only factors when the workgroup has a CU to itself
-#ifdef SIPNET_NO_FACWAVE
-  constexpr bool FacWave = false;
-#else
-#ifdef SIPNET_PAIR_NO_FACWAVE
-  constexpr bool FacWave = RingLds;   // (NCyc: the fourth wavefront is the soil wave S; the factors stay with L)
-#else
   // two chunks per workgroup: the two spare wavefronts of the eight are the chunks' factor waves, and the
   // layout is  C0 C1 W0 W1 | L1 L0 F0 F1 : a carbon wave shares its SIMD with the OTHER chunk's light wave
   // (idle at night, when the carbon wave is the step), a water wave with its chunk's factor wave
@@ -664,8 +591,6 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   // C0 C1 S0 S1 | W1 W0 L1 L0 : the two busiest waves of a chunk, C and S, each share a SIMD with a water or light
   // wave of the OTHER chunk)
   constexpr bool FacWave = RingLds || (Pair && !NCyc);
-#endif
-#endif
   // per-wave private record tiles (each wave stages and awaits its own DMA) + mailboxes
   __shared__ alignas(16) unsigned char ldsTilesAll[NP][NCyc ? 4 : 3][2 * kTileBytes];
   __shared__ R mailLaiAll[NP][2][64], mailPgpAll[NP][2][64], mailPsnAll[NP][2][64];
@@ -728,16 +653,11 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   const int wave = uni((int)threadIdx.x >> 6);
   // 0 carbon, 1 water, 2 light; -1: a placeholder wave that only keeps the SIMD rotation
   // which of the workgroup's chunks; NP == 4: C0..C3 W0..W3 L0..L3, a chunk's three waves on one SIMD
-#ifdef SIPNET_PAIR_NO_FACWAVE
-  const int sub = Pair ? (wave & 1) : NP == 4 ? (wave & 3) : 0;
-  const int role = Pair ? ((wave >> 1) == 3 ? 2 : (wave >> 1) == 2 ? -1 : (wave >> 1)) : NP == 4 ? (wave >> 2) : wave;
-#else
   // pairs: the second four wavefronts serve the OTHER chunk of their SIMD's first one
   const int sub = Pair ? ((NCyc ? (wave >> 2) == 1 : (wave >> 1) == 2) ? ((wave & 1) ^ 1) : (wave & 1)) : NP == 4 ? (wave & 3) : 0;
   // (NCyc pair: C0 C1 S0 S1 | W1 W0 L1 L0 -> roles 0 0 3 3 1 1 2 2)
   const int role = Pair ? (NCyc ? ((wave >> 1) == 0 ? 0 : (wave >> 1) == 1 ? 3 : (wave >> 1) == 2 ? 1 : 2) : (wave >> 1))
                         : NP == 4 ? (wave >> 2) : wave;
-#endif
   const int lane = (int)threadIdx.x & 63;
   auto& mailLai = mailLaiAll[sub];
   auto& mailPgp = mailPgpAll[sub];
@@ -775,14 +695,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   const bool stageOn = Staged && a.statsPart != nullptr;
 #endif
   [[maybe_unused]] const bool firstChunk = blockIdx.x == 0 && sub == 0;  // diagnostics builds report this one
-#ifdef SIPNET_HWID
-  if (lane == 0 && role >= 0 && (blockIdx.x * NP + sub) < 4096) {
-    unsigned hw, xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
-    g_coopHwId[((blockIdx.x * NP + sub) * 4 + role) * 2] = hw;
-    g_coopHwId[((blockIdx.x * NP + sub) * 4 + role) * 2 + 1] = xcc;
-  }
-#endif
+  PROBE_HWID(blockIdx.x * NP + sub, role)
   unsigned char* lds = ldsTilesAll[sub][(role < 0 || role > (NCyc ? 3 : 2)) ? 0 : role];
 
   const int chunksPerSite = (a.n_members + 63) >> 6;
@@ -826,8 +739,12 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   // pays every taken branch with a fetch; NOTES.md "Round 4: code placement"): everything from here on starts at a
   // 32-byte boundary plus a per-instantiation number of s_nop (4 bytes each), measured -- not at wherever the
   // prologue happens to end.  -DSIPNET_PAD_NOPS=k overrides it for all instantiations (tools/build_variants.py).
+// (`s_nop 8 + role` in front: a marker the compiler never emits, executed once per wave and launch, by which
+// tests/test_code_placement.py finds each pinned point in the DISASSEMBLY of the built library and checks that the code
+// behind it starts where the sweeps measured it -- a compiler bump that moves a loop head fails a CPU test instead of
+// silently costing up to 2.7 %)
 #define COOP_CODE_PHASE(ROLE) \
-  asm volatile(".p2align 5\n .rept %0\n s_nop 0\n .endr" ::"n"(coopCodePhase<R, PlainExp, RingLds, Full, NP, NCyc, Ext>(ROLE)))
+  asm volatile("s_nop %1\n .p2align 5\n .rept %0\n s_nop 0\n .endr" ::"n"(coopCodePhase<R, PlainExp, RingLds, Full, NP, NCyc, Ext>(ROLE)), "n"(8 + (ROLE)))
   COOP_CODE_PHASE(4);
   if (role == 0) {
     if (lane == 0) {
@@ -857,15 +774,8 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
 #endif
   __syncthreads();  // the only workgroup barrier: flags initialised before anyone spins
   if (!present) return;
-#ifdef SIPNET_PROBE_PRIO   // (probe: wave priorities by role, 0xCWLF two bits each -- tools/build_variants.py)
-  {
-    constexpr int pr = SIPNET_PROBE_PRIO;
-    if (role == 0) __builtin_amdgcn_s_setprio((pr >> 12) & 3);
-    else if (role == 1) __builtin_amdgcn_s_setprio((pr >> 8) & 3);
-    else if (role == 2) __builtin_amdgcn_s_setprio((pr >> 4) & 3);
-    else __builtin_amdgcn_s_setprio(pr & 3);
-  }
-#endif
+  // (wave priorities by role -- s_setprio for the carbon wave, or carbon > water > light, or the light wave first --
+  // were measured on the layouts whose waves share a SIMD and are worth nothing: profiles/r05_wave_priority_probe.txt)
 
   const unsigned char* __restrict__ planBytes =
       (const unsigned char*)(a.fast + (int64_t)site * a.n_steps_total);
@@ -1672,9 +1582,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
       for (int t = tFirst; t < tLast; t++, recB += sizeof(FastRec)) {
         // Explicit fused multiply-adds only, as on the carbon wave: what the compiler chose to fuse differed
         // between the layouts' instantiations (fp32: the last sublimation of a snow pack, one ulp of ET).
-#ifndef SIPNET_W_CONTRACT_FAST
 #pragma clang fp contract(off)
-#endif
         MARK("W step begin")
         // only the fields this wave uses (80 of the record's 144 hot bytes: a lone wave pays LDS
         // reads by the byte): len invLen | tair tsoil | vpd | rainRate | sublW evapNum | invWspd | bits | evCount
@@ -1997,10 +1905,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   // HBM ring: the value written by the previous step is forwarded from a register
   double lastNpp = 0.0;
   int lastIns = -1;
-#ifdef SIPNET_STAMPS
-  unsigned long long cAcc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cLast;
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(cLast)::"memory");
-#endif
+  CSTAMP_DECL()
 
   // NCyc: what wave S needs of a step's plant side (the litter fluxes, the nitrogen demand of the creation
   // fluxes nitrogen.c:89-104, the resorption of a negative total creation :170-196, the leaf-on nitrogen
@@ -2864,10 +2769,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   }  // steps of this tile
   }  // tiles
 
-#ifdef SIPNET_STAMPS
-  if (firstChunk && lane == 0)
-    for (int k = 0; k < 8; k++) g_coopStamps[k] = cAcc[k];
-#endif
+  CSTAMP_STORE()
   WAIT_STORE(8)
   if (a.statsPart) {  // every NEE store of the launch has reached L2 (see wave L's statistics)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2917,11 +2819,6 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
 #undef seqMoist
 }
 
-#ifdef SIPNET_NO_FACWAVE
-constexpr bool kFacWaveBuilt = false;
-#else
-constexpr bool kFacWaveBuilt = true;
-#endif
 template <class R, bool PlainExp, bool RingLds, bool Full>
 __global__ __launch_bounds__(RingLds ? 256 : 192) void stepCoopKernel(FastArgs a) {
   coopBody<R, PlainExp, RingLds, Full, 1>(a);
@@ -2937,20 +2834,9 @@ __global__ __launch_bounds__(768) void stepCoopQuadKernel(FastArgs a) {
   coopBody<R, PlainExp, false, false, 4>(a);
 }
 
-#ifdef SIPNET_QUAD_FULL_PROBE
-// dev probe (tools/kernel_resources.py step_coop.hip -DSIPNET_QUAD_FULL_PROBE): what a full-state build of
-// the four-chunk layout would cost under its 168-register budget (twelve wavefronts per CU).  Measured:
-// fp64 284 bytes of scratch per lane (71 spilled dwords, the carbon wave's record columns and accumulators)
-// against 0 for the lean build, fp32-mixed 136 -- which is why such batches take the one-wave kernel's
-// Full build instead (28 ms at c10k's shape with the record; spilled registers in the carbon wave's loop
-// go to scratch memory every step).
-template <class R, bool PlainExp>
-__global__ __launch_bounds__(768) void stepCoopQuadFullProbeKernel(FastArgs a) {
-  coopBody<R, PlainExp, false, true, 4>(a);
-}
-template __global__ void stepCoopQuadFullProbeKernel<double, true>(FastArgs);
-template __global__ void stepCoopQuadFullProbeKernel<float, true>(FastArgs);
-#endif
+// (a full-state build of the four-chunk layout was probed in round 4: under its 168-register budget -- twelve
+// wavefronts per CU -- the carbon wave's record columns and accumulators spill, fp64 284 bytes of scratch per lane, fp32-mixed
+// 136; such batches take the one-wave kernel's Full build instead)
 
 // the nitrogen-cycle flag set: four wavefronts per chunk (L W C S), soil + nitrogen on wave S
 template <class R, bool PlainExp>
@@ -3070,7 +2956,7 @@ void launchStepCoop(const FastArgs& a, int precision, int layout, hipStream_t st
   // paired chunks: with the XCD-grouped mapping every group of eight workgroups carries 16 chunks
   const int pairGroups = (a.n_sites & 7) == 0 ? 8 * ((chunks / 8 + 1) / 2) : (chunks + 1) / 2;
   const int quadGroups = (a.n_sites & 7) == 0 ? 8 * ((chunks / 8 + 3) / 4) : (chunks + 3) / 4;
-  const dim3 grid(pair ? pairGroups : quad ? quadGroups : chunks), block(pair ? 512 : quad ? 768 : (ringInLds && kFacWaveBuilt) ? 256 : 192);
+  const dim3 grid(pair ? pairGroups : quad ? quadGroups : chunks), block(pair ? 512 : quad ? 768 : ringInLds ? 256 : 192);
 #ifdef SIPNET_COOP_BOUNDED   // (lean instantiations only: the engine does not send full-state launches here)
 #define COOP_LAUNCH(R, P, L) { hipLaunchKernelGGL((stepCoopKernel<R, P, L, false>), grid, block, 0, stream, a); }
 #define PAIR_LAUNCH(R, P) { hipLaunchKernelGGL((stepCoopPairKernel<R, P, false>), grid, block, 0, stream, a); }

@@ -27,7 +27,8 @@ def build(name, flags):
     for src in FAST_SRCS:
         o = os.path.join(out, src.replace(".hip", ".o"))
         contract = "-ffp-contract=fast-honor-pragmas" if src == "step_coop.hip" else "-ffp-contract=fast"
-        subprocess.check_call([HIPCC] + BASE + [contract, "-fno-honor-nans"] + flags.split() +
+        probe = ["-DSIPNET_PROBES"] if "-DSIPNET_" in flags else []     # (the probes' master switch: csrc/coop_probes.h)
+        subprocess.check_call([HIPCC] + BASE + [contract, "-fno-honor-nans"] + probe + flags.split() +
                               ["-c", os.path.join(CSRC, src), "-o", o])
         objs.append(o)
     objs += [os.path.join(CSRC, o) for o in OTHER_OBJS]

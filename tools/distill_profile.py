@@ -90,6 +90,9 @@ if means:
             d = json.load(open(tj)) if os.path.exists(tj) else {}
             kname = norm(sk)
             d[wl] = {"hbm_bytes_per_launch": hbm, "tag": tag, "fetch_correction": corr, "kernel": kname}
+            for line in log.splitlines():   # (tools/prof_target.py: the device sources the profiled library was built from)
+                if line.startswith("kernel sources sha16"):
+                    d[wl]["source_sha16"] = line.split()[-1]
             # the ALU cross-check of SURVEY 8(d): cycles in which a SIMD's vector ALU was executing, summed over
             # the chip (SQ_ACTIVE_INST_VALU counts quad-cycles) -- bench.py divides by SIMDs x kernel cycles
             av = means.get((sk, "SQ_ACTIVE_INST_VALU"))

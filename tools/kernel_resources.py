@@ -10,7 +10,8 @@ flags = {"step_coop.hip": ["-ffp-contract=fast-honor-pragmas", "-fno-honor-nans"
 out = "/tmp/kres_" + src.replace(".", "_") + ".s"
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
                        "--cuda-device-only", "-S", "-w", os.path.join(REPO, "sipnet_amd", "csrc", src), "-o", out]
-                      + flags + extra, stderr=subprocess.DEVNULL)
+                      + flags + (["-DSIPNET_PROBES"] if any(e.startswith("-DSIPNET_") for e in extra) else []) + extra,
+                      stderr=subprocess.DEVNULL)
 s = open(out).read()
 for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", s, re.S):
     name, body = m.group(1), m.group(2)

@@ -29,3 +29,5 @@ for _ in range(reps):
 torch.cuda.synchronize()
 print("kernel ms", b.last_kernel_ms(), "plane bytes", planes[0].numel() * planes[0].element_size())
 print("step kernel name", b.last_launch()["kernel"])
+from sipnet_amd._lib import kernel_source_sha16
+print("kernel sources sha16", kernel_source_sha16())
