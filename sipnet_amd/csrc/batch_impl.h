@@ -69,6 +69,14 @@ struct sipnet_batch {
   double* d_ring = nullptr;    // [RING_SLOTS][ncol] doubles; fp32-mixed batches: floats (ringElemBytes)
   // second copies for particle-filter resampling (gather into the spare, then swap); lazily made
   double* d_prm2 = nullptr;
+  // Particle filter (round 5): converted parameters are read-only during a forecast, so a resampling of a filter whose
+  // particles carry their parameters need not MOVE 640 bytes per particle -- it moves an index.  prmIndexed: column c's
+  // parameters are column d_prmId[c] of d_prm (the parameter BANK: a row set once by set_params, never copied);
+  // the one-wave step kernel dereferences the index at launch start (FastArgs::prmId), every other reader of d_prm
+  // first gets the bank gathered back into column order (materializeParams).  Not indexed: d_prmId is unused.
+  int32_t* d_prmId = nullptr;
+  int32_t* d_prmId2 = nullptr;
+  bool prmIndexed = false;
   double* d_state2 = nullptr;
   double* d_ring2 = nullptr;
   StepRec* d_plan = nullptr;   // [n_sites][n_steps]
@@ -118,6 +126,7 @@ struct sipnet_batch {
   hipStream_t upStream = nullptr;
 };
 int flushParams(sipnet_batch* b, hipStream_t stream);   // engine.hip: upload + convert what set_params left pending
+int materializeParams(sipnet_batch* b, hipStream_t stream);   // pf.hip: d_prm back into column order (no-op unless prmIndexed)
 
 inline int markBusy(sipnet_batch* b, hipStream_t stream) {
   HIP_TRY(hipEventRecord(b->evBusy, stream));

@@ -354,8 +354,8 @@ static int autoKernel(const int32_t* flags, int32_t n_sites, int32_t n_members, 
     return SIPNET_KERNEL_ONE_WAVE;
   }
   // the nitrogen cycle (with litter pool + anaerobic, which it requires), alone or with the other options; full state
-  // (record, every accumulator) for the nitrogen-cycle set itself, but no diagnostics counters (wantFull == 2)
-  const bool fullOk = wantFull == 0 || (wantFull == 1 && isNCycleFlagSet(flags));
+  // (record, every accumulator) too, but no diagnostics counters (wantFull == 2)
+  const bool fullOk = wantFull <= 1;
   if (blocks <= (int64_t)numCUs && fullOk) return SIPNET_KERNEL_COOP_NCYCLE;
   if (blocks <= 2 * (int64_t)numCUs && fullOk) return SIPNET_KERNEL_COOP_NCYCLE_PAIR;
   return SIPNET_KERNEL_ONE_WAVE;
@@ -460,6 +460,8 @@ void sipnet_batch_destroy(sipnet_batch* b) {
   if (b->d_state) (void)hipFree(b->d_state);
   if (b->d_ring) (void)hipFree(b->d_ring);
   if (b->d_prm2) (void)hipFree(b->d_prm2);
+  if (b->d_prmId) (void)hipFree(b->d_prmId);
+  if (b->d_prmId2) (void)hipFree(b->d_prmId2);
   if (b->d_state2) (void)hipFree(b->d_state2);
   if (b->d_ring2) (void)hipFree(b->d_ring2);
   if (b->d_plan) (void)hipFree(b->d_plan);
@@ -561,6 +563,10 @@ int sipnet_batch_set_params(sipnet_batch* b, int32_t site, int32_t first_member,
 // is the only copy of the members' parameters on the device.  The caller records the batch busy behind it.
 int flushParams(sipnet_batch* b, hipStream_t stream) {
   if (b->pendingParams.empty()) return SIPNET_OK;
+  {   // new rows are converted into column order: a resampled index must be resolved first
+    int rcM = materializeParams(b, stream);
+    if (rcM) return rcM;
+  }
   if (b->hostRawUsed > b->rawStageCap) {
     int rcI = waitIdle(b);
     if (rcI) return rcI;
@@ -600,6 +606,8 @@ int sipnet_batch_setup(sipnet_batch* b, void* hip_stream) {
     if (rc) return rc;
   }
   rc = flushParams(b, stream);
+  if (rc) return rc;
+  rc = materializeParams(b, stream);   // (setupModel() for every column from the parameters it carries now)
   if (rc) return rc;
   SetupArgs a;
   a.siteStart = b->d_siteStart;
@@ -774,9 +782,9 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
       return SIPNET_ERR_BAD_ARGUMENT;
     }
     if (kernel == SIPNET_KERNEL_COOP_NCYCLE || kernel == SIPNET_KERNEL_COOP_NCYCLE_PAIR) {
-      if (!b->flags[SIPNET_F_NITROGEN_CYCLE] || b->d_diag || (wantFull && !isNCycleFlagSet(b->flags))) {
-        setError("sipnet_batch_run: the nitrogen-cycle cooperative kernels run flag sets with the nitrogen cycle on; full "
-                 "state (records, SIPNET_KOPT_FULL_STATE) for the nitrogen-cycle set itself only, never the diagnostics counters");
+      if (!b->flags[SIPNET_F_NITROGEN_CYCLE] || b->d_diag) {
+        setError("sipnet_batch_run: the nitrogen-cycle cooperative kernels run flag sets with the nitrogen cycle on (records "
+                 "and SIPNET_KOPT_FULL_STATE included), never the diagnostics counters");
         return SIPNET_ERR_BAD_ARGUMENT;
       }
     } else if (kernel != SIPNET_KERNEL_ONE_WAVE && b->flags[SIPNET_F_NITROGEN_CYCLE]) {
@@ -802,6 +810,12 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
   }
   rc = kernel != SIPNET_KERNEL_STRICT ? ensureFastRecs(b, stream) : ensureStepRecs(b, stream);
   if (rc) return rc;
+  // a resampled parameter index (particle filter): the one-wave kernel reads through it, every other kernel gets the
+  // parameters back in column order first
+  if (b->prmIndexed && kernel != SIPNET_KERNEL_ONE_WAVE) {
+    rc = materializeParams(b, stream);
+    if (rc) return rc;
+  }
   // ensemble statistics with the launch (sipnet_batch_run_stats): a wavefront of the cooperative
   // kernel sums the planes' tiles per chunk while they are still in L2; any other kernel is
   // followed by three streaming reductions over the finished planes
@@ -841,6 +855,7 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
     f.events = b->d_events;
     f.siteBase = b->d_siteBase;
     f.prm = b->d_prm;
+    f.prmId = (b->prmIndexed && kernel == SIPNET_KERNEL_ONE_WAVE) ? b->d_prmId : nullptr;
     f.state = b->d_state;
     f.ring = b->d_ring;
     f.nee = d_nee;

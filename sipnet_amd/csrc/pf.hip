@@ -57,6 +57,7 @@ struct GatherPart {
   int32_t rows, group0;   // group0: first row group (blockIdx.y) of this part
   int32_t recvRow0;       // where the part starts inside a packed block, in rows of 8-byte words
   int32_t elem4;          // 4-byte elements
+  const int32_t* remap;   // null, or: an OWN source column s is read from column remap[s] (the parameter bank's index)
 };
 struct GatherParts {
   GatherPart p[3];
@@ -68,7 +69,7 @@ __device__ __forceinline__ void gatherRows(const GatherPart& part, int row0, int
                                            int64_t dstPitch) {
   T v[kGatherRows];
   if (s < ncol) {
-    const T* __restrict__ p = (const T*)part.own + (int64_t)row0 * ownPitch + s;
+    const T* __restrict__ p = (const T*)part.own + (int64_t)row0 * ownPitch + (part.remap ? (int64_t)part.remap[s] : s);
     if (nr == kGatherRows) {
 #pragma unroll
       for (int r = 0; r < kGatherRows; r++) v[r] = p[(int64_t)r * ownPitch];
@@ -265,7 +266,24 @@ __global__ __launch_bounds__(256) void fixedWeightGatheredKernel(const double* _
 // as their ancestor.  Integer weights: the result does not depend on the order of the
 // additions, so the ancestors are those of fixedWeightKernel + DeviceScan + ancestorKernel bit for bit
 // (tests/test_gpu_pf.py holds both paths to the same oracle).
-constexpr int kFusedBlocks = 512;
+#ifndef SIPNET_PF_BLOCKS
+#define SIPNET_PF_BLOCKS 512
+#endif
+#ifndef SIPNET_PF_SLEEP
+#define SIPNET_PF_SLEEP 2
+#endif
+constexpr int kFusedBlocks = SIPNET_PF_BLOCKS;   // (<= 512: phase 3 scans the chunk totals two per thread)
+#ifdef SIPNET_PF_STAMPS   // (probe, tools/pf_analysis_time.py: where the launch spends its time -- workgroup 0's clock at every phase)
+__device__ unsigned long long g_pfStamps[8];
+#define PF_STAMP(k)                                                                  \
+  if (blockIdx.x == 0 && threadIdx.x == 0) {                                         \
+    unsigned long long now_;                                                         \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");  \
+    g_pfStamps[k] = now_;                                                            \
+  }
+#else
+#define PF_STAMP(k)
+#endif
 struct FusedArgs {
   // phase 1 (the one-batch analysis): log-weights from the forecast's plane
   const void* plane;
@@ -307,7 +325,7 @@ __device__ __forceinline__ void gridBarrier(unsigned long long* ctr, unsigned lo
   __syncthreads();
   if (threadIdx.x == 0) {
     __hip_atomic_fetch_add(ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(SIPNET_PF_SLEEP);
   }
   __syncthreads();
 }
@@ -346,6 +364,7 @@ __global__ __launch_bounds__(256) void pfFusedKernel(FusedArgs a) {
   const int64_t lo = (int64_t)b * a.chunk, hi = lo + a.chunk < a.nSlots ? lo + a.chunk : a.nSlots;
   int nBarrier = 0;
   double m = -INFINITY;
+  PF_STAMP(0)
   if (!Gathered) {
     // ---- phase 1: this chunk's log-weights and their maximum ----
     double mine = -INFINITY;
@@ -353,7 +372,9 @@ __global__ __launch_bounds__(256) void pfFusedKernel(FusedArgs a) {
       mine = fmax(mine, logWeightOf((const T*)a.plane, a.nSteps, a.ld, i, a.status, a.obs, a.invSigma, a.logw));
     mine = blockMax256(mine, smD);
     if (tid == 0) stAgent(&a.blockMax[b], mine);
+    PF_STAMP(1)
     gridBarrier(a.barrier, a.base + (unsigned long long)(++nBarrier) * nb);
+    PF_STAMP(2)
     double pm = -INFINITY;
     for (int k = tid; k < nb; k += 256) pm = fmax(pm, ldAgent(&a.blockMax[k]));
     m = blockMax256(pm, smD);
@@ -382,7 +403,9 @@ __global__ __launch_bounds__(256) void pfFusedKernel(FusedArgs a) {
     carry += tileTotal;
   }
   if (tid == 0) stAgent((long long*)&a.blockSum[b], carry);
+  PF_STAMP(3)
   gridBarrier(a.barrier, a.base + (unsigned long long)(++nBarrier) * nb);
+  PF_STAMP(4)
   // ---- phase 3: the chunks' offsets (every workgroup for itself), then the ancestors ----
   {
     // two entries per thread (nb <= 512), scanned as pairs
@@ -445,6 +468,7 @@ __global__ __launch_bounds__(256) void pfFusedKernel(FusedArgs a) {
       for (int64_t g = bigLo[q] + tid; g < bigHi[q]; g += 256) a.anc[g - gLo] = bigSlot[q];
     __syncthreads();
   }
+  PF_STAMP(5)
 }
 
 // dst[row][j] = matrix of rank (anc[j] / nmax)[row][anc[j] % nmax] for the three matrices of a checkpoint
@@ -598,23 +622,37 @@ __global__ __launch_bounds__(256) void planFillKernel(const int32_t* __restrict_
 
 // state + ring (+ parameters) of the columns src[0..nOut) in one launch
 // (ringF32: the ring rows are floats, in the batch and in a packed block, where they take SIPNET_RING_SLOTS / 2 rows of words)
+// prmRemap: the batch's parameter index (null: parameters in column order) -- the parameter rows are read through it.
+// idOld / idNew (resampling with an index instead of the parameter rows; then prm must be null): idNew[j] = idOld[src[j]].
 void launchGatherMember(const double* state, const void* ring, bool ringF32, const double* prm, int64_t ncol,
                         const double* recv, const RecvMap& map, const int32_t* src, int64_t nOut,
-                        double* dState, void* dRing, double* dPrm, int64_t dstPitch, hipStream_t stream) {
+                        double* dState, void* dRing, double* dPrm, int64_t dstPitch, hipStream_t stream,
+                        const int32_t* prmRemap = nullptr, const int32_t* idOld = nullptr, int32_t* idNew = nullptr) {
   if (nOut <= 0) return;
   auto groups = [](int rows) { return (rows + kGatherRows - 1) / kGatherRows; };
   GatherParts parts{};
-  parts.p[0] = GatherPart{state, dState, SIPNET_NSTATE, 0, 0, 0};
-  parts.p[1] = GatherPart{ring, dRing, SIPNET_RING_SLOTS, groups(SIPNET_NSTATE), SIPNET_NSTATE, ringF32 ? 1 : 0};
-  parts.n = 2;
-  int total = groups(SIPNET_NSTATE) + groups(SIPNET_RING_SLOTS);
+  parts.n = 0;
+  int total = 0;
+  if (state) {
+    parts.p[parts.n++] = GatherPart{state, dState, SIPNET_NSTATE, total, 0, 0, nullptr};
+    total += groups(SIPNET_NSTATE);
+    parts.p[parts.n++] = GatherPart{ring, dRing, SIPNET_RING_SLOTS, total, SIPNET_NSTATE, ringF32 ? 1 : 0, nullptr};
+    total += groups(SIPNET_RING_SLOTS);
+  }
   if (prm) {
-    parts.p[2] = GatherPart{prm, dPrm, SIPNET_NPARAMS, total, SIPNET_NSTATE + ringWords(ringF32), 0};
-    parts.n = 3;
+    parts.p[parts.n++] = GatherPart{prm, dPrm, SIPNET_NPARAMS, total, SIPNET_NSTATE + ringWords(ringF32), 0, prmRemap};
     total += groups(SIPNET_NPARAMS);
+  } else if (idOld) {   // one row of 4-byte elements
+    parts.p[parts.n++] = GatherPart{idOld, idNew, 1, total, 0, 1, nullptr};
+    total += 1;
   }
   dim3 grid((unsigned)((nOut + 255) / 256), (unsigned)total);
   hipLaunchKernelGGL(gatherMemberKernel, grid, dim3(256), 0, stream, parts, ncol, ncol, recv, map, src, nOut, dstPitch);
+}
+
+__global__ __launch_bounds__(256) void iotaKernel(int32_t* p, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = (int32_t)i;
 }
 
 }  // namespace
@@ -635,6 +673,27 @@ struct PfPeers {
   std::vector<void*> opened;           // hipIpcOpenMemHandle mappings, closed on release
   int parity = 0;
 };
+
+// The parameter bank back in column order (batch_impl.h): gather through the index into the spare, swap.
+int materializeParams(sipnet_batch* b, hipStream_t stream) {
+  if (!b->prmIndexed) return SIPNET_OK;
+  const size_t nc = (size_t)b->ncol;
+  if (b->busy) HIP_TRY(hipStreamWaitEvent(stream, b->evBusy, 0));   // (the last launch may have run on another stream)
+  if (!b->d_prm2) HIP_TRY(hipMalloc(&b->d_prm2, nc * SIPNET_NPARAMS * sizeof(double)));
+  RecvMap none{};
+  launchGatherMember(nullptr, nullptr, false, b->d_prm, b->ncol, nullptr, none, b->d_prmId, b->ncol, nullptr, nullptr, b->d_prm2,
+                     b->ncol, stream);   // dst column j <- bank column d_prmId[j]
+  HIP_TRY(hipGetLastError());
+  std::swap(b->d_prm, b->d_prm2);
+  b->prmIndexed = false;
+  return markBusy(b, stream);
+}
+
+#ifdef SIPNET_PF_STAMPS
+extern "C" int sipnet_debug_read_pf_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pfStamps), 8 * sizeof(unsigned long long));
+}
+#endif
 
 extern "C" {
 
@@ -890,7 +949,8 @@ int sipnet_batch_pack_members(sipnet_batch* b, const int32_t* d_cols, int64_t n,
   // block layout: [NSTATE rows | RING_SLOTS rows (fp32-mixed batches: of floats) | NPARAMS rows] x n columns
   const bool rf = b->precision == SIPNET_F32_MIXED;
   launchGatherMember(b->d_state, b->d_ring, rf, with_params ? b->d_prm : nullptr, b->ncol, nullptr, none, d_cols, n, d_buf,
-                     d_buf + (size_t)SIPNET_NSTATE * n, d_buf + (size_t)(SIPNET_NSTATE + ringWords(rf)) * n, n, stream);
+                     d_buf + (size_t)SIPNET_NSTATE * n, d_buf + (size_t)(SIPNET_NSTATE + ringWords(rf)) * n, n, stream,
+                     b->prmIndexed ? b->d_prmId : nullptr);   // (a resampled index: the rows are read through it)
   HIP_TRY(hipGetLastError());
   return SIPNET_OK;
 }
@@ -914,7 +974,23 @@ int sipnet_batch_resample(sipnet_batch* b, const int32_t* d_src, const double* d
   const size_t nc = (size_t)b->ncol;
   if (!b->d_state2) HIP_TRY(hipMalloc(&b->d_state2, nc * SIPNET_NSTATE * sizeof(double)));
   if (!b->d_ring2) HIP_TRY(hipMalloc(&b->d_ring2, nc * SIPNET_RING_SLOTS * ringElemBytes(b)));
-  if (with_params && !b->d_prm2) HIP_TRY(hipMalloc(&b->d_prm2, nc * SIPNET_NPARAMS * sizeof(double)));
+  // every particle is here and carries its parameters: they stay where set_params put them, an index is resampled
+  // (4 bytes per particle instead of 640; the one-wave forecast kernel reads through it).  With blocks received from
+  // other ranks the rows themselves travel, as before.
+  const bool byIndex = with_params && n_blocks == 0;
+  if (with_params && !byIndex) {
+    rc = materializeParams(b, stream);
+    if (rc) return rc;
+    if (!b->d_prm2) HIP_TRY(hipMalloc(&b->d_prm2, nc * SIPNET_NPARAMS * sizeof(double)));
+  }
+  if (byIndex) {
+    if (!b->d_prmId) HIP_TRY(hipMalloc(&b->d_prmId, nc * sizeof(int32_t)));
+    if (!b->d_prmId2) HIP_TRY(hipMalloc(&b->d_prmId2, nc * sizeof(int32_t)));
+    if (!b->prmIndexed) {
+      hipLaunchKernelGGL(iotaKernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, stream, b->d_prmId, (int64_t)nc);
+      b->prmIndexed = true;
+    }
+  }
   const int words = sipnet_batch_member_words(b, with_params);
   RecvMap map{};
   map.nBlocks = n_blocks;
@@ -935,12 +1011,14 @@ int sipnet_batch_resample(sipnet_batch* b, const int32_t* d_src, const double* d
     setError("sipnet_batch_resample: received columns announced but no buffer given");
     return SIPNET_ERR_BAD_ARGUMENT;
   }
-  launchGatherMember(b->d_state, b->d_ring, b->precision == SIPNET_F32_MIXED, with_params ? b->d_prm : nullptr, b->ncol,
-                     d_recv, map, d_src, b->ncol, b->d_state2, b->d_ring2, b->d_prm2, b->ncol, stream);
+  launchGatherMember(b->d_state, b->d_ring, b->precision == SIPNET_F32_MIXED, (with_params && !byIndex) ? b->d_prm : nullptr, b->ncol,
+                     d_recv, map, d_src, b->ncol, b->d_state2, b->d_ring2, b->d_prm2, b->ncol, stream, nullptr,
+                     byIndex ? b->d_prmId : nullptr, byIndex ? b->d_prmId2 : nullptr);
   HIP_TRY(hipGetLastError());
   std::swap(b->d_state, b->d_state2);
   std::swap(b->d_ring, b->d_ring2);
-  if (with_params) std::swap(b->d_prm, b->d_prm2);
+  if (byIndex) std::swap(b->d_prmId, b->d_prmId2);
+  else if (with_params) std::swap(b->d_prm, b->d_prm2);
   if (b->pfPeers) b->pfPeers->parity ^= 1;   // (connected ranks resample in lockstep, whichever entry point they use)
   rc = markBusy(b, stream);                  // (an upload of new parameters waits for the gather that is writing them)
   if (rc) return rc;
@@ -1063,6 +1141,8 @@ int sipnet_batch_pf_publish(sipnet_batch* b, int32_t with_params, sipnet_pf_peer
   rc = waitIdle(b);                      // (whatever stream the batch last ran on: the spares and the parameters settle)
   if (rc) return rc;
   rc = flushParams(b, nullptr);          // (peers will read the converted block)
+  if (rc) return rc;
+  rc = materializeParams(b, nullptr);    // (... in column order: peers address a particle's rows by its column)
   if (rc) return rc;
   rc = waitIdle(b);
   if (rc) return rc;
@@ -1194,6 +1274,8 @@ int sipnet_batch_pf_resample_peers(sipnet_batch* b, const double* d_gathered, do
   if (rc) return rc;
   hipStream_t stream = (hipStream_t)hip_stream;
   rc = flushParams(b, stream);
+  if (rc) return rc;
+  rc = materializeParams(b, stream);   // (peers read a particle's parameter rows by its column)
   if (rc) return rc;
   PeerPtrs tab{};
   int64_t nTotal = b->ncol, first = 0;

@@ -575,7 +575,6 @@ template <class R, bool PlainExp, bool RingLds, bool Full, int NP, bool NCyc = f
 __device__ __forceinline__ void coopBody(const FastArgs& a) {
   static_assert(!(NP > 1 && RingLds), "two chunks' rings do not fit one CU's LDS");
   static_assert(!NCyc || (NP <= 2 && !RingLds), "nitrogen-cycle layout: one or two chunks, ring in HBM");
-  static_assert(!(Ext && NCyc && Full), "nitrogen cycle + extras: lean state only");
   constexpr bool Opt = Ext && !NCyc;   // the optional pools live on wave C
   // the run-time flags (all false without Ext: dead code then)
   const bool F_growthResp = Ext && a.flags[SIPNET_F_GROWTH_RESP] != 0, F_leafWater = Ext && a.flags[SIPNET_F_LEAF_WATER] != 0;
@@ -2879,6 +2878,15 @@ template <class R, bool PlainExp>
 __global__ __launch_bounds__(512) void stepCoopNXPairKernel(FastArgs a) {
   coopBody<R, PlainExp, false, false, 2, true, true>(a);
 }
+// ... with the record and every accumulator ("everything" + the 44-column record: round 5)
+template <class R, bool PlainExp>
+__global__ __launch_bounds__(256) void stepCoopNXFullKernel(FastArgs a) {
+  coopBody<R, PlainExp, false, true, 1, true, true>(a);
+}
+template <class R, bool PlainExp>
+__global__ __launch_bounds__(512) void stepCoopNXPairFullKernel(FastArgs a) {
+  coopBody<R, PlainExp, false, true, 2, true, true>(a);
+}
 
 #ifdef SIPNET_HWID
 extern "C" int sipnet_debug_read_coop_hwid(unsigned* out) {
@@ -2928,6 +2936,11 @@ void launchStepCoop(const FastArgs& a, int precision, int layout, hipStream_t st
       if (a.plainExp) hipLaunchKernelGGL((K<float, true>), gridN, blockN, 0, stream, a);          \
       else hipLaunchKernelGGL((K<float, false>), gridN, blockN, 0, stream, a);                    \
     }
+#ifndef SIPNET_COOP_BOUNDED
+    if (ext && a.full) {
+      if (pairN) { NCYC_LAUNCH(stepCoopNXPairFullKernel) } else { NCYC_LAUNCH(stepCoopNXFullKernel) }
+    } else
+#endif
     if (ext) {
       if (pairN) { NCYC_LAUNCH(stepCoopNXPairKernel) } else { NCYC_LAUNCH(stepCoopNXKernel) }
 #ifndef SIPNET_COOP_BOUNDED
@@ -2940,7 +2953,8 @@ void launchStepCoop(const FastArgs& a, int precision, int layout, hipStream_t st
 #undef NCYC_LAUNCH
     if (info) {
       snprintf(info->kernel, sizeof info->kernel, "%s<%s, %s>",
-               ext ? (pairN ? "stepCoopNXPairKernel" : "stepCoopNXKernel")
+               (ext && a.full) ? (pairN ? "stepCoopNXPairFullKernel" : "stepCoopNXFullKernel")
+               : ext ? (pairN ? "stepCoopNXPairKernel" : "stepCoopNXKernel")
                    : a.full ? (pairN ? "stepCoopNPairFullKernel" : "stepCoopNFullKernel") : (pairN ? "stepCoopNPairKernel" : "stepCoopNKernel"),
                precision == SIPNET_F64 ? "double" : "float", a.plainExp ? "true" : "false");
       info->grid = (int32_t)gridN.x;

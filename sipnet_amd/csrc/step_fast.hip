@@ -149,7 +149,8 @@ void stepFastKernel(FastArgs a) {
   const bool act = live && !skip;
 
   // ---- per-member constants ---------------------------------------------------
-  const double* __restrict__ pp = a.prm + col;
+  // (a particle filter's batch keeps its parameters where set_params put them and resamples an index: batch_impl.h)
+  const double* __restrict__ pp = a.prm + (a.prmId ? (int64_t)a.prmId[col] : col);
 #define PRM(name) (pp[(int64_t)SP_##name * nc])
   const double leafCSpWt = PRM(leafCSpWt);
   const double convK = kCWeight * (1.0 / kTen9) * (leafCSpWt / PRM(cFracLeaf)) * kSecPerDay;

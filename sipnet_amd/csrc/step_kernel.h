@@ -91,6 +91,7 @@ struct FastArgs {
   const EvRec* events;
   const int32_t* siteBase;    // ... [n_sites][3]: the site's base in ringOps / events, its number of records (<= n_steps_total)
   const double* prm;
+  const int32_t* prmId;   // null, or (one-wave kernel only; a particle filter's batch): column c reads the parameters of column prmId[c]
   double* state;
   double* ring;
   void* nee;

@@ -29,7 +29,12 @@ KERNELS = [("coop_lds", sa.KERNEL_COOP_LDS, 0, "stepCoopKernel<double, true, tru
            # heterotrophic / soil / nitrogen columns, the carbon wave the plants', the water wave its own)
            ("n_full", sa.KERNEL_COOP_NCYCLE, 0, "stepCoopNFullKernel<double, false>"),
            ("n_pair_full", sa.KERNEL_COOP_NCYCLE_PAIR, 0, "stepCoopNPairFullKernel<double, false>"),
-           ("n_one_wave", sa.KERNEL_ONE_WAVE, 0, "stepFastKernel<double, false, 2, 1, true>")]
+           ("n_one_wave", sa.KERNEL_ONE_WAVE, 0, "stepFastKernel<double, false, 2, 1, true>"),
+           # "everything" (the nitrogen cycle + every other optional flag) with the record: round 5
+           ("nx_full", sa.KERNEL_COOP_NCYCLE, 0, "stepCoopNXFullKernel<double, false>"),
+           ("nx_pair_full", sa.KERNEL_COOP_NCYCLE_PAIR, 0, "stepCoopNXPairFullKernel<double, false>"),
+           ("nx_auto", sa.KERNEL_AUTO, 0, "stepCoopNXFullKernel<double, false>")]
+EVERYTHING = dict(litterPool=1, anaerobic=1, nitrogenCycle=1, carbonSaturation=1, flooding=1, growthResp=1, leafWater=1)
 X_FLAGS = dict(anaerobic=1, litterPool=1, carbonSaturation=1, flooding=1, growthResp=1, leafWater=1)
 
 
@@ -56,12 +61,13 @@ def test_full_record_from_the_throughput_kernels(name, kernel, options, expect, 
     """all 36 `.out` columns of every step against the oracle, the 8 event-log columns and the
     carried accumulators against the strict-order kernel; the launch is split at odd steps"""
     flags = sa.flags_from()
-    if name.startswith("x_") or name.startswith("n_"):
-        flags = sa.flags_from(**(X_FLAGS if name.startswith("x_") else dict(litterPool=1, anaerobic=1, nitrogenCycle=1)))
+    if name.startswith(("x_", "n_", "nx_")):
+        flags = sa.flags_from(**(X_FLAGS if name.startswith("x_") else EVERYTHING if name.startswith("nx_")
+                                 else dict(litterPool=1, anaerobic=1, nitrogenCycle=1)))
         base = sa.read_params(os.path.join(os.path.dirname(BASE), "allflags_forest.param"), flags)[0]
     clim, ev, members = _scenario(base, lethal=True)
     members = members[:70]
-    if name.startswith("x_"):
+    if name.startswith(("x_", "nx_")):
         rng = np.random.default_rng(5)
         from sipnet_amd.config import param_index as pi
         members[:, pi("soilCSaturation")] = members[:, pi("soilInit")] * rng.uniform(0.5, 3.0, 70)

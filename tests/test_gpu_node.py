@@ -426,3 +426,76 @@ def test_node_over_two_real_devices_equals_one_batch(base):
         m0, mc = nd.member_range(k)
         np.testing.assert_array_equal(nd.shard_state(k), twin["state"][m0:m0 + mc])
     nd.close()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (one-GPU boxes run the shards on device 0)")
+@pytest.mark.parametrize("nseg", [1, 4])
+def test_site_shards_and_the_overlapped_gather_over_two_real_devices(base, nseg):
+    """devices = [0, 1], SIPNET_SHARD_SITES (config 4's cut): five sites, 3 + 2, every site's forcing, events and plan on
+    ONE device; the statistics all-gather concatenated along the site axis and the member-resolved planes travelling per
+    segment on the second streams (one ncclAllGather per segment and device) -- against ONE batch of all sites"""
+    S, M, T = 5, 96, 48 * 3
+    flags = sa.flags_from()
+    clims = site_clims(S, T)
+    members = synth.perturbed_params(base, M)
+    b = one_batch(flags, clims, members)
+    planes, stats = b.run_stats(0, T)
+    want_planes = planes.cpu().numpy().reshape(3, T, S, M)
+    want_stats = stats.cpu().numpy()
+    b.close()
+    nd = Node(flags, S, M, devices=[0, 1], shard=SHARD_SITES, fast_math=True)
+    assert "RCCL" in nd.collective_library() and [nd.site_range(k)[1] for k in range(2)] in ([2, 3], [3, 2])
+    for s in range(S):
+        nd.set_climate(s, clims[s])
+    nd.set_params(None, members)
+    nd.setup()
+    nd.run(0, T)
+    tot = nd.gather_stats()
+    np.testing.assert_array_equal(nd.member_planes(), want_planes)
+    np.testing.assert_allclose(tot, want_stats, rtol=1e-12, atol=1e-12)
+    nd.setup()
+    nd.run_gathering(0, T, nseg)
+    for k in range(2):
+        np.testing.assert_array_equal(nd.gathered_member_planes(k), want_planes)
+    np.testing.assert_array_equal(nd.member_planes(), want_planes)       # (a shard's own planes, walked segment by segment)
+    assert (nd.status() == 0).all()
+    nd.close()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (one-GPU boxes run the shards on device 0)")
+def test_filter_cycles_with_peer_reads_over_two_real_devices(base):
+    """three cycles of the peer-read filter across two GPUs without a host synchronisation in between (the ONE
+    all-gather per cycle is the only ordering; crossing particles are read out of the other GPU's HBM over xGMI)
+    against the one-batch analysis"""
+    T, n = 48, 1000
+    clim = synth.convert_raw(synth.round_like_file(synth.half_hourly_year_raw(4 * T)))
+    members = synth.perturbed_params(base, n)
+    b = sa.Batch(sa.flags_from(), 1, n, sa.F32_MIXED)
+    b.set_climate(0, clim)
+    b.set_params(0, members)
+    b.setup()
+    obs = []
+    for c in range(3):
+        planes, _ = b.run(c * T, T)
+        tot = planes[0].double().sum(0)
+        obs.append((float(tot.median()), float(tot.std()) * 1.5 + 1e-12))
+        b.pf_analysis_local(planes[0], obs[-1][0], obs[-1][1], 0.1 + 0.3 * c, True, None)
+    want = b.get_state()
+    b.close()
+    nd = Node(sa.flags_from(), 1, n, precision=sa.F32_MIXED, devices=[0, 1], shard=SHARD_MEMBERS, fast_math=True)
+    nd.set_climate(0, clim)
+    nd.set_params(0, members)
+    nd.setup()
+    nd.pf_connect(with_params=True)
+    crossed = 0
+    for c in range(3):
+        nd.forecast(c * T, T)
+        nd.pf_analysis(0, obs[c][0], obs[c][1], 0.1 + 0.3 * c)
+    assert nd.pf_check() == 3
+    nmax = max(nd.member_range(k)[1] for k in range(2))
+    for k in range(2):
+        m0, mc = nd.member_range(k)
+        np.testing.assert_array_equal(nd.shard_state(k), want[m0:m0 + mc])
+        crossed += int(((nd.pf_ancestors(k) // nmax) != k).sum())
+    assert crossed > 0
+    nd.close()

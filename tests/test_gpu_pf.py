@@ -263,3 +263,64 @@ def test_native_exchange_plan_equals_the_torch_formulation(world, n, kind):
     total_sent = sum(int(c.numel()) for r in range(world) for c in sd.pf_exchange_plan(anc, n, world, r)[0])
     total_recv = sum(sum(sd.pf_exchange_plan(anc, n, world, r)[2]) for r in range(world))
     assert total_sent == total_recv
+
+
+@pytest.mark.parametrize("prec", [sa.F64, sa.F32_MIXED], ids=["f64", "f32"])
+def test_resampled_parameter_index_equals_moving_the_rows(base, clim, prec):
+    """A one-batch filter whose particles carry their parameters resamples an INDEX into the parameter bank (4 bytes
+    per particle instead of 640); the one-wave kernel reads through it, every other reader gets the rows back in
+    column order first.  Three cycles on the one-wave kernel (the index composed three times) against a twin whose
+    cooperative kernel forces the rows to be gathered before every forecast: same planes, state, rings and -- read
+    through the index / from the gathered rows -- parameters, bit for bit; then setupModel() (which reads the rows)
+    and a parameter re-draw (which writes them) on the indexed batch"""
+    n, T = 1000, 48
+    members = synth.perturbed_params(base, n)
+
+    def make(kernel):
+        b = sa.Batch(sa.flags_from(), 1, n, prec, fast_math=True, kernel=kernel)
+        b.set_climate(0, clim)
+        b.set_params(0, members)
+        b.setup()
+        return b
+
+    a, c = make(sa.KERNEL_ONE_WAVE), make(sa.KERNEL_COOP_HBM)
+    everyone = torch.arange(n, dtype=torch.int32, device=DEV)
+    w = 32 + (125 if prec == sa.F32_MIXED else 250)
+    lineage = np.arange(n)
+    for cyc in range(3):
+        pa, _ = a.run(cyc * T, T)
+        pc, _ = c.run(cyc * T, T)
+        assert a.last_launch()["kernel"].startswith("stepFastKernel") and c.last_launch()["kernel"].startswith("stepCoopKernel")
+        np.testing.assert_allclose(pa.cpu().numpy(), pc.cpu().numpy(), rtol=0, atol=2e-9 if prec == sa.F64 else 5e-5)
+        # the SAME weights for both (the one-wave kernel's plane), so that both resample the same ancestors
+        nee = pa[0]
+        tot = nee.double().sum(0)
+        obs, sigma = float(tot.median()), float(tot.std()) * 0.6 + 1e-12
+        anc_a, _ = a.pf_analysis_local(nee, obs, sigma, 0.21 + 0.2 * cyc, with_params=True)
+        anc_c, _ = c.pf_analysis_local(nee, obs, sigma, 0.21 + 0.2 * cyc, with_params=True)
+        assert torch.equal(anc_a, anc_c) and 1 < int(torch.unique_consecutive(anc_a).numel()) < n
+        lineage = lineage[anc_a.cpu().numpy()]
+        prm_a, prm_c = a.pack_members(everyone, True)[w:], c.pack_members(everyone, True)[w:]
+        assert torch.equal(prm_a, prm_c)
+        # ... and they are the rows of the original draw's columns `lineage` (converted parameters: compare two columns
+        # that descend from the same draw, and a particle with its ancestor's row before the resampling)
+        same = np.flatnonzero(lineage == lineage[0])
+        assert torch.equal(prm_a[:, same[0]], prm_a[:, same[-1]])
+    assert len(np.unique(lineage)) < n
+    # setupModel() on the indexed batch: every column starts again from the parameters it carries NOW
+    a.setup()
+    c.setup()
+    np.testing.assert_array_equal(a.get_state(), c.get_state())
+    pa, _ = a.run(0, T)
+    pc, _ = c.run(0, T)
+    np.testing.assert_allclose(pa.cpu().numpy(), pc.cpu().numpy(), rtol=0, atol=2e-9 if prec == sa.F64 else 5e-5)
+    assert torch.equal(a.pack_members(everyone, True)[w:], c.pack_members(everyone, True)[w:])
+    # a re-draw after an analysis: new rows for the first 100 columns go into column order, the rest keep what they carry
+    for b in (a, c):
+        b.pf_analysis_local(pa[0], float(pa[0].double().sum(0).median()), 1.0, 0.5, with_params=True)
+        b.set_params(0, members[::-1][:100].copy())
+        b.run(T, T)
+    assert torch.equal(a.pack_members(everyone, True)[w:], c.pack_members(everyone, True)[w:])
+    np.testing.assert_allclose(a.get_state()[:, :13], c.get_state()[:, :13], rtol=1e-6 if prec == sa.F32_MIXED else 1e-11, atol=1e-9)
+    a.close()
+    c.close()

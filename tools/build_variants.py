@@ -31,7 +31,13 @@ def build(name, flags):
         subprocess.check_call([HIPCC] + BASE + [contract, "-fno-honor-nans"] + probe + flags.split() +
                               ["-c", os.path.join(CSRC, src), "-o", o])
         objs.append(o)
-    objs += [os.path.join(CSRC, o) for o in OTHER_OBJS]
+    others = list(OTHER_OBJS)
+    if "-DSIPNET_PF_" in flags:      # particle-filter probes: pf.hip rebuilt too (the Makefile's plain flags)
+        o = os.path.join(out, "pf.o")
+        subprocess.check_call([HIPCC] + BASE + ["-ffp-contract=off"] + flags.split() + ["-c", os.path.join(CSRC, "pf.hip"), "-o", o])
+        objs.append(o)
+        others.remove("pf.o")
+    objs += [os.path.join(CSRC, o) for o in others]
     so = os.path.join(out, "libsipnet_amd.so")
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + objs + ["-ldl"])
     open(os.path.join(out, "FLAGS"), "w").write(flags + "\n")
