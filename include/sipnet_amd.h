@@ -664,6 +664,10 @@ int sipnet_dev_to_host(void *host, const void *dev, size_t bytes, void *hip_stre
  * record block [n_steps][SIPNET_NREC][ld] as a dense [n_steps][n_members] array, for the ensemble output block */
 int sipnet_dev_to_host_2d(void *host, size_t host_pitch, const void *dev, size_t dev_pitch,
                           size_t width_bytes, size_t rows, void *hip_stream);
+/* the same on the device (asynchronous on the stream): a strided column gathered into a dense device array first --
+ * one dense copy to the host then moves it 20 x faster than 17 520 row pieces over PCIe */
+int sipnet_dev_to_dev_2d(void *dst, size_t dst_pitch, const void *src, size_t src_pitch,
+                         size_t width_bytes, size_t rows, void *hip_stream);
 int sipnet_stream_sync(void *hip_stream);
 /* a HIP stream of the caller's own on `device` (non-blocking with respect to the null stream): what a host that
  * pipelines forcings over two batches gives each of them (NULL on failure) */

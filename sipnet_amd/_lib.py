@@ -194,6 +194,7 @@ SIGNATURES = {
     "sipnet_dev_free": (None, [_P]),
     "sipnet_dev_to_host": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "sipnet_dev_to_host_2d": (C.c_int, [_P, C.c_size_t, _P, C.c_size_t, C.c_size_t, C.c_size_t, _P]),
+    "sipnet_dev_to_dev_2d": (C.c_int, [_P, C.c_size_t, _P, C.c_size_t, C.c_size_t, C.c_size_t, _P]),
     "sipnet_stream_sync": (C.c_int, [_P]),
     "sipnet_stream_create": (_P, [C.c_int32]),
     "sipnet_stream_destroy": (None, [_P]),

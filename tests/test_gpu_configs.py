@@ -279,6 +279,10 @@ KERNELS = [
     ("x_anaerobic_sat_flood_lds_f64", sa.F64, sa.KERNEL_COOP_LDS, 0, "stepCoopXKernel<double, false, true, false>"),
     ("x_anaerobic_sat_flood_pair_f64", sa.F64, sa.KERNEL_COOP_PAIR, 0, "stepCoopXPairKernel<double, false, false>"),
     ("x_anaerobic_sat_flood_pair_f32", sa.F32_MIXED, sa.KERNEL_COOP_PAIR, 0, "stepCoopXPairKernel<float, false, false>"),
+    # ... four chunks per workgroup: the fp32-mixed build only (the fp64 one would spill; the engine refuses it)
+    ("x_russell3_quad_f32", sa.F32_MIXED, sa.KERNEL_COOP_QUAD, 0, "stepCoopXQuadKernel<float, false>"),
+    ("x_anaerobic_sat_flood_quad_f32", sa.F32_MIXED, sa.KERNEL_COOP_QUAD, 0, "stepCoopXQuadKernel<float, false>"),
+    ("x_russell3_quad_f32_plain", sa.F32_MIXED, sa.KERNEL_COOP_QUAD, 0, "stepCoopXQuadKernel<float, true>"),
     ("x_everything_ncycle_f64", sa.F64, sa.KERNEL_COOP_NCYCLE, 0, "stepCoopNXKernel<double, false>"),
     ("x_everything_ncycle_f32", sa.F32_MIXED, sa.KERNEL_COOP_NCYCLE, 0, "stepCoopNXKernel<float, false>"),
     ("x_everything_ncycle_pair_f64", sa.F64, sa.KERNEL_COOP_NCYCLE_PAIR, 0, "stepCoopNXPairKernel<double, false>"),

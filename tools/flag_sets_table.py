@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Measured table of every optional flag set (tests/test_gpu_flags.py's 13 + russell_3's) on the kernel
 SIPNET_KERNEL_AUTO picks, at c10k's shape (1 site x 10 240 members) and c4's (32 sites x 1 024), fp64 fast
-math, one synthetic half-hourly year.  usage: flag_sets_table.py [out.md] [shape ...]   (shapes: c10k c4)"""
+math, one synthetic half-hourly year.  usage: flag_sets_table.py [out.md] [shape ...]
+shapes: c10k c4 (fp64) | c3f32 = 1 site x 65 536 members fp32-mixed (four chunks per CU) | c10krec = c10k's shape with
+the 44-column record (the Full builds)"""
 import os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
@@ -26,7 +28,7 @@ SETS = {
     "everything": dict(litterPool=1, anaerobic=1, nitrogenCycle=1, carbonSaturation=1, flooding=1, growthResp=1, leafWater=1),
     "russell_3": dict(growthResp=1, leafWater=1, litterPool=1, waterHResp=0),
 }
-SHAPES = {"c10k": (1, 10240), "c4": (32, 1024)}
+SHAPES = {"c10k": (1, 10240), "c4": (32, 1024), "c3f32": (1, 65536), "c10krec": (1, 10240)}
 T = 17520
 out = sys.argv[1] if len(sys.argv) > 1 else None
 shapes = sys.argv[2:] or ["c10k", "c4"]
@@ -39,15 +41,19 @@ for shape in shapes:
         flags = sa.flags_from(**kw)
         base, _ = sa.read_params(os.path.join(REPO, "tests", "golden", "synth", "allflags.param"), flags)
         members = synth.perturbed_params(base, M)
-        b = sa.Batch(flags, S, M, sa.F64, fast_math=True)
+        f32, rec = shape == "c3f32", shape == "c10krec"
+        b = sa.Batch(flags, S, M, sa.F32_MIXED if f32 else sa.F64, fast_math=None if f32 else True)
         for s in range(S):
             b.set_climate(s, clims[s])
         b.set_params(sa._lib.ALL_SITES, members)
-        planes, _ = b.alloc_outputs(T)
+        planes, recbuf = b.alloc_outputs(T, full=rec)
         ms = []
         for _ in range(3):
             b.setup()
-            b.run(0, T, planes=planes)
+            if rec:
+                b.run(0, T, planes=planes, rec=recbuf)
+            else:
+                b.run(0, T, planes=planes)
             torch.cuda.synchronize()
             ms.append(b.last_kernel_ms())
         k = b.last_launch()["kernel"]
