@@ -283,10 +283,10 @@ def kernel_source_sha16():
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(_HERE, "csrc")
-    for name in sorted(os.listdir(csrc)):
-        if name.endswith((".hip", ".h")):
-            h.update(name.encode())
-            h.update(open(os.path.join(csrc, name), "rb").read())
+    # (the step kernels and what they include; not the engine / filter / node sources around them)
+    for name in ("step_kernel.hip", "step_fast.hip", "step_coop.hip", "step_kernel.h", "fast_math.h", "coop_probes.h", "plan.h"):
+        h.update(name.encode())
+        h.update(open(os.path.join(csrc, name), "rb").read())
     return h.hexdigest()[:16]
 
 
