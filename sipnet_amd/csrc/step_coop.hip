@@ -625,7 +625,12 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   constexpr int NPN = (NCyc && NP > 1) ? NP : 1;
   // (mailPend: GPP - R_a of the step; a full-state launch adds R_a and the root respiration -- wave S writes the
   // record's R_soil / R_tot columns and carries those accumulators)
-  constexpr int kPendRows = (NCyc && Full) ? 3 : 1;
+  // (one-chunk full-state launches with the diagnostics counters: eleven more rows -- the plant side's mass totals before
+  // the step, after the pool updates and after the clamps [carbon, nitrogen], its carbon input and output rates, the
+  // events' carbon output and nitrogen in / out: what wave S needs for checkBalance(), balance.c:122-169.  The
+  // two-chunk layout has no LDS for them: such launches take the one-wave kernel)
+  constexpr int kDiagRows = 11;
+  constexpr int kPendRows = (NCyc && Full) ? (NP == 1 ? 3 + kDiagRows : 3) : 1;
   __shared__ alignas(16) double mailPlant1[NCyc ? 2 : 1][NCyc ? 8 : 1][64], mailPend1[NCyc ? 2 : 1][kPendRows][64], mailMinN1[NCyc ? 2 : 1][64];
   __shared__ alignas(16) double mailStorN1[NCyc ? 2 : 1][64], mailEvent1[NCyc ? 2 : 1][NCyc ? 6 : 1][64], mailDeath1[NCyc ? 4 : 1][64];
   __shared__ alignas(16) double mailSupply1[NCyc ? 3 : 1][64], mailDemand1[1][64];
@@ -1077,17 +1082,10 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         }
         const R qSoilT = K_bsr * qSoil * tillP1;
         post5(&mailFac[t & 1][0][lane], &seqFac, g1, g2, qSoilT, gFine, gCoarse, t);
-        // Two-chunk layout: the staged statistics are summed HERE, not on the light wave (round 5).  The light wave
-        // shares its SIMD with the other chunk's carbon wave, whose step is the launch's critical chain; this wave shares
-        // with a water wave and is busy a quarter of the time.  After the factor post of step t: C has what it waits
-        // for, and it cannot get past step t -- W past t + 1 -- before the factors of t + 1 follow, so neither is back at
-        // the rows of the half that ended with step t - 1.
-        if (Staged && stageOn && t == statNext) stagedAct();
       }
       cur = nxt;
     }
-    if (Staged && stageOn) stagedFinish();
-    else if (!Staged && statsHere) statFinish();
+    if (!Staged && statsHere) statFinish();
     return;
   }
   auto tileFirst = [&](int tile) -> int64_t {
@@ -1138,6 +1136,11 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
     double* __restrict__ recs = Full && a.rec ? a.rec + col : nullptr;
     R* __restrict__ oNee = (R*)(a.nee ? a.nee : a.scratchRow) + col;
     const int64_t ldNee = a.nee ? a.ld : 0;
+    // the diagnostics counters (sipnet_batch_enable_diagnostics): this wave has the soil's pools and, at the end of a
+    // step, the plant side's totals from wave C -- it runs checkBalance() (balance.c:122-169) and counts its own clamps
+    const bool wantDiagS = Full && NP == 1 && a.diag != nullptr;
+    int clampWarnS = 0, balanceWarnS = 0;
+    double maxDCS = 0.0, maxDNS = 0.0;
     // what C needs of these pools at the start of the first step
     postD(&mailMinN[tBegin & 1][lane], 0, minN);
     postFlag(&seqMinN, tBegin);
@@ -1164,6 +1167,8 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         const R eSoilC = (R)soilC, eLitter = (R)litterC, eMinN = (R)minN, eSoilOrgN = (R)soilOrgN;
         const R eLitterN = (R)litterN, eStorN = (R)storN;
         const double minN0 = minN;   // the value C has been given for this step's limitation test
+        // getMassTotals() before the step (balance.c:13-36): this wave's pools, before the step's events
+        const double dgSoilC0 = soilC, dgLitterC0 = litterC, dgSoilOrgN0 = soilOrgN, dgLitterN0 = litterN, dgStorN0 = storN;
         // wave L's soil-temperature factors of this step (the tillage-scaled one and the plain one) and
         // wave W's moisture terms, each pair behind its flag, one round trip
         // In the same round trip, looked at but not waited for: C's plant-side block of this step and W's
@@ -1302,6 +1307,8 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         minN += (double)(((nMin - nVolatilization - nLeaching) - nUptake) * len);
         soilOrgN += (double)(nOrgSoil * len);
         litterN += (double)(nOrgLitter * len);
+        const double dgMinNPost = minN, dgSoilOrgNPost = soilOrgN, dgLitterNPost = litterN, dgStorNPost = storN;
+        if (wantDiagS && minN < 0.0 && fabs(minN) > kEps) clampWarnS++;
         minN = rmax0(minN);   // (plant death, which comes later in the step, does not touch this pool)
         postD(&mailMinN[(t + 1) & 1][lane], 0, minN);
         postFlag(&seqMinN, t + 1);
@@ -1315,6 +1322,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
           litterC += (double)((woodLitter + leafLitter - litterToSoil - rLitter - litterMethane) * len);
           soilC += (double)((soilInputs - rSoil - soilMethane) * len);
         }
+        const double dgSoilCPost = soilC, dgLitterCPost = litterC;
 
         // the end of C's step: its mortality verdict (one word per lane) and, where a stand died, what its
         // biomass adds to these pools (sipnet.c:1688-1767); then ensureNonNegativeStocks() for them
@@ -1347,11 +1355,48 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
             storN = 0.0;
           }
         }
+        if (wantDiagS)   // ensureNonNegativeStocks()' warnings, sipnet.c:1346-1356, for the pools this wave owns
+          clampWarnS += (soilC < 0.0 && fabs(soilC) > kEps) + (litterC < 0.0 && fabs(litterC) > kEps) +
+                        (soilOrgN < 0.0 && fabs(soilOrgN) > kEps) + (litterN < 0.0 && fabs(litterN) > kEps) +
+                        (storN < 0.0 && fabs(storN) > kEps);
         soilC = rmax0(soilC);
         litterC = rmax0(litterC);
         soilOrgN = rmax0(soilOrgN);
         litterN = rmax0(litterN);
         storN = rmax0(storN);
+        if (kPendRows > 3 && wantDiagS) {   // updateBalanceTrackerPostClamp() + checkBalance(), balance.c:40-169
+          double pc0, pn0, pc1, pn1, pc2, pn2, dInC, plantOut, evOutC, evInN, evOutN;
+          const unsigned base = ldsAddr(&mailPend[t & 1][0][lane]);   // rows 3 .. 13, behind the verdict word like rows 0 .. 2
+          asm volatile("ds_read_b64 %0, %11 offset:1536\n\tds_read_b64 %1, %11 offset:2048\n\tds_read_b64 %2, %11 offset:2560\n\t"
+                       "ds_read_b64 %3, %11 offset:3072\n\tds_read_b64 %4, %11 offset:3584\n\tds_read_b64 %5, %11 offset:4096\n\t"
+                       "ds_read_b64 %6, %11 offset:4608\n\tds_read_b64 %7, %11 offset:5120\n\tds_read_b64 %8, %11 offset:5632\n\t"
+                       "ds_read_b64 %9, %11 offset:6144\n\tds_read_b64 %10, %11 offset:6656\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(pc0), "=&v"(pn0), "=&v"(pc1), "=&v"(pn1), "=&v"(pc2), "=&v"(pn2), "=&v"(dInC), "=&v"(plantOut),
+                         "=&v"(evOutC), "=&v"(evInN), "=&v"(evOutN)
+                       : "v"(base) : "memory");
+          // mass totals in the reference's order of summation: plants (wave C's partial sum), soil, litter | plants,
+          // soil organic, litter, mineral, storage
+          const double preC = (pc0 + dgSoilC0) + dgLitterC0, postC = (pc1 + dgSoilCPost) + dgLitterCPost;
+          const double finC = (pc2 + soilC) + litterC;
+          const double preN = (((pn0 + dgSoilOrgN0) + dgLitterN0) + minN0) + dgStorN0;
+          const double postN = (((pn1 + dgSoilOrgNPost) + dgLitterNPost) + dgMinNPost) + dgStorNPost;
+          const double finN = (((pn2 + soilOrgN) + litterN) + minN) + storN;
+          double clampedC = finC - postC, clampedN = finN - postN;
+          if (clampedC < kEps) clampedC = 0.0;
+          if (clampedN < kEps) clampedN = 0.0;
+          double outC = plantOut + (double)rSoil + (double)soilMethane + evOutC;
+          outC += (double)rLitter + (double)litterMethane;
+          const double inC = dInC * (double)len + clampedC;
+          outC *= (double)len;
+          const double inN = ((double)nFixation + evInN) * (double)len + clampedN;
+          const double outN = ((double)nLeaching + (double)nVolatilization + evOutN) * (double)len;
+          const double dC = (finC - preC) - (inC - outC);
+          const double dN = (finN - preN) + (outN - inN);
+          maxDCS = fmax(maxDCS, fabs(dC));
+          maxDNS = fmax(maxDNS, fabs(dN));
+          if (!(fabs(dC) < kEps)) balanceWarnS++;
+          if (!(fabs(dN) < kEps)) balanceWarnS++;
+        }
         postD(&mailStorN[(t + 1) & 1][lane], 0, storN);
         postFlag(&seqStorN, t + 1);
         {  // NEE = -(NPP - R_h), sipnet.c:1433-1450: GPP - R_a from C, R_h = (litter + soil respiration) here
@@ -1410,6 +1455,13 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         ST(yearlyRh) = yRh;
         ST(yearlyRtot) = yRtot;
         ST(yearlyNee) = yNee;
+      }
+      if (wantDiagS) {
+        double* __restrict__ dg = a.diag + col;
+        if (clampWarnS) atomicAdd(dg, (double)clampWarnS);   // (waves C and W add their pools' counts)
+        dg[1 * nc] += (double)balanceWarnS;
+        dg[2 * nc] = fmax(dg[2 * nc], maxDCS);
+        dg[3 * nc] = fmax(dg[3 * nc], maxDNS);
       }
     }
     return;
@@ -1510,7 +1562,10 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         // (staged statistics: after the factor post, so that C has what it waits for.  C and W cannot be back
         // at the half's rows before this wave is done with them: they are kStageR - 1 steps away from it when
         // the action starts, and by day they need this wave's potential photosynthesis to go on)
-        if (Staged && stageOn && !FacWave && t == statNext) stagedAct();   // (with a factor wave: there)
+        // (round 5 moved this to the factor wave of the two-chunk layout -- it shares its SIMD with a water wave, the
+        // light wave with the other chunk's carbon wave -- and measured nothing: c4 run_stats 12.0 -> 11.9 ms.  What the
+        // staged statistics cost there, 1.7 ms, is C's and W's own stage writes, not where the half is summed.)
+        if (Staged && stageOn && t == statNext) stagedAct();
         if (!(bits & FAST_PAR_POS)) continue;  // night: potGrossPsn = 0, nobody waits for it
         {
         const R tair = recR<R>(q1.x);
@@ -1536,7 +1591,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
       }
     }
     WAIT_STORE(0)
-    if (Staged && stageOn && !FacWave) stagedFinish();
+    if (Staged && stageOn) stagedFinish();
     else if (statsHere) statFinish();
     return;
   }
@@ -1876,7 +1931,10 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   const double cLitterC = Full ? ST(litterC) : 0.0, cMinN = Full ? ST(minN) : 0.0;
   const double cSoilOrgN = Full ? ST(soilOrgN) : 0.0, cLitterN = Full ? ST(litterN) : 0.0;
   const double cStorN = Full ? ST(plantStorageN) : 0.0;
-  const bool wantDiag = Full && !NCyc && a.diag != nullptr;   // (NCyc: the pools are spread over two wavefronts: no counters)
+  const bool wantDiag = Full && !NCyc && a.diag != nullptr;
+  // NCyc, one chunk per workgroup: the pools are spread over two wavefronts -- this one sends the plant side's totals to
+  // wave S (mailPend rows 3 .. 13), which runs the balance check; the clamp warnings of the plant pools are counted here
+  const bool wantDiagN = Full && NCyc && NP == 1 && a.diag != nullptr;
   int clampWarn = 0, balanceWarn = 0;
   double maxDC = 0.0;
   double* __restrict__ recp = Full && a.rec ? a.rec + col : nullptr;
@@ -2346,6 +2404,17 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
     if (wantDiag) preC = (plantWoodC + delta) + plantLeafC + fineRootC + coarseRootC + soilC + (Opt && F_litterPool ? litterC : 0.0);
     R recLeafOffComputed = 0, recEvLeafOn = 0, recEvLeafOnFromWood = 0, recEvLeafOffLitter = 0;
     R evInC = 0, evOutC = 0;
+    [[maybe_unused]] R evInN = 0, evOutN = 0;   // NCyc: the events' nitrogen input / output (events.c:530-541, :582-594, :660-672)
+    // the plant side's share of getMassTotals() (balance.c:13-36): carbon, and nitrogen through the fixed C:N ratios
+    auto plantMassC = [&]() -> double { return (plantWoodC + delta) + plantLeafC + fineRootC + coarseRootC; };
+    auto plantMassN = [&]() -> double {
+      return plantWoodC * (double)G_iWoodCN + plantLeafC * (double)G_iLeafCN + fineRootC * (double)G_iFineCN + coarseRootC * (double)G_iWoodCN;
+    };
+    double dgPreC = 0.0, dgPreN = 0.0, dgPostC = 0.0, dgPostN = 0.0;
+    if (wantDiagN) {
+      dgPreC = plantMassC();
+      dgPreN = plantMassN();
+    }
 
     auto leafOnNFromC = [&](R leafOnC) -> R {  // nitrogen.c:84-86
       return rmax0(leafOnC * G_iLeafCN - leafOnC * G_iWoodCN);
@@ -2439,9 +2508,12 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
           evFineRootC += p2 * invLen;
           evCoarseRootC += p3 * invLen;
           if (Full) evInC += (p0 + p1 + p2 + p3) * invLen;  // events.c:530-541
+          if (Full && NCyc) evInN += (p0 * G_iLeafCN + p1 * G_iWoodCN + p2 * G_iFineCN + p3 * G_iWoodCN) * invLen;
         } else if (type == SIPNET_EV_HARVEST) {
           const R woodC = totalWoodC;
           if (Full) evOutC += ((woodC + eLeaf) * p0 + (eFine + eCoarse) * p1) * invLen;  // events.c:582-594
+          if (Full && NCyc)
+            evOutN += ((eWood * G_iWoodCN + eLeaf * G_iLeafCN) * p0 + (eFine * G_iFineCN + eCoarse * G_iWoodCN) * p1) * invLen;
           if (NCyc) {
             evLitterC += (p2 * (eLeaf + woodC)) * invLen;
             evSoilC += (p3 * (eFine + eCoarse)) * invLen;
@@ -2468,6 +2540,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
             evSoilC += p1 * invLen;
           }
           if (Full) evInC += p1 * invLen;
+          if (Full && NCyc) evInN += (p0 + p2) * invLen;
         } else if (type == SIPNET_EV_LEAFON) {
           const R flux = leafOnLimit(PRM_RARE(leafGrowth) * invLen);
           evLeafOnCreation += flux;
@@ -2559,6 +2632,10 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
     if (wantDiag)
       postC = (plantWoodC + delta) + plantLeafC + fineRootC + coarseRootC + (soilC + soilGain) +
               (Opt && F_litterPool ? litterC + litterGain : 0.0);
+    if (wantDiagN) {
+      dgPostC = plantMassC();
+      dgPostN = plantMassN();
+    }
     double deathWood = 0.0, deathRoot = 0.0;  // record columns 41, 42
     // checkForMortality(), sipnet.c:1688-1767
     bool alive = alive0;
@@ -2600,7 +2677,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
       }
     }
     aliveC = alive;
-    if (wantDiag) {  // clamp warnings, sipnet.c:1346-1356
+    if (wantDiag || wantDiagN) {  // clamp warnings, sipnet.c:1346-1356
       clampWarn += (plantWoodC < 0.0 && fabs(plantWoodC) > kEps) + (plantLeafC < 0.0 && fabs(plantLeafC) > kEps) +
                    (coarseRootC < 0.0 && fabs(coarseRootC) > kEps) + (fineRootC < 0.0 && fabs(fineRootC) > kEps);
     }
@@ -2614,6 +2691,19 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
       if (Full) {
         postD(&mailPend[t & 1][0][lane], 1, (double)ffma(rVeg, len, (rCoarseRoot + rFineRoot) * len));
         postD(&mailPend[t & 1][0][lane], 2, (double)((rCoarseRoot + rFineRoot) * len));
+      }
+      if (kPendRows > 3 && wantDiagN) {   // for wave S's balance check: totals before / after the updates / after the clamps, rates
+        postD(&mailPend[t & 1][0][lane], 3, dgPreC);
+        postD(&mailPend[t & 1][0][lane], 4, dgPreN);
+        postD(&mailPend[t & 1][0][lane], 5, dgPostC);
+        postD(&mailPend[t & 1][0][lane], 6, dgPostN);
+        postD(&mailPend[t & 1][0][lane], 7, plantMassC());
+        postD(&mailPend[t & 1][0][lane], 8, plantMassN());
+        postD(&mailPend[t & 1][0][lane], 9, (double)photosynthesis + (double)evInC);
+        postD(&mailPend[t & 1][0][lane], 10, (double)rVeg + (double)rFineRoot + (double)rCoarseRoot);
+        postD(&mailPend[t & 1][0][lane], 11, (double)evOutC);
+        postD(&mailPend[t & 1][0][lane], 12, (double)evInN);
+        postD(&mailPend[t & 1][0][lane], 13, (double)evOutN);
       }
     }
     // confirms the lai(t+1) posted above, or revokes it when the stand died in this step (its
@@ -2817,6 +2907,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
       dg[1 * nc] += (double)balanceWarn;
       dg[2 * nc] = fmax(dg[2 * nc], maxDC);
     }
+    if (wantDiagN && clampWarn) atomicAdd(a.diag + col, (double)clampWarn);   // (the balance counters are wave S's)
   }
 #undef ST
 #undef PRM

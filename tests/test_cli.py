@@ -398,3 +398,19 @@ def test_cli_sites_ensemble_out_one_block_per_forcing(tmp_path):
         names, rows = _out_table(open(tmp_path / f"r{run}" / "sipnet.out").read())
         assert blk["nee"].shape[0] == len(rows)
         _assert_block_matches_text(blk, names, rows, m, f"run {run}")
+
+
+@pytest.mark.gpu
+def test_cli_bounded_waits_option_gives_the_same_files(tmp_path):
+    """--bounded-waits: the ensemble runs on the cooperative kernels' bounded-wait build (a wait that never ends would be
+    reported with exit 7 instead of hanging the GPU); same bits, hence the same text"""
+    stage("niwot", tmp_path)
+    open(tmp_path / "members.txt", "w").write("aMax psnTOpt\n8.3 24\n9.0 22.5\n7.1 25\n")
+    r = run_cli(tmp_path, "-i", "sipnet.in", "--ensemble-params", "members.txt", "--ensemble-out", "a.nc")
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = run_cli(tmp_path, "-i", "sipnet.in", "--ensemble-params", "members.txt", "--ensemble-out", "b.nc", "--bounded-waits")
+    assert r.returncode == 0, r.stdout + r.stderr
+    from sipnet_amd import ensemble_io as eio
+    a, b = eio.read_ensemble_netcdf(tmp_path / "a.nc"), eio.read_ensemble_netcdf(tmp_path / "b.nc")
+    for k in ("nee", "gpp", "evapotranspiration"):
+        np.testing.assert_array_equal(a[k], b[k])

@@ -174,17 +174,21 @@ def test_diagnostics_counters_match_the_oracle_on_the_special_members(name, fast
     b.close()
 
 
-@pytest.mark.parametrize("fast", [False, True], ids=["strict", "one_wave_ncycle"])
-def test_diagnostics_with_the_nitrogen_cycle_on_the_balance_cases(fast, oracle):
-    """the reference's own balance test data (testBalance.c): carbon AND nitrogen residuals"""
+@pytest.mark.parametrize("fast,kernel", [(False, sa.KERNEL_AUTO), (True, sa.KERNEL_ONE_WAVE), (True, sa.KERNEL_AUTO)],
+                         ids=["strict", "one_wave_ncycle", "auto"])
+def test_diagnostics_with_the_nitrogen_cycle_on_the_balance_cases(fast, kernel, oracle):
+    """the reference's own balance test data (testBalance.c): carbon AND nitrogen residuals (auto: the cooperative kernels
+    where the flag set has the nitrogen cycle -- the soil wave runs the check -- or the optional-physics builds)"""
     from tests.test_balance import CONFIGS, load
     for name in sorted(CONFIGS):
         flags, params, clim, events = load(name)
         st, _, want = oracle.run_member(flags, params, clim, events, want_rec=False)
         assert st == 0
-        b = _batch(flags, clim, params[None, :], events, fast=fast, diag=True)
+        b = _batch(flags, clim, params[None, :], events, fast=fast, kernel=kernel, diag=True)
         b.run(want_planes=False)
         d = b.get_diagnostics()
+        if fast and kernel == sa.KERNEL_AUTO:
+            assert b.last_launch()["kernel"].startswith("stepCoop"), b.last_launch()
         b.close()
         assert d["n_clamp_warn"][0] == want.n_clamp_warn and d["n_balance_warn"][0] == want.n_balance_warn == 0, name
         assert d["max_abs_dC"][0] < 1e-8 and d["max_abs_dN"][0] < 1e-8, (name, d)
@@ -230,3 +234,35 @@ def test_diagnostics_of_the_optional_physics_kernels_match_the_oracle(kernel, or
     np.testing.assert_array_equal(d["n_clamp_warn"], np.array([w.n_clamp_warn for w in want]))
     np.testing.assert_array_equal(d["n_balance_warn"], np.array([w.n_balance_warn for w in want]))
     assert d["max_abs_dC"].max() < 1e-9
+
+
+@pytest.mark.parametrize("which,kernel,expect", [("nitrogen", sa.KERNEL_COOP_NCYCLE, "stepCoopNFullKernel<double, false>"),
+                                                  ("everything", sa.KERNEL_AUTO, "stepCoopNXFullKernel<double, false>"),
+                                                  ("nitrogen", sa.KERNEL_ONE_WAVE, "stepFastKernel<double, false, 2, 1, true>")],
+                         ids=["n_full", "nx_full_auto", "one_wave"])
+def test_diagnostics_counters_with_the_nitrogen_cycle_on_the_cooperative_kernels(which, kernel, expect, oracle, base):
+    """round 5: clamp and carbon / nitrogen balance counters with the nitrogen cycle from the cooperative kernels -- the
+    plant side's mass totals travel with wave C's end-of-step post to the soil wave, which runs checkBalance()
+    (balance.c:122-169 over the pools of nitrogen.c:210-239) -- on the events scenario (fertiliser, harvests, a clear-cut,
+    re-planting, leaf events): counters equal to the oracle's, residuals at rounding level; the two-chunk layout refuses"""
+    flags = sa.flags_from(**(EVERYTHING if which == "everything" else dict(litterPool=1, anaerobic=1, nitrogenCycle=1)))
+    nbase = sa.read_params(os.path.join(os.path.dirname(BASE), "allflags_forest.param"), flags)[0]
+    clim, ev, members = _scenario(nbase, lethal=True)
+    members = members[:70]
+    want = [oracle.run_member(flags, members[m], clim, ev, want_rec=False)[2] for m in range(70)]
+    b = _batch(flags, clim, members, ev, fast=True, kernel=kernel, diag=True)
+    b.run(0, 1001, want_planes=False)
+    b.run(1001, clim.n_steps - 1001, want_planes=False)
+    d = b.get_diagnostics()
+    li = b.last_launch()
+    b.close()
+    assert li["kernel"] == expect, li
+    np.testing.assert_array_equal(d["n_clamp_warn"], np.array([w.n_clamp_warn for w in want]))
+    np.testing.assert_array_equal(d["n_balance_warn"], np.array([w.n_balance_warn for w in want]))
+    assert d["max_abs_dC"].max() < 1e-9 and d["max_abs_dN"].max() < 1e-9
+    assert (d["max_abs_dC"] > 0).any() and (d["max_abs_dN"] > 0).any()
+    if kernel == sa.KERNEL_COOP_NCYCLE:
+        b = _batch(flags, clim, members, ev, fast=True, kernel=sa.KERNEL_COOP_NCYCLE_PAIR, diag=True)
+        with pytest.raises(sa.SipnetError, match="one-chunk layout only"):
+            b.run(0, 10, want_planes=False)
+        b.close()
