@@ -342,6 +342,11 @@ std::vector<int> parseDevices(const std::string& arg) {
   return out;
 }
 
+double nowSeconds() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 void check(int rc, const char* what) {
   if (rc != SIPNET_OK) die(rc >= 100 ? 1 : rc, std::string(what) + ": " + sipnet_last_error() + "\n");
 }
@@ -393,6 +398,7 @@ void putBlock(sipnet_ensemble_file* f, const BlockSpec& spec, int T, int64_t ld,
               const double* dPlanes, const double* dRec) {
   std::vector<double> host((size_t)T * n), second;
   const size_t w = (size_t)n * sizeof(double), dense = (size_t)T * w;
+  double tFetch = 0.0, tPut = 0.0;
   // a column of the device result is T pieces of n doubles, ld (planes) or SIPNET_NREC x ld (records) doubles apart: gathered
   // into a dense device array first (a device-side copy), then ONE dense copy to the host -- row pieces straight over
   // PCIe took 3 s per column of 10 240 members x 17 520 steps, this takes 0.15 s
@@ -400,17 +406,24 @@ void putBlock(sipnet_ensemble_file* f, const BlockSpec& spec, int T, int64_t ld,
   double* dDense = strided ? (double*)sipnet_dev_alloc(dense) : nullptr;
   if (strided && !dDense) die(1, std::string(sipnet_last_error()) + "\n");
   auto fetch = [&](std::vector<double>& dst, const double* src, size_t pitch) {
+    const double t0 = nowSeconds();
     if (!strided) {
       check(sipnet_dev_to_host(dst.data(), src, dense, nullptr), "copy back");
-      return;
+    } else {
+      check(sipnet_dev_to_dev_2d(dDense, w, src, pitch, w, (size_t)T, nullptr), "gathering a column");
+      check(sipnet_dev_to_host(dst.data(), dDense, dense, nullptr), "copy back");
     }
-    check(sipnet_dev_to_dev_2d(dDense, w, src, pitch, w, (size_t)T, nullptr), "gathering a column");
-    check(sipnet_dev_to_host(dst.data(), dDense, dense, nullptr), "copy back");
+    tFetch += nowSeconds() - t0;
+  };
+  auto put = [&](int v) {
+    const double t0 = nowSeconds();
+    check(sipnet_io_ensemble_put(f, v, 0, T, member0, n, host.data(), n, 0), "writing the ensemble block");
+    tPut += nowSeconds() - t0;
   };
   if (spec.planesOnly()) {
     for (int v = 0; v < 3; v++) {
       fetch(host, dPlanes + ((size_t)v * Tld) * ld + col0, (size_t)ld * sizeof(double));
-      check(sipnet_io_ensemble_put(f, v, 0, T, member0, n, host.data(), n, 0), "writing the ensemble block");
+      put(v);
     }
   } else {
     const size_t pitch = (size_t)SIPNET_NREC * ld * sizeof(double);
@@ -423,10 +436,14 @@ void putBlock(sipnet_ensemble_file* f, const BlockSpec& spec, int T, int64_t ld,
         fetch(second, dRec + (size_t)r1 * ld + col0, pitch);
         for (size_t i = 0; i < host.size(); i++) host[i] += second[i];
       }
-      check(sipnet_io_ensemble_put(f, (int32_t)v, 0, T, member0, n, host.data(), n, 0), "writing the ensemble block");
+      put((int)v);
     }
   }
   if (dDense) sipnet_dev_free(dDense);
+  char msg[200];
+  snprintf(msg, sizeof msg, "ensemble block: members %d..%d, %zu variable(s): device -> host %.2f s, conversion + file %.2f s\n", member0,
+           member0 + n - 1, spec.planesOnly() ? (size_t)3 : spec.cols.size(), tFetch, tPut);
+  logInfo(msg);
 }
 
 // ---- --sites: many run directories, few batches ---------------------------------------------------------------
@@ -1092,7 +1109,12 @@ int main(int argc, char** argv) {
       if (!dDbg) die(1, std::string(sipnet_last_error()) + "\n");
       check(sipnet_batch_run_debug(b, 0, T, dRec, dDbg, Ms, nullptr), "run");
     } else {
+      const double t0 = nowSeconds();
       check(sipnet_batch_run(b, 0, T, nullptr, nullptr, nullptr, dRec, Ms, nullptr), "run");
+      check(sipnet_stream_sync(nullptr), "run");
+      char msg[160];
+      snprintf(msg, sizeof msg, "members %d..%d: %d steps with the 44-column record in %.3f s\n", m0, m1 - 1, T, nowSeconds() - t0);
+      logInfo(msg);
     }
     if (blockFile && !block.planesOnly()) putBlock(blockFile, block, T, Ms, T, 0, Ms, m0, nullptr, dRec);
     if (blockFile && block.planesOnly()) {   // (with text or checkpoints: the three planes are record columns 0, 1, 2)

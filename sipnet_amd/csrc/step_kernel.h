@@ -91,7 +91,6 @@ struct FastArgs {
   const EvRec* events;
   const int32_t* siteBase;    // ... [n_sites][3]: the site's base in ringOps / events, its number of records (<= n_steps_total)
   const double* prm;
-  const int32_t* prmId;   // null, or (one-wave kernel only; a particle filter's batch): column c reads the parameters of column prmId[c]
   double* state;
   double* ring;
   void* nee;
@@ -117,6 +116,9 @@ struct FastArgs {
   // planes must be given.  launchFinishStats adds the chunks of a site up.
   double* statsPart;
   int32_t statsChunks;           // n_sites * chunksPerSite
+  // (at the END, so that the fields above keep the offsets the cooperative kernels' code was measured with: a field in the
+  // middle re-rolled c10k's register allocation and cost it 1 %)
+  const int32_t* prmId;   // null, or (one-wave kernel only; a particle filter's batch): column c reads the parameters of column prmId[c]
 };
 // What a launcher actually put on the stream (sipnet_batch_last_launch): the instantiation's
 // name as rocprofv3 prints its template arguments, and the launch shape.

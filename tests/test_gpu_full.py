@@ -259,7 +259,10 @@ def test_diagnostics_counters_with_the_nitrogen_cycle_on_the_cooperative_kernels
     assert li["kernel"] == expect, li
     np.testing.assert_array_equal(d["n_clamp_warn"], np.array([w.n_clamp_warn for w in want]))
     np.testing.assert_array_equal(d["n_balance_warn"], np.array([w.n_balance_warn for w in want]))
-    assert d["max_abs_dC"].max() < 1e-9 and d["max_abs_dN"].max() < 1e-9
+    # the largest residuals are the oracle's: rounding level for carbon; for nitrogen the reference's own bookkeeping
+    # leaves a real residual on some event steps of this scenario (which is what its warning counts) -- the same one here
+    np.testing.assert_allclose(d["max_abs_dC"], np.array([w.max_abs_dC for w in want]), rtol=0, atol=1e-9)
+    np.testing.assert_allclose(d["max_abs_dN"], np.array([w.max_abs_dN for w in want]), rtol=1e-6, atol=1e-9)
     assert (d["max_abs_dC"] > 0).any() and (d["max_abs_dN"] > 0).any()
     if kernel == sa.KERNEL_COOP_NCYCLE:
         b = _batch(flags, clim, members, ev, fast=True, kernel=sa.KERNEL_COOP_NCYCLE_PAIR, diag=True)

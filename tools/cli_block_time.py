@@ -33,6 +33,9 @@ def run(label, M, *args):
     r = subprocess.run([CLI, "-i", "sipnet.in", "--ensemble-params", "members.txt", *args], cwd=tmp, capture_output=True, text=True)
     dt = time.time() - t0
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    for line in r.stdout.splitlines():
+        if "ensemble block:" in line or "44-column record in" in line:
+            print("      " + line.strip())
     size = sum(os.path.getsize(os.path.join(tmp, f)) for f in os.listdir(tmp) if f.endswith((".out", ".nc")))
     n = sum(1 for f in os.listdir(tmp) if f.endswith((".out", ".nc")))
     print(f"{label}: {M} members x {T} steps, CLI wall {dt:.2f} s, {n} output file(s), {size/1e9:.3f} GB, "
