@@ -35,7 +35,9 @@
 //                            columns' names and units) INSTEAD of the members' text files: nee, gpp and
 //                            evapotranspiration by default -- the lean throughput kernels, three planes -- or the
 //                            `.out` columns named with --ensemble-out-columns a,b,c|all (the 44-column record);
-//                            --ensemble-out-f32 stores floats; --ensemble-text writes the text files as well.
+//                            --ensemble-out-f32 stores floats; --ensemble-text writes the text files as well;
+//                            --ensemble-out-segment N holds N steps of the record on the device at a time (default:
+//                            about 3 GB worth -- the whole record of 10 240 members x a year would be 63 GB).
 //                            Device shards stream their member ranges into the one file.  With --sites one block
 //                            per distinct forcing: FILE itself when there is one, else <stem>.<k><ext> with k = the
 //                            position in the list of the site's first run; member = position in the list, the global
@@ -356,6 +358,7 @@ struct BlockSpec {
   std::string path;                // empty: no block
   std::vector<int> cols;           // `.out` column indices (sipnet_io_out_column); empty: the three planes
   bool f32 = false, text = false;  // store floats; write the members' text files as well
+  int segment = 0;                 // --ensemble-out-segment: steps of the record held on the device at a time (0: ~3 GB worth)
   bool on() const { return !path.empty(); }
   bool planesOnly() const { return cols.empty(); }
 };
@@ -394,8 +397,9 @@ sipnet_ensemble_file* createBlock(const BlockSpec& spec, const std::string& path
 // members [col0, col0 + n) of a device result -> members [member0, member0 + n) of the block, one variable at a time
 // (a dense [T][n] host array per variable: nothing the size of the record ever exists on the host).
 // planes: dPlanes[3][Tld][ld] (NEE, GPP, ET); records: dRec[Tld][SIPNET_NREC][ld].
+// (step0: the file rows the device arrays' T rows go to -- a run cut into segments fills the block segment by segment)
 void putBlock(sipnet_ensemble_file* f, const BlockSpec& spec, int T, int64_t ld, int64_t Tld, int64_t col0, int n, int member0,
-              const double* dPlanes, const double* dRec) {
+              const double* dPlanes, const double* dRec, int step0 = 0) {
   std::vector<double> host((size_t)T * n), second;
   const size_t w = (size_t)n * sizeof(double), dense = (size_t)T * w;
   double tFetch = 0.0, tPut = 0.0;
@@ -417,7 +421,7 @@ void putBlock(sipnet_ensemble_file* f, const BlockSpec& spec, int T, int64_t ld,
   };
   auto put = [&](int v) {
     const double t0 = nowSeconds();
-    check(sipnet_io_ensemble_put(f, v, 0, T, member0, n, host.data(), n, 0), "writing the ensemble block");
+    check(sipnet_io_ensemble_put(f, v, step0, T, member0, n, host.data(), n, 0), "writing the ensemble block");
     tPut += nowSeconds() - t0;
   };
   if (spec.planesOnly()) {
@@ -441,8 +445,8 @@ void putBlock(sipnet_ensemble_file* f, const BlockSpec& spec, int T, int64_t ld,
   }
   if (dDense) sipnet_dev_free(dDense);
   char msg[200];
-  snprintf(msg, sizeof msg, "ensemble block: members %d..%d, %zu variable(s): device -> host %.2f s, conversion + file %.2f s\n", member0,
-           member0 + n - 1, spec.planesOnly() ? (size_t)3 : spec.cols.size(), tFetch, tPut);
+  snprintf(msg, sizeof msg, "ensemble block: members %d..%d, steps %d..%d, %zu variable(s): device -> host %.2f s, conversion + file %.2f s\n",
+           member0, member0 + n - 1, step0, step0 + T - 1, spec.planesOnly() ? (size_t)3 : spec.cols.size(), tFetch, tPut);
   logInfo(msg);
 }
 
@@ -809,7 +813,7 @@ int main(int argc, char** argv) {
     opts.push_back({kFlagOpts[k][0], no_argument, &tmpFlag, 1});
     opts.push_back({strdup((std::string("no-") + kFlagOpts[k][0]).c_str()), no_argument, &tmpFlag, 0});
   }
-  enum { OPT_RIN = 1001, OPT_ROUT, OPT_DBG, OPT_ENS, OPT_DEV, OPT_MATH, OPT_ESTATS, OPT_SITES, OPT_EOUT, OPT_ECOLS, OPT_EF32, OPT_ETEXT, OPT_BOUNDED };
+  enum { OPT_RIN = 1001, OPT_ROUT, OPT_DBG, OPT_ENS, OPT_DEV, OPT_MATH, OPT_ESTATS, OPT_SITES, OPT_EOUT, OPT_ECOLS, OPT_EF32, OPT_ETEXT, OPT_BOUNDED, OPT_ESEG };
   opts.push_back({"input-file", required_argument, nullptr, 'i'});
   opts.push_back({"file-prefix", required_argument, nullptr, 'f'});
   opts.push_back({"file-name", required_argument, nullptr, 'f'});
@@ -827,6 +831,7 @@ int main(int argc, char** argv) {
   opts.push_back({"ensemble-out-f32", no_argument, nullptr, OPT_EF32});
   opts.push_back({"ensemble-text", no_argument, nullptr, OPT_ETEXT});
   opts.push_back({"bounded-waits", no_argument, nullptr, OPT_BOUNDED});
+  opts.push_back({"ensemble-out-segment", required_argument, nullptr, OPT_ESEG});
   opts.push_back({"help", no_argument, nullptr, 'h'});
   opts.push_back({"version", no_argument, nullptr, 'v'});
   opts.push_back({nullptr, 0, nullptr, 0});
@@ -852,6 +857,7 @@ int main(int argc, char** argv) {
       case OPT_EF32: block.f32 = true; break;
       case OPT_ETEXT: block.text = true; break;
       case OPT_BOUNDED: g_kernelOptions |= SIPNET_KOPT_BOUNDED_WAITS; break;
+      case OPT_ESEG: block.segment = atoi(optarg); break;
       case 'h': usage(argv[0]); return 0;
       case 'v': printf("SIPNET version 2.1.0 (%s)\n", sipnet_version()); return 0;
       default: usage(argv[0]); return 8;  // EXIT_CODE_BAD_CLI_ARGUMENT
@@ -1095,6 +1101,34 @@ int main(int argc, char** argv) {
         }
       putBlock(blockFile, block, T, Ms, T, 0, Ms, m0, dPlanes, nullptr);
       sipnet_dev_free(dPlanes);
+      sipnet_batch_destroy(b);
+      return;
+    }
+    if (!wantText && restartOut.empty() && debugLog.empty()) {
+      // the block alone, named `.out` columns: the 44-column record exists on the device only, a segment of steps at a
+      // time (the whole record of 10 240 members x a half-hourly year is 63 GB: allocating it took 25 s of a 27 s run)
+      int64_t segSteps = (int64_t)(3.0e9 / ((double)SIPNET_NREC * Ms * sizeof(double)));
+      segSteps = std::max<int64_t>(16, segSteps & ~(int64_t)15);
+      if (block.segment > 0) segSteps = block.segment;
+      if (segSteps > T) segSteps = T;
+      double* dSeg = (double*)sipnet_dev_alloc((size_t)segSteps * SIPNET_NREC * Ms * sizeof(double));
+      if (!dSeg) die(1, std::string(sipnet_last_error()) + "\n");
+      for (int t0 = 0; t0 < T; t0 += (int)segSteps) {
+        const int len = (int)std::min<int64_t>(segSteps, T - t0);
+        check(sipnet_batch_run(b, t0, len, nullptr, nullptr, nullptr, dSeg, Ms, nullptr), "run");
+        putBlock(blockFile, block, len, Ms, len, 0, Ms, m0, nullptr, dSeg, t0);
+      }
+      std::vector<int32_t> status(Ms);
+      check(sipnet_batch_get_status(b, status.data(), nullptr), "status");
+      for (int m = 0; m < Ms; m++)
+        if (status[m] != 0) {
+          std::lock_guard<std::mutex> lock(logMutex);
+          logError("member " + std::to_string(m0 + m) + ": status " + std::to_string(status[m]) +
+                   " (NPP allocation params must be less than one individually and add to less than one)\n");
+          int w = worst.load();
+          while (status[m] > w && !worst.compare_exchange_weak(w, status[m])) {}
+        }
+      sipnet_dev_free(dSeg);
       sipnet_batch_destroy(b);
       return;
     }

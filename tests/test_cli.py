@@ -348,8 +348,10 @@ def test_cli_ensemble_out_block_against_the_goldens_and_the_members_text(tmp_pat
     for k in ("nee", "gpp", "evapotranspiration"):
         np.testing.assert_allclose(planes[k], block[k], rtol=0, atol=1e-11)
     # two shards on one device stream into ONE file; single precision
+    # (... and the record held on the device 1 000 steps at a time: six launches per shard, the last one ragged)
     r = run_cli(tmp_path, "-i", "sipnet.in", "--ensemble-params", "members.txt", "--ensemble-out", "sharded.nc",
-                "--devices", "0,0", "--ensemble-out-f32", "--ensemble-out-columns", "nee,plantWoodC,soilWater")
+                "--devices", "0,0", "--ensemble-out-f32", "--ensemble-out-columns", "nee,plantWoodC,soilWater",
+                "--ensemble-out-segment", "1000")
     assert r.returncode == 0, r.stdout + r.stderr
     sh = eio.read_ensemble_netcdf(tmp_path / "sharded.nc")
     assert sh["nee"].dtype == np.float32 and sh["member"].tolist() == [0, 1, 2]

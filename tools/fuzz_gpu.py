@@ -174,6 +174,16 @@ for trial in range(trials):
         else:
             kern, forced = [(sa.KERNEL_AUTO, ""), (sa.KERNEL_COOP_LDS, " coop-lds"), (sa.KERNEL_COOP_HBM, " coop-hbm"),
                             (sa.KERNEL_COOP_PAIR, " coop-pair")][int(rng.integers(0, 4))]
+    # round 5 (a generator of its own: the trials of earlier campaigns stay what their seeds made them): FUZZ_R5=1 adds
+    # the instantiations that are new -- optional physics at four chunks per workgroup (fp32-mixed), the record and the
+    # diagnostics counters from the optional-physics and nitrogen-cycle kernels ("everything" included)
+    r5_full = False
+    if os.environ.get("FUZZ_R5") and (OPT_ONLY or NCYC_ONLY):
+        rng5 = np.random.default_rng(seed0 * 104729 + trial)
+        ncyc_on = bool(flags[sa.FLAG_NAMES.index("nitrogenCycle")])
+        if OPT_ONLY and not ncyc_on and prec == sa.F32_MIXED and rng5.random() < 0.5:
+            kern, forced = sa.KERNEL_COOP_QUAD, " coop-quad"
+        r5_full = bool(rng5.random() < 0.4) and kern not in (sa.KERNEL_COOP_QUAD, sa.KERNEL_COOP_NCYCLE_PAIR)
     if os.environ.get("FUZZ_BOUNDED"): kopt |= sa.KOPT_BOUNDED_WAITS      # the cooperative kernels' build with bounded waits: a protocol bug ends the launch with a report instead of hanging the GPU
     if os.environ.get("FUZZ_KOPT"): kopt = int(os.environ["FUZZ_KOPT"])
     if os.environ.get("FUZZ_KERNEL"):     # rerun a trial on another kernel (with the trial index as third argument)
@@ -185,7 +195,10 @@ for trial in range(trials):
     # a third of the trials also ask for the 44-column record and the diagnostics counters (the
     # "full" instantiations of the throughput kernels, or the strict kernel's)
     want_full = bool(rng.random() < 0.33) and kern not in (sa.KERNEL_COOP_QUAD, sa.KERNEL_COOP_NCYCLE, sa.KERNEL_COOP_NCYCLE_PAIR)    # no full-state builds of these
-    if OPT_ONLY: want_full = False       # (the optional-physics instantiations are lean)
+    if OPT_ONLY: want_full = False       # (round 4's campaigns: lean only)
+    if r5_full:
+        want_full = True
+        kopt &= ~sa.KOPT_BOUNDED_WAITS   # (the bounded-wait build has lean instantiations only)
     if want_full:
         b.enable_diagnostics()
         forced += " full"
