@@ -721,6 +721,7 @@ def main():
                           **({"pipelined_error": pipelined} if isinstance(pipelined, str) else {}),
                           "bytes_up": int(members.nbytes + S * (clims[0].data.nbytes + clims[0].year.nbytes + clims[0].day.nbytes)),
                           "bytes_down": int(host_stats.numel() * 8),
+                          "plan_device_sites": int(b.last_launch()["plan_device_sites"]),   # sites whose plan the device built (plan_device.h)
                           "includes": "climate of every site + raw parameters (one upload for all sites) from host memory, "
                                       "site-plan build + upload, setupModel(), the step kernel with the ensemble statistics from "
                                       "the same launch (sipnet_batch_run_stats), the statistics block into pinned host memory; "

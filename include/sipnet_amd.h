@@ -273,6 +273,11 @@ enum sipnet_kernel_option {
                                         campaigns and tests, never chosen by SIPNET_KERNEL_AUTO */
   SIPNET_KOPT_WAIT_SELFTEST = 64,    /* with SIPNET_KOPT_BOUNDED_WAITS only: the light wavefront stops posting after 100 steps --
                                         the test of the error path itself (the launch must end with SIPNET_ERR_INTERNAL) */
+  SIPNET_KOPT_HOST_PLAN = 128,       /* build every site's per-step records on host threads (plan.cpp) -- without it the
+                                        records of a site without agronomic events and without a resumed checkpoint, whose
+                                        steps are all at least 0.0202 days long, are built on the DEVICE from the site's
+                                        climate (csrc/plan_device.h: 63 MB instead of 143 MB over PCIe at 32 sites x 17 520
+                                        records, no host threads); the records are the same bytes either way */
   SIPNET_KOPT_FULL_STATE = 4         /* throughput kernels: advance EVERY accumulator of the restart
                                         schema (trackers.tot*, trackers.yearly*); without it only
                                         totNee / totGpp advance on the throughput path.  Implied by a
@@ -652,9 +657,18 @@ typedef struct sipnet_launch_info {
   int32_t plan_threads;         /* host threads that built the site plans */
   double plan_build_ms;         /* host: building all site plans */
   double plan_upload_ms;        /* host -> device copy of the plans */
+  int32_t plan_device_sites;    /* sites whose records the device built itself (SIPNET_KOPT_HOST_PLAN: 0) */
+  int32_t reserved;
 } sipnet_launch_info;
 int sipnet_batch_last_launch(sipnet_batch *b, sipnet_launch_info *out);
 const char *sipnet_batch_last_kernel_name(sipnet_batch *b); /* "" before the first run */
+
+/* Test hook: the per-step records and ring evictions the device built for `site` against the host builder's, byte by
+ * byte (ignore_log2: leaving out the log2(vpd) field, which the device path fills only once a member with dVpdExp != 2
+ * exists).  device_info[4]: run descriptors, evictions written, status (0 ok), the step of a non-zero status. */
+int sipnet_debug_plan_compare(sipnet_batch *b, int32_t site, int32_t ignore_log2, int64_t *n_records_differing,
+                              int64_t *n_ops_differing, int32_t *first_step, int32_t *first_offset,
+                              int32_t *device_info);
 
 /* Device buffer helpers for callers without their own allocator (the CLI). */
 void *sipnet_dev_alloc(size_t bytes);

@@ -34,6 +34,7 @@ KOPT_ONE_WAVE_PER_SIMD, KOPT_RUNTIME_FLAGS, KOPT_FULL_STATE, KOPT_NO_REGULAR_TIL
 KOPT_STATS_IN_KERNEL = 16
 KOPT_BOUNDED_WAITS = 32
 KOPT_WAIT_SELFTEST = 64
+KOPT_HOST_PLAN = 128     # every site plan on host threads (default: eligible sites on the device, csrc/plan_device.h)
 SHARD_MEMBERS, SHARD_SITES = 0, 1
 ALL_SITES = -1
 
@@ -86,7 +87,7 @@ class LaunchInfo(C.Structure):
     _fields_ = [("kernel", C.c_char * 96), ("grid", C.c_int32), ("block_threads", C.c_int32),
                 ("waves_per_simd", C.c_int32), ("lds_bytes", C.c_int32), ("num_cus", C.c_int32),
                 ("plan_threads", C.c_int32), ("plan_build_ms", C.c_double),
-                ("plan_upload_ms", C.c_double)]
+                ("plan_upload_ms", C.c_double), ("plan_device_sites", C.c_int32), ("reserved", C.c_int32)]
 
 
 class PfPeer(C.Structure):
@@ -195,6 +196,7 @@ SIGNATURES = {
     "sipnet_dev_to_host": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "sipnet_dev_to_host_2d": (C.c_int, [_P, C.c_size_t, _P, C.c_size_t, C.c_size_t, C.c_size_t, _P]),
     "sipnet_dev_to_dev_2d": (C.c_int, [_P, C.c_size_t, _P, C.c_size_t, C.c_size_t, C.c_size_t, _P]),
+    "sipnet_debug_plan_compare": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
     "sipnet_stream_sync": (C.c_int, [_P]),
     "sipnet_stream_create": (_P, [C.c_int32]),
     "sipnet_stream_destroy": (None, [_P]),

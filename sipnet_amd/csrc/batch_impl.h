@@ -9,6 +9,7 @@
 
 #include "../../include/sipnet_amd.h"
 #include "plan.h"
+#include "plan_device.h"
 #include "step_kernel.h"
 
 namespace sipnet {
@@ -28,6 +29,26 @@ using namespace sipnet;  // internal header: only engine.hip and pf.hip include 
 struct PfScratch;  // pf.hip
 struct PfPeers;
 
+// A site's forcing as the caller handed it over: one PINNED host block ([n][NCLIM] doubles, then year[n], day[n]), kept so
+// that the plan can be rebuilt in any call order and so that the block can leave for the device by an asynchronous copy
+// straight out of sipnet_batch_set_climate (device-built plans, plan_device.h); grow-only.
+struct SiteClim {
+  unsigned char* host = nullptr;
+  unsigned char* dev = nullptr;
+  size_t hostCap = 0, devCap = 0;   // bytes
+  int32_t n = 0;                    // records
+  bool onDevice = false;            // the device block holds this forcing (a copy is at least queued on upStream)
+  hipEvent_t evCopied = nullptr;    // behind that copy: the host may write the pinned block again once it has fired
+  bool copyQueued = false;
+  static size_t bytesFor(int32_t n) { return (size_t)n * (SIPNET_NCLIM * sizeof(double) + 2 * sizeof(int32_t)); }
+  const double* clim() const { return (const double*)host; }
+  const int32_t* year() const { return (const int32_t*)(host + (size_t)n * SIPNET_NCLIM * sizeof(double)); }
+  const int32_t* day() const { return year() + n; }
+  const double* devClim() const { return (const double*)dev; }
+  const int32_t* devYear() const { return (const int32_t*)(dev + (size_t)n * SIPNET_NCLIM * sizeof(double)); }
+  const int32_t* devDay() const { return devYear() + n; }
+};
+
 struct sipnet_batch {
   int32_t flags[SIPNET_NFLAGS];
   int32_t n_sites = 0, n_members = 0, precision = 0, device = 0;
@@ -43,8 +64,7 @@ struct sipnet_batch {
   bool genericExponents = false;  // some member has dVpdExp != 2 or soilRespMoistEffect != 1
 
   // host-side inputs kept so the plan can be rebuilt in any call order
-  std::vector<std::vector<double>> clim;       // per site [n_steps*NCLIM]
-  std::vector<std::vector<int32_t>> year, day;
+  std::vector<SiteClim> sc;                    // per site: climate [n_steps][NCLIM], year, day (pinned)
   std::vector<std::vector<sipnet_event>> events;
   std::vector<SitePlan> plans;
   std::vector<PlanCarry> resume;  // per site: state the plan starts from (restart)
@@ -52,6 +72,19 @@ struct sipnet_batch {
   std::vector<int32_t> siteStatus;
   bool planDirty = true;
   int32_t stepsDone = 0;       // records the carried state reflects, -1 = unknown
+  // device-built site plans (plan_device.h): which sites, the kernels' arguments (scratch carved out of one block)
+  std::vector<uint8_t> devSite;
+  int32_t nDevSites = 0;
+  DevPlanArgs devPlan{};
+  unsigned char* d_planScratch = nullptr;
+  size_t planScratchCap = 0;
+  double* d_devLog2 = nullptr;   // [nDevSites][n_steps] inside d_planScratch
+  double* hostLog2 = nullptr;    // pinned staging of the host-computed log2(vpd)
+  size_t hostLog2Cap = 0;
+  bool devLog2Done = false;
+  int32_t devPlanMaxSteps = 0;
+  hipEvent_t evPlanDone = nullptr;   // behind the plan kernels: what the next forcing's climate copy waits for
+  bool planKernelsQueued = false;
 
   // HBM
   double* d_rawStage = nullptr;  // [rawStageCap][NPARAMS] raw rows of the set_params calls since the last launch

@@ -13,9 +13,7 @@ constexpr double kTiny = 0.000001;            // common/util.h:14
 constexpr double kMeanNppDays = 5.0;          // sipnet.c:39
 constexpr double kTillThreshold = 0.01;       // events.h:56
 constexpr double kTillDecay = 1 / 30.0;       // events.h:58
-// sipnet.c:44-49, :890-891, :968-969
-constexpr double kLambda = 2501000., kLambdaS = 2835000., kRho = 1.3, kCp = 1005.,
-                 kGamma = 66., kEStarSnow = 0.6, kSecPerDay = 86400.0;
+constexpr double kEStarSnow = 0.6;             // sipnet.c:890-891
 }  // namespace
 
 void RingSched::reset(int32_t step) {
@@ -182,10 +180,7 @@ SitePlan buildSitePlan(const int32_t* flags, int32_t n_steps, const double* clim
     n_events = 0;
   }
 
-  const double convS = (kRho * kCp) / kGamma * (1. / kLambdaS) * 1000. * 1000. *
-                       (1. / 10000) * kSecPerDay;
-  const double convE = (kRho * kCp) / kGamma * (1. / kLambda) * 1000. * 1000. *
-                       (1. / 10000) * kSecPerDay;
+  const double convS = planConvS(), convE = planConvE();
 
   RingSched ring;               // fresh: one zero entry, insStep -1
   int trackLastYear = -1;       // trackers.lastYear, sipnet.c:1412

@@ -157,6 +157,17 @@ struct PlanCarry {
   RingSched ring;
 };
 
+// CONV_S / CONV of the snow sublimation and soil evaporation numerators (sipnet.c:44-49, :890-891, :968-969), as the
+// plan folds them into its records (plan.cpp; plan_device.hip takes the same two doubles as kernel arguments)
+inline double planConvS() {
+  constexpr double kLambdaS = 2835000., kRho = 1.3, kCp = 1005., kGamma = 66., kSecPerDay = 86400.0;
+  return (kRho * kCp) / kGamma * (1. / kLambdaS) * 1000. * 1000. * (1. / 10000) * kSecPerDay;
+}
+inline double planConvE() {
+  constexpr double kLambda = 2501000., kRho = 1.3, kCp = 1005., kGamma = 66., kSecPerDay = 86400.0;
+  return (kRho * kCp) / kGamma * (1. / kLambda) * 1000. * 1000. * (1. / 10000) * kSecPerDay;
+}
+
 struct SitePlan {
   std::vector<StepRec> steps;   // only when the caller asked for them (strict-order kernel, checkpoints)
   std::vector<double> gddAfter, dTill;  // per step: trackers.gdd after it, d_till_mod during it

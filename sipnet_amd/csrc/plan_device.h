@@ -1,0 +1,90 @@
+// plan_device.h -- the site plan built ON THE DEVICE from the uploaded climate (plan_device.hip).
+//
+// plan.cpp builds the 256-byte per-step records on host threads and sends them over PCIe (143 MB at 32 sites x
+// 17 520 steps; 4.3 ms of a 20 ms hand-over of one forcing).  For a site without agronomic events and without a
+// resumed checkpoint the same records are produced here from the site's raw climate (63 MB over the wire instead):
+//   planPrepKernel    step lengths and GDD increments as compact arrays                       (one thread per step)
+//   planSeqKernel     the two parts that ARE sequential in floating point, one wavefront each per site:
+//                       - the running-mean ring's eviction schedule (runmean.c:61-116 over step lengths only): a
+//                         two-pointer walk; only the FRONT entry of the ring is ever partly evicted, so the state
+//                         is (front entry, its remaining weight) and the other entries' weights are the lengths of
+//                         their insert steps.  Inside a run of equal step lengths the walk reaches a fixed point
+//                         (same remaining weight, front advancing by one): the rest of the run is described by ONE
+//                         descriptor and filled in parallel (planRunsKernel) -- a year of half-hourly records is
+//                         ~245 sequential steps and one descriptor;
+//                       - the year-to-date GDD sum (sipnet.c:1480-1484; an fp64 add chain, restarted at each year
+//                         roll-over) and the phenology year roll-overs (sipnet.c:811-815: a prefix maximum)
+//   planRunsKernel    the steps covered by run descriptors: their eviction slots / insert steps / weights are the
+//                     template step's, shifted                                                  (one thread per step)
+//   planExpandKernel  the record itself: the member-independent sub-expressions of plan.cpp:319-327 (IEEE divisions,
+//                     no contraction), flag bits, the next step's eviction slots, the 16-step tile summaries
+//                     (cross-lane), the narrow fields of fp32-mixed batches; each record written once.
+// The records are bit-identical to buildSitePlan()'s -- except FastRec::log2vpd, which only members with dVpdExp != 2
+// read: OCML's log2 is not glibc's to the last bit, so that field is filled from a HOST-computed array when (and only
+// when) such a member exists (engine.hip, fillDeviceLog2).  tests/test_gpu_plan_device.py compares downloaded records
+// and eviction lists byte by byte.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "plan.h"
+
+namespace sipnet {
+
+// Sites whose every step is at least this long cannot overflow the 250-slot ring (249 whole entries of at least this
+// weight exceed the 5-day window); shorter steps -- the reference stops with an error at 250 entries -- take the host
+// path, which reports it.
+constexpr double kDevPlanMinLen = 0.0202;
+
+struct DevPlanSite {
+  const double* clim;     // device [n][SIPNET_NCLIM]
+  const int32_t* year;    // device [n]
+  const int32_t* day;     // device [n]
+  int32_t n;              // records of the site
+  int32_t site;           // its position in the batch (records at fast + site * nT)
+  int32_t opBase;         // its first RingOp in the flat array (room for 2 n + 8)
+  int32_t pad;
+};
+
+// what the sequential wavefronts leave per step (64 B; the ring wave writes the first three quarters, the GDD wave
+// the last)
+struct DevPlanSeq {
+  double w0, w1;
+  int32_t ins0, ins1, opFirst, nOps;
+  int32_t packed;         // slot0 | slot1 << 8 | (insSlot + 1) << 16
+  int32_t r0, r1, r2;
+  double gddAfter;
+  int32_t bitsSeq;        // 1: phenology new year (sipnet.c:811-815)
+  int32_t r3;
+};
+static_assert(sizeof(DevPlanSeq) == 64, "DevPlanSeq layout");
+
+// steps t0 + 1 .. t0 + count repeat step t0's evictions with every slot and insert step advanced by the distance
+struct DevPlanRun {
+  int32_t t0, count, nOps, pad;
+};
+constexpr int kDevPlanMinRun = 48;   // shorter runs are walked
+
+struct DevPlanArgs {
+  const DevPlanSite* sites;   // device [nDev]
+  int32_t nDev, nT;           // nT: stride of the per-step arrays (the batch's longest site)
+  FastRec* fast;              // [n_sites][nT]
+  RingOp* ringOps;
+  double* lenC;               // [nDev][nT]
+  double* gddC;               // [nDev][nT]
+  DevPlanSeq* seq;            // [nDev][nT]
+  DevPlanRun* runs;           // [nDev][runCap]
+  int32_t runCap;
+  int32_t* siteOut;           // [nDev][4]: descriptors written, ring evictions written, status (0 ok, 1 ring overflow,
+                              //            2 ring ran empty), the step it happened at
+  int32_t flagGdd, phenMode, moistHResp, narrow;
+  double convS, convE;
+};
+inline int32_t devPlanRunCap(int32_t nT) { return nT / kDevPlanMinRun + 2; }
+void launchDevicePlan(const DevPlanArgs& a, int32_t maxSteps, hipStream_t stream);
+// log2vpd of device-built records from a host-computed array ([nDev][nT], device copy)
+void launchDevicePlanLog2(const DevPlanSite* sites, int32_t nDev, int32_t nT, int32_t maxSteps, FastRec* fast, const double* log2vpd,
+                          int32_t narrow, hipStream_t stream);
+
+}  // namespace sipnet

@@ -208,8 +208,10 @@ def test_the_measured_table_is_the_one_committed_in_profiles():
 # Scratch memory (register spills) of the cooperative kernels.  Which instantiation spills a few values of its general
 # step moves with every edit (round 4: four of them, round 5: five others -- the register allocator's dice), so the rule is
 # by ROLE, not by name: the LEAN kernels SIPNET_KERNEL_AUTO can pick -- every BASELINE workload's kernel among them --
-# run out of registers and LDS alone (0 bytes); the full-state builds and the instantiations only a forced
-# SIPNET_KERNEL_COOP_HBM reaches (one chunk per workgroup with the ring in HBM) may keep up to 64 bytes per lane there.
+# run out of registers and LDS alone: NO scratch instruction in their code (a private segment of a few bytes that no
+# instruction touches -- the frame of SGPRs parked in VGPR lanes -- is tolerated; the measured kernels have none at all);
+# the full-state builds and the instantiations only a forced SIPNET_KERNEL_COOP_HBM reaches (one chunk per workgroup with
+# the ring in HBM) may keep up to 64 bytes per lane there.
 def auto_reachable_lean(t):
     if t["full"]:
         return False
@@ -218,7 +220,7 @@ def auto_reachable_lean(t):
     return True
 
 
-def test_scratch_memory_of_the_cooperative_kernels_is_pinned(tmp_path):
+def test_scratch_memory_of_the_cooperative_kernels_is_pinned(tmp_path, disassembly):
     shutil.copyfile(LIB, tmp_path / "lib.so")
     subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", "lib.so"], cwd=tmp_path, capture_output=True, timeout=300)
     scratch = {}
@@ -240,7 +242,11 @@ def test_scratch_memory_of_the_cooperative_kernels_is_pinned(tmp_path):
     assert len(product) >= 80, len(product)
     lean = {k: v for k, v in product.items() if auto_reachable_lean(instantiation(k))}
     assert len(lean) >= 36, len(lean)
-    assert not {k: v for k, v in lean.items() if v != 0}, {k: v for k, v in lean.items() if v != 0}
+    for k, v in lean.items():
+        key = k[len("void sipnet::"):k.rindex("(")] if k.startswith("void sipnet::") else k
+        ins = disassembly[[d for d in disassembly if key in d][0]]
+        touching = [op for _, op, _, _ in ins if op.startswith("scratch_") or op.startswith("buffer_")]
+        assert not touching and v <= 64, (k, v, touching[:4])
     assert max(product.values()) <= 64, {k: v for k, v in product.items() if v > 64}
     for k in MEASURED:
         assert product[k] == 0, k

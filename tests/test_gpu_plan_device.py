@@ -1,0 +1,179 @@
+"""The site plan built on the device (csrc/plan_device.h) against the host builder (csrc/plan.cpp).
+
+For a site without events / resumed checkpoint whose steps are all >= 0.0202 days the 256-byte per-step records and
+the ring's eviction list are produced by four kernels from the uploaded climate.  These tests download them and compare
+them BYTE BY BYTE with buildSitePlan()'s (sipnet_debug_plan_compare), over forcings that exercise every branch of
+the sequential parts: constant step lengths (one run descriptor), the reference's own half-daily and half-hourly
+files, random lengths, runs of random lengths, ring resets (steps of 5 days and more), several years, a year that steps
+back, sites of different lengths (partial last tiles), every phenology mode, narrow records of fp32-mixed batches.
+They also check what is left to the host (events, short steps), the run-time fill of log2(vpd), and that the step
+kernels' results do not depend on who built the plan.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import sipnet_amd as sa
+from sipnet_amd import synth
+from sipnet_amd._lib import Event, lib
+from sipnet_amd.config import param_index as pi
+from sipnet_amd.io import ClimTable
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+BASE = os.path.join(helpers.REPO, "sipnet_amd", "data", "base_forest.param")
+
+
+@pytest.fixture(scope="module")
+def base():
+    return sa.read_params(BASE, sa.flags_from())[0]
+
+
+def year_clim(n=17520, site=0):
+    return synth.convert_raw(synth.round_like_file(synth.half_hourly_year_raw(n, site=site)))
+
+
+def with_lengths(clim, lengths, years=None):
+    d = clim.data[:len(lengths)].copy()
+    d[:, 0] = lengths
+    y = clim.year[:len(lengths)].copy() if years is None else np.asarray(years, dtype=np.int32)
+    return ClimTable(d, y, clim.day[:len(lengths)].copy())
+
+
+def compare(b, site, ignore_log2=True):
+    nr, no = C.c_int64(), C.c_int64()
+    fs, fo = C.c_int32(), C.c_int32()
+    info = (C.c_int32 * 4)()
+    sa._lib.check(lib().sipnet_debug_plan_compare(b.h, site, int(ignore_log2), C.byref(nr), C.byref(no), C.byref(fs),
+                                                  C.byref(fo), info), "plan_compare")
+    return dict(records=nr.value, ops=no.value, first_step=fs.value, first_offset=fo.value, runs=info[0], n_ops=info[1],
+                status=info[2], status_at=info[3])
+
+
+def forcings():
+    rng = np.random.default_rng(20260503)
+    yc = year_clim()
+    out = {"half-hourly year": yc, "half-hourly, partial last tile": yc.slice(0, 17520 - 7), "one tile": yc.slice(0, 16), "three records": yc.slice(0, 3)}
+    for case in ("niwot", "russell_1"):
+        out[case] = helpers.load_smoke_case(case)["clim"]
+    n = 6000
+    out["random lengths"] = with_lengths(yc, rng.choice([1 / 48, 1 / 24, 0.3, 0.5, 1.0, 2.0, 3.0, 6.0], n))
+    out["uniform random lengths"] = with_lengths(yc, rng.uniform(0.0202, 1.5, n))
+    runs = np.concatenate([np.full(int(rng.integers(1, 400)), float(rng.choice([1 / 48, 1 / 24, 0.25, 1.0, 2.5, 0.1, 5.0, 7.5]))) for _ in range(60)])
+    out["runs of lengths, resets"] = with_lengths(yc, runs[:17000])
+    out["long steps"] = with_lengths(yc, np.concatenate([np.full(200, 3.0), np.full(200, 2.0), np.full(100, 4.9), np.full(300, 0.05), np.full(5, 4.0)]))
+    years = 2001 + np.arange(17520) // 3000
+    years[9000:9100] -= 2                      # a forcing whose years step back (summariseTile's maxima, the prefix maximum)
+    out["several years, one stepping back"] = with_lengths(yc, np.full(17520, 1 / 48), years)
+    return out
+
+
+FORCINGS = forcings() if torch.cuda.is_available() else {}
+
+
+@pytest.mark.parametrize("prec", [sa.F64, sa.F32_MIXED], ids=["f64", "f32mixed"])
+@pytest.mark.parametrize("flagset", ["default", "soil_phenol", "day_of_year", "no_water_hresp"])
+def test_device_built_records_are_the_host_builders_bytes(base, prec, flagset):
+    flags = {"default": sa.flags_from(), "soil_phenol": sa.flags_from(gdd=0, soilPhenol=1), "day_of_year": sa.flags_from(gdd=0),
+             "no_water_hresp": sa.flags_from(waterHResp=0)}[flagset]
+    names = list(FORCINGS)
+    b = sa.Batch(flags, len(names), 64, prec, fast_math=True if prec == sa.F64 else None)
+    for s, k in enumerate(names):
+        b.set_climate(s, FORCINGS[k])
+    b.set_params(None, base)
+    b.setup()
+    assert b.last_launch()["plan_device_sites"] == len(names)
+    for s, k in enumerate(names):
+        r = compare(b, s)
+        assert r["status"] == 0 and r["records"] == 0 and r["ops"] == 0, (k, r)
+    r = compare(b, names.index("half-hourly year"))
+    assert r["runs"] == 1, r                # ~245 walked steps and one descriptor
+    assert compare(b, names.index("niwot"))["runs"] == 0
+    b.close()
+
+
+def test_log2_vpd_is_filled_from_the_hosts_values_when_a_member_reads_it(base):
+    clims = [FORCINGS["half-hourly year"], FORCINGS["niwot"]]
+    odd = np.tile(base, (64, 1))
+    odd[5, pi("dVpdExp")] = 2.5
+    # (a) such a member is known when the plan is built, (b) it appears afterwards: filled before the next launch
+    for late in (False, True):
+        b = sa.Batch(sa.flags_from(), 2, 64, sa.F64, fast_math=True)
+        for s, c in enumerate(clims):
+            b.set_climate(s, c)
+        b.set_params(None, base if late else odd)
+        b.setup()
+        if late:
+            assert compare(b, 0, ignore_log2=False)["records"] > 0      # not filled: nobody reads it
+            b.set_params(None, odd)
+            b.run(0, 4)
+        for s in range(2):
+            r = compare(b, s, ignore_log2=False)
+            assert r["records"] == 0 and r["ops"] == 0, (late, s, r)
+        b.close()
+
+
+@pytest.mark.parametrize("prec", [sa.F64, sa.F32_MIXED], ids=["f64", "f32mixed"])
+def test_results_do_not_depend_on_who_built_the_plan(base, prec):
+    clims = [FORCINGS["half-hourly year"].slice(0, 3000), FORCINGS["niwot"], FORCINGS["runs of lengths, resets"].slice(0, 2500)]
+    members = synth.perturbed_params(base, 128, seed=77)
+    members[3, pi("dVpdExp")] = 1.7
+    planes = {}
+    for opt in (0, sa.KOPT_HOST_PLAN):
+        b = sa.Batch(sa.flags_from(), len(clims), 128, prec, fast_math=True if prec == sa.F64 else None, kernel_options=opt)
+        for s, c in enumerate(clims):
+            b.set_climate(s, c)
+            b.set_params(s, members)
+        b.setup()
+        assert b.last_launch()["plan_device_sites"] == (0 if opt else len(clims))
+        out, _ = b.run()
+        # (rows past a shorter site's last record are not written)
+        planes[opt] = [out[:, :c.n_steps, s * 128:(s + 1) * 128].clone() for s, c in enumerate(clims)]
+        series = [b.site_series(s) for s in range(len(clims))]
+        planes[(opt, "series")] = series
+        planes[(opt, "state")] = b.get_state().copy()
+        b.close()
+    for x, y in zip(planes[0], planes[sa.KOPT_HOST_PLAN]):
+        assert torch.equal(x.contiguous().view(torch.uint8), y.contiguous().view(torch.uint8))   # (bit patterns: NaNs included)
+    assert np.array_equal(planes[(0, "state")], planes[(sa.KOPT_HOST_PLAN, "state")], equal_nan=True)
+    for (g0, d0), (g1, d1) in zip(planes[(0, "series")], planes[(sa.KOPT_HOST_PLAN, "series")]):
+        assert np.array_equal(g0, g1) and np.array_equal(d0, d1)
+
+
+def test_sites_the_host_keeps(base):
+    yc = FORCINGS["half-hourly year"].slice(0, 2000)
+    short = with_lengths(yc, np.full(2000, 0.0201))                # below the bound that rules a ring overflow out: the host's
+    ev = Event(type=2, year=int(yc.year[10]), day=int(yc.day[10]), pad=0, p=(C.c_double * 4)(1.0, 0.0, 0.0, 0.0))   # SIPNET_EV_IRRIG
+    for flags, want in ((sa.flags_from(events=1), 1), (sa.flags_from(events=0), 2)):   # (events switched off: the list is ignored)
+        b = sa.Batch(flags, 3, 64, sa.F64, fast_math=True)
+        b.set_climate(0, yc)
+        b.set_climate(1, short)
+        b.set_climate(2, yc)
+        b.set_events(2, [ev])
+        b.set_params(None, base)
+        b.setup()
+        assert b.last_launch()["plan_device_sites"] == want
+        assert compare(b, 0)["records"] == 0
+        b.run(0, 100)
+        b.close()
+
+
+def test_forcings_back_to_back_on_one_batch(base):
+    """the second forcing's climate copy and plan kernels behind the first's launches; buffers reused and regrown"""
+    b = sa.Batch(sa.flags_from(), 2, 64, sa.F64, fast_math=True)
+    b.set_params(None, base)
+    seq = [(FORCINGS["half-hourly year"].slice(0, 4000), FORCINGS["niwot"]),
+           (FORCINGS["random lengths"], FORCINGS["half-hourly year"].slice(100, 3000)),
+           (FORCINGS["half-hourly year"], FORCINGS["runs of lengths, resets"])]
+    for a, c in seq:
+        b.set_climate(0, a)
+        b.set_climate(1, c)
+        b.setup()
+        b.run(0, min(a.n_steps, c.n_steps, 500))
+        for s in range(2):
+            r = compare(b, s)
+            assert r["status"] == 0 and r["records"] == 0 and r["ops"] == 0, r
+    b.close()
