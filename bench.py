@@ -675,8 +675,7 @@ def main():
                 """one forcing + ensemble handed over from host memory: climate of every site, ONE parameter upload
                 for all sites (SIPNET_ALL_SITES), plan build + upload + setupModel(), the step kernel with the ensemble
                 statistics from the same launch, the statistics block into pinned host memory (asynchronous)"""
-                for s_ in range(S):
-                    bb.set_climate(s_, clims[s_])
+                bb.set_climates(clims)          # (one call: the copies into the pinned blocks run on the plan threads)
                 bb.set_params(None, members)
                 bb.setup()
                 bb.run_stats(0, T, planes=pl, stats=st)
@@ -722,8 +721,8 @@ def main():
                           "bytes_up": int(members.nbytes + S * (clims[0].data.nbytes + clims[0].year.nbytes + clims[0].day.nbytes)),
                           "bytes_down": int(host_stats.numel() * 8),
                           "plan_device_sites": int(b.last_launch()["plan_device_sites"]),   # sites whose plan the device built (plan_device.h)
-                          "includes": "climate of every site + raw parameters (one upload for all sites) from host memory, "
-                                      "site-plan build + upload, setupModel(), the step kernel with the ensemble statistics from "
+                          "includes": "climate of every site (one call) + raw parameters (one upload for all sites) from host memory, "
+                                      "the site plans (built on the device from the climate where eligible, else host-built + uploaded), setupModel(), the step kernel with the ensemble statistics from "
                                       "the same launch (sipnet_batch_run_stats), the statistics block into pinned host memory; "
                                       "ms: one forcing, nothing overlapped (median of 3 after one warm-up); pipelined_ms: per "
                                       "forcing with two batches in flight (the host side of forcing k + 1 under the kernel of "

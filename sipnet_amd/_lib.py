@@ -34,6 +34,7 @@ KOPT_ONE_WAVE_PER_SIMD, KOPT_RUNTIME_FLAGS, KOPT_FULL_STATE, KOPT_NO_REGULAR_TIL
 KOPT_STATS_IN_KERNEL = 16
 KOPT_BOUNDED_WAITS = 32
 KOPT_WAIT_SELFTEST = 64
+KOPT_DEVICE_PLAN = 256   # device plan for every site that can have one, whatever its step lengths (tests)
 KOPT_HOST_PLAN = 128     # every site plan on host threads (default: eligible sites on the device, csrc/plan_device.h)
 SHARD_MEMBERS, SHARD_SITES = 0, 1
 ALL_SITES = -1
@@ -196,6 +197,7 @@ SIGNATURES = {
     "sipnet_dev_to_host": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "sipnet_dev_to_host_2d": (C.c_int, [_P, C.c_size_t, _P, C.c_size_t, C.c_size_t, C.c_size_t, _P]),
     "sipnet_dev_to_dev_2d": (C.c_int, [_P, C.c_size_t, _P, C.c_size_t, C.c_size_t, C.c_size_t, _P]),
+    "sipnet_batch_set_climate_sites": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P]),
     "sipnet_debug_plan_compare": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
     "sipnet_stream_sync": (C.c_int, [_P]),
     "sipnet_stream_create": (_P, [C.c_int32]),

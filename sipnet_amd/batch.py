@@ -96,6 +96,16 @@ class Batch:
               "set_climate")
         self.n_steps = int(self.L.sipnet_batch_nsteps(self.h))     # the longest site's (sites may differ in length)
 
+    def set_climates(self, clims, first_site=0):
+        """sipnet_batch_set_climate_sites: the forcings of sites first_site.. in one call (copied on the plan threads)"""
+        n = len(clims)
+        ns = (C.c_int32 * n)(*[c.n_steps for c in clims])
+        cp = (C.c_void_p * n)(*[c.data.ctypes.data for c in clims])
+        yp = (C.c_void_p * n)(*[c.year.ctypes.data for c in clims])
+        dp = (C.c_void_p * n)(*[c.day.ctypes.data for c in clims])
+        check(self.L.sipnet_batch_set_climate_sites(self.h, first_site, n, ns, cp, yp, dp), "set_climate_sites")
+        self.n_steps = int(self.L.sipnet_batch_nsteps(self.h))
+
     def site_n_steps(self, site):
         """the number of records of this site's forcing (self.n_steps is the longest site's)"""
         return int(self.L.sipnet_batch_site_nsteps(self.h, site))

@@ -81,6 +81,8 @@ struct sipnet_batch {
   double* d_devLog2 = nullptr;   // [nDevSites][n_steps] inside d_planScratch
   double* hostLog2 = nullptr;    // pinned staging of the host-computed log2(vpd)
   size_t hostLog2Cap = 0;
+  double* hostGdd = nullptr;     // pinned [n_sites][n_steps]: trackers.gdd after every record, the plan threads' chain (engine.hip deviceEligible)
+  size_t hostGddCap = 0;
   bool devLog2Done = false;
   int32_t devPlanMaxSteps = 0;
   hipEvent_t evPlanDone = nullptr;   // behind the plan kernels: what the next forcing's climate copy waits for

@@ -4,6 +4,9 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -48,26 +51,98 @@ static int planThreadsFor(int nS) {
   if (n > 16) n = 16;
   return n > nS ? nS : n;
 }
+// The plan threads live as long as the process (a pool: waking a parked thread costs ~10 us, starting one ~30 -- at 15
+// threads per hand-over of a forcing that was 0.4 ms of every setup).  One job at a time: two batches setting up from two
+// host threads (a node's shards) take turns, each with all the threads.
+class PlanPool {
+ public:
+  static PlanPool& get() {
+    static PlanPool p;
+    return p;
+  }
+  // f(i) for every i in [0, n), on up to nThreads threads (the caller's included); returns when all are done
+  void run(int n, int nThreads, const std::function<void(int)>& f) {
+    if (nThreads > n) nThreads = n;
+    if (nThreads <= 1) {
+      for (int i = 0; i < n; i++) f(i);
+      return;
+    }
+    std::lock_guard<std::mutex> oneJob(jobMu);
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      while ((int)workers.size() < nThreads - 1) {
+        const int k = (int)workers.size();
+        workers.emplace_back([this, k] { loop(k); });
+      }
+      job = &f;
+      nItems = n;
+      next.store(0);
+      wanted = nThreads - 1;
+      active = wanted;
+      gen++;
+    }
+    cvWork.notify_all();
+    drain(f);
+    std::unique_lock<std::mutex> lk(mu);
+    cvDone.wait(lk, [&] { return active == 0; });
+    job = nullptr;
+  }
+  ~PlanPool() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      quit = true;
+    }
+    cvWork.notify_all();
+    for (auto& t : workers) t.join();
+  }
+
+ private:
+  void drain(const std::function<void(int)>& f) {
+    for (int i = next.fetch_add(1); i < nItems; i = next.fetch_add(1)) f(i);
+  }
+  void loop(int k) {
+    uint64_t seen = 0;
+    for (;;) {
+      const std::function<void(int)>* f = nullptr;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cvWork.wait(lk, [&] { return quit || gen != seen; });
+        if (quit) return;
+        seen = gen;
+        if (k < wanted) f = job;
+      }
+      if (!f) continue;
+      drain(*f);
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        if (--active == 0) cvDone.notify_all();
+      }
+    }
+  }
+  std::mutex jobMu, mu;
+  std::condition_variable cvWork, cvDone;
+  std::vector<std::thread> workers;
+  const std::function<void(int)>* job = nullptr;
+  std::atomic<int> next{0};
+  int nItems = 0, wanted = 0, active = 0;
+  uint64_t gen = 0;
+  bool quit = false;
+};
+
 // (a worker that fails -- f returns false, or throws: std::bad_alloc on a huge forcing must not reach
 // std::terminate in the caller's process -- stops the others at their next site; *failed says so)
 template <class F>
 static void forEachSite(int nS, int nThreads, std::atomic<bool>* failed, F f) {
-  std::atomic<int> next{0};
-  auto work = [&]() {
-    for (int s = next.fetch_add(1); s < nS && !failed->load(); s = next.fetch_add(1)) {
-      bool ok = false;
-      try {
-        ok = f(s);
-      } catch (...) {
-        ok = false;
-      }
-      if (!ok) failed->store(true);
+  PlanPool::get().run(nS, nThreads, [&](int s) {
+    if (failed->load()) return;
+    bool ok = false;
+    try {
+      ok = f(s);
+    } catch (...) {
+      ok = false;
     }
-  };
-  std::vector<std::thread> pool;
-  for (int i = 1; i < nThreads; i++) pool.emplace_back(work);
-  work();
-  for (auto& th : pool) th.join();
+    if (!ok) failed->store(true);
+  });
 }
 
 // flat record buffers are written by the worker threads (first touch in parallel), so they are
@@ -146,15 +221,52 @@ static int sendClimate(sipnet_batch* b, int32_t site) {
   return SIPNET_OK;
 }
 // may this site's records be built on the device?  No events, no resumed checkpoint, every step long enough that the ring
-// cannot overflow (and positive: the host path words the reference's error)
-static bool deviceEligible(const sipnet_batch* b, int32_t s) {
+// cannot overflow (and positive: the host path words the reference's error) -- and a forcing whose step lengths come in long
+// runs: the ring's schedule is walked by ONE lane outside such runs (plan_device.h), ~0.5 us a step (measured:
+// profiles/r05_plan_device.txt; a host core does a step in 0.07 us), so a half-daily forcing like niwot's stays with the host
+static bool deviceEligible(const sipnet_batch* b, int32_t s, double* gddAfter) {
   if (b->resume[s].set) return false;
   if (b->flags[SIPNET_F_EVENTS] && !b->events[s].empty()) return false;
   const SiteClim& c = b->sc[s];
   const double* r = c.clim();
   bool ok = true;
-  for (int32_t t = 0; t < c.n; t++) ok &= r[(size_t)SIPNET_NCLIM * t] >= kDevPlanMinLen;   // (false for a NaN)
-  return ok;
+  // steps the lane walks: all of a short run; of a long one, those until the entries older than the run have left the
+  // 5-day window and the walk has reached its fixed point
+  int64_t walked = 0;
+  int32_t runLen = 0;
+  double runL = 0.0;
+  auto closeRun = [&]() {
+    const int64_t head = (int64_t)(5.0 / runL) + 6;
+    walked += (runLen >= kDevPlanMinRun + head) ? head : runLen;
+  };
+  // ... and in the same pass trackers.gdd after every record (sipnet.c:1421-1431, :1480-1484: from zero at each year
+  // roll-over), the one add chain of the plan a core runs 8 x faster than a lane: sent along, 8 bytes a step
+  const bool chain = gddAfter && b->flags[SIPNET_F_GDD];
+  const int32_t* year = c.year();
+  double acc = 0.0;
+  int32_t lastYear = -1;   // trackers.lastYear (sipnet.c:1412)
+  for (int32_t t = 0; t < c.n; t++) {
+    const double L = r[(size_t)SIPNET_NCLIM * t];
+    ok &= L >= kDevPlanMinLen;   // (false for a NaN)
+    if (chain) {
+      if (year[t] != lastYear) {
+        acc = 0.0;
+        lastYear = year[t];
+      }
+      acc += r[(size_t)SIPNET_NCLIM * t + 9];
+      gddAfter[t] = acc;
+    }
+    if (t > 0 && L == runL) {
+      runLen++;
+    } else {
+      if (t > 0 && ok) closeRun();
+      runL = L;
+      runLen = 1;
+    }
+  }
+  if (!ok) return false;
+  if (c.n > 0) closeRun();
+  return walked <= kDevPlanMaxWalked || (b->kernelOptions & SIPNET_KOPT_DEVICE_PLAN);
 }
 
 static int buildAndUpload(sipnet_batch* b, bool fastType, bool first, hipStream_t stream) {
@@ -293,12 +405,12 @@ static int fillDeviceLog2(sipnet_batch* b, hipStream_t stream) {
 static int buildOnDevice(sipnet_batch* b, const std::vector<int32_t>& bases, hipStream_t stream) {
   const int nS = b->n_sites, nT = b->n_steps, nDev = b->nDevSites;
   auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
-  const int32_t runCap = devPlanRunCap(nT);
+  const int32_t runCap = devPlanRunCap(nT), nBlk = (nT + 255) / 256;
   const size_t perStep = (size_t)nDev * nT;
   const size_t offSites = 0, offLen = offSites + align(nDev * sizeof(DevPlanSite)), offGdd = offLen + align(perStep * sizeof(double)),
                offSeq = offGdd + align(perStep * sizeof(double)), offRuns = offSeq + align(perStep * sizeof(DevPlanSeq)),
-               offOut = offRuns + align((size_t)nDev * runCap * sizeof(DevPlanRun)), offLog2 = offOut + align((size_t)nDev * 4 * sizeof(int32_t)),
-               total = offLog2 + align(perStep * sizeof(double));
+               offOut = offRuns + align((size_t)nDev * runCap * sizeof(DevPlanRun)), offLog2 = offOut + align((size_t)nDev * 8 * sizeof(int32_t)),
+               offBlk = offLog2 + align(perStep * sizeof(double)), total = offBlk + align((size_t)nDev * nBlk * 2 * sizeof(int32_t));
   if (total > b->planScratchCap) {
     if (b->planKernelsQueued) HIP_TRY(hipEventSynchronize(b->evPlanDone));
     if (b->d_planScratch) HIP_TRY(hipFree(b->d_planScratch));
@@ -310,6 +422,8 @@ static int buildOnDevice(sipnet_batch* b, const std::vector<int32_t>& bases, hip
   // the site table (pinned staging: the small-array block is free again only after its copies, so a block of its own)
   std::vector<DevPlanSite> tab(nDev);
   int32_t maxSteps = 0;
+  // (the scratch block is rewritten: behind the previous forcing's plan kernels)
+  if (b->planKernelsQueued) HIP_TRY(hipStreamWaitEvent(b->upStream, b->evPlanDone, 0));
   for (int s = 0, d = 0; s < nS; s++) {
     if (!b->devSite[s]) continue;
     SiteClim& c = b->sc[s];
@@ -317,6 +431,9 @@ static int buildOnDevice(sipnet_batch* b, const std::vector<int32_t>& bases, hip
       int rc = sendClimate(b, s);
       if (rc) return rc;
     }
+    if (b->flags[SIPNET_F_GDD])   // the host's GDD chain of this site (uploadPlan)
+      HIP_TRY(hipMemcpyAsync(b->d_planScratch + offGdd + (size_t)d * nT * sizeof(double), b->hostGdd + (size_t)s * nT,
+                             (size_t)c.n * sizeof(double), hipMemcpyHostToDevice, b->upStream));
     DevPlanSite& e = tab[d++];
     e.clim = c.devClim();
     e.year = c.devYear();
@@ -338,10 +455,12 @@ static int buildOnDevice(sipnet_batch* b, const std::vector<int32_t>& bases, hip
   a.fast = b->d_fast;
   a.ringOps = b->d_ringOps;
   a.lenC = (double*)(b->d_planScratch + offLen);
-  a.gddC = (double*)(b->d_planScratch + offGdd);
+  a.gddAfter = (const double*)(b->d_planScratch + offGdd);
   a.seq = (DevPlanSeq*)(b->d_planScratch + offSeq);
   a.runs = (DevPlanRun*)(b->d_planScratch + offRuns);
   a.runCap = runCap;
+  a.blockInfo = (int32_t*)(b->d_planScratch + offBlk);
+  a.nBlk = nBlk;
   a.siteOut = (int32_t*)(b->d_planScratch + offOut);
   a.flagGdd = b->flags[SIPNET_F_GDD] != 0;
   a.phenMode = b->flags[SIPNET_F_GDD] ? 0 : b->flags[SIPNET_F_SOIL_PHENOL] ? 1 : 2;
@@ -384,9 +503,13 @@ static int uploadPlan(sipnet_batch* b, hipStream_t stream) {
   std::fill(b->devSite.begin(), b->devSite.end(), 0);
   b->nDevSites = 0;
   if (mayBuildOnDevice(b)) {
+    int rcW = waitStaged(b);   // (the previous hand-over's copy out of the GDD staging block)
+    if (rcW) return rcW;
+    rcW = reservePinned(&b->hostGdd, &b->hostGddCap, (size_t)nS * b->n_steps);
+    if (rcW) return rcW;
     std::atomic<bool> none{false};
     forEachSite(nS, b->planThreads, &none, [&](int s) -> bool {
-      b->devSite[s] = deviceEligible(b, s) ? 1 : 0;
+      b->devSite[s] = deviceEligible(b, s, b->hostGdd + (size_t)s * b->n_steps) ? 1 : 0;
       return true;
     });
     for (int s = 0; s < nS; s++) b->nDevSites += b->devSite[s];
@@ -647,6 +770,7 @@ void sipnet_batch_destroy(sipnet_batch* b) {
   if (b->hostSteps) (void)hipHostFree(b->hostSteps);
   if (b->hostMisc) (void)hipHostFree(b->hostMisc);
   if (b->hostLog2) (void)hipHostFree(b->hostLog2);
+  if (b->hostGdd) (void)hipHostFree(b->hostGdd);
   for (SiteClim& c : b->sc) {
     if (c.host) (void)hipHostFree(c.host);
     if (c.dev) (void)hipFree(c.dev);
@@ -681,14 +805,9 @@ void sipnet_batch_destroy(sipnet_batch* b) {
   delete b;
 }
 
-int sipnet_batch_set_climate(sipnet_batch* b, int32_t site, int32_t n_steps,
-                             const double* clim, const int32_t* year, const int32_t* day) {
-  if (!b || site < 0 || site >= b->n_sites || n_steps <= 0 || !clim || !year || !day) {
-    setError("sipnet_batch_set_climate: bad argument");
-    return SIPNET_ERR_BAD_ARGUMENT;
-  }
-  int rc = useDevice(b);
-  if (rc) return rc;
+// the host side of a hand-over of one site's forcing, in three parts so that the copies of several sites can run on the
+// plan threads (sipnet_batch_set_climate_sites): room in the pinned block, the copy, the send-off
+static int climateReserve(sipnet_batch* b, int32_t site, int32_t n_steps) {
   SiteClim& c = b->sc[site];
   const size_t bytes = SiteClim::bytesFor(n_steps);
   // the previous forcing's copy out of this block must be through before the host writes it again
@@ -704,17 +823,76 @@ int sipnet_batch_set_climate(sipnet_batch* b, int32_t site, int32_t n_steps,
   }
   c.n = n_steps;
   c.onDevice = false;
-  memcpy(c.host, clim, (size_t)n_steps * SIPNET_NCLIM * sizeof(double));
-  memcpy((void*)c.year(), year, (size_t)n_steps * sizeof(int32_t));
-  memcpy((void*)c.day(), day, (size_t)n_steps * sizeof(int32_t));
+  return SIPNET_OK;
+}
+static void climateCopy(sipnet_batch* b, int32_t site, const double* clim, const int32_t* year, const int32_t* day) {
+  SiteClim& c = b->sc[site];
+  memcpy(c.host, clim, (size_t)c.n * SIPNET_NCLIM * sizeof(double));
+  memcpy((void*)c.year(), year, (size_t)c.n * sizeof(int32_t));
+  memcpy((void*)c.day(), day, (size_t)c.n * sizeof(int32_t));
+}
+static void climateDone(sipnet_batch* b) {
   b->n_steps = 0;   // the longest site set so far (sites may differ in length; the plan is rebuilt anyway)
   for (int s = 0; s < b->n_sites; s++) b->n_steps = std::max<int32_t>(b->n_steps, b->sc[s].n);
   b->planDirty = true;
-  // a batch that may build this site's plan on the device sends the forcing off now: the copy runs under the caller's
+}
+
+int sipnet_batch_set_climate(sipnet_batch* b, int32_t site, int32_t n_steps,
+                             const double* clim, const int32_t* year, const int32_t* day) {
+  if (!b || site < 0 || site >= b->n_sites || n_steps <= 0 || !clim || !year || !day) {
+    setError("sipnet_batch_set_climate: bad argument");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  int rc = useDevice(b);
+  if (rc) return rc;
+  rc = climateReserve(b, site, n_steps);
+  if (rc) return rc;
+  climateCopy(b, site, clim, year, day);
+  climateDone(b);
+  // a batch that may build the site's plan on the device sends the forcing off now: the copy runs under the caller's
   // preparation of the next site (63 MB at 32 sites x 17 520 records, against 143 MB of host-built records)
-  if (mayBuildOnDevice(b)) {
-    rc = sendClimate(b, site);
+  return mayBuildOnDevice(b) ? sendClimate(b, site) : SIPNET_OK;
+}
+
+int sipnet_batch_set_climate_sites(sipnet_batch* b, int32_t first_site, int32_t count, const int32_t* n_steps,
+                                   const double* const* clim, const int32_t* const* year, const int32_t* const* day) {
+  if (!b || first_site < 0 || count <= 0 || first_site + count > b->n_sites || !n_steps || !clim || !year || !day) {
+    setError("sipnet_batch_set_climate_sites: bad argument");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  for (int32_t k = 0; k < count; k++) {
+    if (n_steps[k] <= 0 || !clim[k] || !year[k] || !day[k]) {
+      setError("sipnet_batch_set_climate_sites: bad argument");
+      return SIPNET_ERR_BAD_ARGUMENT;
+    }
+  }
+  int rc = useDevice(b);
+  if (rc) return rc;
+  for (int32_t k = 0; k < count; k++) {
+    rc = climateReserve(b, first_site + k, n_steps[k]);
     if (rc) return rc;
+  }
+  // (the copies are memory-bound: a handful of threads saturate the socket; each sends its site off as soon as it is
+  // copied, so the DMA of the first sites runs under the copies of the others)
+  const bool send = mayBuildOnDevice(b);
+  std::atomic<int> firstErr{0};
+  std::string errText;
+  std::mutex errMu;
+  PlanPool::get().run(count, std::min(planThreadsFor(count), 8), [&](int k) {
+    climateCopy(b, first_site + k, clim[k], year[k], day[k]);
+    if (!send) return;
+    int rcS = useDevice(b);
+    if (!rcS) rcS = sendClimate(b, first_site + k);
+    int none = 0;
+    if (rcS && firstErr.compare_exchange_strong(none, rcS)) {
+      std::lock_guard<std::mutex> lk(errMu);
+      errText = sipnet_last_error();   // (the error text is per thread: carried to the caller's)
+    }
+  });
+  climateDone(b);
+  if (firstErr.load()) {
+    setError(errText);
+    return firstErr.load();
   }
   return SIPNET_OK;
 }
@@ -878,11 +1056,11 @@ int sipnet_batch_set_kernel(sipnet_batch* b, int32_t kernel, int32_t options) {
   if (!b || kernel < SIPNET_KERNEL_AUTO || kernel > SIPNET_KERNEL_COOP_NCYCLE_PAIR ||
       (options & ~(SIPNET_KOPT_ONE_WAVE_PER_SIMD | SIPNET_KOPT_RUNTIME_FLAGS | SIPNET_KOPT_FULL_STATE |
                    SIPNET_KOPT_NO_REGULAR_TILES | SIPNET_KOPT_STATS_IN_KERNEL | SIPNET_KOPT_BOUNDED_WAITS | SIPNET_KOPT_WAIT_SELFTEST |
-                   SIPNET_KOPT_HOST_PLAN))) {
+                   SIPNET_KOPT_HOST_PLAN | SIPNET_KOPT_DEVICE_PLAN))) {
     setError("sipnet_batch_set_kernel: bad argument");
     return SIPNET_ERR_BAD_ARGUMENT;
   }
-  if ((options ^ b->kernelOptions) & SIPNET_KOPT_HOST_PLAN) b->planDirty = true;   // (who builds the plan has changed)
+  if ((options ^ b->kernelOptions) & (SIPNET_KOPT_HOST_PLAN | SIPNET_KOPT_DEVICE_PLAN)) b->planDirty = true;   // (who builds the plan has changed)
   b->kernelPolicy = kernel;
   b->kernelOptions = options;
   return SIPNET_OK;
@@ -1636,8 +1814,8 @@ int sipnet_debug_plan_compare(sipnet_batch* b, int32_t site, int32_t ignore_log2
   HIP_TRY(hipMemcpy(dev.data(), b->d_fast + (size_t)site * b->n_steps, (size_t)n * sizeof(FastRec), hipMemcpyDeviceToHost));
   int d = 0;
   for (int s = 0; s < site; s++) d += b->devSite[s];
-  int32_t out4[4];
-  HIP_TRY(hipMemcpy(out4, b->devPlan.siteOut + 4 * d, sizeof out4, hipMemcpyDeviceToHost));
+  int32_t out4[8];
+  HIP_TRY(hipMemcpy(out4, b->devPlan.siteOut + 8 * d, sizeof out4, hipMemcpyDeviceToHost));
   if (device_info) memcpy(device_info, out4, sizeof out4);
   int64_t nr = 0, no = 0;
   int32_t fs = -1, fo = -1;

@@ -3,22 +3,26 @@
 // plan.cpp builds the 256-byte per-step records on host threads and sends them over PCIe (143 MB at 32 sites x
 // 17 520 steps; 4.3 ms of a 20 ms hand-over of one forcing).  For a site without agronomic events and without a
 // resumed checkpoint the same records are produced here from the site's raw climate (63 MB over the wire instead):
-//   planPrepKernel    step lengths and GDD increments as compact arrays                       (one thread per step)
-//   planSeqKernel     the two parts that ARE sequential in floating point, one wavefront each per site:
-//                       - the running-mean ring's eviction schedule (runmean.c:61-116 over step lengths only): a
-//                         two-pointer walk; only the FRONT entry of the ring is ever partly evicted, so the state
-//                         is (front entry, its remaining weight) and the other entries' weights are the lengths of
-//                         their insert steps.  Inside a run of equal step lengths the walk reaches a fixed point
-//                         (same remaining weight, front advancing by one): the rest of the run is described by ONE
-//                         descriptor and filled in parallel (planRunsKernel) -- a year of half-hourly records is
-//                         ~245 sequential steps and one descriptor;
-//                       - the year-to-date GDD sum (sipnet.c:1480-1484; an fp64 add chain, restarted at each year
-//                         roll-over) and the phenology year roll-overs (sipnet.c:811-815: a prefix maximum)
+//   planPrepKernel    step lengths as a compact array, per 256 steps "a length changes here" and the largest year
+//                                                                                               (one thread per step)
+//   planSeqKernel     the part that IS sequential in floating point, one wavefront per site: the running-mean ring's
+//                     eviction schedule (runmean.c:61-116 over step lengths only) as a two-pointer walk; only the FRONT
+//                     entry of the ring is ever partly evicted, so the state is (front entry, its remaining weight) and
+//                     the other entries' weights are the lengths of their insert steps.  Inside a run of equal step
+//                     lengths the walk reaches a fixed point (same remaining weight, front advancing by one): the rest
+//                     of the run is described by ONE descriptor and filled in parallel (planRunsKernel) -- a year of
+//                     half-hourly records is ~245 walked steps and one descriptor.  One lane walks at ~0.5 us a step (a
+//                     lone wavefront issues an instruction every ~6 cycles), a host core at 0.07: forcings without long
+//                     runs stay with the host (kDevPlanMaxWalked)
 //   planRunsKernel    the steps covered by run descriptors: their eviction slots / insert steps / weights are the
 //                     template step's, shifted                                                  (one thread per step)
 //   planExpandKernel  the record itself: the member-independent sub-expressions of plan.cpp:319-327 (IEEE divisions,
-//                     no contraction), flag bits, the next step's eviction slots, the 16-step tile summaries
+//                     no contraction), flag bits (the phenology year roll-overs of sipnet.c:811-815 are a prefix
+//                     maximum over the years), the next step's eviction slots, the 16-step tile summaries
 //                     (cross-lane), the narrow fields of fp32-mixed batches; each record written once.
+// The other sequential quantity, the year-to-date GDD sum (sipnet.c:1480-1484: an fp64 add chain restarted at each year
+// roll-over), is the HOST's: the plan threads run it in the pass over the step lengths that decides who builds the site
+// (~25 us a site; measured on the device: 200 us, the add's dependent-issue latency) and send 8 bytes a step.
 // The records are bit-identical to buildSitePlan()'s -- except FastRec::log2vpd, which only members with dVpdExp != 2
 // read: OCML's log2 is not glibc's to the last bit, so that field is filled from a HOST-computed array when (and only
 // when) such a member exists (engine.hip, fillDeviceLog2).  tests/test_gpu_plan_device.py compares downloaded records
@@ -36,6 +40,9 @@ namespace sipnet {
 // weight exceed the 5-day window); shorter steps -- the reference stops with an error at 250 entries -- take the host
 // path, which reports it.
 constexpr double kDevPlanMinLen = 0.0202;
+// ... and whose step lengths come in long runs: at most this many steps outside the part of a run that one descriptor covers
+// (engine.hip deviceEligible; a year of half-hourly records: ~245)
+constexpr int64_t kDevPlanMaxWalked = 1024;
 
 struct DevPlanSite {
   const double* clim;     // device [n][SIPNET_NCLIM]
@@ -47,16 +54,13 @@ struct DevPlanSite {
   int32_t pad;
 };
 
-// what the sequential wavefronts leave per step (64 B; the ring wave writes the first three quarters, the GDD wave
-// the last)
+// what the ring walk (or planRunsKernel) leaves per step
 struct DevPlanSeq {
   double w0, w1;
   int32_t ins0, ins1, opFirst, nOps;
   int32_t packed;         // slot0 | slot1 << 8 | (insSlot + 1) << 16
   int32_t r0, r1, r2;
-  double gddAfter;
-  int32_t bitsSeq;        // 1: phenology new year (sipnet.c:811-815)
-  int32_t r3;
+  double r3, r4;
 };
 static_assert(sizeof(DevPlanSeq) == 64, "DevPlanSeq layout");
 
@@ -72,12 +76,14 @@ struct DevPlanArgs {
   FastRec* fast;              // [n_sites][nT]
   RingOp* ringOps;
   double* lenC;               // [nDev][nT]
-  double* gddC;               // [nDev][nT]
+  const double* gddAfter;     // [nDev][nT]: trackers.gdd after each record -- the HOST's add chain (see above)
   DevPlanSeq* seq;            // [nDev][nT]
   DevPlanRun* runs;           // [nDev][runCap]
   int32_t runCap;
-  int32_t* siteOut;           // [nDev][4]: descriptors written, ring evictions written, status (0 ok, 1 ring overflow,
-                              //            2 ring ran empty), the step it happened at
+  int32_t* blockInfo;         // [nDev][nBlk][2]: per 256 steps, "a step length changes in here" and the largest year
+  int32_t nBlk;               // ceil(nT / 256)
+  int32_t* siteOut;           // [nDev][8]: descriptors written, ring evictions written, status (0 ok, 1 ring overflow,
+                              //            2 ring ran empty), the step it happened at, ticks (10 ns) of the ring walk
   int32_t flagGdd, phenMode, moistHResp, narrow;
   double convS, convE;
 };

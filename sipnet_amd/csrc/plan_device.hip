@@ -11,13 +11,32 @@ constexpr double kMeanNppDays = 5.0;  // sipnet.c:39
 constexpr double kEStarSnow = 0.6;    // sipnet.c:890-891
 constexpr int kSlots = SIPNET_RING_SLOTS;
 
+// What the ring walk and the record kernel want prepared: the step lengths as a compact array, per 256 steps "a step length
+// changes in here" (the walk finds the end of a run of equal lengths with it) and the block's largest year
+// (planExpandKernel's prefix maximum).
 __global__ __launch_bounds__(256) void planPrepKernel(DevPlanArgs a) {
-  const DevPlanSite S = a.sites[blockIdx.y];
+  const int d = blockIdx.y;
+  const DevPlanSite S = a.sites[d];
   const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= S.n) return;
-  const double* r = S.clim + (size_t)SIPNET_NCLIM * t;
-  a.lenC[(size_t)blockIdx.y * a.nT + t] = r[0];
-  a.gddC[(size_t)blockIdx.y * a.nT + t] = r[9];
+  if (blockIdx.x * 256 >= S.n) return;
+  const bool v = t < S.n;
+  const int tc = v ? t : S.n - 1;
+  const double* r = S.clim + (size_t)SIPNET_NCLIM * tc;
+  const double len = r[0];
+  if (v) a.lenC[(size_t)d * a.nT + t] = len;
+  const int yr = S.year[tc];
+  const bool chg = v && t > 0 && len != S.clim[(size_t)SIPNET_NCLIM * (t - 1)];
+  const int anyChg = __syncthreads_or(chg ? 1 : 0);
+  __shared__ int waveMax[4];
+  int x = v ? yr : INT_MIN;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) x = max(x, __shfl_xor(x, off));
+  if ((threadIdx.x & 63) == 0) waveMax[threadIdx.x >> 6] = x;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a.blockInfo[((size_t)d * a.nBlk + blockIdx.x) * 2] = anyChg;
+    a.blockInfo[((size_t)d * a.nBlk + blockIdx.x) * 2 + 1] = max(max(waveMax[0], waveMax[1]), max(waveMax[2], waveMax[3]));
+  }
 }
 
 // ---- the ring's eviction schedule ----------------------------------------------------------------------------------
@@ -118,22 +137,39 @@ __device__ void ringWalk(const DevPlanArgs& a, const DevPlanSite& S, int d) {
     }
     __syncthreads();
     if (st.ffT0 >= 0) {
-      // first step from st.t on whose length differs (all 64 lanes look, 256 steps per round)
+      // first step from st.t on whose length differs: the rest of st.t's 256-step block looked at directly, then the
+      // blocks' "a length changes in here" flags (64 blocks a round), then the first such block looked at directly
       const double L = st.ffLen;
-      int base = st.t, runEnd = -1;
-      while (runEnd < 0) {
+      const int* info = a.blockInfo + (size_t)d * a.nBlk * 2;
+      auto firstDifferent = [&](int from, int to) -> int {   // first u in [from, to) with len[u] != L, or -1; to - from <= 256
+        int found = -1;
         unsigned long long bad[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-          const int u = base + 64 * k + lane;
-          const bool differs = u >= n || len[u] != L;
-          bad[k] = __ballot(differs);
+          const int u = from + 64 * k + lane;
+          bad[k] = __ballot(u < to && len[u] != L);
         }
 #pragma unroll
         for (int k = 0; k < 4; k++)
-          if (runEnd < 0 && bad[k]) runEnd = base + 64 * k + __builtin_ctzll(bad[k]);
-        base += 256;
+          if (found < 0 && bad[k]) found = from + 64 * k + __builtin_ctzll(bad[k]);
+        return found;
+      };
+      const int nBlkSite = (n + 255) >> 8;
+      int blk = st.t >> 8;
+      int runEnd = firstDifferent(st.t, min(n, (blk + 1) << 8));
+      blk++;
+      while (runEnd < 0 && blk < nBlkSite) {
+        const int bb = blk + lane;
+        const unsigned long long m = __ballot(bb < nBlkSite && info[2 * bb] != 0);
+        if (m) {
+          blk += __builtin_ctzll(m);
+          runEnd = firstDifferent(blk << 8, min(n, (blk + 1) << 8));   // (a change AT the block's first step counts: len[u] != L there)
+          blk++;
+        } else {
+          blk += 64;
+        }
       }
+      if (runEnd < 0) runEnd = n;
       if (lane == 0) {
         const int K = runEnd - st.t;   // steps st.t .. runEnd-1 repeat the template step
         if (K >= kDevPlanMinRun) {
@@ -149,80 +185,17 @@ __device__ void ringWalk(const DevPlanArgs& a, const DevPlanSite& S, int d) {
     }
   }
   if (lane == 0) {
-    int32_t* o = a.siteOut + 4 * d;
+    int32_t* o = a.siteOut + 8 * d;
     o[0] = st.nRuns; o[1] = st.opCount; o[2] = st.status; o[3] = st.statusAt;
-  }
-}
-
-// ---- year-to-date GDD and the phenology year roll-overs -------------------------------------------------------------
-constexpr int kCh = 2048;
-__device__ void gddWalk(const DevPlanArgs& a, const DevPlanSite& S, int d) {
-  __shared__ double g[kCh];
-  __shared__ unsigned long long newYearMask[kCh / 64];
-  __shared__ unsigned char phenBit[kCh];
-  const int lane = threadIdx.x, n = S.n;
-  const double* gdd = a.gddC + (size_t)d * a.nT;
-  DevPlanSeq* seq = a.seq + (size_t)d * a.nT;
-  double acc = 0.0;                   // trackers.gdd (lane 0's copy is the one that counts)
-  int phenLast = n > 0 ? S.year[0] : 0;   // sipnet.c:1524
-  for (int c = 0; c < n; c += kCh) {
-    const int m = min(kCh, n - c);
-    for (int k0 = 0; k0 < m; k0 += 64) {
-      const int k = k0 + lane, t = c + k;
-      const bool v = k < m;
-      const int yr = v ? S.year[t] : INT_MIN;
-      const int yp = (v && t > 0) ? S.year[t - 1] : -1;   // trackers.lastYear starts at -1 (sipnet.c:1412)
-      if (v) g[k] = gdd[t];
-      const unsigned long long mask = __ballot(v && yr != yp);   // updateTrackers(), sipnet.c:1421-1431
-      if (lane == 0) newYearMask[k0 / 64] = mask;
-      // sipnet.c:811-815: year > the largest year seen before (starting from the first record's)
-      int x = yr;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const int y = __shfl_up(x, off);
-        if (lane >= off) x = max(x, y);
-      }
-      int before = __shfl_up(x, 1);
-      if (lane == 0) before = INT_MIN;
-      before = max(before, phenLast);
-      if (v) phenBit[k] = yr > before ? 1 : 0;
-      phenLast = max(phenLast, __shfl(x, 63));
-    }
-    __syncthreads();
-    if (a.flagGdd && lane == 0) {   // sipnet.c:1480-1484: trackers.gdd += gdd, from zero in a new year
-      for (int k0 = 0; k0 < m; k0 += 64) {
-        const unsigned long long mask = newYearMask[k0 / 64];
-        const int cnt = min(64, m - k0);
-        if (mask == 0 && cnt == 64) {
-#pragma unroll 16
-          for (int i = 0; i < 64; i++) {
-            acc += g[k0 + i];
-            g[k0 + i] = acc;
-          }
-        } else {
-          for (int i = 0; i < cnt; i++) {
-            if ((mask >> i) & 1) acc = 0.0;
-            acc += g[k0 + i];
-            g[k0 + i] = acc;
-          }
-        }
-      }
-    }
-    __syncthreads();
-    for (int k = lane; k < m; k += 64) {
-      DevPlanSeq* q = seq + c + k;
-      q->gddAfter = a.flagGdd ? g[k] : 0.0;
-      *(int2*)&q->bitsSeq = make_int2(phenBit[k], 0);
-    }
-    __syncthreads();
   }
 }
 
 __global__ __launch_bounds__(64) void planSeqKernel(DevPlanArgs a) {
   const int d = blockIdx.x;
   const DevPlanSite S = a.sites[d];
-  if (blockIdx.y == 0) ringWalk(a, S, d);
-  else gddWalk(a, S, d);
+  const unsigned long long c0 = wall_clock64();   // (100 MHz: how long the walk took, for the profiles)
+  ringWalk(a, S, d);
+  if (threadIdx.x == 0) a.siteOut[8 * d + 4] = (int32_t)(wall_clock64() - c0);
 }
 
 __device__ inline int wrapSlot(int s) { return s % kSlots; }
@@ -231,7 +204,7 @@ __global__ __launch_bounds__(256) void planRunsKernel(DevPlanArgs a) {
   const int d = blockIdx.y;
   const DevPlanSite S = a.sites[d];
   const int u = blockIdx.x * 256 + threadIdx.x;
-  const int nRuns = a.siteOut[4 * d];
+  const int nRuns = a.siteOut[8 * d];
   if (u >= S.n || nRuns == 0) return;
   const DevPlanRun* runs = a.runs + (size_t)d * a.runCap;
   int lo = 0, hi = nRuns;   // last descriptor with t0 < u
@@ -270,7 +243,7 @@ __global__ __launch_bounds__(256) void planExpandKernel(DevPlanArgs a) {
   const int n = S.n;
   const int u = blockIdx.x * 256 + threadIdx.x;
   const int tileBase = u & ~(kFastTile - 1);
-  if (tileBase >= n) return;           // (whole 16-lane groups leave together)
+  if (blockIdx.x * 256 >= n) return;   // (whole workgroups leave together: barriers below)
   const bool valid = u < n;
   const int uc = valid ? u : n - 1;
   const double* r = S.clim + (size_t)SIPNET_NCLIM * uc;
@@ -278,6 +251,34 @@ __global__ __launch_bounds__(256) void planExpandKernel(DevPlanArgs a) {
                wspd = r[8], gdd = r[9], tod = r[10];
   const int yr = S.year[uc], dy = S.day[uc];
   const int yrPrev = uc > 0 ? S.year[uc - 1] : -1;
+  // phenology new year (sipnet.c:811-815): this record's year exceeds the largest seen before it, starting from the first
+  // record's (sipnet.c:1524) -- the earlier blocks' maxima (planPrepKernel), the earlier wavefronts', the earlier lanes'
+  bool phenNew;
+  {
+    __shared__ int waveMax[4], prevBlocks;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int x = valid ? yr : INT_MIN;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int y = __shfl_up(x, off);
+      if (lane >= off) x = max(x, y);
+    }
+    int before = __shfl_up(x, 1);
+    if (lane == 0) before = INT_MIN;
+    if (lane == 63) waveMax[w] = x;
+    if (w == 0) {
+      const int* info = a.blockInfo + (size_t)d * a.nBlk * 2;
+      int p = S.year[0];
+      for (int bb = lane; bb < (int)blockIdx.x; bb += 64) p = max(p, info[2 * bb + 1]);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) p = max(p, __shfl_xor(p, off));
+      if (lane == 0) prevBlocks = p;
+    }
+    __syncthreads();
+    before = max(before, prevBlocks);
+    for (int k = 0; k < w; k++) before = max(before, waveMax[k]);
+    phenNew = yr > before;
+  }
   const DevPlanSeq* seq = a.seq + (size_t)d * a.nT;
   const DevPlanSeq Q = seq[uc];
   const int nOps = Q.nOps, s0 = Q.packed & 0xff, s1 = (Q.packed >> 8) & 0xff, insSlot = (Q.packed >> 16) - 1;
@@ -292,7 +293,8 @@ __global__ __launch_bounds__(256) void planExpandKernel(DevPlanArgs a) {
   const double tsoil10 = tsoil / 10.0;
   const bool tsoilSame = uc > 0 && (S.clim[(size_t)SIPNET_NCLIM * (uc - 1) + 2] / 10.0) == tsoil10;
   // year-to-date GDD pastLeafGrowth() sees (sipnet.c:706-716): this record's alone in a new year, else the sum so far
-  const double cum = newTrack ? gdd : Q.gddAfter;
+  const double gddAfter = a.flagGdd ? a.gddAfter[(size_t)d * a.nT + uc] : 0.0;   // trackers.gdd after this record (the host's chain)
+  const double cum = newTrack ? gdd : gddAfter;
 
   FastRec f;
   f.len = len;
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(256) void planExpandKernel(DevPlanArgs a) {
   f.cumGdd = a.phenMode == 0 ? cum : a.phenMode == 1 ? tsoil : dayTime;
   f.dayTime = dayTime;
   f.w0 = Q.w0;
-  const int bits = ((Q.bitsSeq & 1) ? FAST_PHEN_NEW_YEAR : 0) | (newTrack ? FAST_TRACK_NEW_YEAR : 0) | (tair > 0 ? FAST_TAIR_POS : 0) |
+  const int bits = (phenNew ? FAST_PHEN_NEW_YEAR : 0) | (newTrack ? FAST_TRACK_NEW_YEAR : 0) | (tair > 0 ? FAST_TAIR_POS : 0) |
                    (par > 0 ? FAST_PAR_POS : 0) | ((tsoil < 0 || !a.moistHResp) ? FAST_TSOIL_NEG : 0) |
                    (Q.w1 != 0.0 ? FAST_HAS_W1 : 0) | (tsoilSame ? FAST_TSOIL_SAME : 0) |
                    (nOps == 1 && insSlot >= 0 ? FAST_RING_REGULAR : 0);
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(256) void planExpandKernel(DevPlanArgs a) {
   f.w1 = Q.w1;
   f.spareD = 0.0;
   f.log2vpd = 0.0;     // filled from the host's values when a member reads it (plan_device.h)
-  f.gddAfter = Q.gddAfter;
+  f.gddAfter = gddAfter;
   f.tillAfter = 0.0;
   f.ins0 = Q.ins0;
   f.ins1 = Q.ins1;
@@ -333,7 +335,7 @@ __global__ __launch_bounds__(256) void planExpandKernel(DevPlanArgs a) {
 
   // the tile's summary (summariseTile, plan.cpp): 16 consecutive lanes
   const int lane = threadIdx.x & 63, g0 = lane & ~(kFastTile - 1), li = lane - g0;
-  const int cnt = min(kFastTile, n - tileBase);
+  const int cnt = max(1, min(kFastTile, n - tileBase));   // (lanes of tiles past the site's end compute on a clamped record and store nothing)
   const unsigned validMask = cnt == 16 ? 0xffffu : ((1u << cnt) - 1u);
   auto first = [&](auto x) { return __shfl(x, g0); };
   auto nextSlot = [](int s) { return s + 1 == kSlots ? 0 : s + 1; };
@@ -381,7 +383,7 @@ void launchDevicePlan(const DevPlanArgs& a, int32_t maxSteps, hipStream_t stream
   if (a.nDev <= 0 || maxSteps <= 0) return;
   const dim3 wide((maxSteps + 255) / 256, a.nDev);
   hipLaunchKernelGGL(planPrepKernel, wide, dim3(256), 0, stream, a);
-  hipLaunchKernelGGL(planSeqKernel, dim3(a.nDev, 2), dim3(64), 0, stream, a);
+  hipLaunchKernelGGL(planSeqKernel, dim3(a.nDev), dim3(64), 0, stream, a);
   hipLaunchKernelGGL(planRunsKernel, wide, dim3(256), 0, stream, a);
   hipLaunchKernelGGL(planExpandKernel, wide, dim3(256), 0, stream, a);
 }

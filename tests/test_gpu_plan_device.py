@@ -46,11 +46,11 @@ def with_lengths(clim, lengths, years=None):
 def compare(b, site, ignore_log2=True):
     nr, no = C.c_int64(), C.c_int64()
     fs, fo = C.c_int32(), C.c_int32()
-    info = (C.c_int32 * 4)()
+    info = (C.c_int32 * 8)()
     sa._lib.check(lib().sipnet_debug_plan_compare(b.h, site, int(ignore_log2), C.byref(nr), C.byref(no), C.byref(fs),
                                                   C.byref(fo), info), "plan_compare")
     return dict(records=nr.value, ops=no.value, first_step=fs.value, first_offset=fo.value, runs=info[0], n_ops=info[1],
-                status=info[2], status_at=info[3])
+                status=info[2], status_at=info[3], ring_walk_us=info[4] / 100.0)
 
 
 def forcings():
@@ -80,9 +80,9 @@ def test_device_built_records_are_the_host_builders_bytes(base, prec, flagset):
     flags = {"default": sa.flags_from(), "soil_phenol": sa.flags_from(gdd=0, soilPhenol=1), "day_of_year": sa.flags_from(gdd=0),
              "no_water_hresp": sa.flags_from(waterHResp=0)}[flagset]
     names = list(FORCINGS)
-    b = sa.Batch(flags, len(names), 64, prec, fast_math=True if prec == sa.F64 else None)
-    for s, k in enumerate(names):
-        b.set_climate(s, FORCINGS[k])
+    # (KOPT_DEVICE_PLAN: the irregular forcings too -- by default their ring schedules are left to the host's cores)
+    b = sa.Batch(flags, len(names), 64, prec, fast_math=True if prec == sa.F64 else None, kernel_options=sa.KOPT_DEVICE_PLAN)
+    b.set_climates([FORCINGS[k] for k in names])
     b.set_params(None, base)
     b.setup()
     assert b.last_launch()["plan_device_sites"] == len(names)
@@ -101,7 +101,7 @@ def test_log2_vpd_is_filled_from_the_hosts_values_when_a_member_reads_it(base):
     odd[5, pi("dVpdExp")] = 2.5
     # (a) such a member is known when the plan is built, (b) it appears afterwards: filled before the next launch
     for late in (False, True):
-        b = sa.Batch(sa.flags_from(), 2, 64, sa.F64, fast_math=True)
+        b = sa.Batch(sa.flags_from(), 2, 64, sa.F64, fast_math=True, kernel_options=sa.KOPT_DEVICE_PLAN)
         for s, c in enumerate(clims):
             b.set_climate(s, c)
         b.set_params(None, base if late else odd)
@@ -122,13 +122,18 @@ def test_results_do_not_depend_on_who_built_the_plan(base, prec):
     members = synth.perturbed_params(base, 128, seed=77)
     members[3, pi("dVpdExp")] = 1.7
     planes = {}
-    for opt in (0, sa.KOPT_HOST_PLAN):
+    for opt in (sa.KOPT_DEVICE_PLAN, sa.KOPT_HOST_PLAN):
         b = sa.Batch(sa.flags_from(), len(clims), 128, prec, fast_math=True if prec == sa.F64 else None, kernel_options=opt)
-        for s, c in enumerate(clims):
-            b.set_climate(s, c)
+        if opt == sa.KOPT_HOST_PLAN:
+            for s, c in enumerate(clims):
+                b.set_climate(s, c)
+        else:
+            b.set_climates(clims[1:], first_site=1)      # (the bulk hand-over, and a single one)
+            b.set_climate(0, clims[0])
+        for s in range(len(clims)):
             b.set_params(s, members)
         b.setup()
-        assert b.last_launch()["plan_device_sites"] == (0 if opt else len(clims))
+        assert b.last_launch()["plan_device_sites"] == (0 if opt == sa.KOPT_HOST_PLAN else len(clims))
         out, _ = b.run()
         # (rows past a shorter site's last record are not written)
         planes[opt] = [out[:, :c.n_steps, s * 128:(s + 1) * 128].clone() for s, c in enumerate(clims)]
@@ -136,10 +141,10 @@ def test_results_do_not_depend_on_who_built_the_plan(base, prec):
         planes[(opt, "series")] = series
         planes[(opt, "state")] = b.get_state().copy()
         b.close()
-    for x, y in zip(planes[0], planes[sa.KOPT_HOST_PLAN]):
+    for x, y in zip(planes[sa.KOPT_DEVICE_PLAN], planes[sa.KOPT_HOST_PLAN]):
         assert torch.equal(x.contiguous().view(torch.uint8), y.contiguous().view(torch.uint8))   # (bit patterns: NaNs included)
-    assert np.array_equal(planes[(0, "state")], planes[(sa.KOPT_HOST_PLAN, "state")], equal_nan=True)
-    for (g0, d0), (g1, d1) in zip(planes[(0, "series")], planes[(sa.KOPT_HOST_PLAN, "series")]):
+    assert np.array_equal(planes[(sa.KOPT_DEVICE_PLAN, "state")], planes[(sa.KOPT_HOST_PLAN, "state")], equal_nan=True)
+    for (g0, d0), (g1, d1) in zip(planes[(sa.KOPT_DEVICE_PLAN, "series")], planes[(sa.KOPT_HOST_PLAN, "series")]):
         assert np.array_equal(g0, g1) and np.array_equal(d0, d1)
 
 
@@ -161,9 +166,27 @@ def test_sites_the_host_keeps(base):
         b.close()
 
 
+def test_the_default_leaves_forcings_without_long_runs_of_equal_steps_to_the_host(base):
+    """one lane walks the ring's schedule outside runs of equal step lengths (~0.5 us a step): niwot's half-daily records
+    (no two neighbours alike) are the host's, a half-hourly year (245 walked steps) the device's"""
+    names = ["half-hourly year", "niwot", "russell_1", "uniform random lengths", "several years, one stepping back"]
+    b = sa.Batch(sa.flags_from(), len(names), 64, sa.F64, fast_math=True)
+    b.set_climates([FORCINGS[k] for k in names])
+    b.set_params(None, base)
+    b.setup()
+    assert b.last_launch()["plan_device_sites"] == 3
+    for s in (0, 2, 4):
+        assert compare(b, s)["records"] == 0
+    for s in (1, 3):
+        with pytest.raises(Exception):
+            compare(b, s)
+    b.run(0, 64)
+    b.close()
+
+
 def test_forcings_back_to_back_on_one_batch(base):
     """the second forcing's climate copy and plan kernels behind the first's launches; buffers reused and regrown"""
-    b = sa.Batch(sa.flags_from(), 2, 64, sa.F64, fast_math=True)
+    b = sa.Batch(sa.flags_from(), 2, 64, sa.F64, fast_math=True, kernel_options=sa.KOPT_DEVICE_PLAN)
     b.set_params(None, base)
     seq = [(FORCINGS["half-hourly year"].slice(0, 4000), FORCINGS["niwot"]),
            (FORCINGS["random lengths"], FORCINGS["half-hourly year"].slice(100, 3000)),

@@ -25,7 +25,7 @@ for rep in range(4):
     t = [time.perf_counter()]
     def mark():
         sync(); t.append(time.perf_counter())
-    for s in range(S): b.set_climate(s, clims[s])
+    b.set_climates(clims)
     mark()
     b.set_params(None, members)
     mark()
@@ -43,7 +43,7 @@ for rep in range(4):
 # the same hand-over without a synchronisation between the phases (what a caller does)
 for rep in range(4):
     sync(); t0 = time.perf_counter()
-    for s in range(S): b.set_climate(s, clims[s])
+    b.set_climates(clims)
     b.set_params(None, members)
     b.setup()
     t1 = time.perf_counter()
