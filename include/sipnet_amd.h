@@ -279,15 +279,18 @@ enum sipnet_kernel_option {
                                         campaigns and tests, never chosen by SIPNET_KERNEL_AUTO */
   SIPNET_KOPT_WAIT_SELFTEST = 64,    /* with SIPNET_KOPT_BOUNDED_WAITS only: the light wavefront stops posting after 100 steps --
                                         the test of the error path itself (the launch must end with SIPNET_ERR_INTERNAL) */
-  SIPNET_KOPT_HOST_PLAN = 128,       /* build every site's per-step records on host threads (plan.cpp) -- without it the
-                                        records of a site without agronomic events and without a resumed checkpoint, whose
-                                        steps are all at least 0.0202 days long, are built on the DEVICE from the site's
-                                        climate (csrc/plan_device.h: 63 MB instead of 143 MB over PCIe at 32 sites x 17 520
-                                        records, no host threads); the records are the same bytes either way */
-  SIPNET_KOPT_DEVICE_PLAN = 256,     /* build a site's records on the device whenever it CAN (no events, no resumed checkpoint,
-                                        steps >= 0.0202 d), also when its step lengths do not come in long runs -- the default
-                                        leaves such a forcing (half-daily niwot) to the host, whose cores walk the ring's
-                                        schedule ~8 x faster than the one lane that has to on the device (tests use this) */
+  SIPNET_KOPT_HOST_PLAN = 128,       /* build every site's per-step records on host threads (plan.cpp).  Without it a site
+                                        whose steps are all at least 0.0202 days long and come in long runs of equal length
+                                        has them built on the DEVICE from its climate (csrc/plan_device.h: 63 MB instead of
+                                        143 MB over PCIe at 32 sites x 17 520 records; fresh or resumed, with or without
+                                        events) -- when the batch is idle at the hand-over; while its previous launch still
+                                        runs (a caller pipelining forcings) the host's idle cores build them.  The records are
+                                        the same bytes either way */
+  SIPNET_KOPT_DEVICE_PLAN = 256,     /* build a site's records on the device whenever it CAN (steps >= 0.0202 d, no site-fatal
+                                        condition): also while the batch is busy, also when its step lengths do not come in
+                                        long runs -- the default leaves such a forcing (half-daily niwot) to the host, whose
+                                        cores walk the ring's schedule ~8 x faster than the one lane that has to on the
+                                        device (tests use this) */
   SIPNET_KOPT_FULL_STATE = 4         /* throughput kernels: advance EVERY accumulator of the restart
                                         schema (trackers.tot*, trackers.yearly*); without it only
                                         totNee / totGpp advance on the throughput path.  Implied by a

@@ -83,6 +83,9 @@ struct sipnet_batch {
   size_t hostLog2Cap = 0;
   double* hostGdd = nullptr;     // pinned [n_sites][n_steps]: trackers.gdd after every record, the plan threads' chain (engine.hip deviceEligible)
   size_t hostGddCap = 0;
+  unsigned char* hostEv = nullptr;   // pinned, only while a site has events: per site evFirst[n_steps] evCount[n_steps] (int32), dTill[n_steps] tillAfter[n_steps]
+  size_t hostEvCap = 0;
+  std::vector<PlanLight> planLight;  // per site: the plan threads' pass before the records are built (engine.hip devicePrepass)
   bool devLog2Done = false;
   int32_t devPlanMaxSteps = 0;
   hipEvent_t evPlanDone = nullptr;   // behind the plan kernels: what the next forcing's climate copy waits for

@@ -195,8 +195,17 @@ static int joinUploads(sipnet_batch* b, hipStream_t stream) {
 }
 
 // ---- device-built site plans (plan_device.h) ---------------------------------------------------------------------------
+// Who builds the plans of a hand-over?  The device, unless told otherwise (SIPNET_KOPT_HOST_PLAN) -- or unless this batch's
+// own last launch is still running: a caller who hands the next forcing over while the previous one computes (one batch
+// back to back, or two batches taking turns: bench.py's pipelined leg) has made the GPU the bottleneck, its host cores are
+// idle, and the four plan kernels would only queue behind the step kernel (measured: c2x16 pipelined 9.6 -> 10.1 ms per
+// forcing with them, against 14.1 -> 10.7 ms for a forcing handed to an idle device).  SIPNET_KOPT_DEVICE_PLAN: always.
 static bool mayBuildOnDevice(const sipnet_batch* b) {
-  return wantsFastRecs(b) && !(b->kernelOptions & SIPNET_KOPT_HOST_PLAN);
+  if (!wantsFastRecs(b) || (b->kernelOptions & SIPNET_KOPT_HOST_PLAN)) return false;
+  if (b->kernelOptions & SIPNET_KOPT_DEVICE_PLAN) return true;
+  const bool running = b->busy && hipEventQuery(b->evBusy) == hipErrorNotReady;
+  (void)hipGetLastError();
+  return !running;
 }
 // the site's forcing block -> its device block, asynchronously on the copy stream (behind the plan kernels that may still
 // be reading the previous forcing there)
@@ -220,53 +229,29 @@ static int sendClimate(sipnet_batch* b, int32_t site) {
   c.onDevice = true;
   return SIPNET_OK;
 }
-// may this site's records be built on the device?  No events, no resumed checkpoint, every step long enough that the ring
-// cannot overflow (and positive: the host path words the reference's error) -- and a forcing whose step lengths come in long
-// runs: the ring's schedule is walked by ONE lane outside such runs (plan_device.h), ~0.5 us a step (measured:
-// profiles/r05_plan_device.txt; a host core does a step in 0.07 us), so a half-daily forcing like niwot's stays with the host
-static bool deviceEligible(const sipnet_batch* b, int32_t s, double* gddAfter) {
-  if (b->resume[s].set) return false;
-  if (b->flags[SIPNET_F_EVENTS] && !b->events[s].empty()) return false;
+// The plan threads' pass over a site before anybody builds its records (plan.cpp buildSitePlanLight): the GDD chain, the
+// events per record and the tillage series, the site-fatal conditions -- and may the DEVICE build the records?  Every step
+// (and every whole entry of a resumed ring) at least kDevPlanMinLen long, so that the ring cannot overflow; no site-fatal
+// condition (the host path words the reference's message); step lengths in long runs: one lane walks the ring's schedule
+// outside such runs at ~0.5 us a step (profiles/r05_plan_device.txt; a host core builds a whole step in 0.07 us), so a
+// half-daily forcing like niwot's stays with the host unless SIPNET_KOPT_DEVICE_PLAN asks.
+static bool devicePrepass(sipnet_batch* b, int32_t s, PlanLight* out) {
   const SiteClim& c = b->sc[s];
-  const double* r = c.clim();
-  bool ok = true;
-  // steps the lane walks: all of a short run; of a long one, those until the entries older than the run have left the
-  // 5-day window and the walk has reached its fixed point
-  int64_t walked = 0;
-  int32_t runLen = 0;
-  double runL = 0.0;
-  auto closeRun = [&]() {
-    const int64_t head = (int64_t)(5.0 / runL) + 6;
-    walked += (runLen >= kDevPlanMinRun + head) ? head : runLen;
-  };
-  // ... and in the same pass trackers.gdd after every record (sipnet.c:1421-1431, :1480-1484: from zero at each year
-  // roll-over), the one add chain of the plan a core runs 8 x faster than a lane: sent along, 8 bytes a step
-  const bool chain = gddAfter && b->flags[SIPNET_F_GDD];
-  const int32_t* year = c.year();
-  double acc = 0.0;
-  int32_t lastYear = -1;   // trackers.lastYear (sipnet.c:1412)
-  for (int32_t t = 0; t < c.n; t++) {
-    const double L = r[(size_t)SIPNET_NCLIM * t];
-    ok &= L >= kDevPlanMinLen;   // (false for a NaN)
-    if (chain) {
-      if (year[t] != lastYear) {
-        acc = 0.0;
-        lastYear = year[t];
-      }
-      acc += r[(size_t)SIPNET_NCLIM * t + 9];
-      gddAfter[t] = acc;
-    }
-    if (t > 0 && L == runL) {
-      runLen++;
-    } else {
-      if (t > 0 && ok) closeRun();
-      runL = L;
-      runLen = 1;
-    }
+  const size_t nT = (size_t)b->n_steps;
+  const bool ev = b->hostEv != nullptr;
+  unsigned char* e = ev ? b->hostEv + (size_t)s * nT * 24 : nullptr;
+  const PlanCarry* init = b->resume[s].set ? &b->resume[s] : nullptr;
+  *out = buildSitePlanLight(b->flags, c.n, c.clim(), c.year(), c.day(), (int32_t)b->events[s].size(), b->events[s].data(), init,
+                            kDevPlanMinLen, kDevPlanMinRun, b->hostGdd + (size_t)s * nT, (int32_t*)e, (int32_t*)(e + 4 * nT),
+                            (double*)(e + 8 * nT), (double*)(e + 16 * nT));
+  if (out->status != SIPNET_OK || !out->lengthsOk) return false;
+  if (init) {   // the ring a checkpoint hands over: its whole entries (all but the front one) count like steps
+    const RingSched& r = init->ring;
+    for (int i = (r.start + 1) % SIPNET_RING_SLOTS; i != (r.last + 1) % SIPNET_RING_SLOTS && r.start != r.last; i = (i + 1) % SIPNET_RING_SLOTS)
+      if (!(r.w[i] >= kDevPlanMinLen)) return false;
+    if (!(r.w[r.start] > 0)) return false;
   }
-  if (!ok) return false;
-  if (c.n > 0) closeRun();
-  return walked <= kDevPlanMaxWalked || (b->kernelOptions & SIPNET_KOPT_DEVICE_PLAN);
+  return out->walked <= kDevPlanMaxWalked || (b->kernelOptions & SIPNET_KOPT_DEVICE_PLAN);
 }
 
 static int buildAndUpload(sipnet_batch* b, bool fastType, bool first, hipStream_t stream) {
@@ -300,12 +285,13 @@ static int buildAndUpload(sipnet_batch* b, bool fastType, bool first, hipStream_
   std::atomic<bool> failed{false};
   forEachSite(nS, nThreads, &failed, [&](int s) -> bool {
     const int nTs = b->siteSteps[s];            // this site's own length (its tail of the stride is never read)
-    if (devPass && b->devSite[s]) {             // what the host still needs of such a site: setupModel()'s inputs
-      const SiteClim& c = b->sc[s];
+    if (devPass && b->devSite[s]) {             // what the host still needs of such a site: setupModel()'s inputs, its events
+      PlanLight& l = b->planLight[s];
       SitePlan p;
-      p.startCumGdd = c.clim()[9];
-      p.startTsoil = c.clim()[2];
-      p.startDayTime = (double)c.day()[0] + c.clim()[10] / 24.0;
+      p.startCumGdd = l.startCumGdd;
+      p.startTsoil = l.startTsoil;
+      p.startDayTime = l.startDayTime;
+      p.events = std::move(l.events);
       b->plans[s] = std::move(p);
       return true;
     }
@@ -410,7 +396,11 @@ static int buildOnDevice(sipnet_batch* b, const std::vector<int32_t>& bases, hip
   const size_t offSites = 0, offLen = offSites + align(nDev * sizeof(DevPlanSite)), offGdd = offLen + align(perStep * sizeof(double)),
                offSeq = offGdd + align(perStep * sizeof(double)), offRuns = offSeq + align(perStep * sizeof(DevPlanSeq)),
                offOut = offRuns + align((size_t)nDev * runCap * sizeof(DevPlanRun)), offLog2 = offOut + align((size_t)nDev * 8 * sizeof(int32_t)),
-               offBlk = offLog2 + align(perStep * sizeof(double)), total = offBlk + align((size_t)nDev * nBlk * 2 * sizeof(int32_t));
+               offBlk = offLog2 + align(perStep * sizeof(double)), offPre = offBlk + align((size_t)nDev * nBlk * 2 * sizeof(int32_t)),
+               offEv = offPre + align((size_t)nDev * SIPNET_RING_SLOTS * sizeof(double)),
+               total = offEv + (b->hostEv ? align(perStep * 24) : 0);
+  // (the events block: evFirst[nDev][nT], evCount[nDev][nT], dTill[nDev][nT], tillAfter[nDev][nT])
+  const size_t offEvCount = offEv + perStep * 4, offDTill = offEv + perStep * 8, offTillAfter = offEv + perStep * 16;
   if (total > b->planScratchCap) {
     if (b->planKernelsQueued) HIP_TRY(hipEventSynchronize(b->evPlanDone));
     if (b->d_planScratch) HIP_TRY(hipFree(b->d_planScratch));
@@ -421,6 +411,7 @@ static int buildOnDevice(sipnet_batch* b, const std::vector<int32_t>& bases, hip
   }
   // the site table (pinned staging: the small-array block is free again only after its copies, so a block of its own)
   std::vector<DevPlanSite> tab(nDev);
+  std::vector<double> preW((size_t)nDev * SIPNET_RING_SLOTS, 0.0);
   int32_t maxSteps = 0;
   // (the scratch block is rewritten: behind the previous forcing's plan kernels)
   if (b->planKernelsQueued) HIP_TRY(hipStreamWaitEvent(b->upStream, b->evPlanDone, 0));
@@ -434,18 +425,49 @@ static int buildOnDevice(sipnet_batch* b, const std::vector<int32_t>& bases, hip
     if (b->flags[SIPNET_F_GDD])   // the host's GDD chain of this site (uploadPlan)
       HIP_TRY(hipMemcpyAsync(b->d_planScratch + offGdd + (size_t)d * nT * sizeof(double), b->hostGdd + (size_t)s * nT,
                              (size_t)c.n * sizeof(double), hipMemcpyHostToDevice, b->upStream));
-    DevPlanSite& e = tab[d++];
+    const bool hasEv = b->planLight[s].hasEvents && b->hostEv;
+    if (hasEv) {   // the events on each record and the tillage series (plan.cpp buildSitePlanLight)
+      const unsigned char* h = b->hostEv + (size_t)s * nT * 24;
+      unsigned char* dv = b->d_planScratch;
+      HIP_TRY(hipMemcpyAsync(dv + offEv + (size_t)d * nT * 4, h, (size_t)c.n * 4, hipMemcpyHostToDevice, b->upStream));
+      HIP_TRY(hipMemcpyAsync(dv + offEvCount + (size_t)d * nT * 4, h + 4 * (size_t)nT, (size_t)c.n * 4, hipMemcpyHostToDevice, b->upStream));
+      HIP_TRY(hipMemcpyAsync(dv + offDTill + (size_t)d * nT * 8, h + 8 * (size_t)nT, (size_t)c.n * 8, hipMemcpyHostToDevice, b->upStream));
+      HIP_TRY(hipMemcpyAsync(dv + offTillAfter + (size_t)d * nT * 8, h + 16 * (size_t)nT, (size_t)c.n * 8, hipMemcpyHostToDevice, b->upStream));
+    }
+    DevPlanSite& e = tab[d];
     e.clim = c.devClim();
     e.year = c.devYear();
     e.day = c.devDay();
+    e.preW = (const double*)(b->d_planScratch + offPre) + (size_t)d * SIPNET_RING_SLOTS;
     e.n = c.n;
     e.site = s;
     e.opBase = bases[3 * s];
+    // the ring the walk starts from: a fresh one (one entry carrying the 5-day window, runmean.c:44-52), or a checkpoint's
+    double* pw = preW.data() + (size_t)d * SIPNET_RING_SLOTS;
+    if (b->resume[s].set) {
+      const PlanCarry& rc0 = b->resume[s];
+      e.preK = (rc0.ring.last - rc0.ring.start + SIPNET_RING_SLOTS) % SIPNET_RING_SLOTS + 1;
+      e.preStart = rc0.ring.start;
+      e.preIns = 0;
+      for (int i = 0; i < e.preK; i++) pw[i] = rc0.ring.w[(rc0.ring.start + i) % SIPNET_RING_SLOTS];
+      e.phenInit = rc0.phenLastYear;
+      e.trackInit = rc0.trackLastYear;
+    } else {
+      e.preK = 1;
+      e.preStart = 0;
+      e.preIns = -1;
+      pw[0] = 5.0;                // MEAN_NPP_DAYS, sipnet.c:39
+      e.phenInit = c.year()[0];   // sipnet.c:1524
+      e.trackInit = -1;           // sipnet.c:1412
+    }
+    e.hasEvents = hasEv ? 1 : 0;
     e.pad = 0;
+    d++;
     maxSteps = std::max(maxSteps, c.n);
   }
   // (a pageable source: the runtime stages these few hundred bytes itself before the call returns)
   HIP_TRY(hipMemcpyAsync(b->d_planScratch + offSites, tab.data(), nDev * sizeof(DevPlanSite), hipMemcpyHostToDevice, b->upStream));
+  HIP_TRY(hipMemcpyAsync(b->d_planScratch + offPre, preW.data(), preW.size() * sizeof(double), hipMemcpyHostToDevice, b->upStream));
   int rc = joinUploads(b, stream);
   if (rc) return rc;
   DevPlanArgs& a = b->devPlan;
@@ -456,6 +478,10 @@ static int buildOnDevice(sipnet_batch* b, const std::vector<int32_t>& bases, hip
   a.ringOps = b->d_ringOps;
   a.lenC = (double*)(b->d_planScratch + offLen);
   a.gddAfter = (const double*)(b->d_planScratch + offGdd);
+  a.evFirst = (const int32_t*)(b->d_planScratch + offEv);
+  a.evCount = (const int32_t*)(b->d_planScratch + offEvCount);
+  a.dTill = (const double*)(b->d_planScratch + offDTill);
+  a.tillAfter = (const double*)(b->d_planScratch + offTillAfter);
   a.seq = (DevPlanSeq*)(b->d_planScratch + offSeq);
   a.runs = (DevPlanRun*)(b->d_planScratch + offRuns);
   a.runCap = runCap;
@@ -503,13 +529,25 @@ static int uploadPlan(sipnet_batch* b, hipStream_t stream) {
   std::fill(b->devSite.begin(), b->devSite.end(), 0);
   b->nDevSites = 0;
   if (mayBuildOnDevice(b)) {
-    int rcW = waitStaged(b);   // (the previous hand-over's copy out of the GDD staging block)
+    int rcW = waitStaged(b);   // (the previous hand-over's copies out of the staging blocks)
     if (rcW) return rcW;
     rcW = reservePinned(&b->hostGdd, &b->hostGddCap, (size_t)nS * b->n_steps);
     if (rcW) return rcW;
+    bool anyEvents = false;
+    for (int s = 0; s < nS; s++)
+      anyEvents |= (b->flags[SIPNET_F_EVENTS] && !b->events[s].empty()) || (b->resume[s].set && b->resume[s].dTill != 0.0);
+    if (anyEvents) {
+      rcW = reservePinned(&b->hostEv, &b->hostEvCap, (size_t)nS * b->n_steps * 24);
+      if (rcW) return rcW;
+    } else if (b->hostEv) {   // (no site has events this time: the block is not looked at)
+      HIP_TRY(hipHostFree(b->hostEv));
+      b->hostEv = nullptr;
+      b->hostEvCap = 0;
+    }
+    b->planLight.assign(nS, PlanLight{});
     std::atomic<bool> none{false};
     forEachSite(nS, b->planThreads, &none, [&](int s) -> bool {
-      b->devSite[s] = deviceEligible(b, s, b->hostGdd + (size_t)s * b->n_steps) ? 1 : 0;
+      b->devSite[s] = devicePrepass(b, s, &b->planLight[s]) ? 1 : 0;
       return true;
     });
     for (int s = 0; s < nS; s++) b->nDevSites += b->devSite[s];
@@ -771,6 +809,7 @@ void sipnet_batch_destroy(sipnet_batch* b) {
   if (b->hostMisc) (void)hipHostFree(b->hostMisc);
   if (b->hostLog2) (void)hipHostFree(b->hostLog2);
   if (b->hostGdd) (void)hipHostFree(b->hostGdd);
+  if (b->hostEv) (void)hipHostFree(b->hostEv);
   for (SiteClim& c : b->sc) {
     if (c.host) (void)hipHostFree(c.host);
     if (c.dev) (void)hipFree(c.dev);
@@ -1783,7 +1822,7 @@ int sipnet_batch_get_site_series(sipnet_batch* b, int32_t site, double* gdd,
   if (b->devSite[site] && b->plans[site].gddAfter.empty()) {   // a device-built site: the series from a host pass of its own
     const SiteClim& c = b->sc[site];
     SitePlan hp = buildSitePlan(b->flags, c.n, c.clim(), c.year(), c.day(), (int32_t)b->events[site].size(), b->events[site].data(),
-                                nullptr, nullptr, /*wantSteps=*/false);
+                                b->resume[site].set ? &b->resume[site] : nullptr, nullptr, /*wantSteps=*/false);
     b->plans[site].gddAfter = std::move(hp.gddAfter);
     b->plans[site].dTill = std::move(hp.dTill);
   }
@@ -1810,7 +1849,8 @@ int sipnet_debug_plan_compare(sipnet_batch* b, int32_t site, int32_t ignore_log2
   const int n = c.n;
   std::vector<FastRec> host(n), dev(n);
   SitePlan hp = buildSitePlan(b->flags, n, c.clim(), c.year(), c.day(), (int32_t)b->events[site].size(), b->events[site].data(),
-                              nullptr, nullptr, /*wantSteps=*/false, nullptr, host.data(), b->precision == SIPNET_F32_MIXED);
+                              b->resume[site].set ? &b->resume[site] : nullptr, nullptr, /*wantSteps=*/false, nullptr, host.data(),
+                              b->precision == SIPNET_F32_MIXED);
   HIP_TRY(hipMemcpy(dev.data(), b->d_fast + (size_t)site * b->n_steps, (size_t)n * sizeof(FastRec), hipMemcpyDeviceToHost));
   int d = 0;
   for (int s = 0; s < site; s++) d += b->devSite[s];
@@ -1839,6 +1879,9 @@ int sipnet_debug_plan_compare(sipnet_batch* b, int32_t site, int32_t ignore_log2
   for (size_t k = 0; k < hp.ringOps.size(); k++)
     if (memcmp(&ops[k], &hp.ringOps[k], sizeof(RingOp)) != 0) no++;
   if ((size_t)out4[1] != hp.ringOps.size()) no += 1 + llabs((long long)out4[1] - (long long)hp.ringOps.size());
+  // (the event records the light pass matched to the climate records)
+  const std::vector<EvRec>& evs = b->plans[site].events;
+  if (evs.size() != hp.events.size() || (!evs.empty() && memcmp(evs.data(), hp.events.data(), evs.size() * sizeof(EvRec)) != 0)) no += 1000000;
   if (n_records_differing) *n_records_differing = nr;
   if (n_ops_differing) *n_ops_differing = no;
   if (first_step) *first_step = fs;

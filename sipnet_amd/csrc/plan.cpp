@@ -360,4 +360,94 @@ SitePlan buildSitePlan(const int32_t* flags, int32_t n_steps, const double* clim
   return plan;
 }
 
+PlanLight buildSitePlanLight(const int32_t* flags, int32_t n_steps, const double* clim, const int32_t* year, const int32_t* day,
+                             int32_t n_events, const sipnet_event* events, const PlanCarry* init, double minLen, int32_t minRun,
+                             double* gddAfter, int32_t* evFirst, int32_t* evCount, double* dTillOut, double* tillAfter) {
+  PlanLight plan;
+  if (!flags[SIPNET_F_EVENTS]) n_events = 0;
+  plan.hasEvents = n_events > 0 || (init && init->set && init->dTill != 0.0);
+  int trackLastYear = -1;       // trackers.lastYear, sipnet.c:1412
+  double trackGdd = 0.0;        // trackers.gdd
+  double dTill = 0.0;           // events.c:809
+  int evNext = 0;
+  if (init && init->set) {      // sipnet.c:1963-1967
+    trackLastYear = init->trackLastYear;
+    trackGdd = init->gdd;
+    dTill = init->dTill;
+  }
+  if (n_events > 0 && n_steps > 0) {   // frontend.c:216-223
+    const bool before = events[0].year != year[0] ? events[0].year < year[0] : events[0].day < day[0];
+    if (before) {
+      plan.status = SIPNET_ERR_INPUT_FILE;
+      plan.message = "First event occurs before the start of the climate file";
+    }
+  }
+  // runs of equal step lengths (plan_device.h: of a long run one lane walks the first 5 days / length + a few steps)
+  int32_t runLen = 0;
+  double runL = 0.0;
+  auto closeRun = [&]() {
+    const int64_t head = (int64_t)(kMeanNppDays / runL) + 6;
+    plan.walked += (runLen >= minRun + head) ? head : runLen;
+  };
+  for (int t = 0; t < n_steps; t++) {
+    const double* r = clim + (size_t)SIPNET_NCLIM * t;
+    const double length = r[0], gdd = r[9];
+    if (!(length >= minLen)) plan.lengthsOk = false;
+    if (!(length > 0) && plan.status == SIPNET_OK) plan.status = SIPNET_ERR_BAD_PARAMETER;   // (worded by buildSitePlan: such a site is the host's)
+    if (t > 0 && length == runL) {
+      runLen++;
+    } else {
+      if (t > 0 && plan.lengthsOk) closeRun();
+      runL = length;
+      runLen = 1;
+    }
+    // sipnet.c:706-716, :1421-1431, :1480-1484
+    double cum = gdd;
+    if (year[t] == trackLastYear) cum += trackGdd;
+    if (year[t] != trackLastYear) {
+      trackGdd = 0.0;
+      trackLastYear = year[t];
+    }
+    if (flags[SIPNET_F_GDD]) trackGdd += gdd;
+    else trackGdd = 0.0;
+    gddAfter[t] = trackGdd;
+    if (t == 0) {
+      plan.startCumGdd = cum;
+      plan.startTsoil = r[2];
+      plan.startDayTime = (double)day[0] + r[10] / 24.0;
+    }
+    if (!plan.hasEvents) continue;
+    // events falling on this record, events.c:470-482
+    const int32_t first = (int32_t)plan.events.size();
+    while (evNext < n_events && events[evNext].year <= year[t] && events[evNext].day <= day[t]) {
+      const sipnet_event& ev = events[evNext];
+      if ((ev.year < year[t] || ev.day < day[t]) && plan.status == SIPNET_OK) {
+        plan.status = SIPNET_ERR_INPUT_FILE;
+        plan.message = "Agronomic event without a corresponding climate record";
+      }
+      if (ev.type == SIPNET_EV_TILL) dTill += ev.p[0];  // events.c:629-639
+      if (ev.type == SIPNET_EV_IRRIG && (int)ev.p[1] != 0 && (int)ev.p[1] != 1 && plan.status == SIPNET_OK) {
+        plan.status = SIPNET_ERR_UNKNOWN_EVENT;  // events.c:497-500
+        plan.message = "Unknown irrigation method type";
+      }
+      EvRec e;
+      e.type = ev.type;
+      e.pad = 0;
+      for (int k = 0; k < 4; k++) e.p[k] = ev.p[k];
+      plan.events.push_back(e);
+      evNext++;
+    }
+    evFirst[t] = first;
+    evCount[t] = (int32_t)plan.events.size() - first;
+    dTillOut[t] = dTill;
+    if (dTill > 0) {   // events.c:811-822
+      dTill *= std::exp(-length * kTillDecay);
+      if (dTill < kTillThreshold) dTill = 0.0;
+    }
+    tillAfter[t] = dTill;
+  }
+  if (n_steps > 0 && plan.lengthsOk) closeRun();
+  return plan;
+}
+
 }  // namespace sipnet

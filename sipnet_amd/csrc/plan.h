@@ -190,4 +190,25 @@ SitePlan buildSitePlan(const int32_t* flags, int32_t n_steps, const double* clim
                        PlanCarry* fin = nullptr, bool wantSteps = true, StepRec* stepsOut = nullptr,
                        FastRec* fastOut = nullptr, bool narrowFast = false);
 
+
+// The host's share of a DEVICE-built plan (plan_device.h): what of buildSitePlan's loop is sequential and cheap on a core --
+// the year-to-date GDD chain, the events falling on each record with the tillage modifier's decay, the site-fatal
+// conditions -- plus the facts that decide who builds the site (every step long enough that the ring cannot overflow, how
+// many steps one lane would have to walk).  No ring schedule, no per-step records.  Same statements as buildSitePlan's,
+// same order; tests/test_gpu_plan_device.py holds the two together byte by byte.
+struct PlanLight {
+  int status = SIPNET_OK;
+  std::string message;
+  std::vector<EvRec> events;               // as SitePlan::events
+  bool hasEvents = false;                  // the four per-step arrays below were written
+  double startCumGdd = 0.0, startTsoil = 0.0, startDayTime = 0.0;
+  bool lengthsOk = true;                   // every step >= minLen (false for a NaN)
+  int64_t walked = 0;                      // steps outside the part of a run of equal lengths that one descriptor covers
+};
+// gddAfter[n]: trackers.gdd after each record (always written).  evFirst / evCount / dTill / tillAfter [n]: written when the
+// site has events (may be null when n_events is 0 or the events flag is off).
+PlanLight buildSitePlanLight(const int32_t* flags, int32_t n_steps, const double* clim, const int32_t* year, const int32_t* day,
+                             int32_t n_events, const sipnet_event* events, const PlanCarry* init, double minLen, int32_t minRun,
+                             double* gddAfter, int32_t* evFirst, int32_t* evCount, double* dTill, double* tillAfter);
+
 }  // namespace sipnet

@@ -1,8 +1,10 @@
 // plan_device.h -- the site plan built ON THE DEVICE from the uploaded climate (plan_device.hip).
 //
 // plan.cpp builds the 256-byte per-step records on host threads and sends them over PCIe (143 MB at 32 sites x
-// 17 520 steps; 4.3 ms of a 20 ms hand-over of one forcing).  For a site without agronomic events and without a
-// resumed checkpoint the same records are produced here from the site's raw climate (63 MB over the wire instead):
+// 17 520 steps; 4.3 ms of a 20 ms hand-over of one forcing).  Here the same records are produced from the site's raw
+// climate (63 MB over the wire instead) -- fresh or resumed from a checkpoint (the ring's live entries are handed over as
+// the walk's initial queue), with or without agronomic events (the host's pass matches them to records and runs the
+// tillage modifier's decay: 24 bytes a step for such a site):
 //   planPrepKernel    step lengths as a compact array, per 256 steps "a length changes here" and the largest year
 //                                                                                               (one thread per step)
 //   planSeqKernel     the part that IS sequential in floating point, one wavefront per site: the running-mean ring's
@@ -48,9 +50,16 @@ struct DevPlanSite {
   const double* clim;     // device [n][SIPNET_NCLIM]
   const int32_t* year;    // device [n]
   const int32_t* day;     // device [n]
+  const double* preW;     // device [SIPNET_RING_SLOTS]: weights of the ring's live entries before the first record, front first
   int32_t n;              // records of the site
   int32_t site;           // its position in the batch (records at fast + site * nT)
   int32_t opBase;         // its first RingOp in the flat array (room for 2 n + 8)
+  int32_t preK;           // number of those entries (a fresh ring: one, carrying the whole window -- runmean.c:44-52)
+  int32_t preStart;       // the front one's slot
+  int32_t preIns;         // their insert step in the eviction records: -1 fresh, 0 resumed (buildSitePlan's init)
+  int32_t phenInit;       // phenologyTrackers.lastYear before the first record (sipnet.c:1524; a checkpoint's)
+  int32_t trackInit;      // trackers.lastYear before the first record (sipnet.c:1412: -1; a checkpoint's)
+  int32_t hasEvents;      // the site's rows of evFirst / evCount / dTill / tillAfter are filled
   int32_t pad;
 };
 
@@ -77,6 +86,12 @@ struct DevPlanArgs {
   RingOp* ringOps;
   double* lenC;               // [nDev][nT]
   const double* gddAfter;     // [nDev][nT]: trackers.gdd after each record -- the HOST's add chain (see above)
+  // sites with events (DevPlanSite::hasEvents), from the host's pass (plan.cpp buildSitePlanLight): the events falling on
+  // each record (site-local EvRec index + count), the tillage modifier during and after each record (events.c:811-822)
+  const int32_t* evFirst;     // [nDev][nT] each
+  const int32_t* evCount;
+  const double* dTill;
+  const double* tillAfter;
   DevPlanSeq* seq;            // [nDev][nT]
   DevPlanRun* runs;           // [nDev][runCap]
   int32_t runCap;

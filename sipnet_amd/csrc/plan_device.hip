@@ -51,8 +51,11 @@ struct RingState {
 
 __device__ void ringWalk(const DevPlanArgs& a, const DevPlanSite& S, int d) {
   __shared__ double win[kWin];
+  __shared__ double pre[256];   // the live entries the walk starts from (a fresh ring's one entry; a checkpoint's ring)
   __shared__ RingState st;
   const int lane = threadIdx.x, n = S.n;
+  const int K = S.preK, preIns = S.preIns;
+  for (int i = lane; i < K; i += 64) pre[i] = S.preW[i];
   const double* len = a.lenC + (size_t)d * a.nT;
   DevPlanSeq* seq = a.seq + (size_t)d * a.nT;
   RingOp* ops = a.ringOps + S.opBase;
@@ -60,8 +63,9 @@ __device__ void ringWalk(const DevPlanArgs& a, const DevPlanSite& S, int d) {
   constexpr int M = kWin - 1;
   int loaded = 0;
   if (lane == 0) {
-    st.t = 0; st.j = -1; st.r0 = -1; st.opCount = 0; st.runStart = 0; st.noFF = 0; st.ffT0 = -1; st.ffNOps = 0;
-    st.status = 0; st.statusAt = -1; st.nRuns = 0; st.wFront = kMeanNppDays; st.ffLen = 0.0;
+    // entries before the first record are "steps" -K .. -1, the front one in slot preStart
+    st.t = 0; st.j = -K; st.r0 = -K - S.preStart; st.opCount = 0; st.runStart = 0; st.noFF = 0; st.ffT0 = -1; st.ffNOps = 0;
+    st.status = 0; st.statusAt = -1; st.nRuns = 0; st.wFront = S.preW[0]; st.ffLen = 0.0;
   }
   __syncthreads();
   while (true) {
@@ -98,13 +102,13 @@ __device__ void ringWalk(const DevPlanArgs& a, const DevPlanSite& S, int d) {
               if (!status) { status = 2; statusAt = t; }
               break;
             }
-            const int slot = (j - r0) % kSlots, ins = j;
+            const int slot = (j - r0) % kSlots, ins = j >= 0 ? j : preIns;
             double wop;
             if (wF > left) {
               wop = left; wF -= left; left = 0;
             } else {
               wop = wF; left -= wF; j++;
-              wF = j < t ? win[j & M] : 0.0;
+              wF = j >= t ? 0.0 : j >= 0 ? win[j & M] : pre[j + K];
             }
             RingOp op; op.w = wop; op.slot = slot; op.insStep = ins;
             ops[opCount++] = op;
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(256) void planExpandKernel(DevPlanArgs a) {
   const double len = r[0], tair = r[1], tsoil = r[2], par = r[3], precip = r[4], vpd = r[5], vpdSoil = r[6], vPress = r[7],
                wspd = r[8], gdd = r[9], tod = r[10];
   const int yr = S.year[uc], dy = S.day[uc];
-  const int yrPrev = uc > 0 ? S.year[uc - 1] : -1;
+  const int yrPrev = uc > 0 ? S.year[uc - 1] : S.trackInit;
   // phenology new year (sipnet.c:811-815): this record's year exceeds the largest seen before it, starting from the first
   // record's (sipnet.c:1524) -- the earlier blocks' maxima (planPrepKernel), the earlier wavefronts', the earlier lanes'
   bool phenNew;
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(256) void planExpandKernel(DevPlanArgs a) {
     if (lane == 63) waveMax[w] = x;
     if (w == 0) {
       const int* info = a.blockInfo + (size_t)d * a.nBlk * 2;
-      int p = S.year[0];
+      int p = S.phenInit;
       for (int bb = lane; bb < (int)blockIdx.x; bb += 64) p = max(p, info[2 * bb + 1]);
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) p = max(p, __shfl_xor(p, off));
@@ -296,6 +300,17 @@ __global__ __launch_bounds__(256) void planExpandKernel(DevPlanArgs a) {
   const double gddAfter = a.flagGdd ? a.gddAfter[(size_t)d * a.nT + uc] : 0.0;   // trackers.gdd after this record (the host's chain)
   const double cum = newTrack ? gdd : gddAfter;
 
+  // events on this record and the tillage modifier (the host's pass; none: zeros)
+  int evFirst = 0, evCount = 0;
+  double dTill = 0.0, tillAfter = 0.0;
+  if (S.hasEvents) {
+    const size_t k = (size_t)d * a.nT + uc;
+    evFirst = a.evFirst[k];
+    evCount = a.evCount[k];
+    dTill = a.dTill[k];
+    tillAfter = a.tillAfter[k];
+  }
+
   FastRec f;
   f.len = len;
   f.invLen = 1.0 / len;
@@ -303,7 +318,7 @@ __global__ __launch_bounds__(256) void planExpandKernel(DevPlanArgs a) {
   f.tsoil = tsoil;
   f.negPar = -par;
   f.vpd = vpd;
-  f.tillP1 = 1.0 + 0.0;
+  f.tillP1 = 1.0 + dTill;
   f.rainRate = precip / len;
   f.sublW = (a.convS * (kEStarSnow - vPress)) * wspd;
   f.evapNum = a.convE * vpdSoil;
@@ -315,21 +330,21 @@ __global__ __launch_bounds__(256) void planExpandKernel(DevPlanArgs a) {
   f.w0 = Q.w0;
   const int bits = (phenNew ? FAST_PHEN_NEW_YEAR : 0) | (newTrack ? FAST_TRACK_NEW_YEAR : 0) | (tair > 0 ? FAST_TAIR_POS : 0) |
                    (par > 0 ? FAST_PAR_POS : 0) | ((tsoil < 0 || !a.moistHResp) ? FAST_TSOIL_NEG : 0) |
-                   (Q.w1 != 0.0 ? FAST_HAS_W1 : 0) | (tsoilSame ? FAST_TSOIL_SAME : 0) |
+                   (Q.w1 != 0.0 ? FAST_HAS_W1 : 0) | (dTill != 0.0 ? FAST_HAS_TILL : 0) | (tsoilSame ? FAST_TSOIL_SAME : 0) |
                    (nOps == 1 && insSlot >= 0 ? FAST_RING_REGULAR : 0);
   f.bitsOps = bits | (nOps << 16);
   f.slots = s0 | (s1 << 8) | (ns0 << 16) | (ns1 << 24);
   f.insSlot = insSlot;
-  f.evCount = 0;
+  f.evCount = evCount;
   f.w1 = Q.w1;
   f.spareD = 0.0;
   f.log2vpd = 0.0;     // filled from the host's values when a member reads it (plan_device.h)
   f.gddAfter = gddAfter;
-  f.tillAfter = 0.0;
+  f.tillAfter = tillAfter;
   f.ins0 = Q.ins0;
   f.ins1 = Q.ins1;
   f.opFirst = Q.opFirst;
-  f.evFirst = 0;
+  f.evFirst = evFirst;
   f.year = yr;
   f.day = dy;
 
@@ -340,7 +355,7 @@ __global__ __launch_bounds__(256) void planExpandKernel(DevPlanArgs a) {
   auto first = [&](auto x) { return __shfl(x, g0); };
   auto nextSlot = [](int s) { return s + 1 == kSlots ? 0 : s + 1; };
   const int nOpsB = first(nOps);
-  bool ok = !(bits & (FAST_PHEN_NEW_YEAR | FAST_TRACK_NEW_YEAR)) && insSlot >= 0 && nOps == nOpsB && f.len == first(f.len) &&
+  bool ok = !(bits & (FAST_PHEN_NEW_YEAR | FAST_TRACK_NEW_YEAR)) && evCount == 0 && insSlot >= 0 && nOps == nOpsB && f.len == first(f.len) &&
             f.invLen == first(f.invLen) && f.w0 == first(f.w0) && f.w1 == first(f.w1);
   {
     const int ps0 = __shfl_up(s0, 1), ps1 = __shfl_up(s1, 1), pIns = __shfl_up(insSlot, 1);

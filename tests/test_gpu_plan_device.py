@@ -152,7 +152,7 @@ def test_sites_the_host_keeps(base):
     yc = FORCINGS["half-hourly year"].slice(0, 2000)
     short = with_lengths(yc, np.full(2000, 0.0201))                # below the bound that rules a ring overflow out: the host's
     ev = Event(type=2, year=int(yc.year[10]), day=int(yc.day[10]), pad=0, p=(C.c_double * 4)(1.0, 0.0, 0.0, 0.0))   # SIPNET_EV_IRRIG
-    for flags, want in ((sa.flags_from(events=1), 1), (sa.flags_from(events=0), 2)):   # (events switched off: the list is ignored)
+    for flags, want in ((sa.flags_from(events=1), 2), (sa.flags_from(events=0), 2)):   # (events: the device's too; switched off: the list is ignored)
         b = sa.Batch(flags, 3, 64, sa.F64, fast_math=True)
         b.set_climate(0, yc)
         b.set_climate(1, short)
@@ -200,3 +200,84 @@ def test_forcings_back_to_back_on_one_batch(base):
             r = compare(b, s)
             assert r["status"] == 0 and r["records"] == 0 and r["ops"] == 0, r
     b.close()
+
+
+def tillage_events(clim, steps):
+    """a tillage and an irrigation event on the records `steps` of the forcing (SIPNET_EV_TILL = 4, SIPNET_EV_IRRIG = 2)"""
+    out = []
+    for k, t in enumerate(steps):
+        typ, p = (4, (0.5, 0.0, 0.0, 0.0)) if k % 2 == 0 else (2, (1.5, 1.0, 0.0, 0.0))
+        out.append(Event(type=typ, year=int(clim.year[t]), day=int(clim.day[t]), pad=0, p=(C.c_double * 4)(*p)))
+    return out
+
+
+@pytest.mark.parametrize("prec", [sa.F64, sa.F32_MIXED], ids=["f64", "f32mixed"])
+def test_sites_with_events_are_built_on_the_device_too(base, prec):
+    """the host's pass hands the events per record and the tillage modifier's decay over (24 bytes a step); records, evictions
+    and event records are the host builder's bytes, and so are the results"""
+    ru = helpers.load_smoke_case("russell_1")            # the reference's own events file on its own forcing
+    yc = FORCINGS["half-hourly year"]
+    # (one event per day at most lands on distinct records only with one record a day; half-hourly: the day's first record)
+    clims = [ru["clim"], yc, yc.slice(0, 9000)]
+    events = [ru["events"], tillage_events(yc, [48 * 40, 48 * 41, 48 * 200, 48 * 300]), []]
+    members = synth.perturbed_params(ru["params"], 64, seed=5)
+    out = {}
+    for opt in (sa.KOPT_DEVICE_PLAN, sa.KOPT_HOST_PLAN):
+        b = sa.Batch(ru["flags"], 3, 64, prec, fast_math=True if prec == sa.F64 else None, kernel_options=opt)
+        for s in range(3):
+            b.set_events(s, events[s])
+        b.set_climates(clims)
+        b.set_params(None, members)
+        b.setup()
+        if opt == sa.KOPT_DEVICE_PLAN:
+            assert b.last_launch()["plan_device_sites"] == 3
+            for s in range(3):
+                r = compare(b, s)
+                assert r["status"] == 0 and r["records"] == 0 and r["ops"] == 0, (s, r)
+        pl, _ = b.run()
+        out[opt] = ([pl[:, :c.n_steps, s * 64:(s + 1) * 64].clone() for s, c in enumerate(clims)], b.get_state().copy(),
+                    [b.site_series(s) for s in range(3)])
+        b.close()
+    for x, y in zip(out[sa.KOPT_DEVICE_PLAN][0], out[sa.KOPT_HOST_PLAN][0]):
+        assert torch.equal(x.contiguous().view(torch.uint8), y.contiguous().view(torch.uint8))
+    assert np.array_equal(out[sa.KOPT_DEVICE_PLAN][1], out[sa.KOPT_HOST_PLAN][1], equal_nan=True)
+    for (g0, d0), (g1, d1) in zip(out[sa.KOPT_DEVICE_PLAN][2], out[sa.KOPT_HOST_PLAN][2]):
+        assert np.array_equal(g0, g1) and np.array_equal(d0, d1)
+    assert any(d.max() > 0 for _, d in out[sa.KOPT_HOST_PLAN][2])          # a tillage modifier was in effect
+
+
+@pytest.mark.parametrize("prec", [sa.F64, sa.F32_MIXED], ids=["f64", "f32mixed"])
+def test_a_resumed_segment_is_built_on_the_device_too(base, prec):
+    """the ring a checkpoint hands over becomes the walk's initial queue (its entries: insert step 0, their own weights); GDD,
+    year roll-overs and the tillage modifier continue from the checkpoint's"""
+    yc = FORCINGS["half-hourly year"]
+    irregular = FORCINGS["runs of lengths, resets"]
+    cases = [(yc, 5000, []), (yc, 100, tillage_events(yc, [48 * 1])), (irregular, 3333, []), (FORCINGS["niwot"], 1000, [])]
+    members = synth.perturbed_params(base, 64, seed=9)
+    for clim, k, ev in cases:
+        b1 = sa.Batch(sa.flags_from(), 1, 64, prec, fast_math=True if prec == sa.F64 else None, kernel_options=sa.KOPT_DEVICE_PLAN)
+        b1.set_events(0, ev)
+        b1.set_climate(0, clim.slice(0, k))
+        b1.set_params(0, members)
+        b1.setup()
+        b1.run(0, k)
+        cks = [b1.export_restart(0, m, k) for m in range(64)]
+        b1.close()
+        seg2 = clim.slice(k, min(clim.n_steps, k + 6000))
+        res = {}
+        for opt in (sa.KOPT_DEVICE_PLAN, sa.KOPT_HOST_PLAN):
+            b2 = sa.Batch(sa.flags_from(), 1, 64, prec, fast_math=True if prec == sa.F64 else None, kernel_options=opt)
+            b2.set_climate(0, seg2)
+            b2.set_params(0, members)
+            b2.set_resume(0, cks[0])
+            b2.setup()
+            if opt == sa.KOPT_DEVICE_PLAN:
+                assert b2.last_launch()["plan_device_sites"] == 1
+                r = compare(b2, 0)
+                assert r["status"] == 0 and r["records"] == 0 and r["ops"] == 0, (k, r)
+            b2.import_restart(0, cks)
+            pl, _ = b2.run()
+            res[opt] = (pl.clone(), b2.get_state().copy())
+            b2.close()
+        assert torch.equal(res[sa.KOPT_DEVICE_PLAN][0].view(torch.uint8), res[sa.KOPT_HOST_PLAN][0].view(torch.uint8))
+        assert np.array_equal(res[sa.KOPT_DEVICE_PLAN][1], res[sa.KOPT_HOST_PLAN][1], equal_nan=True)
