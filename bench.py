@@ -689,6 +689,7 @@ def main():
                 torch.cuda.synchronize()
                 e2e.append(time.perf_counter() - te0)
             e2e_s = float(np.median(e2e[1:]))
+            plan_device_sites = int(b.last_launch()["plan_device_sites"])   # (an idle batch: the device builds the plans, plan_device.h)
             # pipelined: forcings alternate between TWO batches on two streams, so the host side of forcing k + 1
             # (climate copies, plan build, uploads) runs under the step kernel of forcing k; uploads wait for their own
             # batch's last launch only.  Steady-state time per forcing over 8 forcings after 2 of warm-up.
@@ -720,7 +721,8 @@ def main():
                           **({"pipelined_error": pipelined} if isinstance(pipelined, str) else {}),
                           "bytes_up": int(members.nbytes + S * (clims[0].data.nbytes + clims[0].year.nbytes + clims[0].day.nbytes)),
                           "bytes_down": int(host_stats.numel() * 8),
-                          "plan_device_sites": int(b.last_launch()["plan_device_sites"]),   # sites whose plan the device built (plan_device.h)
+                          "plan_device_sites": plan_device_sites,   # sites whose plan the device built in the serial leg (the pipelined
+                                                                    # leg hands forcings to busy batches: the host's cores build)
                           "includes": "climate of every site (one call) + raw parameters (one upload for all sites) from host memory, "
                                       "the site plans (built on the device from the climate where eligible, else host-built + uploaded), setupModel(), the step kernel with the ensemble statistics from "
                                       "the same launch (sipnet_batch_run_stats), the statistics block into pinned host memory; "

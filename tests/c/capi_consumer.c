@@ -40,7 +40,11 @@ int main(int argc, char **argv) {
   memcpy(members + SIPNET_NPARAMS, raw, sizeof raw);
   members[SIPNET_NPARAMS + sipnet_param_index("aMax")] *= 1.1;
   rc = sipnet_batch_set_math(b, SIPNET_MATH_STRICT);
-  if (!rc) rc = sipnet_batch_set_climate(b, 0, T, sipnet_clim_data(clim), sipnet_clim_year(clim), sipnet_clim_day(clim));
+  /* (the several-sites entry with one site: its copies run on the batch's plan threads) */
+  const int32_t n_steps[1] = {T};
+  const double *cl[1] = {sipnet_clim_data(clim)};
+  const int32_t *yr[1] = {sipnet_clim_year(clim)}, *dy[1] = {sipnet_clim_day(clim)};
+  if (!rc) rc = sipnet_batch_set_climate_sites(b, 0, 1, n_steps, cl, yr, dy);
   if (!rc) rc = sipnet_batch_set_params(b, 0, 0, M, members);
   if (!rc) rc = sipnet_batch_setup(b, NULL);
   double *d_nee = (double *)sipnet_dev_alloc(sizeof(double) * (size_t)T * M);

@@ -30,8 +30,12 @@ for dev in 0 0,0; do
 done
 cat $O/pf_consumer_0.log
 for wl in c3 c5 c4; do bash tools/gpu_pmc_branch.sh $wl > /dev/null 2>&1; cp gpurun_out/pmc_branch_$wl.txt $O/; done
-for wl in c4 c2x16; do timeout 600 python tools/e2e_breakdown.py $wl 2>&1 | grep -v amdgpu > $O/e2e_$wl.txt; tail -2 $O/e2e_$wl.txt; done
+for wl in c4 c2x16 c10k; do for who in dev host; do timeout 600 python tools/e2e_breakdown.py $wl $who 2>&1 | grep -v amdgpu > $O/e2e_${wl}_$who.txt; tail -3 $O/e2e_${wl}_$who.txt | cut -c1-200; done; done
+timeout 300 python tools/plan_device_time.py 2>&1 | grep -v amdgpu > $O/plan_device_time.txt
+rm -rf /tmp/prof_plan_c4
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_plan_c4 -- python3 tools/e2e_breakdown.py c4 > $O/e2e_prof_c4.txt 2>&1
+cp "$(find /tmp/prof_plan_c4 -name '*kernel_stats.csv' | head -1)" $O/plan_kernel_stats_c4.csv
 timeout 1500 python tools/cli_block_time.py 10240 512 > $O/cli_block_time.txt 2>&1
 cat $O/cli_block_time.txt
-timeout 900 python -m pytest tests/test_cli.py -x -q -m gpu > $O/pytest_cli.txt 2>&1
-tail -3 $O/pytest_cli.txt
+timeout 2400 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.txt 2>&1
+tail -3 $O/pytest_gpu.txt
