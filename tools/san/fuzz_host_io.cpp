@@ -9,7 +9,8 @@
 // Every seed is parsed as it is (must succeed), then ITERATIONS mutated copies (deterministic: the PRNG is seeded by
 // the seed file's index and the iteration) are parsed; whatever the parsers return is fine, what the sanitizers
 // report is not (they abort the process).  A forcing that still parses also goes through buildSitePlan (both record
-// types, narrow and wide) -- with the mutated events when an events file has been seen.
+// types, narrow and wide) -- with the mutated events when an events file has been seen -- and through buildSitePlanLight,
+// the host's share of a device-built plan, whose every output must equal the full builder's (abort otherwise).
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -109,7 +110,33 @@ static void planFrom(const sipnet_clim_table* t) {
     sipnet::SitePlan p = sipnet::buildSitePlan(g_flags, n, sipnet_clim_data(t), sipnet_clim_year(t), sipnet_clim_day(t),
                                                (int32_t)g_events.size(), g_events.empty() ? nullptr : g_events.data(), nullptr, &fin,
                                                narrow == 0, narrow == 0 ? steps.data() : nullptr, fast.data(), narrow != 0);
-    (void)p;
+    // the light pass a device-built plan gets from the host (plan_device.h) must say what the full builder says: the GDD
+    // chain and the tillage series bit for bit, the same events on the same records, the same verdict on the site
+    if (narrow == 0) {
+      std::vector<double> gdd((size_t)n), dTill((size_t)n), tillAfter((size_t)n);
+      std::vector<int32_t> evFirst((size_t)n), evCount((size_t)n);
+      sipnet::PlanLight l = sipnet::buildSitePlanLight(g_flags, n, sipnet_clim_data(t), sipnet_clim_year(t), sipnet_clim_day(t),
+                                                       (int32_t)g_events.size(), g_events.empty() ? nullptr : g_events.data(), nullptr,
+                                                       0.0202, 48, gdd.data(), evFirst.data(), evCount.data(), dTill.data(), tillAfter.data());
+      bool same = (l.status == SIPNET_OK) == (p.status == SIPNET_OK);
+      if (same && p.status == SIPNET_OK) {
+        same = memcmp(gdd.data(), p.gddAfter.data(), (size_t)n * sizeof(double)) == 0 && l.events.size() == p.events.size() &&
+               (l.events.empty() || memcmp(l.events.data(), p.events.data(), l.events.size() * sizeof(sipnet::EvRec)) == 0) &&
+               memcmp(&l.startCumGdd, &p.startCumGdd, sizeof(double)) == 0 && memcmp(&l.startDayTime, &p.startDayTime, sizeof(double)) == 0;
+        for (int k = 0; same && k < n; k++) {
+          const sipnet::StepRec& sr = steps[(size_t)k];
+          if (l.hasEvents)
+            same = evFirst[(size_t)k] == sr.evFirst && evCount[(size_t)k] == sr.evCount &&
+                   memcmp(&dTill[(size_t)k], &sr.dTill, sizeof(double)) == 0 && memcmp(&tillAfter[(size_t)k], &sr.tillAfter, sizeof(double)) == 0;
+          else
+            same = sr.evCount == 0 && sr.dTill == 0.0 && sr.tillAfter == 0.0;
+        }
+      }
+      if (!same) {
+        fprintf(stderr, "buildSitePlanLight disagrees with buildSitePlan (status %d vs %d)\n", l.status, p.status);
+        abort();
+      }
+    }
   }
 }
 
