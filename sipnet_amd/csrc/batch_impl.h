@@ -156,6 +156,8 @@ struct sipnet_batch {
   // may be running: a caller pipelines forcings over two batches, bench.py's end_to_end.pipelined)
   hipEvent_t evBusy = nullptr;
   bool busy = false;
+  hipStream_t busyStream = nullptr;   // where the last launch went; evBusy is recorded there on demand (markBusy / recordBusy below)
+  bool busyRecorded = true;
   hipEvent_t evStaged = nullptr;   // behind the last copy out of the pinned staging blocks
   hipEvent_t evOrder = nullptr;    // caller's stream -> copy stream ordering
   bool staged = false;
@@ -166,14 +168,55 @@ struct sipnet_batch {
 int flushParams(sipnet_batch* b, hipStream_t stream);   // engine.hip: upload + convert what set_params left pending
 int materializeParams(sipnet_batch* b, hipStream_t stream);   // pf.hip: d_prm back into column order (no-op unless prmIndexed)
 
+// "This batch has work in flight on `stream`."  The event itself is recorded only when somebody needs it (a wait from
+// another stream, a host-side wait or query): work queued later on the SAME stream is ordered behind it anyway, and an
+// event record between two kernels costs the device ~5 us of an otherwise back-to-back dispatch -- two of them per
+// 165 us particle-filter cycle (profiles/r05_c5.md: the gaps around the forecast kernel).
 inline int markBusy(sipnet_batch* b, hipStream_t stream) {
-  HIP_TRY(hipEventRecord(b->evBusy, stream));
+  // (launches move to another stream: the old stream's work gets its event now -- the callers have ordered the new
+  // stream behind it through orderBehindBusy, and the next event will be the new stream's)
+  if (b->busy && !b->busyRecorded && b->busyStream != stream) (void)hipEventRecord(b->evBusy, b->busyStream);
+  (void)hipGetLastError();
+  b->busyStream = stream;
   b->busy = true;
+  b->busyRecorded = false;
+  return SIPNET_OK;
+}
+// the event behind the batch's last launch, recorded if it has not been yet.  A stream the caller has destroyed in the
+// meantime cannot be recorded on: whatever ran on it is waited for through the device instead.
+inline int recordBusy(sipnet_batch* b) {
+  if (!b->busy || b->busyRecorded) return SIPNET_OK;
+  if (hipEventRecord(b->evBusy, b->busyStream) != hipSuccess) {
+    (void)hipGetLastError();
+    HIP_TRY(hipDeviceSynchronize());
+    b->busy = false;
+  }
+  b->busyRecorded = true;
   return SIPNET_OK;
 }
 inline int waitIdle(sipnet_batch* b) {
-  if (b->busy) HIP_TRY(hipEventSynchronize(b->evBusy));
+  if (b->busy) {
+    int rc = recordBusy(b);
+    if (rc) return rc;
+    if (b->busy) HIP_TRY(hipEventSynchronize(b->evBusy));
+  }
   b->busy = false;
+  return SIPNET_OK;
+}
+// is the batch's last launch still running?
+inline bool stillRunning(sipnet_batch* b) {
+  if (!b->busy || recordBusy(b) != SIPNET_OK || !b->busy) return false;
+  const bool running = hipEventQuery(b->evBusy) == hipErrorNotReady;
+  (void)hipGetLastError();
+  return running;
+}
+// `stream` will touch what the batch's last launch reads or writes: a device-side wait, unless that launch went to the
+// same stream (then the stream's own order does it)
+inline int orderBehindBusy(sipnet_batch* b, hipStream_t stream) {
+  if (!b->busy || (!b->busyRecorded && b->busyStream == stream)) return SIPNET_OK;
+  int rc = recordBusy(b);
+  if (rc) return rc;
+  if (b->busy) HIP_TRY(hipStreamWaitEvent(stream, b->evBusy, 0));
   return SIPNET_OK;
 }
 // the pinned staging blocks (raw parameter rows, site records, the small plan arrays): free for the host to write

@@ -203,9 +203,7 @@ static int joinUploads(sipnet_batch* b, hipStream_t stream) {
 static bool mayBuildOnDevice(const sipnet_batch* b) {
   if (!wantsFastRecs(b) || (b->kernelOptions & SIPNET_KOPT_HOST_PLAN)) return false;
   if (b->kernelOptions & SIPNET_KOPT_DEVICE_PLAN) return true;
-  const bool running = b->busy && hipEventQuery(b->evBusy) == hipErrorNotReady;
-  (void)hipGetLastError();
-  return !running;
+  return !stillRunning(const_cast<sipnet_batch*>(b));
 }
 // the site's forcing block -> its device block, asynchronously on the copy stream (behind the plan kernels that may still
 // be reading the previous forcing there)
@@ -267,8 +265,7 @@ static int buildAndUpload(sipnet_batch* b, bool fastType, bool first, hipStream_
   if (rc) return rc;
   rc = fastType ? reserveRecords(b, &b->d_fast, &b->fastCap, nFast) : reserveRecords(b, &b->d_plan, &b->planCap, nSteps);
   if (rc) return rc;
-  const bool deferCopies = b->busy && hipEventQuery(b->evBusy) == hipErrorNotReady;
-  (void)hipGetLastError();
+  const bool deferCopies = stillRunning(b);
   // (sites whose records the device builds itself need no staging: plan_device.h)
   const bool devPass = fastType && first && b->nDevSites > 0;
   const bool anyHostSite = !devPass || b->nDevSites < nS;
@@ -552,7 +549,10 @@ static int uploadPlan(sipnet_batch* b, hipStream_t stream) {
     });
     for (int s = 0; s < nS; s++) b->nDevSites += b->devSite[s];
     // the plan kernels overwrite records this batch's last launch may still be reading on another stream
-    if (b->nDevSites && b->busy) HIP_TRY(hipStreamWaitEvent(stream, b->evBusy, 0));
+    if (b->nDevSites) {
+      int rcO = orderBehindBusy(b, stream);
+      if (rcO) return rcO;
+    }
   }
   int rc = buildAndUpload(b, wantsFastRecs(b), /*first=*/true, stream);
   if (rc) return rc;
@@ -1016,7 +1016,10 @@ int flushParams(sipnet_batch* b, hipStream_t stream) {
   }
   // The conversion writes d_prm: it must not start while this batch's last launch -- possibly on ANOTHER stream of
   // the caller's (a node shard's, the null stream of pf_publish) -- still reads it.  A device-side wait, no host stall.
-  if (b->busy) HIP_TRY(hipStreamWaitEvent(stream, b->evBusy, 0));
+  {
+    int rcO = orderBehindBusy(b, stream);
+    if (rcO) return rcO;
+  }
   // (an earlier conversion on `stream` may still read the device block: the copy stream waits for the caller's first)
   HIP_TRY(hipEventRecord(b->evOrder, stream));
   HIP_TRY(hipStreamWaitEvent(b->upStream, b->evOrder, 0));

@@ -696,7 +696,10 @@ struct PfPeers {
 int materializeParams(sipnet_batch* b, hipStream_t stream) {
   if (!b->prmIndexed) return SIPNET_OK;
   const size_t nc = (size_t)b->ncol;
-  if (b->busy) HIP_TRY(hipStreamWaitEvent(stream, b->evBusy, 0));   // (the last launch may have run on another stream)
+  {   // (the last launch may have run on another stream)
+    int rcO = orderBehindBusy(b, stream);
+    if (rcO) return rcO;
+  }
   if (!b->d_prm2) HIP_TRY(hipMalloc(&b->d_prm2, nc * SIPNET_NPARAMS * sizeof(double)));
   RecvMap none{};
   launchGatherMember(nullptr, nullptr, false, b->d_prm, b->ncol, nullptr, none, b->d_prmId, b->ncol, nullptr, nullptr, b->d_prm2,
