@@ -655,9 +655,12 @@ int32_t sipnet_batch_site_nsteps(const sipnet_batch *b, int32_t site);  /* this 
  * step t) and d_till_mod[t] (eventTrackers.d_till_mod used in step t). */
 int sipnet_batch_get_site_series(sipnet_batch *b, int32_t site, double *gdd,
                                  double *d_till_mod);
-/* Last launch's average kernel time in ms measured with HIP events on the
- * launch stream (for bench.py's roofline line); <0 if none. */
+/* Last launch's kernel time in ms measured with HIP events on the launch stream (for bench.py's roofline
+ * line); <0 if the last launch was not timed.  Launches of 512 steps and more are always timed; a shorter one
+ * (a particle filter's forecast, where the two event records would cost 6 % of the cycle) only when
+ * sipnet_batch_time_next_launch was called before it. */
 double sipnet_batch_last_kernel_ms(sipnet_batch *b);
+int sipnet_batch_time_next_launch(sipnet_batch *b);
 /* What the last sipnet_batch_run actually launched: the step kernel's instantiation as
  * rocprofv3 names it (e.g. "stepCoopKernel<double, true, true>"), its launch shape, and the
  * host-side costs of the last sipnet_batch_setup that rebuilt the site plans. */

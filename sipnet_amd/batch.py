@@ -203,6 +203,11 @@ class Batch:
               "reduce_plane")
         return stats
 
+    def time_next_launch(self):
+        """bracket the next run()'s step kernel with the timing events whatever its length (launches of 512 steps and
+        more always are): last_kernel_ms() after it"""
+        check(self.L.sipnet_batch_time_next_launch(self.h), "time_next_launch")
+
     def last_kernel_ms(self):
         return self.L.sipnet_batch_last_kernel_ms(self.h)
 

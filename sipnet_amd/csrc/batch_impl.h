@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdint>
 #include <string>
 #include <memory>
@@ -150,6 +151,7 @@ struct sipnet_batch {
 
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
+  bool timeNext = false;   // sipnet_batch_time_next_launch: the next step kernel is bracketed by the timing events whatever its length
   double lastMs = -1.0;
   // recorded behind every launch of this batch that reads its inputs (setupModel, a step kernel): what an upload
   // that overwrites those inputs waits for -- this batch's own work only, not the device (another batch's kernel
@@ -171,7 +173,9 @@ int materializeParams(sipnet_batch* b, hipStream_t stream);   // pf.hip: d_prm b
 // "This batch has work in flight on `stream`."  The event itself is recorded only when somebody needs it (a wait from
 // another stream, a host-side wait or query): work queued later on the SAME stream is ordered behind it anyway, and an
 // event record between two kernels costs the device ~5 us of an otherwise back-to-back dispatch -- two of them per
-// 165 us particle-filter cycle (profiles/r05_c5.md: the gaps around the forecast kernel).
+// 165 us particle-filter cycle (profiles/r05_c5.md: the gaps around the forecast kernel).  Long launches (a setup, a run of
+// 512 steps or more) record it at once (recordBusy): there it costs nothing, and a later "is it still running?" gets an
+// answer that does not depend on how fast a fresh event completes.
 inline int markBusy(sipnet_batch* b, hipStream_t stream) {
   // (launches move to another stream: the old stream's work gets its event now -- the callers have ordered the new
   // stream behind it through orderBehindBusy, and the next event will be the new stream's)
@@ -180,6 +184,10 @@ inline int markBusy(sipnet_batch* b, hipStream_t stream) {
   b->busyStream = stream;
   b->busy = true;
   b->busyRecorded = false;
+#ifdef SIPNET_EAGER_BUSY   // (A/B build: the event after every launch, as before round 5)
+  HIP_TRY(hipEventRecord(b->evBusy, stream));
+  b->busyRecorded = true;
+#endif
   return SIPNET_OK;
 }
 // the event behind the batch's last launch, recorded if it has not been yet.  A stream the caller has destroyed in the
@@ -203,12 +211,22 @@ inline int waitIdle(sipnet_batch* b) {
   b->busy = false;
   return SIPNET_OK;
 }
-// is the batch's last launch still running?
+// is the batch's last launch still running?  An event recorded only NOW (after a short launch, see markBusy) takes the
+// device a few microseconds even on an idle stream: it is given 40 before the batch is called busy.  (hipStreamQuery
+// instead of an event was tried: on this runtime it returned only when the stream had drained -- 7.5 ms inside
+// sipnet_batch_set_climate_sites of the pipelined whole-job leg, tools/pipeline_probe.py.)
 inline bool stillRunning(sipnet_batch* b) {
-  if (!b->busy || recordBusy(b) != SIPNET_OK || !b->busy) return false;
-  const bool running = hipEventQuery(b->evBusy) == hipErrorNotReady;
+  if (!b->busy) return false;
+  const bool fresh = !b->busyRecorded;
+  if (recordBusy(b) != SIPNET_OK || !b->busy) return false;
+  hipError_t q = hipEventQuery(b->evBusy);
+  if (fresh && q == hipErrorNotReady) {
+    const auto t0 = std::chrono::steady_clock::now();
+    while (q == hipErrorNotReady && std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(40)) q = hipEventQuery(b->evBusy);
+  }
   (void)hipGetLastError();
-  return running;
+  if (q == hipSuccess) b->busy = false;   // (nothing of this batch is in flight any more)
+  return q == hipErrorNotReady;
 }
 // `stream` will touch what the batch's last launch reads or writes: a device-side wait, unless that launch went to the
 // same stream (then the stream's own order does it)

@@ -1292,7 +1292,12 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
   }
   a.plan = b->d_plan;
   bool boundedWaits = false;
-  HIP_TRY(hipEventRecord(b->ev0, stream));
+  // the timing events around the step kernel: for a long launch, or when asked for (sipnet_batch_time_next_launch) -- a
+  // particle filter's 48-step forecasts run back to back with their analyses, and two event records per cycle cost the
+  // device ~10 us of 165 (batch_impl.h markBusy)
+  const bool timeIt = n_steps >= 512 || b->timeNext;
+  b->timeNext = false;
+  if (timeIt) HIP_TRY(hipEventRecord(b->ev0, stream));
   if (kernel != SIPNET_KERNEL_STRICT) {
     // throughput path: step_fast.hip / step_coop.hip
     FastArgs f;
@@ -1337,7 +1342,7 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
     launchStep(a, b->precision, b->fastMath, stream, &b->lastLaunch);
   }
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipEventRecord(b->ev1, stream));
+  if (timeIt) HIP_TRY(hipEventRecord(b->ev1, stream));
   if (d_stats) {
     if (coop) {
       launchFinishStats(b->d_statsPart, n_steps, b->n_sites, chunksPerSite, d_stats, stream);
@@ -1350,9 +1355,10 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
     }
     HIP_TRY(hipGetLastError());
   }
-  b->timed = true;
+  b->timed = timeIt;
   b->stepsDone = (b->stepsDone == step0) ? step0 + n_steps : -1;
   rc = markBusy(b, stream);
+  if (!rc && n_steps >= 512) rc = recordBusy(b);   // (a long launch: the event now, batch_impl.h markBusy)
   if (rc) return rc;
   if (boundedWaits) {   // the diagnostic build: did a hand-over wait give up?
     unsigned long long stuck[2] = {0, 0};
@@ -1378,6 +1384,12 @@ double sipnet_batch_last_kernel_ms(sipnet_batch* b) {
   if (hipEventElapsedTime(&ms, b->ev0, b->ev1) != hipSuccess) return -1.0;
   b->lastMs = ms;
   return (double)ms;
+}
+
+int sipnet_batch_time_next_launch(sipnet_batch* b) {
+  if (!b) return SIPNET_ERR_BAD_ARGUMENT;
+  b->timeNext = true;
+  return SIPNET_OK;
 }
 
 int sipnet_batch_last_launch(sipnet_batch* b, sipnet_launch_info* out) {

@@ -1,10 +1,9 @@
 #!/bin/bash
-# lazy busy event + the packed light-wave probe: c3 product vs variant, the bench lines of all workloads (traffic from the
+# the final bench lines of all workloads (traffic from the
 # round-5 profiles), the GPU suite
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 O=gpurun_out/r5m; mkdir -p $O
-timeout 900 python tools/variant_bench.py --workload c3 --reps 7 product lpacked > $O/variant_c3_lpacked.txt 2>&1; grep -v amdgpu $O/variant_c3_lpacked.txt | tail -4 | cut -c1-300
 : > $O/bench_all.jsonl
 for wl in c10k c2 c2x16 c3 c4 c5 c10kn c4n c10kr3; do
   extra="--no-cpu-baseline"; [ "$wl" = c10k ] && extra=""

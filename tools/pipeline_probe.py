@@ -30,7 +30,7 @@ for k in range(8):
     bb = ln["b"]
     with torch.cuda.stream(ln["s"]):
         t = [time.perf_counter()]
-        for s_ in range(S): bb.set_climate(s_, clims[s_])
+        bb.set_climates(clims)
         t.append(time.perf_counter())
         bb.set_params(None, members); t.append(time.perf_counter())
         bb.setup(); t.append(time.perf_counter())

@@ -34,7 +34,7 @@ for k in (1, 2, 4, 10, 20, 40, 365):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for a, z in zip(cuts[:-1], cuts[1:]):
-            b.run(a, z - a, planes=planes[:, a:z])
+            b.time_next_launch(); b.run(a, z - a, planes=planes[:, a:z])
         t1 = time.perf_counter()
         torch.cuda.synchronize()
         ts.append(((time.perf_counter() - t0) * 1e3, (t1 - t0) * 1e3))
