@@ -281,3 +281,67 @@ def test_a_resumed_segment_is_built_on_the_device_too(base, prec):
             b2.close()
         assert torch.equal(res[sa.KOPT_DEVICE_PLAN][0].view(torch.uint8), res[sa.KOPT_HOST_PLAN][0].view(torch.uint8))
         assert np.array_equal(res[sa.KOPT_DEVICE_PLAN][1], res[sa.KOPT_HOST_PLAN][1], equal_nan=True)
+
+
+def test_random_forcings_against_the_host_builder(base):
+    """60 random forcings (lengths in runs of random length, resets, years rolling over or stepping back at random records,
+    random tillage / irrigation events, random phenology flags, both precisions), eight sites a batch: records, evictions and
+    event records byte for byte"""
+    rng = np.random.default_rng(2026100305)
+    yc = FORCINGS["half-hourly year"]
+    pool = [1 / 48, 1 / 24, 0.0202, 0.125, 0.25, 0.5, 1.0, 2.0, 3.5, 4.9999, 5.0, 9.0]
+    total = with_events = 0
+    for trial in range(8):
+        clims, events = [], []
+        for s in range(8):
+            n = int(rng.integers(1, 3000))
+            lens = np.concatenate([np.full(int(rng.integers(1, 600)), pool[int(rng.integers(len(pool)))] if rng.random() < 0.8 else float(rng.uniform(0.0202, 6.0)))
+                                   for _ in range(40)])[:n]
+            n = len(lens)
+            years = 2000 + np.cumsum(rng.random(n) < 0.002).astype(np.int32)
+            if rng.random() < 0.3 and n > 10:
+                k = int(rng.integers(1, n))
+                years[k:k + int(rng.integers(1, 50))] -= int(rng.integers(1, 3))
+            c = with_lengths(yc, lens, years)
+            clims.append(c)
+            ev = []
+            if rng.random() < 0.5 and n > 4:
+                days = sorted(set(int(x) for x in rng.integers(0, n, size=int(rng.integers(1, 6)))))
+                seen = set()
+                for t in days:                      # (events must ascend in time and match a record: the first record of a day)
+                    key = (int(c.year[t]), int(c.day[t]))
+                    t0 = int(np.argmax((c.year == key[0]) & (c.day == key[1])))
+                    if key in seen or (ev and (key[0], key[1]) <= (ev[-1].year, ev[-1].day)) or t0 != t and (t0 > 0 and (int(c.year[t0 - 1]), int(c.day[t0 - 1])) >= key):
+                        continue
+                    seen.add(key)
+                    ev += tillage_events(c, [t0]) if rng.random() < 0.6 else tillage_events(c, [t0, t0])[1:]
+            events.append(ev)
+        flags = [sa.flags_from(), sa.flags_from(gdd=0, soilPhenol=1), sa.flags_from(gdd=0), sa.flags_from(waterHResp=0)][trial % 4]
+        prec = sa.F64 if trial % 2 == 0 else sa.F32_MIXED
+        b = sa.Batch(flags, 8, 64, prec, fast_math=True if prec == sa.F64 else None, kernel_options=sa.KOPT_DEVICE_PLAN)
+        for s in range(8):
+            b.set_events(s, events[s])
+        b.set_climates(clims)
+        b.set_params(None, base)
+        try:
+            b.setup()
+        except Exception:
+            # a site-fatal plan (an event the random forcing has no record for): the whole batch is refused, as with the host builder
+            b.close()
+            continue
+        n_dev = b.last_launch()["plan_device_sites"]
+        assert n_dev >= 1
+        checked = 0
+        for s in range(8):
+            try:
+                r = compare(b, s)
+            except Exception:
+                continue                      # (a site the prepass left to the host)
+            assert r["status"] == 0 and r["records"] == 0 and r["ops"] == 0, (trial, s, r)
+            checked += 1
+            with_events += bool(events[s])
+        assert checked == n_dev
+        total += checked
+        b.close()
+    print(f"{total} random sites compared, {with_events} of them with events")
+    assert total >= 32 and with_events >= 8, (total, with_events)
