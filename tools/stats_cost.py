@@ -34,7 +34,7 @@ for name in sys.argv[1:] or ["c10k"]:
     stats = torch.empty((3, T, S, 2), dtype=torch.float64, device=planes.device)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     res = {}
-    for mode in ("run", "run_stats", "run", "run_stats"):
+    for mode in os.environ.get("MODES", "run,run_stats,run,run_stats").split(","):
         k, w = [], []
         for _ in range(4):
             b.setup()
