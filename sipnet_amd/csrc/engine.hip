@@ -419,9 +419,14 @@ static int buildOnDevice(sipnet_batch* b, const std::vector<int32_t>& bases, hip
       int rc = sendClimate(b, s);
       if (rc) return rc;
     }
-    if (b->flags[SIPNET_F_GDD])   // the host's GDD chain of this site (uploadPlan)
+    // the host's GDD chains (uploadPlan): one copy per run of neighbouring device-built sites (32 copies of 140 KB kept the
+    // copy stream busy for 0.6 ms; rows are nT apart on both sides)
+    if (b->flags[SIPNET_F_GDD] && (s == 0 || !b->devSite[s - 1])) {
+      int e = s;
+      while (e < nS && b->devSite[e]) e++;
       HIP_TRY(hipMemcpyAsync(b->d_planScratch + offGdd + (size_t)d * nT * sizeof(double), b->hostGdd + (size_t)s * nT,
-                             (size_t)c.n * sizeof(double), hipMemcpyHostToDevice, b->upStream));
+                             (size_t)(e - s) * nT * sizeof(double), hipMemcpyHostToDevice, b->upStream));
+    }
     const bool hasEv = b->planLight[s].hasEvents && b->hostEv;
     if (hasEv) {   // the events on each record and the tillage series (plan.cpp buildSitePlanLight)
       const unsigned char* h = b->hostEv + (size_t)s * nT * 24;
@@ -589,7 +594,12 @@ static int uploadPlan(sipnet_batch* b, hipStream_t stream) {
   }
   // the small arrays: flattened into one pinned block and sent on the same stream (buildAndUpload has waited for
   // every launch that might still read the previous plan; an empty list keeps one inert entry)
-  const size_t opsBytes = (nOps ? nOps : 1) * sizeof(RingOp), evBytes = (nEv ? nEv : 1) * sizeof(EvRec);
+  // (ring evictions: the HOST-built sites' only -- a device-built site's list is written by its walk, and its room in the flat
+  // array, 2 n + 8 entries, is not sent: 18 MB and 0.32 ms of the copy stream at 32 sites x 17 520 records)
+  size_t nHostOps = 0;
+  for (int s = 0; s < nS; s++)
+    if (!b->devSite[s]) nHostOps += b->plans[s].ringOps.size();
+  const size_t opsBytes = (nHostOps ? nHostOps : 1) * sizeof(RingOp), evBytes = (nEv ? nEv : 1) * sizeof(EvRec);
   auto align16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
   const size_t offEv = align16(opsBytes), offStatus = offEv + align16(evBytes), offStart = offStatus + align16(nS * sizeof(int32_t)),
                offBase = offStart + align16(nS * sizeof(SiteStart)), total = offBase + align16(bases.size() * sizeof(int32_t));
@@ -597,17 +607,35 @@ static int uploadPlan(sipnet_batch* b, hipStream_t stream) {
   if (rc) return rc;
   RingOp* hOps = (RingOp*)b->hostMisc;
   EvRec* hEv = (EvRec*)(b->hostMisc + offEv);
-  for (int s = 0; s < nS; s++) {
-    const SitePlan& p = b->plans[s];
-    if (!p.ringOps.empty()) memcpy(hOps + bases[3 * s], p.ringOps.data(), p.ringOps.size() * sizeof(RingOp));
-    if (!p.events.empty()) memcpy(hEv + bases[3 * s + 1], p.events.data(), p.events.size() * sizeof(EvRec));
+  std::vector<size_t> hostOff(nS, 0);
+  {
+    size_t off = 0;
+    for (int s = 0; s < nS; s++) {
+      const SitePlan& p = b->plans[s];
+      hostOff[s] = off;
+      if (!b->devSite[s] && !p.ringOps.empty()) {
+        memcpy(hOps + off, p.ringOps.data(), p.ringOps.size() * sizeof(RingOp));
+        off += p.ringOps.size();
+      }
+      if (!p.events.empty()) memcpy(hEv + bases[3 * s + 1], p.events.data(), p.events.size() * sizeof(EvRec));
+    }
   }
-  if (nOps == 0) hOps[0] = RingOp{0.0, 0, -1};
   if (nEv == 0) hEv[0] = EvRec{0, 0, {0, 0, 0, 0}};
   memcpy(b->hostMisc + offStatus, b->siteStatus.data(), nS * sizeof(int32_t));
   memcpy(b->hostMisc + offStart, starts.data(), nS * sizeof(SiteStart));
   memcpy(b->hostMisc + offBase, bases.data(), bases.size() * sizeof(int32_t));
-  HIP_TRY(hipMemcpyAsync(b->d_ringOps, hOps, opsBytes, hipMemcpyHostToDevice, b->upStream));
+  if (nOps == 0) {
+    hOps[0] = RingOp{0.0, 0, -1};
+    HIP_TRY(hipMemcpyAsync(b->d_ringOps, hOps, sizeof(RingOp), hipMemcpyHostToDevice, b->upStream));
+  }
+  for (int s = 0; s < nS;) {   // runs of neighbouring host-built sites: contiguous here and there
+    if (b->devSite[s]) { s++; continue; }
+    int e = s;
+    size_t cnt = 0;
+    while (e < nS && !b->devSite[e]) cnt += b->plans[e++].ringOps.size();
+    if (cnt) HIP_TRY(hipMemcpyAsync(b->d_ringOps + bases[3 * s], hOps + hostOff[s], cnt * sizeof(RingOp), hipMemcpyHostToDevice, b->upStream));
+    s = e;
+  }
   HIP_TRY(hipMemcpyAsync(b->d_events, hEv, evBytes, hipMemcpyHostToDevice, b->upStream));
   HIP_TRY(hipMemcpyAsync(b->d_siteStatus, b->hostMisc + offStatus, nS * sizeof(int32_t), hipMemcpyHostToDevice, b->upStream));
   HIP_TRY(hipMemcpyAsync(b->d_siteStart, b->hostMisc + offStart, nS * sizeof(SiteStart), hipMemcpyHostToDevice, b->upStream));
@@ -911,8 +939,9 @@ int sipnet_batch_set_climate_sites(sipnet_batch* b, int32_t first_site, int32_t 
     rc = climateReserve(b, first_site + k, n_steps[k]);
     if (rc) return rc;
   }
-  // (the copies are memory-bound: a handful of threads saturate the socket; each sends its site off as soon as it is
-  // copied, so the DMA of the first sites runs under the copies of the others)
+  // (each thread sends its site off as soon as it is copied, so the DMA of the first sites runs under the copies of the
+  // others.  Eight threads: the copies are bound by the host's memory fabric -- 63 MB in 1.6 ms = 39 GB/s of copy on this
+  // box, the 36 us DMAs wait for them; sixteen threads were slower, 1.9 ms, and slowed the DMAs to 55 us)
   const bool send = mayBuildOnDevice(b);
   std::atomic<int> firstErr{0};
   std::string errText;
