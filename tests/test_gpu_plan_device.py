@@ -345,3 +345,24 @@ def test_random_forcings_against_the_host_builder(base):
         b.close()
     print(f"{total} random sites compared, {with_events} of them with events")
     assert total >= 32 and with_events >= 8, (total, with_events)
+
+
+def test_ten_years_of_half_hourly_records_and_a_single_record(base):
+    """175 200 records (one run descriptor of 174 955 steps, ten GDD chains) beside a forcing of ONE record"""
+    raw = synth.half_hourly_year_raw(17520)
+    one = synth.convert_raw(synth.round_like_file(raw))
+    data = np.tile(one.data, (10, 1))
+    year = np.concatenate([one.year + k for k in range(10)]).astype(np.int32)
+    day = np.tile(one.day, 10)
+    long = ClimTable(data, year, day)
+    b = sa.Batch(sa.flags_from(), 2, 64, sa.F32_MIXED, kernel_options=sa.KOPT_DEVICE_PLAN)
+    b.set_climates([long, one.slice(0, 1)])
+    b.set_params(None, base)
+    b.setup()
+    assert b.last_launch()["plan_device_sites"] == 2
+    r = compare(b, 0)
+    assert r["status"] == 0 and r["records"] == 0 and r["ops"] == 0 and r["runs"] == 1, r
+    r = compare(b, 1)
+    assert r["status"] == 0 and r["records"] == 0 and r["ops"] == 0, r
+    b.run(175200 - 64, 64)
+    b.close()
