@@ -661,6 +661,13 @@ int sipnet_batch_get_site_series(sipnet_batch *b, int32_t site, double *gdd,
  * sipnet_batch_time_next_launch was called before it. */
 double sipnet_batch_last_kernel_ms(sipnet_batch *b);
 int sipnet_batch_time_next_launch(sipnet_batch *b);
+/* Particle filter: tell the NEXT sipnet_batch_run that an analysis with this observation and sigma follows it.  When
+ * that run takes the one-wave kernel's lean build (a filter's many particles, no record) it also leaves the log-weights
+ * of the NEE it sums over its steps in d_logw[ncol] -- the first phase of sipnet_batch_pf_analysis, which then skips
+ * its pass over the plane and one grid barrier (11 us of a 150 us cycle at 131 072 particles x 48 steps) when it is
+ * called with the same plane, number of steps, observation, sigma and d_logw.  Any other launch, or an analysis with
+ * other arguments, computes them as before: the call is a hint, the results are bit-identical either way. */
+int sipnet_batch_pf_arm(sipnet_batch *b, double obs, double sigma, double *d_logw);
 /* What the last sipnet_batch_run actually launched: the step kernel's instantiation as
  * rocprofv3 names it (e.g. "stepCoopKernel<double, true, true>"), its launch shape, and the
  * host-side costs of the last sipnet_batch_setup that rebuilt the site plans. */

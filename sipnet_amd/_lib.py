@@ -193,6 +193,7 @@ SIGNATURES = {
     "sipnet_batch_get_site_series": (C.c_int, [_P, C.c_int32, _P, _P]),
     "sipnet_batch_last_kernel_ms": (C.c_double, [_P]),
     "sipnet_batch_time_next_launch": (C.c_int, [_P]),
+    "sipnet_batch_pf_arm": (C.c_int, [_P, C.c_double, C.c_double, _P]),
     "sipnet_dev_alloc": (_P, [C.c_size_t]),
     "sipnet_dev_free": (None, [_P]),
     "sipnet_dev_to_host": (C.c_int, [_P, _P, C.c_size_t, _P]),

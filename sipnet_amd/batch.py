@@ -293,6 +293,15 @@ class Batch:
             "pf_log_weights")
         return out
 
+    def pf_arm(self, obs, sigma):
+        """sipnet_batch_pf_arm: the next run() (one-wave kernel, planes only) also leaves the log-weights that
+        pf_analysis_local(planes[0], obs, sigma, ...) would otherwise compute in a pass of its own"""
+        t = self._torch
+        if getattr(self, "_pf_buf", None) is None:
+            self._pf_buf = (t.empty(self.ncol, dtype=t.float64, device=self.device),
+                            t.empty(self.ncol, dtype=t.int32, device=self.device))
+        check(self.L.sipnet_batch_pf_arm(self.h, float(obs), float(sigma), C.c_void_p(self._pf_buf[0].data_ptr())), "pf_arm")
+
     def pf_analysis_local(self, plane, obs, sigma, u0, with_params=False, total_out=None):
         """log-weights -> systematic resampling -> resample, all particles in this batch, ONE library call
         (sipnet_batch_pf_analysis).  Returns (ancestors int32 [ncol], logw f64 [ncol]) on the device."""

@@ -151,6 +151,13 @@ struct sipnet_batch {
 
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
+  // sipnet_batch_pf_arm: the next lean one-wave launch also leaves the log-weights of its NEE sum (FastArgs::pfLogw);
+  // pfPre describes what such a launch has left, for the analysis that follows it
+  struct PfArm { bool set = false; double obs = 0.0, sigma = 0.0; double* d_logw = nullptr; } pfArm;
+  struct PfPre { bool valid = false; const void* plane = nullptr; int32_t nSteps = 0, nMax = 0; int64_t ld = 0; double obs = 0.0, sigma = 0.0;
+                 double* d_logw = nullptr; } pfPre;
+  double* d_pfPreMax = nullptr;   // [workgroups of the one-wave launch]: their columns' largest log-weight
+  size_t pfPreMaxCap = 0;
   bool timeNext = false;   // sipnet_batch_time_next_launch: the next step kernel is bracketed by the timing events whatever its length
   double lastMs = -1.0;
   // recorded behind every launch of this batch that reads its inputs (setupModel, a step kernel): what an upload

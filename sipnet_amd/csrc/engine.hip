@@ -862,6 +862,7 @@ void sipnet_batch_destroy(sipnet_batch* b) {
   if (b->d_siteStart) (void)hipFree(b->d_siteStart);
   if (b->d_siteBase) (void)hipFree(b->d_siteBase);
   if (b->d_diag) (void)hipFree(b->d_diag);
+  if (b->d_pfPreMax) (void)hipFree(b->d_pfPreMax);
   if (b->d_statsPart) (void)hipFree(b->d_statsPart);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
@@ -1336,6 +1337,38 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
     f.siteBase = b->d_siteBase;
     f.prm = b->d_prm;
     f.prmId = (b->prmIndexed && kernel == SIPNET_KERNEL_ONE_WAVE) ? b->d_prmId : nullptr;
+    // a particle filter's forecast (sipnet_batch_pf_arm): the one-wave kernel's lean build leaves the log-weights too
+    f.pfLogw = nullptr;
+    f.pfBlockMax = nullptr;
+    f.pfObs = f.pfInvSigma = 0.0;
+    b->pfPre.valid = false;
+    if (b->pfArm.set) {
+      const int64_t blocks1 = (int64_t)b->n_sites * ((b->n_members + 63) / 64);
+      bool sameLength = true;
+      for (int s = 0; s < b->n_sites; s++) sameLength = sameLength && b->siteSteps[s] >= step0 + n_steps;
+      if (kernel == SIPNET_KERNEL_ONE_WAVE && !wantFull && d_nee && sameLength) {
+        if ((size_t)blocks1 > b->pfPreMaxCap) {
+          if (b->d_pfPreMax) HIP_TRY(hipFree(b->d_pfPreMax));
+          b->d_pfPreMax = nullptr;
+          b->pfPreMaxCap = 0;
+          HIP_TRY(hipMalloc((void**)&b->d_pfPreMax, (size_t)blocks1 * sizeof(double)));
+          b->pfPreMaxCap = (size_t)blocks1;
+        }
+        f.pfLogw = b->pfArm.d_logw;
+        f.pfBlockMax = b->d_pfPreMax;
+        f.pfObs = b->pfArm.obs;
+        f.pfInvSigma = 1.0 / b->pfArm.sigma;
+        b->pfPre.valid = true;
+        b->pfPre.plane = d_nee;
+        b->pfPre.nSteps = n_steps;
+        b->pfPre.nMax = (int32_t)blocks1;
+        b->pfPre.ld = ld;
+        b->pfPre.obs = b->pfArm.obs;
+        b->pfPre.sigma = b->pfArm.sigma;
+        b->pfPre.d_logw = b->pfArm.d_logw;
+      }
+      b->pfArm.set = false;
+    }
     f.state = b->d_state;
     f.ring = b->d_ring;
     f.nee = d_nee;
@@ -1413,6 +1446,18 @@ double sipnet_batch_last_kernel_ms(sipnet_batch* b) {
   if (hipEventElapsedTime(&ms, b->ev0, b->ev1) != hipSuccess) return -1.0;
   b->lastMs = ms;
   return (double)ms;
+}
+
+int sipnet_batch_pf_arm(sipnet_batch* b, double obs, double sigma, double* d_logw) {
+  if (!b || !d_logw || !(sigma > 0)) {
+    setError("sipnet_batch_pf_arm: bad argument");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  b->pfArm.set = true;
+  b->pfArm.obs = obs;
+  b->pfArm.sigma = sigma;
+  b->pfArm.d_logw = d_logw;
+  return SIPNET_OK;
 }
 
 int sipnet_batch_time_next_launch(sipnet_batch* b) {

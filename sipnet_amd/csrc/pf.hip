@@ -299,6 +299,9 @@ struct FusedArgs {
   int64_t stride;
   int64_t nSlots, chunk;
   double* blockMax;          // [gridDim.x]
+  // phase 1 done already by the forecast's own launch (FastArgs::pfLogw): logw is filled, preMax[nPre] are partial maxima
+  const double* preMax;
+  int32_t nPre;
   int64_t* cdfLocal;         // [nSlots] inclusive sums inside a chunk
   int64_t* w;                // [nSlots] the fixed-point weights
   int64_t* blockSum;         // [gridDim.x]
@@ -383,7 +386,12 @@ __global__ __launch_bounds__(256) void pfFusedKernel(FusedArgs a) {
   int nBarrier = 0;
   double m = -INFINITY;
   PF_STAMP(0)
-  if (!Gathered) {
+  if (!Gathered && a.preMax) {
+    // ---- phase 1 was the forecast kernel's epilogue: only the maximum is left to take ----
+    double pm = -INFINITY;
+    for (int k = tid; k < a.nPre; k += 256) pm = fmax(pm, a.preMax[k]);
+    m = blockMax256(pm, smD);
+  } else if (!Gathered) {
     // ---- phase 1: this chunk's log-weights and their maximum ----
     double mine = -INFINITY;
     for (int64_t i = lo + tid; i < hi; i += 256)
@@ -1109,7 +1117,14 @@ int sipnet_batch_pf_analysis(sipnet_batch* b, const void* d_plane, int32_t elem_
     if (rc) return rc;
     fa.barrier = sc.d_barrier;
     fa.base = sc.barrierBase;
-    sc.barrierBase += 2;
+    // (the forecast's launch has left the log-weights of exactly this plane, observation and sigma: sipnet_batch_pf_arm)
+    const sipnet_batch::PfPre& pre = b->pfPre;
+    const bool havePre = pre.valid && pre.plane == d_plane && pre.nSteps == n_steps && pre.ld == ld && pre.obs == obs &&
+                         pre.sigma == sigma && pre.d_logw == d_logw && elem_is_f32 == (b->precision == SIPNET_F32_MIXED);
+    fa.preMax = havePre ? b->d_pfPreMax : nullptr;
+    fa.nPre = havePre ? pre.nMax : 0;
+    b->pfPre.valid = false;
+    sc.barrierBase += havePre ? 1 : 2;
     fa.j0 = 0;
     fa.nOut = fa.nTotal = b->ncol;
     fa.u0 = u0;

@@ -231,6 +231,7 @@ void stepFastKernel(FastArgs a) {
   double soilOrgN = Generic ? ST(soilOrgN) : 0.0, litterN = Generic ? ST(litterN) : 0.0;
   double storN = Generic ? ST(plantStorageN) : 0.0;
   double ringSum = ST(ringSum), totNee = ST(totNee), totGpp = ST(totGpp);
+  [[maybe_unused]] double pfNee = 0.0;
   int phenBits = (int)ST(phenBits);
   int ringValidFrom = (int)ST(ringValidFrom);
   int diedAt = (int)ST(diedAt);
@@ -894,6 +895,7 @@ void stepFastKernel(FastArgs a) {
     const R tEt = (transpiration + immedEvap + evaporation + sublimation + evEvap) * len;
     totGpp += (double)tGpp;
     totNee += (double)tNee;
+    if (!Full) pfNee += (double)tNee;   // the launch's own NEE sum, from zero, in step order (FastArgs::pfLogw)
     R tRAbove = 0, tRRoot = 0, tRSoil = 0, tRtot = 0, tNpp = 0;
     if (Full) {  // the rest of updateTrackers(), sipnet.c:1420-1496
       if (bits & FAST_TRACK_NEW_YEAR) yGpp = yRtot = yRa = yRh = yNpp = yNee = 0.0;
@@ -1077,6 +1079,18 @@ void stepFastKernel(FastArgs a) {
       dg[2 * nc] = fmax(dg[2 * nc], maxDC);
       dg[3 * nc] = fmax(dg[3 * nc], maxDN);
     }
+  }
+  // a particle filter's forecast: the log-weights the analysis would compute in a pass over the plane (pf.hip logWeightOf:
+  // the same operations in the same order -- no contraction here either) and the maximum of this wavefront's 64
+  if (!Full && a.pfLogw) {
+#pragma clang fp contract(off)
+    const double z = (pfNee - a.pfObs) * a.pfInvSigma;
+    const double lw = skip ? -INFINITY : -0.5 * z * z;
+    if (live) a.pfLogw[col] = lw;
+    double mx = live ? lw : -INFINITY;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off));
+    if (threadIdx.x == 0) a.pfBlockMax[blockIdx.x] = mx;
   }
 #undef ST
 #undef PRM

@@ -119,6 +119,13 @@ struct FastArgs {
   // (at the END, so that the fields above keep the offsets the cooperative kernels' code was measured with: a field in the
   // middle re-rolled c10k's register allocation and cost it 1 %)
   const int32_t* prmId;   // null, or (one-wave kernel only; a particle filter's batch): column c reads the parameters of column prmId[c]
+  // one-wave kernel, lean launches, a particle filter's forecast (sipnet_batch_pf_arm): the launch also leaves every
+  // column's log-weight of the NEE it has summed over its steps -- -0.5 ((sum_t nee[t] - pfObs) pfInvSigma)^2 in the
+  // arithmetic of pf.hip's logWeightOf, -inf for a member that did not run -- and the maximum of each workgroup's 64
+  // columns: the analysis then starts at its second phase (no pass over the plane, one grid barrier less)
+  double* pfLogw;         // [ncol] or null
+  double* pfBlockMax;     // [workgroups of the launch]
+  double pfObs, pfInvSigma;
 };
 // What a launcher actually put on the stream (sipnet_batch_last_launch): the instantiation's
 // name as rocprofv3 prints its template arguments, and the launch shape.

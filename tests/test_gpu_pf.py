@@ -324,3 +324,44 @@ def test_resampled_parameter_index_equals_moving_the_rows(base, clim, prec):
     np.testing.assert_allclose(a.get_state()[:, :13], c.get_state()[:, :13], rtol=1e-6 if prec == sa.F32_MIXED else 1e-11, atol=1e-9)
     a.close()
     c.close()
+
+
+@pytest.mark.parametrize("prec", [sa.F64, sa.F32_MIXED])
+def test_log_weights_from_the_forecast_launch_equal_the_analysis_own(base, clim, prec):
+    """sipnet_batch_pf_arm: the one-wave forecast kernel leaves the log-weights of its NEE sum; the analysis that follows
+    skips its first phase.  Log-weights, ancestors, total weight and the resampled state are bit-identical to the
+    unarmed cycle -- also with a member that did not run (-inf) and with members past the last full wavefront."""
+    M = 64 * 37 + 19
+    members = synth.perturbed_params(base, M, seed=11)
+    members[70, pi("leafAllocation")] = 0.9            # status 3: weight -inf
+    members[70, pi("woodAllocation")] = 0.9
+    res = {}
+    for armed in (False, True):
+        b = sa.Batch(sa.flags_from(), 1, M, prec, fast_math=True, kernel=sa.KERNEL_ONE_WAVE)
+        b.set_climate(0, clim)
+        b.set_params(0, members)
+        b.setup()
+        planes, _ = b.alloc_outputs(48)
+        out = []
+        for day in range(3):
+            obs, sigma = -0.02 * (day + 1), 0.3
+            if armed:
+                b.pf_arm(obs, sigma)
+            b.run(day * 48, 48, planes=planes)
+            tot = torch.zeros(1, dtype=torch.int64, device=planes.device)
+            anc, logw = b.pf_analysis_local(planes[0], obs, sigma, 0.37, with_params=True, total_out=tot)
+            out.append((anc.clone(), logw.clone(), tot.clone()))
+        # (an analysis with OTHER arguments than the armed ones falls back to its own first phase)
+        if armed:
+            b.pf_arm(1.0, 0.3)
+        b.run(3 * 48, 48, planes=planes)
+        anc, logw = b.pf_analysis_local(planes[0], 2.0, 0.3, 0.11, with_params=True)
+        out.append((anc.clone(), logw.clone(), None))
+        res[armed] = (out, b.get_state().copy(), b.get_rings().copy())
+        assert "stepFastKernel" in b.last_launch()["kernel"]
+        b.close()
+    for (a0, l0, t0), (a1, l1, t1) in zip(res[False][0], res[True][0]):
+        assert torch.equal(a0, a1) and torch.equal(l0.view(torch.int64), l1.view(torch.int64))
+        assert t0 is None or torch.equal(t0, t1)
+    assert torch.isinf(res[True][0][0][1][70])
+    assert np.array_equal(res[False][1], res[True][1], equal_nan=True) and np.array_equal(res[False][2], res[True][2], equal_nan=True)
