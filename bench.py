@@ -455,8 +455,12 @@ def main():
             k = pf_cycle[0] % pf_days
             if k == 0 and pf_cycle[0] > 0:
                 b.setup()
-            if not (distd and not plain):
-                b.pf_arm(pf_obs_k[k], pf_sigma_k[k])   # (the forecast's launch leaves the log-weights of its NEE sum too)
+            # (the forecast's launch leaves the log-weights of its NEE sum too: in the analysis' own buffer, or -- a connected
+            # filter -- in this rank's slice of the all-gather's)
+            if distd and not plain and pf_exchange == "peer":
+                sd.pf_arm_peers(b, pf_obs_k[k], pf_sigma_k[k], rank=rank, world=world)
+            elif not (distd and not plain):
+                b.pf_arm(pf_obs_k[k], pf_sigma_k[k])
             b.run(k * T, T, planes=planes)      # the time-fused step kernel
             slot = pf_totals[pf_cycle[0] % len(pf_totals):][:1]
             pf_cycle[0] += 1

@@ -302,6 +302,11 @@ class Batch:
                             t.empty(self.ncol, dtype=t.int32, device=self.device))
         check(self.L.sipnet_batch_pf_arm(self.h, float(obs), float(sigma), C.c_void_p(self._pf_buf[0].data_ptr())), "pf_arm")
 
+    def pf_arm_block(self, obs, sigma, block):
+        """the same for a connected filter: the next run() leaves the log-weights in `block` (this rank's slice of the
+        all-gather's buffer, pf_local_weights' target), which then only adds the block maxima"""
+        check(self.L.sipnet_batch_pf_arm(self.h, float(obs), float(sigma), C.c_void_p(block.data_ptr())), "pf_arm")
+
     def pf_analysis_local(self, plane, obs, sigma, u0, with_params=False, total_out=None):
         """log-weights -> systematic resampling -> resample, all particles in this batch, ONE library call
         (sipnet_batch_pf_analysis).  Returns (ancestors int32 [ncol], logw f64 [ncol]) on the device."""

@@ -156,6 +156,20 @@ __global__ __launch_bounds__(256) void logWeightKernel(const T* __restrict__ pla
     if (threadIdx.x == 0) part[blockIdx.x] = sm[0];
   }
 }
+// the same block (256-wide maxima behind the log-weights, -inf in the slots no particle fills) when the forecast's own launch
+// has left the log-weights in place and one maximum per 64 columns (FastArgs::pfLogw): four of those per entry
+__global__ __launch_bounds__(256) void blockFromWaveMaximaKernel(const double* __restrict__ waveMax, int64_t nWaves, int64_t ncol,
+                                                               int64_t npad, double* __restrict__ logw, double* __restrict__ part) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t nPart = (npad + 255) / 256;
+  if (i < nPart) {
+    double m = -INFINITY;
+    for (int k = 0; k < 4; k++)
+      if (4 * i + k < nWaves) m = fmax(m, waveMax[4 * i + k]);
+    part[i] = m;
+  }
+  if (ncol + i < npad) logw[ncol + i] = -INFINITY;
+}
 // (the scratch blocks are freed by sipnet_pf_release_scratch, not by a thread-exit destructor: that
 // may run after the HIP runtime has shut down)
 
@@ -1307,6 +1321,23 @@ int sipnet_batch_pf_local_weights(sipnet_batch* b, const void* d_plane, int32_t 
     return SIPNET_ERR_BAD_ARGUMENT;
   }
   const int64_t nmax = b->pfPeers ? b->pfPeers->nmax : b->ncol;
+  // the forecast's launch was told of this analysis (sipnet_batch_pf_arm with d_logw = this block) and has left the
+  // log-weights in it: only the 256-wide maxima and the empty slots remain (wavefront k covers columns 64 k .. 64 k + 63
+  // when the one site's members are a multiple of 64)
+  const sipnet_batch::PfPre& pre = b->pfPre;
+  const bool havePre = pre.valid && pre.plane == d_plane && pre.nSteps == n_steps && pre.ld == ld && pre.obs == obs &&
+                       pre.sigma == sigma && pre.d_logw == d_block && b->n_sites == 1 && b->ncol % 64 == 0 &&
+                       elem_is_f32 == (b->precision == SIPNET_F32_MIXED);
+  b->pfPre.valid = false;
+  if (havePre) {
+    int rc = useDevice(b);
+    if (rc) return rc;
+    const int64_t work = std::max<int64_t>((nmax + 255) / 256, nmax - b->ncol);
+    hipLaunchKernelGGL(blockFromWaveMaximaKernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream,
+                       b->d_pfPreMax, b->ncol / 64, b->ncol, nmax, d_block, d_block + nmax);
+    HIP_TRY(hipGetLastError());
+    return SIPNET_OK;
+  }
   return logWeights(b, d_plane, elem_is_f32, n_steps, ld, obs, sigma, d_block, d_block + nmax, hip_stream, nmax);
 }
 

@@ -246,6 +246,17 @@ def pf_connect_peers(batch, rank=0, world=1, group=None, with_params=True):
     batch.pf_connect(every, rank)
 
 
+def pf_arm_peers(batch, obs, sigma, rank=0, world=1):
+    """before the forecast's run() of a connected filter: that launch then leaves this rank's log-weights in its slice of
+    the all-gather's buffer (sipnet_batch_pf_arm), and pf_analysis_peers only adds the block maxima"""
+    import torch
+    L = batch.pf_block_len()
+    gathered = getattr(batch, "_pf_gathered", None)
+    if gathered is None or gathered.shape != (world, L):
+        gathered = batch._pf_gathered = torch.empty((world, L), dtype=torch.float64, device=batch.device)
+    batch.pf_arm_block(obs, sigma, gathered[rank])
+
+
 def pf_analysis_peers(batch, plane, obs, sigma, u0, rank=0, world=1, group=None, total_out=None,
                       collectives=None, gathered=None, ancestors=None, diagnostics=False):
     """One analysis step of a connected filter (pf_connect_peers): this rank's log-weight block -> ONE

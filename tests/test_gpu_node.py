@@ -391,6 +391,38 @@ def test_peer_resampling_of_an_unconnected_batch_is_the_one_call_analysis(base):
     b.close()
 
 
+@pytest.mark.parametrize("prec", [sa.F64, sa.F32_MIXED])
+def test_the_log_weight_block_from_the_forecast_launch_equals_the_kernel_of_its_own(base, prec):
+    """sipnet_batch_pf_arm with this rank's block as the target: the one-wave forecast leaves the log-weights there,
+    sipnet_batch_pf_local_weights adds the 256-wide maxima -- block, ancestors, total and resampled state as unarmed"""
+    T, n = 48, 64 * 41
+    clim = synth.convert_raw(synth.round_like_file(synth.half_hourly_year_raw(2 * T)))
+    members = synth.perturbed_params(base, n, seed=21)
+    from sipnet_amd.config import param_index as pi
+    members[100, pi("leafAllocation")] = 0.9           # status 3: -inf
+    members[100, pi("woodAllocation")] = 0.9
+    res = {}
+    for armed in (False, True):
+        b = sa.Batch(sa.flags_from(), 1, n, prec, fast_math=True, kernel=sa.KERNEL_ONE_WAVE)
+        b.set_climate(0, clim)
+        b.set_params(0, members)
+        b.setup()
+        planes, _ = b.alloc_outputs(T)
+        L = b.pf_block_len()
+        block = torch.full((1, L), 7.0, dtype=torch.float64, device=DEV)
+        if armed:
+            b.pf_arm_block(-0.03, 0.4, block[0])
+        b.run(0, T, planes=planes)
+        b.pf_local_weights(planes[0], -0.03, 0.4, block[0])
+        total = torch.zeros(1, dtype=torch.int64, device=DEV)
+        anc = b.pf_resample_peers(block, 0.61, total_out=total)
+        res[armed] = (block.clone(), anc.clone(), int(total.item()), b.get_state().copy(), b.get_rings().copy())
+        b.close()
+    assert torch.equal(res[False][0].view(torch.int64), res[True][0].view(torch.int64))
+    assert torch.equal(res[False][1], res[True][1]) and res[False][2] == res[True][2] > 0
+    assert np.array_equal(res[False][3], res[True][3], equal_nan=True) and np.array_equal(res[False][4], res[True][4], equal_nan=True)
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (one-GPU boxes run the shards on device 0)")
 def test_node_over_two_real_devices_equals_one_batch(base):
     """devices = [0, 1]: the thread-per-shard path, the grouped ncclAllGather over two communicators, ragged shards
