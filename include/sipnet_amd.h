@@ -592,6 +592,9 @@ int sipnet_node_setup(sipnet_node *nd);
 int sipnet_node_run(sipnet_node *nd, int32_t step0, int32_t n_steps);
 /* the same without the statistics (planes only: the forecast of a particle-filter cycle) */
 int sipnet_node_forecast(sipnet_node *nd, int32_t step0, int32_t n_steps);
+/* before a forecast whose NEE plane sipnet_node_pf_analysis(nd, 0, obs, sigma, ...) will weigh: every shard's forecast
+ * launch then leaves its log-weights in its slice of the all-gather's buffer itself (sipnet_batch_pf_arm).  A hint. */
+int sipnet_node_pf_arm(sipnet_node *nd, double obs, double sigma);
 int sipnet_node_sync(sipnet_node *nd);
 /* every member's status, status[n_sites][n_members] (HOST), after synchronising every shard's stream */
 int sipnet_node_get_status(sipnet_node *nd, int32_t *status);

@@ -158,6 +158,7 @@ SIGNATURES = {
     "sipnet_node_site_range": (C.c_int, [_P, C.c_int32, _I32P, _I32P]),
     "sipnet_node_stream": (_P, [_P, C.c_int32]),
     "sipnet_node_forecast": (C.c_int, [_P, C.c_int32, C.c_int32]),
+    "sipnet_node_pf_arm": (C.c_int, [_P, C.c_double, C.c_double]),
     "sipnet_node_get_status": (C.c_int, [_P, _P]),
     "sipnet_node_pf_connect": (C.c_int, [_P, C.c_int32]),
     "sipnet_node_pf_analysis": (C.c_int, [_P, C.c_int32, C.c_double, C.c_double, C.c_double]),

@@ -803,6 +803,20 @@ int sipnet_node_pf_connect(sipnet_node* nd, int32_t with_params) {
   return SIPNET_OK;
 }
 
+int sipnet_node_pf_arm(sipnet_node* nd, double obs, double sigma) {
+  if (!nd || !nd->pfConnected || !(sigma > 0)) {
+    setError("sipnet_node_pf_arm: needs sipnet_node_pf_connect and sigma > 0");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  // (host-only: every shard's next forecast launch is told where its log-weight block lies -- its slice of the all-gather's
+  // buffer -- and what it will be weighed against)
+  for (int k = 0; k < nd->n(); k++) {
+    int rc = sipnet_batch_pf_arm(nd->batches[k], obs, sigma, nd->pfGathered[k] + (size_t)k * nd->pfBlock);
+    if (rc) return rc;
+  }
+  return SIPNET_OK;
+}
+
 int sipnet_node_pf_analysis(sipnet_node* nd, int32_t variable, double obs, double sigma, double u0) {
   if (!nd || !nd->pfConnected || nd->nRun <= 0 || variable < 0 || variable > 2) {
     setError("sipnet_node_pf_analysis: needs sipnet_node_pf_connect and a forecast (sipnet_node_forecast / _run)");

@@ -200,6 +200,10 @@ class Node:
     def pf_connect(self, with_params=True):
         check(self.L.sipnet_node_pf_connect(self.h, int(with_params)), "node_pf_connect")
 
+    def pf_arm(self, obs, sigma):
+        """before forecast(): the shards' forecast launches leave their log-weight blocks themselves (sipnet_node_pf_arm)"""
+        check(self.L.sipnet_node_pf_arm(self.h, float(obs), float(sigma)), "node_pf_arm")
+
     def pf_analysis(self, variable, obs, sigma, u0):
         check(self.L.sipnet_node_pf_analysis(self.h, int(variable), float(obs), float(sigma), float(u0)), "node_pf_analysis")
 

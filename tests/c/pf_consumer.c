@@ -101,6 +101,7 @@ int main(int argc, char **argv) {
     double t0 = now_ms();
     for (int c = 0; c < cycles && !rc; c++) {
       rc = sipnet_node_setup(nd);
+      if (!rc) rc = sipnet_node_pf_arm(nd, obs, sigma);   /* (the forecast's launch leaves the log-weight block itself) */
       if (!rc) rc = sipnet_node_forecast(nd, 0, T);
       if (!rc) rc = sipnet_node_pf_analysis(nd, 0, obs, sigma, 0.5);
     }
@@ -113,6 +114,7 @@ int main(int argc, char **argv) {
     t0 = now_ms();
     for (int c = 0; c < cycles && !rc; c++) {
       rc = sipnet_batch_setup(b, NULL);
+      if (!rc) rc = sipnet_batch_pf_arm(b, obs, sigma, logw);
       if (!rc) rc = sipnet_batch_run(b, 0, T, nee, gpp, et, NULL, N, NULL);
       if (!rc) rc = sipnet_batch_pf_analysis(b, nee, 1, T, N, obs, sigma, 0.5, 1, logw, anc, totals + (c & 63), NULL);
     }

@@ -341,6 +341,7 @@ def test_node_filter_several_cycles_and_a_dead_filter(base):
     nd.setup()
     nd.pf_connect(with_params=True)
     for c in range(3):
+        nd.pf_arm(obs[c][0], obs[c][1])          # (a hint: these small shards take a cooperative kernel, which ignores it)
         nd.forecast(c * T, T)
         nd.pf_analysis(0, obs[c][0], obs[c][1], 0.1 + 0.3 * c)
     assert nd.pf_check() == 3
