@@ -74,3 +74,10 @@ def test_shard_pool_under_tsan_and_asan(san_build):
     for exe in ("shard_pool_tsan", "shard_pool_asan"):
         r = run_san(os.path.join(san_build, exe))
         assert r.returncode == 0 and "shard_pool: ok" in r.stdout, exe + ": " + (r.stdout + r.stderr)[-4000:]
+
+
+def test_plan_pool_under_tsan_and_asan(san_build):
+    """the plan threads (csrc/plan_pool.h): jobs of every shape from one caller and from four callers at once"""
+    for exe in ("plan_pool_tsan", "plan_pool_asan"):
+        r = run_san(os.path.join(san_build, exe))
+        assert r.returncode == 0 and "plan pool: ok" in r.stdout, exe + ": " + (r.stdout + r.stderr)[-4000:]
