@@ -68,6 +68,9 @@ def test_parsers_plan_builder_and_block_writer_under_asan_ubsan(san_build, tmp_p
     assert "no sanitizer finding" in r.stdout
     n_parsed = int(r.stdout.split("fuzz_host_io:")[1].split()[0])
     assert n_parsed > len(good)          # some mutants still parse (and went through the plan builder)
+    # the host's share of a device-built plan (buildSitePlanLight) was held against the full builder, resumed segments too
+    tail = r.stdout.split("light plan pass held against the full builder")[1]
+    assert int(tail.split()[0]) > 50 and "included: 1" in tail, tail[:120]
 
 
 def test_shard_pool_under_tsan_and_asan(san_build):

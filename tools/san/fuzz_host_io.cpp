@@ -100,6 +100,8 @@ static std::vector<double> g_params(SIPNET_NPARAMS, 1.0);
 static std::vector<sipnet_event> g_events;
 static long g_ok = 0, g_rejected = 0;
 
+static sipnet::PlanCarry g_carry;
+static long g_lightChecked = 0;
 static void planFrom(const sipnet_clim_table* t) {
   const int32_t n = sipnet_clim_nsteps(t);
   if (n <= 0 || n > 20000) return;
@@ -111,30 +113,39 @@ static void planFrom(const sipnet_clim_table* t) {
                                                (int32_t)g_events.size(), g_events.empty() ? nullptr : g_events.data(), nullptr, &fin,
                                                narrow == 0, narrow == 0 ? steps.data() : nullptr, fast.data(), narrow != 0);
     // the light pass a device-built plan gets from the host (plan_device.h) must say what the full builder says: the GDD
-    // chain and the tillage series bit for bit, the same events on the same records, the same verdict on the site
+    // chain and the tillage series bit for bit, the same events on the same records, the same verdict on the site -- for a
+    // fresh start and, once a checkpoint has been parsed, for a segment resumed from it
     if (narrow == 0) {
-      std::vector<double> gdd((size_t)n), dTill((size_t)n), tillAfter((size_t)n);
-      std::vector<int32_t> evFirst((size_t)n), evCount((size_t)n);
-      sipnet::PlanLight l = sipnet::buildSitePlanLight(g_flags, n, sipnet_clim_data(t), sipnet_clim_year(t), sipnet_clim_day(t),
-                                                       (int32_t)g_events.size(), g_events.empty() ? nullptr : g_events.data(), nullptr,
-                                                       0.0202, 48, gdd.data(), evFirst.data(), evCount.data(), dTill.data(), tillAfter.data());
-      bool same = (l.status == SIPNET_OK) == (p.status == SIPNET_OK);
-      if (same && p.status == SIPNET_OK) {
-        same = memcmp(gdd.data(), p.gddAfter.data(), (size_t)n * sizeof(double)) == 0 && l.events.size() == p.events.size() &&
-               (l.events.empty() || memcmp(l.events.data(), p.events.data(), l.events.size() * sizeof(sipnet::EvRec)) == 0) &&
-               memcmp(&l.startCumGdd, &p.startCumGdd, sizeof(double)) == 0 && memcmp(&l.startDayTime, &p.startDayTime, sizeof(double)) == 0;
-        for (int k = 0; same && k < n; k++) {
-          const sipnet::StepRec& sr = steps[(size_t)k];
-          if (l.hasEvents)
-            same = evFirst[(size_t)k] == sr.evFirst && evCount[(size_t)k] == sr.evCount &&
-                   memcmp(&dTill[(size_t)k], &sr.dTill, sizeof(double)) == 0 && memcmp(&tillAfter[(size_t)k], &sr.tillAfter, sizeof(double)) == 0;
-          else
-            same = sr.evCount == 0 && sr.dTill == 0.0 && sr.tillAfter == 0.0;
+      for (int resumed = 0; resumed < (g_carry.set ? 2 : 1); resumed++) {
+        const sipnet::PlanCarry* init = resumed ? &g_carry : nullptr;
+        sipnet::SitePlan pf = p;
+        if (resumed)
+          pf = sipnet::buildSitePlan(g_flags, n, sipnet_clim_data(t), sipnet_clim_year(t), sipnet_clim_day(t), (int32_t)g_events.size(),
+                                     g_events.empty() ? nullptr : g_events.data(), init, nullptr, true, steps.data(), nullptr, false);
+        std::vector<double> gdd((size_t)n), dTill((size_t)n), tillAfter((size_t)n);
+        std::vector<int32_t> evFirst((size_t)n), evCount((size_t)n);
+        sipnet::PlanLight l = sipnet::buildSitePlanLight(g_flags, n, sipnet_clim_data(t), sipnet_clim_year(t), sipnet_clim_day(t),
+                                                         (int32_t)g_events.size(), g_events.empty() ? nullptr : g_events.data(), init,
+                                                         0.0202, 48, gdd.data(), evFirst.data(), evCount.data(), dTill.data(), tillAfter.data());
+        bool same = (l.status == SIPNET_OK) == (pf.status == SIPNET_OK);
+        if (same && pf.status == SIPNET_OK) {
+          same = memcmp(gdd.data(), pf.gddAfter.data(), (size_t)n * sizeof(double)) == 0 && l.events.size() == pf.events.size() &&
+                 (l.events.empty() || memcmp(l.events.data(), pf.events.data(), l.events.size() * sizeof(sipnet::EvRec)) == 0) &&
+                 memcmp(&l.startCumGdd, &pf.startCumGdd, sizeof(double)) == 0 && memcmp(&l.startDayTime, &pf.startDayTime, sizeof(double)) == 0;
+          for (int k = 0; same && k < n; k++) {
+            const sipnet::StepRec& sr = steps[(size_t)k];
+            if (l.hasEvents)
+              same = evFirst[(size_t)k] == sr.evFirst && evCount[(size_t)k] == sr.evCount &&
+                     memcmp(&dTill[(size_t)k], &sr.dTill, sizeof(double)) == 0 && memcmp(&tillAfter[(size_t)k], &sr.tillAfter, sizeof(double)) == 0;
+            else
+              same = sr.evCount == 0 && sr.dTill == 0.0 && sr.tillAfter == 0.0;
+          }
         }
-      }
-      if (!same) {
-        fprintf(stderr, "buildSitePlanLight disagrees with buildSitePlan (status %d vs %d)\n", l.status, p.status);
-        abort();
+        if (!same) {
+          fprintf(stderr, "buildSitePlanLight disagrees with buildSitePlan (status %d vs %d, resumed %d)\n", l.status, pf.status, resumed);
+          abort();
+        }
+        g_lightChecked++;
       }
     }
   }
@@ -166,6 +177,23 @@ static void parse(const std::string& kind, const std::string& path) {
       (void)sipnet_restart_check(&r, g_flags, 1, r.boundary_year, r.boundary_day + 1, 0.0, 0.5, &warn);
       (void)sipnet_restart_check_boundary_for_write(&r, &warn);
       (void)sipnet_io_write_restart((path + ".rewritten").c_str(), &r);
+      // what sipnet_batch_set_resume keeps of it for the site plan (engine.hip): the plans of the forcings that follow are
+      // also built as resumed segments
+      if (r.mean_length == SIPNET_RING_SLOTS && r.mean_start >= 0 && r.mean_start < SIPNET_RING_SLOTS && r.mean_last >= 0 &&
+          r.mean_last < SIPNET_RING_SLOTS) {
+        g_carry = sipnet::PlanCarry{};
+        g_carry.set = true;
+        g_carry.gdd = r.trackers[SIPNET_RT_GDD];
+        g_carry.trackLastYear = r.trackers_last_year;
+        g_carry.phenLastYear = r.phenology_last_year;
+        g_carry.dTill = r.d_till_mod;
+        g_carry.ring.start = r.mean_start;
+        g_carry.ring.last = r.mean_last;
+        for (int i = 0; i < SIPNET_RING_SLOTS; i++) {
+          g_carry.ring.w[i] = r.mean_weights[i];
+          g_carry.ring.insStep[i] = 0;
+        }
+      }
     }
   }
   (rc == 0 ? g_ok : g_rejected)++;
@@ -214,5 +242,6 @@ int main(int argc, char** argv) {
     }
   }
   printf("fuzz_host_io: %ld inputs parsed, %ld rejected, no sanitizer finding\n", g_ok, g_rejected);
+  printf("light plan pass held against the full builder %ld times (resumed segments included: %d)\n", g_lightChecked, g_carry.set ? 1 : 0);
   return 0;
 }
