@@ -2,7 +2,8 @@
 """bench.py -- ensemble-site-timesteps/s of the batched SIPNET step loop on MI355X.
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W
-  N>1 is launched by torch.distributed.run, one rank per GPU.  One "step" = one pass
+  N>1: one rank per GPU under torch.distributed.run -- started by the driver, or, when the command is given
+  without a launcher (no WORLD_SIZE in the environment), by bench.py itself as a child process (launch_ranks).  One "step" = one pass
   of the hot path over the whole batch: per-member setup + the time-fused step kernel
   over every timestep of the forcing + (N>1) the ensemble statistics (summed inside the
   step kernel's launch) and the RCCL all-gather of the NEE/GPP/ET statistics block.  Inputs (parameters, site plan)
@@ -241,6 +242,30 @@ def fill_probe(sa, synth, flags, base, prec_name, device):
             "kernel_ms": min(ms), "waves_per_simd": li["waves_per_simd"]}
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher in front: start the N ranks ourselves, exactly as the driver's
+    N > 1 command does (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py <same arguments>`), as a CHILD process -- this process has neither imported torch nor
+    touched HIP, and it never replaces itself (an exec from a process that has initialised the GPU takes the machine
+    down on this pool).  The child inherits stdout, so rank 0's one JSON line is this command's one JSON line; the
+    return code is the child's.  The reference's model is one run = one process (frontend.c:130-253): the launcher
+    multiplies that."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:      # a free rendezvous port
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC: RCCL and the peer-mapped checkpoints need it
+    env.setdefault("OMP_NUM_THREADS", "1")               # (what torch.distributed.run would set, without its warning)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    try:
+        return subprocess.call(cmd, env=env)
+    except KeyboardInterrupt:
+        return 130
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -270,7 +295,32 @@ def main():
     ap.add_argument("--rehearse", action="store_true",
                     help="development: run the N>1 path on ONE GPU (all ranks share device 0, gloo "
                          "collectives through host copies); the numbers mean nothing")
+    ap.add_argument("--pretend-world", type=int, default=0,
+                    help="c5 with --force-dist on ONE rank: run the exchange path at the slot count of a filter of this "
+                         "many ranks (the batch connected to a world whose every member is itself: weights, prefix sum and "
+                         "ancestors over P x 131 072 slots, the gather reading 'peers' that are local) -- what an 8-GPU "
+                         "cycle costs apart from the links' own time")
+    ap.add_argument("--launch-probe", action="store_true",
+                    help="development / CPU test: only check that the N ranks come up and can talk (gloo, no GPU "
+                         "touched): rank 0 prints {\"launch_probe\": true, \"ranks_seen\": N}")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as plain `python bench.py --gpus N`: be our own launcher
+        sys.exit(launch_ranks(args.gpus))
+    if args.launch_probe:
+        import torch
+        import torch.distributed as dist
+        if "WORLD_SIZE" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+        dist.init_process_group("gloo")
+        got = [None] * dist.get_world_size()
+        dist.all_gather_object(got, (dist.get_rank(), os.getpid()))
+        if dist.get_rank() == 0:
+            print(json.dumps({"launch_probe": True, "n_gpus": args.gpus, "ranks_seen": len({r for r, _ in got}),
+                              "processes_seen": len({p for _, p in got})}), flush=True)
+        dist.destroy_process_group()
+        return
 
     wl = dict(WORKLOADS[args.workload])
     if args.members:
@@ -282,7 +332,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
-        print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run (WORLD_SIZE={world})",
+        print(f"bench.py: --gpus {args.gpus} under a launcher that started {world} ranks (WORLD_SIZE={world})",
               file=sys.stderr)
         sys.exit(2)
 
@@ -411,10 +461,11 @@ def main():
             pf_obs_k.append(float(tot.median()))
             pf_sigma_k.append(float(tot.std()) * 1.5 + 1e-12)
         b.setup()
+        pretend = args.pretend_world if (distd and world == 1 and args.pf_exchange == "peer") else 0
         pf_exchange = args.pf_exchange if distd else "n/a (1 GPU)"
         if distd and args.pf_exchange == "peer":
             try:    # once per filter, off the cycle: publish / map the checkpoint matrices of every rank
-                sd.pf_connect_peers(b, rank, world, with_params=True)
+                sd.pf_connect_peers(b, rank, world, with_params=True, pretend_world=pretend)
             except Exception as e:   # (no IPC between these processes: the all-to-all path is the other product path)
                 pf_exchange = f"alltoall (peer mapping failed: {e!r})"
             if world > 1:            # every rank takes the same path
@@ -458,7 +509,7 @@ def main():
             # (the forecast's launch leaves the log-weights of its NEE sum too: in the analysis' own buffer, or -- a connected
             # filter -- in this rank's slice of the all-gather's)
             if distd and not plain and pf_exchange == "peer":
-                sd.pf_arm_peers(b, pf_obs_k[k], pf_sigma_k[k], rank=rank, world=world)
+                sd.pf_arm_peers(b, pf_obs_k[k], pf_sigma_k[k], rank=rank, world=world, pretend_world=pretend)
             elif not (distd and not plain):
                 b.pf_arm(pf_obs_k[k], pf_sigma_k[k])
             b.run(k * T, T, planes=planes)      # the time-fused step kernel
@@ -466,7 +517,7 @@ def main():
             pf_cycle[0] += 1
             if distd and not plain and pf_exchange == "peer":
                 _, info = sd.pf_analysis_peers(b, planes[0], pf_obs_k[k], pf_sigma_k[k], 0.5, rank=rank, world=world,
-                                               total_out=slot, collectives=True, diagnostics=record)
+                                               total_out=slot, collectives=True, diagnostics=record, pretend_world=pretend)
                 if record:
                     pf_info.update(info)
                 return
@@ -505,8 +556,15 @@ def main():
         one_pass(False)
     barrier()
     dt = time.perf_counter() - t0
+    if pf and bool((pf_totals == sa.PF_VOID_TOTAL).any()):
+        raise RuntimeError("particle filter: an analysis kernel gave up at its grid barrier (not co-resident): the cycle is void")
     if pf and not bool((pf_totals > 0).all()):
         raise RuntimeError("particle filter: a cycle ended with every particle at zero weight")
+    if pf:
+        pi_ = b.pf_info()       # what the exchange says about itself (sipnet_batch_pf_info)
+        pf_info.update({"pretend_world": pretend, "analysis_one_launch": pi_["fused"], "analysis_grid": pi_["grid"],
+                        "analysis_budget": pi_["budget"], "analysis_slots": pi_["n_slots"], "params_by_index": pi_["params_by_index"],
+                        "crossing_per_cycle": (pi_["crossing"] / pi_["cycles"]) if pi_["cycles"] else None})
     if distd:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.rehearse else b.device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -569,7 +627,8 @@ def main():
             barrier()
             e0.record()
             if distd and pf_exchange == "peer":
-                sd.pf_analysis_peers(b, planes[0], pf_obs, pf_sigma, 0.5, rank=rank, world=world, collectives=True)
+                sd.pf_analysis_peers(b, planes[0], pf_obs, pf_sigma, 0.5, rank=rank, world=world, collectives=True,
+                                     pretend_world=pretend)
             else:
                 sd.pf_analysis(b, planes[0], pf_obs, pf_sigma, u0=0.5, rank=rank, world=world, with_params=True,
                                diagnostics=False, collectives=distd)

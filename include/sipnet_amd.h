@@ -291,6 +291,14 @@ enum sipnet_kernel_option {
                                         long runs -- the default leaves such a forcing (half-daily niwot) to the host, whose
                                         cores walk the ring's schedule ~8 x faster than the one lane that has to on the
                                         device (tests use this) */
+  SIPNET_KOPT_PF_MULTI_LAUNCH = 512, /* particle filter: the analysis as separate launches (log-weights | fixed-point weights |
+                                        prefix sum | ancestors), never the one-launch kernel whose workgroups spin at barriers
+                                        in device memory.  Chosen without being asked when fewer than 8 such workgroups could
+                                        be resident (sipnet_batch_set_device_share, a sliver of a partitioned device) */
+  SIPNET_KOPT_PF_MOVE_PARAMS = 1024, /* particle filter across ranks, particles carrying their parameters: move the 640 bytes
+                                        of converted parameter rows with every resampled particle (round 5) instead of
+                                        replicating all ranks' parameters once at sipnet_batch_pf_connect and moving a 4-byte
+                                        index (the default: 80 x 8 bytes x all ranks' particles of HBM per rank) */
   SIPNET_KOPT_FULL_STATE = 4         /* throughput kernels: advance EVERY accumulator of the restart
                                         schema (trackers.tot*, trackers.yearly*); without it only
                                         totNee / totGpp advance on the throughput path.  Implied by a
@@ -514,15 +522,47 @@ typedef struct sipnet_pf_peer {
   int32_t device, n_particles, precision, with_params;
   int32_t ipc_valid;         /* 0: hipIpcGetMemHandle failed (peers in the same process do not need it) */
   int32_t generic_exponents; /* some particle's parameters need the general-exponent kernel variant */
-  uint64_t address[6];       /* state, spare state, ring, spare ring, parameters, spare parameters */
-  unsigned char ipc[6][64];  /* hipIpcMemHandle_t of the same six allocations */
+  int32_t params_by_index;   /* with_params: every rank will hold ALL ranks' parameters and particles carry an index (default);
+                                0 with SIPNET_KOPT_PF_MOVE_PARAMS: the rows travel with every resampled particle */
+  int32_t reserved;
+  uint64_t address[8];       /* state, spare state, ring, spare ring, parameters, spare parameters, parameter index, its spare */
+  unsigned char ipc[8][64];  /* hipIpcMemHandle_t of the same eight allocations */
 } sipnet_pf_peer;
 /* Allocate the spare buffers and describe this batch's matrices; with_params: particles carry their
  * (converted) parameters.  Exchange the descriptors by any means (they are plain bytes), then ... */
 int sipnet_batch_pf_publish(sipnet_batch *b, int32_t with_params, sipnet_pf_peer *out);
 /* ... connect: peers[world] in rank order, peers[rank] this batch's own.  Once connected, resample only
- * through sipnet_batch_pf_resample_peers (or sipnet_batch_resample on EVERY rank in the same cycle). */
+ * through sipnet_batch_pf_resample_peers (or sipnet_batch_resample on EVERY rank in the same cycle).
+ * with_params (and no SIPNET_KOPT_PF_MOVE_PARAMS): connect copies every rank's converted parameters into a bank on THIS
+ * rank, [SIPNET_NPARAMS][world x nmax] doubles (0.67 GB at 8 x 131 072 particles), once; from then on a particle carries
+ * its column in that bank (4 bytes) instead of its 640 bytes of rows, across ranks as inside one batch, and every
+ * forecast reads its parameters from local HBM.  Parameters are constants of a particle: sipnet_batch_set_params on a
+ * connected batch (or a sipnet_batch_resample that moves rows) makes the next sipnet_batch_pf_resample_peers fail with
+ * SIPNET_ERR_BAD_ARGUMENT until every rank has published and connected again. */
 int sipnet_batch_pf_connect(sipnet_batch *b, int32_t world, int32_t rank, const sipnet_pf_peer *peers);
+/* How many filters may run their analysis on this batch's DEVICE at the same time (default 1; a node sets its shards per
+ * device).  The one-launch analysis keeps every workgroup resident and spinning at barriers in device memory, so its grid
+ * is sized to the device's capacity (hipOccupancyMaxActiveBlocksPerMultiprocessor x compute units) / n_filters, at most
+ * 512; below 8 workgroups the analysis runs as separate launches instead.  A grid that is not co-resident after all (a
+ * share that was promised and not kept) does not hang: a barrier that waits longer than ~0.3 s gives up, the launch's
+ * total weight reads INT64_MIN and the next synchronising call (sipnet_batch_pf_analysis without d_total,
+ * sipnet_node_pf_check) answers SIPNET_ERR_INTERNAL; later launches are not affected. */
+int sipnet_batch_set_device_share(sipnet_batch *b, int32_t n_filters);
+#define SIPNET_PF_VOID_TOTAL INT64_MIN   /* *d_total of an analysis whose grid barrier gave up */
+/* What the last analysis of this batch did and what its exchange has moved (synchronises hip_stream for `crossing`). */
+typedef struct sipnet_pf_info {
+  int32_t fused;           /* 1: the one-launch kernel (pfFusedKernel), 0: separate launches */
+  int32_t grid;            /* its workgroups (0 when not fused) */
+  int32_t budget;          /* workgroups the device share allowed */
+  int32_t world;           /* ranks of the connection (1: not connected) */
+  int64_t n_slots;         /* weight slots the last cross-rank analysis went over (world x nmax) */
+  int64_t cycles;          /* sipnet_batch_pf_resample_peers calls since sipnet_batch_pf_connect */
+  int64_t crossing;        /* particles of THIS rank copied from ANOTHER rank's slot in those cycles: each is one checkpoint
+                              (state 256 B + ring 1 000 / 2 000 B + 4 B of index, or + 640 B of rows) read over xGMI */
+  int32_t params_by_index; /* 1: all ranks' parameters are replicated here, particles carry an index */
+  int32_t device_share;    /* sipnet_batch_set_device_share */
+} sipnet_pf_info;
+int sipnet_batch_pf_info(sipnet_batch *b, sipnet_pf_info *out, void *hip_stream);
 /* doubles per rank in the gathered buffer: nmax + ceil(nmax / 256) */
 int64_t sipnet_batch_pf_block_len(const sipnet_batch *b);
 /* sipnet_batch_pf_log_weights into this rank's block d_block[sipnet_batch_pf_block_len] (DEVICE) */
@@ -691,11 +731,18 @@ const char *sipnet_batch_last_kernel_name(sipnet_batch *b); /* "" before the fir
 
 /* Test hook: the per-step records and ring evictions the device built for `site` against the host builder's, byte by
  * byte (ignore_log2: leaving out the log2(vpd) field, which the device path fills only once a member with dVpdExp != 2
- * exists).  device_info[8]: run descriptors, evictions written, status (0 ok), the step of a non-zero status, 10-ns ticks of
+ * exists).  device_info[8]: run descriptors, evictions written, status (0 ok; 3: the eviction list ran out of room), the step of a non-zero status, 10-ns ticks of
  * the ring walk and of the GDD walk, two spare. */
 int sipnet_debug_plan_compare(sipnet_batch *b, int32_t site, int32_t ignore_log2, int64_t *n_records_differing,
                               int64_t *n_ops_differing, int32_t *first_step, int32_t *first_offset,
                               int32_t *device_info);
+/* Test hooks.  sipnet_debug_set_num_cus: pretend the device has this many compute units (the kernel choice of
+ * SIPNET_KERNEL_AUTO and the particle filter's resident-grid budget follow it: 32 = one partition of a CPX-mode MI355X).
+ * sipnet_debug_pf_barrier: polls a barrier of the one-launch analysis waits before it gives up (0: the default, ~0.3 s), and
+ * a workgroup of the NEXT such launch that leaves without arriving (-1: none) -- the test of the "grid not co-resident"
+ * path without having to produce one. */
+int sipnet_debug_set_num_cus(sipnet_batch *b, int32_t num_cus);
+int sipnet_debug_pf_barrier(sipnet_batch *b, int32_t spin_budget, int32_t absent_workgroup);
 
 /* Device buffer helpers for callers without their own allocator (the CLI). */
 void *sipnet_dev_alloc(size_t bytes);

@@ -8,7 +8,8 @@ torch.distributed; all model arithmetic runs in hand-written HIP kernels
 """
 from ._lib import (KERNEL_AUTO, KERNEL_COOP_HBM, KERNEL_COOP_LDS, KERNEL_COOP_PAIR, KERNEL_COOP_QUAD, KERNEL_COOP_NCYCLE, KERNEL_COOP_NCYCLE_PAIR, KERNEL_ONE_WAVE, KERNEL_STRICT,
                    KOPT_FULL_STATE, KOPT_NO_REGULAR_TILES, KOPT_ONE_WAVE_PER_SIMD, KOPT_RUNTIME_FLAGS,
-                   KOPT_STATS_IN_KERNEL, KOPT_BOUNDED_WAITS, KOPT_WAIT_SELFTEST, KOPT_HOST_PLAN, KOPT_DEVICE_PLAN)
+                   KOPT_STATS_IN_KERNEL, KOPT_BOUNDED_WAITS, KOPT_WAIT_SELFTEST, KOPT_HOST_PLAN, KOPT_DEVICE_PLAN,
+                   KOPT_PF_MULTI_LAUNCH, KOPT_PF_MOVE_PARAMS, PF_VOID_TOTAL)
 from ._lib import (F32_MIXED, F64, NCLIM, NFLAGS, NPARAMS, NREC, NSTATE, RING_SLOTS,
                    Event, Restart, SipnetError, lib)
 from .config import (DEFAULT_FLAGS, FLAG_NAMES, PARAM_NAMES, flags_from, read_config)
@@ -23,6 +24,6 @@ __all__ = [
     "read_events", "write_out", "write_events_out", "write_debug_logs", "format_out_header", "format_out_row", "read_config",
     "flags_from", "FLAG_NAMES", "DEFAULT_FLAGS", "PARAM_NAMES", "F64", "F32_MIXED",
     "KERNEL_AUTO", "KERNEL_ONE_WAVE", "KERNEL_COOP_LDS", "KERNEL_COOP_HBM", "KERNEL_COOP_PAIR", "KERNEL_COOP_QUAD", "KERNEL_COOP_NCYCLE", "KERNEL_COOP_NCYCLE_PAIR", "KERNEL_STRICT",
-    "KOPT_ONE_WAVE_PER_SIMD", "KOPT_RUNTIME_FLAGS", "KOPT_FULL_STATE", "KOPT_NO_REGULAR_TILES", "KOPT_STATS_IN_KERNEL", "KOPT_BOUNDED_WAITS", "KOPT_WAIT_SELFTEST", "KOPT_HOST_PLAN", "KOPT_DEVICE_PLAN",
+    "KOPT_ONE_WAVE_PER_SIMD", "KOPT_RUNTIME_FLAGS", "KOPT_FULL_STATE", "KOPT_NO_REGULAR_TILES", "KOPT_STATS_IN_KERNEL", "KOPT_BOUNDED_WAITS", "KOPT_WAIT_SELFTEST", "KOPT_HOST_PLAN", "KOPT_DEVICE_PLAN", "KOPT_PF_MULTI_LAUNCH", "KOPT_PF_MOVE_PARAMS", "PF_VOID_TOTAL",
     "NPARAMS", "NFLAGS", "NCLIM", "NREC", "NSTATE", "RING_SLOTS",
 ]

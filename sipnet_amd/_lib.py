@@ -36,6 +36,8 @@ KOPT_BOUNDED_WAITS = 32
 KOPT_WAIT_SELFTEST = 64
 KOPT_DEVICE_PLAN = 256   # device plan for every site that can have one, whatever its step lengths (tests)
 KOPT_HOST_PLAN = 128     # every site plan on host threads (default: eligible sites on the device, csrc/plan_device.h)
+KOPT_PF_MULTI_LAUNCH = 512   # particle filter: the analysis as separate launches, never the one-launch kernel
+KOPT_PF_MOVE_PARAMS = 1024   # particle filter across ranks: parameter rows travel with the particles (no replicated bank)
 SHARD_MEMBERS, SHARD_SITES = 0, 1
 ALL_SITES = -1
 
@@ -96,7 +98,18 @@ class PfPeer(C.Structure):
     exchange it with all_gather_object / any byte channel)"""
     _fields_ = [("process_id", C.c_int64), ("device", C.c_int32), ("n_particles", C.c_int32),
                 ("precision", C.c_int32), ("with_params", C.c_int32), ("ipc_valid", C.c_int32),
-                ("generic_exponents", C.c_int32), ("address", C.c_uint64 * 6), ("ipc", (C.c_ubyte * 64) * 6)]
+                ("generic_exponents", C.c_int32), ("params_by_index", C.c_int32), ("reserved", C.c_int32),
+                ("address", C.c_uint64 * 8), ("ipc", (C.c_ubyte * 64) * 8)]
+
+
+class PfInfo(C.Structure):
+    """struct sipnet_pf_info: what the last particle-filter analysis did, what the exchange has moved"""
+    _fields_ = [("fused", C.c_int32), ("grid", C.c_int32), ("budget", C.c_int32), ("world", C.c_int32),
+                ("n_slots", C.c_int64), ("cycles", C.c_int64), ("crossing", C.c_int64),
+                ("params_by_index", C.c_int32), ("device_share", C.c_int32)]
+
+
+PF_VOID_TOTAL = -(1 << 63)
 
 
 RESTART_WARN_BOUNDARY_NOT_MIDNIGHT, RESTART_WARN_BUILD_INFO, RESTART_WARN_TIME_GAP = 1, 2, 4
@@ -202,6 +215,10 @@ SIGNATURES = {
     "sipnet_dev_to_dev_2d": (C.c_int, [_P, C.c_size_t, _P, C.c_size_t, C.c_size_t, C.c_size_t, _P]),
     "sipnet_batch_set_climate_sites": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P]),
     "sipnet_debug_plan_compare": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
+    "sipnet_debug_set_num_cus": (C.c_int, [_P, C.c_int32]),
+    "sipnet_debug_pf_barrier": (C.c_int, [_P, C.c_int32, C.c_int32]),
+    "sipnet_batch_set_device_share": (C.c_int, [_P, C.c_int32]),
+    "sipnet_batch_pf_info": (C.c_int, [_P, _P, _P]),
     "sipnet_stream_sync": (C.c_int, [_P]),
     "sipnet_stream_create": (_P, [C.c_int32]),
     "sipnet_stream_destroy": (None, [_P]),

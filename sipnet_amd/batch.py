@@ -340,6 +340,27 @@ class Batch:
     def pf_block_len(self):
         return int(self.L.sipnet_batch_pf_block_len(self.h))
 
+    def pf_info(self):
+        """sipnet_batch_pf_info: what the last analysis did (one launch or several, its grid, the resident-workgroup
+        budget) and how many of this rank's particles have crossed ranks since pf_connect (synchronises the stream)"""
+        from ._lib import PfInfo
+        d = PfInfo()
+        check(self.L.sipnet_batch_pf_info(self.h, C.byref(d), self._stream()), "pf_info")
+        return {k: getattr(d, k) for k, _ in PfInfo._fields_}
+
+    def debug_set_num_cus(self, n):
+        """test hook: pretend the device has n compute units (32 = one partition of a CPX-mode MI355X)"""
+        check(self.L.sipnet_debug_set_num_cus(self.h, int(n)), "debug_set_num_cus")
+
+    def debug_pf_barrier(self, spin_budget=0, absent_workgroup=-1):
+        """test hook: the poll budget of the one-launch analysis' barriers, and a workgroup of the NEXT such launch that
+        leaves without arriving (the "grid not co-resident" path)"""
+        check(self.L.sipnet_debug_pf_barrier(self.h, int(spin_budget), int(absent_workgroup)), "debug_pf_barrier")
+
+    def set_device_share(self, n_filters):
+        """sipnet_batch_set_device_share: how many filters analyse on this device at the same time"""
+        check(self.L.sipnet_batch_set_device_share(self.h, int(n_filters)), "set_device_share")
+
     def pf_local_weights(self, plane, obs, sigma, block):
         """this rank's block [nmax log-weights | block maxima] of the all-gather, into `block` (f64 device
         tensor of pf_block_len() entries, e.g. this rank's slice of the gathered buffer)"""

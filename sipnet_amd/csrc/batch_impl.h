@@ -116,6 +116,21 @@ struct sipnet_batch {
   int32_t* d_prmId = nullptr;
   int32_t* d_prmId2 = nullptr;
   bool prmIndexed = false;
+  // A filter spread over ranks whose particles carry their parameters (round 6): every rank holds a copy of ALL ranks'
+  // converted parameters, [NPARAMS][world * nmax] (slot = rank * nmax + particle; sipnet_batch_pf_connect fills it once
+  // from the peers' blocks), and a particle's d_prmId is such a slot for as long as the connection lasts -- a resampling
+  // across ranks moves 4 bytes of index per particle instead of 640 bytes of rows, and the forecast reads local HBM.
+  // While d_prmBank is set, d_prmId / d_prmId2 are always maintained (peers read them); prmIndexed then only says that
+  // d_prm, the column-order copy every kernel but the one-wave kernel reads, is behind the index.
+  double* d_prmBank = nullptr;
+  int64_t prmBankPitch = 0;
+  // how many filters may run their one-launch analysis on this device at the same time (a node's shards on one device):
+  // the spinning grid is sized to 1 / deviceShare of what the device holds (pf.hip fusedBudget)
+  int32_t deviceShare = 1;
+  int32_t pfSpinBudget = 0;      // polls a barrier waits before it declares the launch void (0: SIPNET_PF_SPIN_BUDGET)
+  int32_t pfDebugAbsent = -1;    // test hook: this workgroup of the NEXT fused launch leaves without arriving
+  struct PfInfo { int32_t fused = 0, grid = 0, budget = 0; int64_t nSlots = 0, cycles = 0; } pfInfo;
+  unsigned long long* d_pfCrossing = nullptr;   // particles this rank has copied from ANOTHER rank's slot, all cycles
   double* d_state2 = nullptr;
   double* d_ring2 = nullptr;
   StepRec* d_plan = nullptr;   // [n_sites][n_steps]
@@ -176,6 +191,7 @@ struct sipnet_batch {
 };
 int flushParams(sipnet_batch* b, hipStream_t stream);   // engine.hip: upload + convert what set_params left pending
 int materializeParams(sipnet_batch* b, hipStream_t stream);   // pf.hip: d_prm back into column order (no-op unless prmIndexed)
+void pfDropBank(sipnet_batch* b);   // pf.hip: a connected filter's bank of all ranks' parameters is void (new parameters, moved rows)
 
 // "This batch has work in flight on `stream`."  The event itself is recorded only when somebody needs it (a wait from
 // another stream, a host-side wait or query): work queued later on the SAME stream is ordered behind it anyway, and an

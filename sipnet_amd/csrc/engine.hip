@@ -171,6 +171,15 @@ static bool devicePrepass(sipnet_batch* b, int32_t s, PlanLight* out) {
     for (int i = (r.start + 1) % SIPNET_RING_SLOTS; i != (r.last + 1) % SIPNET_RING_SLOTS && r.start != r.last; i = (i + 1) % SIPNET_RING_SLOTS)
       if (!(r.w[i] >= kDevPlanMinLen)) return false;
     if (!(r.w[r.start] > 0)) return false;
+    // ... and together they carry the 5-day window: a ring that holds more reaches the reference's "ring full" stop
+    // (runmean.c:93-95), one that holds less runs empty -- the host builder reports the first and walks the second as the
+    // reference does; the device walk is only handed rings it cannot leave (its status word is a debugging aid)
+    double sum = 0.0;
+    for (int i = r.start;; i = (i + 1) % SIPNET_RING_SLOTS) {
+      sum += r.w[i];
+      if (i == r.last) break;
+    }
+    if (!(std::fabs(sum - 5.0) <= 1e-9)) return false;
   }
   return out->walked <= kDevPlanMaxWalked || (b->kernelOptions & SIPNET_KOPT_DEVICE_PLAN);
 }
@@ -261,6 +270,13 @@ static int buildAndUpload(sipnet_batch* b, bool fastType, bool first, hipStream_
                                  ((size_t)nT + (s2 == nS - 1 ? kFastTile : 0)) * sizeof(FastRec), hipMemcpyHostToDevice, b->upStream));
     }
   }
+  if (deferCopies && !anyHostSite) {
+    // every site is the device's (SIPNET_KOPT_DEVICE_PLAN forced while the previous launch still runs): nothing above has
+    // waited for that launch, and the copy stream is about to overwrite what it reads -- the tile padding here, the site
+    // bases / status / starts / events in uploadPlan.  A device-side wait: the host does not stop.
+    rc = orderBehindBusy(b, b->upStream);
+    if (rc) return rc;
+  }
   // the tile padding behind the last site, when that one is the device's
   if (devPass && b->devSite[nS - 1]) HIP_TRY(hipMemsetAsync(b->d_fast + (size_t)nS * nT, 0, kFastTile * sizeof(FastRec), b->upStream));
   TRACE_T("plan: sites built, copies enqueued");
@@ -305,6 +321,16 @@ static int fillDeviceLog2(sipnet_batch* b, hipStream_t stream) {
   b->devLog2Done = true;
   return markBusy(b, stream);
 }
+
+// Room for a device-built site's eviction list.  Every eviction either removes a whole entry (at most one per entry that ever
+// lived: the n inserted ones + the preK a checkpoint's ring starts with, one for a fresh ring) or ends its step (at most n):
+// 2 n + preK, + 8 spare.  The walk and planRunsKernel are also handed the number and stop writing at it (DevPlanSite::opCap).
+static int32_t devRingPreK(const sipnet_batch* b, int s) {
+  if (!b->resume[s].set) return 1;
+  const RingSched& r = b->resume[s].ring;
+  return (r.last - r.start + SIPNET_RING_SLOTS) % SIPNET_RING_SLOTS + 1;
+}
+static size_t devRingOpRoom(const sipnet_batch* b, int s) { return (size_t)2 * b->siteSteps[s] + devRingPreK(b, s) + 8; }
 
 // The device-built sites' records: scratch carved out of one block, the site table sent, the four plan kernels queued on
 // the caller's stream behind the climate copies.
@@ -371,7 +397,7 @@ static int buildOnDevice(sipnet_batch* b, const std::vector<int32_t>& bases, hip
     double* pw = preW.data() + (size_t)d * SIPNET_RING_SLOTS;
     if (b->resume[s].set) {
       const PlanCarry& rc0 = b->resume[s];
-      e.preK = (rc0.ring.last - rc0.ring.start + SIPNET_RING_SLOTS) % SIPNET_RING_SLOTS + 1;
+      e.preK = devRingPreK(b, s);
       e.preStart = rc0.ring.start;
       e.preIns = 0;
       for (int i = 0; i < e.preK; i++) pw[i] = rc0.ring.w[(rc0.ring.start + i) % SIPNET_RING_SLOTS];
@@ -386,7 +412,7 @@ static int buildOnDevice(sipnet_batch* b, const std::vector<int32_t>& bases, hip
       e.trackInit = -1;           // sipnet.c:1412
     }
     e.hasEvents = hasEv ? 1 : 0;
-    e.pad = 0;
+    e.opCap = (int32_t)devRingOpRoom(b, s);
     d++;
     maxSteps = std::max(maxSteps, c.n);
   }
@@ -496,7 +522,7 @@ static int uploadPlan(sipnet_batch* b, hipStream_t stream) {
     bases[3 * s] = (int32_t)nOps;
     bases[3 * s + 1] = (int32_t)nEv;
     bases[3 * s + 2] = b->siteSteps[s];
-    nOps += b->devSite[s] ? (size_t)2 * b->siteSteps[s] + 8 : p.ringOps.size();   // (the device's list: room for the bound)
+    nOps += b->devSite[s] ? devRingOpRoom(b, s) : p.ringOps.size();   // (the device's list: room for the bound)
     nEv += p.events.size();
     starts[s] = SiteStart{p.startCumGdd, p.startTsoil, p.startDayTime};
   }
@@ -518,7 +544,7 @@ static int uploadPlan(sipnet_batch* b, hipStream_t stream) {
   // the small arrays: flattened into one pinned block and sent on the same stream (buildAndUpload has waited for
   // every launch that might still read the previous plan; an empty list keeps one inert entry)
   // (ring evictions: the HOST-built sites' only -- a device-built site's list is written by its walk, and its room in the flat
-  // array, 2 n + 8 entries, is not sent: 18 MB and 0.32 ms of the copy stream at 32 sites x 17 520 records)
+  // array, 2 n + preK + 8 entries, is not sent: 18 MB and 0.32 ms of the copy stream at 32 sites x 17 520 records)
   size_t nHostOps = 0;
   for (int s = 0; s < nS; s++)
     if (!b->devSite[s]) nHostOps += b->plans[s].ringOps.size();
@@ -774,6 +800,8 @@ void sipnet_batch_destroy(sipnet_batch* b) {
   if (b->d_prm2) (void)hipFree(b->d_prm2);
   if (b->d_prmId) (void)hipFree(b->d_prmId);
   if (b->d_prmId2) (void)hipFree(b->d_prmId2);
+  if (b->d_prmBank) (void)hipFree(b->d_prmBank);
+  if (b->d_pfCrossing) (void)hipFree(b->d_pfCrossing);
   if (b->d_state2) (void)hipFree(b->d_state2);
   if (b->d_ring2) (void)hipFree(b->d_ring2);
   if (b->d_plan) (void)hipFree(b->d_plan);
@@ -957,6 +985,8 @@ int flushParams(sipnet_batch* b, hipStream_t stream) {
   {   // new rows are converted into column order: a resampled index must be resolved first
     int rcM = materializeParams(b, stream);
     if (rcM) return rcM;
+    // (... and the copy of this rank's parameters that a connected filter's peers hold is out of date: connect again)
+    pfDropBank(b);
   }
   if (b->hostRawUsed > b->rawStageCap) {
     int rcI = waitIdle(b);
@@ -1051,13 +1081,35 @@ int sipnet_batch_set_kernel(sipnet_batch* b, int32_t kernel, int32_t options) {
   if (!b || kernel < SIPNET_KERNEL_AUTO || kernel > SIPNET_KERNEL_COOP_NCYCLE_PAIR ||
       (options & ~(SIPNET_KOPT_ONE_WAVE_PER_SIMD | SIPNET_KOPT_RUNTIME_FLAGS | SIPNET_KOPT_FULL_STATE |
                    SIPNET_KOPT_NO_REGULAR_TILES | SIPNET_KOPT_STATS_IN_KERNEL | SIPNET_KOPT_BOUNDED_WAITS | SIPNET_KOPT_WAIT_SELFTEST |
-                   SIPNET_KOPT_HOST_PLAN | SIPNET_KOPT_DEVICE_PLAN))) {
+                   SIPNET_KOPT_HOST_PLAN | SIPNET_KOPT_DEVICE_PLAN | SIPNET_KOPT_PF_MULTI_LAUNCH | SIPNET_KOPT_PF_MOVE_PARAMS))) {
     setError("sipnet_batch_set_kernel: bad argument");
     return SIPNET_ERR_BAD_ARGUMENT;
   }
   if ((options ^ b->kernelOptions) & (SIPNET_KOPT_HOST_PLAN | SIPNET_KOPT_DEVICE_PLAN)) b->planDirty = true;   // (who builds the plan has changed)
   b->kernelPolicy = kernel;
   b->kernelOptions = options;
+  return SIPNET_OK;
+}
+
+int sipnet_batch_set_device_share(sipnet_batch* b, int32_t n_filters) {
+  if (!b || n_filters < 1 || n_filters > 1024) {
+    setError("sipnet_batch_set_device_share: bad argument (1 <= n_filters <= 1024)");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  b->deviceShare = n_filters;
+  return SIPNET_OK;
+}
+
+int sipnet_debug_set_num_cus(sipnet_batch* b, int32_t num_cus) {
+  if (!b || num_cus < 1 || num_cus > 4096) return SIPNET_ERR_BAD_ARGUMENT;
+  b->numCUs = num_cus;
+  return SIPNET_OK;
+}
+
+int sipnet_debug_pf_barrier(sipnet_batch* b, int32_t spin_budget, int32_t absent_workgroup) {
+  if (!b || spin_budget < 0) return SIPNET_ERR_BAD_ARGUMENT;
+  b->pfSpinBudget = spin_budget;
+  b->pfDebugAbsent = absent_workgroup;
   return SIPNET_OK;
 }
 
@@ -1251,6 +1303,11 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
   const bool timeIt = n_steps >= 512 || b->timeNext;
   b->timeNext = false;
   if (timeIt) HIP_TRY(hipEventRecord(b->ev0, stream));
+  // log-weights a previous forecast left belong to the state BEFORE this launch, and an armed analysis belongs to THIS
+  // launch, whichever kernel it takes
+  const bool armed = b->pfArm.set;
+  b->pfArm.set = false;
+  b->pfPre.valid = false;
   if (kernel != SIPNET_KERNEL_STRICT) {
     // throughput path: step_fast.hip / step_coop.hip
     FastArgs f;
@@ -1258,14 +1315,17 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
     f.ringOps = b->d_ringOps;
     f.events = b->d_events;
     f.siteBase = b->d_siteBase;
-    f.prm = b->d_prm;
-    f.prmId = (b->prmIndexed && kernel == SIPNET_KERNEL_ONE_WAVE) ? b->d_prmId : nullptr;
+    // (a particle filter's batch after a resampling: the one-wave kernel reads the parameters through the particles' index --
+    // into the batch's own block, or into the bank of all ranks' parameters of a connected filter)
+    const bool throughIndex = b->prmIndexed && kernel == SIPNET_KERNEL_ONE_WAVE;
+    f.prm = (throughIndex && b->d_prmBank) ? b->d_prmBank : b->d_prm;
+    f.prmPitch = (throughIndex && b->d_prmBank) ? b->prmBankPitch : b->ncol;
+    f.prmId = throughIndex ? b->d_prmId : nullptr;
     // a particle filter's forecast (sipnet_batch_pf_arm): the one-wave kernel's lean build leaves the log-weights too
     f.pfLogw = nullptr;
     f.pfBlockMax = nullptr;
     f.pfObs = f.pfInvSigma = 0.0;
-    b->pfPre.valid = false;
-    if (b->pfArm.set) {
+    if (armed) {
       const int64_t blocks1 = (int64_t)b->n_sites * ((b->n_members + 63) / 64);
       bool sameLength = true;
       for (int s = 0; s < b->n_sites; s++) sameLength = sameLength && b->siteSteps[s] >= step0 + n_steps;
@@ -1290,7 +1350,6 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
         b->pfPre.sigma = b->pfArm.sigma;
         b->pfPre.d_logw = b->pfArm.d_logw;
       }
-      b->pfArm.set = false;
     }
     f.state = b->d_state;
     f.ring = b->d_ring;

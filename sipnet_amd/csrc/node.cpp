@@ -290,6 +290,12 @@ static int createNode(const int32_t* flags, int32_t n_sites, int32_t n_members, 
   int rc = SIPNET_OK;
   for (int k = 0; k < n_devices && rc == SIPNET_OK; k++) {
     rc = sipnet_batch_create(flags, nd->nSites[k], nd->count[k], precision, devices[k], &nd->batches[k]);
+    if (rc == SIPNET_OK) {
+      // shards that share a device analyse at the same time: each may keep 1 / (their number) of it spinning (pf.hip fusedBudget)
+      int32_t sameDevice = 0;
+      for (int q = 0; q < n_devices; q++) sameDevice += devices[q] == devices[k];
+      rc = sipnet_batch_set_device_share(nd->batches[k], sameDevice);
+    }
     if (rc == SIPNET_OK && (hipSetDevice(devices[k]) != hipSuccess ||
                             hipStreamCreateWithFlags(&nd->streams[k], hipStreamNonBlocking) != hipSuccess ||
                             hipEventCreateWithFlags(&nd->evReady[k], hipEventDisableTiming) != hipSuccess ||
@@ -854,6 +860,12 @@ int sipnet_node_pf_check(sipnet_node* nd, int32_t* n_cycles_checked) {
     NODE_HIP(hipMemcpy(tk.data(), nd->pfTotals[k], tk.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
     if (k == 0) t0 = tk;
     for (int c = 0; c < m; c++) {
+      if (tk[c] == SIPNET_PF_VOID_TOTAL) {
+        setError("sipnet_node_pf_check: a cycle's analysis kernel gave up at its grid barrier on shard " + std::to_string(k) +
+                 " (its workgroups were not all resident: something else held device " + std::to_string(nd->devices[k]) +
+                 "); that cycle's resampling is void");
+        return SIPNET_ERR_INTERNAL;
+      }
       if (tk[c] != t0[c]) {
         setError("sipnet_node_pf_check: the shards disagree on a cycle's total weight (the gathered blocks differ)");
         return SIPNET_ERR_INTERNAL;

@@ -16,6 +16,7 @@
 
 #include <unistd.h>
 
+#include <climits>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -106,7 +107,11 @@ __global__ __launch_bounds__(256) void gatherMemberKernel(GatherParts parts, int
   const GatherPart part = parts.p[k];
   const int row0 = ((int)blockIdx.y - part.group0) * kGatherRows;
   const int nr = part.rows - row0 < kGatherRows ? part.rows - row0 : kGatherRows;
-  const int64_t s = src[j];
+  // (clamped: the index vector of an analysis whose launch was void -- pfFusedKernel's barrier gave up -- is whatever the
+  // caller's buffer held; the results are void either way, the reads must stay inside the matrices)
+  int64_t s = src[j];
+  const int64_t sMax = ncol + (map.nBlocks > 0 ? map.start[map.nBlocks] : 0) - 1;
+  s = s < 0 ? 0 : s > sMax ? sMax : s;
   if (part.elem4) gatherRows<float>(part, row0, nr, s, j, ownPitch, ncol, recv, map, dstPitch);
   else gatherRows<double>(part, row0, nr, s, j, ownPitch, ncol, recv, map, dstPitch);
 }
@@ -247,8 +252,11 @@ struct PeerPtrs {            // kernel argument: where rank s keeps its particle
   int32_t world, nmax;
   const double* state[kMaxPeers];
   const void* ring[kMaxPeers];
-  const double* prm[kMaxPeers];
+  const void* third[kMaxPeers];   // the converted parameter rows [NPARAMS][pitch] -- or, with all ranks' parameters replicated
+                                  // on every rank (sipnet_batch::d_prmBank), the particles' index into that bank [pitch] int32
   int32_t pitch[kMaxPeers];  // particles of rank s = the leading dimension of its matrices
+  int32_t rank;                   // the reading rank
+  unsigned long long* crossing;   // += particles read from another rank's matrices (null: not counted)
 };
 // fixed-point weights of all slots (fixedWeightKernel over the gathered blocks)
 __global__ __launch_bounds__(256) void fixedWeightGatheredKernel(const double* __restrict__ gathered, int32_t world,
@@ -270,23 +278,35 @@ __global__ __launch_bounds__(256) void fixedWeightGatheredKernel(const double* _
   const double e = exp(lw - m);
   w[i] = (!(lw > -INFINITY) || !(m > -INFINITY)) ? 0 : llrint(e * 1073741824.0);
 }
-// ---- the analysis in ONE launch (round 5) -------------------------------------------------------------------------
+// ---- the analysis in ONE launch (round 5; geometry, barrier and phases reworked in round 6) ------------------------
 // Log-weights + maximum | fixed-point weights + prefix sum | ancestors were five launches plus hipCUB's two (and
 // its temporaries' fills and copies): 40 us of a 200 us cycle at C5's shape for 15 us of work.  Here they are the
-// phases of one kernel whose workgroups are all resident (at most kFusedBlocks x 256 threads: two workgroups per
-// CU) and meet at barriers in device memory.  Workgroup b owns the contiguous slots [b * chunk, (b + 1) * chunk):
-// it scans them tile by tile with a running carry (cdfLocal = the chunk's own inclusive sums), the chunks' totals
-// are summed by every workgroup for itself (<= 512 values), and every slot writes the run of particles that take it
-// as their ancestor.  Integer weights: the result does not depend on the order of the
-// additions, so the ancestors are those of fixedWeightKernel + DeviceScan + ancestorKernel bit for bit
+// phases of one kernel whose workgroups are all resident and meet at barriers in device memory.  Workgroup b owns the
+// contiguous slots [b * chunk, (b + 1) * chunk) and, inside it, thread t the CONSECUTIVE slots [t * per, (t + 1) * per)
+// (per = chunk / 256): a thread sums its own weights serially, ONE block scan per workgroup places the threads' sums
+// (round 5 scanned every 256 slots with two __syncthreads: a term that grew with the number of ranks, 8 tiles per
+// workgroup at 8 x 131 072 slots), the chunks' totals are summed by every workgroup for itself (<= 512 values), and
+// every slot writes the run of particles that take it as their ancestor.  Integer weights: the result does not depend on
+// the order of the additions, so the ancestors are those of fixedWeightKernel + DeviceScan + ancestorKernel bit for bit
 // (tests/test_gpu_pf.py holds both paths to the same oracle).
+// RESIDENCY.  A workgroup that spins at a device-memory barrier holds its CU slot: if not every workgroup of the grid
+// is resident the launch never ends.  The grid is therefore sized by the host from what the device can hold
+// (hipOccupancyMaxActiveBlocksPerMultiprocessor x the CUs, divided by the number of shards a node has put on the
+// device: fusedBudget below) -- at most kFusedBlocks, and the multi-launch path when next to nothing fits -- and the
+// barrier's poll has a budget: a workgroup that gives up marks the launch void (kPfVoid in the totals, the stuck word),
+// poisons the barrier so that the others leave too, and exits.
 #ifndef SIPNET_PF_BLOCKS
 #define SIPNET_PF_BLOCKS 512
 #endif
 #ifndef SIPNET_PF_SLEEP
 #define SIPNET_PF_SLEEP 2
 #endif
+#ifndef SIPNET_PF_SPIN_BUDGET
+#define SIPNET_PF_SPIN_BUDGET (1 << 19)   // polls of ~0.5-1 us each: a few tenths of a second
+#endif
 constexpr int kFusedBlocks = SIPNET_PF_BLOCKS;   // (<= 512: phase 3 scans the chunk totals two per thread)
+constexpr int kFusedMinBlocks = 8;               // fewer resident workgroups than this: the multi-launch path
+constexpr long long kPfVoid = LLONG_MIN;         // "total weight" of a launch whose barrier gave up
 #ifdef SIPNET_PF_STAMPS   // (probe, tools/pf_analysis_time.py: where the launch spends its time -- workgroup 0's clock at every phase)
 __device__ unsigned long long g_pfStamps[8];
 #define PF_STAMP(k)                                                                  \
@@ -316,11 +336,13 @@ struct FusedArgs {
   // phase 1 done already by the forecast's own launch (FastArgs::pfLogw): logw is filled, preMax[nPre] are partial maxima
   const double* preMax;
   int32_t nPre;
-  int64_t* cdfLocal;         // [nSlots] inclusive sums inside a chunk
   int64_t* w;                // [nSlots] the fixed-point weights
   int64_t* blockSum;         // [gridDim.x]
-  unsigned long long* barrier;   // the barrier's counters and flags (gridBarrier): they only ever grow
-  unsigned long long base;       // barriers passed so far, all launches -- as long as the grid does not change (the host resets otherwise)
+  unsigned long long* barrier;   // THIS launch's barrier set (kBarSetWords words, all zero when the launch starts)
+  unsigned long long* barrierAhead;   // the set of the launch kBarAhead launches from now: zeroed by this one
+  unsigned long long* stuck;     // diagnostics: 1 << 63 | barrier number << 32 | workgroup of the first poll that gave up
+  int32_t spinBudget;
+  int32_t absent;            // test hook (sipnet_debug_pf_barrier): this workgroup leaves at once, without arriving; -1: nobody
   // phase 3
   int64_t j0, nOut, nTotal;
   double u0;
@@ -328,11 +350,11 @@ struct FusedArgs {
   int64_t* total;            // may be null
   int64_t* totalScratch;     // always written
 };
-// What the workgroups exchange (chunk maxima, chunk sums, the chunks' inclusive sums) is written and read with
-// agent-scope relaxed atomics: such accesses are coherent across the chip's eight XCDs (each has an L2 of its own) without
-// cache maintenance.  The first version used plain accesses and release / acquire fences at the barriers: an
-// agent-scope release is an L2 write-back, an acquire an L2 invalidate -- 2 048 waves x 2 barriers of them made the
-// launch 131 us.  Ordering: a workgroup's stores have been acknowledged (vmcnt(0)) before it arrives.
+// What the workgroups exchange (chunk maxima, chunk sums) is written and read with agent-scope relaxed atomics: such
+// accesses are coherent across the chip's eight XCDs (each has an L2 of its own) without cache maintenance.  The first
+// version used plain accesses and release / acquire fences at the barriers: an agent-scope release is an L2 write-back,
+// an acquire an L2 invalidate -- 2 048 waves x 2 barriers of them made the launch 131 us.  Ordering: a workgroup's
+// stores have been acknowledged (vmcnt(0)) before it arrives.
 __device__ __forceinline__ void stAgent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double ldAgent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void stAgent(long long* p, long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -341,28 +363,59 @@ __device__ __forceinline__ long long ldAgent(const long long* p) { return __hip_
 // arriving at ONE counter made a barrier 9 us (measured with s_memrealtime stamps, profiles/r05_pf_analysis_variants.txt)
 // -- more than a launch boundary.  Hence two levels: workgroups arrive at their GROUP's counter (kBarGroup of them per
 // address); a group's last arrival goes on to the top counter; the top's last arrival releases every group through the
-// group's own flag, which is what the group's workgroups poll (32 pollers per address instead of 512).  Counters and
-// flags only ever grow (a launch is told the epoch so far), 64 bytes apart.
+// group's own flag, which is what the group's workgroups poll (32 pollers per address instead of 512), 64 bytes apart.
+// Round 6: every launch has a barrier SET of its own out of a ring of kBarSets (two barriers each, all words zero when
+// the launch starts: launch L clears the set of launch L + kBarAhead, which nothing uses in between -- the launches of one
+// scratch block are ordered by their stream).  Round 5's counters only ever grew across launches, which made every later
+// launch depend on every earlier one having completed its barriers: a launch that failed to start, or a grid that was not
+// co-resident, left the host's epoch ahead of the counters and the NEXT analysis spinning for ever.  Now a void launch
+// spoils its own set only.
 constexpr int kBarGroup = 32;
 constexpr int kBarStride = 8;   // unsigned long longs between two counters: a line of their own
-__device__ __forceinline__ void gridBarrier(unsigned long long* bar, unsigned long long epoch) {
-  // bar[0]: top counter; bar[kBarStride * (1 + g)]: group g's counter; bar[kBarStride * (1 + G + g)]: group g's release flag
+constexpr int kBarGroupsMax = (kFusedBlocks + kBarGroup - 1) / kBarGroup;
+constexpr int kBarWords = kBarStride * (2 + 2 * kBarGroupsMax);   // one barrier: top counter, poison word, G counters, G flags
+constexpr int kBarSetWords = 2 * kBarWords;                       // a launch passes at most two
+constexpr int kBarSets = 64, kBarAhead = 32;
+// false: the barrier gave up (this workgroup's poll ran out of budget, or another's did and poisoned the barrier) -- the
+// launch is void and the caller returns; every thread of the workgroup gets the same answer
+__device__ __forceinline__ bool gridBarrier(unsigned long long* bar, int which, const FusedArgs& a, int* smOk) {
+  // bar[0]: top counter; bar[kBarStride]: poison; bar[kBarStride * (2 + g)]: group g's counter; bar[kBarStride * (2 + G + g)]: its flag
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores have been acknowledged
   __syncthreads();
   if (threadIdx.x == 0) {
     const int nb = (int)gridDim.x, G = (nb + kBarGroup - 1) / kBarGroup, g = (int)blockIdx.x / kBarGroup;
     const int inGroup = (g == G - 1) ? nb - g * kBarGroup : kBarGroup;
-    unsigned long long* flag = bar + kBarStride * (1 + G + g);
-    const unsigned long long a = __hip_atomic_fetch_add(bar + kBarStride * (1 + g), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (a + 1 == epoch * (unsigned long long)inGroup) {
+    unsigned long long* flag = bar + kBarStride * (2 + G + g);
+    unsigned long long* poison = bar + kBarStride;
+    const unsigned long long arrived = __hip_atomic_fetch_add(bar + kBarStride * (2 + g), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (arrived + 1 == (unsigned long long)inGroup) {
       const unsigned long long t = __hip_atomic_fetch_add(bar, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (t + 1 == epoch * (unsigned long long)G)
+      if (t + 1 == (unsigned long long)G)
         for (int k = 0; k < G; k++)
-          __hip_atomic_store(bar + kBarStride * (1 + G + k), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(bar + kBarStride * (2 + G + k), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) __builtin_amdgcn_s_sleep(SIPNET_PF_SLEEP);
+    int ok = 1, polls = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull) {
+      __builtin_amdgcn_s_sleep(SIPNET_PF_SLEEP);
+      if ((++polls & 63) == 0) {
+        if (__hip_atomic_load(poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) { ok = 0; break; }
+        if (polls >= a.spinBudget) {
+          __hip_atomic_store(poison, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned long long rep = (1ull << 63) | ((unsigned long long)(unsigned)which << 32) | (unsigned)blockIdx.x;
+          atomicCAS(a.stuck, 0ull, rep);
+          ok = 0;
+          break;
+        }
+      }
+    }
+    if (!ok) {   // the launch is void: say so where the host looks for the total weight
+      if (a.total) __hip_atomic_store((long long*)a.total, kPfVoid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store((long long*)a.totalScratch, kPfVoid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    *smOk = ok;
   }
   __syncthreads();
+  return *smOk != 0;
 }
 __device__ __forceinline__ double blockMax256(double v, double* sm) {
   sm[threadIdx.x] = v;
@@ -395,25 +448,34 @@ __global__ __launch_bounds__(256) void pfFusedKernel(FusedArgs a) {
   __shared__ double smD[256];
   __shared__ long long smWave[4];
   __shared__ long long prefix[kFusedBlocks + 1];
+  __shared__ int smOk;
   const int tid = (int)threadIdx.x, nb = (int)gridDim.x, b = (int)blockIdx.x;
   const int64_t lo = (int64_t)b * a.chunk, hi = lo + a.chunk < a.nSlots ? lo + a.chunk : a.nSlots;
+  // this thread's own consecutive slots [t0, t1)
+  const int per = (int)(a.chunk >> 8);
+  const int64_t t0 = lo + (int64_t)tid * per < hi ? lo + (int64_t)tid * per : hi, t1 = t0 + per < hi ? t0 + per : hi;
   int nBarrier = 0;
   double m = -INFINITY;
   PF_STAMP(0)
+  // the barrier set of the launch kBarAhead launches from now (gridBarrier)
+  if (b == 0)
+    for (int k = tid; k < kBarSetWords; k += 256) a.barrierAhead[k] = 0ull;
+  if (b == a.absent) return;
   if (!Gathered && a.preMax) {
     // ---- phase 1 was the forecast kernel's epilogue: only the maximum is left to take ----
     double pm = -INFINITY;
     for (int k = tid; k < a.nPre; k += 256) pm = fmax(pm, a.preMax[k]);
     m = blockMax256(pm, smD);
   } else if (!Gathered) {
-    // ---- phase 1: this chunk's log-weights and their maximum ----
+    // ---- phase 1: this chunk's log-weights and their maximum (lanes on neighbouring columns of the plane) ----
     double mine = -INFINITY;
     for (int64_t i = lo + tid; i < hi; i += 256)
       mine = fmax(mine, logWeightOf((const T*)a.plane, a.nSteps, a.ld, i, a.status, a.obs, a.invSigma, a.logw));
     mine = blockMax256(mine, smD);
     if (tid == 0) stAgent(&a.blockMax[b], mine);
     PF_STAMP(1)
-    gridBarrier(a.barrier, a.base + (unsigned long long)(++nBarrier));
+    if (!gridBarrier(a.barrier + kBarWords * nBarrier, nBarrier, a, &smOk)) return;
+    nBarrier++;
     PF_STAMP(2)
     double pm = -INFINITY;
     for (int k = tid; k < nb; k += 256) pm = fmax(pm, ldAgent(&a.blockMax[k]));
@@ -424,27 +486,44 @@ __global__ __launch_bounds__(256) void pfFusedKernel(FusedArgs a) {
     for (int k = tid; k < a.world * P; k += 256) pm = fmax(pm, a.gathered[(int64_t)(k / P) * a.stride + a.nmax + k % P]);
     m = blockMax256(pm, smD);
   }
-  // ---- phase 2: fixed-point weights (fixedWeightKernel's formula) and the chunk's inclusive sums ----
-  long long carry = 0;
-  for (int64_t tile = lo; tile < hi; tile += 256) {
-    const int64_t i = tile + tid;
-    long long w = 0;
-    if (i < hi) {
-      const double lw = Gathered ? a.gathered[(i / a.nmax) * a.stride + i % a.nmax] : a.logw[i];
-      const double e = exp(lw - m);
-      w = (!(lw > -INFINITY) || !(m > -INFINITY)) ? 0 : llrint(e * 1073741824.0);
+  // ---- phase 2: fixed-point weights (fixedWeightKernel's formula) of this thread's slots, their sum; ONE block scan ----
+  const bool mFinite = m > -INFINITY;
+  long long mySum = 0;
+  {
+    int64_t r = 0, c = 0;   // (gathered blocks: slot i sits in rank r's block at column c)
+    if (Gathered) { r = t0 / a.nmax; c = t0 - r * a.nmax; }
+    for (int64_t i = t0; i < t1; i += 8) {
+      double lw[8];
+      const int n8 = t1 - i < 8 ? (int)(t1 - i) : 8;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        lw[k] = -INFINITY;
+        if (k < n8) {
+          if (Gathered) {
+            lw[k] = a.gathered[r * a.stride + c];
+            if (++c == a.nmax) { c = 0; r++; }
+          } else {
+            lw[k] = a.logw[i + k];
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        if (k < n8) {
+          const double e = exp(lw[k] - m);
+          const long long w = (!(lw[k] > -INFINITY) || !mFinite) ? 0 : llrint(e * 1073741824.0);
+          a.w[i + k] = w;   // (read back by this very thread in phase 3: plain accesses)
+          mySum += w;
+        }
+      }
     }
-    long long tileTotal;
-    const long long inc = blockScan256(w, smWave, &tileTotal);
-    if (i < hi) {   // (read back by this very thread in phase 3: plain accesses)
-      a.cdfLocal[i] = carry + inc;
-      a.w[i] = w;
-    }
-    carry += tileTotal;
   }
-  if (tid == 0) stAgent((long long*)&a.blockSum[b], carry);
+  long long chunkTotal;
+  const long long myIncl = blockScan256(mySum, smWave, &chunkTotal);
+  if (tid == 0) stAgent((long long*)&a.blockSum[b], chunkTotal);
   PF_STAMP(3)
-  gridBarrier(a.barrier, a.base + (unsigned long long)(++nBarrier));
+  if (!gridBarrier(a.barrier + kBarWords * nBarrier, nBarrier, a, &smOk)) return;
+  nBarrier++;
   PF_STAMP(4)
   // ---- phase 3: the chunks' offsets (every workgroup for itself), then the ancestors ----
   {
@@ -459,10 +538,6 @@ __global__ __launch_bounds__(256) void pfFusedKernel(FusedArgs a) {
     __syncthreads();
   }
   const long long Sll = prefix[nb];
-  if (b == 0 && tid == 0) {
-    if (a.total) *a.total = Sll;
-    *a.totalScratch = Sll;
-  }
   // ancestorKernel's rule -- particle j takes the first slot i with cdf[i] > P(j), P(j) = min(((j0 + j + u0) S) / nTotal,
   // S - 1) -- turned round: slot i is taken by the particles j with cdf[i-1] <= P(j) < cdf[i], a run of consecutive j
   // (P is non-decreasing in j) that the slot's own thread finds from ITS two sums and writes itself.  No search through
@@ -477,36 +552,58 @@ __global__ __launch_bounds__(256) void pfFusedKernel(FusedArgs a) {
     while (g < a.nTotal && P(g) < c) g++;
     return g;
   };
-  __shared__ int64_t bigLo[256], bigHi[256];
-  __shared__ int32_t bigSlot[256];
+  // heavy particles (more than 32 copies): the whole workgroup writes their runs once every thread has been through its
+  // slots; a list that is full (it cannot be at <= 32 x 256 copies per chunk ... but the runs are not bounded by the chunk)
+  // makes the slot's own thread write the run
+  constexpr int kBigCap = 256;
+  __shared__ int64_t bigLo[kBigCap], bigHi[kBigCap];
+  __shared__ int32_t bigSlot[kBigCap];
   __shared__ int nBig;
-  const long long off = prefix[b];
+  if (tid == 0) nBig = 0;
+  __syncthreads();
   const int64_t gLo = a.j0, gHi = a.j0 + a.nOut;   // this launch writes the ancestors of the global particles [gLo, gHi)
-  for (int64_t tile = lo; tile < hi; tile += 256) {
-    if (tid == 0) nBig = 0;
-    __syncthreads();
-    const int64_t i = tile + tid;
-    if (i < hi) {
-      const long long incl = off + a.cdfLocal[i], w = a.w[i];   // (this thread's own stores of phase 2)
+  {
+    long long excl = prefix[b] + (myIncl - mySum);   // the sum of all weights before slot i
+    int64_t gNext = -1;                              // firstAtLeast(excl) when the previous slot has computed it
+    for (int64_t i = t0; i < t1; i++) {
+      const long long w = a.w[i];   // (this thread's own stores of phase 2)
       if (w > 0 || i == 0) {
-        int64_t g0 = i == 0 ? 0 : firstAtLeast((double)(incl - w));
-        int64_t g1 = firstAtLeast((double)incl);
+        int64_t g0 = i == 0 ? 0 : gNext >= 0 ? gNext : firstAtLeast((double)excl);
+        int64_t g1 = firstAtLeast((double)(excl + w));
+        gNext = g1;                 // (= firstAtLeast of the next weighted slot's lower sum: slots in between weigh nothing)
         if (g0 < gLo) g0 = gLo;
         if (g1 > gHi) g1 = gHi;
-        if (g1 - g0 > 32) {   // a heavy particle: the whole workgroup writes its copies
+        if (g1 - g0 > 32) {
           const int q = atomicAdd(&nBig, 1);
-          bigLo[q] = g0;
-          bigHi[q] = g1;
-          bigSlot[q] = (int32_t)i;
+          if (q < kBigCap) {
+            bigLo[q] = g0;
+            bigHi[q] = g1;
+            bigSlot[q] = (int32_t)i;
+          } else {
+            for (int64_t g = g0; g < g1; g++) a.anc[g - gLo] = (int32_t)i;
+          }
         } else {
           for (int64_t g = g0; g < g1; g++) a.anc[g - gLo] = (int32_t)i;
         }
+        excl += w;
       }
     }
-    __syncthreads();
-    for (int q = 0; q < nBig; q++)
+  }
+  __syncthreads();
+  {
+    const int nq = nBig < kBigCap ? nBig : kBigCap;
+    for (int q = 0; q < nq; q++)
       for (int64_t g = bigLo[q] + tid; g < bigHi[q]; g += 256) a.anc[g - gLo] = bigSlot[q];
-    __syncthreads();
+  }
+  // the total weight, last: a workgroup that gave up at a barrier has written kPfVoid there, and a launch is void as soon as
+  // one did (gridBarrier) -- its poison word says so even if this workgroup was released in the same instant
+  if (b == 0 && tid == 0) {
+    bool spoilt = false;
+    for (int k = 0; k < nBarrier; k++)
+      spoilt = spoilt || __hip_atomic_load(a.barrier + kBarWords * k + kBarStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull;
+    const long long tot = spoilt ? kPfVoid : Sll;
+    if (a.total) *a.total = tot;
+    *a.totalScratch = tot;
   }
   PF_STAMP(5)
 }
@@ -545,10 +642,18 @@ __global__ __launch_bounds__(256) void gatherPeerKernel(PeerParts parts, PeerPtr
   const PeerPart part = parts.p[k];
   const int row0 = ((int)blockIdx.y - part.group0) * kGatherRows;
   const int nr = part.rows - row0 < kGatherRows ? part.rows - row0 : kGatherRows;
-  const int32_t a = anc[j];
-  const int s = a / peers.nmax;
-  const int64_t c = a - s * peers.nmax, pitch = peers.pitch[s];
-  const void* base = k == 0 ? (const void*)peers.state[s] : k == 1 ? peers.ring[s] : (const void*)peers.prm[s];
+  int32_t a = anc[j];   // (clamped like gatherMemberKernel's: a void analysis leaves the caller's buffer as it was)
+  a = a < 0 ? 0 : a;
+  int s = a / peers.nmax;
+  s = s >= peers.world ? peers.world - 1 : s;
+  const int64_t pitch = peers.pitch[s];
+  int64_t c = a - s * peers.nmax;
+  c = c >= pitch ? pitch - 1 : c;
+  const void* base = k == 0 ? (const void*)peers.state[s] : k == 1 ? peers.ring[s] : peers.third[s];
+  if (blockIdx.y == 0 && peers.crossing) {   // how many of this rank's particles crossed a link (sipnet_batch_pf_info)
+    const unsigned long long far = __ballot(s != peers.rank);
+    if ((threadIdx.x & 63) == 0 && far) atomicAdd(peers.crossing, (unsigned long long)__popcll(far));
+  }
   if (part.elem4)
     gatherPeerRows<float>((const float*)base + (int64_t)row0 * pitch + c, pitch, (float*)part.dst + (int64_t)row0 * dstPitch + j,
                           dstPitch, nr);
@@ -668,6 +773,7 @@ void launchGatherMember(const double* state, const void* ring, bool ringF32, con
                         const double* recv, const RecvMap& map, const int32_t* src, int64_t nOut,
                         double* dState, void* dRing, double* dPrm, int64_t dstPitch, hipStream_t stream,
                         const int32_t* prmRemap = nullptr, const int32_t* idOld = nullptr, int32_t* idNew = nullptr) {
+  // (ncol: the leading dimension of the source matrices AND the number of own source columns)
   if (nOut <= 0) return;
   auto groups = [](int rows) { return (rows + kGatherRows - 1) / kGatherRows; };
   GatherParts parts{};
@@ -690,9 +796,16 @@ void launchGatherMember(const double* state, const void* ring, bool ringF32, con
   hipLaunchKernelGGL(gatherMemberKernel, grid, dim3(256), 0, stream, parts, ncol, ncol, recv, map, src, nOut, dstPitch);
 }
 
-__global__ __launch_bounds__(256) void iotaKernel(int32_t* p, int64_t n) {
+__global__ __launch_bounds__(256) void iotaKernel(int32_t* p, int64_t n, int32_t first = 0) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = (int32_t)i;
+  if (i < n) p[i] = first + (int32_t)i;
+}
+// rows of doubles from a peer's matrix (pitch srcPitch) into columns col0.. of the bank (sipnet_batch_pf_connect)
+__global__ __launch_bounds__(256) void copyRowsKernel(double* __restrict__ dst, int64_t dstPitch, const double* __restrict__ src,
+                                                      int64_t srcPitch, int64_t width, int32_t rows) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= width) return;
+  for (int r = blockIdx.y; r < rows; r += gridDim.y) dst[(int64_t)r * dstPitch + c] = src[(int64_t)r * srcPitch + c];
 }
 
 }  // namespace
@@ -710,9 +823,24 @@ struct PfPeers {
   const double* state[2][kMaxPeers] = {};
   const void* ring[2][kMaxPeers] = {};
   const double* prm[2][kMaxPeers] = {};
+  const int32_t* ids[2][kMaxPeers] = {};   // byIndex: the particles' index into the replicated parameter bank
+  bool byIndex = false;                // all ranks' parameters are in sipnet_batch::d_prmBank; particles carry an index
+  bool bankLost = false;               // ... and this batch has since changed its parameters or moved rows: connect again
   std::vector<void*> opened;           // hipIpcOpenMemHandle mappings, closed on release
   int parity = 0;
 };
+
+// the connection's parameter bank is no longer what the particles' indices mean (new parameters were set, or a resampling
+// moved parameter ROWS): the batch goes back to its own column-order block
+void pfDropBank(sipnet_batch* b) {
+  if (!b->d_prmBank) return;
+  (void)hipDeviceSynchronize();
+  (void)hipFree(b->d_prmBank);
+  b->d_prmBank = nullptr;
+  b->prmBankPitch = 0;
+  b->prmIndexed = false;
+  if (b->pfPeers) b->pfPeers->bankLost = true;
+}
 
 // The parameter bank back in column order (batch_impl.h): gather through the index into the spare, swap.
 int materializeParams(sipnet_batch* b, hipStream_t stream) {
@@ -722,8 +850,15 @@ int materializeParams(sipnet_batch* b, hipStream_t stream) {
     int rcO = orderBehindBusy(b, stream);
     if (rcO) return rcO;
   }
-  if (!b->d_prm2) HIP_TRY(hipMalloc(&b->d_prm2, nc * SIPNET_NPARAMS * sizeof(double)));
   RecvMap none{};
+  if (b->d_prmBank) {   // a connected filter: the rows out of the bank of all ranks' parameters; the index stays what it is
+    launchGatherMember(nullptr, nullptr, false, b->d_prmBank, b->prmBankPitch, nullptr, none, b->d_prmId, b->ncol, nullptr, nullptr,
+                       b->d_prm, b->ncol, stream);
+    HIP_TRY(hipGetLastError());
+    b->prmIndexed = false;
+    return markBusy(b, stream);
+  }
+  if (!b->d_prm2) HIP_TRY(hipMalloc(&b->d_prm2, nc * SIPNET_NPARAMS * sizeof(double)));
   launchGatherMember(nullptr, nullptr, false, b->d_prm, b->ncol, nullptr, none, b->d_prmId, b->ncol, nullptr, nullptr, b->d_prm2,
                      b->ncol, stream);   // dst column j <- bank column d_prmId[j]
   HIP_TRY(hipGetLastError());
@@ -790,12 +925,12 @@ struct PfScratch {
   int64_t* d_cdf = nullptr;
   void* d_tmp = nullptr;
   size_t tmpBytes = 0;
-  // the one-launch analysis (pfFusedKernel): chunk totals, the device-memory barrier's arrival count (never reset: a
-  // launch is told its value so far) and the total weight
+  // the one-launch analysis (pfFusedKernel): chunk totals + the total weight, the ring of per-launch barrier sets (all
+  // zero at allocation; launch L uses set L % kBarSets and clears set (L + kBarAhead) % kBarSets), the stuck report
   int64_t* d_blockSum = nullptr;      // [kFusedBlocks] + 1: the total
-  unsigned long long* d_barrier = nullptr;
-  unsigned long long barrierBase = 0;   // barriers passed so far with the current grid
-  int barrierGrid = 0;                  // the grid the counters have counted for (another grid: start over)
+  unsigned long long* d_barrier = nullptr;   // [kBarSets][kBarSetWords] + 1: the stuck word
+  unsigned long long launches = 0;      // fused launches that were accepted by the runtime
+  int occ[3] = {-1, -1, -1};            // resident workgroups per CU of pfFusedKernel<float,false> / <double,false> / <double,true>
   void release() {
     if (d_max) (void)hipFree(d_max);
     if (d_w) (void)hipFree(d_w);
@@ -804,13 +939,14 @@ struct PfScratch {
     if (d_blockSum) (void)hipFree(d_blockSum);
     if (d_barrier) (void)hipFree(d_barrier);
     d_max = nullptr; d_w = d_cdf = nullptr; d_tmp = nullptr; cap = 0; tmpBytes = 0;
-    d_blockSum = nullptr; d_barrier = nullptr; barrierBase = 0; barrierGrid = 0;
+    d_blockSum = nullptr; d_barrier = nullptr; launches = 0;
+    occ[0] = occ[1] = occ[2] = -1;
   }
   // no destructor: a thread_local's would run at thread exit, possibly after the HIP runtime is gone
 };
 namespace {
 constexpr int kMaxParts = 256;
-constexpr size_t kBarrierWords = (size_t)kBarStride * (1 + 2 * ((kFusedBlocks + kBarGroup - 1) / kBarGroup));
+constexpr size_t kBarrierWords = (size_t)kBarSets * kBarSetWords + 1;   // + the stuck word
 thread_local PfScratch g_pf;
 }  // namespace
 
@@ -829,28 +965,68 @@ static int pfScratchFor(PfScratch& sc, int64_t n, hipStream_t stream) {
     HIP_TRY(hipMalloc(&sc.d_blockSum, (size_t)(kFusedBlocks + 1) * sizeof(int64_t)));
     HIP_TRY(hipMalloc(&sc.d_barrier, kBarrierWords * sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(sc.d_barrier, 0, kBarrierWords * sizeof(unsigned long long), stream));
-    sc.barrierBase = 0;
-    sc.barrierGrid = 0;
+    sc.launches = 0;
     sc.cap = n;
   }
   return SIPNET_OK;
 }
-// geometry of the one-launch analysis over nSlots weights: every workgroup resident, contiguous chunks of whole tiles
-static void fusedGeometry(int64_t nSlots, int* grid, int64_t* chunk) {
+// How many workgroups of the one-launch analysis may spin at its barriers at once: what the device holds
+// (hipOccupancyMaxActiveBlocksPerMultiprocessor x its CUs -- the batch's numCUs: a partitioned device reports its own) over
+// the number of filters that may analyse on this device at the same time (sipnet_batch_set_device_share: a node's shards on
+// one device), at most kFusedBlocks.  which: 0 pfFusedKernel<float, false>, 1 <double, false>, 2 <double, true>.
+static int fusedBudget(PfScratch& sc, const sipnet_batch* b, int which) {
+  if (sc.occ[which] < 0) {
+    int occ = 0;
+    hipError_t e = which == 0   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, pfFusedKernel<float, false>, 256, 0)
+                   : which == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, pfFusedKernel<double, false>, 256, 0)
+                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, pfFusedKernel<double, true>, 256, 0);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      occ = 0;   // (unknown: the multi-launch path)
+    }
+    sc.occ[which] = occ;
+  }
+  const int64_t share = b->deviceShare > 0 ? b->deviceShare : 1;
+  const int64_t fit = (int64_t)sc.occ[which] * b->numCUs / share;
+  return (int)(fit < kFusedBlocks ? fit : kFusedBlocks);
+}
+// geometry of the one-launch analysis over nSlots weights with at most `budget` workgroups: contiguous chunks of whole tiles
+static void fusedGeometry(int64_t nSlots, int budget, int* grid, int64_t* chunk) {
   const int64_t tiles = (nSlots + 255) / 256;
-  const int64_t nb = tiles < kFusedBlocks ? tiles : kFusedBlocks;
+  const int64_t nb = tiles < budget ? tiles : budget;
   const int64_t tilesPer = (tiles + nb - 1) / nb;
   *chunk = tilesPer * 256;
   *grid = (int)((nSlots + *chunk - 1) / *chunk);
 }
-// the barrier's counters count arrivals of ONE grid size: another grid (another particle count) starts them over
-static int barrierFor(PfScratch& sc, int grid, hipStream_t stream) {
-  if (sc.barrierGrid != grid) {
-    HIP_TRY(hipMemsetAsync(sc.d_barrier, 0, kBarrierWords * sizeof(unsigned long long), stream));
-    sc.barrierBase = 0;
-    sc.barrierGrid = grid;
+// this launch's barrier set and the one it clears for a later launch; fusedLaunched() once the runtime has accepted the launch
+static void fusedBarrier(PfScratch& sc, FusedArgs* fa, int spinBudget) {
+  fa->barrier = sc.d_barrier + (size_t)(sc.launches % kBarSets) * kBarSetWords;
+  fa->barrierAhead = sc.d_barrier + (size_t)((sc.launches + kBarAhead) % kBarSets) * kBarSetWords;
+  fa->stuck = sc.d_barrier + (size_t)kBarSets * kBarSetWords;
+  fa->spinBudget = spinBudget > 0 ? spinBudget : SIPNET_PF_SPIN_BUDGET;
+}
+// a launch the runtime refused has not touched its set (nor cleared the one ahead): the next one takes the same set
+static int fusedLaunched(PfScratch& sc) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    setError(std::string("pfFusedKernel: ") + hipGetErrorString(e));
+    return SIPNET_ERR_INTERNAL;
   }
+  sc.launches++;
   return SIPNET_OK;
+}
+// the report a void launch left (gridBarrier), for the error message; clears it
+static std::string fusedStuckReport(PfScratch& sc, hipStream_t stream) {
+  unsigned long long rep = 0;
+  unsigned long long* d = sc.d_barrier + (size_t)kBarSets * kBarSetWords;
+  if (hipMemcpyAsync(&rep, d, sizeof rep, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) {
+    (void)hipGetLastError();
+    return "the analysis kernel's grid barrier gave up";
+  }
+  (void)hipMemsetAsync(d, 0, sizeof rep, stream);
+  return "the analysis kernel's grid barrier gave up (barrier " + std::to_string((unsigned)((rep >> 32) & 0x7fffffffu)) + ", workgroup " +
+         std::to_string((unsigned)(rep & 0xffffffffu)) + "): its workgroups were not all resident -- another kernel held the device, or more filters "
+         "analyse on it at once than sipnet_batch_set_device_share says; the launch's results are void";
 }
 static PfScratch& scratchOf(sipnet_batch* b) {
   if (!b->pfScratch) b->pfScratch = new PfScratch();
@@ -858,8 +1034,10 @@ static PfScratch& scratchOf(sipnet_batch* b) {
 }
 
 // partsGiven > 0: the partial maxima of d_logw are in the scratch block already (logWeights put them there)
+// (partPtr: where those maxima are, when not in the scratch block)
 static int ancestorsImpl(PfScratch& sc, const double* d_logw, int64_t n, double u0, int32_t* d_ancestors,
-                         int64_t* d_fixed_weights, int64_t* d_total, int partsGiven, void* hip_stream) {
+                         int64_t* d_fixed_weights, int64_t* d_total, int partsGiven, void* hip_stream,
+                         const double* partPtr = nullptr) {
   if (!d_logw || !d_ancestors || n <= 0 || n > (int64_t)1 << 22 || !(u0 >= 0.0) || !(u0 < 1.0)) {
     setError("sipnet_pf_systematic_ancestors: bad argument (n <= 4194304, 0 <= u0 < 1)");
     return SIPNET_ERR_BAD_ARGUMENT;
@@ -873,7 +1051,7 @@ static int ancestorsImpl(PfScratch& sc, const double* d_logw, int64_t n, double 
     parts = grid < kMaxParts ? grid : kMaxParts;
     hipLaunchKernelGGL(maxPartialKernel, dim3(parts), dim3(256), 0, stream, d_logw, n, sc.d_max);
   }
-  hipLaunchKernelGGL(fixedWeightKernel, dim3(grid), dim3(256), 0, stream, d_logw, n, sc.d_max, parts, sc.d_w);
+  hipLaunchKernelGGL(fixedWeightKernel, dim3(grid), dim3(256), 0, stream, d_logw, n, partPtr ? partPtr : sc.d_max, parts, sc.d_w);
   size_t tmpBytes = sc.tmpBytes;
   HIP_TRY(hipcub::DeviceScan::InclusiveSum(sc.d_tmp, tmpBytes, sc.d_w, sc.d_cdf, (int)n, stream));
   hipLaunchKernelGGL(ancestorKernel, dim3(grid), dim3(256), 0, stream, sc.d_cdf, n, (int64_t)0, n, n, u0, d_ancestors,
@@ -1033,15 +1211,23 @@ int sipnet_batch_resample(sipnet_batch* b, const int32_t* d_src, const double* d
   // (4 bytes per particle instead of 640; the one-wave forecast kernel reads through it).  With blocks received from
   // other ranks the rows themselves travel, as before.
   const bool byIndex = with_params && n_blocks == 0;
+  if (b->d_prmBank && !with_params) {
+    setError("sipnet_batch_resample: this batch is connected to a filter whose particles carry their parameters "
+             "(sipnet_batch_pf_connect): resample with_params");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
   if (with_params && !byIndex) {
     rc = materializeParams(b, stream);
     if (rc) return rc;
+    pfDropBank(b);   // (parameter ROWS are about to move: the connection's index means nothing afterwards)
     if (!b->d_prm2) HIP_TRY(hipMalloc(&b->d_prm2, nc * SIPNET_NPARAMS * sizeof(double)));
   }
   if (byIndex) {
     if (!b->d_prmId) HIP_TRY(hipMalloc(&b->d_prmId, nc * sizeof(int32_t)));
     if (!b->d_prmId2) HIP_TRY(hipMalloc(&b->d_prmId2, nc * sizeof(int32_t)));
-    if (!b->prmIndexed) {
+    if (b->d_prmBank) {
+      b->prmIndexed = true;   // (a connected filter's index is always current: slots of the bank)
+    } else if (!b->prmIndexed) {
       hipLaunchKernelGGL(iotaKernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, stream, b->d_prmId, (int64_t)nc);
       b->prmIndexed = true;
     }
@@ -1109,8 +1295,16 @@ int sipnet_batch_pf_analysis(sipnet_batch* b, const void* d_plane, int32_t elem_
     setError("sipnet_batch_pf_analysis: bad argument (sigma > 0, 0 <= u0 < 1, at most 4194304 particles)");
     return SIPNET_ERR_BAD_ARGUMENT;
   }
-  // log-weights, fixed-point weights, prefix sum and ancestors: ONE launch (pfFusedKernel)
-  {
+  // (the forecast's launch has left the log-weights of exactly this plane, observation and sigma: sipnet_batch_pf_arm)
+  const sipnet_batch::PfPre pre = b->pfPre;
+  const bool havePre = pre.valid && pre.plane == d_plane && pre.nSteps == n_steps && pre.ld == ld && pre.obs == obs &&
+                       pre.sigma == sigma && pre.d_logw == d_logw && elem_is_f32 == (b->precision == SIPNET_F32_MIXED);
+  b->pfPre.valid = false;
+  const int budget = (b->kernelOptions & SIPNET_KOPT_PF_MULTI_LAUNCH) ? 0 : fusedBudget(sc, b, elem_is_f32 ? 0 : 1);
+  b->pfInfo.fused = budget >= kFusedMinBlocks ? 1 : 0;
+  b->pfInfo.budget = budget;
+  if (budget >= kFusedMinBlocks) {
+    // log-weights, fixed-point weights, prefix sum and ancestors: ONE launch (pfFusedKernel)
     FusedArgs fa{};
     fa.plane = d_plane;
     fa.nSteps = n_steps;
@@ -1122,23 +1316,16 @@ int sipnet_batch_pf_analysis(sipnet_batch* b, const void* d_plane, int32_t elem_
     fa.logw = d_logw;
     fa.nSlots = b->ncol;
     int grid;
-    fusedGeometry(fa.nSlots, &grid, &fa.chunk);
+    fusedGeometry(fa.nSlots, budget, &grid, &fa.chunk);
+    b->pfInfo.grid = grid;
     fa.blockMax = sc.d_max;
-    fa.cdfLocal = sc.d_cdf;
     fa.w = sc.d_w;
     fa.blockSum = sc.d_blockSum;
-    rc = barrierFor(sc, grid, (hipStream_t)hip_stream);
-    if (rc) return rc;
-    fa.barrier = sc.d_barrier;
-    fa.base = sc.barrierBase;
-    // (the forecast's launch has left the log-weights of exactly this plane, observation and sigma: sipnet_batch_pf_arm)
-    const sipnet_batch::PfPre& pre = b->pfPre;
-    const bool havePre = pre.valid && pre.plane == d_plane && pre.nSteps == n_steps && pre.ld == ld && pre.obs == obs &&
-                         pre.sigma == sigma && pre.d_logw == d_logw && elem_is_f32 == (b->precision == SIPNET_F32_MIXED);
+    fusedBarrier(sc, &fa, b->pfSpinBudget);
+    fa.absent = b->pfDebugAbsent;
+    b->pfDebugAbsent = -1;
     fa.preMax = havePre ? b->d_pfPreMax : nullptr;
     fa.nPre = havePre ? pre.nMax : 0;
-    b->pfPre.valid = false;
-    sc.barrierBase += havePre ? 1 : 2;
     fa.j0 = 0;
     fa.nOut = fa.nTotal = b->ncol;
     fa.u0 = u0;
@@ -1147,12 +1334,35 @@ int sipnet_batch_pf_analysis(sipnet_batch* b, const void* d_plane, int32_t elem_
     fa.totalScratch = sc.d_blockSum + kFusedBlocks;
     if (elem_is_f32) hipLaunchKernelGGL((pfFusedKernel<float, false>), dim3(grid), dim3(256), 0, (hipStream_t)hip_stream, fa);
     else hipLaunchKernelGGL((pfFusedKernel<double, false>), dim3(grid), dim3(256), 0, (hipStream_t)hip_stream, fa);
-    HIP_TRY(hipGetLastError());
+    rc = fusedLaunched(sc);
+    if (rc) return rc;
+  } else {
+    // next to nothing of the device is ours to spin on (a sliver of a partitioned device, many filters sharing it): the
+    // phases as launches of their own -- log-weights + 256-wide maxima | fixed-point weights | prefix sum | ancestors
+    b->pfInfo.grid = 0;
+    int parts;
+    const double* partPtr = nullptr;
+    if (havePre) {
+      parts = pre.nMax;
+      partPtr = b->d_pfPreMax;
+    } else {
+      rc = logWeights(b, d_plane, elem_is_f32, n_steps, ld, obs, sigma, d_logw, sc.d_max, hip_stream);
+      if (rc) return rc;
+      parts = (int)((b->ncol + 255) / 256);
+    }
+    rc = ancestorsImpl(sc, d_logw, b->ncol, u0, d_ancestors, nullptr, sc.d_blockSum + kFusedBlocks, parts, hip_stream, partPtr);
+    if (rc) return rc;
+    if (d_total)
+      HIP_TRY(hipMemcpyAsync(d_total, sc.d_blockSum + kFusedBlocks, sizeof(int64_t), hipMemcpyDeviceToDevice, (hipStream_t)hip_stream));
   }
   if (!d_total) {   // the synchronous check of sipnet_pf_systematic_ancestors
     int64_t total = 0;
     HIP_TRY(hipMemcpyAsync(&total, sc.d_blockSum + kFusedBlocks, sizeof(int64_t), hipMemcpyDeviceToHost, (hipStream_t)hip_stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)hip_stream));
+    if (total == kPfVoid) {
+      setError("sipnet_batch_pf_analysis: " + fusedStuckReport(sc, (hipStream_t)hip_stream));
+      return SIPNET_ERR_INTERNAL;
+    }
     if (total <= 0) {
       setError("sipnet_batch_pf_analysis: every particle has zero weight");
       return SIPNET_ERR_BAD_PARAMETER;
@@ -1208,6 +1418,7 @@ int sipnet_batch_pf_publish(sipnet_batch* b, int32_t with_params, sipnet_pf_peer
   if (rc) return rc;
   rc = materializeParams(b, nullptr);    // (... in column order: peers address a particle's rows by its column)
   if (rc) return rc;
+  pfDropBank(b);                         // (an earlier connection's bank: the next connect builds a new one)
   rc = waitIdle(b);
   if (rc) return rc;
   memset(out, 0, sizeof *out);
@@ -1217,10 +1428,17 @@ int sipnet_batch_pf_publish(sipnet_batch* b, int32_t with_params, sipnet_pf_peer
   out->precision = b->precision;
   out->with_params = with_params ? 1 : 0;
   out->generic_exponents = b->genericExponents ? 1 : 0;
-  void* ptr[6] = {b->d_state, b->d_state2, b->d_ring, b->d_ring2, with_params ? b->d_prm : nullptr,
-                  with_params ? b->d_prm2 : nullptr};
+  const bool byIndex = with_params && !(b->kernelOptions & SIPNET_KOPT_PF_MOVE_PARAMS);
+  out->params_by_index = byIndex ? 1 : 0;
+  if (byIndex) {   // the particles' index into the bank of all ranks' parameters (filled by connect), double-buffered like the state
+    const size_t nc = (size_t)b->ncol;
+    if (!b->d_prmId) HIP_TRY(hipMalloc(&b->d_prmId, nc * sizeof(int32_t)));
+    if (!b->d_prmId2) HIP_TRY(hipMalloc(&b->d_prmId2, nc * sizeof(int32_t)));
+  }
+  void* ptr[8] = {b->d_state, b->d_state2, b->d_ring, b->d_ring2, with_params ? b->d_prm : nullptr,
+                  with_params ? b->d_prm2 : nullptr, byIndex ? b->d_prmId : nullptr, byIndex ? b->d_prmId2 : nullptr};
   out->ipc_valid = 1;
-  for (int k = 0; k < 6; k++) {
+  for (int k = 0; k < 8; k++) {
     out->address[k] = (uint64_t)(uintptr_t)ptr[k];
     if (!ptr[k]) continue;
     hipIpcMemHandle_t h;
@@ -1266,16 +1484,16 @@ int sipnet_batch_pf_connect(sipnet_batch* b, int32_t world, int32_t rank, const 
   };
   for (int s = 0; s < world; s++) {
     const sipnet_pf_peer& q = peers[s];
-    if (q.precision != me.precision || q.with_params != me.with_params || q.n_particles <= 0)
+    if (q.precision != me.precision || q.with_params != me.with_params || q.params_by_index != me.params_by_index || q.n_particles <= 0)
       return fail("rank " + std::to_string(s) + " published another precision / parameter mode", SIPNET_ERR_BAD_ARGUMENT);
     pp->count[s] = q.n_particles;
     if (q.n_particles > pp->nmax) pp->nmax = q.n_particles;
     if (s < rank) pp->first += q.n_particles;
     pp->nTotal += q.n_particles;
     generic = generic || q.generic_exponents != 0;
-    void* ptr[6];
+    void* ptr[8];
     if (q.process_id == me.process_id) {   // same process (the node object): the addresses themselves
-      for (int k = 0; k < 6; k++) ptr[k] = (void*)(uintptr_t)q.address[k];
+      for (int k = 0; k < 8; k++) ptr[k] = (void*)(uintptr_t)q.address[k];
       if (q.device != b->device) {
         hipError_t e = hipDeviceEnablePeerAccess(q.device, 0);
         if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
@@ -1284,7 +1502,7 @@ int sipnet_batch_pf_connect(sipnet_batch* b, int32_t world, int32_t rank, const 
       }
     } else {                               // another process: map its allocations (dmabuf IPC)
       if (!q.ipc_valid) return fail("rank " + std::to_string(s) + " could not export IPC handles", SIPNET_ERR_NO_DEVICE);
-      for (int k = 0; k < 6; k++) {
+      for (int k = 0; k < 8; k++) {
         ptr[k] = nullptr;
         if (!q.address[k]) continue;
         hipIpcMemHandle_t h;
@@ -1298,13 +1516,50 @@ int sipnet_batch_pf_connect(sipnet_batch* b, int32_t world, int32_t rank, const 
       pp->state[par][s] = (const double*)ptr[0 + par];
       pp->ring[par][s] = ptr[2 + par];
       pp->prm[par][s] = (const double*)ptr[4 + par];
+      pp->ids[par][s] = (const int32_t*)ptr[6 + par];
     }
   }
   if ((int64_t)world * pp->nmax > (int64_t)1 << 22) return fail("more than 4 194 304 weight slots", SIPNET_ERR_BAD_ARGUMENT);
   // particles carry their parameters between ranks: every rank runs the kernel variant the most general
   // parameter set anywhere needs (decided here, once -- not by a device -> host check after every exchange)
   if (generic && me.with_params) b->genericExponents = true;
+  pp->byIndex = me.params_by_index != 0;
+  if (pp->byIndex) {
+    // Every rank's converted parameters, once: [NPARAMS][world * nmax], rank s's particle c in column s * nmax + c (the slot
+    // numbering of the weights).  Parameters are constants of a particle; what a resampling moves from now on is this column
+    // number -- 4 bytes instead of 640, and the forecast's parameter reads stay in local HBM.  (The peers' blocks are read
+    // where they are: peer-mapped HBM, as every later gather reads state and ring.)
+    const int64_t pitch = (int64_t)world * pp->nmax;
+    pfDropBank(b);
+    if (hipMalloc(&b->d_prmBank, (size_t)pitch * SIPNET_NPARAMS * sizeof(double)) != hipSuccess) {
+      (void)hipGetLastError();
+      b->d_prmBank = nullptr;
+      return fail("no memory for the bank of all ranks' parameters (SIPNET_KOPT_PF_MOVE_PARAMS does without)", SIPNET_ERR_INTERNAL);
+    }
+    b->prmBankPitch = pitch;
+    for (int s = 0; s < world; s++) {
+      const int64_t cnt = pp->count[s];
+      hipLaunchKernelGGL(copyRowsKernel, dim3((unsigned)((cnt + 255) / 256), 8), dim3(256), 0, nullptr, b->d_prmBank + (int64_t)s * pp->nmax,
+                         pitch, pp->prm[0][s], cnt, cnt, (int32_t)SIPNET_NPARAMS);
+    }
+    hipLaunchKernelGGL(iotaKernel, dim3((unsigned)((b->ncol + 255) / 256)), dim3(256), 0, nullptr, b->d_prmId, b->ncol, (int32_t)(rank * pp->nmax));
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    if (e != hipSuccess) {
+      pfDropBank(b);
+      return fail(std::string("filling the parameter bank: ") + hipGetErrorString(e), SIPNET_ERR_INTERNAL);
+    }
+    b->prmIndexed = false;   // (d_prm is current too: nothing has been resampled yet)
+  }
+  if ((!b->d_pfCrossing && hipMalloc(&b->d_pfCrossing, sizeof(unsigned long long)) != hipSuccess) ||
+      hipMemset(b->d_pfCrossing, 0, sizeof(unsigned long long)) != hipSuccess) {
+    (void)hipGetLastError();
+    pfDropBank(b);
+    return fail("no memory for the crossing counter", SIPNET_ERR_INTERNAL);
+  }
+  b->pfInfo.cycles = 0;
   b->pfPeers = pp;
+  pp->bankLost = false;
   return SIPNET_OK;
 }
 
@@ -1356,8 +1611,16 @@ int sipnet_batch_pf_resample_peers(sipnet_batch* b, const double* d_gathered, do
   hipStream_t stream = (hipStream_t)hip_stream;
   rc = flushParams(b, stream);
   if (rc) return rc;
-  rc = materializeParams(b, stream);   // (peers read a particle's parameter rows by its column)
-  if (rc) return rc;
+  const bool byIndex = b->pfPeers && b->pfPeers->byIndex;
+  if (byIndex && (b->pfPeers->bankLost || !b->d_prmBank)) {
+    setError("sipnet_batch_pf_resample_peers: this rank's parameters were set anew (or moved as rows by sipnet_batch_resample) after "
+             "sipnet_batch_pf_connect replicated them on every rank: publish and connect again");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  if (!byIndex) {
+    rc = materializeParams(b, stream);   // (peers read a particle's parameter rows by its column)
+    if (rc) return rc;
+  }
   PeerPtrs tab{};
   int64_t nTotal = b->ncol, first = 0;
   bool withParams;
@@ -1365,36 +1628,44 @@ int sipnet_batch_pf_resample_peers(sipnet_batch* b, const double* d_gathered, do
     const PfPeers& pp = *b->pfPeers;
     tab.world = pp.world;
     tab.nmax = pp.nmax;
+    tab.rank = pp.rank;
     for (int s = 0; s < pp.world; s++) {
       tab.state[s] = pp.state[pp.parity][s];
       tab.ring[s] = pp.ring[pp.parity][s];
-      tab.prm[s] = pp.prm[pp.parity][s];
+      tab.third[s] = byIndex ? (const void*)pp.ids[pp.parity][s] : (const void*)pp.prm[pp.parity][s];
       tab.pitch[s] = pp.count[s];
     }
     nTotal = pp.nTotal;
     first = pp.first;
     withParams = pp.withParams != 0;
-    if (tab.state[pp.rank] != b->d_state) {
+    if (tab.state[pp.rank] != b->d_state || (byIndex && tab.third[pp.rank] != (const void*)b->d_prmId)) {
       setError("sipnet_batch_pf_resample_peers: the batch was resampled behind the peers' back");
       return SIPNET_ERR_INTERNAL;
     }
+    tab.crossing = b->d_pfCrossing;
   } else {   // not connected: a filter of this batch alone (parameters travel with the particles)
     tab.world = 1;
     tab.nmax = (int32_t)b->ncol;
+    tab.rank = 0;
     tab.state[0] = b->d_state;
     tab.ring[0] = b->d_ring;
-    tab.prm[0] = b->d_prm;
+    tab.third[0] = b->d_prm;
     tab.pitch[0] = (int32_t)b->ncol;
     withParams = true;
   }
-  rc = ensureSpares(b, withParams);
+  rc = ensureSpares(b, withParams && !byIndex);
   if (rc) return rc;
   const int64_t nSlots = (int64_t)tab.world * tab.nmax, stride = tab.nmax + (tab.nmax + 255) / 256;
   PfScratch& sc = scratchOf(b);
   rc = pfScratchFor(sc, nSlots, stream);
   if (rc) return rc;
   const int64_t n = b->ncol;
-  {   // weights over all slots, prefix sum, the ancestors of MY particles: one launch (pfFusedKernel)
+  const int budget = (b->kernelOptions & SIPNET_KOPT_PF_MULTI_LAUNCH) ? 0 : fusedBudget(sc, b, 2);
+  b->pfInfo.fused = budget >= kFusedMinBlocks ? 1 : 0;
+  b->pfInfo.budget = budget;
+  b->pfInfo.nSlots = nSlots;
+  b->pfInfo.grid = 0;
+  if (budget >= kFusedMinBlocks) {   // weights over all slots, prefix sum, the ancestors of MY particles: one launch (pfFusedKernel)
     FusedArgs fa{};
     fa.gathered = d_gathered;
     fa.world = tab.world;
@@ -1402,16 +1673,14 @@ int sipnet_batch_pf_resample_peers(sipnet_batch* b, const double* d_gathered, do
     fa.stride = stride;
     fa.nSlots = nSlots;
     int grid;
-    fusedGeometry(fa.nSlots, &grid, &fa.chunk);
+    fusedGeometry(fa.nSlots, budget, &grid, &fa.chunk);
+    b->pfInfo.grid = grid;
     fa.blockMax = sc.d_max;
-    fa.cdfLocal = sc.d_cdf;
     fa.w = sc.d_w;
     fa.blockSum = sc.d_blockSum;
-    rc = barrierFor(sc, grid, stream);
-    if (rc) return rc;
-    fa.barrier = sc.d_barrier;
-    fa.base = sc.barrierBase;
-    sc.barrierBase += 1;
+    fusedBarrier(sc, &fa, b->pfSpinBudget);
+    fa.absent = b->pfDebugAbsent;
+    b->pfDebugAbsent = -1;
     fa.j0 = first;
     fa.nOut = n;
     fa.nTotal = nTotal;
@@ -1420,6 +1689,17 @@ int sipnet_batch_pf_resample_peers(sipnet_batch* b, const double* d_gathered, do
     fa.total = d_total;
     fa.totalScratch = sc.d_blockSum + kFusedBlocks;
     hipLaunchKernelGGL((pfFusedKernel<double, true>), dim3(grid), dim3(256), 0, stream, fa);
+    rc = fusedLaunched(sc);
+    if (rc) return rc;
+  } else {   // the same as launches of their own (see sipnet_batch_pf_analysis)
+    const int gridW = (int)((nSlots + 255) / 256);
+    hipLaunchKernelGGL(fixedWeightGatheredKernel, dim3(gridW), dim3(256), 0, stream, d_gathered, tab.world, tab.nmax, stride, sc.d_w);
+    size_t tmpBytes = sc.tmpBytes;
+    HIP_TRY(hipcub::DeviceScan::InclusiveSum(sc.d_tmp, tmpBytes, sc.d_w, sc.d_cdf, (int)nSlots, stream));
+    hipLaunchKernelGGL(ancestorKernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, sc.d_cdf, nSlots, first, n, nTotal, u0,
+                       d_ancestors, sc.d_blockSum + kFusedBlocks);
+    HIP_TRY(hipGetLastError());
+    if (d_total) HIP_TRY(hipMemcpyAsync(d_total, sc.d_blockSum + kFusedBlocks, sizeof(int64_t), hipMemcpyDeviceToDevice, stream));
   }
   auto groups = [](int rows) { return (rows + kGatherRows - 1) / kGatherRows; };
   PeerParts parts{};
@@ -1427,7 +1707,11 @@ int sipnet_batch_pf_resample_peers(sipnet_batch* b, const double* d_gathered, do
   parts.p[1] = PeerPart{b->d_ring2, SIPNET_RING_SLOTS, groups(SIPNET_NSTATE), b->precision == SIPNET_F32_MIXED ? 1 : 0};
   parts.n = 2;
   int total = groups(SIPNET_NSTATE) + groups(SIPNET_RING_SLOTS);
-  if (withParams) {
+  if (byIndex) {          // the particle's column in the bank of all ranks' parameters: one row of 4-byte elements
+    parts.p[2] = PeerPart{b->d_prmId2, 1, total, 1};
+    parts.n = 3;
+    total += 1;
+  } else if (withParams) {
     parts.p[2] = PeerPart{b->d_prm2, SIPNET_NPARAMS, total, 0};
     parts.n = 3;
     total += groups(SIPNET_NPARAMS);
@@ -1437,9 +1721,43 @@ int sipnet_batch_pf_resample_peers(sipnet_batch* b, const double* d_gathered, do
   HIP_TRY(hipGetLastError());
   std::swap(b->d_state, b->d_state2);
   std::swap(b->d_ring, b->d_ring2);
-  if (withParams) std::swap(b->d_prm, b->d_prm2);
-  if (b->pfPeers) b->pfPeers->parity ^= 1;
+  if (byIndex) {
+    std::swap(b->d_prmId, b->d_prmId2);
+    b->prmIndexed = true;   // (d_prm, the column-order copy, is behind the index now: materializeParams)
+  } else if (withParams) {
+    std::swap(b->d_prm, b->d_prm2);
+  }
+  if (b->pfPeers) {
+    b->pfPeers->parity ^= 1;
+    b->pfInfo.cycles++;
+  }
   return markBusy(b, stream);
+}
+
+// what the last analysis did, and how many of this rank's particles have crossed ranks (see sipnet_amd.h)
+int sipnet_batch_pf_info(sipnet_batch* b, sipnet_pf_info* out, void* hip_stream) {
+  if (!b || !out) {
+    setError("sipnet_batch_pf_info: bad argument");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  int rc = useDevice(b);
+  if (rc) return rc;
+  memset(out, 0, sizeof *out);
+  out->fused = b->pfInfo.fused;
+  out->grid = b->pfInfo.grid;
+  out->budget = b->pfInfo.budget;
+  out->world = b->pfPeers ? b->pfPeers->world : 1;
+  out->n_slots = b->pfInfo.nSlots;
+  out->cycles = b->pfInfo.cycles;
+  out->params_by_index = b->d_prmBank ? 1 : 0;
+  out->device_share = b->deviceShare;
+  if (b->d_pfCrossing) {
+    unsigned long long c = 0;
+    HIP_TRY(hipMemcpyAsync(&c, b->d_pfCrossing, sizeof c, hipMemcpyDeviceToHost, (hipStream_t)hip_stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)hip_stream));
+    out->crossing = (int64_t)c;
+  }
+  return SIPNET_OK;
 }
 
 }  // extern "C"

@@ -53,14 +53,14 @@ struct DevPlanSite {
   const double* preW;     // device [SIPNET_RING_SLOTS]: weights of the ring's live entries before the first record, front first
   int32_t n;              // records of the site
   int32_t site;           // its position in the batch (records at fast + site * nT)
-  int32_t opBase;         // its first RingOp in the flat array (room for 2 n + 8)
+  int32_t opBase;         // its first RingOp in the flat array (room for opCap = 2 n + preK + 8: engine.hip devRingOpRoom)
   int32_t preK;           // number of those entries (a fresh ring: one, carrying the whole window -- runmean.c:44-52)
   int32_t preStart;       // the front one's slot
   int32_t preIns;         // their insert step in the eviction records: -1 fresh, 0 resumed (buildSitePlan's init)
   int32_t phenInit;       // phenologyTrackers.lastYear before the first record (sipnet.c:1524; a checkpoint's)
   int32_t trackInit;      // trackers.lastYear before the first record (sipnet.c:1412: -1; a checkpoint's)
   int32_t hasEvents;      // the site's rows of evFirst / evCount / dTill / tillAfter are filled
-  int32_t pad;
+  int32_t opCap;          // entries of room behind opBase: the walk and planRunsKernel never write past it (status 3)
 };
 
 // what the ring walk (or planRunsKernel) leaves per step
@@ -98,7 +98,7 @@ struct DevPlanArgs {
   int32_t* blockInfo;         // [nDev][nBlk][2]: per 256 steps, "a step length changes in here" and the largest year
   int32_t nBlk;               // ceil(nT / 256)
   int32_t* siteOut;           // [nDev][8]: descriptors written, ring evictions written, status (0 ok, 1 ring overflow,
-                              //            2 ring ran empty), the step it happened at, ticks (10 ns) of the ring walk
+                              //            2 ring ran empty, 3 eviction list out of room), the step it happened at, ticks (10 ns) of the ring walk, the room its eviction list had
   int32_t flagGdd, phenMode, moistHResp, narrow;
   double convS, convE;
 };

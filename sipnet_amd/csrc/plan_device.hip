@@ -54,7 +54,7 @@ __device__ void ringWalk(const DevPlanArgs& a, const DevPlanSite& S, int d) {
   __shared__ double pre[256];   // the live entries the walk starts from (a fresh ring's one entry; a checkpoint's ring)
   __shared__ RingState st;
   const int lane = threadIdx.x, n = S.n;
-  const int K = S.preK, preIns = S.preIns;
+  const int K = S.preK, preIns = S.preIns, opCap = S.opCap;
   for (int i = lane; i < K; i += 64) pre[i] = S.preW[i];
   const double* len = a.lenC + (size_t)d * a.nT;
   DevPlanSeq* seq = a.seq + (size_t)d * a.nT;
@@ -111,7 +111,9 @@ __device__ void ringWalk(const DevPlanArgs& a, const DevPlanSite& S, int d) {
               wF = j >= t ? 0.0 : j >= 0 ? win[j & M] : pre[j + K];
             }
             RingOp op; op.w = wop; op.slot = slot; op.insStep = ins;
-            ops[opCount++] = op;
+            if (opCount < opCap) ops[opCount] = op;   // (the room is the bound 2 n + preK: never false for a ring that
+            else if (status != 3) { status = 3; statusAt = t; }   //  carries the window; a neighbour's list is not ours to write)
+            opCount++;
             if (nOps == 0) { s0 = slot; i0 = ins; w0 = wop; }
             else if (nOps == 1) { s1 = slot; i1 = ins; w1 = wop; }
             nOps++;
@@ -180,6 +182,7 @@ __device__ void ringWalk(const DevPlanArgs& a, const DevPlanSite& S, int d) {
           DevPlanRun r; r.t0 = st.ffT0; r.count = K; r.nOps = st.ffNOps; r.pad = 0;
           runs[st.nRuns++] = r;
           st.t += K; st.j += K; st.opCount += st.ffNOps * K;
+          if (st.opCount > opCap && st.status != 3) { st.status = 3; st.statusAt = st.ffT0; }
         } else {
           st.noFF = runEnd;
         }
@@ -190,7 +193,7 @@ __device__ void ringWalk(const DevPlanArgs& a, const DevPlanSite& S, int d) {
   }
   if (lane == 0) {
     int32_t* o = a.siteOut + 8 * d;
-    o[0] = st.nRuns; o[1] = st.opCount; o[2] = st.status; o[3] = st.statusAt;
+    o[0] = st.nRuns; o[1] = st.opCount; o[2] = st.status; o[3] = st.statusAt; o[5] = opCap;
   }
 }
 
@@ -229,10 +232,12 @@ __global__ __launch_bounds__(256) void planRunsKernel(DevPlanArgs a) {
   *(int4*)&q->packed = make_int4(wrapSlot(s0 + i) | (wrapSlot(s1 + i) << 8) | ((wrapSlot(insSlot + i) + 1) << 16), 0, 0, 0);
   RingOp* ops = a.ringOps + S.opBase;
   for (int k = 0; k < r.nOps; k++) {
+    const int dst = T.opFirst + r.nOps * i + k;
+    if (T.opFirst + k >= S.opCap || dst >= S.opCap) break;   // (the walk has set status 3)
     RingOp op = ops[T.opFirst + k];
     op.slot = wrapSlot(op.slot + i);
     op.insStep += i;
-    ops[T.opFirst + r.nOps * i + k] = op;
+    ops[dst] = op;
   }
 }
 

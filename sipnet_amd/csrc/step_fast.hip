@@ -150,8 +150,10 @@ void stepFastKernel(FastArgs a) {
 
   // ---- per-member constants ---------------------------------------------------
   // (a particle filter's batch keeps its parameters where set_params put them and resamples an index: batch_impl.h)
+  // (... or, a filter spread over ranks, in the bank of all ranks' parameters, whose rows are prmPitch columns long)
   const double* __restrict__ pp = a.prm + (a.prmId ? (int64_t)a.prmId[col] : col);
-#define PRM(name) (pp[(int64_t)SP_##name * nc])
+  const int64_t pnc = a.prmPitch;
+#define PRM(name) (pp[(int64_t)SP_##name * pnc])
   const double leafCSpWt = PRM(leafCSpWt);
   const double convK = kCWeight * (1.0 / kTen9) * (leafCSpWt / PRM(cFracLeaf)) * kSecPerDay;
   const double respPerGram = PRM(baseFolRespFrac) * PRM(aMax);
@@ -217,7 +219,7 @@ void stepFastKernel(FastArgs a) {
   const R G_iSoilCSat = Generic ? (R)(1.0 / PRM(soilCSaturation)) : R(0);
   const double leafOffDay = PRM(leafOffDay) > 0 ? PRM(leafOffDay) : 1e300;  // "never" (sipnet.c:735)
   // rarely needed parameters are re-read from HBM inside their (rare) branches
-#define PRM_RARE(name) ((R)pp[(int64_t)SP_##name * nc])
+#define PRM_RARE(name) ((R)pp[(int64_t)SP_##name * pnc])
 
   const Exp2Coef EC = loadExp2Coef();
 

@@ -126,6 +126,7 @@ struct FastArgs {
   double* pfLogw;         // [ncol] or null
   double* pfBlockMax;     // [workgroups of the launch]
   double pfObs, pfInvSigma;
+  int64_t prmPitch;       // one-wave kernel: columns of prm (ncol; a filter's parameter bank shared by all ranks: world * nmax)
 };
 // What a launcher actually put on the stream (sipnet_batch_last_launch): the instantiation's
 // name as rocprofv3 prints its template arguments, and the launch shape.

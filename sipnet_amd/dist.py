@@ -233,11 +233,19 @@ def pf_analysis(batch, plane, obs, sigma, u0, rank=0, world=1, group=None, with_
 
 # ---- the same analysis step without an all-to-all: peer reads (include/sipnet_amd.h, "the filter across ranks
 # WITHOUT an all-to-all") ------------------------------------------------------------------------------------
-def pf_connect_peers(batch, rank=0, world=1, group=None, with_params=True):
+def pf_connect_peers(batch, rank=0, world=1, group=None, with_params=True, pretend_world=0):
     """Once per filter: every rank publishes where its particles' checkpoint matrices live and maps the
-    others' (hipIpc handles between processes).  Host-side, off the cycle."""
+    others' (hipIpc handles between processes).  Host-side, off the cycle.
+    pretend_world = P > 1 (one real rank only): the slot count of a P-rank filter on one GPU -- the batch is connected to a
+    world of P whose every member is itself (its own descriptor P times; it plays rank P // 2), so that the analysis goes
+    over P x nmax weights and the gather reads "peers" that happen to be local: what an 8-GPU cycle costs apart from the
+    links.  pf_arm_peers / pf_analysis_peers must be given the same pretend_world."""
     import torch.distributed as dist
     mine = batch.pf_publish(with_params)
+    if pretend_world > 1:
+        assert world == 1, "pretend_world: one real rank only"
+        batch.pf_connect([mine] * pretend_world, pretend_world // 2)
+        return
     if world > 1:
         every = [None] * world
         dist.all_gather_object(every, mine, group=group)
@@ -246,10 +254,12 @@ def pf_connect_peers(batch, rank=0, world=1, group=None, with_params=True):
     batch.pf_connect(every, rank)
 
 
-def pf_arm_peers(batch, obs, sigma, rank=0, world=1):
+def pf_arm_peers(batch, obs, sigma, rank=0, world=1, pretend_world=0):
     """before the forecast's run() of a connected filter: that launch then leaves this rank's log-weights in its slice of
     the all-gather's buffer (sipnet_batch_pf_arm), and pf_analysis_peers only adds the block maxima"""
     import torch
+    if pretend_world > 1:
+        rank, world = pretend_world // 2, pretend_world
     L = batch.pf_block_len()
     gathered = getattr(batch, "_pf_gathered", None)
     if gathered is None or gathered.shape != (world, L):
@@ -258,7 +268,7 @@ def pf_arm_peers(batch, obs, sigma, rank=0, world=1):
 
 
 def pf_analysis_peers(batch, plane, obs, sigma, u0, rank=0, world=1, group=None, total_out=None,
-                      collectives=None, gathered=None, ancestors=None, diagnostics=False):
+                      collectives=None, gathered=None, ancestors=None, diagnostics=False, pretend_world=0):
     """One analysis step of a connected filter (pf_connect_peers): this rank's log-weight block -> ONE
     all-gather of the blocks -> weights, prefix sum and this rank's ancestors -> one gather that reads each
     ancestor where it lives.  No host synchronisation, no second collective.  Returns (ancestor slots
@@ -267,6 +277,9 @@ def pf_analysis_peers(batch, plane, obs, sigma, u0, rank=0, world=1, group=None,
     import torch.distributed as dist
     if collectives is None:
         collectives = world > 1
+    pretend = pretend_world > 1
+    if pretend:
+        rank, world = pretend_world // 2, pretend_world
     L = batch.pf_block_len()
     if gathered is None:
         gathered = getattr(batch, "_pf_gathered", None)
@@ -274,7 +287,14 @@ def pf_analysis_peers(batch, plane, obs, sigma, u0, rank=0, world=1, group=None,
             gathered = batch._pf_gathered = torch.empty((world, L), dtype=torch.float64, device=batch.device)
     mine = gathered[rank]
     batch.pf_local_weights(plane, obs, sigma, mine)
-    if collectives:
+    if pretend:
+        # the one real rank's all-gather (in place, its own slice), then the block copied into the other ranks' slices: two
+        # device copies of (P - 1) blocks stand where the links' time would be
+        if collectives:
+            dist.all_gather_into_tensor(mine, mine, group=group)
+        gathered[:rank].copy_(mine.expand(rank, L))
+        gathered[rank + 1:].copy_(mine.expand(world - rank - 1, L))
+    elif collectives:
         if _host_staged(mine, group):
             out = torch.empty((world, L), dtype=torch.float64)
             dist.all_gather_into_tensor(out.view(-1), mine.cpu(), group=group)
@@ -290,7 +310,11 @@ def pf_analysis_peers(batch, plane, obs, sigma, u0, rank=0, world=1, group=None,
     logw = gathered[:, :nmax].reshape(-1)
     w = torch.exp(logw - logw.max())
     crossed = int(((anc // nmax) != rank).sum())
-    words = batch.L.sipnet_batch_member_words(batch.h, 1)
+    pinfo = batch.pf_info()
+    # a crossing particle: state + ring + its 4-byte column in the replicated parameter bank -- or its parameter rows
+    per = batch.L.sipnet_batch_member_words(batch.h, 0) * 8 + 4 if pinfo["params_by_index"] else batch.L.sipnet_batch_member_words(batch.h, 1) * 8
     info = {"ess": float(w.sum() ** 2 / (w * w).sum()), "unique_ancestors": int(torch.unique_consecutive(anc).numel()),
-            "received": crossed, "sent": 0, "bytes_received": crossed * words * 8, "exchange": "peer reads"}
+            "received": crossed, "sent": 0, "bytes_received": crossed * per, "bytes_per_crossing_particle": per,
+            "exchange": "peer reads", "params_by_index": pinfo["params_by_index"], "analysis_one_launch": pinfo["fused"],
+            "analysis_grid": pinfo["grid"], "analysis_slots": pinfo["n_slots"]}
     return anc, info

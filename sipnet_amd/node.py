@@ -212,5 +212,13 @@ class Node:
         check(self.L.sipnet_node_pf_check(self.h, C.byref(n)), "node_pf_check")
         return n.value
 
+    def pf_info(self, k):
+        """sipnet_batch_pf_info of shard k's batch"""
+        from ._lib import PfInfo
+        d = PfInfo()
+        check(self.L.sipnet_batch_pf_info(self.L.sipnet_node_batch(self.h, k), C.byref(d), self.L.sipnet_node_stream(self.h, k)),
+              "pf_info")
+        return {f: getattr(d, f) for f, _ in PfInfo._fields_}
+
     def pf_ancestors(self, k):
         return self._to_host(self.L.sipnet_node_pf_ancestors(self.h, k), (self.member_range(k)[1],), np.int32)

@@ -66,3 +66,26 @@ def test_two_rank_gloo_gather_matches_single_process(tmp_path):
         assert np.allclose(mean, full.mean(-1), atol=1e-12)
         assert np.allclose(var, full.var(-1), atol=1e-12)
         assert list(np.load(tmp_path / f"planes_shape{r}.npy")) == [2, 3, n_steps, 50]
+
+
+@pytest.mark.timeout(180)
+def test_bench_starts_its_own_ranks_when_no_launcher_is_in_front():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment: bench.py is its own launcher (a child
+    `python -m torch.distributed.run`, bench.launch_ranks) instead of exiting 2 -- the driver's multi-GPU command may
+    be given either way.  --launch-probe: the ranks only meet over gloo (no GPU here); the same command with the real
+    workload runs under `-m gpu` (tests/test_gpu_multirank.py)."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--launch-probe"],
+                       capture_output=True, text=True, timeout=170, env=env, cwd=REPO)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+    lines = [json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1, r.stdout                       # rank 0's ONE line, relayed
+    assert lines[0]["ranks_seen"] == 2 and lines[0]["processes_seen"] == 2 and lines[0]["n_gpus"] == 2
+    # ... and a failing rank's return code is the command's
+    bad = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--workload", "c2", "--nsteps", "48",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=170,
+                         env=dict(env, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES=""), cwd=REPO)
+    assert bad.returncode not in (0, 2), bad.stderr[-1500:]   # (2 was "needs torch.distributed.run")

@@ -68,6 +68,21 @@ def test_two_ranks_rehearsed_on_one_gpu_equal_a_single_process(workload, members
         assert not np.allclose(a[:, :, 0], a[:, :, 32])          # different forcing per site
 
 
+def test_bench_launches_its_own_ranks():
+    """the driver's command without a launcher in front: `python3 bench.py --gpus 2 ...` starts torch.distributed.run as a
+    child before anything touches the GPU and relays rank 0's one JSON line and the child's return code"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--rehearse", "--workload", "c2", "--nsteps", "480",
+                        "--steps", "2", "--warmup", "1", "--no-fill-probe", "--no-end-to-end"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=helpers.REPO)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [x for x in r.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1, r.stdout[-3000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["ranks_seen"] == 2 and j["scaling"] == "weak"
+    assert j["parity"]["max_abs_dNEE"] < 1e-9
+
+
 @pytest.mark.parametrize("exchange", ["peer", "alltoall"])
 def test_particle_filter_cycle_two_ranks_rehearsed(tmp_path, exchange):
     """c5 with two ranks (two PROCESSES) on this one GPU.  peer: likelihood weights -> ONE all-gather of the

@@ -275,7 +275,8 @@ def _filter_twin(base, clim, members, prec, T, obs_sigma=None, u0=0.43):
 
 
 @pytest.mark.parametrize("prec", [sa.F64, sa.F32_MIXED], ids=["f64", "f32ring"])
-@pytest.mark.parametrize("devices,n", [([0, 0], 1024), ([0, 0, 0], 1000), ([0], 700)], ids=["two-shards", "ragged-three", "rccl-one-rank"])
+@pytest.mark.parametrize("devices,n", [([0, 0], 1024), ([0, 0, 0], 1000), ([0], 700), ([0] * 6, 6 * 64 * 9 + 5)],
+                         ids=["two-shards", "ragged-three", "rccl-one-rank", "six-shards-one-device"])
 def test_node_filter_cycle_equals_the_one_batch_analysis(base, devices, n, prec):
     """forecast -> sipnet_node_pf_analysis (log-weight blocks, ONE all-gather, peer-read resampling) over member
     shards on one GPU against sipnet_batch_pf_analysis over all particles in one batch: same ancestors, state,
@@ -306,6 +307,15 @@ def test_node_filter_cycle_equals_the_one_batch_analysis(base, devices, n, prec)
         np.testing.assert_array_equal(nd.shard_state(k), twin["state"][m0:m0 + mc])
     if nd.n > 1:
         assert crossed > 0                                                   # particles did cross between the shards
+    # what the exchange reports about itself: the crossing particles counted by the gather, the parameters replicated on
+    # every shard (an index travels), and -- six filters analysing on ONE device at the same time -- each one's spinning grid
+    # sized to its share of the resident workgroups (sipnet_batch_set_device_share, set by the node)
+    infos = [nd.pf_info(k) for k in range(nd.n)]
+    assert sum(i["crossing"] for i in infos) == crossed and all(i["cycles"] == 1 and i["world"] == nd.n for i in infos)
+    assert all(i["params_by_index"] == 1 and i["device_share"] == len(devices) for i in infos)
+    assert all(i["fused"] == 1 and i["grid"] <= i["budget"] <= 512 for i in infos), infos
+    if len(devices) == 6:
+        assert all(i["budget"] < 512 for i in infos), infos                  # (8 resident workgroups per CU x 256 CUs / 6 = 341)
     nd.forecast(T, T)
     got = nd.member_planes()[:, :, 0, :]
     np.testing.assert_array_equal(got, twin["next"])
@@ -364,6 +374,120 @@ def test_node_filter_several_cycles_and_a_dead_filter(base):
         nd.pf_check()
     assert e.value.code == 3 and "zero weight" in str(e.value)
     nd.close()
+
+
+@pytest.mark.parametrize("prec", [sa.F64, sa.F32_MIXED], ids=["f64", "f32"])
+def test_the_replicated_parameter_bank_equals_moving_the_rows(base, prec):
+    """Particles that carry their parameters across ranks: by default every shard holds all shards' converted parameters
+    (sipnet_batch_pf_connect copies them once) and a resampled particle brings a 4-byte column number; with
+    SIPNET_KOPT_PF_MOVE_PARAMS its 640 bytes of rows travel instead (round 5).  Three cycles on the ONE-WAVE kernel, which
+    reads the bank through the index (the index composed three times across shards), against the rows: planes, state,
+    rings bit for bit; then setupModel() on the indexed shards (the rows come back out of the bank); and new parameters on
+    a connected shard must be refused at the next exchange, not silently read from the stale copies on the peers."""
+    T, n = 48, 64 * 30 + 11
+    clim = synth.convert_raw(synth.round_like_file(synth.half_hourly_year_raw(5 * T)))
+    members = synth.perturbed_params(base, n, seed=31)
+    out = {}
+    for opt in (0, sa.KOPT_PF_MOVE_PARAMS):
+        nd = Node(sa.flags_from(), 1, n, precision=prec, devices=[0, 0, 0], shard=SHARD_MEMBERS, fast_math=True,
+                  kernel=sa.KERNEL_ONE_WAVE, kernel_options=opt)
+        nd.set_climate(0, clim)
+        nd.set_params(0, members)
+        nd.setup()
+        nd.pf_connect(with_params=True)
+        planes = []
+        for c in range(3):
+            nd.forecast(c * T, T)
+            planes.append(nd.member_planes()[:, :, 0, :].copy())
+            tot = planes[-1][0].sum(0)
+            nd.pf_analysis(0, float(np.median(tot)), float(tot.std()) * 0.6 + 1e-12, 0.15 + 0.3 * c)
+        assert nd.pf_check() == 3
+        assert "stepFastKernel" in nd.kernel_name(0)
+        infos = [nd.pf_info(k) for k in range(3)]
+        assert all(i["params_by_index"] == (0 if opt else 1) and i["cycles"] == 3 for i in infos)
+        nd.forecast(3 * T, T)                                    # the thrice-resampled particles, through the index
+        planes.append(nd.member_planes()[:, :, 0, :].copy())
+        state = np.concatenate([nd.shard_state(k) for k in range(3)])
+        rings = np.concatenate([nd.shard_rings(k)[:, :4 * T + 1] for k in range(3)])
+        nd.setup()                                               # setupModel(): every column from the parameters it carries now
+        nd.forecast(0, T)
+        planes.append(nd.member_planes()[:, :, 0, :].copy())
+        out[opt] = (planes, state, rings, sum(i["crossing"] for i in infos))
+        if not opt:
+            nd.set_params(0, members[:100][::-1].copy())         # ... and a re-draw on a connected filter
+            nd.forecast(T, T)
+            with pytest.raises(sa.SipnetError) as e:
+                nd.pf_analysis(0, 0.0, 1.0, 0.5)
+            assert "connect again" in str(e.value)
+            nd.pf_connect(with_params=True)                      # publish + connect: a new bank
+            nd.forecast(T, T)
+            nd.pf_analysis(0, float(np.median(tot)), 1.0, 0.5)
+            assert nd.pf_check() == 1
+        nd.close()
+    for a, c in zip(out[0][0], out[sa.KOPT_PF_MOVE_PARAMS][0]):
+        assert np.array_equal(a, c, equal_nan=True)
+    assert np.array_equal(out[0][1], out[sa.KOPT_PF_MOVE_PARAMS][1], equal_nan=True)
+    assert np.array_equal(out[0][2], out[sa.KOPT_PF_MOVE_PARAMS][2], equal_nan=True)
+    assert out[0][3] == out[sa.KOPT_PF_MOVE_PARAMS][3] > 0
+
+
+@pytest.mark.parametrize("prec", [sa.F64, sa.F32_MIXED], ids=["f64", "f32"])
+def test_a_pretended_world_of_eight_on_one_batch(base, prec):
+    """The slot count of an 8-rank filter on ONE GPU: a batch connected to a world of eight whose every member is itself
+    (its descriptor eight times), the gathered buffer its own block eight times -- what bench.py --pretend-world times.
+    Rank 5's particles: ancestors = the oracle's over all 8 n slots (cut to rank 5's range), the resampled state = the
+    batch's own columns anc % nmax, the parameters read through the index into the eight-fold bank."""
+    from oracle import pf_oracle as po
+    T, n, world, rank = 48, 64 * 20 + 9, 8, 5
+    clim = synth.convert_raw(synth.round_like_file(synth.half_hourly_year_raw(2 * T)))
+    members = synth.perturbed_params(base, n, seed=41)
+    b = sa.Batch(sa.flags_from(), 1, n, prec, fast_math=True, kernel=sa.KERNEL_ONE_WAVE)
+    b.set_climate(0, clim)
+    b.set_params(0, members)
+    b.setup()
+    p, _ = b.run(0, T)
+    state0 = b.get_state().copy()
+    tot = p[0].double().sum(0)
+    obs, sigma = float(tot.median()), float(tot.std()) * 0.5 + 1e-12
+    d = b.pf_publish(with_params=True)
+    b.pf_connect([d] * world, rank)
+    L = b.pf_block_len()
+    gathered = torch.empty((world, L), dtype=torch.float64, device=DEV)
+    b.pf_local_weights(p[0], obs, sigma, gathered[rank])
+    gathered[:] = gathered[rank].clone()
+    total = torch.zeros(1, dtype=torch.int64, device=DEV)
+    anc = b.pf_resample_peers(gathered, 0.29, total_out=total).cpu().numpy()
+    info = b.pf_info()
+    assert info["world"] == world and info["n_slots"] == world * n and info["params_by_index"] == 1 and info["fused"] == 1
+    # (device exp vs glibc exp may round a weight to the neighbouring integer: the oracle resamples the device's own integers)
+    _, fixed1 = sd_fixed(b.pf_log_weights(p[0], obs, sigma))
+    fixed = np.tile(fixed1, world)
+    assert np.abs(fixed1 - po.fixed_weights(gathered[rank, :n].cpu().numpy())).max() <= 1
+    want = po.systematic_ancestors(fixed, 0.29)[rank * n:(rank + 1) * n]
+    np.testing.assert_array_equal(anc, want)
+    assert int(total.item()) == int(fixed.sum())
+    assert info["crossing"] == int((anc // n != rank).sum()) > 0
+    np.testing.assert_array_equal(b.get_state(), state0[anc % n])
+    # the next forecast reads every particle's parameters through the index into the eight-fold bank: a twin that resamples
+    # the same columns inside ONE batch (sipnet_batch_resample, its own index) must continue bit for bit alike
+    twin = sa.Batch(sa.flags_from(), 1, n, prec, fast_math=True, kernel=sa.KERNEL_ONE_WAVE)
+    twin.set_climate(0, clim)
+    twin.set_params(0, members)
+    twin.setup()
+    twin.run(0, T)
+    twin.resample(torch.from_numpy((anc % n).astype(np.int32)).to(DEV), with_params=True)
+    p2, _ = b.run(T, T)
+    q2, _ = twin.run(T, T)
+    assert torch.equal(p2.view(torch.uint8), q2.view(torch.uint8))
+    np.testing.assert_array_equal(b.get_state(), twin.get_state())
+    b.close()
+    twin.close()
+
+
+def sd_fixed(logw):
+    from sipnet_amd import dist as sd
+    anc, fixed = sd.pf_systematic_ancestors(logw, 0.5, return_fixed=True)
+    return anc, fixed.cpu().numpy()
 
 
 def test_peer_resampling_of_an_unconnected_batch_is_the_one_call_analysis(base):

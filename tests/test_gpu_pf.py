@@ -365,3 +365,94 @@ def test_log_weights_from_the_forecast_launch_equal_the_analysis_own(base, clim,
         assert t0 is None or torch.equal(t0, t1)
     assert torch.isinf(res[True][0][0][1][70])
     assert np.array_equal(res[False][1], res[True][1], equal_nan=True) and np.array_equal(res[False][2], res[True][2], equal_nan=True)
+
+
+# ---- round 6: the one-launch analysis' geometry, residency guard and way out -----------------------------------------
+def _analysis_reference(b, nee, obs, sigma, u0):
+    """the three entry points one by one (multi-launch path): ancestors, integer weights"""
+    logw = b.pf_log_weights(nee, obs, sigma)
+    anc, fixed = sd.pf_systematic_ancestors(logw, u0, return_fixed=True)
+    return anc, fixed, logw
+
+
+@pytest.mark.parametrize("prec", [sa.F64, sa.F32_MIXED], ids=["f64", "f32"])
+def test_one_launch_analysis_geometry_follows_the_device_not_a_constant(base, clim, prec):
+    """The grid of pfFusedKernel is what the device can keep resident (occupancy x compute units / filters sharing the
+    device), not a compile-time 512: a batch that believes it has 32 compute units (one partition of a CPX-mode MI355X),
+    2, or a sixth of the device, and the multi-launch path when next to nothing is left -- all with the ancestors,
+    log-weights and total weight of the reference path, and the oracle's ancestors for those integer weights.  With few
+    workgroups a thread owns SEVERAL consecutive slots (the serial sums + one block scan per workgroup of round 6)."""
+    n = 64 * 150 + 37
+    members = synth.perturbed_params(base, n, seed=5)
+    members[11, pi("leafAllocation")] = 0.9            # status 3: weight -inf
+    members[11, pi("woodAllocation")] = 0.9
+    ref = batch_of(clim, members, prec)
+    planes, _ = ref.run(0, 48)
+    nee = planes[0]
+    tot = nee.double().sum(0)
+    obs, sigma = float(tot.median()), float(tot[torch.isfinite(tot)].std()) * 0.5 + 1e-12
+    anc_ref, fixed, logw_ref = _analysis_reference(ref, nee, obs, sigma, 0.37)
+    np.testing.assert_array_equal(anc_ref.cpu().numpy(), po.systematic_ancestors(fixed.cpu().numpy(), 0.37))
+    ref.close()
+    seen = set()
+    for cus, share, opts in ((256, 1, 0), (32, 1, 0), (2, 1, 0), (256, 6, 0), (1, 6, 0), (256, 1, sa.KOPT_PF_MULTI_LAUNCH)):
+        b = sa.Batch(sa.flags_from(), 1, n, prec, fast_math=True, kernel_options=opts)
+        b.set_climate(0, clim)
+        b.set_params(0, members)
+        b.setup()
+        p, _ = b.run(0, 48)
+        assert torch.equal(p[0], nee)
+        b.debug_set_num_cus(cus)
+        b.set_device_share(share)
+        total = torch.zeros(1, dtype=torch.int64, device=DEV)
+        anc, logw = b.pf_analysis_local(p[0], obs, sigma, 0.37, with_params=True, total_out=total)
+        info = b.pf_info()
+        assert torch.equal(anc, anc_ref) and torch.equal(logw.view(torch.int64), logw_ref.view(torch.int64)), (cus, share, opts, info)
+        assert int(total.item()) == int(fixed.sum().item()) > 0
+        assert info["device_share"] == share
+        if opts or info["budget"] < 8:
+            assert info["fused"] == 0 and info["grid"] == 0, info
+        else:
+            assert info["fused"] == 1 and 1 <= info["grid"] <= min(info["budget"], 512), info
+            assert info["budget"] <= 512, info
+        seen.add((info["fused"], info["grid"]))
+        b.close()
+    assert any(f == 1 and 0 < g * 256 < n for f, g in seen), seen        # several slots per thread did happen
+    assert any(f == 0 for f, g in seen) and len(seen) >= 4, seen
+
+
+def test_a_grid_that_is_not_co_resident_ends_with_an_error_not_a_hang(base, clim):
+    """A workgroup of the one-launch analysis that never arrives (test hook) stands for one that was never scheduled: the
+    others' polls run out of budget, the launch is void -- total weight INT64_MIN, SIPNET_ERR_INTERNAL from the
+    synchronous call -- and the NEXT analysis of the same batch is not affected (round 5's counters grew across launches:
+    every later launch would have spun for ever)."""
+    n = 64 * 64
+    members = synth.perturbed_params(base, n, seed=6)
+    b = sa.Batch(sa.flags_from(), 1, n, sa.F64, fast_math=True)
+    b.set_climate(0, clim)
+    b.set_params(0, members)
+    b.setup()
+    p, _ = b.run(0, 48)
+    tot = p[0].double().sum(0)
+    obs, sigma = float(tot.median()), float(tot.std()) * 0.5 + 1e-12
+    anc_ref, fixed, _ = _analysis_reference(b, p[0], obs, sigma, 0.37)
+    state0 = b.get_state().copy()
+    # (a) asynchronous: the void mark is where the caller looks for the total weight
+    b.debug_pf_barrier(spin_budget=4096, absent_workgroup=3)
+    total = torch.zeros(1, dtype=torch.int64, device=DEV)
+    b.pf_analysis_local(p[0], obs, sigma, 0.37, with_params=True, total_out=total)
+    assert int(total.item()) == sa.PF_VOID_TOTAL
+    # (b) synchronous: an error that names the barrier
+    b.set_state(state0)
+    b.debug_pf_barrier(spin_budget=4096, absent_workgroup=0)
+    with pytest.raises(sa.SipnetError) as e:
+        b.pf_analysis_local(p[0], obs, sigma, 0.37, with_params=True)
+    assert e.value.code == 7 and "gave up" in str(e.value), str(e.value)      # SIPNET_ERR_INTERNAL
+    # (c) afterwards: as if nothing had happened, 70 times (the ring of barrier sets goes round)
+    b.debug_pf_barrier(spin_budget=0, absent_workgroup=-1)
+    for k in range(70):
+        b.set_state(state0)
+        anc, _ = b.pf_analysis_local(p[0], obs, sigma, 0.37, with_params=True, total_out=total)
+        if k in (0, 33, 69):
+            assert torch.equal(anc, anc_ref) and int(total.item()) == int(fixed.sum().item())
+    b.close()

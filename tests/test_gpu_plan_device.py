@@ -50,7 +50,7 @@ def compare(b, site, ignore_log2=True):
     sa._lib.check(lib().sipnet_debug_plan_compare(b.h, site, int(ignore_log2), C.byref(nr), C.byref(no), C.byref(fs),
                                                   C.byref(fo), info), "plan_compare")
     return dict(records=nr.value, ops=no.value, first_step=fs.value, first_offset=fo.value, runs=info[0], n_ops=info[1],
-                status=info[2], status_at=info[3], ring_walk_us=info[4] / 100.0)
+                status=info[2], status_at=info[3], ring_walk_us=info[4] / 100.0, room=info[5])
 
 
 def forcings():
@@ -281,6 +281,61 @@ def test_a_resumed_segment_is_built_on_the_device_too(base, prec):
             b2.close()
         assert torch.equal(res[sa.KOPT_DEVICE_PLAN][0].view(torch.uint8), res[sa.KOPT_HOST_PLAN][0].view(torch.uint8))
         assert np.array_equal(res[sa.KOPT_DEVICE_PLAN][1], res[sa.KOPT_HOST_PLAN][1], equal_nan=True)
+
+
+def test_a_resumed_ring_of_many_entries_fits_its_eviction_list(base):
+    """a checkpoint's ring of ~241 half-hourly entries followed by a segment with a step long enough to evict them all at
+    once: 2 n + preK evictions in the worst case, more than a fresh ring's 2 n -- the list's room follows the checkpoint
+    (engine.hip devRingOpRoom), the walk never writes past it, and the NEXT site's list is the host builder's bytes too"""
+    yc = FORCINGS["half-hourly year"]
+    members = synth.perturbed_params(base, 64, seed=11)
+    b1 = sa.Batch(sa.flags_from(), 1, 64, sa.F64, fast_math=True)
+    b1.set_climate(0, yc.slice(0, 400))
+    b1.set_params(0, members)
+    b1.setup()
+    b1.run(0, 400)
+    ck = b1.export_restart(0, 0, 400)
+    b1.close()
+    half = 1 / 48
+    tails = {"n = 1, one 4.9-day step": [4.9], "a daily step": [1.0, half, half], "999 half-hourly + one 4-day step": [half] * 999 + [4.0],
+             "alternating": [half, 4.0, half, 4.5] * 20}
+    names = list(tails)
+    clims = [with_lengths(yc.slice(400, 400 + len(tails[k])), tails[k]) for k in names]
+    b2 = sa.Batch(sa.flags_from(), len(names), 64, sa.F64, fast_math=True, kernel_options=sa.KOPT_DEVICE_PLAN)
+    b2.set_climates(clims)
+    b2.set_params(None, members)
+    for s in range(len(names)):
+        b2.set_resume(s, ck)
+    b2.setup()
+    assert b2.last_launch()["plan_device_sites"] == len(names)
+    for s, k in enumerate(names):
+        r = compare(b2, s)
+        n = len(tails[k])
+        assert r["status"] == 0 and r["records"] == 0 and r["ops"] == 0 and r["n_ops"] <= r["room"], (k, r)
+        assert r["room"] > 2 * n + 8 + 200, (k, r)       # (the checkpoint's entries are in the bound)
+    assert compare(b2, 0)["n_ops"] > 2 * 1 + 8           # n = 1: the old room (10) would not have held the list
+    b2.close()
+
+
+def test_a_resumed_ring_that_does_not_carry_the_window_is_the_hosts(base):
+    """the device walk assumes the live weights sum to the 5-day window (it cannot run empty or fill up then); a checkpoint
+    whose ring does not is left to the host builder, which treats it as the reference does"""
+    yc = FORCINGS["half-hourly year"]
+    b1 = sa.Batch(sa.flags_from(), 1, 64, sa.F64, fast_math=True)
+    b1.set_climate(0, yc.slice(0, 400))
+    b1.set_params(0, base)
+    b1.setup()
+    b1.run(0, 400)
+    ck = b1.export_restart(0, 0, 400)
+    b1.close()
+    ck.mean_weights[ck.mean_last] += 0.004           # a little more than the window
+    b2 = sa.Batch(sa.flags_from(), 1, 64, sa.F64, fast_math=True, kernel_options=sa.KOPT_DEVICE_PLAN)
+    b2.set_climate(0, yc.slice(400, 2000))
+    b2.set_params(0, base)
+    b2.set_resume(0, ck)
+    b2.setup()
+    assert b2.last_launch()["plan_device_sites"] == 0
+    b2.close()
 
 
 def test_random_forcings_against_the_host_builder(base):
