@@ -117,7 +117,9 @@ __global__ __launch_bounds__(256) void gatherMemberKernel(GatherParts parts, int
 }
 
 // logw[col] = -0.5 * ((sum_t plane[t][col] - obs) / sigma)^2, -inf for members that did not run
-template <typename T>
+// (AgentStore: the log-weight is written through to device scope -- pfFusedKernel's phase 3 reads it from other workgroups,
+// possibly on another XCD, inside the same launch)
+template <typename T, bool AgentStore = false>
 __device__ __forceinline__ double logWeightOf(const T* __restrict__ plane, int32_t nSteps, int64_t ld, int64_t c,
                                               const double* __restrict__ status, double obs, double invSigma,
                                               double* __restrict__ logw) {
@@ -135,7 +137,8 @@ __device__ __forceinline__ double logWeightOf(const T* __restrict__ plane, int32
   for (; t < nSteps; t++) acc += (double)plane[(int64_t)t * ld + c];
   const double z = (acc - obs) * invSigma;
   const double lw = (status[c] != 0.0) ? -INFINITY : -0.5 * z * z;
-  logw[c] = lw;
+  if (AgentStore) __hip_atomic_store(&logw[c], lw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else logw[c] = lw;
   return lw;
 }
 // (part, if given: the block's maximum -- what maxPartialKernel would compute in a launch of its own)
@@ -195,7 +198,34 @@ __global__ __launch_bounds__(256) void maxPartialKernel(const double* __restrict
   if (threadIdx.x == 0) part[blockIdx.x] = sm[0];
 }
 
-// fixed-point weights: w = llrint(exp(logw - max) * 2^30).  Integer weights make the prefix
+// THE fixed-point weight of a log-weight lw under the maximum m: rint(2^30 exp(lw - m)), 0 for a particle that did not run
+// (-inf) or a filter none of whose particles did.  Every device path takes it from here -- the separate-launch kernels, the
+// one-launch analysis, one rank or many -- so that they agree to the bit (the numpy oracle's glibc exp may round a weight
+// to the neighbouring integer; the tests allow that one unit and resample the DEVICE's integers exactly).
+// 2^30 e^x = 2^(30 + x log2 e): n = rint(y), 2^(y - n) by the degree-11 interpolant of fast_math.h (|rel err| <= 1.7e-16),
+// one v_ldexp -- a fifth of OCML's exp() + llrint(), which was what grew with the number of ranks: 8 x 131 072 slots cost
+// every wavefront eight of them (7.9 us of the analysis launch, profiles/r06_pf_analysis_phases.txt).
+__device__ __forceinline__ long long pfFixedWeight(double lw, double m) {
+  const double x = lw - m;                  // <= 0 (NaN when both are -inf)
+  if (!(x >= -21.5)) return 0;              // 2^30 e^x < 0.5 below that; also lw = -inf, m = -inf (NaN), NaN weights
+  const double y = x * 1.4426950408889634074;
+  const double n = __builtin_rint(y), f = y - n;
+  double p = 4.4549605981865186e-10;
+  p = __builtin_fma(p, f, 7.072585949269223e-09);
+  p = __builtin_fma(p, f, 1.0178062445845774e-07);
+  p = __builtin_fma(p, f, 1.321544258792169e-06);
+  p = __builtin_fma(p, f, 1.525273382983612e-05);
+  p = __builtin_fma(p, f, 0.0001540353044173605);
+  p = __builtin_fma(p, f, 0.0013333558146416936);
+  p = __builtin_fma(p, f, 0.009618129107606888);
+  p = __builtin_fma(p, f, 0.0555041086648216);
+  p = __builtin_fma(p, f, 0.24022650695910097);
+  p = __builtin_fma(p, f, 0.6931471805599453);
+  p = __builtin_fma(p, f, 1.0);
+  return (long long)(int)__builtin_rint(__builtin_amdgcn_ldexp(p, (int)n + 30));   // (<= 2^30: an int)
+}
+
+// fixed-point weights: w = rint(exp(logw - max) * 2^30).  Integer weights make the prefix
 // sum exact, so every rank computes bit-identical ancestors from the same gathered logw.
 // (every block first takes the maximum of the `parts` partial maxima itself: one launch less)
 __global__ __launch_bounds__(256) void fixedWeightKernel(const double* __restrict__ logw,
@@ -212,9 +242,7 @@ __global__ __launch_bounds__(256) void fixedWeightKernel(const double* __restric
   }
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const double m = sm[0];
-  const double e = exp(logw[i] - m);
-  w[i] = (!(logw[i] > -INFINITY) || !(m > -INFINITY)) ? 0 : llrint(e * 1073741824.0);
+  w[i] = pfFixedWeight(logw[i], sm[0]);
 }
 
 // ancestor[j] = first slot i with cdf[i] > p_j, p_j = ((j0 + j + u0) * S) / nTotal  (S = cdf[nSlots-1] < 2^53)
@@ -273,10 +301,7 @@ __global__ __launch_bounds__(256) void fixedWeightGatheredKernel(const double* _
   }
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (int64_t)world * nmax) return;
-  const double m = sm[0];
-  const double lw = gathered[(i / nmax) * stride + i % nmax];
-  const double e = exp(lw - m);
-  w[i] = (!(lw > -INFINITY) || !(m > -INFINITY)) ? 0 : llrint(e * 1073741824.0);
+  w[i] = pfFixedWeight(gathered[(i / nmax) * stride + i % nmax], sm[0]);
 }
 // ---- the analysis in ONE launch (round 5; geometry, barrier and phases reworked in round 6) ------------------------
 // Log-weights + maximum | fixed-point weights + prefix sum | ancestors were five launches plus hipCUB's two (and
@@ -306,6 +331,7 @@ __global__ __launch_bounds__(256) void fixedWeightGatheredKernel(const double* _
 #endif
 constexpr int kFusedBlocks = SIPNET_PF_BLOCKS;   // (<= 512: phase 3 scans the chunk totals two per thread)
 constexpr int kFusedMinBlocks = 8;               // fewer resident workgroups than this: the multi-launch path
+constexpr int kFusedMaxPer = 16;                 // ... or more slots per thread than this (phase 3 adds a thread's weights up again)
 constexpr long long kPfVoid = LLONG_MIN;         // "total weight" of a launch whose barrier gave up
 #ifdef SIPNET_PF_STAMPS   // (probe, tools/pf_analysis_time.py: where the launch spends its time -- workgroup 0's clock at every phase)
 __device__ unsigned long long g_pfStamps[8];
@@ -336,7 +362,8 @@ struct FusedArgs {
   // phase 1 done already by the forecast's own launch (FastArgs::pfLogw): logw is filled, preMax[nPre] are partial maxima
   const double* preMax;
   int32_t nPre;
-  int64_t* w;                // [nSlots] the fixed-point weights
+  const double* logwIn;      // [nSlots] phase 2's input in the one-batch analysis (= logw)
+  int64_t* threadIncl;       // [gridDim.x][256] every thread's inclusive sum of weights inside its chunk
   int64_t* blockSum;         // [gridDim.x]
   unsigned long long* barrier;   // THIS launch's barrier set (kBarSetWords words, all zero when the launch starts)
   unsigned long long* barrierAhead;   // the set of the launch kBarAhead launches from now: zeroed by this one
@@ -470,7 +497,7 @@ __global__ __launch_bounds__(256) void pfFusedKernel(FusedArgs a) {
     // ---- phase 1: this chunk's log-weights and their maximum (lanes on neighbouring columns of the plane) ----
     double mine = -INFINITY;
     for (int64_t i = lo + tid; i < hi; i += 256)
-      mine = fmax(mine, logWeightOf((const T*)a.plane, a.nSteps, a.ld, i, a.status, a.obs, a.invSigma, a.logw));
+      mine = fmax(mine, logWeightOf<T, true>((const T*)a.plane, a.nSteps, a.ld, i, a.status, a.obs, a.invSigma, a.logw));
     mine = blockMax256(mine, smD);
     if (tid == 0) stAgent(&a.blockMax[b], mine);
     PF_STAMP(1)
@@ -481,13 +508,33 @@ __global__ __launch_bounds__(256) void pfFusedKernel(FusedArgs a) {
     for (int k = tid; k < nb; k += 256) pm = fmax(pm, ldAgent(&a.blockMax[k]));
     m = blockMax256(pm, smD);
   } else {
+    // the maximum over every rank's block maxima (512 workgroups read the same world x P doubles at the same time: each starts
+    // with another rank's, and no division in the index -- 6.5 us at 8 x 512 maxima before, profiles/r06_pf_analysis_phases.txt)
     const int P = (a.nmax + 255) / 256;
     double pm = -INFINITY;
-    for (int k = tid; k < a.world * P; k += 256) pm = fmax(pm, a.gathered[(int64_t)(k / P) * a.stride + a.nmax + k % P]);
+    for (int q = 0; q < a.world; q += 4) {   // (four ranks' loads in flight: one after the other they were 16 L2 round trips)
+      const double* mx[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        int r = (q + u < a.world ? q + u : q) + b % a.world;
+        r = r >= a.world ? r - a.world : r;
+        mx[u] = a.gathered + (int64_t)r * a.stride + a.nmax;
+      }
+      for (int k = tid; k < P; k += 256) {
+        const double v0 = mx[0][k], v1 = mx[1][k], v2 = mx[2][k], v3 = mx[3][k];
+        pm = fmax(fmax(pm, fmax(v0, v1)), fmax(v2, v3));
+      }
+    }
     m = blockMax256(pm, smD);
+    PF_STAMP(2)
   }
-  // ---- phase 2: fixed-point weights (fixedWeightKernel's formula) of this thread's slots, their sum; ONE block scan ----
-  const bool mFinite = m > -INFINITY;
+  // ---- phase 2: fixed-point weights (pfFixedWeight) of this thread's slots, summed; ONE block scan ----
+  // slot i's log-weight, wherever it lies: the one-batch analysis' own vector, or rank (i / nmax)'s gathered block
+  auto slotLogw = [&](int64_t i) -> double {
+    if (!Gathered) return a.logwIn[i];
+    const int64_t r = i / a.nmax;
+    return a.gathered[r * a.stride + (i - r * a.nmax)];
+  };
   long long mySum = 0;
   {
     int64_t r = 0, c = 0;   // (gathered blocks: slot i sits in rank r's block at column c)
@@ -503,29 +550,24 @@ __global__ __launch_bounds__(256) void pfFusedKernel(FusedArgs a) {
             lw[k] = a.gathered[r * a.stride + c];
             if (++c == a.nmax) { c = 0; r++; }
           } else {
-            lw[k] = a.logw[i + k];
+            lw[k] = a.logwIn[i + k];
           }
         }
       }
 #pragma unroll
-      for (int k = 0; k < 8; k++) {
-        if (k < n8) {
-          const double e = exp(lw[k] - m);
-          const long long w = (!(lw[k] > -INFINITY) || !mFinite) ? 0 : llrint(e * 1073741824.0);
-          a.w[i + k] = w;   // (read back by this very thread in phase 3: plain accesses)
-          mySum += w;
-        }
-      }
+      for (int k = 0; k < 8; k++) mySum += pfFixedWeight(lw[k], m);
     }
   }
   long long chunkTotal;
   const long long myIncl = blockScan256(mySum, smWave, &chunkTotal);
+  // (the threads' inclusive sums inside the chunk: what another workgroup needs to place a particle in this chunk)
+  stAgent((long long*)&a.threadIncl[(int64_t)b * 256 + tid], myIncl);
   if (tid == 0) stAgent((long long*)&a.blockSum[b], chunkTotal);
   PF_STAMP(3)
   if (!gridBarrier(a.barrier + kBarWords * nBarrier, nBarrier, a, &smOk)) return;
   nBarrier++;
   PF_STAMP(4)
-  // ---- phase 3: the chunks' offsets (every workgroup for itself), then the ancestors ----
+  // ---- phase 3: the chunks' offsets (every workgroup for itself), then the ancestors of this workgroup's PARTICLES ----
   {
     // two entries per thread (nb <= 512), scanned as pairs
     const int k0 = 2 * tid, k1 = 2 * tid + 1;
@@ -538,62 +580,75 @@ __global__ __launch_bounds__(256) void pfFusedKernel(FusedArgs a) {
     __syncthreads();
   }
   const long long Sll = prefix[nb];
-  // ancestorKernel's rule -- particle j takes the first slot i with cdf[i] > P(j), P(j) = min(((j0 + j + u0) S) / nTotal,
-  // S - 1) -- turned round: slot i is taken by the particles j with cdf[i-1] <= P(j) < cdf[i], a run of consecutive j
-  // (P is non-decreasing in j) that the slot's own thread finds from ITS two sums and writes itself.  No search through
-  // other chunks' sums: the first version looked them up with eight dependent device-coherent loads per particle, 12 us.
+  PF_STAMP(5)
+  // ancestorKernel's rule, particle by particle: particle g takes the first slot i with cdf[i] > P(g), P(g) = min(((g + u0) S) /
+  // nTotal, S - 1).  The launch's particles [j0, j0 + nOut) are dealt to the workgroups in equal contiguous shares -- round 5 and
+  // the first round-6 version went slot by slot, every slot writing the run of particles that take it: across ranks a launch
+  // writes only ITS rank's particles, whose slots sit in 1 / world of the chunks, so 64 of 512 workgroups did all the divisions and
+  // stores of the phase (8 x 131 072 slots: ~15 us against 2.7 us for one rank's).  A particle finds its slot in three steps that
+  // read nothing but sums: its CHUNK by bisection of the chunks' offsets (LDS), the THREAD of phase 2 whose slots hold it by
+  // bisection of that chunk's 256 inclusive sums (LDS for the two chunks the workgroup's particles start in, device memory
+  // for a particle further on), the SLOT by adding up that thread's <= 16 weights again (pfFixedWeight of log-weights that were
+  // there before the launch, or came from phase 1 through agent-scope stores).  cdf is non-decreasing, so "first slot with
+  // cdf > p" never lands on a slot that weighs nothing; S = 0 puts every particle on slot 0, as ancestorKernel does.
   const double S = (double)Sll, nTot = (double)a.nTotal;
-  auto P = [&](int64_t g) -> double { return fmin((((double)g + a.u0) * S) / nTot, S - 1.0); };   // g: global particle index
-  auto firstAtLeast = [&](double c) -> int64_t {   // the first global particle g in [0, nTotal] with P(g) >= c
-    if (!(S > 0.0)) return a.nTotal;
-    double est = ceil(c * nTot / S - a.u0);
-    int64_t g = est < 0.0 ? 0 : est > nTot ? a.nTotal : (int64_t)est;
-    while (g > 0 && P(g - 1) >= c) g--;
-    while (g < a.nTotal && P(g) < c) g++;
-    return g;
-  };
-  // heavy particles (more than 32 copies): the whole workgroup writes their runs once every thread has been through its
-  // slots; a list that is full (it cannot be at <= 32 x 256 copies per chunk ... but the runs are not bounded by the chunk)
-  // makes the slot's own thread write the run
-  constexpr int kBigCap = 256;
-  __shared__ int64_t bigLo[kBigCap], bigHi[kBigCap];
-  __shared__ int32_t bigSlot[kBigCap];
-  __shared__ int nBig;
-  if (tid == 0) nBig = 0;
-  __syncthreads();
-  const int64_t gLo = a.j0, gHi = a.j0 + a.nOut;   // this launch writes the ancestors of the global particles [gLo, gHi)
-  {
-    long long excl = prefix[b] + (myIncl - mySum);   // the sum of all weights before slot i
-    int64_t gNext = -1;                              // firstAtLeast(excl) when the previous slot has computed it
-    for (int64_t i = t0; i < t1; i++) {
-      const long long w = a.w[i];   // (this thread's own stores of phase 2)
-      if (w > 0 || i == 0) {
-        int64_t g0 = i == 0 ? 0 : gNext >= 0 ? gNext : firstAtLeast((double)excl);
-        int64_t g1 = firstAtLeast((double)(excl + w));
-        gNext = g1;                 // (= firstAtLeast of the next weighted slot's lower sum: slots in between weigh nothing)
-        if (g0 < gLo) g0 = gLo;
-        if (g1 > gHi) g1 = gHi;
-        if (g1 - g0 > 32) {
-          const int q = atomicAdd(&nBig, 1);
-          if (q < kBigCap) {
-            bigLo[q] = g0;
-            bigHi[q] = g1;
-            bigSlot[q] = (int32_t)i;
-          } else {
-            for (int64_t g = g0; g < g1; g++) a.anc[g - gLo] = (int32_t)i;
-          }
-        } else {
-          for (int64_t g = g0; g < g1; g++) a.anc[g - gLo] = (int32_t)i;
-        }
-        excl += w;
-      }
+  __shared__ long long inclA[256], inclB[256];
+  __shared__ int chunkA;
+  const int64_t share = (a.nOut + nb - 1) / nb;           // particles per workgroup
+  const int64_t jLo = (int64_t)b * share, jHi = jLo + share < a.nOut ? jLo + share : a.nOut;
+  auto chunkOf = [&](double p) -> int {                   // first c with (double)prefix[c + 1] > p
+    int lo2 = 0, hi2 = nb - 1;
+    while (lo2 < hi2) {
+      const int mid = (lo2 + hi2) >> 1;
+      if ((double)prefix[mid + 1] > p) hi2 = mid; else lo2 = mid + 1;
     }
-  }
-  __syncthreads();
-  {
-    const int nq = nBig < kBigCap ? nBig : kBigCap;
-    for (int q = 0; q < nq; q++)
-      for (int64_t g = bigLo[q] + tid; g < bigHi[q]; g += 256) a.anc[g - gLo] = bigSlot[q];
+    return lo2;
+  };
+  auto pOf = [&](int64_t j) -> double { return fmin((((double)(a.j0 + j) + a.u0) * S) / nTot, S - 1.0); };
+  if (jLo < jHi) {
+    if (tid == 0) chunkA = chunkOf(pOf(jLo));
+    __syncthreads();
+    const int cA = chunkA, cB = cA + 1 < nb ? cA + 1 : cA;
+    inclA[tid] = ldAgent((const long long*)&a.threadIncl[(int64_t)cA * 256 + tid]);
+    inclB[tid] = ldAgent((const long long*)&a.threadIncl[(int64_t)cB * 256 + tid]);
+    __syncthreads();
+    for (int64_t j = jLo + tid; j < jHi; j += 256) {
+      const double p = pOf(j);
+      const int c = chunkOf(p);
+      const long long base = prefix[c];
+      // the thread of phase 2: first t with (double)(base + incl[c][t]) > p  (incl[c][255] = the chunk's total: exists)
+      int tl = 0, th = 255;
+      if (c == cA || c == cB) {
+        const long long* incl = c == cA ? inclA : inclB;
+        while (tl < th) {
+          const int mid = (tl + th) >> 1;
+          if ((double)(base + incl[mid]) > p) th = mid; else tl = mid + 1;
+        }
+      } else {
+        while (tl < th) {
+          const int mid = (tl + th) >> 1;
+          if ((double)(base + ldAgent((const long long*)&a.threadIncl[(int64_t)c * 256 + mid])) > p) th = mid; else tl = mid + 1;
+        }
+      }
+      long long run = base;
+      if (tl > 0) run += (c == cA) ? inclA[tl - 1] : (c == cB) ? inclB[tl - 1] : ldAgent((const long long*)&a.threadIncl[(int64_t)c * 256 + tl - 1]);
+      // the slot: that thread's weights once more, until the sum passes p (eight log-weights requested at a time: one after
+      // the other they were up to `per` L2 round trips per particle)
+      const int64_t i0 = (int64_t)c * a.chunk + (int64_t)tl * per;
+      const int64_t iEnd = i0 + per < a.nSlots ? i0 + per : a.nSlots;
+      int64_t found = -1;
+      for (int64_t i = i0; i < iEnd && found < 0; i += 8) {
+        double lw[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) lw[k] = i + k < iEnd ? slotLogw(i + k) : -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          run += pfFixedWeight(lw[k], m);
+          if (found < 0 && (double)run > p) found = i + k;
+        }
+      }
+      a.anc[j] = (int32_t)(found < 0 ? iEnd - 1 : found);
+    }
   }
   // the total weight, last: a workgroup that gave up at a barrier has written kPfVoid there, and a launch is void as soon as
   // one did (gridBarrier) -- its poison word says so even if this workgroup was released in the same instant
@@ -605,7 +660,7 @@ __global__ __launch_bounds__(256) void pfFusedKernel(FusedArgs a) {
     if (a.total) *a.total = tot;
     *a.totalScratch = tot;
   }
-  PF_STAMP(5)
+  PF_STAMP(6)
 }
 
 // dst[row][j] = matrix of rank (anc[j] / nmax)[row][anc[j] % nmax] for the three matrices of a checkpoint
@@ -928,6 +983,7 @@ struct PfScratch {
   // the one-launch analysis (pfFusedKernel): chunk totals + the total weight, the ring of per-launch barrier sets (all
   // zero at allocation; launch L uses set L % kBarSets and clears set (L + kBarAhead) % kBarSets), the stuck report
   int64_t* d_blockSum = nullptr;      // [kFusedBlocks] + 1: the total
+  int64_t* d_threadIncl = nullptr;    // [kFusedBlocks][256]
   unsigned long long* d_barrier = nullptr;   // [kBarSets][kBarSetWords] + 1: the stuck word
   unsigned long long launches = 0;      // fused launches that were accepted by the runtime
   int occ[3] = {-1, -1, -1};            // resident workgroups per CU of pfFusedKernel<float,false> / <double,false> / <double,true>
@@ -937,7 +993,9 @@ struct PfScratch {
     if (d_cdf) (void)hipFree(d_cdf);
     if (d_tmp) (void)hipFree(d_tmp);
     if (d_blockSum) (void)hipFree(d_blockSum);
+    if (d_threadIncl) (void)hipFree(d_threadIncl);
     if (d_barrier) (void)hipFree(d_barrier);
+    d_threadIncl = nullptr;
     d_max = nullptr; d_w = d_cdf = nullptr; d_tmp = nullptr; cap = 0; tmpBytes = 0;
     d_blockSum = nullptr; d_barrier = nullptr; launches = 0;
     occ[0] = occ[1] = occ[2] = -1;
@@ -963,6 +1021,7 @@ static int pfScratchFor(PfScratch& sc, int64_t n, hipStream_t stream) {
     HIP_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, sc.tmpBytes, sc.d_w, sc.d_cdf, (int)n, stream));
     HIP_TRY(hipMalloc(&sc.d_tmp, sc.tmpBytes));
     HIP_TRY(hipMalloc(&sc.d_blockSum, (size_t)(kFusedBlocks + 1) * sizeof(int64_t)));
+    HIP_TRY(hipMalloc(&sc.d_threadIncl, (size_t)kFusedBlocks * 256 * sizeof(int64_t)));
     HIP_TRY(hipMalloc(&sc.d_barrier, kBarrierWords * sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(sc.d_barrier, 0, kBarrierWords * sizeof(unsigned long long), stream));
     sc.launches = 0;
@@ -989,6 +1048,10 @@ static int fusedBudget(PfScratch& sc, const sipnet_batch* b, int which) {
   const int64_t share = b->deviceShare > 0 ? b->deviceShare : 1;
   const int64_t fit = (int64_t)sc.occ[which] * b->numCUs / share;
   return (int)(fit < kFusedBlocks ? fit : kFusedBlocks);
+}
+// may the analysis over nSlots weights be ONE launch of at most `budget` resident workgroups?
+static bool fusable(int64_t nSlots, int budget) {
+  return budget >= kFusedMinBlocks && (nSlots + 255) / 256 <= (int64_t)budget * kFusedMaxPer;
 }
 // geometry of the one-launch analysis over nSlots weights with at most `budget` workgroups: contiguous chunks of whole tiles
 static void fusedGeometry(int64_t nSlots, int budget, int* grid, int64_t* chunk) {
@@ -1301,9 +1364,9 @@ int sipnet_batch_pf_analysis(sipnet_batch* b, const void* d_plane, int32_t elem_
                        pre.sigma == sigma && pre.d_logw == d_logw && elem_is_f32 == (b->precision == SIPNET_F32_MIXED);
   b->pfPre.valid = false;
   const int budget = (b->kernelOptions & SIPNET_KOPT_PF_MULTI_LAUNCH) ? 0 : fusedBudget(sc, b, elem_is_f32 ? 0 : 1);
-  b->pfInfo.fused = budget >= kFusedMinBlocks ? 1 : 0;
+  b->pfInfo.fused = fusable(b->ncol, budget) ? 1 : 0;
   b->pfInfo.budget = budget;
-  if (budget >= kFusedMinBlocks) {
+  if (b->pfInfo.fused) {
     // log-weights, fixed-point weights, prefix sum and ancestors: ONE launch (pfFusedKernel)
     FusedArgs fa{};
     fa.plane = d_plane;
@@ -1319,7 +1382,8 @@ int sipnet_batch_pf_analysis(sipnet_batch* b, const void* d_plane, int32_t elem_
     fusedGeometry(fa.nSlots, budget, &grid, &fa.chunk);
     b->pfInfo.grid = grid;
     fa.blockMax = sc.d_max;
-    fa.w = sc.d_w;
+    fa.logwIn = d_logw;
+    fa.threadIncl = sc.d_threadIncl;
     fa.blockSum = sc.d_blockSum;
     fusedBarrier(sc, &fa, b->pfSpinBudget);
     fa.absent = b->pfDebugAbsent;
@@ -1661,11 +1725,11 @@ int sipnet_batch_pf_resample_peers(sipnet_batch* b, const double* d_gathered, do
   if (rc) return rc;
   const int64_t n = b->ncol;
   const int budget = (b->kernelOptions & SIPNET_KOPT_PF_MULTI_LAUNCH) ? 0 : fusedBudget(sc, b, 2);
-  b->pfInfo.fused = budget >= kFusedMinBlocks ? 1 : 0;
+  b->pfInfo.fused = fusable(nSlots, budget) ? 1 : 0;
   b->pfInfo.budget = budget;
   b->pfInfo.nSlots = nSlots;
   b->pfInfo.grid = 0;
-  if (budget >= kFusedMinBlocks) {   // weights over all slots, prefix sum, the ancestors of MY particles: one launch (pfFusedKernel)
+  if (b->pfInfo.fused) {   // weights over all slots, prefix sum, the ancestors of MY particles: one launch (pfFusedKernel)
     FusedArgs fa{};
     fa.gathered = d_gathered;
     fa.world = tab.world;
@@ -1676,7 +1740,7 @@ int sipnet_batch_pf_resample_peers(sipnet_batch* b, const double* d_gathered, do
     fusedGeometry(fa.nSlots, budget, &grid, &fa.chunk);
     b->pfInfo.grid = grid;
     fa.blockMax = sc.d_max;
-    fa.w = sc.d_w;
+    fa.threadIncl = sc.d_threadIncl;
     fa.blockSum = sc.d_blockSum;
     fusedBarrier(sc, &fa, b->pfSpinBudget);
     fa.absent = b->pfDebugAbsent;

@@ -237,14 +237,14 @@ def pf_connect_peers(batch, rank=0, world=1, group=None, with_params=True, prete
     """Once per filter: every rank publishes where its particles' checkpoint matrices live and maps the
     others' (hipIpc handles between processes).  Host-side, off the cycle.
     pretend_world = P > 1 (one real rank only): the slot count of a P-rank filter on one GPU -- the batch is connected to a
-    world of P whose every member is itself (its own descriptor P times; it plays rank P // 2), so that the analysis goes
+    world of P whose every member is itself (its own descriptor P times; it plays the last rank), so that the analysis goes
     over P x nmax weights and the gather reads "peers" that happen to be local: what an 8-GPU cycle costs apart from the
     links.  pf_arm_peers / pf_analysis_peers must be given the same pretend_world."""
     import torch.distributed as dist
     mine = batch.pf_publish(with_params)
     if pretend_world > 1:
         assert world == 1, "pretend_world: one real rank only"
-        batch.pf_connect([mine] * pretend_world, pretend_world // 2)
+        batch.pf_connect([mine] * pretend_world, pretend_world - 1)
         return
     if world > 1:
         every = [None] * world
@@ -259,7 +259,7 @@ def pf_arm_peers(batch, obs, sigma, rank=0, world=1, pretend_world=0):
     the all-gather's buffer (sipnet_batch_pf_arm), and pf_analysis_peers only adds the block maxima"""
     import torch
     if pretend_world > 1:
-        rank, world = pretend_world // 2, pretend_world
+        rank, world = pretend_world - 1, pretend_world
     L = batch.pf_block_len()
     gathered = getattr(batch, "_pf_gathered", None)
     if gathered is None or gathered.shape != (world, L):
@@ -279,7 +279,7 @@ def pf_analysis_peers(batch, plane, obs, sigma, u0, rank=0, world=1, group=None,
         collectives = world > 1
     pretend = pretend_world > 1
     if pretend:
-        rank, world = pretend_world // 2, pretend_world
+        rank, world = pretend_world - 1, pretend_world
     L = batch.pf_block_len()
     if gathered is None:
         gathered = getattr(batch, "_pf_gathered", None)
@@ -288,12 +288,17 @@ def pf_analysis_peers(batch, plane, obs, sigma, u0, rank=0, world=1, group=None,
     mine = gathered[rank]
     batch.pf_local_weights(plane, obs, sigma, mine)
     if pretend:
-        # the one real rank's all-gather (in place, its own slice), then the block copied into the other ranks' slices: two
-        # device copies of (P - 1) blocks stand where the links' time would be
+        # the one real rank's all-gather (in place, its own slice), then its block into the other ranks' slices -- ONE device
+        # kernel over (P - 1) blocks stands where the links' time would be -- each shifted by a constant of its own (maxima
+        # included; -inf stays -inf), so that the pretended ranks differ in total weight and particles do cross between them
         if collectives:
             dist.all_gather_into_tensor(mine, mine, group=group)
-        gathered[:rank].copy_(mine.expand(rank, L))
-        gathered[rank + 1:].copy_(mine.expand(world - rank - 1, L))
+        shifts = getattr(batch, "_pf_pretend_shifts", None)
+        if shifts is None or shifts.shape[0] != rank:
+            # (the other ranks a little heavier than this, the last, one: its particles' weight interval then reaches into
+            # its neighbour's slots)
+            shifts = batch._pf_pretend_shifts = (0.15 * (torch.arange(rank, dtype=torch.float64, device=batch.device) + 1) / rank)[:, None]
+        torch.add(mine.expand(rank, L), shifts, out=gathered[:rank])
     elif collectives:
         if _host_staged(mine, group):
             out = torch.empty((world, L), dtype=torch.float64)

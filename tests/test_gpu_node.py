@@ -454,15 +454,19 @@ def test_a_pretended_world_of_eight_on_one_batch(base, prec):
     L = b.pf_block_len()
     gathered = torch.empty((world, L), dtype=torch.float64, device=DEV)
     b.pf_local_weights(p[0], obs, sigma, gathered[rank])
-    gathered[:] = gathered[rank].clone()
+    # (the same block everywhere would give every rank exactly its own slots back: the pretended peers' weights are shifted,
+    # block maxima included, so that ranks differ in total weight and particles cross)
+    mine = gathered[rank].clone()
+    for r in range(world):
+        gathered[r] = mine + 0.35 * (r - 3)
     total = torch.zeros(1, dtype=torch.int64, device=DEV)
     anc = b.pf_resample_peers(gathered, 0.29, total_out=total).cpu().numpy()
     info = b.pf_info()
     assert info["world"] == world and info["n_slots"] == world * n and info["params_by_index"] == 1 and info["fused"] == 1
     # (device exp vs glibc exp may round a weight to the neighbouring integer: the oracle resamples the device's own integers)
-    _, fixed1 = sd_fixed(b.pf_log_weights(p[0], obs, sigma))
-    fixed = np.tile(fixed1, world)
-    assert np.abs(fixed1 - po.fixed_weights(gathered[rank, :n].cpu().numpy())).max() <= 1
+    lw_all = gathered[:, :n].reshape(-1).contiguous()
+    _, fixed = sd_fixed(lw_all)
+    assert np.abs(fixed - po.fixed_weights(lw_all.cpu().numpy())).max() <= 1
     want = po.systematic_ancestors(fixed, 0.29)[rank * n:(rank + 1) * n]
     np.testing.assert_array_equal(anc, want)
     assert int(total.item()) == int(fixed.sum())

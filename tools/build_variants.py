@@ -24,7 +24,8 @@ def build(name, flags):
     out = os.path.join(REPO, "build", "variants", name)
     os.makedirs(out, exist_ok=True)
     objs = []
-    for src in FAST_SRCS:
+    pf_only = flags.strip() != "" and all(f.startswith("-DSIPNET_PF_") for f in flags.split())   # (the step kernels: the product's objects)
+    for src in ([] if pf_only else FAST_SRCS):
         o = os.path.join(out, src.replace(".hip", ".o"))
         contract = "-ffp-contract=fast-honor-pragmas" if src == "step_coop.hip" else "-ffp-contract=fast"
         probe = ["-DSIPNET_PROBES"] if "-DSIPNET_" in flags else []     # (the probes' master switch: csrc/coop_probes.h)
@@ -37,6 +38,8 @@ def build(name, flags):
         subprocess.check_call([HIPCC] + BASE + ["-ffp-contract=off"] + flags.split() + ["-c", os.path.join(CSRC, "pf.hip"), "-o", o])
         objs.append(o)
         others.remove("pf.o")
+    if pf_only:
+        others += [x.replace(".hip", ".o") for x in FAST_SRCS]
     objs += [os.path.join(CSRC, o) for o in others]
     so = os.path.join(out, "libsipnet_amd.so")
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + objs + ["-ldl"])

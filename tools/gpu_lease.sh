@@ -1,0 +1,73 @@
+#!/bin/bash
+# ONE script for every GPU lease (replaces the per-lease gpu_r4_* / gpu_r5_* scripts of earlier rounds):
+#   gpurun --timeout S -- 'tools/gpu_lease.sh <tag> <recipe> [<recipe> ...]'
+# Results land under gpurun_out/<tag>/ (copy what is to be judged into profiles/).  Recipes:
+#   suite          the whole GPU test suite (pytest -m gpu)
+#   tests:<expr>   pytest -m gpu -k <expr>
+#   bench          the driver's default bench line
+#   bench_all      one bench line per workload (no CPU baseline) -> bench_all.jsonl
+#   force_dist     bench.py --force-dist for every workload + c5 at --pretend-world 8 -> force_dist.jsonl
+#   pf             the cross-rank analysis at the slot counts of 1 / 2 / 4 / 8 ranks (tools/pf_peers_time.py), plain and
+#                  under rocprofv3 --kernel-trace --stats
+#   profile:<wl>   rocprofv3 --kernel-trace --stats of `bench.py --workload <wl>` -> <wl>_kernel_stats.csv
+#   smoke          __graft_entry__.smoke()
+cd "$(dirname "$0")/.." || exit 1
+export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
+TAG=$1; shift
+O=gpurun_out/$TAG; mkdir -p $O
+for R in "$@"; do
+  case $R in
+    suite)
+      timeout 2400 python3 -m pytest tests -q -m gpu -x 2>&1 | tail -15 > $O/pytest_gpu.txt; tail -5 $O/pytest_gpu.txt ;;
+    tests:*)
+      timeout 1800 python3 -m pytest tests -q -m gpu -k "${R#tests:}" 2>&1 | tail -30 > $O/pytest_k.txt; tail -8 $O/pytest_k.txt ;;
+    smoke)
+      timeout 600 python3 -c 'import __graft_entry__ as g; g.smoke()' > $O/smoke.txt 2>&1; tail -3 $O/smoke.txt ;;
+    bench)
+      timeout 1200 python3 bench.py > $O/bench_default.log 2>&1; grep '^{' $O/bench_default.log | tail -1 > $O/bench_default.json
+      python3 -c "import json; d=json.load(open('$O/bench_default.json')); print('value %.4g %s, ms/step %.3f, roofline %s' % (d['value'], d['unit'], d['ms_per_step'], {k: d['roofline'][k] for k in ('achieved', 'frac', 'traffic')}))" ;;
+    bench_all)
+      : > $O/bench_all.jsonl
+      for wl in c10k c2 c2x16 c3 c4 c5 c10kn c10kr3 c4n; do
+        steps=10; warm=2; [ "$wl" = c5 ] && steps=400 && warm=40
+        timeout 900 python3 bench.py --workload $wl --steps $steps --warmup $warm --no-cpu-baseline > $O/bench_$wl.log 2>&1
+        grep '^{' $O/bench_$wl.log | tail -1 >> $O/bench_all.jsonl
+        grep '^{' $O/bench_$wl.log | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('$wl', 'value %.4g' % d['value'], 'ms/step %.4f' % d['ms_per_step'], 'frac %.3f' % d['roofline']['frac'], d['roofline'].get('kernel', '')[:60])"
+      done ;;
+    force_dist)
+      : > $O/force_dist.jsonl
+      for wl in c10k c4 c3 c5 c5p8 c2x16 c10kn c4n c10kr3; do
+        steps=10; warm=2; extra=""; w=$wl
+        [ "$wl" = c5 ] && steps=400 && warm=40   # (a 0.15 ms cycle: RCCL's first-collective costs need a real warm-up)
+        [ "$wl" = c5p8 ] && steps=400 && warm=40 && extra="--pretend-world 8" && w=c5
+        timeout 900 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 \
+            bench.py --gpus 1 --force-dist --workload $w $extra --steps $steps --warmup $warm --no-cpu-baseline --no-fill-probe > $O/force_dist_$wl.log 2>&1
+        echo "rc=$? $wl"
+        grep '^{' $O/force_dist_$wl.log | tail -1 >> $O/force_dist.jsonl
+      done
+      python3 - "$O/force_dist.jsonl" <<'PY'
+import json, sys
+for line in open(sys.argv[1]):
+    j = json.loads(line)
+    d = j["config"].get("dist_overhead", {})
+    pf = j["config"].get("particle_filter", {})
+    print(j["config"]["workload"][:30], "pretend", pf.get("pretend_world"), "| dist %.4f plain %.4f overhead %.4f ms eff %.3f | gather_full %s | crossing/cycle %s slots %s" % (
+        d.get("ms_per_step_dist", -1), d.get("ms_per_step_plain", -1), d.get("dist_overhead_ms", -1),
+        d.get("predicted_weak_scaling_efficiency", -1), (j["config"].get("gather_full") or {}).get("ms"), pf.get("crossing_per_cycle"), pf.get("analysis_slots")))
+PY
+      ;;
+    pf)
+      timeout 900 python3 tools/pf_peers_time.py 131072 300 > $O/pf_peers_time.txt 2>&1; cat $O/pf_peers_time.txt
+      rm -rf /tmp/prof_pf
+      timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_pf -- python3 tools/pf_peers_time.py 131072 100 8 > $O/pf_peers_prof.txt 2>&1
+      cp $(find /tmp/prof_pf -name "*kernel_stats.csv" | head -1) $O/pf_peers_w8_kernel_stats.csv 2>/dev/null
+      head -12 $O/pf_peers_w8_kernel_stats.csv | cut -c1-160 ;;
+    profile:*)
+      wl=${R#profile:}; rm -rf /tmp/prof_$wl
+      steps=10; warm=2; [ "$wl" = c5 ] && steps=400 && warm=40
+      timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$wl -- python3 bench.py --workload $wl --steps $steps --warmup $warm --no-cpu-baseline --no-fill-probe --no-end-to-end > $O/profile_$wl.log 2>&1
+      cp $(find /tmp/prof_$wl -name "*kernel_stats.csv" | head -1) $O/${wl}_kernel_stats.csv 2>/dev/null
+      head -6 $O/${wl}_kernel_stats.csv | cut -c1-200 ;;
+    *) echo "unknown recipe $R" ;;
+  esac
+done

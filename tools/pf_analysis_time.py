@@ -43,6 +43,7 @@ if hasattr(L, "sipnet_debug_read_pf_stamps"):      # a -DSIPNET_PF_STAMPS build:
     import ctypes as C
     st = (C.c_ulonglong * 8)()
     L.sipnet_debug_read_pf_stamps(st)
-    t = [int(x) for x in st][:6]
-    names = ["log-weights + chunk maximum", "barrier 1", "weights + chunk scan", "barrier 2", "chunk offsets + ancestors"]
-    print("phases of the last launch, workgroup 0 (us): " + ", ".join("%s %.2f" % (nm, (b_ - a_) / 100.0) for nm, a_, b_ in zip(names, t[:-1], t[1:])))
+    t = [int(x) for x in st]
+    print("phases of the last launch, workgroup 0 (us): " + ", ".join("%s %.2f" % (nm, (t[j] - t[i]) / 100.0) for nm, i, j in (
+        ("log-weights + chunk maximum", 0, 1), ("barrier 1", 1, 2), ("weights + block scan", 2, 3), ("barrier 2", 3, 4),
+        ("chunk offsets", 4, 5), ("ancestors", 5, 6))))
