@@ -354,6 +354,18 @@ int sipnet_batch_get_diagnostics(sipnet_batch *b, int64_t *n_clamp_warn, int64_t
  *   67..69 phenologyTrackers.didLeafGrowth, didLeafFall, plantSurvivalTracker.isAlive
  * Always runs the strict-order kernel (no fast-math substitutions of the flux expressions
  * unless the batch is fast-math). */
+/* Every member's SUMS over groups of sum_steps consecutive steps instead of the steps themselves (what a consumer of the
+ * reference's per-step output rows, sipnet.c:453-473, aggregates anyway: sum_steps = 48 gives the daily NEE / GPP / ET of a
+ * half-hourly forcing): d_*_sums[ceil(n_steps / sum_steps)][ld] doubles (DEVICE; any may be NULL), groups counted from
+ * step0, the last as long as the run leaves it, each value added in step order by the wavefront that computes it -- inside
+ * the step kernel's own launch (1 / sum_steps of the planes' HBM writes, no second pass).  For batches
+ * sipnet_batch_sums_in_kernel answers 1 for: fp64, SIPNET_MATH_FAST, default physics, no diagnostics / full state, at most
+ * two 64-member chunks per compute unit (the cooperative kernels' stepCoopSumsKernel / stepCoopPairSumsKernel); any other
+ * batch gets SIPNET_ERR_BAD_ARGUMENT and sums its planes (sipnet_node_run_gathering_reduced does either by itself).  A
+ * site that ends inside a group leaves the group's sum over its own records. */
+int sipnet_batch_run_sums(sipnet_batch *b, int32_t step0, int32_t n_steps, int32_t sum_steps, double *d_nee_sums,
+                          double *d_gpp_sums, double *d_et_sums, int64_t ld, void *hip_stream);
+int32_t sipnet_batch_sums_in_kernel(const sipnet_batch *b);
 int sipnet_batch_run_debug(sipnet_batch *b, int32_t step0, int32_t n_steps, double *d_rec,
                            double *d_dbg, int64_t ld, void *hip_stream);
 
@@ -665,6 +677,27 @@ void *sipnet_node_gathered_planes(sipnet_node *nd, int32_t k);
  * plan, a launch error) makes every shard give up BEFORE the segment's collective is enqueued: the call returns that
  * shard's error and the node stays usable. */
 int sipnet_node_run_gathering(sipnet_node *nd, int32_t step0, int32_t n_steps, int32_t n_segments);
+/* The member-resolved exchange in a form that fits under the kernel (the raw fp64 planes of a year are 4.3 GB per rank at
+ * 10 240 members, ~100 ms of link time against 8 ms of compute): segment j's planes are REDUCED on the shard's second stream
+ * while segment j + 1 computes, and the reduced block is what the all-gather moves --
+ *   SIPNET_GATHER_F32   the same [3][steps][ld] as floats (an fp64 node; half the bytes)
+ *   SIPNET_GATHER_SUMS  every member's sums over groups of sum_steps consecutive steps, in step order, as doubles:
+ *                       [3][groups][ld] (sum_steps = 48: the daily NEE / GPP / ET of a half-hourly year, 1 / 48 of the bytes --
+ *                       90 MB per rank at 10 240 members; what a consumer of the reference's per-step rows, sipnet.c:453-473,
+ *                       aggregates anyway).  Groups count from step0; the last may be shorter; segments hold whole groups.
+ * Afterwards sipnet_node_gathered_reduced(nd, k, j, &first_row, &n_rows, &elem_bytes) on device k is segment j of every
+ * shard, [n_devices][3][n_rows][ld] (rows = steps or groups; first_row = its first), column layout as the planes'.  The
+ * shards' own planes are left segment by segment as by sipnet_node_run_gathering (same restrictions until the next run) --
+ * except where SIPNET_GATHER_SUMS sums inside the step kernel's launch (sipnet_node_reduced_in_kernel): no planes then. */
+enum sipnet_gather_form { SIPNET_GATHER_F32 = 1, SIPNET_GATHER_SUMS = 2 };
+int sipnet_node_run_gathering_reduced(sipnet_node *nd, int32_t step0, int32_t n_steps, int32_t n_segments, int32_t form,
+                                      int32_t sum_steps);
+void *sipnet_node_gathered_reduced(sipnet_node *nd, int32_t k, int32_t segment, int32_t *first_row, int32_t *n_rows,
+                                   int32_t *elem_bytes);
+/* 1: the last SIPNET_GATHER_SUMS run summed inside the step kernels' own launches (sipnet_batch_run_sums: every shard's
+ * batch had such a kernel) -- the shards' planes were NOT written; 0: the planes were, and a pass on the second stream
+ * summed them */
+int32_t sipnet_node_reduced_in_kernel(const sipnet_node *nd);
 int32_t sipnet_node_n_segments(const sipnet_node *nd);   /* of the last sipnet_node_run_gathering; 0 after a plain run */
 void *sipnet_node_gathered_segment(sipnet_node *nd, int32_t k, int32_t segment, int32_t *first_step, int32_t *n_steps);
 /* Column layout of a plane row: shard k's member m of its local site s sits at s * count_k + m (count_k =

@@ -181,6 +181,9 @@ SIGNATURES = {
     "sipnet_node_destroy": (None, [_P]),
     "sipnet_node_n_devices": (C.c_int32, [_P]),
     "sipnet_node_batch": (_P, [_P, C.c_int32]),
+    "sipnet_node_run_gathering_reduced": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "sipnet_node_gathered_reduced": (_P, [_P, C.c_int32, C.c_int32, _P, _P, _P]),
+    "sipnet_node_reduced_in_kernel": (C.c_int32, [_P]),
     "sipnet_node_member_range": (C.c_int, [_P, C.c_int32, _I32P, _I32P]),
     "sipnet_node_collective_library": (C.c_char_p, [_P]),
     "sipnet_node_set_climate": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P]),
@@ -215,6 +218,8 @@ SIGNATURES = {
     "sipnet_dev_to_dev_2d": (C.c_int, [_P, C.c_size_t, _P, C.c_size_t, C.c_size_t, C.c_size_t, _P]),
     "sipnet_batch_set_climate_sites": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P]),
     "sipnet_debug_plan_compare": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
+    "sipnet_batch_run_sums": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_int64, _P]),
+    "sipnet_batch_sums_in_kernel": (C.c_int32, [_P]),
     "sipnet_debug_set_num_cus": (C.c_int, [_P, C.c_int32]),
     "sipnet_debug_pf_barrier": (C.c_int, [_P, C.c_int32, C.c_int32]),
     "sipnet_batch_set_device_share": (C.c_int, [_P, C.c_int32]),

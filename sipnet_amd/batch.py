@@ -264,6 +264,22 @@ class Batch:
         check(self.L.sipnet_batch_import_restart(self.h, site, first_member, len(restarts), arr,
                                                  self._stream()), "import_restart")
 
+    def run_sums(self, step0, n_steps, sum_steps, out=None):
+        """sipnet_batch_run_sums: every member's sums over groups of sum_steps steps, summed inside the step kernel's
+        launch -> f64 device tensor [3][groups][ncol] (NEE, GPP, ET)"""
+        t = self._torch
+        groups = (n_steps + sum_steps - 1) // sum_steps
+        if out is None:
+            out = t.empty((3, groups, self.ncol), dtype=t.float64, device=self.device)
+        assert out.dtype == t.float64 and out.is_contiguous() and out.shape == (3, groups, self.ncol)
+        check(self.L.sipnet_batch_run_sums(self.h, int(step0), int(n_steps), int(sum_steps), C.c_void_p(out[0].data_ptr()),
+                                           C.c_void_p(out[1].data_ptr()), C.c_void_p(out[2].data_ptr()), self.ncol,
+                                           self._stream()), "run_sums")
+        return out
+
+    def sums_in_kernel(self):
+        return bool(self.L.sipnet_batch_sums_in_kernel(self.h))
+
     def export_restart(self, site, member, n_steps_done, last_rec=None, prev_pools=None):
         """Checkpoint of one member after n_steps_done records (restartWriteCheckpoint)."""
         from ._lib import Restart

@@ -1062,7 +1062,7 @@ int sipnet_batch_setup(sipnet_batch* b, void* hip_stream) {
 
 static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee, void* d_gpp,
                    void* d_et, double* d_rec, double* d_dbg, int64_t ld, void* hip_stream,
-                   double* d_stats = nullptr);
+                   double* d_stats = nullptr, int32_t sumEvery = 0);
 
 int sipnet_batch_set_math(sipnet_batch* b, int32_t policy) {
   if (!b || (policy != SIPNET_MATH_STRICT && policy != SIPNET_MATH_FAST)) {
@@ -1172,8 +1172,34 @@ int sipnet_batch_run_debug(sipnet_batch* b, int32_t step0, int32_t n_steps, doub
   return runImpl(b, step0, n_steps, nullptr, nullptr, nullptr, d_rec, d_dbg, ld, hip_stream);
 }
 
+// Which cooperative kernel sums a batch's outputs over groups of steps inside its own launch (sipnet_batch_run_sums): fp64,
+// throughput arithmetic, the default physics (flags that are data included), no record / diagnostics / full state, at most
+// two chunks per CU -- AUTO's choice for such a shape, or one of those three layouts forced.  0: none.
+static int sumsKernelFor(const sipnet_batch* b) {
+  if (b->precision != SIPNET_F64 || !b->fastMath || !isDefaultFlagSet(b->flags) || b->d_diag || (b->kernelOptions & SIPNET_KOPT_FULL_STATE))
+    return 0;
+  int kernel = b->kernelPolicy;
+  if (kernel == SIPNET_KERNEL_AUTO) kernel = autoKernel(b->flags, b->n_sites, b->n_members, true, false, 0, b->numCUs, false);
+  return (kernel == SIPNET_KERNEL_COOP_LDS || kernel == SIPNET_KERNEL_COOP_HBM || kernel == SIPNET_KERNEL_COOP_PAIR) ? kernel : 0;
+}
+int32_t sipnet_batch_sums_in_kernel(const sipnet_batch* b) { return b ? (sumsKernelFor(b) != 0) : 0; }
+
+int sipnet_batch_run_sums(sipnet_batch* b, int32_t step0, int32_t n_steps, int32_t sum_steps, double* d_nee_sums, double* d_gpp_sums,
+                          double* d_et_sums, int64_t ld, void* hip_stream) {
+  if (!b || sum_steps <= 0) {
+    setError("sipnet_batch_run_sums: sum_steps must be positive");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  if (!sumsKernelFor(b)) {
+    setError("sipnet_batch_run_sums: no kernel sums this batch's outputs inside its launch (fp64, SIPNET_MATH_FAST, default physics, "
+             "no diagnostics / full state, at most two chunks per CU: sipnet_batch_sums_in_kernel); run the planes and sum them");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  return runImpl(b, step0, n_steps, d_nee_sums, d_gpp_sums, d_et_sums, nullptr, nullptr, ld, hip_stream, nullptr, sum_steps);
+}
+
 static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee, void* d_gpp,
-                   void* d_et, double* d_rec, double* d_dbg, int64_t ld, void* hip_stream, double* d_stats) {
+                   void* d_et, double* d_rec, double* d_dbg, int64_t ld, void* hip_stream, double* d_stats, int32_t sumEvery) {
   if (!b || step0 < 0 || n_steps < 0 || step0 + n_steps > b->n_steps) {
     setError("sipnet_batch_run: step range outside the climate record");
     return SIPNET_ERR_BAD_ARGUMENT;
@@ -1321,6 +1347,8 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
     f.prm = (throughIndex && b->d_prmBank) ? b->d_prmBank : b->d_prm;
     f.prmPitch = (throughIndex && b->d_prmBank) ? b->prmBankPitch : b->ncol;
     f.prmId = throughIndex ? b->d_prmId : nullptr;
+    f.sumEvery = sumEvery;
+    f.padEnd = 0;
     // a particle filter's forecast (sipnet_batch_pf_arm): the one-wave kernel's lean build leaves the log-weights too
     f.pfLogw = nullptr;
     f.pfBlockMax = nullptr;
@@ -1378,7 +1406,7 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
                        : kernel == SIPNET_KERNEL_COOP_QUAD ? COOP_QUAD
                        : kernel == SIPNET_KERNEL_COOP_NCYCLE ? COOP_NCYCLE
                        : kernel == SIPNET_KERNEL_COOP_NCYCLE_PAIR ? COOP_NCYCLE_PAIR : COOP_RING_HBM;
-    boundedWaits = (b->kernelOptions & SIPNET_KOPT_BOUNDED_WAITS) && kernel != SIPNET_KERNEL_ONE_WAVE && !wantFull;
+    boundedWaits = (b->kernelOptions & SIPNET_KOPT_BOUNDED_WAITS) && kernel != SIPNET_KERNEL_ONE_WAVE && !wantFull && !sumEvery;
     if (kernel == SIPNET_KERNEL_ONE_WAVE) launchStepFast(f, b->precision, b->kernelOptions, stream, &b->lastLaunch);
     else if (boundedWaits) bounded::launchStepCoop(f, b->precision, layout, stream, &b->lastLaunch);
     else launchStepCoop(f, b->precision, layout, stream, &b->lastLaunch);

@@ -126,6 +126,14 @@ struct sipnet_node {
   // gathered planes; the all-gathers run on the shards' second streams
   bool segmented = false;
   std::vector<int32_t> segCuts;
+  // sipnet_node_run_gathering_reduced: what travelled instead of the planes -- per shard [3][R][ld] (segment by segment, like
+  // the planes), gathered [n][3][R_j][ld] per segment; R rows = steps (SIPNET_GATHER_F32, floats) or groups of sum_steps steps
+  // (SIPNET_GATHER_SUMS, doubles); redCuts: the segments' first rows
+  int32_t reducedForm = 0, reducedSumSteps = 0;
+  bool reducedInKernel = false;   // the sums came out of the step kernels' own launches (no planes were written)
+  std::vector<int32_t> redCuts;
+  std::vector<void*> reduced, gatheredReduced;
+  size_t reducedCap = 0;   // bytes per shard
   std::vector<hipStream_t> gatherStreams;
   std::vector<hipEvent_t> evSeg, evGathered;
   // event-ordered transport
@@ -250,6 +258,8 @@ static int createNode(const int32_t* flags, int32_t n_sites, int32_t n_members, 
   nd->streams.assign(n_devices, nullptr);
   nd->planes.assign(n_devices, nullptr);
   nd->gatheredPlanes.assign(n_devices, nullptr);
+  nd->reduced.assign(n_devices, nullptr);
+  nd->gatheredReduced.assign(n_devices, nullptr);
   nd->stats.assign(n_devices, nullptr);
   nd->gatheredStats.assign(n_devices, nullptr);
   nd->statsCompact.assign(n_devices, nullptr);
@@ -329,6 +339,37 @@ static int createNode(const int32_t* flags, int32_t n_sites, int32_t n_members, 
   return SIPNET_OK;
 }
 
+// kernels of sipnet_node_run_gathering_reduced (below)
+namespace {
+__global__ __launch_bounds__(256) void planesToF32Kernel(const double* __restrict__ src, float* __restrict__ dst, size_t n2) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // pairs (ld is even)
+  if (i >= n2) return;
+  const double2 v = ((const double2*)src)[i];
+  ((float2*)dst)[i] = make_float2((float)v.x, (float)v.y);
+}
+// out[(v * groups + g) * ld + c] = sum over the steps t of group g, in step order, of plane v's [t][c]   (a thread = a column)
+template <typename T>
+__global__ __launch_bounds__(256) void sumStepsKernel(const T* __restrict__ planes, size_t planeStride, int32_t rows, int32_t k,
+                                                      int32_t groups, int64_t ld, double* __restrict__ out) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ld) return;
+  const int g = blockIdx.y, v = blockIdx.z;
+  const T* __restrict__ p = planes + (size_t)v * planeStride + (size_t)g * k * ld + c;
+  const int cnt = (g + 1) * k <= rows ? k : rows - g * k;
+  double acc = 0.0;
+  int t = 0;
+  for (; t + 8 <= cnt; t += 8) {   // eight loads in flight, added in step order
+    T x[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) x[q] = p[(size_t)(t + q) * ld];
+#pragma unroll
+    for (int q = 0; q < 8; q++) acc += (double)x[q];
+  }
+  for (; t < cnt; t++) acc += (double)p[(size_t)t * ld];
+  out[((size_t)v * groups + g) * ld + c] = acc;
+}
+}  // namespace
+
 extern "C" {
 
 int sipnet_node_create(const int32_t* flags, int32_t n_sites, int32_t n_members, int32_t precision,
@@ -353,6 +394,8 @@ void sipnet_node_destroy(sipnet_node* nd) {
     if (k < (int)nd->comms.size() && nd->comms[k]) nd->rccl->commDestroy(nd->comms[k]);
     if (nd->planes[k]) (void)hipFree(nd->planes[k]);
     if (nd->gatheredPlanes[k]) (void)hipFree(nd->gatheredPlanes[k]);
+    if (nd->reduced[k]) (void)hipFree(nd->reduced[k]);
+    if (nd->gatheredReduced[k]) (void)hipFree(nd->gatheredReduced[k]);
     if (nd->stats[k]) (void)hipFree(nd->stats[k]);
     if (nd->gatheredStats[k]) (void)hipFree(nd->gatheredStats[k]);
     if (nd->statsCompact[k]) (void)hipFree(nd->statsCompact[k]);
@@ -564,9 +607,30 @@ static int runShards(sipnet_node* nd, int32_t step0, int32_t n_steps, bool withS
 // travel (one all-gather per segment, on every shard's SECOND stream) under the step kernel of segment j + 1.
 // Every segment has its own place in the shard's planes and in the gathered block, so nothing is double-buffered
 // and nothing waits for a consumer (288 GB of HBM: the gathered year of c4's shape is 8 x 13.8 GB).
-static int runGathering(sipnet_node* nd, int32_t step0, int32_t n_steps, int32_t n_segments) {
+// ---- member-resolved outputs that fit under the kernel (round 6) ------------------------------------------------------
+// The raw fp64 planes of a year are 4.3 GB per rank at 10 240 members: ~100 ms of xGMI time against 8 ms of compute.  What a
+// consumer of the reference's per-step output (sipnet.c:453-473) aggregates anyway travels instead: the same planes as floats
+// (half the bytes), or every member's sums over groups of sum_steps steps (daily sums of a half-hourly year: 1 / 48 of the
+// bytes, 90 MB per rank) -- produced from segment j's planes on the shard's SECOND stream while segment j + 1 computes (the
+// step kernel of such a shape leaves compute units idle and uses a few per cent of the HBM bandwidth), then all-gathered there.
+
+// form: 0 the planes themselves (sipnet_node_run_gathering), SIPNET_GATHER_F32, SIPNET_GATHER_SUMS (sumSteps steps per group)
+static int runGathering(sipnet_node* nd, int32_t step0, int32_t n_steps, int32_t n_segments, int32_t form = 0, int32_t sumSteps = 0) {
   if (!nd || n_steps <= 0 || n_segments <= 0 || n_segments > n_steps || step0 < 0) {
     setError("sipnet_node_run_gathering: bad argument");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  if (form != 0 && form != SIPNET_GATHER_F32 && form != SIPNET_GATHER_SUMS) {
+    setError("sipnet_node_run_gathering_reduced: form must be SIPNET_GATHER_F32 or SIPNET_GATHER_SUMS");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  if (form == SIPNET_GATHER_F32 && nd->precision != SIPNET_F64) {
+    setError("sipnet_node_run_gathering_reduced: the planes of an fp32-mixed node are floats already (sipnet_node_run_gathering)");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  const int32_t nGroups = form == SIPNET_GATHER_SUMS ? (sumSteps > 0 ? (n_steps + sumSteps - 1) / sumSteps : 0) : n_steps;
+  if (form == SIPNET_GATHER_SUMS && (sumSteps <= 0 || n_segments > nGroups)) {
+    setError("sipnet_node_run_gathering_reduced: sum_steps > 0 and at most one segment per group of steps");
     return SIPNET_ERR_BAD_ARGUMENT;
   }
   const int n = nd->n();
@@ -580,14 +644,35 @@ static int runGathering(sipnet_node* nd, int32_t step0, int32_t n_steps, int32_t
     const int32_t raw = (int32_t)((int64_t)n_steps * j / n_segments);
     const int32_t tile = ((step0 + raw) & ~15) - step0;
     cuts[j] = tile > cuts[j - 1] ? tile : raw;
+    if (form == SIPNET_GATHER_SUMS) cuts[j] = (int32_t)((int64_t)nGroups * j / n_segments) * sumSteps;   // whole groups
   }
+  // rows of the reduced block per segment (steps, or groups of steps) and its element size
+  std::vector<int32_t> redCuts(n_segments + 1, 0);
+  for (int j = 0; j <= n_segments; j++) redCuts[j] = form == SIPNET_GATHER_SUMS ? (cuts[j] + sumSteps - 1) / sumSteps : cuts[j];
+  const size_t redElem = form == SIPNET_GATHER_F32 ? sizeof(float) : sizeof(double);
+  const size_t redBytes = form ? (size_t)3 * nGroups * nd->ld * redElem : 0;
+  // sums: inside the step kernel's own launch where every shard's batch has such a kernel (sipnet_batch_run_sums: no planes
+  // are written at all), else the planes summed by a pass on the second stream
+  bool sumsInKernel = form == SIPNET_GATHER_SUMS;
+  for (int k = 0; k < n && sumsInKernel; k++) sumsInKernel = sipnet_batch_sums_in_kernel(nd->batches[k]) != 0;
+  nd->reducedInKernel = sumsInKernel;
+  const bool growReduced = redBytes > nd->reducedCap;
   int rc = onEveryShard(nd, [&](int k) -> int {
+    if (growReduced) {
+      NODE_HIP(hipStreamSynchronize(nd->streams[k]));
+      NODE_HIP(hipStreamSynchronize(nd->gatherStreams[k]));
+      if (nd->reduced[k]) NODE_HIP(hipFree(nd->reduced[k]));
+      if (nd->gatheredReduced[k]) NODE_HIP(hipFree(nd->gatheredReduced[k]));
+      nd->reduced[k] = nd->gatheredReduced[k] = nullptr;
+      NODE_HIP(hipMalloc(&nd->reduced[k], redBytes));
+      NODE_HIP(hipMalloc(&nd->gatheredReduced[k], redBytes * n));
+    }
     if (grow) {
       NODE_HIP(hipStreamSynchronize(nd->gatherStreams[k]));
       int rcg = growRunBuffers(nd, k, n_steps);
       if (rcg) return rcg;
     }
-    if (growGathered) {
+    if (growGathered && !form) {
       NODE_HIP(hipStreamSynchronize(nd->streams[k]));
       NODE_HIP(hipStreamSynchronize(nd->gatherStreams[k]));
       if (nd->gatheredPlanes[k]) NODE_HIP(hipFree(nd->gatheredPlanes[k]));
@@ -598,7 +683,8 @@ static int runGathering(sipnet_node* nd, int32_t step0, int32_t n_steps, int32_t
   });
   if (rc) return rc;
   if (grow) nd->nAlloc = n_steps;
-  if (growGathered) nd->gatheredPlanesCap = count * n;
+  if (growGathered && !form) nd->gatheredPlanesCap = count * n;
+  if (growReduced) nd->reducedCap = redBytes;
   // every shard's host thread walks the segments on its own: launch, hand over to the second stream, all-gather there
   // (RCCL: one communicator per thread, the multi-thread idiom; shards sharing a device: event-ordered copies, the
   // threads meeting at a host barrier per segment)
@@ -612,6 +698,21 @@ static int runGathering(sipnet_node* nd, int32_t step0, int32_t n_steps, int32_t
       const size_t segOff = (size_t)3 * a * nd->ld * nd->elem();         // the segment in a shard's planes
       char* p = (char*)nd->planes[k] + segOff;
       const int32_t nLoc = step0 + a + len <= have ? len : have - (step0 + a);
+      if (sumsInKernel) {
+        const int32_t rows = redCuts[j + 1] - redCuts[j];
+        const size_t redOff = (size_t)3 * redCuts[j] * nd->ld * sizeof(double), oneRed = (size_t)rows * nd->ld;
+        double* r = (double*)((char*)nd->reduced[k] + redOff);
+        if (nLoc < len) NODE_HIP(hipMemsetAsync(r, 0, 3 * oneRed * sizeof(double), nd->streams[k]));   // (groups past a shard's last record: zero)
+        if (nLoc > 0) {
+          int rcr = sipnet_batch_run_sums(nd->batches[k], step0 + a, nLoc, sumSteps, r, r + oneRed, r + 2 * oneRed, nd->ld, nd->streams[k]);
+          if (rcr) return rcr;
+        }
+        NODE_HIP(hipEventRecord(nd->evSeg[k], nd->streams[k]));
+        NODE_HIP(hipStreamWaitEvent(nd->gatherStreams[k], nd->evSeg[k], 0));
+        int rcg = allGatherShard(nd, k, r, (char*)nd->gatheredReduced[k] + (size_t)n * redOff, 3 * oneRed * sizeof(double), nd->gatherStreams[k]);
+        if (rcg) return rcg;
+        continue;
+      }
       // (a site shard whose forcings end inside the segment: the rows past its end travel as zeros)
       if (nLoc > 0) {
         int rcr = sipnet_batch_run(nd->batches[k], step0 + a, nLoc, p, p + one, p + 2 * one, nullptr, nd->ld, nd->streams[k]);
@@ -619,7 +720,28 @@ static int runGathering(sipnet_node* nd, int32_t step0, int32_t n_steps, int32_t
       }
       NODE_HIP(hipEventRecord(nd->evSeg[k], nd->streams[k]));
       NODE_HIP(hipStreamWaitEvent(nd->gatherStreams[k], nd->evSeg[k], 0));
-      int rcg = allGatherShard(nd, k, p, (char*)nd->gatheredPlanes[k] + (size_t)n * segOff, 3 * one, nd->gatherStreams[k]);
+      if (!form) {
+        int rcg = allGatherShard(nd, k, p, (char*)nd->gatheredPlanes[k] + (size_t)n * segOff, 3 * one, nd->gatherStreams[k]);
+        if (rcg) return rcg;
+        continue;
+      }
+      // the segment's reduced block [3][rows][ld], made on the second stream, then gathered there
+      const int32_t rows = redCuts[j + 1] - redCuts[j];
+      const size_t redOff = (size_t)3 * redCuts[j] * nd->ld * redElem, redLen = (size_t)3 * rows * nd->ld * redElem;
+      char* r = (char*)nd->reduced[k] + redOff;
+      hipStream_t gs = nd->gatherStreams[k];
+      if (form == SIPNET_GATHER_F32) {
+        const size_t n2 = (size_t)3 * len * nd->ld / 2;   // (ld is even)
+        hipLaunchKernelGGL(planesToF32Kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, gs, (const double*)p, (float*)r, n2);
+      } else {
+        const dim3 grid((unsigned)((nd->ld + 255) / 256), (unsigned)rows, 3);
+        if (nd->precision == SIPNET_F64)
+          hipLaunchKernelGGL(sumStepsKernel<double>, grid, dim3(256), 0, gs, (const double*)p, (size_t)len * nd->ld, len, sumSteps, rows, nd->ld, (double*)r);
+        else
+          hipLaunchKernelGGL(sumStepsKernel<float>, grid, dim3(256), 0, gs, (const float*)p, (size_t)len * nd->ld, len, sumSteps, rows, nd->ld, (double*)r);
+      }
+      NODE_HIP(hipGetLastError());
+      int rcg = allGatherShard(nd, k, r, (char*)nd->gatheredReduced[k] + (size_t)n * redOff, redLen, gs);
       if (rcg) return rcg;
     }
     return SIPNET_OK;
@@ -635,11 +757,32 @@ static int runGathering(sipnet_node* nd, int32_t step0, int32_t n_steps, int32_t
   nd->step0 = step0;
   nd->segmented = true;
   nd->segCuts = cuts;
+  nd->reducedForm = form;
+  nd->reducedSumSteps = sumSteps;
+  nd->redCuts = redCuts;
   return SIPNET_OK;
 }
 
 int sipnet_node_run_gathering(sipnet_node* nd, int32_t step0, int32_t n_steps, int32_t n_segments) {
   return runGathering(nd, step0, n_steps, n_segments);
+}
+int sipnet_node_run_gathering_reduced(sipnet_node* nd, int32_t step0, int32_t n_steps, int32_t n_segments, int32_t form,
+                                      int32_t sum_steps) {
+  if (form != SIPNET_GATHER_F32 && form != SIPNET_GATHER_SUMS) {
+    setError("sipnet_node_run_gathering_reduced: form must be SIPNET_GATHER_F32 or SIPNET_GATHER_SUMS");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  return runGathering(nd, step0, n_steps, n_segments, form, sum_steps);
+}
+int32_t sipnet_node_reduced_in_kernel(const sipnet_node* nd) { return (nd && nd->segmented && nd->reducedForm && nd->reducedInKernel) ? 1 : 0; }
+void* sipnet_node_gathered_reduced(sipnet_node* nd, int32_t k, int32_t segment, int32_t* first_row, int32_t* n_rows, int32_t* elem_bytes) {
+  if (!nd || !nd->segmented || !nd->reducedForm || k < 0 || k >= nd->n() || segment < 0 || segment + 1 >= (int32_t)nd->redCuts.size())
+    return nullptr;
+  const size_t redElem = nd->reducedForm == SIPNET_GATHER_F32 ? sizeof(float) : sizeof(double);
+  if (first_row) *first_row = nd->redCuts[segment];
+  if (n_rows) *n_rows = nd->redCuts[segment + 1] - nd->redCuts[segment];
+  if (elem_bytes) *elem_bytes = (int32_t)redElem;
+  return (char*)nd->gatheredReduced[k] + (size_t)nd->n() * 3 * nd->redCuts[segment] * nd->ld * redElem;
 }
 int32_t sipnet_node_n_segments(const sipnet_node* nd) { return (nd && nd->segmented) ? (int32_t)nd->segCuts.size() - 1 : 0; }
 void* sipnet_node_gathered_segment(sipnet_node* nd, int32_t k, int32_t segment, int32_t* first_step, int32_t* n_steps) {

@@ -571,8 +571,22 @@ __device__ constexpr int coopCodePhase(int role) {
 #endif
 }
 
-template <class R, bool PlainExp, bool RingLds, bool Full, int NP, bool NCyc = false, bool Ext = false>
+// (the Sums instantiations' accumulators; an empty type otherwise, so that the other instantiations' code is what it was)
+template <bool On>
+struct CoopSums {
+  double nee = 0.0, et = 0.0, gpp = 0.0;
+  int left = 0;
+};
+template <>
+struct CoopSums<false> {};
+// Sums (round 6; fp64, default physics, lean): the three output planes receive every member's SUMS over groups of
+// a.sumEvery consecutive steps of the launch instead of the steps themselves -- [groups][ld] each, a row per group, the last
+// group as long as the launch leaves it -- accumulated in step order by the wave that computes the value (one add per value and
+// step, a store per group: 1 / sumEvery of the planes' HBM writes; sipnet_batch_run_sums).  Sums = false compiles to the code
+// it was before the parameter existed (tests/test_code_placement.py holds the measured instantiations' loop heads in place).
+template <class R, bool PlainExp, bool RingLds, bool Full, int NP, bool NCyc = false, bool Ext = false, bool Sums = false>
 __device__ __forceinline__ void coopBody(const FastArgs& a) {
+  static_assert(!Sums || (!NCyc && !Ext && !Full && sizeof(R) == 8), "in-kernel sums: fp64, default physics, lean launches");
   static_assert(!(NP > 1 && RingLds), "two chunks' rings do not fit one CU's LDS");
   static_assert(!NCyc || (NP <= 2 && !RingLds), "nitrogen-cycle layout: one or two chunks, ring in HBM");
   constexpr bool Opt = Ext && !NCyc;   // the optional pools live on wave C
@@ -1625,6 +1639,8 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
     R* __restrict__ oEt = (R*)(a.et ? a.et : a.scratchRow) + col;
     R* __restrict__ oGpp = (R*)(a.gpp ? a.gpp : a.scratchRow) + col;
     const int64_t ldEt = a.et ? a.ld : 0, ldGpp = a.gpp ? a.ld : 0;
+    CoopSums<Sums> sumsW;   // Sums: the group's sums so far, and the steps it still lacks
+    if constexpr (Sums) sumsW.left = a.sumEvery;
     const bool wantDiagW = Full && a.diag != nullptr;
     const double K_whc2 = Full ? 2.0 * PRM(soilWHC) : 0.0;
     double* __restrict__ recw = Full && a.rec ? a.rec + col : nullptr;
@@ -1634,7 +1650,11 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
     for (int tileStart = curTile * kFastTile; tileStart < tEnd; tileStart += kFastTile, curTile++) {
       // the DMA of 16 steps ago has landed: all but the two youngest operations (the last step's
       // ET and GPP stores)
-      if (tileStart > tBegin) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      if constexpr (Sums) {
+        if (tileStart > tBegin) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (no store per step to leave in flight)
+      } else {
+        if (tileStart > tBegin) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      }
       stageTile(curTile + 1, (curTile + 1) & 1);
       const int tFirst = tileStart > tBegin ? tileStart : tBegin;
       const int tLast = (tileStart + kFastTile) < tEnd ? (tileStart + kFastTile) : tEnd;
@@ -1825,10 +1845,23 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
         }
 
         const R tEt = ((Ext ? transpiration + immedEvap : ffma(rain, K_immed, transpiration)) + evaporation + sublimation + evEvap) * len;
-        *oEt = tEt;
-        *oGpp = tGpp;
-        oEt += ldEt;
-        oGpp += ldGpp;
+        if constexpr (Sums) {
+          sumsW.et += (double)tEt;
+          sumsW.gpp += (double)tGpp;
+          if (--sumsW.left == 0) {
+            *oEt = (R)sumsW.et;
+            *oGpp = (R)sumsW.gpp;
+            oEt += ldEt;
+            oGpp += ldGpp;
+            sumsW.et = sumsW.gpp = 0.0;
+            sumsW.left = a.sumEvery;
+          }
+        } else {
+          *oEt = tEt;
+          *oGpp = tGpp;
+          oEt += ldEt;
+          oGpp += ldGpp;
+        }
         if (__builtin_expect(stageOn, 0)) {   // sipnet_batch_run_stats on a two- / four-chunk layout: for wave L
           postRaw(&stage[1][(t - tBegin) & (2 * kStageR - 1)][lane], tGpp);
           postRaw(&stage[2][(t - tBegin) & (2 * kStageR - 1)][lane], tEt);
@@ -1845,6 +1878,12 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
           recw[19 * L] = snow;
           recw += (int64_t)SIPNET_NREC * L;
         }
+      }
+    }
+    if constexpr (Sums) {
+      if (sumsW.left != a.sumEvery) {   // the launch's last, shorter group
+        *oEt = (R)sumsW.et;
+        *oGpp = (R)sumsW.gpp;
       }
     }
     WAIT_STORE(4)
@@ -1944,6 +1983,8 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   R* __restrict__ oNee = (R*)(a.nee ? a.nee : a.scratchRow) + col;
   const int64_t ldNee = a.nee ? a.ld : 0;
   const uint32_t ncu = (uint32_t)nc;
+  CoopSums<Sums> sumsC;   // Sums: the group's sum so far, and the steps it still lacks
+  if constexpr (Sums) sumsC.left = a.sumEvery;
 
   post(&mailLai[tBegin & 1][lane], &seqLai, (R)plantLeafC * K_invLcsw, tBegin);
   postAlive(&mailAlive[tBegin & 1][lane], tBegin, false);  // lai(tBegin) is not speculative
@@ -2028,9 +2069,16 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
   for (int tileStart = curTile * kFastTile; tileStart < tEnd; tileStart += kFastTile, curTile++) {
     // the DMA of this tile was issued a tile ago; only the last step's two stores may still be
     // in flight behind it
+    if constexpr (Sums) {   // (no NEE store per step: nothing, or the ring store alone, may stay in flight)
+      if (tileStart > tBegin) {
+        if (RingLds) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      }
+    } else {
     if (tileStart > tBegin) {
       if (RingLds) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // + the ring store
+    }
     }
     stageTile(curTile + 1, (curTile + 1) & 1);
     const int tFirst = tileStart > tBegin ? tileStart : tBegin;
@@ -2152,9 +2200,19 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
             lastIns = insSlot;
             lastNpp = npp;
           }
+          if constexpr (Sums) {
+            sumsC.nee += (double)tNee;
+            if (--sumsC.left == 0) {
+              *oNee = (R)sumsC.nee;
+              oNee += ldNee;
+              sumsC.nee = 0.0;
+              sumsC.left = a.sumEvery;
+            }
+          } else {
           if (!NCyc) {
             *oNee = tNee;
             oNee += ldNee;
+          }
           }
           if (__builtin_expect(stageOn, 0)) postRaw(&stage[0][(t - tBegin) & (2 * kStageR - 1)][lane], tNee);
         };
@@ -2856,14 +2914,27 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
       r[43 * L] = diedNow ? 1.0 : 0.0;
       recp += (int64_t)SIPNET_NREC * L;
     }
+    if constexpr (Sums) {
+      sumsC.nee += (double)tNee;
+      if (--sumsC.left == 0) {
+        *oNee = (R)sumsC.nee;
+        oNee += ldNee;
+        sumsC.nee = 0.0;
+        sumsC.left = a.sumEvery;
+      }
+    } else {
     if (!NCyc) {
       *oNee = tNee;
       oNee += ldNee;
+    }
     }
     if (__builtin_expect(stageOn, 0)) postRaw(&stage[0][(t - tBegin) & (2 * kStageR - 1)][lane], tNee);
     CSTAMP(6)
   }  // steps of this tile
   }  // tiles
+  if constexpr (Sums) {
+    if (sumsC.left != a.sumEvery) *oNee = (R)sumsC.nee;   // the launch's last, shorter group
+  }
 
   CSTAMP_STORE()
   WAIT_STORE(8)
@@ -2930,6 +3001,18 @@ template <class R, bool PlainExp>
 __global__ __launch_bounds__(768) void stepCoopQuadKernel(FastArgs a) {
   coopBody<R, PlainExp, false, false, 4>(a);
 }
+#ifndef SIPNET_COOP_BOUNDED
+// every member's sums over groups of a.sumEvery steps instead of the steps (coopBody, Sums): fp64, default physics, lean;
+// one chunk per workgroup (ring in LDS or HBM) or two
+template <bool PlainExp, bool RingLds>
+__global__ __launch_bounds__(RingLds ? 256 : 192) void stepCoopSumsKernel(FastArgs a) {
+  coopBody<double, PlainExp, RingLds, false, 1, false, false, true>(a);
+}
+template <bool PlainExp>
+__global__ __launch_bounds__(512) void stepCoopPairSumsKernel(FastArgs a) {
+  coopBody<double, PlainExp, false, false, 2, false, false, true>(a);
+}
+#endif
 
 // (a full-state build of the four-chunk layout was probed in round 4: under its 168-register budget -- twelve
 // wavefronts per CU -- the carbon wave's record columns and accumulators spill, fp64 284 bytes of scratch per lane, fp32-mixed
@@ -3094,6 +3177,20 @@ void launchStepCoop(const FastArgs& a, int precision, int layout, hipStream_t st
     else hipLaunchKernelGGL((stepCoopPairKernel<R, P, false>), grid, block, 0, stream, a);          \
   }
 #endif
+#ifndef SIPNET_COOP_BOUNDED
+  if (a.sumEvery > 0) {   // (the engine sends fp64, default-physics, lean launches of these three layouts only)
+    if (pair) {
+      if (a.plainExp) hipLaunchKernelGGL((stepCoopPairSumsKernel<true>), grid, block, 0, stream, a);
+      else hipLaunchKernelGGL((stepCoopPairSumsKernel<false>), grid, block, 0, stream, a);
+    } else if (ringInLds) {
+      if (a.plainExp) hipLaunchKernelGGL((stepCoopSumsKernel<true, true>), grid, block, 0, stream, a);
+      else hipLaunchKernelGGL((stepCoopSumsKernel<false, true>), grid, block, 0, stream, a);
+    } else {
+      if (a.plainExp) hipLaunchKernelGGL((stepCoopSumsKernel<true, false>), grid, block, 0, stream, a);
+      else hipLaunchKernelGGL((stepCoopSumsKernel<false, false>), grid, block, 0, stream, a);
+    }
+  } else
+#endif
   if (ext) {   // (one or two chunks per workgroup, lean: the engine does not ask for anything else)
 #define X_LAUNCH2(R, P, F)                                                                                    \
   {                                                                                                           \
@@ -3135,7 +3232,9 @@ void launchStepCoop(const FastArgs& a, int precision, int layout, hipStream_t st
     const char* r = precision == SIPNET_F64 ? "double" : "float";
     const char* pe = a.plainExp ? "true" : "false";
     const char* fu = a.full ? "true" : "false";
-    if (ext && quad) snprintf(info->kernel, sizeof info->kernel, "stepCoopXQuadKernel<float, %s>", pe);
+    if (a.sumEvery > 0 && pair) snprintf(info->kernel, sizeof info->kernel, "stepCoopPairSumsKernel<%s>", pe);
+    else if (a.sumEvery > 0) snprintf(info->kernel, sizeof info->kernel, "stepCoopSumsKernel<%s, %s>", pe, ringInLds ? "true" : "false");
+    else if (ext && quad) snprintf(info->kernel, sizeof info->kernel, "stepCoopXQuadKernel<float, %s>", pe);
     else if (ext && pair) snprintf(info->kernel, sizeof info->kernel, "stepCoopXPairKernel<%s, %s, %s>", r, pe, fu);
     else if (ext) snprintf(info->kernel, sizeof info->kernel, "stepCoopXKernel<%s, %s, %s, %s>", r, pe, ringInLds ? "true" : "false", fu);
     else if (quad) snprintf(info->kernel, sizeof info->kernel, "stepCoopQuadKernel<%s, %s>", r, pe);

@@ -127,6 +127,8 @@ struct FastArgs {
   double* pfBlockMax;     // [workgroups of the launch]
   double pfObs, pfInvSigma;
   int64_t prmPitch;       // one-wave kernel: columns of prm (ncol; a filter's parameter bank shared by all ranks: world * nmax)
+  int32_t sumEvery;       // > 0 (cooperative kernels' Sums instantiations): nee / gpp / et receive sums over groups of this many steps
+  int32_t padEnd;
 };
 // What a launcher actually put on the stream (sipnet_batch_last_launch): the instantiation's
 // name as rocprofv3 prints its template arguments, and the launch shape.

@@ -162,6 +162,33 @@ class Node:
             t += g.shape[2]
         return out
 
+    def run_gathering_reduced(self, step0, n_steps, n_segments, form, sum_steps=0):
+        """sipnet_node_run_gathering_reduced: the member-resolved exchange in a form that fits under the kernel -- form
+        "f32" (the planes as floats) or "sums" (every member's sums over groups of sum_steps steps, doubles)"""
+        f = {"f32": 1, "sums": 2}[form]
+        check(self.L.sipnet_node_run_gathering_reduced(self.h, step0, n_steps, n_segments, f, int(sum_steps)),
+              "node_run_gathering_reduced")
+        self.n_run = n_steps
+
+    def gathered_reduced_member_rows(self, k):
+        """what device k holds after run_gathering_reduced, as [3][rows][n_sites][n_members] on the host (rows = steps, or
+        groups of steps)"""
+        self.sync()
+        parts = []
+        for j in range(self.L.sipnet_node_n_segments(self.h)):
+            first, rows, eb = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+            ptr = self.L.sipnet_node_gathered_reduced(self.h, k, j, C.byref(first), C.byref(rows), C.byref(eb))
+            if not ptr:
+                raise ValueError("no reduced segment")
+            g = self._to_host(ptr, (self.n, 3, rows.value, self.ld), np.float32 if eb.value == 4 else np.float64)
+            out = np.zeros((3, rows.value, self.n_sites, self.n_members), dtype=g.dtype)
+            for q in range(self.n):
+                m0, mc = self.member_range(q)
+                s0, sc = self.site_range(q)
+                out[:, :, s0:s0 + sc, m0:m0 + mc] = g[q][:, :, :sc * mc].reshape(3, rows.value, sc, mc)
+            parts.append(out)
+        return np.concatenate(parts, axis=1)
+
     def gathered_stats(self, k):
         mx = self.n_sites if self.shard == SHARD_MEMBERS else max(self.site_range(j)[1] for j in range(self.n))
         return self._to_host(self.L.sipnet_node_gathered_stats(self.h, k), (self.n, 3, self.n_run, mx, 2), np.float64)

@@ -114,6 +114,49 @@ int main(int argc, char **argv) {
     covered += len;
   }
   printf("gathering_segments_equal_gathered_planes=%d\n", segmentsEqual && covered == T);
+
+  /* the member-resolved exchange in the form that fits under the kernel: every member's sums over groups of 48 steps (the
+   * daily sums of a half-hourly forcing), reduced on the second stream and all-gathered per segment -- against the planes
+   * gathered above, summed here in the same step order */
+  {
+    const int32_t K = 48, groups = (T + K - 1) / K;
+    rc = sipnet_node_setup(nd);
+    if (!rc) rc = sipnet_node_run_gathering_reduced(nd, 0, T, 4, SIPNET_GATHER_SUMS, K);
+    if (!rc) rc = sipnet_node_sync(nd);
+    if (rc) { printf("run_gathering_reduced=%d %s\n", rc, sipnet_last_error()); return 1; }
+    int sumsEqual = sipnet_node_n_segments(nd) == 4, rowsSeen = 0;
+    double sumNeeDay0Member0 = 0.0, worstSum = 0.0;
+    size_t bytesPerRank = 0;
+    for (int32_t j = 0; j < sipnet_node_n_segments(nd) && sumsEqual; j++) {
+      int32_t first = -1, rows = 0, eb = 0;
+      void *dev = sipnet_node_gathered_reduced(nd, nDev - 1, j, &first, &rows, &eb);
+      if (!dev || first != rowsSeen || rows <= 0 || eb != 8) { sumsEqual = 0; break; }
+      const size_t cnt = (size_t)nDev * 3 * (size_t)rows * (size_t)ld;
+      double *seg = (double *)malloc(sizeof(double) * cnt);
+      rc = sipnet_dev_to_host(seg, dev, sizeof(double) * cnt, NULL);
+      if (rc) { printf("copy_reduced=%d %s\n", rc, sipnet_last_error()); return 1; }
+      bytesPerRank += sizeof(double) * 3 * (size_t)rows * (size_t)ld;
+      for (int32_t k = 0; k < nDev; k++)
+        for (int v = 0; v < 3; v++)
+          for (int32_t r = 0; r < rows; r++) {
+            const int32_t gi = first + r, t0 = gi * K, t1 = (gi + 1) * K < T ? (gi + 1) * K : T;
+            int32_t firstM, count;
+            sipnet_node_member_range(nd, k, &firstM, &count);
+            for (int32_t m = 0; m < count; m++) {
+              double acc = 0.0;
+              for (int32_t t = t0; t < t1; t++) acc += g[(((size_t)k * 3 + (size_t)v) * (size_t)T + (size_t)t) * (size_t)ld + (size_t)m];
+              double d = seg[(((size_t)k * 3 + (size_t)v) * (size_t)rows + (size_t)r) * (size_t)ld + (size_t)m] - acc;
+              if (d < 0) d = -d;
+              if (d > worstSum) worstSum = d;
+              if (k == 0 && v == 0 && gi == 0 && m == 0) sumNeeDay0Member0 = acc;
+            }
+          }
+      free(seg);
+      rowsSeen += rows;
+    }
+    printf("reduced_sums_equal_planes=%d\nreduced_sums_max_abs=%.3e\nreduced_groups=%d\nreduced_bytes_per_rank=%zu\nsum_nee_day0_member_0=%.12f\n",
+           sumsEqual && rowsSeen == groups && worstSum == 0.0, worstSum, (int)groups, bytesPerRank, sumNeeDay0Member0);
+  }
   free(g); free(gs0); free(gsk); free(total); free(members);
   sipnet_node_destroy(nd);
   sipnet_clim_free(clim);

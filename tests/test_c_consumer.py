@@ -86,6 +86,9 @@ def test_node_of_one_device_all_gathers_through_rccl_from_c(oracle, tmp_path):
     assert "RCCL" in kv["collective_library"] and kv["n_devices"] == "1"
     assert kv["gathered_stats_identical"] == "1"
     assert kv["gathering_segments_equal_gathered_planes"] == "1"      # sipnet_node_run_gathering: the overlapped plane gather from C
+    # sipnet_node_run_gathering_reduced from C: every member's sums over groups of 48 steps = the planes summed in step order
+    assert kv["reduced_sums_equal_planes"] == "1" and float(kv["reduced_sums_max_abs"]) == 0.0, out
+    assert int(kv["reduced_groups"]) == (5237 + 47) // 48 and int(kv["reduced_bytes_per_rank"]) == 3 * 110 * 130 * 8
     assert float(kv["stats_vs_planes_max_abs"]) < 1e-9
     assert kv["kernel"].startswith("stepCoopKernel<double")
     case = helpers.load_smoke_case("niwot", str(tmp_path))
@@ -95,6 +98,7 @@ def test_node_of_one_device_all_gathers_through_rccl_from_c(oracle, tmp_path):
     assert (st == 0).all()
     assert float(kv["sum_nee_member_0"]) == pytest.approx(want[0][:, 0].sum(), abs=1e-8)
     assert float(kv["sum_nee_member_last"]) == pytest.approx(want[0][:, 1].sum(), abs=1e-8)
+    assert float(kv["sum_nee_day0_member_0"]) == pytest.approx(want[0][:48, 0].sum(), abs=1e-9)      # ... and the oracle's
 
 
 PF_SRC = os.path.join(helpers.REPO, "tests", "c", "pf_consumer.c")

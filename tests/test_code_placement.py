@@ -48,6 +48,15 @@ def expected_phase(kernel, R, plain_exp, ring_lds, full, NP, ncyc, ext, role):
 
 def instantiation(demangled):
     """'void sipnet::stepCoopPairKernel<double, true, false>(sipnet::FastArgs)' -> template arguments of coopBody"""
+    # (round 6: the in-kernel sums builds -- fp64, lean, default physics; placed like their plain relatives, not measured)
+    m = re.match(r"void sipnet::stepCoopSumsKernel<(\w+), (\w+)>", demangled)
+    if m:
+        return dict(kernel="stepCoopSumsKernel", R="double", plain_exp=m.group(1) == "true", ring_lds=m.group(2) == "true", full=False,
+                    NP=1, ncyc=False, ext=False)
+    m = re.match(r"void sipnet::stepCoopPairSumsKernel<(\w+)>", demangled)
+    if m:
+        return dict(kernel="stepCoopPairSumsKernel", R="double", plain_exp=m.group(1) == "true", ring_lds=False, full=False, NP=2,
+                    ncyc=False, ext=False)
     m = re.match(r"void sipnet::(?:bounded::)?(stepCoop\w*Kernel)<(\w+), (\w+)(?:, (\w+))?(?:, (\w+))?>", demangled)
     if not m:
         return None

@@ -150,6 +150,67 @@ def test_run_gathering_overlapped_plane_gather_equals_one_batch(base, devices, s
     nd.close()
 
 
+@pytest.mark.parametrize("devices,shard,n_sites,prec", [([0, 0], SHARD_MEMBERS, 2, sa.F64), ([0, 0, 0], SHARD_SITES, 5, sa.F64),
+                                                        ([0], SHARD_MEMBERS, 1, sa.F64), ([0, 0], SHARD_MEMBERS, 1, sa.F32_MIXED)],
+                         ids=["members-2-shards", "sites-ragged-3-shards", "rccl-one-rank", "f32mixed-2-shards"])
+def test_reduced_member_resolved_gather_equals_one_batch_and_the_oracle(base, devices, shard, n_sites, prec):
+    """sipnet_node_run_gathering_reduced: every member's DAILY sums of NEE / GPP / ET (groups of 48 half-hourly steps, the
+    last one shorter, summed in step order on the shards' second streams under the next segment's kernel, then all-gathered:
+    1 / 48 of the planes' bytes) against ONE batch's planes summed on the host in the same order -- bit for bit -- and
+    against the CPU oracle's daily sums (1e-9); and the planes as floats (half the bytes) against ONE batch's planes
+    rounded to float.  What EVERY device holds afterwards."""
+    M, T, K = 130, 48 * 6 + 20, 48
+    flags = sa.flags_from()
+    clims = site_clims(n_sites, T)
+    members = synth.perturbed_params(base, M)
+    b = one_batch(flags, clims, members, prec)
+    planes, _ = b.run(0, T)
+    want = planes.cpu().numpy().reshape(3, T, n_sites, M)
+    b.close()
+    groups = (T + K - 1) // K
+    want_sums = np.zeros((3, groups, n_sites, M))
+    for t in range(T):                                  # in step order, like the kernel
+        want_sums[:, t // K] += want[:, t].astype(np.float64)
+    nd = Node(flags, n_sites, M, precision=prec, devices=devices, shard=shard, fast_math=True if prec == sa.F64 else None)
+    for s in range(n_sites):
+        nd.set_climate(s, clims[s])
+    nd.set_params(None, members)
+    nd.setup()
+    nd.run_gathering_reduced(0, T, 3, "sums", K)
+    assert nd.L.sipnet_node_n_segments(nd.h) == 3
+    # fp64 shards sum inside the step kernel's launch (no planes written); fp32-mixed ones sum their planes on the second stream
+    assert nd.L.sipnet_node_reduced_in_kernel(nd.h) == (1 if prec == sa.F64 else 0)
+    if prec == sa.F64:
+        assert "Sums" in nd.kernel_name(0)
+    for k in range(nd.n):
+        got = nd.gathered_reduced_member_rows(k)
+        assert got.dtype == np.float64 and got.shape == want_sums.shape
+        np.testing.assert_array_equal(got, want_sums)
+    if prec == sa.F64:
+        ora = helpers.load_oracle()
+        ref, _, st = ora.run_block(flags, members[:3], clims[0])
+        assert (st == 0).all()
+        ref_sums = np.stack([ref[:, g * K:(g + 1) * K].sum(axis=1) for g in range(groups)], axis=1)    # [3][groups][3 members]
+        np.testing.assert_allclose(got[:, :, 0, :3], ref_sums, rtol=0, atol=1e-9)
+        # ... and the planes as floats
+        nd.setup()
+        nd.run_gathering_reduced(0, T, 4, "f32")
+        for k in range(nd.n):
+            got = nd.gathered_reduced_member_rows(k)
+            assert got.dtype == np.float32
+            np.testing.assert_array_equal(got, want.astype(np.float32))
+    else:
+        with pytest.raises(sa.SipnetError):
+            nd.run_gathering_reduced(0, T, 4, "f32")    # the planes of an fp32-mixed node are floats already
+    with pytest.raises(sa.SipnetError):
+        nd.run_gathering_reduced(0, T, 100, "sums", K)  # more segments than groups
+    # a plain run afterwards is not disturbed
+    nd.setup()
+    nd.run(0, T)
+    assert np.isfinite(nd.gather_stats()).all()
+    nd.close()
+
+
 def test_site_shards_with_sites_of_different_lengths(base):
     """five sites whose forcings end at different records on three site shards (1 + 2 + 2 sites; the shards' longest
     sites differ too): planes, statistics and the overlapped plane gather equal ONE batch of the five sites bit for

@@ -1,0 +1,121 @@
+"""sipnet_batch_run_sums: every member's sums of NEE / GPP / ET over groups of k consecutive steps, accumulated inside the
+step kernel's own launch by the wavefront that computes the value (step_coop.hip, coopBody<..., Sums>: stepCoopSumsKernel,
+stepCoopPairSumsKernel) -- against the SAME batch's per-step planes summed on the host in step order: bit for bit, on every
+layout that has such a kernel, with split launches, groups that do not divide the run, ragged chunks, sites of different
+lengths, members with a general VPD exponent, a member that dies and one that never runs; and against the CPU oracle's
+daily sums (1e-9).  What a consumer of the reference's per-step output rows (sipnet.c:453-473) aggregates anyway."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import sipnet_amd as sa
+from sipnet_amd import synth
+from sipnet_amd.config import param_index as pi
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+BASE = os.path.join(helpers.REPO, "sipnet_amd", "data", "base_forest.param")
+
+
+@pytest.fixture(scope="module")
+def base():
+    return sa.read_params(BASE, sa.flags_from())[0]
+
+
+def host_sums(planes, k):
+    """planes [3][T][ncol] -> [3][ceil(T / k)][ncol], added in step order like the kernel"""
+    T = planes.shape[1]
+    out = np.zeros((3, (T + k - 1) // k, planes.shape[2]))
+    for t in range(T):
+        out[:, t // k] += planes[:, t]
+    return out
+
+
+@pytest.mark.parametrize("kernel,name", [(sa.KERNEL_COOP_LDS, "stepCoopSumsKernel<true, true>"), (sa.KERNEL_COOP_HBM, "stepCoopSumsKernel<true, false>"),
+                                         (sa.KERNEL_COOP_PAIR, "stepCoopPairSumsKernel<true>"), (sa.KERNEL_AUTO, "stepCoopSumsKernel<true, true>")],
+                         ids=["lds-ring", "hbm-ring", "pair", "auto"])
+def test_sums_in_the_launch_equal_the_planes_summed_in_step_order(base, kernel, name):
+    M, T = 64 * 3 + 17, 48 * 5 + 11
+    clims = [synth.convert_raw(synth.round_like_file(synth.half_hourly_year_raw(T, site=s))) for s in range(3)]
+    clims[1] = clims[1].slice(0, T - 29)                     # a site that ends inside a group
+    members = synth.perturbed_params(base, M, seed=3)
+    members[5, pi("leafAllocation")] = 0.9                   # never runs (status 3)
+    members[5, pi("woodAllocation")] = 0.9
+    members[9, pi("plantWoodInit")] = 1e-4                   # starves: dies inside the run
+    members[9, pi("laiInit")] = 1e-4
+
+    def make():
+        b = sa.Batch(sa.flags_from(), 3, M, sa.F64, fast_math=True, kernel=kernel)
+        b.set_climates(clims)
+        b.set_params(None, members)
+        b.setup()
+        return b
+
+    ref = make()
+    planes, _ = ref.run(0, T)
+    want = planes.cpu().numpy()
+    want[:, T - 29:, M:2 * M] = 0.0                          # (rows past the shorter site's end: never written)
+    ran = np.tile(ref.get_status()[:M] == 0, 3)              # (what a member that never runs leaves in a plane means nothing, and
+    assert (~ran).sum() == 3                                 #  depends on where the launches were cut: left out below)
+    ref.close()
+    for k, cuts in ((48, [0, T]), (48, [0, 96, T]), (7, [0, 7 * 9, 7 * 20, T]), (T + 5, [0, T]), (1, [0, 33, T])):
+        b = make()
+        assert b.sums_in_kernel()
+        got = []
+        for a, z in zip(cuts[:-1], cuts[1:]):
+            assert a % k == 0                                # launches start at group boundaries
+            got.append(b.run_sums(a, z - a, k).cpu().numpy())
+            assert b.last_launch()["kernel"] == name, b.last_launch()["kernel"]
+        got = np.concatenate(got, axis=1)
+        ws = host_sums(want, k)
+        # (the shorter site's groups past its end: what a launch does not reach is not written -- compare what is)
+        g_end = (T - 29 + k - 1) // k
+        got, ws = got[:, :, ran], ws[:, :, ran]
+        Mr = M - 1
+        np.testing.assert_array_equal(got[:, :, :Mr], ws[:, :, :Mr])
+        np.testing.assert_array_equal(got[:, :, 2 * Mr:], ws[:, :, 2 * Mr:])
+        np.testing.assert_array_equal(got[:, :g_end, Mr:2 * Mr], ws[:, :g_end, Mr:2 * Mr])
+        # the state after a summing run is the state after the plain run
+        b2 = make()
+        b2.run(0, T)
+        np.testing.assert_array_equal(b.get_state(), b2.get_state())
+        b.close()
+        b2.close()
+
+
+def test_daily_sums_against_the_oracle_and_general_exponents(base):
+    M, T, K = 130, 48 * 4, 48
+    clim = synth.convert_raw(synth.round_like_file(synth.half_hourly_year_raw(T)))
+    members = synth.perturbed_params(base, M, seed=8)
+    members[3, pi("dVpdExp")] = 1.7                          # the general-exponent instantiation
+    b = sa.Batch(sa.flags_from(), 1, M, sa.F64, fast_math=True)
+    b.set_climate(0, clim)
+    b.set_params(0, members)
+    b.setup()
+    got = b.run_sums(0, T, K).cpu().numpy()
+    assert b.last_launch()["kernel"] == "stepCoopSumsKernel<false, true>"
+    b.close()
+    ora = helpers.load_oracle()
+    ref, _, st = ora.run_block(sa.flags_from(), members[:8], clim)
+    assert (st == 0).all()
+    ref_sums = np.stack([ref[:, g * K:(g + 1) * K].sum(axis=1) for g in range(T // K)], axis=1)
+    np.testing.assert_allclose(got[:, :, :8], ref_sums, rtol=0, atol=1e-9)
+
+
+def test_batches_without_such_a_kernel_say_so(base):
+    clim = synth.convert_raw(synth.round_like_file(synth.half_hourly_year_raw(96)))
+    for kw in (dict(prec=sa.F32_MIXED), dict(prec=sa.F64, fast_math=False), dict(prec=sa.F64, fast_math=True, kernel=sa.KERNEL_ONE_WAVE),
+               dict(prec=sa.F64, fast_math=True, flags=sa.flags_from(litterPool=1))):
+        prec = kw.pop("prec")
+        flags = kw.pop("flags", sa.flags_from())
+        b = sa.Batch(flags, 1, 64, prec, **kw)
+        b.set_climate(0, clim)
+        b.set_params(0, base)
+        b.setup()
+        assert not b.sums_in_kernel()
+        with pytest.raises(sa.SipnetError) as e:
+            b.run_sums(0, 96, 48)
+        assert "sums" in str(e.value)
+        b.close()

@@ -59,4 +59,14 @@ print("forecast + gather_planes afterwards           %8.3f ms   (%.2f GB receive
 for nseg in (1, 4, 10, 20, 40):
     ms = timed(lambda: nd.run_gathering(0, T, nseg))
     print("run_gathering, %2d segments                    %8.3f ms   (+%.3f over the forecast)" % (nseg, ms, ms - fc))
+# the member-resolved exchange in the forms that fit under the kernel (sipnet_node_run_gathering_reduced)
+for form, k, what in (("sums", 48, "daily sums per member (doubles)"), ("f32", 0, "the planes as floats")):
+    if form == "f32" and nd.precision != sa.F64:
+        continue
+    rows = (T + k - 1) // k if k else T
+    mb = 3 * rows * nd.ld * (8 if form == "sums" else 4) / 1e6
+    for nseg in (1, 4, 8, 16):
+        ms = timed(lambda: nd.run_gathering_reduced(0, T, nseg, form, k))
+        print("run_gathering_reduced %-4s, %2d segments         %8.3f ms   (+%.3f over the forecast; %s: %.1f MB per rank)" % (
+            form, nseg, ms, ms - fc, what, mb))
 nd.close()
