@@ -1025,6 +1025,8 @@ int sipnet_batch_setup(sipnet_batch* b, void* hip_stream) {
   int rc = useDevice(b);
   if (rc) return rc;
   hipStream_t stream = (hipStream_t)hip_stream;
+  b->pfPre.valid = false;   // (log-weights a forecast left, an analysis it was armed for: of the state this call replaces)
+  b->pfArm.set = false;
   if (b->planDirty) {
     rc = uploadPlan(b, stream);
     if (rc) return rc;
@@ -1525,6 +1527,8 @@ int sipnet_batch_get_state(sipnet_batch* b, double* state, void* hip_stream) {
 
 int sipnet_batch_set_state(sipnet_batch* b, const double* state, void* hip_stream) {
   if (!b || !state) return SIPNET_ERR_BAD_ARGUMENT;
+  b->pfPre.valid = false;
+  b->pfArm.set = false;
   int rc = useDevice(b);
   if (rc) return rc;
   hipStream_t stream = (hipStream_t)hip_stream;
@@ -1670,6 +1674,8 @@ int sipnet_batch_import_restart(sipnet_batch* b, int32_t site, int32_t first_mem
              "sipnet_batch_setup first");
     return SIPNET_ERR_BAD_ARGUMENT;
   }
+  b->pfPre.valid = false;
+  b->pfArm.set = false;
   int rc = useDevice(b);
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize((hipStream_t)hip_stream));

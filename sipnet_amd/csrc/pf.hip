@@ -1265,6 +1265,8 @@ int sipnet_batch_resample(sipnet_batch* b, const int32_t* d_src, const double* d
   int rc = useDevice(b);
   if (rc) return rc;
   hipStream_t stream = (hipStream_t)hip_stream;
+  b->pfPre.valid = false;   // (a forecast's log-weights belong to the particles as they were)
+  b->pfArm.set = false;
   rc = flushParams(b, stream);
   if (rc) return rc;
   const size_t nc = (size_t)b->ncol;

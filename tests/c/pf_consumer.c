@@ -4,8 +4,11 @@
  * log-weight blocks (RCCL with one device per shard), then every shard resamples by reading its ancestors where
  * they live -- timed against the same K cycles on ONE batch without any exchange path
  * (sipnet_batch_pf_analysis), with nothing synchronised inside either loop.  With one shard the two must end
- * in the same state, bit for bit.
- * usage: pf_consumer <param file> <clim file> <n_particles> <dev>[,<dev>...] <cycles> <n_steps>
+ * in the same state, bit for bit -- and with several whenever the shards and the twin take the SAME step kernel: the
+ * kernel follows the shape (two shards of 65 536 particles take the four-chunk cooperative kernel, the twin's 131 072
+ * the one-wave kernel: equal to rounding, not to bits), so both kernels' names are printed next to state_identical and
+ * the largest relative difference, and a seventh argument `1` puts node and twin on the one-wave kernel.
+ * usage: pf_consumer <param file> <clim file> <n_particles> <dev>[,<dev>...] <cycles> <n_steps> [one_wave=0|1]
  *   -> key=value lines; exit 0 on success.  Without a GPU: create=100. */
 #define _POSIX_C_SOURCE 199309L
 #include <stdio.h>
@@ -36,6 +39,7 @@ int main(int argc, char **argv) {
   const int K = atoi(argv[5]);
   const int32_t T = (int32_t)atoi(argv[6]);
   if (T > sipnet_clim_nsteps(clim)) return 2;
+  const int oneWave = argc > 7 && atoi(argv[7]) != 0;
 
   sipnet_node *nd = NULL;
   rc = sipnet_node_create_sharded(flags, 1, N, SIPNET_F32_MIXED, devices, nDev, SIPNET_SHARD_MEMBERS, &nd);
@@ -62,6 +66,8 @@ int main(int argc, char **argv) {
   /* the twin: ONE batch on the first device, no exchange path */
   sipnet_batch *b = NULL;
   rc = sipnet_batch_create(flags, 1, N, SIPNET_F32_MIXED, devices[0], &b);
+  if (!rc && oneWave) rc = sipnet_batch_set_kernel(b, SIPNET_KERNEL_ONE_WAVE, 0);
+  if (!rc && oneWave) rc = sipnet_node_set_kernel(nd, SIPNET_KERNEL_ONE_WAVE, 0);
   if (!rc) rc = sipnet_batch_set_climate(b, 0, T, sipnet_clim_data(clim), sipnet_clim_year(clim), sipnet_clim_day(clim));
   if (!rc) rc = sipnet_batch_set_params(b, 0, 0, N, members);
   if (!rc) rc = sipnet_node_set_climate(nd, 0, T, sipnet_clim_data(clim), sipnet_clim_year(clim), sipnet_clim_day(clim));
@@ -137,6 +143,32 @@ int main(int argc, char **argv) {
   }
   if (rc) { printf("get_state=%d %s\n", rc, sipnet_last_error()); return 1; }
   printf("state_identical=%d\n", memcmp(sNode, sTwin, sizeof(double) * (size_t)N * SIPNET_NSTATE) == 0);
+  {
+    double worst = 0.0;   /* (pools only: the first 13 words of a particle's state) */
+    for (int32_t m = 0; m < N; m++)
+      for (int q = 0; q < 13; q++) {
+        const double u = sNode[(size_t)m * SIPNET_NSTATE + q], v = sTwin[(size_t)m * SIPNET_NSTATE + q];
+        double d = u - v, sc = (u < 0 ? -u : u) + (v < 0 ? -v : v) + 1e-30;
+        if (d < 0) d = -d;
+        if (d / sc > worst) worst = d / sc;
+      }
+    printf("state_max_rel_diff=%.3e\nkernel_twin=%s\n", worst, sipnet_batch_last_kernel_name(b));
+  }
+  {
+    sipnet_pf_info info;   /* what the exchange says about itself */
+    int64_t crossing = 0, cyclesSeen = 0;
+    int32_t byIndex = 0, fused = 0, grid = 0;
+    for (int32_t k = 0; k < nDev; k++)
+      if (sipnet_batch_pf_info(sipnet_node_batch(nd, k), &info, sipnet_node_stream(nd, k)) == 0) {
+        crossing += info.crossing;
+        cyclesSeen = info.cycles;
+        byIndex = info.params_by_index;
+        fused = info.fused;
+        grid = info.grid;
+      }
+    printf("crossing_per_cycle=%.1f\nparams_by_index=%d\nanalysis_one_launch=%d\nanalysis_grid=%d\n",
+           cyclesSeen ? (double)crossing / (double)cyclesSeen : 0.0, (int)byIndex, (int)fused, (int)grid);
+  }
   int64_t distinct = 0;
   for (int32_t m = 1; m < N; m++) distinct += sNode[(size_t)m * SIPNET_NSTATE] != sNode[(size_t)(m - 1) * SIPNET_NSTATE];
   printf("distinct_neighbours=%lld\n", (long long)distinct);

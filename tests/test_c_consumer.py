@@ -104,12 +104,12 @@ def test_node_of_one_device_all_gathers_through_rccl_from_c(oracle, tmp_path):
 PF_SRC = os.path.join(helpers.REPO, "tests", "c", "pf_consumer.c")
 
 
-def run_pf(exe, tmp_path, n, devices, cycles=5, n_steps=48):
+def run_pf(exe, tmp_path, n, devices, cycles=5, n_steps=48, one_wave=0):
     from sipnet_amd import synth
     clim = str(tmp_path / "day.clim")
     synth.write_clim(clim, synth.round_like_file(synth.half_hourly_year_raw(n_steps)))
     r = subprocess.run([exe, os.path.join(helpers.REPO, "sipnet_amd", "data", "base_forest.param"), clim, str(n), devices,
-                        str(cycles), str(n_steps)], capture_output=True, text=True, timeout=600)
+                        str(cycles), str(n_steps), str(one_wave)], capture_output=True, text=True, timeout=600)
     kv = dict(l.split("=", 1) for l in r.stdout.strip().split("\n") if "=" in l)
     return r.returncode, kv, r.stdout + r.stderr
 
@@ -130,6 +130,20 @@ def test_filter_cycles_through_the_node_object_from_c(tmp_path, devices):
     rc, kv, out = run_pf(build(tmp_path, PF_SRC), tmp_path, 16384, devices, cycles=8)
     assert rc == 0 and kv["create"] == "0", out
     assert kv["collective_library"].startswith("librccl" if devices == "0" else "event-ordered")
-    assert kv["state_identical"] == "1", out
+    assert kv["state_identical"] == "1" and float(kv["state_max_rel_diff"]) == 0.0, out
+    assert kv["kernel"] == kv["kernel_twin"], out         # (these shapes take the same kernel; see pf_consumer.c's header)
+    assert kv["params_by_index"] == "1" and kv["analysis_one_launch"] == "1"
+    if devices == "0,0":
+        assert float(kv["crossing_per_cycle"]) > 0, out  # particles crossed between the shards
     assert int(kv["distinct_neighbours"]) > 100          # the filter kept many distinct particles
     assert float(kv["ms_per_cycle_node"]) > 0 and float(kv["ms_per_cycle_plain"]) > 0
+
+
+@pytest.mark.gpu
+def test_filter_consumer_shards_and_twin_on_one_kernel_are_bit_identical(tmp_path):
+    """two shards of 32 768 particles and the twin's 65 536 would take different kernels by shape (equal to rounding, not to
+    bits); with the seventh argument both run the one-wave kernel: identical states"""
+    rc, kv, out = run_pf(build(tmp_path, PF_SRC), tmp_path, 65536, "0,0", cycles=4, one_wave=1)
+    assert rc == 0 and kv["create"] == "0", out
+    assert kv["kernel"].startswith("stepFastKernel") and kv["kernel"] == kv["kernel_twin"], out
+    assert kv["state_identical"] == "1" and float(kv["state_max_rel_diff"]) == 0.0, out

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""dev: the device-side timeline of the LAST forcing of tools/gpu_r5_o.sh's trace (rocprofv3 --kernel-trace --memory-copy-trace of
+"""dev: the device-side timeline of the LAST forcing of a (rocprofv3 --kernel-trace --memory-copy-trace of
 tools/e2e_breakdown.py): copies and kernels with start / end in microseconds from the first copy of the hand-over.
 usage: e2e_timeline.py [gpurun_out/r5o]"""
 import csv, sys

@@ -1,9 +1,9 @@
 #!/bin/bash
-# round 5 fuzz campaigns on the final binary: the new instantiations first (FUZZ_R5: optional physics at four chunks per
+# the fuzz campaigns on the final binary (round 5 on): the new instantiations first (FUZZ_R5: optional physics at four chunks per
 # workgroup in fp32-mixed batches, records + diagnostics counters from the optional-physics and nitrogen-cycle kernels),
 # then round 4's campaigns again (every fp32-mixed trial now runs on narrow record fields)
 cd "$(dirname "$0")/.." || exit 1
-O=${FUZZ_OUT:-gpurun_out/r5fz}; mkdir -p $O
+O=${FUZZ_OUT:-gpurun_out/fuzz}; mkdir -p $O
 run() { name=$1; shift; env "$@" timeout 1500 python tools/fuzz_gpu.py $N $SEED > $O/$name.log 2>&1; echo "rc=$?" >> $O/$name.log; echo "== $name: $(grep -c '^trial' $O/$name.log) trials, $(tail -1 $O/$name.log)"; grep -i 'mismatch\|error\|assert' $O/$name.log | head -3; }
 N=${1:-2000} SEED=100501 run r5_opt FUZZ_R5=1 FUZZ_OPT=1
 N=${2:-1200} SEED=100502 run r5_ncyc FUZZ_R5=1 FUZZ_NCYC=1

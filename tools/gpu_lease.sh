@@ -11,6 +11,12 @@
 #                  under rocprofv3 --kernel-trace --stats
 #   profile:<wl>   rocprofv3 --kernel-trace --stats of `bench.py --workload <wl>` -> <wl>_kernel_stats.csv
 #   smoke          __graft_entry__.smoke()
+#   node_gather    tools/node_gather_time.py at c10k's shape: plain run, planes gathered afterwards / overlapped, daily sums, fp32
+#   pf_consumer    tests/c/pf_consumer.c at c5's shape (131 072 particles x 48 steps, 300 cycles): devices 0 and 0,0
+#   evidence:<tag> the round's evidence on the current binary: rocprofv3 --kernel-trace --stats + separate --pmc passes of every
+#                  workload (tools/gpu_profile_all.sh <tag>), then bench_all force_dist pf node_gather pf_consumer, instruction
+#                  mixes of c3 / c4 / c5's kernels, the whole-job breakdown; distil on the CPU side with tools/collect_evidence.sh
+#   fuzz           tools/gpu_fuzz.sh (the differential campaigns)
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 TAG=$1; shift
@@ -68,6 +74,28 @@ PY
       timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$wl -- python3 bench.py --workload $wl --steps $steps --warmup $warm --no-cpu-baseline --no-fill-probe --no-end-to-end > $O/profile_$wl.log 2>&1
       cp $(find /tmp/prof_$wl -name "*kernel_stats.csv" | head -1) $O/${wl}_kernel_stats.csv 2>/dev/null
       head -6 $O/${wl}_kernel_stats.csv | cut -c1-200 ;;
+    node_gather)
+      for d in 0 0,0; do timeout 600 python3 tools/node_gather_time.py 10240 1 $d 2>&1 | grep -v amdgpu.ids > $O/node_gather_time_$d.txt; cat $O/node_gather_time_$d.txt; done ;;
+    pf_consumer)
+      gcc -std=c99 -O1 -Iinclude tests/c/pf_consumer.c -o /tmp/pf_consumer -Lsipnet_amd -lsipnet_amd -Wl,-rpath,$PWD/sipnet_amd
+      python3 -c "import sys; sys.path.insert(0, '.'); from sipnet_amd import synth; synth.write_clim('/tmp/day.clim', synth.round_like_file(synth.half_hourly_year_raw(48)))"
+      for dev in 0 0,0; do
+        for ow in 0 1; do
+          timeout 300 /tmp/pf_consumer sipnet_amd/data/base_forest.param /tmp/day.clim 131072 $dev 300 48 $ow > $O/pf_consumer_${dev}_onewave$ow.log 2>&1
+          echo "rc=$?" >> $O/pf_consumer_${dev}_onewave$ow.log
+        done
+      done
+      grep -h "ms_per_cycle\|state_identical\|kernel" $O/pf_consumer_*.log ;;
+    evidence:*)
+      export GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$PWD}
+      tag=${R#evidence:}
+      bash tools/gpu_profile_all.sh $tag c10k c2 c2x16 c3 c4 c5 c10kn c4n c10kr3 > $O/profile_all.log 2>&1
+      "$0" $TAG bench_all force_dist pf node_gather pf_consumer
+      for wl in c3 c5 c4; do bash tools/gpu_pmc_branch.sh $wl > /dev/null 2>&1; cp gpurun_out/pmc_branch_$wl.txt $O/; done
+      for wl in c4 c2x16 c10k; do for who in dev host; do timeout 600 python3 tools/e2e_breakdown.py $wl $who 2>&1 | grep -v amdgpu > $O/e2e_${wl}_$who.txt; done; done
+      timeout 900 python3 bench.py > $O/bench_default.log 2>&1; grep '^{' $O/bench_default.log | tail -1 > $O/bench_default.json ;;
+    fuzz)
+      FUZZ_OUT=$O/fuzz bash tools/gpu_fuzz.sh ${FUZZ_ARGS:-600 400 300 600 150} ;;
     *) echo "unknown recipe $R" ;;
   esac
 done

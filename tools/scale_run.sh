@@ -1,37 +1,55 @@
 #!/bin/bash
-# The first run on a node with more than one GPU, as ONE command: the bench line of c10k, c4 and c5 at N = 1, 2, 4, 8
-# through torch.distributed.run (one process per GPU over RCCL: what the driver's SCALE run does), and the same three
-# shapes through the C host (sipnet_node_*: one process, one thread + one RCCL rank per GPU, the all-gather issued from C;
-# tests/c/node_consumer.c, tests/c/pf_consumer.c).  Everything lands under gpurun_out/scale/ (copy what is to be
-# judged into profiles/).  usage: tools/scale_run.sh [max_gpus]   (default: every visible GPU, at most 8)
+# The first run on a node with more than one GPU, as ONE command.  Everything lands under gpurun_out/scale/ and the final
+# table in profiles/scale_table.md (+ scale_lines.jsonl): copy nothing by hand.
+#   usage: tools/scale_run.sh [max_gpus]   (default: every visible GPU, at most 8)
+# What it runs, in this order (each leg under its own timeout; a leg that fails is reported in the table, the rest go on):
+#   1. the two-real-GPU tests that one-GPU boxes skip (member and site shards, overlapped gathers, peer-read filter cycles)
+#   2. `python3 bench.py --gpus N` for N = 1, 2, 4, 8 -- bench.py starts its own ranks (torch.distributed.run as a child;
+#      what the driver's SCALE run does) -- for c10k, c4, c5: the contract's lines (statistics exchange / peer-read filter)
+#   3. the north star's exchange as written: `--gather full` (the member-resolved planes, one all-gather after the pass)
+#      and its segmented-overlap measurement (config.gather_full of the default line) at N = max
+#   4. c5 with `--pf-exchange alltoall` at N = max (the fallback for ranks that cannot map each other's HBM)
+#   5. the C host (sipnet_node_*: one process, one thread + one RCCL rank per GPU): node_consumer (statistics + planes +
+#      the reduced member-resolved gather), pf_consumer (config 5's cycle), at N = 1, 2, 4, 8 with per-GPU work fixed
+#   6. the CLI: `sipnet --sites LIST --devices 0-(N-1)` over 8 x N run directories (whole sites per device)
 cd "$(dirname "$0")/.." || exit 1
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 HAVE=$(python3 -c 'import torch; print(torch.cuda.device_count())')
 MAX=${1:-$HAVE}; [ "$MAX" -gt 8 ] && MAX=8
-O=gpurun_out/scale; mkdir -p $O
-echo "visible GPUs: $HAVE, running up to $MAX" | tee $O/README.txt
-# 1. the two-real-GPU tests that one-GPU boxes skip (member and site shards, the overlapped gather, peer-read filter cycles)
+O=gpurun_out/scale; mkdir -p $O profiles
+: > $O/scale_lines.jsonl
+echo "visible GPUs: $HAVE, running up to $MAX ($(date -u +%FT%TZ))" | tee $O/README.txt
+NS=""; for n in 1 2 4 8; do [ "$n" -le "$MAX" ] && NS="$NS $n"; done
+
+# 1. tests that need two real GPUs
 if [ "$HAVE" -ge 2 ]; then
   timeout 1800 python3 -m pytest tests/test_gpu_node.py tests/test_gpu_multirank.py -q -m gpu -k "two_real or real_devices" > $O/pytest_two_gpus.txt 2>&1
-  tail -3 $O/pytest_two_gpus.txt
+  grep -E "passed|failed|error" $O/pytest_two_gpus.txt | tail -1 | tee -a $O/README.txt
 fi
-# 2. one process per GPU (torch.distributed.run, RCCL): the bench contract's lines
-PORT=29551
+
+# 2. the bench contract's lines (bench.py launches its own ranks)
+line() {   # line <tag> <bench args...>: one bench run, its JSON line tagged and appended
+  local tag=$1; shift
+  timeout 1500 python3 bench.py "$@" > $O/bench_$tag.log 2>&1
+  local rc=$?
+  local j=$(grep '^{' $O/bench_$tag.log | tail -1)
+  if [ -n "$j" ]; then echo "$j" | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); d['leg']='$tag'; d['rc']=$rc; print(json.dumps(d))" >> $O/scale_lines.jsonl
+  else echo "{\"leg\": \"$tag\", \"rc\": $rc, \"failed\": true}" >> $O/scale_lines.jsonl; fi
+  echo "$tag rc=$rc"
+}
 for wl in c10k c4 c5; do
-  for n in 1 2 4 8; do
-    [ "$n" -gt "$MAX" ] && continue
-    if [ "$n" -eq 1 ]; then
-      timeout 1200 python3 bench.py --workload $wl --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_${wl}_n1.log 2>&1
-    else
-      PORT=$((PORT + 1))
-      timeout 1200 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $PORT \
-          bench.py --workload $wl --gpus $n --steps 20 --warmup 3 > $O/bench_${wl}_n$n.log 2>&1
-    fi
-    grep '^{' $O/bench_${wl}_n$n.log | tail -1 >> $O/scale_lines.jsonl
-    grep '^{' $O/bench_${wl}_n$n.log | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('$wl', 'N=%d' % d['n_gpus'], 'value %.4g' % d['value'], 'ms/step %.3f' % d['ms_per_step'])"
+  steps=20; warm=3; [ "$wl" = c5 ] && steps=400 && warm=40
+  for n in $NS; do
+    extra=""; [ "$n" -eq 1 ] && extra="--no-cpu-baseline"
+    line ${wl}_n$n --workload $wl --gpus $n --steps $steps --warmup $warm $extra
   done
 done
-# 3. the C host: one process, one shard per GPU (sipnet_node_*), statistics all-gather and overlapped plane gather from C
+# 3. the member-resolved planes, gathered after the pass (the default line's config.gather_full is the overlapped variant)
+[ "$MAX" -ge 2 ] && for wl in c10k c4; do line ${wl}_full_n$MAX --workload $wl --gpus $MAX --steps 10 --warmup 2 --gather full; done
+# 4. the filter's all-to-all fallback
+[ "$MAX" -ge 2 ] && line c5_alltoall_n$MAX --workload c5 --gpus $MAX --steps 400 --warmup 40 --pf-exchange alltoall
+
+# 5. the C host
 gcc -std=c99 -O1 -Iinclude tests/c/node_consumer.c -o /tmp/node_consumer -Lsipnet_amd -lsipnet_amd -Wl,-rpath,$PWD/sipnet_amd
 gcc -std=c99 -O1 -Iinclude tests/c/pf_consumer.c -o /tmp/pf_consumer -Lsipnet_amd -lsipnet_amd -Wl,-rpath,$PWD/sipnet_amd
 python3 - <<'PY'
@@ -41,14 +59,47 @@ from sipnet_amd import synth
 synth.write_clim("/tmp/year.clim", synth.round_like_file(synth.half_hourly_year_raw(17520)))
 synth.write_clim("/tmp/day.clim", synth.round_like_file(synth.half_hourly_year_raw(48)))
 PY
-for n in 1 2 4 8; do
-  [ "$n" -gt "$MAX" ] && continue
+for n in $NS; do
   devs=$(seq -s, 0 $((n - 1)))
   # weak scaling: 10 240 members / 131 072 particles PER GPU
   timeout 900 /tmp/node_consumer sipnet_amd/data/base_forest.param /tmp/year.clim $((10240 * n)) $devs > $O/node_consumer_n$n.log 2>&1
   echo "rc=$?" >> $O/node_consumer_n$n.log
   timeout 900 /tmp/pf_consumer sipnet_amd/data/base_forest.param /tmp/day.clim $((131072 * n)) $devs 300 48 > $O/pf_consumer_n$n.log 2>&1
   echo "rc=$?" >> $O/pf_consumer_n$n.log
-  grep -h 'ms\|rc=' $O/node_consumer_n$n.log $O/pf_consumer_n$n.log | head -12
+  timeout 900 python3 tools/node_gather_time.py 10240 1 $devs > $O/node_gather_time_n$n.txt 2>&1     # plain / overlapped planes / daily sums / fp32
 done
+
+# 6. the CLI over run directories, whole sites per device
+python3 tools/cli_sites_time.py --sites $((8 * MAX)) --devices 0-$((MAX - 1)) > $O/cli_sites_n$MAX.txt 2>&1 || echo "cli leg rc=$?" >> $O/cli_sites_n$MAX.txt
+
+# the table
+python3 - "$O" <<'PY'
+import json, os, sys
+O = sys.argv[1]
+rows = [json.loads(l) for l in open(os.path.join(O, "scale_lines.jsonl"))]
+base = {}
+out = ["| leg | N | value (%s) | ms / pass | efficiency vs N = 1 | ranks_seen | devices_seen | rc |" % "ensemble-site-timesteps/s", "|---|---|---|---|---|---|---|---|"]
+for d in rows:
+    if d.get("failed"):
+        out.append("| %s | | FAILED | | | | | %s |" % (d["leg"], d["rc"]))
+        continue
+    wl = d["leg"].split("_")[0]
+    n = d["n_gpus"]
+    if d["leg"] == "%s_n1" % wl:
+        base[wl] = d["value"]
+    eff = d["value"] / (n * base[wl]) if wl in base else float("nan")
+    c = d["config"]
+    out.append("| %s | %d | %.4g | %.4f | %.3f | %s | %s | %s |" % (d["leg"], n, d["value"], d["ms_per_step"], eff, c.get("ranks_seen"),
+                                                                 c.get("devices_seen"), d["rc"]))
+for n in (1, 2, 4, 8):
+    for f in ("node_consumer", "pf_consumer"):
+        p = os.path.join(O, "%s_n%d.log" % (f, n))
+        if os.path.exists(p):
+            kv = dict(l.strip().split("=", 1) for l in open(p) if "=" in l)
+            keys = [k for k in kv if k.startswith("ms_") or k in ("rc", "state_identical", "reduced_sums_equal_planes", "collective_library")]
+            out.append("| C host: %s | %d | %s |" % (f, n, ", ".join("%s=%s" % (k, kv[k]) for k in keys)))
+open("profiles/scale_table.md", "w").write("\n".join(out) + "\n")
+open("profiles/scale_lines.jsonl", "w").write(open(os.path.join(O, "scale_lines.jsonl")).read())
+print("\n".join(out))
+PY
 ls $O
