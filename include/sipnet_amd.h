@@ -247,7 +247,29 @@ int sipnet_batch_set_math(sipnet_batch *b, int32_t policy);
  * the oracle this way); a forced kernel that cannot run the batch (a throughput kernel under SIPNET_MATH_STRICT,
  * the four-chunk layout with optional physics or full state, a nitrogen-cycle kernel without the nitrogen cycle or
  * the other way round) makes sipnet_batch_run return SIPNET_ERR_BAD_ARGUMENT.  Nothing in the launch path reads the
- * environment. */
+ * environment.
+ * What AUTO hands to the one-wavefront kernel although a cooperative layout exists for a neighbouring shape, why, and what
+ * it costs (MI355X; profiles/r05_flag_sets.md, r05_bench_all.jsonl, tools/big_batch_time.py):
+ *   shape (SIPNET_MATH_FAST)                                   why no cooperative kernel                          cost
+ *   > 4 chunks per CU, any flag set                            the one-wave kernel IS the faster one there        none (131 072 fp32 members x 1 year:
+ *                                                              (two waves per SIMD hide each other's latencies)   19.3 ms against 20.0 four-chunk cooperative)
+ *   2 < chunks per CU <= 4, optional physics, fp64             the four-chunk build needs 198 VGPRs of the        x 2.0 - 2.2 (c3's shape: 21 - 23 ms against
+ *                                                              layout's 168 (three waves per SIMD): it would      10.2 - 10.7 ms of the fp32-mixed build, which
+ *                                                              spill in the carbon wave's loop                    exists: use SIPNET_F32_MIXED there)
+ *   > 2 chunks per CU, nitrogen cycle (any precision)          a chunk's soil-wave mailboxes + four private       x 2.2 (c3's shape, fp32-mixed: 21.0 ms against
+ *                                                              record tiles are ~60 KB of LDS: four chunks do     9.6 ms for the default physics)
+ *                                                              not fit a CU's 160 KB
+ *   1 < chunks per CU <= 2, nitrogen cycle + the diagnostics   the plant side's mass totals travel to the soil    x 1.7 (c4's shape: 26.7 ms against 15.3 ms for the
+ *   counters (sipnet_batch_enable_diagnostics)                 wave in eleven more mailbox rows per slot:         lean two-chunk launch; the record and
+ *                                                              146.5 + 22 KB > 160 KB (fp64); in an fp32-mixed    SIPNET_KOPT_FULL_STATE alone stay cooperative)
+ *                                                              batch they would fit, but its balance residuals
+ *                                                              are fp32 rounding (1e-3 gC against the check's
+ *                                                              1e-8): every step would count
+ *   > 2 chunks per CU, records / SIPNET_KOPT_FULL_STATE /      no full-state build of the four-chunk layout:      x 1.5 (c10k's members x 4, with the record:
+ *   diagnostics                                                the record columns and accumulators spill under    one-wave Full build; the record's 44 stores
+ *                                                              its register budget (fp64 284 B, fp32 136 B per    per member-step dominate either way)
+ *                                                              lane)
+ * sipnet_kernel_choice answers for any shape without a device; sipnet_batch_last_launch names what a launch took. */
 enum sipnet_kernel {
   SIPNET_KERNEL_AUTO = 0,
   SIPNET_KERNEL_ONE_WAVE = 1, /* stepFastKernel: one wavefront per 64 members */
