@@ -288,17 +288,16 @@ def pf_analysis_peers(batch, plane, obs, sigma, u0, rank=0, world=1, group=None,
     mine = gathered[rank]
     batch.pf_local_weights(plane, obs, sigma, mine)
     if pretend:
-        # the one real rank's all-gather (in place, its own slice), then its block into the other ranks' slices -- ONE device
-        # kernel over (P - 1) blocks stands where the links' time would be -- each shifted by a constant of its own (maxima
-        # included; -inf stays -inf), so that the pretended ranks differ in total weight and particles do cross between them
+        # the one real rank's all-gather (in place, its own slice), then its block into the other ranks' slices: ONE device
+        # copy of (P - 1) blocks stands where the links' time would be.  The blocks are identical, so every pretended rank
+        # keeps exactly its own slots (no particle "crosses") and the ensemble evolves as the one-rank filter's does -- the
+        # cycle is timed like for like against the plain one.  (Blocks shifted against each other make particles cross --
+        # tools/pf_peers_time.py, tests/test_gpu_node.py do that -- but a filter fed rotated copies of itself selects another
+        # ensemble: its forecasts ran up to 30 % longer from the phenology of the survivors alone, which says nothing about
+        # the exchange.)
         if collectives:
             dist.all_gather_into_tensor(mine, mine, group=group)
-        shifts = getattr(batch, "_pf_pretend_shifts", None)
-        if shifts is None or shifts.shape[0] != rank:
-            # (the other ranks a little heavier than this, the last, one: its particles' weight interval then reaches into
-            # its neighbour's slots)
-            shifts = batch._pf_pretend_shifts = (0.15 * (torch.arange(rank, dtype=torch.float64, device=batch.device) + 1) / rank)[:, None]
-        torch.add(mine.expand(rank, L), shifts, out=gathered[:rank])
+        gathered[:rank].copy_(mine.expand(rank, L))
     elif collectives:
         if _host_staged(mine, group):
             out = torch.empty((world, L), dtype=torch.float64)

@@ -9,7 +9,7 @@ cp $E/bench_default.json profiles/${T}_bench_default.json
 python3 - "$E" "$T" <<'PY'
 import json, sys
 E, T = sys.argv[1:3]
-rows = [json.loads(l) for l in open('gpurun_out/%s/force_dist.jsonl' % E) if l.strip().startswith('{')]
+rows = [json.loads(l) for l in open('%s/force_dist.jsonl' % E) if l.strip().startswith('{')]
 json.dump(rows, open('profiles/%s_force_dist.json' % T, 'w'), indent=1)
 print(len(rows), 'force-dist lines')
 PY
