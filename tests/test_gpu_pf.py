@@ -457,3 +457,54 @@ def test_a_grid_that_is_not_co_resident_ends_with_an_error_not_a_hang(base, clim
         if k in (0, 33, 69):
             assert torch.equal(anc, anc_ref) and int(total.item()) == int(fixed.sum().item())
     b.close()
+
+
+def test_random_weights_sizes_and_geometries_against_the_oracle(base, clim):
+    """the one-launch analysis over crafted log-weights (a block handed to sipnet_batch_pf_resample_peers of an unconnected
+    batch: world = 1) for random particle counts, weight patterns (uniform, mild, a handful of heavy particles, one survivor,
+    runs of -inf, a +-30 spread), u0 and pretended device sizes: the ancestors are the multi-launch path's and the numpy
+    oracle's for the device's integer weights; the total weight their sum"""
+    rng = np.random.default_rng(20261003)
+    tried = set()
+    for trial in range(28):
+        n = int(rng.choice([1, 2, 63, 64, 65, 255, 256, 257, 1000, 4096, 10007, 65536, 150001]))
+        kind = str(rng.choice(["uniform", "mild", "degenerate", "one", "holes", "spread"]))
+        if n < 8 and kind in ("degenerate", "one", "holes"):
+            kind = "mild"
+        if kind in ("holes", "spread"):
+            lw = -0.5 * rng.normal(size=n) ** 2 * (30.0 if kind == "spread" else 1.0)
+            if kind == "holes":
+                for _ in range(int(rng.integers(1, 6))):
+                    a = int(rng.integers(0, n))
+                    lw[a:a + int(rng.integers(1, max(2, n // 3)))] = -np.inf
+                lw[int(rng.integers(0, n))] = -0.1            # (somebody survives)
+        else:
+            lw = weights_case(n, kind, seed=int(rng.integers(1 << 30)))
+        u0 = float(rng.choice([0.0, 0.999999999, rng.random()]))
+        cus = int(rng.choice([1, 2, 8, 32, 256]))
+        share = int(rng.choice([1, 1, 3, 6]))
+        b = sa.Batch(sa.flags_from(), 1, n, sa.F64, fast_math=True)
+        b.set_climate(0, clim)
+        b.set_params(0, np.tile(base, (n, 1)))
+        b.setup()
+        b.debug_set_num_cus(cus)
+        b.set_device_share(share)
+        L = b.pf_block_len()
+        block = torch.full((1, L), -np.inf, dtype=torch.float64, device=DEV)
+        block[0, :n] = torch.from_numpy(lw).to(DEV)
+        P = L - n
+        pad = torch.full((P * 256,), -np.inf, dtype=torch.float64, device=DEV)
+        pad[:n] = block[0, :n]
+        block[0, n:] = pad.view(P, 256).max(dim=1).values
+        total = torch.zeros(1, dtype=torch.int64, device=DEV)
+        anc = b.pf_resample_peers(block, u0, total_out=total).cpu().numpy()
+        info = b.pf_info()
+        b.close()
+        ref, fixed = sd.pf_systematic_ancestors(block[0, :n].contiguous(), u0, return_fixed=True)
+        fixed = fixed.cpu().numpy()
+        assert np.abs(fixed - po.fixed_weights(lw)).max() <= 1, (trial, n, kind)
+        np.testing.assert_array_equal(anc, ref.cpu().numpy(), err_msg=str((trial, n, kind, u0, cus, share, info)))
+        np.testing.assert_array_equal(anc, po.systematic_ancestors(fixed, u0), err_msg=str((trial, n, kind, u0, cus, share, info)))
+        assert int(total.item()) == int(fixed.sum()) > 0
+        tried.add((info["fused"], kind))
+    assert {f for f, _ in tried} == {0, 1} and len({k for _, k in tried}) >= 5, tried

@@ -102,4 +102,5 @@ open("profiles/scale_table.md", "w").write("\n".join(out) + "\n")
 open("profiles/scale_lines.jsonl", "w").write(open(os.path.join(O, "scale_lines.jsonl")).read())
 print("\n".join(out))
 PY
+cp profiles/scale_table.md $O/ 2>/dev/null
 ls $O
