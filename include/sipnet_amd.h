@@ -739,7 +739,11 @@ void *sipnet_node_gathered_segment(sipnet_node *nd, int32_t k, int32_t segment, 
  * if a cycle since the last check ended with every particle at zero weight (its resampling then copied
  * particle 0 everywhere), SIPNET_ERR_INTERNAL if the shards disagree.  sipnet_node_pf_ancestors(nd, k):
  * DEVICE k, the slots (shard * nmax + particle, nmax = the largest shard) its particles were copied from in
- * the last cycle. */
+ * the last cycle.  with_params: pf_connect also copies every shard's converted parameters onto every shard once (a
+ * particle that crosses shards then brings a 4-byte column number: sipnet_batch_pf_connect; SIPNET_KOPT_PF_MOVE_PARAMS
+ * through sipnet_node_set_kernel keeps the rows travelling).  Shards that share a device analyse at the same time: the
+ * node tells each batch its share of the device's resident workgroups (sipnet_batch_set_device_share), and a cycle whose
+ * analysis kernel nevertheless gave up at its barrier makes sipnet_node_pf_check answer SIPNET_ERR_INTERNAL. */
 int sipnet_node_pf_connect(sipnet_node *nd, int32_t with_params);
 int sipnet_node_pf_analysis(sipnet_node *nd, int32_t variable, double obs, double sigma, double u0);
 int sipnet_node_pf_check(sipnet_node *nd, int32_t *n_cycles_checked);

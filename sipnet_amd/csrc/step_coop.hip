@@ -525,7 +525,7 @@ __device__ __forceinline__ void accum(double& pool, float x, float len) { pool +
 // the code phase of an instantiation: s_nop count after the 32-byte boundary in coopBody's prologue (see there)
 // (role: 0 carbon, 1 water, 2 light, 3 factor / soil wave -- each wave's code starts at a boundary of its own --
 // 4 the common prologue)
-template <class R, bool PlainExp, bool RingLds, bool Full, int NP, bool NCyc, bool Ext>
+template <class R, bool PlainExp, bool RingLds, bool Full, int NP, bool NCyc, bool Ext, bool Sums = false>
 __device__ constexpr int coopCodePhase(int role) {
 #ifdef SIPNET_PH_C
   if (role == 0) return SIPNET_PH_C;
@@ -539,6 +539,10 @@ __device__ constexpr int coopCodePhase(int role) {
 #ifdef SIPNET_PH_F
   if (role == 3) return SIPNET_PH_F;
 #endif
+  // (the in-kernel sums build of the one-chunk LDS-ring layout, swept in round 6 at c10k's shape, tools/sums_time.py,
+  // profiles/r06_sums_phase_sweep.txt: carbon 8.65 ... 8.46 ms at phase 3, then water 8.52 ... 8.40 at phase 3; its
+  // relatives take their plain family's values)
+  if (Sums && NP == 1 && RingLds && (role == 0 || role == 1)) return 3;
   if (role == 0) {   // the carbon wave (profiles/r04_phase_sweep_roles.txt)
     if (NCyc) return 0;
     if (Ext) return 7;
@@ -676,7 +680,7 @@ __device__ __forceinline__ void coopBody(const FastArgs& a) {
 // behind it starts where the sweeps measured it -- a compiler bump that moves a loop head fails a CPU test instead of
 // silently costing up to 2.7 %)
 #define COOP_CODE_PHASE(ROLE) \
-  asm volatile("s_nop %1\n .p2align 5\n .rept %0\n s_nop 0\n .endr" ::"n"(coopCodePhase<R, PlainExp, RingLds, Full, NP, NCyc, Ext>(ROLE)), "n"(8 + (ROLE)))
+  asm volatile("s_nop %1\n .p2align 5\n .rept %0\n s_nop 0\n .endr" ::"n"(coopCodePhase<R, PlainExp, RingLds, Full, NP, NCyc, Ext, Sums>(ROLE)), "n"(8 + (ROLE)))
   COOP_CODE_PHASE(4);
   if (role == 0) {
     if (lane == 0) {

@@ -27,6 +27,8 @@ pytestmark = pytest.mark.skipif(not os.path.exists(os.path.join(LLVM, "llvm-objd
 def expected_phase(kernel, R, plain_exp, ring_lds, full, NP, ncyc, ext, role):
     """the table of step_coop.hip's coopCodePhase as measured (profiles/r04_phase_sweep.txt, _roles.txt), restated"""
     f64 = R == "double"
+    if kernel == "stepCoopSumsKernel" and ring_lds and role in (0, 1):
+        return 3          # round 6: profiles/r06_sums_phase_sweep.txt
     if role == 0:
         return 0 if ncyc else 7 if ext else 2 if NP == 2 else (4 if full else 6) if (NP == 1 and ring_lds) else 0
     if role == 1:

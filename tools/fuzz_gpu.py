@@ -211,7 +211,41 @@ for trial in range(trials):
         rec_g = torch.cat([r_[1] for r_ in runs_g], dim=0).cpu().numpy()
         diag_g = b.get_diagnostics()
     b_kernel = b.last_launch()["kernel"]
-    status = np.asarray(b.get_status()); state = b.get_state(); b.close()
+    status = np.asarray(b.get_status()); state = b.get_state()
+    sums_ok = bool(os.environ.get("FUZZ_SUMS")) and not want_full and b.sums_in_kernel()
+    b.close()
+    if sums_ok:
+        # round 6 (FUZZ_SUMS=1; a generator of its own): the same trial through sipnet_batch_run_sums -- every member's sums over
+        # groups of k steps out of the step kernel's launch, launches cut at random multiples of k -- against the planes just
+        # computed, added up on the host in step order: bit for bit for every member that runs
+        rs = np.random.default_rng(1000003 * int(trial) + 17)
+        k = int(rs.choice([1, 2, 7, 16, 48, 100]))
+        G = (T + k - 1) // k
+        scuts = sorted(set([0, T] + [int(x) * k for x in rs.integers(1, max(G, 2), size=int(rs.integers(0, 3))) if int(x) * k < T]))
+        bs = sa.Batch(flags, S, M, prec, fast_math=fast, kernel=kern, kernel_options=kopt & ~sa.KOPT_BOUNDED_WAITS)
+        for sidx in range(S):
+            if ev is not None: bs.set_events(sidx, ev)
+            bs.set_climate(sidx, clims[sidx]); bs.set_params(sidx, members)
+        bs.setup()
+        parts = [bs.run_sums(a0, a1 - a0, k).cpu().numpy() for a0, a1 in zip(scuts[:-1], scuts[1:])]
+        ks = bs.last_launch()["kernel"]
+        st_s = bs.get_state(); bs.close()
+        got_s = np.concatenate(parts, axis=1)
+        planes_raw = torch.cat([r_[0] for r_ in runs_g], dim=1).double().cpu().numpy()
+        want_s = np.zeros_like(got_s)
+        for t_ in range(T):
+            want_s[:, t_ // k] += np.where(valid[t_][None], planes_raw[:, t_], 0.0)
+        okc = (np.asarray(status) == 0)
+        # (groups a shorter site's launch does not reach are not written: compare the groups that hold a valid step)
+        gvalid = np.zeros((G, valid.shape[1]), dtype=bool)
+        for t_ in range(T):
+            gvalid[t_ // k] |= valid[t_]
+        sel = gvalid[None] & okc[None, None, :]
+        if not np.array_equal(np.where(sel, got_s, 0.0), np.where(sel, want_s, 0.0)):
+            d_ = np.abs(np.where(sel, got_s - want_s, 0.0)); i_ = np.unravel_index(d_.argmax(), d_.shape)
+            raise AssertionError(f"MISMATCH (sums) trial {trial}: k {k} cuts {scuts} kernel {ks}: {d_.max():.3e} at plane/group/column {i_}")
+        assert np.array_equal(st_s[okc], state[okc]), f"MISMATCH (state after sums) trial {trial}"
+        forced += f" sums(k={k},{len(scuts) - 1} launches,{ks.split('<')[0]})"
     if only >= 0 and os.environ.get("FUZZ_STOP"):    # pools of one member after N steps, this kernel vs the one-wave kernel
         nstop, mdbg = int(os.environ["FUZZ_STOP"]), int(os.environ.get("FUZZ_MEMBER", "0"))
         for kk, nm in ((kern, "forced"), (sa.KERNEL_ONE_WAVE, "one-wave")):
