@@ -239,7 +239,7 @@ int sipnet_batch_set_math(sipnet_batch *b, int32_t policy);
  *     records / SIPNET_KOPT_FULL_STATE there for the nitrogen-cycle set itself and for the sets with further options;
  *     the one-wavefront kernel beyond two chunks per CU;
  *   - records, SIPNET_KOPT_FULL_STATE and the diagnostics counters take the "Full" instantiations of the same
- *     kernels (not the four-chunk layout; the counters with the nitrogen cycle: see sipnet_batch_enable_diagnostics).
+ *     kernels (not the four-chunk layout; the counters with the nitrogen cycle on the one- and -- round 6 -- two-chunk layouts).
  * "Default physics" means the model, not the flag values: events, gdd, soil_phenol and water_hresp may have any
  * legal value (no events; leaf-on by growing degree days, soil temperature or day of year -- russell_4's set; no
  * moisture effect on heterotrophic respiration): they change what the site plan puts into the step records, not the
@@ -259,12 +259,6 @@ int sipnet_batch_set_math(sipnet_batch *b, int32_t policy);
  *   > 2 chunks per CU, nitrogen cycle (any precision)          a chunk's soil-wave mailboxes + four private       x 2.2 (c3's shape, fp32-mixed: 21.0 ms against
  *                                                              record tiles are ~60 KB of LDS: four chunks do     9.6 ms for the default physics)
  *                                                              not fit a CU's 160 KB
- *   1 < chunks per CU <= 2, nitrogen cycle + the diagnostics   the plant side's mass totals travel to the soil    x 1.7 (c4's shape: 26.7 ms against 15.3 ms for the
- *   counters (sipnet_batch_enable_diagnostics)                 wave in eleven more mailbox rows per slot:         lean two-chunk launch; the record and
- *                                                              146.5 + 22 KB > 160 KB (fp64); in an fp32-mixed    SIPNET_KOPT_FULL_STATE alone stay cooperative)
- *                                                              batch they would fit, but its balance residuals
- *                                                              are fp32 rounding (1e-3 gC against the check's
- *                                                              1e-8): every step would count
  *   > 2 chunks per CU, records / SIPNET_KOPT_FULL_STATE /      no full-state build of the four-chunk layout:      x 1.5 (c10k's members x 4, with the record:
  *   diagnostics                                                the record columns and accumulators spill under    one-wave Full build; the record's 44 stores
  *                                                              its register budget (fp64 284 B, fp32 136 B per    per member-step dominate either way)
@@ -367,15 +361,6 @@ int sipnet_batch_enable_diagnostics(sipnet_batch *b, int32_t on);
 int sipnet_batch_get_diagnostics(sipnet_batch *b, int64_t *n_clamp_warn, int64_t *n_balance_warn,
                                  double *max_abs_dC, double *max_abs_dN, void *hip_stream);
 
-/* The same advance with the reference's `--debug-log` content (outputDebugState,
- * debug_log.c:285-312, called after every updateState, sipnet.c:1974): besides the full
- * record d_rec, d_dbg[n_steps][SIPNET_NDBG][ld] (DEVICE, doubles) receives per step
- *   0..55  the 56 `Fluxes` fields in the order of the fluxes log (debug_log.c:70-125)
- *   56..62 trackers.yearlyGpp, yearlyRtot, yearlyRa, yearlyRh, yearlyNpp, yearlyNee, yearlyLitter
- *   63..66 trackers.totRtot, totRa, totRh, totNpp
- *   67..69 phenologyTrackers.didLeafGrowth, didLeafFall, plantSurvivalTracker.isAlive
- * Always runs the strict-order kernel (no fast-math substitutions of the flux expressions
- * unless the batch is fast-math). */
 /* Every member's SUMS over groups of sum_steps consecutive steps instead of the steps themselves (what a consumer of the
  * reference's per-step output rows, sipnet.c:453-473, aggregates anyway: sum_steps = 48 gives the daily NEE / GPP / ET of a
  * half-hourly forcing): d_*_sums[ceil(n_steps / sum_steps)][ld] doubles (DEVICE; any may be NULL), groups counted from
@@ -388,6 +373,16 @@ int sipnet_batch_get_diagnostics(sipnet_batch *b, int64_t *n_clamp_warn, int64_t
 int sipnet_batch_run_sums(sipnet_batch *b, int32_t step0, int32_t n_steps, int32_t sum_steps, double *d_nee_sums,
                           double *d_gpp_sums, double *d_et_sums, int64_t ld, void *hip_stream);
 int32_t sipnet_batch_sums_in_kernel(const sipnet_batch *b);
+
+/* The same advance with the reference's `--debug-log` content (outputDebugState,
+ * debug_log.c:285-312, called after every updateState, sipnet.c:1974): besides the full
+ * record d_rec, d_dbg[n_steps][SIPNET_NDBG][ld] (DEVICE, doubles) receives per step
+ *   0..55  the 56 `Fluxes` fields in the order of the fluxes log (debug_log.c:70-125)
+ *   56..62 trackers.yearlyGpp, yearlyRtot, yearlyRa, yearlyRh, yearlyNpp, yearlyNee, yearlyLitter
+ *   63..66 trackers.totRtot, totRa, totRh, totNpp
+ *   67..69 phenologyTrackers.didLeafGrowth, didLeafFall, plantSurvivalTracker.isAlive
+ * Always runs the strict-order kernel (no fast-math substitutions of the flux expressions
+ * unless the batch is fast-math). */
 int sipnet_batch_run_debug(sipnet_batch *b, int32_t step0, int32_t n_steps, double *d_rec,
                            double *d_dbg, int64_t ld, void *hip_stream);
 

@@ -682,10 +682,11 @@ static int autoKernel(const int32_t* flags, int32_t n_sites, int32_t n_members, 
     return SIPNET_KERNEL_ONE_WAVE;
   }
   // the nitrogen cycle (with litter pool + anaerobic, which it requires), alone or with the other options; full state
-  // (record, every accumulator) too; the diagnostics counters (wantFull == 2) on the one-chunk layout only -- the plant
-  // side's mass totals travel to the soil wave through a mailbox the two-chunk layout has no LDS for
+  // (record, every accumulator) and the diagnostics counters (wantFull == 2) too -- the plant side's mass totals travel to
+  // the soil wave through eleven more mailbox rows: two slots of them on the one-chunk layout, one per chunk on the two-chunk
+  // layout (round 6: the carbon wave waits for the soil wave's balance check of the step before; coop_mailboxes.inc)
   if (blocks <= (int64_t)numCUs) return SIPNET_KERNEL_COOP_NCYCLE;
-  if (blocks <= 2 * (int64_t)numCUs && wantFull <= 1) return SIPNET_KERNEL_COOP_NCYCLE_PAIR;
+  if (blocks <= 2 * (int64_t)numCUs) return SIPNET_KERNEL_COOP_NCYCLE_PAIR;
   return SIPNET_KERNEL_ONE_WAVE;
 }
 
@@ -1259,9 +1260,9 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
       return SIPNET_ERR_BAD_ARGUMENT;
     }
     if (kernel == SIPNET_KERNEL_COOP_NCYCLE || kernel == SIPNET_KERNEL_COOP_NCYCLE_PAIR) {
-      if (!b->flags[SIPNET_F_NITROGEN_CYCLE] || (b->d_diag && kernel == SIPNET_KERNEL_COOP_NCYCLE_PAIR)) {
-        setError("sipnet_batch_run: the nitrogen-cycle cooperative kernels run flag sets with the nitrogen cycle on (records "
-                 "and SIPNET_KOPT_FULL_STATE included); the diagnostics counters on the one-chunk layout only");
+      if (!b->flags[SIPNET_F_NITROGEN_CYCLE]) {
+        setError("sipnet_batch_run: the nitrogen-cycle cooperative kernels run flag sets with the nitrogen cycle on (records, "
+                 "SIPNET_KOPT_FULL_STATE and the diagnostics counters included)");
         return SIPNET_ERR_BAD_ARGUMENT;
       }
     } else if (kernel != SIPNET_KERNEL_ONE_WAVE && b->flags[SIPNET_F_NITROGEN_CYCLE]) {

@@ -143,7 +143,8 @@ def test_auto_kernel_policy_by_shape_and_flags():
     ncyc = dict(litterPool=1, anaerobic=1, nitrogenCycle=1)
     assert choice(10240, **ncyc) == choice(10240, gdd=0, soilPhenol=1, **ncyc) == sa.KERNEL_COOP_NCYCLE
     assert choice(1024, sites=32, **ncyc) == sa.KERNEL_COOP_NCYCLE_PAIR
-    assert choice(32769, **ncyc) == choice(1024, sites=32, full=2, **ncyc) == sa.KERNEL_ONE_WAVE      # (2: diagnostics counters)
+    assert choice(32769, **ncyc) == sa.KERNEL_ONE_WAVE
+    assert choice(1024, sites=32, full=2, **ncyc) == sa.KERNEL_COOP_NCYCLE_PAIR   # (2: diagnostics counters -- round 6: one slot of the mass-total rows per chunk)
     assert choice(10240, full=2, **ncyc) == sa.KERNEL_COOP_NCYCLE           # (round 5: the soil wave runs the balance check)
     assert choice(10240, full=1, **ncyc) == sa.KERNEL_COOP_NCYCLE and choice(1024, sites=32, full=1, **ncyc) == sa.KERNEL_COOP_NCYCLE_PAIR
     # every other optional flag: the optional-physics instantiations of the one- and two-chunk layouts (lean or full
@@ -162,5 +163,5 @@ def test_auto_kernel_policy_by_shape_and_flags():
     assert choice(10240, full=1, **everything) == sa.KERNEL_COOP_NCYCLE          # (round 5: stepCoopNXFullKernel)
     assert choice(1024, sites=32, full=1, **everything) == sa.KERNEL_COOP_NCYCLE_PAIR
     assert choice(10240, full=2, **everything) == sa.KERNEL_COOP_NCYCLE          # diagnostics counters with the nitrogen cycle
-    assert choice(1024, sites=32, full=2, **everything) == sa.KERNEL_ONE_WAVE    # (not on the two-chunk layout: LDS)
+    assert choice(1024, sites=32, full=2, **everything) == sa.KERNEL_COOP_NCYCLE_PAIR    # (round 6)
     assert choice(0) == -1 and choice(64, cus=0) == -1

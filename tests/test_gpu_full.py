@@ -238,13 +238,16 @@ def test_diagnostics_of_the_optional_physics_kernels_match_the_oracle(kernel, or
 
 @pytest.mark.parametrize("which,kernel,expect", [("nitrogen", sa.KERNEL_COOP_NCYCLE, "stepCoopNFullKernel<double, false>"),
                                                   ("everything", sa.KERNEL_AUTO, "stepCoopNXFullKernel<double, false>"),
+                                                  ("nitrogen", sa.KERNEL_COOP_NCYCLE_PAIR, "stepCoopNPairFullKernel<double, false>"),
+                                                  ("everything", sa.KERNEL_COOP_NCYCLE_PAIR, "stepCoopNXPairFullKernel<double, false>"),
                                                   ("nitrogen", sa.KERNEL_ONE_WAVE, "stepFastKernel<double, false, 2, 1, true>")],
-                         ids=["n_full", "nx_full_auto", "one_wave"])
+                         ids=["n_full", "nx_full_auto", "n_pair_full", "nx_pair_full", "one_wave"])
 def test_diagnostics_counters_with_the_nitrogen_cycle_on_the_cooperative_kernels(which, kernel, expect, oracle, base):
     """round 5: clamp and carbon / nitrogen balance counters with the nitrogen cycle from the cooperative kernels -- the
     plant side's mass totals travel with wave C's end-of-step post to the soil wave, which runs checkBalance()
     (balance.c:122-169 over the pools of nitrogen.c:210-239) -- on the events scenario (fertiliser, harvests, a clear-cut,
-    re-planting, leaf events): counters equal to the oracle's, residuals at rounding level; the two-chunk layout refuses"""
+    re-planting, leaf events): counters equal to the oracle's, residuals at rounding level.  Round 6: the two-chunk layout too --
+    one slot of the eleven mass-total rows per chunk, the carbon wave waiting for the soil wave's check of the step before"""
     flags = sa.flags_from(**(EVERYTHING if which == "everything" else dict(litterPool=1, anaerobic=1, nitrogenCycle=1)))
     nbase = sa.read_params(os.path.join(os.path.dirname(BASE), "allflags_forest.param"), flags)[0]
     clim, ev, members = _scenario(nbase, lethal=True)
@@ -264,8 +267,4 @@ def test_diagnostics_counters_with_the_nitrogen_cycle_on_the_cooperative_kernels
     np.testing.assert_allclose(d["max_abs_dC"], np.array([w.max_abs_dC for w in want]), rtol=0, atol=1e-9)
     np.testing.assert_allclose(d["max_abs_dN"], np.array([w.max_abs_dN for w in want]), rtol=1e-6, atol=1e-9)
     assert (d["max_abs_dC"] > 0).any() and (d["max_abs_dN"] > 0).any()
-    if kernel == sa.KERNEL_COOP_NCYCLE:
-        b = _batch(flags, clim, members, ev, fast=True, kernel=sa.KERNEL_COOP_NCYCLE_PAIR, diag=True)
-        with pytest.raises(sa.SipnetError, match="one-chunk layout only"):
-            b.run(0, 10, want_planes=False)
-        b.close()
+

@@ -145,6 +145,27 @@ static void planFrom(const sipnet_clim_table* t) {
           fprintf(stderr, "buildSitePlanLight disagrees with buildSitePlan (status %d vs %d, resumed %d)\n", l.status, pf.status, resumed);
           abort();
         }
+        // the room a DEVICE-built site gets for its eviction list (engine.hip devRingOpRoom: 2 n + the live entries the ring starts
+        // with + 8) bounds the list the host builder produces -- for every ring the device is handed: one that carries the 5-day
+        // window (engine.hip devicePrepass)
+        if (pf.status == SIPNET_OK) {
+          size_t preK = 1;
+          double sum = 5.0;
+          if (init) {
+            const sipnet::RingSched& r = init->ring;
+            preK = (size_t)((r.last - r.start + SIPNET_RING_SLOTS) % SIPNET_RING_SLOTS) + 1;
+            sum = 0.0;
+            for (int i = r.start;; i = (i + 1) % SIPNET_RING_SLOTS) {
+              sum += r.w[i];
+              if (i == r.last) break;
+            }
+          }
+          if (sum - 5.0 <= 1e-9 && 5.0 - sum <= 1e-9 && pf.ringOps.size() > 2 * (size_t)n + preK + 8) {
+            fprintf(stderr, "eviction list of %zu entries for %d steps and %zu initial ring entries: over the device's room\n",
+                    pf.ringOps.size(), (int)n, preK);
+            abort();
+          }
+        }
         g_lightChecked++;
       }
     }
