@@ -604,8 +604,12 @@ struct CoopSums<false> {};
 // group as long as the launch leaves it -- accumulated in step order by the wave that computes the value (one add per value and
 // step, a store per group: 1 / sumEvery of the planes' HBM writes; sipnet_batch_run_sums).  Sums = false compiles to the code
 // it was before the parameter existed (tests/test_code_placement.py holds the measured instantiations' loop heads in place).
-template <class R, bool PlainExp, bool RingLds, bool Full, int NP, bool NCyc = false, bool Ext = false, bool Sums = false>
+// PairDiag (round 6): the two-chunk nitrogen-cycle layouts' full-state builds WITH the diagnostics counters (one slot of the
+// mass-total rows per chunk: coop_mailboxes.inc) -- instantiations of their own, because the counters' code costs the plain
+// full-state build its last registers (230 -> 256 VGPRs + 20 B of scratch: c4's shape with the record 17.9 -> 18.8 ms)
+template <class R, bool PlainExp, bool RingLds, bool Full, int NP, bool NCyc = false, bool Ext = false, bool Sums = false, bool PairDiag = false>
 __device__ __forceinline__ void coopBody(const FastArgs& a) {
+  static_assert(!PairDiag || (NCyc && Full && NP == 2), "PairDiag: the nitrogen cycle's two-chunk full-state layout");
   static_assert(!Sums || (!NCyc && !Ext && !Full && sizeof(R) == 8), "in-kernel sums: fp64, default physics, lean launches");
   static_assert(!(NP > 1 && RingLds), "two chunks' rings do not fit one CU's LDS");
   static_assert(!NCyc || (NP <= 2 && !RingLds), "nitrogen-cycle layout: one or two chunks, ring in HBM");
@@ -806,6 +810,13 @@ template <class R, bool PlainExp>
 __global__ __launch_bounds__(512) void stepCoopNPairFullKernel(FastArgs a) {
   coopBody<R, PlainExp, false, true, 2, true>(a);
 }
+#ifndef SIPNET_COOP_BOUNDED
+// ... with the diagnostics counters (coopBody, PairDiag)
+template <class R, bool PlainExp>
+__global__ __launch_bounds__(512) void stepCoopNPairDiagKernel(FastArgs a) {
+  coopBody<R, PlainExp, false, true, 2, true, false, false, true>(a);
+}
+#endif
 
 // ---- Ext: the optional-physics instantiations (run-time flags; see coopBody) -----------------------------------
 // default pools + growth respiration / leaf water / flooding / litter pool / carbon saturation / anaerobic + methane
@@ -845,6 +856,12 @@ template <class R, bool PlainExp>
 __global__ __launch_bounds__(512) void stepCoopNXPairFullKernel(FastArgs a) {
   coopBody<R, PlainExp, false, true, 2, true, true>(a);
 }
+#ifndef SIPNET_COOP_BOUNDED
+template <class R, bool PlainExp>
+__global__ __launch_bounds__(512) void stepCoopNXPairDiagKernel(FastArgs a) {
+  coopBody<R, PlainExp, false, true, 2, true, true, false, true>(a);
+}
+#endif
 
 #ifdef SIPNET_HWID
 extern "C" int sipnet_debug_read_coop_hwid(unsigned* out) {
@@ -895,7 +912,10 @@ void launchStepCoop(const FastArgs& a, int precision, int layout, hipStream_t st
       else hipLaunchKernelGGL((K<float, false>), gridN, blockN, 0, stream, a);                    \
     }
 #ifndef SIPNET_COOP_BOUNDED
-    if (ext && a.full) {
+    const bool pairDiag = pairN && a.full && a.diag != nullptr;
+    if (pairDiag) {
+      if (ext) { NCYC_LAUNCH(stepCoopNXPairDiagKernel) } else { NCYC_LAUNCH(stepCoopNPairDiagKernel) }
+    } else if (ext && a.full) {
       if (pairN) { NCYC_LAUNCH(stepCoopNXPairFullKernel) } else { NCYC_LAUNCH(stepCoopNXFullKernel) }
     } else
 #endif
@@ -911,7 +931,8 @@ void launchStepCoop(const FastArgs& a, int precision, int layout, hipStream_t st
 #undef NCYC_LAUNCH
     if (info) {
       snprintf(info->kernel, sizeof info->kernel, "%s<%s, %s>",
-               (ext && a.full) ? (pairN ? "stepCoopNXPairFullKernel" : "stepCoopNXFullKernel")
+               (pairN && a.full && a.diag) ? (ext ? "stepCoopNXPairDiagKernel" : "stepCoopNPairDiagKernel")
+               : (ext && a.full) ? (pairN ? "stepCoopNXPairFullKernel" : "stepCoopNXFullKernel")
                : ext ? (pairN ? "stepCoopNXPairKernel" : "stepCoopNXKernel")
                    : a.full ? (pairN ? "stepCoopNPairFullKernel" : "stepCoopNFullKernel") : (pairN ? "stepCoopNPairKernel" : "stepCoopNKernel"),
                precision == SIPNET_F64 ? "double" : "float", a.plainExp ? "true" : "false");

@@ -73,8 +73,9 @@ def instantiation(demangled):
         t.update(NP=4, ext=name == "stepCoopXQuadKernel")
     elif name in ("stepCoopNKernel", "stepCoopNFullKernel", "stepCoopNXKernel", "stepCoopNXFullKernel"):
         t.update(ncyc=True, full="Full" in name, ext="NX" in name)
-    elif name in ("stepCoopNPairKernel", "stepCoopNPairFullKernel", "stepCoopNXPairKernel", "stepCoopNXPairFullKernel"):
-        t.update(ncyc=True, NP=2, full="Full" in name, ext="NX" in name)
+    elif name in ("stepCoopNPairKernel", "stepCoopNPairFullKernel", "stepCoopNXPairKernel", "stepCoopNXPairFullKernel",
+                  "stepCoopNPairDiagKernel", "stepCoopNXPairDiagKernel"):       # (Diag: the full-state build with the counters, round 6)
+        t.update(ncyc=True, NP=2, full="Full" in name or "Diag" in name, ext="NX" in name)
     else:
         return None
     return t

@@ -238,10 +238,10 @@ def test_diagnostics_of_the_optional_physics_kernels_match_the_oracle(kernel, or
 
 @pytest.mark.parametrize("which,kernel,expect", [("nitrogen", sa.KERNEL_COOP_NCYCLE, "stepCoopNFullKernel<double, false>"),
                                                   ("everything", sa.KERNEL_AUTO, "stepCoopNXFullKernel<double, false>"),
-                                                  ("nitrogen", sa.KERNEL_COOP_NCYCLE_PAIR, "stepCoopNPairFullKernel<double, false>"),
-                                                  ("everything", sa.KERNEL_COOP_NCYCLE_PAIR, "stepCoopNXPairFullKernel<double, false>"),
+                                                  ("nitrogen", sa.KERNEL_COOP_NCYCLE_PAIR, "stepCoopNPairDiagKernel<double, false>"),
+                                                  ("everything", sa.KERNEL_COOP_NCYCLE_PAIR, "stepCoopNXPairDiagKernel<double, false>"),
                                                   ("nitrogen", sa.KERNEL_ONE_WAVE, "stepFastKernel<double, false, 2, 1, true>")],
-                         ids=["n_full", "nx_full_auto", "n_pair_full", "nx_pair_full", "one_wave"])
+                         ids=["n_full", "nx_full_auto", "n_pair_diag", "nx_pair_diag", "one_wave"])
 def test_diagnostics_counters_with_the_nitrogen_cycle_on_the_cooperative_kernels(which, kernel, expect, oracle, base):
     """round 5: clamp and carbon / nitrogen balance counters with the nitrogen cycle from the cooperative kernels -- the
     plant side's mass totals travel with wave C's end-of-step post to the soil wave, which runs checkBalance()

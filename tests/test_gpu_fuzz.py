@@ -113,3 +113,17 @@ def test_fuzz_sites_of_different_lengths(campaign):
     print(r.stdout[-3000:])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "30 trials ok" in r.stdout
+
+
+def test_fuzz_in_kernel_sums_on_the_cooperative_layouts():
+    """a fixed-seed slice of the round-6 campaign (FUZZ_COOP=1 FUZZ_SUMS=1): every eligible trial (fp64, lean) is run again
+    through sipnet_batch_run_sums -- random group lengths, launches cut at random multiples of the group -- and its sums must
+    equal the trial's own planes added up in step order, bit for bit, and leave the same state; sites of different lengths
+    in the second slice"""
+    for extra, n, seed in ((dict(), "40", "9"), (dict(FUZZ_RAGGED="1"), "25", "10")):
+        env = dict(os.environ, FUZZ_COOP="1", FUZZ_SUMS="1", **extra)
+        r = subprocess.run([sys.executable, os.path.join(helpers.REPO, "tools", "fuzz_gpu.py"), n, seed],
+                           capture_output=True, text=True, timeout=900, env=env)
+        print(r.stdout[-3000:])
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        assert n + " trials ok" in r.stdout and r.stdout.count(" sums(k=") >= 5

@@ -15,12 +15,13 @@ T = 17520
 flags = sa.flags_from(litterPool=1, anaerobic=1, nitrogenCycle=1)
 base = sa.read_params(os.path.join(REPO, "sipnet_amd", "data", "allflags_forest.param"), flags)[0]
 for S, M in ((1, 10240), (32, 1024)):
-    for what in ("lean", "full_state", "diagnostics"):
-        b = sa.Batch(flags, S, M, sa.F64, fast_math=True, kernel_options=sa.KOPT_FULL_STATE if what == "full_state" else 0)
+    for what in ("lean", "full_state", "diagnostics", "diagnostics, one-wave kernel forced"):
+        b = sa.Batch(flags, S, M, sa.F64, fast_math=True, kernel_options=sa.KOPT_FULL_STATE if what == "full_state" else 0,
+                     kernel=sa.KERNEL_ONE_WAVE if "one-wave" in what else sa.KERNEL_AUTO)
         for s in range(S):
             b.set_climate(s, synth.convert_raw(synth.round_like_file(synth.half_hourly_year_raw(T, site=s))))
         b.set_params(None, synth.perturbed_params(base, M))
-        if what == "diagnostics":
+        if what.startswith("diagnostics"):
             b.enable_diagnostics()
         planes, _ = b.alloc_outputs(T)
         ms = []
@@ -33,5 +34,5 @@ for S, M in ((1, 10240), (32, 1024)):
             torch.cuda.synchronize()
             ms.append(b.last_kernel_ms())
         if ms:
-            print("%-40s %2d x %5d members, %-11s %8.3f ms  %s" % (os.environ.get("SIPNET_LIB", "product")[-40:], S, M, what, min(ms[1:]), b.last_launch()["kernel"]), flush=True)
+            print("%-12s %2d x %5d members, %-36s %8.3f ms  %s" % (os.environ.get("SIPNET_LIB", "product")[-40:], S, M, what, min(ms[1:]), b.last_launch()["kernel"]), flush=True)
         b.close()
