@@ -36,6 +36,11 @@
 //                            evapotranspiration by default -- the lean throughput kernels, three planes -- or the
 //                            `.out` columns named with --ensemble-out-columns a,b,c|all (the 44-column record);
 //                            --ensemble-out-f32 stores floats; --ensemble-text writes the text files as well;
+//                            --ensemble-out-sums K (the three planes only): every member's SUMS over groups of K steps
+//                            instead of the steps (K = 48: daily NEE / GPP / ET of a half-hourly forcing; the block's
+//                            time axis holds each group's first record, its step length the group's) -- summed inside
+//                            the step kernel's launch where the batch has such a kernel (sipnet_batch_run_sums), else
+//                            from the planes on the host;
 //                            --ensemble-out-segment N holds N steps of the record on the device at a time (default:
 //                            about 3 GB worth -- the whole record of 10 240 members x a year would be 63 GB).
 //                            Device shards stream their member ranges into the one file.  With --sites one block
@@ -194,6 +199,7 @@ void usage(const char* prog) {
   printf("  --ensemble-out <file.nc>    (--ensemble-params / --sites) all members' outputs as one NetCDF-3 block instead of\n");
   printf("                              the members' text files: nee, gpp, evapotranspiration -- or, with\n");
   printf("      --ensemble-out-columns <a,b,..|all>  the named .out columns; --ensemble-out-f32 stores floats;\n");
+  printf("      --ensemble-out-sums <K>  (planes only) every member's sums over groups of K steps (48: daily sums);\n");
   printf("      --ensemble-text         writes the text files as well\n");
   printf("  --bounded-waits             cooperative kernels with bounded hand-over waits (a stuck wait is reported, not a hang)\n");
   printf("  -h, --help   -v, --version\n");
@@ -359,6 +365,7 @@ struct BlockSpec {
   std::vector<int> cols;           // `.out` column indices (sipnet_io_out_column); empty: the three planes
   bool f32 = false, text = false;  // store floats; write the members' text files as well
   int segment = 0;                 // --ensemble-out-segment: steps of the record held on the device at a time (0: ~3 GB worth)
+  int sums = 0;                    // --ensemble-out-sums K: sums over groups of K steps instead of the steps (planes only)
   bool on() const { return !path.empty(); }
   bool planesOnly() const { return cols.empty(); }
 };
@@ -813,7 +820,7 @@ int main(int argc, char** argv) {
     opts.push_back({kFlagOpts[k][0], no_argument, &tmpFlag, 1});
     opts.push_back({strdup((std::string("no-") + kFlagOpts[k][0]).c_str()), no_argument, &tmpFlag, 0});
   }
-  enum { OPT_RIN = 1001, OPT_ROUT, OPT_DBG, OPT_ENS, OPT_DEV, OPT_MATH, OPT_ESTATS, OPT_SITES, OPT_EOUT, OPT_ECOLS, OPT_EF32, OPT_ETEXT, OPT_BOUNDED, OPT_ESEG };
+  enum { OPT_RIN = 1001, OPT_ROUT, OPT_DBG, OPT_ENS, OPT_DEV, OPT_MATH, OPT_ESTATS, OPT_SITES, OPT_EOUT, OPT_ECOLS, OPT_EF32, OPT_ETEXT, OPT_BOUNDED, OPT_ESEG, OPT_ESUMS };
   opts.push_back({"input-file", required_argument, nullptr, 'i'});
   opts.push_back({"file-prefix", required_argument, nullptr, 'f'});
   opts.push_back({"file-name", required_argument, nullptr, 'f'});
@@ -832,6 +839,7 @@ int main(int argc, char** argv) {
   opts.push_back({"ensemble-text", no_argument, nullptr, OPT_ETEXT});
   opts.push_back({"bounded-waits", no_argument, nullptr, OPT_BOUNDED});
   opts.push_back({"ensemble-out-segment", required_argument, nullptr, OPT_ESEG});
+  opts.push_back({"ensemble-out-sums", required_argument, nullptr, OPT_ESUMS});
   opts.push_back({"help", no_argument, nullptr, 'h'});
   opts.push_back({"version", no_argument, nullptr, 'v'});
   opts.push_back({nullptr, 0, nullptr, 0});
@@ -858,6 +866,7 @@ int main(int argc, char** argv) {
       case OPT_ETEXT: block.text = true; break;
       case OPT_BOUNDED: g_kernelOptions |= SIPNET_KOPT_BOUNDED_WAITS; break;
       case OPT_ESEG: block.segment = atoi(optarg); break;
+      case OPT_ESUMS: block.sums = atoi(optarg); if (block.sums <= 0) die(8, "--ensemble-out-sums needs a positive number of steps\n"); break;
       case 'h': usage(argv[0]); return 0;
       case 'v': printf("SIPNET version 2.1.0 (%s)\n", sipnet_version()); return 0;
       default: usage(argv[0]); return 8;  // EXIT_CODE_BAD_CLI_ARGUMENT
@@ -879,6 +888,11 @@ int main(int argc, char** argv) {
     return 8;
   }
   if (!blockColumns.empty()) parseBlockColumns(block, blockColumns);
+  if (block.sums > 0 && (!block.on() || !block.planesOnly() || block.text || !sitesFile.empty())) {
+    logError("--ensemble-out-sums sums the three planes of --ensemble-params ... --ensemble-out (no --ensemble-out-columns, "
+             "--ensemble-text or --sites)\n");
+    return 8;
+  }
   g_quiet = ctx.i("quiet") != 0;
   if (!sitesFile.empty()) {
     if (!ensembleFile.empty() || !ensembleStats.empty()) {
@@ -1051,10 +1065,34 @@ int main(int argc, char** argv) {
   const bool wantText = !block.on() || block.text;
   const bool needRec = wantText || !restartOut.empty() || (block.on() && !block.planesOnly());
   const bool blockFast = mathArg == "fast" || (mathArg == "auto" && !ensembleFile.empty());
-  sipnet_ensemble_file* blockFile =
-      block.on() ? createBlock(block, block.path, T, M, clim, nullptr,
-                               "parameter_table=" + ensembleFile + "\nmath=" + (blockFast ? "fast" : "strict"))
-                 : nullptr;
+  // --ensemble-out-sums K: the block's rows are the groups of K steps -- each group's first record on the time axis, its step
+  // length the group's
+  const int sumK = block.on() ? block.sums : 0;
+  const int nGroups = sumK > 0 ? (T + sumK - 1) / sumK : 0;
+  sipnet_ensemble_file* blockFile = nullptr;
+  if (block.on() && sumK > 0) {
+    if (!restartOut.empty() || !debugLog.empty()) die(8, "--ensemble-out-sums does not combine with restart output / --debug-log\n");
+    std::vector<int32_t> gy(nGroups), gd(nGroups);
+    std::vector<double> gc((size_t)nGroups * SIPNET_NCLIM);
+    const double* cd = sipnet_clim_data(clim);
+    for (int g = 0; g < nGroups; g++) {
+      const int t0 = g * sumK, t1 = std::min(T, t0 + sumK);
+      gy[g] = sipnet_clim_year(clim)[t0];
+      gd[g] = sipnet_clim_day(clim)[t0];
+      memcpy(&gc[(size_t)g * SIPNET_NCLIM], cd + (size_t)t0 * SIPNET_NCLIM, SIPNET_NCLIM * sizeof(double));
+      double len = 0.0;
+      for (int t = t0; t < t1; t++) len += cd[(size_t)t * SIPNET_NCLIM];
+      gc[(size_t)g * SIPNET_NCLIM] = len;
+    }
+    const char* names[3] = {"nee", "gpp", "evapotranspiration"};
+    const std::string attrs = "parameter_table=" + ensembleFile + "\nmath=" + (blockFast ? "fast" : "strict") +
+                              "\nsums_over_steps=" + std::to_string(sumK);
+    check(sipnet_io_ensemble_create(block.path.c_str(), nGroups, M, gy.data(), gd.data(), gc.data(), nullptr, 3, names, nullptr,
+                                    block.f32 ? SIPNET_NC_F32 : SIPNET_NC_F64, attrs.c_str(), &blockFile), "creating the ensemble block");
+  } else if (block.on()) {
+    blockFile = createBlock(block, block.path, T, M, clim, nullptr,
+                            "parameter_table=" + ensembleFile + "\nmath=" + (blockFast ? "fast" : "strict"));
+  }
   std::atomic<int> worst{0};
   std::mutex logMutex;
   int hostThreads = 1;
@@ -1085,6 +1123,49 @@ int main(int argc, char** argv) {
       check(sipnet_batch_import_restart(b, 0, 0, Ms, resume.data() + m0, nullptr), "restart checkpoint");
     std::vector<double> state0((size_t)Ms * SIPNET_NSTATE);
     check(sipnet_batch_get_state(b, state0.data(), nullptr), "state");
+    if (!needRec && sumK > 0) {
+      // the block of sums: out of the step kernel's own launch where the batch has such a kernel (1 / K of the bytes ever
+      // leave the kernel), else the planes summed on the host in step order
+      const bool inKernel = sipnet_batch_sums_in_kernel(b) != 0;
+      const size_t rows = inKernel ? (size_t)nGroups : (size_t)T;
+      double* dOut = (double*)sipnet_dev_alloc((size_t)3 * rows * Ms * sizeof(double));
+      if (!dOut) die(1, std::string(sipnet_last_error()) + "\n");
+      if (inKernel)
+        check(sipnet_batch_run_sums(b, 0, T, sumK, dOut, dOut + rows * Ms, dOut + 2 * rows * Ms, Ms, nullptr), "run");
+      else
+        check(sipnet_batch_run(b, 0, T, dOut, dOut + rows * Ms, dOut + 2 * rows * Ms, nullptr, Ms, nullptr), "run");
+      std::vector<int32_t> status(Ms);
+      check(sipnet_batch_get_status(b, status.data(), nullptr), "status");
+      for (int m = 0; m < Ms; m++)
+        if (status[m] != 0) {
+          std::lock_guard<std::mutex> lock(logMutex);
+          logError("member " + std::to_string(m0 + m) + ": status " + std::to_string(status[m]) +
+                   " (NPP allocation params must be less than one individually and add to less than one)\n");
+          int w = worst.load();
+          while (status[m] > w && !worst.compare_exchange_weak(w, status[m])) {}
+        }
+      std::vector<double> host(rows * Ms), sums;
+      for (int v = 0; v < 3; v++) {
+        check(sipnet_dev_to_host(host.data(), dOut + (size_t)v * rows * Ms, rows * Ms * sizeof(double), nullptr), "copy back");
+        const double* src = host.data();
+        if (!inKernel) {
+          sums.assign((size_t)nGroups * Ms, 0.0);
+          for (int t = 0; t < T; t++) {
+            double* acc = &sums[(size_t)(t / sumK) * Ms];
+            const double* row = &host[(size_t)t * Ms];
+            for (int m = 0; m < Ms; m++) acc[m] += row[m];
+          }
+          src = sums.data();
+        }
+        check(sipnet_io_ensemble_put(blockFile, v, 0, nGroups, m0, Ms, src, Ms, 0), "writing the ensemble block");
+      }
+      if (shard == 0)
+        logInfo(std::string("ensemble block: sums over groups of ") + std::to_string(sumK) + " steps, " +
+                (inKernel ? "from the step kernel's launch (" : "from the planes, on the host (") + sipnet_batch_last_kernel_name(b) + ")\n");
+      sipnet_dev_free(dOut);
+      sipnet_batch_destroy(b);
+      return;
+    }
     if (!needRec) {   // the block alone, three planes: the lean kernels, nothing but the planes leaves the device
       double* dPlanes = (double*)sipnet_dev_alloc((size_t)3 * T * Ms * sizeof(double));
       if (!dPlanes) die(1, std::string(sipnet_last_error()) + "\n");

@@ -360,6 +360,50 @@ def test_cli_ensemble_out_block_against_the_goldens_and_the_members_text(tmp_pat
     assert os.path.getsize(tmp_path / "sharded.nc") < 0.2 * os.path.getsize(tmp_path / "all.nc")
 
 
+@pytest.mark.gpu
+def test_cli_ensemble_out_sums_block(tmp_path):
+    """`sipnet --ensemble-params T --ensemble-out e.nc --ensemble-out-sums 8` on niwot-like default physics (russell_4's flags are
+    data): every member's sums over groups of 8 steps (russell's records are 0.125 d: daily sums), the last group shorter --
+    equal, bit for bit, to the full block's planes added up in step order (throughput kernels: the sums come out of the step
+    kernel's own launch; --math strict: from the planes, on the host; two shards stream into ONE file); the block's time axis
+    holds each group's first record, its step length the group's; option errors are CLI errors"""
+    from sipnet_amd import ensemble_io as eio
+    stage("russell_4", tmp_path)                        # (no events, no GDD, soil phenology: the default-physics kernels)
+    open(tmp_path / "members.txt", "w").write("aMax psnTOpt\n" + "\n".join(f"{a} {o}" for a, o in ((7.9, 24.0), (8.1, 23.0), (6.4, 25.5))) + "\n")
+    K = 8
+    r = run_cli(tmp_path, "-i", "sipnet.in", "--ensemble-params", "members.txt", "--ensemble-out", "planes.nc")
+    assert r.returncode == 0, r.stdout + r.stderr
+    planes = eio.read_ensemble_netcdf(tmp_path / "planes.nc")
+    T = planes["nee"].shape[0]
+    G = (T + K - 1) // K
+    want = {}
+    for k in ("nee", "gpp", "evapotranspiration"):
+        acc = np.zeros((G, 3))
+        for t in range(T):
+            acc[t // K] += planes[k][t]
+        want[k] = acc
+    for args, how in ((("--devices", "0"), "from the step kernel's launch"), (("--devices", "0,0"), "from the step kernel's launch"),
+                      (("--math", "strict"), "from the planes, on the host")):
+        out = "sums_%s.nc" % "_".join(a.strip("-").replace(",", "") for a in args)
+        r = run_cli(tmp_path, "-i", "sipnet.in", "--ensemble-params", "members.txt", "--ensemble-out", out, "--ensemble-out-sums", str(K), *args)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert how in r.stdout, r.stdout
+        blk = eio.read_ensemble_netcdf(tmp_path / out)
+        _, dims, gatts, _ = eio.open_ensemble_netcdf(tmp_path / out)
+        assert dims == {"time": G, "member": 3} and gatts["sums_over_steps"] == str(K)
+        assert blk["year"].tolist() == planes["year"][::K].tolist() and blk["day"].tolist() == planes["day"][::K].tolist()
+        np.testing.assert_allclose(blk["length"][:-1], np.add.reduceat(planes["length"], np.arange(0, T, K))[:-1], rtol=1e-12)
+        for k in want:
+            if "strict" in args:
+                np.testing.assert_allclose(blk[k], want[k], rtol=0, atol=1e-10)       # (the strict kernel's planes, summed)
+            else:
+                np.testing.assert_array_equal(blk[k], want[k])
+        assert os.path.getsize(tmp_path / out) < 0.2 * os.path.getsize(tmp_path / "planes.nc")
+    for bad in (("--ensemble-out-sums", "0"), ("--ensemble-out-sums", "8", "--ensemble-out-columns", "nee"), ("--ensemble-out-sums", "8", "--ensemble-text")):
+        r = run_cli(tmp_path, "-i", "sipnet.in", "--ensemble-params", "members.txt", "--ensemble-out", "x.nc", *bad)
+        assert r.returncode == 8, (bad, r.stdout)
+
+
 def _param(d, name):
     for l in open(os.path.join(d, "sipnet.param")):
         t = l.split()

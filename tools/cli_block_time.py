@@ -49,6 +49,7 @@ print(f"   (extrapolated to {MB} members: {t_text * MB / MT:.0f} s, {MB} files)"
 table(MB)
 run("block, three planes (f64)", MB, "--ensemble-out", "ens.nc")
 run("block, three planes (f32)", MB, "--ensemble-out", "ens.nc", "--ensemble-out-f32")
+run("block, DAILY SUMS of the three planes (f64; --ensemble-out-sums 48)", MB, "--ensemble-out", "ens.nc", "--ensemble-out-sums", "48")
 run("block, 8 columns of the record (f32)", MB, "--ensemble-out", "ens.nc", "--ensemble-out-f32", "--ensemble-out-columns",
     "nee,gpp,evapotranspiration,plantWoodC,plantLeafC,soil,soilWater,snow")
 shutil.rmtree(tmp)
