@@ -366,8 +366,10 @@ int sipnet_batch_get_diagnostics(sipnet_batch *b, int64_t *n_clamp_warn, int64_t
  * half-hourly forcing): d_*_sums[ceil(n_steps / sum_steps)][ld] doubles (DEVICE; any may be NULL), groups counted from
  * step0, the last as long as the run leaves it, each value added in step order by the wavefront that computes it -- inside
  * the step kernel's own launch (1 / sum_steps of the planes' HBM writes, no second pass).  For batches
- * sipnet_batch_sums_in_kernel answers 1 for: fp64, SIPNET_MATH_FAST, default physics, no diagnostics / full state, at most
- * two 64-member chunks per compute unit (the cooperative kernels' stepCoopSumsKernel / stepCoopPairSumsKernel); any other
+ * sipnet_batch_sums_in_kernel answers 1 for: fp64, SIPNET_MATH_FAST, any flag set, no diagnostics / full state, at most
+ * two 64-member chunks per compute unit (the cooperative kernels' Sums instantiations: stepCoopSumsKernel, stepCoopPairSumsKernel,
+ * their optional-physics relatives stepCoopXSumsKernel / XPairSums, and the nitrogen-cycle layouts' stepCoopNSumsKernel /
+ * NPairSums, where the soil wave forms NEE and sums it); any other
  * batch gets SIPNET_ERR_BAD_ARGUMENT and sums its planes (sipnet_node_run_gathering_reduced does either by itself).  A
  * site that ends inside a group leaves the group's sum over its own records. */
 int sipnet_batch_run_sums(sipnet_batch *b, int32_t step0, int32_t n_steps, int32_t sum_steps, double *d_nee_sums,

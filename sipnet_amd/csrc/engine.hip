@@ -1176,13 +1176,14 @@ int sipnet_batch_run_debug(sipnet_batch* b, int32_t step0, int32_t n_steps, doub
 }
 
 // Which cooperative kernel sums a batch's outputs over groups of steps inside its own launch (sipnet_batch_run_sums): fp64,
-// throughput arithmetic, the default physics (flags that are data included), no record / diagnostics / full state, at most
-// two chunks per CU -- AUTO's choice for such a shape, or one of those three layouts forced.  0: none.
+// throughput arithmetic, any flag set, no record / diagnostics / full state, at most two chunks per CU -- AUTO's choice for
+// such a shape, or one of those layouts forced.  0: none.
 static int sumsKernelFor(const sipnet_batch* b) {
-  if (b->precision != SIPNET_F64 || !b->fastMath || !isDefaultFlagSet(b->flags) || b->d_diag || (b->kernelOptions & SIPNET_KOPT_FULL_STATE))
-    return 0;
+  if (b->precision != SIPNET_F64 || !b->fastMath || b->d_diag || (b->kernelOptions & SIPNET_KOPT_FULL_STATE)) return 0;
   int kernel = b->kernelPolicy;
   if (kernel == SIPNET_KERNEL_AUTO) kernel = autoKernel(b->flags, b->n_sites, b->n_members, true, false, 0, b->numCUs, false);
+  const bool ncyc = b->flags[SIPNET_F_NITROGEN_CYCLE] != 0;
+  if (ncyc) return (kernel == SIPNET_KERNEL_COOP_NCYCLE || kernel == SIPNET_KERNEL_COOP_NCYCLE_PAIR) ? kernel : 0;
   return (kernel == SIPNET_KERNEL_COOP_LDS || kernel == SIPNET_KERNEL_COOP_HBM || kernel == SIPNET_KERNEL_COOP_PAIR) ? kernel : 0;
 }
 int32_t sipnet_batch_sums_in_kernel(const sipnet_batch* b) { return b ? (sumsKernelFor(b) != 0) : 0; }
@@ -1194,7 +1195,7 @@ int sipnet_batch_run_sums(sipnet_batch* b, int32_t step0, int32_t n_steps, int32
     return SIPNET_ERR_BAD_ARGUMENT;
   }
   if (!sumsKernelFor(b)) {
-    setError("sipnet_batch_run_sums: no kernel sums this batch's outputs inside its launch (fp64, SIPNET_MATH_FAST, default physics, "
+    setError("sipnet_batch_run_sums: no kernel sums this batch's outputs inside its launch (fp64, SIPNET_MATH_FAST, "
              "no diagnostics / full state, at most two chunks per CU: sipnet_batch_sums_in_kernel); run the planes and sum them");
     return SIPNET_ERR_BAD_ARGUMENT;
   }

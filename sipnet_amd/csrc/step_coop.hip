@@ -542,7 +542,7 @@ __device__ constexpr int coopCodePhase(int role) {
   // (the in-kernel sums build of the one-chunk LDS-ring layout, swept in round 6 at c10k's shape, tools/sums_time.py,
   // profiles/r06_sums_phase_sweep.txt: carbon 8.65 ... 8.46 ms at phase 3, then water 8.52 ... 8.40 at phase 3; its
   // relatives take their plain family's values)
-  if (Sums && NP == 1 && RingLds && (role == 0 || role == 1)) return 3;
+  if (Sums && NP == 1 && RingLds && !NCyc && !Ext && (role == 0 || role == 1)) return 3;
   if (role == 0) {   // the carbon wave (profiles/r04_phase_sweep_roles.txt)
     if (NCyc) return 0;
     if (Ext) return 7;
@@ -599,7 +599,7 @@ struct CoopSums {
 };
 template <>
 struct CoopSums<false> {};
-// Sums (round 6; fp64, default physics, lean): the three output planes receive every member's SUMS over groups of
+// Sums (round 6; fp64, lean, every physics family, one or two chunks per workgroup): the three output planes receive every member's SUMS over groups of
 // a.sumEvery consecutive steps of the launch instead of the steps themselves -- [groups][ld] each, a row per group, the last
 // group as long as the launch leaves it -- accumulated in step order by the wave that computes the value (one add per value and
 // step, a store per group: 1 / sumEvery of the planes' HBM writes; sipnet_batch_run_sums).  Sums = false compiles to the code
@@ -610,7 +610,7 @@ struct CoopSums<false> {};
 template <class R, bool PlainExp, bool RingLds, bool Full, int NP, bool NCyc = false, bool Ext = false, bool Sums = false, bool PairDiag = false>
 __device__ __forceinline__ void coopBody(const FastArgs& a) {
   static_assert(!PairDiag || (NCyc && Full && NP == 2), "PairDiag: the nitrogen cycle's two-chunk full-state layout");
-  static_assert(!Sums || (!NCyc && !Ext && !Full && sizeof(R) == 8), "in-kernel sums: fp64, default physics, lean launches");
+  static_assert(!Sums || (!Full && sizeof(R) == 8 && NP <= 2), "in-kernel sums: fp64, lean launches, one or two chunks per workgroup");
   static_assert(!(NP > 1 && RingLds), "two chunks' rings do not fit one CU's LDS");
   static_assert(!NCyc || (NP <= 2 && !RingLds), "nitrogen-cycle layout: one or two chunks, ring in HBM");
   constexpr bool Opt = Ext && !NCyc;   // the optional pools live on wave C
@@ -783,6 +783,23 @@ template <bool PlainExp>
 __global__ __launch_bounds__(512) void stepCoopPairSumsKernel(FastArgs a) {
   coopBody<double, PlainExp, false, false, 2, false, false, true>(a);
 }
+// ... of the optional-physics instantiations (run-time flags) and of the nitrogen-cycle layouts (NEE summed by the soil wave)
+template <bool PlainExp, bool RingLds>
+__global__ __launch_bounds__(RingLds ? 256 : 192) void stepCoopXSumsKernel(FastArgs a) {
+  coopBody<double, PlainExp, RingLds, false, 1, false, true, true>(a);
+}
+template <bool PlainExp>
+__global__ __launch_bounds__(512) void stepCoopXPairSumsKernel(FastArgs a) {
+  coopBody<double, PlainExp, false, false, 2, false, true, true>(a);
+}
+template <bool PlainExp, bool Ext>
+__global__ __launch_bounds__(256) void stepCoopNSumsKernel(FastArgs a) {
+  coopBody<double, PlainExp, false, false, 1, true, Ext, true>(a);
+}
+template <bool PlainExp, bool Ext>
+__global__ __launch_bounds__(512) void stepCoopNPairSumsKernel(FastArgs a) {
+  coopBody<double, PlainExp, false, false, 2, true, Ext, true>(a);
+}
 #endif
 
 // (a full-state build of the four-chunk layout was probed in round 4: under its 168-register budget -- twelve
@@ -913,7 +930,17 @@ void launchStepCoop(const FastArgs& a, int precision, int layout, hipStream_t st
     }
 #ifndef SIPNET_COOP_BOUNDED
     const bool pairDiag = pairN && a.full && a.diag != nullptr;
-    if (pairDiag) {
+    if (a.sumEvery > 0) {   // (fp64, lean: the engine asks for nothing else)
+#define NSUMS(K, P, E) hipLaunchKernelGGL((K<P, E>), gridN, blockN, 0, stream, a)
+      if (pairN) {
+        if (a.plainExp) { if (ext) NSUMS(stepCoopNPairSumsKernel, true, true); else NSUMS(stepCoopNPairSumsKernel, true, false); }
+        else { if (ext) NSUMS(stepCoopNPairSumsKernel, false, true); else NSUMS(stepCoopNPairSumsKernel, false, false); }
+      } else {
+        if (a.plainExp) { if (ext) NSUMS(stepCoopNSumsKernel, true, true); else NSUMS(stepCoopNSumsKernel, true, false); }
+        else { if (ext) NSUMS(stepCoopNSumsKernel, false, true); else NSUMS(stepCoopNSumsKernel, false, false); }
+      }
+#undef NSUMS
+    } else if (pairDiag) {
       if (ext) { NCYC_LAUNCH(stepCoopNXPairDiagKernel) } else { NCYC_LAUNCH(stepCoopNPairDiagKernel) }
     } else if (ext && a.full) {
       if (pairN) { NCYC_LAUNCH(stepCoopNXPairFullKernel) } else { NCYC_LAUNCH(stepCoopNXFullKernel) }
@@ -930,6 +957,10 @@ void launchStepCoop(const FastArgs& a, int precision, int layout, hipStream_t st
     }
 #undef NCYC_LAUNCH
     if (info) {
+      if (a.sumEvery > 0)
+        snprintf(info->kernel, sizeof info->kernel, "%s<%s, %s>", pairN ? "stepCoopNPairSumsKernel" : "stepCoopNSumsKernel",
+                 a.plainExp ? "true" : "false", ext ? "true" : "false");
+      else
       snprintf(info->kernel, sizeof info->kernel, "%s<%s, %s>",
                (pairN && a.full && a.diag) ? (ext ? "stepCoopNXPairDiagKernel" : "stepCoopNPairDiagKernel")
                : (ext && a.full) ? (pairN ? "stepCoopNXPairFullKernel" : "stepCoopNXFullKernel")
@@ -966,7 +997,18 @@ void launchStepCoop(const FastArgs& a, int precision, int layout, hipStream_t st
   }
 #endif
 #ifndef SIPNET_COOP_BOUNDED
-  if (a.sumEvery > 0) {   // (the engine sends fp64, default-physics, lean launches of these three layouts only)
+  if (a.sumEvery > 0 && ext) {   // (the engine sends fp64, lean launches of these three layouts only)
+    if (pair) {
+      if (a.plainExp) hipLaunchKernelGGL((stepCoopXPairSumsKernel<true>), grid, block, 0, stream, a);
+      else hipLaunchKernelGGL((stepCoopXPairSumsKernel<false>), grid, block, 0, stream, a);
+    } else if (ringInLds) {
+      if (a.plainExp) hipLaunchKernelGGL((stepCoopXSumsKernel<true, true>), grid, block, 0, stream, a);
+      else hipLaunchKernelGGL((stepCoopXSumsKernel<false, true>), grid, block, 0, stream, a);
+    } else {
+      if (a.plainExp) hipLaunchKernelGGL((stepCoopXSumsKernel<true, false>), grid, block, 0, stream, a);
+      else hipLaunchKernelGGL((stepCoopXSumsKernel<false, false>), grid, block, 0, stream, a);
+    }
+  } else if (a.sumEvery > 0) {
     if (pair) {
       if (a.plainExp) hipLaunchKernelGGL((stepCoopPairSumsKernel<true>), grid, block, 0, stream, a);
       else hipLaunchKernelGGL((stepCoopPairSumsKernel<false>), grid, block, 0, stream, a);
@@ -1020,8 +1062,8 @@ void launchStepCoop(const FastArgs& a, int precision, int layout, hipStream_t st
     const char* r = precision == SIPNET_F64 ? "double" : "float";
     const char* pe = a.plainExp ? "true" : "false";
     const char* fu = a.full ? "true" : "false";
-    if (a.sumEvery > 0 && pair) snprintf(info->kernel, sizeof info->kernel, "stepCoopPairSumsKernel<%s>", pe);
-    else if (a.sumEvery > 0) snprintf(info->kernel, sizeof info->kernel, "stepCoopSumsKernel<%s, %s>", pe, ringInLds ? "true" : "false");
+    if (a.sumEvery > 0 && pair) snprintf(info->kernel, sizeof info->kernel, "stepCoop%sPairSumsKernel<%s>", ext ? "X" : "", pe);
+    else if (a.sumEvery > 0) snprintf(info->kernel, sizeof info->kernel, "stepCoop%sSumsKernel<%s, %s>", ext ? "X" : "", pe, ringInLds ? "true" : "false");
     else if (ext && quad) snprintf(info->kernel, sizeof info->kernel, "stepCoopXQuadKernel<float, %s>", pe);
     else if (ext && pair) snprintf(info->kernel, sizeof info->kernel, "stepCoopXPairKernel<%s, %s, %s>", r, pe, fu);
     else if (ext) snprintf(info->kernel, sizeof info->kernel, "stepCoopXKernel<%s, %s, %s, %s>", r, pe, ringInLds ? "true" : "false", fu);

@@ -59,6 +59,18 @@ def instantiation(demangled):
     if m:
         return dict(kernel="stepCoopPairSumsKernel", R="double", plain_exp=m.group(1) == "true", ring_lds=False, full=False, NP=2,
                     ncyc=False, ext=False)
+    m = re.match(r"void sipnet::stepCoopXSumsKernel<(\w+), (\w+)>", demangled)
+    if m:
+        return dict(kernel="stepCoopXSumsKernel", R="double", plain_exp=m.group(1) == "true", ring_lds=m.group(2) == "true", full=False,
+                    NP=1, ncyc=False, ext=True)
+    m = re.match(r"void sipnet::stepCoopXPairSumsKernel<(\w+)>", demangled)
+    if m:
+        return dict(kernel="stepCoopXPairSumsKernel", R="double", plain_exp=m.group(1) == "true", ring_lds=False, full=False, NP=2,
+                    ncyc=False, ext=True)
+    m = re.match(r"void sipnet::stepCoopN(Pair)?SumsKernel<(\w+), (\w+)>", demangled)
+    if m:
+        return dict(kernel="stepCoopN%sSumsKernel" % (m.group(1) or ""), R="double", plain_exp=m.group(2) == "true", ring_lds=False,
+                    full=False, NP=2 if m.group(1) else 1, ncyc=True, ext=m.group(3) == "true")
     m = re.match(r"void sipnet::(?:bounded::)?(stepCoop\w*Kernel)<(\w+), (\w+)(?:, (\w+))?(?:, (\w+))?>", demangled)
     if not m:
         return None

@@ -104,10 +104,60 @@ def test_daily_sums_against_the_oracle_and_general_exponents(base):
     np.testing.assert_allclose(got[:, :, :8], ref_sums, rtol=0, atol=1e-9)
 
 
+NCYC = dict(litterPool=1, anaerobic=1, nitrogenCycle=1)
+FLAG_SETS = {"russell_3": dict(growthResp=1, leafWater=1, litterPool=1, waterHResp=0), "anaerobic_litter": dict(anaerobic=1, litterPool=1),
+             "nitrogen": NCYC, "everything": dict(carbonSaturation=1, flooding=1, growthResp=1, leafWater=1, **NCYC)}
+
+
+@pytest.mark.parametrize("which", sorted(FLAG_SETS))
+@pytest.mark.parametrize("sites,kernel_prefix", [(1, ""), (4, "Pair")], ids=["one-chunk", "two-chunk"])
+def test_sums_of_the_optional_physics_and_nitrogen_cycle_layouts(which, sites, kernel_prefix):
+    """the same for every physics family that has cooperative kernels: the optional-physics instantiations (stepCoopXSumsKernel,
+    stepCoopXPairSumsKernel) and the nitrogen-cycle layouts, whose SOIL wave forms NEE and therefore sums it (stepCoopNSumsKernel,
+    stepCoopNPairSumsKernel; "everything": with the other options on top) -- events, split launches, a group length that does
+    not divide the run: bit for bit against the same batch's planes added up in step order"""
+    import ctypes as C
+    from sipnet_amd._lib import Event
+    flags = sa.flags_from(**FLAG_SETS[which])
+    base = sa.read_params(os.path.join(helpers.REPO, "sipnet_amd", "data", "allflags_forest.param"), flags)[0]
+    M, T = 64 * 2 + 9, 48 * 6 + 5
+    clims = [synth.convert_raw(synth.round_like_file(synth.half_hourly_year_raw(T, site=s))) for s in range(sites)]
+    members = synth.perturbed_params(base, M, seed=13)
+    ev = [Event(type=t, year=int(clims[0].year[48 * d]), day=int(clims[0].day[48 * d]), pad=0, p=(C.c_double * 4)(*p))
+          for t, d, p in ((4, 1, (0.5, 0, 0, 0)), (2, 2, (1.5, 1.0, 0, 0)), (0, 3, (1.0, 5.0, 2.0, 0.0)))]       # tillage, irrigation, fertiliser
+    ncyc = "nitrogenCycle" in FLAG_SETS[which]
+    kernel = (sa.KERNEL_COOP_NCYCLE_PAIR if ncyc else sa.KERNEL_COOP_PAIR) if kernel_prefix else sa.KERNEL_AUTO
+
+    def make():
+        b = sa.Batch(flags, sites, M, sa.F64, fast_math=True, kernel=kernel)
+        for s_ in range(sites):
+            b.set_events(s_, ev)
+        b.set_climates(clims)
+        b.set_params(None, members)
+        b.setup()
+        return b
+
+    ref = make()
+    planes, _ = ref.run(0, T)
+    want = planes.cpu().numpy()
+    assert (ref.get_status() == 0).all()
+    state = ref.get_state()
+    ref.close()
+    for k, cuts in ((48, [0, 96, T]), (7, [0, 70, T])):
+        b = make()
+        assert b.sums_in_kernel()
+        got = np.concatenate([b.run_sums(a, z - a, k).cpu().numpy() for a, z in zip(cuts[:-1], cuts[1:])], axis=1)
+        name = b.last_launch()["kernel"]
+        assert name.startswith("stepCoop%s%sSumsKernel" % ("N" if ncyc else "X", kernel_prefix)), name
+        np.testing.assert_array_equal(got, host_sums(want, k))
+        np.testing.assert_array_equal(b.get_state(), state)
+        b.close()
+
+
 def test_batches_without_such_a_kernel_say_so(base):
     clim = synth.convert_raw(synth.round_like_file(synth.half_hourly_year_raw(96)))
     for kw in (dict(prec=sa.F32_MIXED), dict(prec=sa.F64, fast_math=False), dict(prec=sa.F64, fast_math=True, kernel=sa.KERNEL_ONE_WAVE),
-               dict(prec=sa.F64, fast_math=True, flags=sa.flags_from(litterPool=1))):
+               dict(prec=sa.F64, fast_math=True, kernel=sa.KERNEL_COOP_QUAD)):
         prec = kw.pop("prec")
         flags = kw.pop("flags", sa.flags_from())
         b = sa.Batch(flags, 1, 64, prec, **kw)

@@ -15,3 +15,5 @@ N=${5:-400} SEED=100507 run ragged_coop FUZZ_COOP=1 FUZZ_BOUNDED=1 FUZZ_RAGGED=1
 # round 6: the in-kernel sums (sipnet_batch_run_sums) on the cooperative layouts, bit for bit against the trial's own planes
 N=${6:-600} SEED=100608 run coop_sums FUZZ_COOP=1 FUZZ_SUMS=1
 N=${7:-300} SEED=100609 run ragged_coop_sums FUZZ_COOP=1 FUZZ_SUMS=1 FUZZ_RAGGED=1
+N=${8:-400} SEED=100610 run opt_sums FUZZ_R5=1 FUZZ_OPT=1 FUZZ_SUMS=1
+N=${9:-400} SEED=100611 run ncyc_sums FUZZ_R5=1 FUZZ_NCYC=1 FUZZ_SUMS=1
