@@ -305,10 +305,35 @@ def lib():
     return _lib
 
 
+def _strip_comments(text):
+    """C / C++ source without its comments and with runs of white space collapsed (string and character literals kept as they
+    are): what the compiler sees of it, near enough -- a comment edit must not make a committed counter profile look stale"""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c in "\"'":                                   # a literal: copy up to the closing quote
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1])
+            i = j + 1
+        elif text.startswith("//", i):
+            j = text.find("\n", i)
+            i = n if j < 0 else j
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+            out.append(" ")
+        else:
+            out.append(c)
+            i += 1
+    return " ".join("".join(out).split())
+
+
 def kernel_source_sha16():
-    """sha256 (first 16 hex digits) of the device sources the step kernels are built from: stamped into
-    profiles/pmc_traffic.json by the profiling target and checked by bench.py, so that a counter collected on an
-    older kernel is not quoted under a fresh kernel time"""
+    """sha256 (first 16 hex digits) of the device sources the step kernels are built from -- comments and white space
+    left out --: stamped into profiles/pmc_traffic.json by the profiling target and checked by bench.py, so that a counter
+    collected on an older kernel is not quoted under a fresh kernel time"""
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(_HERE, "csrc")
@@ -317,7 +342,7 @@ def kernel_source_sha16():
                  "coop_wave_factor.inc", "coop_wave_light.inc", "coop_wave_soil.inc", "coop_wave_water.inc", "step_kernel.h",
                  "fast_math.h", "coop_probes.h", "plan.h"):
         h.update(name.encode())
-        h.update(open(os.path.join(csrc, name), "rb").read())
+        h.update(_strip_comments(open(os.path.join(csrc, name), "r", errors="replace").read()).encode())
     return h.hexdigest()[:16]
 
 
