@@ -280,7 +280,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fill-probe", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
-    ap.add_argument("--gather", default="stats", choices=["stats", "full", "none"])
+    ap.add_argument("--gather", default="stats", choices=["stats", "sums", "full", "none"],
+                    help="N > 1, what every rank all-gathers per pass: stats = the ensemble statistics block (default), sums = "
+                         "every member's NEE/GPP/ET sums over --sum-steps steps, summed inside the step kernel's launch "
+                         "(sipnet_batch_run_sums) and gathered under the next pass, full = the member-resolved planes")
+    ap.add_argument("--sum-steps", type=int, default=48, help="--gather sums: steps per group (48 = daily sums of a half-hourly year)")
     ap.add_argument("--dump-stats", default="",
                     help="rank 0 writes the whole ensemble's statistics block [3][T][sites][2] (sum, sum of "
                          "squares over ALL ranks' members) of the last pass to this .npy file")
@@ -426,9 +430,18 @@ def main():
     # N > 1, statistics gather: the ensemble statistics of pass k come out of the step kernel's own
     # launch (sipnet_batch_run_stats); their all-gather runs on a side stream under the step kernel
     # of pass k+1, which writes the other of two output-plane / statistics buffers
-    overlap = distd and args.gather == "stats" and not wl.get("pf")
+    overlap = distd and args.gather in ("stats", "sums") and not wl.get("pf")
     side = torch.cuda.Stream(device=b.device) if distd else None
-    if overlap:
+    sum_groups = (T + args.sum_steps - 1) // args.sum_steps
+    if overlap and args.gather == "sums":
+        if not b.sums_in_kernel():
+            raise SystemExit("--gather sums: this batch's kernel has no in-launch sums (fp64 throughput kernels up to two chunks per "
+                             "CU have); the C host's sipnet_node_run_gathering_reduced sums such planes on its second stream")
+        bufs = [dict(sums=torch.empty((3, sum_groups, b.ncol), dtype=torch.float64, device=b.device),
+                     gathered=torch.empty((world, 3, sum_groups, b.ncol), dtype=torch.float64, device=b.device),
+                     ran=torch.cuda.Event(), done=None) for _ in range(2)]
+        npass = [0]
+    elif overlap:
         planes2, _ = b.alloc_outputs(T)
         stats2 = torch.empty_like(stats)
         gathered2 = torch.empty_like(gathered)
@@ -490,11 +503,14 @@ def main():
             b.setup()
             # the step kernel leaves the per-(step, site) sums behind (its light wave adds up the
             # plane tiles while they are in L2; sipnet_batch_run_stats) ...
-            b.run_stats(0, T, planes=buf["planes"], stats=buf["stats"])
+            if args.gather == "sums":   # ... or every member's daily sums (no planes are written at all)
+                b.run_sums(0, T, args.sum_steps, out=buf["sums"])
+            else:
+                b.run_stats(0, T, planes=buf["planes"], stats=buf["stats"])
             buf["ran"].record(main)
-            with torch.cuda.stream(side):   # ... and the 0.84 MB block travels under the next pass
+            with torch.cuda.stream(side):   # ... and the block (0.84 MB of statistics / 90 MB of c10k's daily sums) travels under the next pass
                 side.wait_event(buf["ran"])
-                all_gather_into(buf["gathered"], buf["stats"])
+                all_gather_into(buf["gathered"], buf["sums" if args.gather == "sums" else "stats"])
                 buf["done"] = torch.cuda.Event()
                 buf["done"].record(side)
             return
@@ -588,7 +604,9 @@ def main():
                          "predicted_weak_scaling_efficiency": dtp / dt,
                          "backend": dist.get_backend(), "world": world,
                          "note": "K passes with the exchange path of an N-rank run (RCCL group, "
-                                 + ("side-stream ensemble statistics + all-gather of the statistics block under the next pass's step kernel"
+                                 + ("every member's sums over %d steps from the step kernel's own launch + all-gather of that block under the next pass's step kernel" % args.sum_steps
+                                    if overlap and args.gather == "sums" else
+                                    "side-stream ensemble statistics + all-gather of the statistics block under the next pass's step kernel"
                                     if overlap else ("the particle filter's ONE all-gather of log-weight blocks + peer-read resampling" if pf_exchange == "peer"
                                                      else "the particle filter's all-gather of log-weights + all-to-all of checkpoints") if pf
                                     else f"gather={args.gather} in line")
@@ -672,6 +690,41 @@ def main():
                        "bytes_received_per_rank": int((world - 1) * 3 * T * b.ncol * planes.element_size()),
                        "note": "one pass with the member-resolved planes of every rank all-gathered "
                                "(segment k travels under the kernel of segment k+1)"}
+
+    # ... and the member-resolved form that fits under the kernel: every member's sums over --sum-steps steps (daily sums of a
+    # half-hourly year: 1 / 48 of the planes' bytes), summed inside the step kernel's launch (sipnet_batch_run_sums) in 4 segments,
+    # segment k's block travelling on the side stream while segment k+1 computes; checked against the planes of the pass above
+    gather_sums = None
+    if distd and not pf and b.sums_in_kernel():
+        K, nseg = args.sum_steps, min(4, sum_groups)
+        gcuts = [sum_groups * k // nseg for k in range(nseg + 1)]
+        seg_out = [torch.empty((3, z - a, b.ncol), dtype=torch.float64, device=b.device) for a, z in zip(gcuts[:-1], gcuts[1:])]
+        seg_all = [torch.empty((world,) + tuple(o.shape), dtype=torch.float64, device=b.device) for o in seg_out]
+        for timed_leg in (False, True):     # (once untimed: RCCL's first collective of a new size, the sums kernel's first launch)
+            barrier()
+            main = torch.cuda.current_stream()
+            tg0 = time.perf_counter()
+            b.setup()
+            for k, (a, z) in enumerate(zip(gcuts[:-1], gcuts[1:])):
+                b.run_sums(a * K, min(z * K, T) - a * K, K, out=seg_out[k])
+                ran = torch.cuda.Event()
+                ran.record(main)
+                with torch.cuda.stream(side):
+                    side.wait_event(ran)
+                    all_gather_into(seg_all[k], seg_out[k])
+            barrier()
+            tg = time.perf_counter() - tg0
+        tmax = torch.tensor([tg], dtype=torch.float64, device="cpu" if args.rehearse else b.device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        whole = T // K * K
+        ref = planes[:, :whole].double().reshape(3, whole // K, K, b.ncol).sum(2)
+        mine = torch.cat([g[rank] for g in seg_all], dim=1)[:, :whole // K]
+        gather_sums = {"ms": float(tmax.item()) * 1e3, "segments": nseg, "sum_steps": K, "kernel": b.last_launch()["kernel"],
+                       "bytes_received_per_rank": int((world - 1) * 3 * sum_groups * b.ncol * 8),
+                       "bytes_sent_per_rank": int(3 * sum_groups * b.ncol * 8),
+                       "max_abs_diff_vs_planes": float((mine - ref).abs().max().item()),
+                       "note": "one pass with every member's sums over sum_steps steps, summed inside the step kernel's launch, "
+                               "all-gathered from every rank (segment k travels under the kernel of segment k+1)"}
 
     if args.dump_stats and not pf:
         if distd and args.gather == "stats":
@@ -844,6 +897,7 @@ def main():
                        "parallelism": f"ensemble-sharded x{world}",
                        "ranks_seen": ranks_seen, "devices_seen": devices_seen, "device_ids": device_ids,
                        **({"gather_full": gather_full} if gather_full else {}),
+                       **({"gather_sums": gather_sums} if gather_sums else {}),
                        **({"particle_filter": pf_info} if pf else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,

@@ -42,8 +42,10 @@ for R in "$@"; do
       done ;;
     force_dist)
       : > $O/force_dist.jsonl
-      for wl in c10k c4 c3 c5 c5p8 c2x16 c10kn c4n c10kr3; do
+      for wl in c10k c10ksums c4 c4sums c3 c5 c5p8 c2x16 c10kn c4n c10kr3; do
         steps=10; warm=2; extra=""; w=$wl
+        [ "$wl" = c10ksums ] && w=c10k && extra="--gather sums"   # (every member's daily sums from the kernel's own launch, gathered under the next pass)
+        [ "$wl" = c4sums ] && w=c4 && extra="--gather sums"
         [ "$wl" = c5 ] && steps=400 && warm=40   # (a 0.15 ms cycle: RCCL's first-collective costs need a real warm-up)
         [ "$wl" = c5p8 ] && steps=400 && warm=40 && extra="--pretend-world 8" && w=c5
         timeout 900 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 \
@@ -59,7 +61,8 @@ for line in open(sys.argv[1]):
     pf = j["config"].get("particle_filter", {})
     print(j["config"]["workload"][:30], "pretend", pf.get("pretend_world"), "| dist %.4f plain %.4f overhead %.4f ms eff %.3f | gather_full %s | crossing/cycle %s slots %s" % (
         d.get("ms_per_step_dist", -1), d.get("ms_per_step_plain", -1), d.get("dist_overhead_ms", -1),
-        d.get("predicted_weak_scaling_efficiency", -1), (j["config"].get("gather_full") or {}).get("ms"), pf.get("crossing_per_cycle"), pf.get("analysis_slots")))
+        d.get("predicted_weak_scaling_efficiency", -1), (j["config"].get("gather_full") or {}).get("ms"), pf.get("crossing_per_cycle"), pf.get("analysis_slots")),
+          "| gather", j["config"].get("gather"), "gather_sums", {k: v for k, v in (j["config"].get("gather_sums") or {}).items() if k in ("ms", "max_abs_diff_vs_planes", "kernel")})
 PY
       ;;
     pf)

@@ -7,7 +7,8 @@
 #   2. `python3 bench.py --gpus N` for N = 1, 2, 4, 8 -- bench.py starts its own ranks (torch.distributed.run as a child;
 #      what the driver's SCALE run does) -- for c10k, c4, c5: the contract's lines (statistics exchange / peer-read filter)
 #   3. the north star's exchange as written: `--gather full` (the member-resolved planes, one all-gather after the pass)
-#      and its segmented-overlap measurement (config.gather_full of the default line) at N = max
+#      and its segmented-overlap measurement (config.gather_full of the default line) at N = max; `--gather sums` (every
+#      member's daily sums out of the step kernel's own launch, gathered under the next pass) at every N
 #   4. c5 with `--pf-exchange alltoall` at N = max (the fallback for ranks that cannot map each other's HBM)
 #   5. the C host (sipnet_node_*: one process, one thread + one RCCL rank per GPU): node_consumer (statistics + planes +
 #      the reduced member-resolved gather), pf_consumer (config 5's cycle), at N = 1, 2, 4, 8 with per-GPU work fixed
@@ -46,6 +47,9 @@ for wl in c10k c4 c5; do
 done
 # 3. the member-resolved planes, gathered after the pass (the default line's config.gather_full is the overlapped variant)
 [ "$MAX" -ge 2 ] && for wl in c10k c4; do line ${wl}_full_n$MAX --workload $wl --gpus $MAX --steps 10 --warmup 2 --gather full; done
+# 3b. the member-resolved exchange that fits under the kernel: every member's daily sums from the step kernel's own launch,
+#     all-gathered under the next pass (90 MB per rank and year at c10k) -- at every N, for a curve of its own
+for wl in c10k c4; do for n in $NS; do [ "$n" -ge 2 ] && line ${wl}_sums_n$n --workload $wl --gpus $n --steps 20 --warmup 3 --gather sums; done; done
 # 4. the filter's all-to-all fallback
 [ "$MAX" -ge 2 ] && line c5_alltoall_n$MAX --workload c5 --gpus $MAX --steps 400 --warmup 40 --pf-exchange alltoall
 
@@ -78,7 +82,8 @@ import json, os, sys
 O = sys.argv[1]
 rows = [json.loads(l) for l in open(os.path.join(O, "scale_lines.jsonl"))]
 base = {}
-out = ["| leg | N | value (%s) | ms / pass | efficiency vs N = 1 | ranks_seen | devices_seen | rc |" % "ensemble-site-timesteps/s", "|---|---|---|---|---|---|---|---|"]
+out = ["| leg | N | value (%s) | ms / pass | efficiency vs N = 1 | ranks_seen | devices_seen | rc | exchange per pass | planes gathered, overlapped (ms) | daily sums gathered, overlapped (ms) |" % "ensemble-site-timesteps/s",
+       "|---|---|---|---|---|---|---|---|---|---|---|"]
 for d in rows:
     if d.get("failed"):
         out.append("| %s | | FAILED | | | | | %s |" % (d["leg"], d["rc"]))
@@ -89,8 +94,10 @@ for d in rows:
         base[wl] = d["value"]
     eff = d["value"] / (n * base[wl]) if wl in base else float("nan")
     c = d["config"]
-    out.append("| %s | %d | %.4g | %.4f | %.3f | %s | %s | %s |" % (d["leg"], n, d["value"], d["ms_per_step"], eff, c.get("ranks_seen"),
-                                                                 c.get("devices_seen"), d["rc"]))
+    ms = lambda k: ("%.2f" % c[k]["ms"]) if c.get(k) else ""
+    out.append("| %s | %d | %.4g | %.4f | %.3f | %s | %s | %s | %s | %s | %s |" % (
+        d["leg"], n, d["value"], d["ms_per_step"], eff, c.get("ranks_seen"), c.get("devices_seen"), d["rc"],
+        (c.get("particle_filter") or {}).get("exchange") or c.get("gather", ""), ms("gather_full"), ms("gather_sums")))
 for n in (1, 2, 4, 8):
     for f in ("node_consumer", "pf_consumer"):
         p = os.path.join(O, "%s_n%d.log" % (f, n))
