@@ -1175,16 +1175,17 @@ int sipnet_batch_run_debug(sipnet_batch* b, int32_t step0, int32_t n_steps, doub
   return runImpl(b, step0, n_steps, nullptr, nullptr, nullptr, d_rec, d_dbg, ld, hip_stream);
 }
 
-// Which cooperative kernel sums a batch's outputs over groups of steps inside its own launch (sipnet_batch_run_sums): fp64,
-// throughput arithmetic, any flag set, no record / diagnostics / full state, at most two chunks per CU -- AUTO's choice for
-// such a shape, or one of those layouts forced.  0: none.
+// Which cooperative kernel sums a batch's outputs over groups of steps inside its own launch (sipnet_batch_run_sums):
+// throughput arithmetic (fp64 or fp32-mixed), any flag set, no record / diagnostics / full state, a cooperative layout -- AUTO's
+// choice for the shape, or one of those layouts forced.  0: none (the one-wavefront and strict kernels).
 static int sumsKernelFor(const sipnet_batch* b) {
-  if (b->precision != SIPNET_F64 || !b->fastMath || b->d_diag || (b->kernelOptions & SIPNET_KOPT_FULL_STATE)) return 0;
+  if (!b->fastMath || b->d_diag || (b->kernelOptions & SIPNET_KOPT_FULL_STATE)) return 0;
   int kernel = b->kernelPolicy;
   if (kernel == SIPNET_KERNEL_AUTO) kernel = autoKernel(b->flags, b->n_sites, b->n_members, true, false, 0, b->numCUs, false);
   const bool ncyc = b->flags[SIPNET_F_NITROGEN_CYCLE] != 0;
   if (ncyc) return (kernel == SIPNET_KERNEL_COOP_NCYCLE || kernel == SIPNET_KERNEL_COOP_NCYCLE_PAIR) ? kernel : 0;
-  return (kernel == SIPNET_KERNEL_COOP_LDS || kernel == SIPNET_KERNEL_COOP_HBM || kernel == SIPNET_KERNEL_COOP_PAIR) ? kernel : 0;
+  return (kernel == SIPNET_KERNEL_COOP_LDS || kernel == SIPNET_KERNEL_COOP_HBM || kernel == SIPNET_KERNEL_COOP_PAIR ||
+          kernel == SIPNET_KERNEL_COOP_QUAD) ? kernel : 0;   // (a forced four-chunk layout the batch cannot take: the launch path says so)
 }
 int32_t sipnet_batch_sums_in_kernel(const sipnet_batch* b) { return b ? (sumsKernelFor(b) != 0) : 0; }
 
@@ -1195,8 +1196,8 @@ int sipnet_batch_run_sums(sipnet_batch* b, int32_t step0, int32_t n_steps, int32
     return SIPNET_ERR_BAD_ARGUMENT;
   }
   if (!sumsKernelFor(b)) {
-    setError("sipnet_batch_run_sums: no kernel sums this batch's outputs inside its launch (fp64, SIPNET_MATH_FAST, "
-             "no diagnostics / full state, at most two chunks per CU: sipnet_batch_sums_in_kernel); run the planes and sum them");
+    setError("sipnet_batch_run_sums: no kernel sums this batch's outputs inside its launch (SIPNET_MATH_FAST, no diagnostics / "
+             "full state, a shape AUTO gives a cooperative kernel: sipnet_batch_sums_in_kernel); run the planes and sum them");
     return SIPNET_ERR_BAD_ARGUMENT;
   }
   return runImpl(b, step0, n_steps, d_nee_sums, d_gpp_sums, d_et_sums, nullptr, nullptr, ld, hip_stream, nullptr, sum_steps);
@@ -1413,6 +1414,7 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
     boundedWaits = (b->kernelOptions & SIPNET_KOPT_BOUNDED_WAITS) && kernel != SIPNET_KERNEL_ONE_WAVE && !wantFull && !sumEvery;
     if (kernel == SIPNET_KERNEL_ONE_WAVE) launchStepFast(f, b->precision, b->kernelOptions, stream, &b->lastLaunch);
     else if (boundedWaits) bounded::launchStepCoop(f, b->precision, layout, stream, &b->lastLaunch);
+    else if (sumEvery && (b->precision != SIPNET_F64 || layout == COOP_QUAD)) sums2::launchStepCoopSums(f, b->precision, layout, stream, &b->lastLaunch);
     else launchStepCoop(f, b->precision, layout, stream, &b->lastLaunch);
   } else {
     launchStep(a, b->precision, b->fastMath, stream, &b->lastLaunch);

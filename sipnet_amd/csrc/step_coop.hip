@@ -46,6 +46,9 @@ namespace sipnet {
 #ifdef SIPNET_COOP_BOUNDED
 namespace bounded {   // (step_coop_bounded.hip: the same kernels with bounded waits, under names of their own)
 #endif
+#ifdef SIPNET_COOP_SUMS_TU
+namespace sums2 {     // (step_coop_sums.hip: the in-launch sums of the layouts and precisions this file's own launcher does not carry)
+#endif
 namespace {
 
 constexpr int kTileBytes = kFastTile * (int)sizeof(FastRec);
@@ -599,7 +602,8 @@ struct CoopSums {
 };
 template <>
 struct CoopSums<false> {};
-// Sums (round 6; fp64, lean, every physics family, one or two chunks per workgroup): the three output planes receive every member's SUMS over groups of
+// Sums (round 6; lean, every physics family, layout and arithmetic -- this file's launcher carries fp64 on one and two chunks per
+// workgroup, step_coop_sums.hip the rest; the sums are doubles whatever R is): the three output planes receive every member's SUMS over groups of
 // a.sumEvery consecutive steps of the launch instead of the steps themselves -- [groups][ld] each, a row per group, the last
 // group as long as the launch leaves it -- accumulated in step order by the wave that computes the value (one add per value and
 // step, a store per group: 1 / sumEvery of the planes' HBM writes; sipnet_batch_run_sums).  Sums = false compiles to the code
@@ -610,7 +614,8 @@ struct CoopSums<false> {};
 template <class R, bool PlainExp, bool RingLds, bool Full, int NP, bool NCyc = false, bool Ext = false, bool Sums = false, bool PairDiag = false>
 __device__ __forceinline__ void coopBody(const FastArgs& a) {
   static_assert(!PairDiag || (NCyc && Full && NP == 2), "PairDiag: the nitrogen cycle's two-chunk full-state layout");
-  static_assert(!Sums || (!Full && sizeof(R) == 8 && NP <= 2), "in-kernel sums: fp64, lean launches, one or two chunks per workgroup");
+  static_assert(!Sums || !Full, "in-kernel sums: lean launches");
+  using OutT = typename std::conditional<Sums, double, R>::type;   // what the output rows hold: the steps' values, or sums of them (always doubles)
   static_assert(!(NP > 1 && RingLds), "two chunks' rings do not fit one CU's LDS");
   static_assert(!NCyc || (NP <= 2 && !RingLds), "nitrogen-cycle layout: one or two chunks, ring in HBM");
   constexpr bool Opt = Ext && !NCyc;   // the optional pools live on wave C
@@ -880,17 +885,29 @@ __global__ __launch_bounds__(512) void stepCoopNXPairDiagKernel(FastArgs a) {
 }
 #endif
 
-#ifdef SIPNET_HWID
+#ifdef SIPNET_COOP_SUMS_TU
+// every member's sums over groups of a.sumEvery steps (coopBody, Sums) on ANY layout and precision: the output rows are doubles
+// whatever the arithmetic type (an fp32-mixed batch adds its float values up in double, in step order)
+template <class R, bool PlainExp, int Layout, bool Ext>
+__global__ __launch_bounds__(Layout == COOP_RING_LDS ? 256 : Layout == COOP_RING_HBM ? 192 : Layout == COOP_QUAD ? 768
+                             : Layout == COOP_NCYCLE ? 256 : 512) void stepCoopSumsAtKernel(FastArgs a) {
+  constexpr bool N = Layout == COOP_NCYCLE || Layout == COOP_NCYCLE_PAIR;
+  constexpr int NP = (Layout == COOP_PAIR || Layout == COOP_NCYCLE_PAIR) ? 2 : Layout == COOP_QUAD ? 4 : 1;
+  coopBody<R, PlainExp, Layout == COOP_RING_LDS, false, NP, N, Ext, true>(a);
+}
+#endif
+
+#if defined(SIPNET_HWID) && !defined(SIPNET_COOP_SUMS_TU)
 extern "C" int sipnet_debug_read_coop_hwid(unsigned* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_coopHwId), sizeof(unsigned) * 4096 * 4 * 2);
 }
 #endif
-#ifdef SIPNET_WAITS
+#if defined(SIPNET_WAITS) && !defined(SIPNET_COOP_SUMS_TU)
 extern "C" int sipnet_debug_read_coop_waits(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_coopWaits), 16 * sizeof(unsigned long long));
 }
 #endif
-#ifdef SIPNET_STAMPS
+#if defined(SIPNET_STAMPS) && !defined(SIPNET_COOP_SUMS_TU)
 extern "C" int sipnet_debug_read_coop_stamps(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_coopStamps), 8 * sizeof(unsigned long long));
 }
@@ -903,6 +920,52 @@ int readCoopStuck(unsigned long long out[2], hipStream_t stream) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_coopStuck), 2 * sizeof(unsigned long long));
 }
 #endif
+#ifdef SIPNET_COOP_SUMS_TU
+// the sums launches launchStepCoop does not carry itself: fp32-mixed batches on every layout, fp64 on the four-chunk layout
+void launchStepCoopSums(const FastArgs& a, int precision, int layout, hipStream_t stream, LaunchInfo* info) {
+  const int chunksPerSite = (a.n_members + 63) / 64, chunks = a.n_sites * chunksPerSite;
+  const bool nFamily = layout == COOP_NCYCLE || layout == COOP_NCYCLE_PAIR;
+  const bool ext = nFamily ? !isNCycleFlagSet(a.flags) : !isDefaultFlagSet(a.flags);
+  const bool x8 = (a.n_sites & 7) == 0;   // (the XCD-grouped mapping: every group of eight workgroups carries 16 / 32 chunks)
+  const int per = (layout == COOP_PAIR || layout == COOP_NCYCLE_PAIR) ? 2 : layout == COOP_QUAD ? 4 : 1;
+  const int groups = per == 1 ? chunks : x8 ? 8 * ((chunks / 8 + per - 1) / per) : (chunks + per - 1) / per;
+  const int threads = layout == COOP_RING_LDS ? 256 : layout == COOP_RING_HBM ? 192 : layout == COOP_QUAD ? 768 : layout == COOP_NCYCLE ? 256 : 512;
+  const dim3 grid(groups), block(threads);
+#define SUMS_AT(R, L)                                                                                         \
+  {                                                                                                           \
+    if (a.plainExp) { if (ext) hipLaunchKernelGGL((stepCoopSumsAtKernel<R, true, L, true>), grid, block, 0, stream, a);     \
+                      else hipLaunchKernelGGL((stepCoopSumsAtKernel<R, true, L, false>), grid, block, 0, stream, a); }      \
+    else { if (ext) hipLaunchKernelGGL((stepCoopSumsAtKernel<R, false, L, true>), grid, block, 0, stream, a);               \
+           else hipLaunchKernelGGL((stepCoopSumsAtKernel<R, false, L, false>), grid, block, 0, stream, a); }                \
+  }
+  if (precision == SIPNET_F64) {   // (four chunks, default physics: the engine sends nothing else here)
+    if (a.plainExp) hipLaunchKernelGGL((stepCoopSumsAtKernel<double, true, COOP_QUAD, false>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((stepCoopSumsAtKernel<double, false, COOP_QUAD, false>), grid, block, 0, stream, a);
+  } else {
+    switch (layout) {
+      case COOP_RING_LDS: SUMS_AT(float, COOP_RING_LDS) break;
+      case COOP_RING_HBM: SUMS_AT(float, COOP_RING_HBM) break;
+      case COOP_PAIR: SUMS_AT(float, COOP_PAIR) break;
+      case COOP_QUAD: SUMS_AT(float, COOP_QUAD) break;
+      case COOP_NCYCLE: SUMS_AT(float, COOP_NCYCLE) break;
+      default: SUMS_AT(float, COOP_NCYCLE_PAIR) break;
+    }
+  }
+#undef SUMS_AT
+  if (info) {
+    snprintf(info->kernel, sizeof info->kernel, "stepCoopSumsAtKernel<%s, %s, %d, %s>", precision == SIPNET_F64 ? "double" : "float",
+             a.plainExp ? "true" : "false", layout, ext ? "true" : "false");
+    info->grid = (int32_t)grid.x;
+    info->block = threads;
+    info->wavesPerSimd = per == 4 ? 3 : per;
+    const int elem = precision == SIPNET_F64 ? 8 : 4;
+    info->ldsBytes = nFamily ? per * (3 * 2 * kTileBytes + (2 * 64 * 3 + 2 * 7 * 64) * elem + 2 * 64 * 4 + 16 * 4 + 64 * 8 +
+                                      (16 + 2 + 2 + 2 + 12 + 4 + 3 + 1 + 12) * 64 * 8 + 2 * kTileBytes)
+                             : per * (3 * 2 * kTileBytes + (2 * 64 * 3 + 2 * (ext ? 7 : 6) * 64) * elem + 2 * 64 * 4 + 7 * 4) +
+                                   (layout == COOP_RING_LDS ? SIPNET_RING_SLOTS * 64 : 64) * 8;
+  }
+}
+#else
 void launchStepCoop(const FastArgs& a, int precision, int layout, hipStream_t stream, LaunchInfo* info) {
 #ifdef SIPNET_COOP_BOUNDED
   {
@@ -1080,7 +1143,11 @@ void launchStepCoop(const FastArgs& a, int precision, int layout, hipStream_t st
   }
 }
 
+#endif   // !SIPNET_COOP_SUMS_TU
 #ifdef SIPNET_COOP_BOUNDED
 }  // namespace bounded
+#endif
+#ifdef SIPNET_COOP_SUMS_TU
+}  // namespace sums2
 #endif
 }  // namespace sipnet

@@ -71,6 +71,13 @@ def instantiation(demangled):
     if m:
         return dict(kernel="stepCoopN%sSumsKernel" % (m.group(1) or ""), R="double", plain_exp=m.group(2) == "true", ring_lds=False,
                     full=False, NP=2 if m.group(1) else 1, ncyc=True, ext=m.group(3) == "true")
+    # (step_coop_sums.hip: the sums builds of fp32-mixed batches on every layout and of the four-chunk layout; Layout = CoopLayout)
+    m = re.match(r"void sipnet::sums2::stepCoopSumsAtKernel<(\w+), (\w+), (?:\(sipnet::CoopLayout\))?(\d), (\w+)>", demangled)
+    if m:
+        lay = int(m.group(3))
+        return dict(kernel="stepCoopSumsKernel" if lay == 0 and m.group(4) != "true" else "stepCoopSumsAtKernel", R=m.group(1),
+                    plain_exp=m.group(2) == "true", ring_lds=lay == 0, full=False, NP={2: 2, 5: 2, 3: 4}.get(lay, 1), ncyc=lay in (4, 5),
+                    ext=m.group(4) == "true")
     m = re.match(r"void sipnet::(?:bounded::)?(stepCoop\w*Kernel)<(\w+), (\w+)(?:, (\w+))?(?:, (\w+))?>", demangled)
     if not m:
         return None
@@ -270,6 +277,11 @@ def test_scratch_memory_of_the_cooperative_kernels_is_pinned(tmp_path, disassemb
         key = k[len("void sipnet::"):k.rindex("(")] if k.startswith("void sipnet::") else k
         ins = disassembly[[d for d in disassembly if key in d][0]]
         touching = [op for _, op, _, _ in ins if op.startswith("scratch_") or op.startswith("buffer_")]
+        if "stepCoopSumsAtKernel<double" in k:
+            # the fp64 four-chunk sums build (168 registers, three wavefronts per SIMD) keeps ONE dword in scratch: read and written
+            # once per group of steps, where the group's sum is stored (profiles/r06_sums_time.txt: 12.74 ms, the planes' build 12.92)
+            assert v <= 8 and len(touching) <= 8, (k, v, touching)
+            continue
         assert not touching and v <= 64, (k, v, touching[:4])
     assert max(product.values()) <= 64, {k: v for k, v in product.items() if v > 64}
     for k in MEASURED:

@@ -1,6 +1,6 @@
 """sipnet_batch_run_sums: every member's sums of NEE / GPP / ET over groups of k consecutive steps, accumulated inside the
 step kernel's own launch by the wavefront that computes the value (step_coop.hip, coopBody<..., Sums>: stepCoopSumsKernel,
-stepCoopPairSumsKernel) -- against the SAME batch's per-step planes summed on the host in step order: bit for bit, on every
+stepCoopPairSumsKernel; step_coop_sums.hip: fp32-mixed batches and the four-chunk layout) -- against the SAME batch's per-step planes summed on the host in step order: bit for bit, on every
 layout that has such a kernel, with split launches, groups that do not divide the run, ragged chunks, sites of different
 lengths, members with a general VPD exponent, a member that dies and one that never runs; and against the CPU oracle's
 daily sums (1e-9).  What a consumer of the reference's per-step output rows (sipnet.c:453-473) aggregates anyway."""
@@ -154,13 +154,89 @@ def test_sums_of_the_optional_physics_and_nitrogen_cycle_layouts(which, sites, k
         b.close()
 
 
+LAYOUTS = {"lds": (sa.KERNEL_COOP_LDS, 0), "hbm": (sa.KERNEL_COOP_HBM, 1), "pair": (sa.KERNEL_COOP_PAIR, 2), "quad": (sa.KERNEL_COOP_QUAD, 3),
+           "n": (sa.KERNEL_COOP_NCYCLE, 4), "npair": (sa.KERNEL_COOP_NCYCLE_PAIR, 5)}
+
+
+@pytest.mark.parametrize("prec,layout,which", [
+    (sa.F32_MIXED, "lds", None), (sa.F32_MIXED, "hbm", None), (sa.F32_MIXED, "pair", None), (sa.F32_MIXED, "quad", None), (sa.F64, "quad", None),
+    (sa.F32_MIXED, "lds", "russell_3"), (sa.F32_MIXED, "pair", "anaerobic_litter"), (sa.F32_MIXED, "quad", "russell_3"),
+    (sa.F32_MIXED, "n", "nitrogen"), (sa.F32_MIXED, "npair", "nitrogen"), (sa.F32_MIXED, "n", "everything"), (sa.F32_MIXED, "npair", "everything")],
+    ids=lambda v: v if isinstance(v, str) else ("default" if v is None else ("f64" if v == sa.F64 else "f32mixed")))
+def test_sums_of_fp32_mixed_batches_and_of_the_four_chunk_layout(prec, layout, which):
+    """step_coop_sums.hip (stepCoopSumsAtKernel): the in-launch sums of fp32-mixed batches on every layout and family and of fp64
+    batches on the four-chunk layout.  The sums are DOUBLES whatever the arithmetic type: a float value is widened and added in step
+    order -- bit for bit the same batch's planes added up that way on the host; ragged chunks, three sites of different lengths,
+    split launches, a group length that does not divide the run"""
+    flags = sa.flags_from(**(FLAG_SETS[which] if which else {}))
+    base = sa.read_params(os.path.join(helpers.REPO, "sipnet_amd", "data", "allflags_forest.param" if which else "base_forest.param"), flags)[0]
+    M, T = 64 * 3 + 17, 48 * 5 + 11
+    clims = [synth.convert_raw(synth.round_like_file(synth.half_hourly_year_raw(T, site=s))) for s in range(3)]
+    clims[2] = clims[2].slice(0, T - 40)
+    members = synth.perturbed_params(base, M, seed=21)
+    if not which:
+        members[7, pi("dVpdExp")] = 1.6                      # the general-exponent instantiations
+    kernel, code = LAYOUTS[layout]
+
+    def make():
+        b = sa.Batch(flags, 3, M, prec, fast_math=True if prec == sa.F64 else None, kernel=kernel)
+        b.set_climates(clims)
+        b.set_params(None, members)
+        b.setup()
+        return b
+
+    ref = make()
+    planes, _ = ref.run(0, T)
+    assert (ref.get_status() == 0).all()
+    want = planes.double().cpu().numpy()
+    want[:, T - 40:, 2 * M:] = 0.0
+    state = ref.get_state()
+    ref.close()
+    for k, cuts in ((48, [0, 96, T]), (7, [0, 7 * 11, T]), (T, [0, T])):
+        b = make()
+        assert b.sums_in_kernel()
+        got = np.concatenate([b.run_sums(a, z - a, k).cpu().numpy() for a, z in zip(cuts[:-1], cuts[1:])], axis=1)
+        name = b.last_launch()["kernel"]
+        assert name.startswith("stepCoopSumsAtKernel<%s, " % ("double" if prec == sa.F64 else "float")) and name.endswith(
+            ", %d, %s>" % (code, "true" if which in ("russell_3", "anaerobic_litter", "everything") else "false")), name
+        ws = host_sums(want, k)
+        g_end = (T - 40 + k - 1) // k
+        np.testing.assert_array_equal(got[:, :, :2 * M], ws[:, :, :2 * M])
+        np.testing.assert_array_equal(got[:, :g_end, 2 * M:], ws[:, :g_end, 2 * M:])
+        np.testing.assert_array_equal(b.get_state(), state)
+        b.close()
+
+
+def test_fp32_mixed_daily_sums_against_the_oracle(base):
+    """... and against the CPU oracle's daily sums, within what fp32-mixed arithmetic leaves of a day's sum of 48 half-hourly fluxes"""
+    M, T, K = 64 * 4 * 4, 48 * 6, 48
+    clim = synth.convert_raw(synth.round_like_file(synth.half_hourly_year_raw(T)))
+    members = synth.perturbed_params(base, M, seed=5)
+    b = sa.Batch(sa.flags_from(), 1, M, sa.F32_MIXED, kernel=sa.KERNEL_COOP_QUAD)
+    b.set_climate(0, clim)
+    b.set_params(0, members)
+    b.setup()
+    got = b.run_sums(0, T, K).cpu().numpy()
+    assert b.last_launch()["kernel"] == "stepCoopSumsAtKernel<float, true, 3, false>"
+    b.close()
+    ora = helpers.load_oracle()
+    pick = [0, 63, 64, 500, M - 1]
+    ref, _, st = ora.run_block(sa.flags_from(), members[pick], clim)
+    assert (st == 0).all()
+    ref_sums = np.stack([ref[:, g * K:(g + 1) * K].sum(axis=1) for g in range(T // K)], axis=1)
+    np.testing.assert_allclose(got[:, :, pick], ref_sums, rtol=2e-4, atol=2e-4)
+
+
 def test_batches_without_such_a_kernel_say_so(base):
     clim = synth.convert_raw(synth.round_like_file(synth.half_hourly_year_raw(96)))
-    for kw in (dict(prec=sa.F32_MIXED), dict(prec=sa.F64, fast_math=False), dict(prec=sa.F64, fast_math=True, kernel=sa.KERNEL_ONE_WAVE),
-               dict(prec=sa.F64, fast_math=True, kernel=sa.KERNEL_COOP_QUAD)):
+    for kw in (dict(prec=sa.F32_MIXED, kernel=sa.KERNEL_ONE_WAVE), dict(prec=sa.F64, fast_math=False), dict(prec=sa.F64, fast_math=True, kernel=sa.KERNEL_ONE_WAVE),
+               dict(prec=sa.F64, fast_math=True, diagnostics=True)):
         prec = kw.pop("prec")
         flags = kw.pop("flags", sa.flags_from())
+        diag = kw.pop("diagnostics", False)
         b = sa.Batch(flags, 1, 64, prec, **kw)
+        if diag:
+            b.enable_diagnostics()
         b.set_climate(0, clim)
         b.set_params(0, base)
         b.setup()

@@ -42,10 +42,11 @@ for R in "$@"; do
       done ;;
     force_dist)
       : > $O/force_dist.jsonl
-      for wl in c10k c10ksums c4 c4sums c3 c5 c5p8 c2x16 c10kn c4n c10kr3; do
+      for wl in c10k c10ksums c4 c4sums c3 c3sums c5 c5p8 c2x16 c10kn c4n c10kr3; do
         steps=10; warm=2; extra=""; w=$wl
         [ "$wl" = c10ksums ] && w=c10k && extra="--gather sums"   # (every member's daily sums from the kernel's own launch, gathered under the next pass)
         [ "$wl" = c4sums ] && w=c4 && extra="--gather sums"
+        [ "$wl" = c3sums ] && w=c3 && extra="--gather sums"
         [ "$wl" = c5 ] && steps=400 && warm=40   # (a 0.15 ms cycle: RCCL's first-collective costs need a real warm-up)
         [ "$wl" = c5p8 ] && steps=400 && warm=40 && extra="--pretend-world 8" && w=c5
         timeout 900 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 \
@@ -97,6 +98,18 @@ PY
       for wl in c3 c5 c4; do bash tools/gpu_pmc_branch.sh $wl > /dev/null 2>&1; cp gpurun_out/pmc_branch_$wl.txt $O/; done
       for wl in c4 c2x16 c10k; do for who in dev host; do timeout 600 python3 tools/e2e_breakdown.py $wl $who 2>&1 | grep -v amdgpu > $O/e2e_${wl}_$who.txt; done; done
       timeout 900 python3 bench.py > $O/bench_default.log 2>&1; grep '^{' $O/bench_default.log | tail -1 > $O/bench_default.json ;;
+    sums_time)
+      { timeout 300 python3 tools/sums_time.py 10240 1 5 f64; timeout 300 python3 tools/sums_time.py 1024 32 5 f64; timeout 300 python3 tools/sums_time.py 40960 1 5 f64
+        timeout 300 python3 tools/sums_time.py 65536 1 5 f32; timeout 300 python3 tools/sums_time.py 32768 1 5 f32; timeout 300 python3 tools/sums_time.py 16384 1 5 f32; } 2>&1 | grep -v amdgpu.ids > $O/sums_time.txt
+      cat $O/sums_time.txt ;;
+    fuzz_sums)
+      export FUZZ_OUT=$O
+      run() { name=$1; shift; env "$@" timeout 1500 python3 tools/fuzz_gpu.py $N $SEED > $O/$name.log 2>&1; echo "rc=$?" >> $O/$name.log; echo "== $name: $(grep -c '^trial' $O/$name.log) trials, $(tail -1 $O/$name.log)"; grep -i 'mismatch\|error\|assert' $O/$name.log | head -3; }
+      N=900 SEED=100708 run coop_sums FUZZ_COOP=1 FUZZ_SUMS=1
+      N=400 SEED=100709 run ragged_coop_sums FUZZ_COOP=1 FUZZ_SUMS=1 FUZZ_RAGGED=1
+      N=500 SEED=100710 run opt_sums FUZZ_R5=1 FUZZ_OPT=1 FUZZ_SUMS=1
+      N=500 SEED=100711 run ncyc_sums FUZZ_R5=1 FUZZ_NCYC=1 FUZZ_SUMS=1
+      grep -h "sums(" $O/*_sums.log | grep -o "sums(k=[0-9]*,[0-9]* launches,[A-Za-z]*" | sed 's/.*,//' | sort | uniq -c ;;
     fuzz)
       FUZZ_OUT=$O/fuzz bash tools/gpu_fuzz.sh ${FUZZ_ARGS:-600 400 300 600 150} ;;
     *) echo "unknown recipe $R" ;;

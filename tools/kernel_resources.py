@@ -5,7 +5,7 @@ import os, re, subprocess, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else "step_coop.hip"
 extra = sys.argv[2:]
-flags = {"step_coop.hip": ["-ffp-contract=fast-honor-pragmas", "-fno-honor-nans"],
+flags = {"step_coop.hip": ["-ffp-contract=fast-honor-pragmas", "-fno-honor-nans"], "step_coop_sums.hip": ["-ffp-contract=fast-honor-pragmas", "-fno-honor-nans"],
          "step_fast.hip": ["-ffp-contract=fast", "-fno-honor-nans"]}.get(src, ["-ffp-contract=off"])
 out = "/tmp/kres_" + src.replace(".", "_") + ".s"
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
