@@ -150,10 +150,11 @@ def test_run_gathering_overlapped_plane_gather_equals_one_batch(base, devices, s
     nd.close()
 
 
-@pytest.mark.parametrize("devices,shard,n_sites,prec", [([0, 0], SHARD_MEMBERS, 2, sa.F64), ([0, 0, 0], SHARD_SITES, 5, sa.F64),
-                                                        ([0], SHARD_MEMBERS, 1, sa.F64), ([0, 0], SHARD_MEMBERS, 1, sa.F32_MIXED)],
-                         ids=["members-2-shards", "sites-ragged-3-shards", "rccl-one-rank", "f32mixed-2-shards"])
-def test_reduced_member_resolved_gather_equals_one_batch_and_the_oracle(base, devices, shard, n_sites, prec):
+@pytest.mark.parametrize("devices,shard,n_sites,prec,kernel", [
+    ([0, 0], SHARD_MEMBERS, 2, sa.F64, None), ([0, 0, 0], SHARD_SITES, 5, sa.F64, None), ([0], SHARD_MEMBERS, 1, sa.F64, None),
+    ([0, 0], SHARD_MEMBERS, 1, sa.F32_MIXED, None), ([0, 0], SHARD_MEMBERS, 2, sa.F32_MIXED, sa.KERNEL_ONE_WAVE), ([0, 0], SHARD_MEMBERS, 1, sa.F64, sa.KERNEL_ONE_WAVE)],
+    ids=["members-2-shards", "sites-ragged-3-shards", "rccl-one-rank", "f32mixed-2-shards", "f32mixed-one-wave", "f64-one-wave"])
+def test_reduced_member_resolved_gather_equals_one_batch_and_the_oracle(base, devices, shard, n_sites, prec, kernel):
     """sipnet_node_run_gathering_reduced: every member's DAILY sums of NEE / GPP / ET (groups of 48 half-hourly steps, the
     last one shorter, summed in step order on the shards' second streams under the next segment's kernel, then all-gathered:
     1 / 48 of the planes' bytes) against ONE batch's planes summed on the host in the same order -- bit for bit -- and
@@ -164,6 +165,8 @@ def test_reduced_member_resolved_gather_equals_one_batch_and_the_oracle(base, de
     clims = site_clims(n_sites, T)
     members = synth.perturbed_params(base, M)
     b = one_batch(flags, clims, members, prec)
+    if kernel is not None:
+        b.set_kernel(kernel)
     planes, _ = b.run(0, T)
     want = planes.cpu().numpy().reshape(3, T, n_sites, M)
     b.close()
@@ -171,17 +174,17 @@ def test_reduced_member_resolved_gather_equals_one_batch_and_the_oracle(base, de
     want_sums = np.zeros((3, groups, n_sites, M))
     for t in range(T):                                  # in step order, like the kernel
         want_sums[:, t // K] += want[:, t].astype(np.float64)
-    nd = Node(flags, n_sites, M, precision=prec, devices=devices, shard=shard, fast_math=True if prec == sa.F64 else None)
+    nd = Node(flags, n_sites, M, precision=prec, devices=devices, shard=shard, fast_math=True if prec == sa.F64 else None, kernel=kernel)
     for s in range(n_sites):
         nd.set_climate(s, clims[s])
     nd.set_params(None, members)
     nd.setup()
     nd.run_gathering_reduced(0, T, 3, "sums", K)
     assert nd.L.sipnet_node_n_segments(nd.h) == 3
-    # fp64 shards sum inside the step kernel's launch (no planes written); fp32-mixed ones sum their planes on the second stream
-    assert nd.L.sipnet_node_reduced_in_kernel(nd.h) == (1 if prec == sa.F64 else 0)
-    if prec == sa.F64:
-        assert "Sums" in nd.kernel_name(0)
+    # shards on cooperative kernels sum inside the step kernel's launch (no planes written); the one-wavefront kernel's planes
+    # are summed on the second stream
+    assert nd.L.sipnet_node_reduced_in_kernel(nd.h) == (1 if kernel is None else 0)
+    assert ("Sums" in nd.kernel_name(0)) == (kernel is None), nd.kernel_name(0)
     for k in range(nd.n):
         got = nd.gathered_reduced_member_rows(k)
         assert got.dtype == np.float64 and got.shape == want_sums.shape
