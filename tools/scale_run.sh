@@ -94,7 +94,7 @@ for d in rows:
         base[wl] = d["value"]
     eff = d["value"] / (n * base[wl]) if wl in base else float("nan")
     c = d["config"]
-    ms = lambda k: ("%.2f" % c[k]["ms"]) if c.get(k) else ""
+    ms = lambda k: ("%.2f" % c[k]["ms"]) if (c.get(k) or {}).get("ms") else ("failed" if c.get(k) else "")
     out.append("| %s | %d | %.4g | %.4f | %.3f | %s | %s | %s | %s | %s | %s |" % (
         d["leg"], n, d["value"], d["ms_per_step"], eff, c.get("ranks_seen"), c.get("devices_seen"), d["rc"],
         (c.get("particle_filter") or {}).get("exchange") or c.get("gather", ""), ms("gather_full"), ms("gather_sums")))
