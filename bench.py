@@ -435,8 +435,8 @@ def main():
     sum_groups = (T + args.sum_steps - 1) // args.sum_steps
     if overlap and args.gather == "sums":
         if not b.sums_in_kernel():
-            raise SystemExit("--gather sums: this batch's kernel has no in-launch sums (the cooperative kernels have; the one-wavefront "
-                             "kernel of very large batches has not); the C host's sipnet_node_run_gathering_reduced sums such planes on its second stream")
+            raise SystemExit("--gather sums: this batch's kernel has no in-launch sums (every throughput kernel has; the strict-order one "
+                             "has not); the C host's sipnet_node_run_gathering_reduced sums such planes on its second stream")
         bufs = [dict(sums=torch.empty((3, sum_groups, b.ncol), dtype=torch.float64, device=b.device),
                      gathered=torch.empty((world, 3, sum_groups, b.ncol), dtype=torch.float64, device=b.device),
                      ran=torch.cuda.Event(), done=None) for _ in range(2)]

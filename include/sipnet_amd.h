@@ -368,14 +368,18 @@ int sipnet_batch_get_diagnostics(sipnet_batch *b, int64_t *n_clamp_warn, int64_t
  * the step kernel's own launch (1 / sum_steps of the planes' HBM writes, no second pass).  The sums are doubles whatever
  * the batch's arithmetic: an fp32-mixed batch widens each float value and adds it in double, so the result is bit for bit its
  * float planes added up that way.  For batches sipnet_batch_sums_in_kernel answers 1 for: SIPNET_MATH_FAST (fp64 or
- * fp32-mixed), any flag set, no diagnostics / full state, a shape that AUTO gives a cooperative kernel (or such a layout
- * forced) -- the cooperative kernels' Sums instantiations: fp64 up to two 64-member chunks per compute unit stepCoopSumsKernel,
+ * fp32-mixed), any flag set and shape, no diagnostics / full state -- the cooperative kernels' Sums instantiations: fp64 up to two 64-member chunks per compute unit stepCoopSumsKernel,
  * stepCoopPairSumsKernel, their optional-physics relatives stepCoopXSumsKernel / XPairSums and the nitrogen-cycle layouts'
  * stepCoopNSumsKernel / NPairSums, where the soil wave forms NEE and sums it; fp32-mixed batches on every layout and fp64 on
- * the four-chunk layout stepCoopSumsAtKernel<arithmetic, plain exponents, layout, optional physics> (step_coop_sums.hip).
- * Cost against the planes' launch (MI355X, profiles/r06_sums_time.txt): 10 240 fp64 members +0.08 ms of 8.31, c4's shape
- * -0.10 of 9.68, 65 536 fp32-mixed members (c3) +0.16 of 9.20.  Any other batch (the one-wavefront and strict kernels)
- * gets SIPNET_ERR_BAD_ARGUMENT and sums its planes (sipnet_node_run_gathering_reduced does either by itself).  A
+ * the four-chunk layout stepCoopSumsAtKernel<arithmetic, plain exponents, layout, optional physics> (step_coop_sums.hip);
+ * batches on the one-wavefront kernel (more than four chunks per compute unit, or forced) stepFastSumsKernel
+ * (step_fast_sums.hip).  The cooperative kernels' sums are bit for bit the same batch's planes added up in step order, and
+ * the state they leave is the plain launch's; the one-wavefront sums build equals its plain build to the arithmetic's last
+ * bits only (both are compiled with -ffp-contract=fast, and without the plane stores a few products on rare paths fuse
+ * differently: one flux in ~10^6 differs in its last bit).  Cost against the planes' launch (MI355X,
+ * profiles/r06_sums_time.txt): 10 240 fp64 members +0.08 ms of 8.31, c4's shape -0.10 of 9.68, 65 536 fp32-mixed members
+ * (c3) +0.16 of 9.20.  A batch under SIPNET_MATH_STRICT, with diagnostics or SIPNET_KOPT_FULL_STATE gets
+ * SIPNET_ERR_BAD_ARGUMENT and sums its planes (sipnet_node_run_gathering_reduced does either by itself).  A
  * site that ends inside a group leaves the group's sum over its own records. */
 int sipnet_batch_run_sums(sipnet_batch *b, int32_t step0, int32_t n_steps, int32_t sum_steps, double *d_nee_sums,
                           double *d_gpp_sums, double *d_et_sums, int64_t ld, void *hip_stream);

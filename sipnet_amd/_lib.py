@@ -338,7 +338,7 @@ def kernel_source_sha16():
     h = hashlib.sha256()
     csrc = os.path.join(_HERE, "csrc")
     # (the step kernels and what they include; not the engine / filter / node sources around them)
-    for name in ("step_kernel.hip", "step_fast.hip", "step_coop.hip", "coop_mailboxes.inc", "coop_stats.inc", "coop_wave_carbon.inc",
+    for name in ("step_kernel.hip", "step_fast.hip", "fast_body.inc", "step_coop.hip", "coop_mailboxes.inc", "coop_stats.inc", "coop_wave_carbon.inc",
                  "coop_wave_factor.inc", "coop_wave_light.inc", "coop_wave_soil.inc", "coop_wave_water.inc", "step_kernel.h",
                  "fast_math.h", "coop_probes.h", "plan.h"):
         h.update(name.encode())

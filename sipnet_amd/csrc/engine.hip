@@ -1176,12 +1176,13 @@ int sipnet_batch_run_debug(sipnet_batch* b, int32_t step0, int32_t n_steps, doub
 }
 
 // Which cooperative kernel sums a batch's outputs over groups of steps inside its own launch (sipnet_batch_run_sums):
-// throughput arithmetic (fp64 or fp32-mixed), any flag set, no record / diagnostics / full state, a cooperative layout -- AUTO's
-// choice for the shape, or one of those layouts forced.  0: none (the one-wavefront and strict kernels).
+// throughput arithmetic (fp64 or fp32-mixed), any flag set, no record / diagnostics / full state -- AUTO's choice for the shape,
+// or a throughput kernel forced.  0: none (the strict-order kernel).
 static int sumsKernelFor(const sipnet_batch* b) {
   if (!b->fastMath || b->d_diag || (b->kernelOptions & SIPNET_KOPT_FULL_STATE)) return 0;
   int kernel = b->kernelPolicy;
   if (kernel == SIPNET_KERNEL_AUTO) kernel = autoKernel(b->flags, b->n_sites, b->n_members, true, false, 0, b->numCUs, false);
+  if (kernel == SIPNET_KERNEL_ONE_WAVE) return kernel;
   const bool ncyc = b->flags[SIPNET_F_NITROGEN_CYCLE] != 0;
   if (ncyc) return (kernel == SIPNET_KERNEL_COOP_NCYCLE || kernel == SIPNET_KERNEL_COOP_NCYCLE_PAIR) ? kernel : 0;
   return (kernel == SIPNET_KERNEL_COOP_LDS || kernel == SIPNET_KERNEL_COOP_HBM || kernel == SIPNET_KERNEL_COOP_PAIR ||
@@ -1197,7 +1198,7 @@ int sipnet_batch_run_sums(sipnet_batch* b, int32_t step0, int32_t n_steps, int32
   }
   if (!sumsKernelFor(b)) {
     setError("sipnet_batch_run_sums: no kernel sums this batch's outputs inside its launch (SIPNET_MATH_FAST, no diagnostics / "
-             "full state, a shape AUTO gives a cooperative kernel: sipnet_batch_sums_in_kernel); run the planes and sum them");
+             "full state: sipnet_batch_sums_in_kernel); run the planes and sum them");
     return SIPNET_ERR_BAD_ARGUMENT;
   }
   return runImpl(b, step0, n_steps, d_nee_sums, d_gpp_sums, d_et_sums, nullptr, nullptr, ld, hip_stream, nullptr, sum_steps);
@@ -1412,7 +1413,8 @@ static int runImpl(sipnet_batch* b, int32_t step0, int32_t n_steps, void* d_nee,
                        : kernel == SIPNET_KERNEL_COOP_NCYCLE ? COOP_NCYCLE
                        : kernel == SIPNET_KERNEL_COOP_NCYCLE_PAIR ? COOP_NCYCLE_PAIR : COOP_RING_HBM;
     boundedWaits = (b->kernelOptions & SIPNET_KOPT_BOUNDED_WAITS) && kernel != SIPNET_KERNEL_ONE_WAVE && !wantFull && !sumEvery;
-    if (kernel == SIPNET_KERNEL_ONE_WAVE) launchStepFast(f, b->precision, b->kernelOptions, stream, &b->lastLaunch);
+    if (kernel == SIPNET_KERNEL_ONE_WAVE && sumEvery) sums2::launchStepFastSums(f, b->precision, b->kernelOptions, stream, &b->lastLaunch);
+    else if (kernel == SIPNET_KERNEL_ONE_WAVE) launchStepFast(f, b->precision, b->kernelOptions, stream, &b->lastLaunch);
     else if (boundedWaits) bounded::launchStepCoop(f, b->precision, layout, stream, &b->lastLaunch);
     else if (sumEvery && (b->precision != SIPNET_F64 || layout == COOP_QUAD)) sums2::launchStepCoopSums(f, b->precision, layout, stream, &b->lastLaunch);
     else launchStepCoop(f, b->precision, layout, stream, &b->lastLaunch);

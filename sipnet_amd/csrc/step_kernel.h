@@ -149,6 +149,7 @@ int readCoopStuck(unsigned long long out[2], hipStream_t stream);
 }
 namespace sums2 {     // step_coop_sums.hip: the in-launch sums (FastArgs::sumEvery) of fp32-mixed batches, and of fp64 ones on the four-chunk layout
 void launchStepCoopSums(const FastArgs& a, int precision, int layout, hipStream_t stream, LaunchInfo* info);
+void launchStepFastSums(const FastArgs& a, int precision, int options, hipStream_t stream, LaunchInfo* info);   // step_fast_sums.hip: the one-wavefront kernels'
 }
 // the flag sets the throughput kernels have compiled in; events, gdd and soil_phenol may take any (legal) value
 // in both -- they only change what the plan puts into the records (step_kernel.hip)

@@ -152,8 +152,8 @@ def test_run_gathering_overlapped_plane_gather_equals_one_batch(base, devices, s
 
 @pytest.mark.parametrize("devices,shard,n_sites,prec,kernel", [
     ([0, 0], SHARD_MEMBERS, 2, sa.F64, None), ([0, 0, 0], SHARD_SITES, 5, sa.F64, None), ([0], SHARD_MEMBERS, 1, sa.F64, None),
-    ([0, 0], SHARD_MEMBERS, 1, sa.F32_MIXED, None), ([0, 0], SHARD_MEMBERS, 2, sa.F32_MIXED, sa.KERNEL_ONE_WAVE), ([0, 0], SHARD_MEMBERS, 1, sa.F64, sa.KERNEL_ONE_WAVE)],
-    ids=["members-2-shards", "sites-ragged-3-shards", "rccl-one-rank", "f32mixed-2-shards", "f32mixed-one-wave", "f64-one-wave"])
+    ([0, 0], SHARD_MEMBERS, 1, sa.F32_MIXED, None), ([0, 0], SHARD_MEMBERS, 2, sa.F32_MIXED, sa.KERNEL_ONE_WAVE), ([0, 0], SHARD_MEMBERS, 1, sa.F64, "strict")],
+    ids=["members-2-shards", "sites-ragged-3-shards", "rccl-one-rank", "f32mixed-2-shards", "f32mixed-one-wave", "f64-strict"])
 def test_reduced_member_resolved_gather_equals_one_batch_and_the_oracle(base, devices, shard, n_sites, prec, kernel):
     """sipnet_node_run_gathering_reduced: every member's DAILY sums of NEE / GPP / ET (groups of 48 half-hourly steps, the
     last one shorter, summed in step order on the shards' second streams under the next segment's kernel, then all-gathered:
@@ -164,7 +164,11 @@ def test_reduced_member_resolved_gather_equals_one_batch_and_the_oracle(base, de
     flags = sa.flags_from()
     clims = site_clims(n_sites, T)
     members = synth.perturbed_params(base, M)
+    strict = kernel == "strict"            # (SIPNET_MATH_STRICT: the strict-order kernel has no sums build -- its planes are summed on the second stream)
+    kernel = None if strict else kernel
     b = one_batch(flags, clims, members, prec)
+    if strict:
+        b.set_math(False)
     if kernel is not None:
         b.set_kernel(kernel)
     planes, _ = b.run(0, T)
@@ -174,17 +178,17 @@ def test_reduced_member_resolved_gather_equals_one_batch_and_the_oracle(base, de
     want_sums = np.zeros((3, groups, n_sites, M))
     for t in range(T):                                  # in step order, like the kernel
         want_sums[:, t // K] += want[:, t].astype(np.float64)
-    nd = Node(flags, n_sites, M, precision=prec, devices=devices, shard=shard, fast_math=True if prec == sa.F64 else None, kernel=kernel)
+    nd = Node(flags, n_sites, M, precision=prec, devices=devices, shard=shard, fast_math=(not strict) if prec == sa.F64 else None, kernel=kernel)
     for s in range(n_sites):
         nd.set_climate(s, clims[s])
     nd.set_params(None, members)
     nd.setup()
     nd.run_gathering_reduced(0, T, 3, "sums", K)
     assert nd.L.sipnet_node_n_segments(nd.h) == 3
-    # shards on cooperative kernels sum inside the step kernel's launch (no planes written); the one-wavefront kernel's planes
+    # shards on throughput kernels sum inside the step kernel's launch (no planes written); the strict-order kernel's planes
     # are summed on the second stream
-    assert nd.L.sipnet_node_reduced_in_kernel(nd.h) == (1 if kernel is None else 0)
-    assert ("Sums" in nd.kernel_name(0)) == (kernel is None), nd.kernel_name(0)
+    assert nd.L.sipnet_node_reduced_in_kernel(nd.h) == (0 if strict else 1)
+    assert ("Sums" in nd.kernel_name(0)) == (not strict), nd.kernel_name(0)
     for k in range(nd.n):
         got = nd.gathered_reduced_member_rows(k)
         assert got.dtype == np.float64 and got.shape == want_sums.shape
