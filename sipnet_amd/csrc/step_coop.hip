@@ -544,8 +544,9 @@ __device__ constexpr int coopCodePhase(int role) {
 #endif
   // (the in-kernel sums build of the one-chunk LDS-ring layout, swept in round 6 at c10k's shape, tools/sums_time.py,
   // profiles/r06_sums_phase_sweep.txt: carbon 8.65 ... 8.46 ms at phase 3, then water 8.52 ... 8.40 at phase 3; its
-  // relatives take their plain family's values)
-  if (Sums && NP == 1 && RingLds && !NCyc && !Ext && (role == 0 || role == 1)) return 3;
+  // relatives take their plain family's values -- the fp32-mixed build of the same layout too: 8.57 ms with its family's phases
+  // against 8.90 with these, 16 384 members)
+  if (Sums && sizeof(R) == 8 && NP == 1 && RingLds && !NCyc && !Ext && (role == 0 || role == 1)) return 3;
   if (role == 0) {   // the carbon wave (profiles/r04_phase_sweep_roles.txt)
     if (NCyc) return 0;
     if (Ext) return 7;

@@ -75,7 +75,7 @@ def instantiation(demangled):
     m = re.match(r"void sipnet::sums2::stepCoopSumsAtKernel<(\w+), (\w+), (?:\(sipnet::CoopLayout\))?(\d), (\w+)>", demangled)
     if m:
         lay = int(m.group(3))
-        return dict(kernel="stepCoopSumsKernel" if lay == 0 and m.group(4) != "true" else "stepCoopSumsAtKernel", R=m.group(1),
+        return dict(kernel="stepCoopSumsAtKernel", R=m.group(1),     # (placed like their plain relatives: the fp64 one-chunk sums' own phases are not theirs)
                     plain_exp=m.group(2) == "true", ring_lds=lay == 0, full=False, NP={2: 2, 5: 2, 3: 4}.get(lay, 1), ncyc=lay in (4, 5),
                     ext=m.group(4) == "true")
     m = re.match(r"void sipnet::(?:bounded::)?(stepCoop\w*Kernel)<(\w+), (\w+)(?:, (\w+))?(?:, (\w+))?>", demangled)

@@ -17,7 +17,7 @@ HIPCC = "/opt/rocm/bin/hipcc"
 BASE = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall",
         "-Wno-unused-function"]
 FAST_SRCS = ["step_fast.hip", "step_coop.hip"]                      # -ffp-contract=fast
-OTHER_OBJS = ["engine.o", "step_kernel.o", "step_coop_bounded.o", "pf.o", "plan_device.o", "plan.o", "host_io.o", "restart_io.o", "ensemble_io.o", "node.o"]
+OTHER_OBJS = ["engine.o", "step_kernel.o", "step_coop_bounded.o", "step_coop_sums.o", "step_fast_sums.o", "pf.o", "plan_device.o", "plan.o", "host_io.o", "restart_io.o", "ensemble_io.o", "node.o"]
 
 
 def build(name, flags):
