@@ -16,6 +16,10 @@
 #   evidence:<tag> the round's evidence on the current binary: rocprofv3 --kernel-trace --stats + separate --pmc passes of every
 #                  workload (tools/gpu_profile_all.sh <tag>), then bench_all force_dist pf node_gather pf_consumer, instruction
 #                  mixes of c3 / c4 / c5's kernels, the whole-job breakdown; distil on the CPU side with tools/collect_evidence.sh
+#   evidence_rest  the same without the rocprofv3 passes (run those first -- tools/gpu_profile_all.sh <tag> -- and distil them, so
+#                  that the bench lines carry the fresh counters' tag)
+#   sums_time      tools/sums_time.py: the planes' launch against the in-launch sums at six shapes
+#   fuzz_sums      the four sums campaigns of tools/gpu_fuzz.sh alone
 #   fuzz           tools/gpu_fuzz.sh (the differential campaigns)
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
@@ -90,11 +94,13 @@ PY
         done
       done
       grep -h "ms_per_cycle\|state_identical\|kernel" $O/pf_consumer_*.log ;;
-    evidence:*)
+    evidence:*|evidence_rest)
+      # (evidence_rest: everything but the rocprofv3 passes -- after those have been distilled on the CPU side, so that the bench
+      # lines carry the fresh counters' tag: tools/gpu_profile_all.sh first, tools/distill_profile.py, then this)
       export GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$PWD}
       tag=${R#evidence:}
-      bash tools/gpu_profile_all.sh $tag c10k c2 c2x16 c3 c4 c5 c10kn c4n c10kr3 > $O/profile_all.log 2>&1
-      "$0" $TAG bench_all force_dist pf node_gather pf_consumer
+      [ "$R" != evidence_rest ] && bash tools/gpu_profile_all.sh $tag c10k c2 c2x16 c3 c4 c5 c10kn c4n c10kr3 > $O/profile_all.log 2>&1
+      "$0" $TAG bench_all force_dist pf node_gather pf_consumer sums_time
       for wl in c3 c5 c4; do bash tools/gpu_pmc_branch.sh $wl > /dev/null 2>&1; cp gpurun_out/pmc_branch_$wl.txt $O/; done
       for wl in c4 c2x16 c10k; do for who in dev host; do timeout 600 python3 tools/e2e_breakdown.py $wl $who 2>&1 | grep -v amdgpu > $O/e2e_${wl}_$who.txt; done; done
       timeout 900 python3 bench.py > $O/bench_default.log 2>&1; grep '^{' $O/bench_default.log | tail -1 > $O/bench_default.json ;;
