@@ -21,7 +21,7 @@ for wl in c3 c5 c4; do cp $E/pmc_branch_$wl.txt profiles/${T}_${wl}_instruction_
 { echo "# whole job, one forcing alone: tools/e2e_breakdown.py <workload> dev|host"; for wl in c4 c2x16 c10k; do for who in dev host; do echo "== $wl, plans by the $who"; cut -c1-260 $E/e2e_${wl}_$who.txt; done; done; } > profiles/${T}_e2e_breakdown.txt
 { echo "# sipnet_batch_pf_resample_peers at the slot counts of 1 / 2 / 4 / 8 ranks on one GPU (tools/pf_peers_time.py), then the kernels' own"
   echo "# durations at 8 x 131 072 slots (rocprofv3 --kernel-trace --stats of the same tool, both parameter modes)"
-  cat $E/pf_peers_time.txt; echo; head -4 $E/pf_peers_w8_kernel_stats.csv | cut -c1-260; } > profiles/${T}_pf_peers_time.txt
+  cat $E/pf_peers_time.txt; echo; head -4 $E/pf_peers_w8_kernel_stats.csv | cut -c1-300; } > profiles/${T}_pf_peers_time.txt
 { echo "# tools/node_gather_time.py at c10k's shape: what the member-resolved exchange costs the C host (one shard / two shards on one GPU)"; for d in 0 0,0; do echo "## devices $d"; cat $E/node_gather_time_$d.txt; done; } > profiles/${T}_node_gather_time.txt
 python3 - "$T" <<'PY'
 import json, sys
