@@ -83,22 +83,23 @@ def test_bench_launches_its_own_ranks():
     assert j["parity"]["max_abs_dNEE"] < 1e-9
 
 
-def test_two_ranks_gather_every_members_daily_sums():
+@pytest.mark.parametrize("workload,members,kernel", [("c2", 1024, "stepCoopSumsKernel"), ("c3", 65536, "stepCoopSumsAtKernel<float")])
+def test_two_ranks_gather_every_members_daily_sums(workload, members, kernel):
     """`--gather sums`: the timed passes all-gather every member's NEE / GPP / ET sums over 48 steps, summed inside the step
     kernel's own launch (no planes written), under the next pass; the line's gather_sums leg (the same block in four
     segments) is compared with the planes of a plain pass by bench.py itself"""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--rehearse", "--workload", "c2", "--nsteps", str(48 * 20 + 7),
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--rehearse", "--workload", workload, "--nsteps", str(48 * 20 + 7),
                         "--gather", "sums", "--steps", "2", "--warmup", "1", "--no-fill-probe", "--no-end-to-end", "--no-cpu-baseline"],
                        capture_output=True, text=True, timeout=600, env=env, cwd=helpers.REPO)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     j = _last_json(r.stdout)
     gs = j["config"]["gather_sums"]
     assert j["config"]["gather"] == "sums" and j["config"]["ranks_seen"] == 2
-    assert "Sums" in gs["kernel"] and gs["segments"] == 4 and gs["sum_steps"] == 48
-    assert gs["bytes_sent_per_rank"] == 3 * 21 * 1024 * 8
-    assert gs["max_abs_diff_vs_planes"] < 1e-9
-    assert j["parity"]["max_abs_dNEE"] < 1e-9
+    assert gs["kernel"].startswith(kernel) and gs["segments"] == 4 and gs["sum_steps"] == 48
+    assert gs["bytes_sent_per_rank"] == 3 * 21 * members * 8
+    assert gs["max_abs_diff_vs_planes"] < 1e-9          # (fp32-mixed: the float planes widened and added in step order -- the same bits)
+    assert j["parity"]["max_abs_dNEE"] < (1e-9 if workload == "c2" else 1e-4)
 
 
 @pytest.mark.parametrize("exchange", ["peer", "alltoall"])
