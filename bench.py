@@ -292,6 +292,10 @@ def main():
                     help="run the N>1 path (RCCL process group, side-stream statistics + all-gather, segmented "
                          "full gather, the particle filter's all-gather / all-to-all) even with ONE rank, and "
                          "report its cost against the plain pass as config.dist_overhead_ms")
+    ap.add_argument("--pf-collective", default="direct", choices=["direct", "torch"],
+                    help="c5, N > 1, peer exchange: the all-gather of log-weight blocks through the engine's own RCCL communicator on the "
+                         "batch's stream (sipnet_comm_*; default, falls back to torch when it cannot be created on every rank) or "
+                         "through torch.distributed's process group (its internal stream: two cross-stream waits per cycle)")
     ap.add_argument("--pf-exchange", default="peer", choices=["peer", "alltoall"],
                     help="c5, N > 1: how resampled particles cross ranks -- peer: ONE all-gather of log-weight blocks, "
                          "then every rank reads its ancestors straight out of its peers' HBM (IPC-mapped, xGMI); "
@@ -488,6 +492,25 @@ def main():
                 if int(ok.item()) == 0 and pf_exchange == "peer":
                     pf_exchange = "alltoall (a peer could not map)"
 
+    # the filter's one collective on the batch's own stream: a RCCL communicator of the engine's (sipnet_comm_*), created once;
+    # every rank takes the same path (any rank that cannot create it sends all of them back to torch.distributed's group)
+    pf_comm, pf_collective = None, "n/a"
+    if pf and distd and pf_exchange == "peer":
+        pf_collective = "torch.distributed process group"
+        if args.pf_collective == "direct" and not args.rehearse:
+            why = None
+            try:
+                pf_comm = sd.DirectComm(rank, world, local_rank)
+            except Exception as e:     # noqa: BLE001
+                why = repr(e)[:200]
+            if world > 1:
+                ok = torch.tensor([1 if pf_comm is not None else 0], dtype=torch.int32, device=b.device)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) == 0 and pf_comm is not None:
+                    pf_comm.close()
+                    pf_comm, why = None, "another rank could not create it"
+            pf_collective = "engine's RCCL communicator on the batch's stream (sipnet_comm_all_gather)" if pf_comm is not None \
+                else "torch.distributed process group (direct communicator failed: %s)" % why
     pf_totals = torch.ones(max(args.steps + args.warmup + 1, 1), dtype=torch.int64, device=b.device)
     pf_cycle = [0]
 
@@ -533,7 +556,7 @@ def main():
             pf_cycle[0] += 1
             if distd and not plain and pf_exchange == "peer":
                 _, info = sd.pf_analysis_peers(b, planes[0], pf_obs_k[k], pf_sigma_k[k], 0.5, rank=rank, world=world,
-                                               total_out=slot, collectives=True, diagnostics=record, pretend_world=pretend)
+                                               total_out=slot, collectives=True, diagnostics=record, pretend_world=pretend, comm=pf_comm)
                 if record:
                     pf_info.update(info)
                 return
@@ -646,7 +669,7 @@ def main():
             e0.record()
             if distd and pf_exchange == "peer":
                 sd.pf_analysis_peers(b, planes[0], pf_obs, pf_sigma, 0.5, rank=rank, world=world, collectives=True,
-                                     pretend_world=pretend)
+                                     pretend_world=pretend, comm=pf_comm)
             else:
                 sd.pf_analysis(b, planes[0], pf_obs, pf_sigma, u0=0.5, rank=rank, world=world, with_params=True,
                                diagnostics=False, collectives=distd)
@@ -655,6 +678,7 @@ def main():
             ams.append(e0.elapsed_time(e1))
         pf_info["analysis_ms"] = float(np.mean(ams))
         pf_info["exchange"] = pf_exchange
+        pf_info["collective"] = pf_collective
 
     # N > 1: the north star's exchange as written -- the member-resolved NEE/GPP/ET block of every
     # rank all-gathered -- measured in an extra untimed pass: the launch is cut into 10 segments

@@ -753,6 +753,24 @@ void *sipnet_node_gathered_segment(sipnet_node *nd, int32_t k, int32_t segment, 
 int sipnet_node_pf_connect(sipnet_node *nd, int32_t with_params);
 int sipnet_node_pf_analysis(sipnet_node *nd, int32_t variable, double obs, double sigma, double u0);
 int sipnet_node_pf_check(sipnet_node *nd, int32_t *n_cycles_checked);
+
+/* ---- ranks that are PROCESSES (one per GPU; torch.distributed, MPI): a RCCL communicator of the engine's own ------------
+ * The node object above is one process driving several devices.  Where every rank is a process of its own -- bench.py's
+ * layout, the driver's `torch.distributed.run --nproc-per-node N` -- the hot path's one real collective, the particle
+ * filter's all-gather of log-weight blocks, is enqueued on the CALLER'S stream through this communicator:
+ * no hop onto a library-owned stream and back (torch.distributed's process group runs its collectives on an internal stream:
+ * two cross-stream event waits, ~10 us on a 140 us cycle, profiles/r06_c5_cycle_timeline.txt).  sipnet_comm_unique_id on
+ * rank 0 (ncclGetUniqueId; 128 bytes), the bytes carried to the other ranks by whatever launched them (a broadcast of the
+ * launcher's), sipnet_comm_create on every rank (ncclCommInitRank on `device`; collective: all ranks call it), then
+ * sipnet_comm_all_gather(c, send, recv, bytes_per_rank, stream): recv = [world][bytes_per_rank] on the device, send = this
+ * rank's block -- may be its own slice of recv (in place).  The same librccl the process already holds is used (PyTorch's,
+ * when loaded there).  Errors: SIPNET_ERR_NO_DEVICE with RCCL's message. */
+typedef struct sipnet_comm sipnet_comm;
+int sipnet_comm_unique_id(uint8_t id[128]);
+int sipnet_comm_create(const uint8_t id[128], int32_t world, int32_t rank, int32_t device, sipnet_comm **out);
+int sipnet_comm_all_gather(sipnet_comm *c, const void *d_send, void *d_recv, int64_t bytes_per_rank, void *hip_stream);
+int32_t sipnet_comm_world(const sipnet_comm *c);
+void sipnet_comm_destroy(sipnet_comm *c);
 int32_t *sipnet_node_pf_ancestors(sipnet_node *nd, int32_t k);
 int64_t sipnet_node_pf_block_len(const sipnet_node *nd);
 

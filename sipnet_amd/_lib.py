@@ -186,6 +186,11 @@ SIGNATURES = {
     "sipnet_node_reduced_in_kernel": (C.c_int32, [_P]),
     "sipnet_node_member_range": (C.c_int, [_P, C.c_int32, _I32P, _I32P]),
     "sipnet_node_collective_library": (C.c_char_p, [_P]),
+    "sipnet_comm_unique_id": (C.c_int, [_P]),
+    "sipnet_comm_create": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_P)]),
+    "sipnet_comm_all_gather": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
+    "sipnet_comm_world": (C.c_int32, [_P]),
+    "sipnet_comm_destroy": (None, [_P]),
     "sipnet_node_set_climate": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P]),
     "sipnet_node_set_events": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
     "sipnet_node_set_params": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P]),

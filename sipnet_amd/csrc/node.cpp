@@ -56,6 +56,8 @@ struct Rccl {
   decltype(&ncclGroupEnd) groupEnd = nullptr;
   decltype(&ncclGetErrorString) errorString = nullptr;
   decltype(&ncclGetVersion) getVersion = nullptr;
+  decltype(&ncclGetUniqueId) getUniqueId = nullptr;     // (sipnet_comm_*: ranks that are processes)
+  decltype(&ncclCommInitRank) commInitRank = nullptr;
   std::string path;
 };
 
@@ -86,6 +88,8 @@ Rccl* loadRccl() {
   RCCL_SYM(groupEnd, "ncclGroupEnd")
   RCCL_SYM(errorString, "ncclGetErrorString")
   RCCL_SYM(getVersion, "ncclGetVersion")
+  RCCL_SYM(getUniqueId, "ncclGetUniqueId")
+  RCCL_SYM(commInitRank, "ncclCommInitRank")
 #undef RCCL_SYM
   return &r;
 }
@@ -432,6 +436,83 @@ int sipnet_node_site_range(const sipnet_node* nd, int32_t k, int32_t* first, int
   return SIPNET_OK;
 }
 int64_t sipnet_node_ld(const sipnet_node* nd) { return nd ? nd->ld : 0; }
+// ---- a RCCL communicator for ranks that are processes (include/sipnet_amd.h: sipnet_comm_*) -------------------------------
+struct sipnet_comm {
+  Rccl* rccl = nullptr;
+  ncclComm_t comm = nullptr;
+  int32_t world = 0, rank = 0, device = 0;
+};
+#define COMM_RCCL(r, expr)                                                            \
+  do {                                                                                \
+    ncclResult_t r_ = (expr);                                                         \
+    if (r_ != ncclSuccess) {                                                          \
+      setError(std::string("sipnet_comm: ") + #expr + ": " + (r)->errorString(r_));   \
+      return SIPNET_ERR_NO_DEVICE;                                                    \
+    }                                                                                 \
+  } while (0)
+int sipnet_comm_unique_id(uint8_t id[128]) {
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  Rccl* r = loadRccl();
+  if (!id || !r) {
+    setError("sipnet_comm_unique_id: no usable RCCL (librccl.so.1)");
+    return SIPNET_ERR_NO_DEVICE;
+  }
+  ncclUniqueId u;
+  COMM_RCCL(r, r->getUniqueId(&u));
+  memcpy(id, &u, sizeof u);
+  return SIPNET_OK;
+}
+int sipnet_comm_create(const uint8_t id[128], int32_t world, int32_t rank, int32_t device, sipnet_comm** out) {
+  if (!id || !out || world < 1 || rank < 0 || rank >= world) {
+    setError("sipnet_comm_create: bad argument");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  Rccl* r = loadRccl();
+  if (!r) {
+    setError("sipnet_comm_create: no usable RCCL (librccl.so.1)");
+    return SIPNET_ERR_NO_DEVICE;
+  }
+  if (hipSetDevice(device) != hipSuccess) {
+    (void)hipGetLastError();
+    setError("sipnet_comm_create: no usable HIP device " + std::to_string(device));
+    return SIPNET_ERR_NO_DEVICE;
+  }
+  ncclUniqueId u;
+  memcpy(&u, id, sizeof u);
+  sipnet_comm* c = new sipnet_comm();
+  c->rccl = r;
+  c->world = world;
+  c->rank = rank;
+  c->device = device;
+  ncclResult_t nr = r->commInitRank(&c->comm, world, u, rank);
+  if (nr != ncclSuccess) {
+    setError(std::string("sipnet_comm_create: ncclCommInitRank: ") + r->errorString(nr));
+    delete c;
+    return SIPNET_ERR_NO_DEVICE;
+  }
+  *out = c;
+  return SIPNET_OK;
+}
+int sipnet_comm_all_gather(sipnet_comm* c, const void* d_send, void* d_recv, int64_t bytes_per_rank, void* hip_stream) {
+  if (!c || !d_send || !d_recv || bytes_per_rank <= 0) {
+    setError("sipnet_comm_all_gather: bad argument");
+    return SIPNET_ERR_BAD_ARGUMENT;
+  }
+  if (hipSetDevice(c->device) != hipSuccess) {
+    (void)hipGetLastError();
+    return SIPNET_ERR_NO_DEVICE;
+  }
+  COMM_RCCL(c->rccl, c->rccl->allGather(d_send, d_recv, (size_t)bytes_per_rank, ncclChar, c->comm, (hipStream_t)hip_stream));
+  return SIPNET_OK;
+}
+int32_t sipnet_comm_world(const sipnet_comm* c) { return c ? c->world : 0; }
+void sipnet_comm_destroy(sipnet_comm* c) {
+  if (!c) return;
+  if (c->comm) (void)c->rccl->commDestroy(c->comm);
+  delete c;
+}
+#undef COMM_RCCL
+
 const char* sipnet_node_collective_library(const sipnet_node* nd) {
   static thread_local std::string s;
   if (!nd) return "";

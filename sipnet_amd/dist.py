@@ -254,6 +254,48 @@ def pf_connect_peers(batch, rank=0, world=1, group=None, with_params=True, prete
     batch.pf_connect(every, rank)
 
 
+class DirectComm:
+    """A RCCL communicator of the engine's own among ranks that are processes (sipnet_comm_*): collectives enqueued on the
+    CALLER'S stream -- torch.distributed's process group runs its collectives on an internal stream, two cross-stream event
+    waits away from the kernels around them (~10 us of a 140 us particle-filter cycle).  torch.distributed still launches the
+    ranks and carries the 128-byte id from rank 0 to the others; the librccl is the one the process already holds (PyTorch's)."""
+
+    def __init__(self, rank, world, device, group=None):
+        import ctypes as C
+        import torch.distributed as dist
+        from ._lib import lib, check
+        self.L = lib()
+        ident = (C.c_uint8 * 128)()
+        if rank == 0:
+            check(self.L.sipnet_comm_unique_id(ident), "comm_unique_id")
+        if world > 1:
+            box = [bytes(ident)]
+            dist.broadcast_object_list(box, src=0, group=group)
+            ident = (C.c_uint8 * 128)(*box[0])
+        h = C.c_void_p()
+        check(self.L.sipnet_comm_create(ident, int(world), int(rank), int(device), C.byref(h)), "comm_create")
+        self.h, self.world, self.rank = h, world, rank
+
+    def all_gather(self, mine, gathered, stream):
+        """gathered [world][L] (device, contiguous) <- every rank's `mine` [L]; `mine` may be gathered[rank] (in place)"""
+        import ctypes as C
+        from ._lib import check
+        assert gathered.is_contiguous() and mine.is_contiguous() and gathered.shape[0] == self.world
+        check(self.L.sipnet_comm_all_gather(self.h, C.c_void_p(mine.data_ptr()), C.c_void_p(gathered.data_ptr()),
+                                            mine.numel() * mine.element_size(), stream), "comm_all_gather")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.sipnet_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def pf_arm_peers(batch, obs, sigma, rank=0, world=1, pretend_world=0):
     """before the forecast's run() of a connected filter: that launch then leaves this rank's log-weights in its slice of
     the all-gather's buffer (sipnet_batch_pf_arm), and pf_analysis_peers only adds the block maxima"""
@@ -268,11 +310,12 @@ def pf_arm_peers(batch, obs, sigma, rank=0, world=1, pretend_world=0):
 
 
 def pf_analysis_peers(batch, plane, obs, sigma, u0, rank=0, world=1, group=None, total_out=None,
-                      collectives=None, gathered=None, ancestors=None, diagnostics=False, pretend_world=0):
+                      collectives=None, gathered=None, ancestors=None, diagnostics=False, pretend_world=0, comm=None):
     """One analysis step of a connected filter (pf_connect_peers): this rank's log-weight block -> ONE
     all-gather of the blocks -> weights, prefix sum and this rank's ancestors -> one gather that reads each
     ancestor where it lives.  No host synchronisation, no second collective.  Returns (ancestor slots
-    int32 [ncol] -- rank * nmax + particle --, gathered blocks)."""
+    int32 [ncol] -- rank * nmax + particle --, gathered blocks).  comm: a DirectComm -- the all-gather then goes
+    through the engine's own RCCL communicator on the batch's stream instead of torch.distributed's process group."""
     import torch
     import torch.distributed as dist
     if collectives is None:
@@ -295,11 +338,15 @@ def pf_analysis_peers(batch, plane, obs, sigma, u0, rank=0, world=1, group=None,
         # tools/pf_peers_time.py, tests/test_gpu_node.py do that -- but a filter fed rotated copies of itself selects another
         # ensemble: its forecasts ran up to 30 % longer from the phenology of the survivors alone, which says nothing about
         # the exchange.)
-        if collectives:
+        if collectives and comm is not None:     # (the one real rank's communicator: world 1, in place)
+            comm.all_gather(mine, mine.view(1, L), batch._stream())
+        elif collectives:
             dist.all_gather_into_tensor(mine, mine, group=group)
         gathered[:rank].copy_(mine.expand(rank, L))
     elif collectives:
-        if _host_staged(mine, group):
+        if comm is not None:
+            comm.all_gather(mine, gathered, batch._stream())
+        elif _host_staged(mine, group):
             out = torch.empty((world, L), dtype=torch.float64)
             dist.all_gather_into_tensor(out.view(-1), mine.cpu(), group=group)
             gathered.copy_(out)

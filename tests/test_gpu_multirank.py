@@ -164,13 +164,41 @@ def test_rccl_one_rank_statistics_equal_the_plain_run_bit_for_bit(workload, memb
     assert a.shape == b.shape and np.array_equal(a, b)       # bit for bit
 
 
-@pytest.mark.parametrize("exchange", ["peer", "alltoall"])
-def test_rccl_one_rank_particle_filter_cycle(tmp_path, exchange):
+@pytest.mark.parametrize("exchange,collective", [("peer", "direct"), ("peer", "torch"), ("alltoall", "torch")])
+def test_rccl_one_rank_particle_filter_cycle(tmp_path, exchange, collective):
+    """... the peer exchange's all-gather through the engine's own RCCL communicator on the batch's stream (sipnet_comm_*,
+    bench.py's default) and through torch.distributed's process group: the same ancestors either way"""
     j = _rccl_one_rank(["--workload", "c5", "--members", "4096", "--steps", "3", "--warmup", "1",
-                        "--pf-exchange", exchange], tmp_path)
+                        "--pf-exchange", exchange, "--pf-collective", collective], tmp_path)
     pf = j["config"]["particle_filter"]
     assert pf["exchange"] == exchange
+    if exchange == "peer":
+        assert ("sipnet_comm_all_gather" in pf["collective"]) == (collective == "direct"), pf["collective"]
     assert j["config"]["dist_overhead"]["backend"] == "nccl"
     assert pf["unique_ancestors"] > 64 and pf["ess"] > 64
     assert pf["sent"] == 0 and pf["received"] == 0          # one rank: every ancestor is local
     assert j["parity"]["max_abs_dNEE"] < 2e-6
+
+
+def test_the_engines_own_communicator_one_rank():
+    """sipnet_comm_*: ncclGetUniqueId / ncclCommInitRank / ncclAllGather through the C boundary, one rank (RCCL refuses two ranks
+    on one device): in place and out of place, on a stream of the caller's choice, the library PyTorch already holds"""
+    import ctypes as C
+    import torch
+    import sipnet_amd as sa
+    from sipnet_amd import dist as sd
+    from sipnet_amd._lib import lib
+    comm = sd.DirectComm(0, 1, 0)
+    assert lib().sipnet_comm_world(comm.h) == 1
+    x = torch.arange(4096, dtype=torch.float64, device="cuda:0")
+    out = torch.zeros((1, 4096), dtype=torch.float64, device="cuda:0")
+    side = torch.cuda.Stream(device=0)
+    with torch.cuda.stream(side):
+        comm.all_gather(x, out, C.c_void_p(side.cuda_stream))
+        y = x * 2
+        comm.all_gather(y, y.view(1, 4096), C.c_void_p(side.cuda_stream))     # in place
+    side.synchronize()
+    assert torch.equal(out[0], x) and torch.equal(y, x * 2)
+    with pytest.raises(sa.SipnetError):
+        sd.DirectComm(0, 1, 99)                                                # no such device
+    comm.close()

@@ -46,7 +46,7 @@ for R in "$@"; do
       done ;;
     force_dist)
       : > $O/force_dist.jsonl
-      for wl in c10k c10ksums c4 c4sums c3 c3sums c5 c5p8 c2x16 c2x16sums c10kn c10knsums c4n c4nsums c10kr3 c10kr3sums; do
+      for wl in c10k c10ksums c4 c4sums c3 c3sums c5 c5p8 c5torch c5p8torch c2x16 c2x16sums c10kn c10knsums c4n c4nsums c10kr3 c10kr3sums; do
         steps=10; warm=2; extra=""; w=$wl
         [ "$wl" = c10ksums ] && w=c10k && extra="--gather sums"   # (every member's daily sums from the kernel's own launch, gathered under the next pass)
         [ "$wl" = c4sums ] && w=c4 && extra="--gather sums"
@@ -54,6 +54,9 @@ for R in "$@"; do
         case $wl in c2x16sums|c10knsums|c4nsums|c10kr3sums) w=${wl%sums}; extra="--gather sums" ;; esac
         [ "$wl" = c5 ] && steps=400 && warm=40   # (a 0.15 ms cycle: RCCL's first-collective costs need a real warm-up)
         [ "$wl" = c5p8 ] && steps=400 && warm=40 && extra="--pretend-world 8" && w=c5
+        # (the filter's all-gather through torch.distributed's process group instead of the engine's own communicator)
+        [ "$wl" = c5torch ] && steps=400 && warm=40 && extra="--pf-collective torch" && w=c5
+        [ "$wl" = c5p8torch ] && steps=400 && warm=40 && extra="--pretend-world 8 --pf-collective torch" && w=c5
         timeout 900 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 \
             bench.py --gpus 1 --force-dist --workload $w $extra --steps $steps --warmup $warm --no-cpu-baseline --no-fill-probe > $O/force_dist_$wl.log 2>&1
         echo "rc=$? $wl"

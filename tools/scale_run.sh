@@ -50,8 +50,10 @@ done
 # 3b. the member-resolved exchange that fits under the kernel: every member's daily sums from the step kernel's own launch,
 #     all-gathered under the next pass (90 MB per rank and year at c10k) -- at every N, for a curve of its own
 for wl in c10k c4; do for n in $NS; do [ "$n" -ge 2 ] && line ${wl}_sums_n$n --workload $wl --gpus $n --steps 20 --warmup 3 --gather sums; done; done
-# 4. the filter's all-to-all fallback
+# 4. the filter's all-to-all fallback, and its peer exchange with the all-gather through torch.distributed's process group
+#    (the default line takes the engine's own RCCL communicator on the batch's stream)
 [ "$MAX" -ge 2 ] && line c5_alltoall_n$MAX --workload c5 --gpus $MAX --steps 400 --warmup 40 --pf-exchange alltoall
+[ "$MAX" -ge 2 ] && line c5_torchcoll_n$MAX --workload c5 --gpus $MAX --steps 400 --warmup 40 --pf-collective torch
 
 # 5. the C host
 gcc -std=c99 -O1 -Iinclude tests/c/node_consumer.c -o /tmp/node_consumer -Lsipnet_amd -lsipnet_amd -Wl,-rpath,$PWD/sipnet_amd
