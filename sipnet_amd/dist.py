@@ -264,14 +264,23 @@ class DirectComm:
         import ctypes as C
         import torch.distributed as dist
         from ._lib import lib, check
+        import torch
         self.L = lib()
+        # every rank asks for an id (only rank 0's is used): a rank whose RCCL is unusable finds out HERE, and all ranks agree on
+        # that before any of them enters the collective ncclCommInitRank -- which would otherwise wait for the missing one
         ident = (C.c_uint8 * 128)()
-        if rank == 0:
-            check(self.L.sipnet_comm_unique_id(ident), "comm_unique_id")
+        rc = self.L.sipnet_comm_unique_id(ident)
         if world > 1:
+            ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=torch.device("cuda", int(device)))
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+            if int(ok.item()) == 0:
+                check(rc, "comm_unique_id")
+                raise RuntimeError("DirectComm: another rank has no usable RCCL")
             box = [bytes(ident)]
             dist.broadcast_object_list(box, src=0, group=group)
             ident = (C.c_uint8 * 128)(*box[0])
+        else:
+            check(rc, "comm_unique_id")
         h = C.c_void_p()
         check(self.L.sipnet_comm_create(ident, int(world), int(rank), int(device), C.byref(h)), "comm_create")
         self.h, self.world, self.rank = h, world, rank
