@@ -59,6 +59,22 @@ def test_compute_fails_loudly_without_a_gpu():
         sa.Batch(sa.flags_from(), 1, 64)
 
 
+def test_the_communicator_refuses_bad_arguments_and_a_missing_device():
+    """sipnet_comm_*: argument checks answer before RCCL or a device is touched; on a box without a GPU a well-formed call fails
+    loudly too (no RCCL without a device, or no device: SIPNET_ERR_NO_DEVICE either way)"""
+    L = sa.lib()
+    h = C.c_void_p()
+    ident = (C.c_uint8 * 128)()
+    assert L.sipnet_comm_create(None, 1, 0, 0, C.byref(h)) == _lib.ERR_BAD_ARGUMENT
+    assert L.sipnet_comm_create(ident, 0, 0, 0, C.byref(h)) == _lib.ERR_BAD_ARGUMENT
+    assert L.sipnet_comm_create(ident, 2, 2, 0, C.byref(h)) == _lib.ERR_BAD_ARGUMENT
+    assert L.sipnet_comm_all_gather(None, None, None, 8, None) == _lib.ERR_BAD_ARGUMENT
+    assert L.sipnet_comm_world(None) == 0
+    L.sipnet_comm_destroy(None)
+    if L.sipnet_device_count() == 0:
+        assert L.sipnet_comm_create(ident, 1, 0, 0, C.byref(h)) == _lib.ERR_NO_DEVICE
+
+
 def test_flag_coupling_rules_are_enforced():
     """context.c:195-223 -> SIPNET_ERR_BAD_PARAMETER (the reference exits with code 3)."""
     L = sa.lib()
