@@ -96,10 +96,12 @@ for d in rows:
         base[wl] = d["value"]
     eff = d["value"] / (n * base[wl]) if wl in base else float("nan")
     c = d["config"]
+    pfc = c.get("particle_filter") or {}
     ms = lambda k: ("%.2f" % c[k]["ms"]) if (c.get(k) or {}).get("ms") else ("failed" if c.get(k) else "")
     out.append("| %s | %d | %.4g | %.4f | %.3f | %s | %s | %s | %s | %s | %s |" % (
         d["leg"], n, d["value"], d["ms_per_step"], eff, c.get("ranks_seen"), c.get("devices_seen"), d["rc"],
-        (c.get("particle_filter") or {}).get("exchange") or c.get("gather", ""), ms("gather_full"), ms("gather_sums")))
+        ("%s, %s" % (pfc.get("exchange"), "engine's communicator" if "sipnet_comm" in str(pfc.get("collective")) else "torch process group")) if pfc.get("exchange")
+        else c.get("gather", ""), ms("gather_full"), ms("gather_sums")))
 for n in (1, 2, 4, 8):
     for f in ("node_consumer", "pf_consumer"):
         p = os.path.join(O, "%s_n%d.log" % (f, n))
