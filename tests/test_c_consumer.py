@@ -101,6 +101,45 @@ def test_node_of_one_device_all_gathers_through_rccl_from_c(oracle, tmp_path):
     assert float(kv["sum_nee_day0_member_0"]) == pytest.approx(want[0][:48, 0].sum(), abs=1e-9)      # ... and the oracle's
 
 
+RANK_SRC = os.path.join(helpers.REPO, "tests", "c", "rank_consumer.c")
+
+
+def run_rank(exe, tmp_path, members, world=1, rank=0, device=0):
+    clim = str(tmp_path / "niwot.clim")
+    helpers.gunzip_to(os.path.join(helpers.smoke_dir("niwot"), "sipnet.clim.gz"), clim)
+    r = subprocess.run([exe, os.path.join(helpers.smoke_dir("niwot"), "sipnet.param"), clim, str(members), str(world), str(rank),
+                        str(device), str(tmp_path / "comm.id")], capture_output=True, text=True, timeout=600)
+    kv = dict(l.split("=", 1) for l in r.stdout.strip().split("\n") if "=" in l)
+    return r.returncode, kv, r.stdout + r.stderr
+
+
+@pytest.mark.skipif(sa.lib().sipnet_device_count() > 0, reason="a GPU is present")
+def test_rank_consumer_links_from_c_and_needs_a_device(tmp_path):
+    """a process-per-GPU host (sipnet_batch_* + sipnet_comm_*) compiles as pedantic C99 and links; without a device it says so"""
+    rc, kv, out = run_rank(build(tmp_path, RANK_SRC), tmp_path, 130)
+    assert rc == 0, out
+    assert kv["create"] == "100" and "no usable HIP device" in kv["no_device_message"]
+
+
+@pytest.mark.gpu
+def test_a_process_per_gpu_host_sums_in_the_launch_and_all_gathers_through_the_engines_communicator(oracle, tmp_path):
+    """tests/c/rank_consumer.c with world = 1 (RCCL refuses two ranks on one device): the batch API alone, every member's daily
+    sums out of the step kernel's launch (sipnet_batch_run_sums), ONE all-gather through sipnet_comm_* on the batch's stream --
+    the gathered block against the oracle's daily sums"""
+    rc, kv, out = run_rank(build(tmp_path, RANK_SRC), tmp_path, 130)
+    assert rc == 0 and kv["create"] == "0" and kv["rc"] == "0", out
+    assert kv["comm_world"] == "1" and kv["sums_in_kernel"] == "1" and kv["kernel"].startswith("stepCoopSumsKernel<"), out
+    assert int(kv["groups"]) == (5237 + 47) // 48 and int(kv["bytes_per_rank"]) == 3 * 110 * 130 * 8
+    case = helpers.load_smoke_case("niwot", str(tmp_path))
+    members = np.stack([case["params"], case["params"]])
+    members[1, sa.config.param_index("aMax")] *= 1.0 + 0.001 * 129
+    want, _, st = oracle.run_block(case["flags"], members, case["clim"], None)
+    assert (st == 0).all()
+    assert float(kv["sum_nee_member_0"]) == pytest.approx(want[0][:, 0].sum(), abs=1e-8)
+    assert float(kv["sum_nee_member_last"]) == pytest.approx(want[0][:, 1].sum(), abs=1e-8)
+    assert float(kv["sum_nee_day0_member_0"]) == pytest.approx(want[0][:48, 0].sum(), abs=1e-9)
+
+
 PF_SRC = os.path.join(helpers.REPO, "tests", "c", "pf_consumer.c")
 
 
