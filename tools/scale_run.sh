@@ -12,6 +12,7 @@
 #   4. c5 with `--pf-exchange alltoall` at N = max (the fallback for ranks that cannot map each other's HBM)
 #   5. the C host (sipnet_node_*: one process, one thread + one RCCL rank per GPU): node_consumer (statistics + planes +
 #      the reduced member-resolved gather), pf_consumer (config 5's cycle), at N = 1, 2, 4, 8 with per-GPU work fixed
+#   5b. the C host with a process per GPU (tests/c/rank_consumer.c: sipnet_comm_* among N processes) at N = 1, 2, 4, 8
 #   6. the CLI: `sipnet --sites LIST --devices 0-(N-1)` over 8 x N run directories (whole sites per device)
 cd "$(dirname "$0")/.." || exit 1
 export HSA_ENABLE_IPC_MODE_LEGACY=0
@@ -75,6 +76,18 @@ for n in $NS; do
   timeout 900 python3 tools/node_gather_time.py 10240 1 $devs > $O/node_gather_time_n$n.txt 2>&1     # plain / overlapped planes / daily sums / fp32
 done
 
+# 5b. the C host with a PROCESS per GPU (tests/c/rank_consumer.c: the batch API, in-launch daily sums, ONE all-gather through the
+#     engine's own RCCL communicator -- ncclCommInitRank among N processes, the id through a file)
+gcc -std=c99 -O1 -Iinclude tests/c/rank_consumer.c -o /tmp/rank_consumer -Lsipnet_amd -lsipnet_amd -Wl,-rpath,$PWD/sipnet_amd
+for n in $NS; do
+  rm -f /tmp/comm_n$n.id
+  for r in $(seq 0 $((n - 1))); do
+    timeout 900 /tmp/rank_consumer sipnet_amd/data/base_forest.param /tmp/year.clim $((10240 * n)) $n $r $r /tmp/comm_n$n.id > $O/rank_consumer_n${n}_r$r.log 2>&1 &
+  done
+  wait
+  cp $O/rank_consumer_n${n}_r0.log $O/rank_consumer_n$n.log; echo "ranks_ok=$(grep -l '^rc=0' $O/rank_consumer_n${n}_r*.log | wc -l)" >> $O/rank_consumer_n$n.log
+done
+
 # 6. the CLI over run directories, whole sites per device
 python3 tools/cli_sites_time.py --sites $((8 * MAX)) --devices 0-$((MAX - 1)) > $O/cli_sites_n$MAX.txt 2>&1 || echo "cli leg rc=$?" >> $O/cli_sites_n$MAX.txt
 
@@ -100,14 +113,14 @@ for d in rows:
     ms = lambda k: ("%.2f" % c[k]["ms"]) if (c.get(k) or {}).get("ms") else ("failed" if c.get(k) else "")
     out.append("| %s | %d | %.4g | %.4f | %.3f | %s | %s | %s | %s | %s | %s |" % (
         d["leg"], n, d["value"], d["ms_per_step"], eff, c.get("ranks_seen"), c.get("devices_seen"), d["rc"],
-        ("%s, %s" % (pfc.get("exchange"), "engine's communicator" if "sipnet_comm" in str(pfc.get("collective")) else "torch process group")) if pfc.get("exchange")
-        else c.get("gather", ""), ms("gather_full"), ms("gather_sums")))
+        ("%s, %s" % (pfc.get("exchange"), "engine's communicator" if "sipnet_comm" in str(pfc.get("collective")) else "torch process group")) if pfc.get("exchange") and not str(pfc.get("exchange")).startswith("n/a")
+        else (pfc.get("exchange") or c.get("gather", "")), ms("gather_full"), ms("gather_sums")))
 for n in (1, 2, 4, 8):
-    for f in ("node_consumer", "pf_consumer"):
+    for f in ("node_consumer", "pf_consumer", "rank_consumer"):
         p = os.path.join(O, "%s_n%d.log" % (f, n))
         if os.path.exists(p):
             kv = dict(l.strip().split("=", 1) for l in open(p) if "=" in l)
-            keys = [k for k in kv if k.startswith("ms_") or k in ("rc", "state_identical", "reduced_sums_equal_planes", "collective_library")]
+            keys = [k for k in kv if k.startswith("ms_") or k in ("rc", "state_identical", "reduced_sums_equal_planes", "collective_library", "comm_world", "ranks_ok", "kernel")]
             out.append("| C host: %s | %d | %s |" % (f, n, ", ".join("%s=%s" % (k, kv[k]) for k in keys)))
 open("profiles/scale_table.md", "w").write("\n".join(out) + "\n")
 open("profiles/scale_lines.jsonl", "w").write(open(os.path.join(O, "scale_lines.jsonl")).read())
