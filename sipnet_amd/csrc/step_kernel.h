@@ -127,7 +127,7 @@ struct FastArgs {
   double* pfBlockMax;     // [workgroups of the launch]
   double pfObs, pfInvSigma;
   int64_t prmPitch;       // one-wave kernel: columns of prm (ncol; a filter's parameter bank shared by all ranks: world * nmax)
-  int32_t sumEvery;       // > 0 (cooperative kernels' Sums instantiations): nee / gpp / et receive sums over groups of this many steps
+  int32_t sumEvery;       // > 0 (the Sums builds of the cooperative and the one-wavefront kernels): nee / gpp / et receive DOUBLE sums over groups of this many steps
   int32_t padEnd;
 };
 // What a launcher actually put on the stream (sipnet_batch_last_launch): the instantiation's
