@@ -7,6 +7,10 @@ algorithm the engine implements (systematic resampling, e.g. Douc & Cappe 2005, 
 integer-weight variant of sipnet_amd/csrc/pf.hip so that results are exact) and the
 semantics of the exchange: new particle g of the global set = old particle ancestors[g].
 
+What pins it instead (tests/test_pf.py): hand-computed cases, the defining properties (every count the floor or ceiling of
+its expectation, zero weights never survive, sorted ancestors) and an independent restatement of the textbook walk in exact
+integer arithmetic.
+
 Only tests/ may import this module.
 """
 import numpy as np

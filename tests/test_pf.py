@@ -74,6 +74,42 @@ def test_systematic_resampling_properties(kind):
         assert (po.systematic_ancestors(w, 0.5) == n // 3).all()
 
 
+def test_systematic_resampling_known_answers_and_the_textbook_walk():
+    """the analysis oracle has no reference to be pinned to (PecanProject/sipnet has no filter): hand-computed cases, and the
+    textbook formulation -- ONE uniform draw, n equally spaced pointers walked through the cumulative weights (Douc & Cappe 2005)
+    -- restated independently with exact integer arithmetic: particle j takes the first i with n cdf[i] > (j + u0) S"""
+    from fractions import Fraction
+    # S = 8, pointers (j + 0.5) * 2 = 1, 3, 5, 7 against cdf = 1, 4, 4, 8 (strictly greater: a pointer ON a boundary moves on)
+    assert po.systematic_ancestors(np.array([1, 3, 0, 4]), 0.5).tolist() == [1, 1, 3, 3]
+    assert po.systematic_ancestors(np.array([1, 3, 0, 4]), 0.0).tolist() == [0, 1, 3, 3]          # pointers 0, 2, 4 (ON the boundary 4: moves on), 6
+    assert po.systematic_ancestors(np.array([0, 0, 5, 0]), 0.25).tolist() == [2, 2, 2, 2]
+    assert po.systematic_ancestors(np.array([2, 2, 2, 2]), 0.75).tolist() == [0, 1, 2, 3]
+    rng = np.random.default_rng(11)
+    for n in (1, 2, 7, 64, 1000):
+        for _ in range(6):
+            w = rng.integers(0, 1 << 30, size=n).astype(np.int64)
+            w[rng.random(n) < 0.3] = 0
+            if w.sum() == 0:
+                w[n // 2] = 1
+            u0 = float(rng.choice([0.0, 0.5, rng.random()]))
+            got = po.systematic_ancestors(w, u0)
+            S, cdf = int(w.sum()), np.cumsum(w)
+            i, want = 0, []
+            for j in range(n):
+                ptr = (Fraction(j) + Fraction(u0)) * S          # (u0 is a double: exactly representable as a fraction)
+                ptr = min(ptr, Fraction(n) * (S - 1))           # the oracle's (and the kernels') cap: never past the last weight
+                while n * int(cdf[i]) <= ptr:
+                    i += 1
+                want.append(i)
+            # the float pointer of the oracle is the exact one rounded: they may part only where a pointer sits within
+            # rounding of a boundary of the cumulative weights
+            diff = np.flatnonzero(got != np.array(want))
+            for j in diff:
+                exact = float((Fraction(int(j)) + Fraction(u0)) * S / n)
+                assert min(abs(float(cdf[got[j]]) - exact), abs(float(cdf[want[j]]) - exact)) <= 4e-16 * max(exact, 1.0) * 4, (n, j)
+            assert len(diff) <= max(1, n // 100)
+
+
 @pytest.mark.parametrize("world", [1, 2, 3, 8])
 @pytest.mark.parametrize("kind", ["uniform", "mild", "degenerate", "one"])
 def test_exchange_plan_reassembles_the_global_gather(world, kind):
